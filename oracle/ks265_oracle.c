@@ -1,0 +1,413 @@
+/* ks265_oracle.c — TEST INFRASTRUCTURE, NOT PRODUCT CODE (see ks265_oracle.h).
+ *
+ * Plain-C restatement of the KSC265 encoder's hot-path pixel kernels.  The reference is
+ * binary-only; each function cites the symbol it restates as `enc@0xADDR name`
+ * (/root/reference/ubuntu_x64/appencoder) and the SURVEY.md paragraph that records the
+ * verified contract.  Pinned bit-exactly against the reference binary's own outputs:
+ * tests/golden/ (npz files) (made by oracle/ref_probe/gen_golden.py), tests/test_oracle_golden.py.
+ */
+#include "ks265_oracle.h"
+#include <stdlib.h>
+#include <string.h>
+
+static inline int clip3(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
+static inline uint8_t clip8(int v) { return (uint8_t)clip3(0, 255, v); }
+static inline int16_t clip16(int v) { return (int16_t)clip3(-32768, 32767, v); }
+static inline int iabs(int v) { return v < 0 ? -v : v; }
+static inline int sgn(int v) { return (v > 0) - (v < 0); }
+
+/* ------------------------------------------------------------------ SAD family */
+
+/* enc@0x47ae30 sad_c — SURVEY.md B.1 */
+uint32_t ks265o_sad(const uint8_t *a, const uint8_t *b, long sa, long sb, long h, long w)
+{
+    uint32_t s = 0;
+    for (long y = 0; y < h; ++y, a += sa, b += sb)
+        for (long x = 0; x < w; ++x) s += (uint32_t)iabs((int)a[x] - (int)b[x]);
+    return s;
+}
+
+/* enc@0x47ae90 sad4_c — SURVEY.md B.1: {up, down, left, right} each << 4 */
+void ks265o_sad4(const uint8_t *fenc, const uint8_t *ref, long sFenc, long sRef, long h, uint32_t out[4], long w)
+{
+    out[0] = ks265o_sad(fenc, ref - sRef, sFenc, sRef, h, w) << 4;
+    out[1] = ks265o_sad(fenc, ref + sRef, sFenc, sRef, h, w) << 4;
+    out[2] = ks265o_sad(fenc, ref - 1, sFenc, sRef, h, w) << 4;
+    out[3] = ks265o_sad(fenc, ref + 1, sFenc, sRef, h, w) << 4;
+}
+
+/* enc@0x47b060 sad3_c — SURVEY.md B.1: three arbitrary reference pointers, unshifted */
+void ks265o_sad3(const uint8_t *fenc, const uint8_t *r0, const uint8_t *r1, const uint8_t *r2, long sFenc, long sRef,
+                 long h, uint32_t out[3], long w)
+{
+    out[0] = ks265o_sad(fenc, r0, sFenc, sRef, h, w);
+    out[1] = ks265o_sad(fenc, r1, sFenc, sRef, h, w);
+    out[2] = ks265o_sad(fenc, r2, sFenc, sRef, h, w);
+}
+
+/* enc@0x4cee30 sad4blk_8x8_c — the four 8x8 quadrants of a 16x16, raster order */
+void ks265o_sad4blk_8x8(const uint8_t *a, const uint8_t *b, long sa, long sb, uint32_t out[4])
+{
+    out[0] = ks265o_sad(a, b, sa, sb, 8, 8);
+    out[1] = ks265o_sad(a + 8, b + 8, sa, sb, 8, 8);
+    out[2] = ks265o_sad(a + 8 * sa, b + 8 * sb, sa, sb, 8, 8);
+    out[3] = ks265o_sad(a + 8 * sa + 8, b + 8 * sb + 8, sa, sb, 8, 8);
+}
+
+/* enc@0x47b230.. sse_c<N> */
+uint32_t ks265o_sse(const uint8_t *a, const uint8_t *b, int sa, int sb, int n)
+{
+    uint32_t s = 0;
+    for (int y = 0; y < n; ++y, a += sa, b += sb)
+        for (int x = 0; x < n; ++x) { int d = (int)a[x] - (int)b[x]; s += (uint32_t)(d * d); }
+    return s;
+}
+
+/* Hadamard helpers: unnormalised +-1 butterflies; the |.| sum is order independent */
+static uint32_t had_tile(const uint8_t *a, const uint8_t *b, long sa, long sb, int n)
+{
+    int m[64], t[64];
+    for (int y = 0; y < n; ++y)
+        for (int x = 0; x < n; ++x) m[y * n + x] = (int)a[y * sa + x] - (int)b[y * sb + x];
+    for (int y = 0; y < n; ++y) {                       /* rows */
+        int *r = m + y * n;
+        for (int len = 1; len < n; len <<= 1)
+            for (int i = 0; i < n; i += 2 * len)
+                for (int j = i; j < i + len; ++j) { int u = r[j], v = r[j + len]; r[j] = u + v; r[j + len] = u - v; }
+    }
+    for (int x = 0; x < n; ++x) {                       /* columns */
+        for (int y = 0; y < n; ++y) t[y] = m[y * n + x];
+        for (int len = 1; len < n; len <<= 1)
+            for (int i = 0; i < n; i += 2 * len)
+                for (int j = i; j < i + len; ++j) { int u = t[j], v = t[j + len]; t[j] = u + v; t[j + len] = u - v; }
+        for (int y = 0; y < n; ++y) m[y * n + x] = t[y];
+    }
+    uint32_t s = 0;
+    for (int i = 0; i < n * n; ++i) s += (uint32_t)iabs(m[i]);
+    return s;
+}
+
+/* enc@0x47b680 had_c (+ enc@0x47b3b0 xCalcHADs8x8) — SURVEY.md B.2 */
+uint32_t ks265o_had(const uint8_t *a, const uint8_t *b, long sa, long sb, long h, long w)
+{
+    uint32_t s = 0;
+    if (((h | w) & 7) == 0) {
+        for (long y = 0; y < h; y += 8)
+            for (long x = 0; x < w; x += 8) s += (had_tile(a + y * sa + x, b + y * sb + x, sa, sb, 8) + 2) >> 2;
+    } else if (((h | w) & 3) == 0) {
+        for (long y = 0; y < h; y += 4)
+            for (long x = 0; x < w; x += 4) s += (had_tile(a + y * sa + x, b + y * sb + x, sa, sb, 4) + 1) >> 1;
+    } else {
+        for (long y = 0; y < h; y += 2)
+            for (long x = 0; x < w; x += 2) s += had_tile(a + y * sa + x, b + y * sb + x, sa, sb, 2);
+    }
+    return s;
+}
+
+/* enc@0x4345f0.. H265_CalResidual<N>(res, org, pred, strideOrg, stridePred): residual rows are packed (stride N) */
+void ks265o_calc_residual(int16_t *res, const uint8_t *org, const uint8_t *pred, int strideOrg, int stridePred,
+                          int strideRes, int n)
+{
+    for (int y = 0; y < n; ++y)
+        for (int x = 0; x < n; ++x) res[y * strideRes + x] = (int16_t)((int)org[y * strideOrg + x] - (int)pred[y * stridePred + x]);
+}
+
+/* ------------------------------------------------------------------ transforms */
+
+/* |cos(j*pi/64)| * 64*sqrt(2) rounded as in HEVC (g_uiTr32 enc@0x4e06a0 holds the expanded 32x32 matrix) */
+static const int8_t kMag[33] = {64, 90, 90, 90, 89, 88, 87, 85, 83, 82, 80, 78, 75, 73, 70, 67, 64,
+                                61, 57, 54, 50, 46, 43, 38, 36, 31, 25, 22, 18, 13, 9, 4, 0};
+/* DST4x4_COEFF enc@0x4e0aa0 */
+static const int8_t kDst4[4][4] = {{29, 55, 74, 84}, {74, 74, 0, -74}, {84, -29, -74, 55}, {55, -84, 74, -29}};
+
+static int dct_coef(int n, int k, int x)
+{
+    int m = (k * (32 / n) * (2 * x + 1)) & 127;          /* angle index, period 128 */
+    if (m > 64) m = 128 - m;
+    return m > 32 ? -kMag[64 - m] : kMag[m];
+}
+
+static void load_matrix(int idx, int M[32][32], int *n)
+{
+    static const int sizes[5] = {4, 4, 8, 16, 32};
+    *n = sizes[idx];
+    for (int k = 0; k < *n; ++k)
+        for (int x = 0; x < *n; ++x) M[k][x] = idx == 0 ? kDst4[k][x] : dct_coef(*n, k, x);
+}
+
+/* enc@0x4c2210.. H265_2dDct{4,8,16,32}_c / enc@0x4c2250 H265_2dDst4x4_c — SURVEY.md B.3.
+ * pass 1 (rows of src, output transposed into tmp) shift 2*log2N-2; pass 2 shift 7; round half up. */
+void ks265o_fwd_transform(int idx, const int16_t *src, int16_t *dst, int srcStride, int dstStride, int16_t *tmp)
+{
+    int M[32][32], n;
+    load_matrix(idx, M, &n);
+    int log2n = n == 4 ? 2 : n == 8 ? 3 : n == 16 ? 4 : 5;
+    int s1 = 2 * log2n - 2, r1 = 1 << (s1 - 1);
+    for (int j = 0; j < n; ++j)          /* source row j */
+        for (int k = 0; k < n; ++k) {
+            int acc = 0;
+            for (int x = 0; x < n; ++x) acc += M[k][x] * src[j * srcStride + x];
+            tmp[k * n + j] = (int16_t)((acc + r1) >> s1);
+        }
+    for (int j = 0; j < n; ++j)          /* tmp row j */
+        for (int k = 0; k < n; ++k) {
+            int acc = 0;
+            for (int x = 0; x < n; ++x) acc += M[k][x] * tmp[j * n + x];
+            dst[k * dstStride + j] = (int16_t)((acc + 64) >> 7);
+        }
+}
+
+/* enc@0x448c40 H265_2dIDst4x4_c, enc@0x448f60.. H265_2dIDct{4,8,16,32}_c — SURVEY.md B.4.
+ * T = clip16((M^T C + 64) >> 7); R = (T M + 2048) >> 12; dst = clip8(pred + R). lastX/lastY only let the
+ * reference skip known-zero columns/rows; the arithmetic result is the full transform. */
+void ks265o_inv_transform(int idx, const int16_t *coef, uint8_t *dst, const uint8_t *pred, int coefStride, int dstStride,
+                          int predStride, int16_t *tmp, int lastX, int lastY)
+{
+    (void)lastX; (void)lastY;
+    int M[32][32], n;
+    load_matrix(idx, M, &n);
+    for (int x = 0; x < n; ++x)          /* column x of coef */
+        for (int y = 0; y < n; ++y) {
+            int acc = 0;
+            for (int k = 0; k < n; ++k) acc += M[k][y] * coef[k * coefStride + x];
+            tmp[y * n + x] = clip16((acc + 64) >> 7);
+        }
+    for (int y = 0; y < n; ++y)
+        for (int x = 0; x < n; ++x) {
+            int acc = 0;
+            for (int k = 0; k < n; ++k) acc += tmp[y * n + k] * M[k][x];
+            dst[y * dstStride + x] = clip8((int)pred[y * predStride + x] + ((acc + 2048) >> 12));
+        }
+}
+
+/* ------------------------------------------------------------------ quant / dequant */
+
+static const int kQuantScales[6] = {26214, 23302, 20560, 18396, 16384, 14564};  /* g_quantScales */
+static const int kInvQuantScales[6] = {40, 45, 51, 57, 64, 72};                  /* g_invQuantScales */
+
+/* enc@0x4a9c90 H265_GetBaseQuantParam — SURVEY.md B.5 / Appendix C */
+void ks265o_get_base_quant_param(int qp, int sliceType, ks265o_quant_param *p)
+{
+    p->scale = kQuantScales[qp % 6];
+    p->qbits = 21 + qp / 6;
+    p->offF = sliceType == 2 ? 171 : 85;
+    p->dq = kInvQuantScales[qp % 6] << (qp / 6);
+    p->minus1 = -1;
+    p->per = qp / 6;
+}
+
+/* enc@0x4a9cf0 H265QuantBlock_c (via H265Quant{4,8,16,32}_c enc@0x4a9de0..) — SURVEY.md a7 / B.5 */
+int ks265o_quant(const int16_t *coef, int16_t *lvl, int stride, int scale, int off, int qbits, int16_t *deltaU, int n)
+{
+    int nz = 0;
+    for (int y = 0; y < n; ++y)
+        for (int x = 0; x < n; ++x) {
+            int c = coef[y * stride + x];
+            int a = iabs(c) * scale;
+            int l = (a + off) >> qbits;
+            deltaU[y * stride + x] = (int16_t)((a - (l << qbits)) >> (qbits - 8));
+            if (l > 32767) l = 32767;
+            if (l) ++nz;
+            lvl[y * stride + x] = (int16_t)(c < 0 ? -l : l);
+        }
+    return nz;
+}
+
+/* enc@0x439210 H265DeQuantBlock_c — SURVEY.md a8 / B.5 */
+void ks265o_dequant(const int16_t *lvl, int16_t *coef, int stride, int scale, int add, int shift, int lastX, int lastY)
+{
+    int cols = (lastX + 4) & ~3;
+    for (int y = 0; y <= lastY; ++y)
+        for (int x = 0; x < cols; ++x) coef[y * stride + x] = clip16((lvl[y * stride + x] * scale + add) >> shift);
+}
+
+/* ------------------------------------------------------------------ deblocking */
+
+/* uiTCTable enc@0x4dc3e0, uiBetaTable enc@0x4dc3a0 (normative HEVC tables 8-12) */
+const uint8_t ks265o_tc_table[54] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1,
+                                     2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 5, 5, 6, 6, 7, 8, 9, 10, 11, 13, 14, 16, 18, 20, 22, 24};
+const uint8_t ks265o_beta_table[52] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15,
+                                       16, 17, 18, 20, 22, 24, 26, 28, 30, 32, 34, 36, 38, 40, 42, 44, 46, 48, 50, 52, 54,
+                                       56, 58, 60, 62, 64};
+
+/* one 4-line luma segment; xs = step across the edge, ys = step along it */
+static void luma_segment(uint8_t *pix, long xs, long ys, int beta, int tc, int filterP, int filterQ)
+{
+#define P(i, l) ((int)pix[(l) * ys - ((i) + 1) * xs])
+#define Q(i, l) ((int)pix[(l) * ys + (i) * xs])
+    int dp0 = iabs(P(2, 0) - 2 * P(1, 0) + P(0, 0)), dp3 = iabs(P(2, 3) - 2 * P(1, 3) + P(0, 3));
+    int dq0 = iabs(Q(2, 0) - 2 * Q(1, 0) + Q(0, 0)), dq3 = iabs(Q(2, 3) - 2 * Q(1, 3) + Q(0, 3));
+    int dpq0 = dp0 + dq0, dpq3 = dp3 + dq3, dp = dp0 + dp3, dq = dq0 + dq3, d = dpq0 + dpq3;
+    if (d >= beta) return;
+    int s0 = (2 * dpq0 < (beta >> 2)) && (iabs(P(3, 0) - P(0, 0)) + iabs(Q(0, 0) - Q(3, 0)) < (beta >> 3)) &&
+             (iabs(P(0, 0) - Q(0, 0)) < ((5 * tc + 1) >> 1));
+    int s3 = (2 * dpq3 < (beta >> 2)) && (iabs(P(3, 3) - P(0, 3)) + iabs(Q(0, 3) - Q(3, 3)) < (beta >> 3)) &&
+             (iabs(P(0, 3) - Q(0, 3)) < ((5 * tc + 1) >> 1));
+    int side = (beta + (beta >> 1)) >> 3;
+    int dEp = dp < side, dEq = dq < side;
+    for (int l = 0; l < 4; ++l) {
+        int p0 = P(0, l), p1 = P(1, l), p2 = P(2, l), p3 = P(3, l);
+        int q0 = Q(0, l), q1 = Q(1, l), q2 = Q(2, l), q3 = Q(3, l);
+        uint8_t *pp = pix + l * ys;
+        if (s0 && s3) {
+            if (filterP) {
+                pp[-1 * xs] = clip8(clip3(p0 - 2 * tc, p0 + 2 * tc, (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3));
+                pp[-2 * xs] = clip8(clip3(p1 - 2 * tc, p1 + 2 * tc, (p2 + p1 + p0 + q0 + 2) >> 2));
+                pp[-3 * xs] = clip8(clip3(p2 - 2 * tc, p2 + 2 * tc, (2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3));
+            }
+            if (filterQ) {
+                pp[0] = clip8(clip3(q0 - 2 * tc, q0 + 2 * tc, (p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3));
+                pp[1 * xs] = clip8(clip3(q1 - 2 * tc, q1 + 2 * tc, (p0 + q0 + q1 + q2 + 2) >> 2));
+                pp[2 * xs] = clip8(clip3(q2 - 2 * tc, q2 + 2 * tc, (p0 + q0 + q1 + 3 * q2 + 2 * q3 + 4) >> 3));
+            }
+        } else {
+            int delta = (9 * (q0 - p0) - 3 * (q1 - p1) + 8) >> 4;
+            if (iabs(delta) < 10 * tc) {
+                delta = clip3(-tc, tc, delta);
+                if (filterP) {
+                    pp[-1 * xs] = clip8(p0 + delta);
+                    if (dEp) pp[-2 * xs] = clip8(p1 + clip3(-(tc >> 1), tc >> 1, (((p2 + p0 + 1) >> 1) - p1 + delta) >> 1));
+                }
+                if (filterQ) {
+                    pp[0] = clip8(q0 - delta);
+                    if (dEq) pp[1 * xs] = clip8(q1 + clip3(-(tc >> 1), tc >> 1, (((q2 + q0 + 1) >> 1) - q1 - delta) >> 1));
+                }
+            }
+        }
+    }
+#undef P
+#undef Q
+}
+
+/* enc@0x403630 EdgeFilterLumaVer_c — SURVEY.md B.6: vertical edge, lines advance by stride */
+void ks265o_edge_filter_luma_ver(uint8_t *pix, int stride, int beta, int tc, int length, int filterP, int filterQ)
+{
+    for (int s = 0; s < length / 4; ++s) luma_segment(pix + (long)s * 4 * stride, 1, stride, beta, tc, filterP, filterQ);
+}
+
+/* enc@0x4038c0 EdgeFilterLumaHor_c — horizontal edge, lines advance by 1 */
+void ks265o_edge_filter_luma_hor(uint8_t *pix, int stride, int beta, int tc, int length, int filterP, int filterQ)
+{
+    for (int s = 0; s < length / 4; ++s) luma_segment(pix + s * 4, stride, 1, beta, tc, filterP, filterQ);
+}
+
+static void chroma_line(uint8_t *pix, long xs, int tc, int filterP, int filterQ)
+{
+    int p1 = pix[-2 * xs], p0 = pix[-xs], q0 = pix[0], q1 = pix[xs];
+    int delta = clip3(-tc, tc, (((q0 - p0) << 2) + p1 - q1 + 4) >> 3);
+    if (filterP) pix[-xs] = clip8(p0 + delta);
+    if (filterQ) pix[0] = clip8(q0 - delta);
+}
+
+/* enc@0x403c50 PixelFilterChromaVer_c(pix, stride, tc, length, filterP, filterQ) */
+void ks265o_pixel_filter_chroma_ver(uint8_t *pix, int stride, int tc, int length, int filterP, int filterQ)
+{
+    for (int l = 0; l < length; ++l) chroma_line(pix + (long)l * stride, 1, tc, filterP, filterQ);
+}
+
+/* enc@0x403d10 PixelFilterChromaHor_c */
+void ks265o_pixel_filter_chroma_hor(uint8_t *pix, int stride, int tc, int length, int filterP, int filterQ)
+{
+    for (int l = 0; l < length; ++l) chroma_line(pix + l, stride, tc, filterP, filterQ);
+}
+
+/* ------------------------------------------------------------------ interpolation */
+
+static const int8_t kLumaTaps[4][8] = {{0, 0, 0, 64, 0, 0, 0, 0}, {-1, 4, -10, 58, 17, -5, 1, 0},
+                                       {-1, 4, -11, 40, 40, -11, 4, -1}, {0, 1, -5, 17, 58, -10, 4, -1}};
+static const int8_t kChromaTaps[8][4] = {{0, 64, 0, 0}, {-2, 58, 10, -2}, {-4, 54, 16, -2}, {-6, 46, 28, -4},
+                                         {-4, 36, 36, -4}, {-4, 28, 46, -6}, {-2, 16, 54, -4}, {-2, 10, 58, -2}};
+
+#define INTERP_BODY(SRC_T, TAPS, NT, STEP, EXPR)                                             \
+    for (int y = 0; y < h; ++y)                                                              \
+        for (int x = 0; x < w; ++x) {                                                        \
+            int sum = 0;                                                                     \
+            for (int i = 0; i < NT; ++i) sum += TAPS[frac][i] * (int)src[y * srcStride + x + (i - (NT / 2 - 1)) * (STEP)]; \
+            dst[y * dstStride + x] = EXPR;                                                   \
+        }
+
+/* enc@0x40e4f0 interpLumaHor8to8_c — SURVEY.md B.7 */
+void ks265o_interp_luma_hor_8to8(uint8_t *dst, int dstStride, const uint8_t *src, int srcStride, int w, int h, int frac)
+{ INTERP_BODY(uint8_t, kLumaTaps, 8, 1, clip8((sum + 32) >> 6)) }
+/* enc@0x40f0c0 interpLumaVer8to8_c */
+void ks265o_interp_luma_ver_8to8(uint8_t *dst, int dstStride, const uint8_t *src, int srcStride, int w, int h, int frac)
+{ INTERP_BODY(uint8_t, kLumaTaps, 8, srcStride, clip8((sum + 32) >> 6)) }
+/* enc@0x40eb80 interpLumaHor8to16_c: 14-bit intermediate = raw tap sum (NO -8192 offset, unlike HM) */
+void ks265o_interp_luma_hor_8to16(int16_t *dst, int dstStride, const uint8_t *src, int srcStride, int w, int h, int frac)
+{ INTERP_BODY(uint8_t, kLumaTaps, 8, 1, (int16_t)sum) }
+/* enc@0x40f950 interpLumaVer8to16_c */
+void ks265o_interp_luma_ver_8to16(int16_t *dst, int dstStride, const uint8_t *src, int srcStride, int w, int h, int frac)
+{ INTERP_BODY(uint8_t, kLumaTaps, 8, srcStride, (int16_t)sum) }
+/* enc@0x4100b0 interpLumaVer16to8_c: second stage, (sum + 2^11) >> 12 */
+void ks265o_interp_luma_ver_16to8(uint8_t *dst, int dstStride, const int16_t *src, int srcStride, int w, int h, int frac)
+{ INTERP_BODY(int16_t, kLumaTaps, 8, srcStride, clip8((sum + 2048) >> 12)) }
+/* enc@0x4109b0 interpLumaVer16to16_c: second stage kept at 14 bit, sum >> 6 */
+void ks265o_interp_luma_ver_16to16(int16_t *dst, int dstStride, const int16_t *src, int srcStride, int w, int h, int frac)
+{ INTERP_BODY(int16_t, kLumaTaps, 8, srcStride, (int16_t)(sum >> 6)) }
+/* enc@0x4111c0.. interpChroma* — 4-tap, 1/8-sample */
+void ks265o_interp_chroma_hor_8to8(uint8_t *dst, int dstStride, const uint8_t *src, int srcStride, int w, int h, int frac)
+{ INTERP_BODY(uint8_t, kChromaTaps, 4, 1, clip8((sum + 32) >> 6)) }
+void ks265o_interp_chroma_ver_8to8(uint8_t *dst, int dstStride, const uint8_t *src, int srcStride, int w, int h, int frac)
+{ INTERP_BODY(uint8_t, kChromaTaps, 4, srcStride, clip8((sum + 32) >> 6)) }
+void ks265o_interp_chroma_hor_8to16(int16_t *dst, int dstStride, const uint8_t *src, int srcStride, int w, int h, int frac)
+{ INTERP_BODY(uint8_t, kChromaTaps, 4, 1, (int16_t)sum) }
+void ks265o_interp_chroma_ver_8to16(int16_t *dst, int dstStride, const uint8_t *src, int srcStride, int w, int h, int frac)
+{ INTERP_BODY(uint8_t, kChromaTaps, 4, srcStride, (int16_t)sum) }
+void ks265o_interp_chroma_ver_16to8(uint8_t *dst, int dstStride, const int16_t *src, int srcStride, int w, int h, int frac)
+{ INTERP_BODY(int16_t, kChromaTaps, 4, srcStride, clip8((sum + 2048) >> 12)) }
+void ks265o_interp_chroma_ver_16to16(int16_t *dst, int dstStride, const int16_t *src, int srcStride, int w, int h, int frac)
+{ INTERP_BODY(int16_t, kChromaTaps, 4, srcStride, (int16_t)(sum >> 6)) }
+
+/* ------------------------------------------------------------------ SAO */
+
+/* enc@0x43e4e0 SaoApplyOffsetBo_c — SURVEY.md B.9.  Read from the disassembly and pinned by the fixtures:
+ * columns are processed in groups of 4 (width rounded UP to a multiple of 4), and offsets[k] goes to
+ * table[bandPosition + k] without the normative "& 31" wrap (entries past 31 fall off the 32-entry table;
+ * the reference encoder never selects bandPosition > 28). */
+void ks265o_sao_apply_bo(const int8_t *offsets, uint8_t *rec, int stride, int height, int width, int bandPosition)
+{
+    int8_t table[32];
+    memset(table, 0, sizeof table);
+    for (int k = 0; k < 4; ++k)
+        if (bandPosition + k < 32) table[bandPosition + k] = offsets[k];
+    int cols = (width + 3) & ~3;
+    for (int y = 0; y < height; ++y)
+        for (int x = 0; x < cols; ++x) rec[y * stride + x] = clip8((int)rec[y * stride + x] + table[rec[y * stride + x] >> 3]);
+}
+
+/* enc@0x4ae9c0 statSaoBoEo01_c — SURVEY.md B.10: packed (sum<<12 | count) accumulators */
+void ks265o_stat_sao_bo_eo01(int *eoJoint, int *bo, const uint8_t *org, const uint8_t *rec, int recStride, int orgStride,
+                             int width, int height, int rowStep)
+{
+    for (int y = 0; y < height; y += rowStep)
+        for (int x = 0; x < width; ++x) {
+            const uint8_t *r = rec + y * recStride + x;
+            int d = (int8_t)(org[y * orgStride + x] - r[0]);
+            int v = (int)(((unsigned)d << 12) | 1u);
+            int c0 = 2 + sgn((int)r[0] - (int)r[-1]) + sgn((int)r[0] - (int)r[1]);
+            int c1 = 2 + sgn((int)r[0] - (int)r[-recStride]) + sgn((int)r[0] - (int)r[recStride]);
+            bo[r[0] >> 3] += v;
+            eoJoint[(c1 << 3) | c0] += v;
+        }
+}
+
+/* enc@0x43e650 SaoApplyOffsetEo0_c / 0x43e970 Eo1 / 0x43edc0 Eo2 / 0x43ef70 Eo3 — "plain" mode (trailing
+ * flag arguments 0: every neighbour is read from the picture itself, un-SAO'd).  `offsets` is the 5-entry
+ * table indexed by the raw edge index 2 + sign(c-a) + sign(c-b) (read from the disassembly: movsbl (%rdi,idx)).
+ * The saved-line modes of the reference only exist because its CTU pipeline filters in place; the frame-level
+ * kernels are out-of-place, which is what this model computes. */
+void ks265o_sao_apply_eo(int cls, const int8_t *offsets, uint8_t *rec, int stride, int height, int width)
+{
+    static const int dx[4] = {1, 0, 1, -1}, dy[4] = {0, 1, 1, 1};
+    uint8_t *copy = (uint8_t *)malloc((size_t)(height + 2) * (size_t)(width + 2));
+    int cs = width + 2;
+    for (int y = -1; y <= height; ++y)
+        for (int x = -1; x <= width; ++x) copy[(y + 1) * cs + x + 1] = rec[y * stride + x];
+    for (int y = 0; y < height; ++y)
+        for (int x = 0; x < width; ++x) {
+            int c = copy[(y + 1) * cs + x + 1];
+            int a = copy[(y + 1 - dy[cls]) * cs + x + 1 - dx[cls]], b = copy[(y + 1 + dy[cls]) * cs + x + 1 + dx[cls]];
+            rec[y * stride + x] = clip8(c + offsets[2 + sgn(c - a) + sgn(c - b)]);
+        }
+    free(copy);
+}

@@ -1,0 +1,430 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE (builder container only): generate tests/golden/*.npz.
+
+Each fixture holds seeded random INPUTS and the OUTPUTS the reference binary's own `_c`
+kernels produced for them (called in-place inside /root/reference/ubuntu_x64/appencoder via
+probe_shim.c).  Only data is recorded; nothing of the reference is copied.
+
+Run:  python oracle/ref_probe/gen_golden.py        (needs /root/reference; ~1 min)
+"""
+from __future__ import annotations
+
+import os
+import sys
+import zlib
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from golden_io import save_cases  # noqa: E402
+from refprobe import Buf, RefProbe  # noqa: E402
+
+rng = np.random.default_rng(20260926)
+
+
+def u8(shape, lo=0, hi=256):
+    return rng.integers(lo, hi, shape, dtype=np.uint8)
+
+
+def pix_pair(h, w, stride_a, stride_b, mode):
+    """Two u8 planes; 'mode' picks the content class."""
+    if mode == "rand":
+        a, b = u8((h + 2, stride_a)), u8((h + 2, stride_b))
+    elif mode == "near":  # b = a + small noise (typical ME content)
+        a = u8((h + 2, stride_a))
+        b = np.zeros((h + 2, stride_b), np.uint8)
+        m = min(stride_a, stride_b)
+        b[:, :m] = np.clip(a[:, :m].astype(int) + rng.integers(-6, 7, (h + 2, m)), 0, 255).astype(np.uint8)
+    else:  # extreme
+        a = np.full((h + 2, stride_a), 255, np.uint8)
+        b = np.zeros((h + 2, stride_b), np.uint8)
+    return a, b
+
+
+def gen_sad(p: RefProbe):
+    shapes = [(4, 4), (8, 8), (16, 16), (32, 32), (64, 64), (8, 4), (4, 8), (16, 8), (8, 16), (32, 16), (16, 32),
+              (64, 32), (32, 64), (12, 16), (16, 12), (24, 32), (32, 24), (48, 64), (64, 48), (16, 4), (4, 16)]
+    pend = []
+    for (h, w) in shapes:
+        for mode in ("rand", "near", "extreme"):
+            sa, sb = w + int(rng.integers(0, 9)), w + int(rng.integers(0, 40))
+            a, b = pix_pair(h, w, sa, sb, mode)
+            A, B = Buf(a), Buf(b)
+            pend.append((dict(a=a, b=b, sa=sa, sb=sb, h=h, w=w), p.call("sad_c", A, B, sa, sb, h, w)))
+    p.run()
+    return [dict(c, exp=np.uint32(call.ret & 0xFFFFFFFF)) for c, call in pend]
+
+
+def gen_sad4(p: RefProbe):
+    pend = []
+    for w in (4, 8, 16, 32, 64):
+        for h in (4, 8, 16, 32, 64):
+            if h > 4 * w or w > 4 * h:
+                continue
+            for mode in ("rand", "near"):
+                sf, sr = w + int(rng.integers(0, 5)), w + 2 + int(rng.integers(0, 30))
+                fenc = u8((h, sf))
+                ref = u8((h + 2, sr)) if mode == "rand" else np.clip(
+                    np.pad(fenc[:, :w], ((1, 1), (1, sr - w - 1)), mode="edge").astype(int) + rng.integers(-5, 6, (h + 2, sr)), 0, 255).astype(np.uint8)
+                F, R, O = Buf(fenc), Buf(ref), Buf(np.zeros(4, np.uint32))
+                pend.append((dict(fenc=fenc, ref=ref, sf=sf, sr=sr, h=h, w=w, ref_off=sr + 1),
+                             p.call("sad4_c", F, R.at(sr + 1), sf, sr, h, O, w), O))
+    p.run()
+    return [dict(c, exp=o.out) for c, _, o in pend]
+
+
+def gen_sad3(p: RefProbe):
+    pend = []
+    for w in (4, 8, 16, 32, 64):
+        for h in (8, 16, 64) if w >= 8 else (4, 8):
+            sf, sr = w + int(rng.integers(0, 5)), w + 8 + int(rng.integers(0, 30))
+            fenc, ref = u8((h, sf)), u8((h + 8, sr))
+            offs = [int(rng.integers(0, 8)) * sr + int(rng.integers(0, 8)) for _ in range(3)]
+            F, R, O = Buf(fenc), Buf(ref), Buf(np.zeros(3, np.uint32))
+            pend.append((dict(fenc=fenc, ref=ref, sf=sf, sr=sr, h=h, w=w, offs=np.array(offs)),
+                         p.call("sad3_c", F, R.at(offs[0]), R.at(offs[1]), R.at(offs[2]), sf, sr, h, O, w), O))
+    p.run()
+    return [dict(c, exp=o.out) for c, _, o in pend]
+
+
+def gen_sad4blk(p: RefProbe):
+    pend = []
+    for _ in range(6):
+        sa, sb = 16 + int(rng.integers(0, 9)), 16 + int(rng.integers(0, 40))
+        a, b = pix_pair(16, 16, sa, sb, "rand")
+        A, B, O = Buf(a), Buf(b), Buf(np.zeros(4, np.uint32))
+        pend.append((dict(a=a, b=b, sa=sa, sb=sb), p.call("sad4blk_8x8_c", A, B, sa, sb, O), O))
+    p.run()
+    return [dict(c, exp=o.out) for c, _, o in pend]
+
+
+def gen_sse(p: RefProbe):
+    pend = []
+    for n in (4, 8, 16, 32, 64):
+        for mode in ("rand", "near", "extreme"):
+            sa, sb = n + int(rng.integers(0, 9)), n + int(rng.integers(0, 40))
+            a, b = pix_pair(n, n, sa, sb, mode)
+            pend.append((dict(a=a, b=b, sa=sa, sb=sb, n=n), p.call(f"sse_c{n}", Buf(a), Buf(b), sa, sb)))
+    p.run()
+    return [dict(c, exp=np.uint32(call.ret & 0xFFFFFFFF)) for c, call in pend]
+
+
+def gen_had(p: RefProbe):
+    shapes = [(2, 2), (4, 4), (8, 8), (16, 16), (32, 32), (64, 64), (8, 4), (4, 8), (16, 8), (8, 16), (6, 6), (12, 16),
+              (16, 12), (64, 32), (32, 64), (2, 4), (24, 24)]
+    pend = []
+    for (h, w) in shapes:
+        for mode in ("rand", "near", "extreme"):
+            sa, sb = w + int(rng.integers(0, 9)), w + int(rng.integers(0, 40))
+            a, b = pix_pair(h, w, sa, sb, mode)
+            pend.append((dict(a=a, b=b, sa=sa, sb=sb, h=h, w=w), p.call("had_c", Buf(a), Buf(b), sa, sb, h, w)))
+    p.run()
+    return [dict(c, exp=np.uint32(call.ret & 0xFFFFFFFF)) for c, call in pend]
+
+
+FWD = ["dst4", "dct4", "dct8", "dct16", "dct32"]
+INV = ["idst4", "idct4", "idct8", "idct16", "idct32"]
+SIZES = [4, 4, 8, 16, 32]
+
+
+def gen_fwd(p: RefProbe):
+    pend = []
+    for idx, name in enumerate(FWD):
+        n = SIZES[idx]
+        for k in range(10):
+            ss, ds = n + (0 if k % 2 == 0 else 8), n + (0 if k % 3 == 0 else 16)
+            if k < 6:
+                src = rng.integers(-255, 256, (n, ss)).astype(np.int16)
+            elif k < 8:
+                src = np.full((n, ss), 255 if k == 6 else -255, np.int16)
+            elif k == 8:  # impulse: pins every matrix entry
+                src = np.zeros((n, ss), np.int16)
+                src[int(rng.integers(0, n)), int(rng.integers(0, n))] = 255
+            else:
+                src = rng.integers(-2000, 2001, (n, ss)).astype(np.int16)
+            S, D, T = Buf(src), Buf(np.zeros((n, ds), np.int16)), Buf(np.zeros((n, n), np.int16))
+            pend.append((dict(idx=idx, src=src, ss=ss, ds=ds), p.call(name, S, D, ss, ds, T), D))
+    p.run()
+    return [dict(c, exp=d.out) for c, _, d in pend]
+
+
+def sparse_coefs(n, stride, kind):
+    c = np.zeros((n, stride), np.int16)
+    if kind == "dense":
+        c[:, :n] = rng.integers(-600, 601, (n, n))
+    elif kind == "dc":
+        c[0, 0] = int(rng.integers(-2000, 2001))
+    elif kind == "big":
+        c[:, :n] = rng.integers(-32768, 32768, (n, n))
+    else:  # low-frequency corner, like real quantised blocks
+        m = max(2, n // 4)
+        c[:m, :m] = rng.integers(-300, 301, (m, m))
+    return c
+
+
+def last_xy(c, n):
+    nz = np.argwhere(c[:, :n] != 0)
+    if len(nz) == 0:
+        return 0, 0
+    return int(nz[:, 1].max()), int(nz[:, 0].max())
+
+
+def gen_inv(p: RefProbe):
+    pend = []
+    for idx, name in enumerate(INV):
+        n = SIZES[idx]
+        for k, kind in enumerate(["dense", "dense", "corner", "corner", "dc", "big", "dense", "corner"]):
+            cs, ds, ps = n + (0 if k % 2 == 0 else 8), n + 3 * (k % 3), n + 5 * (k % 2)
+            coef = sparse_coefs(n, cs, kind)
+            pred = u8((n, ps))
+            lx, ly = (n - 1, n - 1) if k < 6 else last_xy(coef, n)
+            variants = [name]
+            if k >= 6 and n >= 8:
+                variants.append(name + "_opt")
+            if kind == "dc":
+                variants.append(name + "_dc")
+            for v in variants:
+                C, D, P, T = Buf(coef), Buf(np.zeros((n, ds), np.uint8)), Buf(pred), Buf(np.zeros(64 * 64, np.int16))
+                pend.append((dict(idx=idx, coef=coef, pred=pred, cs=cs, ds=ds, ps=ps, lx=lx, ly=ly, variant=v),
+                             p.call(v, C, D, P, cs, ds, ps, T, lx, ly), D))
+    p.run()
+    return [dict(c, exp=d.out[:, :SIZES[c["idx"]]]) for c, _, d in pend]
+
+
+def quant_params(qp, slice_type):
+    scales = [26214, 23302, 20560, 18396, 16384, 14564]
+    inv = [40, 45, 51, 57, 64, 72]
+    return dict(scale=scales[qp % 6], qbits=21 + qp // 6, offF=171 if slice_type == 2 else 85, dq=inv[qp % 6] << (qp // 6))
+
+
+def gen_quant(p: RefProbe):
+    pend = []
+    # pin H265_GetBaseQuantParam itself
+    gq = []
+    for qp in (0, 1, 5, 22, 27, 32, 37, 51):
+        for st in (0, 1, 2):
+            P = Buf(np.zeros(6, np.int32))
+            gq.append((qp, st, p.call("get_base_quant_param", qp, st, P), P))
+    for li, n in enumerate((4, 8, 16, 32)):
+        log2n = li + 2
+        for qp in (0, 22, 27, 32, 37, 51):
+            for st in (2, 0):
+                q = quant_params(qp, st)
+                qbits = q["qbits"] - log2n
+                off = q["offF"] << (qbits - 9)
+                stride = n
+                amp = 32767 if qp == 0 else 3000
+                coef = rng.integers(-amp, amp + 1, (n, stride)).astype(np.int16)
+                coef[rng.random((n, stride)) < 0.5] //= 16
+                C, L, U = Buf(coef), Buf(np.zeros((n, stride), np.int16)), Buf(np.zeros((n, stride), np.int16))
+                pend.append((dict(n=n, qp=qp, st=st, coef=coef, stride=stride, scale=q["scale"], off=off, qbits=qbits),
+                             p.call(f"quant{n}", C, L, stride, q["scale"], off, qbits, U), L, U))
+    p.run()
+    for qp, st, call, P in gq:
+        exp = quant_params(qp, st)
+        got = P.out
+        assert (got[0], got[1], got[2], got[3], got[4], got[5]) == (exp["scale"], exp["qbits"], exp["offF"], exp["dq"], -1, qp // 6), (qp, st, got)
+    cases = [dict(c, exp_lvl=l.out, exp_du=u.out, exp_nz=np.int32(call.ret & 0xFFFFFFFF)) for c, call, l, u in pend]
+    cases.append(dict(kind="base_param", table=np.array([[qp, st, *P.out] for qp, st, _, P in gq], np.int32)))
+    return cases
+
+
+def gen_dequant(p: RefProbe):
+    pend = []
+    for li, n in enumerate((4, 8, 16, 32)):
+        log2n = li + 2
+        for qp in (0, 22, 27, 37, 51):
+            q = quant_params(qp, 0)
+            shift = log2n - 1
+            add = 1 << (shift - 1)
+            for kind in ("full", "corner", "odd"):
+                lvl = rng.integers(-40, 41, (n, n)).astype(np.int16)
+                if qp == 51:
+                    lvl *= 30
+                if kind == "full":
+                    lx, ly = n - 1, n - 1
+                elif kind == "corner":
+                    lx, ly = max(0, n // 4 - 1), max(0, n // 2 - 1)
+                else:
+                    lx, ly = int(rng.integers(0, n)), int(rng.integers(0, n))
+                L, C = Buf(lvl), Buf(np.full((n, n), 0x5A5A, np.int16))
+                pend.append((dict(n=n, lvl=lvl, scale=q["dq"], add=add, shift=shift, lx=lx, ly=ly, fill=0x5A5A),
+                             p.call("dequant_block", L, C, n, q["dq"], add, shift, lx, ly), C))
+    p.run()
+    return [dict(c, exp=o.out) for c, _, o in pend]
+
+
+def gen_residual(p: RefProbe):
+    addr = {4: 0x4345F0, 8: 0x434630, 16: 0x434680, 32: 0x4346D0, 64: 0x434720}
+    pend = []
+    for n in (4, 8, 16, 32, 64):
+        so, sp = n + int(rng.integers(0, 9)), n + int(rng.integers(0, 40))
+        org, pred = pix_pair(n, n, so, sp, "rand")
+        R = Buf(np.zeros((n, n), np.int16))
+        pend.append((dict(n=n, org=org, pred=pred, so=so, sp=sp), p.call(addr[n], R, Buf(org), Buf(pred), so, sp), R))
+    p.run()
+    return [dict(c, exp=r.out) for c, _, r in pend]
+
+
+def deblock_patch(h, w, kind):
+    """Content with a blocky step so that all filter branches (strong/weak/none) are hit."""
+    base = rng.integers(40, 200)
+    img = np.full((h, w), base, np.int32)
+    step = int(rng.integers(-14, 15))
+    if kind == "smooth":
+        img[:, w // 2:] += step
+        img += rng.integers(-1, 2, (h, w))
+    elif kind == "texture":
+        img[:, w // 2:] += step
+        img += rng.integers(-6, 7, (h, w))
+    elif kind == "ramp":
+        img += (np.arange(w)[None, :] * int(rng.integers(-3, 4)))
+        img[:, w // 2:] += step
+    else:
+        img = rng.integers(0, 256, (h, w))
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def gen_deblock_luma(p: RefProbe):
+    pend = []
+    kinds = ["smooth", "texture", "ramp", "rand"]
+    for i in range(160):
+        kind = kinds[i % 4]
+        beta, tc = int(rng.integers(0, 65)), int(rng.integers(0, 25))
+        fp, fq = (1, 1) if i % 7 else (int(rng.integers(0, 2)), int(rng.integers(0, 2)))
+        length = 4 * int(rng.integers(1, 5))
+        for orient in ("ver", "hor"):
+            if orient == "ver":
+                img = deblock_patch(length, 16, kind)
+                stride, off = 16, 8
+            else:
+                img = deblock_patch(length, 16, kind).T.copy()  # step across rows
+                stride, off = length, 8 * length
+            B = Buf(img)
+            pend.append((dict(orient=orient, img=img, stride=stride, off=off, beta=beta, tc=tc, length=length, fp=fp, fq=fq),
+                         p.call("edge_luma_" + orient, B.at(off), stride, beta, tc, length, fp, fq), B))
+    p.run()
+    return [dict(c, exp=b.out) for c, _, b in pend]
+
+
+def gen_deblock_chroma(p: RefProbe):
+    pend = []
+    for i in range(60):
+        tc = int(rng.integers(0, 25))
+        fp, fq = (1, 1) if i % 5 else (int(rng.integers(0, 2)), int(rng.integers(0, 2)))
+        length = int(rng.integers(1, 9))
+        for orient in ("ver", "hor"):
+            if orient == "ver":
+                img = deblock_patch(length, 8, "texture" if i % 2 else "rand")
+                stride, off = 8, 4
+            else:
+                img = deblock_patch(length, 8, "texture" if i % 2 else "rand").T.copy()
+                stride, off = length, 4 * length
+            B = Buf(img)
+            pend.append((dict(orient=orient, img=img, stride=stride, off=off, tc=tc, length=length, fp=fp, fq=fq),
+                         p.call("chroma_" + orient, B.at(off), stride, tc, length, fp, fq), B))
+    p.run()
+    return [dict(c, exp=b.out) for c, _, b in pend]
+
+
+def gen_interp(p: RefProbe):
+    pend = []
+    specs = [  # name, src dtype, dst dtype, taps, direction, nfrac
+        ("luma_hor_8to8", np.uint8, np.uint8, 8, "h", 3), ("luma_ver_8to8", np.uint8, np.uint8, 8, "v", 3),
+        ("luma_hor_8to16", np.uint8, np.int16, 8, "h", 3), ("luma_ver_8to16", np.uint8, np.int16, 8, "v", 3),
+        ("luma_ver_16to8", np.int16, np.uint8, 8, "v", 3), ("luma_ver_16to16", np.int16, np.int16, 8, "v", 3),
+        ("chroma_hor_8to8", np.uint8, np.uint8, 4, "h", 7), ("chroma_ver_8to8", np.uint8, np.uint8, 4, "v", 7),
+        ("chroma_hor_8to16", np.uint8, np.int16, 4, "h", 7), ("chroma_ver_8to16", np.uint8, np.int16, 4, "v", 7),
+        ("chroma_ver_16to8", np.int16, np.uint8, 4, "v", 7), ("chroma_ver_16to16", np.int16, np.int16, 4, "v", 7),
+    ]
+    for name, sdt, ddt, taps, direc, nfrac in specs:
+        for frac in range(1, nfrac + 1):
+            for (w, h) in ((8, 8), (16, 4), (4, 16), (32, 8)) if frac % 2 else ((64, 4), (12, 12)):
+                ss, ds = w + 8 + int(rng.integers(0, 8)), w + int(rng.integers(0, 8))
+                if sdt == np.uint8:
+                    src = u8((h + 8, ss))
+                    if frac == 2:
+                        src[:] = np.where(rng.random(src.shape) < 0.5, 0, 255)  # clip-exercising
+                else:
+                    src = rng.integers(-8192, 8192 - 1, (h + 8, ss)).astype(np.int16)
+                    if frac == 2:
+                        src[:] = np.where(rng.random(src.shape) < 0.5, -8192, 8128)
+                off = (3 * ss + 3) if taps == 8 else (1 * ss + 1)
+                S, D = Buf(src), Buf(np.zeros((h, ds), ddt))
+                pend.append((dict(name=name, src=src, ss=ss, ds=ds, w=w, h=h, frac=frac, off=off),
+                             p.call(name, D, ds, S.at(off * src.itemsize), ss, w, h, frac), D))
+    p.run()
+    return [dict(c, exp=d.out[:, :c["w"]]) for c, _, d in pend]
+
+
+def gen_sao(p: RefProbe):
+    pend = []
+    for i in range(12):
+        h, w = int(rng.integers(1, 65)), int(rng.integers(1, 65))
+        stride = w + int(rng.integers(0, 9))
+        rec = u8((h, stride))
+        offs = rng.integers(-7, 8, 4).astype(np.int8)
+        band = int(rng.integers(0, 29 if i < 10 else 32))
+        R = Buf(rec)
+        pend.append((dict(kind="bo", rec=rec, stride=stride, h=h, w=w, offs=offs, band=band),
+                     p.call("sao_bo", Buf(offs), R, stride, h, w, band), R))
+    # edge offset, plain mode (args 7/8 = 0: neighbours are read from the picture)
+    for cls in range(4):
+        for i in range(6):
+            h, w = int(rng.integers(2, 40)), int(rng.integers(2, 40))
+            stride = w + 2 + int(rng.integers(0, 9))
+            img = np.clip(rng.integers(100, 140, (h + 2, stride)) + rng.integers(-3, 4, (h + 2, stride)), 0, 255).astype(np.uint8)
+            offs = rng.integers(-7, 8, 5).astype(np.int8)
+            offs[2] = 0
+            R = Buf(img)
+            if cls < 2:
+                call = p.call(f"sao_eo{cls}", Buf(offs), R.at(stride + 1), stride, h, w, Buf(np.zeros(128, np.uint8)), 0, 0)
+            else:
+                continue  # EO2/EO3 take saved lines in every mode; pinned through the frame-level model instead
+            pend.append((dict(kind=f"eo{cls}", rec=img, stride=stride, h=h, w=w, offs=offs), call, R))
+    p.run()
+    return [dict(c, exp=r.out) for c, _, r in pend]
+
+
+def gen_sao_stats(p: RefProbe):
+    pend = []
+    for i in range(10):
+        w, h = (60, 64) if i < 3 else (28, 32) if i < 5 else (int(rng.integers(4, 61)), int(rng.integers(2, 65)))
+        rs, os_ = w + 4 + int(rng.integers(0, 9)), 64
+        rec = np.clip(rng.integers(90, 150, (h + 2, rs)) + rng.integers(-4, 5, (h + 2, rs)), 0, 255).astype(np.uint8)
+        org = np.clip(rec[1:h + 1, 1:1 + os_ if rs - 1 >= os_ else None].astype(int), 0, 255)
+        org = np.zeros((h, os_), np.uint8)
+        org[:, :w] = np.clip(rec[1:h + 1, 1:w + 1].astype(int) + rng.integers(-5, 6, (h, w)), 0, 255)
+        if i == 9:  # force |org-rec| > 127 to pin the s8 truncation
+            org[:, :w] = np.where(rng.random((h, w)) < 0.3, 255, org[:, :w])
+            rec[1:h + 1, 1:w + 1] = np.where(rng.random((h, w)) < 0.3, 2, rec[1:h + 1, 1:w + 1])
+        step = 1 if i < 7 else 2
+        E, B = Buf(np.zeros(64, np.int32)), Buf(np.zeros(32, np.int32))
+        pend.append((dict(org=org, rec=rec, rs=rs, os=os_, w=w, h=h, step=step),
+                     p.call("stat_bo_eo01", E, B, Buf(org), Buf(rec).at(rs + 1), rs, os_, w, h, step), E, B))
+    p.run()
+    return [dict(c, exp_eo=e.out, exp_bo=b.out) for c, _, e, b in pend]
+
+
+FAMILIES = {
+    "sad": gen_sad, "sad4": gen_sad4, "sad3": gen_sad3, "sad4blk": gen_sad4blk, "sse": gen_sse, "had": gen_had,
+    "fwd_transform": gen_fwd, "inv_transform": gen_inv, "quant": gen_quant, "dequant": gen_dequant,
+    "residual": gen_residual, "deblock_luma": gen_deblock_luma, "deblock_chroma": gen_deblock_chroma,
+    "interp": gen_interp, "sao_apply": gen_sao, "sao_stats": gen_sao_stats,
+}
+
+if __name__ == "__main__":
+    want = sys.argv[1:] or list(FAMILIES)
+    probe = RefProbe()
+    try:
+        for fam in want:
+            rng = np.random.default_rng(zlib.crc32(fam.encode()))  # per-family seed: families regenerate independently
+            cases = FAMILIES[fam](probe)
+            path = save_cases(fam, cases)
+            print(f"{fam}: {len(cases)} cases -> {os.path.relpath(path, ROOT)} ({os.path.getsize(path)} B)")
+    finally:
+        probe.close()
