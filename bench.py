@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the HEVC encode pixel-kernel hot path on MI355X.
+
+One "step" = one picture (3840x2160 4:2:0, BASELINE.json configs[2]) through the whole hot path
+(fractional planes -> integer DIA ME -> sub-pel SATD -> CU decision -> residual/DCT/quant/dequant/IDCT/recon ->
+deblock -> SAO -> border padding), all inputs and outputs resident in HBM.  Each rank (one per GPU) encodes its own
+GOP shard (frames/GOPs shard, no data-path collective) -> weak scaling; value = pictures of all ranks /
+max-over-ranks time.  Prints ONE JSON line on rank 0 with `roofline` (dominant kernel, HIP-event timed) and
+`cpu_baseline` (the CPU oracle port on a bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+# ALGORITHMIC bytes per picture, in units of P = luma samples (DESIGN.md §5 states each derivation)
+ALGO_BYTES_P = {
+    "ref_planes": 16.0,      # read the reference luma once, write 15 fractional planes (+ copy of plane 0)
+    "me_integer": 2.2,       # source P + padded reference ~1.1 P + PU records
+    "me_subpel": 2.2,
+    "cu_decide": 0.05,
+    "reconstruct": 7.5,      # org 1.5 P + pred 1.5 P + levels 3 P + recon 1.5 P
+    "deblock": 3.1,
+    "sao": 6.0,              # statistics 3 P + apply 3 P (fused in one launch)
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--qp", type=int, default=27)
+    ap.add_argument("--iper", type=int, default=128)
+    ap.add_argument("--clip-frames", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from ks265codec_amd.lib import KsContext, KsFrame
+    from ks265codec_amd.synth import lambda_q4, make_clip
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    W, H, qp = args.width, args.height, args.qp
+    ks = KsContext(local_rank)
+    fr = KsFrame(ks, W, H, qp, lambda_q4(qp))
+    # synthetic clip of SURVEY.md §8(d), one GOP shard per rank (different seed per rank = different content)
+    clip = make_clip(W, H, args.clip_frames, seed=7 + rank, abc=(67, 91, 33), pan=(8, 5))
+    dev_clip = [ks.dev(c) for c in clip]
+    srcs = [fr.new_pic() for _ in clip]
+    for d, s in zip(dev_clip, srcs):
+        fr.load_i420(d, s)
+    order = list(range(len(clip))) + list(range(len(clip) - 2, 0, -1))   # ping-pong keeps the motion continuous
+    refs = [fr.new_pic(), fr.new_pic()]
+
+    state = {"n": 0, "cur": 0}
+
+    def step():
+        n = state["n"]
+        key = (n % args.iper) == 0
+        q = qp if key else qp + 1                      # the reference's hidden hierarchy offset: I = Q, P = Q+1
+        fr.set_qp(q, lambda_q4(q))
+        fr.encode_picture(srcs[order[n % len(order)]], refs[state["cur"]], key, refs[state["cur"] ^ 1])
+        state["cur"] ^= 1
+        state["n"] = n + 1
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=ks.device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    fps = world * args.steps / dt
+
+    if rank == 0:
+        # ---- PSNR-Y of the reconstructed pictures (untimed pass; CPSNR_I420::calcPSNR enc@0x4c4060)
+        sse = 0
+        npic = min(8, len(order))
+        for i in range(npic):
+            step()
+            n = state["n"] - 1
+            s = fr.sse_picture(srcs[order[n % len(order)]], refs[state["cur"]])
+            sse += int(s[0])
+        mse = sse / (npic * W * H)
+        psnr_y = 99.0 if mse == 0 else 10.0 * np.log10(255.0 ** 2 / mse)
+
+        # ---- per-stage HIP-event timing on the kernel's own stream -> roofline of the dominant kernel
+        P = float(W * H)
+        planes = ks.zeros(16 * fr.geom.bytes_y)
+        pu = [ks.zeros(fr.geom.bytes_pu), ks.zeros(fr.geom.bytes_pu)]
+        cu8, sao = ks.zeros(fr.geom.bytes_cu8), ks.zeros(fr.geom.bytes_sao)
+        lvl = [ks.zeros(W * H * 2), ks.zeros(W * H // 2), ks.zeros(W * H // 2)]
+        deb, out = fr.new_pic(), fr.new_pic()
+        ref = refs[state["cur"]]
+        src = srcs[order[state["n"] % len(order)]]
+        fr.set_qp(qp + 1, lambda_q4(qp + 1))
+        stages = {
+            "ref_planes": lambda: fr.ref_planes(ref, planes),
+            "me_integer": lambda: fr.me_integer(src, ref, pu[1], pu[0]),
+            "me_subpel": lambda: fr.me_subpel(src, planes, pu[0]),
+            "cu_decide": lambda: fr.cu_decide(pu[0], cu8),
+            "reconstruct": lambda: fr.reconstruct(src, ref, planes, cu8, lvl, deb),
+            "deblock": lambda: fr.deblock(cu8, deb),
+            "sao": lambda: fr.sao(src, deb, sao, out),
+        }
+        import ctypes as C
+        stage_ms = {}
+        reps = 10
+        fr.me_integer(src, ref, None, pu[1])           # a plausible temporal-predictor field
+        for name, fn in stages.items():
+            fn()                                        # warm
+            ks.sync()
+            ks._chk(ks.lib.ks265_timer_start(ks.h))
+            for _ in range(reps):
+                fn()
+            ms = C.c_float()
+            ks._chk(ks.lib.ks265_timer_stop_ms(ks.h, C.byref(ms)))
+            stage_ms[name] = ms.value / reps
+        dom = max(stage_ms, key=stage_ms.get)
+        algo_bytes = ALGO_BYTES_P[dom] * P
+        achieved = algo_bytes / (stage_ms[dom] * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "algorithmic_bytes_per_launch": int(algo_bytes), "avg_launch_ms": round(stage_ms[dom], 4),
+                    "stages_ms": {k: round(v, 4) for k, v in stage_ms.items()},
+                    "stages_frac": {k: round(ALGO_BYTES_P[k] * P / (v * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) for k, v in stage_ms.items()}}
+
+        # ---- CPU baseline: the oracle port (1 thread) on a bounded sample of the same workload
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle_lib import OraclePipeline
+            o = OraclePipeline(W, H, qp, lambda_q4(qp))
+            nb = 3
+            tc0 = time.perf_counter()
+            for t in range(nb):
+                q = qp if t == 0 else qp + 1
+                o.set_qp(q, lambda_q4(q))
+                o.encode_picture(clip[t], t == 0)
+            tc = time.perf_counter() - tc0
+            cpu = {"value": round(nb / tc, 4), "unit": "frames/s", "cores": 1, "kind": "port",
+                   "sample": f"{nb} pictures (1 key + {nb - 1} P) of the same {W}x{H} clip, oracle/ks265_pipeline_oracle.c, 1 thread, {tc:.1f} s"}
+
+        line = {
+            "metric": "encoded frames/sec + PSNR-Y, 2160p -preset slow -qp 27, 1/2/4/8 GPU",
+            "value": round(fps, 2), "unit": "frames/s", "psnr_y": round(float(psnr_y), 3),
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"{W}x{H} 4:2:0 8-bit, hot path only (ME + transform/quant/recon + deblock + SAO; CABAC/RC not included), "
+                                   f"-rc 0 -qp {qp} (I=Q, P=Q+1) -iper {args.iper}, IPPP, me=DIA range 64, subme=8 hpel + 8 qpel SATD, sao on, df on",
+                       "pictures_per_step": 1, "sharding": "one GOP shard per GPU, no data-path collective"},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    fr.close()
+    ks.close()
+
+
+if __name__ == "__main__":
+    main()

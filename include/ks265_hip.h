@@ -1,0 +1,216 @@
+/* ks265_hip.h — C ABI of the MI355X-native HEVC encode pixel-kernel path (libks265hip.so).
+ *
+ * Drop-in boundary for the data-parallel hot path of the KSC265 encoder (ksvc/ks265codec v2.6.1.3,
+ * binary-only).  The reference reaches this path ONLY through writable function-pointer tables
+ * (SURVEY.md §8b "B3": g_sad_Function enc@0x707c60, g_sad4_Function enc@0x707be0, g_sad3_Function
+ * enc@0x707b60, g_sse_Function enc@0x707ba0, g_had_Function enc@0x707b40, g_H265_2dDct_Func enc@0x707ca0,
+ * g_QuantFuncs enc@0x707ce0, g_DeQuantFuncs enc@0x707990, g_H265_2dIDct_Func enc@0x707060,
+ * g_calc_residual_funcs enc@0x706fe0, g_EdgeFilterLuma{Ver,Hor}Func, g_PixelFilterChroma{Ver,Hor}Func,
+ * g_fSaoApplyOffset*, g_statBoEo01_funcs, g_interp{Luma,Chroma}*_func), called per block from inside
+ * CCtuEnc::processOneCtu enc@0x46f320.  A GPU cannot be fed one 8x8 block per call, so every table entry
+ * is exposed here in BATCHED form (section 2: same arithmetic, arrays of block descriptors instead of one
+ * pointer pair), and the per-CTU sequencing of those tables is exposed as whole-frame
+ * stages (section 3).  `enc@0xADDR` = symbol in /root/reference/ubuntu_x64/appencoder.
+ *
+ * Conventions: plain C, no torch types.  Every `dev` pointer is DEVICE memory (HBM) owned by the caller;
+ * descriptor arrays are device memory too.  All calls are asynchronous on the context's HIP stream and
+ * return 0 or a negative ks265_status; no call allocates after ks265_create/ks265_frame_create.
+ * All arithmetic is integer and bit-exact with the reference kernels (tests/golden/).
+ */
+#ifndef KS265_HIP_H
+#define KS265_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ 1. context */
+
+typedef struct ks265_ctx ks265_ctx;
+
+/* error codes follow the reference's qy265def.h:7-22 spirit (QY_OK = 0, failures negative) */
+enum ks265_status {
+    KS265_OK = 0,
+    KS265_FAIL = -1,          /* HIP runtime error (see ks265_last_error)            */
+    KS265_OUTOFMEMORY = -2,   /* QY_OUTOFMEMORY                                       */
+    KS265_POINTER = -3,       /* QY_POINTER: NULL argument                            */
+    KS265_NOTSUPPORTED = -4,  /* QY_NOTSUPPORTED: size / mode outside the HEVC tool set */
+    KS265_NO_DEVICE = -5      /* no gfx950 device visible: the product never falls back to a CPU path */
+};
+
+int ks265_create(ks265_ctx **out, int device);      /* creates its own HIP stream                      */
+void ks265_destroy(ks265_ctx *ctx);
+int ks265_set_stream(ks265_ctx *ctx, void *hip_stream); /* adopt a caller stream (e.g. torch's current) */
+int ks265_synchronize(ks265_ctx *ctx);
+const char *ks265_last_error(ks265_ctx *ctx);
+const char *ks265_version(void);                    /* cf. strLibQy265Version, qy265enc.h              */
+/* HIP-event timing on the context's stream (bench.py roofline leg) */
+int ks265_timer_start(ks265_ctx *ctx);
+int ks265_timer_stop_ms(ks265_ctx *ctx, float *ms);
+
+/* ------------------------------------------------------------------ 2. batched operator tables (B3) */
+
+/* one block of a distortion batch: byte offsets from the two plane base pointers (may be negative
+ * relative to an interior origin); replaces the (u8* a, u8* b) pointer pair of sad_c enc@0x47ae30 */
+typedef struct { int32_t a_off, b_off; int32_t w, h; } ks265_blk;
+/* one source block against three arbitrary reference positions (sad3_c enc@0x47b060) */
+typedef struct { int32_t a_off, b_off[3]; int32_t w, h; } ks265_blk3;
+
+/* g_sad_Function / g_sad_Function_A: out[i] = SAD */
+int ks265_sad_batch(ks265_ctx *, const uint8_t *dev_a, int sa, const uint8_t *dev_b, int sb,
+                    const ks265_blk *dev_blks, int n, uint32_t *dev_out);
+/* g_sad4_Function: out[4i..] = {SAD(b-sb), SAD(b+sb), SAD(b-1), SAD(b+1)} << 4 (sad4_c enc@0x47ae90) */
+int ks265_sad4_batch(ks265_ctx *, const uint8_t *dev_fenc, int sFenc, const uint8_t *dev_ref, int sRef,
+                     const ks265_blk *dev_blks, int n, uint32_t *dev_out);
+/* g_sad3_Function: out[3i..] plain SADs */
+int ks265_sad3_batch(ks265_ctx *, const uint8_t *dev_fenc, int sFenc, const uint8_t *dev_ref, int sRef,
+                     const ks265_blk3 *dev_blks, int n, uint32_t *dev_out);
+/* g_sad4blk_8x8_func (sad4blk_8x8_c enc@0x4cee30): four 8x8 quadrants of 16x16 blocks; w,h ignored */
+int ks265_sad4blk_8x8_batch(ks265_ctx *, const uint8_t *dev_a, int sa, const uint8_t *dev_b, int sb,
+                            const ks265_blk *dev_blks, int n, uint32_t *dev_out);
+/* g_sse_Function (sse_c<N> enc@0x47b230..): w == h in {4,8,16,32,64} */
+int ks265_sse_batch(ks265_ctx *, const uint8_t *dev_a, int sa, const uint8_t *dev_b, int sb,
+                    const ks265_blk *dev_blks, int n, uint32_t *dev_out);
+/* g_had_Function (had_c enc@0x47b680): 8x8 tiles (+2)>>2 | 4x4 tiles (+1)>>1 | 2x2 raw */
+int ks265_had_batch(ks265_ctx *, const uint8_t *dev_a, int sa, const uint8_t *dev_b, int sb,
+                    const ks265_blk *dev_blks, int n, uint32_t *dev_out);
+
+/* g_calc_residual_funcs: res (packed NxN s16 per block) = org - pred */
+int ks265_residual_batch(ks265_ctx *, const uint8_t *dev_org, int so, const uint8_t *dev_pred, int sp,
+                         const ks265_blk *dev_blks, int n, int16_t *dev_res);
+
+/* g_H265_2dDct_Func[idx], idx 0 = DST4, 1 = DCT4, 2 = DCT8, 3 = DCT16, 4 = DCT32.
+ * src/dst: nblk packed NxN s16 blocks (the reference passes strides; batches are packed). */
+int ks265_fwd_transform_batch(ks265_ctx *, int idx, const int16_t *dev_src, int16_t *dev_dst, int nblk);
+/* g_QuantFuncs[log2N-2] (H265QuantBlock_c enc@0x4a9cf0): per-batch scalar parameters as in the reference
+ * call; dev_nz[i] = number of non-zero levels of block i (the reference's return value). */
+int ks265_quant_batch(ks265_ctx *, int n, const int16_t *dev_coef, int16_t *dev_lvl, int16_t *dev_deltaU,
+                      int32_t *dev_nz, int scale, int off, int qbits, int nblk);
+/* g_DeQuantFuncs (H265DeQuantBlock_c enc@0x439210): full-block form (lastX = lastY = N-1) */
+int ks265_dequant_batch(ks265_ctx *, int n, const int16_t *dev_lvl, int16_t *dev_coef, int scale, int add,
+                        int shift, int nblk);
+/* g_H265_2dIDct_Func[idx]: coef (packed NxN) + pred (packed NxN u8) -> recon (packed NxN u8) */
+int ks265_inv_transform_batch(ks265_ctx *, int idx, const int16_t *dev_coef, const uint8_t *dev_pred,
+                              uint8_t *dev_dst, int nblk);
+
+/* one deblocking edge: pix_off = byte offset of q0 of the first line (EdgeFilterLumaVer_c enc@0x403630) */
+typedef struct { int32_t pix_off; int16_t beta, tc; int16_t length; uint8_t dir /*0 ver,1 hor*/, flags /*bit0 filterP, bit1 filterQ*/; } ks265_edge;
+/* g_EdgeFilterLuma{Ver,Hor}Func: edges of one batch must not overlap (true for one direction of one picture) */
+int ks265_edge_filter_luma_batch(ks265_ctx *, uint8_t *dev_plane, int stride, const ks265_edge *dev_edges, int n);
+/* g_PixelFilterChroma{Ver,Hor}Func */
+int ks265_edge_filter_chroma_batch(ks265_ctx *, uint8_t *dev_plane, int stride, const ks265_edge *dev_edges, int n);
+
+/* g_interp{Luma,Chroma}{Hor,Ver}{8to8,8to16,16to8,16to16}_func on whole rectangles.
+ * kind: bit0 chroma, bit1 vertical, bits 2-3: 0 = 8to8, 1 = 8to16, 2 = 16to8, 3 = 16to16. Strides in elements. */
+int ks265_interp_rect(ks265_ctx *, int kind, void *dev_dst, int dstStride, const void *dev_src, int srcStride,
+                      int w, int h, int frac);
+
+/* g_fSaoApplyOffsetBo (SaoApplyOffsetBo_c enc@0x43e4e0) on a rectangle, in place; width is rounded up to 4
+ * and bands past 31 are dropped exactly like the reference */
+int ks265_sao_apply_bo_rect(ks265_ctx *, const int8_t offsets[4], uint8_t *dev_rec, int stride, int height,
+                            int width, int bandPosition);
+/* SaoApplyOffsetEo{0..3}_c enc@0x43e650.. in their plain mode, out of place (dst may not alias src):
+ * offsets[5] indexed by 2 + sign(c-a) + sign(c-b) */
+int ks265_sao_apply_eo_rect(ks265_ctx *, int eoClass, const int8_t offsets[5], const uint8_t *dev_src,
+                            uint8_t *dev_dst, int stride, int height, int width);
+/* g_statBoEo01_funcs (statSaoBoEo01_c enc@0x4ae9c0): packed accumulators (sum << 12 | count), eoJoint[64], bo[32];
+ * one launch accumulates nrect rectangles (x, y, w, h) each into its own 96-int record (eoJoint then bo) */
+typedef struct { int32_t org_off, rec_off, w, h; } ks265_sao_rect;
+int ks265_sao_stats_batch(ks265_ctx *, const uint8_t *dev_org, int orgStride, const uint8_t *dev_rec, int recStride,
+                          const ks265_sao_rect *dev_rects, int nrect, int rowStep, int32_t *dev_out /*nrect x 96*/);
+
+/* ------------------------------------------------------------------ 3. whole-frame stages (a13 sequencing) */
+
+typedef struct ks265_frame ks265_frame;
+
+typedef struct {
+    int32_t width, height;     /* luma, multiples of 8                                            */
+    int32_t qp;                /* slice QP actually used for this picture (after the reference's
+                                  hidden hierarchy offset, SURVEY.md §5: I = Q, P = Q+1)          */
+    int32_t lambda_q4;         /* motion lambda in Q4 fixed point (host-side float setup only)     */
+    int32_t me_range;          /* integer search range in pels, <= 64 (all presets use 64)         */
+    int32_t me_method;         /* 0 = DIA (interMeDia enc@0x48fbe0, -me 0)                          */
+    int32_t subme;             /* 0 = integer only, 1 = 8 half-pel + 8 quarter-pel SATD points      */
+    int32_t deblock;           /* -df                                                               */
+    int32_t sao;               /* -sao: 0 off, >0 BO + EO0..3                                        */
+    int32_t beta_offset_div2, tc_offset_div2;
+} ks265_frame_cfg;
+
+/* geometry of the padded picture buffers the caller allocates (one call, no allocation) */
+typedef struct {
+    int32_t pad_y, pad_c;          /* border in samples (80 / 40)                  */
+    int32_t stride_y, stride_c;    /* bytes per row                                */
+    int32_t rows_y, rows_c;        /* rows incl. borders                           */
+    int64_t bytes_y, bytes_c;      /* plane allocations                            */
+    int32_t ctu_cols, ctu_rows;
+    int32_t pu_per_ctu;            /* 85: 1 + 4 + 16 + 64                          */
+    int64_t bytes_pu;              /* ks265_pu records                             */
+    int64_t bytes_cu8;             /* ks265_cu8 records, (H/8) x (W/8)             */
+    int64_t bytes_sao;             /* ks265_sao_param records, 3 per CTU           */
+} ks265_frame_geom;
+
+/* motion / cost record of one PU (level 0: 64x64 ... level 3: 8x8; raster order inside the CTU) */
+typedef struct { int16_t mvx, mvy; int16_t mvpx, mvpy; uint32_t cost; uint32_t dist; } ks265_pu;   /* quarter-pel units; mvp = predictor used for the rate term; dist = SAD (stage A) or SATD (stage B) */
+/* final coding decision per 8x8 luma block */
+typedef struct { int16_t mvx, mvy; uint8_t log2_cu; uint8_t cbf; /* bit0 Y, bit1 Cb, bit2 Cr */ uint8_t pred_mode; /* 0 inter, 1 intra(flat) */ uint8_t rsv; } ks265_cu8;
+/* SAO decision per CTU and component */
+typedef struct { int8_t type; /* -1 off, 0 BO, 1..4 EO class 0..3 */ int8_t band; int8_t offset[4]; int8_t rsv[2]; } ks265_sao_param;
+
+/* a padded YUV 4:2:0 picture in HBM (pointers to the first byte of each allocation) */
+typedef struct { uint8_t *y, *u, *v; } ks265_pic;
+
+int ks265_frame_geometry(const ks265_frame_cfg *cfg, ks265_frame_geom *geom);
+int ks265_frame_create(ks265_ctx *ctx, const ks265_frame_cfg *cfg, ks265_frame **out);
+void ks265_frame_destroy(ks265_frame *f);
+int ks265_frame_set_qp(ks265_frame *f, int qp, int lambda_q4);
+
+/* expandPicture_c enc@0x4a6ae0: replicate the picture edge into the borders of all three planes */
+int ks265_pad_picture(ks265_frame *f, ks265_pic pic);
+/* copy an unpadded I420 frame (dev, W*H*3/2 bytes) into a padded picture and pad it */
+int ks265_load_i420(ks265_frame *f, const uint8_t *dev_i420, ks265_pic dst);
+/* inverse: padded picture -> packed I420 */
+int ks265_store_i420(ks265_frame *f, ks265_pic src, uint8_t *dev_i420);
+
+/* Stage A0: the 15 fractional-sample luma planes of a reference picture (normative 8-tap filters,
+ * interpLuma* enc@0x40e4f0..0x4109b0); dev_planes = 16 x bytes_y (plane 0 is a copy of ref.y) */
+int ks265_ref_planes(ks265_frame *f, ks265_pic ref, uint8_t *dev_planes);
+/* Stage A: integer-pel motion search for every PU of every CTU (motionSearchOneRef enc@0x483f40 ->
+ * interMeDia enc@0x48fbe0 over sad4_c); prev_pu = PU records of the previous picture (temporal
+ * predictor) or NULL */
+int ks265_me_integer(ks265_frame *f, ks265_pic src, ks265_pic ref, const ks265_pu *dev_prev_pu, ks265_pu *dev_pu);
+/* Stage B: 8 half-pel + 8 quarter-pel refinement with SATD (subMeSquare enc@0x4b5660 ->
+ * subMeHpel_RealInterp / subMeQpel_8Sad_*_RealInterp + had_c) */
+int ks265_me_subpel(ks265_frame *f, ks265_pic src, const uint8_t *dev_planes, ks265_pu *dev_pu);
+/* Stage C: CU quadtree decision from the PU costs (the bottom-up compare of processTree enc@0x4722a0) */
+int ks265_cu_decide(ks265_frame *f, const ks265_pu *dev_pu, ks265_cu8 *dev_cu8);
+/* Stage C': key picture — every CU 32x32-TU "flat" intra (pred = 128); stands in for the out-of-scope
+ * intra path so that a GOP has a reconstructed first picture */
+int ks265_cu_flat_intra(ks265_frame *f, ks265_cu8 *dev_cu8);
+/* Stage D: prediction (luma from the planes, chroma 4-tap on the fly) -> residual -> DCT -> quant ->
+ * dequant -> IDCT -> recon, the reconstruct() chain enc@0x481da0; levels are s16 planes of W x H (Y) and
+ * W/2 x H/2 (Cb, Cr) coefficients stored TU-in-place; recon is a padded picture */
+int ks265_reconstruct(ks265_frame *f, ks265_pic src, ks265_pic ref, const uint8_t *dev_planes, ks265_cu8 *dev_cu8,
+                      int16_t *dev_lvl_y, int16_t *dev_lvl_u, int16_t *dev_lvl_v, ks265_pic recon);
+/* Stage E: in-place deblocking of a reconstructed picture (CalcBsInterP enc@0x402960, ctuDeblockFilterVer
+ * enc@0x403de0, CtuDeblockFilterHorT enc@0x477200) */
+int ks265_deblock(ks265_frame *f, const ks265_cu8 *dev_cu8, ks265_pic recon);
+/* Stage F: SAO statistics + decision + apply (CEncSao::modeDecisionCtu enc@0x4af690, qy265SaoApplyOffset
+ * enc@0x43fc00); dst becomes the next reference picture (borders padded) */
+int ks265_sao(ks265_frame *f, ks265_pic src, ks265_pic deblocked, ks265_sao_param *dev_sao, ks265_pic dst);
+
+/* the whole hot path for one picture: A0 (if is_key == 0) A B C D E F in stream order.
+ * Workspace (planes, PU/CU/SAO records, levels) lives inside the frame object. */
+int ks265_encode_picture(ks265_frame *f, ks265_pic src, ks265_pic ref, int is_key, ks265_pic recon_out);
+/* accessors to the frame object's internal workspace (device pointers) */
+int16_t *ks265_frame_levels(ks265_frame *f, int comp);
+ks265_pu *ks265_frame_pu(ks265_frame *f);
+ks265_cu8 *ks265_frame_cu8(ks265_frame *f);
+ks265_sao_param *ks265_frame_sao(ks265_frame *f);
+uint8_t *ks265_frame_planes(ks265_frame *f);
+/* luma SSE between two padded pictures (PSNR-Y of the bench line; CPSNR_I420::calcPSNR enc@0x4c4060) */
+int ks265_sse_picture(ks265_frame *f, ks265_pic a, ks265_pic b, uint64_t *dev_sse3);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

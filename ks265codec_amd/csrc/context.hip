@@ -1,0 +1,68 @@
+// context.hip — ks265_ctx lifetime, stream adoption, event timing (include/ks265_hip.h §1)
+#include "ks265_internal.h"
+
+extern "C" {
+
+const char *ks265_version(void) { return "ks265hip 0.1 (gfx950) — pixel-kernel path of libqycodec V2.6.1.3"; }
+
+int ks265_create(ks265_ctx **out, int device)
+{
+    if (!out) return KS265_POINTER;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return KS265_NO_DEVICE;
+    ks265_ctx *c = new ks265_ctx();
+    c->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return KS265_FAIL; }
+    c->own_stream = true;
+    hipEventCreate(&c->ev0);
+    hipEventCreate(&c->ev1);
+    *out = c;
+    return KS265_OK;
+}
+
+void ks265_destroy(ks265_ctx *c)
+{
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    if (c->ev0) hipEventDestroy(c->ev0);
+    if (c->ev1) hipEventDestroy(c->ev1);
+    if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int ks265_set_stream(ks265_ctx *c, void *s)
+{
+    if (!c) return KS265_POINTER;
+    if (c->own_stream && c->stream) { hipStreamSynchronize(c->stream); hipStreamDestroy(c->stream); }
+    c->stream = (hipStream_t)s;
+    c->own_stream = false;
+    return KS265_OK;
+}
+
+int ks265_synchronize(ks265_ctx *c)
+{
+    if (!c) return KS265_POINTER;
+    return ks265_hip(c, hipStreamSynchronize(c->stream));
+}
+
+const char *ks265_last_error(ks265_ctx *c) { return c ? c->last_error.c_str() : "null context"; }
+
+int ks265_timer_start(ks265_ctx *c)
+{
+    if (!c) return KS265_POINTER;
+    return ks265_hip(c, hipEventRecord(c->ev0, c->stream));
+}
+
+int ks265_timer_stop_ms(ks265_ctx *c, float *ms)
+{
+    if (!c || !ms) return KS265_POINTER;
+    int r = ks265_hip(c, hipEventRecord(c->ev1, c->stream));
+    if (r) return r;
+    r = ks265_hip(c, hipEventSynchronize(c->ev1));
+    if (r) return r;
+    return ks265_hip(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
+}
+
+}  // extern "C"

@@ -1,0 +1,99 @@
+// frame_api.hip — ks265_frame lifetime and the per-picture sequencing of the stages (include/ks265_hip.h §3).
+// The order is the reference's per-CTU order hoisted to whole pictures: ME -> sub-pel -> CU decision ->
+// reconstruct -> deblock -> SAO; every stage is one or two launches on the context's stream, no host synchronisation.
+#include "frame_common.h"
+
+static int dev_alloc(ks265_ctx *ctx, void **p, size_t bytes, bool zero)
+{
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) return ks265_hip(ctx, e);
+    if (zero) {
+        e = hipMemsetAsync(*p, 0, bytes, ctx->stream);
+        if (e != hipSuccess) return ks265_hip(ctx, e);
+    }
+    return KS265_OK;
+}
+
+extern "C" {
+
+int ks265_frame_create(ks265_ctx *ctx, const ks265_frame_cfg *cfg, ks265_frame **out)
+{
+    if (!ctx || !cfg || !out) return KS265_POINTER;
+    *out = nullptr;
+    ks265_frame_geom geom;
+    int r = ks265_frame_geometry(cfg, &geom);
+    if (r) return r;
+    if (cfg->me_method != 0) return KS265_NOTSUPPORTED;
+    ks265_frame *f = new ks265_frame();
+    f->ctx = ctx; f->cfg = *cfg; f->geom = geom;
+    KsGeom &g = f->g;
+    g.W = cfg->width; g.H = cfg->height; g.sy = geom.stride_y; g.sc = geom.stride_c; g.bytes_y = geom.bytes_y; g.bytes_c = geom.bytes_c;
+    g.ctu_cols = geom.ctu_cols; g.ctu_rows = geom.ctu_rows; g.w8 = cfg->width / 8; g.h8 = cfg->height / 8;
+    g.org_y = (long)KS_PAD_Y * g.sy + KS_PAD_Y; g.org_c = (long)KS_PAD_C * g.sc + KS_PAD_C;
+    hipSetDevice(ctx->device);
+    const size_t npx = (size_t)g.W * g.H;
+    r = dev_alloc(ctx, (void **)&f->planes, (size_t)16 * g.bytes_y, true);
+    for (int i = 0; i < 2 && !r; ++i) r = dev_alloc(ctx, (void **)&f->pu[i], (size_t)geom.bytes_pu, true);
+    if (!r) r = dev_alloc(ctx, (void **)&f->cu8, (size_t)geom.bytes_cu8, true);
+    if (!r) r = dev_alloc(ctx, (void **)&f->sao, (size_t)geom.bytes_sao, true);
+    if (!r) r = dev_alloc(ctx, (void **)&f->lvl[0], npx * 2, true);
+    if (!r) r = dev_alloc(ctx, (void **)&f->lvl[1], npx / 2, true);
+    if (!r) r = dev_alloc(ctx, (void **)&f->lvl[2], npx / 2, true);
+    if (!r) r = dev_alloc(ctx, (void **)&f->deb[0], (size_t)g.bytes_y, true);
+    if (!r) r = dev_alloc(ctx, (void **)&f->deb[1], (size_t)g.bytes_c, true);
+    if (!r) r = dev_alloc(ctx, (void **)&f->deb[2], (size_t)g.bytes_c, true);
+    if (!r) r = dev_alloc(ctx, (void **)&f->sse, 3 * sizeof(unsigned long long), true);
+    if (r) { ks265_frame_destroy(f); return r; }
+    *out = f;
+    return KS265_OK;
+}
+
+void ks265_frame_destroy(ks265_frame *f)
+{
+    if (!f) return;
+    if (f->ctx) { hipSetDevice(f->ctx->device); hipStreamSynchronize(f->ctx->stream); }
+    void *ptrs[] = {f->planes, f->pu[0], f->pu[1], f->cu8, f->sao, f->lvl[0], f->lvl[1], f->lvl[2], f->deb[0], f->deb[1], f->deb[2], f->sse};
+    for (void *p : ptrs)
+        if (p) hipFree(p);
+    delete f;
+}
+
+int ks265_frame_set_qp(ks265_frame *f, int qp, int lambda_q4)
+{
+    KS_FRAME_CHECK(f);
+    if (qp < 0 || qp > 51 || lambda_q4 < 0) return KS265_NOTSUPPORTED;
+    f->cfg.qp = qp; f->cfg.lambda_q4 = lambda_q4;
+    return KS265_OK;
+}
+
+int ks265_encode_picture(ks265_frame *f, ks265_pic src, ks265_pic ref, int is_key, ks265_pic recon_out)
+{
+    KS_FRAME_CHECK(f);
+    if (!src.y || !recon_out.y) return KS265_POINTER;
+    int r;
+    ks265_pu *pu = f->pu[f->cur_pu];
+    if (is_key) {
+        if ((r = ks265_cu_flat_intra(f, f->cu8))) return r;
+        f->have_prev = false;
+    } else {
+        if (!ref.y) return KS265_POINTER;
+        if ((r = ks265_ref_planes(f, ref, f->planes))) return r;
+        if ((r = ks265_me_integer(f, src, ref, f->have_prev ? f->pu[f->cur_pu ^ 1] : nullptr, pu))) return r;
+        if (f->cfg.subme && (r = ks265_me_subpel(f, src, f->planes, pu))) return r;
+        if ((r = ks265_cu_decide(f, pu, f->cu8))) return r;
+    }
+    ks265_pic deb = ks_deb_pic(f);
+    if ((r = ks265_reconstruct(f, src, ref, f->planes, f->cu8, f->lvl[0], f->lvl[1], f->lvl[2], deb))) return r;
+    if (f->cfg.deblock && (r = ks265_deblock(f, f->cu8, deb))) return r;
+    if ((r = ks265_sao(f, src, deb, f->sao, recon_out))) return r;
+    if (!is_key) { f->cur_pu ^= 1; f->have_prev = true; }
+    return KS265_OK;
+}
+
+int16_t *ks265_frame_levels(ks265_frame *f, int comp) { return f && comp >= 0 && comp < 3 ? f->lvl[comp] : nullptr; }
+ks265_pu *ks265_frame_pu(ks265_frame *f) { return f ? f->pu[f->cur_pu ^ (f->have_prev ? 1 : 0)] : nullptr; }   /* records of the last coded P picture */
+ks265_cu8 *ks265_frame_cu8(ks265_frame *f) { return f ? f->cu8 : nullptr; }
+ks265_sao_param *ks265_frame_sao(ks265_frame *f) { return f ? f->sao : nullptr; }
+uint8_t *ks265_frame_planes(ks265_frame *f) { return f ? f->planes : nullptr; }
+
+}  // extern "C"

@@ -1,0 +1,53 @@
+// frame_common.h — whole-frame stage plumbing shared by frame_*.hip (not part of the C ABI)
+#pragma once
+#include "ks265_internal.h"
+
+#define KS_PAD_Y 80
+#define KS_PAD_C 40
+#define KS_PLANE_MARGIN 72           // fractional planes are defined on [-72, W+72) x [-72, H+72)
+#define KS_COST_INVALID 0xFFFFFFFFu
+
+// geometry handed to kernels by value
+struct KsGeom {
+    int W, H;                 // luma size
+    int sy, sc;               // strides
+    long bytes_y, bytes_c;
+    int ctu_cols, ctu_rows;
+    int w8, h8;
+    long org_y, org_c;        // byte offset of sample (0,0) inside a padded plane
+};
+
+struct ks265_frame {
+    ks265_ctx *ctx = nullptr;
+    ks265_frame_cfg cfg{};
+    ks265_frame_geom geom{};
+    KsGeom g{};
+    // workspace (device)
+    uint8_t *planes = nullptr;          // 16 x bytes_y
+    ks265_pu *pu[2] = {nullptr, nullptr};
+    int cur_pu = 0;
+    bool have_prev = false;
+    ks265_cu8 *cu8 = nullptr;
+    ks265_sao_param *sao = nullptr;
+    int16_t *lvl[3] = {nullptr, nullptr, nullptr};
+    uint8_t *deb[3] = {nullptr, nullptr, nullptr};   // reconstructed picture before SAO (padded geometry)
+    unsigned long long *sse = nullptr;
+};
+
+static inline ks265_pic ks_deb_pic(ks265_frame *f) { return ks265_pic{f->deb[0], f->deb[1], f->deb[2]}; }
+
+__device__ __forceinline__ const uint8_t *ks_org_y(const KsGeom &g, const uint8_t *p) { return p + g.org_y; }
+__device__ __forceinline__ uint8_t *ks_org_y(const KsGeom &g, uint8_t *p) { return p + g.org_y; }
+__device__ __forceinline__ const uint8_t *ks_org_c(const KsGeom &g, const uint8_t *p) { return p + g.org_c; }
+__device__ __forceinline__ uint8_t *ks_org_c(const KsGeom &g, uint8_t *p) { return p + g.org_c; }
+
+// PU indexing inside a CTU: level l (0: 64x64 .. 3: 8x8), raster
+__device__ __forceinline__ int ks_level_base(int l) { return l == 0 ? 0 : l == 1 ? 1 : l == 2 ? 5 : 21; }
+__device__ __forceinline__ int ks_pu_index(int l, int px, int py) { return ks_level_base(l) + py * (1 << l) + px; }
+__device__ __forceinline__ bool ks_pu_inside(const KsGeom &g, int cx, int cy, int l, int px, int py)
+{
+    int s = 64 >> l, x0 = cx * 64 + px * s, y0 = cy * 64 + py * s;
+    return x0 + s <= g.W && y0 + s <= g.H;
+}
+
+#define KS_FRAME_CHECK(f) do { if (!(f) || !(f)->ctx) return KS265_POINTER; } while (0)

@@ -1,0 +1,276 @@
+// frame_loop.hip — in-loop filters.
+//   Stage E  ks265_deblock : boundary strength (CalcBsInterP enc@0x402960, single reference) fused with the normative edge
+//            filters (EdgeFilterLuma{Ver,Hor}_c enc@0x403630/0x4038c0, PixelFilterChroma{Ver,Hor}_c enc@0x403c50/0x403d10);
+//            all vertical edges of the picture in one launch, then all horizontal ones, in place: one thread per 4-line
+//            segment, neighbouring threads touch neighbouring 8-byte (ver) / 4-byte (hor) columns -> coalesced rows.
+//   Stage F  ks265_sao     : per CTU statistics (register accumulators + DPP reductions for the 16 EO bins, LDS atomics for
+//            the 32 bands; s8 difference truncation of statSaoBoEo01_c enc@0x4ae9c0), decision, and out-of-place apply.
+#include "frame_common.h"
+
+using namespace ks265;
+
+__device__ __forceinline__ int edge_bs(const ks265_cu8 p, const ks265_cu8 q, int pos8)
+{
+    const int cu8n = 1 << (q.log2_cu - 3), tu8n = min(cu8n, 4);
+    const bool tu_edge = (pos8 % tu8n) == 0, cu_edge = (pos8 % cu8n) == 0;
+    if (!tu_edge && !cu_edge) return 0;
+    if (p.pred_mode == 1 || q.pred_mode == 1) return 2;
+    if (tu_edge && ((p.cbf | q.cbf) & 1)) return 1;
+    if (cu_edge && (abs((int)p.mvx - (int)q.mvx) >= 4 || abs((int)p.mvy - (int)q.mvy) >= 4)) return 1;
+    return 0;
+}
+
+// DIR 0: vertical edges (filter across x), DIR 1: horizontal edges.
+// thread = (edge block bx/by, 4-line segment); luma first, then the two chroma planes (bS == 2 only)
+template <int DIR>
+__global__ __launch_bounds__(256) void deblock_kernel(KsGeom g, int qp, int beta, int tc_off2, const ks265_cu8 *cu8, uint8_t *ry, uint8_t *ru, uint8_t *rv)
+{
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const int nseg_l = DIR == 0 ? g.w8 * (g.H / 4) : (g.W / 4) * g.h8;       // luma segments (incl. the skipped picture-edge column/row)
+    if (gid < nseg_l) {
+        int bx, by, seg;                                                      // 8x8 block of Q, 4-line segment inside it (0/1)
+        if (DIR == 0) { bx = gid % g.w8; int y4 = gid / g.w8; by = y4 >> 1; seg = y4 & 1; }
+        else { int x4 = gid % (g.W / 4); by = gid / (g.W / 4); bx = x4 >> 1; seg = x4 & 1; }
+        if ((DIR == 0 ? bx : by) == 0) return;
+        const ks265_cu8 q = cu8[(long)by * g.w8 + bx], p = DIR == 0 ? cu8[(long)by * g.w8 + bx - 1] : cu8[(long)(by - 1) * g.w8 + bx];
+        const int bs = edge_bs(p, q, DIR == 0 ? bx : by);
+        if (!bs) return;
+        const int tc = kTcTable[clip3(0, 53, qp + 2 * (bs - 1) + tc_off2)];
+        uint8_t *Y = ks_org_y(g, ry);
+        int px[4][8];
+        if (DIR == 0) {
+            uint8_t *p0 = Y + (long)(by * 8 + seg * 4) * g.sy + bx * 8 - 4;
+#pragma unroll
+            for (int l = 0; l < 4; ++l) {
+                const unsigned a = *(const unsigned *)(p0 + (long)l * g.sy), b = *(const unsigned *)(p0 + (long)l * g.sy + 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { px[l][i] = (a >> (8 * i)) & 255; px[l][4 + i] = (b >> (8 * i)) & 255; }
+            }
+            deblock_luma_segment(px, beta, tc, true, true);
+#pragma unroll
+            for (int l = 0; l < 4; ++l) {
+                unsigned a = 0, b = 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { a |= (unsigned)px[l][i] << (8 * i); b |= (unsigned)px[l][4 + i] << (8 * i); }
+                *(unsigned *)(p0 + (long)l * g.sy) = a; *(unsigned *)(p0 + (long)l * g.sy + 4) = b;
+            }
+        } else {
+            uint8_t *p0 = Y + (long)(by * 8 - 4) * g.sy + bx * 8 + seg * 4;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const unsigned a = *(const unsigned *)(p0 + (long)i * g.sy);
+#pragma unroll
+                for (int l = 0; l < 4; ++l) px[l][i] = (a >> (8 * l)) & 255;
+            }
+            deblock_luma_segment(px, beta, tc, true, true);
+#pragma unroll
+            for (int i = 1; i < 7; ++i) {
+                unsigned a = 0;
+#pragma unroll
+                for (int l = 0; l < 4; ++l) a |= (unsigned)px[l][i] << (8 * l);
+                *(unsigned *)(p0 + (long)i * g.sy) = a;
+            }
+        }
+        return;
+    }
+    // chroma: one thread per (comp, 8x8 luma block on the 16-sample grid) = 4 chroma lines
+    int cid = gid - nseg_l;
+    const int nblk = g.w8 * g.h8;
+    if (cid >= 2 * nblk) return;
+    const int comp = cid / nblk; cid -= comp * nblk;
+    const int bx = cid % g.w8, by = cid / g.w8;
+    if (DIR == 0 ? (bx == 0 || (bx & 1)) : (by == 0 || (by & 1))) return;
+    const ks265_cu8 q = cu8[(long)by * g.w8 + bx], p = DIR == 0 ? cu8[(long)by * g.w8 + bx - 1] : cu8[(long)(by - 1) * g.w8 + bx];
+    if (edge_bs(p, q, DIR == 0 ? bx : by) != 2) return;
+    const int tc = kTcTable[clip3(0, 53, chroma_qp(qp) + 2 + tc_off2)];
+    uint8_t *C = ks_org_c(g, comp ? rv : ru) + (long)by * 4 * g.sc + bx * 4;
+    const long xs = DIR == 0 ? 1 : g.sc, ys = DIR == 0 ? g.sc : 1;
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+        uint8_t *pp = C + l * ys;
+        int p1 = pp[-2 * xs], p0 = pp[-xs], q0 = pp[0], q1 = pp[xs];
+        deblock_chroma_line(p1, p0, q0, q1, tc, true, true);
+        pp[-xs] = (uint8_t)p0; pp[0] = (uint8_t)q0;
+    }
+}
+
+extern "C" int ks265_deblock(ks265_frame *f, const ks265_cu8 *cu8, ks265_pic recon)
+{
+    KS_FRAME_CHECK(f);
+    if (!cu8 || !recon.y) return KS265_POINTER;
+    const KsGeom &g = f->g;
+    const int qp = f->cfg.qp;
+    const int b = qp + 2 * f->cfg.beta_offset_div2, beta_idx = b < 0 ? 0 : (b > 51 ? 51 : b);
+    static const unsigned char beta_tab[52] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 20, 22, 24,
+                                               26, 28, 30, 32, 34, 36, 38, 40, 42, 44, 46, 48, 50, 52, 54, 56, 58, 60, 62, 64};
+    const int beta = beta_tab[beta_idx];
+    const int n0 = g.w8 * (g.H / 4) + 2 * g.w8 * g.h8, n1 = (g.W / 4) * g.h8 + 2 * g.w8 * g.h8;
+    hipLaunchKernelGGL(deblock_kernel<0>, dim3((n0 + 255) / 256), dim3(256), 0, f->ctx->stream, g, qp, beta, 2 * f->cfg.tc_offset_div2, cu8, recon.y, recon.u, recon.v);
+    hipLaunchKernelGGL(deblock_kernel<1>, dim3((n1 + 255) / 256), dim3(256), 0, f->ctx->stream, g, qp, beta, 2 * f->cfg.tc_offset_div2, cu8, recon.y, recon.u, recon.v);
+    return ks265_check_launch(f->ctx);
+}
+
+// ------------------------------------------------------------------ Stage F: SAO
+struct SaoStats { int cnt[5][32]; int sum[5][32]; };      // [0] BO bands, [1..4] EO class 0..3 (4 categories used)
+
+__device__ __forceinline__ int sao_offset(int sum, int cnt, int lo, int hi)
+{
+    if (!cnt) return 0;
+    int o = sum >= 0 ? (sum + cnt / 2) / cnt : -((-sum + cnt / 2) / cnt);
+    return clip3(lo, hi, o);
+}
+
+__device__ long long sao_eval(const SaoStats *s, int type, int lam, ks265_sao_param *out)
+{
+    const long long lam2 = (long long)lam * lam;
+    ks265_sao_param o;
+    o.type = (int8_t)type; o.band = 0; o.offset[0] = o.offset[1] = o.offset[2] = o.offset[3] = 0; o.rsv[0] = o.rsv[1] = 0;
+    long long res;
+    if (type == 0) {
+        int best = 0; long long bd = 0;
+        for (int p = 0; p <= 28; ++p) {
+            long long d = 0;
+            for (int k = 0; k < 4; ++k) {
+                const int of = sao_offset(s->sum[0][p + k], s->cnt[0][p + k], -7, 7);
+                d += (long long)s->cnt[0][p + k] * of * of - 2LL * of * s->sum[0][p + k];
+            }
+            if (p == 0 || d < bd) { bd = d; best = p; }
+        }
+        int bits = 7;
+        for (int k = 0; k < 4; ++k) {
+            const int of = sao_offset(s->sum[0][best + k], s->cnt[0][best + k], -7, 7);
+            o.offset[k] = (int8_t)of; bits += abs(of) + 2;
+        }
+        o.band = (int8_t)best;
+        res = bd * 256 + lam2 * bits;
+    } else {
+        long long d = 0; int bits = 4;
+        for (int c = 0; c < 4; ++c) {
+            const int of = sao_offset(s->sum[type][c], s->cnt[type][c], c < 2 ? 0 : -7, c < 2 ? 7 : 0);
+            o.offset[c] = (int8_t)of;
+            d += (long long)s->cnt[type][c] * of * of - 2LL * of * s->sum[type][c];
+            bits += abs(of) + 1;
+        }
+        res = d * 256 + lam2 * bits;
+    }
+    *out = o;
+    return res;
+}
+
+// statistics of one component of one CTU into LDS
+__device__ __forceinline__ void sao_collect(const uint8_t *org, const uint8_t *rec, long stride, int x0, int y0, int w, int h, int picW, int picH,
+                                            SaoStats *st, int tid)
+{
+    for (int i = tid; i < 5 * 32; i += 256) { (&st->cnt[0][0])[i] = 0; (&st->sum[0][0])[i] = 0; }
+    __syncthreads();
+    int ecnt[4][4], esum[4][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { ecnt[k][c] = 0; esum[k][c] = 0; }
+    const int dxs[4] = {1, 0, 1, -1}, dys[4] = {0, 1, 1, 1};
+    for (int i = tid; i < w * h; i += 256) {
+        const int x = x0 + i % w, y = y0 + i / w;
+        const uint8_t *r = rec + (long)y * stride + x;
+        const int c = r[0], d = (int)(int8_t)(uint8_t)(org[(long)y * stride + x] - c);
+        atomicAdd(&st->cnt[0][c >> 3], 1);
+        atomicAdd(&st->sum[0][c >> 3], d);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ax = x - dxs[k], ay = y - dys[k], bx = x + dxs[k], by = y + dys[k];
+            if (ax < 0 || bx < 0 || ax >= picW || bx >= picW || ay < 0 || by >= picH) continue;
+            const int e = 2 + sgn(c - (int)r[-dys[k] * stride - dxs[k]]) + sgn(c - (int)r[dys[k] * stride + dxs[k]]);
+#pragma unroll
+            for (int cat = 0; cat < 4; ++cat) {
+                const bool hit = e == (cat < 2 ? cat : cat + 1);
+                ecnt[k][cat] += hit; esum[k][cat] += hit ? d : 0;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int cat = 0; cat < 4; ++cat) {
+            const int cs = (int)wave_sum((unsigned)ecnt[k][cat]), ss = (int)wave_sum((unsigned)esum[k][cat]);
+            if ((tid & 63) == 0) { atomicAdd(&st->cnt[1 + k][cat], cs); atomicAdd(&st->sum[1 + k][cat], ss); }
+        }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void sao_apply_ctu(const uint8_t *rec, uint8_t *dst, long stride, int x0, int y0, int w, int h, int picW, int picH,
+                                              const ks265_sao_param p, int tid)
+{
+    const int dxs[4] = {1, 0, 1, -1}, dys[4] = {0, 1, 1, 1};
+    for (int i = tid; i < w * h; i += 256) {
+        const int x = x0 + i % w, y = y0 + i / w;
+        const uint8_t *r = rec + (long)y * stride + x;
+        const int c = r[0];
+        int o = 0;
+        if (p.type == 0) {
+            const int k = (c >> 3) - p.band;
+            if (k >= 0 && k < 4) o = p.offset[k];
+        } else if (p.type > 0) {
+            const int k = p.type - 1;
+            const int ax = x - dxs[k], ay = y - dys[k], bx = x + dxs[k], by = y + dys[k];
+            if (!(ax < 0 || bx < 0 || ax >= picW || bx >= picW || ay < 0 || by >= picH)) {
+                const int e = 2 + sgn(c - (int)r[-dys[k] * stride - dxs[k]]) + sgn(c - (int)r[dys[k] * stride + dxs[k]]);
+                if (e != 2) o = p.offset[e < 2 ? e : e - 1];
+            }
+        }
+        dst[(long)y * stride + x] = (uint8_t)clip8(c + o);
+    }
+}
+
+__global__ __launch_bounds__(256) void sao_ctu_kernel(KsGeom g, int lam, int enable, const uint8_t *sy, const uint8_t *su, const uint8_t *sv,
+                                                      const uint8_t *dy, const uint8_t *du, const uint8_t *dv, ks265_sao_param *sao, uint8_t *oy,
+                                                      uint8_t *ou, uint8_t *ov)
+{
+    __shared__ SaoStats st[3];
+    __shared__ ks265_sao_param sel[3];
+    __shared__ long long jl[5], jc[5];
+    __shared__ ks265_sao_param cand[3][5];
+    const int tid = threadIdx.x, ctu = blockIdx.x, cx = ctu % g.ctu_cols, cy = ctu / g.ctu_cols;
+    const int x0 = cx * 64, y0 = cy * 64, w = min(64, g.W - x0), h = min(64, g.H - y0);
+    sao_collect(ks_org_y(g, sy), ks_org_y(g, dy), g.sy, x0, y0, w, h, g.W, g.H, &st[0], tid);
+    sao_collect(ks_org_c(g, su), ks_org_c(g, du), g.sc, x0 / 2, y0 / 2, w / 2, h / 2, g.W / 2, g.H / 2, &st[1], tid);
+    sao_collect(ks_org_c(g, sv), ks_org_c(g, dv), g.sc, x0 / 2, y0 / 2, w / 2, h / 2, g.W / 2, g.H / 2, &st[2], tid);
+    if (tid < 15) {                                    // 3 components x 5 types evaluated in parallel
+        const int comp = tid / 5, t = tid % 5;
+        long long j = sao_eval(&st[comp], t, lam, &cand[comp][t]);
+        if (comp == 0) jl[t] = j;
+        else if (comp == 1) jc[t] = j;
+    }
+    __syncthreads();
+    if (tid >= 10 && tid < 15) {                       // chroma cost is the sum over Cb and Cr
+        ks265_sao_param tmp;
+        jc[tid - 10] += sao_eval(&st[2], tid - 10, lam, &tmp);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        ks265_sao_param off;
+        off.type = -1; off.band = 0; off.offset[0] = off.offset[1] = off.offset[2] = off.offset[3] = 0; off.rsv[0] = off.rsv[1] = 0;
+        sel[0] = sel[1] = sel[2] = off;
+        long long bj = 0, bjc = 0;
+        if (enable)
+            for (int t = 0; t < 5; ++t) {
+                if (jl[t] < bj) { bj = jl[t]; sel[0] = cand[0][t]; }
+                if (jc[t] < bjc) { bjc = jc[t]; sel[1] = cand[1][t]; sel[2] = cand[2][t]; }
+            }
+        sao[(long)ctu * 3 + 0] = sel[0]; sao[(long)ctu * 3 + 1] = sel[1]; sao[(long)ctu * 3 + 2] = sel[2];
+    }
+    __syncthreads();
+    sao_apply_ctu(ks_org_y(g, dy), ks_org_y(g, oy), g.sy, x0, y0, w, h, g.W, g.H, sel[0], tid);
+    sao_apply_ctu(ks_org_c(g, du), ks_org_c(g, ou), g.sc, x0 / 2, y0 / 2, w / 2, h / 2, g.W / 2, g.H / 2, sel[1], tid);
+    sao_apply_ctu(ks_org_c(g, dv), ks_org_c(g, ov), g.sc, x0 / 2, y0 / 2, w / 2, h / 2, g.W / 2, g.H / 2, sel[2], tid);
+}
+
+extern "C" int ks265_sao(ks265_frame *f, ks265_pic src, ks265_pic deb, ks265_sao_param *sao, ks265_pic dst)
+{
+    KS_FRAME_CHECK(f);
+    if (!src.y || !deb.y || !sao || !dst.y) return KS265_POINTER;
+    hipLaunchKernelGGL(sao_ctu_kernel, dim3(f->g.ctu_cols * f->g.ctu_rows), dim3(256), 0, f->ctx->stream, f->g, f->cfg.lambda_q4, f->cfg.sao, src.y, src.u,
+                       src.v, deb.y, deb.u, deb.v, sao, dst.y, dst.u, dst.v);
+    int r = ks265_check_launch(f->ctx);
+    if (r) return r;
+    return ks265_pad_picture(f, dst);
+}

@@ -1,0 +1,205 @@
+// frame_util.hip — picture plumbing: geometry, border padding (expandPicture_c enc@0x4a6ae0), I420 load/store,
+// the fractional-sample planes (stage A0) and picture SSE.
+#include "frame_common.h"
+
+using namespace ks265;
+
+static inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
+
+extern "C" int ks265_frame_geometry(const ks265_frame_cfg *cfg, ks265_frame_geom *g)
+{
+    if (!cfg || !g) return KS265_POINTER;
+    if (cfg->width <= 0 || cfg->height <= 0 || (cfg->width & 7) || (cfg->height & 7) || cfg->me_range > 64 || cfg->me_range < 1 ||
+        cfg->qp < 0 || cfg->qp > 51) return KS265_NOTSUPPORTED;
+    g->pad_y = KS_PAD_Y; g->pad_c = KS_PAD_C;
+    g->stride_y = align_up(cfg->width + 2 * KS_PAD_Y, 128);
+    g->stride_c = align_up(cfg->width / 2 + 2 * KS_PAD_C, 64);
+    g->rows_y = cfg->height + 2 * KS_PAD_Y;
+    g->rows_c = cfg->height / 2 + 2 * KS_PAD_C;
+    g->bytes_y = (int64_t)g->stride_y * g->rows_y;
+    g->bytes_c = (int64_t)g->stride_c * g->rows_c;
+    g->ctu_cols = (cfg->width + 63) / 64;
+    g->ctu_rows = (cfg->height + 63) / 64;
+    g->pu_per_ctu = 85;
+    g->bytes_pu = (int64_t)g->ctu_cols * g->ctu_rows * 85 * (int64_t)sizeof(ks265_pu);
+    g->bytes_cu8 = (int64_t)(cfg->width / 8) * (cfg->height / 8) * (int64_t)sizeof(ks265_cu8);
+    g->bytes_sao = (int64_t)g->ctu_cols * g->ctu_rows * 3 * (int64_t)sizeof(ks265_sao_param);
+    return KS265_OK;
+}
+
+// ------------------------------------------------------------------ border padding: one thread per 4 border bytes
+__global__ __launch_bounds__(256) void pad_plane_kernel(uint8_t *plane, int stride, int w, int h, int pad)
+{
+    int fw = w + 2 * pad, fh = h + 2 * pad;
+    int x4 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4, y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x4 >= fw || y >= fh) return;
+    int yy = y - pad, xx = x4 - pad;
+    bool inside_rows = yy >= 0 && yy < h;
+    if (inside_rows && xx >= 0 && xx + 3 < w) return;          // interior dword: untouched
+    int sy = min(max(yy, 0), h - 1);
+    const uint8_t *srow = plane + (long)(sy + pad) * stride + pad;
+    unsigned v = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v |= (unsigned)srow[min(max(xx + i, 0), w - 1)] << (8 * i);
+    *(unsigned *)(plane + (long)y * stride + x4) = v;
+}
+
+static void launch_pad(ks265_frame *f, uint8_t *plane, int stride, int w, int h, int pad)
+{
+    dim3 grid(((w + 2 * pad) / 4 + 63) / 64, (h + 2 * pad + 3) / 4);
+    hipLaunchKernelGGL(pad_plane_kernel, grid, dim3(256), 0, f->ctx->stream, plane, stride, w, h, pad);
+}
+
+extern "C" int ks265_pad_picture(ks265_frame *f, ks265_pic pic)
+{
+    KS_FRAME_CHECK(f);
+    launch_pad(f, pic.y, f->g.sy, f->g.W, f->g.H, KS_PAD_Y);
+    launch_pad(f, pic.u, f->g.sc, f->g.W / 2, f->g.H / 2, KS_PAD_C);
+    launch_pad(f, pic.v, f->g.sc, f->g.W / 2, f->g.H / 2, KS_PAD_C);
+    return ks265_check_launch(f->ctx);
+}
+
+// ------------------------------------------------------------------ I420 <-> padded picture (dword per thread)
+__global__ __launch_bounds__(256) void copy_rows_kernel(uint8_t *dst, long dstStride, const uint8_t *src, long srcStride, int w, int h)
+{
+    int x4 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4, y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x4 >= w || y >= h) return;
+    *(unsigned *)(dst + y * dstStride + x4) = *(const unsigned *)(src + y * srcStride + x4);
+}
+static void launch_copy(ks265_frame *f, uint8_t *dst, long ds, const uint8_t *src, long ss, int w, int h)
+{
+    hipLaunchKernelGGL(copy_rows_kernel, dim3((w / 4 + 63) / 64, (h + 3) / 4), dim3(256), 0, f->ctx->stream, dst, ds, src, ss, w, h);
+}
+
+extern "C" int ks265_load_i420(ks265_frame *f, const uint8_t *i420, ks265_pic dst)
+{
+    KS_FRAME_CHECK(f);
+    if (!i420) return KS265_POINTER;
+    int W = f->g.W, H = f->g.H;
+    launch_copy(f, dst.y + f->g.org_y, f->g.sy, i420, W, W, H);
+    launch_copy(f, dst.u + f->g.org_c, f->g.sc, i420 + (long)W * H, W / 2, W / 2, H / 2);
+    launch_copy(f, dst.v + f->g.org_c, f->g.sc, i420 + (long)W * H * 5 / 4, W / 2, W / 2, H / 2);
+    return ks265_pad_picture(f, dst);
+}
+
+extern "C" int ks265_store_i420(ks265_frame *f, ks265_pic src, uint8_t *i420)
+{
+    KS_FRAME_CHECK(f);
+    if (!i420) return KS265_POINTER;
+    int W = f->g.W, H = f->g.H;
+    launch_copy(f, i420, W, src.y + f->g.org_y, f->g.sy, W, H);
+    launch_copy(f, i420 + (long)W * H, W / 2, src.u + f->g.org_c, f->g.sc, W / 2, H / 2);
+    launch_copy(f, i420 + (long)W * H * 5 / 4, W / 2, src.v + f->g.org_c, f->g.sc, W / 2, H / 2);
+    return ks265_check_launch(f->ctx);
+}
+
+// ------------------------------------------------------------------ Stage A0: the 15 fractional planes
+// One workgroup = one 64x16 output tile; the (64+8) x (16+7) source tile is staged in LDS, the three horizontal
+// 8-tap intermediates (raw 16-bit sums, interpLumaHor8to16_c enc@0x40eb80) are built once in LDS and every thread
+// then produces 4 adjacent samples of all 15 planes (one dword store per plane): fy = 0 planes round the
+// intermediate ((s+32)>>6 == interpLumaHor8to8_c enc@0x40e4f0), fx = 0 planes filter the source vertically
+// (interpLumaVer8to8_c enc@0x40f0c0), the nine 2-D planes filter the intermediates (interpLumaVer16to8_c enc@0x4100b0).
+// hipcc (ROCm 7.2) folds clip8(x >> s) pairs into gfx950's v_ashr_pk_u8_i32 and then ORs the packed pair with
+// `v_lshl_or_b32` assuming bits 31:16 of its result are zero; on MI355X they are not (measured: the upper two
+// samples of every packed dword came back OR-contaminated).  An empty asm on the shifted value keeps the
+// shift and the clamp apart so the instruction is never selected.
+__device__ __forceinline__ int no_pk(int v) { asm volatile("" : "+v"(v)); return v; }
+
+#define PT_W 64
+#define PT_H 16
+#define PT_SW 72      // source tile width  (x-3 .. x+64+4, padded to a dword multiple)
+#define PT_SH 23      // source tile height (y-3 .. y+16+3)
+__global__ __launch_bounds__(256) void ref_planes_kernel(KsGeom g, const uint8_t *ref, uint8_t *planes)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t S[PT_SH][PT_SW];   // dword stores: the array must be 4-byte aligned in LDS
+    __shared__ short Hm[3][PT_SH][PT_W];
+    const int tid = threadIdx.x;
+    const int x0 = -KS_PLANE_MARGIN + blockIdx.x * PT_W, y0 = -KS_PLANE_MARGIN + blockIdx.y * PT_H;
+    const uint8_t *R = ks_org_y(g, ref);
+    // source tile: dword loads (x0 - 4 is dword aligned: origin, margin and tile width are multiples of 4)
+    for (int i = tid; i < PT_SH * (PT_SW / 4); i += 256) {
+        int r = i / (PT_SW / 4), c = i - r * (PT_SW / 4);
+        int yy = min(y0 - 3 + r, g.H + KS_PAD_Y - 1);                 // rows past the border only feed discarded outputs
+        *(unsigned *)&S[r][c * 4] = *(const unsigned *)(R + (long)yy * g.sy + x0 - 4 + c * 4);
+    }
+    __syncthreads();
+    // horizontal intermediates; S column of sample x is (x - x0) + 4
+    for (int i = tid; i < PT_SH * PT_W; i += 256) {
+        int r = i / PT_W, x = i - r * PT_W;
+        int s1 = 0, s2 = 0, s3 = 0;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            int p = S[r][x + 1 + t];          // sample x - 3 + t
+            s1 += kLumaTaps[1][t] * p; s2 += kLumaTaps[2][t] * p; s3 += kLumaTaps[3][t] * p;
+        }
+        Hm[0][r][x] = (short)s1; Hm[1][r][x] = (short)s2; Hm[2][r][x] = (short)s3;
+    }
+    __syncthreads();
+    const int tx = (tid & 15) * 4, ty = tid >> 4;      // 4 samples at (x0 + tx .. +3, y0 + ty)
+    const int X = x0 + tx, Y = y0 + ty;
+    if (X >= g.W + KS_PLANE_MARGIN || Y >= g.H + KS_PLANE_MARGIN) return;
+    unsigned out[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p) out[p] = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int x = tx + i, r = ty + 3;              // row of sample Y inside the tile
+        out[0] |= (unsigned)S[r][x + 4] << (8 * i);
+#pragma unroll
+        for (int fx = 1; fx < 4; ++fx) out[fx] |= (unsigned)clip8(no_pk(((int)Hm[fx - 1][r][x] + 32) >> 6)) << (8 * i);
+#pragma unroll
+        for (int fy = 1; fy < 4; ++fy) {
+            int sv = 0, s1 = 0, s2 = 0, s3 = 0;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                int c = kLumaTaps[fy][t];
+                sv += c * (int)S[ty + t][x + 4];
+                s1 += c * (int)Hm[0][ty + t][x]; s2 += c * (int)Hm[1][ty + t][x]; s3 += c * (int)Hm[2][ty + t][x];
+            }
+            out[fy * 4 + 0] |= (unsigned)clip8(no_pk((sv + 32) >> 6)) << (8 * i);
+            out[fy * 4 + 1] |= (unsigned)clip8(no_pk((s1 + 2048) >> 12)) << (8 * i);
+            out[fy * 4 + 2] |= (unsigned)clip8(no_pk((s2 + 2048) >> 12)) << (8 * i);
+            out[fy * 4 + 3] |= (unsigned)clip8(no_pk((s3 + 2048) >> 12)) << (8 * i);
+        }
+    }
+    long off = g.org_y + (long)Y * g.sy + X;
+#pragma unroll
+    for (int p = 0; p < 16; ++p) *(unsigned *)(planes + p * g.bytes_y + off) = out[p];
+}
+
+extern "C" int ks265_ref_planes(ks265_frame *f, ks265_pic ref, uint8_t *planes)
+{
+    KS_FRAME_CHECK(f);
+    if (!ref.y || !planes) return KS265_POINTER;
+    dim3 grid((f->g.W + 2 * KS_PLANE_MARGIN + PT_W - 1) / PT_W, (f->g.H + 2 * KS_PLANE_MARGIN + PT_H - 1) / PT_H);
+    hipLaunchKernelGGL(ref_planes_kernel, grid, dim3(256), 0, f->ctx->stream, f->g, ref.y, planes);
+    return ks265_check_launch(f->ctx);
+}
+
+// ------------------------------------------------------------------ picture SSE (PSNR): sse3[0..2] += per-plane sums
+__global__ __launch_bounds__(256) void sse_plane_kernel(const uint8_t *a, const uint8_t *b, long stride, int w, int h, unsigned long long *out)
+{
+    int x4 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4, y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    unsigned s = 0;
+    if (x4 < w && y < h) {
+        unsigned va = *(const unsigned *)(a + y * stride + x4), vb = *(const unsigned *)(b + y * stride + x4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { int d = (int)((va >> (8 * i)) & 255) - (int)((vb >> (8 * i)) & 255); s += (unsigned)(d * d); }
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0 && s) atomicAdd(out, (unsigned long long)s);
+}
+
+extern "C" int ks265_sse_picture(ks265_frame *f, ks265_pic a, ks265_pic b, uint64_t *sse3)
+{
+    KS_FRAME_CHECK(f);
+    if (!sse3) return KS265_POINTER;
+    int W = f->g.W, H = f->g.H;
+    hipError_t e = hipMemsetAsync(sse3, 0, 3 * sizeof(uint64_t), f->ctx->stream);
+    if (e != hipSuccess) return ks265_hip(f->ctx, e);
+    unsigned long long *o = (unsigned long long *)sse3;
+    hipLaunchKernelGGL(sse_plane_kernel, dim3((W / 4 + 63) / 64, (H + 3) / 4), dim3(256), 0, f->ctx->stream, a.y + f->g.org_y, b.y + f->g.org_y, (long)f->g.sy, W, H, o);
+    hipLaunchKernelGGL(sse_plane_kernel, dim3((W / 8 + 63) / 64, (H / 2 + 3) / 4), dim3(256), 0, f->ctx->stream, a.u + f->g.org_c, b.u + f->g.org_c, (long)f->g.sc, W / 2, H / 2, o + 1);
+    hipLaunchKernelGGL(sse_plane_kernel, dim3((W / 8 + 63) / 64, (H / 2 + 3) / 4), dim3(256), 0, f->ctx->stream, a.v + f->g.org_c, b.v + f->g.org_c, (long)f->g.sc, W / 2, H / 2, o + 2);
+    return ks265_check_launch(f->ctx);
+}

@@ -1,0 +1,301 @@
+"""ctypes binding of include/ks265_hip.h.  Device buffers are torch CUDA(HIP) tensors; only their
+data_ptr() crosses the C ABI."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libks265hip.so")
+
+# descriptor layouts of include/ks265_hip.h
+BLK = np.dtype([("a_off", "<i4"), ("b_off", "<i4"), ("w", "<i4"), ("h", "<i4")])
+BLK3 = np.dtype([("a_off", "<i4"), ("b_off", "<i4", 3), ("w", "<i4"), ("h", "<i4")])
+EDGE = np.dtype([("pix_off", "<i4"), ("beta", "<i2"), ("tc", "<i2"), ("length", "<i2"), ("dir", "u1"), ("flags", "u1")])
+SAO_RECT = np.dtype([("org_off", "<i4"), ("rec_off", "<i4"), ("w", "<i4"), ("h", "<i4")])
+PU = np.dtype([("mvx", "<i2"), ("mvy", "<i2"), ("mvpx", "<i2"), ("mvpy", "<i2"), ("cost", "<u4"), ("dist", "<u4")])
+CU8 = np.dtype([("mvx", "<i2"), ("mvy", "<i2"), ("log2_cu", "u1"), ("cbf", "u1"), ("pred_mode", "u1"), ("rsv", "u1")])
+SAO_PARAM = np.dtype([("type", "i1"), ("band", "i1"), ("offset", "i1", 4), ("rsv", "i1", 2)])
+
+
+class FrameCfg(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("width", "height", "qp", "lambda_q4", "me_range", "me_method", "subme", "deblock", "sao",
+                                          "beta_offset_div2", "tc_offset_div2")]
+
+
+class FrameGeom(C.Structure):
+    _fields_ = [("pad_y", C.c_int32), ("pad_c", C.c_int32), ("stride_y", C.c_int32), ("stride_c", C.c_int32),
+                ("rows_y", C.c_int32), ("rows_c", C.c_int32), ("bytes_y", C.c_int64), ("bytes_c", C.c_int64),
+                ("ctu_cols", C.c_int32), ("ctu_rows", C.c_int32), ("pu_per_ctu", C.c_int32), ("bytes_pu", C.c_int64),
+                ("bytes_cu8", C.c_int64), ("bytes_sao", C.c_int64)]
+
+
+class Pic(C.Structure):
+    _fields_ = [("y", C.c_void_p), ("u", C.c_void_p), ("v", C.c_void_p)]
+
+
+class Ks265Error(RuntimeError):
+    pass
+
+
+_lib = None
+
+# every symbol include/ks265_hip.h declares (checked by tests/test_abi.py against the header text)
+EXPORTS = [
+    "ks265_create", "ks265_destroy", "ks265_set_stream", "ks265_synchronize", "ks265_last_error", "ks265_version",
+    "ks265_timer_start", "ks265_timer_stop_ms",
+    "ks265_sad_batch", "ks265_sad4_batch", "ks265_sad3_batch", "ks265_sad4blk_8x8_batch", "ks265_sse_batch", "ks265_had_batch",
+    "ks265_residual_batch", "ks265_fwd_transform_batch", "ks265_quant_batch", "ks265_dequant_batch", "ks265_inv_transform_batch",
+    "ks265_edge_filter_luma_batch", "ks265_edge_filter_chroma_batch", "ks265_interp_rect",
+    "ks265_sao_apply_bo_rect", "ks265_sao_apply_eo_rect", "ks265_sao_stats_batch",
+    "ks265_frame_geometry", "ks265_frame_create", "ks265_frame_destroy", "ks265_frame_set_qp", "ks265_pad_picture",
+    "ks265_load_i420", "ks265_store_i420", "ks265_ref_planes", "ks265_me_integer", "ks265_me_subpel", "ks265_cu_decide",
+    "ks265_cu_flat_intra", "ks265_reconstruct", "ks265_deblock", "ks265_sao", "ks265_encode_picture",
+    "ks265_frame_levels", "ks265_frame_pu", "ks265_frame_cu8", "ks265_frame_sao", "ks265_frame_planes", "ks265_sse_picture",
+]
+
+
+def load_library() -> C.CDLL:
+    """Load libks265hip.so; fail loudly if it has not been built (no CPU fallback exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise Ks265Error(f"{LIB_PATH} missing: run `python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950)")
+        _lib = C.CDLL(LIB_PATH)
+        _lib.ks265_last_error.restype = C.c_char_p
+        _lib.ks265_version.restype = C.c_char_p
+        for n in ("ks265_frame_levels", "ks265_frame_pu", "ks265_frame_cu8", "ks265_frame_sao", "ks265_frame_planes"):
+            if hasattr(_lib, n):
+                getattr(_lib, n).restype = C.c_void_p
+    return _lib
+
+
+def _p(t) -> C.c_void_p:
+    """device pointer of a torch tensor (or None)"""
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+class KsContext:
+    """Owns a ks265_ctx bound to torch's current HIP stream on `device`."""
+
+    def __init__(self, device: int = 0):
+        import torch
+
+        self.lib = load_library()
+        if not torch.cuda.is_available():
+            raise Ks265Error("no HIP device visible: the ks265 pixel path has no CPU fallback")
+        self.torch = torch
+        self.device = torch.device("cuda", device)
+        h = C.c_void_p()
+        self._chk(self.lib.ks265_create(C.byref(h), C.c_int(device)), None)
+        self.h = h
+        torch.cuda.set_device(device)
+        self._chk(self.lib.ks265_set_stream(self.h, C.c_void_p(torch.cuda.current_stream(device).cuda_stream)))
+
+    def _chk(self, rc: int, h="self"):
+        if rc != 0:
+            msg = self.lib.ks265_last_error(self.h).decode() if h == "self" and getattr(self, "h", None) else ""
+            raise Ks265Error(f"ks265 call failed rc={rc} {msg}")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.ks265_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- helpers
+    def dev(self, arr: np.ndarray):
+        """host numpy (any dtype incl. structured) -> device byte-exact tensor of the same dtype family"""
+        t = self.torch
+        a = np.ascontiguousarray(arr)
+        raw = t.from_numpy(a.view(np.uint8).reshape(-1).copy()).to(self.device)
+        return raw
+
+    def zeros(self, nbytes: int):
+        return self.torch.zeros(int(nbytes), dtype=self.torch.uint8, device=self.device)
+
+    def host(self, t, dtype, shape=None) -> np.ndarray:
+        a = t.cpu().numpy().view(dtype)
+        return a.reshape(shape) if shape is not None else a
+
+    def sync(self):
+        self._chk(self.lib.ks265_synchronize(self.h))
+
+    # ---- section 2: batched operator tables (names follow the reference tables)
+    def _dist(self, fn, a, sa, b, sb, blks: np.ndarray, k: int) -> np.ndarray:
+        n = len(blks)
+        out = self.zeros(4 * n * k)
+        self._chk(fn(self.h, _p(a), C.c_int(sa), _p(b), C.c_int(sb), _p(self.dev(blks)), C.c_int(n), _p(out)))
+        return self.host(out, np.uint32, (n, k) if k > 1 else (n,))
+
+    def sad(self, a, sa, b, sb, blks): return self._dist(self.lib.ks265_sad_batch, a, sa, b, sb, blks, 1)
+    def sse(self, a, sa, b, sb, blks): return self._dist(self.lib.ks265_sse_batch, a, sa, b, sb, blks, 1)
+    def had(self, a, sa, b, sb, blks): return self._dist(self.lib.ks265_had_batch, a, sa, b, sb, blks, 1)
+    def sad4(self, a, sa, b, sb, blks): return self._dist(self.lib.ks265_sad4_batch, a, sa, b, sb, blks, 4)
+    def sad3(self, a, sa, b, sb, blks): return self._dist(self.lib.ks265_sad3_batch, a, sa, b, sb, blks, 3)
+    def sad4blk_8x8(self, a, sa, b, sb, blks): return self._dist(self.lib.ks265_sad4blk_8x8_batch, a, sa, b, sb, blks, 4)
+
+    def residual(self, org, so, pred, sp, blks: np.ndarray) -> np.ndarray:
+        total = int((blks["w"].astype(np.int64) ** 2).sum())
+        out = self.zeros(2 * total)
+        self._chk(self.lib.ks265_residual_batch(self.h, _p(org), C.c_int(so), _p(pred), C.c_int(sp), _p(self.dev(blks)), C.c_int(len(blks)), _p(out)))
+        return self.host(out, np.int16)
+
+    def fwd_transform(self, idx: int, src: np.ndarray) -> np.ndarray:
+        nblk = src.shape[0]
+        d, out = self.dev(src.astype(np.int16)), self.zeros(src.size * 2)
+        self._chk(self.lib.ks265_fwd_transform_batch(self.h, C.c_int(idx), _p(d), _p(out), C.c_int(nblk)))
+        return self.host(out, np.int16, src.shape)
+
+    def inv_transform(self, idx: int, coef: np.ndarray, pred: np.ndarray) -> np.ndarray:
+        nblk = coef.shape[0]
+        dc, dp, out = self.dev(coef.astype(np.int16)), self.dev(pred.astype(np.uint8)), self.zeros(pred.size)
+        self._chk(self.lib.ks265_inv_transform_batch(self.h, C.c_int(idx), _p(dc), _p(dp), _p(out), C.c_int(nblk)))
+        return self.host(out, np.uint8, pred.shape)
+
+    def quant(self, n: int, coef: np.ndarray, scale: int, off: int, qbits: int):
+        nblk = coef.shape[0]
+        dc = self.dev(coef.astype(np.int16))
+        lvl, du, nz = self.zeros(coef.size * 2), self.zeros(coef.size * 2), self.zeros(4 * nblk)
+        self._chk(self.lib.ks265_quant_batch(self.h, C.c_int(n), _p(dc), _p(lvl), _p(du), _p(nz), C.c_int(scale), C.c_int(off), C.c_int(qbits), C.c_int(nblk)))
+        return self.host(lvl, np.int16, coef.shape), self.host(du, np.int16, coef.shape), self.host(nz, np.int32)
+
+    def dequant(self, n: int, lvl: np.ndarray, scale: int, add: int, shift: int) -> np.ndarray:
+        nblk = lvl.shape[0]
+        dl, out = self.dev(lvl.astype(np.int16)), self.zeros(lvl.size * 2)
+        self._chk(self.lib.ks265_dequant_batch(self.h, C.c_int(n), _p(dl), _p(out), C.c_int(scale), C.c_int(add), C.c_int(shift), C.c_int(nblk)))
+        return self.host(out, np.int16, lvl.shape)
+
+    def edge_filter(self, plane, stride: int, edges: np.ndarray, chroma: bool = False):
+        fn = self.lib.ks265_edge_filter_chroma_batch if chroma else self.lib.ks265_edge_filter_luma_batch
+        self._chk(fn(self.h, _p(plane), C.c_int(stride), _p(self.dev(edges)), C.c_int(len(edges))))
+
+    def interp_rect(self, kind: int, dst, ds: int, src, src_byte_off: int, ss: int, w: int, h: int, frac: int):
+        self._chk(self.lib.ks265_interp_rect(self.h, C.c_int(kind), _p(dst), C.c_int(ds), C.c_void_p(src.data_ptr() + src_byte_off),
+                                             C.c_int(ss), C.c_int(w), C.c_int(h), C.c_int(frac)))
+
+    def sao_apply_bo(self, offsets: np.ndarray, rec, stride: int, h: int, w: int, band: int):
+        o = (C.c_int8 * 4)(*[int(x) for x in offsets])
+        self._chk(self.lib.ks265_sao_apply_bo_rect(self.h, o, _p(rec), C.c_int(stride), C.c_int(h), C.c_int(w), C.c_int(band)))
+
+    def sao_apply_eo(self, cls: int, offsets: np.ndarray, src, dst, byte_off: int, stride: int, h: int, w: int):
+        o = (C.c_int8 * 5)(*[int(x) for x in offsets])
+        self._chk(self.lib.ks265_sao_apply_eo_rect(self.h, C.c_int(cls), o, C.c_void_p(src.data_ptr() + byte_off),
+                                                   C.c_void_p(dst.data_ptr() + byte_off), C.c_int(stride), C.c_int(h), C.c_int(w)))
+
+    def sao_stats(self, org, os_: int, rec, rs: int, rects: np.ndarray, row_step: int) -> np.ndarray:
+        out = self.zeros(4 * 96 * len(rects))
+        self._chk(self.lib.ks265_sao_stats_batch(self.h, _p(org), C.c_int(os_), _p(rec), C.c_int(rs), _p(self.dev(rects)), C.c_int(len(rects)),
+                                                 C.c_int(row_step), _p(out)))
+        return self.host(out, np.int32, (len(rects), 96))
+
+
+class DevPic:
+    """A padded YUV 4:2:0 picture in HBM (three torch byte tensors)."""
+
+    def __init__(self, ks: "KsContext", geom: FrameGeom):
+        self.y, self.u, self.v = ks.zeros(geom.bytes_y), ks.zeros(geom.bytes_c), ks.zeros(geom.bytes_c)
+
+    def c(self) -> Pic:
+        return Pic(self.y.data_ptr(), self.u.data_ptr(), self.v.data_ptr())
+
+
+class KsFrame:
+    """Whole-frame stages of include/ks265_hip.h section 3 (one picture size, one stream)."""
+
+    def __init__(self, ks: KsContext, width: int, height: int, qp: int, lambda_q4: int, me_range: int = 64, subme: int = 1,
+                 deblock: int = 1, sao: int = 1):
+        self.ks, self.lib = ks, ks.lib
+        self.cfg = FrameCfg(width, height, qp, lambda_q4, me_range, 0, subme, deblock, sao, 0, 0)
+        self.geom = FrameGeom()
+        ks._chk(self.lib.ks265_frame_geometry(C.byref(self.cfg), C.byref(self.geom)))
+        h = C.c_void_p()
+        ks._chk(self.lib.ks265_frame_create(ks.h, C.byref(self.cfg), C.byref(h)))
+        self.h = h
+        self.width, self.height = width, height
+        self.nctu = self.geom.ctu_cols * self.geom.ctu_rows
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.ks265_frame_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def new_pic(self) -> DevPic:
+        return DevPic(self.ks, self.geom)
+
+    def set_qp(self, qp: int, lambda_q4: int):
+        self.cfg.qp, self.cfg.lambda_q4 = qp, lambda_q4
+        self.ks._chk(self.lib.ks265_frame_set_qp(self.h, C.c_int(qp), C.c_int(lambda_q4)))
+
+    def load_i420(self, dev_i420, pic: DevPic):
+        self.ks._chk(self.lib.ks265_load_i420(self.h, _p(dev_i420), pic.c()))
+
+    def store_i420(self, pic: DevPic):
+        out = self.ks.zeros(self.width * self.height * 3 // 2)
+        self.ks._chk(self.lib.ks265_store_i420(self.h, pic.c(), _p(out)))
+        return out
+
+    def pad(self, pic: DevPic):
+        self.ks._chk(self.lib.ks265_pad_picture(self.h, pic.c()))
+
+    def ref_planes(self, ref: DevPic, planes):
+        self.ks._chk(self.lib.ks265_ref_planes(self.h, ref.c(), _p(planes)))
+
+    def me_integer(self, src: DevPic, ref: DevPic, prev_pu, pu):
+        self.ks._chk(self.lib.ks265_me_integer(self.h, src.c(), ref.c(), _p(prev_pu), _p(pu)))
+
+    def me_subpel(self, src: DevPic, planes, pu):
+        self.ks._chk(self.lib.ks265_me_subpel(self.h, src.c(), _p(planes), _p(pu)))
+
+    def cu_decide(self, pu, cu8):
+        self.ks._chk(self.lib.ks265_cu_decide(self.h, _p(pu), _p(cu8)))
+
+    def cu_flat_intra(self, cu8):
+        self.ks._chk(self.lib.ks265_cu_flat_intra(self.h, _p(cu8)))
+
+    def reconstruct(self, src: DevPic, ref: DevPic, planes, cu8, lvl, recon: DevPic):
+        self.ks._chk(self.lib.ks265_reconstruct(self.h, src.c(), ref.c(), _p(planes), _p(cu8), _p(lvl[0]), _p(lvl[1]), _p(lvl[2]), recon.c()))
+
+    def deblock(self, cu8, recon: DevPic):
+        self.ks._chk(self.lib.ks265_deblock(self.h, _p(cu8), recon.c()))
+
+    def sao(self, src: DevPic, deb: DevPic, sao, dst: DevPic):
+        self.ks._chk(self.lib.ks265_sao(self.h, src.c(), deb.c(), _p(sao), dst.c()))
+
+    def encode_picture(self, src: DevPic, ref: DevPic, is_key: bool, recon_out: DevPic):
+        self.ks._chk(self.lib.ks265_encode_picture(self.h, src.c(), ref.c(), C.c_int(1 if is_key else 0), recon_out.c()))
+
+    def sse_picture(self, a: DevPic, b: DevPic) -> np.ndarray:
+        out = self.ks.zeros(24)
+        self.ks._chk(self.lib.ks265_sse_picture(self.h, a.c(), b.c(), _p(out)))
+        return self.ks.host(out, np.uint64)
+
+    # internal workspace views (device pointers wrapped as ctypes addresses)
+    def ws_ptr(self, name: str, comp: int = 0) -> int:
+        fn = getattr(self.lib, "ks265_frame_" + name)
+        return fn(self.h, C.c_int(comp)) if name == "levels" else fn(self.h)
+
+    def ws_read(self, name: str, nbytes: int, comp: int = 0) -> np.ndarray:
+        """copy `nbytes` of an internal workspace buffer to the host"""
+        t = self.ks.torch
+        out = t.empty(nbytes, dtype=t.uint8, device=self.ks.device)
+        src = self.ws_ptr(name, comp)
+        hip = C.CDLL("libamdhip64.so")
+        self.ks.sync()
+        rc = hip.hipMemcpy(C.c_void_p(out.data_ptr()), C.c_void_p(src), C.c_size_t(nbytes), C.c_int(3))  # device to device
+        if rc != 0:
+            raise Ks265Error(f"hipMemcpy rc={rc}")
+        return out.cpu().numpy()

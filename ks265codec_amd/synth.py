@@ -1,0 +1,47 @@
+"""Synthetic I420 clips of SURVEY.md §8(d): smooth sinusoid luma + static texture, global pan, moving textured
+squares, optional fresh per-frame noise; slow sinusoid chroma.  Deterministic (seeded numpy)."""
+from __future__ import annotations
+
+import numpy as np
+
+
+def make_clip(width: int, height: int, frames: int, seed: int = 42, noisy: bool = True, abc=(37, 53, 19), pan=(5, 3)) -> np.ndarray:
+    """returns uint8 array [frames, width*height*3/2] (planar I420, frames concatenated, no header)"""
+    rng = np.random.default_rng(seed)
+    a, b, c = abc
+    big_w, big_h = width + pan[0] * frames + 16, height + pan[1] * frames + 16
+    yy, xx = np.mgrid[0:big_h, 0:big_w].astype(np.float64)
+    base = 128 + 60 * np.sin(xx / a) + 50 * np.cos(yy / b) + 20 * np.sin((xx + yy) / c) + rng.integers(-10, 11, (big_h, big_w))
+    nsq = 6 + int(rng.integers(0, 3))
+    squares = []
+    for _ in range(nsq):
+        s = int(rng.integers(max(16, height // 12), max(32, height // 4)))
+        squares.append(dict(size=s, x=float(rng.integers(0, max(1, width - s))), y=float(rng.integers(0, max(1, height - s))),
+                            vx=float(rng.integers(-9, 10)), vy=float(rng.integers(-6, 7)),
+                            tex=np.clip(rng.integers(40, 216) + rng.integers(-25, 26, (s, s)), 0, 255)))
+    cy, cx = np.mgrid[0:height // 2, 0:width // 2].astype(np.float64)
+    out = np.empty((frames, width * height * 3 // 2), np.uint8)
+    for t in range(frames):
+        ox, oy = pan[0] * t, pan[1] * t
+        y = base[oy:oy + height, ox:ox + width].copy()
+        for q in squares:
+            px = int(round(q["x"] + q["vx"] * t)) % max(1, width - q["size"])
+            py = int(round(q["y"] + q["vy"] * t)) % max(1, height - q["size"])
+            y[py:py + q["size"], px:px + q["size"]] = q["tex"]
+        if noisy:
+            y = y + rng.integers(-2, 3, (height, width))
+        u = 128 + 30 * np.sin((cx + 2 * t) / 41.0) + 20 * np.cos(cy / 29.0)
+        v = 128 + 25 * np.cos((cx - t) / 33.0) + 25 * np.sin((cy + t) / 47.0)
+        out[t] = np.concatenate([np.clip(np.rint(p), 0, 255).astype(np.uint8).reshape(-1) for p in (y, u, v)])
+    return out
+
+
+def psnr(a: np.ndarray, b: np.ndarray) -> float:
+    d = a.astype(np.float64) - b.astype(np.float64)
+    mse = float((d * d).mean())
+    return 99.0 if mse == 0 else 10.0 * np.log10(255.0 * 255.0 / mse)
+
+
+def lambda_q4(qp: int) -> int:
+    """motion lambda in Q4 (host-side float setup, HM-style sqrt(0.57 * 2^((qp-12)/3)))"""
+    return int(round(16.0 * (0.57 * 2.0 ** ((qp - 12) / 3.0)) ** 0.5))

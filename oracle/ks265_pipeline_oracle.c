@@ -1,0 +1,558 @@
+/* ks265_pipeline_oracle.c — TEST INFRASTRUCTURE, NOT PRODUCT CODE (see ks265_pipeline_oracle.h).
+ * Whole-frame stages restated on the CPU from the pinned kernels of ks265_oracle.c. */
+#include "ks265_pipeline_oracle.h"
+#include "ks265_oracle.h"
+#include <stdlib.h>
+#include <string.h>
+
+#define PAD_Y 80
+#define PAD_C 40
+#define PLANE_MARGIN 72              /* fractional planes are defined on [-72, W+72) x [-72, H+72) */
+#define COST_INVALID 0xFFFFFFFFu
+
+static inline int imin(int a, int b) { return a < b ? a : b; }
+static inline int imax(int a, int b) { return a > b ? a : b; }
+static inline int iclip(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
+static inline int iabs_(int v) { return v < 0 ? -v : v; }
+static inline int isgn(int v) { return (v > 0) - (v < 0); }
+static inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
+
+int kso_frame_geometry(const kso_frame_cfg *cfg, kso_frame_geom *g)
+{
+    if (!cfg || !g || cfg->width <= 0 || cfg->height <= 0 || (cfg->width & 7) || (cfg->height & 7)) return -4;
+    g->pad_y = PAD_Y; g->pad_c = PAD_C;
+    g->stride_y = align_up(cfg->width + 2 * PAD_Y, 128);
+    g->stride_c = align_up(cfg->width / 2 + 2 * PAD_C, 64);
+    g->rows_y = cfg->height + 2 * PAD_Y;
+    g->rows_c = cfg->height / 2 + 2 * PAD_C;
+    g->bytes_y = (int64_t)g->stride_y * g->rows_y;
+    g->bytes_c = (int64_t)g->stride_c * g->rows_c;
+    g->ctu_cols = (cfg->width + 63) / 64;
+    g->ctu_rows = (cfg->height + 63) / 64;
+    g->pu_per_ctu = 85;
+    g->bytes_pu = (int64_t)g->ctu_cols * g->ctu_rows * 85 * (int64_t)sizeof(kso_pu);
+    g->bytes_cu8 = (int64_t)(cfg->width / 8) * (cfg->height / 8) * (int64_t)sizeof(kso_cu8);
+    g->bytes_sao = (int64_t)g->ctu_cols * g->ctu_rows * 3 * (int64_t)sizeof(kso_sao_param);
+    return 0;
+}
+
+/* pointer to sample (0,0) of a padded plane */
+static inline uint8_t *org_y(const kso_frame_geom *g, uint8_t *p) { return p + (long)PAD_Y * g->stride_y + PAD_Y; }
+static inline uint8_t *org_c(const kso_frame_geom *g, uint8_t *p) { return p + (long)PAD_C * g->stride_c + PAD_C; }
+
+/* expandPicture_c enc@0x4a6ae0: replicate the edge samples into the border */
+static void pad_plane(uint8_t *o, int stride, int w, int h, int pad)
+{
+    for (int y = 0; y < h; ++y) {
+        uint8_t *r = o + (long)y * stride;
+        memset(r - pad, r[0], (size_t)pad);
+        memset(r + w, r[w - 1], (size_t)pad);
+    }
+    for (int y = 1; y <= pad; ++y) {
+        memcpy(o - (long)y * stride - pad, o - pad, (size_t)(w + 2 * pad));
+        memcpy(o + (long)(h - 1 + y) * stride - pad, o + (long)(h - 1) * stride - pad, (size_t)(w + 2 * pad));
+    }
+}
+
+void kso_pad_picture(const kso_frame_cfg *cfg, kso_pic pic)
+{
+    kso_frame_geom g; kso_frame_geometry(cfg, &g);
+    pad_plane(org_y(&g, pic.y), g.stride_y, cfg->width, cfg->height, PAD_Y);
+    pad_plane(org_c(&g, pic.u), g.stride_c, cfg->width / 2, cfg->height / 2, PAD_C);
+    pad_plane(org_c(&g, pic.v), g.stride_c, cfg->width / 2, cfg->height / 2, PAD_C);
+}
+
+void kso_load_i420(const kso_frame_cfg *cfg, const uint8_t *i420, kso_pic dst)
+{
+    kso_frame_geom g; kso_frame_geometry(cfg, &g);
+    int w = cfg->width, h = cfg->height;
+    for (int y = 0; y < h; ++y) memcpy(org_y(&g, dst.y) + (long)y * g.stride_y, i420 + (long)y * w, (size_t)w);
+    const uint8_t *u = i420 + (long)w * h, *v = u + (long)(w / 2) * (h / 2);
+    for (int y = 0; y < h / 2; ++y) {
+        memcpy(org_c(&g, dst.u) + (long)y * g.stride_c, u + (long)y * (w / 2), (size_t)(w / 2));
+        memcpy(org_c(&g, dst.v) + (long)y * g.stride_c, v + (long)y * (w / 2), (size_t)(w / 2));
+    }
+    kso_pad_picture(cfg, dst);
+}
+
+void kso_store_i420(const kso_frame_cfg *cfg, kso_pic src, uint8_t *i420)
+{
+    kso_frame_geom g; kso_frame_geometry(cfg, &g);
+    int w = cfg->width, h = cfg->height;
+    for (int y = 0; y < h; ++y) memcpy(i420 + (long)y * w, org_y(&g, src.y) + (long)y * g.stride_y, (size_t)w);
+    uint8_t *u = i420 + (long)w * h, *v = u + (long)(w / 2) * (h / 2);
+    for (int y = 0; y < h / 2; ++y) {
+        memcpy(u + (long)y * (w / 2), org_c(&g, src.u) + (long)y * g.stride_c, (size_t)(w / 2));
+        memcpy(v + (long)y * (w / 2), org_c(&g, src.v) + (long)y * g.stride_c, (size_t)(w / 2));
+    }
+}
+
+/* ------------------------------------------------------------------ Stage A0: fractional planes
+ * plane[fy*4+fx](x,y) = normative luma sample at (x + fx/4, y + fy/4): interpLumaHor8to8_c enc@0x40e4f0 (fy = 0),
+ * interpLumaVer8to8_c enc@0x40f0c0 (fx = 0), interpLumaHor8to16_c enc@0x40eb80 + interpLumaVer16to8_c enc@0x4100b0. */
+void kso_ref_planes(const kso_frame_cfg *cfg, kso_pic ref, uint8_t *planes)
+{
+    kso_frame_geom g; kso_frame_geometry(cfg, &g);
+    int W = cfg->width + 2 * PLANE_MARGIN, H = cfg->height + 2 * PLANE_MARGIN, s = g.stride_y;
+    const uint8_t *src = org_y(&g, ref.y) - (long)PLANE_MARGIN * s - PLANE_MARGIN;
+    memset(planes, 0, (size_t)(16 * g.bytes_y));
+    memcpy(planes, ref.y, (size_t)g.bytes_y);
+    int16_t *tmp = (int16_t *)malloc(sizeof(int16_t) * (size_t)W * (size_t)(H + 7));
+    for (int fy = 0; fy < 4; ++fy)
+        for (int fx = 0; fx < 4; ++fx) {
+            if (!fx && !fy) continue;
+            uint8_t *dst = org_y(&g, planes + (long)(fy * 4 + fx) * g.bytes_y) - (long)PLANE_MARGIN * s - PLANE_MARGIN;
+            if (!fy) ks265o_interp_luma_hor_8to8(dst, s, src, s, W, H, fx);
+            else if (!fx) ks265o_interp_luma_ver_8to8(dst, s, src, s, W, H, fy);
+            else {
+                ks265o_interp_luma_hor_8to16(tmp, W, src - 3 * (long)s, s, W, H + 7, fx);
+                ks265o_interp_luma_ver_16to8(dst, s, tmp + 3 * W, W, W, H, fy);
+            }
+        }
+    free(tmp);
+}
+
+/* ------------------------------------------------------------------ motion-vector rate
+ * stands in for createMvdCostTable enc@0x48b850 (lambda(qp) x exp-Golomb length of the quarter-pel mvd) */
+static int se_bits(int v)
+{
+    unsigned u = (unsigned)(v <= 0 ? -2 * v : 2 * v - 1) + 1u;
+    int n = 0;
+    while (u >> (n + 1)) ++n;
+    return 2 * n + 1;
+}
+static int mv_cost(int mvx, int mvy, int px, int py, int lambda_q4) { return (lambda_q4 * (se_bits(mvx - px) + se_bits(mvy - py))) >> 4; }
+
+/* PU index helpers: level l (0: 64x64 .. 3: 8x8), raster inside the CTU */
+static const int kLevelBase[4] = {0, 1, 5, 21};
+static inline int pu_index(int l, int px, int py) { return kLevelBase[l] + py * (1 << l) + px; }
+/* 1 if the PU lies completely inside the picture */
+static int pu_inside(const kso_frame_cfg *cfg, int cx, int cy, int l, int px, int py)
+{
+    int s = 64 >> l, x0 = cx * 64 + px * s, y0 = cy * 64 + py * s;
+    return x0 + s <= cfg->width && y0 + s <= cfg->height;
+}
+
+/* motion predictor of a PU: integer MV of the nearest valid ancestor; for a root PU the temporal predictor
+ * (co-located 64x64 MV of the previous picture, rounded to integer pel) or zero.  (meInitPoint enc@0x48af50
+ * gathers spatial/merge candidates from already coded CTUs; a frame-parallel search cannot — SURVEY.md §7.3.) */
+static void pu_predictor(const kso_frame_cfg *cfg, const kso_pu *ctu_pu, const kso_pu *prev_ctu_pu, int cx, int cy, int l, int px, int py,
+                         int *mx, int *my, int *root)
+{
+    for (int a = l - 1; a >= 0; --a) {
+        int ax = px >> (l - a), ay = py >> (l - a);
+        if (pu_inside(cfg, cx, cy, a, ax, ay)) {
+            const kso_pu *p = &ctu_pu[pu_index(a, ax, ay)];
+            *mx = p->mvx >> 2; *my = p->mvy >> 2; *root = 0;
+            return;
+        }
+    }
+    *root = 1; *mx = 0; *my = 0;
+    if (prev_ctu_pu && prev_ctu_pu[0].cost != COST_INVALID) {
+        int r = cfg->me_range;
+        *mx = iclip(-r, r, (prev_ctu_pu[0].mvx + 2) >> 2);
+        *my = iclip(-r, r, (prev_ctu_pu[0].mvy + 2) >> 2);
+    }
+}
+
+/* ------------------------------------------------------------------ Stage A: integer search
+ * interMeDia enc@0x48fbe0 over sad4_c enc@0x47ae90, for every PU of every CTU, coarse to fine. */
+void kso_me_integer(const kso_frame_cfg *cfg, kso_pic src, kso_pic ref, const kso_pu *prev_pu, kso_pu *pu)
+{
+    kso_frame_geom g; kso_frame_geometry(cfg, &g);
+    const uint8_t *S = org_y(&g, src.y), *R = org_y(&g, ref.y);
+    long st = g.stride_y;
+    int range = cfg->me_range, lam = cfg->lambda_q4;
+    for (int cy = 0; cy < g.ctu_rows; ++cy)
+        for (int cx = 0; cx < g.ctu_cols; ++cx) {
+            kso_pu *cp = pu + (long)(cy * g.ctu_cols + cx) * 85;
+            const kso_pu *pp = prev_pu ? prev_pu + (long)(cy * g.ctu_cols + cx) * 85 : NULL;
+            for (int l = 0; l < 4; ++l)
+                for (int py = 0; py < (1 << l); ++py)
+                    for (int px = 0; px < (1 << l); ++px) {
+                        kso_pu *o = &cp[pu_index(l, px, py)];
+                        int s = 64 >> l, x0 = cx * 64 + px * s, y0 = cy * 64 + py * s;
+                        if (!pu_inside(cfg, cx, cy, l, px, py)) { memset(o, 0, sizeof *o); o->cost = COST_INVALID; o->dist = COST_INVALID; continue; }
+                        int pmx, pmy, root;
+                        pu_predictor(cfg, cp, pp, cx, cy, l, px, py, &pmx, &pmy, &root);
+                        const uint8_t *fenc = S + (long)y0 * st + x0;
+                        int mx = pmx, my = pmy;
+                        uint32_t sad = ks265o_sad(fenc, R + (long)(y0 + my) * st + x0 + mx, st, st, s, s);
+                        uint32_t bcost = sad + (uint32_t)mv_cost(mx << 2, my << 2, pmx << 2, pmy << 2, lam);
+                        if (root && (pmx || pmy)) {            /* second start candidate: the zero vector */
+                            uint32_t s0 = ks265o_sad(fenc, R + (long)y0 * st + x0, st, st, s, s);
+                            uint32_t c0 = s0 + (uint32_t)mv_cost(0, 0, pmx << 2, pmy << 2, lam);
+                            if (c0 < bcost) { bcost = c0; mx = 0; my = 0; }
+                        }
+                        int iters = root ? range : imax(range >> 2, 1), i = 0;
+                        bcost <<= 4;
+                        do {
+                            uint32_t c[4];
+                            ks265o_sad4(fenc, R + (long)(y0 + my) * st + x0 + mx, st, st, s, c, s);
+                            const int dx[4] = {0, 0, -1, 1}, dy[4] = {-1, 1, 0, 0};
+                            const uint32_t code[4] = {1, 3, 4, 12};
+                            for (int k = 0; k < 4; ++k) {
+                                int nx = mx + dx[k], ny = my + dy[k];
+                                if (iabs_(nx) > range || iabs_(ny) > range) continue;
+                                uint32_t v = c[k] + ((uint32_t)mv_cost(nx << 2, ny << 2, pmx << 2, pmy << 2, lam) << 4) + code[k];
+                                if (v < bcost) bcost = v;
+                            }
+                            if (!(bcost & 15)) break;
+                            mx -= (int)((int32_t)(bcost << 28) >> 30);
+                            my -= (int)((int32_t)(bcost << 30) >> 30);
+                            bcost &= ~15u;
+                        } while (++i < iters);
+                        bcost >>= 4;
+                        o->mvx = (int16_t)(mx << 2); o->mvy = (int16_t)(my << 2);
+                        o->mvpx = (int16_t)(pmx << 2); o->mvpy = (int16_t)(pmy << 2);
+                        o->cost = bcost;
+                        o->dist = bcost - (uint32_t)mv_cost(mx << 2, my << 2, pmx << 2, pmy << 2, lam);
+                    }
+        }
+}
+
+/* ------------------------------------------------------------------ Stage B: sub-pel refinement
+ * subMeSquare enc@0x4b5660: 8 half-pel then 8 quarter-pel candidates in the raster order of hpel_x/y, qpel_x/y
+ * (SURVEY.md B.11), prediction by the normative filters (here: the precomputed planes), cost = had_c + mv rate. */
+void kso_me_subpel(const kso_frame_cfg *cfg, kso_pic src, const uint8_t *planes, kso_pu *pu)
+{
+    kso_frame_geom g; kso_frame_geometry(cfg, &g);
+    const uint8_t *S = org_y(&g, src.y);
+    long st = g.stride_y;
+    int lam = cfg->lambda_q4;
+    static const int ox[8] = {-1, 0, 1, -1, 1, -1, 0, 1}, oy[8] = {-1, -1, -1, 0, 0, 1, 1, 1};
+    for (int cy = 0; cy < g.ctu_rows; ++cy)
+        for (int cx = 0; cx < g.ctu_cols; ++cx) {
+            kso_pu *cp = pu + (long)(cy * g.ctu_cols + cx) * 85;
+            for (int l = 0; l < 4; ++l)
+                for (int py = 0; py < (1 << l); ++py)
+                    for (int px = 0; px < (1 << l); ++px) {
+                        kso_pu *o = &cp[pu_index(l, px, py)];
+                        if (o->cost == COST_INVALID) continue;
+                        int s = 64 >> l, x0 = cx * 64 + px * s, y0 = cy * 64 + py * s;
+                        const uint8_t *fenc = S + (long)y0 * st + x0;
+                        int bx = o->mvx, by = o->mvy;
+                        uint32_t bd = ks265o_had(fenc, org_y(&g, (uint8_t *)planes) + (long)(y0 + (by >> 2)) * st + x0 + (bx >> 2), st, st, s, s);
+                        uint32_t bc = bd + (uint32_t)mv_cost(bx, by, o->mvpx, o->mvpy, lam);
+                        for (int step = 2; step >= 1; --step) {
+                            int cx0 = bx, cy0 = by;
+                            for (int k = 0; k < 8; ++k) {
+                                int qx = cx0 + ox[k] * step, qy = cy0 + oy[k] * step;
+                                const uint8_t *pl = org_y(&g, (uint8_t *)planes + (long)((qy & 3) * 4 + (qx & 3)) * g.bytes_y);
+                                uint32_t d = ks265o_had(fenc, pl + (long)(y0 + (qy >> 2)) * st + x0 + (qx >> 2), st, st, s, s);
+                                uint32_t c = d + (uint32_t)mv_cost(qx, qy, o->mvpx, o->mvpy, lam);
+                                if (c < bc) { bc = c; bd = d; bx = qx; by = qy; }
+                            }
+                        }
+                        o->mvx = (int16_t)bx; o->mvy = (int16_t)by; o->cost = bc; o->dist = bd;
+                    }
+        }
+}
+
+/* ------------------------------------------------------------------ Stage C: CU quadtree
+ * bottom-up compare of processTree enc@0x4722a0 (the reference adds RD cost and early exits; closed code). */
+static uint32_t decide_node(const kso_frame_cfg *cfg, const kso_pu *cp, int cx, int cy, int l, int px, int py, uint8_t *split /*[85]*/)
+{
+    int s = 64 >> l, x0 = cx * 64 + px * s, y0 = cy * 64 + py * s;
+    if (x0 >= cfg->width || y0 >= cfg->height) return 0;           /* not in the picture: nothing to code */
+    int idx = pu_index(l, px, py);
+    uint32_t own = cp[idx].cost;
+    if (l == 3) { split[idx] = 0; return own; }
+    uint64_t sum = (uint64_t)((cfg->lambda_q4 * 12) >> 4);       /* signalling overhead of three extra CUs */
+    for (int k = 0; k < 4; ++k) sum += decide_node(cfg, cp, cx, cy, l + 1, px * 2 + (k & 1), py * 2 + (k >> 1), split);
+    if (own != COST_INVALID && (uint64_t)own <= sum) { split[idx] = 0; return own; }
+    split[idx] = 1;
+    return sum > 0xFFFFFFFEu ? 0xFFFFFFFEu : (uint32_t)sum;
+}
+static void emit_node(const kso_frame_cfg *cfg, const kso_pu *cp, int cx, int cy, int l, int px, int py, const uint8_t *split, kso_cu8 *cu8)
+{
+    int s = 64 >> l, x0 = cx * 64 + px * s, y0 = cy * 64 + py * s, w8 = cfg->width / 8;
+    if (x0 >= cfg->width || y0 >= cfg->height) return;
+    int idx = pu_index(l, px, py);
+    if (l < 3 && split[idx]) {
+        for (int k = 0; k < 4; ++k) emit_node(cfg, cp, cx, cy, l + 1, px * 2 + (k & 1), py * 2 + (k >> 1), split, cu8);
+        return;
+    }
+    for (int by = 0; by < s / 8; ++by)
+        for (int bx = 0; bx < s / 8; ++bx) {
+            kso_cu8 *c = &cu8[(long)(y0 / 8 + by) * w8 + x0 / 8 + bx];
+            c->mvx = cp[idx].mvx; c->mvy = cp[idx].mvy; c->log2_cu = (uint8_t)(6 - l); c->cbf = 0; c->pred_mode = 0; c->rsv = 0;
+        }
+}
+void kso_cu_decide(const kso_frame_cfg *cfg, const kso_pu *pu, kso_cu8 *cu8)
+{
+    kso_frame_geom g; kso_frame_geometry(cfg, &g);
+    for (int cy = 0; cy < g.ctu_rows; ++cy)
+        for (int cx = 0; cx < g.ctu_cols; ++cx) {
+            const kso_pu *cp = pu + (long)(cy * g.ctu_cols + cx) * 85;
+            uint8_t split[85];
+            memset(split, 0, sizeof split);
+            decide_node(cfg, cp, cx, cy, 0, 0, 0, split);
+            emit_node(cfg, cp, cx, cy, 0, 0, 0, split, cu8);
+        }
+}
+
+/* key picture stand-in for the (out-of-scope) intra path: largest CU in {32,16,8} that fits, flat prediction */
+void kso_cu_flat_intra(const kso_frame_cfg *cfg, kso_cu8 *cu8)
+{
+    int w8 = cfg->width / 8, h8 = cfg->height / 8;
+    for (int by = 0; by < h8; ++by)
+        for (int bx = 0; bx < w8; ++bx) {
+            int lg = 3;
+            for (int t = 5; t > 3; --t) {
+                int n = 1 << (t - 3), ax = bx / n * n, ay = by / n * n;
+                if (ax + n <= w8 && ay + n <= h8) { lg = t; break; }
+            }
+            kso_cu8 *c = &cu8[(long)by * w8 + bx];
+            c->mvx = 0; c->mvy = 0; c->log2_cu = (uint8_t)lg; c->cbf = 0; c->pred_mode = 1; c->rsv = 0;
+        }
+}
+
+/* ------------------------------------------------------------------ Stage D: reconstruct() enc@0x481da0 */
+static int chroma_qp(int qp)
+{
+    static const int tab[14] = {29, 30, 31, 32, 33, 33, 34, 34, 35, 35, 36, 36, 37, 37};
+    return qp < 30 ? qp : (qp >= 44 ? qp - 6 : tab[qp - 30]);
+}
+
+/* residual -> fwd transform -> quant -> dequant -> inverse -> recon for one NxN TU; returns cbf */
+static int code_tu(const uint8_t *org, int so, const uint8_t *pred /*packed n*/, int n, int qp, int intra, int16_t *lvl, int lstride,
+                   uint8_t *rec, int rstride)
+{
+    int16_t res[32 * 32], coef[32 * 32], lv[32 * 32], du[32 * 32], dq[32 * 32], tmp[32 * 32];
+    int log2n = n == 4 ? 2 : n == 8 ? 3 : n == 16 ? 4 : 5, idx = log2n - 1;   /* DCT table index (DST4 is intra-luma-4x4 only) */
+    ks265o_calc_residual(res, org, pred, so, n, n, n);
+    ks265o_fwd_transform(idx, res, coef, n, n, tmp);
+    ks265o_quant_param p;
+    ks265o_get_base_quant_param(qp, intra ? 2 : 0, &p);
+    int qbits = p.qbits - log2n;
+    int nz = ks265o_quant(coef, lv, n, p.scale, p.offF << (qbits - 9), qbits, du, n);
+    for (int y = 0; y < n; ++y) memcpy(lvl + (long)y * lstride, lv + y * n, sizeof(int16_t) * (size_t)n);
+    if (!nz) {
+        for (int y = 0; y < n; ++y) memcpy(rec + (long)y * rstride, pred + y * n, (size_t)n);
+        return 0;
+    }
+    int shift = log2n - 1;
+    ks265o_dequant(lv, dq, n, p.dq, 1 << (shift - 1), shift, n - 1, n - 1);
+    ks265o_inv_transform(idx, dq, rec, pred, n, rstride, n, tmp, n - 1, n - 1);
+    return 1;
+}
+
+void kso_reconstruct(const kso_frame_cfg *cfg, kso_pic src, kso_pic ref, const uint8_t *planes, kso_cu8 *cu8,
+                     int16_t *lvl_y, int16_t *lvl_u, int16_t *lvl_v, kso_pic recon)
+{
+    kso_frame_geom g; kso_frame_geometry(cfg, &g);
+    int W = cfg->width, H = cfg->height, w8 = W / 8, h8 = H / 8, qp = cfg->qp, qpc = chroma_qp(qp);
+    long sy = g.stride_y, sc = g.stride_c;
+    for (int by = 0; by < h8; ++by)
+        for (int bx = 0; bx < w8; ++bx) {
+            kso_cu8 *c = &cu8[(long)by * w8 + bx];
+            int n8 = 1 << (c->log2_cu - 3);
+            int tu8 = imin(n8, 4);                              /* TU = min(CU, 32) */
+            if ((bx % tu8) || (by % tu8)) continue;             /* visit each TU once, at its top-left 8x8 block */
+            int n = tu8 * 8, x0 = bx * 8, y0 = by * 8, intra = c->pred_mode == 1;
+            int mvx = c->mvx, mvy = c->mvy, cbf = 0;
+            uint8_t pred[32 * 32];
+            /* luma */
+            if (intra) memset(pred, 128, sizeof pred);
+            else {
+                const uint8_t *pl = org_y(&g, (uint8_t *)planes + (long)((mvy & 3) * 4 + (mvx & 3)) * g.bytes_y) + (long)(y0 + (mvy >> 2)) * sy + x0 + (mvx >> 2);
+                for (int y = 0; y < n; ++y) memcpy(pred + y * n, pl + (long)y * sy, (size_t)n);
+            }
+            cbf |= code_tu(org_y(&g, src.y) + (long)y0 * sy + x0, (int)sy, pred, n, qp, intra, lvl_y + (long)y0 * W + x0, W,
+                           org_y(&g, recon.y) + (long)y0 * sy + x0, (int)sy);
+            /* chroma: 4-tap 1/8-sample MC (interpChroma* enc@0x4111c0..), TU n/2 */
+            int nc = n / 2, xc = x0 / 2, yc = y0 / 2;
+            for (int comp = 0; comp < 2; ++comp) {
+                const uint8_t *rp = org_c(&g, comp ? ref.v : ref.u);
+                if (intra) memset(pred, 128, sizeof pred);
+                else {
+                    const uint8_t *p0 = rp + (long)(yc + (mvy >> 3)) * sc + xc + (mvx >> 3);
+                    int fx = mvx & 7, fy = mvy & 7;
+                    if (!fx && !fy) for (int y = 0; y < nc; ++y) memcpy(pred + y * nc, p0 + (long)y * sc, (size_t)nc);
+                    else if (!fy) ks265o_interp_chroma_hor_8to8(pred, nc, p0, (int)sc, nc, nc, fx);
+                    else if (!fx) ks265o_interp_chroma_ver_8to8(pred, nc, p0, (int)sc, nc, nc, fy);
+                    else {
+                        int16_t t16[16 * 19];
+                        ks265o_interp_chroma_hor_8to16(t16, nc, p0 - sc, (int)sc, nc, nc + 3, fx);
+                        ks265o_interp_chroma_ver_16to8(pred, nc, t16 + nc, nc, nc, nc, fy);
+                    }
+                }
+                int16_t *lv = (comp ? lvl_v : lvl_u) + (long)yc * (W / 2) + xc;
+                uint8_t *rc = org_c(&g, comp ? recon.v : recon.u) + (long)yc * sc + xc;
+                const uint8_t *oc = org_c(&g, comp ? src.v : src.u) + (long)yc * sc + xc;
+                if (code_tu(oc, (int)sc, pred, nc, qpc, intra, lv, W / 2, rc, (int)sc)) cbf |= 2 << comp;
+            }
+            for (int yy = 0; yy < tu8; ++yy)
+                for (int xx = 0; xx < tu8; ++xx) cu8[(long)(by + yy) * w8 + bx + xx].cbf = (uint8_t)cbf;
+        }
+}
+
+/* ------------------------------------------------------------------ Stage E: deblocking
+ * bS as CalcBsInterP enc@0x402960 (single reference picture); all vertical edges of the picture, then all
+ * horizontal ones (ctuDeblockFilterVer enc@0x403de0 / CtuDeblockFilterHorT enc@0x477200 do the same per CTU). */
+static int edge_bs(const kso_cu8 *p, const kso_cu8 *q, int pos8 /*edge position in 8-sample units along its normal*/)
+{
+    int cu8n = 1 << (q->log2_cu - 3), tu8n = imin(cu8n, 4);
+    int tu_edge = (pos8 % tu8n) == 0, cu_edge = (pos8 % cu8n) == 0;
+    if (!tu_edge && !cu_edge) return 0;
+    if (p->pred_mode == 1 || q->pred_mode == 1) return 2;
+    if (tu_edge && ((p->cbf | q->cbf) & 1)) return 1;
+    if (cu_edge && (iabs_(p->mvx - q->mvx) >= 4 || iabs_(p->mvy - q->mvy) >= 4)) return 1;
+    return 0;
+}
+
+void kso_deblock(const kso_frame_cfg *cfg, const kso_cu8 *cu8, kso_pic recon)
+{
+    kso_frame_geom g; kso_frame_geometry(cfg, &g);
+    int W = cfg->width, H = cfg->height, w8 = W / 8, h8 = H / 8, qp = cfg->qp;
+    int beta = ks265o_beta_table[iclip(0, 51, qp + 2 * cfg->beta_offset_div2)];
+    uint8_t *Y = org_y(&g, recon.y);
+    for (int dir = 0; dir < 2; ++dir) {
+        /* luma, 8x8 grid */
+        for (int by = 0; by < h8; ++by)
+            for (int bx = 0; bx < w8; ++bx) {
+                if (dir == 0 ? bx == 0 : by == 0) continue;
+                const kso_cu8 *q = &cu8[(long)by * w8 + bx], *p = dir == 0 ? q - 1 : q - w8;
+                int bs = edge_bs(p, q, dir == 0 ? bx : by);
+                if (!bs) continue;
+                int tc = ks265o_tc_table[iclip(0, 53, qp + 2 * (bs - 1) + 2 * cfg->tc_offset_div2)];
+                uint8_t *pix = Y + (long)by * 8 * g.stride_y + bx * 8;
+                if (dir == 0) ks265o_edge_filter_luma_ver(pix, g.stride_y, beta, tc, 8, 1, 1);
+                else ks265o_edge_filter_luma_hor(pix, g.stride_y, beta, tc, 8, 1, 1);
+            }
+        /* chroma, 8x8 chroma grid = 16 luma samples, only bS == 2 */
+        int qpc = chroma_qp(qp);
+        for (int by = 0; by < h8; ++by)
+            for (int bx = 0; bx < w8; ++bx) {
+                if (dir == 0 ? (bx == 0 || (bx & 1)) : (by == 0 || (by & 1))) continue;
+                const kso_cu8 *q = &cu8[(long)by * w8 + bx], *p = dir == 0 ? q - 1 : q - w8;
+                if (edge_bs(p, q, dir == 0 ? bx : by) != 2) continue;
+                int tc = ks265o_tc_table[iclip(0, 53, qpc + 2 + 2 * cfg->tc_offset_div2)];
+                for (int comp = 0; comp < 2; ++comp) {
+                    uint8_t *pix = org_c(&g, comp ? recon.v : recon.u) + (long)by * 4 * g.stride_c + bx * 4;
+                    if (dir == 0) ks265o_pixel_filter_chroma_ver(pix, g.stride_c, tc, 4, 1, 1);
+                    else ks265o_pixel_filter_chroma_hor(pix, g.stride_c, tc, 4, 1, 1);
+                }
+            }
+    }
+}
+
+/* ------------------------------------------------------------------ Stage F: SAO
+ * statistics with the reference's s8 difference truncation (statSaoBoEo01_c enc@0x4ae9c0), all four
+ * EO classes + BO over the whole CTU; decision = distortion estimate + lambda * rate estimate (CEncSao::modeDecisionCtu
+ * enc@0x4af690 is closed RD code); apply out of place from the deblocked picture (SaoApplyOffset*_c enc@0x43e4e0..). */
+typedef struct { int cnt[5][32]; int sum[5][32]; } sao_stats;   /* [0] BO 32 bands, [1..4] EO class 0..3 x 4 categories */
+
+static const int kEoDx[4] = {1, 0, 1, -1}, kEoDy[4] = {0, 1, 1, 1};
+
+static void sao_collect(const uint8_t *org, const uint8_t *rec, long stride, int x0, int y0, int w, int h, int picW, int picH, sao_stats *s)
+{
+    memset(s, 0, sizeof *s);
+    for (int y = y0; y < y0 + h; ++y)
+        for (int x = x0; x < x0 + w; ++x) {
+            int c = rec[(long)y * stride + x];
+            int d = (int8_t)(uint8_t)(org[(long)y * stride + x] - c);
+            s->cnt[0][c >> 3]++; s->sum[0][c >> 3] += d;
+            for (int k = 0; k < 4; ++k) {
+                int ax = x - kEoDx[k], ay = y - kEoDy[k], bx = x + kEoDx[k], by = y + kEoDy[k];
+                if (ax < 0 || bx < 0 || ax >= picW || bx >= picW || ay < 0 || by >= picH) continue;
+                int e = 2 + isgn(c - rec[(long)ay * stride + ax]) + isgn(c - rec[(long)by * stride + bx]);
+                if (e == 2) continue;
+                int cat = e < 2 ? e : e - 1;
+                s->cnt[1 + k][cat]++; s->sum[1 + k][cat] += d;
+            }
+        }
+}
+
+static int sao_offset(int sum, int cnt, int lo, int hi)
+{
+    if (!cnt) return 0;
+    int o = sum >= 0 ? (sum + cnt / 2) / cnt : -((-sum + cnt / 2) / cnt);
+    return iclip(lo, hi, o);
+}
+
+/* best (cost, params) of one type for one component; cost = 256 * deltaD + lambda_q4^2 * bits */
+static int64_t sao_eval(const sao_stats *s, int type, int lam, kso_sao_param *out)
+{
+    int64_t lam2 = (int64_t)lam * lam;
+    memset(out, 0, sizeof *out);
+    out->type = (int8_t)type;
+    if (type == 0) {
+        int off[32]; int64_t dd[32];
+        for (int b = 0; b < 32; ++b) {
+            off[b] = sao_offset(s->sum[0][b], s->cnt[0][b], -7, 7);
+            dd[b] = (int64_t)s->cnt[0][b] * off[b] * off[b] - 2LL * off[b] * s->sum[0][b];
+        }
+        int best = 0; int64_t bd = 0;
+        for (int p = 0; p <= 28; ++p) {
+            int64_t d = dd[p] + dd[p + 1] + dd[p + 2] + dd[p + 3];
+            if (p == 0 || d < bd) { bd = d; best = p; }
+        }
+        int bits = 7;
+        for (int k = 0; k < 4; ++k) { out->offset[k] = (int8_t)off[best + k]; bits += iabs_(off[best + k]) + 2; }
+        out->band = (int8_t)best;
+        return bd * 256 + lam2 * bits;
+    }
+    int64_t d = 0; int bits = 4;
+    for (int c = 0; c < 4; ++c) {
+        int o = sao_offset(s->sum[type][c], s->cnt[type][c], c < 2 ? 0 : -7, c < 2 ? 7 : 0);
+        out->offset[c] = (int8_t)o;
+        d += (int64_t)s->cnt[type][c] * o * o - 2LL * o * s->sum[type][c];
+        bits += iabs_(o) + 1;
+    }
+    return d * 256 + lam2 * bits;
+}
+
+static void sao_apply_ctu(const uint8_t *rec, uint8_t *dst, long stride, int x0, int y0, int w, int h, int picW, int picH, const kso_sao_param *p)
+{
+    for (int y = y0; y < y0 + h; ++y)
+        for (int x = x0; x < x0 + w; ++x) {
+            int c = rec[(long)y * stride + x], o = 0;
+            if (p->type == 0) {
+                int k = (c >> 3) - p->band;
+                if (k >= 0 && k < 4) o = p->offset[k];
+            } else if (p->type > 0) {
+                int k = p->type - 1;
+                int ax = x - kEoDx[k], ay = y - kEoDy[k], bx = x + kEoDx[k], by = y + kEoDy[k];
+                if (!(ax < 0 || bx < 0 || ax >= picW || bx >= picW || ay < 0 || by >= picH)) {
+                    int e = 2 + isgn(c - rec[(long)ay * stride + ax]) + isgn(c - rec[(long)by * stride + bx]);
+                    if (e != 2) o = p->offset[e < 2 ? e : e - 1];
+                }
+            }
+            int v = c + o;
+            dst[(long)y * stride + x] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+        }
+}
+
+void kso_sao(const kso_frame_cfg *cfg, kso_pic src, kso_pic deb, kso_sao_param *sao, kso_pic dst)
+{
+    kso_frame_geom g; kso_frame_geometry(cfg, &g);
+    int W = cfg->width, H = cfg->height, lam = cfg->lambda_q4;
+    for (int cy = 0; cy < g.ctu_rows; ++cy)
+        for (int cx = 0; cx < g.ctu_cols; ++cx) {
+            kso_sao_param *sp = sao + (long)(cy * g.ctu_cols + cx) * 3;
+            int x0 = cx * 64, y0 = cy * 64, w = imin(64, W - x0), h = imin(64, H - y0);
+            sao_stats st[3];
+            sao_collect(org_y(&g, src.y), org_y(&g, deb.y), g.stride_y, x0, y0, w, h, W, H, &st[0]);
+            sao_collect(org_c(&g, src.u), org_c(&g, deb.u), g.stride_c, x0 / 2, y0 / 2, w / 2, h / 2, W / 2, H / 2, &st[1]);
+            sao_collect(org_c(&g, src.v), org_c(&g, deb.v), g.stride_c, x0 / 2, y0 / 2, w / 2, h / 2, W / 2, H / 2, &st[2]);
+            /* luma decides alone; Cb and Cr share the type (sao_type_idx_chroma / sao_eo_class_chroma) */
+            kso_sao_param best[3], cand[3];
+            int64_t bj = 0, bjc = 0;
+            for (int c = 0; c < 3; ++c) { memset(&best[c], 0, sizeof best[c]); best[c].type = -1; }
+            if (cfg->sao) {
+                for (int t = 0; t < 5; ++t) {
+                    int64_t j = sao_eval(&st[0], t, lam, &cand[0]);
+                    if (j < bj) { bj = j; best[0] = cand[0]; }
+                    int64_t jc = sao_eval(&st[1], t, lam, &cand[1]) + sao_eval(&st[2], t, lam, &cand[2]);
+                    if (jc < bjc) { bjc = jc; best[1] = cand[1]; best[2] = cand[2]; }
+                }
+            }
+            for (int c = 0; c < 3; ++c) sp[c] = best[c];
+            sao_apply_ctu(org_y(&g, deb.y), org_y(&g, dst.y), g.stride_y, x0, y0, w, h, W, H, &sp[0]);
+            sao_apply_ctu(org_c(&g, deb.u), org_c(&g, dst.u), g.stride_c, x0 / 2, y0 / 2, w / 2, h / 2, W / 2, H / 2, &sp[1]);
+            sao_apply_ctu(org_c(&g, deb.v), org_c(&g, dst.v), g.stride_c, x0 / 2, y0 / 2, w / 2, h / 2, W / 2, H / 2, &sp[2]);
+        }
+    kso_pad_picture(cfg, dst);
+}

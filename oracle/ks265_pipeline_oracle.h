@@ -1,0 +1,53 @@
+/* ks265_pipeline_oracle.h — TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * CPU restatement of the whole-frame stages of include/ks265_hip.h §3, composed ONLY from the pinned
+ * kernel restatements of ks265_oracle.h (each pinned against the reference binary).  The sequencing
+ * follows the reference's per-CTU pipeline (motionSearchOneRef enc@0x483f40 ->
+ * interMeDia enc@0x48fbe0 -> subMeSquare enc@0x4b5660 -> reconstruct enc@0x481da0 ->
+ * CLoopFilterCtu::Execute enc@0x49dd30) restructured frame-wide (SURVEY.md §7.3 "granularity
+ * inversion"): the CU decisions are the build's own because the reference's RDO is closed code
+ * (SURVEY.md §7.1), so stage-level parity is GPU == this file, bit for bit, on the same inputs.
+ *
+ * Struct layouts are identical to include/ks265_hip.h so the same numpy dtypes serve both.
+ */
+#ifndef KS265_PIPELINE_ORACLE_H
+#define KS265_PIPELINE_ORACLE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {
+    int32_t width, height, qp, lambda_q4, me_range, me_method, subme, deblock, sao, beta_offset_div2, tc_offset_div2;
+} kso_frame_cfg;
+
+typedef struct {
+    int32_t pad_y, pad_c, stride_y, stride_c, rows_y, rows_c;
+    int64_t bytes_y, bytes_c;
+    int32_t ctu_cols, ctu_rows, pu_per_ctu;
+    int64_t bytes_pu, bytes_cu8, bytes_sao;
+} kso_frame_geom;
+
+typedef struct { int16_t mvx, mvy, mvpx, mvpy; uint32_t cost, dist; } kso_pu;
+typedef struct { int16_t mvx, mvy; uint8_t log2_cu, cbf, pred_mode, rsv; } kso_cu8;
+typedef struct { int8_t type, band, offset[4], rsv[2]; } kso_sao_param;
+typedef struct { uint8_t *y, *u, *v; } kso_pic;
+
+int kso_frame_geometry(const kso_frame_cfg *cfg, kso_frame_geom *g);
+void kso_pad_picture(const kso_frame_cfg *cfg, kso_pic pic);
+void kso_load_i420(const kso_frame_cfg *cfg, const uint8_t *i420, kso_pic dst);
+void kso_store_i420(const kso_frame_cfg *cfg, kso_pic src, uint8_t *i420);
+void kso_ref_planes(const kso_frame_cfg *cfg, kso_pic ref, uint8_t *planes);
+void kso_me_integer(const kso_frame_cfg *cfg, kso_pic src, kso_pic ref, const kso_pu *prev_pu, kso_pu *pu);
+void kso_me_subpel(const kso_frame_cfg *cfg, kso_pic src, const uint8_t *planes, kso_pu *pu);
+void kso_cu_decide(const kso_frame_cfg *cfg, const kso_pu *pu, kso_cu8 *cu8);
+void kso_cu_flat_intra(const kso_frame_cfg *cfg, kso_cu8 *cu8);
+void kso_reconstruct(const kso_frame_cfg *cfg, kso_pic src, kso_pic ref, const uint8_t *planes, kso_cu8 *cu8,
+                     int16_t *lvl_y, int16_t *lvl_u, int16_t *lvl_v, kso_pic recon);
+void kso_deblock(const kso_frame_cfg *cfg, const kso_cu8 *cu8, kso_pic recon);
+void kso_sao(const kso_frame_cfg *cfg, kso_pic src, kso_pic deblocked, kso_sao_param *sao, kso_pic dst);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

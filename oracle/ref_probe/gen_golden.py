@@ -365,7 +365,7 @@ def gen_sao(p: RefProbe):
     pend = []
     for i in range(12):
         h, w = int(rng.integers(1, 65)), int(rng.integers(1, 65))
-        stride = w + int(rng.integers(0, 9))
+        stride = ((w + 3) & ~3) + int(rng.integers(0, 9))  # the reference touches round_up(w, 4) columns per row
         rec = u8((h, stride))
         offs = rng.integers(-7, 8, 4).astype(np.int8)
         band = int(rng.integers(0, 29 if i < 10 else 32))

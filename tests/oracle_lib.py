@@ -40,3 +40,96 @@ def ptr(a: np.ndarray, byte_off: int = 0) -> C.c_void_p:
 
 L = C.c_long
 I = C.c_int
+
+
+# ------------------------------------------------------------------ pipeline oracle (ks265_pipeline_oracle.h)
+class OFrameCfg(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("width", "height", "qp", "lambda_q4", "me_range", "me_method", "subme", "deblock", "sao",
+                                          "beta_offset_div2", "tc_offset_div2")]
+
+
+class OFrameGeom(C.Structure):
+    _fields_ = [("pad_y", C.c_int32), ("pad_c", C.c_int32), ("stride_y", C.c_int32), ("stride_c", C.c_int32),
+                ("rows_y", C.c_int32), ("rows_c", C.c_int32), ("bytes_y", C.c_int64), ("bytes_c", C.c_int64),
+                ("ctu_cols", C.c_int32), ("ctu_rows", C.c_int32), ("pu_per_ctu", C.c_int32), ("bytes_pu", C.c_int64),
+                ("bytes_cu8", C.c_int64), ("bytes_sao", C.c_int64)]
+
+
+class OPic(C.Structure):
+    _fields_ = [("y", C.c_void_p), ("u", C.c_void_p), ("v", C.c_void_p)]
+
+
+PU = np.dtype([("mvx", "<i2"), ("mvy", "<i2"), ("mvpx", "<i2"), ("mvpy", "<i2"), ("cost", "<u4"), ("dist", "<u4")])
+CU8 = np.dtype([("mvx", "<i2"), ("mvy", "<i2"), ("log2_cu", "u1"), ("cbf", "u1"), ("pred_mode", "u1"), ("rsv", "u1")])
+SAO_PARAM = np.dtype([("type", "i1"), ("band", "i1"), ("offset", "i1", 4), ("rsv", "i1", 2)])
+
+
+class HostPic:
+    """padded picture in host memory"""
+
+    def __init__(self, geom: OFrameGeom):
+        self.y = np.zeros(geom.bytes_y, np.uint8)
+        self.u = np.zeros(geom.bytes_c, np.uint8)
+        self.v = np.zeros(geom.bytes_c, np.uint8)
+
+    def c(self) -> OPic:
+        return OPic(self.y.ctypes.data, self.u.ctypes.data, self.v.ctypes.data)
+
+
+class OraclePipeline:
+    """CPU restatement of the frame stages (test checker / cpu_baseline 'port')."""
+
+    def __init__(self, width, height, qp, lambda_q4, me_range=64, subme=1, deblock=1, sao=1):
+        self.o = lib()
+        self.cfg = OFrameCfg(width, height, qp, lambda_q4, me_range, 0, subme, deblock, sao, 0, 0)
+        self.geom = OFrameGeom()
+        assert self.o.kso_frame_geometry(C.byref(self.cfg), C.byref(self.geom)) == 0
+        g = self.geom
+        self.nctu = g.ctu_cols * g.ctu_rows
+        self.planes = np.zeros(16 * g.bytes_y, np.uint8)
+        self.pu = np.zeros(self.nctu * 85, PU)
+        self.prev_pu = np.zeros(self.nctu * 85, PU)
+        self.have_prev = False
+        self.cu8 = np.zeros((height // 8) * (width // 8), CU8)
+        self.sao = np.zeros(self.nctu * 3, SAO_PARAM)
+        self.lvl = [np.zeros(width * height, np.int16), np.zeros(width * height // 4, np.int16), np.zeros(width * height // 4, np.int16)]
+        self.src, self.rec, self.deb = HostPic(g), HostPic(g), HostPic(g)
+        self.ref = HostPic(g)
+
+    def set_qp(self, qp, lambda_q4):
+        self.cfg.qp, self.cfg.lambda_q4 = qp, lambda_q4
+
+    def load(self, pic: HostPic, i420: np.ndarray):
+        self.o.kso_load_i420(C.byref(self.cfg), ptr(np.ascontiguousarray(i420)), pic.c())
+
+    def store(self, pic: HostPic) -> np.ndarray:
+        out = np.zeros(self.cfg.width * self.cfg.height * 3 // 2, np.uint8)
+        self.o.kso_store_i420(C.byref(self.cfg), pic.c(), ptr(out))
+        return out
+
+    def encode_picture(self, i420: np.ndarray, is_key: bool) -> np.ndarray:
+        """runs all stages; self.ref is replaced by the new reconstructed picture; returns recon I420"""
+        o, cfg = self.o, C.byref(self.cfg)
+        self.load(self.src, i420)
+        if is_key:
+            o.kso_cu_flat_intra(cfg, ptr(self.cu8))
+            self.have_prev = False
+        else:
+            o.kso_ref_planes(cfg, self.ref.c(), ptr(self.planes))
+            o.kso_me_integer(cfg, self.src.c(), self.ref.c(), ptr(self.prev_pu) if self.have_prev else None, ptr(self.pu))
+            self.pu_int = self.pu.copy()
+            if self.cfg.subme:
+                o.kso_me_subpel(cfg, self.src.c(), ptr(self.planes), ptr(self.pu))
+            o.kso_cu_decide(cfg, ptr(self.pu), ptr(self.cu8))
+        o.kso_reconstruct(cfg, self.src.c(), self.ref.c(), ptr(self.planes), ptr(self.cu8), ptr(self.lvl[0]), ptr(self.lvl[1]), ptr(self.lvl[2]),
+                          self.rec.c())
+        self.rec_pre = [self.rec.y.copy(), self.rec.u.copy(), self.rec.v.copy()]
+        if self.cfg.deblock:
+            o.kso_deblock(cfg, ptr(self.cu8), self.rec.c())
+        new_ref = HostPic(self.geom)
+        o.kso_sao(cfg, self.src.c(), self.rec.c(), ptr(self.sao), new_ref.c())
+        self.ref = new_ref
+        if not is_key:
+            self.prev_pu, self.pu = self.pu, self.prev_pu
+            self.have_prev = True
+        return self.store(self.ref)

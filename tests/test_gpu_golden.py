@@ -1,0 +1,199 @@
+"""GPU parity, batched operator tables: the HIP kernels (through the C ABI) must reproduce, bit for bit,
+the outputs of the reference binary's own `_c` kernels recorded in tests/golden/ — and agree with the
+CPU oracle on the same inputs.  Run on the MI355X box: pytest -m gpu."""
+from __future__ import annotations
+
+import numpy as np
+import pytest
+
+from golden_io import load_cases
+
+pytestmark = pytest.mark.gpu
+
+SIZES = [4, 4, 8, 16, 32]
+
+
+@pytest.fixture(scope="module")
+def ks():
+    from ks265codec_amd.lib import KsContext
+    c = KsContext(0)
+    yield c
+    c.close()
+
+
+def _planes(ks, cases, ka, kb):
+    """Concatenate the per-case planes into two big device byte buffers; return per-case base offsets."""
+    offs_a, offs_b, pa, pb = [], [], [], []
+    na = nb = 0
+    for c in cases:
+        offs_a.append(na); offs_b.append(nb)
+        pa.append(c[ka].reshape(-1)); pb.append(c[kb].reshape(-1))
+        na += c[ka].size; nb += c[kb].size
+    return ks.dev(np.concatenate(pa)), ks.dev(np.concatenate(pb)), offs_a, offs_b
+
+
+def _run_dist(ks, fn, cases, groups):
+    """strides are per-call scalars in the ABI (as in the reference tables) -> one batch per (sa, sb)"""
+    from ks265codec_amd.lib import BLK
+    A, B, oa, ob = _planes(ks, cases, "a", "b")
+    got = {}
+    by_stride = {}
+    for i, c in enumerate(cases):
+        by_stride.setdefault((int(c["sa"]), int(c["sb"])), []).append(i)
+    for (sa, sb), idxs in by_stride.items():
+        blks = np.zeros(len(idxs), BLK)
+        for j, i in enumerate(idxs):
+            w, h = groups(cases[i])
+            blks[j] = (oa[i], ob[i], w, h)
+        r = fn(A, sa, B, sb, blks)
+        for j, i in enumerate(idxs):
+            got[i] = r[j]
+    return got
+
+
+def test_sad(ks):
+    cases = load_cases("sad")
+    got = _run_dist(ks, ks.sad, cases, lambda c: (c["w"], c["h"]))
+    for i, c in enumerate(cases):
+        assert got[i] == c["exp"], (c["h"], c["w"])
+
+
+def test_sse(ks):
+    cases = load_cases("sse")
+    got = _run_dist(ks, ks.sse, cases, lambda c: (c["n"], c["n"]))
+    for i, c in enumerate(cases):
+        assert got[i] == c["exp"]
+
+
+def test_had(ks):
+    cases = load_cases("had")
+    got = _run_dist(ks, ks.had, cases, lambda c: (c["w"], c["h"]))
+    for i, c in enumerate(cases):
+        assert got[i] == c["exp"], (c["h"], c["w"])
+
+
+def test_sad4blk(ks):
+    cases = load_cases("sad4blk")
+    got = _run_dist(ks, ks.sad4blk_8x8, cases, lambda c: (16, 16))
+    for i, c in enumerate(cases):
+        assert (got[i] == c["exp"]).all()
+
+
+def test_sad4(ks):
+    from ks265codec_amd.lib import BLK
+    for c in load_cases("sad4"):
+        F, R = ks.dev(c["fenc"]), ks.dev(c["ref"])
+        blks = np.zeros(1, BLK); blks[0] = (0, c["ref_off"], c["w"], c["h"])
+        got = ks.sad4(F, int(c["sf"]), R, int(c["sr"]), blks)
+        assert (got[0] == c["exp"]).all(), (c["w"], c["h"])
+
+
+def test_sad3(ks):
+    from ks265codec_amd.lib import BLK3
+    for c in load_cases("sad3"):
+        F, R = ks.dev(c["fenc"]), ks.dev(c["ref"])
+        blks = np.zeros(1, BLK3)
+        blks[0]["a_off"] = 0; blks[0]["b_off"] = c["offs"]; blks[0]["w"] = c["w"]; blks[0]["h"] = c["h"]
+        got = ks.sad3(F, int(c["sf"]), R, int(c["sr"]), blks)
+        assert (got[0] == c["exp"]).all()
+
+
+def test_residual(ks):
+    from ks265codec_amd.lib import BLK
+    for c in load_cases("residual"):
+        n = c["n"]
+        blks = np.zeros(1, BLK); blks[0] = (0, 0, n, n)
+        got = ks.residual(ks.dev(c["org"]), int(c["so"]), ks.dev(c["pred"]), int(c["sp"]), blks)
+        assert (got.reshape(n, n) == c["exp"]).all()
+
+
+def test_fwd_transform(ks):
+    cases = load_cases("fwd_transform")
+    for idx in range(5):
+        n = SIZES[idx]
+        sel = [c for c in cases if c["idx"] == idx]
+        src = np.stack([c["src"][:, :n] for c in sel])
+        got = ks.fwd_transform(idx, src)
+        for g, c in zip(got, sel):
+            assert (g == c["exp"][:, :n]).all(), idx
+
+
+def test_inv_transform(ks):
+    cases = load_cases("inv_transform")
+    for idx in range(5):
+        n = SIZES[idx]
+        sel = [c for c in cases if c["idx"] == idx]
+        coef = np.stack([c["coef"][:, :n] for c in sel])
+        pred = np.stack([c["pred"][:, :n] for c in sel])
+        got = ks.inv_transform(idx, coef, pred)
+        for g, c in zip(got, sel):
+            assert (g == c["exp"]).all(), (idx, c["variant"])
+
+
+def test_quant(ks):
+    for c in load_cases("quant"):
+        if c.get("kind") == "base_param":
+            continue
+        n = c["n"]
+        lvl, du, nz = ks.quant(n, c["coef"][None], int(c["scale"]), int(c["off"]), int(c["qbits"]))
+        assert (lvl[0] == c["exp_lvl"]).all() and (du[0] == c["exp_du"]).all() and nz[0] == c["exp_nz"], (n, c["qp"])
+
+
+def test_dequant(ks):
+    for c in load_cases("dequant"):
+        n = c["n"]
+        if c["lx"] != n - 1 or c["ly"] != n - 1:
+            continue  # the batched ABI is the full-block form; sub-rectangle semantics are pinned on the oracle
+        got = ks.dequant(n, c["lvl"][None], int(c["scale"]), int(c["add"]), int(c["shift"]))
+        assert (got[0] == c["exp"]).all()
+
+
+@pytest.mark.parametrize("fam,chroma", [("deblock_luma", False), ("deblock_chroma", True)])
+def test_deblock_edges(ks, fam, chroma):
+    from ks265codec_amd.lib import EDGE
+    cases = load_cases(fam)
+    for c in cases:
+        img = ks.dev(c["img"])
+        e = np.zeros(1, EDGE)
+        e[0]["pix_off"] = c["off"]; e[0]["beta"] = c.get("beta", 0); e[0]["tc"] = c["tc"]; e[0]["length"] = c["length"]
+        e[0]["dir"] = 0 if c["orient"] == "ver" else 1
+        e[0]["flags"] = int(c["fp"]) | (int(c["fq"]) << 1)
+        ks.edge_filter(img, int(c["stride"]), e, chroma=chroma)
+        got = ks.host(img, np.uint8, c["img"].shape)
+        assert (got == c["exp"]).all()
+
+
+def test_interp(ks):
+    io_code = {"8to8": 0, "8to16": 1, "16to8": 2, "16to16": 3}
+    for c in load_cases("interp"):
+        name = str(c["name"])
+        comp, direc, io = name.split("_")
+        kind = (1 if comp == "chroma" else 0) | (2 if direc == "ver" else 0) | (io_code[io] << 2)
+        ddt = np.uint8 if io.endswith("to8") else np.int16
+        src = ks.dev(c["src"])
+        dst = ks.zeros(c["h"] * c["ds"] * np.dtype(ddt).itemsize)
+        ks.interp_rect(kind, dst, int(c["ds"]), src, int(c["off"]) * c["src"].itemsize, int(c["ss"]), int(c["w"]), int(c["h"]), int(c["frac"]))
+        got = ks.host(dst, ddt, (c["h"], c["ds"]))[:, :c["w"]]
+        assert (got == c["exp"]).all(), (name, c["frac"])
+
+
+def test_sao_apply(ks):
+    for c in load_cases("sao_apply"):
+        kind = str(c["kind"])
+        rec = ks.dev(c["rec"])
+        if kind == "bo":
+            ks.sao_apply_bo(c["offs"], rec, int(c["stride"]), int(c["h"]), int(c["w"]), int(c["band"]))
+            got = ks.host(rec, np.uint8, c["rec"].shape)
+        else:
+            dst = ks.dev(c["rec"])
+            ks.sao_apply_eo(int(kind[2]), c["offs"], rec, dst, int(c["stride"]) + 1, int(c["stride"]), int(c["h"]), int(c["w"]))
+            got = ks.host(dst, np.uint8, c["rec"].shape)
+        assert (got == c["exp"]).all(), kind
+
+
+def test_sao_stats(ks):
+    from ks265codec_amd.lib import SAO_RECT
+    for c in load_cases("sao_stats"):
+        r = np.zeros(1, SAO_RECT); r[0] = (0, c["rs"] + 1, c["w"], c["h"])
+        got = ks.sao_stats(ks.dev(c["org"]), int(c["os"]), ks.dev(c["rec"]), int(c["rs"]), r, int(c["step"]))
+        assert (got[0, :64] == c["exp_eo"]).all() and (got[0, 64:] == c["exp_bo"]).all()
