@@ -16,6 +16,7 @@ def make_clip(width: int, height: int, frames: int, seed: int = 42, noisy: bool 
     squares = []
     for _ in range(nsq):
         s = int(rng.integers(max(16, height // 12), max(32, height // 4)))
+        s = max(1, min(s, width // 2, height // 2))                 # tiny test pictures: keep the squares inside
         squares.append(dict(size=s, x=float(rng.integers(0, max(1, width - s))), y=float(rng.integers(0, max(1, height - s))),
                             vx=float(rng.integers(-9, 10)), vy=float(rng.integers(-6, 7)),
                             tex=np.clip(rng.integers(40, 216) + rng.integers(-25, 26, (s, s)), 0, 255)))

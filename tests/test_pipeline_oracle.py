@@ -1,0 +1,131 @@
+"""CPU: properties of the frame-stage oracle (oracle/ks265_pipeline_oracle.c) that do not need a GPU:
+geometry identical to the product's, planes == block-wise normative interpolation, motion found on a known pan,
+decoder-side consistency of the reconstruct stage (recon == pred + inverse(dequant(levels))), idempotent padding."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from oracle_lib import I, OraclePipeline, lib, ptr
+from ks265codec_amd.synth import lambda_q4, make_clip, psnr
+
+
+def _run(W, H, n, seed=3, **kw):
+    clip = make_clip(W, H, n, seed=seed, abc=(17, 23, 9))
+    o = OraclePipeline(W, H, 27, lambda_q4(27), **kw)
+    recs = []
+    for t in range(n):
+        qp = 27 if t == 0 else 28
+        o.set_qp(qp, lambda_q4(qp))
+        recs.append(o.encode_picture(clip[t], t == 0))
+    return clip, o, recs
+
+
+def test_geometry_matches_product_library():
+    from ks265codec_amd import build as kb
+    kb.build()
+    from ks265codec_amd.lib import FrameCfg, FrameGeom, load_library
+    l = load_library()
+    for (w, h) in [(416, 240), (1280, 720), (1920, 1080), (3840, 2160), (200, 136)]:
+        o = OraclePipeline(w, h, 27, 80)
+        g = FrameGeom()
+        assert l.ks265_frame_geometry(C.byref(FrameCfg(w, h, 27, 80, 64, 0, 1, 1, 1, 0, 0)), C.byref(g)) == 0
+        for name, _ in FrameGeom._fields_:
+            assert getattr(g, name) == getattr(o.geom, name), name
+
+
+def test_pan_is_found_and_quality_is_sane():
+    clip, o, recs = _run(256, 192, 3)
+    W, H = 256, 192
+    cu = o.cu8.reshape(H // 8, W // 8)
+    assert np.median(cu["mvx"]) == 20 and np.median(cu["mvy"]) == 12      # global pan (5, 3) pixels in quarter-pel units
+    for t in range(3):
+        assert psnr(clip[t][:W * H], recs[t][:W * H]) > 32.0
+    assert set(np.unique(cu["log2_cu"])) <= {3, 4, 5, 6}
+
+
+def test_planes_equal_blockwise_interpolation():
+    """plane[fy*4+fx] must equal the pinned block interpolators applied at an arbitrary block"""
+    clip, o, _ = _run(128, 72, 2)
+    g, ol = o.geom, lib()
+    P = o.planes.reshape(16, g.rows_y, g.stride_y)
+    # o.planes were built from the reference of picture 1 = reconstruction of picture 0: rebuild that picture
+    o2 = OraclePipeline(128, 72, 27, lambda_q4(27))
+    o2.encode_picture(clip[0], True)
+    R = o2.ref.y.reshape(g.rows_y, g.stride_y)
+    x0, y0, w, h = 37, 11, 24, 16
+    for fy in range(4):
+        for fx in range(4):
+            if not fx and not fy:
+                continue
+            dst = np.zeros((h, w), np.uint8)
+            base = (g.pad_y + y0) * g.stride_y + g.pad_y + x0
+            if not fy:
+                ol.ks265o_interp_luma_hor_8to8(ptr(dst), I(w), ptr(R, base), I(g.stride_y), I(w), I(h), I(fx))
+            elif not fx:
+                ol.ks265o_interp_luma_ver_8to8(ptr(dst), I(w), ptr(R, base), I(g.stride_y), I(w), I(h), I(fy))
+            else:
+                tmp = np.zeros((h + 7, w), np.int16)
+                ol.ks265o_interp_luma_hor_8to16(ptr(tmp), I(w), ptr(R, base - 3 * g.stride_y), I(g.stride_y), I(w), I(h + 7), I(fx))
+                ol.ks265o_interp_luma_ver_16to8(ptr(dst), I(w), ptr(tmp, 3 * w * 2), I(w), I(w), I(h), I(fy))
+            got = P[fy * 4 + fx][g.pad_y + y0:g.pad_y + y0 + h, g.pad_y + x0:g.pad_y + x0 + w]
+            assert (got == dst).all(), (fx, fy)
+
+
+def test_padding_is_idempotent_and_replicates_edges():
+    _, o, _ = _run(64, 40, 1)
+    g = o.geom
+    before = o.ref.y.copy()
+    o.o.kso_pad_picture(C.byref(o.cfg), o.ref.c())
+    assert (before == o.ref.y).all()
+    Y = o.ref.y.reshape(g.rows_y, g.stride_y)
+    assert (Y[:g.pad_y, g.pad_y:g.pad_y + 64] == Y[g.pad_y, g.pad_y:g.pad_y + 64]).all()
+    assert (Y[g.pad_y:g.pad_y + 40, :g.pad_y] == Y[g.pad_y:g.pad_y + 40, g.pad_y:g.pad_y + 1]).all()
+
+
+def test_levels_reproduce_the_reconstruction():
+    """decoder-side property: pred + IDCT(dequant(levels)) == the pre-deblock reconstruction, for every luma TU"""
+    clip, o, _ = _run(128, 72, 2)
+    W, H, g, ol = 128, 72, o.geom, lib()
+    cu = o.cu8.reshape(H // 8, W // 8)
+    P = o.planes.reshape(16, g.rows_y, g.stride_y)
+    rec = o.rec_pre[0].reshape(g.rows_y, g.stride_y)
+    lv = o.lvl[0].reshape(H, W)
+    qp = o.cfg.qp
+    inv = [40, 45, 51, 57, 64, 72]
+    checked = 0
+    for by in range(H // 8):
+        for bx in range(W // 8):
+            c = cu[by, bx]
+            t8 = min(1 << (int(c["log2_cu"]) - 3), 4)
+            if bx % t8 or by % t8:
+                continue
+            n, x0, y0 = t8 * 8, bx * 8, by * 8
+            log2n = {8: 3, 16: 4, 32: 5}[n]
+            mvx, mvy = int(c["mvx"]), int(c["mvy"])
+            pl = P[(mvy & 3) * 4 + (mvx & 3)]
+            pred = np.ascontiguousarray(pl[g.pad_y + y0 + (mvy >> 2):g.pad_y + y0 + (mvy >> 2) + n, g.pad_y + x0 + (mvx >> 2):g.pad_y + x0 + (mvx >> 2) + n])
+            lvl = np.ascontiguousarray(lv[y0:y0 + n, x0:x0 + n])
+            out = np.zeros((n, n), np.uint8)
+            if (lvl != 0).any():
+                dq = np.zeros((n, n), np.int16)
+                shift = log2n - 1
+                ol.ks265o_dequant(ptr(lvl), ptr(dq), I(n), I(inv[qp % 6] << (qp // 6)), I(1 << (shift - 1)), I(shift), I(n - 1), I(n - 1))
+                tmp = np.zeros((n, n), np.int16)
+                ol.ks265o_inv_transform(I(log2n - 1), ptr(dq), ptr(out), ptr(pred), I(n), I(n), I(n), ptr(tmp), I(n - 1), I(n - 1))
+            else:
+                out = pred
+            assert (out == rec[g.pad_y + y0:g.pad_y + y0 + n, g.pad_y + x0:g.pad_y + x0 + n]).all(), (bx, by)
+            checked += 1
+    assert checked > 10
+
+
+def test_ragged_picture_sizes_code_every_block():
+    """widths/heights that are multiples of 8 but not of 64: every 8x8 block gets a CU, invalid PUs are marked"""
+    for (w, h) in [(72, 40), (200, 136), (8, 8)]:
+        _, o, recs = _run(w, h, 2)
+        cu = o.cu8.reshape(h // 8, w // 8)
+        assert (cu["log2_cu"] >= 3).all() and (cu["log2_cu"] <= 6).all()
+        pu = o.prev_pu.reshape(-1, 85)
+        assert (pu["cost"][:, 0] == 0xFFFFFFFF).any() or (w % 64 == 0 and h % 64 == 0)
