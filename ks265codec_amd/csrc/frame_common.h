@@ -50,4 +50,14 @@ __device__ __forceinline__ bool ks_pu_inside(const KsGeom &g, int cx, int cy, in
     return x0 + s <= g.W && y0 + s <= g.H;
 }
 
+// XCD-aware block -> work-item map (cdna_hip_programming.md T1): block b runs on XCD b % 8; give every XCD a contiguous
+// raster range of CTUs so that horizontally / vertically adjacent CTUs (which share reference rows and 128-byte lines)
+// meet in the same 4 MiB L2.  Bijective for any n; speed only, never correctness.
+__device__ __forceinline__ int ks_xcd_swizzle(int b, int n)
+{
+    const int per = n >> 3, rem = n & 7;                 // XCD x owns per + (x < rem) items
+    const int x = b & 7, j = b >> 3;
+    return x * per + min(x, rem) + j;
+}
+
 #define KS_FRAME_CHECK(f) do { if (!(f) || !(f)->ctx) return KS265_POINTER; } while (0)

@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void me_int_kernel(KsGeom g, int range, int la
     __shared__ __attribute__((aligned(16))) uint8_t win[WIN_ROWS * WIN_STRIDE];
     __shared__ __attribute__((aligned(16))) uint8_t fenc[64 * FENC_STRIDE];
     __shared__ int pmv[85];
-    const int tid = threadIdx.x, ctu = blockIdx.x, cx = ctu % g.ctu_cols, cy = ctu / g.ctu_cols;
+    const int tid = threadIdx.x, ctu = ks_xcd_swizzle(blockIdx.x, g.ctu_cols * g.ctu_rows), cx = ctu % g.ctu_cols, cy = ctu / g.ctu_cols;
     const uint8_t *R = ks_org_y(g, ref), *Sp = ks_org_y(g, src);
     // reference window: 16-byte global loads (x0 - 80 is 16-byte aligned), dword LDS stores
     for (int i = tid; i < WIN_ROWS * (WIN_W / 16); i += 256) {
@@ -188,105 +188,129 @@ extern "C" int ks265_me_integer(ks265_frame *f, ks265_pic src, ks265_pic ref, co
 }
 
 // ------------------------------------------------------------------ Stage B: sub-pel SATD refinement
-// One workgroup per CTU.  For each PU level the 64 8x8 tiles of the CTU are evaluated 32 at a time (8 lanes per tile,
-// lane = tile row): per candidate each tile adds its (sum|H8 d H8^T| + 2) >> 2 to its PU's LDS accumulator
-// (xCalcHADs8x8 enc@0x47b3b0 normalisation); a PU-owner thread then walks the candidates in the reference's order.
-__device__ __forceinline__ unsigned tile_satd8(const unsigned f0, const unsigned f1, const uint8_t *pred_row, int lane)
+// One workgroup per CTU, ONE WAVE PER PU LEVEL (wave w = level w), one lane per 8x8 tile of the CTU in Z-order, so the
+// lanes of one PU are an aligned group of 1 / 4 / 16 / 64 lanes and PU costs are DPP group sums - no LDS, no barriers,
+// no atomics.  Each lane holds the 64 differences of its tile in registers (see satd8x8).  Tile SATD = (sum|H8 d H8^T| + 2) >> 2 (xCalcHADs8x8 enc@0x47b3b0), PU cost = sum
+// over its tiles (had_c enc@0x47b680); candidate order and tie-breaking are the reference's (subMeSquare enc@0x4b5660).
+// SATD of one 8x8 source tile (16 dwords f: row r = f[2r], f[2r+1]) against a prediction tile at arbitrary byte alignment.
+// All 64 differences live in registers; the six butterfly stages are plain v_add_u32 / v_sub_u32 (full rate; measured on
+// MI355X: packed 16-bit VOP3P adds run at half rate, so packing two candidates per register buys nothing).
+// |.| + accumulate is ONE v_sad_u32 per coefficient: a bias of 2^15 added to difference (0,0) reaches every Hadamard output
+// with weight +1, so all outputs are positive and v_sad_u32(c + 2^15, 2^15, acc) = acc + |c|.
+template <int DBG>
+__device__ __forceinline__ unsigned satd8x8(const unsigned (&f)[16], const uint8_t *pp, long stride)
 {
-    // 8 pixels of the prediction row at arbitrary byte alignment (global memory)
-    const uint8_t *pa = (const uint8_t *)((uintptr_t)pred_row & ~(uintptr_t)3);
-    unsigned sh = (unsigned)((uintptr_t)pred_row & 3);
-    unsigned a0 = *(const unsigned *)pa, a1 = *(const unsigned *)(pa + 4), a2 = *(const unsigned *)(pa + 8);
-    unsigned p0 = align_bytes(a1, a0, sh), p1 = align_bytes(a2, a1, sh);
-    int d[8];
+    const unsigned sh = (unsigned)((uintptr_t)pp & 3);
+    const uint8_t *q = pp - sh;
+    int d[64];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        d[i] = (int)((f0 >> (8 * i)) & 255) - (int)((p0 >> (8 * i)) & 255);
-        d[4 + i] = (int)((f1 >> (8 * i)) & 255) - (int)((p1 >> (8 * i)) & 255);
+    for (int r = 0; r < 8; ++r) {
+        const unsigned *row = (const unsigned *)(q + r * stride);
+        unsigned a0, a1, a2;
+        if (DBG == 1) { a0 = f[r] * 3u; a1 = f[r + 1] * 5u; a2 = f[r + 2] * 7u; } else { a0 = row[0]; a1 = row[1]; a2 = row[2]; }
+        if (DBG == 2) { d[r] = (int)(a0 ^ a1 ^ a2); continue; }
+        const unsigned A[2] = {align_bytes(a1, a0, sh), align_bytes(a2, a1, sh)};
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) d[r * 8 + h * 4 + i] = (int)((f[2 * r + h] >> (8 * i)) & 255) - (int)((A[h] >> (8 * i)) & 255);
     }
-    // horizontal 8-point Hadamard in registers
+    if (DBG == 2) { unsigned t = 0; for (int r = 0; r < 8; ++r) t ^= (unsigned)d[r]; return t & 1023u; }
+    d[0] += 0x8000;
 #pragma unroll
-    for (int len = 1; len < 8; len <<= 1)
+    for (int len = 1; len < 64; len <<= 1)
 #pragma unroll
-        for (int i = 0; i < 8; i += 2 * len)
+        for (int i = 0; i < 64; i += 2 * len)
 #pragma unroll
-            for (int j = i; j < i + len; ++j) { int u = d[j], v = d[j + len]; d[j] = u + v; d[j + len] = u - v; }
-    // vertical 8-point Hadamard across the 8 lanes of the tile
+            for (int j = i; j < i + len; ++j) { const int u = d[j], v = d[j + len]; d[j] = u + v; d[j + len] = u - v; }
     unsigned acc = 0;
+    const unsigned bias = 0x8000u;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        int v = d[i], p;
-        p = lane_xor<1>(v); v = (lane & 1) ? p - v : v + p;
-        p = lane_xor<2>(v); v = (lane & 2) ? p - v : v + p;
-        p = lane_xor<4>(v); v = (lane & 4) ? p - v : v + p;
-        acc += (unsigned)abs(v);
-    }
-    return (group_sum<8>(acc) + 2) >> 2;
+    for (int i = 0; i < 64; ++i) asm("v_sad_u32 %0, %1, %2, %0" : "+v"(acc) : "v"(d[i]), "s"(bias));   // no clang builtin for v_sad_u32
+    return (acc + 2) >> 2;
 }
 
+// sum over the aligned group of 1 / 4 / 16 / 64 lanes that forms one PU at `level` (wave-uniform)
+__device__ __forceinline__ unsigned pu_group_sum(unsigned v, int level)
+{
+    if (level <= 2) {
+        v += (unsigned)dpp_mov<KS265_DPP_QUAD_XOR1>((int)v);
+        v += (unsigned)dpp_mov<KS265_DPP_QUAD_XOR2>((int)v);
+    }
+    if (level <= 1) {
+        v += (unsigned)dpp_mov<KS265_DPP_ROW_HALF_MIRROR>((int)v);
+        v += (unsigned)dpp_mov<KS265_DPP_ROW_MIRROR>((int)v);
+    }
+    if (level == 0) {
+        v += (unsigned)__builtin_amdgcn_ds_swizzle((int)v, 0x1F | (16 << 10));
+        v += (unsigned)__shfl_xor((int)v, 32, 64);
+    }
+    return v;
+}
+
+#ifndef KS_SUBPEL_LOCKSTEP
+#define KS_SUBPEL_LOCKSTEP 1
+#endif
+template <int DBG>
 __global__ __launch_bounds__(256) void me_subpel_kernel(KsGeom g, int lam, const uint8_t *src, const uint8_t *planes, ks265_pu *pus)
 {
-    __shared__ unsigned cost[64][9];          // per PU of the current level x candidate (0 = centre, 1..8 = ring)
-    __shared__ int cmv[64];                   // current centre of each PU (packed qpel mv)
-    __shared__ unsigned best[64][2];          // best cost / dist so far
-    const int tid = threadIdx.x, lane = tid & 63, ctu = blockIdx.x, cx = ctu % g.ctu_cols, cy = ctu / g.ctu_cols;
+    const int tid = threadIdx.x, lane = tid & 63, level = tid >> 6;
+    const int ctu = ks_xcd_swizzle(blockIdx.x, g.ctu_cols * g.ctu_rows), cx = ctu % g.ctu_cols, cy = ctu / g.ctu_cols;
     ks265_pu *cp = pus + (long)ctu * 85;
     const uint8_t *Sp = ks_org_y(g, src);
-    const int ox[9] = {0, -1, 0, 1, -1, 1, -1, 0, 1}, oy[9] = {0, -1, -1, -1, 0, 0, 1, 1, 1};
-    for (int l = 0; l < 4; ++l) {
-        const int npu = 1 << (2 * l), sh8 = 3 - l;               // tiles per PU side = 1 << sh8
-        for (int i = tid; i < npu; i += 256) {
-            const ks265_pu p = cp[ks_level_base(l) + i];
-            cmv[i] = ((int)p.mvx & 0xFFFF) | ((int)p.mvy << 16);
-            best[i][0] = KS_COST_INVALID; best[i][1] = KS_COST_INVALID;
+    const int G = 1 << (2 * (3 - level));                          // lanes (tiles) per PU: 64, 16, 4, 1
+    // Z-order: lane bits (y2 x2 y1 x1 y0 x0)
+    const int tx = (lane & 1) | ((lane >> 1) & 2) | ((lane >> 2) & 4), ty = ((lane >> 1) & 1) | ((lane >> 2) & 2) | ((lane >> 3) & 4);
+    const int x0 = cx * 64 + tx * 8, y0 = cy * 64 + ty * 8;
+    const int px = tx >> (3 - level), py = ty >> (3 - level), pidx = ks_level_base(level) + py * (1 << level) + px;
+    ks265_pu p = cp[pidx];
+    const bool valid = p.cost != KS_COST_INVALID;                  // the whole PU lies inside the picture
+    unsigned f[16];
+    {
+        const uint8_t *frow = Sp + (long)(valid ? y0 : cy * 64) * g.sy + (valid ? x0 : cx * 64);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { const uint2 v = *(const uint2 *)(frow + (long)r * g.sy); f[2 * r] = v.x; f[2 * r + 1] = v.y; }
+    }
+    const long base = (long)(valid ? y0 : 0) * g.sy + (valid ? x0 : 0) + g.org_y;
+    int bx = p.mvx, by = p.mvy;
+    unsigned bc = 0, bd = 0;
+    // candidate k: 0 = centre, 1..8 = the ring in raster order (hpel_x/y, qpel_x/y tables).
+    // Evaluation order is free as long as the winner is the reference's: smallest cost, ties to the smallest k (the reference
+    // walks k upwards with a strict '<').  Half-pel candidates are therefore visited plane by plane (centre; the two on the
+    // vertical plane; the two on the horizontal plane; the four on the diagonal plane) so that consecutive candidates hit
+    // the same cache lines.
+    auto cand = [](int k, int &dx, int &dy) { const int gi = k == 0 ? 4 : (k - 1 + (k > 4)); dx = gi % 3 - 1; dy = gi / 3 - 1; };
+    const unsigned order_hpel = 0x63154720u;                      // nibble n = n-th candidate visited: 0, 2,7 (vertical), 4,5 (horizontal), 1,3,6 (+ 8 below: diagonal)
+#pragma unroll 1
+    for (int phase = 0; phase < 2; ++phase) {                     // 0: centre + half-pel ring, 1: quarter-pel ring
+        const int step = phase == 0 ? 2 : 1;
+        const int cx0 = bx, cy0 = by;
+        int bk = 0;
+#pragma unroll 1
+        for (int n = phase; n < 9; ++n) {
+            if (KS_SUBPEL_LOCKSTEP) __syncthreads();               // the four levels touch the same plane rows together -> L1 reuse
+            // keep the 16 packed source dwords opaque inside the loop: otherwise LICM hoists the 64 unpacked source bytes
+            // out of the candidate loop (+64 VGPRs, occupancy 2); the byte selects ride on the SDWA subtract anyway
+#pragma unroll
+            for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(f[i]));
+            const int k = phase == 0 ? (n == 8 ? 8 : (int)((order_hpel >> (4 * n)) & 15u)) : n;
+            int dx, dy;
+            cand(k, dx, dy);
+            const int qx = cx0 + dx * step, qy = cy0 + dy * step;
+            const int ax = valid ? qx : 0, ay = valid ? qy : 0;
+            const uint8_t *pp = planes + (long)((ay & 3) * 4 + (ax & 3)) * g.bytes_y + base + (long)(ay >> 2) * g.sy + (ax >> 2);
+            const unsigned sd = satd8x8<DBG>(f, pp, g.sy);
+            const unsigned dd = pu_group_sum(valid ? sd : 0, level);
+            const unsigned cc = dd + (unsigned)mv_cost(qx, qy, p.mvpx, p.mvpy, lam);
+            // phase 0 starts from nothing (n == 0 is the centre); phase 1 starts from the half-pel winner, which every
+            // quarter-pel candidate must beat strictly (it is "earlier" than all of them)
+            const bool first = phase == 0 && n == 0;
+            if (first || cc < bc || (cc == bc && phase == 0 && k < bk)) { bc = cc; bd = dd; bx = qx; by = qy; bk = k; }
         }
-        for (int phase = 0; phase < 2; ++phase) {               // 0: centre + half-pel ring, 1: quarter-pel ring
-            const int step = phase == 0 ? 2 : 1, k0 = phase == 0 ? 0 : 1;
-            for (int i = tid; i < 64 * 9; i += 256) cost[i / 9][i % 9] = 0;
-            __syncthreads();
-            for (int tp = 0; tp < 2; ++tp) {
-                const int tile = tp * 32 + (tid >> 3), tx = tile & 7, ty = tile >> 3, r = tid & 7;
-                const int x0 = cx * 64 + tx * 8, y0 = cy * 64 + ty * 8;
-                const int ppx = tx >> sh8, ppy = ty >> sh8, pi = ppy * (1 << l) + ppx;
-                const bool valid = x0 < g.W && y0 < g.H && cp[ks_level_base(l) + pi].cost != KS_COST_INVALID;
-                if (!__any(valid)) continue;
-                const uint8_t *frow = Sp + (long)(y0 + r) * g.sy + x0;
-                const unsigned f0 = valid ? *(const unsigned *)frow : 0, f1 = valid ? *(const unsigned *)(frow + 4) : 0;
-                const int c = cmv[pi], bx = (int)(short)(c & 0xFFFF), by = c >> 16;
-                for (int k = k0; k < 9; ++k) {
-                    int qx = bx + ox[k] * step, qy = by + oy[k] * step;
-                    if (!valid) { qx = 0; qy = 0; }
-                    const uint8_t *pl = planes + (long)((qy & 3) * 4 + (qx & 3)) * g.bytes_y + g.org_y;
-                    const uint8_t *prow = pl + (long)((valid ? y0 + r : 0) + (qy >> 2)) * g.sy + (valid ? x0 : 0) + (qx >> 2);
-                    unsigned s = tile_satd8(f0, f1, prow, lane);
-                    if (valid && r == 0) atomicAdd(&cost[pi][k], s);
-                }
-            }
-            __syncthreads();
-            for (int i = tid; i < npu; i += 256) {
-                const ks265_pu p = cp[ks_level_base(l) + i];
-                if (p.cost == KS_COST_INVALID) continue;
-                const int c = cmv[i], cx0 = (int)(short)(c & 0xFFFF), cy0 = c >> 16;
-                unsigned bc = best[i][0], bd = best[i][1];
-                int bx = cx0, by = cy0;
-                for (int k = k0; k < 9; ++k) {
-                    int qx = cx0 + ox[k] * step, qy = cy0 + oy[k] * step;
-                    unsigned d = cost[i][k], cc = d + (unsigned)mv_cost(qx, qy, p.mvpx, p.mvpy, lam);
-                    if (k == 0 || cc < bc) { bc = cc; bd = d; bx = qx; by = qy; }
-                }
-                best[i][0] = bc; best[i][1] = bd;
-                cmv[i] = (bx & 0xFFFF) | (by << 16);
-            }
-            __syncthreads();
-        }
-        for (int i = tid; i < npu; i += 256) {
-            ks265_pu p = cp[ks_level_base(l) + i];
-            if (p.cost == KS_COST_INVALID) continue;
-            const int c = cmv[i];
-            p.mvx = (int16_t)(c & 0xFFFF); p.mvy = (int16_t)(c >> 16); p.cost = best[i][0]; p.dist = best[i][1];
-            cp[ks_level_base(l) + i] = p;
-        }
-        __syncthreads();
+    }
+    if (valid && (lane & (G - 1)) == 0) {
+        p.mvx = (int16_t)bx; p.mvy = (int16_t)by; p.cost = bc; p.dist = bd;
+        cp[pidx] = p;
     }
 }
 
@@ -294,7 +318,10 @@ extern "C" int ks265_me_subpel(ks265_frame *f, ks265_pic src, const uint8_t *pla
 {
     KS_FRAME_CHECK(f);
     if (!src.y || !planes || !pu) return KS265_POINTER;
-    hipLaunchKernelGGL(me_subpel_kernel, dim3(f->g.ctu_cols * f->g.ctu_rows), dim3(256), 0, f->ctx->stream, f->g, f->cfg.lambda_q4, src.y, planes, pu);
+    static int dbg = getenv("KS_DBG_SUBPEL") ? atoi(getenv("KS_DBG_SUBPEL")) : 0;
+    if (dbg == 1) hipLaunchKernelGGL(me_subpel_kernel<1>, dim3(f->g.ctu_cols * f->g.ctu_rows), dim3(256), 0, f->ctx->stream, f->g, f->cfg.lambda_q4, src.y, planes, pu);
+    else if (dbg == 2) hipLaunchKernelGGL(me_subpel_kernel<2>, dim3(f->g.ctu_cols * f->g.ctu_rows), dim3(256), 0, f->ctx->stream, f->g, f->cfg.lambda_q4, src.y, planes, pu);
+    else hipLaunchKernelGGL(me_subpel_kernel<0>, dim3(f->g.ctu_cols * f->g.ctu_rows), dim3(256), 0, f->ctx->stream, f->g, f->cfg.lambda_q4, src.y, planes, pu);
     return ks265_check_launch(f->ctx);
 }
 
