@@ -157,67 +157,136 @@ __device__ long long sao_eval(const SaoStats *s, int type, int lam, ks265_sao_pa
     return res;
 }
 
-// statistics of one component of one CTU into LDS
-__device__ __forceinline__ void sao_collect(const uint8_t *org, const uint8_t *rec, long stride, int x0, int y0, int w, int h, int picW, int picH,
-                                            SaoStats *st, int tid)
+// ---- LDS-staged CTU tiles: deblocked samples with a 1-sample halo (row pitch TP, sample (0,0) at [1][4]) + source samples.
+// One thread owns a 4x4 block: 6 rows x 3 dwords of the deblocked tile feed all four EO classes of its 16 samples.
+// Per-thread EO statistics are PACKED: per class one register of four 8-bit counts and two registers of two 16-bit sums
+// of the biased difference (d + 128, d = the reference's s8-truncated org - rec, statSaoBoEo01_c enc@0x4ae9c0); 16 samples
+// per thread cannot overflow the fields.  Band statistics go to LDS with one 64-bit atomic per sample (sum << 32 | count).
+template <int TS>
+struct SaoTile {
+    static constexpr int TP = TS + 8;                      // row pitch (bytes): columns -4 .. TS+3
+    uint8_t rec[(TS + 2) * TP];
+    uint8_t org[TS * TS];
+};
+struct SaoAcc { unsigned long long bo[32]; int ecnt[4][4]; int esum[4][4]; };
+
+template <int TS>
+__device__ __forceinline__ void sao_load_tile(SaoTile<TS> &t, const uint8_t *org, const uint8_t *rec, long stride, int x0, int y0, int lt, int nt)
 {
-    for (int i = tid; i < 5 * 32; i += 256) { (&st->cnt[0][0])[i] = 0; (&st->sum[0][0])[i] = 0; }
-    __syncthreads();
-    int ecnt[4][4], esum[4][4];
+    constexpr int TP = SaoTile<TS>::TP;
+    for (int i = lt; i < (TS + 2) * (TP / 4); i += nt) {
+        const int r = i / (TP / 4), c = i - r * (TP / 4);
+        *(unsigned *)&t.rec[r * TP + c * 4] = *(const unsigned *)(rec + (long)(y0 - 1 + r) * stride + x0 - 4 + c * 4);
+    }
+    for (int i = lt; i < TS * (TS / 4); i += nt) {
+        const int r = i / (TS / 4), c = i - r * (TS / 4);
+        *(unsigned *)&t.org[r * TS + c * 4] = *(const unsigned *)(org + (long)(y0 + r) * stride + x0 + c * 4);
+    }
+}
+
+__device__ __forceinline__ int eo_index(int c, int a, int b) { return 2 + sgn(c - a) + sgn(c - b); }
+
+// statistics of this thread's 4x4 block (bx4, by4 in units of 4 samples); w, h = valid tile size; (gx, gy) = picture coords of the tile
+template <int TS>
+__device__ __forceinline__ void sao_stats_block(const SaoTile<TS> &t, int bx4, int by4, int w, int h, int gx, int gy, int picW, int picH,
+                                                SaoAcc *acc, bool active, int lane)
+{
+    constexpr int TP = SaoTile<TS>::TP;
+    unsigned cntp[4] = {0, 0, 0, 0}, sumlo[4] = {0, 0, 0, 0}, sumhi[4] = {0, 0, 0, 0};
+    if (active) {
+        const int x4 = bx4 * 4, y4 = by4 * 4;
+        unsigned rows[6][3];
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
+        for (int r = 0; r < 6; ++r) {
+            const unsigned *p = (const unsigned *)&t.rec[(y4 + r) * TP + x4];     // tile row y4-1+r, columns x4-4 .. x4+7
+            rows[r][0] = p[0]; rows[r][1] = p[1]; rows[r][2] = p[2];
+        }
+        auto px = [&](int r, int x) -> int {                    // sample at block-relative (x, r-1), x in -1..4
+            const int bi = x + 4;
+            return (int)((rows[r][bi >> 2] >> (8 * (bi & 3))) & 255);
+        };
 #pragma unroll
-        for (int c = 0; c < 4; ++c) { ecnt[k][c] = 0; esum[k][c] = 0; }
-    const int dxs[4] = {1, 0, 1, -1}, dys[4] = {0, 1, 1, 1};
-    for (int i = tid; i < w * h; i += 256) {
-        const int x = x0 + i % w, y = y0 + i / w;
-        const uint8_t *r = rec + (long)y * stride + x;
-        const int c = r[0], d = (int)(int8_t)(uint8_t)(org[(long)y * stride + x] - c);
-        atomicAdd(&st->cnt[0][c >> 3], 1);
-        atomicAdd(&st->sum[0][c >> 3], d);
+        for (int yy = 0; yy < 4; ++yy) {
+            const unsigned ov = *(const unsigned *)&t.org[(y4 + yy) * TS + x4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int ax = x - dxs[k], ay = y - dys[k], bx = x + dxs[k], by = y + dys[k];
-            if (ax < 0 || bx < 0 || ax >= picW || bx >= picW || ay < 0 || by >= picH) continue;
-            const int e = 2 + sgn(c - (int)r[-dys[k] * stride - dxs[k]]) + sgn(c - (int)r[dys[k] * stride + dxs[k]]);
+            for (int xx = 0; xx < 4; ++xx) {
+                const int lx = x4 + xx, ly = y4 + yy;
+                if (lx >= w || ly >= h) continue;
+                const int c = px(yy + 1, xx);
+                const int d = (int)(int8_t)(uint8_t)(((ov >> (8 * xx)) & 255) - c);
+                const unsigned ud = (unsigned)(d + 128);
+                atomicAdd(&acc->bo[c >> 3], ((unsigned long long)ud << 32) | 1ull);
+                const int X = gx + lx, Y = gy + ly;
+                const bool okL = X > 0, okR = X < picW - 1, okU = Y > 0, okD = Y < picH - 1;
+                const int e[4] = {eo_index(c, px(yy + 1, xx - 1), px(yy + 1, xx + 1)), eo_index(c, px(yy, xx), px(yy + 2, xx)),
+                                  eo_index(c, px(yy, xx - 1), px(yy + 2, xx + 1)), eo_index(c, px(yy, xx + 1), px(yy + 2, xx - 1))};
+                const bool ok[4] = {okL && okR, okU && okD, okL && okR && okU && okD, okL && okR && okU && okD};
 #pragma unroll
-            for (int cat = 0; cat < 4; ++cat) {
-                const bool hit = e == (cat < 2 ? cat : cat + 1);
-                ecnt[k][cat] += hit; esum[k][cat] += hit ? d : 0;
+                for (int k = 0; k < 4; ++k) {
+                    if (!ok[k] || e[k] == 2) continue;
+                    const int cat = e[k] < 2 ? e[k] : e[k] - 1;
+                    cntp[k] += 1u << (8 * cat);
+                    if (cat < 2) sumlo[k] += ud << (16 * cat); else sumhi[k] += ud << (16 * (cat - 2));
+                }
             }
         }
     }
+    // unpack, un-bias, reduce over the wave, one LDS atomic per (class, category) per wave
 #pragma unroll
     for (int k = 0; k < 4; ++k)
 #pragma unroll
         for (int cat = 0; cat < 4; ++cat) {
-            const int cs = (int)wave_sum((unsigned)ecnt[k][cat]), ss = (int)wave_sum((unsigned)esum[k][cat]);
-            if ((tid & 63) == 0) { atomicAdd(&st->cnt[1 + k][cat], cs); atomicAdd(&st->sum[1 + k][cat], ss); }
+            const int cn = (int)((cntp[k] >> (8 * cat)) & 255u);
+            const int sb = (int)(((cat < 2 ? sumlo[k] : sumhi[k]) >> (16 * (cat & 1))) & 0xFFFFu);
+            const int cs = (int)wave_sum((unsigned)cn), ss = (int)wave_sum((unsigned)(sb - 128 * cn));
+            if (lane == 0 && cs) { atomicAdd(&acc->ecnt[k][cat], cs); atomicAdd(&acc->esum[k][cat], ss); }
         }
-    __syncthreads();
 }
 
-__device__ __forceinline__ void sao_apply_ctu(const uint8_t *rec, uint8_t *dst, long stride, int x0, int y0, int w, int h, int picW, int picH,
-                                              const ks265_sao_param p, int tid)
+__device__ __forceinline__ void sao_acc_to_stats(const SaoAcc *a, SaoStats *st, int lt, int nt)
 {
+    for (int i = lt; i < 32; i += nt) {
+        const unsigned long long v = a->bo[i];
+        const int cn = (int)(v & 0xFFFFFFFFull);
+        st->cnt[0][i] = cn; st->sum[0][i] = (int)(v >> 32) - 128 * cn;
+    }
+    for (int i = lt; i < 16; i += nt) { st->cnt[1 + (i >> 2)][i & 3] = a->ecnt[i >> 2][i & 3]; st->sum[1 + (i >> 2)][i & 3] = a->esum[i >> 2][i & 3]; }
+}
+
+// apply to this thread's 4x4 block, from the LDS tile to the destination picture (one dword per row)
+template <int TS>
+__device__ __forceinline__ void sao_apply_block(const SaoTile<TS> &t, int bx4, int by4, int w, int h, int gx, int gy, int picW, int picH,
+                                                const ks265_sao_param p, uint8_t *dst, long stride)
+{
+    constexpr int TP = SaoTile<TS>::TP;
+    const int x4 = bx4 * 4, y4 = by4 * 4;
+    if (x4 >= w || y4 >= h) return;
     const int dxs[4] = {1, 0, 1, -1}, dys[4] = {0, 1, 1, 1};
-    for (int i = tid; i < w * h; i += 256) {
-        const int x = x0 + i % w, y = y0 + i / w;
-        const uint8_t *r = rec + (long)y * stride + x;
-        const int c = r[0];
-        int o = 0;
-        if (p.type == 0) {
-            const int k = (c >> 3) - p.band;
-            if (k >= 0 && k < 4) o = p.offset[k];
-        } else if (p.type > 0) {
-            const int k = p.type - 1;
-            const int ax = x - dxs[k], ay = y - dys[k], bx = x + dxs[k], by = y + dys[k];
-            if (!(ax < 0 || bx < 0 || ax >= picW || bx >= picW || ay < 0 || by >= picH)) {
-                const int e = 2 + sgn(c - (int)r[-dys[k] * stride - dxs[k]]) + sgn(c - (int)r[dys[k] * stride + dxs[k]]);
-                if (e != 2) o = p.offset[e < 2 ? e : e - 1];
+    const int k = p.type > 0 ? p.type - 1 : 0, dx = dxs[k], dy = dys[k];
+#pragma unroll
+    for (int yy = 0; yy < 4; ++yy) {
+        if (y4 + yy >= h) break;
+        unsigned o = 0;
+#pragma unroll
+        for (int xx = 0; xx < 4; ++xx) {
+            const int lx = x4 + xx, ly = y4 + yy;
+            const uint8_t *r = &t.rec[(ly + 1) * TP + lx + 4];
+            const int c = r[0];
+            int off = 0;
+            if (p.type == 0) {
+                const int kk = (c >> 3) - p.band;
+                if (kk >= 0 && kk < 4) off = p.offset[kk];
+            } else if (p.type > 0) {
+                const int X = gx + lx, Y = gy + ly;
+                const int ax = X - dx, ay = Y - dy, bx = X + dx, by = Y + dy;
+                if (!(ax < 0 || bx < 0 || ax >= picW || bx >= picW || ay < 0 || by >= picH)) {
+                    const int e = eo_index(c, (int)r[-dy * TP - dx], (int)r[dy * TP + dx]);
+                    if (e != 2) off = p.offset[e < 2 ? e : e - 1];
+                }
             }
+            o |= (unsigned)clip8(c + off) << (8 * xx);
         }
-        dst[(long)y * stride + x] = (uint8_t)clip8(c + o);
+        *(unsigned *)(dst + (long)(gy + y4 + yy) * stride + gx + x4) = o;       // widths are multiples of 4 (W % 8 == 0)
     }
 }
 
@@ -225,15 +294,31 @@ __global__ __launch_bounds__(256) void sao_ctu_kernel(KsGeom g, int lam, int ena
                                                       const uint8_t *dy, const uint8_t *du, const uint8_t *dv, ks265_sao_param *sao, uint8_t *oy,
                                                       uint8_t *ou, uint8_t *ov)
 {
+    __shared__ __attribute__((aligned(16))) SaoTile<64> tl;
+    __shared__ __attribute__((aligned(16))) SaoTile<32> tc[2];
+    __shared__ __attribute__((aligned(16))) SaoAcc acc[3];
     __shared__ SaoStats st[3];
     __shared__ ks265_sao_param sel[3];
     __shared__ long long jl[5], jc[5];
     __shared__ ks265_sao_param cand[3][5];
-    const int tid = threadIdx.x, ctu = blockIdx.x, cx = ctu % g.ctu_cols, cy = ctu / g.ctu_cols;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ctu = ks_xcd_swizzle(blockIdx.x, g.ctu_cols * g.ctu_rows), cx = ctu % g.ctu_cols, cy = ctu / g.ctu_cols;
     const int x0 = cx * 64, y0 = cy * 64, w = min(64, g.W - x0), h = min(64, g.H - y0);
-    sao_collect(ks_org_y(g, sy), ks_org_y(g, dy), g.sy, x0, y0, w, h, g.W, g.H, &st[0], tid);
-    sao_collect(ks_org_c(g, su), ks_org_c(g, du), g.sc, x0 / 2, y0 / 2, w / 2, h / 2, g.W / 2, g.H / 2, &st[1], tid);
-    sao_collect(ks_org_c(g, sv), ks_org_c(g, dv), g.sc, x0 / 2, y0 / 2, w / 2, h / 2, g.W / 2, g.H / 2, &st[2], tid);
+    for (int i = tid; i < (int)(sizeof(acc) / 4); i += 256) ((int *)acc)[i] = 0;
+    sao_load_tile<64>(tl, ks_org_y(g, sy), ks_org_y(g, dy), g.sy, x0, y0, tid, 256);
+    {
+        const int cc = tid >> 7;                          // threads 0..127 stage Cb, 128..255 stage Cr
+        sao_load_tile<32>(tc[cc], ks_org_c(g, cc ? sv : su), ks_org_c(g, cc ? dv : du), g.sc, x0 / 2, y0 / 2, tid & 127, 128);
+    }
+    __syncthreads();
+    // luma: 16 x 16 blocks of 4x4 = 256 threads; chroma: 8 x 8 blocks per component, wave 0 = Cb, wave 1 = Cr
+    sao_stats_block<64>(tl, tid & 15, tid >> 4, w, h, x0, y0, g.W, g.H, &acc[0], true, lane);
+    sao_stats_block<32>(tc[wave & 1], lane & 7, lane >> 3, w / 2, h / 2, x0 / 2, y0 / 2, g.W / 2, g.H / 2, &acc[1 + (wave & 1)], wave < 2, lane);
+    __syncthreads();
+    sao_acc_to_stats(&acc[0], &st[0], tid, 256);
+    sao_acc_to_stats(&acc[1], &st[1], tid, 256);
+    sao_acc_to_stats(&acc[2], &st[2], tid, 256);
+    __syncthreads();
     if (tid < 15) {                                    // 3 components x 5 types evaluated in parallel
         const int comp = tid / 5, t = tid % 5;
         long long j = sao_eval(&st[comp], t, lam, &cand[comp][t]);
@@ -259,9 +344,8 @@ __global__ __launch_bounds__(256) void sao_ctu_kernel(KsGeom g, int lam, int ena
         sao[(long)ctu * 3 + 0] = sel[0]; sao[(long)ctu * 3 + 1] = sel[1]; sao[(long)ctu * 3 + 2] = sel[2];
     }
     __syncthreads();
-    sao_apply_ctu(ks_org_y(g, dy), ks_org_y(g, oy), g.sy, x0, y0, w, h, g.W, g.H, sel[0], tid);
-    sao_apply_ctu(ks_org_c(g, du), ks_org_c(g, ou), g.sc, x0 / 2, y0 / 2, w / 2, h / 2, g.W / 2, g.H / 2, sel[1], tid);
-    sao_apply_ctu(ks_org_c(g, dv), ks_org_c(g, ov), g.sc, x0 / 2, y0 / 2, w / 2, h / 2, g.W / 2, g.H / 2, sel[2], tid);
+    sao_apply_block<64>(tl, tid & 15, tid >> 4, w, h, x0, y0, g.W, g.H, sel[0], ks_org_y(g, oy), g.sy);
+    if (wave < 2) sao_apply_block<32>(tc[wave], lane & 7, lane >> 3, w / 2, h / 2, x0 / 2, y0 / 2, g.W / 2, g.H / 2, sel[1 + wave], ks_org_c(g, wave ? ov : ou), g.sc);
 }
 
 extern "C" int ks265_sao(ks265_frame *f, ks265_pic src, ks265_pic deb, ks265_sao_param *sao, ks265_pic dst)

@@ -1,156 +1,200 @@
 // frame_recon.hip — Stage D: prediction -> residual -> forward transform -> quant -> dequant -> inverse transform -> recon
 // (the reconstruct() chain enc@0x481da0: calc_residual -> g_H265_2dDct_Func -> g_QuantFuncs -> g_DeQuantFuncs ->
 // g_H265_2dIDct_Func).  One workgroup per 32x32 luma region (+ its two 16x16 chroma regions); the region holds TUs of
-// 8..32 (luma) / 4..16 (chroma) samples, every thread works on elements of its own TU; the four 1-D passes run out of
-// LDS with int32 accumulators and the exact stage shifts of the reference.
+// 8..32 (luma) / 4..16 (chroma) samples.  All four 1-D passes are row-times-row dot products out of LDS:
+//   fwd 1  T[k][j] = M[k] . X[j]        fwd 2  C[k][j] = M[k] . T[j]      (H265_2dDct*_c enc@0x4c2210.., shifts 2log2N-2, 7)
+//   inv 1  T[y][x] = Mt[y] . Ct[x]      inv 2  R[y][x] = T[y] . Mt[x]     (H265_2dIDct*_c enc@0x448f60.., shifts 7, 12)
+// (Ct = dequantised coefficients stored transposed, Mt = transposed matrix), so every operand is read along a row with
+// 8-byte LDS reads and multiplied with v_dot2c_i32_i16 (all intermediates fit int16 exactly as in the reference's
+// `short` buffers; accumulation is int32).  Row pitch 36 shorts = 18 dwords makes the row-per-lane ds_read_b64 walks
+// bank-conflict free.  Each thread produces 4 adjacent outputs that share one of the two operand rows.
 #include "frame_common.h"
 
 using namespace ks265;
 
-struct QP {
-    int scale, offF, dq, qp6;
-};
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+#define RP 36                      // LDS row pitch of the sample/coefficient tiles, in shorts
 
-__device__ __forceinline__ QP make_qp(int qp, bool intra)
+// matrices of all four sizes, row pitch n + 4 shorts; offset of size n (4, 8, 16, 32)
+__device__ __forceinline__ int mat_off(int log2n) { return log2n == 2 ? 0 : log2n == 3 ? 32 : log2n == 4 ? 128 : 448; }   // 4*8, 8*12, 16*20, 32*36
+#define MAT_SHORTS (448 + 32 * 36)
+
+__device__ __forceinline__ int dot2(unsigned a, unsigned b, int c) { return __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b), c, false); }
+
+// out[i] = shared[0..n) . rows[i * pitch + 0..n), i = 0..3 ; all pointers 8-byte aligned, n a multiple of 4
+__device__ __forceinline__ void quad_dot(const short *shared, const short *rows, int pitch, int n, int (&out)[4])
 {
-    QP q;
-    q.scale = kQuantScales[qp % 6];
-    q.qp6 = qp / 6;
-    q.offF = intra ? 171 : 85;
-    q.dq = kInvQuantScales[qp % 6] << (qp / 6);
-    return q;
+    out[0] = out[1] = out[2] = out[3] = 0;
+    for (int x = 0; x < n; x += 4) {
+        const uint2 s = *(const uint2 *)(shared + x);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint2 r = *(const uint2 *)(rows + i * pitch + x);
+            out[i] = dot2(s.x, r.x, out[i]);
+            out[i] = dot2(s.y, r.y, out[i]);
+        }
+    }
 }
 
-// chroma sample prediction (interpChroma* enc@0x4111c0..): 4-tap, 1/8 sample, normative 2-D order
-__device__ __forceinline__ int chroma_pred(const uint8_t *ref, long stride, int fx, int fy)
+// four chroma prediction samples (interpChroma* enc@0x4111c0..): 4-tap, 1/8 sample, normative 2-D order.
+// rp -> sample 0 of the quad at integer position; horizontal taps via v_dot4_i32_i8 on (p - 128).
+__device__ __forceinline__ void chroma_pred4(const uint8_t *rp, long stride, int fx, int fy, int (&out)[4])
 {
-    if (!fx && !fy) return ref[0];
+    auto hrow = [&](const uint8_t *row, int (&h)[4]) {            // raw 4-tap sums of samples 0..3 (bytes -1 .. 5)
+        const uint8_t *q = row - 1;
+        const unsigned sh = (unsigned)((uintptr_t)q & 3);
+        const unsigned *a = (const unsigned *)(q - sh);
+        const unsigned a0 = a[0] ^ 0x80808080u, a1 = a[1] ^ 0x80808080u, a2 = a[2] ^ 0x80808080u;
+        const unsigned w0 = align_bytes(a1, a0, sh), w1 = align_bytes(a2, a1, sh);   // bytes -1..2, 3..6
+        const signed char *c = kChromaTaps[fx];
+        const int taps = (int)((unsigned)(unsigned char)c[0] | ((unsigned)(unsigned char)c[1] << 8) | ((unsigned)(unsigned char)c[2] << 16) | ((unsigned)(unsigned char)c[3] << 24));
+        h[0] = __builtin_amdgcn_sdot4((int)w0, taps, 8192, false);
+        h[1] = __builtin_amdgcn_sdot4((int)align_bytes(w1, w0, 1), taps, 8192, false);
+        h[2] = __builtin_amdgcn_sdot4((int)align_bytes(w1, w0, 2), taps, 8192, false);
+        h[3] = __builtin_amdgcn_sdot4((int)align_bytes(w1, w0, 3), taps, 8192, false);
+    };
     if (!fy) {
-        int s = 0;
+        if (!fx) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) s += kChromaTaps[fx][t] * (int)ref[t - 1];
-        return clip8((s + 32) >> 6);
-    }
-    if (!fx) {
-        int s = 0;
+            for (int i = 0; i < 4; ++i) out[i] = rp[i];
+            return;
+        }
+        int h[4]; hrow(rp, h);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) s += kChromaTaps[fy][t] * (int)ref[(t - 1) * stride];
-        return clip8((s + 32) >> 6);
+        for (int i = 0; i < 4; ++i) out[i] = clip8((h[i] + 32) >> 6);
+        return;
     }
-    int v = 0;
+    int v[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        int s = 0;
+        const int cy = kChromaTaps[fy][r];
+        if (!fx) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) s += kChromaTaps[fx][t] * (int)ref[(r - 1) * stride + t - 1];
-        v += kChromaTaps[fy][r] * (int)(short)s;
+            for (int i = 0; i < 4; ++i) v[i] += cy * (int)rp[(r - 1) * stride + i];
+        } else {
+            int h[4]; hrow(rp + (r - 1) * stride, h);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] += cy * (int)(short)h[i];
+        }
     }
-    return clip8((v + 2048) >> 12);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) out[i] = fx ? clip8((v[i] + 2048) >> 12) : clip8((v[i] + 32) >> 6);
 }
 
 template <int RS /*region size in samples: 32 luma, 16 chroma*/>
 __device__ __forceinline__ void code_region(const KsGeom &g, int comp, int qp, int rx8, int ry8, const ks265_cu8 *blk /*LDS [16]*/,
-                                            const unsigned char *tu_log2 /*LDS [16]: log2 of TU size in 8x8 blocks*/, const short *M32, short *X,
-                                            short *T, unsigned char *P, int *nzcnt /*LDS [16]*/, const uint8_t *src, const uint8_t *ref,
+                                            const unsigned char *tu_log2 /*LDS [16]: log2 of TU size in 8x8 blocks*/, const short *Mf, const short *Mt,
+                                            short *X, short *T, unsigned char *P, int *nzcnt /*LDS [16]*/, const uint8_t *src, const uint8_t *ref,
                                             const uint8_t *planes, int16_t *lvl, uint8_t *rec, int tid)
 {
     constexpr int UNIT = RS / 4;                      // samples per 8x8-luma block along one axis
-    constexpr int NE = RS * RS;
+    constexpr int NQ = RS * RS / 4;                   // quads (4 adjacent samples of one row)
     const long stride = comp == 0 ? g.sy : g.sc;
     const int lstride = comp == 0 ? g.W : g.W / 2;
     const int X0 = rx8 * UNIT, Y0 = ry8 * UNIT;       // region origin in this component's samples
     const uint8_t *S = comp == 0 ? ks_org_y(g, src) : ks_org_c(g, src);
     uint8_t *Rc = comp == 0 ? ks_org_y(g, rec) : ks_org_c(g, rec);
+    const int qx = (tid % (RS / 4)) * 4, qy = tid / (RS / 4);      // this thread's quad: samples (qx..qx+3, qy)
+    const bool has_quad = tid < NQ;
+    const int b = has_quad ? (qy / UNIT) * 4 + qx / UNIT : 0;
+    const ks265_cu8 c = blk[b];
+    const bool coded = has_quad && c.log2_cu != 0;                 // block inside the picture
+    // TU geometry of the quad
+    const int t8 = 1 << tu_log2[b], tbx = (b & 3) & ~(t8 - 1), tby = (b >> 2) & ~(t8 - 1), tb = tby * 4 + tbx;
+    const int ox = tbx * UNIT, oy = tby * UNIT, n = t8 * UNIT, log2n = tu_log2[b] + (RS == 32 ? 3 : 2);
+    const short *mf = Mf + mat_off(log2n), *mt = Mt + mat_off(log2n);
+    const int mp = n + 4;                                          // matrix row pitch
 
     if (tid < 16) nzcnt[tid] = 0;
     // ---- prediction + residual
-    for (int e = tid; e < NE; e += 256) {
-        const int ex = e % RS, ey = e / RS, b = (ey / UNIT) * 4 + ex / UNIT;
-        const ks265_cu8 c = blk[b];
-        int pred = 128, res = 0;
-        if (c.log2_cu) {                              // block inside the picture
+    if (has_quad) {
+        int pred[4] = {128, 128, 128, 128}, res[4] = {0, 0, 0, 0};
+        if (coded) {
             if (c.pred_mode == 0) {
                 if (comp == 0) {
-                    const uint8_t *pl = planes + (long)((c.mvy & 3) * 4 + (c.mvx & 3)) * g.bytes_y + g.org_y;
-                    pred = pl[(long)(Y0 + ey + (c.mvy >> 2)) * g.sy + X0 + ex + (c.mvx >> 2)];
+                    const uint8_t *pp = planes + (long)((c.mvy & 3) * 4 + (c.mvx & 3)) * g.bytes_y + g.org_y + (long)(Y0 + qy + (c.mvy >> 2)) * g.sy + X0 + qx + (c.mvx >> 2);
+                    const unsigned sh = (unsigned)((uintptr_t)pp & 3);
+                    const unsigned *a = (const unsigned *)(pp - sh);
+                    const unsigned v = align_bytes(a[1], a[0], sh);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) pred[i] = (v >> (8 * i)) & 255;
                 } else {
-                    const uint8_t *rp = ks_org_c(g, ref) + (long)(Y0 + ey + (c.mvy >> 3)) * g.sc + X0 + ex + (c.mvx >> 3);
-                    pred = chroma_pred(rp, g.sc, c.mvx & 7, c.mvy & 7);
+                    const uint8_t *rp = ks_org_c(g, ref) + (long)(Y0 + qy + (c.mvy >> 3)) * g.sc + X0 + qx + (c.mvx >> 3);
+                    chroma_pred4(rp, g.sc, c.mvx & 7, c.mvy & 7, pred);
                 }
             }
-            res = (int)S[(long)(Y0 + ey) * stride + X0 + ex] - pred;
+            const unsigned sv = *(const unsigned *)(S + (long)(Y0 + qy) * stride + X0 + qx);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) res[i] = (int)((sv >> (8 * i)) & 255) - pred[i];
         }
-        P[e] = (unsigned char)pred;
-        X[e] = (short)res;
+        *(unsigned *)(P + qy * RS + qx) = (unsigned)pred[0] | ((unsigned)pred[1] << 8) | ((unsigned)pred[2] << 16) | ((unsigned)pred[3] << 24);
+        *(uint2 *)(X + qy * RP + qx) = make_uint2(((unsigned)res[0] & 0xFFFF) | ((unsigned)res[1] << 16), ((unsigned)res[2] & 0xFFFF) | ((unsigned)res[3] << 16));
     }
     __syncthreads();
-    // per-element TU geometry
-    auto tu_of = [&](int ex, int ey, int &ox, int &oy, int &n, int &log2n, int &tb) {
-        const int bx = ex / UNIT, by = ey / UNIT, b = by * 4 + bx, t8 = 1 << tu_log2[b];
-        const int tbx = bx & ~(t8 - 1), tby = by & ~(t8 - 1);
-        ox = tbx * UNIT; oy = tby * UNIT; n = t8 * UNIT; tb = tby * 4 + tbx;
-        log2n = tu_log2[b] + (RS == 32 ? 3 : 2);
-    };
-    // ---- forward pass 1: T[k][j] = rnd(sum_x M[k][x] X[j][x], 2 log2N - 2)
-    for (int e = tid; e < NE; e += 256) {
-        const int ex = e % RS, ey = e / RS;
-        int ox, oy, n, log2n, tb; tu_of(ex, ey, ox, oy, n, log2n, tb);
-        const int k = ey - oy, j = ex - ox, s1 = 2 * log2n - 2;
-        const short *m = M32 + (k << (5 - log2n)) * 32, *xr = X + (oy + j) * RS + ox;
-        int acc = 0;
-        for (int x = 0; x < n; ++x) acc += (int)m[x] * (int)xr[x];
-        T[e] = (short)((acc + (1 << (s1 - 1))) >> s1);
+    // ---- forward pass 1: T[k][j] = rnd(M[k] . X[j], 2 log2N - 2)
+    if (has_quad) {
+        const int k = qy - oy, j = qx - ox, s1 = 2 * log2n - 2;
+        int acc[4];
+        quad_dot(mf + k * mp, X + (oy + j) * RP + ox, RP, n, acc);
+        unsigned short o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = (unsigned short)(short)((acc[i] + (1 << (s1 - 1))) >> s1);
+        *(uint2 *)(T + qy * RP + qx) = make_uint2(o[0] | ((unsigned)o[1] << 16), o[2] | ((unsigned)o[3] << 16));
     }
     __syncthreads();
-    // ---- forward pass 2 + quant + dequant (coefficient (k, j) lives at element (oy + k, ox + j))
-    const QP q = make_qp(qp, false);
-    for (int e = tid; e < NE; e += 256) {
-        const int ex = e % RS, ey = e / RS, b = (ey / UNIT) * 4 + ex / UNIT;
-        int ox, oy, n, log2n, tb; tu_of(ex, ey, ox, oy, n, log2n, tb);
-        const int k = ey - oy, j = ex - ox;
-        const short *m = M32 + (k << (5 - log2n)) * 32, *tr = T + (oy + j) * RS + ox;
-        int acc = 0;
-        for (int x = 0; x < n; ++x) acc += (int)m[x] * (int)tr[x];
-        const int coef = (short)((acc + 64) >> 7);
-        const ks265_cu8 c = blk[b];
-        int l = 0, dqv = 0;
-        if (c.log2_cu) {
-            const int qbits = 21 + q.qp6 - log2n, offF = c.pred_mode == 1 ? 171 : 85, du_unused = 0;
-            (void)du_unused;
-            int du;
-            l = quant_one(coef, q.scale, offF << (qbits - 9), qbits, du);
-            const int shift = log2n - 1;
-            dqv = dequant_one(l, q.dq, 1 << (shift - 1), shift);
-            lvl[(long)(Y0 + ey) * lstride + X0 + ex] = (int16_t)l;
-            if (l) atomicAdd(&nzcnt[tb], 1);
+    // ---- forward pass 2 + quant + dequant; coefficient (k, j) belongs to element (oy + k, ox + j); the dequantised
+    //      value is stored transposed, at (oy + j, ox + k), for the inverse passes
+    if (has_quad) {
+        const int k = qy - oy, j = qx - ox;
+        int acc[4];
+        quad_dot(mf + k * mp, T + (oy + j) * RP + ox, RP, n, acc);
+        const int qp6 = qp / 6, scale = kQuantScales[qp % 6], dqs = kInvQuantScales[qp % 6] << qp6;
+        const int qbits = 21 + qp6 - log2n, off = (c.pred_mode == 1 ? 171 : 85) << (qbits - 9), shift = log2n - 1;
+        unsigned short lv[4];
+        int nz = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int coef = (short)((acc[i] + 64) >> 7);
+            int l = 0, dqv = 0, du;
+            if (coded) {
+                l = quant_one(coef, scale, off, qbits, du);
+                dqv = dequant_one(l, dqs, 1 << (shift - 1), shift);
+                nz += l != 0;
+            }
+            lv[i] = (unsigned short)(short)l;
+            X[(oy + j + i) * RP + ox + k] = (short)dqv;
         }
-        X[e] = (short)dqv;
-    }
-    __syncthreads();
-    // ---- inverse pass 1: T[y][x] = clip16((sum_k M[k][y] C[k][x] + 64) >> 7)
-    for (int e = tid; e < NE; e += 256) {
-        const int ex = e % RS, ey = e / RS;
-        int ox, oy, n, log2n, tb; tu_of(ex, ey, ox, oy, n, log2n, tb);
-        const int y = ey - oy, sh = 5 - log2n;
-        int acc = 0;
-        if (nzcnt[tb])
-            for (int k = 0; k < n; ++k) acc += (int)M32[(k << sh) * 32 + y] * (int)X[(oy + k) * RS + ex];
-        T[e] = (short)clip16((acc + 64) >> 7);
-    }
-    __syncthreads();
-    // ---- inverse pass 2 + pred add: R = (sum_k T[y][k] M[k][x] + 2048) >> 12
-    for (int e = tid; e < NE; e += 256) {
-        const int ex = e % RS, ey = e / RS, b = (ey / UNIT) * 4 + ex / UNIT;
-        if (!blk[b].log2_cu) continue;
-        int ox, oy, n, log2n, tb; tu_of(ex, ey, ox, oy, n, log2n, tb);
-        const int x = ex - ox, sh = 5 - log2n;
-        int r = 0;
-        if (nzcnt[tb]) {
-            int acc = 0;
-            for (int k = 0; k < n; ++k) acc += (int)T[ey * RS + ox + k] * (int)M32[(k << sh) * 32 + x];
-            r = (acc + 2048) >> 12;
+        if (coded) {
+            *(uint2 *)(lvl + (long)(Y0 + qy) * lstride + X0 + qx) = make_uint2(lv[0] | ((unsigned)lv[1] << 16), lv[2] | ((unsigned)lv[3] << 16));
+            if (nz) atomicAdd(&nzcnt[tb], nz);
         }
-        Rc[(long)(Y0 + ey) * stride + X0 + ex] = (uint8_t)clip8((int)P[e] + r);
+    }
+    __syncthreads();
+    const bool live = has_quad && nzcnt[tb] != 0;
+    // ---- inverse pass 1: T[y][x] = clip16((Mt[y] . Ct[x] + 64) >> 7)
+    if (has_quad) {
+        const int y = qy - oy, x = qx - ox;
+        int acc[4] = {0, 0, 0, 0};
+        if (live) quad_dot(mt + y * mp, X + (oy + x) * RP + ox, RP, n, acc);
+        unsigned short o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = (unsigned short)(short)clip16((acc[i] + 64) >> 7);
+        *(uint2 *)(T + qy * RP + qx) = make_uint2(o[0] | ((unsigned)o[1] << 16), o[2] | ((unsigned)o[3] << 16));
+    }
+    __syncthreads();
+    // ---- inverse pass 2 + prediction add: R[y][x] = (T[y] . Mt[x] + 2048) >> 12
+    if (coded) {
+        const int x = qx - ox;
+        int acc[4] = {0, 0, 0, 0};
+        if (live) quad_dot(T + qy * RP + ox, mt + x * mp, mp, n, acc);
+        const unsigned pv = *(const unsigned *)(P + qy * RS + qx);
+        unsigned o = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = live ? (acc[i] + 2048) >> 12 : 0;
+            o |= (unsigned)clip8((int)((pv >> (8 * i)) & 255) + r) << (8 * i);
+        }
+        *(unsigned *)(Rc + (long)(Y0 + qy) * stride + X0 + qx) = o;
     }
     __syncthreads();
 }
@@ -159,17 +203,25 @@ __global__ __launch_bounds__(256) void reconstruct_kernel(KsGeom g, int qp, cons
                                                           const uint8_t *ref_u, const uint8_t *ref_v, const uint8_t *planes, ks265_cu8 *cu8,
                                                           int16_t *lvl_y, int16_t *lvl_u, int16_t *lvl_v, uint8_t *rec_y, uint8_t *rec_u, uint8_t *rec_v)
 {
-    __shared__ short M32[32 * 32];
-    __shared__ short X[32 * 32];
-    __shared__ short T[32 * 32];
-    __shared__ unsigned char P[32 * 32];
+    __shared__ __attribute__((aligned(16))) short Mf[MAT_SHORTS];
+    __shared__ __attribute__((aligned(16))) short Mt[MAT_SHORTS];
+    __shared__ __attribute__((aligned(16))) short X[32 * RP];
+    __shared__ __attribute__((aligned(16))) short T[32 * RP];
+    __shared__ __attribute__((aligned(16))) unsigned char P[32 * 32];
     __shared__ ks265_cu8 blk[16];
     __shared__ unsigned char tu_log2[16];
     __shared__ int nzcnt[16];
     __shared__ int cbf[16];
     const int tid = threadIdx.x;
     const int rx = blockIdx.x, ry = blockIdx.y;            // 32x32 region index
-    load_matrix(M32, 4, 32, tid, 256);
+    for (int l2 = 2; l2 <= 5; ++l2) {
+        const int n = 1 << l2, base = mat_off(l2), mp = n + 4;
+        for (int i = tid; i < n * n; i += 256) {
+            const int k = i / n, x = i % n, v = dct_coef(n, k, x);
+            Mf[base + k * mp + x] = (short)v;
+            Mt[base + x * mp + k] = (short)v;
+        }
+    }
     if (tid < 16) {
         const int bx = rx * 4 + (tid & 3), by = ry * 4 + (tid >> 2);
         ks265_cu8 c;
@@ -181,19 +233,19 @@ __global__ __launch_bounds__(256) void reconstruct_kernel(KsGeom g, int qp, cons
     }
     __syncthreads();
     const int qpc = chroma_qp(qp);
-    code_region<32>(g, 0, qp, rx * 4, ry * 4, blk, tu_log2, M32, X, T, P, nzcnt, src_y, nullptr, planes, lvl_y, rec_y, tid);
+    code_region<32>(g, 0, qp, rx * 4, ry * 4, blk, tu_log2, Mf, Mt, X, T, P, nzcnt, src_y, nullptr, planes, lvl_y, rec_y, tid);
     if (tid < 16 && blk[tid].log2_cu) {
         const int t8 = 1 << tu_log2[tid], tb = ((tid >> 2) & ~(t8 - 1)) * 4 + ((tid & 3) & ~(t8 - 1));
         if (nzcnt[tb]) cbf[tid] |= 1;
     }
     __syncthreads();
-    code_region<16>(g, 1, qpc, rx * 4, ry * 4, blk, tu_log2, M32, X, T, P, nzcnt, src_u, ref_u, planes, lvl_u, rec_u, tid);
+    code_region<16>(g, 1, qpc, rx * 4, ry * 4, blk, tu_log2, Mf, Mt, X, T, P, nzcnt, src_u, ref_u, planes, lvl_u, rec_u, tid);
     if (tid < 16 && blk[tid].log2_cu) {
         const int t8 = 1 << tu_log2[tid], tb = ((tid >> 2) & ~(t8 - 1)) * 4 + ((tid & 3) & ~(t8 - 1));
         if (nzcnt[tb]) cbf[tid] |= 2;
     }
     __syncthreads();
-    code_region<16>(g, 2, qpc, rx * 4, ry * 4, blk, tu_log2, M32, X, T, P, nzcnt, src_v, ref_v, planes, lvl_v, rec_v, tid);
+    code_region<16>(g, 2, qpc, rx * 4, ry * 4, blk, tu_log2, Mf, Mt, X, T, P, nzcnt, src_v, ref_v, planes, lvl_v, rec_v, tid);
     if (tid < 16 && blk[tid].log2_cu) {
         const int t8 = 1 << tu_log2[tid], tb = ((tid >> 2) & ~(t8 - 1)) * 4 + ((tid & 3) & ~(t8 - 1));
         if (nzcnt[tb]) cbf[tid] |= 4;

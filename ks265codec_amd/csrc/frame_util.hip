@@ -107,12 +107,12 @@ __device__ __forceinline__ int no_pk(int v) { asm volatile("" : "+v"(v)); return
 
 #define PT_W 64
 #define PT_H 16
-#define PT_SW 72      // source tile width  (x-3 .. x+64+4, padded to a dword multiple)
+#define PT_SW 76      // source tile width  (x-4 .. x+64+7; the horizontal pass reads 16 bytes from column x)
 #define PT_SH 23      // source tile height (y-3 .. y+16+3)
 __global__ __launch_bounds__(256) void ref_planes_kernel(KsGeom g, const uint8_t *ref, uint8_t *planes)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t S[PT_SH][PT_SW];   // dword stores: the array must be 4-byte aligned in LDS
-    __shared__ short Hm[3][PT_SH][PT_W];
+    __shared__ __attribute__((aligned(16))) uint8_t S[PT_SH][PT_SW];   // dword accesses: the array must be 4-byte aligned in LDS
+    __shared__ __attribute__((aligned(16))) short Hm[3][PT_SH][PT_W];
     const int tid = threadIdx.x;
     const int x0 = -KS_PLANE_MARGIN + blockIdx.x * PT_W, y0 = -KS_PLANE_MARGIN + blockIdx.y * PT_H;
     const uint8_t *R = ks_org_y(g, ref);
@@ -123,44 +123,83 @@ __global__ __launch_bounds__(256) void ref_planes_kernel(KsGeom g, const uint8_t
         *(unsigned *)&S[r][c * 4] = *(const unsigned *)(R + (long)yy * g.sy + x0 - 4 + c * 4);
     }
     __syncthreads();
-    // horizontal intermediates; S column of sample x is (x - x0) + 4
-    for (int i = tid; i < PT_SH * PT_W; i += 256) {
-        int r = i / PT_W, x = i - r * PT_W;
-        int s1 = 0, s2 = 0, s3 = 0;
+    // horizontal intermediates, 4 samples per work item: sample x needs S bytes x+1 .. x+8 (S column of sample x is x + 4).
+    // v_dot4_i32_i8 on (pixel - 128): sum c*(p-128) = sum c*p - 128*64, so 8192 is added back.
+    for (int i = tid; i < PT_SH * (PT_W / 4); i += 256) {
+        const int r = i / (PT_W / 4), x4 = (i - r * (PT_W / 4)) * 4;
+        const unsigned *sp = (const unsigned *)&S[r][x4];
+        const unsigned d0 = sp[0] ^ 0x80808080u, d1 = sp[1] ^ 0x80808080u, d2 = sp[2] ^ 0x80808080u, d3 = sp[3] ^ 0x80808080u;
+        short o[3][4];
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            int p = S[r][x + 1 + t];          // sample x - 3 + t
-            s1 += kLumaTaps[1][t] * p; s2 += kLumaTaps[2][t] * p; s3 += kLumaTaps[3][t] * p;
+        for (int px = 0; px < 4; ++px) {
+            // bytes x4+px+1 .. +4 and +5 .. +8
+            const unsigned lo = px == 3 ? d1 : align_bytes(d1, d0, px + 1), hi = px == 3 ? d2 : align_bytes(d2, d1, px + 1);
+#pragma unroll
+            for (int fx = 1; fx < 4; ++fx) {
+                const signed char *c = kLumaTaps[fx];
+                const int tl = (int)((unsigned)(unsigned char)c[0] | ((unsigned)(unsigned char)c[1] << 8) | ((unsigned)(unsigned char)c[2] << 16) | ((unsigned)(unsigned char)c[3] << 24));
+                const int th = (int)((unsigned)(unsigned char)c[4] | ((unsigned)(unsigned char)c[5] << 8) | ((unsigned)(unsigned char)c[6] << 16) | ((unsigned)(unsigned char)c[7] << 24));
+                int sum = __builtin_amdgcn_sdot4((int)lo, tl, 8192, false);
+                sum = __builtin_amdgcn_sdot4((int)hi, th, sum, false);
+                o[fx - 1][px] = (short)sum;
+            }
         }
-        Hm[0][r][x] = (short)s1; Hm[1][r][x] = (short)s2; Hm[2][r][x] = (short)s3;
+        (void)d3;
+#pragma unroll
+        for (int fx = 0; fx < 3; ++fx) *(uint2 *)&Hm[fx][r][x4] = *(const uint2 *)o[fx];
     }
     __syncthreads();
     const int tx = (tid & 15) * 4, ty = tid >> 4;      // 4 samples at (x0 + tx .. +3, y0 + ty)
     const int X = x0 + tx, Y = y0 + ty;
     if (X >= g.W + KS_PLANE_MARGIN || Y >= g.H + KS_PLANE_MARGIN) return;
+    // the eight tile rows ty .. ty+7 feed every vertical filter of this thread: one dword (4 source bytes) and three
+    // 8-byte reads (4 intermediates each) per row, shared by the three vertical fractions
+    int acc[3][4][4];                                   // [fy-1][plane column 0..3 (0 = source, 1..3 = Hm)][pixel]
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[a][b][c] = 0;
     unsigned out[16];
 #pragma unroll
-    for (int p = 0; p < 16; ++p) out[p] = 0;
+    for (int t = 0; t < 8; ++t) {
+        const unsigned sv = *(const unsigned *)&S[ty + t][tx + 4];
+        short hv[3][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int x = tx + i, r = ty + 3;              // row of sample Y inside the tile
-        out[0] |= (unsigned)S[r][x + 4] << (8 * i);
+        for (int k = 0; k < 3; ++k) *(uint2 *)hv[k] = *(const uint2 *)&Hm[k][ty + t][tx];
+        if (t == 3) {                                   // the row of the output sample itself: fy = 0 planes
+            out[0] = sv;
 #pragma unroll
-        for (int fx = 1; fx < 4; ++fx) out[fx] |= (unsigned)clip8(no_pk(((int)Hm[fx - 1][r][x] + 32) >> 6)) << (8 * i);
+            for (int k = 0; k < 3; ++k) {
+                unsigned v = 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v |= (unsigned)clip8(no_pk(((int)hv[k][i] + 32) >> 6)) << (8 * i);
+                out[1 + k] = v;
+            }
+        }
 #pragma unroll
         for (int fy = 1; fy < 4; ++fy) {
-            int sv = 0, s1 = 0, s2 = 0, s3 = 0;
+            const int c = kLumaTaps[fy][t];
 #pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                int c = kLumaTaps[fy][t];
-                sv += c * (int)S[ty + t][x + 4];
-                s1 += c * (int)Hm[0][ty + t][x]; s2 += c * (int)Hm[1][ty + t][x]; s3 += c * (int)Hm[2][ty + t][x];
+            for (int i = 0; i < 4; ++i) {
+                acc[fy - 1][0][i] += c * (int)((sv >> (8 * i)) & 255);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) acc[fy - 1][1 + k][i] += c * (int)hv[k][i];
             }
-            out[fy * 4 + 0] |= (unsigned)clip8(no_pk((sv + 32) >> 6)) << (8 * i);
-            out[fy * 4 + 1] |= (unsigned)clip8(no_pk((s1 + 2048) >> 12)) << (8 * i);
-            out[fy * 4 + 2] |= (unsigned)clip8(no_pk((s2 + 2048) >> 12)) << (8 * i);
-            out[fy * 4 + 3] |= (unsigned)clip8(no_pk((s3 + 2048) >> 12)) << (8 * i);
         }
+    }
+#pragma unroll
+    for (int fy = 1; fy < 4; ++fy) {
+        unsigned v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v0 |= (unsigned)clip8(no_pk((acc[fy - 1][0][i] + 32) >> 6)) << (8 * i);
+            v1 |= (unsigned)clip8(no_pk((acc[fy - 1][1][i] + 2048) >> 12)) << (8 * i);
+            v2 |= (unsigned)clip8(no_pk((acc[fy - 1][2][i] + 2048) >> 12)) << (8 * i);
+            v3 |= (unsigned)clip8(no_pk((acc[fy - 1][3][i] + 2048) >> 12)) << (8 * i);
+        }
+        out[fy * 4 + 0] = v0; out[fy * 4 + 1] = v1; out[fy * 4 + 2] = v2; out[fy * 4 + 3] = v3;
     }
     long off = g.org_y + (long)Y * g.sy + X;
 #pragma unroll
