@@ -40,7 +40,7 @@ __device__ __forceinline__ void pu_predictor(const KsGeom &g, int range, const i
 }
 
 template <int LEVEL>
-__device__ __forceinline__ void me_level(const KsGeom &g, int cx, int cy, int range, int lam, const uint8_t *win, const uint8_t *fenc, int *pmv,
+__device__ __forceinline__ void me_level(const KsGeom &g, int cx, int cy, int range, int lam, int method, const uint8_t *win, const uint8_t *fenc, int *pmv,
                                          const ks265_pu *prev_ctu, ks265_pu *out_ctu, int tid)
 {
     constexpr int S = 64 >> LEVEL;
@@ -88,50 +88,91 @@ __device__ __forceinline__ void me_level(const KsGeom &g, int cx, int cy, int ra
             unsigned c0 = group_sum<G>(seg_sad(0, 0)) + (unsigned)mv_cost(0, 0, pmx << 2, pmy << 2, lam);
             if (root && (pmx | pmy) && c0 < bcost) { bcost = c0; mx = 0; my = 0; }
         }
-        const int iters = root ? range : max(range >> 2, 1);
-        int it = 0;
-        bool active = valid;
-        bcost <<= 4;
-        while (__any(active)) {
-            // four neighbours; left / right share the centre row reads
-            unsigned s_up = seg_sad(mx, my - 1), s_dn = seg_sad(mx, my + 1), s_lf, s_rt;
-            {
-                int wx = bx0 + mx - 1 + WIN_XL, wy = by0 + my + WIN_YT;
-                const uint8_t *p = win + wy * WIN_STRIDE + (wx & ~3);
-                unsigned sl = wx & 3, sr = sl + 2;                  // right = left + 2 bytes
-                bool carry = sr >= 4;
-                sr &= 3;
-                unsigned q0 = lds_u32(p), q1 = lds_u32(p + 4);
-                s_lf = 0; s_rt = 0;
-#pragma unroll
-                for (int j = 0; j < D; ++j) {
-                    unsigned q2 = lds_u32(p + 4 * (j + 2));
-                    s_lf = sad_u8x4(f[j], align_bytes(q1, q0, sl), s_lf);
-                    s_rt = sad_u8x4(f[j], align_bytes(carry ? q2 : q1, carry ? q1 : q0, sr), s_rt);
-                    q0 = q1; q1 = q2;
+        if (method == 1) {
+            // interMeHex enc@0x48fde0 (x264-lineage hexagon search, tables hex2 enc@0x4e52e0 / mod6m1 enc@0x4e52c0): every lane of a PU
+            // carries the same (mx, my, dir); candidates outside +-range cost KS_COST_INF and are read at the (valid) origin instead
+            auto cost_at = [&](int x, int y) -> unsigned {
+                const bool in = abs(x) <= range && abs(y) <= range;
+                const unsigned sd = group_sum<G>(seg_sad(in ? x : 0, in ? y : 0));
+                return in ? sd + (unsigned)mv_cost(x << 2, y << 2, pmx << 2, pmy << 2, lam) : 0x07FFFFFFu;
+            };
+            auto hx = [](int i) { return (int)((0x01343101u >> (4 * i)) & 15u) - 2; };   // hex2[i][0] + 2 = 1,0,1,3,4,3,1,0
+            auto hy = [](int i) { return (int)((0x20024420u >> (4 * i)) & 15u) - 2; };   // hex2[i][1] + 2 = 0,2,4,4,2,0,0,2
+            unsigned bc3 = bcost << 3;
+#pragma unroll 1
+            for (int d = 0; d < 6; ++d) bc3 = min(bc3, (cost_at(mx + hx(d + 1), my + hy(d + 1)) << 3) + (unsigned)(d + 2));
+            bool moving = valid && (bc3 & 7);
+            int dir = 0;
+            if (moving) { dir = (int)(bc3 & 7) - 2; mx += hx(dir + 1); my += hy(dir + 1); }
+#pragma unroll 1
+            for (int i = (range >> 1) - 1; i > 0 && __any(moving); --i) {
+                unsigned nb = bc3 & ~7u;
+#pragma unroll 1
+                for (int k = 0; k < 3; ++k) nb = min(nb, (cost_at(mx + hx(dir + k), my + hy(dir + k)) << 3) + (unsigned)(k + 1));
+                if (moving) {
+                    bc3 = nb;
+                    if (!(bc3 & 7)) moving = false;
+                    else {
+                        dir += (int)(bc3 & 7) - 2;
+                        dir = (int)((0x05432105u >> (4 * (dir + 1))) & 15u);                  // mod6m1 = 5,0,1,2,3,4,5,0
+                        mx += hx(dir + 1); my += hy(dir + 1);
+                    }
                 }
             }
-            unsigned c[4] = {group_sum<G>(s_up), group_sum<G>(s_dn), group_sum<G>(s_lf), group_sum<G>(s_rt)};
-            if (active) {
-                const int dx[4] = {0, 0, -1, 1}, dy[4] = {-1, 1, 0, 0};
-                const unsigned code[4] = {1, 3, 4, 12};
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    int nx = mx + dx[k], ny = my + dy[k];
-                    if (abs(nx) > range || abs(ny) > range) continue;
-                    unsigned v = (c[k] << 4) + ((unsigned)mv_cost(nx << 2, ny << 2, pmx << 2, pmy << 2, lam) << 4) + code[k];
-                    bcost = min(bcost, v);
+            unsigned bc4 = (bc3 >> 3) << 4;
+            // square1 = (0,0) (0,-1) (0,1) (-1,0) (1,0) (-1,-1) (-1,1) (1,-1) (1,1)
+            auto sqx = [](int k) { return (int)((0x220020111ull >> (4 * k)) & 15ull) - 1; };
+            auto sqy = [](int k) { return (int)((0x202011201ull >> (4 * k)) & 15ull) - 1; };
+#pragma unroll 1
+            for (int k = 1; k < 9; ++k) bc4 = min(bc4, (cost_at(mx + sqx(k), my + sqy(k)) << 4) + (unsigned)k);
+            if (valid) { mx += sqx((int)(bc4 & 15)); my += sqy((int)(bc4 & 15)); }
+            bcost = bc4 >> 4;
+        } else {
+            const int iters = root ? range : max(range >> 2, 1);
+            int it = 0;
+            bool active = valid;
+            bcost <<= 4;
+            while (__any(active)) {
+                // four neighbours; left / right share the centre row reads
+                unsigned s_up = seg_sad(mx, my - 1), s_dn = seg_sad(mx, my + 1), s_lf, s_rt;
+                {
+                    int wx = bx0 + mx - 1 + WIN_XL, wy = by0 + my + WIN_YT;
+                    const uint8_t *p = win + wy * WIN_STRIDE + (wx & ~3);
+                    unsigned sl = wx & 3, sr = sl + 2;                  // right = left + 2 bytes
+                    bool carry = sr >= 4;
+                    sr &= 3;
+                    unsigned q0 = lds_u32(p), q1 = lds_u32(p + 4);
+                    s_lf = 0; s_rt = 0;
+    #pragma unroll
+                    for (int j = 0; j < D; ++j) {
+                        unsigned q2 = lds_u32(p + 4 * (j + 2));
+                        s_lf = sad_u8x4(f[j], align_bytes(q1, q0, sl), s_lf);
+                        s_rt = sad_u8x4(f[j], align_bytes(carry ? q2 : q1, carry ? q1 : q0, sr), s_rt);
+                        q0 = q1; q1 = q2;
+                    }
                 }
-                if (!(bcost & 15)) active = false;
-                else {
-                    mx -= (int)((int)(bcost << 28) >> 30);
-                    my -= (int)((int)(bcost << 30) >> 30);
-                    bcost &= ~15u;
-                    if (++it >= iters) active = false;
+                unsigned c[4] = {group_sum<G>(s_up), group_sum<G>(s_dn), group_sum<G>(s_lf), group_sum<G>(s_rt)};
+                if (active) {
+                    const int dx[4] = {0, 0, -1, 1}, dy[4] = {-1, 1, 0, 0};
+                    const unsigned code[4] = {1, 3, 4, 12};
+    #pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        int nx = mx + dx[k], ny = my + dy[k];
+                        if (abs(nx) > range || abs(ny) > range) continue;
+                        unsigned v = (c[k] << 4) + ((unsigned)mv_cost(nx << 2, ny << 2, pmx << 2, pmy << 2, lam) << 4) + code[k];
+                        bcost = min(bcost, v);
+                    }
+                    if (!(bcost & 15)) active = false;
+                    else {
+                        mx -= (int)((int)(bcost << 28) >> 30);
+                        my -= (int)((int)(bcost << 30) >> 30);
+                        bcost &= ~15u;
+                        if (++it >= iters) active = false;
+                    }
                 }
             }
+            bcost >>= 4;
         }
-        bcost >>= 4;
         if (valid && gl == 0) {
             int idx = ks_pu_index(LEVEL, px, py);
             pmv[idx] = (mx & 0xFFFF) | (my << 16);
@@ -143,7 +184,7 @@ __device__ __forceinline__ void me_level(const KsGeom &g, int cx, int cy, int ra
     }
 }
 
-__global__ __launch_bounds__(256) void me_int_kernel(KsGeom g, int range, int lam, const uint8_t *src, const uint8_t *ref, const ks265_pu *prev,
+__global__ __launch_bounds__(256) void me_int_kernel(KsGeom g, int range, int lam, int method, const uint8_t *src, const uint8_t *ref, const ks265_pu *prev,
                                                      ks265_pu *out)
 {
     __shared__ __attribute__((aligned(16))) uint8_t win[WIN_ROWS * WIN_STRIDE];
@@ -168,22 +209,22 @@ __global__ __launch_bounds__(256) void me_int_kernel(KsGeom g, int range, int la
     __syncthreads();
     const ks265_pu *prev_ctu = prev ? prev + (long)ctu * 85 : nullptr;
     ks265_pu *out_ctu = out + (long)ctu * 85;
-    me_level<0>(g, cx, cy, range, lam, win, fenc, pmv, prev_ctu, out_ctu, tid);
+    me_level<0>(g, cx, cy, range, lam, method, win, fenc, pmv, prev_ctu, out_ctu, tid);
     __syncthreads();
-    me_level<1>(g, cx, cy, range, lam, win, fenc, pmv, prev_ctu, out_ctu, tid);
+    me_level<1>(g, cx, cy, range, lam, method, win, fenc, pmv, prev_ctu, out_ctu, tid);
     __syncthreads();
-    me_level<2>(g, cx, cy, range, lam, win, fenc, pmv, prev_ctu, out_ctu, tid);
+    me_level<2>(g, cx, cy, range, lam, method, win, fenc, pmv, prev_ctu, out_ctu, tid);
     __syncthreads();
-    me_level<3>(g, cx, cy, range, lam, win, fenc, pmv, prev_ctu, out_ctu, tid);
+    me_level<3>(g, cx, cy, range, lam, method, win, fenc, pmv, prev_ctu, out_ctu, tid);
 }
 
 extern "C" int ks265_me_integer(ks265_frame *f, ks265_pic src, ks265_pic ref, const ks265_pu *prev_pu, ks265_pu *pu)
 {
     KS_FRAME_CHECK(f);
     if (!src.y || !ref.y || !pu) return KS265_POINTER;
-    if (f->cfg.me_method != 0) return KS265_NOTSUPPORTED;
+    if (f->cfg.me_method != 0 && f->cfg.me_method != 1) return KS265_NOTSUPPORTED;
     hipLaunchKernelGGL(me_int_kernel, dim3(f->g.ctu_cols * f->g.ctu_rows), dim3(256), 0, f->ctx->stream, f->g, f->cfg.me_range, f->cfg.lambda_q4,
-                       src.y, ref.y, prev_pu, pu);
+                       f->cfg.me_method, src.y, ref.y, prev_pu, pu);
     return ks265_check_launch(f->ctx);
 }
 

@@ -211,9 +211,9 @@ class KsFrame:
     """Whole-frame stages of include/ks265_hip.h section 3 (one picture size, one stream)."""
 
     def __init__(self, ks: KsContext, width: int, height: int, qp: int, lambda_q4: int, me_range: int = 64, subme: int = 1,
-                 deblock: int = 1, sao: int = 1):
+                 deblock: int = 1, sao: int = 1, me_method: int = 0):
         self.ks, self.lib = ks, ks.lib
-        self.cfg = FrameCfg(width, height, qp, lambda_q4, me_range, 0, subme, deblock, sao, 0, 0)
+        self.cfg = FrameCfg(width, height, qp, lambda_q4, me_range, me_method, subme, deblock, sao, 0, 0)
         self.geom = FrameGeom()
         ks._chk(self.lib.ks265_frame_geometry(C.byref(self.cfg), C.byref(self.geom)))
         h = C.c_void_p()

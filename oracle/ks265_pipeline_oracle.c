@@ -155,6 +155,53 @@ static void pu_predictor(const kso_frame_cfg *cfg, const kso_pu *ctu_pu, const k
     }
 }
 
+/* interMeHex enc@0x48fde0: the x264-lineage hexagon search the reference's tables describe (hex2 enc@0x4e52e0,
+ * mod6m1 enc@0x4e52c0): full hexagon, then half hexagons that do not overlap the previous one (packed (cost<<3)+dir costs),
+ * then the 8-neighbour square refinement.  Candidates outside +-range are never evaluated.  ref0 = reference sample at mv (0,0). */
+#define KSO_COST_INF 0x07FFFFFFu
+static uint32_t hex_cost(const uint8_t *fenc, const uint8_t *ref0, long st, int s, int range, int lam, int pmx, int pmy, int x, int y)
+{
+    if (iabs_(x) > range || iabs_(y) > range) return KSO_COST_INF;
+    return ks265o_sad(fenc, ref0 + (long)y * st + x, st, st, s, s) + (uint32_t)mv_cost(x << 2, y << 2, pmx << 2, pmy << 2, lam);
+}
+static uint32_t search_hex(const uint8_t *fenc, const uint8_t *ref0, long st, int s, int range, int lam, int pmx, int pmy, int *pmxo, int *pmyo,
+                           uint32_t bcost)
+{
+    static const int hex2[8][2] = {{-1, -2}, {-2, 0}, {-1, 2}, {1, 2}, {2, 0}, {1, -2}, {-1, -2}, {-2, 0}};
+    static const int mod6m1[8] = {5, 0, 1, 2, 3, 4, 5, 0};
+    static const int square1[9][2] = {{0, 0}, {0, -1}, {0, 1}, {-1, 0}, {1, 0}, {-1, -1}, {-1, 1}, {1, -1}, {1, 1}};
+    int bmx = *pmxo, bmy = *pmyo;
+    bcost <<= 3;
+    for (int d = 0; d < 6; ++d) {
+        uint32_t v = (hex_cost(fenc, ref0, st, s, range, lam, pmx, pmy, bmx + hex2[d + 1][0], bmy + hex2[d + 1][1]) << 3) + (uint32_t)(d + 2);
+        if (v < bcost) bcost = v;
+    }
+    if (bcost & 7) {
+        int dir = (int)(bcost & 7) - 2;
+        bmx += hex2[dir + 1][0]; bmy += hex2[dir + 1][1];
+        for (int i = (range >> 1) - 1; i > 0; --i) {
+            bcost &= ~7u;
+            for (int k = 0; k < 3; ++k) {
+                uint32_t v = (hex_cost(fenc, ref0, st, s, range, lam, pmx, pmy, bmx + hex2[dir + k][0], bmy + hex2[dir + k][1]) << 3) + (uint32_t)(k + 1);
+                if (v < bcost) bcost = v;
+            }
+            if (!(bcost & 7)) break;
+            dir += (int)(bcost & 7) - 2;
+            dir = mod6m1[dir + 1];
+            bmx += hex2[dir + 1][0]; bmy += hex2[dir + 1][1];
+        }
+    }
+    bcost >>= 3;
+    bcost <<= 4;
+    for (int k = 1; k < 9; ++k) {
+        uint32_t v = (hex_cost(fenc, ref0, st, s, range, lam, pmx, pmy, bmx + square1[k][0], bmy + square1[k][1]) << 4) + (uint32_t)k;
+        if (v < bcost) bcost = v;
+    }
+    bmx += square1[bcost & 15][0]; bmy += square1[bcost & 15][1];
+    *pmxo = bmx; *pmyo = bmy;
+    return bcost >> 4;
+}
+
 /* ------------------------------------------------------------------ Stage A: integer search
  * interMeDia enc@0x48fbe0 over sad4_c enc@0x47ae90, for every PU of every CTU, coarse to fine. */
 void kso_me_integer(const kso_frame_cfg *cfg, kso_pic src, kso_pic ref, const kso_pu *prev_pu, kso_pu *pu)
@@ -184,6 +231,9 @@ void kso_me_integer(const kso_frame_cfg *cfg, kso_pic src, kso_pic ref, const ks
                             uint32_t c0 = s0 + (uint32_t)mv_cost(0, 0, pmx << 2, pmy << 2, lam);
                             if (c0 < bcost) { bcost = c0; mx = 0; my = 0; }
                         }
+                        if (cfg->me_method == 1) {
+                            bcost = search_hex(fenc, R + (long)y0 * st + x0, st, s, range, lam, pmx, pmy, &mx, &my, bcost);
+                        } else {
                         int iters = root ? range : imax(range >> 2, 1), i = 0;
                         bcost <<= 4;
                         do {
@@ -203,6 +253,7 @@ void kso_me_integer(const kso_frame_cfg *cfg, kso_pic src, kso_pic ref, const ks
                             bcost &= ~15u;
                         } while (++i < iters);
                         bcost >>= 4;
+                        }
                         o->mvx = (int16_t)(mx << 2); o->mvy = (int16_t)(my << 2);
                         o->mvpx = (int16_t)(pmx << 2); o->mvpy = (int16_t)(pmy << 2);
                         o->cost = bcost;

@@ -79,9 +79,9 @@ class HostPic:
 class OraclePipeline:
     """CPU restatement of the frame stages (test checker / cpu_baseline 'port')."""
 
-    def __init__(self, width, height, qp, lambda_q4, me_range=64, subme=1, deblock=1, sao=1):
+    def __init__(self, width, height, qp, lambda_q4, me_range=64, subme=1, deblock=1, sao=1, me_method=0):
         self.o = lib()
-        self.cfg = OFrameCfg(width, height, qp, lambda_q4, me_range, 0, subme, deblock, sao, 0, 0)
+        self.cfg = OFrameCfg(width, height, qp, lambda_q4, me_range, me_method, subme, deblock, sao, 0, 0)
         self.geom = OFrameGeom()
         assert self.o.kso_frame_geometry(C.byref(self.cfg), C.byref(self.geom)) == 0
         g = self.geom

@@ -27,16 +27,16 @@ def _cmp_region(name, a, b, stride, org, w, h, margin=0):
     assert len(bad) == 0, f"{name}: {len(bad)} mismatches, first at (y,x)={bad[0] - margin} gpu={sa[tuple(bad[0])]} oracle={sb[tuple(bad[0])]}"
 
 
-@pytest.mark.parametrize("W,H,seed", [(416, 240, 1234), (200, 136, 5), (1280, 720, 43)])
-def test_stages_match_oracle(ks, W, H, seed):
+@pytest.mark.parametrize("W,H,seed,me", [(416, 240, 1234, 0), (200, 136, 5, 0), (1280, 720, 43, 0), (416, 240, 77, 1), (1280, 720, 9, 1)])
+def test_stages_match_oracle(ks, W, H, seed, me):
     from ks265codec_amd.lib import CU8, PU, SAO_PARAM, KsFrame
     from ks265codec_amd.synth import lambda_q4, make_clip
     from oracle_lib import OraclePipeline
 
     nfr = 3 if W <= 416 else 2
     clip = make_clip(W, H, nfr, seed=seed, abc=(17, 23, 9))
-    o = OraclePipeline(W, H, 27, lambda_q4(27))
-    f = KsFrame(ks, W, H, 27, lambda_q4(27))
+    o = OraclePipeline(W, H, 27, lambda_q4(27), me_method=me)
+    f = KsFrame(ks, W, H, 27, lambda_q4(27), me_method=me)
     g = f.geom
     org_y, org_c = g.pad_y * g.stride_y + g.pad_y, g.pad_c * g.stride_c + g.pad_c
     src, ref, deb, dst = f.new_pic(), f.new_pic(), f.new_pic(), f.new_pic()
