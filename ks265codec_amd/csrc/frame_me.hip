@@ -238,7 +238,6 @@ extern "C" int ks265_me_integer(ks265_frame *f, ks265_pic src, ks265_pic ref, co
 // MI355X: packed 16-bit VOP3P adds run at half rate, so packing two candidates per register buys nothing).
 // |.| + accumulate is ONE v_sad_u32 per coefficient: a bias of 2^15 added to difference (0,0) reaches every Hadamard output
 // with weight +1, so all outputs are positive and v_sad_u32(c + 2^15, 2^15, acc) = acc + |c|.
-template <int DBG>
 __device__ __forceinline__ unsigned satd8x8(const unsigned (&f)[16], const uint8_t *pp, long stride)
 {
     const unsigned sh = (unsigned)((uintptr_t)pp & 3);
@@ -247,16 +246,13 @@ __device__ __forceinline__ unsigned satd8x8(const unsigned (&f)[16], const uint8
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
         const unsigned *row = (const unsigned *)(q + r * stride);
-        unsigned a0, a1, a2;
-        if (DBG == 1) { a0 = f[r] * 3u; a1 = f[r + 1] * 5u; a2 = f[r + 2] * 7u; } else { a0 = row[0]; a1 = row[1]; a2 = row[2]; }
-        if (DBG == 2) { d[r] = (int)(a0 ^ a1 ^ a2); continue; }
+        const unsigned a0 = row[0], a1 = row[1], a2 = row[2];
         const unsigned A[2] = {align_bytes(a1, a0, sh), align_bytes(a2, a1, sh)};
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int i = 0; i < 4; ++i) d[r * 8 + h * 4 + i] = (int)((f[2 * r + h] >> (8 * i)) & 255) - (int)((A[h] >> (8 * i)) & 255);
     }
-    if (DBG == 2) { unsigned t = 0; for (int r = 0; r < 8; ++r) t ^= (unsigned)d[r]; return t & 1023u; }
     d[0] += 0x8000;
 #pragma unroll
     for (int len = 1; len < 64; len <<= 1)
@@ -292,7 +288,6 @@ __device__ __forceinline__ unsigned pu_group_sum(unsigned v, int level)
 #ifndef KS_SUBPEL_LOCKSTEP
 #define KS_SUBPEL_LOCKSTEP 1
 #endif
-template <int DBG>
 __global__ __launch_bounds__(256) void me_subpel_kernel(KsGeom g, int lam, const uint8_t *src, const uint8_t *planes, ks265_pu *pus)
 {
     const int tid = threadIdx.x, lane = tid & 63, level = tid >> 6;
@@ -340,7 +335,7 @@ __global__ __launch_bounds__(256) void me_subpel_kernel(KsGeom g, int lam, const
             const int qx = cx0 + dx * step, qy = cy0 + dy * step;
             const int ax = valid ? qx : 0, ay = valid ? qy : 0;
             const uint8_t *pp = planes + (long)((ay & 3) * 4 + (ax & 3)) * g.bytes_y + base + (long)(ay >> 2) * g.sy + (ax >> 2);
-            const unsigned sd = satd8x8<DBG>(f, pp, g.sy);
+            const unsigned sd = satd8x8(f, pp, g.sy);
             const unsigned dd = pu_group_sum(valid ? sd : 0, level);
             const unsigned cc = dd + (unsigned)mv_cost(qx, qy, p.mvpx, p.mvpy, lam);
             // phase 0 starts from nothing (n == 0 is the centre); phase 1 starts from the half-pel winner, which every
@@ -359,10 +354,7 @@ extern "C" int ks265_me_subpel(ks265_frame *f, ks265_pic src, const uint8_t *pla
 {
     KS_FRAME_CHECK(f);
     if (!src.y || !planes || !pu) return KS265_POINTER;
-    static int dbg = getenv("KS_DBG_SUBPEL") ? atoi(getenv("KS_DBG_SUBPEL")) : 0;
-    if (dbg == 1) hipLaunchKernelGGL(me_subpel_kernel<1>, dim3(f->g.ctu_cols * f->g.ctu_rows), dim3(256), 0, f->ctx->stream, f->g, f->cfg.lambda_q4, src.y, planes, pu);
-    else if (dbg == 2) hipLaunchKernelGGL(me_subpel_kernel<2>, dim3(f->g.ctu_cols * f->g.ctu_rows), dim3(256), 0, f->ctx->stream, f->g, f->cfg.lambda_q4, src.y, planes, pu);
-    else hipLaunchKernelGGL(me_subpel_kernel<0>, dim3(f->g.ctu_cols * f->g.ctu_rows), dim3(256), 0, f->ctx->stream, f->g, f->cfg.lambda_q4, src.y, planes, pu);
+    hipLaunchKernelGGL(me_subpel_kernel, dim3(f->g.ctu_cols * f->g.ctu_rows), dim3(256), 0, f->ctx->stream, f->g, f->cfg.lambda_q4, src.y, planes, pu);
     return ks265_check_launch(f->ctx);
 }
 
