@@ -121,43 +121,33 @@ def main():
         mse = sse / (npic * W * H)
         psnr_y = 99.0 if mse == 0 else 10.0 * np.log10(255.0 ** 2 / mse)
 
-        # ---- per-stage HIP-event timing on the kernel's own stream -> roofline of the dominant kernel
+        # ---- per-stage HIP-event timing IN SITU: events recorded on the kernels' own stream between the stages of
+        #      ks265_encode_picture while the real pipeline runs -> roofline of the dominant kernel
         P = float(W * H)
-        planes = ks.zeros(16 * fr.geom.bytes_y)
-        pu = [ks.zeros(fr.geom.bytes_pu), ks.zeros(fr.geom.bytes_pu)]
-        cu8, sao = ks.zeros(fr.geom.bytes_cu8), ks.zeros(fr.geom.bytes_sao)
-        lvl = [ks.zeros(W * H * 2), ks.zeros(W * H // 2), ks.zeros(W * H // 2)]
-        deb, out = fr.new_pic(), fr.new_pic()
-        ref = refs[state["cur"]]
-        src = srcs[order[state["n"] % len(order)]]
-        fr.set_qp(qp + 1, lambda_q4(qp + 1))
-        stages = {
-            "ref_planes": lambda: fr.ref_planes(ref, planes),
-            "me_integer": lambda: fr.me_integer(src, ref, pu[1], pu[0]),
-            "me_subpel": lambda: fr.me_subpel(src, planes, pu[0]),
-            "cu_decide": lambda: fr.cu_decide(pu[0], cu8),
-            "reconstruct": lambda: fr.reconstruct(src, ref, planes, cu8, lvl, deb),
-            "deblock": lambda: fr.deblock(cu8, deb),
-            "sao": lambda: fr.sao(src, deb, sao, out),
-        }
-        import ctypes as C
-        stage_ms = {}
-        reps = 10
-        fr.me_integer(src, ref, None, pu[1])           # a plausible temporal-predictor field
-        for name, fn in stages.items():
-            fn()                                        # warm
-            ks.sync()
-            ks._chk(ks.lib.ks265_timer_start(ks.h))
-            for _ in range(reps):
-                fn()
-            ms = C.c_float()
-            ks._chk(ks.lib.ks265_timer_stop_ms(ks.h, C.byref(ms)))
-            stage_ms[name] = ms.value / reps
+        fr.set_profiling(True)
+        acc, nacc = {}, 0
+        for _ in range(24):
+            key = (state["n"] % args.iper) == 0
+            step()
+            if key:
+                continue
+            ms = fr.stage_ms()
+            for k, v in ms.items():
+                acc[k] = acc.get(k, 0.0) + v
+            nacc += 1
+        fr.set_profiling(False)
+        stage_ms = {k: v / nacc for k, v in acc.items()}
         dom = max(stage_ms, key=stage_ms.get)
         algo_bytes = ALGO_BYTES_P[dom] * P
         achieved = algo_bytes / (stage_ms[dom] * 1e-3) / 1e9
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")      # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/hbm_traffic.py)
+        if os.path.exists(tfile):
+            t = json.load(open(tfile)).get(f"{W}x{H}", {}).get(dom)
+            if t:
+                traffic = t["bytes_per_launch"]
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "algorithmic_bytes_per_launch": int(algo_bytes), "avg_launch_ms": round(stage_ms[dom], 4),
                     "stages_ms": {k: round(v, 4) for k, v in stage_ms.items()},
                     "stages_frac": {k: round(ALGO_BYTES_P[k] * P / (v * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) for k, v in stage_ms.items()}}

@@ -201,6 +201,10 @@ int ks265_sao(ks265_frame *f, ks265_pic src, ks265_pic deblocked, ks265_sao_para
 /* the whole hot path for one picture: A0 (if is_key == 0) A B C D E F in stream order.
  * Workspace (planes, PU/CU/SAO records, levels) lives inside the frame object. */
 int ks265_encode_picture(ks265_frame *f, ks265_pic src, ks265_pic ref, int is_key, ks265_pic recon_out);
+/* in-situ stage timing: HIP events recorded on the context's stream between the stages of ks265_encode_picture;
+ * ms[] = {ref_planes, me_integer, me_subpel, cu_decide, reconstruct, deblock, sao(+padding)} of the last picture, -1 = not run */
+int ks265_frame_set_profiling(ks265_frame *f, int enable);
+int ks265_frame_stage_ms(ks265_frame *f, float ms[7]);
 /* accessors to the frame object's internal workspace (device pointers) */
 int16_t *ks265_frame_levels(ks265_frame *f, int comp);
 ks265_pu *ks265_frame_pu(ks265_frame *f);

@@ -52,6 +52,8 @@ void ks265_frame_destroy(ks265_frame *f)
 {
     if (!f) return;
     if (f->ctx) { hipSetDevice(f->ctx->device); hipStreamSynchronize(f->ctx->stream); }
+    for (int i = 0; i <= KS_NSTAGE; ++i)
+        if (f->ev[i]) hipEventDestroy(f->ev[i]);
     void *ptrs[] = {f->planes, f->pu[0], f->pu[1], f->cu8, f->sao, f->lvl[0], f->lvl[1], f->lvl[2], f->deb[0], f->deb[1], f->deb[2], f->sse};
     for (void *p : ptrs)
         if (p) hipFree(p);
@@ -72,21 +74,62 @@ int ks265_encode_picture(ks265_frame *f, ks265_pic src, ks265_pic ref, int is_ke
     if (!src.y || !recon_out.y) return KS265_POINTER;
     int r;
     ks265_pu *pu = f->pu[f->cur_pu];
+    int evi = 0;
+    auto mark = [&](int stage_done) {                      // stage boundary: event stage_done closes stage (stage_done - 1)
+        if (!f->profiling) return;
+        while (evi < stage_done) f->ev_valid[evi++] = false;   // skipped stages of a key picture
+        hipEventRecord(f->ev[stage_done], f->ctx->stream);
+        f->ev_valid[stage_done] = true;
+        evi = stage_done + 1;
+    };
+    mark(0);
     if (is_key) {
         if ((r = ks265_cu_flat_intra(f, f->cu8))) return r;
         f->have_prev = false;
     } else {
         if (!ref.y) return KS265_POINTER;
         if ((r = ks265_ref_planes(f, ref, f->planes))) return r;
+        mark(1);
         if ((r = ks265_me_integer(f, src, ref, f->have_prev ? f->pu[f->cur_pu ^ 1] : nullptr, pu))) return r;
+        mark(2);
         if (f->cfg.subme && (r = ks265_me_subpel(f, src, f->planes, pu))) return r;
+        mark(3);
         if ((r = ks265_cu_decide(f, pu, f->cu8))) return r;
     }
+    mark(4);
     ks265_pic deb = ks_deb_pic(f);
     if ((r = ks265_reconstruct(f, src, ref, f->planes, f->cu8, f->lvl[0], f->lvl[1], f->lvl[2], deb))) return r;
+    mark(5);
     if (f->cfg.deblock && (r = ks265_deblock(f, f->cu8, deb))) return r;
+    mark(6);
     if ((r = ks265_sao(f, src, deb, f->sao, recon_out))) return r;
+    mark(7);
     if (!is_key) { f->cur_pu ^= 1; f->have_prev = true; }
+    return KS265_OK;
+}
+
+int ks265_frame_set_profiling(ks265_frame *f, int enable)
+{
+    KS_FRAME_CHECK(f);
+    if (enable && !f->ev[0])
+        for (int i = 0; i <= KS_NSTAGE; ++i)
+            if (hipEventCreate(&f->ev[i]) != hipSuccess) return KS265_FAIL;
+    f->profiling = enable != 0;
+    return KS265_OK;
+}
+
+/* elapsed milliseconds of the stages of the LAST ks265_encode_picture call (synchronises the stream); -1 = stage not run */
+int ks265_frame_stage_ms(ks265_frame *f, float ms[7])
+{
+    KS_FRAME_CHECK(f);
+    if (!ms) return KS265_POINTER;
+    if (!f->profiling) return KS265_NOTSUPPORTED;
+    int r = ks265_hip(f->ctx, hipStreamSynchronize(f->ctx->stream));
+    if (r) return r;
+    for (int s = 0; s < KS_NSTAGE; ++s) {
+        ms[s] = -1.0f;
+        if (f->ev_valid[s] && f->ev_valid[s + 1]) hipEventElapsedTime(&ms[s], f->ev[s], f->ev[s + 1]);
+    }
     return KS265_OK;
 }
 

@@ -6,6 +6,7 @@
 #define KS_PAD_C 40
 #define KS_PLANE_MARGIN 72           // fractional planes are defined on [-72, W+72) x [-72, H+72)
 #define KS_COST_INVALID 0xFFFFFFFFu
+#define KS_NSTAGE 7                   // ref_planes, me_integer, me_subpel, cu_decide, reconstruct, deblock, sao (+ padding)
 
 // geometry handed to kernels by value
 struct KsGeom {
@@ -32,6 +33,10 @@ struct ks265_frame {
     int16_t *lvl[3] = {nullptr, nullptr, nullptr};
     uint8_t *deb[3] = {nullptr, nullptr, nullptr};   // reconstructed picture before SAO (padded geometry)
     unsigned long long *sse = nullptr;
+    // optional in-situ stage timing (HIP events on the context's stream, between the stages of ks265_encode_picture)
+    bool profiling = false;
+    hipEvent_t ev[KS_NSTAGE + 1] = {};
+    bool ev_valid[KS_NSTAGE + 1] = {};
 };
 
 static inline ks265_pic ks_deb_pic(ks265_frame *f) { return ks265_pic{f->deb[0], f->deb[1], f->deb[2]}; }

@@ -213,7 +213,10 @@ __global__ __launch_bounds__(256) void reconstruct_kernel(KsGeom g, int qp, cons
     __shared__ int nzcnt[16];
     __shared__ int cbf[16];
     const int tid = threadIdx.x;
-    const int rx = blockIdx.x, ry = blockIdx.y;            // 32x32 region index
+    // XCD-aware mapping (T1): each XCD gets a contiguous raster range of regions, so the four regions that share a 128-byte
+    // line of the source / prediction / level rows meet in one L2 instead of four (measured: FETCH_SIZE 3.9x the algorithmic reads)
+    const int nrx = (g.W + 31) / 32, nreg = nrx * ((g.H + 31) / 32);
+    const int reg = ks_xcd_swizzle(blockIdx.x, nreg), rx = reg % nrx, ry = reg / nrx;
     for (int l2 = 2; l2 <= 5; ++l2) {
         const int n = 1 << l2, base = mat_off(l2), mp = n + 4;
         for (int i = tid; i < n * n; i += 256) {
@@ -259,7 +262,7 @@ extern "C" int ks265_reconstruct(ks265_frame *f, ks265_pic src, ks265_pic ref, c
 {
     KS_FRAME_CHECK(f);
     if (!src.y || !cu8 || !lvl_y || !lvl_u || !lvl_v || !recon.y) return KS265_POINTER;
-    dim3 grid((f->g.W + 31) / 32, (f->g.H + 31) / 32);
+    dim3 grid(((f->g.W + 31) / 32) * ((f->g.H + 31) / 32));
     hipLaunchKernelGGL(reconstruct_kernel, grid, dim3(256), 0, f->ctx->stream, f->g, f->cfg.qp, src.y, src.u, src.v, ref.u, ref.v, planes, cu8, lvl_y,
                        lvl_u, lvl_v, recon.y, recon.u, recon.v);
     return ks265_check_launch(f->ctx);

@@ -114,7 +114,9 @@ __global__ __launch_bounds__(256) void ref_planes_kernel(KsGeom g, const uint8_t
     __shared__ __attribute__((aligned(16))) uint8_t S[PT_SH][PT_SW];   // dword accesses: the array must be 4-byte aligned in LDS
     __shared__ __attribute__((aligned(16))) short Hm[3][PT_SH][PT_W];
     const int tid = threadIdx.x;
-    const int x0 = -KS_PLANE_MARGIN + blockIdx.x * PT_W, y0 = -KS_PLANE_MARGIN + blockIdx.y * PT_H;
+    const int ntx = (g.W + 2 * KS_PLANE_MARGIN + PT_W - 1) / PT_W, nty = (g.H + 2 * KS_PLANE_MARGIN + PT_H - 1) / PT_H;
+    const int tile = ks_xcd_swizzle(blockIdx.x, ntx * nty);       // XCD-aware: neighbouring tiles (shared source rows / lines) in one L2
+    const int x0 = -KS_PLANE_MARGIN + (tile % ntx) * PT_W, y0 = -KS_PLANE_MARGIN + (tile / ntx) * PT_H;
     const uint8_t *R = ks_org_y(g, ref);
     // source tile: dword loads (x0 - 4 is dword aligned: origin, margin and tile width are multiples of 4)
     for (int i = tid; i < PT_SH * (PT_SW / 4); i += 256) {
@@ -210,7 +212,7 @@ extern "C" int ks265_ref_planes(ks265_frame *f, ks265_pic ref, uint8_t *planes)
 {
     KS_FRAME_CHECK(f);
     if (!ref.y || !planes) return KS265_POINTER;
-    dim3 grid((f->g.W + 2 * KS_PLANE_MARGIN + PT_W - 1) / PT_W, (f->g.H + 2 * KS_PLANE_MARGIN + PT_H - 1) / PT_H);
+    dim3 grid(((f->g.W + 2 * KS_PLANE_MARGIN + PT_W - 1) / PT_W) * ((f->g.H + 2 * KS_PLANE_MARGIN + PT_H - 1) / PT_H));
     hipLaunchKernelGGL(ref_planes_kernel, grid, dim3(256), 0, f->ctx->stream, f->g, ref.y, planes);
     return ks265_check_launch(f->ctx);
 }
@@ -226,7 +228,13 @@ __global__ __launch_bounds__(256) void sse_plane_kernel(const uint8_t *a, const 
         for (int i = 0; i < 4; ++i) { int d = (int)((va >> (8 * i)) & 255) - (int)((vb >> (8 * i)) & 255); s += (unsigned)(d * d); }
     }
     s = wave_sum(s);
-    if ((threadIdx.x & 63) == 0 && s) atomicAdd(out, (unsigned long long)s);
+    __shared__ unsigned part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned t = part[0] + part[1] + part[2] + part[3];
+        if (t) atomicAdd(out, (unsigned long long)t);
+    }
 }
 
 extern "C" int ks265_sse_picture(ks265_frame *f, ks265_pic a, ks265_pic b, uint64_t *sse3)

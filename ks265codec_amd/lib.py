@@ -53,7 +53,7 @@ EXPORTS = [
     "ks265_frame_geometry", "ks265_frame_create", "ks265_frame_destroy", "ks265_frame_set_qp", "ks265_pad_picture",
     "ks265_load_i420", "ks265_store_i420", "ks265_ref_planes", "ks265_me_integer", "ks265_me_subpel", "ks265_cu_decide",
     "ks265_cu_flat_intra", "ks265_reconstruct", "ks265_deblock", "ks265_sao", "ks265_encode_picture",
-    "ks265_frame_levels", "ks265_frame_pu", "ks265_frame_cu8", "ks265_frame_sao", "ks265_frame_planes", "ks265_sse_picture",
+    "ks265_frame_set_profiling", "ks265_frame_stage_ms", "ks265_frame_levels", "ks265_frame_pu", "ks265_frame_cu8", "ks265_frame_sao", "ks265_frame_planes", "ks265_sse_picture",
 ]
 
 
@@ -277,6 +277,16 @@ class KsFrame:
 
     def encode_picture(self, src: DevPic, ref: DevPic, is_key: bool, recon_out: DevPic):
         self.ks._chk(self.lib.ks265_encode_picture(self.h, src.c(), ref.c(), C.c_int(1 if is_key else 0), recon_out.c()))
+
+    STAGES = ("ref_planes", "me_integer", "me_subpel", "cu_decide", "reconstruct", "deblock", "sao")
+
+    def set_profiling(self, on: bool):
+        self.ks._chk(self.lib.ks265_frame_set_profiling(self.h, C.c_int(1 if on else 0)))
+
+    def stage_ms(self) -> dict:
+        ms = (C.c_float * 7)()
+        self.ks._chk(self.lib.ks265_frame_stage_ms(self.h, ms))
+        return {n: float(ms[i]) for i, n in enumerate(self.STAGES)}
 
     def sse_picture(self, a: DevPic, b: DevPic) -> np.ndarray:
         out = self.ks.zeros(24)
