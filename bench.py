@@ -2,7 +2,7 @@
 """bench.py — throughput of the HEVC encode pixel-kernel hot path on MI355X.
 
 One "step" = one picture (3840x2160 4:2:0, BASELINE.json configs[2]) through the whole hot path
-(fractional planes -> integer DIA ME -> sub-pel SATD -> CU decision -> residual/DCT/quant/dequant/IDCT/recon ->
+(fractional planes -> integer ME (UMH by default, as -preset slow) -> sub-pel SATD -> CU decision -> residual/DCT/quant/dequant/IDCT/recon ->
 deblock -> SAO -> border padding), all inputs and outputs resident in HBM.  Each rank (one per GPU) encodes its own
 GOP shard (frames/GOPs shard, no data-path collective) -> weak scaling; value = pictures of all ranks /
 max-over-ranks time.  Prints ONE JSON line on rank 0 with `roofline` (dominant kernel, HIP-event timed) and
@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--qp", type=int, default=27)
     ap.add_argument("--iper", type=int, default=128)
     ap.add_argument("--clip-frames", type=int, default=5)
+    ap.add_argument("--me", choices=["dia", "hex", "umh"], default="umh", help="integer search: -preset slow resolves to -me 2 (UMH), SURVEY.md §5")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -68,7 +69,8 @@ def main():
 
     W, H, qp = args.width, args.height, args.qp
     ks = KsContext(local_rank)
-    fr = KsFrame(ks, W, H, qp, lambda_q4(qp))
+    me_method = {"dia": 0, "hex": 1, "umh": 2}[args.me]
+    fr = KsFrame(ks, W, H, qp, lambda_q4(qp), me_method=me_method)
     # synthetic clip of SURVEY.md §8(d), one GOP shard per rank (different seed per rank = different content)
     clip = make_clip(W, H, args.clip_frames, seed=7 + rank, abc=(67, 91, 33), pan=(8, 5))
     dev_clip = [ks.dev(c) for c in clip]
@@ -156,7 +158,7 @@ def main():
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             from oracle_lib import OraclePipeline
-            o = OraclePipeline(W, H, qp, lambda_q4(qp))
+            o = OraclePipeline(W, H, qp, lambda_q4(qp), me_method=me_method)
             nb = 3
             tc0 = time.perf_counter()
             for t in range(nb):
@@ -173,7 +175,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{W}x{H} 4:2:0 8-bit, hot path only (ME + transform/quant/recon + deblock + SAO; CABAC/RC not included), "
-                                   f"-rc 0 -qp {qp} (I=Q, P=Q+1) -iper {args.iper}, IPPP, me=DIA range 64, subme=8 hpel + 8 qpel SATD, sao on, df on",
+                                   f"-rc 0 -qp {qp} (I=Q, P=Q+1) -iper {args.iper}, IPPP, -me {me_method} ({args.me.upper()}) range 64, subme=8 hpel + 8 qpel SATD, sao on, df on",
                        "pictures_per_step": 1, "sharding": "one GOP shard per GPU, no data-path collective"},
             "roofline": roofline, "cpu_baseline": cpu,
         }

@@ -23,7 +23,7 @@ int ks265_frame_create(ks265_ctx *ctx, const ks265_frame_cfg *cfg, ks265_frame *
     ks265_frame_geom geom;
     int r = ks265_frame_geometry(cfg, &geom);
     if (r) return r;
-    if (cfg->me_method != 0 && cfg->me_method != 1) return KS265_NOTSUPPORTED;   /* 0 = DIA, 1 = HEX; UMH / EPZS not built */
+    if (cfg->me_method < 0 || cfg->me_method > 2) return KS265_NOTSUPPORTED;   /* 0 = DIA, 1 = HEX, 2 = UMH (-me); EPZS / Cross not built */
     ks265_frame *f = new ks265_frame();
     f->ctx = ctx; f->cfg = *cfg; f->geom = geom;
     KsGeom &g = f->g;

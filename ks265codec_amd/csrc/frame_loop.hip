@@ -120,7 +120,16 @@ __device__ __forceinline__ int sao_offset(int sum, int cnt, int lo, int hi)
     return clip3(lo, hi, o);
 }
 
-__device__ long long sao_eval(const SaoStats *s, int type, int lam, ks265_sao_param *out)
+// per-band offset and distortion change, computed once per band (one integer division each) by 32 threads per component
+struct SaoBand { signed char off[32]; long long dd[32]; };
+__device__ __forceinline__ void sao_band_prepare(const SaoStats *s, SaoBand *b, int band)
+{
+    const int of = sao_offset(s->sum[0][band], s->cnt[0][band], -7, 7);
+    b->off[band] = (signed char)of;
+    b->dd[band] = (long long)s->cnt[0][band] * of * of - 2LL * of * s->sum[0][band];
+}
+
+__device__ long long sao_eval(const SaoStats *s, const SaoBand *bnd, int type, int lam, ks265_sao_param *out)
 {
     const long long lam2 = (long long)lam * lam;
     ks265_sao_param o;
@@ -129,18 +138,11 @@ __device__ long long sao_eval(const SaoStats *s, int type, int lam, ks265_sao_pa
     if (type == 0) {
         int best = 0; long long bd = 0;
         for (int p = 0; p <= 28; ++p) {
-            long long d = 0;
-            for (int k = 0; k < 4; ++k) {
-                const int of = sao_offset(s->sum[0][p + k], s->cnt[0][p + k], -7, 7);
-                d += (long long)s->cnt[0][p + k] * of * of - 2LL * of * s->sum[0][p + k];
-            }
+            const long long d = bnd->dd[p] + bnd->dd[p + 1] + bnd->dd[p + 2] + bnd->dd[p + 3];
             if (p == 0 || d < bd) { bd = d; best = p; }
         }
         int bits = 7;
-        for (int k = 0; k < 4; ++k) {
-            const int of = sao_offset(s->sum[0][best + k], s->cnt[0][best + k], -7, 7);
-            o.offset[k] = (int8_t)of; bits += abs(of) + 2;
-        }
+        for (int k = 0; k < 4; ++k) { o.offset[k] = bnd->off[best + k]; bits += abs((int)bnd->off[best + k]) + 2; }
         o.band = (int8_t)best;
         res = bd * 256 + lam2 * bits;
     } else {
@@ -193,6 +195,8 @@ __device__ __forceinline__ void sao_stats_block(const SaoTile<TS> &t, int bx4, i
 {
     constexpr int TP = SaoTile<TS>::TP;
     unsigned cntp[4] = {0, 0, 0, 0}, sumlo[4] = {0, 0, 0, 0}, sumhi[4] = {0, 0, 0, 0};
+    int run_band = -1;                                      // band statistics are run-length merged: neighbouring samples mostly
+    unsigned long long run_acc = 0;                         // share a band, so a 4x4 block flushes 1-3 LDS atomics instead of 16
     if (active) {
         const int x4 = bx4 * 4, y4 = by4 * 4;
         unsigned rows[6][3];
@@ -215,7 +219,11 @@ __device__ __forceinline__ void sao_stats_block(const SaoTile<TS> &t, int bx4, i
                 const int c = px(yy + 1, xx);
                 const int d = (int)(int8_t)(uint8_t)(((ov >> (8 * xx)) & 255) - c);
                 const unsigned ud = (unsigned)(d + 128);
-                atomicAdd(&acc->bo[c >> 3], ((unsigned long long)ud << 32) | 1ull);
+                if ((c >> 3) != run_band) {
+                    if (run_band >= 0) atomicAdd(&acc->bo[run_band], run_acc);
+                    run_band = c >> 3; run_acc = 0;
+                }
+                run_acc += ((unsigned long long)ud << 32) | 1ull;
                 const int X = gx + lx, Y = gy + ly;
                 const bool okL = X > 0, okR = X < picW - 1, okU = Y > 0, okD = Y < picH - 1;
                 const int e[4] = {eo_index(c, px(yy + 1, xx - 1), px(yy + 1, xx + 1)), eo_index(c, px(yy, xx), px(yy + 2, xx)),
@@ -231,6 +239,7 @@ __device__ __forceinline__ void sao_stats_block(const SaoTile<TS> &t, int bx4, i
             }
         }
     }
+    if (run_band >= 0) atomicAdd(&acc->bo[run_band], run_acc);
     // unpack, un-bias, reduce over the wave, one LDS atomic per (class, category) per wave
 #pragma unroll
     for (int k = 0; k < 4; ++k)
@@ -298,6 +307,7 @@ __global__ __launch_bounds__(256) void sao_ctu_kernel(KsGeom g, int lam, int ena
     __shared__ __attribute__((aligned(16))) SaoTile<32> tc[2];
     __shared__ __attribute__((aligned(16))) SaoAcc acc[3];
     __shared__ SaoStats st[3];
+    __shared__ SaoBand bnd[3];
     __shared__ ks265_sao_param sel[3];
     __shared__ long long jl[5], jc[5];
     __shared__ ks265_sao_param cand[3][5];
@@ -319,16 +329,18 @@ __global__ __launch_bounds__(256) void sao_ctu_kernel(KsGeom g, int lam, int ena
     sao_acc_to_stats(&acc[1], &st[1], tid, 256);
     sao_acc_to_stats(&acc[2], &st[2], tid, 256);
     __syncthreads();
+    if (tid < 96) sao_band_prepare(&st[tid >> 5], &bnd[tid >> 5], tid & 31);
+    __syncthreads();
     if (tid < 15) {                                    // 3 components x 5 types evaluated in parallel
         const int comp = tid / 5, t = tid % 5;
-        long long j = sao_eval(&st[comp], t, lam, &cand[comp][t]);
+        long long j = sao_eval(&st[comp], &bnd[comp], t, lam, &cand[comp][t]);
         if (comp == 0) jl[t] = j;
         else if (comp == 1) jc[t] = j;
     }
     __syncthreads();
     if (tid >= 10 && tid < 15) {                       // chroma cost is the sum over Cb and Cr
         ks265_sao_param tmp;
-        jc[tid - 10] += sao_eval(&st[2], tid - 10, lam, &tmp);
+        jc[tid - 10] += sao_eval(&st[2], &bnd[2], tid - 10, lam, &tmp);
     }
     __syncthreads();
     if (tid == 0) {

@@ -88,9 +88,9 @@ __device__ __forceinline__ void me_level(const KsGeom &g, int cx, int cy, int ra
             unsigned c0 = group_sum<G>(seg_sad(0, 0)) + (unsigned)mv_cost(0, 0, pmx << 2, pmy << 2, lam);
             if (root && (pmx | pmy) && c0 < bcost) { bcost = c0; mx = 0; my = 0; }
         }
-        if (method == 1) {
-            // interMeHex enc@0x48fde0 (x264-lineage hexagon search, tables hex2 enc@0x4e52e0 / mod6m1 enc@0x4e52c0): every lane of a PU
-            // carries the same (mx, my, dir); candidates outside +-range cost KS_COST_INF and are read at the (valid) origin instead
+        if (method != 0) {
+            // Every lane of a PU carries the same (mx, my, bcost); candidates outside +-range cost KS_COST_INF and are read at the
+            // (always valid) origin instead.  Groups that do not take a step keep executing it with en = false.
             auto cost_at = [&](int x, int y) -> unsigned {
                 const bool in = abs(x) <= range && abs(y) <= range;
                 const unsigned sd = group_sum<G>(seg_sad(in ? x : 0, in ? y : 0));
@@ -98,35 +98,96 @@ __device__ __forceinline__ void me_level(const KsGeom &g, int cx, int cy, int ra
             };
             auto hx = [](int i) { return (int)((0x01343101u >> (4 * i)) & 15u) - 2; };   // hex2[i][0] + 2 = 1,0,1,3,4,3,1,0
             auto hy = [](int i) { return (int)((0x20024420u >> (4 * i)) & 15u) - 2; };   // hex2[i][1] + 2 = 0,2,4,4,2,0,0,2
-            unsigned bc3 = bcost << 3;
+            // interMeHex enc@0x48fde0 (x264-lineage hexagon search, tables hex2 enc@0x4e52e0 / mod6m1 enc@0x4e52c0) + square refinement
+            auto hex_refine = [&](bool en) {
+                unsigned bc3 = bcost << 3;
 #pragma unroll 1
-            for (int d = 0; d < 6; ++d) bc3 = min(bc3, (cost_at(mx + hx(d + 1), my + hy(d + 1)) << 3) + (unsigned)(d + 2));
-            bool moving = valid && (bc3 & 7);
-            int dir = 0;
-            if (moving) { dir = (int)(bc3 & 7) - 2; mx += hx(dir + 1); my += hy(dir + 1); }
+                for (int d = 0; d < 6; ++d) bc3 = min(bc3, (cost_at(mx + hx(d + 1), my + hy(d + 1)) << 3) + (unsigned)(d + 2));
+                bool moving = en && (bc3 & 7);
+                int dir = 0;
+                if (moving) { dir = (int)(bc3 & 7) - 2; mx += hx(dir + 1); my += hy(dir + 1); }
 #pragma unroll 1
-            for (int i = (range >> 1) - 1; i > 0 && __any(moving); --i) {
-                unsigned nb = bc3 & ~7u;
+                for (int i = (range >> 1) - 1; i > 0 && __any(moving); --i) {
+                    unsigned nb = bc3 & ~7u;
 #pragma unroll 1
-                for (int k = 0; k < 3; ++k) nb = min(nb, (cost_at(mx + hx(dir + k), my + hy(dir + k)) << 3) + (unsigned)(k + 1));
-                if (moving) {
-                    bc3 = nb;
-                    if (!(bc3 & 7)) moving = false;
-                    else {
-                        dir += (int)(bc3 & 7) - 2;
-                        dir = (int)((0x05432105u >> (4 * (dir + 1))) & 15u);                  // mod6m1 = 5,0,1,2,3,4,5,0
-                        mx += hx(dir + 1); my += hy(dir + 1);
+                    for (int k = 0; k < 3; ++k) nb = min(nb, (cost_at(mx + hx(dir + k), my + hy(dir + k)) << 3) + (unsigned)(k + 1));
+                    if (moving) {
+                        bc3 = nb;
+                        if (!(bc3 & 7)) moving = false;
+                        else {
+                            dir += (int)(bc3 & 7) - 2;
+                            dir = (int)((0x05432105u >> (4 * (dir + 1))) & 15u);                  // mod6m1 = 5,0,1,2,3,4,5,0
+                            mx += hx(dir + 1); my += hy(dir + 1);
+                        }
                     }
                 }
-            }
-            unsigned bc4 = (bc3 >> 3) << 4;
-            // square1 = (0,0) (0,-1) (0,1) (-1,0) (1,0) (-1,-1) (-1,1) (1,-1) (1,1)
-            auto sqx = [](int k) { return (int)((0x220020111ull >> (4 * k)) & 15ull) - 1; };
-            auto sqy = [](int k) { return (int)((0x202011201ull >> (4 * k)) & 15ull) - 1; };
+                unsigned bc4 = (bc3 >> 3) << 4;
+                // square1 = (0,0) (0,-1) (0,1) (-1,0) (1,0) (-1,-1) (-1,1) (1,-1) (1,1)
+                auto sqx = [](int k) { return (int)((0x220020111ull >> (4 * k)) & 15ull) - 1; };
+                auto sqy = [](int k) { return (int)((0x202011201ull >> (4 * k)) & 15ull) - 1; };
 #pragma unroll 1
-            for (int k = 1; k < 9; ++k) bc4 = min(bc4, (cost_at(mx + sqx(k), my + sqy(k)) << 4) + (unsigned)k);
-            if (valid) { mx += sqx((int)(bc4 & 15)); my += sqy((int)(bc4 & 15)); }
-            bcost = bc4 >> 4;
+                for (int k = 1; k < 9; ++k) bc4 = min(bc4, (cost_at(mx + sqx(k), my + sqy(k)) << 4) + (unsigned)k);
+                if (en) { mx += sqx((int)(bc4 & 15)); my += sqy((int)(bc4 & 15)); bcost = bc4 >> 4; }
+            };
+            if (method == 1) hex_refine(valid);
+            else {
+                // interMeUMH enc@0x4907b0: x264-lineage uneven multi-hexagon search with the reference's 16-point order
+                // (Big_Hexagon_X/Y enc@0x4e5320/0x4e5300); see oracle search_umh for the step list
+                auto try_mv = [&](int x, int y, bool en) {
+                    const unsigned v = cost_at(en ? x : 0, en ? y : 0);
+                    if (en && v < bcost) { bcost = v; mx = x; my = y; }
+                };
+                auto dia1 = [&](int ox, int oy, bool en) {
+                    if (!__any(en)) return;
+                    try_mv(ox, oy - 1, en); try_mv(ox, oy + 1, en); try_mv(ox - 1, oy, en); try_mv(ox + 1, oy, en);
+                };
+                // uneven cross: +-i along x for odd i in [start, xmax), then along y in [start, ymax); start is odd for every group
+                auto cross = [&](int ox, int oy, int start, int xmax, int ymax, bool en) {
+                    if (!__any(en)) return;
+#pragma unroll 1
+                    for (int i = 1; i < xmax; i += 2) { const bool e = en && i >= start; if (!__any(e)) continue; try_mv(ox + i, oy, e); try_mv(ox - i, oy, e); }
+#pragma unroll 1
+                    for (int i = 1; i < ymax; i += 2) { const bool e = en && i >= start; if (!__any(e)) continue; try_mv(ox, oy + i, e); try_mv(ox, oy - i, e); }
+                };
+                auto nib = [](unsigned long long w, int k, int bias) { return (int)((w >> (4 * k)) & 15ull) - bias; };
+                const unsigned area = (unsigned)(S * S), th2000 = 2000u * area / 256u, th500 = 500u * area / 256u;
+                const unsigned ucost1 = bcost;
+                dia1(pmx, pmy, valid);
+                dia1(0, 0, valid && (pmx | pmy));
+                const unsigned ucost2 = bcost;
+                { const int cx0 = mx, cy0 = my; dia1(cx0, cy0, valid && (cx0 | cy0) && ((cx0 - pmx) | (cy0 - pmy))); }
+                int cross_start = bcost == ucost2 ? 3 : 1;
+                int ox = mx, oy = my;
+                bool done = false;
+                const bool et = valid && bcost == ucost2 && bcost < th2000;
+                if (__any(et)) {
+                    // (0,-2) (-1,-1) (1,-1) (-2,0) (2,0) (-1,1) (1,1) (0,2), stored +2
+#pragma unroll 1
+                    for (int k = 0; k < 8; ++k) try_mv(ox + nib(0x23140312ull, k, 2), oy + nib(0x43322110ull, k, 2), et);
+                    done = et && bcost == ucost1 && bcost < th500;
+                    const bool et2 = et && !done && bcost == ucost2;
+                    if (__any(et2)) {
+                        const int r = (range >> 1) | 1;
+                        cross(ox, oy, 3, r, r, et2);
+                        // (-1,-2) (1,-2) (-2,-1) (2,-1) (-2,1) (2,1) (-1,2) (1,2), stored +2
+#pragma unroll 1
+                        for (int k = 0; k < 8; ++k) try_mv(ox + nib(0x31404031ull, k, 2), oy + nib(0x44331100ull, k, 2), et2);
+                        if (et2) { if (bcost == ucost2) done = true; else cross_start = r + 2; }
+                    }
+                }
+                const bool mainp = valid && !done;
+                if (__any(mainp)) {
+                    cross(ox, oy, cross_start, range, range >> 1, mainp);
+                    try_mv(ox - 2, oy - 2, mainp); try_mv(ox - 2, oy + 2, mainp); try_mv(ox + 2, oy - 2, mainp); try_mv(ox + 2, oy + 2, mainp);
+                    ox = mx; oy = my;
+                    // Big_Hexagon: (-4,0)(4,0)(0,-4)(0,4)(-4,-1)(4,1)(-4,1)(4,-1)(-4,-2)(4,2)(-4,2)(4,-2)(-2,-3)(2,3)(-2,3)(2,-3), stored +4
+#pragma unroll 1
+                    for (int i = 1; i <= range >> 2; ++i)
+#pragma unroll 1
+                        for (int j = 0; j < 16; ++j) try_mv(ox + nib(0x6262808080804480ull, j, 4) * i, oy + nib(0x1771266235538044ull, j, 4) * i, mainp);
+                    hex_refine(mainp);
+                }
+            }
         } else {
             const int iters = root ? range : max(range >> 2, 1);
             int it = 0;
@@ -222,7 +283,7 @@ extern "C" int ks265_me_integer(ks265_frame *f, ks265_pic src, ks265_pic ref, co
 {
     KS_FRAME_CHECK(f);
     if (!src.y || !ref.y || !pu) return KS265_POINTER;
-    if (f->cfg.me_method != 0 && f->cfg.me_method != 1) return KS265_NOTSUPPORTED;
+    if (f->cfg.me_method < 0 || f->cfg.me_method > 2) return KS265_NOTSUPPORTED;
     hipLaunchKernelGGL(me_int_kernel, dim3(f->g.ctu_cols * f->g.ctu_rows), dim3(256), 0, f->ctx->stream, f->g, f->cfg.me_range, f->cfg.lambda_q4,
                        f->cfg.me_method, src.y, ref.y, prev_pu, pu);
     return ks265_check_launch(f->ctx);

@@ -202,6 +202,66 @@ static uint32_t search_hex(const uint8_t *fenc, const uint8_t *ref0, long st, in
     return bcost >> 4;
 }
 
+/* interMeUMH enc@0x4907b0: uneven multi-hexagon search.  The reference's control code is closed; its tables (SURVEY.md B.11:
+ * Big_Hexagon_X/Y enc@0x4e5320/0x4e5300, hex2, mod6m1) are those of the x264 lineage it follows, so the published
+ * x264 algorithm is restated with the reference's 16-point order: radius-1 diamonds at the predictor / zero / best, early
+ * termination (SAD thresholds 2000 / 500 scaled from a 16x16 block to the PU area), uneven cross, 5x5 corners, 16-point hexagon
+ * grid at radii 4 .. 4*(range/4), then the hexagon + square refinement of search_hex. */
+typedef struct { const uint8_t *fenc, *ref0; long st; int s, range, lam, pmx, pmy; int bmx, bmy; uint32_t bcost; } umh_ctx;
+static void umh_try(umh_ctx *c, int x, int y)
+{
+    uint32_t v = hex_cost(c->fenc, c->ref0, c->st, c->s, c->range, c->lam, c->pmx, c->pmy, x, y);
+    if (v < c->bcost) { c->bcost = v; c->bmx = x; c->bmy = y; }
+}
+static void umh_dia1(umh_ctx *c, int ox, int oy) { umh_try(c, ox, oy - 1); umh_try(c, ox, oy + 1); umh_try(c, ox - 1, oy); umh_try(c, ox + 1, oy); }
+static void umh_cross(umh_ctx *c, int ox, int oy, int start, int xmax, int ymax)
+{
+    for (int i = start; i < xmax; i += 2) { umh_try(c, ox + i, oy); umh_try(c, ox - i, oy); }
+    for (int i = start; i < ymax; i += 2) { umh_try(c, ox, oy + i); umh_try(c, ox, oy - i); }
+}
+static uint32_t search_umh(const uint8_t *fenc, const uint8_t *ref0, long st, int s, int range, int lam, int pmx, int pmy, int *pmxo, int *pmyo,
+                           uint32_t bcost)
+{
+    static const int bhx[16] = {-4, 4, 0, 0, -4, 4, -4, 4, -4, 4, -4, 4, -2, 2, -2, 2};
+    static const int bhy[16] = {0, 0, -4, 4, -1, 1, 1, -1, -2, 2, 2, -2, -3, 3, 3, -3};
+    umh_ctx c = {fenc, ref0, st, s, range, lam, pmx, pmy, *pmxo, *pmyo, bcost};
+    const uint32_t area = (uint32_t)s * (uint32_t)s;
+    const uint32_t th2000 = 2000u * area / 256u, th500 = 500u * area / 256u;
+    int cross_start = 1, done = 0;
+    uint32_t ucost1 = c.bcost, ucost2;
+    umh_dia1(&c, pmx, pmy);
+    if (pmx | pmy) umh_dia1(&c, 0, 0);
+    ucost2 = c.bcost;
+    if ((c.bmx | c.bmy) && ((c.bmx - pmx) | (c.bmy - pmy))) umh_dia1(&c, c.bmx, c.bmy);
+    if (c.bcost == ucost2) cross_start = 3;
+    int ox = c.bmx, oy = c.bmy;
+    if (c.bcost == ucost2 && c.bcost < th2000) {
+        static const int o8x[8] = {0, -1, 1, -2, 2, -1, 1, 0}, o8y[8] = {-2, -1, -1, 0, 0, 1, 1, 2};
+        for (int k = 0; k < 8; ++k) umh_try(&c, ox + o8x[k], oy + o8y[k]);
+        if (c.bcost == ucost1 && c.bcost < th500) done = 1;
+        else if (c.bcost == ucost2) {
+            int r = (range >> 1) | 1;
+            static const int o8bx[8] = {-1, 1, -2, 2, -2, 2, -1, 1}, o8by[8] = {-2, -2, -1, -1, 1, 1, 2, 2};
+            umh_cross(&c, ox, oy, 3, r, r);
+            for (int k = 0; k < 8; ++k) umh_try(&c, ox + o8bx[k], oy + o8by[k]);
+            if (c.bcost == ucost2) done = 1;
+            else cross_start = r + 2;
+        }
+    }
+    if (!done) {
+        static const int c4x[4] = {-2, -2, 2, 2}, c4y[4] = {-2, 2, -2, 2};
+        umh_cross(&c, ox, oy, cross_start, range, range >> 1);
+        for (int k = 0; k < 4; ++k) umh_try(&c, ox + c4x[k], oy + c4y[k]);
+        ox = c.bmx; oy = c.bmy;
+        for (int i = 1; i <= range >> 2; ++i)
+            for (int j = 0; j < 16; ++j) umh_try(&c, ox + bhx[j] * i, oy + bhy[j] * i);
+        *pmxo = c.bmx; *pmyo = c.bmy;
+        return search_hex(fenc, ref0, st, s, range, lam, pmx, pmy, pmxo, pmyo, c.bcost);
+    }
+    *pmxo = c.bmx; *pmyo = c.bmy;
+    return c.bcost;
+}
+
 /* ------------------------------------------------------------------ Stage A: integer search
  * interMeDia enc@0x48fbe0 over sad4_c enc@0x47ae90, for every PU of every CTU, coarse to fine. */
 void kso_me_integer(const kso_frame_cfg *cfg, kso_pic src, kso_pic ref, const kso_pu *prev_pu, kso_pu *pu)
@@ -233,6 +293,8 @@ void kso_me_integer(const kso_frame_cfg *cfg, kso_pic src, kso_pic ref, const ks
                         }
                         if (cfg->me_method == 1) {
                             bcost = search_hex(fenc, R + (long)y0 * st + x0, st, s, range, lam, pmx, pmy, &mx, &my, bcost);
+                        } else if (cfg->me_method == 2) {
+                            bcost = search_umh(fenc, R + (long)y0 * st + x0, st, s, range, lam, pmx, pmy, &mx, &my, bcost);
                         } else {
                         int iters = root ? range : imax(range >> 2, 1), i = 0;
                         bcost <<= 4;

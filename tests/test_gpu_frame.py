@@ -27,7 +27,7 @@ def _cmp_region(name, a, b, stride, org, w, h, margin=0):
     assert len(bad) == 0, f"{name}: {len(bad)} mismatches, first at (y,x)={bad[0] - margin} gpu={sa[tuple(bad[0])]} oracle={sb[tuple(bad[0])]}"
 
 
-@pytest.mark.parametrize("W,H,seed,me", [(416, 240, 1234, 0), (200, 136, 5, 0), (1280, 720, 43, 0), (416, 240, 77, 1), (1280, 720, 9, 1)])
+@pytest.mark.parametrize("W,H,seed,me", [(416, 240, 1234, 0), (200, 136, 5, 0), (1280, 720, 43, 0), (416, 240, 77, 1), (1280, 720, 9, 1), (416, 240, 31, 2), (200, 136, 8, 2), (1280, 720, 21, 2)])
 def test_stages_match_oracle(ks, W, H, seed, me):
     from ks265codec_amd.lib import CU8, PU, SAO_PARAM, KsFrame
     from ks265codec_amd.synth import lambda_q4, make_clip
