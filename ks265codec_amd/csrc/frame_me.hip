@@ -8,6 +8,7 @@
 //            vertical Hadamard across lanes.
 //   Stage C  ks265_cu_decide  : bottom-up quadtree compare.
 #include "frame_common.h"
+#include <type_traits>
 
 using namespace ks265;
 
@@ -89,6 +90,7 @@ __device__ __forceinline__ void me_level(const KsGeom &g, int cx, int cy, int ra
             if (root && (pmx | pmy) && c0 < bcost) { bcost = c0; mx = 0; my = 0; }
         }
         if (method != 0) {
+            const int ext = root ? range : max(range >> 2, 4);     // pattern extent (see oracle): full range for a root PU, a quarter around an inherited vector
             // Every lane of a PU carries the same (mx, my, bcost); candidates outside +-range cost KS_COST_INF and are read at the
             // (always valid) origin instead.  Groups that do not take a step keep executing it with en = false.
             auto cost_at = [&](int x, int y) -> unsigned {
@@ -96,21 +98,48 @@ __device__ __forceinline__ void me_level(const KsGeom &g, int cx, int cy, int ra
                 const unsigned sd = group_sum<G>(seg_sad(in ? x : 0, in ? y : 0));
                 return in ? sd + (unsigned)mv_cost(x << 2, y << 2, pmx << 2, pmy << 2, lam) : 0x07FFFFFFu;
             };
+            // N candidates at once: the N partial SADs are accumulated first and the N group reductions (DPP / swizzle chains)
+            // are then independent instruction streams the scheduler interleaves - the search is latency bound, not ALU bound
+            auto cost_multi = [&](auto n_tag, const int *xs, const int *ys, unsigned *out) {
+                constexpr int N = decltype(n_tag)::value;
+                unsigned part[N];
+#pragma unroll
+                for (int n = 0; n < N; ++n) {
+                    const bool in = abs(xs[n]) <= range && abs(ys[n]) <= range;
+                    part[n] = seg_sad(in ? xs[n] : 0, in ? ys[n] : 0);
+                }
+#pragma unroll
+                for (int n = 0; n < N; ++n) {
+                    const bool in = abs(xs[n]) <= range && abs(ys[n]) <= range;
+                    const unsigned sd = group_sum<G>(part[n]);
+                    out[n] = in ? sd + (unsigned)mv_cost(xs[n] << 2, ys[n] << 2, pmx << 2, pmy << 2, lam) : 0x07FFFFFFu;
+                }
+            };
             auto hx = [](int i) { return (int)((0x01343101u >> (4 * i)) & 15u) - 2; };   // hex2[i][0] + 2 = 1,0,1,3,4,3,1,0
             auto hy = [](int i) { return (int)((0x20024420u >> (4 * i)) & 15u) - 2; };   // hex2[i][1] + 2 = 0,2,4,4,2,0,0,2
             // interMeHex enc@0x48fde0 (x264-lineage hexagon search, tables hex2 enc@0x4e52e0 / mod6m1 enc@0x4e52c0) + square refinement
             auto hex_refine = [&](bool en) {
                 unsigned bc3 = bcost << 3;
-#pragma unroll 1
-                for (int d = 0; d < 6; ++d) bc3 = min(bc3, (cost_at(mx + hx(d + 1), my + hy(d + 1)) << 3) + (unsigned)(d + 2));
+                {
+                    int xs[6], ys[6]; unsigned c6[6];
+#pragma unroll
+                    for (int d = 0; d < 6; ++d) { xs[d] = mx + hx(d + 1); ys[d] = my + hy(d + 1); }
+                    cost_multi(std::integral_constant<int, 6>{}, xs, ys, c6);
+#pragma unroll
+                    for (int d = 0; d < 6; ++d) bc3 = min(bc3, (c6[d] << 3) + (unsigned)(d + 2));
+                }
                 bool moving = en && (bc3 & 7);
                 int dir = 0;
                 if (moving) { dir = (int)(bc3 & 7) - 2; mx += hx(dir + 1); my += hy(dir + 1); }
 #pragma unroll 1
-                for (int i = (range >> 1) - 1; i > 0 && __any(moving); --i) {
+                for (int i = (ext >> 1) - 1; i > 0 && __any(moving); --i) {
                     unsigned nb = bc3 & ~7u;
-#pragma unroll 1
-                    for (int k = 0; k < 3; ++k) nb = min(nb, (cost_at(mx + hx(dir + k), my + hy(dir + k)) << 3) + (unsigned)(k + 1));
+                    int xs[3], ys[3]; unsigned c3[3];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) { xs[k] = mx + hx(dir + k); ys[k] = my + hy(dir + k); }
+                    cost_multi(std::integral_constant<int, 3>{}, xs, ys, c3);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) nb = min(nb, (c3[k] << 3) + (unsigned)(k + 1));
                     if (moving) {
                         bc3 = nb;
                         if (!(bc3 & 7)) moving = false;
@@ -125,29 +154,55 @@ __device__ __forceinline__ void me_level(const KsGeom &g, int cx, int cy, int ra
                 // square1 = (0,0) (0,-1) (0,1) (-1,0) (1,0) (-1,-1) (-1,1) (1,-1) (1,1)
                 auto sqx = [](int k) { return (int)((0x220020111ull >> (4 * k)) & 15ull) - 1; };
                 auto sqy = [](int k) { return (int)((0x202011201ull >> (4 * k)) & 15ull) - 1; };
-#pragma unroll 1
-                for (int k = 1; k < 9; ++k) bc4 = min(bc4, (cost_at(mx + sqx(k), my + sqy(k)) << 4) + (unsigned)k);
+                {
+                    int xs[8], ys[8]; unsigned c8[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) { xs[k] = mx + sqx(k + 1); ys[k] = my + sqy(k + 1); }
+                    cost_multi(std::integral_constant<int, 8>{}, xs, ys, c8);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) bc4 = min(bc4, (c8[k] << 4) + (unsigned)(k + 1));
+                }
                 if (en) { mx += sqx((int)(bc4 & 15)); my += sqy((int)(bc4 & 15)); bcost = bc4 >> 4; }
             };
             if (method == 1) hex_refine(valid);
             else {
                 // interMeUMH enc@0x4907b0: x264-lineage uneven multi-hexagon search with the reference's 16-point order
                 // (Big_Hexagon_X/Y enc@0x4e5320/0x4e5300); see oracle search_umh for the step list
-                auto try_mv = [&](int x, int y, bool en) {
-                    const unsigned v = cost_at(en ? x : 0, en ? y : 0);
-                    if (en && v < bcost) { bcost = v; mx = x; my = y; }
+                // N candidates evaluated together, then taken in order with the sequential "strictly better" rule of the reference
+                auto try_multi = [&](auto n_tag, const int *xs, const int *ys, bool en) {
+                    constexpr int N = decltype(n_tag)::value;
+                    int ax[N], ay[N]; unsigned cs[N];
+#pragma unroll
+                    for (int n = 0; n < N; ++n) { ax[n] = en ? xs[n] : 0; ay[n] = en ? ys[n] : 0; }
+                    cost_multi(n_tag, ax, ay, cs);
+#pragma unroll
+                    for (int n = 0; n < N; ++n)
+                        if (en && cs[n] < bcost) { bcost = cs[n]; mx = xs[n]; my = ys[n]; }
                 };
                 auto dia1 = [&](int ox, int oy, bool en) {
                     if (!__any(en)) return;
-                    try_mv(ox, oy - 1, en); try_mv(ox, oy + 1, en); try_mv(ox - 1, oy, en); try_mv(ox + 1, oy, en);
+                    const int xs[4] = {ox, ox, ox - 1, ox + 1}, ys[4] = {oy - 1, oy + 1, oy, oy};
+                    try_multi(std::integral_constant<int, 4>{}, xs, ys, en);
                 };
-                // uneven cross: +-i along x for odd i in [start, xmax), then along y in [start, ymax); start is odd for every group
+                // uneven cross: +-i along x for odd i in [start, xmax), then along y in [start, ymax); start is odd for every group.
+                // Four candidates (+i, -i, +(i+2), -(i+2)) per step.
                 auto cross = [&](int ox, int oy, int start, int xmax, int ymax, bool en) {
                     if (!__any(en)) return;
 #pragma unroll 1
-                    for (int i = 1; i < xmax; i += 2) { const bool e = en && i >= start; if (!__any(e)) continue; try_mv(ox + i, oy, e); try_mv(ox - i, oy, e); }
+                    for (int i = 1; i < xmax; i += 4) {
+                        const bool e0 = en && i >= start, e1 = en && i + 2 >= start && i + 2 < xmax;
+                        if (!__any(e0 || e1)) continue;
+                        // a disabled pair is parked on an out-of-range coordinate: it costs KS_COST_INF and can never win
+                        const int xs[4] = {e0 ? ox + i : 1000, e0 ? ox - i : 1000, e1 ? ox + i + 2 : 1000, e1 ? ox - i - 2 : 1000}, ys[4] = {oy, oy, oy, oy};
+                        try_multi(std::integral_constant<int, 4>{}, xs, ys, e0 || e1);
+                    }
 #pragma unroll 1
-                    for (int i = 1; i < ymax; i += 2) { const bool e = en && i >= start; if (!__any(e)) continue; try_mv(ox, oy + i, e); try_mv(ox, oy - i, e); }
+                    for (int i = 1; i < ymax; i += 4) {
+                        const bool e0 = en && i >= start, e1 = en && i + 2 >= start && i + 2 < ymax;
+                        if (!__any(e0 || e1)) continue;
+                        const int xs[4] = {ox, ox, ox, ox}, ys[4] = {e0 ? oy + i : 1000, e0 ? oy - i : 1000, e1 ? oy + i + 2 : 1000, e1 ? oy - i - 2 : 1000};
+                        try_multi(std::integral_constant<int, 4>{}, xs, ys, e0 || e1);
+                    }
                 };
                 auto nib = [](unsigned long long w, int k, int bias) { return (int)((w >> (4 * k)) & 15ull) - bias; };
                 const unsigned area = (unsigned)(S * S), th2000 = 2000u * area / 256u, th500 = 500u * area / 256u;
@@ -162,29 +217,45 @@ __device__ __forceinline__ void me_level(const KsGeom &g, int cx, int cy, int ra
                 const bool et = valid && bcost == ucost2 && bcost < th2000;
                 if (__any(et)) {
                     // (0,-2) (-1,-1) (1,-1) (-2,0) (2,0) (-1,1) (1,1) (0,2), stored +2
-#pragma unroll 1
-                    for (int k = 0; k < 8; ++k) try_mv(ox + nib(0x23140312ull, k, 2), oy + nib(0x43322110ull, k, 2), et);
+                    {
+                        int xs[8], ys[8];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) { xs[k] = ox + nib(0x23140312ull, k, 2); ys[k] = oy + nib(0x43322110ull, k, 2); }
+                        try_multi(std::integral_constant<int, 8>{}, xs, ys, et);
+                    }
                     done = et && bcost == ucost1 && bcost < th500;
                     const bool et2 = et && !done && bcost == ucost2;
                     if (__any(et2)) {
-                        const int r = (range >> 1) | 1;
+                        const int r = (ext >> 1) | 1;
                         cross(ox, oy, 3, r, r, et2);
                         // (-1,-2) (1,-2) (-2,-1) (2,-1) (-2,1) (2,1) (-1,2) (1,2), stored +2
-#pragma unroll 1
-                        for (int k = 0; k < 8; ++k) try_mv(ox + nib(0x31404031ull, k, 2), oy + nib(0x44331100ull, k, 2), et2);
+                        {
+                            int xs[8], ys[8];
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) { xs[k] = ox + nib(0x31404031ull, k, 2); ys[k] = oy + nib(0x44331100ull, k, 2); }
+                            try_multi(std::integral_constant<int, 8>{}, xs, ys, et2);
+                        }
                         if (et2) { if (bcost == ucost2) done = true; else cross_start = r + 2; }
                     }
                 }
                 const bool mainp = valid && !done;
                 if (__any(mainp)) {
-                    cross(ox, oy, cross_start, range, range >> 1, mainp);
-                    try_mv(ox - 2, oy - 2, mainp); try_mv(ox - 2, oy + 2, mainp); try_mv(ox + 2, oy - 2, mainp); try_mv(ox + 2, oy + 2, mainp);
+                    cross(ox, oy, cross_start, ext, ext >> 1, mainp);
+                    {
+                        const int xs[4] = {ox - 2, ox - 2, ox + 2, ox + 2}, ys[4] = {oy - 2, oy + 2, oy - 2, oy + 2};
+                        try_multi(std::integral_constant<int, 4>{}, xs, ys, mainp);
+                    }
                     ox = mx; oy = my;
                     // Big_Hexagon: (-4,0)(4,0)(0,-4)(0,4)(-4,-1)(4,1)(-4,1)(4,-1)(-4,-2)(4,2)(-4,2)(4,-2)(-2,-3)(2,3)(-2,3)(2,-3), stored +4
 #pragma unroll 1
-                    for (int i = 1; i <= range >> 2; ++i)
+                    for (int i = 1; i <= (range >> 2) && __any(mainp && i <= (ext >> 2)); ++i)
 #pragma unroll 1
-                        for (int j = 0; j < 16; ++j) try_mv(ox + nib(0x6262808080804480ull, j, 4) * i, oy + nib(0x1771266235538044ull, j, 4) * i, mainp);
+                        for (int j0 = 0; j0 < 16; j0 += 8) {
+                            int xs[8], ys[8];
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) { xs[j] = ox + nib(0x6262808080804480ull, j0 + j, 4) * i; ys[j] = oy + nib(0x1771266235538044ull, j0 + j, 4) * i; }
+                            try_multi(std::integral_constant<int, 8>{}, xs, ys, mainp && i <= (ext >> 2));
+                        }
                     hex_refine(mainp);
                 }
             }

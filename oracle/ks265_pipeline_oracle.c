@@ -164,7 +164,7 @@ static uint32_t hex_cost(const uint8_t *fenc, const uint8_t *ref0, long st, int 
     if (iabs_(x) > range || iabs_(y) > range) return KSO_COST_INF;
     return ks265o_sad(fenc, ref0 + (long)y * st + x, st, st, s, s) + (uint32_t)mv_cost(x << 2, y << 2, pmx << 2, pmy << 2, lam);
 }
-static uint32_t search_hex(const uint8_t *fenc, const uint8_t *ref0, long st, int s, int range, int lam, int pmx, int pmy, int *pmxo, int *pmyo,
+static uint32_t search_hex(const uint8_t *fenc, const uint8_t *ref0, long st, int s, int range, int ext, int lam, int pmx, int pmy, int *pmxo, int *pmyo,
                            uint32_t bcost)
 {
     static const int hex2[8][2] = {{-1, -2}, {-2, 0}, {-1, 2}, {1, 2}, {2, 0}, {1, -2}, {-1, -2}, {-2, 0}};
@@ -179,7 +179,7 @@ static uint32_t search_hex(const uint8_t *fenc, const uint8_t *ref0, long st, in
     if (bcost & 7) {
         int dir = (int)(bcost & 7) - 2;
         bmx += hex2[dir + 1][0]; bmy += hex2[dir + 1][1];
-        for (int i = (range >> 1) - 1; i > 0; --i) {
+        for (int i = (ext >> 1) - 1; i > 0; --i) {
             bcost &= ~7u;
             for (int k = 0; k < 3; ++k) {
                 uint32_t v = (hex_cost(fenc, ref0, st, s, range, lam, pmx, pmy, bmx + hex2[dir + k][0], bmy + hex2[dir + k][1]) << 3) + (uint32_t)(k + 1);
@@ -206,7 +206,7 @@ static uint32_t search_hex(const uint8_t *fenc, const uint8_t *ref0, long st, in
  * Big_Hexagon_X/Y enc@0x4e5320/0x4e5300, hex2, mod6m1) are those of the x264 lineage it follows, so the published
  * x264 algorithm is restated with the reference's 16-point order: radius-1 diamonds at the predictor / zero / best, early
  * termination (SAD thresholds 2000 / 500 scaled from a 16x16 block to the PU area), uneven cross, 5x5 corners, 16-point hexagon
- * grid at radii 4 .. 4*(range/4), then the hexagon + square refinement of search_hex. */
+ * grid at radii 4 .. 4*(ext/4), then the hexagon + square refinement of search_hex.  `ext` = pattern extent, `range` = validity clamp. */
 typedef struct { const uint8_t *fenc, *ref0; long st; int s, range, lam, pmx, pmy; int bmx, bmy; uint32_t bcost; } umh_ctx;
 static void umh_try(umh_ctx *c, int x, int y)
 {
@@ -219,7 +219,7 @@ static void umh_cross(umh_ctx *c, int ox, int oy, int start, int xmax, int ymax)
     for (int i = start; i < xmax; i += 2) { umh_try(c, ox + i, oy); umh_try(c, ox - i, oy); }
     for (int i = start; i < ymax; i += 2) { umh_try(c, ox, oy + i); umh_try(c, ox, oy - i); }
 }
-static uint32_t search_umh(const uint8_t *fenc, const uint8_t *ref0, long st, int s, int range, int lam, int pmx, int pmy, int *pmxo, int *pmyo,
+static uint32_t search_umh(const uint8_t *fenc, const uint8_t *ref0, long st, int s, int range, int ext, int lam, int pmx, int pmy, int *pmxo, int *pmyo,
                            uint32_t bcost)
 {
     static const int bhx[16] = {-4, 4, 0, 0, -4, 4, -4, 4, -4, 4, -4, 4, -2, 2, -2, 2};
@@ -240,7 +240,7 @@ static uint32_t search_umh(const uint8_t *fenc, const uint8_t *ref0, long st, in
         for (int k = 0; k < 8; ++k) umh_try(&c, ox + o8x[k], oy + o8y[k]);
         if (c.bcost == ucost1 && c.bcost < th500) done = 1;
         else if (c.bcost == ucost2) {
-            int r = (range >> 1) | 1;
+            int r = (ext >> 1) | 1;
             static const int o8bx[8] = {-1, 1, -2, 2, -2, 2, -1, 1}, o8by[8] = {-2, -2, -1, -1, 1, 1, 2, 2};
             umh_cross(&c, ox, oy, 3, r, r);
             for (int k = 0; k < 8; ++k) umh_try(&c, ox + o8bx[k], oy + o8by[k]);
@@ -250,13 +250,13 @@ static uint32_t search_umh(const uint8_t *fenc, const uint8_t *ref0, long st, in
     }
     if (!done) {
         static const int c4x[4] = {-2, -2, 2, 2}, c4y[4] = {-2, 2, -2, 2};
-        umh_cross(&c, ox, oy, cross_start, range, range >> 1);
+        umh_cross(&c, ox, oy, cross_start, ext, ext >> 1);
         for (int k = 0; k < 4; ++k) umh_try(&c, ox + c4x[k], oy + c4y[k]);
         ox = c.bmx; oy = c.bmy;
-        for (int i = 1; i <= range >> 2; ++i)
+        for (int i = 1; i <= ext >> 2; ++i)
             for (int j = 0; j < 16; ++j) umh_try(&c, ox + bhx[j] * i, oy + bhy[j] * i);
         *pmxo = c.bmx; *pmyo = c.bmy;
-        return search_hex(fenc, ref0, st, s, range, lam, pmx, pmy, pmxo, pmyo, c.bcost);
+        return search_hex(fenc, ref0, st, s, range, ext, lam, pmx, pmy, pmxo, pmyo, c.bcost);
     }
     *pmxo = c.bmx; *pmyo = c.bmy;
     return c.bcost;
@@ -291,10 +291,13 @@ void kso_me_integer(const kso_frame_cfg *cfg, kso_pic src, kso_pic ref, const ks
                             uint32_t c0 = s0 + (uint32_t)mv_cost(0, 0, pmx << 2, pmy << 2, lam);
                             if (c0 < bcost) { bcost = c0; mx = 0; my = 0; }
                         }
+                        /* pattern extent: the full range for a root PU, a quarter of it (>= 4) around an inherited vector
+                         * (the reference shrinks merange per PU: TPredUnit+0x1f1 range shift) */
+                        const int ext = root ? range : imax(range >> 2, 4);
                         if (cfg->me_method == 1) {
-                            bcost = search_hex(fenc, R + (long)y0 * st + x0, st, s, range, lam, pmx, pmy, &mx, &my, bcost);
+                            bcost = search_hex(fenc, R + (long)y0 * st + x0, st, s, range, ext, lam, pmx, pmy, &mx, &my, bcost);
                         } else if (cfg->me_method == 2) {
-                            bcost = search_umh(fenc, R + (long)y0 * st + x0, st, s, range, lam, pmx, pmy, &mx, &my, bcost);
+                            bcost = search_umh(fenc, R + (long)y0 * st + x0, st, s, range, ext, lam, pmx, pmy, &mx, &my, bcost);
                         } else {
                         int iters = root ? range : imax(range >> 2, 1), i = 0;
                         bcost <<= 4;
