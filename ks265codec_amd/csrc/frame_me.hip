@@ -42,7 +42,7 @@ __device__ __forceinline__ void pu_predictor(const KsGeom &g, int range, const i
 
 template <int LEVEL>
 __device__ __forceinline__ void me_level(const KsGeom &g, int cx, int cy, int range, int lam, int method, const uint8_t *win, const uint8_t *fenc, int *pmv,
-                                         const ks265_pu *prev_ctu, ks265_pu *out_ctu, int tid)
+                                         unsigned (*comb)[4], const ks265_pu *prev_ctu, ks265_pu *out_ctu, int tid)
 {
     constexpr int S = 64 >> LEVEL;
     constexpr int G = LEVEL <= 1 ? 64 : (LEVEL == 2 ? 16 : 8);     // lanes per PU
@@ -50,13 +50,15 @@ __device__ __forceinline__ void me_level(const KsGeom &g, int cx, int cy, int ra
     constexpr int NPU = 1 << (2 * LEVEL);
     constexpr int PER_PASS = 256 / G;
     for (int pass = 0; pass * PER_PASS < NPU; ++pass) {
-        const int pu = pass * PER_PASS + tid / G;
-        const bool exists = pu < NPU;
+        // level 0 has one PU: all four waves search it as replicas and split the large independent candidate batches (UMH)
+        const int wv = LEVEL == 0 ? (tid >> 6) : 0;
+        const int pu = LEVEL == 0 ? 0 : pass * PER_PASS + tid / G;
+        const bool exists = pu < NPU && (LEVEL != 0 || method == 2 || wv == 0);   // replicas only help the UMH batches
         const int px = exists ? (pu & ((1 << LEVEL) - 1)) : 0, py = exists ? (pu >> LEVEL) : 0;
         const int gl = tid % G;
         const int row = LEVEL == 1 ? (gl & 31) : gl, xoff = LEVEL == 1 ? (gl >> 5) * 16 : 0;
         const bool valid = exists && ks_pu_inside(g, cx, cy, LEVEL, px, py);
-        if (exists && !valid && gl == 0) {                          // PU not (completely) inside the picture: marked, never searched
+        if (exists && !valid && gl == 0 && wv == 0) {               // PU not (completely) inside the picture: marked, never searched
             ks265_pu o; o.mvx = o.mvy = o.mvpx = o.mvpy = 0; o.cost = KS_COST_INVALID; o.dist = KS_COST_INVALID;
             out_ctu[ks_pu_index(LEVEL, px, py)] = o;
         }
@@ -240,22 +242,78 @@ __device__ __forceinline__ void me_level(const KsGeom &g, int cx, int cy, int ra
                 }
                 const bool mainp = valid && !done;
                 if (__any(mainp)) {
-                    cross(ox, oy, cross_start, ext, ext >> 1, mainp);
-                    {
-                        const int xs[4] = {ox - 2, ox - 2, ox + 2, ox + 2}, ys[4] = {oy - 2, oy + 2, oy - 2, oy + 2};
-                        try_multi(std::integral_constant<int, 4>{}, xs, ys, mainp);
+                    // Cross, corners and the hexagon grid are evaluated around a FIXED centre: their candidates are independent and
+                    // the reference's sequential "first strictly better" scan equals argmin by (cost, scan position).  At level 0
+                    // the four replica waves therefore each take a quarter of the candidates, remember the scan position (key) of
+                    // their winner and merge through LDS.
+                    constexpr bool COOP = LEVEL == 0;
+                    constexpr int NW = COOP ? 4 : 1;
+                    unsigned bkey = 0;                                   // 0 = the incumbent
+                    auto try_k = [&](auto n_tag, const int *xs, const int *ys, const unsigned *keys, bool en) {
+                        constexpr int N = decltype(n_tag)::value;
+                        int ax[N], ay[N]; unsigned cs[N];
+#pragma unroll
+                        for (int n = 0; n < N; ++n) { ax[n] = en ? xs[n] : 0; ay[n] = en ? ys[n] : 0; }
+                        cost_multi(n_tag, ax, ay, cs);
+#pragma unroll
+                        for (int n = 0; n < N; ++n)
+                            if (en && cs[n] < bcost) { bcost = cs[n]; mx = xs[n]; my = ys[n]; bkey = keys[n]; }
+                    };
+                    auto merge = [&]() {
+                        if (!COOP) return;
+                        if ((tid & 63) == 0) { comb[wv][0] = bcost; comb[wv][1] = bkey; comb[wv][2] = (unsigned)mx; comb[wv][3] = (unsigned)my; }
+                        __syncthreads();
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) {
+                            const unsigned c = comb[w][0], k = comb[w][1];
+                            if (c < bcost || (c == bcost && k < bkey)) { bcost = c; bkey = k; mx = (int)comb[w][2]; my = (int)comb[w][3]; }
+                        }
+                        __syncthreads();
+                        bkey = 0;
+                    };
+                    {   // uneven cross around (ox, oy): +-i for odd i in [cross_start, ext) along x, [cross_start, ext / 2) along y
+                        const int xmax = ext, ymax = ext >> 1;
+                        int it = 0;
+#pragma unroll 1
+                        for (int i = 1; i < xmax; i += 4, ++it) {
+                            if (COOP && (it & 3) != wv) continue;
+                            const bool e0 = mainp && i >= cross_start, e1 = mainp && i + 2 >= cross_start && i + 2 < xmax;
+                            if (!__any(e0 || e1)) continue;
+                            const int xs[4] = {e0 ? ox + i : 1000, e0 ? ox - i : 1000, e1 ? ox + i + 2 : 1000, e1 ? ox - i - 2 : 1000}, ys[4] = {oy, oy, oy, oy};
+                            const unsigned kb = (1u << 24) | ((unsigned)i << 2), keys[4] = {kb, kb + 1, kb + 4, kb + 5};
+                            try_k(std::integral_constant<int, 4>{}, xs, ys, keys, e0 || e1);
+                        }
+#pragma unroll 1
+                        for (int i = 1; i < ymax; i += 4, ++it) {
+                            if (COOP && (it & 3) != wv) continue;
+                            const bool e0 = mainp && i >= cross_start, e1 = mainp && i + 2 >= cross_start && i + 2 < ymax;
+                            if (!__any(e0 || e1)) continue;
+                            const int xs[4] = {ox, ox, ox, ox}, ys[4] = {e0 ? oy + i : 1000, e0 ? oy - i : 1000, e1 ? oy + i + 2 : 1000, e1 ? oy - i - 2 : 1000};
+                            const unsigned kb = (2u << 24) | ((unsigned)i << 2), keys[4] = {kb, kb + 1, kb + 4, kb + 5};
+                            try_k(std::integral_constant<int, 4>{}, xs, ys, keys, e0 || e1);
+                        }
+                        if (!COOP || wv == 0) {
+                            const int xs[4] = {ox - 2, ox - 2, ox + 2, ox + 2}, ys[4] = {oy - 2, oy + 2, oy - 2, oy + 2};
+                            const unsigned keys[4] = {3u << 24, (3u << 24) + 1, (3u << 24) + 2, (3u << 24) + 3};
+                            try_k(std::integral_constant<int, 4>{}, xs, ys, keys, mainp);
+                        }
                     }
+                    merge();
                     ox = mx; oy = my;
                     // Big_Hexagon: (-4,0)(4,0)(0,-4)(0,4)(-4,-1)(4,1)(-4,1)(4,-1)(-4,-2)(4,2)(-4,2)(4,-2)(-2,-3)(2,3)(-2,3)(2,-3), stored +4
 #pragma unroll 1
                     for (int i = 1; i <= (range >> 2) && __any(mainp && i <= (ext >> 2)); ++i)
 #pragma unroll 1
-                        for (int j0 = 0; j0 < 16; j0 += 8) {
-                            int xs[8], ys[8];
+                        for (int j0 = COOP ? 4 * wv : 0; j0 < (COOP ? 4 * wv + 4 : 16); j0 += 4) {
+                            int xs[4], ys[4]; unsigned keys[4];
 #pragma unroll
-                            for (int j = 0; j < 8; ++j) { xs[j] = ox + nib(0x6262808080804480ull, j0 + j, 4) * i; ys[j] = oy + nib(0x1771266235538044ull, j0 + j, 4) * i; }
-                            try_multi(std::integral_constant<int, 8>{}, xs, ys, mainp && i <= (ext >> 2));
+                            for (int j = 0; j < 4; ++j) {
+                                xs[j] = ox + nib(0x6262808080804480ull, j0 + j, 4) * i; ys[j] = oy + nib(0x1771266235538044ull, j0 + j, 4) * i;
+                                keys[j] = (4u << 24) | ((unsigned)i << 4) | (unsigned)(j0 + j);
+                            }
+                            try_k(std::integral_constant<int, 4>{}, xs, ys, keys, mainp && i <= (ext >> 2));
                         }
+                    merge();
                     hex_refine(mainp);
                 }
             }
@@ -305,7 +363,7 @@ __device__ __forceinline__ void me_level(const KsGeom &g, int cx, int cy, int ra
             }
             bcost >>= 4;
         }
-        if (valid && gl == 0) {
+        if (valid && gl == 0 && wv == 0) {
             int idx = ks_pu_index(LEVEL, px, py);
             pmv[idx] = (mx & 0xFFFF) | (my << 16);
             ks265_pu o;
@@ -316,12 +374,15 @@ __device__ __forceinline__ void me_level(const KsGeom &g, int cx, int cy, int ra
     }
 }
 
-__global__ __launch_bounds__(256) void me_int_kernel(KsGeom g, int range, int lam, int method, const uint8_t *src, const uint8_t *ref, const ks265_pu *prev,
+template <int METHOD>   // one instantiation per search pattern: DIA keeps its small register footprint (3 workgroups / CU)
+__global__ __launch_bounds__(256) void me_int_kernel(KsGeom g, int range, int lam, const uint8_t *src, const uint8_t *ref, const ks265_pu *prev,
                                                      ks265_pu *out)
 {
     __shared__ __attribute__((aligned(16))) uint8_t win[WIN_ROWS * WIN_STRIDE];
     __shared__ __attribute__((aligned(16))) uint8_t fenc[64 * FENC_STRIDE];
     __shared__ int pmv[85];
+    __shared__ unsigned comb[4][4];
+    constexpr int method = METHOD;
     const int tid = threadIdx.x, ctu = ks_xcd_swizzle(blockIdx.x, g.ctu_cols * g.ctu_rows), cx = ctu % g.ctu_cols, cy = ctu / g.ctu_cols;
     const uint8_t *R = ks_org_y(g, ref), *Sp = ks_org_y(g, src);
     // reference window: 16-byte global loads (x0 - 80 is 16-byte aligned), dword LDS stores
@@ -341,13 +402,13 @@ __global__ __launch_bounds__(256) void me_int_kernel(KsGeom g, int range, int la
     __syncthreads();
     const ks265_pu *prev_ctu = prev ? prev + (long)ctu * 85 : nullptr;
     ks265_pu *out_ctu = out + (long)ctu * 85;
-    me_level<0>(g, cx, cy, range, lam, method, win, fenc, pmv, prev_ctu, out_ctu, tid);
+    me_level<0>(g, cx, cy, range, lam, method, win, fenc, pmv, comb, prev_ctu, out_ctu, tid);
     __syncthreads();
-    me_level<1>(g, cx, cy, range, lam, method, win, fenc, pmv, prev_ctu, out_ctu, tid);
+    me_level<1>(g, cx, cy, range, lam, method, win, fenc, pmv, comb, prev_ctu, out_ctu, tid);
     __syncthreads();
-    me_level<2>(g, cx, cy, range, lam, method, win, fenc, pmv, prev_ctu, out_ctu, tid);
+    me_level<2>(g, cx, cy, range, lam, method, win, fenc, pmv, comb, prev_ctu, out_ctu, tid);
     __syncthreads();
-    me_level<3>(g, cx, cy, range, lam, method, win, fenc, pmv, prev_ctu, out_ctu, tid);
+    me_level<3>(g, cx, cy, range, lam, method, win, fenc, pmv, comb, prev_ctu, out_ctu, tid);
 }
 
 extern "C" int ks265_me_integer(ks265_frame *f, ks265_pic src, ks265_pic ref, const ks265_pu *prev_pu, ks265_pu *pu)
@@ -355,8 +416,10 @@ extern "C" int ks265_me_integer(ks265_frame *f, ks265_pic src, ks265_pic ref, co
     KS_FRAME_CHECK(f);
     if (!src.y || !ref.y || !pu) return KS265_POINTER;
     if (f->cfg.me_method < 0 || f->cfg.me_method > 2) return KS265_NOTSUPPORTED;
-    hipLaunchKernelGGL(me_int_kernel, dim3(f->g.ctu_cols * f->g.ctu_rows), dim3(256), 0, f->ctx->stream, f->g, f->cfg.me_range, f->cfg.lambda_q4,
-                       f->cfg.me_method, src.y, ref.y, prev_pu, pu);
+    const dim3 grid(f->g.ctu_cols * f->g.ctu_rows), block(256);
+    if (f->cfg.me_method == 0) hipLaunchKernelGGL(me_int_kernel<0>, grid, block, 0, f->ctx->stream, f->g, f->cfg.me_range, f->cfg.lambda_q4, src.y, ref.y, prev_pu, pu);
+    else if (f->cfg.me_method == 1) hipLaunchKernelGGL(me_int_kernel<1>, grid, block, 0, f->ctx->stream, f->g, f->cfg.me_range, f->cfg.lambda_q4, src.y, ref.y, prev_pu, pu);
+    else hipLaunchKernelGGL(me_int_kernel<2>, grid, block, 0, f->ctx->stream, f->g, f->cfg.me_range, f->cfg.lambda_q4, src.y, ref.y, prev_pu, pu);
     return ks265_check_launch(f->ctx);
 }
 
