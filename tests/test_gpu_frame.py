@@ -121,3 +121,101 @@ def test_encode_picture_end_to_end(ks, W, H):
         assert psnr(clip[t][:W * H], got[:W * H]) > 30.0
         a, b = b, a
     f.close()
+
+
+@pytest.mark.parametrize("W,H,qp,me_range,me,subme,deblock,sao", [
+    (64, 64, 40, 16, 0, 1, 1, 1),      # single CTU, coarse QP, small search range
+    (8, 8, 22, 64, 2, 1, 1, 1),        # smallest legal picture: one 8x8 CU, every larger PU invalid
+    (136, 72, 0, 8, 1, 1, 0, 1),       # QP 0 (level clipping path), deblock off
+    (264, 200, 51, 64, 2, 0, 1, 0),    # QP 51, integer-only ME, SAO off
+    (72, 200, 33, 32, 0, 1, 1, 1),     # tall, ragged in both directions
+])
+def test_config_edges_end_to_end(ks, W, H, qp, me_range, me, subme, deblock, sao):
+    """configuration and size edges: encode_picture == oracle pipeline, bit for bit"""
+    from ks265codec_amd.lib import KsFrame
+    from ks265codec_amd.synth import lambda_q4, make_clip
+    from oracle_lib import OraclePipeline
+
+    clip = make_clip(W, H, 3, seed=W * 1000 + H, abc=(11, 13, 7), pan=(3, 2))
+    kw = dict(me_range=me_range, subme=subme, deblock=deblock, sao=sao, me_method=me)
+    o = OraclePipeline(W, H, qp, lambda_q4(qp), **kw)
+    f = KsFrame(ks, W, H, qp, lambda_q4(qp), **kw)
+    src, a, b = f.new_pic(), f.new_pic(), f.new_pic()
+    for t in range(3):
+        exp = o.encode_picture(clip[t], t == 0)
+        f.load_i420(ks.dev(clip[t]), src)
+        f.encode_picture(src, a, t == 0, b)
+        got = ks.host(f.store_i420(b), np.uint8)
+        assert (got == exp).all(), f"frame {t}: {int((got != exp).sum())} recon bytes differ"
+        a, b = b, a
+    f.close()
+
+
+def test_full_size_properties_2160p(ks):
+    """BASELINE size (3840x2160): properties that need no CPU oracle run - run-to-run determinism, border replication,
+    invalid-PU marking in the ragged last CTU row, PSNR sanity, and decoder-side consistency: for sampled TUs the
+    pre-deblock reconstruction equals prediction + IDCT(dequant(levels)) recomputed through the BATCHED operator ABI
+    (which is pinned to the reference kernels by test_gpu_golden.py)."""
+    from ks265codec_amd.lib import CU8, PU, KsFrame
+    from ks265codec_amd.synth import lambda_q4, make_clip, psnr
+
+    W, H = 3840, 2160
+    clip = make_clip(W, H, 2, seed=7, abc=(67, 91, 33), pan=(8, 5))
+    outs = []
+    for rep in range(2):
+        f = KsFrame(ks, W, H, 27, lambda_q4(27), me_method=1)
+        g = f.geom
+        src, a, b = f.new_pic(), f.new_pic(), f.new_pic()
+        for t in range(2):
+            q = 27 + (t > 0)
+            f.set_qp(q, lambda_q4(q))
+            f.load_i420(ks.dev(clip[t]), src)
+            f.encode_picture(src, a, t == 0, b)
+            a, b = b, a
+        rec = ks.host(f.store_i420(a), np.uint8)
+        outs.append(rec)
+        if rep == 1:
+            assert psnr(clip[1][:W * H], rec[:W * H]) > 31.0
+            Y = ks.host(a.y, np.uint8).reshape(g.rows_y, g.stride_y)
+            assert (Y[:g.pad_y, g.pad_y:g.pad_y + W] == Y[g.pad_y, g.pad_y:g.pad_y + W]).all()
+            assert (Y[g.pad_y + H:, g.pad_y:g.pad_y + W] == Y[g.pad_y + H - 1, g.pad_y:g.pad_y + W]).all()
+            assert (Y[g.pad_y:g.pad_y + H, g.pad_y + W:g.pad_y + W + g.pad_y] == Y[g.pad_y:g.pad_y + H, g.pad_y + W - 1:g.pad_y + W]).all()
+            # last CTU row is 48 samples high: its 64x64 PUs are invalid, the 16x16 PUs of its first rows are valid
+            pu = f.ws_read("pu", g.bytes_pu).view(PU).reshape(-1, 85)
+            last = pu[(g.ctu_rows - 1) * g.ctu_cols:]
+            assert (last["cost"][:, 0] == 0xFFFFFFFF).all() and (last["cost"][:, 5] != 0xFFFFFFFF).all()
+            # stage D on its own, keeping the pre-deblock reconstruction
+            planes = ks.zeros(16 * g.bytes_y)
+            f.ref_planes(b, planes)                       # b = reconstruction of picture 0 = the reference of picture 1
+            cu8 = ks.dev(f.ws_read("cu8", g.bytes_cu8))
+            lvl = [ks.zeros(W * H * 2), ks.zeros(W * H // 2), ks.zeros(W * H // 2)]
+            pre = f.new_pic()
+            f.reconstruct(src, b, planes, cu8, lvl, pre)
+            cu = ks.host(cu8, CU8).reshape(H // 8, W // 8)
+            lv = ks.host(lvl[0], np.int16).reshape(H, W)
+            P = ks.host(planes, np.uint8).reshape(16, g.rows_y, g.stride_y)
+            R = ks.host(pre.y, np.uint8).reshape(g.rows_y, g.stride_y)
+            rng = np.random.default_rng(3)
+            inv = [40, 45, 51, 57, 64, 72]
+            coded = 0
+            for _ in range(300):
+                by, bx = int(rng.integers(0, H // 8)), int(rng.integers(0, W // 8))
+                c = cu[by, bx]
+                t8 = min(1 << (int(c["log2_cu"]) - 3), 4)
+                by, bx = by // t8 * t8, bx // t8 * t8
+                n, log2n = t8 * 8, {8: 3, 16: 4, 32: 5}[t8 * 8]
+                mvx, mvy = int(c["mvx"]), int(c["mvy"])
+                y0, x0 = g.pad_y + by * 8 + (mvy >> 2), g.pad_y + bx * 8 + (mvx >> 2)
+                pred = np.ascontiguousarray(P[(mvy & 3) * 4 + (mvx & 3)][y0:y0 + n, x0:x0 + n])
+                blk = np.ascontiguousarray(lv[by * 8:by * 8 + n, bx * 8:bx * 8 + n])
+                exp = pred
+                assert bool(c["cbf"] & 1) == bool((blk != 0).any())
+                if (blk != 0).any():
+                    dq = ks.dequant(n, blk[None], inv[28 % 6] << (28 // 6), 1 << (log2n - 2), log2n - 1)
+                    exp = ks.inv_transform(log2n - 1, dq, pred[None])[0]
+                    coded += 1
+                got = R[g.pad_y + by * 8:g.pad_y + by * 8 + n, g.pad_y + bx * 8:g.pad_y + bx * 8 + n]
+                assert (got == exp).all(), (bx, by, n)
+            assert coded > 20
+        f.close()
+    assert (outs[0] == outs[1]).all()          # run-to-run deterministic
