@@ -395,7 +395,9 @@ void ks265o_stat_sao_bo_eo01(int *eoJoint, int *bo, const uint8_t *org, const ui
  * flag arguments 0: every neighbour is read from the picture itself, un-SAO'd).  `offsets` is the 5-entry
  * table indexed by the raw edge index 2 + sign(c-a) + sign(c-b) (read from the disassembly: movsbl (%rdi,idx)).
  * The saved-line modes of the reference only exist because its CTU pipeline filters in place; the frame-level
- * kernels are out-of-place, which is what this model computes. */
+ * kernels are out-of-place, which is what this model computes.  All four classes are pinned: EO0/EO1 with their
+ * flag arguments 0, EO2/EO3 (which always read a saved row/column and take a centred offset pointer) with the saved
+ * row/column pointed into the picture itself (oracle/ref_probe/gen_golden.py). */
 void ks265o_sao_apply_eo(int cls, const int8_t *offsets, uint8_t *rec, int stride, int height, int width)
 {
     static const int dx[4] = {1, 0, 1, -1}, dy[4] = {0, 1, 1, 1};
@@ -410,4 +412,29 @@ void ks265o_sao_apply_eo(int cls, const int8_t *offsets, uint8_t *rec, int strid
             rec[y * stride + x] = clip8(c + offsets[2 + sgn(c - a) + sgn(c - b)]);
         }
     free(copy);
+}
+
+/* ------------------------------------------------------------------ bi-prediction helpers (second wave, EncInterMeBi* / ComInterPrediction*)
+ * enc@0x435160 DefaultWeightedBi_c(dst, p0, p1, dstStride, srcStride, width, height): average of two 14-bit predictions.
+ * The reference's 14-bit intermediates carry no -8192 offset (see interpLumaHor8to16_c), so the normative
+ * (a + b + 2^14 + 64) >> 7 becomes (a + b + 64) >> 7.  Pinned by tests/golden/bipred.npz. */
+void ks265o_default_weighted_bi(uint8_t *dst, const int16_t *p0, const int16_t *p1, int dstStride, int srcStride, int width, int height)
+{
+    for (int y = 0; y < height; ++y)
+        for (int x = 0; x < width; ++x) dst[y * dstStride + x] = clip8(((int)p0[y * srcStride + x] + (int)p1[y * srcStride + x] + 64) >> 7);
+}
+
+/* enc@0x47b1a0 calcBiMeOrg_c(dst, pred, org, stride, height, width): the bi-pred search target dst = clip8(2 org - pred)
+ * (g_calcBiMeOrgFuncs); returns the clipping loss sum |2 org - pred - dst|. */
+uint32_t ks265o_calc_bi_me_org(uint8_t *dst, const uint8_t *pred, const uint8_t *org, int stride, int height, int width)
+{
+    uint32_t loss = 0;
+    for (int y = 0; y < height; ++y)
+        for (int x = 0; x < width; ++x) {
+            int v = 2 * (int)org[y * stride + x] - (int)pred[y * stride + x];
+            uint8_t c = clip8(v);
+            dst[y * stride + x] = c;
+            loss += (uint32_t)iabs(v - (int)c);
+        }
+    return loss;
 }

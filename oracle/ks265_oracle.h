@@ -86,6 +86,10 @@ void ks265o_sao_apply_eo(int cls, const int8_t *offsets, uint8_t *rec, int strid
 void ks265o_stat_sao_bo_eo01(int *eoJoint, int *bo, const uint8_t *org, const uint8_t *rec, int recStride, int orgStride,
                              int width, int height, int rowStep);
 
+/* ---- bi-prediction helpers, pinned now for the B-picture row (enc@0x435160 DefaultWeightedBi_c, enc@0x47b1a0 calcBiMeOrg_c) ---- */
+void ks265o_default_weighted_bi(uint8_t *dst, const int16_t *p0, const int16_t *p1, int dstStride, int srcStride, int width, int height);
+uint32_t ks265o_calc_bi_me_org(uint8_t *dst, const uint8_t *pred, const uint8_t *org, int stride, int height, int width);
+
 #ifdef __cplusplus
 }
 #endif

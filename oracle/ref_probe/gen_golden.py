@@ -384,7 +384,13 @@ def gen_sao(p: RefProbe):
             if cls < 2:
                 call = p.call(f"sao_eo{cls}", Buf(offs), R.at(stride + 1), stride, h, w, Buf(np.zeros(128, np.uint8)), 0, 0)
             else:
-                continue  # EO2/EO3 take saved lines in every mode; pinned through the frame-level model instead
+                # EO2 / EO3 always read the row above from a saved line and the column beside the block from a saved column
+                # (read from the disassembly): point both into the picture itself -> the plain normative filter.
+                # Unlike EO0/EO1 their offset pointer is centred: it addresses offsets[-2..2] (sign sum without the +2).
+                if cls == 2:   # 135 degrees: up-left / down-right
+                    call = p.call("sao_eo2", Buf(offs).at(2), R.at(stride + 1), stride, h, R.at(1), R.at(0), stride, w)          # saved column entry k = row k-1
+                else:          # 45 degrees: up-right / down-left
+                    call = p.call("sao_eo3", Buf(offs).at(2), R.at(stride + 1), stride, h, R.at(1), R.at(2 * stride), stride, w)  # saved column entry k = row k+1
             pend.append((dict(kind=f"eo{cls}", rec=img, stride=stride, h=h, w=w, offs=offs), call, R))
     p.run()
     return [dict(c, exp=r.out) for c, _, r in pend]
@@ -410,11 +416,31 @@ def gen_sao_stats(p: RefProbe):
     return [dict(c, exp_eo=e.out, exp_bo=b.out) for c, _, e, b in pend]
 
 
+def gen_bipred(p: RefProbe):
+    pend = []
+    for (w, h) in ((4, 4), (8, 8), (16, 8), (32, 32), (64, 16), (12, 16), (24, 8), (48, 64)):
+        for k in range(2):
+            ss, ds = w + int(rng.integers(0, 9)), w + int(rng.integers(0, 9))
+            if k == 0:
+                p0, p1 = rng.integers(0, 16321, (h, ss)).astype(np.int16), rng.integers(0, 16321, (h, ss)).astype(np.int16)
+            else:  # extremes incl. values a sharpening filter can produce (negative / above 255 << 6)
+                p0, p1 = rng.integers(-4096, 20000, (h, ss)).astype(np.int16), rng.integers(-4096, 20000, (h, ss)).astype(np.int16)
+            D = Buf(np.zeros((h, ds), np.uint8))
+            pend.append((dict(kind="wbi", p0=p0, p1=p1, ss=ss, ds=ds, w=w, h=h), p.call(0x435160, D, Buf(p0), Buf(p1), ds, ss, w, h), D))
+    for (w, h) in ((8, 8), (16, 16), (32, 8), (64, 64)):
+        st = w + int(rng.integers(0, 9))
+        org, pred = u8((h, st)), u8((h, st))
+        D = Buf(np.zeros((h, st), np.uint8))
+        pend.append((dict(kind="biorg", org=org, pred=pred, st=st, w=w, h=h), p.call(0x47B1A0, D, Buf(pred), Buf(org), st, h, w), D))
+    p.run()
+    return [dict(c, exp=d.out, ret=np.uint32(call.ret & 0xFFFFFFFF)) for c, call, d in pend]
+
+
 FAMILIES = {
     "sad": gen_sad, "sad4": gen_sad4, "sad3": gen_sad3, "sad4blk": gen_sad4blk, "sse": gen_sse, "had": gen_had,
     "fwd_transform": gen_fwd, "inv_transform": gen_inv, "quant": gen_quant, "dequant": gen_dequant,
     "residual": gen_residual, "deblock_luma": gen_deblock_luma, "deblock_chroma": gen_deblock_chroma,
-    "interp": gen_interp, "sao_apply": gen_sao, "sao_stats": gen_sao_stats,
+    "interp": gen_interp, "sao_apply": gen_sao, "sao_stats": gen_sao_stats, "bipred": gen_bipred,
 }
 
 if __name__ == "__main__":
