@@ -42,7 +42,7 @@ __device__ __forceinline__ void pu_predictor(const KsGeom &g, int range, const i
 
 template <int LEVEL>
 __device__ __forceinline__ void me_level(const KsGeom &g, int cx, int cy, int range, int lam, int method, const uint8_t *win, const uint8_t *fenc, int *pmv,
-                                         unsigned (*comb)[4], const ks265_pu *prev_ctu, ks265_pu *out_ctu, int tid)
+                                         unsigned (*comb)[4], const unsigned char *selut, const ks265_pu *prev_ctu, ks265_pu *out_ctu, int tid)
 {
     constexpr int S = 64 >> LEVEL;
     constexpr int G = LEVEL <= 1 ? 64 : (LEVEL == 2 ? 16 : 8);     // lanes per PU
@@ -68,6 +68,11 @@ __device__ __forceinline__ void me_level(const KsGeom &g, int cx, int cy, int ra
 #pragma unroll
         for (int j = 0; j < D; ++j) f[j] = lds_u32(fenc + by0 * FENC_STRIDE + bx0 + 4 * j);
 
+        // rate of an integer vector: lambda x se(v) bits from the LDS table (index = quarter-pel difference + 512; every lane of the
+        // wave evaluates it, so the clz-based formula would cost more than the SAD of an 8x8 PU)
+        auto imv_cost = [&](int x, int y, int ppx, int ppy) -> unsigned {
+            return (unsigned)((lam * ((int)selut[((x - ppx) << 2) + 512] + (int)selut[((y - ppy) << 2) + 512])) >> 4);
+        };
         int pmx = 0, pmy = 0; bool root = true;
         if (valid) pu_predictor(g, range, pmv, prev_ctu, cx, cy, LEVEL, px, py, pmx, pmy, root);
 
@@ -86,9 +91,9 @@ __device__ __forceinline__ void me_level(const KsGeom &g, int cx, int cy, int ra
         };
 
         int mx = pmx, my = pmy;
-        unsigned bcost = group_sum<G>(seg_sad(mx, my)) + (unsigned)mv_cost(mx << 2, my << 2, pmx << 2, pmy << 2, lam);
+        unsigned bcost = group_sum<G>(seg_sad(mx, my)) + imv_cost(mx, my, pmx, pmy);
         if (__any(valid && root && (pmx | pmy))) {                  // second start candidate: the zero vector
-            unsigned c0 = group_sum<G>(seg_sad(0, 0)) + (unsigned)mv_cost(0, 0, pmx << 2, pmy << 2, lam);
+            unsigned c0 = group_sum<G>(seg_sad(0, 0)) + imv_cost(0, 0, pmx, pmy);
             if (root && (pmx | pmy) && c0 < bcost) { bcost = c0; mx = 0; my = 0; }
         }
         if (method != 0) {
@@ -98,7 +103,7 @@ __device__ __forceinline__ void me_level(const KsGeom &g, int cx, int cy, int ra
             auto cost_at = [&](int x, int y) -> unsigned {
                 const bool in = abs(x) <= range && abs(y) <= range;
                 const unsigned sd = group_sum<G>(seg_sad(in ? x : 0, in ? y : 0));
-                return in ? sd + (unsigned)mv_cost(x << 2, y << 2, pmx << 2, pmy << 2, lam) : 0x07FFFFFFu;
+                return in ? sd + imv_cost(in ? x : 0, in ? y : 0, pmx, pmy) : 0x07FFFFFFu;
             };
             // N candidates at once: the N partial SADs are accumulated first and the N group reductions (DPP / swizzle chains)
             // are then independent instruction streams the scheduler interleaves - the search is latency bound, not ALU bound
@@ -114,7 +119,7 @@ __device__ __forceinline__ void me_level(const KsGeom &g, int cx, int cy, int ra
                 for (int n = 0; n < N; ++n) {
                     const bool in = abs(xs[n]) <= range && abs(ys[n]) <= range;
                     const unsigned sd = group_sum<G>(part[n]);
-                    out[n] = in ? sd + (unsigned)mv_cost(xs[n] << 2, ys[n] << 2, pmx << 2, pmy << 2, lam) : 0x07FFFFFFu;
+                    out[n] = in ? sd + imv_cost(in ? xs[n] : 0, in ? ys[n] : 0, pmx, pmy) : 0x07FFFFFFu;
                 }
             };
             auto hx = [](int i) { return (int)((0x01343101u >> (4 * i)) & 15u) - 2; };   // hex2[i][0] + 2 = 1,0,1,3,4,3,1,0
@@ -349,7 +354,7 @@ __device__ __forceinline__ void me_level(const KsGeom &g, int cx, int cy, int ra
                     for (int k = 0; k < 4; ++k) {
                         int nx = mx + dx[k], ny = my + dy[k];
                         if (abs(nx) > range || abs(ny) > range) continue;
-                        unsigned v = (c[k] << 4) + ((unsigned)mv_cost(nx << 2, ny << 2, pmx << 2, pmy << 2, lam) << 4) + code[k];
+                        unsigned v = (c[k] << 4) + (imv_cost(nx, ny, pmx, pmy) << 4) + code[k];
                         bcost = min(bcost, v);
                     }
                     if (!(bcost & 15)) active = false;
@@ -368,7 +373,7 @@ __device__ __forceinline__ void me_level(const KsGeom &g, int cx, int cy, int ra
             pmv[idx] = (mx & 0xFFFF) | (my << 16);
             ks265_pu o;
             o.mvx = (int16_t)(mx << 2); o.mvy = (int16_t)(my << 2); o.mvpx = (int16_t)(pmx << 2); o.mvpy = (int16_t)(pmy << 2);
-            o.cost = bcost; o.dist = bcost - (unsigned)mv_cost(mx << 2, my << 2, pmx << 2, pmy << 2, lam);
+            o.cost = bcost; o.dist = bcost - imv_cost(mx, my, pmx, pmy);
             out_ctu[idx] = o;
         }
     }
@@ -382,9 +387,11 @@ __global__ __launch_bounds__(256) void me_int_kernel(KsGeom g, int range, int la
     __shared__ __attribute__((aligned(16))) uint8_t fenc[64 * FENC_STRIDE];
     __shared__ int pmv[85];
     __shared__ unsigned comb[4][4];
+    __shared__ unsigned char selut[1032];                 // se(v) bit length, v = index - 512 quarter-pel units
     constexpr int method = METHOD;
     const int tid = threadIdx.x, ctu = ks_xcd_swizzle(blockIdx.x, g.ctu_cols * g.ctu_rows), cx = ctu % g.ctu_cols, cy = ctu / g.ctu_cols;
     const uint8_t *R = ks_org_y(g, ref), *Sp = ks_org_y(g, src);
+    for (int i = threadIdx.x; i < 1025; i += 256) selut[i] = (unsigned char)se_bits(i - 512);
     // reference window: 16-byte global loads (x0 - 80 is 16-byte aligned), dword LDS stores
     for (int i = tid; i < WIN_ROWS * (WIN_W / 16); i += 256) {
         int r = i / (WIN_W / 16), c = i - r * (WIN_W / 16);
@@ -402,13 +409,13 @@ __global__ __launch_bounds__(256) void me_int_kernel(KsGeom g, int range, int la
     __syncthreads();
     const ks265_pu *prev_ctu = prev ? prev + (long)ctu * 85 : nullptr;
     ks265_pu *out_ctu = out + (long)ctu * 85;
-    me_level<0>(g, cx, cy, range, lam, method, win, fenc, pmv, comb, prev_ctu, out_ctu, tid);
+    me_level<0>(g, cx, cy, range, lam, method, win, fenc, pmv, comb, selut, prev_ctu, out_ctu, tid);
     __syncthreads();
-    me_level<1>(g, cx, cy, range, lam, method, win, fenc, pmv, comb, prev_ctu, out_ctu, tid);
+    me_level<1>(g, cx, cy, range, lam, method, win, fenc, pmv, comb, selut, prev_ctu, out_ctu, tid);
     __syncthreads();
-    me_level<2>(g, cx, cy, range, lam, method, win, fenc, pmv, comb, prev_ctu, out_ctu, tid);
+    me_level<2>(g, cx, cy, range, lam, method, win, fenc, pmv, comb, selut, prev_ctu, out_ctu, tid);
     __syncthreads();
-    me_level<3>(g, cx, cy, range, lam, method, win, fenc, pmv, comb, prev_ctu, out_ctu, tid);
+    me_level<3>(g, cx, cy, range, lam, method, win, fenc, pmv, comb, selut, prev_ctu, out_ctu, tid);
 }
 
 extern "C" int ks265_me_integer(ks265_frame *f, ks265_pic src, ks265_pic ref, const ks265_pu *prev_pu, ks265_pu *pu)
