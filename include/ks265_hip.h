@@ -134,6 +134,7 @@ typedef struct {
     int32_t deblock;           /* -df                                                               */
     int32_t sao;               /* -sao: 0 off, >0 BO + EO0..3                                        */
     int32_t beta_offset_div2, tc_offset_div2;
+    int32_t bframes;           /* > 0: allocate the second-list workspace (planes, PU records) for B pictures (-bframes) */
 } ks265_frame_cfg;
 
 /* geometry of the padded picture buffers the caller allocates (one call, no allocation) */
@@ -152,7 +153,10 @@ typedef struct {
 /* motion / cost record of one PU (level 0: 64x64 ... level 3: 8x8; raster order inside the CTU) */
 typedef struct { int16_t mvx, mvy; int16_t mvpx, mvpy; uint32_t cost; uint32_t dist; } ks265_pu;   /* quarter-pel units; mvp = predictor used for the rate term; dist = SAD (stage A) or SATD (stage B) */
 /* final coding decision per 8x8 luma block */
-typedef struct { int16_t mvx, mvy; uint8_t log2_cu; uint8_t cbf; /* bit0 Y, bit1 Cb, bit2 Cr */ uint8_t pred_mode; /* 0 inter, 1 intra(flat) */ uint8_t rsv; } ks265_cu8;
+typedef struct { int16_t mvx, mvy; /* list 0 */ int16_t mv1x, mv1y; /* list 1 */ uint8_t log2_cu; uint8_t cbf; /* bit0 Y, bit1 Cb, bit2 Cr */
+                 uint8_t pred_mode; /* 0 inter, 1 intra(flat) */ uint8_t inter_dir; /* 1 = L0, 2 = L1, 3 = bi */ } ks265_cu8;
+/* B pictures: the per-PU winner among L0, L1 and bi-prediction */
+typedef struct { int16_t mvx, mvy, mv1x, mv1y; uint32_t cost; uint32_t inter_dir; } ks265_pu_b;
 /* SAO decision per CTU and component */
 typedef struct { int8_t type; /* -1 off, 0 BO, 1..4 EO class 0..3 */ int8_t band; int8_t offset[4]; int8_t rsv[2]; } ks265_sao_param;
 
@@ -191,6 +195,15 @@ int ks265_cu_flat_intra(ks265_frame *f, ks265_cu8 *dev_cu8);
  * W/2 x H/2 (Cb, Cr) coefficients stored TU-in-place; recon is a padded picture */
 int ks265_reconstruct(ks265_frame *f, ks265_pic src, ks265_pic ref, const uint8_t *dev_planes, ks265_cu8 *dev_cu8,
                       int16_t *dev_lvl_y, int16_t *dev_lvl_u, int16_t *dev_lvl_v, ks265_pic recon);
+/* the same for a B picture: list-1 reference and planes; bi-predicted blocks use the exact 14-bit average
+ * (DefaultWeightedBi_c enc@0x435160 over interp*8to16 / 16to16) */
+int ks265_reconstruct_b(ks265_frame *f, ks265_pic src, ks265_pic ref0, const uint8_t *dev_planes0, ks265_pic ref1, const uint8_t *dev_planes1,
+                        ks265_cu8 *dev_cu8, int16_t *dev_lvl_y, int16_t *dev_lvl_u, int16_t *dev_lvl_v, ks265_pic recon);
+/* Stage B': B pictures - per PU the cheapest of L0, L1 (the two uni-directional searches) and the bi-predictive pair of
+ * their winners (SATD against the rounded average; interMeBi* enc@0x486c10.. lineage, no joint refinement yet) */
+int ks265_bi_decide(ks265_frame *f, ks265_pic src, const uint8_t *dev_planes0, const uint8_t *dev_planes1, const ks265_pu *dev_pu0,
+                    const ks265_pu *dev_pu1, ks265_pu_b *dev_pub);
+int ks265_cu_decide_b(ks265_frame *f, const ks265_pu_b *dev_pub, ks265_cu8 *dev_cu8);
 /* Stage E: in-place deblocking of a reconstructed picture (CalcBsInterP enc@0x402960, ctuDeblockFilterVer
  * enc@0x403de0, CtuDeblockFilterHorT enc@0x477200) */
 int ks265_deblock(ks265_frame *f, const ks265_cu8 *dev_cu8, ks265_pic recon);
@@ -201,6 +214,8 @@ int ks265_sao(ks265_frame *f, ks265_pic src, ks265_pic deblocked, ks265_sao_para
 /* the whole hot path for one picture: A0 (if is_key == 0) A B C D E F in stream order.
  * Workspace (planes, PU/CU/SAO records, levels) lives inside the frame object. */
 int ks265_encode_picture(ks265_frame *f, ks265_pic src, ks265_pic ref, int is_key, ks265_pic recon_out);
+/* a B picture: ref0 = list 0 (past), ref1 = list 1 (future); needs cfg.bframes > 0 at ks265_frame_create */
+int ks265_encode_picture_b(ks265_frame *f, ks265_pic src, ks265_pic ref0, ks265_pic ref1, ks265_pic recon_out);
 /* in-situ stage timing: HIP events recorded on the context's stream between the stages of ks265_encode_picture;
  * ms[] = {ref_planes, me_integer, me_subpel, cu_decide, reconstruct, deblock, sao(+padding)} of the last picture, -1 = not run */
 int ks265_frame_set_profiling(ks265_frame *f, int enable);

@@ -34,6 +34,11 @@ int ks265_frame_create(ks265_ctx *ctx, const ks265_frame_cfg *cfg, ks265_frame *
     const size_t npx = (size_t)g.W * g.H;
     r = dev_alloc(ctx, (void **)&f->planes, (size_t)16 * g.bytes_y, true);
     for (int i = 0; i < 2 && !r; ++i) r = dev_alloc(ctx, (void **)&f->pu[i], (size_t)geom.bytes_pu, true);
+    if (!r && cfg->bframes > 0) {
+        r = dev_alloc(ctx, (void **)&f->planes1, (size_t)16 * g.bytes_y, true);
+        if (!r) r = dev_alloc(ctx, (void **)&f->pu1, (size_t)geom.bytes_pu, true);
+        if (!r) r = dev_alloc(ctx, (void **)&f->pub, (size_t)geom.ctu_cols * geom.ctu_rows * 85 * sizeof(ks265_pu_b), true);
+    }
     if (!r) r = dev_alloc(ctx, (void **)&f->cu8, (size_t)geom.bytes_cu8, true);
     if (!r) r = dev_alloc(ctx, (void **)&f->sao, (size_t)geom.bytes_sao, true);
     if (!r) r = dev_alloc(ctx, (void **)&f->lvl[0], npx * 2, true);
@@ -54,7 +59,7 @@ void ks265_frame_destroy(ks265_frame *f)
     if (f->ctx) { hipSetDevice(f->ctx->device); hipStreamSynchronize(f->ctx->stream); }
     for (int i = 0; i <= KS_NSTAGE; ++i)
         if (f->ev[i]) hipEventDestroy(f->ev[i]);
-    void *ptrs[] = {f->planes, f->pu[0], f->pu[1], f->cu8, f->sao, f->lvl[0], f->lvl[1], f->lvl[2], f->deb[0], f->deb[1], f->deb[2], f->sse};
+    void *ptrs[] = {f->planes1, f->pu1, f->pub, f->planes, f->pu[0], f->pu[1], f->cu8, f->sao, f->lvl[0], f->lvl[1], f->lvl[2], f->deb[0], f->deb[1], f->deb[2], f->sse};
     for (void *p : ptrs)
         if (p) hipFree(p);
     delete f;
@@ -106,6 +111,29 @@ int ks265_encode_picture(ks265_frame *f, ks265_pic src, ks265_pic ref, int is_ke
     mark(7);
     if (!is_key) { f->cur_pu ^= 1; f->have_prev = true; }
     return KS265_OK;
+}
+
+/* B picture: both uni-directional searches, the bi candidate, the CU tree, then the common back end.
+ * The temporal predictor chain of the P pictures (pu ping-pong) is left untouched. */
+int ks265_encode_picture_b(ks265_frame *f, ks265_pic src, ks265_pic ref0, ks265_pic ref1, ks265_pic recon_out)
+{
+    KS_FRAME_CHECK(f);
+    if (!src.y || !ref0.y || !ref1.y || !recon_out.y) return KS265_POINTER;
+    if (!f->planes1) return KS265_NOTSUPPORTED;               /* created with cfg.bframes == 0 */
+    int r;
+    ks265_pu *pu0 = f->pu[f->cur_pu];                         /* scratch: the next P picture overwrites it */
+    if ((r = ks265_ref_planes(f, ref0, f->planes))) return r;
+    if ((r = ks265_ref_planes(f, ref1, f->planes1))) return r;
+    if ((r = ks265_me_integer(f, src, ref0, nullptr, pu0))) return r;
+    if (f->cfg.subme && (r = ks265_me_subpel(f, src, f->planes, pu0))) return r;
+    if ((r = ks265_me_integer(f, src, ref1, nullptr, f->pu1))) return r;
+    if (f->cfg.subme && (r = ks265_me_subpel(f, src, f->planes1, f->pu1))) return r;
+    if ((r = ks265_bi_decide(f, src, f->planes, f->planes1, pu0, f->pu1, f->pub))) return r;
+    if ((r = ks265_cu_decide_b(f, f->pub, f->cu8))) return r;
+    ks265_pic deb = ks_deb_pic(f);
+    if ((r = ks265_reconstruct_b(f, src, ref0, f->planes, ref1, f->planes1, f->cu8, f->lvl[0], f->lvl[1], f->lvl[2], deb))) return r;
+    if (f->cfg.deblock && (r = ks265_deblock(f, f->cu8, deb))) return r;
+    return ks265_sao(f, src, deb, f->sao, recon_out);
 }
 
 int ks265_frame_set_profiling(ks265_frame *f, int enable)

@@ -25,6 +25,9 @@ struct ks265_frame {
     KsGeom g{};
     // workspace (device)
     uint8_t *planes = nullptr;          // 16 x bytes_y
+    uint8_t *planes1 = nullptr;         // list 1 (B pictures), cfg.bframes > 0
+    ks265_pu *pu1 = nullptr;
+    ks265_pu_b *pub = nullptr;
     ks265_pu *pu[2] = {nullptr, nullptr};
     int cur_pu = 0;
     bool have_prev = false;

@@ -16,7 +16,12 @@ __device__ __forceinline__ int edge_bs(const ks265_cu8 p, const ks265_cu8 q, int
     if (!tu_edge && !cu_edge) return 0;
     if (p.pred_mode == 1 || q.pred_mode == 1) return 2;
     if (tu_edge && ((p.cbf | q.cbf) & 1)) return 1;
-    if (cu_edge && (abs((int)p.mvx - (int)q.mvx) >= 4 || abs((int)p.mvy - (int)q.mvy) >= 4)) return 1;
+    if (cu_edge) {
+        // CalcBsInterP enc@0x402960 / CalcBsInterB enc@0x4029d0 with one picture per list
+        if (p.inter_dir != q.inter_dir) return 1;
+        if ((p.inter_dir & 1) && (abs((int)p.mvx - (int)q.mvx) >= 4 || abs((int)p.mvy - (int)q.mvy) >= 4)) return 1;
+        if ((p.inter_dir & 2) && (abs((int)p.mv1x - (int)q.mv1x) >= 4 || abs((int)p.mv1y - (int)q.mv1y) >= 4)) return 1;
+    }
     return 0;
 }
 

@@ -561,12 +561,14 @@ extern "C" int ks265_me_subpel(ks265_frame *f, ks265_pic src, const uint8_t *pla
 }
 
 // ------------------------------------------------------------------ Stage C: CU quadtree (64 threads per CTU)
-__global__ __launch_bounds__(64) void cu_decide_kernel(KsGeom g, int lam, const ks265_pu *pus, ks265_cu8 *cu8)
+// REC = ks265_pu (P pictures: list 0 only) or ks265_pu_b (B pictures: the per-PU winner with its direction)
+template <typename REC>
+__global__ __launch_bounds__(64) void cu_decide_kernel(KsGeom g, int lam, const REC *pus, ks265_cu8 *cu8)
 {
     __shared__ unsigned bestc[85];
     __shared__ unsigned char split[85];
     const int t = threadIdx.x, ctu = blockIdx.x, cx = ctu % g.ctu_cols, cy = ctu / g.ctu_cols;
-    const ks265_pu *cp = pus + (long)ctu * 85;
+    const REC *cp = pus + (long)ctu * 85;
     const unsigned pen = (unsigned)((lam * 12) >> 4);
     for (int l = 3; l >= 0; --l) {
         const int n = 1 << l, s = 64 >> l;
@@ -591,9 +593,11 @@ __global__ __launch_bounds__(64) void cu_decide_kernel(KsGeom g, int lam, const 
     if (X >= g.W || Y >= g.H) return;
     int l = 0;
     while (l < 3 && split[ks_pu_index(l, bx >> (3 - l), by >> (3 - l))]) ++l;
-    const ks265_pu p = cp[ks_pu_index(l, bx >> (3 - l), by >> (3 - l))];
+    const REC p = cp[ks_pu_index(l, bx >> (3 - l), by >> (3 - l))];
     ks265_cu8 c;
-    c.mvx = p.mvx; c.mvy = p.mvy; c.log2_cu = (uint8_t)(6 - l); c.cbf = 0; c.pred_mode = 0; c.rsv = 0;
+    c.mvx = p.mvx; c.mvy = p.mvy; c.log2_cu = (uint8_t)(6 - l); c.cbf = 0; c.pred_mode = 0;
+    if constexpr (std::is_same<REC, ks265_pu_b>::value) { c.mv1x = p.mv1x; c.mv1y = p.mv1y; c.inter_dir = (uint8_t)p.inter_dir; }
+    else { c.mv1x = 0; c.mv1y = 0; c.inter_dir = 1; }
     cu8[(long)(Y >> 3) * g.w8 + (X >> 3)] = c;
 }
 
@@ -607,7 +611,7 @@ __global__ __launch_bounds__(256) void cu_flat_intra_kernel(KsGeom g, ks265_cu8 
         if (ax + n <= g.w8 && ay + n <= g.h8) { lg = t; break; }
     }
     ks265_cu8 c;
-    c.mvx = 0; c.mvy = 0; c.log2_cu = (uint8_t)lg; c.cbf = 0; c.pred_mode = 1; c.rsv = 0;
+    c.mvx = 0; c.mvy = 0; c.mv1x = 0; c.mv1y = 0; c.log2_cu = (uint8_t)lg; c.cbf = 0; c.pred_mode = 1; c.inter_dir = 0;
     cu8[i] = c;
 }
 
@@ -615,7 +619,94 @@ extern "C" int ks265_cu_decide(ks265_frame *f, const ks265_pu *pu, ks265_cu8 *cu
 {
     KS_FRAME_CHECK(f);
     if (!pu || !cu8) return KS265_POINTER;
-    hipLaunchKernelGGL(cu_decide_kernel, dim3(f->g.ctu_cols * f->g.ctu_rows), dim3(64), 0, f->ctx->stream, f->g, f->cfg.lambda_q4, pu, cu8);
+    hipLaunchKernelGGL(cu_decide_kernel<ks265_pu>, dim3(f->g.ctu_cols * f->g.ctu_rows), dim3(64), 0, f->ctx->stream, f->g, f->cfg.lambda_q4, pu, cu8);
+    return ks265_check_launch(f->ctx);
+}
+
+extern "C" int ks265_cu_decide_b(ks265_frame *f, const ks265_pu_b *pub, ks265_cu8 *cu8)
+{
+    KS_FRAME_CHECK(f);
+    if (!pub || !cu8) return KS265_POINTER;
+    hipLaunchKernelGGL(cu_decide_kernel<ks265_pu_b>, dim3(f->g.ctu_cols * f->g.ctu_rows), dim3(64), 0, f->ctx->stream, f->g, f->cfg.lambda_q4, pub, cu8);
+    return ks265_check_launch(f->ctx);
+}
+
+// ------------------------------------------------------------------ Stage B': bi-predictive candidate of a B picture
+// Same shape as the sub-pel kernel (wave = PU level, lane = 8x8 tile in Z-order): SATD of the source tile against the rounded
+// average of the two list winners' plane tiles, PU cost by DPP group sum, then L0 / L1 / bi by cost (ties: L0, L1, bi).
+__device__ __forceinline__ unsigned satd8x8_avg(const unsigned (&f)[16], const uint8_t *pa, const uint8_t *pb, long stride)
+{
+    const unsigned sha = (unsigned)((uintptr_t)pa & 3), shb = (unsigned)((uintptr_t)pb & 3);
+    const uint8_t *qa = pa - sha, *qb = pb - shb;
+    int d[64];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const unsigned *ra = (const unsigned *)(qa + r * stride), *rb = (const unsigned *)(qb + r * stride);
+        const unsigned a0 = ra[0], a1 = ra[1], a2 = ra[2], b0 = rb[0], b1 = rb[1], b2 = rb[2];
+        const unsigned A[2] = {align_bytes(a1, a0, sha), align_bytes(a2, a1, sha)}, B[2] = {align_bytes(b1, b0, shb), align_bytes(b2, b1, shb)};
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int avg = (int)(((A[h] >> (8 * i)) & 255) + ((B[h] >> (8 * i)) & 255) + 1) >> 1;
+                d[r * 8 + h * 4 + i] = (int)((f[2 * r + h] >> (8 * i)) & 255) - avg;
+            }
+    }
+    d[0] += 0x8000;
+#pragma unroll
+    for (int len = 1; len < 64; len <<= 1)
+#pragma unroll
+        for (int i = 0; i < 64; i += 2 * len)
+#pragma unroll
+            for (int j = i; j < i + len; ++j) { const int u = d[j], v = d[j + len]; d[j] = u + v; d[j + len] = u - v; }
+    unsigned acc = 0;
+    const unsigned bias = 0x8000u;
+#pragma unroll
+    for (int i = 0; i < 64; ++i) asm("v_sad_u32 %0, %1, %2, %0" : "+v"(acc) : "v"(d[i]), "s"(bias));
+    return (acc + 2) >> 2;
+}
+
+__global__ __launch_bounds__(256) void bi_decide_kernel(KsGeom g, int lam, const uint8_t *src, const uint8_t *planes0, const uint8_t *planes1,
+                                                        const ks265_pu *pu0, const ks265_pu *pu1, ks265_pu_b *pub)
+{
+    const int tid = threadIdx.x, lane = tid & 63, level = tid >> 6;
+    const int ctu = ks_xcd_swizzle(blockIdx.x, g.ctu_cols * g.ctu_rows), cx = ctu % g.ctu_cols, cy = ctu / g.ctu_cols;
+    const int G = 1 << (2 * (3 - level));
+    const int tx = (lane & 1) | ((lane >> 1) & 2) | ((lane >> 2) & 4), ty = ((lane >> 1) & 1) | ((lane >> 2) & 2) | ((lane >> 3) & 4);
+    const int x0 = cx * 64 + tx * 8, y0 = cy * 64 + ty * 8;
+    const int px = tx >> (3 - level), py = ty >> (3 - level), pidx = ks_level_base(level) + py * (1 << level) + px;
+    const ks265_pu a = pu0[(long)ctu * 85 + pidx], b = pu1[(long)ctu * 85 + pidx];
+    const bool valid = a.cost != KS_COST_INVALID;
+    ks265_pu_b o;
+    o.mvx = a.mvx; o.mvy = a.mvy; o.mv1x = b.mvx; o.mv1y = b.mvy; o.cost = a.cost; o.inter_dir = 1;
+    if (__any(valid)) {
+        const uint8_t *Sp = ks_org_y(g, src);
+        unsigned f[16];
+        const uint8_t *frow = Sp + (long)(valid ? y0 : cy * 64) * g.sy + (valid ? x0 : cx * 64);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { const uint2 v = *(const uint2 *)(frow + (long)r * g.sy); f[2 * r] = v.x; f[2 * r + 1] = v.y; }
+        const long base = (long)(valid ? y0 : 0) * g.sy + (valid ? x0 : 0) + g.org_y;
+        const int ax = valid ? a.mvx : 0, ay = valid ? a.mvy : 0, bx = valid ? b.mvx : 0, by = valid ? b.mvy : 0;
+        const uint8_t *pa = planes0 + (long)((ay & 3) * 4 + (ax & 3)) * g.bytes_y + base + (long)(ay >> 2) * g.sy + (ax >> 2);
+        const uint8_t *pb = planes1 + (long)((by & 3) * 4 + (bx & 3)) * g.bytes_y + base + (long)(by >> 2) * g.sy + (bx >> 2);
+        const unsigned sd = satd8x8_avg(f, pa, pb, g.sy);
+        const unsigned dd = pu_group_sum(valid ? sd : 0, level);
+        if (valid) {
+            if (b.cost < o.cost) { o.cost = b.cost; o.inter_dir = 2; }
+            const unsigned c = dd + (unsigned)mv_cost(a.mvx, a.mvy, a.mvpx, a.mvpy, lam) + (unsigned)mv_cost(b.mvx, b.mvy, b.mvpx, b.mvpy, lam);
+            if (c < o.cost) { o.cost = c; o.inter_dir = 3; }
+        }
+    }
+    if ((lane & (G - 1)) == 0) pub[(long)ctu * 85 + pidx] = o;
+}
+
+extern "C" int ks265_bi_decide(ks265_frame *f, ks265_pic src, const uint8_t *planes0, const uint8_t *planes1, const ks265_pu *pu0, const ks265_pu *pu1,
+                               ks265_pu_b *pub)
+{
+    KS_FRAME_CHECK(f);
+    if (!src.y || !planes0 || !planes1 || !pu0 || !pu1 || !pub) return KS265_POINTER;
+    hipLaunchKernelGGL(bi_decide_kernel, dim3(f->g.ctu_cols * f->g.ctu_rows), dim3(256), 0, f->ctx->stream, f->g, f->cfg.lambda_q4, src.y, planes0, planes1,
+                       pu0, pu1, pub);
     return ks265_check_launch(f->ctx);
 }
 

@@ -36,18 +36,25 @@ __device__ __forceinline__ void quad_dot(const short *shared, const short *rows,
     }
 }
 
-// four chroma prediction samples (interpChroma* enc@0x4111c0..): 4-tap, 1/8 sample, normative 2-D order.
-// rp -> sample 0 of the quad at integer position; horizontal taps via v_dot4_i32_i8 on (p - 128).
-__device__ __forceinline__ void chroma_pred4(const uint8_t *rp, long stride, int fx, int fy, int (&out)[4])
+// ---- fractional-sample prediction of 4 adjacent samples as RAW sums, shared by uni- and bi-prediction.
+// kind 0: v = sample; kind 1: one fraction, v = tap sum (scale 64); kind 2: both fractions, v = vertical taps over the
+// (int16) horizontal tap sums (scale 4096).  Horizontal taps via v_dot4_i32_i8 on (p - 128): + 8192 restores the bias.
+//   uni-prediction (interp*8to8 / 16to8):      0: v          1: clip8((v + 32) >> 6)   2: clip8((v + 2048) >> 12)
+//   14-bit for bi  (interp*8to16 / 16to16):    0: v << 6     1: v                      2: v >> 6
+__device__ __forceinline__ int pack_taps4(const signed char *c)
 {
-    auto hrow = [&](const uint8_t *row, int (&h)[4]) {            // raw 4-tap sums of samples 0..3 (bytes -1 .. 5)
+    return (int)((unsigned)(unsigned char)c[0] | ((unsigned)(unsigned char)c[1] << 8) | ((unsigned)(unsigned char)c[2] << 16) | ((unsigned)(unsigned char)c[3] << 24));
+}
+// chroma (interpChroma* enc@0x4111c0..): 4 taps, 1/8 sample; rp -> sample 0 at the integer position
+__device__ __forceinline__ int chroma_raw4(const uint8_t *rp, long stride, int fx, int fy, int (&v)[4])
+{
+    auto hrow = [&](const uint8_t *row, int (&h)[4]) {            // bytes -1 .. 5
         const uint8_t *q = row - 1;
         const unsigned sh = (unsigned)((uintptr_t)q & 3);
         const unsigned *a = (const unsigned *)(q - sh);
         const unsigned a0 = a[0] ^ 0x80808080u, a1 = a[1] ^ 0x80808080u, a2 = a[2] ^ 0x80808080u;
         const unsigned w0 = align_bytes(a1, a0, sh), w1 = align_bytes(a2, a1, sh);   // bytes -1..2, 3..6
-        const signed char *c = kChromaTaps[fx];
-        const int taps = (int)((unsigned)(unsigned char)c[0] | ((unsigned)(unsigned char)c[1] << 8) | ((unsigned)(unsigned char)c[2] << 16) | ((unsigned)(unsigned char)c[3] << 24));
+        const int taps = pack_taps4(kChromaTaps[fx]);
         h[0] = __builtin_amdgcn_sdot4((int)w0, taps, 8192, false);
         h[1] = __builtin_amdgcn_sdot4((int)align_bytes(w1, w0, 1), taps, 8192, false);
         h[2] = __builtin_amdgcn_sdot4((int)align_bytes(w1, w0, 2), taps, 8192, false);
@@ -56,15 +63,13 @@ __device__ __forceinline__ void chroma_pred4(const uint8_t *rp, long stride, int
     if (!fy) {
         if (!fx) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) out[i] = rp[i];
-            return;
+            for (int i = 0; i < 4; ++i) v[i] = rp[i];
+            return 0;
         }
-        int h[4]; hrow(rp, h);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) out[i] = clip8((h[i] + 32) >> 6);
-        return;
+        hrow(rp, v);
+        return 1;
     }
-    int v[4] = {0, 0, 0, 0};
+    v[0] = v[1] = v[2] = v[3] = 0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int cy = kChromaTaps[fy][r];
@@ -77,15 +82,56 @@ __device__ __forceinline__ void chroma_pred4(const uint8_t *rp, long stride, int
             for (int i = 0; i < 4; ++i) v[i] += cy * (int)(short)h[i];
         }
     }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) out[i] = fx ? clip8((v[i] + 2048) >> 12) : clip8((v[i] + 32) >> 6);
+    return fx ? 2 : 1;
 }
+// luma (interpLuma* enc@0x40e4f0..): 8 taps, 1/4 sample
+__device__ __forceinline__ int luma_raw4(const uint8_t *rp, long stride, int fx, int fy, int (&v)[4])
+{
+    auto hrow = [&](const uint8_t *row, int (&h)[4]) {            // bytes -3 .. 7
+        const uint8_t *q = row - 3;
+        const unsigned sh = (unsigned)((uintptr_t)q & 3);
+        const unsigned *a = (const unsigned *)(q - sh);
+        const unsigned a0 = a[0] ^ 0x80808080u, a1 = a[1] ^ 0x80808080u, a2 = a[2] ^ 0x80808080u, a3 = a[3] ^ 0x80808080u;
+        const unsigned w0 = align_bytes(a1, a0, sh), w1 = align_bytes(a2, a1, sh), w2 = align_bytes(a3, a2, sh);   // bytes -3..0, 1..4, 5..8
+        const int tl = pack_taps4(kLumaTaps[fx]), th = pack_taps4(kLumaTaps[fx] + 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned lo = i ? align_bytes(w1, w0, i) : w0, hi = i ? align_bytes(w2, w1, i) : w1;
+            h[i] = __builtin_amdgcn_sdot4((int)hi, th, __builtin_amdgcn_sdot4((int)lo, tl, 8192, false), false);
+        }
+    };
+    if (!fy) {
+        if (!fx) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = rp[i];
+            return 0;
+        }
+        hrow(rp, v);
+        return 1;
+    }
+    v[0] = v[1] = v[2] = v[3] = 0;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int cy = kLumaTaps[fy][r];
+        if (!fx) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] += cy * (int)rp[(r - 3) * stride + i];
+        } else {
+            int h[4]; hrow(rp + (r - 3) * stride, h);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] += cy * (int)(short)h[i];
+        }
+    }
+    return fx ? 2 : 1;
+}
+__device__ __forceinline__ int uni_round(int kind, int v) { return kind == 0 ? v : kind == 1 ? clip8((v + 32) >> 6) : clip8((v + 2048) >> 12); }
+__device__ __forceinline__ int to14(int kind, int v) { return kind == 0 ? v << 6 : kind == 1 ? v : v >> 6; }
 
 template <int RS /*region size in samples: 32 luma, 16 chroma*/>
 __device__ __forceinline__ void code_region(const KsGeom &g, int comp, int qp, int rx8, int ry8, const ks265_cu8 *blk /*LDS [16]*/,
                                             const unsigned char *tu_log2 /*LDS [16]: log2 of TU size in 8x8 blocks*/, const short *Mf, const short *Mt,
                                             short *X, short *T, unsigned char *P, int *nzcnt /*LDS [16]*/, const uint8_t *src, const uint8_t *ref,
-                                            const uint8_t *planes, int16_t *lvl, uint8_t *rec, int tid)
+                                            const uint8_t *planes, const uint8_t *ref1, const uint8_t *planes1, int16_t *lvl, uint8_t *rec, int tid)
 {
     constexpr int UNIT = RS / 4;                      // samples per 8x8-luma block along one axis
     constexpr int NQ = RS * RS / 4;                   // quads (4 adjacent samples of one row)
@@ -111,16 +157,39 @@ __device__ __forceinline__ void code_region(const KsGeom &g, int comp, int qp, i
         int pred[4] = {128, 128, 128, 128}, res[4] = {0, 0, 0, 0};
         if (coded) {
             if (c.pred_mode == 0) {
-                if (comp == 0) {
-                    const uint8_t *pp = planes + (long)((c.mvy & 3) * 4 + (c.mvx & 3)) * g.bytes_y + g.org_y + (long)(Y0 + qy + (c.mvy >> 2)) * g.sy + X0 + qx + (c.mvx >> 2);
-                    const unsigned sh = (unsigned)((uintptr_t)pp & 3);
-                    const unsigned *a = (const unsigned *)(pp - sh);
-                    const unsigned v = align_bytes(a[1], a[0], sh);
+                // ref / ref1 are the planes of THIS component (luma for comp 0: only used by bi-prediction)
+                const int dir = c.inter_dir;
+                if (dir == 3) {
+                    // bi-prediction: exact 14-bit average of the two lists (DefaultWeightedBi_c enc@0x435160)
+                    int v0[4], v1[4];
+                    const uint8_t *o0 = comp == 0 ? ks_org_y(g, ref) : ks_org_c(g, ref), *o1 = comp == 0 ? ks_org_y(g, ref1) : ks_org_c(g, ref1);
+                    int k0, k1;
+                    if (comp == 0) {
+                        k0 = luma_raw4(o0 + (long)(Y0 + qy + (c.mvy >> 2)) * g.sy + X0 + qx + (c.mvx >> 2), g.sy, c.mvx & 3, c.mvy & 3, v0);
+                        k1 = luma_raw4(o1 + (long)(Y0 + qy + (c.mv1y >> 2)) * g.sy + X0 + qx + (c.mv1x >> 2), g.sy, c.mv1x & 3, c.mv1y & 3, v1);
+                    } else {
+                        k0 = chroma_raw4(o0 + (long)(Y0 + qy + (c.mvy >> 3)) * g.sc + X0 + qx + (c.mvx >> 3), g.sc, c.mvx & 7, c.mvy & 7, v0);
+                        k1 = chroma_raw4(o1 + (long)(Y0 + qy + (c.mv1y >> 3)) * g.sc + X0 + qx + (c.mv1x >> 3), g.sc, c.mv1x & 7, c.mv1y & 7, v1);
+                    }
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) pred[i] = (v >> (8 * i)) & 255;
+                    for (int i = 0; i < 4; ++i) pred[i] = clip8(((int)(short)to14(k0, v0[i]) + (int)(short)to14(k1, v1[i]) + 64) >> 7);
                 } else {
-                    const uint8_t *rp = ks_org_c(g, ref) + (long)(Y0 + qy + (c.mvy >> 3)) * g.sc + X0 + qx + (c.mvx >> 3);
-                    chroma_pred4(rp, g.sc, c.mvx & 7, c.mvy & 7, pred);
+                    const int ux = dir == 2 ? c.mv1x : c.mvx, uy = dir == 2 ? c.mv1y : c.mvy;
+                    if (comp == 0) {
+                        const uint8_t *pb = dir == 2 ? planes1 : planes;
+                        const uint8_t *pp = pb + (long)((uy & 3) * 4 + (ux & 3)) * g.bytes_y + g.org_y + (long)(Y0 + qy + (uy >> 2)) * g.sy + X0 + qx + (ux >> 2);
+                        const unsigned sh = (unsigned)((uintptr_t)pp & 3);
+                        const unsigned *a = (const unsigned *)(pp - sh);
+                        const unsigned v = align_bytes(a[1], a[0], sh);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) pred[i] = (v >> (8 * i)) & 255;
+                    } else {
+                        const uint8_t *rp = ks_org_c(g, dir == 2 ? ref1 : ref) + (long)(Y0 + qy + (uy >> 3)) * g.sc + X0 + qx + (ux >> 3);
+                        int v[4];
+                        const int k = chroma_raw4(rp, g.sc, ux & 7, uy & 7, v);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) pred[i] = uni_round(k, v[i]);
+                    }
                 }
             }
             const unsigned sv = *(const unsigned *)(S + (long)(Y0 + qy) * stride + X0 + qx);
@@ -199,8 +268,10 @@ __device__ __forceinline__ void code_region(const KsGeom &g, int comp, int qp, i
     __syncthreads();
 }
 
+// list-1 pointers are null for I / P pictures (no block carries inter_dir 2 or 3 there)
 __global__ __launch_bounds__(256) void reconstruct_kernel(KsGeom g, int qp, const uint8_t *src_y, const uint8_t *src_u, const uint8_t *src_v,
-                                                          const uint8_t *ref_u, const uint8_t *ref_v, const uint8_t *planes, ks265_cu8 *cu8,
+                                                          const uint8_t *ref_y, const uint8_t *ref_u, const uint8_t *ref_v, const uint8_t *planes,
+                                                          const uint8_t *ref1_y, const uint8_t *ref1_u, const uint8_t *ref1_v, const uint8_t *planes1, ks265_cu8 *cu8,
                                                           int16_t *lvl_y, int16_t *lvl_u, int16_t *lvl_v, uint8_t *rec_y, uint8_t *rec_u, uint8_t *rec_v)
 {
     __shared__ __attribute__((aligned(16))) short Mf[MAT_SHORTS];
@@ -228,7 +299,7 @@ __global__ __launch_bounds__(256) void reconstruct_kernel(KsGeom g, int qp, cons
     if (tid < 16) {
         const int bx = rx * 4 + (tid & 3), by = ry * 4 + (tid >> 2);
         ks265_cu8 c;
-        c.mvx = 0; c.mvy = 0; c.log2_cu = 0; c.cbf = 0; c.pred_mode = 0; c.rsv = 0;
+        c.mvx = 0; c.mvy = 0; c.mv1x = 0; c.mv1y = 0; c.log2_cu = 0; c.cbf = 0; c.pred_mode = 0; c.inter_dir = 0;
         if (bx < g.w8 && by < g.h8) c = cu8[(long)by * g.w8 + bx];
         blk[tid] = c;
         tu_log2[tid] = (unsigned char)(c.log2_cu ? min((int)c.log2_cu - 3, 2) : 0);
@@ -236,19 +307,19 @@ __global__ __launch_bounds__(256) void reconstruct_kernel(KsGeom g, int qp, cons
     }
     __syncthreads();
     const int qpc = chroma_qp(qp);
-    code_region<32>(g, 0, qp, rx * 4, ry * 4, blk, tu_log2, Mf, Mt, X, T, P, nzcnt, src_y, nullptr, planes, lvl_y, rec_y, tid);
+    code_region<32>(g, 0, qp, rx * 4, ry * 4, blk, tu_log2, Mf, Mt, X, T, P, nzcnt, src_y, ref_y, planes, ref1_y, planes1, lvl_y, rec_y, tid);
     if (tid < 16 && blk[tid].log2_cu) {
         const int t8 = 1 << tu_log2[tid], tb = ((tid >> 2) & ~(t8 - 1)) * 4 + ((tid & 3) & ~(t8 - 1));
         if (nzcnt[tb]) cbf[tid] |= 1;
     }
     __syncthreads();
-    code_region<16>(g, 1, qpc, rx * 4, ry * 4, blk, tu_log2, Mf, Mt, X, T, P, nzcnt, src_u, ref_u, planes, lvl_u, rec_u, tid);
+    code_region<16>(g, 1, qpc, rx * 4, ry * 4, blk, tu_log2, Mf, Mt, X, T, P, nzcnt, src_u, ref_u, planes, ref1_u, planes1, lvl_u, rec_u, tid);
     if (tid < 16 && blk[tid].log2_cu) {
         const int t8 = 1 << tu_log2[tid], tb = ((tid >> 2) & ~(t8 - 1)) * 4 + ((tid & 3) & ~(t8 - 1));
         if (nzcnt[tb]) cbf[tid] |= 2;
     }
     __syncthreads();
-    code_region<16>(g, 2, qpc, rx * 4, ry * 4, blk, tu_log2, Mf, Mt, X, T, P, nzcnt, src_v, ref_v, planes, lvl_v, rec_v, tid);
+    code_region<16>(g, 2, qpc, rx * 4, ry * 4, blk, tu_log2, Mf, Mt, X, T, P, nzcnt, src_v, ref_v, planes, ref1_v, planes1, lvl_v, rec_v, tid);
     if (tid < 16 && blk[tid].log2_cu) {
         const int t8 = 1 << tu_log2[tid], tb = ((tid >> 2) & ~(t8 - 1)) * 4 + ((tid & 3) & ~(t8 - 1));
         if (nzcnt[tb]) cbf[tid] |= 4;
@@ -257,13 +328,27 @@ __global__ __launch_bounds__(256) void reconstruct_kernel(KsGeom g, int qp, cons
     }
 }
 
+static int launch_reconstruct(ks265_frame *f, ks265_pic src, ks265_pic ref0, const uint8_t *planes0, ks265_pic ref1, const uint8_t *planes1, ks265_cu8 *cu8,
+                              int16_t *lvl_y, int16_t *lvl_u, int16_t *lvl_v, ks265_pic recon)
+{
+    dim3 grid(((f->g.W + 31) / 32) * ((f->g.H + 31) / 32));
+    hipLaunchKernelGGL(reconstruct_kernel, grid, dim3(256), 0, f->ctx->stream, f->g, f->cfg.qp, src.y, src.u, src.v, ref0.y, ref0.u, ref0.v, planes0, ref1.y,
+                       ref1.u, ref1.v, planes1, cu8, lvl_y, lvl_u, lvl_v, recon.y, recon.u, recon.v);
+    return ks265_check_launch(f->ctx);
+}
+
 extern "C" int ks265_reconstruct(ks265_frame *f, ks265_pic src, ks265_pic ref, const uint8_t *planes, ks265_cu8 *cu8, int16_t *lvl_y, int16_t *lvl_u,
                                  int16_t *lvl_v, ks265_pic recon)
 {
     KS_FRAME_CHECK(f);
     if (!src.y || !cu8 || !lvl_y || !lvl_u || !lvl_v || !recon.y) return KS265_POINTER;
-    dim3 grid(((f->g.W + 31) / 32) * ((f->g.H + 31) / 32));
-    hipLaunchKernelGGL(reconstruct_kernel, grid, dim3(256), 0, f->ctx->stream, f->g, f->cfg.qp, src.y, src.u, src.v, ref.u, ref.v, planes, cu8, lvl_y,
-                       lvl_u, lvl_v, recon.y, recon.u, recon.v);
-    return ks265_check_launch(f->ctx);
+    return launch_reconstruct(f, src, ref, planes, ks265_pic{nullptr, nullptr, nullptr}, nullptr, cu8, lvl_y, lvl_u, lvl_v, recon);
+}
+
+extern "C" int ks265_reconstruct_b(ks265_frame *f, ks265_pic src, ks265_pic ref0, const uint8_t *planes0, ks265_pic ref1, const uint8_t *planes1,
+                                   ks265_cu8 *cu8, int16_t *lvl_y, int16_t *lvl_u, int16_t *lvl_v, ks265_pic recon)
+{
+    KS_FRAME_CHECK(f);
+    if (!src.y || !ref0.y || !ref1.y || !planes0 || !planes1 || !cu8 || !lvl_y || !lvl_u || !lvl_v || !recon.y) return KS265_POINTER;
+    return launch_reconstruct(f, src, ref0, planes0, ref1, planes1, cu8, lvl_y, lvl_u, lvl_v, recon);
 }

@@ -16,13 +16,14 @@ BLK3 = np.dtype([("a_off", "<i4"), ("b_off", "<i4", 3), ("w", "<i4"), ("h", "<i4
 EDGE = np.dtype([("pix_off", "<i4"), ("beta", "<i2"), ("tc", "<i2"), ("length", "<i2"), ("dir", "u1"), ("flags", "u1")])
 SAO_RECT = np.dtype([("org_off", "<i4"), ("rec_off", "<i4"), ("w", "<i4"), ("h", "<i4")])
 PU = np.dtype([("mvx", "<i2"), ("mvy", "<i2"), ("mvpx", "<i2"), ("mvpy", "<i2"), ("cost", "<u4"), ("dist", "<u4")])
-CU8 = np.dtype([("mvx", "<i2"), ("mvy", "<i2"), ("log2_cu", "u1"), ("cbf", "u1"), ("pred_mode", "u1"), ("rsv", "u1")])
+CU8 = np.dtype([("mvx", "<i2"), ("mvy", "<i2"), ("mv1x", "<i2"), ("mv1y", "<i2"), ("log2_cu", "u1"), ("cbf", "u1"), ("pred_mode", "u1"), ("inter_dir", "u1")])
+PU_B = np.dtype([("mvx", "<i2"), ("mvy", "<i2"), ("mv1x", "<i2"), ("mv1y", "<i2"), ("cost", "<u4"), ("inter_dir", "<u4")])
 SAO_PARAM = np.dtype([("type", "i1"), ("band", "i1"), ("offset", "i1", 4), ("rsv", "i1", 2)])
 
 
 class FrameCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("width", "height", "qp", "lambda_q4", "me_range", "me_method", "subme", "deblock", "sao",
-                                          "beta_offset_div2", "tc_offset_div2")]
+                                          "beta_offset_div2", "tc_offset_div2", "bframes")]
 
 
 class FrameGeom(C.Structure):
@@ -52,7 +53,8 @@ EXPORTS = [
     "ks265_sao_apply_bo_rect", "ks265_sao_apply_eo_rect", "ks265_sao_stats_batch",
     "ks265_frame_geometry", "ks265_frame_create", "ks265_frame_destroy", "ks265_frame_set_qp", "ks265_pad_picture",
     "ks265_load_i420", "ks265_store_i420", "ks265_ref_planes", "ks265_me_integer", "ks265_me_subpel", "ks265_cu_decide",
-    "ks265_cu_flat_intra", "ks265_reconstruct", "ks265_deblock", "ks265_sao", "ks265_encode_picture",
+    "ks265_cu_flat_intra", "ks265_reconstruct", "ks265_reconstruct_b", "ks265_bi_decide", "ks265_cu_decide_b", "ks265_deblock", "ks265_sao",
+    "ks265_encode_picture", "ks265_encode_picture_b",
     "ks265_frame_set_profiling", "ks265_frame_stage_ms", "ks265_frame_levels", "ks265_frame_pu", "ks265_frame_cu8", "ks265_frame_sao", "ks265_frame_planes", "ks265_sse_picture",
 ]
 
@@ -211,9 +213,9 @@ class KsFrame:
     """Whole-frame stages of include/ks265_hip.h section 3 (one picture size, one stream)."""
 
     def __init__(self, ks: KsContext, width: int, height: int, qp: int, lambda_q4: int, me_range: int = 64, subme: int = 1,
-                 deblock: int = 1, sao: int = 1, me_method: int = 0):
+                 deblock: int = 1, sao: int = 1, me_method: int = 0, bframes: int = 0):
         self.ks, self.lib = ks, ks.lib
-        self.cfg = FrameCfg(width, height, qp, lambda_q4, me_range, me_method, subme, deblock, sao, 0, 0)
+        self.cfg = FrameCfg(width, height, qp, lambda_q4, me_range, me_method, subme, deblock, sao, 0, 0, bframes)
         self.geom = FrameGeom()
         ks._chk(self.lib.ks265_frame_geometry(C.byref(self.cfg), C.byref(self.geom)))
         h = C.c_void_p()
@@ -268,6 +270,19 @@ class KsFrame:
 
     def reconstruct(self, src: DevPic, ref: DevPic, planes, cu8, lvl, recon: DevPic):
         self.ks._chk(self.lib.ks265_reconstruct(self.h, src.c(), ref.c(), _p(planes), _p(cu8), _p(lvl[0]), _p(lvl[1]), _p(lvl[2]), recon.c()))
+
+    def reconstruct_b(self, src: DevPic, ref0: DevPic, planes0, ref1: DevPic, planes1, cu8, lvl, recon: DevPic):
+        self.ks._chk(self.lib.ks265_reconstruct_b(self.h, src.c(), ref0.c(), _p(planes0), ref1.c(), _p(planes1), _p(cu8), _p(lvl[0]), _p(lvl[1]), _p(lvl[2]),
+                                                  recon.c()))
+
+    def bi_decide(self, src: DevPic, planes0, planes1, pu0, pu1, pub):
+        self.ks._chk(self.lib.ks265_bi_decide(self.h, src.c(), _p(planes0), _p(planes1), _p(pu0), _p(pu1), _p(pub)))
+
+    def cu_decide_b(self, pub, cu8):
+        self.ks._chk(self.lib.ks265_cu_decide_b(self.h, _p(pub), _p(cu8)))
+
+    def encode_picture_b(self, src: DevPic, ref0: DevPic, ref1: DevPic, recon_out: DevPic):
+        self.ks._chk(self.lib.ks265_encode_picture_b(self.h, src.c(), ref0.c(), ref1.c(), recon_out.c()))
 
     def deblock(self, cu8, recon: DevPic):
         self.ks._chk(self.lib.ks265_deblock(self.h, _p(cu8), recon.c()))

@@ -392,7 +392,7 @@ static void emit_node(const kso_frame_cfg *cfg, const kso_pu *cp, int cx, int cy
     for (int by = 0; by < s / 8; ++by)
         for (int bx = 0; bx < s / 8; ++bx) {
             kso_cu8 *c = &cu8[(long)(y0 / 8 + by) * w8 + x0 / 8 + bx];
-            c->mvx = cp[idx].mvx; c->mvy = cp[idx].mvy; c->log2_cu = (uint8_t)(6 - l); c->cbf = 0; c->pred_mode = 0; c->rsv = 0;
+            c->mvx = cp[idx].mvx; c->mvy = cp[idx].mvy; c->mv1x = 0; c->mv1y = 0; c->log2_cu = (uint8_t)(6 - l); c->cbf = 0; c->pred_mode = 0; c->inter_dir = 1;
         }
 }
 void kso_cu_decide(const kso_frame_cfg *cfg, const kso_pu *pu, kso_cu8 *cu8)
@@ -408,6 +408,84 @@ void kso_cu_decide(const kso_frame_cfg *cfg, const kso_pu *pu, kso_cu8 *cu8)
         }
 }
 
+/* ------------------------------------------------------------------ B pictures
+ * Per PU: L0 cost and L1 cost come from the two uni-directional searches; the bi-predictive candidate pairs the two winners
+ * (no joint refinement yet: interMeBiFull enc@0x4896d0 refines around them) and is judged on SATD against the rounded
+ * average of the two 8-bit predictions (the final reconstruction uses the exact 14-bit average).  Ties prefer L0, then L1. */
+void kso_bi_decide(const kso_frame_cfg *cfg, kso_pic src, const uint8_t *planes0, const uint8_t *planes1, const kso_pu *pu0, const kso_pu *pu1,
+                   kso_pu_b *pub)
+{
+    kso_frame_geom g; kso_frame_geometry(cfg, &g);
+    const uint8_t *S = org_y(&g, src.y);
+    long st = g.stride_y;
+    int lam = cfg->lambda_q4;
+    for (int cy = 0; cy < g.ctu_rows; ++cy)
+        for (int cx = 0; cx < g.ctu_cols; ++cx) {
+            long cb = (long)(cy * g.ctu_cols + cx) * 85;
+            for (int l = 0; l < 4; ++l)
+                for (int py = 0; py < (1 << l); ++py)
+                    for (int px = 0; px < (1 << l); ++px) {
+                        int i = pu_index(l, px, py);
+                        const kso_pu *a = &pu0[cb + i], *b = &pu1[cb + i];
+                        kso_pu_b *o = &pub[cb + i];
+                        o->mvx = a->mvx; o->mvy = a->mvy; o->mv1x = b->mvx; o->mv1y = b->mvy; o->cost = a->cost; o->inter_dir = 1;
+                        if (a->cost == COST_INVALID) continue;
+                        if (b->cost < o->cost) { o->cost = b->cost; o->inter_dir = 2; }
+                        int s = 64 >> l, x0 = cx * 64 + px * s, y0 = cy * 64 + py * s;
+                        const uint8_t *p0 = org_y(&g, (uint8_t *)planes0 + (long)((a->mvy & 3) * 4 + (a->mvx & 3)) * g.bytes_y) + (long)(y0 + (a->mvy >> 2)) * st + x0 + (a->mvx >> 2);
+                        const uint8_t *p1 = org_y(&g, (uint8_t *)planes1 + (long)((b->mvy & 3) * 4 + (b->mvx & 3)) * g.bytes_y) + (long)(y0 + (b->mvy >> 2)) * st + x0 + (b->mvx >> 2);
+                        uint8_t avg[64 * 64];
+                        for (int y = 0; y < s; ++y)
+                            for (int x = 0; x < s; ++x) avg[y * s + x] = (uint8_t)((p0[(long)y * st + x] + p1[(long)y * st + x] + 1) >> 1);
+                        uint32_t d = ks265o_had(S + (long)y0 * st + x0, avg, st, s, s, s);
+                        uint32_t c = d + (uint32_t)mv_cost(a->mvx, a->mvy, a->mvpx, a->mvpy, lam) + (uint32_t)mv_cost(b->mvx, b->mvy, b->mvpx, b->mvpy, lam);
+                        if (c < o->cost) { o->cost = c; o->inter_dir = 3; }
+                    }
+        }
+}
+
+static uint32_t decide_node_b(const kso_frame_cfg *cfg, const kso_pu_b *cp, int cx, int cy, int l, int px, int py, uint8_t *split)
+{
+    int s = 64 >> l, x0 = cx * 64 + px * s, y0 = cy * 64 + py * s;
+    if (x0 >= cfg->width || y0 >= cfg->height) return 0;
+    int idx = pu_index(l, px, py);
+    uint32_t own = cp[idx].cost;
+    if (l == 3) { split[idx] = 0; return own; }
+    uint64_t sum = (uint64_t)((cfg->lambda_q4 * 12) >> 4);
+    for (int k = 0; k < 4; ++k) sum += decide_node_b(cfg, cp, cx, cy, l + 1, px * 2 + (k & 1), py * 2 + (k >> 1), split);
+    if (own != COST_INVALID && (uint64_t)own <= sum) { split[idx] = 0; return own; }
+    split[idx] = 1;
+    return sum > 0xFFFFFFFEu ? 0xFFFFFFFEu : (uint32_t)sum;
+}
+static void emit_node_b(const kso_frame_cfg *cfg, const kso_pu_b *cp, int cx, int cy, int l, int px, int py, const uint8_t *split, kso_cu8 *cu8)
+{
+    int s = 64 >> l, x0 = cx * 64 + px * s, y0 = cy * 64 + py * s, w8 = cfg->width / 8;
+    if (x0 >= cfg->width || y0 >= cfg->height) return;
+    int idx = pu_index(l, px, py);
+    if (l < 3 && split[idx]) {
+        for (int k = 0; k < 4; ++k) emit_node_b(cfg, cp, cx, cy, l + 1, px * 2 + (k & 1), py * 2 + (k >> 1), split, cu8);
+        return;
+    }
+    for (int by = 0; by < s / 8; ++by)
+        for (int bx = 0; bx < s / 8; ++bx) {
+            kso_cu8 *c = &cu8[(long)(y0 / 8 + by) * w8 + x0 / 8 + bx];
+            c->mvx = cp[idx].mvx; c->mvy = cp[idx].mvy; c->mv1x = cp[idx].mv1x; c->mv1y = cp[idx].mv1y;
+            c->log2_cu = (uint8_t)(6 - l); c->cbf = 0; c->pred_mode = 0; c->inter_dir = (uint8_t)cp[idx].inter_dir;
+        }
+}
+void kso_cu_decide_b(const kso_frame_cfg *cfg, const kso_pu_b *pub, kso_cu8 *cu8)
+{
+    kso_frame_geom g; kso_frame_geometry(cfg, &g);
+    for (int cy = 0; cy < g.ctu_rows; ++cy)
+        for (int cx = 0; cx < g.ctu_cols; ++cx) {
+            const kso_pu_b *cp = pub + (long)(cy * g.ctu_cols + cx) * 85;
+            uint8_t split[85];
+            memset(split, 0, sizeof split);
+            decide_node_b(cfg, cp, cx, cy, 0, 0, 0, split);
+            emit_node_b(cfg, cp, cx, cy, 0, 0, 0, split, cu8);
+        }
+}
+
 /* key picture stand-in for the (out-of-scope) intra path: largest CU in {32,16,8} that fits, flat prediction */
 void kso_cu_flat_intra(const kso_frame_cfg *cfg, kso_cu8 *cu8)
 {
@@ -420,7 +498,7 @@ void kso_cu_flat_intra(const kso_frame_cfg *cfg, kso_cu8 *cu8)
                 if (ax + n <= w8 && ay + n <= h8) { lg = t; break; }
             }
             kso_cu8 *c = &cu8[(long)by * w8 + bx];
-            c->mvx = 0; c->mvy = 0; c->log2_cu = (uint8_t)lg; c->cbf = 0; c->pred_mode = 1; c->rsv = 0;
+            c->mvx = 0; c->mvy = 0; c->mv1x = 0; c->mv1y = 0; c->log2_cu = (uint8_t)lg; c->cbf = 0; c->pred_mode = 1; c->inter_dir = 0;
         }
 }
 
@@ -454,8 +532,37 @@ static int code_tu(const uint8_t *org, int so, const uint8_t *pred /*packed n*/,
     return 1;
 }
 
-void kso_reconstruct(const kso_frame_cfg *cfg, kso_pic src, kso_pic ref, const uint8_t *planes, kso_cu8 *cu8,
-                     int16_t *lvl_y, int16_t *lvl_u, int16_t *lvl_v, kso_pic recon)
+/* 14-bit prediction block of one list for bi-prediction (normative separable order, no -8192 offset in this codec):
+ * integer position: sample << 6 (InterpolateCopy8to16); one fraction: the raw tap sum (interp*8to16); two: H 8to16 then V 16to16 */
+static void pred14_luma(const uint8_t *ref0 /*sample (0,0)*/, long st, int x0, int y0, int n, int mvx, int mvy, int16_t *out /*n x n*/)
+{
+    const uint8_t *p = ref0 + (long)(y0 + (mvy >> 2)) * st + x0 + (mvx >> 2);
+    int fx = mvx & 3, fy = mvy & 3;
+    if (!fx && !fy) { for (int y = 0; y < n; ++y) for (int x = 0; x < n; ++x) out[y * n + x] = (int16_t)(p[(long)y * st + x] << 6); }
+    else if (!fy) ks265o_interp_luma_hor_8to16(out, n, p, (int)st, n, n, fx);
+    else if (!fx) ks265o_interp_luma_ver_8to16(out, n, p, (int)st, n, n, fy);
+    else {
+        int16_t tmp[32 * 39];
+        ks265o_interp_luma_hor_8to16(tmp, n, p - 3 * st, (int)st, n, n + 7, fx);
+        ks265o_interp_luma_ver_16to16(out, n, tmp + 3 * n, n, n, n, fy);
+    }
+}
+static void pred14_chroma(const uint8_t *ref0, long st, int xc, int yc, int n, int mvx, int mvy, int16_t *out)
+{
+    const uint8_t *p = ref0 + (long)(yc + (mvy >> 3)) * st + xc + (mvx >> 3);
+    int fx = mvx & 7, fy = mvy & 7;
+    if (!fx && !fy) { for (int y = 0; y < n; ++y) for (int x = 0; x < n; ++x) out[y * n + x] = (int16_t)(p[(long)y * st + x] << 6); }
+    else if (!fy) ks265o_interp_chroma_hor_8to16(out, n, p, (int)st, n, n, fx);
+    else if (!fx) ks265o_interp_chroma_ver_8to16(out, n, p, (int)st, n, n, fy);
+    else {
+        int16_t tmp[16 * 19];
+        ks265o_interp_chroma_hor_8to16(tmp, n, p - st, (int)st, n, n + 3, fx);
+        ks265o_interp_chroma_ver_16to16(out, n, tmp + n, n, n, n, fy);
+    }
+}
+
+void kso_reconstruct(const kso_frame_cfg *cfg, kso_pic src, kso_pic ref, const uint8_t *planes, kso_pic ref1, const uint8_t *planes1,
+                     kso_cu8 *cu8, int16_t *lvl_y, int16_t *lvl_u, int16_t *lvl_v, kso_pic recon)
 {
     kso_frame_geom g; kso_frame_geometry(cfg, &g);
     int W = cfg->width, H = cfg->height, w8 = W / 8, h8 = H / 8, qp = cfg->qp, qpc = chroma_qp(qp);
@@ -470,9 +577,17 @@ void kso_reconstruct(const kso_frame_cfg *cfg, kso_pic src, kso_pic ref, const u
             int mvx = c->mvx, mvy = c->mvy, cbf = 0;
             uint8_t pred[32 * 32];
             /* luma */
+            const int dir = intra ? 0 : c->inter_dir, mv1x = c->mv1x, mv1y = c->mv1y;
             if (intra) memset(pred, 128, sizeof pred);
-            else {
-                const uint8_t *pl = org_y(&g, (uint8_t *)planes + (long)((mvy & 3) * 4 + (mvx & 3)) * g.bytes_y) + (long)(y0 + (mvy >> 2)) * sy + x0 + (mvx >> 2);
+            else if (dir == 3) {                                /* bi: DefaultWeightedBi_c enc@0x435160 on the two 14-bit predictions */
+                int16_t a0[32 * 32], a1[32 * 32];
+                pred14_luma(org_y(&g, ref.y), sy, x0, y0, n, mvx, mvy, a0);
+                pred14_luma(org_y(&g, ref1.y), sy, x0, y0, n, mv1x, mv1y, a1);
+                ks265o_default_weighted_bi(pred, a0, a1, n, n, n, n);
+            } else {
+                const uint8_t *pb = dir == 2 ? planes1 : planes;
+                const int ux = dir == 2 ? mv1x : mvx, uy = dir == 2 ? mv1y : mvy;
+                const uint8_t *pl = org_y(&g, (uint8_t *)pb + (long)((uy & 3) * 4 + (ux & 3)) * g.bytes_y) + (long)(y0 + (uy >> 2)) * sy + x0 + (ux >> 2);
                 for (int y = 0; y < n; ++y) memcpy(pred + y * n, pl + (long)y * sy, (size_t)n);
             }
             cbf |= code_tu(org_y(&g, src.y) + (long)y0 * sy + x0, (int)sy, pred, n, qp, intra, lvl_y + (long)y0 * W + x0, W,
@@ -480,11 +595,17 @@ void kso_reconstruct(const kso_frame_cfg *cfg, kso_pic src, kso_pic ref, const u
             /* chroma: 4-tap 1/8-sample MC (interpChroma* enc@0x4111c0..), TU n/2 */
             int nc = n / 2, xc = x0 / 2, yc = y0 / 2;
             for (int comp = 0; comp < 2; ++comp) {
-                const uint8_t *rp = org_c(&g, comp ? ref.v : ref.u);
+                const uint8_t *rp = org_c(&g, dir == 2 ? (comp ? ref1.v : ref1.u) : (comp ? ref.v : ref.u));
                 if (intra) memset(pred, 128, sizeof pred);
-                else {
-                    const uint8_t *p0 = rp + (long)(yc + (mvy >> 3)) * sc + xc + (mvx >> 3);
-                    int fx = mvx & 7, fy = mvy & 7;
+                else if (dir == 3) {
+                    int16_t a0[16 * 16], a1[16 * 16];
+                    pred14_chroma(org_c(&g, comp ? ref.v : ref.u), sc, xc, yc, nc, mvx, mvy, a0);
+                    pred14_chroma(org_c(&g, comp ? ref1.v : ref1.u), sc, xc, yc, nc, mv1x, mv1y, a1);
+                    ks265o_default_weighted_bi(pred, a0, a1, nc, nc, nc, nc);
+                } else {
+                    const int ux = dir == 2 ? mv1x : mvx, uy = dir == 2 ? mv1y : mvy;
+                    const uint8_t *p0 = rp + (long)(yc + (uy >> 3)) * sc + xc + (ux >> 3);
+                    int fx = ux & 7, fy = uy & 7;
                     if (!fx && !fy) for (int y = 0; y < nc; ++y) memcpy(pred + y * nc, p0 + (long)y * sc, (size_t)nc);
                     else if (!fy) ks265o_interp_chroma_hor_8to8(pred, nc, p0, (int)sc, nc, nc, fx);
                     else if (!fx) ks265o_interp_chroma_ver_8to8(pred, nc, p0, (int)sc, nc, nc, fy);
@@ -514,7 +635,13 @@ static int edge_bs(const kso_cu8 *p, const kso_cu8 *q, int pos8 /*edge position 
     if (!tu_edge && !cu_edge) return 0;
     if (p->pred_mode == 1 || q->pred_mode == 1) return 2;
     if (tu_edge && ((p->cbf | q->cbf) & 1)) return 1;
-    if (cu_edge && (iabs_(p->mvx - q->mvx) >= 4 || iabs_(p->mvy - q->mvy) >= 4)) return 1;
+    if (cu_edge) {
+        /* CalcBsInterP enc@0x402960 / CalcBsInterB enc@0x4029d0 with one picture per list: different reference sets, or any
+         * used vector differing by a full sample */
+        if (p->inter_dir != q->inter_dir) return 1;
+        if ((p->inter_dir & 1) && (iabs_(p->mvx - q->mvx) >= 4 || iabs_(p->mvy - q->mvy) >= 4)) return 1;
+        if ((p->inter_dir & 2) && (iabs_(p->mv1x - q->mv1x) >= 4 || iabs_(p->mv1y - q->mv1y) >= 4)) return 1;
+    }
     return 0;
 }
 

@@ -18,7 +18,7 @@ extern "C" {
 #endif
 
 typedef struct {
-    int32_t width, height, qp, lambda_q4, me_range, me_method, subme, deblock, sao, beta_offset_div2, tc_offset_div2;
+    int32_t width, height, qp, lambda_q4, me_range, me_method, subme, deblock, sao, beta_offset_div2, tc_offset_div2, bframes;
 } kso_frame_cfg;
 
 typedef struct {
@@ -29,7 +29,8 @@ typedef struct {
 } kso_frame_geom;
 
 typedef struct { int16_t mvx, mvy, mvpx, mvpy; uint32_t cost, dist; } kso_pu;
-typedef struct { int16_t mvx, mvy; uint8_t log2_cu, cbf, pred_mode, rsv; } kso_cu8;
+typedef struct { int16_t mvx, mvy, mv1x, mv1y; uint8_t log2_cu, cbf, pred_mode, inter_dir; } kso_cu8;   /* inter_dir: 1 = L0, 2 = L1, 3 = Bi */
+typedef struct { int16_t mvx, mvy, mv1x, mv1y; uint32_t cost; uint32_t inter_dir; } kso_pu_b;
 typedef struct { int8_t type, band, offset[4], rsv[2]; } kso_sao_param;
 typedef struct { uint8_t *y, *u, *v; } kso_pic;
 
@@ -42,8 +43,12 @@ void kso_me_integer(const kso_frame_cfg *cfg, kso_pic src, kso_pic ref, const ks
 void kso_me_subpel(const kso_frame_cfg *cfg, kso_pic src, const uint8_t *planes, kso_pu *pu);
 void kso_cu_decide(const kso_frame_cfg *cfg, const kso_pu *pu, kso_cu8 *cu8);
 void kso_cu_flat_intra(const kso_frame_cfg *cfg, kso_cu8 *cu8);
-void kso_reconstruct(const kso_frame_cfg *cfg, kso_pic src, kso_pic ref, const uint8_t *planes, kso_cu8 *cu8,
-                     int16_t *lvl_y, int16_t *lvl_u, int16_t *lvl_v, kso_pic recon);
+void kso_reconstruct(const kso_frame_cfg *cfg, kso_pic src, kso_pic ref, const uint8_t *planes, kso_pic ref1, const uint8_t *planes1,
+                     kso_cu8 *cu8, int16_t *lvl_y, int16_t *lvl_u, int16_t *lvl_v, kso_pic recon);
+/* B pictures: per-PU choice among L0, L1 and the bi-predictive average (interMeBi* lineage), then the CU quadtree on it */
+void kso_bi_decide(const kso_frame_cfg *cfg, kso_pic src, const uint8_t *planes0, const uint8_t *planes1, const kso_pu *pu0, const kso_pu *pu1,
+                   kso_pu_b *pub);
+void kso_cu_decide_b(const kso_frame_cfg *cfg, const kso_pu_b *pub, kso_cu8 *cu8);
 void kso_deblock(const kso_frame_cfg *cfg, const kso_cu8 *cu8, kso_pic recon);
 void kso_sao(const kso_frame_cfg *cfg, kso_pic src, kso_pic deblocked, kso_sao_param *sao, kso_pic dst);
 

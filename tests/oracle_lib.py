@@ -45,7 +45,7 @@ I = C.c_int
 # ------------------------------------------------------------------ pipeline oracle (ks265_pipeline_oracle.h)
 class OFrameCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("width", "height", "qp", "lambda_q4", "me_range", "me_method", "subme", "deblock", "sao",
-                                          "beta_offset_div2", "tc_offset_div2")]
+                                          "beta_offset_div2", "tc_offset_div2", "bframes")]
 
 
 class OFrameGeom(C.Structure):
@@ -60,7 +60,8 @@ class OPic(C.Structure):
 
 
 PU = np.dtype([("mvx", "<i2"), ("mvy", "<i2"), ("mvpx", "<i2"), ("mvpy", "<i2"), ("cost", "<u4"), ("dist", "<u4")])
-CU8 = np.dtype([("mvx", "<i2"), ("mvy", "<i2"), ("log2_cu", "u1"), ("cbf", "u1"), ("pred_mode", "u1"), ("rsv", "u1")])
+CU8 = np.dtype([("mvx", "<i2"), ("mvy", "<i2"), ("mv1x", "<i2"), ("mv1y", "<i2"), ("log2_cu", "u1"), ("cbf", "u1"), ("pred_mode", "u1"), ("inter_dir", "u1")])
+PU_B = np.dtype([("mvx", "<i2"), ("mvy", "<i2"), ("mv1x", "<i2"), ("mv1y", "<i2"), ("cost", "<u4"), ("inter_dir", "<u4")])
 SAO_PARAM = np.dtype([("type", "i1"), ("band", "i1"), ("offset", "i1", 4), ("rsv", "i1", 2)])
 
 
@@ -81,7 +82,7 @@ class OraclePipeline:
 
     def __init__(self, width, height, qp, lambda_q4, me_range=64, subme=1, deblock=1, sao=1, me_method=0):
         self.o = lib()
-        self.cfg = OFrameCfg(width, height, qp, lambda_q4, me_range, me_method, subme, deblock, sao, 0, 0)
+        self.cfg = OFrameCfg(width, height, qp, lambda_q4, me_range, me_method, subme, deblock, sao, 0, 0, 1)
         self.geom = OFrameGeom()
         assert self.o.kso_frame_geometry(C.byref(self.cfg), C.byref(self.geom)) == 0
         g = self.geom
@@ -107,29 +108,52 @@ class OraclePipeline:
         self.o.kso_store_i420(C.byref(self.cfg), pic.c(), ptr(out))
         return out
 
-    def encode_picture(self, i420: np.ndarray, is_key: bool) -> np.ndarray:
-        """runs all stages; self.ref is replaced by the new reconstructed picture; returns recon I420"""
+    def encode(self, i420: np.ndarray, kind: str, ref0: "HostPic | None" = None, ref1: "HostPic | None" = None) -> "HostPic":
+        """one picture through all stages; kind 'I' (flat key picture), 'P' (ref0) or 'B' (ref0 = L0 past, ref1 = L1 future);
+        returns the reconstructed padded picture.  Intermediate results stay in self.* for stage-by-stage comparison."""
         o, cfg = self.o, C.byref(self.cfg)
         self.load(self.src, i420)
-        if is_key:
+        null = OPic(None, None, None)
+        r0 = ref0.c() if ref0 is not None else null
+        r1 = ref1.c() if ref1 is not None else null
+        p1 = None
+        if kind == "I":
             o.kso_cu_flat_intra(cfg, ptr(self.cu8))
             self.have_prev = False
         else:
-            o.kso_ref_planes(cfg, self.ref.c(), ptr(self.planes))
-            o.kso_me_integer(cfg, self.src.c(), self.ref.c(), ptr(self.prev_pu) if self.have_prev else None, ptr(self.pu))
+            o.kso_ref_planes(cfg, r0, ptr(self.planes))
+            o.kso_me_integer(cfg, self.src.c(), r0, ptr(self.prev_pu) if (self.have_prev and kind == "P") else None, ptr(self.pu))
             self.pu_int = self.pu.copy()
             if self.cfg.subme:
                 o.kso_me_subpel(cfg, self.src.c(), ptr(self.planes), ptr(self.pu))
-            o.kso_cu_decide(cfg, ptr(self.pu), ptr(self.cu8))
-        o.kso_reconstruct(cfg, self.src.c(), self.ref.c(), ptr(self.planes), ptr(self.cu8), ptr(self.lvl[0]), ptr(self.lvl[1]), ptr(self.lvl[2]),
+            if kind == "P":
+                o.kso_cu_decide(cfg, ptr(self.pu), ptr(self.cu8))
+            else:
+                if not hasattr(self, "planes1"):
+                    self.planes1 = np.zeros(16 * self.geom.bytes_y, np.uint8)
+                    self.pu1 = np.zeros(self.nctu * 85, PU)
+                    self.pub = np.zeros(self.nctu * 85, PU_B)
+                o.kso_ref_planes(cfg, r1, ptr(self.planes1))
+                o.kso_me_integer(cfg, self.src.c(), r1, None, ptr(self.pu1))
+                self.pu1_int = self.pu1.copy()
+                if self.cfg.subme:
+                    o.kso_me_subpel(cfg, self.src.c(), ptr(self.planes1), ptr(self.pu1))
+                o.kso_bi_decide(cfg, self.src.c(), ptr(self.planes), ptr(self.planes1), ptr(self.pu), ptr(self.pu1), ptr(self.pub))
+                o.kso_cu_decide_b(cfg, ptr(self.pub), ptr(self.cu8))
+                p1 = ptr(self.planes1)
+        o.kso_reconstruct(cfg, self.src.c(), r0, ptr(self.planes), r1, p1, ptr(self.cu8), ptr(self.lvl[0]), ptr(self.lvl[1]), ptr(self.lvl[2]),
                           self.rec.c())
         self.rec_pre = [self.rec.y.copy(), self.rec.u.copy(), self.rec.v.copy()]
         if self.cfg.deblock:
             o.kso_deblock(cfg, ptr(self.cu8), self.rec.c())
-        new_ref = HostPic(self.geom)
-        o.kso_sao(cfg, self.src.c(), self.rec.c(), ptr(self.sao), new_ref.c())
-        self.ref = new_ref
-        if not is_key:
+        out = HostPic(self.geom)
+        o.kso_sao(cfg, self.src.c(), self.rec.c(), ptr(self.sao), out.c())
+        if kind == "P":
             self.prev_pu, self.pu = self.pu, self.prev_pu
             self.have_prev = True
+        return out
+
+    def encode_picture(self, i420: np.ndarray, is_key: bool) -> np.ndarray:
+        """IPPP convenience: self.ref is replaced by the new reconstructed picture; returns recon I420"""
+        self.ref = self.encode(i420, "I" if is_key else "P", None if is_key else self.ref)
         return self.store(self.ref)

@@ -39,18 +39,18 @@ def test_python_export_list_matches_header():
 def test_struct_layouts_match_header(lib):
     from ks265codec_amd import lib as L
     assert L.BLK.itemsize == 16 and L.BLK3.itemsize == 24 and L.EDGE.itemsize == 12 and L.SAO_RECT.itemsize == 16
-    assert L.PU.itemsize == 16 and L.CU8.itemsize == 8 and L.SAO_PARAM.itemsize == 8
-    assert C.sizeof(L.FrameCfg) == 44 and C.sizeof(L.FrameGeom) == 80
+    assert L.PU.itemsize == 16 and L.CU8.itemsize == 12 and L.PU_B.itemsize == 16 and L.SAO_PARAM.itemsize == 8
+    assert C.sizeof(L.FrameCfg) == 48 and C.sizeof(L.FrameGeom) == 80
 
 
 def test_geometry_and_argument_errors_without_gpu(lib):
     from ks265codec_amd.lib import FrameCfg, FrameGeom
     g = FrameGeom()
-    cfg = FrameCfg(3840, 2160, 27, 80, 64, 0, 1, 1, 1, 0, 0)
+    cfg = FrameCfg(3840, 2160, 27, 80, 64, 0, 1, 1, 1, 0, 0, 0)
     assert lib.ks265_frame_geometry(C.byref(cfg), C.byref(g)) == 0
     assert (g.stride_y, g.rows_y, g.ctu_cols, g.ctu_rows, g.pu_per_ctu) == (4096, 2320, 60, 34, 85)
     assert g.stride_y % 128 == 0 and (g.pad_y * g.stride_y + g.pad_y) % 16 == 0
-    bad = FrameCfg(3841, 2160, 27, 80, 64, 0, 1, 1, 1, 0, 0)
+    bad = FrameCfg(3841, 2160, 27, 80, 64, 0, 1, 1, 1, 0, 0, 0)
     assert lib.ks265_frame_geometry(C.byref(bad), C.byref(g)) == -4          # KS265_NOTSUPPORTED
     assert lib.ks265_frame_geometry(None, C.byref(g)) == -3                  # KS265_POINTER
     assert lib.ks265_sad_batch(None, None, 0, None, 0, None, 0, None) == -3

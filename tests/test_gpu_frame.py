@@ -219,3 +219,65 @@ def test_full_size_properties_2160p(ks):
             assert coded > 20
         f.close()
     assert (outs[0] == outs[1]).all()          # run-to-run deterministic
+
+
+@pytest.mark.parametrize("W,H,seed,me", [(416, 240, 5, 1), (200, 136, 6, 0), (1280, 720, 7, 2)])
+def test_b_pictures_match_oracle(ks, W, H, seed, me):
+    """B pictures (two lists, bi-prediction with the exact 14-bit average): stage by stage and through ks265_encode_picture_b,
+    coding order I0 P4 B1 B2 B3 like -bframes 3."""
+    from ks265codec_amd.lib import CU8, PU, PU_B, KsFrame
+    from ks265codec_amd.synth import lambda_q4, make_clip
+    from oracle_lib import OraclePipeline
+
+    clip = make_clip(W, H, 5, seed=seed, abc=(17, 23, 9))
+    o = OraclePipeline(W, H, 27, lambda_q4(27), me_method=me)
+    f = KsFrame(ks, W, H, 27, lambda_q4(27), me_method=me, bframes=3)
+    g = f.geom
+    org_y, org_c = g.pad_y * g.stride_y + g.pad_y, g.pad_c * g.stride_c + g.pad_c
+    src = f.new_pic()
+    dpb_o, dpb_g = {}, {}
+
+    def code(t, kind, r0=None, r1=None, qp=27, staged=False):
+        o.set_qp(qp, lambda_q4(qp)); f.set_qp(qp, lambda_q4(qp))
+        dpb_o[t] = o.encode(clip[t], kind, dpb_o.get(r0), dpb_o.get(r1))
+        f.load_i420(ks.dev(clip[t]), src)
+        out = f.new_pic()
+        if kind != "B":
+            f.encode_picture(src, dpb_g[r0] if r0 is not None else out, kind == "I", out)
+        elif not staged:
+            f.encode_picture_b(src, dpb_g[r0], dpb_g[r1], out)
+        else:
+            planes0, planes1 = ks.zeros(16 * g.bytes_y), ks.zeros(16 * g.bytes_y)
+            pu0, pu1, pub = ks.zeros(g.bytes_pu), ks.zeros(g.bytes_pu), ks.zeros(g.bytes_pu)
+            cu8, sao = ks.zeros(g.bytes_cu8), ks.zeros(g.bytes_sao)
+            lvl = [ks.zeros(W * H * 2), ks.zeros(W * H // 2), ks.zeros(W * H // 2)]
+            deb = f.new_pic()
+            f.ref_planes(dpb_g[r0], planes0); f.ref_planes(dpb_g[r1], planes1)
+            f.me_integer(src, dpb_g[r0], None, pu0); f.me_subpel(src, planes0, pu0)
+            f.me_integer(src, dpb_g[r1], None, pu1); f.me_subpel(src, planes1, pu1)
+            assert (ks.host(pu0, PU) == o.pu).all() and (ks.host(pu1, PU) == o.pu1).all(), "list searches differ"
+            f.bi_decide(src, planes0, planes1, pu0, pu1, pub)
+            gb = ks.host(pub, PU_B)
+            assert (gb == o.pub).all(), f"bi decision differs for {int((gb != o.pub).sum())} PUs"
+            assert len(set(np.unique(gb["inter_dir"][gb["cost"] != 0xFFFFFFFF]))) == 3, "fixture should exercise L0, L1 and bi"
+            f.cu_decide_b(pub, cu8)
+            f.reconstruct_b(src, dpb_g[r0], planes0, dpb_g[r1], planes1, cu8, lvl, deb)
+            assert (ks.host(cu8, CU8) == o.cu8).all()
+            for c in range(3):
+                assert (ks.host(lvl[c], np.int16) == o.lvl[c]).all(), f"levels comp {c}"
+            _cmp_region("recon.y", ks.host(deb.y, np.uint8), o.rec_pre[0], g.stride_y, org_y, W, H)
+            _cmp_region("recon.u", ks.host(deb.u, np.uint8), o.rec_pre[1], g.stride_c, org_c, W // 2, H // 2)
+            _cmp_region("recon.v", ks.host(deb.v, np.uint8), o.rec_pre[2], g.stride_c, org_c, W // 2, H // 2)
+            f.deblock(cu8, deb)
+            _cmp_region("deblock.y", ks.host(deb.y, np.uint8), o.rec.y, g.stride_y, org_y, W, H)
+            f.sao(src, deb, sao, out)
+        dpb_g[t] = out
+        got, exp = ks.host(f.store_i420(out), np.uint8), o.store(dpb_o[t])
+        assert (got == exp).all(), f"picture {t} ({kind}): {int((got != exp).sum())} recon bytes differ"
+
+    code(0, "I")
+    code(4, "P", 0, qp=28)
+    code(1, "B", 0, 4, qp=30, staged=True)
+    code(2, "B", 0, 4, qp=30)
+    code(3, "B", 0, 4, qp=30, staged=True)
+    f.close()

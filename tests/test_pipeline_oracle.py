@@ -30,7 +30,7 @@ def test_geometry_matches_product_library():
     for (w, h) in [(416, 240), (1280, 720), (1920, 1080), (3840, 2160), (200, 136)]:
         o = OraclePipeline(w, h, 27, 80)
         g = FrameGeom()
-        assert l.ks265_frame_geometry(C.byref(FrameCfg(w, h, 27, 80, 64, 0, 1, 1, 1, 0, 0)), C.byref(g)) == 0
+        assert l.ks265_frame_geometry(C.byref(FrameCfg(w, h, 27, 80, 64, 0, 1, 1, 1, 0, 0, 0)), C.byref(g)) == 0
         for name, _ in FrameGeom._fields_:
             assert getattr(g, name) == getattr(o.geom, name), name
 
