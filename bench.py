@@ -47,12 +47,16 @@ def main():
     ap.add_argument("--iper", type=int, default=128)
     ap.add_argument("--clip-frames", type=int, default=5)
     ap.add_argument("--me", choices=["dia", "hex", "umh"], default="umh", help="integer search: -preset slow resolves to -me 2 (UMH), SURVEY.md §5")
+    ap.add_argument("--bframes", type=int, default=0, help="-bframes: B pictures between anchors (coding order P b b b); 0 = IPPP")
+    ap.add_argument("--b-spread", action="store_true", help="config-5 style: anchor chain on rank 0, RCCL broadcast of every reconstructed anchor, "
+                    "B pictures dealt to the other ranks (needs --bframes > 0); default = one GOP shard per rank, no collective")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
     import torch
     from ks265codec_amd.lib import KsContext, KsFrame
     from ks265codec_amd.synth import lambda_q4, make_clip
+    from ks265codec_amd import gop
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -70,26 +74,41 @@ def main():
     W, H, qp = args.width, args.height, args.qp
     ks = KsContext(local_rank)
     me_method = {"dia": 0, "hex": 1, "umh": 2}[args.me]
-    fr = KsFrame(ks, W, H, qp, lambda_q4(qp), me_method=me_method)
+    fr = KsFrame(ks, W, H, qp, lambda_q4(qp), me_method=me_method, bframes=args.bframes)
     # synthetic clip of SURVEY.md §8(d), one GOP shard per rank (different seed per rank = different content)
-    clip = make_clip(W, H, args.clip_frames, seed=7 + rank, abc=(67, 91, 33), pan=(8, 5))
+    clip = make_clip(W, H, args.clip_frames, seed=7 + (0 if args.b_spread else rank), abc=(67, 91, 33), pan=(8, 5))
     dev_clip = [ks.dev(c) for c in clip]
     srcs = [fr.new_pic() for _ in clip]
     for d, s in zip(dev_clip, srcs):
         fr.load_i420(d, s)
     order = list(range(len(clip))) + list(range(len(clip) - 2, 0, -1))   # ping-pong keeps the motion continuous
-    refs = [fr.new_pic(), fr.new_pic()]
+    # decoded-picture buffer: two anchors (previous / next I-or-P picture) + one scratch output for non-reference B pictures
+    anchors = [fr.new_pic(), fr.new_pic()]
+    bout = fr.new_pic()
+    nb = args.bframes
 
-    state = {"n": 0, "cur": 0}
+    sched = gop.coding_order(nb, args.iper)
+    state = {"n": 0, "cur": 0, "last": None}
+
+    def src_of(d):
+        return srcs[order[d % len(order)]]
 
     def step():
-        n = state["n"]
-        key = (n % args.iper) == 0
-        q = qp if key else qp + 1                      # the reference's hidden hierarchy offset: I = Q, P = Q+1
-        fr.set_qp(q, lambda_q4(q))
-        fr.encode_picture(srcs[order[n % len(order)]], refs[state["cur"]], key, refs[state["cur"] ^ 1])
-        state["cur"] ^= 1
-        state["n"] = n + 1
+        d, kind = next(sched)
+        cur = state["cur"]
+        if kind == "B":
+            q = qp + 2                                  # the reference's hidden hierarchy offsets: I = Q, P = Q+1, B = Q+2..
+            fr.set_qp(q, lambda_q4(q))
+            fr.encode_picture_b(src_of(d), anchors[cur ^ 1], anchors[cur], bout)   # list 0 = previous anchor, list 1 = the anchor just coded
+            state["last"] = (d, bout)
+        else:
+            q = qp if kind == "I" else qp + 1
+            fr.set_qp(q, lambda_q4(q))
+            fr.encode_picture(src_of(d), anchors[cur], kind == "I", anchors[cur ^ 1])
+            state["cur"] = cur ^ 1
+            state["last"] = (d, anchors[cur ^ 1])
+        state["kind"] = kind
+        state["n"] += 1
 
     def barrier():
         torch.cuda.synchronize()
@@ -97,19 +116,49 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
+    if args.b_spread:
+        if nb <= 0:
+            raise SystemExit("--b-spread needs --bframes > 0")
+        slots = [fr.new_pic(), fr.new_pic(), fr.new_pic()]
+
+        def enc_anchor(d, kind, prev, out):
+            q = qp if kind == "I" else qp + 1
+            fr.set_qp(q, lambda_q4(q))
+            fr.encode_picture(src_of(d), slots[prev] if prev is not None else slots[out], kind == "I", slots[out])
+
+        def enc_b(d, s0, s1):
+            fr.set_qp(qp + 2, lambda_q4(qp + 2))
+            fr.encode_picture_b(src_of(d), slots[s0], slots[s1], bout)
+
+        def bcast(slot):
+            if dist is not None:
+                for t in (slots[slot].y, slots[slot].u, slots[slot].v):
+                    dist.broadcast(t, src=0)          # RCCL over xGMI: the only exchange step of the path
+
+        per = nb + 1
+        n_mg = max(1, (args.steps * world) // per)
+        gop.spread_b(rank, world, max(1, args.warmup // per), nb, enc_anchor, enc_b, bcast)
+        barrier()
+        t0 = time.perf_counter()
+        gop.spread_b(rank, world, n_mg, nb, enc_anchor, enc_b, bcast)
+        barrier()
+        dt = time.perf_counter() - t0
+        total_pictures = 1 + n_mg * per
+    else:
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        dt = time.perf_counter() - t0
+        total_pictures = world * args.steps
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device=ks.device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    fps = world * args.steps / dt
+    fps = total_pictures / dt
 
     if rank == 0:
         # ---- PSNR-Y of the reconstructed pictures (untimed pass; CPSNR_I420::calcPSNR enc@0x4c4060)
@@ -117,8 +166,8 @@ def main():
         npic = min(8, len(order))
         for i in range(npic):
             step()
-            n = state["n"] - 1
-            s = fr.sse_picture(srcs[order[n % len(order)]], refs[state["cur"]])
+            d, pic = state["last"]
+            s = fr.sse_picture(src_of(d), pic)
             sse += int(s[0])
         mse = sse / (npic * W * H)
         psnr_y = 99.0 if mse == 0 else 10.0 * np.log10(255.0 ** 2 / mse)
@@ -129,9 +178,8 @@ def main():
         fr.set_profiling(True)
         acc, nacc = {}, 0
         for _ in range(24):
-            key = (state["n"] % args.iper) == 0
             step()
-            if key:
+            if state["kind"] != "P":                   # stage events are recorded by ks265_encode_picture (I / P pictures)
                 continue
             ms = fr.stage_ms()
             for k, v in ms.items():
@@ -159,15 +207,20 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             from oracle_lib import OraclePipeline
             o = OraclePipeline(W, H, qp, lambda_q4(qp), me_method=me_method)
-            nb = 3
+            nbase = 3
             tc0 = time.perf_counter()
-            for t in range(nb):
-                q = qp if t == 0 else qp + 1
-                o.set_qp(q, lambda_q4(q))
-                o.encode_picture(clip[t], t == 0)
+            if args.bframes == 0:
+                for t in range(nbase):
+                    q = qp if t == 0 else qp + 1
+                    o.set_qp(q, lambda_q4(q))
+                    o.encode_picture(clip[t], t == 0)
+            else:                                       # I0, P2, B1 of the same clip
+                o.set_qp(qp, lambda_q4(qp)); i0 = o.encode(clip[0], "I")
+                o.set_qp(qp + 1, lambda_q4(qp + 1)); p2 = o.encode(clip[2], "P", i0)
+                o.set_qp(qp + 2, lambda_q4(qp + 2)); o.encode(clip[1], "B", i0, p2)
             tc = time.perf_counter() - tc0
-            cpu = {"value": round(nb / tc, 4), "unit": "frames/s", "cores": 1, "kind": "port",
-                   "sample": f"{nb} pictures (1 key + {nb - 1} P) of the same {W}x{H} clip, oracle/ks265_pipeline_oracle.c, 1 thread, {tc:.1f} s"}
+            cpu = {"value": round(nbase / tc, 4), "unit": "frames/s", "cores": 1, "kind": "port",
+                   "sample": f"{nbase} pictures (1 key + {nbase - 1} {'P' if args.bframes == 0 else 'P/B'}) of the same {W}x{H} clip, oracle/ks265_pipeline_oracle.c, 1 thread, {tc:.1f} s"}
 
         line = {
             "metric": "encoded frames/sec + PSNR-Y, 2160p -preset slow -qp 27, 1/2/4/8 GPU",
@@ -175,8 +228,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{W}x{H} 4:2:0 8-bit, hot path only (ME + transform/quant/recon + deblock + SAO; CABAC/RC not included), "
-                                   f"-rc 0 -qp {qp} (I=Q, P=Q+1) -iper {args.iper}, IPPP, -me {me_method} ({args.me.upper()}) range 64, subme=8 hpel + 8 qpel SATD, sao on, df on",
-                       "pictures_per_step": 1, "sharding": "one GOP shard per GPU, no data-path collective"},
+                                   f"-rc 0 -qp {qp} (I=Q, P=Q+1, B=Q+2) -iper {args.iper}, -bframes {args.bframes}, -me {me_method} ({args.me.upper()}) range 64, subme=8 hpel + 8 qpel SATD, sao on, df on",
+                       "pictures_per_step": 1,
+                       "sharding": "anchor chain on rank 0 + RCCL broadcast of reconstructed anchors, B pictures spread" if args.b_spread else "one GOP shard per GPU, no data-path collective"},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)

@@ -1,6 +1,9 @@
-"""CPU, world_size 2 over gloo: the N>1 path of bench.py shards GOPs across ranks with no data-path collective
-(SURVEY.md §8e); only a barrier and a MAX all-reduce of the elapsed time cross ranks.  The per-rank work here is the
-CPU oracle (no GPU in this container); the sharding / reduction logic is the same code shape as bench.py."""
+"""CPU, world_size 2 over gloo: the N>1 paths of bench.py.
+  * default: GOPs sharded across ranks with NO data-path collective - only a barrier and a MAX all-reduce of the
+    elapsed time cross ranks;
+  * --b-spread (config 5): anchor chain on rank 0, every reconstructed anchor BROADCAST (RCCL on the GPU box, gloo here), the B
+    pictures dealt to the other ranks.
+The per-rank work here is the CPU oracle (no GPU in this container); the scheduling code (ks265codec_amd/gop.py) is the one bench.py runs."""
 from __future__ import annotations
 
 import os
@@ -12,19 +15,21 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+
+from ks265codec_amd.gop import b_owner, coding_order, shard_gops, spread_b  # noqa: E402
 
 
-def shard_gops(n_frames: int, iper: int, world: int, rank: int):
-    """frames [k*iper, (k+1)*iper) go to rank k % world — closed GOP per shard"""
-    return [(k * iper, min((k + 1) * iper, n_frames)) for k in range((n_frames + iper - 1) // iper) if k % world == rank]
-
-
-def _worker(rank, world, port, q):
+def _setup(rank, world, port):
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.dirname(HERE))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+
+
+def _shard_worker(rank, world, port, q):
+    _setup(rank, world, port)
     from oracle_lib import OraclePipeline
     from ks265codec_amd.synth import lambda_q4, make_clip
     W, H, iper, total = 64, 48, 2, 8
@@ -44,17 +49,21 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_gop_sharding_two_ranks():
-    world, port = 2, 29611
+def _run(worker, world, port):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=120) for _ in range(world))
+    res = sorted(q.get(timeout=180) for _ in range(world))
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
+    return res
+
+
+def test_gop_sharding_two_ranks():
+    res = _run(_shard_worker, 2, 29611)
     frames = sorted(sum((r[1] for r in res), []))
     assert frames == list(range(8))                                # every frame coded exactly once
     assert res[0][1] == [0, 1, 4, 5] and res[1][1] == [2, 3, 6, 7]
@@ -66,15 +75,71 @@ def test_gop_sharding_two_ranks():
     from ks265codec_amd.synth import lambda_q4, make_clip
     clip = make_clip(64, 48, 8, seed=11, abc=(17, 23, 9))
     o = OraclePipeline(64, 48, 27, lambda_q4(27))
-    for (a, b) in [(2, 4)]:
-        for t in range(a, b):
-            rec = o.encode_picture(clip[t], t == a)
-            assert int(rec.astype(np.int64).sum()) == res[1][2][t]
+    for t in range(2, 4):
+        rec = o.encode_picture(clip[t], t == 2)
+        assert int(rec.astype(np.int64).sum()) == res[1][2][t]
 
 
-def test_shard_gops_covers_everything():
+def _spread_run(rank, world, nmg, nb, bcast):
+    """the oracle behind gop.spread_b; returns {display index: checksum of the recon}"""
+    sys.path.insert(0, HERE)
+    from oracle_lib import HostPic, OraclePipeline
+    from ks265codec_amd.synth import lambda_q4, make_clip
+    W, H = 64, 48
+    clip = make_clip(W, H, 1 + nmg * (nb + 1), seed=5, abc=(17, 23, 9))
+    o = OraclePipeline(W, H, 27, lambda_q4(27))
+    slots = [HostPic(o.geom) for _ in range(3)]
+    sums = {}
+
+    def put(slot, pic):
+        for a, b in ((slots[slot].y, pic.y), (slots[slot].u, pic.u), (slots[slot].v, pic.v)):
+            a[:] = b
+
+    def enc_anchor(d, kind, prev, out):
+        o.set_qp(27 if kind == "I" else 28, lambda_q4(28))
+        pic = o.encode(clip[d], kind, slots[prev] if prev is not None else None)
+        put(out, pic)
+        sums[d] = int(o.store(pic).astype(np.int64).sum())
+
+    def enc_b(d, s0, s1):
+        o.set_qp(29, lambda_q4(29))
+        sums[d] = int(o.store(o.encode(clip[d], "B", slots[s0], slots[s1])).astype(np.int64).sum())
+
+    mine = spread_b(rank, world, nmg, nb, enc_anchor, enc_b, lambda s: bcast(slots[s]))
+    return mine, sums
+
+
+def _spread_worker(rank, world, port, q):
+    _setup(rank, world, port)
+
+    def bcast(pic):
+        for arr in (pic.y, pic.u, pic.v):
+            t = torch.from_numpy(arr)                              # shares memory with the numpy plane
+            dist.broadcast(t, src=0)
+
+    mine, sums = _spread_run(rank, world, 2, 3, bcast)
+    q.put((rank, mine, sums))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_b_spread_two_ranks_matches_single_process():
+    """anchors on rank 0 + broadcast, B pictures on rank 1: every picture coded once and identical to the 1-process run"""
+    res = _run(_spread_worker, 2, 29613)
+    (_, mine0, sums0), (_, mine1, sums1) = res
+    assert [k for _, k in mine0] == ["I", "P", "P"] and all(k == "B" for _, k in mine1) and len(mine1) == 6
+    single_mine, single = _spread_run(0, 1, 2, 3, lambda pic: None)
+    assert sorted(d for d, _ in mine0 + mine1) == sorted(d for d, _ in single_mine) == list(range(9))
+    merged = dict(sums0); merged.update(sums1)
+    assert merged == single
+
+
+def test_schedules_cover_everything():
     for world in (1, 2, 4, 8):
         seen = []
         for r in range(world):
             seen += [t for a, b in shard_gops(1000, 128, world, r) for t in range(a, b)]
         assert sorted(seen) == list(range(1000))
+        assert sorted(b_owner(j, world) for j in range(7)) == sorted([0] * 7 if world == 1 else [1 + j % (world - 1) for j in range(7)])
+    it = coding_order(3, 8)
+    assert [next(it) for _ in range(10)] == [(0, "I"), (4, "P"), (1, "B"), (2, "B"), (3, "B"), (8, "I"), (5, "B"), (6, "B"), (7, "B"), (12, "P")]
