@@ -8,7 +8,8 @@
  *
  * Pinning: every function here is checked bit-for-bit against outputs of the reference
  * binary's own `_c` kernels (oracle/ref_probe/, fixtures in tests/golden/ (npz files),
- * test: tests/test_oracle_golden.py).  Parity is therefore PINNED at kernel level.
+ * test: tests/test_oracle_golden.py), and slotted behind the reference's own operator tables they leave its .265 byte-identical
+ * (oracle/ref_probe/seam_harness.py, tests/test_seam.py).  Parity is therefore PINNED at kernel level.
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may call this.
  */
