@@ -15,8 +15,7 @@ int ks265_create(ks265_ctx **out, int device)
     c->device = device;
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return KS265_FAIL; }
     c->own_stream = true;
-    hipEventCreate(&c->ev0);
-    hipEventCreate(&c->ev1);
+    if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) { ks265_destroy(c); return KS265_FAIL; }
     *out = c;
     return KS265_OK;
 }
@@ -24,18 +23,18 @@ int ks265_create(ks265_ctx **out, int device)
 void ks265_destroy(ks265_ctx *c)
 {
     if (!c) return;
-    hipSetDevice(c->device);
-    hipStreamSynchronize(c->stream);
-    if (c->ev0) hipEventDestroy(c->ev0);
-    if (c->ev1) hipEventDestroy(c->ev1);
-    if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
 
 int ks265_set_stream(ks265_ctx *c, void *s)
 {
     if (!c) return KS265_POINTER;
-    if (c->own_stream && c->stream) { hipStreamSynchronize(c->stream); hipStreamDestroy(c->stream); }
+    if (c->own_stream && c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
     c->stream = (hipStream_t)s;
     c->own_stream = false;
     return KS265_OK;

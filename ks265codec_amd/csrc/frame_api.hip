@@ -30,7 +30,7 @@ int ks265_frame_create(ks265_ctx *ctx, const ks265_frame_cfg *cfg, ks265_frame *
     g.W = cfg->width; g.H = cfg->height; g.sy = geom.stride_y; g.sc = geom.stride_c; g.bytes_y = geom.bytes_y; g.bytes_c = geom.bytes_c;
     g.ctu_cols = geom.ctu_cols; g.ctu_rows = geom.ctu_rows; g.w8 = cfg->width / 8; g.h8 = cfg->height / 8;
     g.org_y = (long)KS_PAD_Y * g.sy + KS_PAD_Y; g.org_c = (long)KS_PAD_C * g.sc + KS_PAD_C;
-    hipSetDevice(ctx->device);
+    (void)hipSetDevice(ctx->device);
     const size_t npx = (size_t)g.W * g.H;
     r = dev_alloc(ctx, (void **)&f->planes, (size_t)16 * g.bytes_y, true);
     for (int i = 0; i < 2 && !r; ++i) r = dev_alloc(ctx, (void **)&f->pu[i], (size_t)geom.bytes_pu, true);
@@ -56,12 +56,12 @@ int ks265_frame_create(ks265_ctx *ctx, const ks265_frame_cfg *cfg, ks265_frame *
 void ks265_frame_destroy(ks265_frame *f)
 {
     if (!f) return;
-    if (f->ctx) { hipSetDevice(f->ctx->device); hipStreamSynchronize(f->ctx->stream); }
+    if (f->ctx) { (void)hipSetDevice(f->ctx->device); (void)hipStreamSynchronize(f->ctx->stream); }
     for (int i = 0; i <= KS_NSTAGE; ++i)
-        if (f->ev[i]) hipEventDestroy(f->ev[i]);
+        if (f->ev[i]) (void)hipEventDestroy(f->ev[i]);
     void *ptrs[] = {f->planes1, f->pu1, f->pub, f->planes, f->pu[0], f->pu[1], f->cu8, f->sao, f->lvl[0], f->lvl[1], f->lvl[2], f->deb[0], f->deb[1], f->deb[2], f->sse};
     for (void *p : ptrs)
-        if (p) hipFree(p);
+        if (p) (void)hipFree(p);
     delete f;
 }
 
@@ -83,7 +83,7 @@ int ks265_encode_picture(ks265_frame *f, ks265_pic src, ks265_pic ref, int is_ke
     auto mark = [&](int stage_done) {                      // stage boundary: event stage_done closes stage (stage_done - 1)
         if (!f->profiling) return;
         while (evi < stage_done) f->ev_valid[evi++] = false;   // skipped stages of a key picture
-        hipEventRecord(f->ev[stage_done], f->ctx->stream);
+        (void)hipEventRecord(f->ev[stage_done], f->ctx->stream);
         f->ev_valid[stage_done] = true;
         evi = stage_done + 1;
     };
@@ -156,7 +156,7 @@ int ks265_frame_stage_ms(ks265_frame *f, float ms[7])
     if (r) return r;
     for (int s = 0; s < KS_NSTAGE; ++s) {
         ms[s] = -1.0f;
-        if (f->ev_valid[s] && f->ev_valid[s + 1]) hipEventElapsedTime(&ms[s], f->ev[s], f->ev[s + 1]);
+        if (f->ev_valid[s] && f->ev_valid[s + 1] && hipEventElapsedTime(&ms[s], f->ev[s], f->ev[s + 1]) != hipSuccess) ms[s] = -1.0f;
     }
     return KS265_OK;
 }

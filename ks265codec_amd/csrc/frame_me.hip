@@ -100,11 +100,6 @@ __device__ __forceinline__ void me_level(const KsGeom &g, int cx, int cy, int ra
             const int ext = root ? range : max(range >> 2, 4);     // pattern extent (see oracle): full range for a root PU, a quarter around an inherited vector
             // Every lane of a PU carries the same (mx, my, bcost); candidates outside +-range cost KS_COST_INF and are read at the
             // (always valid) origin instead.  Groups that do not take a step keep executing it with en = false.
-            auto cost_at = [&](int x, int y) -> unsigned {
-                const bool in = abs(x) <= range && abs(y) <= range;
-                const unsigned sd = group_sum<G>(seg_sad(in ? x : 0, in ? y : 0));
-                return in ? sd + imv_cost(in ? x : 0, in ? y : 0, pmx, pmy) : 0x07FFFFFFu;
-            };
             // N candidates at once: the N partial SADs are accumulated first and the N group reductions (DPP / swizzle chains)
             // are then independent instruction streams the scheduler interleaves - the search is latency bound, not ALU bound
             auto cost_multi = [&](auto n_tag, const int *xs, const int *ys, unsigned *out) {
@@ -252,7 +247,6 @@ __device__ __forceinline__ void me_level(const KsGeom &g, int cx, int cy, int ra
                     // the four replica waves therefore each take a quarter of the candidates, remember the scan position (key) of
                     // their winner and merge through LDS.
                     constexpr bool COOP = LEVEL == 0;
-                    constexpr int NW = COOP ? 4 : 1;
                     unsigned bkey = 0;                                   // 0 = the incumbent
                     auto try_k = [&](auto n_tag, const int *xs, const int *ys, const unsigned *keys, bool en) {
                         constexpr int N = decltype(n_tag)::value;
@@ -380,7 +374,7 @@ __device__ __forceinline__ void me_level(const KsGeom &g, int cx, int cy, int ra
 }
 
 template <int METHOD>   // one instantiation per search pattern: DIA keeps its small register footprint (3 workgroups / CU)
-__global__ __launch_bounds__(256) void me_int_kernel(KsGeom g, int range, int lam, const uint8_t *src, const uint8_t *ref, const ks265_pu *prev,
+__global__ __launch_bounds__(256, 3) void me_int_kernel(KsGeom g, int range, int lam, const uint8_t *src, const uint8_t *ref, const ks265_pu *prev,
                                                      ks265_pu *out)
 {
     __shared__ __attribute__((aligned(16))) uint8_t win[WIN_ROWS * WIN_STRIDE];
@@ -462,10 +456,17 @@ __device__ __forceinline__ unsigned satd8x8(const unsigned (&f)[16], const uint8
         for (int i = 0; i < 64; i += 2 * len)
 #pragma unroll
             for (int j = i; j < i + len; ++j) { const int u = d[j], v = d[j + len]; d[j] = u + v; d[j + len] = u - v; }
-    unsigned acc = 0;
+    // four independent accumulator chains: a single chain of 64 dependent v_sad_u32 showed up as 38 % issue stalls (SQ_WAIT_INST_ANY)
+    unsigned a0 = 0, a1 = 0, a2 = 0, a3 = 0;
     const unsigned bias = 0x8000u;
 #pragma unroll
-    for (int i = 0; i < 64; ++i) asm("v_sad_u32 %0, %1, %2, %0" : "+v"(acc) : "v"(d[i]), "s"(bias));   // no clang builtin for v_sad_u32
+    for (int i = 0; i < 64; i += 4) {                                   // no clang builtin for v_sad_u32
+        asm("v_sad_u32 %0, %1, %2, %0" : "+v"(a0) : "v"(d[i]), "s"(bias));
+        asm("v_sad_u32 %0, %1, %2, %0" : "+v"(a1) : "v"(d[i + 1]), "s"(bias));
+        asm("v_sad_u32 %0, %1, %2, %0" : "+v"(a2) : "v"(d[i + 2]), "s"(bias));
+        asm("v_sad_u32 %0, %1, %2, %0" : "+v"(a3) : "v"(d[i + 3]), "s"(bias));
+    }
+    const unsigned acc = (a0 + a1) + (a2 + a3);
     return (acc + 2) >> 2;
 }
 
@@ -659,10 +660,16 @@ __device__ __forceinline__ unsigned satd8x8_avg(const unsigned (&f)[16], const u
         for (int i = 0; i < 64; i += 2 * len)
 #pragma unroll
             for (int j = i; j < i + len; ++j) { const int u = d[j], v = d[j + len]; d[j] = u + v; d[j + len] = u - v; }
-    unsigned acc = 0;
+    unsigned a0 = 0, a1 = 0, a2 = 0, a3 = 0;
     const unsigned bias = 0x8000u;
 #pragma unroll
-    for (int i = 0; i < 64; ++i) asm("v_sad_u32 %0, %1, %2, %0" : "+v"(acc) : "v"(d[i]), "s"(bias));
+    for (int i = 0; i < 64; i += 4) {                                   // no clang builtin for v_sad_u32
+        asm("v_sad_u32 %0, %1, %2, %0" : "+v"(a0) : "v"(d[i]), "s"(bias));
+        asm("v_sad_u32 %0, %1, %2, %0" : "+v"(a1) : "v"(d[i + 1]), "s"(bias));
+        asm("v_sad_u32 %0, %1, %2, %0" : "+v"(a2) : "v"(d[i + 2]), "s"(bias));
+        asm("v_sad_u32 %0, %1, %2, %0" : "+v"(a3) : "v"(d[i + 3]), "s"(bias));
+    }
+    const unsigned acc = (a0 + a1) + (a2 + a3);
     return (acc + 2) >> 2;
 }
 
