@@ -10,6 +10,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libks265hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wextra", "-Wno-unused-parameter", "-Wno-unused-function"]
+FLAGS += os.environ.get("KS265_EXTRA_FLAGS", "").split()          # tuning experiments only (e.g. -DKS_SUBPEL_NT=64)
 
 
 def sources() -> list[str]:

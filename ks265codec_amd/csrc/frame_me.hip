@@ -488,68 +488,155 @@ __device__ __forceinline__ unsigned pu_group_sum(unsigned v, int level)
     return v;
 }
 
-#ifndef KS_SUBPEL_LOCKSTEP
-#define KS_SUBPEL_LOCKSTEP 1
+// Stage B: sub-pel refinement of all 85 PUs of a CTU (subMeSquare enc@0x4b5660 lineage: centre + 8 half-pel, then 8 quarter-pel
+// candidates around the half-pel winner, SATD + mv rate).
+//
+// The four quadtree levels of a CTU look at the same 64 8x8 tiles, and where a PU and its ancestors search around the same
+// centre (most of them: only ~30 % of the 256 (level, tile) pairs of a CTU are distinct on the bench clip) the tile SATDs of
+// the whole ring are identical.  Each phase therefore (1) builds the list of DISTINCT (tile, centre) items of the CTU,
+// (2) evaluates every ring candidate of every item once, items spread over the threads, SATDs into LDS, and (3) lets each
+// (level, tile) pair pick its item's SATDs, sum them over the PU and keep the winner.  Pure memoisation: every value used is
+// the one the pair would have computed itself, so the result is that of the straightforward evaluation, bit for bit.
+#ifndef KS_SUBPEL_NC
+#define KS_SUBPEL_NC 4                                             // CTUs pooled per work-group (one wave each)
 #endif
-__global__ __launch_bounds__(256) void me_subpel_kernel(KsGeom g, int lam, const uint8_t *src, const uint8_t *planes, ks265_pu *pus)
+template <int NC>
+__global__ __launch_bounds__(NC * 64) void me_subpel_kernel(KsGeom g, int lam, const uint8_t *src, const uint8_t *planes, ks265_pu *pus)
 {
-    const int tid = threadIdx.x, lane = tid & 63, level = tid >> 6;
-    const int ctu = ks_xcd_swizzle(blockIdx.x, g.ctu_cols * g.ctu_rows), cx = ctu % g.ctu_cols, cy = ctu / g.ctu_cols;
-    ks265_pu *cp = pus + (long)ctu * 85;
+    constexpr int NT = NC * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nctu = g.ctu_cols * g.ctu_rows;
+    const int grp = ks_xcd_swizzle(blockIdx.x, (nctu + NC - 1) / NC);
+    const int ctu = grp * NC + wave;                               // this wave keeps the books of one CTU, all four levels
+    const bool have = ctu < nctu;
+    ks265_pu *cp = pus + (long)(have ? ctu : 0) * 85;
     const uint8_t *Sp = ks_org_y(g, src);
-    const int G = 1 << (2 * (3 - level));                          // lanes (tiles) per PU: 64, 16, 4, 1
     // Z-order: lane bits (y2 x2 y1 x1 y0 x0)
     const int tx = (lane & 1) | ((lane >> 1) & 2) | ((lane >> 2) & 4), ty = ((lane >> 1) & 1) | ((lane >> 2) & 2) | ((lane >> 3) & 4);
-    const int x0 = cx * 64 + tx * 8, y0 = cy * 64 + ty * 8;
-    const int px = tx >> (3 - level), py = ty >> (3 - level), pidx = ks_level_base(level) + py * (1 << level) + px;
-    ks265_pu p = cp[pidx];
-    const bool valid = p.cost != KS_COST_INVALID;                  // the whole PU lies inside the picture
-    unsigned f[16];
-    {
-        const uint8_t *frow = Sp + (long)(valid ? y0 : cy * 64) * g.sy + (valid ? x0 : cx * 64);
+    bool valid[4];
+    int pidx[4], bx[4], by[4];
+    unsigned bc[4], bd[4];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) { const uint2 v = *(const uint2 *)(frow + (long)r * g.sy); f[2 * r] = v.x; f[2 * r + 1] = v.y; }
+    for (int l = 0; l < 4; ++l) {
+        const int px = tx >> (3 - l), py = ty >> (3 - l);
+        pidx[l] = ks_level_base(l) + py * (1 << l) + px;
+        const ks265_pu p = cp[pidx[l]];
+        valid[l] = have && p.cost != KS_COST_INVALID;              // the whole PU lies inside the picture
+        bx[l] = p.mvx; by[l] = p.mvy; bc[l] = 0; bd[l] = 0;
     }
-    const long base = (long)(valid ? y0 : 0) * g.sy + (valid ? x0 : 0) + g.org_y;
-    int bx = p.mvx, by = p.mvy;
-    unsigned bc = 0, bd = 0;
     // candidate k: 0 = centre, 1..8 = the ring in raster order (hpel_x/y, qpel_x/y tables).
     // Evaluation order is free as long as the winner is the reference's: smallest cost, ties to the smallest k (the reference
-    // walks k upwards with a strict '<').  Half-pel candidates are therefore visited plane by plane (centre; the two on the
-    // vertical plane; the two on the horizontal plane; the four on the diagonal plane) so that consecutive candidates hit
-    // the same cache lines.
+    // walks k upwards with a strict '<').  Half-pel candidates are visited plane by plane (centre; the two on the vertical
+    // plane; the two on the horizontal plane; the four on the diagonal plane) so that consecutive candidates hit the same
+    // cache lines.
     auto cand = [](int k, int &dx, int &dy) { const int gi = k == 0 ? 4 : (k - 1 + (k > 4)); dx = gi % 3 - 1; dy = gi / 3 - 1; };
-    const unsigned order_hpel = 0x63154720u;                      // nibble n = n-th candidate visited: 0, 2,7 (vertical), 4,5 (horizontal), 1,3,6 (+ 8 below: diagonal)
+    auto visit = [](int phase, int n) { return phase == 0 ? (n == 8 ? 8 : (int)((0x63154720u >> (4 * n)) & 15u)) : n; };
+    __shared__ int s_key[NC][4][64];
+    __shared__ unsigned short s_idx[NC][4][64];
+    __shared__ unsigned short s_item[NC * 256];
+    __shared__ int s_cnt[NC * 4];
+    __shared__ unsigned s_sat[9][NC * 256];
 #pragma unroll 1
     for (int phase = 0; phase < 2; ++phase) {                     // 0: centre + half-pel ring, 1: quarter-pel ring
         const int step = phase == 0 ? 2 : 1;
-        const int cx0 = bx, cy0 = by;
-        int bk = 0;
-#pragma unroll 1
-        for (int n = phase; n < 9; ++n) {
-            if (KS_SUBPEL_LOCKSTEP) __syncthreads();               // the four levels touch the same plane rows together -> L1 reuse
-            // keep the 16 packed source dwords opaque inside the loop: otherwise LICM hoists the 64 unpacked source bytes
-            // out of the candidate loop (+64 VGPRs, occupancy 2); the byte selects ride on the SDWA subtract anyway
+        int owner[4];
+        __syncthreads();                                           // the previous phase's readers are done
 #pragma unroll
-            for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(f[i]));
-            const int k = phase == 0 ? (n == 8 ? 8 : (int)((order_hpel >> (4 * n)) & 15u)) : n;
-            int dx, dy;
-            cand(k, dx, dy);
-            const int qx = cx0 + dx * step, qy = cy0 + dy * step;
-            const int ax = valid ? qx : 0, ay = valid ? qy : 0;
-            const uint8_t *pp = planes + (long)((ay & 3) * 4 + (ax & 3)) * g.bytes_y + base + (long)(ay >> 2) * g.sy + (ax >> 2);
-            const unsigned sd = satd8x8(f, pp, g.sy);
-            const unsigned dd = pu_group_sum(valid ? sd : 0, level);
-            const unsigned cc = dd + (unsigned)mv_cost(qx, qy, p.mvpx, p.mvpy, lam);
-            // phase 0 starts from nothing (n == 0 is the centre); phase 1 starts from the half-pel winner, which every
-            // quarter-pel candidate must beat strictly (it is "earlier" than all of them)
-            const bool first = phase == 0 && n == 0;
-            if (first || cc < bc || (cc == bc && phase == 0 && k < bk)) { bc = cc; bd = dd; bx = qx; by = qy; bk = k; }
+        for (int l = 0; l < 4; ++l)
+            s_key[wave][l][lane] = valid[l] ? ((bx[l] & 0xFFFF) | (by[l] << 16)) : (int)(0x80000000u | (unsigned)l);
+        // (1) the distinct (tile, centre) items; a wave only reads its own keys here, no barrier needed yet
+        unsigned long long bal[4];
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+            const int me = valid[l] ? ((bx[l] & 0xFFFF) | (by[l] << 16)) : (int)(0x80000000u | (unsigned)l);
+            owner[l] = l;
+#pragma unroll
+            for (int m = 3; m >= 0; --m) {
+                const int km = valid[m] ? ((bx[m] & 0xFFFF) | (by[m] << 16)) : (int)(0x80000000u | (unsigned)m);
+                if (km == me) owner[l] = m;                        // the coarsest level with this centre
+            }
+            bal[l] = __ballot(valid[l] && owner[l] == l);
+            if (lane == 0) s_cnt[wave * 4 + l] = __popcll(bal[l]);
+        }
+        __syncthreads();
+        int nitems = 0;
+        {
+            int off = 0;
+#pragma unroll
+            for (int q = 0; q < NC * 4; ++q) { const int c = s_cnt[q]; off += q < wave * 4 ? c : 0; nitems += c; }
+#pragma unroll
+            for (int l = 0; l < 4; ++l) {
+                if (valid[l] && owner[l] == l) {
+                    const int idx = off + __popcll(bal[l] & ((1ull << lane) - 1ull));
+                    s_idx[wave][l][lane] = (unsigned short)idx;
+                    s_item[idx] = (unsigned short)(lane | (l << 6) | (wave << 8));
+                }
+                off += __popcll(bal[l]);
+            }
+        }
+        __syncthreads();
+        // (2) every candidate of every distinct item, once; items spread over all threads of the group
+#pragma unroll 1
+        for (int i = tid; i < nitems; i += NT) {
+            const int it = s_item[i], il = it & 63, iw = it >> 8, key = s_key[iw][(it >> 6) & 3][il];
+            const int ictu = grp * NC + iw, icx0 = ictu % g.ctu_cols, icy0 = ictu / g.ctu_cols;
+            const int itx = (il & 1) | ((il >> 1) & 2) | ((il >> 2) & 4), ity = ((il >> 1) & 1) | ((il >> 2) & 2) | ((il >> 3) & 4);
+            const int ix0 = icx0 * 64 + itx * 8, iy0 = icy0 * 64 + ity * 8;
+            const int icx = (int)(short)(key & 0xFFFF), icy = key >> 16;
+            unsigned f[16];
+            const uint8_t *frow = Sp + (long)iy0 * g.sy + ix0;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { const uint2 v = *(const uint2 *)(frow + (long)r * g.sy); f[2 * r] = v.x; f[2 * r + 1] = v.y; }
+            const long ibase = (long)iy0 * g.sy + ix0 + g.org_y;
+#pragma unroll 1
+            for (int n = phase; n < 9; ++n) {
+                // keep the 16 packed source dwords opaque inside the loop: otherwise LICM hoists the 64 unpacked source
+                // bytes out of the candidate loop (+64 VGPRs); the byte selects ride on the SDWA subtract anyway
+#pragma unroll
+                for (int q = 0; q < 16; ++q) asm volatile("" : "+v"(f[q]));
+                int dx, dy;
+                cand(visit(phase, n), dx, dy);
+                const int ax = icx + dx * step, ay = icy + dy * step;
+                const uint8_t *pp = planes + (long)((ay & 3) * 4 + (ax & 3)) * g.bytes_y + ibase + (long)(ay >> 2) * g.sy + (ax >> 2);
+#ifdef KS_EXP_NOSATD
+                s_sat[n][i] = f[n] + pp[0];
+#else
+                s_sat[n][i] = satd8x8(f, pp, g.sy);
+#endif
+            }
+        }
+        __syncthreads();
+        // (3) per (level, tile): PU sums and the winner
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+            const int myitem = valid[l] ? s_idx[wave][owner[l]][lane] : 0;
+            const ks265_pu p = cp[pidx[l]];
+            const int cx0 = bx[l], cy0 = by[l];
+            int bk = 0;
+#pragma unroll 1
+            for (int n = phase; n < 9; ++n) {
+                const int k = visit(phase, n);
+                int dx, dy;
+                cand(k, dx, dy);
+                const int qx = cx0 + dx * step, qy = cy0 + dy * step;
+                const unsigned sd = s_sat[n][myitem];
+                const unsigned dd = pu_group_sum(valid[l] ? sd : 0, l);
+                const unsigned cc = dd + (unsigned)mv_cost(qx, qy, p.mvpx, p.mvpy, lam);
+                // phase 0 starts from nothing (n == 0 is the centre); phase 1 starts from the half-pel winner, which every
+                // quarter-pel candidate must beat strictly (it is "earlier" than all of them)
+                const bool first = phase == 0 && n == 0;
+                if (first || cc < bc[l] || (cc == bc[l] && phase == 0 && k < bk)) { bc[l] = cc; bd[l] = dd; bx[l] = qx; by[l] = qy; bk = k; }
+            }
         }
     }
-    if (valid && (lane & (G - 1)) == 0) {
-        p.mvx = (int16_t)bx; p.mvy = (int16_t)by; p.cost = bc; p.dist = bd;
-        cp[pidx] = p;
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+        const int G = 1 << (2 * (3 - l));                          // lanes (tiles) per PU: 64, 16, 4, 1
+        if (valid[l] && (lane & (G - 1)) == 0) {
+            ks265_pu o = cp[pidx[l]];
+            o.mvx = (int16_t)bx[l]; o.mvy = (int16_t)by[l]; o.cost = bc[l]; o.dist = bd[l];
+            cp[pidx[l]] = o;
+        }
     }
 }
 
@@ -557,7 +644,7 @@ extern "C" int ks265_me_subpel(ks265_frame *f, ks265_pic src, const uint8_t *pla
 {
     KS_FRAME_CHECK(f);
     if (!src.y || !planes || !pu) return KS265_POINTER;
-    hipLaunchKernelGGL(me_subpel_kernel, dim3(f->g.ctu_cols * f->g.ctu_rows), dim3(256), 0, f->ctx->stream, f->g, f->cfg.lambda_q4, src.y, planes, pu);
+    hipLaunchKernelGGL(me_subpel_kernel<KS_SUBPEL_NC>, dim3((f->g.ctu_cols * f->g.ctu_rows + KS_SUBPEL_NC - 1) / KS_SUBPEL_NC), dim3(KS_SUBPEL_NC * 64), 0, f->ctx->stream, f->g, f->cfg.lambda_q4, src.y, planes, pu);
     return ks265_check_launch(f->ctx);
 }
 
