@@ -470,6 +470,8 @@ __device__ __forceinline__ unsigned satd8x8(const unsigned (&f)[16], const uint8
     return (acc + 2) >> 2;
 }
 
+typedef int ks_v4i __attribute__((ext_vector_type(4)));
+
 // sum over the aligned group of 1 / 4 / 16 / 64 lanes that forms one PU at `level` (wave-uniform)
 __device__ __forceinline__ unsigned pu_group_sum(unsigned v, int level)
 {
@@ -500,8 +502,11 @@ __device__ __forceinline__ unsigned pu_group_sum(unsigned v, int level)
 #ifndef KS_SUBPEL_NC
 #define KS_SUBPEL_NC 4                                             // CTUs pooled per work-group (one wave each)
 #endif
+#ifndef KS_SUBPEL_OCC
+#define KS_SUBPEL_OCC 3
+#endif
 template <int NC>
-__global__ __launch_bounds__(NC * 64) void me_subpel_kernel(KsGeom g, int lam, const uint8_t *src, const uint8_t *planes, ks265_pu *pus)
+__global__ __launch_bounds__(NC * 64, KS_SUBPEL_OCC) void me_subpel_kernel(KsGeom g, int lam, const uint8_t *src, const uint8_t *planes, ks265_pu *pus)
 {
     constexpr int NT = NC * 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -531,11 +536,41 @@ __global__ __launch_bounds__(NC * 64) void me_subpel_kernel(KsGeom g, int lam, c
     // cache lines.
     auto cand = [](int k, int &dx, int &dy) { const int gi = k == 0 ? 4 : (k - 1 + (k > 4)); dx = gi % 3 - 1; dy = gi / 3 - 1; };
     auto visit = [](int phase, int n) { return phase == 0 ? (n == 8 ? 8 : (int)((0x63154720u >> (4 * n)) & 15u)) : n; };
+    // MFMA operands of the Hadamard SATD (see phase (2) below)
+    const int n16 = lane & 15, gk = lane >> 4;
+    ks_v4i Hm[4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            unsigned v = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) v |= ((__popc((mb * 16 + n16) & (gk * 16 + w * 4 + b)) & 1) ? 0xFFu : 0x01u) << (8 * b);
+            Hm[mb][w] = (int)v;
+        }
+    // `before` = the (Z-ordered) lanes whose tile precedes this lane's tile in RASTER order.  Items are listed level by level
+    // in raster order, so that the 16 columns of an MFMA operand block are mostly x-adjacent tiles: with equal centres their
+    // rows are adjacent 8-byte pieces of the same cache lines (the L1 sees a few lines per load instead of 64).
+    unsigned long long before = 0;
+    {
+        const unsigned long long row0 = 0x0000000000330033ull, col0 = 0x0000050500000505ull;   // lanes with ty == 0 / tx == 0
+        unsigned long long cols = 0;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int zy = ((t & 1) << 1) | ((t & 2) << 2) | ((t & 4) << 3), zx = (t & 1) | ((t & 2) << 1) | ((t & 4) << 2);
+            if (t < ty) before |= row0 << zy;
+            if (t < tx) cols |= col0 << zx;
+        }
+        const int zyme = ((ty & 1) << 1) | ((ty & 2) << 2) | ((ty & 4) << 3);
+        before |= (row0 << zyme) & cols;
+    }
+    const ks_v4i CinN = {0x8000, 0x8000, 0x8000, 0x8000};
+    const ks_v4i Cin0 = {gk == 0 ? 0x8000 + 64 : 0x8000, 0x8000, 0x8000, 0x8000};   // output row = 4 * gk + register
     __shared__ int s_key[NC][4][64];
     __shared__ unsigned short s_idx[NC][4][64];
     __shared__ unsigned short s_item[NC * 256];
     __shared__ int s_cnt[NC * 4];
-    __shared__ unsigned s_sat[9][NC * 256];
+    __shared__ unsigned short s_sat[9][NC * 256];                 // an 8x8 SATD is at most 8 * 8 * 8 * 255 / 4 = 32640
 #pragma unroll 1
     for (int phase = 0; phase < 2; ++phase) {                     // 0: centre + half-pel ring, 1: quarter-pel ring
         const int step = phase == 0 ? 2 : 1;
@@ -567,7 +602,7 @@ __global__ __launch_bounds__(NC * 64) void me_subpel_kernel(KsGeom g, int lam, c
 #pragma unroll
             for (int l = 0; l < 4; ++l) {
                 if (valid[l] && owner[l] == l) {
-                    const int idx = off + __popcll(bal[l] & ((1ull << lane) - 1ull));
+                    const int idx = off + __popcll(bal[l] & before);   // raster order within the level
                     s_idx[wave][l][lane] = (unsigned short)idx;
                     s_item[idx] = (unsigned short)(lane | (l << 6) | (wave << 8));
                 }
@@ -575,34 +610,76 @@ __global__ __launch_bounds__(NC * 64) void me_subpel_kernel(KsGeom g, int lam, c
             }
         }
         __syncthreads();
-        // (2) every candidate of every distinct item, once; items spread over all threads of the group
+        // (2) every candidate of every distinct item, once.  A wave takes 64 items at a time and runs their 8x8 Hadamard
+        // transforms on the matrix cores: with x the 64 pixels of a tile, the 2-D Hadamard transform is the 64x64 +-1 matrix
+        // H = H8 (x) H8 applied to x, i.e. an i8 GEMM  C[64 coefficients][64 tiles] = H . X  with exact i32 accumulation:
+        // 16 v_mfma_i32_16x16x64_i8 per operand matrix.  Two MFMAs chained on one accumulator give the transform of the
+        // DIFFERENCE directly: C = bias + H.(ref - 128) + H.(~(src - 128)), and ~(s - 128) = -(s - 128) - 1 whose "-1" lands
+        // on coefficient 0 only (+64 folded into that accumulator's start value).  bias = 2^15 keeps every coefficient
+        // positive in 16 bits, so |c| + accumulate is one v_sad_u16 against the bias.  sum |c| does not depend on the order
+        // of the Hadamard rows, nor on how the K slots of the A and B operands are numbered (both operands use the same
+        // numbering), so the sum equals had_c's (enc@0x47b680) butterfly network bit for bit.
+        // Operand layout: lane = (column n16 = lane & 15, K group gk = lane >> 4); its 16 K slots hold rows 2gk, 2gk+1 of the tile.
 #pragma unroll 1
-        for (int i = tid; i < nitems; i += NT) {
-            const int it = s_item[i], il = it & 63, iw = it >> 8, key = s_key[iw][(it >> 6) & 3][il];
-            const int ictu = grp * NC + iw, icx0 = ictu % g.ctu_cols, icy0 = ictu / g.ctu_cols;
-            const int itx = (il & 1) | ((il >> 1) & 2) | ((il >> 2) & 4), ity = ((il >> 1) & 1) | ((il >> 2) & 2) | ((il >> 3) & 4);
-            const int ix0 = icx0 * 64 + itx * 8, iy0 = icy0 * 64 + ity * 8;
-            const int icx = (int)(short)(key & 0xFFFF), icy = key >> 16;
-            unsigned f[16];
-            const uint8_t *frow = Sp + (long)iy0 * g.sy + ix0;
+        for (int base = wave * 64; base < nitems; base += NT) {
+            long ib[4];
+            int icx[4], icy[4];
+            ks_v4i S[4];
 #pragma unroll
-            for (int r = 0; r < 8; ++r) { const uint2 v = *(const uint2 *)(frow + (long)r * g.sy); f[2 * r] = v.x; f[2 * r + 1] = v.y; }
-            const long ibase = (long)iy0 * g.sy + ix0 + g.org_y;
-#pragma unroll 1
-            for (int n = phase; n < 9; ++n) {
-                // keep the 16 packed source dwords opaque inside the loop: otherwise LICM hoists the 64 unpacked source
-                // bytes out of the candidate loop (+64 VGPRs); the byte selects ride on the SDWA subtract anyway
-#pragma unroll
-                for (int q = 0; q < 16; ++q) asm volatile("" : "+v"(f[q]));
+            for (int nb = 0; nb < 4; ++nb) {
+                const int ii = base + nb * 16 + n16;
+                const int it = s_item[ii < nitems ? ii : base];     // the last chunk is padded with copies of its first item
+                const int il = it & 63, iw = it >> 8, key = s_key[iw][(it >> 6) & 3][il];
+                const int ictu = grp * NC + iw, icx0 = ictu % g.ctu_cols, icy0 = ictu / g.ctu_cols;
+                const int itx = (il & 1) | ((il >> 1) & 2) | ((il >> 2) & 4), ity = ((il >> 1) & 1) | ((il >> 2) & 2) | ((il >> 3) & 4);
+                const long ro = (long)(icy0 * 64 + ity * 8 + 2 * gk) * g.sy + icx0 * 64 + itx * 8;
+                icx[nb] = (int)(short)(key & 0xFFFF); icy[nb] = key >> 16;
+                ib[nb] = ro + g.org_y;
+                const uint2 a0 = *(const uint2 *)(Sp + ro), a1 = *(const uint2 *)(Sp + ro + g.sy);
+                S[nb] = ks_v4i{(int)(a0.x ^ 0x7F7F7F7Fu), (int)(a0.y ^ 0x7F7F7F7Fu), (int)(a1.x ^ 0x7F7F7F7Fu), (int)(a1.y ^ 0x7F7F7F7Fu)};
+            }
+            // the reference rows of candidate n + 1 are requested before candidate n is transformed (register double buffer)
+            auto fetch = [&](int n, uint2 (&r)[8]) {
                 int dx, dy;
                 cand(visit(phase, n), dx, dy);
-                const int ax = icx + dx * step, ay = icy + dy * step;
-                const uint8_t *pp = planes + (long)((ay & 3) * 4 + (ax & 3)) * g.bytes_y + ibase + (long)(ay >> 2) * g.sy + (ax >> 2);
-#ifdef KS_EXP_NOSATD
-                s_sat[n][i] = f[n] + pp[0];
-#else
-                s_sat[n][i] = satd8x8(f, pp, g.sy);
-#endif
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) {
+                    const int ax = icx[nb] + dx * step, ay = icy[nb] + dy * step;
+                    const uint8_t *pp = planes + (long)((ay & 3) * 4 + (ax & 3)) * g.bytes_y + ib[nb] + (long)(ay >> 2) * g.sy + (ax >> 2);
+                    __builtin_memcpy(&r[2 * nb], pp, 8);            // byte-aligned 8-byte loads (global_load_dwordx2)
+                    __builtin_memcpy(&r[2 * nb + 1], pp + g.sy, 8);
+                }
+            };
+            uint2 cur[8];
+            fetch(phase, cur);
+#pragma unroll 1
+            for (int n = phase; n < 9; ++n) {
+                uint2 nxt[8];
+                fetch(n < 8 ? n + 1 : n, nxt);
+                unsigned acc[4];
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) {
+                    const uint2 r0 = cur[2 * nb], r1 = cur[2 * nb + 1];
+                    const ks_v4i B = {(int)(r0.x ^ 0x80808080u), (int)(r0.y ^ 0x80808080u), (int)(r1.x ^ 0x80808080u), (int)(r1.y ^ 0x80808080u)};
+                    unsigned a = 0;
+#pragma unroll
+                    for (int mb = 0; mb < 4; ++mb) {
+                        ks_v4i C = __builtin_amdgcn_mfma_i32_16x16x64_i8(Hm[mb], B, mb == 0 ? Cin0 : CinN, 0, 0, 0);
+                        C = __builtin_amdgcn_mfma_i32_16x16x64_i8(Hm[mb], S[nb], C, 0, 0, 0);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) a = __builtin_amdgcn_sad_u16((unsigned)C[r], 0x8000u, a);
+                    }
+                    acc[nb] = a;
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) cur[q] = nxt[q];
+                // acc[nb] = this lane's share (16 of the 64 coefficients) of item nb*16 + n16: butterfly over the four K groups
+                // so that lane L ends up with the total of item base + L
+                const bool o1 = gk & 1, o2 = gk & 2;
+                const unsigned t0 = (o1 ? acc[1] : acc[0]) + (unsigned)__builtin_amdgcn_ds_swizzle((int)(o1 ? acc[0] : acc[1]), 0x1F | (16 << 10));
+                const unsigned t1 = (o1 ? acc[3] : acc[2]) + (unsigned)__builtin_amdgcn_ds_swizzle((int)(o1 ? acc[2] : acc[3]), 0x1F | (16 << 10));
+                const unsigned tot = (o2 ? t1 : t0) + (unsigned)__shfl_xor((int)(o2 ? t0 : t1), 32, 64);
+                if (base + lane < nitems) s_sat[n][base + lane] = (unsigned short)((tot + 2) >> 2);
             }
         }
         __syncthreads();
