@@ -27,6 +27,7 @@ int ks265_frame_create(ks265_ctx *ctx, const ks265_frame_cfg *cfg, ks265_frame *
     ks265_frame *f = new ks265_frame();
     f->ctx = ctx; f->cfg = *cfg; f->geom = geom;
     KsGeom &g = f->g;
+    if ((long long)16 * geom.bytes_y >= (1ll << 32)) return KS265_NOTSUPPORTED;   /* stage B addresses the 16 planes with 32-bit offsets (8K = 0.6 GB fits) */
     g.W = cfg->width; g.H = cfg->height; g.sy = geom.stride_y; g.sc = geom.stride_c; g.bytes_y = geom.bytes_y; g.bytes_c = geom.bytes_c;
     g.ctu_cols = geom.ctu_cols; g.ctu_rows = geom.ctu_rows; g.w8 = cfg->width / 8; g.h8 = cfg->height / 8;
     g.org_y = (long)KS_PAD_Y * g.sy + KS_PAD_Y; g.org_c = (long)KS_PAD_C * g.sc + KS_PAD_C;

@@ -500,10 +500,10 @@ __device__ __forceinline__ unsigned pu_group_sum(unsigned v, int level)
 // (level, tile) pair pick its item's SATDs, sum them over the PU and keep the winner.  Pure memoisation: every value used is
 // the one the pair would have computed itself, so the result is that of the straightforward evaluation, bit for bit.
 #ifndef KS_SUBPEL_NC
-#define KS_SUBPEL_NC 4                                             // CTUs pooled per work-group (one wave each)
+#define KS_SUBPEL_NC 8                                             // CTUs pooled per work-group (one wave each)
 #endif
 #ifndef KS_SUBPEL_OCC
-#define KS_SUBPEL_OCC 3
+#define KS_SUBPEL_OCC 2
 #endif
 template <int NC>
 __global__ __launch_bounds__(NC * 64, KS_SUBPEL_OCC) void me_subpel_kernel(KsGeom g, int lam, const uint8_t *src, const uint8_t *planes, ks265_pu *pus)
@@ -516,10 +516,17 @@ __global__ __launch_bounds__(NC * 64, KS_SUBPEL_OCC) void me_subpel_kernel(KsGeo
     const bool have = ctu < nctu;
     ks265_pu *cp = pus + (long)(have ? ctu : 0) * 85;
     const uint8_t *Sp = ks_org_y(g, src);
+    __shared__ int s_org[NC];                                      // pixel origin of each wave's CTU: x | y << 16
+    __shared__ int s_key[NC][4][64];
+    __shared__ unsigned short s_idx[NC][4][64];
+    __shared__ unsigned short s_item[NC * 256];
+    __shared__ int s_cnt[NC * 4];
+    __shared__ unsigned short s_sat[9][NC * 256];                 // an 8x8 SATD is at most 8 * 8 * 8 * 255 / 4 = 32640
+    if (lane == 0) s_org[wave] = have ? ((ctu % g.ctu_cols) * 64) | (((ctu / g.ctu_cols) * 64) << 16) : 0;
     // Z-order: lane bits (y2 x2 y1 x1 y0 x0)
     const int tx = (lane & 1) | ((lane >> 1) & 2) | ((lane >> 2) & 4), ty = ((lane >> 1) & 1) | ((lane >> 2) & 2) | ((lane >> 3) & 4);
     bool valid[4];
-    int pidx[4], bx[4], by[4];
+    int pidx[4], bx[4], by[4], mvpx[4], mvpy[4];
     unsigned bc[4], bd[4];
 #pragma unroll
     for (int l = 0; l < 4; ++l) {
@@ -527,27 +534,30 @@ __global__ __launch_bounds__(NC * 64, KS_SUBPEL_OCC) void me_subpel_kernel(KsGeo
         pidx[l] = ks_level_base(l) + py * (1 << l) + px;
         const ks265_pu p = cp[pidx[l]];
         valid[l] = have && p.cost != KS_COST_INVALID;              // the whole PU lies inside the picture
-        bx[l] = p.mvx; by[l] = p.mvy; bc[l] = 0; bd[l] = 0;
+        bx[l] = p.mvx; by[l] = p.mvy; mvpx[l] = p.mvpx; mvpy[l] = p.mvpy; bc[l] = 0; bd[l] = 0;
     }
-    // candidate k: 0 = centre, 1..8 = the ring in raster order (hpel_x/y, qpel_x/y tables).
+    // Candidates: k = 0 is the centre, k = 1..8 the ring in raster order (hpel_x/y, qpel_x/y tables).
     // Evaluation order is free as long as the winner is the reference's: smallest cost, ties to the smallest k (the reference
     // walks k upwards with a strict '<').  Half-pel candidates are visited plane by plane (centre; the two on the vertical
     // plane; the two on the horizontal plane; the four on the diagonal plane) so that consecutive candidates hit the same
-    // cache lines.
-    auto cand = [](int k, int &dx, int &dy) { const int gi = k == 0 ? 4 : (k - 1 + (k > 4)); dx = gi % 3 - 1; dy = gi / 3 - 1; };
-    auto visit = [](int phase, int n) { return phase == 0 ? (n == 8 ? 8 : (int)((0x63154720u >> (4 * n)) & 15u)) : n; };
-    // MFMA operands of the Hadamard SATD (see phase (2) below)
+    // cache lines; quarter-pel candidates in ring order.  Tables: 2-bit fields (d + 1), field n = n-th candidate visited.
+    constexpr unsigned kVisit0 = 0x63154720u;                     // nibble n = k of the n-th half-pel candidate visited (n < 8; n == 8 -> 8)
+    constexpr unsigned kDx[2] = {0x22215u, 0x24891u}, kDy[2] = {0x28161u, 0x2a501u};
+
+    // MFMA operands of the Hadamard SATD (see phase (2) below).  A operand = rows mb*16 + n16 of H = H8 (x) H8 in natural
+    // (Sylvester) order: H[m][k] = (-1)^popcount(m & k); this lane's 16 K slots are k = gk*16 .. gk*16 + 15.
     const int n16 = lane & 15, gk = lane >> 4;
     ks_v4i Hm[4];
+    {
+        const unsigned pat = (n16 & 2) ? ((n16 & 1) ? 0x01FFFF01u : 0xFFFF0101u) : ((n16 & 1) ? 0xFF01FF01u : 0x01010101u);   // signs over k & 3
 #pragma unroll
-    for (int mb = 0; mb < 4; ++mb)
+        for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            unsigned v = 0;
-#pragma unroll
-            for (int b = 0; b < 4; ++b) v |= ((__popc((mb * 16 + n16) & (gk * 16 + w * 4 + b)) & 1) ? 0xFFu : 0x01u) << (8 * b);
-            Hm[mb][w] = (int)v;
-        }
+            for (int w = 0; w < 4; ++w)
+                Hm[mb][w] = (int)((__popc((mb * 16 + n16) & (gk * 16 + w * 4)) & 1) ? pat ^ 0xFEFEFEFEu : pat);
+    }
+    const ks_v4i CinN = {0x8000, 0x8000, 0x8000, 0x8000};
+    const ks_v4i Cin0 = {gk == 0 ? 0x8000 + 64 : 0x8000, 0x8000, 0x8000, 0x8000};   // output row = 4 * gk + register
     // `before` = the (Z-ordered) lanes whose tile precedes this lane's tile in RASTER order.  Items are listed level by level
     // in raster order, so that the 16 columns of an MFMA operand block are mostly x-adjacent tiles: with equal centres their
     // rows are adjacent 8-byte pieces of the same cache lines (the L1 sees a few lines per load instead of 64).
@@ -564,32 +574,24 @@ __global__ __launch_bounds__(NC * 64, KS_SUBPEL_OCC) void me_subpel_kernel(KsGeo
         const int zyme = ((ty & 1) << 1) | ((ty & 2) << 2) | ((ty & 4) << 3);
         before |= (row0 << zyme) & cols;
     }
-    const ks_v4i CinN = {0x8000, 0x8000, 0x8000, 0x8000};
-    const ks_v4i Cin0 = {gk == 0 ? 0x8000 + 64 : 0x8000, 0x8000, 0x8000, 0x8000};   // output row = 4 * gk + register
-    __shared__ int s_key[NC][4][64];
-    __shared__ unsigned short s_idx[NC][4][64];
-    __shared__ unsigned short s_item[NC * 256];
-    __shared__ int s_cnt[NC * 4];
-    __shared__ unsigned short s_sat[9][NC * 256];                 // an 8x8 SATD is at most 8 * 8 * 8 * 255 / 4 = 32640
-#pragma unroll 1
+#pragma unroll
     for (int phase = 0; phase < 2; ++phase) {                     // 0: centre + half-pel ring, 1: quarter-pel ring
         const int step = phase == 0 ? 2 : 1;
         int owner[4];
-        __syncthreads();                                           // the previous phase's readers are done
-#pragma unroll
-        for (int l = 0; l < 4; ++l)
-            s_key[wave][l][lane] = valid[l] ? ((bx[l] & 0xFFFF) | (by[l] << 16)) : (int)(0x80000000u | (unsigned)l);
-        // (1) the distinct (tile, centre) items; a wave only reads its own keys here, no barrier needed yet
+        __syncthreads();                                           // the previous phase's readers are done (and s_org is written)
+        // (1) the distinct (tile, centre) items of the group
+        int key[4];
         unsigned long long bal[4];
 #pragma unroll
         for (int l = 0; l < 4; ++l) {
-            const int me = valid[l] ? ((bx[l] & 0xFFFF) | (by[l] << 16)) : (int)(0x80000000u | (unsigned)l);
+            key[l] = valid[l] ? ((bx[l] & 0xFFFF) | (by[l] << 16)) : (int)(0x80000000u | (unsigned)l);
+            s_key[wave][l][lane] = key[l];
+        }
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
             owner[l] = l;
 #pragma unroll
-            for (int m = 3; m >= 0; --m) {
-                const int km = valid[m] ? ((bx[m] & 0xFFFF) | (by[m] << 16)) : (int)(0x80000000u | (unsigned)m);
-                if (km == me) owner[l] = m;                        // the coarsest level with this centre
-            }
+            for (int m = 3; m >= 0; --m) if (key[m] == key[l]) owner[l] = m;   // the coarsest level with this centre
             bal[l] = __ballot(valid[l] && owner[l] == l);
             if (lane == 0) s_cnt[wave * 4 + l] = __popcll(bal[l]);
         }
@@ -622,44 +624,34 @@ __global__ __launch_bounds__(NC * 64, KS_SUBPEL_OCC) void me_subpel_kernel(KsGeo
         // Operand layout: lane = (column n16 = lane & 15, K group gk = lane >> 4); its 16 K slots hold rows 2gk, 2gk+1 of the tile.
 #pragma unroll 1
         for (int base = wave * 64; base < nitems; base += NT) {
-            long ib[4];
+            unsigned ibo[4];                                        // byte offset of this lane's two rows inside a plane
             int icx[4], icy[4];
             ks_v4i S[4];
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb) {
                 const int ii = base + nb * 16 + n16;
                 const int it = s_item[ii < nitems ? ii : base];     // the last chunk is padded with copies of its first item
-                const int il = it & 63, iw = it >> 8, key = s_key[iw][(it >> 6) & 3][il];
-                const int ictu = grp * NC + iw, icx0 = ictu % g.ctu_cols, icy0 = ictu / g.ctu_cols;
+                const int il = it & 63, iw = it >> 8, ikey = s_key[iw][(it >> 6) & 3][il], org = s_org[iw];
                 const int itx = (il & 1) | ((il >> 1) & 2) | ((il >> 2) & 4), ity = ((il >> 1) & 1) | ((il >> 2) & 2) | ((il >> 3) & 4);
-                const long ro = (long)(icy0 * 64 + ity * 8 + 2 * gk) * g.sy + icx0 * 64 + itx * 8;
-                icx[nb] = (int)(short)(key & 0xFFFF); icy[nb] = key >> 16;
-                ib[nb] = ro + g.org_y;
-                const uint2 a0 = *(const uint2 *)(Sp + ro), a1 = *(const uint2 *)(Sp + ro + g.sy);
+                const unsigned ro = (unsigned)(((org >> 16) + ity * 8 + 2 * gk) * g.sy + (org & 0xFFFF) + itx * 8);
+                icx[nb] = (int)(short)(ikey & 0xFFFF); icy[nb] = ikey >> 16;
+                ibo[nb] = ro + (unsigned)g.org_y;
+                const uint2 a0 = *(const uint2 *)(Sp + ro), a1 = *(const uint2 *)(Sp + ro + (unsigned)g.sy);
                 S[nb] = ks_v4i{(int)(a0.x ^ 0x7F7F7F7Fu), (int)(a0.y ^ 0x7F7F7F7Fu), (int)(a1.x ^ 0x7F7F7F7Fu), (int)(a1.y ^ 0x7F7F7F7Fu)};
             }
-            // the reference rows of candidate n + 1 are requested before candidate n is transformed (register double buffer)
-            auto fetch = [&](int n, uint2 (&r)[8]) {
-                int dx, dy;
-                cand(visit(phase, n), dx, dy);
-#pragma unroll
-                for (int nb = 0; nb < 4; ++nb) {
-                    const int ax = icx[nb] + dx * step, ay = icy[nb] + dy * step;
-                    const uint8_t *pp = planes + (long)((ay & 3) * 4 + (ax & 3)) * g.bytes_y + ib[nb] + (long)(ay >> 2) * g.sy + (ax >> 2);
-                    __builtin_memcpy(&r[2 * nb], pp, 8);            // byte-aligned 8-byte loads (global_load_dwordx2)
-                    __builtin_memcpy(&r[2 * nb + 1], pp + g.sy, 8);
-                }
-            };
-            uint2 cur[8];
-            fetch(phase, cur);
 #pragma unroll 1
             for (int n = phase; n < 9; ++n) {
-                uint2 nxt[8];
-                fetch(n < 8 ? n + 1 : n, nxt);
+                const int dxs = ((int)((kDx[phase] >> (2 * n)) & 3u) - 1) * step, dys = ((int)((kDy[phase] >> (2 * n)) & 3u) - 1) * step;
                 unsigned acc[4];
 #pragma unroll
                 for (int nb = 0; nb < 4; ++nb) {
-                    const uint2 r0 = cur[2 * nb], r1 = cur[2 * nb + 1];
+                    const int ax = icx[nb] + dxs, ay = icy[nb] + dys;
+                    // 16 planes of bytes_y each: every offset fits 32 bits (checked at frame creation)
+                    const unsigned off = (unsigned)((ay & 3) * 4 + (ax & 3)) * (unsigned)g.bytes_y + (unsigned)((int)ibo[nb] + (ay >> 2) * g.sy + (ax >> 2));
+                    const uint8_t *pp = planes + off;
+                    uint2 r0, r1;
+                    __builtin_memcpy(&r0, pp, 8);                    // byte-aligned 8-byte loads (global_load_dwordx2)
+                    __builtin_memcpy(&r1, pp + g.sy, 8);
                     const ks_v4i B = {(int)(r0.x ^ 0x80808080u), (int)(r0.y ^ 0x80808080u), (int)(r1.x ^ 0x80808080u), (int)(r1.y ^ 0x80808080u)};
                     unsigned a = 0;
 #pragma unroll
@@ -671,8 +663,6 @@ __global__ __launch_bounds__(NC * 64, KS_SUBPEL_OCC) void me_subpel_kernel(KsGeo
                     }
                     acc[nb] = a;
                 }
-#pragma unroll
-                for (int q = 0; q < 8; ++q) cur[q] = nxt[q];
                 // acc[nb] = this lane's share (16 of the 64 coefficients) of item nb*16 + n16: butterfly over the four K groups
                 // so that lane L ends up with the total of item base + L
                 const bool o1 = gk & 1, o2 = gk & 2;
@@ -683,26 +673,29 @@ __global__ __launch_bounds__(NC * 64, KS_SUBPEL_OCC) void me_subpel_kernel(KsGeo
             }
         }
         __syncthreads();
-        // (3) per (level, tile): PU sums and the winner
+        // (3) per (level, tile): PU sums and the winner.  The mv rate is separable: lambda * (bits(x) + bits(y)) >> 4 with three
+        // possible x and three possible y per PU.
 #pragma unroll
         for (int l = 0; l < 4; ++l) {
             const int myitem = valid[l] ? s_idx[wave][owner[l]][lane] : 0;
-            const ks265_pu p = cp[pidx[l]];
             const int cx0 = bx[l], cy0 = by[l];
+            int bitx[3], bity[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { bitx[j] = se_bits(cx0 + (j - 1) * step - mvpx[l]); bity[j] = se_bits(cy0 + (j - 1) * step - mvpy[l]); }
             int bk = 0;
-#pragma unroll 1
+#pragma unroll
             for (int n = phase; n < 9; ++n) {
-                const int k = visit(phase, n);
-                int dx, dy;
-                cand(k, dx, dy);
-                const int qx = cx0 + dx * step, qy = cy0 + dy * step;
+                const int k = phase == 0 ? (n == 8 ? 8 : (int)((kVisit0 >> (4 * n)) & 15u)) : n;
+                const int jx = (int)((kDx[phase] >> (2 * n)) & 3u), jy = (int)((kDy[phase] >> (2 * n)) & 3u);
                 const unsigned sd = s_sat[n][myitem];
                 const unsigned dd = pu_group_sum(valid[l] ? sd : 0, l);
-                const unsigned cc = dd + (unsigned)mv_cost(qx, qy, p.mvpx, p.mvpy, lam);
+                const unsigned cc = dd + (unsigned)((lam * (bitx[jx] + bity[jy])) >> 4);
                 // phase 0 starts from nothing (n == 0 is the centre); phase 1 starts from the half-pel winner, which every
                 // quarter-pel candidate must beat strictly (it is "earlier" than all of them)
                 const bool first = phase == 0 && n == 0;
-                if (first || cc < bc[l] || (cc == bc[l] && phase == 0 && k < bk)) { bc[l] = cc; bd[l] = dd; bx[l] = qx; by[l] = qy; bk = k; }
+                if (first || cc < bc[l] || (cc == bc[l] && phase == 0 && k < bk)) {
+                    bc[l] = cc; bd[l] = dd; bx[l] = cx0 + (jx - 1) * step; by[l] = cy0 + (jy - 1) * step; bk = k;
+                }
             }
         }
     }
@@ -710,8 +703,8 @@ __global__ __launch_bounds__(NC * 64, KS_SUBPEL_OCC) void me_subpel_kernel(KsGeo
     for (int l = 0; l < 4; ++l) {
         const int G = 1 << (2 * (3 - l));                          // lanes (tiles) per PU: 64, 16, 4, 1
         if (valid[l] && (lane & (G - 1)) == 0) {
-            ks265_pu o = cp[pidx[l]];
-            o.mvx = (int16_t)bx[l]; o.mvy = (int16_t)by[l]; o.cost = bc[l]; o.dist = bd[l];
+            ks265_pu o;
+            o.mvx = (int16_t)bx[l]; o.mvy = (int16_t)by[l]; o.mvpx = (int16_t)mvpx[l]; o.mvpy = (int16_t)mvpy[l]; o.cost = bc[l]; o.dist = bd[l];
             cp[pidx[l]] = o;
         }
     }
