@@ -4,8 +4,8 @@
 //            diamond loop (interMeDia enc@0x48fbe0) coarse to fine.  One lane = one row segment of one PU;
 //            v_sad_u8 on packed dwords, v_alignbyte for the unaligned window reads, DPP/ds_swizzle group reductions.
 //   Stage B  ks265_me_subpel  : 8 half-pel + 8 quarter-pel SATD candidates per PU on the precomputed fractional planes
-//            (subMeSquare enc@0x4b5660; had_c enc@0x47b680).  8 lanes per 8x8 tile: horizontal Hadamard in registers,
-//            vertical Hadamard across lanes.
+//            (subMeSquare enc@0x4b5660; had_c enc@0x47b680).  Distinct (tile, centre) items per CTU group, their 8x8
+//            Hadamard transforms as i8 MFMA GEMMs (H8 (x) H8), PU sums by DPP.
 //   Stage C  ks265_cu_decide  : bottom-up quadtree compare.
 #include "frame_common.h"
 #include <type_traits>
@@ -117,12 +117,34 @@ __device__ __forceinline__ void me_level(const KsGeom &g, int cx, int cy, int ra
                     out[n] = in ? sd + imv_cost(in ? xs[n] : 0, in ? ys[n] : 0, pmx, pmy) : 0x07FFFFFFu;
                 }
             };
+            // Level 0 under UMH: the CTU has ONE 64x64 PU and the work-group four waves.  All four carry the same search state
+            // (replicas); every batch of candidates is dealt out over the waves (each reads the 64x64 window once per candidate
+            // it owns - the search is LDS-bandwidth bound, so four replicas evaluating the same candidate would cost four
+            // times the LDS traffic) and the partial winners are merged through LDS.  The reference's sequential "first
+            // strictly better" scan equals argmin by (cost, scan position), so the merge keeps a scan key next to each cost.
+            const bool coop = LEVEL == 0 && method == 2;
+            auto wave_min = [&](unsigned v) -> unsigned {
+                if (!coop) return v;
+                if ((tid & 63) == 0) comb[wv][0] = v;
+                __syncthreads();
+                const unsigned r = min(min(comb[0][0], comb[1][0]), min(comb[2][0], comb[3][0]));
+                __syncthreads();
+                return r;
+            };
             auto hx = [](int i) { return (int)((0x01343101u >> (4 * i)) & 15u) - 2; };   // hex2[i][0] + 2 = 1,0,1,3,4,3,1,0
             auto hy = [](int i) { return (int)((0x20024420u >> (4 * i)) & 15u) - 2; };   // hex2[i][1] + 2 = 0,2,4,4,2,0,0,2
             // interMeHex enc@0x48fde0 (x264-lineage hexagon search, tables hex2 enc@0x4e52e0 / mod6m1 enc@0x4e52c0) + square refinement
             auto hex_refine = [&](bool en) {
                 unsigned bc3 = bcost << 3;
-                {
+                if (coop) {                                          // directions wv and wv + 4 (the latter only for wv < 2)
+                    const int d0 = wv, d1 = wv + 4;
+                    const int xs[2] = {mx + hx(d0 + 1), d1 < 6 ? mx + hx(d1 + 1) : 1000}, ys[2] = {my + hy(d0 + 1), d1 < 6 ? my + hy(d1 + 1) : 0};
+                    unsigned c2[2];
+                    cost_multi(std::integral_constant<int, 2>{}, xs, ys, c2);
+                    bc3 = min(bc3, (c2[0] << 3) + (unsigned)(d0 + 2));
+                    bc3 = min(bc3, (c2[1] << 3) + (unsigned)(d1 + 2));
+                    bc3 = wave_min(bc3);
+                } else {
                     int xs[6], ys[6]; unsigned c6[6];
 #pragma unroll
                     for (int d = 0; d < 6; ++d) { xs[d] = mx + hx(d + 1); ys[d] = my + hy(d + 1); }
@@ -136,12 +158,20 @@ __device__ __forceinline__ void me_level(const KsGeom &g, int cx, int cy, int ra
 #pragma unroll 1
                 for (int i = (ext >> 1) - 1; i > 0 && __any(moving); --i) {
                     unsigned nb = bc3 & ~7u;
-                    int xs[3], ys[3]; unsigned c3[3];
+                    if (coop) {                                      // one direction per wave, the fourth wave idles
+                        const int k = wv;
+                        const int xs[1] = {k < 3 ? mx + hx(dir + k) : 1000}, ys[1] = {k < 3 ? my + hy(dir + k) : 0};
+                        unsigned c1[1];
+                        cost_multi(std::integral_constant<int, 1>{}, xs, ys, c1);
+                        nb = wave_min(min(nb, (c1[0] << 3) + (unsigned)(k + 1)));
+                    } else {
+                        int xs[3], ys[3]; unsigned c3[3];
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) { xs[k] = mx + hx(dir + k); ys[k] = my + hy(dir + k); }
-                    cost_multi(std::integral_constant<int, 3>{}, xs, ys, c3);
+                        for (int k = 0; k < 3; ++k) { xs[k] = mx + hx(dir + k); ys[k] = my + hy(dir + k); }
+                        cost_multi(std::integral_constant<int, 3>{}, xs, ys, c3);
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) nb = min(nb, (c3[k] << 3) + (unsigned)(k + 1));
+                        for (int k = 0; k < 3; ++k) nb = min(nb, (c3[k] << 3) + (unsigned)(k + 1));
+                    }
                     if (moving) {
                         bc3 = nb;
                         if (!(bc3 & 7)) moving = false;
@@ -156,7 +186,15 @@ __device__ __forceinline__ void me_level(const KsGeom &g, int cx, int cy, int ra
                 // square1 = (0,0) (0,-1) (0,1) (-1,0) (1,0) (-1,-1) (-1,1) (1,-1) (1,1)
                 auto sqx = [](int k) { return (int)((0x220020111ull >> (4 * k)) & 15ull) - 1; };
                 auto sqy = [](int k) { return (int)((0x202011201ull >> (4 * k)) & 15ull) - 1; };
-                {
+                if (coop) {                                          // square points wv and wv + 4
+                    const int k0 = wv, k1 = wv + 4;
+                    const int xs[2] = {mx + sqx(k0 + 1), mx + sqx(k1 + 1)}, ys[2] = {my + sqy(k0 + 1), my + sqy(k1 + 1)};
+                    unsigned c2[2];
+                    cost_multi(std::integral_constant<int, 2>{}, xs, ys, c2);
+                    bc4 = min(bc4, (c2[0] << 4) + (unsigned)(k0 + 1));
+                    bc4 = min(bc4, (c2[1] << 4) + (unsigned)(k1 + 1));
+                    bc4 = wave_min(bc4);
+                } else {
                     int xs[8], ys[8]; unsigned c8[8];
 #pragma unroll
                     for (int k = 0; k < 8; ++k) { xs[k] = mx + sqx(k + 1); ys[k] = my + sqy(k + 1); }
@@ -169,9 +207,12 @@ __device__ __forceinline__ void me_level(const KsGeom &g, int cx, int cy, int ra
             if (method == 1) hex_refine(valid);
             else {
                 // interMeUMH enc@0x4907b0: x264-lineage uneven multi-hexagon search with the reference's 16-point order
-                // (Big_Hexagon_X/Y enc@0x4e5320/0x4e5300); see oracle search_umh for the step list
-                // N candidates evaluated together, then taken in order with the sequential "strictly better" rule of the reference
-                auto try_multi = [&](auto n_tag, const int *xs, const int *ys, bool en) {
+                // (Big_Hexagon_X/Y enc@0x4e5320/0x4e5300); see oracle search_umh for the step list.
+                // A batch of N candidates is evaluated together and then taken in scan order with the sequential "strictly
+                // better" rule of the reference.  Each candidate carries its scan position (key) so that batches dealt out
+                // over the level-0 replica waves merge to the same winner: argmin by (cost, key), key 0 = the incumbent.
+                unsigned bkey = 0;
+                auto try_k = [&](auto n_tag, const int *xs, const int *ys, const unsigned *keys, bool en) {
                     constexpr int N = decltype(n_tag)::value;
                     int ax[N], ay[N]; unsigned cs[N];
 #pragma unroll
@@ -179,32 +220,71 @@ __device__ __forceinline__ void me_level(const KsGeom &g, int cx, int cy, int ra
                     cost_multi(n_tag, ax, ay, cs);
 #pragma unroll
                     for (int n = 0; n < N; ++n)
-                        if (en && cs[n] < bcost) { bcost = cs[n]; mx = xs[n]; my = ys[n]; }
+                        if (en && cs[n] < bcost) { bcost = cs[n]; mx = xs[n]; my = ys[n]; bkey = keys[n]; }
+                };
+                auto merge = [&]() {
+                    if (!coop) { bkey = 0; return; }
+                    if ((tid & 63) == 0) { comb[wv][0] = bcost; comb[wv][1] = bkey; comb[wv][2] = (unsigned)mx; comb[wv][3] = (unsigned)my; }
+                    __syncthreads();
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        const unsigned c = comb[w][0], k = comb[w][1];
+                        if (c < bcost || (c == bcost && k < bkey)) { bcost = c; bkey = k; mx = (int)comb[w][2]; my = (int)comb[w][3]; }
+                    }
+                    __syncthreads();
+                    bkey = 0;
+                };
+                // N = 4 or 8 candidates around a fixed point; level 0: candidates wv, wv + 4 go to wave wv
+                auto try_multi = [&](auto n_tag, const int *xs, const int *ys, bool en) {
+                    constexpr int N = decltype(n_tag)::value;
+                    if (coop) {
+                        constexpr int M = N / 4;
+                        int ax[M], ay[M]; unsigned keys[M];
+#pragma unroll
+                        for (int m = 0; m < M; ++m) {
+                            ax[m] = wv == 0 ? xs[4 * m] : (wv == 1 ? xs[4 * m + 1] : (wv == 2 ? xs[4 * m + 2] : xs[4 * m + 3]));
+                            ay[m] = wv == 0 ? ys[4 * m] : (wv == 1 ? ys[4 * m + 1] : (wv == 2 ? ys[4 * m + 2] : ys[4 * m + 3]));
+                            keys[m] = (unsigned)(1 + 4 * m + wv);
+                        }
+                        try_k(std::integral_constant<int, M>{}, ax, ay, keys, en);
+                    } else {
+                        unsigned keys[N];
+#pragma unroll
+                        for (int n = 0; n < N; ++n) keys[n] = (unsigned)(n + 1);
+                        try_k(n_tag, xs, ys, keys, en);
+                    }
+                    merge();
                 };
                 auto dia1 = [&](int ox, int oy, bool en) {
                     if (!__any(en)) return;
                     const int xs[4] = {ox, ox, ox - 1, ox + 1}, ys[4] = {oy - 1, oy + 1, oy, oy};
                     try_multi(std::integral_constant<int, 4>{}, xs, ys, en);
                 };
-                // uneven cross: +-i along x for odd i in [start, xmax), then along y in [start, ymax); start is odd for every group.
-                // Four candidates (+i, -i, +(i+2), -(i+2)) per step.
+                // uneven cross around a fixed (ox, oy): +-i along x for odd i in [start, xmax), then along y in [start, ymax); start is
+                // odd for every group.  Four candidates (+i, -i, +(i+2), -(i+2)) per step; level 0 deals the steps out over the waves.
                 auto cross = [&](int ox, int oy, int start, int xmax, int ymax, bool en) {
                     if (!__any(en)) return;
+                    int it = 0;
 #pragma unroll 1
-                    for (int i = 1; i < xmax; i += 4) {
+                    for (int i = 1; i < xmax; i += 4, ++it) {
+                        if (coop && (it & 3) != wv) continue;
                         const bool e0 = en && i >= start, e1 = en && i + 2 >= start && i + 2 < xmax;
                         if (!__any(e0 || e1)) continue;
                         // a disabled pair is parked on an out-of-range coordinate: it costs KS_COST_INF and can never win
                         const int xs[4] = {e0 ? ox + i : 1000, e0 ? ox - i : 1000, e1 ? ox + i + 2 : 1000, e1 ? ox - i - 2 : 1000}, ys[4] = {oy, oy, oy, oy};
-                        try_multi(std::integral_constant<int, 4>{}, xs, ys, e0 || e1);
+                        const unsigned kb = (1u << 24) | ((unsigned)i << 2), keys[4] = {kb, kb + 1, kb + 4, kb + 5};
+                        try_k(std::integral_constant<int, 4>{}, xs, ys, keys, e0 || e1);
                     }
 #pragma unroll 1
-                    for (int i = 1; i < ymax; i += 4) {
+                    for (int i = 1; i < ymax; i += 4, ++it) {
+                        if (coop && (it & 3) != wv) continue;
                         const bool e0 = en && i >= start, e1 = en && i + 2 >= start && i + 2 < ymax;
                         if (!__any(e0 || e1)) continue;
                         const int xs[4] = {ox, ox, ox, ox}, ys[4] = {e0 ? oy + i : 1000, e0 ? oy - i : 1000, e1 ? oy + i + 2 : 1000, e1 ? oy - i - 2 : 1000};
-                        try_multi(std::integral_constant<int, 4>{}, xs, ys, e0 || e1);
+                        const unsigned kb = (2u << 24) | ((unsigned)i << 2), keys[4] = {kb, kb + 1, kb + 4, kb + 5};
+                        try_k(std::integral_constant<int, 4>{}, xs, ys, keys, e0 || e1);
                     }
+                    merge();
                 };
                 auto nib = [](unsigned long long w, int k, int bias) { return (int)((w >> (4 * k)) & 15ull) - bias; };
                 const unsigned area = (unsigned)(S * S), th2000 = 2000u * area / 256u, th500 = 500u * area / 256u;
@@ -242,68 +322,18 @@ __device__ __forceinline__ void me_level(const KsGeom &g, int cx, int cy, int ra
                 }
                 const bool mainp = valid && !done;
                 if (__any(mainp)) {
-                    // Cross, corners and the hexagon grid are evaluated around a FIXED centre: their candidates are independent and
-                    // the reference's sequential "first strictly better" scan equals argmin by (cost, scan position).  At level 0
-                    // the four replica waves therefore each take a quarter of the candidates, remember the scan position (key) of
-                    // their winner and merge through LDS.
-                    constexpr bool COOP = LEVEL == 0;
-                    unsigned bkey = 0;                                   // 0 = the incumbent
-                    auto try_k = [&](auto n_tag, const int *xs, const int *ys, const unsigned *keys, bool en) {
-                        constexpr int N = decltype(n_tag)::value;
-                        int ax[N], ay[N]; unsigned cs[N];
-#pragma unroll
-                        for (int n = 0; n < N; ++n) { ax[n] = en ? xs[n] : 0; ay[n] = en ? ys[n] : 0; }
-                        cost_multi(n_tag, ax, ay, cs);
-#pragma unroll
-                        for (int n = 0; n < N; ++n)
-                            if (en && cs[n] < bcost) { bcost = cs[n]; mx = xs[n]; my = ys[n]; bkey = keys[n]; }
-                    };
-                    auto merge = [&]() {
-                        if (!COOP) return;
-                        if ((tid & 63) == 0) { comb[wv][0] = bcost; comb[wv][1] = bkey; comb[wv][2] = (unsigned)mx; comb[wv][3] = (unsigned)my; }
-                        __syncthreads();
-#pragma unroll
-                        for (int w = 0; w < 4; ++w) {
-                            const unsigned c = comb[w][0], k = comb[w][1];
-                            if (c < bcost || (c == bcost && k < bkey)) { bcost = c; bkey = k; mx = (int)comb[w][2]; my = (int)comb[w][3]; }
-                        }
-                        __syncthreads();
-                        bkey = 0;
-                    };
-                    {   // uneven cross around (ox, oy): +-i for odd i in [cross_start, ext) along x, [cross_start, ext / 2) along y
-                        const int xmax = ext, ymax = ext >> 1;
-                        int it = 0;
-#pragma unroll 1
-                        for (int i = 1; i < xmax; i += 4, ++it) {
-                            if (COOP && (it & 3) != wv) continue;
-                            const bool e0 = mainp && i >= cross_start, e1 = mainp && i + 2 >= cross_start && i + 2 < xmax;
-                            if (!__any(e0 || e1)) continue;
-                            const int xs[4] = {e0 ? ox + i : 1000, e0 ? ox - i : 1000, e1 ? ox + i + 2 : 1000, e1 ? ox - i - 2 : 1000}, ys[4] = {oy, oy, oy, oy};
-                            const unsigned kb = (1u << 24) | ((unsigned)i << 2), keys[4] = {kb, kb + 1, kb + 4, kb + 5};
-                            try_k(std::integral_constant<int, 4>{}, xs, ys, keys, e0 || e1);
-                        }
-#pragma unroll 1
-                        for (int i = 1; i < ymax; i += 4, ++it) {
-                            if (COOP && (it & 3) != wv) continue;
-                            const bool e0 = mainp && i >= cross_start, e1 = mainp && i + 2 >= cross_start && i + 2 < ymax;
-                            if (!__any(e0 || e1)) continue;
-                            const int xs[4] = {ox, ox, ox, ox}, ys[4] = {e0 ? oy + i : 1000, e0 ? oy - i : 1000, e1 ? oy + i + 2 : 1000, e1 ? oy - i - 2 : 1000};
-                            const unsigned kb = (2u << 24) | ((unsigned)i << 2), keys[4] = {kb, kb + 1, kb + 4, kb + 5};
-                            try_k(std::integral_constant<int, 4>{}, xs, ys, keys, e0 || e1);
-                        }
-                        if (!COOP || wv == 0) {
-                            const int xs[4] = {ox - 2, ox - 2, ox + 2, ox + 2}, ys[4] = {oy - 2, oy + 2, oy - 2, oy + 2};
-                            const unsigned keys[4] = {3u << 24, (3u << 24) + 1, (3u << 24) + 2, (3u << 24) + 3};
-                            try_k(std::integral_constant<int, 4>{}, xs, ys, keys, mainp);
-                        }
+                    // cross, corners and the hexagon grid are evaluated around a FIXED centre: independent candidates
+                    cross(ox, oy, cross_start, ext, ext >> 1, mainp);
+                    {
+                        const int xs[4] = {ox - 2, ox - 2, ox + 2, ox + 2}, ys[4] = {oy - 2, oy + 2, oy - 2, oy + 2};
+                        try_multi(std::integral_constant<int, 4>{}, xs, ys, mainp);
                     }
-                    merge();
                     ox = mx; oy = my;
                     // Big_Hexagon: (-4,0)(4,0)(0,-4)(0,4)(-4,-1)(4,1)(-4,1)(4,-1)(-4,-2)(4,2)(-4,2)(4,-2)(-2,-3)(2,3)(-2,3)(2,-3), stored +4
 #pragma unroll 1
                     for (int i = 1; i <= (range >> 2) && __any(mainp && i <= (ext >> 2)); ++i)
 #pragma unroll 1
-                        for (int j0 = COOP ? 4 * wv : 0; j0 < (COOP ? 4 * wv + 4 : 16); j0 += 4) {
+                        for (int j0 = coop ? 4 * wv : 0; j0 < (coop ? 4 * wv + 4 : 16); j0 += 4) {
                             int xs[4], ys[4]; unsigned keys[4];
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
@@ -425,51 +455,6 @@ extern "C" int ks265_me_integer(ks265_frame *f, ks265_pic src, ks265_pic ref, co
 }
 
 // ------------------------------------------------------------------ Stage B: sub-pel SATD refinement
-// One workgroup per CTU, ONE WAVE PER PU LEVEL (wave w = level w), one lane per 8x8 tile of the CTU in Z-order, so the
-// lanes of one PU are an aligned group of 1 / 4 / 16 / 64 lanes and PU costs are DPP group sums - no LDS, no barriers,
-// no atomics.  Each lane holds the 64 differences of its tile in registers (see satd8x8).  Tile SATD = (sum|H8 d H8^T| + 2) >> 2 (xCalcHADs8x8 enc@0x47b3b0), PU cost = sum
-// over its tiles (had_c enc@0x47b680); candidate order and tie-breaking are the reference's (subMeSquare enc@0x4b5660).
-// SATD of one 8x8 source tile (16 dwords f: row r = f[2r], f[2r+1]) against a prediction tile at arbitrary byte alignment.
-// All 64 differences live in registers; the six butterfly stages are plain v_add_u32 / v_sub_u32 (full rate; measured on
-// MI355X: packed 16-bit VOP3P adds run at half rate, so packing two candidates per register buys nothing).
-// |.| + accumulate is ONE v_sad_u32 per coefficient: a bias of 2^15 added to difference (0,0) reaches every Hadamard output
-// with weight +1, so all outputs are positive and v_sad_u32(c + 2^15, 2^15, acc) = acc + |c|.
-__device__ __forceinline__ unsigned satd8x8(const unsigned (&f)[16], const uint8_t *pp, long stride)
-{
-    const unsigned sh = (unsigned)((uintptr_t)pp & 3);
-    const uint8_t *q = pp - sh;
-    int d[64];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        const unsigned *row = (const unsigned *)(q + r * stride);
-        const unsigned a0 = row[0], a1 = row[1], a2 = row[2];
-        const unsigned A[2] = {align_bytes(a1, a0, sh), align_bytes(a2, a1, sh)};
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) d[r * 8 + h * 4 + i] = (int)((f[2 * r + h] >> (8 * i)) & 255) - (int)((A[h] >> (8 * i)) & 255);
-    }
-    d[0] += 0x8000;
-#pragma unroll
-    for (int len = 1; len < 64; len <<= 1)
-#pragma unroll
-        for (int i = 0; i < 64; i += 2 * len)
-#pragma unroll
-            for (int j = i; j < i + len; ++j) { const int u = d[j], v = d[j + len]; d[j] = u + v; d[j + len] = u - v; }
-    // four independent accumulator chains: a single chain of 64 dependent v_sad_u32 showed up as 38 % issue stalls (SQ_WAIT_INST_ANY)
-    unsigned a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-    const unsigned bias = 0x8000u;
-#pragma unroll
-    for (int i = 0; i < 64; i += 4) {                                   // no clang builtin for v_sad_u32
-        asm("v_sad_u32 %0, %1, %2, %0" : "+v"(a0) : "v"(d[i]), "s"(bias));
-        asm("v_sad_u32 %0, %1, %2, %0" : "+v"(a1) : "v"(d[i + 1]), "s"(bias));
-        asm("v_sad_u32 %0, %1, %2, %0" : "+v"(a2) : "v"(d[i + 2]), "s"(bias));
-        asm("v_sad_u32 %0, %1, %2, %0" : "+v"(a3) : "v"(d[i + 3]), "s"(bias));
-    }
-    const unsigned acc = (a0 + a1) + (a2 + a3);
-    return (acc + 2) >> 2;
-}
-
 typedef int ks_v4i __attribute__((ext_vector_type(4)));
 
 // sum over the aligned group of 1 / 4 / 16 / 64 lanes that forms one PU at `level` (wave-uniform)
@@ -790,8 +775,11 @@ extern "C" int ks265_cu_decide_b(ks265_frame *f, const ks265_pu_b *pub, ks265_cu
 }
 
 // ------------------------------------------------------------------ Stage B': bi-predictive candidate of a B picture
-// Same shape as the sub-pel kernel (wave = PU level, lane = 8x8 tile in Z-order): SATD of the source tile against the rounded
-// average of the two list winners' plane tiles, PU cost by DPP group sum, then L0 / L1 / bi by cost (ties: L0, L1, bi).
+// One workgroup per CTU, wave = PU level, lane = 8x8 tile in Z-order: SATD of the source tile against the rounded average of the
+// two list winners' plane tiles, PU cost by DPP group sum, then L0 / L1 / bi by cost (ties: L0, L1, bi).  One SATD per
+// (level, tile), so the Hadamard stays on the VALU here: all 64 differences of a tile live in registers, six butterfly stages of
+// plain v_add_u32 / v_sub_u32, and |.| + accumulate is ONE v_sad_u32 per coefficient (a bias of 2^15 added to difference
+// (0,0) reaches every Hadamard output with weight +1, so all outputs are positive).
 __device__ __forceinline__ unsigned satd8x8_avg(const unsigned (&f)[16], const uint8_t *pa, const uint8_t *pb, long stride)
 {
     const unsigned sha = (unsigned)((uintptr_t)pa & 3), shb = (unsigned)((uintptr_t)pb & 3);
