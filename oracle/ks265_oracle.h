@@ -91,6 +91,11 @@ void ks265o_stat_sao_bo_eo01(int *eoJoint, int *bo, const uint8_t *org, const ui
 void ks265o_default_weighted_bi(uint8_t *dst, const int16_t *p0, const int16_t *p1, int dstStride, int srcStride, int width, int height);
 uint32_t ks265o_calc_bi_me_org(uint8_t *dst, const uint8_t *pred, const uint8_t *org, int stride, int height, int width);
 
+/* ---- intra prediction (ks265_intra_oracle.c): g_IntraPredFunction enc@0x7070a0 family, IntraPredFilterRef_c enc@0x424110.
+ * `ref` / `src` / `dst` point at the corner sample of a linear reference array: [1 + x] = top, [-1 - y] = left. */
+void ks265o_intra_pred(uint8_t *dst, int stride, const uint8_t *ref, int mode, int log2, int edge_filter);
+void ks265o_intra_filter_ref(const uint8_t *src, uint8_t *dst, int size, int strong_enabled);
+
 #ifdef __cplusplus
 }
 #endif

@@ -436,11 +436,57 @@ def gen_bipred(p: RefProbe):
     return [dict(c, exp=d.out, ret=np.uint32(call.ret & 0xFFFFFFFF)) for c, call, d in pend]
 
 
+INTRA_FUNCS = {  # name: (address, modes)  -- nm -C appencoder: h265_codec::IntraPred*_c(uchar*, int, uchar*, int, int, bool)
+    "planar": (0x425AF0, [0]), "dc": (0x425D80, [1]), "chroma_dc": (0x425C60, [1]), "hor_plus_2": (0x425F60, [2]),
+    "hor_plus_3_9": (0x4260E0, range(3, 10)), "hor0_10": (0x426300, [10]), "hor_minus_11_17": (0x4264C0, range(11, 18)),
+    "ver_minus_18": (0x426720, [18]), "ver_minus_19_25": (0x4267E0, range(19, 26)), "ver0_26": (0x4269D0, [26]),
+    "ver_plus_27_33": (0x426BB0, range(27, 34)), "ver_plus_34": (0x426CE0, [34]),
+}
+
+
+def gen_intra(p: RefProbe):
+    """every mode x size x edge-filter flag through the reference's IntraPred*_c, plus IntraPredFilterRef_c enc@0x424110"""
+    pend = []
+    for name, (addr, modes) in INTRA_FUNCS.items():
+        for mode in modes:
+            for log2 in (2, 3, 4, 5):
+                for filt in (0, 1):
+                    n = 1 << log2
+                    kind = int(rng.integers(0, 3))
+                    if kind == 0:
+                        ref = u8(4 * n + 17)
+                    elif kind == 1:   # smooth ramp + noise (typical picture content)
+                        ref = np.clip(np.linspace(int(rng.integers(0, 256)), int(rng.integers(0, 256)), 4 * n + 17) + rng.integers(-3, 4, 4 * n + 17), 0, 255).astype(np.uint8)
+                    else:             # extremes: clipping of the mode 10 / 26 edge filter
+                        ref = rng.choice(np.array([0, 255], np.uint8), 4 * n + 17)
+                    ds = n + int(rng.integers(0, 5))
+                    D = Buf(np.full((n, ds), 7, np.uint8))
+                    p.call(addr, D, ds, Buf(ref).at(2 * n + 8), mode, log2, filt)
+                    pend.append((dict(kind="pred", func=name, mode=mode, log2=log2, filt=filt, ref=ref, corner=2 * n + 8, ds=ds), D))
+    for size in (4, 8, 16, 32):
+        for flag in (0, 1):
+            for kind in range(4):
+                n = 4 * size + 17
+                if kind == 0:
+                    src = u8(n)
+                elif kind == 1:       # flat: the strong-filter condition holds (size 32, flag 1)
+                    src = np.clip(120 + rng.integers(-2, 3, n), 0, 255).astype(np.uint8)
+                elif kind == 2:       # ramp: flat in the second-difference sense
+                    src = np.clip(np.linspace(40, 200, n) + rng.integers(-1, 2, n), 0, 255).astype(np.uint8)
+                else:
+                    src = rng.choice(np.array([0, 255], np.uint8), n)
+                D = Buf(np.full(n, 9, np.uint8))
+                p.call(0x424110, Buf(src).at(2 * size + 8), D.at(2 * size + 8), size, flag)
+                pend.append((dict(kind="filter", size=size, flag=flag, src=src, corner=2 * size + 8), D))
+    p.run()
+    return [dict(c, exp=d.out) for c, d in pend]
+
+
 FAMILIES = {
     "sad": gen_sad, "sad4": gen_sad4, "sad3": gen_sad3, "sad4blk": gen_sad4blk, "sse": gen_sse, "had": gen_had,
     "fwd_transform": gen_fwd, "inv_transform": gen_inv, "quant": gen_quant, "dequant": gen_dequant,
     "residual": gen_residual, "deblock_luma": gen_deblock_luma, "deblock_chroma": gen_deblock_chroma,
-    "interp": gen_interp, "sao_apply": gen_sao, "sao_stats": gen_sao_stats, "bipred": gen_bipred,
+    "interp": gen_interp, "sao_apply": gen_sao, "sao_stats": gen_sao_stats, "bipred": gen_bipred, "intra": gen_intra,
 }
 
 if __name__ == "__main__":
