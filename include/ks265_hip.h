@@ -119,6 +119,21 @@ typedef struct { int32_t org_off, rec_off, w, h; } ks265_sao_rect;
 int ks265_sao_stats_batch(ks265_ctx *, const uint8_t *dev_org, int orgStride, const uint8_t *dev_rec, int recStride,
                           const ks265_sao_rect *dev_rects, int nrect, int rowStep, int32_t *dev_out /*nrect x 96*/);
 
+/* g_IntraPredFunction enc@0x7070a0 (35 modes x sizes).  The reference kernels
+ * IntraPredPlanar_0_c enc@0x425af0 / IntraPredDC_1_c enc@0x425d80 / IntraPredChromeDC_1_c enc@0x425c60 /
+ * IntraPredAng{Hor,Ver}*_c enc@0x425f60..0x426ce0 all take (u8 *dst, int dstStride, u8 *ref, int mode, int log2Size, bool edgeFilter)
+ * with `ref` pointing at the corner sample p[-1][-1] of a linear array: ref[1 + x] = top and top-right (x < 2N),
+ * ref[-1 - y] = left and bottom-left (y < 2N).  One descriptor = one such call; ref_off / dst_off are byte offsets of the
+ * corner sample / the block's first sample in dev_ref / dev_dst.  mode 0 planar, 1 DC, 2..34 angular; log2 2..5;
+ * edge_filter = the boundary smoothing of DC / 10 / 26 (luma; chroma DC passes 0 = IntraPredChromeDC_1_c). */
+typedef struct { int32_t ref_off, dst_off; int16_t dst_stride; uint8_t mode, log2, edge_filter, rsv[3]; } ks265_intra_blk;
+int ks265_intra_pred_batch(ks265_ctx *, const uint8_t *dev_ref, uint8_t *dev_dst, const ks265_intra_blk *dev_blks, int n);
+/* g_IntraPredFilterRefFunc enc@0x706d48 -> IntraPredFilterRef_c enc@0x424110 (src, dst, size, strongEnabled): [1 2 1]/4 smoothing of
+ * the 4*size + 1 samples around the corner (ends copied); size 32 with strong_enabled tests the flatness condition itself and
+ * writes the bi-linear array instead.  Offsets address the corner sample. */
+typedef struct { int32_t src_off, dst_off, size, strong_enabled; } ks265_intra_ref;
+int ks265_intra_filter_ref_batch(ks265_ctx *, const uint8_t *dev_src, uint8_t *dev_dst, const ks265_intra_ref *dev_refs, int n);
+
 /* ------------------------------------------------------------------ 3. whole-frame stages (a13 sequencing) */
 
 typedef struct ks265_frame ks265_frame;

@@ -2,6 +2,7 @@
 // One wavefront (or one workgroup for transforms) per block descriptor; the arithmetic comes from
 // ks265_dev.h and is bit-exact with the reference `_c` kernels (tests/test_gpu_golden.py).
 #include "ks265_internal.h"
+#include "intra_dev.h"
 
 using namespace ks265;
 
@@ -303,6 +304,45 @@ __global__ __launch_bounds__(256) void sao_stats_batch_kernel(const uint8_t *org
 #define CHECK_CTX(ctx) do { if (!(ctx)) return KS265_POINTER; } while (0)
 #define LAUNCH_END(ctx) return ks265_check_launch(ctx)
 
+// ------------------------------------------------------------------ intra prediction (g_IntraPredFunction enc@0x7070a0)
+// one wave per block: the 4N + 1 reference samples go to LDS, every lane predicts samples lane, lane + 64, ...
+__global__ __launch_bounds__(256) void intra_pred_batch_kernel(const uint8_t *ref, uint8_t *dst, const ks265_intra_blk *blks, int n)
+{
+    __shared__ uint8_t sref[4][132];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, b = blockIdx.x * 4 + w;
+    if (b >= n) return;                                             // wave-uniform; no block-wide barrier below
+    const ks265_intra_blk d = blks[b];
+    const int N = 1 << d.log2;
+    uint8_t *r = &sref[w][2 * 32 + 1];                              // corner
+    for (int i = lane; i < 4 * N + 1; i += 64) r[i - 2 * N] = ref[d.ref_off + i - 2 * N];
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0);
+    int dc = N;
+    if (d.mode == 1) {
+        for (int i = 0; i < N; ++i) dc += r[1 + i] + r[-1 - i];
+        dc >>= d.log2 + 1;
+    }
+    for (int p = lane; p < N * N; p += 64) {
+        const int x = p & (N - 1), y = p >> d.log2;
+        dst[d.dst_off + y * d.dst_stride + x] = (uint8_t)intra_sample(r, d.mode, d.log2, x, y, dc, d.edge_filter != 0);
+    }
+}
+
+// IntraPredFilterRef_c enc@0x424110: one wave per reference array
+__global__ __launch_bounds__(256) void intra_filter_ref_batch_kernel(const uint8_t *src, uint8_t *dst, const ks265_intra_ref *refs, int n)
+{
+    __shared__ uint8_t sref[4][132];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, b = blockIdx.x * 4 + w;
+    if (b >= n) return;
+    const ks265_intra_ref d = refs[b];
+    uint8_t *r = &sref[w][2 * 32 + 1];
+    for (int i = lane; i < 4 * d.size + 1; i += 64) r[i - 2 * d.size] = src[d.src_off + i - 2 * d.size];
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0);
+    const bool bil = d.size == 32 && d.strong_enabled && intra_strong_flat(r);
+    for (int i = lane; i < 4 * d.size + 1; i += 64) dst[d.dst_off + i - 2 * d.size] = (uint8_t)intra_filtered(r, d.size, i - 2 * d.size, bil);
+}
+
 extern "C" {
 
 int ks265_sad_batch(ks265_ctx *ctx, const uint8_t *a, int sa, const uint8_t *b, int sb, const ks265_blk *blks, int n, uint32_t *out)
@@ -440,6 +480,19 @@ int ks265_sao_stats_batch(ks265_ctx *ctx, const uint8_t *org, int os, const uint
 {
     CHECK_CTX(ctx); if (nrect <= 0) return KS265_OK; if (rowStep < 1) return KS265_NOTSUPPORTED;
     hipLaunchKernelGGL(sao_stats_batch_kernel, dim3(nrect), dim3(256), 0, ctx->stream, org, os, rec, rs, rects, nrect, rowStep, out);
+    LAUNCH_END(ctx);
+}
+
+int ks265_intra_pred_batch(ks265_ctx *ctx, const uint8_t *ref, uint8_t *dst, const ks265_intra_blk *blks, int n)
+{
+    CHECK_CTX(ctx); if (!ref || !dst || !blks) return KS265_POINTER; if (n <= 0) return KS265_OK;
+    hipLaunchKernelGGL(intra_pred_batch_kernel, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, ref, dst, blks, n);
+    LAUNCH_END(ctx);
+}
+int ks265_intra_filter_ref_batch(ks265_ctx *ctx, const uint8_t *src, uint8_t *dst, const ks265_intra_ref *refs, int n)
+{
+    CHECK_CTX(ctx); if (!src || !dst || !refs) return KS265_POINTER; if (n <= 0) return KS265_OK;
+    hipLaunchKernelGGL(intra_filter_ref_batch_kernel, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, src, dst, refs, n);
     LAUNCH_END(ctx);
 }
 

@@ -15,6 +15,8 @@ BLK = np.dtype([("a_off", "<i4"), ("b_off", "<i4"), ("w", "<i4"), ("h", "<i4")])
 BLK3 = np.dtype([("a_off", "<i4"), ("b_off", "<i4", 3), ("w", "<i4"), ("h", "<i4")])
 EDGE = np.dtype([("pix_off", "<i4"), ("beta", "<i2"), ("tc", "<i2"), ("length", "<i2"), ("dir", "u1"), ("flags", "u1")])
 SAO_RECT = np.dtype([("org_off", "<i4"), ("rec_off", "<i4"), ("w", "<i4"), ("h", "<i4")])
+INTRA_BLK = np.dtype([("ref_off", "<i4"), ("dst_off", "<i4"), ("dst_stride", "<i2"), ("mode", "u1"), ("log2", "u1"), ("edge_filter", "u1"), ("rsv", "u1", (3,))])
+INTRA_REF = np.dtype([("src_off", "<i4"), ("dst_off", "<i4"), ("size", "<i4"), ("strong_enabled", "<i4")])
 PU = np.dtype([("mvx", "<i2"), ("mvy", "<i2"), ("mvpx", "<i2"), ("mvpy", "<i2"), ("cost", "<u4"), ("dist", "<u4")])
 CU8 = np.dtype([("mvx", "<i2"), ("mvy", "<i2"), ("mv1x", "<i2"), ("mv1y", "<i2"), ("log2_cu", "u1"), ("cbf", "u1"), ("pred_mode", "u1"), ("inter_dir", "u1")])
 PU_B = np.dtype([("mvx", "<i2"), ("mvy", "<i2"), ("mv1x", "<i2"), ("mv1y", "<i2"), ("cost", "<u4"), ("inter_dir", "<u4")])
@@ -50,7 +52,7 @@ EXPORTS = [
     "ks265_sad_batch", "ks265_sad4_batch", "ks265_sad3_batch", "ks265_sad4blk_8x8_batch", "ks265_sse_batch", "ks265_had_batch",
     "ks265_residual_batch", "ks265_fwd_transform_batch", "ks265_quant_batch", "ks265_dequant_batch", "ks265_inv_transform_batch",
     "ks265_edge_filter_luma_batch", "ks265_edge_filter_chroma_batch", "ks265_interp_rect",
-    "ks265_sao_apply_bo_rect", "ks265_sao_apply_eo_rect", "ks265_sao_stats_batch",
+    "ks265_sao_apply_bo_rect", "ks265_sao_apply_eo_rect", "ks265_sao_stats_batch", "ks265_intra_pred_batch", "ks265_intra_filter_ref_batch",
     "ks265_frame_geometry", "ks265_frame_create", "ks265_frame_destroy", "ks265_frame_set_qp", "ks265_pad_picture",
     "ks265_load_i420", "ks265_store_i420", "ks265_ref_planes", "ks265_me_integer", "ks265_me_subpel", "ks265_cu_decide",
     "ks265_cu_flat_intra", "ks265_reconstruct", "ks265_reconstruct_b", "ks265_bi_decide", "ks265_cu_decide_b", "ks265_deblock", "ks265_sao",
@@ -197,6 +199,13 @@ class KsContext:
         self._chk(self.lib.ks265_sao_stats_batch(self.h, _p(org), C.c_int(os_), _p(rec), C.c_int(rs), _p(self.dev(rects)), C.c_int(len(rects)),
                                                  C.c_int(row_step), _p(out)))
         return self.host(out, np.int32, (len(rects), 96))
+
+    def intra_pred(self, ref, dst, blks: np.ndarray):
+        """g_IntraPredFunction: predict every described block from dev `ref` into dev `dst` (in place)"""
+        self._chk(self.lib.ks265_intra_pred_batch(self.h, _p(ref), _p(dst), _p(self.dev(blks)), C.c_int(len(blks))))
+
+    def intra_filter_ref(self, src, dst, refs: np.ndarray):
+        self._chk(self.lib.ks265_intra_filter_ref_batch(self.h, _p(src), _p(dst), _p(self.dev(refs)), C.c_int(len(refs))))
 
 
 class DevPic:

@@ -197,3 +197,36 @@ def test_sao_stats(ks):
         r = np.zeros(1, SAO_RECT); r[0] = (0, c["rs"] + 1, c["w"], c["h"])
         got = ks.sao_stats(ks.dev(c["org"]), int(c["os"]), ks.dev(c["rec"]), int(c["rs"]), r, int(c["step"]))
         assert (got[0, :64] == c["exp_eo"]).all() and (got[0, 64:] == c["exp_bo"]).all()
+
+
+def test_intra(ks):
+    """§8(f) rank 1: g_IntraPredFunction / IntraPredFilterRef_c through the C ABI against the reference's own outputs"""
+    from ks265codec_amd.lib import INTRA_BLK, INTRA_REF
+    cases = load_cases("intra")
+    pred = [c for c in cases if str(c["kind"]) == "pred"]
+    filt = [c for c in cases if str(c["kind"]) == "filter"]
+    # one ref arena + one dst arena, all blocks in ONE launch
+    ref_off, dst_off, refs, blks = 0, 0, [], np.zeros(len(pred), INTRA_BLK)
+    for i, c in enumerate(pred):
+        n = 1 << c["log2"]
+        edge = 0 if str(c["func"]) == "chroma_dc" else c["filt"]
+        blks[i] = (ref_off + c["corner"], dst_off, c["ds"], c["mode"], c["log2"], edge, (0, 0, 0))
+        refs.append(c["ref"]); ref_off += len(c["ref"]); dst_off += n * c["ds"]
+    dst = ks.dev(np.full(dst_off, 7, np.uint8))
+    ks.intra_pred(ks.dev(np.concatenate(refs)), dst, blks)
+    got = ks.host(dst, np.uint8)
+    for b, c in zip(blks, pred):
+        n = 1 << c["log2"]
+        g = got[b["dst_off"]:b["dst_off"] + n * c["ds"]].reshape(n, c["ds"])
+        assert (g == c["exp"]).all(), (str(c["func"]), c["mode"], n, c["filt"])
+    off, srcs, rr = 0, [], np.zeros(len(filt), INTRA_REF)
+    for i, c in enumerate(filt):
+        rr[i] = (off + c["corner"], off + c["corner"], c["size"], c["flag"])
+        srcs.append(c["src"]); off += len(c["src"])
+    dst = ks.dev(np.full(off, 9, np.uint8))
+    ks.intra_filter_ref(ks.dev(np.concatenate(srcs)), dst, rr)
+    got = ks.host(dst, np.uint8)
+    off = 0
+    for c in filt:
+        assert (got[off:off + len(c["src"])] == c["exp"]).all(), (c["size"], c["flag"])
+        off += len(c["src"])
