@@ -169,7 +169,7 @@ typedef struct {
 typedef struct { int16_t mvx, mvy; int16_t mvpx, mvpy; uint32_t cost; uint32_t dist; } ks265_pu;   /* quarter-pel units; mvp = predictor used for the rate term; dist = SAD (stage A) or SATD (stage B) */
 /* final coding decision per 8x8 luma block */
 typedef struct { int16_t mvx, mvy; /* list 0 */ int16_t mv1x, mv1y; /* list 1 */ uint8_t log2_cu; uint8_t cbf; /* bit0 Y, bit1 Cb, bit2 Cr */
-                 uint8_t pred_mode; /* 0 inter, 1 intra(flat) */ uint8_t inter_dir; /* 1 = L0, 2 = L1, 3 = bi */ } ks265_cu8;
+                 uint8_t pred_mode; /* 0 inter, 1 intra(flat 128 stand-in), 2 intra (mvx = luma mode) */ uint8_t inter_dir; /* 1 = L0, 2 = L1, 3 = bi */ } ks265_cu8;
 /* B pictures: the per-PU winner among L0, L1 and bi-prediction */
 typedef struct { int16_t mvx, mvy, mv1x, mv1y; uint32_t cost; uint32_t inter_dir; } ks265_pu_b;
 /* SAO decision per CTU and component */
@@ -219,6 +219,14 @@ int ks265_reconstruct_b(ks265_frame *f, ks265_pic src, ks265_pic ref0, const uin
 int ks265_bi_decide(ks265_frame *f, ks265_pic src, const uint8_t *dev_planes0, const uint8_t *dev_planes1, const ks265_pu *dev_pu0,
                     const ks265_pu *dev_pu1, ks265_pu_b *dev_pub);
 int ks265_cu_decide_b(ks265_frame *f, const ks265_pu_b *dev_pub, ks265_cu8 *dev_cu8);
+/* Intra pictures.  ks265_intra_decide: every 8x8 / 16x16 / 32x32 block tries all 35 luma modes of
+ * g_IntraPredFunction on reference samples taken from the SOURCE picture (decideBestLumaModeBySadFast enc@0x499170 lineage),
+ * cost = SATD (had_c) + lambda * mode bits, then the CU quadtree bottom-up; cu8 of an intra CU: pred_mode = 2, mvx = luma mode,
+ * chroma = the luma mode.  ks265_intra_reconstruct: CTU wavefront, CUs in z-order, neighbours from the reconstructed picture
+ * (H.265 6.4.1 availability, 8.4.4.2.2 substitution, 8.4.4.2.3 smoothing = IntraPredFilterRef_c enc@0x424110), then the
+ * reconstruct() chain enc@0x481da0 per TU (TU = CU, at most 32x32). */
+int ks265_intra_decide(ks265_frame *, ks265_pic src, ks265_cu8 *dev_cu8);
+int ks265_intra_reconstruct(ks265_frame *, ks265_pic src, ks265_cu8 *dev_cu8, int16_t *dev_lvl_y, int16_t *dev_lvl_u, int16_t *dev_lvl_v, ks265_pic recon);
 /* Stage E: in-place deblocking of a reconstructed picture (CalcBsInterP enc@0x402960, ctuDeblockFilterVer
  * enc@0x403de0, CtuDeblockFilterHorT enc@0x477200) */
 int ks265_deblock(ks265_frame *f, const ks265_cu8 *dev_cu8, ks265_pic recon);

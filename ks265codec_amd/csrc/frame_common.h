@@ -36,6 +36,7 @@ struct ks265_frame {
     int16_t *lvl[3] = {nullptr, nullptr, nullptr};
     uint8_t *deb[3] = {nullptr, nullptr, nullptr};   // reconstructed picture before SAO (padded geometry)
     unsigned long long *sse = nullptr;
+    int *progress = nullptr;            // intra wavefront: CTUs finished per CTU row
     // optional in-situ stage timing (HIP events on the context's stream, between the stages of ks265_encode_picture)
     bool profiling = false;
     hipEvent_t ev[KS_NSTAGE + 1] = {};

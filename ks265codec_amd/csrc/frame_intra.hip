@@ -1,0 +1,402 @@
+// frame_intra.hip — intra pictures (intra prediction kernels + mode pre-selection).
+//   ks265_intra_decide       all 35 luma modes of every 8x8 / 16x16 / 32x32 block predicted from SOURCE neighbours
+//                            (decideBestLumaModeBySadFast enc@0x499170 lineage: pre-selection on source pixels is embarrassingly
+//                            parallel), cost = SATD + lambda * mode bits, CU quadtree bottom-up.  One workgroup per CTU.
+//   ks265_intra_reconstruct  the sequential part: CTUs as a wavefront (one workgroup per CTU row, two CTUs behind the row above,
+//                            progress counters in HBM), CUs in z-order, neighbours from the RECONSTRUCTED picture with the
+//                            normative availability / substitution / smoothing rules, then the reconstruct() chain per TU.
+// Prediction arithmetic = g_IntraPredFunction enc@0x7070a0 / IntraPredFilterRef_c enc@0x424110 (intra_dev.h, pinned).
+#include "frame_common.h"
+#include "intra_dev.h"
+#include "recon_dev.h"
+
+using namespace ks265;
+
+__device__ __forceinline__ int spread4(int v) { return (v & 1) | ((v & 2) << 1) | ((v & 4) << 2) | ((v & 8) << 3); }
+// H.265 6.4.1 (z-scan order availability): is luma sample (nx, ny) available to the block whose first sample is (x, y)?
+__device__ __forceinline__ bool intra_avail(const KsGeom &g, int x, int y, int nx, int ny)
+{
+    if (nx < 0 || ny < 0 || nx >= g.W || ny >= g.H) return false;
+    const int ca = (y >> 6) * g.ctu_cols + (x >> 6), na = (ny >> 6) * g.ctu_cols + (nx >> 6);
+    if (na != ca) return na < ca;
+    return (spread4((nx & 63) >> 2) | (spread4((ny & 63) >> 2) << 1)) < (spread4((x & 63) >> 2) | (spread4((y & 63) >> 2) << 1));
+}
+
+// Availability mask of the 2 nu + 1 neighbour UNITS of the n x n luma block at (x, y): a unit = 8 luma samples (all CUs are
+// >= 8x8 and aligned, so availability is constant inside a unit); bit j: j < nu left side bottom-up, j == nu the corner,
+// j > nu the top side left to right.  The chroma blocks of the CU have the same mask (their units are 4 chroma samples).
+// Every wave computes it for itself (lanes 0..2nu), so no barrier is needed.
+__device__ __forceinline__ unsigned intra_unit_mask(const KsGeom &g, int x, int y, int n, int lane)
+{
+    const int nu = n >> 2;                                           // 2n / 8
+    bool av = false;
+    if (lane <= 2 * nu) {
+        const int sx = lane <= nu ? x - 1 : x + (lane - nu - 1) * 8;
+        const int sy = lane < nu ? y + 2 * n - 1 - lane * 8 : y - 1;
+        av = intra_avail(g, x, y, sx, sy);
+    }
+    return (unsigned)__ballot(av);
+}
+
+// Reference sample at scan position q (0 = bottom-left end, 2n = corner, 4n = top-right end) of the n x n block at (x, y) of a
+// plane (component samples, unit = u samples), with the substitution process of H.265 8.4.4.2.2 expressed on the unit mask:
+// an unavailable sample takes the last sample of the nearest available unit below it in scan order, or - if there is none -
+// the first sample of the first available unit.  COHERENT: the plane is being written by other workgroups (L2-coherent loads).
+template <bool COHERENT>
+__device__ __forceinline__ int intra_ref_sample(const uint8_t *plane, int stride, unsigned mask, int x, int y, int n, int u, int q)
+{
+    if (mask == 0) return 128;
+    const int nu = 2 * n / u;
+    const int j = q < 2 * n ? q / u : (q == 2 * n ? nu : nu + 1 + (q - 2 * n - 1) / u);
+    if (!((mask >> j) & 1u)) {
+        const unsigned below = mask & ((1u << j) - 1u);
+        if (below) {
+            const int jj = 31 - __clz((int)below);
+            q = jj < nu ? jj * u + u - 1 : (jj == nu ? 2 * n : 2 * n + (jj - nu) * u);
+        } else {
+            const int jj = __ffs((int)mask) - 1;
+            q = jj < nu ? jj * u : (jj == nu ? 2 * n : 2 * n + 1 + (jj - nu - 1) * u);
+        }
+    }
+    const int sx = q > 2 * n ? x + (q - 2 * n - 1) : x - 1, sy = q < 2 * n ? y + (2 * n - 1 - q) : y - 1;
+    const uint8_t *p = plane + (long)sy * stride + sx;
+    if (COHERENT) return (int)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return (int)*p;
+}
+
+// ------------------------------------------------------------------ reconstruction (wavefront)
+struct IntraLds {
+    short Mf[MAT_SHORTS], Mt[MAT_SHORTS];
+    short X[3][32 * RP], T[3][32 * RP];                  // [component]; chroma uses the first 16 rows
+    unsigned char P[3][32 * 32];
+    unsigned char raw[3][132], fil[132];                 // reference arrays, corner at index 66 (luma: 64 + 1 + 64; chroma 32 + 1 + 32)
+    int nz[3];
+    ks265_cu8 cu[64];
+};
+
+// one thread's role in a TU phase: component + quad, or idle
+struct TuRole { int comp, n, log2n, qx, qy; bool on; };
+
+__global__ __launch_bounds__(256) void intra_recon_kernel(KsGeom g, int qp, const uint8_t *src_y, const uint8_t *src_u, const uint8_t *src_v, ks265_cu8 *cu8,
+                                                          int16_t *lvl_y, int16_t *lvl_u, int16_t *lvl_v, uint8_t *rec_y, uint8_t *rec_u, uint8_t *rec_v,
+                                                          int *progress)
+{
+    __shared__ __attribute__((aligned(16))) IntraLds L;
+    const int tid = threadIdx.x, lane = tid & 63, cy = blockIdx.x;
+    build_matrices(L.Mf, L.Mt, tid, 256);
+    const int qpc = chroma_qp(qp);
+    const uint8_t *S[3] = {ks_org_y(g, src_y), ks_org_c(g, src_u), ks_org_c(g, src_v)};
+    uint8_t *R[3] = {ks_org_y(g, rec_y), ks_org_c(g, rec_u), ks_org_c(g, rec_v)};
+    int16_t *LV[3] = {lvl_y, lvl_u, lvl_v};
+    for (int cx = 0; cx < g.ctu_cols; ++cx) {
+        // wavefront: the row above must be two CTUs ahead (top-right neighbours)
+        if (cy > 0 && tid == 0) {
+            const int need = min(cx + 2, g.ctu_cols);
+            while (__hip_atomic_load(progress + cy - 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(8);
+        }
+        __syncthreads();                                             // nobody still walks the previous CTU's map
+        if (tid < 64) {
+            const int bx = cx * 8 + (tid & 7), by = cy * 8 + (tid >> 3);
+            ks265_cu8 c;
+            c.mvx = 0; c.mvy = 0; c.mv1x = 0; c.mv1y = 0; c.log2_cu = 0; c.cbf = 0; c.pred_mode = 0; c.inter_dir = 0;
+            if (bx < g.w8 && by < g.h8) c = cu8[(long)by * g.w8 + bx];
+            L.cu[tid] = c;
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int z = 0; z < 64; ++z) {                              // 8x8 blocks of the CTU in z-order; a CU is coded at its first block
+            const int lx = (z & 1) | ((z >> 1) & 2) | ((z >> 2) & 4), ly = ((z >> 1) & 1) | ((z >> 2) & 2) | ((z >> 3) & 4);
+            const ks265_cu8 c = L.cu[ly * 8 + lx];
+            if (c.log2_cu == 0) continue;                           // outside the picture
+            const int n8 = 1 << (c.log2_cu - 3);
+            if ((lx & (n8 - 1)) || (ly & (n8 - 1))) continue;
+            const int n = 8 * n8, log2 = c.log2_cu, mode = c.mvx, x0 = cx * 64 + lx * 8, y0 = cy * 64 + ly * 8;
+            const unsigned mask = intra_unit_mask(g, x0, y0, n, lane);
+            if (tid < 3) L.nz[tid] = 0;
+            // ---- reference samples of the three components (HBM, L2-coherent), one sample per thread
+            {
+                const int lenY = 4 * n + 1, lenC = 2 * n + 1;
+                if (tid < lenY) L.raw[0][66 - 2 * n + tid] = (unsigned char)intra_ref_sample<true>(R[0], g.sy, mask, x0, y0, n, 8, tid);
+                if (tid < 2 * lenC) {
+                    const int cc = 1 + tid / lenC, q = tid % lenC;
+                    L.raw[cc][66 - n + q] = (unsigned char)intra_ref_sample<true>(R[cc], g.sc, mask, x0 >> 1, y0 >> 1, n >> 1, 4, q);
+                }
+            }
+            __syncthreads();
+            const bool filt = intra_filter_flag(mode, n);
+            if (filt && tid <= 4 * n) {
+                const bool bil = n == 32 && intra_strong_flat(&L.raw[0][66]);
+                L.fil[66 - 2 * n + tid] = (unsigned char)intra_filtered(&L.raw[0][66], n, tid - 2 * n, bil);
+            }
+            __syncthreads();
+            // ---- the TU phases: n <= 16: Y, Cb, Cr together; n == 32: Y, then Cb + Cr
+            for (int phase = 0; phase < (n == 32 ? 2 : 1); ++phase) {
+                TuRole r;
+                r.on = false; r.comp = 0; r.n = n; r.log2n = log2; r.qx = 0; r.qy = 0;
+                {
+                    const int nqY = n * n / 4, nqC = n * n / 16;
+                    int t = tid;
+                    if (n == 32) {
+                        if (phase == 0) { r.on = true; r.comp = 0; }
+                        else if (t < 2 * nqC) { r.on = true; r.comp = 1 + t / nqC; t %= nqC; }
+                    } else if (t < nqY) { r.on = true; r.comp = 0; }
+                    else if (t < nqY + 2 * nqC) { r.on = true; t -= nqY; r.comp = 1 + t / nqC; t %= nqC; }
+                    if (r.comp) { r.n = n >> 1; r.log2n = log2 - 1; }
+                    r.qx = (t % (r.n / 4)) * 4; r.qy = t / (r.n / 4);
+                }
+                const int cp = r.comp, nn = r.n, l2 = r.log2n, mp = nn + 4;
+                short *X = L.X[cp], *T = L.T[cp];
+                unsigned char *P = L.P[cp];
+                const short *mf = L.Mf + mat_off(l2), *mt = L.Mt + mat_off(l2);
+                const int px = cp ? x0 >> 1 : x0, py = cp ? y0 >> 1 : y0, stride = cp ? g.sc : g.sy, lstride = cp ? g.W / 2 : g.W;
+                // prediction + residual
+                if (r.on) {
+                    const unsigned char *ref = cp == 0 ? (filt ? &L.fil[66] : &L.raw[0][66]) : &L.raw[cp][66];
+                    int dc = nn;
+                    if (mode == 1) {
+                        for (int i = 0; i < nn; ++i) dc += ref[1 + i] + ref[-1 - i];
+                        dc >>= l2 + 1;
+                    }
+                    const unsigned sv = *(const unsigned *)(S[cp] + (long)(py + r.qy) * stride + px + r.qx);
+                    int pr[4];
+                    unsigned short res[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        pr[i] = intra_sample(ref, mode, l2, r.qx + i, r.qy, dc, cp == 0);
+                        res[i] = (unsigned short)(short)((int)((sv >> (8 * i)) & 255) - pr[i]);
+                    }
+                    *(unsigned *)(P + r.qy * 32 + r.qx) = (unsigned)pr[0] | ((unsigned)pr[1] << 8) | ((unsigned)pr[2] << 16) | ((unsigned)pr[3] << 24);
+                    *(uint2 *)(X + r.qy * RP + r.qx) = make_uint2(res[0] | ((unsigned)res[1] << 16), res[2] | ((unsigned)res[3] << 16));
+                }
+                __syncthreads();
+                // forward pass 1: T[k][j] = rnd(M[k] . X[j], 2 log2N - 2)
+                if (r.on) {
+                    const int s1 = 2 * l2 - 2;
+                    int acc[4];
+                    quad_dot(mf + r.qy * mp, X + r.qx * RP, RP, nn, acc);
+                    unsigned short o[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[i] = (unsigned short)(short)((acc[i] + (1 << (s1 - 1))) >> s1);
+                    *(uint2 *)(T + r.qy * RP + r.qx) = make_uint2(o[0] | ((unsigned)o[1] << 16), o[2] | ((unsigned)o[3] << 16));
+                }
+                __syncthreads();
+                // forward pass 2 + quant + dequant (stored transposed for the inverse passes)
+                if (r.on) {
+                    int acc[4];
+                    quad_dot(mf + r.qy * mp, T + r.qx * RP, RP, nn, acc);
+                    const int q = cp ? qpc : qp, qp6 = q / 6, scale = kQuantScales[q % 6], dqs = kInvQuantScales[q % 6] << qp6;
+                    const int qbits = 21 + qp6 - l2, off = 171 << (qbits - 9), shift = l2 - 1;
+                    unsigned short lv[4];
+                    int nzc = 0;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int coef = (short)((acc[i] + 64) >> 7);
+                        int du;
+                        const int l = quant_one(coef, scale, off, qbits, du);
+                        nzc += l != 0;
+                        lv[i] = (unsigned short)(short)l;
+                        X[(r.qx + i) * RP + r.qy] = (short)dequant_one(l, dqs, 1 << (shift - 1), shift);
+                    }
+                    *(uint2 *)(LV[cp] + (long)(py + r.qy) * lstride + px + r.qx) = make_uint2(lv[0] | ((unsigned)lv[1] << 16), lv[2] | ((unsigned)lv[3] << 16));
+                    if (nzc) atomicAdd(&L.nz[cp], nzc);
+                }
+                __syncthreads();
+                const bool live = r.on && L.nz[cp] != 0;
+                // inverse pass 1: T[y][x] = clip16((Mt[y] . Ct[x] + 64) >> 7)
+                if (r.on) {
+                    int acc[4] = {0, 0, 0, 0};
+                    if (live) quad_dot(mt + r.qy * mp, X + r.qx * RP, RP, nn, acc);
+                    unsigned short o[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[i] = (unsigned short)(short)clip16((acc[i] + 64) >> 7);
+                    *(uint2 *)(T + r.qy * RP + r.qx) = make_uint2(o[0] | ((unsigned)o[1] << 16), o[2] | ((unsigned)o[3] << 16));
+                }
+                __syncthreads();
+                // inverse pass 2 + prediction -> reconstructed samples
+                if (r.on) {
+                    int acc[4] = {0, 0, 0, 0};
+                    if (live) quad_dot(T + r.qy * RP, mt + r.qx * mp, mp, nn, acc);
+                    const unsigned pv = *(const unsigned *)(P + r.qy * 32 + r.qx);
+                    unsigned o = 0;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o |= (unsigned)clip8((int)((pv >> (8 * i)) & 255) + (live ? (acc[i] + 2048) >> 12 : 0)) << (8 * i);
+                    *(unsigned *)(R[cp] + (long)(py + r.qy) * stride + px + r.qx) = o;
+                }
+                __syncthreads();
+            }
+            if (tid < n8 * n8) {
+                const int cbf = (L.nz[0] ? 1 : 0) | (L.nz[1] ? 2 : 0) | (L.nz[2] ? 4 : 0);
+                cu8[(long)(cy * 8 + ly + tid / n8) * g.w8 + cx * 8 + lx + tid % n8].cbf = (uint8_t)cbf;
+            }
+            __threadfence();                                         // the CU's samples are in L2 before anyone gathers them
+            __syncthreads();
+        }
+        if (tid == 0) __hip_atomic_store(progress + cy, cx + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+extern "C" int ks265_intra_reconstruct(ks265_frame *f, ks265_pic src, ks265_cu8 *cu8, int16_t *lvl_y, int16_t *lvl_u, int16_t *lvl_v, ks265_pic recon)
+{
+    KS_FRAME_CHECK(f);
+    if (!src.y || !cu8 || !lvl_y || !lvl_u || !lvl_v || !recon.y) return KS265_POINTER;
+    if (hipMemsetAsync(f->progress, 0, sizeof(int) * (size_t)f->g.ctu_rows, f->ctx->stream) != hipSuccess) return ks265_hip(f->ctx, hipGetLastError());
+    hipLaunchKernelGGL(intra_recon_kernel, dim3(f->g.ctu_rows), dim3(256), 0, f->ctx->stream, f->g, f->cfg.qp, src.y, src.u, src.v, cu8, lvl_y, lvl_u, lvl_v,
+                       recon.y, recon.u, recon.v, f->progress);
+    return ks265_check_launch(f->ctx);
+}
+
+// ------------------------------------------------------------------ mode pre-selection + CU quadtree (one workgroup per CTU)
+typedef int ks_v4i __attribute__((ext_vector_type(4)));
+
+struct DecideLds {
+    unsigned char ref[84][2][132];          // [block][raw / smoothed], corner at index 66; blocks: 4 of 32x32, 16 of 16x16, 64 of 8x8 (raster per level)
+    unsigned short dc[84];
+    unsigned best[4][84];                   // per wave: min over its modes of (cost << 6) | mode
+    unsigned cost[85];
+    unsigned char mode[85], split[85];
+};
+
+__device__ __forceinline__ int intra_mode_bits(int mode) { return (mode == 0 || mode == 1 || mode == 26) ? 3 : 6; }   // default MPM set vs. escape code
+
+__global__ __launch_bounds__(256) void intra_decide_kernel(KsGeom g, int lam, const uint8_t *src_y, ks265_cu8 *cu8)
+{
+    __shared__ __attribute__((aligned(16))) DecideLds L;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ctu = ks_xcd_swizzle(blockIdx.x, g.ctu_cols * g.ctu_rows), cx = ctu % g.ctu_cols, cy = ctu / g.ctu_cols;
+    const uint8_t *S = ks_org_y(g, src_y);
+    // ---- (1) reference arrays of all 84 blocks from the source picture, raw and smoothed; one block per wave at a time
+#pragma unroll 1
+    for (int b = wave; b < 84; b += 4) {
+        const int l = b < 4 ? 1 : (b < 20 ? 2 : 3), i = b - (l == 1 ? 0 : (l == 2 ? 4 : 20)), n = 64 >> l;
+        const int x0 = cx * 64 + (i & ((1 << l) - 1)) * n, y0 = cy * 64 + (i >> l) * n;
+        if (x0 + n > g.W || y0 + n > g.H) continue;                 // not (completely) inside the picture: never a CU
+        const unsigned mask = intra_unit_mask(g, x0, y0, n, lane);
+        unsigned char *raw = &L.ref[b][0][66], *fil = &L.ref[b][1][66];
+        for (int q = lane; q <= 4 * n; q += 64) raw[q - 2 * n] = (unsigned char)intra_ref_sample<false>(S, g.sy, mask, x0, y0, n, 8, q);
+        __builtin_amdgcn_wave_barrier();
+        const bool bil = n == 32 && intra_strong_flat(raw);
+        for (int q = lane; q <= 4 * n; q += 64) fil[q - 2 * n] = (unsigned char)intra_filtered(raw, n, q - 2 * n, bil);
+        if (lane == 0) {
+            int dc = n;
+            for (int k = 0; k < n; ++k) dc += raw[1 + k] + raw[-1 - k];
+            L.dc[b] = (unsigned short)(dc >> (7 - l));              // log2(n) + 1
+        }
+    }
+    __syncthreads();
+    // ---- (2) all 35 modes of every block: SATD of (source - prediction) on the matrix cores (see me_subpel_kernel for the operand
+    //      layout: lane = (tile column n16, row pair gk); tiles numbered in Z-order so that a block is an aligned lane group)
+    const int n16 = lane & 15, gk = lane >> 4;
+    ks_v4i Hm[4];
+    {
+        const unsigned pat = (n16 & 2) ? ((n16 & 1) ? 0x01FFFF01u : 0xFFFF0101u) : ((n16 & 1) ? 0xFF01FF01u : 0x01010101u);
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int w = 0; w < 4; ++w) Hm[mb][w] = (int)((__popc((mb * 16 + n16) & (gk * 16 + w * 4)) & 1) ? pat ^ 0xFEFEFEFEu : pat);
+    }
+    const ks_v4i CinN = {0x8000, 0x8000, 0x8000, 0x8000};
+    const ks_v4i Cin0 = {gk == 0 ? 0x8000 + 64 : 0x8000, 0x8000, 0x8000, 0x8000};
+    ks_v4i Sop[4];
+    int ttx[4], tty[4];                                             // tile coordinates (8-sample units) of this lane's four operand columns
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+        const int t = nb * 16 + n16;
+        ttx[nb] = (t & 1) | ((t >> 1) & 2) | ((t >> 2) & 4); tty[nb] = ((t >> 1) & 1) | ((t >> 2) & 2) | ((t >> 3) & 4);
+        const uint8_t *p = S + (long)(cy * 64 + tty[nb] * 8 + 2 * gk) * g.sy + cx * 64 + ttx[nb] * 8;
+        const uint2 a0 = *(const uint2 *)p, a1 = *(const uint2 *)(p + g.sy);
+        Sop[nb] = ks_v4i{(int)(a0.x ^ 0x7F7F7F7Fu), (int)(a0.y ^ 0x7F7F7F7Fu), (int)(a1.x ^ 0x7F7F7F7Fu), (int)(a1.y ^ 0x7F7F7F7Fu)};
+    }
+    const int ltx = (lane & 1) | ((lane >> 1) & 2) | ((lane >> 2) & 4), lty = ((lane >> 1) & 1) | ((lane >> 2) & 2) | ((lane >> 3) & 4);
+#pragma unroll 1
+    for (int l = 1; l <= 3; ++l) {
+        const int n = 64 >> l, log2 = 6 - l, t8 = n >> 3, base = l == 1 ? 0 : (l == 2 ? 4 : 20);
+        unsigned best = 0xFFFFFFFFu;
+#pragma unroll 1
+        for (int mode = wave; mode < 35; mode += 4) {
+            const int which = intra_filter_flag(mode, n) ? 1 : 0;
+            unsigned acc[4];
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                const int b = base + (tty[nb] / t8) * (1 << l) + ttx[nb] / t8;
+                const unsigned char *ref = &L.ref[b][which][66];
+                const int ox = (ttx[nb] % t8) * 8, oy = (tty[nb] % t8) * 8 + 2 * gk, dc = L.dc[b];
+                unsigned w[4];
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        unsigned v = 0;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) v |= (unsigned)intra_sample(ref, mode, log2, ox + 4 * h + c, oy + r, dc, true) << (8 * c);
+                        w[2 * r + h] = v ^ 0x80808080u;
+                    }
+                const ks_v4i B = {(int)w[0], (int)w[1], (int)w[2], (int)w[3]};
+                unsigned a = 0;
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) {
+                    ks_v4i C = __builtin_amdgcn_mfma_i32_16x16x64_i8(Hm[mb], B, mb == 0 ? Cin0 : CinN, 0, 0, 0);
+                    C = __builtin_amdgcn_mfma_i32_16x16x64_i8(Hm[mb], Sop[nb], C, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) a = __builtin_amdgcn_sad_u16((unsigned)C[r], 0x8000u, a);
+                }
+                acc[nb] = a;
+            }
+            const bool o1 = gk & 1, o2 = gk & 2;
+            const unsigned t0 = (o1 ? acc[1] : acc[0]) + (unsigned)__builtin_amdgcn_ds_swizzle((int)(o1 ? acc[0] : acc[1]), 0x1F | (16 << 10));
+            const unsigned t1 = (o1 ? acc[3] : acc[2]) + (unsigned)__builtin_amdgcn_ds_swizzle((int)(o1 ? acc[2] : acc[3]), 0x1F | (16 << 10));
+            const unsigned tot = (o2 ? t1 : t0) + (unsigned)__shfl_xor((int)(o2 ? t0 : t1), 32, 64);
+            unsigned sd = (tot + 2) >> 2;                               // SATD of tile `lane` (Z-order), had_c normalisation
+            if (l <= 2) { sd += (unsigned)dpp_mov<KS265_DPP_QUAD_XOR1>((int)sd); sd += (unsigned)dpp_mov<KS265_DPP_QUAD_XOR2>((int)sd); }
+            if (l <= 1) { sd += (unsigned)dpp_mov<KS265_DPP_ROW_HALF_MIRROR>((int)sd); sd += (unsigned)dpp_mov<KS265_DPP_ROW_MIRROR>((int)sd); }
+            const unsigned c = sd + (unsigned)((lam * intra_mode_bits(mode)) >> 4);
+            best = min(best, (c << 6) | (unsigned)mode);
+        }
+        // the first lane of every block publishes this wave's winner
+        if ((lane & (t8 * t8 - 1)) == 0) L.best[wave][base + (lty / t8) * (1 << l) + ltx / t8] = best;
+    }
+    __syncthreads();
+    if (tid < 84) {
+        const int b = tid, l = b < 4 ? 1 : (b < 20 ? 2 : 3), i = b - (l == 1 ? 0 : (l == 2 ? 4 : 20)), n = 64 >> l;
+        const int x0 = cx * 64 + (i & ((1 << l) - 1)) * n, y0 = cy * 64 + (i >> l) * n;
+        const unsigned m = min(min(L.best[0][b], L.best[1][b]), min(L.best[2][b], L.best[3][b]));
+        const bool inside = x0 + n <= g.W && y0 + n <= g.H;
+        L.cost[1 + b] = inside ? m >> 6 : KS_COST_INVALID;           // PU index = 1 + b (level bases 1, 5, 21)
+        L.mode[1 + b] = (unsigned char)(m & 63u);
+    }
+    __syncthreads();
+    // ---- (3) CU quadtree bottom-up (kso_intra_decide: a node keeps its own cost if it is <= the children's sum + split overhead)
+    if (tid == 0) {
+        // 85 nodes, leaves first; node value v[idx]
+        unsigned v[85];
+        for (int l = 3; l >= 0; --l)
+            for (int i = 0; i < (1 << (2 * l)); ++i) {
+                const int px = i & ((1 << l) - 1), py = i >> l, s = 64 >> l, x0 = cx * 64 + px * s, y0 = cy * 64 + py * s, idx = ks_pu_index(l, px, py);
+                if (x0 >= g.W || y0 >= g.H) { v[idx] = 0; L.split[idx] = 0; continue; }
+                const unsigned own = l == 0 ? KS_COST_INVALID : L.cost[idx];
+                if (l == 3) { v[idx] = own; L.split[idx] = 0; continue; }
+                unsigned long long sum = (unsigned long long)((lam * 12) >> 4);
+                for (int k = 0; k < 4; ++k) sum += v[ks_pu_index(l + 1, px * 2 + (k & 1), py * 2 + (k >> 1))];
+                if (own != KS_COST_INVALID && (unsigned long long)own <= sum) { v[idx] = own; L.split[idx] = 0; }
+                else { v[idx] = sum > 0xFFFFFFFEull ? 0xFFFFFFFEu : (unsigned)sum; L.split[idx] = 1; }
+            }
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const int bx = tid & 7, by = tid >> 3, X = cx * 8 + bx, Y = cy * 8 + by;
+        if (X < g.w8 && Y < g.h8) {
+            int l = 1, idx = ks_pu_index(1, bx >> 2, by >> 2);
+            while (l < 3 && L.split[idx]) { ++l; idx = ks_pu_index(l, bx >> (3 - l), by >> (3 - l)); }
+            ks265_cu8 c;
+            c.mvx = L.mode[idx]; c.mvy = 0; c.mv1x = 0; c.mv1y = 0; c.log2_cu = (uint8_t)(6 - l); c.cbf = 0; c.pred_mode = 2; c.inter_dir = 0;
+            cu8[(long)Y * g.w8 + X] = c;
+        }
+    }
+}
+
+extern "C" int ks265_intra_decide(ks265_frame *f, ks265_pic src, ks265_cu8 *cu8)
+{
+    KS_FRAME_CHECK(f);
+    if (!src.y || !cu8) return KS265_POINTER;
+    hipLaunchKernelGGL(intra_decide_kernel, dim3(f->g.ctu_cols * f->g.ctu_rows), dim3(256), 0, f->ctx->stream, f->g, f->cfg.lambda_q4, src.y, cu8);
+    return ks265_check_launch(f->ctx);
+}

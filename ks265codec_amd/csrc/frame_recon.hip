@@ -9,32 +9,9 @@
 // `short` buffers; accumulation is int32).  Row pitch 36 shorts = 18 dwords makes the row-per-lane ds_read_b64 walks
 // bank-conflict free.  Each thread produces 4 adjacent outputs that share one of the two operand rows.
 #include "frame_common.h"
+#include "recon_dev.h"
 
 using namespace ks265;
-
-typedef short s16x2 __attribute__((ext_vector_type(2)));
-#define RP 36                      // LDS row pitch of the sample/coefficient tiles, in shorts
-
-// matrices of all four sizes, row pitch n + 4 shorts; offset of size n (4, 8, 16, 32)
-__device__ __forceinline__ int mat_off(int log2n) { return log2n == 2 ? 0 : log2n == 3 ? 32 : log2n == 4 ? 128 : 448; }   // 4*8, 8*12, 16*20, 32*36
-#define MAT_SHORTS (448 + 32 * 36)
-
-__device__ __forceinline__ int dot2(unsigned a, unsigned b, int c) { return __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b), c, false); }
-
-// out[i] = shared[0..n) . rows[i * pitch + 0..n), i = 0..3 ; all pointers 8-byte aligned, n a multiple of 4
-__device__ __forceinline__ void quad_dot(const short *shared, const short *rows, int pitch, int n, int (&out)[4])
-{
-    out[0] = out[1] = out[2] = out[3] = 0;
-    for (int x = 0; x < n; x += 4) {
-        const uint2 s = *(const uint2 *)(shared + x);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint2 r = *(const uint2 *)(rows + i * pitch + x);
-            out[i] = dot2(s.x, r.x, out[i]);
-            out[i] = dot2(s.y, r.y, out[i]);
-        }
-    }
-}
 
 // ---- fractional-sample prediction of 4 adjacent samples as RAW sums, shared by uni- and bi-prediction.
 // kind 0: v = sample; kind 1: one fraction, v = tap sum (scale 64); kind 2: both fractions, v = vertical taps over the

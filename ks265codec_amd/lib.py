@@ -55,7 +55,7 @@ EXPORTS = [
     "ks265_sao_apply_bo_rect", "ks265_sao_apply_eo_rect", "ks265_sao_stats_batch", "ks265_intra_pred_batch", "ks265_intra_filter_ref_batch",
     "ks265_frame_geometry", "ks265_frame_create", "ks265_frame_destroy", "ks265_frame_set_qp", "ks265_pad_picture",
     "ks265_load_i420", "ks265_store_i420", "ks265_ref_planes", "ks265_me_integer", "ks265_me_subpel", "ks265_cu_decide",
-    "ks265_cu_flat_intra", "ks265_reconstruct", "ks265_reconstruct_b", "ks265_bi_decide", "ks265_cu_decide_b", "ks265_deblock", "ks265_sao",
+    "ks265_cu_flat_intra", "ks265_intra_decide", "ks265_intra_reconstruct", "ks265_reconstruct", "ks265_reconstruct_b", "ks265_bi_decide", "ks265_cu_decide_b", "ks265_deblock", "ks265_sao",
     "ks265_encode_picture", "ks265_encode_picture_b",
     "ks265_frame_set_profiling", "ks265_frame_stage_ms", "ks265_frame_levels", "ks265_frame_pu", "ks265_frame_cu8", "ks265_frame_sao", "ks265_frame_planes", "ks265_sse_picture",
 ]
@@ -233,6 +233,12 @@ class KsFrame:
         self.width, self.height = width, height
         self.nctu = self.geom.ctu_cols * self.geom.ctu_rows
 
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
     def close(self):
         if getattr(self, "h", None):
             self.lib.ks265_frame_destroy(self.h)
@@ -270,6 +276,12 @@ class KsFrame:
 
     def me_subpel(self, src: DevPic, planes, pu):
         self.ks._chk(self.lib.ks265_me_subpel(self.h, src.c(), _p(planes), _p(pu)))
+
+    def intra_decide(self, src: DevPic, cu8):
+        self.ks._chk(self.lib.ks265_intra_decide(self.h, src.c(), _p(cu8)))
+
+    def intra_reconstruct(self, src: DevPic, cu8, lvl, recon: DevPic):
+        self.ks._chk(self.lib.ks265_intra_reconstruct(self.h, src.c(), _p(cu8), _p(lvl[0]), _p(lvl[1]), _p(lvl[2]), recon.c()))
 
     def cu_decide(self, pu, cu8):
         self.ks._chk(self.lib.ks265_cu_decide(self.h, _p(pu), _p(cu8)))

@@ -633,7 +633,7 @@ static int edge_bs(const kso_cu8 *p, const kso_cu8 *q, int pos8 /*edge position 
     int cu8n = 1 << (q->log2_cu - 3), tu8n = imin(cu8n, 4);
     int tu_edge = (pos8 % tu8n) == 0, cu_edge = (pos8 % cu8n) == 0;
     if (!tu_edge && !cu_edge) return 0;
-    if (p->pred_mode == 1 || q->pred_mode == 1) return 2;
+    if (p->pred_mode != 0 || q->pred_mode != 0) return 2;
     if (tu_edge && ((p->cbf | q->cbf) & 1)) return 1;
     if (cu_edge) {
         /* CalcBsInterP enc@0x402960 / CalcBsInterB enc@0x4029d0 with one picture per list: different reference sets, or any
@@ -798,4 +798,167 @@ void kso_sao(const kso_frame_cfg *cfg, kso_pic src, kso_pic deb, kso_sao_param *
             sao_apply_ctu(org_c(&g, deb.v), org_c(&g, dst.v), g.stride_c, x0 / 2, y0 / 2, w / 2, h / 2, W / 2, H / 2, &sp[2]);
         }
     kso_pad_picture(cfg, dst);
+}
+
+/* ================================================================== intra pictures
+ * Kernels: ks265o_intra_pred / ks265o_intra_filter_ref (pinned against IntraPred*_c / IntraPredFilterRef_c, tests/golden/intra.npz).
+ * Sequencing (the build's own, like the CU decision of P pictures: decideBestLumaModeBySadFast enc@0x499170 / decideLumaMode
+ * enc@0x49acc0 are closed RDO code):
+ *   kso_intra_decide       every 8x8 / 16x16 / 32x32 block: all 35 luma modes predicted from SOURCE neighbours ("pre-selection is
+ *                          embarrassingly parallel on source pixels"), cost = SATD + lambda * mode bits, then the CU quadtree bottom-up;
+ *   kso_intra_reconstruct  CTUs in raster order, CUs in z-order: neighbours from the RECONSTRUCTED picture with the normative
+ *                          availability (H.265 6.4.1) and substitution (8.4.4.2.2) rules, reference smoothing (8.4.4.2.3), prediction,
+ *                          residual -> transform -> quant -> dequant -> inverse -> recon per TU (= CU, at most 32x32);
+ *                          chroma uses the luma mode (DM), unsmoothed references, no edge filter.
+ * cu8 of an intra CU: pred_mode = 2, mvx = luma mode. */
+static int morton4(int x, int y)       /* z-scan address of the 4x4 unit (x, y), x, y < 16 */
+{
+    int z = 0;
+    for (int b = 0; b < 4; ++b) z |= (((x >> b) & 1) << (2 * b)) | (((y >> b) & 1) << (2 * b + 1));
+    return z;
+}
+/* is luma sample (nx, ny) available to the block whose first sample is (x, y)?  inside the picture and earlier in decoding order */
+static int intra_avail(int W, int H, int x, int y, int nx, int ny)
+{
+    if (nx < 0 || ny < 0 || nx >= W || ny >= H) return 0;
+    int cols = (W + 63) / 64, ca = (y >> 6) * cols + (x >> 6), na = (ny >> 6) * cols + (nx >> 6);
+    if (na != ca) return na < ca;
+    return morton4((nx & 63) >> 2, (ny & 63) >> 2) < morton4((x & 63) >> 2, (y & 63) >> 2);
+}
+/* reference samples of the n x n block at (x, y) (component samples; sh = 0 luma, 1 chroma) from plane `p` (sample (0,0), stride st);
+ * r = corner pointer of a 4n + 1 array */
+static void intra_gather(const uint8_t *p, long st, int W, int H, int sh, int x, int y, int n, uint8_t *r)
+{
+    uint8_t av[4 * 32 + 1];
+    int any = 0;
+    for (int k = -2 * n; k <= 2 * n; ++k) {
+        int sx = k > 0 ? x + k - 1 : x - 1, sy = k < 0 ? y - k - 1 : y - 1;
+        int a = intra_avail(W, H, x << sh, y << sh, sx < 0 ? -1 : sx << sh, sy < 0 ? -1 : sy << sh);
+        av[k + 2 * n] = (uint8_t)a;
+        any |= a;
+        r[k] = a ? p[(long)sy * st + sx] : 0;
+    }
+    if (!any) { for (int k = -2 * n; k <= 2 * n; ++k) r[k] = 128; return; }
+    if (!av[0]) {
+        int k = -2 * n + 1;
+        while (!av[k + 2 * n]) ++k;
+        r[-2 * n] = r[k];
+    }
+    for (int k = -2 * n + 1; k <= 2 * n; ++k)
+        if (!av[k + 2 * n]) r[k] = r[k - 1];
+}
+static int intra_filter_flag(int mode, int n)
+{
+    if (mode == 1 || n <= 4) return 0;
+    int d1 = mode > 26 ? mode - 26 : 26 - mode, d2 = mode > 10 ? mode - 10 : 10 - mode, d = d1 < d2 ? d1 : d2;
+    return d > (n == 8 ? 7 : (n == 16 ? 1 : 0));
+}
+static int intra_mode_bits(int mode) { return (mode == 0 || mode == 1 || mode == 26) ? 3 : 6; }   /* default MPM set vs. escape code */
+
+/* best luma mode of one block from source neighbours; returns the cost */
+static uint32_t intra_best_mode(const kso_frame_cfg *cfg, const uint8_t *S, long st, int x, int y, int n, int *best_mode)
+{
+    uint8_t raw[4 * 32 + 1], fil[4 * 32 + 1], pred[32 * 32];
+    int log2 = n == 8 ? 3 : (n == 16 ? 4 : 5);
+    intra_gather(S, st, cfg->width, cfg->height, 0, x, y, n, raw + 2 * n);
+    ks265o_intra_filter_ref(raw + 2 * n, fil + 2 * n, n, 1);
+    uint32_t best = COST_INVALID;
+    for (int mode = 0; mode < 35; ++mode) {
+        ks265o_intra_pred(pred, n, (intra_filter_flag(mode, n) ? fil : raw) + 2 * n, mode, log2, 1);
+        uint32_t c = ks265o_had(S + (long)y * st + x, pred, st, n, n, n) + (uint32_t)((cfg->lambda_q4 * intra_mode_bits(mode)) >> 4);
+        if (c < best) { best = c; *best_mode = mode; }
+    }
+    return best;
+}
+typedef struct { uint32_t cost[85]; uint8_t mode[85], split[85]; } intra_ctu;
+static uint32_t intra_node(const kso_frame_cfg *cfg, intra_ctu *t, int cx, int cy, int l, int px, int py)
+{
+    int s = 64 >> l, x0 = cx * 64 + px * s, y0 = cy * 64 + py * s;
+    if (x0 >= cfg->width || y0 >= cfg->height) return 0;
+    int idx = pu_index(l, px, py);
+    uint32_t own = l == 0 ? COST_INVALID : t->cost[idx];          /* no 64x64 intra CU: its TUs would be four 32x32 anyway */
+    if (l == 3) { t->split[idx] = 0; return own; }
+    uint64_t sum = (uint64_t)((cfg->lambda_q4 * 12) >> 4);
+    for (int k = 0; k < 4; ++k) sum += intra_node(cfg, t, cx, cy, l + 1, px * 2 + (k & 1), py * 2 + (k >> 1));
+    if (own != COST_INVALID && (uint64_t)own <= sum) { t->split[idx] = 0; return own; }
+    t->split[idx] = 1;
+    return sum > 0xFFFFFFFEu ? 0xFFFFFFFEu : (uint32_t)sum;
+}
+static void intra_emit(const kso_frame_cfg *cfg, const intra_ctu *t, int cx, int cy, int l, int px, int py, kso_cu8 *cu8)
+{
+    int s = 64 >> l, x0 = cx * 64 + px * s, y0 = cy * 64 + py * s, w8 = cfg->width / 8;
+    if (x0 >= cfg->width || y0 >= cfg->height) return;
+    int idx = pu_index(l, px, py);
+    if (l < 3 && t->split[idx]) {
+        for (int k = 0; k < 4; ++k) intra_emit(cfg, t, cx, cy, l + 1, px * 2 + (k & 1), py * 2 + (k >> 1), cu8);
+        return;
+    }
+    for (int by = 0; by < s / 8; ++by)
+        for (int bx = 0; bx < s / 8; ++bx) {
+            kso_cu8 *c = &cu8[(long)(y0 / 8 + by) * w8 + x0 / 8 + bx];
+            c->mvx = t->mode[idx]; c->mvy = 0; c->mv1x = 0; c->mv1y = 0; c->log2_cu = (uint8_t)(6 - l); c->cbf = 0; c->pred_mode = 2; c->inter_dir = 0;
+        }
+}
+void kso_intra_decide(const kso_frame_cfg *cfg, kso_pic src, kso_cu8 *cu8)
+{
+    kso_frame_geom g; kso_frame_geometry(cfg, &g);
+    const uint8_t *S = org_y(&g, src.y);
+    for (int cy = 0; cy < g.ctu_rows; ++cy)
+        for (int cx = 0; cx < g.ctu_cols; ++cx) {
+            intra_ctu t;
+            memset(&t, 0, sizeof t);
+            for (int l = 1; l < 4; ++l)
+                for (int py = 0; py < (1 << l); ++py)
+                    for (int px = 0; px < (1 << l); ++px) {
+                        int s = 64 >> l, x0 = cx * 64 + px * s, y0 = cy * 64 + py * s, idx = pu_index(l, px, py), m = 0;
+                        t.cost[idx] = COST_INVALID;
+                        if (x0 + s > cfg->width || y0 + s > cfg->height) continue;
+                        t.cost[idx] = intra_best_mode(cfg, S, g.stride_y, x0, y0, s, &m);
+                        t.mode[idx] = (uint8_t)m;
+                    }
+            intra_node(cfg, &t, cx, cy, 0, 0, 0);
+            intra_emit(cfg, &t, cx, cy, 0, 0, 0, cu8);
+        }
+}
+
+static void intra_code_cu(const kso_frame_cfg *cfg, const kso_frame_geom *g, kso_pic src, kso_cu8 *cu8, int bx, int by, int16_t *lvl_y, int16_t *lvl_u,
+                          int16_t *lvl_v, kso_pic recon)
+{
+    int W = cfg->width, H = cfg->height, w8 = W / 8, qp = cfg->qp, qpc = chroma_qp(qp);
+    long sy = g->stride_y, sc = g->stride_c;
+    kso_cu8 *c = &cu8[(long)by * w8 + bx];
+    int n = 1 << c->log2_cu, x0 = bx * 8, y0 = by * 8, mode = c->mvx, log2 = c->log2_cu, cbf = 0;
+    uint8_t raw[4 * 32 + 1], fil[4 * 32 + 1], pred[32 * 32];
+    uint8_t *Ry = org_y(g, recon.y);
+    intra_gather(Ry, sy, W, H, 0, x0, y0, n, raw + 2 * n);
+    const uint8_t *r = raw + 2 * n;
+    if (intra_filter_flag(mode, n)) { ks265o_intra_filter_ref(raw + 2 * n, fil + 2 * n, n, 1); r = fil + 2 * n; }
+    ks265o_intra_pred(pred, n, r, mode, log2, 1);
+    cbf |= code_tu(org_y(g, src.y) + (long)y0 * sy + x0, (int)sy, pred, n, qp, 1, lvl_y + (long)y0 * W + x0, W, Ry + (long)y0 * sy + x0, (int)sy);
+    int nc = n / 2, xc = x0 / 2, yc = y0 / 2;
+    for (int comp = 0; comp < 2; ++comp) {
+        uint8_t *Rc = org_c(g, comp ? recon.v : recon.u);
+        intra_gather(Rc, sc, W, H, 1, xc, yc, nc, raw + 2 * nc);
+        ks265o_intra_pred(pred, nc, raw + 2 * nc, mode, log2 - 1, 0);
+        int16_t *lv = (comp ? lvl_v : lvl_u) + (long)yc * (W / 2) + xc;
+        const uint8_t *oc = org_c(g, comp ? src.v : src.u) + (long)yc * sc + xc;
+        if (code_tu(oc, (int)sc, pred, nc, qpc, 1, lv, W / 2, Rc + (long)yc * sc + xc, (int)sc)) cbf |= 2 << comp;
+    }
+    for (int yy = 0; yy < n / 8; ++yy)
+        for (int xx = 0; xx < n / 8; ++xx) cu8[(long)(by + yy) * w8 + bx + xx].cbf = (uint8_t)cbf;
+}
+void kso_intra_reconstruct(const kso_frame_cfg *cfg, kso_pic src, kso_cu8 *cu8, int16_t *lvl_y, int16_t *lvl_u, int16_t *lvl_v, kso_pic recon)
+{
+    kso_frame_geom g; kso_frame_geometry(cfg, &g);
+    int w8 = cfg->width / 8, h8 = cfg->height / 8;
+    for (int cy = 0; cy < g.ctu_rows; ++cy)
+        for (int cx = 0; cx < g.ctu_cols; ++cx)
+            for (int z = 0; z < 64; ++z) {                          /* 8x8 blocks of the CTU in z-order */
+                int lx = (z & 1) | ((z >> 1) & 2) | ((z >> 2) & 4), ly = ((z >> 1) & 1) | ((z >> 2) & 2) | ((z >> 3) & 4);
+                int bx = cx * 8 + lx, by = cy * 8 + ly;
+                if (bx >= w8 || by >= h8) continue;
+                int n8 = 1 << (cu8[(long)by * w8 + bx].log2_cu - 3);
+                if ((lx % n8) || (ly % n8)) continue;                /* visit each CU once, at its first 8x8 block */
+                intra_code_cu(cfg, &g, src, cu8, bx, by, lvl_y, lvl_u, lvl_v, recon);
+            }
 }

@@ -29,7 +29,7 @@ typedef struct {
 } kso_frame_geom;
 
 typedef struct { int16_t mvx, mvy, mvpx, mvpy; uint32_t cost, dist; } kso_pu;
-typedef struct { int16_t mvx, mvy, mv1x, mv1y; uint8_t log2_cu, cbf, pred_mode, inter_dir; } kso_cu8;   /* inter_dir: 1 = L0, 2 = L1, 3 = Bi */
+typedef struct { int16_t mvx, mvy, mv1x, mv1y; uint8_t log2_cu, cbf, pred_mode, inter_dir; } kso_cu8;   /* pred_mode: 0 inter, 1 flat intra, 2 intra (mvx = luma mode); inter_dir: 1 = L0, 2 = L1, 3 = Bi */
 typedef struct { int16_t mvx, mvy, mv1x, mv1y; uint32_t cost; uint32_t inter_dir; } kso_pu_b;
 typedef struct { int8_t type, band, offset[4], rsv[2]; } kso_sao_param;
 typedef struct { uint8_t *y, *u, *v; } kso_pic;
@@ -49,6 +49,10 @@ void kso_reconstruct(const kso_frame_cfg *cfg, kso_pic src, kso_pic ref, const u
 void kso_bi_decide(const kso_frame_cfg *cfg, kso_pic src, const uint8_t *planes0, const uint8_t *planes1, const kso_pu *pu0, const kso_pu *pu1,
                    kso_pu_b *pub);
 void kso_cu_decide_b(const kso_frame_cfg *cfg, const kso_pu_b *pub, kso_cu8 *cu8);
+/* intra pictures: mode pre-selection on source neighbours + CU quadtree, then the sequential reconstruction.
+ * Intra CU in cu8: pred_mode = 2, mvx = luma mode (0 planar, 1 DC, 2..34 angular), chroma = the luma mode (DM). */
+void kso_intra_decide(const kso_frame_cfg *cfg, kso_pic src, kso_cu8 *cu8);
+void kso_intra_reconstruct(const kso_frame_cfg *cfg, kso_pic src, kso_cu8 *cu8, int16_t *lvl_y, int16_t *lvl_u, int16_t *lvl_v, kso_pic recon);
 void kso_deblock(const kso_frame_cfg *cfg, const kso_cu8 *cu8, kso_pic recon);
 void kso_sao(const kso_frame_cfg *cfg, kso_pic src, kso_pic deblocked, kso_sao_param *sao, kso_pic dst);
 

@@ -80,8 +80,9 @@ class HostPic:
 class OraclePipeline:
     """CPU restatement of the frame stages (test checker / cpu_baseline 'port')."""
 
-    def __init__(self, width, height, qp, lambda_q4, me_range=64, subme=1, deblock=1, sao=1, me_method=0):
+    def __init__(self, width, height, qp, lambda_q4, me_range=64, subme=1, deblock=1, sao=1, me_method=0, intra=False):
         self.o = lib()
+        self.intra = intra                      # key pictures: real intra prediction (True) or the flat stand-in
         self.cfg = OFrameCfg(width, height, qp, lambda_q4, me_range, me_method, subme, deblock, sao, 0, 0, 1)
         self.geom = OFrameGeom()
         assert self.o.kso_frame_geometry(C.byref(self.cfg), C.byref(self.geom)) == 0
@@ -118,7 +119,10 @@ class OraclePipeline:
         r1 = ref1.c() if ref1 is not None else null
         p1 = None
         if kind == "I":
-            o.kso_cu_flat_intra(cfg, ptr(self.cu8))
+            if self.intra:
+                o.kso_intra_decide(cfg, self.src.c(), ptr(self.cu8))
+            else:
+                o.kso_cu_flat_intra(cfg, ptr(self.cu8))
             self.have_prev = False
         else:
             o.kso_ref_planes(cfg, r0, ptr(self.planes))
@@ -141,8 +145,11 @@ class OraclePipeline:
                 o.kso_bi_decide(cfg, self.src.c(), ptr(self.planes), ptr(self.planes1), ptr(self.pu), ptr(self.pu1), ptr(self.pub))
                 o.kso_cu_decide_b(cfg, ptr(self.pub), ptr(self.cu8))
                 p1 = ptr(self.planes1)
-        o.kso_reconstruct(cfg, self.src.c(), r0, ptr(self.planes), r1, p1, ptr(self.cu8), ptr(self.lvl[0]), ptr(self.lvl[1]), ptr(self.lvl[2]),
-                          self.rec.c())
+        if kind == "I" and self.intra:
+            o.kso_intra_reconstruct(cfg, self.src.c(), ptr(self.cu8), ptr(self.lvl[0]), ptr(self.lvl[1]), ptr(self.lvl[2]), self.rec.c())
+        else:
+            o.kso_reconstruct(cfg, self.src.c(), r0, ptr(self.planes), r1, p1, ptr(self.cu8), ptr(self.lvl[0]), ptr(self.lvl[1]), ptr(self.lvl[2]),
+                              self.rec.c())
         self.rec_pre = [self.rec.y.copy(), self.rec.u.copy(), self.rec.v.copy()]
         if self.cfg.deblock:
             o.kso_deblock(cfg, ptr(self.cu8), self.rec.c())

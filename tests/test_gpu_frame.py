@@ -281,3 +281,35 @@ def test_b_pictures_match_oracle(ks, W, H, seed, me):
     code(2, "B", 0, 4, qp=30)
     code(3, "B", 0, 4, qp=30, staged=True)
     f.close()
+
+
+@pytest.mark.parametrize("W,H,qp", [(416, 240, 27), (200, 136, 37), (1920, 1080, 30)])
+def test_intra_picture(ks, W, H, qp):
+    """intra mode pre-selection + CU tree, then the wavefront reconstruction, stage by stage against the oracle"""
+    from ks265codec_amd.lib import CU8, KsFrame
+    from ks265codec_amd.synth import lambda_q4, make_clip
+    from oracle_lib import OraclePipeline
+
+    clip = make_clip(W, H, 1, seed=11)
+    o = OraclePipeline(W, H, qp, lambda_q4(qp), intra=True)
+    with KsFrame(ks, W, H, qp, lambda_q4(qp)) as f:
+        g = f.geom
+        org_y, org_c = g.pad_y * g.stride_y + g.pad_y, g.pad_c * g.stride_c + g.pad_c
+        src, rec = f.new_pic(), f.new_pic()
+        cu8 = ks.zeros(g.bytes_cu8)
+        lvl = [ks.zeros(W * H * 2), ks.zeros(W * H // 2), ks.zeros(W * H // 2)]
+        o.encode(clip[0], "I")
+        f.load_i420(ks.dev(clip[0]), src)
+        f.intra_decide(src, cu8)
+        gc = ks.host(cu8, CU8)
+        oc = o.cu8.copy(); oc["cbf"] = 0                        # the oracle's map already carries the cbf of its reconstruction
+        assert (gc == oc).all(), f"intra decision differs in {int((gc != oc).sum())} of {gc.size} blocks"
+        assert (gc["pred_mode"] == 2).all() and len(np.unique(gc["mvx"])) > 8        # a real mix of modes
+        f.intra_reconstruct(src, cu8, lvl, rec)
+        gc = ks.host(cu8, CU8)
+        assert (gc == o.cu8).all(), f"cbf differs in {int((gc != o.cu8).sum())} blocks"
+        for k, (a, b, n) in enumerate(zip(lvl, o.lvl, (W * H, W * H // 4, W * H // 4))):
+            assert (ks.host(a, np.int16)[:n] == b).all(), f"intra levels differ (component {k})"
+        _cmp_region("intra rec.y", ks.host(rec.y, np.uint8), o.rec_pre[0], g.stride_y, org_y, W, H)
+        _cmp_region("intra rec.u", ks.host(rec.u, np.uint8), o.rec_pre[1], g.stride_c, org_c, W // 2, H // 2)
+        _cmp_region("intra rec.v", ks.host(rec.v, np.uint8), o.rec_pre[2], g.stride_c, org_c, W // 2, H // 2)
