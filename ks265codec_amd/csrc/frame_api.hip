@@ -90,8 +90,13 @@ int ks265_encode_picture(ks265_frame *f, ks265_pic src, ks265_pic ref, int is_ke
         evi = stage_done + 1;
     };
     mark(0);
+    ks265_pic deb = ks_deb_pic(f);
     if (is_key) {
-        if ((r = ks265_cu_flat_intra(f, f->cu8))) return r;
+        /* intra picture: mode pre-selection + CU tree on the source, then the wavefront reconstruction */
+        mark(3);
+        if ((r = ks265_intra_decide(f, src, f->cu8))) return r;
+        mark(4);
+        if ((r = ks265_intra_reconstruct(f, src, f->cu8, f->lvl[0], f->lvl[1], f->lvl[2], deb))) return r;
         f->have_prev = false;
     } else {
         if (!ref.y) return KS265_POINTER;
@@ -102,10 +107,9 @@ int ks265_encode_picture(ks265_frame *f, ks265_pic src, ks265_pic ref, int is_ke
         if (f->cfg.subme && (r = ks265_me_subpel(f, src, f->planes, pu))) return r;
         mark(3);
         if ((r = ks265_cu_decide(f, pu, f->cu8))) return r;
+        mark(4);
+        if ((r = ks265_reconstruct(f, src, ref, f->planes, f->cu8, f->lvl[0], f->lvl[1], f->lvl[2], deb))) return r;
     }
-    mark(4);
-    ks265_pic deb = ks_deb_pic(f);
-    if ((r = ks265_reconstruct(f, src, ref, f->planes, f->cu8, f->lvl[0], f->lvl[1], f->lvl[2], deb))) return r;
     mark(5);
     if (f->cfg.deblock && (r = ks265_deblock(f, f->cu8, deb))) return r;
     mark(6);

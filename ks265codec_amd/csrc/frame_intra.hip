@@ -72,6 +72,13 @@ struct IntraLds {
     unsigned char raw[3][132], fil[132];                 // reference arrays, corner at index 66 (luma: 64 + 1 + 64; chroma 32 + 1 + 32)
     int nz[3];
     ks265_cu8 cu[64];
+    // reconstructed samples around the CTU being coded: row 0 = the row above the CTU (x = -1 .. 127: top-left, top, top-right),
+    // rows 1..64 = the CTU with column 3 = the last column of the previous CTU of this row; sample (x, y) of the CTU sits at
+    // [(1 + y) * pitch + 4 + x].  Every neighbour gather of a CU reads this window, never HBM.
+    unsigned char WY[65 * 136];
+    unsigned char WC[2][33 * 72];
+    unsigned char SY[64 * 64], SC[2][32 * 32];           // the CTU's source samples (one HBM round trip per CTU instead of one per CU)
+    int dcv[3];
 };
 
 // one thread's role in a TU phase: component + quad, or idle
@@ -85,9 +92,13 @@ __global__ __launch_bounds__(256) void intra_recon_kernel(KsGeom g, int qp, cons
     const int tid = threadIdx.x, lane = tid & 63, cy = blockIdx.x;
     build_matrices(L.Mf, L.Mt, tid, 256);
     const int qpc = chroma_qp(qp);
-    const uint8_t *S[3] = {ks_org_y(g, src_y), ks_org_c(g, src_u), ks_org_c(g, src_v)};
-    uint8_t *R[3] = {ks_org_y(g, rec_y), ks_org_c(g, rec_u), ks_org_c(g, rec_v)};
-    int16_t *LV[3] = {lvl_y, lvl_u, lvl_v};
+    // quantiser constants of the two QPs, fetched once (a table load inside the CU loop would sit behind every outstanding store)
+    const int qsc[2] = {kQuantScales[qp % 6], kQuantScales[qpc % 6]}, qdq[2] = {kInvQuantScales[qp % 6] << (qp / 6), kInvQuantScales[qpc % 6] << (qpc / 6)};
+    const int qp6[2] = {qp / 6, qpc / 6};
+    // (component pointers are picked with selects, not from an array: a dynamically indexed pointer array loses the global address
+    //  space, its stores become FLAT stores, and FLAT stores count against lgkmcnt - every LDS barrier would wait for HBM)
+    const uint8_t *const S0 = ks_org_y(g, src_y), *const S1 = ks_org_c(g, src_u), *const S2 = ks_org_c(g, src_v);
+    uint8_t *const R0 = ks_org_y(g, rec_y), *const R1 = ks_org_c(g, rec_u), *const R2 = ks_org_c(g, rec_v);
     for (int cx = 0; cx < g.ctu_cols; ++cx) {
         // wavefront: the row above must be two CTUs ahead (top-right neighbours)
         if (cy > 0 && tid == 0) {
@@ -101,6 +112,25 @@ __global__ __launch_bounds__(256) void intra_recon_kernel(KsGeom g, int qp, cons
             c.mvx = 0; c.mvy = 0; c.mv1x = 0; c.mv1y = 0; c.log2_cu = 0; c.cbf = 0; c.pred_mode = 0; c.inter_dir = 0;
             if (bx < g.w8 && by < g.h8) c = cu8[(long)by * g.w8 + bx];
             L.cu[tid] = c;
+            // the previous CTU's last column becomes this CTU's left neighbour column
+            L.WY[(1 + tid) * 136 + 3] = L.WY[(1 + tid) * 136 + 4 + 63];
+            L.WC[tid >> 5][(1 + (tid & 31)) * 72 + 3] = L.WC[tid >> 5][(1 + (tid & 31)) * 72 + 4 + 31];
+        }
+        {   // source samples of the CTU: 64 rows x 64 bytes luma (16-byte pieces), 2 x 32 x 32 chroma; rows below the picture are padding, never used
+            const int r = tid >> 2, c = (tid & 3) * 16;
+            *(uint4 *)&L.SY[r * 64 + c] = *(const uint4 *)(S0 + (long)(cy * 64 + r) * g.sy + cx * 64 + c);
+            const int cc = tid >> 7, t = tid & 127, rc = t >> 2, c8 = (t & 3) * 8;
+            *(uint2 *)&L.SC[cc][rc * 32 + c8] = *(const uint2 *)((cc ? S2 : S1) + (long)(cy * 32 + rc) * g.sc + cx * 32 + c8);
+        }
+        if (cy > 0) {                                                // the row above: finished by another workgroup -> L2-coherent loads
+            if (tid < 129) {
+                const int x = cx * 64 - 1 + tid;
+                if (x >= 0 && x < g.W) L.WY[3 + tid] = __hip_atomic_load(R0 + (long)(cy * 64 - 1) * g.sy + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (tid < 130) {
+                const int cc = tid / 65, k = tid % 65, x = cx * 32 - 1 + k;
+                if (x >= 0 && x < g.W / 2) L.WC[cc][3 + k] = __hip_atomic_load((cc ? R2 : R1) + (long)(cy * 32 - 1) * g.sc + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
         __syncthreads();
 #pragma unroll 1
@@ -113,22 +143,34 @@ __global__ __launch_bounds__(256) void intra_recon_kernel(KsGeom g, int qp, cons
             const int n = 8 * n8, log2 = c.log2_cu, mode = c.mvx, x0 = cx * 64 + lx * 8, y0 = cy * 64 + ly * 8;
             const unsigned mask = intra_unit_mask(g, x0, y0, n, lane);
             if (tid < 3) L.nz[tid] = 0;
-            // ---- reference samples of the three components (HBM, L2-coherent), one sample per thread
+            // ---- reference samples of the three components from the LDS window, one sample per thread
             {
                 const int lenY = 4 * n + 1, lenC = 2 * n + 1;
-                if (tid < lenY) L.raw[0][66 - 2 * n + tid] = (unsigned char)intra_ref_sample<true>(R[0], g.sy, mask, x0, y0, n, 8, tid);
+                if (tid < lenY) L.raw[0][66 - 2 * n + tid] = (unsigned char)intra_ref_sample<false>(&L.WY[136 + 4], 136, mask, lx * 8, ly * 8, n, 8, tid);
                 if (tid < 2 * lenC) {
                     const int cc = 1 + tid / lenC, q = tid % lenC;
-                    L.raw[cc][66 - n + q] = (unsigned char)intra_ref_sample<true>(R[cc], g.sc, mask, x0 >> 1, y0 >> 1, n >> 1, 4, q);
+                    L.raw[cc][66 - n + q] = (unsigned char)intra_ref_sample<false>(&L.WC[cc - 1][72 + 4], 72, mask, lx * 4, ly * 4, n >> 1, 4, q);
                 }
             }
-            __syncthreads();
+            lds_barrier();
             const bool filt = intra_filter_flag(mode, n);
-            if (filt && tid <= 4 * n) {
-                const bool bil = n == 32 && intra_strong_flat(&L.raw[0][66]);
-                L.fil[66 - 2 * n + tid] = (unsigned char)intra_filtered(&L.raw[0][66], n, tid - 2 * n, bil);
+            if (filt) {
+                if (tid <= 4 * n) {
+                    const bool bil = n == 32 && intra_strong_flat(&L.raw[0][66]);
+                    L.fil[66 - 2 * n + tid] = (unsigned char)intra_filtered(&L.raw[0][66], n, tid - 2 * n, bil);
+                }
+                lds_barrier();
+            } else if (mode == 1) {                                  // DC (never smoothed): wave w sums the 2N neighbours of component w
+                const int w = tid >> 6;
+                if (w < 3) {
+                    const int nn = w ? n >> 1 : n;
+                    const unsigned char *ref = &L.raw[w][66];
+                    int v = lane < nn ? ref[1 + lane] : (lane < 2 * nn ? ref[-1 - (lane - nn)] : 0);
+                    v = (int)group_sum<64>((unsigned)v);
+                    if (lane == 0) L.dcv[w] = (v + nn) >> ((w ? log2 - 1 : log2) + 1);
+                }
+                lds_barrier();
             }
-            __syncthreads();
             // ---- the TU phases: n <= 16: Y, Cb, Cr together; n == 32: Y, then Cb + Cr
             for (int phase = 0; phase < (n == 32 ? 2 : 1); ++phase) {
                 TuRole r;
@@ -152,12 +194,9 @@ __global__ __launch_bounds__(256) void intra_recon_kernel(KsGeom g, int qp, cons
                 // prediction + residual
                 if (r.on) {
                     const unsigned char *ref = cp == 0 ? (filt ? &L.fil[66] : &L.raw[0][66]) : &L.raw[cp][66];
-                    int dc = nn;
-                    if (mode == 1) {
-                        for (int i = 0; i < nn; ++i) dc += ref[1 + i] + ref[-1 - i];
-                        dc >>= l2 + 1;
-                    }
-                    const unsigned sv = *(const unsigned *)(S[cp] + (long)(py + r.qy) * stride + px + r.qx);
+                    const int dc = mode == 1 ? L.dcv[cp] : 0;
+                    const unsigned sv = cp == 0 ? *(const unsigned *)&L.SY[(ly * 8 + r.qy) * 64 + lx * 8 + r.qx]
+                                                : *(const unsigned *)&L.SC[cp - 1][(ly * 4 + r.qy) * 32 + lx * 4 + r.qx];
                     int pr[4];
                     unsigned short res[4];
 #pragma unroll
@@ -168,7 +207,7 @@ __global__ __launch_bounds__(256) void intra_recon_kernel(KsGeom g, int qp, cons
                     *(unsigned *)(P + r.qy * 32 + r.qx) = (unsigned)pr[0] | ((unsigned)pr[1] << 8) | ((unsigned)pr[2] << 16) | ((unsigned)pr[3] << 24);
                     *(uint2 *)(X + r.qy * RP + r.qx) = make_uint2(res[0] | ((unsigned)res[1] << 16), res[2] | ((unsigned)res[3] << 16));
                 }
-                __syncthreads();
+                lds_barrier();
                 // forward pass 1: T[k][j] = rnd(M[k] . X[j], 2 log2N - 2)
                 if (r.on) {
                     const int s1 = 2 * l2 - 2;
@@ -179,13 +218,13 @@ __global__ __launch_bounds__(256) void intra_recon_kernel(KsGeom g, int qp, cons
                     for (int i = 0; i < 4; ++i) o[i] = (unsigned short)(short)((acc[i] + (1 << (s1 - 1))) >> s1);
                     *(uint2 *)(T + r.qy * RP + r.qx) = make_uint2(o[0] | ((unsigned)o[1] << 16), o[2] | ((unsigned)o[3] << 16));
                 }
-                __syncthreads();
+                lds_barrier();
                 // forward pass 2 + quant + dequant (stored transposed for the inverse passes)
                 if (r.on) {
                     int acc[4];
                     quad_dot(mf + r.qy * mp, T + r.qx * RP, RP, nn, acc);
-                    const int q = cp ? qpc : qp, qp6 = q / 6, scale = kQuantScales[q % 6], dqs = kInvQuantScales[q % 6] << qp6;
-                    const int qbits = 21 + qp6 - l2, off = 171 << (qbits - 9), shift = l2 - 1;
+                    const int ci = cp ? 1 : 0, scale = qsc[ci], dqs = qdq[ci];
+                    const int qbits = 21 + qp6[ci] - l2, off = 171 << (qbits - 9), shift = l2 - 1;
                     unsigned short lv[4];
                     int nzc = 0;
 #pragma unroll
@@ -197,10 +236,10 @@ __global__ __launch_bounds__(256) void intra_recon_kernel(KsGeom g, int qp, cons
                         lv[i] = (unsigned short)(short)l;
                         X[(r.qx + i) * RP + r.qy] = (short)dequant_one(l, dqs, 1 << (shift - 1), shift);
                     }
-                    *(uint2 *)(LV[cp] + (long)(py + r.qy) * lstride + px + r.qx) = make_uint2(lv[0] | ((unsigned)lv[1] << 16), lv[2] | ((unsigned)lv[3] << 16));
+                    *(uint2 *)((cp == 0 ? lvl_y : (cp == 1 ? lvl_u : lvl_v)) + (long)(py + r.qy) * lstride + px + r.qx) = make_uint2(lv[0] | ((unsigned)lv[1] << 16), lv[2] | ((unsigned)lv[3] << 16));
                     if (nzc) atomicAdd(&L.nz[cp], nzc);
                 }
-                __syncthreads();
+                lds_barrier();
                 const bool live = r.on && L.nz[cp] != 0;
                 // inverse pass 1: T[y][x] = clip16((Mt[y] . Ct[x] + 64) >> 7)
                 if (r.on) {
@@ -211,7 +250,7 @@ __global__ __launch_bounds__(256) void intra_recon_kernel(KsGeom g, int qp, cons
                     for (int i = 0; i < 4; ++i) o[i] = (unsigned short)(short)clip16((acc[i] + 64) >> 7);
                     *(uint2 *)(T + r.qy * RP + r.qx) = make_uint2(o[0] | ((unsigned)o[1] << 16), o[2] | ((unsigned)o[3] << 16));
                 }
-                __syncthreads();
+                lds_barrier();
                 // inverse pass 2 + prediction -> reconstructed samples
                 if (r.on) {
                     int acc[4] = {0, 0, 0, 0};
@@ -220,17 +259,20 @@ __global__ __launch_bounds__(256) void intra_recon_kernel(KsGeom g, int qp, cons
                     unsigned o = 0;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) o |= (unsigned)clip8((int)((pv >> (8 * i)) & 255) + (live ? (acc[i] + 2048) >> 12 : 0)) << (8 * i);
-                    *(unsigned *)(R[cp] + (long)(py + r.qy) * stride + px + r.qx) = o;
+                    *(unsigned *)((cp == 0 ? R0 : (cp == 1 ? R1 : R2)) + (long)(py + r.qy) * stride + px + r.qx) = o;
+                    if (cp == 0) *(unsigned *)&L.WY[(1 + ly * 8 + r.qy) * 136 + 4 + lx * 8 + r.qx] = o;
+                    else *(unsigned *)&L.WC[cp - 1][(1 + ly * 4 + r.qy) * 72 + 4 + lx * 4 + r.qx] = o;
                 }
-                __syncthreads();
+                lds_barrier();
             }
             if (tid < n8 * n8) {
                 const int cbf = (L.nz[0] ? 1 : 0) | (L.nz[1] ? 2 : 0) | (L.nz[2] ? 4 : 0);
                 cu8[(long)(cy * 8 + ly + tid / n8) * g.w8 + cx * 8 + lx + tid % n8].cbf = (uint8_t)cbf;
             }
-            __threadfence();                                         // the CU's samples are in L2 before anyone gathers them
-            __syncthreads();
+            lds_barrier();
         }
+        __threadfence();                                             // this CTU's samples are in L2 before the row below is released
+        __syncthreads();
         if (tid == 0) __hip_atomic_store(progress + cy, cx + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
@@ -364,7 +406,7 @@ __global__ __launch_bounds__(256) void intra_decide_kernel(KsGeom g, int lam, co
         L.mode[1 + b] = (unsigned char)(m & 63u);
     }
     __syncthreads();
-    // ---- (3) CU quadtree bottom-up (kso_intra_decide: a node keeps its own cost if it is <= the children's sum + split overhead)
+    // ---- (3) CU quadtree bottom-up (a node keeps its own cost if it is <= the children's sum + split overhead)
     if (tid == 0) {
         // 85 nodes, leaves first; node value v[idx]
         unsigned v[85];

@@ -14,7 +14,7 @@ __device__ __forceinline__ int edge_bs(const ks265_cu8 p, const ks265_cu8 q, int
     const int cu8n = 1 << (q.log2_cu - 3), tu8n = min(cu8n, 4);
     const bool tu_edge = (pos8 % tu8n) == 0, cu_edge = (pos8 % cu8n) == 0;
     if (!tu_edge && !cu_edge) return 0;
-    if (p.pred_mode == 1 || q.pred_mode == 1) return 2;
+    if (p.pred_mode != 0 || q.pred_mode != 0) return 2;
     if (tu_edge && ((p.cbf | q.cbf) & 1)) return 1;
     if (cu_edge) {
         // CalcBsInterP enc@0x402960 / CalcBsInterB enc@0x4029d0 with one picture per list

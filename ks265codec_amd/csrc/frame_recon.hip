@@ -195,7 +195,7 @@ __device__ __forceinline__ void code_region(const KsGeom &g, int comp, int qp, i
         int acc[4];
         quad_dot(mf + k * mp, T + (oy + j) * RP + ox, RP, n, acc);
         const int qp6 = qp / 6, scale = kQuantScales[qp % 6], dqs = kInvQuantScales[qp % 6] << qp6;
-        const int qbits = 21 + qp6 - log2n, off = (c.pred_mode == 1 ? 171 : 85) << (qbits - 9), shift = log2n - 1;
+        const int qbits = 21 + qp6 - log2n, off = (c.pred_mode != 0 ? 171 : 85) << (qbits - 9), shift = log2n - 1;
         unsigned short lv[4];
         int nz = 0;
 #pragma unroll

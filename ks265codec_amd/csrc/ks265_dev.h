@@ -96,6 +96,18 @@ __device__ __forceinline__ int quant_one(int c, int scale, int off, int qbits, i
 // H265DeQuantBlock_c enc@0x439210, one level
 __device__ __forceinline__ int dequant_one(int l, int scale, int add, int shift) { return clip16((l * scale + add) >> shift); }
 
+// Work-group barrier that orders LDS traffic only: waits for this wave's LDS operations (lgkmcnt(0)) and joins the barrier, but
+// leaves global stores in flight.  __syncthreads() also drains vmcnt, i.e. every barrier behind a store to HBM stalls for the
+// full store latency (measured: ~3 us per CU in the intra wavefront).  Only for code whose later phases never read back, through
+// global memory, what an earlier phase of the same work-group stored.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xC07F);          // vmcnt = 63 (no wait), expcnt = 7 (no wait), lgkmcnt = 0
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 // ------------------------------------------------------------------ deblocking (normative, EdgeFilterLuma*_c enc@0x403630/0x4038c0)
 __device__ __constant__ const unsigned char kTcTable[54] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1,
                                                             2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 5, 5, 6, 6, 7, 8, 9, 10, 11, 13, 14, 16, 18, 20, 22, 24};

@@ -129,3 +129,27 @@ def test_ragged_picture_sizes_code_every_block():
         assert (cu["log2_cu"] >= 3).all() and (cu["log2_cu"] <= 6).all()
         pu = o.prev_pu.reshape(-1, 85)
         assert (pu["cost"][:, 0] == 0xFFFFFFFF).any() or (w % 64 == 0 and h % 64 == 0)
+
+
+def test_intra_picture_properties():
+    """SURVEY.md §8(f) rank 1 on the CPU side: the intra picture of the oracle is a legal HEVC intra decision (modes 0..34, CU 8..32, no
+    64x64), beats the flat stand-in on rate at the same quantiser, and a smooth ramp is coded almost for free by planar / angular modes"""
+    W, H = 200, 136
+    clip = make_clip(W, H, 1, seed=5)
+    res = {}
+    for intra in (False, True):
+        o = OraclePipeline(W, H, 27, lambda_q4(27), intra=intra)
+        rec = o.encode_picture(clip[0], True)
+        res[intra] = (psnr(clip[0][:W * H], rec[:W * H]), sum(int(np.abs(l.astype(np.int64)).sum()) for l in o.lvl), o.cu8.copy())
+    cu = res[True][2]
+    assert (cu["pred_mode"] == 2).all() and cu["mvx"].min() >= 0 and cu["mvx"].max() <= 34
+    assert set(np.unique(cu["log2_cu"])) <= {3, 4, 5}
+    assert res[True][1] < 0.7 * res[False][1] and res[True][0] > res[False][0] - 0.5          # much less residual energy at about the same PSNR
+    # a pure diagonal ramp: every block is predicted (almost) exactly from its neighbours -> hardly any coefficient survives
+    yy, xx = np.mgrid[0:H, 0:W]
+    ramp = np.clip(40 + xx + yy // 2, 0, 255).astype(np.uint8)
+    pic = np.concatenate([ramp.reshape(-1), np.full(W * H // 2, 128, np.uint8)])
+    o = OraclePipeline(W, H, 27, lambda_q4(27), intra=True)
+    rec = o.encode_picture(pic, True)
+    nzl = int((o.lvl[0] != 0).sum())
+    assert psnr(pic[:W * H], rec[:W * H]) > 40.0 and nzl < W * H // 40, nzl
