@@ -12,6 +12,9 @@
 
 using namespace ks265;
 
+#ifndef KS_RING_BATCH
+#define KS_RING_BATCH 8      // hexagon-grid points per batch at levels 2 / 3 (independent reduction chains; the search is latency bound)
+#endif
 #define WIN_XL 80                 // window column 0 is picture x = ctu_x*64 - 80
 #define WIN_YT 65                 // window row 0 is picture y = ctu_y*64 - 65
 #define WIN_W 224                 // loaded bytes per row (x in [-80, 144))
@@ -331,17 +334,21 @@ __device__ __forceinline__ void me_level(const KsGeom &g, int cx, int cy, int ra
                     ox = mx; oy = my;
                     // Big_Hexagon: (-4,0)(4,0)(0,-4)(0,4)(-4,-1)(4,1)(-4,1)(4,-1)(-4,-2)(4,2)(-4,2)(4,-2)(-2,-3)(2,3)(-2,3)(2,-3), stored +4
 #pragma unroll 1
-                    for (int i = 1; i <= (range >> 2) && __any(mainp && i <= (ext >> 2)); ++i)
-#pragma unroll 1
-                        for (int j0 = coop ? 4 * wv : 0; j0 < (coop ? 4 * wv + 4 : 16); j0 += 4) {
-                            int xs[4], ys[4]; unsigned keys[4];
+                    for (int i = 1; i <= (range >> 2) && __any(mainp && i <= (ext >> 2)); ++i) {
+                        auto ring = [&](auto n_tag, int j0) {                 // N consecutive points of ring i in one batch
+                            constexpr int N = decltype(n_tag)::value;
+                            int xs[N], ys[N]; unsigned keys[N];
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) {
+                            for (int j = 0; j < N; ++j) {
                                 xs[j] = ox + nib(0x6262808080804480ull, j0 + j, 4) * i; ys[j] = oy + nib(0x1771266235538044ull, j0 + j, 4) * i;
                                 keys[j] = (4u << 24) | ((unsigned)i << 4) | (unsigned)(j0 + j);
                             }
-                            try_k(std::integral_constant<int, 4>{}, xs, ys, keys, mainp && i <= (ext >> 2));
-                        }
+                            try_k(n_tag, xs, ys, keys, mainp && i <= (ext >> 2));
+                        };
+                        if (coop) ring(std::integral_constant<int, 4>{}, 4 * wv);        // level 0: a quarter of the ring per wave
+                        else if (LEVEL == 1) { ring(std::integral_constant<int, 4>{}, 0); ring(std::integral_constant<int, 4>{}, 4); ring(std::integral_constant<int, 4>{}, 8); ring(std::integral_constant<int, 4>{}, 12); }
+                        else { ring(std::integral_constant<int, KS_RING_BATCH>{}, 0); if (KS_RING_BATCH == 8) ring(std::integral_constant<int, KS_RING_BATCH>{}, 8); }
+                    }
                     merge();
                     hex_refine(mainp);
                 }
