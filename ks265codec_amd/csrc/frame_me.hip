@@ -410,6 +410,10 @@ __device__ __forceinline__ void me_level(const KsGeom &g, int cx, int cy, int ra
     }
 }
 
+#ifdef KS_EXP_LEVEL_CLOCK
+__device__ unsigned long long ks_dbg_cycles[4];
+extern "C" void ks265_dbg_cycles(unsigned long long *out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(ks_dbg_cycles), 32); }
+#endif
 template <int METHOD>   // one instantiation per search pattern: DIA keeps its small register footprint (3 workgroups / CU)
 __global__ __launch_bounds__(256, 3) void me_int_kernel(KsGeom g, int range, int lam, const uint8_t *src, const uint8_t *ref, const ks265_pu *prev,
                                                      ks265_pu *out)
@@ -440,13 +444,23 @@ __global__ __launch_bounds__(256, 3) void me_int_kernel(KsGeom g, int range, int
     __syncthreads();
     const ks265_pu *prev_ctu = prev ? prev + (long)ctu * 85 : nullptr;
     ks265_pu *out_ctu = out + (long)ctu * 85;
+#ifdef KS_EXP_LEVEL_CLOCK
+    long long t0 = __builtin_readcyclecounter();
+#define KS_TICK(i) do { long long t1 = __builtin_readcyclecounter(); if (tid == 0) atomicAdd((unsigned long long *)&ks_dbg_cycles[i], (unsigned long long)(t1 - t0)); t0 = t1; } while (0)
+#else
+#define KS_TICK(i)
+#endif
     me_level<0>(g, cx, cy, range, lam, method, win, fenc, pmv, comb, selut, prev_ctu, out_ctu, tid);
+    KS_TICK(0);
     __syncthreads();
     me_level<1>(g, cx, cy, range, lam, method, win, fenc, pmv, comb, selut, prev_ctu, out_ctu, tid);
+    KS_TICK(1);
     __syncthreads();
     me_level<2>(g, cx, cy, range, lam, method, win, fenc, pmv, comb, selut, prev_ctu, out_ctu, tid);
+    KS_TICK(2);
     __syncthreads();
     me_level<3>(g, cx, cy, range, lam, method, win, fenc, pmv, comb, selut, prev_ctu, out_ctu, tid);
+    KS_TICK(3);
 }
 
 extern "C" int ks265_me_integer(ks265_frame *f, ks265_pic src, ks265_pic ref, const ks265_pu *prev_pu, ks265_pu *pu)
