@@ -134,6 +134,20 @@ int ks265_intra_pred_batch(ks265_ctx *, const uint8_t *dev_ref, uint8_t *dev_dst
 typedef struct { int32_t src_off, dst_off, size, strong_enabled; } ks265_intra_ref;
 int ks265_intra_filter_ref_batch(ks265_ctx *, const uint8_t *dev_src, uint8_t *dev_dst, const ks265_intra_ref *dev_refs, int n);
 
+/* Lookahead / pre-analysis leaf kernels (the frame-level cost logic calcFrameCost enc@0x4a7410 / scenecut
+ * enc@0x47e9d0 stays host code - a lowres search is stage A of section 3 run on a half-size frame object).
+ * g_downsampleFunc enc@0x707b10 -> downsample_c enc@0x4a6a60 (dst, src, dstStride, srcStride, w, h): 2:1 both ways, w x h = OUTPUT size */
+int ks265_downsample_rect(ks265_ctx *, const uint8_t *dev_src, int srcStride, uint8_t *dev_dst, int dstStride, int w, int h);
+/* weightBi_sad_c enc@0x4a7170 (org, orgStride, ref0, ref1, stride0, stride1, w, h): SAD against the rounded average of two references;
+ * descriptor: a_off = org offset, b_off[0] / b_off[1] = offsets in ref0 / ref1 (b_off[2] unused) */
+int ks265_weight_bi_sad_batch(ks265_ctx *, const uint8_t *dev_org, int orgStride, const uint8_t *dev_ref0, int stride0, const uint8_t *dev_ref1, int stride1,
+                              const ks265_blk3 *dev_blks, int n, uint32_t *dev_out);
+/* g_acEnergyPlaneFunc enc@0x707b20 -> acEnergyPlane_c enc@0x4650e0 (src, stride, log2Size): ssd - (sum^2 >> 2 log2N) in 32-bit unsigned
+ * arithmetic (the wrap of sum^2 for bright 32x32 blocks is part of the contract); _batch: explicit block offsets, _map: every aligned
+ * N x N block of a w x h plane in raster order (the per-block variance map of calcFrameAdaptQuant enc@0x4653c0) */
+int ks265_ac_energy_batch(ks265_ctx *, const uint8_t *dev_src, int stride, int log2, const int32_t *dev_offs, int n, uint32_t *dev_out);
+int ks265_ac_energy_map(ks265_ctx *, const uint8_t *dev_plane, int stride, int w, int h, int log2, uint32_t *dev_out);
+
 /* ------------------------------------------------------------------ 3. whole-frame stages (a13 sequencing) */
 
 typedef struct ks265_frame ks265_frame;

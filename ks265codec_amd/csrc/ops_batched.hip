@@ -343,6 +343,61 @@ __global__ __launch_bounds__(256) void intra_filter_ref_batch_kernel(const uint8
     for (int i = lane; i < 4 * d.size + 1; i += 64) dst[d.dst_off + i - 2 * d.size] = (uint8_t)intra_filtered(r, d.size, i - 2 * d.size, bil);
 }
 
+// ------------------------------------------------------------------ lookahead leaf kernels
+// downsample_c enc@0x4a6a60: one thread = 4 adjacent output samples (8 source bytes of two rows)
+__global__ __launch_bounds__(256) void downsample_kernel(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int h)
+{
+    const int x = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4, y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    const uint8_t *p = src + (long)(2 * y) * ss + 2 * x;
+    if (x + 4 <= w) {
+        uint2 a, b;
+        __builtin_memcpy(&a, p, 8);
+        __builtin_memcpy(&b, p + ss, 8);
+        const unsigned long long ra = a.x | ((unsigned long long)a.y << 32), rb = b.x | ((unsigned long long)b.y << 32);
+        for (int i = 0; i < 4; ++i) {
+            const int u = (int)((((ra >> (16 * i)) & 255) + ((rb >> (16 * i)) & 255) + 1) >> 1), v = (int)((((ra >> (16 * i + 8)) & 255) + ((rb >> (16 * i + 8)) & 255) + 1) >> 1);
+            dst[(long)y * ds + x + i] = (uint8_t)((u + v + 1) >> 1);
+        }
+    } else {
+        for (int i = 0; x + i < w; ++i) {
+            const int u = (p[2 * i] + p[2 * i + ss] + 1) >> 1, v = (p[2 * i + 1] + p[2 * i + 1 + ss] + 1) >> 1;
+            dst[(long)y * ds + x + i] = (uint8_t)((u + v + 1) >> 1);
+        }
+    }
+}
+// weightBi_sad_c enc@0x4a7170: one wave per block
+__global__ __launch_bounds__(256) void weight_bi_sad_batch_kernel(const uint8_t *org, int so, const uint8_t *r0, int s0, const uint8_t *r1, int s1,
+                                                                  const ks265_blk3 *blks, int n, uint32_t *out)
+{
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (b >= n) return;
+    const ks265_blk3 d = blks[b];
+    unsigned acc = 0;
+    for (int i = lane; i < d.w * d.h; i += 64) {
+        const int x = i % d.w, y = i / d.w;
+        const int p = (r0[d.b_off[0] + y * s0 + x] + r1[d.b_off[1] + y * s1 + x] + 1) >> 1;
+        acc += (unsigned)abs(p - (int)org[d.a_off + y * so + x]);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) out[b] = acc;
+}
+// acEnergyPlane_c enc@0x4650e0: one wave per N x N block; offs == nullptr: the aligned blocks of a w x h plane in raster order
+__global__ __launch_bounds__(256) void ac_energy_batch_kernel(const uint8_t *src, int stride, int log2, const int32_t *offs, int n, int bw, uint32_t *out)
+{
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (b >= n) return;
+    const int N = 1 << log2;
+    const long off = offs ? (long)offs[b] : ((long)(b / bw) * N) * stride + (long)(b % bw) * N;
+    unsigned sum = 0, ssd = 0;
+    for (int i = lane; i < N * N; i += 64) {
+        const unsigned p = src[off + (long)(i >> log2) * stride + (i & (N - 1))];
+        sum += p; ssd += p * p;
+    }
+    sum = wave_sum(sum); ssd = wave_sum(ssd);
+    if (lane == 0) out[b] = ssd - ((sum * sum) >> (2 * log2));     // 32-bit wrap of sum^2 included, as in the reference
+}
+
 extern "C" {
 
 int ks265_sad_batch(ks265_ctx *ctx, const uint8_t *a, int sa, const uint8_t *b, int sb, const ks265_blk *blks, int n, uint32_t *out)
@@ -493,6 +548,34 @@ int ks265_intra_filter_ref_batch(ks265_ctx *ctx, const uint8_t *src, uint8_t *ds
 {
     CHECK_CTX(ctx); if (!src || !dst || !refs) return KS265_POINTER; if (n <= 0) return KS265_OK;
     hipLaunchKernelGGL(intra_filter_ref_batch_kernel, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, src, dst, refs, n);
+    LAUNCH_END(ctx);
+}
+
+int ks265_downsample_rect(ks265_ctx *ctx, const uint8_t *src, int srcStride, uint8_t *dst, int dstStride, int w, int h)
+{
+    CHECK_CTX(ctx); if (!src || !dst) return KS265_POINTER; if (w <= 0 || h <= 0) return KS265_OK;
+    hipLaunchKernelGGL(downsample_kernel, dim3((w + 255) / 256, (h + 3) / 4), dim3(256), 0, ctx->stream, src, srcStride, dst, dstStride, w, h);
+    LAUNCH_END(ctx);
+}
+int ks265_weight_bi_sad_batch(ks265_ctx *ctx, const uint8_t *org, int so, const uint8_t *ref0, int s0, const uint8_t *ref1, int s1, const ks265_blk3 *blks, int n,
+                              uint32_t *out)
+{
+    CHECK_CTX(ctx); if (!org || !ref0 || !ref1 || !blks || !out) return KS265_POINTER; if (n <= 0) return KS265_OK;
+    hipLaunchKernelGGL(weight_bi_sad_batch_kernel, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, org, so, ref0, s0, ref1, s1, blks, n, out);
+    LAUNCH_END(ctx);
+}
+int ks265_ac_energy_batch(ks265_ctx *ctx, const uint8_t *src, int stride, int log2, const int32_t *offs, int n, uint32_t *out)
+{
+    CHECK_CTX(ctx); if (!src || !offs || !out) return KS265_POINTER; if (log2 < 2 || log2 > 5) return KS265_NOTSUPPORTED; if (n <= 0) return KS265_OK;
+    hipLaunchKernelGGL(ac_energy_batch_kernel, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, src, stride, log2, offs, n, 1, out);
+    LAUNCH_END(ctx);
+}
+int ks265_ac_energy_map(ks265_ctx *ctx, const uint8_t *plane, int stride, int w, int h, int log2, uint32_t *out)
+{
+    CHECK_CTX(ctx); if (!plane || !out) return KS265_POINTER; if (log2 < 2 || log2 > 5) return KS265_NOTSUPPORTED;
+    const int bw = w >> log2, bh = h >> log2, n = bw * bh;
+    if (n <= 0) return KS265_OK;
+    hipLaunchKernelGGL(ac_energy_batch_kernel, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, plane, stride, log2, (const int32_t *)nullptr, n, bw, out);
     LAUNCH_END(ctx);
 }
 

@@ -53,6 +53,7 @@ EXPORTS = [
     "ks265_residual_batch", "ks265_fwd_transform_batch", "ks265_quant_batch", "ks265_dequant_batch", "ks265_inv_transform_batch",
     "ks265_edge_filter_luma_batch", "ks265_edge_filter_chroma_batch", "ks265_interp_rect",
     "ks265_sao_apply_bo_rect", "ks265_sao_apply_eo_rect", "ks265_sao_stats_batch", "ks265_intra_pred_batch", "ks265_intra_filter_ref_batch",
+    "ks265_downsample_rect", "ks265_weight_bi_sad_batch", "ks265_ac_energy_batch", "ks265_ac_energy_map",
     "ks265_frame_geometry", "ks265_frame_create", "ks265_frame_destroy", "ks265_frame_set_qp", "ks265_pad_picture",
     "ks265_load_i420", "ks265_store_i420", "ks265_ref_planes", "ks265_me_integer", "ks265_me_subpel", "ks265_cu_decide",
     "ks265_cu_flat_intra", "ks265_intra_decide", "ks265_intra_reconstruct", "ks265_reconstruct", "ks265_reconstruct_b", "ks265_bi_decide", "ks265_cu_decide_b", "ks265_deblock", "ks265_sao",
@@ -199,6 +200,27 @@ class KsContext:
         self._chk(self.lib.ks265_sao_stats_batch(self.h, _p(org), C.c_int(os_), _p(rec), C.c_int(rs), _p(self.dev(rects)), C.c_int(len(rects)),
                                                  C.c_int(row_step), _p(out)))
         return self.host(out, np.int32, (len(rects), 96))
+
+    def downsample(self, src, ss: int, w: int, h: int, ds: int):
+        dst = self.zeros(ds * h)
+        self._chk(self.lib.ks265_downsample_rect(self.h, _p(src), C.c_int(ss), _p(dst), C.c_int(ds), C.c_int(w), C.c_int(h)))
+        return self.host(dst, np.uint8, (h, ds))
+
+    def weight_bi_sad(self, org, so: int, r0, s0: int, r1, s1: int, blks: np.ndarray) -> np.ndarray:
+        out = self.zeros(4 * len(blks))
+        self._chk(self.lib.ks265_weight_bi_sad_batch(self.h, _p(org), C.c_int(so), _p(r0), C.c_int(s0), _p(r1), C.c_int(s1), _p(self.dev(blks)), C.c_int(len(blks)), _p(out)))
+        return self.host(out, np.uint32)
+
+    def ac_energy(self, src, stride: int, log2: int, offs: np.ndarray) -> np.ndarray:
+        out = self.zeros(4 * len(offs))
+        self._chk(self.lib.ks265_ac_energy_batch(self.h, _p(src), C.c_int(stride), C.c_int(log2), _p(self.dev(np.asarray(offs, np.int32))), C.c_int(len(offs)), _p(out)))
+        return self.host(out, np.uint32)
+
+    def ac_energy_map(self, plane, stride: int, w: int, h: int, log2: int) -> np.ndarray:
+        n = (w >> log2) * (h >> log2)
+        out = self.zeros(4 * n)
+        self._chk(self.lib.ks265_ac_energy_map(self.h, _p(plane), C.c_int(stride), C.c_int(w), C.c_int(h), C.c_int(log2), _p(out)))
+        return self.host(out, np.uint32, (h >> log2, w >> log2))
 
     def intra_pred(self, ref, dst, blks: np.ndarray):
         """g_IntraPredFunction: predict every described block from dev `ref` into dev `dst` (in place)"""

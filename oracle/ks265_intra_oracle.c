@@ -97,3 +97,36 @@ void ks265o_intra_filter_ref(const uint8_t *src, uint8_t *dst, int size, int str
     dst[-n2] = src[-n2]; dst[n2] = src[n2];
     for (int i = -n2 + 1; i < n2; ++i) dst[i] = (uint8_t)((src[i - 1] + 2 * src[i] + src[i + 1] + 2) >> 2);
 }
+
+/* ------------------------------------------------------------------ lookahead leaf kernels, pinned by tests/golden/lookahead.npz
+ * downsample_c enc@0x4a6a60 (dst, src, dstStride, srcStride, w, h): 2:1 in both directions, w x h OUTPUT samples:
+ *   out = (((s[2x] + s[2x + S] + 1) >> 1) + ((s[2x+1] + s[2x+1 + S] + 1) >> 1) + 1) >> 1   (vertical pairs first, then their mean) */
+void ks265o_downsample(uint8_t *dst, const uint8_t *src, int dstStride, int srcStride, int w, int h)
+{
+    for (int y = 0; y < h; ++y, dst += dstStride, src += 2 * srcStride)
+        for (int x = 0; x < w; ++x) {
+            int a = (src[2 * x] + src[2 * x + srcStride] + 1) >> 1, b = (src[2 * x + 1] + src[2 * x + 1 + srcStride] + 1) >> 1;
+            dst[x] = (uint8_t)((a + b + 1) >> 1);
+        }
+}
+/* weightBi_sad_c enc@0x4a7170 (org, orgStride, ref0, ref1, stride0, stride1, w, h): SAD of org against the rounded average of two references */
+uint32_t ks265o_weight_bi_sad(const uint8_t *org, unsigned orgStride, const uint8_t *ref0, const uint8_t *ref1, unsigned stride0, unsigned stride1, int w, int h)
+{
+    uint32_t s = 0;
+    for (int y = 0; y < h; ++y, org += orgStride, ref0 += stride0, ref1 += stride1)
+        for (int x = 0; x < w; ++x) {
+            int p = (ref0[x] + ref1[x] + 1) >> 1, d = p - org[x];
+            s += (uint32_t)(d < 0 ? -d : d);
+        }
+    return s;
+}
+/* acEnergyPlane_c enc@0x4650e0 (src, stride, log2Size): AC energy of an N x N block, ssd - (sum^2 >> 2 log2N), all in 32-bit
+ * unsigned arithmetic as the reference computes it (sum^2 wraps for a bright 32x32 block; the wrap is part of the contract) */
+uint32_t ks265o_ac_energy_plane(const uint8_t *src, int stride, int log2)
+{
+    const int n = 1 << log2;
+    uint32_t sum = 0, ssd = 0;
+    for (int y = 0; y < n; ++y)
+        for (int x = 0; x < n; ++x) { uint32_t p = src[y * stride + x]; sum += p; ssd += p * p; }
+    return ssd - ((sum * sum) >> (2 * log2));
+}

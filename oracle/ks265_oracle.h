@@ -96,6 +96,11 @@ uint32_t ks265o_calc_bi_me_org(uint8_t *dst, const uint8_t *pred, const uint8_t 
 void ks265o_intra_pred(uint8_t *dst, int stride, const uint8_t *ref, int mode, int log2, int edge_filter);
 void ks265o_intra_filter_ref(const uint8_t *src, uint8_t *dst, int size, int strong_enabled);
 
+/* ---- lookahead leaf kernels: downsample_c enc@0x4a6a60, weightBi_sad_c enc@0x4a7170, acEnergyPlane_c enc@0x4650e0 */
+void ks265o_downsample(uint8_t *dst, const uint8_t *src, int dstStride, int srcStride, int w, int h);
+uint32_t ks265o_weight_bi_sad(const uint8_t *org, unsigned orgStride, const uint8_t *ref0, const uint8_t *ref1, unsigned stride0, unsigned stride1, int w, int h);
+uint32_t ks265o_ac_energy_plane(const uint8_t *src, int stride, int log2);
+
 #ifdef __cplusplus
 }
 #endif

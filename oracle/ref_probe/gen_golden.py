@@ -482,11 +482,36 @@ def gen_intra(p: RefProbe):
     return [dict(c, exp=d.out) for c, d in pend]
 
 
+def gen_lookahead(p: RefProbe):
+    """downsample_c enc@0x4a6a60, weightBi_sad_c enc@0x4a7170, acEnergyPlane_c enc@0x4650e0"""
+    pend = []
+    for (w, h) in ((8, 8), (16, 4), (33, 7), (64, 36), (120, 68)):
+        ss, ds = 2 * w + int(rng.integers(0, 9)), w + int(rng.integers(0, 9))
+        src = u8((2 * h, ss))
+        D = Buf(np.zeros((h, ds), np.uint8))
+        pend.append((dict(kind="down", src=src, ss=ss, ds=ds, w=w, h=h), p.call(0x4A6A60, D, Buf(src), ds, ss, w, h), D))
+    for (w, h) in ((8, 8), (16, 16), (32, 32), (8, 4), (24, 12), (64, 64)):
+        for k in range(2):
+            so, s0, s1 = w + int(rng.integers(0, 9)), w + int(rng.integers(0, 9)), w + int(rng.integers(0, 9))
+            org, r0, r1 = u8((h, so)), u8((h, s0)), u8((h, s1))
+            if k:
+                r0[:] = 255; r1[:] = 255; org[:] = 0
+            pend.append((dict(kind="wbsad", org=org, r0=r0, r1=r1, so=so, s0=s0, s1=s1, w=w, h=h), p.call(0x4A7170, Buf(org), so, Buf(r0), Buf(r1), s0, s1, w, h), None))
+    for log2 in (2, 3, 4, 5):
+        for k in range(3):
+            n = 1 << log2
+            st = n + int(rng.integers(0, 9))
+            src = u8((n, st)) if k == 0 else (np.full((n, st), 255, np.uint8) if k == 1 else np.clip(200 + rng.integers(-30, 56, (n, st)), 0, 255).astype(np.uint8))
+            pend.append((dict(kind="acenergy", src=src, st=st, log2=log2), p.call(0x4650E0, Buf(src), st, log2), None))
+    p.run()
+    return [dict(c, exp=d.out) if d is not None else dict(c, ret=np.uint32(call.ret & 0xFFFFFFFF)) for c, call, d in pend]
+
+
 FAMILIES = {
     "sad": gen_sad, "sad4": gen_sad4, "sad3": gen_sad3, "sad4blk": gen_sad4blk, "sse": gen_sse, "had": gen_had,
     "fwd_transform": gen_fwd, "inv_transform": gen_inv, "quant": gen_quant, "dequant": gen_dequant,
     "residual": gen_residual, "deblock_luma": gen_deblock_luma, "deblock_chroma": gen_deblock_chroma,
-    "interp": gen_interp, "sao_apply": gen_sao, "sao_stats": gen_sao_stats, "bipred": gen_bipred, "intra": gen_intra,
+    "interp": gen_interp, "sao_apply": gen_sao, "sao_stats": gen_sao_stats, "bipred": gen_bipred, "intra": gen_intra, "lookahead": gen_lookahead,
 }
 
 if __name__ == "__main__":

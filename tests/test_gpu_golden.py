@@ -230,3 +230,28 @@ def test_intra(ks):
     for c in filt:
         assert (got[off:off + len(c["src"])] == c["exp"]).all(), (c["size"], c["flag"])
         off += len(c["src"])
+
+
+def test_lookahead_kernels(ks):
+    """§8(f) rank 2 leaf kernels through the C ABI: downsample_c, weightBi_sad_c, acEnergyPlane_c (+ the whole-plane map)"""
+    from ks265codec_amd.lib import BLK3
+    for c in load_cases("lookahead"):
+        kind = str(c["kind"])
+        if kind == "down":
+            got = ks.downsample(ks.dev(c["src"]), int(c["ss"]), int(c["w"]), int(c["h"]), int(c["ds"]))
+            assert (got[:, :c["w"]] == c["exp"][:, :c["w"]]).all(), (c["w"], c["h"])
+        elif kind == "wbsad":
+            b = np.zeros(1, BLK3); b[0] = (0, (0, 0, 0), c["w"], c["h"])
+            got = ks.weight_bi_sad(ks.dev(c["org"]), int(c["so"]), ks.dev(c["r0"]), int(c["s0"]), ks.dev(c["r1"]), int(c["s1"]), b)
+            assert got[0] == c["ret"], (c["w"], c["h"])
+        else:
+            got = ks.ac_energy(ks.dev(c["src"]), int(c["st"]), int(c["log2"]), np.zeros(1, np.int32))
+            assert got[0] == c["ret"], c["log2"]
+    # the map variant = the batch variant at every aligned block
+    rng = np.random.default_rng(3)
+    plane = rng.integers(0, 256, (72, 136), dtype=np.uint8)
+    for log2 in (3, 4):
+        n = 1 << log2
+        m = ks.ac_energy_map(ks.dev(plane), 136, 128, 64, log2)
+        offs = np.array([y * n * 136 + x * n for y in range(64 // n) for x in range(128 // n)], np.int32)
+        assert (m.reshape(-1) == ks.ac_energy(ks.dev(plane), 136, log2, offs)).all()
