@@ -71,6 +71,7 @@ struct IntraLds {
     unsigned char P[3][32 * 32];
     unsigned char raw[3][132], fil[132];                 // reference arrays, corner at index 66 (luma: 64 + 1 + 64; chroma 32 + 1 + 32)
     int nz[3];
+    int cbf[64];
     ks265_cu8 cu[64];
     // reconstructed samples around the CTU being coded: row 0 = the row above the CTU (x = -1 .. 127: top-left, top, top-right),
     // rows 1..64 = the CTU with column 3 = the last column of the previous CTU of this row; sample (x, y) of the CTU sits at
@@ -81,24 +82,127 @@ struct IntraLds {
     int dcv[3];
 };
 
-// one thread's role in a TU phase: component + quad, or idle
+// one thread's role in a TU pipeline: component + quad, or idle
 struct TuRole { int comp, n, log2n, qx, qy; bool on; };
+
+// everything a TU pipeline needs besides the role (uniform per kernel / per CU)
+struct TuCtx {
+    const KsGeom *g;
+    int16_t *lvl_y, *lvl_u, *lvl_v;
+    uint8_t *R0, *R1, *R2;
+    int qsc[2], qdq[2], qp6[2];
+    int x0, y0, lx, ly, mode;
+    bool filt;
+};
+
+// BLOCK: the quads of a TU are spread over several waves -> work-group barriers (LDS only); otherwise the whole TU lives in one
+// wave: LDS operations of one wave complete in order, so waiting for this wave's own LDS traffic is enough.
+template <bool BLOCK>
+__device__ __forceinline__ void tu_sync()
+{
+    if (BLOCK) lds_barrier();
+    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+// prediction -> residual -> forward transform -> quant -> dequant -> inverse transform -> reconstructed samples of one quad
+// (the reconstruct() chain enc@0x481da0, same arithmetic as code_region of frame_recon.hip with the intra rounding offset 171)
+template <bool BLOCK>
+__device__ __forceinline__ void tu_pipeline(IntraLds &L, const TuRole &r, const TuCtx &c)
+{
+    const int cp = r.comp, nn = r.n, l2 = r.log2n, mp = nn + 4;
+    short *X = L.X[cp], *T = L.T[cp];
+    unsigned char *P = L.P[cp];
+    const short *mf = L.Mf + mat_off(l2), *mt = L.Mt + mat_off(l2);
+    const int px = cp ? c.x0 >> 1 : c.x0, py = cp ? c.y0 >> 1 : c.y0, stride = cp ? c.g->sc : c.g->sy, lstride = cp ? c.g->W / 2 : c.g->W;
+    if (r.on) {
+        const unsigned char *ref = cp == 0 ? (c.filt ? &L.fil[66] : &L.raw[0][66]) : &L.raw[cp][66];
+        const int dc = c.mode == 1 ? L.dcv[cp] : 0;
+        const unsigned sv = cp == 0 ? *(const unsigned *)&L.SY[(c.ly * 8 + r.qy) * 64 + c.lx * 8 + r.qx]
+                                    : *(const unsigned *)&L.SC[cp - 1][(c.ly * 4 + r.qy) * 32 + c.lx * 4 + r.qx];
+        int pr[4];
+        unsigned short res[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            pr[i] = intra_sample(ref, c.mode, l2, r.qx + i, r.qy, dc, cp == 0);
+            res[i] = (unsigned short)(short)((int)((sv >> (8 * i)) & 255) - pr[i]);
+        }
+        *(unsigned *)(P + r.qy * 32 + r.qx) = (unsigned)pr[0] | ((unsigned)pr[1] << 8) | ((unsigned)pr[2] << 16) | ((unsigned)pr[3] << 24);
+        *(uint2 *)(X + r.qy * RP + r.qx) = make_uint2(res[0] | ((unsigned)res[1] << 16), res[2] | ((unsigned)res[3] << 16));
+    }
+    tu_sync<BLOCK>();
+    if (r.on) {                                                     // forward pass 1: T[k][j] = rnd(M[k] . X[j], 2 log2N - 2)
+        const int s1 = 2 * l2 - 2;
+        int acc[4];
+        quad_dot(mf + r.qy * mp, X + r.qx * RP, RP, nn, acc);
+        unsigned short o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = (unsigned short)(short)((acc[i] + (1 << (s1 - 1))) >> s1);
+        *(uint2 *)(T + r.qy * RP + r.qx) = make_uint2(o[0] | ((unsigned)o[1] << 16), o[2] | ((unsigned)o[3] << 16));
+    }
+    tu_sync<BLOCK>();
+    if (r.on) {                                                     // forward pass 2 + quant + dequant (stored transposed)
+        int acc[4];
+        quad_dot(mf + r.qy * mp, T + r.qx * RP, RP, nn, acc);
+        const int ci = cp ? 1 : 0, scale = c.qsc[ci], dqs = c.qdq[ci];
+        const int qbits = 21 + c.qp6[ci] - l2, off = 171 << (qbits - 9), shift = l2 - 1;
+        unsigned short lv[4];
+        int nzc = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int coef = (short)((acc[i] + 64) >> 7);
+            int du;
+            const int l = quant_one(coef, scale, off, qbits, du);
+            nzc += l != 0;
+            lv[i] = (unsigned short)(short)l;
+            X[(r.qx + i) * RP + r.qy] = (short)dequant_one(l, dqs, 1 << (shift - 1), shift);
+        }
+        *(uint2 *)((cp == 0 ? c.lvl_y : (cp == 1 ? c.lvl_u : c.lvl_v)) + (long)(py + r.qy) * lstride + px + r.qx) =
+            make_uint2(lv[0] | ((unsigned)lv[1] << 16), lv[2] | ((unsigned)lv[3] << 16));
+        if (nzc) atomicAdd(&L.nz[cp], nzc);
+    }
+    tu_sync<BLOCK>();
+    const bool live = r.on && L.nz[cp] != 0;
+    if (r.on) {                                                     // inverse pass 1: T[y][x] = clip16((Mt[y] . Ct[x] + 64) >> 7)
+        int acc[4] = {0, 0, 0, 0};
+        if (live) quad_dot(mt + r.qy * mp, X + r.qx * RP, RP, nn, acc);
+        unsigned short o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = (unsigned short)(short)clip16((acc[i] + 64) >> 7);
+        *(uint2 *)(T + r.qy * RP + r.qx) = make_uint2(o[0] | ((unsigned)o[1] << 16), o[2] | ((unsigned)o[3] << 16));
+    }
+    tu_sync<BLOCK>();
+    if (r.on) {                                                     // inverse pass 2 + prediction -> reconstructed samples
+        int acc[4] = {0, 0, 0, 0};
+        if (live) quad_dot(T + r.qy * RP, mt + r.qx * mp, mp, nn, acc);
+        const unsigned pv = *(const unsigned *)(P + r.qy * 32 + r.qx);
+        unsigned o = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o |= (unsigned)clip8((int)((pv >> (8 * i)) & 255) + (live ? (acc[i] + 2048) >> 12 : 0)) << (8 * i);
+        *(unsigned *)((cp == 0 ? c.R0 : (cp == 1 ? c.R1 : c.R2)) + (long)(py + r.qy) * stride + px + r.qx) = o;
+        if (cp == 0) *(unsigned *)&L.WY[(1 + c.ly * 8 + r.qy) * 136 + 4 + c.lx * 8 + r.qx] = o;
+        else *(unsigned *)&L.WC[cp - 1][(1 + c.ly * 4 + r.qy) * 72 + 4 + c.lx * 4 + r.qx] = o;
+    }
+    tu_sync<BLOCK>();
+}
 
 __global__ __launch_bounds__(256) void intra_recon_kernel(KsGeom g, int qp, const uint8_t *src_y, const uint8_t *src_u, const uint8_t *src_v, ks265_cu8 *cu8,
                                                           int16_t *lvl_y, int16_t *lvl_u, int16_t *lvl_v, uint8_t *rec_y, uint8_t *rec_u, uint8_t *rec_v,
                                                           int *progress)
 {
     __shared__ __attribute__((aligned(16))) IntraLds L;
-    const int tid = threadIdx.x, lane = tid & 63, cy = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, cy = blockIdx.x;
     build_matrices(L.Mf, L.Mt, tid, 256);
     const int qpc = chroma_qp(qp);
+    TuCtx c;
+    c.g = &g; c.lvl_y = lvl_y; c.lvl_u = lvl_u; c.lvl_v = lvl_v;
     // quantiser constants of the two QPs, fetched once (a table load inside the CU loop would sit behind every outstanding store)
-    const int qsc[2] = {kQuantScales[qp % 6], kQuantScales[qpc % 6]}, qdq[2] = {kInvQuantScales[qp % 6] << (qp / 6), kInvQuantScales[qpc % 6] << (qpc / 6)};
-    const int qp6[2] = {qp / 6, qpc / 6};
+    c.qsc[0] = kQuantScales[qp % 6]; c.qsc[1] = kQuantScales[qpc % 6];
+    c.qdq[0] = kInvQuantScales[qp % 6] << (qp / 6); c.qdq[1] = kInvQuantScales[qpc % 6] << (qpc / 6);
+    c.qp6[0] = qp / 6; c.qp6[1] = qpc / 6;
     // (component pointers are picked with selects, not from an array: a dynamically indexed pointer array loses the global address
     //  space, its stores become FLAT stores, and FLAT stores count against lgkmcnt - every LDS barrier would wait for HBM)
     const uint8_t *const S0 = ks_org_y(g, src_y), *const S1 = ks_org_c(g, src_u), *const S2 = ks_org_c(g, src_v);
-    uint8_t *const R0 = ks_org_y(g, rec_y), *const R1 = ks_org_c(g, rec_u), *const R2 = ks_org_c(g, rec_v);
+    c.R0 = ks_org_y(g, rec_y); c.R1 = ks_org_c(g, rec_u); c.R2 = ks_org_c(g, rec_v);
     for (int cx = 0; cx < g.ctu_cols; ++cx) {
         // wavefront: the row above must be two CTUs ahead (top-right neighbours)
         if (cy > 0 && tid == 0) {
@@ -108,168 +212,119 @@ __global__ __launch_bounds__(256) void intra_recon_kernel(KsGeom g, int qp, cons
         __syncthreads();                                             // nobody still walks the previous CTU's map
         if (tid < 64) {
             const int bx = cx * 8 + (tid & 7), by = cy * 8 + (tid >> 3);
-            ks265_cu8 c;
-            c.mvx = 0; c.mvy = 0; c.mv1x = 0; c.mv1y = 0; c.log2_cu = 0; c.cbf = 0; c.pred_mode = 0; c.inter_dir = 0;
-            if (bx < g.w8 && by < g.h8) c = cu8[(long)by * g.w8 + bx];
-            L.cu[tid] = c;
+            ks265_cu8 cu;
+            cu.mvx = 0; cu.mvy = 0; cu.mv1x = 0; cu.mv1y = 0; cu.log2_cu = 0; cu.cbf = 0; cu.pred_mode = 0; cu.inter_dir = 0;
+            if (bx < g.w8 && by < g.h8) cu = cu8[(long)by * g.w8 + bx];
+            L.cu[tid] = cu;
+            L.cbf[tid] = 0;
             // the previous CTU's last column becomes this CTU's left neighbour column
             L.WY[(1 + tid) * 136 + 3] = L.WY[(1 + tid) * 136 + 4 + 63];
             L.WC[tid >> 5][(1 + (tid & 31)) * 72 + 3] = L.WC[tid >> 5][(1 + (tid & 31)) * 72 + 4 + 31];
         }
         {   // source samples of the CTU: 64 rows x 64 bytes luma (16-byte pieces), 2 x 32 x 32 chroma; rows below the picture are padding, never used
-            const int r = tid >> 2, c = (tid & 3) * 16;
-            *(uint4 *)&L.SY[r * 64 + c] = *(const uint4 *)(S0 + (long)(cy * 64 + r) * g.sy + cx * 64 + c);
+            const int r = tid >> 2, cc16 = (tid & 3) * 16;
+            *(uint4 *)&L.SY[r * 64 + cc16] = *(const uint4 *)(S0 + (long)(cy * 64 + r) * g.sy + cx * 64 + cc16);
             const int cc = tid >> 7, t = tid & 127, rc = t >> 2, c8 = (t & 3) * 8;
             *(uint2 *)&L.SC[cc][rc * 32 + c8] = *(const uint2 *)((cc ? S2 : S1) + (long)(cy * 32 + rc) * g.sc + cx * 32 + c8);
         }
         if (cy > 0) {                                                // the row above: finished by another workgroup -> L2-coherent loads
             if (tid < 129) {
                 const int x = cx * 64 - 1 + tid;
-                if (x >= 0 && x < g.W) L.WY[3 + tid] = __hip_atomic_load(R0 + (long)(cy * 64 - 1) * g.sy + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (x >= 0 && x < g.W) L.WY[3 + tid] = __hip_atomic_load(c.R0 + (long)(cy * 64 - 1) * g.sy + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             if (tid < 130) {
                 const int cc = tid / 65, k = tid % 65, x = cx * 32 - 1 + k;
-                if (x >= 0 && x < g.W / 2) L.WC[cc][3 + k] = __hip_atomic_load((cc ? R2 : R1) + (long)(cy * 32 - 1) * g.sc + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (x >= 0 && x < g.W / 2) L.WC[cc][3 + k] = __hip_atomic_load((cc ? c.R2 : c.R1) + (long)(cy * 32 - 1) * g.sc + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         __syncthreads();
 #pragma unroll 1
         for (int z = 0; z < 64; ++z) {                              // 8x8 blocks of the CTU in z-order; a CU is coded at its first block
             const int lx = (z & 1) | ((z >> 1) & 2) | ((z >> 2) & 4), ly = ((z >> 1) & 1) | ((z >> 2) & 2) | ((z >> 3) & 4);
-            const ks265_cu8 c = L.cu[ly * 8 + lx];
-            if (c.log2_cu == 0) continue;                           // outside the picture
-            const int n8 = 1 << (c.log2_cu - 3);
+            const ks265_cu8 cu = L.cu[ly * 8 + lx];
+            if (cu.log2_cu == 0) continue;                          // outside the picture
+            const int n8 = 1 << (cu.log2_cu - 3);
             if ((lx & (n8 - 1)) || (ly & (n8 - 1))) continue;
-            const int n = 8 * n8, log2 = c.log2_cu, mode = c.mvx, x0 = cx * 64 + lx * 8, y0 = cy * 64 + ly * 8;
-            const unsigned mask = intra_unit_mask(g, x0, y0, n, lane);
-            if (tid < 3) L.nz[tid] = 0;
-            // ---- reference samples of the three components from the LDS window, one sample per thread
-            {
-                const int lenY = 4 * n + 1, lenC = 2 * n + 1;
-                if (tid < lenY) L.raw[0][66 - 2 * n + tid] = (unsigned char)intra_ref_sample<false>(&L.WY[136 + 4], 136, mask, lx * 8, ly * 8, n, 8, tid);
-                if (tid < 2 * lenC) {
-                    const int cc = 1 + tid / lenC, q = tid % lenC;
-                    L.raw[cc][66 - n + q] = (unsigned char)intra_ref_sample<false>(&L.WC[cc - 1][72 + 4], 72, mask, lx * 4, ly * 4, n >> 1, 4, q);
-                }
-            }
-            lds_barrier();
-            const bool filt = intra_filter_flag(mode, n);
-            if (filt) {
-                if (tid <= 4 * n) {
-                    const bool bil = n == 32 && intra_strong_flat(&L.raw[0][66]);
-                    L.fil[66 - 2 * n + tid] = (unsigned char)intra_filtered(&L.raw[0][66], n, tid - 2 * n, bil);
+            const int n = 8 * n8, log2 = cu.log2_cu;
+            c.mode = cu.mvx; c.lx = lx; c.ly = ly; c.x0 = cx * 64 + lx * 8; c.y0 = cy * 64 + ly * 8;
+            c.filt = intra_filter_flag(c.mode, n);
+            if (n == 32) {
+                // ---- 32x32: the luma TU needs all four waves (256 quads) -> work-group barriers; chroma as a second phase
+                lds_barrier();                                       // waves 0 / 1 may still be inside a small CU
+                const unsigned mask = intra_unit_mask(g, c.x0, c.y0, n, lane);
+                if (tid < 3) L.nz[tid] = 0;
+                if (tid < 129) L.raw[0][66 - 64 + tid] = (unsigned char)intra_ref_sample<false>(&L.WY[136 + 4], 136, mask, lx * 8, ly * 8, 32, 8, tid);
+                if (tid < 130) {
+                    const int cc = 1 + tid / 65, q = tid % 65;
+                    L.raw[cc][66 - 32 + q] = (unsigned char)intra_ref_sample<false>(&L.WC[cc - 1][72 + 4], 72, mask, lx * 4, ly * 4, 16, 4, q);
                 }
                 lds_barrier();
-            } else if (mode == 1) {                                  // DC (never smoothed): wave w sums the 2N neighbours of component w
-                const int w = tid >> 6;
-                if (w < 3) {
-                    const int nn = w ? n >> 1 : n;
-                    const unsigned char *ref = &L.raw[w][66];
+                if (c.filt) {
+                    if (tid <= 128) L.fil[66 - 64 + tid] = (unsigned char)intra_filtered(&L.raw[0][66], 32, tid - 64, intra_strong_flat(&L.raw[0][66]));
+                } else if (c.mode == 1 && wave < 3) {
+                    const int nn = wave ? 16 : 32;
+                    const unsigned char *ref = &L.raw[wave][66];
                     int v = lane < nn ? ref[1 + lane] : (lane < 2 * nn ? ref[-1 - (lane - nn)] : 0);
-                    v = (int)group_sum<64>((unsigned)v);
-                    if (lane == 0) L.dcv[w] = (v + nn) >> ((w ? log2 - 1 : log2) + 1);
+                    v = (int)wave_sum((unsigned)v);
+                    if (lane == 0) L.dcv[wave] = (v + nn) >> (wave ? 5 : 6);
                 }
                 lds_barrier();
-            }
-            // ---- the TU phases: n <= 16: Y, Cb, Cr together; n == 32: Y, then Cb + Cr
-            for (int phase = 0; phase < (n == 32 ? 2 : 1); ++phase) {
                 TuRole r;
-                r.on = false; r.comp = 0; r.n = n; r.log2n = log2; r.qx = 0; r.qy = 0;
-                {
-                    const int nqY = n * n / 4, nqC = n * n / 16;
-                    int t = tid;
-                    if (n == 32) {
-                        if (phase == 0) { r.on = true; r.comp = 0; }
-                        else if (t < 2 * nqC) { r.on = true; r.comp = 1 + t / nqC; t %= nqC; }
-                    } else if (t < nqY) { r.on = true; r.comp = 0; }
-                    else if (t < nqY + 2 * nqC) { r.on = true; t -= nqY; r.comp = 1 + t / nqC; t %= nqC; }
-                    if (r.comp) { r.n = n >> 1; r.log2n = log2 - 1; }
-                    r.qx = (t % (r.n / 4)) * 4; r.qy = t / (r.n / 4);
-                }
-                const int cp = r.comp, nn = r.n, l2 = r.log2n, mp = nn + 4;
-                short *X = L.X[cp], *T = L.T[cp];
-                unsigned char *P = L.P[cp];
-                const short *mf = L.Mf + mat_off(l2), *mt = L.Mt + mat_off(l2);
-                const int px = cp ? x0 >> 1 : x0, py = cp ? y0 >> 1 : y0, stride = cp ? g.sc : g.sy, lstride = cp ? g.W / 2 : g.W;
-                // prediction + residual
-                if (r.on) {
-                    const unsigned char *ref = cp == 0 ? (filt ? &L.fil[66] : &L.raw[0][66]) : &L.raw[cp][66];
-                    const int dc = mode == 1 ? L.dcv[cp] : 0;
-                    const unsigned sv = cp == 0 ? *(const unsigned *)&L.SY[(ly * 8 + r.qy) * 64 + lx * 8 + r.qx]
-                                                : *(const unsigned *)&L.SC[cp - 1][(ly * 4 + r.qy) * 32 + lx * 4 + r.qx];
-                    int pr[4];
-                    unsigned short res[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        pr[i] = intra_sample(ref, mode, l2, r.qx + i, r.qy, dc, cp == 0);
-                        res[i] = (unsigned short)(short)((int)((sv >> (8 * i)) & 255) - pr[i]);
+                r.on = true; r.comp = 0; r.n = 32; r.log2n = 5; r.qx = (tid & 7) * 4; r.qy = tid >> 3;
+                tu_pipeline<true>(L, r, c);
+                r.on = tid < 128; r.comp = 1 + ((tid >> 6) & 1); r.n = 16; r.log2n = 4; r.qx = (tid & 3) * 4; r.qy = (tid & 63) >> 2;
+                tu_pipeline<true>(L, r, c);
+                if (tid < 16 && (L.nz[0] | L.nz[1] | L.nz[2])) L.cbf[(ly + (tid >> 2)) * 8 + lx + (tid & 3)] = (L.nz[0] ? 1 : 0) | (L.nz[1] ? 2 : 0) | (L.nz[2] ? 4 : 0);
+                lds_barrier();
+            } else if (wave < 2) {
+                // ---- 8x8 / 16x16: wave 0 codes the luma TU, wave 1 both chroma TUs, each on its own (no work-group barrier: a wave's
+                //      gathers only read what the same wave reconstructed, or what was there before the CTU started)
+                const unsigned mask = intra_unit_mask(g, c.x0, c.y0, n, lane);
+                TuRole r;
+                if (wave == 0) {
+                    if (lane == 0) L.nz[0] = 0;
+                    for (int q = lane; q <= 4 * n; q += 64) L.raw[0][66 - 2 * n + q] = (unsigned char)intra_ref_sample<false>(&L.WY[136 + 4], 136, mask, lx * 8, ly * 8, n, 8, q);
+                    tu_sync<false>();
+                    if (c.filt) {
+                        for (int q = lane; q <= 4 * n; q += 64) L.fil[66 - 2 * n + q] = (unsigned char)intra_filtered(&L.raw[0][66], n, q - 2 * n, false);
+                    } else if (c.mode == 1) {
+                        const unsigned char *ref = &L.raw[0][66];
+                        int v = lane < n ? ref[1 + lane] : (lane < 2 * n ? ref[-1 - (lane - n)] : 0);
+                        v = (int)wave_sum((unsigned)v);
+                        if (lane == 0) L.dcv[0] = (v + n) >> (log2 + 1);
                     }
-                    *(unsigned *)(P + r.qy * 32 + r.qx) = (unsigned)pr[0] | ((unsigned)pr[1] << 8) | ((unsigned)pr[2] << 16) | ((unsigned)pr[3] << 24);
-                    *(uint2 *)(X + r.qy * RP + r.qx) = make_uint2(res[0] | ((unsigned)res[1] << 16), res[2] | ((unsigned)res[3] << 16));
-                }
-                lds_barrier();
-                // forward pass 1: T[k][j] = rnd(M[k] . X[j], 2 log2N - 2)
-                if (r.on) {
-                    const int s1 = 2 * l2 - 2;
-                    int acc[4];
-                    quad_dot(mf + r.qy * mp, X + r.qx * RP, RP, nn, acc);
-                    unsigned short o[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) o[i] = (unsigned short)(short)((acc[i] + (1 << (s1 - 1))) >> s1);
-                    *(uint2 *)(T + r.qy * RP + r.qx) = make_uint2(o[0] | ((unsigned)o[1] << 16), o[2] | ((unsigned)o[3] << 16));
-                }
-                lds_barrier();
-                // forward pass 2 + quant + dequant (stored transposed for the inverse passes)
-                if (r.on) {
-                    int acc[4];
-                    quad_dot(mf + r.qy * mp, T + r.qx * RP, RP, nn, acc);
-                    const int ci = cp ? 1 : 0, scale = qsc[ci], dqs = qdq[ci];
-                    const int qbits = 21 + qp6[ci] - l2, off = 171 << (qbits - 9), shift = l2 - 1;
-                    unsigned short lv[4];
-                    int nzc = 0;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int coef = (short)((acc[i] + 64) >> 7);
-                        int du;
-                        const int l = quant_one(coef, scale, off, qbits, du);
-                        nzc += l != 0;
-                        lv[i] = (unsigned short)(short)l;
-                        X[(r.qx + i) * RP + r.qy] = (short)dequant_one(l, dqs, 1 << (shift - 1), shift);
+                    tu_sync<false>();
+                    const int sh = log2 - 2;                         // quads per row = n / 4
+                    r.on = lane < (n * n >> 2); r.comp = 0; r.n = n; r.log2n = log2; r.qx = (lane & ((1 << sh) - 1)) * 4; r.qy = lane >> sh;
+                    tu_pipeline<false>(L, r, c);
+                    if (lane < n8 * n8 && L.nz[0]) atomicOr(&L.cbf[(ly + lane / n8) * 8 + lx + lane % n8], 1);
+                } else {
+                    const int nc = n >> 1, lenC = 2 * n + 1;
+                    if (lane < 2) L.nz[1 + lane] = 0;
+                    for (int q = lane; q < 2 * lenC; q += 64) {
+                        const int cc = q >= lenC ? 1 : 0, qq = q - cc * lenC;
+                        L.raw[1 + cc][66 - n + qq] = (unsigned char)intra_ref_sample<false>(&L.WC[cc][72 + 4], 72, mask, lx * 4, ly * 4, nc, 4, qq);
                     }
-                    *(uint2 *)((cp == 0 ? lvl_y : (cp == 1 ? lvl_u : lvl_v)) + (long)(py + r.qy) * lstride + px + r.qx) = make_uint2(lv[0] | ((unsigned)lv[1] << 16), lv[2] | ((unsigned)lv[3] << 16));
-                    if (nzc) atomicAdd(&L.nz[cp], nzc);
+                    tu_sync<false>();
+                    if (c.mode == 1 && lane < 2) {
+                        const unsigned char *ref = &L.raw[1 + lane][66];
+                        int v = nc;
+                        for (int i = 0; i < nc; ++i) v += ref[1 + i] + ref[-1 - i];
+                        L.dcv[1 + lane] = v >> log2;                 // log2(nc) + 1
+                    }
+                    tu_sync<false>();
+                    const int sh = log2 - 3, nq = nc * nc >> 2;      // quads per row = nc / 4; quads per component
+                    const int t = lane < nq ? lane : lane - nq;
+                    r.on = lane < 2 * nq; r.comp = lane < nq ? 1 : 2; r.n = nc; r.log2n = log2 - 1; r.qx = (t & ((1 << sh) - 1)) * 4; r.qy = t >> sh;
+                    tu_pipeline<false>(L, r, c);
+                    if (lane < n8 * n8 && (L.nz[1] | L.nz[2])) atomicOr(&L.cbf[(ly + lane / n8) * 8 + lx + lane % n8], (L.nz[1] ? 2 : 0) | (L.nz[2] ? 4 : 0));
                 }
-                lds_barrier();
-                const bool live = r.on && L.nz[cp] != 0;
-                // inverse pass 1: T[y][x] = clip16((Mt[y] . Ct[x] + 64) >> 7)
-                if (r.on) {
-                    int acc[4] = {0, 0, 0, 0};
-                    if (live) quad_dot(mt + r.qy * mp, X + r.qx * RP, RP, nn, acc);
-                    unsigned short o[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) o[i] = (unsigned short)(short)clip16((acc[i] + 64) >> 7);
-                    *(uint2 *)(T + r.qy * RP + r.qx) = make_uint2(o[0] | ((unsigned)o[1] << 16), o[2] | ((unsigned)o[3] << 16));
-                }
-                lds_barrier();
-                // inverse pass 2 + prediction -> reconstructed samples
-                if (r.on) {
-                    int acc[4] = {0, 0, 0, 0};
-                    if (live) quad_dot(T + r.qy * RP, mt + r.qx * mp, mp, nn, acc);
-                    const unsigned pv = *(const unsigned *)(P + r.qy * 32 + r.qx);
-                    unsigned o = 0;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) o |= (unsigned)clip8((int)((pv >> (8 * i)) & 255) + (live ? (acc[i] + 2048) >> 12 : 0)) << (8 * i);
-                    *(unsigned *)((cp == 0 ? R0 : (cp == 1 ? R1 : R2)) + (long)(py + r.qy) * stride + px + r.qx) = o;
-                    if (cp == 0) *(unsigned *)&L.WY[(1 + ly * 8 + r.qy) * 136 + 4 + lx * 8 + r.qx] = o;
-                    else *(unsigned *)&L.WC[cp - 1][(1 + ly * 4 + r.qy) * 72 + 4 + lx * 4 + r.qx] = o;
-                }
-                lds_barrier();
             }
-            if (tid < n8 * n8) {
-                const int cbf = (L.nz[0] ? 1 : 0) | (L.nz[1] ? 2 : 0) | (L.nz[2] ? 4 : 0);
-                cu8[(long)(cy * 8 + ly + tid / n8) * g.w8 + cx * 8 + lx + tid % n8].cbf = (uint8_t)cbf;
-            }
-            lds_barrier();
+        }
+        lds_barrier();
+        if (tid < 64) {
+            const int bx = cx * 8 + (tid & 7), by = cy * 8 + (tid >> 3);
+            if (bx < g.w8 && by < g.h8) cu8[(long)by * g.w8 + bx].cbf = (uint8_t)L.cbf[tid];
         }
         __threadfence();                                             // this CTU's samples are in L2 before the row below is released
         __syncthreads();
