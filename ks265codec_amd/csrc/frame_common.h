@@ -36,6 +36,7 @@ struct ks265_frame {
     int16_t *lvl[3] = {nullptr, nullptr, nullptr};
     uint8_t *deb[3] = {nullptr, nullptr, nullptr};   // reconstructed picture before SAO (padded geometry)
     unsigned long long *sse = nullptr;
+    short *mats = nullptr;              // forward + transposed DCT matrices of all sizes in the kernels' LDS layout (2 x MAT_SHORTS)
     int *progress = nullptr;            // intra wavefront: CTUs finished per CTU row
     // optional in-situ stage timing (HIP events on the context's stream, between the stages of ks265_encode_picture)
     bool profiling = false;
@@ -68,5 +69,7 @@ __device__ __forceinline__ int ks_xcd_swizzle(int b, int n)
     const int x = b & 7, j = b >> 3;
     return x * per + min(x, rem) + j;
 }
+
+int ks265_frame_build_matrices(ks265_frame *f);      // frame_recon.hip
 
 #define KS_FRAME_CHECK(f) do { if (!(f) || !(f)->ctx) return KS265_POINTER; } while (0)

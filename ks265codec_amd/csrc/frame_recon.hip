@@ -245,11 +245,19 @@ __device__ __forceinline__ void code_region(const KsGeom &g, int comp, int qp, i
     __syncthreads();
 }
 
+// the forward and transposed DCT matrices of all four sizes, LDS layout (recon_dev.h), built once per frame object
+__global__ __launch_bounds__(256) void build_matrices_kernel(short *mats) { build_matrices(mats, mats + MAT_SHORTS, threadIdx.x, 256); }
+int ks265_frame_build_matrices(ks265_frame *f)
+{
+    hipLaunchKernelGGL(build_matrices_kernel, dim3(1), dim3(256), 0, f->ctx->stream, f->mats);
+    return ks265_check_launch(f->ctx);
+}
+
 // list-1 pointers are null for I / P pictures (no block carries inter_dir 2 or 3 there)
 __global__ __launch_bounds__(256) void reconstruct_kernel(KsGeom g, int qp, const uint8_t *src_y, const uint8_t *src_u, const uint8_t *src_v,
                                                           const uint8_t *ref_y, const uint8_t *ref_u, const uint8_t *ref_v, const uint8_t *planes,
                                                           const uint8_t *ref1_y, const uint8_t *ref1_u, const uint8_t *ref1_v, const uint8_t *planes1, ks265_cu8 *cu8,
-                                                          int16_t *lvl_y, int16_t *lvl_u, int16_t *lvl_v, uint8_t *rec_y, uint8_t *rec_u, uint8_t *rec_v)
+                                                          int16_t *lvl_y, int16_t *lvl_u, int16_t *lvl_v, uint8_t *rec_y, uint8_t *rec_u, uint8_t *rec_v, const short *mats)
 {
     __shared__ __attribute__((aligned(16))) short Mf[MAT_SHORTS];
     __shared__ __attribute__((aligned(16))) short Mt[MAT_SHORTS];
@@ -265,13 +273,10 @@ __global__ __launch_bounds__(256) void reconstruct_kernel(KsGeom g, int qp, cons
     // line of the source / prediction / level rows meet in one L2 instead of four (measured: FETCH_SIZE 3.9x the algorithmic reads)
     const int nrx = (g.W + 31) / 32, nreg = nrx * ((g.H + 31) / 32);
     const int reg = ks_xcd_swizzle(blockIdx.x, nreg), rx = reg % nrx, ry = reg / nrx;
-    for (int l2 = 2; l2 <= 5; ++l2) {
-        const int n = 1 << l2, base = mat_off(l2), mp = n + 4;
-        for (int i = tid; i < n * n; i += 256) {
-            const int k = i / n, x = i % n, v = dct_coef(n, k, x);
-            Mf[base + k * mp + x] = (short)v;
-            Mt[base + x * mp + k] = (short)v;
-        }
+    // transform matrices: built once per frame object (ks265_frame_create), 6.4 KB copied from L2 with 16-byte loads
+    for (int i = tid; i < MAT_SHORTS / 8; i += 256) {
+        ((uint4 *)Mf)[i] = ((const uint4 *)mats)[i];
+        ((uint4 *)Mt)[i] = ((const uint4 *)(mats + MAT_SHORTS))[i];
     }
     if (tid < 16) {
         const int bx = rx * 4 + (tid & 3), by = ry * 4 + (tid >> 2);
@@ -310,7 +315,7 @@ static int launch_reconstruct(ks265_frame *f, ks265_pic src, ks265_pic ref0, con
 {
     dim3 grid(((f->g.W + 31) / 32) * ((f->g.H + 31) / 32));
     hipLaunchKernelGGL(reconstruct_kernel, grid, dim3(256), 0, f->ctx->stream, f->g, f->cfg.qp, src.y, src.u, src.v, ref0.y, ref0.u, ref0.v, planes0, ref1.y,
-                       ref1.u, ref1.v, planes1, cu8, lvl_y, lvl_u, lvl_v, recon.y, recon.u, recon.v);
+                       ref1.u, ref1.v, planes1, cu8, lvl_y, lvl_u, lvl_v, recon.y, recon.u, recon.v, f->mats);
     return ks265_check_launch(f->ctx);
 }
 
