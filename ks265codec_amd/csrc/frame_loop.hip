@@ -245,14 +245,17 @@ __device__ __forceinline__ void sao_stats_block(const SaoTile<TS> &t, int bx4, i
         }
     }
     if (run_band >= 0) atomicAdd(&acc->bo[run_band], run_acc);
-    // unpack, un-bias, reduce over the wave, one LDS atomic per (class, category) per wave
+    if (!__any(active)) return;                             // a wave without blocks (chroma: waves 2, 3) has nothing to reduce
+    // unpack, reduce over the wave - count (<= 64 x 16 = 1024: 11 bits) and biased sum (<= 64 x 16 x 255 < 2^18) share one word,
+    // so one DPP reduction per (class, category) - un-bias, one LDS atomic pair per (class, category) per wave
 #pragma unroll
     for (int k = 0; k < 4; ++k)
 #pragma unroll
         for (int cat = 0; cat < 4; ++cat) {
-            const int cn = (int)((cntp[k] >> (8 * cat)) & 255u);
-            const int sb = (int)(((cat < 2 ? sumlo[k] : sumhi[k]) >> (16 * (cat & 1))) & 0xFFFFu);
-            const int cs = (int)wave_sum((unsigned)cn), ss = (int)wave_sum((unsigned)(sb - 128 * cn));
+            const unsigned cn = (cntp[k] >> (8 * cat)) & 255u;
+            const unsigned sb = ((cat < 2 ? sumlo[k] : sumhi[k]) >> (16 * (cat & 1))) & 0xFFFFu;
+            const unsigned tot = wave_sum((sb << 11) | cn);
+            const int cs = (int)(tot & 2047u), ss = (int)(tot >> 11) - 128 * cs;
             if (lane == 0 && cs) { atomicAdd(&acc->ecnt[k][cat], cs); atomicAdd(&acc->esum[k][cat], ss); }
         }
 }

@@ -27,35 +27,46 @@ extern "C" int ks265_frame_geometry(const ks265_frame_cfg *cfg, ks265_frame_geom
     return KS265_OK;
 }
 
-// ------------------------------------------------------------------ border padding: one thread per 4 border bytes
-__global__ __launch_bounds__(256) void pad_plane_kernel(uint8_t *plane, int stride, int w, int h, int pad)
+// ------------------------------------------------------------------ border padding (expandPicture_c enc@0x4a6ae0): one thread per 4 border
+// bytes, ONLY border dwords are enumerated (top / bottom bands, then the left / right strips of the picture rows), the three
+// planes of a picture in one launch (blockIdx.y = plane)
+struct PadPlane { uint8_t *p; int stride, w, h, pad; };
+struct PadArgs { PadPlane pl[3]; };
+
+__global__ __launch_bounds__(256) void pad_picture_kernel(PadArgs a)
 {
-    int fw = w + 2 * pad, fh = h + 2 * pad;
-    int x4 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4, y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x4 >= fw || y >= fh) return;
-    int yy = y - pad, xx = x4 - pad;
-    bool inside_rows = yy >= 0 && yy < h;
-    if (inside_rows && xx >= 0 && xx + 3 < w) return;          // interior dword: untouched
-    int sy = min(max(yy, 0), h - 1);
-    const uint8_t *srow = plane + (long)(sy + pad) * stride + pad;
+    const PadPlane q = a.pl[blockIdx.y];
+    const int fw4 = (q.w + 2 * q.pad) / 4, side4 = 2 * q.pad / 4;
+    const int nband = 2 * q.pad * fw4, nside = q.h * side4;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nband + nside) return;
+    int y, x4;
+    if (i < nband) {
+        const int r = i / fw4;
+        y = r < q.pad ? r : q.h + r;
+        x4 = (i - r * fw4) * 4;
+    } else {
+        const int j = i - nband, r = j / side4, k = (j - r * side4) * 4;
+        y = q.pad + r;
+        x4 = k < q.pad ? k : q.w + k;
+    }
+    const int sy = min(max(y - q.pad, 0), q.h - 1), xx = x4 - q.pad;
+    const uint8_t *srow = q.p + (long)(sy + q.pad) * q.stride + q.pad;
     unsigned v = 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v |= (unsigned)srow[min(max(xx + i, 0), w - 1)] << (8 * i);
-    *(unsigned *)(plane + (long)y * stride + x4) = v;
-}
-
-static void launch_pad(ks265_frame *f, uint8_t *plane, int stride, int w, int h, int pad)
-{
-    dim3 grid(((w + 2 * pad) / 4 + 63) / 64, (h + 2 * pad + 3) / 4);
-    hipLaunchKernelGGL(pad_plane_kernel, grid, dim3(256), 0, f->ctx->stream, plane, stride, w, h, pad);
+    for (int b = 0; b < 4; ++b) v |= (unsigned)srow[min(max(xx + b, 0), q.w - 1)] << (8 * b);
+    *(unsigned *)(q.p + (long)y * q.stride + x4) = v;
 }
 
 extern "C" int ks265_pad_picture(ks265_frame *f, ks265_pic pic)
 {
     KS_FRAME_CHECK(f);
-    launch_pad(f, pic.y, f->g.sy, f->g.W, f->g.H, KS_PAD_Y);
-    launch_pad(f, pic.u, f->g.sc, f->g.W / 2, f->g.H / 2, KS_PAD_C);
-    launch_pad(f, pic.v, f->g.sc, f->g.W / 2, f->g.H / 2, KS_PAD_C);
+    PadArgs a;
+    a.pl[0] = PadPlane{pic.y, f->g.sy, f->g.W, f->g.H, KS_PAD_Y};
+    a.pl[1] = PadPlane{pic.u, f->g.sc, f->g.W / 2, f->g.H / 2, KS_PAD_C};
+    a.pl[2] = PadPlane{pic.v, f->g.sc, f->g.W / 2, f->g.H / 2, KS_PAD_C};
+    const int items = 2 * KS_PAD_Y * ((f->g.W + 2 * KS_PAD_Y) / 4) + f->g.H * (2 * KS_PAD_Y / 4);      // luma has the most
+    hipLaunchKernelGGL(pad_picture_kernel, dim3((items + 255) / 256, 3), dim3(256), 0, f->ctx->stream, a);
     return ks265_check_launch(f->ctx);
 }
 
