@@ -236,7 +236,8 @@ int ks265_cu_decide_b(ks265_frame *f, const ks265_pu_b *dev_pub, ks265_cu8 *dev_
 /* Intra pictures.  ks265_intra_decide: every 8x8 / 16x16 / 32x32 block tries all 35 luma modes of
  * g_IntraPredFunction on reference samples taken from the SOURCE picture (decideBestLumaModeBySadFast enc@0x499170 lineage),
  * cost = SATD (had_c) + lambda * mode bits, then the CU quadtree bottom-up; cu8 of an intra CU: pred_mode = 2, mvx = luma mode,
- * chroma = the luma mode.  ks265_intra_reconstruct: CTU wavefront, CUs in z-order, neighbours from the reconstructed picture
+ * chroma = the luma mode.  ks265_intra_reconstruct: CTU wavefront (the reference's own WPP order,
+ * CCtuEncWpp::waitForTopRightCtu enc@0x46f4a0: a CTU starts when its top-right neighbour is done), CUs in z-order, neighbours from the reconstructed picture
  * (H.265 6.4.1 availability, 8.4.4.2.2 substitution, 8.4.4.2.3 smoothing = IntraPredFilterRef_c enc@0x424110), then the
  * reconstruct() chain enc@0x481da0 per TU (TU = CU, at most 32x32). */
 int ks265_intra_decide(ks265_frame *, ks265_pic src, ks265_cu8 *dev_cu8);

@@ -2,7 +2,8 @@
 //   ks265_intra_decide       all 35 luma modes of every 8x8 / 16x16 / 32x32 block predicted from SOURCE neighbours
 //                            (decideBestLumaModeBySadFast enc@0x499170 lineage: pre-selection on source pixels is embarrassingly
 //                            parallel), cost = SATD + lambda * mode bits, CU quadtree bottom-up.  One workgroup per CTU.
-//   ks265_intra_reconstruct  the sequential part: CTUs as a wavefront (one workgroup per CTU row, two CTUs behind the row above,
+//   ks265_intra_reconstruct  the sequential part: CTUs as a wavefront = the reference's WPP order (CCtuEncWpp::waitForTopRightCtu
+//                            enc@0x46f4a0) (one workgroup per CTU row, two CTUs behind the row above,
 //                            progress counters in HBM), CUs in z-order, neighbours from the RECONSTRUCTED picture with the
 //                            normative availability / substitution / smoothing rules, then the reconstruct() chain per TU.
 // Prediction arithmetic = g_IntraPredFunction enc@0x7070a0 / IntraPredFilterRef_c enc@0x424110 (intra_dev.h, pinned).
