@@ -40,6 +40,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--hier-b", type=int, default=0, metavar="G", help="hierarchical-B mini-GOPs of G pictures (power of two, e.g. 8 = the reference's -latency offline default); B pictures of the inner layers are references")
     ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
@@ -74,7 +75,7 @@ def main():
     W, H, qp = args.width, args.height, args.qp
     ks = KsContext(local_rank)
     me_method = {"dia": 0, "hex": 1, "umh": 2}[args.me]
-    fr = KsFrame(ks, W, H, qp, lambda_q4(qp), me_method=me_method, bframes=args.bframes)
+    fr = KsFrame(ks, W, H, qp, lambda_q4(qp), me_method=me_method, bframes=max(args.bframes, args.hier_b - 1 if args.hier_b else 0))
     # synthetic clip of SURVEY.md §8(d), one GOP shard per rank (different seed per rank = different content)
     clip = make_clip(W, H, args.clip_frames, seed=7 + (0 if args.b_spread else rank), abc=(67, 91, 33), pan=(8, 5))
     dev_clip = [ks.dev(c) for c in clip]
@@ -87,13 +88,30 @@ def main():
     bout = fr.new_pic()
     nb = args.bframes
 
-    sched = gop.coding_order(nb, args.iper)
+    sched = gop.hier_order(args.hier_b, args.iper) if args.hier_b else gop.coding_order(nb, args.iper)
+    dpb = [fr.new_pic() for _ in range(args.hier_b + 1)] if args.hier_b else []      # slot = display index mod (G + 1)
     state = {"n": 0, "cur": 0, "last": None}
 
     def src_of(d):
         return srcs[order[d % len(order)]]
 
+    def step_hier():
+        d, kind, r0, r1, layer = next(sched)
+        G1 = args.hier_b + 1
+        q = qp if kind == "I" else qp + 1 + layer            # I = Q, P = Q+1, B of layer k = Q+1+k (hidden hierarchy offsets)
+        fr.set_qp(q, lambda_q4(q))
+        out = dpb[d % G1]
+        if kind == "B":
+            fr.encode_picture_b(src_of(d), dpb[r0 % G1], dpb[r1 % G1], out)
+        else:
+            fr.encode_picture(src_of(d), dpb[r0 % G1] if r0 is not None else out, kind == "I", out)
+        state["last"] = (d, out)
+        state["kind"] = kind
+        state["n"] += 1
+
     def step():
+        if args.hier_b:
+            return step_hier()
         d, kind = next(sched)
         cur = state["cur"]
         if kind == "B":
@@ -229,13 +247,14 @@ def main():
             cpu = {"value": round(nbase / tc, 4), "unit": "frames/s", "cores": 1, "kind": "port",
                    "sample": f"{nbase} pictures (1 key + {nbase - 1} {'P' if args.bframes == 0 else 'P/B'}) of the same {W}x{H} clip, oracle/ks265_pipeline_oracle.c, 1 thread, {tc:.1f} s"}
 
+        bf_desc = f"{args.hier_b - 1} (hierarchical GOP {args.hier_b}, B-ref)" if args.hier_b else str(args.bframes)
         line = {
             "metric": "encoded frames/sec + PSNR-Y, 2160p -preset slow -qp 27, 1/2/4/8 GPU",
             "value": round(fps, 2), "unit": "frames/s", "psnr_y": round(float(psnr_y), 3),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{W}x{H} 4:2:0 8-bit, hot path only (ME + transform/quant/recon + deblock + SAO; CABAC/RC not included), "
-                                   f"-rc 0 -qp {qp} (I=Q, P=Q+1, B=Q+2) -iper {args.iper}, -bframes {args.bframes}, -ref 1 -ref0 1 (one reference picture per list), -me {me_method} ({args.me.upper()}) range 64, subme=8 hpel + 8 qpel SATD, sao on, df on",
+                                   f"-rc 0 -qp {qp} (I=Q, P=Q+1, B=Q+2) -iper {args.iper}, -bframes {bf_desc}, -ref 1 -ref0 1 (one reference picture per list), -me {me_method} ({args.me.upper()}) range 64, subme=8 hpel + 8 qpel SATD, sao on, df on",
                        "pictures_per_step": 1,
                        "key_picture_ms": {"intra_decide": key_ms.get("cu_decide"), "intra_reconstruct": key_ms.get("reconstruct"), "total": round(sum(key_ms.values()), 3),
                                           "note": f"one intra picture per -iper {args.iper} pictures; it is in the timed region whenever the schedule puts one there"},

@@ -29,6 +29,30 @@ def coding_order(bframes: int, iper: int) -> Iterator[tuple[int, str]]:
         d = a
 
 
+def hier_order(gop_size: int, iper: int) -> Iterator[tuple[int, str, int | None, int | None, int]]:
+    """Hierarchical-B coding order (the reference's default at `-latency offline`: bframes -1 -> GOP 8):
+    yields (display index, kind, ref0, ref1, temporal layer); ref0 / ref1 are DISPLAY indices of list-0 (past) / list-1 (future)
+    references, all already coded.  Per mini-GOP: the anchor (layer 0), then the middle B picture of every open interval, breadth
+    first - GOP 8: 8, 4, 2, 6, 1, 3, 5, 7.  B pictures of all layers but the last are themselves references (B-ref)."""
+    assert gop_size >= 1 and gop_size & (gop_size - 1) == 0, "power of two"
+    yield 0, "I", None, None, 0
+    d = 0
+    while True:
+        a = d + gop_size
+        yield a, ("I" if a % iper == 0 else "P"), (None if a % iper == 0 else d), None, 0
+        level, layer = [(d, a)], 1
+        while level:
+            nxt = []
+            for lo, hi in level:
+                if hi - lo < 2:
+                    continue
+                mid = (lo + hi) // 2
+                yield mid, "B", lo, hi, layer
+                nxt += [(lo, mid), (mid, hi)]
+            level, layer = nxt, layer + 1
+        d = a
+
+
 def b_owner(j: int, world: int) -> int:
     """rank that codes the j-th B picture of a mini-GOP: ranks 1..world-1 round-robin (rank 0 when alone)"""
     return 0 if world == 1 else 1 + j % (world - 1)

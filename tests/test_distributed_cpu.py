@@ -143,3 +143,28 @@ def test_schedules_cover_everything():
         assert sorted(b_owner(j, world) for j in range(7)) == sorted([0] * 7 if world == 1 else [1 + j % (world - 1) for j in range(7)])
     it = coding_order(3, 8)
     assert [next(it) for _ in range(10)] == [(0, "I"), (4, "P"), (1, "B"), (2, "B"), (3, "B"), (8, "I"), (5, "B"), (6, "B"), (7, "B"), (12, "P")]
+
+
+def test_hierarchical_b_order_is_decodable():
+    """hier_order: every picture once, references coded before use, list 0 in the past and list 1 in the future, DPB slot scheme of
+    bench.py (display index mod G+1) never overwrites a picture that is still needed"""
+    import itertools
+    from ks265codec_amd.gop import hier_order
+    for G, iper in ((8, 128), (4, 8), (2, 128), (1, 4)):
+        seq = list(itertools.islice(hier_order(G, iper), 1 + 5 * G))
+        coded, slot = set(), {}
+        for d, kind, r0, r1, layer in seq:
+            assert d not in coded
+            for r in (r0, r1):
+                if r is not None:
+                    assert r in coded and slot[r % (G + 1)] == r, (G, d, r)      # coded, and still in its DPB slot
+            if kind == "B":
+                assert r0 < d < r1 and layer >= 1
+            elif kind == "P":
+                assert r0 == d - G and r1 is None and layer == 0
+            else:
+                assert d % iper == 0 and r0 is None
+            coded.add(d)
+            slot[d % (G + 1)] = d
+        assert sorted(coded) == list(range(5 * G + 1))
+    assert [x[0] for x in itertools.islice(hier_order(8, 128), 9)] == [0, 8, 4, 2, 6, 1, 3, 5, 7]

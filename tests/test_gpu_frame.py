@@ -313,3 +313,36 @@ def test_intra_picture(ks, W, H, qp):
         _cmp_region("intra rec.y", ks.host(rec.y, np.uint8), o.rec_pre[0], g.stride_y, org_y, W, H)
         _cmp_region("intra rec.u", ks.host(rec.u, np.uint8), o.rec_pre[1], g.stride_c, org_c, W // 2, H // 2)
         _cmp_region("intra rec.v", ks.host(rec.v, np.uint8), o.rec_pre[2], g.stride_c, org_c, W // 2, H // 2)
+
+
+def test_hierarchical_b_gop_matches_oracle(ks):
+    """GOP 8 hierarchical B (the reference's -latency offline default): B pictures used as references, temporal-layer QP offsets;
+    every reconstructed picture equals the oracle's"""
+    import itertools
+    from ks265codec_amd.gop import hier_order
+    from ks265codec_amd.lib import KsFrame
+    from ks265codec_amd.synth import lambda_q4, make_clip
+    from oracle_lib import OraclePipeline
+
+    W, H, G = 200, 136, 4
+    clip = make_clip(W, H, 2 * G + 1, seed=21, abc=(17, 23, 9))
+    o = OraclePipeline(W, H, 27, lambda_q4(27), me_method=1)
+    with KsFrame(ks, W, H, 27, lambda_q4(27), me_method=1, bframes=G - 1) as f:
+        src = f.new_pic()
+        dpb_g = [f.new_pic() for _ in range(G + 1)]
+        dpb_o = {}
+        kinds = []
+        for d, kind, r0, r1, layer in itertools.islice(hier_order(G, 128), 2 * G + 1):
+            q = 27 if kind == "I" else 28 + layer
+            o.set_qp(q, lambda_q4(q)); f.set_qp(q, lambda_q4(q))
+            dpb_o[d] = o.encode(clip[d], kind, dpb_o.get(r0), dpb_o.get(r1))
+            f.load_i420(ks.dev(clip[d]), src)
+            out = dpb_g[d % (G + 1)]
+            if kind == "B":
+                f.encode_picture_b(src, dpb_g[r0 % (G + 1)], dpb_g[r1 % (G + 1)], out)
+            else:
+                f.encode_picture(src, dpb_g[r0 % (G + 1)] if r0 is not None else out, kind == "I", out)
+            got, exp = ks.host(f.store_i420(out), np.uint8), o.store(dpb_o[d])
+            assert (got == exp).all(), f"picture {d} ({kind}, layer {layer}): {int((got != exp).sum())} bytes differ"
+            kinds.append(kind)
+        assert kinds.count("B") == 2 * (G - 1) and kinds.count("P") == 2
