@@ -37,7 +37,7 @@ def run(only: str | None = None) -> dict:
         os.chmod(enc, 0o755)
         shim = os.path.join(tmp, "seam_shim.so")
         subprocess.check_call(["gcc", "-O2", "-w", "-shared", "-fPIC", "-o", shim, os.path.join(HERE, "seam_shim.c"),
-                               os.path.join(ROOT, "oracle", "ks265_oracle.c"), "-ldl", "-lpthread"])
+                               os.path.join(ROOT, "oracle", "ks265_oracle.c"), os.path.join(ROOT, "oracle", "ks265_intra_oracle.c"), "-ldl", "-lpthread"])
         report = {"reference": "ubuntu_x64/appencoder (libqycodec V2.6.1.3), -threads 1", "runs": []}
         for cfg in CONFIGS:
             clip = make_clip(cfg["w"], cfg["h"], cfg["frames"], seed=cfg["seed"], abc=cfg["abc"])

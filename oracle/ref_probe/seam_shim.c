@@ -16,9 +16,9 @@
 
 void ks265o_sao_apply_eo(int cls, const int8_t *offsets, uint8_t *rec, int stride, int height, int width);
 
-enum { C_SAD, C_SAD4, C_SAD3, C_SAD4BLK, C_SSE, C_HAD, C_DCT, C_QUANT, C_IDCT, C_RESID, C_DBK_LUMA, C_DBK_CHROMA, C_INTERP, C_SAO_BO, C_SAO_STAT, C_N };
+enum { C_SAD, C_SAD4, C_SAD3, C_SAD4BLK, C_SSE, C_HAD, C_DCT, C_QUANT, C_IDCT, C_RESID, C_DBK_LUMA, C_DBK_CHROMA, C_INTERP, C_SAO_BO, C_SAO_STAT, C_INTRA, C_INTRA_FILTER, C_N };
 static const char *kNames[C_N] = {"sad", "sad4", "sad3", "sad4blk", "sse", "had", "fwd_transform", "quant", "inv_transform", "residual",
-                                  "deblock_luma", "deblock_chroma", "interp", "sao_bo", "sao_stats"};
+                                  "deblock_luma", "deblock_chroma", "interp", "sao_bo", "sao_stats", "intra_pred", "intra_filter_ref"};
 static unsigned long g_cnt[C_N];
 
 static uint32_t w_sad(uint8_t *a, uint8_t *b, long sa, long sb, long h, long w) { ++g_cnt[C_SAD]; return ks265o_sad(a, b, sa, sb, h, w); }
@@ -49,6 +49,18 @@ static void w_sao_bo(int8_t *o, uint8_t *r, int s, int h, int w, int band) { ++g
 /* statSaoBoEo01_luma_c enc@0x4aeb20 / _chroma_c enc@0x4aeb50: fixed windows 60 / 28 columns, source pitch 64 / 32 */
 static void w_stat_luma(int *eo, int *bo, uint8_t *org, uint8_t *rec, int rs, int h) { ++g_cnt[C_SAO_STAT]; ks265o_stat_sao_bo_eo01(eo, bo, org, rec, rs, 64, 60, h, 1); }
 static void w_stat_chroma(int *eo, int *bo, uint8_t *org, uint8_t *rec, int rs, int h) { ++g_cnt[C_SAO_STAT]; ks265o_stat_sao_bo_eo01(eo, bo, org, rec, rs, 32, 28, h, 1); }
+
+/* g_IntraPredFunction enc@0x7070a0: 280 entries, index = (isChroma * 4 + log2Size - 2) * 35 + mode (layout read back from the
+ * initialised table: luma groups hold IntraPredLumaDC / AngHor0Luma_10 / AngVer0Luma_26 = boundary smoothing always on, the chroma
+ * groups their unsmoothed counterparts, 32x32 the plain versions).  One wrapper per entry with its mode / size / smoothing fixed,
+ * so nothing depends on what the caller passes in the (mode, log2Size, edgeFilter) arguments of the specialised SIMD kernels. */
+#define IPW(G, M) static void w_ip_##G##_##M(uint8_t *d, int ds, uint8_t *r, int m, int l, int f) { (void)m; (void)l; (void)f; ++g_cnt[C_INTRA]; ks265o_intra_pred(d, ds, r, M, ((G) & 3) + 2, (G) < 3); }
+#define IP35(X, G) X(G, 0) X(G, 1) X(G, 2) X(G, 3) X(G, 4) X(G, 5) X(G, 6) X(G, 7) X(G, 8) X(G, 9) X(G, 10) X(G, 11) X(G, 12) X(G, 13) X(G, 14) X(G, 15) X(G, 16) X(G, 17) \
+    X(G, 18) X(G, 19) X(G, 20) X(G, 21) X(G, 22) X(G, 23) X(G, 24) X(G, 25) X(G, 26) X(G, 27) X(G, 28) X(G, 29) X(G, 30) X(G, 31) X(G, 32) X(G, 33) X(G, 34)
+IP35(IPW, 0) IP35(IPW, 1) IP35(IPW, 2) IP35(IPW, 3) IP35(IPW, 4) IP35(IPW, 5) IP35(IPW, 6) IP35(IPW, 7)
+#define IPT(G, M) (void *)w_ip_##G##_##M,
+static void *const kIntraTab[280] = {IP35(IPT, 0) IP35(IPT, 1) IP35(IPT, 2) IP35(IPT, 3) IP35(IPT, 4) IP35(IPT, 5) IP35(IPT, 6) IP35(IPT, 7)};
+static void w_intra_filter(uint8_t *src, uint8_t *dst, int size, signed char strong) { ++g_cnt[C_INTRA_FILTER]; ks265o_intra_filter_ref(src, dst, size, strong); }
 
 static void dump_counts(void)
 {
@@ -96,7 +108,22 @@ static void patch(void)
         *(void **)0x706890 = (void *)w_chroma_ver_16to8; *(void **)0x706888 = (void *)w_chroma_ver_16to16;
     }
     if (WANT("saobo")) { t = (void **)0x706e20; for (int i = 0; i < 4; ++i) t[i] = (void *)w_sao_bo; }
+    if (WANT("intra")) {
+        t = (void **)0x7070a0; for (int i = 0; i < 280; ++i) t[i] = kIntraTab[i];
+        *(void **)0x706d48 = (void *)w_intra_filter;
+    }
     if (WANT("saostat")) { t = (void **)0x707db0; t[0] = (void *)w_stat_luma; t[1] = (void *)w_stat_chroma; }
+    {   /* optional: dump the intra prediction table (280 entries at g_IntraPredFunction enc@0x7070a0) and g_IntraPredFilterRefFunc */
+        const char *dp = getenv("KS265_SEAM_DUMP");
+        if (dp) {
+            FILE *f = fopen(dp, "w");
+            if (f) {
+                for (int i = 0; i < 280; ++i) fprintf(f, "%d %lx\n", i, (unsigned long)((void **)0x7070a0)[i]);
+                fprintf(f, "filter %lx\n", (unsigned long)*(void **)0x706d48);
+                fclose(f);
+            }
+        }
+    }
     atexit(dump_counts);
 }
 
