@@ -23,6 +23,8 @@ CONFIGS = [
     dict(name="416x240 veryfast qp32", w=416, h=240, frames=8, seed=1234, abc=(17, 23, 9), args=["-preset", "veryfast", "-rc", "0", "-qp", "32", "-iper", "128"]),
     dict(name="416x240 slow qp27", w=416, h=240, frames=6, seed=1234, abc=(17, 23, 9), args=["-preset", "slow", "-rc", "0", "-qp", "27", "-iper", "128"]),
     dict(name="416x240 slow qp27 bframes 3", w=416, h=240, frames=9, seed=99, abc=(17, 23, 9), args=["-preset", "slow", "-rc", "0", "-qp", "27", "-iper", "128", "-bframes", "3"]),
+    # rate control on: adaptive quantisation calls acEnergyPlane (config 4 of BASELINE.json in miniature)
+    dict(name="416x240 slow crf24 bframes 3", w=416, h=240, frames=9, seed=7, abc=(17, 23, 9), args=["-preset", "slow", "-rc", "3", "-crf", "24", "-iper", "128", "-bframes", "3"]),
 ]
 
 

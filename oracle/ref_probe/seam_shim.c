@@ -16,9 +16,9 @@
 
 void ks265o_sao_apply_eo(int cls, const int8_t *offsets, uint8_t *rec, int stride, int height, int width);
 
-enum { C_SAD, C_SAD4, C_SAD3, C_SAD4BLK, C_SSE, C_HAD, C_DCT, C_QUANT, C_IDCT, C_RESID, C_DBK_LUMA, C_DBK_CHROMA, C_INTERP, C_SAO_BO, C_SAO_STAT, C_INTRA, C_INTRA_FILTER, C_N };
+enum { C_SAD, C_SAD4, C_SAD3, C_SAD4BLK, C_SSE, C_HAD, C_DCT, C_QUANT, C_IDCT, C_RESID, C_DBK_LUMA, C_DBK_CHROMA, C_INTERP, C_SAO_BO, C_SAO_STAT, C_INTRA, C_INTRA_FILTER, C_DOWNSAMPLE, C_WBSAD, C_ACENERGY, C_N };
 static const char *kNames[C_N] = {"sad", "sad4", "sad3", "sad4blk", "sse", "had", "fwd_transform", "quant", "inv_transform", "residual",
-                                  "deblock_luma", "deblock_chroma", "interp", "sao_bo", "sao_stats", "intra_pred", "intra_filter_ref"};
+                                  "deblock_luma", "deblock_chroma", "interp", "sao_bo", "sao_stats", "intra_pred", "intra_filter_ref", "downsample", "weight_bi_sad", "ac_energy"};
 static unsigned long g_cnt[C_N];
 
 static uint32_t w_sad(uint8_t *a, uint8_t *b, long sa, long sb, long h, long w) { ++g_cnt[C_SAD]; return ks265o_sad(a, b, sa, sb, h, w); }
@@ -61,6 +61,12 @@ IP35(IPW, 0) IP35(IPW, 1) IP35(IPW, 2) IP35(IPW, 3) IP35(IPW, 4) IP35(IPW, 5) IP
 #define IPT(G, M) (void *)w_ip_##G##_##M,
 static void *const kIntraTab[280] = {IP35(IPT, 0) IP35(IPT, 1) IP35(IPT, 2) IP35(IPT, 3) IP35(IPT, 4) IP35(IPT, 5) IP35(IPT, 6) IP35(IPT, 7)};
 static void w_intra_filter(uint8_t *src, uint8_t *dst, int size, signed char strong) { ++g_cnt[C_INTRA_FILTER]; ks265o_intra_filter_ref(src, dst, size, strong); }
+
+/* lookahead leaf kernels: g_downsampleFunc enc@0x707b10, weightBi_sad table enc@0x707af0 (8x8, 16x16, 32x32), g_acEnergyPlaneFunc enc@0x707b20 (8x8, 16x16) */
+static void w_downsample(uint8_t *d, uint8_t *s, int ds, int ss, int w, int h) { ++g_cnt[C_DOWNSAMPLE]; ks265o_downsample(d, s, ds, ss, w, h); }
+static uint32_t w_wbsad(uint8_t *o, unsigned so, uint8_t *r0, uint8_t *r1, unsigned s0, unsigned s1, int w, int h) { ++g_cnt[C_WBSAD]; return ks265o_weight_bi_sad(o, so, r0, r1, s0, s1, w, h); }
+static uint32_t w_acenergy8(uint8_t *s, int st, int l) { (void)l; ++g_cnt[C_ACENERGY]; return ks265o_ac_energy_plane(s, st, 3); }
+static uint32_t w_acenergy16(uint8_t *s, int st, int l) { (void)l; ++g_cnt[C_ACENERGY]; return ks265o_ac_energy_plane(s, st, 4); }
 
 static void dump_counts(void)
 {
@@ -112,6 +118,11 @@ static void patch(void)
         t = (void **)0x7070a0; for (int i = 0; i < 280; ++i) t[i] = kIntraTab[i];
         *(void **)0x706d48 = (void *)w_intra_filter;
     }
+    if (WANT("lookahead")) {
+        *(void **)0x707b10 = (void *)w_downsample;
+        t = (void **)0x707af0; for (int i = 0; i < 3; ++i) t[i] = (void *)w_wbsad;
+        *(void **)0x707b20 = (void *)w_acenergy8; *(void **)0x707b28 = (void *)w_acenergy16;
+    }
     if (WANT("saostat")) { t = (void **)0x707db0; t[0] = (void *)w_stat_luma; t[1] = (void *)w_stat_chroma; }
     {   /* optional: dump the intra prediction table (280 entries at g_IntraPredFunction enc@0x7070a0) and g_IntraPredFilterRefFunc */
         const char *dp = getenv("KS265_SEAM_DUMP");
@@ -120,6 +131,7 @@ static void patch(void)
             if (f) {
                 for (int i = 0; i < 280; ++i) fprintf(f, "%d %lx\n", i, (unsigned long)((void **)0x7070a0)[i]);
                 fprintf(f, "filter %lx\n", (unsigned long)*(void **)0x706d48);
+                for (unsigned long a = 0x707ae0; a < 0x707b48; a += 8) fprintf(f, "at%lx %lx\n", a, (unsigned long)*(void **)a);
                 fclose(f);
             }
         }
