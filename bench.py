@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
 """bench.py — throughput of the HEVC encode pixel-kernel hot path on MI355X.
 
-One "step" = one picture (3840x2160 4:2:0, BASELINE.json configs[2]) through the whole hot path
+One "step" = one picture (3840x2160 4:2:0, BASELINE.json configs[2]) of every GOP shard of the rank through the whole hot path
 (fractional planes -> integer ME (UMH by default, as -preset slow) -> sub-pel SATD -> CU decision -> residual/DCT/quant/dequant/IDCT/recon ->
-deblock -> SAO -> border padding), all inputs and outputs resident in HBM.  Each rank (one per GPU) encodes its own
-GOP shard (frames/GOPs shard, no data-path collective) -> weak scaling; value = pictures of all ranks /
-max-over-ranks time.  Prints ONE JSON line on rank 0 with `roofline` (dominant kernel, HIP-event timed) and
+deblock -> SAO -> border padding; key pictures: intra mode pre-selection + wavefront reconstruction), all inputs and outputs resident in
+HBM.  Each rank (one per GPU) encodes --streams (default 3) independent GOP shards, each on its own HIP stream: GOPs are
+independent units (frames/GOPs shard, no data-path collective) and the search kernels are latency bound, so the
+kernels of different shards overlap (+38 % pictures/s over one stream).  Weak scaling; value = pictures of all ranks / max-over-ranks time.  Prints ONE JSON line on rank 0 with `roofline` (dominant kernel, HIP-event timed) and
 `cpu_baseline` (the CPU oracle port on a bounded sample).
 """
 from __future__ import annotations
@@ -51,6 +52,7 @@ def main():
     ap.add_argument("--bframes", type=int, default=0, help="-bframes: B pictures between anchors (coding order P b b b); 0 = IPPP")
     ap.add_argument("--b-spread", action="store_true", help="config-5 style: anchor chain on rank 0, RCCL broadcast of every reconstructed anchor, "
                     "B pictures dealt to the other ranks (needs --bframes > 0); default = one GOP shard per rank, no collective")
+    ap.add_argument("--streams", type=int, default=3, help="independent GOP shards in flight per GPU, each on its own HIP stream (their kernels overlap: the search kernels are latency bound)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -64,69 +66,97 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    # functional test of the N > 1 logic on a box with fewer GPUs than ranks: KS265_BENCH_BACKEND=gloo KS265_BENCH_ONE_DEVICE=1
+    # (every rank on device 0, host-side collectives).  The driver's runs use neither: one rank per GPU over RCCL.
+    backend = os.environ.get("KS265_BENCH_BACKEND", "nccl")
+    dev_index = 0 if os.environ.get("KS265_BENCH_ONE_DEVICE") else local_rank
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev_index)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     W, H, qp = args.width, args.height, args.qp
-    ks = KsContext(local_rank)
     me_method = {"dia": 0, "hex": 1, "umh": 2}[args.me]
-    fr = KsFrame(ks, W, H, qp, lambda_q4(qp), me_method=me_method, bframes=max(args.bframes, args.hier_b - 1 if args.hier_b else 0))
-    # synthetic clip of SURVEY.md §8(d), one GOP shard per rank (different seed per rank = different content)
-    clip = make_clip(W, H, args.clip_frames, seed=7 + (0 if args.b_spread else rank), abc=(67, 91, 33), pan=(8, 5))
-    dev_clip = [ks.dev(c) for c in clip]
-    srcs = [fr.new_pic() for _ in clip]
-    for d, s in zip(dev_clip, srcs):
-        fr.load_i420(d, s)
-    order = list(range(len(clip))) + list(range(len(clip) - 2, 0, -1))   # ping-pong keeps the motion continuous
-    # decoded-picture buffer: two anchors (previous / next I-or-P picture) + one scratch output for non-reference B pictures
-    anchors = [fr.new_pic(), fr.new_pic()]
-    bout = fr.new_pic()
     nb = args.bframes
+    nstreams = 1 if args.b_spread else max(1, args.streams)
 
-    sched = gop.hier_order(args.hier_b, args.iper) if args.hier_b else gop.coding_order(nb, args.iper)
-    dpb = [fr.new_pic() for _ in range(args.hier_b + 1)] if args.hier_b else []      # slot = display index mod (G + 1)
-    state = {"n": 0, "cur": 0, "last": None}
+    def make_shard(sidx):
+        """one independent GOP shard: its own context (= HIP stream), frame object, clip, decoded-picture buffer and schedule"""
+        # shard 0 lives on torch's default stream; every further shard gets a stream of its own (KsContext adopts the torch stream
+        # that is current when it is created), so that kernels of different shards can overlap on the GPU
+        import contextlib
+        tstream = None if sidx == 0 else torch.cuda.Stream(device=dev_index)
+        with (torch.cuda.stream(tstream) if tstream is not None else contextlib.nullcontext()):
+            ks = KsContext(dev_index)
+            fr = KsFrame(ks, W, H, qp, lambda_q4(qp), me_method=me_method, bframes=max(args.bframes, args.hier_b - 1 if args.hier_b else 0))
+            # synthetic clip of SURVEY.md §8(d), one GOP shard per stream (different seed per shard = different content)
+            clip = make_clip(W, H, args.clip_frames, seed=7 + (0 if args.b_spread else rank * nstreams + sidx), abc=(67, 91, 33), pan=(8, 5))
+            dev_clip = [ks.dev(c) for c in clip]
+            srcs = [fr.new_pic() for _ in clip]
+            for d, s in zip(dev_clip, srcs):
+                fr.load_i420(d, s)
+            order = list(range(len(clip))) + list(range(len(clip) - 2, 0, -1))   # ping-pong keeps the motion continuous
+            # decoded-picture buffer: two anchors (previous / next I-or-P picture) + one scratch output for non-reference B pictures
+            anchors = [fr.new_pic(), fr.new_pic()]
+            bout = fr.new_pic()
 
-    def src_of(d):
-        return srcs[order[d % len(order)]]
+            sched = gop.hier_order(args.hier_b, args.iper) if args.hier_b else gop.coding_order(nb, args.iper)
+            dpb = [fr.new_pic() for _ in range(args.hier_b + 1)] if args.hier_b else []      # slot = display index mod (G + 1)
+            state = {"n": 0, "cur": 0, "last": None}
 
-    def step_hier():
-        d, kind, r0, r1, layer = next(sched)
-        G1 = args.hier_b + 1
-        q = qp if kind == "I" else qp + 1 + layer            # I = Q, P = Q+1, B of layer k = Q+1+k (hidden hierarchy offsets)
-        fr.set_qp(q, lambda_q4(q))
-        out = dpb[d % G1]
-        if kind == "B":
-            fr.encode_picture_b(src_of(d), dpb[r0 % G1], dpb[r1 % G1], out)
-        else:
-            fr.encode_picture(src_of(d), dpb[r0 % G1] if r0 is not None else out, kind == "I", out)
-        state["last"] = (d, out)
-        state["kind"] = kind
-        state["n"] += 1
+            def src_of(d):
+                return srcs[order[d % len(order)]]
 
-    def step():
-        if args.hier_b:
-            return step_hier()
-        d, kind = next(sched)
-        cur = state["cur"]
-        if kind == "B":
-            q = qp + 2                                  # the reference's hidden hierarchy offsets: I = Q, P = Q+1, B = Q+2..
-            fr.set_qp(q, lambda_q4(q))
-            fr.encode_picture_b(src_of(d), anchors[cur ^ 1], anchors[cur], bout)   # list 0 = previous anchor, list 1 = the anchor just coded
-            state["last"] = (d, bout)
-        else:
-            q = qp if kind == "I" else qp + 1
-            fr.set_qp(q, lambda_q4(q))
-            fr.encode_picture(src_of(d), anchors[cur], kind == "I", anchors[cur ^ 1])
-            state["cur"] = cur ^ 1
-            state["last"] = (d, anchors[cur ^ 1])
-        state["kind"] = kind
-        state["n"] += 1
+            def step_hier():
+                d, kind, r0, r1, layer = next(sched)
+                G1 = args.hier_b + 1
+                q = qp if kind == "I" else qp + 1 + layer            # I = Q, P = Q+1, B of layer k = Q+1+k (SURVEY.md §5: hidden hierarchy offsets)
+                fr.set_qp(q, lambda_q4(q))
+                out = dpb[d % G1]
+                if kind == "B":
+                    fr.encode_picture_b(src_of(d), dpb[r0 % G1], dpb[r1 % G1], out)
+                else:
+                    fr.encode_picture(src_of(d), dpb[r0 % G1] if r0 is not None else out, kind == "I", out)
+                state["last"] = (d, out)
+                state["kind"] = kind
+                state["n"] += 1
+
+            def step():
+                if args.hier_b:
+                    return step_hier()
+                d, kind = next(sched)
+                cur = state["cur"]
+                if kind == "B":
+                    q = qp + 2                                  # the reference's hidden hierarchy offsets: I = Q, P = Q+1, B = Q+2.. (SURVEY.md §5)
+                    fr.set_qp(q, lambda_q4(q))
+                    fr.encode_picture_b(src_of(d), anchors[cur ^ 1], anchors[cur], bout)   # list 0 = previous anchor, list 1 = the anchor just coded
+                    state["last"] = (d, bout)
+                else:
+                    q = qp if kind == "I" else qp + 1
+                    fr.set_qp(q, lambda_q4(q))
+                    fr.encode_picture(src_of(d), anchors[cur], kind == "I", anchors[cur ^ 1])
+                    state["cur"] = cur ^ 1
+                    state["last"] = (d, anchors[cur ^ 1])
+                state["kind"] = kind
+                state["n"] += 1
+        torch.cuda.synchronize()
+        import types
+        return types.SimpleNamespace(ks=ks, fr=fr, clip=clip, srcs=srcs, order=order, anchors=anchors, bout=bout, state=state, step=step, src_of=src_of)
+
+    shards = [make_shard(i) for i in range(nstreams)]
+    sh0 = shards[0]
+    clip = sh0.clip
+    ks, fr, srcs, order, anchors, bout, state, src_of = sh0.ks, sh0.fr, sh0.srcs, sh0.order, sh0.anchors, sh0.bout, sh0.state, sh0.src_of
+
+    def step():                                         # one step = one picture on every stream of this rank (kernels of different shards overlap)
+        for sh in shards:
+            sh.step()
 
     def barrier():
         torch.cuda.synchronize()
@@ -165,15 +195,18 @@ def main():
     else:
         for _ in range(args.warmup):
             step()
+        # two marker kernels bracket the timed region in a kernel trace (tools/rocpd_stats.py then reports exactly these launches)
         barrier()
+        ks.marker(1)
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
         barrier()
         dt = time.perf_counter() - t0
-        total_pictures = world * args.steps
+        ks.marker(2)
+        total_pictures = world * args.steps * nstreams
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=ks.device)
+        tt = torch.tensor([dt], dtype=torch.float64, device=ks.device if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     fps = total_pictures / dt
@@ -183,7 +216,7 @@ def main():
         sse = 0
         npic = min(8, len(order))
         for i in range(npic):
-            step()
+            sh0.step()
             d, pic = state["last"]
             s = fr.sse_picture(src_of(d), pic)
             sse += int(s[0])
@@ -194,15 +227,23 @@ def main():
         #      ks265_encode_picture while the real pipeline runs -> roofline of the dominant kernel
         P = float(W * H)
         fr.set_profiling(True)
-        acc, nacc = {}, 0
-        for _ in range(24):
-            step()
-            if state["kind"] != "P":                   # stage events are recorded by ks265_encode_picture (I / P pictures)
-                continue
-            ms = fr.stage_ms()
-            for k, v in ms.items():
-                acc[k] = acc.get(k, 0.0) + v
-            nacc += 1
+
+        def stage_pass(all_shards):
+            acc, nacc = {}, 0
+            for _ in range(24):
+                (step if all_shards else sh0.step)()
+                if state["kind"] != "P":               # stage events are recorded by ks265_encode_picture (I / P pictures)
+                    continue
+                ms = fr.stage_ms()
+                for k, v in ms.items():
+                    acc[k] = acc.get(k, 0.0) + v
+                nacc += 1
+            torch.cuda.synchronize()
+            return {k: v / nacc for k, v in acc.items()}
+
+        torch.cuda.synchronize()
+        stage_alone = stage_pass(False)                 # shard 0 alone on the GPU: the kernels' own durations (= a --streams 1 run)
+        stage_run = stage_pass(True) if nstreams > 1 else stage_alone   # event-to-event intervals on shard 0's stream while the other shards run
         # one key picture on its own (not part of the schedule): intra mode pre-selection + wavefront reconstruction + loop filters
         fr.set_qp(qp, lambda_q4(qp))
         kout = fr.new_pic()
@@ -211,7 +252,7 @@ def main():
         torch.cuda.synchronize()
         key_ms = {k: round(v, 3) for k, v in fr.stage_ms().items() if v > 0}
         fr.set_profiling(False)
-        stage_ms = {k: v / nacc for k, v in acc.items()}
+        stage_ms = stage_alone
         dom = max(stage_ms, key=stage_ms.get)
         algo_bytes = ALGO_BYTES_P[dom] * P
         achieved = algo_bytes / (stage_ms[dom] * 1e-3) / 1e9
@@ -225,6 +266,9 @@ def main():
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "algorithmic_bytes_per_launch": int(algo_bytes), "avg_launch_ms": round(stage_ms[dom], 4),
                     "stages_ms": {k: round(v, 4) for k, v in stage_ms.items()},
+                    "streams_in_run": nstreams,
+                    "stage_intervals_ms_in_run": {k: round(v, 4) for k, v in stage_run.items()},
+                    "note": "avg_launch_ms / stages_ms / frac: HIP events around each stage with ONE shard on the GPU = the kernel's own duration; it agrees with the rocprofv3 kernel trace of `bench.py --streams 1` (profiles/). With the run's --streams shards in flight the kernels of different shards overlap: stage_intervals_ms_in_run are event-to-event intervals on one shard's stream under that load (queueing behind the other shards' kernels included), the kernel durations of that condition are in the rocprofv3 trace of the default command (profiles/).",
                     "stages_frac": {k: round(ALGO_BYTES_P[k] * P / (v * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) for k, v in stage_ms.items()}}
 
         # ---- CPU baseline: the oracle port (1 thread) on a bounded sample of the same workload
@@ -255,17 +299,18 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{W}x{H} 4:2:0 8-bit, hot path only (ME + transform/quant/recon + deblock + SAO; CABAC/RC not included), "
                                    f"-rc 0 -qp {qp} (I=Q, P=Q+1, B=Q+2) -iper {args.iper}, -bframes {bf_desc}, -ref 1 -ref0 1 (one reference picture per list), -me {me_method} ({args.me.upper()}) range 64, subme=8 hpel + 8 qpel SATD, sao on, df on",
-                       "pictures_per_step": 1,
+                       "pictures_per_step": nstreams, "streams_per_gpu": nstreams,
                        "key_picture_ms": {"intra_decide": key_ms.get("cu_decide"), "intra_reconstruct": key_ms.get("reconstruct"), "total": round(sum(key_ms.values()), 3),
                                           "note": f"one intra picture per -iper {args.iper} pictures; it is in the timed region whenever the schedule puts one there"},
-                       "sharding": "anchor chain on rank 0 + RCCL broadcast of reconstructed anchors, B pictures spread" if args.b_spread else "one GOP shard per GPU, no data-path collective"},
+                       "sharding": "anchor chain on rank 0 + RCCL broadcast of reconstructed anchors, B pictures spread" if args.b_spread else f"{nstreams} GOP shard(s) in flight per GPU on separate HIP streams, no data-path collective"},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    fr.close()
+    for sh in shards:
+        sh.fr.close()
     ks.close()
 
 

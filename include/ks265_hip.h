@@ -45,6 +45,8 @@ int ks265_synchronize(ks265_ctx *ctx);
 const char *ks265_last_error(ks265_ctx *ctx);
 const char *ks265_version(void);                    /* cf. strLibQy265Version, qy265enc.h              */
 /* HIP-event timing on the context's stream (bench.py roofline leg) */
+/* a one-thread kernel named ks265_marker_kernel on the context's stream: brackets a region of interest in a kernel trace (profiling aid) */
+int ks265_marker(ks265_ctx *, int id);
 int ks265_timer_start(ks265_ctx *ctx);
 int ks265_timer_stop_ms(ks265_ctx *ctx, float *ms);
 
