@@ -53,6 +53,7 @@ def main():
     ap.add_argument("--b-spread", action="store_true", help="config-5 style: anchor chain on rank 0, RCCL broadcast of every reconstructed anchor, "
                     "B pictures dealt to the other ranks (needs --bframes > 0); default = one GOP shard per rank, no collective")
     ap.add_argument("--streams", type=int, default=3, help="independent GOP shards in flight per GPU, each on its own HIP stream (their kernels overlap: the search kernels are latency bound)")
+    ap.add_argument("--refs", type=int, default=1, help="list-0 reference pictures a P picture searches (-ref / -ref0; -preset slow resolves to 1 / 3: three for the first picture of a mini-GOP); IPPP only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -94,7 +95,7 @@ def main():
         tstream = None if sidx == 0 else torch.cuda.Stream(device=dev_index)
         with (torch.cuda.stream(tstream) if tstream is not None else contextlib.nullcontext()):
             ks = KsContext(dev_index)
-            fr = KsFrame(ks, W, H, qp, lambda_q4(qp), me_method=me_method, bframes=max(args.bframes, args.hier_b - 1 if args.hier_b else 0))
+            fr = KsFrame(ks, W, H, qp, lambda_q4(qp), me_method=me_method, bframes=max(args.bframes, args.hier_b - 1 if args.hier_b else 0), refs=max(1, args.refs))
             # synthetic clip of SURVEY.md §8(d), one GOP shard per stream (different seed per shard = different content)
             clip = make_clip(W, H, args.clip_frames, seed=7 + (0 if args.b_spread else rank * nstreams + sidx), abc=(67, 91, 33), pan=(8, 5))
             dev_clip = [ks.dev(c) for c in clip]
@@ -108,7 +109,7 @@ def main():
 
             sched = gop.hier_order(args.hier_b, args.iper) if args.hier_b else gop.coding_order(nb, args.iper)
             dpb = [fr.new_pic() for _ in range(args.hier_b + 1)] if args.hier_b else []      # slot = display index mod (G + 1)
-            state = {"n": 0, "cur": 0, "last": None}
+            state = {"n": 0, "cur": 0, "last": None, "since_key": 0}
 
             def src_of(d):
                 return srcs[order[d % len(order)]]
@@ -127,9 +128,31 @@ def main():
                 state["kind"] = kind
                 state["n"] += 1
 
+            ring = [fr.new_pic() for _ in range(args.refs + 1)] if args.refs > 1 else []   # multi-reference IPPP: the picture being written + the most recent ones
+
+            def step_mref():
+                d, kind = next(sched)
+                R, cur = len(ring), state["cur"]
+                nxt = (cur + 1) % R
+                q = qp if kind == "I" else qp + 1
+                fr.set_qp(q, lambda_q4(q))
+                avail = 0 if kind == "I" else min(args.refs, state["since_key"])
+                if avail <= 1:
+                    fr.encode_picture(src_of(d), ring[cur], kind == "I", ring[nxt])
+                else:
+                    fr.encode_picture_mref(src_of(d), [ring[(cur - i) % R] for i in range(avail)], ring[nxt])
+                state["since_key"] = 1 if kind == "I" else state["since_key"] + 1
+                state["cur"] = nxt
+                state["last"] = (d, ring[nxt])
+                state["ref0"] = ring[cur]
+                state["kind"] = kind if avail <= 1 else "Pm"     # "Pm": several references; ks265_encode_picture_mref records no stage events
+                state["n"] += 1
+
             def step():
                 if args.hier_b:
                     return step_hier()
+                if args.refs > 1:
+                    return step_mref()
                 d, kind = next(sched)
                 cur = state["cur"]
                 if kind == "B":
@@ -228,11 +251,15 @@ def main():
         P = float(W * H)
         fr.set_profiling(True)
 
+        probe_out = fr.new_pic()
+
         def stage_pass(all_shards):
             acc, nacc = {}, 0
             for _ in range(24):
                 (step if all_shards else sh0.step)()
-                if state["kind"] != "P":               # stage events are recorded by ks265_encode_picture (I / P pictures)
+                if state["kind"] == "Pm":              # multi-reference run: time the stages on an extra single-reference picture (same kernels per launch)
+                    fr.encode_picture(src_of(state["last"][0]), state["ref0"], False, probe_out)
+                elif state["kind"] != "P":             # stage events are recorded by ks265_encode_picture (I / P pictures)
                     continue
                 ms = fr.stage_ms()
                 for k, v in ms.items():
@@ -298,7 +325,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{W}x{H} 4:2:0 8-bit, hot path only (ME + transform/quant/recon + deblock + SAO; CABAC/RC not included), "
-                                   f"-rc 0 -qp {qp} (I=Q, P=Q+1, B=Q+2) -iper {args.iper}, -bframes {bf_desc}, -ref 1 -ref0 1 (one reference picture per list), -me {me_method} ({args.me.upper()}) range 64, subme=8 hpel + 8 qpel SATD, sao on, df on",
+                                   f"-rc 0 -qp {qp} (I=Q, P=Q+1, B=Q+2) -iper {args.iper}, -bframes {bf_desc}, -ref {max(1, args.refs)} -ref0 {max(1, args.refs)} ({'one reference picture per list' if args.refs <= 1 else 'every P picture searches that many list-0 pictures'}), -me {me_method} ({args.me.upper()}) range 64, subme=8 hpel + 8 qpel SATD, sao on, df on",
                        "pictures_per_step": nstreams, "streams_per_gpu": nstreams,
                        "key_picture_ms": {"intra_decide": key_ms.get("cu_decide"), "intra_reconstruct": key_ms.get("reconstruct"), "total": round(sum(key_ms.values()), 3),
                                           "note": f"one intra picture per -iper {args.iper} pictures; it is in the timed region whenever the schedule puts one there"},

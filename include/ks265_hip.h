@@ -166,6 +166,7 @@ typedef struct {
     int32_t sao;               /* -sao: 0 off, >0 BO + EO0..3                                        */
     int32_t beta_offset_div2, tc_offset_div2;
     int32_t bframes;           /* > 0: allocate the second-list workspace (planes, PU records) for B pictures (-bframes) */
+    int32_t refs;              /* list-0 reference pictures a P picture may search (-ref / -ref0), 0 or 1 = one, at most 4 */
 } ks265_frame_cfg;
 
 /* geometry of the padded picture buffers the caller allocates (one call, no allocation) */
@@ -250,6 +251,16 @@ int ks265_deblock(ks265_frame *f, const ks265_cu8 *dev_cu8, ks265_pic recon);
 /* Stage F: SAO statistics + decision + apply (CEncSao::modeDecisionCtu enc@0x4af690, qy265SaoApplyOffset
  * enc@0x43fc00); dst becomes the next reference picture (borders padded) */
 int ks265_sao(ks265_frame *f, ks265_pic src, ks265_pic deblocked, ks265_sao_param *dev_sao, ks265_pic dst);
+
+/* Multi-reference P pictures (-ref / -ref0; motionSearchOneRef enc@0x483f40 runs once per reference picture): search every picture
+ * with stages A0 / A / B, then ks265_ref_decide picks per PU the picture with the smallest cost + lambda * ref_idx bits (truncated
+ * unary, ties to the nearest picture; pub.inter_dir = 1 | idx << 4, carried into cu8.inter_dir), ks265_cu_decide_b builds the CU tree,
+ * ks265_reconstruct_mref predicts every CU from its own picture.  pu / refs / planes: HOST arrays of device pointers, nearest first. */
+int ks265_ref_decide(ks265_frame *f, int nref, const ks265_pu *const *dev_pu, ks265_pu_b *dev_pub);
+int ks265_reconstruct_mref(ks265_frame *f, ks265_pic src, int nref, const ks265_pic *refs, const uint8_t *const *dev_planes, ks265_cu8 *dev_cu8,
+                           int16_t *dev_lvl_y, int16_t *dev_lvl_u, int16_t *dev_lvl_v, ks265_pic recon);
+/* a P picture with nref <= cfg.refs list-0 pictures (refs[0] = the nearest); nref == 1 is ks265_encode_picture(is_key = 0) */
+int ks265_encode_picture_mref(ks265_frame *f, ks265_pic src, const ks265_pic *refs, int nref, ks265_pic recon_out);
 
 /* the whole hot path for one picture: A0 (if is_key == 0) A B C D E F in stream order.
  * Workspace (planes, PU/CU/SAO records, levels) lives inside the frame object. */

@@ -40,6 +40,12 @@ int ks265_frame_create(ks265_ctx *ctx, const ks265_frame_cfg *cfg, ks265_frame *
         if (!r) r = dev_alloc(ctx, (void **)&f->pu1, (size_t)geom.bytes_pu, true);
         if (!r) r = dev_alloc(ctx, (void **)&f->pub, (size_t)geom.ctu_cols * geom.ctu_rows * 85 * sizeof(ks265_pu_b), true);
     }
+    if (cfg->refs > 4) { ks265_frame_destroy(f); return KS265_NOTSUPPORTED; }
+    for (int x = 0; x + 1 < cfg->refs && !r; ++x) {              /* list-0 pictures 1..refs-1 of multi-reference P pictures */
+        r = dev_alloc(ctx, (void **)&f->planes_x[x], (size_t)16 * g.bytes_y, true);
+        if (!r) r = dev_alloc(ctx, (void **)&f->pu_x[x], (size_t)geom.bytes_pu, true);
+    }
+    if (cfg->refs > 1 && !f->pub && !r) r = dev_alloc(ctx, (void **)&f->pub, (size_t)geom.ctu_cols * geom.ctu_rows * 85 * sizeof(ks265_pu_b), true);
     if (!r) r = dev_alloc(ctx, (void **)&f->cu8, (size_t)geom.bytes_cu8, true);
     if (!r) r = dev_alloc(ctx, (void **)&f->sao, (size_t)geom.bytes_sao, true);
     if (!r) r = dev_alloc(ctx, (void **)&f->lvl[0], npx * 2, true);
@@ -63,7 +69,7 @@ void ks265_frame_destroy(ks265_frame *f)
     if (f->ctx) { (void)hipSetDevice(f->ctx->device); (void)hipStreamSynchronize(f->ctx->stream); }
     for (int i = 0; i <= KS_NSTAGE; ++i)
         if (f->ev[i]) (void)hipEventDestroy(f->ev[i]);
-    void *ptrs[] = {f->planes1, f->pu1, f->pub, f->planes, f->pu[0], f->pu[1], f->cu8, f->sao, f->lvl[0], f->lvl[1], f->lvl[2], f->deb[0], f->deb[1], f->deb[2], f->sse, f->progress, f->mats};
+    void *ptrs[] = {f->planes1, f->pu1, f->pub, f->planes, f->pu[0], f->pu[1], f->cu8, f->sao, f->lvl[0], f->lvl[1], f->lvl[2], f->deb[0], f->deb[1], f->deb[2], f->sse, f->progress, f->mats, f->planes_x[0], f->planes_x[1], f->planes_x[2], f->pu_x[0], f->pu_x[1], f->pu_x[2]};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete f;
@@ -118,6 +124,36 @@ int ks265_encode_picture(ks265_frame *f, ks265_pic src, ks265_pic ref, int is_ke
     if ((r = ks265_sao(f, src, deb, f->sao, recon_out))) return r;
     mark(7);
     if (!is_key) { f->cur_pu ^= 1; f->have_prev = true; }
+    return KS265_OK;
+}
+
+/* P picture with several list-0 pictures: one search per picture, the per-PU choice, the CU tree, then the common back end */
+int ks265_encode_picture_mref(ks265_frame *f, ks265_pic src, const ks265_pic *refs, int nref, ks265_pic recon_out)
+{
+    KS_FRAME_CHECK(f);
+    if (!src.y || !refs || !recon_out.y) return KS265_POINTER;
+    if (nref < 1 || nref > (f->cfg.refs > 1 ? f->cfg.refs : 1)) return KS265_NOTSUPPORTED;
+    if (nref == 1) return ks265_encode_picture(f, src, refs[0], 0, recon_out);
+    int r;
+    ks265_pu *pu0 = f->pu[f->cur_pu];
+    const ks265_pu *pus[4] = {pu0, f->pu_x[0], f->pu_x[1], f->pu_x[2]};
+    const uint8_t *planes[4] = {f->planes, f->planes_x[0], f->planes_x[1], f->planes_x[2]};
+    for (int i = 0; i < nref; ++i) {
+        if (!refs[i].y) return KS265_POINTER;
+        uint8_t *pl = i == 0 ? f->planes : f->planes_x[i - 1];
+        ks265_pu *pu = i == 0 ? pu0 : f->pu_x[i - 1];
+        if ((r = ks265_ref_planes(f, refs[i], pl))) return r;
+        /* the temporal predictor (previous picture's vectors) belongs to the nearest picture only */
+        if ((r = ks265_me_integer(f, src, refs[i], i == 0 && f->have_prev ? f->pu[f->cur_pu ^ 1] : nullptr, pu))) return r;
+        if (f->cfg.subme && (r = ks265_me_subpel(f, src, pl, pu))) return r;
+    }
+    if ((r = ks265_ref_decide(f, nref, pus, f->pub))) return r;
+    if ((r = ks265_cu_decide_b(f, f->pub, f->cu8))) return r;
+    ks265_pic deb = ks_deb_pic(f);
+    if ((r = ks265_reconstruct_mref(f, src, nref, refs, planes, f->cu8, f->lvl[0], f->lvl[1], f->lvl[2], deb))) return r;
+    if (f->cfg.deblock && (r = ks265_deblock(f, f->cu8, deb))) return r;
+    if ((r = ks265_sao(f, src, deb, f->sao, recon_out))) return r;
+    f->cur_pu ^= 1; f->have_prev = true;                          /* the nearest picture's vectors seed the next picture */
     return KS265_OK;
 }
 

@@ -26,6 +26,8 @@ struct ks265_frame {
     // workspace (device)
     uint8_t *planes = nullptr;          // 16 x bytes_y
     uint8_t *planes1 = nullptr;         // list 1 (B pictures), cfg.bframes > 0
+    uint8_t *planes_x[3] = {nullptr, nullptr, nullptr};   // list-0 pictures 1..3 of multi-reference P pictures, cfg.refs > 1
+    ks265_pu *pu_x[3] = {nullptr, nullptr, nullptr};
     ks265_pu *pu1 = nullptr;
     ks265_pu_b *pub = nullptr;
     ks265_pu *pu[2] = {nullptr, nullptr};

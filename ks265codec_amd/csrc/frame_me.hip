@@ -890,3 +890,38 @@ extern "C" int ks265_cu_flat_intra(ks265_frame *f, ks265_cu8 *cu8)
     hipLaunchKernelGGL(cu_flat_intra_kernel, dim3((f->g.w8 * f->g.h8 + 255) / 256), dim3(256), 0, f->ctx->stream, f->g, cu8);
     return ks265_check_launch(f->ctx);
 }
+
+// ------------------------------------------------------------------ multi-reference P pictures (-ref / -ref0)
+// motionSearchOneRef enc@0x483f40 runs once per reference picture; per PU the picture with the smallest cost + lambda * ref_idx bits
+// wins (truncated unary: idx < nref - 1 ? idx + 1 : nref - 1 bits; ties to the nearest picture).  Winner: inter_dir = 1 | idx << 4.
+__global__ __launch_bounds__(256) void ref_decide_kernel(long n, int nref, int lam, const ks265_pu *p0, const ks265_pu *p1, const ks265_pu *p2, const ks265_pu *p3,
+                                                         ks265_pu_b *pub)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    ks265_pu a = p0[i];
+    ks265_pu_b o;
+    o.mvx = a.mvx; o.mvy = a.mvy; o.mv1x = 0; o.mv1y = 0; o.cost = a.cost; o.inter_dir = 1;
+    if (a.cost != KS_COST_INVALID) {
+        unsigned best = KS_COST_INVALID;
+        for (int r = 0; r < nref; ++r) {
+            const ks265_pu q = r == 0 ? a : (r == 1 ? p1[i] : (r == 2 ? p2[i] : p3[i]));
+            const int bits = nref == 1 ? 0 : (r < nref - 1 ? r + 1 : nref - 1);
+            const unsigned c = q.cost + (unsigned)((lam * bits) >> 4);
+            if (c < best) { best = c; o.mvx = q.mvx; o.mvy = q.mvy; o.cost = c; o.inter_dir = 1u | ((unsigned)r << 4); }
+        }
+    }
+    pub[i] = o;
+}
+
+extern "C" int ks265_ref_decide(ks265_frame *f, int nref, const ks265_pu *const *pu, ks265_pu_b *pub)
+{
+    KS_FRAME_CHECK(f);
+    if (!pu || !pub) return KS265_POINTER;
+    if (nref < 1 || nref > 4) return KS265_NOTSUPPORTED;
+    for (int r = 0; r < nref; ++r) if (!pu[r]) return KS265_POINTER;
+    const long n = (long)f->g.ctu_cols * f->g.ctu_rows * 85;
+    hipLaunchKernelGGL(ref_decide_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, f->ctx->stream, n, nref, f->cfg.lambda_q4, pu[0], nref > 1 ? pu[1] : pu[0],
+                       nref > 2 ? pu[2] : pu[0], nref > 3 ? pu[3] : pu[0], pub);
+    return ks265_check_launch(f->ctx);
+}

@@ -25,7 +25,7 @@ SAO_PARAM = np.dtype([("type", "i1"), ("band", "i1"), ("offset", "i1", 4), ("rsv
 
 class FrameCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("width", "height", "qp", "lambda_q4", "me_range", "me_method", "subme", "deblock", "sao",
-                                          "beta_offset_div2", "tc_offset_div2", "bframes")]
+                                          "beta_offset_div2", "tc_offset_div2", "bframes", "refs")]
 
 
 class FrameGeom(C.Structure):
@@ -57,7 +57,7 @@ EXPORTS = [
     "ks265_frame_geometry", "ks265_frame_create", "ks265_frame_destroy", "ks265_frame_set_qp", "ks265_pad_picture",
     "ks265_load_i420", "ks265_store_i420", "ks265_ref_planes", "ks265_me_integer", "ks265_me_subpel", "ks265_cu_decide",
     "ks265_cu_flat_intra", "ks265_intra_decide", "ks265_intra_reconstruct", "ks265_reconstruct", "ks265_reconstruct_b", "ks265_bi_decide", "ks265_cu_decide_b", "ks265_deblock", "ks265_sao",
-    "ks265_encode_picture", "ks265_encode_picture_b",
+    "ks265_encode_picture", "ks265_encode_picture_b", "ks265_encode_picture_mref", "ks265_ref_decide", "ks265_reconstruct_mref",
     "ks265_frame_set_profiling", "ks265_frame_stage_ms", "ks265_frame_levels", "ks265_frame_pu", "ks265_frame_cu8", "ks265_frame_sao", "ks265_frame_planes", "ks265_sse_picture",
 ]
 
@@ -247,9 +247,9 @@ class KsFrame:
     """Whole-frame stages of include/ks265_hip.h section 3 (one picture size, one stream)."""
 
     def __init__(self, ks: KsContext, width: int, height: int, qp: int, lambda_q4: int, me_range: int = 64, subme: int = 1,
-                 deblock: int = 1, sao: int = 1, me_method: int = 0, bframes: int = 0):
+                 deblock: int = 1, sao: int = 1, me_method: int = 0, bframes: int = 0, refs: int = 1):
         self.ks, self.lib = ks, ks.lib
-        self.cfg = FrameCfg(width, height, qp, lambda_q4, me_range, me_method, subme, deblock, sao, 0, 0, bframes)
+        self.cfg = FrameCfg(width, height, qp, lambda_q4, me_range, me_method, subme, deblock, sao, 0, 0, bframes, refs)
         self.geom = FrameGeom()
         ks._chk(self.lib.ks265_frame_geometry(C.byref(self.cfg), C.byref(self.geom)))
         h = C.c_void_p()
@@ -326,6 +326,20 @@ class KsFrame:
 
     def cu_decide_b(self, pub, cu8):
         self.ks._chk(self.lib.ks265_cu_decide_b(self.h, _p(pub), _p(cu8)))
+
+    def encode_picture_mref(self, src: DevPic, refs: list, out: DevPic):
+        """P picture searching len(refs) list-0 pictures (nearest first); needs KsFrame(refs >= len(refs))"""
+        arr = (Pic * len(refs))(*[r.c() for r in refs])
+        self.ks._chk(self.lib.ks265_encode_picture_mref(self.h, src.c(), arr, C.c_int(len(refs)), out.c()))
+
+    def ref_decide(self, pus: list, pub):
+        arr = (C.c_void_p * len(pus))(*[p.data_ptr() for p in pus])
+        self.ks._chk(self.lib.ks265_ref_decide(self.h, C.c_int(len(pus)), arr, _p(pub)))
+
+    def reconstruct_mref(self, src: DevPic, refs: list, planes: list, cu8, lvl, recon: DevPic):
+        ra = (Pic * len(refs))(*[r.c() for r in refs])
+        pa = (C.c_void_p * len(planes))(*[p.data_ptr() for p in planes])
+        self.ks._chk(self.lib.ks265_reconstruct_mref(self.h, src.c(), C.c_int(len(refs)), ra, pa, _p(cu8), _p(lvl[0]), _p(lvl[1]), _p(lvl[2]), recon.c()))
 
     def encode_picture_b(self, src: DevPic, ref0: DevPic, ref1: DevPic, recon_out: DevPic):
         self.ks._chk(self.lib.ks265_encode_picture_b(self.h, src.c(), ref0.c(), ref1.c(), recon_out.c()))

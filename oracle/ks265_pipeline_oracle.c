@@ -561,8 +561,9 @@ static void pred14_chroma(const uint8_t *ref0, long st, int xc, int yc, int n, i
     }
 }
 
-void kso_reconstruct(const kso_frame_cfg *cfg, kso_pic src, kso_pic ref, const uint8_t *planes, kso_pic ref1, const uint8_t *planes1,
-                     kso_cu8 *cu8, int16_t *lvl_y, int16_t *lvl_u, int16_t *lvl_v, kso_pic recon)
+/* list 0 may hold several reference pictures (multi-reference P pictures, -ref / -ref0): the CU's picture is refs0[inter_dir >> 4] */
+static void reconstruct_impl(const kso_frame_cfg *cfg, kso_pic src, const kso_pic *refs0, const uint8_t *const *planes0, kso_pic ref1, const uint8_t *planes1,
+                             kso_cu8 *cu8, int16_t *lvl_y, int16_t *lvl_u, int16_t *lvl_v, kso_pic recon)
 {
     kso_frame_geom g; kso_frame_geometry(cfg, &g);
     int W = cfg->width, H = cfg->height, w8 = W / 8, h8 = H / 8, qp = cfg->qp, qpc = chroma_qp(qp);
@@ -577,7 +578,9 @@ void kso_reconstruct(const kso_frame_cfg *cfg, kso_pic src, kso_pic ref, const u
             int mvx = c->mvx, mvy = c->mvy, cbf = 0;
             uint8_t pred[32 * 32];
             /* luma */
-            const int dir = intra ? 0 : c->inter_dir, mv1x = c->mv1x, mv1y = c->mv1y;
+            const int dir = intra ? 0 : (c->inter_dir & 3), mv1x = c->mv1x, mv1y = c->mv1y;
+            const kso_pic ref = refs0[intra ? 0 : (c->inter_dir >> 4)];
+            const uint8_t *planes = planes0[intra ? 0 : (c->inter_dir >> 4)];
             if (intra) memset(pred, 128, sizeof pred);
             else if (dir == 3) {                                /* bi: DefaultWeightedBi_c enc@0x435160 on the two 14-bit predictions */
                 int16_t a0[32 * 32], a1[32 * 32];
@@ -623,6 +626,39 @@ void kso_reconstruct(const kso_frame_cfg *cfg, kso_pic src, kso_pic ref, const u
             for (int yy = 0; yy < tu8; ++yy)
                 for (int xx = 0; xx < tu8; ++xx) cu8[(long)(by + yy) * w8 + bx + xx].cbf = (uint8_t)cbf;
         }
+}
+
+void kso_reconstruct(const kso_frame_cfg *cfg, kso_pic src, kso_pic ref, const uint8_t *planes, kso_pic ref1, const uint8_t *planes1,
+                     kso_cu8 *cu8, int16_t *lvl_y, int16_t *lvl_u, int16_t *lvl_v, kso_pic recon)
+{
+    reconstruct_impl(cfg, src, &ref, &planes, ref1, planes1, cu8, lvl_y, lvl_u, lvl_v, recon);
+}
+void kso_reconstruct_mref(const kso_frame_cfg *cfg, kso_pic src, int nref, const kso_pic *refs, const uint8_t *const *planes, kso_cu8 *cu8, int16_t *lvl_y,
+                          int16_t *lvl_u, int16_t *lvl_v, kso_pic recon)
+{
+    (void)nref;
+    kso_pic none = {0, 0, 0};
+    reconstruct_impl(cfg, src, refs, planes, none, 0, cu8, lvl_y, lvl_u, lvl_v, recon);
+}
+
+/* Multi-reference P pictures (-ref / -ref0: motionSearchOneRef enc@0x483f40 is called once per reference picture): per PU the reference
+ * with the smallest cost + lambda * ref_idx bits wins (truncated unary: idx < nref - 1 ? idx + 1 : nref - 1 bits; ties to the
+ * nearest picture).  pub: the winner's vector, inter_dir = 1 | idx << 4. */
+void kso_ref_decide(const kso_frame_cfg *cfg, int nref, const kso_pu *const *pu, kso_pu_b *pub)
+{
+    kso_frame_geom g; kso_frame_geometry(cfg, &g);
+    long n = (long)g.ctu_cols * g.ctu_rows * 85;
+    for (long i = 0; i < n; ++i) {
+        kso_pu_b *o = &pub[i];
+        o->mvx = pu[0][i].mvx; o->mvy = pu[0][i].mvy; o->mv1x = 0; o->mv1y = 0; o->cost = pu[0][i].cost; o->inter_dir = 1;
+        if (pu[0][i].cost == COST_INVALID) continue;
+        uint32_t best = COST_INVALID;
+        for (int r = 0; r < nref; ++r) {
+            int bits = nref == 1 ? 0 : (r < nref - 1 ? r + 1 : nref - 1);
+            uint32_t c = pu[r][i].cost + (uint32_t)((cfg->lambda_q4 * bits) >> 4);
+            if (c < best) { best = c; o->mvx = pu[r][i].mvx; o->mvy = pu[r][i].mvy; o->cost = c; o->inter_dir = 1u | ((uint32_t)r << 4); }
+        }
+    }
 }
 
 /* ------------------------------------------------------------------ Stage E: deblocking

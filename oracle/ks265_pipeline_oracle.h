@@ -18,7 +18,7 @@ extern "C" {
 #endif
 
 typedef struct {
-    int32_t width, height, qp, lambda_q4, me_range, me_method, subme, deblock, sao, beta_offset_div2, tc_offset_div2, bframes;
+    int32_t width, height, qp, lambda_q4, me_range, me_method, subme, deblock, sao, beta_offset_div2, tc_offset_div2, bframes, refs;
 } kso_frame_cfg;
 
 typedef struct {
@@ -53,6 +53,10 @@ void kso_cu_decide_b(const kso_frame_cfg *cfg, const kso_pu_b *pub, kso_cu8 *cu8
  * Intra CU in cu8: pred_mode = 2, mvx = luma mode (0 planar, 1 DC, 2..34 angular), chroma = the luma mode (DM). */
 void kso_intra_decide(const kso_frame_cfg *cfg, kso_pic src, kso_cu8 *cu8);
 void kso_intra_reconstruct(const kso_frame_cfg *cfg, kso_pic src, kso_cu8 *cu8, int16_t *lvl_y, int16_t *lvl_u, int16_t *lvl_v, kso_pic recon);
+/* multi-reference P pictures: the per-PU choice among nref list-0 pictures (inter_dir = 1 | idx << 4), and the reconstruction from them */
+void kso_ref_decide(const kso_frame_cfg *cfg, int nref, const kso_pu *const *pu, kso_pu_b *pub);
+void kso_reconstruct_mref(const kso_frame_cfg *cfg, kso_pic src, int nref, const kso_pic *refs, const uint8_t *const *planes, kso_cu8 *cu8, int16_t *lvl_y,
+                          int16_t *lvl_u, int16_t *lvl_v, kso_pic recon);
 void kso_deblock(const kso_frame_cfg *cfg, const kso_cu8 *cu8, kso_pic recon);
 void kso_sao(const kso_frame_cfg *cfg, kso_pic src, kso_pic deblocked, kso_sao_param *sao, kso_pic dst);
 

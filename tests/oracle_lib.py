@@ -45,7 +45,7 @@ I = C.c_int
 # ------------------------------------------------------------------ pipeline oracle (ks265_pipeline_oracle.h)
 class OFrameCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("width", "height", "qp", "lambda_q4", "me_range", "me_method", "subme", "deblock", "sao",
-                                          "beta_offset_div2", "tc_offset_div2", "bframes")]
+                                          "beta_offset_div2", "tc_offset_div2", "bframes", "refs")]
 
 
 class OFrameGeom(C.Structure):
@@ -83,7 +83,7 @@ class OraclePipeline:
     def __init__(self, width, height, qp, lambda_q4, me_range=64, subme=1, deblock=1, sao=1, me_method=0, intra=True):
         self.o = lib()
         self.intra = intra                      # key pictures: real intra prediction (True) or the flat stand-in
-        self.cfg = OFrameCfg(width, height, qp, lambda_q4, me_range, me_method, subme, deblock, sao, 0, 0, 1)
+        self.cfg = OFrameCfg(width, height, qp, lambda_q4, me_range, me_method, subme, deblock, sao, 0, 0, 1, 4)
         self.geom = OFrameGeom()
         assert self.o.kso_frame_geometry(C.byref(self.cfg), C.byref(self.geom)) == 0
         g = self.geom
@@ -158,6 +158,40 @@ class OraclePipeline:
         if kind == "P":
             self.prev_pu, self.pu = self.pu, self.prev_pu
             self.have_prev = True
+        return out
+
+    def encode_mref(self, i420: np.ndarray, refs: "list[HostPic]") -> "HostPic":
+        """P picture searching several list-0 pictures (nearest first): one search per picture, per-PU choice, CU tree, reconstruction"""
+        o, cfg = self.o, C.byref(self.cfg)
+        if len(refs) == 1:
+            return self.encode(i420, "P", refs[0])
+        self.load(self.src, i420)
+        n = len(refs)
+        if not hasattr(self, "planes_x"):
+            self.planes_x = [np.zeros(16 * self.geom.bytes_y, np.uint8) for _ in range(3)]
+            self.pu_x = [np.zeros(self.nctu * 85, PU) for _ in range(3)]
+        if not hasattr(self, "pub"):
+            self.pub = np.zeros(self.nctu * 85, PU_B)
+        planes = [self.planes] + self.planes_x[:n - 1]
+        pus = [self.pu] + self.pu_x[:n - 1]
+        for i, r in enumerate(refs):
+            o.kso_ref_planes(cfg, r.c(), ptr(planes[i]))
+            o.kso_me_integer(cfg, self.src.c(), r.c(), ptr(self.prev_pu) if (i == 0 and self.have_prev) else None, ptr(pus[i]))
+            if self.cfg.subme:
+                o.kso_me_subpel(cfg, self.src.c(), ptr(planes[i]), ptr(pus[i]))
+        pu_arr = (C.c_void_p * n)(*[p.ctypes.data for p in pus])
+        o.kso_ref_decide(cfg, C.c_int(n), pu_arr, ptr(self.pub))
+        o.kso_cu_decide_b(cfg, ptr(self.pub), ptr(self.cu8))
+        ref_arr = (OPic * n)(*[r.c() for r in refs])
+        pl_arr = (C.c_void_p * n)(*[p.ctypes.data for p in planes])
+        o.kso_reconstruct_mref(cfg, self.src.c(), C.c_int(n), ref_arr, pl_arr, ptr(self.cu8), ptr(self.lvl[0]), ptr(self.lvl[1]), ptr(self.lvl[2]), self.rec.c())
+        self.rec_pre = [self.rec.y.copy(), self.rec.u.copy(), self.rec.v.copy()]
+        if self.cfg.deblock:
+            o.kso_deblock(cfg, ptr(self.cu8), self.rec.c())
+        out = HostPic(self.geom)
+        o.kso_sao(cfg, self.src.c(), self.rec.c(), ptr(self.sao), out.c())
+        self.prev_pu, self.pu = self.pu, self.prev_pu
+        self.have_prev = True
         return out
 
     def encode_picture(self, i420: np.ndarray, is_key: bool) -> np.ndarray:

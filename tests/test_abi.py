@@ -40,7 +40,8 @@ def test_struct_layouts_match_header(lib):
     from ks265codec_amd import lib as L
     assert L.BLK.itemsize == 16 and L.BLK3.itemsize == 24 and L.EDGE.itemsize == 12 and L.SAO_RECT.itemsize == 16
     assert L.PU.itemsize == 16 and L.CU8.itemsize == 12 and L.PU_B.itemsize == 16 and L.SAO_PARAM.itemsize == 8
-    assert C.sizeof(L.FrameCfg) == 48 and C.sizeof(L.FrameGeom) == 80
+    assert L.INTRA_BLK.itemsize == 16 and L.INTRA_REF.itemsize == 16
+    assert C.sizeof(L.FrameCfg) == 52 and C.sizeof(L.FrameGeom) == 80          # 13 x int32 (..., bframes, refs)
 
 
 def test_geometry_and_argument_errors_without_gpu(lib):

@@ -346,3 +346,37 @@ def test_hierarchical_b_gop_matches_oracle(ks):
             assert (got == exp).all(), f"picture {d} ({kind}, layer {layer}): {int((got != exp).sum())} bytes differ"
             kinds.append(kind)
         assert kinds.count("B") == 2 * (G - 1) and kinds.count("P") == 2
+
+
+@pytest.mark.parametrize("W,H,me,nref", [(200, 136, 1, 3), (416, 240, 2, 2), (1280, 720, 0, 4)])
+def test_multi_reference_p_pictures(ks, W, H, me, nref):
+    """-ref / -ref0: P pictures searching up to four list-0 pictures (one search per picture, per-PU choice with ref_idx rate, CU tree,
+    reconstruction from each CU's own picture, bS = 1 across different pictures): every reconstructed picture equals the oracle's"""
+    from ks265codec_amd.lib import CU8, KsFrame
+    from ks265codec_amd.synth import lambda_q4, make_clip
+    from oracle_lib import OraclePipeline
+
+    n = nref + 3
+    clip = make_clip(W, H, n, seed=W + nref, abc=(17, 23, 9))
+    o = OraclePipeline(W, H, 27, lambda_q4(27), me_method=me)
+    with KsFrame(ks, W, H, 27, lambda_q4(27), me_method=me, refs=nref) as f:
+        src = f.new_pic()
+        dpb_o, dpb_g, used = [], [], set()
+        for t in range(n):
+            q = 27 if t == 0 else 28
+            o.set_qp(q, lambda_q4(q)); f.set_qp(q, lambda_q4(q))
+            f.load_i420(ks.dev(clip[t]), src)
+            out = f.new_pic()
+            if t == 0:
+                eo = o.encode(clip[0], "I")
+                f.encode_picture(src, out, True, out)
+            else:
+                eo = o.encode_mref(clip[t], dpb_o[:nref])
+                f.encode_picture_mref(src, dpb_g[:nref], out)
+                gc = ks.host(ks.dev(f.ws_read("cu8", f.geom.bytes_cu8)), CU8)
+                assert (gc == o.cu8).all(), f"picture {t}: cu8 differs in {int((gc != o.cu8).sum())} blocks"
+                used |= set(np.unique(gc["inter_dir"] >> 4))
+            got, exp = ks.host(f.store_i420(out), np.uint8), o.store(eo)
+            assert (got == exp).all(), f"picture {t}: {int((got != exp).sum())} bytes differ"
+            dpb_o.insert(0, eo); dpb_g.insert(0, out)
+        assert len(used) >= 2, "the fixture should really use more than one reference picture"
