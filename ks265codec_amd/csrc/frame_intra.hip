@@ -208,7 +208,10 @@ __global__ __launch_bounds__(256) void intra_recon_kernel(KsGeom g, int qp, cons
         // wavefront: the row above must be two CTUs ahead (top-right neighbours)
         if (cy > 0 && tid == 0) {
             const int need = min(cx + 2, g.ctu_cols);
-            while (__hip_atomic_load(progress + cy - 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(8);
+            // bounded: rows are dispatched in order, so the row above is always resident and this never spins long; if it ever did
+            // (a lost launch), give up after ~1 s instead of hanging the GPU - the picture is then wrong, which every parity check sees
+            for (int spins = 0; __hip_atomic_load(progress + cy - 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < need && spins < (1 << 22); ++spins)
+                __builtin_amdgcn_s_sleep(8);
         }
         __syncthreads();                                             // nobody still walks the previous CTU's map
         if (tid < 64) {
