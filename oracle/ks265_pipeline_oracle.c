@@ -97,19 +97,19 @@ void kso_ref_planes(const kso_frame_cfg *cfg, kso_pic ref, uint8_t *planes)
     const uint8_t *src = org_y(&g, ref.y) - (long)PLANE_MARGIN * s - PLANE_MARGIN;
     memset(planes, 0, (size_t)(16 * g.bytes_y));
     memcpy(planes, ref.y, (size_t)g.bytes_y);
-    int16_t *tmp = (int16_t *)malloc(sizeof(int16_t) * (size_t)W * (size_t)(H + 7));
-    for (int fy = 0; fy < 4; ++fy)
-        for (int fx = 0; fx < 4; ++fx) {
-            if (!fx && !fy) continue;
-            uint8_t *dst = org_y(&g, planes + (long)(fy * 4 + fx) * g.bytes_y) - (long)PLANE_MARGIN * s - PLANE_MARGIN;
-            if (!fy) ks265o_interp_luma_hor_8to8(dst, s, src, s, W, H, fx);
-            else if (!fx) ks265o_interp_luma_ver_8to8(dst, s, src, s, W, H, fy);
-            else {
-                ks265o_interp_luma_hor_8to16(tmp, W, src - 3 * (long)s, s, W, H + 7, fx);
-                ks265o_interp_luma_ver_16to8(dst, s, tmp + 3 * W, W, W, H, fy);
-            }
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int k = 1; k < 16; ++k) {
+        const int fy = k >> 2, fx = k & 3;
+        uint8_t *dst = org_y(&g, planes + (long)k * g.bytes_y) - (long)PLANE_MARGIN * s - PLANE_MARGIN;
+        if (!fy) ks265o_interp_luma_hor_8to8(dst, s, src, s, W, H, fx);
+        else if (!fx) ks265o_interp_luma_ver_8to8(dst, s, src, s, W, H, fy);
+        else {
+            int16_t *tmp = (int16_t *)malloc(sizeof(int16_t) * (size_t)W * (size_t)(H + 7));
+            ks265o_interp_luma_hor_8to16(tmp, W, src - 3 * (long)s, s, W, H + 7, fx);
+            ks265o_interp_luma_ver_16to8(dst, s, tmp + 3 * W, W, W, H, fy);
+            free(tmp);
         }
-    free(tmp);
+    }
 }
 
 /* ------------------------------------------------------------------ motion-vector rate
@@ -270,6 +270,7 @@ void kso_me_integer(const kso_frame_cfg *cfg, kso_pic src, kso_pic ref, const ks
     const uint8_t *S = org_y(&g, src.y), *R = org_y(&g, ref.y);
     long st = g.stride_y;
     int range = cfg->me_range, lam = cfg->lambda_q4;
+#pragma omp parallel for collapse(2) schedule(dynamic, 1)
     for (int cy = 0; cy < g.ctu_rows; ++cy)
         for (int cx = 0; cx < g.ctu_cols; ++cx) {
             kso_pu *cp = pu + (long)(cy * g.ctu_cols + cx) * 85;
@@ -337,6 +338,7 @@ void kso_me_subpel(const kso_frame_cfg *cfg, kso_pic src, const uint8_t *planes,
     long st = g.stride_y;
     int lam = cfg->lambda_q4;
     static const int ox[8] = {-1, 0, 1, -1, 1, -1, 0, 1}, oy[8] = {-1, -1, -1, 0, 0, 1, 1, 1};
+#pragma omp parallel for collapse(2) schedule(dynamic, 1)
     for (int cy = 0; cy < g.ctu_rows; ++cy)
         for (int cx = 0; cx < g.ctu_cols; ++cx) {
             kso_pu *cp = pu + (long)(cy * g.ctu_cols + cx) * 85;
@@ -419,6 +421,7 @@ void kso_bi_decide(const kso_frame_cfg *cfg, kso_pic src, const uint8_t *planes0
     const uint8_t *S = org_y(&g, src.y);
     long st = g.stride_y;
     int lam = cfg->lambda_q4;
+#pragma omp parallel for collapse(2) schedule(dynamic, 1)
     for (int cy = 0; cy < g.ctu_rows; ++cy)
         for (int cx = 0; cx < g.ctu_cols; ++cx) {
             long cb = (long)(cy * g.ctu_cols + cx) * 85;
@@ -808,6 +811,7 @@ void kso_sao(const kso_frame_cfg *cfg, kso_pic src, kso_pic deb, kso_sao_param *
 {
     kso_frame_geom g; kso_frame_geometry(cfg, &g);
     int W = cfg->width, H = cfg->height, lam = cfg->lambda_q4;
+#pragma omp parallel for collapse(2) schedule(dynamic, 1)   /* reads src / deb, writes the CTU's own part of dst and sao */
     for (int cy = 0; cy < g.ctu_rows; ++cy)
         for (int cx = 0; cx < g.ctu_cols; ++cx) {
             kso_sao_param *sp = sao + (long)(cy * g.ctu_cols + cx) * 3;
@@ -939,6 +943,7 @@ void kso_intra_decide(const kso_frame_cfg *cfg, kso_pic src, kso_cu8 *cu8)
 {
     kso_frame_geom g; kso_frame_geometry(cfg, &g);
     const uint8_t *S = org_y(&g, src.y);
+#pragma omp parallel for collapse(2) schedule(dynamic, 1)
     for (int cy = 0; cy < g.ctu_rows; ++cy)
         for (int cx = 0; cx < g.ctu_cols; ++cx) {
             intra_ctu t;

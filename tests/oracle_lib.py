@@ -15,7 +15,7 @@ _lib = None
 
 def build_oracle() -> str:
     so = os.path.join(ORACLE_DIR, "libks265_oracle.so")
-    srcs = [os.path.join(ORACLE_DIR, f) for f in ("ks265_oracle.c", "ks265_pipeline_oracle.c", "ks265_oracle.h", "ks265_pipeline_oracle.h")]
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("ks265_oracle.c", "ks265_intra_oracle.c", "ks265_pipeline_oracle.c", "ks265_oracle.h", "ks265_pipeline_oracle.h", "Makefile")]
     srcs = [s for s in srcs if os.path.exists(s)]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-s", "-C", ORACLE_DIR])
