@@ -78,3 +78,14 @@ def test_product_does_not_touch_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle_lib" not in text and "libks265_oracle" not in text and "ks265o_" not in text and "kso_" not in text, f
+
+
+def test_header_is_plain_c(tmp_path):
+    """the drop-in boundary is a C ABI: include/ks265_hip.h must compile as C99 (-pedantic) with the documented struct sizes"""
+    import subprocess
+    src = tmp_path / "h.c"
+    src.write_text('#include "ks265_hip.h"\nint main(void) { ks265_frame_cfg c = {0}; (void)c;\n'
+                   '  return sizeof(ks265_intra_blk) == 16 && sizeof(ks265_cu8) == 12 && sizeof(ks265_pu) == 16 && sizeof(ks265_frame_cfg) == 52 ? 0 : 1; }\n')
+    exe = tmp_path / "h"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    assert subprocess.call([str(exe)]) == 0
