@@ -40,7 +40,7 @@ ALGO_BYTES_P = {
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--steps", type=int, default=128, help="timed steps; the default covers one whole -iper 128 GOP per shard, key picture included")
     ap.add_argument("--hier-b", type=int, default=0, metavar="G", help="hierarchical-B mini-GOPs of G pictures (power of two, e.g. 8 = the reference's -latency offline default); B pictures of the inner layers are references")
     ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--width", type=int, default=3840)
@@ -173,6 +173,14 @@ def main():
         return types.SimpleNamespace(ks=ks, fr=fr, clip=clip, srcs=srcs, order=order, anchors=anchors, bout=bout, state=state, step=step, src_of=src_of)
 
     shards = [make_shard(i) for i in range(nstreams)]
+    # de-phase the shards: shard i starts i/nstreams of a GOP ahead, so that the key pictures (intra wavefront: 34 of 256 CUs busy)
+    # of different shards do not fall on the same step but run underneath the other shards' P pictures - as independent
+    # streams in a real deployment would
+    if not args.b_spread and not args.hier_b and nstreams > 1:
+        for i, sh in enumerate(shards):
+            for _ in range((i * args.iper) // nstreams):
+                sh.step()
+        torch.cuda.synchronize()
     sh0 = shards[0]
     clip = sh0.clip
     ks, fr, srcs, order, anchors, bout, state, src_of = sh0.ks, sh0.fr, sh0.srcs, sh0.order, sh0.anchors, sh0.bout, sh0.state, sh0.src_of
