@@ -6,7 +6,8 @@ One "step" = one picture (3840x2160 4:2:0, BASELINE.json configs[2]) of every GO
 deblock -> SAO -> border padding; key pictures: intra mode pre-selection + wavefront reconstruction), all inputs and outputs resident in
 HBM.  Each rank (one per GPU) encodes --streams (default 3) independent GOP shards, each on its own HIP stream: GOPs are
 independent units (frames/GOPs shard, no data-path collective) and the search kernels are latency bound, so the
-kernels of different shards overlap (+38 % pictures/s over one stream).  Weak scaling; value = pictures of all ranks / max-over-ranks time.  Prints ONE JSON line on rank 0 with `roofline` (dominant kernel, HIP-event timed) and
+kernels of different shards overlap (+53 % pictures/s over one stream on a whole -iper 128 GOP: the intra wavefront of a key
+picture keeps only 34 of 256 CUs busy and runs underneath the other shards' P pictures).  Weak scaling; value = pictures of all ranks / max-over-ranks time.  Prints ONE JSON line on rank 0 with `roofline` (dominant kernel, HIP-event timed) and
 `cpu_baseline` (the CPU oracle port on a bounded sample).
 """
 from __future__ import annotations
