@@ -422,16 +422,8 @@ __global__ __launch_bounds__(256) void intra_decide_kernel(KsGeom g, int lam, co
                 const unsigned char *ref = &L.ref[b][which][66];
                 const int ox = (ttx[nb] % t8) * 8, oy = (tty[nb] % t8) * 8 + 2 * gk, dc = L.dc[b];
                 unsigned w[4];
-#pragma unroll
-                for (int r = 0; r < 2; ++r)
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        unsigned v = 0;
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) v |= (unsigned)intra_sample(ref, mode, log2, ox + 4 * h + c, oy + r, dc, true) << (8 * c);
-                        w[2 * r + h] = v ^ 0x80808080u;
-                    }
-                const ks_v4i B = {(int)w[0], (int)w[1], (int)w[2], (int)w[3]};
+                intra_rows2x8(ref, mode, log2, ox, oy, dc, true, w);
+                const ks_v4i B = {(int)(w[0] ^ 0x80808080u), (int)(w[1] ^ 0x80808080u), (int)(w[2] ^ 0x80808080u), (int)(w[3] ^ 0x80808080u)};
                 unsigned a = 0;
 #pragma unroll
                 for (int mb = 0; mb < 4; ++mb) {

@@ -65,6 +65,59 @@ __device__ __forceinline__ int intra_sample(const uint8_t *r, int mode, int log2
     return ((32 - fact) * a + fact * at(i + idx + 2) + 16) >> 5;
 }
 
+// Two rows x eight columns of one block at once (rows y0, y0 + 1, columns x0 .. x0 + 7) as four packed dwords (row 0 low / high,
+// row 1 low / high) - the unit an MFMA operand column of the SATD needs.  Same arithmetic as intra_sample; for the angular modes
+// the per-row (vertical) or per-column (horizontal) index / fraction is computed once and neighbouring samples share their
+// reference reads, which cuts the instruction count per sample about four-fold against sixteen independent intra_sample calls.
+__device__ __forceinline__ void intra_rows2x8(const uint8_t *r, int mode, int log2, int x0, int y0, int dc, bool edge, unsigned (&w)[4])
+{
+    const int ang = mode >= 2 ? intra_angle(mode) : 0;
+    if (mode < 2 || ang == 0) {                                    // planar, DC, pure horizontal / vertical: the generic path
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            unsigned v = 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v |= (unsigned)intra_sample(r, mode, log2, x0 + 4 * (q & 1) + c, y0 + (q >> 1), dc, edge) << (8 * c);
+            w[q] = v;
+        }
+        return;
+    }
+    const bool ver = mode >= 18;
+    const int inv = ang < 0 ? intra_inv_angle(mode) : 0;
+    auto at = [&](int k) -> int {                                  // main reference, extended to negative k by projecting the side
+        if (k >= 0) return ver ? r[k] : r[-k];
+        const int s = (k * inv + 128) >> 8;
+        return ver ? r[-s] : r[s];
+    };
+    if (ver) {
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int t = (y0 + rr + 1) * ang, idx = t >> 5, f = t & 31;
+            int v[9];
+#pragma unroll
+            for (int c = 0; c < 9; ++c) v[c] = at(x0 + idx + 1 + c);
+            unsigned lo = 0, hi = 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                lo |= (unsigned)(f ? ((32 - f) * v[c] + f * v[c + 1] + 16) >> 5 : v[c]) << (8 * c);
+                hi |= (unsigned)(f ? ((32 - f) * v[c + 4] + f * v[c + 5] + 16) >> 5 : v[c + 4]) << (8 * c);
+            }
+            w[2 * rr] = lo; w[2 * rr + 1] = hi;
+        }
+    } else {
+        unsigned o[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {                              // column x0 + c: index / fraction depend on x only
+            const int t = (x0 + c + 1) * ang, idx = t >> 5, f = t & 31;
+            const int a = at(y0 + idx + 1), b = at(y0 + idx + 2), d = at(y0 + idx + 3);
+            const int p0 = f ? ((32 - f) * a + f * b + 16) >> 5 : a, p1 = f ? ((32 - f) * b + f * d + 16) >> 5 : b;
+            o[c >> 2] |= (unsigned)p0 << (8 * (c & 3));
+            o[2 + (c >> 2)] |= (unsigned)p1 << (8 * (c & 3));
+        }
+        w[0] = o[0]; w[1] = o[1]; w[2] = o[2]; w[3] = o[3];
+    }
+}
+
 // IntraPredFilterRef_c enc@0x424110: sample k (-2 size .. 2 size) of the smoothed array; `bilinear` = the size-32 strong filter
 // applies (decided once per array by intra_strong_flat)
 __device__ __forceinline__ bool intra_strong_flat(const uint8_t *s)
