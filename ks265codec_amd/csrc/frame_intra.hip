@@ -122,11 +122,9 @@ __device__ __forceinline__ void tu_pipeline(IntraLds &L, const TuRole &r, const 
                                     : *(const unsigned *)&L.SC[cp - 1][(c.ly * 4 + r.qy) * 32 + c.lx * 4 + r.qx];
         int pr[4];
         unsigned short res[4];
+        intra_quad(ref, c.mode, l2, r.qx, r.qy, dc, cp == 0, pr);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            pr[i] = intra_sample(ref, c.mode, l2, r.qx + i, r.qy, dc, cp == 0);
-            res[i] = (unsigned short)(short)((int)((sv >> (8 * i)) & 255) - pr[i]);
-        }
+        for (int i = 0; i < 4; ++i) res[i] = (unsigned short)(short)((int)((sv >> (8 * i)) & 255) - pr[i]);
         *(unsigned *)(P + r.qy * 32 + r.qx) = (unsigned)pr[0] | ((unsigned)pr[1] << 8) | ((unsigned)pr[2] << 16) | ((unsigned)pr[3] << 24);
         *(uint2 *)(X + r.qy * RP + r.qx) = make_uint2(res[0] | ((unsigned)res[1] << 16), res[2] | ((unsigned)res[3] << 16));
     }

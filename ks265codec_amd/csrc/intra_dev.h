@@ -65,6 +65,28 @@ __device__ __forceinline__ int intra_sample(const uint8_t *r, int mode, int log2
     return ((32 - fact) * a + fact * at(i + idx + 2) + 16) >> 5;
 }
 
+// Four adjacent samples of one row (x0 .. x0 + 3, y): vertical angular modes share the row's index / fraction and five reference
+// reads; everything else goes through intra_sample.
+__device__ __forceinline__ void intra_quad(const uint8_t *r, int mode, int log2, int x0, int y, int dc, bool edge, int (&o)[4])
+{
+    const int ang = mode >= 18 ? intra_angle(mode) : 0;
+    if (ang == 0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) o[c] = intra_sample(r, mode, log2, x0 + c, y, dc, edge);
+        return;
+    }
+    const int inv = ang < 0 ? intra_inv_angle(mode) : 0;
+    const int t = (y + 1) * ang, idx = t >> 5, f = t & 31;
+    int v[5];
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+        const int k = x0 + idx + 1 + c;
+        v[c] = k >= 0 ? r[k] : r[-((k * inv + 128) >> 8)];
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) o[c] = f ? ((32 - f) * v[c] + f * v[c + 1] + 16) >> 5 : v[c];
+}
+
 // Two rows x eight columns of one block at once (rows y0, y0 + 1, columns x0 .. x0 + 7) as four packed dwords (row 0 low / high,
 // row 1 low / high) - the unit an MFMA operand column of the SATD needs.  Same arithmetic as intra_sample; for the angular modes
 // the per-row (vertical) or per-column (horizontal) index / fraction is computed once and neighbouring samples share their
