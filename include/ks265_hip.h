@@ -244,6 +244,14 @@ int ks265_cu_decide_b(ks265_frame *f, const ks265_pu_b *dev_pub, ks265_cu8 *dev_
  * (H.265 6.4.1 availability, 8.4.4.2.2 substitution, 8.4.4.2.3 smoothing = IntraPredFilterRef_c enc@0x424110), then the
  * reconstruct() chain enc@0x481da0 per TU (TU = CU, at most 32x32). */
 int ks265_intra_decide(ks265_frame *, ks265_pic src, ks265_cu8 *dev_cu8);
+int ks265_intra_decide_ex(ks265_frame *, ks265_pic src, ks265_cu8 *dev_cu8, uint32_t *dev_cost /* optional: nctu x 85 pre-selection costs, PU indexing */);
+/* Lookahead frame cost (calcFrameCost enc@0x4a7410 / scenecut enc@0x47e9d0 lineage - the reference's cost logic is
+ * closed, this is the composition its kernels belong to): on HALF-RESOLUTION pictures (ks265_downsample_rect = downsample_c, then
+ * ks265_pad_picture; a ks265_frame created at the half size), per 8x8 block the intra pre-selection cost against the integer-search cost
+ * of the 8x8 PU.  dev_out[4] = { sum intra, sum inter, sum min(intra, inter), blocks | intra-cheaper blocks << 32 }; the host compares the
+ * sums (scene cut / slice type), ks265_ac_energy_map gives the adaptive-quantisation variance map. */
+int ks265_lookahead_reduce(ks265_frame *, const uint32_t *dev_intra_cost, const ks265_pu *dev_pu, uint64_t *dev_out);
+int ks265_lookahead_picture(ks265_frame *, ks265_pic cur_lowres, ks265_pic ref_lowres, uint32_t *dev_cost_ws /* nctu x 85 */, uint64_t *dev_out);
 int ks265_intra_reconstruct(ks265_frame *, ks265_pic src, ks265_cu8 *dev_cu8, int16_t *dev_lvl_y, int16_t *dev_lvl_u, int16_t *dev_lvl_v, ks265_pic recon);
 /* Stage E: in-place deblocking of a reconstructed picture (CalcBsInterP enc@0x402960, ctuDeblockFilterVer
  * enc@0x403de0, CtuDeblockFilterHorT enc@0x477200) */

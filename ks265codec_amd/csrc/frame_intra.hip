@@ -357,7 +357,7 @@ struct DecideLds {
 
 __device__ __forceinline__ int intra_mode_bits(int mode) { return (mode == 0 || mode == 1 || mode == 26) ? 3 : 6; }   // default MPM set vs. escape code
 
-__global__ __launch_bounds__(256) void intra_decide_kernel(KsGeom g, int lam, const uint8_t *src_y, ks265_cu8 *cu8)
+__global__ __launch_bounds__(256) void intra_decide_kernel(KsGeom g, int lam, const uint8_t *src_y, ks265_cu8 *cu8, unsigned *cost_out)
 {
     __shared__ __attribute__((aligned(16))) DecideLds L;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -455,6 +455,7 @@ __global__ __launch_bounds__(256) void intra_decide_kernel(KsGeom g, int lam, co
         L.mode[1 + b] = (unsigned char)(m & 63u);
     }
     __syncthreads();
+    if (cost_out && tid < 85) cost_out[(long)ctu * 85 + tid] = tid == 0 ? KS_COST_INVALID : L.cost[tid];     // pre-selection costs (lookahead)
     // ---- (3) CU quadtree bottom-up (a node keeps its own cost if it is <= the children's sum + split overhead)
     if (tid == 0) {
         // 85 nodes, leaves first; node value v[idx]
@@ -484,10 +485,53 @@ __global__ __launch_bounds__(256) void intra_decide_kernel(KsGeom g, int lam, co
     }
 }
 
-extern "C" int ks265_intra_decide(ks265_frame *f, ks265_pic src, ks265_cu8 *cu8)
+extern "C" int ks265_intra_decide_ex(ks265_frame *f, ks265_pic src, ks265_cu8 *cu8, uint32_t *cost_out)
 {
     KS_FRAME_CHECK(f);
     if (!src.y || !cu8) return KS265_POINTER;
-    hipLaunchKernelGGL(intra_decide_kernel, dim3(f->g.ctu_cols * f->g.ctu_rows), dim3(256), 0, f->ctx->stream, f->g, f->cfg.lambda_q4, src.y, cu8);
+    hipLaunchKernelGGL(intra_decide_kernel, dim3(f->g.ctu_cols * f->g.ctu_rows), dim3(256), 0, f->ctx->stream, f->g, f->cfg.lambda_q4, src.y, cu8, cost_out);
     return ks265_check_launch(f->ctx);
+}
+extern "C" int ks265_intra_decide(ks265_frame *f, ks265_pic src, ks265_cu8 *cu8) { return ks265_intra_decide_ex(f, src, cu8, nullptr); }
+
+// ------------------------------------------------------------------ lookahead frame cost
+// calcFrameCost enc@0x4a7410 / scenecut enc@0x47e9d0 lineage on half-resolution pictures (downsample_c): per 8x8 block the intra
+// pre-selection cost against the integer-search cost of the 8x8 PU; out = { sum intra, sum inter, sum min, blocks | intra-cheaper << 32 }
+__global__ __launch_bounds__(256) void lookahead_reduce_kernel(long nctu, const unsigned *intra_cost, const ks265_pu *pu, unsigned long long *out)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;             // one thread per (CTU, 8x8 PU)
+    unsigned long long v[4] = {0, 0, 0, 0};
+    if (i < nctu * 64) {
+        const long k = (i >> 6) * 85 + 21 + (i & 63);
+        const unsigned a = intra_cost[k], b = pu[k].cost;
+        if (a != KS_COST_INVALID && b != KS_COST_INVALID) { v[0] = a; v[1] = b; v[2] = min(a, b); v[3] = 1ull | ((unsigned long long)(a < b) << 32); }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        unsigned lo = wave_sum((unsigned)(v[q] & 0xFFFFFFFFull)), hi = wave_sum((unsigned)(v[q] >> 32));
+        // sums of 64 values below 2^26 fit 32 bits; v[3] carries two counters in its halves
+        if ((threadIdx.x & 63) == 0) atomicAdd(&out[q], (unsigned long long)lo | ((unsigned long long)hi << 32));
+    }
+}
+
+extern "C" int ks265_lookahead_reduce(ks265_frame *f, const uint32_t *intra_cost, const ks265_pu *pu, uint64_t *out)
+{
+    KS_FRAME_CHECK(f);
+    if (!intra_cost || !pu || !out) return KS265_POINTER;
+    const long nctu = (long)f->g.ctu_cols * f->g.ctu_rows;
+    if (hipMemsetAsync(out, 0, 32, f->ctx->stream) != hipSuccess) return ks265_hip(f->ctx, hipGetLastError());
+    hipLaunchKernelGGL(lookahead_reduce_kernel, dim3((unsigned)((nctu * 64 + 255) / 256)), dim3(256), 0, f->ctx->stream, nctu, intra_cost, pu, (unsigned long long *)out);
+    return ks265_check_launch(f->ctx);
+}
+
+// the whole low-resolution analysis of one picture: cur / ref are pictures of THIS (half-size) frame object, made with
+// ks265_downsample_rect + ks265_pad_picture; cost_ws = nctu x 85 uint32 scratch; uses the frame's cu8 / PU workspace
+extern "C" int ks265_lookahead_picture(ks265_frame *f, ks265_pic cur, ks265_pic ref, uint32_t *cost_ws, uint64_t *out)
+{
+    KS_FRAME_CHECK(f);
+    if (!cur.y || !ref.y || !cost_ws || !out) return KS265_POINTER;
+    int r;
+    if ((r = ks265_intra_decide_ex(f, cur, f->cu8, cost_ws))) return r;
+    if ((r = ks265_me_integer(f, cur, ref, nullptr, f->pu[f->cur_pu]))) return r;
+    return ks265_lookahead_reduce(f, cost_ws, f->pu[f->cur_pu], out);
 }

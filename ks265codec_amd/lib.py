@@ -56,7 +56,7 @@ EXPORTS = [
     "ks265_downsample_rect", "ks265_weight_bi_sad_batch", "ks265_ac_energy_batch", "ks265_ac_energy_map",
     "ks265_frame_geometry", "ks265_frame_create", "ks265_frame_destroy", "ks265_frame_set_qp", "ks265_pad_picture",
     "ks265_load_i420", "ks265_store_i420", "ks265_ref_planes", "ks265_me_integer", "ks265_me_subpel", "ks265_cu_decide",
-    "ks265_cu_flat_intra", "ks265_intra_decide", "ks265_intra_reconstruct", "ks265_reconstruct", "ks265_reconstruct_b", "ks265_bi_decide", "ks265_cu_decide_b", "ks265_deblock", "ks265_sao",
+    "ks265_cu_flat_intra", "ks265_intra_decide", "ks265_intra_decide_ex", "ks265_lookahead_reduce", "ks265_lookahead_picture", "ks265_intra_reconstruct", "ks265_reconstruct", "ks265_reconstruct_b", "ks265_bi_decide", "ks265_cu_decide_b", "ks265_deblock", "ks265_sao",
     "ks265_encode_picture", "ks265_encode_picture_b", "ks265_encode_picture_mref", "ks265_ref_decide", "ks265_reconstruct_mref",
     "ks265_frame_set_profiling", "ks265_frame_stage_ms", "ks265_frame_levels", "ks265_frame_pu", "ks265_frame_cu8", "ks265_frame_sao", "ks265_frame_planes", "ks265_sse_picture",
 ]
@@ -304,6 +304,13 @@ class KsFrame:
 
     def intra_decide(self, src: DevPic, cu8):
         self.ks._chk(self.lib.ks265_intra_decide(self.h, src.c(), _p(cu8)))
+
+    def lookahead_picture(self, cur: DevPic, ref: DevPic) -> np.ndarray:
+        """low-resolution frame cost: returns [sum intra, sum inter, sum min, blocks | intra-cheaper << 32] (this frame object = half size)"""
+        nctu = self.geom.ctu_cols * self.geom.ctu_rows
+        ws, out = self.ks.zeros(4 * 85 * nctu), self.ks.zeros(32)
+        self.ks._chk(self.lib.ks265_lookahead_picture(self.h, cur.c(), ref.c(), _p(ws), _p(out)))
+        return self.ks.host(out, np.uint64)
 
     def intra_reconstruct(self, src: DevPic, cu8, lvl, recon: DevPic):
         self.ks._chk(self.lib.ks265_intra_reconstruct(self.h, src.c(), _p(cu8), _p(lvl[0]), _p(lvl[1]), _p(lvl[2]), recon.c()))

@@ -939,7 +939,11 @@ static void intra_emit(const kso_frame_cfg *cfg, const intra_ctu *t, int cx, int
             c->mvx = t->mode[idx]; c->mvy = 0; c->mv1x = 0; c->mv1y = 0; c->log2_cu = (uint8_t)(6 - l); c->cbf = 0; c->pred_mode = 2; c->inter_dir = 0;
         }
 }
-void kso_intra_decide(const kso_frame_cfg *cfg, kso_pic src, kso_cu8 *cu8)
+/* cost_out (optional): the pre-selection cost of every block, PU indexing (85 per CTU; level 0 and blocks not inside the picture: COST_INVALID) */
+static void intra_decide_impl(const kso_frame_cfg *cfg, kso_pic src, kso_cu8 *cu8, uint32_t *cost_out);
+void kso_intra_decide(const kso_frame_cfg *cfg, kso_pic src, kso_cu8 *cu8) { intra_decide_impl(cfg, src, cu8, NULL); }
+void kso_intra_decide_ex(const kso_frame_cfg *cfg, kso_pic src, kso_cu8 *cu8, uint32_t *cost_out) { intra_decide_impl(cfg, src, cu8, cost_out); }
+static void intra_decide_impl(const kso_frame_cfg *cfg, kso_pic src, kso_cu8 *cu8, uint32_t *cost_out)
 {
     kso_frame_geom g; kso_frame_geometry(cfg, &g);
     const uint8_t *S = org_y(&g, src.y);
@@ -957,9 +961,29 @@ void kso_intra_decide(const kso_frame_cfg *cfg, kso_pic src, kso_cu8 *cu8)
                         t.cost[idx] = intra_best_mode(cfg, S, g.stride_y, x0, y0, s, &m);
                         t.mode[idx] = (uint8_t)m;
                     }
+            t.cost[0] = COST_INVALID;
+            if (cost_out) memcpy(cost_out + (long)(cy * g.ctu_cols + cx) * 85, t.cost, sizeof t.cost);
             intra_node(cfg, &t, cx, cy, 0, 0, 0);
             intra_emit(cfg, &t, cx, cy, 0, 0, 0, cu8);
         }
+}
+
+/* ------------------------------------------------------------------ lookahead frame cost (calcFrameCost enc@0x4a7410 / scenecut
+ * enc@0x47e9d0 lineage on the half-resolution pictures of downsample_c; the reference's cost logic is closed, this is the x264-lineage
+ * composition its kernels belong to).  Per 8x8 block of the low-resolution picture: intra cost = the pre-selection cost of the block,
+ * inter cost = the integer search cost of the 8x8 PU against the previous low-resolution picture; the frame sums feed the slice-type /
+ * scene-cut decision of the host (a cut when the inter sum is not clearly below the intra sum). */
+void kso_lookahead_reduce(const kso_frame_cfg *cfg, const uint32_t *intra_cost, const kso_pu *pu, uint64_t out[4])
+{
+    kso_frame_geom g; kso_frame_geometry(cfg, &g);
+    uint64_t si = 0, sp = 0, sm = 0, nb = 0, ni = 0;
+    for (long c = 0; c < (long)g.ctu_cols * g.ctu_rows; ++c)
+        for (int i = 21; i < 85; ++i) {
+            uint32_t a = intra_cost[c * 85 + i], b = pu[c * 85 + i].cost;
+            if (a == COST_INVALID || b == COST_INVALID) continue;
+            si += a; sp += b; sm += a < b ? a : b; ++nb; ni += a < b;
+        }
+    out[0] = si; out[1] = sp; out[2] = sm; out[3] = nb | (ni << 32);
 }
 
 static void intra_code_cu(const kso_frame_cfg *cfg, const kso_frame_geom *g, kso_pic src, kso_cu8 *cu8, int bx, int by, int16_t *lvl_y, int16_t *lvl_u,

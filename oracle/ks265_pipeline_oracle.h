@@ -52,6 +52,9 @@ void kso_cu_decide_b(const kso_frame_cfg *cfg, const kso_pu_b *pub, kso_cu8 *cu8
 /* intra pictures: mode pre-selection on source neighbours + CU quadtree, then the sequential reconstruction.
  * Intra CU in cu8: pred_mode = 2, mvx = luma mode (0 planar, 1 DC, 2..34 angular), chroma = the luma mode (DM). */
 void kso_intra_decide(const kso_frame_cfg *cfg, kso_pic src, kso_cu8 *cu8);
+void kso_intra_decide_ex(const kso_frame_cfg *cfg, kso_pic src, kso_cu8 *cu8, uint32_t *cost_out /* nctu x 85, PU indexing */);
+/* lookahead frame cost on low-resolution pictures: out = { sum intra, sum inter, sum min, blocks | intra-cheaper blocks << 32 } over the 8x8 blocks */
+void kso_lookahead_reduce(const kso_frame_cfg *cfg, const uint32_t *intra_cost, const kso_pu *pu, uint64_t out[4]);
 void kso_intra_reconstruct(const kso_frame_cfg *cfg, kso_pic src, kso_cu8 *cu8, int16_t *lvl_y, int16_t *lvl_u, int16_t *lvl_v, kso_pic recon);
 /* multi-reference P pictures: the per-PU choice among nref list-0 pictures (inter_dir = 1 | idx << 4), and the reconstruction from them */
 void kso_ref_decide(const kso_frame_cfg *cfg, int nref, const kso_pu *const *pu, kso_pu_b *pub);

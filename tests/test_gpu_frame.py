@@ -380,3 +380,52 @@ def test_multi_reference_p_pictures(ks, W, H, me, nref):
             assert (got == exp).all(), f"picture {t}: {int((got != exp).sum())} bytes differ"
             dpb_o.insert(0, eo); dpb_g.insert(0, out)
         assert len(used) >= 2, "the fixture should really use more than one reference picture"
+
+
+def test_lookahead_frame_cost(ks):
+    """§8(f) rank 2 frame stage: half-resolution pictures (downsample_c + padding), per 8x8 block intra pre-selection cost vs. integer-search
+    cost, frame sums - GPU == oracle composition; a scene cut (unrelated picture) must push the inter sum above the intra sum"""
+    import ctypes as C
+    from ks265codec_amd.lib import KsFrame, PU
+    from ks265codec_amd.synth import lambda_q4, make_clip
+    from oracle_lib import I, HostPic, OraclePipeline, lib as olib, ptr
+
+    W, H = 416, 240
+    w, h = W // 2, H // 2
+    clip = make_clip(W, H, 3, seed=5)
+    other = make_clip(W, H, 1, seed=99, abc=(5, 7, 3))[0]                    # unrelated content = a scene cut
+    frames = [clip[0], clip[1], other]
+    o_full, o_low = OraclePipeline(W, H, 30, lambda_q4(30)), OraclePipeline(w, h, 30, lambda_q4(30))
+    ol = olib()
+    with KsFrame(ks, W, H, 30, lambda_q4(30)) as ff, KsFrame(ks, w, h, 30, lambda_q4(30)) as fl:
+        gf, gl = ff.geom, fl.geom
+        of, olo = gf.pad_y * gf.stride_y + gf.pad_y, gl.pad_y * gl.stride_y + gl.pad_y
+        src = ff.new_pic()
+        low_g, low_o = [], []
+        for fr_ in frames:
+            ff.load_i420(ks.dev(fr_), src)
+            lg = fl.new_pic()
+            ks._chk(ks.lib.ks265_downsample_rect(ks.h, C.c_void_p(src.y.data_ptr() + of), C.c_int(gf.stride_y), C.c_void_p(lg.y.data_ptr() + olo), C.c_int(gl.stride_y),
+                                                 C.c_int(w), C.c_int(h)))
+            fl.pad(lg)
+            low_g.append(lg)
+            o_full.load(o_full.src, fr_)
+            lo = HostPic(o_low.geom)
+            ol.ks265o_downsample(ptr(lo.y, olo), ptr(o_full.src.y, of), I(gl.stride_y), I(gf.stride_y), I(w), I(h))
+            lo.u[:] = 0; lo.v[:] = 0
+            ol.kso_pad_picture(C.byref(o_low.cfg), lo.c())
+            low_o.append(lo)
+            assert (ks.host(lg.y, np.uint8) == lo.y).all(), "low-resolution picture differs"
+        res = []
+        for cur, ref in ((1, 0), (2, 1)):
+            got = fl.lookahead_picture(low_g[cur], low_g[ref])
+            cost = np.zeros(o_low.nctu * 85, np.uint32)
+            pu = np.zeros(o_low.nctu * 85, PU)
+            exp = np.zeros(4, np.uint64)
+            ol.kso_intra_decide_ex(C.byref(o_low.cfg), low_o[cur].c(), ptr(o_low.cu8), ptr(cost))
+            ol.kso_me_integer(C.byref(o_low.cfg), low_o[cur].c(), low_o[ref].c(), None, ptr(pu))
+            ol.kso_lookahead_reduce(C.byref(o_low.cfg), ptr(cost), ptr(pu), ptr(exp))
+            assert (got == exp).all(), (got, exp)
+            res.append(got)
+        same, cut = res
+        assert same[1] < same[0] // 2 and cut[1] > cut[0], (same, cut)         # continuous motion: inter far cheaper; scene cut: intra cheaper
