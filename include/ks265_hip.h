@@ -41,7 +41,14 @@ enum ks265_status {
 int ks265_create(ks265_ctx **out, int device);      /* creates its own HIP stream                      */
 void ks265_destroy(ks265_ctx *ctx);
 int ks265_set_stream(ks265_ctx *ctx, void *hip_stream); /* adopt a caller stream (e.g. torch's current) */
+/* waits for the context's stream; also reads (and clears) the device-side error word that kernels set when they could not complete
+ * correctly (today: the intra wavefront's bounded wait timing out) -> KS265_FAIL with ks265_last_error() naming the condition; the
+ * pictures encoded since the previous ks265_synchronize must then be re-encoded */
 int ks265_synchronize(ks265_ctx *ctx);
+/* test hook: KS265_DBG_WAVEFRONT_SPINS = the number of polls a CTU row of the intra wavefront waits for the row above (value < 0
+ * restores the default, about one second); 0 forces the timeout path */
+enum { KS265_DBG_WAVEFRONT_SPINS = 1 };
+int ks265_debug_set(ks265_ctx *ctx, int what, int value);
 const char *ks265_last_error(ks265_ctx *ctx);
 const char *ks265_version(void);                    /* cf. strLibQy265Version, qy265enc.h              */
 /* HIP-event timing on the context's stream (bench.py roofline leg) */
@@ -174,7 +181,7 @@ typedef struct {
     int32_t pad_y, pad_c;          /* border in samples (80 / 40)                  */
     int32_t stride_y, stride_c;    /* bytes per row                                */
     int32_t rows_y, rows_c;        /* rows incl. borders                           */
-    int64_t bytes_y, bytes_c;      /* plane allocations                            */
+    int64_t bytes_y, bytes_c;      /* plane allocations = stride x (rows + 1): one slack row, so that aligned window loads of the last padded row stay inside the allocation */
     int32_t ctu_cols, ctu_rows;
     int32_t pu_per_ctu;            /* 85: 1 + 4 + 16 + 64                          */
     int64_t bytes_pu;              /* ks265_pu records                             */
@@ -197,6 +204,7 @@ typedef struct { uint8_t *y, *u, *v; } ks265_pic;
 
 int ks265_frame_geometry(const ks265_frame_cfg *cfg, ks265_frame_geom *geom);
 int ks265_frame_create(ks265_ctx *ctx, const ks265_frame_cfg *cfg, ks265_frame **out);
+/* frames keep a pointer to their context: destroy every frame BEFORE ks265_destroy(ctx) */
 void ks265_frame_destroy(ks265_frame *f);
 int ks265_frame_set_qp(ks265_frame *f, int qp, int lambda_q4);
 

@@ -20,6 +20,9 @@ int ks265_create(ks265_ctx **out, int device)
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return KS265_FAIL; }
     c->own_stream = true;
     if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) { ks265_destroy(c); return KS265_FAIL; }
+    if (hipHostMalloc((void **)&c->err_host, sizeof(unsigned), hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void **)&c->err_dev, c->err_host, 0) != hipSuccess) { ks265_destroy(c); return KS265_FAIL; }
+    *c->err_host = 0;
     *out = c;
     return KS265_OK;
 }
@@ -32,6 +35,7 @@ void ks265_destroy(ks265_ctx *c)
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->err_host) (void)hipHostFree(c->err_host);
     delete c;
 }
 
@@ -47,7 +51,22 @@ int ks265_set_stream(ks265_ctx *c, void *s)
 int ks265_synchronize(ks265_ctx *c)
 {
     if (!c) return KS265_POINTER;
-    return ks265_hip(c, hipStreamSynchronize(c->stream));
+    int r = ks265_hip(c, hipStreamSynchronize(c->stream));
+    if (r) return r;
+    const unsigned e = __atomic_exchange_n(c->err_host, 0u, __ATOMIC_ACQ_REL);      // kernels OR bits in; report once, then clear
+    if (e) {
+        c->last_error = (e & KS_DEVERR_WAVEFRONT_TIMEOUT) ? "intra wavefront timeout: a CTU row waited too long for the row above; the key picture is invalid, re-encode it"
+                                                          : "device-side error flag set";
+        return KS265_FAIL;
+    }
+    return KS265_OK;
+}
+
+int ks265_debug_set(ks265_ctx *c, int what, int value)
+{
+    if (!c) return KS265_POINTER;
+    if (what == KS265_DBG_WAVEFRONT_SPINS) { c->wavefront_spin_limit = value < 0 ? (1 << 22) : value; return KS265_OK; }
+    return KS265_NOTSUPPORTED;
 }
 
 int ks265_marker(ks265_ctx *c, int id)

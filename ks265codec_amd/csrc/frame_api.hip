@@ -24,10 +24,11 @@ int ks265_frame_create(ks265_ctx *ctx, const ks265_frame_cfg *cfg, ks265_frame *
     int r = ks265_frame_geometry(cfg, &geom);
     if (r) return r;
     if (cfg->me_method < 0 || cfg->me_method > 2) return KS265_NOTSUPPORTED;   /* 0 = DIA, 1 = HEX, 2 = UMH (-me); EPZS / Cross not built */
-    ks265_frame *f = new ks265_frame();
+    if (cfg->refs > 4) return KS265_NOTSUPPORTED;
+    if ((long long)16 * geom.bytes_y >= (1ll << 32)) return KS265_NOTSUPPORTED;   /* stage B addresses the 16 planes with 32-bit offsets (8K = 0.6 GB fits) */
+    ks265_frame *f = new ks265_frame();                                            /* every validation above: nothing to undo on those returns */
     f->ctx = ctx; f->cfg = *cfg; f->geom = geom;
     KsGeom &g = f->g;
-    if ((long long)16 * geom.bytes_y >= (1ll << 32)) return KS265_NOTSUPPORTED;   /* stage B addresses the 16 planes with 32-bit offsets (8K = 0.6 GB fits) */
     g.W = cfg->width; g.H = cfg->height; g.sy = geom.stride_y; g.sc = geom.stride_c; g.bytes_y = geom.bytes_y; g.bytes_c = geom.bytes_c;
     g.ctu_cols = geom.ctu_cols; g.ctu_rows = geom.ctu_rows; g.w8 = cfg->width / 8; g.h8 = cfg->height / 8;
     g.org_y = (long)KS_PAD_Y * g.sy + KS_PAD_Y; g.org_c = (long)KS_PAD_C * g.sc + KS_PAD_C;
@@ -40,7 +41,6 @@ int ks265_frame_create(ks265_ctx *ctx, const ks265_frame_cfg *cfg, ks265_frame *
         if (!r) r = dev_alloc(ctx, (void **)&f->pu1, (size_t)geom.bytes_pu, true);
         if (!r) r = dev_alloc(ctx, (void **)&f->pub, (size_t)geom.ctu_cols * geom.ctu_rows * 85 * sizeof(ks265_pu_b), true);
     }
-    if (cfg->refs > 4) { ks265_frame_destroy(f); return KS265_NOTSUPPORTED; }
     for (int x = 0; x + 1 < cfg->refs && !r; ++x) {              /* list-0 pictures 1..refs-1 of multi-reference P pictures */
         r = dev_alloc(ctx, (void **)&f->planes_x[x], (size_t)16 * g.bytes_y, true);
         if (!r) r = dev_alloc(ctx, (void **)&f->pu_x[x], (size_t)geom.bytes_pu, true);

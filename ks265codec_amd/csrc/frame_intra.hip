@@ -186,7 +186,7 @@ __device__ __forceinline__ void tu_pipeline(IntraLds &L, const TuRole &r, const 
 
 __global__ __launch_bounds__(256) void intra_recon_kernel(KsGeom g, int qp, const uint8_t *src_y, const uint8_t *src_u, const uint8_t *src_v, ks265_cu8 *cu8,
                                                           int16_t *lvl_y, int16_t *lvl_u, int16_t *lvl_v, uint8_t *rec_y, uint8_t *rec_u, uint8_t *rec_v,
-                                                          int *progress)
+                                                          int *progress, unsigned *err_word, int spin_limit)
 {
     __shared__ __attribute__((aligned(16))) IntraLds L;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, cy = blockIdx.x;
@@ -206,10 +206,14 @@ __global__ __launch_bounds__(256) void intra_recon_kernel(KsGeom g, int qp, cons
         // wavefront: the row above must be two CTUs ahead (top-right neighbours)
         if (cy > 0 && tid == 0) {
             const int need = min(cx + 2, g.ctu_cols);
-            // bounded: rows are dispatched in order, so the row above is always resident and this never spins long; if it ever did
-            // (a lost launch), give up after ~1 s instead of hanging the GPU - the picture is then wrong, which every parity check sees
-            for (int spins = 0; __hip_atomic_load(progress + cy - 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < need && spins < (1 << 22); ++spins)
+            // bounded: rows are normally dispatched in order, so the row above is resident and this never spins long; if it ever does
+            // (a lost launch, a row that is not resident under heavy multi-stream load), give up after ~1 s instead of hanging the GPU
+            // and SAY SO: the error word makes ks265_synchronize return KS265_FAIL (the picture is invalid and must be re-encoded)
+            int spins = 0;
+            while (__hip_atomic_load(progress + cy - 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < need) {
+                if (spins++ >= spin_limit) { __hip_atomic_fetch_or(err_word, KS_DEVERR_WAVEFRONT_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
                 __builtin_amdgcn_s_sleep(8);
+            }
         }
         __syncthreads();                                             // nobody still walks the previous CTU's map
         if (tid < 64) {
@@ -340,7 +344,7 @@ extern "C" int ks265_intra_reconstruct(ks265_frame *f, ks265_pic src, ks265_cu8 
     if (!src.y || !cu8 || !lvl_y || !lvl_u || !lvl_v || !recon.y) return KS265_POINTER;
     if (hipMemsetAsync(f->progress, 0, sizeof(int) * (size_t)f->g.ctu_rows, f->ctx->stream) != hipSuccess) return ks265_hip(f->ctx, hipGetLastError());
     hipLaunchKernelGGL(intra_recon_kernel, dim3(f->g.ctu_rows), dim3(256), 0, f->ctx->stream, f->g, f->cfg.qp, src.y, src.u, src.v, cu8, lvl_y, lvl_u, lvl_v,
-                       recon.y, recon.u, recon.v, f->progress);
+                       recon.y, recon.u, recon.v, f->progress, f->ctx->err_dev, f->ctx->wavefront_spin_limit);
     return ks265_check_launch(f->ctx);
 }
 

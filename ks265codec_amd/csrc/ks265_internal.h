@@ -12,7 +12,12 @@ struct ks265_ctx {
     bool own_stream = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::string last_error;
+    // device-side error word: pinned, device-mapped host memory that kernels OR error bits into (KS_DEVERR_*); ks265_synchronize
+    // reads and clears it after the stream has drained and turns a set bit into KS265_FAIL
+    unsigned *err_host = nullptr, *err_dev = nullptr;
+    int wavefront_spin_limit = 1 << 22;          // ks265_debug_set(KS265_DBG_WAVEFRONT_SPINS): test hook for the timeout path
 };
+#define KS_DEVERR_WAVEFRONT_TIMEOUT 1u           // intra wavefront: the CTU row above did not make progress in time
 
 // record a HIP error (if any) from the launch just issued; kernels are asynchronous, so this only
 // catches launch-configuration errors — execution errors surface at ks265_synchronize()

@@ -18,11 +18,13 @@ def shard_gops(n_frames: int, iper: int, world: int, rank: int) -> list[tuple[in
 
 
 def coding_order(bframes: int, iper: int) -> Iterator[tuple[int, str]]:
-    """(display index, kind) in coding order: I, then per mini-GOP the anchor followed by its B pictures"""
+    """(display index, kind) in coding order: I, then per mini-GOP the anchor followed by its B pictures.  A key picture falls on EVERY
+    multiple of iper: when iper is not a multiple of bframes + 1 the mini-GOP in front of the boundary is shortened (-iper 128
+    -bframes 2 -> ... 126 P, 128 I with one B picture in between), never skipped."""
     d = 0
     yield d, "I"
     while True:
-        a = d + bframes + 1
+        a = min(d + bframes + 1, (d // iper + 1) * iper)
         yield a, ("I" if a % iper == 0 else "P")
         for b in range(d + 1, a):
             yield b, "B"
@@ -35,6 +37,7 @@ def hier_order(gop_size: int, iper: int) -> Iterator[tuple[int, str, int | None,
     references, all already coded.  Per mini-GOP: the anchor (layer 0), then the middle B picture of every open interval, breadth
     first - GOP 8: 8, 4, 2, 6, 1, 3, 5, 7.  B pictures of all layers but the last are themselves references (B-ref)."""
     assert gop_size >= 1 and gop_size & (gop_size - 1) == 0, "power of two"
+    assert iper % gop_size == 0, "key pictures must fall on mini-GOP boundaries (iper % gop_size == 0)"
     yield 0, "I", None, None, 0
     d = 0
     while True:

@@ -48,7 +48,7 @@ _lib = None
 # every symbol include/ks265_hip.h declares (checked by tests/test_abi.py against the header text)
 EXPORTS = [
     "ks265_create", "ks265_destroy", "ks265_set_stream", "ks265_synchronize", "ks265_last_error", "ks265_version",
-    "ks265_timer_start", "ks265_timer_stop_ms", "ks265_marker",
+    "ks265_timer_start", "ks265_timer_stop_ms", "ks265_marker", "ks265_debug_set",
     "ks265_sad_batch", "ks265_sad4_batch", "ks265_sad3_batch", "ks265_sad4blk_8x8_batch", "ks265_sse_batch", "ks265_had_batch",
     "ks265_residual_batch", "ks265_fwd_transform_batch", "ks265_quant_batch", "ks265_dequant_batch", "ks265_inv_transform_batch",
     "ks265_edge_filter_luma_batch", "ks265_edge_filter_chroma_batch", "ks265_interp_rect",
@@ -132,6 +132,9 @@ class KsContext:
 
     def sync(self):
         self._chk(self.lib.ks265_synchronize(self.h))
+
+    def debug_set(self, what: int, value: int):
+        self._chk(self.lib.ks265_debug_set(self.h, C.c_int(what), C.c_int(value)))
 
     def marker(self, ident: int = 0):
         self._chk(self.lib.ks265_marker(self.h, C.c_int(ident)))

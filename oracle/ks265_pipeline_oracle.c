@@ -25,8 +25,8 @@ int kso_frame_geometry(const kso_frame_cfg *cfg, kso_frame_geom *g)
     g->stride_c = align_up(cfg->width / 2 + 2 * PAD_C, 64);
     g->rows_y = cfg->height + 2 * PAD_Y;
     g->rows_c = cfg->height / 2 + 2 * PAD_C;
-    g->bytes_y = (int64_t)g->stride_y * g->rows_y;
-    g->bytes_c = (int64_t)g->stride_c * g->rows_c;
+    g->bytes_y = (int64_t)g->stride_y * (g->rows_y + 1);   /* one slack row: window / tile loads of the last padded row may run up to 64 bytes past it */
+    g->bytes_c = (int64_t)g->stride_c * (g->rows_c + 1);
     g->ctu_cols = (cfg->width + 63) / 64;
     g->ctu_rows = (cfg->height + 63) / 64;
     g->pu_per_ctu = 85;

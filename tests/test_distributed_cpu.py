@@ -6,6 +6,7 @@
 The per-rank work here is the CPU oracle (no GPU in this container); the scheduling code (ks265codec_amd/gop.py) is the one bench.py runs."""
 from __future__ import annotations
 
+import itertools
 import os
 import sys
 
@@ -143,6 +144,12 @@ def test_schedules_cover_everything():
         assert sorted(b_owner(j, world) for j in range(7)) == sorted([0] * 7 if world == 1 else [1 + j % (world - 1) for j in range(7)])
     it = coding_order(3, 8)
     assert [next(it) for _ in range(10)] == [(0, "I"), (4, "P"), (1, "B"), (2, "B"), (3, "B"), (8, "I"), (5, "B"), (6, "B"), (7, "B"), (12, "P")]
+    # iper not a multiple of bframes + 1 -> the mini-GOP before the boundary is shortened, a key picture on EVERY multiple of iper
+    seq = list(itertools.islice(coding_order(2, 8), 40))
+    assert sorted(d for d, _ in seq) == list(range(len(seq))) or sorted(d for d, _ in seq)[:30] == list(range(30))
+    keys = [d for d, k in seq if k == "I"]
+    assert keys[:4] == [0, 8, 16, 24], keys
+    assert [x for x in seq[:8]] == [(0, "I"), (3, "P"), (1, "B"), (2, "B"), (6, "P"), (4, "B"), (5, "B"), (8, "I")]
 
 
 def test_hierarchical_b_order_is_decodable():

@@ -1,0 +1,210 @@
+"""GPU parity on the configurations BASELINE.json names (VERDICT r1 "configs_untested"): what bench.py times is what is checked.
+
+  config 1  1280x720  veryfast (-me 1 HEX, qp 32)          -> test_config1_720p_hex_qp32
+  config 2  1920x1080 slow (-me 2 UMH, qp 27)              -> test_config2_1080p_umh
+  config 3  3840x2160 slow (-me 2 UMH, qp 27) = bench.py   -> test_config3_2160p_umh (2 pictures vs the OpenMP oracle)
+  config 4  -bframes 3 pixel path with UMH at 720p         -> test_config4_bframes3_umh_720p
+  bounded randomised sweep (40 configurations) collected by pytest, log kept under gpurun_out/ -> test_fuzz_bounded
+"""
+from __future__ import annotations
+
+import itertools
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ks():
+    from ks265codec_amd.lib import KsContext
+    c = KsContext(0)
+    yield c
+    c.close()
+
+
+def _ippp(ks, W, H, qp, me, nfr, seed, abc=(37, 53, 19), pan=(5, 3), hidden_offset=True):
+    from ks265codec_amd.lib import KsFrame
+    from ks265codec_amd.synth import lambda_q4, make_clip, psnr
+    from oracle_lib import OraclePipeline
+
+    clip = make_clip(W, H, nfr, seed=seed, abc=abc, pan=pan)
+    o = OraclePipeline(W, H, qp, lambda_q4(qp), me_method=me)
+    with KsFrame(ks, W, H, qp, lambda_q4(qp), me_method=me) as f:
+        src, a, b = f.new_pic(), f.new_pic(), f.new_pic()
+        for t in range(nfr):
+            q = qp + (1 if (t > 0 and hidden_offset) else 0)          # the reference's hidden hierarchy offset: I = Q, P = Q+1
+            o.set_qp(q, lambda_q4(q)); f.set_qp(q, lambda_q4(q))
+            exp = o.encode_picture(clip[t], t == 0)
+            f.load_i420(ks.dev(clip[t]), src)
+            f.encode_picture(src, a, t == 0, b)
+            got = ks.host(f.store_i420(b), np.uint8)
+            assert (got == exp).all(), f"{W}x{H} me={me} qp={q} picture {t}: {int((got != exp).sum())} recon bytes differ"
+            assert psnr(clip[t][:W * H], got[:W * H]) > 28.0
+            a, b = b, a
+
+
+def test_config1_720p_hex_qp32(ks):
+    _ippp(ks, 1280, 720, 32, 1, 3, seed=43)
+
+
+def test_config2_1080p_umh(ks):
+    _ippp(ks, 1920, 1080, 27, 2, 3, seed=42)
+
+
+def test_config3_2160p_umh(ks):
+    """the exact bench workload (3840x2160, UMH, qp 27/28, deblock + SAO): key picture + one P picture against the OpenMP oracle"""
+    _ippp(ks, 3840, 2160, 27, 2, 2, seed=7, abc=(67, 91, 33), pan=(8, 5))
+
+
+def test_config4_bframes3_umh_720p(ks):
+    """-bframes 3 with UMH: coding order I0 P4 B1 B2 B3 P8 B5 B6 B7 through ks265_encode_picture_b"""
+    from ks265codec_amd.gop import coding_order
+    from ks265codec_amd.lib import KsFrame
+    from ks265codec_amd.synth import lambda_q4, make_clip
+    from oracle_lib import OraclePipeline
+
+    W, H = 1280, 720
+    clip = make_clip(W, H, 9, seed=44)
+    o = OraclePipeline(W, H, 27, lambda_q4(27), me_method=2)
+    with KsFrame(ks, W, H, 27, lambda_q4(27), me_method=2, bframes=3) as f:
+        src = f.new_pic()
+        dg, do = {}, {}
+        prev_anchor = {}
+        last = None
+        for d, kind in itertools.islice(coding_order(3, 128), 9):
+            if kind == "B":
+                r0, r1 = prev_anchor[last], last
+            else:
+                r0, r1 = last, None
+                prev_anchor[d], last = last, d
+            q = {"I": 27, "P": 28, "B": 30}[kind]
+            o.set_qp(q, lambda_q4(q)); f.set_qp(q, lambda_q4(q))
+            do[d] = o.encode(clip[d], kind, do.get(r0), do.get(r1))
+            f.load_i420(ks.dev(clip[d]), src)
+            out = f.new_pic()
+            if kind == "B":
+                f.encode_picture_b(src, dg[r0], dg[r1], out)
+            else:
+                f.encode_picture(src, dg[r0] if r0 is not None else out, kind == "I", out)
+            dg[d] = out
+            got, exp = ks.host(f.store_i420(out), np.uint8), o.store(do[d])
+            assert (got == exp).all(), f"picture {d} ({kind}): {int((got != exp).sum())} bytes differ"
+
+
+def test_full_size_properties_2160p_umh(ks):
+    """3840x2160 with the bench's search method: run-to-run determinism and PSNR sanity over a 4-picture GOP head"""
+    from ks265codec_amd.lib import KsFrame
+    from ks265codec_amd.synth import lambda_q4, make_clip, psnr
+
+    W, H = 3840, 2160
+    clip = make_clip(W, H, 4, seed=7, abc=(67, 91, 33), pan=(8, 5))
+    outs = []
+    for rep in range(2):
+        with KsFrame(ks, W, H, 27, lambda_q4(27), me_method=2) as f:
+            src, a, b = f.new_pic(), f.new_pic(), f.new_pic()
+            recs = []
+            for t in range(4):
+                q = 27 + (t > 0)
+                f.set_qp(q, lambda_q4(q))
+                f.load_i420(ks.dev(clip[t]), src)
+                f.encode_picture(src, a, t == 0, b)
+                recs.append(ks.host(f.store_i420(b), np.uint8))
+                a, b = b, a
+            outs.append(recs)
+    for t in range(4):
+        assert (outs[0][t] == outs[1][t]).all(), f"picture {t} not deterministic"
+        assert psnr(clip[t][:W * H], outs[0][t][:W * H]) > 31.0
+
+
+def test_fuzz_bounded(ks):
+    """40 random configurations (sizes 8..472 x 8..312, QP 0..51, DIA/HEX/UMH, range, sub-pel / deblock / SAO switches, IPPP / multi-reference /
+    hierarchical B): every reconstructed picture equals the oracle's.  The per-case log is written to gpurun_out/fuzz_bounded.log."""
+    from ks265codec_amd.gop import hier_order
+    from ks265codec_amd.lib import KsFrame
+    from ks265codec_amd.synth import lambda_q4, make_clip
+    from oracle_lib import OraclePipeline
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+    log = open(os.path.join(root, "gpurun_out", "fuzz_bounded.log"), "w")
+    rng = np.random.default_rng(20260927)
+    fails = []
+    for it in range(40):
+        W, H = int(rng.integers(1, 60)) * 8, int(rng.integers(1, 40)) * 8
+        qp, me = int(rng.integers(0, 52)), int(rng.integers(0, 3))
+        kw = dict(me_range=int(rng.choice([8, 16, 32, 64])), subme=int(rng.integers(0, 2)), deblock=int(rng.integers(0, 2)), sao=int(rng.integers(0, 2)), me_method=me)
+        mode = str(rng.choice(["ippp", "mref", "hier"]))
+        clip = make_clip(W, H, 9, seed=int(rng.integers(0, 10000)), noisy=bool(rng.integers(0, 2)))
+        o = OraclePipeline(W, H, qp, lambda_q4(qp), **kw)
+        tag = f"{it} {W}x{H} qp{qp} {kw} {mode}"
+        try:
+            with KsFrame(ks, W, H, qp, lambda_q4(qp), bframes=3, refs=3, **kw) as f:
+                src = f.new_pic()
+                if mode == "hier":
+                    G = 4
+                    dg, do = [f.new_pic() for _ in range(G + 1)], {}
+                    for d, kind, r0, r1, layer in itertools.islice(hier_order(G, 128), 2 * G + 1):
+                        q = min(51, qp if kind == "I" else qp + 1 + layer)
+                        o.set_qp(q, lambda_q4(q)); f.set_qp(q, lambda_q4(q))
+                        do[d] = o.encode(clip[d], kind, do.get(r0), do.get(r1))
+                        f.load_i420(ks.dev(clip[d]), src)
+                        out = dg[d % (G + 1)]
+                        if kind == "B":
+                            f.encode_picture_b(src, dg[r0 % (G + 1)], dg[r1 % (G + 1)], out)
+                        else:
+                            f.encode_picture(src, dg[r0 % (G + 1)] if r0 is not None else out, kind == "I", out)
+                        got, exp = ks.host(f.store_i420(out), np.uint8), o.store(do[d])
+                        assert (got == exp).all(), (d, kind, int((got != exp).sum()))
+                else:
+                    dpo, dpg = [], []
+                    for t in range(6):
+                        f.load_i420(ks.dev(clip[t]), src)
+                        out = f.new_pic()
+                        if t == 0:
+                            eo = o.encode(clip[0], "I"); f.encode_picture(src, out, True, out)
+                        elif mode == "mref":
+                            eo = o.encode_mref(clip[t], dpo[:3]); f.encode_picture_mref(src, dpg[:3], out)
+                        else:
+                            eo = o.encode(clip[t], "P", dpo[0]); f.encode_picture(src, dpg[0], False, out)
+                        got, exp = ks.host(f.store_i420(out), np.uint8), o.store(eo)
+                        assert (got == exp).all(), (t, int((got != exp).sum()))
+                        dpo.insert(0, eo); dpg.insert(0, out)
+            log.write("ok   " + tag + "\n")
+        except AssertionError as e:
+            fails.append(tag)
+            log.write(f"FAIL {tag} {e}\n")
+        log.flush()
+    log.write(f"failures {len(fails)} of 40\n")
+    log.close()
+    assert not fails, fails
+
+
+def test_wavefront_timeout_is_reported(ks):
+    """the intra wavefront's bounded wait must not time out silently.  With the poll budget forced to 0 every CTU row
+    below the first gives up at once -> the device error word is set, ks265_synchronize returns KS265_FAIL and names the condition; after
+    restoring the budget the same picture encodes correctly again (== oracle)."""
+    from ks265codec_amd.lib import KsFrame, Ks265Error
+    from ks265codec_amd.synth import lambda_q4, make_clip
+    from oracle_lib import OraclePipeline
+
+    W, H = 416, 240
+    clip = make_clip(W, H, 1, seed=3)
+    exp = OraclePipeline(W, H, 30, lambda_q4(30)).encode_picture(clip[0], True)
+    with KsFrame(ks, W, H, 30, lambda_q4(30)) as f:
+        src, out = f.new_pic(), f.new_pic()
+        f.load_i420(ks.dev(clip[0]), src)
+        ks.sync()
+        ks.debug_set(1, 0)
+        try:
+            f.encode_picture(src, out, True, out)
+            with pytest.raises(Ks265Error, match="wavefront"):
+                ks.sync()
+        finally:
+            ks.debug_set(1, -1)
+        ks.sync()                                    # the error word was cleared by the failing call
+        f.encode_picture(src, out, True, out)
+        ks.sync()
+        assert (ks.host(f.store_i420(out), np.uint8) == exp).all()

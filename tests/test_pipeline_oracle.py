@@ -49,11 +49,11 @@ def test_planes_equal_blockwise_interpolation():
     """plane[fy*4+fx] must equal the pinned block interpolators applied at an arbitrary block"""
     clip, o, _ = _run(128, 72, 2)
     g, ol = o.geom, lib()
-    P = o.planes.reshape(16, g.rows_y, g.stride_y)
+    P = o.planes.reshape(16, -1, g.stride_y)[:, :g.rows_y]
     # o.planes were built from the reference of picture 1 = reconstruction of picture 0: rebuild that picture
     o2 = OraclePipeline(128, 72, 27, lambda_q4(27))
     o2.encode_picture(clip[0], True)
-    R = o2.ref.y.reshape(g.rows_y, g.stride_y)
+    R = o2.ref.y.reshape(-1, g.stride_y)[:g.rows_y]
     x0, y0, w, h = 37, 11, 24, 16
     for fy in range(4):
         for fx in range(4):
@@ -79,7 +79,7 @@ def test_padding_is_idempotent_and_replicates_edges():
     before = o.ref.y.copy()
     o.o.kso_pad_picture(C.byref(o.cfg), o.ref.c())
     assert (before == o.ref.y).all()
-    Y = o.ref.y.reshape(g.rows_y, g.stride_y)
+    Y = o.ref.y.reshape(-1, g.stride_y)[:g.rows_y]
     assert (Y[:g.pad_y, g.pad_y:g.pad_y + 64] == Y[g.pad_y, g.pad_y:g.pad_y + 64]).all()
     assert (Y[g.pad_y:g.pad_y + 40, :g.pad_y] == Y[g.pad_y:g.pad_y + 40, g.pad_y:g.pad_y + 1]).all()
 
@@ -89,8 +89,8 @@ def test_levels_reproduce_the_reconstruction():
     clip, o, _ = _run(128, 72, 2)
     W, H, g, ol = 128, 72, o.geom, lib()
     cu = o.cu8.reshape(H // 8, W // 8)
-    P = o.planes.reshape(16, g.rows_y, g.stride_y)
-    rec = o.rec_pre[0].reshape(g.rows_y, g.stride_y)
+    P = o.planes.reshape(16, -1, g.stride_y)[:, :g.rows_y]
+    rec = o.rec_pre[0].reshape(-1, g.stride_y)[:g.rows_y]
     lv = o.lvl[0].reshape(H, W)
     qp = o.cfg.qp
     inv = [40, 45, 51, 57, 64, 72]
