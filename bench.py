@@ -50,6 +50,8 @@ def main():
     ap.add_argument("--iper", type=int, default=128)
     ap.add_argument("--clip-frames", type=int, default=5)
     ap.add_argument("--me", choices=["dia", "hex", "umh"], default="umh", help="integer search: -preset slow resolves to -me 2 (UMH), SURVEY.md §5")
+    ap.add_argument("--me-hex-thr", type=int, default=16, help="tME+0x368 of the reference: with -me 2 a PU whose start-point SAD is below this many units per sample runs "
+                    "interMeHex instead of interMeUMH; -preset slow resolves to 16, veryslow to 0 (always UMH)")
     ap.add_argument("--bframes", type=int, default=0, help="-bframes: B pictures between anchors (coding order P b b b); 0 = IPPP")
     ap.add_argument("--b-spread", action="store_true", help="config-5 style: anchor chain on rank 0, RCCL broadcast of every reconstructed anchor, "
                     "B pictures dealt to the other ranks (needs --bframes > 0); default = one GOP shard per rank, no collective")
@@ -96,7 +98,7 @@ def main():
         tstream = None if sidx == 0 else torch.cuda.Stream(device=dev_index)
         with (torch.cuda.stream(tstream) if tstream is not None else contextlib.nullcontext()):
             ks = KsContext(dev_index)
-            fr = KsFrame(ks, W, H, qp, lambda_q4(qp), me_method=me_method, bframes=max(args.bframes, args.hier_b - 1 if args.hier_b else 0), refs=max(1, args.refs))
+            fr = KsFrame(ks, W, H, qp, lambda_q4(qp), me_method=me_method, me_hex_thr=(args.me_hex_thr if me_method == 2 else 0), bframes=max(args.bframes, args.hier_b - 1 if args.hier_b else 0), refs=max(1, args.refs))
             # synthetic clip of SURVEY.md §8(d), one GOP shard per stream (different seed per shard = different content)
             clip = make_clip(W, H, args.clip_frames, seed=7 + (0 if args.b_spread else rank * nstreams + sidx), abc=(67, 91, 33), pan=(8, 5))
             dev_clip = [ks.dev(c) for c in clip]
@@ -311,7 +313,7 @@ def main():
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             from oracle_lib import OraclePipeline
-            o = OraclePipeline(W, H, qp, lambda_q4(qp), me_method=me_method)
+            o = OraclePipeline(W, H, qp, lambda_q4(qp), me_method=me_method, me_hex_thr=(args.me_hex_thr if me_method == 2 else 0))
             nbase = 3
             tc0 = time.perf_counter()
             if args.bframes == 0:
@@ -342,7 +344,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{W}x{H} 4:2:0 8-bit, hot path only (ME + transform/quant/recon + deblock + SAO; CABAC/RC not included), "
-                                   f"-rc 0 -qp {qp} (I=Q, P=Q+1, B=Q+2) -iper {args.iper}, -bframes {bf_desc}, -ref {max(1, args.refs)} -ref0 {max(1, args.refs)} ({'one reference picture per list' if args.refs <= 1 else 'every P picture searches that many list-0 pictures'}), -me {me_method} ({args.me.upper()}) range 64, subme=8 hpel + 8 qpel SATD, sao on, df on",
+                                   f"-rc 0 -qp {qp} (I=Q, P=Q+1, B=Q+2) -iper {args.iper}, -bframes {bf_desc}, -ref {max(1, args.refs)} -ref0 {max(1, args.refs)} ({'one reference picture per list' if args.refs <= 1 else 'every P picture searches that many list-0 pictures'}), -me {me_method} ({args.me.upper()}{', interMeHex below ' + str(args.me_hex_thr) + ' SAD/sample as at -preset slow' if me_method == 2 and args.me_hex_thr else ''}) range 64, subme=8 hpel + 8 qpel SATD, sao on, df on",
                        "pictures_per_step": nstreams, "streams_per_gpu": nstreams,
                        "key_picture_ms": {"intra_decide": key_ms.get("cu_decide"), "intra_reconstruct": key_ms.get("reconstruct"), "total": round(sum(key_ms.values()), 3),
                                           "note": f"one intra picture per -iper {args.iper} pictures; it is in the timed region whenever the schedule puts one there"},

@@ -167,13 +167,15 @@ typedef struct {
                                   hidden hierarchy offset, SURVEY.md §5: I = Q, P = Q+1)          */
     int32_t lambda_q4;         /* motion lambda in Q4 fixed point (host-side float setup only)     */
     int32_t me_range;          /* integer search range in pels, <= 64 (all presets use 64)         */
-    int32_t me_method;         /* 0 = DIA (interMeDia enc@0x48fbe0, -me 0)                          */
+    int32_t me_method;         /* -me: 0 = DIA (interMeDia enc@0x48fbe0), 1 = HEX (interMeHex enc@0x48fde0), 2 = UMH (interMeUMH enc@0x4907b0) */
     int32_t subme;             /* 0 = integer only, 1 = 8 half-pel + 8 quarter-pel SATD points      */
     int32_t deblock;           /* -df                                                               */
     int32_t sao;               /* -sao: 0 off, >0 BO + EO0..3                                        */
     int32_t beta_offset_div2, tc_offset_div2;
     int32_t bframes;           /* > 0: allocate the second-list workspace (planes, PU records) for B pictures (-bframes) */
     int32_t refs;              /* list-0 reference pictures a P picture may search (-ref / -ref0), 0 or 1 = one, at most 4 */
+    int32_t me_hex_thr;        /* tME+0x368 of motionSearchOneRef enc@0x483f40: with -me 2, a PU whose start-point SAD is below this many units
+                                  per sample runs interMeHex instead of interMeUMH; 16 at -preset slow, 0 (= always UMH) at veryslow */
 } ks265_frame_cfg;
 
 /* geometry of the padded picture buffers the caller allocates (one call, no allocation) */

@@ -12,469 +12,7 @@
 
 using namespace ks265;
 
-#ifndef KS_RING_BATCH
-#define KS_RING_BATCH 8      // hexagon-grid points per batch at levels 2 / 3 (independent reduction chains; the search is latency bound)
-#endif
-#define WIN_XL 80                 // window column 0 is picture x = ctu_x*64 - 80
-#define WIN_YT 65                 // window row 0 is picture y = ctu_y*64 - 65
-#define WIN_W 224                 // loaded bytes per row (x in [-80, 144))
-#define WIN_ROWS 194              // y in [-65, 129)
-#define WIN_STRIDE 228            // 57 dwords (odd): row-per-lane ds_read_b32 is bank-conflict free
-#define FENC_STRIDE 68            // 17 dwords (odd)
-
-__device__ __forceinline__ unsigned lds_u32(const uint8_t *p) { return *(const unsigned *)p; }
-
-// motion predictor (see oracle pu_predictor): nearest valid ancestor's integer MV, else temporal / zero
-__device__ __forceinline__ void pu_predictor(const KsGeom &g, int range, const int *pmv, const ks265_pu *prev_ctu, int cx, int cy, int l, int px,
-                                             int py, int &mx, int &my, bool &root)
-{
-    for (int a = l - 1; a >= 0; --a) {
-        int ax = px >> (l - a), ay = py >> (l - a);
-        if (ks_pu_inside(g, cx, cy, a, ax, ay)) {
-            int v = pmv[ks_pu_index(a, ax, ay)];
-            mx = (int)(short)(v & 0xFFFF); my = v >> 16; root = false;
-            return;
-        }
-    }
-    root = true; mx = 0; my = 0;
-    if (prev_ctu && prev_ctu[0].cost != KS_COST_INVALID) {
-        mx = clip3(-range, range, ((int)prev_ctu[0].mvx + 2) >> 2);
-        my = clip3(-range, range, ((int)prev_ctu[0].mvy + 2) >> 2);
-    }
-}
-
-template <int LEVEL>
-__device__ __forceinline__ void me_level(const KsGeom &g, int cx, int cy, int range, int lam, int method, const uint8_t *win, const uint8_t *fenc, int *pmv,
-                                         unsigned (*comb)[4], const unsigned char *selut, const ks265_pu *prev_ctu, ks265_pu *out_ctu, int tid)
-{
-    constexpr int S = 64 >> LEVEL;
-    constexpr int G = LEVEL <= 1 ? 64 : (LEVEL == 2 ? 16 : 8);     // lanes per PU
-    constexpr int D = LEVEL == 0 ? 16 : (LEVEL == 3 ? 2 : 4);      // dwords (4 pixels) per lane
-    constexpr int NPU = 1 << (2 * LEVEL);
-    constexpr int PER_PASS = 256 / G;
-    for (int pass = 0; pass * PER_PASS < NPU; ++pass) {
-        // level 0 has one PU: all four waves search it as replicas and split the large independent candidate batches (UMH)
-        const int wv = LEVEL == 0 ? (tid >> 6) : 0;
-        const int pu = LEVEL == 0 ? 0 : pass * PER_PASS + tid / G;
-        const bool exists = pu < NPU && (LEVEL != 0 || method == 2 || wv == 0);   // replicas only help the UMH batches
-        const int px = exists ? (pu & ((1 << LEVEL) - 1)) : 0, py = exists ? (pu >> LEVEL) : 0;
-        const int gl = tid % G;
-        const int row = LEVEL == 1 ? (gl & 31) : gl, xoff = LEVEL == 1 ? (gl >> 5) * 16 : 0;
-        const bool valid = exists && ks_pu_inside(g, cx, cy, LEVEL, px, py);
-        if (exists && !valid && gl == 0 && wv == 0) {               // PU not (completely) inside the picture: marked, never searched
-            ks265_pu o; o.mvx = o.mvy = o.mvpx = o.mvpy = 0; o.cost = KS_COST_INVALID; o.dist = KS_COST_INVALID;
-            out_ctu[ks_pu_index(LEVEL, px, py)] = o;
-        }
-        if (!__any(valid)) continue;                                // wave-uniform
-        const int bx0 = px * S + xoff, by0 = py * S + row;          // this lane's segment inside the CTU
-        unsigned f[D];
-#pragma unroll
-        for (int j = 0; j < D; ++j) f[j] = lds_u32(fenc + by0 * FENC_STRIDE + bx0 + 4 * j);
-
-        // rate of an integer vector: lambda x se(v) bits from the LDS table (index = quarter-pel difference + 512; every lane of the
-        // wave evaluates it, so the clz-based formula would cost more than the SAD of an 8x8 PU)
-        auto imv_cost = [&](int x, int y, int ppx, int ppy) -> unsigned {
-            return (unsigned)((lam * ((int)selut[((x - ppx) << 2) + 512] + (int)selut[((y - ppy) << 2) + 512])) >> 4);
-        };
-        int pmx = 0, pmy = 0; bool root = true;
-        if (valid) pu_predictor(g, range, pmv, prev_ctu, cx, cy, LEVEL, px, py, pmx, pmy, root);
-
-        // SAD of this lane's segment at integer displacement (dx, dy), partial (before the group reduction)
-        auto seg_sad = [&](int dx, int dy) -> unsigned {
-            int wx = bx0 + dx + WIN_XL, wy = by0 + dy + WIN_YT;
-            const uint8_t *p = win + wy * WIN_STRIDE + (wx & ~3);
-            unsigned sh = wx & 3, acc = 0, lo = lds_u32(p);
-#pragma unroll
-            for (int j = 0; j < D; ++j) {
-                unsigned hi = lds_u32(p + 4 * (j + 1));
-                acc = sad_u8x4(f[j], align_bytes(hi, lo, sh), acc);
-                lo = hi;
-            }
-            return acc;
-        };
-
-        int mx = pmx, my = pmy;
-        unsigned bcost = group_sum<G>(seg_sad(mx, my)) + imv_cost(mx, my, pmx, pmy);
-        if (__any(valid && root && (pmx | pmy))) {                  // second start candidate: the zero vector
-            unsigned c0 = group_sum<G>(seg_sad(0, 0)) + imv_cost(0, 0, pmx, pmy);
-            if (root && (pmx | pmy) && c0 < bcost) { bcost = c0; mx = 0; my = 0; }
-        }
-        if (method != 0) {
-            const int ext = root ? range : max(range >> 2, 4);     // pattern extent (see oracle): full range for a root PU, a quarter around an inherited vector
-            // Every lane of a PU carries the same (mx, my, bcost); candidates outside +-range cost KS_COST_INF and are read at the
-            // (always valid) origin instead.  Groups that do not take a step keep executing it with en = false.
-            // N candidates at once: the N partial SADs are accumulated first and the N group reductions (DPP / swizzle chains)
-            // are then independent instruction streams the scheduler interleaves - the search is latency bound, not ALU bound
-            auto cost_multi = [&](auto n_tag, const int *xs, const int *ys, unsigned *out) {
-                constexpr int N = decltype(n_tag)::value;
-                unsigned part[N];
-#pragma unroll
-                for (int n = 0; n < N; ++n) {
-                    const bool in = abs(xs[n]) <= range && abs(ys[n]) <= range;
-                    part[n] = seg_sad(in ? xs[n] : 0, in ? ys[n] : 0);
-                }
-#pragma unroll
-                for (int n = 0; n < N; ++n) {
-                    const bool in = abs(xs[n]) <= range && abs(ys[n]) <= range;
-                    const unsigned sd = group_sum<G>(part[n]);
-                    out[n] = in ? sd + imv_cost(in ? xs[n] : 0, in ? ys[n] : 0, pmx, pmy) : 0x07FFFFFFu;
-                }
-            };
-            // Level 0 under UMH: the CTU has ONE 64x64 PU and the work-group four waves.  All four carry the same search state
-            // (replicas); every batch of candidates is dealt out over the waves (each reads the 64x64 window once per candidate
-            // it owns - the search is LDS-bandwidth bound, so four replicas evaluating the same candidate would cost four
-            // times the LDS traffic) and the partial winners are merged through LDS.  The reference's sequential "first
-            // strictly better" scan equals argmin by (cost, scan position), so the merge keeps a scan key next to each cost.
-            const bool coop = LEVEL == 0 && method == 2;
-            auto wave_min = [&](unsigned v) -> unsigned {
-                if (!coop) return v;
-                if ((tid & 63) == 0) comb[wv][0] = v;
-                __syncthreads();
-                const unsigned r = min(min(comb[0][0], comb[1][0]), min(comb[2][0], comb[3][0]));
-                __syncthreads();
-                return r;
-            };
-            auto hx = [](int i) { return (int)((0x01343101u >> (4 * i)) & 15u) - 2; };   // hex2[i][0] + 2 = 1,0,1,3,4,3,1,0
-            auto hy = [](int i) { return (int)((0x20024420u >> (4 * i)) & 15u) - 2; };   // hex2[i][1] + 2 = 0,2,4,4,2,0,0,2
-            // interMeHex enc@0x48fde0 (x264-lineage hexagon search, tables hex2 enc@0x4e52e0 / mod6m1 enc@0x4e52c0) + square refinement
-            auto hex_refine = [&](bool en) {
-                unsigned bc3 = bcost << 3;
-                if (coop) {                                          // directions wv and wv + 4 (the latter only for wv < 2)
-                    const int d0 = wv, d1 = wv + 4;
-                    const int xs[2] = {mx + hx(d0 + 1), d1 < 6 ? mx + hx(d1 + 1) : 1000}, ys[2] = {my + hy(d0 + 1), d1 < 6 ? my + hy(d1 + 1) : 0};
-                    unsigned c2[2];
-                    cost_multi(std::integral_constant<int, 2>{}, xs, ys, c2);
-                    bc3 = min(bc3, (c2[0] << 3) + (unsigned)(d0 + 2));
-                    bc3 = min(bc3, (c2[1] << 3) + (unsigned)(d1 + 2));
-                    bc3 = wave_min(bc3);
-                } else {
-                    int xs[6], ys[6]; unsigned c6[6];
-#pragma unroll
-                    for (int d = 0; d < 6; ++d) { xs[d] = mx + hx(d + 1); ys[d] = my + hy(d + 1); }
-                    cost_multi(std::integral_constant<int, 6>{}, xs, ys, c6);
-#pragma unroll
-                    for (int d = 0; d < 6; ++d) bc3 = min(bc3, (c6[d] << 3) + (unsigned)(d + 2));
-                }
-                bool moving = en && (bc3 & 7);
-                int dir = 0;
-                if (moving) { dir = (int)(bc3 & 7) - 2; mx += hx(dir + 1); my += hy(dir + 1); }
-#pragma unroll 1
-                for (int i = (ext >> 1) - 1; i > 0 && __any(moving); --i) {
-                    unsigned nb = bc3 & ~7u;
-                    if (coop) {                                      // one direction per wave, the fourth wave idles
-                        const int k = wv;
-                        const int xs[1] = {k < 3 ? mx + hx(dir + k) : 1000}, ys[1] = {k < 3 ? my + hy(dir + k) : 0};
-                        unsigned c1[1];
-                        cost_multi(std::integral_constant<int, 1>{}, xs, ys, c1);
-                        nb = wave_min(min(nb, (c1[0] << 3) + (unsigned)(k + 1)));
-                    } else {
-                        int xs[3], ys[3]; unsigned c3[3];
-#pragma unroll
-                        for (int k = 0; k < 3; ++k) { xs[k] = mx + hx(dir + k); ys[k] = my + hy(dir + k); }
-                        cost_multi(std::integral_constant<int, 3>{}, xs, ys, c3);
-#pragma unroll
-                        for (int k = 0; k < 3; ++k) nb = min(nb, (c3[k] << 3) + (unsigned)(k + 1));
-                    }
-                    if (moving) {
-                        bc3 = nb;
-                        if (!(bc3 & 7)) moving = false;
-                        else {
-                            dir += (int)(bc3 & 7) - 2;
-                            dir = (int)((0x05432105u >> (4 * (dir + 1))) & 15u);                  // mod6m1 = 5,0,1,2,3,4,5,0
-                            mx += hx(dir + 1); my += hy(dir + 1);
-                        }
-                    }
-                }
-                unsigned bc4 = (bc3 >> 3) << 4;
-                // square1 = (0,0) (0,-1) (0,1) (-1,0) (1,0) (-1,-1) (-1,1) (1,-1) (1,1)
-                auto sqx = [](int k) { return (int)((0x220020111ull >> (4 * k)) & 15ull) - 1; };
-                auto sqy = [](int k) { return (int)((0x202011201ull >> (4 * k)) & 15ull) - 1; };
-                if (coop) {                                          // square points wv and wv + 4
-                    const int k0 = wv, k1 = wv + 4;
-                    const int xs[2] = {mx + sqx(k0 + 1), mx + sqx(k1 + 1)}, ys[2] = {my + sqy(k0 + 1), my + sqy(k1 + 1)};
-                    unsigned c2[2];
-                    cost_multi(std::integral_constant<int, 2>{}, xs, ys, c2);
-                    bc4 = min(bc4, (c2[0] << 4) + (unsigned)(k0 + 1));
-                    bc4 = min(bc4, (c2[1] << 4) + (unsigned)(k1 + 1));
-                    bc4 = wave_min(bc4);
-                } else {
-                    int xs[8], ys[8]; unsigned c8[8];
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) { xs[k] = mx + sqx(k + 1); ys[k] = my + sqy(k + 1); }
-                    cost_multi(std::integral_constant<int, 8>{}, xs, ys, c8);
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) bc4 = min(bc4, (c8[k] << 4) + (unsigned)(k + 1));
-                }
-                if (en) { mx += sqx((int)(bc4 & 15)); my += sqy((int)(bc4 & 15)); bcost = bc4 >> 4; }
-            };
-            if (method == 1) hex_refine(valid);
-            else {
-                // interMeUMH enc@0x4907b0: x264-lineage uneven multi-hexagon search with the reference's 16-point order
-                // (Big_Hexagon_X/Y enc@0x4e5320/0x4e5300); see oracle search_umh for the step list.
-                // A batch of N candidates is evaluated together and then taken in scan order with the sequential "strictly
-                // better" rule of the reference.  Each candidate carries its scan position (key) so that batches dealt out
-                // over the level-0 replica waves merge to the same winner: argmin by (cost, key), key 0 = the incumbent.
-                unsigned bkey = 0;
-                auto try_k = [&](auto n_tag, const int *xs, const int *ys, const unsigned *keys, bool en) {
-                    constexpr int N = decltype(n_tag)::value;
-                    int ax[N], ay[N]; unsigned cs[N];
-#pragma unroll
-                    for (int n = 0; n < N; ++n) { ax[n] = en ? xs[n] : 0; ay[n] = en ? ys[n] : 0; }
-                    cost_multi(n_tag, ax, ay, cs);
-#pragma unroll
-                    for (int n = 0; n < N; ++n)
-                        if (en && cs[n] < bcost) { bcost = cs[n]; mx = xs[n]; my = ys[n]; bkey = keys[n]; }
-                };
-                auto merge = [&]() {
-                    if (!coop) { bkey = 0; return; }
-                    if ((tid & 63) == 0) { comb[wv][0] = bcost; comb[wv][1] = bkey; comb[wv][2] = (unsigned)mx; comb[wv][3] = (unsigned)my; }
-                    __syncthreads();
-#pragma unroll
-                    for (int w = 0; w < 4; ++w) {
-                        const unsigned c = comb[w][0], k = comb[w][1];
-                        if (c < bcost || (c == bcost && k < bkey)) { bcost = c; bkey = k; mx = (int)comb[w][2]; my = (int)comb[w][3]; }
-                    }
-                    __syncthreads();
-                    bkey = 0;
-                };
-                // N = 4 or 8 candidates around a fixed point; level 0: candidates wv, wv + 4 go to wave wv
-                auto try_multi = [&](auto n_tag, const int *xs, const int *ys, bool en) {
-                    constexpr int N = decltype(n_tag)::value;
-                    if (coop) {
-                        constexpr int M = N / 4;
-                        int ax[M], ay[M]; unsigned keys[M];
-#pragma unroll
-                        for (int m = 0; m < M; ++m) {
-                            ax[m] = wv == 0 ? xs[4 * m] : (wv == 1 ? xs[4 * m + 1] : (wv == 2 ? xs[4 * m + 2] : xs[4 * m + 3]));
-                            ay[m] = wv == 0 ? ys[4 * m] : (wv == 1 ? ys[4 * m + 1] : (wv == 2 ? ys[4 * m + 2] : ys[4 * m + 3]));
-                            keys[m] = (unsigned)(1 + 4 * m + wv);
-                        }
-                        try_k(std::integral_constant<int, M>{}, ax, ay, keys, en);
-                    } else {
-                        unsigned keys[N];
-#pragma unroll
-                        for (int n = 0; n < N; ++n) keys[n] = (unsigned)(n + 1);
-                        try_k(n_tag, xs, ys, keys, en);
-                    }
-                    merge();
-                };
-                auto dia1 = [&](int ox, int oy, bool en) {
-                    if (!__any(en)) return;
-                    const int xs[4] = {ox, ox, ox - 1, ox + 1}, ys[4] = {oy - 1, oy + 1, oy, oy};
-                    try_multi(std::integral_constant<int, 4>{}, xs, ys, en);
-                };
-                // uneven cross around a fixed (ox, oy): +-i along x for odd i in [start, xmax), then along y in [start, ymax); start is
-                // odd for every group.  Four candidates (+i, -i, +(i+2), -(i+2)) per step; level 0 deals the steps out over the waves.
-                auto cross = [&](int ox, int oy, int start, int xmax, int ymax, bool en) {
-                    if (!__any(en)) return;
-                    int it = 0;
-#pragma unroll 1
-                    for (int i = 1; i < xmax; i += 4, ++it) {
-                        if (coop && (it & 3) != wv) continue;
-                        const bool e0 = en && i >= start, e1 = en && i + 2 >= start && i + 2 < xmax;
-                        if (!__any(e0 || e1)) continue;
-                        // a disabled pair is parked on an out-of-range coordinate: it costs KS_COST_INF and can never win
-                        const int xs[4] = {e0 ? ox + i : 1000, e0 ? ox - i : 1000, e1 ? ox + i + 2 : 1000, e1 ? ox - i - 2 : 1000}, ys[4] = {oy, oy, oy, oy};
-                        const unsigned kb = (1u << 24) | ((unsigned)i << 2), keys[4] = {kb, kb + 1, kb + 4, kb + 5};
-                        try_k(std::integral_constant<int, 4>{}, xs, ys, keys, e0 || e1);
-                    }
-#pragma unroll 1
-                    for (int i = 1; i < ymax; i += 4, ++it) {
-                        if (coop && (it & 3) != wv) continue;
-                        const bool e0 = en && i >= start, e1 = en && i + 2 >= start && i + 2 < ymax;
-                        if (!__any(e0 || e1)) continue;
-                        const int xs[4] = {ox, ox, ox, ox}, ys[4] = {e0 ? oy + i : 1000, e0 ? oy - i : 1000, e1 ? oy + i + 2 : 1000, e1 ? oy - i - 2 : 1000};
-                        const unsigned kb = (2u << 24) | ((unsigned)i << 2), keys[4] = {kb, kb + 1, kb + 4, kb + 5};
-                        try_k(std::integral_constant<int, 4>{}, xs, ys, keys, e0 || e1);
-                    }
-                    merge();
-                };
-                auto nib = [](unsigned long long w, int k, int bias) { return (int)((w >> (4 * k)) & 15ull) - bias; };
-                const unsigned area = (unsigned)(S * S), th2000 = 2000u * area / 256u, th500 = 500u * area / 256u;
-                const unsigned ucost1 = bcost;
-                dia1(pmx, pmy, valid);
-                dia1(0, 0, valid && (pmx | pmy));
-                const unsigned ucost2 = bcost;
-                { const int cx0 = mx, cy0 = my; dia1(cx0, cy0, valid && (cx0 | cy0) && ((cx0 - pmx) | (cy0 - pmy))); }
-                int cross_start = bcost == ucost2 ? 3 : 1;
-                int ox = mx, oy = my;
-                bool done = false;
-                const bool et = valid && bcost == ucost2 && bcost < th2000;
-                if (__any(et)) {
-                    // (0,-2) (-1,-1) (1,-1) (-2,0) (2,0) (-1,1) (1,1) (0,2), stored +2
-                    {
-                        int xs[8], ys[8];
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) { xs[k] = ox + nib(0x23140312ull, k, 2); ys[k] = oy + nib(0x43322110ull, k, 2); }
-                        try_multi(std::integral_constant<int, 8>{}, xs, ys, et);
-                    }
-                    done = et && bcost == ucost1 && bcost < th500;
-                    const bool et2 = et && !done && bcost == ucost2;
-                    if (__any(et2)) {
-                        const int r = (ext >> 1) | 1;
-                        cross(ox, oy, 3, r, r, et2);
-                        // (-1,-2) (1,-2) (-2,-1) (2,-1) (-2,1) (2,1) (-1,2) (1,2), stored +2
-                        {
-                            int xs[8], ys[8];
-#pragma unroll
-                            for (int k = 0; k < 8; ++k) { xs[k] = ox + nib(0x31404031ull, k, 2); ys[k] = oy + nib(0x44331100ull, k, 2); }
-                            try_multi(std::integral_constant<int, 8>{}, xs, ys, et2);
-                        }
-                        if (et2) { if (bcost == ucost2) done = true; else cross_start = r + 2; }
-                    }
-                }
-                const bool mainp = valid && !done;
-                if (__any(mainp)) {
-                    // cross, corners and the hexagon grid are evaluated around a FIXED centre: independent candidates
-                    cross(ox, oy, cross_start, ext, ext >> 1, mainp);
-                    {
-                        const int xs[4] = {ox - 2, ox - 2, ox + 2, ox + 2}, ys[4] = {oy - 2, oy + 2, oy - 2, oy + 2};
-                        try_multi(std::integral_constant<int, 4>{}, xs, ys, mainp);
-                    }
-                    ox = mx; oy = my;
-                    // Big_Hexagon: (-4,0)(4,0)(0,-4)(0,4)(-4,-1)(4,1)(-4,1)(4,-1)(-4,-2)(4,2)(-4,2)(4,-2)(-2,-3)(2,3)(-2,3)(2,-3), stored +4
-#pragma unroll 1
-                    for (int i = 1; i <= (range >> 2) && __any(mainp && i <= (ext >> 2)); ++i) {
-                        auto ring = [&](auto n_tag, int j0) {                 // N consecutive points of ring i in one batch
-                            constexpr int N = decltype(n_tag)::value;
-                            int xs[N], ys[N]; unsigned keys[N];
-#pragma unroll
-                            for (int j = 0; j < N; ++j) {
-                                xs[j] = ox + nib(0x6262808080804480ull, j0 + j, 4) * i; ys[j] = oy + nib(0x1771266235538044ull, j0 + j, 4) * i;
-                                keys[j] = (4u << 24) | ((unsigned)i << 4) | (unsigned)(j0 + j);
-                            }
-                            try_k(n_tag, xs, ys, keys, mainp && i <= (ext >> 2));
-                        };
-                        if (coop) ring(std::integral_constant<int, 4>{}, 4 * wv);        // level 0: a quarter of the ring per wave
-                        else if (LEVEL == 1) { ring(std::integral_constant<int, 4>{}, 0); ring(std::integral_constant<int, 4>{}, 4); ring(std::integral_constant<int, 4>{}, 8); ring(std::integral_constant<int, 4>{}, 12); }
-                        else { ring(std::integral_constant<int, KS_RING_BATCH>{}, 0); if (KS_RING_BATCH == 8) ring(std::integral_constant<int, KS_RING_BATCH>{}, 8); }
-                    }
-                    merge();
-                    hex_refine(mainp);
-                }
-            }
-        } else {
-            const int iters = root ? range : max(range >> 2, 1);
-            int it = 0;
-            bool active = valid;
-            bcost <<= 4;
-            while (__any(active)) {
-                // four neighbours; left / right share the centre row reads
-                unsigned s_up = seg_sad(mx, my - 1), s_dn = seg_sad(mx, my + 1), s_lf, s_rt;
-                {
-                    int wx = bx0 + mx - 1 + WIN_XL, wy = by0 + my + WIN_YT;
-                    const uint8_t *p = win + wy * WIN_STRIDE + (wx & ~3);
-                    unsigned sl = wx & 3, sr = sl + 2;                  // right = left + 2 bytes
-                    bool carry = sr >= 4;
-                    sr &= 3;
-                    unsigned q0 = lds_u32(p), q1 = lds_u32(p + 4);
-                    s_lf = 0; s_rt = 0;
-    #pragma unroll
-                    for (int j = 0; j < D; ++j) {
-                        unsigned q2 = lds_u32(p + 4 * (j + 2));
-                        s_lf = sad_u8x4(f[j], align_bytes(q1, q0, sl), s_lf);
-                        s_rt = sad_u8x4(f[j], align_bytes(carry ? q2 : q1, carry ? q1 : q0, sr), s_rt);
-                        q0 = q1; q1 = q2;
-                    }
-                }
-                unsigned c[4] = {group_sum<G>(s_up), group_sum<G>(s_dn), group_sum<G>(s_lf), group_sum<G>(s_rt)};
-                if (active) {
-                    const int dx[4] = {0, 0, -1, 1}, dy[4] = {-1, 1, 0, 0};
-                    const unsigned code[4] = {1, 3, 4, 12};
-    #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        int nx = mx + dx[k], ny = my + dy[k];
-                        if (abs(nx) > range || abs(ny) > range) continue;
-                        unsigned v = (c[k] << 4) + (imv_cost(nx, ny, pmx, pmy) << 4) + code[k];
-                        bcost = min(bcost, v);
-                    }
-                    if (!(bcost & 15)) active = false;
-                    else {
-                        mx -= (int)((int)(bcost << 28) >> 30);
-                        my -= (int)((int)(bcost << 30) >> 30);
-                        bcost &= ~15u;
-                        if (++it >= iters) active = false;
-                    }
-                }
-            }
-            bcost >>= 4;
-        }
-        if (valid && gl == 0 && wv == 0) {
-            int idx = ks_pu_index(LEVEL, px, py);
-            pmv[idx] = (mx & 0xFFFF) | (my << 16);
-            ks265_pu o;
-            o.mvx = (int16_t)(mx << 2); o.mvy = (int16_t)(my << 2); o.mvpx = (int16_t)(pmx << 2); o.mvpy = (int16_t)(pmy << 2);
-            o.cost = bcost; o.dist = bcost - imv_cost(mx, my, pmx, pmy);
-            out_ctu[idx] = o;
-        }
-    }
-}
-
-#ifdef KS_EXP_LEVEL_CLOCK
-__device__ unsigned long long ks_dbg_cycles[4];
-extern "C" void ks265_dbg_cycles(unsigned long long *out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(ks_dbg_cycles), 32); }
-#endif
-template <int METHOD>   // one instantiation per search pattern: DIA keeps its small register footprint (3 workgroups / CU)
-__global__ __launch_bounds__(256, 3) void me_int_kernel(KsGeom g, int range, int lam, const uint8_t *src, const uint8_t *ref, const ks265_pu *prev,
-                                                     ks265_pu *out)
-{
-    __shared__ __attribute__((aligned(16))) uint8_t win[WIN_ROWS * WIN_STRIDE];
-    __shared__ __attribute__((aligned(16))) uint8_t fenc[64 * FENC_STRIDE];
-    __shared__ int pmv[85];
-    __shared__ unsigned comb[4][4];
-    __shared__ unsigned char selut[1032];                 // se(v) bit length, v = index - 512 quarter-pel units
-    constexpr int method = METHOD;
-    const int tid = threadIdx.x, ctu = ks_xcd_swizzle(blockIdx.x, g.ctu_cols * g.ctu_rows), cx = ctu % g.ctu_cols, cy = ctu / g.ctu_cols;
-    const uint8_t *R = ks_org_y(g, ref), *Sp = ks_org_y(g, src);
-    for (int i = threadIdx.x; i < 1025; i += 256) selut[i] = (unsigned char)se_bits(i - 512);
-    // reference window: 16-byte global loads (x0 - 80 is 16-byte aligned), dword LDS stores
-    for (int i = tid; i < WIN_ROWS * (WIN_W / 16); i += 256) {
-        int r = i / (WIN_W / 16), c = i - r * (WIN_W / 16);
-        int yy = min(cy * 64 - WIN_YT + r, g.H + KS_PAD_Y - 1);     // rows past the border are never used by a valid PU
-        uint4 v = *(const uint4 *)(R + (long)yy * g.sy + cx * 64 - WIN_XL + c * 16);
-        unsigned *d = (unsigned *)(win + r * WIN_STRIDE + c * 16);
-        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-    }
-    {
-        int r = tid >> 2, c = tid & 3;
-        uint4 v = *(const uint4 *)(Sp + (long)(cy * 64 + r) * g.sy + cx * 64 + c * 16);
-        unsigned *d = (unsigned *)(fenc + r * FENC_STRIDE + c * 16);
-        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-    }
-    __syncthreads();
-    const ks265_pu *prev_ctu = prev ? prev + (long)ctu * 85 : nullptr;
-    ks265_pu *out_ctu = out + (long)ctu * 85;
-#ifdef KS_EXP_LEVEL_CLOCK
-    long long t0 = __builtin_readcyclecounter();
-#define KS_TICK(i) do { long long t1 = __builtin_readcyclecounter(); if (tid == 0) atomicAdd((unsigned long long *)&ks_dbg_cycles[i], (unsigned long long)(t1 - t0)); t0 = t1; } while (0)
-#else
-#define KS_TICK(i)
-#endif
-    me_level<0>(g, cx, cy, range, lam, method, win, fenc, pmv, comb, selut, prev_ctu, out_ctu, tid);
-    KS_TICK(0);
-    __syncthreads();
-    me_level<1>(g, cx, cy, range, lam, method, win, fenc, pmv, comb, selut, prev_ctu, out_ctu, tid);
-    KS_TICK(1);
-    __syncthreads();
-    me_level<2>(g, cx, cy, range, lam, method, win, fenc, pmv, comb, selut, prev_ctu, out_ctu, tid);
-    KS_TICK(2);
-    __syncthreads();
-    me_level<3>(g, cx, cy, range, lam, method, win, fenc, pmv, comb, selut, prev_ctu, out_ctu, tid);
-    KS_TICK(3);
-}
-
-extern "C" int ks265_me_integer(ks265_frame *f, ks265_pic src, ks265_pic ref, const ks265_pu *prev_pu, ks265_pu *pu)
-{
-    KS_FRAME_CHECK(f);
-    if (!src.y || !ref.y || !pu) return KS265_POINTER;
-    if (f->cfg.me_method < 0 || f->cfg.me_method > 2) return KS265_NOTSUPPORTED;
-    const dim3 grid(f->g.ctu_cols * f->g.ctu_rows), block(256);
-    if (f->cfg.me_method == 0) hipLaunchKernelGGL(me_int_kernel<0>, grid, block, 0, f->ctx->stream, f->g, f->cfg.me_range, f->cfg.lambda_q4, src.y, ref.y, prev_pu, pu);
-    else if (f->cfg.me_method == 1) hipLaunchKernelGGL(me_int_kernel<1>, grid, block, 0, f->ctx->stream, f->g, f->cfg.me_range, f->cfg.lambda_q4, src.y, ref.y, prev_pu, pu);
-    else hipLaunchKernelGGL(me_int_kernel<2>, grid, block, 0, f->ctx->stream, f->g, f->cfg.me_range, f->cfg.lambda_q4, src.y, ref.y, prev_pu, pu);
-    return ks265_check_launch(f->ctx);
-}
-
+#define KS_COST_INF_ME 0x07FFFFFFu
 // ------------------------------------------------------------------ Stage B: sub-pel SATD refinement
 typedef int ks_v4i __attribute__((ext_vector_type(4)));
 

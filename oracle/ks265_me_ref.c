@@ -1,0 +1,245 @@
+/* ks265_me_ref.c — TEST INFRASTRUCTURE (oracle).  CPU restatement of the reference's integer-pel SEARCH CONTROL:
+ *
+ *   interMeDia enc@0x48fbe0, interMeHex enc@0x48fde0, interMeUMH enc@0x4907b0   (h265_codec::interMe*(TPredUnit*, tME*))
+ *
+ * written from the disassembly of /root/reference/ubuntu_x64/appencoder (binary-only SDK; `enc@` = virtual address) and PINNED
+ * against the reference itself: oracle/ref_probe/me_trace_shim.c hooks the three functions inside real `appencoder` runs and records
+ * (source block, reference plane, start point + cost, mvd cost tables, merange, mv limits) -> (best mv, cost, converged flag);
+ * tests/golden/me_search.npz holds those traces and tests/test_me_search.py replays them through the functions below.
+ *
+ * Fields the functions read (offsets found in the disassembly; SURVEY.md Appendix C has the DIA subset):
+ *   TPredUnit: +3 flag "skip the cross stage" (UMH), +5 log2 width, +6 log2 height, +0x38 distortion function (sad_c / had_c signature),
+ *              +0xf8 / +0xfc PU position in the picture, +0x1f1 range shift (DIA)
+ *   tME:       +0x8 reference plane origin, +0x18 / +0x20 p_cost_mvx / p_cost_mvy (u16, indexed by the QUARTER-pel mv = integer mv << 2),
+ *              +0x30 / +0x38 source block + stride, +0x40 pointer to the current best position, +0x50 reference stride,
+ *              +0x54 / +0x56 best mv (integer pel, in: start point), +0x68 merange, +0x6c..0x72 mv_min_x, mv_max_x, mv_min_y, mv_max_y,
+ *              +0x90 best cost (in: cost of the start point), +0x3a8 costs[4], +0x3b8 "converged" flag
+ * Search-pattern tables are rodata of the binary (hex2 enc@0x4e52e0, mod6m1 enc@0x4e52c0, Hexagon enc@0x4e5340, Big_Hexagon_X/Y
+ * enc@0x4e5320 / 0x4e5300); their values were read from the file and are listed below.
+ *
+ * Every candidate evaluation is cost = distortion + cmx[x << 2] + cmy[y << 2]; the packed forms ((cost << 4) + direction code for
+ * the 4-neighbour steps, (cost << 3) + code for the hexagon) make the comparison order irrelevant: ties go to the smaller code.
+ */
+#include <stdint.h>
+#include "ks265_oracle.h"
+#include "ks265_me_ref.h"
+
+static const int8_t kHex2[8][2] = {{-1, -2}, {-2, 0}, {-1, 2}, {1, 2}, {2, 0}, {1, -2}, {-1, -2}, {-2, 0}};
+static const uint8_t kMod6m1[8] = {5, 0, 1, 2, 3, 4, 5, 0};
+static const int8_t kHexagon[6][2] = {{-2, 0}, {2, 0}, {-1, -2}, {1, 2}, {-1, 2}, {1, -2}};
+static const int8_t kBigX[16] = {-4, 4, 0, 0, -4, 4, -4, 4, -4, 4, -4, 4, -2, 2, -2, 2};
+static const int8_t kBigY[16] = {0, 0, -4, 4, -1, 1, 1, -1, -2, 2, 2, -2, -3, 3, 3, -3};
+
+#define W_(m) (1 << (m)->log2w)
+#define H_(m) (1 << (m)->log2h)
+static inline const uint8_t *P(const kso_me *m, int x, int y) { return m->ref0 + (long)y * m->stride + x; }
+static inline uint32_t mvcost(const kso_me *m, int x, int y) { return (uint32_t)m->cmx[x * 4] + m->cmy[y * 4]; }
+static inline int in_range(const kso_me *m, int x, int y) { return x >= m->mv_min_x && x <= m->mv_max_x && y >= m->mv_min_y && y <= m->mv_max_y; }
+static inline uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
+/* availability of a candidate block position (not a reference concept):
+ *   chk 0  everything may be read (the reference itself: its pictures are padded far enough)
+ *   chk 1  trace replay: a read outside the recorded region aborts the replay (oob)
+ *   chk 2  frame pipeline: the GPU stages a window of +-66 samples around the PU; a candidate outside [gx0, gx1] x [gy0, gy1] is
+ *          SKIPPED (never evaluated, never selected).  With mv limits of +-64 only interMeDia, which has no range test, can get there. */
+static inline int avail(kso_me *m, int x, int y)
+{
+    if (!m->chk || (x >= m->gx0 && x <= m->gx1 && y >= m->gy0 && y <= m->gy1)) return 1;
+    if (m->chk == 1) m->oob = 1;
+    return 0;
+}
+#define NOCAND 0xffffffffu
+/* cost of one candidate through the PU's distortion function (TPredUnit+0x38), or NOCAND */
+static inline uint32_t dist_cost(kso_me *m, int x, int y)
+{
+    return avail(m, x, y) ? m->dist(m->fenc, P(m, x, y), m->fstride, m->stride, H_(m), W_(m)) + mvcost(m, x, y) : NOCAND;
+}
+/* cost of one candidate through the SAD tables (g_sad3_Function / g_sad4_Function entries are plain SADs), or NOCAND */
+static inline uint32_t sad_cost(kso_me *m, int x, int y)
+{
+    return avail(m, x, y) ? ks265o_sad(m->fenc, P(m, x, y), m->fstride, m->stride, H_(m), W_(m)) + mvcost(m, x, y) : NOCAND;
+}
+static inline uint32_t pmin(uint32_t b, uint32_t cost, int shift, uint32_t code) { return cost == NOCAND ? b : umin(b, (cost << shift) + code); }
+/* the 4-neighbour step shared by all three functions (one g_sad4_Function call = sad4_c enc@0x47ae90: {up, down, left, right} << 4):
+ * min over the packed candidates, codes 1 up, 3 down, 4 left, 12 right */
+static inline uint32_t diamond_min(kso_me *m, int x, int y, uint32_t b)
+{
+    b = pmin(b, sad_cost(m, x, y - 1), 4, 1);
+    b = pmin(b, sad_cost(m, x, y + 1), 4, 3);
+    b = pmin(b, sad_cost(m, x - 1, y), 4, 4);
+    b = pmin(b, sad_cost(m, x + 1, y), 4, 12);
+    return b;
+}
+#define DX(b) ((int32_t)((uint32_t)(b) << 28) >> 30)      /* bits 2-3 of the code as a signed 2-bit number: the step to SUBTRACT */
+#define DY(b) ((int32_t)((uint32_t)(b) << 30) >> 30)
+
+/* interMeDia enc@0x48fbe0: no mv-range test at all, at most merange >> shift steps */
+void kso_ref_me_dia(kso_me *m)
+{
+    int x = m->mx, y = m->my;
+    uint32_t b = m->cost << 4;
+    const int iters = m->merange >> m->range_shift;
+    for (int i = 0; i < iters; ++i) {
+        b = diamond_min(m, x, y, b);
+        if (!(b & 15)) break;
+        x -= DX(b); y -= DY(b);
+        b &= ~15u;
+    }
+    m->mx = x; m->my = y; m->cost = b >> 4; m->converged = 1;
+}
+
+/* the closing square refinement of interMeHex (enc@0x49044d..0x490718): 4 neighbours through sad4, 4 diagonals through the PU's
+ * distortion function, codes 5 (-1,-1), 7 (-1,+1), 13 (+1,-1), 15 (+1,+1); no range test */
+static void square_refine(kso_me *m, int x, int y, uint32_t bcost)
+{
+    uint32_t b = diamond_min(m, x, y, bcost << 4);
+    b = pmin(b, dist_cost(m, x - 1, y - 1), 4, 5);
+    b = pmin(b, dist_cost(m, x - 1, y + 1), 4, 7);
+    b = pmin(b, dist_cost(m, x + 1, y - 1), 4, 13);
+    b = pmin(b, dist_cost(m, x + 1, y + 1), 4, 15);
+    m->cost = b >> 4;
+    m->mx = x - DX(b); m->my = y - DY(b);
+    m->converged = (DX(b) | DY(b)) == 0;
+}
+
+/* interMeHex enc@0x48fde0: x264's hexagon walk ((cost << 3) + code), then the square refinement.  Differences from x264 that the
+ * disassembly shows: the range test comes AFTER each move (enc@0x490350); a move that leaves [mv_min, mv_max] is undone, the old centre's
+ * cost is recomputed with the PU's distortion function (enc@0x4903d0..0x490446) and the walk stops there. */
+void kso_ref_me_hex(kso_me *m)
+{
+    int x = m->mx, y = m->my;
+    uint32_t b = m->cost << 3;
+    for (int k = 0; k < 6; ++k) {                         /* two sad3 calls: hex2[1..3] codes 2..4, then hex2[4..6] codes 5..7 */
+        const int cx = x + kHex2[k + 1][0], cy = y + kHex2[k + 1][1];
+        b = pmin(b, sad_cost(m, cx, cy), 3, (uint32_t)(k + 2));
+    }
+    if (b & 7) {
+        int dir = (int)(b & 7) - 2;
+        b &= ~7u;
+        x += kHex2[dir + 1][0]; y += kHex2[dir + 1][1];
+        for (int i = (m->merange >> 1) - 1; i > 0; --i) {
+            const int ox = x, oy = y;
+            for (int k = 0; k < 3; ++k) {
+                const int cx = x + kHex2[dir + k][0], cy = y + kHex2[dir + k][1];
+                b = pmin(b, sad_cost(m, cx, cy), 3, (uint32_t)(k + 1));
+            }
+            if (!(b & 7)) break;
+            dir = kMod6m1[dir + (int)(b & 7) - 1];
+            x += kHex2[dir + 1][0]; y += kHex2[dir + 1][1];
+            if (!in_range(m, x, y)) {
+                x = ox; y = oy;
+                b = dist_cost(m, x, y) << 3;                 /* the old centre was evaluated before: always available */
+                break;
+            }
+            b &= ~7u;
+        }
+    }
+    square_refine(m, x, y, b >> 3);
+}
+
+/* one candidate of the UMH stages: range test, full distortion, strict improvement (enc@0x49115d, 0x490a5d, 0x49121f, 0x490e30, ...) */
+static inline int umh_try(kso_me *m, int x, int y)
+{
+    if (!in_range(m, x, y)) return 0;
+    const uint32_t c = dist_cost(m, x, y);
+    if (c >= m->cost) return 0;                                   /* NOCAND never wins */
+    m->cost = c; m->mx = x; m->my = y;
+    return 1;
+}
+
+/* interMeUMH enc@0x4907b0.  Not x264's UMH: a diamond step, two early exits on per-pixel thresholds (62 and 50 per 16 samples), a sparse
+ * cross (step 8, offsets 4, 12, .. 2*merange - 4), the 6-point hexagon, merange/8 rings of the 16-point big hexagon, then either one
+ * diamond step (cost already below the first threshold) or a hexagon walk followed by a diamond walk of at most merange/2 steps. */
+void kso_ref_me_umh(kso_me *m)
+{
+    const uint32_t t1 = 62u << (m->log2w + m->log2h - 4);
+    const uint32_t cost0 = m->cost;
+    {   /* step 1 (enc@0x490884..0x490953): diamond around the start point; the exit below tests the cost BEFORE this step */
+        const uint32_t b = diamond_min(m, m->mx, m->my, cost0 << 4);
+        m->cost = b >> 4; m->mx -= DX(b); m->my -= DY(b);
+        if (t1 > cost0) { m->converged = (DX(b) | DY(b)) == 0; return; }
+    }
+    if (!m->skip_cross && m->cost > (50u << (m->log2w + m->log2h - 4))) {            /* enc@0x490ccb..0x490e21 */
+        const int n = 2 * m->merange - 4, cx = m->mx, cy = m->my;                      /* centre stays fixed */
+        if (n > 3)
+            for (int i = 4; i <= n; i += 8) {
+                umh_try(m, cx + i, cy);
+                umh_try(m, cx - i, cy);
+                umh_try(m, cx, cy + i);
+                umh_try(m, cx, cy - i);
+            }
+    }
+    {   /* enc@0x490968..0x4909cf: 6-point hexagon around the current best (fixed centre) */
+        const int cx = m->mx, cy = m->my;
+        for (int k = 0; k < 6; ++k) umh_try(m, cx + kHexagon[k][0], cy + kHexagon[k][1]);
+    }
+    if (m->merange > 7) {                                                               /* enc@0x4909d1..0x490b46 */
+        const int cx = m->mx, cy = m->my;
+        for (int r = 1; r <= (m->merange >> 3); ++r)
+            for (int k = 0; k < 16; ++k) umh_try(m, cx + r * kBigX[k], cy + r * kBigY[k]);
+    }
+    if (t1 >= m->cost) {                                                                /* enc@0x4915d2: one diamond step and out */
+        const uint32_t b = diamond_min(m, m->mx, m->my, m->cost << 4);
+        m->cost = b >> 4; m->mx -= DX(b); m->my -= DY(b);
+        m->converged = (DX(b) | DY(b)) == 0;
+        return;
+    }
+    {   /* hexagon walk (enc@0x490b5a..0x490cc6): full hexagon, then the three new points in the direction of the last move */
+        int cx = m->mx, cy = m->my, dir = -1;
+        for (int k = 0; k < 6; ++k)
+            if (umh_try(m, cx + kHex2[k][0], cy + kHex2[k][1])) dir = k + 5;
+        if (m->mx != cx || m->my != cy) {
+            for (int it = 1; it < (m->merange >> 1); ++it) {
+                const int d6 = dir % 6;
+                cx = m->mx; cy = m->my; dir = -1;
+                for (int j = d6; j <= d6 + 2; ++j)
+                    if (umh_try(m, cx + kHex2[j][0], cy + kHex2[j][1])) dir = j + 5;
+                if (m->mx == cx && m->my == cy) break;
+            }
+        }
+    }
+    {   /* diamond walk (enc@0x490efa..0x4910ca): at most merange/2 steps; a step that leaves the mv range is TAKEN and ends the walk */
+        int x = m->mx, y = m->my;
+        uint32_t b = m->cost << 4;
+        const int iters = m->merange >> 1;
+        for (int i = 0; i < iters; ++i) {
+            b = diamond_min(m, x, y, b);
+            if (!(b & 15)) break;
+            x -= DX(b); y -= DY(b);
+            b &= ~15u;
+            if (!in_range(m, x, y)) break;
+        }
+        m->mx = x; m->my = y; m->cost = b >> 4; m->converged = 1;
+    }
+}
+
+int kso_me_replay(int method, const uint8_t *fenc, int log2w, int log2h, const uint8_t *plane, int rx0, int ry0, int rw, int rh,
+                  int pux, int puy, const uint16_t *cmx, int xlo, int xhi, const uint16_t *cmy, int ylo, int yhi,
+                  int merange, int range_shift, const int lim[4], int skip_cross, int use_had, int sx, int sy, uint32_t cost0, int32_t out[4])
+{
+    /* the functions index the tables with the quarter-pel mv; the trace holds one entry per integer mv -> expand to stride 4 */
+    static _Thread_local uint16_t tx[4 * 512], ty[4 * 512];
+    if (xhi - xlo >= 512 || yhi - ylo >= 512) return -2;
+    for (int x = xlo; x <= xhi; ++x) tx[4 * (x - xlo)] = cmx[x - xlo];
+    for (int y = ylo; y <= yhi; ++y) ty[4 * (y - ylo)] = cmy[y - ylo];
+    kso_me m = {0};
+    m.fenc = fenc; m.fstride = 1 << log2w;
+    m.ref0 = plane + (long)(puy - ry0) * rw + (pux - rx0); m.stride = rw;
+    m.log2w = log2w; m.log2h = log2h;
+    m.cmx = tx - 4 * xlo; m.cmy = ty - 4 * ylo;
+    m.merange = merange; m.range_shift = range_shift;
+    m.mv_min_x = lim[0]; m.mv_max_x = lim[1]; m.mv_min_y = lim[2]; m.mv_max_y = lim[3];
+    m.skip_cross = skip_cross;
+    m.dist = use_had ? ks265o_had : ks265o_sad;
+    m.mx = sx; m.my = sy; m.cost = cost0;
+    m.chk = 1;
+    m.gx0 = rx0 - pux; m.gx1 = rx0 + rw - (1 << log2w) - pux;
+    m.gy0 = ry0 - puy; m.gy1 = ry0 + rh - (1 << log2h) - puy;
+    if (m.gx0 < xlo + 1) m.gx0 = xlo + 1;                    /* the mv cost of a candidate is read next to its block */
+    if (m.gx1 > xhi - 1) m.gx1 = xhi - 1;
+    if (m.gy0 < ylo + 1) m.gy0 = ylo + 1;
+    if (m.gy1 > yhi - 1) m.gy1 = yhi - 1;
+    if (method == 0) kso_ref_me_dia(&m); else if (method == 1) kso_ref_me_hex(&m); else kso_ref_me_umh(&m);
+    if (m.oob) return -1;
+    out[0] = m.mx; out[1] = m.my; out[2] = (int32_t)m.cost; out[3] = m.converged;
+    return 0;
+}

@@ -1,6 +1,7 @@
 /* ks265_pipeline_oracle.c — TEST INFRASTRUCTURE, NOT PRODUCT CODE (see ks265_pipeline_oracle.h).
  * Whole-frame stages restated on the CPU from the pinned kernels of ks265_oracle.c. */
 #include "ks265_pipeline_oracle.h"
+#include "ks265_me_ref.h"
 #include "ks265_oracle.h"
 #include <stdlib.h>
 #include <string.h>
@@ -155,115 +156,21 @@ static void pu_predictor(const kso_frame_cfg *cfg, const kso_pu *ctu_pu, const k
     }
 }
 
-/* interMeHex enc@0x48fde0: the x264-lineage hexagon search the reference's tables describe (hex2 enc@0x4e52e0,
- * mod6m1 enc@0x4e52c0): full hexagon, then half hexagons that do not overlap the previous one (packed (cost<<3)+dir costs),
- * then the 8-neighbour square refinement.  Candidates outside +-range are never evaluated.  ref0 = reference sample at mv (0,0). */
-#define KSO_COST_INF 0x07FFFFFFu
-static uint32_t hex_cost(const uint8_t *fenc, const uint8_t *ref0, long st, int s, int range, int lam, int pmx, int pmy, int x, int y)
-{
-    if (iabs_(x) > range || iabs_(y) > range) return KSO_COST_INF;
-    return ks265o_sad(fenc, ref0 + (long)y * st + x, st, st, s, s) + (uint32_t)mv_cost(x << 2, y << 2, pmx << 2, pmy << 2, lam);
-}
-static uint32_t search_hex(const uint8_t *fenc, const uint8_t *ref0, long st, int s, int range, int ext, int lam, int pmx, int pmy, int *pmxo, int *pmyo,
-                           uint32_t bcost)
-{
-    static const int hex2[8][2] = {{-1, -2}, {-2, 0}, {-1, 2}, {1, 2}, {2, 0}, {1, -2}, {-1, -2}, {-2, 0}};
-    static const int mod6m1[8] = {5, 0, 1, 2, 3, 4, 5, 0};
-    static const int square1[9][2] = {{0, 0}, {0, -1}, {0, 1}, {-1, 0}, {1, 0}, {-1, -1}, {-1, 1}, {1, -1}, {1, 1}};
-    int bmx = *pmxo, bmy = *pmyo;
-    bcost <<= 3;
-    for (int d = 0; d < 6; ++d) {
-        uint32_t v = (hex_cost(fenc, ref0, st, s, range, lam, pmx, pmy, bmx + hex2[d + 1][0], bmy + hex2[d + 1][1]) << 3) + (uint32_t)(d + 2);
-        if (v < bcost) bcost = v;
-    }
-    if (bcost & 7) {
-        int dir = (int)(bcost & 7) - 2;
-        bmx += hex2[dir + 1][0]; bmy += hex2[dir + 1][1];
-        for (int i = (ext >> 1) - 1; i > 0; --i) {
-            bcost &= ~7u;
-            for (int k = 0; k < 3; ++k) {
-                uint32_t v = (hex_cost(fenc, ref0, st, s, range, lam, pmx, pmy, bmx + hex2[dir + k][0], bmy + hex2[dir + k][1]) << 3) + (uint32_t)(k + 1);
-                if (v < bcost) bcost = v;
-            }
-            if (!(bcost & 7)) break;
-            dir += (int)(bcost & 7) - 2;
-            dir = mod6m1[dir + 1];
-            bmx += hex2[dir + 1][0]; bmy += hex2[dir + 1][1];
-        }
-    }
-    bcost >>= 3;
-    bcost <<= 4;
-    for (int k = 1; k < 9; ++k) {
-        uint32_t v = (hex_cost(fenc, ref0, st, s, range, lam, pmx, pmy, bmx + square1[k][0], bmy + square1[k][1]) << 4) + (uint32_t)k;
-        if (v < bcost) bcost = v;
-    }
-    bmx += square1[bcost & 15][0]; bmy += square1[bcost & 15][1];
-    *pmxo = bmx; *pmyo = bmy;
-    return bcost >> 4;
-}
-
-/* interMeUMH enc@0x4907b0: uneven multi-hexagon search.  The reference's control code is closed; its tables (SURVEY.md B.11:
- * Big_Hexagon_X/Y enc@0x4e5320/0x4e5300, hex2, mod6m1) are those of the x264 lineage it follows, so the published
- * x264 algorithm is restated with the reference's 16-point order: radius-1 diamonds at the predictor / zero / best, early
- * termination (SAD thresholds 2000 / 500 scaled from a 16x16 block to the PU area), uneven cross, 5x5 corners, 16-point hexagon
- * grid at radii 4 .. 4*(ext/4), then the hexagon + square refinement of search_hex.  `ext` = pattern extent, `range` = validity clamp. */
-typedef struct { const uint8_t *fenc, *ref0; long st; int s, range, lam, pmx, pmy; int bmx, bmy; uint32_t bcost; } umh_ctx;
-static void umh_try(umh_ctx *c, int x, int y)
-{
-    uint32_t v = hex_cost(c->fenc, c->ref0, c->st, c->s, c->range, c->lam, c->pmx, c->pmy, x, y);
-    if (v < c->bcost) { c->bcost = v; c->bmx = x; c->bmy = y; }
-}
-static void umh_dia1(umh_ctx *c, int ox, int oy) { umh_try(c, ox, oy - 1); umh_try(c, ox, oy + 1); umh_try(c, ox - 1, oy); umh_try(c, ox + 1, oy); }
-static void umh_cross(umh_ctx *c, int ox, int oy, int start, int xmax, int ymax)
-{
-    for (int i = start; i < xmax; i += 2) { umh_try(c, ox + i, oy); umh_try(c, ox - i, oy); }
-    for (int i = start; i < ymax; i += 2) { umh_try(c, ox, oy + i); umh_try(c, ox, oy - i); }
-}
-static uint32_t search_umh(const uint8_t *fenc, const uint8_t *ref0, long st, int s, int range, int ext, int lam, int pmx, int pmy, int *pmxo, int *pmyo,
-                           uint32_t bcost)
-{
-    static const int bhx[16] = {-4, 4, 0, 0, -4, 4, -4, 4, -4, 4, -4, 4, -2, 2, -2, 2};
-    static const int bhy[16] = {0, 0, -4, 4, -1, 1, 1, -1, -2, 2, 2, -2, -3, 3, 3, -3};
-    umh_ctx c = {fenc, ref0, st, s, range, lam, pmx, pmy, *pmxo, *pmyo, bcost};
-    const uint32_t area = (uint32_t)s * (uint32_t)s;
-    const uint32_t th2000 = 2000u * area / 256u, th500 = 500u * area / 256u;
-    int cross_start = 1, done = 0;
-    uint32_t ucost1 = c.bcost, ucost2;
-    umh_dia1(&c, pmx, pmy);
-    if (pmx | pmy) umh_dia1(&c, 0, 0);
-    ucost2 = c.bcost;
-    if ((c.bmx | c.bmy) && ((c.bmx - pmx) | (c.bmy - pmy))) umh_dia1(&c, c.bmx, c.bmy);
-    if (c.bcost == ucost2) cross_start = 3;
-    int ox = c.bmx, oy = c.bmy;
-    if (c.bcost == ucost2 && c.bcost < th2000) {
-        static const int o8x[8] = {0, -1, 1, -2, 2, -1, 1, 0}, o8y[8] = {-2, -1, -1, 0, 0, 1, 1, 2};
-        for (int k = 0; k < 8; ++k) umh_try(&c, ox + o8x[k], oy + o8y[k]);
-        if (c.bcost == ucost1 && c.bcost < th500) done = 1;
-        else if (c.bcost == ucost2) {
-            int r = (ext >> 1) | 1;
-            static const int o8bx[8] = {-1, 1, -2, 2, -2, 2, -1, 1}, o8by[8] = {-2, -2, -1, -1, 1, 1, 2, 2};
-            umh_cross(&c, ox, oy, 3, r, r);
-            for (int k = 0; k < 8; ++k) umh_try(&c, ox + o8bx[k], oy + o8by[k]);
-            if (c.bcost == ucost2) done = 1;
-            else cross_start = r + 2;
-        }
-    }
-    if (!done) {
-        static const int c4x[4] = {-2, -2, 2, 2}, c4y[4] = {-2, 2, -2, 2};
-        umh_cross(&c, ox, oy, cross_start, ext, ext >> 1);
-        for (int k = 0; k < 4; ++k) umh_try(&c, ox + c4x[k], oy + c4y[k]);
-        ox = c.bmx; oy = c.bmy;
-        for (int i = 1; i <= ext >> 2; ++i)
-            for (int j = 0; j < 16; ++j) umh_try(&c, ox + bhx[j] * i, oy + bhy[j] * i);
-        *pmxo = c.bmx; *pmyo = c.bmy;
-        return search_hex(fenc, ref0, st, s, range, ext, lam, pmx, pmy, pmxo, pmyo, c.bcost);
-    }
-    *pmxo = c.bmx; *pmyo = c.bmy;
-    return c.bcost;
-}
-
-/* ------------------------------------------------------------------ Stage A: integer search
- * interMeDia enc@0x48fbe0 over sad4_c enc@0x47ae90, for every PU of every CTU, coarse to fine. */
+/* ------------------------------------------------------------------ Stage A: integer search (motionSearchOneRef enc@0x483f40)
+ * For every PU of every CTU, coarse to fine.  The search PATTERNS are the reference's own functions, restated in ks265_me_ref.c from the
+ * disassembly and pinned against traces of the reference binary (tests/golden/me_search.npz): interMeDia enc@0x48fbe0 (-me 0),
+ * interMeHex enc@0x48fde0 (-me 1), interMeUMH enc@0x4907b0 (-me 2).  What surrounds them follows motionSearchOneRef as far as a
+ * frame-parallel search can:
+ *   - start point: the predictor (meInitPoint enc@0x48af50 picks the best of the spatial / merge / zero candidates of already coded
+ *     CTUs; here: nearest valid ancestor's vector, for a root PU the co-located vector of the previous picture and the zero vector);
+ *   - mvd cost tables p_cost_mvx / p_cost_mvy = lambda x se-Golomb bits of the quarter-pel difference to the predictor, one u16 table
+ *     per component (createMvdCostTable enc@0x48b850);
+ *   - -me 2 at -preset slow: tME+0x368 = 16 -> a PU whose start-point SAD is below 16 per sample runs interMeHex instead of interMeUMH
+ *     (enc@0x483fe8..0x48400d, 0x484060); cfg->me_hex_thr carries that threshold (0 = always UMH, what -preset veryslow resolves to);
+ *   - merange: the full range for a root PU, a quarter of it (>= 4) around an inherited vector (adaptiveMeSearchRange enc@0x483e70
+ *     shrinks tME+0x68 from the spread of the neighbouring candidates; closed heuristics);
+ *   - mv limits +-me_range around the PU position; candidates further than 66 samples away are skipped (the GPU's staged window). */
+#define ME_TAB 80
 void kso_me_integer(const kso_frame_cfg *cfg, kso_pic src, kso_pic ref, const kso_pu *prev_pu, kso_pu *pu)
 {
     kso_frame_geom g; kso_frame_geometry(cfg, &g);
@@ -283,47 +190,36 @@ void kso_me_integer(const kso_frame_cfg *cfg, kso_pic src, kso_pic ref, const ks
                         if (!pu_inside(cfg, cx, cy, l, px, py)) { memset(o, 0, sizeof *o); o->cost = COST_INVALID; o->dist = COST_INVALID; continue; }
                         int pmx, pmy, root;
                         pu_predictor(cfg, cp, pp, cx, cy, l, px, py, &pmx, &pmy, &root);
-                        const uint8_t *fenc = S + (long)y0 * st + x0;
-                        int mx = pmx, my = pmy;
-                        uint32_t sad = ks265o_sad(fenc, R + (long)(y0 + my) * st + x0 + mx, st, st, s, s);
-                        uint32_t bcost = sad + (uint32_t)mv_cost(mx << 2, my << 2, pmx << 2, pmy << 2, lam);
+                        uint16_t tx[4 * (2 * ME_TAB + 1)], ty[4 * (2 * ME_TAB + 1)];       /* indexed by the quarter-pel mv like the reference's */
+                        for (int v = -ME_TAB; v <= ME_TAB; ++v) {
+                            tx[4 * (v + ME_TAB)] = (uint16_t)((lam * se_bits((v - pmx) << 2)) >> 4);
+                            ty[4 * (v + ME_TAB)] = (uint16_t)((lam * se_bits((v - pmy) << 2)) >> 4);
+                        }
+                        kso_me m;
+                        memset(&m, 0, sizeof m);
+                        m.fenc = S + (long)y0 * st + x0; m.fstride = (int)st;
+                        m.ref0 = R + (long)y0 * st + x0; m.stride = (int)st;
+                        m.log2w = m.log2h = 6 - l;
+                        m.cmx = tx + 4 * ME_TAB; m.cmy = ty + 4 * ME_TAB;
+                        m.merange = root ? range : imax(range >> 2, 4);
+                        m.mv_min_x = m.mv_min_y = -range; m.mv_max_x = m.mv_max_y = range;
+                        m.dist = ks265o_sad;
+                        m.chk = 2; m.gx0 = m.gy0 = -66; m.gx1 = m.gy1 = 66;
+                        m.mx = pmx; m.my = pmy;
+                        uint32_t sad0 = ks265o_sad(m.fenc, m.ref0 + (long)pmy * st + pmx, st, st, s, s);
+                        m.cost = sad0 + m.cmx[4 * pmx] + m.cmy[4 * pmy];
                         if (root && (pmx || pmy)) {            /* second start candidate: the zero vector */
-                            uint32_t s0 = ks265o_sad(fenc, R + (long)y0 * st + x0, st, st, s, s);
-                            uint32_t c0 = s0 + (uint32_t)mv_cost(0, 0, pmx << 2, pmy << 2, lam);
-                            if (c0 < bcost) { bcost = c0; mx = 0; my = 0; }
+                            uint32_t s0 = ks265o_sad(m.fenc, m.ref0, st, st, s, s);
+                            uint32_t c0 = s0 + m.cmx[0] + m.cmy[0];
+                            if (c0 < m.cost) { m.cost = c0; m.mx = 0; m.my = 0; sad0 = s0; }
                         }
-                        /* pattern extent: the full range for a root PU, a quarter of it (>= 4) around an inherited vector
-                         * (the reference shrinks merange per PU: TPredUnit+0x1f1 range shift) */
-                        const int ext = root ? range : imax(range >> 2, 4);
-                        if (cfg->me_method == 1) {
-                            bcost = search_hex(fenc, R + (long)y0 * st + x0, st, s, range, ext, lam, pmx, pmy, &mx, &my, bcost);
-                        } else if (cfg->me_method == 2) {
-                            bcost = search_umh(fenc, R + (long)y0 * st + x0, st, s, range, ext, lam, pmx, pmy, &mx, &my, bcost);
-                        } else {
-                        int iters = root ? range : imax(range >> 2, 1), i = 0;
-                        bcost <<= 4;
-                        do {
-                            uint32_t c[4];
-                            ks265o_sad4(fenc, R + (long)(y0 + my) * st + x0 + mx, st, st, s, c, s);
-                            const int dx[4] = {0, 0, -1, 1}, dy[4] = {-1, 1, 0, 0};
-                            const uint32_t code[4] = {1, 3, 4, 12};
-                            for (int k = 0; k < 4; ++k) {
-                                int nx = mx + dx[k], ny = my + dy[k];
-                                if (iabs_(nx) > range || iabs_(ny) > range) continue;
-                                uint32_t v = c[k] + ((uint32_t)mv_cost(nx << 2, ny << 2, pmx << 2, pmy << 2, lam) << 4) + code[k];
-                                if (v < bcost) bcost = v;
-                            }
-                            if (!(bcost & 15)) break;
-                            mx -= (int)((int32_t)(bcost << 28) >> 30);
-                            my -= (int)((int32_t)(bcost << 30) >> 30);
-                            bcost &= ~15u;
-                        } while (++i < iters);
-                        bcost >>= 4;
-                        }
-                        o->mvx = (int16_t)(mx << 2); o->mvy = (int16_t)(my << 2);
+                        if (cfg->me_method == 0) kso_ref_me_dia(&m);
+                        else if (cfg->me_method == 1 || (cfg->me_hex_thr > 0 && sad0 < ((uint32_t)cfg->me_hex_thr << (2 * (6 - l))))) kso_ref_me_hex(&m);
+                        else kso_ref_me_umh(&m);
+                        o->mvx = (int16_t)(m.mx << 2); o->mvy = (int16_t)(m.my << 2);
                         o->mvpx = (int16_t)(pmx << 2); o->mvpy = (int16_t)(pmy << 2);
-                        o->cost = bcost;
-                        o->dist = bcost - (uint32_t)mv_cost(mx << 2, my << 2, pmx << 2, pmy << 2, lam);
+                        o->cost = m.cost;
+                        o->dist = m.cost - (uint32_t)(m.cmx[4 * m.mx] + m.cmy[4 * m.my]);
                     }
         }
 }
