@@ -29,7 +29,7 @@ using namespace ks265;
 #define WIN_STRIDE 228            // 57 dwords (odd)
 #define FENC_STRIDE 68            // 17 dwords (odd)
 #define ME_WLIM 66                // candidates further than this from the PU position are not staged: skipped (oracle chk = 2)
-#define JOB_CAP 768
+#define JOB_CAP 1024
 
 enum { PH_INIT, PH_DIA, PH_H6, PH_HSTEP, PH_SQUARE, PH_U1, PH_UCROSS, PH_UHEX6, PH_UBIG, PH_UFINAL, PH_UHW0, PH_UHW, PH_UDW, PH_DONE };
 
@@ -58,7 +58,8 @@ __device__ __forceinline__ unsigned mv_rate(int lam, int x, int y, int pmx, int 
 struct MeLds {
     uint8_t win[WIN_ROWS * WIN_STRIDE];
     uint8_t fenc[64 * FENC_STRIDE];
-    unsigned jobs[JOB_CAP];                // pu (6) | key (8) << 6 | (x + 128) << 14 | (y + 128) << 22
+    int4 desc[64];                         // per PU of the level, published by its owner: phase | dir << 8 | merange << 16, best x | y << 16, predictor
+    unsigned short jobs[JOB_CAP];          // stub: owner (6) | candidate index k << 6; 0xFFFF = unused slot
     unsigned long long best[64];           // per PU of the level: (cost << 8 | key) << 32 | (x + 128) << 8 | (y + 128)
     int pred[64];                          // per PU of the level: predictor, x | y << 16
     int pmv[85];                           // integer vectors of the finished PUs (predictors of the next level)
@@ -79,7 +80,7 @@ __device__ __forceinline__ int phase_count(const Owner &o, bool root_zero)
     case PH_H6: case PH_UHEX6: case PH_UHW0: return 6;
     case PH_HSTEP: case PH_UHW: return 3;
     case PH_SQUARE: return 8;
-    case PH_UCROSS: { const int n = 2 * o.merange - 4; return n > 3 ? ((n - 4) / 8 + 1) * 4 : 0; }
+    case PH_UCROSS: return 4 * (o.merange >> 2);                 // i = 4, 12, .. <= 2 * merange - 4: merange >> 2 steps
     case PH_UBIG: return 16 * (o.merange >> 3);
     default: return 0;
     }
@@ -105,7 +106,7 @@ __device__ __forceinline__ bool phase_cand(const Owner &o, int k, int range, int
     case PH_UHEX6: dx = hexagon_x(k); dy = hexagon_y(k); key = k + 1; ranged = true; break;
     case PH_UBIG: { const int r = (k >> 4) + 1, j = k & 15; dx = r * bigx(j); dy = r * bigy(j); key = k + 1; ranged = true; break; }
     case PH_UHW0: dx = hex2x(k); dy = hex2y(k); key = k + 1; ranged = true; break;
-    case PH_UHW: { const int j = o.dir % 6 + k; dx = hex2x(j); dy = hex2y(j); key = k + 1; ranged = true; break; }
+    case PH_UHW: { const int j = o.dir + k; dx = hex2x(j); dy = hex2y(j); key = k + 1; ranged = true; break; }      // dir already reduced mod 6
     default: return false;
     }
     x = o.mx + dx; y = o.my + dy;
@@ -176,50 +177,50 @@ __global__ __launch_bounds__(256, 3) void me_int_kernel(KsGeom g, int range, int
 
 #pragma unroll 1
         for (;;) {
-            // ---- wave 0: every owner counts the eligible candidates of its phase, gets job slots, emits
-            int nj = 0;
+            // ---- wave 0: every pending owner publishes its state, takes phase_count() job slots (a slot = one candidate, eligible or
+            //      not) and fills them with stubs (owner, k); the candidates themselves are expanded by the evaluating lanes
+            bool emitted = false;
             if (tid < 64) {
-                if (o.ph != PH_DONE) {
-                    const int n = phase_count(o, root_zero);
-                    for (int k = 0; k < n; ++k) { int x, y, key; nj += phase_cand(o, k, range, x, y, key) ? 1 : 0; }
-                }
-                int incl = nj;                                                          // inclusive scan over the 64 lanes
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(incl, d); if (lane >= d) incl += v; }
-                const bool fits = incl <= JOB_CAP;                                      // owners that do not fit wait for the next round
-                // slots are handed out in lane order to the owners that fit; an owner that does not fit stops the hand-out for
-                // everybody behind it too (incl is monotonic), so `incl - nj` is this owner's first slot
-                int base = incl - nj;
-                if (o.ph != PH_DONE && fits && nj > 0) {
-                    const int n = phase_count(o, root_zero);
-                    int s = base;
-                    for (int k = 0; k < n; ++k) {
-                        int x, y, key;
-                        if (phase_cand(o, k, range, x, y, key)) L.jobs[s++] = (unsigned)tid | ((unsigned)key << 6) | ((unsigned)(x + 128) << 14) | ((unsigned)(y + 128) << 22);
-                    }
-                    L.best[tid] = o.ph == PH_INIT ? ~0ull : ((unsigned long long)(o.cost << 8) << 32);
-                }
-                const unsigned long long fitmask = __ballot(fits);
-                const int nfit = fitmask == ~0ull ? 64 : __ffsll((unsigned long long)~fitmask) - 1;   // owners [0, nfit) fit
-                const int total = __shfl(incl, max(nfit - 1, 0));
                 const bool pending = o.ph != PH_DONE;
+                const int cnt = pending ? phase_count(o, root_zero) : 0;
+                if (lane == 0) L.njobs = 0;
+                __builtin_amdgcn_wave_barrier();
+                int base = 0;
+                if (cnt > 0) base = atomicAdd(&L.njobs, cnt);                            // slot order is arbitrary: the winner does not depend on it
+                if (cnt > 0) {
+                    emitted = base + cnt <= JOB_CAP;                                     // an owner that does not fit waits for the next round
+                    const int end = min(base + cnt, JOB_CAP);
+                    for (int s = base; s < end; ++s) L.jobs[s] = emitted ? (unsigned short)(tid | ((s - base) << 6)) : (unsigned short)0xFFFF;
+                    if (emitted) {
+                        L.desc[tid] = make_int4(o.ph | (o.dir << 8) | (o.merange << 16), (o.mx & 0xFFFF) | (o.my << 16), (o.pmx & 0xFFFF) | (o.pmy << 16), 0);
+                        L.best[tid] = o.ph == PH_INIT ? ~0ull : ((unsigned long long)(o.cost << 8) << 32);
+                    }
+                }
                 const unsigned long long anyp = __ballot(pending);
-                if (lane == 0) { L.njobs = nfit > 0 ? total : 0; L.active = anyp != 0ull; }
-                if (!(fits && lane < nfit)) nj = -1;                                    // this owner waits
+                if (lane == 0) L.active = anyp != 0ull;
             }
             __syncthreads();
-            const int njobs = L.njobs;
+            const int njobs = min(L.njobs, JOB_CAP);
             if (!L.active) break;
             // ---- all lanes: one lane = one 8x8 tile of one candidate
             const int items = njobs << l2t;
             for (int base = 0; base < items; base += 256) {
                 const int it = base + tid;
-                const bool live = it < items;
-                unsigned sad = 0, job = 0;
+                unsigned sad = 0;
+                int pu = 0, x = 0, y = 0, key = 0;
+                bool live = it < items;
                 if (live) {
-                    job = L.jobs[it >> l2t];
-                    const int pu = job & 63, tile = it & ((1 << l2t) - 1);
-                    const int x = (int)((job >> 14) & 255u) - 128, y = (int)((job >> 22) & 255u) - 128;
+                    const unsigned stub = L.jobs[it >> l2t];
+                    live = stub != 0xFFFFu;
+                    pu = stub & 63;
+                    const int4 d = L.desc[pu];
+                    Owner c;
+                    c.ph = d.x & 255; c.dir = (d.x >> 8) & 255; c.merange = d.x >> 16; c.mx = (int)(short)(d.y & 0xFFFF); c.my = d.y >> 16;
+                    c.pmx = (int)(short)(d.z & 0xFFFF); c.pmy = d.z >> 16;
+                    live = live && phase_cand(c, (int)(stub >> 6), range, x, y, key);
+                }
+                if (live) {
+                    const int tile = it & ((1 << l2t) - 1);
                     const int ppx = pu & ((1 << level) - 1), ppy = pu >> level;
                     const int bx = ppx * S + (tile & (tpr - 1)) * 8, by = ppy * S + (tile >> (3 - level)) * 8;
                     const int wx = bx + x + WIN_XL, wy = by + y + WIN_YT;
@@ -236,29 +237,27 @@ __global__ __launch_bounds__(256, 3) void me_int_kernel(KsGeom g, int range, int
                 }
                 for (int d = (1 << l2t) >> 1; d > 0; d >>= 1) sad += __shfl_xor(sad, d);   // the tiles of a job are adjacent lanes
                 if (live && (it & ((1 << l2t) - 1)) == 0) {
-                    const int pu = job & 63;
-                    const int x = (int)((job >> 14) & 255u) - 128, y = (int)((job >> 22) & 255u) - 128;
                     const int pr = L.pred[pu];
                     const unsigned cost = sad + mv_rate(lam, x, y, (int)(short)(pr & 0xFFFF), pr >> 16);
-                    const unsigned long long v = ((unsigned long long)((cost << 8) | ((job >> 6) & 255u)) << 32) | (unsigned long long)(((unsigned)(x + 128) << 8) | (unsigned)(y + 128));
+                    const unsigned long long v = ((unsigned long long)((cost << 8) | (unsigned)key) << 32) | (unsigned long long)(((unsigned)(x + 128) << 8) | (unsigned)(y + 128));
                     atomicMin(&L.best[pu], v);
                 }
             }
             __syncthreads();
             // ---- owners advance (the transitions of oracle/ks265_me_ref.c)
-            if (tid < 64 && o.ph != PH_DONE && nj >= 0) {
-                bool again;
+            if (tid < 64 && emitted) {
+                bool first = true;
                 do {
-                    again = false;
                     bool improved = false;
                     int key = 0, wx = o.mx, wy = o.my;
                     unsigned wcost = o.cost;
-                    if (nj > 0) {
+                    if (first) {
                         const unsigned long long b = L.best[tid];
                         key = (int)((b >> 32) & 255u);
                         improved = key != 0;
                         if (improved) { wcost = (unsigned)(b >> 40); wx = (int)((b >> 8) & 255u) - 128; wy = (int)(b & 255u) - 128; }
                     }
+                    first = false;
                     if (o.ph != PH_HSTEP) { o.cost = wcost; o.mx = wx; o.my = wy; }     // interMeHex's walk may refuse the move (below)
                     switch (o.ph) {
                     case PH_INIT: {
@@ -289,13 +288,17 @@ __global__ __launch_bounds__(256, 3) void me_int_kernel(KsGeom g, int range, int
                         if (o.ph == PH_UHEX6 && o.merange > 7) o.ph = PH_UBIG;
                         else o.ph = t1 >= o.cost ? PH_UFINAL : PH_UHW0;
                         break;
-                    case PH_UHW0:
+                    case PH_UHW0:                                                       // dir is kept reduced mod 6: (k + 5) % 6 = mod6m1[k]
                         if (!improved) { o.it = 0; o.ph = (o.merange >> 1) > 0 ? PH_UDW : PH_DONE; }
-                        else { o.dir = key - 1 + 5; o.it = 1; o.ph = o.it < (o.merange >> 1) ? PH_UHW : PH_UDW; if (o.ph == PH_UDW) { o.it = 0; if ((o.merange >> 1) <= 0) o.ph = PH_DONE; } }
+                        else {
+                            o.dir = mod6m1(key - 1); o.it = 1;
+                            if (o.it < (o.merange >> 1)) o.ph = PH_UHW;
+                            else { o.it = 0; o.ph = (o.merange >> 1) > 0 ? PH_UDW : PH_DONE; }
+                        }
                         break;
                     case PH_UHW:
                         if (!improved) { o.it = 0; o.ph = PH_UDW; }
-                        else { o.dir = o.dir % 6 + key - 1 + 5; ++o.it; if (o.it >= (o.merange >> 1)) { o.it = 0; o.ph = PH_UDW; } }
+                        else { o.dir = mod6m1(o.dir + key - 1); ++o.it; if (o.it >= (o.merange >> 1)) { o.it = 0; o.ph = PH_UDW; } }
                         break;
                     case PH_UDW:                                                        // a step that leaves the mv range is taken and ends the walk
                         if (!improved) o.ph = PH_DONE;
@@ -303,13 +306,7 @@ __global__ __launch_bounds__(256, 3) void me_int_kernel(KsGeom g, int range, int
                         break;
                     default: break;
                     }
-                    if (o.ph != PH_DONE) {                                              // a phase without eligible candidates passes as "no improvement"
-                        const int n = phase_count(o, root_zero);
-                        int c = 0;
-                        for (int k = 0; k < n; ++k) { int x, y, kk; c += phase_cand(o, k, range, x, y, kk) ? 1 : 0; }
-                        if (c == 0) { nj = 0; again = true; }
-                    }
-                } while (again);
+                } while (o.ph != PH_DONE && phase_count(o, root_zero) == 0);            // a phase without candidates passes as "no improvement"
             }
         }
         // ---- results of the level
