@@ -29,7 +29,7 @@ using namespace ks265;
 #define WIN_STRIDE 228            // 57 dwords (odd)
 #define FENC_STRIDE 68            // 17 dwords (odd)
 #define ME_WLIM 66                // candidates further than this from the PU position are not staged: skipped (oracle chk = 2)
-#define JOB_CAP 1024
+#define JOB_CAP 256                // job slots per group and round (an owner that does not fit waits a round)
 
 enum { PH_INIT, PH_DIA, PH_H6, PH_HSTEP, PH_SQUARE, PH_U1, PH_UCROSS, PH_UHEX6, PH_UBIG, PH_UFINAL, PH_UHW0, PH_UHW, PH_UDW, PH_DONE };
 
@@ -55,15 +55,19 @@ __device__ __forceinline__ unsigned mv_rate(int lam, int x, int y, int pmx, int 
     return (unsigned)((lam * se_bits_dev((x - pmx) << 2)) >> 4) + (unsigned)((lam * se_bits_dev((y - pmy) << 2)) >> 4);
 }
 
+// per-wave engine state (level 0 uses wave 0's copy for the whole work-group)
+struct GroupLds {
+    unsigned short jobs[JOB_CAP];          // stub: owner (6) | candidate index k << 6; 0xFFFF = unused slot
+    int2 desc[16];                         // per PU of the group, published by its owner: phase | dir << 8 | merange << 16, best x | y << 16
+    unsigned long long best[16];           // per PU: (cost << 8 | key) << 32 | (x + 128) << 8 | (y + 128)
+    int pred[16];                          // per PU: predictor, x | y << 16
+    int njobs, active;
+};
 struct MeLds {
     uint8_t win[WIN_ROWS * WIN_STRIDE];
     uint8_t fenc[64 * FENC_STRIDE];
-    int4 desc[64];                         // per PU of the level, published by its owner: phase | dir << 8 | merange << 16, best x | y << 16, predictor
-    unsigned short jobs[JOB_CAP];          // stub: owner (6) | candidate index k << 6; 0xFFFF = unused slot
-    unsigned long long best[64];           // per PU of the level: (cost << 8 | key) << 32 | (x + 128) << 8 | (y + 128)
-    int pred[64];                          // per PU of the level: predictor, x | y << 16
-    int pmv[85];                           // integer vectors of the finished PUs (predictors of the next level)
-    int njobs, active;
+    GroupLds grp[4];
+    int pmv[85];                           // integer vectors of the finished PUs (predictors of the finer levels)
 };
 
 struct Owner {
@@ -114,11 +118,206 @@ __device__ __forceinline__ bool phase_cand(const Owner &o, int k, int range, int
     return abs(x) <= lim && abs(y) <= lim;
 }
 
+// One LEVEL of one GROUP of PUs.  WG = true: the group is the CTU's single 64x64 PU and all 256 lanes of the work-group evaluate its
+// candidates (work-group barriers between the steps of a round).  WG = false: the group is the part of a level that lies in one 32x32
+// quadrant (1 / 4 / 16 PUs) and belongs to ONE WAVE, which runs its rounds on its own: owners = its first lanes, evaluation = its 64
+// lanes, no barrier at all (a wave's LDS operations complete in order) - the four waves of a CTU and the waves of the other CTUs on
+// the CU drift apart and hide each other's latencies, and a slow PU only holds up its own quadrant.
+template <bool WG>
+__device__ __forceinline__ void me_group(const KsGeom &g, int cx, int cy, int range, int lam, int method, int hex_thr, MeLds &L, GroupLds &Q, int level,
+                                         int l2n /* log2 PUs per side of the group */, int qx0, int qy0 /* PU-grid origin of the group */,
+                                         const ks265_pu *prev_ctu, ks265_pu *out_ctu, int t /* lane index inside the group's lanes */)
+{
+    constexpr int NT = WG ? 256 : 64;
+    const int S = 64 >> level, npu = 1 << (2 * l2n), l2t = 6 - 2 * level;              // tiles per PU = 1 << l2t (64, 16, 4, 1)
+    const int tpr = 8 >> level;                                                          // tiles per PU row
+    auto sync = [&]() { if (WG) __syncthreads(); else __builtin_amdgcn_wave_barrier(); };
+    Owner o;
+    o.ph = PH_DONE; o.mx = o.my = o.pmx = o.pmy = 0; o.merange = 0; o.it = 0; o.dir = 0; o.cost = 0; o.cost0 = 0;
+    bool root = false, inside = false;
+    const int px = qx0 + (t & ((1 << l2n) - 1)), py = qy0 + ((t >> l2n) & ((1 << l2n) - 1));
+    const bool is_owner = t < npu;
+    if (is_owner) {
+        inside = ks_pu_inside(g, cx, cy, level, px, py);
+        if (inside) {
+            root = true;
+            for (int a = level - 1; a >= 0; --a) {
+                const int ax = px >> (level - a), ay = py >> (level - a);
+                if (ks_pu_inside(g, cx, cy, a, ax, ay)) {
+                    const int v = L.pmv[ks_pu_index(a, ax, ay)];
+                    o.pmx = (int)(short)(v & 0xFFFF); o.pmy = v >> 16; root = false;
+                    break;
+                }
+            }
+            if (root && prev_ctu && prev_ctu[0].cost != KS_COST_INVALID) {
+                o.pmx = clip3(-range, range, ((int)prev_ctu[0].mvx + 2) >> 2);
+                o.pmy = clip3(-range, range, ((int)prev_ctu[0].mvy + 2) >> 2);
+            }
+            o.merange = root ? range : max(range >> 2, 4);
+            o.ph = PH_INIT;
+            Q.pred[t] = (o.pmx & 0xFFFF) | (o.pmy << 16);
+        } else {                                                                        // PU not (completely) inside the picture: marked, never searched
+            ks265_pu e; e.mvx = e.mvy = e.mvpx = e.mvpy = 0; e.cost = KS_COST_INVALID; e.dist = KS_COST_INVALID;
+            out_ctu[ks_pu_index(level, px, py)] = e;
+        }
+    }
+    const bool root_zero = root && (o.pmx | o.pmy);
+    const unsigned t1 = 62u << (2 * (6 - level) - 4), t2 = 50u << (2 * (6 - level) - 4);
+
+#pragma unroll 1
+    for (;;) {
+        // ---- owners: publish the state, take phase_count() job slots (a slot = one candidate, eligible or not), fill them with stubs
+        //      (owner, k); the candidates themselves are expanded by the evaluating lanes
+        bool emitted = false;
+        const bool pending = o.ph != PH_DONE;
+        if (WG ? t < 64 : true) {
+            const int cnt = pending ? phase_count(o, root_zero) : 0;
+            if (t == 0) Q.njobs = 0;
+            __builtin_amdgcn_wave_barrier();
+            if (cnt > 0) {
+                const int base = atomicAdd(&Q.njobs, cnt);                              // slot order is arbitrary: the winner does not depend on it
+                emitted = base + cnt <= JOB_CAP;                                        // an owner that does not fit waits for the next round
+                const int end = min(base + cnt, JOB_CAP);
+                for (int s = base; s < end; ++s) Q.jobs[s] = emitted ? (unsigned short)(t | ((s - base) << 6)) : (unsigned short)0xFFFF;
+                if (emitted) {
+                    Q.desc[t] = make_int2(o.ph | (o.dir << 8) | (o.merange << 16), (o.mx & 0xFFFF) | (o.my << 16));
+                    Q.best[t] = o.ph == PH_INIT ? ~0ull : ((unsigned long long)(o.cost << 8) << 32);
+                }
+            }
+            if (WG) { const unsigned long long anyp = __ballot(pending); if (t == 0) Q.active = anyp != 0ull; }
+        }
+        sync();
+        bool active;
+        if (WG) active = Q.active != 0; else active = __ballot(pending) != 0ull;
+        if (!active) break;
+        const int njobs = min(Q.njobs, JOB_CAP);
+        // ---- all lanes of the group: one lane = one 8x8 tile of one candidate
+        const int items = njobs << l2t;
+        for (int base = 0; base < items; base += NT) {
+            const int it = base + t;
+            unsigned sad = 0;
+            int pu = 0, x = 0, y = 0, key = 0;
+            bool live = it < items;
+            if (live) {
+                const unsigned stub = Q.jobs[it >> l2t];
+                live = stub != 0xFFFFu;
+                pu = stub & 63;
+                const int2 d = Q.desc[pu & 15];
+                Owner c;
+                c.ph = d.x & 255; c.dir = (d.x >> 8) & 255; c.merange = d.x >> 16; c.mx = (int)(short)(d.y & 0xFFFF); c.my = d.y >> 16;
+                c.pmx = c.pmy = 0;
+                if (c.ph == PH_INIT) { const int pr = Q.pred[pu & 15]; c.pmx = (int)(short)(pr & 0xFFFF); c.pmy = pr >> 16; }
+                live = live && phase_cand(c, (int)(stub >> 6), range, x, y, key);
+            }
+            if (live) {
+                const int tile = it & ((1 << l2t) - 1);
+                const int ppx = qx0 + (pu & ((1 << l2n) - 1)), ppy = qy0 + (pu >> l2n);
+                const int bx = ppx * S + (tile & (tpr - 1)) * 8, by = ppy * S + (tile >> (3 - level)) * 8;
+                const int wx = bx + x + WIN_XL, wy = by + y + WIN_YT;
+                const uint8_t *p = L.win + wy * WIN_STRIDE + (wx & ~3);
+                const uint8_t *f = L.fenc + by * FENC_STRIDE + bx;
+                const unsigned sh = wx & 3;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const unsigned w0 = *(const unsigned *)(p + r * WIN_STRIDE), w1 = *(const unsigned *)(p + r * WIN_STRIDE + 4), w2 = *(const unsigned *)(p + r * WIN_STRIDE + 8);
+                    const unsigned f0 = *(const unsigned *)(f + r * FENC_STRIDE), f1 = *(const unsigned *)(f + r * FENC_STRIDE + 4);
+                    sad = sad_u8x4(f0, align_bytes(w1, w0, sh), sad);
+                    sad = sad_u8x4(f1, align_bytes(w2, w1, sh), sad);
+                }
+            }
+            // the tiles of a job are adjacent lanes: 1 / 4 / 16 / 64 of them
+            if (level <= 2) { sad += (unsigned)dpp_mov<KS265_DPP_QUAD_XOR1>((int)sad); sad += (unsigned)dpp_mov<KS265_DPP_QUAD_XOR2>((int)sad); }
+            if (level <= 1) { sad += (unsigned)dpp_mov<KS265_DPP_ROW_HALF_MIRROR>((int)sad); sad += (unsigned)dpp_mov<KS265_DPP_ROW_MIRROR>((int)sad); }
+            if (level == 0) { sad += (unsigned)__builtin_amdgcn_ds_swizzle((int)sad, 0x1F | (16 << 10)); sad += (unsigned)__shfl_xor((int)sad, 32, 64); }
+            if (live && (it & ((1 << l2t) - 1)) == 0) {
+                const int pr = Q.pred[pu & 15];
+                const unsigned cost = sad + mv_rate(lam, x, y, (int)(short)(pr & 0xFFFF), pr >> 16);
+                const unsigned long long v = ((unsigned long long)((cost << 8) | (unsigned)key) << 32) | (unsigned long long)(((unsigned)(x + 128) << 8) | (unsigned)(y + 128));
+                atomicMin(&Q.best[pu & 15], v);
+            }
+        }
+        sync();
+        // ---- owners advance (the transitions of oracle/ks265_me_ref.c)
+        if (emitted) {
+            bool first = true;
+            do {
+                bool improved = false;
+                int key = 0, wx = o.mx, wy = o.my;
+                unsigned wcost = o.cost;
+                if (first) {
+                    const unsigned long long b = Q.best[t];
+                    key = (int)((b >> 32) & 255u);
+                    improved = key != 0;
+                    if (improved) { wcost = (unsigned)(b >> 40); wx = (int)((b >> 8) & 255u) - 128; wy = (int)(b & 255u) - 128; }
+                }
+                first = false;
+                if (o.ph != PH_HSTEP) { o.cost = wcost; o.mx = wx; o.my = wy; }         // interMeHex's walk may refuse the move (below)
+                switch (o.ph) {
+                case PH_INIT: {
+                    const unsigned sad0 = o.cost - mv_rate(lam, o.mx, o.my, o.pmx, o.pmy);
+                    if (method == 0) { o.ph = o.merange > 0 ? PH_DIA : PH_DONE; o.it = 0; }
+                    else if (method == 1 || (hex_thr > 0 && sad0 < ((unsigned)hex_thr << (2 * (6 - level))))) o.ph = PH_H6;
+                    else { o.ph = PH_U1; o.cost0 = o.cost; }
+                    break;
+                }
+                case PH_DIA:                                                            // interMeDia: no range test, merange steps
+                    if (!improved || ++o.it >= o.merange) o.ph = PH_DONE;
+                    break;
+                case PH_H6:
+                    if (!improved) o.ph = PH_SQUARE;
+                    else { o.dir = key - 2; o.it = (o.merange >> 1) - 1; o.ph = o.it > 0 ? PH_HSTEP : PH_SQUARE; }
+                    break;
+                case PH_HSTEP:                                                          // enc@0x490350: a move that leaves the mv range is undone and ends the walk
+                    if (!improved || abs(wx) > range || abs(wy) > range) o.ph = PH_SQUARE;
+                    else { o.cost = wcost; o.mx = wx; o.my = wy; o.dir = mod6m1(o.dir + key - 1); --o.it; o.ph = o.it > 0 ? PH_HSTEP : PH_SQUARE; }
+                    break;
+                case PH_SQUARE: case PH_UFINAL: o.ph = PH_DONE; break;
+                case PH_U1:
+                    if (t1 > o.cost0) o.ph = PH_DONE;
+                    else o.ph = o.cost > t2 ? PH_UCROSS : PH_UHEX6;
+                    break;
+                case PH_UCROSS: o.ph = PH_UHEX6; break;
+                case PH_UHEX6: case PH_UBIG:
+                    if (o.ph == PH_UHEX6 && o.merange > 7) o.ph = PH_UBIG;
+                    else o.ph = t1 >= o.cost ? PH_UFINAL : PH_UHW0;
+                    break;
+                case PH_UHW0:                                                           // dir is kept reduced mod 6: (k + 5) % 6 = mod6m1[k]
+                    if (!improved) { o.it = 0; o.ph = (o.merange >> 1) > 0 ? PH_UDW : PH_DONE; }
+                    else {
+                        o.dir = mod6m1(key - 1); o.it = 1;
+                        if (o.it < (o.merange >> 1)) o.ph = PH_UHW;
+                        else { o.it = 0; o.ph = (o.merange >> 1) > 0 ? PH_UDW : PH_DONE; }
+                    }
+                    break;
+                case PH_UHW:
+                    if (!improved) { o.it = 0; o.ph = PH_UDW; }
+                    else { o.dir = mod6m1(o.dir + key - 1); ++o.it; if (o.it >= (o.merange >> 1)) { o.it = 0; o.ph = PH_UDW; } }
+                    break;
+                case PH_UDW:                                                            // a step that leaves the mv range is taken and ends the walk
+                    if (!improved) o.ph = PH_DONE;
+                    else if (abs(o.mx) > range || abs(o.my) > range || ++o.it >= (o.merange >> 1)) o.ph = PH_DONE;
+                    break;
+                default: break;
+                }
+            } while (o.ph != PH_DONE && phase_count(o, root_zero) == 0);                // a phase without candidates passes as "no improvement"
+        }
+    }
+    // ---- results of the group
+    if (is_owner && inside) {
+        const int idx = ks_pu_index(level, px, py);
+        L.pmv[idx] = (o.mx & 0xFFFF) | (o.my << 16);
+        ks265_pu e;
+        e.mvx = (int16_t)(o.mx << 2); e.mvy = (int16_t)(o.my << 2); e.mvpx = (int16_t)(o.pmx << 2); e.mvpy = (int16_t)(o.pmy << 2);
+        e.cost = o.cost; e.dist = o.cost - mv_rate(lam, o.mx, o.my, o.pmx, o.pmy);
+        out_ctu[idx] = e;
+    }
+}
+
 __global__ __launch_bounds__(256, 3) void me_int_kernel(KsGeom g, int range, int lam, int method, int hex_thr, const uint8_t *src, const uint8_t *ref,
                                                         const ks265_pu *prev, ks265_pu *out)
 {
     __shared__ __attribute__((aligned(16))) MeLds L;
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ctu = ks_xcd_swizzle(blockIdx.x, g.ctu_cols * g.ctu_rows), cx = ctu % g.ctu_cols, cy = ctu / g.ctu_cols;
     const uint8_t *R = ks_org_y(g, ref), *Sp = ks_org_y(g, src);
     // reference window: 16-byte global loads (x0 - 80 is 16-byte aligned), dword LDS stores
@@ -137,188 +336,15 @@ __global__ __launch_bounds__(256, 3) void me_int_kernel(KsGeom g, int range, int
     }
     const ks265_pu *prev_ctu = prev ? prev + (long)ctu * 85 : nullptr;
     ks265_pu *out_ctu = out + (long)ctu * 85;
-
+    __syncthreads();
+    // the 64x64 PU: the whole work-group
+    me_group<true>(g, cx, cy, range, lam, method, hex_thr, L, L.grp[0], 0, 0, 0, 0, prev_ctu, out_ctu, tid);
+    __syncthreads();                                                                    // its vector is the predictor of everything below
+    // 32x32, 16x16, 8x8: one quadrant per wave, each wave on its own
+    const int qx = wave & 1, qy = wave >> 1;
 #pragma unroll 1
-    for (int level = 0; level < 4; ++level) {
-        const int S = 64 >> level, npu = 1 << (2 * level), l2t = 6 - 2 * level;       // tiles per PU = 1 << l2t (64, 16, 4, 1)
-        const int tpr = 8 >> level;                                                     // tiles per PU row
-        __syncthreads();                                                                // window staged / previous level's pmv visible
-        // ---- owners
-        Owner o;
-        o.ph = PH_DONE; o.mx = o.my = o.pmx = o.pmy = 0; o.merange = 0; o.it = 0; o.dir = 0; o.cost = 0; o.cost0 = 0;
-        bool root = false;
-        const int px = tid & ((1 << level) - 1), py = (tid >> level) & ((1 << level) - 1);
-        const bool is_owner = tid < npu;
-        if (is_owner) {
-            if (ks_pu_inside(g, cx, cy, level, px, py)) {
-                root = true;
-                for (int a = level - 1; a >= 0; --a) {
-                    const int ax = px >> (level - a), ay = py >> (level - a);
-                    if (ks_pu_inside(g, cx, cy, a, ax, ay)) {
-                        const int v = L.pmv[ks_pu_index(a, ax, ay)];
-                        o.pmx = (int)(short)(v & 0xFFFF); o.pmy = v >> 16; root = false;
-                        break;
-                    }
-                }
-                if (root && prev_ctu && prev_ctu[0].cost != KS_COST_INVALID) {
-                    o.pmx = clip3(-range, range, ((int)prev_ctu[0].mvx + 2) >> 2);
-                    o.pmy = clip3(-range, range, ((int)prev_ctu[0].mvy + 2) >> 2);
-                }
-                o.merange = root ? range : max(range >> 2, 4);
-                o.ph = PH_INIT;
-                L.pred[tid] = (o.pmx & 0xFFFF) | (o.pmy << 16);
-            } else {                                                                    // PU not (completely) inside the picture: marked, never searched
-                ks265_pu e; e.mvx = e.mvy = e.mvpx = e.mvpy = 0; e.cost = KS_COST_INVALID; e.dist = KS_COST_INVALID;
-                out_ctu[ks_pu_index(level, px, py)] = e;
-            }
-        }
-        const bool root_zero = root && (o.pmx | o.pmy);
-        const unsigned t1 = 62u << (2 * (6 - level) - 4), t2 = 50u << (2 * (6 - level) - 4);
-
-#pragma unroll 1
-        for (;;) {
-            // ---- wave 0: every pending owner publishes its state, takes phase_count() job slots (a slot = one candidate, eligible or
-            //      not) and fills them with stubs (owner, k); the candidates themselves are expanded by the evaluating lanes
-            bool emitted = false;
-            if (tid < 64) {
-                const bool pending = o.ph != PH_DONE;
-                const int cnt = pending ? phase_count(o, root_zero) : 0;
-                if (lane == 0) L.njobs = 0;
-                __builtin_amdgcn_wave_barrier();
-                int base = 0;
-                if (cnt > 0) base = atomicAdd(&L.njobs, cnt);                            // slot order is arbitrary: the winner does not depend on it
-                if (cnt > 0) {
-                    emitted = base + cnt <= JOB_CAP;                                     // an owner that does not fit waits for the next round
-                    const int end = min(base + cnt, JOB_CAP);
-                    for (int s = base; s < end; ++s) L.jobs[s] = emitted ? (unsigned short)(tid | ((s - base) << 6)) : (unsigned short)0xFFFF;
-                    if (emitted) {
-                        L.desc[tid] = make_int4(o.ph | (o.dir << 8) | (o.merange << 16), (o.mx & 0xFFFF) | (o.my << 16), (o.pmx & 0xFFFF) | (o.pmy << 16), 0);
-                        L.best[tid] = o.ph == PH_INIT ? ~0ull : ((unsigned long long)(o.cost << 8) << 32);
-                    }
-                }
-                const unsigned long long anyp = __ballot(pending);
-                if (lane == 0) L.active = anyp != 0ull;
-            }
-            __syncthreads();
-            const int njobs = min(L.njobs, JOB_CAP);
-            if (!L.active) break;
-            // ---- all lanes: one lane = one 8x8 tile of one candidate
-            const int items = njobs << l2t;
-            for (int base = 0; base < items; base += 256) {
-                const int it = base + tid;
-                unsigned sad = 0;
-                int pu = 0, x = 0, y = 0, key = 0;
-                bool live = it < items;
-                if (live) {
-                    const unsigned stub = L.jobs[it >> l2t];
-                    live = stub != 0xFFFFu;
-                    pu = stub & 63;
-                    const int4 d = L.desc[pu];
-                    Owner c;
-                    c.ph = d.x & 255; c.dir = (d.x >> 8) & 255; c.merange = d.x >> 16; c.mx = (int)(short)(d.y & 0xFFFF); c.my = d.y >> 16;
-                    c.pmx = (int)(short)(d.z & 0xFFFF); c.pmy = d.z >> 16;
-                    live = live && phase_cand(c, (int)(stub >> 6), range, x, y, key);
-                }
-                if (live) {
-                    const int tile = it & ((1 << l2t) - 1);
-                    const int ppx = pu & ((1 << level) - 1), ppy = pu >> level;
-                    const int bx = ppx * S + (tile & (tpr - 1)) * 8, by = ppy * S + (tile >> (3 - level)) * 8;
-                    const int wx = bx + x + WIN_XL, wy = by + y + WIN_YT;
-                    const uint8_t *p = L.win + wy * WIN_STRIDE + (wx & ~3);
-                    const uint8_t *f = L.fenc + by * FENC_STRIDE + bx;
-                    const unsigned sh = wx & 3;
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) {
-                        const unsigned w0 = *(const unsigned *)(p + r * WIN_STRIDE), w1 = *(const unsigned *)(p + r * WIN_STRIDE + 4), w2 = *(const unsigned *)(p + r * WIN_STRIDE + 8);
-                        const unsigned f0 = *(const unsigned *)(f + r * FENC_STRIDE), f1 = *(const unsigned *)(f + r * FENC_STRIDE + 4);
-                        sad = sad_u8x4(f0, align_bytes(w1, w0, sh), sad);
-                        sad = sad_u8x4(f1, align_bytes(w2, w1, sh), sad);
-                    }
-                }
-                for (int d = (1 << l2t) >> 1; d > 0; d >>= 1) sad += __shfl_xor(sad, d);   // the tiles of a job are adjacent lanes
-                if (live && (it & ((1 << l2t) - 1)) == 0) {
-                    const int pr = L.pred[pu];
-                    const unsigned cost = sad + mv_rate(lam, x, y, (int)(short)(pr & 0xFFFF), pr >> 16);
-                    const unsigned long long v = ((unsigned long long)((cost << 8) | (unsigned)key) << 32) | (unsigned long long)(((unsigned)(x + 128) << 8) | (unsigned)(y + 128));
-                    atomicMin(&L.best[pu], v);
-                }
-            }
-            __syncthreads();
-            // ---- owners advance (the transitions of oracle/ks265_me_ref.c)
-            if (tid < 64 && emitted) {
-                bool first = true;
-                do {
-                    bool improved = false;
-                    int key = 0, wx = o.mx, wy = o.my;
-                    unsigned wcost = o.cost;
-                    if (first) {
-                        const unsigned long long b = L.best[tid];
-                        key = (int)((b >> 32) & 255u);
-                        improved = key != 0;
-                        if (improved) { wcost = (unsigned)(b >> 40); wx = (int)((b >> 8) & 255u) - 128; wy = (int)(b & 255u) - 128; }
-                    }
-                    first = false;
-                    if (o.ph != PH_HSTEP) { o.cost = wcost; o.mx = wx; o.my = wy; }     // interMeHex's walk may refuse the move (below)
-                    switch (o.ph) {
-                    case PH_INIT: {
-                        const unsigned sad0 = o.cost - mv_rate(lam, o.mx, o.my, o.pmx, o.pmy);
-                        if (method == 0) { o.ph = o.merange > 0 ? PH_DIA : PH_DONE; o.it = 0; }
-                        else if (method == 1 || (hex_thr > 0 && sad0 < ((unsigned)hex_thr << (2 * (6 - level))))) o.ph = PH_H6;
-                        else { o.ph = PH_U1; o.cost0 = o.cost; }
-                        break;
-                    }
-                    case PH_DIA:                                                        // interMeDia: no range test, merange steps
-                        if (!improved || ++o.it >= o.merange) o.ph = PH_DONE;
-                        break;
-                    case PH_H6:
-                        if (!improved) o.ph = PH_SQUARE;
-                        else { o.dir = key - 2; o.it = (o.merange >> 1) - 1; o.ph = o.it > 0 ? PH_HSTEP : PH_SQUARE; }
-                        break;
-                    case PH_HSTEP:                                                      // enc@0x490350: a move that leaves the mv range is undone and ends the walk
-                        if (!improved || abs(wx) > range || abs(wy) > range) o.ph = PH_SQUARE;
-                        else { o.cost = wcost; o.mx = wx; o.my = wy; o.dir = mod6m1(o.dir + key - 1); --o.it; o.ph = o.it > 0 ? PH_HSTEP : PH_SQUARE; }
-                        break;
-                    case PH_SQUARE: case PH_UFINAL: o.ph = PH_DONE; break;
-                    case PH_U1:
-                        if (t1 > o.cost0) o.ph = PH_DONE;
-                        else o.ph = o.cost > t2 ? PH_UCROSS : PH_UHEX6;
-                        break;
-                    case PH_UCROSS: o.ph = PH_UHEX6; break;
-                    case PH_UHEX6: case PH_UBIG:
-                        if (o.ph == PH_UHEX6 && o.merange > 7) o.ph = PH_UBIG;
-                        else o.ph = t1 >= o.cost ? PH_UFINAL : PH_UHW0;
-                        break;
-                    case PH_UHW0:                                                       // dir is kept reduced mod 6: (k + 5) % 6 = mod6m1[k]
-                        if (!improved) { o.it = 0; o.ph = (o.merange >> 1) > 0 ? PH_UDW : PH_DONE; }
-                        else {
-                            o.dir = mod6m1(key - 1); o.it = 1;
-                            if (o.it < (o.merange >> 1)) o.ph = PH_UHW;
-                            else { o.it = 0; o.ph = (o.merange >> 1) > 0 ? PH_UDW : PH_DONE; }
-                        }
-                        break;
-                    case PH_UHW:
-                        if (!improved) { o.it = 0; o.ph = PH_UDW; }
-                        else { o.dir = mod6m1(o.dir + key - 1); ++o.it; if (o.it >= (o.merange >> 1)) { o.it = 0; o.ph = PH_UDW; } }
-                        break;
-                    case PH_UDW:                                                        // a step that leaves the mv range is taken and ends the walk
-                        if (!improved) o.ph = PH_DONE;
-                        else if (abs(o.mx) > range || abs(o.my) > range || ++o.it >= (o.merange >> 1)) o.ph = PH_DONE;
-                        break;
-                    default: break;
-                    }
-                } while (o.ph != PH_DONE && phase_count(o, root_zero) == 0);            // a phase without candidates passes as "no improvement"
-            }
-        }
-        // ---- results of the level
-        if (is_owner && ks_pu_inside(g, cx, cy, level, px, py)) {
-            const int idx = ks_pu_index(level, px, py);
-            L.pmv[idx] = (o.mx & 0xFFFF) | (o.my << 16);
-            ks265_pu e;
-            e.mvx = (int16_t)(o.mx << 2); e.mvy = (int16_t)(o.my << 2); e.mvpx = (int16_t)(o.pmx << 2); e.mvpy = (int16_t)(o.pmy << 2);
-            e.cost = o.cost; e.dist = o.cost - mv_rate(lam, o.mx, o.my, o.pmx, o.pmy);
-            out_ctu[idx] = e;
-        }
-    }
+    for (int level = 1; level < 4; ++level)
+        me_group<false>(g, cx, cy, range, lam, method, hex_thr, L, L.grp[wave], level, level - 1, qx << (level - 1), qy << (level - 1), prev_ctu, out_ctu, lane);
 }
 
 extern "C" int ks265_me_integer(ks265_frame *f, ks265_pic src, ks265_pic ref, const ks265_pu *prev_pu, ks265_pu *pu)
