@@ -2,47 +2,63 @@
 //
 // The search PATTERNS are the reference's own control flow — interMeDia enc@0x48fbe0, interMeHex enc@0x48fde0, interMeUMH
 // enc@0x4907b0 — as restated from the disassembly in oracle/ks265_me_ref.c and pinned there against traces of the reference binary
-// (tests/golden/me_search.npz).  This file runs the same state machines for all PUs of a CTU level at once:
+// (tests/golden/me_search.npz).  This file runs the same state machines for many PUs at once:
 //
-//   * one work-group (4 waves) per CTU; the 64x64 source block and the +-66 / +-80 reference window are staged in LDS once
-//     (every window byte leaves HBM once per CTU); row pitches 57 / 17 dwords (odd);
-//   * levels 64x64 .. 8x8 coarse to fine (a PU's predictor is its nearest valid ancestor's vector);
-//   * per level, lanes 0 .. NPU-1 of wave 0 are the OWNERS of the PUs: each holds its PU's search state (phase, best vector, cost,
-//     direction, iteration count) in registers and, once per round, emits the candidates of its current phase as JOBS into LDS —
+//   * one work-group (4 waves) per CTU; the 64x64 source block and the +-66 reference window are staged in LDS once (every window
+//     byte leaves HBM once per CTU); row pitches 51 / 17 dwords (odd);
+//   * the 64x64 PU is searched by the whole work-group; then every wave takes one 32x32 quadrant and runs its 32x32, 16x16 and 8x8
+//     levels ON ITS OWN, without work-group barriers (a PU's predictor is its nearest valid ancestor's vector, which lies in the
+//     same quadrant; a wave's LDS operations complete in order): waves drift apart and hide each other's latencies;
+//   * OWNERS: the first lanes of a group hold the search state of one PU each (phase, best vector, cost, direction, iteration
+//     count) in registers.  Once per round an owner publishes a descriptor of its phase and takes one JOB slot per candidate —
 //     4 for a diamond step, 3 / 6 for hexagon steps, 8 for the square refinement, up to 64 for the sparse cross and 128 for the
 //     big-hexagon rings (fixed-centre stages: all candidates are independent);
-//   * all 256 lanes then evaluate the jobs: ONE LANE = ONE 8x8 TILE OF ONE CANDIDATE (v_sad_u8 on packed dwords, v_alignbyte for
-//     the unaligned window rows) — no per-candidate reduction chain for 8x8 PUs, 2 / 4 / 6 xor-shuffle steps for 16 / 32 / 64;
-//     a diamond step of any level fills the work-group exactly (NPU x 4 candidates x tiles = 256 lanes);
-//   * the job's first lane adds the mv rate and folds (cost, key, x, y) into its PU's 64-bit LDS slot with ds_min_u64.  Keys
+//   * all lanes of the group then evaluate the jobs: ONE LANE = ONE 8x8 TILE OF ONE CANDIDATE (candidate offset from a small LDS
+//     table, v_sad_u8 on packed dwords, v_alignbyte for the unaligned window rows); the 1 / 4 / 16 / 64 tiles of a candidate are
+//     adjacent lanes (DPP / swizzle sums); a diamond step of any level fills the group exactly;
+//   * the job's first lane adds the mv rate and folds (cost, key, x, y) into a 64-bit LDS slot of its PU with ds_min_u64.  Keys
 //     reproduce the reference's tie rules: the direction codes of the packed (cost << 4) + code / (cost << 3) + code forms, or the
 //     scan position for the "first strictly better" stages; key 0 = the incumbent;
-//   * owners read the winner and advance their state machine.  Rounds repeat until every owner is done.
+//   * owners read the winner and advance their state machine.  Rounds repeat until every owner of the group is done;
+//   * the FIRST round is speculative: the start point, its four diamond neighbours (first step of interMeDia / interMeUMH), the six
+//     hexagon points (first step of interMeHex) and the four diagonals (interMeHex's closing square) are evaluated together.  A PU
+//     whose search converges at its start point - most of them - is finished after that single round.
 #include "frame_common.h"
 
 using namespace ks265;
 
-#define WIN_XL 80                 // window column 0 is picture x = ctu_x*64 - 80 (16-byte aligned loads)
+#define WIN_LOAD_XL 80            // global loads start at picture x = ctu_x*64 - 80 (16-byte aligned), 14 x 16 bytes per row
+#define WIN_XL 68                 // LDS window column 0 is picture x = ctu_x*64 - 68
 #define WIN_YT 66                 // window row 0 is picture y = ctu_y*64 - 66
-#define WIN_W 224                 // loaded bytes per row (x in [-80, 144))
 #define WIN_ROWS 196              // y in [-66, 130)
-#define WIN_STRIDE 228            // 57 dwords (odd)
+#define WIN_STRIDE 204            // 51 dwords (odd): x in [-68, 136)
 #define FENC_STRIDE 68            // 17 dwords (odd)
 #define ME_WLIM 66                // candidates further than this from the PU position are not staged: skipped (oracle chk = 2)
-#define JOB_CAP 256                // job slots per group and round (an owner that does not fit waits a round)
+#define JOB_CAP 256               // job slots per group and round (an owner that does not fit waits a round)
 
-enum { PH_INIT, PH_DIA, PH_H6, PH_HSTEP, PH_SQUARE, PH_U1, PH_UCROSS, PH_UHEX6, PH_UBIG, PH_UFINAL, PH_UHW0, PH_UHW, PH_UDW, PH_DONE };
+enum { PH_INIT, PH_START, PH_DIA, PH_H6, PH_HSTEP, PH_SQUARE, PH_U1, PH_UCROSS, PH_UHEX6, PH_UBIG, PH_UFINAL, PH_UHW0, PH_UHW, PH_UDW, PH_DONE };
 
-__device__ __forceinline__ int nib32(unsigned w, int k) { return (int)((w >> (4 * k)) & 15u); }
-__device__ __forceinline__ int nib64(unsigned long long w, int k) { return (int)((w >> (4 * k)) & 15ull); }
-// search-pattern tables of the reference (rodata of the binary, values read from the file), stored with a bias
-__device__ __forceinline__ int hex2x(int i) { return nib32(0x01343101u, i) - 2; }                   // hex2 enc@0x4e52e0
-__device__ __forceinline__ int hex2y(int i) { return nib32(0x20024420u, i) - 2; }
-__device__ __forceinline__ int hexagon_x(int i) { return nib32(0x00313140u, i) - 2; }               // Hexagon enc@0x4e5340
-__device__ __forceinline__ int hexagon_y(int i) { return nib32(0x00044022u, i) - 2; }
-__device__ __forceinline__ int bigx(int i) { return nib64(0x6262808080804480ull, i) - 4; }          // Big_Hexagon_X enc@0x4e5320
-__device__ __forceinline__ int bigy(int i) { return nib64(0x1771266235538044ull, i) - 4; }          // Big_Hexagon_Y enc@0x4e5300
-__device__ __forceinline__ int mod6m1(int i) { return nib32(0x05432105u, i); }                      // mod6m1 enc@0x4e52c0
+// Candidate offsets (dx, dy), key and result slot: dx & 0xFF | (dy & 0xFF) << 8 | key << 16 | slot << 24.  key 0 = "key is k + keyadd".
+// The pattern tables are rodata of the reference binary (values read from the file).
+#define CT(dx, dy, key, slot) ((unsigned)((dx) & 0xFF) | ((unsigned)((dy) & 0xFF) << 8) | ((unsigned)(key) << 16) | ((unsigned)(slot) << 24))
+#define TB_SQUARE 0               // the 4-neighbour step codes 1 up, 3 down, 4 left, 12 right, then interMeHex's diagonals 5, 7, 13, 15
+#define TB_HEX2 8                 // hex2 enc@0x4e52e0 (8 entries: the hexagon repeated so that dir + 2 never wraps)
+#define TB_HEXAGON 16             // Hexagon enc@0x4e5340
+#define TB_BIG 24                 // Big_Hexagon_X / _Y enc@0x4e5320 / 0x4e5300
+#define TB_CROSS 40
+#define TB_START 44               // speculative first round: start, diamond (slot 1), diagonals (slot 2), hex2[1..6] with interMeHex's codes (slot 3)
+#define TB_SIZE 59
+__device__ const unsigned kCandTab[TB_SIZE] = {
+    CT(0, -1, 1, 0), CT(0, 1, 3, 0), CT(-1, 0, 4, 0), CT(1, 0, 12, 0), CT(-1, -1, 5, 0), CT(-1, 1, 7, 0), CT(1, -1, 13, 0), CT(1, 1, 15, 0),
+    CT(-1, -2, 0, 0), CT(-2, 0, 0, 0), CT(-1, 2, 0, 0), CT(1, 2, 0, 0), CT(2, 0, 0, 0), CT(1, -2, 0, 0), CT(-1, -2, 0, 0), CT(-2, 0, 0, 0),
+    CT(-2, 0, 0, 0), CT(2, 0, 0, 0), CT(-1, -2, 0, 0), CT(1, 2, 0, 0), CT(-1, 2, 0, 0), CT(1, -2, 0, 0), 0, 0,
+    CT(-4, 0, 0, 0), CT(4, 0, 0, 0), CT(0, -4, 0, 0), CT(0, 4, 0, 0), CT(-4, -1, 0, 0), CT(4, 1, 0, 0), CT(-4, 1, 0, 0), CT(4, -1, 0, 0),
+    CT(-4, -2, 0, 0), CT(4, 2, 0, 0), CT(-4, 2, 0, 0), CT(4, -2, 0, 0), CT(-2, -3, 0, 0), CT(2, 3, 0, 0), CT(-2, 3, 0, 0), CT(2, -3, 0, 0),
+    CT(1, 0, 0, 0), CT(-1, 0, 0, 0), CT(0, 1, 0, 0), CT(0, -1, 0, 0),
+    CT(0, 0, 1, 0), CT(0, -1, 1, 1), CT(0, 1, 3, 1), CT(-1, 0, 4, 1), CT(1, 0, 12, 1), CT(-1, -1, 5, 2), CT(-1, 1, 7, 2), CT(1, -1, 13, 2), CT(1, 1, 15, 2),
+    CT(-2, 0, 2, 3), CT(-1, 2, 3, 3), CT(1, 2, 4, 3), CT(2, 0, 5, 3), CT(1, -2, 6, 3), CT(-1, -2, 7, 3),
+};
+__device__ __forceinline__ int mod6m1(int i) { return (int)((0x05432105u >> (4 * i)) & 15u); }      // mod6m1 enc@0x4e52c0
 
 __device__ __forceinline__ int se_bits_dev(int v)
 {
@@ -55,17 +71,18 @@ __device__ __forceinline__ unsigned mv_rate(int lam, int x, int y, int pmx, int 
     return (unsigned)((lam * se_bits_dev((x - pmx) << 2)) >> 4) + (unsigned)((lam * se_bits_dev((y - pmy) << 2)) >> 4);
 }
 
-// per-wave engine state (level 0 uses wave 0's copy for the whole work-group)
+// per-wave engine state (the 64x64 level uses wave 0's copy for the whole work-group)
 struct GroupLds {
-    unsigned short jobs[JOB_CAP];          // stub: owner (6) | candidate index k << 6; 0xFFFF = unused slot
-    int2 desc[16];                         // per PU of the group, published by its owner: phase | dir << 8 | merange << 16, best x | y << 16
-    unsigned long long best[16];           // per PU: (cost << 8 | key) << 32 | (x + 128) << 8 | (y + 128)
+    unsigned short jobs[JOB_CAP];          // stub: owner (4) | candidate index k << 4; 0xFFFF = unused slot
+    int2 desc[16];                         // per PU of the group, published by its owner: centre x | y << 16, candidate-table parameters (DP_*)
+    unsigned long long best[16][4];        // per PU and slot: (cost << 8 | key) << 32 | (x + 128) << 8 | (y + 128)
     int pred[16];                          // per PU: predictor, x | y << 16
     int njobs, active;
 };
 struct MeLds {
     uint8_t win[WIN_ROWS * WIN_STRIDE];
     uint8_t fenc[64 * FENC_STRIDE];
+    unsigned ctab[64];
     GroupLds grp[4];
     int pmv[85];                           // integer vectors of the finished PUs (predictors of the finer levels)
 };
@@ -75,54 +92,38 @@ struct Owner {
     unsigned cost, cost0;
 };
 
-// number of candidates phase `ph` can emit (before eligibility)
-__device__ __forceinline__ int phase_count(const Owner &o, bool root_zero)
+// descriptor parameters: candidate k of a phase is ctab[tb + (k & km)] scaled by m0 + ms * (k >> ksh); its key is the table's, or k + keyadd
+#define DP(tb, km, ksh, m0, ms, keyadd, ranged) ((tb) | ((km) << 6) | ((ksh) << 13) | ((m0) << 16) | ((ms) << 20) | ((keyadd) << 24) | ((ranged) << 28))
+#define DP_INIT (1 << 29)
+
+// number of candidates of the owner's phase and its descriptor parameters
+__device__ __forceinline__ int phase_desc(const Owner &o, int nstart, int &dp)
 {
     switch (o.ph) {
-    case PH_INIT: return root_zero ? 2 : 1;
-    case PH_DIA: case PH_U1: case PH_UFINAL: case PH_UDW: return 4;
-    case PH_H6: case PH_UHEX6: case PH_UHW0: return 6;
-    case PH_HSTEP: case PH_UHW: return 3;
-    case PH_SQUARE: return 8;
-    case PH_UCROSS: return 4 * (o.merange >> 2);                 // i = 4, 12, .. <= 2 * merange - 4: merange >> 2 steps
-    case PH_UBIG: return 16 * (o.merange >> 3);
-    default: return 0;
+    case PH_INIT: dp = DP_INIT; return 2;                                                // predictor (key 1), zero vector (key 2)
+    case PH_START: dp = DP(TB_START, 15, 0, 1, 0, 0, 0); return nstart;
+    case PH_DIA: case PH_U1: case PH_UFINAL: case PH_UDW: dp = DP(TB_SQUARE, 7, 0, 1, 0, 0, 0); return 4;
+    case PH_SQUARE: dp = DP(TB_SQUARE, 7, 0, 1, 0, 0, 0); return 8;
+    case PH_H6: dp = DP(TB_HEX2 + 1, 7, 0, 1, 0, 2, 0); return 6;                        // hex2[1..6], codes 2..7
+    case PH_HSTEP: dp = DP(TB_HEX2, 7, 0, 1, 0, 1, 0) + o.dir; return 3;                 // hex2[dir .. dir + 2], codes 1..3
+    case PH_UCROSS: dp = DP(TB_CROSS, 3, 2, 4, 8, 1, 1); return 4 * (o.merange >> 2);    // i = 4, 12, .. <= 2 * merange - 4; +i, -i along x, then y
+    case PH_UHEX6: dp = DP(TB_HEXAGON, 7, 0, 1, 0, 1, 1); return 6;
+    case PH_UBIG: dp = DP(TB_BIG, 15, 4, 1, 1, 1, 1); return 16 * (o.merange >> 3);      // ring r = 1 + (k >> 4)
+    case PH_UHW0: dp = DP(TB_HEX2, 7, 0, 1, 0, 1, 1); return 6;
+    case PH_UHW: dp = DP(TB_HEX2, 7, 0, 1, 0, 1, 1) + o.dir; return 3;                   // dir is kept reduced mod 6
+    default: dp = 0; return 0;
     }
 }
-// k-th candidate of the owner's phase: position, key, and whether the reference would evaluate it (mv-range test where its code has
-// one) and the window holds it
-__device__ __forceinline__ bool phase_cand(const Owner &o, int k, int range, int &x, int &y, int &key)
-{
-    bool ranged = false;
-    int dx = 0, dy = 0;
-    switch (o.ph) {
-    case PH_INIT: x = k ? 0 : o.pmx; y = k ? 0 : o.pmy; key = k + 1; return true;
-    case PH_DIA: case PH_U1: case PH_UFINAL: case PH_UDW:                               // up 1, down 3, left 4, right 12
-        dx = k == 2 ? -1 : (k == 3 ? 1 : 0); dy = k == 0 ? -1 : (k == 1 ? 1 : 0); key = k == 0 ? 1 : (k == 1 ? 3 : (k == 2 ? 4 : 12));
-        break;
-    case PH_SQUARE:                                                                      // + (-1,-1) 5, (-1,1) 7, (1,-1) 13, (1,1) 15
-        if (k < 4) { dx = k == 2 ? -1 : (k == 3 ? 1 : 0); dy = k == 0 ? -1 : (k == 1 ? 1 : 0); key = k == 0 ? 1 : (k == 1 ? 3 : (k == 2 ? 4 : 12)); }
-        else { dx = k < 6 ? -1 : 1; dy = (k & 1) ? 1 : -1; key = k == 4 ? 5 : (k == 5 ? 7 : (k == 6 ? 13 : 15)); }
-        break;
-    case PH_H6: dx = hex2x(k + 1); dy = hex2y(k + 1); key = k + 2; break;
-    case PH_HSTEP: dx = hex2x(o.dir + k); dy = hex2y(o.dir + k); key = k + 1; break;
-    case PH_UCROSS: { const int i = 4 + 8 * (k >> 2), d = k & 3; dx = d == 0 ? i : (d == 1 ? -i : 0); dy = d == 2 ? i : (d == 3 ? -i : 0); key = k + 1; ranged = true; break; }
-    case PH_UHEX6: dx = hexagon_x(k); dy = hexagon_y(k); key = k + 1; ranged = true; break;
-    case PH_UBIG: { const int r = (k >> 4) + 1, j = k & 15; dx = r * bigx(j); dy = r * bigy(j); key = k + 1; ranged = true; break; }
-    case PH_UHW0: dx = hex2x(k); dy = hex2y(k); key = k + 1; ranged = true; break;
-    case PH_UHW: { const int j = o.dir + k; dx = hex2x(j); dy = hex2y(j); key = k + 1; ranged = true; break; }      // dir already reduced mod 6
-    default: return false;
-    }
-    x = o.mx + dx; y = o.my + dy;
-    const int lim = ranged ? range : ME_WLIM;
-    return abs(x) <= lim && abs(y) <= lim;
-}
+
+#ifdef KS_EXP_ME_CLOCK
+__device__ unsigned long long ks_me_dbg[32];      // per level: [0] rounds, [1] emit, [2] eval, [3] advance cycles, [4] jobs, [5] level cycles (wave 0 lane 0)
+extern "C" void ks265_me_dbg(unsigned long long *out, int reset) { if (reset) { unsigned long long z[32] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(ks_me_dbg), z, sizeof z); } else (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(ks_me_dbg), sizeof(unsigned long long) * 32); }
+#define ME_NOW() ((long long)__builtin_readcyclecounter())
+#endif
 
 // One LEVEL of one GROUP of PUs.  WG = true: the group is the CTU's single 64x64 PU and all 256 lanes of the work-group evaluate its
 // candidates (work-group barriers between the steps of a round).  WG = false: the group is the part of a level that lies in one 32x32
-// quadrant (1 / 4 / 16 PUs) and belongs to ONE WAVE, which runs its rounds on its own: owners = its first lanes, evaluation = its 64
-// lanes, no barrier at all (a wave's LDS operations complete in order) - the four waves of a CTU and the waves of the other CTUs on
-// the CU drift apart and hide each other's latencies, and a slow PU only holds up its own quadrant.
+// quadrant (1 / 4 / 16 PUs) and belongs to ONE WAVE: owners = its first lanes, evaluation = its 64 lanes, no barrier at all.
 template <bool WG>
 __device__ __forceinline__ void me_group(const KsGeom &g, int cx, int cy, int range, int lam, int method, int hex_thr, MeLds &L, GroupLds &Q, int level,
                                          int l2n /* log2 PUs per side of the group */, int qx0, int qy0 /* PU-grid origin of the group */,
@@ -132,15 +133,17 @@ __device__ __forceinline__ void me_group(const KsGeom &g, int cx, int cy, int ra
     const int S = 64 >> level, npu = 1 << (2 * l2n), l2t = 6 - 2 * level;              // tiles per PU = 1 << l2t (64, 16, 4, 1)
     const int tpr = 8 >> level;                                                          // tiles per PU row
     auto sync = [&]() { if (WG) __syncthreads(); else __builtin_amdgcn_wave_barrier(); };
+    // speculative first round: start + diamond for interMeDia / an always-UMH search, + diagonals + hexagon when interMeHex can run
+    const int nstart = (method == 1 || (method == 2 && hex_thr > 0)) ? 15 : 5;
     Owner o;
     o.ph = PH_DONE; o.mx = o.my = o.pmx = o.pmy = 0; o.merange = 0; o.it = 0; o.dir = 0; o.cost = 0; o.cost0 = 0;
-    bool root = false, inside = false;
+    bool inside = false;
     const int px = qx0 + (t & ((1 << l2n) - 1)), py = qy0 + ((t >> l2n) & ((1 << l2n) - 1));
     const bool is_owner = t < npu;
     if (is_owner) {
         inside = ks_pu_inside(g, cx, cy, level, px, py);
         if (inside) {
-            root = true;
+            bool root = true;
             for (int a = level - 1; a >= 0; --a) {
                 const int ax = px >> (level - a), ay = py >> (level - a);
                 if (ks_pu_inside(g, cx, cy, a, ax, ay)) {
@@ -154,34 +157,43 @@ __device__ __forceinline__ void me_group(const KsGeom &g, int cx, int cy, int ra
                 o.pmy = clip3(-range, range, ((int)prev_ctu[0].mvy + 2) >> 2);
             }
             o.merange = root ? range : max(range >> 2, 4);
-            o.ph = PH_INIT;
+            o.mx = o.pmx; o.my = o.pmy;
+            o.ph = (root && (o.pmx | o.pmy)) ? PH_INIT : PH_START;                     // a root PU with a temporal predictor also tries the zero vector
             Q.pred[t] = (o.pmx & 0xFFFF) | (o.pmy << 16);
         } else {                                                                        // PU not (completely) inside the picture: marked, never searched
             ks265_pu e; e.mvx = e.mvy = e.mvpx = e.mvpy = 0; e.cost = KS_COST_INVALID; e.dist = KS_COST_INVALID;
             out_ctu[ks_pu_index(level, px, py)] = e;
         }
     }
-    const bool root_zero = root && (o.pmx | o.pmy);
     const unsigned t1 = 62u << (2 * (6 - level) - 4), t2 = 50u << (2 * (6 - level) - 4);
+#ifdef KS_EXP_ME_CLOCK
+    long long acc[5] = {0, 0, 0, 0, 0}; const long long tl0 = ME_NOW();
+#endif
 
 #pragma unroll 1
     for (;;) {
-        // ---- owners: publish the state, take phase_count() job slots (a slot = one candidate, eligible or not), fill them with stubs
+#ifdef KS_EXP_ME_CLOCK
+        const long long tr0 = ME_NOW();
+#endif
+        // ---- owners: publish the phase descriptor, take one job slot per candidate (eligible or not), fill the slots with stubs
         //      (owner, k); the candidates themselves are expanded by the evaluating lanes
         bool emitted = false;
         const bool pending = o.ph != PH_DONE;
         if (WG ? t < 64 : true) {
-            const int cnt = pending ? phase_count(o, root_zero) : 0;
+            int dp = 0;
+            const int cnt = pending ? phase_desc(o, nstart, dp) : 0;
             if (t == 0) Q.njobs = 0;
             __builtin_amdgcn_wave_barrier();
             if (cnt > 0) {
                 const int base = atomicAdd(&Q.njobs, cnt);                              // slot order is arbitrary: the winner does not depend on it
                 emitted = base + cnt <= JOB_CAP;                                        // an owner that does not fit waits for the next round
                 const int end = min(base + cnt, JOB_CAP);
-                for (int s = base; s < end; ++s) Q.jobs[s] = emitted ? (unsigned short)(t | ((s - base) << 6)) : (unsigned short)0xFFFF;
+                for (int s = base; s < end; ++s) Q.jobs[s] = emitted ? (unsigned short)(t | ((s - base) << 4)) : (unsigned short)0xFFFF;
                 if (emitted) {
-                    Q.desc[t] = make_int2(o.ph | (o.dir << 8) | (o.merange << 16), (o.mx & 0xFFFF) | (o.my << 16));
-                    Q.best[t] = o.ph == PH_INIT ? ~0ull : ((unsigned long long)(o.cost << 8) << 32);
+                    Q.desc[t] = make_int2((o.mx & 0xFFFF) | (o.my << 16), dp);
+                    const unsigned long long inc = (o.ph == PH_INIT || o.ph == PH_START) ? ~0ull : ((unsigned long long)(o.cost << 8) << 32);
+                    Q.best[t][0] = inc;
+                    if (o.ph == PH_START) { Q.best[t][1] = ~0ull; Q.best[t][2] = ~0ull; Q.best[t][3] = ~0ull; }
                 }
             }
             if (WG) { const unsigned long long anyp = __ballot(pending); if (t == 0) Q.active = anyp != 0ull; }
@@ -191,23 +203,32 @@ __device__ __forceinline__ void me_group(const KsGeom &g, int cx, int cy, int ra
         if (WG) active = Q.active != 0; else active = __ballot(pending) != 0ull;
         if (!active) break;
         const int njobs = min(Q.njobs, JOB_CAP);
+#ifdef KS_EXP_ME_CLOCK
+        const long long tr1 = ME_NOW();
+#endif
         // ---- all lanes of the group: one lane = one 8x8 tile of one candidate
         const int items = njobs << l2t;
         for (int base = 0; base < items; base += NT) {
             const int it = base + t;
             unsigned sad = 0;
-            int pu = 0, x = 0, y = 0, key = 0;
+            int pu = 0, x = 0, y = 0, key = 0, slot = 0;
             bool live = it < items;
             if (live) {
                 const unsigned stub = Q.jobs[it >> l2t];
-                live = stub != 0xFFFFu;
-                pu = stub & 63;
-                const int2 d = Q.desc[pu & 15];
-                Owner c;
-                c.ph = d.x & 255; c.dir = (d.x >> 8) & 255; c.merange = d.x >> 16; c.mx = (int)(short)(d.y & 0xFFFF); c.my = d.y >> 16;
-                c.pmx = c.pmy = 0;
-                if (c.ph == PH_INIT) { const int pr = Q.pred[pu & 15]; c.pmx = (int)(short)(pr & 0xFFFF); c.pmy = pr >> 16; }
-                live = live && phase_cand(c, (int)(stub >> 6), range, x, y, key);
+                pu = stub & 15;
+                const int k = (int)(stub >> 4);
+                const int2 d = Q.desc[pu];
+                const int dp = d.y;
+                const unsigned e = L.ctab[(dp & 63) + (k & ((dp >> 6) & 127))];
+                const int mult = ((dp >> 16) & 15) + ((dp >> 20) & 15) * (k >> ((dp >> 13) & 7));
+                x = (int)(short)(d.x & 0xFFFF) + (int)(signed char)(e & 0xFF) * mult;
+                y = (d.x >> 16) + (int)(signed char)((e >> 8) & 0xFF) * mult;
+                const int keyadd = (dp >> 24) & 15;
+                key = keyadd ? k + keyadd : (int)((e >> 16) & 0xFF);
+                slot = (int)(e >> 24);
+                if (dp & DP_INIT) { x = k ? 0 : x; y = k ? 0 : y; key = k + 1; slot = 0; }
+                const int lim = (dp >> 28) & 1 ? range : ME_WLIM;
+                live = stub != 0xFFFFu && abs(x) <= lim && abs(y) <= lim;
             }
             if (live) {
                 const int tile = it & ((1 << l2t) - 1);
@@ -230,13 +251,16 @@ __device__ __forceinline__ void me_group(const KsGeom &g, int cx, int cy, int ra
             if (level <= 1) { sad += (unsigned)dpp_mov<KS265_DPP_ROW_HALF_MIRROR>((int)sad); sad += (unsigned)dpp_mov<KS265_DPP_ROW_MIRROR>((int)sad); }
             if (level == 0) { sad += (unsigned)__builtin_amdgcn_ds_swizzle((int)sad, 0x1F | (16 << 10)); sad += (unsigned)__shfl_xor((int)sad, 32, 64); }
             if (live && (it & ((1 << l2t) - 1)) == 0) {
-                const int pr = Q.pred[pu & 15];
+                const int pr = Q.pred[pu];
                 const unsigned cost = sad + mv_rate(lam, x, y, (int)(short)(pr & 0xFFFF), pr >> 16);
                 const unsigned long long v = ((unsigned long long)((cost << 8) | (unsigned)key) << 32) | (unsigned long long)(((unsigned)(x + 128) << 8) | (unsigned)(y + 128));
-                atomicMin(&Q.best[pu & 15], v);
+                atomicMin(&Q.best[pu][slot], v);
             }
         }
         sync();
+#ifdef KS_EXP_ME_CLOCK
+        const long long tr2 = ME_NOW();
+#endif
         // ---- owners advance (the transitions of oracle/ks265_me_ref.c)
         if (emitted) {
             bool first = true;
@@ -244,20 +268,40 @@ __device__ __forceinline__ void me_group(const KsGeom &g, int cx, int cy, int ra
                 bool improved = false;
                 int key = 0, wx = o.mx, wy = o.my;
                 unsigned wcost = o.cost;
-                if (first) {
-                    const unsigned long long b = Q.best[t];
-                    key = (int)((b >> 32) & 255u);
-                    improved = key != 0;
-                    if (improved) { wcost = (unsigned)(b >> 40); wx = (int)((b >> 8) & 255u) - 128; wy = (int)(b & 255u) - 128; }
+                auto take = [&](unsigned long long b) { key = (int)((b >> 32) & 255u); wcost = (unsigned)(b >> 40); wx = (int)((b >> 8) & 255u) - 128; wy = (int)(b & 255u) - 128; };
+                if (first && o.ph != PH_START) {
+                    const unsigned long long b = Q.best[t][0];
+                    improved = ((b >> 32) & 255u) != 0;
+                    if (improved) take(b);
                 }
-                first = false;
-                if (o.ph != PH_HSTEP) { o.cost = wcost; o.mx = wx; o.my = wy; }         // interMeHex's walk may refuse the move (below)
+                if (o.ph != PH_HSTEP && o.ph != PH_START) { o.cost = wcost; o.mx = wx; o.my = wy; }   // interMeHex's walk may refuse the move (below)
                 switch (o.ph) {
-                case PH_INIT: {
+                case PH_INIT: o.ph = PH_START; break;                                   // the better of the two start candidates is the start point
+                case PH_START: {                                                        // start cost, then the first step of the PU's pattern
+                    const unsigned long long b0 = Q.best[t][0], b1 = Q.best[t][1];
+                    o.cost = (unsigned)(b0 >> 40);
                     const unsigned sad0 = o.cost - mv_rate(lam, o.mx, o.my, o.pmx, o.pmy);
-                    if (method == 0) { o.ph = o.merange > 0 ? PH_DIA : PH_DONE; o.it = 0; }
-                    else if (method == 1 || (hex_thr > 0 && sad0 < ((unsigned)hex_thr << (2 * (6 - level))))) o.ph = PH_H6;
-                    else { o.ph = PH_U1; o.cost0 = o.cost; }
+                    if (method == 0) {                                                  // interMeDia, first step
+                        improved = (unsigned)(b1 >> 40) < o.cost;
+                        if (improved) { take(b1); o.cost = wcost; o.mx = wx; o.my = wy; }
+                        o.it = 0; o.ph = PH_DIA;
+                        if (!improved || ++o.it >= o.merange) o.ph = PH_DONE;
+                    } else if (method == 1 || (hex_thr > 0 && sad0 < ((unsigned)hex_thr << (2 * (6 - level))))) {   // interMeHex
+                        const unsigned long long b3 = Q.best[t][3];
+                        if ((unsigned)(b3 >> 40) < o.cost) {                            // the hexagon moves: continue as after PH_H6
+                            take(b3); o.cost = wcost; o.mx = wx; o.my = wy;
+                            o.dir = key - 2; o.it = (o.merange >> 1) - 1; o.ph = o.it > 0 ? PH_HSTEP : PH_SQUARE;
+                        } else {                                                        // it does not: the closing square was evaluated as well
+                            const unsigned long long b2 = Q.best[t][2], bs = b1 < b2 ? b1 : b2;
+                            if ((unsigned)(bs >> 40) < o.cost) { take(bs); o.cost = wcost; o.mx = wx; o.my = wy; }
+                            o.ph = PH_DONE;
+                        }
+                    } else {                                                            // interMeUMH, step 1
+                        o.cost0 = o.cost;
+                        if ((unsigned)(b1 >> 40) < o.cost) { take(b1); o.cost = wcost; o.mx = wx; o.my = wy; }
+                        if (t1 > o.cost0) o.ph = PH_DONE;
+                        else o.ph = o.cost > t2 ? PH_UCROSS : PH_UHEX6;
+                    }
                     break;
                 }
                 case PH_DIA:                                                            // interMeDia: no range test, merange steps
@@ -299,9 +343,18 @@ __device__ __forceinline__ void me_group(const KsGeom &g, int cx, int cy, int ra
                     break;
                 default: break;
                 }
-            } while (o.ph != PH_DONE && phase_count(o, root_zero) == 0);                // a phase without candidates passes as "no improvement"
+                first = false;
+                int dpx;
+                if (o.ph == PH_DONE || phase_desc(o, nstart, dpx) != 0) break;          // a phase without candidates passes as "no improvement"
+            } while (true);
         }
+#ifdef KS_EXP_ME_CLOCK
+        { const long long tr3 = ME_NOW(); acc[0] += 1; acc[1] += tr1 - tr0; acc[2] += tr2 - tr1; acc[3] += tr3 - tr2; acc[4] += njobs; }
+#endif
     }
+#ifdef KS_EXP_ME_CLOCK
+    if (t == 0 && (WG || qx0 + qy0 == 0)) { for (int i = 0; i < 5; ++i) atomicAdd(&ks_me_dbg[level * 8 + i], (unsigned long long)acc[i]); atomicAdd(&ks_me_dbg[level * 8 + 5], (unsigned long long)(ME_NOW() - tl0)); }
+#endif
     // ---- results of the group
     if (is_owner && inside) {
         const int idx = ks_pu_index(level, px, py);
@@ -320,13 +373,17 @@ __global__ __launch_bounds__(256, 3) void me_int_kernel(KsGeom g, int range, int
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ctu = ks_xcd_swizzle(blockIdx.x, g.ctu_cols * g.ctu_rows), cx = ctu % g.ctu_cols, cy = ctu / g.ctu_cols;
     const uint8_t *R = ks_org_y(g, ref), *Sp = ks_org_y(g, src);
-    // reference window: 16-byte global loads (x0 - 80 is 16-byte aligned), dword LDS stores
-    for (int i = tid; i < WIN_ROWS * (WIN_W / 16); i += 256) {
-        const int r = i / (WIN_W / 16), c = i - r * (WIN_W / 16);
+    // reference window: 16-byte global loads from x0 - 80 (16-byte aligned), the dwords of x in [-68, 136) go to LDS
+    for (int i = tid; i < WIN_ROWS * 14; i += 256) {
+        const int r = i / 14, c = i - r * 14;
         const int yy = min(cy * 64 - WIN_YT + r, g.H + KS_PAD_Y - 1);     // rows past the border are never used by a valid PU
-        const uint4 v = *(const uint4 *)(R + (long)yy * g.sy + cx * 64 - WIN_XL + c * 16);
-        unsigned *d = (unsigned *)(L.win + r * WIN_STRIDE + c * 16);
-        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        const uint4 v = *(const uint4 *)(R + (long)yy * g.sy + cx * 64 - WIN_LOAD_XL + c * 16);
+        const int j0 = c * 4 - (WIN_LOAD_XL - WIN_XL) / 4;                // first LDS dword of this piece (may hang over either end of the row)
+        unsigned *d = (unsigned *)(L.win + r * WIN_STRIDE) + j0;
+        if (j0 >= 0 && j0 < WIN_STRIDE / 4) d[0] = v.x;
+        if (j0 + 1 >= 0 && j0 + 1 < WIN_STRIDE / 4) d[1] = v.y;
+        if (j0 + 2 >= 0 && j0 + 2 < WIN_STRIDE / 4) d[2] = v.z;
+        if (j0 + 3 >= 0 && j0 + 3 < WIN_STRIDE / 4) d[3] = v.w;
     }
     {
         const int r = tid >> 2, c = tid & 3;
@@ -334,6 +391,7 @@ __global__ __launch_bounds__(256, 3) void me_int_kernel(KsGeom g, int range, int
         unsigned *d = (unsigned *)(L.fenc + r * FENC_STRIDE + c * 16);
         d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
     }
+    if (tid < TB_SIZE) L.ctab[tid] = kCandTab[tid];
     const ks265_pu *prev_ctu = prev ? prev + (long)ctu * 85 : nullptr;
     ks265_pu *out_ctu = out + (long)ctu * 85;
     __syncthreads();
