@@ -206,55 +206,77 @@ __device__ __forceinline__ void me_group(const KsGeom &g, int cx, int cy, int ra
 #ifdef KS_EXP_ME_CLOCK
         const long long tr1 = ME_NOW();
 #endif
-        // ---- all lanes of the group: one lane = one 8x8 tile of one candidate
+        // ---- all lanes of the group: one lane = one 8x8 tile of one candidate; NI items per lane are in flight together (their LDS
+        //      round trips - stub, descriptor, table entry, window rows, result slot - overlap instead of queueing behind each other)
         const int items = njobs << l2t;
-        for (int base = 0; base < items; base += NT) {
-            const int it = base + t;
-            unsigned sad = 0;
-            int pu = 0, x = 0, y = 0, key = 0, slot = 0;
-            bool live = it < items;
-            if (live) {
-                const unsigned stub = Q.jobs[it >> l2t];
-                pu = stub & 15;
-                const int k = (int)(stub >> 4);
-                const int2 d = Q.desc[pu];
-                const int dp = d.y;
-                const unsigned e = L.ctab[(dp & 63) + (k & ((dp >> 6) & 127))];
-                const int mult = ((dp >> 16) & 15) + ((dp >> 20) & 15) * (k >> ((dp >> 13) & 7));
-                x = (int)(short)(d.x & 0xFFFF) + (int)(signed char)(e & 0xFF) * mult;
-                y = (d.x >> 16) + (int)(signed char)((e >> 8) & 0xFF) * mult;
-                const int keyadd = (dp >> 24) & 15;
-                key = keyadd ? k + keyadd : (int)((e >> 16) & 0xFF);
-                slot = (int)(e >> 24);
-                if (dp & DP_INIT) { x = k ? 0 : x; y = k ? 0 : y; key = k + 1; slot = 0; }
-                const int lim = (dp >> 28) & 1 ? range : ME_WLIM;
-                live = stub != 0xFFFFu && abs(x) <= lim && abs(y) <= lim;
-            }
-            if (live) {
-                const int tile = it & ((1 << l2t) - 1);
-                const int ppx = qx0 + (pu & ((1 << l2n) - 1)), ppy = qy0 + (pu >> l2n);
-                const int bx = ppx * S + (tile & (tpr - 1)) * 8, by = ppy * S + (tile >> (3 - level)) * 8;
-                const int wx = bx + x + WIN_XL, wy = by + y + WIN_YT;
-                const uint8_t *p = L.win + wy * WIN_STRIDE + (wx & ~3);
-                const uint8_t *f = L.fenc + by * FENC_STRIDE + bx;
-                const unsigned sh = wx & 3;
+        constexpr int NI = 1;
+        for (int base = 0; base < items; base += NT * NI) {
+            int pu[NI], x[NI], y[NI], key[NI], slot[NI], kk[NI];
+            bool live[NI];
+            unsigned sad[NI], stub[NI];
+            int2 dsc[NI];
+            unsigned ent[NI];
 #pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    const unsigned w0 = *(const unsigned *)(p + r * WIN_STRIDE), w1 = *(const unsigned *)(p + r * WIN_STRIDE + 4), w2 = *(const unsigned *)(p + r * WIN_STRIDE + 8);
-                    const unsigned f0 = *(const unsigned *)(f + r * FENC_STRIDE), f1 = *(const unsigned *)(f + r * FENC_STRIDE + 4);
-                    sad = sad_u8x4(f0, align_bytes(w1, w0, sh), sad);
-                    sad = sad_u8x4(f1, align_bytes(w2, w1, sh), sad);
+            for (int n = 0; n < NI; ++n) {
+                const int it = base + n * NT + t;
+                live[n] = it < items;
+                stub[n] = Q.jobs[min(it, items - 1) >> l2t];
+            }
+#pragma unroll
+            for (int n = 0; n < NI; ++n) { pu[n] = stub[n] & 15; kk[n] = (int)(stub[n] >> 4) & 127; dsc[n] = Q.desc[pu[n]]; }
+#pragma unroll
+            for (int n = 0; n < NI; ++n) ent[n] = L.ctab[(dsc[n].y & 63) + (kk[n] & ((dsc[n].y >> 6) & 127))];
+            const uint8_t *p[NI], *f[NI];
+            unsigned sh[NI];
+#pragma unroll
+            for (int n = 0; n < NI; ++n) {
+                const int dp = dsc[n].y, k = kk[n];
+                const unsigned e = ent[n];
+                const int mult = ((dp >> 16) & 15) + ((dp >> 20) & 15) * (k >> ((dp >> 13) & 7));
+                x[n] = (int)(short)(dsc[n].x & 0xFFFF) + (int)(signed char)(e & 0xFF) * mult;
+                y[n] = (dsc[n].x >> 16) + (int)(signed char)((e >> 8) & 0xFF) * mult;
+                const int keyadd = (dp >> 24) & 15;
+                key[n] = keyadd ? k + keyadd : (int)((e >> 16) & 0xFF);
+                slot[n] = (int)(e >> 24);
+                if (dp & DP_INIT) { x[n] = k ? 0 : x[n]; y[n] = k ? 0 : y[n]; key[n] = k + 1; slot[n] = 0; }
+                const int lim = (dp >> 28) & 1 ? range : ME_WLIM;
+                live[n] = live[n] && stub[n] != 0xFFFFu && abs(x[n]) <= lim && abs(y[n]) <= lim;
+                const int tile = (base + n * NT + t) & ((1 << l2t) - 1);
+                const int ppx = qx0 + (pu[n] & ((1 << l2n) - 1)), ppy = qy0 + (pu[n] >> l2n);
+                const int bx = ppx * S + (tile & (tpr - 1)) * 8, by = ppy * S + (tile >> (3 - level)) * 8;
+                const int wx = bx + (live[n] ? x[n] : 0) + WIN_XL, wy = by + (live[n] ? y[n] : 0) + WIN_YT;   // a dead item reads (and discards) the zero displacement
+                p[n] = L.win + wy * WIN_STRIDE + (wx & ~3);
+                f[n] = L.fenc + by * FENC_STRIDE + bx;
+                sh[n] = wx & 3;
+                sad[n] = 0;
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+#pragma unroll
+                for (int n = 0; n < NI; ++n) {
+                    const unsigned w0 = *(const unsigned *)(p[n] + r * WIN_STRIDE), w1 = *(const unsigned *)(p[n] + r * WIN_STRIDE + 4), w2 = *(const unsigned *)(p[n] + r * WIN_STRIDE + 8);
+                    const unsigned f0 = *(const unsigned *)(f[n] + r * FENC_STRIDE), f1 = *(const unsigned *)(f[n] + r * FENC_STRIDE + 4);
+                    sad[n] = sad_u8x4(f0, align_bytes(w1, w0, sh[n]), sad[n]);
+                    sad[n] = sad_u8x4(f1, align_bytes(w2, w1, sh[n]), sad[n]);
                 }
             }
-            // the tiles of a job are adjacent lanes: 1 / 4 / 16 / 64 of them
-            if (level <= 2) { sad += (unsigned)dpp_mov<KS265_DPP_QUAD_XOR1>((int)sad); sad += (unsigned)dpp_mov<KS265_DPP_QUAD_XOR2>((int)sad); }
-            if (level <= 1) { sad += (unsigned)dpp_mov<KS265_DPP_ROW_HALF_MIRROR>((int)sad); sad += (unsigned)dpp_mov<KS265_DPP_ROW_MIRROR>((int)sad); }
-            if (level == 0) { sad += (unsigned)__builtin_amdgcn_ds_swizzle((int)sad, 0x1F | (16 << 10)); sad += (unsigned)__shfl_xor((int)sad, 32, 64); }
-            if (live && (it & ((1 << l2t) - 1)) == 0) {
-                const int pr = Q.pred[pu];
-                const unsigned cost = sad + mv_rate(lam, x, y, (int)(short)(pr & 0xFFFF), pr >> 16);
-                const unsigned long long v = ((unsigned long long)((cost << 8) | (unsigned)key) << 32) | (unsigned long long)(((unsigned)(x + 128) << 8) | (unsigned)(y + 128));
-                atomicMin(&Q.best[pu][slot], v);
+#pragma unroll
+            for (int n = 0; n < NI; ++n) {
+                unsigned sd = sad[n];
+                // the tiles of a job are adjacent lanes: 1 / 4 / 16 / 64 of them
+                if (level <= 2) { sd += (unsigned)dpp_mov<KS265_DPP_QUAD_XOR1>((int)sd); sd += (unsigned)dpp_mov<KS265_DPP_QUAD_XOR2>((int)sd); }
+                if (level <= 1) { sd += (unsigned)dpp_mov<KS265_DPP_ROW_HALF_MIRROR>((int)sd); sd += (unsigned)dpp_mov<KS265_DPP_ROW_MIRROR>((int)sd); }
+                if (level == 0) { sd += (unsigned)__builtin_amdgcn_ds_swizzle((int)sd, 0x1F | (16 << 10)); sd += (unsigned)__shfl_xor((int)sd, 32, 64); }
+                sad[n] = sd;
+            }
+#pragma unroll
+            for (int n = 0; n < NI; ++n) {
+                if (live[n] && ((base + n * NT + t) & ((1 << l2t) - 1)) == 0) {
+                    const int pr = Q.pred[pu[n]];
+                    const unsigned cost = sad[n] + mv_rate(lam, x[n], y[n], (int)(short)(pr & 0xFFFF), pr >> 16);
+                    const unsigned long long v = ((unsigned long long)((cost << 8) | (unsigned)key[n]) << 32) | (unsigned long long)(((unsigned)(x[n] + 128) << 8) | (unsigned)(y[n] + 128));
+                    atomicMin(&Q.best[pu[n]][slot[n]], v);
+                }
             }
         }
         sync();
@@ -371,38 +393,64 @@ __global__ __launch_bounds__(256, 3) void me_int_kernel(KsGeom g, int range, int
 {
     __shared__ __attribute__((aligned(16))) MeLds L;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef KS_EXP_ME_CLOCK
+    const long long tk0 = ME_NOW();
+#endif
     const int ctu = ks_xcd_swizzle(blockIdx.x, g.ctu_cols * g.ctu_rows), cx = ctu % g.ctu_cols, cy = ctu / g.ctu_cols;
     const uint8_t *R = ks_org_y(g, ref), *Sp = ks_org_y(g, src);
-    // reference window: 16-byte global loads from x0 - 80 (16-byte aligned), the dwords of x in [-68, 136) go to LDS
-    for (int i = tid; i < WIN_ROWS * 14; i += 256) {
-        const int r = i / 14, c = i - r * 14;
-        const int yy = min(cy * 64 - WIN_YT + r, g.H + KS_PAD_Y - 1);     // rows past the border are never used by a valid PU
-        const uint4 v = *(const uint4 *)(R + (long)yy * g.sy + cx * 64 - WIN_LOAD_XL + c * 16);
-        const int j0 = c * 4 - (WIN_LOAD_XL - WIN_XL) / 4;                // first LDS dword of this piece (may hang over either end of the row)
-        unsigned *d = (unsigned *)(L.win + r * WIN_STRIDE) + j0;
-        if (j0 >= 0 && j0 < WIN_STRIDE / 4) d[0] = v.x;
-        if (j0 + 1 >= 0 && j0 + 1 < WIN_STRIDE / 4) d[1] = v.y;
-        if (j0 + 2 >= 0 && j0 + 2 < WIN_STRIDE / 4) d[2] = v.z;
-        if (j0 + 3 >= 0 && j0 + 3 < WIN_STRIDE / 4) d[3] = v.w;
-    }
+    // reference window: 16-byte global loads from x0 - 80 (16-byte aligned), the dwords of x in [-68, 136) go to LDS.  All loads of a
+    // thread are issued before the first store (11 pieces in flight per lane: the prologue is one memory latency, not eleven)
     {
-        const int r = tid >> 2, c = tid & 3;
-        const uint4 v = *(const uint4 *)(Sp + (long)(cy * 64 + r) * g.sy + cx * 64 + c * 16);
-        unsigned *d = (unsigned *)(L.fenc + r * FENC_STRIDE + c * 16);
-        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        constexpr int NPIECE = (WIN_ROWS * 14 + 255) / 256;
+        uint4 v[NPIECE];
+        const uint4 fsrc = *(const uint4 *)(Sp + (long)(cy * 64 + (tid >> 2)) * g.sy + cx * 64 + (tid & 3) * 16);
+#pragma unroll
+        for (int n = 0; n < NPIECE; ++n) {
+            const int i = min(tid + 256 * n, WIN_ROWS * 14 - 1), r = i / 14, c = i - r * 14;
+            const int yy = min(cy * 64 - WIN_YT + r, g.H + KS_PAD_Y - 1);     // rows past the border are never used by a valid PU
+            v[n] = *(const uint4 *)(R + (long)yy * g.sy + cx * 64 - WIN_LOAD_XL + c * 16);
+        }
+#pragma unroll
+        for (int n = 0; n < NPIECE; ++n) {
+            const int i = tid + 256 * n, r = i / 14, c = i - r * 14;
+            const int j0 = c * 4 - (WIN_LOAD_XL - WIN_XL) / 4;            // first LDS dword of this piece (may hang over either end of the row)
+            unsigned *d = (unsigned *)(L.win + r * WIN_STRIDE) + j0;
+            if (i < WIN_ROWS * 14) {
+                if (j0 >= 0) d[0] = v[n].x;
+                if (j0 + 1 >= 0 && j0 + 1 < WIN_STRIDE / 4) d[1] = v[n].y;
+                if (j0 + 2 >= 0 && j0 + 2 < WIN_STRIDE / 4) d[2] = v[n].z;
+                if (j0 + 3 < WIN_STRIDE / 4) d[3] = v[n].w;
+            }
+        }
+        unsigned *d = (unsigned *)(L.fenc + (tid >> 2) * FENC_STRIDE + (tid & 3) * 16);
+        d[0] = fsrc.x; d[1] = fsrc.y; d[2] = fsrc.z; d[3] = fsrc.w;
     }
     if (tid < TB_SIZE) L.ctab[tid] = kCandTab[tid];
     const ks265_pu *prev_ctu = prev ? prev + (long)ctu * 85 : nullptr;
     ks265_pu *out_ctu = out + (long)ctu * 85;
     __syncthreads();
+#ifdef KS_EXP_ME_CLOCK
+    const long long tk1 = ME_NOW();
+#endif
+#ifdef KS_EXP_ME_PROLOGUE_ONLY
+    if (tid == 0) out_ctu[0].cost = L.win[tid * 7] + L.fenc[9];
+    return;
+#endif
     // the 64x64 PU: the whole work-group
     me_group<true>(g, cx, cy, range, lam, method, hex_thr, L, L.grp[0], 0, 0, 0, 0, prev_ctu, out_ctu, tid);
     __syncthreads();                                                                    // its vector is the predictor of everything below
+#ifdef KS_EXP_ME_CLOCK
+    const long long tk2 = ME_NOW();
+#endif
     // 32x32, 16x16, 8x8: one quadrant per wave, each wave on its own
     const int qx = wave & 1, qy = wave >> 1;
 #pragma unroll 1
     for (int level = 1; level < 4; ++level)
         me_group<false>(g, cx, cy, range, lam, method, hex_thr, L, L.grp[wave], level, level - 1, qx << (level - 1), qy << (level - 1), prev_ctu, out_ctu, lane);
+#ifdef KS_EXP_ME_CLOCK
+    const long long tk3 = ME_NOW();
+    if (lane == 0) { atomicAdd(&ks_me_dbg[6], (unsigned long long)(tk1 - tk0)); atomicAdd(&ks_me_dbg[7], (unsigned long long)(tk2 - tk1)); atomicAdd(&ks_me_dbg[14], (unsigned long long)(tk3 - tk2)); atomicAdd(&ks_me_dbg[15], 1ull); }
+#endif
 }
 
 extern "C" int ks265_me_integer(ks265_frame *f, ks265_pic src, ks265_pic ref, const ks265_pu *prev_pu, ks265_pu *pu)
