@@ -1,0 +1,89 @@
+"""Shared by tests/test_stream.py, tests/test_gpu_stream.py and tests/golden/gen_stream_golden.py: the stream-level parity cases.
+Each case encodes a short synthetic GOP with a per-picture `encode(kind, display index, refs)` callback supplied by the caller (CPU
+oracle pipeline or HIP pipeline) and writes the Annex-B stream with the host bitstream writer."""
+from __future__ import annotations
+
+import itertools
+
+import numpy as np
+
+CASES = {
+    # name: (W, H, qp, me_method, me_hex_thr, sao, deblock, gop kind, frames / parameter)
+    "ippp_416x240_umh": (416, 240, 27, 2, 16, 1, 1, "ippp", 4),
+    "ippp_200x136_hex_qp37": (200, 136, 37, 1, 0, 1, 1, "ippp", 4),
+    "ippp_136x72_dia_qp12": (136, 72, 12, 0, 0, 1, 1, "ippp", 3),
+    "ippp_72x200_nodeblock_qp45": (72, 200, 45, 1, 0, 1, 0, "ippp", 3),
+    "ippp_8x8": (8, 8, 30, 1, 0, 1, 1, "ippp", 3),
+    "ippp_64x64_nosao_qp5": (64, 64, 5, 2, 0, 0, 1, "ippp", 3),
+    "mref3_416x240": (416, 240, 27, 2, 16, 1, 1, "mref", 3),
+    "hierb4_416x240": (416, 240, 27, 1, 0, 1, 1, "hier", 4),
+    "ippp_1280x720_umh": (1280, 720, 27, 2, 16, 1, 1, "ippp", 3),
+}
+
+
+def schedule(kind: str, par: int):
+    """list of (display index, picture kind, list-0 display indices, list-1 display indices, qp offset, rps [(display index, used)], is reference)"""
+    from ks265codec_amd.gop import hier_order
+    out = []
+    if kind == "ippp":
+        for t in range(par):
+            out.append((t, "I" if t == 0 else "P", [t - 1] if t else [], [], 0 if t == 0 else 1, [(t - 1, True)] if t else [], True))
+    elif kind == "mref":
+        for t in range(par + 3):
+            refs = [t - 1 - i for i in range(min(par, t))]
+            out.append((t, "I" if t == 0 else "P", refs, [], 0 if t == 0 else 1, [(p, True) for p in refs], True))
+    else:
+        G = par
+        seq = list(itertools.islice(hier_order(G, 128), 2 * G + 1))
+        done = set()
+        for i, (d, k, r0, r1, layer) in enumerate(seq):
+            later = seq[i + 1:]
+            needed = {r for (_, _, a, b, _) in later for r in (a, b) if r is not None and r in done}
+            cur = {r for r in (r0, r1) if r is not None}
+            rps = [(p, p in cur) for p in sorted(needed | cur)]
+            isref = any(d in (a, b) for (_, _, a, b, _) in later)
+            out.append((d, k, [r0] if r0 is not None else [], [r1] if r1 is not None else [], 0 if k == "I" else 1 + layer, rps, isref))
+            done.add(d)
+    return out
+
+
+def make_stream(name: str, encode):
+    """encode(display index, kind, l0 display indices, l1 display indices, qp) -> (cu8, [lvl_y, lvl_u, lvl_v], sao records or None, recon I420);
+    returns (stream bytes, {display index: recon I420})"""
+    from ks265codec_amd import stream as S
+    W, H, qp, me, thr, sao, df, kind, par = CASES[name]
+    sched = schedule(kind, par)
+    nref = max([len(s[2]) + len(s[3]) for s in sched] + [1])
+    reorder = par if kind == "hier" else 0
+    w = S.StreamWriter(W, H, sao=sao, deblock=df, max_dec_pic_buffering=max(nref, par if kind == "hier" else 1) + 2, max_num_reorder=reorder)
+    bs = w.headers()
+    recs = {}
+    for d, k, l0, l1, dq, rps, isref in sched:
+        cu8, lvl, saop, rec = encode(d, k, l0, l1, min(51, qp + dq))
+        recs[d] = rec
+        if k == "I":
+            bs += w.slice(S.NAL_IDR_W_RADL, S.SLICE_I, 0, min(51, qp + dq), cu8, lvl, saop if sao else None)
+        else:
+            nal = S.NAL_TRAIL_R if isref else S.NAL_TRAIL_N
+            bs += w.slice(nal, S.SLICE_P if k == "P" else S.SLICE_B, d, min(51, qp + dq), cu8, lvl, saop if sao else None, rps=rps, l0=l0, l1=l1)
+    return bs, recs
+
+
+def oracle_encoder(name: str):
+    """the CPU oracle pipeline as the per-picture encoder of make_stream"""
+    from ks265codec_amd.synth import lambda_q4, make_clip
+    from oracle_lib import OraclePipeline
+    W, H, qp, me, thr, sao, df, kind, par = CASES[name]
+    n = 1 + max(s[0] for s in schedule(kind, par))
+    clip = make_clip(W, H, n, seed=len(name) * 7 + W, abc=(17, 23, 9))
+    o = OraclePipeline(W, H, qp, lambda_q4(qp), me_method=me, me_hex_thr=thr, sao=sao, deblock=df)
+    dpb = {}
+
+    def encode(d, k, l0, l1, q):
+        o.set_qp(q, lambda_q4(q))
+        if k == "P" and len(l0) > 1:
+            dpb[d] = o.encode_mref(clip[d], [dpb[r] for r in l0])
+        else:
+            dpb[d] = o.encode(clip[d], k, dpb.get(l0[0]) if l0 else None, dpb.get(l1[0]) if l1 else None)
+        return o.cu8.copy(), [a.copy() for a in o.lvl], o.sao.copy(), o.store(dpb[d])
+    return encode
