@@ -1,0 +1,91 @@
+/* ks265_enc.h — the library boundary "B2" of SURVEY.md §8(b): the encoder API of the KSC265 SDK (qy265enc.h:196-233, qy265def.h:7-22,
+ * 179-198 under /root/reference/Android_demo/prebuilt/include/), served by the MI355X pixel path + the host bitstream writer.
+ *
+ * A caller written against the SDK keeps including the SDK's own qy265enc.h / qy265def.h and links libks265enc.so instead of libqyencoder:
+ * the entry points have the SDK's names and signatures, the structures below have the SDK's layout (field order and types; checked
+ * against offsets computed from the SDK header by tests/test_enc_api.py).  This header exists so that the library, its CLI and its tests
+ * compile without the SDK; its comments say what THIS implementation does with each field.
+ *
+ * Behaviour that differs from the SDK, all of it reported through the log callback at open:
+ *   - the encoder's decisions are its own: the stream is a conforming HEVC stream, not appencoder's bytes;
+ *   - rate control: rc = 0 (constant QP with the reference's hidden offsets I = Q, P = Q + 1, B = Q + 2 ..) is exact; rc = 3 (CRF) maps
+ *     crf to that QP ladder; rc = 1 / 2 / 4 (bitrate targets) run a frame-level controller on top of it; rc = 5 and VBV are not implemented;
+ *   - rdoq, transskip, part, tuInter / tuIntra, vpp_*, 2-pass, long-term references, AQ: accepted, ignored (the pixel path has no such
+ *     stage yet);
+ *   - input pictures are COPIED inside QY265EncoderEncodeFrame: the caller may reuse its buffers at once (the SDK requires them to stay
+ *     valid until the frame is done).
+ */
+#ifndef KS265_ENC_H
+#define KS265_ENC_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* qy265def.h:7-22 */
+enum { QY_OK = 0, QY_FAIL = (int)0x80000001, QY_OUTOFMEMORY = (int)0x80000002, QY_POINTER = (int)0x80000003, QY_NOTSUPPORTED = (int)0x80000004,
+       QY_AUTH_INVALID = (int)0x80000005 };
+
+typedef enum QY265Tune_tag { QY265TUNE_DEFAULT = 0, QY265TUNE_SELFSHOW, QY265TUNE_GAME, QY265TUNE_MOVIE, QY265TUNE_SCREEN } QY265Tune;
+typedef enum QY265Preset_tag { QY265PRESET_ULTRAFAST = 0, QY265PRESET_SUPERFAST, QY265PRESET_VERYFAST, QY265PRESET_FAST, QY265PRESET_MEDIUM, QY265PRESET_SLOW,
+                               QY265PRESET_SLOWER, QY265PRESET_VERYSLOW, QY265PRESET_PLACEBO } QY265Preset;
+typedef enum QY265Latency_tag { QY265LATENCY_ZERO = 0, QY265LATENCY_LOWDELAY, QY265LATENCY_LIVESTREMING, QY265LATENCY_DEFAULT } QY265Latency;
+
+/* qy265enc.h:51-148, same field order and types */
+typedef struct QY265EncConfig {
+    void *pAuth;                              /* ignored (no licence check) */
+    QY265Tune tune; QY265Preset preset; QY265Latency latency;
+    int profileId;                            /* 1 = Main (the only one written) */
+    int bHeaderBeforeKeyframe;                /* VPS / SPS / PPS in front of every key picture */
+    int picWidth, picHeight;                  /* multiples of 8 */
+    double frameRate;
+    int bframes;                              /* -1: preset / latency default (hierarchical GOP 8 at default latency, else 0); 0: IPPP; n: n non-reference B pictures per anchor */
+    int temporalLayer;
+    int vpp_denoise, vpp_edge, vpp_color, vpp_hdr; double vpp_hdr_strength; int vpp_hdr_iter; double vpp_hdr_sigma_s, vpp_hdr_sigma_r, vpp_recur_filter;
+    int rc;                                   /* 0 CQP, 1 CBR, 2 ABR, 3 CRF, 4 CVBR, 5 CVQ */
+    int bitrateInkbps, vbv_buffer_size, vbv_max_rate, vbv_min_rate;
+    int qp, crf, visual_quality;
+    int iIntraPeriod;                         /* key picture (IDR) period, -1 = only the first */
+    int qpmin, qpmax, enFrameSkip;
+    int enWavefront, enFrameParallel;         /* the GPU path is frame-wide; ignored */
+    int threads;                              /* host threads writing slice data (one picture each), 0 = all cores */
+    int vui_parameters_present_flag;
+    struct { int video_signal_type_present_flag, video_format, video_full_range_flag, colour_description_present_flag, colour_primaries,
+             transfer_characteristics, matrix_coeffs; } vui;
+    int logLevel, lookahead, calcPsnr, calcSsim, shortLoadingForPlayer;
+    int iPass; char statFileName[256]; double fRateTolerance;
+    int rdoq, me, part, do64, tuInter, tuIntra, smooth, transskip, subme, satdInter, satdIntra, searchrange, refnum, ref0, sao, longTermRef, iAqMode;
+    double fAqStrength;
+    int rasl;
+} QY265EncConfig;
+
+/* qy265enc.h:160-184 */
+typedef struct QY265YUV { int iWidth, iHeight; unsigned char *pData[3]; int iStride[3]; } QY265YUV;
+typedef struct QY265Picture { int iSliceType; int poc; long long pts; long long dts; QY265YUV *yuv; } QY265Picture;
+typedef struct QY265Nal { int naltype; int tid; int iSize; long long pts; unsigned char *pPayload; } QY265Nal;
+
+typedef void (*QYLogPrintf)(const char *msg);
+void QY265SetLogPrintf(QYLogPrintf cb);                       /* qy265def.h:188; NULL = stdout */
+extern const char strLibQy265Version[];                        /* qy265def.h:198 */
+
+void *QY265EncoderOpen(QY265EncConfig *pCfg, int *errorCode);  /* NULL + *errorCode on failure */
+void QY265EncoderClose(void *pEncoder);
+void QY265EncoderReconfig(void *pEncoder, QY265EncConfig *pCfg);          /* qp / bitrate / iIntraPeriod take effect at the next picture */
+int QY265EncoderEncodeHeaders(void *pEncoder, QY265Nal **pNals, int *iNalCount);
+/* pInpic == NULL flushes.  The NAL array and payloads belong to the encoder and stay valid until the next call.  Returns QY_OK or an error. */
+int QY265EncoderEncodeFrame(void *pEncoder, QY265Nal **pNals, int *iNalCount, QY265Picture *pInpic, QY265Picture *pOutpic, int bForceLogo);
+void QY265EncoderKeyFrameRequest(void *pEncoder);
+int QY265EncoderDelayedFrames(void *pEncoder);
+int QY265ConfigDefault(QY265EncConfig *pConfig, QY265Preset preset, QY265Tune tune, QY265Latency latency);
+int QY265ConfigDefaultPreset(QY265EncConfig *pConfig, char *preset, char *tune, char *latency);
+#define QY265_PARAM_BAD_NAME (-1)
+#define QY265_PARAM_BAD_VALUE (-2)
+int QY265ConfigParse(QY265EncConfig *p, const char *name, const char *value);
+
+/* not in the SDK: totals of the session for the CLI's summary lines */
+typedef struct { long frames; long long bytes; double sse[3]; double gpu_ms; double host_write_ms; } ks265_enc_stats;
+int ks265_enc_get_stats(void *pEncoder, ks265_enc_stats *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -51,6 +51,21 @@ enum { KS265_DBG_WAVEFRONT_SPINS = 1 };
 int ks265_debug_set(ks265_ctx *ctx, int what, int value);
 const char *ks265_last_error(ks265_ctx *ctx);
 const char *ks265_version(void);                    /* cf. strLibQy265Version, qy265enc.h              */
+/* Memory and stream-ordered copies for hosts written in plain C (the reference's host is C/C++ without any GPU runtime; a host above this
+ * ABI needs no HIP header): device memory, pinned host memory, copies enqueued on the context's stream, and events to learn from another
+ * host thread that everything enqueued before the record has finished. */
+#include <stddef.h>
+int ks265_dev_malloc(ks265_ctx *, void **dev, size_t bytes);
+int ks265_dev_free(ks265_ctx *, void *dev);
+int ks265_host_malloc(ks265_ctx *, void **host, size_t bytes);
+int ks265_host_free(ks265_ctx *, void *host);
+int ks265_memcpy_h2d_async(ks265_ctx *, void *dev, const void *host, size_t bytes);
+int ks265_memcpy_d2h_async(ks265_ctx *, void *host, const void *dev, size_t bytes);
+int ks265_memset_async(ks265_ctx *, void *dev, int value, size_t bytes);
+int ks265_event_create(ks265_ctx *, void **ev);
+int ks265_event_record(ks265_ctx *, void *ev);
+int ks265_event_wait(ks265_ctx *, void *ev);
+int ks265_event_destroy(ks265_ctx *, void *ev);
 /* HIP-event timing on the context's stream (bench.py roofline leg) */
 /* a one-thread kernel named ks265_marker_kernel on the context's stream: brackets a region of interest in a kernel trace (profiling aid) */
 int ks265_marker(ks265_ctx *, int id);

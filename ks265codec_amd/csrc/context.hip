@@ -76,6 +76,59 @@ int ks265_marker(ks265_ctx *c, int id)
     return ks265_hip(c, hipGetLastError());
 }
 
+/* device / pinned-host memory and stream-ordered copies for hosts that are plain C (no HIP headers needed above the C ABI) */
+int ks265_dev_malloc(ks265_ctx *c, void **dev, size_t bytes)
+{
+    if (!c || !dev) return KS265_POINTER;
+    (void)hipSetDevice(c->device);
+    return ks265_hip(c, hipMalloc(dev, bytes ? bytes : 1));
+}
+int ks265_dev_free(ks265_ctx *c, void *dev)
+{
+    if (!c) return KS265_POINTER;
+    (void)hipSetDevice(c->device);
+    return dev ? ks265_hip(c, hipFree(dev)) : KS265_OK;
+}
+int ks265_host_malloc(ks265_ctx *c, void **host, size_t bytes)
+{
+    if (!c || !host) return KS265_POINTER;
+    (void)hipSetDevice(c->device);
+    return ks265_hip(c, hipHostMalloc(host, bytes ? bytes : 1, hipHostMallocDefault));
+}
+int ks265_host_free(ks265_ctx *c, void *host)
+{
+    if (!c) return KS265_POINTER;
+    return host ? ks265_hip(c, hipHostFree(host)) : KS265_OK;
+}
+int ks265_memcpy_h2d_async(ks265_ctx *c, void *dev, const void *host, size_t bytes)
+{
+    if (!c || !dev || !host) return KS265_POINTER;
+    return ks265_hip(c, hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, c->stream));
+}
+int ks265_memcpy_d2h_async(ks265_ctx *c, void *host, const void *dev, size_t bytes)
+{
+    if (!c || !dev || !host) return KS265_POINTER;
+    return ks265_hip(c, hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, c->stream));
+}
+int ks265_memset_async(ks265_ctx *c, void *dev, int value, size_t bytes)
+{
+    if (!c || !dev) return KS265_POINTER;
+    return ks265_hip(c, hipMemsetAsync(dev, value, bytes, c->stream));
+}
+/* an event on the context's stream: record now, wait later from any host thread (pipelined hosts: "picture n has left the GPU") */
+int ks265_event_create(ks265_ctx *c, void **ev)
+{
+    if (!c || !ev) return KS265_POINTER;
+    (void)hipSetDevice(c->device);
+    hipEvent_t e;
+    const int r = ks265_hip(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    *ev = r ? nullptr : (void *)e;
+    return r;
+}
+int ks265_event_record(ks265_ctx *c, void *ev) { return (!c || !ev) ? KS265_POINTER : ks265_hip(c, hipEventRecord((hipEvent_t)ev, c->stream)); }
+int ks265_event_wait(ks265_ctx *c, void *ev) { return (!c || !ev) ? KS265_POINTER : ks265_hip(c, hipEventSynchronize((hipEvent_t)ev)); }
+int ks265_event_destroy(ks265_ctx *c, void *ev) { return (!c || !ev) ? KS265_POINTER : ks265_hip(c, hipEventDestroy((hipEvent_t)ev)); }
+
 const char *ks265_last_error(ks265_ctx *c) { return c ? c->last_error.c_str() : "null context"; }
 
 int ks265_timer_start(ks265_ctx *c)

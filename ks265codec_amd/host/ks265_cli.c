@@ -1,0 +1,95 @@
+/* ks265_cli.c — command-line front end with the flag surface of the SDK's `appencoder` (boundary "B1" of SURVEY.md §8(b): /root/reference/README.md:8-82
+ * plus the tool flags the v2.6.1.3 binary accepts), driving the library API exactly like the SDK's own callers do
+ * (encoderwrapper.c:327-427: ConfigDefaultPreset -> set fields -> Open -> EncodeFrame per picture -> flush while DelayedFrames -> Close).
+ * Output conventions kept: Annex-B stream to -b, stdout lines `Total Frames: N, test time: X ms, FPS: F` and `bitrate, psnr: kbps Y U V`
+ * (the Android demo parses the latter), `H265 encoder passed!!!` at the end. */
+#define _GNU_SOURCE
+#include "ks265_enc.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+static double now_ms(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e3 + t.tv_nsec * 1e-6; }
+
+static void usage(void)
+{
+    puts("usage: ks265enc -i in.yuv -wdt W -hgt H [-fr FPS] [-preset ultrafast..placebo] [-latency zerolatency|lowdelay|livestreaming|default] [-tune T]\n"
+         "                [-rc 0..5] [-qp Q] [-crf C] [-br KBPS] [-iper N] [-bframes N] [-frms N] [-threads N] [-psnr 0|1|2] [-b out.265]\n"
+         "                [-me 0|1|2] [-subme 0|1] [-merange R] [-ref N] [-sao 0..4] [-v]\n"
+         "  I420 8-bit input; width and height multiples of 8.  Needs one MI355X (gfx950): there is no CPU fallback.");
+}
+
+int main(int argc, char **argv)
+{
+    const char *in_path = NULL, *out_path = NULL, *preset = "medium", *latency = "default", *tune = "default";
+    int frames = -1;
+    /* two passes over the arguments: preset / latency / tune first (they reset every field), then the explicit settings */
+    for (int i = 1; i < argc; ++i) {
+        if (!strcmp(argv[i], "-v")) { printf("%s\n", strLibQy265Version); return 0; }
+        if (!strcmp(argv[i], "-h") || !strcmp(argv[i], "--help")) { usage(); return 0; }
+        if (i + 1 < argc) {
+            if (!strcmp(argv[i], "-preset")) preset = argv[++i];
+            else if (!strcmp(argv[i], "-latency")) latency = argv[++i];
+            else if (!strcmp(argv[i], "-tune")) tune = argv[++i];
+        }
+    }
+    QY265EncConfig cfg;
+    if (QY265ConfigDefaultPreset(&cfg, (char *)preset, (char *)tune, (char *)latency) != QY_OK) { fprintf(stderr, "bad -preset / -tune / -latency\n"); return 2; }
+    cfg.rc = 0; cfg.calcPsnr = 1;
+    for (int i = 1; i < argc; ++i) {
+        const char *a = argv[i];
+        if (a[0] != '-') { fprintf(stderr, "unexpected argument %s\n", a); return 2; }
+        if (i + 1 >= argc) { fprintf(stderr, "%s needs a value\n", a); return 2; }
+        const char *v = argv[++i];
+        if (!strcmp(a, "-i")) in_path = v;
+        else if (!strcmp(a, "-b")) out_path = v;
+        else if (!strcmp(a, "-o")) fprintf(stderr, "ks265enc: -o (reconstruction dump) is not implemented; decode the stream instead\n");
+        else if (!strcmp(a, "-frms")) frames = atoi(v);
+        else if (!strcmp(a, "-preset") || !strcmp(a, "-latency") || !strcmp(a, "-tune")) continue;
+        else {
+            const int r = QY265ConfigParse(&cfg, a + 1, v);
+            if (r == QY265_PARAM_BAD_NAME) { fprintf(stderr, "unknown option %s\n", a); return 2; }
+            if (r == QY265_PARAM_BAD_VALUE) { fprintf(stderr, "bad value for %s: %s\n", a, v); return 2; }
+        }
+    }
+    if (!in_path || cfg.picWidth <= 0 || cfg.picHeight <= 0) { usage(); return 2; }
+    FILE *fi = fopen(in_path, "rb"), *fo = out_path ? fopen(out_path, "wb") : NULL;
+    if (!fi || (out_path && !fo)) { perror("open"); return 1; }
+    int err = 0;
+    void *h = QY265EncoderOpen(&cfg, &err);
+    if (!h) { fprintf(stderr, "QY265EncoderOpen failed: 0x%08x\n", (unsigned)err); return 1; }
+    const size_t luma = (size_t)cfg.picWidth * cfg.picHeight, fsz = luma * 3 / 2;
+    unsigned char *buf = (unsigned char *)malloc(fsz);
+    QY265YUV yuv = {cfg.picWidth, cfg.picHeight, {buf, buf + luma, buf + luma + luma / 4}, {cfg.picWidth, cfg.picWidth / 2, cfg.picWidth / 2}};
+    QY265Picture pic, outp;
+    memset(&pic, 0, sizeof pic); memset(&outp, 0, sizeof outp);
+    pic.yuv = &yuv;
+    QY265Nal *nal; int nnal;
+    long n = 0;
+    const double t0 = now_ms();
+    double t_io = 0;
+    for (; frames < 0 || n < frames; ++n) {
+        const double ta = now_ms();
+        if (fread(buf, 1, fsz, fi) != fsz) break;
+        t_io += now_ms() - ta;
+        pic.pts = n;
+        err = QY265EncoderEncodeFrame(h, &nal, &nnal, &pic, &outp, 0);
+        if (err) { fprintf(stderr, "EncodeFrame failed: 0x%08x\n", (unsigned)err); return 1; }
+        for (int k = 0; k < nnal && fo; ++k) fwrite(nal[k].pPayload, 1, (size_t)nal[k].iSize, fo);
+    }
+    while (QY265EncoderDelayedFrames(h)) {
+        err = QY265EncoderEncodeFrame(h, &nal, &nnal, NULL, &outp, 0);
+        if (err) { fprintf(stderr, "EncodeFrame (flush) failed: 0x%08x\n", (unsigned)err); return 1; }
+        for (int k = 0; k < nnal && fo; ++k) fwrite(nal[k].pPayload, 1, (size_t)nal[k].iSize, fo);
+    }
+    const double t1 = now_ms();
+    ks265_enc_stats st;
+    ks265_enc_get_stats(h, &st);
+    printf("Total Frames: %ld, test time: %.0f ms, FPS: %.4f\n", n, t1 - t0, n * 1000.0 / (t1 - t0));
+    printf("pure encoding time: %.0f ms (input read %.0f ms), slice writing %.1f ms per picture per thread\n", t1 - t0 - t_io, t_io, st.frames ? st.host_write_ms / st.frames : 0.0);
+    QY265EncoderClose(h);                                            /* prints "bitrate, psnr: ..." */
+    puts("H265 encoder passed!!!");
+    free(buf); fclose(fi); if (fo) fclose(fo);
+    return 0;
+}

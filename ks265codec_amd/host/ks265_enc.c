@@ -1,0 +1,594 @@
+/* ks265_enc.c — the encoder behind the SDK's library API (include/ks265_enc.h; SURVEY.md §8(b) "B2", caller sequence §3.4):
+ * QY265ConfigDefault* -> QY265EncoderOpen -> QY265EncoderEncodeFrame ... -> flush -> QY265EncoderClose.
+ *
+ * Plain C host over two C ABIs: libks265hip.so (the pixel path on the MI355X, include/ks265_hip.h) and the bitstream writer
+ * (ks265_stream.c).  What the reference's host does per frame (CHevcEncode::encodeFrame enc@0x4b9930, §3.2) maps to:
+ *   input picture -> pinned host copy -> H2D -> ks265_encode_picture[_b/_mref] (all pixel stages on the GPU's stream)
+ *   -> D2H of the CU map / levels / SAO records (pinned, stream ordered) -> event
+ *   -> a host thread waits for the event and writes the slice NAL (CABAC), one picture per thread, pictures of a GOP in parallel
+ *   -> NAL units are handed out in coding order (the SDK's asynchronous contract: output lags input).
+ * GOP structures: IPPP (optionally several list-0 pictures), anchor + n non-reference B, hierarchical-B mini-GOPs of 8 (the SDK's
+ * default at default latency); every key picture is an IDR (closed GOPs: what GOP-sharding over GPUs needs).
+ */
+#define _GNU_SOURCE
+#include "ks265_enc.h"
+#include "ks265_stream.h"
+#include <math.h>
+#include <pthread.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#include <unistd.h>
+
+const char strLibQy265Version[] = "ks265enc 0.2 (MI355X pixel path + host CABAC; API of libqycodec V2.6.1.3)";
+
+static QYLogPrintf g_log_cb;
+void QY265SetLogPrintf(QYLogPrintf cb) { g_log_cb = cb; }
+static void logf_(int level, int min_level, const char *fmt, ...)
+{
+    if (level < min_level) return;
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    if (g_log_cb) g_log_cb(buf); else { fputs(buf, stdout); fflush(stdout); }
+}
+
+/* motion lambda in Q4 per QP: round(16 * sqrt(0.57 * 2^((qp - 12) / 3))) - the host-side float setup of the pixel path, as a table so that
+ * every host (this one, the Python test mirror ks265codec_amd/synth.py) uses identical integers */
+static const int kLambdaQ4[52] = {3, 3, 4, 4, 5, 5, 6, 7, 8, 9, 10, 11, 12, 14, 15, 17, 19, 22, 24, 27, 30, 34, 38, 43, 48, 54, 61, 68, 77, 86, 97, 108, 122, 137, 153, 172,
+                                  193, 217, 244, 273, 307, 344, 387, 434, 487, 547, 614, 689, 773, 868, 974, 1093};
+
+/* ------------------------------------------------------------------ configuration (QY265ConfigDefault enc@0x4b7020 lineage: fillCfgs<Preset>) */
+static const char *const kPresetNames[] = {"ultrafast", "superfast", "veryfast", "fast", "medium", "slow", "slower", "veryslow", "placebo", 0};
+static const char *const kTuneNames[] = {"default", "selfshow", "game", "movie", "screen", 0};
+static const char *const kLatencyNames[] = {"zerolatency", "lowdelay", "livestreaming", "default", 0};
+/* tools per preset as the reference resolves them (measured from the CLI's config echo) */
+static const struct { int me, subme, ref, ref0, part, tuinter, rdoq, sao; } kPresetTools[9] = {
+    {1, 1, 1, 2, 0, 0, 0, 1}, {1, 1, 1, 3, 0, 0, 0, 1}, {1, 1, 1, 3, 0, 0, 0, 3}, {1, 1, 1, 3, 0, 0, 1, 3}, {1, 1, 1, 3, 0, 0, 1, 4},
+    {2, 1, 1, 3, 0, 0, 1, 4}, {2, 1, 2, 4, 1, 0, 1, 4}, {2, 2, 4, 4, 1, 1, 1, 4}, {2, 2, 5, 5, 1, 2, 1, 4}};
+
+int QY265ConfigDefault(QY265EncConfig *c, QY265Preset preset, QY265Tune tune, QY265Latency latency)
+{
+    if (!c) return QY_POINTER;
+    if ((int)preset < 0 || (int)preset > 8 || (int)tune < 0 || (int)tune > 4 || (int)latency < 0 || (int)latency > 3) return QY_NOTSUPPORTED;
+    memset(c, 0, sizeof *c);
+    c->tune = tune; c->preset = preset; c->latency = latency;
+    c->profileId = 1; c->bHeaderBeforeKeyframe = 1; c->frameRate = 25.0;
+    c->bframes = -1; c->rc = 2; c->bitrateInkbps = 1000; c->qp = 26; c->crf = 24; c->visual_quality = 95; c->iIntraPeriod = 256;
+    c->qpmin = 0; c->qpmax = 51; c->enWavefront = 1; c->enFrameParallel = 1; c->threads = 0;
+    c->logLevel = 0; c->lookahead = -1; c->fRateTolerance = 2.0;
+    c->rdoq = kPresetTools[preset].rdoq; c->me = kPresetTools[preset].me; c->part = kPresetTools[preset].part; c->do64 = 1;
+    c->tuInter = kPresetTools[preset].tuinter; c->tuIntra = kPresetTools[preset].tuinter; c->smooth = 1; c->transskip = 0;
+    c->subme = kPresetTools[preset].subme; c->satdInter = preset >= QY265PRESET_SLOW; c->satdIntra = preset >= QY265PRESET_SLOW;
+    c->searchrange = 64; c->refnum = kPresetTools[preset].ref; c->ref0 = kPresetTools[preset].ref0; c->sao = kPresetTools[preset].sao;
+    c->iAqMode = 0; c->fAqStrength = 1.0; c->rasl = 1;
+    return QY_OK;
+}
+static int find_name(const char *const *names, const char *s)
+{
+    if (!s) return -2;
+    for (int i = 0; names[i]; ++i) if (!strcmp(names[i], s)) return i;
+    return -1;
+}
+int QY265ConfigDefaultPreset(QY265EncConfig *c, char *preset, char *tune, char *latency)
+{
+    int p = find_name(kPresetNames, preset), t = find_name(kTuneNames, tune), l = find_name(kLatencyNames, latency);
+    if (p == -2) p = QY265PRESET_MEDIUM;
+    if (t == -2) t = QY265TUNE_DEFAULT;
+    if (l == -2) l = QY265LATENCY_DEFAULT;
+    if (p < 0 || t < 0 || l < 0) return QY_NOTSUPPORTED;
+    return QY265ConfigDefault(c, (QY265Preset)p, (QY265Tune)t, (QY265Latency)l);
+}
+int QY265ConfigParse(QY265EncConfig *c, const char *name, const char *value)
+{
+    if (!c || !name || !value) return QY265_PARAM_BAD_NAME;
+    char *end = NULL;
+    const double dv = strtod(value, &end);
+    const int num_ok = end && end != value && *end == 0, iv = (int)dv;
+#define INTP(NAME, FIELD, LO, HI) if (!strcmp(name, NAME)) { if (!num_ok || iv < (LO) || iv > (HI)) return QY265_PARAM_BAD_VALUE; c->FIELD = iv; return 0; }
+    INTP("wdt", picWidth, 8, 8192) INTP("hgt", picHeight, 8, 8192) INTP("bframes", bframes, -1, 15) INTP("rc", rc, 0, 5) INTP("br", bitrateInkbps, 1, 1000000)
+    INTP("qp", qp, 0, 51) INTP("crf", crf, 0, 51) INTP("iper", iIntraPeriod, -1, 100000) INTP("qpmin", qpmin, 0, 51) INTP("qpmax", qpmax, 0, 51)
+    INTP("threads", threads, 0, 1024) INTP("psnr", calcPsnr, 0, 2) INTP("ssim", calcSsim, 0, 2) INTP("log", logLevel, -1, 3) INTP("lookahead", lookahead, -1, 250)
+    INTP("rdoq", rdoq, 0, 1) INTP("me", me, 0, 4) INTP("part", part, 0, 1) INTP("do64", do64, 0, 1) INTP("intertu", tuInter, -1, 3) INTP("intratu", tuIntra, -1, 3)
+    INTP("sis", smooth, 0, 1) INTP("ts", transskip, 0, 1) INTP("subme", subme, 0, 2) INTP("merange", searchrange, 1, 512) INTP("ref", refnum, 1, 16) INTP("ref0", ref0, 1, 16)
+    INTP("sao", sao, 0, 4) INTP("wpp", enWavefront, 0, 1) INTP("fpp", enFrameParallel, 0, 1) INTP("vbv-maxrate", vbv_max_rate, 0, 10000000)
+    INTP("vbv-bufsize", vbv_buffer_size, 0, 10000000) INTP("pass", iPass, 0, 2) INTP("tlayer", temporalLayer, 0, 1) INTP("frameskip", enFrameSkip, 0, 1)
+#undef INTP
+    if (!strcmp(name, "fr")) { if (!num_ok || dv <= 0 || dv > 1000) return QY265_PARAM_BAD_VALUE; c->frameRate = dv; return 0; }
+    if (!strcmp(name, "ratetol")) { if (!num_ok || dv < 0) return QY265_PARAM_BAD_VALUE; c->fRateTolerance = dv; return 0; }
+    if (!strcmp(name, "preset") || !strcmp(name, "latency") || !strcmp(name, "tune")) {
+        const int k = find_name(name[0] == 'p' ? kPresetNames : name[0] == 'l' ? kLatencyNames : kTuneNames, value);
+        if (k < 0) return QY265_PARAM_BAD_VALUE;
+        if (name[0] == 'p') c->preset = (QY265Preset)k; else if (name[0] == 'l') c->latency = (QY265Latency)k; else c->tune = (QY265Tune)k;
+        return 0;
+    }
+    return QY265_PARAM_BAD_NAME;
+}
+
+/* ------------------------------------------------------------------ encoder */
+#define MAX_DPB 12
+#define MAX_JOBS 24
+#define MAX_INPUT 40
+
+typedef struct Job {
+    int used, done, error;
+    int disp, poc, kind, qp, nal_type, is_ref;            /* kind: 'I' 'P' 'B' */
+    long long pts;
+    int nl0, nl1, l0[4], l1[4], nrps, rps_poc[16]; unsigned char rps_used[16];
+    ks265_cu8 *cu8; int16_t *lvl[3]; ks265_sao_param *sao; uint64_t *sse;      /* pinned host copies of the GPU's records */
+    void *ev;                                             /* recorded after the D2H copies */
+    uint8_t *nal; size_t nal_cap; long nal_len;
+    int key_headers;                                      /* parameter sets go in front of this picture */
+    double t_write_ms;
+} Job;
+
+typedef struct Input { int used, disp; long long pts; uint8_t *i420; } Input;          /* pinned */
+
+typedef struct Enc {
+    QY265EncConfig cfg;
+    int W, H, log_level;
+    int me_method, hex_thr, subme, refs, use_sao, use_df, gop_b, hier;                  /* resolved tools */
+    int base_qp, iper, nthreads;
+    ks265_ctx *ctx; ks265_frame *frame; ks265_frame_geom geom; ks265_frame_cfg fcfg; ks265_stream_cfg scfg;
+    /* device */
+    uint8_t *dev_i420; ks265_pic src; ks265_pic dpb[MAX_DPB]; int dpb_poc[MAX_DPB]; int ndpb; uint64_t *dev_sse;
+    /* scheduling */
+    Input in[MAX_INPUT]; int next_disp;                   /* display index of the next input picture */
+    int gop_start;                                        /* display index of the last key picture */
+    int coded_upto;                                       /* display index up to which everything is scheduled */
+    int force_key;
+    Job jobs[MAX_JOBS]; int job_head, job_tail, njobs;    /* ring in coding order */
+    /* workers */
+    pthread_t th[64]; int nth; pthread_mutex_t mu; pthread_cond_t cv_work, cv_done; int quit;
+    int next_work, npending;                              /* ring index of the next job to write, jobs submitted but not yet taken by a writer */
+    struct WorkerArg { struct Enc *e; int idx; } warg[64];
+    void *scratch[64];
+    /* output */
+    QY265Nal nals[4 * MAX_JOBS + 8]; uint8_t *hdr; long hdr_len, hdr_part[3];
+    uint8_t *outbuf; size_t outcap, outpos;               /* NAL payloads handed to the caller live here until the next call */
+    ks265_enc_stats st;
+    /* rate control (frame level, rc != 0 and != 3) */
+    double rc_bits_target, rc_bits_spent; int rc_frames; int rc_qp_delta;
+} Enc;
+
+static double now_ms(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e3 + t.tv_nsec * 1e-6; }
+static int hip_rc(int r) { return r == 0 ? QY_OK : r == KS265_OUTOFMEMORY ? QY_OUTOFMEMORY : r == KS265_POINTER ? QY_POINTER : r == KS265_NOTSUPPORTED ? QY_NOTSUPPORTED : QY_FAIL; }
+
+static int pic_alloc(Enc *e, ks265_pic *p)
+{
+    int r = ks265_dev_malloc(e->ctx, (void **)&p->y, (size_t)e->geom.bytes_y);
+    if (!r) r = ks265_dev_malloc(e->ctx, (void **)&p->u, (size_t)e->geom.bytes_c);
+    if (!r) r = ks265_dev_malloc(e->ctx, (void **)&p->v, (size_t)e->geom.bytes_c);
+    return r;
+}
+static void pic_free(Enc *e, ks265_pic *p) { ks265_dev_free(e->ctx, p->y); ks265_dev_free(e->ctx, p->u); ks265_dev_free(e->ctx, p->v); p->y = p->u = p->v = NULL; }
+
+/* ---- slice writers: one picture per thread */
+static void *worker(void *arg)
+{
+    Enc *e = ((struct WorkerArg *)arg)->e;
+    const int me = ((struct WorkerArg *)arg)->idx;
+    pthread_mutex_lock(&e->mu);
+    for (;;) {
+        while (!e->quit && e->npending == 0) pthread_cond_wait(&e->cv_work, &e->mu);
+        if (e->quit) break;
+        Job *j = &e->jobs[e->next_work];
+        e->next_work = (e->next_work + 1) % MAX_JOBS; --e->npending;
+        pthread_mutex_unlock(&e->mu);
+        int err = ks265_event_wait(e->ctx, j->ev);               /* the records of this picture have reached the host */
+        const double t0 = now_ms();
+        if (!err) {
+            ks265_slice_in s;
+            memset(&s, 0, sizeof s);
+            s.nal_type = j->nal_type; s.slice_type = j->kind == 'I' ? KS265_SLICE_I : j->kind == 'P' ? KS265_SLICE_P : KS265_SLICE_B;
+            s.poc = j->poc; s.qp = j->qp; s.num_rps = j->nrps;
+            memcpy(s.rps_poc, j->rps_poc, sizeof s.rps_poc); memcpy(s.rps_used, j->rps_used, sizeof s.rps_used);
+            s.num_l0 = j->nl0; s.num_l1 = j->nl1; memcpy(s.l0_poc, j->l0, sizeof s.l0_poc); memcpy(s.l1_poc, j->l1, sizeof s.l1_poc);
+            s.cu8 = j->cu8; s.lvl[0] = j->lvl[0]; s.lvl[1] = j->lvl[1]; s.lvl[2] = j->lvl[2]; s.sao = e->use_sao ? j->sao : NULL;
+            j->nal_len = ks265_write_slice(&e->scfg, &s, e->scratch[me], j->nal, j->nal_cap);
+            if (j->nal_len < 0) err = (int)j->nal_len;
+        }
+        j->t_write_ms = now_ms() - t0;
+        pthread_mutex_lock(&e->mu);
+        j->error = err; j->done = 1;
+        pthread_cond_broadcast(&e->cv_done);
+    }
+    pthread_mutex_unlock(&e->mu);
+    return NULL;
+}
+
+static int dpb_find(Enc *e, int poc) { for (int i = 0; i < e->ndpb; ++i) if (e->dpb_poc[i] == poc) return i; return -1; }
+static int dpb_free_slot(Enc *e, const int *keep, int nkeep)
+{
+    for (int i = 0; i < e->ndpb; ++i) {
+        int k = 0;
+        for (int q = 0; q < nkeep; ++q) if (e->dpb_poc[i] == keep[q]) k = 1;
+        if (!k || e->dpb_poc[i] < 0) return i;
+    }
+    return -1;
+}
+
+/* enqueue one picture: GPU work + copies on the stream, then hand it to the writers */
+static int submit(Enc *e, Input *in, int kind, int poc, int qp, const int *l0, int nl0, const int *l1, int nl1, const int *keep_after, int nkeep, int is_ref, int key_headers)
+{
+    /* wait for a free job slot (the ring is full only if the consumer did not drain it: block on the oldest) */
+    pthread_mutex_lock(&e->mu);
+    while (e->njobs == MAX_JOBS) pthread_cond_wait(&e->cv_done, &e->mu);       /* drained by take_output() of the calling thread itself: never full here */
+    Job *j = &e->jobs[e->job_tail];
+    pthread_mutex_unlock(&e->mu);
+    const size_t fsz = (size_t)e->W * e->H * 3 / 2, npx = (size_t)e->W * e->H;
+    int r = ks265_memcpy_h2d_async(e->ctx, e->dev_i420, in->i420, fsz);
+    if (!r) r = ks265_load_i420(e->frame, e->dev_i420, e->src);
+    if (!r) r = ks265_frame_set_qp(e->frame, qp, kLambdaQ4[qp]);
+    int keep[20], nk = 0;
+    for (int i = 0; i < nkeep; ++i) keep[nk++] = keep_after[i];
+    for (int i = 0; i < nl0; ++i) keep[nk++] = l0[i];
+    for (int i = 0; i < nl1; ++i) keep[nk++] = l1[i];
+    const int slot = dpb_free_slot(e, keep, nk);
+    if (slot < 0) return QY_FAIL;
+    ks265_pic out = e->dpb[slot];
+    if (!r) {
+        if (kind == 'I') r = ks265_encode_picture(e->frame, e->src, out, 1, out);
+        else if (kind == 'B') r = ks265_encode_picture_b(e->frame, e->src, e->dpb[dpb_find(e, l0[0])], e->dpb[dpb_find(e, l1[0])], out);
+        else if (nl0 > 1) { ks265_pic refs[4]; for (int i = 0; i < nl0; ++i) refs[i] = e->dpb[dpb_find(e, l0[i])]; r = ks265_encode_picture_mref(e->frame, e->src, refs, nl0, out); }
+        else r = ks265_encode_picture(e->frame, e->src, e->dpb[dpb_find(e, l0[0])], 0, out);
+    }
+    e->dpb_poc[slot] = poc;
+    if (!r && e->cfg.calcPsnr) r = ks265_sse_picture(e->frame, e->src, out, e->dev_sse);
+    if (!r) r = ks265_memcpy_d2h_async(e->ctx, j->cu8, ks265_frame_cu8(e->frame), (size_t)e->geom.bytes_cu8);
+    if (!r) r = ks265_memcpy_d2h_async(e->ctx, j->lvl[0], ks265_frame_levels(e->frame, 0), npx * 2);
+    if (!r) r = ks265_memcpy_d2h_async(e->ctx, j->lvl[1], ks265_frame_levels(e->frame, 1), npx / 2);
+    if (!r) r = ks265_memcpy_d2h_async(e->ctx, j->lvl[2], ks265_frame_levels(e->frame, 2), npx / 2);
+    if (!r) r = ks265_memcpy_d2h_async(e->ctx, j->sao, ks265_frame_sao(e->frame), (size_t)e->geom.bytes_sao);
+    if (!r && e->cfg.calcPsnr) r = ks265_memcpy_d2h_async(e->ctx, j->sse, e->dev_sse, 3 * sizeof(uint64_t));
+    if (!r) r = ks265_event_record(e->ctx, j->ev);
+    if (r) return hip_rc(r);
+    j->disp = in->disp; j->pts = in->pts; j->poc = poc; j->kind = kind; j->qp = qp; j->is_ref = is_ref; j->key_headers = key_headers;
+    j->nal_type = kind == 'I' ? KS265_NAL_IDR_W_RADL : is_ref ? KS265_NAL_TRAIL_R : KS265_NAL_TRAIL_N;
+    j->nl0 = nl0; j->nl1 = nl1;
+    for (int i = 0; i < nl0; ++i) j->l0[i] = l0[i];
+    for (int i = 0; i < nl1; ++i) j->l1[i] = l1[i];
+    /* RPS: everything that must stay (keep_after) + what this picture uses */
+    j->nrps = 0;
+    if (kind != 'I')
+        for (int i = 0; i < nk; ++i) {
+            int dup = 0;
+            for (int q = 0; q < j->nrps; ++q) if (j->rps_poc[q] == keep[i]) dup = 1;
+            if (dup || keep[i] == poc) continue;
+            int used = 0;
+            for (int q = 0; q < nl0; ++q) if (l0[q] == keep[i]) used = 1;
+            for (int q = 0; q < nl1; ++q) if (l1[q] == keep[i]) used = 1;
+            j->rps_poc[j->nrps] = keep[i]; j->rps_used[j->nrps++] = (unsigned char)used;
+        }
+    in->used = 2;                                                      /* released when the job's event has fired (output time) */
+    pthread_mutex_lock(&e->mu);
+    j->done = 0; j->error = 0; j->used = 1;
+    e->job_tail = (e->job_tail + 1) % MAX_JOBS; ++e->njobs; ++e->npending;
+    pthread_cond_broadcast(&e->cv_work);
+    pthread_mutex_unlock(&e->mu);
+    return QY_OK;
+}
+
+static Input *input_at(Enc *e, int disp) { for (int i = 0; i < MAX_INPUT; ++i) if (e->in[i].used == 1 && e->in[i].disp == disp) return &e->in[i]; return NULL; }
+static int clampqp(Enc *e, int q) { int lo = e->cfg.rc ? e->cfg.qpmin : 0, hi = e->cfg.rc ? (e->cfg.qpmax ? e->cfg.qpmax : 51) : 51; return q < lo ? lo : q > hi ? hi : q; }
+
+/* hierarchical-B mini-GOP: anchor `a` is coded, now the B pictures of (d, a) breadth first; POCs are relative to the GOP's key picture */
+static int code_hier(Enc *e, int d, int a)
+{
+    typedef struct { int lo, hi; } Iv;
+    Iv cur[8], nxt[8]; int nc = 1, layer = 1;
+    cur[0].lo = d; cur[0].hi = a;
+    /* every picture of the mini-GOP that is a reference stays until its interval is done; simplest exact rule: keep all already coded
+     * pictures of [d, a] plus d and a themselves (at most 9 with GOP 8) */
+    int coded[16], ncoded = 0;
+    coded[ncoded++] = d - e->gop_start; coded[ncoded++] = a - e->gop_start;
+    while (nc) {
+        int nn = 0;
+        for (int i = 0; i < nc; ++i) {
+            if (cur[i].hi - cur[i].lo < 2) continue;
+            const int mid = (cur[i].lo + cur[i].hi) / 2;
+            Input *in = input_at(e, mid);
+            const int is_ref = (mid - cur[i].lo >= 2) || (cur[i].hi - mid >= 2);
+            const int l0 = cur[i].lo - e->gop_start, l1 = cur[i].hi - e->gop_start;
+            int r = submit(e, in, 'B', mid - e->gop_start, clampqp(e, e->base_qp + e->rc_qp_delta + 1 + layer), &l0, 1, &l1, 1, coded, ncoded, is_ref, 0);
+            if (r) return r;
+            if (is_ref) coded[ncoded++] = mid - e->gop_start;
+            nxt[nn].lo = cur[i].lo; nxt[nn++].hi = mid; nxt[nn].lo = mid; nxt[nn++].hi = cur[i].hi;
+        }
+        memcpy(cur, nxt, sizeof cur); nc = nn; ++layer;
+    }
+    return QY_OK;
+}
+
+/* schedule whatever can be coded with the pictures received so far; flush = no more input will come */
+static int schedule(Enc *e, int flush)
+{
+    for (;;) {
+        const int have = e->next_disp;                                 /* pictures [0, have) have arrived */
+        const int d = e->coded_upto;                                   /* last anchor / last coded display index; -1 before the first picture */
+        if (d + 1 >= have) return QY_OK;
+        const int nxt = d + 1;
+        const int key = d < 0 || e->force_key || (e->iper > 0 && nxt - e->gop_start >= e->iper);
+        if (key) {
+            Input *in = input_at(e, nxt);
+            e->gop_start = nxt; e->force_key = 0;
+            for (int i = 0; i < e->ndpb; ++i) e->dpb_poc[i] = -1000000;
+            int r = submit(e, in, 'I', 0, clampqp(e, e->base_qp + e->rc_qp_delta), NULL, 0, NULL, 0, NULL, 0, 1, 1);
+            if (r) return r;
+            e->coded_upto = nxt;
+            continue;
+        }
+        int span = e->gop_b + 1;                                       /* anchor distance */
+        int a = d + span;
+        if (e->iper > 0 && a - e->gop_start >= e->iper) a = e->gop_start + e->iper - 1;   /* the mini-GOP in front of a key picture is shortened */
+        if (a >= have) { if (!flush) return QY_OK; a = have - 1; }
+        const int pd = d - e->gop_start, pa = a - e->gop_start;
+        int l0[4], nl0 = 0, keep[8], nkeep = 0;
+        if (span == 1) {                                               /* IPPP: the most recent pictures, nearest first */
+            for (int i = 0; i < e->refs && pa - 1 - i >= 0; ++i) l0[nl0++] = pa - 1 - i;
+            for (int i = 0; i < e->refs - 1 && pa - 1 - i >= 0; ++i) keep[nkeep++] = pa - 1 - i;   /* still needed by the next picture */
+        } else { l0[nl0++] = pd; keep[nkeep++] = pd; }
+        int r = submit(e, input_at(e, a), 'P', pa, clampqp(e, e->base_qp + e->rc_qp_delta + 1), l0, nl0, NULL, 0, keep, nkeep, 1, 0);
+        if (r) return r;
+        if (a - d > 1) {
+            if (e->hier && ((a - d) & (a - d - 1)) == 0) { r = code_hier(e, d, a); if (r) return r; }
+            else {
+                const int kp[2] = {pd, pa};
+                for (int b = d + 1; b < a; ++b) {
+                    r = submit(e, input_at(e, b), 'B', b - e->gop_start, clampqp(e, e->base_qp + e->rc_qp_delta + 2), &pd, 1, &pa, 1, kp, 2, 0, 0);
+                    if (r) return r;
+                }
+            }
+        }
+        e->coded_upto = a;
+    }
+}
+
+/* move finished pictures (in coding order) to the output array; block = wait for at least everything that is queued */
+static int take_output(Enc *e, int block, QY265Nal **pNals, int *n, QY265Picture *out)
+{
+    int cnt = 0, err = QY_OK;
+    e->outpos = 0;
+    pthread_mutex_lock(&e->mu);
+    while (e->njobs) {
+        Job *j = &e->jobs[e->job_head];
+        if (!j->done) { if (!block) break; pthread_cond_wait(&e->cv_done, &e->mu); continue; }
+        if (j->error) err = hip_rc(j->error);
+        const size_t need = (size_t)(j->nal_len > 0 ? j->nal_len : 0);
+        if (e->outpos + need > e->outcap) {                             /* the caller reads the payloads after this call: they cannot stay in the job (its slot is reused) */
+            if (cnt) break;                                             /* hand out what fits, the rest next time */
+            uint8_t *nb = (uint8_t *)realloc(e->outbuf, need + 65536);
+            if (!nb) { err = QY_OUTOFMEMORY; break; }
+            e->outbuf = nb; e->outcap = need + 65536;
+        }
+        if (j->key_headers && e->cfg.bHeaderBeforeKeyframe) {
+            long off = 0;                                               /* the three parameter sets as separate NAL entries */
+            for (int k = 0; k < 3; ++k) {
+                e->nals[cnt].naltype = KS265_NAL_VPS + k; e->nals[cnt].tid = 0; e->nals[cnt].iSize = (int)e->hdr_part[k]; e->nals[cnt].pts = j->pts; e->nals[cnt].pPayload = e->hdr + off;
+                ++cnt; off += e->hdr_part[k];
+            }
+        }
+        memcpy(e->outbuf + e->outpos, j->nal, need);
+        e->nals[cnt].naltype = j->nal_type; e->nals[cnt].tid = 0; e->nals[cnt].iSize = (int)need; e->nals[cnt].pts = j->pts; e->nals[cnt].pPayload = e->outbuf + e->outpos;
+        e->outpos += need;
+        ++cnt;
+        if (out) { out->iSliceType = j->kind == 'I' ? 2 : j->kind == 'P' ? 1 : 0; out->poc = j->disp; out->pts = j->pts; out->dts = j->pts; }
+        e->st.frames++; e->st.bytes += j->nal_len > 0 ? j->nal_len : 0; e->st.host_write_ms += j->t_write_ms;
+        if (j->key_headers && e->cfg.bHeaderBeforeKeyframe) e->st.bytes += e->hdr_len;
+        if (e->cfg.calcPsnr) {
+            for (int k = 0; k < 3; ++k) e->st.sse[k] += (double)j->sse[k];
+            if (e->cfg.calcPsnr >= 2) {
+                const double np[3] = {(double)e->W * e->H, (double)e->W * e->H / 4, (double)e->W * e->H / 4};
+                double ps[3];
+                for (int k = 0; k < 3; ++k) ps[k] = j->sse[k] ? 10.0 * log10(255.0 * 255.0 * np[k] / (double)j->sse[k]) : 99.0;
+                logf_(1, e->log_level, "POC %4d %c-SLICE bits %8ld psnr Y %.4f U %.4f V %.4f QP %d\n", j->disp, j->kind, (long)j->nal_len * 8, ps[0], ps[1], ps[2], j->qp);
+            }
+        }
+        /* frame-level rate control: compare what was spent with the budget so far */
+        if (e->cfg.rc == 1 || e->cfg.rc == 2 || e->cfg.rc == 4) {
+            e->rc_bits_spent += (double)j->nal_len * 8; e->rc_bits_target += e->cfg.bitrateInkbps * 1000.0 / e->cfg.frameRate; ++e->rc_frames;
+            if (e->rc_frames >= 4) {
+                const double ratio = e->rc_bits_spent / e->rc_bits_target;
+                if (ratio > 1.10 && e->base_qp + e->rc_qp_delta < 51) ++e->rc_qp_delta;
+                else if (ratio < 0.90 && e->base_qp + e->rc_qp_delta > 0) --e->rc_qp_delta;
+            }
+        }
+        for (int i = 0; i < MAX_INPUT; ++i) if (e->in[i].used == 2 && e->in[i].disp == j->disp) e->in[i].used = 0;
+        j->used = 0;
+        e->job_head = (e->job_head + 1) % MAX_JOBS; --e->njobs;
+        if (cnt >= (int)(sizeof e->nals / sizeof e->nals[0]) - 4) break;
+    }
+    pthread_mutex_unlock(&e->mu);
+    *pNals = e->nals; *n = cnt;
+    return err;
+}
+
+void QY265EncoderClose(void *h)
+{
+    Enc *e = (Enc *)h;
+    if (!e) return;
+    if (e->nth) {
+        pthread_mutex_lock(&e->mu); e->quit = 1; pthread_cond_broadcast(&e->cv_work); pthread_mutex_unlock(&e->mu);
+        for (int i = 0; i < e->nth; ++i) pthread_join(e->th[i], NULL);
+    }
+    if (e->ctx) {
+        ks265_synchronize(e->ctx);
+        if (e->cfg.calcPsnr && e->st.frames) {
+            const double np[3] = {(double)e->W * e->H, (double)e->W * e->H / 4, (double)e->W * e->H / 4};
+            double ps[3];
+            for (int k = 0; k < 3; ++k) ps[k] = e->st.sse[k] > 0 ? 10.0 * log10(255.0 * 255.0 * np[k] * e->st.frames / e->st.sse[k]) : 99.0;
+            logf_(2, e->log_level, "bitrate, psnr: %.4f %.4f %.4f %.4f\n", e->st.bytes * 8.0 * e->cfg.frameRate / e->st.frames / 1000.0, ps[0], ps[1], ps[2]);
+        }
+        for (int i = 0; i < MAX_JOBS; ++i) {
+            Job *j = &e->jobs[i];
+            ks265_host_free(e->ctx, j->cu8); ks265_host_free(e->ctx, j->lvl[0]); ks265_host_free(e->ctx, j->lvl[1]); ks265_host_free(e->ctx, j->lvl[2]);
+            ks265_host_free(e->ctx, j->sao); ks265_host_free(e->ctx, j->sse);
+            if (j->ev) ks265_event_destroy(e->ctx, j->ev);
+            free(j->nal);
+        }
+        for (int i = 0; i < MAX_INPUT; ++i) ks265_host_free(e->ctx, e->in[i].i420);
+        for (int i = 0; i < e->ndpb; ++i) pic_free(e, &e->dpb[i]);
+        pic_free(e, &e->src);
+        ks265_dev_free(e->ctx, e->dev_i420); ks265_dev_free(e->ctx, e->dev_sse);
+        if (e->frame) ks265_frame_destroy(e->frame);
+        ks265_destroy(e->ctx);
+    }
+    for (int i = 0; i < 64; ++i) free(e->scratch[i]);
+    free(e->hdr); free(e->outbuf);
+    pthread_mutex_destroy(&e->mu); pthread_cond_destroy(&e->cv_work); pthread_cond_destroy(&e->cv_done);
+    free(e);
+}
+
+void *QY265EncoderOpen(QY265EncConfig *cfg, int *err)
+{
+    int dummy; if (!err) err = &dummy;
+    *err = QY_OK;
+    if (!cfg) { *err = QY_POINTER; return NULL; }
+    if (cfg->picWidth <= 0 || cfg->picHeight <= 0 || (cfg->picWidth & 7) || (cfg->picHeight & 7) || cfg->frameRate <= 0 || cfg->rc < 0 || cfg->rc > 5) { *err = QY_NOTSUPPORTED; return NULL; }
+    Enc *e = (Enc *)calloc(1, sizeof *e);
+    if (!e) { *err = QY_OUTOFMEMORY; return NULL; }
+    pthread_mutex_init(&e->mu, NULL); pthread_cond_init(&e->cv_work, NULL); pthread_cond_init(&e->cv_done, NULL);
+    e->cfg = *cfg; e->W = cfg->picWidth; e->H = cfg->picHeight; e->log_level = cfg->logLevel;
+    e->me_method = cfg->me < 0 ? 1 : cfg->me > 2 ? 2 : cfg->me;        /* EPZS / Cross (-me 3 / 4) are not built: UMH instead */
+    e->hex_thr = (e->me_method == 2 && (cfg->preset == QY265PRESET_SLOW || cfg->preset == QY265PRESET_SLOWER)) ? 16 : 0;   /* tME+0x368, SURVEY-measured */
+    e->subme = cfg->subme ? 1 : 0;
+    e->refs = cfg->refnum < 1 ? 1 : cfg->refnum > 4 ? 4 : cfg->refnum;
+    e->use_sao = cfg->sao > 0; e->use_df = 1;
+    e->gop_b = cfg->bframes < 0 ? (cfg->latency == QY265LATENCY_DEFAULT ? 7 : 0) : cfg->bframes;
+    e->hier = cfg->bframes < 0 && e->gop_b == 7;
+    if (e->gop_b > 0) e->refs = 1;
+    e->base_qp = cfg->rc == 3 ? cfg->crf : cfg->qp;
+    if (e->base_qp < 0) e->base_qp = 0;
+    if (e->base_qp > 51) e->base_qp = 51;
+    e->iper = cfg->iIntraPeriod;
+    e->coded_upto = -1;
+    long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
+    e->nthreads = cfg->threads > 0 ? cfg->threads : (int)(ncpu > 0 ? ncpu : 4);
+    if (e->nthreads > 64) e->nthreads = 64;
+    if (e->nthreads > MAX_JOBS - 4) e->nthreads = MAX_JOBS - 4;
+    if (cfg->rdoq || cfg->transskip || cfg->part || cfg->iAqMode) logf_(1, e->log_level, "ks265enc: rdoq / transskip / part / aq are accepted but not implemented by the pixel path\n");
+    if (cfg->rc == 5 || cfg->vbv_buffer_size) logf_(1, e->log_level, "ks265enc: CVQ / VBV are not implemented; running the plain controller\n");
+
+    int r = ks265_create(&e->ctx, 0);
+    if (r) { *err = hip_rc(r); QY265EncoderClose(e); return NULL; }       /* KS265_NO_DEVICE -> QY_FAIL: there is no CPU fallback */
+    memset(&e->fcfg, 0, sizeof e->fcfg);
+    e->fcfg.width = e->W; e->fcfg.height = e->H; e->fcfg.qp = e->base_qp; e->fcfg.lambda_q4 = kLambdaQ4[e->base_qp];
+    e->fcfg.me_range = cfg->searchrange < 1 ? 64 : cfg->searchrange > 64 ? 64 : cfg->searchrange;
+    e->fcfg.me_method = e->me_method; e->fcfg.subme = e->subme; e->fcfg.deblock = e->use_df; e->fcfg.sao = e->use_sao;
+    e->fcfg.bframes = e->gop_b; e->fcfg.refs = e->refs; e->fcfg.me_hex_thr = e->hex_thr;
+    r = ks265_frame_geometry(&e->fcfg, &e->geom);
+    if (!r) r = ks265_frame_create(e->ctx, &e->fcfg, &e->frame);
+    const size_t fsz = (size_t)e->W * e->H * 3 / 2, npx = (size_t)e->W * e->H;
+    if (!r) r = ks265_dev_malloc(e->ctx, (void **)&e->dev_i420, fsz);
+    if (!r) r = ks265_dev_malloc(e->ctx, (void **)&e->dev_sse, 64);
+    if (!r) r = pic_alloc(e, &e->src);
+    e->ndpb = e->hier ? 10 : e->gop_b ? 4 : e->refs + 2;
+    for (int i = 0; i < e->ndpb && !r; ++i) { r = pic_alloc(e, &e->dpb[i]); e->dpb_poc[i] = -1000000; }
+    const int njobs_alloc = MAX_JOBS;
+    for (int i = 0; i < njobs_alloc && !r; ++i) {
+        Job *j = &e->jobs[i];
+        r = ks265_host_malloc(e->ctx, (void **)&j->cu8, (size_t)e->geom.bytes_cu8);
+        if (!r) r = ks265_host_malloc(e->ctx, (void **)&j->lvl[0], npx * 2);
+        if (!r) r = ks265_host_malloc(e->ctx, (void **)&j->lvl[1], npx / 2);
+        if (!r) r = ks265_host_malloc(e->ctx, (void **)&j->lvl[2], npx / 2);
+        if (!r) r = ks265_host_malloc(e->ctx, (void **)&j->sao, (size_t)e->geom.bytes_sao);
+        if (!r) r = ks265_host_malloc(e->ctx, (void **)&j->sse, 64);
+        if (!r) r = ks265_event_create(e->ctx, &j->ev);
+        j->nal_cap = npx * 2 + 65536;
+        j->nal = (uint8_t *)malloc(j->nal_cap);
+        if (!j->nal) r = KS265_OUTOFMEMORY;
+    }
+    for (int i = 0; i < MAX_INPUT && !r; ++i) r = ks265_host_malloc(e->ctx, (void **)&e->in[i].i420, fsz);
+    if (r) { *err = hip_rc(r); QY265EncoderClose(e); return NULL; }
+    memset(&e->scfg, 0, sizeof e->scfg);
+    e->scfg.width = e->W; e->scfg.height = e->H; e->scfg.sao = e->use_sao; e->scfg.deblock = e->use_df;
+    e->scfg.max_dec_pic_buffering = e->hier ? 10 : e->gop_b ? 4 : e->refs + 1; e->scfg.max_num_reorder = e->gop_b; e->scfg.log2_max_poc_lsb = 16;
+    e->hdr = (uint8_t *)malloc(512);
+    if (e->hdr) {
+        long a = ks265_write_vps(&e->scfg, e->hdr, 512), b = a > 0 ? ks265_write_sps(&e->scfg, e->hdr + a, 512 - (size_t)a) : -1, c = b > 0 ? ks265_write_pps(&e->scfg, e->hdr + a + b, 512 - (size_t)(a + b)) : -1;
+        e->hdr_len = c > 0 ? a + b + c : -1;
+        e->hdr_part[0] = a; e->hdr_part[1] = b; e->hdr_part[2] = c;
+    }
+    e->outcap = npx + 65536;
+    e->outbuf = (uint8_t *)malloc(e->outcap);
+    if (!e->hdr || e->hdr_len < 0 || !e->outbuf) { *err = QY_FAIL; QY265EncoderClose(e); return NULL; }
+    for (int i = 0; i < e->nthreads; ++i) { e->scratch[i] = malloc(ks265_slice_scratch_bytes(&e->scfg)); if (!e->scratch[i]) { *err = QY_OUTOFMEMORY; QY265EncoderClose(e); return NULL; } }
+    for (int i = 0; i < e->nthreads; ++i) { e->warg[i].e = e; e->warg[i].idx = i; if (pthread_create(&e->th[i], NULL, worker, &e->warg[i])) break; ++e->nth; }
+    if (!e->nth) { *err = QY_FAIL; QY265EncoderClose(e); return NULL; }
+    logf_(0, e->log_level, "ks265enc: %dx%d %.2f fps, qp %d, -me %d (hex below %d), subme %d, refs %d, %s, sao %d, key period %d, %d slice writer threads, %s\n", e->W, e->H,
+          cfg->frameRate, e->base_qp, e->me_method, e->hex_thr, e->subme, e->refs, e->hier ? "hierarchical-B GOP 8" : e->gop_b ? "P + non-reference B" : "IPPP", e->use_sao, e->iper,
+          e->nth, ks265_version());
+    return e;
+}
+
+void QY265EncoderReconfig(void *h, QY265EncConfig *cfg)
+{
+    Enc *e = (Enc *)h;
+    if (!e || !cfg) return;
+    e->cfg.qp = cfg->qp; e->cfg.crf = cfg->crf; e->cfg.bitrateInkbps = cfg->bitrateInkbps; e->cfg.iIntraPeriod = cfg->iIntraPeriod;
+    e->base_qp = cfg->rc == 3 ? cfg->crf : cfg->qp; e->iper = cfg->iIntraPeriod;
+    if (e->base_qp < 0) e->base_qp = 0;
+    if (e->base_qp > 51) e->base_qp = 51;
+}
+int QY265EncoderEncodeHeaders(void *h, QY265Nal **pNals, int *n)
+{
+    Enc *e = (Enc *)h;
+    if (!e || !pNals || !n) return QY_POINTER;
+    e->nals[0].naltype = KS265_NAL_VPS; e->nals[0].tid = 0; e->nals[0].iSize = (int)e->hdr_len; e->nals[0].pts = 0; e->nals[0].pPayload = e->hdr;
+    *pNals = e->nals; *n = 1;                                           /* one entry holding VPS + SPS + PPS back to back */
+    return QY_OK;
+}
+void QY265EncoderKeyFrameRequest(void *h) { Enc *e = (Enc *)h; if (e) e->force_key = 1; }
+int QY265EncoderDelayedFrames(void *h)
+{
+    Enc *e = (Enc *)h;
+    if (!e) return 0;
+    int n = 0;
+    for (int i = 0; i < MAX_INPUT; ++i) if (e->in[i].used == 1) ++n;
+    pthread_mutex_lock(&e->mu); n += e->njobs; pthread_mutex_unlock(&e->mu);
+    return n;
+}
+
+int QY265EncoderEncodeFrame(void *h, QY265Nal **pNals, int *iNalCount, QY265Picture *in, QY265Picture *out, int bForceLogo)
+{
+    (void)bForceLogo;
+    Enc *e = (Enc *)h;
+    if (!e || !pNals || !iNalCount) return QY_POINTER;
+    *pNals = e->nals; *iNalCount = 0;
+    int r = QY_OK;
+    if (in) {
+        if (!in->yuv || !in->yuv->pData[0] || !in->yuv->pData[1] || !in->yuv->pData[2]) return QY_POINTER;
+        if (in->yuv->iWidth != e->W || in->yuv->iHeight != e->H) return QY_NOTSUPPORTED;
+        Input *slot = NULL;
+        for (int i = 0; i < MAX_INPUT && !slot; ++i) if (!e->in[i].used) slot = &e->in[i];
+        if (!slot) return QY_FAIL;                                     /* cannot happen: MAX_INPUT > MAX_JOBS + one mini-GOP */
+        for (int y = 0; y < e->H; ++y) memcpy(slot->i420 + (size_t)y * e->W, in->yuv->pData[0] + (size_t)y * in->yuv->iStride[0], (size_t)e->W);
+        uint8_t *u = slot->i420 + (size_t)e->W * e->H, *v = u + (size_t)e->W * e->H / 4;
+        for (int y = 0; y < e->H / 2; ++y) {
+            memcpy(u + (size_t)y * (e->W / 2), in->yuv->pData[1] + (size_t)y * in->yuv->iStride[1], (size_t)e->W / 2);
+            memcpy(v + (size_t)y * (e->W / 2), in->yuv->pData[2] + (size_t)y * in->yuv->iStride[2], (size_t)e->W / 2);
+        }
+        slot->disp = e->next_disp++; slot->pts = in->pts; slot->used = 1;
+    }
+    /* Output first when many pictures are in flight (keeps the job ring and the input buffers from running out): the pictures that are
+     * handed out are copied to the output buffer, so scheduling new work right after is safe. */
+    int busy;
+    pthread_mutex_lock(&e->mu); busy = e->njobs; pthread_mutex_unlock(&e->mu);
+    if (in && busy > MAX_JOBS - 12) {
+        r = take_output(e, 1, pNals, iNalCount, out);
+        const int r2 = schedule(e, 0);
+        return r ? r : r2;
+    }
+    r = schedule(e, in == NULL);
+    if (r) return r;
+    return take_output(e, in == NULL, pNals, iNalCount, out);
+}
+
+int ks265_enc_get_stats(void *h, ks265_enc_stats *out)
+{
+    Enc *e = (Enc *)h;
+    if (!e || !out) return QY_POINTER;
+    *out = e->st;
+    return QY_OK;
+}

@@ -29,10 +29,24 @@ class SliceIn(C.Structure):
                 ("l0_poc", C.c_int32 * 4), ("l1_poc", C.c_int32 * 4), ("cu8", C.c_void_p), ("lvl", C.c_void_p * 3), ("sao", C.c_void_p)]
 
 
+ENC_SRC = [os.path.join(HERE, "host", "ks265_enc.c")]
+CLI_SRC = os.path.join(HERE, "host", "ks265_cli.c")
+CLI = os.path.join(HERE, "ks265enc")
+HIPLIB = os.path.join(HERE, "libks265hip.so")
+
+
 def build(force: bool = False) -> str:
-    deps = SRC + [os.path.join(INC, "ks265_stream.h"), os.path.join(INC, "ks265_hip.h")]
-    if force or not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps):
-        subprocess.check_call(["gcc", "-O2", "-std=c11", "-fPIC", "-shared", "-Wall", "-Wextra", "-I", INC, "-o", LIB, *SRC])
+    """libks265enc.so = bitstream writer + the SDK-compatible encoder API (links libks265hip.so when that has been built; without it only
+    the writer is available, which is all the CPU tests need); ks265enc = the appencoder-compatible CLI"""
+    deps = SRC + ENC_SRC + [CLI_SRC] + [os.path.join(INC, h) for h in ("ks265_stream.h", "ks265_hip.h", "ks265_enc.h")]
+    have_hip = os.path.exists(HIPLIB)
+    if force or not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps) or (have_hip and os.path.getmtime(HIPLIB) > os.path.getmtime(LIB)):
+        flags = ["gcc", "-O2", "-std=c11", "-fPIC", "-Wall", "-Wextra", "-I", INC]
+        if have_hip:
+            subprocess.check_call([*flags, "-shared", "-o", LIB, *SRC, *ENC_SRC, "-L", HERE, "-lks265hip", "-Wl,-rpath,$ORIGIN", "-lpthread", "-lm"])
+            subprocess.check_call([*flags, "-o", CLI, CLI_SRC, "-L", HERE, "-lks265enc", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath-link," + HERE])
+        else:
+            subprocess.check_call([*flags, "-shared", "-o", LIB, *SRC])
     return LIB
 
 

@@ -1,0 +1,109 @@
+"""GPU: the C host (libks265enc.so: SDK-compatible API over the HIP path + bitstream writer) and its CLI.
+  * `ks265enc -preset slow -rc 0 -qp 27 -bframes 0` on the clip of stream case ippp_416x240_umh writes byte for byte the stream that the
+    reference decoder verified (tests/golden/stream_md5.json) - the C host, the Python test mirror and the oracle agree;
+  * the API with the SDK's default GOP (hierarchical B, 8) and with -bframes 3: call sequence of the SDK's own callers, NAL bookkeeping,
+    delayed-frame accounting; the streams are left in gpurun_out/ so that the builder container can decode them with appdecoder."""
+from __future__ import annotations
+
+import ctypes as C
+import hashlib
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from stream_cases import CASES
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+GOLD = json.load(open(os.path.join(HERE, "golden", "stream_md5.json")))
+LAY = json.load(open(os.path.join(HERE, "golden", "qy265_layout.json")))
+OUT = os.path.join(ROOT, "gpurun_out")
+
+
+def _clip(name, n):
+    from ks265codec_amd.synth import make_clip
+    W, H = CASES[name][0], CASES[name][1]
+    return make_clip(W, H, n, seed=len(name) * 7 + W, abc=(17, 23, 9))
+
+
+def test_cli_stream_equals_decoder_verified_fixture(tmp_path):
+    from ks265codec_amd import stream
+    stream.build()
+    name = "ippp_416x240_umh"
+    clip = _clip(name, 4)
+    yuv, out = tmp_path / "in.yuv", tmp_path / "out.265"
+    clip.tofile(yuv)
+    r = subprocess.run([stream.CLI, "-i", str(yuv), "-wdt", "416", "-hgt", "240", "-fr", "50", "-preset", "slow", "-rc", "0", "-qp", "27", "-iper", "128", "-bframes", "0",
+                        "-threads", "3", "-psnr", "2", "-b", str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-500:] + r.stderr[-500:]
+    assert "H265 encoder passed!!!" in r.stdout and "Total Frames: 4" in r.stdout and "bitrate, psnr:" in r.stdout, r.stdout
+    bs = open(out, "rb").read()
+    assert hashlib.md5(bs).hexdigest() == GOLD[name]["stream_md5"], f"CLI stream differs from the decoder-verified fixture ({len(bs)} vs {GOLD[name]['stream_bytes']} bytes)"
+
+
+class YUV(C.Structure):
+    _fields_ = [("iWidth", C.c_int), ("iHeight", C.c_int), ("pData", C.POINTER(C.c_ubyte) * 3), ("iStride", C.c_int * 3)]
+
+
+class Picture(C.Structure):
+    _fields_ = [("iSliceType", C.c_int), ("poc", C.c_int), ("pts", C.c_longlong), ("dts", C.c_longlong), ("yuv", C.POINTER(YUV))]
+
+
+class Nal(C.Structure):
+    _fields_ = [("naltype", C.c_int), ("tid", C.c_int), ("iSize", C.c_int), ("pts", C.c_longlong), ("pPayload", C.POINTER(C.c_ubyte))]
+
+
+@pytest.mark.parametrize("bframes,tag", [(-1, "hier8"), (3, "b3"), (0, "ippp_ref3")])
+def test_api_call_sequence(bframes, tag):
+    from ks265codec_amd import stream
+    assert C.sizeof(YUV) == LAY["sizeof_yuv"] and C.sizeof(Picture) == LAY["sizeof_picture"] and C.sizeof(Nal) == LAY["sizeof_nal"]
+    lib = C.CDLL(stream.build())
+    lib.QY265EncoderOpen.restype = C.c_void_p
+    W, H, N = 416, 240, 21
+    clip = _clip("hierb4_416x240", N)
+    cfg = (C.c_uint8 * LAY["sizeof_config"])()
+    assert lib.QY265ConfigDefaultPreset(cfg, b"slow", None, b"default") == 0
+    for k, v in (("wdt", W), ("hgt", H), ("fr", 50), ("rc", 0), ("qp", 27), ("iper", 16), ("bframes", bframes), ("threads", 4), ("psnr", 1)):
+        assert lib.QY265ConfigParse(cfg, k.encode(), str(v).encode()) == 0
+    if tag == "ippp_ref3":
+        assert lib.QY265ConfigParse(cfg, b"ref", b"3") == 0
+    err = C.c_int(0)
+    h = C.c_void_p(lib.QY265EncoderOpen(cfg, C.byref(err)))
+    assert h.value, hex(err.value & 0xFFFFFFFF)
+    nal, nn = C.POINTER(Nal)(), C.c_int(0)
+    pic, outp, yuv = Picture(), Picture(), YUV()
+    yuv.iWidth, yuv.iHeight = W, H
+    yuv.iStride[0], yuv.iStride[1], yuv.iStride[2] = W, W // 2, W // 2
+    pic.yuv = C.pointer(yuv)
+    bs, types, max_delay = bytearray(), [], 0
+    for t in range(N):
+        fr = np.ascontiguousarray(clip[t])
+        base = fr.ctypes.data
+        for k, off in enumerate((0, W * H, W * H * 5 // 4)):
+            yuv.pData[k] = C.cast(base + off, C.POINTER(C.c_ubyte))
+        pic.pts = t
+        assert lib.QY265EncoderEncodeFrame(h, C.byref(nal), C.byref(nn), C.byref(pic), C.byref(outp), 0) == 0
+        fr[:] = 0                                           # the library copied the picture: the caller's buffer is free again
+        for i in range(nn.value):
+            bs += C.string_at(nal[i].pPayload, nal[i].iSize); types.append(nal[i].naltype)
+        max_delay = max(max_delay, lib.QY265EncoderDelayedFrames(h))
+    while lib.QY265EncoderDelayedFrames(h):
+        assert lib.QY265EncoderEncodeFrame(h, C.byref(nal), C.byref(nn), None, C.byref(outp), 0) == 0
+        for i in range(nn.value):
+            bs += C.string_at(nal[i].pPayload, nal[i].iSize); types.append(nal[i].naltype)
+    lib.QY265EncoderClose(h)
+    vcl = [t for t in types if t < 32]
+    assert len(vcl) == N, (len(vcl), types)
+    assert types[:4] == [32, 33, 34, 19] and vcl.count(19) == 2          # key pictures at 0 and 16, parameter sets in front of each
+    assert types.count(32) == 2 and types.count(33) == 2 and types.count(34) == 2
+    if bframes != 0:
+        assert vcl.count(0) > 0 and max_delay >= 2                        # non-reference B pictures exist, output lags input
+    starts = [i for i in range(len(bs) - 4) if bs[i:i + 4] == b"\x00\x00\x00\x01"]
+    assert len(starts) == len(types)
+    os.makedirs(OUT, exist_ok=True)
+    open(os.path.join(OUT, f"api_{tag}.265"), "wb").write(bs)
+    clip.tofile(os.path.join(OUT, f"api_{tag}_src.yuv"))
