@@ -55,7 +55,7 @@ def make_stream(name: str, encode):
     sched = schedule(kind, par)
     nref = max([len(s[2]) + len(s[3]) for s in sched] + [1])
     reorder = par if kind == "hier" else 0
-    w = S.StreamWriter(W, H, sao=sao, deblock=df, max_dec_pic_buffering=max(nref, par if kind == "hier" else 1) + 2, max_num_reorder=reorder)
+    w = S.StreamWriter(W, H, sao=sao, deblock=df, max_dec_pic_buffering=(par + 2) if kind == "hier" else nref + 1, max_num_reorder=reorder)      # the C host's rule (ks265_enc.c)
     bs = w.headers()
     recs = {}
     for d, k, l0, l1, dq, rps, isref in sched:

@@ -17,6 +17,10 @@ import pytest
 from stream_cases import CASES
 
 pytestmark = pytest.mark.gpu
+# torch carries its own copy of the HIP runtime: let it load first, so that the other GPU test modules of the same pytest process (which use
+# torch for device memory) are not handed the system copy that libks265enc.so -> libks265hip.so would otherwise pull in
+import torch  # noqa: E402
+torch.cuda.is_available()
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 GOLD = json.load(open(os.path.join(HERE, "golden", "stream_md5.json")))
@@ -81,7 +85,7 @@ def test_api_call_sequence(bframes, tag):
     pic.yuv = C.pointer(yuv)
     bs, types, max_delay = bytearray(), [], 0
     for t in range(N):
-        fr = np.ascontiguousarray(clip[t])
+        fr = clip[t].copy()
         base = fr.ctypes.data
         for k, off in enumerate((0, W * H, W * H * 5 // 4)):
             yuv.pData[k] = C.cast(base + off, C.POINTER(C.c_ubyte))
