@@ -108,8 +108,8 @@ int QY265ConfigParse(QY265EncConfig *c, const char *name, const char *value)
 
 /* ------------------------------------------------------------------ encoder */
 #define MAX_DPB 12
-#define MAX_JOBS 24
-#define MAX_INPUT 40
+#define MAX_JOBS 48
+#define MAX_INPUT 64
 
 typedef struct Job {
     int used, done, error;
@@ -345,15 +345,16 @@ static int schedule(Enc *e, int flush)
     }
 }
 
-/* move finished pictures (in coding order) to the output array; block = wait for at least everything that is queued */
-static int take_output(Enc *e, int block, QY265Nal **pNals, int *n, QY265Picture *out)
+/* move finished pictures (in coding order) to the output array; wait while more than `max_in_flight` pictures are queued
+ * (0 = drain everything, MAX_JOBS = never wait) */
+static int take_output(Enc *e, int max_in_flight, QY265Nal **pNals, int *n, QY265Picture *out)
 {
     int cnt = 0, err = QY_OK;
     e->outpos = 0;
     pthread_mutex_lock(&e->mu);
     while (e->njobs) {
         Job *j = &e->jobs[e->job_head];
-        if (!j->done) { if (!block) break; pthread_cond_wait(&e->cv_done, &e->mu); continue; }
+        if (!j->done) { if (e->njobs <= max_in_flight) break; pthread_cond_wait(&e->cv_done, &e->mu); continue; }
         if (j->error) err = hip_rc(j->error);
         const size_t need = (size_t)(j->nal_len > 0 ? j->nal_len : 0);
         if (e->outpos + need > e->outcap) {                             /* the caller reads the payloads after this call: they cannot stay in the job (its slot is reused) */
@@ -466,7 +467,7 @@ void *QY265EncoderOpen(QY265EncConfig *cfg, int *err)
     long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
     e->nthreads = cfg->threads > 0 ? cfg->threads : (int)(ncpu > 0 ? ncpu : 4);
     if (e->nthreads > 64) e->nthreads = 64;
-    if (e->nthreads > MAX_JOBS - 4) e->nthreads = MAX_JOBS - 4;
+    if (e->nthreads > MAX_JOBS - 14) e->nthreads = MAX_JOBS - 14;             /* more writers than pictures that can be in flight would idle */
     if (cfg->rdoq || cfg->transskip || cfg->part || cfg->iAqMode) logf_(1, e->log_level, "ks265enc: rdoq / transskip / part / aq are accepted but not implemented by the pixel path\n");
     if (cfg->rc == 5 || cfg->vbv_buffer_size) logf_(1, e->log_level, "ks265enc: CVQ / VBV are not implemented; running the plain controller\n");
 
@@ -571,18 +572,16 @@ int QY265EncoderEncodeFrame(void *h, QY265Nal **pNals, int *iNalCount, QY265Pict
         }
         slot->disp = e->next_disp++; slot->pts = in->pts; slot->used = 1;
     }
-    /* Output first when many pictures are in flight (keeps the job ring and the input buffers from running out): the pictures that are
-     * handed out are copied to the output buffer, so scheduling new work right after is safe. */
-    int busy;
-    pthread_mutex_lock(&e->mu); busy = e->njobs; pthread_mutex_unlock(&e->mu);
-    if (in && busy > MAX_JOBS - 12) {
-        r = take_output(e, 1, pNals, iNalCount, out);
+    /* Output first (finished pictures are copied to the output buffer, so scheduling new work right after is safe); when the ring of
+     * in-flight pictures is nearly full, wait for the oldest ones - only as many as needed, the writers keep running. */
+    if (in) {
+        r = take_output(e, MAX_JOBS - 12, pNals, iNalCount, out);
         const int r2 = schedule(e, 0);
         return r ? r : r2;
     }
-    r = schedule(e, in == NULL);
+    r = schedule(e, 1);
     if (r) return r;
-    return take_output(e, in == NULL, pNals, iNalCount, out);
+    return take_output(e, 0, pNals, iNalCount, out);
 }
 
 int ks265_enc_get_stats(void *h, ks265_enc_stats *out)
