@@ -58,6 +58,9 @@ def main():
     ap.add_argument("--streams", type=int, default=3, help="independent GOP shards in flight per GPU, each on its own HIP stream (their kernels overlap: the search kernels are latency bound)")
     ap.add_argument("--refs", type=int, default=1, help="list-0 reference pictures a P picture searches (-ref / -ref0; -preset slow resolves to 1 / 3: three for the first picture of a mini-GOP); IPPP only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--leg", choices=["both", "encoded", "hot"], default="both", help="encoded: the whole encoder through the SDK-compatible C API (host pictures in, "
+                    "Annex-B NAL units out: H2D, pixel path, D2H, CABAC) = the headline value; hot: the device-resident pixel path only (roofline leg)")
+    ap.add_argument("--host-threads", type=int, default=0, help="slice-writer threads of the encoded leg per rank (0 = min(32, host cores / ranks))")
     args = ap.parse_args()
 
     import torch
@@ -89,6 +92,22 @@ def main():
     me_method = {"dia": 0, "hex": 1, "umh": 2}[args.me]
     nb = args.bframes
     nstreams = 1 if args.b_spread else max(1, args.streams)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    encoded = None
+    if args.leg != "hot" and not args.b_spread:
+        encoded = encoded_leg(args, torch, dist, rank, world, dev_index, backend, sync_all)
+        if args.leg == "encoded":
+            if rank == 0:
+                print(json.dumps(encoded_line(args, encoded, world, None, None)), flush=True)
+            if dist is not None:
+                dist.barrier(); dist.destroy_process_group()
+            return
 
     def make_shard(sidx):
         """one independent GOP shard: its own context (= HIP stream), frame object, clip, decoded-picture buffer and schedule"""
@@ -351,6 +370,8 @@ def main():
                        "sharding": "anchor chain on rank 0 + RCCL broadcast of reconstructed anchors, B pictures spread" if args.b_spread else f"{nstreams} GOP shard(s) in flight per GPU on separate HIP streams, no data-path collective"},
             "roofline": roofline, "cpu_baseline": cpu,
         }
+        if encoded is not None:
+            line = encoded_line(args, encoded, world, line, cpu)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
@@ -358,6 +379,121 @@ def main():
     for sh in shards:
         sh.fr.close()
     ks.close()
+
+
+def encoded_leg(args, torch, dist, rank, world, dev_index, backend, sync_all):
+    """The whole encoder on this rank's GPU through the SDK-compatible C API (libks265enc.so, include/ks265_enc.h): per step one host picture goes
+    in (QY265EncoderEncodeFrame: copy to pinned memory, H2D, pixel path, D2H of the records, CABAC on the writer threads), NAL units come out.
+    Timed: `steps` pictures incl. the flush that drains the pipeline, bracketed by barriers; the maximum over ranks counts."""
+    import ctypes as C
+    from ks265codec_amd import stream
+    from ks265codec_amd.synth import make_clip
+    lay = json.load(open(os.path.join(ROOT, "tests", "golden", "qy265_layout.json")))
+    lib = C.CDLL(stream.build())
+    lib.QY265EncoderOpen.restype = C.c_void_p
+
+    class YUV(C.Structure):
+        _fields_ = [("iWidth", C.c_int), ("iHeight", C.c_int), ("pData", C.POINTER(C.c_ubyte) * 3), ("iStride", C.c_int * 3)]
+
+    class Picture(C.Structure):
+        _fields_ = [("iSliceType", C.c_int), ("poc", C.c_int), ("pts", C.c_longlong), ("dts", C.c_longlong), ("yuv", C.POINTER(YUV))]
+
+    class Nal(C.Structure):
+        _fields_ = [("naltype", C.c_int), ("tid", C.c_int), ("iSize", C.c_int), ("pts", C.c_longlong), ("pPayload", C.POINTER(C.c_ubyte))]
+
+    class Stats(C.Structure):
+        _fields_ = [("frames", C.c_long), ("bytes", C.c_longlong), ("sse", C.c_double * 3), ("gpu_ms", C.c_double), ("host_write_ms", C.c_double)]
+
+    W, H = args.width, args.height
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        cores = os.cpu_count() or 8
+    threads = args.host_threads or max(2, min(32, cores // max(1, world)))
+    os.environ["KS265_DEVICE"] = str(dev_index)
+    cfg = (C.c_uint8 * lay["sizeof_config"])()
+    preset = b"slow" if args.me == "umh" and args.me_hex_thr == 16 else b"veryslow" if args.me == "umh" else b"medium"
+    assert lib.QY265ConfigDefaultPreset(cfg, preset, None, b"default") == 0
+    gop_b = (args.hier_b - 1) if args.hier_b else args.bframes
+    for k, v in (("wdt", W), ("hgt", H), ("fr", 50), ("rc", 0), ("qp", args.qp), ("iper", args.iper), ("bframes", -1 if args.hier_b == 8 else gop_b), ("threads", threads),
+                 ("psnr", 1), ("log", 3), ("me", {"dia": 0, "hex": 1, "umh": 2}[args.me]), ("subme", 1), ("ref", max(1, args.refs))):
+        assert lib.QY265ConfigParse(cfg, k.encode(), str(v).encode()) == 0, k
+    clip = make_clip(W, H, args.clip_frames, seed=7 + rank, abc=(67, 91, 33), pan=(8, 5))
+    order = list(range(len(clip))) + list(range(len(clip) - 2, 0, -1))          # ping-pong keeps the motion continuous
+    err = C.c_int(0)
+    h = C.c_void_p(lib.QY265EncoderOpen(cfg, C.byref(err)))
+    if not h.value:
+        raise SystemExit(f"QY265EncoderOpen failed: 0x{err.value & 0xFFFFFFFF:08x} (the encoder needs the MI355X: there is no CPU fallback)")
+    nal, nn, pic, outp, yuv = C.POINTER(Nal)(), C.c_int(0), Picture(), Picture(), YUV()
+    yuv.iWidth, yuv.iHeight = W, H
+    yuv.iStride[0], yuv.iStride[1], yuv.iStride[2] = W, W // 2, W // 2
+    pic.yuv = C.pointer(yuv)
+    state = {"t": 0, "bytes": 0, "nals": 0}
+
+    def feed(n):
+        for _ in range(n):
+            fr = clip[order[state["t"] % len(order)]]
+            for k, off in enumerate((0, W * H, W * H * 5 // 4)):
+                yuv.pData[k] = C.cast(fr.ctypes.data + off, C.POINTER(C.c_ubyte))
+            pic.pts = state["t"]
+            state["t"] += 1
+            rc = lib.QY265EncoderEncodeFrame(h, C.byref(nal), C.byref(nn), C.byref(pic), C.byref(outp), 0)
+            assert rc == 0, hex(rc & 0xFFFFFFFF)
+            state["nals"] += nn.value
+            state["bytes"] += sum(nal[i].iSize for i in range(nn.value))
+
+    def flush():
+        while lib.QY265EncoderDelayedFrames(h):
+            rc = lib.QY265EncoderEncodeFrame(h, C.byref(nal), C.byref(nn), None, C.byref(outp), 0)
+            assert rc == 0, hex(rc & 0xFFFFFFFF)
+            state["nals"] += nn.value
+            state["bytes"] += sum(nal[i].iSize for i in range(nn.value))
+
+    feed(args.warmup); flush()
+    b0 = state["bytes"]
+    sync_all()
+    t0 = time.perf_counter()
+    feed(args.steps); flush()
+    sync_all()
+    dt = time.perf_counter() - t0
+    st = Stats()
+    lib.ks265_enc_get_stats(h, C.byref(st))
+    lib.QY265EncoderClose(h)
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=torch.device("cuda", dev_index) if backend == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    mse = st.sse[0] / max(1, st.frames) / (W * H)
+    return {"fps": world * args.steps / dt, "dt": dt, "host_threads": threads, "host_cores": cores, "bytes_per_picture": (state["bytes"] - b0) / args.steps,
+            "psnr_y": 99.0 if mse == 0 else 10.0 * np.log10(255.0 ** 2 / mse), "slice_write_ms_per_picture": st.host_write_ms / max(1, st.frames), "preset": preset.decode(),
+            "gop": f"hierarchical-B {args.hier_b}" if args.hier_b else (f"P + {gop_b} B" if gop_b else "IPPP")}
+
+
+def encoded_line(args, enc, world, hot, cpu):
+    """the bench line: value = encoded frames/s (the whole encoder); the device-resident pixel-path leg (if run) supplies roofline / stage times"""
+    W, H = args.width, args.height
+    line = {
+        "metric": "encoded frames/sec + PSNR-Y, 2160p -preset slow -qp 27, 1/2/4/8 GPU",
+        "value": round(enc["fps"], 2), "unit": "frames/s", "psnr_y": round(float(enc["psnr_y"]), 3),
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * enc["dt"] / args.steps, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": f"{W}x{H} 4:2:0 8-bit synthetic clip, ENCODED end to end through the SDK-compatible C API (QY265EncoderEncodeFrame): host I420 in -> pinned copy -> H2D -> "
+                               f"pixel path on the MI355X (-preset {enc['preset']}: -me {args.me}, subme 1, deblock + SAO) -> D2H of CU map / levels / SAO -> CABAC slice data on "
+                               f"{enc['host_threads']} host threads -> Annex-B NAL units out; -rc 0 -qp {args.qp} (I=Q, P=Q+1, B=Q+2..) -iper {args.iper}, {enc['gop']}, "
+                               f"-ref {max(1, args.refs)}; the stream decodes with the reference's appdecoder to the encoder's reconstruction (tests/test_stream.py)",
+                   "pictures_per_step": 1, "host_threads_per_gpu": enc["host_threads"], "host_cores": enc["host_cores"],
+                   "bytes_per_picture": int(enc["bytes_per_picture"]), "kbps_at_50fps": round(enc["bytes_per_picture"] * 8 * 50 / 1000.0, 1),
+                   "slice_write_ms_per_picture_per_thread": round(enc["slice_write_ms_per_picture"], 2),
+                   "not_in_the_path": "rate-distortion optimised quantisation / sign-data hiding (the reference's -rdoq at -preset slow), skip / merge modes, lookahead: the stream is larger than appencoder's at the same QP",
+                   "sharding": "one encoder per GPU (rank), each on its own synthetic clip = its own closed GOPs; no data-path collective"},
+        "roofline": None, "cpu_baseline": cpu,
+    }
+    if hot is not None:
+        line["roofline"] = hot["roofline"]
+        line["hot_path"] = {"value": hot["value"], "unit": "frames/s", "psnr_y": hot["psnr_y"], "ms_per_step": hot["ms_per_step"],
+                            "what": "device-resident pixel path only (inputs and outputs stay in HBM, no host): " + hot["config"]["workload"],
+                            "streams_per_gpu": hot["config"]["streams_per_gpu"], "key_picture_ms": hot["config"]["key_picture_ms"]}
+    return line
 
 
 if __name__ == "__main__":

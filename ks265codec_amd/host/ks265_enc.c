@@ -471,7 +471,10 @@ void *QY265EncoderOpen(QY265EncConfig *cfg, int *err)
     if (cfg->rdoq || cfg->transskip || cfg->part || cfg->iAqMode) logf_(1, e->log_level, "ks265enc: rdoq / transskip / part / aq are accepted but not implemented by the pixel path\n");
     if (cfg->rc == 5 || cfg->vbv_buffer_size) logf_(1, e->log_level, "ks265enc: CVQ / VBV are not implemented; running the plain controller\n");
 
-    int r = ks265_create(&e->ctx, 0);
+    /* the SDK's config has no device field: one encoder = one GPU, chosen by KS265_DEVICE (default 0); N GPUs = N processes or N handles,
+     * each on its own closed GOPs */
+    const char *dev_env = getenv("KS265_DEVICE");
+    int r = ks265_create(&e->ctx, dev_env ? atoi(dev_env) : 0);
     if (r) { *err = hip_rc(r); QY265EncoderClose(e); return NULL; }       /* KS265_NO_DEVICE -> QY_FAIL: there is no CPU fallback */
     memset(&e->fcfg, 0, sizeof e->fcfg);
     e->fcfg.width = e->W; e->fcfg.height = e->H; e->fcfg.qp = e->base_qp; e->fcfg.lambda_q4 = kLambdaQ4[e->base_qp];
