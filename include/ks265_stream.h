@@ -8,7 +8,7 @@
  * decoder (ubuntu_x64/appdecoder) must decode it to exactly the reconstruction the HIP path produced (tests/test_stream.py).
  *
  * Tool set written (what the pixel path produces): 64x64 CTBs, CUs 64..8, 2Nx2N partitions, TU = CU up to 32x32 (64x64 CUs carry four
- * 32x32 transform units), intra 35 modes with DM chroma, inter uni- and bi-prediction from explicit (AMVP) vectors, no merge / skip,
+ * 32x32 transform units), intra 35 modes with DM chroma, inter uni- and bi-prediction with explicit (AMVP) vectors or, where the chosen motion equals a merge candidate, merge / skip signalling,
  * no temporal MVP, no sign-data hiding, no transform skip, one slice per picture, flat quantisation, deblocking and SAO as signalled.
  */
 #ifndef KS265_STREAM_H

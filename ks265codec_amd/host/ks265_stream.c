@@ -346,12 +346,13 @@ typedef struct {
     int W, H, w8, h8, ctb_cols, ctb_rows;
     Cabac c;
     Scans scans;
+    uint8_t *skip;                         /* cu_skip_flag of every 8x8 block coded so far (context of the neighbours) */
 } Enc;
 
 size_t ks265_slice_scratch_bytes(const ks265_stream_cfg *cfg)
 {
     /* Enc + an RBSP buffer generous enough for any picture: the levels are 16-bit, worst case about 3 bytes per sample */
-    return sizeof(Enc) + (size_t)cfg->width * (size_t)cfg->height * 4 + 65536;
+    return sizeof(Enc) + (size_t)cfg->width * (size_t)cfg->height * 4 + 65536 + (size_t)(cfg->width >> 3) * (size_t)(cfg->height >> 3);
 }
 
 static inline const ks265_cu8 *cu_at(const Enc *e, int x, int y) { return &e->in->cu8[(long)(y >> 3) * e->w8 + (x >> 3)]; }
@@ -602,6 +603,66 @@ static void amvp(const Enc *e, int x, int y, int size, int listx, int ref_idx, i
     for (; n < 2; ++n) { cand[n][0] = 0; cand[n][1] = 0; }
 }
 
+
+/* ------------------------------------------------------------------ merge mode (8.5.3.2.2 .. 8.5.3.2.5; no temporal candidate)
+ * Pure signalling: the pixel path chose a vector per CU; when that motion equals one of the normative merge candidates the CU is written
+ * with merge_idx instead of ref_idx / mvd / mvp (and as a skipped CU when it has no residual) - the decoder reconstructs the same samples. */
+typedef struct { int pf[2], ri[2], mv[2][2]; } Motion;
+static void blk_motion_all(const ks265_cu8 *b, Motion *m)
+{
+    memset(m, 0, sizeof *m);
+    for (int l = 0; l < 2; ++l) { int ri = 0, x = 0, y = 0; m->pf[l] = blk_motion(b, l, &ri, &x, &y); if (m->pf[l]) { m->ri[l] = ri; m->mv[l][0] = x; m->mv[l][1] = y; } }
+}
+static int same_motion(const Motion *a, const Motion *b)
+{
+    for (int l = 0; l < 2; ++l) {
+        if (a->pf[l] != b->pf[l]) return 0;
+        if (a->pf[l] && (a->ri[l] != b->ri[l] || a->mv[l][0] != b->mv[l][0] || a->mv[l][1] != b->mv[l][1])) return 0;
+    }
+    return 1;
+}
+#define MAX_MERGE 5
+static int merge_candidates(const Enc *e, int x, int y, int size, Motion cand[MAX_MERGE])
+{
+    const int nx[5] = {x - 1, x + size - 1, x + size, x - 1, x - 1}, ny[5] = {y + size - 1, y - 1, y - 1, y + size, y - 1};   /* A1 B1 B0 A0 B2 */
+    Motion m[5]; int av[5];
+    for (int k = 0; k < 5; ++k) {
+        av[k] = avail_z(e, x, y, nx[k], ny[k]);
+        if (av[k]) { const ks265_cu8 *b = cu_at(e, nx[k], ny[k]); if (is_intra(b)) av[k] = 0; else blk_motion_all(b, &m[k]); }
+    }
+    /* pruning compares with the neighbouring BLOCK (available and inter), whether or not that block made it into the list itself */
+    int fl[5];
+    fl[0] = av[0];
+    fl[1] = av[1] && !(av[0] && same_motion(&m[1], &m[0]));                               /* B1 vs A1 */
+    fl[2] = av[2] && !(av[1] && same_motion(&m[2], &m[1]));                               /* B0 vs B1 */
+    fl[3] = av[3] && !(av[0] && same_motion(&m[3], &m[0]));                               /* A0 vs A1 */
+    fl[4] = av[4] && !(av[0] && same_motion(&m[4], &m[0])) && !(av[1] && same_motion(&m[4], &m[1])) && fl[0] + fl[1] + fl[2] + fl[3] != 4;
+    int n = 0;
+    for (int k = 0; k < 5 && n < MAX_MERGE; ++k) if (fl[k]) cand[n++] = m[k];
+    const int isb = e->in->slice_type == KS265_SLICE_B;
+    if (isb && n > 1 && n < MAX_MERGE) {                                                  /* combined bi-predictive candidates */
+        static const int l0i[12] = {0, 1, 0, 2, 1, 2, 0, 3, 1, 3, 2, 3}, l1i[12] = {1, 0, 2, 0, 2, 1, 3, 0, 3, 1, 3, 2};
+        const int norig = n;
+        for (int c = 0; c < norig * (norig - 1) && n < MAX_MERGE; ++c) {
+            const Motion *a = &cand[l0i[c]], *b = &cand[l1i[c]];
+            if (a->pf[0] && b->pf[1] && (ref_poc(e, 0, a->ri[0]) != ref_poc(e, 1, b->ri[1]) || a->mv[0][0] != b->mv[1][0] || a->mv[0][1] != b->mv[1][1])) {
+                Motion *o = &cand[n++];
+                memset(o, 0, sizeof *o);
+                o->pf[0] = 1; o->ri[0] = a->ri[0]; o->mv[0][0] = a->mv[0][0]; o->mv[0][1] = a->mv[0][1];
+                o->pf[1] = 1; o->ri[1] = b->ri[1]; o->mv[1][0] = b->mv[1][0]; o->mv[1][1] = b->mv[1][1];
+            }
+        }
+    }
+    const int nref = isb ? (e->in->num_l0 < e->in->num_l1 ? e->in->num_l0 : e->in->num_l1) : e->in->num_l0;
+    for (int z = 0; n < MAX_MERGE; ++z) {                                                 /* zero candidates */
+        Motion *o = &cand[n++];
+        memset(o, 0, sizeof *o);
+        o->pf[0] = 1; o->ri[0] = z < nref ? z : 0;
+        if (isb) { o->pf[1] = 1; o->ri[1] = z < nref ? z : 0; }
+    }
+    return n;
+}
+
 static int mvd_bits(int d)                                            /* bins of one mvd component (for the candidate choice only) */
 {
     const int a = d < 0 ? -d : d;
@@ -655,8 +716,26 @@ static int coding_unit(Enc *e, int x, int y, int log2)
     const int size = 1 << log2, intra = is_intra(cu), st = e->in->slice_type;
     if (cu->pred_mode == 1) return KS265_NOTSUPPORTED;               /* the flat-128 stand-in is not an HEVC prediction mode */
     if (intra && log2 > 5) return KS265_NOTSUPPORTED;
+    int merge_idx = -1;
     if (st != KS265_SLICE_I) {
-        cb_bin(c, CX_SKIP + 0, 0);                                   /* cu_skip_flag: no neighbour is ever skipped -> ctxInc 0 */
+        int skip = 0;
+        if (!intra) {
+            Motion cand[MAX_MERGE], mine;
+            const int n = merge_candidates(e, x, y, size, cand);
+            blk_motion_all(cu, &mine);
+            for (int k = 0; k < n && merge_idx < 0; ++k) if (same_motion(&mine, &cand[k])) merge_idx = k;
+            int any = cu->cbf & 7;
+            if (log2 == 6) for (int k = 1; k < 4; ++k) any |= cu_at(e, x + (k & 1) * 32, y + (k >> 1) * 32)->cbf & 7;
+            skip = merge_idx >= 0 && !any;
+        }
+        const int inc = (x > 0 && e->skip[(long)(y >> 3) * e->w8 + ((x - 1) >> 3)]) + (y > 0 && e->skip[(long)((y - 1) >> 3) * e->w8 + (x >> 3)]);
+        cb_bin(c, CX_SKIP + inc, skip);                               /* cu_skip_flag */
+        if (skip) {
+            for (int by = 0; by < size >> 3; ++by) memset(e->skip + (long)((y >> 3) + by) * e->w8 + (x >> 3), 1, (size_t)(size >> 3));
+            cb_bin(c, CX_MERGE_IDX, merge_idx > 0);                   /* merge_idx: TR, cMax = 4, first bin with context */
+            for (int k = 1; k < MAX_MERGE - 1 && k <= merge_idx; ++k) cb_bypass(c, merge_idx > k);
+            return 0;
+        }
         cb_bin(c, CX_PRED_MODE, intra);
     } else if (!intra) return KS265_NOTSUPPORTED;
     if (!intra || log2 == 3) cb_bin(c, CX_PART_MODE, 1);             /* part_mode: PART_2Nx2N */
@@ -688,8 +767,12 @@ static int coding_unit(Enc *e, int x, int y, int log2)
         }
         cb_bin(c, CX_CHROMA_PRED, 0);                                /* intra_chroma_pred_mode = 4: derived from luma */
     } else {
-        cb_bin(c, CX_MERGE_FLAG, 0);
+        cb_bin(c, CX_MERGE_FLAG, merge_idx >= 0);
         const int dir = cu->inter_dir & 3;
+        if (merge_idx >= 0) {
+            cb_bin(c, CX_MERGE_IDX, merge_idx > 0);
+            for (int k = 1; k < MAX_MERGE - 1 && k <= merge_idx; ++k) cb_bypass(c, merge_idx > k);
+        } else {
         if (st == KS265_SLICE_B) {
             /* inter_pred_idc: nPbW + nPbH != 12 always (2Nx2N, >= 8x8) */
             const int depth = 6 - log2;
@@ -716,6 +799,7 @@ static int coding_unit(Enc *e, int x, int y, int log2)
             mvd_coding(c, mvx - cand[pick][0], mvy - cand[pick][1]);
             cb_bin(c, CX_MVP, pick);
         }
+        }
     }
     /* transform tree (7.3.8.8): max_transform_hierarchy_depth = 0 -> one TU per CU, except 64x64 CUs (four 32x32 TUs, split inferred) */
     if (log2 == 6) {
@@ -725,8 +809,7 @@ static int coding_unit(Enc *e, int x, int y, int log2)
             cby[k] = q->cbf & 1; ccb[k] = (q->cbf >> 1) & 1; ccr[k] = (q->cbf >> 2) & 1;
             any |= q->cbf & 7; acb |= ccb[k]; acr |= ccr[k];
         }
-        cb_bin(c, CX_ROOT_CBF, any != 0);                            /* inter only (intra 64x64 refused above) */
-        if (!any) return 0;
+        if (merge_idx < 0) { cb_bin(c, CX_ROOT_CBF, any != 0); if (!any) return 0; }      /* rqt_root_cbf: inferred 1 for a merged 2Nx2N CU (which has residual, else it was skipped) */
         cb_bin(c, CX_CBF_CHROMA + 0, acb);
         cb_bin(c, CX_CBF_CHROMA + 0, acr);
         for (int k = 0; k < 4; ++k) {
@@ -738,7 +821,7 @@ static int coding_unit(Enc *e, int x, int y, int log2)
         return 0;
     }
     const int cbf_y = cu->cbf & 1, cbf_cb = (cu->cbf >> 1) & 1, cbf_cr = (cu->cbf >> 2) & 1;
-    if (!intra) {
+    if (!intra && merge_idx < 0) {
         cb_bin(c, CX_ROOT_CBF, (cu->cbf & 7) != 0);
         if (!(cu->cbf & 7)) return 0;
     }
@@ -810,10 +893,12 @@ long ks265_write_slice(const ks265_stream_cfg *cfg, const ks265_slice_in *in, vo
     if (!idr && !check_default_lists(in)) return KS265_NOTSUPPORTED;
     Enc *e = (Enc *)scratch;
     uint8_t *rbsp = (uint8_t *)scratch + sizeof(Enc);
-    const size_t rcap = ks265_slice_scratch_bytes(cfg) - sizeof(Enc);
+    const size_t rcap = ks265_slice_scratch_bytes(cfg) - sizeof(Enc) - (size_t)(cfg->width >> 3) * (size_t)(cfg->height >> 3);
     e->cfg = cfg; e->in = in; e->W = cfg->width; e->H = cfg->height; e->w8 = e->W >> 3; e->h8 = e->H >> 3;
     e->ctb_cols = (e->W + 63) >> 6; e->ctb_rows = (e->H + 63) >> 6;
     scans_init(&e->scans);
+    e->skip = (uint8_t *)scratch + ks265_slice_scratch_bytes(cfg) - (size_t)e->w8 * (size_t)e->h8;
+    memset(e->skip, 0, (size_t)e->w8 * (size_t)e->h8);
     BitW b; bw_init(&b, rbsp, rcap);
     const int sao_on = cfg->sao && in->sao != NULL;
     bw_put(&b, 1, 1);                                                /* first_slice_segment_in_pic_flag */
@@ -845,7 +930,7 @@ long ks265_write_slice(const ks265_stream_cfg *cfg, const ks265_slice_in *in, vo
         bw_put(&b, (uint32_t)over, 1);                               /* num_ref_idx_active_override_flag */
         if (over) { bw_ue(&b, (uint32_t)(in->num_l0 - 1)); if (in->slice_type == KS265_SLICE_B) bw_ue(&b, (uint32_t)(in->num_l1 - 1)); }
         if (in->slice_type == KS265_SLICE_B) bw_put(&b, 0, 1);       /* mvd_l1_zero_flag */
-        bw_ue(&b, 4);                                                /* five_minus_max_num_merge_cand: MaxNumMergeCand = 1 (merge is not used) */
+        bw_ue(&b, 5 - MAX_MERGE);                                    /* five_minus_max_num_merge_cand */
     }
     bw_se(&b, in->qp - 26);                                          /* slice_qp_delta */
     bw_put(&b, 1, 1);                                                /* byte_alignment(): alignment_bit_equal_to_one, then zeros */
