@@ -110,6 +110,11 @@ int ks265_fwd_transform_batch(ks265_ctx *, int idx, const int16_t *dev_src, int1
  * call; dev_nz[i] = number of non-zero levels of block i (the reference's return value). */
 int ks265_quant_batch(ks265_ctx *, int n, const int16_t *dev_coef, int16_t *dev_lvl, int16_t *dev_deltaU,
                       int32_t *dev_nz, int scale, int off, int qbits, int nblk);
+/* postQuant enc@0x4ace80 -> signBitHidingHDQ enc@0x4aa150 (the step between g_QuantFuncs and g_DeQuantFuncs when sign-data hiding is on): per 4x4
+ * coefficient group whose first and last level are more than 3 scan positions apart the parity of the level sum is made to carry the
+ * first level's sign; packed N x N blocks, levels in place; scan_idx 0 diagonal, 1 horizontal, 2 vertical (N <= 8 only, as in H.265).
+ * Blocks with fewer than two levels are left alone (postQuant does not call the function for them). */
+int ks265_sign_hiding_batch(ks265_ctx *, int n, int scan_idx, int16_t *dev_lvl, const int16_t *dev_coef, const int16_t *dev_deltaU, int nblk);
 /* g_DeQuantFuncs (H265DeQuantBlock_c enc@0x439210): full-block form (lastX = lastY = N-1) */
 int ks265_dequant_batch(ks265_ctx *, int n, const int16_t *dev_lvl, int16_t *dev_coef, int scale, int add,
                         int shift, int nblk);
@@ -191,6 +196,8 @@ typedef struct {
     int32_t refs;              /* list-0 reference pictures a P picture may search (-ref / -ref0), 0 or 1 = one, at most 4 */
     int32_t me_hex_thr;        /* tME+0x368 of motionSearchOneRef enc@0x483f40: with -me 2, a PU whose start-point SAD is below this many units
                                   per sample runs interMeHex instead of interMeUMH; 16 at -preset slow, 0 (= always UMH) at veryslow */
+    int32_t sdh;               /* the postQuant seam (postQuant enc@0x4ace80 between H265QuantBlock and H265DeQuantBlock): 1 = sign-data hiding on the
+                                  quantised levels (signBitHidingHDQ enc@0x4aa150; the reference's PPS has sign_data_hiding_enabled_flag = 1) */
 } ks265_frame_cfg;
 
 /* geometry of the padded picture buffers the caller allocates (one call, no allocation) */

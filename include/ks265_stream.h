@@ -9,7 +9,7 @@
  *
  * Tool set written (what the pixel path produces): 64x64 CTBs, CUs 64..8, 2Nx2N partitions, TU = CU up to 32x32 (64x64 CUs carry four
  * 32x32 transform units), intra 35 modes with DM chroma, inter uni- and bi-prediction with explicit (AMVP) vectors or, where the chosen motion equals a merge candidate, merge / skip signalling,
- * no temporal MVP, no sign-data hiding, no transform skip, one slice per picture, flat quantisation, deblocking and SAO as signalled.
+ * no temporal MVP, sign-data hiding as configured, no transform skip, one slice per picture, flat quantisation, deblocking and SAO as signalled.
  */
 #ifndef KS265_STREAM_H
 #define KS265_STREAM_H
@@ -28,6 +28,7 @@ typedef struct {
     int32_t max_dec_pic_buffering;         /* pictures the decoder must hold (references + current), >= 1                           */
     int32_t max_num_reorder;               /* pictures that may precede a picture in decoding order and follow it in output order   */
     int32_t log2_max_poc_lsb;              /* 4..16                                                                                 */
+    int32_t sdh;                           /* sign_data_hiding_enabled_flag: the levels were produced with ks265_frame_cfg.sdh = 1                  */
 } ks265_stream_cfg;
 
 enum { KS265_SLICE_B = 0, KS265_SLICE_P = 1, KS265_SLICE_I = 2 };

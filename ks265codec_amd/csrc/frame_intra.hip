@@ -72,6 +72,8 @@ struct IntraLds {
     unsigned char P[3][32 * 32];
     unsigned char raw[3][132], fil[132];                 // reference arrays, corner at index 66 (luma: 64 + 1 + 64; chroma 32 + 1 + 32)
     int nz[3];
+    int lastcg[3];
+    short LV[3][32 * RP], DU[3][32 * RP], CF[3][32 * RP];   // levels / quantisation remainders / coefficients of the TU (sign-data hiding)
     int cbf[64];
     ks265_cu8 cu[64];
     // reconstructed samples around the CTU being coded: row 0 = the row above the CTU (x = -1 .. 127: top-left, top, top-right),
@@ -94,6 +96,7 @@ struct TuCtx {
     int qsc[2], qdq[2], qp6[2];
     int x0, y0, lx, ly, mode;
     bool filt;
+    bool sdh;
 };
 
 // BLOCK: the quads of a TU are spread over several waves -> work-group barriers (LDS only); otherwise the whole TU lives in one
@@ -153,13 +156,44 @@ __device__ __forceinline__ void tu_pipeline(IntraLds &L, const TuRole &r, const 
             const int l = quant_one(coef, scale, off, qbits, du);
             nzc += l != 0;
             lv[i] = (unsigned short)(short)l;
-            X[(r.qx + i) * RP + r.qy] = (short)dequant_one(l, dqs, 1 << (shift - 1), shift);
+            if (c.sdh) { const int o = r.qy * RP + r.qx + i; L.LV[cp][o] = (short)l; L.DU[cp][o] = (short)du; L.CF[cp][o] = (short)coef; }
+            else X[(r.qx + i) * RP + r.qy] = (short)dequant_one(l, dqs, 1 << (shift - 1), shift);
         }
-        *(uint2 *)((cp == 0 ? c.lvl_y : (cp == 1 ? c.lvl_u : c.lvl_v)) + (long)(py + r.qy) * lstride + px + r.qx) =
+        if (!c.sdh) *(uint2 *)((cp == 0 ? c.lvl_y : (cp == 1 ? c.lvl_u : c.lvl_v)) + (long)(py + r.qy) * lstride + px + r.qx) =
             make_uint2(lv[0] | ((unsigned)lv[1] << 16), lv[2] | ((unsigned)lv[3] << 16));
         if (nzc) atomicAdd(&L.nz[cp], nzc);
     }
     tu_sync<BLOCK>();
+    if (c.sdh) {
+        // the postQuant seam (postQuant enc@0x4ace80): sign-data hiding with the TU's scan (H.265 7.4.9.11: intra 4x4 / 8x8 luma and 4x4 chroma
+        // follow the prediction mode); the lane holding the top row of a 4x4 coefficient group handles that group
+        const int scan = (nn == 4 || (nn == 8 && cp == 0)) ? ((c.mode >= 6 && c.mode <= 14) ? 2 : (c.mode >= 22 && c.mode <= 30) ? 1 : 0) : 0;
+        const bool owner = r.on && (r.qy & 3) == 0 && L.nz[cp] > 1;
+        const int cbase = r.qy * RP + r.qx;
+        unsigned survey = 0;
+        int gorder = 0;
+        if (owner) {
+            survey = sbh_survey(L.LV[cp], cbase, scan);
+            gorder = sbh_group_order(scan, nn >> 2, r.qx >> 2, r.qy >> 2) + 1;
+            if (survey >> 17) atomicMax(&L.lastcg[cp], gorder);
+        }
+        tu_sync<BLOCK>();
+        if (owner && survey) sbh_apply(L.LV[cp], L.DU[cp], L.CF[cp], cbase, scan, survey, L.lastcg[cp] == gorder);
+        tu_sync<BLOCK>();
+        if (r.on) {
+            const int ci = cp ? 1 : 0, dqs = c.qdq[ci], shift = l2 - 1;
+            unsigned short lv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int l = L.LV[cp][r.qy * RP + r.qx + i];
+                lv[i] = (unsigned short)(short)l;
+                X[(r.qx + i) * RP + r.qy] = (short)dequant_one(l, dqs, 1 << (shift - 1), shift);
+            }
+            *(uint2 *)((cp == 0 ? c.lvl_y : (cp == 1 ? c.lvl_u : c.lvl_v)) + (long)(py + r.qy) * lstride + px + r.qx) =
+                make_uint2(lv[0] | ((unsigned)lv[1] << 16), lv[2] | ((unsigned)lv[3] << 16));
+        }
+        tu_sync<BLOCK>();
+    }
     const bool live = r.on && L.nz[cp] != 0;
     if (r.on) {                                                     // inverse pass 1: T[y][x] = clip16((Mt[y] . Ct[x] + 64) >> 7)
         int acc[4] = {0, 0, 0, 0};
@@ -186,13 +220,14 @@ __device__ __forceinline__ void tu_pipeline(IntraLds &L, const TuRole &r, const 
 
 __global__ __launch_bounds__(256) void intra_recon_kernel(KsGeom g, int qp, const uint8_t *src_y, const uint8_t *src_u, const uint8_t *src_v, ks265_cu8 *cu8,
                                                           int16_t *lvl_y, int16_t *lvl_u, int16_t *lvl_v, uint8_t *rec_y, uint8_t *rec_u, uint8_t *rec_v,
-                                                          int *progress, unsigned *err_word, int spin_limit)
+                                                          int *progress, unsigned *err_word, int spin_limit, int sdh_on)
 {
     __shared__ __attribute__((aligned(16))) IntraLds L;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, cy = blockIdx.x;
     build_matrices(L.Mf, L.Mt, tid, 256);
     const int qpc = chroma_qp(qp);
     TuCtx c;
+    c.sdh = sdh_on != 0;
     c.g = &g; c.lvl_y = lvl_y; c.lvl_u = lvl_u; c.lvl_v = lvl_v;
     // quantiser constants of the two QPs, fetched once (a table load inside the CU loop would sit behind every outstanding store)
     c.qsc[0] = kQuantScales[qp % 6]; c.qsc[1] = kQuantScales[qpc % 6];
@@ -258,7 +293,7 @@ __global__ __launch_bounds__(256) void intra_recon_kernel(KsGeom g, int qp, cons
                 // ---- 32x32: the luma TU needs all four waves (256 quads) -> work-group barriers; chroma as a second phase
                 lds_barrier();                                       // waves 0 / 1 may still be inside a small CU
                 const unsigned mask = intra_unit_mask(g, c.x0, c.y0, n, lane);
-                if (tid < 3) L.nz[tid] = 0;
+                if (tid < 3) { L.nz[tid] = 0; L.lastcg[tid] = 0; }
                 if (tid < 129) L.raw[0][66 - 64 + tid] = (unsigned char)intra_ref_sample<false>(&L.WY[136 + 4], 136, mask, lx * 8, ly * 8, 32, 8, tid);
                 if (tid < 130) {
                     const int cc = 1 + tid / 65, q = tid % 65;
@@ -288,7 +323,7 @@ __global__ __launch_bounds__(256) void intra_recon_kernel(KsGeom g, int qp, cons
                 const unsigned mask = intra_unit_mask(g, c.x0, c.y0, n, lane);
                 TuRole r;
                 if (wave == 0) {
-                    if (lane == 0) L.nz[0] = 0;
+                    if (lane == 0) { L.nz[0] = 0; L.lastcg[0] = 0; }
                     for (int q = lane; q <= 4 * n; q += 64) L.raw[0][66 - 2 * n + q] = (unsigned char)intra_ref_sample<false>(&L.WY[136 + 4], 136, mask, lx * 8, ly * 8, n, 8, q);
                     tu_sync<false>();
                     if (c.filt) {
@@ -306,7 +341,7 @@ __global__ __launch_bounds__(256) void intra_recon_kernel(KsGeom g, int qp, cons
                     if (lane < n8 * n8 && L.nz[0]) atomicOr(&L.cbf[(ly + lane / n8) * 8 + lx + lane % n8], 1);
                 } else {
                     const int nc = n >> 1, lenC = 2 * n + 1;
-                    if (lane < 2) L.nz[1 + lane] = 0;
+                    if (lane < 2) { L.nz[1 + lane] = 0; L.lastcg[1 + lane] = 0; }
                     for (int q = lane; q < 2 * lenC; q += 64) {
                         const int cc = q >= lenC ? 1 : 0, qq = q - cc * lenC;
                         L.raw[1 + cc][66 - n + qq] = (unsigned char)intra_ref_sample<false>(&L.WC[cc][72 + 4], 72, mask, lx * 4, ly * 4, nc, 4, qq);
@@ -344,7 +379,7 @@ extern "C" int ks265_intra_reconstruct(ks265_frame *f, ks265_pic src, ks265_cu8 
     if (!src.y || !cu8 || !lvl_y || !lvl_u || !lvl_v || !recon.y) return KS265_POINTER;
     if (hipMemsetAsync(f->progress, 0, sizeof(int) * (size_t)f->g.ctu_rows, f->ctx->stream) != hipSuccess) return ks265_hip(f->ctx, hipGetLastError());
     hipLaunchKernelGGL(intra_recon_kernel, dim3(f->g.ctu_rows), dim3(256), 0, f->ctx->stream, f->g, f->cfg.qp, src.y, src.u, src.v, cu8, lvl_y, lvl_u, lvl_v,
-                       recon.y, recon.u, recon.v, f->progress, f->ctx->err_dev, f->ctx->wavefront_spin_limit);
+                       recon.y, recon.u, recon.v, f->progress, f->ctx->err_dev, f->ctx->wavefront_spin_limit, f->cfg.sdh);
     return ks265_check_launch(f->ctx);
 }
 

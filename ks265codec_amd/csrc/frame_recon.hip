@@ -111,7 +111,8 @@ template <int RS /*region size in samples: 32 luma, 16 chroma*/, bool MREF>
 __device__ __forceinline__ void code_region(const KsGeom &g, int comp, int qp, int rx8, int ry8, const ks265_cu8 *blk /*LDS [16]*/,
                                             const unsigned char *tu_log2 /*LDS [16]: log2 of TU size in 8x8 blocks*/, const short *Mf, const short *Mt,
                                             short *X, short *T, unsigned char *P, int *nzcnt /*LDS [16]*/, const uint8_t *src, const uint8_t *ref,
-                                            const uint8_t *planes, const uint8_t *ref1, const uint8_t *planes1, int16_t *lvl, uint8_t *rec, int tid, const KsCompRefs xr)
+                                            const uint8_t *planes, const uint8_t *ref1, const uint8_t *planes1, int16_t *lvl, uint8_t *rec, int tid, const KsCompRefs xr,
+                                            bool sdh, short *LV, short *DU, short *CF, int *lastcg /*LDS [16]*/)
 {
     constexpr int UNIT = RS / 4;                      // samples per 8x8-luma block along one axis
     constexpr int NQ = RS * RS / 4;                   // quads (4 adjacent samples of one row)
@@ -131,7 +132,7 @@ __device__ __forceinline__ void code_region(const KsGeom &g, int comp, int qp, i
     const short *mf = Mf + mat_off(log2n), *mt = Mt + mat_off(log2n);
     const int mp = n + 4;                                          // matrix row pitch
 
-    if (tid < 16) nzcnt[tid] = 0;
+    if (tid < 16) { nzcnt[tid] = 0; lastcg[tid] = 0; }
     // ---- prediction + residual
     if (has_quad) {
         int pred[4] = {128, 128, 128, 128}, res[4] = {0, 0, 0, 0};
@@ -209,21 +210,57 @@ __device__ __forceinline__ void code_region(const KsGeom &g, int comp, int qp, i
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int coef = (short)((acc[i] + 64) >> 7);
-            int l = 0, dqv = 0, du;
+            int l = 0, dqv = 0, du = 0;
             if (coded) {
                 l = quant_one(coef, scale, off, qbits, du);
                 dqv = dequant_one(l, dqs, 1 << (shift - 1), shift);
                 nz += l != 0;
             }
             lv[i] = (unsigned short)(short)l;
-            X[(oy + j + i) * RP + ox + k] = (short)dqv;
+            if (sdh) { const int o = (oy + k) * RP + ox + j + i; LV[o] = (short)l; DU[o] = (short)du; CF[o] = (short)coef; }
+            else X[(oy + j + i) * RP + ox + k] = (short)dqv;
         }
         if (coded) {
-            *(uint2 *)(lvl + (long)(Y0 + qy) * lstride + X0 + qx) = make_uint2(lv[0] | ((unsigned)lv[1] << 16), lv[2] | ((unsigned)lv[3] << 16));
+            if (!sdh) *(uint2 *)(lvl + (long)(Y0 + qy) * lstride + X0 + qx) = make_uint2(lv[0] | ((unsigned)lv[1] << 16), lv[2] | ((unsigned)lv[3] << 16));
             if (nz) atomicAdd(&nzcnt[tb], nz);
         }
     }
     __syncthreads();
+    if (sdh) {
+        // ---- the postQuant seam (postQuant enc@0x4ace80): sign-data hiding, one lane per 4x4 coefficient group of the region
+        constexpr int NCG = RS / 4;                                   // groups per region row
+        unsigned survey = 0;
+        int cbase = 0, gtb = 0, gorder = 0;
+        const bool owner = tid < NCG * NCG;
+        if (owner) {
+            const int gx = tid % NCG, gy = tid / NCG;                // group coordinates in the region
+            const int gb = (gy * 4 / UNIT) * 4 + gx * 4 / UNIT;      // its 8x8-luma block
+            const int g8 = 1 << tu_log2[gb], gtbx = (gb & 3) & ~(g8 - 1), gtby = (gb >> 2) & ~(g8 - 1);
+            gtb = gtby * 4 + gtbx;
+            const int gn = g8 * UNIT;
+            cbase = gy * 4 * RP + gx * 4;
+            if (blk[gb].log2_cu != 0 && nzcnt[gtb] > 1) {
+                survey = sbh_survey(LV, cbase, 0);
+                gorder = sbh_group_order(0, gn / 4, gx - gtbx * UNIT / 4, gy - gtby * UNIT / 4) + 1;
+                if (survey >> 17) atomicMax(&lastcg[gtb], gorder);
+            }
+        }
+        __syncthreads();
+        if (owner && survey) sbh_apply(LV, DU, CF, cbase, 0, survey, lastcg[gtb] == gorder);
+        __syncthreads();
+        if (has_quad) {
+            const int k = qy - oy, j = qx - ox, qp6 = qp / 6, dqs = kInvQuantScales[qp % 6] << qp6, shift = log2n - 1;
+            unsigned short lv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int l = coded ? LV[(oy + k) * RP + ox + j + i] : 0;
+                lv[i] = (unsigned short)(short)l;
+                X[(oy + j + i) * RP + ox + k] = (short)(coded ? dequant_one(l, dqs, 1 << (shift - 1), shift) : 0);
+            }
+            if (coded) *(uint2 *)(lvl + (long)(Y0 + qy) * lstride + X0 + qx) = make_uint2(lv[0] | ((unsigned)lv[1] << 16), lv[2] | ((unsigned)lv[3] << 16));
+        }
+        __syncthreads();
+    }
     const bool live = has_quad && nzcnt[tb] != 0;
     // ---- inverse pass 1: T[y][x] = clip16((Mt[y] . Ct[x] + 64) >> 7)
     if (has_quad) {
@@ -268,7 +305,7 @@ template <bool MREF>
 __global__ __launch_bounds__(256) void reconstruct_kernel(KsGeom g, int qp, const uint8_t *src_y, const uint8_t *src_u, const uint8_t *src_v,
                                                           const uint8_t *ref_y, const uint8_t *ref_u, const uint8_t *ref_v, const uint8_t *planes,
                                                           const uint8_t *ref1_y, const uint8_t *ref1_u, const uint8_t *ref1_v, const uint8_t *planes1, ks265_cu8 *cu8,
-                                                          int16_t *lvl_y, int16_t *lvl_u, int16_t *lvl_v, uint8_t *rec_y, uint8_t *rec_u, uint8_t *rec_v, const short *mats, const KsRefExtra xr)
+                                                          int16_t *lvl_y, int16_t *lvl_u, int16_t *lvl_v, uint8_t *rec_y, uint8_t *rec_u, uint8_t *rec_v, const short *mats, const KsRefExtra xr, int sdh_on)
 {
     __shared__ __attribute__((aligned(16))) short Mf[MAT_SHORTS];
     __shared__ __attribute__((aligned(16))) short Mt[MAT_SHORTS];
@@ -279,7 +316,10 @@ __global__ __launch_bounds__(256) void reconstruct_kernel(KsGeom g, int qp, cons
     __shared__ unsigned char tu_log2[16];
     __shared__ int nzcnt[16];
     __shared__ int cbf[16];
+    __shared__ int lastcg[16];
+    __shared__ __attribute__((aligned(16))) short LV[32 * RP], DU[32 * RP], CF[32 * RP];      // levels / remainders / coefficients of the region (sign-data hiding)
     const int tid = threadIdx.x;
+    const bool sdh = sdh_on != 0;
     // XCD-aware mapping (T1): each XCD gets a contiguous raster range of regions, so the four regions that share a 128-byte
     // line of the source / prediction / level rows meet in one L2 instead of four (measured: FETCH_SIZE 3.9x the algorithmic reads)
     const int nrx = (g.W + 31) / 32, nreg = nrx * ((g.H + 31) / 32);
@@ -300,19 +340,19 @@ __global__ __launch_bounds__(256) void reconstruct_kernel(KsGeom g, int qp, cons
     }
     __syncthreads();
     const int qpc = chroma_qp(qp);
-    code_region<32, MREF>(g, 0, qp, rx * 4, ry * 4, blk, tu_log2, Mf, Mt, X, T, P, nzcnt, src_y, ref_y, planes, ref1_y, planes1, lvl_y, rec_y, tid, xr.y);
+    code_region<32, MREF>(g, 0, qp, rx * 4, ry * 4, blk, tu_log2, Mf, Mt, X, T, P, nzcnt, src_y, ref_y, planes, ref1_y, planes1, lvl_y, rec_y, tid, xr.y, sdh, LV, DU, CF, lastcg);
     if (tid < 16 && blk[tid].log2_cu) {
         const int t8 = 1 << tu_log2[tid], tb = ((tid >> 2) & ~(t8 - 1)) * 4 + ((tid & 3) & ~(t8 - 1));
         if (nzcnt[tb]) cbf[tid] |= 1;
     }
     __syncthreads();
-    code_region<16, MREF>(g, 1, qpc, rx * 4, ry * 4, blk, tu_log2, Mf, Mt, X, T, P, nzcnt, src_u, ref_u, planes, ref1_u, planes1, lvl_u, rec_u, tid, xr.u);
+    code_region<16, MREF>(g, 1, qpc, rx * 4, ry * 4, blk, tu_log2, Mf, Mt, X, T, P, nzcnt, src_u, ref_u, planes, ref1_u, planes1, lvl_u, rec_u, tid, xr.u, sdh, LV, DU, CF, lastcg);
     if (tid < 16 && blk[tid].log2_cu) {
         const int t8 = 1 << tu_log2[tid], tb = ((tid >> 2) & ~(t8 - 1)) * 4 + ((tid & 3) & ~(t8 - 1));
         if (nzcnt[tb]) cbf[tid] |= 2;
     }
     __syncthreads();
-    code_region<16, MREF>(g, 2, qpc, rx * 4, ry * 4, blk, tu_log2, Mf, Mt, X, T, P, nzcnt, src_v, ref_v, planes, ref1_v, planes1, lvl_v, rec_v, tid, xr.v);
+    code_region<16, MREF>(g, 2, qpc, rx * 4, ry * 4, blk, tu_log2, Mf, Mt, X, T, P, nzcnt, src_v, ref_v, planes, ref1_v, planes1, lvl_v, rec_v, tid, xr.v, sdh, LV, DU, CF, lastcg);
     if (tid < 16 && blk[tid].log2_cu) {
         const int t8 = 1 << tu_log2[tid], tb = ((tid >> 2) & ~(t8 - 1)) * 4 + ((tid & 3) & ~(t8 - 1));
         if (nzcnt[tb]) cbf[tid] |= 4;
@@ -326,7 +366,7 @@ static int launch_reconstruct(ks265_frame *f, ks265_pic src, ks265_pic ref0, con
 {
     dim3 grid(((f->g.W + 31) / 32) * ((f->g.H + 31) / 32));
     hipLaunchKernelGGL(reconstruct_kernel<false>, grid, dim3(256), 0, f->ctx->stream, f->g, f->cfg.qp, src.y, src.u, src.v, ref0.y, ref0.u, ref0.v, planes0, ref1.y,
-                       ref1.u, ref1.v, planes1, cu8, lvl_y, lvl_u, lvl_v, recon.y, recon.u, recon.v, f->mats, KsRefExtra{});
+                       ref1.u, ref1.v, planes1, cu8, lvl_y, lvl_u, lvl_v, recon.y, recon.u, recon.v, f->mats, KsRefExtra{}, f->cfg.sdh);
     return ks265_check_launch(f->ctx);
 }
 
@@ -346,7 +386,7 @@ extern "C" int ks265_reconstruct_mref(ks265_frame *f, ks265_pic src, int nref, c
     dim3 grid(((f->g.W + 31) / 32) * ((f->g.H + 31) / 32));
     hipLaunchKernelGGL(reconstruct_kernel<true>, grid, dim3(256), 0, f->ctx->stream, f->g, f->cfg.qp, src.y, src.u, src.v, refs[0].y, refs[0].u, refs[0].v, planes[0],
                        (const uint8_t *)nullptr, (const uint8_t *)nullptr, (const uint8_t *)nullptr, (const uint8_t *)nullptr, cu8, lvl_y, lvl_u, lvl_v, recon.y, recon.u,
-                       recon.v, f->mats, xr);
+                       recon.v, f->mats, xr, f->cfg.sdh);
     return ks265_check_launch(f->ctx);
 }
 

@@ -3,6 +3,7 @@
 // ks265_dev.h and is bit-exact with the reference `_c` kernels (tests/test_gpu_golden.py).
 #include "ks265_internal.h"
 #include "intra_dev.h"
+#include "recon_dev.h"
 
 using namespace ks265;
 
@@ -398,6 +399,42 @@ __global__ __launch_bounds__(256) void ac_energy_batch_kernel(const uint8_t *src
     if (lane == 0) out[b] = ssd - ((sum * sum) >> (2 * log2));     // 32-bit wrap of sum^2 included, as in the reference
 }
 
+// postQuant enc@0x4ace80 -> signBitHidingHDQ enc@0x4aa150 on packed N x N blocks: one wave per block, the block staged in LDS, one lane per
+// 4x4 coefficient group (the helpers of recon_dev.h that the fused reconstruction kernels use)
+__global__ __launch_bounds__(64) void sign_hiding_batch_kernel(int log2n, int scan_idx, int16_t *lvl, const int16_t *coef, const int16_t *deltaU, int nblk)
+{
+    __shared__ short LV[32 * RP], DU[32 * RP], CF[32 * RP];
+    __shared__ int lastcg, nz;
+    const int n = 1 << log2n, lane = threadIdx.x, blk = blockIdx.x;
+    if (blk >= nblk) return;
+    const long base = (long)blk * n * n;
+    if (lane == 0) { lastcg = 0; nz = 0; }
+    __syncthreads();
+    int cnt = 0;
+    for (int i = lane; i < n * n; i += 64) {
+        const int y = i / n, x = i % n;
+        LV[y * RP + x] = lvl[base + i]; DU[y * RP + x] = deltaU[base + i]; CF[y * RP + x] = coef[base + i];
+        cnt += lvl[base + i] != 0;
+    }
+    if (cnt) atomicAdd(&nz, cnt);
+    __syncthreads();
+    const int nsb = n >> 2;
+    unsigned survey = 0;
+    int cbase = 0, order = 0;
+    const bool owner = lane < nsb * nsb && nz > 1;                    // postQuant calls it only for blocks with more than one level
+    if (owner) {
+        const int gx = lane % nsb, gy = lane / nsb;
+        cbase = gy * 4 * RP + gx * 4;
+        survey = sbh_survey(LV, cbase, scan_idx);
+        order = sbh_group_order(scan_idx, nsb, gx, gy) + 1;
+        if (survey >> 17) atomicMax(&lastcg, order);
+    }
+    __syncthreads();
+    if (owner && survey) sbh_apply(LV, DU, CF, cbase, scan_idx, survey, lastcg == order);
+    __syncthreads();
+    for (int i = lane; i < n * n; i += 64) lvl[base + i] = LV[(i / n) * RP + (i % n)];
+}
+
 extern "C" {
 
 int ks265_sad_batch(ks265_ctx *ctx, const uint8_t *a, int sa, const uint8_t *b, int sb, const ks265_blk *blks, int n, uint32_t *out)
@@ -576,6 +613,15 @@ int ks265_ac_energy_map(ks265_ctx *ctx, const uint8_t *plane, int stride, int w,
     const int bw = w >> log2, bh = h >> log2, n = bw * bh;
     if (n <= 0) return KS265_OK;
     hipLaunchKernelGGL(ac_energy_batch_kernel, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, plane, stride, log2, (const int32_t *)nullptr, n, bw, out);
+    LAUNCH_END(ctx);
+}
+
+int ks265_sign_hiding_batch(ks265_ctx *ctx, int n, int scan_idx, int16_t *lvl, const int16_t *coef, const int16_t *deltaU, int nblk)
+{
+    CHECK_CTX(ctx); if (!lvl || !coef || !deltaU) return KS265_POINTER;
+    if ((n != 4 && n != 8 && n != 16 && n != 32) || scan_idx < 0 || scan_idx > 2 || (scan_idx && n > 8)) return KS265_NOTSUPPORTED;
+    if (nblk <= 0) return KS265_OK;
+    hipLaunchKernelGGL(sign_hiding_batch_kernel, dim3(nblk), dim3(64), 0, ctx->stream, n == 4 ? 2 : n == 8 ? 3 : n == 16 ? 4 : 5, scan_idx, lvl, coef, deltaU, nblk);
     LAUNCH_END(ctx);
 }
 

@@ -42,4 +42,68 @@ __device__ __forceinline__ void build_matrices(short *Mf, short *Mt, int tid, in
     }
 }
 
+// ------------------------------------------------------------------ the postQuant seam: sign-data hiding on a TU held in LDS
+// signBitHidingHDQ enc@0x4aa150 (its CPU restatement is pinned against the reference binary: tests/golden/sbh.npz).  Every 4x4
+// coefficient group is handled by ONE lane (groups are independent); the only TU-wide fact a group needs is whether it is the last group
+// in scan order that holds a level (then its candidates start at its last level instead of position 15).
+// Arrays: LV levels, DU quantisation remainders (deltaU), CF coefficients; element (x = horizontal, y = vertical frequency) of the TU at
+// [(oy + y) * RP + ox + x].
+__device__ __forceinline__ void sbh_pos(int scan_idx, int q, int &x, int &y)          // position q of a 4x4 group in coding order (H.265 6.5.3 - 6.5.5)
+{
+    if (scan_idx == 0) { x = (int)((0x3323213210210100ull >> (4 * q)) & 3ull); y = (int)((0x3231230123012010ull >> (4 * q)) & 3ull); }
+    else if (scan_idx == 1) { x = q & 3; y = q >> 2; }
+    else { x = q >> 2; y = q & 3; }
+}
+__device__ __forceinline__ int sbh_group_order(int scan_idx, int nsb, int cgx, int cgy)   // index of group (cgx, cgy) in the TU's group scan
+{
+    if (scan_idx == 1) return cgy * nsb + cgx;
+    if (scan_idx == 2) return cgx * nsb + cgy;
+    const int d = cgx + cgy;
+    if (d < nsb) return d * (d + 1) / 2 + cgx;
+    const int m = 2 * nsb - 1 - d;
+    return nsb * nsb - m * (m + 1) / 2 + (cgx - (d - nsb + 1));
+}
+// phase A: scan the lane's group; returns first | last << 8 | (sum & 1) << 16 | any << 17
+__device__ __forceinline__ unsigned sbh_survey(const short *LV, int base /* (oy + 4 cgy) * RP + ox + 4 cgx */, int scan_idx)
+{
+    int first = 16, last = -1, sum = 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        int x, y; sbh_pos(scan_idx, q, x, y);
+        const int l = LV[base + y * RP + x];
+        if (l) { if (first == 16) first = q; last = q; }
+        sum += l;
+    }
+    return last < 0 ? 0u : ((unsigned)first | ((unsigned)last << 8) | ((unsigned)(sum & 1) << 16) | (1u << 17));
+}
+// phase B: fix the parity of the lane's group if its first sign is hidden and the parity is wrong
+__device__ __forceinline__ void sbh_apply(short *LV, const short *DU, const short *CF, int base, int scan_idx, unsigned survey, bool is_last_group)
+{
+    if (!(survey >> 17)) return;
+    const int first = survey & 255, last = (survey >> 8) & 255, parity = (survey >> 16) & 1;
+    if (last - first < 4) return;
+    int fx, fy; sbh_pos(scan_idx, first, fx, fy);
+    const int signbit = LV[base + fy * RP + fx] > 0 ? 0 : 1;
+    if (signbit == parity) return;
+    int min_cost = 0x7fffffff, min_off = -1, final_change = 0;
+    for (int q = is_last_group ? last : 15; q >= 0; --q) {
+        int x, y; sbh_pos(scan_idx, q, x, y);
+        const int o = base + y * RP + x, l = LV[o], du = DU[o];
+        int cost, change;
+        if (l != 0) {
+            if (du > 0) { cost = -du; change = 1; }
+            else if (q == first && (l == 1 || l == -1)) { cost = 0x7fffffff; change = 0; }
+            else { cost = du; change = -1; }
+        } else if (q < first) {
+            if ((CF[o] >= 0 ? 0 : 1) != signbit) { cost = 0x7fffffff; change = 0; }
+            else { cost = -du; change = 1; }
+        } else { cost = -du; change = 1; }
+        if (cost < min_cost) { min_cost = cost; final_change = change; min_off = o; }
+    }
+    if (min_off < 0) return;
+    const int l = LV[min_off];
+    if (l == 32767 || l == -32768) final_change = -1;
+    LV[min_off] = (short)(CF[min_off] >= 0 ? l + final_change : l - final_change);
+}
+
 }  // namespace ks265

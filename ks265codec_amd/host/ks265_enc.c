@@ -481,6 +481,7 @@ void *QY265EncoderOpen(QY265EncConfig *cfg, int *err)
     e->fcfg.me_range = cfg->searchrange < 1 ? 64 : cfg->searchrange > 64 ? 64 : cfg->searchrange;
     e->fcfg.me_method = e->me_method; e->fcfg.subme = e->subme; e->fcfg.deblock = e->use_df; e->fcfg.sao = e->use_sao;
     e->fcfg.bframes = e->gop_b; e->fcfg.refs = e->refs; e->fcfg.me_hex_thr = e->hex_thr;
+    e->fcfg.sdh = 1;                                                    /* the reference's streams have sign_data_hiding_enabled_flag = 1 at every preset */
     r = ks265_frame_geometry(&e->fcfg, &e->geom);
     if (!r) r = ks265_frame_create(e->ctx, &e->fcfg, &e->frame);
     const size_t fsz = (size_t)e->W * e->H * 3 / 2, npx = (size_t)e->W * e->H;
@@ -507,6 +508,7 @@ void *QY265EncoderOpen(QY265EncConfig *cfg, int *err)
     if (r) { *err = hip_rc(r); QY265EncoderClose(e); return NULL; }
     memset(&e->scfg, 0, sizeof e->scfg);
     e->scfg.width = e->W; e->scfg.height = e->H; e->scfg.sao = e->use_sao; e->scfg.deblock = e->use_df;
+    e->scfg.sdh = e->fcfg.sdh;
     e->scfg.max_dec_pic_buffering = e->hier ? 10 : e->gop_b ? 4 : e->refs + 1; e->scfg.max_num_reorder = e->gop_b; e->scfg.log2_max_poc_lsb = 16;
     e->hdr = (uint8_t *)malloc(512);
     if (e->hdr) {

@@ -144,7 +144,7 @@ long ks265_write_pps(const ks265_stream_cfg *cfg, uint8_t *out, size_t cap)
     bw_put(&b, 0, 1);                    /* dependent_slice_segments_enabled_flag */
     bw_put(&b, 0, 1);                    /* output_flag_present_flag */
     bw_put(&b, 0, 3);                    /* num_extra_slice_header_bits */
-    bw_put(&b, 0, 1);                    /* sign_data_hiding_enabled_flag */
+    bw_put(&b, cfg->sdh ? 1 : 0, 1);     /* sign_data_hiding_enabled_flag */
     bw_put(&b, 0, 1);                    /* cabac_init_present_flag */
     bw_ue(&b, 0); bw_ue(&b, 0);          /* num_ref_idx_l0 / l1_default_active_minus1 */
     bw_se(&b, 0);                        /* init_qp_minus26 */
@@ -511,7 +511,6 @@ static void residual_coding(Enc *e, const int16_t *blk, int stride, int log2, in
                 const int v = blk[(ys * 4 + p4[n].y) * stride + xs * 4 + p4[n].x];
                 absv[nsig] = v < 0 ? -v : v; sign[nsig] = v < 0; npos[nsig] = n; ++nsig;
             }
-        (void)npos;
         if (!nsig) continue;                                         /* the inferred DC of a coded sub-block is always significant */
         int ctx_set = (i > 0 && cidx == 0) ? 2 : 0;
         if (c1 == 0) ++ctx_set;
@@ -525,7 +524,10 @@ static void residual_coding(Enc *e, const int16_t *blk, int stride, int log2, in
             else if (c1 < 3 && c1 > 0) ++c1;
         }
         if (c1 == 0 && first_g2 >= 0) cb_bin(c, CX_G2 + (cidx ? 4 : 0) + ctx_set, absv[first_g2] > 2);
-        for (int k = 0; k < nsig; ++k) cb_bypass(c, sign[k]);        /* no sign data hiding */
+        /* coeff_sign_flag; with sign-data hiding the sign of the group's first coefficient in scan order (= the last one coded) is inferred from
+         * the parity of the level sum when the first and the last significant position are more than 3 apart */
+        const int hidden = e->cfg->sdh && npos[0] - npos[nsig - 1] > 3;
+        for (int k = 0; k < nsig - hidden; ++k) cb_bypass(c, sign[k]);
         if (c1 == 0 || nsig > 8) {
             int first_coeff2 = 1, rice = 0;
             for (int k = 0; k < nsig; ++k) {

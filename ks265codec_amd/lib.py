@@ -25,7 +25,7 @@ SAO_PARAM = np.dtype([("type", "i1"), ("band", "i1"), ("offset", "i1", 4), ("rsv
 
 class FrameCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("width", "height", "qp", "lambda_q4", "me_range", "me_method", "subme", "deblock", "sao",
-                                          "beta_offset_div2", "tc_offset_div2", "bframes", "refs", "me_hex_thr")]
+                                          "beta_offset_div2", "tc_offset_div2", "bframes", "refs", "me_hex_thr", "sdh")]
 
 
 class FrameGeom(C.Structure):
@@ -52,7 +52,7 @@ EXPORTS = [
     "ks265_dev_malloc", "ks265_dev_free", "ks265_host_malloc", "ks265_host_free", "ks265_memcpy_h2d_async", "ks265_memcpy_d2h_async", "ks265_memset_async",
     "ks265_event_create", "ks265_event_record", "ks265_event_wait", "ks265_event_destroy",
     "ks265_sad_batch", "ks265_sad4_batch", "ks265_sad3_batch", "ks265_sad4blk_8x8_batch", "ks265_sse_batch", "ks265_had_batch",
-    "ks265_residual_batch", "ks265_fwd_transform_batch", "ks265_quant_batch", "ks265_dequant_batch", "ks265_inv_transform_batch",
+    "ks265_residual_batch", "ks265_fwd_transform_batch", "ks265_quant_batch", "ks265_sign_hiding_batch", "ks265_dequant_batch", "ks265_inv_transform_batch",
     "ks265_edge_filter_luma_batch", "ks265_edge_filter_chroma_batch", "ks265_interp_rect",
     "ks265_sao_apply_bo_rect", "ks265_sao_apply_eo_rect", "ks265_sao_stats_batch", "ks265_intra_pred_batch", "ks265_intra_filter_ref_batch",
     "ks265_downsample_rect", "ks265_weight_bi_sad_batch", "ks265_ac_energy_batch", "ks265_ac_energy_map",
@@ -180,6 +180,11 @@ class KsContext:
         self._chk(self.lib.ks265_quant_batch(self.h, C.c_int(n), _p(dc), _p(lvl), _p(du), _p(nz), C.c_int(scale), C.c_int(off), C.c_int(qbits), C.c_int(nblk)))
         return self.host(lvl, np.int16, coef.shape), self.host(du, np.int16, coef.shape), self.host(nz, np.int32)
 
+    def sign_hiding(self, n: int, scan_idx: int, lvl: np.ndarray, coef: np.ndarray, delta_u: np.ndarray) -> np.ndarray:
+        dl, dc, du = self.dev(lvl.astype(np.int16)), self.dev(coef.astype(np.int16)), self.dev(delta_u.astype(np.int16))
+        self._chk(self.lib.ks265_sign_hiding_batch(self.h, C.c_int(n), C.c_int(scan_idx), _p(dl), _p(dc), _p(du), C.c_int(lvl.shape[0])))
+        return self.host(dl, np.int16, lvl.shape)
+
     def dequant(self, n: int, lvl: np.ndarray, scale: int, add: int, shift: int) -> np.ndarray:
         nblk = lvl.shape[0]
         dl, out = self.dev(lvl.astype(np.int16)), self.zeros(lvl.size * 2)
@@ -252,9 +257,9 @@ class KsFrame:
     """Whole-frame stages of include/ks265_hip.h section 3 (one picture size, one stream)."""
 
     def __init__(self, ks: KsContext, width: int, height: int, qp: int, lambda_q4: int, me_range: int = 64, subme: int = 1,
-                 deblock: int = 1, sao: int = 1, me_method: int = 0, bframes: int = 0, refs: int = 1, me_hex_thr: int = 0):
+                 deblock: int = 1, sao: int = 1, me_method: int = 0, bframes: int = 0, refs: int = 1, me_hex_thr: int = 0, sdh: int = 0):
         self.ks, self.lib = ks, ks.lib
-        self.cfg = FrameCfg(width, height, qp, lambda_q4, me_range, me_method, subme, deblock, sao, 0, 0, bframes, refs, me_hex_thr)
+        self.cfg = FrameCfg(width, height, qp, lambda_q4, me_range, me_method, subme, deblock, sao, 0, 0, bframes, refs, me_hex_thr, sdh)
         self.geom = FrameGeom()
         ks._chk(self.lib.ks265_frame_geometry(C.byref(self.cfg), C.byref(self.geom)))
         h = C.c_void_p()

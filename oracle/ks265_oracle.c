@@ -213,6 +213,82 @@ int ks265o_quant(const int16_t *coef, int16_t *lvl, int stride, int scale, int o
     return nz;
 }
 
+/* enc@0x4aa150 signBitHidingHDQ (called by postQuant enc@0x4ace80 after scanSigFlags enc@0x4a9f00 when sign-data hiding is on and the block
+ * has more than one level): per 4x4 coefficient group whose first and last non-zero scan positions are more than 3 apart, the sign of the
+ * first level is not coded but inferred from the parity of the group's level sum; if the parity is wrong, the level whose change costs
+ * least (deltaU = quantisation remainder of ks265o_quant) moves by one.  The HM-lineage algorithm (HM TComTrQuant::signBitHidingHDQ), read
+ * against the disassembly: candidates n from 15 (the last group: from its last level) down to 0; a non-zero level or a zero between the
+ * ends costs -|deltaU| and moves towards the remainder's sign; the first level may not drop from 1 to 0; a zero before the first level costs
+ * -deltaU and only qualifies if the coefficient's sign equals the hidden sign; strictly smaller cost wins; +-32767 can only shrink.
+ * lvl / coef / deltaU: N x N with `stride`; scan_idx 0 diagonal, 1 horizontal, 2 vertical.  Returns the number of non-zero levels. */
+static void sbh_scan(int scan_idx, int log2, int *pos /* N*N raster positions y * N + x in coding order */)
+{
+    const int n = 1 << log2, nsb = n >> 2;
+    int i = 0;
+    int sbx[64], sby[64], px[16], py[16], k = 0;
+    /* sub-blocks and positions inside a sub-block follow the same pattern (H.265 6.5.3 .. 6.5.5) */
+    for (int pass = 0; pass < 2; ++pass) {
+        const int size = pass ? 4 : nsb;
+        int *ox = pass ? px : sbx, *oy = pass ? py : sby;
+        k = 0;
+        if (scan_idx == 0) {
+            int x = 0, y = 0, stop = 0;
+            while (!stop) {
+                while (y >= 0) { if (x < size && y < size) { ox[k] = x; oy[k] = y; ++k; } --y; ++x; }
+                y = x; x = 0;
+                if (k >= size * size) stop = 1;
+            }
+        } else if (scan_idx == 1) { for (int y = 0; y < size; ++y) for (int x = 0; x < size; ++x) { ox[k] = x; oy[k] = y; ++k; } }
+        else { for (int x = 0; x < size; ++x) for (int y = 0; y < size; ++y) { ox[k] = x; oy[k] = y; ++k; } }
+    }
+    /* 8x8 with a horizontal / vertical scan: the reference's g_iScanIdx8 tables walk the four sub-blocks in that same order */
+    for (int s = 0; s < nsb * nsb; ++s)
+        for (int q = 0; q < 16; ++q) pos[i++] = (sby[s] * 4 + py[q]) * n + sbx[s] * 4 + px[q];
+}
+int ks265o_sign_bit_hiding(int16_t *lvl, const int16_t *coef, const int16_t *deltaU, int stride, int log2, int scan_idx)
+{
+    const int n = 1 << log2, ncg = (n * n) >> 4;
+    int pos[1024];
+    sbh_scan(scan_idx, log2, pos);
+#define AT(a, p) (a)[((p) / n) * stride + ((p) % n)]
+    int last_cg = -1;
+    for (int cg = ncg - 1; cg >= 0 && last_cg < 0; --cg)
+        for (int q = 0; q < 16; ++q) if (AT(lvl, pos[cg * 16 + q])) { last_cg = cg; break; }
+    for (int cg = last_cg; cg >= 0; --cg) {
+        const int *sp = pos + cg * 16;
+        int first = 16, last = -1, sum = 0;
+        for (int q = 15; q >= 0; --q) if (AT(lvl, sp[q])) { last = q; break; }
+        for (int q = 0; q < 16; ++q) if (AT(lvl, sp[q])) { first = q; break; }
+        if (last - first < 4) continue;
+        for (int q = first; q <= last; ++q) sum += AT(lvl, sp[q]);
+        const int signbit = AT(lvl, sp[first]) > 0 ? 0 : 1;
+        if (signbit == (sum & 1)) continue;
+        int min_cost = 0x7fffffff, min_pos = -1, final_change = 0;
+        for (int q = (cg == last_cg ? last : 15); q >= 0; --q) {
+            const int p = sp[q], l = AT(lvl, p), du = AT(deltaU, p);
+            int cost, change;
+            if (l != 0) {
+                if (du > 0) { cost = -du; change = 1; }
+                else if (q == first && (l == 1 || l == -1)) { cost = 0x7fffffff; change = 0; }
+                else { cost = du; change = -1; }
+            } else if (q < first) {
+                const int this_sign = AT(coef, p) >= 0 ? 0 : 1;
+                if (this_sign != signbit) { cost = 0x7fffffff; change = 0; }
+                else { cost = -du; change = 1; }
+            } else { cost = -du; change = 1; }
+            if (cost < min_cost) { min_cost = cost; final_change = change; min_pos = p; }
+        }
+        if (min_pos < 0) continue;
+        if (AT(lvl, min_pos) == 32767 || AT(lvl, min_pos) == -32768) final_change = -1;
+        if (AT(coef, min_pos) >= 0) AT(lvl, min_pos) = (int16_t)(AT(lvl, min_pos) + final_change);
+        else AT(lvl, min_pos) = (int16_t)(AT(lvl, min_pos) - final_change);
+    }
+    int nz = 0;
+    for (int y = 0; y < n; ++y) for (int x = 0; x < n; ++x) nz += lvl[y * stride + x] != 0;
+#undef AT
+    return nz;
+}
+
 /* enc@0x439210 H265DeQuantBlock_c — SURVEY.md a8 / B.5 */
 void ks265o_dequant(const int16_t *lvl, int16_t *coef, int stride, int scale, int add, int shift, int lastX, int lastY)
 {

@@ -51,6 +51,8 @@ void ks265o_get_base_quant_param(int qp, int sliceType /*2 = I*/, ks265o_quant_p
 int ks265o_quant(const int16_t *coef, int16_t *lvl, int stride, int scale, int off, int qbits, int16_t *deltaU, int n);
 
 /* ---- a8: dequant (enc@0x439210 H265DeQuantBlock_c) ---- */
+/* postQuant enc@0x4ace80 -> signBitHidingHDQ enc@0x4aa150 (sign-data hiding on the quantised levels) */
+int ks265o_sign_bit_hiding(int16_t *lvl, const int16_t *coef, const int16_t *deltaU, int stride, int log2, int scan_idx);
 void ks265o_dequant(const int16_t *lvl, int16_t *coef, int stride, int scale, int add, int shift, int lastX, int lastY);
 
 /* ---- a9: inverse transform + pred add + clip (enc@0x448c40 H265_2dIDst4x4_c, 0x448f60.. H265_2dIDctNxN_c)

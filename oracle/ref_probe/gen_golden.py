@@ -507,11 +507,41 @@ def gen_lookahead(p: RefProbe):
     return [dict(c, exp=d.out) if d is not None else dict(c, ret=np.uint32(call.ret & 0xFFFFFFFF)) for c, call, d in pend]
 
 
+def gen_sbh(p: RefProbe):
+    """postQuant enc@0x4ace80 with sign-data hiding: scanSigFlags enc@0x4a9f00 + signBitHidingHDQ enc@0x4aa150 on quantised blocks (composite probe
+    op 0xFFFF0001 of probe_shim.c).  Inputs are produced like the encoder does: random coefficients -> the reference's own quantiser."""
+    pend = []
+    for li, n in enumerate((4, 8, 16, 32)):
+        log2n = li + 2
+        for qp in (12, 22, 27, 32, 37, 45):
+            for scan in ((0, 1, 2) if n <= 8 else (0,)):
+                for rep in range(3 if n <= 8 else 4):
+                    q = quant_params(qp, 0)
+                    qbits = q["qbits"] - log2n
+                    off = q["offF"] << (qbits - 9)
+                    amp = [200, 800, 3000][rep % 3] * (4 if qp > 36 else 1)
+                    coef = rng.integers(-amp, amp + 1, (n, n)).astype(np.int16)
+                    fy, fx = np.mgrid[0:n, 0:n]
+                    coef = (coef / (1.0 + (fx + fy) * (0.6 if rep < 2 else 0.15))).astype(np.int16)       # energy falls with frequency like real residuals
+                    C, L, U = Buf(coef), Buf(np.zeros((n, n), np.int16)), Buf(np.zeros((n, n), np.int16))
+                    qcall = p.call(f"quant{n}", C, L, n, q["scale"], off, qbits, U)
+                    pend.append((dict(n=n, qp=qp, scan=scan, coef=coef), qcall, L, U))
+    p.run()
+    second = []
+    for c, qcall, L, U in pend:
+        nz = int(qcall.ret & 0xFFFFFFFF)
+        lv, du = L.out.copy(), U.out.copy()
+        Lb, Cb, Ub = Buf(lv), Buf(c["coef"]), Buf(du)
+        second.append((dict(c, lvl=lv, deltaU=du, nz=np.int32(nz)), p.call(0xFFFF0001, Lb, Cb, Ub, int(np.log2(c["n"])), nz, c["scan"]), Lb))
+    p.run()
+    return [dict(c, exp_lvl=Lb.out, exp_nz=np.int32(call.ret & 0xFFFFFFFF)) for c, call, Lb in second]
+
+
 FAMILIES = {
     "sad": gen_sad, "sad4": gen_sad4, "sad3": gen_sad3, "sad4blk": gen_sad4blk, "sse": gen_sse, "had": gen_had,
     "fwd_transform": gen_fwd, "inv_transform": gen_inv, "quant": gen_quant, "dequant": gen_dequant,
     "residual": gen_residual, "deblock_luma": gen_deblock_luma, "deblock_chroma": gen_deblock_chroma,
-    "interp": gen_interp, "sao_apply": gen_sao, "sao_stats": gen_sao_stats, "bipred": gen_bipred, "intra": gen_intra, "lookahead": gen_lookahead,
+    "interp": gen_interp, "sao_apply": gen_sao, "sao_stats": gen_sao_stats, "bipred": gen_bipred, "intra": gen_intra, "lookahead": gen_lookahead, "sbh": gen_sbh,
 }
 
 if __name__ == "__main__":

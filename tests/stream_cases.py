@@ -18,7 +18,15 @@ CASES = {
     "mref3_416x240": (416, 240, 27, 2, 16, 1, 1, "mref", 3),
     "hierb4_416x240": (416, 240, 27, 1, 0, 1, 1, "hier", 4),
     "ippp_1280x720_umh": (1280, 720, 27, 2, 16, 1, 1, "ippp", 3),
+    # sign-data hiding on (the reference's PPS setting): levels changed by signBitHidingHDQ in the pixel path, hidden signs in the stream
+    "sdh_ippp_416x240_umh": (416, 240, 27, 2, 16, 1, 1, "ippp", 4),
+    "sdh_hierb4_416x240": (416, 240, 30, 1, 0, 1, 1, "hier", 4),
+    "sdh_ippp_200x136_qp12": (200, 136, 12, 1, 0, 1, 1, "ippp", 3),
 }
+
+
+def case_sdh(name: str) -> int:
+    return 1 if name.startswith("sdh_") else 0
 
 
 def schedule(kind: str, par: int):
@@ -55,7 +63,7 @@ def make_stream(name: str, encode):
     sched = schedule(kind, par)
     nref = max([len(s[2]) + len(s[3]) for s in sched] + [1])
     reorder = par if kind == "hier" else 0
-    w = S.StreamWriter(W, H, sao=sao, deblock=df, max_dec_pic_buffering=(par + 2) if kind == "hier" else nref + 1, max_num_reorder=reorder)      # the C host's rule (ks265_enc.c)
+    w = S.StreamWriter(W, H, sao=sao, deblock=df, max_dec_pic_buffering=(par + 2) if kind == "hier" else nref + 1, max_num_reorder=reorder, sdh=case_sdh(name))      # the C host's rule (ks265_enc.c)
     bs = w.headers()
     recs = {}
     for d, k, l0, l1, dq, rps, isref in sched:
@@ -76,7 +84,7 @@ def oracle_encoder(name: str):
     W, H, qp, me, thr, sao, df, kind, par = CASES[name]
     n = 1 + max(s[0] for s in schedule(kind, par))
     clip = make_clip(W, H, n, seed=len(name) * 7 + W, abc=(17, 23, 9))
-    o = OraclePipeline(W, H, qp, lambda_q4(qp), me_method=me, me_hex_thr=thr, sao=sao, deblock=df)
+    o = OraclePipeline(W, H, qp, lambda_q4(qp), me_method=me, me_hex_thr=thr, sao=sao, deblock=df, sdh=case_sdh(name))
     dpb = {}
 
     def encode(d, k, l0, l1, q):

@@ -255,3 +255,17 @@ def test_lookahead_kernels(ks):
         m = ks.ac_energy_map(ks.dev(plane), 136, 128, 64, log2)
         offs = np.array([y * n * 136 + x * n for y in range(64 // n) for x in range(128 // n)], np.int32)
         assert (m.reshape(-1) == ks.ac_energy(ks.dev(plane), 136, log2, offs)).all()
+
+
+def test_sign_hiding(ks):
+    """ks265_sign_hiding_batch == signBitHidingHDQ enc@0x4aa150 as executed inside the reference binary (tests/golden/sbh.npz)"""
+    cases = load_cases("sbh")
+    for n in (4, 8, 16, 32):
+        for scan in (0, 1, 2):
+            sel = [c for c in cases if int(c["n"]) == n and int(c["scan"]) == scan]
+            if not sel:
+                continue
+            got = ks.sign_hiding(n, scan, np.stack([c["lvl"] for c in sel]), np.stack([c["coef"] for c in sel]), np.stack([c["deltaU"] for c in sel]))
+            for g, c in zip(got, sel):
+                exp = c["exp_lvl"] if int(c["nz"]) > 1 else c["lvl"]
+                assert (g == exp).all(), (n, scan, int(c["qp"]))

@@ -38,7 +38,7 @@ def test_headers_and_argument_errors():
     nal_types = [(h[i + 4] >> 1) & 63 for i in range(len(h) - 4) if h[i:i + 4] == b"\x00\x00\x00\x01"]
     assert nal_types == [32, 33, 34]                               # VPS, SPS, PPS
     assert b"\x00\x00\x00" not in h.replace(b"\x00\x00\x00\x01", b"")          # emulation prevention
-    bad = S.StreamCfg(417, 240, 0, 0, 1, 1, 0, 0, 2, 0, 16)
+    bad = S.StreamCfg(417, 240, 0, 0, 1, 1, 0, 0, 2, 0, 16, 0)
     out = np.zeros(256, np.uint8)
     assert w.l.ks265_write_sps(C.byref(bad), out.ctypes.data_as(C.c_void_p), C.c_size_t(256)) == -4      # KS265_NOTSUPPORTED
     assert w.l.ks265_write_sps(None, out.ctypes.data_as(C.c_void_p), C.c_size_t(256)) == -3              # KS265_POINTER
