@@ -118,6 +118,10 @@ int ks265_sign_hiding_batch(ks265_ctx *, int n, int scan_idx, int16_t *dev_lvl, 
 /* g_DeQuantFuncs (H265DeQuantBlock_c enc@0x439210): full-block form (lastX = lastY = N-1) */
 int ks265_dequant_batch(ks265_ctx *, int n, const int16_t *dev_lvl, int16_t *dev_coef, int scale, int add,
                         int shift, int nblk);
+/* the same function with its lastX / lastY arguments (position of the last significant level): only rows 0..lastY and columns
+ * 0..round_up(lastX + 1, 4) - 1 of each block are written, the rest of dev_coef keeps what it held; blocks of n rows x `stride` */
+int ks265_dequant_rect_batch(ks265_ctx *, int n, int stride, const int16_t *dev_lvl, int16_t *dev_coef, int scale, int add,
+                             int shift, int lastX, int lastY, int nblk);
 /* g_H265_2dIDct_Func[idx]: coef (packed NxN) + pred (packed NxN u8) -> recon (packed NxN u8) */
 int ks265_inv_transform_batch(ks265_ctx *, int idx, const int16_t *dev_coef, const uint8_t *dev_pred,
                               uint8_t *dev_dst, int nblk);

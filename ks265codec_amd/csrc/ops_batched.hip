@@ -193,6 +193,16 @@ __global__ __launch_bounds__(256) void quant_batch_kernel(int nn, const int16_t 
     if (threadIdx.x == 0) nz[b] = (int)(part[0] + part[1] + part[2] + part[3]);
 }
 
+// H265DeQuantBlock_c enc@0x439210 with its lastX / lastY arguments: only rows 0..lastY and columns 0..round_up(lastX + 1, 4) - 1 are written
+__global__ __launch_bounds__(256) void dequant_rect_batch_kernel(const int16_t *lvl, int16_t *coef, int n, int stride, int scale, int add, int shift, int lastX, int lastY, int nblk)
+{
+    const int cols = (lastX + 4) & ~3, per = cols * (lastY + 1);
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long)per * nblk) return;
+    const int b = (int)(t / per), r = (int)(t % per), y = r / cols, x = r % cols;
+    const long o = (long)b * n * stride + (long)y * stride + x;
+    coef[o] = (int16_t)dequant_one(lvl[o], scale, add, shift);
+}
 __global__ __launch_bounds__(256) void dequant_batch_kernel(const int16_t *lvl, int16_t *coef, int scale, int add, int shift, long total)
 {
     long t = (long)blockIdx.x * 256 + threadIdx.x;
@@ -508,6 +518,15 @@ int ks265_quant_batch(ks265_ctx *ctx, int n, const int16_t *coef, int16_t *lvl, 
 {
     CHECK_CTX(ctx); if (n != 4 && n != 8 && n != 16 && n != 32) return KS265_NOTSUPPORTED; if (nblk <= 0) return KS265_OK;
     hipLaunchKernelGGL(quant_batch_kernel, dim3(nblk), dim3(256), 0, ctx->stream, n * n, coef, lvl, deltaU, nz, scale, off, qbits, nblk);
+    LAUNCH_END(ctx);
+}
+int ks265_dequant_rect_batch(ks265_ctx *ctx, int n, int stride, const int16_t *lvl, int16_t *coef, int scale, int add, int shift, int lastX, int lastY, int nblk)
+{
+    CHECK_CTX(ctx); if (!lvl || !coef) return KS265_POINTER;
+    if ((n != 4 && n != 8 && n != 16 && n != 32) || stride < n || lastX < 0 || lastY < 0 || lastX >= n || lastY >= n) return KS265_NOTSUPPORTED;
+    if (nblk <= 0) return KS265_OK;
+    const long total = (long)((lastX + 4) & ~3) * (lastY + 1) * nblk;
+    hipLaunchKernelGGL(dequant_rect_batch_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, lvl, coef, n, stride, scale, add, shift, lastX, lastY, nblk);
     LAUNCH_END(ctx);
 }
 int ks265_dequant_batch(ks265_ctx *ctx, int n, const int16_t *lvl, int16_t *coef, int scale, int add, int shift, int nblk)

@@ -52,7 +52,7 @@ EXPORTS = [
     "ks265_dev_malloc", "ks265_dev_free", "ks265_host_malloc", "ks265_host_free", "ks265_memcpy_h2d_async", "ks265_memcpy_d2h_async", "ks265_memset_async",
     "ks265_event_create", "ks265_event_record", "ks265_event_wait", "ks265_event_destroy",
     "ks265_sad_batch", "ks265_sad4_batch", "ks265_sad3_batch", "ks265_sad4blk_8x8_batch", "ks265_sse_batch", "ks265_had_batch",
-    "ks265_residual_batch", "ks265_fwd_transform_batch", "ks265_quant_batch", "ks265_sign_hiding_batch", "ks265_dequant_batch", "ks265_inv_transform_batch",
+    "ks265_residual_batch", "ks265_fwd_transform_batch", "ks265_quant_batch", "ks265_sign_hiding_batch", "ks265_dequant_batch", "ks265_dequant_rect_batch", "ks265_inv_transform_batch",
     "ks265_edge_filter_luma_batch", "ks265_edge_filter_chroma_batch", "ks265_interp_rect",
     "ks265_sao_apply_bo_rect", "ks265_sao_apply_eo_rect", "ks265_sao_stats_batch", "ks265_intra_pred_batch", "ks265_intra_filter_ref_batch",
     "ks265_downsample_rect", "ks265_weight_bi_sad_batch", "ks265_ac_energy_batch", "ks265_ac_energy_map",
@@ -189,6 +189,12 @@ class KsContext:
         nblk = lvl.shape[0]
         dl, out = self.dev(lvl.astype(np.int16)), self.zeros(lvl.size * 2)
         self._chk(self.lib.ks265_dequant_batch(self.h, C.c_int(n), _p(dl), _p(out), C.c_int(scale), C.c_int(add), C.c_int(shift), C.c_int(nblk)))
+        return self.host(out, np.int16, lvl.shape)
+
+    def dequant_rect(self, n: int, lvl: np.ndarray, coef_init: np.ndarray, scale: int, add: int, shift: int, last_x: int, last_y: int) -> np.ndarray:
+        dl, out = self.dev(lvl.astype(np.int16)), self.dev(coef_init.astype(np.int16))
+        self._chk(self.lib.ks265_dequant_rect_batch(self.h, C.c_int(n), C.c_int(n), _p(dl), _p(out), C.c_int(scale), C.c_int(add), C.c_int(shift),
+                                                    C.c_int(last_x), C.c_int(last_y), C.c_int(lvl.shape[0])))
         return self.host(out, np.int16, lvl.shape)
 
     def edge_filter(self, plane, stride: int, edges: np.ndarray, chroma: bool = False):
