@@ -57,9 +57,14 @@ def main():
                     "B pictures dealt to the other ranks (needs --bframes > 0); default = one GOP shard per rank, no collective")
     ap.add_argument("--streams", type=int, default=3, help="independent GOP shards in flight per GPU, each on its own HIP stream (their kernels overlap: the search kernels are latency bound)")
     ap.add_argument("--refs", type=int, default=1, help="list-0 reference pictures a P picture searches (-ref / -ref0; -preset slow resolves to 1 / 3: three for the first picture of a mini-GOP); IPPP only")
+    ap.add_argument("--no-pre-search", action="store_true", help="hot-path leg: stage A without the pyramid pre-search start candidates (the encoder always runs them)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--leg", choices=["both", "encoded", "hot"], default="both", help="encoded: the whole encoder through the SDK-compatible C API (host pictures in, "
                     "Annex-B NAL units out: H2D, pixel path, D2H, CABAC) = the headline value; hot: the device-resident pixel path only (roofline leg)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak", help="weak (default): every rank encodes --steps pictures of its own clip.  strong: ONE fixed job of --job-frames pictures "
+                    "(closed GOPs of -iper pictures) is split over the ranks GOP by GOP, rank 0 gathers the ranks' NAL units in stream order; value = job frames / wall time (encoded leg only)")
+    ap.add_argument("--job-frames", type=int, default=1024, help="--scaling strong: pictures of the fixed job")
+    ap.add_argument("--out", default=None, help="--scaling strong: rank 0 writes the gathered Annex-B stream here")
     ap.add_argument("--host-threads", type=int, default=0, help="slice-writer threads of the encoded leg per rank (0 = min(32, host cores / ranks))")
     args = ap.parse_args()
 
@@ -100,6 +105,10 @@ def main():
         torch.cuda.synchronize()
 
     encoded = None
+    if args.scaling == "strong":
+        args.leg = "encoded"
+        if args.b_spread:
+            raise SystemExit("--scaling strong splits closed GOPs over the ranks; --b-spread is the other sharding")
     if args.leg != "hot" and not args.b_spread:
         encoded = encoded_leg(args, torch, dist, rank, world, dev_index, backend, sync_all)
         if args.leg == "encoded":
@@ -117,7 +126,7 @@ def main():
         tstream = None if sidx == 0 else torch.cuda.Stream(device=dev_index)
         with (torch.cuda.stream(tstream) if tstream is not None else contextlib.nullcontext()):
             ks = KsContext(dev_index)
-            fr = KsFrame(ks, W, H, qp, lambda_q4(qp), me_method=me_method, me_hex_thr=(args.me_hex_thr if me_method == 2 else 0), bframes=max(args.bframes, args.hier_b - 1 if args.hier_b else 0), refs=max(1, args.refs))
+            fr = KsFrame(ks, W, H, qp, lambda_q4(qp), me_method=me_method, me_hex_thr=(args.me_hex_thr if me_method == 2 else 0), bframes=max(args.bframes, args.hier_b - 1 if args.hier_b else 0), refs=max(1, args.refs), sdh=1, pre_search=0 if args.no_pre_search else 1)
             # synthetic clip of SURVEY.md §8(d), one GOP shard per stream (different seed per shard = different content)
             clip = make_clip(W, H, args.clip_frames, seed=7 + (0 if args.b_spread else rank * nstreams + sidx), abc=(67, 91, 33), pan=(8, 5))
             dev_clip = [ks.dev(c) for c in clip]
@@ -231,10 +240,10 @@ def main():
             fr.set_qp(qp + 2, lambda_q4(qp + 2))
             fr.encode_picture_b(src_of(d), slots[s0], slots[s1], bout)
 
-        def bcast(slot):
+        def bcast(slot, src):
             if dist is not None:
                 for t in (slots[slot].y, slots[slot].u, slots[slot].v):
-                    dist.broadcast(t, src=0)          # RCCL over xGMI: the only exchange step of the path
+                    dist.broadcast(t, src=src)        # RCCL over xGMI: the only exchange step of the path
 
         per = nb + 1
         n_mg = max(1, (args.steps * world) // per)
@@ -328,33 +337,11 @@ def main():
                     "note": "avg_launch_ms / stages_ms / frac: HIP events around each stage with ONE shard on the GPU = the kernel's own duration; it agrees with the rocprofv3 kernel trace of `bench.py --streams 1` (profiles/). With the run's --streams shards in flight the kernels of different shards overlap: stage_intervals_ms_in_run are event-to-event intervals on one shard's stream under that load (queueing behind the other shards' kernels included), the kernel durations of that condition are in the rocprofv3 trace of the default command (profiles/).",
                     "stages_frac": {k: round(ALGO_BYTES_P[k] * P / (v * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) for k, v in stage_ms.items()}}
 
-        # ---- CPU baseline: the oracle port (1 thread) on a bounded sample of the same workload
+        # ---- CPU baseline on this box's host cores: the reference's own CLI encoder when it is staged (oracle/_ref/appencoder or $KS265_REF_ENCODER,
+        #      SURVEY.md §8d-iii), else the oracle port; a bounded sample of the same workload either way
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            from oracle_lib import OraclePipeline
-            o = OraclePipeline(W, H, qp, lambda_q4(qp), me_method=me_method, me_hex_thr=(args.me_hex_thr if me_method == 2 else 0))
-            nbase = 3
-            tc0 = time.perf_counter()
-            if args.bframes == 0:
-                t = 0
-                while t < 3 or (time.perf_counter() - tc0 < 8.0 and t < 24):     # 1 key + P pictures until ~10 s of wall time (bounded)
-                    q = qp if t == 0 else qp + 1
-                    o.set_qp(q, lambda_q4(q))
-                    o.encode_picture(clip[order[t % len(order)]], t == 0)
-                    t += 1
-                nbase = t
-            else:                                       # I0, P2, B1 of the same clip
-                o.set_qp(qp, lambda_q4(qp)); i0 = o.encode(clip[0], "I")
-                o.set_qp(qp + 1, lambda_q4(qp + 1)); p2 = o.encode(clip[2], "P", i0)
-                o.set_qp(qp + 2, lambda_q4(qp + 2)); o.encode(clip[1], "B", i0, p2)
-            tc = time.perf_counter() - tc0
-            try:
-                ncores = int(os.environ.get("OMP_NUM_THREADS", "0")) or len(os.sched_getaffinity(0))
-            except Exception:
-                ncores = os.cpu_count() or 1
-            cpu = {"value": round(nbase / tc, 4), "unit": "frames/s", "cores": ncores, "kind": "port",
-                   "sample": f"{nbase} pictures (1 key + {nbase - 1} {'P' if args.bframes == 0 else 'P/B'}) of the same {W}x{H} clip, oracle/ks265_pipeline_oracle.c, "
-                             f"OpenMP over CTUs on {ncores} host threads (the intra wavefront of the key picture is sequential), {tc:.1f} s"}
+            cpu = reference_leg(args, clip, order) or port_leg(args, clip, order, me_method)
 
         bf_desc = f"{args.hier_b - 1} (hierarchical GOP {args.hier_b}, B-ref)" if args.hier_b else str(args.bframes)
         line = {
@@ -367,7 +354,7 @@ def main():
                        "pictures_per_step": nstreams, "streams_per_gpu": nstreams,
                        "key_picture_ms": {"intra_decide": key_ms.get("cu_decide"), "intra_reconstruct": key_ms.get("reconstruct"), "total": round(sum(key_ms.values()), 3),
                                           "note": f"one intra picture per -iper {args.iper} pictures; it is in the timed region whenever the schedule puts one there"},
-                       "sharding": "anchor chain on rank 0 + RCCL broadcast of reconstructed anchors, B pictures spread" if args.b_spread else f"{nstreams} GOP shard(s) in flight per GPU on separate HIP streams, no data-path collective"},
+                       "sharding": "anchor chain rotating over the ranks + RCCL broadcast of every reconstructed anchor from its owner, B pictures spread over the ranks not coding an anchor" if args.b_spread else f"{nstreams} GOP shard(s) in flight per GPU on separate HIP streams, no data-path collective"},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         if encoded is not None:
@@ -379,6 +366,79 @@ def main():
     for sh in shards:
         sh.fr.close()
     ks.close()
+
+
+def host_cores():
+    try:
+        return int(os.environ.get("OMP_NUM_THREADS", "0")) or len(os.sched_getaffinity(0))
+    except Exception:
+        return os.cpu_count() or 1
+
+
+def port_leg(args, clip, order, me_method):
+    """cpu_baseline kind "port": oracle/ks265_pipeline_oracle.c (OpenMP over CTUs) on a few pictures of the bench clip"""
+    from oracle_lib import OraclePipeline
+    from ks265codec_amd.synth import lambda_q4
+    W, H, qp = args.width, args.height, args.qp
+    o = OraclePipeline(W, H, qp, lambda_q4(qp), me_method=me_method, me_hex_thr=(args.me_hex_thr if me_method == 2 else 0), sdh=1, pre_search=0 if args.no_pre_search else 1)
+    nbase = 3
+    tc0 = time.perf_counter()
+    if args.bframes == 0:
+        t = 0
+        while t < 3 or (time.perf_counter() - tc0 < 8.0 and t < 24):     # 1 key + P pictures until ~10 s of wall time (bounded)
+            q = qp if t == 0 else qp + 1
+            o.set_qp(q, lambda_q4(q))
+            o.encode_picture(clip[order[t % len(order)]], t == 0)
+            t += 1
+        nbase = t
+    else:                                       # I0, P2, B1 of the same clip
+        o.set_qp(qp, lambda_q4(qp)); i0 = o.encode(clip[0], "I")
+        o.set_qp(qp + 1, lambda_q4(qp + 1)); p2 = o.encode(clip[2], "P", i0)
+        o.set_qp(qp + 2, lambda_q4(qp + 2)); o.encode(clip[1], "B", i0, p2)
+    tc = time.perf_counter() - tc0
+    ncores = host_cores()
+    return {"value": round(nbase / tc, 4), "unit": "frames/s", "cores": ncores, "kind": "port",
+            "sample": f"{nbase} pictures (1 key + {nbase - 1} {'P' if args.bframes == 0 else 'P/B'}) of the same {W}x{H} clip, oracle/ks265_pipeline_oracle.c, "
+                      f"OpenMP over CTUs on {ncores} host threads (the intra wavefront of the key picture is sequential), {tc:.1f} s; pixel path only (no CABAC)"}
+
+
+def reference_leg(args, clip, order):
+    """cpu_baseline kind "reference": the reference's CLI encoder (appencoder V2.6.1.3, /root/reference/ubuntu_x64, staged by __graft_entry__.build() as
+    oracle/_ref/appencoder; $KS265_REF_ENCODER overrides) on a bounded run of the bench clip, on this box's host cores.  It is the WHOLE reference encoder
+    (lookahead, RDO, CABAC) at the preset the metric names: the same job the `encoded` value measures.  None when no executable is there."""
+    import re, subprocess, tempfile
+    exe = os.environ.get("KS265_REF_ENCODER") or os.path.join(ROOT, "oracle", "_ref", "appencoder")
+    if not (os.path.isfile(exe) and os.access(exe, os.X_OK)):
+        return None
+    W, H = args.width, args.height
+    cores = host_cores()
+    threads = int(os.environ.get("KS265_REF_THREADS", "0")) or min(cores, 64)
+    n = int(os.environ.get("KS265_REF_FRAMES", "0")) or int(min(256, max(64, 64 * (3840 * 2160) // (W * H))))
+    preset = "slow" if args.me == "umh" and args.me_hex_thr == 16 else "veryslow" if args.me == "umh" else "medium"
+    with tempfile.TemporaryDirectory(prefix="ks265_ref_") as td:
+        yuv = os.path.join(td, "clip.yuv")
+        with open(yuv, "wb") as f:
+            for t in range(n):
+                f.write(clip[order[t % len(order)]].tobytes())
+        bf = [] if args.hier_b == 8 else ["-bframes", str(args.hier_b - 1 if args.hier_b else args.bframes)]
+        cmd = [exe, "-i", yuv, "-wdt", str(W), "-hgt", str(H), "-fr", "50", "-preset", preset, "-rc", "0", "-qp", str(args.qp), "-iper", str(args.iper),
+               "-threads", str(threads), "-psnr", "1", "-b", os.path.join(td, "o.265"), *bf]
+        t0 = time.perf_counter()
+        try:
+            out = subprocess.run(cmd, capture_output=True, text=True, cwd=td, timeout=600).stdout
+        except Exception as e:                                   # a broken executable must not take the bench line down
+            print(f"[bench] reference leg failed: {e!r}", file=sys.stderr)
+            return None
+        wall = time.perf_counter() - t0
+    m = re.search(r"FPS:\s*([0-9.]+)", out)
+    b = re.search(r"bitrate, psnr:\s*([0-9.]+)\s+([0-9.]+)", out)
+    if not m:
+        print("[bench] reference leg: no FPS line in appencoder's output", file=sys.stderr)
+        return None
+    return {"value": float(m.group(1)), "unit": "frames/s", "cores": threads, "kind": "reference",
+            "kbps_at_50fps": float(b.group(1)) if b else None, "psnr_y": float(b.group(2)) if b else None,
+            "sample": f"appencoder V2.6.1.3 -preset {preset} -rc 0 -qp {args.qp} -iper {args.iper} {' '.join(bf) or '(default hierarchical-B GOP 8)'} -threads {threads} on {n} pictures of the "
+                      f"same {W}x{H} clip (ping-pong over {len(clip)} pictures), {wall:.1f} s wall incl. reading the .yuv; box has {cores} host threads; FPS as the encoder prints it"}
 
 
 def encoded_leg(args, torch, dist, rank, world, dev_index, backend, sync_all):
@@ -420,15 +480,30 @@ def encoded_leg(args, torch, dist, rank, world, dev_index, backend, sync_all):
         assert lib.QY265ConfigParse(cfg, k.encode(), str(v).encode()) == 0, k
     clip = make_clip(W, H, args.clip_frames, seed=7 + rank, abc=(67, 91, 33), pan=(8, 5))
     order = list(range(len(clip))) + list(range(len(clip) - 2, 0, -1))          # ping-pong keeps the motion continuous
-    err = C.c_int(0)
-    h = C.c_void_p(lib.QY265EncoderOpen(cfg, C.byref(err)))
-    if not h.value:
-        raise SystemExit(f"QY265EncoderOpen failed: 0x{err.value & 0xFFFFFFFF:08x} (the encoder needs the MI355X: there is no CPU fallback)")
+    strong = args.scaling == "strong"
+    if strong:
+        clip = make_clip(W, H, args.clip_frames, seed=7, abc=(67, 91, 33), pan=(8, 5))      # ONE job: every rank reads the same clip, its own GOPs of it
+
+    def open_encoder():
+        err = C.c_int(0)
+        hh = C.c_void_p(lib.QY265EncoderOpen(cfg, C.byref(err)))
+        if not hh.value:
+            raise SystemExit(f"QY265EncoderOpen failed: 0x{err.value & 0xFFFFFFFF:08x} (the encoder needs the MI355X: there is no CPU fallback)")
+        return hh
+
+    h = open_encoder()
     nal, nn, pic, outp, yuv = C.POINTER(Nal)(), C.c_int(0), Picture(), Picture(), YUV()
     yuv.iWidth, yuv.iHeight = W, H
     yuv.iStride[0], yuv.iStride[1], yuv.iStride[2] = W, W // 2, W // 2
     pic.yuv = C.pointer(yuv)
-    state = {"t": 0, "bytes": 0, "nals": 0}
+    state = {"t": 0, "bytes": 0, "nals": 0, "keep": None}
+
+    def collect():
+        state["nals"] += nn.value
+        for i in range(nn.value):
+            state["bytes"] += nal[i].iSize
+            if state["keep"] is not None:
+                state["keep"].append(C.string_at(nal[i].pPayload, nal[i].iSize))
 
     def feed(n):
         for _ in range(n):
@@ -439,21 +514,51 @@ def encoded_leg(args, torch, dist, rank, world, dev_index, backend, sync_all):
             state["t"] += 1
             rc = lib.QY265EncoderEncodeFrame(h, C.byref(nal), C.byref(nn), C.byref(pic), C.byref(outp), 0)
             assert rc == 0, hex(rc & 0xFFFFFFFF)
-            state["nals"] += nn.value
-            state["bytes"] += sum(nal[i].iSize for i in range(nn.value))
+            collect()
 
     def flush():
         while lib.QY265EncoderDelayedFrames(h):
             rc = lib.QY265EncoderEncodeFrame(h, C.byref(nal), C.byref(nn), None, C.byref(outp), 0)
             assert rc == 0, hex(rc & 0xFFFFFFFF)
-            state["nals"] += nn.value
-            state["bytes"] += sum(nal[i].iSize for i in range(nn.value))
+            collect()
 
     feed(args.warmup); flush()
+    job = None
+    if strong:
+        # the fixed job: pictures 0 .. F-1 of the clip in closed GOPs of -iper pictures; rank r takes a contiguous run of GOPs (ks265codec_amd/gop.py shard_gops),
+        # on a fresh encoder (the warm-up one is closed: its pictures are not part of the job); the ranks' streams are gathered on rank 0 in GOP order
+        from ks265codec_amd import gop
+        F, per = args.job_frames, (args.iper if args.iper > 0 else args.job_frames)
+        mine = gop.shard_gops(F, per, world, rank, contiguous=True)
+        lib.QY265EncoderClose(h)
+        h = open_encoder()
+        state.update(bytes=0, nals=0, keep=[])
     b0 = state["bytes"]
     sync_all()
     t0 = time.perf_counter()
-    feed(args.steps); flush()
+    if strong:
+        for a, b in mine:
+            state["t"] = a
+            feed(b - a)
+        flush()
+        blob = b"".join(state["keep"])
+        if dist is not None:
+            dv = torch.device("cuda", dev_index) if backend == "nccl" else torch.device("cpu")
+            sizes = [torch.zeros(1, dtype=torch.int64, device=dv) for _ in range(world)]
+            dist.all_gather(sizes, torch.tensor([len(blob)], dtype=torch.int64, device=dv))
+            cap = int(max(int(x.item()) for x in sizes))
+            buf = torch.zeros(cap, dtype=torch.uint8)
+            buf[:len(blob)] = torch.frombuffer(bytearray(blob), dtype=torch.uint8)
+            buf = buf.to(dv)
+            parts = [torch.empty(cap, dtype=torch.uint8, device=dv) for _ in range(world)] if rank == 0 else None
+            dist.gather(buf, parts, dst=0)              # the only exchange step of the strong-scaling job: coded bytes to rank 0 (RCCL when backend = nccl)
+            if rank == 0:
+                blob = b"".join(bytes(p[:int(n.item())].cpu().numpy().tobytes()) for p, n in zip(parts, sizes))
+        job = {"frames": F, "gops": -(-F // per), "bytes": len(blob) if rank == 0 else 0, "frames_this_rank": sum(b - a for a, b in mine)}
+        if rank == 0 and args.out:
+            open(args.out, "wb").write(blob)
+    else:
+        feed(args.steps); flush()
     sync_all()
     dt = time.perf_counter() - t0
     st = Stats()
@@ -464,6 +569,12 @@ def encoded_leg(args, torch, dist, rank, world, dev_index, backend, sync_all):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     mse = st.sse[0] / max(1, st.frames) / (W * H)
+    if strong:
+        import hashlib
+        return {"fps": job["frames"] / dt, "dt": dt, "host_threads": threads, "host_cores": cores, "bytes_per_picture": job["bytes"] / job["frames"], "job": job,
+                "md5": hashlib.md5(blob).hexdigest() if rank == 0 else None,
+                "psnr_y": 99.0 if mse == 0 else 10.0 * np.log10(255.0 ** 2 / mse), "slice_write_ms_per_picture": st.host_write_ms / max(1, st.frames), "preset": preset.decode(),
+                "gop": f"hierarchical-B {args.hier_b}" if args.hier_b else (f"P + {gop_b} B" if gop_b else "IPPP")}
     return {"fps": world * args.steps / dt, "dt": dt, "host_threads": threads, "host_cores": cores, "bytes_per_picture": (state["bytes"] - b0) / args.steps,
             "psnr_y": 99.0 if mse == 0 else 10.0 * np.log10(255.0 ** 2 / mse), "slice_write_ms_per_picture": st.host_write_ms / max(1, st.frames), "preset": preset.decode(),
             "gop": f"hierarchical-B {args.hier_b}" if args.hier_b else (f"P + {gop_b} B" if gop_b else "IPPP")}
@@ -472,11 +583,13 @@ def encoded_leg(args, torch, dist, rank, world, dev_index, backend, sync_all):
 def encoded_line(args, enc, world, hot, cpu):
     """the bench line: value = encoded frames/s (the whole encoder); the device-resident pixel-path leg (if run) supplies roofline / stage times"""
     W, H = args.width, args.height
+    strong = args.scaling == "strong"
+    steps = enc["job"]["frames_this_rank"] if strong else args.steps          # strong: pictures rank 0 coded of the fixed job
     line = {
         "metric": "encoded frames/sec + PSNR-Y, 2160p -preset slow -qp 27, 1/2/4/8 GPU",
         "value": round(enc["fps"], 2), "unit": "frames/s", "psnr_y": round(float(enc["psnr_y"]), 3),
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * enc["dt"] / args.steps, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": round(1e3 * enc["dt"] / steps, 4),
+        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": f"{W}x{H} 4:2:0 8-bit synthetic clip, ENCODED end to end through the SDK-compatible C API (QY265EncoderEncodeFrame): host I420 in -> pinned copy -> H2D -> "
                                f"pixel path on the MI355X (-preset {enc['preset']}: -me {args.me}, subme 1, deblock + SAO) -> D2H of CU map / levels / SAO -> CABAC slice data on "
                                f"{enc['host_threads']} host threads -> Annex-B NAL units out; -rc 0 -qp {args.qp} (I=Q, P=Q+1, B=Q+2..) -iper {args.iper}, {enc['gop']}, "
@@ -484,10 +597,16 @@ def encoded_line(args, enc, world, hot, cpu):
                    "pictures_per_step": 1, "host_threads_per_gpu": enc["host_threads"], "host_cores": enc["host_cores"],
                    "bytes_per_picture": int(enc["bytes_per_picture"]), "kbps_at_50fps": round(enc["bytes_per_picture"] * 8 * 50 / 1000.0, 1),
                    "slice_write_ms_per_picture_per_thread": round(enc["slice_write_ms_per_picture"], 2),
-                   "not_in_the_path": "rate-distortion optimised quantisation / sign-data hiding (the reference's -rdoq at -preset slow), skip / merge modes, lookahead: the stream is larger than appencoder's at the same QP",
-                   "sharding": "one encoder per GPU (rank), each on its own synthetic clip = its own closed GOPs; no data-path collective"},
+                   "in_the_path": "sign-data hiding (signBitHidingHDQ), merge / skip SIGNALLING where the chosen motion equals a merge candidate, AMVP with the better of the two predictors",
+                   "not_in_the_path": "rate-distortion optimised quantisation (the reference's -rdoq at -preset slow), merge / skip as a DECISION, intra CUs in P/B pictures, lookahead / cuTree: "
+                                      "at the same QP the stream is several times larger than appencoder's (BASELINE.md §2b has the same-clip table)",
+                   "sharding": (f"ONE job of {enc['job']['frames']} pictures = {enc['job']['gops']} closed GOPs dealt to the ranks in contiguous runs; every rank encodes its GOPs, the coded bytes are "
+                                f"gathered on rank 0 in stream order (the only exchange step; inside the timed region); stream md5 {enc['md5']}") if strong else
+                               "one encoder per GPU (rank), each on its own synthetic clip = its own closed GOPs; no data-path collective"},
         "roofline": None, "cpu_baseline": cpu,
     }
+    if strong:
+        line["config"]["job"] = {"frames": enc["job"]["frames"], "gops": enc["job"]["gops"], "stream_bytes": enc["job"]["bytes"], "stream_md5": enc["md5"]}
     if hot is not None:
         line["roofline"] = hot["roofline"]
         line["hot_path"] = {"value": hot["value"], "unit": "frames/s", "psnr_y": hot["psnr_y"], "ms_per_step": hot["ms_per_step"],

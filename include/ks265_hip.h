@@ -202,6 +202,9 @@ typedef struct {
                                   per sample runs interMeHex instead of interMeUMH; 16 at -preset slow, 0 (= always UMH) at veryslow */
     int32_t sdh;               /* the postQuant seam (postQuant enc@0x4ace80 between H265QuantBlock and H265DeQuantBlock): 1 = sign-data hiding on the
                                   quantised levels (signBitHidingHDQ enc@0x4aa150; the reference's PPS has sign_data_hiding_enabled_flag = 1) */
+    int32_t pre_search;        /* 1 = stage A evaluates one more start candidate per PU: the vector of an exhaustive search on a three-level pyramid
+                                  (ks265_presearch; the reference's lookahead searches 2:1 pictures, downsample_c enc@0x4a6a60, and meInitPoint
+                                  enc@0x48af50 picks the best of several start candidates) */
 } ks265_frame_cfg;
 
 /* geometry of the padded picture buffers the caller allocates (one call, no allocation) */
@@ -246,6 +249,10 @@ int ks265_store_i420(ks265_frame *f, ks265_pic src, uint8_t *dev_i420);
 /* Stage A0: the 15 fractional-sample luma planes of a reference picture (normative 8-tap filters,
  * interpLuma* enc@0x40e4f0..0x4109b0); dev_planes = 16 x bytes_y (plane 0 is a copy of ref.y) */
 int ks265_ref_planes(ks265_frame *f, ks265_pic ref, uint8_t *dev_planes);
+/* Stage A0 (cfg.pre_search; run by ks265_me_integer itself, exported for stage tests): exhaustive motion search on a pyramid built with
+ * downsample_c enc@0x4a6a60 - L2 blocks of 8x8 over +-range/4, L1 blocks +-2, 16x16 picture blocks +-1; cost SAD + |mx| + |my|.
+ * dev_field: ceil(W/16) x ceil(H/16) x {mvx, mvy} int16, integer pel (NULL = the frame's own buffer) */
+int ks265_presearch(ks265_frame *f, ks265_pic src, ks265_pic ref, int16_t *dev_field);
 /* Stage A: integer-pel motion search for every PU of every CTU (motionSearchOneRef enc@0x483f40 ->
  * interMeDia enc@0x48fbe0 over sad4_c); prev_pu = PU records of the previous picture (temporal
  * predictor) or NULL */

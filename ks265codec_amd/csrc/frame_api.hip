@@ -72,6 +72,8 @@ void ks265_frame_destroy(ks265_frame *f)
     void *ptrs[] = {f->planes1, f->pu1, f->pub, f->planes, f->pu[0], f->pu[1], f->cu8, f->sao, f->lvl[0], f->lvl[1], f->lvl[2], f->deb[0], f->deb[1], f->deb[2], f->sse, f->progress, f->mats, f->planes_x[0], f->planes_x[1], f->planes_x[2], f->pu_x[0], f->pu_x[1], f->pu_x[2]};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    for (uint8_t *p : f->pyr)
+        if (p) (void)hipFree(p);
     delete f;
 }
 

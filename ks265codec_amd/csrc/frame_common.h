@@ -40,6 +40,7 @@ struct ks265_frame {
     unsigned long long *sse = nullptr;
     short *mats = nullptr;              // forward + transposed DCT matrices of all sizes in the kernels' LDS layout (2 x MAT_SHORTS)
     int *progress = nullptr;            // intra wavefront: CTUs finished per CTU row
+    uint8_t *pyr[7] = {};               // pre-search (cfg.pre_search): L1 / L2 of the source, L1 / L2 of the reference, L2 / L1 vectors, the 16x16 vector field
     // optional in-situ stage timing (HIP events on the context's stream, between the stages of ks265_encode_picture)
     bool profiling = false;
     hipEvent_t ev[KS_NSTAGE + 1] = {};

@@ -77,6 +77,7 @@ struct GroupLds {
     int2 desc[16];                         // per PU of the group, published by its owner: centre x | y << 16, candidate-table parameters (DP_*)
     unsigned long long best[16][4];        // per PU and slot: (cost << 8 | key) << 32 | (x + 128) << 8 | (y + 128)
     int pred[16];                          // per PU: predictor, x | y << 16
+    int fld[16];                           // per PU: pre-search candidate of PH_INIT, x | y << 16
     int njobs, active;
 };
 struct MeLds {
@@ -88,19 +89,21 @@ struct MeLds {
 };
 
 struct Owner {
-    int ph, mx, my, pmx, pmy, merange, it, dir;
+    int ph, mx, my, pmx, pmy, merange, it, dir, iflags;
     unsigned cost, cost0;
 };
 
 // descriptor parameters: candidate k of a phase is ctab[tb + (k & km)] scaled by m0 + ms * (k >> ksh); its key is the table's, or k + keyadd
 #define DP(tb, km, ksh, m0, ms, keyadd, ranged) ((tb) | ((km) << 6) | ((ksh) << 13) | ((m0) << 16) | ((ms) << 20) | ((keyadd) << 24) | ((ranged) << 28))
 #define DP_INIT (1 << 29)
+#define DP_INIT_ZERO (1 << 30)       // PH_INIT: candidate 1 (the zero vector) takes part (root PU with a non-zero temporal predictor)
+#define DP_INIT_FIELD (1 << 31)      // PH_INIT: candidate 2 (the pre-search vector, GroupLds::fld) takes part
 
 // number of candidates of the owner's phase and its descriptor parameters
 __device__ __forceinline__ int phase_desc(const Owner &o, int nstart, int &dp)
 {
     switch (o.ph) {
-    case PH_INIT: dp = DP_INIT; return 2;                                                // predictor (key 1), zero vector (key 2)
+    case PH_INIT: dp = DP_INIT | o.iflags; return 3;                                      // predictor (key 1), zero vector (key 2), pre-search vector (key 3)
     case PH_START: dp = DP(TB_START, 15, 0, 1, 0, 0, 0); return nstart;
     case PH_DIA: case PH_U1: case PH_UFINAL: case PH_UDW: dp = DP(TB_SQUARE, 7, 0, 1, 0, 0, 0); return 4;
     case PH_SQUARE: dp = DP(TB_SQUARE, 7, 0, 1, 0, 0, 0); return 8;
@@ -127,7 +130,7 @@ extern "C" void ks265_me_dbg(unsigned long long *out, int reset) { if (reset) { 
 template <bool WG>
 __device__ __forceinline__ void me_group(const KsGeom &g, int cx, int cy, int range, int lam, int method, int hex_thr, MeLds &L, GroupLds &Q, int level,
                                          int l2n /* log2 PUs per side of the group */, int qx0, int qy0 /* PU-grid origin of the group */,
-                                         const ks265_pu *prev_ctu, ks265_pu *out_ctu, int t /* lane index inside the group's lanes */)
+                                         const ks265_pu *prev_ctu, ks265_pu *out_ctu, const short2 *field, int nb0x, int nb0y, int t /* lane index inside the group's lanes */)
 {
     constexpr int NT = WG ? 256 : 64;
     const int S = 64 >> level, npu = 1 << (2 * l2n), l2t = 6 - 2 * level;              // tiles per PU = 1 << l2t (64, 16, 4, 1)
@@ -136,7 +139,7 @@ __device__ __forceinline__ void me_group(const KsGeom &g, int cx, int cy, int ra
     // speculative first round: start + diamond for interMeDia / an always-UMH search, + diagonals + hexagon when interMeHex can run
     const int nstart = (method == 1 || (method == 2 && hex_thr > 0)) ? 15 : 5;
     Owner o;
-    o.ph = PH_DONE; o.mx = o.my = o.pmx = o.pmy = 0; o.merange = 0; o.it = 0; o.dir = 0; o.cost = 0; o.cost0 = 0;
+    o.ph = PH_DONE; o.mx = o.my = o.pmx = o.pmy = 0; o.merange = 0; o.it = 0; o.dir = 0; o.cost = 0; o.cost0 = 0; o.iflags = 0;
     bool inside = false;
     const int px = qx0 + (t & ((1 << l2n) - 1)), py = qy0 + ((t >> l2n) & ((1 << l2n) - 1));
     const bool is_owner = t < npu;
@@ -158,7 +161,12 @@ __device__ __forceinline__ void me_group(const KsGeom &g, int cx, int cy, int ra
             }
             o.merange = root ? range : max(range >> 2, 4);
             o.mx = o.pmx; o.my = o.pmy;
-            o.ph = (root && (o.pmx | o.pmy)) ? PH_INIT : PH_START;                     // a root PU with a temporal predictor also tries the zero vector
+            if (root && (o.pmx | o.pmy)) o.iflags |= DP_INIT_ZERO;                     // a root PU with a temporal predictor also tries the zero vector
+            if (field) {                                                               // and every PU the pre-search vector of the 16x16 block under its centre
+                const short2 fv = field[min((cy * 64 + py * S + S / 2) >> 4, nb0y - 1) * nb0x + min((cx * 64 + px * S + S / 2) >> 4, nb0x - 1)];
+                if (fv.x != o.pmx || fv.y != o.pmy) { o.iflags |= (int)DP_INIT_FIELD; Q.fld[t] = ((int)fv.x & 0xFFFF) | ((int)fv.y << 16); }
+            }
+            o.ph = o.iflags ? PH_INIT : PH_START;
             Q.pred[t] = (o.pmx & 0xFFFF) | (o.pmy << 16);
         } else {                                                                        // PU not (completely) inside the picture: marked, never searched
             ks265_pu e; e.mvx = e.mvy = e.mvpx = e.mvpy = 0; e.cost = KS_COST_INVALID; e.dist = KS_COST_INVALID;
@@ -238,9 +246,14 @@ __device__ __forceinline__ void me_group(const KsGeom &g, int cx, int cy, int ra
                 const int keyadd = (dp >> 24) & 15;
                 key[n] = keyadd ? k + keyadd : (int)((e >> 16) & 0xFF);
                 slot[n] = (int)(e >> 24);
-                if (dp & DP_INIT) { x[n] = k ? 0 : x[n]; y[n] = k ? 0 : y[n]; key[n] = k + 1; slot[n] = 0; }
+                bool cand_on = true;
+                if (dp & DP_INIT) {
+                    if (k == 1) { x[n] = 0; y[n] = 0; cand_on = (dp & DP_INIT_ZERO) != 0; }
+                    else if (k == 2) { const int fv = Q.fld[pu[n]]; x[n] = (int)(short)(fv & 0xFFFF); y[n] = fv >> 16; cand_on = (dp & (int)DP_INIT_FIELD) != 0; }
+                    key[n] = k + 1; slot[n] = 0;
+                }
                 const int lim = (dp >> 28) & 1 ? range : ME_WLIM;
-                live[n] = live[n] && stub[n] != 0xFFFFu && abs(x[n]) <= lim && abs(y[n]) <= lim;
+                live[n] = live[n] && cand_on && stub[n] != 0xFFFFu && abs(x[n]) <= lim && abs(y[n]) <= lim;
                 const int tile = (base + n * NT + t) & ((1 << l2t) - 1);
                 const int ppx = qx0 + (pu[n] & ((1 << l2n) - 1)), ppy = qy0 + (pu[n] >> l2n);
                 const int bx = ppx * S + (tile & (tpr - 1)) * 8, by = ppy * S + (tile >> (3 - level)) * 8;
@@ -389,7 +402,7 @@ __device__ __forceinline__ void me_group(const KsGeom &g, int cx, int cy, int ra
 }
 
 __global__ __launch_bounds__(256, 3) void me_int_kernel(KsGeom g, int range, int lam, int method, int hex_thr, const uint8_t *src, const uint8_t *ref,
-                                                        const ks265_pu *prev, ks265_pu *out)
+                                                        const ks265_pu *prev, ks265_pu *out, const short2 *field, int nb0x, int nb0y)
 {
     __shared__ __attribute__((aligned(16))) MeLds L;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -437,7 +450,7 @@ __global__ __launch_bounds__(256, 3) void me_int_kernel(KsGeom g, int range, int
     return;
 #endif
     // the 64x64 PU: the whole work-group
-    me_group<true>(g, cx, cy, range, lam, method, hex_thr, L, L.grp[0], 0, 0, 0, 0, prev_ctu, out_ctu, tid);
+    me_group<true>(g, cx, cy, range, lam, method, hex_thr, L, L.grp[0], 0, 0, 0, 0, prev_ctu, out_ctu, field, nb0x, nb0y, tid);
     __syncthreads();                                                                    // its vector is the predictor of everything below
 #ifdef KS_EXP_ME_CLOCK
     const long long tk2 = ME_NOW();
@@ -446,7 +459,7 @@ __global__ __launch_bounds__(256, 3) void me_int_kernel(KsGeom g, int range, int
     const int qx = wave & 1, qy = wave >> 1;
 #pragma unroll 1
     for (int level = 1; level < 4; ++level)
-        me_group<false>(g, cx, cy, range, lam, method, hex_thr, L, L.grp[wave], level, level - 1, qx << (level - 1), qy << (level - 1), prev_ctu, out_ctu, lane);
+        me_group<false>(g, cx, cy, range, lam, method, hex_thr, L, L.grp[wave], level, level - 1, qx << (level - 1), qy << (level - 1), prev_ctu, out_ctu, field, nb0x, nb0y, lane);
 #ifdef KS_EXP_ME_CLOCK
     const long long tk3 = ME_NOW();
     if (lane == 0) { atomicAdd(&ks_me_dbg[6], (unsigned long long)(tk1 - tk0)); atomicAdd(&ks_me_dbg[7], (unsigned long long)(tk2 - tk1)); atomicAdd(&ks_me_dbg[14], (unsigned long long)(tk3 - tk2)); atomicAdd(&ks_me_dbg[15], 1ull); }
@@ -458,7 +471,14 @@ extern "C" int ks265_me_integer(ks265_frame *f, ks265_pic src, ks265_pic ref, co
     KS_FRAME_CHECK(f);
     if (!src.y || !ref.y || !pu) return KS265_POINTER;
     if (f->cfg.me_method < 0 || f->cfg.me_method > 2) return KS265_NOTSUPPORTED;
+    const short2 *field = nullptr;
+    if (f->cfg.pre_search) {                                                 // stage A0 first: the pre-search field of this (source, reference) pair
+        const int r = ks265_presearch(f, src, ref, nullptr);
+        if (r) return r;
+        field = (const short2 *)f->pyr[6];
+    }
     const dim3 grid(f->g.ctu_cols * f->g.ctu_rows), block(256);
-    hipLaunchKernelGGL(me_int_kernel, grid, block, 0, f->ctx->stream, f->g, f->cfg.me_range, f->cfg.lambda_q4, f->cfg.me_method, f->cfg.me_hex_thr, src.y, ref.y, prev_pu, pu);
+    hipLaunchKernelGGL(me_int_kernel, grid, block, 0, f->ctx->stream, f->g, f->cfg.me_range, f->cfg.lambda_q4, f->cfg.me_method, f->cfg.me_hex_thr, src.y, ref.y, prev_pu, pu,
+                       field, (f->g.W + 15) / 16, (f->g.H + 15) / 16);
     return ks265_check_launch(f->ctx);
 }

@@ -15,7 +15,7 @@ static double now_ms(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &
 static void usage(void)
 {
     puts("usage: ks265enc -i in.yuv -wdt W -hgt H [-fr FPS] [-preset ultrafast..placebo] [-latency zerolatency|lowdelay|livestreaming|default] [-tune T]\n"
-         "                [-rc 0..5] [-qp Q] [-crf C] [-br KBPS] [-iper N] [-bframes N] [-frms N] [-threads N] [-psnr 0|1|2] [-b out.265]\n"
+         "                [-rc 0..5] [-qp Q] [-crf C] [-br KBPS] [-iper N] [-bframes N] [-frms N] [-threads N] [-psnr 0|1|2] [-b out.265] [-o recon.yuv]\n"
          "                [-me 0|1|2] [-subme 0|1] [-merange R] [-ref N] [-sao 0..4] [-v]\n"
          "  I420 8-bit input; width and height multiples of 8.  Needs one MI355X (gfx950): there is no CPU fallback.");
 }
@@ -23,6 +23,7 @@ static void usage(void)
 int main(int argc, char **argv)
 {
     const char *in_path = NULL, *out_path = NULL, *preset = "medium", *latency = "default", *tune = "default";
+    const char *rec_path = NULL;
     int frames = -1;
     /* two passes over the arguments: preset / latency / tune first (they reset every field), then the explicit settings */
     for (int i = 1; i < argc; ++i) {
@@ -44,7 +45,7 @@ int main(int argc, char **argv)
         const char *v = argv[++i];
         if (!strcmp(a, "-i")) in_path = v;
         else if (!strcmp(a, "-b")) out_path = v;
-        else if (!strcmp(a, "-o")) fprintf(stderr, "ks265enc: -o (reconstruction dump) is not implemented; decode the stream instead\n");
+        else if (!strcmp(a, "-o")) rec_path = v;
         else if (!strcmp(a, "-frms")) frames = atoi(v);
         else if (!strcmp(a, "-preset") || !strcmp(a, "-latency") || !strcmp(a, "-tune")) continue;
         else {
@@ -59,6 +60,7 @@ int main(int argc, char **argv)
     int err = 0;
     void *h = QY265EncoderOpen(&cfg, &err);
     if (!h) { fprintf(stderr, "QY265EncoderOpen failed: 0x%08x\n", (unsigned)err); return 1; }
+    if (rec_path && ks265_enc_set_recon_file(h, rec_path) != QY_OK) { fprintf(stderr, "cannot write the reconstruction to %s\n", rec_path); return 1; }
     const size_t luma = (size_t)cfg.picWidth * cfg.picHeight, fsz = luma * 3 / 2;
     unsigned char *buf = (unsigned char *)malloc(fsz);
     QY265YUV yuv = {cfg.picWidth, cfg.picHeight, {buf, buf + luma, buf + luma + luma / 4}, {cfg.picWidth, cfg.picWidth / 2, cfg.picWidth / 2}};

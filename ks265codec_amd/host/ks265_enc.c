@@ -13,6 +13,7 @@
 #define _GNU_SOURCE
 #include "ks265_enc.h"
 #include "ks265_stream.h"
+#include <fcntl.h>
 #include <math.h>
 #include <pthread.h>
 #include <stdarg.h>
@@ -117,6 +118,7 @@ typedef struct Job {
     long long pts;
     int nl0, nl1, l0[4], l1[4], nrps, rps_poc[16]; unsigned char rps_used[16];
     ks265_cu8 *cu8; int16_t *lvl[3]; ks265_sao_param *sao; uint64_t *sse;      /* pinned host copies of the GPU's records */
+    uint8_t *recon;                                       /* pinned I420 copy of the reconstruction (only with ks265_enc_set_recon_file) */
     void *ev;                                             /* recorded after the D2H copies */
     uint8_t *nal; size_t nal_cap; long nal_len;
     int key_headers;                                      /* parameter sets go in front of this picture */
@@ -132,6 +134,7 @@ typedef struct Enc {
     int base_qp, iper, nthreads;
     ks265_ctx *ctx; ks265_frame *frame; ks265_frame_geom geom; ks265_frame_cfg fcfg; ks265_stream_cfg scfg;
     /* device */
+    int recon_fd; uint8_t *dev_recon;                     /* reconstruction dump (the CLI's -o) */
     uint8_t *dev_i420; ks265_pic src; ks265_pic dpb[MAX_DPB]; int dpb_poc[MAX_DPB]; int ndpb; uint64_t *dev_sse;
     /* scheduling */
     Input in[MAX_INPUT]; int next_disp;                   /* display index of the next input picture */
@@ -177,6 +180,10 @@ static void *worker(void *arg)
         e->next_work = (e->next_work + 1) % MAX_JOBS; --e->npending;
         pthread_mutex_unlock(&e->mu);
         int err = ks265_event_wait(e->ctx, j->ev);               /* the records of this picture have reached the host */
+        if (!err && e->recon_fd >= 0 && j->recon) {
+            const size_t fsz = (size_t)e->W * e->H * 3 / 2;
+            if (pwrite(e->recon_fd, j->recon, fsz, (off_t)j->disp * (off_t)fsz) != (ssize_t)fsz) err = KS265_FAIL;
+        }
         const double t0 = now_ms();
         if (!err) {
             ks265_slice_in s;
@@ -242,6 +249,10 @@ static int submit(Enc *e, Input *in, int kind, int poc, int qp, const int *l0, i
     if (!r) r = ks265_memcpy_d2h_async(e->ctx, j->lvl[2], ks265_frame_levels(e->frame, 2), npx / 2);
     if (!r) r = ks265_memcpy_d2h_async(e->ctx, j->sao, ks265_frame_sao(e->frame), (size_t)e->geom.bytes_sao);
     if (!r && e->cfg.calcPsnr) r = ks265_memcpy_d2h_async(e->ctx, j->sse, e->dev_sse, 3 * sizeof(uint64_t));
+    if (!r && e->recon_fd >= 0) {
+        r = ks265_store_i420(e->frame, out, e->dev_recon);
+        if (!r) r = ks265_memcpy_d2h_async(e->ctx, j->recon, e->dev_recon, fsz);
+    }
     if (!r) r = ks265_event_record(e->ctx, j->ev);
     if (r) return hip_rc(r);
     j->disp = in->disp; j->pts = in->pts; j->poc = poc; j->kind = kind; j->qp = qp; j->is_ref = is_ref; j->key_headers = key_headers;
@@ -424,14 +435,15 @@ void QY265EncoderClose(void *h)
         for (int i = 0; i < MAX_JOBS; ++i) {
             Job *j = &e->jobs[i];
             ks265_host_free(e->ctx, j->cu8); ks265_host_free(e->ctx, j->lvl[0]); ks265_host_free(e->ctx, j->lvl[1]); ks265_host_free(e->ctx, j->lvl[2]);
-            ks265_host_free(e->ctx, j->sao); ks265_host_free(e->ctx, j->sse);
+            ks265_host_free(e->ctx, j->sao); ks265_host_free(e->ctx, j->sse); ks265_host_free(e->ctx, j->recon);
             if (j->ev) ks265_event_destroy(e->ctx, j->ev);
             free(j->nal);
         }
         for (int i = 0; i < MAX_INPUT; ++i) ks265_host_free(e->ctx, e->in[i].i420);
         for (int i = 0; i < e->ndpb; ++i) pic_free(e, &e->dpb[i]);
         pic_free(e, &e->src);
-        ks265_dev_free(e->ctx, e->dev_i420); ks265_dev_free(e->ctx, e->dev_sse);
+        ks265_dev_free(e->ctx, e->dev_i420); ks265_dev_free(e->ctx, e->dev_sse); ks265_dev_free(e->ctx, e->dev_recon);
+        if (e->recon_fd >= 0) close(e->recon_fd);
         if (e->frame) ks265_frame_destroy(e->frame);
         ks265_destroy(e->ctx);
     }
@@ -448,6 +460,7 @@ void *QY265EncoderOpen(QY265EncConfig *cfg, int *err)
     if (!cfg) { *err = QY_POINTER; return NULL; }
     if (cfg->picWidth <= 0 || cfg->picHeight <= 0 || (cfg->picWidth & 7) || (cfg->picHeight & 7) || cfg->frameRate <= 0 || cfg->rc < 0 || cfg->rc > 5) { *err = QY_NOTSUPPORTED; return NULL; }
     Enc *e = (Enc *)calloc(1, sizeof *e);
+    if (e) e->recon_fd = -1;
     if (!e) { *err = QY_OUTOFMEMORY; return NULL; }
     pthread_mutex_init(&e->mu, NULL); pthread_cond_init(&e->cv_work, NULL); pthread_cond_init(&e->cv_done, NULL);
     e->cfg = *cfg; e->W = cfg->picWidth; e->H = cfg->picHeight; e->log_level = cfg->logLevel;
@@ -482,6 +495,7 @@ void *QY265EncoderOpen(QY265EncConfig *cfg, int *err)
     e->fcfg.me_method = e->me_method; e->fcfg.subme = e->subme; e->fcfg.deblock = e->use_df; e->fcfg.sao = e->use_sao;
     e->fcfg.bframes = e->gop_b; e->fcfg.refs = e->refs; e->fcfg.me_hex_thr = e->hex_thr;
     e->fcfg.sdh = 1;                                                    /* the reference's streams have sign_data_hiding_enabled_flag = 1 at every preset */
+    e->fcfg.pre_search = 1;                                             /* stage A0: pyramid pre-search vectors as start candidates of the integer search */
     r = ks265_frame_geometry(&e->fcfg, &e->geom);
     if (!r) r = ks265_frame_create(e->ctx, &e->fcfg, &e->frame);
     const size_t fsz = (size_t)e->W * e->H * 3 / 2, npx = (size_t)e->W * e->H;
@@ -595,4 +609,19 @@ int ks265_enc_get_stats(void *h, ks265_enc_stats *out)
     if (!e || !out) return QY_POINTER;
     *out = e->st;
     return QY_OK;
+}
+
+/* extension: dump the encoder's reconstruction as I420, every picture at its display position (the reference CLI's -o).  Call right after
+ * QY265EncoderOpen, before the first picture.  Costs one more D2H of W*H*3/2 bytes per picture: a checking aid, not part of the normal path. */
+int ks265_enc_set_recon_file(void *h, const char *path)
+{
+    Enc *e = (Enc *)h;
+    if (!e || !path) return QY_POINTER;
+    if (e->next_disp != 0 || e->recon_fd >= 0) return QY_NOTSUPPORTED;
+    const size_t fsz = (size_t)e->W * e->H * 3 / 2;
+    int r = ks265_dev_malloc(e->ctx, (void **)&e->dev_recon, fsz);
+    for (int i = 0; i < MAX_JOBS && !r; ++i) r = ks265_host_malloc(e->ctx, (void **)&e->jobs[i].recon, fsz);
+    if (r) return hip_rc(r);
+    e->recon_fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    return e->recon_fd >= 0 ? QY_OK : QY_FAIL;
 }

@@ -156,6 +156,87 @@ static void pu_predictor(const kso_frame_cfg *cfg, const kso_pu *ctu_pu, const k
     }
 }
 
+/* ------------------------------------------------------------------ Stage A0: motion pre-search on a three-level pyramid
+ * The reference's lookahead runs a low-resolution motion search on 2:1 pictures (downsample_c enc@0x4a6a60 feeds estimateFrameCost; SURVEY.md
+ * section 8(f) rank 2) and meInitPoint enc@0x48af50 starts the integer search from the best of several candidates.  A frame-parallel search has
+ * no spatial neighbours to draw candidates from, so the candidate that makes the local pattern searches (DIA / HEX / UMH walk downhill from
+ * their start point and cannot find a displaced match in texture without a gradient) robust comes from here: an EXHAUSTIVE search where it is
+ * cheap.  L1 = downsample_c(luma), L2 = downsample_c(L1).  Per 8x8 block of L2 (32x32 samples) every vector of +-range/4; per 8x8 block of
+ * L1 (16x16 samples) +-2 around twice the L2 vector; per 16x16 block of the picture +-1 around twice the L1 vector.  Cost = SAD + |mx| + |my|
+ * (ties and flat areas fall to the shorter vector), first minimum in raster order of (my, mx).  Low-resolution reads clamp to the picture
+ * (no border), the full-resolution step reads the padded planes like stage A.  Output: one integer vector per 16x16 block. */
+static void pyr_down(const uint8_t *src, long st, int w, int h, uint8_t *dst /* w/2 x h/2, packed */)
+{
+    ks265o_downsample(dst, src, w / 2, (int)st, w / 2, h / 2);
+}
+static uint32_t sad_clamped(const uint8_t *cur, const uint8_t *ref, int W, int H, int x0, int y0, int bw, int bh, int mx, int my)
+{
+    uint32_t s = 0;
+    for (int y = 0; y < bh; ++y) {
+        const int ry = iclip(0, H - 1, y0 + y + my);
+        for (int x = 0; x < bw; ++x) {
+            const int rx = iclip(0, W - 1, x0 + x + mx);
+            const int d = cur[(long)(y0 + y) * W + x0 + x] - ref[(long)ry * W + rx];
+            s += (uint32_t)(d < 0 ? -d : d);
+        }
+    }
+    return s;
+}
+void kso_presearch(const kso_frame_cfg *cfg, kso_pic src, kso_pic ref, int16_t *field)
+{
+    kso_frame_geom g; kso_frame_geometry(cfg, &g);
+    const int W = cfg->width, H = cfg->height, W1 = W / 2, H1 = H / 2, W2 = W / 4, H2 = H / 4;
+    const uint8_t *S = org_y(&g, src.y), *R = org_y(&g, ref.y);
+    const long st = g.stride_y;
+    uint8_t *c1 = malloc((size_t)W1 * H1), *r1 = malloc((size_t)W1 * H1), *c2 = malloc((size_t)W2 * H2), *r2 = malloc((size_t)W2 * H2);
+    pyr_down(S, st, W, H, c1); pyr_down(R, st, W, H, r1); pyr_down(c1, W1, W1, H1, c2); pyr_down(r1, W1, W1, H1, r2);
+    const int nb2x = (W2 + 7) / 8, nb2y = (H2 + 7) / 8, nb1x = (W1 + 7) / 8, nb1y = (H1 + 7) / 8, nb0x = (W + 15) / 16, nb0y = (H + 15) / 16;
+    int16_t *mv2 = malloc(sizeof(int16_t) * 2 * (size_t)nb2x * nb2y), *mv1 = malloc(sizeof(int16_t) * 2 * (size_t)nb1x * nb1y);
+    const int R2 = imax(cfg->me_range >> 2, 1), range = cfg->me_range;
+#pragma omp parallel for collapse(2) schedule(dynamic, 1)
+    for (int by = 0; by < nb2y; ++by)
+        for (int bx = 0; bx < nb2x; ++bx) {
+            const int bw = imin(8, W2 - 8 * bx), bh = imin(8, H2 - 8 * by);
+            uint32_t best = 0xffffffffu; int bmx = 0, bmy = 0;
+            for (int my = -R2; my <= R2; ++my)
+                for (int mx = -R2; mx <= R2; ++mx) {
+                    const uint32_t c = sad_clamped(c2, r2, W2, H2, 8 * bx, 8 * by, bw, bh, mx, my) + (uint32_t)(iabs_(mx) + iabs_(my));
+                    if (c < best) { best = c; bmx = mx; bmy = my; }
+                }
+            mv2[2 * (by * nb2x + bx)] = (int16_t)bmx; mv2[2 * (by * nb2x + bx) + 1] = (int16_t)bmy;
+        }
+#pragma omp parallel for collapse(2) schedule(dynamic, 1)
+    for (int by = 0; by < nb1y; ++by)
+        for (int bx = 0; bx < nb1x; ++bx) {
+            const int bw = imin(8, W1 - 8 * bx), bh = imin(8, H1 - 8 * by);
+            const int16_t *p = &mv2[2 * ((by >> 1) * nb2x + (bx >> 1))];
+            uint32_t best = 0xffffffffu; int bmx = 0, bmy = 0;
+            for (int dy = -2; dy <= 2; ++dy)
+                for (int dx = -2; dx <= 2; ++dx) {
+                    const int mx = 2 * p[0] + dx, my = 2 * p[1] + dy;
+                    const uint32_t c = sad_clamped(c1, r1, W1, H1, 8 * bx, 8 * by, bw, bh, mx, my) + (uint32_t)(iabs_(mx) + iabs_(my));
+                    if (c < best) { best = c; bmx = mx; bmy = my; }
+                }
+            mv1[2 * (by * nb1x + bx)] = (int16_t)bmx; mv1[2 * (by * nb1x + bx) + 1] = (int16_t)bmy;
+        }
+#pragma omp parallel for collapse(2) schedule(dynamic, 1)
+    for (int by = 0; by < nb0y; ++by)
+        for (int bx = 0; bx < nb0x; ++bx) {
+            const int bw = imin(16, W - 16 * bx), bh = imin(16, H - 16 * by);
+            const int16_t *p = &mv1[2 * (by * nb1x + bx)];
+            const uint8_t *fenc = S + (long)(16 * by) * st + 16 * bx;
+            uint32_t best = 0xffffffffu; int bmx = 0, bmy = 0;
+            for (int dy = -1; dy <= 1; ++dy)
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int mx = iclip(-range, range, 2 * p[0] + dx), my = iclip(-range, range, 2 * p[1] + dy);
+                    const uint32_t c = ks265o_sad(fenc, R + (long)(16 * by + my) * st + 16 * bx + mx, st, st, bh, bw) + (uint32_t)(iabs_(mx) + iabs_(my));
+                    if (c < best) { best = c; bmx = mx; bmy = my; }
+                }
+            field[2 * (by * nb0x + bx)] = (int16_t)bmx; field[2 * (by * nb0x + bx) + 1] = (int16_t)bmy;
+        }
+    free(c1); free(r1); free(c2); free(r2); free(mv2); free(mv1);
+}
+
 /* ------------------------------------------------------------------ Stage A: integer search (motionSearchOneRef enc@0x483f40)
  * For every PU of every CTU, coarse to fine.  The search PATTERNS are the reference's own functions, restated in ks265_me_ref.c from the
  * disassembly and pinned against traces of the reference binary (tests/golden/me_search.npz): interMeDia enc@0x48fbe0 (-me 0),
@@ -177,6 +258,9 @@ void kso_me_integer(const kso_frame_cfg *cfg, kso_pic src, kso_pic ref, const ks
     const uint8_t *S = org_y(&g, src.y), *R = org_y(&g, ref.y);
     long st = g.stride_y;
     int range = cfg->me_range, lam = cfg->lambda_q4;
+    const int nb0x = (cfg->width + 15) / 16, nb0y = (cfg->height + 15) / 16;
+    int16_t *field = NULL;
+    if (cfg->pre_search) { field = malloc(sizeof(int16_t) * 2 * (size_t)nb0x * nb0y); kso_presearch(cfg, src, ref, field); }
 #pragma omp parallel for collapse(2) schedule(dynamic, 1)
     for (int cy = 0; cy < g.ctu_rows; ++cy)
         for (int cx = 0; cx < g.ctu_cols; ++cx) {
@@ -213,6 +297,15 @@ void kso_me_integer(const kso_frame_cfg *cfg, kso_pic src, kso_pic ref, const ks
                             uint32_t c0 = s0 + m.cmx[0] + m.cmy[0];
                             if (c0 < m.cost) { m.cost = c0; m.mx = 0; m.my = 0; sad0 = s0; }
                         }
+                        if (field) {                            /* third start candidate: the pre-search vector of the 16x16 block under the PU's centre */
+                            const int16_t *f = &field[2 * (imin((y0 + s / 2) >> 4, nb0y - 1) * nb0x + imin((x0 + s / 2) >> 4, nb0x - 1))];
+                            const int fx = f[0], fy = f[1];
+                            if (fx != m.mx || fy != m.my) {
+                                uint32_t s1 = ks265o_sad(m.fenc, m.ref0 + (long)fy * st + fx, st, st, s, s);
+                                uint32_t c1 = s1 + m.cmx[4 * fx] + m.cmy[4 * fy];
+                                if (c1 < m.cost) { m.cost = c1; m.mx = fx; m.my = fy; sad0 = s1; }
+                            }
+                        }
                         if (cfg->me_method == 0) kso_ref_me_dia(&m);
                         else if (cfg->me_method == 1 || (cfg->me_hex_thr > 0 && sad0 < ((uint32_t)cfg->me_hex_thr << (2 * (6 - l))))) kso_ref_me_hex(&m);
                         else kso_ref_me_umh(&m);
@@ -222,6 +315,7 @@ void kso_me_integer(const kso_frame_cfg *cfg, kso_pic src, kso_pic ref, const ks
                         o->dist = m.cost - (uint32_t)(m.cmx[4 * m.mx] + m.cmy[4 * m.my]);
                     }
         }
+    free(field);
 }
 
 /* ------------------------------------------------------------------ Stage B: sub-pel refinement

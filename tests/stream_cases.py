@@ -22,11 +22,19 @@ CASES = {
     "sdh_ippp_416x240_umh": (416, 240, 27, 2, 16, 1, 1, "ippp", 4),
     "sdh_hierb4_416x240": (416, 240, 30, 1, 0, 1, 1, "hier", 4),
     "sdh_ippp_200x136_qp12": (200, 136, 12, 1, 0, 1, 1, "ippp", 3),
+    # what the C host (ks265_enc.c) runs: sign-data hiding + the pre-search start candidates of stage A
+    "ps_ippp_416x240_umh": (416, 240, 27, 2, 16, 1, 1, "ippp", 4),
+    "ps_hierb4_416x240": (416, 240, 30, 1, 0, 1, 1, "hier", 4),
+    "ps_mref3_200x136": (200, 136, 33, 2, 16, 1, 1, "mref", 3),
 }
 
 
 def case_sdh(name: str) -> int:
-    return 1 if name.startswith("sdh_") else 0
+    return 1 if name.startswith(("sdh_", "ps_")) else 0
+
+
+def case_ps(name: str) -> int:
+    return 1 if name.startswith("ps_") else 0
 
 
 def schedule(kind: str, par: int):
@@ -84,7 +92,7 @@ def oracle_encoder(name: str):
     W, H, qp, me, thr, sao, df, kind, par = CASES[name]
     n = 1 + max(s[0] for s in schedule(kind, par))
     clip = make_clip(W, H, n, seed=len(name) * 7 + W, abc=(17, 23, 9))
-    o = OraclePipeline(W, H, qp, lambda_q4(qp), me_method=me, me_hex_thr=thr, sao=sao, deblock=df, sdh=case_sdh(name))
+    o = OraclePipeline(W, H, qp, lambda_q4(qp), me_method=me, me_hex_thr=thr, sao=sao, deblock=df, sdh=case_sdh(name), pre_search=case_ps(name))
     dpb = {}
 
     def encode(d, k, l0, l1, q):

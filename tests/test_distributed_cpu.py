@@ -106,31 +106,33 @@ def _spread_run(rank, world, nmg, nb, bcast):
         o.set_qp(29, lambda_q4(29))
         sums[d] = int(o.store(o.encode(clip[d], "B", slots[s0], slots[s1])).astype(np.int64).sum())
 
-    mine = spread_b(rank, world, nmg, nb, enc_anchor, enc_b, lambda s: bcast(slots[s]))
+    mine = spread_b(rank, world, nmg, nb, enc_anchor, enc_b, lambda s, src: bcast(slots[s], src))
     return mine, sums
 
 
 def _spread_worker(rank, world, port, q):
     _setup(rank, world, port)
 
-    def bcast(pic):
+    def bcast(pic, src):
         for arr in (pic.y, pic.u, pic.v):
             t = torch.from_numpy(arr)                              # shares memory with the numpy plane
-            dist.broadcast(t, src=0)
+            dist.broadcast(t, src=src)
 
-    mine, sums = _spread_run(rank, world, 2, 3, bcast)
+    mine, sums = _spread_run(rank, world, 4, 3, bcast)
     q.put((rank, mine, sums))
     dist.barrier()
     dist.destroy_process_group()
 
 
 def test_b_spread_two_ranks_matches_single_process():
-    """anchors on rank 0 + broadcast, B pictures on rank 1: every picture coded once and identical to the 1-process run"""
+    """anchor chain rotating over the two ranks + broadcast from the owner, B pictures on the rank that is not coding the next anchor:
+    every picture coded once and identical to the 1-process run"""
     res = _run(_spread_worker, 2, 29613)
     (_, mine0, sums0), (_, mine1, sums1) = res
-    assert [k for _, k in mine0] == ["I", "P", "P"] and all(k == "B" for _, k in mine1) and len(mine1) == 6
-    single_mine, single = _spread_run(0, 1, 2, 3, lambda pic: None)
-    assert sorted(d for d, _ in mine0 + mine1) == sorted(d for d, _ in single_mine) == list(range(9))
+    assert [d for d, k in mine0 if k != "B"] == [0, 8, 16] and [d for d, k in mine1 if k != "B"] == [4, 12]
+    assert sum(k == "B" for _, k in mine0) == 6 and sum(k == "B" for _, k in mine1) == 6
+    single_mine, single = _spread_run(0, 1, 4, 3, lambda pic, src: None)
+    assert sorted(d for d, _ in mine0 + mine1) == sorted(d for d, _ in single_mine) == list(range(17))
     merged = dict(sums0); merged.update(sums1)
     assert merged == single
 
@@ -141,7 +143,16 @@ def test_schedules_cover_everything():
         for r in range(world):
             seen += [t for a, b in shard_gops(1000, 128, world, r) for t in range(a, b)]
         assert sorted(seen) == list(range(1000))
-        assert sorted(b_owner(j, world) for j in range(7)) == sorted([0] * 7 if world == 1 else [1 + j % (world - 1) for j in range(7)])
+        # B pictures: never on the rank that codes the next anchor of the chain, and over many mini-GOPs every rank gets its share
+        from ks265codec_amd.gop import anchor_owner
+        load = [0] * world
+        for k in range(8 * world):
+            for j in range(3):
+                r = b_owner(j, world, k, 3)
+                assert world == 1 or r != anchor_owner(k + 2, world)
+                load[r] += 1
+        assert max(load) - min(load) <= 3, load
+        assert sorted(anchor_owner(k, world) for k in range(world)) == list(range(world))
     it = coding_order(3, 8)
     assert [next(it) for _ in range(10)] == [(0, "I"), (4, "P"), (1, "B"), (2, "B"), (3, "B"), (8, "I"), (5, "B"), (6, "B"), (7, "B"), (12, "P")]
     # iper not a multiple of bframes + 1 -> the mini-GOP before the boundary is shortened, a key picture on EVERY multiple of iper

@@ -37,7 +37,7 @@ def _clip(name, n):
 def test_cli_stream_equals_decoder_verified_fixture(tmp_path):
     from ks265codec_amd import stream
     stream.build()
-    name = "sdh_ippp_416x240_umh"                      # the C host codes with sign-data hiding, like the reference
+    name = "ps_ippp_416x240_umh"                       # the C host codes with sign-data hiding (like the reference) and the pre-search candidates
     clip = _clip(name, 4)
     yuv, out = tmp_path / "in.yuv", tmp_path / "out.265"
     clip.tofile(yuv)
@@ -111,3 +111,60 @@ def test_api_call_sequence(bframes, tag):
     os.makedirs(OUT, exist_ok=True)
     open(os.path.join(OUT, f"api_{tag}.265"), "wb").write(bs)
     clip.tofile(os.path.join(OUT, f"api_{tag}_src.yuv"))
+
+
+REF_DEC = os.path.join(ROOT, "oracle", "_ref", "appdecoder")          # staged by __graft_entry__.build() in the builder container; travels with the snapshot
+
+
+@pytest.mark.skipif(not os.path.exists(REF_DEC), reason="the reference's decoder was not staged (oracle/_ref/appdecoder)")
+@pytest.mark.parametrize("W,H,n,opts", [
+    (1280, 720, 25, ["-preset", "veryfast", "-qp", "32", "-iper", "16"]),                      # the SDK's default GOP: hierarchical B of 8, two closed GOPs
+    (1920, 1080, 10, ["-preset", "slow", "-qp", "27", "-bframes", "0", "-iper", "128"]),       # config 2's tools: UMH, three list-0 pictures
+    (1920, 1088, 9, ["-preset", "medium", "-qp", "30", "-bframes", "3", "-iper", "128"]),      # anchors + non-reference B pictures
+    (3840, 2160, 6, ["-preset", "slow", "-qp", "27", "-iper", "128"]),                         # the bench workload (config 3)
+])
+def test_reference_decoder_reproduces_the_gpu_reconstruction(tmp_path, W, H, n, opts):
+    """the conformance contract end to end ON THIS BOX: what the MI355X reconstructed (ks265enc -o) is byte for byte what the reference's
+    own decoder makes of the stream the host wrote (ks265enc -b) - at the sizes the bench runs, not only at the fixture sizes"""
+    from ks265codec_amd import stream
+    from ks265codec_amd.synth import make_clip
+    stream.build()
+    clip = make_clip(W, H, n, seed=W + n, abc=(37, 53, 19), pan=(5, 3))
+    yuv, out, rec, dec = tmp_path / "in.yuv", tmp_path / "out.265", tmp_path / "rec.yuv", tmp_path / "dec.yuv"
+    clip.tofile(yuv)
+    r = subprocess.run([stream.CLI, "-i", str(yuv), "-wdt", str(W), "-hgt", str(H), "-fr", "50", "-rc", "0", *opts, "-threads", "8", "-psnr", "1", "-b", str(out), "-o", str(rec)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0 and "H265 encoder passed!!!" in r.stdout, r.stdout[-500:] + r.stderr[-500:]
+    d = subprocess.run([REF_DEC, "-b", str(out), "-o", str(dec), "-threads", "4"], capture_output=True, text=True, cwd=tmp_path)
+    assert "decoder passed" in d.stdout, d.stdout[-400:] + d.stderr[-400:]
+    a, b = np.fromfile(rec, np.uint8), np.fromfile(dec, np.uint8)
+    assert a.size == b.size == n * W * H * 3 // 2, (a.size, b.size)
+    fsz = W * H * 3 // 2
+    bad = [t for t in range(n) if not (a[t * fsz:(t + 1) * fsz] == b[t * fsz:(t + 1) * fsz]).all()]
+    assert not bad, f"pictures {bad} decode differently from the encoder's reconstruction"
+    src = clip.reshape(n, -1)[:, :W * H].astype(np.int64)
+    mse = float(((src - a.reshape(n, -1)[:, :W * H].astype(np.int64)) ** 2).mean())
+    m = [ln for ln in r.stdout.splitlines() if ln.startswith("bitrate, psnr:")]
+    assert m and abs(float(m[0].split()[3]) - 10 * np.log10(255.0 ** 2 / mse)) < 0.02, (m, mse)      # the PSNR the encoder prints is that of this reconstruction
+
+
+def test_strong_scaling_job_is_rank_count_invariant(tmp_path):
+    """bench.py --scaling strong: ONE fixed job split GOP by GOP over the ranks; the gathered stream of a 2-rank run (both ranks on this box's
+    one GPU, host-side gloo collectives) is byte for byte the 1-rank stream"""
+    import sys
+    env = dict(os.environ, KS265_BENCH_BACKEND="gloo", KS265_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1")
+    common = ["--scaling", "strong", "--job-frames", "24", "--iper", "8", "--width", "640", "--height", "368", "--warmup", "2", "--host-threads", "4"]
+    o1, o2 = tmp_path / "w1.265", tmp_path / "w2.265"
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", *common, "--out", str(o1)], capture_output=True, text=True, env=env, cwd=ROOT)
+    assert r1.returncode == 0, r1.stdout[-500:] + r1.stderr[-800:]
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29677",
+                         os.path.join(ROOT, "bench.py"), "--gpus", "2", *common, "--out", str(o2)], capture_output=True, text=True, env=env, cwd=ROOT)
+    assert r2.returncode == 0, r2.stdout[-500:] + r2.stderr[-800:]
+    l1 = json.loads([ln for ln in r1.stdout.splitlines() if ln.startswith("{")][-1])
+    l2 = json.loads([ln for ln in r2.stdout.splitlines() if ln.startswith("{")][-1])
+    assert l1["scaling"] == l2["scaling"] == "strong" and l2["n_gpus"] == 2
+    assert l1["config"]["job"]["frames"] == l2["config"]["job"]["frames"] == 24
+    assert open(o1, "rb").read() == open(o2, "rb").read()
+    if os.path.exists(REF_DEC):
+        d = subprocess.run([REF_DEC, "-b", str(o2), "-o", str(tmp_path / "d.yuv"), "-threads", "2"], capture_output=True, text=True, cwd=tmp_path)
+        assert "decoder passed" in d.stdout and os.path.getsize(tmp_path / "d.yuv") == 24 * 640 * 368 * 3 // 2
