@@ -462,7 +462,8 @@ def encoded_leg(args, torch, dist, rank, world, dev_index, backend, sync_all):
         _fields_ = [("naltype", C.c_int), ("tid", C.c_int), ("iSize", C.c_int), ("pts", C.c_longlong), ("pPayload", C.POINTER(C.c_ubyte))]
 
     class Stats(C.Structure):
-        _fields_ = [("frames", C.c_long), ("bytes", C.c_longlong), ("sse", C.c_double * 3), ("gpu_ms", C.c_double), ("host_write_ms", C.c_double)]
+        _fields_ = [("frames", C.c_long), ("bytes", C.c_longlong), ("sse", C.c_double * 3), ("gpu_ms", C.c_double), ("host_write_ms", C.c_double),
+                    ("in_copy_ms", C.c_double), ("submit_ms", C.c_double), ("output_ms", C.c_double), ("lat_gpu_ms", C.c_double), ("lat_queue_ms", C.c_double)]
 
     W, H = args.width, args.height
     try:
@@ -577,6 +578,8 @@ def encoded_leg(args, torch, dist, rank, world, dev_index, backend, sync_all):
                 "gop": f"hierarchical-B {args.hier_b}" if args.hier_b else (f"P + {gop_b} B" if gop_b else "IPPP")}
     return {"fps": world * args.steps / dt, "dt": dt, "host_threads": threads, "host_cores": cores, "bytes_per_picture": (state["bytes"] - b0) / args.steps,
             "psnr_y": 99.0 if mse == 0 else 10.0 * np.log10(255.0 ** 2 / mse), "slice_write_ms_per_picture": st.host_write_ms / max(1, st.frames), "preset": preset.decode(),
+            "caller_ms_per_picture": {"input_copy": round(st.in_copy_ms / max(1, st.frames), 3), "enqueue": round(st.submit_ms / max(1, st.frames), 3), "output": round(st.output_ms / max(1, st.frames), 3),
+                                      "latency_enqueue_to_records_on_host": round(st.lat_gpu_ms / max(1, st.frames), 2), "latency_enqueue_to_writer_pickup": round(st.lat_queue_ms / max(1, st.frames), 2)},
             "gop": f"hierarchical-B {args.hier_b}" if args.hier_b else (f"P + {gop_b} B" if gop_b else "IPPP")}
 
 
@@ -597,6 +600,7 @@ def encoded_line(args, enc, world, hot, cpu):
                    "pictures_per_step": 1, "host_threads_per_gpu": enc["host_threads"], "host_cores": enc["host_cores"],
                    "bytes_per_picture": int(enc["bytes_per_picture"]), "kbps_at_50fps": round(enc["bytes_per_picture"] * 8 * 50 / 1000.0, 1),
                    "slice_write_ms_per_picture_per_thread": round(enc["slice_write_ms_per_picture"], 2),
+                   "caller_ms_per_picture": enc.get("caller_ms_per_picture"),
                    "in_the_path": "sign-data hiding (signBitHidingHDQ), merge / skip SIGNALLING where the chosen motion equals a merge candidate, AMVP with the better of the two predictors",
                    "not_in_the_path": "rate-distortion optimised quantisation (the reference's -rdoq at -preset slow), merge / skip as a DECISION, intra CUs in P/B pictures, lookahead / cuTree: "
                                       "at the same QP the stream is several times larger than appencoder's (BASELINE.md §2b has the same-clip table)",

@@ -82,7 +82,10 @@ int QY265ConfigDefaultPreset(QY265EncConfig *pConfig, char *preset, char *tune, 
 int QY265ConfigParse(QY265EncConfig *p, const char *name, const char *value);
 
 /* not in the SDK: totals of the session for the CLI's summary lines */
-typedef struct { long frames; long long bytes; double sse[3]; double gpu_ms; double host_write_ms; } ks265_enc_stats;
+typedef struct { long frames; long long bytes; double sse[3]; double gpu_ms; double host_write_ms;
+                 double in_copy_ms, submit_ms, output_ms;   /* calling thread: input copy to pinned memory, enqueueing GPU work, waiting for / copying output */
+                 double lat_gpu_ms, lat_queue_ms;           /* summed per picture: enqueue -> records on the host; enqueue -> a writer thread picked the picture up */
+} ks265_enc_stats;
 int ks265_enc_get_stats(void *pEncoder, ks265_enc_stats *out);
 /* extension: write the reconstruction (I420, display order) to `path` - the reference CLI's `-o`; call between Open and the first picture */
 int ks265_enc_set_recon_file(void *pEncoder, const char *path);

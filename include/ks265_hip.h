@@ -61,10 +61,14 @@ int ks265_host_malloc(ks265_ctx *, void **host, size_t bytes);
 int ks265_host_free(ks265_ctx *, void *host);
 int ks265_memcpy_h2d_async(ks265_ctx *, void *dev, const void *host, size_t bytes);
 int ks265_memcpy_d2h_async(ks265_ctx *, void *host, const void *dev, size_t bytes);
+int ks265_memcpy_d2d_async(ks265_ctx *, void *dev_dst, const void *dev_src, size_t bytes);
 int ks265_memset_async(ks265_ctx *, void *dev, int value, size_t bytes);
 int ks265_event_create(ks265_ctx *, void **ev);
 int ks265_event_record(ks265_ctx *, void *ev);
 int ks265_event_wait(ks265_ctx *, void *ev);
+/* everything enqueued on this context's stream after the call waits for the event (recorded on ANOTHER context's stream of the same device):
+ * copy-in / compute / copy-out streams of a pipelined host hand pictures over without blocking a host thread */
+int ks265_stream_wait_event(ks265_ctx *, void *ev);
 int ks265_event_destroy(ks265_ctx *, void *ev);
 /* HIP-event timing on the context's stream (bench.py roofline leg) */
 /* a one-thread kernel named ks265_marker_kernel on the context's stream: brackets a region of interest in a kernel trace (profiling aid) */
@@ -327,6 +331,11 @@ int16_t *ks265_frame_levels(ks265_frame *f, int comp);
 ks265_pu *ks265_frame_pu(ks265_frame *f);
 ks265_cu8 *ks265_frame_cu8(ks265_frame *f);
 ks265_sao_param *ks265_frame_sao(ks265_frame *f);
+/* The records of the picture just coded as ONE contiguous block in HBM, so that a pipelined host needs one device-side copy and one D2H per
+ * picture: off[0..5] = byte offsets of { CU map, levels Y, Cb, Cr, SAO records, 64 caller-defined bytes (e.g. the three SSE sums) }, each
+ * aligned to 256, off[6] = size of the block.  ks265_frame_pack_records copies them there on the context's stream (dev_extra64 may be NULL). */
+int ks265_frame_records_layout(ks265_frame *f, size_t off[7]);
+int ks265_frame_pack_records(ks265_frame *f, void *dev_dst, const void *dev_extra64);
 uint8_t *ks265_frame_planes(ks265_frame *f);
 /* luma SSE between two padded pictures (PSNR-Y of the bench line; CPSNR_I420::calcPSNR enc@0x4c4060) */
 int ks265_sse_picture(ks265_frame *f, ks265_pic a, ks265_pic b, uint64_t *dev_sse3);

@@ -29,6 +29,7 @@ typedef struct {
     int32_t max_num_reorder;               /* pictures that may precede a picture in decoding order and follow it in output order   */
     int32_t log2_max_poc_lsb;              /* 4..16                                                                                 */
     int32_t sdh;                           /* sign_data_hiding_enabled_flag: the levels were produced with ks265_frame_cfg.sdh = 1                  */
+    int32_t wpp;                           /* entropy_coding_sync_enabled_flag: every CTU row is a substream with an entry point (the reference's WPP) */
 } ks265_stream_cfg;
 
 enum { KS265_SLICE_B = 0, KS265_SLICE_P = 1, KS265_SLICE_I = 2 };
@@ -66,6 +67,16 @@ long ks265_write_pps(const ks265_stream_cfg *cfg, uint8_t *out, size_t cap);
  * bytes. */
 size_t ks265_slice_scratch_bytes(const ks265_stream_cfg *cfg);
 long ks265_write_slice(const ks265_stream_cfg *cfg, const ks265_slice_in *in, void *scratch, uint8_t *out, size_t cap);
+
+/* cfg->wpp = 1: the same picture row by row, so that SEVERAL host threads can write one picture (the reference's WPP tasks, qy265executeEncCtuTaskWpp
+ * enc@0x475d20).  ks265_wpp_begin prepares the job in `mem` (ks265_wpp_bytes), ks265_wpp_code_row codes one CTU row into its substream - thread-safe for
+ * different rows; rows must be handed out in ascending order, a row waits while the row above is less than two CTUs ahead - and ks265_wpp_finish, after all
+ * rows, assembles slice header (entry points), substreams and emulation prevention into the NAL unit.  ks265_write_slice does exactly this on one thread. */
+size_t ks265_wpp_bytes(const ks265_stream_cfg *cfg);
+int ks265_wpp_begin(const ks265_stream_cfg *cfg, const ks265_slice_in *in, void *mem);
+int ks265_wpp_rows(const void *mem);
+int ks265_wpp_code_row(void *mem, int row);
+long ks265_wpp_finish(void *mem, uint8_t *out, size_t cap);
 
 #ifdef __cplusplus
 }

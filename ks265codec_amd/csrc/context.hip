@@ -110,6 +110,11 @@ int ks265_memcpy_d2h_async(ks265_ctx *c, void *host, const void *dev, size_t byt
     if (!c || !dev || !host) return KS265_POINTER;
     return ks265_hip(c, hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, c->stream));
 }
+int ks265_memcpy_d2d_async(ks265_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    if (!c || !dst || !src) return KS265_POINTER;
+    return ks265_hip(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->stream));
+}
 int ks265_memset_async(ks265_ctx *c, void *dev, int value, size_t bytes)
 {
     if (!c || !dev) return KS265_POINTER;
@@ -121,12 +126,15 @@ int ks265_event_create(ks265_ctx *c, void **ev)
     if (!c || !ev) return KS265_POINTER;
     (void)hipSetDevice(c->device);
     hipEvent_t e;
-    const int r = ks265_hip(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    const int r = ks265_hip(c, hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventBlockingSync)      /* a waiting host thread sleeps instead of spinning inside the runtime */);
     *ev = r ? nullptr : (void *)e;
     return r;
 }
 int ks265_event_record(ks265_ctx *c, void *ev) { return (!c || !ev) ? KS265_POINTER : ks265_hip(c, hipEventRecord((hipEvent_t)ev, c->stream)); }
 int ks265_event_wait(ks265_ctx *c, void *ev) { return (!c || !ev) ? KS265_POINTER : ks265_hip(c, hipEventSynchronize((hipEvent_t)ev)); }
+/* make everything enqueued on c's stream AFTER this call wait for the event (recorded on another context's stream): the hand-over between the
+ * copy-in, compute and copy-out streams of a pipelined host; no host thread blocks */
+int ks265_stream_wait_event(ks265_ctx *c, void *ev) { return (!c || !ev) ? KS265_POINTER : ks265_hip(c, hipStreamWaitEvent(c->stream, (hipEvent_t)ev, 0)); }
 int ks265_event_destroy(ks265_ctx *c, void *ev) { return (!c || !ev) ? KS265_POINTER : ks265_hip(c, hipEventDestroy((hipEvent_t)ev)); }
 
 const char *ks265_last_error(ks265_ctx *c) { return c ? c->last_error.c_str() : "null context"; }

@@ -211,6 +211,49 @@ int16_t *ks265_frame_levels(ks265_frame *f, int comp) { return f && comp >= 0 &&
 ks265_pu *ks265_frame_pu(ks265_frame *f) { return f ? f->pu[f->cur_pu ^ (f->have_prev ? 1 : 0)] : nullptr; }   /* records of the last coded P picture */
 ks265_cu8 *ks265_frame_cu8(ks265_frame *f) { return f ? f->cu8 : nullptr; }
 ks265_sao_param *ks265_frame_sao(ks265_frame *f) { return f ? f->sao : nullptr; }
+
+// ------------------------------------------------------------------ the records of one picture as ONE contiguous block (hosts: one copy-out per picture)
+struct PackSegs { const uint8_t *src[6]; unsigned long long off[6], bytes[6]; };
+__global__ __launch_bounds__(256) void pack_records_kernel(PackSegs sg, uint8_t *dst)
+{
+    const int seg = blockIdx.y;
+    const uint8_t *s = sg.src[seg];
+    if (!s) return;
+    uint8_t *d = dst + sg.off[seg];
+    const unsigned long long n16 = sg.bytes[seg] >> 4, n4 = (sg.bytes[seg] & 15) >> 2;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (unsigned long long)gridDim.x * 256)
+        ((uint4 *)d)[i] = ((const uint4 *)s)[i];
+    if (blockIdx.x == 0 && threadIdx.x < n4) ((unsigned *)(d + (n16 << 4)))[threadIdx.x] = ((const unsigned *)(s + (n16 << 4)))[threadIdx.x];
+}
+static void records_layout(const ks265_frame *f, size_t off[7])
+{
+    const size_t npx = (size_t)f->g.W * f->g.H;
+    const size_t sz[6] = {(size_t)f->geom.bytes_cu8, npx * 2, npx / 2, npx / 2, (size_t)f->geom.bytes_sao, 64};
+    size_t o = 0;
+    for (int i = 0; i < 6; ++i) { off[i] = o; o += (sz[i] + 255) & ~(size_t)255; }
+    off[6] = o;
+}
+int ks265_frame_records_layout(ks265_frame *f, size_t off[7])
+{
+    if (!f || !off) return KS265_POINTER;
+    records_layout(f, off);
+    return KS265_OK;
+}
+int ks265_frame_pack_records(ks265_frame *f, void *dev_dst, const void *dev_extra64)
+{
+    KS_FRAME_CHECK(f);
+    if (!dev_dst) return KS265_POINTER;
+    size_t off[7];
+    records_layout(f, off);
+    const size_t npx = (size_t)f->g.W * f->g.H;
+    PackSegs sg;
+    const void *src[6] = {f->cu8, f->lvl[0], f->lvl[1], f->lvl[2], f->sao, dev_extra64};
+    const size_t sz[6] = {(size_t)f->geom.bytes_cu8, npx * 2, npx / 2, npx / 2, (size_t)f->geom.bytes_sao, 64};
+    for (int i = 0; i < 6; ++i) { sg.src[i] = (const uint8_t *)src[i]; sg.off[i] = off[i]; sg.bytes[i] = sz[i]; }
+    const unsigned gx = (unsigned)((npx * 2 / 16 + 256 * 8 - 1) / (256 * 8));               // the largest segment: 8 x 16 bytes per thread
+    hipLaunchKernelGGL(pack_records_kernel, dim3(gx ? gx : 1, 6), dim3(256), 0, f->ctx->stream, sg, (uint8_t *)dev_dst);
+    return ks265_check_launch(f->ctx);
+}
 uint8_t *ks265_frame_planes(ks265_frame *f) { return f ? f->planes : nullptr; }
 
 }  // extern "C"

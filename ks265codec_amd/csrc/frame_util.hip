@@ -228,23 +228,30 @@ extern "C" int ks265_ref_planes(ks265_frame *f, ks265_pic ref, uint8_t *planes)
     return ks265_check_launch(f->ctx);
 }
 
-// ------------------------------------------------------------------ picture SSE (PSNR): sse3[0..2] += per-plane sums
-__global__ __launch_bounds__(256) void sse_plane_kernel(const uint8_t *a, const uint8_t *b, long stride, int w, int h, unsigned long long *out)
+// ------------------------------------------------------------------ picture SSE (PSNR): sse3[plane] += sum of squared differences
+// one launch for the three planes: blockIdx.y = plane, a work-group = 8 rows, a thread = dwords of one row (stride 32 dwords)
+__global__ __launch_bounds__(256) void sse_picture_kernel(KsGeom g, const uint8_t *ay, const uint8_t *au, const uint8_t *av, const uint8_t *by, const uint8_t *bu, const uint8_t *bv,
+                                                          unsigned long long *out)
 {
-    int x4 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4, y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int pl = blockIdx.y;
+    const int w = pl ? g.W / 2 : g.W, h = pl ? g.H / 2 : g.H;
+    const long stride = pl ? g.sc : g.sy, org = pl ? g.org_c : g.org_y;
+    const uint8_t *a = (pl == 0 ? ay : pl == 1 ? au : av) + org, *b = (pl == 0 ? by : pl == 1 ? bu : bv) + org;
+    const int y = blockIdx.x * 8 + (threadIdx.x >> 5);
     unsigned s = 0;
-    if (x4 < w && y < h) {
-        unsigned va = *(const unsigned *)(a + y * stride + x4), vb = *(const unsigned *)(b + y * stride + x4);
+    if (y < h)
+        for (int x4 = (threadIdx.x & 31) * 4; x4 < w; x4 += 128) {
+            const unsigned va = *(const unsigned *)(a + y * stride + x4), vb = *(const unsigned *)(b + y * stride + x4);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { int d = (int)((va >> (8 * i)) & 255) - (int)((vb >> (8 * i)) & 255); s += (unsigned)(d * d); }
-    }
-    s = wave_sum(s);
+            for (int i = 0; i < 4; ++i) { const int d = (int)((va >> (8 * i)) & 255) - (int)((vb >> (8 * i)) & 255); s += (unsigned)(d * d); }
+        }
+    s = wave_sum(s);                                                 // <= 8 rows x 4096 samples x 255^2 per work-group: fits 32 bits up to 8K pictures
     __shared__ unsigned part[4];
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned t = part[0] + part[1] + part[2] + part[3];
-        if (t) atomicAdd(out, (unsigned long long)t);
+        const unsigned long long t = (unsigned long long)part[0] + part[1] + part[2] + part[3];
+        if (t) atomicAdd(out + pl, t);
     }
 }
 
@@ -252,12 +259,8 @@ extern "C" int ks265_sse_picture(ks265_frame *f, ks265_pic a, ks265_pic b, uint6
 {
     KS_FRAME_CHECK(f);
     if (!sse3) return KS265_POINTER;
-    int W = f->g.W, H = f->g.H;
     hipError_t e = hipMemsetAsync(sse3, 0, 3 * sizeof(uint64_t), f->ctx->stream);
     if (e != hipSuccess) return ks265_hip(f->ctx, e);
-    unsigned long long *o = (unsigned long long *)sse3;
-    hipLaunchKernelGGL(sse_plane_kernel, dim3((W / 4 + 63) / 64, (H + 3) / 4), dim3(256), 0, f->ctx->stream, a.y + f->g.org_y, b.y + f->g.org_y, (long)f->g.sy, W, H, o);
-    hipLaunchKernelGGL(sse_plane_kernel, dim3((W / 8 + 63) / 64, (H / 2 + 3) / 4), dim3(256), 0, f->ctx->stream, a.u + f->g.org_c, b.u + f->g.org_c, (long)f->g.sc, W / 2, H / 2, o + 1);
-    hipLaunchKernelGGL(sse_plane_kernel, dim3((W / 8 + 63) / 64, (H / 2 + 3) / 4), dim3(256), 0, f->ctx->stream, a.v + f->g.org_c, b.v + f->g.org_c, (long)f->g.sc, W / 2, H / 2, o + 2);
+    hipLaunchKernelGGL(sse_picture_kernel, dim3((unsigned)((f->g.H + 7) / 8), 3), dim3(256), 0, f->ctx->stream, f->g, a.y, a.u, a.v, b.y, b.u, b.v, (unsigned long long *)sse3);
     return ks265_check_launch(f->ctx);
 }

@@ -90,6 +90,8 @@ int main(int argc, char **argv)
     ks265_enc_get_stats(h, &st);
     printf("Total Frames: %ld, test time: %.0f ms, FPS: %.4f\n", n, t1 - t0, n * 1000.0 / (t1 - t0));
     printf("pure encoding time: %.0f ms (input read %.0f ms), slice writing %.1f ms per picture per thread\n", t1 - t0 - t_io, t_io, st.frames ? st.host_write_ms / st.frames : 0.0);
+    printf("calling thread: input copy %.0f ms, enqueueing GPU work %.0f ms, output (wait + copy) %.0f ms\n", st.in_copy_ms, st.submit_ms, st.output_ms);
+    printf("per picture: enqueue -> records on the host %.2f ms, enqueue -> writer pick-up %.2f ms\n", st.frames ? st.lat_gpu_ms / st.frames : 0.0, st.frames ? st.lat_queue_ms / st.frames : 0.0);
     QY265EncoderClose(h);                                            /* prints "bitrate, psnr: ..." */
     puts("H265 encoder passed!!!");
     free(buf); fclose(fi); if (fo) fclose(fo);

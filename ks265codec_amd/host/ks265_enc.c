@@ -3,8 +3,9 @@
  *
  * Plain C host over two C ABIs: libks265hip.so (the pixel path on the MI355X, include/ks265_hip.h) and the bitstream writer
  * (ks265_stream.c).  What the reference's host does per frame (CHevcEncode::encodeFrame enc@0x4b9930, §3.2) maps to:
- *   input picture -> pinned host copy -> H2D -> ks265_encode_picture[_b/_mref] (all pixel stages on the GPU's stream)
- *   -> D2H of the CU map / levels / SAO records (pinned, stream ordered) -> event
+ *   input picture -> pinned host copy -> H2D (copy-in stream) -> ks265_encode_picture[_b/_mref] (all pixel stages on the compute stream)
+ *   -> records to a staging set (D2D) -> D2H of the CU map / levels / SAO records (copy-out stream, pinned) -> event; the three streams hand
+ *      over by events, so the copies of neighbouring pictures run under the kernels of the current one
  *   -> a host thread waits for the event and writes the slice NAL (CABAC), one picture per thread, pictures of a GOP in parallel
  *   -> NAL units are handed out in coding order (the SDK's asynchronous contract: output lags input).
  * GOP structures: IPPP (optionally several list-0 pictures), anchor + n non-reference B, hierarchical-B mini-GOPs of 8 (the SDK's
@@ -109,20 +110,23 @@ int QY265ConfigParse(QY265EncConfig *c, const char *name, const char *value)
 
 /* ------------------------------------------------------------------ encoder */
 #define MAX_DPB 12
-#define MAX_JOBS 48
-#define MAX_INPUT 64
+#define MAX_JOBS 128                                      /* upper bound of the ring of pictures in flight; the encoder sizes its ring (Enc::ring) by picture size */
+#define MAX_INPUT (MAX_JOBS + 16)
 
 typedef struct Job {
     int used, done, error;
     int disp, poc, kind, qp, nal_type, is_ref;            /* kind: 'I' 'P' 'B' */
     long long pts;
     int nl0, nl1, l0[4], l1[4], nrps, rps_poc[16]; unsigned char rps_used[16];
-    ks265_cu8 *cu8; int16_t *lvl[3]; ks265_sao_param *sao; uint64_t *sse;      /* pinned host copies of the GPU's records */
+    uint8_t *rec;                                         /* pinned host copy of the GPU's records: one block (ks265_frame_records_layout) */
+    ks265_cu8 *cu8; int16_t *lvl[3]; ks265_sao_param *sao; uint64_t *sse;      /* pointers into rec */
+    int ev_err;
+    void *wpp; ks265_slice_in sin; int started, nrows, next_row, rows_done;   /* row-wise writing of the slice (ks265_wpp_*) */
     uint8_t *recon;                                       /* pinned I420 copy of the reconstruction (only with ks265_enc_set_recon_file) */
     void *ev;                                             /* recorded after the D2H copies */
     uint8_t *nal; size_t nal_cap; long nal_len;
     int key_headers;                                      /* parameter sets go in front of this picture */
-    double t_write_ms;
+    double t_write_ms, t_submit, t_event, t_taken;      /* wall-clock marks: enqueued, records on the host (seen by a writer), writer started */
 } Job;
 
 typedef struct Input { int used, disp; long long pts; uint8_t *i420; } Input;          /* pinned */
@@ -133,20 +137,28 @@ typedef struct Enc {
     int me_method, hex_thr, subme, refs, use_sao, use_df, gop_b, hier;                  /* resolved tools */
     int base_qp, iper, nthreads;
     ks265_ctx *ctx; ks265_frame *frame; ks265_frame_geom geom; ks265_frame_cfg fcfg; ks265_stream_cfg scfg;
-    /* device */
+    /* device: three streams - copy-in (ctx_in), the pixel path (ctx), copy-out (ctx_out) - so that the H2D of picture n+1 and the D2H of
+     * picture n-1 run under the kernels of picture n.  Hand-over by events only (no host thread blocks): input buffers and output staging
+     * sets rotate over NPIPE slots. */
+#define NPIPE 3
+    ks265_ctx *ctx_in, *ctx_out;
+    uint8_t *dev_in[NPIPE]; void *ev_h2d[NPIPE], *ev_loaded[NPIPE];
+    uint8_t *stg[NPIPE]; size_t rec_off[7];               /* staging blocks of the records (device) and their layout */
+    void *ev_staged[NPIPE], *ev_drained[NPIPE];
+    long seq;                                             /* pictures submitted */
     int recon_fd; uint8_t *dev_recon;                     /* reconstruction dump (the CLI's -o) */
-    uint8_t *dev_i420; ks265_pic src; ks265_pic dpb[MAX_DPB]; int dpb_poc[MAX_DPB]; int ndpb; uint64_t *dev_sse;
+    ks265_pic src; ks265_pic dpb[MAX_DPB]; int dpb_poc[MAX_DPB]; int ndpb; uint64_t *dev_sse;
     /* scheduling */
     Input in[MAX_INPUT]; int next_disp;                   /* display index of the next input picture */
     int gop_start;                                        /* display index of the last key picture */
     int coded_upto;                                       /* display index up to which everything is scheduled */
     int force_key;
-    Job jobs[MAX_JOBS]; int job_head, job_tail, njobs;    /* ring in coding order */
+    Job jobs[MAX_JOBS]; int ring, job_head, job_tail, njobs;   /* ring of `ring` pictures in coding order */
     /* workers */
     pthread_t th[64]; int nth; pthread_mutex_t mu; pthread_cond_t cv_work, cv_done; int quit;
-    int next_work, npending;                              /* ring index of the next job to write, jobs submitted but not yet taken by a writer */
+    int next_work, npending;                              /* ring index of the next job to write, jobs whose records are on the host but not yet taken by a writer */
+    pthread_t disp; int disp_on; pthread_cond_t cv_disp; int next_ready, nwait;   /* the one thread that waits for GPU events (in submission order) */
     struct WorkerArg { struct Enc *e; int idx; } warg[64];
-    void *scratch[64];
     /* output */
     QY265Nal nals[4 * MAX_JOBS + 8]; uint8_t *hdr; long hdr_len, hdr_part[3];
     uint8_t *outbuf; size_t outcap, outpos;               /* NAL payloads handed to the caller live here until the next call */
@@ -167,39 +179,99 @@ static int pic_alloc(Enc *e, ks265_pic *p)
 }
 static void pic_free(Enc *e, ks265_pic *p) { ks265_dev_free(e->ctx, p->y); ks265_dev_free(e->ctx, p->u); ks265_dev_free(e->ctx, p->v); p->y = p->u = p->v = NULL; }
 
-/* ---- slice writers: one picture per thread */
+/* ---- the dispatcher: ONE host thread waits for the pictures' events, in submission order (the copy-out stream finishes them in that order), and
+ *      releases them to the writers.  Writers that waited inside the GPU runtime themselves would contend with the calling thread's enqueues. */
+static void *dispatcher(void *arg)
+{
+    Enc *e = (Enc *)arg;
+    pthread_mutex_lock(&e->mu);
+    for (;;) {
+        while (!e->quit && e->nwait == 0) pthread_cond_wait(&e->cv_disp, &e->mu);
+        if (e->quit) break;
+        Job *j = &e->jobs[e->next_ready];
+        pthread_mutex_unlock(&e->mu);
+        const int err = ks265_event_wait(e->ctx_out, j->ev);
+        j->t_event = now_ms();
+        pthread_mutex_lock(&e->mu);
+        j->ev_err = err;
+        e->next_ready = (e->next_ready + 1) % e->ring; --e->nwait; ++e->npending;
+        pthread_cond_broadcast(&e->cv_work);
+    }
+    pthread_mutex_unlock(&e->mu);
+    return NULL;
+}
+
+/* ---- slice writers.  Every picture is written as CTU-row substreams (entropy_coding_sync, the reference's WPP: ks265_wpp_*).  A writer thread takes
+ *      the next picture and codes its rows one after the other - pictures of a GOP in parallel, no waiting inside a picture.  A key picture's slice is
+ *      an order of magnitude longer than a P picture's and output is in coding order, so idle writers JOIN a key picture that is in progress: its rows
+ *      are handed out in ascending order, each row runs at most two CTUs behind the row above (the wavefront of qy265executeEncCtuTaskWpp enc@0x475d20). */
+static Job *find_helpable(Enc *e)
+{
+    for (int i = 0, k = e->job_head; i < e->njobs; ++i, k = (k + 1) % e->ring) {
+        Job *j = &e->jobs[k];
+        if (j->used && j->started && !j->done && j->kind == 'I' && j->next_row < j->nrows) return j;
+    }
+    return NULL;
+}
 static void *worker(void *arg)
 {
     Enc *e = ((struct WorkerArg *)arg)->e;
-    const int me = ((struct WorkerArg *)arg)->idx;
     pthread_mutex_lock(&e->mu);
     for (;;) {
-        while (!e->quit && e->npending == 0) pthread_cond_wait(&e->cv_work, &e->mu);
+        Job *j = NULL;
+        int owner = 0;
+        while (!e->quit) {
+            if (e->npending > 0) { j = &e->jobs[e->next_work]; e->next_work = (e->next_work + 1) % e->ring; --e->npending; owner = 1; break; }
+            if ((j = find_helpable(e)) != NULL) break;
+            pthread_cond_wait(&e->cv_work, &e->mu);
+        }
         if (e->quit) break;
-        Job *j = &e->jobs[e->next_work];
-        e->next_work = (e->next_work + 1) % MAX_JOBS; --e->npending;
-        pthread_mutex_unlock(&e->mu);
-        int err = ks265_event_wait(e->ctx, j->ev);               /* the records of this picture have reached the host */
-        if (!err && e->recon_fd >= 0 && j->recon) {
-            const size_t fsz = (size_t)e->W * e->H * 3 / 2;
-            if (pwrite(e->recon_fd, j->recon, fsz, (off_t)j->disp * (off_t)fsz) != (ssize_t)fsz) err = KS265_FAIL;
+        if (owner) {
+            pthread_mutex_unlock(&e->mu);
+            j->t_taken = now_ms();
+            int err = j->ev_err;                                 /* the dispatcher saw this picture's records reach the host */
+            if (!err && e->recon_fd >= 0 && j->recon) {
+                const size_t fsz = (size_t)e->W * e->H * 3 / 2;
+                if (pwrite(e->recon_fd, j->recon, fsz, (off_t)j->disp * (off_t)fsz) != (ssize_t)fsz) err = KS265_FAIL;
+            }
+            if (!err) {
+                ks265_slice_in *s = &j->sin;
+                memset(s, 0, sizeof *s);
+                s->nal_type = j->nal_type; s->slice_type = j->kind == 'I' ? KS265_SLICE_I : j->kind == 'P' ? KS265_SLICE_P : KS265_SLICE_B;
+                s->poc = j->poc; s->qp = j->qp; s->num_rps = j->nrps;
+                memcpy(s->rps_poc, j->rps_poc, sizeof s->rps_poc); memcpy(s->rps_used, j->rps_used, sizeof s->rps_used);
+                s->num_l0 = j->nl0; s->num_l1 = j->nl1; memcpy(s->l0_poc, j->l0, sizeof s->l0_poc); memcpy(s->l1_poc, j->l1, sizeof s->l1_poc);
+                s->cu8 = j->cu8; s->lvl[0] = j->lvl[0]; s->lvl[1] = j->lvl[1]; s->lvl[2] = j->lvl[2]; s->sao = e->use_sao ? j->sao : NULL;
+                err = ks265_wpp_begin(&e->scfg, s, j->wpp);
+            }
+            pthread_mutex_lock(&e->mu);
+            j->t_write_ms = 0;
+            if (err) {                                           /* nothing to write: the picture is finished (with its error) */
+                j->error = err; j->done = 1;
+                pthread_cond_broadcast(&e->cv_done);
+                continue;
+            }
+            j->nrows = ks265_wpp_rows(j->wpp); j->next_row = 0; j->rows_done = 0; j->started = 1;
+            if (j->kind == 'I') pthread_cond_broadcast(&e->cv_work);   /* idle writers may join */
         }
-        const double t0 = now_ms();
-        if (!err) {
-            ks265_slice_in s;
-            memset(&s, 0, sizeof s);
-            s.nal_type = j->nal_type; s.slice_type = j->kind == 'I' ? KS265_SLICE_I : j->kind == 'P' ? KS265_SLICE_P : KS265_SLICE_B;
-            s.poc = j->poc; s.qp = j->qp; s.num_rps = j->nrps;
-            memcpy(s.rps_poc, j->rps_poc, sizeof s.rps_poc); memcpy(s.rps_used, j->rps_used, sizeof s.rps_used);
-            s.num_l0 = j->nl0; s.num_l1 = j->nl1; memcpy(s.l0_poc, j->l0, sizeof s.l0_poc); memcpy(s.l1_poc, j->l1, sizeof s.l1_poc);
-            s.cu8 = j->cu8; s.lvl[0] = j->lvl[0]; s.lvl[1] = j->lvl[1]; s.lvl[2] = j->lvl[2]; s.sao = e->use_sao ? j->sao : NULL;
-            j->nal_len = ks265_write_slice(&e->scfg, &s, e->scratch[me], j->nal, j->nal_cap);
-            if (j->nal_len < 0) err = (int)j->nal_len;
+        while (j->next_row < j->nrows) {
+            const int row = j->next_row++;
+            pthread_mutex_unlock(&e->mu);
+            const double t0 = now_ms();
+            (void)ks265_wpp_code_row(j->wpp, row);               /* a failure is kept in the job memory and reported by ks265_wpp_finish */
+            const double dt = now_ms() - t0;
+            pthread_mutex_lock(&e->mu);
+            j->t_write_ms += dt;
+            if (++j->rows_done == j->nrows) {                    /* the thread that finishes the last row assembles the NAL unit */
+                pthread_mutex_unlock(&e->mu);
+                const double t1 = now_ms();
+                const long n = ks265_wpp_finish(j->wpp, j->nal, j->nal_cap);
+                pthread_mutex_lock(&e->mu);
+                j->t_write_ms += now_ms() - t1;
+                j->nal_len = n; j->error = n < 0 ? (int)n : 0; j->done = 1;
+                pthread_cond_broadcast(&e->cv_done);
+            }
         }
-        j->t_write_ms = now_ms() - t0;
-        pthread_mutex_lock(&e->mu);
-        j->error = err; j->done = 1;
-        pthread_cond_broadcast(&e->cv_done);
     }
     pthread_mutex_unlock(&e->mu);
     return NULL;
@@ -221,12 +293,20 @@ static int submit(Enc *e, Input *in, int kind, int poc, int qp, const int *l0, i
 {
     /* wait for a free job slot (the ring is full only if the consumer did not drain it: block on the oldest) */
     pthread_mutex_lock(&e->mu);
-    while (e->njobs == MAX_JOBS) pthread_cond_wait(&e->cv_done, &e->mu);       /* drained by take_output() of the calling thread itself: never full here */
+    while (e->njobs == e->ring) pthread_cond_wait(&e->cv_done, &e->mu);       /* drained by take_output() of the calling thread itself: never full here */
     Job *j = &e->jobs[e->job_tail];
     pthread_mutex_unlock(&e->mu);
-    const size_t fsz = (size_t)e->W * e->H * 3 / 2, npx = (size_t)e->W * e->H;
-    int r = ks265_memcpy_h2d_async(e->ctx, e->dev_i420, in->i420, fsz);
-    if (!r) r = ks265_load_i420(e->frame, e->dev_i420, e->src);
+    const size_t fsz = (size_t)e->W * e->H * 3 / 2;
+    const int k = (int)(e->seq % NPIPE);
+    const int recycled = e->seq >= NPIPE;
+    /* copy-in stream: the slot's previous picture must have been unpacked before the buffer is overwritten */
+    int r = recycled ? ks265_stream_wait_event(e->ctx_in, e->ev_loaded[k]) : 0;
+    if (!r) r = ks265_memcpy_h2d_async(e->ctx_in, e->dev_in[k], in->i420, fsz);
+    if (!r) r = ks265_event_record(e->ctx_in, e->ev_h2d[k]);
+    /* pixel path */
+    if (!r) r = ks265_stream_wait_event(e->ctx, e->ev_h2d[k]);
+    if (!r) r = ks265_load_i420(e->frame, e->dev_in[k], e->src);
+    if (!r) r = ks265_event_record(e->ctx, e->ev_loaded[k]);
     if (!r) r = ks265_frame_set_qp(e->frame, qp, kLambdaQ4[qp]);
     int keep[20], nk = 0;
     for (int i = 0; i < nkeep; ++i) keep[nk++] = keep_after[i];
@@ -243,18 +323,22 @@ static int submit(Enc *e, Input *in, int kind, int poc, int qp, const int *l0, i
     }
     e->dpb_poc[slot] = poc;
     if (!r && e->cfg.calcPsnr) r = ks265_sse_picture(e->frame, e->src, out, e->dev_sse);
-    if (!r) r = ks265_memcpy_d2h_async(e->ctx, j->cu8, ks265_frame_cu8(e->frame), (size_t)e->geom.bytes_cu8);
-    if (!r) r = ks265_memcpy_d2h_async(e->ctx, j->lvl[0], ks265_frame_levels(e->frame, 0), npx * 2);
-    if (!r) r = ks265_memcpy_d2h_async(e->ctx, j->lvl[1], ks265_frame_levels(e->frame, 1), npx / 2);
-    if (!r) r = ks265_memcpy_d2h_async(e->ctx, j->lvl[2], ks265_frame_levels(e->frame, 2), npx / 2);
-    if (!r) r = ks265_memcpy_d2h_async(e->ctx, j->sao, ks265_frame_sao(e->frame), (size_t)e->geom.bytes_sao);
-    if (!r && e->cfg.calcPsnr) r = ks265_memcpy_d2h_async(e->ctx, j->sse, e->dev_sse, 3 * sizeof(uint64_t));
     if (!r && e->recon_fd >= 0) {
         r = ks265_store_i420(e->frame, out, e->dev_recon);
         if (!r) r = ks265_memcpy_d2h_async(e->ctx, j->recon, e->dev_recon, fsz);
     }
-    if (!r) r = ks265_event_record(e->ctx, j->ev);
+    /* the records leave the frame object's buffers for a staging set (device to device, a few microseconds), so that the next picture can start
+     * while the copy-out stream drains this one */
+    if (!r && recycled) r = ks265_stream_wait_event(e->ctx, e->ev_drained[k]);
+    if (!r) r = ks265_frame_pack_records(e->frame, e->stg[k], e->cfg.calcPsnr ? e->dev_sse : NULL);
+    if (!r) r = ks265_event_record(e->ctx, e->ev_staged[k]);
+    /* copy-out stream */
+    if (!r) r = ks265_stream_wait_event(e->ctx_out, e->ev_staged[k]);
+    if (!r) r = ks265_memcpy_d2h_async(e->ctx_out, j->rec, e->stg[k], e->rec_off[6]);
+    if (!r) r = ks265_event_record(e->ctx_out, e->ev_drained[k]);
+    if (!r) r = ks265_event_record(e->ctx_out, j->ev);
     if (r) return hip_rc(r);
+    ++e->seq;
     j->disp = in->disp; j->pts = in->pts; j->poc = poc; j->kind = kind; j->qp = qp; j->is_ref = is_ref; j->key_headers = key_headers;
     j->nal_type = kind == 'I' ? KS265_NAL_IDR_W_RADL : is_ref ? KS265_NAL_TRAIL_R : KS265_NAL_TRAIL_N;
     j->nl0 = nl0; j->nl1 = nl1;
@@ -272,11 +356,12 @@ static int submit(Enc *e, Input *in, int kind, int poc, int qp, const int *l0, i
             for (int q = 0; q < nl1; ++q) if (l1[q] == keep[i]) used = 1;
             j->rps_poc[j->nrps] = keep[i]; j->rps_used[j->nrps++] = (unsigned char)used;
         }
+    j->t_submit = now_ms();
     in->used = 2;                                                      /* released when the job's event has fired (output time) */
     pthread_mutex_lock(&e->mu);
-    j->done = 0; j->error = 0; j->used = 1;
-    e->job_tail = (e->job_tail + 1) % MAX_JOBS; ++e->njobs; ++e->npending;
-    pthread_cond_broadcast(&e->cv_work);
+    j->done = 0; j->error = 0; j->used = 1; j->started = 0; j->nrows = 0; j->next_row = 0; j->rows_done = 0;
+    e->job_tail = (e->job_tail + 1) % e->ring; ++e->njobs; ++e->nwait;
+    pthread_cond_signal(&e->cv_disp);
     pthread_mutex_unlock(&e->mu);
     return QY_OK;
 }
@@ -387,6 +472,7 @@ static int take_output(Enc *e, int max_in_flight, QY265Nal **pNals, int *n, QY26
         ++cnt;
         if (out) { out->iSliceType = j->kind == 'I' ? 2 : j->kind == 'P' ? 1 : 0; out->poc = j->disp; out->pts = j->pts; out->dts = j->pts; }
         e->st.frames++; e->st.bytes += j->nal_len > 0 ? j->nal_len : 0; e->st.host_write_ms += j->t_write_ms;
+        e->st.lat_gpu_ms += j->t_event - j->t_submit; e->st.lat_queue_ms += j->t_taken - j->t_submit;
         if (j->key_headers && e->cfg.bHeaderBeforeKeyframe) e->st.bytes += e->hdr_len;
         if (e->cfg.calcPsnr) {
             for (int k = 0; k < 3; ++k) e->st.sse[k] += (double)j->sse[k];
@@ -408,7 +494,7 @@ static int take_output(Enc *e, int max_in_flight, QY265Nal **pNals, int *n, QY26
         }
         for (int i = 0; i < MAX_INPUT; ++i) if (e->in[i].used == 2 && e->in[i].disp == j->disp) e->in[i].used = 0;
         j->used = 0;
-        e->job_head = (e->job_head + 1) % MAX_JOBS; --e->njobs;
+        e->job_head = (e->job_head + 1) % e->ring; --e->njobs;
         if (cnt >= (int)(sizeof e->nals / sizeof e->nals[0]) - 4) break;
     }
     pthread_mutex_unlock(&e->mu);
@@ -420,12 +506,15 @@ void QY265EncoderClose(void *h)
 {
     Enc *e = (Enc *)h;
     if (!e) return;
-    if (e->nth) {
-        pthread_mutex_lock(&e->mu); e->quit = 1; pthread_cond_broadcast(&e->cv_work); pthread_mutex_unlock(&e->mu);
+    if (e->nth || e->disp_on) {
+        pthread_mutex_lock(&e->mu); e->quit = 1; pthread_cond_broadcast(&e->cv_work); pthread_cond_broadcast(&e->cv_disp); pthread_mutex_unlock(&e->mu);
         for (int i = 0; i < e->nth; ++i) pthread_join(e->th[i], NULL);
+        if (e->disp_on) pthread_join(e->disp, NULL);
     }
     if (e->ctx) {
+        if (e->ctx_in) ks265_synchronize(e->ctx_in);
         ks265_synchronize(e->ctx);
+        if (e->ctx_out) ks265_synchronize(e->ctx_out);
         if (e->cfg.calcPsnr && e->st.frames) {
             const double np[3] = {(double)e->W * e->H, (double)e->W * e->H / 4, (double)e->W * e->H / 4};
             double ps[3];
@@ -434,22 +523,30 @@ void QY265EncoderClose(void *h)
         }
         for (int i = 0; i < MAX_JOBS; ++i) {
             Job *j = &e->jobs[i];
-            ks265_host_free(e->ctx, j->cu8); ks265_host_free(e->ctx, j->lvl[0]); ks265_host_free(e->ctx, j->lvl[1]); ks265_host_free(e->ctx, j->lvl[2]);
-            ks265_host_free(e->ctx, j->sao); ks265_host_free(e->ctx, j->sse); ks265_host_free(e->ctx, j->recon);
+            ks265_host_free(e->ctx, j->rec); ks265_host_free(e->ctx, j->recon);
             if (j->ev) ks265_event_destroy(e->ctx, j->ev);
             free(j->nal);
         }
         for (int i = 0; i < MAX_INPUT; ++i) ks265_host_free(e->ctx, e->in[i].i420);
         for (int i = 0; i < e->ndpb; ++i) pic_free(e, &e->dpb[i]);
         pic_free(e, &e->src);
-        ks265_dev_free(e->ctx, e->dev_i420); ks265_dev_free(e->ctx, e->dev_sse); ks265_dev_free(e->ctx, e->dev_recon);
+        for (int k = 0; k < NPIPE; ++k) {
+            ks265_dev_free(e->ctx, e->dev_in[k]); ks265_dev_free(e->ctx, e->stg[k]);
+            if (e->ev_h2d[k]) ks265_event_destroy(e->ctx, e->ev_h2d[k]);
+            if (e->ev_loaded[k]) ks265_event_destroy(e->ctx, e->ev_loaded[k]);
+            if (e->ev_staged[k]) ks265_event_destroy(e->ctx, e->ev_staged[k]);
+            if (e->ev_drained[k]) ks265_event_destroy(e->ctx, e->ev_drained[k]);
+        }
+        ks265_dev_free(e->ctx, e->dev_sse); ks265_dev_free(e->ctx, e->dev_recon);
         if (e->recon_fd >= 0) close(e->recon_fd);
         if (e->frame) ks265_frame_destroy(e->frame);
+        if (e->ctx_in) ks265_destroy(e->ctx_in);
+        if (e->ctx_out) ks265_destroy(e->ctx_out);
         ks265_destroy(e->ctx);
     }
-    for (int i = 0; i < 64; ++i) free(e->scratch[i]);
+    for (int i = 0; i < MAX_JOBS; ++i) free(e->jobs[i].wpp);
     free(e->hdr); free(e->outbuf);
-    pthread_mutex_destroy(&e->mu); pthread_cond_destroy(&e->cv_work); pthread_cond_destroy(&e->cv_done);
+    pthread_mutex_destroy(&e->mu); pthread_cond_destroy(&e->cv_work); pthread_cond_destroy(&e->cv_done); pthread_cond_destroy(&e->cv_disp);
     free(e);
 }
 
@@ -462,7 +559,7 @@ void *QY265EncoderOpen(QY265EncConfig *cfg, int *err)
     Enc *e = (Enc *)calloc(1, sizeof *e);
     if (e) e->recon_fd = -1;
     if (!e) { *err = QY_OUTOFMEMORY; return NULL; }
-    pthread_mutex_init(&e->mu, NULL); pthread_cond_init(&e->cv_work, NULL); pthread_cond_init(&e->cv_done, NULL);
+    pthread_mutex_init(&e->mu, NULL); pthread_cond_init(&e->cv_work, NULL); pthread_cond_init(&e->cv_done, NULL); pthread_cond_init(&e->cv_disp, NULL);
     e->cfg = *cfg; e->W = cfg->picWidth; e->H = cfg->picHeight; e->log_level = cfg->logLevel;
     e->me_method = cfg->me < 0 ? 1 : cfg->me > 2 ? 2 : cfg->me;        /* EPZS / Cross (-me 3 / 4) are not built: UMH instead */
     e->hex_thr = (e->me_method == 2 && (cfg->preset == QY265PRESET_SLOW || cfg->preset == QY265PRESET_SLOWER)) ? 16 : 0;   /* tME+0x368, SURVEY-measured */
@@ -480,7 +577,7 @@ void *QY265EncoderOpen(QY265EncConfig *cfg, int *err)
     long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
     e->nthreads = cfg->threads > 0 ? cfg->threads : (int)(ncpu > 0 ? ncpu : 4);
     if (e->nthreads > 64) e->nthreads = 64;
-    if (e->nthreads > MAX_JOBS - 14) e->nthreads = MAX_JOBS - 14;             /* more writers than pictures that can be in flight would idle */
+
     if (cfg->rdoq || cfg->transskip || cfg->part || cfg->iAqMode) logf_(1, e->log_level, "ks265enc: rdoq / transskip / part / aq are accepted but not implemented by the pixel path\n");
     if (cfg->rc == 5 || cfg->vbv_buffer_size) logf_(1, e->log_level, "ks265enc: CVQ / VBV are not implemented; running the plain controller\n");
 
@@ -499,30 +596,47 @@ void *QY265EncoderOpen(QY265EncConfig *cfg, int *err)
     r = ks265_frame_geometry(&e->fcfg, &e->geom);
     if (!r) r = ks265_frame_create(e->ctx, &e->fcfg, &e->frame);
     const size_t fsz = (size_t)e->W * e->H * 3 / 2, npx = (size_t)e->W * e->H;
-    if (!r) r = ks265_dev_malloc(e->ctx, (void **)&e->dev_i420, fsz);
+    const int dev_id = dev_env ? atoi(dev_env) : 0;
+    if (!r) r = ks265_frame_records_layout(e->frame, e->rec_off);
+    if (!r) r = ks265_create(&e->ctx_in, dev_id);
+    if (!r) r = ks265_create(&e->ctx_out, dev_id);
+    for (int k = 0; k < NPIPE && !r; ++k) {
+        r = ks265_dev_malloc(e->ctx, (void **)&e->dev_in[k], fsz);
+        if (!r) r = ks265_dev_malloc(e->ctx, (void **)&e->stg[k], e->rec_off[6]);
+        if (!r) r = ks265_event_create(e->ctx, &e->ev_h2d[k]);
+        if (!r) r = ks265_event_create(e->ctx, &e->ev_loaded[k]);
+        if (!r) r = ks265_event_create(e->ctx, &e->ev_staged[k]);
+        if (!r) r = ks265_event_create(e->ctx, &e->ev_drained[k]);
+    }
     if (!r) r = ks265_dev_malloc(e->ctx, (void **)&e->dev_sse, 64);
     if (!r) r = pic_alloc(e, &e->src);
     e->ndpb = e->hier ? 10 : e->gop_b ? 4 : e->refs + 2;
     for (int i = 0; i < e->ndpb && !r; ++i) { r = pic_alloc(e, &e->dpb[i]); e->dpb_poc[i] = -1000000; }
-    const int njobs_alloc = MAX_JOBS;
+    /* ring of pictures in flight: a key picture's slice takes one writer thread many picture periods, and output is in coding order - the ring must
+     * hold everything that is coded meanwhile, or the GPU idles behind it.  About 4 GB of pinned records, at least 24 and at most MAX_JOBS pictures. */
+    e->ring = (int)(((size_t)4 << 30) / (e->rec_off[6] + fsz));
+    if (e->ring > MAX_JOBS) e->ring = MAX_JOBS;
+    if (e->ring < 24) e->ring = 24;
+    if (e->nthreads > e->ring - 14) e->nthreads = e->ring - 14;               /* more writers than pictures that can be in flight would idle */
+    const int njobs_alloc = e->ring;
     for (int i = 0; i < njobs_alloc && !r; ++i) {
         Job *j = &e->jobs[i];
-        r = ks265_host_malloc(e->ctx, (void **)&j->cu8, (size_t)e->geom.bytes_cu8);
-        if (!r) r = ks265_host_malloc(e->ctx, (void **)&j->lvl[0], npx * 2);
-        if (!r) r = ks265_host_malloc(e->ctx, (void **)&j->lvl[1], npx / 2);
-        if (!r) r = ks265_host_malloc(e->ctx, (void **)&j->lvl[2], npx / 2);
-        if (!r) r = ks265_host_malloc(e->ctx, (void **)&j->sao, (size_t)e->geom.bytes_sao);
-        if (!r) r = ks265_host_malloc(e->ctx, (void **)&j->sse, 64);
+        r = ks265_host_malloc(e->ctx, (void **)&j->rec, e->rec_off[6]);
+        if (!r) {
+            j->cu8 = (ks265_cu8 *)(j->rec + e->rec_off[0]); j->lvl[0] = (int16_t *)(j->rec + e->rec_off[1]); j->lvl[1] = (int16_t *)(j->rec + e->rec_off[2]);
+            j->lvl[2] = (int16_t *)(j->rec + e->rec_off[3]); j->sao = (ks265_sao_param *)(j->rec + e->rec_off[4]); j->sse = (uint64_t *)(j->rec + e->rec_off[5]);
+        }
         if (!r) r = ks265_event_create(e->ctx, &j->ev);
         j->nal_cap = npx * 2 + 65536;
         j->nal = (uint8_t *)malloc(j->nal_cap);
         if (!j->nal) r = KS265_OUTOFMEMORY;
     }
-    for (int i = 0; i < MAX_INPUT && !r; ++i) r = ks265_host_malloc(e->ctx, (void **)&e->in[i].i420, fsz);
+    for (int i = 0; i < e->ring + 16 && !r; ++i) r = ks265_host_malloc(e->ctx, (void **)&e->in[i].i420, fsz);
     if (r) { *err = hip_rc(r); QY265EncoderClose(e); return NULL; }
     memset(&e->scfg, 0, sizeof e->scfg);
     e->scfg.width = e->W; e->scfg.height = e->H; e->scfg.sao = e->use_sao; e->scfg.deblock = e->use_df;
     e->scfg.sdh = e->fcfg.sdh;
+    e->scfg.wpp = 1;                                                    /* CTU rows as substreams: what lets several writer threads share one picture */
     e->scfg.max_dec_pic_buffering = e->hier ? 10 : e->gop_b ? 4 : e->refs + 1; e->scfg.max_num_reorder = e->gop_b; e->scfg.log2_max_poc_lsb = 16;
     e->hdr = (uint8_t *)malloc(512);
     if (e->hdr) {
@@ -533,9 +647,10 @@ void *QY265EncoderOpen(QY265EncConfig *cfg, int *err)
     e->outcap = npx + 65536;
     e->outbuf = (uint8_t *)malloc(e->outcap);
     if (!e->hdr || e->hdr_len < 0 || !e->outbuf) { *err = QY_FAIL; QY265EncoderClose(e); return NULL; }
-    for (int i = 0; i < e->nthreads; ++i) { e->scratch[i] = malloc(ks265_slice_scratch_bytes(&e->scfg)); if (!e->scratch[i]) { *err = QY_OUTOFMEMORY; QY265EncoderClose(e); return NULL; } }
+    for (int i = 0; i < e->ring; ++i) { e->jobs[i].wpp = malloc(ks265_wpp_bytes(&e->scfg)); if (!e->jobs[i].wpp) { *err = QY_OUTOFMEMORY; QY265EncoderClose(e); return NULL; } }   /* virtual until used */
     for (int i = 0; i < e->nthreads; ++i) { e->warg[i].e = e; e->warg[i].idx = i; if (pthread_create(&e->th[i], NULL, worker, &e->warg[i])) break; ++e->nth; }
-    if (!e->nth) { *err = QY_FAIL; QY265EncoderClose(e); return NULL; }
+    if (e->nth && !pthread_create(&e->disp, NULL, dispatcher, e)) e->disp_on = 1;
+    if (!e->nth || !e->disp_on) { *err = QY_FAIL; QY265EncoderClose(e); return NULL; }
     logf_(0, e->log_level, "ks265enc: %dx%d %.2f fps, qp %d, -me %d (hex below %d), subme %d, refs %d, %s, sao %d, key period %d, %d slice writer threads, %s\n", e->W, e->H,
           cfg->frameRate, e->base_qp, e->me_method, e->hex_thr, e->subme, e->refs, e->hier ? "hierarchical-B GOP 8" : e->gop_b ? "P + non-reference B" : "IPPP", e->use_sao, e->iper,
           e->nth, ks265_version());
@@ -581,26 +696,42 @@ int QY265EncoderEncodeFrame(void *h, QY265Nal **pNals, int *iNalCount, QY265Pict
         if (!in->yuv || !in->yuv->pData[0] || !in->yuv->pData[1] || !in->yuv->pData[2]) return QY_POINTER;
         if (in->yuv->iWidth != e->W || in->yuv->iHeight != e->H) return QY_NOTSUPPORTED;
         Input *slot = NULL;
-        for (int i = 0; i < MAX_INPUT && !slot; ++i) if (!e->in[i].used) slot = &e->in[i];
+        const double tc0 = now_ms();
+        for (int i = 0; i < e->ring + 16 && !slot; ++i) if (!e->in[i].used) slot = &e->in[i];
         if (!slot) return QY_FAIL;                                     /* cannot happen: MAX_INPUT > MAX_JOBS + one mini-GOP */
-        for (int y = 0; y < e->H; ++y) memcpy(slot->i420 + (size_t)y * e->W, in->yuv->pData[0] + (size_t)y * in->yuv->iStride[0], (size_t)e->W);
         uint8_t *u = slot->i420 + (size_t)e->W * e->H, *v = u + (size_t)e->W * e->H / 4;
+        if (in->yuv->iStride[0] == e->W && in->yuv->iStride[1] == e->W / 2 && in->yuv->iStride[2] == e->W / 2) {    /* packed planes: three block copies */
+            memcpy(slot->i420, in->yuv->pData[0], (size_t)e->W * e->H);
+            memcpy(u, in->yuv->pData[1], (size_t)e->W * e->H / 4);
+            memcpy(v, in->yuv->pData[2], (size_t)e->W * e->H / 4);
+        } else {
+        for (int y = 0; y < e->H; ++y) memcpy(slot->i420 + (size_t)y * e->W, in->yuv->pData[0] + (size_t)y * in->yuv->iStride[0], (size_t)e->W);
         for (int y = 0; y < e->H / 2; ++y) {
             memcpy(u + (size_t)y * (e->W / 2), in->yuv->pData[1] + (size_t)y * in->yuv->iStride[1], (size_t)e->W / 2);
             memcpy(v + (size_t)y * (e->W / 2), in->yuv->pData[2] + (size_t)y * in->yuv->iStride[2], (size_t)e->W / 2);
         }
+        }
         slot->disp = e->next_disp++; slot->pts = in->pts; slot->used = 1;
+        e->st.in_copy_ms += now_ms() - tc0;
     }
     /* Output first (finished pictures are copied to the output buffer, so scheduling new work right after is safe); when the ring of
      * in-flight pictures is nearly full, wait for the oldest ones - only as many as needed, the writers keep running. */
     if (in) {
-        r = take_output(e, MAX_JOBS - 12, pNals, iNalCount, out);
+        const double t0 = now_ms();
+        r = take_output(e, e->ring - 12, pNals, iNalCount, out);
+        const double t1 = now_ms();
         const int r2 = schedule(e, 0);
+        e->st.output_ms += t1 - t0; e->st.submit_ms += now_ms() - t1;
         return r ? r : r2;
     }
+    const double t0 = now_ms();
     r = schedule(e, 1);
+    const double t1 = now_ms();
+    e->st.submit_ms += t1 - t0;
     if (r) return r;
-    return take_output(e, 0, pNals, iNalCount, out);
+    r = take_output(e, 0, pNals, iNalCount, out);
+    e->st.output_ms += now_ms() - t1;
+    return r;
 }
 
 int ks265_enc_get_stats(void *h, ks265_enc_stats *out)
@@ -620,7 +751,7 @@ int ks265_enc_set_recon_file(void *h, const char *path)
     if (e->next_disp != 0 || e->recon_fd >= 0) return QY_NOTSUPPORTED;
     const size_t fsz = (size_t)e->W * e->H * 3 / 2;
     int r = ks265_dev_malloc(e->ctx, (void **)&e->dev_recon, fsz);
-    for (int i = 0; i < MAX_JOBS && !r; ++i) r = ks265_host_malloc(e->ctx, (void **)&e->jobs[i].recon, fsz);
+    for (int i = 0; i < e->ring && !r; ++i) r = ks265_host_malloc(e->ctx, (void **)&e->jobs[i].recon, fsz);
     if (r) return hip_rc(r);
     e->recon_fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
     return e->recon_fd >= 0 ? QY_OK : QY_FAIL;

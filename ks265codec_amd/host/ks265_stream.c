@@ -157,7 +157,7 @@ long ks265_write_pps(const ks265_stream_cfg *cfg, uint8_t *out, size_t cap)
     bw_put(&b, 0, 1);                    /* weighted_bipred_flag */
     bw_put(&b, 0, 1);                    /* transquant_bypass_enabled_flag */
     bw_put(&b, 0, 1);                    /* tiles_enabled_flag */
-    bw_put(&b, 0, 1);                    /* entropy_coding_sync_enabled_flag */
+    bw_put(&b, cfg->wpp ? 1 : 0, 1);     /* entropy_coding_sync_enabled_flag */
     bw_put(&b, 0, 1);                    /* pps_loop_filter_across_slices_enabled_flag */
     bw_put(&b, 1, 1);                    /* deblocking_filter_control_present_flag */
     bw_put(&b, 0, 1);                    /* deblocking_filter_override_enabled_flag */
@@ -349,10 +349,13 @@ typedef struct {
     uint8_t *skip;                         /* cu_skip_flag of every 8x8 block coded so far (context of the neighbours) */
 } Enc;
 
+size_t ks265_wpp_bytes(const ks265_stream_cfg *cfg);
 size_t ks265_slice_scratch_bytes(const ks265_stream_cfg *cfg)
 {
     /* Enc + an RBSP buffer generous enough for any picture: the levels are 16-bit, worst case about 3 bytes per sample */
-    return sizeof(Enc) + (size_t)cfg->width * (size_t)cfg->height * 4 + 65536 + (size_t)(cfg->width >> 3) * (size_t)(cfg->height >> 3);
+    const size_t whole = sizeof(Enc) + (size_t)cfg->width * (size_t)cfg->height * 4 + 65536 + (size_t)(cfg->width >> 3) * (size_t)(cfg->height >> 3);
+    const size_t rows = ks265_wpp_bytes(cfg);                         /* cfg->wpp: the row-wise writer's job memory */
+    return whole > rows ? whole : rows;
 }
 
 static inline const ks265_cu8 *cu_at(const Enc *e, int x, int y) { return &e->in->cu8[(long)(y >> 3) * e->w8 + (x >> 3)]; }
@@ -885,23 +888,24 @@ static int check_default_lists(const ks265_slice_in *in)
     return 1;
 }
 
-long ks265_write_slice(const ks265_stream_cfg *cfg, const ks265_slice_in *in, void *scratch, uint8_t *out, size_t cap)
+/* argument checks shared by the whole-slice and the row-wise entry points */
+static int slice_args_ok(const ks265_stream_cfg *cfg, const ks265_slice_in *in)
 {
-    if (!cfg || !in || !scratch || !out || !in->cu8 || !in->lvl[0] || !in->lvl[1] || !in->lvl[2]) return KS265_POINTER;
+    if (!cfg || !in || !in->cu8 || !in->lvl[0] || !in->lvl[1] || !in->lvl[2]) return KS265_POINTER;
     if (!cfg_ok(cfg) || in->qp < 0 || in->qp > 51 || in->num_rps < 0 || in->num_rps > 15) return KS265_NOTSUPPORTED;
     if (in->slice_type < 0 || in->slice_type > 2) return KS265_NOTSUPPORTED;
     const int idr = in->nal_type == KS265_NAL_IDR_W_RADL || in->nal_type == KS265_NAL_IDR_N_LP;
     if (idr && (in->slice_type != KS265_SLICE_I || in->poc != 0)) return KS265_NOTSUPPORTED;
     if (!idr && !check_default_lists(in)) return KS265_NOTSUPPORTED;
-    Enc *e = (Enc *)scratch;
-    uint8_t *rbsp = (uint8_t *)scratch + sizeof(Enc);
-    const size_t rcap = ks265_slice_scratch_bytes(cfg) - sizeof(Enc) - (size_t)(cfg->width >> 3) * (size_t)(cfg->height >> 3);
-    e->cfg = cfg; e->in = in; e->W = cfg->width; e->H = cfg->height; e->w8 = e->W >> 3; e->h8 = e->H >> 3;
-    e->ctb_cols = (e->W + 63) >> 6; e->ctb_rows = (e->H + 63) >> 6;
-    scans_init(&e->scans);
-    e->skip = (uint8_t *)scratch + ks265_slice_scratch_bytes(cfg) - (size_t)e->w8 * (size_t)e->h8;
-    memset(e->skip, 0, (size_t)e->w8 * (size_t)e->h8);
-    BitW b; bw_init(&b, rbsp, rcap);
+    return KS265_OK;
+}
+
+/* slice_segment_header() up to and including byte_alignment(); nentry > 0: entry points of the CTU-row substreams (entry_bytes[i] = coded size of
+ * substream i INCLUDING its emulation prevention bytes, 7.4.7.1) */
+static int write_slice_header(BitW *bp, const ks265_stream_cfg *cfg, const ks265_slice_in *in, int nentry, const long *entry_bytes)
+{
+    BitW b = *bp;
+    const int idr = in->nal_type == KS265_NAL_IDR_W_RADL || in->nal_type == KS265_NAL_IDR_N_LP;
     const int sao_on = cfg->sao && in->sao != NULL;
     bw_put(&b, 1, 1);                                                /* first_slice_segment_in_pic_flag */
     if (in->nal_type >= 16 && in->nal_type <= 23) bw_put(&b, 0, 1);  /* no_output_of_prior_pics_flag */
@@ -935,15 +939,180 @@ long ks265_write_slice(const ks265_stream_cfg *cfg, const ks265_slice_in *in, vo
         bw_ue(&b, 5 - MAX_MERGE);                                    /* five_minus_max_num_merge_cand */
     }
     bw_se(&b, in->qp - 26);                                          /* slice_qp_delta */
+    if (cfg->wpp) {                                                  /* entropy_coding_sync_enabled_flag: the CTU rows are substreams with entry points */
+        bw_ue(&b, (uint32_t)nentry);                                 /* num_entry_point_offsets */
+        if (nentry > 0) {
+            long mx = 1;
+            for (int i = 0; i < nentry; ++i) if (entry_bytes[i] > mx) mx = entry_bytes[i];
+            int len = 1;
+            while (len < 32 && ((mx - 1) >> len)) ++len;
+            bw_ue(&b, (uint32_t)(len - 1));                          /* offset_len_minus1 */
+            for (int i = 0; i < nentry; ++i) {                       /* entry_point_offset_minus1[i], u(len): possibly more than 25 bits -> two pieces */
+                const uint32_t v = (uint32_t)(entry_bytes[i] - 1);
+                if (len > 16) { bw_put(&b, v >> 16, len - 16); bw_put(&b, v & 0xFFFFu, 16); } else bw_put(&b, v, len);
+            }
+        }
+    }
     bw_put(&b, 1, 1);                                                /* byte_alignment(): alignment_bit_equal_to_one, then zeros */
     while (b.nacc) bw_put(&b, 0, 1);
-    if (b.overflow) return KS265_NOTSUPPORTED;
+    *bp = b;
+    return b.overflow ? KS265_NOTSUPPORTED : KS265_OK;
+}
+
+static void enc_setup(Enc *e, const ks265_stream_cfg *cfg, const ks265_slice_in *in, uint8_t *skip)
+{
+    e->cfg = cfg; e->in = in; e->W = cfg->width; e->H = cfg->height; e->w8 = e->W >> 3; e->h8 = e->H >> 3;
+    e->ctb_cols = (e->W + 63) >> 6; e->ctb_rows = (e->H + 63) >> 6;
+    e->skip = skip;
+}
+
+/* ------------------------------------------------------------------ CTU rows as substreams (entropy_coding_sync_enabled_flag = 1; the reference's WPP,
+ * CCtuEncWpp::processOneCtu enc@0x46f5f0): every row is coded by its own arithmetic coder whose contexts start from the state the row above had
+ * after its second CTU (9.3.2.2 / 9.3.2.4); rows of one picture can therefore be written by different host threads, each at most two CTUs behind the
+ * row above.  Shared between the rows: the skip-flag map (context of cu_skip_flag) and the progress counters. */
+#include <stdatomic.h>
+#include <sched.h>
+typedef struct {
+    const ks265_stream_cfg *cfg; const ks265_slice_in *in;
+    int rows, cols, error;
+    size_t row_cap;
+    uint8_t *skip, *rowbuf;
+    long *row_len;
+    atomic_int *progress;                  /* CTUs of the row that are finished (contexts of the second one saved before the count passes 2) */
+    uint8_t *snap;                         /* rows x CX_COUNT */
+    Scans scans;
+} Wpp;
+
+static size_t wpp_row_cap(const ks265_stream_cfg *cfg) { return (size_t)((cfg->width + 63) >> 6) * (64 * 64 * 3 / 2) * 3 + 4096; }
+size_t ks265_wpp_bytes(const ks265_stream_cfg *cfg)
+{
+    const size_t rows = (size_t)((cfg->height + 63) >> 6);
+    return ((sizeof(Wpp) + 63) & ~(size_t)63) + (size_t)(cfg->width >> 3) * (size_t)(cfg->height >> 3) + rows * (wpp_row_cap(cfg) + sizeof(long) + sizeof(atomic_int) + CX_COUNT) + 256;
+}
+int ks265_wpp_begin(const ks265_stream_cfg *cfg, const ks265_slice_in *in, void *mem)
+{
+    if (!mem) return KS265_POINTER;
+    const int r = slice_args_ok(cfg, in);
+    if (r) return r;
+    if (!cfg->wpp) return KS265_NOTSUPPORTED;
+    Wpp *w = (Wpp *)mem;
+    uint8_t *p = (uint8_t *)mem + ((sizeof(Wpp) + 63) & ~(size_t)63);
+    w->cfg = cfg; w->in = in; w->rows = (cfg->height + 63) >> 6; w->cols = (cfg->width + 63) >> 6; w->error = 0; w->row_cap = wpp_row_cap(cfg);
+    w->row_len = (long *)p; p += sizeof(long) * (size_t)w->rows;
+    w->progress = (atomic_int *)p; p += sizeof(atomic_int) * (size_t)w->rows;
+    w->snap = p; p += (size_t)CX_COUNT * (size_t)w->rows;
+    w->skip = p; p += (size_t)(cfg->width >> 3) * (size_t)(cfg->height >> 3);
+    w->rowbuf = (uint8_t *)(((uintptr_t)p + 63) & ~(uintptr_t)63);
+    memset(w->skip, 0, (size_t)(cfg->width >> 3) * (size_t)(cfg->height >> 3));
+    for (int i = 0; i < w->rows; ++i) { atomic_init(&w->progress[i], 0); w->row_len[i] = 0; }
+    scans_init(&w->scans);
+    return KS265_OK;
+}
+int ks265_wpp_rows(const void *mem) { return mem ? ((const Wpp *)mem)->rows : 0; }
+
+/* one CTU row.  Rows must be STARTED in order (row r - 1 before row r) by whoever distributes them; a row waits (yielding) while the row above is
+ * less than two CTUs ahead.  Thread-safe for different rows of the same picture. */
+int ks265_wpp_code_row(void *mem, int ry)
+{
+    Wpp *w = (Wpp *)mem;
+    if (!w || ry < 0 || ry >= w->rows) return KS265_POINTER;
+    Enc es, *e = &es;
+    enc_setup(e, w->cfg, w->in, w->skip);
+    e->scans = w->scans;
+    const ks265_slice_in *in = w->in;
+    const int sao_on = w->cfg->sao && in->sao != NULL;
+    cb_init(&e->c, w->rowbuf + (size_t)ry * w->row_cap, w->row_cap, in->slice_type == KS265_SLICE_I ? 0 : in->slice_type == KS265_SLICE_P ? 1 : 2, in->qp);
+    int rc = KS265_OK;
+    for (int rx = 0; rx < w->cols; ++rx) {
+        if (ry > 0) {
+            const int need = rx + 2 < w->cols ? rx + 2 : w->cols;
+            int spins = 0;
+            while (atomic_load_explicit(&w->progress[ry - 1], memory_order_acquire) < need) { if (++spins > 64) { sched_yield(); spins = 0; } }
+            if (rx == 0 && w->cols > 1) memcpy(e->c.state, w->snap + (size_t)(ry - 1) * CX_COUNT, CX_COUNT);     /* synchronisation process 9.3.2.4 */
+        }
+        if (!rc) {
+            if (sao_on) sao_ctb(e, rx, ry);
+            rc = coding_quadtree(e, rx << 6, ry << 6, 6);
+            const int last = ry == w->rows - 1 && rx == w->cols - 1;
+            cb_terminate(&e->c, last);                               /* end_of_slice_segment_flag */
+            if (!last && rx == w->cols - 1) cb_terminate(&e->c, 1);  /* end_of_subset_one_bit; byte_alignment() comes with the flush below */
+        }
+        if (rx == 1) memcpy(w->snap + (size_t)ry * CX_COUNT, e->c.state, CX_COUNT);                               /* storage process 9.3.2.3 */
+        atomic_store_explicit(&w->progress[ry], rx + 1, memory_order_release);                                     /* also after an error: nobody may hang */
+    }
+    cb_finish(&e->c);
+    if (e->c.overflow && !rc) rc = KS265_NOTSUPPORTED;
+    w->row_len[ry] = (long)e->c.pos;
+    if (rc) w->error = rc;
+    return rc;
+}
+
+static long count_ep(const uint8_t *p, long n)
+{
+    long cnt = 0; int zeros = 0;
+    for (long i = 0; i < n; ++i) {
+        if (zeros >= 2 && p[i] <= 3) { ++cnt; zeros = 0; }
+        zeros = p[i] == 0 ? zeros + 1 : 0;
+    }
+    return cnt;
+}
+/* after every row has been coded: slice header with the entry points, then the substreams; returns the NAL size */
+long ks265_wpp_finish(void *mem, uint8_t *out, size_t cap)
+{
+    Wpp *w = (Wpp *)mem;
+    if (!w || !out) return KS265_POINTER;
+    if (w->error) return w->error;
+    long entry[256];
+    if (w->rows > 256) return KS265_NOTSUPPORTED;
+    for (int i = 0; i + 1 < w->rows; ++i) entry[i] = w->row_len[i] + count_ep(w->rowbuf + (size_t)i * w->row_cap, w->row_len[i]);
+    uint8_t hdr[2048];
+    BitW b; bw_init(&b, hdr, sizeof hdr);
+    const int r = write_slice_header(&b, w->cfg, w->in, w->rows - 1, entry);
+    if (r) return r;
+    /* Annex B wrapping of header + substreams as one RBSP (the emulation prevention state carries over the seams; a substream never ends in 00) */
+    size_t o = 0; int zeros = 0;
+    if (cap < 6) return KS265_NOTSUPPORTED;
+    out[o++] = 0; out[o++] = 0; out[o++] = 0; out[o++] = 1; out[o++] = (uint8_t)(w->in->nal_type << 1); out[o++] = 1;
+    for (int seg = -1; seg < w->rows; ++seg) {
+        const uint8_t *p = seg < 0 ? hdr : w->rowbuf + (size_t)seg * w->row_cap;
+        const size_t n = seg < 0 ? b.pos : (size_t)w->row_len[seg];
+        if (o + n + n / 2 + 8 > cap) return KS265_NOTSUPPORTED;
+        for (size_t i = 0; i < n; ++i) {
+            if (zeros >= 2 && p[i] <= 3) { out[o++] = 3; zeros = 0; }
+            out[o++] = p[i];
+            zeros = p[i] == 0 ? zeros + 1 : 0;
+        }
+    }
+    return (long)o;
+}
+
+long ks265_write_slice(const ks265_stream_cfg *cfg, const ks265_slice_in *in, void *scratch, uint8_t *out, size_t cap)
+{
+    if (!scratch || !out) return KS265_POINTER;
+    int r = slice_args_ok(cfg, in);
+    if (r) return r;
+    if (cfg->wpp) {                                                  /* the rows one after the other on this thread */
+        r = ks265_wpp_begin(cfg, in, scratch);
+        for (int ry = 0; !r && ry < ks265_wpp_rows(scratch); ++ry) r = ks265_wpp_code_row(scratch, ry);
+        return r ? r : ks265_wpp_finish(scratch, out, cap);
+    }
+    Enc *e = (Enc *)scratch;
+    uint8_t *rbsp = (uint8_t *)scratch + sizeof(Enc);
+    const size_t skip_bytes = (size_t)(cfg->width >> 3) * (size_t)(cfg->height >> 3);
+    const size_t rcap = sizeof(Enc) + (size_t)cfg->width * (size_t)cfg->height * 4 + 65536 - sizeof(Enc);
+    enc_setup(e, cfg, in, rbsp + rcap);
+    scans_init(&e->scans);
+    memset(e->skip, 0, skip_bytes);
+    BitW b; bw_init(&b, rbsp, rcap);
+    const int sao_on = cfg->sao && in->sao != NULL;
+    r = write_slice_header(&b, cfg, in, 0, NULL);
+    if (r) return r;
 
     cb_init(&e->c, rbsp + b.pos, rcap - b.pos, in->slice_type == KS265_SLICE_I ? 0 : in->slice_type == KS265_SLICE_P ? 1 : 2, in->qp);
     for (int ry = 0; ry < e->ctb_rows; ++ry)
         for (int rx = 0; rx < e->ctb_cols; ++rx) {
             if (sao_on) sao_ctb(e, rx, ry);
-            const int r = coding_quadtree(e, rx << 6, ry << 6, 6);
+            r = coding_quadtree(e, rx << 6, ry << 6, 6);
             if (r) return r;
             cb_terminate(&e->c, ry == e->ctb_rows - 1 && rx == e->ctb_cols - 1);   /* end_of_slice_segment_flag */
         }

@@ -49,14 +49,14 @@ _lib = None
 EXPORTS = [
     "ks265_create", "ks265_destroy", "ks265_set_stream", "ks265_synchronize", "ks265_last_error", "ks265_version",
     "ks265_timer_start", "ks265_timer_stop_ms", "ks265_marker", "ks265_debug_set",
-    "ks265_dev_malloc", "ks265_dev_free", "ks265_host_malloc", "ks265_host_free", "ks265_memcpy_h2d_async", "ks265_memcpy_d2h_async", "ks265_memset_async",
-    "ks265_event_create", "ks265_event_record", "ks265_event_wait", "ks265_event_destroy",
+    "ks265_dev_malloc", "ks265_dev_free", "ks265_host_malloc", "ks265_host_free", "ks265_memcpy_h2d_async", "ks265_memcpy_d2h_async", "ks265_memcpy_d2d_async", "ks265_memset_async",
+    "ks265_event_create", "ks265_event_record", "ks265_event_wait", "ks265_stream_wait_event", "ks265_event_destroy",
     "ks265_sad_batch", "ks265_sad4_batch", "ks265_sad3_batch", "ks265_sad4blk_8x8_batch", "ks265_sse_batch", "ks265_had_batch",
     "ks265_residual_batch", "ks265_fwd_transform_batch", "ks265_quant_batch", "ks265_sign_hiding_batch", "ks265_dequant_batch", "ks265_dequant_rect_batch", "ks265_inv_transform_batch",
     "ks265_edge_filter_luma_batch", "ks265_edge_filter_chroma_batch", "ks265_interp_rect",
     "ks265_sao_apply_bo_rect", "ks265_sao_apply_eo_rect", "ks265_sao_stats_batch", "ks265_intra_pred_batch", "ks265_intra_filter_ref_batch",
     "ks265_downsample_rect", "ks265_weight_bi_sad_batch", "ks265_ac_energy_batch", "ks265_ac_energy_map",
-    "ks265_frame_geometry", "ks265_frame_create", "ks265_frame_destroy", "ks265_frame_set_qp", "ks265_pad_picture",
+    "ks265_frame_records_layout", "ks265_frame_pack_records", "ks265_frame_geometry", "ks265_frame_create", "ks265_frame_destroy", "ks265_frame_set_qp", "ks265_pad_picture",
     "ks265_load_i420", "ks265_store_i420", "ks265_ref_planes", "ks265_presearch", "ks265_me_integer", "ks265_me_subpel", "ks265_cu_decide",
     "ks265_cu_flat_intra", "ks265_intra_decide", "ks265_intra_decide_ex", "ks265_lookahead_reduce", "ks265_lookahead_picture", "ks265_intra_reconstruct", "ks265_reconstruct", "ks265_reconstruct_b", "ks265_bi_decide", "ks265_cu_decide_b", "ks265_deblock", "ks265_sao",
     "ks265_encode_picture", "ks265_encode_picture_b", "ks265_encode_picture_mref", "ks265_ref_decide", "ks265_reconstruct_mref",

@@ -26,15 +26,24 @@ CASES = {
     "ps_ippp_416x240_umh": (416, 240, 27, 2, 16, 1, 1, "ippp", 4),
     "ps_hierb4_416x240": (416, 240, 30, 1, 0, 1, 1, "hier", 4),
     "ps_mref3_200x136": (200, 136, 33, 2, 16, 1, 1, "mref", 3),
+    # + entropy_coding_sync (CTU rows as substreams with entry points): the C host's streams
+    "wpp_ippp_416x240_umh": (416, 240, 27, 2, 16, 1, 1, "ippp", 4),
+    "wpp_hierb4_416x240": (416, 240, 30, 1, 0, 1, 1, "hier", 4),
+    "wpp_ippp_56x200_qp12": (56, 200, 12, 1, 0, 1, 1, "ippp", 3),      # one CTU per row: no context hand-over, every row starts from the initial contexts
+    "wpp_ippp_1280x720_umh": (1280, 720, 27, 2, 16, 1, 1, "ippp", 3),
 }
 
 
 def case_sdh(name: str) -> int:
-    return 1 if name.startswith(("sdh_", "ps_")) else 0
+    return 1 if name.startswith(("sdh_", "ps_", "wpp_")) else 0
 
 
 def case_ps(name: str) -> int:
-    return 1 if name.startswith("ps_") else 0
+    return 1 if name.startswith(("ps_", "wpp_")) else 0
+
+
+def case_wpp(name: str) -> int:
+    return 1 if name.startswith("wpp_") else 0
 
 
 def schedule(kind: str, par: int):
@@ -71,7 +80,7 @@ def make_stream(name: str, encode):
     sched = schedule(kind, par)
     nref = max([len(s[2]) + len(s[3]) for s in sched] + [1])
     reorder = par if kind == "hier" else 0
-    w = S.StreamWriter(W, H, sao=sao, deblock=df, max_dec_pic_buffering=(par + 2) if kind == "hier" else nref + 1, max_num_reorder=reorder, sdh=case_sdh(name))      # the C host's rule (ks265_enc.c)
+    w = S.StreamWriter(W, H, sao=sao, deblock=df, max_dec_pic_buffering=(par + 2) if kind == "hier" else nref + 1, max_num_reorder=reorder, sdh=case_sdh(name), wpp=case_wpp(name))      # the C host's rule (ks265_enc.c)
     bs = w.headers()
     recs = {}
     for d, k, l0, l1, dq, rps, isref in sched:
