@@ -254,7 +254,7 @@ int ks265_store_i420(ks265_frame *f, ks265_pic src, uint8_t *dev_i420);
  * interpLuma* enc@0x40e4f0..0x4109b0); dev_planes = 16 x bytes_y (plane 0 is a copy of ref.y) */
 int ks265_ref_planes(ks265_frame *f, ks265_pic ref, uint8_t *dev_planes);
 /* Stage A0 (cfg.pre_search; run by ks265_me_integer itself, exported for stage tests): exhaustive motion search on a pyramid built with
- * downsample_c enc@0x4a6a60 - L2 blocks of 8x8 over +-range/4, L1 blocks +-2, 16x16 picture blocks +-1; cost SAD + |mx| + |my|.
+ * downsample_c enc@0x4a6a60 - L2 blocks of 8x8 over +-(range/4 - 1), L1 blocks +-2, 16x16 picture blocks +-1; cost SAD + |mx| + |my|.
  * dev_field: ceil(W/16) x ceil(H/16) x {mvx, mvy} int16, integer pel (NULL = the frame's own buffer) */
 int ks265_presearch(ks265_frame *f, ks265_pic src, ks265_pic ref, int16_t *dev_field);
 /* Stage A: integer-pel motion search for every PU of every CTU (motionSearchOneRef enc@0x483f40 ->

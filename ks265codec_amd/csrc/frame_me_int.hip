@@ -86,6 +86,8 @@ struct MeLds {
     unsigned ctab[64];
     GroupLds grp[4];
     int pmv[85];                           // integer vectors of the finished PUs (predictors of the finer levels)
+    int fld16[16];                         // pre-search vector of the CTU's sixteen 16x16 blocks, x | y << 16 (0x80000000: none)
+    unsigned best16[16];
 };
 
 struct Owner {
@@ -163,8 +165,9 @@ __device__ __forceinline__ void me_group(const KsGeom &g, int cx, int cy, int ra
             o.mx = o.pmx; o.my = o.pmy;
             if (root && (o.pmx | o.pmy)) o.iflags |= DP_INIT_ZERO;                     // a root PU with a temporal predictor also tries the zero vector
             if (field) {                                                               // and every PU the pre-search vector of the 16x16 block under its centre
-                const short2 fv = field[min((cy * 64 + py * S + S / 2) >> 4, nb0y - 1) * nb0x + min((cx * 64 + px * S + S / 2) >> 4, nb0x - 1)];
-                if (fv.x != o.pmx || fv.y != o.pmy) { o.iflags |= (int)DP_INIT_FIELD; Q.fld[t] = ((int)fv.x & 0xFFFF) | ((int)fv.y << 16); }
+                const int fw = L.fld16[(((py * S + S / 2) >> 4) << 2) + ((px * S + S / 2) >> 4)];
+                const int fx = (int)(short)(fw & 0xFFFF), fy = fw >> 16;
+                if (fw != (int)0x80000000 && (fx != o.pmx || fy != o.pmy)) { o.iflags |= (int)DP_INIT_FIELD; Q.fld[t] = fw; }
             }
             o.ph = o.iflags ? PH_INIT : PH_START;
             Q.pred[t] = (o.pmx & 0xFFFF) | (o.pmy << 16);
@@ -439,9 +442,48 @@ __global__ __launch_bounds__(256, 3) void me_int_kernel(KsGeom g, int range, int
         d[0] = fsrc.x; d[1] = fsrc.y; d[2] = fsrc.z; d[3] = fsrc.w;
     }
     if (tid < TB_SIZE) L.ctab[tid] = kCandTab[tid];
+    if (tid < 16) { L.best16[tid] = 0xFFFFFFFFu; L.fld16[tid] = (int)0x80000000; }
     const ks265_pu *prev_ctu = prev ? prev + (long)ctu * 85 : nullptr;
     ks265_pu *out_ctu = out + (long)ctu * 85;
     __syncthreads();
+    // stage A0, last step: the full-resolution +-1 refinement of the pre-search vectors (`field` = the L1 vectors) of the CTU's sixteen 16x16 blocks,
+    // from the window that is in LDS anyway.  item = block (16) x candidate (9) x 8x8 tile (4); cost = SAD + |mx| + |my|, first minimum in raster order
+    if (field) {
+        for (int it = tid; it < 16 * 36; it += 256) {
+            const int blk = it / 36, rem = it - blk * 36, k = rem >> 2, tile = rem & 3;
+            const int bx = blk & 3, by = blk >> 2, gx = cx * 4 + bx, gy = cy * 4 + by;
+            const bool bvalid = gx < nb0x && gy < nb0y;
+            const short2 p = field[min(gy, nb0y - 1) * nb0x + min(gx, nb0x - 1)];
+            const int mx = clip3(-range, range, 2 * p.x + (k % 3 - 1)), my = clip3(-range, range, 2 * p.y + (k / 3 - 1));
+            const int tx = bx * 16 + (tile & 1) * 8, ty = by * 16 + (tile >> 1) * 8;
+            const bool tvalid = bvalid && cx * 64 + tx < g.W && cy * 64 + ty < g.H;
+            const int wx = tx + (tvalid ? mx : 0) + WIN_XL, wy = ty + (tvalid ? my : 0) + WIN_YT;
+            const uint8_t *pw = L.win + wy * WIN_STRIDE + (wx & ~3), *pf = L.fenc + ty * FENC_STRIDE + tx;
+            const unsigned sh = wx & 3;
+            unsigned sd = 0;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const unsigned w0 = *(const unsigned *)(pw + r * WIN_STRIDE), w1 = *(const unsigned *)(pw + r * WIN_STRIDE + 4), w2 = *(const unsigned *)(pw + r * WIN_STRIDE + 8);
+                const unsigned f0 = *(const unsigned *)(pf + r * FENC_STRIDE), f1 = *(const unsigned *)(pf + r * FENC_STRIDE + 4);
+                sd = sad_u8x4(f0, align_bytes(w1, w0, sh), sd);
+                sd = sad_u8x4(f1, align_bytes(w2, w1, sh), sd);
+            }
+            if (!tvalid) sd = 0;
+            sd += (unsigned)dpp_mov<KS265_DPP_QUAD_XOR1>((int)sd); sd += (unsigned)dpp_mov<KS265_DPP_QUAD_XOR2>((int)sd);
+            if (tile == 0 && bvalid) atomicMin(&L.best16[blk], ((sd + (unsigned)(abs(mx) + abs(my))) << 4) | (unsigned)k);
+        }
+        __syncthreads();
+        if (tid < 16) {
+            const int gx = cx * 4 + (tid & 3), gy = cy * 4 + (tid >> 2);
+            if (gx < nb0x && gy < nb0y) {
+                const short2 p = field[gy * nb0x + gx];
+                const int k = (int)(L.best16[tid] & 15u);
+                const int mx = clip3(-range, range, 2 * p.x + (k % 3 - 1)), my = clip3(-range, range, 2 * p.y + (k / 3 - 1));
+                L.fld16[tid] = (mx & 0xFFFF) | (my << 16);
+            }
+        }
+        __syncthreads();
+    }
 #ifdef KS_EXP_ME_CLOCK
     const long long tk1 = ME_NOW();
 #endif
@@ -475,7 +517,7 @@ extern "C" int ks265_me_integer(ks265_frame *f, ks265_pic src, ks265_pic ref, co
     if (f->cfg.pre_search) {                                                 // stage A0 first: the pre-search field of this (source, reference) pair
         const int r = ks265_presearch(f, src, ref, nullptr);
         if (r) return r;
-        field = (const short2 *)f->pyr[6];
+        field = (const short2 *)f->pyr[5];                                   // the L1 vectors: the kernel does the full-resolution step itself
     }
     const dim3 grid(f->g.ctu_cols * f->g.ctu_rows), block(256);
     hipLaunchKernelGGL(me_int_kernel, grid, block, 0, f->ctx->stream, f->g, f->cfg.me_range, f->cfg.lambda_q4, f->cfg.me_method, f->cfg.me_hex_thr, src.y, ref.y, prev_pu, pu,

@@ -161,7 +161,7 @@ static void pu_predictor(const kso_frame_cfg *cfg, const kso_pu *ctu_pu, const k
  * section 8(f) rank 2) and meInitPoint enc@0x48af50 starts the integer search from the best of several candidates.  A frame-parallel search has
  * no spatial neighbours to draw candidates from, so the candidate that makes the local pattern searches (DIA / HEX / UMH walk downhill from
  * their start point and cannot find a displaced match in texture without a gradient) robust comes from here: an EXHAUSTIVE search where it is
- * cheap.  L1 = downsample_c(luma), L2 = downsample_c(L1).  Per 8x8 block of L2 (32x32 samples) every vector of +-range/4; per 8x8 block of
+ * cheap.  L1 = downsample_c(luma), L2 = downsample_c(L1).  Per 8x8 block of L2 (32x32 samples) every vector of +-(range/4 - 1) (31 columns at range 64: two blocks share a 64-lane wave on the GPU); per 8x8 block of
  * L1 (16x16 samples) +-2 around twice the L2 vector; per 16x16 block of the picture +-1 around twice the L1 vector.  Cost = SAD + |mx| + |my|
  * (ties and flat areas fall to the shorter vector), first minimum in raster order of (my, mx).  Low-resolution reads clamp to the picture
  * (no border), the full-resolution step reads the padded planes like stage A.  Output: one integer vector per 16x16 block. */
@@ -192,7 +192,7 @@ void kso_presearch(const kso_frame_cfg *cfg, kso_pic src, kso_pic ref, int16_t *
     pyr_down(S, st, W, H, c1); pyr_down(R, st, W, H, r1); pyr_down(c1, W1, W1, H1, c2); pyr_down(r1, W1, W1, H1, r2);
     const int nb2x = (W2 + 7) / 8, nb2y = (H2 + 7) / 8, nb1x = (W1 + 7) / 8, nb1y = (H1 + 7) / 8, nb0x = (W + 15) / 16, nb0y = (H + 15) / 16;
     int16_t *mv2 = malloc(sizeof(int16_t) * 2 * (size_t)nb2x * nb2y), *mv1 = malloc(sizeof(int16_t) * 2 * (size_t)nb1x * nb1y);
-    const int R2 = imax(cfg->me_range >> 2, 1), range = cfg->me_range;
+    const int R2 = imax((cfg->me_range >> 2) - 1, 1), range = cfg->me_range;
 #pragma omp parallel for collapse(2) schedule(dynamic, 1)
     for (int by = 0; by < nb2y; ++by)
         for (int bx = 0; bx < nb2x; ++bx) {
