@@ -55,6 +55,7 @@ int ks265_frame_create(ks265_ctx *ctx, const ks265_frame_cfg *cfg, ks265_frame *
     if (!r) r = dev_alloc(ctx, (void **)&f->deb[1], (size_t)g.bytes_c, true);
     if (!r) r = dev_alloc(ctx, (void **)&f->deb[2], (size_t)g.bytes_c, true);
     if (!r) r = dev_alloc(ctx, (void **)&f->sse, 3 * sizeof(unsigned long long), true);
+    if (!r) r = dev_alloc(ctx, (void **)&f->sse_acc, 4 * sizeof(unsigned long long), true);
     if (!r) r = dev_alloc(ctx, (void **)&f->progress, sizeof(int) * (size_t)g.ctu_rows, true);
     if (!r) r = dev_alloc(ctx, (void **)&f->mats, sizeof(short) * 2 * 1600, true);      /* 2 x MAT_SHORTS (recon_dev.h) */
     if (!r) r = ks265_frame_build_matrices(f);
@@ -69,7 +70,7 @@ void ks265_frame_destroy(ks265_frame *f)
     if (f->ctx) { (void)hipSetDevice(f->ctx->device); (void)hipStreamSynchronize(f->ctx->stream); }
     for (int i = 0; i <= KS_NSTAGE; ++i)
         if (f->ev[i]) (void)hipEventDestroy(f->ev[i]);
-    void *ptrs[] = {f->planes1, f->pu1, f->pub, f->planes, f->pu[0], f->pu[1], f->cu8, f->sao, f->lvl[0], f->lvl[1], f->lvl[2], f->deb[0], f->deb[1], f->deb[2], f->sse, f->progress, f->mats, f->planes_x[0], f->planes_x[1], f->planes_x[2], f->pu_x[0], f->pu_x[1], f->pu_x[2]};
+    void *ptrs[] = {f->planes1, f->pu1, f->pub, f->planes, f->pu[0], f->pu[1], f->cu8, f->sao, f->lvl[0], f->lvl[1], f->lvl[2], f->deb[0], f->deb[1], f->deb[2], f->sse, f->sse_acc, f->progress, f->mats, f->planes_x[0], f->planes_x[1], f->planes_x[2], f->pu_x[0], f->pu_x[1], f->pu_x[2]};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (uint8_t *p : f->pyr)

@@ -38,6 +38,7 @@ struct ks265_frame {
     int16_t *lvl[3] = {nullptr, nullptr, nullptr};
     uint8_t *deb[3] = {nullptr, nullptr, nullptr};   // reconstructed picture before SAO (padded geometry)
     unsigned long long *sse = nullptr;
+    unsigned long long *sse_acc = nullptr;   // ks265_sse_picture: three running sums + finished work-groups (zero between calls)
     short *mats = nullptr;              // forward + transposed DCT matrices of all sizes in the kernels' LDS layout (2 x MAT_SHORTS)
     int *progress = nullptr;            // intra wavefront: CTUs finished per CTU row
     uint8_t *pyr[7] = {};               // pre-search (cfg.pre_search): L1 / L2 of the source, L1 / L2 of the reference, L2 / L1 vectors, the 16x16 vector field

@@ -71,15 +71,18 @@ extern "C" int ks265_pad_picture(ks265_frame *f, ks265_pic pic)
 }
 
 // ------------------------------------------------------------------ I420 <-> padded picture (dword per thread)
-__global__ __launch_bounds__(256) void copy_rows_kernel(uint8_t *dst, long dstStride, const uint8_t *src, long srcStride, int w, int h)
+// the three planes in one launch: blockIdx.z = plane (chroma planes use the upper-left quarter of the grid)
+struct CopyPlanes { uint8_t *dst[3]; const uint8_t *src[3]; long ds[3], ss[3]; int w, h; };
+__global__ __launch_bounds__(256) void copy_planes_kernel(CopyPlanes a)
 {
-    int x4 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4, y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int pl = blockIdx.z, w = pl ? a.w / 2 : a.w, h = pl ? a.h / 2 : a.h;
+    const int x4 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4, y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x4 >= w || y >= h) return;
-    *(unsigned *)(dst + y * dstStride + x4) = *(const unsigned *)(src + y * srcStride + x4);
+    *(unsigned *)(a.dst[pl] + y * a.ds[pl] + x4) = *(const unsigned *)(a.src[pl] + y * a.ss[pl] + x4);
 }
-static void launch_copy(ks265_frame *f, uint8_t *dst, long ds, const uint8_t *src, long ss, int w, int h)
+static void launch_copy3(ks265_frame *f, const CopyPlanes &a)
 {
-    hipLaunchKernelGGL(copy_rows_kernel, dim3((w / 4 + 63) / 64, (h + 3) / 4), dim3(256), 0, f->ctx->stream, dst, ds, src, ss, w, h);
+    hipLaunchKernelGGL(copy_planes_kernel, dim3((a.w / 4 + 63) / 64, (a.h + 3) / 4, 3), dim3(256), 0, f->ctx->stream, a);
 }
 
 extern "C" int ks265_load_i420(ks265_frame *f, const uint8_t *i420, ks265_pic dst)
@@ -87,9 +90,10 @@ extern "C" int ks265_load_i420(ks265_frame *f, const uint8_t *i420, ks265_pic ds
     KS_FRAME_CHECK(f);
     if (!i420) return KS265_POINTER;
     int W = f->g.W, H = f->g.H;
-    launch_copy(f, dst.y + f->g.org_y, f->g.sy, i420, W, W, H);
-    launch_copy(f, dst.u + f->g.org_c, f->g.sc, i420 + (long)W * H, W / 2, W / 2, H / 2);
-    launch_copy(f, dst.v + f->g.org_c, f->g.sc, i420 + (long)W * H * 5 / 4, W / 2, W / 2, H / 2);
+    CopyPlanes a;
+    a.dst[0] = dst.y + f->g.org_y; a.dst[1] = dst.u + f->g.org_c; a.dst[2] = dst.v + f->g.org_c; a.ds[0] = f->g.sy; a.ds[1] = a.ds[2] = f->g.sc;
+    a.src[0] = i420; a.src[1] = i420 + (long)W * H; a.src[2] = i420 + (long)W * H * 5 / 4; a.ss[0] = W; a.ss[1] = a.ss[2] = W / 2; a.w = W; a.h = H;
+    launch_copy3(f, a);
     return ks265_pad_picture(f, dst);
 }
 
@@ -98,9 +102,10 @@ extern "C" int ks265_store_i420(ks265_frame *f, ks265_pic src, uint8_t *i420)
     KS_FRAME_CHECK(f);
     if (!i420) return KS265_POINTER;
     int W = f->g.W, H = f->g.H;
-    launch_copy(f, i420, W, src.y + f->g.org_y, f->g.sy, W, H);
-    launch_copy(f, i420 + (long)W * H, W / 2, src.u + f->g.org_c, f->g.sc, W / 2, H / 2);
-    launch_copy(f, i420 + (long)W * H * 5 / 4, W / 2, src.v + f->g.org_c, f->g.sc, W / 2, H / 2);
+    CopyPlanes a;
+    a.src[0] = src.y + f->g.org_y; a.src[1] = src.u + f->g.org_c; a.src[2] = src.v + f->g.org_c; a.ss[0] = f->g.sy; a.ss[1] = a.ss[2] = f->g.sc;
+    a.dst[0] = i420; a.dst[1] = i420 + (long)W * H; a.dst[2] = i420 + (long)W * H * 5 / 4; a.ds[0] = W; a.ds[1] = a.ds[2] = W / 2; a.w = W; a.h = H;
+    launch_copy3(f, a);
     return ks265_check_launch(f->ctx);
 }
 
@@ -231,7 +236,7 @@ extern "C" int ks265_ref_planes(ks265_frame *f, ks265_pic ref, uint8_t *planes)
 // ------------------------------------------------------------------ picture SSE (PSNR): sse3[plane] += sum of squared differences
 // one launch for the three planes: blockIdx.y = plane, a work-group = 8 rows, a thread = dwords of one row (stride 32 dwords)
 __global__ __launch_bounds__(256) void sse_picture_kernel(KsGeom g, const uint8_t *ay, const uint8_t *au, const uint8_t *av, const uint8_t *by, const uint8_t *bu, const uint8_t *bv,
-                                                          unsigned long long *out)
+                                                          unsigned long long *acc /* [0..2] running sums, [3] work-groups done; all zero between calls */, unsigned long long *out)
 {
     const int pl = blockIdx.y;
     const int w = pl ? g.W / 2 : g.W, h = pl ? g.H / 2 : g.H;
@@ -251,7 +256,14 @@ __global__ __launch_bounds__(256) void sse_picture_kernel(KsGeom g, const uint8_
     __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned long long t = (unsigned long long)part[0] + part[1] + part[2] + part[3];
-        if (t) atomicAdd(out + pl, t);
+        if (t) atomicAdd(acc + pl, t);
+        __threadfence();
+        // the last work-group to finish hands the sums out and leaves the accumulators zeroed for the next call (no memset launch per picture)
+        if (atomicAdd(acc + 3, 1ull) == (unsigned long long)gridDim.x * gridDim.y - 1ull) {
+            __threadfence();
+            for (int i = 0; i < 3; ++i) out[i] = atomicExch(acc + i, 0ull);
+            atomicExch(acc + 3, 0ull);
+        }
     }
 }
 
@@ -259,8 +271,6 @@ extern "C" int ks265_sse_picture(ks265_frame *f, ks265_pic a, ks265_pic b, uint6
 {
     KS_FRAME_CHECK(f);
     if (!sse3) return KS265_POINTER;
-    hipError_t e = hipMemsetAsync(sse3, 0, 3 * sizeof(uint64_t), f->ctx->stream);
-    if (e != hipSuccess) return ks265_hip(f->ctx, e);
-    hipLaunchKernelGGL(sse_picture_kernel, dim3((unsigned)((f->g.H + 7) / 8), 3), dim3(256), 0, f->ctx->stream, f->g, a.y, a.u, a.v, b.y, b.u, b.v, (unsigned long long *)sse3);
+    hipLaunchKernelGGL(sse_picture_kernel, dim3((unsigned)((f->g.H + 7) / 8), 3), dim3(256), 0, f->ctx->stream, f->g, a.y, a.u, a.v, b.y, b.u, b.v, f->sse_acc, (unsigned long long *)sse3);
     return ks265_check_launch(f->ctx);
 }
