@@ -126,7 +126,7 @@ def main():
         tstream = None if sidx == 0 else torch.cuda.Stream(device=dev_index)
         with (torch.cuda.stream(tstream) if tstream is not None else contextlib.nullcontext()):
             ks = KsContext(dev_index)
-            fr = KsFrame(ks, W, H, qp, lambda_q4(qp), me_method=me_method, me_hex_thr=(args.me_hex_thr if me_method == 2 else 0), bframes=max(args.bframes, args.hier_b - 1 if args.hier_b else 0), refs=max(1, args.refs), sdh=1, pre_search=0 if args.no_pre_search else 1)
+            fr = KsFrame(ks, W, H, qp, lambda_q4(qp), me_method=me_method, me_hex_thr=(args.me_hex_thr if me_method == 2 else 0), bframes=max(args.bframes, args.hier_b - 1 if args.hier_b else 0), refs=max(1, args.refs), sdh=1, pre_search=0 if args.no_pre_search else 1, merge=1)
             # synthetic clip of SURVEY.md §8(d), one GOP shard per stream (different seed per shard = different content)
             clip = make_clip(W, H, args.clip_frames, seed=7 + (0 if args.b_spread else rank * nstreams + sidx), abc=(67, 91, 33), pan=(8, 5))
             dev_clip = [ks.dev(c) for c in clip]
@@ -380,7 +380,7 @@ def port_leg(args, clip, order, me_method):
     from oracle_lib import OraclePipeline
     from ks265codec_amd.synth import lambda_q4
     W, H, qp = args.width, args.height, args.qp
-    o = OraclePipeline(W, H, qp, lambda_q4(qp), me_method=me_method, me_hex_thr=(args.me_hex_thr if me_method == 2 else 0), sdh=1, pre_search=0 if args.no_pre_search else 1)
+    o = OraclePipeline(W, H, qp, lambda_q4(qp), me_method=me_method, me_hex_thr=(args.me_hex_thr if me_method == 2 else 0), sdh=1, pre_search=0 if args.no_pre_search else 1, merge=1)
     nbase = 3
     tc0 = time.perf_counter()
     if args.bframes == 0:
@@ -523,9 +523,10 @@ def encoded_leg(args, torch, dist, rank, world, dev_index, backend, sync_all):
             assert rc == 0, hex(rc & 0xFFFFFFFF)
             collect()
 
-    feed(args.warmup); flush()
     job = None
+    win = None
     if strong:
+        feed(args.warmup); flush()
         # the fixed job: pictures 0 .. F-1 of the clip in closed GOPs of -iper pictures; rank r takes a contiguous run of GOPs (ks265codec_amd/gop.py shard_gops),
         # on a fresh encoder (the warm-up one is closed: its pictures are not part of the job); the ranks' streams are gathered on rank 0 in GOP order
         from ks265codec_amd import gop
@@ -535,9 +536,9 @@ def encoded_leg(args, torch, dist, rank, world, dev_index, backend, sync_all):
         h = open_encoder()
         state.update(bytes=0, nals=0, keep=[])
     b0 = state["bytes"]
-    sync_all()
-    t0 = time.perf_counter()
     if strong:
+        sync_all()
+        t0 = time.perf_counter()
         for a, b in mine:
             state["t"] = a
             feed(b - a)
@@ -558,10 +559,39 @@ def encoded_leg(args, torch, dist, rank, world, dev_index, backend, sync_all):
         job = {"frames": F, "gops": -(-F // per), "bytes": len(blob) if rank == 0 else 0, "frames_this_rank": sum(b - a for a, b in mine)}
         if rank == 0 and args.out:
             open(args.out, "wb").write(blob)
+        sync_all()
+        dt = time.perf_counter() - t0
     else:
-        feed(args.steps); flush()
-    sync_all()
-    dt = time.perf_counter() - t0
+        # Weak mode: STEADY-STATE throughput of the asynchronous encoder (output lags input by the SDK's contract).  Untimed: the W warm-up pictures and
+        # as many more as it takes to fill the pipeline and to stand just behind a key picture (the ring of pictures in flight is then full and every
+        # EncodeFrame call returns only when a picture has left the encoder: back-pressure = one picture in, one picture out).  Timed window A: exactly
+        # K pictures (no key picture among them when K < iper).  Timed window B (only when A holds no key picture): exactly one whole GOP of -iper
+        # pictures = iper - 1 P/B pictures + ONE key picture.  `value` is the whole-GOP rate (the key picture's share included); A is reported beside it.
+        iper = args.iper if args.iper > 0 else 1 << 30
+        fill = args.warmup + 132
+        if iper < 1 << 20:
+            fill = -(-fill // iper) * iper + 1                # first picture of window A = the one right after a key picture
+        feed(fill)
+        sync_all()
+        b0 = state["bytes"]
+        t0 = time.perf_counter()
+        feed(args.steps)
+        sync_all()                                            # barrier + device synchronize on both sides (all ranks)
+        dt_a = time.perf_counter() - t0
+        bytes_a = state["bytes"] - b0
+        dt, npic = dt_a, args.steps
+        win = {"A": {"pictures": args.steps, "seconds": round(dt_a, 5), "key_pictures": (fill + args.steps - 1) // iper - (fill - 1) // iper}}
+        if win["A"]["key_pictures"] == 0 and iper < 1 << 20:
+            pos = fill + args.steps
+            feed(-pos % iper + 1 if pos % iper != 1 else 0)   # untimed: up to the picture right after the next key picture
+            sync_all()
+            t0 = time.perf_counter()
+            feed(iper)
+            sync_all()
+            dt = time.perf_counter() - t0
+            npic = iper
+            win["B"] = {"pictures": iper, "seconds": round(dt, 5), "key_pictures": 1}
+        flush()
     st = Stats()
     lib.ks265_enc_get_stats(h, C.byref(st))
     lib.QY265EncoderClose(h)
@@ -576,7 +606,12 @@ def encoded_leg(args, torch, dist, rank, world, dev_index, backend, sync_all):
                 "md5": hashlib.md5(blob).hexdigest() if rank == 0 else None,
                 "psnr_y": 99.0 if mse == 0 else 10.0 * np.log10(255.0 ** 2 / mse), "slice_write_ms_per_picture": st.host_write_ms / max(1, st.frames), "preset": preset.decode(),
                 "gop": f"hierarchical-B {args.hier_b}" if args.hier_b else (f"P + {gop_b} B" if gop_b else "IPPP")}
-    return {"fps": world * args.steps / dt, "dt": dt, "host_threads": threads, "host_cores": cores, "bytes_per_picture": (state["bytes"] - b0) / args.steps,
+    if dist is not None:
+        ta = torch.tensor([win["A"]["seconds"]], dtype=torch.float64, device=torch.device("cuda", dev_index) if backend == "nccl" else "cpu")
+        dist.all_reduce(ta, op=dist.ReduceOp.MAX)
+        win["A"]["seconds"] = round(float(ta.item()), 5)
+    win["A"]["fps_all_ranks"] = round(world * win["A"]["pictures"] / win["A"]["seconds"], 2)
+    return {"fps": world * npic / dt, "dt": dt * args.steps / npic, "windows": win, "host_threads": threads, "host_cores": cores, "bytes_per_picture": bytes_a / args.steps,
             "psnr_y": 99.0 if mse == 0 else 10.0 * np.log10(255.0 ** 2 / mse), "slice_write_ms_per_picture": st.host_write_ms / max(1, st.frames), "preset": preset.decode(),
             "caller_ms_per_picture": {"input_copy": round(st.in_copy_ms / max(1, st.frames), 3), "enqueue": round(st.submit_ms / max(1, st.frames), 3), "output": round(st.output_ms / max(1, st.frames), 3),
                                       "latency_enqueue_to_records_on_host": round(st.lat_gpu_ms / max(1, st.frames), 2), "latency_enqueue_to_writer_pickup": round(st.lat_queue_ms / max(1, st.frames), 2)},
@@ -597,6 +632,10 @@ def encoded_line(args, enc, world, hot, cpu):
                                f"pixel path on the MI355X (-preset {enc['preset']}: -me {args.me}, subme 1, deblock + SAO) -> D2H of CU map / levels / SAO -> CABAC slice data on "
                                f"{enc['host_threads']} host threads -> Annex-B NAL units out; -rc 0 -qp {args.qp} (I=Q, P=Q+1, B=Q+2..) -iper {args.iper}, {enc['gop']}, "
                                f"-ref {max(1, args.refs)}; the stream decodes with the reference's appdecoder to the encoder's reconstruction (tests/test_stream.py)",
+                   "timed": None if strong else ("steady state of the asynchronous encoder (pipeline full before and after, back-pressure: one picture in = one picture out), barrier + "
+                             "device synchronize on both sides of each window.  A = exactly --steps pictures; B = one whole GOP of -iper pictures incl. its key picture "
+                             "(run when A holds no key picture).  value = pictures / seconds of B (of A when A already holds its key pictures); ms_per_step = 1000 / value per GPU") ,
+                   "windows": enc.get("windows"),
                    "pictures_per_step": 1, "host_threads_per_gpu": enc["host_threads"], "host_cores": enc["host_cores"],
                    "bytes_per_picture": int(enc["bytes_per_picture"]), "kbps_at_50fps": round(enc["bytes_per_picture"] * 8 * 50 / 1000.0, 1),
                    "slice_write_ms_per_picture_per_thread": round(enc["slice_write_ms_per_picture"], 2),

@@ -209,6 +209,8 @@ typedef struct {
     int32_t pre_search;        /* 1 = stage A evaluates one more start candidate per PU: the vector of an exhaustive search on a three-level pyramid
                                   (ks265_presearch; the reference's lookahead searches 2:1 pictures, downsample_c enc@0x4a6a60, and meInitPoint
                                   enc@0x48af50 picks the best of several start candidates) */
+    int32_t merge;             /* 1 = stage C2 after the CU decision: every CU may adopt the motion of one of its spatial merge neighbours or the zero vector
+                                  (ks265_merge_pass; the reference's merge / skip decision: GetMergeCandsFor*, skipFastDecision) - single reference per list */
 } ks265_frame_cfg;
 
 /* geometry of the padded picture buffers the caller allocates (one call, no allocation) */
@@ -264,6 +266,12 @@ int ks265_me_integer(ks265_frame *f, ks265_pic src, ks265_pic ref, const ks265_p
 /* Stage B: 8 half-pel + 8 quarter-pel refinement with SATD (subMeSquare enc@0x4b5660 ->
  * subMeHpel_RealInterp / subMeQpel_8Sad_*_RealInterp + had_c) */
 int ks265_me_subpel(ks265_frame *f, ks265_pic src, const uint8_t *dev_planes, ks265_pu *dev_pu);
+/* Stage C2 (cfg.merge; run by ks265_encode_picture[_b] itself, exported for stage tests): merge pass on the motion field of the CU decision.
+ * Per CU the five spatial merge neighbours of H.265 8.5.3.2.3 (inside the picture, earlier in z-scan order, inter) and the zero vector are tried as the
+ * CU's own motion: SATD of the prediction (fractional planes; bi = rounded average) + lambda x (position + 1) against the search cost + 2 lambda.
+ * dev_pu for P pictures, dev_pub for B pictures (the other NULL); cu_in and cu_out must differ (all CUs decide on the same input field). */
+int ks265_merge_pass(ks265_frame *f, ks265_pic src, const uint8_t *dev_planes0, const uint8_t *dev_planes1, const ks265_pu *dev_pu, const ks265_pu_b *dev_pub,
+                     const ks265_cu8 *dev_cu_in, ks265_cu8 *dev_cu_out);
 /* Stage C: CU quadtree decision from the PU costs (the bottom-up compare of processTree enc@0x4722a0) */
 int ks265_cu_decide(ks265_frame *f, const ks265_pu *dev_pu, ks265_cu8 *dev_cu8);
 /* Stage C': key picture — every CU 32x32-TU "flat" intra (pred = 128); stands in for the out-of-scope

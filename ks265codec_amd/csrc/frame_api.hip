@@ -47,6 +47,7 @@ int ks265_frame_create(ks265_ctx *ctx, const ks265_frame_cfg *cfg, ks265_frame *
     }
     if (cfg->refs > 1 && !f->pub && !r) r = dev_alloc(ctx, (void **)&f->pub, (size_t)geom.ctu_cols * geom.ctu_rows * 85 * sizeof(ks265_pu_b), true);
     if (!r) r = dev_alloc(ctx, (void **)&f->cu8, (size_t)geom.bytes_cu8, true);
+    if (!r && cfg->merge) r = dev_alloc(ctx, (void **)&f->cu8_tmp, (size_t)geom.bytes_cu8, true);
     if (!r) r = dev_alloc(ctx, (void **)&f->sao, (size_t)geom.bytes_sao, true);
     if (!r) r = dev_alloc(ctx, (void **)&f->lvl[0], npx * 2, true);
     if (!r) r = dev_alloc(ctx, (void **)&f->lvl[1], npx / 2, true);
@@ -70,7 +71,7 @@ void ks265_frame_destroy(ks265_frame *f)
     if (f->ctx) { (void)hipSetDevice(f->ctx->device); (void)hipStreamSynchronize(f->ctx->stream); }
     for (int i = 0; i <= KS_NSTAGE; ++i)
         if (f->ev[i]) (void)hipEventDestroy(f->ev[i]);
-    void *ptrs[] = {f->planes1, f->pu1, f->pub, f->planes, f->pu[0], f->pu[1], f->cu8, f->sao, f->lvl[0], f->lvl[1], f->lvl[2], f->deb[0], f->deb[1], f->deb[2], f->sse, f->sse_acc, f->progress, f->mats, f->planes_x[0], f->planes_x[1], f->planes_x[2], f->pu_x[0], f->pu_x[1], f->pu_x[2]};
+    void *ptrs[] = {f->planes1, f->pu1, f->pub, f->planes, f->pu[0], f->pu[1], f->cu8, f->sao, f->lvl[0], f->lvl[1], f->lvl[2], f->deb[0], f->deb[1], f->deb[2], f->sse, f->sse_acc, f->cu8_tmp, f->progress, f->mats, f->planes_x[0], f->planes_x[1], f->planes_x[2], f->pu_x[0], f->pu_x[1], f->pu_x[2]};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (uint8_t *p : f->pyr)
@@ -117,7 +118,10 @@ int ks265_encode_picture(ks265_frame *f, ks265_pic src, ks265_pic ref, int is_ke
         mark(2);
         if (f->cfg.subme && (r = ks265_me_subpel(f, src, f->planes, pu))) return r;
         mark(3);
-        if ((r = ks265_cu_decide(f, pu, f->cu8))) return r;
+        if (f->cfg.merge) {                                    /* stage C2: the CU decision goes to the spare map, the merge pass writes the final one */
+            if ((r = ks265_cu_decide(f, pu, f->cu8_tmp))) return r;
+            if ((r = ks265_merge_pass(f, src, f->planes, nullptr, pu, nullptr, f->cu8_tmp, f->cu8))) return r;
+        } else if ((r = ks265_cu_decide(f, pu, f->cu8))) return r;
         mark(4);
         if ((r = ks265_reconstruct(f, src, ref, f->planes, f->cu8, f->lvl[0], f->lvl[1], f->lvl[2], deb))) return r;
     }
@@ -176,7 +180,10 @@ int ks265_encode_picture_b(ks265_frame *f, ks265_pic src, ks265_pic ref0, ks265_
     if ((r = ks265_me_integer(f, src, ref1, nullptr, f->pu1))) return r;
     if (f->cfg.subme && (r = ks265_me_subpel(f, src, f->planes1, f->pu1))) return r;
     if ((r = ks265_bi_decide(f, src, f->planes, f->planes1, pu0, f->pu1, f->pub))) return r;
-    if ((r = ks265_cu_decide_b(f, f->pub, f->cu8))) return r;
+    if (f->cfg.merge) {
+        if ((r = ks265_cu_decide_b(f, f->pub, f->cu8_tmp))) return r;
+        if ((r = ks265_merge_pass(f, src, f->planes, f->planes1, nullptr, f->pub, f->cu8_tmp, f->cu8))) return r;
+    } else if ((r = ks265_cu_decide_b(f, f->pub, f->cu8))) return r;
     ks265_pic deb = ks_deb_pic(f);
     if ((r = ks265_reconstruct_b(f, src, ref0, f->planes, ref1, f->planes1, f->cu8, f->lvl[0], f->lvl[1], f->lvl[2], deb))) return r;
     if (f->cfg.deblock && (r = ks265_deblock(f, f->cu8, deb))) return r;

@@ -34,6 +34,7 @@ struct ks265_frame {
     int cur_pu = 0;
     bool have_prev = false;
     ks265_cu8 *cu8 = nullptr;
+    ks265_cu8 *cu8_tmp = nullptr;        // cfg.merge: the CU decision's map, input of the merge pass
     ks265_sao_param *sao = nullptr;
     int16_t *lvl[3] = {nullptr, nullptr, nullptr};
     uint8_t *deb[3] = {nullptr, nullptr, nullptr};   // reconstructed picture before SAO (padded geometry)

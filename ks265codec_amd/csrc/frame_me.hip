@@ -421,6 +421,110 @@ extern "C" int ks265_bi_decide(ks265_frame *f, ks265_pic src, const uint8_t *pla
     return ks265_check_launch(f->ctx);
 }
 
+// ------------------------------------------------------------------ Stage C2: merge pass (cfg.merge)
+// The reference decides merge / skip per CU against the candidates of already coded neighbours (GetMergeCandsFor*, skipFastDecision; closed code).
+// A frame-parallel decision has no coded neighbours: this pass works on the motion field the CU decision left behind.  Every CU looks at its five
+// spatial merge neighbours (A1 B1 B0 A0 B2 of H.265 8.5.3.2.3: inside the picture, earlier in z-scan order, inter) and at the zero vector, takes each
+// one's motion as its own and keeps the cheapest if it beats what the search found: SATD of the prediction + lambda x (position in the list + 1)
+// against the CU's search cost + 2 lambda.  All CUs decide on the same input field (cu_in -> cu_out): the result does not depend on any order.
+// One work-group per CTU; lane = 8x8 tile in z-order (as in bi_decide), wave w evaluates candidates w and w + 4; a tile's SATD against the (averaged)
+// plane tiles, CU sums by DPP at the CU's own level, the winner per CU through one LDS minimum.
+struct MergeMotion { int dir, mvx, mvy, mv1x, mv1y; bool ok; };
+__device__ __forceinline__ int z_of_8(int x, int y)
+{
+    const int bx = (x >> 3) & 7, by = (y >> 3) & 7;
+    return (bx & 1) | ((by & 1) << 1) | ((bx & 2) << 1) | ((by & 2) << 2) | ((bx & 4) << 2) | ((by & 4) << 3);
+}
+__device__ __forceinline__ MergeMotion merge_cand(const KsGeom &g, const ks265_cu8 *cu_in, int x, int y, int n, int k, bool is_b)
+{
+    MergeMotion m; m.dir = is_b ? 3 : 1; m.mvx = m.mvy = m.mv1x = m.mv1y = 0; m.ok = true;
+    if (k == 5) return m;
+    const int nx = k == 1 ? x + n - 1 : k == 2 ? x + n : x - 1, ny = k == 0 ? y + n - 1 : k == 3 ? y + n : y - 1;       // A1 B1 B0 A0 B2
+    m.ok = false;
+    if (nx < 0 || ny < 0 || nx >= g.W || ny >= g.H) return m;
+    const int ctb = (y >> 6) * g.ctu_cols + (x >> 6), nctb = (ny >> 6) * g.ctu_cols + (nx >> 6);
+    if (nctb > ctb || (nctb == ctb && z_of_8(nx, ny) >= z_of_8(x, y))) return m;
+    const ks265_cu8 c = cu_in[(long)(ny >> 3) * g.w8 + (nx >> 3)];
+    if (c.pred_mode != 0 || c.log2_cu < 3) return m;
+    m.dir = c.inter_dir & 3; m.mvx = c.mvx; m.mvy = c.mvy; m.mv1x = c.mv1x; m.mv1y = c.mv1y; m.ok = true;
+    return m;
+}
+__global__ __launch_bounds__(256) void merge_pass_kernel(KsGeom g, int lam, const uint8_t *src, const uint8_t *planes0, const uint8_t *planes1, const ks265_pu *pu,
+                                                         const ks265_pu_b *pub, const ks265_cu8 *cu_in, ks265_cu8 *cu_out)
+{
+    __shared__ unsigned long long jbest[64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ctu = ks_xcd_swizzle(blockIdx.x, g.ctu_cols * g.ctu_rows), cx = ctu % g.ctu_cols, cy = ctu / g.ctu_cols;
+    const int tx = (lane & 1) | ((lane >> 1) & 2) | ((lane >> 2) & 4), ty = ((lane >> 1) & 1) | ((lane >> 2) & 2) | ((lane >> 3) & 4);
+    const int x0 = cx * 64 + tx * 8, y0 = cy * 64 + ty * 8;
+    const bool inside = x0 < g.W && y0 < g.H, is_b = pub != nullptr;
+    ks265_cu8 c;
+    c.mvx = c.mvy = c.mv1x = c.mv1y = 0; c.log2_cu = 0; c.cbf = 0; c.pred_mode = 1; c.inter_dir = 0;
+    if (inside) c = cu_in[(long)(y0 >> 3) * g.w8 + (x0 >> 3)];
+    const int log2 = c.log2_cu >= 3 ? c.log2_cu : 3, n = 1 << log2, cux = x0 & ~(n - 1), cuy = y0 & ~(n - 1), level = 6 - log2;
+    const int leader = lane & ~((1 << (2 * (log2 - 3))) - 1);
+    const long rb = (long)ctu * 85 + ks_level_base(level) + ((cuy & 63) >> log2) * (1 << level) + ((cux & 63) >> log2);
+    const unsigned cur = is_b ? pub[rb].cost : pu[rb].cost;
+    const bool valid = inside && c.pred_mode == 0 && c.log2_cu >= 3 && cur != KS_COST_INVALID;
+    if (tid < 64) jbest[tid] = ~0ull;
+    // which candidates exist for this tile's CU (every tile of a CU computes the same mask)
+    unsigned mask = 0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) mask |= (valid && merge_cand(g, cu_in, cux, cuy, n, k, is_b).ok ? 1u : 0u) << k;
+    unsigned f[16];
+    {
+        const uint8_t *frow = ks_org_y(g, src) + (long)(valid ? y0 : cy * 64) * g.sy + (valid ? x0 : cx * 64);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { const uint2 v = *(const uint2 *)(frow + (long)r * g.sy); f[2 * r] = v.x; f[2 * r + 1] = v.y; }
+    }
+    __syncthreads();
+    const long base = (long)(valid ? y0 : 0) * g.sy + (valid ? x0 : 0) + g.org_y;
+#pragma unroll 1
+    for (int k = wave; k < 6; k += 4) {
+        const bool on = (mask >> k) & 1u;
+        const MergeMotion m = merge_cand(g, cu_in, cux, cuy, n, k, is_b);
+        const int ax = on ? m.mvx : 0, ay = on ? m.mvy : 0, bx = on ? m.mv1x : 0, by = on ? m.mv1y : 0, dir = on ? m.dir : 1;
+        const uint8_t *pa = planes0 + (long)((ay & 3) * 4 + (ax & 3)) * g.bytes_y + base + (long)(ay >> 2) * g.sy + (ax >> 2);
+        const uint8_t *pb = (dir & 2) ? planes1 + (long)((by & 3) * 4 + (bx & 3)) * g.bytes_y + base + (long)(by >> 2) * g.sy + (bx >> 2) : pa;
+        if (!(dir & 1)) pa = pb;
+        unsigned sd = 0;
+        if (__any(on)) sd = satd8x8_avg(f, pa, pb, g.sy);
+        if (!on) sd = 0;
+        // CU sums at all four levels, each lane picks its CU's
+        const unsigned s3 = sd;
+        unsigned s2 = s3 + (unsigned)dpp_mov<KS265_DPP_QUAD_XOR1>((int)s3); s2 += (unsigned)dpp_mov<KS265_DPP_QUAD_XOR2>((int)s2);
+        unsigned s1 = s2 + (unsigned)dpp_mov<KS265_DPP_ROW_HALF_MIRROR>((int)s2); s1 += (unsigned)dpp_mov<KS265_DPP_ROW_MIRROR>((int)s1);
+        unsigned s0 = s1 + (unsigned)__builtin_amdgcn_ds_swizzle((int)s1, 0x1F | (16 << 10)); s0 += (unsigned)__shfl_xor((int)s0, 32, 64);
+        const unsigned sum = level == 3 ? s3 : level == 2 ? s2 : level == 1 ? s1 : s0;
+        if (on && lane == leader) {
+            const int pos = __popc(mask & ((1u << k) - 1u));
+            const unsigned long long j = (unsigned long long)sum + (unsigned long long)((lam * 16 * (pos + 1)) >> 4);
+            atomicMin(&jbest[leader], (j << 8) | (unsigned long long)k);
+        }
+    }
+    __syncthreads();
+    if (tid < 64 && inside) {
+        ks265_cu8 o = c;
+        if (valid) {
+            const unsigned long long jb = jbest[leader], jc = (unsigned long long)cur + (unsigned long long)((lam * 32) >> 4);
+            if ((jb >> 8) < jc) {
+                const MergeMotion m = merge_cand(g, cu_in, cux, cuy, n, (int)(jb & 255ull), is_b);
+                o.mvx = (int16_t)m.mvx; o.mvy = (int16_t)m.mvy; o.mv1x = (int16_t)m.mv1x; o.mv1y = (int16_t)m.mv1y; o.inter_dir = (uint8_t)(m.dir & 3);
+            }
+        }
+        cu_out[(long)(y0 >> 3) * g.w8 + (x0 >> 3)] = o;
+    }
+}
+
+extern "C" int ks265_merge_pass(ks265_frame *f, ks265_pic src, const uint8_t *planes0, const uint8_t *planes1, const ks265_pu *pu, const ks265_pu_b *pub,
+                                const ks265_cu8 *cu_in, ks265_cu8 *cu_out)
+{
+    KS_FRAME_CHECK(f);
+    if (!src.y || !planes0 || !cu_in || !cu_out || cu_in == cu_out || (!pu && !pub) || (pub && !planes1)) return KS265_POINTER;
+    hipLaunchKernelGGL(merge_pass_kernel, dim3(f->g.ctu_cols * f->g.ctu_rows), dim3(256), 0, f->ctx->stream, f->g, f->cfg.lambda_q4, src.y, planes0, planes1, pu, pub, cu_in, cu_out);
+    return ks265_check_launch(f->ctx);
+}
+
 extern "C" int ks265_cu_flat_intra(ks265_frame *f, ks265_cu8 *cu8)
 {
     KS_FRAME_CHECK(f);

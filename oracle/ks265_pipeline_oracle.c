@@ -400,6 +400,76 @@ void kso_cu_decide(const kso_frame_cfg *cfg, const kso_pu *pu, kso_cu8 *cu8)
         }
 }
 
+/* ------------------------------------------------------------------ Stage C2: merge pass (cfg->merge)
+ * The reference decides merge / skip per CU against the candidates of already coded neighbours (GetMergeCandsFor*, skipFastDecision; closed code,
+ * SURVEY.md B.9).  A frame-parallel decision has no coded neighbours, so this pass works on the motion field the CU decision left behind: every CU
+ * looks at its five spatial merge neighbours (A1, B1, B0, A0, B2 of H.265 8.5.3.2.3: inside the picture, earlier in z-scan order, inter) and at the
+ * zero vector, takes each one's motion as its own, and keeps the cheapest if it beats what the search found: SATD of the prediction + lambda x
+ * (position in the list + 1) against the CU's search cost + lambda x 2.  All CUs decide at once on the SAME input field (cu_in -> cu_out), so the
+ * result does not depend on any order; where a neighbour changes its motion in the same pass the adopted vector may no longer be a merge candidate
+ * when the slice is written - it is then coded explicitly, which is only a (rare) loss of bits, never of correctness.  Single reference per list. */
+static int z_of(int x, int y)                         /* z-scan address of the 8x8 block holding luma sample (x, y): CTB raster, then Morton inside the CTB */
+{
+    int bx = (x >> 3) & 7, by = (y >> 3) & 7, m = 0;
+    for (int b = 0; b < 3; ++b) m |= ((bx >> b) & 1) << (2 * b) | ((by >> b) & 1) << (2 * b + 1);
+    return m;
+}
+void kso_merge_pass(const kso_frame_cfg *cfg, kso_pic src, const uint8_t *planes0, const uint8_t *planes1, const kso_pu *pu, const kso_pu_b *pub,
+                    const kso_cu8 *cu_in, kso_cu8 *cu_out)
+{
+    kso_frame_geom g; kso_frame_geometry(cfg, &g);
+    const uint8_t *S = org_y(&g, src.y);
+    const long st = g.stride_y;
+    const int lam = cfg->lambda_q4, w8 = cfg->width / 8, h8 = cfg->height / 8, is_b = pub != NULL;
+    memcpy(cu_out, cu_in, sizeof(kso_cu8) * (size_t)w8 * h8);
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int by = 0; by < h8; ++by)
+        for (int bx = 0; bx < w8; ++bx) {
+            const kso_cu8 *c = &cu_in[(long)by * w8 + bx];
+            if (c->pred_mode != 0 || c->log2_cu < 3) continue;
+            const int n = 1 << c->log2_cu, x = bx * 8, y = by * 8;
+            if ((x & (n - 1)) || (y & (n - 1))) continue;                         /* a CU is handled at its first 8x8 block */
+            const int cx = x >> 6, cy = y >> 6, l = 6 - c->log2_cu, idx = pu_index(l, (x & 63) >> c->log2_cu, (y & 63) >> c->log2_cu);
+            const long rb = (long)(cy * g.ctu_cols + cx) * 85 + idx;
+            const uint32_t cur = (is_b ? pub[rb].cost : pu[rb].cost);
+            if (cur == COST_INVALID) continue;
+            uint64_t best = (uint64_t)cur + (uint64_t)((lam * 32) >> 4);
+            int bestk = -1;
+            kso_cu8 bm = *c;
+            const int nx[5] = {x - 1, x + n - 1, x + n, x - 1, x - 1}, ny[5] = {y + n - 1, y - 1, y - 1, y + n, y - 1};   /* A1 B1 B0 A0 B2 */
+            const int ctb = cy * g.ctu_cols + cx, zc = z_of(x, y);
+            int pos = 0;
+            for (int k = 0; k < 6; ++k) {
+                kso_cu8 m;
+                if (k < 5) {
+                    if (nx[k] < 0 || ny[k] < 0 || nx[k] >= cfg->width || ny[k] >= cfg->height) continue;
+                    const int nctb = (ny[k] >> 6) * g.ctu_cols + (nx[k] >> 6);
+                    if (nctb > ctb || (nctb == ctb && z_of(nx[k], ny[k]) >= zc)) continue;                              /* not yet coded when this CU is */
+                    m = cu_in[(long)(ny[k] >> 3) * w8 + (nx[k] >> 3)];
+                    if (m.pred_mode != 0 || m.log2_cu < 3) continue;
+                } else { memset(&m, 0, sizeof m); m.inter_dir = is_b ? 3 : 1; }
+                const int dir = m.inter_dir & 3;
+                const uint8_t *p0 = NULL, *p1 = NULL;
+                if (dir & 1) p0 = org_y(&g, (uint8_t *)planes0 + (long)((m.mvy & 3) * 4 + (m.mvx & 3)) * g.bytes_y) + (long)(y + (m.mvy >> 2)) * st + x + (m.mvx >> 2);
+                if (dir & 2) p1 = org_y(&g, (uint8_t *)planes1 + (long)((m.mv1y & 3) * 4 + (m.mv1x & 3)) * g.bytes_y) + (long)(y + (m.mv1y >> 2)) * st + x + (m.mv1x >> 2);
+                if (!p0) p0 = p1;
+                if (!p1) p1 = p0;
+                uint8_t avg[64 * 64];
+                for (int yy = 0; yy < n; ++yy)
+                    for (int xx = 0; xx < n; ++xx) avg[yy * n + xx] = (uint8_t)((p0[(long)yy * st + xx] + p1[(long)yy * st + xx] + 1) >> 1);
+                const uint64_t j = (uint64_t)ks265o_had(S + (long)y * st + x, avg, st, n, n, n) + (uint64_t)((lam * 16 * (pos + 1)) >> 4);
+                ++pos;
+                if (j < best) { best = j; bestk = k; bm = m; }
+            }
+            if (bestk < 0) continue;
+            for (int yy = 0; yy < n / 8; ++yy)
+                for (int xx = 0; xx < n / 8; ++xx) {
+                    kso_cu8 *o = &cu_out[(long)(by + yy) * w8 + bx + xx];
+                    o->mvx = bm.mvx; o->mvy = bm.mvy; o->mv1x = bm.mv1x; o->mv1y = bm.mv1y; o->inter_dir = (uint8_t)(bm.inter_dir & 3);
+                }
+        }
+}
+
 /* ------------------------------------------------------------------ B pictures
  * Per PU: L0 cost and L1 cost come from the two uni-directional searches; the bi-predictive candidate pairs the two winners
  * (no joint refinement yet: interMeBiFull enc@0x4896d0 refines around them) and is judged on SATD against the rounded

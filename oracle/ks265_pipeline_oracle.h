@@ -18,7 +18,7 @@ extern "C" {
 #endif
 
 typedef struct {
-    int32_t width, height, qp, lambda_q4, me_range, me_method, subme, deblock, sao, beta_offset_div2, tc_offset_div2, bframes, refs, me_hex_thr, sdh, pre_search;
+    int32_t width, height, qp, lambda_q4, me_range, me_method, subme, deblock, sao, beta_offset_div2, tc_offset_div2, bframes, refs, me_hex_thr, sdh, pre_search, merge;
 } kso_frame_cfg;
 
 typedef struct {
@@ -50,6 +50,9 @@ void kso_reconstruct(const kso_frame_cfg *cfg, kso_pic src, kso_pic ref, const u
 void kso_bi_decide(const kso_frame_cfg *cfg, kso_pic src, const uint8_t *planes0, const uint8_t *planes1, const kso_pu *pu0, const kso_pu *pu1,
                    kso_pu_b *pub);
 void kso_cu_decide_b(const kso_frame_cfg *cfg, const kso_pu_b *pub, kso_cu8 *cu8);
+/* stage C2 (cfg->merge): every CU may adopt the motion of one of its spatial merge neighbours (or the zero vector); pu for P pictures, pub for B pictures (the other NULL) */
+void kso_merge_pass(const kso_frame_cfg *cfg, kso_pic src, const uint8_t *planes0, const uint8_t *planes1, const kso_pu *pu, const kso_pu_b *pub,
+                    const kso_cu8 *cu_in, kso_cu8 *cu_out);
 /* intra pictures: mode pre-selection on source neighbours + CU quadtree, then the sequential reconstruction.
  * Intra CU in cu8: pred_mode = 2, mvx = luma mode (0 planar, 1 DC, 2..34 angular), chroma = the luma mode (DM). */
 void kso_intra_decide(const kso_frame_cfg *cfg, kso_pic src, kso_cu8 *cu8);

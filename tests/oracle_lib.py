@@ -45,7 +45,7 @@ I = C.c_int
 # ------------------------------------------------------------------ pipeline oracle (ks265_pipeline_oracle.h)
 class OFrameCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("width", "height", "qp", "lambda_q4", "me_range", "me_method", "subme", "deblock", "sao",
-                                          "beta_offset_div2", "tc_offset_div2", "bframes", "refs", "me_hex_thr", "sdh", "pre_search")]
+                                          "beta_offset_div2", "tc_offset_div2", "bframes", "refs", "me_hex_thr", "sdh", "pre_search", "merge")]
 
 
 class OFrameGeom(C.Structure):
@@ -80,10 +80,10 @@ class HostPic:
 class OraclePipeline:
     """CPU restatement of the frame stages (test checker / cpu_baseline 'port')."""
 
-    def __init__(self, width, height, qp, lambda_q4, me_range=64, subme=1, deblock=1, sao=1, me_method=0, intra=True, me_hex_thr=0, sdh=0, pre_search=0):
+    def __init__(self, width, height, qp, lambda_q4, me_range=64, subme=1, deblock=1, sao=1, me_method=0, intra=True, me_hex_thr=0, sdh=0, pre_search=0, merge=0):
         self.o = lib()
         self.intra = intra                      # key pictures: real intra prediction (True) or the flat stand-in
-        self.cfg = OFrameCfg(width, height, qp, lambda_q4, me_range, me_method, subme, deblock, sao, 0, 0, 1, 4, me_hex_thr, sdh, pre_search)
+        self.cfg = OFrameCfg(width, height, qp, lambda_q4, me_range, me_method, subme, deblock, sao, 0, 0, 1, 4, me_hex_thr, sdh, pre_search, merge)
         self.geom = OFrameGeom()
         assert self.o.kso_frame_geometry(C.byref(self.cfg), C.byref(self.geom)) == 0
         g = self.geom
@@ -132,6 +132,9 @@ class OraclePipeline:
                 o.kso_me_subpel(cfg, self.src.c(), ptr(self.planes), ptr(self.pu))
             if kind == "P":
                 o.kso_cu_decide(cfg, ptr(self.pu), ptr(self.cu8))
+                if self.cfg.merge:
+                    tmp = self.cu8.copy()
+                    o.kso_merge_pass(cfg, self.src.c(), ptr(self.planes), None, ptr(self.pu), None, ptr(tmp), ptr(self.cu8))
             else:
                 if not hasattr(self, "planes1"):
                     self.planes1 = np.zeros(16 * self.geom.bytes_y, np.uint8)
@@ -144,6 +147,9 @@ class OraclePipeline:
                     o.kso_me_subpel(cfg, self.src.c(), ptr(self.planes1), ptr(self.pu1))
                 o.kso_bi_decide(cfg, self.src.c(), ptr(self.planes), ptr(self.planes1), ptr(self.pu), ptr(self.pu1), ptr(self.pub))
                 o.kso_cu_decide_b(cfg, ptr(self.pub), ptr(self.cu8))
+                if self.cfg.merge:
+                    tmp = self.cu8.copy()
+                    o.kso_merge_pass(cfg, self.src.c(), ptr(self.planes), ptr(self.planes1), None, ptr(self.pub), ptr(tmp), ptr(self.cu8))
                 p1 = ptr(self.planes1)
         if kind == "I" and self.intra:
             o.kso_intra_reconstruct(cfg, self.src.c(), ptr(self.cu8), ptr(self.lvl[0]), ptr(self.lvl[1]), ptr(self.lvl[2]), self.rec.c())

@@ -31,19 +31,27 @@ CASES = {
     "wpp_hierb4_416x240": (416, 240, 30, 1, 0, 1, 1, "hier", 4),
     "wpp_ippp_56x200_qp12": (56, 200, 12, 1, 0, 1, 1, "ippp", 3),      # one CTU per row: no context hand-over, every row starts from the initial contexts
     "wpp_ippp_1280x720_umh": (1280, 720, 27, 2, 16, 1, 1, "ippp", 3),
+    # everything the C host (ks265_enc.c) switches on: sign-data hiding, pre-search, merge pass, WPP substreams
+    "enc_ippp_416x240_umh": (416, 240, 27, 2, 16, 1, 1, "ippp", 4),
+    "enc_hierb4_416x240": (416, 240, 30, 1, 0, 1, 1, "hier", 4),
+    "enc_ippp_1280x720_qp32": (1280, 720, 32, 1, 0, 1, 1, "ippp", 3),
 }
 
 
 def case_sdh(name: str) -> int:
-    return 1 if name.startswith(("sdh_", "ps_", "wpp_")) else 0
+    return 1 if name.startswith(("sdh_", "ps_", "wpp_", "enc_")) else 0
 
 
 def case_ps(name: str) -> int:
-    return 1 if name.startswith(("ps_", "wpp_")) else 0
+    return 1 if name.startswith(("ps_", "wpp_", "enc_")) else 0
 
 
 def case_wpp(name: str) -> int:
-    return 1 if name.startswith("wpp_") else 0
+    return 1 if name.startswith(("wpp_", "enc_")) else 0
+
+
+def case_merge(name: str) -> int:
+    return 1 if name.startswith("enc_") else 0
 
 
 def schedule(kind: str, par: int):
@@ -101,7 +109,7 @@ def oracle_encoder(name: str):
     W, H, qp, me, thr, sao, df, kind, par = CASES[name]
     n = 1 + max(s[0] for s in schedule(kind, par))
     clip = make_clip(W, H, n, seed=len(name) * 7 + W, abc=(17, 23, 9))
-    o = OraclePipeline(W, H, qp, lambda_q4(qp), me_method=me, me_hex_thr=thr, sao=sao, deblock=df, sdh=case_sdh(name), pre_search=case_ps(name))
+    o = OraclePipeline(W, H, qp, lambda_q4(qp), me_method=me, me_hex_thr=thr, sao=sao, deblock=df, sdh=case_sdh(name), pre_search=case_ps(name), merge=case_merge(name))
     dpb = {}
 
     def encode(d, k, l0, l1, q):

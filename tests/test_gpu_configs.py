@@ -25,14 +25,14 @@ def ks():
     c.close()
 
 
-def _ippp(ks, W, H, qp, me, nfr, seed, abc=(37, 53, 19), pan=(5, 3), hidden_offset=True, hex_thr=0, pre_search=0):
+def _ippp(ks, W, H, qp, me, nfr, seed, abc=(37, 53, 19), pan=(5, 3), hidden_offset=True, hex_thr=0, pre_search=0, merge=0):
     from ks265codec_amd.lib import KsFrame
     from ks265codec_amd.synth import lambda_q4, make_clip, psnr
     from oracle_lib import OraclePipeline
 
     clip = make_clip(W, H, nfr, seed=seed, abc=abc, pan=pan)
-    o = OraclePipeline(W, H, qp, lambda_q4(qp), me_method=me, me_hex_thr=hex_thr, pre_search=pre_search)
-    with KsFrame(ks, W, H, qp, lambda_q4(qp), me_method=me, me_hex_thr=hex_thr, pre_search=pre_search) as f:
+    o = OraclePipeline(W, H, qp, lambda_q4(qp), me_method=me, me_hex_thr=hex_thr, pre_search=pre_search, merge=merge)
+    with KsFrame(ks, W, H, qp, lambda_q4(qp), me_method=me, me_hex_thr=hex_thr, pre_search=pre_search, merge=merge) as f:
         src, a, b = f.new_pic(), f.new_pic(), f.new_pic()
         for t in range(nfr):
             q = qp + (1 if (t > 0 and hidden_offset) else 0)          # the reference's hidden hierarchy offset: I = Q, P = Q+1
@@ -89,12 +89,12 @@ def test_presearch_field(ks, W, H, me, rng_):
 
 
 def test_config1_720p_hex_qp32_presearch(ks):
-    _ippp(ks, 1280, 720, 32, 1, 4, seed=43, pre_search=1)
+    _ippp(ks, 1280, 720, 32, 1, 4, seed=43, pre_search=1, merge=1)
 
 
 def test_config3_2160p_umh_presearch(ks):
     """the bench workload with the pre-search candidates on (what the encoder runs)"""
-    _ippp(ks, 3840, 2160, 27, 2, 3, seed=7, abc=(67, 91, 33), pan=(8, 5), hex_thr=16, pre_search=1)
+    _ippp(ks, 3840, 2160, 27, 2, 3, seed=7, abc=(67, 91, 33), pan=(8, 5), hex_thr=16, pre_search=1, merge=1)
 
 
 def test_config4_bframes3_umh_720p(ks):
@@ -173,7 +173,7 @@ def test_fuzz_bounded(ks):
     for it in range(40):
         W, H = int(rng.integers(1, 60)) * 8, int(rng.integers(1, 40)) * 8
         qp, me = int(rng.integers(0, 52)), int(rng.integers(0, 3))
-        kw = dict(me_range=int(rng.choice([8, 16, 32, 64])), subme=int(rng.integers(0, 2)), deblock=int(rng.integers(0, 2)), sao=int(rng.integers(0, 2)), me_method=me, me_hex_thr=int(rng.choice([0, 0, 16, 40])), sdh=int(rng.integers(0, 2)), pre_search=int(rng.integers(0, 2)))
+        kw = dict(me_range=int(rng.choice([8, 16, 32, 64])), subme=int(rng.integers(0, 2)), deblock=int(rng.integers(0, 2)), sao=int(rng.integers(0, 2)), me_method=me, me_hex_thr=int(rng.choice([0, 0, 16, 40])), sdh=int(rng.integers(0, 2)), pre_search=int(rng.integers(0, 2)), merge=int(rng.integers(0, 2)))
         mode = str(rng.choice(["ippp", "mref", "hier"]))
         clip = make_clip(W, H, 9, seed=int(rng.integers(0, 10000)), noisy=bool(rng.integers(0, 2)))
         o = OraclePipeline(W, H, qp, lambda_q4(qp), **kw)
