@@ -73,7 +73,7 @@ struct IntraLds {
     unsigned char raw[3][132], fil[132];                 // reference arrays, corner at index 66 (luma: 64 + 1 + 64; chroma 32 + 1 + 32)
     int nz[3];
     int lastcg[3];
-    short LV[3][32 * RP], DU[3][32 * RP], CF[3][32 * RP];   // levels / quantisation remainders / coefficients of the TU (sign-data hiding)
+    __attribute__((aligned(8))) short LV[3][32 * RP], DU[3][32 * RP], CF[3][32 * RP];   // levels / quantisation remainders / coefficients of the TU (sign-data hiding)
     int cbf[64];
     ks265_cu8 cu[64];
     // reconstructed samples around the CTU being coded: row 0 = the row above the CTU (x = -1 .. 127: top-left, top, top-right),
@@ -157,8 +157,10 @@ __device__ __forceinline__ void tu_pipeline(IntraLds &L, const TuRole &r, const 
             nzc += l != 0;
             lv[i] = (unsigned short)(short)l;
             if (c.sdh) { const int o = r.qy * RP + r.qx + i; L.LV[cp][o] = (short)l; L.DU[cp][o] = (short)du; L.CF[cp][o] = (short)coef; }
-            else X[(r.qx + i) * RP + r.qy] = (short)dequant_one(l, dqs, 1 << (shift - 1), shift);
+            X[(r.qx + i) * RP + r.qy] = (short)dequant_one(l, dqs, 1 << (shift - 1), shift);
         }
+        // (with sign-data hiding the level plane is written after the hiding step, from LDS: a second store to the same address from another wave
+        //  could overtake this one - the LDS-only barriers of this kernel do not order HBM stores)
         if (!c.sdh) *(uint2 *)((cp == 0 ? c.lvl_y : (cp == 1 ? c.lvl_u : c.lvl_v)) + (long)(py + r.qy) * lstride + px + r.qx) =
             make_uint2(lv[0] | ((unsigned)lv[1] << 16), lv[2] | ((unsigned)lv[3] << 16));
         if (nzc) atomicAdd(&L.nz[cp], nzc);
@@ -166,36 +168,35 @@ __device__ __forceinline__ void tu_pipeline(IntraLds &L, const TuRole &r, const 
     tu_sync<BLOCK>();
     if (c.sdh) {
         // the postQuant seam (postQuant enc@0x4ace80): sign-data hiding with the TU's scan (H.265 7.4.9.11: intra 4x4 / 8x8 luma and 4x4 chroma
-        // follow the prediction mode); the lane holding the top row of a 4x4 coefficient group handles that group
+        // follow the prediction mode); the lane holding the top row of a 4x4 coefficient group handles that group from registers (recon_dev.h) and
+        // patches the one level that moves: the level plane in HBM and the dequantised (transposed) tile
         const int scan = (nn == 4 || (nn == 8 && cp == 0)) ? ((c.mode >= 6 && c.mode <= 14) ? 2 : (c.mode >= 22 && c.mode <= 30) ? 1 : 0) : 0;
         const bool owner = r.on && (r.qy & 3) == 0 && L.nz[cp] > 1;
         const int cbase = r.qy * RP + r.qx;
         unsigned survey = 0;
         int gorder = 0;
+        SbhRegs sr;
         if (owner) {
-            survey = sbh_survey(L.LV[cp], cbase, scan);
+            sbh_load(L.LV[cp], L.DU[cp], L.CF[cp], cbase, sr);
+            survey = sbh_survey_rs(sr, scan);
             gorder = sbh_group_order(scan, nn >> 2, r.qx >> 2, r.qy >> 2) + 1;
             if (survey >> 17) atomicMax(&L.lastcg[cp], gorder);
         }
         tu_sync<BLOCK>();
-        if (owner && survey) sbh_apply(L.LV[cp], L.DU[cp], L.CF[cp], cbase, scan, survey, L.lastcg[cp] == gorder);
-        tu_sync<BLOCK>();
-        if (r.on) {
-            const int ci = cp ? 1 : 0, dqs = c.qdq[ci], shift = l2 - 1;
-            unsigned short lv[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int l = L.LV[cp][r.qy * RP + r.qx + i];
-                lv[i] = (unsigned short)(short)l;
-                X[(r.qx + i) * RP + r.qy] = (short)dequant_one(l, dqs, 1 << (shift - 1), shift);
+        if (owner && survey) {
+            int nl = 0;
+            const int pos = sbh_apply_rs(sr, scan, survey, L.lastcg[cp] == gorder, nl);
+            if (pos >= 0) {
+                const int row = r.qy + (pos >> 2), col = r.qx + (pos & 3), ci = cp ? 1 : 0, shift = l2 - 1;
+                L.LV[cp][row * RP + col] = (short)nl;
+                X[col * RP + row] = (short)dequant_one(nl, c.qdq[ci], 1 << (shift - 1), shift);
             }
-            *(uint2 *)((cp == 0 ? c.lvl_y : (cp == 1 ? c.lvl_u : c.lvl_v)) + (long)(py + r.qy) * lstride + px + r.qx) =
-                make_uint2(lv[0] | ((unsigned)lv[1] << 16), lv[2] | ((unsigned)lv[3] << 16));
         }
         tu_sync<BLOCK>();
     }
     const bool live = r.on && L.nz[cp] != 0;
     if (r.on) {                                                     // inverse pass 1: T[y][x] = clip16((Mt[y] . Ct[x] + 64) >> 7)
+        if (c.sdh) *(uint2 *)((cp == 0 ? c.lvl_y : (cp == 1 ? c.lvl_u : c.lvl_v)) + (long)(py + r.qy) * lstride + px + r.qx) = *(const uint2 *)(L.LV[cp] + r.qy * RP + r.qx);
         int acc[4] = {0, 0, 0, 0};
         if (live) quad_dot(mt + r.qy * mp, X + r.qx * RP, RP, nn, acc);
         unsigned short o[4];

@@ -218,10 +218,10 @@ __device__ __forceinline__ void code_region(const KsGeom &g, int comp, int qp, i
             }
             lv[i] = (unsigned short)(short)l;
             if (sdh) { const int o = (oy + k) * RP + ox + j + i; LV[o] = (short)l; DU[o] = (short)du; CF[o] = (short)coef; }
-            else X[(oy + j + i) * RP + ox + k] = (short)dqv;
+            X[(oy + j + i) * RP + ox + k] = (short)dqv;
         }
         if (coded) {
-            if (!sdh) *(uint2 *)(lvl + (long)(Y0 + qy) * lstride + X0 + qx) = make_uint2(lv[0] | ((unsigned)lv[1] << 16), lv[2] | ((unsigned)lv[3] << 16));
+            *(uint2 *)(lvl + (long)(Y0 + qy) * lstride + X0 + qx) = make_uint2(lv[0] | ((unsigned)lv[1] << 16), lv[2] | ((unsigned)lv[3] << 16));
             if (nz) atomicAdd(&nzcnt[tb], nz);
         }
     }
@@ -230,34 +230,34 @@ __device__ __forceinline__ void code_region(const KsGeom &g, int comp, int qp, i
         // ---- the postQuant seam (postQuant enc@0x4ace80): sign-data hiding, one lane per 4x4 coefficient group of the region
         constexpr int NCG = RS / 4;                                   // groups per region row
         unsigned survey = 0;
-        int cbase = 0, gtb = 0, gorder = 0;
+        int cbase = 0, gtb = 0, gorder = 0, gn = 0, goy = 0, gox = 0;
+        SbhRegs sr;
         const bool owner = tid < NCG * NCG;
         if (owner) {
             const int gx = tid % NCG, gy = tid / NCG;                // group coordinates in the region
             const int gb = (gy * 4 / UNIT) * 4 + gx * 4 / UNIT;      // its 8x8-luma block
             const int g8 = 1 << tu_log2[gb], gtbx = (gb & 3) & ~(g8 - 1), gtby = (gb >> 2) & ~(g8 - 1);
             gtb = gtby * 4 + gtbx;
-            const int gn = g8 * UNIT;
+            gn = g8 * UNIT; goy = gtby * UNIT; gox = gtbx * UNIT;
             cbase = gy * 4 * RP + gx * 4;
             if (blk[gb].log2_cu != 0 && nzcnt[gtb] > 1) {
-                survey = sbh_survey(LV, cbase, 0);
+                sbh_load(LV, DU, CF, cbase, sr);
+                survey = sbh_survey_r<0>(sr);
                 gorder = sbh_group_order(0, gn / 4, gx - gtbx * UNIT / 4, gy - gtby * UNIT / 4) + 1;
                 if (survey >> 17) atomicMax(&lastcg[gtb], gorder);
             }
         }
         __syncthreads();
-        if (owner && survey) sbh_apply(LV, DU, CF, cbase, 0, survey, lastcg[gtb] == gorder);
-        __syncthreads();
-        if (has_quad) {
-            const int k = qy - oy, j = qx - ox, qp6 = qp / 6, dqs = kInvQuantScales[qp % 6] << qp6, shift = log2n - 1;
-            unsigned short lv[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int l = coded ? LV[(oy + k) * RP + ox + j + i] : 0;
-                lv[i] = (unsigned short)(short)l;
-                X[(oy + j + i) * RP + ox + k] = (short)(coded ? dequant_one(l, dqs, 1 << (shift - 1), shift) : 0);
+        if (owner && survey) {
+            // the one level that moves: patched where the quantiser left it - the level plane in HBM and the dequantised (transposed) tile
+            int nl = 0;
+            const int pos = sbh_apply_r<0>(sr, survey, lastcg[gtb] == gorder, nl);
+            if (pos >= 0) {
+                const int row = cbase / RP + (pos >> 2), col = cbase % RP + (pos & 3), l2n = 31 - __clz(gn), shift = l2n - 1;
+                const int dqs = kInvQuantScales[qp % 6] << (qp / 6);
+                lvl[(long)(Y0 + row) * lstride + X0 + col] = (int16_t)nl;
+                X[(goy + (col - gox)) * RP + gox + (row - goy)] = (short)dequant_one(nl, dqs, 1 << (shift - 1), shift);
             }
-            if (coded) *(uint2 *)(lvl + (long)(Y0 + qy) * lstride + X0 + qx) = make_uint2(lv[0] | ((unsigned)lv[1] << 16), lv[2] | ((unsigned)lv[3] << 16));
         }
         __syncthreads();
     }

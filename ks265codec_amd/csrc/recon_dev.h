@@ -106,4 +106,79 @@ __device__ __forceinline__ void sbh_apply(short *LV, const short *DU, const shor
     LV[min_off] = (short)(CF[min_off] >= 0 ? l + final_change : l - final_change);
 }
 
+// ---- the same in registers: the owner lane reads its group's four rows of LV / DU / CF once (twelve 8-byte LDS reads, all in flight together),
+// surveys it, and after the TU-wide "last group" is known decides from the registers alone.  The caller patches the one level that moved.
+struct SbhRegs { uint2 lv[4], du[4]; unsigned neg; };                       // rows of the 4x4 group; neg: bit y * 4 + x = coefficient < 0
+__device__ __forceinline__ void sbh_load(const short *LV, const short *DU, const short *CF, int base, SbhRegs &r)
+{
+    r.neg = 0;
+#pragma unroll
+    for (int y = 0; y < 4; ++y) {
+        r.lv[y] = *(const uint2 *)(LV + base + y * RP);
+        r.du[y] = *(const uint2 *)(DU + base + y * RP);
+        const uint2 c = *(const uint2 *)(CF + base + y * RP);
+        r.neg |= (((c.x >> 15) & 1u) | ((c.x >> 30) & 2u) | ((c.y >> 13) & 4u) | ((c.y >> 28) & 8u)) << (4 * y);
+    }
+}
+__device__ __forceinline__ int sbh_el(const uint2 (&a)[4], int x, int y)    // element (x, y), x and y compile-time after unrolling
+{
+    const unsigned w = x < 2 ? a[y].x : a[y].y;
+    return (int)(short)((x & 1) ? (w >> 16) : (w & 0xFFFFu));
+}
+template <int SCAN> __device__ __forceinline__ constexpr int sbh_px(int q) { return SCAN == 0 ? (int)((0x3323213210210100ull >> (4 * q)) & 3ull) : SCAN == 1 ? (q & 3) : (q >> 2); }
+template <int SCAN> __device__ __forceinline__ constexpr int sbh_py(int q) { return SCAN == 0 ? (int)((0x3231230123012010ull >> (4 * q)) & 3ull) : SCAN == 1 ? (q >> 2) : (q & 3); }
+// phase A on the registers: first | last << 8 | (sum & 1) << 16 | any << 17
+template <int SCAN> __device__ __forceinline__ unsigned sbh_survey_r(const SbhRegs &r)
+{
+    int first = 16, last = -1, sum = 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int l = sbh_el(r.lv, sbh_px<SCAN>(q), sbh_py<SCAN>(q));
+        if (l) { if (first == 16) first = q; last = q; }
+        sum += l;
+    }
+    return last < 0 ? 0u : ((unsigned)first | ((unsigned)last << 8) | ((unsigned)(sum & 1) << 16) | (1u << 17));
+}
+// phase B on the registers: returns the position (x | y << 2) of the level that moves and its new value, or -1
+template <int SCAN> __device__ __forceinline__ int sbh_apply_r(const SbhRegs &r, unsigned survey, bool is_last_group, int &new_level)
+{
+    if (!(survey >> 17)) return -1;
+    const int first = survey & 255, last = (survey >> 8) & 255, parity = (survey >> 16) & 1;
+    if (last - first < 4) return -1;
+    int lfirst = 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) if (q == first) lfirst = sbh_el(r.lv, sbh_px<SCAN>(q), sbh_py<SCAN>(q));
+    const int signbit = lfirst > 0 ? 0 : 1;
+    if (signbit == parity) return -1;
+    const int start = is_last_group ? last : 15;
+    int min_cost = 0x7fffffff, min_pos = -1, final_change = 0, min_l = 0;
+    bool min_neg = false;
+#pragma unroll
+    for (int q = 15; q >= 0; --q) {
+        const int x = sbh_px<SCAN>(q), y = sbh_py<SCAN>(q);
+        const int l = sbh_el(r.lv, x, y), du = sbh_el(r.du, x, y);
+        const bool neg = (r.neg >> (4 * y + x)) & 1u;
+        int cost, change;
+        if (l != 0) {
+            if (du > 0) { cost = -du; change = 1; }
+            else if (q == first && (l == 1 || l == -1)) { cost = 0x7fffffff; change = 0; }
+            else { cost = du; change = -1; }
+        } else if (q < first) {
+            if ((neg ? 1 : 0) != signbit) { cost = 0x7fffffff; change = 0; }
+            else { cost = -du; change = 1; }
+        } else { cost = -du; change = 1; }
+        if (q <= start && cost < min_cost) { min_cost = cost; final_change = change; min_pos = x | (y << 2); min_l = l; min_neg = neg; }
+    }
+    if (min_pos < 0) return -1;
+    if (min_l == 32767 || min_l == -32768) final_change = -1;
+    new_level = (int)(short)(!min_neg ? min_l + final_change : min_l - final_change);
+    return min_pos;
+}
+// run-time scan index (intra 4x4 / 8x8 follow the prediction mode): three unrolled variants
+__device__ __forceinline__ unsigned sbh_survey_rs(const SbhRegs &r, int scan) { return scan == 0 ? sbh_survey_r<0>(r) : scan == 1 ? sbh_survey_r<1>(r) : sbh_survey_r<2>(r); }
+__device__ __forceinline__ int sbh_apply_rs(const SbhRegs &r, int scan, unsigned survey, bool is_last, int &nl)
+{
+    return scan == 0 ? sbh_apply_r<0>(r, survey, is_last, nl) : scan == 1 ? sbh_apply_r<1>(r, survey, is_last, nl) : sbh_apply_r<2>(r, survey, is_last, nl);
+}
+
 }  // namespace ks265
