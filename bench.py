@@ -463,7 +463,7 @@ def encoded_leg(args, torch, dist, rank, world, dev_index, backend, sync_all):
 
     class Stats(C.Structure):
         _fields_ = [("frames", C.c_long), ("bytes", C.c_longlong), ("sse", C.c_double * 3), ("gpu_ms", C.c_double), ("host_write_ms", C.c_double),
-                    ("in_copy_ms", C.c_double), ("submit_ms", C.c_double), ("output_ms", C.c_double), ("lat_gpu_ms", C.c_double), ("lat_queue_ms", C.c_double)]
+                    ("in_copy_ms", C.c_double), ("submit_ms", C.c_double), ("output_ms", C.c_double), ("lat_gpu_ms", C.c_double), ("lat_queue_ms", C.c_double), ("key_wall_ms", C.c_double), ("key_cpu_ms", C.c_double), ("keys", C.c_long)]
 
     W, H = args.width, args.height
     try:
@@ -614,7 +614,8 @@ def encoded_leg(args, torch, dist, rank, world, dev_index, backend, sync_all):
     return {"fps": world * npic / dt, "dt": dt * args.steps / npic, "windows": win, "host_threads": threads, "host_cores": cores, "bytes_per_picture": bytes_a / args.steps,
             "psnr_y": 99.0 if mse == 0 else 10.0 * np.log10(255.0 ** 2 / mse), "slice_write_ms_per_picture": st.host_write_ms / max(1, st.frames), "preset": preset.decode(),
             "caller_ms_per_picture": {"input_copy": round(st.in_copy_ms / max(1, st.frames), 3), "enqueue": round(st.submit_ms / max(1, st.frames), 3), "output": round(st.output_ms / max(1, st.frames), 3),
-                                      "latency_enqueue_to_records_on_host": round(st.lat_gpu_ms / max(1, st.frames), 2), "latency_enqueue_to_writer_pickup": round(st.lat_queue_ms / max(1, st.frames), 2)},
+                                      "latency_enqueue_to_records_on_host": round(st.lat_gpu_ms / max(1, st.frames), 2), "latency_enqueue_to_writer_pickup": round(st.lat_queue_ms / max(1, st.frames), 2),
+                                      "key_picture_slice_wall_ms": round(st.key_wall_ms / max(1, st.keys), 2), "key_picture_slice_thread_ms": round(st.key_cpu_ms / max(1, st.keys), 2)},
             "gop": f"hierarchical-B {args.hier_b}" if args.hier_b else (f"P + {gop_b} B" if gop_b else "IPPP")}
 
 

@@ -85,6 +85,7 @@ int QY265ConfigParse(QY265EncConfig *p, const char *name, const char *value);
 typedef struct { long frames; long long bytes; double sse[3]; double gpu_ms; double host_write_ms;
                  double in_copy_ms, submit_ms, output_ms;   /* calling thread: input copy to pinned memory, enqueueing GPU work, waiting for / copying output */
                  double lat_gpu_ms, lat_queue_ms;           /* summed per picture: enqueue -> records on the host; enqueue -> a writer thread picked the picture up */
+                 double key_wall_ms, key_cpu_ms; long keys; /* key pictures: records on the host -> slice finished (wall), summed thread time of its rows */
 } ks265_enc_stats;
 int ks265_enc_get_stats(void *pEncoder, ks265_enc_stats *out);
 /* extension: write the reconstruction (I420, display order) to `path` - the reference CLI's `-o`; call between Open and the first picture */

@@ -62,6 +62,9 @@ int ks265_host_free(ks265_ctx *, void *host);
 int ks265_memcpy_h2d_async(ks265_ctx *, void *dev, const void *host, size_t bytes);
 int ks265_memcpy_d2h_async(ks265_ctx *, void *host, const void *dev, size_t bytes);
 int ks265_memcpy_d2d_async(ks265_ctx *, void *dev_dst, const void *dev_src, size_t bytes);
+/* device -> pinned host memory of ks265_host_malloc as a kernel of 32 work-groups on the context's stream (stores straight over PCIe): unlike a runtime
+ * copy that may run as a machine-filling shader, it leaves the compute units to whatever the other streams launch */
+int ks265_copy_out_async(ks265_ctx *, void *pinned_host, const void *dev, size_t bytes);
 int ks265_memset_async(ks265_ctx *, void *dev, int value, size_t bytes);
 int ks265_event_create(ks265_ctx *, void **ev);
 int ks265_event_record(ks265_ctx *, void *ev);

@@ -115,6 +115,23 @@ int ks265_memcpy_d2d_async(ks265_ctx *c, void *dst, const void *src, size_t byte
     if (!c || !dst || !src) return KS265_POINTER;
     return ks265_hip(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->stream));
 }
+// Device-to-host copy as a kernel with a SMALL grid writing straight into device-mapped pinned host memory: the runtime's own device-to-host copies
+// may run as a full-grid shader copy that fills every compute unit with waves waiting on PCIe and stalls whatever the other streams want to launch;
+// 32 work-groups keep enough stores in flight to fill the link and leave the machine to the pixel path.
+__global__ __launch_bounds__(256) void copy_out_kernel(uint4 *dst, const uint4 *src, size_t n16, unsigned char *dst_tail, const unsigned char *src_tail, int ntail)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+    if (blockIdx.x == 0 && (int)threadIdx.x < ntail) dst_tail[threadIdx.x] = src_tail[threadIdx.x];
+}
+int ks265_copy_out_async(ks265_ctx *c, void *pinned_host, const void *dev, size_t bytes)
+{
+    if (!c || !dev || !pinned_host) return KS265_POINTER;
+    if (((uintptr_t)pinned_host | (uintptr_t)dev) & 15) return ks265_hip(c, hipMemcpyAsync(pinned_host, dev, bytes, hipMemcpyDeviceToHost, c->stream));
+    const size_t n16 = bytes >> 4;
+    hipLaunchKernelGGL(copy_out_kernel, dim3(32), dim3(256), 0, c->stream, (uint4 *)pinned_host, (const uint4 *)dev, n16, (unsigned char *)pinned_host + (n16 << 4),
+                       (const unsigned char *)dev + (n16 << 4), (int)(bytes & 15));
+    return ks265_check_launch(c);
+}
 int ks265_memset_async(ks265_ctx *c, void *dev, int value, size_t bytes)
 {
     if (!c || !dev) return KS265_POINTER;

@@ -111,7 +111,7 @@ int QY265ConfigParse(QY265EncConfig *c, const char *name, const char *value)
 /* ------------------------------------------------------------------ encoder */
 #define MAX_DPB 12
 #define MAX_JOBS 128                                      /* upper bound of the ring of pictures in flight; the encoder sizes its ring (Enc::ring) by picture size */
-#define MAX_INPUT (MAX_JOBS + 16)
+#define MAX_INPUT (MAX_JOBS + 32)
 
 typedef struct Job {
     int used, done, error;
@@ -126,7 +126,7 @@ typedef struct Job {
     void *ev;                                             /* recorded after the D2H copies */
     uint8_t *nal; size_t nal_cap; long nal_len;
     int key_headers;                                      /* parameter sets go in front of this picture */
-    double t_write_ms, t_submit, t_event, t_taken;      /* wall-clock marks: enqueued, records on the host (seen by a writer), writer started */
+    double t_write_ms, t_submit, t_event, t_taken, t_done;      /* wall-clock marks: enqueued, records on the host (seen by a writer), writer started */
 } Job;
 
 typedef struct Input { int used, disp; long long pts; uint8_t *i420; } Input;          /* pinned */
@@ -158,6 +158,8 @@ typedef struct Enc {
     pthread_t th[64]; int nth; pthread_mutex_t mu; pthread_cond_t cv_work, cv_done; int quit;
     int next_work, npending;                              /* ring index of the next job to write, jobs whose records are on the host but not yet taken by a writer */
     pthread_t disp; int disp_on; pthread_cond_t cv_disp; int next_ready, nwait;   /* the one thread that waits for GPU events (in submission order) */
+    /* the scheduler thread: GOP decisions + every GPU enqueue of a picture (some thirty runtime calls) happen here, not on the caller's thread */
+    pthread_t sched; int sched_on; pthread_cond_t cv_sched, cv_sched_done; int sched_seen, sched_flush, sched_idle, sched_err;
     struct WorkerArg { struct Enc *e; int idx; } warg[64];
     /* output */
     QY265Nal nals[4 * MAX_JOBS + 8]; uint8_t *hdr; long hdr_len, hdr_part[3];
@@ -203,7 +205,8 @@ static void *dispatcher(void *arg)
 
 /* ---- slice writers.  Every picture is written as CTU-row substreams (entropy_coding_sync, the reference's WPP: ks265_wpp_*).  A writer thread takes
  *      the next picture and codes its rows one after the other - pictures of a GOP in parallel, no waiting inside a picture.  A key picture's slice is
- *      an order of magnitude longer than a P picture's and output is in coding order, so idle writers JOIN a key picture that is in progress: its rows
+ *      an order of magnitude longer than a P picture's and output is in coding order, so writers that look for work JOIN a key picture that is in
+ *      progress before they start another picture: its rows
  *      are handed out in ascending order, each row runs at most two CTUs behind the row above (the wavefront of qy265executeEncCtuTaskWpp enc@0x475d20). */
 static Job *find_helpable(Enc *e)
 {
@@ -221,8 +224,9 @@ static void *worker(void *arg)
         Job *j = NULL;
         int owner = 0;
         while (!e->quit) {
-            if (e->npending > 0) { j = &e->jobs[e->next_work]; e->next_work = (e->next_work + 1) % e->ring; --e->npending; owner = 1; break; }
+            /* a key picture in progress comes first: output is in coding order, everything coded after it waits for its slice */
             if ((j = find_helpable(e)) != NULL) break;
+            if (e->npending > 0) { j = &e->jobs[e->next_work]; e->next_work = (e->next_work + 1) % e->ring; --e->npending; owner = 1; break; }
             pthread_cond_wait(&e->cv_work, &e->mu);
         }
         if (e->quit) break;
@@ -268,7 +272,7 @@ static void *worker(void *arg)
                 const long n = ks265_wpp_finish(j->wpp, j->nal, j->nal_cap);
                 pthread_mutex_lock(&e->mu);
                 j->t_write_ms += now_ms() - t1;
-                j->nal_len = n; j->error = n < 0 ? (int)n : 0; j->done = 1;
+                j->nal_len = n; j->error = n < 0 ? (int)n : 0; j->done = 1; j->t_done = now_ms();
                 pthread_cond_broadcast(&e->cv_done);
             }
         }
@@ -293,7 +297,8 @@ static int submit(Enc *e, Input *in, int kind, int poc, int qp, const int *l0, i
 {
     /* wait for a free job slot (the ring is full only if the consumer did not drain it: block on the oldest) */
     pthread_mutex_lock(&e->mu);
-    while (e->njobs == e->ring) pthread_cond_wait(&e->cv_done, &e->mu);       /* drained by take_output() of the calling thread itself: never full here */
+    while (e->njobs == e->ring && !e->quit) pthread_cond_wait(&e->cv_done, &e->mu);
+    if (e->quit) { pthread_mutex_unlock(&e->mu); return QY_FAIL; }       /* drained by take_output() of the calling thread itself: never full here */
     Job *j = &e->jobs[e->job_tail];
     pthread_mutex_unlock(&e->mu);
     const size_t fsz = (size_t)e->W * e->H * 3 / 2;
@@ -334,7 +339,11 @@ static int submit(Enc *e, Input *in, int kind, int poc, int qp, const int *l0, i
     if (!r) r = ks265_event_record(e->ctx, e->ev_staged[k]);
     /* copy-out stream */
     if (!r) r = ks265_stream_wait_event(e->ctx_out, e->ev_staged[k]);
-    if (!r) r = ks265_memcpy_d2h_async(e->ctx_out, j->rec, e->stg[k], e->rec_off[6]);
+    if (!r) {
+        static int mode = -1;                                              /* KS265_D2H=runtime: the runtime's own copy (diagnosis) */
+        if (mode < 0) { const char *m = getenv("KS265_D2H"); mode = m && !strcmp(m, "runtime"); }
+        r = mode ? ks265_memcpy_d2h_async(e->ctx_out, j->rec, e->stg[k], e->rec_off[6]) : ks265_copy_out_async(e->ctx_out, j->rec, e->stg[k], e->rec_off[6]);
+    }
     if (!r) r = ks265_event_record(e->ctx_out, e->ev_drained[k]);
     if (!r) r = ks265_event_record(e->ctx_out, j->ev);
     if (r) return hip_rc(r);
@@ -362,6 +371,7 @@ static int submit(Enc *e, Input *in, int kind, int poc, int qp, const int *l0, i
     j->done = 0; j->error = 0; j->used = 1; j->started = 0; j->nrows = 0; j->next_row = 0; j->rows_done = 0;
     e->job_tail = (e->job_tail + 1) % e->ring; ++e->njobs; ++e->nwait;
     pthread_cond_signal(&e->cv_disp);
+    pthread_cond_broadcast(&e->cv_sched_done);                         /* progress: a caller waiting for the scheduler (input back-pressure, flush) looks again */
     pthread_mutex_unlock(&e->mu);
     return QY_OK;
 }
@@ -398,10 +408,9 @@ static int code_hier(Enc *e, int d, int a)
 }
 
 /* schedule whatever can be coded with the pictures received so far; flush = no more input will come */
-static int schedule(Enc *e, int flush)
+static int schedule(Enc *e, int flush, int have /* pictures [0, have) have arrived */)
 {
     for (;;) {
-        const int have = e->next_disp;                                 /* pictures [0, have) have arrived */
         const int d = e->coded_upto;                                   /* last anchor / last coded display index; -1 before the first picture */
         if (d + 1 >= have) return QY_OK;
         const int nxt = d + 1;
@@ -441,6 +450,33 @@ static int schedule(Enc *e, int flush)
     }
 }
 
+/* ---- the scheduler thread: runs schedule() whenever pictures have arrived (or a flush was asked for).  The caller's thread only copies the input
+ *      picture and collects output; this thread takes the GOP decisions and enqueues the GPU work of every picture. */
+static void *scheduler(void *arg)
+{
+    Enc *e = (Enc *)arg;
+    pthread_mutex_lock(&e->mu);
+    for (;;) {
+        while (!e->quit && e->sched_seen == e->next_disp && !e->sched_flush) { e->sched_idle = 1; pthread_cond_broadcast(&e->cv_sched_done); pthread_cond_wait(&e->cv_sched, &e->mu); }
+        if (e->quit) break;
+        e->sched_idle = 0;
+        const int flush = e->sched_flush, have = e->next_disp;
+        pthread_mutex_unlock(&e->mu);
+        const double t0 = now_ms();
+        const int r = schedule(e, flush, have);
+        const double dt = now_ms() - t0;
+        pthread_mutex_lock(&e->mu);
+        e->st.submit_ms += dt;
+        if (r && !e->sched_err) e->sched_err = r;
+        e->sched_seen = have;
+        if (flush && have == e->next_disp) e->sched_flush = 0;          /* everything that had arrived is scheduled */
+    }
+    e->sched_idle = 1;
+    pthread_cond_broadcast(&e->cv_sched_done);
+    pthread_mutex_unlock(&e->mu);
+    return NULL;
+}
+
 /* move finished pictures (in coding order) to the output array; wait while more than `max_in_flight` pictures are queued
  * (0 = drain everything, MAX_JOBS = never wait) */
 static int take_output(Enc *e, int max_in_flight, QY265Nal **pNals, int *n, QY265Picture *out)
@@ -473,6 +509,7 @@ static int take_output(Enc *e, int max_in_flight, QY265Nal **pNals, int *n, QY26
         if (out) { out->iSliceType = j->kind == 'I' ? 2 : j->kind == 'P' ? 1 : 0; out->poc = j->disp; out->pts = j->pts; out->dts = j->pts; }
         e->st.frames++; e->st.bytes += j->nal_len > 0 ? j->nal_len : 0; e->st.host_write_ms += j->t_write_ms;
         e->st.lat_gpu_ms += j->t_event - j->t_submit; e->st.lat_queue_ms += j->t_taken - j->t_submit;
+        if (j->kind == 'I') { e->st.key_wall_ms += j->t_done - j->t_event; e->st.key_cpu_ms += j->t_write_ms; e->st.keys++; }
         if (j->key_headers && e->cfg.bHeaderBeforeKeyframe) e->st.bytes += e->hdr_len;
         if (e->cfg.calcPsnr) {
             for (int k = 0; k < 3; ++k) e->st.sse[k] += (double)j->sse[k];
@@ -506,8 +543,9 @@ void QY265EncoderClose(void *h)
 {
     Enc *e = (Enc *)h;
     if (!e) return;
-    if (e->nth || e->disp_on) {
-        pthread_mutex_lock(&e->mu); e->quit = 1; pthread_cond_broadcast(&e->cv_work); pthread_cond_broadcast(&e->cv_disp); pthread_mutex_unlock(&e->mu);
+    if (e->nth || e->disp_on || e->sched_on) {
+        pthread_mutex_lock(&e->mu); e->quit = 1; pthread_cond_broadcast(&e->cv_work); pthread_cond_broadcast(&e->cv_disp); pthread_cond_broadcast(&e->cv_sched); pthread_cond_broadcast(&e->cv_done); pthread_mutex_unlock(&e->mu);
+        if (e->sched_on) pthread_join(e->sched, NULL);
         for (int i = 0; i < e->nth; ++i) pthread_join(e->th[i], NULL);
         if (e->disp_on) pthread_join(e->disp, NULL);
     }
@@ -546,7 +584,7 @@ void QY265EncoderClose(void *h)
     }
     for (int i = 0; i < MAX_JOBS; ++i) free(e->jobs[i].wpp);
     free(e->hdr); free(e->outbuf);
-    pthread_mutex_destroy(&e->mu); pthread_cond_destroy(&e->cv_work); pthread_cond_destroy(&e->cv_done); pthread_cond_destroy(&e->cv_disp);
+    pthread_mutex_destroy(&e->mu); pthread_cond_destroy(&e->cv_work); pthread_cond_destroy(&e->cv_done); pthread_cond_destroy(&e->cv_disp); pthread_cond_destroy(&e->cv_sched); pthread_cond_destroy(&e->cv_sched_done);
     free(e);
 }
 
@@ -559,7 +597,7 @@ void *QY265EncoderOpen(QY265EncConfig *cfg, int *err)
     Enc *e = (Enc *)calloc(1, sizeof *e);
     if (e) e->recon_fd = -1;
     if (!e) { *err = QY_OUTOFMEMORY; return NULL; }
-    pthread_mutex_init(&e->mu, NULL); pthread_cond_init(&e->cv_work, NULL); pthread_cond_init(&e->cv_done, NULL); pthread_cond_init(&e->cv_disp, NULL);
+    pthread_mutex_init(&e->mu, NULL); pthread_cond_init(&e->cv_work, NULL); pthread_cond_init(&e->cv_done, NULL); pthread_cond_init(&e->cv_disp, NULL); pthread_cond_init(&e->cv_sched, NULL); pthread_cond_init(&e->cv_sched_done, NULL);
     e->cfg = *cfg; e->W = cfg->picWidth; e->H = cfg->picHeight; e->log_level = cfg->logLevel;
     e->me_method = cfg->me < 0 ? 1 : cfg->me > 2 ? 2 : cfg->me;        /* EPZS / Cross (-me 3 / 4) are not built: UMH instead */
     e->hex_thr = (e->me_method == 2 && (cfg->preset == QY265PRESET_SLOW || cfg->preset == QY265PRESET_SLOWER)) ? 16 : 0;   /* tME+0x368, SURVEY-measured */
@@ -632,7 +670,7 @@ void *QY265EncoderOpen(QY265EncConfig *cfg, int *err)
         j->nal = (uint8_t *)malloc(j->nal_cap);
         if (!j->nal) r = KS265_OUTOFMEMORY;
     }
-    for (int i = 0; i < e->ring + 16 && !r; ++i) r = ks265_host_malloc(e->ctx, (void **)&e->in[i].i420, fsz);
+    for (int i = 0; i < e->ring + 32 && !r; ++i) r = ks265_host_malloc(e->ctx, (void **)&e->in[i].i420, fsz);
     if (r) { *err = hip_rc(r); QY265EncoderClose(e); return NULL; }
     memset(&e->scfg, 0, sizeof e->scfg);
     e->scfg.width = e->W; e->scfg.height = e->H; e->scfg.sao = e->use_sao; e->scfg.deblock = e->use_df;
@@ -651,7 +689,8 @@ void *QY265EncoderOpen(QY265EncConfig *cfg, int *err)
     for (int i = 0; i < e->ring; ++i) { e->jobs[i].wpp = malloc(ks265_wpp_bytes(&e->scfg)); if (!e->jobs[i].wpp) { *err = QY_OUTOFMEMORY; QY265EncoderClose(e); return NULL; } }   /* virtual until used */
     for (int i = 0; i < e->nthreads; ++i) { e->warg[i].e = e; e->warg[i].idx = i; if (pthread_create(&e->th[i], NULL, worker, &e->warg[i])) break; ++e->nth; }
     if (e->nth && !pthread_create(&e->disp, NULL, dispatcher, e)) e->disp_on = 1;
-    if (!e->nth || !e->disp_on) { *err = QY_FAIL; QY265EncoderClose(e); return NULL; }
+    if (e->disp_on && !pthread_create(&e->sched, NULL, scheduler, e)) e->sched_on = 1;
+    if (!e->nth || !e->disp_on || !e->sched_on) { *err = QY_FAIL; QY265EncoderClose(e); return NULL; }
     logf_(0, e->log_level, "ks265enc: %dx%d %.2f fps, qp %d, -me %d (hex below %d), subme %d, refs %d, %s, sao %d, key period %d, %d slice writer threads, %s\n", e->W, e->H,
           cfg->frameRate, e->base_qp, e->me_method, e->hex_thr, e->subme, e->refs, e->hier ? "hierarchical-B GOP 8" : e->gop_b ? "P + non-reference B" : "IPPP", e->use_sao, e->iper,
           e->nth, ks265_version());
@@ -698,8 +737,14 @@ int QY265EncoderEncodeFrame(void *h, QY265Nal **pNals, int *iNalCount, QY265Pict
         if (in->yuv->iWidth != e->W || in->yuv->iHeight != e->H) return QY_NOTSUPPORTED;
         Input *slot = NULL;
         const double tc0 = now_ms();
-        for (int i = 0; i < e->ring + 16 && !slot; ++i) if (!e->in[i].used) slot = &e->in[i];
-        if (!slot) return QY_FAIL;                                     /* cannot happen: MAX_INPUT > MAX_JOBS + one mini-GOP */
+        pthread_mutex_lock(&e->mu);
+        /* back-pressure on the input side: at most 16 pictures wait for the scheduler thread (it may itself be waiting for ring space, which only this
+         * thread's take_output frees - then go on and collect) */
+        while (!e->quit && e->next_disp - (e->coded_upto + 1) > 16 && e->njobs <= e->ring - 12) pthread_cond_wait(&e->cv_sched_done, &e->mu);
+        for (int i = 0; i < e->ring + 32 && !slot; ++i) if (!e->in[i].used) slot = &e->in[i];
+        if (slot) slot->used = 3;                                      /* being filled */
+        pthread_mutex_unlock(&e->mu);
+        if (!slot) return QY_FAIL;                                     /* cannot happen: there are more input slots than pictures in flight + one mini-GOP */
         uint8_t *u = slot->i420 + (size_t)e->W * e->H, *v = u + (size_t)e->W * e->H / 4;
         if (in->yuv->iStride[0] == e->W && in->yuv->iStride[1] == e->W / 2 && in->yuv->iStride[2] == e->W / 2) {    /* packed planes: three block copies */
             memcpy(slot->i420, in->yuv->pData[0], (size_t)e->W * e->H);
@@ -712,26 +757,35 @@ int QY265EncoderEncodeFrame(void *h, QY265Nal **pNals, int *iNalCount, QY265Pict
             memcpy(v + (size_t)y * (e->W / 2), in->yuv->pData[2] + (size_t)y * in->yuv->iStride[2], (size_t)e->W / 2);
         }
         }
+        pthread_mutex_lock(&e->mu);
         slot->disp = e->next_disp++; slot->pts = in->pts; slot->used = 1;
+        pthread_cond_signal(&e->cv_sched);                             /* the scheduler thread takes it from here */
+        pthread_mutex_unlock(&e->mu);
         e->st.in_copy_ms += now_ms() - tc0;
-    }
-    /* Output first (finished pictures are copied to the output buffer, so scheduling new work right after is safe); when the ring of
-     * in-flight pictures is nearly full, wait for the oldest ones - only as many as needed, the writers keep running. */
-    if (in) {
+        /* finished pictures (copied to the output buffer); when the ring of in-flight pictures is nearly full, wait for the oldest ones -
+         * only as many as needed, the writers keep running */
         const double t0 = now_ms();
         r = take_output(e, e->ring - 12, pNals, iNalCount, out);
-        const double t1 = now_ms();
-        const int r2 = schedule(e, 0);
-        e->st.output_ms += t1 - t0; e->st.submit_ms += now_ms() - t1;
-        return r ? r : r2;
+        e->st.output_ms += now_ms() - t0;
+        return r ? r : e->sched_err;
     }
+    /* flush: everything that has arrived is scheduled (short mini-GOPs at the end), then every picture in flight is collected */
     const double t0 = now_ms();
-    r = schedule(e, 1);
-    const double t1 = now_ms();
-    e->st.submit_ms += t1 - t0;
-    if (r) return r;
-    r = take_output(e, 0, pNals, iNalCount, out);
-    e->st.output_ms += now_ms() - t1;
+    pthread_mutex_lock(&e->mu);
+    e->sched_flush = 1;
+    pthread_cond_signal(&e->cv_sched);
+    /* wait for the scheduler - unless the ring fills up first (it then waits for THIS thread to collect output): hand out what is ready and let the
+     * caller come back, as the SDK's flush loop does anyway (EncodeFrame(NULL) while DelayedFrames() > 0) */
+    int all = 0;
+    for (;;) {
+        all = !e->sched_flush && e->sched_idle && e->sched_seen == e->next_disp;
+        if (all || e->quit || e->njobs > e->ring - 12) break;
+        pthread_cond_wait(&e->cv_sched_done, &e->mu);
+    }
+    pthread_mutex_unlock(&e->mu);
+    if (e->sched_err) return e->sched_err;
+    r = take_output(e, all ? 0 : e->ring - 12, pNals, iNalCount, out);
+    e->st.output_ms += now_ms() - t0;
     return r;
 }
 
