@@ -347,6 +347,15 @@ ks265_sao_param *ks265_frame_sao(ks265_frame *f);
  * aligned to 256, off[6] = size of the block.  ks265_frame_pack_records copies them there on the context's stream (dev_extra64 may be NULL). */
 int ks265_frame_records_layout(ks265_frame *f, size_t off[7]);
 int ks265_frame_pack_records(ks265_frame *f, void *dev_dst, const void *dev_extra64);
+/* The same records in COMPACT form: the level planes cut into lines of 64 bytes (32 levels of a row; planes Y, Cb, Cr one after the other, each rounded up
+ * to whole lines), only the lines that hold a level are stored.  off[0..6] = byte offsets of { CU map, SAO records, 64 caller bytes, header of four uint32
+ * (unused, unused, data_lines, lines), chunk table (uint32 per 1024 lines: index in the data area of the chunk's first stored line), line bitmap (bit L of
+ * the little-endian 64-bit words: line L is stored), data area }, off[7] = capacity of the block (data area sized for every line).  ks265_frame_pack_compact
+ * builds the block in HBM on the frame's stream; ks265_copy_out_compact_async copies its fixed part and the data_lines stored lines to mapped pinned host
+ * memory on ANOTHER context's stream (a 32-work-group kernel; the size is read on the device, the host learns it from the header). */
+int ks265_frame_compact_layout(ks265_frame *f, size_t off[8]);
+int ks265_frame_pack_compact(ks265_frame *f, void *dev_dst, const void *dev_extra64);
+int ks265_copy_out_compact_async(ks265_ctx *copy_ctx, ks265_frame *f, void *pinned_host, const void *dev_block);
 uint8_t *ks265_frame_planes(ks265_frame *f);
 /* luma SSE between two padded pictures (PSNR-Y of the bench line; CPSNR_I420::calcPSNR enc@0x4c4060) */
 int ks265_sse_picture(ks265_frame *f, ks265_pic a, ks265_pic b, uint64_t *dev_sse3);

@@ -262,6 +262,131 @@ int ks265_frame_pack_records(ks265_frame *f, void *dev_dst, const void *dev_extr
     hipLaunchKernelGGL(pack_records_kernel, dim3(gx ? gx : 1, 6), dim3(256), 0, f->ctx->stream, sg, (uint8_t *)dev_dst);
     return ks265_check_launch(f->ctx);
 }
+// ------------------------------------------------------------------ compact records: the level planes without their all-zero 64-byte lines
+// A P / B picture's levels are almost all zero; what leaves the GPU per picture is then ~2 MB instead of 26 MB (2160p).  The three level planes are cut
+// into lines of 64 bytes (32 levels of one row); a line bitmap says which lines hold a level, those lines follow back to back.  A work-group handles a
+// chunk of 1024 lines: ballots give the bitmap words and the line's rank inside the chunk, one atomic add reserves the chunk's room in the data area and
+// the chunk table records where (chunks may land in any order; inside a chunk the lines keep their order).  The last work-group to finish publishes the
+// total and clears the running counters for the next picture (no memset launch).
+#define KS_CL_LINE 64
+#define KS_CL_CHUNK 1024
+struct CompactArgs { const uint8_t *plane[3]; unsigned long long plane_bytes[3]; unsigned first_line[4]; unsigned nchunk; };
+__global__ __launch_bounds__(256) void pack_compact_kernel(CompactArgs a, unsigned *hdr /* run_lines, done, data_lines, nlines */, unsigned *table, unsigned long long *bitmap, uint4 *data)
+{
+    __shared__ unsigned cnt[16], base_sh;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const unsigned chunk = blockIdx.x, nlines = a.first_line[3];
+    uint4 v[4][4];
+    bool nz[4];
+    unsigned rank_in_wave[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const unsigned L = chunk * KS_CL_CHUNK + p * 256 + t;
+        nz[p] = false;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[p][q] = make_uint4(0, 0, 0, 0);
+        if (L < nlines) {
+            const int pl = L >= a.first_line[2] ? 2 : L >= a.first_line[1] ? 1 : 0;
+            const unsigned long long off = (unsigned long long)(L - a.first_line[pl]) * KS_CL_LINE;
+            const uint8_t *src = a.plane[pl] + off;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (off + 16 * q + 16 <= a.plane_bytes[pl]) v[p][q] = *(const uint4 *)(src + 16 * q);       // planes are multiples of 16 bytes long
+            unsigned o = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o |= v[p][q].x | v[p][q].y | v[p][q].z | v[p][q].w;
+            nz[p] = o != 0;
+        }
+        const unsigned long long b = __ballot(nz[p]);
+        rank_in_wave[p] = (unsigned)__popcll(b & ((1ull << lane) - 1ull));
+        if (lane == 0) {
+            cnt[p * 4 + wave] = (unsigned)__popcll(b);
+            const unsigned word = chunk * (KS_CL_CHUNK / 64) + p * 4 + wave;
+            if (word * 64 < nlines) bitmap[word] = b;
+        }
+    }
+    __syncthreads();
+    if (t == 0) {
+        unsigned tot = 0;
+        for (int i = 0; i < 16; ++i) { const unsigned c = cnt[i]; cnt[i] = tot; tot += c; }
+        const unsigned base = tot ? atomicAdd(&hdr[0], tot) : 0u;
+        table[chunk] = base;
+        base_sh = base;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+        if (nz[p]) {
+            uint4 *d = data + (unsigned long long)(base_sh + cnt[p * 4 + wave] + rank_in_wave[p]) * (KS_CL_LINE / 16);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) d[q] = v[p][q];
+        }
+    __syncthreads();
+    if (t == 0) {
+        __threadfence();
+        if (atomicAdd(&hdr[1], 1u) == a.nchunk - 1u) {
+            __threadfence();
+            hdr[2] = atomicExch(&hdr[0], 0u);
+            hdr[3] = nlines;
+            atomicExch(&hdr[1], 0u);
+        }
+    }
+}
+// copy-out of a compact block: the fixed part, then as many data lines as the header says (read on the device: the host does not know the size yet)
+__global__ __launch_bounds__(256) void copy_out_compact_kernel(uint4 *dst, const uint4 *src, unsigned long long fixed16, const unsigned *hdr)
+{
+    const unsigned long long n16 = fixed16 + (unsigned long long)hdr[2] * (KS_CL_LINE / 16);
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (unsigned long long)gridDim.x * 256) dst[i] = src[i];
+}
+static void compact_layout(const ks265_frame *f, size_t off[8])
+{
+    const size_t npx = (size_t)f->g.W * f->g.H;
+    const size_t pb[3] = {npx * 2, npx / 2, npx / 2};
+    size_t nlines = 0;
+    for (int i = 0; i < 3; ++i) nlines += (pb[i] + KS_CL_LINE - 1) / KS_CL_LINE;
+    const size_t nchunk = (nlines + KS_CL_CHUNK - 1) / KS_CL_CHUNK;
+    const size_t sz[7] = {(size_t)f->geom.bytes_cu8, (size_t)f->geom.bytes_sao, 64, 64, nchunk * 4, nchunk * (KS_CL_CHUNK / 8), nlines * KS_CL_LINE};
+    size_t o = 0;
+    for (int i = 0; i < 7; ++i) { off[i] = o; o += (sz[i] + 255) & ~(size_t)255; }
+    off[7] = o;
+}
+int ks265_frame_compact_layout(ks265_frame *f, size_t off[8])
+{
+    if (!f || !off) return KS265_POINTER;
+    compact_layout(f, off);
+    return KS265_OK;
+}
+int ks265_frame_pack_compact(ks265_frame *f, void *dev_dst, const void *dev_extra64)
+{
+    KS_FRAME_CHECK(f);
+    if (!dev_dst) return KS265_POINTER;
+    size_t off[8];
+    compact_layout(f, off);
+    const size_t npx = (size_t)f->g.W * f->g.H;
+    PackSegs sg = {};
+    const void *src[3] = {f->cu8, f->sao, dev_extra64};
+    const size_t sz[3] = {(size_t)f->geom.bytes_cu8, (size_t)f->geom.bytes_sao, 64};
+    for (int i = 0; i < 3; ++i) { sg.src[i] = (const uint8_t *)src[i]; sg.off[i] = off[i]; sg.bytes[i] = sz[i]; }
+    const unsigned gx = (unsigned)((sz[0] / 16 + 256 * 8 - 1) / (256 * 8));
+    hipLaunchKernelGGL(pack_records_kernel, dim3(gx ? gx : 1, 3), dim3(256), 0, f->ctx->stream, sg, (uint8_t *)dev_dst);
+    CompactArgs a;
+    const size_t pb[3] = {npx * 2, npx / 2, npx / 2};
+    unsigned fl = 0;
+    for (int i = 0; i < 3; ++i) { a.plane[i] = (const uint8_t *)f->lvl[i]; a.plane_bytes[i] = pb[i]; a.first_line[i] = fl; fl += (unsigned)((pb[i] + KS_CL_LINE - 1) / KS_CL_LINE); }
+    a.first_line[3] = fl; a.nchunk = (fl + KS_CL_CHUNK - 1) / KS_CL_CHUNK;
+    uint8_t *d = (uint8_t *)dev_dst;
+    hipLaunchKernelGGL(pack_compact_kernel, dim3(a.nchunk), dim3(256), 0, f->ctx->stream, a, (unsigned *)(d + off[3]), (unsigned *)(d + off[4]), (unsigned long long *)(d + off[5]), (uint4 *)(d + off[6]));
+    return ks265_check_launch(f->ctx);
+}
+int ks265_copy_out_compact_async(ks265_ctx *ctx, ks265_frame *f, void *pinned_host, const void *dev_block)
+{
+    if (!ctx || !f || !pinned_host || !dev_block) return KS265_POINTER;
+    size_t off[8];
+    compact_layout(f, off);
+    hipLaunchKernelGGL(copy_out_compact_kernel, dim3(32), dim3(256), 0, ctx->stream, (uint4 *)pinned_host, (const uint4 *)dev_block, (unsigned long long)(off[6] / 16),
+                       (const unsigned *)((const uint8_t *)dev_block + off[3]));
+    return ks265_check_launch(ctx);
+}
 uint8_t *ks265_frame_planes(ks265_frame *f) { return f ? f->planes : nullptr; }
 
 }  // extern "C"

@@ -118,8 +118,9 @@ typedef struct Job {
     int disp, poc, kind, qp, nal_type, is_ref;            /* kind: 'I' 'P' 'B' */
     long long pts;
     int nl0, nl1, l0[4], l1[4], nrps, rps_poc[16]; unsigned char rps_used[16];
-    uint8_t *rec;                                         /* pinned host copy of the GPU's records: one block (ks265_frame_records_layout) */
-    ks265_cu8 *cu8; int16_t *lvl[3]; ks265_sao_param *sao; uint64_t *sse;      /* pointers into rec */
+    uint8_t *cmp;                                         /* pinned host copy of the GPU's records in compact form (ks265_frame_compact_layout) */
+    uint8_t *lvlbuf; uint64_t *dirty;                     /* the level planes expanded from it (plain memory) and the lines the previous picture in this slot set */
+    ks265_cu8 *cu8; int16_t *lvl[3]; ks265_sao_param *sao; uint64_t *sse;      /* cu8 / sao / sse point into cmp, lvl into lvlbuf */
     int ev_err;
     void *wpp; ks265_slice_in sin; int started, nrows, next_row, rows_done;   /* row-wise writing of the slice (ks265_wpp_*) */
     uint8_t *recon;                                       /* pinned I420 copy of the reconstruction (only with ks265_enc_set_recon_file) */
@@ -143,7 +144,7 @@ typedef struct Enc {
 #define NPIPE 3
     ks265_ctx *ctx_in, *ctx_out;
     uint8_t *dev_in[NPIPE]; void *ev_h2d[NPIPE], *ev_loaded[NPIPE];
-    uint8_t *stg[NPIPE]; size_t rec_off[7];               /* staging blocks of the records (device) and their layout */
+    uint8_t *stg[NPIPE]; size_t cmp_off[8];               /* staging blocks of the (compact) records on the device and their layout */
     void *ev_staged[NPIPE], *ev_drained[NPIPE];
     long seq;                                             /* pictures submitted */
     int recon_fd; uint8_t *dev_recon;                     /* reconstruction dump (the CLI's -o) */
@@ -208,6 +209,48 @@ static void *dispatcher(void *arg)
  *      an order of magnitude longer than a P picture's and output is in coding order, so writers that look for work JOIN a key picture that is in
  *      progress before they start another picture: its rows
  *      are handed out in ascending order, each row runs at most two CTUs behind the row above (the wavefront of qy265executeEncCtuTaskWpp enc@0x475d20). */
+/* the level planes of one CTU row of a picture from its compact records: clear the lines the previous picture in this job slot had set there, put this
+ * picture's lines in place.  Done by the thread that writes the row (rows of a key picture by different threads); a line that straddles two CTU rows is
+ * written twice with the same bytes.  ctu_row < 0: the whole picture. */
+static void expand_levels(Enc *e, Job *j, int ctu_row)
+{
+    const size_t npx = (size_t)e->W * e->H, pb[3] = {npx * 2, npx / 2, npx / 2};
+    uint8_t *plane[3] = {(uint8_t *)j->lvl[0], (uint8_t *)j->lvl[1], (uint8_t *)j->lvl[2]};
+    size_t first[4]; first[0] = 0;
+    for (int p = 0; p < 3; ++p) first[p + 1] = first[p] + (pb[p] + 63) / 64;
+    const uint32_t *table = (const uint32_t *)(j->cmp + e->cmp_off[4]);
+    const uint64_t *bm = (const uint64_t *)(j->cmp + e->cmp_off[5]);
+    const uint8_t *data = j->cmp + e->cmp_off[6];
+    for (int p = 0; p < 3; ++p) {
+        /* byte range of the CTU row in this plane -> line range */
+        const size_t rowb = (size_t)(p ? e->W / 2 : e->W) * 2, rows = (size_t)(p ? e->H / 2 : e->H), ch = p ? 32 : 64;
+        size_t y0 = ctu_row < 0 ? 0 : (size_t)ctu_row * ch, y1 = ctu_row < 0 ? rows : y0 + ch;
+        if (y1 > rows) y1 = rows;
+        if (y0 >= y1) continue;
+        const size_t l0 = first[p] + y0 * rowb / 64, l1 = first[p] + (y1 * rowb + 63) / 64;
+        for (int pass = 0; pass < 2; ++pass)                           /* 0: clear the old lines, 1: place the new ones */
+            for (size_t w = l0 / 64; w <= (l1 - 1) / 64; ++w) {
+                uint64_t bits = pass ? bm[w] : j->dirty[w];
+                if (w == l0 / 64) bits &= ~0ull << (l0 & 63);
+                if (w == (l1 - 1) / 64 && (l1 & 63)) bits &= ~0ull >> (64 - (l1 & 63));
+                if (!bits) continue;
+                size_t k = 0;
+                if (pass) {                                            /* rank of the word's first line in the data area: chunk base + lines of the chunk's earlier words */
+                    k = (size_t)table[w / 16];
+                    for (size_t q = w & ~(size_t)15; q < w; ++q) k += (size_t)__builtin_popcountll(bm[q]);
+                    k += (size_t)__builtin_popcountll(bm[w] & ~bits & ((bits & (~bits + 1)) - 1));      /* lines of this word below the range */
+                }
+                while (bits) {
+                    const int b = __builtin_ctzll(bits);
+                    bits &= bits - 1;
+                    const size_t L = w * 64 + (size_t)b;
+                    const size_t off = (L - first[p]) * 64, n = pb[p] - off < 64 ? pb[p] - off : 64;
+                    if (pass) memcpy(plane[p] + off, data + (k++) * 64, n); else memset(plane[p] + off, 0, n);
+                }
+            }
+    }
+}
+
 static Job *find_helpable(Enc *e)
 {
     for (int i = 0, k = e->job_head; i < e->njobs; ++i, k = (k + 1) % e->ring) {
@@ -262,6 +305,7 @@ static void *worker(void *arg)
             const int row = j->next_row++;
             pthread_mutex_unlock(&e->mu);
             const double t0 = now_ms();
+            expand_levels(e, j, row);
             (void)ks265_wpp_code_row(j->wpp, row);               /* a failure is kept in the job memory and reported by ks265_wpp_finish */
             const double dt = now_ms() - t0;
             pthread_mutex_lock(&e->mu);
@@ -270,6 +314,7 @@ static void *worker(void *arg)
                 pthread_mutex_unlock(&e->mu);
                 const double t1 = now_ms();
                 const long n = ks265_wpp_finish(j->wpp, j->nal, j->nal_cap);
+                memcpy(j->dirty, j->cmp + e->cmp_off[5], e->cmp_off[6] - e->cmp_off[5]);      /* what the next picture in this slot has to clear */
                 pthread_mutex_lock(&e->mu);
                 j->t_write_ms += now_ms() - t1;
                 j->nal_len = n; j->error = n < 0 ? (int)n : 0; j->done = 1; j->t_done = now_ms();
@@ -335,15 +380,11 @@ static int submit(Enc *e, Input *in, int kind, int poc, int qp, const int *l0, i
     /* the records leave the frame object's buffers for a staging set (device to device, a few microseconds), so that the next picture can start
      * while the copy-out stream drains this one */
     if (!r && recycled) r = ks265_stream_wait_event(e->ctx, e->ev_drained[k]);
-    if (!r) r = ks265_frame_pack_records(e->frame, e->stg[k], e->cfg.calcPsnr ? e->dev_sse : NULL);
+    if (!r) r = ks265_frame_pack_compact(e->frame, e->stg[k], e->cfg.calcPsnr ? e->dev_sse : NULL);
     if (!r) r = ks265_event_record(e->ctx, e->ev_staged[k]);
     /* copy-out stream */
     if (!r) r = ks265_stream_wait_event(e->ctx_out, e->ev_staged[k]);
-    if (!r) {
-        static int mode = -1;                                              /* KS265_D2H=runtime: the runtime's own copy (diagnosis) */
-        if (mode < 0) { const char *m = getenv("KS265_D2H"); mode = m && !strcmp(m, "runtime"); }
-        r = mode ? ks265_memcpy_d2h_async(e->ctx_out, j->rec, e->stg[k], e->rec_off[6]) : ks265_copy_out_async(e->ctx_out, j->rec, e->stg[k], e->rec_off[6]);
-    }
+    if (!r) r = ks265_copy_out_compact_async(e->ctx_out, e->frame, j->cmp, e->stg[k]);   /* fixed part + the stored lines only (~2 MB for a P picture at 2160p) */
     if (!r) r = ks265_event_record(e->ctx_out, e->ev_drained[k]);
     if (!r) r = ks265_event_record(e->ctx_out, j->ev);
     if (r) return hip_rc(r);
@@ -561,7 +602,7 @@ void QY265EncoderClose(void *h)
         }
         for (int i = 0; i < MAX_JOBS; ++i) {
             Job *j = &e->jobs[i];
-            ks265_host_free(e->ctx, j->rec); ks265_host_free(e->ctx, j->recon);
+            ks265_host_free(e->ctx, j->cmp); ks265_host_free(e->ctx, j->recon); free(j->lvlbuf); free(j->dirty);
             if (j->ev) ks265_event_destroy(e->ctx, j->ev);
             free(j->nal);
         }
@@ -636,12 +677,13 @@ void *QY265EncoderOpen(QY265EncConfig *cfg, int *err)
     if (!r) r = ks265_frame_create(e->ctx, &e->fcfg, &e->frame);
     const size_t fsz = (size_t)e->W * e->H * 3 / 2, npx = (size_t)e->W * e->H;
     const int dev_id = dev_env ? atoi(dev_env) : 0;
-    if (!r) r = ks265_frame_records_layout(e->frame, e->rec_off);
+    if (!r) r = ks265_frame_compact_layout(e->frame, e->cmp_off);
     if (!r) r = ks265_create(&e->ctx_in, dev_id);
     if (!r) r = ks265_create(&e->ctx_out, dev_id);
     for (int k = 0; k < NPIPE && !r; ++k) {
         r = ks265_dev_malloc(e->ctx, (void **)&e->dev_in[k], fsz);
-        if (!r) r = ks265_dev_malloc(e->ctx, (void **)&e->stg[k], e->rec_off[6]);
+        if (!r) r = ks265_dev_malloc(e->ctx, (void **)&e->stg[k], e->cmp_off[7]);
+        if (!r) r = ks265_memset_async(e->ctx, e->stg[k], 0, e->cmp_off[7]);   /* the header's running counters start at zero */
         if (!r) r = ks265_event_create(e->ctx, &e->ev_h2d[k]);
         if (!r) r = ks265_event_create(e->ctx, &e->ev_loaded[k]);
         if (!r) r = ks265_event_create(e->ctx, &e->ev_staged[k]);
@@ -652,18 +694,21 @@ void *QY265EncoderOpen(QY265EncConfig *cfg, int *err)
     e->ndpb = e->hier ? 10 : e->gop_b ? 4 : e->refs + 2;
     for (int i = 0; i < e->ndpb && !r; ++i) { r = pic_alloc(e, &e->dpb[i]); e->dpb_poc[i] = -1000000; }
     /* ring of pictures in flight: a key picture's slice takes one writer thread many picture periods, and output is in coding order - the ring must
-     * hold everything that is coded meanwhile, or the GPU idles behind it.  About 4 GB of pinned records, at least 24 and at most MAX_JOBS pictures. */
-    e->ring = (int)(((size_t)4 << 30) / (e->rec_off[6] + fsz));
+     * hold everything that is coded meanwhile, or the GPU idles behind it.  About 6 GB of records (pinned compact block + expanded level planes + pinned input), at least 24 and at most MAX_JOBS pictures. */
+    e->ring = (int)(((size_t)6 << 30) / (e->cmp_off[7] + npx * 3 + fsz));
     if (e->ring > MAX_JOBS) e->ring = MAX_JOBS;
     if (e->ring < 24) e->ring = 24;
     if (e->nthreads > e->ring - 14) e->nthreads = e->ring - 14;               /* more writers than pictures that can be in flight would idle */
     const int njobs_alloc = e->ring;
     for (int i = 0; i < njobs_alloc && !r; ++i) {
         Job *j = &e->jobs[i];
-        r = ks265_host_malloc(e->ctx, (void **)&j->rec, e->rec_off[6]);
+        r = ks265_host_malloc(e->ctx, (void **)&j->cmp, e->cmp_off[7]);
         if (!r) {
-            j->cu8 = (ks265_cu8 *)(j->rec + e->rec_off[0]); j->lvl[0] = (int16_t *)(j->rec + e->rec_off[1]); j->lvl[1] = (int16_t *)(j->rec + e->rec_off[2]);
-            j->lvl[2] = (int16_t *)(j->rec + e->rec_off[3]); j->sao = (ks265_sao_param *)(j->rec + e->rec_off[4]); j->sse = (uint64_t *)(j->rec + e->rec_off[5]);
+            j->lvlbuf = (uint8_t *)calloc(npx * 3 + 64, 1);                 /* zero pages until a picture touches them */
+            j->dirty = (uint64_t *)calloc((e->cmp_off[6] - e->cmp_off[5]) / 8 + 1, 8);
+            if (!j->lvlbuf || !j->dirty) r = KS265_OUTOFMEMORY;
+            j->cu8 = (ks265_cu8 *)(j->cmp + e->cmp_off[0]); j->sao = (ks265_sao_param *)(j->cmp + e->cmp_off[1]); j->sse = (uint64_t *)(j->cmp + e->cmp_off[2]);
+            j->lvl[0] = (int16_t *)j->lvlbuf; j->lvl[1] = (int16_t *)(j->lvlbuf + npx * 2); j->lvl[2] = (int16_t *)(j->lvlbuf + npx * 2 + npx / 2);
         }
         if (!r) r = ks265_event_create(e->ctx, &j->ev);
         j->nal_cap = npx * 2 + 65536;

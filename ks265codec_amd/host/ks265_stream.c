@@ -450,13 +450,26 @@ static void residual_coding(Enc *e, const int16_t *blk, int stride, int log2, in
     Cabac *c = &e->c;
     const int size = 1 << log2, nsb_log2 = log2 - 2, nsb = 1 << (2 * nsb_log2);
     const XY *sbs = e->scans.sb[scan_idx][nsb_log2], *p4 = e->scans.pos4[scan_idx];
+    /* which 4x4 sub-blocks hold a level at all: four 8-byte reads per sub-block (most TUs of a P picture hold a handful of levels) */
+    uint8_t sbnz[8][8];
+    {
+        const int ns = 1 << nsb_log2;
+        for (int ys = 0; ys < ns; ++ys)
+            for (int xs = 0; xs < ns; ++xs) {
+                uint64_t a, o = 0;
+                for (int r = 0; r < 4; ++r) { memcpy(&a, blk + (ys * 4 + r) * stride + xs * 4, 8); o |= a; }
+                sbnz[ys][xs] = o != 0;
+            }
+    }
     /* last significant coefficient in scan order */
     int last_sb = -1, last_n = -1;
-    for (int i = nsb - 1; i >= 0 && last_sb < 0; --i)
+    for (int i = nsb - 1; i >= 0 && last_sb < 0; --i) {
+        if (!sbnz[sbs[i].y][sbs[i].x]) continue;
         for (int n = 15; n >= 0; --n) {
             const int x = sbs[i].x * 4 + p4[n].x, y = sbs[i].y * 4 + p4[n].y;
             if (blk[y * stride + x]) { last_sb = i; last_n = n; break; }
         }
+    }
     if (last_sb < 0) return;                                         /* cbf said otherwise: never reached */
     int lx = sbs[last_sb].x * 4 + p4[last_n].x, ly = sbs[last_sb].y * 4 + p4[last_n].y;
     if (scan_idx == 2) { const int t = lx; lx = ly; ly = t; }       /* vertical scan: the coordinates are swapped in the syntax */
@@ -477,10 +490,11 @@ static void residual_coding(Enc *e, const int16_t *blk, int stride, int log2, in
         int absv[16], sign[16], npos[16], nsig = 0;
         /* which coefficients of this sub-block are significant */
         uint16_t sigmask = 0;
-        for (int n = (i == last_sb ? last_n : 15); n >= 0; --n) {
-            const int v = blk[(ys * 4 + p4[n].y) * stride + xs * 4 + p4[n].x];
-            if (v) sigmask |= (uint16_t)(1u << n);
-        }
+        if (sbnz[ys][xs])
+            for (int n = (i == last_sb ? last_n : 15); n >= 0; --n) {
+                const int v = blk[(ys * 4 + p4[n].y) * stride + xs * 4 + p4[n].x];
+                if (v) sigmask |= (uint16_t)(1u << n);
+            }
         const int right = xs + 1 < (1 << nsb_log2) ? csbf[ys][xs + 1] : 0, below = ys + 1 < (1 << nsb_log2) ? csbf[ys + 1][xs] : 0;
         int coded = sigmask != 0, infer_dc = 0;
         if (i < last_sb && i > 0) { cb_bin(c, CX_CSBF + ((right | below) ? 1 : 0) + (cidx ? 2 : 0), coded); infer_dc = 1; }
