@@ -611,7 +611,7 @@ def encoded_leg(args, torch, dist, rank, world, dev_index, backend, sync_all):
         dist.all_reduce(ta, op=dist.ReduceOp.MAX)
         win["A"]["seconds"] = round(float(ta.item()), 5)
     win["A"]["fps_all_ranks"] = round(world * win["A"]["pictures"] / win["A"]["seconds"], 2)
-    return {"fps": world * npic / dt, "dt": dt * args.steps / npic, "windows": win, "host_threads": threads, "host_cores": cores, "bytes_per_picture": bytes_a / args.steps,
+    return {"fps": world * npic / dt, "dt": dt * args.steps / npic, "windows": win, "host_threads": threads, "host_cores": cores, "bytes_per_picture": st.bytes / max(1, st.frames),
             "psnr_y": 99.0 if mse == 0 else 10.0 * np.log10(255.0 ** 2 / mse), "slice_write_ms_per_picture": st.host_write_ms / max(1, st.frames), "preset": preset.decode(),
             "caller_ms_per_picture": {"input_copy": round(st.in_copy_ms / max(1, st.frames), 3), "enqueue": round(st.submit_ms / max(1, st.frames), 3), "output": round(st.output_ms / max(1, st.frames), 3),
                                       "latency_enqueue_to_records_on_host": round(st.lat_gpu_ms / max(1, st.frames), 2), "latency_enqueue_to_writer_pickup": round(st.lat_queue_ms / max(1, st.frames), 2),
@@ -639,6 +639,7 @@ def encoded_line(args, enc, world, hot, cpu):
                    "windows": enc.get("windows"),
                    "pictures_per_step": 1, "host_threads_per_gpu": enc["host_threads"], "host_cores": enc["host_cores"],
                    "bytes_per_picture": int(enc["bytes_per_picture"]), "kbps_at_50fps": round(enc["bytes_per_picture"] * 8 * 50 / 1000.0, 1),
+                   "bytes_per_picture_note": "all pictures this encoder coded in the run (warm-up, fill and the timed windows; key pictures in their proportion)",
                    "slice_write_ms_per_picture_per_thread": round(enc["slice_write_ms_per_picture"], 2),
                    "caller_ms_per_picture": enc.get("caller_ms_per_picture"),
                    "in_the_path": "sign-data hiding (signBitHidingHDQ), merge / skip SIGNALLING where the chosen motion equals a merge candidate, AMVP with the better of the two predictors",
