@@ -260,8 +260,11 @@ int ks265_store_i420(ks265_frame *f, ks265_pic src, uint8_t *dev_i420);
 int ks265_ref_planes(ks265_frame *f, ks265_pic ref, uint8_t *dev_planes);
 /* Stage A0 (cfg.pre_search; run by ks265_me_integer itself, exported for stage tests): exhaustive motion search on a pyramid built with
  * downsample_c enc@0x4a6a60 - L2 blocks of 8x8 over +-(range/4 - 1), L1 blocks +-2, 16x16 picture blocks +-1; cost SAD + |mx| + |my|.
- * dev_field: ceil(W/16) x ceil(H/16) x {mvx, mvy} int16, integer pel (NULL = the frame's own buffer) */
-int ks265_presearch(ks265_frame *f, ks265_pic src, ks265_pic ref, int16_t *dev_field);
+ * Above them a 1/8-resolution level: every CTU (one 8x8 block) over +-range/4 = +-2 range samples; its vector x 8 is the CTU's WINDOW OFFSET - stage A searches
+ * +-range around it, so a reference several pictures away is in reach (the reference searches around its predicted vector; its pictures have no window).
+ * dev_field: ceil(W/16) x ceil(H/16) x {mvx, mvy} int16, integer pel (NULL = skip the stand-alone full-resolution step); dev_ctu_off: ctu_cols x ctu_rows x
+ * {ox, oy} int16 (NULL = the frame's own buffer) */
+int ks265_presearch(ks265_frame *f, ks265_pic src, ks265_pic ref, int16_t *dev_field, int16_t *dev_ctu_off);
 /* Stage A: integer-pel motion search for every PU of every CTU (motionSearchOneRef enc@0x483f40 ->
  * interMeDia enc@0x48fbe0 over sad4_c); prev_pu = PU records of the previous picture (temporal
  * predictor) or NULL */

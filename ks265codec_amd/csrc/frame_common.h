@@ -42,7 +42,7 @@ struct ks265_frame {
     unsigned long long *sse_acc = nullptr;   // ks265_sse_picture: three running sums + finished work-groups (zero between calls)
     short *mats = nullptr;              // forward + transposed DCT matrices of all sizes in the kernels' LDS layout (2 x MAT_SHORTS)
     int *progress = nullptr;            // intra wavefront: CTUs finished per CTU row
-    uint8_t *pyr[7] = {};               // pre-search (cfg.pre_search): L1 / L2 of the source, L1 / L2 of the reference, L2 / L1 vectors, the 16x16 vector field
+    uint8_t *pyr[10] = {};              // pre-search (cfg.pre_search): L1 / L2 of the source, L1 / L2 of the reference, L2 / L1 vectors, the 16x16 field, L3 of both, CTU window offsets
     // optional in-situ stage timing (HIP events on the context's stream, between the stages of ks265_encode_picture)
     bool profiling = false;
     hipEvent_t ev[KS_NSTAGE + 1] = {};
@@ -73,6 +73,15 @@ __device__ __forceinline__ int ks_xcd_swizzle(int b, int n)
     const int per = n >> 3, rem = n & 7;                 // XCD x owns per + (x < rem) items
     const int x = b & 7, j = b >> 3;
     return x * per + min(x, rem) + j;
+}
+
+// legal vectors of the PUs of a CTU around its window offset (pre-search, else zero): +-range around the offset, and never so far that a block of the CTU
+// leaves the 64-sample margin of the padded planes
+__device__ __forceinline__ void ctu_mv_limits(const KsGeom &g, int range, int cx, int cy, int ox, int oy, int &lox, int &hix, int &loy, int &hiy)
+{
+    const int xe = min(cx * 64 + 64, g.W), ye = min(cy * 64 + 64, g.H);
+    lox = max(ox - range, -64 - cx * 64); hix = min(ox + range, g.W + 64 - xe);
+    loy = max(oy - range, -64 - cy * 64); hiy = min(oy + range, g.H + 64 - ye);
 }
 
 int ks265_frame_build_matrices(ks265_frame *f);      // frame_recon.hip

@@ -447,6 +447,9 @@ __device__ __forceinline__ MergeMotion merge_cand(const KsGeom &g, const ks265_c
     const ks265_cu8 c = cu_in[(long)(ny >> 3) * g.w8 + (nx >> 3)];
     if (c.pred_mode != 0 || c.log2_cu < 3) return m;
     m.dir = c.inter_dir & 3; m.mvx = c.mvx; m.mvy = c.mvy; m.mv1x = c.mv1x; m.mv1y = c.mv1y; m.ok = true;
+    // a neighbour's vector may come from a CTU with another window offset: taken over here it must keep this CU's block inside the planes' margin
+    if ((m.dir & 1) && (x + (m.mvx >> 2) < -70 || x + (m.mvx >> 2) + n > g.W + 70 || y + (m.mvy >> 2) < -70 || y + (m.mvy >> 2) + n > g.H + 70)) m.ok = false;
+    if ((m.dir & 2) && (x + (m.mv1x >> 2) < -70 || x + (m.mv1x >> 2) + n > g.W + 70 || y + (m.mv1y >> 2) < -70 || y + (m.mv1y >> 2) + n > g.H + 70)) m.ok = false;
     return m;
 }
 __global__ __launch_bounds__(256) void merge_pass_kernel(KsGeom g, int lam, const uint8_t *src, const uint8_t *planes0, const uint8_t *planes1, const ks265_pu *pu,

@@ -90,6 +90,8 @@ struct MeLds {
     unsigned best16[16];
 };
 
+struct MeLim { int ox, oy, lox, hix, loy, hiy; };        // the CTU's window offset and the vectors its PUs may take
+
 struct Owner {
     int ph, mx, my, pmx, pmy, merange, it, dir, iflags;
     unsigned cost, cost0;
@@ -130,7 +132,7 @@ extern "C" void ks265_me_dbg(unsigned long long *out, int reset) { if (reset) { 
 // candidates (work-group barriers between the steps of a round).  WG = false: the group is the part of a level that lies in one 32x32
 // quadrant (1 / 4 / 16 PUs) and belongs to ONE WAVE: owners = its first lanes, evaluation = its 64 lanes, no barrier at all.
 template <bool WG>
-__device__ __forceinline__ void me_group(const KsGeom &g, int cx, int cy, int range, int lam, int method, int hex_thr, MeLds &L, GroupLds &Q, int level,
+__device__ __forceinline__ void me_group(const KsGeom &g, int cx, int cy, int range, const MeLim &lm, int lam, int method, int hex_thr, MeLds &L, GroupLds &Q, int level,
                                          int l2n /* log2 PUs per side of the group */, int qx0, int qy0 /* PU-grid origin of the group */,
                                          const ks265_pu *prev_ctu, ks265_pu *out_ctu, const short2 *field, int nb0x, int nb0y, int t /* lane index inside the group's lanes */)
 {
@@ -157,13 +159,16 @@ __device__ __forceinline__ void me_group(const KsGeom &g, int cx, int cy, int ra
                     break;
                 }
             }
-            if (root && prev_ctu && prev_ctu[0].cost != KS_COST_INVALID) {
-                o.pmx = clip3(-range, range, ((int)prev_ctu[0].mvx + 2) >> 2);
-                o.pmy = clip3(-range, range, ((int)prev_ctu[0].mvy + 2) >> 2);
+            if (root) {                                                                // no predictor: the legal vector nearest to zero
+                o.pmx = clip3(lm.lox, lm.hix, 0); o.pmy = clip3(lm.loy, lm.hiy, 0);
+                if (prev_ctu && prev_ctu[0].cost != KS_COST_INVALID) {
+                    o.pmx = clip3(lm.lox, lm.hix, ((int)prev_ctu[0].mvx + 2) >> 2);
+                    o.pmy = clip3(lm.loy, lm.hiy, ((int)prev_ctu[0].mvy + 2) >> 2);
+                }
             }
             o.merange = root ? range : max(range >> 2, 4);
             o.mx = o.pmx; o.my = o.pmy;
-            if (root && (o.pmx | o.pmy)) o.iflags |= DP_INIT_ZERO;                     // a root PU with a temporal predictor also tries the zero vector
+            if (root && (o.pmx | o.pmy) && lm.lox <= 0 && lm.hix >= 0 && lm.loy <= 0 && lm.hiy >= 0) o.iflags |= DP_INIT_ZERO;   // a root PU with a predictor also tries the zero vector
             if (field) {                                                               // and every PU the pre-search vector of the 16x16 block under its centre
                 const int fw = L.fld16[(((py * S + S / 2) >> 4) << 2) + ((px * S + S / 2) >> 4)];
                 const int fx = (int)(short)(fw & 0xFFFF), fy = fw >> 16;
@@ -255,12 +260,14 @@ __device__ __forceinline__ void me_group(const KsGeom &g, int cx, int cy, int ra
                     else if (k == 2) { const int fv = Q.fld[pu[n]]; x[n] = (int)(short)(fv & 0xFFFF); y[n] = fv >> 16; cand_on = (dp & (int)DP_INIT_FIELD) != 0; }
                     key[n] = k + 1; slot[n] = 0;
                 }
-                const int lim = (dp >> 28) & 1 ? range : ME_WLIM;
-                live[n] = live[n] && cand_on && stub[n] != 0xFFFFu && abs(x[n]) <= lim && abs(y[n]) <= lim;
+                // "ranged" phases test the mv range (interMeUMH's cross / hexagon / rings); every candidate must lie in the staged window
+                const bool inr = (dp >> 28) & 1 ? (x[n] >= lm.lox && x[n] <= lm.hix && y[n] >= lm.loy && y[n] <= lm.hiy)
+                                                : (abs(x[n] - lm.ox) <= ME_WLIM && abs(y[n] - lm.oy) <= ME_WLIM);
+                live[n] = live[n] && cand_on && stub[n] != 0xFFFFu && inr;
                 const int tile = (base + n * NT + t) & ((1 << l2t) - 1);
                 const int ppx = qx0 + (pu[n] & ((1 << l2n) - 1)), ppy = qy0 + (pu[n] >> l2n);
                 const int bx = ppx * S + (tile & (tpr - 1)) * 8, by = ppy * S + (tile >> (3 - level)) * 8;
-                const int wx = bx + (live[n] ? x[n] : 0) + WIN_XL, wy = by + (live[n] ? y[n] : 0) + WIN_YT;   // a dead item reads (and discards) the zero displacement
+                const int wx = bx + (live[n] ? x[n] - lm.ox : 0) + WIN_XL, wy = by + (live[n] ? y[n] - lm.oy : 0) + WIN_YT;   // window coordinates are relative to the offset; a dead item reads (and discards) the centre
                 p[n] = L.win + wy * WIN_STRIDE + (wx & ~3);
                 f[n] = L.fenc + by * FENC_STRIDE + bx;
                 sh[n] = wx & 3;
@@ -290,7 +297,7 @@ __device__ __forceinline__ void me_group(const KsGeom &g, int cx, int cy, int ra
                 if (live[n] && ((base + n * NT + t) & ((1 << l2t) - 1)) == 0) {
                     const int pr = Q.pred[pu[n]];
                     const unsigned cost = sad[n] + mv_rate(lam, x[n], y[n], (int)(short)(pr & 0xFFFF), pr >> 16);
-                    const unsigned long long v = ((unsigned long long)((cost << 8) | (unsigned)key[n]) << 32) | (unsigned long long)(((unsigned)(x[n] + 128) << 8) | (unsigned)(y[n] + 128));
+                    const unsigned long long v = ((unsigned long long)((cost << 8) | (unsigned)key[n]) << 32) | (unsigned long long)(((unsigned)(x[n] - lm.ox + 128) << 8) | (unsigned)(y[n] - lm.oy + 128));
                     atomicMin(&Q.best[pu[n]][slot[n]], v);
                 }
             }
@@ -306,7 +313,7 @@ __device__ __forceinline__ void me_group(const KsGeom &g, int cx, int cy, int ra
                 bool improved = false;
                 int key = 0, wx = o.mx, wy = o.my;
                 unsigned wcost = o.cost;
-                auto take = [&](unsigned long long b) { key = (int)((b >> 32) & 255u); wcost = (unsigned)(b >> 40); wx = (int)((b >> 8) & 255u) - 128; wy = (int)(b & 255u) - 128; };
+                auto take = [&](unsigned long long b) { key = (int)((b >> 32) & 255u); wcost = (unsigned)(b >> 40); wx = (int)((b >> 8) & 255u) - 128 + lm.ox; wy = (int)(b & 255u) - 128 + lm.oy; };
                 if (first && o.ph != PH_START) {
                     const unsigned long long b = Q.best[t][0];
                     improved = ((b >> 32) & 255u) != 0;
@@ -350,7 +357,7 @@ __device__ __forceinline__ void me_group(const KsGeom &g, int cx, int cy, int ra
                     else { o.dir = key - 2; o.it = (o.merange >> 1) - 1; o.ph = o.it > 0 ? PH_HSTEP : PH_SQUARE; }
                     break;
                 case PH_HSTEP:                                                          // enc@0x490350: a move that leaves the mv range is undone and ends the walk
-                    if (!improved || abs(wx) > range || abs(wy) > range) o.ph = PH_SQUARE;
+                    if (!improved || wx < lm.lox || wx > lm.hix || wy < lm.loy || wy > lm.hiy) o.ph = PH_SQUARE;
                     else { o.cost = wcost; o.mx = wx; o.my = wy; o.dir = mod6m1(o.dir + key - 1); --o.it; o.ph = o.it > 0 ? PH_HSTEP : PH_SQUARE; }
                     break;
                 case PH_SQUARE: case PH_UFINAL: o.ph = PH_DONE; break;
@@ -377,7 +384,7 @@ __device__ __forceinline__ void me_group(const KsGeom &g, int cx, int cy, int ra
                     break;
                 case PH_UDW:                                                            // a step that leaves the mv range is taken and ends the walk
                     if (!improved) o.ph = PH_DONE;
-                    else if (abs(o.mx) > range || abs(o.my) > range || ++o.it >= (o.merange >> 1)) o.ph = PH_DONE;
+                    else if (o.mx < lm.lox || o.mx > lm.hix || o.my < lm.loy || o.my > lm.hiy || ++o.it >= (o.merange >> 1)) o.ph = PH_DONE;
                     break;
                 default: break;
                 }
@@ -405,7 +412,7 @@ __device__ __forceinline__ void me_group(const KsGeom &g, int cx, int cy, int ra
 }
 
 __global__ __launch_bounds__(256, 3) void me_int_kernel(KsGeom g, int range, int lam, int method, int hex_thr, const uint8_t *src, const uint8_t *ref,
-                                                        const ks265_pu *prev, ks265_pu *out, const short2 *field, int nb0x, int nb0y)
+                                                        const ks265_pu *prev, ks265_pu *out, const short2 *field, int nb0x, int nb0y, const short2 *ctu_off)
 {
     __shared__ __attribute__((aligned(16))) MeLds L;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -414,6 +421,12 @@ __global__ __launch_bounds__(256, 3) void me_int_kernel(KsGeom g, int range, int
 #endif
     const int ctu = ks_xcd_swizzle(blockIdx.x, g.ctu_cols * g.ctu_rows), cx = ctu % g.ctu_cols, cy = ctu / g.ctu_cols;
     const uint8_t *R = ks_org_y(g, ref), *Sp = ks_org_y(g, src);
+    MeLim lm;
+    {
+        const short2 ov = ctu_off ? ctu_off[ctu] : make_short2(0, 0);       // multiples of 16
+        lm.ox = ov.x; lm.oy = ov.y;
+        ctu_mv_limits(g, range, cx, cy, lm.ox, lm.oy, lm.lox, lm.hix, lm.loy, lm.hiy);
+    }
     // reference window: 16-byte global loads from x0 - 80 (16-byte aligned), the dwords of x in [-68, 136) go to LDS.  All loads of a
     // thread are issued before the first store (11 pieces in flight per lane: the prologue is one memory latency, not eleven)
     {
@@ -423,8 +436,10 @@ __global__ __launch_bounds__(256, 3) void me_int_kernel(KsGeom g, int range, int
 #pragma unroll
         for (int n = 0; n < NPIECE; ++n) {
             const int i = min(tid + 256 * n, WIN_ROWS * 14 - 1), r = i / 14, c = i - r * 14;
-            const int yy = min(cy * 64 - WIN_YT + r, g.H + KS_PAD_Y - 1);     // rows past the border are never used by a valid PU
-            v[n] = *(const uint4 *)(R + (long)yy * g.sy + cx * 64 - WIN_LOAD_XL + c * 16);
+            // rows / 16-byte pieces outside the padded plane are never used by a legal candidate (ctu_mv_limits): clamp the addresses
+            const int yy = min(max(cy * 64 - WIN_YT + lm.oy + r, -KS_PAD_Y), g.H + KS_PAD_Y - 1);
+            const int xx = min(max(cx * 64 - WIN_LOAD_XL + lm.ox + c * 16, -KS_PAD_Y), g.sy - KS_PAD_Y - 16);
+            v[n] = *(const uint4 *)(R + (long)yy * g.sy + xx);
         }
 #pragma unroll
         for (int n = 0; n < NPIECE; ++n) {
@@ -454,10 +469,10 @@ __global__ __launch_bounds__(256, 3) void me_int_kernel(KsGeom g, int range, int
             const int bx = blk & 3, by = blk >> 2, gx = cx * 4 + bx, gy = cy * 4 + by;
             const bool bvalid = gx < nb0x && gy < nb0y;
             const short2 p = field[min(gy, nb0y - 1) * nb0x + min(gx, nb0x - 1)];
-            const int mx = clip3(-range, range, 2 * p.x + (k % 3 - 1)), my = clip3(-range, range, 2 * p.y + (k / 3 - 1));
+            const int mx = clip3(lm.lox, lm.hix, 2 * p.x + (k % 3 - 1)), my = clip3(lm.loy, lm.hiy, 2 * p.y + (k / 3 - 1));
             const int tx = bx * 16 + (tile & 1) * 8, ty = by * 16 + (tile >> 1) * 8;
             const bool tvalid = bvalid && cx * 64 + tx < g.W && cy * 64 + ty < g.H;
-            const int wx = tx + (tvalid ? mx : 0) + WIN_XL, wy = ty + (tvalid ? my : 0) + WIN_YT;
+            const int wx = tx + (tvalid ? mx - lm.ox : 0) + WIN_XL, wy = ty + (tvalid ? my - lm.oy : 0) + WIN_YT;
             const uint8_t *pw = L.win + wy * WIN_STRIDE + (wx & ~3), *pf = L.fenc + ty * FENC_STRIDE + tx;
             const unsigned sh = wx & 3;
             unsigned sd = 0;
@@ -478,7 +493,7 @@ __global__ __launch_bounds__(256, 3) void me_int_kernel(KsGeom g, int range, int
             if (gx < nb0x && gy < nb0y) {
                 const short2 p = field[gy * nb0x + gx];
                 const int k = (int)(L.best16[tid] & 15u);
-                const int mx = clip3(-range, range, 2 * p.x + (k % 3 - 1)), my = clip3(-range, range, 2 * p.y + (k / 3 - 1));
+                const int mx = clip3(lm.lox, lm.hix, 2 * p.x + (k % 3 - 1)), my = clip3(lm.loy, lm.hiy, 2 * p.y + (k / 3 - 1));
                 L.fld16[tid] = (mx & 0xFFFF) | (my << 16);
             }
         }
@@ -492,7 +507,7 @@ __global__ __launch_bounds__(256, 3) void me_int_kernel(KsGeom g, int range, int
     return;
 #endif
     // the 64x64 PU: the whole work-group
-    me_group<true>(g, cx, cy, range, lam, method, hex_thr, L, L.grp[0], 0, 0, 0, 0, prev_ctu, out_ctu, field, nb0x, nb0y, tid);
+    me_group<true>(g, cx, cy, range, lm, lam, method, hex_thr, L, L.grp[0], 0, 0, 0, 0, prev_ctu, out_ctu, field, nb0x, nb0y, tid);
     __syncthreads();                                                                    // its vector is the predictor of everything below
 #ifdef KS_EXP_ME_CLOCK
     const long long tk2 = ME_NOW();
@@ -501,7 +516,7 @@ __global__ __launch_bounds__(256, 3) void me_int_kernel(KsGeom g, int range, int
     const int qx = wave & 1, qy = wave >> 1;
 #pragma unroll 1
     for (int level = 1; level < 4; ++level)
-        me_group<false>(g, cx, cy, range, lam, method, hex_thr, L, L.grp[wave], level, level - 1, qx << (level - 1), qy << (level - 1), prev_ctu, out_ctu, field, nb0x, nb0y, lane);
+        me_group<false>(g, cx, cy, range, lm, lam, method, hex_thr, L, L.grp[wave], level, level - 1, qx << (level - 1), qy << (level - 1), prev_ctu, out_ctu, field, nb0x, nb0y, lane);
 #ifdef KS_EXP_ME_CLOCK
     const long long tk3 = ME_NOW();
     if (lane == 0) { atomicAdd(&ks_me_dbg[6], (unsigned long long)(tk1 - tk0)); atomicAdd(&ks_me_dbg[7], (unsigned long long)(tk2 - tk1)); atomicAdd(&ks_me_dbg[14], (unsigned long long)(tk3 - tk2)); atomicAdd(&ks_me_dbg[15], 1ull); }
@@ -515,12 +530,12 @@ extern "C" int ks265_me_integer(ks265_frame *f, ks265_pic src, ks265_pic ref, co
     if (f->cfg.me_method < 0 || f->cfg.me_method > 2) return KS265_NOTSUPPORTED;
     const short2 *field = nullptr;
     if (f->cfg.pre_search) {                                                 // stage A0 first: the pre-search field of this (source, reference) pair
-        const int r = ks265_presearch(f, src, ref, nullptr);
+        const int r = ks265_presearch(f, src, ref, nullptr, nullptr);
         if (r) return r;
         field = (const short2 *)f->pyr[5];                                   // the L1 vectors: the kernel does the full-resolution step itself
     }
     const dim3 grid(f->g.ctu_cols * f->g.ctu_rows), block(256);
     hipLaunchKernelGGL(me_int_kernel, grid, block, 0, f->ctx->stream, f->g, f->cfg.me_range, f->cfg.lambda_q4, f->cfg.me_method, f->cfg.me_hex_thr, src.y, ref.y, prev_pu, pu,
-                       field, (f->g.W + 15) / 16, (f->g.H + 15) / 16);
+                       field, (f->g.W + 15) / 16, (f->g.H + 15) / 16, field ? (const short2 *)f->pyr[9] : nullptr);
     return ks265_check_launch(f->ctx);
 }

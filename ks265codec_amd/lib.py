@@ -313,11 +313,11 @@ class KsFrame:
         self.ks._chk(self.lib.ks265_ref_planes(self.h, ref.c(), _p(planes)))
 
     def presearch(self, src: DevPic, ref: DevPic) -> np.ndarray:
-        """stage A0: the pre-search vector field, [ceil(H/16), ceil(W/16), 2] int16 (integer pel)"""
+        """stage A0: the pre-search vector field, [ceil(H/16), ceil(W/16), 2] int16 (integer pel), and the CTUs' window offsets [rows, cols, 2]"""
         nbx, nby = (self.cfg.width + 15) // 16, (self.cfg.height + 15) // 16
-        out = self.ks.zeros(nbx * nby * 4)
-        self.ks._chk(self.lib.ks265_presearch(self.h, src.c(), ref.c(), _p(out)))
-        return self.ks.host(out, np.int16, (nby, nbx, 2))
+        out, off = self.ks.zeros(nbx * nby * 4), self.ks.zeros(self.geom.ctu_cols * self.geom.ctu_rows * 4)
+        self.ks._chk(self.lib.ks265_presearch(self.h, src.c(), ref.c(), _p(out), _p(off)))
+        return self.ks.host(out, np.int16, (nby, nbx, 2)), self.ks.host(off, np.int16, (self.geom.ctu_rows, self.geom.ctu_cols, 2))
 
     def me_integer(self, src: DevPic, ref: DevPic, prev_pu, pu):
         self.ks._chk(self.lib.ks265_me_integer(self.h, src.c(), ref.c(), _p(prev_pu), _p(pu)))

@@ -137,7 +137,7 @@ static int pu_inside(const kso_frame_cfg *cfg, int cx, int cy, int l, int px, in
 /* motion predictor of a PU: integer MV of the nearest valid ancestor; for a root PU the temporal predictor
  * (co-located 64x64 MV of the previous picture, rounded to integer pel) or zero.  (meInitPoint enc@0x48af50
  * gathers spatial/merge candidates from already coded CTUs; a frame-parallel search cannot — SURVEY.md §7.3.) */
-static void pu_predictor(const kso_frame_cfg *cfg, const kso_pu *ctu_pu, const kso_pu *prev_ctu_pu, int cx, int cy, int l, int px, int py,
+static void pu_predictor(const kso_frame_cfg *cfg, const kso_pu *ctu_pu, const kso_pu *prev_ctu_pu, int cx, int cy, int l, int px, int py, const int lim[4],
                          int *mx, int *my, int *root)
 {
     for (int a = l - 1; a >= 0; --a) {
@@ -148,11 +148,10 @@ static void pu_predictor(const kso_frame_cfg *cfg, const kso_pu *ctu_pu, const k
             return;
         }
     }
-    *root = 1; *mx = 0; *my = 0;
+    *root = 1; *mx = iclip(lim[0], lim[1], 0); *my = iclip(lim[2], lim[3], 0);      /* no predictor: the legal vector nearest to zero */
     if (prev_ctu_pu && prev_ctu_pu[0].cost != COST_INVALID) {
-        int r = cfg->me_range;
-        *mx = iclip(-r, r, (prev_ctu_pu[0].mvx + 2) >> 2);
-        *my = iclip(-r, r, (prev_ctu_pu[0].mvy + 2) >> 2);
+        *mx = iclip(lim[0], lim[1], (prev_ctu_pu[0].mvx + 2) >> 2);
+        *my = iclip(lim[2], lim[3], (prev_ctu_pu[0].mvy + 2) >> 2);
     }
 }
 
@@ -182,24 +181,71 @@ static uint32_t sad_clamped(const uint8_t *cur, const uint8_t *ref, int W, int H
     }
     return s;
 }
-void kso_presearch(const kso_frame_cfg *cfg, kso_pic src, kso_pic ref, int16_t *field)
+/* legal vectors of the PUs of CTU (cx, cy) around the window offset (ox, oy): +-range around the offset, and never so far that a block of the CTU
+ * leaves the 64-sample margin of the padded planes */
+void kso_ctu_mv_limits(const kso_frame_cfg *cfg, int cx, int cy, int ox, int oy, int lim[4] /* lox, hix, loy, hiy */)
+{
+    const int xe = imin(cx * 64 + 64, cfg->width), ye = imin(cy * 64 + 64, cfg->height), r = cfg->me_range;
+    lim[0] = imax(ox - r, -64 - cx * 64); lim[1] = imin(ox + r, cfg->width + 64 - xe);
+    lim[2] = imax(oy - r, -64 - cy * 64); lim[3] = imin(oy + r, cfg->height + 64 - ye);
+}
+void kso_presearch(const kso_frame_cfg *cfg, kso_pic src, kso_pic ref, int16_t *field, int16_t *ctu_off /* ctu_cols x ctu_rows x {ox, oy} */)
 {
     kso_frame_geom g; kso_frame_geometry(cfg, &g);
-    const int W = cfg->width, H = cfg->height, W1 = W / 2, H1 = H / 2, W2 = W / 4, H2 = H / 4;
+    const int W = cfg->width, H = cfg->height, W1 = W / 2, H1 = H / 2, W2 = W / 4, H2 = H / 4, W3 = W / 8, H3 = H / 8;
     const uint8_t *S = org_y(&g, src.y), *R = org_y(&g, ref.y);
     const long st = g.stride_y;
     uint8_t *c1 = malloc((size_t)W1 * H1), *r1 = malloc((size_t)W1 * H1), *c2 = malloc((size_t)W2 * H2), *r2 = malloc((size_t)W2 * H2);
+    uint8_t *c3 = malloc((size_t)W3 * H3 + 8), *r3 = malloc((size_t)W3 * H3 + 8);
     pyr_down(S, st, W, H, c1); pyr_down(R, st, W, H, r1); pyr_down(c1, W1, W1, H1, c2); pyr_down(r1, W1, W1, H1, r2);
+    /* L3 = 1/8 resolution: downsample_c needs even source sizes; W2, H2 are even, W3 = W2 / 2 */
+    pyr_down(c2, W2, W2, H2, c3); pyr_down(r2, W2, W2, H2, r3);
     const int nb2x = (W2 + 7) / 8, nb2y = (H2 + 7) / 8, nb1x = (W1 + 7) / 8, nb1y = (H1 + 7) / 8, nb0x = (W + 15) / 16, nb0y = (H + 15) / 16;
     int16_t *mv2 = malloc(sizeof(int16_t) * 2 * (size_t)nb2x * nb2y), *mv1 = malloc(sizeof(int16_t) * 2 * (size_t)nb1x * nb1y);
-    const int R2 = imax((cfg->me_range >> 2) - 1, 1), range = cfg->me_range;
+    const int R2 = imax((cfg->me_range >> 2) - 1, 1), R3 = imax(cfg->me_range >> 2, 1);
+    /* L3: one 8x8 block = one CTU; every vector of +-range/4 (+-2 range in samples).  A CTU VOTES for its best vector when that vector lies where the
+     * zero-centred window (+-range, searched with margin) does not reach and matches at least a quarter better than the best vector that window covers.
+     * If one vector collects the votes of at least half of the CTUs (a pan, a reference several pictures away) it becomes the picture's WINDOW OFFSET
+     * (x 8, per CTU clipped so that the CTU's blocks stay inside the planes' margin): stage A then searches +-range around it instead of around zero.
+     * Periodic content and 1/8-resolution aliasing produce scattered votes, never a majority: the windows stay where they are. */
+    const int side3 = 2 * R3 + 1;
+    int *votes = calloc((size_t)side3 * side3, sizeof(int));
+    int16_t *cand = malloc(sizeof(int16_t) * 2 * (size_t)g.ctu_cols * g.ctu_rows);
+#pragma omp parallel for collapse(2) schedule(dynamic, 1)
+    for (int cy = 0; cy < g.ctu_rows; ++cy)
+        for (int cx = 0; cx < g.ctu_cols; ++cx) {
+            const int bw = imin(8, W3 - 8 * cx), bh = imin(8, H3 - 8 * cy);
+            uint32_t best = 0xffffffffu, near = 0xffffffffu; int bmx = 0, bmy = 0;
+            for (int my = -R3; my <= R3; ++my)
+                for (int mx = -R3; mx <= R3; ++mx) {
+                    const uint32_t c = sad_clamped(c3, r3, W3, H3, 8 * cx, 8 * cy, bw, bh, mx, my) + (uint32_t)(iabs_(mx) + iabs_(my));
+                    if (c < best) { best = c; bmx = mx; bmy = my; }
+                    if (iabs_(8 * mx) <= cfg->me_range / 2 && iabs_(8 * my) <= cfg->me_range / 2 && c < near) near = c;
+                }
+            if ((iabs_(8 * bmx) <= cfg->me_range / 2 && iabs_(8 * bmy) <= cfg->me_range / 2) || 4 * (uint64_t)best >= 3 * (uint64_t)near) { bmx = 0; bmy = 0; }
+            cand[2 * (cy * g.ctu_cols + cx)] = (int16_t)bmx; cand[2 * (cy * g.ctu_cols + cx) + 1] = (int16_t)bmy;
+        }
+    int gmx = 0, gmy = 0, top = 0;
+    for (int i = 0; i < g.ctu_cols * g.ctu_rows; ++i) if (cand[2 * i] || cand[2 * i + 1]) ++votes[(cand[2 * i + 1] + R3) * side3 + cand[2 * i] + R3];
+    for (int i = 0; i < side3 * side3; ++i) if (votes[i] > top) { top = votes[i]; gmx = i % side3 - R3; gmy = i / side3 - R3; }     /* ties: the first in raster order */
+    if (2 * top < g.ctu_cols * g.ctu_rows) { gmx = 0; gmy = 0; }
+    for (int cy = 0; cy < g.ctu_rows; ++cy)
+        for (int cx = 0; cx < g.ctu_cols; ++cx) {
+            const int xe = imin(cx * 64 + 64, W), ye = imin(cy * 64 + 64, H);
+            /* multiples of 16: the GPU stages its window with 16-byte loads */
+            ctu_off[2 * (cy * g.ctu_cols + cx)] = (int16_t)(iclip(-64 - cx * 64, W + 64 - xe, 8 * gmx) & ~15);
+            ctu_off[2 * (cy * g.ctu_cols + cx) + 1] = (int16_t)(iclip(-64 - cy * 64, H + 64 - ye, 8 * gmy) & ~15);
+        }
+    free(votes); free(cand);
 #pragma omp parallel for collapse(2) schedule(dynamic, 1)
     for (int by = 0; by < nb2y; ++by)
         for (int bx = 0; bx < nb2x; ++bx) {
             const int bw = imin(8, W2 - 8 * bx), bh = imin(8, H2 - 8 * by);
+            const int16_t *o = &ctu_off[2 * ((by >> 1) * g.ctu_cols + (bx >> 1))];
+            const int c2x = o[0] / 4, c2y = o[1] / 4;              /* multiples of 16: exact */
             uint32_t best = 0xffffffffu; int bmx = 0, bmy = 0;
-            for (int my = -R2; my <= R2; ++my)
-                for (int mx = -R2; mx <= R2; ++mx) {
+            for (int my = c2y - R2; my <= c2y + R2; ++my)
+                for (int mx = c2x - R2; mx <= c2x + R2; ++mx) {
                     const uint32_t c = sad_clamped(c2, r2, W2, H2, 8 * bx, 8 * by, bw, bh, mx, my) + (uint32_t)(iabs_(mx) + iabs_(my));
                     if (c < best) { best = c; bmx = mx; bmy = my; }
                 }
@@ -224,17 +270,20 @@ void kso_presearch(const kso_frame_cfg *cfg, kso_pic src, kso_pic ref, int16_t *
         for (int bx = 0; bx < nb0x; ++bx) {
             const int bw = imin(16, W - 16 * bx), bh = imin(16, H - 16 * by);
             const int16_t *p = &mv1[2 * (by * nb1x + bx)];
+            const int16_t *o = &ctu_off[2 * ((by >> 2) * g.ctu_cols + (bx >> 2))];
+            int lim[4];
+            kso_ctu_mv_limits(cfg, bx >> 2, by >> 2, o[0], o[1], lim);
             const uint8_t *fenc = S + (long)(16 * by) * st + 16 * bx;
             uint32_t best = 0xffffffffu; int bmx = 0, bmy = 0;
             for (int dy = -1; dy <= 1; ++dy)
                 for (int dx = -1; dx <= 1; ++dx) {
-                    const int mx = iclip(-range, range, 2 * p[0] + dx), my = iclip(-range, range, 2 * p[1] + dy);
+                    const int mx = iclip(lim[0], lim[1], 2 * p[0] + dx), my = iclip(lim[2], lim[3], 2 * p[1] + dy);
                     const uint32_t c = ks265o_sad(fenc, R + (long)(16 * by + my) * st + 16 * bx + mx, st, st, bh, bw) + (uint32_t)(iabs_(mx) + iabs_(my));
                     if (c < best) { best = c; bmx = mx; bmy = my; }
                 }
             field[2 * (by * nb0x + bx)] = (int16_t)bmx; field[2 * (by * nb0x + bx) + 1] = (int16_t)bmy;
         }
-    free(c1); free(r1); free(c2); free(r2); free(mv2); free(mv1);
+    free(c1); free(r1); free(c2); free(r2); free(c3); free(r3); free(mv2); free(mv1);
 }
 
 /* ------------------------------------------------------------------ Stage A: integer search (motionSearchOneRef enc@0x483f40)
@@ -251,7 +300,7 @@ void kso_presearch(const kso_frame_cfg *cfg, kso_pic src, kso_pic ref, int16_t *
  *   - merange: the full range for a root PU, a quarter of it (>= 4) around an inherited vector (adaptiveMeSearchRange enc@0x483e70
  *     shrinks tME+0x68 from the spread of the neighbouring candidates; closed heuristics);
  *   - mv limits +-me_range around the PU position; candidates further than 66 samples away are skipped (the GPU's staged window). */
-#define ME_TAB 80
+#define ME_TAB 208                      /* |window offset| <= 2 range, + range, + slack */
 void kso_me_integer(const kso_frame_cfg *cfg, kso_pic src, kso_pic ref, const kso_pu *prev_pu, kso_pu *pu)
 {
     kso_frame_geom g; kso_frame_geometry(cfg, &g);
@@ -259,13 +308,20 @@ void kso_me_integer(const kso_frame_cfg *cfg, kso_pic src, kso_pic ref, const ks
     long st = g.stride_y;
     int range = cfg->me_range, lam = cfg->lambda_q4;
     const int nb0x = (cfg->width + 15) / 16, nb0y = (cfg->height + 15) / 16;
-    int16_t *field = NULL;
-    if (cfg->pre_search) { field = malloc(sizeof(int16_t) * 2 * (size_t)nb0x * nb0y); kso_presearch(cfg, src, ref, field); }
+    int16_t *field = NULL, *ctu_off = NULL;
+    if (cfg->pre_search) {
+        field = malloc(sizeof(int16_t) * 2 * (size_t)nb0x * nb0y); ctu_off = malloc(sizeof(int16_t) * 2 * (size_t)g.ctu_cols * g.ctu_rows);
+        kso_presearch(cfg, src, ref, field, ctu_off);
+    }
 #pragma omp parallel for collapse(2) schedule(dynamic, 1)
     for (int cy = 0; cy < g.ctu_rows; ++cy)
         for (int cx = 0; cx < g.ctu_cols; ++cx) {
             kso_pu *cp = pu + (long)(cy * g.ctu_cols + cx) * 85;
             const kso_pu *pp = prev_pu ? prev_pu + (long)(cy * g.ctu_cols + cx) * 85 : NULL;
+            /* the CTU's window offset (pre-search, else zero) and the vectors its PUs may take */
+            const int ox = ctu_off ? ctu_off[2 * (cy * g.ctu_cols + cx)] : 0, oy = ctu_off ? ctu_off[2 * (cy * g.ctu_cols + cx) + 1] : 0;
+            int lim[4];
+            kso_ctu_mv_limits(cfg, cx, cy, ox, oy, lim);
             for (int l = 0; l < 4; ++l)
                 for (int py = 0; py < (1 << l); ++py)
                     for (int px = 0; px < (1 << l); ++px) {
@@ -273,7 +329,7 @@ void kso_me_integer(const kso_frame_cfg *cfg, kso_pic src, kso_pic ref, const ks
                         int s = 64 >> l, x0 = cx * 64 + px * s, y0 = cy * 64 + py * s;
                         if (!pu_inside(cfg, cx, cy, l, px, py)) { memset(o, 0, sizeof *o); o->cost = COST_INVALID; o->dist = COST_INVALID; continue; }
                         int pmx, pmy, root;
-                        pu_predictor(cfg, cp, pp, cx, cy, l, px, py, &pmx, &pmy, &root);
+                        pu_predictor(cfg, cp, pp, cx, cy, l, px, py, lim, &pmx, &pmy, &root);
                         uint16_t tx[4 * (2 * ME_TAB + 1)], ty[4 * (2 * ME_TAB + 1)];       /* indexed by the quarter-pel mv like the reference's */
                         for (int v = -ME_TAB; v <= ME_TAB; ++v) {
                             tx[4 * (v + ME_TAB)] = (uint16_t)((lam * se_bits((v - pmx) << 2)) >> 4);
@@ -286,13 +342,13 @@ void kso_me_integer(const kso_frame_cfg *cfg, kso_pic src, kso_pic ref, const ks
                         m.log2w = m.log2h = 6 - l;
                         m.cmx = tx + 4 * ME_TAB; m.cmy = ty + 4 * ME_TAB;
                         m.merange = root ? range : imax(range >> 2, 4);
-                        m.mv_min_x = m.mv_min_y = -range; m.mv_max_x = m.mv_max_y = range;
+                        m.mv_min_x = lim[0]; m.mv_max_x = lim[1]; m.mv_min_y = lim[2]; m.mv_max_y = lim[3];
                         m.dist = ks265o_sad;
-                        m.chk = 2; m.gx0 = m.gy0 = -66; m.gx1 = m.gy1 = 66;
+                        m.chk = 2; m.gx0 = ox - 66; m.gx1 = ox + 66; m.gy0 = oy - 66; m.gy1 = oy + 66;       /* the staged window */
                         m.mx = pmx; m.my = pmy;
                         uint32_t sad0 = ks265o_sad(m.fenc, m.ref0 + (long)pmy * st + pmx, st, st, s, s);
                         m.cost = sad0 + m.cmx[4 * pmx] + m.cmy[4 * pmy];
-                        if (root && (pmx || pmy)) {            /* second start candidate: the zero vector */
+                        if (root && (pmx || pmy) && lim[0] <= 0 && lim[1] >= 0 && lim[2] <= 0 && lim[3] >= 0) {   /* second start candidate: the zero vector */
                             uint32_t s0 = ks265o_sad(m.fenc, m.ref0, st, st, s, s);
                             uint32_t c0 = s0 + m.cmx[0] + m.cmy[0];
                             if (c0 < m.cost) { m.cost = c0; m.mx = 0; m.my = 0; sad0 = s0; }
@@ -315,7 +371,7 @@ void kso_me_integer(const kso_frame_cfg *cfg, kso_pic src, kso_pic ref, const ks
                         o->dist = m.cost - (uint32_t)(m.cmx[4 * m.mx] + m.cmy[4 * m.my]);
                     }
         }
-    free(field);
+    free(field); free(ctu_off);
 }
 
 /* ------------------------------------------------------------------ Stage B: sub-pel refinement
@@ -449,6 +505,9 @@ void kso_merge_pass(const kso_frame_cfg *cfg, kso_pic src, const uint8_t *planes
                     if (m.pred_mode != 0 || m.log2_cu < 3) continue;
                 } else { memset(&m, 0, sizeof m); m.inter_dir = is_b ? 3 : 1; }
                 const int dir = m.inter_dir & 3;
+                /* a neighbour's vector may come from a CTU with another window offset: taken over here it must keep this CU's block inside the planes' margin */
+                if ((dir & 1) && (x + (m.mvx >> 2) < -70 || x + (m.mvx >> 2) + n > cfg->width + 70 || y + (m.mvy >> 2) < -70 || y + (m.mvy >> 2) + n > cfg->height + 70)) continue;
+                if ((dir & 2) && (x + (m.mv1x >> 2) < -70 || x + (m.mv1x >> 2) + n > cfg->width + 70 || y + (m.mv1y >> 2) < -70 || y + (m.mv1y >> 2) + n > cfg->height + 70)) continue;
                 const uint8_t *p0 = NULL, *p1 = NULL;
                 if (dir & 1) p0 = org_y(&g, (uint8_t *)planes0 + (long)((m.mvy & 3) * 4 + (m.mvx & 3)) * g.bytes_y) + (long)(y + (m.mvy >> 2)) * st + x + (m.mvx >> 2);
                 if (dir & 2) p1 = org_y(&g, (uint8_t *)planes1 + (long)((m.mv1y & 3) * 4 + (m.mv1x & 3)) * g.bytes_y) + (long)(y + (m.mv1y >> 2)) * st + x + (m.mv1x >> 2);

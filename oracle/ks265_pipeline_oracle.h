@@ -39,7 +39,9 @@ void kso_pad_picture(const kso_frame_cfg *cfg, kso_pic pic);
 void kso_load_i420(const kso_frame_cfg *cfg, const uint8_t *i420, kso_pic dst);
 void kso_store_i420(const kso_frame_cfg *cfg, kso_pic src, uint8_t *i420);
 void kso_ref_planes(const kso_frame_cfg *cfg, kso_pic ref, uint8_t *planes);
-void kso_presearch(const kso_frame_cfg *cfg, kso_pic src, kso_pic ref, int16_t *field /* ceil(W/16) x ceil(H/16) x {mvx, mvy}, integer pel */);
+void kso_presearch(const kso_frame_cfg *cfg, kso_pic src, kso_pic ref, int16_t *field /* ceil(W/16) x ceil(H/16) x {mvx, mvy}, integer pel */,
+                   int16_t *ctu_off /* ctu_cols x ctu_rows x {ox, oy}: window offset of every CTU */);
+void kso_ctu_mv_limits(const kso_frame_cfg *cfg, int cx, int cy, int ox, int oy, int lim[4]);
 void kso_me_integer(const kso_frame_cfg *cfg, kso_pic src, kso_pic ref, const kso_pu *prev_pu, kso_pu *pu);
 void kso_me_subpel(const kso_frame_cfg *cfg, kso_pic src, const uint8_t *planes, kso_pu *pu);
 void kso_cu_decide(const kso_frame_cfg *cfg, const kso_pu *pu, kso_cu8 *cu8);
