@@ -348,6 +348,9 @@ ks265_sao_param *ks265_frame_sao(ks265_frame *f);
 /* The records of the picture just coded as ONE contiguous block in HBM, so that a pipelined host needs one device-side copy and one D2H per
  * picture: off[0..5] = byte offsets of { CU map, levels Y, Cb, Cr, SAO records, 64 caller-defined bytes (e.g. the three SSE sums) }, each
  * aligned to 256, off[6] = size of the block.  ks265_frame_pack_records copies them there on the context's stream (dev_extra64 may be NULL). */
+/* A host may code key pictures on a second frame object (another context = another stream, concurrently with the P pictures of the previous GOP); the frame
+ * object that continues with the P pictures must then forget its temporal predictors, as ks265_encode_picture(is_key) does itself */
+int ks265_frame_reset_prediction(ks265_frame *f);
 int ks265_frame_records_layout(ks265_frame *f, size_t off[7]);
 int ks265_frame_pack_records(ks265_frame *f, void *dev_dst, const void *dev_extra64);
 /* The same records in COMPACT form: the level planes cut into lines of 64 bytes (32 levels of a row; planes Y, Cb, Cr one after the other, each rounded up

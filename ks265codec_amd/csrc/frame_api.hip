@@ -190,6 +190,14 @@ int ks265_encode_picture_b(ks265_frame *f, ks265_pic src, ks265_pic ref0, ks265_
     return ks265_sao(f, src, deb, f->sao, recon_out);
 }
 
+/* forget the temporal predictors (the next P picture starts like the first one after a key picture): for hosts that code key pictures on another frame object */
+int ks265_frame_reset_prediction(ks265_frame *f)
+{
+    KS_FRAME_CHECK(f);
+    f->have_prev = false;
+    return KS265_OK;
+}
+
 int ks265_frame_set_profiling(ks265_frame *f, int enable)
 {
     KS_FRAME_CHECK(f);

@@ -109,7 +109,7 @@ int QY265ConfigParse(QY265EncConfig *c, const char *name, const char *value)
 }
 
 /* ------------------------------------------------------------------ encoder */
-#define MAX_DPB 12
+#define MAX_DPB 14
 #define MAX_JOBS 128                                      /* upper bound of the ring of pictures in flight; the encoder sizes its ring (Enc::ring) by picture size */
 #define MAX_INPUT (MAX_JOBS + 32)
 
@@ -149,6 +149,10 @@ typedef struct Enc {
     long seq;                                             /* pictures submitted */
     int recon_fd; uint8_t *dev_recon;                     /* reconstruction dump (the CLI's -o) */
     ks265_pic src; ks265_pic dpb[MAX_DPB]; int dpb_poc[MAX_DPB]; int ndpb; uint64_t *dev_sse;
+    /* key pictures on their own stream and frame object: an intra picture keeps 34 of 256 compute units busy for ~26 ms (2160p); coded as soon as its
+     * input arrives - the pixel path is tens of pictures behind the input - it runs underneath the P pictures of the previous GOP instead of between
+     * two GOPs.  Its reconstruction goes to one of two DPB slots of its own; the first P picture of the GOP waits for ev_key. */
+    int key_overlap, nkeys; ks265_ctx *ctx_key; ks265_frame *frame_key; ks265_pic src_key; uint64_t *dev_sse_key; void *ev_key, *ev_firstp[2];
     /* scheduling */
     Input in[MAX_INPUT]; int next_disp;                   /* display index of the next input picture */
     int gop_start;                                        /* display index of the last key picture */
@@ -326,7 +330,7 @@ static void *worker(void *arg)
     return NULL;
 }
 
-static int dpb_find(Enc *e, int poc) { for (int i = 0; i < e->ndpb; ++i) if (e->dpb_poc[i] == poc) return i; return -1; }
+static int dpb_find(Enc *e, int poc) { for (int i = 0; i < e->ndpb + 2 * e->key_overlap; ++i) if (e->dpb_poc[i] == poc) return i; return -1; }   /* incl. the key pictures' own slots */
 static int dpb_free_slot(Enc *e, const int *keep, int nkeep)
 {
     for (int i = 0; i < e->ndpb; ++i) {
@@ -353,35 +357,53 @@ static int submit(Enc *e, Input *in, int kind, int poc, int qp, const int *l0, i
     int r = recycled ? ks265_stream_wait_event(e->ctx_in, e->ev_loaded[k]) : 0;
     if (!r) r = ks265_memcpy_h2d_async(e->ctx_in, e->dev_in[k], in->i420, fsz);
     if (!r) r = ks265_event_record(e->ctx_in, e->ev_h2d[k]);
-    /* pixel path */
-    if (!r) r = ks265_stream_wait_event(e->ctx, e->ev_h2d[k]);
-    if (!r) r = ks265_load_i420(e->frame, e->dev_in[k], e->src);
-    if (!r) r = ks265_event_record(e->ctx, e->ev_loaded[k]);
-    if (!r) r = ks265_frame_set_qp(e->frame, qp, kLambdaQ4[qp]);
+    /* pixel path: the main stream / frame object, or the key pictures' own */
+    const int on_key = kind == 'I' && e->key_overlap && (e->iper <= 0 || e->iper >= 32);
+    ks265_ctx *cx = on_key ? e->ctx_key : e->ctx;
+    ks265_frame *fr = on_key ? e->frame_key : e->frame;
+    ks265_pic srcp = on_key ? e->src_key : e->src;
+    uint64_t *dsse = on_key ? e->dev_sse_key : e->dev_sse;
+    if (!r) r = ks265_stream_wait_event(cx, e->ev_h2d[k]);
+    if (!r) r = ks265_load_i420(fr, e->dev_in[k], srcp);
+    if (!r) r = ks265_event_record(cx, e->ev_loaded[k]);
+    if (!r) r = ks265_frame_set_qp(fr, qp, kLambdaQ4[qp]);
     int keep[20], nk = 0;
     for (int i = 0; i < nkeep; ++i) keep[nk++] = keep_after[i];
     for (int i = 0; i < nl0; ++i) keep[nk++] = l0[i];
     for (int i = 0; i < nl1; ++i) keep[nk++] = l1[i];
-    const int slot = dpb_free_slot(e, keep, nk);
+    int slot;
+    if (on_key) {
+        slot = e->ndpb + (e->nkeys & 1);
+        /* everything enqueued on the main stream so far belongs to earlier GOPs: when this mark fires, the readers of the previous key picture are through.
+         * The slot written now held the key picture two GOPs back: wait for the mark set when the previous key picture was submitted */
+        if (!r && e->nkeys >= 1) r = ks265_event_record(e->ctx, e->ev_firstp[(e->nkeys - 1) & 1]);
+        if (!r && e->nkeys >= 2) r = ks265_stream_wait_event(cx, e->ev_firstp[e->nkeys & 1]);
+    } else slot = dpb_free_slot(e, keep, nk);
     if (slot < 0) return QY_FAIL;
     ks265_pic out = e->dpb[slot];
     if (!r) {
-        if (kind == 'I') r = ks265_encode_picture(e->frame, e->src, out, 1, out);
-        else if (kind == 'B') r = ks265_encode_picture_b(e->frame, e->src, e->dpb[dpb_find(e, l0[0])], e->dpb[dpb_find(e, l1[0])], out);
-        else if (nl0 > 1) { ks265_pic refs[4]; for (int i = 0; i < nl0; ++i) refs[i] = e->dpb[dpb_find(e, l0[i])]; r = ks265_encode_picture_mref(e->frame, e->src, refs, nl0, out); }
-        else r = ks265_encode_picture(e->frame, e->src, e->dpb[dpb_find(e, l0[0])], 0, out);
+        if (kind == 'I') r = ks265_encode_picture(fr, srcp, out, 1, out);
+        else if (kind == 'B') r = ks265_encode_picture_b(fr, srcp, e->dpb[dpb_find(e, l0[0])], e->dpb[dpb_find(e, l1[0])], out);
+        else if (nl0 > 1) { ks265_pic refs[4]; for (int i = 0; i < nl0; ++i) refs[i] = e->dpb[dpb_find(e, l0[i])]; r = ks265_encode_picture_mref(fr, srcp, refs, nl0, out); }
+        else r = ks265_encode_picture(fr, srcp, e->dpb[dpb_find(e, l0[0])], 0, out);
     }
     e->dpb_poc[slot] = poc;
-    if (!r && e->cfg.calcPsnr) r = ks265_sse_picture(e->frame, e->src, out, e->dev_sse);
+    if (!r && e->cfg.calcPsnr) r = ks265_sse_picture(fr, srcp, out, dsse);
     if (!r && e->recon_fd >= 0) {
-        r = ks265_store_i420(e->frame, out, e->dev_recon);
-        if (!r) r = ks265_memcpy_d2h_async(e->ctx, j->recon, e->dev_recon, fsz);
+        r = ks265_store_i420(fr, out, e->dev_recon);
+        if (!r) r = ks265_memcpy_d2h_async(cx, j->recon, e->dev_recon, fsz);
     }
     /* the records leave the frame object's buffers for a staging set (device to device, a few microseconds), so that the next picture can start
      * while the copy-out stream drains this one */
-    if (!r && recycled) r = ks265_stream_wait_event(e->ctx, e->ev_drained[k]);
-    if (!r) r = ks265_frame_pack_compact(e->frame, e->stg[k], e->cfg.calcPsnr ? e->dev_sse : NULL);
-    if (!r) r = ks265_event_record(e->ctx, e->ev_staged[k]);
+    if (!r && recycled) r = ks265_stream_wait_event(cx, e->ev_drained[k]);
+    if (!r) r = ks265_frame_pack_compact(fr, e->stg[k], e->cfg.calcPsnr ? dsse : NULL);
+    if (!r) r = ks265_event_record(cx, e->ev_staged[k]);
+    if (on_key) {                                                      /* everything coded after it on the main stream waits for the key picture; its temporal predictors start over */
+        if (!r) r = ks265_event_record(cx, e->ev_key);
+        if (!r) r = ks265_stream_wait_event(e->ctx, e->ev_key);
+        if (!r) r = ks265_frame_reset_prediction(e->frame);
+        ++e->nkeys;
+    }
     /* copy-out stream */
     if (!r) r = ks265_stream_wait_event(e->ctx_out, e->ev_staged[k]);
     if (!r) r = ks265_copy_out_compact_async(e->ctx_out, e->frame, j->cmp, e->stg[k]);   /* fixed part + the stored lines only (~2 MB for a P picture at 2160p) */
@@ -459,7 +481,7 @@ static int schedule(Enc *e, int flush, int have /* pictures [0, have) have arriv
         if (key) {
             Input *in = input_at(e, nxt);
             e->gop_start = nxt; e->force_key = 0;
-            for (int i = 0; i < e->ndpb; ++i) e->dpb_poc[i] = -1000000;
+            for (int i = 0; i < e->ndpb + 2 * e->key_overlap; ++i) e->dpb_poc[i] = -1000000;
             int r = submit(e, in, 'I', 0, clampqp(e, e->base_qp + e->rc_qp_delta), NULL, 0, NULL, 0, NULL, 0, 1, 1);
             if (r) return r;
             e->coded_upto = nxt;
@@ -607,7 +629,12 @@ void QY265EncoderClose(void *h)
             free(j->nal);
         }
         for (int i = 0; i < MAX_INPUT; ++i) ks265_host_free(e->ctx, e->in[i].i420);
-        for (int i = 0; i < e->ndpb; ++i) pic_free(e, &e->dpb[i]);
+        for (int i = 0; i < e->ndpb + 2; ++i) pic_free(e, &e->dpb[i]);
+        pic_free(e, &e->src_key); ks265_dev_free(e->ctx, e->dev_sse_key);
+        if (e->ev_key) ks265_event_destroy(e->ctx, e->ev_key);
+        for (int i = 0; i < 2; ++i) if (e->ev_firstp[i]) ks265_event_destroy(e->ctx, e->ev_firstp[i]);
+        if (e->ctx_key) ks265_synchronize(e->ctx_key);
+        if (e->frame_key) ks265_frame_destroy(e->frame_key);
         pic_free(e, &e->src);
         for (int k = 0; k < NPIPE; ++k) {
             ks265_dev_free(e->ctx, e->dev_in[k]); ks265_dev_free(e->ctx, e->stg[k]);
@@ -619,6 +646,7 @@ void QY265EncoderClose(void *h)
         ks265_dev_free(e->ctx, e->dev_sse); ks265_dev_free(e->ctx, e->dev_recon);
         if (e->recon_fd >= 0) close(e->recon_fd);
         if (e->frame) ks265_frame_destroy(e->frame);
+        if (e->ctx_key) ks265_destroy(e->ctx_key);
         if (e->ctx_in) ks265_destroy(e->ctx_in);
         if (e->ctx_out) ks265_destroy(e->ctx_out);
         ks265_destroy(e->ctx);
@@ -693,6 +721,15 @@ void *QY265EncoderOpen(QY265EncConfig *cfg, int *err)
     if (!r) r = pic_alloc(e, &e->src);
     e->ndpb = e->hier ? 10 : e->gop_b ? 4 : e->refs + 2;
     for (int i = 0; i < e->ndpb && !r; ++i) { r = pic_alloc(e, &e->dpb[i]); e->dpb_poc[i] = -1000000; }
+    e->key_overlap = getenv("KS265_NO_KEY_OVERLAP") ? 0 : 1;
+    if (e->key_overlap) {
+        if (!r) r = ks265_create(&e->ctx_key, dev_id);
+        if (!r) r = ks265_frame_create(e->ctx_key, &e->fcfg, &e->frame_key);
+        if (!r) r = pic_alloc(e, &e->src_key);
+        if (!r) r = ks265_dev_malloc(e->ctx, (void **)&e->dev_sse_key, 64);
+        if (!r) r = ks265_event_create(e->ctx, &e->ev_key);
+        for (int i = 0; i < 2 && !r; ++i) { r = pic_alloc(e, &e->dpb[e->ndpb + i]); e->dpb_poc[e->ndpb + i] = -1000000; if (!r) r = ks265_event_create(e->ctx, &e->ev_firstp[i]); }
+    }
     /* ring of pictures in flight: a key picture's slice takes one writer thread many picture periods, and output is in coding order - the ring must
      * hold everything that is coded meanwhile, or the GPU idles behind it.  About 6 GB of records (pinned compact block + expanded level planes + pinned input), at least 24 and at most MAX_JOBS pictures. */
     e->ring = (int)(((size_t)6 << 30) / (e->cmp_off[7] + npx * 3 + fsz));
@@ -849,6 +886,7 @@ int ks265_enc_set_recon_file(void *h, const char *path)
     Enc *e = (Enc *)h;
     if (!e || !path) return QY_POINTER;
     if (e->next_disp != 0 || e->recon_fd >= 0) return QY_NOTSUPPORTED;
+    e->key_overlap = 0;                                                /* the dump shares one device buffer: key pictures stay on the main stream */
     const size_t fsz = (size_t)e->W * e->H * 3 / 2;
     int r = ks265_dev_malloc(e->ctx, (void **)&e->dev_recon, fsz);
     for (int i = 0; i < e->ring && !r; ++i) r = ks265_host_malloc(e->ctx, (void **)&e->jobs[i].recon, fsz);
