@@ -463,7 +463,8 @@ def encoded_leg(args, torch, dist, rank, world, dev_index, backend, sync_all):
 
     class Stats(C.Structure):
         _fields_ = [("frames", C.c_long), ("bytes", C.c_longlong), ("sse", C.c_double * 3), ("gpu_ms", C.c_double), ("host_write_ms", C.c_double),
-                    ("in_copy_ms", C.c_double), ("submit_ms", C.c_double), ("output_ms", C.c_double), ("lat_gpu_ms", C.c_double), ("lat_queue_ms", C.c_double), ("key_wall_ms", C.c_double), ("key_cpu_ms", C.c_double), ("keys", C.c_long)]
+                    ("in_copy_ms", C.c_double), ("submit_ms", C.c_double), ("output_ms", C.c_double), ("lat_gpu_ms", C.c_double), ("lat_queue_ms", C.c_double), ("key_wall_ms", C.c_double), ("key_cpu_ms", C.c_double), ("keys", C.c_long),
+                    ("occ_samples", C.c_long), ("occ_ring", C.c_long), ("occ_gpu", C.c_long), ("occ_ready", C.c_long)]
 
     W, H = args.width, args.height
     try:
@@ -615,7 +616,9 @@ def encoded_leg(args, torch, dist, rank, world, dev_index, backend, sync_all):
             "psnr_y": 99.0 if mse == 0 else 10.0 * np.log10(255.0 ** 2 / mse), "slice_write_ms_per_picture": st.host_write_ms / max(1, st.frames), "preset": preset.decode(),
             "caller_ms_per_picture": {"input_copy": round(st.in_copy_ms / max(1, st.frames), 3), "enqueue": round(st.submit_ms / max(1, st.frames), 3), "output": round(st.output_ms / max(1, st.frames), 3),
                                       "latency_enqueue_to_records_on_host": round(st.lat_gpu_ms / max(1, st.frames), 2), "latency_enqueue_to_writer_pickup": round(st.lat_queue_ms / max(1, st.frames), 2),
-                                      "key_picture_slice_wall_ms": round(st.key_wall_ms / max(1, st.keys), 2), "key_picture_slice_thread_ms": round(st.key_cpu_ms / max(1, st.keys), 2)},
+                                      "key_picture_slice_wall_ms": round(st.key_wall_ms / max(1, st.keys), 2), "key_picture_slice_thread_ms": round(st.key_cpu_ms / max(1, st.keys), 2),
+                                      "ring_occupancy_at_submission": {"in_ring": round(st.occ_ring / max(1, st.occ_samples), 1), "not_through_gpu": round(st.occ_gpu / max(1, st.occ_samples), 1),
+                                                                       "waiting_for_a_writer": round(st.occ_ready / max(1, st.occ_samples), 1)}},
             "gop": f"hierarchical-B {args.hier_b}" if args.hier_b else (f"P + {gop_b} B" if gop_b else "IPPP")}
 
 

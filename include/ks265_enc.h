@@ -86,6 +86,7 @@ typedef struct { long frames; long long bytes; double sse[3]; double gpu_ms; dou
                  double in_copy_ms, submit_ms, output_ms;   /* calling thread: input copy to pinned memory, enqueueing GPU work, waiting for / copying output */
                  double lat_gpu_ms, lat_queue_ms;           /* summed per picture: enqueue -> records on the host; enqueue -> a writer thread picked the picture up */
                  double key_wall_ms, key_cpu_ms; long keys; /* key pictures: records on the host -> slice finished (wall), summed thread time of its rows */
+                 long occ_samples, occ_ring, occ_gpu, occ_ready;   /* sampled at every submission: pictures in the ring, of them not yet through the GPU, of them waiting for a writer */
 } ks265_enc_stats;
 int ks265_enc_get_stats(void *pEncoder, ks265_enc_stats *out);
 /* extension: write the reconstruction (I420, display order) to `path` - the reference CLI's `-o`; call between Open and the first picture */

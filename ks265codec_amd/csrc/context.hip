@@ -143,7 +143,7 @@ int ks265_event_create(ks265_ctx *c, void **ev)
     if (!c || !ev) return KS265_POINTER;
     (void)hipSetDevice(c->device);
     hipEvent_t e;
-    const int r = ks265_hip(c, hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventBlockingSync)      /* a waiting host thread sleeps instead of spinning inside the runtime */);
+    const int r = ks265_hip(c, hipEventCreateWithFlags(&e, getenv("KS265_EVENT_BLOCKING") ? (hipEventDisableTiming | hipEventBlockingSync) : hipEventDisableTiming)   /* a waiting host thread spins inside the runtime: hosts keep ONE thread waiting (blocking-sync events wake up about a millisecond late) */);
     *ev = r ? nullptr : (void *)e;
     return r;
 }

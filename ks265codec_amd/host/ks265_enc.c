@@ -433,6 +433,7 @@ static int submit(Enc *e, Input *in, int kind, int poc, int qp, const int *l0, i
     pthread_mutex_lock(&e->mu);
     j->done = 0; j->error = 0; j->used = 1; j->started = 0; j->nrows = 0; j->next_row = 0; j->rows_done = 0;
     e->job_tail = (e->job_tail + 1) % e->ring; ++e->njobs; ++e->nwait;
+    e->st.occ_samples++; e->st.occ_ring += e->njobs; e->st.occ_gpu += e->nwait; e->st.occ_ready += e->npending;
     pthread_cond_signal(&e->cv_disp);
     pthread_cond_broadcast(&e->cv_sched_done);                         /* progress: a caller waiting for the scheduler (input back-pressure, flush) looks again */
     pthread_mutex_unlock(&e->mu);
