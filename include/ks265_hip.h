@@ -182,6 +182,12 @@ int ks265_downsample_rect(ks265_ctx *, const uint8_t *dev_src, int srcStride, ui
  * descriptor: a_off = org offset, b_off[0] / b_off[1] = offsets in ref0 / ref1 (b_off[2] unused) */
 int ks265_weight_bi_sad_batch(ks265_ctx *, const uint8_t *dev_org, int orgStride, const uint8_t *dev_ref0, int stride0, const uint8_t *dev_ref1, int stride1,
                               const ks265_blk3 *dev_blks, int n, uint32_t *dev_out);
+/* g_interMeBiFull_func / g_interMeBiHadFull_func (interMeBiFull_c enc@0x4896d0, interMeBiHadFull_c enc@0x4897e0): the 8 x 8 integer window of the joint
+ * bi-prediction refinement.  Block i: a_off = target block (clip8(2 org - pred) of calcBiMeOrg), b_off = top-left window position in the reference plane,
+ * w x h the block (had: multiples of 4); mvcost[16 i ..] = 8 column costs then 8 row costs.  out[2 i] = minimum of SAD|HAD + mvcost[x] + mvcost[8 + y]
+ * (first in scan order, rows outside), out[2 i + 1] = (y << 16) | x. */
+int ks265_bi_full_batch(ks265_ctx *, int use_had, const uint8_t *dev_org, int so, const uint8_t *dev_ref, int sr, const ks265_blk *dev_blks,
+                        const uint16_t *dev_mvcost, int n, uint32_t *dev_out);
 /* g_acEnergyPlaneFunc enc@0x707b20 -> acEnergyPlane_c enc@0x4650e0 (src, stride, log2Size): ssd - (sum^2 >> 2 log2N) in 32-bit unsigned
  * arithmetic (the wrap of sum^2 for bright 32x32 blocks is part of the contract); _batch: explicit block offsets, _map: every aligned
  * N x N block of a w x h plane in raster order (the per-block variance map of calcFrameAdaptQuant enc@0x4653c0) */
@@ -214,6 +220,9 @@ typedef struct {
                                   enc@0x48af50 picks the best of several start candidates) */
     int32_t merge;             /* 1 = stage C2 after the CU decision: every CU may adopt the motion of one of its spatial merge neighbours or the zero vector
                                   (ks265_merge_pass; the reference's merge / skip decision: GetMergeCandsFor*, skipFastDecision) - single reference per list */
+    int32_t bi_refine;         /* 1 = B pictures: joint refinement of the bi-predictive pair inside ks265_bi_decide (motionSearchBI enc@0x484910): the cheaper
+                                  list stays, the other one is searched again against clip8(2 org - pred) (calcBiMeOrg enc@0x47b1a0) over the 8 x 8 integer
+                                  window of interMeBiFull enc@0x4896d0 / interMeBiFull_opt enc@0x4898e0, then over the sub-pel ring */
 } ks265_frame_cfg;
 
 /* geometry of the padded picture buffers the caller allocates (one call, no allocation) */

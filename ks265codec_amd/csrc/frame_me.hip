@@ -339,24 +339,8 @@ extern "C" int ks265_cu_decide_b(ks265_frame *f, const ks265_pu_b *pub, ks265_cu
 // (level, tile), so the Hadamard stays on the VALU here: all 64 differences of a tile live in registers, six butterfly stages of
 // plain v_add_u32 / v_sub_u32, and |.| + accumulate is ONE v_sad_u32 per coefficient (a bias of 2^15 added to difference
 // (0,0) reaches every Hadamard output with weight +1, so all outputs are positive).
-__device__ __forceinline__ unsigned satd8x8_avg(const unsigned (&f)[16], const uint8_t *pa, const uint8_t *pb, long stride)
+__device__ __forceinline__ unsigned satd8x8_regs(int (&d)[64])
 {
-    const unsigned sha = (unsigned)((uintptr_t)pa & 3), shb = (unsigned)((uintptr_t)pb & 3);
-    const uint8_t *qa = pa - sha, *qb = pb - shb;
-    int d[64];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        const unsigned *ra = (const unsigned *)(qa + r * stride), *rb = (const unsigned *)(qb + r * stride);
-        const unsigned a0 = ra[0], a1 = ra[1], a2 = ra[2], b0 = rb[0], b1 = rb[1], b2 = rb[2];
-        const unsigned A[2] = {align_bytes(a1, a0, sha), align_bytes(a2, a1, sha)}, B[2] = {align_bytes(b1, b0, shb), align_bytes(b2, b1, shb)};
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int avg = (int)(((A[h] >> (8 * i)) & 255) + ((B[h] >> (8 * i)) & 255) + 1) >> 1;
-                d[r * 8 + h * 4 + i] = (int)((f[2 * r + h] >> (8 * i)) & 255) - avg;
-            }
-    }
     d[0] += 0x8000;
 #pragma unroll
     for (int len = 1; len < 64; len <<= 1)
@@ -377,7 +361,50 @@ __device__ __forceinline__ unsigned satd8x8_avg(const unsigned (&f)[16], const u
     return (acc + 2) >> 2;
 }
 
-__global__ __launch_bounds__(256) void bi_decide_kernel(KsGeom g, int lam, const uint8_t *src, const uint8_t *planes0, const uint8_t *planes1,
+__device__ __forceinline__ int bitx_of(unsigned long long packed, int i) { return (int)((packed >> (8 * i)) & 255); }
+
+// 8x8 tile at an arbitrary byte address -> 16 packed dwords
+__device__ __forceinline__ void load_tile8(const uint8_t *p, long stride, unsigned (&t)[16])
+{
+    const unsigned sh = (unsigned)((uintptr_t)p & 3);
+    const uint8_t *q = p - sh;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const unsigned *rw = (const unsigned *)(q + r * stride);
+        const unsigned a0 = rw[0], a1 = rw[1], a2 = rw[2];
+        t[2 * r] = align_bytes(a1, a0, sh); t[2 * r + 1] = align_bytes(a2, a1, sh);
+    }
+}
+
+__device__ __forceinline__ unsigned satd8x8_avg(const unsigned (&f)[16], const uint8_t *pa, const uint8_t *pb, long stride)
+{
+    const unsigned sha = (unsigned)((uintptr_t)pa & 3), shb = (unsigned)((uintptr_t)pb & 3);
+    const uint8_t *qa = pa - sha, *qb = pb - shb;
+    int d[64];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const unsigned *ra = (const unsigned *)(qa + r * stride), *rb = (const unsigned *)(qb + r * stride);
+        const unsigned a0 = ra[0], a1 = ra[1], a2 = ra[2], b0 = rb[0], b1 = rb[1], b2 = rb[2];
+        const unsigned A[2] = {align_bytes(a1, a0, sha), align_bytes(a2, a1, sha)}, B[2] = {align_bytes(b1, b0, shb), align_bytes(b2, b1, shb)};
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int avg = (int)(((A[h] >> (8 * i)) & 255) + ((B[h] >> (8 * i)) & 255) + 1) >> 1;
+                d[r * 8 + h * 4 + i] = (int)((f[2 * r + h] >> (8 * i)) & 255) - avg;
+            }
+    }
+    return satd8x8_regs(d);
+}
+
+// cfg.bi_refine - joint refinement of the pair (motionSearchBI enc@0x484910 / interMeBiFull_opt enc@0x4898e0 / interMeBiFull_c enc@0x4896d0), per
+// (level, tile) lane like the rest of the kernel.  The cheaper list keeps its vector; T = clip8(2 org - pred_kept) (calcBiMeOrg enc@0x47b1a0) is the
+// target of the other one.  Integer step: the 15 x 15 window of the tile sits in 60 registers (rows realigned once), the 64 positions are SADs of
+// register rows (v_sad_u8, static v_alignbyte per column), summed over the PU's lanes by DPP, + vector rate, first minimum in row-major order
+// (key = cost << 6 | position).  Sub-pel step: the two rings of stage B on T, SAD + rate like the integer step.  The refined pair replaces the decision when
+// its SATD against the rounded average + both vector rates is lower.
+template <bool REFINE>
+__global__ __launch_bounds__(256, REFINE ? 2 : 1) void bi_decide_kernel(KsGeom g, int lam, const uint8_t *src, const uint8_t *planes0, const uint8_t *planes1,
                                                         const ks265_pu *pu0, const ks265_pu *pu1, ks265_pu_b *pub)
 {
     const int tid = threadIdx.x, lane = tid & 63, level = tid >> 6;
@@ -407,6 +434,95 @@ __global__ __launch_bounds__(256) void bi_decide_kernel(KsGeom g, int lam, const
             const unsigned c = dd + (unsigned)mv_cost(a.mvx, a.mvy, a.mvpx, a.mvpy, lam) + (unsigned)mv_cost(b.mvx, b.mvy, b.mvpx, b.mvpy, lam);
             if (c < o.cost) { o.cost = c; o.inter_dir = 3; }
         }
+        if (REFINE) {
+            const bool keep1 = valid && b.cost < a.cost;                 // list whose vector stays (uniform over the PU's lanes)
+            const uint8_t *pk = keep1 ? pb : pa;
+            const uint8_t *planesO = keep1 ? planes0 : planes1;
+            const int omx = keep1 ? ax : bx, omy = keep1 ? ay : by;
+            const int opx = valid ? (keep1 ? a.mvpx : b.mvpx) : 0, opy = valid ? (keep1 ? a.mvpy : b.mvpy) : 0;
+            unsigned T[16];
+            {
+                unsigned k[16];
+                load_tile8(pk, g.sy, k);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    unsigned w = 0;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int v = 2 * (int)((f[i] >> (8 * q)) & 255) - (int)((k[i] >> (8 * q)) & 255);
+                        w |= (unsigned)clip3(0, 255, v) << (8 * q);
+                    }
+                    T[i] = w;
+                }
+            }
+            const int xe = min(cx * 64 + 64, g.W), ye = min(cy * 64 + 64, g.H);
+            const int lox = -64 - cx * 64, hix = g.W + 64 - xe, loy = -64 - cy * 64, hiy = g.H + 64 - ye;
+            int imx = clip3(4 * lox, 4 * hix, omx) >> 2, imy = clip3(4 * loy, 4 * hiy, omy) >> 2;
+            imx = imx <= lox + 3 ? lox + 4 : (imx >= hix - 3 ? hix - 4 : imx);
+            imy = imy <= loy + 3 ? loy + 4 : (imy >= hiy - 3 ? hiy - 4 : imy);
+            const int sx = valid ? imx - 3 - (opx < 0) : 0, sy = valid ? imy - 3 - (opy < 0) : 0;   // idle lanes read around the picture origin
+            unsigned long long bitx = 0;                                   // eight column bit counts (< 64 each), one byte apiece: indexed by the runtime column
+            int bity[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { bitx |= (unsigned long long)se_bits(4 * (sx + i) - opx) << (8 * i); bity[i] = se_bits(4 * (sy + i) - opy); }
+            unsigned bkey = 0xFFFFFFFFu;
+            {
+                unsigned w[15][4];
+                const uint8_t *r0 = planesO + base + (long)sy * g.sy + sx;
+                const unsigned sh = (unsigned)((uintptr_t)r0 & 3);
+                const uint8_t *q0 = r0 - sh;
+#pragma unroll
+                for (int r = 0; r < 15; ++r) {
+                    const unsigned *rw = (const unsigned *)(q0 + (long)r * g.sy);
+                    const unsigned a0 = rw[0], a1 = rw[1], a2 = rw[2], a3 = rw[3], a4 = rw[4];
+                    w[r][0] = align_bytes(a1, a0, sh); w[r][1] = align_bytes(a2, a1, sh); w[r][2] = align_bytes(a3, a2, sh); w[r][3] = align_bytes(a4, a3, sh);
+                }
+#pragma unroll 1
+                for (int dx = 0; dx < 8; ++dx) {                          // columns one after the other: the window rows move one byte per step
+#pragma unroll
+                    for (int dy = 0; dy < 8; ++dy) {
+                        unsigned sd2 = 0;
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) { sd2 = sad_u8x4(T[2 * r], w[dy + r][0], sd2); sd2 = sad_u8x4(T[2 * r + 1], w[dy + r][1], sd2); }
+                        const unsigned tot = pu_group_sum(valid ? sd2 : 0, level) + (unsigned)((lam * (bitx_of(bitx, dx) + bity[dy])) >> 4);
+                        bkey = min(bkey, (tot << 6) | (unsigned)(dy * 8 + dx));
+                    }
+#pragma unroll
+                    for (int r = 0; r < 15; ++r) {
+                        w[r][0] = align_bytes(w[r][1], w[r][0], 1); w[r][1] = align_bytes(w[r][2], w[r][1], 1);
+                        w[r][2] = align_bytes(w[r][3], w[r][2], 1); w[r][3] >>= 8;
+                    }
+                }
+            }
+            int rbx = 4 * (sx + (int)(bkey & 7)), rby = 4 * (sy + (int)((bkey >> 3) & 7));
+            unsigned bc = bkey >> 6;                                                   // SAD + rate of the integer winner
+#pragma unroll 1
+            for (int step = 2; step >= 1; --step) {
+                const int c0x = rbx, c0y = rby;
+#pragma unroll 1
+                for (int k = 0; k < 8; ++k) {
+                    const int kk = k < 4 ? k : k + 1;                                  // ring order of stage B: (-1,-1) (0,-1) (1,-1) (-1,0) (1,0) (-1,1) (0,1) (1,1)
+                    const int qx = c0x + (kk % 3 - 1) * step, qy = c0y + (kk / 3 - 1) * step;
+                    const uint8_t *pl = planesO + (long)((qy & 3) * 4 + (qx & 3)) * g.bytes_y + base + (long)(qy >> 2) * g.sy + (qx >> 2);
+                    unsigned q8[16], sd3 = 0;
+                    load_tile8(pl, g.sy, q8);
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) sd3 = sad_u8x4(T[i], q8[i], sd3);
+                    const unsigned cc = pu_group_sum(valid ? sd3 : 0, level) + (unsigned)mv_cost(qx, qy, opx, opy, lam);
+                    if (cc < bc) { bc = cc; rbx = qx; rby = qy; }
+                }
+            }
+            const uint8_t *po = planesO + (long)((rby & 3) * 4 + (rbx & 3)) * g.bytes_y + base + (long)(rby >> 2) * g.sy + (rbx >> 2);
+            const unsigned d2 = pu_group_sum(valid ? satd8x8_avg(f, pk, po, g.sy) : 0, level);
+            if (valid) {
+                const unsigned c2 = d2 + (unsigned)(keep1 ? mv_cost(b.mvx, b.mvy, b.mvpx, b.mvpy, lam) : mv_cost(a.mvx, a.mvy, a.mvpx, a.mvpy, lam))
+                                    + (unsigned)mv_cost(rbx, rby, opx, opy, lam);
+                if (c2 < o.cost) {
+                    o.cost = c2; o.inter_dir = 3;
+                    if (keep1) { o.mvx = (int16_t)rbx; o.mvy = (int16_t)rby; } else { o.mv1x = (int16_t)rbx; o.mv1y = (int16_t)rby; }
+                }
+            }
+        }
     }
     if ((lane & (G - 1)) == 0) pub[(long)ctu * 85 + pidx] = o;
 }
@@ -416,8 +532,12 @@ extern "C" int ks265_bi_decide(ks265_frame *f, ks265_pic src, const uint8_t *pla
 {
     KS_FRAME_CHECK(f);
     if (!src.y || !planes0 || !planes1 || !pu0 || !pu1 || !pub) return KS265_POINTER;
-    hipLaunchKernelGGL(bi_decide_kernel, dim3(f->g.ctu_cols * f->g.ctu_rows), dim3(256), 0, f->ctx->stream, f->g, f->cfg.lambda_q4, src.y, planes0, planes1,
-                       pu0, pu1, pub);
+    if (f->cfg.bi_refine)
+        hipLaunchKernelGGL(bi_decide_kernel<true>, dim3(f->g.ctu_cols * f->g.ctu_rows), dim3(256), 0, f->ctx->stream, f->g, f->cfg.lambda_q4, src.y, planes0,
+                           planes1, pu0, pu1, pub);
+    else
+        hipLaunchKernelGGL(bi_decide_kernel<false>, dim3(f->g.ctu_cols * f->g.ctu_rows), dim3(256), 0, f->ctx->stream, f->g, f->cfg.lambda_q4, src.y, planes0,
+                           planes1, pu0, pu1, pub);
     return ks265_check_launch(f->ctx);
 }
 

@@ -393,6 +393,56 @@ __global__ __launch_bounds__(256) void weight_bi_sad_batch_kernel(const uint8_t 
     acc = wave_sum(acc);
     if (lane == 0) out[b] = acc;
 }
+// interMeBiFull_c enc@0x4896d0 / interMeBiHadFull_c enc@0x4897e0: one wave per block, lane = window position (y * 8 + x); out = {cost, (y << 16) | x}
+template <bool HAD>
+__global__ __launch_bounds__(256) void bi_full_batch_kernel(const uint8_t *org, int so, const uint8_t *ref, int sr, const ks265_blk *blks, const uint16_t *mvcost,
+                                                            int n, uint32_t *out)
+{
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (b >= n) return;
+    const ks265_blk d = blks[b];
+    const uint16_t *mc = mvcost + (long)b * 16;
+    const uint8_t *po = org + d.a_off;
+    unsigned cost;
+    if (!HAD) {
+        const uint8_t *pr = ref + d.b_off + (long)(lane >> 3) * sr + (lane & 7);
+        unsigned acc = 0;
+        for (int y = 0; y < d.h; ++y)
+            for (int x = 0; x < d.w; ++x) acc += (unsigned)abs((int)po[(long)y * so + x] - (int)pr[(long)y * sr + x]);
+        cost = acc;
+    } else {
+        cost = 0;                                                            // had_c tiling of the block (8x8 tiles, else 4x4), positions one after the other
+        for (int pos = 0; pos < 64; ++pos) {
+            const uint8_t *pr = ref + d.b_off + (long)(pos >> 3) * sr + (pos & 7);
+            unsigned total = 0;
+            if (((d.w | d.h) & 7) == 0) {
+                for (int t = 0; t < (d.w >> 3) * (d.h >> 3); ++t) {
+                    const int ty = t / (d.w >> 3), x0 = (t - ty * (d.w >> 3)) << 3, y0 = ty << 3, x = lane & 7, y = lane >> 3;
+                    const int v = (int)po[(long)(y0 + y) * so + x0 + x] - (int)pr[(long)(y0 + y) * sr + x0 + x];
+                    total += (had8x8_abs_sum(v, lane) + 2) >> 2;
+                }
+            } else {
+                const int tx = d.w >> 2, nt = tx * (d.h >> 2);
+                for (int t0 = 0; t0 < nt; t0 += 4) {
+                    const int t = t0 + (lane >> 4);
+                    int v = 0;
+                    if (t < nt) {
+                        const int ty = t / tx, x0 = (t - ty * tx) << 2, y0 = ty << 2, x = lane & 3, y = (lane >> 2) & 3;
+                        v = (int)po[(long)(y0 + y) * so + x0 + x] - (int)pr[(long)(y0 + y) * sr + x0 + x];
+                    }
+                    const unsigned sg = (had4x4_abs_sum16(v, lane) + 1) >> 1;
+                    total += wave_sum((lane & 15) == 0 && t < nt ? sg : 0);
+                }
+            }
+            if (lane == pos) cost = total;
+        }
+    }
+    cost += (unsigned)mc[lane & 7] + (unsigned)mc[8 + (lane >> 3)];
+    unsigned long long key = ((unsigned long long)cost << 6) | (unsigned)lane;      // first minimum in scan order (rows outside, columns inside)
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { const unsigned long long o = __shfl_xor(key, m, 64); key = o < key ? o : key; }
+    if (lane == 0) { const int best = (int)(key & 63); out[2 * b] = (uint32_t)(key >> 6); out[2 * b + 1] = (uint32_t)(((best >> 3) << 16) | (best & 7)); }
+}
 // acEnergyPlane_c enc@0x4650e0: one wave per N x N block; offs == nullptr: the aligned blocks of a w x h plane in raster order
 __global__ __launch_bounds__(256) void ac_energy_batch_kernel(const uint8_t *src, int stride, int log2, const int32_t *offs, int n, int bw, uint32_t *out)
 {
@@ -618,6 +668,14 @@ int ks265_weight_bi_sad_batch(ks265_ctx *ctx, const uint8_t *org, int so, const 
 {
     CHECK_CTX(ctx); if (!org || !ref0 || !ref1 || !blks || !out) return KS265_POINTER; if (n <= 0) return KS265_OK;
     hipLaunchKernelGGL(weight_bi_sad_batch_kernel, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, org, so, ref0, s0, ref1, s1, blks, n, out);
+    LAUNCH_END(ctx);
+}
+int ks265_bi_full_batch(ks265_ctx *ctx, int use_had, const uint8_t *org, int so, const uint8_t *ref, int sr, const ks265_blk *blks, const uint16_t *mvcost, int n,
+                        uint32_t *out)
+{
+    CHECK_CTX(ctx); if (!org || !ref || !blks || !mvcost || !out) return KS265_POINTER; if (n <= 0) return KS265_OK;
+    if (use_had) hipLaunchKernelGGL(bi_full_batch_kernel<true>, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, org, so, ref, sr, blks, mvcost, n, out);
+    else hipLaunchKernelGGL(bi_full_batch_kernel<false>, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, org, so, ref, sr, blks, mvcost, n, out);
     LAUNCH_END(ctx);
 }
 int ks265_ac_energy_batch(ks265_ctx *ctx, const uint8_t *src, int stride, int log2, const int32_t *offs, int n, uint32_t *out)

@@ -25,7 +25,7 @@ SAO_PARAM = np.dtype([("type", "i1"), ("band", "i1"), ("offset", "i1", 4), ("rsv
 
 class FrameCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("width", "height", "qp", "lambda_q4", "me_range", "me_method", "subme", "deblock", "sao",
-                                          "beta_offset_div2", "tc_offset_div2", "bframes", "refs", "me_hex_thr", "sdh", "pre_search", "merge")]
+                                          "beta_offset_div2", "tc_offset_div2", "bframes", "refs", "me_hex_thr", "sdh", "pre_search", "merge", "bi_refine")]
 
 
 class FrameGeom(C.Structure):
@@ -58,7 +58,7 @@ EXPORTS = [
     "ks265_downsample_rect", "ks265_weight_bi_sad_batch", "ks265_ac_energy_batch", "ks265_ac_energy_map",
     "ks265_frame_reset_prediction", "ks265_frame_records_layout", "ks265_frame_pack_records", "ks265_frame_compact_layout", "ks265_frame_pack_compact", "ks265_copy_out_compact_async", "ks265_frame_geometry", "ks265_frame_create", "ks265_frame_destroy", "ks265_frame_set_qp", "ks265_pad_picture",
     "ks265_load_i420", "ks265_store_i420", "ks265_ref_planes", "ks265_presearch", "ks265_me_integer", "ks265_me_subpel", "ks265_merge_pass", "ks265_cu_decide",
-    "ks265_cu_flat_intra", "ks265_intra_decide", "ks265_intra_decide_ex", "ks265_lookahead_reduce", "ks265_lookahead_picture", "ks265_intra_reconstruct", "ks265_reconstruct", "ks265_reconstruct_b", "ks265_bi_decide", "ks265_cu_decide_b", "ks265_deblock", "ks265_sao",
+    "ks265_cu_flat_intra", "ks265_intra_decide", "ks265_intra_decide_ex", "ks265_lookahead_reduce", "ks265_lookahead_picture", "ks265_intra_reconstruct", "ks265_reconstruct", "ks265_reconstruct_b", "ks265_bi_decide", "ks265_bi_full_batch", "ks265_cu_decide_b", "ks265_deblock", "ks265_sao",
     "ks265_encode_picture", "ks265_encode_picture_b", "ks265_encode_picture_mref", "ks265_ref_decide", "ks265_reconstruct_mref",
     "ks265_frame_set_profiling", "ks265_frame_stage_ms", "ks265_frame_levels", "ks265_frame_pu", "ks265_frame_cu8", "ks265_frame_sao", "ks265_frame_planes", "ks265_sse_picture",
 ]
@@ -230,6 +230,12 @@ class KsContext:
         self._chk(self.lib.ks265_weight_bi_sad_batch(self.h, _p(org), C.c_int(so), _p(r0), C.c_int(s0), _p(r1), C.c_int(s1), _p(self.dev(blks)), C.c_int(len(blks)), _p(out)))
         return self.host(out, np.uint32)
 
+    def bi_full(self, use_had: int, org, so: int, ref, sr: int, blks: np.ndarray, mvcost: np.ndarray) -> np.ndarray:
+        out = self.zeros(8 * len(blks))
+        d_blks, d_mvc = self.dev(blks), self.dev(np.ascontiguousarray(mvcost, np.uint16))      # both alive across the call (a temporary's block would be reused)
+        self._chk(self.lib.ks265_bi_full_batch(self.h, C.c_int(int(use_had)), _p(org), C.c_int(so), _p(ref), C.c_int(sr), _p(d_blks), _p(d_mvc), C.c_int(len(blks)), _p(out)))
+        return self.host(out, np.uint32, (len(blks), 2))
+
     def ac_energy(self, src, stride: int, log2: int, offs: np.ndarray) -> np.ndarray:
         out = self.zeros(4 * len(offs))
         self._chk(self.lib.ks265_ac_energy_batch(self.h, _p(src), C.c_int(stride), C.c_int(log2), _p(self.dev(np.asarray(offs, np.int32))), C.c_int(len(offs)), _p(out)))
@@ -263,9 +269,9 @@ class KsFrame:
     """Whole-frame stages of include/ks265_hip.h section 3 (one picture size, one stream)."""
 
     def __init__(self, ks: KsContext, width: int, height: int, qp: int, lambda_q4: int, me_range: int = 64, subme: int = 1,
-                 deblock: int = 1, sao: int = 1, me_method: int = 0, bframes: int = 0, refs: int = 1, me_hex_thr: int = 0, sdh: int = 0, pre_search: int = 0, merge: int = 0):
+                 deblock: int = 1, sao: int = 1, me_method: int = 0, bframes: int = 0, refs: int = 1, me_hex_thr: int = 0, sdh: int = 0, pre_search: int = 0, merge: int = 0, bi_refine: int = 0):
         self.ks, self.lib = ks, ks.lib
-        self.cfg = FrameCfg(width, height, qp, lambda_q4, me_range, me_method, subme, deblock, sao, 0, 0, bframes, refs, me_hex_thr, sdh, pre_search, merge)
+        self.cfg = FrameCfg(width, height, qp, lambda_q4, me_range, me_method, subme, deblock, sao, 0, 0, bframes, refs, me_hex_thr, sdh, pre_search, merge, bi_refine)
         self.geom = FrameGeom()
         ks._chk(self.lib.ks265_frame_geometry(C.byref(self.cfg), C.byref(self.geom)))
         h = C.c_void_p()

@@ -500,6 +500,24 @@ void ks265o_default_weighted_bi(uint8_t *dst, const int16_t *p0, const int16_t *
         for (int x = 0; x < width; ++x) dst[y * dstStride + x] = clip8(((int)p0[y * srcStride + x] + (int)p1[y * srcStride + x] + 64) >> 7);
 }
 
+/* enc@0x4896d0 interMeBiFull_c / enc@0x4897e0 interMeBiHadFull_c (best, org, ref, orgStride, refStride, mvcost, h, log2w): the integer step of the joint
+ * bi-prediction refinement (g_interMeBiFull_func / g_interMeBiHadFull_func; caller interMeBiFull_opt enc@0x4898e0).  `org` is the search target
+ * clip8(2 org - pred_other) of calcBiMeOrg, `ref` the top-left corner of an 8 x 8 window of integer positions; position (x, y) costs
+ * SAD (or HAD) + mvcost[x] + mvcost[8 + y], rows outside, columns inside, a later position wins only if strictly cheaper (unsigned compare against
+ * 0xfffffff at the start).  Returns the cost, *best = (y << 16) | x.  Pinned by tests/golden/bifull.npz. */
+uint32_t ks265o_inter_me_bi_full(int32_t *best, const uint8_t *org, const uint8_t *ref, int orgStride, int refStride, const uint16_t *mvcost, int h, int log2w, int use_had)
+{
+    uint32_t bc = 0xfffffffu;
+    for (int y = 0; y < 8; ++y)
+        for (int x = 0; x < 8; ++x) {
+            const uint8_t *r = ref + (long)y * refStride + x;
+            uint32_t c = (use_had ? ks265o_had(org, r, orgStride, refStride, h, 1 << log2w) : ks265o_sad(org, r, orgStride, refStride, h, 1 << log2w))
+                         + mvcost[x] + mvcost[8 + y];
+            if (c < bc) { bc = c; *best = (y << 16) | x; }
+        }
+    return bc;
+}
+
 /* enc@0x47b1a0 calcBiMeOrg_c(dst, pred, org, stride, height, width): the bi-pred search target dst = clip8(2 org - pred)
  * (g_calcBiMeOrgFuncs); returns the clipping loss sum |2 org - pred - dst|. */
 uint32_t ks265o_calc_bi_me_org(uint8_t *dst, const uint8_t *pred, const uint8_t *org, int stride, int height, int width)

@@ -91,6 +91,7 @@ void ks265o_stat_sao_bo_eo01(int *eoJoint, int *bo, const uint8_t *org, const ui
 
 /* ---- bi-prediction helpers, pinned now for the B-picture row (enc@0x435160 DefaultWeightedBi_c, enc@0x47b1a0 calcBiMeOrg_c) ---- */
 void ks265o_default_weighted_bi(uint8_t *dst, const int16_t *p0, const int16_t *p1, int dstStride, int srcStride, int width, int height);
+uint32_t ks265o_inter_me_bi_full(int32_t *best, const uint8_t *org, const uint8_t *ref, int orgStride, int refStride, const uint16_t *mvcost, int h, int log2w, int use_had);
 uint32_t ks265o_calc_bi_me_org(uint8_t *dst, const uint8_t *pred, const uint8_t *org, int stride, int height, int width);
 
 /* ---- intra prediction (ks265_intra_oracle.c): g_IntraPredFunction enc@0x7070a0 family, IntraPredFilterRef_c enc@0x424110.

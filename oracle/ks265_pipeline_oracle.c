@@ -530,9 +530,17 @@ void kso_merge_pass(const kso_frame_cfg *cfg, kso_pic src, const uint8_t *planes
 }
 
 /* ------------------------------------------------------------------ B pictures
- * Per PU: L0 cost and L1 cost come from the two uni-directional searches; the bi-predictive candidate pairs the two winners
- * (no joint refinement yet: interMeBiFull enc@0x4896d0 refines around them) and is judged on SATD against the rounded
- * average of the two 8-bit predictions (the final reconstruction uses the exact 14-bit average).  Ties prefer L0, then L1. */
+ * Per PU: L0 cost and L1 cost come from the two uni-directional searches; the bi-predictive candidate pairs the two winners and is judged on SATD
+ * against the rounded average of the two 8-bit predictions (the final reconstruction uses the exact 14-bit average).  Ties prefer L0, then L1.
+ *
+ * cfg->bi_refine: joint refinement (motionSearchB enc@0x484e90 -> motionSearchBI enc@0x484910 -> interMeBiFull_opt enc@0x4898e0).  The cheaper list
+ * stays as it is; the search target of the other one is T = clip8(2 org - pred_kept) (calcBiMeOrg enc@0x47b1a0), so that SAD(T, p) = 2 |org - (kept + p) / 2|.
+ * Integer step: the list's own vector, clamped to the legal range in quarter samples and floored to integer (motionSearchBI), is moved at least four
+ * samples inside the range, and the 8 x 8 window starts 3 + (mvp < 0) samples before it (interMeBiFull_opt); each position costs SAD + vector rate,
+ * rows outside, columns inside, first minimum (interMeBiFull_c enc@0x4896d0, restated and pinned as ks265o_inter_me_bi_full; the rate here is this
+ * pipeline's mv_cost on both components, not the reference's two 16-bit tables).  Sub-pel step: the two rings of kso_me_subpel on T, judged by SAD + rate like
+ * the integer step (one measure from the window to the quarter sample; the reference's sub-pel search uses its Hadamard cost).  The refined pair
+ * replaces the decision if its cost - SATD of the source against the rounded average + both vector rates, the measure of the unrefined pair - is lower. */
 void kso_bi_decide(const kso_frame_cfg *cfg, kso_pic src, const uint8_t *planes0, const uint8_t *planes1, const kso_pu *pu0, const kso_pu *pu1,
                    kso_pu_b *pub)
 {
@@ -562,6 +570,46 @@ void kso_bi_decide(const kso_frame_cfg *cfg, kso_pic src, const uint8_t *planes0
                         uint32_t d = ks265o_had(S + (long)y0 * st + x0, avg, st, s, s, s);
                         uint32_t c = d + (uint32_t)mv_cost(a->mvx, a->mvy, a->mvpx, a->mvpy, lam) + (uint32_t)mv_cost(b->mvx, b->mvy, b->mvpx, b->mvpy, lam);
                         if (c < o->cost) { o->cost = c; o->inter_dir = 3; }
+                        if (!cfg->bi_refine) continue;
+                        const int keep1 = b->cost < a->cost;                         /* list whose vector stays */
+                        const kso_pu *K = keep1 ? b : a, *O = keep1 ? a : b;
+                        const uint8_t *pk = keep1 ? p1 : p0, *planesO = keep1 ? planes0 : planes1;
+                        uint8_t T[64 * 64], orgp[64 * 64], kp[64 * 64];
+                        for (int y = 0; y < s; ++y) { memcpy(orgp + y * s, S + (long)(y0 + y) * st + x0, (size_t)s); memcpy(kp + y * s, pk + (long)y * st, (size_t)s); }
+                        ks265o_calc_bi_me_org(T, kp, orgp, s, s, s);
+                        const int xe = imin(cx * 64 + 64, cfg->width), ye = imin(cy * 64 + 64, cfg->height);
+                        const int lox = -64 - cx * 64, hix = cfg->width + 64 - xe, loy = -64 - cy * 64, hiy = cfg->height + 64 - ye;
+                        int imx = iclip(4 * lox, 4 * hix, O->mvx) >> 2, imy = iclip(4 * loy, 4 * hiy, O->mvy) >> 2;
+                        if (imx <= lox + 3) imx = lox + 4; else if (imx >= hix - 3) imx = hix - 4;
+                        if (imy <= loy + 3) imy = loy + 4; else if (imy >= hiy - 3) imy = hiy - 4;
+                        const int sx = imx - 3 - (O->mvpx < 0), sy = imy - 3 - (O->mvpy < 0);
+                        const uint8_t *R = org_y(&g, (uint8_t *)planesO);
+                        uint32_t bc = 0xfffffffu; int bx = 0, by = 0;
+                        for (int y = 0; y < 8; ++y)
+                            for (int x = 0; x < 8; ++x) {
+                                uint32_t cc = ks265o_sad(T, R + (long)(y0 + sy + y) * st + x0 + sx + x, s, st, s, s)
+                                              + (uint32_t)mv_cost(4 * (sx + x), 4 * (sy + y), O->mvpx, O->mvpy, lam);
+                                if (cc < bc) { bc = cc; bx = 4 * (sx + x); by = 4 * (sy + y); }
+                            }
+                        static const int rx[8] = {-1, 0, 1, -1, 1, -1, 0, 1}, ry[8] = {-1, -1, -1, 0, 0, 1, 1, 1};
+                        for (int step = 2; step >= 1; --step) {                       /* bc carries on: SAD + rate of the integer winner */
+                            int cx0 = bx, cy0 = by;
+                            for (int k = 0; k < 8; ++k) {
+                                int qx = cx0 + rx[k] * step, qy = cy0 + ry[k] * step;
+                                const uint8_t *pl = org_y(&g, (uint8_t *)planesO + (long)((qy & 3) * 4 + (qx & 3)) * g.bytes_y);
+                                uint32_t cc = ks265o_sad(T, pl + (long)(y0 + (qy >> 2)) * st + x0 + (qx >> 2), s, st, s, s) + (uint32_t)mv_cost(qx, qy, O->mvpx, O->mvpy, lam);
+                                if (cc < bc) { bc = cc; bx = qx; by = qy; }
+                            }
+                        }
+                        const uint8_t *po = org_y(&g, (uint8_t *)planesO + (long)((by & 3) * 4 + (bx & 3)) * g.bytes_y) + (long)(y0 + (by >> 2)) * st + x0 + (bx >> 2);
+                        for (int y = 0; y < s; ++y)
+                            for (int x = 0; x < s; ++x) avg[y * s + x] = (uint8_t)((kp[y * s + x] + po[(long)y * st + x] + 1) >> 1);
+                        uint32_t c2 = ks265o_had(S + (long)y0 * st + x0, avg, st, s, s, s) + (uint32_t)mv_cost(K->mvx, K->mvy, K->mvpx, K->mvpy, lam)
+                                      + (uint32_t)mv_cost(bx, by, O->mvpx, O->mvpy, lam);
+                        if (c2 < o->cost) {
+                            o->cost = c2; o->inter_dir = 3;
+                            if (keep1) { o->mvx = (int16_t)bx; o->mvy = (int16_t)by; } else { o->mv1x = (int16_t)bx; o->mv1y = (int16_t)by; }
+                        }
                     }
         }
 }

@@ -436,6 +436,38 @@ def gen_bipred(p: RefProbe):
     return [dict(c, exp=d.out, ret=np.uint32(call.ret & 0xFFFFFFFF)) for c, call, d in pend]
 
 
+def gen_bifull(p: RefProbe):
+    """interMeBiFull_c enc@0x4896d0 / interMeBiHadFull_c enc@0x4897e0: the 8 x 8 integer window of the joint bi-prediction refinement.  Both go
+    through g_sad_Function / g_had_Function, which the encoder fills at start-up: the first call of the job is the reference's own
+    initEncGlobeVar enc@0x47a740 (its argument is not read)."""
+    p.call(0x47A740, 0)
+    pend = []
+    for had in (0, 1):
+        for (w, h) in ((8, 8), (16, 16), (16, 8), (8, 16), (32, 32), (32, 16), (64, 64), (64, 32), (16, 32), (4, 8)):
+            if had and w == 4:
+                continue
+            for k in range(3):
+                so, sr = (64, w + 7 + int(rng.integers(0, 9))) if k else (w, w + 7)
+                if w >= 32:     # the SIMD kernels behind g_sad_Function[3..4] round both strides down to a multiple of the width (sad_32xn_AVX2 enc@0x4cdb70:
+                    so, sr = 64, 128 + 64 * int(rng.integers(0, 2))   # sar 5 / shl 5) and read the target with aligned loads: picture-like strides only
+                ref = u8((h + 7, sr))
+                org = u8((h, so))
+                if k == 1:      # the target is a noisy copy of one window position: a clear minimum away from (0, 0)
+                    yy, xx = int(rng.integers(0, 8)), int(rng.integers(0, 8))
+                    org[:, :w] = np.clip(ref[yy:yy + h, xx:xx + w].astype(int) + rng.integers(-3, 4, (h, w)), 0, 255)
+                if k == 2:      # flat content: every position ties on distortion, the vector cost and the scan order decide
+                    ref[:] = 77
+                    org[:] = 80
+                mvc = rng.integers(0, 40 if k else 400, 16).astype(np.uint16)
+                if k == 2 and w == 16:
+                    mvc[:] = 5  # complete tie: first position in scan order
+                B = Buf(np.zeros(1, np.int32))
+                pend.append((dict(had=had, w=w, h=h, so=so, sr=sr, org=org, ref=ref, mvcost=mvc),
+                             p.call(0x4897E0 if had else 0x4896D0, B, Buf(org), Buf(ref), so, sr, Buf(mvc), h, int(np.log2(w))), B))
+    p.run()
+    return [dict(c, exp_cost=np.uint32(call.ret & 0xFFFFFFFF), exp_best=b.out) for c, call, b in pend]
+
+
 INTRA_FUNCS = {  # name: (address, modes)  -- nm -C appencoder: h265_codec::IntraPred*_c(uchar*, int, uchar*, int, int, bool)
     "planar": (0x425AF0, [0]), "dc": (0x425D80, [1]), "chroma_dc": (0x425C60, [1]), "hor_plus_2": (0x425F60, [2]),
     "hor_plus_3_9": (0x4260E0, range(3, 10)), "hor0_10": (0x426300, [10]), "hor_minus_11_17": (0x4264C0, range(11, 18)),
@@ -541,7 +573,7 @@ FAMILIES = {
     "sad": gen_sad, "sad4": gen_sad4, "sad3": gen_sad3, "sad4blk": gen_sad4blk, "sse": gen_sse, "had": gen_had,
     "fwd_transform": gen_fwd, "inv_transform": gen_inv, "quant": gen_quant, "dequant": gen_dequant,
     "residual": gen_residual, "deblock_luma": gen_deblock_luma, "deblock_chroma": gen_deblock_chroma,
-    "interp": gen_interp, "sao_apply": gen_sao, "sao_stats": gen_sao_stats, "bipred": gen_bipred, "intra": gen_intra, "lookahead": gen_lookahead, "sbh": gen_sbh,
+    "interp": gen_interp, "sao_apply": gen_sao, "sao_stats": gen_sao_stats, "bipred": gen_bipred, "bifull": gen_bifull, "intra": gen_intra, "lookahead": gen_lookahead, "sbh": gen_sbh,
 }
 
 if __name__ == "__main__":

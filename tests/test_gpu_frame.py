@@ -221,21 +221,24 @@ def test_full_size_properties_2160p(ks):
     assert (outs[0] == outs[1]).all()          # run-to-run deterministic
 
 
-@pytest.mark.parametrize("W,H,seed,me", [(416, 240, 5, 1), (200, 136, 6, 0), (1280, 720, 7, 2)])
-def test_b_pictures_match_oracle(ks, W, H, seed, me):
+@pytest.mark.parametrize("W,H,seed,me,refine", [(416, 240, 5, 1, 0), (200, 136, 6, 0, 0), (1280, 720, 7, 2, 0),
+                                                (416, 240, 5, 1, 1), (200, 136, 6, 0, 1), (72, 56, 8, 1, 1), (1280, 720, 7, 2, 1)])
+def test_b_pictures_match_oracle(ks, W, H, seed, me, refine):
     """B pictures (two lists, bi-prediction with the exact 14-bit average): stage by stage and through ks265_encode_picture_b,
-    coding order I0 P4 B1 B2 B3 like -bframes 3."""
+    coding order I0 P4 B1 B2 B3 like -bframes 3.  refine = 1: with the joint refinement of the pair (cfg.bi_refine: motionSearchBI enc@0x484910,
+    interMeBiFull enc@0x4896d0) - the PU records after ks265_bi_decide must equal the oracle's, refined vectors included."""
     from ks265codec_amd.lib import CU8, PU, PU_B, KsFrame
     from ks265codec_amd.synth import lambda_q4, make_clip
     from oracle_lib import OraclePipeline
 
     clip = make_clip(W, H, 5, seed=seed, abc=(17, 23, 9))
-    o = OraclePipeline(W, H, 27, lambda_q4(27), me_method=me)
-    f = KsFrame(ks, W, H, 27, lambda_q4(27), me_method=me, bframes=3)
+    o = OraclePipeline(W, H, 27, lambda_q4(27), me_method=me, bi_refine=refine)
+    f = KsFrame(ks, W, H, 27, lambda_q4(27), me_method=me, bframes=3, bi_refine=refine)
     g = f.geom
     org_y, org_c = g.pad_y * g.stride_y + g.pad_y, g.pad_c * g.stride_c + g.pad_c
     src = f.new_pic()
     dpb_o, dpb_g = {}, {}
+    refined = [0]
 
     def code(t, kind, r0=None, r1=None, qp=27, staged=False):
         o.set_qp(qp, lambda_q4(qp)); f.set_qp(qp, lambda_q4(qp))
@@ -260,6 +263,8 @@ def test_b_pictures_match_oracle(ks, W, H, seed, me):
             gb = ks.host(pub, PU_B)
             assert (gb == o.pub).all(), f"bi decision differs for {int((gb != o.pub).sum())} PUs"
             assert len(set(np.unique(gb["inter_dir"][gb["cost"] != 0xFFFFFFFF]))) == 3, "fixture should exercise L0, L1 and bi"
+            h0, h1 = ks.host(pu0, PU), ks.host(pu1, PU)
+            refined[0] += int(((gb["inter_dir"] == 3) & ((gb["mvx"] != h0["mvx"]) | (gb["mvy"] != h0["mvy"]) | (gb["mv1x"] != h1["mvx"]) | (gb["mv1y"] != h1["mvy"]))).sum())
             f.cu_decide_b(pub, cu8)
             f.reconstruct_b(src, dpb_g[r0], planes0, dpb_g[r1], planes1, cu8, lvl, deb)
             assert (ks.host(cu8, CU8) == o.cu8).all()
@@ -281,6 +286,7 @@ def test_b_pictures_match_oracle(ks, W, H, seed, me):
     code(2, "B", 0, 4, qp=30)
     code(3, "B", 0, 4, qp=30, staged=True)
     f.close()
+    assert (refined[0] > 0) == bool(refine), f"{refined[0]} bi-predictive PUs carry a refined vector"
 
 
 @pytest.mark.parametrize("W,H,qp", [(416, 240, 27), (200, 136, 37), (1920, 1080, 30)])

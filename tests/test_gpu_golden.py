@@ -72,7 +72,23 @@ def test_had(ks):
         assert got[i] == c["exp"], (c["h"], c["w"])
 
 
-def test_sad4blk(ks):
+def test_bi_full_window(ks):
+    """interMeBiFull_c enc@0x4896d0 / interMeBiHadFull_c enc@0x4897e0 against the reference's own outputs (tests/golden/bifull.npz), ties included"""
+    from ks265codec_amd.lib import BLK
+    cases = load_cases("bifull")
+    A, B, oa, ob = _planes(ks, cases, "org", "ref")
+    groups = {}
+    for i, c in enumerate(cases):
+        groups.setdefault((int(c["had"]), int(c["so"]), int(c["sr"])), []).append(i)
+    for (had, so, sr), idxs in groups.items():
+        blks = np.zeros(len(idxs), BLK)
+        for j, i in enumerate(idxs):
+            blks[j] = (oa[i], ob[i], cases[i]["w"], cases[i]["h"])
+        got = ks.bi_full(had, A, so, B, sr, blks, np.stack([cases[i]["mvcost"] for i in idxs]))
+        for j, i in enumerate(idxs):
+            c = cases[i]
+            assert got[j, 0] == c["exp_cost"] and got[j, 1] == np.uint32(c["exp_best"][0]), (had, int(c["w"]), int(c["h"]), got[j], int(c["exp_cost"]), int(c["exp_best"][0]))
+
     cases = load_cases("sad4blk")
     got = _run_dist(ks, ks.sad4blk_8x8, cases, lambda c: (16, 16))
     for i, c in enumerate(cases):
