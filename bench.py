@@ -498,12 +498,15 @@ def encoded_leg(args, torch, dist, rank, world, dev_index, backend, sync_all):
     yuv.iWidth, yuv.iHeight = W, H
     yuv.iStride[0], yuv.iStride[1], yuv.iStride[2] = W, W // 2, W // 2
     pic.yuv = C.pointer(yuv)
-    state = {"t": 0, "bytes": 0, "nals": 0, "keep": None}
+    state = {"t": 0, "bytes": 0, "nals": 0, "pics": 0, "keep": None}
+    lib.ks265_enc_lanes.restype = C.c_int
+    lanes = lib.ks265_enc_lanes(h)
 
     def collect():
         state["nals"] += nn.value
         for i in range(nn.value):
             state["bytes"] += nal[i].iSize
+            state["pics"] += nal[i].naltype < 32                 # VCL NAL units = coded pictures (one slice each)
             if state["keep"] is not None:
                 state["keep"].append(C.string_at(nal[i].pPayload, nal[i].iSize))
 
@@ -517,6 +520,11 @@ def encoded_leg(args, torch, dist, rank, world, dev_index, backend, sync_all):
             rc = lib.QY265EncoderEncodeFrame(h, C.byref(nal), C.byref(nn), C.byref(pic), C.byref(outp), 0)
             assert rc == 0, hex(rc & 0xFFFFFFFF)
             collect()
+
+    def feed_until(npics):
+        """keep feeding until `npics` coded pictures have come OUT of the encoder (GOP lanes: input runs ahead of the output in bursts, the output side is the clock)"""
+        while state["pics"] < npics:
+            feed(1)
 
     def flush():
         while lib.QY265EncoderDelayedFrames(h):
@@ -536,7 +544,6 @@ def encoded_leg(args, torch, dist, rank, world, dev_index, backend, sync_all):
         lib.QY265EncoderClose(h)
         h = open_encoder()
         state.update(bytes=0, nals=0, keep=[])
-    b0 = state["bytes"]
     if strong:
         sync_all()
         t0 = time.perf_counter()
@@ -569,29 +576,51 @@ def encoded_leg(args, torch, dist, rank, world, dev_index, backend, sync_all):
         # K pictures (no key picture among them when K < iper).  Timed window B (only when A holds no key picture): exactly one whole GOP of -iper
         # pictures = iper - 1 P/B pictures + ONE key picture.  `value` is the whole-GOP rate (the key picture's share included); A is reported beside it.
         iper = args.iper if args.iper > 0 else 1 << 30
-        fill = args.warmup + 132
-        if iper < 1 << 20:
-            fill = -(-fill // iper) * iper + 1                # first picture of window A = the one right after a key picture
-        feed(fill)
-        sync_all()
-        b0 = state["bytes"]
-        t0 = time.perf_counter()
-        feed(args.steps)
-        sync_all()                                            # barrier + device synchronize on both sides (all ranks)
-        dt_a = time.perf_counter() - t0
-        bytes_a = state["bytes"] - b0
-        dt, npic = dt_a, args.steps
-        win = {"A": {"pictures": args.steps, "seconds": round(dt_a, 5), "key_pictures": (fill + args.steps - 1) // iper - (fill - 1) // iper}}
-        if win["A"]["key_pictures"] == 0 and iper < 1 << 20:
-            pos = fill + args.steps
-            feed(-pos % iper + 1 if pos % iper != 1 else 0)   # untimed: up to the picture right after the next key picture
+        if lanes > 1:
+            # GOP lanes: `lanes` closed GOPs are coded at once and handed out in GOP order, so pictures leave the encoder in bursts (a GOP that was coded
+            # while its predecessor was being handed out comes at once) and the input side runs ahead of the output by up to a GOP per lane.  The clock is
+            # therefore the OUTPUT side, over whole rounds of `lanes` GOPs, which begin and end at the same phase of that pattern.  Untimed: the warm-up and
+            # everything until 2 rounds are out (every lane has finished two GOPs, all buffers are full).  Window A = the next --steps pictures out (inside a
+            # GOP: reported, not the value).  Window B = the next whole round of lanes x iper pictures out, `lanes` key pictures among them = `value`.
+            rnd = lanes * iper
+            feed(args.warmup)
+            feed_until(-(-(args.warmup + 2 * rnd) // rnd) * rnd)
             sync_all()
-            t0 = time.perf_counter()
-            feed(iper)
+            p0, t0 = state["pics"], time.perf_counter()
+            feed_until(p0 + args.steps)
+            sync_all()
+            dt_a = time.perf_counter() - t0
+            win = {"A": {"pictures": state["pics"] - p0, "seconds": round(dt_a, 5), "clock": "pictures out of the encoder"}}
+            feed_until(-(-state["pics"] // rnd) * rnd)            # untimed: to the end of the current round
+            sync_all()
+            p0, t0 = state["pics"], time.perf_counter()
+            feed_until(p0 + rnd)
             sync_all()
             dt = time.perf_counter() - t0
-            npic = iper
-            win["B"] = {"pictures": iper, "seconds": round(dt, 5), "key_pictures": 1}
+            npic = state["pics"] - p0
+            win["B"] = {"pictures": npic, "seconds": round(dt, 5), "key_pictures": lanes, "clock": "pictures out of the encoder", "gop_lanes": lanes}
+        else:
+            fill = args.warmup + 132
+            if iper < 1 << 20:
+                fill = -(-fill // iper) * iper + 1                # first picture of window A = the one right after a key picture
+            feed(fill)
+            sync_all()
+            t0 = time.perf_counter()
+            feed(args.steps)
+            sync_all()                                            # barrier + device synchronize on both sides (all ranks)
+            dt_a = time.perf_counter() - t0
+            dt, npic = dt_a, args.steps
+            win = {"A": {"pictures": args.steps, "seconds": round(dt_a, 5), "key_pictures": (fill + args.steps - 1) // iper - (fill - 1) // iper}}
+            if win["A"]["key_pictures"] == 0 and iper < 1 << 20:
+                pos = fill + args.steps
+                feed(-pos % iper + 1 if pos % iper != 1 else 0)   # untimed: up to the picture right after the next key picture
+                sync_all()
+                t0 = time.perf_counter()
+                feed(iper)
+                sync_all()
+                dt = time.perf_counter() - t0
+                npic = iper
+                win["B"] = {"pictures": iper, "seconds": round(dt, 5), "key_pictures": 1}
         flush()
     st = Stats()
     lib.ks265_enc_get_stats(h, C.byref(st))
@@ -604,7 +633,7 @@ def encoded_leg(args, torch, dist, rank, world, dev_index, backend, sync_all):
     if strong:
         import hashlib
         return {"fps": job["frames"] / dt, "dt": dt, "host_threads": threads, "host_cores": cores, "bytes_per_picture": job["bytes"] / job["frames"], "job": job,
-                "md5": hashlib.md5(blob).hexdigest() if rank == 0 else None,
+                "md5": hashlib.md5(blob).hexdigest() if rank == 0 else None, "gop_lanes": lanes,
                 "psnr_y": 99.0 if mse == 0 else 10.0 * np.log10(255.0 ** 2 / mse), "slice_write_ms_per_picture": st.host_write_ms / max(1, st.frames), "preset": preset.decode(),
                 "gop": f"hierarchical-B {args.hier_b}" if args.hier_b else (f"P + {gop_b} B" if gop_b else "IPPP")}
     if dist is not None:
@@ -612,7 +641,7 @@ def encoded_leg(args, torch, dist, rank, world, dev_index, backend, sync_all):
         dist.all_reduce(ta, op=dist.ReduceOp.MAX)
         win["A"]["seconds"] = round(float(ta.item()), 5)
     win["A"]["fps_all_ranks"] = round(world * win["A"]["pictures"] / win["A"]["seconds"], 2)
-    return {"fps": world * npic / dt, "dt": dt * args.steps / npic, "windows": win, "host_threads": threads, "host_cores": cores, "bytes_per_picture": st.bytes / max(1, st.frames),
+    return {"fps": world * npic / dt, "dt": dt * args.steps / npic, "windows": win, "gop_lanes": lanes, "host_threads": threads, "host_cores": cores, "bytes_per_picture": st.bytes / max(1, st.frames),
             "psnr_y": 99.0 if mse == 0 else 10.0 * np.log10(255.0 ** 2 / mse), "slice_write_ms_per_picture": st.host_write_ms / max(1, st.frames), "preset": preset.decode(),
             "caller_ms_per_picture": {"input_copy": round(st.in_copy_ms / max(1, st.frames), 3), "enqueue": round(st.submit_ms / max(1, st.frames), 3), "output": round(st.output_ms / max(1, st.frames), 3),
                                       "latency_enqueue_to_records_on_host": round(st.lat_gpu_ms / max(1, st.frames), 2), "latency_enqueue_to_writer_pickup": round(st.lat_queue_ms / max(1, st.frames), 2),
@@ -636,9 +665,14 @@ def encoded_line(args, enc, world, hot, cpu):
                                f"pixel path on the MI355X (-preset {enc['preset']}: -me {args.me}, subme 1, deblock + SAO) -> D2H of CU map / levels / SAO -> CABAC slice data on "
                                f"{enc['host_threads']} host threads -> Annex-B NAL units out; -rc 0 -qp {args.qp} (I=Q, P=Q+1, B=Q+2..) -iper {args.iper}, {enc['gop']}, "
                                f"-ref {max(1, args.refs)}; the stream decodes with the reference's appdecoder to the encoder's reconstruction (tests/test_stream.py)",
-                   "timed": None if strong else ("steady state of the asynchronous encoder (pipeline full before and after, back-pressure: one picture in = one picture out), barrier + "
+                   "timed": None if strong else (("steady state of the asynchronous encoder with %d GOP lanes (closed GOPs coded concurrently on the one GPU, output in stream order; "
+                             "pictures leave in bursts, so the clock is the OUTPUT side): untimed until two whole rounds of lanes x iper pictures are out, barrier + device synchronize on "
+                             "both sides of each window.  A = the next --steps pictures out (inside a GOP); B = the next whole round of lanes x iper pictures out, one key picture per "
+                             "lane among them.  value = pictures / seconds of B; ms_per_step = 1000 / value per GPU" % enc["gop_lanes"]) if enc.get("gop_lanes", 1) > 1 else
+                             "steady state of the asynchronous encoder (pipeline full before and after, back-pressure: one picture in = one picture out), barrier + "
                              "device synchronize on both sides of each window.  A = exactly --steps pictures; B = one whole GOP of -iper pictures incl. its key picture "
-                             "(run when A holds no key picture).  value = pictures / seconds of B (of A when A already holds its key pictures); ms_per_step = 1000 / value per GPU") ,
+                             "(run when A holds no key picture).  value = pictures / seconds of B (of A when A already holds its key pictures); ms_per_step = 1000 / value per GPU"),
+                   "gop_lanes": enc.get("gop_lanes", 1),
                    "windows": enc.get("windows"),
                    "pictures_per_step": 1, "host_threads_per_gpu": enc["host_threads"], "host_cores": enc["host_cores"],
                    "bytes_per_picture": int(enc["bytes_per_picture"]), "kbps_at_50fps": round(enc["bytes_per_picture"] * 8 * 50 / 1000.0, 1),

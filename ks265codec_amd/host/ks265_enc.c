@@ -130,7 +130,7 @@ typedef struct Job {
     double t_write_ms, t_submit, t_event, t_taken, t_done;      /* wall-clock marks: enqueued, records on the host (seen by a writer), writer started */
 } Job;
 
-typedef struct Input { int used, disp; long long pts; uint8_t *i420; } Input;          /* pinned */
+typedef struct Input { int used, disp, key; long long pts; uint8_t *i420; } Input;     /* pinned; key: this picture starts a closed GOP whatever the period says (GOP lanes) */
 
 typedef struct Enc {
     QY265EncConfig cfg;
@@ -346,7 +346,10 @@ static int submit(Enc *e, Input *in, int kind, int poc, int qp, const int *l0, i
 {
     /* wait for a free job slot (the ring is full only if the consumer did not drain it: block on the oldest) */
     pthread_mutex_lock(&e->mu);
-    while (e->njobs == e->ring && !e->quit) pthread_cond_wait(&e->cv_done, &e->mu);
+    while (e->njobs == e->ring && !e->quit) {
+        pthread_cond_broadcast(&e->cv_sched_done);                      /* a caller waiting for this thread in lane_put goes on and collects output instead */
+        pthread_cond_wait(&e->cv_done, &e->mu);                         /* take_output signals when it has freed ring slots */
+    }
     if (e->quit) { pthread_mutex_unlock(&e->mu); return QY_FAIL; }       /* drained by take_output() of the calling thread itself: never full here */
     Job *j = &e->jobs[e->job_tail];
     pthread_mutex_unlock(&e->mu);
@@ -478,9 +481,9 @@ static int schedule(Enc *e, int flush, int have /* pictures [0, have) have arriv
         const int d = e->coded_upto;                                   /* last anchor / last coded display index; -1 before the first picture */
         if (d + 1 >= have) return QY_OK;
         const int nxt = d + 1;
-        const int key = d < 0 || e->force_key || (e->iper > 0 && nxt - e->gop_start >= e->iper);
+        Input *in = input_at(e, nxt);
+        const int key = d < 0 || e->force_key || (e->iper > 0 && nxt - e->gop_start >= e->iper) || (in && in->key);
         if (key) {
-            Input *in = input_at(e, nxt);
             e->gop_start = nxt; e->force_key = 0;
             for (int i = 0; i < e->ndpb + 2 * e->key_overlap; ++i) e->dpb_poc[i] = -1000000;
             int r = submit(e, in, 'I', 0, clampqp(e, e->base_qp + e->rc_qp_delta), NULL, 0, NULL, 0, NULL, 0, 1, 1);
@@ -543,12 +546,12 @@ static void *scheduler(void *arg)
 
 /* move finished pictures (in coding order) to the output array; wait while more than `max_in_flight` pictures are queued
  * (0 = drain everything, MAX_JOBS = never wait) */
-static int take_output(Enc *e, int max_in_flight, QY265Nal **pNals, int *n, QY265Picture *out)
+static int take_output(Enc *e, int max_in_flight, int max_pics, QY265Nal **pNals, int *n, QY265Picture *out, int *pics)
 {
-    int cnt = 0, err = QY_OK;
+    int cnt = 0, err = QY_OK, taken = 0;
     e->outpos = 0;
     pthread_mutex_lock(&e->mu);
-    while (e->njobs) {
+    while (e->njobs && taken < max_pics) {
         Job *j = &e->jobs[e->job_head];
         if (!j->done) { if (e->njobs <= max_in_flight) break; pthread_cond_wait(&e->cv_done, &e->mu); continue; }
         if (j->error) err = hip_rc(j->error);
@@ -595,17 +598,18 @@ static int take_output(Enc *e, int max_in_flight, QY265Nal **pNals, int *n, QY26
         }
         for (int i = 0; i < MAX_INPUT; ++i) if (e->in[i].used == 2 && e->in[i].disp == j->disp) e->in[i].used = 0;
         j->used = 0;
-        e->job_head = (e->job_head + 1) % e->ring; --e->njobs;
+        e->job_head = (e->job_head + 1) % e->ring; --e->njobs; ++taken;
         if (cnt >= (int)(sizeof e->nals / sizeof e->nals[0]) - 4) break;
     }
+    if (taken) pthread_cond_broadcast(&e->cv_done);                    /* the scheduler thread may be waiting for ring space */
     pthread_mutex_unlock(&e->mu);
     *pNals = e->nals; *n = cnt;
+    if (pics) *pics = taken;
     return err;
 }
 
-void QY265EncoderClose(void *h)
+static void lane_close(Enc *e, int report)
 {
-    Enc *e = (Enc *)h;
     if (!e) return;
     if (e->nth || e->disp_on || e->sched_on) {
         pthread_mutex_lock(&e->mu); e->quit = 1; pthread_cond_broadcast(&e->cv_work); pthread_cond_broadcast(&e->cv_disp); pthread_cond_broadcast(&e->cv_sched); pthread_cond_broadcast(&e->cv_done); pthread_mutex_unlock(&e->mu);
@@ -617,7 +621,7 @@ void QY265EncoderClose(void *h)
         if (e->ctx_in) ks265_synchronize(e->ctx_in);
         ks265_synchronize(e->ctx);
         if (e->ctx_out) ks265_synchronize(e->ctx_out);
-        if (e->cfg.calcPsnr && e->st.frames) {
+        if (report && e->cfg.calcPsnr && e->st.frames) {
             const double np[3] = {(double)e->W * e->H, (double)e->W * e->H / 4, (double)e->W * e->H / 4};
             double ps[3];
             for (int k = 0; k < 3; ++k) ps[k] = e->st.sse[k] > 0 ? 10.0 * log10(255.0 * 255.0 * np[k] * e->st.frames / e->st.sse[k]) : 99.0;
@@ -658,7 +662,7 @@ void QY265EncoderClose(void *h)
     free(e);
 }
 
-void *QY265EncoderOpen(QY265EncConfig *cfg, int *err)
+static Enc *lane_open(QY265EncConfig *cfg, int *err)
 {
     int dummy; if (!err) err = &dummy;
     *err = QY_OK;
@@ -693,7 +697,7 @@ void *QY265EncoderOpen(QY265EncConfig *cfg, int *err)
      * each on its own closed GOPs */
     const char *dev_env = getenv("KS265_DEVICE");
     int r = ks265_create(&e->ctx, dev_env ? atoi(dev_env) : 0);
-    if (r) { *err = hip_rc(r); QY265EncoderClose(e); return NULL; }       /* KS265_NO_DEVICE -> QY_FAIL: there is no CPU fallback */
+    if (r) { *err = hip_rc(r); lane_close(e, 0); return NULL; }       /* KS265_NO_DEVICE -> QY_FAIL: there is no CPU fallback */
     memset(&e->fcfg, 0, sizeof e->fcfg);
     e->fcfg.width = e->W; e->fcfg.height = e->H; e->fcfg.qp = e->base_qp; e->fcfg.lambda_q4 = kLambdaQ4[e->base_qp];
     e->fcfg.me_range = cfg->searchrange < 1 ? 64 : cfg->searchrange > 64 ? 64 : cfg->searchrange;
@@ -755,7 +759,7 @@ void *QY265EncoderOpen(QY265EncConfig *cfg, int *err)
         if (!j->nal) r = KS265_OUTOFMEMORY;
     }
     for (int i = 0; i < e->ring + 32 && !r; ++i) r = ks265_host_malloc(e->ctx, (void **)&e->in[i].i420, fsz);
-    if (r) { *err = hip_rc(r); QY265EncoderClose(e); return NULL; }
+    if (r) { *err = hip_rc(r); lane_close(e, 0); return NULL; }
     memset(&e->scfg, 0, sizeof e->scfg);
     e->scfg.width = e->W; e->scfg.height = e->H; e->scfg.sao = e->use_sao; e->scfg.deblock = e->use_df;
     e->scfg.sdh = e->fcfg.sdh;
@@ -769,39 +773,35 @@ void *QY265EncoderOpen(QY265EncConfig *cfg, int *err)
     }
     e->outcap = npx + 65536;
     e->outbuf = (uint8_t *)malloc(e->outcap);
-    if (!e->hdr || e->hdr_len < 0 || !e->outbuf) { *err = QY_FAIL; QY265EncoderClose(e); return NULL; }
-    for (int i = 0; i < e->ring; ++i) { e->jobs[i].wpp = malloc(ks265_wpp_bytes(&e->scfg)); if (!e->jobs[i].wpp) { *err = QY_OUTOFMEMORY; QY265EncoderClose(e); return NULL; } }   /* virtual until used */
+    if (!e->hdr || e->hdr_len < 0 || !e->outbuf) { *err = QY_FAIL; lane_close(e, 0); return NULL; }
+    for (int i = 0; i < e->ring; ++i) { e->jobs[i].wpp = malloc(ks265_wpp_bytes(&e->scfg)); if (!e->jobs[i].wpp) { *err = QY_OUTOFMEMORY; lane_close(e, 0); return NULL; } }   /* virtual until used */
     for (int i = 0; i < e->nthreads; ++i) { e->warg[i].e = e; e->warg[i].idx = i; if (pthread_create(&e->th[i], NULL, worker, &e->warg[i])) break; ++e->nth; }
     if (e->nth && !pthread_create(&e->disp, NULL, dispatcher, e)) e->disp_on = 1;
     if (e->disp_on && !pthread_create(&e->sched, NULL, scheduler, e)) e->sched_on = 1;
-    if (!e->nth || !e->disp_on || !e->sched_on) { *err = QY_FAIL; QY265EncoderClose(e); return NULL; }
+    if (!e->nth || !e->disp_on || !e->sched_on) { *err = QY_FAIL; lane_close(e, 0); return NULL; }
     logf_(0, e->log_level, "ks265enc: %dx%d %.2f fps, qp %d, -me %d (hex below %d), subme %d, refs %d, %s, sao %d, key period %d, %d slice writer threads, %s\n", e->W, e->H,
           cfg->frameRate, e->base_qp, e->me_method, e->hex_thr, e->subme, e->refs, e->hier ? "hierarchical-B GOP 8" : e->gop_b ? "P + non-reference B" : "IPPP", e->use_sao, e->iper,
           e->nth, ks265_version());
     return e;
 }
 
-void QY265EncoderReconfig(void *h, QY265EncConfig *cfg)
+static void lane_reconfig(Enc *e, QY265EncConfig *cfg)
 {
-    Enc *e = (Enc *)h;
     if (!e || !cfg) return;
     e->cfg.qp = cfg->qp; e->cfg.crf = cfg->crf; e->cfg.bitrateInkbps = cfg->bitrateInkbps; e->cfg.iIntraPeriod = cfg->iIntraPeriod;
     e->base_qp = cfg->rc == 3 ? cfg->crf : cfg->qp; e->iper = cfg->iIntraPeriod;
     if (e->base_qp < 0) e->base_qp = 0;
     if (e->base_qp > 51) e->base_qp = 51;
 }
-int QY265EncoderEncodeHeaders(void *h, QY265Nal **pNals, int *n)
+static int lane_headers(Enc *e, QY265Nal **pNals, int *n)
 {
-    Enc *e = (Enc *)h;
     if (!e || !pNals || !n) return QY_POINTER;
     e->nals[0].naltype = KS265_NAL_VPS; e->nals[0].tid = 0; e->nals[0].iSize = (int)e->hdr_len; e->nals[0].pts = 0; e->nals[0].pPayload = e->hdr;
     *pNals = e->nals; *n = 1;                                           /* one entry holding VPS + SPS + PPS back to back */
     return QY_OK;
 }
-void QY265EncoderKeyFrameRequest(void *h) { Enc *e = (Enc *)h; if (e) e->force_key = 1; }
-int QY265EncoderDelayedFrames(void *h)
+static int lane_delayed(Enc *e)
 {
-    Enc *e = (Enc *)h;
     if (!e) return 0;
     int n = 0;
     for (int i = 0; i < MAX_INPUT; ++i) if (e->in[i].used == 1) ++n;
@@ -809,57 +809,49 @@ int QY265EncoderDelayedFrames(void *h)
     return n;
 }
 
-int QY265EncoderEncodeFrame(void *h, QY265Nal **pNals, int *iNalCount, QY265Picture *in, QY265Picture *out, int bForceLogo)
+/* one picture into the lane: copy to a pinned slot, hand it to the scheduler thread.  key: it starts a closed GOP regardless of the period */
+static int lane_put(Enc *e, QY265Picture *in, int key)
 {
-    (void)bForceLogo;
-    Enc *e = (Enc *)h;
-    if (!e || !pNals || !iNalCount) return QY_POINTER;
-    *pNals = e->nals; *iNalCount = 0;
-    int r = QY_OK;
-    if (in) {
-        if (!in->yuv || !in->yuv->pData[0] || !in->yuv->pData[1] || !in->yuv->pData[2]) return QY_POINTER;
-        if (in->yuv->iWidth != e->W || in->yuv->iHeight != e->H) return QY_NOTSUPPORTED;
-        Input *slot = NULL;
-        const double tc0 = now_ms();
-        pthread_mutex_lock(&e->mu);
-        /* back-pressure on the input side: at most 16 pictures wait for the scheduler thread (it may itself be waiting for ring space, which only this
-         * thread's take_output frees - then go on and collect) */
-        while (!e->quit && e->next_disp - (e->coded_upto + 1) > 16 && e->njobs <= e->ring - 12) pthread_cond_wait(&e->cv_sched_done, &e->mu);
-        for (int i = 0; i < e->ring + 32 && !slot; ++i) if (!e->in[i].used) slot = &e->in[i];
-        if (slot) slot->used = 3;                                      /* being filled */
-        pthread_mutex_unlock(&e->mu);
-        if (!slot) return QY_FAIL;                                     /* cannot happen: there are more input slots than pictures in flight + one mini-GOP */
-        uint8_t *u = slot->i420 + (size_t)e->W * e->H, *v = u + (size_t)e->W * e->H / 4;
-        if (in->yuv->iStride[0] == e->W && in->yuv->iStride[1] == e->W / 2 && in->yuv->iStride[2] == e->W / 2) {    /* packed planes: three block copies */
-            memcpy(slot->i420, in->yuv->pData[0], (size_t)e->W * e->H);
-            memcpy(u, in->yuv->pData[1], (size_t)e->W * e->H / 4);
-            memcpy(v, in->yuv->pData[2], (size_t)e->W * e->H / 4);
-        } else {
+    if (!in->yuv || !in->yuv->pData[0] || !in->yuv->pData[1] || !in->yuv->pData[2]) return QY_POINTER;
+    if (in->yuv->iWidth != e->W || in->yuv->iHeight != e->H) return QY_NOTSUPPORTED;
+    Input *slot = NULL;
+    const double tc0 = now_ms();
+    pthread_mutex_lock(&e->mu);
+    /* back-pressure on the input side: at most 16 pictures wait for the scheduler thread (it may itself be waiting for ring space, which only the
+     * caller's take_output frees - then go on and collect) */
+    while (!e->quit && e->next_disp - (e->coded_upto + 1) > 16 && e->njobs <= e->ring - 12) pthread_cond_wait(&e->cv_sched_done, &e->mu);
+    for (int i = 0; i < e->ring + 32 && !slot; ++i) if (!e->in[i].used) slot = &e->in[i];
+    if (slot) slot->used = 3;                                          /* being filled */
+    pthread_mutex_unlock(&e->mu);
+    if (!slot) return QY_FAIL;                                         /* one lane: cannot happen (more input slots than pictures in flight + one mini-GOP); lanes: the caller checked lane_has_slot */
+    uint8_t *u = slot->i420 + (size_t)e->W * e->H, *v = u + (size_t)e->W * e->H / 4;
+    if (in->yuv->iStride[0] == e->W && in->yuv->iStride[1] == e->W / 2 && in->yuv->iStride[2] == e->W / 2) {    /* packed planes: three block copies */
+        memcpy(slot->i420, in->yuv->pData[0], (size_t)e->W * e->H);
+        memcpy(u, in->yuv->pData[1], (size_t)e->W * e->H / 4);
+        memcpy(v, in->yuv->pData[2], (size_t)e->W * e->H / 4);
+    } else {
         for (int y = 0; y < e->H; ++y) memcpy(slot->i420 + (size_t)y * e->W, in->yuv->pData[0] + (size_t)y * in->yuv->iStride[0], (size_t)e->W);
         for (int y = 0; y < e->H / 2; ++y) {
             memcpy(u + (size_t)y * (e->W / 2), in->yuv->pData[1] + (size_t)y * in->yuv->iStride[1], (size_t)e->W / 2);
             memcpy(v + (size_t)y * (e->W / 2), in->yuv->pData[2] + (size_t)y * in->yuv->iStride[2], (size_t)e->W / 2);
         }
-        }
-        pthread_mutex_lock(&e->mu);
-        slot->disp = e->next_disp++; slot->pts = in->pts; slot->used = 1;
-        pthread_cond_signal(&e->cv_sched);                             /* the scheduler thread takes it from here */
-        pthread_mutex_unlock(&e->mu);
-        e->st.in_copy_ms += now_ms() - tc0;
-        /* finished pictures (copied to the output buffer); when the ring of in-flight pictures is nearly full, wait for the oldest ones -
-         * only as many as needed, the writers keep running */
-        const double t0 = now_ms();
-        r = take_output(e, e->ring - 12, pNals, iNalCount, out);
-        e->st.output_ms += now_ms() - t0;
-        return r ? r : e->sched_err;
     }
-    /* flush: everything that has arrived is scheduled (short mini-GOPs at the end), then every picture in flight is collected */
-    const double t0 = now_ms();
+    pthread_mutex_lock(&e->mu);
+    slot->disp = e->next_disp++; slot->pts = in->pts; slot->key = key; slot->used = 1;
+    pthread_cond_signal(&e->cv_sched);                                 /* the scheduler thread takes it from here */
+    pthread_mutex_unlock(&e->mu);
+    e->st.in_copy_ms += now_ms() - tc0;
+    return QY_OK;
+}
+
+/* flush, first half: everything that has arrived gets scheduled (short mini-GOPs at the end).  Returns 1 when the scheduler is through, 0 when the ring
+ * filled up first (the scheduler then waits for the caller to collect output: hand out what is ready and come back, as the SDK's flush loop does anyway -
+ * EncodeFrame(NULL) while DelayedFrames() > 0) */
+static int lane_flush_begin(Enc *e)
+{
     pthread_mutex_lock(&e->mu);
     e->sched_flush = 1;
     pthread_cond_signal(&e->cv_sched);
-    /* wait for the scheduler - unless the ring fills up first (it then waits for THIS thread to collect output): hand out what is ready and let the
-     * caller come back, as the SDK's flush loop does anyway (EncodeFrame(NULL) while DelayedFrames() > 0) */
     int all = 0;
     for (;;) {
         all = !e->sched_flush && e->sched_idle && e->sched_seen == e->next_disp;
@@ -867,25 +859,37 @@ int QY265EncoderEncodeFrame(void *h, QY265Nal **pNals, int *iNalCount, QY265Pict
         pthread_cond_wait(&e->cv_sched_done, &e->mu);
     }
     pthread_mutex_unlock(&e->mu);
+    return all;
+}
+
+static int lane_encode_frame(Enc *e, QY265Nal **pNals, int *iNalCount, QY265Picture *in, QY265Picture *out)
+{
+    *pNals = e->nals; *iNalCount = 0;
+    int r = QY_OK;
+    if (in) {
+        r = lane_put(e, in, 0);
+        if (r) return r;
+        /* finished pictures (copied to the output buffer); when the ring of in-flight pictures is nearly full, wait for the oldest ones -
+         * only as many as needed, the writers keep running */
+        const double t0 = now_ms();
+        r = take_output(e, e->ring - 12, 1 << 30, pNals, iNalCount, out, NULL);
+        e->st.output_ms += now_ms() - t0;
+        return r ? r : e->sched_err;
+    }
+    /* flush: then every picture in flight is collected */
+    const double t0 = now_ms();
+    const int all = lane_flush_begin(e);
     if (e->sched_err) return e->sched_err;
-    r = take_output(e, all ? 0 : e->ring - 12, pNals, iNalCount, out);
+    r = take_output(e, all ? 0 : e->ring - 12, 1 << 30, pNals, iNalCount, out, NULL);
     e->st.output_ms += now_ms() - t0;
     return r;
 }
 
-int ks265_enc_get_stats(void *h, ks265_enc_stats *out)
-{
-    Enc *e = (Enc *)h;
-    if (!e || !out) return QY_POINTER;
-    *out = e->st;
-    return QY_OK;
-}
 
 /* extension: dump the encoder's reconstruction as I420, every picture at its display position (the reference CLI's -o).  Call right after
  * QY265EncoderOpen, before the first picture.  Costs one more D2H of W*H*3/2 bytes per picture: a checking aid, not part of the normal path. */
-int ks265_enc_set_recon_file(void *h, const char *path)
+static int lane_set_recon_file(Enc *e, const char *path)
 {
-    Enc *e = (Enc *)h;
     if (!e || !path) return QY_POINTER;
     if (e->next_disp != 0 || e->recon_fd >= 0) return QY_NOTSUPPORTED;
     e->key_overlap = 0;                                                /* the dump shares one device buffer: key pictures stay on the main stream */
@@ -895,4 +899,270 @@ int ks265_enc_set_recon_file(void *h, const char *path)
     if (r) return hip_rc(r);
     e->recon_fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
     return e->recon_fd >= 0 ? QY_OK : QY_FAIL;
+}
+
+/* ------------------------------------------------------------------ GOP lanes
+ * One lane (Enc) keeps one picture pipeline busy: a P picture needs its predecessor, so a single closed GOP fills about half of the MI355X (one stream
+ * of the hot path runs at half the rate of three, bench.py).  Closed GOPs are independent - the shards of SURVEY.md 8(e) - so the encoder codes several of
+ * them AT ONCE on one GPU: the handle owns L lanes, every lane a complete pipeline (streams, workspace, DPB, scheduler / dispatcher / writer threads);
+ * GOP k of the input goes to lane k mod L, each GOP's first picture marked as a key picture in band; output is handed out in GOP order (all of GOP k,
+ * then GOP k + 1 from the next lane), so the stream is byte for byte the one a single lane writes (tests/test_gpu_enc_api.py).  The reference's
+ * enFrameParallel (frames of one stream coded concurrently on CPU threads) is the switch: lanes run with enFrameParallel != 0, IPPP (-bframes 0),
+ * fixed QP (-rc 0) and a key period of at least 32 pictures - B pictures in front of a key picture reference it (the GOPs are not closed), the rate
+ * controllers carry state across GOPs.  KS265_GOP_LANES = 1..4 overrides the default of 2.  Cost: output lags the input by up to L GOPs. */
+#define MAX_LANES 4
+#define MAX_CHUNKS 64
+typedef struct Chunk { int lane, closed; long count, delivered, base; } Chunk;
+typedef struct Top {
+    int nlanes; Enc *lane[MAX_LANES];
+    int iper, key_request, cur_lane;
+    long n_in, chunk_left;
+    Chunk ch[MAX_CHUNKS]; int ch_head, ch_n;
+    QY265Nal *onals; size_t *ooff; int on, on_cap;                   /* output of the current call: NAL payloads copied out of the lanes */
+    uint8_t *obuf; size_t ocap, opos;
+    double output_ms;
+} Top;
+
+static int lane_has_slot(Enc *e)
+{
+    int ok = 0;
+    pthread_mutex_lock(&e->mu);
+    for (int i = 0; i < e->ring + 32 && !ok; ++i) ok = !e->in[i].used;
+    pthread_mutex_unlock(&e->mu);
+    return ok;
+}
+
+/* wait until the oldest picture of the lane is written (pictures are in the lane: as input or in flight) */
+static int lane_wait_head(Enc *e)
+{
+    pthread_mutex_lock(&e->mu);
+    while (!e->quit && !e->sched_err && !(e->njobs && e->jobs[e->job_head].done)) {
+        struct timespec ts; clock_gettime(CLOCK_REALTIME, &ts);
+        ts.tv_nsec += 50 * 1000000L; if (ts.tv_nsec >= 1000000000L) { ts.tv_nsec -= 1000000000L; ++ts.tv_sec; }
+        pthread_cond_timedwait(&e->cv_done, &e->mu, &ts);
+    }
+    const int r = e->quit ? QY_FAIL : e->sched_err;
+    pthread_mutex_unlock(&e->mu);
+    return r;
+}
+
+static int top_append(Top *t, const QY265Nal *nals, int n)
+{
+    for (int i = 0; i < n; ++i) {
+        if (t->on == t->on_cap) {
+            const int nc = t->on_cap ? 2 * t->on_cap : 1024;
+            QY265Nal *a = (QY265Nal *)realloc(t->onals, (size_t)nc * sizeof *a);
+            if (a) t->onals = a;
+            size_t *b = a ? (size_t *)realloc(t->ooff, (size_t)nc * sizeof *b) : NULL;
+            if (!a || !b) return QY_OUTOFMEMORY;
+            t->ooff = b; t->on_cap = nc;
+        }
+        const size_t need = (size_t)nals[i].iSize;
+        if (t->opos + need > t->ocap) {
+            const size_t nc = (t->opos + need) * 2 + 65536;
+            uint8_t *nb = (uint8_t *)realloc(t->obuf, nc);
+            if (!nb) return QY_OUTOFMEMORY;
+            t->obuf = nb; t->ocap = nc;
+        }
+        memcpy(t->obuf + t->opos, nals[i].pPayload, need);
+        t->onals[t->on] = nals[i]; t->ooff[t->on] = t->opos;
+        ++t->on; t->opos += need;
+    }
+    return QY_OK;
+}
+
+/* move finished pictures to the call's output, GOP after GOP; block = wait until at least one picture has come */
+static int top_collect(Top *t, int block, QY265Picture *out)
+{
+    while (t->ch_n) {
+        Chunk *c = &t->ch[t->ch_head];
+        if (c->delivered == c->count) {
+            if (!c->closed) break;                                      /* the GOP still receives input */
+            t->ch_head = (t->ch_head + 1) % MAX_CHUNKS; --t->ch_n;
+            continue;
+        }
+        Enc *e = t->lane[c->lane];
+        if (block) { const int r = lane_wait_head(e); if (r) return r; }
+        QY265Nal *nals; int n = 0, pics = 0;
+        const int r = take_output(e, MAX_JOBS + 1, (int)(c->count - c->delivered), &nals, &n, out, &pics);
+        if (r) return r;
+        if (!pics) { if (block) continue; break; }
+        const int ra = top_append(t, nals, n);
+        if (ra) return ra;
+        c->delivered += pics;
+        if (out) out->poc = (int)(c->base + c->delivered - 1);         /* IPPP: coding order = display order */
+        block = 0;
+    }
+    return QY_OK;
+}
+
+static int top_lanes_wanted(const QY265EncConfig *cfg)
+{
+    const char *env = getenv("KS265_GOP_LANES");
+    int n = env ? atoi(env) : 2;
+    if (n < 1) n = 1;
+    if (n > MAX_LANES) n = MAX_LANES;
+    const int ippp = cfg->bframes == 0 || (cfg->bframes < 0 && cfg->latency != QY265LATENCY_DEFAULT);
+    if (!cfg->enFrameParallel || !ippp || cfg->rc != 0 || cfg->iIntraPeriod < 32) n = 1;
+    return n;
+}
+
+void *QY265EncoderOpen(QY265EncConfig *cfg, int *err)
+{
+    int dummy; if (!err) err = &dummy;
+    *err = QY_OK;
+    if (!cfg) { *err = QY_POINTER; return NULL; }
+    Top *t = (Top *)calloc(1, sizeof *t);
+    if (!t) { *err = QY_OUTOFMEMORY; return NULL; }
+    t->nlanes = top_lanes_wanted(cfg);
+    t->iper = cfg->iIntraPeriod; t->cur_lane = -1;
+    QY265EncConfig lc = *cfg;
+    if (t->nlanes > 1) {                                                /* the writer threads are shared out: every lane sees 1 / L of the pictures */
+        long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
+        int th = cfg->threads > 0 ? cfg->threads : (int)(ncpu > 0 ? ncpu : 4);
+        if (th > 64) th = 64;
+        lc.threads = (th + t->nlanes - 1) / t->nlanes;
+        if (lc.threads < 2) lc.threads = 2;
+    }
+    for (int i = 0; i < t->nlanes; ++i) {
+        if (i) lc.logLevel = cfg->logLevel > 2 ? cfg->logLevel : 3;     /* one start-up line */
+        t->lane[i] = lane_open(&lc, err);
+        if (!t->lane[i]) {
+            if (i == 0) { free(t); return NULL; }
+            t->nlanes = i;                                              /* e.g. out of memory for another pipeline: go on with the lanes there are */
+            *err = QY_OK;
+            break;
+        }
+    }
+    if (t->nlanes > 1) logf_(0, cfg->logLevel, "ks265enc: %d GOP lanes (closed GOPs of %d pictures coded concurrently, output in GOP order)\n", t->nlanes, t->iper);
+    return t;
+}
+
+void QY265EncoderClose(void *h)
+{
+    Top *t = (Top *)h;
+    if (!t) return;
+    if (t->nlanes > 1) {                                                /* one summary line over all lanes */
+        Enc *e0 = t->lane[0];
+        ks265_enc_stats st; memset(&st, 0, sizeof st);
+        for (int i = 0; i < t->nlanes; ++i) { const ks265_enc_stats *s = &t->lane[i]->st; st.frames += s->frames; st.bytes += s->bytes; for (int k = 0; k < 3; ++k) st.sse[k] += s->sse[k]; }
+        if (e0->cfg.calcPsnr && st.frames) {
+            const double np[3] = {(double)e0->W * e0->H, (double)e0->W * e0->H / 4, (double)e0->W * e0->H / 4};
+            double ps[3];
+            for (int k = 0; k < 3; ++k) ps[k] = st.sse[k] > 0 ? 10.0 * log10(255.0 * 255.0 * np[k] * st.frames / st.sse[k]) : 99.0;
+            logf_(2, e0->log_level, "bitrate, psnr: %.4f %.4f %.4f %.4f\n", st.bytes * 8.0 * e0->cfg.frameRate / st.frames / 1000.0, ps[0], ps[1], ps[2]);
+        }
+    }
+    for (int i = 0; i < t->nlanes; ++i) lane_close(t->lane[i], t->nlanes == 1);
+    free(t->onals); free(t->ooff); free(t->obuf);
+    free(t);
+}
+
+void QY265EncoderReconfig(void *h, QY265EncConfig *cfg)
+{
+    Top *t = (Top *)h;
+    if (!t || !cfg) return;
+    for (int i = 0; i < t->nlanes; ++i) lane_reconfig(t->lane[i], cfg);
+    if (t->nlanes > 1 && cfg->iIntraPeriod >= 1) t->iper = cfg->iIntraPeriod;
+}
+int QY265EncoderEncodeHeaders(void *h, QY265Nal **pNals, int *n)
+{
+    Top *t = (Top *)h;
+    if (!t || !pNals || !n) return QY_POINTER;
+    return lane_headers(t->lane[0], pNals, n);
+}
+void QY265EncoderKeyFrameRequest(void *h)
+{
+    Top *t = (Top *)h;
+    if (!t) return;
+    if (t->nlanes == 1) t->lane[0]->force_key = 1; else t->key_request = 1;   /* lanes: the next picture opens a new GOP on the next lane */
+}
+int QY265EncoderDelayedFrames(void *h)
+{
+    Top *t = (Top *)h;
+    if (!t) return 0;
+    int n = 0;
+    for (int i = 0; i < t->nlanes; ++i) n += lane_delayed(t->lane[i]);
+    return n;
+}
+
+int QY265EncoderEncodeFrame(void *h, QY265Nal **pNals, int *iNalCount, QY265Picture *in, QY265Picture *out, int bForceLogo)
+{
+    (void)bForceLogo;
+    Top *t = (Top *)h;
+    if (!t || !pNals || !iNalCount) return QY_POINTER;
+    if (t->nlanes == 1) return lane_encode_frame(t->lane[0], pNals, iNalCount, in, out);
+    *pNals = NULL; *iNalCount = 0;
+    t->on = 0; t->opos = 0;
+    int r = QY_OK;
+    if (in) {
+        int first = 0;
+        if (t->chunk_left <= 0 || t->key_request) {                     /* a new GOP: the next lane */
+            if (t->ch_n) t->ch[(t->ch_head + t->ch_n - 1) % MAX_CHUNKS].closed = 1;
+            while (t->ch_n == MAX_CHUNKS && !r) r = top_collect(t, 1, out);
+            if (r) return r;
+            t->cur_lane = (t->cur_lane + 1) % t->nlanes;
+            Chunk *c = &t->ch[(t->ch_head + t->ch_n) % MAX_CHUNKS];
+            c->lane = t->cur_lane; c->closed = 0; c->count = 0; c->delivered = 0; c->base = t->n_in;
+            ++t->ch_n;
+            t->chunk_left = t->iper > 0 ? t->iper : (1L << 40);
+            t->key_request = 0; first = 1;
+        }
+        Enc *e = t->lane[t->cur_lane];
+        const double t0 = now_ms();
+        while (!lane_has_slot(e)) {                                     /* this lane is as far ahead as its buffers allow: finish older GOPs first */
+            r = top_collect(t, 1, out);
+            if (r) return r;
+        }
+        t->output_ms += now_ms() - t0;
+        r = lane_put(e, in, first);
+        if (r) return r;
+        ++t->ch[(t->ch_head + t->ch_n - 1) % MAX_CHUNKS].count; ++t->n_in; --t->chunk_left;
+        const double t1 = now_ms();
+        r = top_collect(t, 0, out);
+        t->output_ms += now_ms() - t1;
+        if (!r) for (int i = 0; i < t->nlanes && !r; ++i) r = t->lane[i]->sched_err;
+    } else {
+        const double t0 = now_ms();
+        if (t->ch_n) t->ch[(t->ch_head + t->ch_n - 1) % MAX_CHUNKS].closed = 1;
+        t->chunk_left = 0;
+        for (int i = 0; i < t->nlanes; ++i) {
+            if (lane_delayed(t->lane[i])) lane_flush_begin(t->lane[i]);
+            if (t->lane[i]->sched_err) return t->lane[i]->sched_err;
+        }
+        r = top_collect(t, 1, out);
+        t->output_ms += now_ms() - t0;
+    }
+    for (int i = 0; i < t->on; ++i) t->onals[i].pPayload = t->obuf + t->ooff[i];
+    *pNals = t->onals; *iNalCount = t->on;
+    return r;
+}
+
+int ks265_enc_get_stats(void *h, ks265_enc_stats *out)
+{
+    Top *t = (Top *)h;
+    if (!t || !out) return QY_POINTER;
+    *out = t->lane[0]->st;
+    for (int i = 1; i < t->nlanes; ++i) {                               /* sums over the lanes (per-picture averages divide by frames as before) */
+        const ks265_enc_stats *s = &t->lane[i]->st;
+        out->frames += s->frames; out->bytes += s->bytes;
+        for (int k = 0; k < 3; ++k) out->sse[k] += s->sse[k];
+        out->gpu_ms += s->gpu_ms; out->host_write_ms += s->host_write_ms; out->in_copy_ms += s->in_copy_ms; out->submit_ms += s->submit_ms;
+        out->lat_gpu_ms += s->lat_gpu_ms; out->lat_queue_ms += s->lat_queue_ms; out->key_wall_ms += s->key_wall_ms; out->key_cpu_ms += s->key_cpu_ms; out->keys += s->keys;
+        out->occ_samples += s->occ_samples; out->occ_ring += s->occ_ring; out->occ_gpu += s->occ_gpu; out->occ_ready += s->occ_ready;
+    }
+    if (t->nlanes > 1) out->output_ms = t->output_ms;
+    return QY_OK;
+}
+
+int ks265_enc_lanes(void *h) { const Top *t = (const Top *)h; return t ? t->nlanes : 0; }
+
+int ks265_enc_set_recon_file(void *h, const char *path)
+{
+    Top *t = (Top *)h;
+    if (!t || !path) return QY_POINTER;
+    if (t->n_in) return QY_NOTSUPPORTED;
+    for (int i = 1; i < t->nlanes; ++i) lane_close(t->lane[i], 0);     /* the dump is one file in display order: one lane */
+    t->nlanes = 1;
+    return lane_set_recon_file(t->lane[0], path);
 }

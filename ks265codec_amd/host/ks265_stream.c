@@ -219,13 +219,28 @@ typedef struct {
     uint8_t *p; size_t cap, pos; int overflow;
     uint32_t low, range; int bits_left, num_buffered; unsigned buffered_byte;
     uint8_t state[CX_COUNT];               /* pStateIdx << 1 | valMps */
+#ifdef KS265_BIT_STATS
+    int cat;                               /* diagnostic build only (scratch): information content of the bins by syntax category */
+#endif
 } Cabac;
+#ifdef KS265_BIT_STATS
+#include <math.h>
+enum { CAT_CU, CAT_MERGE, CAT_MOTION, CAT_COEF, CAT_SAO, CAT_INTRA, CAT_N };
+static __thread double g_bit_stats[CAT_N];
+void ks265_bit_stats(double *out, int reset) { for (int i = 0; i < CAT_N; ++i) { out[i] = g_bit_stats[i]; if (reset) g_bit_stats[i] = 0; } }
+#define CAT(c, k) ((c)->cat = (k))
+#define CAT_GET(c) ((c)->cat)
+#else
+#define CAT(c, k) ((void)0)
+#define CAT_GET(c) 0
+#endif
 
 static void cb_out(Cabac *c, unsigned v) { if (c->pos < c->cap) c->p[c->pos++] = (uint8_t)v; else c->overflow = 1; }
 static void cb_init(Cabac *c, uint8_t *p, size_t cap, int init_type, int qp)
 {
     c->p = p; c->cap = cap; c->pos = 0; c->overflow = 0;
     c->low = 0; c->range = 510; c->bits_left = 23; c->num_buffered = 0; c->buffered_byte = 0xFF;
+    CAT(c, 0);
     for (int i = 0; i < CX_COUNT; ++i) {                           /* 9.3.2.2 */
         const int iv = kInit[init_type][i], slope = (iv >> 4) * 5 - 45, offset = ((iv & 15) << 3) - 16;
         int pre = ((slope * (qp < 0 ? 0 : qp > 51 ? 51 : qp)) >> 4) + offset;
@@ -255,6 +270,9 @@ static inline void cb_bin(Cabac *c, int ctx, int bin)
 {
     uint8_t s = c->state[ctx];
     const unsigned lps = kRangeTabLps[s >> 1][(c->range >> 6) & 3];
+#ifdef KS265_BIT_STATS
+    g_bit_stats[c->cat] += log2((double)c->range / (double)(((bin & 1) != (s & 1)) ? lps : c->range - lps));
+#endif
     c->range -= lps;
     if ((bin & 1) != (s & 1)) {
         int nb = 0;
@@ -275,6 +293,9 @@ static inline void cb_bin(Cabac *c, int ctx, int bin)
 }
 static inline void cb_bypass(Cabac *c, int bin)
 {
+#ifdef KS265_BIT_STATS
+    g_bit_stats[c->cat] += 1.0;
+#endif
     c->low <<= 1;
     if (bin) c->low += c->range;
     if (--c->bits_left < 12) cb_write_out(c);
@@ -393,6 +414,7 @@ static void sao_ctb(Enc *e, int rx, int ry)
 {
     Cabac *c = &e->c;
     const ks265_sao_param *p = e->in->sao + (long)(ry * e->ctb_cols + rx) * 3;
+    CAT(c, CAT_SAO);
     if (rx > 0) cb_bin(c, CX_SAO_MERGE, 0);                          /* sao_merge_left_flag */
     if (ry > 0) cb_bin(c, CX_SAO_MERGE, 0);                          /* sao_merge_up_flag */
     for (int ci = 0; ci < 3; ++ci) {
@@ -405,6 +427,7 @@ static void sao_ctb(Enc *e, int rx, int ry)
         sao_offsets(e, q);
         if (q->type > 0 && ci < 2) cb_bypass_bits(c, (uint32_t)(q->type - 1), 2);   /* sao_eo_class_luma / _chroma */
     }
+    CAT(c, CAT_CU);
 }
 
 /* ------------------------------------------------------------------ residual_coding (7.3.8.11, 9.3.4.2.4 .. 9.3.4.2.7) */
@@ -448,6 +471,8 @@ static void code_remaining(Cabac *c, unsigned v, int rice)                 /* co
 static void residual_coding(Enc *e, const int16_t *blk, int stride, int log2, int cidx, int scan_idx)
 {
     Cabac *c = &e->c;
+    const int cat0 = CAT_GET(c); (void)cat0;
+    CAT(c, CAT_COEF);
     const int size = 1 << log2, nsb_log2 = log2 - 2, nsb = 1 << (2 * nsb_log2);
     const XY *sbs = e->scans.sb[scan_idx][nsb_log2], *p4 = e->scans.pos4[scan_idx];
     /* which 4x4 sub-blocks hold a level at all: four 8-byte reads per sub-block (most TUs of a P picture hold a handful of levels) */
@@ -470,7 +495,7 @@ static void residual_coding(Enc *e, const int16_t *blk, int stride, int log2, in
             if (blk[y * stride + x]) { last_sb = i; last_n = n; break; }
         }
     }
-    if (last_sb < 0) return;                                         /* cbf said otherwise: never reached */
+    if (last_sb < 0) { CAT(c, cat0); return; }                                         /* cbf said otherwise: never reached */
     int lx = sbs[last_sb].x * 4 + p4[last_n].x, ly = sbs[last_sb].y * 4 + p4[last_n].y;
     if (scan_idx == 2) { const int t = lx; lx = ly; ly = t; }       /* vertical scan: the coordinates are swapped in the syntax */
     int px, sx, nx, py, sy, ny;
@@ -557,6 +582,7 @@ static void residual_coding(Enc *e, const int16_t *blk, int stride, int log2, in
             }
         }
     }
+    CAT(c, cat0);
 }
 
 /* ------------------------------------------------------------------ motion vector prediction (8.5.3.2.6, 8.5.3.2.7; no temporal candidate) */
@@ -748,11 +774,14 @@ static int coding_unit(Enc *e, int x, int y, int log2)
             skip = merge_idx >= 0 && !any;
         }
         const int inc = (x > 0 && e->skip[(long)(y >> 3) * e->w8 + ((x - 1) >> 3)]) + (y > 0 && e->skip[(long)((y - 1) >> 3) * e->w8 + (x >> 3)]);
+        CAT(c, CAT_CU);
         cb_bin(c, CX_SKIP + inc, skip);                               /* cu_skip_flag */
         if (skip) {
+            CAT(c, CAT_MERGE);
             for (int by = 0; by < size >> 3; ++by) memset(e->skip + (long)((y >> 3) + by) * e->w8 + (x >> 3), 1, (size_t)(size >> 3));
             cb_bin(c, CX_MERGE_IDX, merge_idx > 0);                   /* merge_idx: TR, cMax = 4, first bin with context */
             for (int k = 1; k < MAX_MERGE - 1 && k <= merge_idx; ++k) cb_bypass(c, merge_idx > k);
+            CAT(c, CAT_CU);
             return 0;
         }
         cb_bin(c, CX_PRED_MODE, intra);
@@ -774,6 +803,7 @@ static int coding_unit(Enc *e, int x, int y, int log2)
         }
         int idx = -1;
         for (int k = 0; k < 3; ++k) if (mpm[k] == mode) idx = k;
+        CAT(c, CAT_INTRA);
         cb_bin(c, CX_PREV_INTRA, idx >= 0);
         if (idx >= 0) { cb_bypass(c, idx > 0); if (idx > 0) cb_bypass(c, idx > 1); }
         else {
@@ -785,13 +815,16 @@ static int coding_unit(Enc *e, int x, int y, int log2)
             cb_bypass_bits(c, (uint32_t)rem, 5);
         }
         cb_bin(c, CX_CHROMA_PRED, 0);                                /* intra_chroma_pred_mode = 4: derived from luma */
+        CAT(c, CAT_CU);
     } else {
+        CAT(c, CAT_MERGE);
         cb_bin(c, CX_MERGE_FLAG, merge_idx >= 0);
         const int dir = cu->inter_dir & 3;
         if (merge_idx >= 0) {
             cb_bin(c, CX_MERGE_IDX, merge_idx > 0);
             for (int k = 1; k < MAX_MERGE - 1 && k <= merge_idx; ++k) cb_bypass(c, merge_idx > k);
         } else {
+        CAT(c, CAT_MOTION);
         if (st == KS265_SLICE_B) {
             /* inter_pred_idc: nPbW + nPbH != 12 always (2Nx2N, >= 8x8) */
             const int depth = 6 - log2;
@@ -819,6 +852,7 @@ static int coding_unit(Enc *e, int x, int y, int log2)
             cb_bin(c, CX_MVP, pick);
         }
         }
+        CAT(c, CAT_CU);
     }
     /* transform tree (7.3.8.8): max_transform_hierarchy_depth = 0 -> one TU per CU, except 64x64 CUs (four 32x32 TUs, split inferred) */
     if (log2 == 6) {

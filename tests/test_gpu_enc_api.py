@@ -10,6 +10,7 @@ import hashlib
 import json
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -47,6 +48,93 @@ def test_cli_stream_equals_decoder_verified_fixture(tmp_path):
     assert "H265 encoder passed!!!" in r.stdout and "Total Frames: 4" in r.stdout and "bitrate, psnr:" in r.stdout, r.stdout
     bs = open(out, "rb").read()
     assert hashlib.md5(bs).hexdigest() == GOLD[name]["stream_md5"], f"CLI stream differs from the decoder-verified fixture ({len(bs)} vs {GOLD[name]['stream_bytes']} bytes)"
+
+
+@pytest.mark.parametrize("W,H,n,iper", [(416, 240, 230, 32), (200, 136, 150, 48)])
+def test_gop_lanes_write_the_one_lane_stream(tmp_path, W, H, n, iper):
+    """GOP lanes (closed GOPs coded concurrently on one GPU, ks265_enc.c): 2 and 3 lanes write byte for byte what one lane writes - GOP order kept,
+    the last (short) GOP and the flush included"""
+    from ks265codec_amd import stream
+    from ks265codec_amd.synth import make_clip
+    stream.build()
+    clip = make_clip(W, H, 23, seed=77, abc=(17, 23, 9))
+    yuv = tmp_path / "in.yuv"
+    with open(yuv, "wb") as f:
+        for t in range(n):
+            f.write(clip[t % 23].tobytes())
+    md5 = {}
+    for lanes in (1, 2, 3):
+        out = tmp_path / f"l{lanes}.265"
+        r = subprocess.run([stream.CLI, "-i", str(yuv), "-wdt", str(W), "-hgt", str(H), "-fr", "50", "-preset", "slow", "-rc", "0", "-qp", "30", "-iper", str(iper), "-bframes", "0",
+                            "-threads", "6", "-psnr", "1", "-b", str(out)], capture_output=True, text=True, env=dict(os.environ, KS265_GOP_LANES=str(lanes)))
+        assert r.returncode == 0, r.stdout[-500:] + r.stderr[-500:]
+        assert f"Total Frames: {n}" in r.stdout and "H265 encoder passed!!!" in r.stdout, r.stdout[-400:]
+        assert ("GOP lanes" in (r.stdout + r.stderr)) == (lanes > 1), r.stdout[:600] + r.stderr[:600]
+        md5[lanes] = hashlib.md5(open(out, "rb").read()).hexdigest()
+    assert md5[1] == md5[2] == md5[3], md5
+    if os.path.exists(REF_DEC):
+        d = subprocess.run([REF_DEC, "-b", str(tmp_path / "l2.265"), "-o", str(tmp_path / "d.yuv"), "-threads", "2"], capture_output=True, text=True, cwd=tmp_path)
+        assert d.returncode == 0 and os.path.getsize(tmp_path / "d.yuv") == n * W * H * 3 // 2, d.stdout[-300:] + d.stderr[-300:]
+
+
+_LANES_DRIVER = r"""
+import ctypes as C, hashlib, json, os, sys
+import torch; torch.cuda.is_available()
+sys.path.insert(0, sys.argv[1])
+from ks265codec_amd import stream
+from ks265codec_amd.synth import make_clip
+W, H, N, iper = 416, 240, int(sys.argv[2]), int(sys.argv[3])
+LAY = json.load(open(os.path.join(sys.argv[1], "tests", "golden", "qy265_layout.json")))
+lib = C.CDLL(stream.build()); lib.QY265EncoderOpen.restype = C.c_void_p
+class YUV(C.Structure): _fields_ = [("iWidth", C.c_int), ("iHeight", C.c_int), ("pData", C.POINTER(C.c_ubyte) * 3), ("iStride", C.c_int * 3)]
+class Picture(C.Structure): _fields_ = [("iSliceType", C.c_int), ("poc", C.c_int), ("pts", C.c_longlong), ("dts", C.c_longlong), ("yuv", C.POINTER(YUV))]
+class Nal(C.Structure): _fields_ = [("naltype", C.c_int), ("tid", C.c_int), ("iSize", C.c_int), ("pts", C.c_longlong), ("pPayload", C.POINTER(C.c_ubyte))]
+clip = make_clip(W, H, 7, seed=3, abc=(17, 23, 9))
+cfg = (C.c_uint8 * LAY["sizeof_config"])()
+assert lib.QY265ConfigDefaultPreset(cfg, b"medium", None, b"default") == 0
+for k, v in (("wdt", W), ("hgt", H), ("fr", 50), ("rc", 0), ("qp", 34), ("iper", iper), ("bframes", 0), ("threads", 6), ("psnr", 0), ("log", 3)):
+    assert lib.QY265ConfigParse(cfg, k.encode(), str(v).encode()) == 0
+err = C.c_int(0)
+h = C.c_void_p(lib.QY265EncoderOpen(cfg, C.byref(err))); assert h.value
+nal, nn, pic, outp, yuv = C.POINTER(Nal)(), C.c_int(0), Picture(), Picture(), YUV()
+yuv.iWidth, yuv.iHeight = W, H
+yuv.iStride[0], yuv.iStride[1], yuv.iStride[2] = W, W // 2, W // 2
+pic.yuv = C.pointer(yuv)
+md, pts, pocs = hashlib.md5(), [], []
+def take():
+    for i in range(nn.value):
+        md.update(C.string_at(nal[i].pPayload, nal[i].iSize))
+        if nal[i].naltype < 32: pts.append(nal[i].pts)
+    if nn.value: pocs.append(outp.poc)
+for t in range(N):
+    fr = clip[t % 7]
+    for k, off in enumerate((0, W * H, W * H * 5 // 4)): yuv.pData[k] = C.cast(fr.ctypes.data + off, C.POINTER(C.c_ubyte))
+    pic.pts = t
+    assert lib.QY265EncoderEncodeFrame(h, C.byref(nal), C.byref(nn), C.byref(pic), C.byref(outp), 0) == 0
+    take()
+while lib.QY265EncoderDelayedFrames(h):
+    assert lib.QY265EncoderEncodeFrame(h, C.byref(nal), C.byref(nn), None, C.byref(outp), 0) == 0
+    take()
+lanes = lib.ks265_enc_lanes(h)
+lib.QY265EncoderClose(h)
+assert pts == list(range(N)), "pictures must leave in stream order"
+assert pocs == sorted(pocs) and pocs[-1] == N - 1, pocs[-5:]
+print(json.dumps({"md5": md.hexdigest(), "lanes": lanes}))
+"""
+
+
+@pytest.mark.parametrize("n,iper", [(1500, 300), (700, 64)])
+def test_gop_lanes_under_a_fast_caller(tmp_path, n, iper):
+    """the caller feeds as fast as the API takes pictures (no file read in between): with GOPs longer than a lane's ring the lanes fill up completely, input
+    waits for older GOPs to leave, the scheduler threads wait for ring space - and the stream still is the one-lane stream.  Each run is a process of its
+    own under a hard time limit: a dead-lock shows as a failure, not as a hung test session."""
+    res = {}
+    for lanes in (1, 2, 3):
+        r = subprocess.run([sys.executable, "-c", _LANES_DRIVER, ROOT, str(n), str(iper)], capture_output=True, text=True, timeout=120, env=dict(os.environ, KS265_GOP_LANES=str(lanes)))
+        assert r.returncode == 0, r.stdout[-800:] + r.stderr[-800:]
+        res[lanes] = json.loads(r.stdout.strip().splitlines()[-1])
+        assert res[lanes]["lanes"] == lanes
+    assert res[1]["md5"] == res[2]["md5"] == res[3]["md5"], res
 
 
 class YUV(C.Structure):
