@@ -471,7 +471,7 @@ def encoded_leg(args, torch, dist, rank, world, dev_index, backend, sync_all):
         cores = len(os.sched_getaffinity(0))
     except Exception:
         cores = os.cpu_count() or 8
-    threads = args.host_threads or max(2, min(32, cores // max(1, world)))
+    threads = args.host_threads or max(2, min(32, cores // max(1, world)))        # slice writers of this rank's encoder (shared out over its GOP lanes, if any)
     os.environ["KS265_DEVICE"] = str(dev_index)
     cfg = (C.c_uint8 * lay["sizeof_config"])()
     preset = b"slow" if args.me == "umh" and args.me_hex_thr == 16 else b"veryslow" if args.me == "umh" else b"medium"

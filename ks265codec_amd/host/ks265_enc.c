@@ -130,11 +130,80 @@ typedef struct Job {
     double t_write_ms, t_submit, t_event, t_taken, t_done;      /* wall-clock marks: enqueued, records on the host (seen by a writer), writer started */
 } Job;
 
+/* The caller's picture has to be copied (the API gives the buffer back at once): 12 MB at 2160p, ~0.9 ms for one thread - more than the GPU needs for the
+ * picture.  A few helper threads share the copy with the calling thread. */
+#define COPY_HELPERS 3
+typedef struct CopyPool {
+    pthread_t th[COPY_HELPERS]; int nth, quit;
+    pthread_mutex_t mu; pthread_cond_t cv_work, cv_done;
+    struct { uint8_t *d; const uint8_t *s; size_t n; } task[COPY_HELPERS];
+    unsigned posted, pending;                             /* bit k: task k waits for helper k / is not finished */
+} CopyPool;
+static void *copy_helper(void *arg)
+{
+    CopyPool *p = (CopyPool *)((void **)arg)[0]; const int k = (int)(intptr_t)((void **)arg)[1];
+    free(arg);
+    pthread_mutex_lock(&p->mu);
+    for (;;) {
+        while (!p->quit && !(p->posted & (1u << k))) pthread_cond_wait(&p->cv_work, &p->mu);
+        if (p->quit) break;
+        p->posted &= ~(1u << k);
+        pthread_mutex_unlock(&p->mu);
+        memcpy(p->task[k].d, p->task[k].s, p->task[k].n);
+        pthread_mutex_lock(&p->mu);
+        p->pending &= ~(1u << k);
+        if (!p->pending) pthread_cond_signal(&p->cv_done);
+    }
+    pthread_mutex_unlock(&p->mu);
+    return NULL;
+}
+static CopyPool *copy_pool_create(void)
+{
+    CopyPool *p = (CopyPool *)calloc(1, sizeof *p);
+    if (!p) return NULL;
+    pthread_mutex_init(&p->mu, NULL); pthread_cond_init(&p->cv_work, NULL); pthread_cond_init(&p->cv_done, NULL);
+    for (int k = 0; k < COPY_HELPERS; ++k) {
+        void **a = (void **)malloc(2 * sizeof *a);
+        if (!a) break;
+        a[0] = p; a[1] = (void *)(intptr_t)k;
+        if (pthread_create(&p->th[k], NULL, copy_helper, a)) { free(a); break; }
+        ++p->nth;
+    }
+    return p;
+}
+static void copy_pool_destroy(CopyPool *p)
+{
+    if (!p) return;
+    pthread_mutex_lock(&p->mu); p->quit = 1; pthread_cond_broadcast(&p->cv_work); pthread_mutex_unlock(&p->mu);
+    for (int k = 0; k < p->nth; ++k) pthread_join(p->th[k], NULL);
+    pthread_mutex_destroy(&p->mu); pthread_cond_destroy(&p->cv_work); pthread_cond_destroy(&p->cv_done);
+    free(p);
+}
+/* memcpy shared between the calling thread and the helpers (one caller at a time: the API's calling thread) */
+static void copy_shared(CopyPool *p, uint8_t *d, const uint8_t *s, size_t n)
+{
+    if (!p || !p->nth || n < ((size_t)1 << 20)) { memcpy(d, s, n); return; }
+    const size_t part = (n / (size_t)(p->nth + 1) + 4095) & ~(size_t)4095;
+    size_t off = part;                                    /* the caller takes the first part */
+    pthread_mutex_lock(&p->mu);
+    for (int k = 0; k < p->nth && off < n; ++k, off += part) {
+        p->task[k].d = d + off; p->task[k].s = s + off; p->task[k].n = n - off < part ? n - off : part;
+        p->posted |= 1u << k; p->pending |= 1u << k;
+    }
+    pthread_cond_broadcast(&p->cv_work);
+    pthread_mutex_unlock(&p->mu);
+    memcpy(d, s, part < n ? part : n);
+    pthread_mutex_lock(&p->mu);
+    while (p->pending) pthread_cond_wait(&p->cv_done, &p->mu);
+    pthread_mutex_unlock(&p->mu);
+}
+
 typedef struct Input { int used, disp, key; long long pts; uint8_t *i420; } Input;     /* pinned; key: this picture starts a closed GOP whatever the period says (GOP lanes) */
 
 typedef struct Enc {
     QY265EncConfig cfg;
     int W, H, log_level;
+    CopyPool *pool;                                       /* shared by the lanes of one handle (owned by it) */
     int me_method, hex_thr, subme, refs, use_sao, use_df, gop_b, hier;                  /* resolved tools */
     int base_qp, iper, nthreads;
     ks265_ctx *ctx; ks265_frame *frame; ks265_frame_geom geom; ks265_frame_cfg fcfg; ks265_stream_cfg scfg;
@@ -826,9 +895,9 @@ static int lane_put(Enc *e, QY265Picture *in, int key)
     if (!slot) return QY_FAIL;                                         /* one lane: cannot happen (more input slots than pictures in flight + one mini-GOP); lanes: the caller checked lane_has_slot */
     uint8_t *u = slot->i420 + (size_t)e->W * e->H, *v = u + (size_t)e->W * e->H / 4;
     if (in->yuv->iStride[0] == e->W && in->yuv->iStride[1] == e->W / 2 && in->yuv->iStride[2] == e->W / 2) {    /* packed planes: three block copies */
-        memcpy(slot->i420, in->yuv->pData[0], (size_t)e->W * e->H);
-        memcpy(u, in->yuv->pData[1], (size_t)e->W * e->H / 4);
-        memcpy(v, in->yuv->pData[2], (size_t)e->W * e->H / 4);
+        copy_shared(e->pool, slot->i420, in->yuv->pData[0], (size_t)e->W * e->H);
+        copy_shared(e->pool, u, in->yuv->pData[1], (size_t)e->W * e->H / 4);
+        copy_shared(e->pool, v, in->yuv->pData[2], (size_t)e->W * e->H / 4);
     } else {
         for (int y = 0; y < e->H; ++y) memcpy(slot->i420 + (size_t)y * e->W, in->yuv->pData[0] + (size_t)y * in->yuv->iStride[0], (size_t)e->W);
         for (int y = 0; y < e->H / 2; ++y) {
@@ -909,7 +978,10 @@ static int lane_set_recon_file(Enc *e, const char *path)
  * then GOP k + 1 from the next lane), so the stream is byte for byte the one a single lane writes (tests/test_gpu_enc_api.py).  The reference's
  * enFrameParallel (frames of one stream coded concurrently on CPU threads) is the switch: lanes run with enFrameParallel != 0, IPPP (-bframes 0),
  * fixed QP (-rc 0) and a key period of at least 32 pictures - B pictures in front of a key picture reference it (the GOPs are not closed), the rate
- * controllers carry state across GOPs.  KS265_GOP_LANES = 1..4 overrides the default of 2.  Cost: output lags the input by up to L GOPs. */
+ * controllers carry state across GOPs.  Cost: output lags the input by up to L GOPs, and L pipelines' worth of buffers.
+ * Off by default (KS265_GOP_LANES = 2..4 switches it on): measured at 2160p on the round-2 box, two lanes reach 1.05x of one (1123 vs 1068 frames/s) -
+ * with twice the pictures in flight the slice writers, not the GPU, set the pace (their time per picture grows from 19 to 59 ms of thread time as the
+ * threads spread over the host), DESIGN.md section 6. */
 #define MAX_LANES 4
 #define MAX_CHUNKS 64
 typedef struct Chunk { int lane, closed; long count, delivered, base; } Chunk;
@@ -918,6 +990,7 @@ typedef struct Top {
     int iper, key_request, cur_lane;
     long n_in, chunk_left;
     Chunk ch[MAX_CHUNKS]; int ch_head, ch_n;
+    CopyPool *pool;
     QY265Nal *onals; size_t *ooff; int on, on_cap;                   /* output of the current call: NAL payloads copied out of the lanes */
     uint8_t *obuf; size_t ocap, opos;
     double output_ms;
@@ -999,7 +1072,7 @@ static int top_collect(Top *t, int block, QY265Picture *out)
 static int top_lanes_wanted(const QY265EncConfig *cfg)
 {
     const char *env = getenv("KS265_GOP_LANES");
-    int n = env ? atoi(env) : 2;
+    int n = env ? atoi(env) : 1;
     if (n < 1) n = 1;
     if (n > MAX_LANES) n = MAX_LANES;
     const int ippp = cfg->bframes == 0 || (cfg->bframes < 0 && cfg->latency != QY265LATENCY_DEFAULT);
@@ -1034,6 +1107,8 @@ void *QY265EncoderOpen(QY265EncConfig *cfg, int *err)
             break;
         }
     }
+    if ((size_t)cfg->picWidth * cfg->picHeight >= ((size_t)1 << 20)) t->pool = copy_pool_create();
+    for (int i = 0; i < t->nlanes; ++i) t->lane[i]->pool = t->pool;
     if (t->nlanes > 1) logf_(0, cfg->logLevel, "ks265enc: %d GOP lanes (closed GOPs of %d pictures coded concurrently, output in GOP order)\n", t->nlanes, t->iper);
     return t;
 }
@@ -1054,6 +1129,7 @@ void QY265EncoderClose(void *h)
         }
     }
     for (int i = 0; i < t->nlanes; ++i) lane_close(t->lane[i], t->nlanes == 1);
+    copy_pool_destroy(t->pool);
     free(t->onals); free(t->ooff); free(t->obuf);
     free(t);
 }

@@ -69,7 +69,7 @@ def test_gop_lanes_write_the_one_lane_stream(tmp_path, W, H, n, iper):
                             "-threads", "6", "-psnr", "1", "-b", str(out)], capture_output=True, text=True, env=dict(os.environ, KS265_GOP_LANES=str(lanes)))
         assert r.returncode == 0, r.stdout[-500:] + r.stderr[-500:]
         assert f"Total Frames: {n}" in r.stdout and "H265 encoder passed!!!" in r.stdout, r.stdout[-400:]
-        assert ("GOP lanes" in (r.stdout + r.stderr)) == (lanes > 1), r.stdout[:600] + r.stderr[:600]
+        assert ("GOP lanes" in (r.stdout + r.stderr)) == (lanes > 1), r.stdout[:600] + r.stderr[:600]      # switched on by KS265_GOP_LANES only
         md5[lanes] = hashlib.md5(open(out, "rb").read()).hexdigest()
     assert md5[1] == md5[2] == md5[3], md5
     if os.path.exists(REF_DEC):
