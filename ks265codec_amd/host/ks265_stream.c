@@ -266,6 +266,7 @@ static void cb_write_out(Cabac *c)
         c->buffered_byte = lead;
     }
 }
+static const uint8_t kRenorm[32] = {6, 5, 4, 4, 3, 3, 3, 3, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
 static inline void cb_bin(Cabac *c, int ctx, int bin)
 {
     uint8_t s = c->state[ctx];
@@ -275,11 +276,9 @@ static inline void cb_bin(Cabac *c, int ctx, int bin)
 #endif
     c->range -= lps;
     if ((bin & 1) != (s & 1)) {
-        int nb = 0;
-        unsigned r = lps;
-        while (r < 256) { r <<= 1; ++nb; }
+        const int nb = kRenorm[lps >> 3];                               /* lps in 6 .. 240: shifts until bit 8 is set */
         c->low = (c->low + c->range) << nb;
-        c->range = r;
+        c->range = lps << nb;
         if ((s >> 1) == 0) s ^= 1;
         c->state[ctx] = (uint8_t)((kTransIdxLps[s >> 1] << 1) | (s & 1));
         c->bits_left -= nb;
@@ -300,7 +299,20 @@ static inline void cb_bypass(Cabac *c, int bin)
     if (bin) c->low += c->range;
     if (--c->bits_left < 12) cb_write_out(c);
 }
-static void cb_bypass_bits(Cabac *c, uint32_t v, int n) { for (int i = n - 1; i >= 0; --i) cb_bypass(c, (int)((v >> i) & 1u)); }
+/* n bypass bins at once, most significant first (9.3.4.3.4 n times: low = 2 low + bin x range, written out after at most 8 of them) */
+static void cb_bypass_bits(Cabac *c, uint32_t v, int n)
+{
+#ifdef KS265_BIT_STATS
+    g_bit_stats[c->cat] += n;
+#endif
+    while (n > 0) {
+        const int k = n > 8 ? 8 : n;
+        n -= k;
+        c->low = (c->low << k) + c->range * ((v >> n) & ((1u << k) - 1));
+        c->bits_left -= k;
+        if (c->bits_left < 12) cb_write_out(c);
+    }
+}
 static void cb_terminate(Cabac *c, int bin)
 {
     c->range -= 2;
@@ -348,9 +360,12 @@ static void build_scan(int scan_idx, int size, XY *out)
     } else if (scan_idx == 1) { for (int y = 0; y < size; ++y) for (int x = 0; x < size; ++x) { out[i].x = (uint8_t)x; out[i].y = (uint8_t)y; ++i; } }
     else { for (int x = 0; x < size; ++x) for (int y = 0; y < size; ++y) { out[i].x = (uint8_t)x; out[i].y = (uint8_t)y; ++i; } }
 }
+static const uint8_t kCtxIdxMap4x4[16] = {0, 1, 4, 5, 2, 3, 4, 5, 6, 6, 8, 8, 7, 7, 8, 8};
 typedef struct {
     XY pos4[3][16];          /* positions inside a 4x4 sub-block, per scanIdx */
     XY sb[3][4][64];         /* sub-block order for log2 size 2..5 (1, 4, 16, 64 sub-blocks), per scanIdx */
+    /* sig_coeff_flag context (9.3.4.2.5) of scan position n of a sub-block, offset from CX_SIG: [log2 - 2][chroma][scanIdx][sub-block is not the first][csbf right + 2 below][n] */
+    uint8_t sigctx[4][2][3][2][4][16];
 } Scans;
 static void scans_init(Scans *s)
 {
@@ -358,6 +373,26 @@ static void scans_init(Scans *s)
         build_scan(k, 4, s->pos4[k]);
         for (int l = 0; l < 4; ++l) build_scan(k, 1 << l, s->sb[k][l]);
     }
+    for (int log2 = 2; log2 <= 5; ++log2)
+        for (int ch = 0; ch < 2; ++ch)
+            for (int k = 0; k < 3; ++k)
+                for (int nf = 0; nf < 2; ++nf)
+                    for (int pc = 0; pc < 4; ++pc)
+                        for (int n = 0; n < 16; ++n) {
+                            const int xp = s->pos4[k][n].x, yp = s->pos4[k][n].y;
+                            int sc;
+                            if (log2 == 2) sc = kCtxIdxMap4x4[(yp << 2) + xp];
+                            else if (!nf && xp + yp == 0) sc = 0;
+                            else {
+                                if (pc == 0) sc = (xp + yp == 0) ? 2 : (xp + yp < 3) ? 1 : 0;
+                                else if (pc == 1) sc = (yp == 0) ? 2 : (yp == 1) ? 1 : 0;
+                                else if (pc == 2) sc = (xp == 0) ? 2 : (xp == 1) ? 1 : 0;
+                                else sc = 2;
+                                if (!ch) { if (nf) sc += 3; sc += log2 == 3 ? (k == 0 ? 9 : 15) : 21; }
+                                else sc += log2 == 3 ? 9 : 12;
+                            }
+                            s->sigctx[log2 - 2][ch][k][nf][pc][n] = (uint8_t)(ch ? 27 + sc : sc);
+                        }
 }
 
 /* ------------------------------------------------------------------ slice state */
@@ -431,7 +466,6 @@ static void sao_ctb(Enc *e, int rx, int ry)
 }
 
 /* ------------------------------------------------------------------ residual_coding (7.3.8.11, 9.3.4.2.4 .. 9.3.4.2.7) */
-static const uint8_t kCtxIdxMap4x4[16] = {0, 1, 4, 5, 2, 3, 4, 5, 6, 6, 8, 8, 7, 7, 8, 8};
 
 static void code_last_prefix(Cabac *c, int ctx_base, int v, int log2, int cidx)
 {
@@ -513,13 +547,17 @@ static void residual_coding(Enc *e, const int16_t *blk, int stride, int log2, in
     for (int i = last_sb; i >= 0; --i) {
         const int xs = sbs[i].x, ys = sbs[i].y;
         int absv[16], sign[16], npos[16], nsig = 0;
-        /* which coefficients of this sub-block are significant */
+        /* the sub-block's levels in scan order, and which of them are significant */
+        int16_t v16[16];
         uint16_t sigmask = 0;
-        if (sbnz[ys][xs])
+        if (sbnz[ys][xs]) {
+            const int16_t *b0 = blk + (ys * 4) * stride + xs * 4;
             for (int n = (i == last_sb ? last_n : 15); n >= 0; --n) {
-                const int v = blk[(ys * 4 + p4[n].y) * stride + xs * 4 + p4[n].x];
+                const int v = b0[p4[n].y * stride + p4[n].x];
+                v16[n] = (int16_t)v;
                 if (v) sigmask |= (uint16_t)(1u << n);
             }
+        }
         const int right = xs + 1 < (1 << nsb_log2) ? csbf[ys][xs + 1] : 0, below = ys + 1 < (1 << nsb_log2) ? csbf[ys + 1][xs] : 0;
         int coded = sigmask != 0, infer_dc = 0;
         if (i < last_sb && i > 0) { cb_bin(c, CX_CSBF + ((right | below) ? 1 : 0) + (cidx ? 2 : 0), coded); infer_dc = 1; }
@@ -527,32 +565,21 @@ static void residual_coding(Enc *e, const int16_t *blk, int stride, int log2, in
         csbf[ys][xs] = (uint8_t)coded;
         if (!coded) continue;
         /* sig_coeff_flag */
-        const int prev_csbf = right + 2 * below;
+        const uint8_t *sctx = e->scans.sigctx[log2 - 2][cidx != 0][scan_idx][(xs | ys) != 0][right + 2 * below];
         for (int n = (i == last_sb ? last_n - 1 : 15); n >= 0; --n) {
             const int sig = (sigmask >> n) & 1;
             if (n > 0 || !infer_dc) {
-                const int xp = p4[n].x, yp = p4[n].y, xc = xs * 4 + xp, yc = ys * 4 + yp;
-                int sc;
-                if (log2 == 2) sc = kCtxIdxMap4x4[(yc << 2) + xc];
-                else if (xc + yc == 0) sc = 0;
-                else {
-                    if (prev_csbf == 0) sc = (xp + yp == 0) ? 2 : (xp + yp < 3) ? 1 : 0;
-                    else if (prev_csbf == 1) sc = (yp == 0) ? 2 : (yp == 1) ? 1 : 0;
-                    else if (prev_csbf == 2) sc = (xp == 0) ? 2 : (xp == 1) ? 1 : 0;
-                    else sc = 2;
-                    if (cidx == 0) { if (xs || ys) sc += 3; sc += log2 == 3 ? (scan_idx == 0 ? 9 : 15) : 21; }
-                    else sc += log2 == 3 ? 9 : 12;
-                }
-                cb_bin(c, CX_SIG + (cidx == 0 ? sc : 27 + sc), sig);
+                cb_bin(c, CX_SIG + sctx[n], sig);
                 if (sig) infer_dc = 0;
             }
         }
         /* levels of the sub-block in coding order (high scan position first) */
-        for (int n = 15; n >= 0; --n)
-            if ((sigmask >> n) & 1) {
-                const int v = blk[(ys * 4 + p4[n].y) * stride + xs * 4 + p4[n].x];
-                absv[nsig] = v < 0 ? -v : v; sign[nsig] = v < 0; npos[nsig] = n; ++nsig;
-            }
+        for (unsigned m = sigmask; m; ) {
+            const int n = 31 - __builtin_clz(m);
+            m &= ~(1u << n);
+            const int v = v16[n];
+            absv[nsig] = v < 0 ? -v : v; sign[nsig] = v < 0; npos[nsig] = n; ++nsig;
+        }
         if (!nsig) continue;                                         /* the inferred DC of a coded sub-block is always significant */
         int ctx_set = (i > 0 && cidx == 0) ? 2 : 0;
         if (c1 == 0) ++ctx_set;
