@@ -262,6 +262,12 @@ extern "C" int ks265_me_subpel(ks265_frame *f, ks265_pic src, const uint8_t *pla
     return ks265_check_launch(f->ctx);
 }
 
+// Price of splitting an inter CU into four, in bits at the motion lambda, on top of the children's SATD + vector rate (flags, vectors, the smaller
+// transforms of one TU per CU): 40 for the one-list records of P pictures, 80 for the two-list records (B pictures, multi-reference P).  At 12 (the flags
+// alone, round 1) the P pictures of the test clips were 3-5 % and the P / B pictures of a hierarchical GOP 15 % (qp 27) to 32 % (qp 35) larger for 0.03-0.07 dB
+// (the oracle's comment has the table).
+#define KS_SPLIT_BITS_P 40
+#define KS_SPLIT_BITS_B 80
 // ------------------------------------------------------------------ Stage C: CU quadtree (64 threads per CTU)
 // REC = ks265_pu (P pictures: list 0 only) or ks265_pu_b (B pictures: the per-PU winner with its direction)
 template <typename REC>
@@ -271,7 +277,7 @@ __global__ __launch_bounds__(64) void cu_decide_kernel(KsGeom g, int lam, const 
     __shared__ unsigned char split[85];
     const int t = threadIdx.x, ctu = blockIdx.x, cx = ctu % g.ctu_cols, cy = ctu / g.ctu_cols;
     const REC *cp = pus + (long)ctu * 85;
-    const unsigned pen = (unsigned)((lam * 12) >> 4);
+    const unsigned pen = (unsigned)((lam * (std::is_same<REC, ks265_pu_b>::value ? KS_SPLIT_BITS_B : KS_SPLIT_BITS_P)) >> 4);
     for (int l = 3; l >= 0; --l) {
         const int n = 1 << l, s = 64 >> l;
         for (int i = t; i < n * n; i += 64) {

@@ -413,6 +413,19 @@ void kso_me_subpel(const kso_frame_cfg *cfg, kso_pic src, const uint8_t *planes,
         }
 }
 
+/* Price of splitting an inter CU into four, in bits at the motion lambda, on top of the children's SATD + vector rate: their flags and vectors, and the
+ * smaller transforms the residual then gets (one TU per CU).  12 in round 1 (the flags alone).  Measured in round 2 with this oracle + the stream writer, bytes
+ * of the P / B pictures and their PSNR-Y at the same QP (one QP step: 17 % for 0.71 dB):
+ *   P pictures (IPPP, three clip types, 416x240 / 832x480, qp 27..30):  40: -2.9 .. -5.3 % at -0.02 .. -0.04 dB;  80: -0.4 .. -7.2 % at -0.05 .. -0.08 dB
+ *   hierarchical-B 8, 832x480 bench-style clip, all P / B pictures:     40: -11.3 % at -0.03 dB;  80: -15.0 % at -0.07 dB (qp 27), -31.8 % at -0.06 dB (qp 35);
+ *                                                                      100: -15.4 % at -0.09 dB; 200: -14 % at -0.15 dB
+ * hence 40 for the one-list records of P pictures and 80 for the two-list records (B pictures, multi-reference P); intra pictures barely move (own constant). */
+#ifndef SPLIT_BITS_P
+#define SPLIT_BITS_P 40
+#endif
+#ifndef SPLIT_BITS_B
+#define SPLIT_BITS_B 80
+#endif
 /* ------------------------------------------------------------------ Stage C: CU quadtree
  * bottom-up compare of processTree enc@0x4722a0 (the reference adds RD cost and early exits; closed code). */
 static uint32_t decide_node(const kso_frame_cfg *cfg, const kso_pu *cp, int cx, int cy, int l, int px, int py, uint8_t *split /*[85]*/)
@@ -422,7 +435,7 @@ static uint32_t decide_node(const kso_frame_cfg *cfg, const kso_pu *cp, int cx, 
     int idx = pu_index(l, px, py);
     uint32_t own = cp[idx].cost;
     if (l == 3) { split[idx] = 0; return own; }
-    uint64_t sum = (uint64_t)((cfg->lambda_q4 * 12) >> 4);       /* signalling overhead of three extra CUs */
+    uint64_t sum = (uint64_t)((cfg->lambda_q4 * SPLIT_BITS_P) >> 4); /* what three extra CUs cost beyond their own SATD + vector rate */
     for (int k = 0; k < 4; ++k) sum += decide_node(cfg, cp, cx, cy, l + 1, px * 2 + (k & 1), py * 2 + (k >> 1), split);
     if (own != COST_INVALID && (uint64_t)own <= sum) { split[idx] = 0; return own; }
     split[idx] = 1;
@@ -621,7 +634,7 @@ static uint32_t decide_node_b(const kso_frame_cfg *cfg, const kso_pu_b *cp, int 
     int idx = pu_index(l, px, py);
     uint32_t own = cp[idx].cost;
     if (l == 3) { split[idx] = 0; return own; }
-    uint64_t sum = (uint64_t)((cfg->lambda_q4 * 12) >> 4);
+    uint64_t sum = (uint64_t)((cfg->lambda_q4 * SPLIT_BITS_B) >> 4);
     for (int k = 0; k < 4; ++k) sum += decide_node_b(cfg, cp, cx, cy, l + 1, px * 2 + (k & 1), py * 2 + (k >> 1), split);
     if (own != COST_INVALID && (uint64_t)own <= sum) { split[idx] = 0; return own; }
     split[idx] = 1;
