@@ -319,7 +319,11 @@ int ks265_intra_decide_ex(ks265_frame *, ks265_pic src, ks265_cu8 *dev_cu8, uint
  * closed, this is the composition its kernels belong to): on HALF-RESOLUTION pictures (ks265_downsample_rect = downsample_c, then
  * ks265_pad_picture; a ks265_frame created at the half size), per 8x8 block the intra pre-selection cost against the integer-search cost
  * of the 8x8 PU.  dev_out[4] = { sum intra, sum inter, sum min(intra, inter), blocks | intra-cheaper blocks << 32 }; the host compares the
- * sums (scene cut / slice type), ks265_ac_energy_map gives the adaptive-quantisation variance map. */
+ * sums (scene cut / slice type), ks265_ac_energy_map gives the adaptive-quantisation variance map.
+ * Size rule: the half-size frame obeys ks265_frame_geometry (multiples of 8), i.e. the SOURCE must be a multiple of 16 in both directions; for other
+ * sources (1920x1080 -> 960x540) create the lookahead frame at the half size rounded DOWN to a multiple of 8 (960x536) and downsample that part of
+ * the picture: the lookahead then ignores the last source rows / columns (< 16), which the cost sums tolerate.  ks265_frame_create(…540…) returns
+ * KS265_NOTSUPPORTED. */
 int ks265_lookahead_reduce(ks265_frame *, const uint32_t *dev_intra_cost, const ks265_pu *dev_pu, uint64_t *dev_out);
 int ks265_lookahead_picture(ks265_frame *, ks265_pic cur_lowres, ks265_pic ref_lowres, uint32_t *dev_cost_ws /* nctu x 85 */, uint64_t *dev_out);
 int ks265_intra_reconstruct(ks265_frame *, ks265_pic src, ks265_cu8 *dev_cu8, int16_t *dev_lvl_y, int16_t *dev_lvl_u, int16_t *dev_lvl_v, ks265_pic recon);
