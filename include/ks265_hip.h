@@ -73,6 +73,15 @@ int ks265_event_wait(ks265_ctx *, void *ev);
  * copy-in / compute / copy-out streams of a pipelined host hand pictures over without blocking a host thread */
 int ks265_stream_wait_event(ks265_ctx *, void *ev);
 int ks265_event_destroy(ks265_ctx *, void *ev);
+/* Launch sequences as graphs: between ks265_capture_begin and ks265_capture_end everything enqueued on this context's stream by THIS thread (kernel launches,
+ * async memsets of the stage functions) is recorded instead of run (hipStreamBeginCapture, relaxed mode: other threads may go on using the runtime);
+ * ks265_capture_end returns an executable graph, ks265_graph_launch enqueues all of it with one runtime call.  A host whose pictures repeat the same
+ * launch sequence with the same device pointers (IPPP: a handful of buffer rotations) replays it instead of issuing ~20 launches per picture.  Nothing that
+ * synchronises or allocates may run inside a capture; event hand-overs to other streams stay outside. */
+int ks265_capture_begin(ks265_ctx *);
+int ks265_capture_end(ks265_ctx *, void **graph_exec);
+int ks265_graph_launch(ks265_ctx *, void *graph_exec);
+int ks265_graph_destroy(ks265_ctx *, void *graph_exec);
 /* HIP-event timing on the context's stream (bench.py roofline leg) */
 /* a one-thread kernel named ks265_marker_kernel on the context's stream: brackets a region of interest in a kernel trace (profiling aid) */
 int ks265_marker(ks265_ctx *, int id);
@@ -361,6 +370,10 @@ ks265_sao_param *ks265_frame_sao(ks265_frame *f);
 /* The records of the picture just coded as ONE contiguous block in HBM, so that a pipelined host needs one device-side copy and one D2H per
  * picture: off[0..5] = byte offsets of { CU map, levels Y, Cb, Cr, SAO records, 64 caller-defined bytes (e.g. the three SSE sums) }, each
  * aligned to 256, off[6] = size of the block.  ks265_frame_pack_records copies them there on the context's stream (dev_extra64 may be NULL). */
+/* host-side state a P picture's launch sequence depends on (bit 0: which PU buffer it writes, bit 1: a previous P picture's vectors exist) and the
+ * transition ks265_encode_picture(…, is_key = 0, …) makes - for hosts that replay a captured picture (ks265_graph_launch) instead of calling it */
+int ks265_frame_p_state(ks265_frame *);
+int ks265_frame_p_advance(ks265_frame *);
 /* A host may code key pictures on a second frame object (another context = another stream, concurrently with the P pictures of the previous GOP); the frame
  * object that continues with the P pictures must then forget its temporal predictors, as ks265_encode_picture(is_key) does itself */
 int ks265_frame_reset_prediction(ks265_frame *f);

@@ -152,6 +152,22 @@ int ks265_event_wait(ks265_ctx *c, void *ev) { return (!c || !ev) ? KS265_POINTE
 /* make everything enqueued on c's stream AFTER this call wait for the event (recorded on another context's stream): the hand-over between the
  * copy-in, compute and copy-out streams of a pipelined host; no host thread blocks */
 int ks265_stream_wait_event(ks265_ctx *c, void *ev) { return (!c || !ev) ? KS265_POINTER : ks265_hip(c, hipStreamWaitEvent(c->stream, (hipEvent_t)ev, 0)); }
+int ks265_capture_begin(ks265_ctx *c) { return !c ? KS265_POINTER : ks265_hip(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed)); }
+int ks265_capture_end(ks265_ctx *c, void **graph_exec)
+{
+    if (!c || !graph_exec) return KS265_POINTER;
+    *graph_exec = nullptr;
+    hipGraph_t g = nullptr;
+    int r = ks265_hip(c, hipStreamEndCapture(c->stream, &g));
+    if (r || !g) return r ? r : KS265_FAIL;
+    hipGraphExec_t ex = nullptr;
+    r = ks265_hip(c, hipGraphInstantiate(&ex, g, nullptr, nullptr, 0));
+    (void)hipGraphDestroy(g);
+    if (!r) *graph_exec = (void *)ex;
+    return r;
+}
+int ks265_graph_launch(ks265_ctx *c, void *graph_exec) { return (!c || !graph_exec) ? KS265_POINTER : ks265_hip(c, hipGraphLaunch((hipGraphExec_t)graph_exec, c->stream)); }
+int ks265_graph_destroy(ks265_ctx *c, void *graph_exec) { return (!c || !graph_exec) ? KS265_POINTER : ks265_hip(c, hipGraphExecDestroy((hipGraphExec_t)graph_exec)); }
 int ks265_event_destroy(ks265_ctx *c, void *ev) { return (!c || !ev) ? KS265_POINTER : ks265_hip(c, hipEventDestroy((hipEvent_t)ev)); }
 
 const char *ks265_last_error(ks265_ctx *c) { return c ? c->last_error.c_str() : "null context"; }

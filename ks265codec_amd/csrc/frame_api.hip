@@ -198,6 +198,14 @@ int ks265_frame_reset_prediction(ks265_frame *f)
     return KS265_OK;
 }
 
+int ks265_frame_p_state(ks265_frame *f) { return f ? (f->cur_pu & 1) | (f->have_prev ? 2 : 0) : -1; }
+int ks265_frame_p_advance(ks265_frame *f)
+{
+    KS_FRAME_CHECK(f);
+    f->cur_pu ^= 1; f->have_prev = true;
+    return KS265_OK;
+}
+
 int ks265_frame_set_profiling(ks265_frame *f, int enable)
 {
     KS_FRAME_CHECK(f);

@@ -216,6 +216,10 @@ typedef struct Enc {
     uint8_t *stg[NPIPE]; size_t cmp_off[8];               /* staging blocks of the (compact) records on the device and their layout */
     void *ev_staged[NPIPE], *ev_drained[NPIPE];
     long seq;                                             /* pictures submitted */
+    /* single-reference P pictures as graphs: the launch sequence of a picture (unpack, the pixel path, SSE, packing of the records: ~20 launches) only
+     * depends on a few rotating device pointers, the QP and two bits of frame state; each combination is captured once and replayed with one runtime call */
+#define MAX_GRAPHS 64
+    int use_graph, ngraph; struct { uint64_t key[8]; void *exec; } graph[MAX_GRAPHS];
     int recon_fd; uint8_t *dev_recon;                     /* reconstruction dump (the CLI's -o) */
     ks265_pic src; ks265_pic dpb[MAX_DPB]; int dpb_poc[MAX_DPB]; int ndpb; uint64_t *dev_sse;
     /* key pictures on their own stream and frame object: an intra picture keeps 34 of 256 compute units busy for ~26 ms (2160p); coded as soon as its
@@ -436,8 +440,12 @@ static int submit(Enc *e, Input *in, int kind, int poc, int qp, const int *l0, i
     ks265_pic srcp = on_key ? e->src_key : e->src;
     uint64_t *dsse = on_key ? e->dev_sse_key : e->dev_sse;
     if (!r) r = ks265_stream_wait_event(cx, e->ev_h2d[k]);
-    if (!r) r = ks265_load_i420(fr, e->dev_in[k], srcp);
-    if (!r) r = ks265_event_record(cx, e->ev_loaded[k]);
+    /* graph path: a P picture with one reference on the main stream, once the first pictures have made every lazy allocation */
+    const int graphable = e->use_graph && kind == 'P' && nl0 == 1 && !on_key && e->recon_fd < 0 && e->seq >= 8;
+    if (!graphable) {
+        if (!r) r = ks265_load_i420(fr, e->dev_in[k], srcp);
+        if (!r) r = ks265_event_record(cx, e->ev_loaded[k]);
+    }
     if (!r) r = ks265_frame_set_qp(fr, qp, kLambdaQ4[qp]);
     int keep[20], nk = 0;
     for (int i = 0; i < nkeep; ++i) keep[nk++] = keep_after[i];
@@ -453,6 +461,34 @@ static int submit(Enc *e, Input *in, int kind, int poc, int qp, const int *l0, i
     } else slot = dpb_free_slot(e, keep, nk);
     if (slot < 0) return QY_FAIL;
     ks265_pic out = e->dpb[slot];
+    if (!r && graphable) {
+        const ks265_pic refp = e->dpb[dpb_find(e, l0[0])];
+        const uint64_t key[8] = {(uint64_t)(uintptr_t)refp.y, (uint64_t)(uintptr_t)out.y, (uint64_t)(uintptr_t)e->dev_in[k], (uint64_t)(uintptr_t)e->stg[k],
+                                 (uint64_t)qp, (uint64_t)ks265_frame_p_state(fr), (uint64_t)(e->cfg.calcPsnr != 0), (uint64_t)(uintptr_t)srcp.y};
+        void *exec = NULL;
+        for (int i = 0; i < e->ngraph && !exec; ++i) if (!memcmp(e->graph[i].key, key, sizeof key)) exec = e->graph[i].exec;
+        if (recycled) r = ks265_stream_wait_event(cx, e->ev_drained[k]);       /* the staging block of this rotation slot has been copied out */
+        if (!r && exec) {
+            r = ks265_graph_launch(cx, exec);
+            if (!r) r = ks265_frame_p_advance(fr);
+        } else if (!r) {
+            const int keep_it = e->ngraph < MAX_GRAPHS;
+            if (keep_it) r = ks265_capture_begin(cx);
+            if (!r) r = ks265_load_i420(fr, e->dev_in[k], srcp);
+            if (!r) r = ks265_encode_picture(fr, srcp, refp, 0, out);
+            if (!r && e->cfg.calcPsnr) r = ks265_sse_picture(fr, srcp, out, dsse);
+            if (!r) r = ks265_frame_pack_compact(fr, e->stg[k], e->cfg.calcPsnr ? dsse : NULL);
+            if (keep_it) {
+                void *ex = NULL;
+                const int rc = ks265_capture_end(cx, &ex);                      /* also ends a capture that failed half-way */
+                if (!r) r = rc;
+                if (!r) { memcpy(e->graph[e->ngraph].key, key, sizeof key); e->graph[e->ngraph].exec = ex; ++e->ngraph; r = ks265_graph_launch(cx, ex); }
+            }
+        }
+        if (!r) r = ks265_event_record(cx, e->ev_loaded[k]);                  /* the input buffer is free again (a little later than on the plain path) */
+        if (!r) r = ks265_event_record(cx, e->ev_staged[k]);
+        e->dpb_poc[slot] = poc;
+    } else {
     if (!r) {
         if (kind == 'I') r = ks265_encode_picture(fr, srcp, out, 1, out);
         else if (kind == 'B') r = ks265_encode_picture_b(fr, srcp, e->dpb[dpb_find(e, l0[0])], e->dpb[dpb_find(e, l1[0])], out);
@@ -470,6 +506,7 @@ static int submit(Enc *e, Input *in, int kind, int poc, int qp, const int *l0, i
     if (!r && recycled) r = ks265_stream_wait_event(cx, e->ev_drained[k]);
     if (!r) r = ks265_frame_pack_compact(fr, e->stg[k], e->cfg.calcPsnr ? dsse : NULL);
     if (!r) r = ks265_event_record(cx, e->ev_staged[k]);
+    }
     if (on_key) {                                                      /* everything coded after it on the main stream waits for the key picture; its temporal predictors start over */
         if (!r) r = ks265_event_record(cx, e->ev_key);
         if (!r) r = ks265_stream_wait_event(e->ctx, e->ev_key);
@@ -717,6 +754,7 @@ static void lane_close(Enc *e, int report)
             if (e->ev_staged[k]) ks265_event_destroy(e->ctx, e->ev_staged[k]);
             if (e->ev_drained[k]) ks265_event_destroy(e->ctx, e->ev_drained[k]);
         }
+        for (int i = 0; i < e->ngraph; ++i) ks265_graph_destroy(e->ctx, e->graph[i].exec);
         ks265_dev_free(e->ctx, e->dev_sse); ks265_dev_free(e->ctx, e->dev_recon);
         if (e->recon_fd >= 0) close(e->recon_fd);
         if (e->frame) ks265_frame_destroy(e->frame);
@@ -797,6 +835,7 @@ static Enc *lane_open(QY265EncConfig *cfg, int *err)
     e->ndpb = e->hier ? 10 : e->gop_b ? 4 : e->refs + 2;
     for (int i = 0; i < e->ndpb && !r; ++i) { r = pic_alloc(e, &e->dpb[i]); e->dpb_poc[i] = -1000000; }
     e->key_overlap = getenv("KS265_NO_KEY_OVERLAP") ? 0 : 1;
+    e->use_graph = getenv("KS265_NO_GRAPH") ? 0 : 1;
     if (e->key_overlap) {
         if (!r) r = ks265_create(&e->ctx_key, dev_id);
         if (!r) r = ks265_frame_create(e->ctx_key, &e->fcfg, &e->frame_key);

@@ -135,6 +135,10 @@ def test_gop_lanes_under_a_fast_caller(tmp_path, n, iper):
         res[lanes] = json.loads(r.stdout.strip().splitlines()[-1])
         assert res[lanes]["lanes"] == lanes
     assert res[1]["md5"] == res[2]["md5"] == res[3]["md5"], res
+    # P pictures are replayed as captured graphs from the ninth picture on (ks265_capture_begin / ks265_graph_launch): same stream as the launch-by-launch path
+    r = subprocess.run([sys.executable, "-c", _LANES_DRIVER, ROOT, str(n), str(iper)], capture_output=True, text=True, timeout=120, env=dict(os.environ, KS265_GOP_LANES="1", KS265_NO_GRAPH="1"))
+    assert r.returncode == 0, r.stdout[-800:] + r.stderr[-800:]
+    assert json.loads(r.stdout.strip().splitlines()[-1])["md5"] == res[1]["md5"], "graph replay and plain launches disagree"
 
 
 class YUV(C.Structure):
