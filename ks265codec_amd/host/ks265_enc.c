@@ -216,10 +216,10 @@ typedef struct Enc {
     uint8_t *stg[NPIPE]; size_t cmp_off[8];               /* staging blocks of the (compact) records on the device and their layout */
     void *ev_staged[NPIPE], *ev_drained[NPIPE];
     long seq;                                             /* pictures submitted */
-    /* single-reference P pictures as graphs: the launch sequence of a picture (unpack, the pixel path, SSE, packing of the records: ~20 launches) only
+    /* single-reference P pictures and B pictures as graphs: the launch sequence of a picture (unpack, the pixel path, SSE, packing of the records: ~20 launches) only
      * depends on a few rotating device pointers, the QP and two bits of frame state; each combination is captured once and replayed with one runtime call */
-#define MAX_GRAPHS 64
-    int use_graph, ngraph; struct { uint64_t key[8]; void *exec; } graph[MAX_GRAPHS];
+#define MAX_GRAPHS 256
+    int use_graph, ngraph; struct { uint64_t key[9]; void *exec; } graph[MAX_GRAPHS];
     int recon_fd; uint8_t *dev_recon;                     /* reconstruction dump (the CLI's -o) */
     ks265_pic src; ks265_pic dpb[MAX_DPB]; int dpb_poc[MAX_DPB]; int ndpb; uint64_t *dev_sse;
     /* key pictures on their own stream and frame object: an intra picture keeps 34 of 256 compute units busy for ~26 ms (2160p); coded as soon as its
@@ -441,7 +441,7 @@ static int submit(Enc *e, Input *in, int kind, int poc, int qp, const int *l0, i
     uint64_t *dsse = on_key ? e->dev_sse_key : e->dev_sse;
     if (!r) r = ks265_stream_wait_event(cx, e->ev_h2d[k]);
     /* graph path: a P picture with one reference on the main stream, once the first pictures have made every lazy allocation */
-    const int graphable = e->use_graph && kind == 'P' && nl0 == 1 && !on_key && e->recon_fd < 0 && e->seq >= 8;
+    const int graphable = e->use_graph && ((kind == 'P' && nl0 == 1) || (kind == 'B' && nl0 == 1 && nl1 == 1)) && !on_key && e->recon_fd < 0 && e->seq >= 8;
     if (!graphable) {
         if (!r) r = ks265_load_i420(fr, e->dev_in[k], srcp);
         if (!r) r = ks265_event_record(cx, e->ev_loaded[k]);
@@ -462,20 +462,20 @@ static int submit(Enc *e, Input *in, int kind, int poc, int qp, const int *l0, i
     if (slot < 0) return QY_FAIL;
     ks265_pic out = e->dpb[slot];
     if (!r && graphable) {
-        const ks265_pic refp = e->dpb[dpb_find(e, l0[0])];
-        const uint64_t key[8] = {(uint64_t)(uintptr_t)refp.y, (uint64_t)(uintptr_t)out.y, (uint64_t)(uintptr_t)e->dev_in[k], (uint64_t)(uintptr_t)e->stg[k],
-                                 (uint64_t)qp, (uint64_t)ks265_frame_p_state(fr), (uint64_t)(e->cfg.calcPsnr != 0), (uint64_t)(uintptr_t)srcp.y};
+        const ks265_pic refp = e->dpb[dpb_find(e, l0[0])], ref1p = kind == 'B' ? e->dpb[dpb_find(e, l1[0])] : refp;
+        const uint64_t key[9] = {(uint64_t)(uintptr_t)refp.y, (uint64_t)(uintptr_t)out.y, (uint64_t)(uintptr_t)e->dev_in[k], (uint64_t)(uintptr_t)e->stg[k],
+                                 (uint64_t)qp, (uint64_t)ks265_frame_p_state(fr), (uint64_t)(e->cfg.calcPsnr != 0), (uint64_t)kind, (uint64_t)(uintptr_t)ref1p.y};
         void *exec = NULL;
         for (int i = 0; i < e->ngraph && !exec; ++i) if (!memcmp(e->graph[i].key, key, sizeof key)) exec = e->graph[i].exec;
         if (recycled) r = ks265_stream_wait_event(cx, e->ev_drained[k]);       /* the staging block of this rotation slot has been copied out */
         if (!r && exec) {
             r = ks265_graph_launch(cx, exec);
-            if (!r) r = ks265_frame_p_advance(fr);
+            if (!r && kind == 'P') r = ks265_frame_p_advance(fr);              /* a B picture leaves the P pictures' predictor chain alone */
         } else if (!r) {
             const int keep_it = e->ngraph < MAX_GRAPHS;
             if (keep_it) r = ks265_capture_begin(cx);
             if (!r) r = ks265_load_i420(fr, e->dev_in[k], srcp);
-            if (!r) r = ks265_encode_picture(fr, srcp, refp, 0, out);
+            if (!r) r = kind == 'B' ? ks265_encode_picture_b(fr, srcp, refp, ref1p, out) : ks265_encode_picture(fr, srcp, refp, 0, out);
             if (!r && e->cfg.calcPsnr) r = ks265_sse_picture(fr, srcp, out, dsse);
             if (!r) r = ks265_frame_pack_compact(fr, e->stg[k], e->cfg.calcPsnr ? dsse : NULL);
             if (keep_it) {

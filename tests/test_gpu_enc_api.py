@@ -92,7 +92,7 @@ class Nal(C.Structure): _fields_ = [("naltype", C.c_int), ("tid", C.c_int), ("iS
 clip = make_clip(W, H, 7, seed=3, abc=(17, 23, 9))
 cfg = (C.c_uint8 * LAY["sizeof_config"])()
 assert lib.QY265ConfigDefaultPreset(cfg, b"medium", None, b"default") == 0
-for k, v in (("wdt", W), ("hgt", H), ("fr", 50), ("rc", 0), ("qp", 34), ("iper", iper), ("bframes", 0), ("threads", 6), ("psnr", 0), ("log", 3)):
+for k, v in (("wdt", W), ("hgt", H), ("fr", 50), ("rc", 0), ("qp", 34), ("iper", iper), ("bframes", int(os.environ.get("KS_TEST_BFRAMES", "0"))), ("threads", 6), ("psnr", 0), ("log", 3)):
     assert lib.QY265ConfigParse(cfg, k.encode(), str(v).encode()) == 0
 err = C.c_int(0)
 h = C.c_void_p(lib.QY265EncoderOpen(cfg, C.byref(err))); assert h.value
@@ -117,8 +117,11 @@ while lib.QY265EncoderDelayedFrames(h):
     take()
 lanes = lib.ks265_enc_lanes(h)
 lib.QY265EncoderClose(h)
-assert pts == list(range(N)), "pictures must leave in stream order"
-assert pocs == sorted(pocs) and pocs[-1] == N - 1, pocs[-5:]
+if int(os.environ.get("KS_TEST_BFRAMES", "0")) == 0:
+    assert pts == list(range(N)), "pictures must leave in stream order"
+    assert pocs == sorted(pocs) and pocs[-1] == N - 1, pocs[-5:]
+else:
+    assert sorted(pts) == list(range(N))
 print(json.dumps({"md5": md.hexdigest(), "lanes": lanes}))
 """
 
@@ -139,6 +142,18 @@ def test_gop_lanes_under_a_fast_caller(tmp_path, n, iper):
     r = subprocess.run([sys.executable, "-c", _LANES_DRIVER, ROOT, str(n), str(iper)], capture_output=True, text=True, timeout=120, env=dict(os.environ, KS265_GOP_LANES="1", KS265_NO_GRAPH="1"))
     assert r.returncode == 0, r.stdout[-800:] + r.stderr[-800:]
     assert json.loads(r.stdout.strip().splitlines()[-1])["md5"] == res[1]["md5"], "graph replay and plain launches disagree"
+
+
+@pytest.mark.parametrize("bframes", [-1, 3])
+def test_b_pictures_replayed_as_graphs(bframes):
+    """hierarchical-B 8 and P + 3 B: from the ninth picture on P and B pictures are replayed as captured graphs (one per rotation of the buffers involved);
+    the stream equals the launch-by-launch one"""
+    md5 = {}
+    for tag, env in (("graph", {}), ("plain", {"KS265_NO_GRAPH": "1"})):
+        r = subprocess.run([sys.executable, "-c", _LANES_DRIVER, ROOT, "170", "64"], capture_output=True, text=True, timeout=120, env=dict(os.environ, KS_TEST_BFRAMES=str(bframes), **env))
+        assert r.returncode == 0, r.stdout[-800:] + r.stderr[-800:]
+        md5[tag] = json.loads(r.stdout.strip().splitlines()[-1])["md5"]
+    assert md5["graph"] == md5["plain"], md5
 
 
 class YUV(C.Structure):
