@@ -500,6 +500,51 @@ void ks265o_default_weighted_bi(uint8_t *dst, const int16_t *p0, const int16_t *
         for (int x = 0; x < width; ++x) dst[y * dstStride + x] = clip8(((int)p0[y * srcStride + x] + (int)p1[y * srcStride + x] + 64) >> 7);
 }
 
+/* enc@0x46a8a0 estBitRdoq(TEstBitsSbac &, log2 size, is luma, context states) = estCBFBit enc@0x46a480 + estSignificantCoeffGroupMapBit enc@0x46a4f0 +
+ * estSignificantMapBit enc@0x46a540 + estSignificantCoefficientsBit enc@0x46a790: the bit-estimation tables rdoQuant enc@0x4aac50 prices its decisions with
+ * (HM lineage: TComTrQuant::xRateDistOptQuant / TEncSbac::estBit).  ctx = the encoder's CABAC context states, one byte each (pStateIdx << 1 | valMps) in the
+ * reference's own order: cbf at 0x0d (+5 for chroma), coded_sub_block_flag at 0x1d (+2), sig_coeff_flag at 0x21 (luma) / 0x3c (chroma), last_sig_coeff prefix at
+ * 0x4b (x) / 0x69 (y), greater1 at 0x87 (luma, 16) / 0x97 (chroma, 8), greater2 at 0x9f (luma, 4) / 0xa3 (chroma, 2), rqt_root_cbf at 0xaa.  entropy = the 128
+ * entries of g_iEntroyBits enc@0x4e0040 (bits x 2^15 of coding bin b in state s: entropy[s ^ b]) - data, passed in: the tests take it from the fixtures.
+ * out = TEstBitsSbac as 180 words: [0..3] group flag [2][2]; [4..45] sig flag = 0 per context, [46..87] sig flag = 1; [88..97] last-x prefix bits, [98..107]
+ * last-y; [108..139] greater1 [16][2]; [156..163] greater2 [4][2]; [168..177] cbf [5][2]; [178..179] root cbf.  Words not listed keep their value.
+ * Pinned by tests/golden/estbits.npz. */
+void ks265o_est_bit_rdoq(int32_t *out, int log2, int luma, const uint8_t *ctx, const int32_t *entropy)
+{
+    const uint8_t *c = ctx + 0x0d + (luma ? 0 : 5);
+    for (int i = 0; i < 5; ++i) { out[168 + 2 * i] = entropy[c[i]]; out[169 + 2 * i] = entropy[c[i] ^ 1]; }
+    out[178] = entropy[ctx[0xaa]]; out[179] = entropy[ctx[0xaa] ^ 1];
+    c = ctx + 0x1d + (luma ? 0 : 2);
+    for (int i = 0; i < 2; ++i) { out[2 * i] = entropy[c[i]]; out[2 * i + 1] = entropy[c[i] ^ 1]; }
+    /* sig_coeff_flag: context 0 (DC) and the size's own range */
+    c = ctx + (luma ? 0x21 : 0x3c);
+    int first, end;
+    if (log2 > 3) { first = luma ? 21 : 12; end = luma ? 27 : 15; }
+    else if (log2 == 3) { first = 9; end = luma ? 21 : 12; }
+    else { first = 1; end = 9; }
+    out[4] = entropy[c[0]]; out[46] = entropy[c[0] ^ 1];
+    for (int i = first; i < end; ++i) { out[4 + i] = entropy[c[i]]; out[46 + i] = entropy[c[i] ^ 1]; }
+    /* last_sig_coeff_{x,y}_prefix: bits of "k ones then a zero", the last entry all ones */
+    const int off = luma ? 3 * log2 - 6 + ((log2 - 1) >> 2) : 15, shift = luma ? (log2 + 1) >> 2 : log2 - 2, n = 2 * log2 - 1;
+    for (int d = 0; d < 2; ++d) {
+        const uint8_t *l = ctx + 0x4b + 0x1e * d;
+        int32_t bits = 0;
+        for (int k = 0; k < n; ++k) {
+            const uint8_t s = l[off + (k >> shift)];
+            out[88 + 10 * d + k] = bits + entropy[s];
+            bits += entropy[s ^ 1];
+        }
+        out[88 + 10 * d + n] = bits;
+    }
+    if (luma) {
+        for (int i = 0; i < 16; ++i) { out[108 + 2 * i] = entropy[ctx[0x87 + i]]; out[109 + 2 * i] = entropy[ctx[0x87 + i] ^ 1]; }
+        for (int i = 0; i < 4; ++i) { out[156 + 2 * i] = entropy[ctx[0x9f + i]]; out[157 + 2 * i] = entropy[ctx[0x9f + i] ^ 1]; }
+    } else {
+        for (int i = 0; i < 8; ++i) { out[108 + 2 * i] = entropy[ctx[0x97 + i]]; out[109 + 2 * i] = entropy[ctx[0x97 + i] ^ 1]; }
+        for (int i = 0; i < 2; ++i) { out[156 + 2 * i] = entropy[ctx[0xa3 + i]]; out[157 + 2 * i] = entropy[ctx[0xa3 + i] ^ 1]; }
+    }
+}
+
 /* enc@0x4896d0 interMeBiFull_c / enc@0x4897e0 interMeBiHadFull_c (best, org, ref, orgStride, refStride, mvcost, h, log2w): the integer step of the joint
  * bi-prediction refinement (g_interMeBiFull_func / g_interMeBiHadFull_func; caller interMeBiFull_opt enc@0x4898e0).  `org` is the search target
  * clip8(2 org - pred_other) of calcBiMeOrg, `ref` the top-left corner of an 8 x 8 window of integer positions; position (x, y) costs

@@ -468,6 +468,24 @@ def gen_bifull(p: RefProbe):
     return [dict(c, exp_cost=np.uint32(call.ret & 0xFFFFFFFF), exp_best=b.out) for c, call, b in pend]
 
 
+def gen_estbits(p: RefProbe):
+    """estBitRdoq enc@0x46a8a0 (TEstBitsSbac &, log2 size, is luma, context states): the bit-estimation tables rdoQuant enc@0x4aac50 works with, built from the
+    CABAC context states (one byte each: pStateIdx << 1 | valMps) through g_iEntroyBits enc@0x4e0040.  Two kinds of cases: `table` - every context byte equals v,
+    so the outputs spell out g_iEntroyBits[v] and [v ^ 1] (the reference's 128 entropy values become fixture data); `random` - random states."""
+    pend = []
+    def one(kind, log2, luma, ctx):
+        out = Buf(np.zeros(0x2D0 // 4, np.int32))
+        pend.append((dict(kind=kind, log2=log2, luma=luma, ctx=ctx), p.call(0x46A8A0, out, log2, luma, Buf(ctx)), out))
+    for v in range(128):
+        one("table", 3, 1, np.full(256, v, np.uint8))
+    for log2 in (2, 3, 4, 5):
+        for luma in (0, 1):
+            for _ in range(3):
+                one("random", log2, luma, rng.integers(0, 126, 256).astype(np.uint8))
+    p.run()
+    return [dict(c, exp=o.out) for c, _, o in pend]
+
+
 INTRA_FUNCS = {  # name: (address, modes)  -- nm -C appencoder: h265_codec::IntraPred*_c(uchar*, int, uchar*, int, int, bool)
     "planar": (0x425AF0, [0]), "dc": (0x425D80, [1]), "chroma_dc": (0x425C60, [1]), "hor_plus_2": (0x425F60, [2]),
     "hor_plus_3_9": (0x4260E0, range(3, 10)), "hor0_10": (0x426300, [10]), "hor_minus_11_17": (0x4264C0, range(11, 18)),
@@ -573,7 +591,7 @@ FAMILIES = {
     "sad": gen_sad, "sad4": gen_sad4, "sad3": gen_sad3, "sad4blk": gen_sad4blk, "sse": gen_sse, "had": gen_had,
     "fwd_transform": gen_fwd, "inv_transform": gen_inv, "quant": gen_quant, "dequant": gen_dequant,
     "residual": gen_residual, "deblock_luma": gen_deblock_luma, "deblock_chroma": gen_deblock_chroma,
-    "interp": gen_interp, "sao_apply": gen_sao, "sao_stats": gen_sao_stats, "bipred": gen_bipred, "bifull": gen_bifull, "intra": gen_intra, "lookahead": gen_lookahead, "sbh": gen_sbh,
+    "interp": gen_interp, "sao_apply": gen_sao, "sao_stats": gen_sao_stats, "bipred": gen_bipred, "bifull": gen_bifull, "estbits": gen_estbits, "intra": gen_intra, "lookahead": gen_lookahead, "sbh": gen_sbh,
 }
 
 if __name__ == "__main__":
