@@ -374,6 +374,7 @@ ks265_sao_param *ks265_frame_sao(ks265_frame *f);
  * transition ks265_encode_picture(…, is_key = 0, …) makes - for hosts that replay a captured picture (ks265_graph_launch) instead of calling it */
 int ks265_frame_p_state(ks265_frame *);
 int ks265_frame_p_advance(ks265_frame *);
+int ks265_frame_p_restore(ks265_frame *, int state);     /* back to a state ks265_frame_p_state returned (a capture that failed after the calls were made) */
 /* A host may code key pictures on a second frame object (another context = another stream, concurrently with the P pictures of the previous GOP); the frame
  * object that continues with the P pictures must then forget its temporal predictors, as ks265_encode_picture(is_key) does itself */
 int ks265_frame_reset_prediction(ks265_frame *f);

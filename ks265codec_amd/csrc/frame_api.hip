@@ -199,6 +199,13 @@ int ks265_frame_reset_prediction(ks265_frame *f)
 }
 
 int ks265_frame_p_state(ks265_frame *f) { return f ? (f->cur_pu & 1) | (f->have_prev ? 2 : 0) : -1; }
+int ks265_frame_p_restore(ks265_frame *f, int state)
+{
+    KS_FRAME_CHECK(f);
+    if (state < 0 || state > 3) return KS265_NOTSUPPORTED;
+    f->cur_pu = state & 1; f->have_prev = (state & 2) != 0;
+    return KS265_OK;
+}
 int ks265_frame_p_advance(ks265_frame *f)
 {
     KS_FRAME_CHECK(f);

@@ -472,8 +472,9 @@ static int submit(Enc *e, Input *in, int kind, int poc, int qp, const int *l0, i
             r = ks265_graph_launch(cx, exec);
             if (!r && kind == 'P') r = ks265_frame_p_advance(fr);              /* a B picture leaves the P pictures' predictor chain alone */
         } else if (!r) {
-            const int keep_it = e->ngraph < MAX_GRAPHS;
-            if (keep_it) r = ks265_capture_begin(cx);
+            int keep_it = e->ngraph < MAX_GRAPHS;
+            const int state0 = ks265_frame_p_state(fr);
+            if (keep_it && ks265_capture_begin(cx)) { keep_it = 0; e->use_graph = 0; }   /* no capture on this runtime: launch by launch from here on */
             if (!r) r = ks265_load_i420(fr, e->dev_in[k], srcp);
             if (!r) r = kind == 'B' ? ks265_encode_picture_b(fr, srcp, refp, ref1p, out) : ks265_encode_picture(fr, srcp, refp, 0, out);
             if (!r && e->cfg.calcPsnr) r = ks265_sse_picture(fr, srcp, out, dsse);
@@ -481,8 +482,15 @@ static int submit(Enc *e, Input *in, int kind, int poc, int qp, const int *l0, i
             if (keep_it) {
                 void *ex = NULL;
                 const int rc = ks265_capture_end(cx, &ex);                      /* also ends a capture that failed half-way */
-                if (!r) r = rc;
-                if (!r) { memcpy(e->graph[e->ngraph].key, key, sizeof key); e->graph[e->ngraph].exec = ex; ++e->ngraph; r = ks265_graph_launch(cx, ex); }
+                if (!r && !rc) { memcpy(e->graph[e->ngraph].key, key, sizeof key); e->graph[e->ngraph].exec = ex; ++e->ngraph; r = ks265_graph_launch(cx, ex); }
+                else if (!r) {                                                  /* recorded but not instantiated: nothing ran.  Do the picture launch by launch, graphs off */
+                    e->use_graph = 0;
+                    r = ks265_frame_p_restore(fr, state0);
+                    if (!r) r = ks265_load_i420(fr, e->dev_in[k], srcp);
+                    if (!r) r = kind == 'B' ? ks265_encode_picture_b(fr, srcp, refp, ref1p, out) : ks265_encode_picture(fr, srcp, refp, 0, out);
+                    if (!r && e->cfg.calcPsnr) r = ks265_sse_picture(fr, srcp, out, dsse);
+                    if (!r) r = ks265_frame_pack_compact(fr, e->stg[k], e->cfg.calcPsnr ? dsse : NULL);
+                }
             }
         }
         if (!r) r = ks265_event_record(cx, e->ev_loaded[k]);                  /* the input buffer is free again (a little later than on the plain path) */
