@@ -112,7 +112,7 @@ __device__ __forceinline__ void code_region(const KsGeom &g, int comp, int qp, i
                                             const unsigned char *tu_log2 /*LDS [16]: log2 of TU size in 8x8 blocks*/, const short *Mf, const short *Mt,
                                             short *X, short *T, unsigned char *P, int *nzcnt /*LDS [16]*/, const uint8_t *src, const uint8_t *ref,
                                             const uint8_t *planes, const uint8_t *ref1, const uint8_t *planes1, int16_t *lvl, uint8_t *rec, int tid, const KsCompRefs xr,
-                                            bool sdh, short *LV, short *DU, short *CF, int *lastcg /*LDS [16]*/)
+                                            bool sdh, short *LV, short *DU, short *CF, int *lastcg /*LDS [16]*/, int dec_k)
 {
     constexpr int UNIT = RS / 4;                      // samples per 8x8-luma block along one axis
     constexpr int NQ = RS * RS / 4;                   // quads (4 adjacent samples of one row)
@@ -222,10 +222,31 @@ __device__ __forceinline__ void code_region(const KsGeom &g, int comp, int qp, i
         }
         if (coded) {
             *(uint2 *)(lvl + (long)(Y0 + qy) * lstride + X0 + qx) = make_uint2(lv[0] | ((unsigned)lv[1] << 16), lv[2] | ((unsigned)lv[3] << 16));
-            if (nz) atomicAdd(&nzcnt[tb], nz);
+            if (nz) {
+                atomicAdd(&nzcnt[tb], nz);
+                if (dec_k) {                                       // largest magnitude of the TU (lastcg is free until the sign-data hiding phase)
+                    int mx = 0;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) mx = max(mx, abs((int)(short)lv[i]));
+                    atomicMax(&lastcg[tb], mx);
+                }
+            }
         }
     }
     __syncthreads();
+    if (dec_k) {
+        // ---- cfg.decimate: a TU holding nothing but a few +-1 levels is dropped (levels zeroed in HBM, no residual, cbf 0)
+        if (tid < 16) {
+            const int d8 = 1 << tu_log2[tid], dtb = ((tid >> 2) & ~(d8 - 1)) * 4 + ((tid & 3) & ~(d8 - 1));
+            const int dl2 = tu_log2[tid] + (RS == 32 ? 3 : 2);
+            if (dtb == tid && blk[tid].log2_cu != 0 && blk[tid].pred_mode == 0 && nzcnt[tid] > 0 && lastcg[tid] <= 1 && nzcnt[tid] <= dec_k * (dl2 - 1)) nzcnt[tid] = -1;
+        }
+        __syncthreads();
+        if (coded && nzcnt[tb] < 0) *(uint2 *)(lvl + (long)(Y0 + qy) * lstride + X0 + qx) = make_uint2(0u, 0u);
+        __syncthreads();
+        if (tid < 16) { if (nzcnt[tid] < 0) nzcnt[tid] = 0; lastcg[tid] = 0; }
+        __syncthreads();
+    }
     if (sdh) {
         // ---- the postQuant seam (postQuant enc@0x4ace80): sign-data hiding, one lane per 4x4 coefficient group of the region
         constexpr int NCG = RS / 4;                                   // groups per region row
@@ -305,7 +326,7 @@ template <bool MREF>
 __global__ __launch_bounds__(256) void reconstruct_kernel(KsGeom g, int qp, const uint8_t *src_y, const uint8_t *src_u, const uint8_t *src_v,
                                                           const uint8_t *ref_y, const uint8_t *ref_u, const uint8_t *ref_v, const uint8_t *planes,
                                                           const uint8_t *ref1_y, const uint8_t *ref1_u, const uint8_t *ref1_v, const uint8_t *planes1, ks265_cu8 *cu8,
-                                                          int16_t *lvl_y, int16_t *lvl_u, int16_t *lvl_v, uint8_t *rec_y, uint8_t *rec_u, uint8_t *rec_v, const short *mats, const KsRefExtra xr, int sdh_on)
+                                                          int16_t *lvl_y, int16_t *lvl_u, int16_t *lvl_v, uint8_t *rec_y, uint8_t *rec_u, uint8_t *rec_v, const short *mats, const KsRefExtra xr, int sdh_on, int dec_k)
 {
     __shared__ __attribute__((aligned(16))) short Mf[MAT_SHORTS];
     __shared__ __attribute__((aligned(16))) short Mt[MAT_SHORTS];
@@ -340,19 +361,19 @@ __global__ __launch_bounds__(256) void reconstruct_kernel(KsGeom g, int qp, cons
     }
     __syncthreads();
     const int qpc = chroma_qp(qp);
-    code_region<32, MREF>(g, 0, qp, rx * 4, ry * 4, blk, tu_log2, Mf, Mt, X, T, P, nzcnt, src_y, ref_y, planes, ref1_y, planes1, lvl_y, rec_y, tid, xr.y, sdh, LV, DU, CF, lastcg);
+    code_region<32, MREF>(g, 0, qp, rx * 4, ry * 4, blk, tu_log2, Mf, Mt, X, T, P, nzcnt, src_y, ref_y, planes, ref1_y, planes1, lvl_y, rec_y, tid, xr.y, sdh, LV, DU, CF, lastcg, dec_k);
     if (tid < 16 && blk[tid].log2_cu) {
         const int t8 = 1 << tu_log2[tid], tb = ((tid >> 2) & ~(t8 - 1)) * 4 + ((tid & 3) & ~(t8 - 1));
         if (nzcnt[tb]) cbf[tid] |= 1;
     }
     __syncthreads();
-    code_region<16, MREF>(g, 1, qpc, rx * 4, ry * 4, blk, tu_log2, Mf, Mt, X, T, P, nzcnt, src_u, ref_u, planes, ref1_u, planes1, lvl_u, rec_u, tid, xr.u, sdh, LV, DU, CF, lastcg);
+    code_region<16, MREF>(g, 1, qpc, rx * 4, ry * 4, blk, tu_log2, Mf, Mt, X, T, P, nzcnt, src_u, ref_u, planes, ref1_u, planes1, lvl_u, rec_u, tid, xr.u, sdh, LV, DU, CF, lastcg, dec_k);
     if (tid < 16 && blk[tid].log2_cu) {
         const int t8 = 1 << tu_log2[tid], tb = ((tid >> 2) & ~(t8 - 1)) * 4 + ((tid & 3) & ~(t8 - 1));
         if (nzcnt[tb]) cbf[tid] |= 2;
     }
     __syncthreads();
-    code_region<16, MREF>(g, 2, qpc, rx * 4, ry * 4, blk, tu_log2, Mf, Mt, X, T, P, nzcnt, src_v, ref_v, planes, ref1_v, planes1, lvl_v, rec_v, tid, xr.v, sdh, LV, DU, CF, lastcg);
+    code_region<16, MREF>(g, 2, qpc, rx * 4, ry * 4, blk, tu_log2, Mf, Mt, X, T, P, nzcnt, src_v, ref_v, planes, ref1_v, planes1, lvl_v, rec_v, tid, xr.v, sdh, LV, DU, CF, lastcg, dec_k);
     if (tid < 16 && blk[tid].log2_cu) {
         const int t8 = 1 << tu_log2[tid], tb = ((tid >> 2) & ~(t8 - 1)) * 4 + ((tid & 3) & ~(t8 - 1));
         if (nzcnt[tb]) cbf[tid] |= 4;
@@ -366,7 +387,7 @@ static int launch_reconstruct(ks265_frame *f, ks265_pic src, ks265_pic ref0, con
 {
     dim3 grid(((f->g.W + 31) / 32) * ((f->g.H + 31) / 32));
     hipLaunchKernelGGL(reconstruct_kernel<false>, grid, dim3(256), 0, f->ctx->stream, f->g, f->cfg.qp, src.y, src.u, src.v, ref0.y, ref0.u, ref0.v, planes0, ref1.y,
-                       ref1.u, ref1.v, planes1, cu8, lvl_y, lvl_u, lvl_v, recon.y, recon.u, recon.v, f->mats, KsRefExtra{}, f->cfg.sdh);
+                       ref1.u, ref1.v, planes1, cu8, lvl_y, lvl_u, lvl_v, recon.y, recon.u, recon.v, f->mats, KsRefExtra{}, f->cfg.sdh, f->cfg.decimate);
     return ks265_check_launch(f->ctx);
 }
 
@@ -386,7 +407,7 @@ extern "C" int ks265_reconstruct_mref(ks265_frame *f, ks265_pic src, int nref, c
     dim3 grid(((f->g.W + 31) / 32) * ((f->g.H + 31) / 32));
     hipLaunchKernelGGL(reconstruct_kernel<true>, grid, dim3(256), 0, f->ctx->stream, f->g, f->cfg.qp, src.y, src.u, src.v, refs[0].y, refs[0].u, refs[0].v, planes[0],
                        (const uint8_t *)nullptr, (const uint8_t *)nullptr, (const uint8_t *)nullptr, (const uint8_t *)nullptr, cu8, lvl_y, lvl_u, lvl_v, recon.y, recon.u,
-                       recon.v, f->mats, xr, f->cfg.sdh);
+                       recon.v, f->mats, xr, f->cfg.sdh, f->cfg.decimate);
     return ks265_check_launch(f->ctx);
 }
 

@@ -821,6 +821,7 @@ static Enc *lane_open(QY265EncConfig *cfg, int *err)
     e->fcfg.sdh = 1;                                                    /* the reference's streams have sign_data_hiding_enabled_flag = 1 at every preset */
     e->fcfg.pre_search = 1;                                             /* stage A0: pyramid pre-search vectors as start candidates of the integer search */
     e->fcfg.merge = 1;                                                  /* stage C2: merge pass on the motion field (pictures with one reference per list) */
+    e->fcfg.decimate = 2;                                               /* inter TUs holding only a few +-1 levels are dropped (ks265_frame_cfg.decimate) */
     e->fcfg.bi_refine = 1;                                              /* B pictures: joint refinement of the bi-predictive pair (motionSearchBI enc@0x484910) */
     r = ks265_frame_geometry(&e->fcfg, &e->geom);
     if (!r) r = ks265_frame_create(e->ctx, &e->fcfg, &e->frame);

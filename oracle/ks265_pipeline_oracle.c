@@ -701,7 +701,7 @@ static int tu_scan_idx(int intra, int mode, int n, int is_chroma)
 }
 /* sdh: the postQuant seam (postQuant enc@0x4ace80) - after the quantiser, before dequantisation: sign-data hiding with the TU's scan */
 static int code_tu(const uint8_t *org, int so, const uint8_t *pred /*packed n*/, int n, int qp, int intra, int16_t *lvl, int lstride,
-                   uint8_t *rec, int rstride, int sdh, int scan_idx)
+                   uint8_t *rec, int rstride, int sdh, int scan_idx, int decimate)
 {
     int16_t res[32 * 32], coef[32 * 32], lv[32 * 32], du[32 * 32], dq[32 * 32], tmp[32 * 32];
     int log2n = n == 4 ? 2 : n == 8 ? 3 : n == 16 ? 4 : 5, idx = log2n - 1;   /* DCT table index (DST4 is intra-luma-4x4 only) */
@@ -711,6 +711,13 @@ static int code_tu(const uint8_t *org, int so, const uint8_t *pred /*packed n*/,
     ks265o_get_base_quant_param(qp, intra ? 2 : 0, &p);
     int qbits = p.qbits - log2n;
     int nz = ks265o_quant(coef, lv, n, p.scale, p.offF << (qbits - 9), qbits, du, n);
+    /* cfg->decimate = K > 0 (inter TUs): a block whose levels are all +-1 and at most K (4x4), 2K (8x8), 3K (16x16), 4K (32x32) of them is not worth its bits - the
+     * levels are dropped, the block becomes prediction only (x264-lineage coefficient decimation; where the reference does this is inside its closed RD code) */
+    if (decimate > 0 && !intra && nz > 0 && nz <= decimate * (log2n - 1)) {
+        int mx = 0;
+        for (int i = 0; i < n * n; ++i) { const int a = lv[i] < 0 ? -lv[i] : lv[i]; if (a > mx) mx = a; }
+        if (mx <= 1) { memset(lv, 0, sizeof(int16_t) * (size_t)(n * n)); nz = 0; }
+    }
     if (sdh && nz > 1) nz = ks265o_sign_bit_hiding(lv, coef, du, n, log2n, scan_idx);
     for (int y = 0; y < n; ++y) memcpy(lvl + (long)y * lstride, lv + y * n, sizeof(int16_t) * (size_t)n);
     if (!nz) {
@@ -785,7 +792,7 @@ static void reconstruct_impl(const kso_frame_cfg *cfg, kso_pic src, const kso_pi
                 for (int y = 0; y < n; ++y) memcpy(pred + y * n, pl + (long)y * sy, (size_t)n);
             }
             cbf |= code_tu(org_y(&g, src.y) + (long)y0 * sy + x0, (int)sy, pred, n, qp, intra, lvl_y + (long)y0 * W + x0, W,
-                           org_y(&g, recon.y) + (long)y0 * sy + x0, (int)sy, cfg->sdh, 0);
+                           org_y(&g, recon.y) + (long)y0 * sy + x0, (int)sy, cfg->sdh, 0, cfg->decimate);
             /* chroma: 4-tap 1/8-sample MC (interpChroma* enc@0x4111c0..), TU n/2 */
             int nc = n / 2, xc = x0 / 2, yc = y0 / 2;
             for (int comp = 0; comp < 2; ++comp) {
@@ -812,7 +819,7 @@ static void reconstruct_impl(const kso_frame_cfg *cfg, kso_pic src, const kso_pi
                 int16_t *lv = (comp ? lvl_v : lvl_u) + (long)yc * (W / 2) + xc;
                 uint8_t *rc = org_c(&g, comp ? recon.v : recon.u) + (long)yc * sc + xc;
                 const uint8_t *oc = org_c(&g, comp ? src.v : src.u) + (long)yc * sc + xc;
-                if (code_tu(oc, (int)sc, pred, nc, qpc, intra, lv, W / 2, rc, (int)sc, cfg->sdh, 0)) cbf |= 2 << comp;
+                if (code_tu(oc, (int)sc, pred, nc, qpc, intra, lv, W / 2, rc, (int)sc, cfg->sdh, 0, cfg->decimate)) cbf |= 2 << comp;
             }
             for (int yy = 0; yy < tu8; ++yy)
                 for (int xx = 0; xx < tu8; ++xx) cu8[(long)(by + yy) * w8 + bx + xx].cbf = (uint8_t)cbf;
@@ -1188,7 +1195,7 @@ static void intra_code_cu(const kso_frame_cfg *cfg, const kso_frame_geom *g, kso
     if (intra_filter_flag(mode, n)) { ks265o_intra_filter_ref(raw + 2 * n, fil + 2 * n, n, 1); r = fil + 2 * n; }
     ks265o_intra_pred(pred, n, r, mode, log2, 1);
     cbf |= code_tu(org_y(g, src.y) + (long)y0 * sy + x0, (int)sy, pred, n, qp, 1, lvl_y + (long)y0 * W + x0, W, Ry + (long)y0 * sy + x0, (int)sy, cfg->sdh,
-                   tu_scan_idx(1, mode, n, 0));
+                   tu_scan_idx(1, mode, n, 0), 0);
     int nc = n / 2, xc = x0 / 2, yc = y0 / 2;
     for (int comp = 0; comp < 2; ++comp) {
         uint8_t *Rc = org_c(g, comp ? recon.v : recon.u);
@@ -1196,7 +1203,7 @@ static void intra_code_cu(const kso_frame_cfg *cfg, const kso_frame_geom *g, kso
         ks265o_intra_pred(pred, nc, raw + 2 * nc, mode, log2 - 1, 0);
         int16_t *lv = (comp ? lvl_v : lvl_u) + (long)yc * (W / 2) + xc;
         const uint8_t *oc = org_c(g, comp ? src.v : src.u) + (long)yc * sc + xc;
-        if (code_tu(oc, (int)sc, pred, nc, qpc, 1, lv, W / 2, Rc + (long)yc * sc + xc, (int)sc, cfg->sdh, tu_scan_idx(1, mode, nc, 1))) cbf |= 2 << comp;
+        if (code_tu(oc, (int)sc, pred, nc, qpc, 1, lv, W / 2, Rc + (long)yc * sc + xc, (int)sc, cfg->sdh, tu_scan_idx(1, mode, nc, 1), 0)) cbf |= 2 << comp;
     }
     for (int yy = 0; yy < n / 8; ++yy)
         for (int xx = 0; xx < n / 8; ++xx) cu8[(long)(by + yy) * w8 + bx + xx].cbf = (uint8_t)cbf;

@@ -18,7 +18,7 @@ extern "C" {
 #endif
 
 typedef struct {
-    int32_t width, height, qp, lambda_q4, me_range, me_method, subme, deblock, sao, beta_offset_div2, tc_offset_div2, bframes, refs, me_hex_thr, sdh, pre_search, merge, bi_refine;
+    int32_t width, height, qp, lambda_q4, me_range, me_method, subme, deblock, sao, beta_offset_div2, tc_offset_div2, bframes, refs, me_hex_thr, sdh, pre_search, merge, bi_refine, decimate;
 } kso_frame_cfg;
 
 typedef struct {

@@ -232,8 +232,8 @@ def test_b_pictures_match_oracle(ks, W, H, seed, me, refine):
     from oracle_lib import OraclePipeline
 
     clip = make_clip(W, H, 5, seed=seed, abc=(17, 23, 9))
-    o = OraclePipeline(W, H, 27, lambda_q4(27), me_method=me, bi_refine=refine)
-    f = KsFrame(ks, W, H, 27, lambda_q4(27), me_method=me, bframes=3, bi_refine=refine)
+    o = OraclePipeline(W, H, 27, lambda_q4(27), me_method=me, bi_refine=refine, decimate=2 * refine)       # refine = 1 also switches the coefficient decimation on
+    f = KsFrame(ks, W, H, 27, lambda_q4(27), me_method=me, bframes=3, bi_refine=refine, decimate=2 * refine)
     g = f.geom
     org_y, org_c = g.pad_y * g.stride_y + g.pad_y, g.pad_c * g.stride_c + g.pad_c
     src = f.new_pic()
