@@ -232,8 +232,8 @@ typedef struct {
     int32_t bi_refine;         /* 1 = B pictures: joint refinement of the bi-predictive pair inside ks265_bi_decide (motionSearchBI enc@0x484910): the cheaper
                                   list stays, the other one is searched again against clip8(2 org - pred) (calcBiMeOrg enc@0x47b1a0) over the 8 x 8 integer
                                   window of interMeBiFull enc@0x4896d0 / interMeBiFull_opt enc@0x4898e0, then over the sub-pel ring */
-    int32_t decimate;          /* K > 0: coefficient decimation at the postQuant seam of inter TUs - a block whose levels are all +-1 and at most K (4x4), 2K (8x8),
-                                  3K (16x16), 4K (32x32) of them is dropped (prediction only, cbf 0); the encoder host uses 2.  Where the reference makes this kind of
+    int32_t decimate;          /* K > 0: coefficient decimation at the postQuant seam of inter LUMA TUs - a block whose levels are all +-1 and at most 2K (8x8),
+                                  3K (16x16), 4K (32x32) of them is dropped (prediction only, cbf 0); chroma is left alone; the encoder host uses 2.  Where the reference makes this kind of
                                   decision is inside its closed RD code (tuDecision enc@0x4825a0 lineage); measured effect: DESIGN.md 8 */
 } ks265_frame_cfg;
 

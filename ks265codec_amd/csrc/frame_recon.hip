@@ -235,7 +235,7 @@ __device__ __forceinline__ void code_region(const KsGeom &g, int comp, int qp, i
     }
     __syncthreads();
     if (dec_k) {
-        // ---- cfg.decimate: a TU holding nothing but a few +-1 levels is dropped (levels zeroed in HBM, no residual, cbf 0)
+        // ---- cfg.decimate (luma only: the chroma calls pass 0): a TU holding nothing but a few +-1 levels is dropped (levels zeroed in HBM, no residual, cbf 0)
         if (tid < 16) {
             const int d8 = 1 << tu_log2[tid], dtb = ((tid >> 2) & ~(d8 - 1)) * 4 + ((tid & 3) & ~(d8 - 1));
             const int dl2 = tu_log2[tid] + (RS == 32 ? 3 : 2);
@@ -367,13 +367,13 @@ __global__ __launch_bounds__(256) void reconstruct_kernel(KsGeom g, int qp, cons
         if (nzcnt[tb]) cbf[tid] |= 1;
     }
     __syncthreads();
-    code_region<16, MREF>(g, 1, qpc, rx * 4, ry * 4, blk, tu_log2, Mf, Mt, X, T, P, nzcnt, src_u, ref_u, planes, ref1_u, planes1, lvl_u, rec_u, tid, xr.u, sdh, LV, DU, CF, lastcg, dec_k);
+    code_region<16, MREF>(g, 1, qpc, rx * 4, ry * 4, blk, tu_log2, Mf, Mt, X, T, P, nzcnt, src_u, ref_u, planes, ref1_u, planes1, lvl_u, rec_u, tid, xr.u, sdh, LV, DU, CF, lastcg, 0);
     if (tid < 16 && blk[tid].log2_cu) {
         const int t8 = 1 << tu_log2[tid], tb = ((tid >> 2) & ~(t8 - 1)) * 4 + ((tid & 3) & ~(t8 - 1));
         if (nzcnt[tb]) cbf[tid] |= 2;
     }
     __syncthreads();
-    code_region<16, MREF>(g, 2, qpc, rx * 4, ry * 4, blk, tu_log2, Mf, Mt, X, T, P, nzcnt, src_v, ref_v, planes, ref1_v, planes1, lvl_v, rec_v, tid, xr.v, sdh, LV, DU, CF, lastcg, dec_k);
+    code_region<16, MREF>(g, 2, qpc, rx * 4, ry * 4, blk, tu_log2, Mf, Mt, X, T, P, nzcnt, src_v, ref_v, planes, ref1_v, planes1, lvl_v, rec_v, tid, xr.v, sdh, LV, DU, CF, lastcg, 0);
     if (tid < 16 && blk[tid].log2_cu) {
         const int t8 = 1 << tu_log2[tid], tb = ((tid >> 2) & ~(t8 - 1)) * 4 + ((tid & 3) & ~(t8 - 1));
         if (nzcnt[tb]) cbf[tid] |= 4;

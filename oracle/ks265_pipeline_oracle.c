@@ -711,8 +711,11 @@ static int code_tu(const uint8_t *org, int so, const uint8_t *pred /*packed n*/,
     ks265o_get_base_quant_param(qp, intra ? 2 : 0, &p);
     int qbits = p.qbits - log2n;
     int nz = ks265o_quant(coef, lv, n, p.scale, p.offF << (qbits - 9), qbits, du, n);
-    /* cfg->decimate = K > 0 (inter TUs): a block whose levels are all +-1 and at most K (4x4), 2K (8x8), 3K (16x16), 4K (32x32) of them is not worth its bits - the
-     * levels are dropped, the block becomes prediction only (x264-lineage coefficient decimation; where the reference does this is inside its closed RD code) */
+    /* cfg->decimate = K > 0 (inter LUMA TUs): a block whose levels are all +-1 and at most 2K (8x8), 3K (16x16), 4K (32x32) of them is not worth its bits - the
+     * levels are dropped, the block becomes prediction only (x264-lineage coefficient decimation; where the reference does this is inside its closed RD code).
+     * Chroma is left alone: measured with this oracle + the stream writer over 19 P pictures (416x240, 832x480; qp 27), K = 2 on chroma saved 1 % of the bytes
+     * and cost 2.4 - 3.2 dB of chroma PSNR (nearly all chroma levels are +-1); luma only: -10 % / -18 % of the bytes for -0.31 / -0.37 dB PSNR-Y (one QP step
+     * is -17 % for -0.71 dB). */
     if (decimate > 0 && !intra && nz > 0 && nz <= decimate * (log2n - 1)) {
         int mx = 0;
         for (int i = 0; i < n * n; ++i) { const int a = lv[i] < 0 ? -lv[i] : lv[i]; if (a > mx) mx = a; }
@@ -819,7 +822,7 @@ static void reconstruct_impl(const kso_frame_cfg *cfg, kso_pic src, const kso_pi
                 int16_t *lv = (comp ? lvl_v : lvl_u) + (long)yc * (W / 2) + xc;
                 uint8_t *rc = org_c(&g, comp ? recon.v : recon.u) + (long)yc * sc + xc;
                 const uint8_t *oc = org_c(&g, comp ? src.v : src.u) + (long)yc * sc + xc;
-                if (code_tu(oc, (int)sc, pred, nc, qpc, intra, lv, W / 2, rc, (int)sc, cfg->sdh, 0, cfg->decimate)) cbf |= 2 << comp;
+                if (code_tu(oc, (int)sc, pred, nc, qpc, intra, lv, W / 2, rc, (int)sc, cfg->sdh, 0, 0)) cbf |= 2 << comp;      /* no decimation of chroma: see code_tu */
             }
             for (int yy = 0; yy < tu8; ++yy)
                 for (int xx = 0; xx < tu8; ++xx) cu8[(long)(by + yy) * w8 + bx + xx].cbf = (uint8_t)cbf;
