@@ -684,7 +684,7 @@ def encoded_line(args, enc, world, hot, cpu):
                    "in_the_path": "pyramid pre-search, merge pass (merge / skip decided on SATD + rate, signalled where the motion equals a merge candidate), AMVP with the better of the two "
                                   "predictors, joint refinement of bi-predictive pairs (B pictures), sign-data hiding (signBitHidingHDQ); P / B pictures replayed as captured HIP graphs",
                    "not_in_the_path": "rate-distortion optimised quantisation (the reference's -rdoq at -preset slow), skip / CU size judged with the residual's cost, intra CUs in P/B pictures, "
-                                      "lookahead / cuTree: at equal PSNR the stream is 1.8x (IPPP) to 3.4x (hierarchical B) the size of appencoder's (BASELINE.md 2b has the same-clip table)",
+                                      "lookahead / cuTree: at equal PSNR the stream is 1.7x (IPPP) to 3.2x (hierarchical B) the size of appencoder's (BASELINE.md 2b has the same-clip table)",
                    "sharding": (f"ONE job of {enc['job']['frames']} pictures = {enc['job']['gops']} closed GOPs dealt to the ranks in contiguous runs; every rank encodes its GOPs, the coded bytes are "
                                 f"gathered on rank 0 in stream order (the only exchange step; inside the timed region); stream md5 {enc['md5']}") if strong else
                                "one encoder per GPU (rank), each on its own synthetic clip = its own closed GOPs; no data-path collective"},
