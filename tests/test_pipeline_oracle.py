@@ -153,3 +153,43 @@ def test_intra_picture_properties():
     rec = o.encode_picture(pic, True)
     nzl = int((o.lvl[0] != 0).sum())
     assert psnr(pic[:W * H], rec[:W * H]) > 40.0 and nzl < W * H // 40, nzl
+
+
+def test_bi_refinement_and_decimation_properties():
+    """the two late tools of round 2 at the oracle level (the GPU tests compare the kernels with exactly these functions):
+      * cfg.bi_refine never raises a PU's cost, only touches bi-predictive PUs' vectors, and keeps them inside the planes' margin;
+      * cfg.decimate only removes levels: where a luma TU is dropped its levels are all zero and the CU's luma cbf is clear, every other level is untouched when the
+        motion is the same (first P picture after the key picture), chroma levels are never touched."""
+    W, H = 200, 136
+    clip = make_clip(W, H, 5, seed=6, abc=(17, 23, 9))
+    pubs = {}
+    for r in (0, 1):
+        o = OraclePipeline(W, H, 27, lambda_q4(27), me_method=1, bi_refine=r)
+        d = {0: o.encode(clip[0], "I")}
+        o.set_qp(28, lambda_q4(28)); d[4] = o.encode(clip[4], "P", d[0])
+        o.set_qp(30, lambda_q4(30)); o.encode(clip[2], "B", d[0], d[4])
+        pubs[r] = (o.pub.copy(), o.pu.copy(), o.pu1.copy())
+    a, b = pubs[0][0], pubs[1][0]
+    valid = a["cost"] != 0xFFFFFFFF
+    assert (b["cost"][valid] <= a["cost"][valid]).all() and (b["cost"][valid] < a["cost"][valid]).any()
+    moved = valid & ((a["mvx"] != b["mvx"]) | (a["mvy"] != b["mvy"]) | (a["mv1x"] != b["mv1x"]) | (a["mv1y"] != b["mv1y"]))
+    assert moved.any() and (b["inter_dir"][moved] == 3).all()
+    for k in ("mvx", "mv1x"):
+        assert (np.abs(b[k][valid].astype(int)) <= 4 * (W + 80)).all()
+    # decimation: same key picture, same motion search on the first P picture -> only levels of dropped luma TUs differ
+    lv = {}
+    for k in (0, 2):
+        o = OraclePipeline(W, H, 30, lambda_q4(30), me_method=1, decimate=k)
+        d0 = o.encode(clip[0], "I")
+        o.set_qp(31, lambda_q4(31)); o.encode(clip[1], "P", d0)
+        lv[k] = ([x.copy() for x in o.lvl], o.cu8.copy())
+    y0, y2 = lv[0][0][0].reshape(H, W), lv[2][0][0].reshape(H, W)
+    changed = y0 != y2
+    assert changed.any() and (y2[changed] == 0).all() and (np.abs(y0[changed]) == 1).all()
+    assert (lv[0][0][1] == lv[2][0][1]).all() and (lv[0][0][2] == lv[2][0][2]).all()
+    cu0, cu2 = lv[0][1].reshape(H // 8, W // 8), lv[2][1].reshape(H // 8, W // 8)
+    blk = changed.reshape(H // 8, 8, W // 8, 8).any(axis=(1, 3))
+    assert ((cu2["cbf"][blk] & 1) == 0).all() and ((cu0["cbf"][blk] & 1) == 1).all()
+    diff = cu0["cbf"] != cu2["cbf"]                                  # a dropped 16x16 / 32x32 TU clears the flag of all its 8x8 blocks
+    assert blk[diff | blk].any() and ((cu2["cbf"][diff] & 1) == 0).all() and ((cu0["cbf"][diff] & 1) == 1).all()
+    assert ((cu0["cbf"] & 6) == (cu2["cbf"] & 6)).all()
