@@ -500,6 +500,35 @@ void ks265o_default_weighted_bi(uint8_t *dst, const int16_t *p0, const int16_t *
         for (int x = 0; x < width; ++x) dst[y * dstStride + x] = clip8(((int)p0[y * srcStride + x] + (int)p1[y * srcStride + x] + 64) >> 7);
 }
 
+/* CalcBsInterP enc@0x402960 / CalcBsInterB enc@0x4029d0 (TNborData *p, TNborData *q, int transform edge): boundary strength of the edge between two blocks
+ * (H.265 8.7.2.4 in the reference's data layout).  A block record is three words: word 0 - bits 2..3 lists used (0 = intra), bits 16..19 / 20..23 the reference
+ * PICTURE id of list 0 / 1 (ids compare across lists), bit 24 coded residual; bytes 4..7 the list-0 vector, 8..11 the list-1 vector (quarter samples).
+ * 2 if p is intra (the callers pass the pair both ways round); 1 on a transform edge with residual on either side; 1 if the blocks use different reference
+ * pictures or a different number of vectors, or any paired vector component differs by 4 or more; for two bi-predictive blocks on the same two pictures both
+ * pairings count when the two pictures are one.  The P variant looks at list 0 only.  Pinned by tests/golden/bs.npz (800 cases). */
+static int bs_far(const int16_t *a, const int16_t *b) { return iabs(a[0] - b[0]) > 3 || iabs(a[1] - b[1]) > 3; }
+int ks265o_calc_bs(const int32_t *p, const int32_t *q, int tu_edge, int is_b)
+{
+    const uint32_t wp = (uint32_t)p[0], wq = (uint32_t)q[0];
+    const int16_t *mp = (const int16_t *)p + 2, *mq = (const int16_t *)q + 2;          /* [0..1] list 0, [2..3] list 1 */
+    if (!(wp & 0xc)) return 2;
+    if ((((wp | wq) >> 24) & 1) && tu_edge) return 1;
+    if (!is_b) return ((wp ^ wq) & 0xf0000) ? 1 : bs_far(mp, mq);
+    const unsigned lp = (wp >> 2) & 3, lq = (wq >> 2) & 3;
+    if ((lp == 3) != (lq == 3)) return 1;                                              /* one vector against two */
+    if (lp != 3) {                                                                      /* one vector each, whichever list it lives in */
+        const int ip = lp >> 1, iq = lq >> 1;
+        if (((wp >> (16 + 4 * ip)) & 15) != ((wq >> (16 + 4 * iq)) & 15)) return 1;
+        return bs_far(mp + 2 * ip, mq + 2 * iq);
+    }
+    const unsigned p0 = (wp >> 16) & 15, p1 = (wp >> 20) & 15, q0 = (wq >> 16) & 15, q1 = (wq >> 20) & 15;
+    const int straight = p0 == q0 && p1 == q1, crossed = p0 == q1 && p1 == q0;
+    if (!straight && !crossed) return 1;
+    const int far_straight = bs_far(mp, mq) || bs_far(mp + 2, mq + 2), far_crossed = bs_far(mp, mq + 2) || bs_far(mp + 2, mq);
+    if (p0 == p1) return far_straight && far_crossed;                                   /* both pictures are one: either pairing may match */
+    return straight ? far_straight : far_crossed;
+}
+
 /* enc@0x46a8a0 estBitRdoq(TEstBitsSbac &, log2 size, is luma, context states) = estCBFBit enc@0x46a480 + estSignificantCoeffGroupMapBit enc@0x46a4f0 +
  * estSignificantMapBit enc@0x46a540 + estSignificantCoefficientsBit enc@0x46a790: the bit-estimation tables rdoQuant enc@0x4aac50 prices its decisions with
  * (HM lineage: TComTrQuant::xRateDistOptQuant / TEncSbac::estBit).  ctx = the encoder's CABAC context states, one byte each (pStateIdx << 1 | valMps) in the

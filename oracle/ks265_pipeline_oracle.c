@@ -882,6 +882,9 @@ static int edge_bs(const kso_cu8 *p, const kso_cu8 *q, int pos8 /*edge position 
     return 0;
 }
 
+/* test hook: the boundary strength this pipeline gives an edge (tests/test_oracle_golden.py holds it against ks265o_calc_bs, the restatement pinned on the reference) */
+int kso_test_edge_bs(const kso_cu8 *p, const kso_cu8 *q, int pos8) { return edge_bs(p, q, pos8); }
+
 void kso_deblock(const kso_frame_cfg *cfg, const kso_cu8 *cu8, kso_pic recon)
 {
     kso_frame_geom g; kso_frame_geometry(cfg, &g);

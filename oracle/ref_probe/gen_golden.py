@@ -486,6 +486,43 @@ def gen_estbits(p: RefProbe):
     return [dict(c, exp=o.out) for c, _, o in pend]
 
 
+def gen_bs(p: RefProbe):
+    """CalcBsInterP enc@0x402960 / CalcBsInterB enc@0x4029d0 (TNborData *p, TNborData *q, int transform edge): the boundary strength of an edge between two
+    blocks.  TNborData, as the two functions read it: word 0 - bits 2..3 lists used (0 = intra), bits 16..19 / 20..23 reference picture id of list 0 / 1,
+    bit 24 coded residual; then the vectors: list 0 (x, y) at bytes 4, 6, list 1 at 8, 10.  Other bits of word 0 are filled with noise (they are not read)."""
+    pend = []
+    def nbor(lists, r0, r1, cbf, mv):
+        w0 = (lists << 2) | (r0 << 16) | (r1 << 20) | (cbf << 24) | (int(rng.integers(0, 4))) | (int(rng.integers(0, 0x1000)) << 4 & 0xFFF0) | (int(rng.integers(0, 64)) << 25 & 0xFE000000)
+        a = np.zeros(3, np.int32)
+        a[0] = np.int32(np.uint32(w0 & 0xFFFFFFFF).view(np.int32)) if False else np.array([w0 & 0xFFFFFFFF], np.uint32).view(np.int32)[0]
+        b = a.view(np.int16)
+        b[2:6] = mv
+        return a
+    for is_b in (0, 1):
+        for i in range(400):
+            lists_p = int(rng.integers(0, 4)) if is_b else int(rng.integers(0, 2))
+            lists_q = int(rng.integers(1, 4)) if is_b else 1
+            if i % 3 == 0: lists_q = lists_p if lists_p else lists_q            # same structure: the vector / reference comparisons are reached
+            nref = 2 if i % 2 else 3
+            r = rng.integers(0, nref, 4)
+            base = rng.integers(-40, 41, 4).astype(np.int16)
+            kind = i % 5
+            if kind == 0: d = np.zeros(4, np.int16)
+            elif kind == 1: d = rng.integers(-3, 4, 4).astype(np.int16)          # inside the one-sample limit
+            elif kind == 2: d = rng.integers(-4, 5, 4).astype(np.int16)          # on the limit
+            else: d = rng.integers(-9, 10, 4).astype(np.int16)
+            mvq = base + d
+            if is_b and i % 4 == 1: mvq = np.array([base[2] + d[0], base[3] + d[1], base[0] + d[2], base[1] + d[3]], np.int16)   # crossed pairing
+            P = nbor(lists_p, int(r[0]), int(r[1]), int(rng.integers(0, 2)) if i % 7 == 0 else 0, base)
+            Q = nbor(lists_q, int(r[2]) if i % 3 else int(r[0]), int(r[3]) if i % 3 else int(r[1]), int(rng.integers(0, 2)) if i % 11 == 0 else 0, mvq)
+            if is_b and i % 6 == 2:                                             # references swapped between the lists
+                Q = nbor(lists_q, int(r[1]), int(r[0]), 0, mvq)
+            tu = int(rng.integers(0, 2))
+            pend.append((dict(is_b=is_b, p=P, q=Q, tu=tu), p.call(0x4029D0 if is_b else 0x402960, Buf(P), Buf(Q), tu)))
+    p.run()
+    return [dict(c, exp=np.int32(call.ret & 0xFFFFFFFF)) for c, call in pend]
+
+
 INTRA_FUNCS = {  # name: (address, modes)  -- nm -C appencoder: h265_codec::IntraPred*_c(uchar*, int, uchar*, int, int, bool)
     "planar": (0x425AF0, [0]), "dc": (0x425D80, [1]), "chroma_dc": (0x425C60, [1]), "hor_plus_2": (0x425F60, [2]),
     "hor_plus_3_9": (0x4260E0, range(3, 10)), "hor0_10": (0x426300, [10]), "hor_minus_11_17": (0x4264C0, range(11, 18)),
@@ -591,7 +628,7 @@ FAMILIES = {
     "sad": gen_sad, "sad4": gen_sad4, "sad3": gen_sad3, "sad4blk": gen_sad4blk, "sse": gen_sse, "had": gen_had,
     "fwd_transform": gen_fwd, "inv_transform": gen_inv, "quant": gen_quant, "dequant": gen_dequant,
     "residual": gen_residual, "deblock_luma": gen_deblock_luma, "deblock_chroma": gen_deblock_chroma,
-    "interp": gen_interp, "sao_apply": gen_sao, "sao_stats": gen_sao_stats, "bipred": gen_bipred, "bifull": gen_bifull, "estbits": gen_estbits, "intra": gen_intra, "lookahead": gen_lookahead, "sbh": gen_sbh,
+    "interp": gen_interp, "sao_apply": gen_sao, "sao_stats": gen_sao_stats, "bipred": gen_bipred, "bifull": gen_bifull, "estbits": gen_estbits, "bs": gen_bs, "intra": gen_intra, "lookahead": gen_lookahead, "sbh": gen_sbh,
 }
 
 if __name__ == "__main__":
