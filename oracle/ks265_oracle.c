@@ -500,6 +500,24 @@ void ks265o_default_weighted_bi(uint8_t *dst, const int16_t *p0, const int16_t *
         for (int x = 0; x < width; ++x) dst[y * dstStride + x] = clip8(((int)p0[y * srcStride + x] + (int)p1[y * srcStride + x] + 64) >> 7);
 }
 
+/* CEncSao::estIterOffset enc@0x4adbe0: the reference's choice of one SAO offset (HM lineage: TEncSampleAdaptiveOffset::estIterOffset in integers).  Starting at
+ * *offset (the rounded mean difference of the class, clipped by the caller) the candidate walks towards zero, zero excluded; a candidate costs
+ * count * off^2 - 2 * off * diffSum + ((lambda_q8 * (rate_base + |off| + 1) + 128) >> 8); whenever that is strictly below *best_cost it becomes the answer.
+ * *offset leaves as 0 if nothing beat the preset *best_cost.  32-bit arithmetic as in the binary.  Pinned by tests/golden/sao_iter.npz.
+ * (The frame stage's own SAO decision - sao_offset / sao_eval of the pipeline oracle - is a different, simpler rule; this is the reference's, for the day it replaces it.) */
+void ks265o_sao_est_iter_offset(int lambda_q8, int rate_base, int32_t *offset, int count, int diff_sum, int32_t *best_cost)
+{
+    int off = *offset;
+    const int step = off <= 0 ? 1 : -1;
+    *offset = 0;
+    for (; off != 0; off += step) {
+        const int32_t dist = (int32_t)((uint32_t)off * ((uint32_t)count * (uint32_t)off - 2u * (uint32_t)diff_sum));
+        const int32_t rate = (int32_t)(((uint32_t)lambda_q8 * (uint32_t)(rate_base + iabs(off) + 1) + 128u)) >> 8;
+        const int32_t cost = (int32_t)((uint32_t)dist + (uint32_t)rate);
+        if (cost < *best_cost) { *offset = off; *best_cost = cost; }
+    }
+}
+
 /* CalcBsInterP enc@0x402960 / CalcBsInterB enc@0x4029d0 (TNborData *p, TNborData *q, int transform edge): boundary strength of the edge between two blocks
  * (H.265 8.7.2.4 in the reference's data layout).  A block record is three words: word 0 - bits 2..3 lists used (0 = intra), bits 16..19 / 20..23 the reference
  * PICTURE id of list 0 / 1 (ids compare across lists), bit 24 coded residual; bytes 4..7 the list-0 vector, 8..11 the list-1 vector (quarter samples).

@@ -523,6 +523,28 @@ def gen_bs(p: RefProbe):
     return [dict(c, exp=np.int32(call.ret & 0xFFFFFFFF)) for c, call in pend]
 
 
+def gen_sao_iter(p: RefProbe):
+    """CEncSao::estIterOffset enc@0x4adbe0 (this, is chroma, rate base, int &offset, count, diffSum, int &bestCost): the offset of one SAO class is walked from its
+    start value towards zero; each step costs count * off^2 - 2 * off * diffSum + ((lambda * (base + |off| + 1) + 128) >> 8), lambda (Q8) at this+0x520 (luma) /
+    +0x524 (chroma); a strictly cheaper step replaces *offset / *bestCost (the caller presets *bestCost, e.g. with the cost of no offset)."""
+    pend = []
+    for i in range(240):
+        this = np.zeros(0x540 // 4, np.int32)
+        lam_y, lam_c = int(rng.integers(1, 6000)), int(rng.integers(1, 6000))
+        this[0x520 // 4], this[0x524 // 4] = lam_y, lam_c
+        chroma = int(rng.integers(0, 2))
+        base = int(rng.integers(0, 6))
+        count = int(rng.integers(1, 4000))
+        off0 = int(rng.integers(-7, 8))
+        diff = int(np.clip(off0 * count + rng.integers(-count, count + 1), -2 ** 20, 2 ** 20)) if i % 4 else int(rng.integers(-20000, 20001))
+        best0 = int(rng.integers(-50000, 50001)) if i % 3 else 0x7FFFFFFF
+        O, B = Buf(np.array([off0], np.int32)), Buf(np.array([best0], np.int32))
+        pend.append((dict(lam_y=lam_y, lam_c=lam_c, chroma=chroma, base=base, count=count, diff=diff, off0=off0, best0=best0),
+                     p.call(0x4ADBE0, Buf(this), chroma, base, O, count, diff, B), O, B))
+    p.run()
+    return [dict(c, exp_off=o.out[0], exp_best=b.out[0]) for c, _, o, b in pend]
+
+
 INTRA_FUNCS = {  # name: (address, modes)  -- nm -C appencoder: h265_codec::IntraPred*_c(uchar*, int, uchar*, int, int, bool)
     "planar": (0x425AF0, [0]), "dc": (0x425D80, [1]), "chroma_dc": (0x425C60, [1]), "hor_plus_2": (0x425F60, [2]),
     "hor_plus_3_9": (0x4260E0, range(3, 10)), "hor0_10": (0x426300, [10]), "hor_minus_11_17": (0x4264C0, range(11, 18)),
@@ -628,7 +650,7 @@ FAMILIES = {
     "sad": gen_sad, "sad4": gen_sad4, "sad3": gen_sad3, "sad4blk": gen_sad4blk, "sse": gen_sse, "had": gen_had,
     "fwd_transform": gen_fwd, "inv_transform": gen_inv, "quant": gen_quant, "dequant": gen_dequant,
     "residual": gen_residual, "deblock_luma": gen_deblock_luma, "deblock_chroma": gen_deblock_chroma,
-    "interp": gen_interp, "sao_apply": gen_sao, "sao_stats": gen_sao_stats, "bipred": gen_bipred, "bifull": gen_bifull, "estbits": gen_estbits, "bs": gen_bs, "intra": gen_intra, "lookahead": gen_lookahead, "sbh": gen_sbh,
+    "interp": gen_interp, "sao_apply": gen_sao, "sao_stats": gen_sao_stats, "bipred": gen_bipred, "bifull": gen_bifull, "estbits": gen_estbits, "bs": gen_bs, "sao_iter": gen_sao_iter, "intra": gen_intra, "lookahead": gen_lookahead, "sbh": gen_sbh,
 }
 
 if __name__ == "__main__":
