@@ -518,6 +518,49 @@ void ks265o_sao_est_iter_offset(int lambda_q8, int rate_base, int32_t *offset, i
     }
 }
 
+/* CEncSao::BoTypeDistEstimation enc@0x4adc70 / CEncSao::EoTypeDistEstimation enc@0x4adf60: the reference's SAO offsets and type costs from the class statistics
+ * (count[k] = samples of class k, sum[k] = sum of (source - reconstruction) over them).  Per class: no samples -> sum is cleared, offset 0; else the start value is
+ * the mean rounded to nearest (half away from zero) and clipped to [-3, 3], refined by estIterOffset against the price of one bin ((lambda + 128) >> 8, which is
+ * also what an unused class costs); edge categories 0, 1 only take positive offsets, 2, 3 only negative ones (else 0).  Band offset: rate base 1, the band
+ * position is the first of the 28 windows of four consecutive bands with the smallest cost sum.  Edge offset: rate base 0, returns the cost sum of the four
+ * categories.  Pinned by tests/golden/sao_type.npz. */
+static int32_t sao_start_offset(int32_t d, int32_t count, int sign_half)   /* (d + sign * count >> 1) / count (C division), clipped */
+{
+    int32_t v = (d + ((sign_half * count) >> 1)) / count;
+    return v > 3 ? 3 : (v < -3 ? -3 : v);
+}
+void ks265o_sao_bo_type_estimation(int lambda_q8, int32_t *count /*32*/, int32_t *sum /*32*/, int32_t *band, int32_t *offsets /*32*/)
+{
+    const int32_t zero = (lambda_q8 + 128) >> 8;
+    int32_t cost[32];
+    for (int k = 0; k < 32; ++k) {
+        if (!count[k]) { sum[k] = 0; cost[k] = zero; offsets[k] = 0; continue; }
+        int32_t off = sao_start_offset(sum[k], count[k], (sum[k] > 0) - (sum[k] < 0)), best = zero;
+        ks265o_sao_est_iter_offset(lambda_q8, 1, &off, count[k], sum[k], &best);
+        offsets[k] = off; cost[k] = best;
+    }
+    int32_t bc = 0xffff000;
+    for (int k = 0; k < 28; ++k) {
+        const int32_t c = cost[k] + cost[k + 1] + cost[k + 2] + cost[k + 3];
+        if (c < bc) { bc = c; *band = k; }
+    }
+}
+int32_t ks265o_sao_eo_type_estimation(int lambda_q8, const int32_t *count /*4*/, int32_t *sum /*4*/, int32_t *offsets /*4*/)
+{
+    const int32_t zero = (lambda_q8 + 128) >> 8;
+    int32_t total = 0;
+    for (int k = 0; k < 4; ++k) {
+        offsets[k] = 0;
+        if (!count[k]) { sum[k] = 0; total += zero; continue; }
+        const int positive = k < 2;
+        if (positive ? sum[k] <= 0 : sum[k] >= 0) { total += zero; continue; }
+        int32_t off = sao_start_offset(sum[k], count[k], positive ? 1 : -1), best = zero;
+        ks265o_sao_est_iter_offset(lambda_q8, 0, &off, count[k], sum[k], &best);
+        offsets[k] = off; total += best;
+    }
+    return total;
+}
+
 /* CalcBsInterP enc@0x402960 / CalcBsInterB enc@0x4029d0 (TNborData *p, TNborData *q, int transform edge): boundary strength of the edge between two blocks
  * (H.265 8.7.2.4 in the reference's data layout).  A block record is three words: word 0 - bits 2..3 lists used (0 = intra), bits 16..19 / 20..23 the reference
  * PICTURE id of list 0 / 1 (ids compare across lists), bit 24 coded residual; bytes 4..7 the list-0 vector, 8..11 the list-1 vector (quarter samples).

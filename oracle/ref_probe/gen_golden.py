@@ -545,6 +545,43 @@ def gen_sao_iter(p: RefProbe):
     return [dict(c, exp_off=o.out[0], exp_best=b.out[0]) for c, _, o, b in pend]
 
 
+def gen_sao_type(p: RefProbe):
+    """CEncSao::BoTypeDistEstimation enc@0x4adc70 (this, component, int &band, int *offsets) and CEncSao::EoTypeDistEstimation enc@0x4adf60 (this, component,
+    class, int *offsets) -> cost: the reference's SAO offsets and type costs from the statistics kept in the object - band counts at this + 128 comp, band sums at
+    this + 0x270 + 128 comp (32 each); edge counts at this + 0x180 + 80 comp + 20 class, edge sums at this + 0x3f0 + the same (4 categories each); lambda (Q8) at
+    +0x520 / +0x524.  Both call estIterOffset; both write 0 into the sum of an empty class."""
+    pend = []
+    def this_buf():
+        t = np.zeros(0x540 // 4, np.int32)
+        t[0x520 // 4], t[0x524 // 4] = int(rng.integers(1, 6000)), int(rng.integers(1, 6000))
+        return t
+    for i in range(60):
+        t = this_buf()
+        comp = int(rng.integers(0, 3))
+        cnt = rng.integers(0, 600, 32).astype(np.int32) * (rng.random(32) < 0.7)
+        d = (cnt * rng.uniform(-4, 4, 32) + rng.integers(-30, 31, 32)).astype(np.int32)
+        if i % 5 == 0: d[:] = 0
+        t[comp * 32:comp * 32 + 32] = cnt
+        t[0x270 // 4 + comp * 32:0x270 // 4 + comp * 32 + 32] = d
+        T, B, O = Buf(t), Buf(np.array([-1], np.int32)), Buf(np.zeros(32, np.int32))
+        pend.append((dict(kind="bo", comp=comp, this=t), p.call(0x4ADC70, T, comp, B, O), T, B, O))
+    for i in range(120):
+        t = this_buf()
+        comp, cls = int(rng.integers(0, 3)), int(rng.integers(0, 4))
+        cnt = rng.integers(0, 3000, 4).astype(np.int32) * (rng.random(4) < 0.8)
+        d = (cnt * rng.uniform(-3.5, 3.5, 4) * np.array([1, 1, -1, -1]) * (1 if i % 4 else -1) + rng.integers(-20, 21, 4)).astype(np.int32)
+        base = 0x180 // 4 + comp * 20 + cls * 5
+        t[base:base + 4] = cnt
+        t[0x3F0 // 4 + comp * 20 + cls * 5:0x3F0 // 4 + comp * 20 + cls * 5 + 4] = d
+        T, O = Buf(t), Buf(np.zeros(4, np.int32))
+        pend.append((dict(kind="eo", comp=comp, cls=cls, this=t), p.call(0x4ADF60, T, comp, cls, O), T, None, O))
+    p.run()
+    out = []
+    for c, call, T, B, O in pend:
+        out.append(dict(c, exp_this=T.out, exp_off=O.out, exp_band=(B.out[0] if B is not None else np.int32(0)), exp_ret=np.int32(np.uint32(call.ret & 0xFFFFFFFF).astype(np.int64) if False else np.array([call.ret & 0xFFFFFFFF], np.uint32).view(np.int32)[0])))
+    return out
+
+
 INTRA_FUNCS = {  # name: (address, modes)  -- nm -C appencoder: h265_codec::IntraPred*_c(uchar*, int, uchar*, int, int, bool)
     "planar": (0x425AF0, [0]), "dc": (0x425D80, [1]), "chroma_dc": (0x425C60, [1]), "hor_plus_2": (0x425F60, [2]),
     "hor_plus_3_9": (0x4260E0, range(3, 10)), "hor0_10": (0x426300, [10]), "hor_minus_11_17": (0x4264C0, range(11, 18)),
@@ -650,7 +687,7 @@ FAMILIES = {
     "sad": gen_sad, "sad4": gen_sad4, "sad3": gen_sad3, "sad4blk": gen_sad4blk, "sse": gen_sse, "had": gen_had,
     "fwd_transform": gen_fwd, "inv_transform": gen_inv, "quant": gen_quant, "dequant": gen_dequant,
     "residual": gen_residual, "deblock_luma": gen_deblock_luma, "deblock_chroma": gen_deblock_chroma,
-    "interp": gen_interp, "sao_apply": gen_sao, "sao_stats": gen_sao_stats, "bipred": gen_bipred, "bifull": gen_bifull, "estbits": gen_estbits, "bs": gen_bs, "sao_iter": gen_sao_iter, "intra": gen_intra, "lookahead": gen_lookahead, "sbh": gen_sbh,
+    "interp": gen_interp, "sao_apply": gen_sao, "sao_stats": gen_sao_stats, "bipred": gen_bipred, "bifull": gen_bifull, "estbits": gen_estbits, "bs": gen_bs, "sao_iter": gen_sao_iter, "sao_type": gen_sao_type, "intra": gen_intra, "lookahead": gen_lookahead, "sbh": gen_sbh,
 }
 
 if __name__ == "__main__":
