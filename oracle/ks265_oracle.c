@@ -523,7 +523,8 @@ void ks265o_sao_est_iter_offset(int lambda_q8, int rate_base, int32_t *offset, i
  * the mean rounded to nearest (half away from zero) and clipped to [-3, 3], refined by estIterOffset against the price of one bin ((lambda + 128) >> 8, which is
  * also what an unused class costs); edge categories 0, 1 only take positive offsets, 2, 3 only negative ones (else 0).  Band offset: rate base 1, the band
  * position is the first of the 28 windows of four consecutive bands with the smallest cost sum.  Edge offset: rate base 0, returns the cost sum of the four
- * categories.  Pinned by tests/golden/sao_type.npz. */
+ * categories.  Pinned by tests/golden/sao_type.npz.  Their callers add the type's own rate and keep the cheapest (read from the binary, not probed: calcRDcostBoY
+ * enc@0x4ade40: window cost + ((7 lambda + 128) >> 8); calcRDcostEoY enc@0x4ae290: category cost + ((4 lambda + 128) >> 8); checkRDCostY enc@0x4ad810: strictly cheaper wins). */
 static int32_t sao_start_offset(int32_t d, int32_t count, int sign_half)   /* (d + sign * count >> 1) / count (C division), clipped */
 {
     int32_t v = (d + ((sign_half * count) >> 1)) / count;
