@@ -654,6 +654,22 @@ uint32_t ks265o_inter_me_bi_full(int32_t *best, const uint8_t *org, const uint8_
     return bc;
 }
 
+/* enc@0x434510 ExplicitWeightedP_c / enc@0x434460 ExplicitWeightedBi_c: explicit weighted prediction (H.265 8.5.3.3.4.3) on the 14-bit intermediates, which in
+ * this codec carry no -8192 offset.  wp = WeightParams as the two functions read it: {shift, w0, o0, -, w1, o1}; shift = log2WD of the standard (>= 1).
+ *   uni: clip8(((p * w0 + 2^(shift-1)) >> shift) + o0)        bi: clip8((p0 * w0 + p1 * w1 + ((o0 + o1 + 1) << shift)) >> (shift + 1))
+ * Pinned by tests/golden/wpred.npz.  The frame stages do not use weighted prediction (the encoder host never signals it). */
+void ks265o_explicit_weighted_p(uint8_t *dst, const int16_t *p0, int dstStride, int srcStride, int width, int height, const int32_t *wp)
+{
+    for (int y = 0; y < height; ++y)
+        for (int x = 0; x < width; ++x) dst[y * dstStride + x] = clip8((((int)p0[y * srcStride + x] * wp[1] + (1 << (wp[0] - 1))) >> wp[0]) + wp[2]);
+}
+void ks265o_explicit_weighted_bi(uint8_t *dst, const int16_t *p0, const int16_t *p1, int dstStride, int srcStride, int width, int height, const int32_t *wp)
+{
+    const int rnd = (int)((uint32_t)(wp[2] + wp[5] + 1) << wp[0]);
+    for (int y = 0; y < height; ++y)
+        for (int x = 0; x < width; ++x) dst[y * dstStride + x] = clip8(((int)p0[y * srcStride + x] * wp[1] + (int)p1[y * srcStride + x] * wp[4] + rnd) >> (wp[0] + 1));
+}
+
 /* enc@0x47b1a0 calcBiMeOrg_c(dst, pred, org, stride, height, width): the bi-pred search target dst = clip8(2 org - pred)
  * (g_calcBiMeOrgFuncs); returns the clipping loss sum |2 org - pred - dst|. */
 uint32_t ks265o_calc_bi_me_org(uint8_t *dst, const uint8_t *pred, const uint8_t *org, int stride, int height, int width)

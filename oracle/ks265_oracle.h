@@ -97,6 +97,8 @@ int32_t ks265o_sao_eo_type_estimation(int lambda_q8, const int32_t *count, int32
 int ks265o_calc_bs(const int32_t *p /*3 words*/, const int32_t *q, int tu_edge, int is_b);
 void ks265o_est_bit_rdoq(int32_t *out /*180 words*/, int log2, int luma, const uint8_t *ctx, const int32_t *entropy /*128*/);
 uint32_t ks265o_inter_me_bi_full(int32_t *best, const uint8_t *org, const uint8_t *ref, int orgStride, int refStride, const uint16_t *mvcost, int h, int log2w, int use_had);
+void ks265o_explicit_weighted_p(uint8_t *dst, const int16_t *p0, int dstStride, int srcStride, int width, int height, const int32_t *wp);
+void ks265o_explicit_weighted_bi(uint8_t *dst, const int16_t *p0, const int16_t *p1, int dstStride, int srcStride, int width, int height, const int32_t *wp);
 uint32_t ks265o_calc_bi_me_org(uint8_t *dst, const uint8_t *pred, const uint8_t *org, int stride, int height, int width);
 
 /* ---- intra prediction (ks265_intra_oracle.c): g_IntraPredFunction enc@0x7070a0 family, IntraPredFilterRef_c enc@0x424110.

@@ -582,6 +582,24 @@ def gen_sao_type(p: RefProbe):
     return out
 
 
+def gen_wpred(p: RefProbe):
+    """ExplicitWeightedP_c enc@0x434510 (dst, src14, dstStride, srcStride, w, h, WeightParams *) and ExplicitWeightedBi_c enc@0x434460 (dst, src0, src1, dstStride,
+    srcStride, w, h, WeightParams *): explicit weighted prediction on the 14-bit intermediates.  WeightParams as the two functions read it: {shift, w0, o0, -, w1, o1}."""
+    pend = []
+    for (w, h) in ((4, 4), (8, 8), (16, 4), (32, 16), (64, 64), (12, 8)):
+        for k in range(4):
+            ss, ds = w + int(rng.integers(0, 9)), w + int(rng.integers(0, 9))
+            hi = 16321 if k < 2 else 20000
+            p0, p1 = rng.integers(-2000 if k >= 2 else 0, hi, (h, ss)).astype(np.int16), rng.integers(-2000 if k >= 2 else 0, hi, (h, ss)).astype(np.int16)
+            wp = np.array([int(rng.integers(1, 8)) + 6 * (k % 2 == 0), int(rng.integers(-128, 128)), int(rng.integers(-128, 128)), 0, int(rng.integers(-128, 128)), int(rng.integers(-128, 128))], np.int32)
+            D = Buf(np.zeros((h, ds), np.uint8))
+            pend.append((dict(kind="p", p0=p0, ss=ss, ds=ds, w=w, h=h, wp=wp), p.call(0x434510, D, Buf(p0), ds, ss, w, h, Buf(wp)), D))
+            D2 = Buf(np.zeros((h, ds), np.uint8))
+            pend.append((dict(kind="bi", p0=p0, p1=p1, ss=ss, ds=ds, w=w, h=h, wp=wp), p.call(0x434460, D2, Buf(p0), Buf(p1), ds, ss, w, h, Buf(wp)), D2))
+    p.run()
+    return [dict(c, exp=d.out) for c, _, d in pend]
+
+
 INTRA_FUNCS = {  # name: (address, modes)  -- nm -C appencoder: h265_codec::IntraPred*_c(uchar*, int, uchar*, int, int, bool)
     "planar": (0x425AF0, [0]), "dc": (0x425D80, [1]), "chroma_dc": (0x425C60, [1]), "hor_plus_2": (0x425F60, [2]),
     "hor_plus_3_9": (0x4260E0, range(3, 10)), "hor0_10": (0x426300, [10]), "hor_minus_11_17": (0x4264C0, range(11, 18)),
@@ -687,7 +705,7 @@ FAMILIES = {
     "sad": gen_sad, "sad4": gen_sad4, "sad3": gen_sad3, "sad4blk": gen_sad4blk, "sse": gen_sse, "had": gen_had,
     "fwd_transform": gen_fwd, "inv_transform": gen_inv, "quant": gen_quant, "dequant": gen_dequant,
     "residual": gen_residual, "deblock_luma": gen_deblock_luma, "deblock_chroma": gen_deblock_chroma,
-    "interp": gen_interp, "sao_apply": gen_sao, "sao_stats": gen_sao_stats, "bipred": gen_bipred, "bifull": gen_bifull, "estbits": gen_estbits, "bs": gen_bs, "sao_iter": gen_sao_iter, "sao_type": gen_sao_type, "intra": gen_intra, "lookahead": gen_lookahead, "sbh": gen_sbh,
+    "interp": gen_interp, "sao_apply": gen_sao, "sao_stats": gen_sao_stats, "bipred": gen_bipred, "bifull": gen_bifull, "estbits": gen_estbits, "bs": gen_bs, "sao_iter": gen_sao_iter, "sao_type": gen_sao_type, "wpred": gen_wpred, "intra": gen_intra, "lookahead": gen_lookahead, "sbh": gen_sbh,
 }
 
 if __name__ == "__main__":
