@@ -9,8 +9,48 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <pthread.h>
 
 static double now_ms(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e3 + t.tv_nsec * 1e-6; }
+
+/* the input file is read one picture ahead on a thread of its own: at 2160p a picture is 12 MB, ~0.6 ms from the page cache - as long as the encoder's share
+ * of the calling thread (input copy, output) */
+typedef struct {
+    FILE *f; size_t fsz; unsigned char *buf[2];
+    pthread_mutex_t mu; pthread_cond_t cv;
+    int state[2];                                   /* 0 = free, 1 = filled, 2 = end of file */
+    long limit, nread; int quit;
+} Reader;
+static void *reader_main(void *arg)
+{
+    Reader *r = (Reader *)arg;
+    for (int k = 0;; k ^= 1) {
+        pthread_mutex_lock(&r->mu);
+        while (r->state[k] != 0 && !r->quit) pthread_cond_wait(&r->cv, &r->mu);
+        const int stop = r->quit;
+        pthread_mutex_unlock(&r->mu);
+        if (stop) return NULL;
+        const int ok = (r->limit < 0 || r->nread < r->limit) && fread(r->buf[k], 1, r->fsz, r->f) == r->fsz;
+        pthread_mutex_lock(&r->mu);
+        r->state[k] = ok ? 1 : 2;
+        if (ok) ++r->nread;
+        pthread_cond_broadcast(&r->cv);
+        pthread_mutex_unlock(&r->mu);
+        if (!ok) return NULL;
+    }
+}
+/* the next picture (NULL at the end of the input); the buffer stays valid until the following call */
+static unsigned char *reader_next(Reader *r, int *cur)
+{
+    pthread_mutex_lock(&r->mu);
+    if (*cur >= 0) { r->state[*cur] = 0; pthread_cond_broadcast(&r->cv); }     /* the previous picture's buffer may be refilled */
+    const int k = *cur < 0 ? 0 : *cur ^ 1;
+    while (r->state[k] == 0) pthread_cond_wait(&r->cv, &r->mu);
+    const int st = r->state[k];
+    pthread_mutex_unlock(&r->mu);
+    *cur = k;
+    return st == 1 ? r->buf[k] : NULL;
+}
 
 static void usage(void)
 {
@@ -62,8 +102,15 @@ int main(int argc, char **argv)
     if (!h) { fprintf(stderr, "QY265EncoderOpen failed: 0x%08x\n", (unsigned)err); return 1; }
     if (rec_path && ks265_enc_set_recon_file(h, rec_path) != QY_OK) { fprintf(stderr, "cannot write the reconstruction to %s\n", rec_path); return 1; }
     const size_t luma = (size_t)cfg.picWidth * cfg.picHeight, fsz = luma * 3 / 2;
-    unsigned char *buf = (unsigned char *)malloc(fsz);
-    QY265YUV yuv = {cfg.picWidth, cfg.picHeight, {buf, buf + luma, buf + luma + luma / 4}, {cfg.picWidth, cfg.picWidth / 2, cfg.picWidth / 2}};
+    Reader rd;
+    memset(&rd, 0, sizeof rd);
+    rd.f = fi; rd.fsz = fsz; rd.limit = frames;
+    rd.buf[0] = (unsigned char *)malloc(fsz); rd.buf[1] = (unsigned char *)malloc(fsz);
+    if (!rd.buf[0] || !rd.buf[1]) { fprintf(stderr, "out of memory\n"); return 1; }
+    pthread_mutex_init(&rd.mu, NULL); pthread_cond_init(&rd.cv, NULL);
+    pthread_t rth;
+    if (pthread_create(&rth, NULL, reader_main, &rd)) { fprintf(stderr, "cannot start the reader thread\n"); return 1; }
+    QY265YUV yuv = {cfg.picWidth, cfg.picHeight, {NULL, NULL, NULL}, {cfg.picWidth, cfg.picWidth / 2, cfg.picWidth / 2}};
     QY265Picture pic, outp;
     memset(&pic, 0, sizeof pic); memset(&outp, 0, sizeof outp);
     pic.yuv = &yuv;
@@ -71,15 +118,20 @@ int main(int argc, char **argv)
     long n = 0;
     const double t0 = now_ms();
     double t_io = 0;
-    for (; frames < 0 || n < frames; ++n) {
+    int cur = -1;
+    for (;; ++n) {
         const double ta = now_ms();
-        if (fread(buf, 1, fsz, fi) != fsz) break;
+        unsigned char *buf = reader_next(&rd, &cur);                    /* waits only if the reader is behind */
         t_io += now_ms() - ta;
+        if (!buf) break;
+        yuv.pData[0] = buf; yuv.pData[1] = buf + luma; yuv.pData[2] = buf + luma + luma / 4;
         pic.pts = n;
         err = QY265EncoderEncodeFrame(h, &nal, &nnal, &pic, &outp, 0);
         if (err) { fprintf(stderr, "EncodeFrame failed: 0x%08x\n", (unsigned)err); return 1; }
         for (int k = 0; k < nnal && fo; ++k) fwrite(nal[k].pPayload, 1, (size_t)nal[k].iSize, fo);
     }
+    pthread_mutex_lock(&rd.mu); rd.quit = 1; pthread_cond_broadcast(&rd.cv); pthread_mutex_unlock(&rd.mu);
+    pthread_join(rth, NULL);
     while (QY265EncoderDelayedFrames(h)) {
         err = QY265EncoderEncodeFrame(h, &nal, &nnal, NULL, &outp, 0);
         if (err) { fprintf(stderr, "EncodeFrame (flush) failed: 0x%08x\n", (unsigned)err); return 1; }
@@ -89,11 +141,11 @@ int main(int argc, char **argv)
     ks265_enc_stats st;
     ks265_enc_get_stats(h, &st);
     printf("Total Frames: %ld, test time: %.0f ms, FPS: %.4f\n", n, t1 - t0, n * 1000.0 / (t1 - t0));
-    printf("pure encoding time: %.0f ms (input read %.0f ms), slice writing %.1f ms per picture per thread\n", t1 - t0 - t_io, t_io, st.frames ? st.host_write_ms / st.frames : 0.0);
+    printf("pure encoding time: %.0f ms (waiting for the input reader %.0f ms), slice writing %.1f ms per picture per thread\n", t1 - t0 - t_io, t_io, st.frames ? st.host_write_ms / st.frames : 0.0);
     printf("calling thread: input copy %.0f ms, enqueueing GPU work %.0f ms, output (wait + copy) %.0f ms\n", st.in_copy_ms, st.submit_ms, st.output_ms);
     printf("per picture: enqueue -> records on the host %.2f ms, enqueue -> writer pick-up %.2f ms\n", st.frames ? st.lat_gpu_ms / st.frames : 0.0, st.frames ? st.lat_queue_ms / st.frames : 0.0);
     QY265EncoderClose(h);                                            /* prints "bitrate, psnr: ..." */
     puts("H265 encoder passed!!!");
-    free(buf); fclose(fi); if (fo) fclose(fo);
+    free(rd.buf[0]); free(rd.buf[1]); fclose(fi); if (fo) fclose(fo);
     return 0;
 }
