@@ -1,0 +1,202 @@
+/* TEST INFRASTRUCTURE: a CPU stand-in for the subset of libks265hip.so the encoder host (ks265codec_amd/host/ks265_enc.c) calls, so that the host's threads,
+ * rings, GOP scheduling, GOP lanes, graph cache and bitstream writer can be exercised by `-m "not gpu"` tests.  It is NOT a CPU fallback of the product (nothing in
+ * ks265codec_amd/ knows it) and it does not encode: every "picture" gets a fixed, valid set of records - 8x8 CUs, DC intra without residual in key pictures, one
+ * vector per CU derived from hashes of the source and reference pictures otherwise - so that the stream the writer produces depends on which pictures met in which
+ * order, which is what the host tests look at.  Streams are synchronous (everything runs inside the call), events are always complete; a captured "graph" is the
+ * list of the recorded calls, replayed by ks265_graph_launch. */
+#include "ks265_hip.h"
+#include "../oracle/ks265_pipeline_oracle.h"
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+struct ks265_ctx { int capturing; struct Op *ops; int nops; };
+typedef struct Op { int kind; ks265_frame *f; const void *a; ks265_pic p0, p1, p2, p3; int i0; void *dst; } Op;
+typedef struct Graph { Op *ops; int n; } Graph;
+struct ks265_frame {
+    ks265_ctx *ctx; ks265_frame_cfg cfg; ks265_frame_geom g;
+    int cur_pu, have_prev;
+    ks265_cu8 *cu8; ks265_sao_param *sao; uint64_t kind_hash;
+};
+
+const char *ks265_version(void) { return "ks265hip CPU stub (tests only)"; }
+const char *ks265_last_error(ks265_ctx *c) { (void)c; return "stub"; }
+int ks265_create(ks265_ctx **out, int device) { (void)device; if (getenv("KS265_STUB_NO_DEVICE")) return KS265_NO_DEVICE; *out = (ks265_ctx *)calloc(1, sizeof **out); return *out ? KS265_OK : KS265_OUTOFMEMORY; }
+void ks265_destroy(ks265_ctx *c) { if (c) { free(c->ops); free(c); } }
+int ks265_synchronize(ks265_ctx *c) { (void)c; return KS265_OK; }
+int ks265_dev_malloc(ks265_ctx *c, void **p, size_t n) { (void)c; *p = calloc(1, n ? n : 1); return *p ? KS265_OK : KS265_OUTOFMEMORY; }
+int ks265_dev_free(ks265_ctx *c, void *p) { (void)c; free(p); return KS265_OK; }
+int ks265_host_malloc(ks265_ctx *c, void **p, size_t n) { return ks265_dev_malloc(c, p, n); }
+int ks265_host_free(ks265_ctx *c, void *p) { return ks265_dev_free(c, p); }
+int ks265_memcpy_h2d_async(ks265_ctx *c, void *d, const void *s, size_t n) { (void)c; memcpy(d, s, n); return KS265_OK; }
+int ks265_memcpy_d2h_async(ks265_ctx *c, void *d, const void *s, size_t n) { (void)c; memcpy(d, s, n); return KS265_OK; }
+int ks265_memset_async(ks265_ctx *c, void *d, int v, size_t n) { (void)c; memset(d, v, n); return KS265_OK; }
+int ks265_event_create(ks265_ctx *c, void **ev) { (void)c; *ev = malloc(4); return *ev ? KS265_OK : KS265_OUTOFMEMORY; }
+int ks265_event_record(ks265_ctx *c, void *ev) { (void)c; (void)ev; return KS265_OK; }
+int ks265_event_wait(ks265_ctx *c, void *ev) { (void)c; (void)ev; return KS265_OK; }
+int ks265_stream_wait_event(ks265_ctx *c, void *ev) { (void)c; (void)ev; return KS265_OK; }
+int ks265_event_destroy(ks265_ctx *c, void *ev) { (void)c; free(ev); return KS265_OK; }
+
+int ks265_frame_geometry(const ks265_frame_cfg *cfg, ks265_frame_geom *geom)
+{
+    kso_frame_cfg oc; kso_frame_geom og;
+    memset(&oc, 0, sizeof oc);
+    oc.width = cfg->width; oc.height = cfg->height; oc.qp = cfg->qp; oc.me_range = cfg->me_range;
+    if (kso_frame_geometry(&oc, &og)) return KS265_NOTSUPPORTED;
+    geom->pad_y = og.pad_y; geom->pad_c = og.pad_c; geom->stride_y = og.stride_y; geom->stride_c = og.stride_c; geom->rows_y = og.rows_y; geom->rows_c = og.rows_c;
+    geom->bytes_y = og.bytes_y; geom->bytes_c = og.bytes_c; geom->ctu_cols = og.ctu_cols; geom->ctu_rows = og.ctu_rows; geom->pu_per_ctu = og.pu_per_ctu;
+    geom->bytes_pu = og.bytes_pu; geom->bytes_cu8 = og.bytes_cu8; geom->bytes_sao = og.bytes_sao;
+    return KS265_OK;
+}
+int ks265_frame_create(ks265_ctx *ctx, const ks265_frame_cfg *cfg, ks265_frame **out)
+{
+    ks265_frame *f = (ks265_frame *)calloc(1, sizeof *f);
+    if (!f) return KS265_OUTOFMEMORY;
+    f->ctx = ctx; f->cfg = *cfg;
+    if (ks265_frame_geometry(cfg, &f->g)) { free(f); return KS265_NOTSUPPORTED; }
+    f->cu8 = (ks265_cu8 *)calloc(1, (size_t)f->g.bytes_cu8); f->sao = (ks265_sao_param *)calloc(1, (size_t)f->g.bytes_sao);
+    *out = f;
+    return KS265_OK;
+}
+void ks265_frame_destroy(ks265_frame *f) { if (f) { free(f->cu8); free(f->sao); free(f); } }
+int ks265_frame_set_qp(ks265_frame *f, int qp, int l) { f->cfg.qp = qp; f->cfg.lambda_q4 = l; return KS265_OK; }
+int ks265_frame_p_state(ks265_frame *f) { return (f->cur_pu & 1) | (f->have_prev ? 2 : 0); }
+int ks265_frame_p_advance(ks265_frame *f) { f->cur_pu ^= 1; f->have_prev = 1; return KS265_OK; }
+int ks265_frame_p_restore(ks265_frame *f, int s) { f->cur_pu = s & 1; f->have_prev = (s >> 1) & 1; return KS265_OK; }
+int ks265_frame_reset_prediction(ks265_frame *f) { f->have_prev = 0; return KS265_OK; }
+
+static uint64_t hash_bytes(const uint8_t *p, size_t n) { uint64_t h = 1469598103934665603ull; for (size_t i = 0; i < n; ++i) { h ^= p[i]; h *= 1099511628211ull; } return h; }
+static uint8_t *luma0(const ks265_frame *f, ks265_pic p) { return p.y + (size_t)f->g.pad_y * f->g.stride_y + f->g.pad_y; }
+/* a picture is identified by the first two rows of its luma plane (load_i420 puts the source there, the "encode" below writes its own identity there) */
+static uint64_t pic_id(const ks265_frame *f, ks265_pic p) { return hash_bytes(luma0(f, p), (size_t)f->cfg.width) ^ (hash_bytes(luma0(f, p) + f->g.stride_y, (size_t)f->cfg.width) << 1); }
+
+static void do_load(ks265_frame *f, const uint8_t *i420, ks265_pic dst)
+{
+    const int W = f->cfg.width, H = f->cfg.height;
+    for (int y = 0; y < H; ++y) memcpy(luma0(f, dst) + (size_t)y * f->g.stride_y, i420 + (size_t)y * W, (size_t)W);
+    const uint8_t *u = i420 + (size_t)W * H, *v = u + (size_t)W * H / 4;
+    for (int y = 0; y < H / 2; ++y) {
+        memcpy(dst.u + (size_t)(f->g.pad_c + y) * f->g.stride_c + f->g.pad_c, u + (size_t)y * (W / 2), (size_t)W / 2);
+        memcpy(dst.v + (size_t)(f->g.pad_c + y) * f->g.stride_c + f->g.pad_c, v + (size_t)y * (W / 2), (size_t)W / 2);
+    }
+}
+static void do_encode(ks265_frame *f, int kind /*0 key, 1 P, 2 B*/, ks265_pic src, ks265_pic r0, ks265_pic r1, ks265_pic out, int state_at_capture)
+{
+    const int w8 = f->cfg.width / 8, h8 = f->cfg.height / 8;
+    const uint64_t hs = pic_id(f, src), h0 = kind ? pic_id(f, r0) : 0, h1 = kind == 2 ? pic_id(f, r1) : 0;
+    /* of the frame state only "a previous P picture exists" may show in the result (the PU ping-pong buffer is an implementation detail: two lanes are at different
+     * parities for the same picture) */
+    const uint64_t mix = hs ^ (h0 * 3) ^ (h1 * 5) ^ ((uint64_t)f->cfg.qp << 40) ^ ((uint64_t)((state_at_capture >> 1) & 1) << 50);
+    for (int i = 0; i < w8 * h8; ++i) {
+        ks265_cu8 c; memset(&c, 0, sizeof c);
+        c.log2_cu = 3;
+        if (kind == 0) { c.pred_mode = 2; c.mvx = 1; }                                   /* DC */
+        else {
+            const uint64_t m = mix ^ ((uint64_t)i * 0x9E3779B97F4A7C15ull);
+            c.inter_dir = kind == 2 ? (uint8_t)(1 + (m >> 7) % 3) : 1;
+            c.mvx = (int16_t)((m & 15) - 8); c.mvy = (int16_t)(((m >> 4) & 7) - 4);
+            c.mv1x = (int16_t)(((m >> 8) & 15) - 8); c.mv1y = (int16_t)(((m >> 12) & 7) - 4);
+        }
+        f->cu8[i] = c;
+    }
+    for (int i = 0; i < f->g.ctu_cols * f->g.ctu_rows * 3; ++i) { memset(&f->sao[i], 0, sizeof f->sao[i]); f->sao[i].type = -1; }
+    /* the "reconstruction": the source with the identity of this coding step stamped into the first two rows */
+    const int W = f->cfg.width, H = f->cfg.height;
+    for (int y = 0; y < H; ++y) memmove(luma0(f, out) + (size_t)y * f->g.stride_y, luma0(f, src) + (size_t)y * f->g.stride_y, (size_t)W);
+    for (int x = 0; x < W; ++x) { luma0(f, out)[x] = (uint8_t)(mix >> (8 * (x & 7))); luma0(f, out)[f->g.stride_y + x] = (uint8_t)((mix * 7) >> (8 * (x & 7))); }
+    f->kind_hash = mix;
+}
+static void do_pack(ks265_frame *f, uint8_t *dst, const uint64_t *extra)
+{
+    const size_t npx = (size_t)f->cfg.width * f->cfg.height, pb[3] = {npx * 2, npx / 2, npx / 2};
+    size_t nlines = 0;
+    for (int i = 0; i < 3; ++i) nlines += (pb[i] + 63) / 64;
+    const size_t nchunk = (nlines + 1023) / 1024;
+    const size_t sz[7] = {(size_t)f->g.bytes_cu8, (size_t)f->g.bytes_sao, 64, 64, nchunk * 4, nchunk * 128, nlines * 64};
+    size_t off[8], o = 0;
+    for (int i = 0; i < 7; ++i) { off[i] = o; o += (sz[i] + 255) & ~(size_t)255; }
+    memcpy(dst + off[0], f->cu8, sz[0]); memcpy(dst + off[1], f->sao, sz[1]);
+    if (extra) memcpy(dst + off[2], extra, 64); else memset(dst + off[2], 0, 64);
+    uint32_t *hdr = (uint32_t *)(dst + off[3]);
+    memset(hdr, 0, 64); hdr[2] = 0; hdr[3] = (uint32_t)nlines;                            /* no level line is set: all residuals are zero */
+    memset(dst + off[4], 0, sz[4]); memset(dst + off[5], 0, sz[5]);
+}
+int ks265_frame_compact_layout(ks265_frame *f, size_t off[8])
+{
+    const size_t npx = (size_t)f->cfg.width * f->cfg.height, pb[3] = {npx * 2, npx / 2, npx / 2};
+    size_t nlines = 0;
+    for (int i = 0; i < 3; ++i) nlines += (pb[i] + 63) / 64;
+    const size_t nchunk = (nlines + 1023) / 1024;
+    const size_t sz[7] = {(size_t)f->g.bytes_cu8, (size_t)f->g.bytes_sao, 64, 64, nchunk * 4, nchunk * 128, nlines * 64};
+    size_t o = 0;
+    for (int i = 0; i < 7; ++i) { off[i] = o; o += (sz[i] + 255) & ~(size_t)255; }
+    off[7] = o;
+    return KS265_OK;
+}
+
+/* ---- calls that a capture records */
+enum { OP_LOAD, OP_ENC, OP_SSE, OP_PACK };
+static int run_op(const Op *o)
+{
+    switch (o->kind) {
+    case OP_LOAD: do_load(o->f, (const uint8_t *)o->a, o->p0); break;
+    case OP_ENC: do_encode(o->f, o->i0 & 3, o->p0, o->p1, o->p2, o->p3, o->i0 >> 2); break;
+    case OP_SSE: { uint64_t *d = (uint64_t *)o->dst; d[0] = o->f->kind_hash & 0xFFFFF; d[1] = 17; d[2] = 23; break; }
+    case OP_PACK: do_pack(o->f, (uint8_t *)o->dst, (const uint64_t *)o->a); break;
+    }
+    return KS265_OK;
+}
+static int issue(ks265_ctx *c, Op o)
+{
+    if (!c->capturing) return run_op(&o);
+    Op *n = (Op *)realloc(c->ops, (size_t)(c->nops + 1) * sizeof *n);
+    if (!n) return KS265_OUTOFMEMORY;
+    c->ops = n; c->ops[c->nops++] = o;
+    return KS265_OK;
+}
+int ks265_capture_begin(ks265_ctx *c) { if (getenv("KS265_STUB_NO_CAPTURE")) return KS265_FAIL; c->capturing = 1; c->nops = 0; return KS265_OK; }
+int ks265_capture_end(ks265_ctx *c, void **exec)
+{
+    *exec = NULL;
+    if (!c->capturing) return KS265_FAIL;
+    c->capturing = 0;
+    if (getenv("KS265_STUB_NO_INSTANTIATE")) { c->nops = 0; return KS265_FAIL; }
+    Graph *g = (Graph *)malloc(sizeof *g);
+    g->ops = (Op *)malloc((size_t)(c->nops ? c->nops : 1) * sizeof(Op)); memcpy(g->ops, c->ops, (size_t)c->nops * sizeof(Op)); g->n = c->nops; c->nops = 0;
+    *exec = g;
+    return KS265_OK;
+}
+int ks265_graph_launch(ks265_ctx *c, void *exec) { (void)c; const Graph *g = (const Graph *)exec; for (int i = 0; i < g->n; ++i) run_op(&g->ops[i]); return KS265_OK; }
+int ks265_graph_destroy(ks265_ctx *c, void *exec) { (void)c; Graph *g = (Graph *)exec; if (g) { free(g->ops); free(g); } return KS265_OK; }
+
+int ks265_load_i420(ks265_frame *f, const uint8_t *i420, ks265_pic dst) { Op o = {OP_LOAD, f, i420, dst, dst, dst, dst, 0, NULL}; return issue(f->ctx, o); }
+int ks265_store_i420(ks265_frame *f, ks265_pic src, uint8_t *i420)
+{
+    const int W = f->cfg.width, H = f->cfg.height;
+    for (int y = 0; y < H; ++y) memcpy(i420 + (size_t)y * W, luma0(f, src) + (size_t)y * f->g.stride_y, (size_t)W);
+    memset(i420 + (size_t)W * H, 128, (size_t)W * H / 2);
+    return KS265_OK;
+}
+int ks265_encode_picture(ks265_frame *f, ks265_pic src, ks265_pic ref, int is_key, ks265_pic out)
+{
+    Op o = {OP_ENC, f, NULL, src, ref, ref, out, (is_key ? 0 : 1) | (ks265_frame_p_state(f) << 2), NULL};
+    const int r = issue(f->ctx, o);
+    if (!is_key) { f->cur_pu ^= 1; f->have_prev = 1; } else f->have_prev = 0;
+    return r;
+}
+int ks265_encode_picture_b(ks265_frame *f, ks265_pic src, ks265_pic r0, ks265_pic r1, ks265_pic out)
+{
+    Op o = {OP_ENC, f, NULL, src, r0, r1, out, 2 | (ks265_frame_p_state(f) << 2), NULL};
+    return issue(f->ctx, o);
+}
+int ks265_encode_picture_mref(ks265_frame *f, ks265_pic src, const ks265_pic *refs, int nref, ks265_pic out) { return ks265_encode_picture(f, src, refs[nref - 1], 0, out); }
+int ks265_sse_picture(ks265_frame *f, ks265_pic a, ks265_pic b, uint64_t *sse3) { Op o = {OP_SSE, f, NULL, a, b, b, b, 0, sse3}; return issue(f->ctx, o); }
+int ks265_frame_pack_compact(ks265_frame *f, void *dst, const void *extra) { Op o = {OP_PACK, f, extra, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}, 0, dst}; return issue(f->ctx, o); }
+int ks265_copy_out_compact_async(ks265_ctx *c, ks265_frame *f, void *host, const void *dev)
+{
+    (void)c;
+    size_t off[8];
+    ks265_frame_compact_layout(f, off);
+    memcpy(host, dev, off[6]);
+    return KS265_OK;
+}

@@ -1,0 +1,47 @@
+"""Drives the SDK-compatible encoder API of a libks265enc build given by $KS265_STUB_LIB (tests/test_host_pipeline_cpu.py: the host linked against the CPU stand-in of
+the device library, tests/hip_stub.c) as fast as the API takes pictures, and prints one JSON line: stream md5, lanes, pts of the coded pictures in output order ...
+argv: repo root, pictures, key period, bframes, width, height [, output file]"""
+import ctypes as C, hashlib, json, os, sys
+ROOT, N, iper, bframes, W, H = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6])
+out_path = sys.argv[7] if len(sys.argv) > 7 else None
+import numpy as np
+LAY = json.load(open(os.path.join(ROOT, "tests", "golden", "qy265_layout.json")))
+lib = C.CDLL(os.environ["KS265_STUB_LIB"]); lib.QY265EncoderOpen.restype = C.c_void_p
+class YUV(C.Structure): _fields_ = [("iWidth", C.c_int), ("iHeight", C.c_int), ("pData", C.POINTER(C.c_ubyte) * 3), ("iStride", C.c_int * 3)]
+class Picture(C.Structure): _fields_ = [("iSliceType", C.c_int), ("poc", C.c_int), ("pts", C.c_longlong), ("dts", C.c_longlong), ("yuv", C.POINTER(YUV))]
+class Nal(C.Structure): _fields_ = [("naltype", C.c_int), ("tid", C.c_int), ("iSize", C.c_int), ("pts", C.c_longlong), ("pPayload", C.POINTER(C.c_ubyte))]
+rng = np.random.default_rng(3)
+clip = rng.integers(0, 256, (11, W * H * 3 // 2), dtype=np.uint8)
+cfg = (C.c_uint8 * LAY["sizeof_config"])()
+assert lib.QY265ConfigDefaultPreset(cfg, b"medium", None, b"default") == 0
+for k, v in (("wdt", W), ("hgt", H), ("fr", 50), ("rc", 0), ("qp", 34), ("iper", iper), ("bframes", bframes), ("threads", 5), ("psnr", 1), ("log", 3)):
+    assert lib.QY265ConfigParse(cfg, k.encode(), str(v).encode()) == 0
+err = C.c_int(0)
+h = C.c_void_p(lib.QY265EncoderOpen(cfg, C.byref(err))); assert h.value, hex(err.value & 0xFFFFFFFF)
+nal, nn, pic, outp, yuv = C.POINTER(Nal)(), C.c_int(0), Picture(), Picture(), YUV()
+yuv.iWidth, yuv.iHeight = W, H
+yuv.iStride[0], yuv.iStride[1], yuv.iStride[2] = W, W // 2, W // 2
+pic.yuv = C.pointer(yuv)
+md, pts, types, bs = hashlib.md5(), [], [], bytearray()
+maxdelay = 0
+def take():
+    for i in range(nn.value):
+        b = C.string_at(nal[i].pPayload, nal[i].iSize); md.update(b); bs.extend(b); types.append(nal[i].naltype)
+        if nal[i].naltype < 32: pts.append(nal[i].pts)
+for t in range(N):
+    fr = clip[t % 11]
+    for k, off in enumerate((0, W * H, W * H * 5 // 4)): yuv.pData[k] = C.cast(fr.ctypes.data + off, C.POINTER(C.c_ubyte))
+    pic.pts = t
+    assert lib.QY265EncoderEncodeFrame(h, C.byref(nal), C.byref(nn), C.byref(pic), C.byref(outp), 0) == 0
+    take()
+    maxdelay = max(maxdelay, lib.QY265EncoderDelayedFrames(h))
+    if os.environ.get("KS_TEST_KEYREQ") and t in (17, 18, 40): lib.QY265EncoderKeyFrameRequest(h)
+calls = 0
+while lib.QY265EncoderDelayedFrames(h):
+    assert lib.QY265EncoderEncodeFrame(h, C.byref(nal), C.byref(nn), None, C.byref(outp), 0) == 0
+    take(); calls += 1
+    assert calls < 100000
+lanes = lib.ks265_enc_lanes(h)
+lib.QY265EncoderClose(h)
+if out_path: open(out_path, "wb").write(bytes(bs))
+print(json.dumps({"md5": md.hexdigest(), "lanes": lanes, "pts": pts, "idr": types.count(19), "vcl": len(pts), "bytes": len(bs), "maxdelay": maxdelay}))

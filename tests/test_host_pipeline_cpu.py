@@ -1,0 +1,85 @@
+"""CPU: the encoder host (ks265codec_amd/host/ks265_enc.c + ks265_stream.c) linked against tests/hip_stub.c, a stand-in for the device library that hands out fixed,
+valid records whose content depends on WHICH pictures met in WHICH order.  No pixel is encoded here; what is tested is everything around the GPU: input slots and
+back-pressure, the scheduler / dispatcher / writer threads, rings that fill up, GOP structures, flush, GOP lanes (output order, full rings, wake-ups), the graph cache
+(replay == launch by launch, capture failures), and that what the writer emits is a stream the reference decoder accepts.  Every run is a process under a time limit."""
+from __future__ import annotations
+
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF_DEC = os.path.join(ROOT, "oracle", "_ref", "appdecoder")
+
+
+@pytest.fixture(scope="module")
+def stub_lib(tmp_path_factory):
+    from oracle_lib import build_oracle
+    build_oracle()
+    d = tmp_path_factory.mktemp("stubenc")
+    so = str(d / "libks265enc_stub.so")
+    host = os.path.join(ROOT, "ks265codec_amd", "host")
+    subprocess.check_call(["gcc", "-O2", "-std=gnu11", "-fPIC", "-Wall", "-Wextra", "-I", os.path.join(ROOT, "include"), "-shared", "-o", so,
+                           os.path.join(host, "ks265_enc.c"), os.path.join(host, "ks265_stream.c"), os.path.join(HERE, "hip_stub.c"),
+                           "-L", os.path.join(ROOT, "oracle"), "-lks265_oracle", "-Wl,-rpath," + os.path.join(ROOT, "oracle"), "-lpthread", "-lm"])
+    return so
+
+
+def run(stub_lib, n, iper, bframes, W=128, H=72, out=None, timeout=120, **env):
+    e = dict(os.environ, KS265_STUB_LIB=stub_lib, **{k: str(v) for k, v in env.items()})
+    args = [sys.executable, os.path.join(HERE, "host_driver.py"), ROOT, str(n), str(iper), str(bframes), str(W), str(H)] + ([str(out)] if out else [])
+    r = subprocess.run(args, capture_output=True, text=True, timeout=timeout, env=e)
+    assert r.returncode == 0, r.stdout[-600:] + r.stderr[-1200:]
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def test_lanes_hand_out_the_one_lane_stream(stub_lib, tmp_path):
+    res = {L: run(stub_lib, 150, 32, 0, out=tmp_path / f"l{L}.265", KS265_GOP_LANES=L) for L in (1, 2, 3)}
+    for L, r in res.items():
+        assert r["lanes"] == L and r["vcl"] == 150 and r["idr"] == 5 and r["pts"] == list(range(150)), (L, r["vcl"], r["idr"])
+    assert res[1]["md5"] == res[2]["md5"] == res[3]["md5"]
+    assert res[2]["maxdelay"] > 32                                           # the second GOP is held back until the first one has left
+    if os.path.exists(REF_DEC):                                              # the records of the stand-in make a stream the reference decoder accepts
+        d = subprocess.run([REF_DEC, "-b", str(tmp_path / "l2.265"), "-o", str(tmp_path / "d.yuv"), "-threads", "2"], capture_output=True, text=True, cwd=tmp_path)
+        assert d.returncode == 0 and os.path.getsize(tmp_path / "d.yuv") == 150 * 128 * 72 * 3 // 2, d.stdout[-300:] + d.stderr[-300:]
+
+
+@pytest.mark.parametrize("n,iper", [(700, 300), (420, 140)])
+def test_lanes_with_gops_longer_than_the_ring(stub_lib, n, iper):
+    """64x64 pictures: the ring holds 128 pictures, a GOP more - a lane that may not hand out yet fills up completely (scheduler waiting for ring space, input waiting
+    for slots) and must come back to life when its turn comes"""
+    res = {L: run(stub_lib, n, iper, 0, W=64, H=64, KS265_GOP_LANES=L) for L in (1, 2, 3)}
+    assert res[1]["md5"] == res[2]["md5"] == res[3]["md5"] and all(r["pts"] == list(range(n)) for r in res.values())
+
+
+@pytest.mark.parametrize("bframes", [0, -1, 3])
+def test_graph_replay_equals_launch_by_launch(stub_lib, bframes):
+    """IPPP, hierarchical B (8) and P + 3 B: replay of captured pictures, plain launches, a runtime without capture and one whose instantiation fails all write the same
+    stream (the last two fall back for good after the first attempt)"""
+    iper = 64
+    a = run(stub_lib, 170, iper, bframes)
+    assert a["vcl"] == 170 and sorted(a["pts"]) == list(range(170))
+    for env in ({"KS265_NO_GRAPH": 1}, {"KS265_STUB_NO_CAPTURE": 1}, {"KS265_STUB_NO_INSTANTIATE": 1}):
+        b = run(stub_lib, 170, iper, bframes, **env)
+        assert b["md5"] == a["md5"], env
+    if bframes:
+        assert a["pts"] != list(range(170)) and a["maxdelay"] >= 2           # coding order differs from display order
+
+
+def test_key_frame_requests(stub_lib):
+    """QY265EncoderKeyFrameRequest in the middle of GOPs: one lane codes the next scheduled picture as a key picture, lanes open a new GOP on the next lane; all
+    pictures come out, in order, with the extra key pictures"""
+    for L in (1, 2):
+        r = run(stub_lib, 100, 32, 0, KS265_GOP_LANES=L, KS_TEST_KEYREQ=1)
+        assert r["vcl"] == 100 and r["pts"] == list(range(100)) and r["idr"] >= 5, (L, r["idr"])
+
+
+def test_no_device_means_no_encoder(stub_lib):
+    """the host has no CPU path of its own: when the device library reports no device, QY265EncoderOpen fails"""
+    e = dict(os.environ, KS265_STUB_LIB=stub_lib, KS265_STUB_NO_DEVICE="1")
+    r = subprocess.run([sys.executable, os.path.join(HERE, "host_driver.py"), ROOT, "3", "32", "0", "64", "64"], capture_output=True, text=True, timeout=60, env=e)
+    assert r.returncode != 0 and "AssertionError" in r.stderr
