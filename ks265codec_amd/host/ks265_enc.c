@@ -198,7 +198,9 @@ static void copy_shared(CopyPool *p, uint8_t *d, const uint8_t *s, size_t n)
     pthread_mutex_unlock(&p->mu);
 }
 
-typedef struct Input { int used, disp, key; long long pts; uint8_t *i420; } Input;     /* pinned; key: this picture starts a closed GOP whatever the period says (GOP lanes) */
+typedef struct Input { int used, disp, key, base_qp; long long pts; uint8_t *i420; } Input;     /* pinned; key: this picture starts a closed GOP whatever the period says (GOP lanes,
+                                                                                                 * QY265EncoderKeyFrameRequest); base_qp: the QP in force when the picture was handed in (QY265EncoderReconfig) -
+                                                                                                 * both travel WITH the picture: the scheduler thread may be several pictures behind the caller */
 
 typedef struct Enc {
     QY265EncConfig cfg;
@@ -578,7 +580,7 @@ static int code_hier(Enc *e, int d, int a)
             Input *in = input_at(e, mid);
             const int is_ref = (mid - cur[i].lo >= 2) || (cur[i].hi - mid >= 2);
             const int l0 = cur[i].lo - e->gop_start, l1 = cur[i].hi - e->gop_start;
-            int r = submit(e, in, 'B', mid - e->gop_start, clampqp(e, e->base_qp + e->rc_qp_delta + 1 + layer), &l0, 1, &l1, 1, coded, ncoded, is_ref, 0);
+            int r = submit(e, in, 'B', mid - e->gop_start, clampqp(e, in->base_qp + e->rc_qp_delta + 1 + layer), &l0, 1, &l1, 1, coded, ncoded, is_ref, 0);
             if (r) return r;
             if (is_ref) coded[ncoded++] = mid - e->gop_start;
             nxt[nn].lo = cur[i].lo; nxt[nn++].hi = mid; nxt[nn].lo = mid; nxt[nn++].hi = cur[i].hi;
@@ -596,11 +598,11 @@ static int schedule(Enc *e, int flush, int have /* pictures [0, have) have arriv
         if (d + 1 >= have) return QY_OK;
         const int nxt = d + 1;
         Input *in = input_at(e, nxt);
-        const int key = d < 0 || e->force_key || (e->iper > 0 && nxt - e->gop_start >= e->iper) || (in && in->key);
+        const int key = d < 0 || (e->iper > 0 && nxt - e->gop_start >= e->iper) || (in && in->key);
         if (key) {
-            e->gop_start = nxt; e->force_key = 0;
+            e->gop_start = nxt;
             for (int i = 0; i < e->ndpb + 2 * e->key_overlap; ++i) e->dpb_poc[i] = -1000000;
-            int r = submit(e, in, 'I', 0, clampqp(e, e->base_qp + e->rc_qp_delta), NULL, 0, NULL, 0, NULL, 0, 1, 1);
+            int r = submit(e, in, 'I', 0, clampqp(e, in->base_qp + e->rc_qp_delta), NULL, 0, NULL, 0, NULL, 0, 1, 1);
             if (r) return r;
             e->coded_upto = nxt;
             continue;
@@ -608,6 +610,10 @@ static int schedule(Enc *e, int flush, int have /* pictures [0, have) have arriv
         int span = e->gop_b + 1;                                       /* anchor distance */
         int a = d + span;
         if (e->iper > 0 && a - e->gop_start >= e->iper) a = e->gop_start + e->iper - 1;   /* the mini-GOP in front of a key picture is shortened */
+        for (int k = nxt + 1; k <= a && k < have; ++k) {                 /* a picture asked to be a key picture: the mini-GOP in front of it is shortened as well */
+            const Input *ik = input_at(e, k);
+            if (ik && ik->key) { a = k - 1; break; }
+        }
         if (a >= have) { if (!flush) return QY_OK; a = have - 1; }
         const int pd = d - e->gop_start, pa = a - e->gop_start;
         int l0[4], nl0 = 0, keep[8], nkeep = 0;
@@ -615,14 +621,16 @@ static int schedule(Enc *e, int flush, int have /* pictures [0, have) have arriv
             for (int i = 0; i < e->refs && pa - 1 - i >= 0; ++i) l0[nl0++] = pa - 1 - i;
             for (int i = 0; i < e->refs - 1 && pa - 1 - i >= 0; ++i) keep[nkeep++] = pa - 1 - i;   /* still needed by the next picture */
         } else { l0[nl0++] = pd; keep[nkeep++] = pd; }
-        int r = submit(e, input_at(e, a), 'P', pa, clampqp(e, e->base_qp + e->rc_qp_delta + 1), l0, nl0, NULL, 0, keep, nkeep, 1, 0);
+        Input *ina = input_at(e, a);
+        int r = submit(e, ina, 'P', pa, clampqp(e, ina->base_qp + e->rc_qp_delta + 1), l0, nl0, NULL, 0, keep, nkeep, 1, 0);
         if (r) return r;
         if (a - d > 1) {
             if (e->hier && ((a - d) & (a - d - 1)) == 0) { r = code_hier(e, d, a); if (r) return r; }
             else {
                 const int kp[2] = {pd, pa};
                 for (int b = d + 1; b < a; ++b) {
-                    r = submit(e, input_at(e, b), 'B', b - e->gop_start, clampqp(e, e->base_qp + e->rc_qp_delta + 2), &pd, 1, &pa, 1, kp, 2, 0, 0);
+                    Input *inb = input_at(e, b);
+                    r = submit(e, inb, 'B', b - e->gop_start, clampqp(e, inb->base_qp + e->rc_qp_delta + 2), &pd, 1, &pa, 1, kp, 2, 0, 0);
                     if (r) return r;
                 }
             }
@@ -954,7 +962,8 @@ static int lane_put(Enc *e, QY265Picture *in, int key)
         }
     }
     pthread_mutex_lock(&e->mu);
-    slot->disp = e->next_disp++; slot->pts = in->pts; slot->key = key; slot->used = 1;
+    slot->disp = e->next_disp++; slot->pts = in->pts; slot->key = key || e->force_key; slot->base_qp = e->base_qp; slot->used = 1;
+    e->force_key = 0;
     pthread_cond_signal(&e->cv_sched);                                 /* the scheduler thread takes it from here */
     pthread_mutex_unlock(&e->mu);
     e->st.in_copy_ms += now_ms() - tc0;

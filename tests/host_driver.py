@@ -28,10 +28,23 @@ def take():
     for i in range(nn.value):
         b = C.string_at(nal[i].pPayload, nal[i].iSize); md.update(b); bs.extend(b); types.append(nal[i].naltype)
         if nal[i].naltype < 32: pts.append(nal[i].pts)
+strided = bool(os.environ.get("KS_TEST_STRIDE"))
+if strided:                                                # planes with padded rows: the library copies row by row
+    pad = 24
+    yuv.iStride[0], yuv.iStride[1], yuv.iStride[2] = W + pad, W // 2 + pad, W // 2 + pad
+    planes = [np.zeros((H, W + pad), np.uint8), np.zeros((H // 2, W // 2 + pad), np.uint8), np.zeros((H // 2, W // 2 + pad), np.uint8)]
 for t in range(N):
     fr = clip[t % 11]
-    for k, off in enumerate((0, W * H, W * H * 5 // 4)): yuv.pData[k] = C.cast(fr.ctypes.data + off, C.POINTER(C.c_ubyte))
+    if strided:
+        planes[0][:, :W] = fr[:W * H].reshape(H, W); planes[0][:, W:] = t & 255
+        planes[1][:, :W // 2] = fr[W * H:W * H * 5 // 4].reshape(H // 2, W // 2); planes[2][:, :W // 2] = fr[W * H * 5 // 4:].reshape(H // 2, W // 2)
+        for k in range(3): yuv.pData[k] = C.cast(planes[k].ctypes.data, C.POINTER(C.c_ubyte))
+    else:
+        for k, off in enumerate((0, W * H, W * H * 5 // 4)): yuv.pData[k] = C.cast(fr.ctypes.data + off, C.POINTER(C.c_ubyte))
     pic.pts = t
+    if os.environ.get("KS_TEST_RECONFIG") and t in (40, 90):
+        assert lib.QY265ConfigParse(cfg, b"qp", str(30 + t // 40).encode()) == 0
+        lib.QY265EncoderReconfig(h, cfg)
     assert lib.QY265EncoderEncodeFrame(h, C.byref(nal), C.byref(nn), C.byref(pic), C.byref(outp), 0) == 0
     take()
     maxdelay = max(maxdelay, lib.QY265EncoderDelayedFrames(h))

@@ -73,9 +73,13 @@ def test_graph_replay_equals_launch_by_launch(stub_lib, bframes):
 def test_key_frame_requests(stub_lib):
     """QY265EncoderKeyFrameRequest in the middle of GOPs: one lane codes the next scheduled picture as a key picture, lanes open a new GOP on the next lane; all
     pictures come out, in order, with the extra key pictures"""
-    for L in (1, 2):
-        r = run(stub_lib, 100, 32, 0, KS265_GOP_LANES=L, KS_TEST_KEYREQ=1)
-        assert r["vcl"] == 100 and r["pts"] == list(range(100)) and r["idr"] >= 5, (L, r["idr"])
+    res = {L: run(stub_lib, 100, 32, 0, KS265_GOP_LANES=L, KS_TEST_KEYREQ=1) for L in (1, 2, 3)}
+    for L, r in res.items():
+        assert r["vcl"] == 100 and r["pts"] == list(range(100)) and r["idr"] == 5, (L, r["idr"])    # 0, the requested 18, 19, 41, and 73 = 41 + the period
+    assert res[1]["md5"] == res[2]["md5"] == res[3]["md5"]                  # the request travels with the next picture: no dependence on the scheduler's lag
+    for bframes in (-1, 3):                                                 # with B pictures the mini-GOP in front of the requested key picture is shortened
+        a, b = run(stub_lib, 100, 32, bframes, KS_TEST_KEYREQ=1), run(stub_lib, 100, 32, bframes, KS_TEST_KEYREQ=1, KS265_NO_GRAPH=1)
+        assert a["vcl"] == 100 and sorted(a["pts"]) == list(range(100)) and a["idr"] == 5 and a["md5"] == b["md5"], (bframes, a["idr"])
 
 
 def test_no_device_means_no_encoder(stub_lib):
@@ -83,3 +87,13 @@ def test_no_device_means_no_encoder(stub_lib):
     e = dict(os.environ, KS265_STUB_LIB=stub_lib, KS265_STUB_NO_DEVICE="1")
     r = subprocess.run([sys.executable, os.path.join(HERE, "host_driver.py"), ROOT, "3", "32", "0", "64", "64"], capture_output=True, text=True, timeout=60, env=e)
     assert r.returncode != 0 and "AssertionError" in r.stderr
+
+
+def test_strided_input_and_reconfigure(stub_lib):
+    """planes with padded rows are copied row by row (same stream as packed planes); QY265EncoderReconfig changes the QP in the middle of the stream: new graph keys,
+    all pictures still come out"""
+    a, b = run(stub_lib, 60, 32, 0), run(stub_lib, 60, 32, 0, KS_TEST_STRIDE=1)
+    assert a["md5"] == b["md5"]
+    c = run(stub_lib, 130, 64, 0, KS_TEST_RECONFIG=1)
+    d = run(stub_lib, 130, 64, 0, KS_TEST_RECONFIG=1, KS265_NO_GRAPH=1)
+    assert c["vcl"] == 130 and c["md5"] == d["md5"] and c["md5"] != run(stub_lib, 130, 64, 0)["md5"]
