@@ -548,8 +548,8 @@ static int submit(Enc *e, Input *in, int kind, int poc, int qp, const int *l0, i
             j->rps_poc[j->nrps] = keep[i]; j->rps_used[j->nrps++] = (unsigned char)used;
         }
     j->t_submit = now_ms();
-    in->used = 2;                                                      /* released when the job's event has fired (output time) */
     pthread_mutex_lock(&e->mu);
+    in->used = 2;                                                      /* released when the job's event has fired (output time); under the lock: the caller counts the pictures in flight */
     j->done = 0; j->error = 0; j->used = 1; j->started = 0; j->nrows = 0; j->next_row = 0; j->rows_done = 0;
     e->job_tail = (e->job_tail + 1) % e->ring; ++e->njobs; ++e->nwait;
     e->st.occ_samples++; e->st.occ_ring += e->njobs; e->st.occ_gpu += e->nwait; e->st.occ_ready += e->npending;
@@ -559,7 +559,15 @@ static int submit(Enc *e, Input *in, int kind, int poc, int qp, const int *l0, i
     return QY_OK;
 }
 
-static Input *input_at(Enc *e, int disp) { for (int i = 0; i < MAX_INPUT; ++i) if (e->in[i].used == 1 && e->in[i].disp == disp) return &e->in[i]; return NULL; }
+/* the input slot of display index disp (scheduler thread; under the lock: the caller's thread marks slots while it fills them) */
+static Input *input_at(Enc *e, int disp)
+{
+    Input *r = NULL;
+    pthread_mutex_lock(&e->mu);
+    for (int i = 0; i < MAX_INPUT && !r; ++i) if (e->in[i].used == 1 && e->in[i].disp == disp) r = &e->in[i];
+    pthread_mutex_unlock(&e->mu);
+    return r;
+}
 static int clampqp(Enc *e, int q) { int lo = e->cfg.rc ? e->cfg.qpmin : 0, hi = e->cfg.rc ? (e->cfg.qpmax ? e->cfg.qpmax : 51) : 51; return q < lo ? lo : q > hi ? hi : q; }
 
 /* hierarchical-B mini-GOP: anchor `a` is coded, now the B pictures of (d, a) breadth first; POCs are relative to the GOP's key picture */
@@ -604,7 +612,7 @@ static int schedule(Enc *e, int flush, int have /* pictures [0, have) have arriv
             for (int i = 0; i < e->ndpb + 2 * e->key_overlap; ++i) e->dpb_poc[i] = -1000000;
             int r = submit(e, in, 'I', 0, clampqp(e, in->base_qp + e->rc_qp_delta), NULL, 0, NULL, 0, NULL, 0, 1, 1);
             if (r) return r;
-            e->coded_upto = nxt;
+            pthread_mutex_lock(&e->mu); e->coded_upto = nxt; pthread_mutex_unlock(&e->mu);
             continue;
         }
         int span = e->gop_b + 1;                                       /* anchor distance */
@@ -635,7 +643,7 @@ static int schedule(Enc *e, int flush, int have /* pictures [0, have) have arriv
                 }
             }
         }
-        e->coded_upto = a;
+        pthread_mutex_lock(&e->mu); e->coded_upto = a; pthread_mutex_unlock(&e->mu);
     }
 }
 
@@ -929,8 +937,10 @@ static int lane_delayed(Enc *e)
 {
     if (!e) return 0;
     int n = 0;
+    pthread_mutex_lock(&e->mu);                                        /* one snapshot: a picture moves from "waiting" to "in flight" under this lock */
     for (int i = 0; i < MAX_INPUT; ++i) if (e->in[i].used == 1) ++n;
-    pthread_mutex_lock(&e->mu); n += e->njobs; pthread_mutex_unlock(&e->mu);
+    n += e->njobs;
+    pthread_mutex_unlock(&e->mu);
     return n;
 }
 
