@@ -954,7 +954,7 @@ static int lane_put(Enc *e, QY265Picture *in, int key)
     pthread_mutex_lock(&e->mu);
     /* back-pressure on the input side: at most 16 pictures wait for the scheduler thread (it may itself be waiting for ring space, which only the
      * caller's take_output frees - then go on and collect) */
-    while (!e->quit && e->next_disp - (e->coded_upto + 1) > 16 && e->njobs <= e->ring - 12) pthread_cond_wait(&e->cv_sched_done, &e->mu);
+    while (!e->quit && !e->sched_err && e->next_disp - (e->coded_upto + 1) > 16 && e->njobs <= e->ring - 12) pthread_cond_wait(&e->cv_sched_done, &e->mu);   /* a scheduler that failed makes no more progress */
     for (int i = 0; i < e->ring + 32 && !slot; ++i) if (!e->in[i].used) slot = &e->in[i];
     if (slot) slot->used = 3;                                          /* being filled */
     pthread_mutex_unlock(&e->mu);

@@ -177,8 +177,15 @@ int ks265_store_i420(ks265_frame *f, ks265_pic src, uint8_t *i420)
     memset(i420 + (size_t)W * H, 128, (size_t)W * H / 2);
     return KS265_OK;
 }
+static int fail_now(void)                                      /* KS265_STUB_FAIL_AT = k: the k-th picture enqueued in this process fails like a launch error */
+{
+    static int n, at = -2;
+    if (at == -2) { const char *e = getenv("KS265_STUB_FAIL_AT"); at = e ? atoi(e) : -1; }
+    return at >= 0 && __atomic_fetch_add(&n, 1, __ATOMIC_RELAXED) == at;
+}
 int ks265_encode_picture(ks265_frame *f, ks265_pic src, ks265_pic ref, int is_key, ks265_pic out)
 {
+    if (fail_now()) return KS265_FAIL;
     Op o = {OP_ENC, f, NULL, src, ref, ref, out, (is_key ? 0 : 1) | (ks265_frame_p_state(f) << 2), NULL};
     const int r = issue(f->ctx, o);
     if (!is_key) { f->cur_pu ^= 1; f->have_prev = 1; } else f->have_prev = 0;

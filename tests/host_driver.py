@@ -45,7 +45,12 @@ for t in range(N):
     if os.environ.get("KS_TEST_RECONFIG") and t in (40, 90):
         assert lib.QY265ConfigParse(cfg, b"qp", str(30 + t // 40).encode()) == 0
         lib.QY265EncoderReconfig(h, cfg)
-    assert lib.QY265EncoderEncodeFrame(h, C.byref(nal), C.byref(nn), C.byref(pic), C.byref(outp), 0) == 0
+    rc = lib.QY265EncoderEncodeFrame(h, C.byref(nal), C.byref(nn), C.byref(pic), C.byref(outp), 0)
+    if rc and os.environ.get("KS_TEST_EXPECT_ERROR"):       # a device failure: the API reports it, closing the encoder must not hang
+        lib.QY265EncoderClose(h)
+        print(json.dumps({"error": rc & 0xFFFFFFFF, "at": t}))
+        sys.exit(0)
+    assert rc == 0, hex(rc & 0xFFFFFFFF)
     take()
     maxdelay = max(maxdelay, lib.QY265EncoderDelayedFrames(h))
     if os.environ.get("KS_TEST_KEYREQ") and t in (17, 18, 40): lib.QY265EncoderKeyFrameRequest(h)

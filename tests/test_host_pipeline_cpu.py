@@ -97,3 +97,12 @@ def test_strided_input_and_reconfigure(stub_lib):
     c = run(stub_lib, 130, 64, 0, KS_TEST_RECONFIG=1)
     d = run(stub_lib, 130, 64, 0, KS_TEST_RECONFIG=1, KS265_NO_GRAPH=1)
     assert c["vcl"] == 130 and c["md5"] == d["md5"] and c["md5"] != run(stub_lib, 130, 64, 0)["md5"]
+
+
+@pytest.mark.parametrize("lanes", [1, 2])
+@pytest.mark.parametrize("at", [0, 1, 5])
+def test_device_failure_is_reported_not_hung(stub_lib, lanes, at):
+    """the at-th picture fails on the device (a launch error): QY265EncoderEncodeFrame returns QY_FAIL within a few calls - also when the caller had run 17 pictures
+    ahead of the scheduler thread and was waiting for it - and QY265EncoderClose comes back"""
+    r = run(stub_lib, 100, 32, 0, timeout=60, KS265_GOP_LANES=lanes, KS265_STUB_FAIL_AT=at, KS_TEST_EXPECT_ERROR=1)
+    assert r.get("error") == 0x80000001 and r["at"] <= at + 40, r
