@@ -54,6 +54,10 @@ for t in range(N):
     take()
     maxdelay = max(maxdelay, lib.QY265EncoderDelayedFrames(h))
     if os.environ.get("KS_TEST_KEYREQ") and t in (17, 18, 40): lib.QY265EncoderKeyFrameRequest(h)
+if os.environ.get("KS_TEST_CLOSE_EARLY"):                 # no flush: pictures are still in flight on every thread when the handle is closed
+    lib.QY265EncoderClose(h)
+    print(json.dumps({"closed_early": True, "vcl": len(pts)}))
+    sys.exit(0)
 calls = 0
 while lib.QY265EncoderDelayedFrames(h):
     assert lib.QY265EncoderEncodeFrame(h, C.byref(nal), C.byref(nn), None, C.byref(outp), 0) == 0

@@ -106,3 +106,34 @@ def test_device_failure_is_reported_not_hung(stub_lib, lanes, at):
     ahead of the scheduler thread and was waiting for it - and QY265EncoderClose comes back"""
     r = run(stub_lib, 100, 32, 0, timeout=60, KS265_GOP_LANES=lanes, KS265_STUB_FAIL_AT=at, KS_TEST_EXPECT_ERROR=1)
     assert r.get("error") == 0x80000001 and r["at"] <= at + 40, r
+
+
+@pytest.mark.parametrize("lanes,bframes", [(1, 0), (2, 0), (1, -1)])
+def test_close_without_flush(stub_lib, lanes, bframes):
+    """QY265EncoderClose while pictures are waiting for the scheduler, in flight and half written: every thread is joined, nothing hangs"""
+    r = run(stub_lib, 90, 32, bframes, timeout=60, KS265_GOP_LANES=lanes, KS_TEST_CLOSE_EARLY=1)
+    assert r["closed_early"] and r["vcl"] < 90
+
+
+def test_two_encoders_in_one_process(stub_lib):
+    """two handles driven from two threads at once (the API calls release the GIL): no shared state between handles - both write the stream a lone encoder writes"""
+    code = (
+        "import sys, os, threading, subprocess, json\n"
+        "sys.argv = ['d'] + sys.argv[1:]\n"
+        "src = open(os.path.join(sys.argv[1], 'tests', 'host_driver.py')).read()\n"
+        "import io, contextlib\n"
+        "outs = [io.StringIO(), io.StringIO()]\n"
+        "def work(k):\n"
+        "    g = {'__name__': 'drv%d' % k}\n"
+        "    import builtins\n"
+        "    g['print'] = lambda *a, **kw: outs[k].write(' '.join(str(x) for x in a) + '\\n')\n"
+        "    exec(compile(src, 'host_driver.py', 'exec'), g)\n"
+        "ts = [threading.Thread(target=work, args=(k,)) for k in range(2)]\n"
+        "[t.start() for t in ts]; [t.join() for t in ts]\n"
+        "print(outs[0].getvalue().strip().splitlines()[-1]); print(outs[1].getvalue().strip().splitlines()[-1])\n")
+    e = dict(os.environ, KS265_STUB_LIB=stub_lib)
+    r = subprocess.run([sys.executable, "-c", code, ROOT, "120", "32", "0", "128", "72"], capture_output=True, text=True, timeout=120, env=e)
+    assert r.returncode == 0, r.stdout[-400:] + r.stderr[-1200:]
+    a, b = (json.loads(l) for l in r.stdout.strip().splitlines()[-2:])
+    lone = run(stub_lib, 120, 32, 0)
+    assert a["md5"] == b["md5"] == lone["md5"]
