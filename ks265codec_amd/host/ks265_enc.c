@@ -233,6 +233,7 @@ typedef struct Enc {
     int gop_start;                                        /* display index of the last key picture */
     int coded_upto;                                       /* display index up to which everything is scheduled */
     int force_key;
+    int gop_end, gop_end_seen;                            /* GOP lanes: display index of the last picture of a GOP that ended early (-1: none); what the scheduler has acted on */
     Job jobs[MAX_JOBS]; int ring, job_head, job_tail, njobs;   /* ring of `ring` pictures in coding order */
     /* workers */
     pthread_t th[64]; int nth; pthread_mutex_t mu; pthread_cond_t cv_work, cv_done; int quit;
@@ -599,7 +600,7 @@ static int code_hier(Enc *e, int d, int a)
 }
 
 /* schedule whatever can be coded with the pictures received so far; flush = no more input will come */
-static int schedule(Enc *e, int flush, int have /* pictures [0, have) have arrived */)
+static int schedule(Enc *e, int flush, int have /* pictures [0, have) have arrived */, int gop_end /* a GOP ends at this picture whatever follows, or -1 */)
 {
     for (;;) {
         const int d = e->coded_upto;                                   /* last anchor / last coded display index; -1 before the first picture */
@@ -622,6 +623,7 @@ static int schedule(Enc *e, int flush, int have /* pictures [0, have) have arriv
             const Input *ik = input_at(e, k);
             if (ik && ik->key) { a = k - 1; break; }
         }
+        if (gop_end >= nxt && a > gop_end) a = gop_end;                 /* the GOP was closed behind this picture (its successor goes to another lane) */
         if (a >= have) { if (!flush) return QY_OK; a = have - 1; }
         const int pd = d - e->gop_start, pa = a - e->gop_start;
         int l0[4], nl0 = 0, keep[8], nkeep = 0;
@@ -654,18 +656,18 @@ static void *scheduler(void *arg)
     Enc *e = (Enc *)arg;
     pthread_mutex_lock(&e->mu);
     for (;;) {
-        while (!e->quit && e->sched_seen == e->next_disp && !e->sched_flush) { e->sched_idle = 1; pthread_cond_broadcast(&e->cv_sched_done); pthread_cond_wait(&e->cv_sched, &e->mu); }
+        while (!e->quit && e->sched_seen == e->next_disp && !e->sched_flush && e->gop_end_seen == e->gop_end) { e->sched_idle = 1; pthread_cond_broadcast(&e->cv_sched_done); pthread_cond_wait(&e->cv_sched, &e->mu); }
         if (e->quit) break;
         e->sched_idle = 0;
-        const int flush = e->sched_flush, have = e->next_disp;
+        const int flush = e->sched_flush, have = e->next_disp, gop_end = e->gop_end;
         pthread_mutex_unlock(&e->mu);
         const double t0 = now_ms();
-        const int r = schedule(e, flush, have);
+        const int r = schedule(e, flush, have, gop_end);
         const double dt = now_ms() - t0;
         pthread_mutex_lock(&e->mu);
         e->st.submit_ms += dt;
         if (r && !e->sched_err) e->sched_err = r;
-        e->sched_seen = have;
+        e->sched_seen = have; e->gop_end_seen = gop_end;
         if (flush && have == e->next_disp) e->sched_flush = 0;          /* everything that had arrived is scheduled */
     }
     e->sched_idle = 1;
@@ -816,7 +818,7 @@ static Enc *lane_open(QY265EncConfig *cfg, int *err)
     if (e->base_qp < 0) e->base_qp = 0;
     if (e->base_qp > 51) e->base_qp = 51;
     e->iper = cfg->iIntraPeriod;
-    e->coded_upto = -1;
+    e->coded_upto = -1; e->gop_end = e->gop_end_seen = -1;
     long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
     e->nthreads = cfg->threads > 0 ? cfg->threads : (int)(ncpu > 0 ? ncpu : 4);
     if (e->nthreads > 64) e->nthreads = 64;
@@ -1043,15 +1045,15 @@ static int lane_set_recon_file(Enc *e, const char *path)
  * them AT ONCE on one GPU: the handle owns L lanes, every lane a complete pipeline (streams, workspace, DPB, scheduler / dispatcher / writer threads);
  * GOP k of the input goes to lane k mod L, each GOP's first picture marked as a key picture in band; output is handed out in GOP order (all of GOP k,
  * then GOP k + 1 from the next lane), so the stream is byte for byte the one a single lane writes (tests/test_gpu_enc_api.py).  The reference's
- * enFrameParallel (frames of one stream coded concurrently on CPU threads) is the switch: lanes run with enFrameParallel != 0, IPPP (-bframes 0),
- * fixed QP (-rc 0) and a key period of at least 32 pictures - B pictures in front of a key picture reference it (the GOPs are not closed), the rate
- * controllers carry state across GOPs.  Cost: output lags the input by up to L GOPs, and L pipelines' worth of buffers.
+ * enFrameParallel (frames of one stream coded concurrently on CPU threads) is the switch: lanes run with enFrameParallel != 0, fixed QP (-rc 0) and a key
+ * period of at least 32 pictures (the rate controllers carry state across GOPs).  Every GOP structure works: the scheduler closes a GOP in front of a key picture
+ * (the mini-GOP there is shortened to end in a P picture), so nothing references across lanes.  Cost: output lags the input by up to L GOPs, and L pipelines' worth of buffers.
  * Off by default (KS265_GOP_LANES = 2..4 switches it on): measured at 2160p on the round-2 box, two lanes reach 1.05x of one (1123 vs 1068 frames/s) -
  * with twice the pictures in flight the slice writers, not the GPU, set the pace (their time per picture grows from 19 to 59 ms of thread time as the
  * threads spread over the host), DESIGN.md section 6. */
 #define MAX_LANES 4
 #define MAX_CHUNKS 64
-typedef struct Chunk { int lane, closed; long count, delivered, base; } Chunk;
+typedef struct Chunk { int lane, closed; long count, delivered, base; int disp0; /* the lane's own display index of the GOP's first picture */ } Chunk;
 typedef struct Top {
     int nlanes; Enc *lane[MAX_LANES];
     int iper, key_request, cur_lane;
@@ -1130,10 +1132,25 @@ static int top_collect(Top *t, int block, QY265Picture *out)
         const int ra = top_append(t, nals, n);
         if (ra) return ra;
         c->delivered += pics;
-        if (out) out->poc = (int)(c->base + c->delivered - 1);         /* IPPP: coding order = display order */
+        if (out) out->poc = (int)(c->base + (out->poc - c->disp0));    /* the lane reports its own display index */
         block = 0;
     }
     return QY_OK;
+}
+
+/* no more input for the newest GOP.  early: it ends before its period is over (a key-picture request) - with B pictures the lane's scheduler is still waiting
+ * for the rest of a mini-GOP, so it is told where the GOP ends (short mini-GOP there, as in front of a key picture); a GOP of full length ends by itself */
+static void top_close_chunk(Top *t, int early)
+{
+    Chunk *c = &t->ch[(t->ch_head + t->ch_n - 1) % MAX_CHUNKS];
+    c->closed = 1;
+    if (early) {
+        Enc *e = t->lane[c->lane];
+        pthread_mutex_lock(&e->mu);
+        e->gop_end = e->next_disp - 1;                                  /* the lane's own index of the GOP's last picture */
+        pthread_cond_signal(&e->cv_sched);
+        pthread_mutex_unlock(&e->mu);
+    }
 }
 
 static int top_lanes_wanted(const QY265EncConfig *cfg)
@@ -1142,8 +1159,7 @@ static int top_lanes_wanted(const QY265EncConfig *cfg)
     int n = env ? atoi(env) : 1;
     if (n < 1) n = 1;
     if (n > MAX_LANES) n = MAX_LANES;
-    const int ippp = cfg->bframes == 0 || (cfg->bframes < 0 && cfg->latency != QY265LATENCY_DEFAULT);
-    if (!cfg->enFrameParallel || !ippp || cfg->rc != 0 || cfg->iIntraPeriod < 32) n = 1;
+    if (!cfg->enFrameParallel || cfg->rc != 0 || cfg->iIntraPeriod < 32) n = 1;
     return n;
 }
 
@@ -1241,12 +1257,12 @@ int QY265EncoderEncodeFrame(void *h, QY265Nal **pNals, int *iNalCount, QY265Pict
     if (in) {
         int first = 0;
         if (t->chunk_left <= 0 || t->key_request) {                     /* a new GOP: the next lane */
-            if (t->ch_n) t->ch[(t->ch_head + t->ch_n - 1) % MAX_CHUNKS].closed = 1;
+            if (t->ch_n) top_close_chunk(t, t->chunk_left > 0);
             while (t->ch_n == MAX_CHUNKS && !r) r = top_collect(t, 1, out);
             if (r) return r;
             t->cur_lane = (t->cur_lane + 1) % t->nlanes;
             Chunk *c = &t->ch[(t->ch_head + t->ch_n) % MAX_CHUNKS];
-            c->lane = t->cur_lane; c->closed = 0; c->count = 0; c->delivered = 0; c->base = t->n_in;
+            c->lane = t->cur_lane; c->closed = 0; c->count = 0; c->delivered = 0; c->base = t->n_in; c->disp0 = t->lane[t->cur_lane]->next_disp;
             ++t->ch_n;
             t->chunk_left = t->iper > 0 ? t->iper : (1L << 40);
             t->key_request = 0; first = 1;
@@ -1267,7 +1283,7 @@ int QY265EncoderEncodeFrame(void *h, QY265Nal **pNals, int *iNalCount, QY265Pict
         if (!r) for (int i = 0; i < t->nlanes && !r; ++i) r = t->lane[i]->sched_err;
     } else {
         const double t0 = now_ms();
-        if (t->ch_n) t->ch[(t->ch_head + t->ch_n - 1) % MAX_CHUNKS].closed = 1;
+        if (t->ch_n) top_close_chunk(t, 0);                              /* the lanes are flushed below */
         t->chunk_left = 0;
         for (int i = 0; i < t->nlanes; ++i) {
             if (lane_delayed(t->lane[i])) lane_flush_begin(t->lane[i]);

@@ -28,6 +28,8 @@ def take():
     for i in range(nn.value):
         b = C.string_at(nal[i].pPayload, nal[i].iSize); md.update(b); bs.extend(b); types.append(nal[i].naltype)
         if nal[i].naltype < 32: pts.append(nal[i].pts)
+    if nn.value and pts:
+        assert outp.poc == pts[-1], ("the output picture's display index", outp.poc, pts[-1])    # pts = display index in this driver
 strided = bool(os.environ.get("KS_TEST_STRIDE"))
 if strided:                                                # planes with padded rows: the library copies row by row
     pad = 24

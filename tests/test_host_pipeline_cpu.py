@@ -37,12 +37,16 @@ def run(stub_lib, n, iper, bframes, W=128, H=72, out=None, timeout=120, **env):
     return json.loads(r.stdout.strip().splitlines()[-1])
 
 
-def test_lanes_hand_out_the_one_lane_stream(stub_lib, tmp_path):
-    res = {L: run(stub_lib, 150, 32, 0, out=tmp_path / f"l{L}.265", KS265_GOP_LANES=L) for L in (1, 2, 3)}
+@pytest.mark.parametrize("bframes", [0, -1, 3])
+def test_lanes_hand_out_the_one_lane_stream(stub_lib, tmp_path, bframes):
+    """IPPP, hierarchical B (8), P + 3 B: the scheduler closes every GOP in front of the next key picture, so GOPs can be coded on different lanes"""
+    res = {L: run(stub_lib, 150, 32, bframes, out=tmp_path / f"l{L}.265", KS265_GOP_LANES=L) for L in (1, 2, 3)}
     for L, r in res.items():
-        assert r["lanes"] == L and r["vcl"] == 150 and r["idr"] == 5 and r["pts"] == list(range(150)), (L, r["vcl"], r["idr"])
+        assert r["lanes"] == L and r["vcl"] == 150 and r["idr"] == 5 and sorted(r["pts"]) == list(range(150)), (L, r["vcl"], r["idr"])
+        assert (r["pts"] == list(range(150))) == (bframes == 0)
     assert res[1]["md5"] == res[2]["md5"] == res[3]["md5"]
-    assert res[2]["maxdelay"] > 32                                           # the second GOP is held back until the first one has left
+    if bframes == 0:
+        assert res[2]["maxdelay"] > 32                                       # the second GOP is held back until the first one has left
     if os.path.exists(REF_DEC):                                              # the records of the stand-in make a stream the reference decoder accepts
         d = subprocess.run([REF_DEC, "-b", str(tmp_path / "l2.265"), "-o", str(tmp_path / "d.yuv"), "-threads", "2"], capture_output=True, text=True, cwd=tmp_path)
         assert d.returncode == 0 and os.path.getsize(tmp_path / "d.yuv") == 150 * 128 * 72 * 3 // 2, d.stdout[-300:] + d.stderr[-300:]
@@ -80,6 +84,8 @@ def test_key_frame_requests(stub_lib):
     for bframes in (-1, 3):                                                 # with B pictures the mini-GOP in front of the requested key picture is shortened
         a, b = run(stub_lib, 100, 32, bframes, KS_TEST_KEYREQ=1), run(stub_lib, 100, 32, bframes, KS_TEST_KEYREQ=1, KS265_NO_GRAPH=1)
         assert a["vcl"] == 100 and sorted(a["pts"]) == list(range(100)) and a["idr"] == 5 and a["md5"] == b["md5"], (bframes, a["idr"])
+        c = run(stub_lib, 100, 32, bframes, KS_TEST_KEYREQ=1, KS265_GOP_LANES=2)     # lanes: the GOP that ends early is told so (its lane schedules what it has)
+        assert c["md5"] == a["md5"]
 
 
 def test_no_device_means_no_encoder(stub_lib):
