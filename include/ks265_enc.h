@@ -89,7 +89,7 @@ typedef struct { long frames; long long bytes; double sse[3]; double gpu_ms; dou
                  long occ_samples, occ_ring, occ_gpu, occ_ready;   /* sampled at every submission: pictures in the ring, of them not yet through the GPU, of them waiting for a writer */
 } ks265_enc_stats;
 int ks265_enc_get_stats(void *pEncoder, ks265_enc_stats *out);
-/* extension: closed GOPs coded concurrently by this handle ("GOP lanes": KS265_GOP_LANES = 2..4 with enFrameParallel, IPPP, -rc 0, key period >= 32;
+/* extension: closed GOPs coded concurrently by this handle ("GOP lanes": KS265_GOP_LANES = 2..4 with enFrameParallel, -rc 0, key period >= 32, any GOP structure;
  * default 1).  Output stays in stream order and is byte for byte the one-lane stream; it lags the input by up to that many GOPs. */
 int ks265_enc_lanes(void *pEncoder);
 /* extension: write the reconstruction (I420, display order) to `path` - the reference CLI's `-o`; call between Open and the first picture */
