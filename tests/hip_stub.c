@@ -1,7 +1,8 @@
 /* TEST INFRASTRUCTURE: a CPU stand-in for the subset of libks265hip.so the encoder host (ks265codec_amd/host/ks265_enc.c) calls, so that the host's threads,
  * rings, GOP scheduling, GOP lanes, graph cache and bitstream writer can be exercised by `-m "not gpu"` tests.  It is NOT a CPU fallback of the product (nothing in
- * ks265codec_amd/ knows it) and it does not encode: every "picture" gets a fixed, valid set of records - 8x8 CUs, DC intra without residual in key pictures, one
- * vector per CU derived from hashes of the source and reference pictures otherwise - so that the stream the writer produces depends on which pictures met in which
+ * ks265codec_amd/ knows it) and it does not encode: every "picture" gets a fixed, valid set of records - 8x8 CUs, DC intra in key pictures, otherwise one or two vectors
+ * per CU, and a few levels in every fifth block, all derived from hashes of the source and reference pictures (packed into the compact record format like
+ * the device does) - so that the stream the writer produces depends on which pictures met in which
  * order, which is what the host tests look at.  Streams are synchronous (everything runs inside the call), events are always complete; a captured "graph" is the
  * list of the recorded calls, replayed by ks265_graph_launch. */
 #include "ks265_hip.h"
@@ -17,6 +18,7 @@ struct ks265_frame {
     ks265_ctx *ctx; ks265_frame_cfg cfg; ks265_frame_geom g;
     int cur_pu, have_prev;
     ks265_cu8 *cu8; ks265_sao_param *sao; uint64_t kind_hash;
+    int16_t *lvl[3];                                          /* level planes, W x H and two W/2 x H/2, packed */
 };
 
 const char *ks265_version(void) { return "ks265hip CPU stub (tests only)"; }
@@ -55,10 +57,12 @@ int ks265_frame_create(ks265_ctx *ctx, const ks265_frame_cfg *cfg, ks265_frame *
     f->ctx = ctx; f->cfg = *cfg;
     if (ks265_frame_geometry(cfg, &f->g)) { free(f); return KS265_NOTSUPPORTED; }
     f->cu8 = (ks265_cu8 *)calloc(1, (size_t)f->g.bytes_cu8); f->sao = (ks265_sao_param *)calloc(1, (size_t)f->g.bytes_sao);
+    const size_t npx = (size_t)cfg->width * cfg->height;
+    f->lvl[0] = (int16_t *)calloc(npx, 2); f->lvl[1] = (int16_t *)calloc(npx / 4 + 1, 2); f->lvl[2] = (int16_t *)calloc(npx / 4 + 1, 2);
     *out = f;
     return KS265_OK;
 }
-void ks265_frame_destroy(ks265_frame *f) { if (f) { free(f->cu8); free(f->sao); free(f); } }
+void ks265_frame_destroy(ks265_frame *f) { if (f) { free(f->cu8); free(f->sao); free(f->lvl[0]); free(f->lvl[1]); free(f->lvl[2]); free(f); } }
 int ks265_frame_set_qp(ks265_frame *f, int qp, int l) { f->cfg.qp = qp; f->cfg.lambda_q4 = l; return KS265_OK; }
 int ks265_frame_p_state(ks265_frame *f) { return (f->cur_pu & 1) | (f->have_prev ? 2 : 0); }
 int ks265_frame_p_advance(ks265_frame *f) { f->cur_pu ^= 1; f->have_prev = 1; return KS265_OK; }
@@ -97,6 +101,20 @@ static void do_encode(ks265_frame *f, int kind /*0 key, 1 P, 2 B*/, ks265_pic sr
             c.mvx = (int16_t)((m & 15) - 8); c.mvy = (int16_t)(((m >> 4) & 7) - 4);
             c.mv1x = (int16_t)(((m >> 8) & 15) - 8); c.mv1y = (int16_t)(((m >> 12) & 7) - 4);
         }
+        /* a few levels in about every fifth block (luma 8x8, chroma 4x4), the coded-block flags to match: the host's expansion of the compact records and the
+         * writer's residual coding get something to do; which blocks and what values depends on the pictures that met, like the vectors */
+        const uint64_t r = mix ^ ((uint64_t)i * 0xD1B54A32D192ED03ull);
+        const int W = f->cfg.width, bx = i % w8, by = i / w8;
+        int16_t *ly = f->lvl[0] + (size_t)by * 8 * W + bx * 8, *lu = f->lvl[1] + (size_t)by * 4 * (W / 2) + bx * 4, *lv = f->lvl[2] + (size_t)by * 4 * (W / 2) + bx * 4;
+        for (int y = 0; y < 8; ++y) memset(ly + (size_t)y * W, 0, 16);
+        for (int y = 0; y < 4; ++y) { memset(lu + (size_t)y * (W / 2), 0, 8); memset(lv + (size_t)y * (W / 2), 0, 8); }
+        if ((r >> 20) % 5 == 0) {
+            const int n = 1 + (int)((r >> 24) & 3);
+            for (int k = 0; k < n; ++k) { const int pos = (int)((r >> (28 + 6 * k)) & 63), v = (int)((r >> (52 + 2 * k)) & 3) + 1; ly[(size_t)(pos >> 3) * W + (pos & 7)] = (int16_t)((k & 1) ? -v : v); }
+            c.cbf |= 1;
+            if ((r >> 60) & 1) { lu[(size_t)((r >> 8) & 3) * (W / 2) + ((r >> 10) & 3)] = (int16_t)(1 + ((r >> 12) & 1)); c.cbf |= 2; }
+            if ((r >> 61) & 1) { lv[(size_t)((r >> 14) & 3) * (W / 2) + ((r >> 16) & 3)] = (int16_t)-(1 + ((r >> 18) & 1)); c.cbf |= 4; }
+        }
         f->cu8[i] = c;
     }
     for (int i = 0; i < f->g.ctu_cols * f->g.ctu_rows * 3; ++i) { memset(&f->sao[i], 0, sizeof f->sao[i]); f->sao[i].type = -1; }
@@ -106,20 +124,35 @@ static void do_encode(ks265_frame *f, int kind /*0 key, 1 P, 2 B*/, ks265_pic sr
     for (int x = 0; x < W; ++x) { luma0(f, out)[x] = (uint8_t)(mix >> (8 * (x & 7))); luma0(f, out)[f->g.stride_y + x] = (uint8_t)((mix * 7) >> (8 * (x & 7))); }
     f->kind_hash = mix;
 }
+int ks265_frame_compact_layout(ks265_frame *f, size_t off[8]);
 static void do_pack(ks265_frame *f, uint8_t *dst, const uint64_t *extra)
 {
+    size_t off[8];
+    ks265_frame_compact_layout(f, off);
     const size_t npx = (size_t)f->cfg.width * f->cfg.height, pb[3] = {npx * 2, npx / 2, npx / 2};
-    size_t nlines = 0;
-    for (int i = 0; i < 3; ++i) nlines += (pb[i] + 63) / 64;
-    const size_t nchunk = (nlines + 1023) / 1024;
-    const size_t sz[7] = {(size_t)f->g.bytes_cu8, (size_t)f->g.bytes_sao, 64, 64, nchunk * 4, nchunk * 128, nlines * 64};
-    size_t off[8], o = 0;
-    for (int i = 0; i < 7; ++i) { off[i] = o; o += (sz[i] + 255) & ~(size_t)255; }
-    memcpy(dst + off[0], f->cu8, sz[0]); memcpy(dst + off[1], f->sao, sz[1]);
+    size_t first[4]; first[0] = 0;
+    for (int p = 0; p < 3; ++p) first[p + 1] = first[p] + (pb[p] + 63) / 64;
+    const size_t nlines = first[3], nchunk = (nlines + 1023) / 1024;
+    memcpy(dst + off[0], f->cu8, (size_t)f->g.bytes_cu8); memcpy(dst + off[1], f->sao, (size_t)f->g.bytes_sao);
     if (extra) memcpy(dst + off[2], extra, 64); else memset(dst + off[2], 0, 64);
-    uint32_t *hdr = (uint32_t *)(dst + off[3]);
-    memset(hdr, 0, 64); hdr[2] = 0; hdr[3] = (uint32_t)nlines;                            /* no level line is set: all residuals are zero */
-    memset(dst + off[4], 0, sz[4]); memset(dst + off[5], 0, sz[5]);
+    uint32_t *hdr = (uint32_t *)(dst + off[3]), *table = (uint32_t *)(dst + off[4]);
+    uint64_t *bm = (uint64_t *)(dst + off[5]);
+    uint8_t *data = dst + off[6];
+    memset(bm, 0, nchunk * 128);
+    uint32_t stored = 0;
+    for (size_t L = 0; L < nlines; ++L) {                        /* the stored lines in line order; the device packs chunk by chunk in any order, the table says where */
+        if ((L & 1023) == 0) table[L >> 10] = stored;
+        const int p = L >= first[2] ? 2 : L >= first[1] ? 1 : 0;
+        const size_t o = (L - first[p]) * 64, n = pb[p] - o < 64 ? pb[p] - o : 64;
+        const uint8_t *src = (const uint8_t *)f->lvl[p] + o;
+        int nz = 0;
+        for (size_t k = 0; k < n; ++k) nz |= src[k];
+        if (!nz) continue;
+        bm[L >> 6] |= 1ull << (L & 63);
+        memset(data + (size_t)stored * 64, 0, 64); memcpy(data + (size_t)stored * 64, src, n);
+        ++stored;
+    }
+    memset(hdr, 0, 64); hdr[2] = stored; hdr[3] = (uint32_t)nlines;
 }
 int ks265_frame_compact_layout(ks265_frame *f, size_t off[8])
 {
@@ -204,6 +237,6 @@ int ks265_copy_out_compact_async(ks265_ctx *c, ks265_frame *f, void *host, const
     (void)c;
     size_t off[8];
     ks265_frame_compact_layout(f, off);
-    memcpy(host, dev, off[6]);
+    memcpy(host, dev, off[6] + (size_t)((const uint32_t *)((const uint8_t *)dev + off[3]))[2] * 64);     /* the fixed part + the stored lines */
     return KS265_OK;
 }
