@@ -67,7 +67,7 @@ def test_graph_replay_equals_launch_by_launch(stub_lib, bframes):
     iper = 64
     a = run(stub_lib, 170, iper, bframes)
     assert a["vcl"] == 170 and sorted(a["pts"]) == list(range(170))
-    for env in ({"KS265_NO_GRAPH": 1}, {"KS265_STUB_NO_CAPTURE": 1}, {"KS265_STUB_NO_INSTANTIATE": 1}):
+    for env in ({"KS265_NO_GRAPH": 1}, {"KS265_STUB_NO_CAPTURE": 1}, {"KS265_STUB_NO_INSTANTIATE": 1}, {"KS265_FLAG_WAIT": 1}):   # the last: completion by a word in pinned memory
         b = run(stub_lib, 170, iper, bframes, **env)
         assert b["md5"] == a["md5"], env
     if bframes:
