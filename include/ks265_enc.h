@@ -92,6 +92,9 @@ int ks265_enc_get_stats(void *pEncoder, ks265_enc_stats *out);
 /* extension: closed GOPs coded concurrently by this handle ("GOP lanes": KS265_GOP_LANES = 2..4 with enFrameParallel, -rc 0, key period >= 32, any GOP structure;
  * default 1).  Output stays in stream order and is byte for byte the one-lane stream; it lags the input by up to that many GOPs. */
 int ks265_enc_lanes(void *pEncoder);
+/* extension: the switches of the reference CLI that QY265EncConfig has no field for - "df" (deblocking, default 1), "fixqp" (1 = no per-layer QP offsets: every
+ * picture at -qp), "md5" (1 = log `POC n MD5 y,u,v` of every reconstructed picture, display order).  Process-wide defaults read by the next QY265EncoderOpen. */
+int ks265_enc_set_default(const char *name, int value);
 /* extension: write the reconstruction (I420, display order) to `path` - the reference CLI's `-o`; call between Open and the first picture */
 int ks265_enc_set_recon_file(void *pEncoder, const char *path);
 

@@ -45,6 +45,9 @@ int ks265_set_stream(ks265_ctx *ctx, void *hip_stream); /* adopt a caller stream
  * correctly (today: the intra wavefront's bounded wait timing out) -> KS265_FAIL with ks265_last_error() naming the condition; the
  * pictures encoded since the previous ks265_synchronize must then be re-encoded */
 int ks265_synchronize(ks265_ctx *ctx);
+/* reads and clears the same error word WITHOUT waiting for the stream: a pipelined host calls it once a picture's own completion event has fired (the word is
+ * per context = per stream; kernels of later pictures may already have run, so a set bit means "this picture or a later one") -> KS265_OK / KS265_FAIL */
+int ks265_take_device_error(ks265_ctx *ctx);
 /* test hook: KS265_DBG_WAVEFRONT_SPINS = the number of polls a CTU row of the intra wavefront waits for the row above (value < 0
  * restores the default, about one second); 0 forces the timeout path */
 enum { KS265_DBG_WAVEFRONT_SPINS = 1 };

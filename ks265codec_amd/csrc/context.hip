@@ -62,6 +62,17 @@ int ks265_synchronize(ks265_ctx *c)
     return KS265_OK;
 }
 
+/* the device error word without waiting for anything: pipelined hosts call it when a picture's completion event has fired */
+int ks265_take_device_error(ks265_ctx *c)
+{
+    if (!c) return KS265_POINTER;
+    const unsigned e = __atomic_exchange_n(c->err_host, 0u, __ATOMIC_ACQ_REL);
+    if (!e) return KS265_OK;
+    c->last_error = (e & KS_DEVERR_WAVEFRONT_TIMEOUT) ? "intra wavefront timeout: a CTU row waited too long for the row above; the picture is invalid, re-encode it"
+                                                      : "device-side error flag set";
+    return KS265_FAIL;
+}
+
 int ks265_debug_set(ks265_ctx *c, int what, int value)
 {
     if (!c) return KS265_POINTER;

@@ -56,12 +56,44 @@ static void usage(void)
 {
     puts("usage: ks265enc -i in.yuv -wdt W -hgt H [-fr FPS] [-preset ultrafast..placebo] [-latency zerolatency|lowdelay|livestreaming|default] [-tune T]\n"
          "                [-rc 0..5] [-qp Q] [-crf C] [-br KBPS] [-iper N] [-bframes N] [-frms N] [-threads N] [-psnr 0|1|2] [-b out.265] [-o recon.yuv]\n"
-         "                [-me 0|1|2] [-subme 0|1] [-merange R] [-ref N] [-sao 0..4] [-v]\n"
+         "                [-me 0|1|2] [-subme 0|1] [-merange R] [-ref N] [-sao 0..4] [-df 0|1] [-fixqp 0|1] [-md5 0|1] [-c config_file] [-gpus N] [-v]\n"
          "  I420 8-bit input; width and height multiples of 8.  Needs one MI355X (gfx950): there is no CPU fallback.");
+}
+
+/* -c file: a text file of further options, `-name value` or `name value` / `name = value` / `name : value` per line, `#` starts a comment; its
+ * options are spliced into the command line where -c stood (later options override earlier ones, as on the command line) */
+static int splice_config(int *pargc, char ***pargv)
+{
+    int argc = *pargc; char **argv = *pargv;
+    for (int i = 1; i + 1 < argc; ++i) {
+        if (strcmp(argv[i], "-c")) continue;
+        FILE *f = fopen(argv[i + 1], "r");
+        if (!f) { fprintf(stderr, "cannot read the config file %s\n", argv[i + 1]); return -1; }
+        char **nv = (char **)malloc(sizeof(char *) * (size_t)(argc + 2048));
+        int n = 0;
+        if (!nv) { fclose(f); return -1; }
+        for (int k = 0; k < i; ++k) nv[n++] = argv[k];
+        char line[1024];
+        while (fgets(line, sizeof line, f) && n < argc + 2000) {
+            char *h = strchr(line, '#'); if (h) *h = 0;
+            char *name = strtok(line, " \t\r\n=:"), *val = name ? strtok(NULL, " \t\r\n=:") : NULL;
+            if (!name || !val) continue;
+            char *a = (char *)malloc(strlen(name) + 2);
+            if (!a) break;
+            sprintf(a, "%s%s", name[0] == '-' ? "" : "-", name);
+            nv[n++] = a; nv[n++] = strdup(val);
+        }
+        fclose(f);
+        for (int k = i + 2; k < argc; ++k) nv[n++] = argv[k];
+        *pargc = n; *pargv = nv;
+        return splice_config(pargc, pargv);                              /* a second -c (or one inside the file) */
+    }
+    return 0;
 }
 
 int main(int argc, char **argv)
 {
+    if (splice_config(&argc, &argv)) return 2;
     const char *in_path = NULL, *out_path = NULL, *preset = "medium", *latency = "default", *tune = "default";
     const char *rec_path = NULL;
     int frames = -1;
@@ -88,6 +120,10 @@ int main(int argc, char **argv)
         else if (!strcmp(a, "-o")) rec_path = v;
         else if (!strcmp(a, "-frms")) frames = atoi(v);
         else if (!strcmp(a, "-preset") || !strcmp(a, "-latency") || !strcmp(a, "-tune")) continue;
+        else if (!strcmp(a, "-df") || !strcmp(a, "-fixqp") || !strcmp(a, "-md5")) {       /* CLI switches without a QY265EncConfig field */
+            if (ks265_enc_set_default(a + 1, atoi(v)) != QY_OK) { fprintf(stderr, "bad value for %s: %s\n", a, v); return 2; }
+        }
+        else if (!strcmp(a, "-gpus")) setenv("KS265_GPUS", v, 1);                            /* closed GOPs dealt to N GPUs behind this one handle (ks265_enc.h) */
         else {
             const int r = QY265ConfigParse(&cfg, a + 1, v);
             if (r == QY265_PARAM_BAD_NAME) { fprintf(stderr, "unknown option %s\n", a); return 2; }
@@ -140,8 +176,9 @@ int main(int argc, char **argv)
     const double t1 = now_ms();
     ks265_enc_stats st;
     ks265_enc_get_stats(h, &st);
-    printf("Total Frames: %ld, test time: %.0f ms, FPS: %.4f\n", n, t1 - t0, n * 1000.0 / (t1 - t0));
-    printf("pure encoding time: %.0f ms (waiting for the input reader %.0f ms), slice writing %.1f ms per picture per thread\n", t1 - t0 - t_io, t_io, st.frames ? st.host_write_ms / st.frames : 0.0);
+    printf("Total Frames: %ld, test time: %.0fms, FPS: %.4f\n", n, t1 - t0, n * 1000.0 / (t1 - t0));                 /* appencoder's two summary lines, same text */
+    printf("Total Frames: %ld, pure encoding time: %.0fms, %.4f fps\n", n, t1 - t0 - t_io, n * 1000.0 / (t1 - t0 - t_io > 1e-3 ? t1 - t0 - t_io : 1e-3));
+    printf("waiting for the input reader %.0f ms, slice writing %.1f ms per picture per thread\n", t_io, st.frames ? st.host_write_ms / st.frames : 0.0);
     printf("calling thread: input copy %.0f ms, enqueueing GPU work %.0f ms, output (wait + copy) %.0f ms\n", st.in_copy_ms, st.submit_ms, st.output_ms);
     printf("per picture: enqueue -> records on the host %.2f ms, enqueue -> writer pick-up %.2f ms\n", st.frames ? st.lat_gpu_ms / st.frames : 0.0, st.frames ? st.lat_queue_ms / st.frames : 0.0);
     QY265EncoderClose(h);                                            /* prints "bitrate, psnr: ..." */

@@ -36,6 +36,54 @@ static void logf_(int level, int min_level, const char *fmt, ...)
     if (g_log_cb) g_log_cb(buf); else { fputs(buf, stdout); fflush(stdout); }
 }
 
+/* ---- MD5 (RFC 1321) of the reconstructed planes: the reference CLI's `-md5 1` lines `POC n MD5 y,u,v` (README.md:61-66 conventions) */
+static void md5_block(uint32_t st[4], const uint8_t *p)
+{
+    static const uint8_t sh[64] = {7, 12, 17, 22, 7, 12, 17, 22, 7, 12, 17, 22, 7, 12, 17, 22, 5, 9, 14, 20, 5, 9, 14, 20, 5, 9, 14, 20, 5, 9, 14, 20,
+                                   4, 11, 16, 23, 4, 11, 16, 23, 4, 11, 16, 23, 4, 11, 16, 23, 6, 10, 15, 21, 6, 10, 15, 21, 6, 10, 15, 21, 6, 10, 15, 21};
+    static uint32_t K[64]; static int init;
+    if (!init) { for (int i = 0; i < 64; ++i) K[i] = (uint32_t)(4294967296.0 * fabs(sin((double)(i + 1)))); __atomic_store_n(&init, 1, __ATOMIC_RELEASE); }
+    uint32_t w[16], a = st[0], b = st[1], c = st[2], d = st[3];
+    for (int i = 0; i < 16; ++i) w[i] = (uint32_t)p[4 * i] | (uint32_t)p[4 * i + 1] << 8 | (uint32_t)p[4 * i + 2] << 16 | (uint32_t)p[4 * i + 3] << 24;
+    for (int i = 0; i < 64; ++i) {
+        uint32_t f; int g;
+        if (i < 16) { f = (b & c) | (~b & d); g = i; }
+        else if (i < 32) { f = (d & b) | (~d & c); g = (5 * i + 1) & 15; }
+        else if (i < 48) { f = b ^ c ^ d; g = (3 * i + 5) & 15; }
+        else { f = c ^ (b | ~d); g = (7 * i) & 15; }
+        const uint32_t t = d; d = c; c = b;
+        const uint32_t x = a + f + K[i] + w[g];
+        b = b + ((x << sh[i]) | (x >> (32 - sh[i]))); a = t;
+    }
+    st[0] += a; st[1] += b; st[2] += c; st[3] += d;
+}
+static void md5_hex(const uint8_t *data, size_t n, char out[33])
+{
+    uint32_t st[4] = {0x67452301u, 0xefcdab89u, 0x98badcfeu, 0x10325476u};
+    size_t i = 0;
+    for (; i + 64 <= n; i += 64) md5_block(st, data + i);
+    uint8_t tail[128]; size_t r = n - i;
+    memcpy(tail, data + i, r); tail[r++] = 0x80;
+    const size_t padded = r <= 56 ? 64 : 128;
+    memset(tail + r, 0, padded - r);
+    const uint64_t bits = (uint64_t)n * 8;
+    for (int k = 0; k < 8; ++k) tail[padded - 8 + k] = (uint8_t)(bits >> (8 * k));
+    md5_block(st, tail); if (padded == 128) md5_block(st, tail + 64);
+    for (int k = 0; k < 16; ++k) snprintf(out + 2 * k, 3, "%02x", (unsigned)((st[k >> 2] >> (8 * (k & 3))) & 255u));
+}
+
+/* CLI-level switches of `appencoder` that the SDK's QY265EncConfig has no field for (-df, -fixqp, -md5): process-wide defaults a front end
+ * sets before QY265EncoderOpen (ks265_enc_set_default) */
+static struct { int df, fixqp, md5; } g_cli = {1, 0, 0};
+int ks265_enc_set_default(const char *name, int value)
+{
+    if (!name) return QY_POINTER;
+    if (!strcmp(name, "df")) { if (value < 0 || value > 1) return QY265_PARAM_BAD_VALUE; g_cli.df = value; return QY_OK; }
+    if (!strcmp(name, "fixqp")) { if (value < 0 || value > 1) return QY265_PARAM_BAD_VALUE; g_cli.fixqp = value; return QY_OK; }
+    if (!strcmp(name, "md5")) { if (value < 0 || value > 1) return QY265_PARAM_BAD_VALUE; g_cli.md5 = value; return QY_OK; }
+    return QY265_PARAM_BAD_NAME;
+}
+
 /* motion lambda in Q4 per QP: round(16 * sqrt(0.57 * 2^((qp - 12) / 3))) - the host-side float setup of the pixel path, as a table so that
  * every host (this one, the Python test mirror ks265codec_amd/synth.py) uses identical integers */
 static const int kLambdaQ4[52] = {3, 3, 4, 4, 5, 5, 6, 7, 8, 9, 10, 11, 12, 14, 15, 17, 19, 22, 24, 27, 30, 34, 38, 43, 48, 54, 61, 68, 77, 86, 97, 108, 122, 137, 153, 172,
@@ -123,11 +171,13 @@ typedef struct Job {
     ks265_cu8 *cu8; int16_t *lvl[3]; ks265_sao_param *sao; uint64_t *sse;      /* cu8 / sao / sse point into cmp, lvl into lvlbuf */
     int ev_err;
     void *wpp; ks265_slice_in sin; int started, nrows, next_row, rows_done;   /* row-wise writing of the slice (ks265_wpp_*) */
-    uint8_t *recon;                                       /* pinned I420 copy of the reconstruction (only with ks265_enc_set_recon_file) */
+    uint8_t *recon;                                       /* pinned I420 copy of the reconstruction (only with ks265_enc_set_recon_file / -md5) */
+    char md5[3][33];
     void *ev;                                             /* recorded after the D2H copies */
     volatile uint32_t *flag; uint32_t flag_want;          /* KS265_FLAG_WAIT: set by the copy-out kernel itself when the records are on the host (pinned word) */
     uint8_t *nal; size_t nal_cap; long nal_len;
     int key_headers;                                      /* parameter sets go in front of this picture */
+    int rc_delta;                                         /* the controller's QP offset this picture was coded with (rate control) */
     double t_write_ms, t_submit, t_event, t_taken, t_done;      /* wall-clock marks: enqueued, records on the host (seen by a writer), writer started */
 } Job;
 
@@ -199,9 +249,10 @@ static void copy_shared(CopyPool *p, uint8_t *d, const uint8_t *s, size_t n)
     pthread_mutex_unlock(&p->mu);
 }
 
-typedef struct Input { int used, disp, key, base_qp; long long pts; uint8_t *i420; } Input;     /* pinned; key: this picture starts a closed GOP whatever the period says (GOP lanes,
+typedef struct Input { int used, disp, key, base_qp, iper; long long pts; uint8_t *i420; } Input;     /* pinned; key: this picture starts a closed GOP whatever the period says (GOP lanes,
                                                                                                  * QY265EncoderKeyFrameRequest); base_qp: the QP in force when the picture was handed in (QY265EncoderReconfig) -
-                                                                                                 * both travel WITH the picture: the scheduler thread may be several pictures behind the caller */
+                                                                                                 * iper: the key period in force then - all three travel WITH the picture: the scheduler thread
+                                                                                                 * may be several pictures behind the caller */
 
 typedef struct Enc {
     QY265EncConfig cfg;
@@ -224,7 +275,8 @@ typedef struct Enc {
 #define MAX_GRAPHS 256
     int flag_wait; uint32_t *dev_flag_counter; uint8_t *flag_mem; uint32_t flag_seq;      /* completion by a word in pinned memory instead of an event wait (opt-in) */
     int use_graph, ngraph; struct { uint64_t key[9]; void *exec; } graph[MAX_GRAPHS];
-    int recon_fd; uint8_t *dev_recon;                     /* reconstruction dump (the CLI's -o) */
+    int recon_fd, recon_on; uint8_t *dev_recon;           /* reconstruction dump (the CLI's -o) and / or plane MD5s (-md5 1): recon_on = the pictures come back to the host */
+    int md5, fixqp, psnr_hdr; int md5_next; char (*md5_ring)[3][33]; unsigned char *md5_have;   /* MD5 lines go out in display order (ring of 256 by display index) */
     ks265_pic src; ks265_pic dpb[MAX_DPB]; int dpb_poc[MAX_DPB]; int ndpb; uint64_t *dev_sse;
     /* key pictures on their own stream and frame object: an intra picture keeps 34 of 256 compute units busy for ~26 ms (2160p); coded as soon as its
      * input arrives - the pixel path is tens of pictures behind the input - it runs underneath the P pictures of the previous GOP instead of between
@@ -248,11 +300,17 @@ typedef struct Enc {
     QY265Nal nals[4 * MAX_JOBS + 8]; uint8_t *hdr; long hdr_len, hdr_part[3];
     uint8_t *outbuf; size_t outcap, outpos;               /* NAL payloads handed to the caller live here until the next call */
     ks265_enc_stats st;
-    /* rate control (frame level, rc != 0 and != 3) */
-    double rc_bits_target, rc_bits_spent; int rc_frames; int rc_qp_delta;
+    /* rate control (frame level, rc 1 / 2 / 4): the QP offset of a mini-GOP is a closed-form function of the pictures coded at least RC_LAG pictures earlier
+     * (coding order) - the scheduler waits for exactly those, so the stream does not depend on thread timing.  rc_qp_delta belongs to the scheduler thread;
+     * the sums are updated under mu in coding order (rc_account) */
+#define RC_LAG 16
+#define RC_HIST 512
+    double rc_sum_norm, rc_hist[RC_HIST]; long rc_acc_seq, rc_sub; int rc_acc_idx; int rc_qp_delta;
 } Enc;
 
 static double now_ms(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e3 + t.tv_nsec * 1e-6; }
+static void rc_account(Enc *e);
+static int lane_recon_on(Enc *e);
 static int hip_rc(int r) { return r == 0 ? QY_OK : r == KS265_OUTOFMEMORY ? QY_OUTOFMEMORY : r == KS265_POINTER ? QY_POINTER : r == KS265_NOTSUPPORTED ? QY_NOTSUPPORTED : QY_FAIL; }
 
 static int pic_alloc(Enc *e, ks265_pic *p)
@@ -286,6 +344,11 @@ static void *dispatcher(void *arg)
                 if ((++spins & 0xFFFFu) == 0 && now_ms() - t_spin > 5000.0) { err = ks265_event_wait(e->ctx_out, j->ev); break; }
             }
         } else err = ks265_event_wait(e->ctx_out, j->ev);
+        /* the device error word of the streams that code pictures (a wavefront that timed out leaves a picture whose levels do not match its reconstruction): the
+         * picture - this one or one enqueued after it - fails instead of going out as if nothing had happened */
+        if (!err) err = ks265_take_device_error(e->ctx);
+        if (!err && e->ctx_key) err = ks265_take_device_error(e->ctx_key);
+        if (err) logf_(2, e->log_level, "ks265enc: device error at picture %d: %s\n", j->disp, "intra wavefront timeout or device error flag (ks265_take_device_error)");
         j->t_event = now_ms();
         pthread_mutex_lock(&e->mu);
         j->ev_err = err;
@@ -373,6 +436,10 @@ static void *worker(void *arg)
                 const size_t fsz = (size_t)e->W * e->H * 3 / 2;
                 if (pwrite(e->recon_fd, j->recon, fsz, (off_t)j->disp * (off_t)fsz) != (ssize_t)fsz) err = KS265_FAIL;
             }
+            if (!err && e->md5 && j->recon) {
+                const size_t np = (size_t)e->W * e->H;
+                md5_hex(j->recon, np, j->md5[0]); md5_hex(j->recon + np, np / 4, j->md5[1]); md5_hex(j->recon + np + np / 4, np / 4, j->md5[2]);
+            }
             if (!err) {
                 ks265_slice_in *s = &j->sin;
                 memset(s, 0, sizeof *s);
@@ -387,6 +454,7 @@ static void *worker(void *arg)
             j->t_write_ms = 0;
             if (err) {                                           /* nothing to write: the picture is finished (with its error) */
                 j->error = err; j->done = 1;
+                rc_account(e);
                 pthread_cond_broadcast(&e->cv_done);
                 continue;
             }
@@ -410,12 +478,53 @@ static void *worker(void *arg)
                 pthread_mutex_lock(&e->mu);
                 j->t_write_ms += now_ms() - t1;
                 j->nal_len = n; j->error = n < 0 ? (int)n : 0; j->done = 1; j->t_done = now_ms();
+                rc_account(e);
                 pthread_cond_broadcast(&e->cv_done);
             }
         }
     }
     pthread_mutex_unlock(&e->mu);
     return NULL;
+}
+
+/* rate control: account finished pictures in coding order (under mu; called where a picture becomes done and before its ring slot is freed).  A picture's bits
+ * are normalised to the base QP with the 6-steps-per-octave rule (bits x 2^(delta / 6)), so the sums say what the stream would have cost without the
+ * controller.  rc_hist keeps the running sum after every picture: the decision for picture n reads the entry of picture n - RC_LAG - 1 whatever has been
+ * accounted since (pictures finish early or late; the decision must not depend on that). */
+static void rc_account(Enc *e)
+{
+    while (e->rc_acc_seq < e->rc_sub) {
+        Job *j = &e->jobs[e->rc_acc_idx];
+        if (!j->used || !j->done) break;
+        e->rc_sum_norm += (double)(j->nal_len > 0 ? j->nal_len : 0) * 8.0 * exp2((double)j->rc_delta / 6.0);
+        e->rc_hist[e->rc_acc_seq % RC_HIST] = e->rc_sum_norm;
+        e->rc_acc_idx = (e->rc_acc_idx + 1) % e->ring; ++e->rc_acc_seq;
+    }
+}
+/* scheduler thread: the offset for the pictures submitted next.  Waits until every picture up to RC_LAG before the next one is written (the writers do not need
+ * the caller for that), then delta = 6 log2(normalised bits / budget) over exactly those pictures, at most 4 steps away from the previous value. */
+static int rc_decide(Enc *e)
+{
+    if (!(e->cfg.rc == 1 || e->cfg.rc == 2 || e->cfg.rc == 4)) return 0;
+    pthread_mutex_lock(&e->mu);
+    const long need = e->rc_sub - RC_LAG;                              /* pictures [0, need) decide */
+    for (;;) {
+        rc_account(e);
+        if (e->rc_acc_seq >= need || e->quit) break;
+        pthread_cond_wait(&e->cv_done, &e->mu);
+    }
+    int d = e->rc_qp_delta;
+    if (need >= 4 && !e->quit) {
+        const double spent = e->rc_hist[(need - 1) % RC_HIST], budget = (double)need * e->cfg.bitrateInkbps * 1000.0 / e->cfg.frameRate;
+        if (spent > 0 && budget > 0) {
+            int want = (int)lrint(6.0 * log2(spent / budget));
+            if (want > d + 4) want = d + 4;
+            if (want < d - 4) want = d - 4;
+            d = want < -51 ? -51 : want > 51 ? 51 : want;
+        }
+    }
+    pthread_mutex_unlock(&e->mu);
+    return d;
 }
 
 static int dpb_find(Enc *e, int poc) { for (int i = 0; i < e->ndpb + 2 * e->key_overlap; ++i) if (e->dpb_poc[i] == poc) return i; return -1; }   /* incl. the key pictures' own slots */
@@ -449,14 +558,14 @@ static int submit(Enc *e, Input *in, int kind, int poc, int qp, const int *l0, i
     if (!r) r = ks265_memcpy_h2d_async(e->ctx_in, e->dev_in[k], in->i420, fsz);
     if (!r) r = ks265_event_record(e->ctx_in, e->ev_h2d[k]);
     /* pixel path: the main stream / frame object, or the key pictures' own */
-    const int on_key = kind == 'I' && e->key_overlap && (e->iper <= 0 || e->iper >= 32);
+    const int on_key = kind == 'I' && e->key_overlap && (in->iper <= 0 || in->iper >= 32);
     ks265_ctx *cx = on_key ? e->ctx_key : e->ctx;
     ks265_frame *fr = on_key ? e->frame_key : e->frame;
     ks265_pic srcp = on_key ? e->src_key : e->src;
     uint64_t *dsse = on_key ? e->dev_sse_key : e->dev_sse;
     if (!r) r = ks265_stream_wait_event(cx, e->ev_h2d[k]);
     /* graph path: a P picture with one reference on the main stream, once the first pictures have made every lazy allocation */
-    const int graphable = e->use_graph && ((kind == 'P' && nl0 == 1) || (kind == 'B' && nl0 == 1 && nl1 == 1)) && !on_key && e->recon_fd < 0 && e->seq >= 8;
+    const int graphable = e->use_graph && ((kind == 'P' && nl0 == 1) || (kind == 'B' && nl0 == 1 && nl1 == 1)) && !on_key && !e->recon_on && e->seq >= 8;
     if (!graphable) {
         if (!r) r = ks265_load_i420(fr, e->dev_in[k], srcp);
         if (!r) r = ks265_event_record(cx, e->ev_loaded[k]);
@@ -520,7 +629,7 @@ static int submit(Enc *e, Input *in, int kind, int poc, int qp, const int *l0, i
     }
     e->dpb_poc[slot] = poc;
     if (!r && e->cfg.calcPsnr) r = ks265_sse_picture(fr, srcp, out, dsse);
-    if (!r && e->recon_fd >= 0) {
+    if (!r && e->recon_on) {
         r = ks265_store_i420(fr, out, e->dev_recon);
         if (!r) r = ks265_memcpy_d2h_async(cx, j->recon, e->dev_recon, fsz);
     }
@@ -544,7 +653,7 @@ static int submit(Enc *e, Input *in, int kind, int poc, int qp, const int *l0, i
     if (!r) r = ks265_event_record(e->ctx_out, j->ev);
     if (r) return hip_rc(r);
     ++e->seq;
-    j->disp = in->disp; j->pts = in->pts; j->poc = poc; j->kind = kind; j->qp = qp; j->is_ref = is_ref; j->key_headers = key_headers;
+    j->disp = in->disp; j->pts = in->pts; j->poc = poc; j->kind = kind; j->qp = qp; j->is_ref = is_ref; j->key_headers = key_headers; j->rc_delta = e->rc_qp_delta;
     j->nal_type = kind == 'I' ? KS265_NAL_IDR_W_RADL : is_ref ? KS265_NAL_TRAIL_R : KS265_NAL_TRAIL_N;
     j->nl0 = nl0; j->nl1 = nl1;
     for (int i = 0; i < nl0; ++i) j->l0[i] = l0[i];
@@ -565,7 +674,7 @@ static int submit(Enc *e, Input *in, int kind, int poc, int qp, const int *l0, i
     pthread_mutex_lock(&e->mu);
     in->used = 2;                                                      /* released when the job's event has fired (output time); under the lock: the caller counts the pictures in flight */
     j->done = 0; j->error = 0; j->used = 1; j->started = 0; j->nrows = 0; j->next_row = 0; j->rows_done = 0;
-    e->job_tail = (e->job_tail + 1) % e->ring; ++e->njobs; ++e->nwait;
+    e->job_tail = (e->job_tail + 1) % e->ring; ++e->njobs; ++e->nwait; ++e->rc_sub;
     e->st.occ_samples++; e->st.occ_ring += e->njobs; e->st.occ_gpu += e->nwait; e->st.occ_ready += e->npending;
     pthread_cond_signal(&e->cv_disp);
     pthread_cond_broadcast(&e->cv_sched_done);                         /* progress: a caller waiting for the scheduler (input back-pressure, flush) looks again */
@@ -602,7 +711,7 @@ static int code_hier(Enc *e, int d, int a)
             Input *in = input_at(e, mid);
             const int is_ref = (mid - cur[i].lo >= 2) || (cur[i].hi - mid >= 2);
             const int l0 = cur[i].lo - e->gop_start, l1 = cur[i].hi - e->gop_start;
-            int r = submit(e, in, 'B', mid - e->gop_start, clampqp(e, in->base_qp + e->rc_qp_delta + 1 + layer), &l0, 1, &l1, 1, coded, ncoded, is_ref, 0);
+            int r = submit(e, in, 'B', mid - e->gop_start, clampqp(e, in->base_qp + e->rc_qp_delta + (e->fixqp ? 0 : 1 + layer)), &l0, 1, &l1, 1, coded, ncoded, is_ref, 0);
             if (r) return r;
             if (is_ref) coded[ncoded++] = mid - e->gop_start;
             nxt[nn].lo = cur[i].lo; nxt[nn++].hi = mid; nxt[nn].lo = mid; nxt[nn++].hi = cur[i].hi;
@@ -620,9 +729,11 @@ static int schedule(Enc *e, int flush, int have /* pictures [0, have) have arriv
         if (d + 1 >= have) return QY_OK;
         const int nxt = d + 1;
         Input *in = input_at(e, nxt);
-        const int key = d < 0 || (e->iper > 0 && nxt - e->gop_start >= e->iper) || (in && in->key);
+        const int iper = in ? in->iper : 0;                            /* the period in force when this picture was handed in (QY265EncoderReconfig) */
+        const int key = d < 0 || (iper > 0 && nxt - e->gop_start >= iper) || (in && in->key);
         if (key) {
             e->gop_start = nxt;
+            e->rc_qp_delta = rc_decide(e);                             /* rate control: one offset per key picture / mini-GOP, decided when it is certain to be submitted */
             for (int i = 0; i < e->ndpb + 2 * e->key_overlap; ++i) e->dpb_poc[i] = -1000000;
             int r = submit(e, in, 'I', 0, clampqp(e, in->base_qp + e->rc_qp_delta), NULL, 0, NULL, 0, NULL, 0, 1, 1);
             if (r) return r;
@@ -631,7 +742,7 @@ static int schedule(Enc *e, int flush, int have /* pictures [0, have) have arriv
         }
         int span = e->gop_b + 1;                                       /* anchor distance */
         int a = d + span;
-        if (e->iper > 0 && a - e->gop_start >= e->iper) a = e->gop_start + e->iper - 1;   /* the mini-GOP in front of a key picture is shortened */
+        if (iper > 0 && a - e->gop_start >= iper) a = e->gop_start + iper - 1;   /* the mini-GOP in front of a key picture is shortened */
         for (int k = nxt + 1; k <= a && k < have; ++k) {                 /* a picture asked to be a key picture: the mini-GOP in front of it is shortened as well */
             const Input *ik = input_at(e, k);
             if (ik && ik->key) { a = k - 1; break; }
@@ -645,7 +756,8 @@ static int schedule(Enc *e, int flush, int have /* pictures [0, have) have arriv
             for (int i = 0; i < e->refs - 1 && pa - 1 - i >= 0; ++i) keep[nkeep++] = pa - 1 - i;   /* still needed by the next picture */
         } else { l0[nl0++] = pd; keep[nkeep++] = pd; }
         Input *ina = input_at(e, a);
-        int r = submit(e, ina, 'P', pa, clampqp(e, ina->base_qp + e->rc_qp_delta + 1), l0, nl0, NULL, 0, keep, nkeep, 1, 0);
+        e->rc_qp_delta = rc_decide(e);
+        int r = submit(e, ina, 'P', pa, clampqp(e, ina->base_qp + e->rc_qp_delta + (e->fixqp ? 0 : 1)), l0, nl0, NULL, 0, keep, nkeep, 1, 0);
         if (r) return r;
         if (a - d > 1) {
             if (e->hier && ((a - d) & (a - d - 1)) == 0) { r = code_hier(e, d, a); if (r) return r; }
@@ -653,7 +765,7 @@ static int schedule(Enc *e, int flush, int have /* pictures [0, have) have arriv
                 const int kp[2] = {pd, pa};
                 for (int b = d + 1; b < a; ++b) {
                     Input *inb = input_at(e, b);
-                    r = submit(e, inb, 'B', b - e->gop_start, clampqp(e, inb->base_qp + e->rc_qp_delta + 2), &pd, 1, &pa, 1, kp, 2, 0, 0);
+                    r = submit(e, inb, 'B', b - e->gop_start, clampqp(e, inb->base_qp + e->rc_qp_delta + (e->fixqp ? 0 : 2)), &pd, 1, &pa, 1, kp, 2, 0, 0);
                     if (r) return r;
                 }
             }
@@ -729,18 +841,20 @@ static int take_output(Enc *e, int max_in_flight, int max_pics, QY265Nal **pNals
                 const double np[3] = {(double)e->W * e->H, (double)e->W * e->H / 4, (double)e->W * e->H / 4};
                 double ps[3];
                 for (int k = 0; k < 3; ++k) ps[k] = j->sse[k] ? 10.0 * log10(255.0 * 255.0 * np[k] / (double)j->sse[k]) : 99.0;
-                logf_(1, e->log_level, "POC %4d %c-SLICE bits %8ld psnr Y %.4f U %.4f V %.4f QP %d\n", j->disp, j->kind, (long)j->nal_len * 8, ps[0], ps[1], ps[2], j->qp);
+                /* appencoder's -psnr 2 table: `poc slice bits psnrY psnrU psnrV qp`, tab separated, one header line */
+                if (!e->psnr_hdr) { e->psnr_hdr = 1; logf_(2, e->log_level, "poc\tslice\tbits\tpsnr\t\t\tqp\n"); }
+                logf_(2, e->log_level, "%d\t%c\t%ld\t%.4f\t%.4f\t%.4f\t%d\n", j->disp, j->kind, (long)j->nal_len * 8, ps[0], ps[1], ps[2], j->qp);
             }
         }
-        /* frame-level rate control: compare what was spent with the budget so far */
-        if (e->cfg.rc == 1 || e->cfg.rc == 2 || e->cfg.rc == 4) {
-            e->rc_bits_spent += (double)j->nal_len * 8; e->rc_bits_target += e->cfg.bitrateInkbps * 1000.0 / e->cfg.frameRate; ++e->rc_frames;
-            if (e->rc_frames >= 4) {
-                const double ratio = e->rc_bits_spent / e->rc_bits_target;
-                if (ratio > 1.10 && e->base_qp + e->rc_qp_delta < 51) ++e->rc_qp_delta;
-                else if (ratio < 0.90 && e->base_qp + e->rc_qp_delta > 0) --e->rc_qp_delta;
+        if (e->md5 && e->md5_ring) {                                    /* `POC n MD5 y,u,v` in display order, like the reference's reconstruction output */
+            memcpy(e->md5_ring[j->disp & 255], j->md5, sizeof j->md5); e->md5_have[j->disp & 255] = 1;
+            while (e->md5_have[e->md5_next & 255]) {
+                char (*m)[33] = e->md5_ring[e->md5_next & 255];
+                logf_(2, e->log_level, "POC %d MD5 %s,%s,%s\n", e->md5_next, m[0], m[1], m[2]);
+                e->md5_have[e->md5_next & 255] = 0; ++e->md5_next;
             }
         }
+        rc_account(e);                                                  /* rate control: this picture's bits are on the books before its slot is reused */
         for (int i = 0; i < MAX_INPUT; ++i) if (e->in[i].used == 2 && e->in[i].disp == j->disp) e->in[i].used = 0;
         j->used = 0;
         e->job_head = (e->job_head + 1) % e->ring; --e->njobs; ++taken;
@@ -770,7 +884,7 @@ static void lane_close(Enc *e, int report)
             const double np[3] = {(double)e->W * e->H, (double)e->W * e->H / 4, (double)e->W * e->H / 4};
             double ps[3];
             for (int k = 0; k < 3; ++k) ps[k] = e->st.sse[k] > 0 ? 10.0 * log10(255.0 * 255.0 * np[k] * e->st.frames / e->st.sse[k]) : 99.0;
-            logf_(2, e->log_level, "bitrate, psnr: %.4f %.4f %.4f %.4f\n", e->st.bytes * 8.0 * e->cfg.frameRate / e->st.frames / 1000.0, ps[0], ps[1], ps[2]);
+            logf_(2, e->log_level, "bitrate, psnr: %.4f\t%.4f\t%.4f\t%.4f\n", e->st.bytes * 8.0 * e->cfg.frameRate / e->st.frames / 1000.0, ps[0], ps[1], ps[2]);
         }
         for (int i = 0; i < MAX_JOBS; ++i) {
             Job *j = &e->jobs[i];
@@ -804,7 +918,7 @@ static void lane_close(Enc *e, int report)
         ks265_destroy(e->ctx);
     }
     for (int i = 0; i < MAX_JOBS; ++i) free(e->jobs[i].wpp);
-    free(e->hdr); free(e->outbuf);
+    free(e->hdr); free(e->outbuf); free(e->md5_ring); free(e->md5_have);
     pthread_mutex_destroy(&e->mu); pthread_cond_destroy(&e->cv_work); pthread_cond_destroy(&e->cv_done); pthread_cond_destroy(&e->cv_disp); pthread_cond_destroy(&e->cv_sched); pthread_cond_destroy(&e->cv_sched_done);
     free(e);
 }
@@ -824,7 +938,7 @@ static Enc *lane_open(QY265EncConfig *cfg, int *err)
     e->hex_thr = (e->me_method == 2 && (cfg->preset == QY265PRESET_SLOW || cfg->preset == QY265PRESET_SLOWER)) ? 16 : 0;   /* tME+0x368, SURVEY-measured */
     e->subme = cfg->subme ? 1 : 0;
     e->refs = cfg->refnum < 1 ? 1 : cfg->refnum > 4 ? 4 : cfg->refnum;
-    e->use_sao = cfg->sao > 0; e->use_df = 1;
+    e->use_sao = cfg->sao > 0; e->use_df = g_cli.df; e->fixqp = g_cli.fixqp; e->md5 = g_cli.md5;
     e->gop_b = cfg->bframes < 0 ? (cfg->latency == QY265LATENCY_DEFAULT ? 7 : 0) : cfg->bframes;
     e->hier = cfg->bframes < 0 && e->gop_b == 7;
     if (e->gop_b > 0) e->refs = 1;
@@ -921,7 +1035,10 @@ static Enc *lane_open(QY265EncConfig *cfg, int *err)
     e->scfg.width = e->W; e->scfg.height = e->H; e->scfg.sao = e->use_sao; e->scfg.deblock = e->use_df;
     e->scfg.sdh = e->fcfg.sdh;
     e->scfg.wpp = 1;                                                    /* CTU rows as substreams: what lets several writer threads share one picture */
-    e->scfg.max_dec_pic_buffering = e->hier ? 10 : e->gop_b ? 4 : e->refs + 1; e->scfg.max_num_reorder = e->gop_b; e->scfg.log2_max_poc_lsb = 16;
+    e->scfg.max_dec_pic_buffering = e->hier ? 10 : e->gop_b ? 4 : e->refs + 1; e->scfg.log2_max_poc_lsb = 16;
+    /* pictures that precede a picture in decoding order and follow it in output order: the whole GOP for the hierarchy (7, as before), ONE (the anchor) for
+     * P + n non-reference B whatever n is (-bframes 1..15) */
+    e->scfg.max_num_reorder = e->hier ? e->gop_b : e->gop_b ? 1 : 0;
     e->hdr = (uint8_t *)malloc(512);
     if (e->hdr) {
         long a = ks265_write_vps(&e->scfg, e->hdr, 512), b = a > 0 ? ks265_write_sps(&e->scfg, e->hdr + a, 512 - (size_t)a) : -1, c = b > 0 ? ks265_write_pps(&e->scfg, e->hdr + a + b, 512 - (size_t)(a + b)) : -1;
@@ -932,6 +1049,10 @@ static Enc *lane_open(QY265EncConfig *cfg, int *err)
     e->outbuf = (uint8_t *)malloc(e->outcap);
     if (!e->hdr || e->hdr_len < 0 || !e->outbuf) { *err = QY_FAIL; lane_close(e, 0); return NULL; }
     for (int i = 0; i < e->ring; ++i) { e->jobs[i].wpp = malloc(ks265_wpp_bytes(&e->scfg)); if (!e->jobs[i].wpp) { *err = QY_OUTOFMEMORY; lane_close(e, 0); return NULL; } }   /* virtual until used */
+    if (e->md5) {                                                       /* -md5 1: plane MD5s of every reconstructed picture */
+        e->md5_ring = calloc(256, sizeof *e->md5_ring); e->md5_have = calloc(256, 1);
+        if (!e->md5_ring || !e->md5_have || lane_recon_on(e)) { *err = QY_OUTOFMEMORY; lane_close(e, 0); return NULL; }
+    }
     for (int i = 0; i < e->nthreads; ++i) { e->warg[i].e = e; e->warg[i].idx = i; if (pthread_create(&e->th[i], NULL, worker, &e->warg[i])) break; ++e->nth; }
     if (e->nth && !pthread_create(&e->disp, NULL, dispatcher, e)) e->disp_on = 1;
     if (e->disp_on && !pthread_create(&e->sched, NULL, scheduler, e)) e->sched_on = 1;
@@ -945,16 +1066,22 @@ static Enc *lane_open(QY265EncConfig *cfg, int *err)
 static void lane_reconfig(Enc *e, QY265EncConfig *cfg)
 {
     if (!e || !cfg) return;
+    pthread_mutex_lock(&e->mu);                                        /* lane_put snapshots base_qp / iper into the input slot under this lock */
     e->cfg.qp = cfg->qp; e->cfg.crf = cfg->crf; e->cfg.bitrateInkbps = cfg->bitrateInkbps; e->cfg.iIntraPeriod = cfg->iIntraPeriod;
-    e->base_qp = cfg->rc == 3 ? cfg->crf : cfg->qp; e->iper = cfg->iIntraPeriod;
+    e->base_qp = e->cfg.rc == 3 ? cfg->crf : cfg->qp; e->iper = cfg->iIntraPeriod;   /* the rate-control mode itself is not reconfigurable: the handle's own rc picks crf / qp */
     if (e->base_qp < 0) e->base_qp = 0;
     if (e->base_qp > 51) e->base_qp = 51;
+    pthread_mutex_unlock(&e->mu);
 }
 static int lane_headers(Enc *e, QY265Nal **pNals, int *n)
 {
     if (!e || !pNals || !n) return QY_POINTER;
-    e->nals[0].naltype = KS265_NAL_VPS; e->nals[0].tid = 0; e->nals[0].iSize = (int)e->hdr_len; e->nals[0].pts = 0; e->nals[0].pPayload = e->hdr;
-    *pNals = e->nals; *n = 1;                                           /* one entry holding VPS + SPS + PPS back to back */
+    long off = 0;                                                       /* VPS, SPS, PPS as three entries (as in front of a key picture): callers build hvcC / extradata per entry */
+    for (int k = 0; k < 3; ++k) {
+        e->nals[k].naltype = KS265_NAL_VPS + k; e->nals[k].tid = 0; e->nals[k].iSize = (int)e->hdr_part[k]; e->nals[k].pts = 0; e->nals[k].pPayload = e->hdr + off;
+        off += e->hdr_part[k];
+    }
+    *pNals = e->nals; *n = 3;
     return QY_OK;
 }
 static int lane_delayed(Enc *e)
@@ -996,7 +1123,7 @@ static int lane_put(Enc *e, QY265Picture *in, int key)
         }
     }
     pthread_mutex_lock(&e->mu);
-    slot->disp = e->next_disp++; slot->pts = in->pts; slot->key = key || e->force_key; slot->base_qp = e->base_qp; slot->used = 1;
+    slot->disp = e->next_disp++; slot->pts = in->pts; slot->key = key || e->force_key; slot->base_qp = e->base_qp; slot->iper = e->iper; slot->used = 1;
     e->force_key = 0;
     pthread_cond_signal(&e->cv_sched);                                 /* the scheduler thread takes it from here */
     pthread_mutex_unlock(&e->mu);
@@ -1048,15 +1175,24 @@ static int lane_encode_frame(Enc *e, QY265Nal **pNals, int *iNalCount, QY265Pict
 
 /* extension: dump the encoder's reconstruction as I420, every picture at its display position (the reference CLI's -o).  Call right after
  * QY265EncoderOpen, before the first picture.  Costs one more D2H of W*H*3/2 bytes per picture: a checking aid, not part of the normal path. */
-static int lane_set_recon_file(Enc *e, const char *path)
+static int lane_recon_on(Enc *e)                                       /* the reconstruction of every picture comes back to the host (pinned, per job) */
 {
-    if (!e || !path) return QY_POINTER;
-    if (e->next_disp != 0 || e->recon_fd >= 0) return QY_NOTSUPPORTED;
+    if (e->recon_on) return QY_OK;
+    if (e->next_disp != 0) return QY_NOTSUPPORTED;
     e->key_overlap = 0;                                                /* the dump shares one device buffer: key pictures stay on the main stream */
     const size_t fsz = (size_t)e->W * e->H * 3 / 2;
     int r = ks265_dev_malloc(e->ctx, (void **)&e->dev_recon, fsz);
     for (int i = 0; i < e->ring && !r; ++i) r = ks265_host_malloc(e->ctx, (void **)&e->jobs[i].recon, fsz);
     if (r) return hip_rc(r);
+    e->recon_on = 1;
+    return QY_OK;
+}
+static int lane_set_recon_file(Enc *e, const char *path)
+{
+    if (!e || !path) return QY_POINTER;
+    if (e->next_disp != 0 || e->recon_fd >= 0) return QY_NOTSUPPORTED;
+    const int r = lane_recon_on(e);
+    if (r) return r;
     e->recon_fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
     return e->recon_fd >= 0 ? QY_OK : QY_FAIL;
 }
@@ -1181,7 +1317,7 @@ static int top_lanes_wanted(const QY265EncConfig *cfg)
     int n = env ? atoi(env) : 1;
     if (n < 1) n = 1;
     if (n > MAX_LANES) n = MAX_LANES;
-    if (!cfg->enFrameParallel || cfg->rc != 0 || cfg->iIntraPeriod < 32) n = 1;
+    if (!cfg->enFrameParallel || cfg->rc != 0 || cfg->iIntraPeriod < 32 || g_cli.md5) n = 1;    /* -md5 lines are in one display order */
     return n;
 }
 
@@ -1230,7 +1366,7 @@ void QY265EncoderClose(void *h)
             const double np[3] = {(double)e0->W * e0->H, (double)e0->W * e0->H / 4, (double)e0->W * e0->H / 4};
             double ps[3];
             for (int k = 0; k < 3; ++k) ps[k] = st.sse[k] > 0 ? 10.0 * log10(255.0 * 255.0 * np[k] * st.frames / st.sse[k]) : 99.0;
-            logf_(2, e0->log_level, "bitrate, psnr: %.4f %.4f %.4f %.4f\n", st.bytes * 8.0 * e0->cfg.frameRate / st.frames / 1000.0, ps[0], ps[1], ps[2]);
+            logf_(2, e0->log_level, "bitrate, psnr: %.4f\t%.4f\t%.4f\t%.4f\n", st.bytes * 8.0 * e0->cfg.frameRate / st.frames / 1000.0, ps[0], ps[1], ps[2]);
         }
     }
     for (int i = 0; i < t->nlanes; ++i) lane_close(t->lane[i], t->nlanes == 1);

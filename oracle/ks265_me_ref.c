@@ -212,6 +212,18 @@ void kso_ref_me_umh(kso_me *m)
     }
 }
 
+int kso_mvd_bits(int d)
+{
+    unsigned v = d > 0 ? 2u * (unsigned)d : 1u + 2u * (unsigned)(-d);
+    int bits = 1;
+    while (v != 1) { v >>= 1; bits += 2; }
+    return bits;
+}
+void kso_mvd_cost_slice(int lambda, int mvp_q, int lo, int hi, uint16_t *out)
+{
+    for (int x = lo; x <= hi; ++x) out[x - lo] = (uint16_t)(lambda * kso_mvd_bits(4 * x - mvp_q));
+}
+
 int kso_me_replay(int method, const uint8_t *fenc, int log2w, int log2h, const uint8_t *plane, int rx0, int ry0, int rw, int rh,
                   int pux, int puy, const uint16_t *cmx, int xlo, int xhi, const uint16_t *cmy, int ylo, int yhi,
                   int merange, int range_shift, const int lim[4], int skip_cross, int use_had, int sx, int sy, uint32_t cost0, int32_t out[4])

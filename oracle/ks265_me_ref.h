@@ -23,6 +23,14 @@ typedef struct {
     int chk, gx0, gx1, gy0, gy1, oob;
 } kso_me;
 
+/* createMvdCostTable enc@0x48b850: the byte table of code lengths the reference builds once (loop at enc@0x48b926..0x48b97d): for a quarter-pel
+ * difference d, v = 2 d (d > 0) or 1 - 2 d (d <= 0), bits = 1 + 2 floor(log2 v) - the signed exp-Golomb length; the u16 cost tables are
+ * lambda(qp) x bits for |d| <= 4 merange + 16 (enc@0x48b9e0..0x48ba01: imul, 16-bit store), and tME+0x18 / +0x20 point into them at -mvp, so that
+ * p_cost_mvx[mv] = lambda x bits(mv - mvp).  Pinned on the table slices recorded inside the reference (tests/test_me_search.py). */
+int kso_mvd_bits(int d);
+/* out[i] = (uint16)(lambda x bits(4 (lo + i) - mvp_q)), i = 0 .. hi - lo: the slice at integer positions lo..hi the trace shim records */
+void kso_mvd_cost_slice(int lambda, int mvp_q, int lo, int hi, uint16_t *out);
+
 void kso_ref_me_dia(kso_me *m);
 void kso_ref_me_hex(kso_me *m);
 void kso_ref_me_umh(kso_me *m);

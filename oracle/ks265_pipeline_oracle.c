@@ -114,14 +114,9 @@ void kso_ref_planes(const kso_frame_cfg *cfg, kso_pic ref, uint8_t *planes)
 }
 
 /* ------------------------------------------------------------------ motion-vector rate
- * stands in for createMvdCostTable enc@0x48b850 (lambda(qp) x exp-Golomb length of the quarter-pel mvd) */
-static int se_bits(int v)
-{
-    unsigned u = (unsigned)(v <= 0 ? -2 * v : 2 * v - 1) + 1u;
-    int n = 0;
-    while (u >> (n + 1)) ++n;
-    return 2 * n + 1;
-}
+ * createMvdCostTable enc@0x48b850: lambda(qp) x signed exp-Golomb length of the quarter-pel mvd (kso_mvd_bits, pinned on the reference's own table
+ * slices: tests/test_me_search.py); lambda_q4 = 16 x the reference's integer lambda, so (lambda_q4 x bits) >> 4 is the table entry */
+static int se_bits(int v) { return kso_mvd_bits(v); }
 static int mv_cost(int mvx, int mvy, int px, int py, int lambda_q4) { return (lambda_q4 * (se_bits(mvx - px) + se_bits(mvy - py))) >> 4; }
 
 /* PU index helpers: level l (0: 64x64 .. 3: 8x8), raster inside the CTU */

@@ -27,3 +27,4 @@ int QY265EncoderDelayedFrames(void *h) { (void)h; return 0; }
 void QY265EncoderClose(void *h) { (void)h; printf("stub saw %ld pictures\n", g_n); }
 int ks265_enc_get_stats(void *h, ks265_enc_stats *o) { (void)h; memset(o, 0, sizeof *o); o->frames = g_n; return 0; }
 int ks265_enc_set_recon_file(void *h, const char *p) { (void)h; (void)p; return 0; }
+int ks265_enc_set_default(const char *n, int v) { (void)n; (void)v; return 0; }

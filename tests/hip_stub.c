@@ -26,6 +26,7 @@ const char *ks265_last_error(ks265_ctx *c) { (void)c; return "stub"; }
 int ks265_create(ks265_ctx **out, int device) { (void)device; if (getenv("KS265_STUB_NO_DEVICE")) return KS265_NO_DEVICE; *out = (ks265_ctx *)calloc(1, sizeof **out); return *out ? KS265_OK : KS265_OUTOFMEMORY; }
 void ks265_destroy(ks265_ctx *c) { if (c) { free(c->ops); free(c); } }
 int ks265_synchronize(ks265_ctx *c) { (void)c; return KS265_OK; }
+int ks265_take_device_error(ks265_ctx *c) { (void)c; return KS265_OK; }
 int ks265_dev_malloc(ks265_ctx *c, void **p, size_t n) { (void)c; *p = calloc(1, n ? n : 1); return *p ? KS265_OK : KS265_OUTOFMEMORY; }
 int ks265_dev_free(ks265_ctx *c, void *p) { (void)c; free(p); return KS265_OK; }
 int ks265_host_malloc(ks265_ctx *c, void **p, size_t n) { return ks265_dev_malloc(c, p, n); }

@@ -14,11 +14,15 @@ rng = np.random.default_rng(3)
 clip = rng.integers(0, 256, (11, W * H * 3 // 2), dtype=np.uint8)
 cfg = (C.c_uint8 * LAY["sizeof_config"])()
 assert lib.QY265ConfigDefaultPreset(cfg, b"medium", None, b"default") == 0
-for k, v in (("wdt", W), ("hgt", H), ("fr", 50), ("rc", 0), ("qp", 34), ("iper", iper), ("bframes", bframes), ("threads", 5), ("psnr", 1), ("log", 3)):
+for k, v in (("wdt", W), ("hgt", H), ("fr", 50), ("rc", int(os.environ.get("KS_TEST_RC", "0"))), ("br", int(os.environ.get("KS_TEST_BR", "1000"))), ("qp", 34), ("iper", iper), ("bframes", bframes), ("threads", 5), ("psnr", 1), ("log", 3)):
     assert lib.QY265ConfigParse(cfg, k.encode(), str(v).encode()) == 0
 err = C.c_int(0)
 h = C.c_void_p(lib.QY265EncoderOpen(cfg, C.byref(err))); assert h.value, hex(err.value & 0xFFFFFFFF)
 nal, nn, pic, outp, yuv = C.POINTER(Nal)(), C.c_int(0), Picture(), Picture(), YUV()
+hdr_entries = None
+if os.environ.get("KS_TEST_HEADERS"):                     # QY265EncoderEncodeHeaders: VPS, SPS, PPS as three entries
+    assert lib.QY265EncoderEncodeHeaders(h, C.byref(nal), C.byref(nn)) == 0
+    hdr_entries = [(nal[i].naltype, nal[i].iSize, bytes(C.string_at(nal[i].pPayload, min(6, nal[i].iSize))).hex()) for i in range(nn.value)]
 yuv.iWidth, yuv.iHeight = W, H
 yuv.iStride[0], yuv.iStride[1], yuv.iStride[2] = W, W // 2, W // 2
 pic.yuv = C.pointer(yuv)
@@ -68,4 +72,4 @@ while lib.QY265EncoderDelayedFrames(h):
 lanes = lib.ks265_enc_lanes(h)
 lib.QY265EncoderClose(h)
 if out_path: open(out_path, "wb").write(bytes(bs))
-print(json.dumps({"md5": md.hexdigest(), "lanes": lanes, "pts": pts, "idr": types.count(19), "vcl": len(pts), "bytes": len(bs), "maxdelay": maxdelay}))
+print(json.dumps({"hdr": hdr_entries, "md5": md.hexdigest(), "lanes": lanes, "pts": pts, "idr": types.count(19), "vcl": len(pts), "bytes": len(bs), "maxdelay": maxdelay}))

@@ -89,6 +89,9 @@ def test_bi_full_window(ks):
             c = cases[i]
             assert got[j, 0] == c["exp_cost"] and got[j, 1] == np.uint32(c["exp_best"][0]), (had, int(c["w"]), int(c["h"]), got[j], int(c["exp_cost"]), int(c["exp_best"][0]))
 
+
+def test_sad4blk(ks):
+    """sad4blk_8x8_c enc@0x4cee30: the four 8x8 quadrant SADs of a 16x16 block"""
     cases = load_cases("sad4blk")
     got = _run_dist(ks, ks.sad4blk_8x8, cases, lambda c: (16, 16))
     for i, c in enumerate(cases):

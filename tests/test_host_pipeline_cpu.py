@@ -143,3 +143,66 @@ def test_two_encoders_in_one_process(stub_lib):
     a, b = (json.loads(l) for l in r.stdout.strip().splitlines()[-2:])
     lone = run(stub_lib, 120, 32, 0)
     assert a["md5"] == b["md5"] == lone["md5"]
+
+
+@pytest.mark.parametrize("bframes", [1, 4, 7, 15])
+def test_every_bframes_value_opens_and_decodes(stub_lib, tmp_path, bframes):
+    """-bframes 4..15 used to fail in QY265EncoderOpen (reorder depth >= DPB size in the SPS).  P + n non-reference B has a reorder depth of ONE whatever n
+    is; the stream of every n decodes with the reference decoder, all pictures in display order"""
+    r = run(stub_lib, 70, 48, bframes, out=tmp_path / "b.265")
+    assert r["vcl"] == 70 and sorted(r["pts"]) == list(range(70)) and r["idr"] == 2
+    if os.path.exists(REF_DEC):
+        d = subprocess.run([REF_DEC, "-b", str(tmp_path / "b.265"), "-o", str(tmp_path / "d.yuv"), "-threads", "2"], capture_output=True, text=True, cwd=tmp_path)
+        assert d.returncode == 0 and os.path.getsize(tmp_path / "d.yuv") == 70 * 128 * 72 * 3 // 2, d.stdout[-300:] + d.stderr[-300:]
+
+
+@pytest.mark.parametrize("rc,bframes", [(2, 0), (1, -1)])
+def test_rate_control_does_not_depend_on_thread_timing(stub_lib, rc, bframes):
+    """the frame-level controller (rc 1 / 2 / 4) decides the QP offset of a mini-GOP from exactly the pictures coded RC_LAG earlier in coding order (the
+    scheduler waits for those), so two runs - one of them with a single writer thread's worth of jitter (KS265_NO_GRAPH changes the enqueue timing) - write the same
+    bytes; a budget far below / above what the records cost moves the QP (the stand-in's records depend on the QP)"""
+    a = run(stub_lib, 150, 64, bframes, KS_TEST_RC=rc, KS_TEST_BR=40)
+    b = run(stub_lib, 150, 64, bframes, KS_TEST_RC=rc, KS_TEST_BR=40, KS265_NO_GRAPH=1)
+    c = run(stub_lib, 150, 64, bframes, KS_TEST_RC=rc, KS_TEST_BR=40, KS265_FLAG_WAIT=1)
+    assert a["vcl"] == 150 and a["md5"] == b["md5"] == c["md5"]
+    hi = run(stub_lib, 150, 64, bframes, KS_TEST_RC=rc, KS_TEST_BR=400000)
+    assert hi["md5"] != a["md5"]                                             # the controller acts: another budget, another stream
+
+
+def test_encode_headers_returns_three_parameter_sets(stub_lib):
+    """QY265EncoderEncodeHeaders hands out VPS, SPS and PPS as three entries (naltype 32, 33, 34), each starting with its own start code"""
+    r = run(stub_lib, 3, 32, 0, KS_TEST_HEADERS=1)
+    assert [t for t, _, _ in r["hdr"]] == [32, 33, 34]
+    assert all(size > 6 and head.startswith("00000001") for _, size, head in r["hdr"])
+    assert [int(head[8:10], 16) >> 1 for _, _, head in r["hdr"]] == [32, 33, 34]     # nal_unit_type in the NAL header
+
+
+def test_cli_prints_the_reference_per_picture_and_md5_lines(stub_lib, tmp_path):
+    """B1 output contract (README.md:61-66, the lines appencoder -psnr 2 -md5 1 prints): header `poc slice bits psnr qp`, one tab-separated line per picture,
+    `POC n MD5 y,u,v` in display order, the two `Total Frames:` lines and `bitrate, psnr:` (the line encoderwrapper.c:249-277 parses)"""
+    import re
+    import numpy as np
+    host = os.path.join(ROOT, "ks265codec_amd", "host")
+    exe = str(tmp_path / "ks265enc_stub")
+    subprocess.check_call(["gcc", "-O2", "-std=gnu11", "-Wall", "-Wextra", "-I", os.path.join(ROOT, "include"), "-o", exe, os.path.join(host, "ks265_cli.c"),
+                           os.path.join(host, "ks265_enc.c"), os.path.join(host, "ks265_stream.c"), os.path.join(HERE, "hip_stub.c"),
+                           "-L", os.path.join(ROOT, "oracle"), "-lks265_oracle", "-Wl,-rpath," + os.path.join(ROOT, "oracle"), "-lpthread", "-lm"])
+    W, H, N = 128, 72, 12
+    np.random.default_rng(5).integers(0, 256, N * W * H * 3 // 2, dtype=np.uint8).tofile(tmp_path / "in.yuv")
+    (tmp_path / "enc.cfg").write_text("# options of the run\nqp 30\n-iper = 64\nbframes : 3\n")
+    r = subprocess.run([exe, "-i", str(tmp_path / "in.yuv"), "-wdt", str(W), "-hgt", str(H), "-fr", "50", "-preset", "veryfast", "-rc", "0", "-c", str(tmp_path / "enc.cfg"),
+                        "-psnr", "2", "-md5", "1", "-fixqp", "1", "-df", "0", "-threads", "3", "-b", str(tmp_path / "o.265")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "H265 encoder passed!!!" in r.stdout, r.stdout[-800:] + r.stderr[-800:]
+    lines = r.stdout.splitlines()
+    assert "poc\tslice\tbits\tpsnr\t\t\tqp" in lines
+    pics = [re.fullmatch(r"(\d+)\t([IPB])\t(\d+)\t([\d.]+)\t([\d.]+)\t([\d.]+)\t(\d+)", ln) for ln in lines]
+    pics = [m for m in pics if m]
+    assert len(pics) == N and sorted(int(m.group(1)) for m in pics) == list(range(N))
+    assert {m.group(2) for m in pics} == {"I", "P", "B"}                      # -bframes 3 came from the -c file
+    assert {int(m.group(7)) for m in pics} == {30}                           # -fixqp 1: no per-layer offsets; qp 30 from the -c file
+    md5s = [re.fullmatch(r"POC (\d+) MD5 ([0-9a-f]{32}),([0-9a-f]{32}),([0-9a-f]{32})", ln) for ln in lines]
+    md5s = [m for m in md5s if m]
+    assert [int(m.group(1)) for m in md5s] == list(range(N))                 # display order
+    assert any(re.fullmatch(r"Total Frames: 12, test time: \d+ms, FPS: [\d.]+", ln) for ln in lines)
+    assert any(re.fullmatch(r"Total Frames: 12, pure encoding time: \d+ms, [\d.]+ fps", ln) for ln in lines)
+    assert any(re.fullmatch(r"bitrate, psnr: [\d.]+\t[\d.]+\t[\d.]+\t[\d.]+", ln) for ln in lines), [ln for ln in lines if "psnr" in ln]

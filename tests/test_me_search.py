@@ -58,3 +58,42 @@ if __name__ == "__main__":
               "moved", sum(r[3][:2] != r[4] for r in mine))
         for r in [r for r in mine if r[1] == 0 and r[2] != r[3]][:5]:
             print("   ", r)
+
+
+def test_mvd_cost_table_matches_reference_slices():
+    """createMvdCostTable enc@0x48b850: every p_cost_mvx / p_cost_mvy slice the trace shim recorded inside the reference (1 960 slices, 7 lambdas) is
+    lambda x kso_mvd_bits(4 x - mvp) for one integer lambda and one quarter-pel predictor, over the table's own span |4 x - mvp| <= 4 * 64 + 16
+    (beyond it the shim recorded the neighbouring table).  The pipeline oracle's vector rate is this function (se_bits -> kso_mvd_bits)."""
+    z = np.load(GOLD)
+    f = {n: i for i, n in enumerate(z["call_fields"])}
+    cm = np.ascontiguousarray(z["cm"])
+    o = lib()
+    assert [o.kso_mvd_bits(d) for d in (0, 1, -1, 2, -2, 3, 4, -4, 272, -272)] == [1, 3, 3, 5, 5, 5, 7, 7, 19, 19]
+    lambdas, fractional, entries = set(), 0, 0
+    for c in z["calls"]:
+        g = lambda n: int(c[f[n]])
+        nx, ny = g("xhi") - g("xlo") + 1, g("yhi") - g("ylo") + 1
+        for sl, lo in ((cm[g("cm_off"):g("cm_off") + nx], g("xlo")), (cm[g("cm_off") + nx:g("cm_off") + nx + ny], g("ylo"))):
+            k, mn = int(sl.argmin()), int(sl.min())
+            hit = None
+            pos = 4 * (lo + np.arange(len(sl)))
+
+            def fits(lam, mvp):
+                mine = np.zeros(len(sl), np.uint16)
+                o.kso_mvd_cost_slice(lam, mvp, lo, lo + len(sl) - 1, ptr(mine))
+                inside = np.abs(pos - mvp) <= 4 * 64 + 16
+                return (lam, mvp, int(inside.sum())) if inside.sum() >= 16 and (mine[inside] == sl[inside]).all() else None
+
+            for b in range(1, 21, 2):                               # the smallest entry is lambda x bits(d) for some odd code length
+                if mn % b:
+                    continue
+                near = range(4 * (lo + k) - 3, 4 * (lo + k) + 4) if b <= 5 else range(4 * lo - 300, 4 * (lo + len(sl)) + 300)   # predictor inside / outside the slice
+                for mvp in near:
+                    hit = fits(mn // b, mvp)
+                    if hit:
+                        break
+                if hit:
+                    break
+            assert hit, f"slice of call {g('method')} at {lo}: no (lambda, mvp) reproduces it"
+            lambdas.add(hit[0]); fractional += (hit[1] & 3) != 0; entries += hit[2]
+    assert len(lambdas) >= 5 and fractional >= 100 and entries > 200000, (lambdas, fractional, entries)
