@@ -126,7 +126,7 @@ def main():
         tstream = None if sidx == 0 else torch.cuda.Stream(device=dev_index)
         with (torch.cuda.stream(tstream) if tstream is not None else contextlib.nullcontext()):
             ks = KsContext(dev_index)
-            fr = KsFrame(ks, W, H, qp, lambda_q4(qp), me_method=me_method, me_hex_thr=(args.me_hex_thr if me_method == 2 else 0), bframes=max(args.bframes, args.hier_b - 1 if args.hier_b else 0), refs=max(1, args.refs), sdh=1, pre_search=0 if args.no_pre_search else 1, merge=1, bi_refine=1, decimate=2)
+            fr = KsFrame(ks, W, H, qp, lambda_q4(qp), me_method=me_method, me_hex_thr=(args.me_hex_thr if me_method == 2 else 0), bframes=max(args.bframes, args.hier_b - 1 if args.hier_b else 0), refs=max(1, args.refs), sdh=1, pre_search=0 if args.no_pre_search else 1, merge=1, bi_refine=1, rdo=4)
             # synthetic clip of SURVEY.md §8(d), one GOP shard per stream (different seed per shard = different content)
             clip = make_clip(W, H, args.clip_frames, seed=7 + (0 if args.b_spread else rank * nstreams + sidx), abc=(67, 91, 33), pan=(8, 5))
             dev_clip = [ks.dev(c) for c in clip]
@@ -149,7 +149,7 @@ def main():
                 d, kind, r0, r1, layer = next(sched)
                 G1 = args.hier_b + 1
                 q = qp if kind == "I" else qp + 1 + layer            # I = Q, P = Q+1, B of layer k = Q+1+k (hidden hierarchy offsets)
-                fr.set_qp(q, lambda_q4(q))
+                fr.set_qp(q, lambda_q4(q, inter=kind != "I"))       # P / B pictures: the encoder host's inter table (ks265_enc.c kLambdaInterQ4)
                 out = dpb[d % G1]
                 if kind == "B":
                     fr.encode_picture_b(src_of(d), dpb[r0 % G1], dpb[r1 % G1], out)
@@ -166,7 +166,7 @@ def main():
                 R, cur = len(ring), state["cur"]
                 nxt = (cur + 1) % R
                 q = qp if kind == "I" else qp + 1
-                fr.set_qp(q, lambda_q4(q))
+                fr.set_qp(q, lambda_q4(q, inter=kind != "I"))
                 avail = 0 if kind == "I" else min(args.refs, state["since_key"])
                 if avail <= 1:
                     fr.encode_picture(src_of(d), ring[cur], kind == "I", ring[nxt])
@@ -188,12 +188,12 @@ def main():
                 cur = state["cur"]
                 if kind == "B":
                     q = qp + 2                                  # the reference's hidden hierarchy offsets: I = Q, P = Q+1, B = Q+2..
-                    fr.set_qp(q, lambda_q4(q))
+                    fr.set_qp(q, lambda_q4(q, inter=True))
                     fr.encode_picture_b(src_of(d), anchors[cur ^ 1], anchors[cur], bout)   # list 0 = previous anchor, list 1 = the anchor just coded
                     state["last"] = (d, bout)
                 else:
                     q = qp if kind == "I" else qp + 1
-                    fr.set_qp(q, lambda_q4(q))
+                    fr.set_qp(q, lambda_q4(q, inter=kind != "I"))
                     fr.encode_picture(src_of(d), anchors[cur], kind == "I", anchors[cur ^ 1])
                     state["cur"] = cur ^ 1
                     state["last"] = (d, anchors[cur ^ 1])
@@ -233,11 +233,11 @@ def main():
 
         def enc_anchor(d, kind, prev, out):
             q = qp if kind == "I" else qp + 1
-            fr.set_qp(q, lambda_q4(q))
+            fr.set_qp(q, lambda_q4(q, inter=kind != "I"))
             fr.encode_picture(src_of(d), slots[prev] if prev is not None else slots[out], kind == "I", slots[out])
 
         def enc_b(d, s0, s1):
-            fr.set_qp(qp + 2, lambda_q4(qp + 2))
+            fr.set_qp(qp + 2, lambda_q4(qp + 2, inter=True))
             fr.encode_picture_b(src_of(d), slots[s0], slots[s1], bout)
 
         def bcast(slot, src):
@@ -380,7 +380,7 @@ def port_leg(args, clip, order, me_method):
     from oracle_lib import OraclePipeline
     from ks265codec_amd.synth import lambda_q4
     W, H, qp = args.width, args.height, args.qp
-    o = OraclePipeline(W, H, qp, lambda_q4(qp), me_method=me_method, me_hex_thr=(args.me_hex_thr if me_method == 2 else 0), sdh=1, pre_search=0 if args.no_pre_search else 1, merge=1, bi_refine=1, decimate=2)
+    o = OraclePipeline(W, H, qp, lambda_q4(qp), me_method=me_method, me_hex_thr=(args.me_hex_thr if me_method == 2 else 0), sdh=1, pre_search=0 if args.no_pre_search else 1, merge=1, bi_refine=1, rdo=4)
     nbase = 3
     tc0 = time.perf_counter()
     if args.bframes == 0:

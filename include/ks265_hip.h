@@ -238,6 +238,13 @@ typedef struct {
     int32_t decimate;          /* K > 0: coefficient decimation at the postQuant seam of inter LUMA TUs - a block whose levels are all +-1 and at most 2K (8x8),
                                   3K (16x16), 4K (32x32) of them is dropped (prediction only, cbf 0); chroma is left alone; the encoder host uses 2.  Where the reference makes this kind of
                                   decision is inside its closed RD code (tuDecision enc@0x4825a0 lineage); measured effect: DESIGN.md 8 */
+    int32_t rdo;               /* K > 0: coefficient-group pruning at the postQuant seam, before sign-data hiding - the sub-block decision of HM-lineage RDOQ (the reference's
+                                  rdoQuant enc@0x4aac50 is closed code; -rdoq 1 at -preset slow) with STATIC bit costs: a 4x4 group of levels of an inter TU (luma and chroma;
+                                  also the intra CUs of P / B pictures) is kept only if the distortion it removes, sum d (2 c - d) >> 2 (7 - log2 N) over its levels (c coefficient,
+                                  d dequantised level), exceeds lambda_mode x K / 4 x its bits (quarter bits: 14 / 20 / 26 + 8 floor(log2(|l| - 1)) per level + 10 + the zeros
+                                  around); lambda_mode = (lambda_q4 / 16)^2.  The encoder host uses K = 4 with the P / B lambda table; key pictures are never pruned */
+    int32_t intra_inter;       /* 1 = P / B pictures may hold intra CUs (EncIntraMD.cpp lineage: decideLumaMode enc@0x49acc0): the pre-selection cost of ks265_intra_decide competes in
+                                  the CU decision, intra CUs are reconstructed after the inter CUs from reconstructed neighbours (CTU wavefront) */
 } ks265_frame_cfg;
 
 /* geometry of the padded picture buffers the caller allocates (one call, no allocation) */

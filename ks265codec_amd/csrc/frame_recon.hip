@@ -112,7 +112,7 @@ __device__ __forceinline__ void code_region(const KsGeom &g, int comp, int qp, i
                                             const unsigned char *tu_log2 /*LDS [16]: log2 of TU size in 8x8 blocks*/, const short *Mf, const short *Mt,
                                             short *X, short *T, unsigned char *P, int *nzcnt /*LDS [16]*/, const uint8_t *src, const uint8_t *ref,
                                             const uint8_t *planes, const uint8_t *ref1, const uint8_t *planes1, int16_t *lvl, uint8_t *rec, int tid, const KsCompRefs xr,
-                                            bool sdh, short *LV, short *DU, short *CF, int *lastcg /*LDS [16]*/, int dec_k)
+                                            bool sdh, short *LV, short *DU, short *CF, int *lastcg /*LDS [16]*/, int dec_k, long long rdo_lam2k /* lambda_q4^2 x cfg.rdo, 0 = off */)
 {
     constexpr int UNIT = RS / 4;                      // samples per 8x8-luma block along one axis
     constexpr int NQ = RS * RS / 4;                   // quads (4 adjacent samples of one row)
@@ -217,7 +217,7 @@ __device__ __forceinline__ void code_region(const KsGeom &g, int comp, int qp, i
                 nz += l != 0;
             }
             lv[i] = (unsigned short)(short)l;
-            if (sdh) { const int o = (oy + k) * RP + ox + j + i; LV[o] = (short)l; DU[o] = (short)du; CF[o] = (short)coef; }
+            if (sdh || rdo_lam2k) { const int o = (oy + k) * RP + ox + j + i; LV[o] = (short)l; DU[o] = (short)du; CF[o] = (short)coef; }
             X[(oy + j + i) * RP + ox + k] = (short)dqv;
         }
         if (coded) {
@@ -245,6 +245,29 @@ __device__ __forceinline__ void code_region(const KsGeom &g, int comp, int qp, i
         if (coded && nzcnt[tb] < 0) *(uint2 *)(lvl + (long)(Y0 + qy) * lstride + X0 + qx) = make_uint2(0u, 0u);
         __syncthreads();
         if (tid < 16) { if (nzcnt[tid] < 0) nzcnt[tid] = 0; lastcg[tid] = 0; }
+        __syncthreads();
+    }
+    if (rdo_lam2k) {
+        // ---- cfg.rdo: coefficient-group pruning (recon_dev.h), one lane per 4x4 coefficient group of the region; inter blocks only
+        constexpr int NCG = RS / 4;
+        if (tid < NCG * NCG) {
+            const int gx = tid % NCG, gy = tid / NCG, gb = (gy * 4 / UNIT) * 4 + gx * 4 / UNIT;
+            const int g8 = 1 << tu_log2[gb], gtb = ((gb >> 2) & ~(g8 - 1)) * 4 + ((gb & 3) & ~(g8 - 1));
+            const int gox = (gtb & 3) * UNIT, goy = (gtb >> 2) * UNIT, r0 = gy * 4, c0 = gx * 4, cbase = r0 * RP + c0;
+            if (blk[gb].log2_cu != 0 && blk[gb].pred_mode == 0 && nzcnt[gtb] > 0) {
+                const int l2n = 31 - __clz(g8 * UNIT);
+                const int cnt = rdo_group_prune(LV, CF, cbase, kInvQuantScales[qp % 6] << (qp / 6), l2n, rdo_lam2k);
+                if (cnt) {
+#pragma unroll
+                    for (int y = 0; y < 4; ++y) {
+                        *(uint2 *)(LV + cbase + y * RP) = make_uint2(0u, 0u);
+                        *(uint2 *)(lvl + (long)(Y0 + r0 + y) * lstride + X0 + c0) = make_uint2(0u, 0u);
+                        *(uint2 *)(X + (goy + (c0 + y - gox)) * RP + gox + (r0 - goy)) = make_uint2(0u, 0u);      // the dequantised tile is stored transposed
+                    }
+                    atomicSub(&nzcnt[gtb], cnt);
+                }
+            }
+        }
         __syncthreads();
     }
     if (sdh) {
@@ -320,13 +343,14 @@ int ks265_frame_build_matrices(ks265_frame *f)
 }
 
 struct KsRefExtra { KsCompRefs y, u, v; };
+static inline long long ks_rdo_lam2k(const ks265_frame *f) { return (long long)f->cfg.lambda_q4 * f->cfg.lambda_q4 * (f->cfg.rdo > 0 ? f->cfg.rdo : 0); }
 
 // list-1 pointers are null for I / P pictures (no block carries inter_dir 2 or 3 there)
 template <bool MREF>
 __global__ __launch_bounds__(256) void reconstruct_kernel(KsGeom g, int qp, const uint8_t *src_y, const uint8_t *src_u, const uint8_t *src_v,
                                                           const uint8_t *ref_y, const uint8_t *ref_u, const uint8_t *ref_v, const uint8_t *planes,
                                                           const uint8_t *ref1_y, const uint8_t *ref1_u, const uint8_t *ref1_v, const uint8_t *planes1, ks265_cu8 *cu8,
-                                                          int16_t *lvl_y, int16_t *lvl_u, int16_t *lvl_v, uint8_t *rec_y, uint8_t *rec_u, uint8_t *rec_v, const short *mats, const KsRefExtra xr, int sdh_on, int dec_k)
+                                                          int16_t *lvl_y, int16_t *lvl_u, int16_t *lvl_v, uint8_t *rec_y, uint8_t *rec_u, uint8_t *rec_v, const short *mats, const KsRefExtra xr, int sdh_on, int dec_k, long long rdo_lam2k)
 {
     __shared__ __attribute__((aligned(16))) short Mf[MAT_SHORTS];
     __shared__ __attribute__((aligned(16))) short Mt[MAT_SHORTS];
@@ -361,19 +385,19 @@ __global__ __launch_bounds__(256) void reconstruct_kernel(KsGeom g, int qp, cons
     }
     __syncthreads();
     const int qpc = chroma_qp(qp);
-    code_region<32, MREF>(g, 0, qp, rx * 4, ry * 4, blk, tu_log2, Mf, Mt, X, T, P, nzcnt, src_y, ref_y, planes, ref1_y, planes1, lvl_y, rec_y, tid, xr.y, sdh, LV, DU, CF, lastcg, dec_k);
+    code_region<32, MREF>(g, 0, qp, rx * 4, ry * 4, blk, tu_log2, Mf, Mt, X, T, P, nzcnt, src_y, ref_y, planes, ref1_y, planes1, lvl_y, rec_y, tid, xr.y, sdh, LV, DU, CF, lastcg, dec_k, rdo_lam2k);
     if (tid < 16 && blk[tid].log2_cu) {
         const int t8 = 1 << tu_log2[tid], tb = ((tid >> 2) & ~(t8 - 1)) * 4 + ((tid & 3) & ~(t8 - 1));
         if (nzcnt[tb]) cbf[tid] |= 1;
     }
     __syncthreads();
-    code_region<16, MREF>(g, 1, qpc, rx * 4, ry * 4, blk, tu_log2, Mf, Mt, X, T, P, nzcnt, src_u, ref_u, planes, ref1_u, planes1, lvl_u, rec_u, tid, xr.u, sdh, LV, DU, CF, lastcg, 0);
+    code_region<16, MREF>(g, 1, qpc, rx * 4, ry * 4, blk, tu_log2, Mf, Mt, X, T, P, nzcnt, src_u, ref_u, planes, ref1_u, planes1, lvl_u, rec_u, tid, xr.u, sdh, LV, DU, CF, lastcg, 0, rdo_lam2k);
     if (tid < 16 && blk[tid].log2_cu) {
         const int t8 = 1 << tu_log2[tid], tb = ((tid >> 2) & ~(t8 - 1)) * 4 + ((tid & 3) & ~(t8 - 1));
         if (nzcnt[tb]) cbf[tid] |= 2;
     }
     __syncthreads();
-    code_region<16, MREF>(g, 2, qpc, rx * 4, ry * 4, blk, tu_log2, Mf, Mt, X, T, P, nzcnt, src_v, ref_v, planes, ref1_v, planes1, lvl_v, rec_v, tid, xr.v, sdh, LV, DU, CF, lastcg, 0);
+    code_region<16, MREF>(g, 2, qpc, rx * 4, ry * 4, blk, tu_log2, Mf, Mt, X, T, P, nzcnt, src_v, ref_v, planes, ref1_v, planes1, lvl_v, rec_v, tid, xr.v, sdh, LV, DU, CF, lastcg, 0, rdo_lam2k);
     if (tid < 16 && blk[tid].log2_cu) {
         const int t8 = 1 << tu_log2[tid], tb = ((tid >> 2) & ~(t8 - 1)) * 4 + ((tid & 3) & ~(t8 - 1));
         if (nzcnt[tb]) cbf[tid] |= 4;
@@ -387,7 +411,7 @@ static int launch_reconstruct(ks265_frame *f, ks265_pic src, ks265_pic ref0, con
 {
     dim3 grid(((f->g.W + 31) / 32) * ((f->g.H + 31) / 32));
     hipLaunchKernelGGL(reconstruct_kernel<false>, grid, dim3(256), 0, f->ctx->stream, f->g, f->cfg.qp, src.y, src.u, src.v, ref0.y, ref0.u, ref0.v, planes0, ref1.y,
-                       ref1.u, ref1.v, planes1, cu8, lvl_y, lvl_u, lvl_v, recon.y, recon.u, recon.v, f->mats, KsRefExtra{}, f->cfg.sdh, f->cfg.decimate);
+                       ref1.u, ref1.v, planes1, cu8, lvl_y, lvl_u, lvl_v, recon.y, recon.u, recon.v, f->mats, KsRefExtra{}, f->cfg.sdh, f->cfg.decimate, ks_rdo_lam2k(f));
     return ks265_check_launch(f->ctx);
 }
 
@@ -407,7 +431,7 @@ extern "C" int ks265_reconstruct_mref(ks265_frame *f, ks265_pic src, int nref, c
     dim3 grid(((f->g.W + 31) / 32) * ((f->g.H + 31) / 32));
     hipLaunchKernelGGL(reconstruct_kernel<true>, grid, dim3(256), 0, f->ctx->stream, f->g, f->cfg.qp, src.y, src.u, src.v, refs[0].y, refs[0].u, refs[0].v, planes[0],
                        (const uint8_t *)nullptr, (const uint8_t *)nullptr, (const uint8_t *)nullptr, (const uint8_t *)nullptr, cu8, lvl_y, lvl_u, lvl_v, recon.y, recon.u,
-                       recon.v, f->mats, xr, f->cfg.sdh, f->cfg.decimate);
+                       recon.v, f->mats, xr, f->cfg.sdh, f->cfg.decimate, ks_rdo_lam2k(f));
     return ks265_check_launch(f->ctx);
 }
 

@@ -174,6 +174,34 @@ template <int SCAN> __device__ __forceinline__ int sbh_apply_r(const SbhRegs &r,
     new_level = (int)(short)(!min_neg ? min_l + final_change : min_l - final_change);
     return min_pos;
 }
+// ------------------------------------------------------------------ cfg.rdo: coefficient-group pruning at the postQuant seam (oracle: code_tu, rdo_level_q2)
+// One lane per 4x4 group, like sign-data hiding (which runs afterwards on the pruned levels): the group is kept only if the distortion its levels remove
+// outweighs lambda_mode x K / 4 x a static estimate of their bits (the sub-block decision of HM-lineage RDOQ, rdoQuant enc@0x4aac50, with static costs).
+__device__ __forceinline__ int rdo_level_q2(int a) { return a == 1 ? 14 : a == 2 ? 20 : 26 + 8 * (31 - __clz(a - 1)); }
+// the lane's group: levels and coefficients at [base + y * RP + x]; returns the number of levels the group holds if it is to be pruned, else 0
+__device__ __forceinline__ int rdo_group_prune(const short *LV, const short *CF, int base, int dqs, int log2n, long long lam2k)
+{
+    const int shift = log2n - 1, sh2 = 2 * (7 - log2n);
+    long long gain = 0;
+    int bits = 0, cnt = 0;
+#pragma unroll
+    for (int y = 0; y < 4; ++y) {
+        const uint2 lv = *(const uint2 *)(LV + base + y * RP), cf = *(const uint2 *)(CF + base + y * RP);
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            const unsigned wl = x < 2 ? lv.x : lv.y, wc = x < 2 ? cf.x : cf.y;
+            const int l = (int)(short)((x & 1) ? (wl >> 16) : (wl & 0xFFFFu)), c = (int)(short)((x & 1) ? (wc >> 16) : (wc & 0xFFFFu));
+            if (!l) continue;
+            const int d = dequant_one(l, dqs, 1 << (shift - 1), shift);
+            gain += (long long)d * (2 * c - d);
+            bits += rdo_level_q2(l < 0 ? -l : l); ++cnt;
+        }
+    }
+    if (!cnt) return 0;
+    bits += 10 + (16 - cnt);
+    return ((gain >> sh2) << 12) <= lam2k * bits ? cnt : 0;
+}
+
 // run-time scan index (intra 4x4 / 8x8 follow the prediction mode): three unrolled variants
 __device__ __forceinline__ unsigned sbh_survey_rs(const SbhRegs &r, int scan) { return scan == 0 ? sbh_survey_r<0>(r) : scan == 1 ? sbh_survey_r<1>(r) : sbh_survey_r<2>(r); }
 __device__ __forceinline__ int sbh_apply_rs(const SbhRegs &r, int scan, unsigned survey, bool is_last, int &nl)

@@ -89,6 +89,11 @@ int ks265_enc_set_default(const char *name, int value)
 static const int kLambdaQ4[52] = {3, 3, 4, 4, 5, 5, 6, 7, 8, 9, 10, 11, 12, 14, 15, 17, 19, 22, 24, 27, 30, 34, 38, 43, 48, 54, 61, 68, 77, 86, 97, 108, 122, 137, 153, 172,
                                   193, 217, 244, 273, 307, 344, 387, 434, 487, 547, 614, 689, 773, 868, 974, 1093};
 
+/* P / B pictures: lambda_mode carries HM's factor for pictures that are not key pictures, clip(2, 4, (qp - 12) / 6) - round(16 * sqrt(0.57 * f * 2^((qp - 12) / 3))).
+ * The reference's own integer motion lambda (read from its mvd cost tables, tests/test_me_search.py: 8 at qp 27, 9 at 28, 16 at 33, 18 at 34) is within 10 percent of it.
+ * It prices vectors, CU splits, merge, SAO and the coefficient-group pruning (ks265_frame_cfg.rdo) of those pictures; measured effect: DESIGN.md */
+static const int kLambdaInterQ4[52] = {4, 5, 5, 6, 7, 8, 9, 10, 11, 12, 14, 15, 17, 19, 22, 24, 27, 30, 34, 38, 43, 48, 54, 61, 68, 80, 93, 108, 125, 145, 167, 193, 222, 256, 294, 337, 387, 434, 487, 547, 614, 689, 773, 868, 974, 1093, 1227, 1378, 1546, 1736, 1948, 2187};
+
 /* ------------------------------------------------------------------ configuration (QY265ConfigDefault enc@0x4b7020 lineage: fillCfgs<Preset>) */
 static const char *const kPresetNames[] = {"ultrafast", "superfast", "veryfast", "fast", "medium", "slow", "slower", "veryslow", "placebo", 0};
 static const char *const kTuneNames[] = {"default", "selfshow", "game", "movie", "screen", 0};
@@ -570,7 +575,7 @@ static int submit(Enc *e, Input *in, int kind, int poc, int qp, const int *l0, i
         if (!r) r = ks265_load_i420(fr, e->dev_in[k], srcp);
         if (!r) r = ks265_event_record(cx, e->ev_loaded[k]);
     }
-    if (!r) r = ks265_frame_set_qp(fr, qp, kLambdaQ4[qp]);
+    if (!r) r = ks265_frame_set_qp(fr, qp, kind == 'I' ? kLambdaQ4[qp] : kLambdaInterQ4[qp]);
     int keep[20], nk = 0;
     for (int i = 0; i < nkeep; ++i) keep[nk++] = keep_after[i];
     for (int i = 0; i < nl0; ++i) keep[nk++] = l0[i];
@@ -967,7 +972,7 @@ static Enc *lane_open(QY265EncConfig *cfg, int *err)
     e->fcfg.sdh = 1;                                                    /* the reference's streams have sign_data_hiding_enabled_flag = 1 at every preset */
     e->fcfg.pre_search = 1;                                             /* stage A0: pyramid pre-search vectors as start candidates of the integer search */
     e->fcfg.merge = 1;                                                  /* stage C2: merge pass on the motion field (pictures with one reference per list) */
-    e->fcfg.decimate = 2;                                               /* inter TUs holding only a few +-1 levels are dropped (ks265_frame_cfg.decimate) */
+    e->fcfg.rdo = 4;                                                    /* coefficient-group pruning at lambda x 1 (ks265_frame_cfg.rdo): supersedes the coefficient decimation of round 2 */
     e->fcfg.bi_refine = 1;                                              /* B pictures: joint refinement of the bi-predictive pair (motionSearchBI enc@0x484910) */
     r = ks265_frame_geometry(&e->fcfg, &e->geom);
     if (!r) r = ks265_frame_create(e->ctx, &e->fcfg, &e->frame);

@@ -423,46 +423,72 @@ void kso_me_subpel(const kso_frame_cfg *cfg, kso_pic src, const uint8_t *planes,
 #endif
 /* ------------------------------------------------------------------ Stage C: CU quadtree
  * bottom-up compare of processTree enc@0x4722a0 (the reference adds RD cost and early exits; closed code). */
-static uint32_t decide_node(const kso_frame_cfg *cfg, const kso_pu *cp, int cx, int cy, int l, int px, int py, uint8_t *split /*[85]*/)
+/* cfg->intra_inter: P / B pictures may hold intra CUs (EncIntraMD.cpp lineage; decideLumaMode enc@0x49acc0 is closed RD code).  A frame-parallel decision has the
+ * pre-selection cost of every block from SOURCE neighbours (kso_intra_decide_ex: SATD + lambda x mode bits): it competes with the block's inter cost, with a
+ * price for what an intra CU costs beyond its mode (pred_mode_flag, no merge / skip, a residual that the reconstructed neighbours make larger than the source
+ * neighbours promise).  icost / imode: 85 per CTU, PU indexing; NULL = no intra candidates. */
+#ifndef INTRA_BIAS_BITS
+#define INTRA_BIAS_BITS 24
+#endif
+static uint32_t node_own_cost(const kso_frame_cfg *cfg, uint32_t inter, const uint32_t *icost, int idx, int l, uint8_t *use_intra)
+{
+    use_intra[idx] = 0;
+    if (!icost || l == 0 || icost[idx] == COST_INVALID) return inter;
+    const uint64_t ic = (uint64_t)icost[idx] + (uint64_t)((cfg->lambda_q4 * INTRA_BIAS_BITS) >> 4);
+    if (inter == COST_INVALID || ic < inter) { use_intra[idx] = 1; return ic > 0xFFFFFFFEu ? 0xFFFFFFFEu : (uint32_t)ic; }
+    return inter;
+}
+static uint32_t decide_node(const kso_frame_cfg *cfg, const kso_pu *cp, const uint32_t *icost, int cx, int cy, int l, int px, int py, uint8_t *split /*[85]*/, uint8_t *use_intra /*[85]*/)
 {
     int s = 64 >> l, x0 = cx * 64 + px * s, y0 = cy * 64 + py * s;
     if (x0 >= cfg->width || y0 >= cfg->height) return 0;           /* not in the picture: nothing to code */
     int idx = pu_index(l, px, py);
-    uint32_t own = cp[idx].cost;
+    uint32_t own = node_own_cost(cfg, cp[idx].cost, icost, idx, l, use_intra);
     if (l == 3) { split[idx] = 0; return own; }
     uint64_t sum = (uint64_t)((cfg->lambda_q4 * SPLIT_BITS_P) >> 4); /* what three extra CUs cost beyond their own SATD + vector rate */
-    for (int k = 0; k < 4; ++k) sum += decide_node(cfg, cp, cx, cy, l + 1, px * 2 + (k & 1), py * 2 + (k >> 1), split);
+    for (int k = 0; k < 4; ++k) sum += decide_node(cfg, cp, icost, cx, cy, l + 1, px * 2 + (k & 1), py * 2 + (k >> 1), split, use_intra);
     if (own != COST_INVALID && (uint64_t)own <= sum) { split[idx] = 0; return own; }
     split[idx] = 1;
     return sum > 0xFFFFFFFEu ? 0xFFFFFFFEu : (uint32_t)sum;
 }
-static void emit_node(const kso_frame_cfg *cfg, const kso_pu *cp, int cx, int cy, int l, int px, int py, const uint8_t *split, kso_cu8 *cu8)
+static void emit_intra(const kso_frame_cfg *cfg, int x0, int y0, int s, int mode, int l, kso_cu8 *cu8)
+{
+    const int w8 = cfg->width / 8;
+    for (int by = 0; by < s / 8; ++by)
+        for (int bx = 0; bx < s / 8; ++bx) {
+            kso_cu8 *c = &cu8[(long)(y0 / 8 + by) * w8 + x0 / 8 + bx];
+            c->mvx = (int16_t)mode; c->mvy = 0; c->mv1x = 0; c->mv1y = 0; c->log2_cu = (uint8_t)(6 - l); c->cbf = 0; c->pred_mode = 2; c->inter_dir = 0;
+        }
+}
+static void emit_node(const kso_frame_cfg *cfg, const kso_pu *cp, const uint8_t *imode, int cx, int cy, int l, int px, int py, const uint8_t *split, const uint8_t *use_intra, kso_cu8 *cu8)
 {
     int s = 64 >> l, x0 = cx * 64 + px * s, y0 = cy * 64 + py * s, w8 = cfg->width / 8;
     if (x0 >= cfg->width || y0 >= cfg->height) return;
     int idx = pu_index(l, px, py);
     if (l < 3 && split[idx]) {
-        for (int k = 0; k < 4; ++k) emit_node(cfg, cp, cx, cy, l + 1, px * 2 + (k & 1), py * 2 + (k >> 1), split, cu8);
+        for (int k = 0; k < 4; ++k) emit_node(cfg, cp, imode, cx, cy, l + 1, px * 2 + (k & 1), py * 2 + (k >> 1), split, use_intra, cu8);
         return;
     }
+    if (use_intra[idx]) { emit_intra(cfg, x0, y0, s, imode[idx], l, cu8); return; }
     for (int by = 0; by < s / 8; ++by)
         for (int bx = 0; bx < s / 8; ++bx) {
             kso_cu8 *c = &cu8[(long)(y0 / 8 + by) * w8 + x0 / 8 + bx];
             c->mvx = cp[idx].mvx; c->mvy = cp[idx].mvy; c->mv1x = 0; c->mv1y = 0; c->log2_cu = (uint8_t)(6 - l); c->cbf = 0; c->pred_mode = 0; c->inter_dir = 1;
         }
 }
-void kso_cu_decide(const kso_frame_cfg *cfg, const kso_pu *pu, kso_cu8 *cu8)
+void kso_cu_decide_ii(const kso_frame_cfg *cfg, const kso_pu *pu, const uint32_t *icost, const uint8_t *imode, kso_cu8 *cu8)
 {
     kso_frame_geom g; kso_frame_geometry(cfg, &g);
     for (int cy = 0; cy < g.ctu_rows; ++cy)
         for (int cx = 0; cx < g.ctu_cols; ++cx) {
-            const kso_pu *cp = pu + (long)(cy * g.ctu_cols + cx) * 85;
-            uint8_t split[85];
-            memset(split, 0, sizeof split);
-            decide_node(cfg, cp, cx, cy, 0, 0, 0, split);
-            emit_node(cfg, cp, cx, cy, 0, 0, 0, split, cu8);
+            const long cb = (long)(cy * g.ctu_cols + cx) * 85;
+            uint8_t split[85], use_intra[85];
+            memset(split, 0, sizeof split); memset(use_intra, 0, sizeof use_intra);
+            decide_node(cfg, pu + cb, icost ? icost + cb : NULL, cx, cy, 0, 0, 0, split, use_intra);
+            emit_node(cfg, pu + cb, imode ? imode + cb : NULL, cx, cy, 0, 0, 0, split, use_intra, cu8);
         }
 }
+void kso_cu_decide(const kso_frame_cfg *cfg, const kso_pu *pu, kso_cu8 *cu8) { kso_cu_decide_ii(cfg, pu, NULL, NULL, cu8); }
 
 /* ------------------------------------------------------------------ Stage C2: merge pass (cfg->merge)
  * The reference decides merge / skip per CU against the candidates of already coded neighbours (GetMergeCandsFor*, skipFastDecision; closed code,
@@ -622,28 +648,29 @@ void kso_bi_decide(const kso_frame_cfg *cfg, kso_pic src, const uint8_t *planes0
         }
 }
 
-static uint32_t decide_node_b(const kso_frame_cfg *cfg, const kso_pu_b *cp, int cx, int cy, int l, int px, int py, uint8_t *split)
+static uint32_t decide_node_b(const kso_frame_cfg *cfg, const kso_pu_b *cp, const uint32_t *icost, int cx, int cy, int l, int px, int py, uint8_t *split, uint8_t *use_intra)
 {
     int s = 64 >> l, x0 = cx * 64 + px * s, y0 = cy * 64 + py * s;
     if (x0 >= cfg->width || y0 >= cfg->height) return 0;
     int idx = pu_index(l, px, py);
-    uint32_t own = cp[idx].cost;
+    uint32_t own = node_own_cost(cfg, cp[idx].cost, icost, idx, l, use_intra);
     if (l == 3) { split[idx] = 0; return own; }
     uint64_t sum = (uint64_t)((cfg->lambda_q4 * SPLIT_BITS_B) >> 4);
-    for (int k = 0; k < 4; ++k) sum += decide_node_b(cfg, cp, cx, cy, l + 1, px * 2 + (k & 1), py * 2 + (k >> 1), split);
+    for (int k = 0; k < 4; ++k) sum += decide_node_b(cfg, cp, icost, cx, cy, l + 1, px * 2 + (k & 1), py * 2 + (k >> 1), split, use_intra);
     if (own != COST_INVALID && (uint64_t)own <= sum) { split[idx] = 0; return own; }
     split[idx] = 1;
     return sum > 0xFFFFFFFEu ? 0xFFFFFFFEu : (uint32_t)sum;
 }
-static void emit_node_b(const kso_frame_cfg *cfg, const kso_pu_b *cp, int cx, int cy, int l, int px, int py, const uint8_t *split, kso_cu8 *cu8)
+static void emit_node_b(const kso_frame_cfg *cfg, const kso_pu_b *cp, const uint8_t *imode, int cx, int cy, int l, int px, int py, const uint8_t *split, const uint8_t *use_intra, kso_cu8 *cu8)
 {
     int s = 64 >> l, x0 = cx * 64 + px * s, y0 = cy * 64 + py * s, w8 = cfg->width / 8;
     if (x0 >= cfg->width || y0 >= cfg->height) return;
     int idx = pu_index(l, px, py);
     if (l < 3 && split[idx]) {
-        for (int k = 0; k < 4; ++k) emit_node_b(cfg, cp, cx, cy, l + 1, px * 2 + (k & 1), py * 2 + (k >> 1), split, cu8);
+        for (int k = 0; k < 4; ++k) emit_node_b(cfg, cp, imode, cx, cy, l + 1, px * 2 + (k & 1), py * 2 + (k >> 1), split, use_intra, cu8);
         return;
     }
+    if (use_intra[idx]) { emit_intra(cfg, x0, y0, s, imode[idx], l, cu8); return; }
     for (int by = 0; by < s / 8; ++by)
         for (int bx = 0; bx < s / 8; ++bx) {
             kso_cu8 *c = &cu8[(long)(y0 / 8 + by) * w8 + x0 / 8 + bx];
@@ -651,18 +678,19 @@ static void emit_node_b(const kso_frame_cfg *cfg, const kso_pu_b *cp, int cx, in
             c->log2_cu = (uint8_t)(6 - l); c->cbf = 0; c->pred_mode = 0; c->inter_dir = (uint8_t)cp[idx].inter_dir;
         }
 }
-void kso_cu_decide_b(const kso_frame_cfg *cfg, const kso_pu_b *pub, kso_cu8 *cu8)
+void kso_cu_decide_b_ii(const kso_frame_cfg *cfg, const kso_pu_b *pub, const uint32_t *icost, const uint8_t *imode, kso_cu8 *cu8)
 {
     kso_frame_geom g; kso_frame_geometry(cfg, &g);
     for (int cy = 0; cy < g.ctu_rows; ++cy)
         for (int cx = 0; cx < g.ctu_cols; ++cx) {
-            const kso_pu_b *cp = pub + (long)(cy * g.ctu_cols + cx) * 85;
-            uint8_t split[85];
-            memset(split, 0, sizeof split);
-            decide_node_b(cfg, cp, cx, cy, 0, 0, 0, split);
-            emit_node_b(cfg, cp, cx, cy, 0, 0, 0, split, cu8);
+            const long cb = (long)(cy * g.ctu_cols + cx) * 85;
+            uint8_t split[85], use_intra[85];
+            memset(split, 0, sizeof split); memset(use_intra, 0, sizeof use_intra);
+            decide_node_b(cfg, pub + cb, icost ? icost + cb : NULL, cx, cy, 0, 0, 0, split, use_intra);
+            emit_node_b(cfg, pub + cb, imode ? imode + cb : NULL, cx, cy, 0, 0, 0, split, use_intra, cu8);
         }
 }
+void kso_cu_decide_b(const kso_frame_cfg *cfg, const kso_pu_b *pub, kso_cu8 *cu8) { kso_cu_decide_b_ii(cfg, pub, NULL, NULL, cu8); }
 
 /* key picture stand-in for the (out-of-scope) intra path: largest CU in {32,16,8} that fits, flat prediction */
 void kso_cu_flat_intra(const kso_frame_cfg *cfg, kso_cu8 *cu8)
@@ -695,15 +723,26 @@ static int tu_scan_idx(int intra, int mode, int n, int is_chroma)
     return (mode >= 6 && mode <= 14) ? 2 : (mode >= 22 && mode <= 30) ? 1 : 0;
 }
 /* sdh: the postQuant seam (postQuant enc@0x4ace80) - after the quantiser, before dequantisation: sign-data hiding with the TU's scan */
+/* cfg->rdo = K > 0: coefficient-group pruning at the postQuant seam - the sub-block decision of HM-lineage RDOQ (rdoQuant enc@0x4aac50 is closed code; its tables
+ * estBitRdoq enc@0x46a8a0 are pinned, this is the frame-parallel form with STATIC bit costs).  A 4x4 group of levels is kept only if the distortion its levels remove
+ * outweighs lambda_mode x K / 4 x their bits:
+ *   gain  = sum over the group's levels of c^2 - (c - d)^2   (c = transform coefficient, d = dequantised level; the forward transform scales by 2^(7 - log2 N), so
+ *           the pixel-domain SSE is gain >> 2 (7 - log2 N))
+ *   bits  = sum of rdo_level_q2(|level|) + 10 + (16 - levels)   in quarter bits: significance + greater-1/2 flags + sign (3.5 bits for +-1, 5 for +-2, then the
+ *           exp-Golomb remainder), coded_sub_block_flag, the significance flags of the zeros around
+ *   kept iff (gain >> 2 (7 - log2 N)) << 12 > lambda_q4^2 x bits x K        (lambda_mode = (lambda_q4 / 16)^2; K = 4 is lambda x 1)
+ * Inter TUs of every component, and the intra CUs of P / B pictures; key pictures keep every level (their quality is inherited by the whole GOP: measured with
+ * tools/rd_eval.py, pruning them costs 3 % at equal PSNR).  Runs before sign-data hiding, which then works on the pruned levels. */
+static int rdo_level_q2(int a) { return a == 1 ? 14 : a == 2 ? 20 : 26 + 8 * (31 - __builtin_clz((unsigned)(a - 1))); }
 static int code_tu(const uint8_t *org, int so, const uint8_t *pred /*packed n*/, int n, int qp, int intra, int16_t *lvl, int lstride,
-                   uint8_t *rec, int rstride, int sdh, int scan_idx, int decimate)
+                   uint8_t *rec, int rstride, int sdh, int scan_idx, int decimate, int rdo, int lambda_q4)
 {
     int16_t res[32 * 32], coef[32 * 32], lv[32 * 32], du[32 * 32], dq[32 * 32], tmp[32 * 32];
     int log2n = n == 4 ? 2 : n == 8 ? 3 : n == 16 ? 4 : 5, idx = log2n - 1;   /* DCT table index (DST4 is intra-luma-4x4 only) */
     ks265o_calc_residual(res, org, pred, so, n, n, n);
     ks265o_fwd_transform(idx, res, coef, n, n, tmp);
     ks265o_quant_param p;
-    ks265o_get_base_quant_param(qp, intra ? 2 : 0, &p);
+    ks265o_get_base_quant_param(qp, intra == 1 ? 2 : 0, &p);        /* intra: 1 = a CU of an I slice (offset 171), 2 = an intra CU of a P / B slice (the slice's offset, 85) */
     int qbits = p.qbits - log2n;
     int nz = ks265o_quant(coef, lv, n, p.scale, p.offF << (qbits - 9), qbits, du, n);
     /* cfg->decimate = K > 0 (inter LUMA TUs): a block whose levels are all +-1 and at most 2K (8x8), 3K (16x16), 4K (32x32) of them is not worth its bits - the
@@ -715,6 +754,30 @@ static int code_tu(const uint8_t *org, int so, const uint8_t *pred /*packed n*/,
         int mx = 0;
         for (int i = 0; i < n * n; ++i) { const int a = lv[i] < 0 ? -lv[i] : lv[i]; if (a > mx) mx = a; }
         if (mx <= 1) { memset(lv, 0, sizeof(int16_t) * (size_t)(n * n)); nz = 0; }
+    }
+    if (rdo > 0 && intra != 1 && nz > 0) {
+        const int sh2 = 2 * (7 - log2n), dshift = log2n - 1;
+        const int64_t lam2 = (int64_t)lambda_q4 * lambda_q4;
+        for (int gy = 0; gy < n; gy += 4)
+            for (int gx = 0; gx < n; gx += 4) {
+                int64_t gain = 0; int bits = 0, cnt = 0;
+                for (int y = gy; y < gy + 4; ++y)
+                    for (int x = gx; x < gx + 4; ++x) {
+                        const int l = lv[y * n + x];
+                        if (!l) continue;
+                        const int c = coef[y * n + x];
+                        int d = (l * p.dq + (1 << (dshift - 1))) >> dshift;
+                        d = d < -32768 ? -32768 : d > 32767 ? 32767 : d;
+                        gain += (int64_t)d * (2 * c - d);                  /* c^2 - (c - d)^2 */
+                        bits += rdo_level_q2(l < 0 ? -l : l); ++cnt;
+                    }
+                if (!cnt) continue;
+                bits += 10 + (16 - cnt);
+                if (((gain >> sh2) << 12) <= lam2 * bits * rdo) {
+                    for (int y = gy; y < gy + 4; ++y) for (int x = gx; x < gx + 4; ++x) lv[y * n + x] = 0;
+                    nz -= cnt;
+                }
+            }
     }
     if (sdh && nz > 1) nz = ks265o_sign_bit_hiding(lv, coef, du, n, log2n, scan_idx);
     for (int y = 0; y < n; ++y) memcpy(lvl + (long)y * lstride, lv + y * n, sizeof(int16_t) * (size_t)n);
@@ -770,6 +833,7 @@ static void reconstruct_impl(const kso_frame_cfg *cfg, kso_pic src, const kso_pi
             int n8 = 1 << (c->log2_cu - 3);
             int tu8 = imin(n8, 4);                              /* TU = min(CU, 32) */
             if ((bx % tu8) || (by % tu8)) continue;             /* visit each TU once, at its top-left 8x8 block */
+            if (c->pred_mode == 2) continue;                    /* an intra CU of a P / B picture: coded afterwards from reconstructed neighbours (kso_intra_inter_reconstruct) */
             int n = tu8 * 8, x0 = bx * 8, y0 = by * 8, intra = c->pred_mode == 1;
             int mvx = c->mvx, mvy = c->mvy, cbf = 0;
             uint8_t pred[32 * 32];
@@ -790,7 +854,7 @@ static void reconstruct_impl(const kso_frame_cfg *cfg, kso_pic src, const kso_pi
                 for (int y = 0; y < n; ++y) memcpy(pred + y * n, pl + (long)y * sy, (size_t)n);
             }
             cbf |= code_tu(org_y(&g, src.y) + (long)y0 * sy + x0, (int)sy, pred, n, qp, intra, lvl_y + (long)y0 * W + x0, W,
-                           org_y(&g, recon.y) + (long)y0 * sy + x0, (int)sy, cfg->sdh, 0, cfg->decimate);
+                           org_y(&g, recon.y) + (long)y0 * sy + x0, (int)sy, cfg->sdh, 0, cfg->decimate, cfg->rdo, cfg->lambda_q4);
             /* chroma: 4-tap 1/8-sample MC (interpChroma* enc@0x4111c0..), TU n/2 */
             int nc = n / 2, xc = x0 / 2, yc = y0 / 2;
             for (int comp = 0; comp < 2; ++comp) {
@@ -817,7 +881,7 @@ static void reconstruct_impl(const kso_frame_cfg *cfg, kso_pic src, const kso_pi
                 int16_t *lv = (comp ? lvl_v : lvl_u) + (long)yc * (W / 2) + xc;
                 uint8_t *rc = org_c(&g, comp ? recon.v : recon.u) + (long)yc * sc + xc;
                 const uint8_t *oc = org_c(&g, comp ? src.v : src.u) + (long)yc * sc + xc;
-                if (code_tu(oc, (int)sc, pred, nc, qpc, intra, lv, W / 2, rc, (int)sc, cfg->sdh, 0, 0)) cbf |= 2 << comp;      /* no decimation of chroma: see code_tu */
+                if (code_tu(oc, (int)sc, pred, nc, qpc, intra, lv, W / 2, rc, (int)sc, cfg->sdh, 0, 0, cfg->rdo, cfg->lambda_q4)) cbf |= 2 << comp;      /* no decimation of chroma: see code_tu */
             }
             for (int yy = 0; yy < tu8; ++yy)
                 for (int xx = 0; xx < tu8; ++xx) cu8[(long)(by + yy) * w8 + bx + xx].cbf = (uint8_t)cbf;
@@ -1136,10 +1200,12 @@ static void intra_emit(const kso_frame_cfg *cfg, const intra_ctu *t, int cx, int
         }
 }
 /* cost_out (optional): the pre-selection cost of every block, PU indexing (85 per CTU; level 0 and blocks not inside the picture: COST_INVALID) */
-static void intra_decide_impl(const kso_frame_cfg *cfg, kso_pic src, kso_cu8 *cu8, uint32_t *cost_out);
-void kso_intra_decide(const kso_frame_cfg *cfg, kso_pic src, kso_cu8 *cu8) { intra_decide_impl(cfg, src, cu8, NULL); }
-void kso_intra_decide_ex(const kso_frame_cfg *cfg, kso_pic src, kso_cu8 *cu8, uint32_t *cost_out) { intra_decide_impl(cfg, src, cu8, cost_out); }
-static void intra_decide_impl(const kso_frame_cfg *cfg, kso_pic src, kso_cu8 *cu8, uint32_t *cost_out)
+static void intra_decide_impl(const kso_frame_cfg *cfg, kso_pic src, kso_cu8 *cu8, uint32_t *cost_out, uint8_t *mode_out);
+void kso_intra_decide(const kso_frame_cfg *cfg, kso_pic src, kso_cu8 *cu8) { intra_decide_impl(cfg, src, cu8, NULL, NULL); }
+void kso_intra_decide_ex(const kso_frame_cfg *cfg, kso_pic src, kso_cu8 *cu8, uint32_t *cost_out) { intra_decide_impl(cfg, src, cu8, cost_out, NULL); }
+/* the candidates of P / B pictures (cfg->intra_inter): cost and best mode of every block, no CU tree (cu8 may be NULL) */
+void kso_intra_candidates(const kso_frame_cfg *cfg, kso_pic src, uint32_t *cost_out, uint8_t *mode_out) { intra_decide_impl(cfg, src, NULL, cost_out, mode_out); }
+static void intra_decide_impl(const kso_frame_cfg *cfg, kso_pic src, kso_cu8 *cu8, uint32_t *cost_out, uint8_t *mode_out)
 {
     kso_frame_geom g; kso_frame_geometry(cfg, &g);
     const uint8_t *S = org_y(&g, src.y);
@@ -1159,6 +1225,8 @@ static void intra_decide_impl(const kso_frame_cfg *cfg, kso_pic src, kso_cu8 *cu
                     }
             t.cost[0] = COST_INVALID;
             if (cost_out) memcpy(cost_out + (long)(cy * g.ctu_cols + cx) * 85, t.cost, sizeof t.cost);
+            if (mode_out) memcpy(mode_out + (long)(cy * g.ctu_cols + cx) * 85, t.mode, sizeof t.mode);
+            if (!cu8) continue;
             intra_node(cfg, &t, cx, cy, 0, 0, 0);
             intra_emit(cfg, &t, cx, cy, 0, 0, 0, cu8);
         }
@@ -1182,8 +1250,9 @@ void kso_lookahead_reduce(const kso_frame_cfg *cfg, const uint32_t *intra_cost, 
     out[0] = si; out[1] = sp; out[2] = sm; out[3] = nb | (ni << 32);
 }
 
+/* islice: the quantiser's rounding offset follows the SLICE type (H265_GetBaseQuantParam enc@0x4a9c90: 171 in I slices, 85 otherwise), also for intra CUs */
 static void intra_code_cu(const kso_frame_cfg *cfg, const kso_frame_geom *g, kso_pic src, kso_cu8 *cu8, int bx, int by, int16_t *lvl_y, int16_t *lvl_u,
-                          int16_t *lvl_v, kso_pic recon)
+                          int16_t *lvl_v, kso_pic recon, int islice)
 {
     int W = cfg->width, H = cfg->height, w8 = W / 8, qp = cfg->qp, qpc = chroma_qp(qp);
     long sy = g->stride_y, sc = g->stride_c;
@@ -1195,8 +1264,8 @@ static void intra_code_cu(const kso_frame_cfg *cfg, const kso_frame_geom *g, kso
     const uint8_t *r = raw + 2 * n;
     if (intra_filter_flag(mode, n)) { ks265o_intra_filter_ref(raw + 2 * n, fil + 2 * n, n, 1); r = fil + 2 * n; }
     ks265o_intra_pred(pred, n, r, mode, log2, 1);
-    cbf |= code_tu(org_y(g, src.y) + (long)y0 * sy + x0, (int)sy, pred, n, qp, 1, lvl_y + (long)y0 * W + x0, W, Ry + (long)y0 * sy + x0, (int)sy, cfg->sdh,
-                   tu_scan_idx(1, mode, n, 0), 0);
+    cbf |= code_tu(org_y(g, src.y) + (long)y0 * sy + x0, (int)sy, pred, n, qp, islice ? 1 : 2, lvl_y + (long)y0 * W + x0, W, Ry + (long)y0 * sy + x0, (int)sy, cfg->sdh,
+                   tu_scan_idx(1, mode, n, 0), 0, islice ? 0 : cfg->rdo, cfg->lambda_q4);
     int nc = n / 2, xc = x0 / 2, yc = y0 / 2;
     for (int comp = 0; comp < 2; ++comp) {
         uint8_t *Rc = org_c(g, comp ? recon.v : recon.u);
@@ -1204,7 +1273,7 @@ static void intra_code_cu(const kso_frame_cfg *cfg, const kso_frame_geom *g, kso
         ks265o_intra_pred(pred, nc, raw + 2 * nc, mode, log2 - 1, 0);
         int16_t *lv = (comp ? lvl_v : lvl_u) + (long)yc * (W / 2) + xc;
         const uint8_t *oc = org_c(g, comp ? src.v : src.u) + (long)yc * sc + xc;
-        if (code_tu(oc, (int)sc, pred, nc, qpc, 1, lv, W / 2, Rc + (long)yc * sc + xc, (int)sc, cfg->sdh, tu_scan_idx(1, mode, nc, 1), 0)) cbf |= 2 << comp;
+        if (code_tu(oc, (int)sc, pred, nc, qpc, islice ? 1 : 2, lv, W / 2, Rc + (long)yc * sc + xc, (int)sc, cfg->sdh, tu_scan_idx(1, mode, nc, 1), 0, islice ? 0 : cfg->rdo, cfg->lambda_q4)) cbf |= 2 << comp;
     }
     for (int yy = 0; yy < n / 8; ++yy)
         for (int xx = 0; xx < n / 8; ++xx) cu8[(long)(by + yy) * w8 + bx + xx].cbf = (uint8_t)cbf;
@@ -1221,6 +1290,24 @@ void kso_intra_reconstruct(const kso_frame_cfg *cfg, kso_pic src, kso_cu8 *cu8, 
                 if (bx >= w8 || by >= h8) continue;
                 int n8 = 1 << (cu8[(long)by * w8 + bx].log2_cu - 3);
                 if ((lx % n8) || (ly % n8)) continue;                /* visit each CU once, at its first 8x8 block */
-                intra_code_cu(cfg, &g, src, cu8, bx, by, lvl_y, lvl_u, lvl_v, recon);
+                intra_code_cu(cfg, &g, src, cu8, bx, by, lvl_y, lvl_u, lvl_v, recon, 1);
+            }
+}
+/* cfg->intra_inter: the intra CUs (pred_mode 2) of a P / B picture, after kso_reconstruct has written every inter CU: CTUs in raster order, CUs in z-order, neighbours
+ * from the reconstructed picture (inter and intra alike: constrained_intra_pred_flag = 0) */
+void kso_intra_inter_reconstruct(const kso_frame_cfg *cfg, kso_pic src, kso_cu8 *cu8, int16_t *lvl_y, int16_t *lvl_u, int16_t *lvl_v, kso_pic recon)
+{
+    kso_frame_geom g; kso_frame_geometry(cfg, &g);
+    int w8 = cfg->width / 8, h8 = cfg->height / 8;
+    for (int cy = 0; cy < g.ctu_rows; ++cy)
+        for (int cx = 0; cx < g.ctu_cols; ++cx)
+            for (int z = 0; z < 64; ++z) {
+                int lx = (z & 1) | ((z >> 1) & 2) | ((z >> 2) & 4), ly = ((z >> 1) & 1) | ((z >> 2) & 2) | ((z >> 3) & 4);
+                int bx = cx * 8 + lx, by = cy * 8 + ly;
+                if (bx >= w8 || by >= h8) continue;
+                if (cu8[(long)by * w8 + bx].pred_mode != 2) continue;
+                int n8 = 1 << (cu8[(long)by * w8 + bx].log2_cu - 3);
+                if ((lx % n8) || (ly % n8)) continue;
+                intra_code_cu(cfg, &g, src, cu8, bx, by, lvl_y, lvl_u, lvl_v, recon, 0);
             }
 }

@@ -18,7 +18,7 @@ extern "C" {
 #endif
 
 typedef struct {
-    int32_t width, height, qp, lambda_q4, me_range, me_method, subme, deblock, sao, beta_offset_div2, tc_offset_div2, bframes, refs, me_hex_thr, sdh, pre_search, merge, bi_refine, decimate;
+    int32_t width, height, qp, lambda_q4, me_range, me_method, subme, deblock, sao, beta_offset_div2, tc_offset_div2, bframes, refs, me_hex_thr, sdh, pre_search, merge, bi_refine, decimate, rdo, intra_inter;
 } kso_frame_cfg;
 
 typedef struct {
@@ -46,6 +46,11 @@ void kso_me_integer(const kso_frame_cfg *cfg, kso_pic src, kso_pic ref, const ks
 void kso_me_subpel(const kso_frame_cfg *cfg, kso_pic src, const uint8_t *planes, kso_pu *pu);
 void kso_cu_decide(const kso_frame_cfg *cfg, const kso_pu *pu, kso_cu8 *cu8);
 void kso_cu_flat_intra(const kso_frame_cfg *cfg, kso_cu8 *cu8);
+/* cfg->intra_inter: the CU trees with intra candidates (icost / imode: 85 per CTU from kso_intra_candidates; NULL = none), and the intra CUs' reconstruction pass */
+void kso_cu_decide_ii(const kso_frame_cfg *cfg, const kso_pu *pu, const uint32_t *icost, const uint8_t *imode, kso_cu8 *cu8);
+void kso_cu_decide_b_ii(const kso_frame_cfg *cfg, const kso_pu_b *pub, const uint32_t *icost, const uint8_t *imode, kso_cu8 *cu8);
+void kso_intra_candidates(const kso_frame_cfg *cfg, kso_pic src, uint32_t *cost_out, uint8_t *mode_out);
+void kso_intra_inter_reconstruct(const kso_frame_cfg *cfg, kso_pic src, kso_cu8 *cu8, int16_t *lvl_y, int16_t *lvl_u, int16_t *lvl_v, kso_pic recon);
 void kso_reconstruct(const kso_frame_cfg *cfg, kso_pic src, kso_pic ref, const uint8_t *planes, kso_pic ref1, const uint8_t *planes1,
                      kso_cu8 *cu8, int16_t *lvl_y, int16_t *lvl_u, int16_t *lvl_v, kso_pic recon);
 /* B pictures: per-PU choice among L0, L1 and the bi-predictive average (interMeBi* lineage), then the CU quadtree on it */

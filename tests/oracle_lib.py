@@ -45,7 +45,7 @@ I = C.c_int
 # ------------------------------------------------------------------ pipeline oracle (ks265_pipeline_oracle.h)
 class OFrameCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("width", "height", "qp", "lambda_q4", "me_range", "me_method", "subme", "deblock", "sao",
-                                          "beta_offset_div2", "tc_offset_div2", "bframes", "refs", "me_hex_thr", "sdh", "pre_search", "merge", "bi_refine", "decimate")]
+                                          "beta_offset_div2", "tc_offset_div2", "bframes", "refs", "me_hex_thr", "sdh", "pre_search", "merge", "bi_refine", "decimate", "rdo", "intra_inter")]
 
 
 class OFrameGeom(C.Structure):
@@ -80,10 +80,10 @@ class HostPic:
 class OraclePipeline:
     """CPU restatement of the frame stages (test checker / cpu_baseline 'port')."""
 
-    def __init__(self, width, height, qp, lambda_q4, me_range=64, subme=1, deblock=1, sao=1, me_method=0, intra=True, me_hex_thr=0, sdh=0, pre_search=0, merge=0, bi_refine=0, decimate=0):
+    def __init__(self, width, height, qp, lambda_q4, me_range=64, subme=1, deblock=1, sao=1, me_method=0, intra=True, me_hex_thr=0, sdh=0, pre_search=0, merge=0, bi_refine=0, decimate=0, rdo=0, intra_inter=0):
         self.o = lib()
         self.intra = intra                      # key pictures: real intra prediction (True) or the flat stand-in
-        self.cfg = OFrameCfg(width, height, qp, lambda_q4, me_range, me_method, subme, deblock, sao, 0, 0, 1, 4, me_hex_thr, sdh, pre_search, merge, bi_refine, decimate)
+        self.cfg = OFrameCfg(width, height, qp, lambda_q4, me_range, me_method, subme, deblock, sao, 0, 0, 1, 4, me_hex_thr, sdh, pre_search, merge, bi_refine, decimate, rdo, intra_inter)
         self.geom = OFrameGeom()
         assert self.o.kso_frame_geometry(C.byref(self.cfg), C.byref(self.geom)) == 0
         g = self.geom
@@ -130,8 +130,16 @@ class OraclePipeline:
             self.pu_int = self.pu.copy()
             if self.cfg.subme:
                 o.kso_me_subpel(cfg, self.src.c(), ptr(self.planes), ptr(self.pu))
+            ii = self.cfg.intra_inter
+            if ii:                                       # intra candidates of this picture: cost + mode of every block from source neighbours
+                if not hasattr(self, "icost"):
+                    self.icost, self.imode = np.zeros(self.nctu * 85, np.uint32), np.zeros(self.nctu * 85, np.uint8)
+                o.kso_intra_candidates(cfg, self.src.c(), ptr(self.icost), ptr(self.imode))
             if kind == "P":
-                o.kso_cu_decide(cfg, ptr(self.pu), ptr(self.cu8))
+                if ii:
+                    o.kso_cu_decide_ii(cfg, ptr(self.pu), ptr(self.icost), ptr(self.imode), ptr(self.cu8))
+                else:
+                    o.kso_cu_decide(cfg, ptr(self.pu), ptr(self.cu8))
                 if self.cfg.merge:
                     tmp = self.cu8.copy()
                     o.kso_merge_pass(cfg, self.src.c(), ptr(self.planes), None, ptr(self.pu), None, ptr(tmp), ptr(self.cu8))
@@ -146,7 +154,10 @@ class OraclePipeline:
                 if self.cfg.subme:
                     o.kso_me_subpel(cfg, self.src.c(), ptr(self.planes1), ptr(self.pu1))
                 o.kso_bi_decide(cfg, self.src.c(), ptr(self.planes), ptr(self.planes1), ptr(self.pu), ptr(self.pu1), ptr(self.pub))
-                o.kso_cu_decide_b(cfg, ptr(self.pub), ptr(self.cu8))
+                if ii:
+                    o.kso_cu_decide_b_ii(cfg, ptr(self.pub), ptr(self.icost), ptr(self.imode), ptr(self.cu8))
+                else:
+                    o.kso_cu_decide_b(cfg, ptr(self.pub), ptr(self.cu8))
                 if self.cfg.merge:
                     tmp = self.cu8.copy()
                     o.kso_merge_pass(cfg, self.src.c(), ptr(self.planes), ptr(self.planes1), None, ptr(self.pub), ptr(tmp), ptr(self.cu8))
@@ -156,6 +167,8 @@ class OraclePipeline:
         else:
             o.kso_reconstruct(cfg, self.src.c(), r0, ptr(self.planes), r1, p1, ptr(self.cu8), ptr(self.lvl[0]), ptr(self.lvl[1]), ptr(self.lvl[2]),
                               self.rec.c())
+            if self.cfg.intra_inter:
+                o.kso_intra_inter_reconstruct(cfg, self.src.c(), ptr(self.cu8), ptr(self.lvl[0]), ptr(self.lvl[1]), ptr(self.lvl[2]), self.rec.c())
         self.rec_pre = [self.rec.y.copy(), self.rec.u.copy(), self.rec.v.copy()]
         if self.cfg.deblock:
             o.kso_deblock(cfg, ptr(self.cu8), self.rec.c())

@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""Coding efficiency on the CPU: the ORACLE pipeline (the specification the HIP stages equal bit for bit) + the host's stream writer on a bench-style clip,
+next to the reference encoder `appencoder` on the same clip - bitrate and PSNR-Y per QP, and the bitrate ratio at the reference's PSNR-Y.
+Builder container only (needs oracle/_ref/appencoder or /root/reference); a design aid for the RD tools of DESIGN.md, not part of the product.
+
+usage: tools/rd_eval.py [--size 832x480] [--frames 17] [--gop ippp|hier] [--qps 27,29,31] [--tools k=v,...] [--no-ref] [--tag text]
+"""
+from __future__ import annotations
+
+import argparse
+import itertools
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+ENCODER_TOOLS = dict(me_method=2, me_hex_thr=16, sdh=1, pre_search=1, merge=1, bi_refine=1, decimate=2)
+
+
+def stats_lib():
+    """the stream writer built with -DKS265_BIT_STATS: information content of the slice data per syntax category"""
+    import ctypes as C
+    from ks265codec_amd import stream as S
+    so = os.path.join(tempfile.gettempdir(), "libks265_stats.so")
+    subprocess.check_call(["gcc", "-O2", "-std=gnu11", "-fPIC", "-DKS265_BIT_STATS", "-I", os.path.join(ROOT, "include"), "-shared", "-o", so,
+                           os.path.join(ROOT, "ks265codec_amd/host/ks265_stream.c"), "-lm"])
+    S._lib = C.CDLL(so)
+    for n in ("ks265_write_vps", "ks265_write_sps", "ks265_write_pps", "ks265_write_slice"):
+        getattr(S._lib, n).restype = C.c_long
+    S._lib.ks265_slice_scratch_bytes.restype = C.c_size_t
+    return S._lib
+
+
+STAT_NAMES = ["cu", "merge", "motion", "coef", "sao", "intra"]
+
+
+def encode_ours(clip, W, H, qp, gop, tools, verbose=False, stats=None, pdelta=1, cascade=None, lam_scale=1.0):
+    from ks265codec_amd import stream as S
+    from ks265codec_amd.gop import hier_order
+    from ks265codec_amd.synth import lambda_q4, psnr
+    from oracle_lib import OraclePipeline
+    n = len(clip)
+    o = OraclePipeline(W, H, qp, lambda_q4(qp), **tools)
+    G = 8
+    w = S.StreamWriter(W, H, max_dec_pic_buffering=10 if gop == "hier" else 2, max_num_reorder=7 if gop == "hier" else 0, sdh=tools.get("sdh", 0), wpp=0 if stats else 1)
+    import ctypes as C
+    st = (C.c_double * 6)()
+    agg = {}
+    bs = w.headers()
+    per = []
+    ps = []
+    if gop == "ippp":
+        seq = [(t, "I" if t == 0 else "P", t - 1 if t else None, None, 0) for t in range(n)]
+    else:
+        seq = [s for s in itertools.islice(hier_order(G, 1 << 20), n) if s[0] < n]
+    dpb = {}
+    for i, (d, kind, r0, r1, layer) in enumerate(seq):
+        q = min(51, qp if kind == "I" else qp + pdelta + layer + (cascade[d % len(cascade)] if cascade and gop == "ippp" else 0))
+        ls = lam_scale if lam_scale > 0 else (min(4.0, max(2.0, (q - 12) / 6.0))) ** 0.5      # <= 0: HM's factor for non-key pictures, clip(2, 4, (qp - 12) / 6) on lambda_mode
+        o.set_qp(q, lambda_q4(q) if kind == "I" else int(round(lambda_q4(q) * ls)))
+        dpb[d] = o.encode(clip[d], kind, dpb.get(r0), dpb.get(r1))
+        rec = o.store(dpb[d])
+        later = seq[i + 1:]
+        needed = {r for (_, _, a, b, _) in later for r in (a, b) if r is not None and r in dpb and r != d}
+        cur = {r for r in (r0, r1) if r is not None}
+        rps = [(p, p in cur) for p in sorted(needed | cur)]
+        isref = any(d in (a, b) for (_, _, a, b, _) in later)
+        if stats:
+            stats.ks265_bit_stats(st, 1)
+        if kind == "I":
+            b = w.slice(S.NAL_IDR_W_RADL, S.SLICE_I, 0, q, o.cu8, o.lvl, o.sao)
+        elif kind == "P":
+            b = w.slice(S.NAL_TRAIL_R, S.SLICE_P, d, q, o.cu8, o.lvl, o.sao, rps=rps, l0=[r0])
+        else:
+            b = w.slice(S.NAL_TRAIL_R if isref else S.NAL_TRAIL_N, S.SLICE_B, d, q, o.cu8, o.lvl, o.sao, rps=rps, l0=[r0], l1=[r1])
+        bs += b
+        if stats:
+            stats.ks265_bit_stats(st, 1)
+            cu = o.cu8.reshape(H // 8, W // 8)
+            t = agg.setdefault(f"{kind}{layer if kind == 'B' else ''}", dict(n=0, bits=np.zeros(6), cus={}))
+            t["n"] += 1; t["bits"] += np.array(st[:]) / 8
+            if kind != "I":
+                for lg in (3, 4, 5, 6):
+                    m = cu["log2_cu"] == lg
+                    ncu = int(m.sum()) >> (2 * (lg - 3))
+                    coded = int((m & (cu["cbf"] != 0)).sum()) >> (2 * (lg - 3))
+                    intra = int((m & (cu["pred_mode"] != 0)).sum()) >> (2 * (lg - 3))
+                    c = t["cus"].setdefault(lg, [0, 0, 0]); c[0] += ncu; c[1] += coded; c[2] += intra
+        p = psnr(clip[d][:W * H], rec[:W * H])
+        per.append((d, kind, layer, len(b), p))
+        ps.append((clip[d][:W * H].astype(np.float64) - rec[:W * H]) ** 2)
+        if verbose:
+            print(f"   {d:3d} {kind} L{layer} {len(b):7d} B  {p:.2f} dB", flush=True)
+        for k in [k for k in dpb if k not in needed and k != d and k not in cur]:
+            del dpb[k]
+    mse = float(np.mean([x.mean() for x in ps]))
+    if stats:
+        for k, t in sorted(agg.items()):
+            print(f"      {k}: " + "  ".join(f"{nm} {t['bits'][i] / t['n']:.0f}" for i, nm in enumerate(STAT_NAMES)) + "   CUs(n coded intra) " +
+                  "  ".join(f"{1 << lg}: {c[0] / t['n']:.0f} {c[1] / t['n']:.0f} {c[2] / t['n']:.0f}" for lg, c in sorted(t["cus"].items())))
+    return bs, 10 * np.log10(255.0 ** 2 / mse), per
+
+
+def encode_ref(yuv_path, W, H, qp, gop, n, threads=4):
+    enc = os.path.join(ROOT, "oracle", "_ref", "appencoder")
+    if not os.path.exists(enc):
+        enc = "/root/reference/ubuntu_x64/appencoder"
+    d = tempfile.mkdtemp(prefix="rdref")
+    exe = os.path.join(d, "appencoder")
+    subprocess.check_call(["cp", enc, exe]); os.chmod(exe, 0o755)
+    args = [exe, "-i", yuv_path, "-wdt", str(W), "-hgt", str(H), "-fr", "50", "-preset", "slow", "-rc", "0", "-qp", str(qp), "-iper", "128", "-threads", str(threads), "-psnr", "2",
+            "-b", os.path.join(d, "o.265")]
+    if gop == "ippp":
+        args += ["-bframes", "0"]
+    r = subprocess.run(args, capture_output=True, text=True, cwd=d)
+    m = re.search(r"bitrate, psnr:\s*([\d.]+)\s+([\d.]+)", r.stdout)
+    size = os.path.getsize(os.path.join(d, "o.265"))
+    per = [(int(a), b, int(c) // 8, float(e)) for a, b, c, e in re.findall(r"^(\d+)\t([IPB])\t(\d+)\t([\d.]+)\t", r.stdout, re.M)]
+    subprocess.call(["rm", "-rf", d])
+    return size, float(m.group(2)), per
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--size", default="832x480")
+    ap.add_argument("--frames", type=int, default=17)
+    ap.add_argument("--gop", default="ippp")
+    ap.add_argument("--qps", default="27,29,31")
+    ap.add_argument("--ref-qp", type=int, default=27)
+    ap.add_argument("--tools", default="")
+    ap.add_argument("--no-ref", action="store_true")
+    ap.add_argument("--seed", type=int, default=7)
+    ap.add_argument("--tag", default="")
+    ap.add_argument("-v", action="store_true")
+    ap.add_argument("--stats", action="store_true")
+    ap.add_argument("--pdelta", type=int, default=1)
+    ap.add_argument("--cascade", default="")
+    ap.add_argument("--lam-scale", type=float, default=1.0)
+    a = ap.parse_args()
+    from ks265codec_amd.synth import make_clip
+    W, H = (int(x) for x in a.size.split("x"))
+    big = W >= 3000
+    clip = make_clip(W, H, a.frames, seed=a.seed, abc=(67, 91, 33) if big else (37, 53, 19), pan=(8, 5) if big else (5, 3))
+    tools = dict(ENCODER_TOOLS)
+    for kv in filter(None, a.tools.split(",")):
+        k, v = kv.split("=")
+        tools[k] = int(v)
+    ref = None
+    if not a.no_ref:
+        with tempfile.NamedTemporaryFile(suffix=".yuv", delete=False) as f:
+            clip.tofile(f)
+        size, p, per = encode_ref(f.name, W, H, a.ref_qp, a.gop, a.frames)
+        os.unlink(f.name)
+        ref = (size, p)
+        bykind = {}
+        for d, k, b, e in per:
+            bykind.setdefault(k, []).append(b)
+        print(f"reference  qp {a.ref_qp}: {size:8d} B  {p:.3f} dB   " + "  ".join(f"{k}: {int(np.mean(v))} B x{len(v)}" for k, v in bykind.items()), flush=True)
+    pts = []
+    for qp in (int(x) for x in a.qps.split(",")):
+        t0 = time.time()
+        bs, p, per = encode_ours(clip, W, H, qp, a.gop, tools, a.v, stats_lib() if a.stats else None, a.pdelta, [int(x) for x in a.cascade.split(',')] if a.cascade else None, a.lam_scale)
+        bykind = {}
+        for d, k, l, b, e in per:
+            bykind.setdefault(f"{k}{l if k == 'B' else ''}", []).append(b)
+        pts.append((len(bs), p))
+        print(f"ours {a.tag} qp {qp}: {len(bs):8d} B  {p:.3f} dB   " + "  ".join(f"{k}: {int(np.mean(v))} B x{len(v)}" for k, v in bykind.items()) + f"   ({time.time() - t0:.0f} s)", flush=True)
+    if ref and len(pts) >= 2:
+        pts.sort(key=lambda t: t[1])
+        lo = [t for t in pts if t[1] <= ref[1]]
+        hi = [t for t in pts if t[1] >= ref[1]]
+        if lo and hi:
+            (b0, p0), (b1, p1) = lo[-1], hi[0]
+            b = b0 if p1 == p0 else np.exp(np.log(b0) + (ref[1] - p0) / (p1 - p0) * (np.log(b1) - np.log(b0)))
+            print(f"==> at the reference's PSNR-Y {ref[1]:.2f} dB: ours {b:.0f} B vs {ref[0]} B = {b / ref[0]:.3f} x   {a.tag}")
+        else:
+            print(f"==> reference PSNR {ref[1]:.2f} outside our range {pts[0][1]:.2f}..{pts[-1][1]:.2f}")
+    print(json.dumps({"size": a.size, "gop": a.gop, "frames": a.frames, "tools": tools, "ref": ref, "ours": pts, "tag": a.tag}))
+
+
+if __name__ == "__main__":
+    main()
