@@ -2,7 +2,7 @@
 """bench.py — throughput of the HEVC encode pixel-kernel hot path on MI355X.
 
 One "step" = one picture (3840x2160 4:2:0, BASELINE.json configs[2]) of every GOP shard of the rank through the whole hot path
-(fractional planes -> integer ME (UMH by default, as -preset slow) -> sub-pel SATD -> CU decision -> residual/DCT/quant/dequant/IDCT/recon ->
+(integer ME (UMH by default, as -preset slow) -> sub-pel SATD -> CU decision -> residual/DCT/quant/dequant/IDCT/recon ->
 deblock -> SAO -> border padding; key pictures: intra mode pre-selection + wavefront reconstruction), all inputs and outputs resident in
 HBM.  Each rank (one per GPU) encodes --streams (default 3) independent GOP shards, each on its own HIP stream: GOPs are
 independent units (frames/GOPs shard, no data-path collective) and the search kernels are latency bound, so the
@@ -28,7 +28,6 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB
 
 # ALGORITHMIC bytes per picture, in units of P = luma samples (DESIGN.md §5 states each derivation)
 ALGO_BYTES_P = {
-    "ref_planes": 16.0,      # read the reference luma once, write 15 fractional planes (+ copy of plane 0)
     "me_integer": 2.2,       # source P + padded reference ~1.1 P + PU records
     "me_subpel": 2.2,
     "cu_decide": 0.05,

@@ -286,9 +286,9 @@ int ks265_load_i420(ks265_frame *f, const uint8_t *dev_i420, ks265_pic dst);
 /* inverse: padded picture -> packed I420 */
 int ks265_store_i420(ks265_frame *f, ks265_pic src, uint8_t *dev_i420);
 
-/* Stage A0: the 15 fractional-sample luma planes of a reference picture (normative 8-tap filters,
- * interpLuma* enc@0x40e4f0..0x4109b0); dev_planes = 16 x bytes_y (plane 0 is a copy of ref.y) */
-int ks265_ref_planes(ks265_frame *f, ks265_pic ref, uint8_t *dev_planes);
+/* (Rounds 1 - 2 had a stage "ks265_ref_planes" here: sixteen precomputed fractional-sample planes per reference picture.  Every stage below now interpolates the
+ * samples it needs from the padded reference picture itself - the normative 8-tap filters of interpLuma* enc@0x40e4f0..0x4109b0, per candidate as
+ * subMeHpel_RealInterp enc@0x4b4e90 does - so the stages take the reference PICTURE.) */
 /* Stage A0 (cfg.pre_search; run by ks265_me_integer itself, exported for stage tests): exhaustive motion search on a pyramid built with
  * downsample_c enc@0x4a6a60 - L2 blocks of 8x8 over +-(range/4 - 1), L1 blocks +-2, 16x16 picture blocks +-1; cost SAD + |mx| + |my|.
  * Above them a 1/8-resolution level: every CTU (one 8x8 block) over +-range/4 = +-2 range samples; its vector x 8 is the CTU's WINDOW OFFSET - stage A searches
@@ -302,30 +302,30 @@ int ks265_presearch(ks265_frame *f, ks265_pic src, ks265_pic ref, int16_t *dev_f
 int ks265_me_integer(ks265_frame *f, ks265_pic src, ks265_pic ref, const ks265_pu *dev_prev_pu, ks265_pu *dev_pu);
 /* Stage B: 8 half-pel + 8 quarter-pel refinement with SATD (subMeSquare enc@0x4b5660 ->
  * subMeHpel_RealInterp / subMeQpel_8Sad_*_RealInterp + had_c) */
-int ks265_me_subpel(ks265_frame *f, ks265_pic src, const uint8_t *dev_planes, ks265_pu *dev_pu);
+int ks265_me_subpel(ks265_frame *f, ks265_pic src, ks265_pic ref, ks265_pu *dev_pu);
 /* Stage C2 (cfg.merge; run by ks265_encode_picture[_b] itself, exported for stage tests): merge pass on the motion field of the CU decision.
  * Per CU the five spatial merge neighbours of H.265 8.5.3.2.3 (inside the picture, earlier in z-scan order, inter) and the zero vector are tried as the
- * CU's own motion: SATD of the prediction (fractional planes; bi = rounded average) + lambda x (position + 1) against the search cost + 2 lambda.
- * dev_pu for P pictures, dev_pub for B pictures (the other NULL); cu_in and cu_out must differ (all CUs decide on the same input field). */
-int ks265_merge_pass(ks265_frame *f, ks265_pic src, const uint8_t *dev_planes0, const uint8_t *dev_planes1, const ks265_pu *dev_pu, const ks265_pu_b *dev_pub,
+ * CU's own motion: SATD of the prediction (bi = rounded average) + lambda x (position + 1) against the search cost + 2 lambda.
+ * dev_pu for P pictures (ref1 = null picture), dev_pub for B pictures (the other NULL); cu_in and cu_out must differ (all CUs decide on the same input field). */
+int ks265_merge_pass(ks265_frame *f, ks265_pic src, ks265_pic ref0, ks265_pic ref1, const ks265_pu *dev_pu, const ks265_pu_b *dev_pub,
                      const ks265_cu8 *dev_cu_in, ks265_cu8 *dev_cu_out);
 /* Stage C: CU quadtree decision from the PU costs (the bottom-up compare of processTree enc@0x4722a0) */
 int ks265_cu_decide(ks265_frame *f, const ks265_pu *dev_pu, ks265_cu8 *dev_cu8);
 /* Stage C': key picture — every CU 32x32-TU "flat" intra (pred = 128); stands in for the out-of-scope
  * intra path so that a GOP has a reconstructed first picture */
 int ks265_cu_flat_intra(ks265_frame *f, ks265_cu8 *dev_cu8);
-/* Stage D: prediction (luma from the planes, chroma 4-tap on the fly) -> residual -> DCT -> quant ->
+/* Stage D: prediction (luma 8-tap, chroma 4-tap, both from the reference picture) -> residual -> DCT -> quant ->
  * dequant -> IDCT -> recon, the reconstruct() chain enc@0x481da0; levels are s16 planes of W x H (Y) and
  * W/2 x H/2 (Cb, Cr) coefficients stored TU-in-place; recon is a padded picture */
-int ks265_reconstruct(ks265_frame *f, ks265_pic src, ks265_pic ref, const uint8_t *dev_planes, ks265_cu8 *dev_cu8,
+int ks265_reconstruct(ks265_frame *f, ks265_pic src, ks265_pic ref, ks265_cu8 *dev_cu8,
                       int16_t *dev_lvl_y, int16_t *dev_lvl_u, int16_t *dev_lvl_v, ks265_pic recon);
-/* the same for a B picture: list-1 reference and planes; bi-predicted blocks use the exact 14-bit average
+/* the same for a B picture with its list-1 reference; bi-predicted blocks use the exact 14-bit average
  * (DefaultWeightedBi_c enc@0x435160 over interp*8to16 / 16to16) */
-int ks265_reconstruct_b(ks265_frame *f, ks265_pic src, ks265_pic ref0, const uint8_t *dev_planes0, ks265_pic ref1, const uint8_t *dev_planes1,
+int ks265_reconstruct_b(ks265_frame *f, ks265_pic src, ks265_pic ref0, ks265_pic ref1,
                         ks265_cu8 *dev_cu8, int16_t *dev_lvl_y, int16_t *dev_lvl_u, int16_t *dev_lvl_v, ks265_pic recon);
 /* Stage B': B pictures - per PU the cheapest of L0, L1 (the two uni-directional searches) and the bi-predictive pair of
  * their winners (SATD against the rounded average; interMeBi* enc@0x486c10.. lineage, no joint refinement yet) */
-int ks265_bi_decide(ks265_frame *f, ks265_pic src, const uint8_t *dev_planes0, const uint8_t *dev_planes1, const ks265_pu *dev_pu0,
+int ks265_bi_decide(ks265_frame *f, ks265_pic src, ks265_pic ref0, ks265_pic ref1, const ks265_pu *dev_pu0,
                     const ks265_pu *dev_pu1, ks265_pu_b *dev_pub);
 int ks265_cu_decide_b(ks265_frame *f, const ks265_pu_b *dev_pub, ks265_cu8 *dev_cu8);
 /* Intra pictures.  ks265_intra_decide: every 8x8 / 16x16 / 32x32 block tries all 35 luma modes of
@@ -359,9 +359,9 @@ int ks265_sao(ks265_frame *f, ks265_pic src, ks265_pic deblocked, ks265_sao_para
 /* Multi-reference P pictures (-ref / -ref0; motionSearchOneRef enc@0x483f40 runs once per reference picture): search every picture
  * with stages A0 / A / B, then ks265_ref_decide picks per PU the picture with the smallest cost + lambda * ref_idx bits (truncated
  * unary, ties to the nearest picture; pub.inter_dir = 1 | idx << 4, carried into cu8.inter_dir), ks265_cu_decide_b builds the CU tree,
- * ks265_reconstruct_mref predicts every CU from its own picture.  pu / refs / planes: HOST arrays of device pointers, nearest first. */
+ * ks265_reconstruct_mref predicts every CU from its own picture.  pu / refs: HOST arrays, nearest first. */
 int ks265_ref_decide(ks265_frame *f, int nref, const ks265_pu *const *dev_pu, ks265_pu_b *dev_pub);
-int ks265_reconstruct_mref(ks265_frame *f, ks265_pic src, int nref, const ks265_pic *refs, const uint8_t *const *dev_planes, ks265_cu8 *dev_cu8,
+int ks265_reconstruct_mref(ks265_frame *f, ks265_pic src, int nref, const ks265_pic *refs, ks265_cu8 *dev_cu8,
                            int16_t *dev_lvl_y, int16_t *dev_lvl_u, int16_t *dev_lvl_v, ks265_pic recon);
 /* a P picture with nref <= cfg.refs list-0 pictures (refs[0] = the nearest); nref == 1 is ks265_encode_picture(is_key = 0) */
 int ks265_encode_picture_mref(ks265_frame *f, ks265_pic src, const ks265_pic *refs, int nref, ks265_pic recon_out);
@@ -372,7 +372,7 @@ int ks265_encode_picture(ks265_frame *f, ks265_pic src, ks265_pic ref, int is_ke
 /* a B picture: ref0 = list 0 (past), ref1 = list 1 (future); needs cfg.bframes > 0 at ks265_frame_create */
 int ks265_encode_picture_b(ks265_frame *f, ks265_pic src, ks265_pic ref0, ks265_pic ref1, ks265_pic recon_out);
 /* in-situ stage timing: HIP events recorded on the context's stream between the stages of ks265_encode_picture;
- * ms[] = {ref_planes, me_integer, me_subpel, cu_decide, reconstruct, deblock, sao(+padding)} of the last picture, -1 = not run */
+ * ms[] = {(unused, -1 or 0), me_integer, me_subpel, cu_decide, reconstruct, deblock, sao(+padding)} of the last picture, -1 = not run */
 int ks265_frame_set_profiling(ks265_frame *f, int enable);
 int ks265_frame_stage_ms(ks265_frame *f, float ms[7]);
 /* accessors to the frame object's internal workspace (device pointers) */
@@ -406,7 +406,6 @@ int ks265_copy_out_compact_async(ks265_ctx *copy_ctx, ks265_frame *f, void *pinn
  * word instead of calling the runtime.  dev_counter: one zero-initialised word in HBM per copy stream (work-groups count themselves in; left at zero). */
 int ks265_copy_out_compact_flag_async(ks265_ctx *copy_ctx, ks265_frame *f, void *pinned_host, const void *dev_block, uint32_t *dev_counter, volatile uint32_t *pinned_flag,
                                       uint32_t value);
-uint8_t *ks265_frame_planes(ks265_frame *f);
 /* luma SSE between two padded pictures (PSNR-Y of the bench line; CPSNR_I420::calcPSNR enc@0x4c4060) */
 int ks265_sse_picture(ks265_frame *f, ks265_pic a, ks265_pic b, uint64_t *dev_sse3);
 

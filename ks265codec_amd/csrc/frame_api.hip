@@ -25,7 +25,7 @@ int ks265_frame_create(ks265_ctx *ctx, const ks265_frame_cfg *cfg, ks265_frame *
     if (r) return r;
     if (cfg->me_method < 0 || cfg->me_method > 2) return KS265_NOTSUPPORTED;   /* 0 = DIA, 1 = HEX, 2 = UMH (-me); EPZS / Cross not built */
     if (cfg->refs > 4) return KS265_NOTSUPPORTED;
-    if ((long long)16 * geom.bytes_y >= (1ll << 32)) return KS265_NOTSUPPORTED;   /* stage B addresses the 16 planes with 32-bit offsets (8K = 0.6 GB fits) */
+    if ((long long)geom.bytes_y >= (1ll << 31)) return KS265_NOTSUPPORTED;         /* stage B addresses a luma plane with 32-bit offsets */
     ks265_frame *f = new ks265_frame();                                            /* every validation above: nothing to undo on those returns */
     f->ctx = ctx; f->cfg = *cfg; f->geom = geom;
     KsGeom &g = f->g;
@@ -34,16 +34,14 @@ int ks265_frame_create(ks265_ctx *ctx, const ks265_frame_cfg *cfg, ks265_frame *
     g.org_y = (long)KS_PAD_Y * g.sy + KS_PAD_Y; g.org_c = (long)KS_PAD_C * g.sc + KS_PAD_C;
     (void)hipSetDevice(ctx->device);
     const size_t npx = (size_t)g.W * g.H;
-    r = dev_alloc(ctx, (void **)&f->planes, (size_t)16 * g.bytes_y, true);
+    r = KS265_OK;
     for (int i = 0; i < 2 && !r; ++i) r = dev_alloc(ctx, (void **)&f->pu[i], (size_t)geom.bytes_pu, true);
     if (!r && cfg->bframes > 0) {
-        r = dev_alloc(ctx, (void **)&f->planes1, (size_t)16 * g.bytes_y, true);
-        if (!r) r = dev_alloc(ctx, (void **)&f->pu1, (size_t)geom.bytes_pu, true);
+        r = dev_alloc(ctx, (void **)&f->pu1, (size_t)geom.bytes_pu, true);
         if (!r) r = dev_alloc(ctx, (void **)&f->pub, (size_t)geom.ctu_cols * geom.ctu_rows * 85 * sizeof(ks265_pu_b), true);
     }
     for (int x = 0; x + 1 < cfg->refs && !r; ++x) {              /* list-0 pictures 1..refs-1 of multi-reference P pictures */
-        r = dev_alloc(ctx, (void **)&f->planes_x[x], (size_t)16 * g.bytes_y, true);
-        if (!r) r = dev_alloc(ctx, (void **)&f->pu_x[x], (size_t)geom.bytes_pu, true);
+        r = dev_alloc(ctx, (void **)&f->pu_x[x], (size_t)geom.bytes_pu, true);
     }
     if (cfg->refs > 1 && !f->pub && !r) r = dev_alloc(ctx, (void **)&f->pub, (size_t)geom.ctu_cols * geom.ctu_rows * 85 * sizeof(ks265_pu_b), true);
     if (!r) r = dev_alloc(ctx, (void **)&f->cu8, (size_t)geom.bytes_cu8, true);
@@ -71,7 +69,7 @@ void ks265_frame_destroy(ks265_frame *f)
     if (f->ctx) { (void)hipSetDevice(f->ctx->device); (void)hipStreamSynchronize(f->ctx->stream); }
     for (int i = 0; i <= KS_NSTAGE; ++i)
         if (f->ev[i]) (void)hipEventDestroy(f->ev[i]);
-    void *ptrs[] = {f->planes1, f->pu1, f->pub, f->planes, f->pu[0], f->pu[1], f->cu8, f->sao, f->lvl[0], f->lvl[1], f->lvl[2], f->deb[0], f->deb[1], f->deb[2], f->sse, f->sse_acc, f->cu8_tmp, f->progress, f->mats, f->planes_x[0], f->planes_x[1], f->planes_x[2], f->pu_x[0], f->pu_x[1], f->pu_x[2]};
+    void *ptrs[] = {f->pu1, f->pub, f->pu[0], f->pu[1], f->cu8, f->sao, f->lvl[0], f->lvl[1], f->lvl[2], f->deb[0], f->deb[1], f->deb[2], f->sse, f->sse_acc, f->cu8_tmp, f->progress, f->mats, f->pu_x[0], f->pu_x[1], f->pu_x[2]};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (uint8_t *p : f->pyr)
@@ -112,18 +110,17 @@ int ks265_encode_picture(ks265_frame *f, ks265_pic src, ks265_pic ref, int is_ke
         f->have_prev = false;
     } else {
         if (!ref.y) return KS265_POINTER;
-        if ((r = ks265_ref_planes(f, ref, f->planes))) return r;
         mark(1);
         if ((r = ks265_me_integer(f, src, ref, f->have_prev ? f->pu[f->cur_pu ^ 1] : nullptr, pu))) return r;
         mark(2);
-        if (f->cfg.subme && (r = ks265_me_subpel(f, src, f->planes, pu))) return r;
+        if (f->cfg.subme && (r = ks265_me_subpel(f, src, ref, pu))) return r;
         mark(3);
         if (f->cfg.merge) {                                    /* stage C2: the CU decision goes to the spare map, the merge pass writes the final one */
             if ((r = ks265_cu_decide(f, pu, f->cu8_tmp))) return r;
-            if ((r = ks265_merge_pass(f, src, f->planes, nullptr, pu, nullptr, f->cu8_tmp, f->cu8))) return r;
+            if ((r = ks265_merge_pass(f, src, ref, ks265_pic{nullptr, nullptr, nullptr}, pu, nullptr, f->cu8_tmp, f->cu8))) return r;
         } else if ((r = ks265_cu_decide(f, pu, f->cu8))) return r;
         mark(4);
-        if ((r = ks265_reconstruct(f, src, ref, f->planes, f->cu8, f->lvl[0], f->lvl[1], f->lvl[2], deb))) return r;
+        if ((r = ks265_reconstruct(f, src, ref, f->cu8, f->lvl[0], f->lvl[1], f->lvl[2], deb))) return r;
     }
     mark(5);
     if (f->cfg.deblock && (r = ks265_deblock(f, f->cu8, deb))) return r;
@@ -144,20 +141,17 @@ int ks265_encode_picture_mref(ks265_frame *f, ks265_pic src, const ks265_pic *re
     int r;
     ks265_pu *pu0 = f->pu[f->cur_pu];
     const ks265_pu *pus[4] = {pu0, f->pu_x[0], f->pu_x[1], f->pu_x[2]};
-    const uint8_t *planes[4] = {f->planes, f->planes_x[0], f->planes_x[1], f->planes_x[2]};
     for (int i = 0; i < nref; ++i) {
         if (!refs[i].y) return KS265_POINTER;
-        uint8_t *pl = i == 0 ? f->planes : f->planes_x[i - 1];
         ks265_pu *pu = i == 0 ? pu0 : f->pu_x[i - 1];
-        if ((r = ks265_ref_planes(f, refs[i], pl))) return r;
         /* the temporal predictor (previous picture's vectors) belongs to the nearest picture only */
         if ((r = ks265_me_integer(f, src, refs[i], i == 0 && f->have_prev ? f->pu[f->cur_pu ^ 1] : nullptr, pu))) return r;
-        if (f->cfg.subme && (r = ks265_me_subpel(f, src, pl, pu))) return r;
+        if (f->cfg.subme && (r = ks265_me_subpel(f, src, refs[i], pu))) return r;
     }
     if ((r = ks265_ref_decide(f, nref, pus, f->pub))) return r;
     if ((r = ks265_cu_decide_b(f, f->pub, f->cu8))) return r;
     ks265_pic deb = ks_deb_pic(f);
-    if ((r = ks265_reconstruct_mref(f, src, nref, refs, planes, f->cu8, f->lvl[0], f->lvl[1], f->lvl[2], deb))) return r;
+    if ((r = ks265_reconstruct_mref(f, src, nref, refs, f->cu8, f->lvl[0], f->lvl[1], f->lvl[2], deb))) return r;
     if (f->cfg.deblock && (r = ks265_deblock(f, f->cu8, deb))) return r;
     if ((r = ks265_sao(f, src, deb, f->sao, recon_out))) return r;
     f->cur_pu ^= 1; f->have_prev = true;                          /* the nearest picture's vectors seed the next picture */
@@ -170,22 +164,20 @@ int ks265_encode_picture_b(ks265_frame *f, ks265_pic src, ks265_pic ref0, ks265_
 {
     KS_FRAME_CHECK(f);
     if (!src.y || !ref0.y || !ref1.y || !recon_out.y) return KS265_POINTER;
-    if (!f->planes1) return KS265_NOTSUPPORTED;               /* created with cfg.bframes == 0 */
+    if (!f->pu1) return KS265_NOTSUPPORTED;                   /* created with cfg.bframes == 0 */
     int r;
     ks265_pu *pu0 = f->pu[f->cur_pu];                         /* scratch: the next P picture overwrites it */
-    if ((r = ks265_ref_planes(f, ref0, f->planes))) return r;
-    if ((r = ks265_ref_planes(f, ref1, f->planes1))) return r;
     if ((r = ks265_me_integer(f, src, ref0, nullptr, pu0))) return r;
-    if (f->cfg.subme && (r = ks265_me_subpel(f, src, f->planes, pu0))) return r;
+    if (f->cfg.subme && (r = ks265_me_subpel(f, src, ref0, pu0))) return r;
     if ((r = ks265_me_integer(f, src, ref1, nullptr, f->pu1))) return r;
-    if (f->cfg.subme && (r = ks265_me_subpel(f, src, f->planes1, f->pu1))) return r;
-    if ((r = ks265_bi_decide(f, src, f->planes, f->planes1, pu0, f->pu1, f->pub))) return r;
+    if (f->cfg.subme && (r = ks265_me_subpel(f, src, ref1, f->pu1))) return r;
+    if ((r = ks265_bi_decide(f, src, ref0, ref1, pu0, f->pu1, f->pub))) return r;
     if (f->cfg.merge) {
         if ((r = ks265_cu_decide_b(f, f->pub, f->cu8_tmp))) return r;
-        if ((r = ks265_merge_pass(f, src, f->planes, f->planes1, nullptr, f->pub, f->cu8_tmp, f->cu8))) return r;
+        if ((r = ks265_merge_pass(f, src, ref0, ref1, nullptr, f->pub, f->cu8_tmp, f->cu8))) return r;
     } else if ((r = ks265_cu_decide_b(f, f->pub, f->cu8))) return r;
     ks265_pic deb = ks_deb_pic(f);
-    if ((r = ks265_reconstruct_b(f, src, ref0, f->planes, ref1, f->planes1, f->cu8, f->lvl[0], f->lvl[1], f->lvl[2], deb))) return r;
+    if ((r = ks265_reconstruct_b(f, src, ref0, ref1, f->cu8, f->lvl[0], f->lvl[1], f->lvl[2], deb))) return r;
     if (f->cfg.deblock && (r = ks265_deblock(f, f->cu8, deb))) return r;
     return ks265_sao(f, src, deb, f->sao, recon_out);
 }
@@ -434,6 +426,5 @@ int ks265_copy_out_compact_flag_async(ks265_ctx *ctx, ks265_frame *f, void *pinn
                        (const unsigned *)((const uint8_t *)dev_block + off[3]), (unsigned *)dev_counter, (volatile unsigned *)pinned_flag, (unsigned)value);
     return ks265_check_launch(ctx);
 }
-uint8_t *ks265_frame_planes(ks265_frame *f) { return f ? f->planes : nullptr; }
 
 }  // extern "C"

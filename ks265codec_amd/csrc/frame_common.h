@@ -4,9 +4,8 @@
 
 #define KS_PAD_Y 80
 #define KS_PAD_C 40
-#define KS_PLANE_MARGIN 72           // fractional planes are defined on [-72, W+72) x [-72, H+72)
 #define KS_COST_INVALID 0xFFFFFFFFu
-#define KS_NSTAGE 7                   // ref_planes, me_integer, me_subpel, cu_decide, reconstruct, deblock, sao (+ padding)
+#define KS_NSTAGE 7                   // (unused: the fractional planes of rounds 1 - 2), me_integer, me_subpel, cu_decide, reconstruct, deblock, sao (+ padding)
 
 // geometry handed to kernels by value
 struct KsGeom {
@@ -24,9 +23,7 @@ struct ks265_frame {
     ks265_frame_geom geom{};
     KsGeom g{};
     // workspace (device)
-    uint8_t *planes = nullptr;          // 16 x bytes_y
-    uint8_t *planes1 = nullptr;         // list 1 (B pictures), cfg.bframes > 0
-    uint8_t *planes_x[3] = {nullptr, nullptr, nullptr};   // list-0 pictures 1..3 of multi-reference P pictures, cfg.refs > 1
+    // (no fractional planes: every consumer interpolates from the reference picture itself, interp_dev.h)
     ks265_pu *pu_x[3] = {nullptr, nullptr, nullptr};
     ks265_pu *pu1 = nullptr;
     ks265_pu_b *pub = nullptr;

@@ -8,6 +8,7 @@
 //            Hadamard transforms as i8 MFMA GEMMs (H8 (x) H8), PU sums by DPP.
 //   Stage C  ks265_cu_decide  : bottom-up quadtree compare.
 #include "frame_common.h"
+#include "interp_dev.h"
 #include <type_traits>
 
 using namespace ks265;
@@ -15,6 +16,7 @@ using namespace ks265;
 #define KS_COST_INF_ME 0x07FFFFFFu
 // ------------------------------------------------------------------ Stage B: sub-pel SATD refinement
 typedef int ks_v4i __attribute__((ext_vector_type(4)));
+typedef short ks_s16x2 __attribute__((ext_vector_type(2)));
 
 // sum over the aligned group of 1 / 4 / 16 / 64 lanes that forms one PU at `level` (wave-uniform)
 __device__ __forceinline__ unsigned pu_group_sum(unsigned v, int level)
@@ -50,9 +52,8 @@ __device__ __forceinline__ unsigned pu_group_sum(unsigned v, int level)
 #define KS_SUBPEL_OCC 2
 #endif
 template <int NC>
-__global__ __launch_bounds__(NC * 64, KS_SUBPEL_OCC) void me_subpel_kernel(KsGeom g, int lam, const uint8_t *src, const uint8_t *planes, ks265_pu *pus)
+__global__ __launch_bounds__(NC * 64, KS_SUBPEL_OCC) void me_subpel_kernel(KsGeom g, int lam, const uint8_t *src, const uint8_t *ref, ks265_pu *pus)
 {
-    constexpr int NT = NC * 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nctu = g.ctu_cols * g.ctu_rows;
     const int grp = ks_xcd_swizzle(blockIdx.x, (nctu + NC - 1) / NC);
@@ -66,6 +67,7 @@ __global__ __launch_bounds__(NC * 64, KS_SUBPEL_OCC) void me_subpel_kernel(KsGeo
     __shared__ unsigned short s_item[NC * 256];
     __shared__ int s_cnt[NC * 4];
     __shared__ unsigned short s_sat[9][NC * 256];                 // an 8x8 SATD is at most 8 * 8 * 8 * 255 / 4 = 32640
+    __shared__ __attribute__((aligned(16))) unsigned short s_hx[NC][16][8 * 16];   // per wave and item column: horizontally filtered rows, [pixel][row 0..15]
     if (lane == 0) s_org[wave] = have ? ((ctu % g.ctu_cols) * 64) | (((ctu / g.ctu_cols) * 64) << 16) : 0;
     // Z-order: lane bits (y2 x2 y1 x1 y0 x0)
     const int tx = (lane & 1) | ((lane >> 1) & 2) | ((lane >> 2) & 4), ty = ((lane >> 1) & 1) | ((lane >> 2) & 2) | ((lane >> 3) & 4);
@@ -166,54 +168,102 @@ __global__ __launch_bounds__(NC * 64, KS_SUBPEL_OCC) void me_subpel_kernel(KsGeo
         // of the Hadamard rows, nor on how the K slots of the A and B operands are numbered (both operands use the same
         // numbering), so the sum equals had_c's (enc@0x47b680) butterfly network bit for bit.
         // Operand layout: lane = (column n16 = lane & 15, K group gk = lane >> 4); its 16 K slots hold rows 2gk, 2gk+1 of the tile.
+        // The candidates' samples are interpolated from the reference picture (no fractional planes): ONE instruction stream for every fraction - horizontal taps of the
+        // lane's own fx (the integer position is the tap set {0 0 0 64 0 0 0 0}) into 16-bit intermediates, vertical taps of its own fy, (sum + 2048) >> 12 - which
+        // equals the one-dimensional filters' (sum + 32) >> 6 and the plain sample exactly (a factor 64 moves through the shift), so lanes whose centres have
+        // different fractions do not diverge.  The three x positions of a ring are filtered ONCE per item: the item's four lanes (K groups) filter four rows each of
+        // its 16-row neighbourhood, exchange them through LDS (row pairs packed for v_dot2_i32_i16; a wave's own LDS traffic completes in order, no barrier), and
+        // every lane then reads the ten rows its two output rows of the three y positions need.
+        // Items are dealt to the waves in blocks of 16 (one MFMA operand block: lane = (item column n16, K group gk)), block b to wave b mod NC: the pooled
+        // items of the group's CTUs spread evenly over the waves.
 #pragma unroll 1
-        for (int base = wave * 64; base < nitems; base += NT) {
-            unsigned ibo[4];                                        // byte offset of this lane's two rows inside a plane
-            int icx[4], icy[4];
-            ks_v4i S[4];
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb) {
-                const int ii = base + nb * 16 + n16;
-                const int it = s_item[ii < nitems ? ii : base];     // the last chunk is padded with copies of its first item
+        for (int blk = wave; blk * 16 < nitems; blk += NC) {
+            {
+                const int ii = blk * 16 + n16;
+                const int it = s_item[ii < nitems ? ii : blk * 16];  // the last block is padded with copies of its first item
                 const int il = it & 63, iw = it >> 8, ikey = s_key[iw][(it >> 6) & 3][il], org = s_org[iw];
                 const int itx = (il & 1) | ((il >> 1) & 2) | ((il >> 2) & 4), ity = ((il >> 1) & 1) | ((il >> 2) & 2) | ((il >> 3) & 4);
-                const unsigned ro = (unsigned)(((org >> 16) + ity * 8 + 2 * gk) * g.sy + (org & 0xFFFF) + itx * 8);
-                icx[nb] = (int)(short)(ikey & 0xFFFF); icy[nb] = ikey >> 16;
-                ibo[nb] = ro + (unsigned)g.org_y;
+                const unsigned ro = (unsigned)(((org >> 16) + ity * 8 + 2 * gk) * g.sy + (org & 0xFFFF) + itx * 8);   // this lane's two rows of the tile
+                const int cx = (int)(short)(ikey & 0xFFFF), cy = ikey >> 16;
                 const uint2 a0 = *(const uint2 *)(Sp + ro), a1 = *(const uint2 *)(Sp + ro + (unsigned)g.sy);
-                S[nb] = ks_v4i{(int)(a0.x ^ 0x7F7F7F7Fu), (int)(a0.y ^ 0x7F7F7F7Fu), (int)(a1.x ^ 0x7F7F7F7Fu), (int)(a1.y ^ 0x7F7F7F7Fu)};
-            }
-#pragma unroll 1
-            for (int n = phase; n < 9; ++n) {
-                const int dxs = ((int)((kDx[phase] >> (2 * n)) & 3u) - 1) * step, dys = ((int)((kDy[phase] >> (2 * n)) & 3u) - 1) * step;
-                unsigned acc[4];
+                const ks_v4i S = ks_v4i{(int)(a0.x ^ 0x7F7F7F7Fu), (int)(a0.y ^ 0x7F7F7F7Fu), (int)(a1.x ^ 0x7F7F7F7Fu), (int)(a1.y ^ 0x7F7F7F7Fu)};
+                const int aymin = cy - step, rbase = (aymin >> 2) - 3;      // first input row of the neighbourhood, relative to the tile row of K group 0
+                unsigned short *hx = &s_hx[wave][n16][0];                    // [pixel 0..7][row 0..15] of this item
+                // vertical taps of the three y positions as row-pair weights: output row r starts at this lane's row s = roff + r (0, 1 or 2)
+                unsigned W0[3][5], W1[3][5];
 #pragma unroll
-                for (int nb = 0; nb < 4; ++nb) {
-                    const int ax = icx[nb] + dxs, ay = icy[nb] + dys;
-                    // 16 planes of bytes_y each: every offset fits 32 bits (checked at frame creation)
-                    const unsigned off = (unsigned)((ay & 3) * 4 + (ax & 3)) * (unsigned)g.bytes_y + (unsigned)((int)ibo[nb] + (ay >> 2) * g.sy + (ax >> 2));
-                    const uint8_t *pp = planes + off;
-                    uint2 r0, r1;
-                    __builtin_memcpy(&r0, pp, 8);                    // byte-aligned 8-byte loads (global_load_dwordx2)
-                    __builtin_memcpy(&r1, pp + g.sy, 8);
-                    const ks_v4i B = {(int)(r0.x ^ 0x80808080u), (int)(r0.y ^ 0x80808080u), (int)(r1.x ^ 0x80808080u), (int)(r1.y ^ 0x80808080u)};
-                    unsigned a = 0;
+                for (int gy = 0; gy < 3; ++gy) {
+                    const int ay = cy + (gy - 1) * step, roff = (ay >> 2) - (aymin >> 2);     // 0 or 1
+                    int c[8];
+                    luma_taps(ay & 3, c);
+                    unsigned E0[6], E1[5];                             // E0[k + 1]: taps (2k, 2k + 1) = an even start; E1: an odd start
+                    E0[0] = 0;
 #pragma unroll
-                    for (int mb = 0; mb < 4; ++mb) {
-                        ks_v4i C = __builtin_amdgcn_mfma_i32_16x16x64_i8(Hm[mb], B, mb == 0 ? Cin0 : CinN, 0, 0, 0);
-                        C = __builtin_amdgcn_mfma_i32_16x16x64_i8(Hm[mb], S[nb], C, 0, 0, 0);
+                    for (int k = 0; k < 4; ++k) E0[k + 1] = ((unsigned)c[2 * k] & 0xFFFFu) | ((unsigned)c[2 * k + 1] << 16);
+                    E0[5] = 0;
+                    E1[0] = (unsigned)c[0] << 16;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) a = __builtin_amdgcn_sad_u16((unsigned)C[r], 0x8000u, a);
-                    }
-                    acc[nb] = a;
+                    for (int k = 1; k < 4; ++k) E1[k] = ((unsigned)c[2 * k - 1] & 0xFFFFu) | ((unsigned)c[2 * k] << 16);
+                    E1[4] = (unsigned)c[7] & 0xFFFFu;
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) { W0[gy][k] = roff ? E1[k] : E0[k + 1]; W1[gy][k] = roff ? E0[k] : E1[k]; }     // s = 0: E0[k + 1]; s = 1: E1[k]; s = 2: E0[k]
                 }
-                // acc[nb] = this lane's share (16 of the 64 coefficients) of item nb*16 + n16: butterfly over the four K groups
-                // so that lane L ends up with the total of item base + L
-                const bool o1 = gk & 1, o2 = gk & 2;
-                const unsigned t0 = (o1 ? acc[1] : acc[0]) + (unsigned)__builtin_amdgcn_ds_swizzle((int)(o1 ? acc[0] : acc[1]), 0x1F | (16 << 10));
-                const unsigned t1 = (o1 ? acc[3] : acc[2]) + (unsigned)__builtin_amdgcn_ds_swizzle((int)(o1 ? acc[2] : acc[3]), 0x1F | (16 << 10));
-                const unsigned tot = (o2 ? t1 : t0) + (unsigned)__shfl_xor((int)(o2 ? t0 : t1), 32, 64);
-                if (base + lane < nitems) s_sat[n][base + lane] = (unsigned short)((tot + 2) >> 2);
+#pragma unroll
+                for (int gx = 0; gx < 3; ++gx) {
+                    const int ax = cx + (gx - 1) * step;
+                    int tl, th;
+                    luma_taps_packed(ax & 3, tl, th);
+                    // rows 4 gk .. 4 gk + 3 of the neighbourhood: picture row = tile row (2 gk) + rbase + 2 gk + j
+                    const uint8_t *hp = ref + (unsigned)((int)ro + (int)g.org_y + (rbase + 2 * gk) * g.sy + (ax >> 2));
+#pragma unroll
+                    for (int jp = 0; jp < 2; ++jp) {
+                        int h0[8], h1[8];
+                        luma_hrow8(hp + (2 * jp) * g.sy, tl, th, h0);
+                        luma_hrow8(hp + (2 * jp + 1) * g.sy, tl, th, h1);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) *(unsigned *)&hx[i * 16 + 4 * gk + 2 * jp] = ((unsigned)h0[i] & 0xFFFFu) | ((unsigned)h1[i] << 16);
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    unsigned P[8][5];                                    // per pixel: row pairs (0,1) (2,3) .. (8,9) of this lane's ten rows 2 gk .. 2 gk + 9
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+#pragma unroll
+                        for (int k = 0; k < 5; ++k) P[i][k] = ((const unsigned *)hx)[i * 8 + gk + k];      // dword reads (the start is only 4-byte aligned for odd K groups)
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the next x position overwrites the exchange area
+#pragma unroll
+                    for (int gy = 0; gy < 3; ++gy) {
+                        if (phase == 1 && gx == 1 && gy == 1) continue;  // the centre of the quarter ring is the half-pel winner itself
+                        unsigned rw[4];
+#pragma unroll
+                        for (int r = 0; r < 2; ++r) {
+                            int px[8];
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) {
+                                int v = 2048;
+#pragma unroll
+                                for (int k = 0; k < 5; ++k) v = __builtin_amdgcn_sdot2(__builtin_bit_cast(ks_s16x2, r ? W1[gy][k] : W0[gy][k]), __builtin_bit_cast(ks_s16x2, P[i][k]), v, false);
+                                px[i] = clip8(ks_no_pk(v >> 12));
+                            }
+                            const uint2 pr = ks_pack_row8(px);
+                            rw[2 * r] = pr.x; rw[2 * r + 1] = pr.y;
+                        }
+                        const ks_v4i B = {(int)(rw[0] ^ 0x80808080u), (int)(rw[1] ^ 0x80808080u), (int)(rw[2] ^ 0x80808080u), (int)(rw[3] ^ 0x80808080u)};
+                        unsigned a = 0;
+#pragma unroll
+                        for (int mb = 0; mb < 4; ++mb) {
+                            ks_v4i C = __builtin_amdgcn_mfma_i32_16x16x64_i8(Hm[mb], B, mb == 0 ? Cin0 : CinN, 0, 0, 0);
+                            C = __builtin_amdgcn_mfma_i32_16x16x64_i8(Hm[mb], S, C, 0, 0, 0);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) a = __builtin_amdgcn_sad_u16((unsigned)C[r], 0x8000u, a);
+                        }
+                        // a = this lane's share (16 of the 64 coefficients) of item n16 of the block: sum over the four K groups
+                        a += (unsigned)__builtin_amdgcn_ds_swizzle((int)a, 0x1F | (16 << 10));
+                        a += (unsigned)__shfl_xor((int)a, 32, 64);
+                        constexpr int kSlot0[9] = {5, 1, 6, 3, 0, 4, 7, 2, 8}, kSlot1[9] = {1, 2, 3, 4, 0, 5, 6, 7, 8};   // [gy * 3 + gx] -> n of the kDx / kDy tables (inverse of those tables)
+                        const int n = phase == 0 ? kSlot0[gy * 3 + gx] : kSlot1[gy * 3 + gx];
+                        if (gk == 0 && ii < nitems) s_sat[n][ii] = (unsigned short)((a + 2) >> 2);
+                    }
+                }
             }
         }
         __syncthreads();
@@ -254,11 +304,11 @@ __global__ __launch_bounds__(NC * 64, KS_SUBPEL_OCC) void me_subpel_kernel(KsGeo
     }
 }
 
-extern "C" int ks265_me_subpel(ks265_frame *f, ks265_pic src, const uint8_t *planes, ks265_pu *pu)
+extern "C" int ks265_me_subpel(ks265_frame *f, ks265_pic src, ks265_pic ref, ks265_pu *pu)
 {
     KS_FRAME_CHECK(f);
-    if (!src.y || !planes || !pu) return KS265_POINTER;
-    hipLaunchKernelGGL(me_subpel_kernel<KS_SUBPEL_NC>, dim3((f->g.ctu_cols * f->g.ctu_rows + KS_SUBPEL_NC - 1) / KS_SUBPEL_NC), dim3(KS_SUBPEL_NC * 64), 0, f->ctx->stream, f->g, f->cfg.lambda_q4, src.y, planes, pu);
+    if (!src.y || !ref.y || !pu) return KS265_POINTER;
+    hipLaunchKernelGGL(me_subpel_kernel<KS_SUBPEL_NC>, dim3((f->g.ctu_cols * f->g.ctu_rows + KS_SUBPEL_NC - 1) / KS_SUBPEL_NC), dim3(KS_SUBPEL_NC * 64), 0, f->ctx->stream, f->g, f->cfg.lambda_q4, src.y, ref.y, pu);
     return ks265_check_launch(f->ctx);
 }
 
@@ -382,24 +432,17 @@ __device__ __forceinline__ void load_tile8(const uint8_t *p, long stride, unsign
     }
 }
 
-__device__ __forceinline__ unsigned satd8x8_avg(const unsigned (&f)[16], const uint8_t *pa, const uint8_t *pb, long stride)
+// SATD of the source tile f against the rounded average of two prediction tiles (16 packed dwords each: luma_pred_tile8)
+__device__ __forceinline__ unsigned satd8x8_avg(const unsigned (&f)[16], const unsigned (&A)[16], const unsigned (&B)[16])
 {
-    const unsigned sha = (unsigned)((uintptr_t)pa & 3), shb = (unsigned)((uintptr_t)pb & 3);
-    const uint8_t *qa = pa - sha, *qb = pb - shb;
     int d[64];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        const unsigned *ra = (const unsigned *)(qa + r * stride), *rb = (const unsigned *)(qb + r * stride);
-        const unsigned a0 = ra[0], a1 = ra[1], a2 = ra[2], b0 = rb[0], b1 = rb[1], b2 = rb[2];
-        const unsigned A[2] = {align_bytes(a1, a0, sha), align_bytes(a2, a1, sha)}, B[2] = {align_bytes(b1, b0, shb), align_bytes(b2, b1, shb)};
+    for (int w = 0; w < 16; ++w)
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int avg = (int)(((A[h] >> (8 * i)) & 255) + ((B[h] >> (8 * i)) & 255) + 1) >> 1;
-                d[r * 8 + h * 4 + i] = (int)((f[2 * r + h] >> (8 * i)) & 255) - avg;
-            }
-    }
+        for (int i = 0; i < 4; ++i) {
+            const int avg = (int)(((A[w] >> (8 * i)) & 255) + ((B[w] >> (8 * i)) & 255) + 1) >> 1;
+            d[w * 4 + i] = (int)((f[w] >> (8 * i)) & 255) - avg;
+        }
     return satd8x8_regs(d);
 }
 
@@ -410,7 +453,7 @@ __device__ __forceinline__ unsigned satd8x8_avg(const unsigned (&f)[16], const u
 // (key = cost << 6 | position).  Sub-pel step: the two rings of stage B on T, SAD + rate like the integer step.  The refined pair replaces the decision when
 // its SATD against the rounded average + both vector rates is lower.
 template <bool REFINE>
-__global__ __launch_bounds__(256, REFINE ? 2 : 1) void bi_decide_kernel(KsGeom g, int lam, const uint8_t *src, const uint8_t *planes0, const uint8_t *planes1,
+__global__ __launch_bounds__(256, REFINE ? 2 : 1) void bi_decide_kernel(KsGeom g, int lam, const uint8_t *src, const uint8_t *ref0, const uint8_t *ref1,
                                                         const ks265_pu *pu0, const ks265_pu *pu1, ks265_pu_b *pub)
 {
     const int tid = threadIdx.x, lane = tid & 63, level = tid >> 6;
@@ -431,9 +474,10 @@ __global__ __launch_bounds__(256, REFINE ? 2 : 1) void bi_decide_kernel(KsGeom g
         for (int r = 0; r < 8; ++r) { const uint2 v = *(const uint2 *)(frow + (long)r * g.sy); f[2 * r] = v.x; f[2 * r + 1] = v.y; }
         const long base = (long)(valid ? y0 : 0) * g.sy + (valid ? x0 : 0) + g.org_y;
         const int ax = valid ? a.mvx : 0, ay = valid ? a.mvy : 0, bx = valid ? b.mvx : 0, by = valid ? b.mvy : 0;
-        const uint8_t *pa = planes0 + (long)((ay & 3) * 4 + (ax & 3)) * g.bytes_y + base + (long)(ay >> 2) * g.sy + (ax >> 2);
-        const uint8_t *pb = planes1 + (long)((by & 3) * 4 + (bx & 3)) * g.bytes_y + base + (long)(by >> 2) * g.sy + (bx >> 2);
-        const unsigned sd = satd8x8_avg(f, pa, pb, g.sy);
+        unsigned PA[16], PB[16];                                       // the two lists' prediction tiles, interpolated from the reference pictures (interp_dev.h)
+        luma_pred_tile8(ref0 + base, g.sy, ax, ay, PA);
+        luma_pred_tile8(ref1 + base, g.sy, bx, by, PB);
+        const unsigned sd = satd8x8_avg(f, PA, PB);
         const unsigned dd = pu_group_sum(valid ? sd : 0, level);
         if (valid) {
             if (b.cost < o.cost) { o.cost = b.cost; o.inter_dir = 2; }
@@ -442,14 +486,14 @@ __global__ __launch_bounds__(256, REFINE ? 2 : 1) void bi_decide_kernel(KsGeom g
         }
         if (REFINE) {
             const bool keep1 = valid && b.cost < a.cost;                 // list whose vector stays (uniform over the PU's lanes)
-            const uint8_t *pk = keep1 ? pb : pa;
-            const uint8_t *planesO = keep1 ? planes0 : planes1;
+            const uint8_t *refO = keep1 ? ref0 : ref1;
             const int omx = keep1 ? ax : bx, omy = keep1 ? ay : by;
             const int opx = valid ? (keep1 ? a.mvpx : b.mvpx) : 0, opy = valid ? (keep1 ? a.mvpy : b.mvpy) : 0;
             unsigned T[16];
             {
                 unsigned k[16];
-                load_tile8(pk, g.sy, k);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) k[i] = keep1 ? PB[i] : PA[i];
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     unsigned w = 0;
@@ -474,7 +518,7 @@ __global__ __launch_bounds__(256, REFINE ? 2 : 1) void bi_decide_kernel(KsGeom g
             unsigned bkey = 0xFFFFFFFFu;
             {
                 unsigned w[15][4];
-                const uint8_t *r0 = planesO + base + (long)sy * g.sy + sx;
+                const uint8_t *r0 = refO + base + (long)sy * g.sy + sx;
                 const unsigned sh = (unsigned)((uintptr_t)r0 & 3);
                 const uint8_t *q0 = r0 - sh;
 #pragma unroll
@@ -509,17 +553,19 @@ __global__ __launch_bounds__(256, REFINE ? 2 : 1) void bi_decide_kernel(KsGeom g
                 for (int k = 0; k < 8; ++k) {
                     const int kk = k < 4 ? k : k + 1;                                  // ring order of stage B: (-1,-1) (0,-1) (1,-1) (-1,0) (1,0) (-1,1) (0,1) (1,1)
                     const int qx = c0x + (kk % 3 - 1) * step, qy = c0y + (kk / 3 - 1) * step;
-                    const uint8_t *pl = planesO + (long)((qy & 3) * 4 + (qx & 3)) * g.bytes_y + base + (long)(qy >> 2) * g.sy + (qx >> 2);
                     unsigned q8[16], sd3 = 0;
-                    load_tile8(pl, g.sy, q8);
+                    luma_pred_tile8(refO + base, g.sy, qx, qy, q8);
 #pragma unroll
                     for (int i = 0; i < 16; ++i) sd3 = sad_u8x4(T[i], q8[i], sd3);
                     const unsigned cc = pu_group_sum(valid ? sd3 : 0, level) + (unsigned)mv_cost(qx, qy, opx, opy, lam);
                     if (cc < bc) { bc = cc; rbx = qx; rby = qy; }
                 }
             }
-            const uint8_t *po = planesO + (long)((rby & 3) * 4 + (rbx & 3)) * g.bytes_y + base + (long)(rby >> 2) * g.sy + (rbx >> 2);
-            const unsigned d2 = pu_group_sum(valid ? satd8x8_avg(f, pk, po, g.sy) : 0, level);
+            unsigned PO[16], PK[16];
+            luma_pred_tile8(refO + base, g.sy, rbx, rby, PO);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) PK[i] = keep1 ? PB[i] : PA[i];
+            const unsigned d2 = pu_group_sum(valid ? satd8x8_avg(f, PK, PO) : 0, level);
             if (valid) {
                 const unsigned c2 = d2 + (unsigned)(keep1 ? mv_cost(b.mvx, b.mvy, b.mvpx, b.mvpy, lam) : mv_cost(a.mvx, a.mvy, a.mvpx, a.mvpy, lam))
                                     + (unsigned)mv_cost(rbx, rby, opx, opy, lam);
@@ -533,17 +579,17 @@ __global__ __launch_bounds__(256, REFINE ? 2 : 1) void bi_decide_kernel(KsGeom g
     if ((lane & (G - 1)) == 0) pub[(long)ctu * 85 + pidx] = o;
 }
 
-extern "C" int ks265_bi_decide(ks265_frame *f, ks265_pic src, const uint8_t *planes0, const uint8_t *planes1, const ks265_pu *pu0, const ks265_pu *pu1,
+extern "C" int ks265_bi_decide(ks265_frame *f, ks265_pic src, ks265_pic ref0, ks265_pic ref1, const ks265_pu *pu0, const ks265_pu *pu1,
                                ks265_pu_b *pub)
 {
     KS_FRAME_CHECK(f);
-    if (!src.y || !planes0 || !planes1 || !pu0 || !pu1 || !pub) return KS265_POINTER;
+    if (!src.y || !ref0.y || !ref1.y || !pu0 || !pu1 || !pub) return KS265_POINTER;
     if (f->cfg.bi_refine)
-        hipLaunchKernelGGL(bi_decide_kernel<true>, dim3(f->g.ctu_cols * f->g.ctu_rows), dim3(256), 0, f->ctx->stream, f->g, f->cfg.lambda_q4, src.y, planes0,
-                           planes1, pu0, pu1, pub);
+        hipLaunchKernelGGL(bi_decide_kernel<true>, dim3(f->g.ctu_cols * f->g.ctu_rows), dim3(256), 0, f->ctx->stream, f->g, f->cfg.lambda_q4, src.y, ref0.y,
+                           ref1.y, pu0, pu1, pub);
     else
-        hipLaunchKernelGGL(bi_decide_kernel<false>, dim3(f->g.ctu_cols * f->g.ctu_rows), dim3(256), 0, f->ctx->stream, f->g, f->cfg.lambda_q4, src.y, planes0,
-                           planes1, pu0, pu1, pub);
+        hipLaunchKernelGGL(bi_decide_kernel<false>, dim3(f->g.ctu_cols * f->g.ctu_rows), dim3(256), 0, f->ctx->stream, f->g, f->cfg.lambda_q4, src.y, ref0.y,
+                           ref1.y, pu0, pu1, pub);
     return ks265_check_launch(f->ctx);
 }
 
@@ -578,7 +624,7 @@ __device__ __forceinline__ MergeMotion merge_cand(const KsGeom &g, const ks265_c
     if ((m.dir & 2) && (x + (m.mv1x >> 2) < -70 || x + (m.mv1x >> 2) + n > g.W + 70 || y + (m.mv1y >> 2) < -70 || y + (m.mv1y >> 2) + n > g.H + 70)) m.ok = false;
     return m;
 }
-__global__ __launch_bounds__(256) void merge_pass_kernel(KsGeom g, int lam, const uint8_t *src, const uint8_t *planes0, const uint8_t *planes1, const ks265_pu *pu,
+__global__ __launch_bounds__(256) void merge_pass_kernel(KsGeom g, int lam, const uint8_t *src, const uint8_t *ref0, const uint8_t *ref1, const ks265_pu *pu,
                                                          const ks265_pu_b *pub, const ks265_cu8 *cu_in, ks265_cu8 *cu_out)
 {
     __shared__ unsigned long long jbest[64];
@@ -613,11 +659,15 @@ __global__ __launch_bounds__(256) void merge_pass_kernel(KsGeom g, int lam, cons
         const bool on = (mask >> k) & 1u;
         const MergeMotion m = merge_cand(g, cu_in, cux, cuy, n, k, is_b);
         const int ax = on ? m.mvx : 0, ay = on ? m.mvy : 0, bx = on ? m.mv1x : 0, by = on ? m.mv1y : 0, dir = on ? m.dir : 1;
-        const uint8_t *pa = planes0 + (long)((ay & 3) * 4 + (ax & 3)) * g.bytes_y + base + (long)(ay >> 2) * g.sy + (ax >> 2);
-        const uint8_t *pb = (dir & 2) ? planes1 + (long)((by & 3) * 4 + (bx & 3)) * g.bytes_y + base + (long)(by >> 2) * g.sy + (bx >> 2) : pa;
-        if (!(dir & 1)) pa = pb;
         unsigned sd = 0;
-        if (__any(on)) sd = satd8x8_avg(f, pa, pb, g.sy);
+        if (__any(on)) {
+            unsigned PA[16], PB[16];                                   // the candidate's prediction tiles, interpolated from the reference pictures (interp_dev.h)
+            if (dir & 1) luma_pred_tile8(ref0 + base, g.sy, ax, ay, PA);
+            if (dir & 2) luma_pred_tile8(ref1 + base, g.sy, bx, by, PB);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { if (!(dir & 1)) PA[i] = PB[i]; if (!(dir & 2)) PB[i] = PA[i]; }
+            sd = satd8x8_avg(f, PA, PB);
+        }
         if (!on) sd = 0;
         // CU sums at all four levels, each lane picks its CU's
         const unsigned s3 = sd;
@@ -645,12 +695,12 @@ __global__ __launch_bounds__(256) void merge_pass_kernel(KsGeom g, int lam, cons
     }
 }
 
-extern "C" int ks265_merge_pass(ks265_frame *f, ks265_pic src, const uint8_t *planes0, const uint8_t *planes1, const ks265_pu *pu, const ks265_pu_b *pub,
+extern "C" int ks265_merge_pass(ks265_frame *f, ks265_pic src, ks265_pic ref0, ks265_pic ref1, const ks265_pu *pu, const ks265_pu_b *pub,
                                 const ks265_cu8 *cu_in, ks265_cu8 *cu_out)
 {
     KS_FRAME_CHECK(f);
-    if (!src.y || !planes0 || !cu_in || !cu_out || cu_in == cu_out || (!pu && !pub) || (pub && !planes1)) return KS265_POINTER;
-    hipLaunchKernelGGL(merge_pass_kernel, dim3(f->g.ctu_cols * f->g.ctu_rows), dim3(256), 0, f->ctx->stream, f->g, f->cfg.lambda_q4, src.y, planes0, planes1, pu, pub, cu_in, cu_out);
+    if (!src.y || !ref0.y || !cu_in || !cu_out || cu_in == cu_out || (!pu && !pub) || (pub && !ref1.y)) return KS265_POINTER;
+    hipLaunchKernelGGL(merge_pass_kernel, dim3(f->g.ctu_cols * f->g.ctu_rows), dim3(256), 0, f->ctx->stream, f->g, f->cfg.lambda_q4, src.y, ref0.y, ref1.y, pu, pub, cu_in, cu_out);
     return ks265_check_launch(f->ctx);
 }
 

@@ -104,14 +104,14 @@ __device__ __forceinline__ int luma_raw4(const uint8_t *rp, long stride, int fx,
 __device__ __forceinline__ int uni_round(int kind, int v) { return kind == 0 ? v : kind == 1 ? clip8((v + 32) >> 6) : clip8((v + 2048) >> 12); }
 __device__ __forceinline__ int to14(int kind, int v) { return kind == 0 ? v << 6 : kind == 1 ? v : v >> 6; }
 
-// further list-0 reference pictures (multi-reference P pictures): this component's planes of pictures 1..3 and their fractional planes
-struct KsCompRefs { const uint8_t *r[3]; const uint8_t *p[3]; };
+// further list-0 reference pictures (multi-reference P pictures): this component's planes of pictures 1..3
+struct KsCompRefs { const uint8_t *r[3]; };
 
 template <int RS /*region size in samples: 32 luma, 16 chroma*/, bool MREF>
 __device__ __forceinline__ void code_region(const KsGeom &g, int comp, int qp, int rx8, int ry8, const ks265_cu8 *blk /*LDS [16]*/,
                                             const unsigned char *tu_log2 /*LDS [16]: log2 of TU size in 8x8 blocks*/, const short *Mf, const short *Mt,
                                             short *X, short *T, unsigned char *P, int *nzcnt /*LDS [16]*/, const uint8_t *src, const uint8_t *ref,
-                                            const uint8_t *planes, const uint8_t *ref1, const uint8_t *planes1, int16_t *lvl, uint8_t *rec, int tid, const KsCompRefs xr,
+                                            const uint8_t *ref1, int16_t *lvl, uint8_t *rec, int tid, const KsCompRefs xr,
                                             bool sdh, short *LV, short *DU, short *CF, int *lastcg /*LDS [16]*/, int dec_k, long long rdo_lam2k /* lambda_q4^2 x cfg.rdo, 0 = off */)
 {
     constexpr int UNIT = RS / 4;                      // samples per 8x8-luma block along one axis
@@ -143,7 +143,6 @@ __device__ __forceinline__ void code_region(const KsGeom &g, int comp, int qp, i
                 if (MREF) {                                         // list-0 picture of this CU: inter_dir >> 4 (selects, not an indexed array: keeps the global address space)
                     const int ri = c.inter_dir >> 4;
                     ref = ri == 0 ? ref : (ri == 1 ? xr.r[0] : (ri == 2 ? xr.r[1] : xr.r[2]));
-                    planes = ri == 0 ? planes : (ri == 1 ? xr.p[0] : (ri == 2 ? xr.p[1] : xr.p[2]));
                 }
                 if (dir == 3) {
                     // bi-prediction: exact 14-bit average of the two lists (DefaultWeightedBi_c enc@0x435160)
@@ -162,13 +161,12 @@ __device__ __forceinline__ void code_region(const KsGeom &g, int comp, int qp, i
                 } else {
                     const int ux = dir == 2 ? c.mv1x : c.mvx, uy = dir == 2 ? c.mv1y : c.mvy;
                     if (comp == 0) {
-                        const uint8_t *pb = dir == 2 ? planes1 : planes;
-                        const uint8_t *pp = pb + (long)((uy & 3) * 4 + (ux & 3)) * g.bytes_y + g.org_y + (long)(Y0 + qy + (uy >> 2)) * g.sy + X0 + qx + (ux >> 2);
-                        const unsigned sh = (unsigned)((uintptr_t)pp & 3);
-                        const unsigned *a = (const unsigned *)(pp - sh);
-                        const unsigned v = align_bytes(a[1], a[0], sh);
+                        // luma: the normative 8-tap filters on the reference picture itself (round 2 read one of sixteen precomputed planes here)
+                        const uint8_t *rp = ks_org_y(g, dir == 2 ? ref1 : ref) + (long)(Y0 + qy + (uy >> 2)) * g.sy + X0 + qx + (ux >> 2);
+                        int v[4];
+                        const int k = luma_raw4(rp, g.sy, ux & 3, uy & 3, v);
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) pred[i] = (v >> (8 * i)) & 255;
+                        for (int i = 0; i < 4; ++i) pred[i] = uni_round(k, v[i]);
                     } else {
                         const uint8_t *rp = ks_org_c(g, dir == 2 ? ref1 : ref) + (long)(Y0 + qy + (uy >> 3)) * g.sc + X0 + qx + (ux >> 3);
                         int v[4];
@@ -348,8 +346,8 @@ static inline long long ks_rdo_lam2k(const ks265_frame *f) { return (long long)f
 // list-1 pointers are null for I / P pictures (no block carries inter_dir 2 or 3 there)
 template <bool MREF>
 __global__ __launch_bounds__(256) void reconstruct_kernel(KsGeom g, int qp, const uint8_t *src_y, const uint8_t *src_u, const uint8_t *src_v,
-                                                          const uint8_t *ref_y, const uint8_t *ref_u, const uint8_t *ref_v, const uint8_t *planes,
-                                                          const uint8_t *ref1_y, const uint8_t *ref1_u, const uint8_t *ref1_v, const uint8_t *planes1, ks265_cu8 *cu8,
+                                                          const uint8_t *ref_y, const uint8_t *ref_u, const uint8_t *ref_v,
+                                                          const uint8_t *ref1_y, const uint8_t *ref1_u, const uint8_t *ref1_v, ks265_cu8 *cu8,
                                                           int16_t *lvl_y, int16_t *lvl_u, int16_t *lvl_v, uint8_t *rec_y, uint8_t *rec_u, uint8_t *rec_v, const short *mats, const KsRefExtra xr, int sdh_on, int dec_k, long long rdo_lam2k)
 {
     __shared__ __attribute__((aligned(16))) short Mf[MAT_SHORTS];
@@ -385,19 +383,19 @@ __global__ __launch_bounds__(256) void reconstruct_kernel(KsGeom g, int qp, cons
     }
     __syncthreads();
     const int qpc = chroma_qp(qp);
-    code_region<32, MREF>(g, 0, qp, rx * 4, ry * 4, blk, tu_log2, Mf, Mt, X, T, P, nzcnt, src_y, ref_y, planes, ref1_y, planes1, lvl_y, rec_y, tid, xr.y, sdh, LV, DU, CF, lastcg, dec_k, rdo_lam2k);
+    code_region<32, MREF>(g, 0, qp, rx * 4, ry * 4, blk, tu_log2, Mf, Mt, X, T, P, nzcnt, src_y, ref_y, ref1_y, lvl_y, rec_y, tid, xr.y, sdh, LV, DU, CF, lastcg, dec_k, rdo_lam2k);
     if (tid < 16 && blk[tid].log2_cu) {
         const int t8 = 1 << tu_log2[tid], tb = ((tid >> 2) & ~(t8 - 1)) * 4 + ((tid & 3) & ~(t8 - 1));
         if (nzcnt[tb]) cbf[tid] |= 1;
     }
     __syncthreads();
-    code_region<16, MREF>(g, 1, qpc, rx * 4, ry * 4, blk, tu_log2, Mf, Mt, X, T, P, nzcnt, src_u, ref_u, planes, ref1_u, planes1, lvl_u, rec_u, tid, xr.u, sdh, LV, DU, CF, lastcg, 0, rdo_lam2k);
+    code_region<16, MREF>(g, 1, qpc, rx * 4, ry * 4, blk, tu_log2, Mf, Mt, X, T, P, nzcnt, src_u, ref_u, ref1_u, lvl_u, rec_u, tid, xr.u, sdh, LV, DU, CF, lastcg, 0, rdo_lam2k);
     if (tid < 16 && blk[tid].log2_cu) {
         const int t8 = 1 << tu_log2[tid], tb = ((tid >> 2) & ~(t8 - 1)) * 4 + ((tid & 3) & ~(t8 - 1));
         if (nzcnt[tb]) cbf[tid] |= 2;
     }
     __syncthreads();
-    code_region<16, MREF>(g, 2, qpc, rx * 4, ry * 4, blk, tu_log2, Mf, Mt, X, T, P, nzcnt, src_v, ref_v, planes, ref1_v, planes1, lvl_v, rec_v, tid, xr.v, sdh, LV, DU, CF, lastcg, 0, rdo_lam2k);
+    code_region<16, MREF>(g, 2, qpc, rx * 4, ry * 4, blk, tu_log2, Mf, Mt, X, T, P, nzcnt, src_v, ref_v, ref1_v, lvl_v, rec_v, tid, xr.v, sdh, LV, DU, CF, lastcg, 0, rdo_lam2k);
     if (tid < 16 && blk[tid].log2_cu) {
         const int t8 = 1 << tu_log2[tid], tb = ((tid >> 2) & ~(t8 - 1)) * 4 + ((tid & 3) & ~(t8 - 1));
         if (nzcnt[tb]) cbf[tid] |= 4;
@@ -406,47 +404,46 @@ __global__ __launch_bounds__(256) void reconstruct_kernel(KsGeom g, int qp, cons
     }
 }
 
-static int launch_reconstruct(ks265_frame *f, ks265_pic src, ks265_pic ref0, const uint8_t *planes0, ks265_pic ref1, const uint8_t *planes1, ks265_cu8 *cu8,
+static int launch_reconstruct(ks265_frame *f, ks265_pic src, ks265_pic ref0, ks265_pic ref1, ks265_cu8 *cu8,
                               int16_t *lvl_y, int16_t *lvl_u, int16_t *lvl_v, ks265_pic recon)
 {
     dim3 grid(((f->g.W + 31) / 32) * ((f->g.H + 31) / 32));
-    hipLaunchKernelGGL(reconstruct_kernel<false>, grid, dim3(256), 0, f->ctx->stream, f->g, f->cfg.qp, src.y, src.u, src.v, ref0.y, ref0.u, ref0.v, planes0, ref1.y,
-                       ref1.u, ref1.v, planes1, cu8, lvl_y, lvl_u, lvl_v, recon.y, recon.u, recon.v, f->mats, KsRefExtra{}, f->cfg.sdh, f->cfg.decimate, ks_rdo_lam2k(f));
+    hipLaunchKernelGGL(reconstruct_kernel<false>, grid, dim3(256), 0, f->ctx->stream, f->g, f->cfg.qp, src.y, src.u, src.v, ref0.y, ref0.u, ref0.v, ref1.y,
+                       ref1.u, ref1.v, cu8, lvl_y, lvl_u, lvl_v, recon.y, recon.u, recon.v, f->mats, KsRefExtra{}, f->cfg.sdh, f->cfg.decimate, ks_rdo_lam2k(f));
     return ks265_check_launch(f->ctx);
 }
 
 // multi-reference P pictures (-ref / -ref0): list 0 holds nref <= 4 pictures, the CU's picture is refs[inter_dir >> 4]
-extern "C" int ks265_reconstruct_mref(ks265_frame *f, ks265_pic src, int nref, const ks265_pic *refs, const uint8_t *const *planes, ks265_cu8 *cu8, int16_t *lvl_y,
+extern "C" int ks265_reconstruct_mref(ks265_frame *f, ks265_pic src, int nref, const ks265_pic *refs, ks265_cu8 *cu8, int16_t *lvl_y,
                                       int16_t *lvl_u, int16_t *lvl_v, ks265_pic recon)
 {
     KS_FRAME_CHECK(f);
-    if (!src.y || !refs || !planes || !cu8 || !lvl_y || !lvl_u || !lvl_v || !recon.y) return KS265_POINTER;
+    if (!src.y || !refs || !cu8 || !lvl_y || !lvl_u || !lvl_v || !recon.y) return KS265_POINTER;
     if (nref < 1 || nref > 4) return KS265_NOTSUPPORTED;
     KsRefExtra xr{};
     for (int r = 1; r < nref; ++r) {
-        if (!refs[r].y || !planes[r]) return KS265_POINTER;
+        if (!refs[r].y) return KS265_POINTER;
         xr.y.r[r - 1] = refs[r].y; xr.u.r[r - 1] = refs[r].u; xr.v.r[r - 1] = refs[r].v;
-        xr.y.p[r - 1] = xr.u.p[r - 1] = xr.v.p[r - 1] = planes[r];
     }
     dim3 grid(((f->g.W + 31) / 32) * ((f->g.H + 31) / 32));
-    hipLaunchKernelGGL(reconstruct_kernel<true>, grid, dim3(256), 0, f->ctx->stream, f->g, f->cfg.qp, src.y, src.u, src.v, refs[0].y, refs[0].u, refs[0].v, planes[0],
-                       (const uint8_t *)nullptr, (const uint8_t *)nullptr, (const uint8_t *)nullptr, (const uint8_t *)nullptr, cu8, lvl_y, lvl_u, lvl_v, recon.y, recon.u,
+    hipLaunchKernelGGL(reconstruct_kernel<true>, grid, dim3(256), 0, f->ctx->stream, f->g, f->cfg.qp, src.y, src.u, src.v, refs[0].y, refs[0].u, refs[0].v,
+                       (const uint8_t *)nullptr, (const uint8_t *)nullptr, (const uint8_t *)nullptr, cu8, lvl_y, lvl_u, lvl_v, recon.y, recon.u,
                        recon.v, f->mats, xr, f->cfg.sdh, f->cfg.decimate, ks_rdo_lam2k(f));
     return ks265_check_launch(f->ctx);
 }
 
-extern "C" int ks265_reconstruct(ks265_frame *f, ks265_pic src, ks265_pic ref, const uint8_t *planes, ks265_cu8 *cu8, int16_t *lvl_y, int16_t *lvl_u,
+extern "C" int ks265_reconstruct(ks265_frame *f, ks265_pic src, ks265_pic ref, ks265_cu8 *cu8, int16_t *lvl_y, int16_t *lvl_u,
                                  int16_t *lvl_v, ks265_pic recon)
 {
     KS_FRAME_CHECK(f);
     if (!src.y || !cu8 || !lvl_y || !lvl_u || !lvl_v || !recon.y) return KS265_POINTER;
-    return launch_reconstruct(f, src, ref, planes, ks265_pic{nullptr, nullptr, nullptr}, nullptr, cu8, lvl_y, lvl_u, lvl_v, recon);
+    return launch_reconstruct(f, src, ref, ks265_pic{nullptr, nullptr, nullptr}, cu8, lvl_y, lvl_u, lvl_v, recon);
 }
 
-extern "C" int ks265_reconstruct_b(ks265_frame *f, ks265_pic src, ks265_pic ref0, const uint8_t *planes0, ks265_pic ref1, const uint8_t *planes1,
+extern "C" int ks265_reconstruct_b(ks265_frame *f, ks265_pic src, ks265_pic ref0, ks265_pic ref1,
                                    ks265_cu8 *cu8, int16_t *lvl_y, int16_t *lvl_u, int16_t *lvl_v, ks265_pic recon)
 {
     KS_FRAME_CHECK(f);
-    if (!src.y || !ref0.y || !ref1.y || !planes0 || !planes1 || !cu8 || !lvl_y || !lvl_u || !lvl_v || !recon.y) return KS265_POINTER;
-    return launch_reconstruct(f, src, ref0, planes0, ref1, planes1, cu8, lvl_y, lvl_u, lvl_v, recon);
+    if (!src.y || !ref0.y || !ref1.y || !cu8 || !lvl_y || !lvl_u || !lvl_v || !recon.y) return KS265_POINTER;
+    return launch_reconstruct(f, src, ref0, ref1, cu8, lvl_y, lvl_u, lvl_v, recon);
 }

@@ -109,130 +109,6 @@ extern "C" int ks265_store_i420(ks265_frame *f, ks265_pic src, uint8_t *i420)
     return ks265_check_launch(f->ctx);
 }
 
-// ------------------------------------------------------------------ Stage A0: the 15 fractional planes
-// One workgroup = one 64x16 output tile; the (64+8) x (16+7) source tile is staged in LDS, the three horizontal
-// 8-tap intermediates (raw 16-bit sums, interpLumaHor8to16_c enc@0x40eb80) are built once in LDS and every thread
-// then produces 4 adjacent samples of all 15 planes (one dword store per plane): fy = 0 planes round the
-// intermediate ((s+32)>>6 == interpLumaHor8to8_c enc@0x40e4f0), fx = 0 planes filter the source vertically
-// (interpLumaVer8to8_c enc@0x40f0c0), the nine 2-D planes filter the intermediates (interpLumaVer16to8_c enc@0x4100b0).
-// hipcc (ROCm 7.2) folds clip8(x >> s) pairs into gfx950's v_ashr_pk_u8_i32 and then ORs the packed pair with
-// `v_lshl_or_b32` assuming bits 31:16 of its result are zero; on MI355X they are not (measured: the upper two
-// samples of every packed dword came back OR-contaminated).  An empty asm on the shifted value keeps the
-// shift and the clamp apart so the instruction is never selected.
-__device__ __forceinline__ int no_pk(int v) { asm volatile("" : "+v"(v)); return v; }
-
-#define PT_W 64
-#define PT_H 16
-#define PT_SW 76      // source tile width  (x-4 .. x+64+7; the horizontal pass reads 16 bytes from column x)
-#define PT_SH 23      // source tile height (y-3 .. y+16+3)
-__global__ __launch_bounds__(256) void ref_planes_kernel(KsGeom g, const uint8_t *ref, uint8_t *planes)
-{
-    __shared__ __attribute__((aligned(16))) uint8_t S[PT_SH][PT_SW];   // dword accesses: the array must be 4-byte aligned in LDS
-    __shared__ __attribute__((aligned(16))) short Hm[3][PT_SH][PT_W];
-    const int tid = threadIdx.x;
-    const int ntx = (g.W + 2 * KS_PLANE_MARGIN + PT_W - 1) / PT_W, nty = (g.H + 2 * KS_PLANE_MARGIN + PT_H - 1) / PT_H;
-    const int tile = ks_xcd_swizzle(blockIdx.x, ntx * nty);       // XCD-aware: neighbouring tiles (shared source rows / lines) in one L2
-    const int x0 = -KS_PLANE_MARGIN + (tile % ntx) * PT_W, y0 = -KS_PLANE_MARGIN + (tile / ntx) * PT_H;
-    const uint8_t *R = ks_org_y(g, ref);
-    // source tile: dword loads (x0 - 4 is dword aligned: origin, margin and tile width are multiples of 4)
-    for (int i = tid; i < PT_SH * (PT_SW / 4); i += 256) {
-        int r = i / (PT_SW / 4), c = i - r * (PT_SW / 4);
-        int yy = min(y0 - 3 + r, g.H + KS_PAD_Y - 1);                 // rows past the border only feed discarded outputs
-        *(unsigned *)&S[r][c * 4] = *(const unsigned *)(R + (long)yy * g.sy + x0 - 4 + c * 4);
-    }
-    __syncthreads();
-    // horizontal intermediates, 4 samples per work item: sample x needs S bytes x+1 .. x+8 (S column of sample x is x + 4).
-    // v_dot4_i32_i8 on (pixel - 128): sum c*(p-128) = sum c*p - 128*64, so 8192 is added back.
-    for (int i = tid; i < PT_SH * (PT_W / 4); i += 256) {
-        const int r = i / (PT_W / 4), x4 = (i - r * (PT_W / 4)) * 4;
-        const unsigned *sp = (const unsigned *)&S[r][x4];
-        const unsigned d0 = sp[0] ^ 0x80808080u, d1 = sp[1] ^ 0x80808080u, d2 = sp[2] ^ 0x80808080u, d3 = sp[3] ^ 0x80808080u;
-        short o[3][4];
-#pragma unroll
-        for (int px = 0; px < 4; ++px) {
-            // bytes x4+px+1 .. +4 and +5 .. +8
-            const unsigned lo = px == 3 ? d1 : align_bytes(d1, d0, px + 1), hi = px == 3 ? d2 : align_bytes(d2, d1, px + 1);
-#pragma unroll
-            for (int fx = 1; fx < 4; ++fx) {
-                const signed char *c = kLumaTaps[fx];
-                const int tl = (int)((unsigned)(unsigned char)c[0] | ((unsigned)(unsigned char)c[1] << 8) | ((unsigned)(unsigned char)c[2] << 16) | ((unsigned)(unsigned char)c[3] << 24));
-                const int th = (int)((unsigned)(unsigned char)c[4] | ((unsigned)(unsigned char)c[5] << 8) | ((unsigned)(unsigned char)c[6] << 16) | ((unsigned)(unsigned char)c[7] << 24));
-                int sum = __builtin_amdgcn_sdot4((int)lo, tl, 8192, false);
-                sum = __builtin_amdgcn_sdot4((int)hi, th, sum, false);
-                o[fx - 1][px] = (short)sum;
-            }
-        }
-        (void)d3;
-#pragma unroll
-        for (int fx = 0; fx < 3; ++fx) *(uint2 *)&Hm[fx][r][x4] = *(const uint2 *)o[fx];
-    }
-    __syncthreads();
-    const int tx = (tid & 15) * 4, ty = tid >> 4;      // 4 samples at (x0 + tx .. +3, y0 + ty)
-    const int X = x0 + tx, Y = y0 + ty;
-    if (X >= g.W + KS_PLANE_MARGIN || Y >= g.H + KS_PLANE_MARGIN) return;
-    // the eight tile rows ty .. ty+7 feed every vertical filter of this thread: one dword (4 source bytes) and three
-    // 8-byte reads (4 intermediates each) per row, shared by the three vertical fractions
-    int acc[3][4][4];                                   // [fy-1][plane column 0..3 (0 = source, 1..3 = Hm)][pixel]
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) acc[a][b][c] = 0;
-    unsigned out[16];
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-        const unsigned sv = *(const unsigned *)&S[ty + t][tx + 4];
-        short hv[3][4];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) *(uint2 *)hv[k] = *(const uint2 *)&Hm[k][ty + t][tx];
-        if (t == 3) {                                   // the row of the output sample itself: fy = 0 planes
-            out[0] = sv;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                unsigned v = 0;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) v |= (unsigned)clip8(no_pk(((int)hv[k][i] + 32) >> 6)) << (8 * i);
-                out[1 + k] = v;
-            }
-        }
-#pragma unroll
-        for (int fy = 1; fy < 4; ++fy) {
-            const int c = kLumaTaps[fy][t];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                acc[fy - 1][0][i] += c * (int)((sv >> (8 * i)) & 255);
-#pragma unroll
-                for (int k = 0; k < 3; ++k) acc[fy - 1][1 + k][i] += c * (int)hv[k][i];
-            }
-        }
-    }
-#pragma unroll
-    for (int fy = 1; fy < 4; ++fy) {
-        unsigned v0 = 0, v1 = 0, v2 = 0, v3 = 0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            v0 |= (unsigned)clip8(no_pk((acc[fy - 1][0][i] + 32) >> 6)) << (8 * i);
-            v1 |= (unsigned)clip8(no_pk((acc[fy - 1][1][i] + 2048) >> 12)) << (8 * i);
-            v2 |= (unsigned)clip8(no_pk((acc[fy - 1][2][i] + 2048) >> 12)) << (8 * i);
-            v3 |= (unsigned)clip8(no_pk((acc[fy - 1][3][i] + 2048) >> 12)) << (8 * i);
-        }
-        out[fy * 4 + 0] = v0; out[fy * 4 + 1] = v1; out[fy * 4 + 2] = v2; out[fy * 4 + 3] = v3;
-    }
-    long off = g.org_y + (long)Y * g.sy + X;
-#pragma unroll
-    for (int p = 0; p < 16; ++p) *(unsigned *)(planes + p * g.bytes_y + off) = out[p];
-}
-
-extern "C" int ks265_ref_planes(ks265_frame *f, ks265_pic ref, uint8_t *planes)
-{
-    KS_FRAME_CHECK(f);
-    if (!ref.y || !planes) return KS265_POINTER;
-    dim3 grid(((f->g.W + 2 * KS_PLANE_MARGIN + PT_W - 1) / PT_W) * ((f->g.H + 2 * KS_PLANE_MARGIN + PT_H - 1) / PT_H));
-    hipLaunchKernelGGL(ref_planes_kernel, grid, dim3(256), 0, f->ctx->stream, f->g, ref.y, planes);
-    return ks265_check_launch(f->ctx);
-}
-
 // ------------------------------------------------------------------ picture SSE (PSNR): sse3[plane] += sum of squared differences
 // one launch for the three planes: blockIdx.y = plane, a work-group = 8 rows, a thread = dwords of one row (stride 32 dwords)
 __global__ __launch_bounds__(256) void sse_picture_kernel(KsGeom g, const uint8_t *ay, const uint8_t *au, const uint8_t *av, const uint8_t *by, const uint8_t *bu, const uint8_t *bv,

@@ -57,10 +57,10 @@ EXPORTS = [
     "ks265_sao_apply_bo_rect", "ks265_sao_apply_eo_rect", "ks265_sao_stats_batch", "ks265_intra_pred_batch", "ks265_intra_filter_ref_batch",
     "ks265_downsample_rect", "ks265_weight_bi_sad_batch", "ks265_ac_energy_batch", "ks265_ac_energy_map",
     "ks265_frame_reset_prediction", "ks265_frame_records_layout", "ks265_frame_pack_records", "ks265_frame_compact_layout", "ks265_frame_pack_compact", "ks265_copy_out_compact_flag_async", "ks265_copy_out_compact_async", "ks265_frame_geometry", "ks265_frame_create", "ks265_frame_destroy", "ks265_frame_set_qp", "ks265_pad_picture",
-    "ks265_load_i420", "ks265_store_i420", "ks265_ref_planes", "ks265_presearch", "ks265_me_integer", "ks265_me_subpel", "ks265_merge_pass", "ks265_cu_decide",
+    "ks265_load_i420", "ks265_store_i420", "ks265_presearch", "ks265_me_integer", "ks265_me_subpel", "ks265_merge_pass", "ks265_cu_decide",
     "ks265_cu_flat_intra", "ks265_intra_decide", "ks265_intra_decide_ex", "ks265_lookahead_reduce", "ks265_lookahead_picture", "ks265_intra_reconstruct", "ks265_reconstruct", "ks265_reconstruct_b", "ks265_bi_decide", "ks265_bi_full_batch", "ks265_capture_begin", "ks265_capture_end", "ks265_graph_launch", "ks265_graph_destroy", "ks265_frame_p_state", "ks265_frame_p_advance", "ks265_frame_p_restore", "ks265_cu_decide_b", "ks265_deblock", "ks265_sao",
     "ks265_encode_picture", "ks265_encode_picture_b", "ks265_encode_picture_mref", "ks265_ref_decide", "ks265_reconstruct_mref",
-    "ks265_frame_set_profiling", "ks265_frame_stage_ms", "ks265_frame_levels", "ks265_frame_pu", "ks265_frame_cu8", "ks265_frame_sao", "ks265_frame_planes", "ks265_sse_picture",
+    "ks265_frame_set_profiling", "ks265_frame_stage_ms", "ks265_frame_levels", "ks265_frame_pu", "ks265_frame_cu8", "ks265_frame_sao", "ks265_sse_picture",
 ]
 
 
@@ -73,7 +73,7 @@ def load_library() -> C.CDLL:
         _lib = C.CDLL(LIB_PATH)
         _lib.ks265_last_error.restype = C.c_char_p
         _lib.ks265_version.restype = C.c_char_p
-        for n in ("ks265_frame_levels", "ks265_frame_pu", "ks265_frame_cu8", "ks265_frame_sao", "ks265_frame_planes"):
+        for n in ("ks265_frame_levels", "ks265_frame_pu", "ks265_frame_cu8", "ks265_frame_sao"):
             if hasattr(_lib, n):
                 getattr(_lib, n).restype = C.c_void_p
     return _lib
@@ -315,9 +315,6 @@ class KsFrame:
     def pad(self, pic: DevPic):
         self.ks._chk(self.lib.ks265_pad_picture(self.h, pic.c()))
 
-    def ref_planes(self, ref: DevPic, planes):
-        self.ks._chk(self.lib.ks265_ref_planes(self.h, ref.c(), _p(planes)))
-
     def presearch(self, src: DevPic, ref: DevPic) -> np.ndarray:
         """stage A0: the pre-search vector field, [ceil(H/16), ceil(W/16), 2] int16 (integer pel), and the CTUs' window offsets [rows, cols, 2]"""
         nbx, nby = (self.cfg.width + 15) // 16, (self.cfg.height + 15) // 16
@@ -328,8 +325,8 @@ class KsFrame:
     def me_integer(self, src: DevPic, ref: DevPic, prev_pu, pu):
         self.ks._chk(self.lib.ks265_me_integer(self.h, src.c(), ref.c(), _p(prev_pu), _p(pu)))
 
-    def me_subpel(self, src: DevPic, planes, pu):
-        self.ks._chk(self.lib.ks265_me_subpel(self.h, src.c(), _p(planes), _p(pu)))
+    def me_subpel(self, src: DevPic, ref: DevPic, pu):
+        self.ks._chk(self.lib.ks265_me_subpel(self.h, src.c(), ref.c(), _p(pu)))
 
     def intra_decide(self, src: DevPic, cu8):
         self.ks._chk(self.lib.ks265_intra_decide(self.h, src.c(), _p(cu8)))
@@ -350,15 +347,14 @@ class KsFrame:
     def cu_flat_intra(self, cu8):
         self.ks._chk(self.lib.ks265_cu_flat_intra(self.h, _p(cu8)))
 
-    def reconstruct(self, src: DevPic, ref: DevPic, planes, cu8, lvl, recon: DevPic):
-        self.ks._chk(self.lib.ks265_reconstruct(self.h, src.c(), ref.c(), _p(planes), _p(cu8), _p(lvl[0]), _p(lvl[1]), _p(lvl[2]), recon.c()))
+    def reconstruct(self, src: DevPic, ref: DevPic, cu8, lvl, recon: DevPic):
+        self.ks._chk(self.lib.ks265_reconstruct(self.h, src.c(), ref.c(), _p(cu8), _p(lvl[0]), _p(lvl[1]), _p(lvl[2]), recon.c()))
 
-    def reconstruct_b(self, src: DevPic, ref0: DevPic, planes0, ref1: DevPic, planes1, cu8, lvl, recon: DevPic):
-        self.ks._chk(self.lib.ks265_reconstruct_b(self.h, src.c(), ref0.c(), _p(planes0), ref1.c(), _p(planes1), _p(cu8), _p(lvl[0]), _p(lvl[1]), _p(lvl[2]),
-                                                  recon.c()))
+    def reconstruct_b(self, src: DevPic, ref0: DevPic, ref1: DevPic, cu8, lvl, recon: DevPic):
+        self.ks._chk(self.lib.ks265_reconstruct_b(self.h, src.c(), ref0.c(), ref1.c(), _p(cu8), _p(lvl[0]), _p(lvl[1]), _p(lvl[2]), recon.c()))
 
-    def bi_decide(self, src: DevPic, planes0, planes1, pu0, pu1, pub):
-        self.ks._chk(self.lib.ks265_bi_decide(self.h, src.c(), _p(planes0), _p(planes1), _p(pu0), _p(pu1), _p(pub)))
+    def bi_decide(self, src: DevPic, ref0: DevPic, ref1: DevPic, pu0, pu1, pub):
+        self.ks._chk(self.lib.ks265_bi_decide(self.h, src.c(), ref0.c(), ref1.c(), _p(pu0), _p(pu1), _p(pub)))
 
     def cu_decide_b(self, pub, cu8):
         self.ks._chk(self.lib.ks265_cu_decide_b(self.h, _p(pub), _p(cu8)))
@@ -372,10 +368,9 @@ class KsFrame:
         arr = (C.c_void_p * len(pus))(*[p.data_ptr() for p in pus])
         self.ks._chk(self.lib.ks265_ref_decide(self.h, C.c_int(len(pus)), arr, _p(pub)))
 
-    def reconstruct_mref(self, src: DevPic, refs: list, planes: list, cu8, lvl, recon: DevPic):
+    def reconstruct_mref(self, src: DevPic, refs: list, cu8, lvl, recon: DevPic):
         ra = (Pic * len(refs))(*[r.c() for r in refs])
-        pa = (C.c_void_p * len(planes))(*[p.data_ptr() for p in planes])
-        self.ks._chk(self.lib.ks265_reconstruct_mref(self.h, src.c(), C.c_int(len(refs)), ra, pa, _p(cu8), _p(lvl[0]), _p(lvl[1]), _p(lvl[2]), recon.c()))
+        self.ks._chk(self.lib.ks265_reconstruct_mref(self.h, src.c(), C.c_int(len(refs)), ra, _p(cu8), _p(lvl[0]), _p(lvl[1]), _p(lvl[2]), recon.c()))
 
     def encode_picture_b(self, src: DevPic, ref0: DevPic, ref1: DevPic, recon_out: DevPic):
         self.ks._chk(self.lib.ks265_encode_picture_b(self.h, src.c(), ref0.c(), ref1.c(), recon_out.c()))
@@ -389,7 +384,7 @@ class KsFrame:
     def encode_picture(self, src: DevPic, ref: DevPic, is_key: bool, recon_out: DevPic):
         self.ks._chk(self.lib.ks265_encode_picture(self.h, src.c(), ref.c(), C.c_int(1 if is_key else 0), recon_out.c()))
 
-    STAGES = ("ref_planes", "me_integer", "me_subpel", "cu_decide", "reconstruct", "deblock", "sao")
+    STAGES = ("unused", "me_integer", "me_subpel", "cu_decide", "reconstruct", "deblock", "sao")
 
     def set_profiling(self, on: bool):
         self.ks._chk(self.lib.ks265_frame_set_profiling(self.h, C.c_int(1 if on else 0)))
@@ -397,7 +392,7 @@ class KsFrame:
     def stage_ms(self) -> dict:
         ms = (C.c_float * 7)()
         self.ks._chk(self.lib.ks265_frame_stage_ms(self.h, ms))
-        return {n: float(ms[i]) for i, n in enumerate(self.STAGES)}
+        return {n: float(ms[i]) for i, n in enumerate(self.STAGES) if n != "unused"}    # slot 0 held the fractional-plane stage of rounds 1 - 2
 
     def sse_picture(self, a: DevPic, b: DevPic) -> np.ndarray:
         out = self.ks.zeros(24)

@@ -40,7 +40,6 @@ def test_stages_match_oracle(ks, W, H, seed, me):
     g = f.geom
     org_y, org_c = g.pad_y * g.stride_y + g.pad_y, g.pad_c * g.stride_c + g.pad_c
     src, ref, deb, dst = f.new_pic(), f.new_pic(), f.new_pic(), f.new_pic()
-    planes = ks.zeros(16 * g.bytes_y)
     pu = [ks.zeros(g.bytes_pu), ks.zeros(g.bytes_pu)]
     cu8, sao = ks.zeros(g.bytes_cu8), ks.zeros(g.bytes_sao)
     lvl = [ks.zeros(W * H * 2), ks.zeros(W * H // 2), ks.zeros(W * H // 2)]
@@ -57,20 +56,15 @@ def test_stages_match_oracle(ks, W, H, seed, me):
         if key:
             f.cu_flat_intra(cu8)
         else:
-            f.ref_planes(ref, planes)
-            P = ks.host(planes, np.uint8).reshape(16, -1)
-            OP = o.planes.reshape(16, -1)
-            for k in range(16):
-                _cmp_region(f"plane{k}", P[k], OP[k], g.stride_y, org_y, W, H, margin=72)
             f.me_integer(src, ref, pu[1] if have_prev else None, pu[0])
             got = ks.host(pu[0], PU)
             assert (got == o.pu_int).all(), f"integer ME: {int((got != o.pu_int).sum())} PU records differ (frame {t})"
-            f.me_subpel(src, planes, pu[0])
+            f.me_subpel(src, ref, pu[0])           # the candidates' samples are interpolated from the reference picture (the oracle reads its sixteen planes)
             got = ks.host(pu[0], PU)
             exp = o.prev_pu  # the oracle swapped its buffers after the picture
             assert (got == exp).all(), f"sub-pel ME: {int((got != exp).sum())} PU records differ (frame {t})"
             f.cu_decide(pu[0], cu8)
-        f.reconstruct(src, ref, planes, cu8, lvl, deb)
+        f.reconstruct(src, ref, cu8, lvl, deb)
         gc = ks.host(cu8, CU8)
         assert (gc == o.cu8).all(), f"cu8 map differs in {int((gc != o.cu8).sum())} blocks (frame {t})"
         for c in range(3):
@@ -185,15 +179,21 @@ def test_full_size_properties_2160p(ks):
             last = pu[(g.ctu_rows - 1) * g.ctu_cols:]
             assert (last["cost"][:, 0] == 0xFFFFFFFF).all() and (last["cost"][:, 5] != 0xFFFFFFFF).all()
             # stage D on its own, keeping the pre-deblock reconstruction
-            planes = ks.zeros(16 * g.bytes_y)
-            f.ref_planes(b, planes)                       # b = reconstruction of picture 0 = the reference of picture 1
+            # b = reconstruction of picture 0 = the reference of picture 1; the fractional-sample predictions of the check below come from the oracle's planes
+            # (pinned interpolators): the HIP path has none any more, it interpolates per block
+            import ctypes as C
+            from oracle_lib import OFrameCfg, OPic, lib as olib, ptr
+            ocfg = OFrameCfg(W, H, 28, lambda_q4(28), 64, 1, 1, 1, 1, 0, 0, 1, 4, 0, 0, 0, 0, 0, 0, 0, 0)
+            hb = [ks.host(b.y, np.uint8).copy(), ks.host(b.u, np.uint8).copy(), ks.host(b.v, np.uint8).copy()]
+            oplanes = np.zeros(16 * g.bytes_y, np.uint8)
+            olib().kso_ref_planes(C.byref(ocfg), OPic(hb[0].ctypes.data, hb[1].ctypes.data, hb[2].ctypes.data), ptr(oplanes))
             cu8 = ks.dev(f.ws_read("cu8", g.bytes_cu8))
             lvl = [ks.zeros(W * H * 2), ks.zeros(W * H // 2), ks.zeros(W * H // 2)]
             pre = f.new_pic()
-            f.reconstruct(src, b, planes, cu8, lvl, pre)
+            f.reconstruct(src, b, cu8, lvl, pre)
             cu = ks.host(cu8, CU8).reshape(H // 8, W // 8)
             lv = ks.host(lvl[0], np.int16).reshape(H, W)
-            P = ks.host(planes, np.uint8).reshape(16, -1, g.stride_y)[:, :g.rows_y]
+            P = oplanes.reshape(16, -1, g.stride_y)[:, :g.rows_y]
             R = ks.host(pre.y, np.uint8).reshape(-1, g.stride_y)[:g.rows_y]
             rng = np.random.default_rng(3)
             inv = [40, 45, 51, 57, 64, 72]
@@ -250,23 +250,21 @@ def test_b_pictures_match_oracle(ks, W, H, seed, me, refine):
         elif not staged:
             f.encode_picture_b(src, dpb_g[r0], dpb_g[r1], out)
         else:
-            planes0, planes1 = ks.zeros(16 * g.bytes_y), ks.zeros(16 * g.bytes_y)
             pu0, pu1, pub = ks.zeros(g.bytes_pu), ks.zeros(g.bytes_pu), ks.zeros(g.bytes_pu)
             cu8, sao = ks.zeros(g.bytes_cu8), ks.zeros(g.bytes_sao)
             lvl = [ks.zeros(W * H * 2), ks.zeros(W * H // 2), ks.zeros(W * H // 2)]
             deb = f.new_pic()
-            f.ref_planes(dpb_g[r0], planes0); f.ref_planes(dpb_g[r1], planes1)
-            f.me_integer(src, dpb_g[r0], None, pu0); f.me_subpel(src, planes0, pu0)
-            f.me_integer(src, dpb_g[r1], None, pu1); f.me_subpel(src, planes1, pu1)
+            f.me_integer(src, dpb_g[r0], None, pu0); f.me_subpel(src, dpb_g[r0], pu0)
+            f.me_integer(src, dpb_g[r1], None, pu1); f.me_subpel(src, dpb_g[r1], pu1)
             assert (ks.host(pu0, PU) == o.pu).all() and (ks.host(pu1, PU) == o.pu1).all(), "list searches differ"
-            f.bi_decide(src, planes0, planes1, pu0, pu1, pub)
+            f.bi_decide(src, dpb_g[r0], dpb_g[r1], pu0, pu1, pub)
             gb = ks.host(pub, PU_B)
             assert (gb == o.pub).all(), f"bi decision differs for {int((gb != o.pub).sum())} PUs"
             assert len(set(np.unique(gb["inter_dir"][gb["cost"] != 0xFFFFFFFF]))) == 3, "fixture should exercise L0, L1 and bi"
             h0, h1 = ks.host(pu0, PU), ks.host(pu1, PU)
             refined[0] += int(((gb["inter_dir"] == 3) & ((gb["mvx"] != h0["mvx"]) | (gb["mvy"] != h0["mvy"]) | (gb["mv1x"] != h1["mvx"]) | (gb["mv1y"] != h1["mvy"]))).sum())
             f.cu_decide_b(pub, cu8)
-            f.reconstruct_b(src, dpb_g[r0], planes0, dpb_g[r1], planes1, cu8, lvl, deb)
+            f.reconstruct_b(src, dpb_g[r0], dpb_g[r1], cu8, lvl, deb)
             assert (ks.host(cu8, CU8) == o.cu8).all()
             for c in range(3):
                 assert (ks.host(lvl[c], np.int16) == o.lvl[c]).all(), f"levels comp {c}"
