@@ -471,7 +471,8 @@ def encoded_leg(args, torch, dist, rank, world, dev_index, backend, sync_all):
     except Exception:
         cores = os.cpu_count() or 8
     threads = args.host_threads or max(2, min(32, cores // max(1, world)))        # slice writers of this rank's encoder (shared out over its GOP lanes, if any)
-    os.environ["KS265_DEVICE"] = str(dev_index)
+    os.environ["KS265_DEVICE"] = str(dev_index)            # one process per GPU (the driver's launch contract): this rank's encoder handle owns exactly its GPU
+    os.environ.pop("KS265_GPUS", None); os.environ.pop("KS265_DEVICES", None)
     cfg = (C.c_uint8 * lay["sizeof_config"])()
     preset = b"slow" if args.me == "umh" and args.me_hex_thr == 16 else b"veryslow" if args.me == "umh" else b"medium"
     assert lib.QY265ConfigDefaultPreset(cfg, preset, None, b"default") == 0

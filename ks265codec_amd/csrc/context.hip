@@ -51,6 +51,7 @@ int ks265_set_stream(ks265_ctx *c, void *s)
 int ks265_synchronize(ks265_ctx *c)
 {
     if (!c) return KS265_POINTER;
+    ks_use_device(c);
     int r = ks265_hip(c, hipStreamSynchronize(c->stream));
     if (r) return r;
     const unsigned e = __atomic_exchange_n(c->err_host, 0u, __ATOMIC_ACQ_REL);      // kernels OR bits in; report once, then clear
@@ -114,16 +115,19 @@ int ks265_host_free(ks265_ctx *c, void *host)
 int ks265_memcpy_h2d_async(ks265_ctx *c, void *dev, const void *host, size_t bytes)
 {
     if (!c || !dev || !host) return KS265_POINTER;
+    ks_use_device(c);
     return ks265_hip(c, hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, c->stream));
 }
 int ks265_memcpy_d2h_async(ks265_ctx *c, void *host, const void *dev, size_t bytes)
 {
     if (!c || !dev || !host) return KS265_POINTER;
+    ks_use_device(c);
     return ks265_hip(c, hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, c->stream));
 }
 int ks265_memcpy_d2d_async(ks265_ctx *c, void *dst, const void *src, size_t bytes)
 {
     if (!c || !dst || !src) return KS265_POINTER;
+    ks_use_device(c);
     return ks265_hip(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->stream));
 }
 // Device-to-host copy as a kernel with a SMALL grid writing straight into device-mapped pinned host memory: the runtime's own device-to-host copies
@@ -137,6 +141,7 @@ __global__ __launch_bounds__(256) void copy_out_kernel(uint4 *dst, const uint4 *
 int ks265_copy_out_async(ks265_ctx *c, void *pinned_host, const void *dev, size_t bytes)
 {
     if (!c || !dev || !pinned_host) return KS265_POINTER;
+    ks_use_device(c);
     if (((uintptr_t)pinned_host | (uintptr_t)dev) & 15) return ks265_hip(c, hipMemcpyAsync(pinned_host, dev, bytes, hipMemcpyDeviceToHost, c->stream));
     const size_t n16 = bytes >> 4;
     hipLaunchKernelGGL(copy_out_kernel, dim3(32), dim3(256), 0, c->stream, (uint4 *)pinned_host, (const uint4 *)dev, n16, (unsigned char *)pinned_host + (n16 << 4),
@@ -146,6 +151,7 @@ int ks265_copy_out_async(ks265_ctx *c, void *pinned_host, const void *dev, size_
 int ks265_memset_async(ks265_ctx *c, void *dev, int value, size_t bytes)
 {
     if (!c || !dev) return KS265_POINTER;
+    ks_use_device(c);
     return ks265_hip(c, hipMemsetAsync(dev, value, bytes, c->stream));
 }
 /* an event on the context's stream: record now, wait later from any host thread (pipelined hosts: "picture n has left the GPU") */
@@ -158,17 +164,18 @@ int ks265_event_create(ks265_ctx *c, void **ev)
     *ev = r ? nullptr : (void *)e;
     return r;
 }
-int ks265_event_record(ks265_ctx *c, void *ev) { return (!c || !ev) ? KS265_POINTER : ks265_hip(c, hipEventRecord((hipEvent_t)ev, c->stream)); }
+int ks265_event_record(ks265_ctx *c, void *ev) { if (!c || !ev) return KS265_POINTER; ks_use_device(c); return ks265_hip(c, hipEventRecord((hipEvent_t)ev, c->stream)); }
 int ks265_event_wait(ks265_ctx *c, void *ev) { return (!c || !ev) ? KS265_POINTER : ks265_hip(c, hipEventSynchronize((hipEvent_t)ev)); }
 /* make everything enqueued on c's stream AFTER this call wait for the event (recorded on another context's stream): the hand-over between the
  * copy-in, compute and copy-out streams of a pipelined host; no host thread blocks */
-int ks265_stream_wait_event(ks265_ctx *c, void *ev) { return (!c || !ev) ? KS265_POINTER : ks265_hip(c, hipStreamWaitEvent(c->stream, (hipEvent_t)ev, 0)); }
-int ks265_capture_begin(ks265_ctx *c) { return !c ? KS265_POINTER : ks265_hip(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed)); }
+int ks265_stream_wait_event(ks265_ctx *c, void *ev) { if (!c || !ev) return KS265_POINTER; ks_use_device(c); return ks265_hip(c, hipStreamWaitEvent(c->stream, (hipEvent_t)ev, 0)); }
+int ks265_capture_begin(ks265_ctx *c) { if (!c) return KS265_POINTER; ks_use_device(c); return ks265_hip(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed)); }
 int ks265_capture_end(ks265_ctx *c, void **graph_exec)
 {
     if (!c || !graph_exec) return KS265_POINTER;
     *graph_exec = nullptr;
     hipGraph_t g = nullptr;
+    ks_use_device(c);
     int r = ks265_hip(c, hipStreamEndCapture(c->stream, &g));
     if (r || !g) return r ? r : KS265_FAIL;
     hipGraphExec_t ex = nullptr;
@@ -177,7 +184,7 @@ int ks265_capture_end(ks265_ctx *c, void **graph_exec)
     if (!r) *graph_exec = (void *)ex;
     return r;
 }
-int ks265_graph_launch(ks265_ctx *c, void *graph_exec) { return (!c || !graph_exec) ? KS265_POINTER : ks265_hip(c, hipGraphLaunch((hipGraphExec_t)graph_exec, c->stream)); }
+int ks265_graph_launch(ks265_ctx *c, void *graph_exec) { if (!c || !graph_exec) return KS265_POINTER; ks_use_device(c); return ks265_hip(c, hipGraphLaunch((hipGraphExec_t)graph_exec, c->stream)); }
 int ks265_graph_destroy(ks265_ctx *c, void *graph_exec) { return (!c || !graph_exec) ? KS265_POINTER : ks265_hip(c, hipGraphExecDestroy((hipGraphExec_t)graph_exec)); }
 int ks265_event_destroy(ks265_ctx *c, void *ev) { return (!c || !ev) ? KS265_POINTER : ks265_hip(c, hipEventDestroy((hipEvent_t)ev)); }
 

@@ -411,6 +411,7 @@ int ks265_frame_pack_compact(ks265_frame *f, void *dev_dst, const void *dev_extr
 int ks265_copy_out_compact_async(ks265_ctx *ctx, ks265_frame *f, void *pinned_host, const void *dev_block)
 {
     if (!ctx || !f || !pinned_host || !dev_block) return KS265_POINTER;
+    ks_use_device(ctx);
     size_t off[8];
     compact_layout(f, off);
     hipLaunchKernelGGL(copy_out_compact_kernel, dim3(32), dim3(256), 0, ctx->stream, (uint4 *)pinned_host, (const uint4 *)dev_block, (unsigned long long)(off[6] / 16),
@@ -420,6 +421,7 @@ int ks265_copy_out_compact_async(ks265_ctx *ctx, ks265_frame *f, void *pinned_ho
 int ks265_copy_out_compact_flag_async(ks265_ctx *ctx, ks265_frame *f, void *pinned_host, const void *dev_block, uint32_t *dev_counter, volatile uint32_t *pinned_flag, uint32_t value)
 {
     if (!ctx || !f || !pinned_host || !dev_block || !dev_counter || !pinned_flag) return KS265_POINTER;
+    ks_use_device(ctx);
     size_t off[8];
     compact_layout(f, off);
     hipLaunchKernelGGL(copy_out_compact_flag_kernel, dim3(32), dim3(256), 0, ctx->stream, (uint4 *)pinned_host, (const uint4 *)dev_block, (unsigned long long)(off[6] / 16),

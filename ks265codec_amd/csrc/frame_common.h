@@ -83,4 +83,6 @@ __device__ __forceinline__ void ctu_mv_limits(const KsGeom &g, int range, int cx
 
 int ks265_frame_build_matrices(ks265_frame *f);      // frame_recon.hip
 
-#define KS_FRAME_CHECK(f) do { if (!(f) || !(f)->ctx) return KS265_POINTER; } while (0)
+// every frame-level entry point: the calling thread's current device is the frame's (a host with one encoder lane per GPU drives several devices from several
+// threads; kernel launches go to the CURRENT device's streams only)
+#define KS_FRAME_CHECK(f) do { if (!(f) || !(f)->ctx) return KS265_POINTER; ks_use_device((f)->ctx); } while (0)

@@ -19,6 +19,9 @@ struct ks265_ctx {
 };
 #define KS_DEVERR_WAVEFRONT_TIMEOUT 1u           // intra wavefront: the CTU row above did not make progress in time
 
+// make the context's device the calling thread's current device (the runtime keeps it per thread; setting the device that is already current costs a
+// thread-local compare inside the runtime - no caching here: several translation units and direct hipSetDevice calls would defeat it)
+static inline void ks_use_device(const ks265_ctx *ctx) { (void)hipSetDevice(ctx->device); }
 // record a HIP error (if any) from the launch just issued; kernels are asynchronous, so this only
 // catches launch-configuration errors — execution errors surface at ks265_synchronize()
 static inline int ks265_check_launch(ks265_ctx *ctx)

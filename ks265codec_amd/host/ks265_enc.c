@@ -928,7 +928,7 @@ static void lane_close(Enc *e, int report)
     free(e);
 }
 
-static Enc *lane_open(QY265EncConfig *cfg, int *err)
+static Enc *lane_open(QY265EncConfig *cfg, int device, int *err)
 {
     int dummy; if (!err) err = &dummy;
     *err = QY_OK;
@@ -959,10 +959,9 @@ static Enc *lane_open(QY265EncConfig *cfg, int *err)
     if (cfg->rdoq || cfg->transskip || cfg->part || cfg->iAqMode) logf_(1, e->log_level, "ks265enc: rdoq / transskip / part / aq are accepted but not implemented by the pixel path\n");
     if (cfg->rc == 5 || cfg->vbv_buffer_size) logf_(1, e->log_level, "ks265enc: CVQ / VBV are not implemented; running the plain controller\n");
 
-    /* the SDK's config has no device field: one encoder = one GPU, chosen by KS265_DEVICE (default 0); N GPUs = N processes or N handles,
-     * each on its own closed GOPs */
-    const char *dev_env = getenv("KS265_DEVICE");
-    int r = ks265_create(&e->ctx, dev_env ? atoi(dev_env) : 0);
+    /* the SDK's config has no device field: the lane's GPU comes from the handle (KS265_DEVICE: one GPU, default 0; KS265_GPUS / KS265_DEVICES: closed GOPs dealt
+     * to lanes on several GPUs, QY265EncoderOpen) */
+    int r = ks265_create(&e->ctx, device);
     if (r) { *err = hip_rc(r); lane_close(e, 0); return NULL; }       /* KS265_NO_DEVICE -> QY_FAIL: there is no CPU fallback */
     memset(&e->fcfg, 0, sizeof e->fcfg);
     e->fcfg.width = e->W; e->fcfg.height = e->H; e->fcfg.qp = e->base_qp; e->fcfg.lambda_q4 = kLambdaQ4[e->base_qp];
@@ -977,7 +976,7 @@ static Enc *lane_open(QY265EncConfig *cfg, int *err)
     r = ks265_frame_geometry(&e->fcfg, &e->geom);
     if (!r) r = ks265_frame_create(e->ctx, &e->fcfg, &e->frame);
     const size_t fsz = (size_t)e->W * e->H * 3 / 2, npx = (size_t)e->W * e->H;
-    const int dev_id = dev_env ? atoi(dev_env) : 0;
+    const int dev_id = device;
     if (!r) r = ks265_frame_compact_layout(e->frame, e->cmp_off);
     if (!r) r = ks265_create(&e->ctx_in, dev_id);
     if (!r) r = ks265_create(&e->ctx_out, dev_id);
@@ -1062,7 +1061,7 @@ static Enc *lane_open(QY265EncConfig *cfg, int *err)
     if (e->nth && !pthread_create(&e->disp, NULL, dispatcher, e)) e->disp_on = 1;
     if (e->disp_on && !pthread_create(&e->sched, NULL, scheduler, e)) e->sched_on = 1;
     if (!e->nth || !e->disp_on || !e->sched_on) { *err = QY_FAIL; lane_close(e, 0); return NULL; }
-    logf_(0, e->log_level, "ks265enc: %dx%d %.2f fps, qp %d, -me %d (hex below %d), subme %d, refs %d, %s, sao %d, key period %d, %d slice writer threads, %s\n", e->W, e->H,
+    logf_(0, e->log_level, "ks265enc: GPU %d: %dx%d %.2f fps, qp %d, -me %d (hex below %d), subme %d, refs %d, %s, sao %d, key period %d, %d slice writer threads, %s\n", device, e->W, e->H,
           cfg->frameRate, e->base_qp, e->me_method, e->hex_thr, e->subme, e->refs, e->hier ? "hierarchical-B GOP 8" : e->gop_b ? "P + non-reference B" : "IPPP", e->use_sao, e->iper,
           e->nth, ks265_version());
     return e;
@@ -1214,7 +1213,7 @@ static int lane_set_recon_file(Enc *e, const char *path)
  * Off by default (KS265_GOP_LANES = 2..4 switches it on): measured at 2160p on the round-2 box, two lanes reach 1.05x of one (1123 vs 1068 frames/s) -
  * with twice the pictures in flight the slice writers, not the GPU, set the pace (their time per picture grows from 19 to 59 ms of thread time as the
  * threads spread over the host), DESIGN.md section 6. */
-#define MAX_LANES 4
+#define MAX_LANES 16
 #define MAX_CHUNKS 64
 typedef struct Chunk { int lane, closed; long count, delivered, base; int disp0; /* the lane's own display index of the GOP's first picture */ } Chunk;
 typedef struct Top {
@@ -1316,13 +1315,33 @@ static void top_close_chunk(Top *t, int early)
     }
 }
 
-static int top_lanes_wanted(const QY265EncConfig *cfg)
+/* The GPUs of this handle: KS265_DEVICES = "0,2,5" (an explicit list) or KS265_GPUS = N (devices 0 .. N - 1; the CLI's -gpus N), else KS265_DEVICE / 0.
+ * Closed GOPs are independent ("frames / GOPs shard naturally across the GPUs of one node", no data-path collective), so a GPU is simply another
+ * GOP lane: lane i runs on device dev[i mod ndev], KS265_GOP_LANES lanes per GPU.  The stream is byte for byte the one-GPU stream. */
+static int top_devices(int dev[MAX_LANES])
+{
+    int n = 0;
+    const char *list = getenv("KS265_DEVICES"), *cnt = getenv("KS265_GPUS"), *one = getenv("KS265_DEVICE");
+    if (list && *list) {
+        const char *p = list;
+        while (*p && n < MAX_LANES) {
+            char *end; const long v = strtol(p, &end, 10);
+            if (end == p) break;
+            if (v >= 0 && v < 1024) dev[n++] = (int)v;
+            p = *end == ',' ? end + 1 : end;
+        }
+    } else if (cnt && atoi(cnt) > 0) { for (int i = 0; i < atoi(cnt) && i < MAX_LANES; ++i) dev[n++] = i; }
+    if (!n) dev[n++] = one ? atoi(one) : 0;
+    return n;
+}
+static int top_lanes_wanted(const QY265EncConfig *cfg, int ndev)
 {
     const char *env = getenv("KS265_GOP_LANES");
-    int n = env ? atoi(env) : 1;
-    if (n < 1) n = 1;
+    int per = env ? atoi(env) : 1;
+    if (per < 1) per = 1;
+    int n = per * ndev;
     if (n > MAX_LANES) n = MAX_LANES;
-    if (!cfg->enFrameParallel || cfg->rc != 0 || cfg->iIntraPeriod < 32 || g_cli.md5) n = 1;    /* -md5 lines are in one display order */
+    if (!cfg->enFrameParallel || cfg->rc != 0 || cfg->iIntraPeriod < 32 || g_cli.md5) n = 1;    /* the controllers carry state across GOPs; -md5 lines are in one display order */
     return n;
 }
 
@@ -1333,19 +1352,24 @@ void *QY265EncoderOpen(QY265EncConfig *cfg, int *err)
     if (!cfg) { *err = QY_POINTER; return NULL; }
     Top *t = (Top *)calloc(1, sizeof *t);
     if (!t) { *err = QY_OUTOFMEMORY; return NULL; }
-    t->nlanes = top_lanes_wanted(cfg);
+    int dev[MAX_LANES];
+    const int ndev = top_devices(dev);
+    t->nlanes = top_lanes_wanted(cfg, ndev);
+    if (ndev > 1 && t->nlanes == 1) logf_(2, cfg->logLevel, "ks265enc: %d GPUs asked for, but GOP sharding needs enFrameParallel, -rc 0 and a key period >= 32: one GPU\n", ndev);
     t->iper = cfg->iIntraPeriod; t->cur_lane = -1;
     QY265EncConfig lc = *cfg;
     if (t->nlanes > 1) {                                                /* the writer threads are shared out: every lane sees 1 / L of the pictures */
         long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
-        int th = cfg->threads > 0 ? cfg->threads : (int)(ncpu > 0 ? ncpu : 4);
-        if (th > 64) th = 64;
-        lc.threads = (th + t->nlanes - 1) / t->nlanes;
+        /* the host's threads are the budget: every lane also runs a scheduler, a dispatcher (polling) and shares the copy helpers - three service threads apiece;
+         * what is left is dealt to the lanes as slice writers, at most 32 each (one GPU's pictures keep about that many busy) */
+        const int th = cfg->threads > 0 ? cfg->threads : (int)(ncpu > 0 ? ncpu : 4) - 3 * t->nlanes;    /* an explicit -threads is the total */
+        lc.threads = th / t->nlanes;
+        if (lc.threads > 32) lc.threads = 32;
         if (lc.threads < 2) lc.threads = 2;
     }
     for (int i = 0; i < t->nlanes; ++i) {
         if (i) lc.logLevel = cfg->logLevel > 2 ? cfg->logLevel : 3;     /* one start-up line */
-        t->lane[i] = lane_open(&lc, err);
+        t->lane[i] = lane_open(&lc, dev[i % ndev], err);
         if (!t->lane[i]) {
             if (i == 0) { free(t); return NULL; }
             t->nlanes = i;                                              /* e.g. out of memory for another pipeline: go on with the lanes there are */
@@ -1355,7 +1379,7 @@ void *QY265EncoderOpen(QY265EncConfig *cfg, int *err)
     }
     if ((size_t)cfg->picWidth * cfg->picHeight >= ((size_t)1 << 20)) t->pool = copy_pool_create();
     for (int i = 0; i < t->nlanes; ++i) t->lane[i]->pool = t->pool;
-    if (t->nlanes > 1) logf_(0, cfg->logLevel, "ks265enc: %d GOP lanes (closed GOPs of %d pictures coded concurrently, output in GOP order)\n", t->nlanes, t->iper);
+    if (t->nlanes > 1) logf_(0, cfg->logLevel, "ks265enc: %d GOP lanes on %d GPU(s) (closed GOPs of %d pictures coded concurrently, output in GOP order)\n", t->nlanes, ndev < t->nlanes ? ndev : t->nlanes, t->iper);
     return t;
 }
 

@@ -8,6 +8,7 @@
 #include "ks265_hip.h"
 #include "../oracle/ks265_pipeline_oracle.h"
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -23,7 +24,14 @@ struct ks265_frame {
 
 const char *ks265_version(void) { return "ks265hip CPU stub (tests only)"; }
 const char *ks265_last_error(ks265_ctx *c) { (void)c; return "stub"; }
-int ks265_create(ks265_ctx **out, int device) { (void)device; if (getenv("KS265_STUB_NO_DEVICE")) return KS265_NO_DEVICE; *out = (ks265_ctx *)calloc(1, sizeof **out); return *out ? KS265_OK : KS265_OUTOFMEMORY; }
+int ks265_create(ks265_ctx **out, int device)
+{
+    const char *nd = getenv("KS265_STUB_DEVICES");                     /* how many GPUs the stand-in "has" (default 8) */
+    if (getenv("KS265_STUB_NO_DEVICE") || device < 0 || device >= (nd ? atoi(nd) : 8)) return KS265_NO_DEVICE;
+    if (getenv("KS265_STUB_LOG_DEVICES")) fprintf(stderr, "stub: context on device %d\n", device);
+    *out = (ks265_ctx *)calloc(1, sizeof **out);
+    return *out ? KS265_OK : KS265_OUTOFMEMORY;
+}
 void ks265_destroy(ks265_ctx *c) { if (c) { free(c->ops); free(c); } }
 int ks265_synchronize(ks265_ctx *c) { (void)c; return KS265_OK; }
 int ks265_take_device_error(ks265_ctx *c) { (void)c; return KS265_OK; }

@@ -72,6 +72,12 @@ def test_gop_lanes_write_the_one_lane_stream(tmp_path, W, H, n, iper):
         assert ("GOP lanes" in (r.stdout + r.stderr)) == (lanes > 1), r.stdout[:600] + r.stderr[:600]      # switched on by KS265_GOP_LANES only
         md5[lanes] = hashlib.md5(open(out, "rb").read()).hexdigest()
     assert md5[1] == md5[2] == md5[3], md5
+    # the same lanes reached through the device list (one handle, N GPUs: KS265_DEVICES / ks265enc -gpus N); this box has one GPU, so the list names it twice
+    out = tmp_path / "dev.265"
+    r = subprocess.run([stream.CLI, "-i", str(yuv), "-wdt", str(W), "-hgt", str(H), "-fr", "50", "-preset", "slow", "-rc", "0", "-qp", "30", "-iper", str(iper), "-bframes", "0",
+                        "-threads", "6", "-psnr", "1", "-b", str(out)], capture_output=True, text=True, env=dict(os.environ, KS265_DEVICES="0,0"))
+    assert r.returncode == 0 and "2 GOP lanes on 2 GPU(s)" in (r.stdout + r.stderr), r.stdout[-400:] + r.stderr[-400:]
+    assert hashlib.md5(open(out, "rb").read()).hexdigest() == md5[1]
     if os.path.exists(REF_DEC):
         d = subprocess.run([REF_DEC, "-b", str(tmp_path / "l2.265"), "-o", str(tmp_path / "d.yuv"), "-threads", "2"], capture_output=True, text=True, cwd=tmp_path)
         assert d.returncode == 0 and os.path.getsize(tmp_path / "d.yuv") == n * W * H * 3 // 2, d.stdout[-300:] + d.stderr[-300:]

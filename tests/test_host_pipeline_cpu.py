@@ -206,3 +206,24 @@ def test_cli_prints_the_reference_per_picture_and_md5_lines(stub_lib, tmp_path):
     assert any(re.fullmatch(r"Total Frames: 12, test time: \d+ms, FPS: [\d.]+", ln) for ln in lines)
     assert any(re.fullmatch(r"Total Frames: 12, pure encoding time: \d+ms, [\d.]+ fps", ln) for ln in lines)
     assert any(re.fullmatch(r"bitrate, psnr: [\d.]+\t[\d.]+\t[\d.]+\t[\d.]+", ln) for ln in lines), [ln for ln in lines if "psnr" in ln]
+
+
+def test_gops_dealt_to_several_gpus_behind_one_handle(stub_lib, tmp_path):
+    """one handle, N GPUs - KS265_GPUS = N (the CLI's -gpus N) or KS265_DEVICES = list makes every GPU a GOP lane (closed GOPs, no data-path
+    collective: SURVEY.md 8e); the stream is byte for byte the one-GPU stream, every listed device gets a context, a device the box does not have fails the open"""
+    one = run(stub_lib, 200, 32, 0, out=tmp_path / "g1.265")
+    for env in ({"KS265_GPUS": 2}, {"KS265_GPUS": 4}, {"KS265_DEVICES": "3,5"}, {"KS265_GPUS": 2, "KS265_GOP_LANES": 2}):
+        e = dict(os.environ, KS265_STUB_LIB=stub_lib, KS265_STUB_LOG_DEVICES="1", **{k: str(v) for k, v in env.items()})
+        r = subprocess.run([sys.executable, os.path.join(HERE, "host_driver.py"), ROOT, "200", "32", "0", "128", "72"], capture_output=True, text=True, timeout=120, env=e)
+        assert r.returncode == 0, r.stdout[-400:] + r.stderr[-800:]
+        res = json.loads(r.stdout.strip().splitlines()[-1])
+        devs = {int(ln.rsplit(" ", 1)[1]) for ln in r.stderr.splitlines() if ln.startswith("stub: context on device")}
+        want = {3, 5} if "KS265_DEVICES" in env else set(range(env["KS265_GPUS"]))
+        assert devs == want, (env, devs)
+        assert res["lanes"] == len(want) * int(env.get("KS265_GOP_LANES", 1)) and res["md5"] == one["md5"] and res["pts"] == list(range(200)), env
+    for bframes in (-1, 3):                                                  # B-picture GOPs shard the same way
+        a, b = run(stub_lib, 150, 32, bframes), run(stub_lib, 150, 32, bframes, KS265_GPUS=3)
+        assert b["lanes"] == 3 and a["md5"] == b["md5"]
+    e = dict(os.environ, KS265_STUB_LIB=stub_lib, KS265_GPUS="2", KS265_STUB_DEVICES="1")
+    r = subprocess.run([sys.executable, os.path.join(HERE, "host_driver.py"), ROOT, "40", "32", "0", "128", "72"], capture_output=True, text=True, timeout=120, env=e)
+    assert r.returncode == 0 and json.loads(r.stdout.strip().splitlines()[-1])["lanes"] == 1      # the second GPU is not there: the handle goes on with the lanes it has
