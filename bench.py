@@ -125,7 +125,7 @@ def main():
         tstream = None if sidx == 0 else torch.cuda.Stream(device=dev_index)
         with (torch.cuda.stream(tstream) if tstream is not None else contextlib.nullcontext()):
             ks = KsContext(dev_index)
-            fr = KsFrame(ks, W, H, qp, lambda_q4(qp), me_method=me_method, me_hex_thr=(args.me_hex_thr if me_method == 2 else 0), bframes=max(args.bframes, args.hier_b - 1 if args.hier_b else 0), refs=max(1, args.refs), sdh=1, pre_search=0 if args.no_pre_search else 1, merge=1, bi_refine=1, rdo=4)
+            fr = KsFrame(ks, W, H, qp, lambda_q4(qp), me_method=me_method, me_hex_thr=(args.me_hex_thr if me_method == 2 else 0), bframes=max(args.bframes, args.hier_b - 1 if args.hier_b else 0), refs=max(1, args.refs), sdh=1, pre_search=0 if args.no_pre_search else 1, merge=1, bi_refine=1, rdo=4, intra_inter=1)
             # synthetic clip of SURVEY.md §8(d), one GOP shard per stream (different seed per shard = different content)
             clip = make_clip(W, H, args.clip_frames, seed=7 + (0 if args.b_spread else rank * nstreams + sidx), abc=(67, 91, 33), pan=(8, 5))
             dev_clip = [ks.dev(c) for c in clip]
@@ -379,7 +379,7 @@ def port_leg(args, clip, order, me_method):
     from oracle_lib import OraclePipeline
     from ks265codec_amd.synth import lambda_q4
     W, H, qp = args.width, args.height, args.qp
-    o = OraclePipeline(W, H, qp, lambda_q4(qp), me_method=me_method, me_hex_thr=(args.me_hex_thr if me_method == 2 else 0), sdh=1, pre_search=0 if args.no_pre_search else 1, merge=1, bi_refine=1, rdo=4)
+    o = OraclePipeline(W, H, qp, lambda_q4(qp), me_method=me_method, me_hex_thr=(args.me_hex_thr if me_method == 2 else 0), sdh=1, pre_search=0 if args.no_pre_search else 1, merge=1, bi_refine=1, rdo=4, intra_inter=1)
     nbase = 3
     tc0 = time.perf_counter()
     if args.bframes == 0:
@@ -463,7 +463,7 @@ def encoded_leg(args, torch, dist, rank, world, dev_index, backend, sync_all):
     class Stats(C.Structure):
         _fields_ = [("frames", C.c_long), ("bytes", C.c_longlong), ("sse", C.c_double * 3), ("gpu_ms", C.c_double), ("host_write_ms", C.c_double),
                     ("in_copy_ms", C.c_double), ("submit_ms", C.c_double), ("output_ms", C.c_double), ("lat_gpu_ms", C.c_double), ("lat_queue_ms", C.c_double), ("key_wall_ms", C.c_double), ("key_cpu_ms", C.c_double), ("keys", C.c_long),
-                    ("occ_samples", C.c_long), ("occ_ring", C.c_long), ("occ_gpu", C.c_long), ("occ_ready", C.c_long)]
+                    ("occ_samples", C.c_long), ("occ_ring", C.c_long), ("occ_gpu", C.c_long), ("occ_ready", C.c_long), ("submit_wait_ms", C.c_double)]
 
     W, H = args.width, args.height
     try:
@@ -645,7 +645,7 @@ def encoded_leg(args, torch, dist, rank, world, dev_index, backend, sync_all):
     win["A"]["fps_all_ranks"] = round(world * win["A"]["pictures"] / win["A"]["seconds"], 2)
     return {"fps": world * npic / dt, "dt": dt * args.steps / npic, "windows": win, "gop_lanes": lanes, "host_threads": threads, "host_cores": cores, "bytes_per_picture": st.bytes / max(1, st.frames),
             "psnr_y": 99.0 if mse == 0 else 10.0 * np.log10(255.0 ** 2 / mse), "slice_write_ms_per_picture": st.host_write_ms / max(1, st.frames), "preset": preset.decode(),
-            "caller_ms_per_picture": {"input_copy": round(st.in_copy_ms / max(1, st.frames), 3), "enqueue": round(st.submit_ms / max(1, st.frames), 3), "output": round(st.output_ms / max(1, st.frames), 3),
+            "caller_ms_per_picture": {"input_copy": round(st.in_copy_ms / max(1, st.frames), 3), "enqueue": round((st.submit_ms - st.submit_wait_ms) / max(1, st.frames), 3), "enqueue_waiting_for_ring_space": round(st.submit_wait_ms / max(1, st.frames), 3), "output": round(st.output_ms / max(1, st.frames), 3),
                                       "latency_enqueue_to_records_on_host": round(st.lat_gpu_ms / max(1, st.frames), 2), "latency_enqueue_to_writer_pickup": round(st.lat_queue_ms / max(1, st.frames), 2),
                                       "key_picture_slice_wall_ms": round(st.key_wall_ms / max(1, st.keys), 2), "key_picture_slice_thread_ms": round(st.key_cpu_ms / max(1, st.keys), 2),
                                       "ring_occupancy_at_submission": {"in_ring": round(st.occ_ring / max(1, st.occ_samples), 1), "not_through_gpu": round(st.occ_gpu / max(1, st.occ_samples), 1),

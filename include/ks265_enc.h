@@ -87,6 +87,7 @@ typedef struct { long frames; long long bytes; double sse[3]; double gpu_ms; dou
                  double lat_gpu_ms, lat_queue_ms;           /* summed per picture: enqueue -> records on the host; enqueue -> a writer thread picked the picture up */
                  double key_wall_ms, key_cpu_ms; long keys; /* key pictures: records on the host -> slice finished (wall), summed thread time of its rows */
                  long occ_samples, occ_ring, occ_gpu, occ_ready;   /* sampled at every submission: pictures in the ring, of them not yet through the GPU, of them waiting for a writer */
+                 double submit_wait_ms;                     /* the part of submit_ms the scheduler thread spent WAITING for a free ring slot (not runtime calls) */
 } ks265_enc_stats;
 int ks265_enc_get_stats(void *pEncoder, ks265_enc_stats *out);
 /* extension: closed GOPs coded concurrently by this handle ("GOP lanes": KS265_GOP_LANES = 2..4 with enFrameParallel, -rc 0, key period >= 32, any GOP structure;

@@ -44,6 +44,9 @@ int ks265_frame_create(ks265_ctx *ctx, const ks265_frame_cfg *cfg, ks265_frame *
         r = dev_alloc(ctx, (void **)&f->pu_x[x], (size_t)geom.bytes_pu, true);
     }
     if (cfg->refs > 1 && !f->pub && !r) r = dev_alloc(ctx, (void **)&f->pub, (size_t)geom.ctu_cols * geom.ctu_rows * 85 * sizeof(ks265_pu_b), true);
+    if (!r && cfg->intra_inter) {                                  /* intra candidates of P / B pictures: cost and mode of every block */
+        r = dev_alloc(ctx, (void **)&f->icost, (size_t)geom.ctu_cols * geom.ctu_rows * 85 * sizeof(uint32_t), true);
+    }
     if (!r) r = dev_alloc(ctx, (void **)&f->cu8, (size_t)geom.bytes_cu8, true);
     if (!r && cfg->merge) r = dev_alloc(ctx, (void **)&f->cu8_tmp, (size_t)geom.bytes_cu8, true);
     if (!r) r = dev_alloc(ctx, (void **)&f->sao, (size_t)geom.bytes_sao, true);
@@ -55,7 +58,7 @@ int ks265_frame_create(ks265_ctx *ctx, const ks265_frame_cfg *cfg, ks265_frame *
     if (!r) r = dev_alloc(ctx, (void **)&f->deb[2], (size_t)g.bytes_c, true);
     if (!r) r = dev_alloc(ctx, (void **)&f->sse, 3 * sizeof(unsigned long long), true);
     if (!r) r = dev_alloc(ctx, (void **)&f->sse_acc, 4 * sizeof(unsigned long long), true);
-    if (!r) r = dev_alloc(ctx, (void **)&f->progress, sizeof(int) * (size_t)g.ctu_rows, true);
+    if (!r) r = dev_alloc(ctx, (void **)&f->progress, sizeof(int) * (size_t)g.ctu_rows * g.ctu_cols, true);   /* intra wavefront flags: per CTU row (key pictures), per CTU (cfg.intra_inter) */
     if (!r) r = dev_alloc(ctx, (void **)&f->mats, sizeof(short) * 2 * 1600, true);      /* 2 x MAT_SHORTS (recon_dev.h) */
     if (!r) r = ks265_frame_build_matrices(f);
     if (r) { ks265_frame_destroy(f); return r; }
@@ -69,7 +72,7 @@ void ks265_frame_destroy(ks265_frame *f)
     if (f->ctx) { (void)hipSetDevice(f->ctx->device); (void)hipStreamSynchronize(f->ctx->stream); }
     for (int i = 0; i <= KS_NSTAGE; ++i)
         if (f->ev[i]) (void)hipEventDestroy(f->ev[i]);
-    void *ptrs[] = {f->pu1, f->pub, f->pu[0], f->pu[1], f->cu8, f->sao, f->lvl[0], f->lvl[1], f->lvl[2], f->deb[0], f->deb[1], f->deb[2], f->sse, f->sse_acc, f->cu8_tmp, f->progress, f->mats, f->pu_x[0], f->pu_x[1], f->pu_x[2]};
+    void *ptrs[] = {f->pu1, f->pub, f->pu[0], f->pu[1], f->cu8, f->sao, f->lvl[0], f->lvl[1], f->lvl[2], f->deb[0], f->deb[1], f->deb[2], f->sse, f->sse_acc, f->cu8_tmp, f->progress, f->mats, f->icost, f->pu_x[0], f->pu_x[1], f->pu_x[2]};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (uint8_t *p : f->pyr)
@@ -115,12 +118,15 @@ int ks265_encode_picture(ks265_frame *f, ks265_pic src, ks265_pic ref, int is_ke
         mark(2);
         if (f->cfg.subme && (r = ks265_me_subpel(f, src, ref, pu))) return r;
         mark(3);
+        const bool ii = f->cfg.intra_inter != 0;              /* intra CUs may compete: their candidates first */
+        if (ii && (r = ks265_intra_candidates(f, src, pu, f->icost))) return r;
         if (f->cfg.merge) {                                    /* stage C2: the CU decision goes to the spare map, the merge pass writes the final one */
-            if ((r = ks265_cu_decide(f, pu, f->cu8_tmp))) return r;
+            if ((r = ks265_cu_decide_ii(f, pu, ii ? f->icost : nullptr, f->cu8_tmp))) return r;
             if ((r = ks265_merge_pass(f, src, ref, ks265_pic{nullptr, nullptr, nullptr}, pu, nullptr, f->cu8_tmp, f->cu8))) return r;
-        } else if ((r = ks265_cu_decide(f, pu, f->cu8))) return r;
+        } else if ((r = ks265_cu_decide_ii(f, pu, ii ? f->icost : nullptr, f->cu8))) return r;
         mark(4);
         if ((r = ks265_reconstruct(f, src, ref, f->cu8, f->lvl[0], f->lvl[1], f->lvl[2], deb))) return r;
+        if (ii && (r = ks265_intra_inter_reconstruct(f, src, f->cu8, f->lvl[0], f->lvl[1], f->lvl[2], deb))) return r;
     }
     mark(5);
     if (f->cfg.deblock && (r = ks265_deblock(f, f->cu8, deb))) return r;
@@ -172,12 +178,15 @@ int ks265_encode_picture_b(ks265_frame *f, ks265_pic src, ks265_pic ref0, ks265_
     if ((r = ks265_me_integer(f, src, ref1, nullptr, f->pu1))) return r;
     if (f->cfg.subme && (r = ks265_me_subpel(f, src, ref1, f->pu1))) return r;
     if ((r = ks265_bi_decide(f, src, ref0, ref1, pu0, f->pu1, f->pub))) return r;
+    const bool ii = f->cfg.intra_inter != 0;
+    if (ii && (r = ks265_intra_candidates(f, src, f->pub, f->icost))) return r;
     if (f->cfg.merge) {
-        if ((r = ks265_cu_decide_b(f, f->pub, f->cu8_tmp))) return r;
+        if ((r = ks265_cu_decide_b_ii(f, f->pub, ii ? f->icost : nullptr, f->cu8_tmp))) return r;
         if ((r = ks265_merge_pass(f, src, ref0, ref1, nullptr, f->pub, f->cu8_tmp, f->cu8))) return r;
-    } else if ((r = ks265_cu_decide_b(f, f->pub, f->cu8))) return r;
+    } else if ((r = ks265_cu_decide_b_ii(f, f->pub, ii ? f->icost : nullptr, f->cu8))) return r;
     ks265_pic deb = ks_deb_pic(f);
     if ((r = ks265_reconstruct_b(f, src, ref0, ref1, f->cu8, f->lvl[0], f->lvl[1], f->lvl[2], deb))) return r;
+    if (ii && (r = ks265_intra_inter_reconstruct(f, src, f->cu8, f->lvl[0], f->lvl[1], f->lvl[2], deb))) return r;
     if (f->cfg.deblock && (r = ks265_deblock(f, f->cu8, deb))) return r;
     return ks265_sao(f, src, deb, f->sao, recon_out);
 }
@@ -233,6 +242,7 @@ int ks265_frame_stage_ms(ks265_frame *f, float ms[7])
 int16_t *ks265_frame_levels(ks265_frame *f, int comp) { return f && comp >= 0 && comp < 3 ? f->lvl[comp] : nullptr; }
 ks265_pu *ks265_frame_pu(ks265_frame *f) { return f ? f->pu[f->cur_pu ^ (f->have_prev ? 1 : 0)] : nullptr; }   /* records of the last coded P picture */
 ks265_cu8 *ks265_frame_cu8(ks265_frame *f) { return f ? f->cu8 : nullptr; }
+uint32_t *ks265_frame_ibest(ks265_frame *f) { return f ? f->icost : nullptr; }        /* cfg.intra_inter: the intra candidates of the last P / B picture (null without) */
 ks265_sao_param *ks265_frame_sao(ks265_frame *f) { return f ? f->sao : nullptr; }
 
 // ------------------------------------------------------------------ the records of one picture as ONE contiguous block (hosts: one copy-out per picture)

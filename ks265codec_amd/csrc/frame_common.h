@@ -39,6 +39,7 @@ struct ks265_frame {
     unsigned long long *sse_acc = nullptr;   // ks265_sse_picture: three running sums + finished work-groups (zero between calls)
     short *mats = nullptr;              // forward + transposed DCT matrices of all sizes in the kernels' LDS layout (2 x MAT_SHORTS)
     int *progress = nullptr;            // intra wavefront: CTUs finished per CTU row
+    uint32_t *icost = nullptr;                             // cfg.intra_inter: intra candidates of the P / B picture being coded (85 per CTU: cost << 6 | mode)
     uint8_t *pyr[10] = {};              // pre-search (cfg.pre_search): L1 / L2 of the source, L1 / L2 of the reference, L2 / L1 vectors, the 16x16 field, L3 of both, CTU window offsets
     // optional in-situ stage timing (HIP events on the context's stream, between the stages of ks265_encode_picture)
     bool profiling = false;

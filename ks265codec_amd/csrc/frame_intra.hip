@@ -8,6 +8,7 @@
 //                            normative availability / substitution / smoothing rules, then the reconstruct() chain per TU.
 // Prediction arithmetic = g_IntraPredFunction enc@0x7070a0 / IntraPredFilterRef_c enc@0x424110 (intra_dev.h, pinned).
 #include "frame_common.h"
+#include <cstddef>
 #include "intra_dev.h"
 #include "recon_dev.h"
 
@@ -97,6 +98,9 @@ struct TuCtx {
     int x0, y0, lx, ly, mode;
     bool filt;
     bool sdh;
+    bool keep;                                  // levels go through LDS (sign-data hiding and / or coefficient-group pruning)
+    int qoff;                                   // the quantiser's rounding offset: 171 in I slices, 85 in P / B slices (H265_GetBaseQuantParam enc@0x4a9c90)
+    long long rdo_lam2k;                        // cfg.rdo x lambda_q4^2 for the intra CUs of P / B pictures, 0 = off
 };
 
 // BLOCK: the quads of a TU are spread over several waves -> work-group barriers (LDS only); otherwise the whole TU lives in one
@@ -146,7 +150,7 @@ __device__ __forceinline__ void tu_pipeline(IntraLds &L, const TuRole &r, const 
         int acc[4];
         quad_dot(mf + r.qy * mp, T + r.qx * RP, RP, nn, acc);
         const int ci = cp ? 1 : 0, scale = c.qsc[ci], dqs = c.qdq[ci];
-        const int qbits = 21 + c.qp6[ci] - l2, off = 171 << (qbits - 9), shift = l2 - 1;
+        const int qbits = 21 + c.qp6[ci] - l2, off = c.qoff << (qbits - 9), shift = l2 - 1;
         unsigned short lv[4];
         int nzc = 0;
 #pragma unroll
@@ -156,16 +160,32 @@ __device__ __forceinline__ void tu_pipeline(IntraLds &L, const TuRole &r, const 
             const int l = quant_one(coef, scale, off, qbits, du);
             nzc += l != 0;
             lv[i] = (unsigned short)(short)l;
-            if (c.sdh) { const int o = r.qy * RP + r.qx + i; L.LV[cp][o] = (short)l; L.DU[cp][o] = (short)du; L.CF[cp][o] = (short)coef; }
+            if (c.keep) { const int o = r.qy * RP + r.qx + i; L.LV[cp][o] = (short)l; L.DU[cp][o] = (short)du; L.CF[cp][o] = (short)coef; }
             X[(r.qx + i) * RP + r.qy] = (short)dequant_one(l, dqs, 1 << (shift - 1), shift);
         }
         // (with sign-data hiding the level plane is written after the hiding step, from LDS: a second store to the same address from another wave
         //  could overtake this one - the LDS-only barriers of this kernel do not order HBM stores)
-        if (!c.sdh) *(uint2 *)((cp == 0 ? c.lvl_y : (cp == 1 ? c.lvl_u : c.lvl_v)) + (long)(py + r.qy) * lstride + px + r.qx) =
+        if (!c.keep) *(uint2 *)((cp == 0 ? c.lvl_y : (cp == 1 ? c.lvl_u : c.lvl_v)) + (long)(py + r.qy) * lstride + px + r.qx) =
             make_uint2(lv[0] | ((unsigned)lv[1] << 16), lv[2] | ((unsigned)lv[3] << 16));
         if (nzc) atomicAdd(&L.nz[cp], nzc);
     }
     tu_sync<BLOCK>();
+    if (c.rdo_lam2k) {
+        // cfg.rdo (intra CUs of P / B pictures): coefficient-group pruning before sign-data hiding, the lane holding the top row of a 4x4 group handles it
+        if (r.on && (r.qy & 3) == 0 && L.nz[cp] > 0) {
+            const int cbase = r.qy * RP + r.qx;
+            const int cnt = rdo_group_prune(L.LV[cp], L.CF[cp], cbase, c.qdq[cp ? 1 : 0], l2, c.rdo_lam2k);
+            if (cnt) {
+#pragma unroll
+                for (int y = 0; y < 4; ++y) {
+                    *(uint2 *)(L.LV[cp] + cbase + y * RP) = make_uint2(0u, 0u);
+                    *(uint2 *)(X + (r.qx + y) * RP + r.qy) = make_uint2(0u, 0u);         // the dequantised tile is stored transposed
+                }
+                atomicSub(&L.nz[cp], cnt);
+            }
+        }
+        tu_sync<BLOCK>();
+    }
     if (c.sdh) {
         // the postQuant seam (postQuant enc@0x4ace80): sign-data hiding with the TU's scan (H.265 7.4.9.11: intra 4x4 / 8x8 luma and 4x4 chroma
         // follow the prediction mode); the lane holding the top row of a 4x4 coefficient group handles that group from registers (recon_dev.h) and
@@ -196,7 +216,7 @@ __device__ __forceinline__ void tu_pipeline(IntraLds &L, const TuRole &r, const 
     }
     const bool live = r.on && L.nz[cp] != 0;
     if (r.on) {                                                     // inverse pass 1: T[y][x] = clip16((Mt[y] . Ct[x] + 64) >> 7)
-        if (c.sdh) *(uint2 *)((cp == 0 ? c.lvl_y : (cp == 1 ? c.lvl_u : c.lvl_v)) + (long)(py + r.qy) * lstride + px + r.qx) = *(const uint2 *)(L.LV[cp] + r.qy * RP + r.qx);
+        if (c.keep) *(uint2 *)((cp == 0 ? c.lvl_y : (cp == 1 ? c.lvl_u : c.lvl_v)) + (long)(py + r.qy) * lstride + px + r.qx) = *(const uint2 *)(L.LV[cp] + r.qy * RP + r.qx);
         int acc[4] = {0, 0, 0, 0};
         if (live) quad_dot(mt + r.qy * mp, X + r.qx * RP, RP, nn, acc);
         unsigned short o[4];
@@ -219,16 +239,39 @@ __device__ __forceinline__ void tu_pipeline(IntraLds &L, const TuRole &r, const 
     tu_sync<BLOCK>();
 }
 
+// PMODE = false: an intra picture (every CU).  PMODE = true (cfg.intra_inter): the intra CUs (pred_mode 2) of a P / B picture AFTER reconstruct_kernel has written every
+// inter CU - a CTU without intra CUs is passed over at once, the others load their own reconstructed samples into the window first (inter neighbours count like intra
+// ones: constrained_intra_pred_flag = 0), quantise with the slice's rounding offset and prune coefficient groups like the inter TUs (cfg.rdo).
+template <bool PMODE>
 __global__ __launch_bounds__(256) void intra_recon_kernel(KsGeom g, int qp, const uint8_t *src_y, const uint8_t *src_u, const uint8_t *src_v, ks265_cu8 *cu8,
                                                           int16_t *lvl_y, int16_t *lvl_u, int16_t *lvl_v, uint8_t *rec_y, uint8_t *rec_u, uint8_t *rec_v,
-                                                          int *progress, unsigned *err_word, int spin_limit, int sdh_on)
+                                                          int *progress, unsigned *err_word, int spin_limit, int sdh_on, long long rdo_lam2k)
 {
     __shared__ __attribute__((aligned(16))) IntraLds L;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, cy = blockIdx.x;
-    build_matrices(L.Mf, L.Mt, tid, 256);
+    // PMODE: one work-group per CTU in raster order (a CTU's neighbours have smaller indices, so the work-groups it may wait for were dispatched before it);
+    // an intra picture: one work-group per CTU ROW walking its CTUs (every CTU has work, the row is the natural unit)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, cy = PMODE ? (int)blockIdx.x / g.ctu_cols : (int)blockIdx.x;
+    const int cx_first = PMODE ? (int)blockIdx.x % g.ctu_cols : 0, cx_end = PMODE ? cx_first + 1 : g.ctu_cols;
+    if (PMODE) {                                                     // most CTUs of a P / B picture hold no intra CU: leave before any set-up
+        __shared__ int s_any;
+        if (tid < 64) {
+            const int bx = cx_first * 8 + (tid & 7), by = cy * 8 + (tid >> 3);
+            bool intra = false;
+            if (bx < g.w8 && by < g.h8) { const ks265_cu8 q = cu8[(long)by * g.w8 + bx]; intra = q.pred_mode == 2; }
+            const unsigned long long any = __ballot(intra);
+            if (tid == 0) s_any = any != 0ull;
+        }
+        __syncthreads();
+        if (!s_any) {
+            if (tid == 0) __hip_atomic_store(progress + blockIdx.x, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+    }
+    build_matrices(L.Mf, L.Mt, tid, 256);                            // (cheaper than fetching the frame's copy: no memory latency)
     const int qpc = chroma_qp(qp);
     TuCtx c;
     c.sdh = sdh_on != 0;
+    c.rdo_lam2k = PMODE ? rdo_lam2k : 0; c.keep = c.sdh || c.rdo_lam2k != 0; c.qoff = PMODE ? 85 : 171;
     c.g = &g; c.lvl_y = lvl_y; c.lvl_u = lvl_u; c.lvl_v = lvl_v;
     // quantiser constants of the two QPs, fetched once (a table load inside the CU loop would sit behind every outstanding store)
     c.qsc[0] = kQuantScales[qp % 6]; c.qsc[1] = kQuantScales[qpc % 6];
@@ -238,9 +281,36 @@ __global__ __launch_bounds__(256) void intra_recon_kernel(KsGeom g, int qp, cons
     //  space, its stores become FLAT stores, and FLAT stores count against lgkmcnt - every LDS barrier would wait for HBM)
     const uint8_t *const S0 = ks_org_y(g, src_y), *const S1 = ks_org_c(g, src_u), *const S2 = ks_org_c(g, src_v);
     c.R0 = ks_org_y(g, rec_y); c.R1 = ks_org_c(g, rec_u); c.R2 = ks_org_c(g, rec_v);
-    for (int cx = 0; cx < g.ctu_cols; ++cx) {
-        // wavefront: the row above must be two CTUs ahead (top-right neighbours)
-        if (cy > 0 && tid == 0) {
+    for (int cx = cx_first; cx < cx_end; ++cx) {
+        __syncthreads();                                             // nobody still walks the previous CTU's map
+        if (tid < 64) {
+            const int bx = cx * 8 + (tid & 7), by = cy * 8 + (tid >> 3);
+            ks265_cu8 cu;
+            cu.mvx = 0; cu.mvy = 0; cu.mv1x = 0; cu.mv1y = 0; cu.log2_cu = 0; cu.cbf = 0; cu.pred_mode = 0; cu.inter_dir = 0;
+            if (bx < g.w8 && by < g.h8) cu = cu8[(long)by * g.w8 + bx];
+            L.cu[tid] = cu;
+            L.cbf[tid] = PMODE && cu.pred_mode != 2 ? cu.cbf : 0;        // the inter CUs keep what reconstruct_kernel found
+            if (!PMODE) {
+                // the previous CTU's last column becomes this CTU's left neighbour column
+                L.WY[(1 + tid) * 136 + 3] = L.WY[(1 + tid) * 136 + 4 + 63];
+                L.WC[tid >> 5][(1 + (tid & 31)) * 72 + 3] = L.WC[tid >> 5][(1 + (tid & 31)) * 72 + 4 + 31];
+            }
+        }
+        if (PMODE) {
+            // the four neighbour CTUs whose samples this CTU's intra CUs may read (left, top-left, top, top-right) must be through - with or without intra CUs of
+            // their own (those without flagged themselves at once)
+            if (tid < 4) {
+                const int nx = tid == 0 ? cx - 1 : cx - 2 + tid, ny = tid == 0 ? cy : cy - 1;
+                if (nx >= 0 && nx < g.ctu_cols && ny >= 0) {
+                    int spins = 0;
+                    while (__hip_atomic_load(progress + ny * g.ctu_cols + nx, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+                        if (spins++ >= spin_limit) { __hip_atomic_fetch_or(err_word, KS_DEVERR_WAVEFRONT_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+                        __builtin_amdgcn_s_sleep(8);
+                    }
+                }
+            }
+        } else if (cy > 0 && tid == 0) {
+            // wavefront: the row above must be two CTUs ahead (top-right neighbours)
             const int need = min(cx + 2, g.ctu_cols);
             // bounded: rows are normally dispatched in order, so the row above is resident and this never spins long; if it ever does
             // (a lost launch, a row that is not resident under heavy multi-stream load), give up after ~1 s instead of hanging the GPU
@@ -251,23 +321,31 @@ __global__ __launch_bounds__(256) void intra_recon_kernel(KsGeom g, int qp, cons
                 __builtin_amdgcn_s_sleep(8);
             }
         }
-        __syncthreads();                                             // nobody still walks the previous CTU's map
-        if (tid < 64) {
-            const int bx = cx * 8 + (tid & 7), by = cy * 8 + (tid >> 3);
-            ks265_cu8 cu;
-            cu.mvx = 0; cu.mvy = 0; cu.mv1x = 0; cu.mv1y = 0; cu.log2_cu = 0; cu.cbf = 0; cu.pred_mode = 0; cu.inter_dir = 0;
-            if (bx < g.w8 && by < g.h8) cu = cu8[(long)by * g.w8 + bx];
-            L.cu[tid] = cu;
-            L.cbf[tid] = 0;
-            // the previous CTU's last column becomes this CTU's left neighbour column
-            L.WY[(1 + tid) * 136 + 3] = L.WY[(1 + tid) * 136 + 4 + 63];
-            L.WC[tid >> 5][(1 + (tid & 31)) * 72 + 3] = L.WC[tid >> 5][(1 + (tid & 31)) * 72 + 4 + 31];
-        }
+        __syncthreads();
         {   // source samples of the CTU: 64 rows x 64 bytes luma (16-byte pieces), 2 x 32 x 32 chroma; rows below the picture are padding, never used
             const int r = tid >> 2, cc16 = (tid & 3) * 16;
             *(uint4 *)&L.SY[r * 64 + cc16] = *(const uint4 *)(S0 + (long)(cy * 64 + r) * g.sy + cx * 64 + cc16);
             const int cc = tid >> 7, t = tid & 127, rc = t >> 2, c8 = (t & 3) * 8;
             *(uint2 *)&L.SC[cc][rc * 32 + c8] = *(const uint2 *)((cc ? S2 : S1) + (long)(cy * 32 + rc) * g.sc + cx * 32 + c8);
+            if (PMODE) {
+                // the CTU's own reconstructed samples (the inter CUs, written by reconstruct_kernel before this launch) and its left neighbour column (this
+                // work-group's own earlier stores, or the inter kernel's: L2-coherent loads)
+                {   // (window rows start 4 bytes into an 8-byte grid: dword stores)
+                    const uint4 wy = *(const uint4 *)(c.R0 + (long)(cy * 64 + r) * g.sy + cx * 64 + cc16);
+                    unsigned *dy = (unsigned *)&L.WY[(1 + r) * 136 + 4 + cc16];
+                    dy[0] = wy.x; dy[1] = wy.y; dy[2] = wy.z; dy[3] = wy.w;
+                    const uint2 wc = *(const uint2 *)((cc ? c.R2 : c.R1) + (long)(cy * 32 + rc) * g.sc + cx * 32 + c8);
+                    unsigned *dc = (unsigned *)&L.WC[cc][(1 + rc) * 72 + 4 + c8];
+                    dc[0] = wc.x; dc[1] = wc.y;
+                }
+                if (cx > 0) {
+                    if (tid < 64) L.WY[(1 + tid) * 136 + 3] = __hip_atomic_load(c.R0 + (long)(cy * 64 + tid) * g.sy + cx * 64 - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else if (tid < 128) {
+                        const int k = tid - 64, pc = k >> 5, rr = k & 31;
+                        L.WC[pc][(1 + rr) * 72 + 3] = __hip_atomic_load((pc ? c.R2 : c.R1) + (long)(cy * 32 + rr) * g.sc + cx * 32 - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            }
         }
         if (cy > 0) {                                                // the row above: finished by another workgroup -> L2-coherent loads
             if (tid < 129) {
@@ -285,6 +363,7 @@ __global__ __launch_bounds__(256) void intra_recon_kernel(KsGeom g, int qp, cons
             const int lx = (z & 1) | ((z >> 1) & 2) | ((z >> 2) & 4), ly = ((z >> 1) & 1) | ((z >> 2) & 2) | ((z >> 3) & 4);
             const ks265_cu8 cu = L.cu[ly * 8 + lx];
             if (cu.log2_cu == 0) continue;                          // outside the picture
+            if (PMODE && cu.pred_mode != 2) continue;               // an inter CU: reconstructed already
             const int n8 = 1 << (cu.log2_cu - 3);
             if ((lx & (n8 - 1)) || (ly & (n8 - 1))) continue;
             const int n = 8 * n8, log2 = cu.log2_cu;
@@ -370,7 +449,7 @@ __global__ __launch_bounds__(256) void intra_recon_kernel(KsGeom g, int qp, cons
         }
         __threadfence();                                             // this CTU's samples are in L2 before the row below is released
         __syncthreads();
-        if (tid == 0) __hip_atomic_store(progress + cy, cx + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) __hip_atomic_store(progress + (PMODE ? (int)blockIdx.x : cy), PMODE ? 1 : cx + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -379,8 +458,20 @@ extern "C" int ks265_intra_reconstruct(ks265_frame *f, ks265_pic src, ks265_cu8 
     KS_FRAME_CHECK(f);
     if (!src.y || !cu8 || !lvl_y || !lvl_u || !lvl_v || !recon.y) return KS265_POINTER;
     if (hipMemsetAsync(f->progress, 0, sizeof(int) * (size_t)f->g.ctu_rows, f->ctx->stream) != hipSuccess) return ks265_hip(f->ctx, hipGetLastError());
-    hipLaunchKernelGGL(intra_recon_kernel, dim3(f->g.ctu_rows), dim3(256), 0, f->ctx->stream, f->g, f->cfg.qp, src.y, src.u, src.v, cu8, lvl_y, lvl_u, lvl_v,
-                       recon.y, recon.u, recon.v, f->progress, f->ctx->err_dev, f->ctx->wavefront_spin_limit, f->cfg.sdh);
+    hipLaunchKernelGGL(intra_recon_kernel<false>, dim3(f->g.ctu_rows), dim3(256), 0, f->ctx->stream, f->g, f->cfg.qp, src.y, src.u, src.v, cu8, lvl_y, lvl_u, lvl_v,
+                       recon.y, recon.u, recon.v, f->progress, f->ctx->err_dev, f->ctx->wavefront_spin_limit, f->cfg.sdh, 0ll);
+    return ks265_check_launch(f->ctx);
+}
+// cfg.intra_inter: the intra CUs of a P / B picture, after ks265_reconstruct[_b / _mref] has written the inter CUs into `recon`
+extern "C" int ks265_intra_inter_reconstruct(ks265_frame *f, ks265_pic src, ks265_cu8 *cu8, int16_t *lvl_y, int16_t *lvl_u, int16_t *lvl_v, ks265_pic recon)
+{
+    KS_FRAME_CHECK(f);
+    if (!src.y || !cu8 || !lvl_y || !lvl_u || !lvl_v || !recon.y) return KS265_POINTER;
+    const int nctu = f->g.ctu_cols * f->g.ctu_rows;
+    if (hipMemsetAsync(f->progress, 0, sizeof(int) * (size_t)nctu, f->ctx->stream) != hipSuccess) return ks265_hip(f->ctx, hipGetLastError());
+    const long long lam2k = (long long)f->cfg.lambda_q4 * f->cfg.lambda_q4 * (f->cfg.rdo > 0 ? f->cfg.rdo : 0);
+    hipLaunchKernelGGL(intra_recon_kernel<true>, dim3(nctu), dim3(256), 0, f->ctx->stream, f->g, f->cfg.qp, src.y, src.u, src.v, cu8, lvl_y, lvl_u, lvl_v,
+                       recon.y, recon.u, recon.v, f->progress, f->ctx->err_dev, f->ctx->wavefront_spin_limit, f->cfg.sdh, lam2k);
     return ks265_check_launch(f->ctx);
 }
 
@@ -391,35 +482,72 @@ struct DecideLds {
     unsigned char ref[84][2][132];          // [block][raw / smoothed], corner at index 66; blocks: 4 of 32x32, 16 of 16x16, 64 of 8x8 (raster per level)
     unsigned short dc[84];
     unsigned best[4][84];                   // per wave: min over its modes of (cost << 6) | mode
-    unsigned cost[85];
+    unsigned cost[85], node[85];            // node: the CU tree's running values (a private array would live in scratch memory)
     unsigned char mode[85], split[85];
+    // the source samples every reference array is gathered from: row 0 = the row above the CTU (x = -4 .. 131), rows 1 .. 64 = the CTU with the four samples left
+    // of it; sample (x, y) of the CTU at [(1 + y) * 136 + 4 + x] (a byte load per reference sample from HBM / L2 was this kernel's critical path)
+    __attribute__((aligned(16))) unsigned char W[65 * 136];
 };
 
 __device__ __forceinline__ int intra_mode_bits(int mode) { return (mode == 0 || mode == 1 || mode == 26) ? 3 : 6; }   // default MPM set vs. escape code
 
-__global__ __launch_bounds__(256) void intra_decide_kernel(KsGeom g, int lam, const uint8_t *src_y, ks265_cu8 *cu8, unsigned *cost_out)
+// Two uses.  Key pictures (gate_pu null): one work-group per CTU does everything and builds the CU tree.  Candidates of a P / B picture (gate_pu = the CTU's inter
+// PU records, ks265_pu / ks265_pu_b: 16 bytes, cost at byte 8; cfg.intra_inter): 11 of the 35 modes, THREE work-groups per CTU - one per level (32 / 16 / 8) - each writes (cost << 6 | mode) of its blocks to best_out (the
+// caller sets the array to 0xFFFFFFFF = "no candidate").  Gate: a CTU is evaluated only if one of its 8x8 PUs costs at
+// least what an intra CU costs before its first residual bit, lambda x KS_INTRA_GATE_BITS >> 4 (= the bias of the CU decision): where every 8x8 block is predicted
+// better than that, no block goes intra - most CTUs of a P / B picture leave here.
+#define KS_INTRA_GATE_BITS 96
+__global__ __launch_bounds__(256) void intra_decide_kernel(KsGeom g, int lam, const uint8_t *src_y, ks265_cu8 *cu8, unsigned *cost_out, unsigned *best_out, const uint4 *gate_pu)
 {
     __shared__ __attribute__((aligned(16))) DecideLds L;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ctu = ks_xcd_swizzle(blockIdx.x, g.ctu_cols * g.ctu_rows), cx = ctu % g.ctu_cols, cy = ctu / g.ctu_cols;
+    const int lsel = gate_pu ? 1 + (int)(blockIdx.x % 3u) : 0;      // lsel: the one level this work-group handles (0 = all)
+    // the modes by index: key pictures all 35; candidates planar, DC and every fourth angular mode (2, 6 .. 34: the oracle's INTRA_INTER_MODE_STEP - a third of the
+    // work for +0.5 % bytes at most)
+    const int mi0 = 0, mi1 = gate_pu ? 11 : 35;
+    const int ctu = ks_xcd_swizzle(gate_pu ? (int)(blockIdx.x / 3u) : (int)blockIdx.x, g.ctu_cols * g.ctu_rows), cx = ctu % g.ctu_cols, cy = ctu / g.ctu_cols;
     const uint8_t *S = ks_org_y(g, src_y);
+    if (gate_pu) {
+        __shared__ int s_go;
+        if (tid < 64) {
+            const unsigned c = gate_pu[(long)ctu * 85 + 21 + tid].z;                    // cost of 8x8 PU `tid`
+            const unsigned long long any = __ballot(c != KS_COST_INVALID && c >= (unsigned)((lam * KS_INTRA_GATE_BITS) >> 4));
+            if (tid == 0) s_go = any != 0ull;
+        }
+        __syncthreads();
+        if (!s_go) return;
+    }
     // ---- (1) reference arrays of all 84 blocks from the source picture, raw and smoothed; one block per wave at a time
+    {   // the window: row 0 = 34 dwords (x = -4 .. 131), rows 1 .. 64 = 17 dwords (x = -4 .. 63): 1122 dwords, all loads of a thread in flight together
+        unsigned v[5];
+        int at[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int i = tid + 256 * k, r = i < 34 ? 0 : 1 + (i - 34) / 17, d = i < 34 ? i : (i - 34) % 17;
+            at[k] = i < 34 + 64 * 17 && cx * 64 + 4 * d < g.W + KS_PAD_Y ? r * 136 + 4 * d : -1;
+            v[k] = at[k] >= 0 ? *(const unsigned *)(S + (long)(cy * 64 + r - 1) * g.sy + cx * 64 - 4 + 4 * d) : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < 5; ++k) if (at[k] >= 0) *(unsigned *)&L.W[at[k]] = v[k];
+    }
+    __syncthreads();
+    const unsigned char *const Wo = &L.W[136 + 4] - (long)(cy * 64) * 136 - cx * 64;     // picture coordinates into the window
 #pragma unroll 1
     for (int b = wave; b < 84; b += 4) {
         const int l = b < 4 ? 1 : (b < 20 ? 2 : 3), i = b - (l == 1 ? 0 : (l == 2 ? 4 : 20)), n = 64 >> l;
         const int x0 = cx * 64 + (i & ((1 << l) - 1)) * n, y0 = cy * 64 + (i >> l) * n;
+        if (lsel && l != lsel) continue;
         if (x0 + n > g.W || y0 + n > g.H) continue;                 // not (completely) inside the picture: never a CU
         const unsigned mask = intra_unit_mask(g, x0, y0, n, lane);
         unsigned char *raw = &L.ref[b][0][66], *fil = &L.ref[b][1][66];
-        for (int q = lane; q <= 4 * n; q += 64) raw[q - 2 * n] = (unsigned char)intra_ref_sample<false>(S, g.sy, mask, x0, y0, n, 8, q);
+        for (int q = lane; q <= 4 * n; q += 64) raw[q - 2 * n] = (unsigned char)intra_ref_sample<false>(Wo, 136, mask, x0, y0, n, 8, q);
         __builtin_amdgcn_wave_barrier();
         const bool bil = n == 32 && intra_strong_flat(raw);
         for (int q = lane; q <= 4 * n; q += 64) fil[q - 2 * n] = (unsigned char)intra_filtered(raw, n, q - 2 * n, bil);
-        if (lane == 0) {
-            int dc = n;
-            for (int k = 0; k < n; ++k) dc += raw[1 + k] + raw[-1 - k];
-            L.dc[b] = (unsigned short)(dc >> (7 - l));              // log2(n) + 1
-        }
+        int dc = lane < n ? raw[1 + lane] + raw[-1 - lane] : 0;     // DC: the n samples above and the n samples left
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) dc += __shfl_xor(dc, o, 64);
+        if (lane == 0) L.dc[b] = (unsigned short)((dc + n) >> (7 - l));              // log2(n) + 1
     }
     __syncthreads();
     // ---- (2) all 35 modes of every block: SATD of (source - prediction) on the matrix cores (see me_subpel_kernel for the operand
@@ -448,10 +576,12 @@ __global__ __launch_bounds__(256) void intra_decide_kernel(KsGeom g, int lam, co
     const int ltx = (lane & 1) | ((lane >> 1) & 2) | ((lane >> 2) & 4), lty = ((lane >> 1) & 1) | ((lane >> 2) & 2) | ((lane >> 3) & 4);
 #pragma unroll 1
     for (int l = 1; l <= 3; ++l) {
+        if (lsel && l != lsel) continue;
         const int n = 64 >> l, log2 = 6 - l, t8 = n >> 3, base = l == 1 ? 0 : (l == 2 ? 4 : 20);
         unsigned best = 0xFFFFFFFFu;
 #pragma unroll 1
-        for (int mode = wave; mode < 35; mode += 4) {
+        for (int mi = mi0 + wave; mi < mi1; mi += 4) {
+            const int mode = gate_pu && mi >= 2 ? 2 + (mi - 2) * 4 : mi;
             const int which = intra_filter_flag(mode, n) ? 1 : 0;
             unsigned acc[4];
 #pragma unroll
@@ -495,11 +625,18 @@ __global__ __launch_bounds__(256) void intra_decide_kernel(KsGeom g, int lam, co
         L.mode[1 + b] = (unsigned char)(m & 63u);
     }
     __syncthreads();
+    if (best_out) {                                                  // candidates of a P / B picture: this work-group's level and modes
+        if (tid >= 1 && tid < 85) {
+            const int b = tid - 1, l = b < 4 ? 1 : (b < 20 ? 2 : 3);
+            if (l == lsel && L.cost[tid] != KS_COST_INVALID) best_out[(long)ctu * 85 + tid] = (L.cost[tid] << 6) | (unsigned)L.mode[tid];
+        }
+        return;
+    }
     if (cost_out && tid < 85) cost_out[(long)ctu * 85 + tid] = tid == 0 ? KS_COST_INVALID : L.cost[tid];     // pre-selection costs (lookahead)
     // ---- (3) CU quadtree bottom-up (a node keeps its own cost if it is <= the children's sum + split overhead)
     if (tid == 0) {
         // 85 nodes, leaves first; node value v[idx]
-        unsigned v[85];
+        unsigned *const v = L.node;
         for (int l = 3; l >= 0; --l)
             for (int i = 0; i < (1 << (2 * l)); ++i) {
                 const int px = i & ((1 << l) - 1), py = i >> l, s = 64 >> l, x0 = cx * 64 + px * s, y0 = cy * 64 + py * s, idx = ks_pu_index(l, px, py);
@@ -529,7 +666,20 @@ extern "C" int ks265_intra_decide_ex(ks265_frame *f, ks265_pic src, ks265_cu8 *c
 {
     KS_FRAME_CHECK(f);
     if (!src.y || !cu8) return KS265_POINTER;
-    hipLaunchKernelGGL(intra_decide_kernel, dim3(f->g.ctu_cols * f->g.ctu_rows), dim3(256), 0, f->ctx->stream, f->g, f->cfg.lambda_q4, src.y, cu8, cost_out);
+    hipLaunchKernelGGL(intra_decide_kernel, dim3(f->g.ctu_cols * f->g.ctu_rows), dim3(256), 0, f->ctx->stream, f->g, f->cfg.lambda_q4, src.y, cu8, cost_out, (unsigned *)nullptr, (const uint4 *)nullptr);
+    return ks265_check_launch(f->ctx);
+}
+// cfg.intra_inter: the intra candidates of a P / B picture - per block (85 per CTU, PU indexing) cost << 6 | best mode, 0xFFFFFFFF where there is none (a CTU the
+// gate left out, a block outside the picture, the 64x64 level)
+extern "C" int ks265_intra_candidates(ks265_frame *f, ks265_pic src, const void *dev_pu_records, uint32_t *dev_best)
+{
+    KS_FRAME_CHECK(f);
+    if (!src.y || !dev_pu_records || !dev_best) return KS265_POINTER;
+    static_assert(sizeof(ks265_pu) == 16 && sizeof(ks265_pu_b) == 16 && offsetof(ks265_pu, cost) == 8 && offsetof(ks265_pu_b, cost) == 8, "the gate reads the cost of either record type at byte 8");
+    const int nctu = f->g.ctu_cols * f->g.ctu_rows;
+    if (hipMemsetAsync(dev_best, 0xFF, sizeof(uint32_t) * 85 * (size_t)nctu, f->ctx->stream) != hipSuccess) return ks265_hip(f->ctx, hipGetLastError());
+    hipLaunchKernelGGL(intra_decide_kernel, dim3(nctu * 3), dim3(256), 0, f->ctx->stream, f->g, f->cfg.lambda_q4, src.y, (ks265_cu8 *)nullptr, (unsigned *)nullptr, dev_best,
+                       (const uint4 *)dev_pu_records);
     return ks265_check_launch(f->ctx);
 }
 extern "C" int ks265_intra_decide(ks265_frame *f, ks265_pic src, ks265_cu8 *cu8) { return ks265_intra_decide_ex(f, src, cu8, nullptr); }

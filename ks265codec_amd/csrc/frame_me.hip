@@ -320,11 +320,14 @@ extern "C" int ks265_me_subpel(ks265_frame *f, ks265_pic src, ks265_pic ref, ks2
 #define KS_SPLIT_BITS_B 80
 // ------------------------------------------------------------------ Stage C: CU quadtree (64 threads per CTU)
 // REC = ks265_pu (P pictures: list 0 only) or ks265_pu_b (B pictures: the per-PU winner with its direction)
+// cfg.intra_inter: ibest (85 per CTU from ks265_intra_candidates: cost << 6 | mode, all ones = none; else null) - a block's intra pre-selection cost + lambda x KS_INTRA_BIAS_BITS competes with
+// its inter cost (oracle: node_own_cost)
+#define KS_INTRA_BIAS_BITS 96
 template <typename REC>
-__global__ __launch_bounds__(64) void cu_decide_kernel(KsGeom g, int lam, const REC *pus, ks265_cu8 *cu8)
+__global__ __launch_bounds__(64) void cu_decide_kernel(KsGeom g, int lam, const REC *pus, ks265_cu8 *cu8, const unsigned *ibest)
 {
     __shared__ unsigned bestc[85];
-    __shared__ unsigned char split[85];
+    __shared__ unsigned char split[85], use_intra[85];
     const int t = threadIdx.x, ctu = blockIdx.x, cx = ctu % g.ctu_cols, cy = ctu / g.ctu_cols;
     const REC *cp = pus + (long)ctu * 85;
     const unsigned pen = (unsigned)((lam * (std::is_same<REC, ks265_pu_b>::value ? KS_SPLIT_BITS_B : KS_SPLIT_BITS_P)) >> 4);
@@ -333,7 +336,15 @@ __global__ __launch_bounds__(64) void cu_decide_kernel(KsGeom g, int lam, const 
         for (int i = t; i < n * n; i += 64) {
             const int px = i & (n - 1), py = i >> l, idx = ks_level_base(l) + i;
             const int x0 = cx * 64 + px * s, y0 = cy * 64 + py * s;
-            unsigned own = cp[idx].cost, res; unsigned char sp = 0;
+            unsigned own = cp[idx].cost, res; unsigned char sp = 0, ui = 0;
+            if (ibest && l > 0) {
+                const unsigned v = ibest[(long)ctu * 85 + idx];
+                if (v != 0xFFFFFFFFu) {
+                    const unsigned long long ic = (unsigned long long)(v >> 6) + (unsigned long long)((lam * KS_INTRA_BIAS_BITS) >> 4);
+                    if (own == KS_COST_INVALID || ic < own) { ui = 1; own = ic > 0xFFFFFFFEull ? 0xFFFFFFFEu : (unsigned)ic; }
+                }
+            }
+            use_intra[idx] = ui;
             if (x0 >= g.W || y0 >= g.H) res = 0;
             else if (l == 3) res = own;
             else {
@@ -351,11 +362,13 @@ __global__ __launch_bounds__(64) void cu_decide_kernel(KsGeom g, int lam, const 
     if (X >= g.W || Y >= g.H) return;
     int l = 0;
     while (l < 3 && split[ks_pu_index(l, bx >> (3 - l), by >> (3 - l))]) ++l;
-    const REC p = cp[ks_pu_index(l, bx >> (3 - l), by >> (3 - l))];
+    const int pidx = ks_pu_index(l, bx >> (3 - l), by >> (3 - l));
+    const REC p = cp[pidx];
     ks265_cu8 c;
     c.mvx = p.mvx; c.mvy = p.mvy; c.log2_cu = (uint8_t)(6 - l); c.cbf = 0; c.pred_mode = 0;
     if constexpr (std::is_same<REC, ks265_pu_b>::value) { c.mv1x = p.mv1x; c.mv1y = p.mv1y; c.inter_dir = (uint8_t)p.inter_dir; }
     else { c.mv1x = 0; c.mv1y = 0; c.inter_dir = 1; }
+    if (use_intra[pidx]) { c.mvx = (int16_t)(ibest[(long)ctu * 85 + pidx] & 63u); c.mvy = 0; c.mv1x = 0; c.mv1y = 0; c.pred_mode = 2; c.inter_dir = 0; }    // an intra CU: mvx = its luma mode
     cu8[(long)(Y >> 3) * g.w8 + (X >> 3)] = c;
 }
 
@@ -373,21 +386,23 @@ __global__ __launch_bounds__(256) void cu_flat_intra_kernel(KsGeom g, ks265_cu8 
     cu8[i] = c;
 }
 
-extern "C" int ks265_cu_decide(ks265_frame *f, const ks265_pu *pu, ks265_cu8 *cu8)
+extern "C" int ks265_cu_decide_ii(ks265_frame *f, const ks265_pu *pu, const uint32_t *ibest, ks265_cu8 *cu8)
 {
     KS_FRAME_CHECK(f);
     if (!pu || !cu8) return KS265_POINTER;
-    hipLaunchKernelGGL(cu_decide_kernel<ks265_pu>, dim3(f->g.ctu_cols * f->g.ctu_rows), dim3(64), 0, f->ctx->stream, f->g, f->cfg.lambda_q4, pu, cu8);
+    hipLaunchKernelGGL(cu_decide_kernel<ks265_pu>, dim3(f->g.ctu_cols * f->g.ctu_rows), dim3(64), 0, f->ctx->stream, f->g, f->cfg.lambda_q4, pu, cu8, ibest);
     return ks265_check_launch(f->ctx);
 }
+extern "C" int ks265_cu_decide(ks265_frame *f, const ks265_pu *pu, ks265_cu8 *cu8) { return ks265_cu_decide_ii(f, pu, nullptr, cu8); }
 
-extern "C" int ks265_cu_decide_b(ks265_frame *f, const ks265_pu_b *pub, ks265_cu8 *cu8)
+extern "C" int ks265_cu_decide_b_ii(ks265_frame *f, const ks265_pu_b *pub, const uint32_t *ibest, ks265_cu8 *cu8)
 {
     KS_FRAME_CHECK(f);
     if (!pub || !cu8) return KS265_POINTER;
-    hipLaunchKernelGGL(cu_decide_kernel<ks265_pu_b>, dim3(f->g.ctu_cols * f->g.ctu_rows), dim3(64), 0, f->ctx->stream, f->g, f->cfg.lambda_q4, pub, cu8);
+    hipLaunchKernelGGL(cu_decide_kernel<ks265_pu_b>, dim3(f->g.ctu_cols * f->g.ctu_rows), dim3(64), 0, f->ctx->stream, f->g, f->cfg.lambda_q4, pub, cu8, ibest);
     return ks265_check_launch(f->ctx);
 }
+extern "C" int ks265_cu_decide_b(ks265_frame *f, const ks265_pu_b *pub, ks265_cu8 *cu8) { return ks265_cu_decide_b_ii(f, pub, nullptr, cu8); }
 
 // ------------------------------------------------------------------ Stage B': bi-predictive candidate of a B picture
 // One workgroup per CTU, wave = PU level, lane = 8x8 tile in Z-order: SATD of the source tile against the rounded average of the

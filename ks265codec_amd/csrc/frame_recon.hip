@@ -125,7 +125,7 @@ __device__ __forceinline__ void code_region(const KsGeom &g, int comp, int qp, i
     const bool has_quad = tid < NQ;
     const int b = has_quad ? (qy / UNIT) * 4 + qx / UNIT : 0;
     const ks265_cu8 c = blk[b];
-    const bool coded = has_quad && c.log2_cu != 0;                 // block inside the picture
+    const bool coded = has_quad && c.log2_cu != 0 && c.pred_mode != 2;     // block inside the picture; an intra CU of a P / B picture (pred_mode 2) is coded afterwards (ks265_intra_inter_reconstruct)
     // TU geometry of the quad
     const int t8 = 1 << tu_log2[b], tbx = (b & 3) & ~(t8 - 1), tby = (b >> 2) & ~(t8 - 1), tb = tby * 4 + tbx;
     const int ox = tbx * UNIT, oy = tby * UNIT, n = t8 * UNIT, log2n = tu_log2[b] + (RS == 32 ? 3 : 2);

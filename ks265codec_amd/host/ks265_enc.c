@@ -548,10 +548,12 @@ static int submit(Enc *e, Input *in, int kind, int poc, int qp, const int *l0, i
 {
     /* wait for a free job slot (the ring is full only if the consumer did not drain it: block on the oldest) */
     pthread_mutex_lock(&e->mu);
+    const double tw0 = now_ms();
     while (e->njobs == e->ring && !e->quit) {
         pthread_cond_broadcast(&e->cv_sched_done);                      /* a caller waiting for this thread in lane_put goes on and collects output instead */
         pthread_cond_wait(&e->cv_done, &e->mu);                         /* take_output signals when it has freed ring slots */
     }
+    e->st.submit_wait_ms += now_ms() - tw0;
     if (e->quit) { pthread_mutex_unlock(&e->mu); return QY_FAIL; }       /* drained by take_output() of the calling thread itself: never full here */
     Job *j = &e->jobs[e->job_tail];
     pthread_mutex_unlock(&e->mu);
@@ -971,6 +973,7 @@ static Enc *lane_open(QY265EncConfig *cfg, int device, int *err)
     e->fcfg.sdh = 1;                                                    /* the reference's streams have sign_data_hiding_enabled_flag = 1 at every preset */
     e->fcfg.pre_search = 1;                                             /* stage A0: pyramid pre-search vectors as start candidates of the integer search */
     e->fcfg.merge = 1;                                                  /* stage C2: merge pass on the motion field (pictures with one reference per list) */
+    e->fcfg.intra_inter = 1;                                            /* P / B pictures may hold intra CUs (uncovered regions, occlusions) */
     e->fcfg.rdo = 4;                                                    /* coefficient-group pruning at lambda x 1 (ks265_frame_cfg.rdo): supersedes the coefficient decimation of round 2 */
     e->fcfg.bi_refine = 1;                                              /* B pictures: joint refinement of the bi-predictive pair (motionSearchBI enc@0x484910) */
     r = ks265_frame_geometry(&e->fcfg, &e->geom);
@@ -1495,7 +1498,7 @@ int ks265_enc_get_stats(void *h, ks265_enc_stats *out)
         for (int k = 0; k < 3; ++k) out->sse[k] += s->sse[k];
         out->gpu_ms += s->gpu_ms; out->host_write_ms += s->host_write_ms; out->in_copy_ms += s->in_copy_ms; out->submit_ms += s->submit_ms;
         out->lat_gpu_ms += s->lat_gpu_ms; out->lat_queue_ms += s->lat_queue_ms; out->key_wall_ms += s->key_wall_ms; out->key_cpu_ms += s->key_cpu_ms; out->keys += s->keys;
-        out->occ_samples += s->occ_samples; out->occ_ring += s->occ_ring; out->occ_gpu += s->occ_gpu; out->occ_ready += s->occ_ready;
+        out->submit_wait_ms += s->submit_wait_ms; out->occ_samples += s->occ_samples; out->occ_ring += s->occ_ring; out->occ_gpu += s->occ_gpu; out->occ_ready += s->occ_ready;
     }
     if (t->nlanes > 1) out->output_ms = t->output_ms;
     return QY_OK;

@@ -426,9 +426,11 @@ void kso_me_subpel(const kso_frame_cfg *cfg, kso_pic src, const uint8_t *planes,
 /* cfg->intra_inter: P / B pictures may hold intra CUs (EncIntraMD.cpp lineage; decideLumaMode enc@0x49acc0 is closed RD code).  A frame-parallel decision has the
  * pre-selection cost of every block from SOURCE neighbours (kso_intra_decide_ex: SATD + lambda x mode bits): it competes with the block's inter cost, with a
  * price for what an intra CU costs beyond its mode (pred_mode_flag, no merge / skip, a residual that the reconstructed neighbours make larger than the source
- * neighbours promise).  icost / imode: 85 per CTU, PU indexing; NULL = no intra candidates. */
+ * neighbours promise): 96 bits at the picture's lambda - measured with tools/rd_eval.py (832x480, rdo 4, HM lambda): 24 / 64 / 96 / 160 bits give 1.447 / 1.440 / 1.430 / 1.429 x the
+ * reference's bytes at equal PSNR for IPPP (no intra CUs: 1.45) and 96 gives 1.337 against 1.385 for hierarchical B (anchors 8 pictures apart uncover a lot).
+ * icost / imode: 85 per CTU, PU indexing; NULL = no intra candidates. */
 #ifndef INTRA_BIAS_BITS
-#define INTRA_BIAS_BITS 24
+#define INTRA_BIAS_BITS 96
 #endif
 static uint32_t node_own_cost(const kso_frame_cfg *cfg, uint32_t inter, const uint32_t *icost, int idx, int l, uint8_t *use_intra)
 {
@@ -1156,7 +1158,10 @@ static int intra_filter_flag(int mode, int n)
 static int intra_mode_bits(int mode) { return (mode == 0 || mode == 1 || mode == 26) ? 3 : 6; }   /* default MPM set vs. escape code */
 
 /* best luma mode of one block from source neighbours; returns the cost */
-static uint32_t intra_best_mode(const kso_frame_cfg *cfg, const uint8_t *S, long st, int x, int y, int n, int *best_mode)
+/* coarse: the candidates of P / B pictures try planar, DC and every fourth angular mode (2, 6, .. 34: 11 of the 35) - measured on the 832x480 clips: +0.5 % bytes
+ * (hierarchical B) / none (IPPP) against all 35, for a third of the kernel's work (tools/rd_eval.py) */
+#define INTRA_INTER_MODE_STEP 4
+static uint32_t intra_best_mode(const kso_frame_cfg *cfg, const uint8_t *S, long st, int x, int y, int n, int *best_mode, int coarse)
 {
     uint8_t raw[4 * 32 + 1], fil[4 * 32 + 1], pred[32 * 32];
     int log2 = n == 8 ? 3 : (n == 16 ? 4 : 5);
@@ -1164,6 +1169,7 @@ static uint32_t intra_best_mode(const kso_frame_cfg *cfg, const uint8_t *S, long
     ks265o_intra_filter_ref(raw + 2 * n, fil + 2 * n, n, 1);
     uint32_t best = COST_INVALID;
     for (int mode = 0; mode < 35; ++mode) {
+        if (coarse && mode >= 2 && ((mode - 2) % INTRA_INTER_MODE_STEP)) continue;
         ks265o_intra_pred(pred, n, (intra_filter_flag(mode, n) ? fil : raw) + 2 * n, mode, log2, 1);
         uint32_t c = ks265o_had(S + (long)y * st + x, pred, st, n, n, n) + (uint32_t)((cfg->lambda_q4 * intra_mode_bits(mode)) >> 4);
         if (c < best) { best = c; *best_mode = mode; }
@@ -1203,8 +1209,24 @@ static void intra_emit(const kso_frame_cfg *cfg, const intra_ctu *t, int cx, int
 static void intra_decide_impl(const kso_frame_cfg *cfg, kso_pic src, kso_cu8 *cu8, uint32_t *cost_out, uint8_t *mode_out);
 void kso_intra_decide(const kso_frame_cfg *cfg, kso_pic src, kso_cu8 *cu8) { intra_decide_impl(cfg, src, cu8, NULL, NULL); }
 void kso_intra_decide_ex(const kso_frame_cfg *cfg, kso_pic src, kso_cu8 *cu8, uint32_t *cost_out) { intra_decide_impl(cfg, src, cu8, cost_out, NULL); }
-/* the candidates of P / B pictures (cfg->intra_inter): cost and best mode of every block, no CU tree (cu8 may be NULL) */
-void kso_intra_candidates(const kso_frame_cfg *cfg, kso_pic src, uint32_t *cost_out, uint8_t *mode_out) { intra_decide_impl(cfg, src, NULL, cost_out, mode_out); }
+/* the candidates of P / B pictures (cfg->intra_inter): cost and best mode of every block, no CU tree.  Gate: a CTU is evaluated only if one of its 8x8 PUs has an
+ * inter cost of at least lambda x INTRA_BIAS_BITS >> 4 - what an intra CU costs before its first residual bit; where every 8x8 block is predicted better than that no
+ * block goes intra (costs invalid).  pu_records: the picture's ks265_pu / ks265_pu_b records (16 bytes each, cost at byte 8).  Measured on hierarchical-B pictures
+ * at 832x480 and 1920x1080: 7 - 26 % of the CTUs pass, none of the CTUs that end up with an intra CU is gated out. */
+void kso_intra_candidates(const kso_frame_cfg *cfg, kso_pic src, const void *pu_records, uint32_t *cost_out, uint8_t *mode_out)
+{
+    kso_frame_geom g; kso_frame_geometry(cfg, &g);
+    intra_decide_impl(cfg, src, NULL, cost_out, mode_out);
+    const uint32_t thr = (uint32_t)((cfg->lambda_q4 * INTRA_BIAS_BITS) >> 4);
+    for (long c = 0; c < (long)g.ctu_cols * g.ctu_rows; ++c) {
+        int go = 0;
+        for (int i = 21; i < 85 && !go; ++i) {
+            const uint32_t cost = ((const uint32_t *)pu_records)[(c * 85 + i) * 4 + 2];
+            go = cost != COST_INVALID && cost >= thr;
+        }
+        if (!go) for (int i = 0; i < 85; ++i) { cost_out[c * 85 + i] = COST_INVALID; mode_out[c * 85 + i] = 0; }
+    }
+}
 static void intra_decide_impl(const kso_frame_cfg *cfg, kso_pic src, kso_cu8 *cu8, uint32_t *cost_out, uint8_t *mode_out)
 {
     kso_frame_geom g; kso_frame_geometry(cfg, &g);
@@ -1220,7 +1242,7 @@ static void intra_decide_impl(const kso_frame_cfg *cfg, kso_pic src, kso_cu8 *cu
                         int s = 64 >> l, x0 = cx * 64 + px * s, y0 = cy * 64 + py * s, idx = pu_index(l, px, py), m = 0;
                         t.cost[idx] = COST_INVALID;
                         if (x0 + s > cfg->width || y0 + s > cfg->height) continue;
-                        t.cost[idx] = intra_best_mode(cfg, S, g.stride_y, x0, y0, s, &m);
+                        t.cost[idx] = intra_best_mode(cfg, S, g.stride_y, x0, y0, s, &m, !cu8 && mode_out);
                         t.mode[idx] = (uint8_t)m;
                     }
             t.cost[0] = COST_INVALID;

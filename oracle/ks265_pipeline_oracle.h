@@ -49,7 +49,7 @@ void kso_cu_flat_intra(const kso_frame_cfg *cfg, kso_cu8 *cu8);
 /* cfg->intra_inter: the CU trees with intra candidates (icost / imode: 85 per CTU from kso_intra_candidates; NULL = none), and the intra CUs' reconstruction pass */
 void kso_cu_decide_ii(const kso_frame_cfg *cfg, const kso_pu *pu, const uint32_t *icost, const uint8_t *imode, kso_cu8 *cu8);
 void kso_cu_decide_b_ii(const kso_frame_cfg *cfg, const kso_pu_b *pub, const uint32_t *icost, const uint8_t *imode, kso_cu8 *cu8);
-void kso_intra_candidates(const kso_frame_cfg *cfg, kso_pic src, uint32_t *cost_out, uint8_t *mode_out);
+void kso_intra_candidates(const kso_frame_cfg *cfg, kso_pic src, const void *pu_records, uint32_t *cost_out, uint8_t *mode_out);
 void kso_intra_inter_reconstruct(const kso_frame_cfg *cfg, kso_pic src, kso_cu8 *cu8, int16_t *lvl_y, int16_t *lvl_u, int16_t *lvl_v, kso_pic recon);
 void kso_reconstruct(const kso_frame_cfg *cfg, kso_pic src, kso_pic ref, const uint8_t *planes, kso_pic ref1, const uint8_t *planes1,
                      kso_cu8 *cu8, int16_t *lvl_y, int16_t *lvl_u, int16_t *lvl_v, kso_pic recon);

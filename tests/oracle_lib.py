@@ -131,10 +131,10 @@ class OraclePipeline:
             if self.cfg.subme:
                 o.kso_me_subpel(cfg, self.src.c(), ptr(self.planes), ptr(self.pu))
             ii = self.cfg.intra_inter
-            if ii:                                       # intra candidates of this picture: cost + mode of every block from source neighbours
-                if not hasattr(self, "icost"):
-                    self.icost, self.imode = np.zeros(self.nctu * 85, np.uint32), np.zeros(self.nctu * 85, np.uint8)
-                o.kso_intra_candidates(cfg, self.src.c(), ptr(self.icost), ptr(self.imode))
+            if ii and not hasattr(self, "icost"):
+                self.icost, self.imode = np.zeros(self.nctu * 85, np.uint32), np.zeros(self.nctu * 85, np.uint8)
+            if ii and kind == "P":                       # intra candidates of this picture: cost + mode of every block from source neighbours, gated by the inter costs
+                o.kso_intra_candidates(cfg, self.src.c(), ptr(self.pu), ptr(self.icost), ptr(self.imode))
             if kind == "P":
                 if ii:
                     o.kso_cu_decide_ii(cfg, ptr(self.pu), ptr(self.icost), ptr(self.imode), ptr(self.cu8))
@@ -154,6 +154,8 @@ class OraclePipeline:
                 if self.cfg.subme:
                     o.kso_me_subpel(cfg, self.src.c(), ptr(self.planes1), ptr(self.pu1))
                 o.kso_bi_decide(cfg, self.src.c(), ptr(self.planes), ptr(self.planes1), ptr(self.pu), ptr(self.pu1), ptr(self.pub))
+                if ii:
+                    o.kso_intra_candidates(cfg, self.src.c(), ptr(self.pub), ptr(self.icost), ptr(self.imode))
                 if ii:
                     o.kso_cu_decide_b_ii(cfg, ptr(self.pub), ptr(self.icost), ptr(self.imode), ptr(self.cu8))
                 else:

@@ -26,7 +26,7 @@ def ks():
 
 
 # the tool set the C host (ks265_enc.c) and bench.py switch on for -preset slow: what is timed is what is checked (VERDICT r2 "weak 1a")
-ENCODER_TOOLS = dict(sdh=1, pre_search=1, merge=1, bi_refine=1, rdo=4)
+ENCODER_TOOLS = dict(sdh=1, pre_search=1, merge=1, bi_refine=1, rdo=4, intra_inter=1)
 
 
 def _ippp(ks, W, H, qp, me, nfr, seed, abc=(37, 53, 19), pan=(5, 3), hidden_offset=True, hex_thr=0, **tools):
@@ -136,8 +136,8 @@ def test_config4_bframes3_umh_720p(ks):
 
     W, H = 1280, 720
     clip = make_clip(W, H, 9, seed=44)
-    o = OraclePipeline(W, H, 27, lambda_q4(27), me_method=2, me_hex_thr=16)
-    with KsFrame(ks, W, H, 27, lambda_q4(27), me_method=2, bframes=3, me_hex_thr=16) as f:
+    o = OraclePipeline(W, H, 27, lambda_q4(27), me_method=2, me_hex_thr=16, **ENCODER_TOOLS)        # the encoder's tool set (what ks265enc -bframes 3 runs)
+    with KsFrame(ks, W, H, 27, lambda_q4(27), me_method=2, bframes=3, me_hex_thr=16, **ENCODER_TOOLS) as f:
         src = f.new_pic()
         dg, do = {}, {}
         prev_anchor = {}
@@ -149,7 +149,8 @@ def test_config4_bframes3_umh_720p(ks):
                 r0, r1 = last, None
                 prev_anchor[d], last = last, d
             q = {"I": 27, "P": 28, "B": 30}[kind]
-            o.set_qp(q, lambda_q4(q)); f.set_qp(q, lambda_q4(q))
+            lam = lambda_q4(q, inter=kind != "I")
+            o.set_qp(q, lam); f.set_qp(q, lam)
             do[d] = o.encode(clip[d], kind, do.get(r0), do.get(r1))
             f.load_i420(ks.dev(clip[d]), src)
             out = f.new_pic()
@@ -160,6 +161,39 @@ def test_config4_bframes3_umh_720p(ks):
             dg[d] = out
             got, exp = ks.host(f.store_i420(out), np.uint8), o.store(do[d])
             assert (got == exp).all(), f"picture {d} ({kind}): {int((got != exp).sum())} bytes differ"
+
+
+def test_hier_b8_1080p_encoder_tools(ks):
+    """the SDK's default GOP (hierarchical B, 8) at 1920x1080 with the encoder's tool set: anchors 8 pictures apart (intra CUs where the motion uncovers),
+    three layers of B pictures with the joint refinement, coefficient-group pruning everywhere - every picture == oracle"""
+    from ks265codec_amd.gop import hier_order
+    from ks265codec_amd.lib import KsFrame
+    from ks265codec_amd.synth import lambda_q4, make_clip
+    from oracle_lib import OraclePipeline
+
+    W, H, G = 1920, 1080, 8
+    clip = make_clip(W, H, G + 1, seed=45)
+    o = OraclePipeline(W, H, 27, lambda_q4(27), me_method=2, me_hex_thr=16, **ENCODER_TOOLS)
+    nintra = 0
+    with KsFrame(ks, W, H, 27, lambda_q4(27), me_method=2, bframes=3, me_hex_thr=16, **ENCODER_TOOLS) as f:
+        src = f.new_pic()
+        dg, do = [f.new_pic() for _ in range(G + 1)], {}
+        for d, kind, r0, r1, layer in itertools.islice(hier_order(G, 128), G + 1):
+            q = 27 if kind == "I" else 28 + layer
+            lam = lambda_q4(q, inter=kind != "I")
+            o.set_qp(q, lam); f.set_qp(q, lam)
+            do[d] = o.encode(clip[d], kind, do.get(r0), do.get(r1))
+            f.load_i420(ks.dev(clip[d]), src)
+            out = dg[d % (G + 1)]
+            if kind == "B":
+                f.encode_picture_b(src, dg[r0 % (G + 1)], dg[r1 % (G + 1)], out)
+            else:
+                f.encode_picture(src, dg[r0 % (G + 1)] if r0 is not None else out, kind == "I", out)
+            got, exp = ks.host(f.store_i420(out), np.uint8), o.store(do[d])
+            assert (got == exp).all(), f"picture {d} ({kind}, layer {layer}): {int((got != exp).sum())} bytes differ"
+            if kind != "I":
+                nintra += int((o.cu8["pred_mode"] == 2).sum())
+    assert nintra > 0, "the clip should make some CU of a P / B picture intra"
 
 
 def test_full_size_properties_2160p_umh(ks):
@@ -201,7 +235,7 @@ def test_fuzz_bounded(ks, tmp_path):
     for it in range(40):
         W, H = int(rng.integers(1, 60)) * 8, int(rng.integers(1, 40)) * 8
         qp, me = int(rng.integers(0, 52)), int(rng.integers(0, 3))
-        kw = dict(me_range=int(rng.choice([8, 16, 32, 64])), subme=int(rng.integers(0, 2)), deblock=int(rng.integers(0, 2)), sao=int(rng.integers(0, 2)), me_method=me, me_hex_thr=int(rng.choice([0, 0, 16, 40])), sdh=int(rng.integers(0, 2)), pre_search=int(rng.integers(0, 2)), merge=int(rng.integers(0, 2)), bi_refine=int(rng.integers(0, 2)), decimate=int(rng.integers(0, 4)), rdo=int(rng.choice([0, 0, 2, 4, 9])))
+        kw = dict(me_range=int(rng.choice([8, 16, 32, 64])), subme=int(rng.integers(0, 2)), deblock=int(rng.integers(0, 2)), sao=int(rng.integers(0, 2)), me_method=me, me_hex_thr=int(rng.choice([0, 0, 16, 40])), sdh=int(rng.integers(0, 2)), pre_search=int(rng.integers(0, 2)), merge=int(rng.integers(0, 2)), bi_refine=int(rng.integers(0, 2)), decimate=int(rng.integers(0, 4)), rdo=int(rng.choice([0, 0, 2, 4, 9])), intra_inter=int(rng.integers(0, 2)))
         mode = str(rng.choice(["ippp", "mref", "hier"]))
         clip = make_clip(W, H, 9, seed=int(rng.integers(0, 10000)), noisy=bool(rng.integers(0, 2)), pan=(int(rng.integers(0, 100)), int(rng.integers(0, 60))) if it % 3 == 0 else (5, 3))
         o = OraclePipeline(W, H, qp, lambda_q4(qp), **kw)
