@@ -577,30 +577,31 @@ def encoded_leg(args, torch, dist, rank, world, dev_index, backend, sync_all):
         # pictures = iper - 1 P/B pictures + ONE key picture.  `value` is the whole-GOP rate (the key picture's share included); A is reported beside it.
         iper = args.iper if args.iper > 0 else 1 << 30
         if lanes > 1:
-            # GOP lanes: `lanes` closed GOPs are coded at once and handed out in GOP order, so pictures leave the encoder in bursts (a GOP that was coded
-            # while its predecessor was being handed out comes at once) and the input side runs ahead of the output by up to a GOP per lane.  The clock is
-            # therefore the OUTPUT side, over whole rounds of `lanes` GOPs, which begin and end at the same phase of that pattern.  Untimed: the warm-up and
-            # everything until 2 rounds are out (every lane has finished two GOPs, all buffers are full).  Window A = the next --steps pictures out (inside a
-            # GOP: reported, not the value).  Window B = the next whole round of lanes x iper pictures out, `lanes` key pictures among them = `value`.
+            # GOP lanes: `lanes` closed GOPs are coded at once and handed out in GOP order; every lane buffers a whole GOP of input beyond the one it is coding, and
+            # while the caller sits in a device synchronize the lanes go on coding from those buffers - "pictures in" or "pictures out" between two synchronizes
+            # is then not the number of pictures the GPU coded between them.  So each window is a closed piece of work: the encoder is EMPTY on both sides
+            # (flush + barrier + device synchronize), the pictures fed in between are exactly the pictures coded in between.  Untimed: the warm-up and two whole
+            # rounds of `lanes` GOPs (graphs captured, buffers touched).  Window A = --steps pictures.  Window B = four whole rounds (4 x `lanes` GOPs, as many key
+            # pictures) = `value`; it includes starting from and draining to an empty pipeline, which a long-running encoder pays once (about 5 % of the window).
             rnd = lanes * iper
-            feed(args.warmup)
-            feed_until(-(-(args.warmup + 2 * rnd) // rnd) * rnd)
-            sync_all()
-            p0, t0 = state["pics"], time.perf_counter()
-            feed_until(p0 + args.steps)
+            feed(-(-(args.warmup + 2 * rnd) // rnd) * rnd)
+            flush(); sync_all()
+            t0 = time.perf_counter()
+            feed(args.steps); flush()
             sync_all()
             dt_a = time.perf_counter() - t0
-            win = {"A": {"pictures": state["pics"] - p0, "seconds": round(dt_a, 5), "clock": "pictures out of the encoder"}}
-            feed_until(-(-state["pics"] // rnd) * rnd)            # untimed: to the end of the current round
+            win = {"A": {"pictures": args.steps, "seconds": round(dt_a, 5), "clock": "fed, coded and flushed between two synchronizes"}}
             sync_all()
-            p0, i0, t0 = state["pics"], state["t"], time.perf_counter()
-            feed_until(p0 + rnd)
-            t_out = time.perf_counter() - t0
+            o0, t0 = state["pics"], time.perf_counter()
+            feed(4 * rnd)
+            t_in = time.perf_counter() - t0
+            flush()
             sync_all()
             dt = time.perf_counter() - t0
-            npic = state["pics"] - p0
-            win["B"] = {"pictures": npic, "seconds": round(dt, 5), "key_pictures": lanes, "clock": "pictures out of the encoder", "gop_lanes": lanes,
-                        "pictures_in": state["t"] - i0, "seconds_before_the_closing_synchronize": round(t_out, 5)}
+            npic = 4 * rnd
+            assert state["pics"] - o0 == npic, (state["pics"] - o0, npic)
+            win["B"] = {"pictures": npic, "seconds": round(dt, 5), "key_pictures": 4 * lanes, "clock": "fed, coded and flushed between two synchronizes", "gop_lanes": lanes,
+                        "seconds_feeding": round(t_in, 5)}
         else:
             fill = args.warmup + 132
             if iper < 1 << 20:

@@ -296,6 +296,24 @@ __global__ __launch_bounds__(256) void intra_recon_kernel(KsGeom g, int qp, cons
                 L.WC[tid >> 5][(1 + (tid & 31)) * 72 + 3] = L.WC[tid >> 5][(1 + (tid & 31)) * 72 + 4 + 31];
             }
         }
+        auto load_own = [&]() {
+            // source samples of the CTU: 64 rows x 64 bytes luma (16-byte pieces), 2 x 32 x 32 chroma; rows below the picture are padding, never used
+            const int r = tid >> 2, cc16 = (tid & 3) * 16;
+            *(uint4 *)&L.SY[r * 64 + cc16] = *(const uint4 *)(S0 + (long)(cy * 64 + r) * g.sy + cx * 64 + cc16);
+            const int cc = tid >> 7, t = tid & 127, rc = t >> 2, c8 = (t & 3) * 8;
+            *(uint2 *)&L.SC[cc][rc * 32 + c8] = *(const uint2 *)((cc ? S2 : S1) + (long)(cy * 32 + rc) * g.sc + cx * 32 + c8);
+            if (PMODE) {
+                // the CTU's own reconstructed samples (the inter CUs, written by reconstruct_kernel before this launch; window rows start 4 bytes into an
+                // 8-byte grid: dword stores)
+                const uint4 wy = *(const uint4 *)(c.R0 + (long)(cy * 64 + r) * g.sy + cx * 64 + cc16);
+                unsigned *dy = (unsigned *)&L.WY[(1 + r) * 136 + 4 + cc16];
+                dy[0] = wy.x; dy[1] = wy.y; dy[2] = wy.z; dy[3] = wy.w;
+                const uint2 wc = *(const uint2 *)((cc ? c.R2 : c.R1) + (long)(cy * 32 + rc) * g.sc + cx * 32 + c8);
+                unsigned *dc = (unsigned *)&L.WC[cc][(1 + rc) * 72 + 4 + c8];
+                dc[0] = wc.x; dc[1] = wc.y;
+            }
+        };
+        if (PMODE) load_own();                                       // nothing of this depends on the neighbours: under way before the wait
         if (PMODE) {
             // the four neighbour CTUs whose samples this CTU's intra CUs may read (left, top-left, top, top-right) must be through - with or without intra CUs of
             // their own (those without flagged themselves at once)
@@ -322,29 +340,12 @@ __global__ __launch_bounds__(256) void intra_recon_kernel(KsGeom g, int qp, cons
             }
         }
         __syncthreads();
-        {   // source samples of the CTU: 64 rows x 64 bytes luma (16-byte pieces), 2 x 32 x 32 chroma; rows below the picture are padding, never used
-            const int r = tid >> 2, cc16 = (tid & 3) * 16;
-            *(uint4 *)&L.SY[r * 64 + cc16] = *(const uint4 *)(S0 + (long)(cy * 64 + r) * g.sy + cx * 64 + cc16);
-            const int cc = tid >> 7, t = tid & 127, rc = t >> 2, c8 = (t & 3) * 8;
-            *(uint2 *)&L.SC[cc][rc * 32 + c8] = *(const uint2 *)((cc ? S2 : S1) + (long)(cy * 32 + rc) * g.sc + cx * 32 + c8);
-            if (PMODE) {
-                // the CTU's own reconstructed samples (the inter CUs, written by reconstruct_kernel before this launch) and its left neighbour column (this
-                // work-group's own earlier stores, or the inter kernel's: L2-coherent loads)
-                {   // (window rows start 4 bytes into an 8-byte grid: dword stores)
-                    const uint4 wy = *(const uint4 *)(c.R0 + (long)(cy * 64 + r) * g.sy + cx * 64 + cc16);
-                    unsigned *dy = (unsigned *)&L.WY[(1 + r) * 136 + 4 + cc16];
-                    dy[0] = wy.x; dy[1] = wy.y; dy[2] = wy.z; dy[3] = wy.w;
-                    const uint2 wc = *(const uint2 *)((cc ? c.R2 : c.R1) + (long)(cy * 32 + rc) * g.sc + cx * 32 + c8);
-                    unsigned *dc = (unsigned *)&L.WC[cc][(1 + rc) * 72 + 4 + c8];
-                    dc[0] = wc.x; dc[1] = wc.y;
-                }
-                if (cx > 0) {
-                    if (tid < 64) L.WY[(1 + tid) * 136 + 3] = __hip_atomic_load(c.R0 + (long)(cy * 64 + tid) * g.sy + cx * 64 - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    else if (tid < 128) {
-                        const int k = tid - 64, pc = k >> 5, rr = k & 31;
-                        L.WC[pc][(1 + rr) * 72 + 3] = __hip_atomic_load((pc ? c.R2 : c.R1) + (long)(cy * 32 + rr) * g.sc + cx * 32 - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                }
+        if (!PMODE) load_own();
+        if (PMODE && cx > 0) {                                       // the left neighbour column: another work-group's stores (L2-coherent loads)
+            if (tid < 64) L.WY[(1 + tid) * 136 + 3] = __hip_atomic_load(c.R0 + (long)(cy * 64 + tid) * g.sy + cx * 64 - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else if (tid < 128) {
+                const int k = tid - 64, pc = k >> 5, rr = k & 31;
+                L.WC[pc][(1 + rr) * 72 + 3] = __hip_atomic_load((pc ? c.R2 : c.R1) + (long)(cy * 32 + rr) * g.sc + cx * 32 - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         if (cy > 0) {                                                // the row above: finished by another workgroup -> L2-coherent loads

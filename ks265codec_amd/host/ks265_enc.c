@@ -164,7 +164,8 @@ int QY265ConfigParse(QY265EncConfig *c, const char *name, const char *value)
 /* ------------------------------------------------------------------ encoder */
 #define MAX_DPB 14
 #define MAX_JOBS 128                                      /* upper bound of the ring of pictures in flight; the encoder sizes its ring (Enc::ring) by picture size */
-#define MAX_INPUT (MAX_JOBS + 32)
+typedef struct TopWake { pthread_mutex_t mu; pthread_cond_t cv; unsigned long seq; } TopWake;
+#define MAX_INPUT (MAX_JOBS + 32 + 256)                /* input slots: the ring + a mini-GOP (+ in a GOP lane: a whole GOP of the next round, Enc::nin) */
 
 typedef struct Job {
     int used, done, error;
@@ -288,11 +289,13 @@ typedef struct Enc {
      * two GOPs.  Its reconstruction goes to one of two DPB slots of its own; the first P picture of the GOP waits for ev_key. */
     int key_overlap, nkeys; ks265_ctx *ctx_key; ks265_frame *frame_key; ks265_pic src_key; uint64_t *dev_sse_key; void *ev_key, *ev_firstp[2];
     /* scheduling */
-    Input in[MAX_INPUT]; int next_disp;                   /* display index of the next input picture */
+    Input in[MAX_INPUT]; int nin, next_disp;                   /* display index of the next input picture */
     int gop_start;                                        /* display index of the last key picture */
     int coded_upto;                                       /* display index up to which everything is scheduled */
     int force_key;
     int gop_end, gop_end_seen;                            /* GOP lanes: display index of the last picture of a GOP that ended early (-1: none); what the scheduler has acted on */
+    int multi;                                            /* one of several GOP lanes of a handle */
+    struct TopWake *wake;                                 /* lanes: the handle's caller sleeps here until a picture of ANY lane is finished */
     Job jobs[MAX_JOBS]; int ring, job_head, job_tail, njobs;   /* ring of `ring` pictures in coding order */
     /* workers */
     pthread_t th[64]; int nth; pthread_mutex_t mu; pthread_cond_t cv_work, cv_done; int quit;
@@ -315,6 +318,12 @@ typedef struct Enc {
 
 static double now_ms(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e3 + t.tv_nsec * 1e-6; }
 static void rc_account(Enc *e);
+static void lane_wake_top(Enc *e)
+{
+    TopWake *w = e->wake;
+    if (!w) return;
+    pthread_mutex_lock(&w->mu); ++w->seq; pthread_cond_broadcast(&w->cv); pthread_mutex_unlock(&w->mu);
+}
 static int lane_recon_on(Enc *e);
 static int hip_rc(int r) { return r == 0 ? QY_OK : r == KS265_OUTOFMEMORY ? QY_OUTOFMEMORY : r == KS265_POINTER ? QY_POINTER : r == KS265_NOTSUPPORTED ? QY_NOTSUPPORTED : QY_FAIL; }
 
@@ -460,7 +469,7 @@ static void *worker(void *arg)
             if (err) {                                           /* nothing to write: the picture is finished (with its error) */
                 j->error = err; j->done = 1;
                 rc_account(e);
-                pthread_cond_broadcast(&e->cv_done);
+                pthread_cond_broadcast(&e->cv_done); lane_wake_top(e);
                 continue;
             }
             j->nrows = ks265_wpp_rows(j->wpp); j->next_row = 0; j->rows_done = 0; j->started = 1;
@@ -484,7 +493,7 @@ static void *worker(void *arg)
                 j->t_write_ms += now_ms() - t1;
                 j->nal_len = n; j->error = n < 0 ? (int)n : 0; j->done = 1; j->t_done = now_ms();
                 rc_account(e);
-                pthread_cond_broadcast(&e->cv_done);
+                pthread_cond_broadcast(&e->cv_done); lane_wake_top(e);
             }
         }
     }
@@ -930,7 +939,7 @@ static void lane_close(Enc *e, int report)
     free(e);
 }
 
-static Enc *lane_open(QY265EncConfig *cfg, int device, int *err)
+static Enc *lane_open(QY265EncConfig *cfg, int device, int multi, int *err)
 {
     int dummy; if (!err) err = &dummy;
     *err = QY_OK;
@@ -1036,7 +1045,14 @@ static Enc *lane_open(QY265EncConfig *cfg, int device, int *err)
         j->nal = (uint8_t *)malloc(j->nal_cap);
         if (!j->nal) r = KS265_OUTOFMEMORY;
     }
-    for (int i = 0; i < e->ring + 32 && !r; ++i) r = ks265_host_malloc(e->ctx, (void **)&e->in[i].i420, fsz);
+    /* input slots: the ring + a mini-GOP.  A GOP lane takes a whole GOP more: the caller hands the GOPs out in stream order, so a lane that could not hold its next GOP
+     * while it is still coding the current one would make the caller wait - and the OTHER lanes, whose next GOPs come after, run dry (measured: lanes idle a third of
+     * the time with ring + 32 slots) */
+    e->nin = e->ring + 32 + (multi ? (cfg->iIntraPeriod < 256 ? cfg->iIntraPeriod : 256) : 0);
+    if (getenv("KS265_INPUT_SLOTS")) e->nin = atoi(getenv("KS265_INPUT_SLOTS"));
+    if (e->nin < e->ring + 32) e->nin = e->ring + 32;
+    if (e->nin > MAX_INPUT) e->nin = MAX_INPUT;
+    for (int i = 0; i < e->nin && !r; ++i) r = ks265_host_malloc(e->ctx, (void **)&e->in[i].i420, fsz);
     if (r) { *err = hip_rc(r); lane_close(e, 0); return NULL; }
     memset(&e->scfg, 0, sizeof e->scfg);
     e->scfg.width = e->W; e->scfg.height = e->H; e->scfg.sao = e->use_sao; e->scfg.deblock = e->use_df;
@@ -1111,9 +1127,10 @@ static int lane_put(Enc *e, QY265Picture *in, int key)
     const double tc0 = now_ms();
     pthread_mutex_lock(&e->mu);
     /* back-pressure on the input side: at most 16 pictures wait for the scheduler thread (it may itself be waiting for ring space, which only the
-     * caller's take_output frees - then go on and collect) */
-    while (!e->quit && !e->sched_err && e->next_disp - (e->coded_upto + 1) > 16 && e->njobs <= e->ring - 12) pthread_cond_wait(&e->cv_sched_done, &e->mu);   /* a scheduler that failed makes no more progress */
-    for (int i = 0; i < e->ring + 32 && !slot; ++i) if (!e->in[i].used) slot = &e->in[i];
+     * caller's take_output frees - then go on and collect).  GOP lanes (multi): the input slots are the limit (lane_has_slot) - a lane takes a whole GOP in
+     * while it is still coding the previous one, or the caller would wait here while the other lanes run dry */
+    while (!e->multi && !e->quit && !e->sched_err && e->next_disp - (e->coded_upto + 1) > 16 && e->njobs <= e->ring - 12) pthread_cond_wait(&e->cv_sched_done, &e->mu);   /* a scheduler that failed makes no more progress */
+    for (int i = 0; i < e->nin && !slot; ++i) if (!e->in[i].used) slot = &e->in[i];
     if (slot) slot->used = 3;                                          /* being filled */
     pthread_mutex_unlock(&e->mu);
     if (!slot) return QY_FAIL;                                         /* one lane: cannot happen (more input slots than pictures in flight + one mini-GOP); lanes: the caller checked lane_has_slot */
@@ -1218,7 +1235,12 @@ static int lane_set_recon_file(Enc *e, const char *path)
  * threads spread over the host), DESIGN.md section 6. */
 #define MAX_LANES 16
 #define MAX_CHUNKS 64
-typedef struct Chunk { int lane, closed; long count, delivered, base; int disp0; /* the lane's own display index of the GOP's first picture */ } Chunk;
+/* stash: pictures of a GOP that is not yet at the head of the output order are taken out of their lane as they finish (their NAL units copied here), so that the
+ * lane's ring of pictures in flight never fills up with finished work waiting for an earlier GOP of another lane */
+typedef struct Chunk {
+    int lane, closed; long count, delivered, base; int disp0; /* the lane's own display index of the GOP's first picture */
+    long stashed; QY265Nal *snal; size_t *soff; int sn, sn_cap; uint8_t *sbuf; size_t scap, spos; QY265Picture sout;
+} Chunk;
 typedef struct Top {
     int nlanes; Enc *lane[MAX_LANES];
     int iper, key_request, cur_lane;
@@ -1228,79 +1250,122 @@ typedef struct Top {
     QY265Nal *onals; size_t *ooff; int on, on_cap;                   /* output of the current call: NAL payloads copied out of the lanes */
     uint8_t *obuf; size_t ocap, opos;
     double output_ms;
+    TopWake wake;
 } Top;
 
 static int lane_has_slot(Enc *e)
 {
     int ok = 0;
     pthread_mutex_lock(&e->mu);
-    for (int i = 0; i < e->ring + 32 && !ok; ++i) ok = !e->in[i].used;
+    for (int i = 0; i < e->nin && !ok; ++i) ok = !e->in[i].used;
     pthread_mutex_unlock(&e->mu);
     return ok;
 }
 
-/* wait until the oldest picture of the lane is written (pictures are in the lane: as input or in flight) */
-static int lane_wait_head(Enc *e)
-{
-    pthread_mutex_lock(&e->mu);
-    while (!e->quit && !e->sched_err && !(e->njobs && e->jobs[e->job_head].done)) {
-        struct timespec ts; clock_gettime(CLOCK_REALTIME, &ts);
-        ts.tv_nsec += 50 * 1000000L; if (ts.tv_nsec >= 1000000000L) { ts.tv_nsec -= 1000000000L; ++ts.tv_sec; }
-        pthread_cond_timedwait(&e->cv_done, &e->mu, &ts);
-    }
-    const int r = e->quit ? QY_FAIL : e->sched_err;
-    pthread_mutex_unlock(&e->mu);
-    return r;
-}
-
-static int top_append(Top *t, const QY265Nal *nals, int n)
+static int nal_append(QY265Nal **dn, size_t **doff, int *dcnt, int *dcap, uint8_t **dbuf, size_t *bcap, size_t *bpos, const QY265Nal *nals, int n)
 {
     for (int i = 0; i < n; ++i) {
-        if (t->on == t->on_cap) {
-            const int nc = t->on_cap ? 2 * t->on_cap : 1024;
-            QY265Nal *a = (QY265Nal *)realloc(t->onals, (size_t)nc * sizeof *a);
-            if (a) t->onals = a;
-            size_t *b = a ? (size_t *)realloc(t->ooff, (size_t)nc * sizeof *b) : NULL;
+        if (*dcnt == *dcap) {
+            const int nc = *dcap ? 2 * *dcap : 1024;
+            QY265Nal *a = (QY265Nal *)realloc(*dn, (size_t)nc * sizeof *a);
+            if (a) *dn = a;
+            size_t *b = a ? (size_t *)realloc(*doff, (size_t)nc * sizeof *b) : NULL;
             if (!a || !b) return QY_OUTOFMEMORY;
-            t->ooff = b; t->on_cap = nc;
+            *doff = b; *dcap = nc;
         }
         const size_t need = (size_t)nals[i].iSize;
-        if (t->opos + need > t->ocap) {
-            const size_t nc = (t->opos + need) * 2 + 65536;
-            uint8_t *nb = (uint8_t *)realloc(t->obuf, nc);
+        if (*bpos + need > *bcap) {
+            const size_t nc = (*bpos + need) * 2 + 65536;
+            uint8_t *nb = (uint8_t *)realloc(*dbuf, nc);
             if (!nb) return QY_OUTOFMEMORY;
-            t->obuf = nb; t->ocap = nc;
+            *dbuf = nb; *bcap = nc;
         }
-        memcpy(t->obuf + t->opos, nals[i].pPayload, need);
-        t->onals[t->on] = nals[i]; t->ooff[t->on] = t->opos;
-        ++t->on; t->opos += need;
+        memcpy(*dbuf + *bpos, nals[i].pPayload, need);
+        (*dn)[*dcnt] = nals[i]; (*doff)[*dcnt] = *bpos;
+        ++*dcnt; *bpos += need;
     }
     return QY_OK;
 }
+static int top_append(Top *t, const QY265Nal *nals, int n) { return nal_append(&t->onals, &t->ooff, &t->on, &t->on_cap, &t->obuf, &t->ocap, &t->opos, nals, n); }
 
 /* move finished pictures to the call's output, GOP after GOP; block = wait until at least one picture has come */
-static int top_collect(Top *t, int block, QY265Picture *out)
+static int top_collect_pass(Top *t, QY265Picture *out, long *progress, long *pending)
 {
     while (t->ch_n) {
         Chunk *c = &t->ch[t->ch_head];
+        if (c->sn) {                                                    /* what was taken out of the lane while earlier GOPs were still going out */
+            for (int i = 0; i < c->sn; ++i) c->snal[i].pPayload = c->sbuf + c->soff[i];
+            const int ra = top_append(t, c->snal, c->sn);
+            if (ra) return ra;
+            c->delivered += c->stashed; *progress += c->stashed; c->stashed = 0; c->sn = 0; c->spos = 0;
+            if (out) { out->iSliceType = c->sout.iSliceType; out->pts = c->sout.pts; out->dts = c->sout.dts; out->poc = (int)(c->base + (c->sout.poc - c->disp0)); }
+        }
         if (c->delivered == c->count) {
             if (!c->closed) break;                                      /* the GOP still receives input */
+            free(c->snal); free(c->soff); free(c->sbuf); c->snal = NULL; c->soff = NULL; c->sbuf = NULL; c->sn_cap = 0; c->scap = 0;
             t->ch_head = (t->ch_head + 1) % MAX_CHUNKS; --t->ch_n;
             continue;
         }
-        Enc *e = t->lane[c->lane];
-        if (block) { const int r = lane_wait_head(e); if (r) return r; }
         QY265Nal *nals; int n = 0, pics = 0;
-        const int r = take_output(e, MAX_JOBS + 1, (int)(c->count - c->delivered), &nals, &n, out, &pics);
+        const int r = take_output(t->lane[c->lane], MAX_JOBS + 1, (int)(c->count - c->delivered), &nals, &n, out, &pics);
         if (r) return r;
-        if (!pics) { if (block) continue; break; }
+        if (!pics) break;
         const int ra = top_append(t, nals, n);
         if (ra) return ra;
-        c->delivered += pics;
+        c->delivered += pics; *progress += pics;
         if (out) out->poc = (int)(c->base + (out->poc - c->disp0));    /* the lane reports its own display index */
-        block = 0;
+    }
+    /* the GOPs behind the head: whatever their lanes have finished goes into the stash (a lane hands its pictures out in its own order: only its oldest unfinished
+     * GOP can be taken from) */
+    unsigned busy = 0;                                                  /* lanes whose oldest unfinished GOP has been seen */
+    for (int k = 0; k < t->ch_n; ++k) {
+        Chunk *c = &t->ch[(t->ch_head + k) % MAX_CHUNKS];
+        *pending += c->count - c->delivered - c->stashed;
+        if (busy >> c->lane & 1u) continue;
+        if (c->delivered + c->stashed == c->count && c->closed) continue;   /* all taken: the lane's next GOP is its oldest unfinished one */
+        busy |= 1u << c->lane;
+        if (k == 0) continue;                                           /* the head goes out directly (above) */
+        for (;;) {
+            const long left = c->count - c->delivered - c->stashed;
+            if (left <= 0) break;
+            QY265Nal *nals; int n = 0, pics = 0;
+            const int r = take_output(t->lane[c->lane], MAX_JOBS + 1, (int)left, &nals, &n, &c->sout, &pics);
+            if (r) return r;
+            if (!pics) break;
+            const int ra = nal_append(&c->snal, &c->soff, &c->sn, &c->sn_cap, &c->sbuf, &c->scap, &c->spos, nals, n);
+            if (ra) return ra;
+            c->stashed += pics; *progress += pics; *pending -= pics;
+        }
     }
     return QY_OK;
+}
+
+/* move finished pictures to the call's output, GOP after GOP (and, from the lanes behind, to their stash); block = do not come back before SOMETHING has moved
+ * (a picture out, or into a stash: either frees a lane's buffers), unless nothing is on its way at all */
+static int top_collect(Top *t, int block, QY265Picture *out)
+{
+    for (;;) {
+        pthread_mutex_lock(&t->wake.mu);
+        const unsigned long seen = t->wake.seq;
+        pthread_mutex_unlock(&t->wake.mu);
+        long progress = 0, pending = 0;
+        const int r = top_collect_pass(t, out, &progress, &pending);
+        if (r || !block || progress || !pending) return r;
+        for (int i = 0; i < t->nlanes; ++i) {
+            Enc *e = t->lane[i];
+            pthread_mutex_lock(&e->mu);
+            const int bad = e->quit ? QY_FAIL : e->sched_err;
+            pthread_mutex_unlock(&e->mu);
+            if (bad) return bad;
+        }
+        pthread_mutex_lock(&t->wake.mu);
+        if (t->wake.seq == seen) {                                      /* a writer thread of any lane finishing a picture wakes this up; the time limit covers a failing lane */
+            struct timespec ts; clock_gettime(CLOCK_REALTIME, &ts);
+            ts.tv_nsec += 20 * 1000000L; if (ts.tv_nsec >= 1000000000L) { ts.tv_nsec -= 1000000000L; ++ts.tv_sec; }
+            pthread_cond_timedwait(&t->wake.cv, &t->wake.mu, &ts);
+        }
+        pthread_mutex_unlock(&t->wake.mu);
+    }
 }
 
 /* no more input for the newest GOP.  early: it ends before its period is over (a key-picture request) - with B pictures the lane's scheduler is still waiting
@@ -1372,7 +1437,7 @@ void *QY265EncoderOpen(QY265EncConfig *cfg, int *err)
     }
     for (int i = 0; i < t->nlanes; ++i) {
         if (i) lc.logLevel = cfg->logLevel > 2 ? cfg->logLevel : 3;     /* one start-up line */
-        t->lane[i] = lane_open(&lc, dev[i % ndev], err);
+        t->lane[i] = lane_open(&lc, dev[i % ndev], t->nlanes > 1, err);
         if (!t->lane[i]) {
             if (i == 0) { free(t); return NULL; }
             t->nlanes = i;                                              /* e.g. out of memory for another pipeline: go on with the lanes there are */
@@ -1381,7 +1446,8 @@ void *QY265EncoderOpen(QY265EncConfig *cfg, int *err)
         }
     }
     if ((size_t)cfg->picWidth * cfg->picHeight >= ((size_t)1 << 20)) t->pool = copy_pool_create();
-    for (int i = 0; i < t->nlanes; ++i) t->lane[i]->pool = t->pool;
+    pthread_mutex_init(&t->wake.mu, NULL); pthread_cond_init(&t->wake.cv, NULL);
+    for (int i = 0; i < t->nlanes; ++i) { t->lane[i]->pool = t->pool; t->lane[i]->multi = t->nlanes > 1; t->lane[i]->wake = t->nlanes > 1 ? &t->wake : NULL; }
     if (t->nlanes > 1) logf_(0, cfg->logLevel, "ks265enc: %d GOP lanes on %d GPU(s) (closed GOPs of %d pictures coded concurrently, output in GOP order)\n", t->nlanes, ndev < t->nlanes ? ndev : t->nlanes, t->iper);
     return t;
 }
@@ -1402,7 +1468,9 @@ void QY265EncoderClose(void *h)
         }
     }
     for (int i = 0; i < t->nlanes; ++i) lane_close(t->lane[i], t->nlanes == 1);
+    pthread_mutex_destroy(&t->wake.mu); pthread_cond_destroy(&t->wake.cv);
     copy_pool_destroy(t->pool);
+    for (int i = 0; i < MAX_CHUNKS; ++i) { free(t->ch[i].snal); free(t->ch[i].soff); free(t->ch[i].sbuf); }
     free(t->onals); free(t->ooff); free(t->obuf);
     free(t);
 }
@@ -1432,6 +1500,7 @@ int QY265EncoderDelayedFrames(void *h)
     if (!t) return 0;
     int n = 0;
     for (int i = 0; i < t->nlanes; ++i) n += lane_delayed(t->lane[i]);
+    for (int k = 0; k < t->ch_n; ++k) n += (int)t->ch[(t->ch_head + k) % MAX_CHUNKS].stashed;   /* taken out of their lane, waiting for an earlier GOP to go out */
     return n;
 }
 
@@ -1452,7 +1521,8 @@ int QY265EncoderEncodeFrame(void *h, QY265Nal **pNals, int *iNalCount, QY265Pict
             if (r) return r;
             t->cur_lane = (t->cur_lane + 1) % t->nlanes;
             Chunk *c = &t->ch[(t->ch_head + t->ch_n) % MAX_CHUNKS];
-            c->lane = t->cur_lane; c->closed = 0; c->count = 0; c->delivered = 0; c->base = t->n_in; c->disp0 = t->lane[t->cur_lane]->next_disp;
+            memset(c, 0, sizeof *c);
+            c->lane = t->cur_lane; c->base = t->n_in; c->disp0 = t->lane[t->cur_lane]->next_disp;
             ++t->ch_n;
             t->chunk_left = t->iper > 0 ? t->iper : (1L << 40);
             t->key_request = 0; first = 1;

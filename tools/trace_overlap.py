@@ -29,6 +29,28 @@ def main(db):
         depth += d; last = t
     tot = sum(r[1] - r[0] for r in rows)
     print(f"dispatches {len(rows)}  span {span / 1e6:.3f} ms  GPU busy (union) {busy / 1e6:.3f} ms = {busy / span:.3f}  sum of kernel durations {tot / 1e6:.3f} ms  >= 2 kernels in flight {over / 1e6:.3f} ms = {over / span:.3f}")
+    nw = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    if nw:                                                           # the same per window of the span: where the GPU idles, where queues overlap
+        t0 = rows[0][0]; w = span / nw
+        acc = [[0, 0, {}] for _ in range(nw)]
+        pics = [0] * nw                                              # pictures per window: one SAO launch each
+        depth = 0; last = ev[0][0]
+        def add(a, b, k):
+            while a < b:
+                i = min(nw - 1, int((a - t0) / w)); e = min(b, t0 + (i + 1) * w) if i < nw - 1 else b
+                if e <= a: e = b if i >= nw - 1 else min(b, a + 1)      # (rounding at a window boundary: always advance)
+                acc[i][k] += e - a; a = e
+        for t, d in ev:
+            if depth >= 1: add(last, t, 0)
+            if depth >= 2: add(last, t, 1)
+            depth += d; last = t
+        if qcol:
+            for r in rows:
+                i = min(nw - 1, int((r[0] - t0) / w)); acc[i][2][r[3]] = acc[i][2].get(r[3], 0) + r[1] - r[0]
+        for r in rows:
+            if "sao_ctu_kernel" in r[2]: pics[min(nw - 1, int((r[1] - t0) / w))] += 1
+        for i, (b, o, q) in enumerate(acc):
+            print(f"  window {i:2d} [{i * w / 1e6:8.1f} ms]: busy {b / w:.2f}  >=2 {o / w:.2f}  pictures {pics[i]:4d} = {pics[i] / (w / 1e9):7.1f} /s  " + "  ".join(f"q{k}: {v / w:.2f}" for k, v in sorted(q.items())))
     if qcol:
         q = {}
         for r in rows:
