@@ -67,7 +67,8 @@ __global__ __launch_bounds__(NC * 64, KS_SUBPEL_OCC) void me_subpel_kernel(KsGeo
     __shared__ unsigned short s_item[NC * 256];
     __shared__ int s_cnt[NC * 4];
     __shared__ unsigned short s_sat[9][NC * 256];                 // an 8x8 SATD is at most 8 * 8 * 8 * 255 / 4 = 32640
-    __shared__ __attribute__((aligned(16))) unsigned short s_hx[NC][16][8 * 16];   // per wave and item column: horizontally filtered rows, [pixel][row 0..15]
+    __shared__ __attribute__((aligned(16))) unsigned short s_hx[NC][16][8 * 16 + 8];   // per wave and item column: horizontally filtered rows, [pixel][row 0..15]; + 4 dwords: the 16 columns of a
+                                                                                      // block start in different banks (68 = 4 mod 32; unpadded, all of them hit the same)
     if (lane == 0) s_org[wave] = have ? ((ctu % g.ctu_cols) * 64) | (((ctu / g.ctu_cols) * 64) << 16) : 0;
     // Z-order: lane bits (y2 x2 y1 x1 y0 x0)
     const int tx = (lane & 1) | ((lane >> 1) & 2) | ((lane >> 2) & 4), ty = ((lane >> 1) & 1) | ((lane >> 2) & 2) | ((lane >> 3) & 4);
@@ -176,18 +177,41 @@ __global__ __launch_bounds__(NC * 64, KS_SUBPEL_OCC) void me_subpel_kernel(KsGeo
         // every lane then reads the ten rows its two output rows of the three y positions need.
         // Items are dealt to the waves in blocks of 16 (one MFMA operand block: lane = (item column n16, K group gk)), block b to wave b mod NC: the pooled
         // items of the group's CTUs spread evenly over the waves.
+        // The loads are software-pipelined: the 20 dwords a lane filters for x position gx + 1 (or for the first x position of the wave's NEXT block) are requested
+        // before the lane turns to the three y positions of gx - at two waves per SIMD nothing else would cover an L2 round trip per x position.
+        struct Item { int ii, cx, cy; unsigned ro; ks_v4i S; };
+        auto setup = [&](int blk, Item &t) {
+            t.ii = blk * 16 + n16;
+            const int it = s_item[t.ii < nitems ? t.ii : blk * 16];    // the last block is padded with copies of its first item
+            const int il = it & 63, iw = it >> 8, ikey = s_key[iw][(it >> 6) & 3][il], org = s_org[iw];
+            const int itx = (il & 1) | ((il >> 1) & 2) | ((il >> 2) & 4), ity = ((il >> 1) & 1) | ((il >> 2) & 2) | ((il >> 3) & 4);
+            t.ro = (unsigned)(((org >> 16) + ity * 8 + 2 * gk) * g.sy + (org & 0xFFFF) + itx * 8);   // this lane's two rows of the tile
+            t.cx = (int)(short)(ikey & 0xFFFF); t.cy = ikey >> 16;
+            const uint2 a0 = *(const uint2 *)(Sp + t.ro), a1 = *(const uint2 *)(Sp + t.ro + (unsigned)g.sy);
+            t.S = ks_v4i{(int)(a0.x ^ 0x7F7F7F7Fu), (int)(a0.y ^ 0x7F7F7F7Fu), (int)(a1.x ^ 0x7F7F7F7Fu), (int)(a1.y ^ 0x7F7F7F7Fu)};
+        };
+        unsigned raw[4][5], rsh = 0;
+        // rows 4 gk .. 4 gk + 3 of the item's 16-row neighbourhood at x position gx: picture row = tile row (2 gk) + rbase + 2 gk + j
+        auto request = [&](const Item &t, int gx) {
+            const int ax = t.cx + (gx - 1) * step, rbase = ((t.cy - step) >> 2) - 3;
+            const uint8_t *hp = ref + (unsigned)((int)t.ro + (int)g.org_y + (rbase + 2 * gk) * g.sy + (ax >> 2));
+            rsh = luma_hrow8_shift(hp);                              // (the row pitch is a multiple of 4: one shift for the four rows)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) luma_hrow8_load(hp + j * g.sy, raw[j]);
+        };
+        Item cur;
+        int blk = wave;
+        bool more = blk * 16 < nitems;
+        if (more) { setup(blk, cur); request(cur, 0); }
 #pragma unroll 1
-        for (int blk = wave; blk * 16 < nitems; blk += NC) {
+        while (more) {
+            const int nblk = blk + NC;
+            const bool nmore = nblk * 16 < nitems;
+            Item nxt = cur;
             {
-                const int ii = blk * 16 + n16;
-                const int it = s_item[ii < nitems ? ii : blk * 16];  // the last block is padded with copies of its first item
-                const int il = it & 63, iw = it >> 8, ikey = s_key[iw][(it >> 6) & 3][il], org = s_org[iw];
-                const int itx = (il & 1) | ((il >> 1) & 2) | ((il >> 2) & 4), ity = ((il >> 1) & 1) | ((il >> 2) & 2) | ((il >> 3) & 4);
-                const unsigned ro = (unsigned)(((org >> 16) + ity * 8 + 2 * gk) * g.sy + (org & 0xFFFF) + itx * 8);   // this lane's two rows of the tile
-                const int cx = (int)(short)(ikey & 0xFFFF), cy = ikey >> 16;
-                const uint2 a0 = *(const uint2 *)(Sp + ro), a1 = *(const uint2 *)(Sp + ro + (unsigned)g.sy);
-                const ks_v4i S = ks_v4i{(int)(a0.x ^ 0x7F7F7F7Fu), (int)(a0.y ^ 0x7F7F7F7Fu), (int)(a1.x ^ 0x7F7F7F7Fu), (int)(a1.y ^ 0x7F7F7F7Fu)};
-                const int aymin = cy - step, rbase = (aymin >> 2) - 3;      // first input row of the neighbourhood, relative to the tile row of K group 0
+                const int ii = cur.ii, cx = cur.cx, cy = cur.cy;
+                const ks_v4i S = cur.S;
+                const int aymin = cy - step;                                 // first input row of the neighbourhood: (aymin >> 2) - 3 relative to the tile row
                 unsigned short *hx = &s_hx[wave][n16][0];                    // [pixel 0..7][row 0..15] of this item
                 // vertical taps of the three y positions as row-pair weights: output row r starts at this lane's row s = roff + r (0, 1 or 2)
                 unsigned W0[3][5], W1[3][5];
@@ -213,16 +237,16 @@ __global__ __launch_bounds__(NC * 64, KS_SUBPEL_OCC) void me_subpel_kernel(KsGeo
                     const int ax = cx + (gx - 1) * step;
                     int tl, th;
                     luma_taps_packed(ax & 3, tl, th);
-                    // rows 4 gk .. 4 gk + 3 of the neighbourhood: picture row = tile row (2 gk) + rbase + 2 gk + j
-                    const uint8_t *hp = ref + (unsigned)((int)ro + (int)g.org_y + (rbase + 2 * gk) * g.sy + (ax >> 2));
 #pragma unroll
                     for (int jp = 0; jp < 2; ++jp) {
                         int h0[8], h1[8];
-                        luma_hrow8(hp + (2 * jp) * g.sy, tl, th, h0);
-                        luma_hrow8(hp + (2 * jp + 1) * g.sy, tl, th, h1);
+                        luma_hrow8_calc(raw[2 * jp], rsh, tl, th, h0);
+                        luma_hrow8_calc(raw[2 * jp + 1], rsh, tl, th, h1);
 #pragma unroll
                         for (int i = 0; i < 8; ++i) *(unsigned *)&hx[i * 16 + 4 * gk + 2 * jp] = ((unsigned)h0[i] & 0xFFFFu) | ((unsigned)h1[i] << 16);
                     }
+                    if (gx < 2) request(cur, gx + 1);
+                    else if (nmore) { setup(nblk, nxt); request(nxt, 0); }
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     unsigned P[8][5];                                    // per pixel: row pairs (0,1) (2,3) .. (8,9) of this lane's ten rows 2 gk .. 2 gk + 9
 #pragma unroll
@@ -265,6 +289,7 @@ __global__ __launch_bounds__(NC * 64, KS_SUBPEL_OCC) void me_subpel_kernel(KsGeo
                     }
                 }
             }
+            cur = nxt; blk = nblk; more = nmore;
         }
         __syncthreads();
         // (3) per (level, tile): PU sums and the winner.  The mv rate is separable: lambda * (bits(x) + bits(y)) >> 4 with three

@@ -35,11 +35,18 @@ __device__ __forceinline__ void luma_taps(int f, int (&c)[8])
 
 // raw horizontal tap sums of 8 adjacent samples of one row: h[i] = sum_k taps[k] * row[i - 3 + k] (scale 64, fits 16 bits).
 // v_dot4_i32_i8 on (sample - 128): the + 8192 restores the bias (the taps sum to 64).  tl / th = taps 0..3 / 4..7 packed.
-__device__ __forceinline__ void luma_hrow8(const uint8_t *row, int tl, int th, int (&h)[8])
+// In two steps so that a caller can have the loads of its NEXT rows in flight while it filters these: luma_hrow8_load fetches the five aligned dwords that
+// cover samples -3 .. +12 of the row, luma_hrow8_calc (sh = the address's low two bits, as luma_hrow8_shift gives them) does the arithmetic.
+__device__ __forceinline__ unsigned luma_hrow8_shift(const uint8_t *row) { return (unsigned)((uintptr_t)(row - 3) & 3); }
+__device__ __forceinline__ void luma_hrow8_load(const uint8_t *row, unsigned (&a)[5])
 {
     const uint8_t *q = row - 3;
-    const unsigned sh = (unsigned)((uintptr_t)q & 3);
-    const unsigned *a = (const unsigned *)(q - sh);
+    const unsigned *p = (const unsigned *)(q - ((uintptr_t)q & 3));
+#pragma unroll
+    for (int i = 0; i < 5; ++i) a[i] = p[i];
+}
+__device__ __forceinline__ void luma_hrow8_calc(const unsigned (&a)[5], unsigned sh, int tl, int th, int (&h)[8])
+{
     const unsigned a0 = a[0] ^ 0x80808080u, a1 = a[1] ^ 0x80808080u, a2 = a[2] ^ 0x80808080u, a3 = a[3] ^ 0x80808080u, a4 = a[4] ^ 0x80808080u;
     unsigned w[4];
     w[0] = align_bytes(a1, a0, sh); w[1] = align_bytes(a2, a1, sh); w[2] = align_bytes(a3, a2, sh); w[3] = align_bytes(a4, a3, sh);   // bytes -3..0, 1..4, 5..8, 9..12
@@ -49,6 +56,12 @@ __device__ __forceinline__ void luma_hrow8(const uint8_t *row, int tl, int th, i
         const unsigned lo = s ? align_bytes(w[k + 1], w[k], s) : w[k], hi = s ? align_bytes(w[k + 2], w[k + 1], s) : w[k + 1];
         h[i] = __builtin_amdgcn_sdot4((int)hi, th, __builtin_amdgcn_sdot4((int)lo, tl, 8192, false), false);
     }
+}
+__device__ __forceinline__ void luma_hrow8(const uint8_t *row, int tl, int th, int (&h)[8])
+{
+    unsigned a[5];
+    luma_hrow8_load(row, a);
+    luma_hrow8_calc(a, luma_hrow8_shift(row), tl, th, h);
 }
 
 // 8 samples of one row, unfiltered (fx = 0)
