@@ -74,7 +74,6 @@ struct IntraLds {
     unsigned char raw[3][132], fil[132];                 // reference arrays, corner at index 66 (luma: 64 + 1 + 64; chroma 32 + 1 + 32)
     int nz[3];
     int lastcg[3];
-    __attribute__((aligned(8))) short LV[3][32 * RP], DU[3][32 * RP], CF[3][32 * RP];   // levels / quantisation remainders / coefficients of the TU (sign-data hiding)
     int cbf[64];
     ks265_cu8 cu[64];
     // reconstructed samples around the CTU being coded: row 0 = the row above the CTU (x = -1 .. 127: top-left, top, top-right),
@@ -98,7 +97,6 @@ struct TuCtx {
     int x0, y0, lx, ly, mode;
     bool filt;
     bool sdh;
-    bool keep;                                  // levels go through LDS (sign-data hiding and / or coefficient-group pruning)
     int qoff;                                   // the quantiser's rounding offset: 171 in I slices, 85 in P / B slices (H265_GetBaseQuantParam enc@0x4a9c90)
     long long rdo_lam2k;                        // cfg.rdo x lambda_q4^2 for the intra CUs of P / B pictures, 0 = off
 };
@@ -146,77 +144,128 @@ __device__ __forceinline__ void tu_pipeline(IntraLds &L, const TuRole &r, const 
         *(uint2 *)(T + r.qy * RP + r.qx) = make_uint2(o[0] | ((unsigned)o[1] << 16), o[2] | ((unsigned)o[3] << 16));
     }
     tu_sync<BLOCK>();
-    if (r.on) {                                                     // forward pass 2 + quant + dequant (stored transposed)
+    // ---- forward pass 2 + quantisation, then the postQuant seam IN REGISTERS: a lane holds one row of four coefficients of its 4x4 coefficient group, the group's four
+    // rows sit Q = N / 4 lanes apart in the same wave, so what a group needs to know about itself travels by two xor-shuffles - no LDS round trip, no lane walking
+    // sixteen coefficients on its own (that serial walk, not the transforms, was the time of a TU: 5.4 of 11.2 us for a 16x16 TU, 2160p, round 3).
+    int lvq[4] = {0, 0, 0, 0}, duq[4] = {0, 0, 0, 0}, cfq[4] = {0, 0, 0, 0};
+    const int ci = cp ? 1 : 0, dqs = c.qdq[ci], dshift = l2 - 1, Q = nn >> 2;
+    if (r.on) {
         int acc[4];
         quad_dot(mf + r.qy * mp, T + r.qx * RP, RP, nn, acc);
-        const int ci = cp ? 1 : 0, scale = c.qsc[ci], dqs = c.qdq[ci];
-        const int qbits = 21 + c.qp6[ci] - l2, off = c.qoff << (qbits - 9), shift = l2 - 1;
-        unsigned short lv[4];
-        int nzc = 0;
+        const int scale = c.qsc[ci], qbits = 21 + c.qp6[ci] - l2, off = c.qoff << (qbits - 9);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int coef = (short)((acc[i] + 64) >> 7);
+            cfq[i] = (short)((acc[i] + 64) >> 7);
             int du;
-            const int l = quant_one(coef, scale, off, qbits, du);
-            nzc += l != 0;
-            lv[i] = (unsigned short)(short)l;
-            if (c.keep) { const int o = r.qy * RP + r.qx + i; L.LV[cp][o] = (short)l; L.DU[cp][o] = (short)du; L.CF[cp][o] = (short)coef; }
-            X[(r.qx + i) * RP + r.qy] = (short)dequant_one(l, dqs, 1 << (shift - 1), shift);
+            lvq[i] = (short)quant_one(cfq[i], scale, off, qbits, du);
+            duq[i] = (short)du;                                     // (16 bits, as the reference keeps its deltaU)
         }
-        // (with sign-data hiding the level plane is written after the hiding step, from LDS: a second store to the same address from another wave
-        //  could overtake this one - the LDS-only barriers of this kernel do not order HBM stores)
-        if (!c.keep) *(uint2 *)((cp == 0 ? c.lvl_y : (cp == 1 ? c.lvl_u : c.lvl_v)) + (long)(py + r.qy) * lstride + px + r.qx) =
+    }
+    if (c.rdo_lam2k) {
+        // cfg.rdo (intra CUs of P / B pictures): coefficient-group pruning before sign-data hiding (recon_dev.h rdo_group_prune, the oracle's code_tu)
+        long long gain = 0;
+        int bc = 0;                                                   // bits << 8 | levels
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (lvq[i]) {
+                const int d = dequant_one(lvq[i], dqs, 1 << (dshift - 1), dshift);
+                gain += (long long)d * (2 * cfq[i] - d);
+                bc += (rdo_level_q2(lvq[i] < 0 ? -lvq[i] : lvq[i]) << 8) | 1;
+            }
+#pragma unroll
+        for (int k = 1; k <= 2; ++k) {
+            const int lo = __shfl_xor((int)(unsigned)gain, Q * k, 64), hi = __shfl_xor((int)(gain >> 32), Q * k, 64);
+            gain += (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+            bc += __shfl_xor(bc, Q * k, 64);
+        }
+        const int cnt = bc & 255, bits = (bc >> 8) + 10 + (16 - cnt);
+        if (cnt && ((gain >> (2 * (7 - l2))) << 12) <= c.rdo_lam2k * bits) { lvq[0] = 0; lvq[1] = 0; lvq[2] = 0; lvq[3] = 0; }
+    }
+    {   // levels per component of this wave (a wave holds one component, the chroma wave of a small CU both chroma components)
+        const int cp0 = __builtin_amdgcn_readfirstlane(cp);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            int cnt = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) cnt += __popcll(__ballot(r.on && cp == cp0 + k && lvq[i] != 0));
+            if (cnt && (threadIdx.x & 63) == 0) atomicAdd(&L.nz[cp0 + k], cnt);
+        }
+    }
+    int qpos[4] = {0, 0, 0, 0};
+    unsigned nzmask = 0, negmask = 0;
+    int csum = 0, gorder = 0;
+    if (c.sdh) {
+        // the postQuant seam (postQuant enc@0x4ace80): sign-data hiding with the TU's scan (H.265 7.4.9.11: intra 4x4 / 8x8 luma and 4x4 chroma follow the
+        // prediction mode).  Survey: the group's levels as masks in SCAN order (bit q = position q holds a level / a negative one) and their sum
+        const int scan = (nn == 4 || (nn == 8 && cp == 0)) ? ((c.mode >= 6 && c.mode <= 14) ? 2 : (c.mode >= 22 && c.mode <= 30) ? 1 : 0) : 0;
+        const int y = r.qy & 3;
+        unsigned v = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            qpos[i] = scan == 0 ? (int)((0xfda6eb73c8419520ull >> (4 * (y * 4 + i))) & 15ull) : scan == 1 ? y * 4 + i : i * 4 + y;
+            if (lvq[i]) v |= (lvq[i] < 0 ? 0x10001u : 1u) << qpos[i];
+            csum += lvq[i];
+        }
+#pragma unroll
+        for (int k = 1; k <= 2; ++k) { v ^= (unsigned)__shfl_xor((int)v, Q * k, 64); csum += __shfl_xor(csum, Q * k, 64); }   // (the rows' masks are disjoint: xor = or)
+        nzmask = v & 0xFFFFu; negmask = v >> 16;
+        if (r.on && nzmask) {
+            gorder = sbh_group_order(scan, nn >> 2, r.qx >> 2, r.qy >> 2) + 1;
+            if (y == 0) atomicMax(&L.lastcg[cp], gorder);            // the last group in scan order that holds a level
+        }
+        tu_sync<BLOCK>();
+        // fix the parity of the group if its first sign is hidden and the parity is wrong (signBitHidingHDQ enc@0x4aa150): the cheapest +-1 among the positions up to
+        // `start`, ties to the highest position (the reference walks downwards with a strict '<')
+        const int first = nzmask ? __ffs((int)nzmask) - 1 : 0, last = nzmask ? 31 - __clz((int)nzmask) : -1;
+        const int signbit = (int)((negmask >> first) & 1u);
+        unsigned key = 0xFFFFFFFFu;
+        int ksel = 0;
+        if (r.on && nzmask && last - first >= 4 && signbit != (csum & 1)) {
+            const int start = L.lastcg[cp] == gorder ? last : 15;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int q = qpos[i], l = lvq[i], du = duq[i];
+                int cost = 0;
+                bool ok = q <= start;
+                if (l != 0) {
+                    if (du > 0) cost = -du;
+                    else if (q == first && (l == 1 || l == -1)) ok = false;
+                    else cost = du;
+                } else if (q < first) {
+                    if ((cfq[i] < 0 ? 1 : 0) != signbit) ok = false;
+                    else cost = -du;
+                } else cost = -du;
+                const unsigned kk = ok ? ((unsigned)(cost + 32768) << 4) | (unsigned)(15 - q) : 0xFFFFFFFFu;
+                if (kk < key) { key = kk; ksel = i; }
+            }
+        }
+        unsigned kmin = key;
+#pragma unroll
+        for (int k = 1; k <= 2; ++k) kmin = min(kmin, (unsigned)__shfl_xor((int)kmin, Q * k, 64));
+        if (key != 0xFFFFFFFFu && key == kmin) {                       // this lane holds the position that moves
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (i == ksel) {
+                    const int l = lvq[i], du = duq[i];
+                    int change = l != 0 ? (du > 0 ? 1 : -1) : 1;
+                    if (l == 32767 || l == -32768) change = -1;
+                    lvq[i] = (int)(short)(cfq[i] >= 0 ? l + change : l - change);
+                }
+        }
+    }
+    if (r.on) {                                                     // the final levels: to the level plane, dequantised (transposed) for the inverse transform
+        unsigned short lv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            lv[i] = (unsigned short)(short)lvq[i];
+            X[(r.qx + i) * RP + r.qy] = (short)dequant_one(lvq[i], dqs, 1 << (dshift - 1), dshift);
+        }
+        *(uint2 *)((cp == 0 ? c.lvl_y : (cp == 1 ? c.lvl_u : c.lvl_v)) + (long)(py + r.qy) * lstride + px + r.qx) =
             make_uint2(lv[0] | ((unsigned)lv[1] << 16), lv[2] | ((unsigned)lv[3] << 16));
-        if (nzc) atomicAdd(&L.nz[cp], nzc);
     }
     tu_sync<BLOCK>();
-    if (c.rdo_lam2k) {
-        // cfg.rdo (intra CUs of P / B pictures): coefficient-group pruning before sign-data hiding, the lane holding the top row of a 4x4 group handles it
-        if (r.on && (r.qy & 3) == 0 && L.nz[cp] > 0) {
-            const int cbase = r.qy * RP + r.qx;
-            const int cnt = rdo_group_prune(L.LV[cp], L.CF[cp], cbase, c.qdq[cp ? 1 : 0], l2, c.rdo_lam2k);
-            if (cnt) {
-#pragma unroll
-                for (int y = 0; y < 4; ++y) {
-                    *(uint2 *)(L.LV[cp] + cbase + y * RP) = make_uint2(0u, 0u);
-                    *(uint2 *)(X + (r.qx + y) * RP + r.qy) = make_uint2(0u, 0u);         // the dequantised tile is stored transposed
-                }
-                atomicSub(&L.nz[cp], cnt);
-            }
-        }
-        tu_sync<BLOCK>();
-    }
-    if (c.sdh) {
-        // the postQuant seam (postQuant enc@0x4ace80): sign-data hiding with the TU's scan (H.265 7.4.9.11: intra 4x4 / 8x8 luma and 4x4 chroma
-        // follow the prediction mode); the lane holding the top row of a 4x4 coefficient group handles that group from registers (recon_dev.h) and
-        // patches the one level that moves: the level plane in HBM and the dequantised (transposed) tile
-        const int scan = (nn == 4 || (nn == 8 && cp == 0)) ? ((c.mode >= 6 && c.mode <= 14) ? 2 : (c.mode >= 22 && c.mode <= 30) ? 1 : 0) : 0;
-        const bool owner = r.on && (r.qy & 3) == 0 && L.nz[cp] > 1;
-        const int cbase = r.qy * RP + r.qx;
-        unsigned survey = 0;
-        int gorder = 0;
-        SbhRegs sr;
-        if (owner) {
-            sbh_load(L.LV[cp], L.DU[cp], L.CF[cp], cbase, sr);
-            survey = sbh_survey_rs(sr, scan);
-            gorder = sbh_group_order(scan, nn >> 2, r.qx >> 2, r.qy >> 2) + 1;
-            if (survey >> 17) atomicMax(&L.lastcg[cp], gorder);
-        }
-        tu_sync<BLOCK>();
-        if (owner && survey) {
-            int nl = 0;
-            const int pos = sbh_apply_rs(sr, scan, survey, L.lastcg[cp] == gorder, nl);
-            if (pos >= 0) {
-                const int row = r.qy + (pos >> 2), col = r.qx + (pos & 3), ci = cp ? 1 : 0, shift = l2 - 1;
-                L.LV[cp][row * RP + col] = (short)nl;
-                X[col * RP + row] = (short)dequant_one(nl, c.qdq[ci], 1 << (shift - 1), shift);
-            }
-        }
-        tu_sync<BLOCK>();
-    }
     const bool live = r.on && L.nz[cp] != 0;
     if (r.on) {                                                     // inverse pass 1: T[y][x] = clip16((Mt[y] . Ct[x] + 64) >> 7)
-        if (c.keep) *(uint2 *)((cp == 0 ? c.lvl_y : (cp == 1 ? c.lvl_u : c.lvl_v)) + (long)(py + r.qy) * lstride + px + r.qx) = *(const uint2 *)(L.LV[cp] + r.qy * RP + r.qx);
         int acc[4] = {0, 0, 0, 0};
         if (live) quad_dot(mt + r.qy * mp, X + r.qx * RP, RP, nn, acc);
         unsigned short o[4];
@@ -271,7 +320,7 @@ __global__ __launch_bounds__(256) void intra_recon_kernel(KsGeom g, int qp, cons
     const int qpc = chroma_qp(qp);
     TuCtx c;
     c.sdh = sdh_on != 0;
-    c.rdo_lam2k = PMODE ? rdo_lam2k : 0; c.keep = c.sdh || c.rdo_lam2k != 0; c.qoff = PMODE ? 85 : 171;
+    c.rdo_lam2k = PMODE ? rdo_lam2k : 0; c.qoff = PMODE ? 85 : 171;
     c.g = &g; c.lvl_y = lvl_y; c.lvl_u = lvl_u; c.lvl_v = lvl_v;
     // quantiser constants of the two QPs, fetched once (a table load inside the CU loop would sit behind every outstanding store)
     c.qsc[0] = kQuantScales[qp % 6]; c.qsc[1] = kQuantScales[qpc % 6];
@@ -498,15 +547,15 @@ __device__ __forceinline__ int intra_mode_bits(int mode) { return (mode == 0 || 
 // least what an intra CU costs before its first residual bit, lambda x KS_INTRA_GATE_BITS >> 4 (= the bias of the CU decision): where every 8x8 block is predicted
 // better than that, no block goes intra - most CTUs of a P / B picture leave here.
 #define KS_INTRA_GATE_BITS 96
-__global__ __launch_bounds__(256) void intra_decide_kernel(KsGeom g, int lam, const uint8_t *src_y, ks265_cu8 *cu8, unsigned *cost_out, unsigned *best_out, const uint4 *gate_pu)
+__global__ __launch_bounds__(256) void intra_decide_kernel(KsGeom g, int lam, const uint8_t *src_y, ks265_cu8 *cu8, unsigned *cost_out, unsigned *best_out, const uint4 *gate_pu, unsigned nlev)
 {
     __shared__ __attribute__((aligned(16))) DecideLds L;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int lsel = gate_pu ? 1 + (int)(blockIdx.x % 3u) : 0;      // lsel: the one level this work-group handles (0 = all)
+    const int lsel = gate_pu ? 1 + (int)(blockIdx.x % nlev) : 0;      // lsel: the one level this work-group handles (0 = all); nlev = 3, or 2: no 8x8 candidates
     // the modes by index: key pictures all 35; candidates planar, DC and every fourth angular mode (2, 6 .. 34: the oracle's INTRA_INTER_MODE_STEP - a third of the
     // work for +0.5 % bytes at most)
     const int mi0 = 0, mi1 = gate_pu ? 11 : 35;
-    const int ctu = ks_xcd_swizzle(gate_pu ? (int)(blockIdx.x / 3u) : (int)blockIdx.x, g.ctu_cols * g.ctu_rows), cx = ctu % g.ctu_cols, cy = ctu / g.ctu_cols;
+    const int ctu = ks_xcd_swizzle(gate_pu ? (int)(blockIdx.x / nlev) : (int)blockIdx.x, g.ctu_cols * g.ctu_rows), cx = ctu % g.ctu_cols, cy = ctu / g.ctu_cols;
     const uint8_t *S = ks_org_y(g, src_y);
     if (gate_pu) {
         __shared__ int s_go;
@@ -667,7 +716,7 @@ extern "C" int ks265_intra_decide_ex(ks265_frame *f, ks265_pic src, ks265_cu8 *c
 {
     KS_FRAME_CHECK(f);
     if (!src.y || !cu8) return KS265_POINTER;
-    hipLaunchKernelGGL(intra_decide_kernel, dim3(f->g.ctu_cols * f->g.ctu_rows), dim3(256), 0, f->ctx->stream, f->g, f->cfg.lambda_q4, src.y, cu8, cost_out, (unsigned *)nullptr, (const uint4 *)nullptr);
+    hipLaunchKernelGGL(intra_decide_kernel, dim3(f->g.ctu_cols * f->g.ctu_rows), dim3(256), 0, f->ctx->stream, f->g, f->cfg.lambda_q4, src.y, cu8, cost_out, (unsigned *)nullptr, (const uint4 *)nullptr, 3u);
     return ks265_check_launch(f->ctx);
 }
 // cfg.intra_inter: the intra candidates of a P / B picture - per block (85 per CTU, PU indexing) cost << 6 | best mode, 0xFFFFFFFF where there is none (a CTU the
@@ -679,8 +728,9 @@ extern "C" int ks265_intra_candidates(ks265_frame *f, ks265_pic src, const void 
     static_assert(sizeof(ks265_pu) == 16 && sizeof(ks265_pu_b) == 16 && offsetof(ks265_pu, cost) == 8 && offsetof(ks265_pu_b, cost) == 8, "the gate reads the cost of either record type at byte 8");
     const int nctu = f->g.ctu_cols * f->g.ctu_rows;
     if (hipMemsetAsync(dev_best, 0xFF, sizeof(uint32_t) * 85 * (size_t)nctu, f->ctx->stream) != hipSuccess) return ks265_hip(f->ctx, hipGetLastError());
-    hipLaunchKernelGGL(intra_decide_kernel, dim3(nctu * 3), dim3(256), 0, f->ctx->stream, f->g, f->cfg.lambda_q4, src.y, (ks265_cu8 *)nullptr, (unsigned *)nullptr, dev_best,
-                       (const uint4 *)dev_pu_records);
+    const unsigned nlev = f->cfg.intra_inter >= 2 ? 2u : 3u;        // intra_inter 2: 32x32 and 16x16 candidates only
+    hipLaunchKernelGGL(intra_decide_kernel, dim3(nctu * nlev), dim3(256), 0, f->ctx->stream, f->g, f->cfg.lambda_q4, src.y, (ks265_cu8 *)nullptr, (unsigned *)nullptr, dev_best,
+                       (const uint4 *)dev_pu_records, nlev);
     return ks265_check_launch(f->ctx);
 }
 extern "C" int ks265_intra_decide(ks265_frame *f, ks265_pic src, ks265_cu8 *cu8) { return ks265_intra_decide_ex(f, src, cu8, nullptr); }

@@ -435,7 +435,7 @@ void kso_me_subpel(const kso_frame_cfg *cfg, kso_pic src, const uint8_t *planes,
 static uint32_t node_own_cost(const kso_frame_cfg *cfg, uint32_t inter, const uint32_t *icost, int idx, int l, uint8_t *use_intra)
 {
     use_intra[idx] = 0;
-    if (!icost || l == 0 || icost[idx] == COST_INVALID) return inter;
+    if (!icost || l == 0 || icost[idx] == COST_INVALID || (l == 3 && cfg->intra_inter >= 2)) return inter;   /* intra_inter 2: no 8x8 intra CUs in P / B pictures */
     const uint64_t ic = (uint64_t)icost[idx] + (uint64_t)((cfg->lambda_q4 * INTRA_BIAS_BITS) >> 4);
     if (inter == COST_INVALID || ic < inter) { use_intra[idx] = 1; return ic > 0xFFFFFFFEu ? 0xFFFFFFFEu : (uint32_t)ic; }
     return inter;

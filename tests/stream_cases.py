@@ -67,7 +67,7 @@ def case_rdo(name: str) -> int:
 
 
 def case_ii(name: str) -> int:
-    return 1 if name.startswith("enc_") else 0            # the C host: intra CUs in P / B pictures
+    return (2 if "1280x720" in name else 1) if name.startswith("enc_") else 0   # the C host: intra CUs in P / B pictures (one case with 2 = 16x16 and 32x32 only)
 
 
 def case_lambda(name: str, q: int, kind: str) -> int:
