@@ -542,7 +542,7 @@ struct DecideLds {
 __device__ __forceinline__ int intra_mode_bits(int mode) { return (mode == 0 || mode == 1 || mode == 26) ? 3 : 6; }   // default MPM set vs. escape code
 
 // Two uses.  Key pictures (gate_pu null): one work-group per CTU does everything and builds the CU tree.  Candidates of a P / B picture (gate_pu = the CTU's inter
-// PU records, ks265_pu / ks265_pu_b: 16 bytes, cost at byte 8; cfg.intra_inter): 11 of the 35 modes, THREE work-groups per CTU - one per level (32 / 16 / 8) - each writes (cost << 6 | mode) of its blocks to best_out (the
+// PU records, ks265_pu / ks265_pu_b: 16 bytes, cost at byte 8; cfg.intra_inter): 19 of the 35 modes, THREE work-groups per CTU - one per level (32 / 16 / 8) - each writes (cost << 6 | mode) of its blocks to best_out (the
 // caller sets the array to 0xFFFFFFFF = "no candidate").  Gate: a CTU is evaluated only if one of its 8x8 PUs costs at
 // least what an intra CU costs before its first residual bit, lambda x KS_INTRA_GATE_BITS >> 4 (= the bias of the CU decision): where every 8x8 block is predicted
 // better than that, no block goes intra - most CTUs of a P / B picture leave here.
@@ -552,9 +552,9 @@ __global__ __launch_bounds__(256) void intra_decide_kernel(KsGeom g, int lam, co
     __shared__ __attribute__((aligned(16))) DecideLds L;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lsel = gate_pu ? 1 + (int)(blockIdx.x % nlev) : 0;      // lsel: the one level this work-group handles (0 = all); nlev = 3, or 2: no 8x8 candidates
-    // the modes by index: key pictures all 35; candidates planar, DC and every fourth angular mode (2, 6 .. 34: the oracle's INTRA_INTER_MODE_STEP - a third of the
-    // work for +0.5 % bytes at most)
-    const int mi0 = 0, mi1 = gate_pu ? 11 : 35;
+    // the modes by index: key pictures all 35; candidates planar, DC and every second angular mode (2, 4 .. 34: the oracle's INTRA_INTER_MODE_STEP - no measurable
+    // loss against all 35)
+    const int mi0 = 0, mi1 = gate_pu ? 19 : 35;
     const int ctu = ks_xcd_swizzle(gate_pu ? (int)(blockIdx.x / nlev) : (int)blockIdx.x, g.ctu_cols * g.ctu_rows), cx = ctu % g.ctu_cols, cy = ctu / g.ctu_cols;
     const uint8_t *S = ks_org_y(g, src_y);
     if (gate_pu) {
@@ -631,7 +631,7 @@ __global__ __launch_bounds__(256) void intra_decide_kernel(KsGeom g, int lam, co
         unsigned best = 0xFFFFFFFFu;
 #pragma unroll 1
         for (int mi = mi0 + wave; mi < mi1; mi += 4) {
-            const int mode = gate_pu && mi >= 2 ? 2 + (mi - 2) * 4 : mi;
+            const int mode = gate_pu && mi >= 2 ? 2 + (mi - 2) * 2 : mi;
             const int which = intra_filter_flag(mode, n) ? 1 : 0;
             unsigned acc[4];
 #pragma unroll

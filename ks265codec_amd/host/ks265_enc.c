@@ -1158,7 +1158,7 @@ static int lane_put(Enc *e, QY265Picture *in, int key)
 /* flush, first half: everything that has arrived gets scheduled (short mini-GOPs at the end).  Returns 1 when the scheduler is through, 0 when the ring
  * filled up first (the scheduler then waits for the caller to collect output: hand out what is ready and come back, as the SDK's flush loop does anyway -
  * EncodeFrame(NULL) while DelayedFrames() > 0) */
-static int lane_flush_begin(Enc *e)
+static int lane_flush_begin(Enc *e, int wait)
 {
     pthread_mutex_lock(&e->mu);
     e->sched_flush = 1;
@@ -1166,7 +1166,7 @@ static int lane_flush_begin(Enc *e)
     int all = 0;
     for (;;) {
         all = !e->sched_flush && e->sched_idle && e->sched_seen == e->next_disp;
-        if (all || e->quit || e->njobs > e->ring - 12) break;
+        if (all || !wait || e->quit || e->njobs > e->ring - 12) break;   /* GOP lanes do not wait here: while the caller sat in one lane's flush nobody would collect from the others */
         pthread_cond_wait(&e->cv_sched_done, &e->mu);
     }
     pthread_mutex_unlock(&e->mu);
@@ -1189,7 +1189,7 @@ static int lane_encode_frame(Enc *e, QY265Nal **pNals, int *iNalCount, QY265Pict
     }
     /* flush: then every picture in flight is collected */
     const double t0 = now_ms();
-    const int all = lane_flush_begin(e);
+    const int all = lane_flush_begin(e, 1);
     if (e->sched_err) return e->sched_err;
     r = take_output(e, all ? 0 : e->ring - 12, 1 << 30, pNals, iNalCount, out, NULL);
     e->st.output_ms += now_ms() - t0;
@@ -1425,6 +1425,10 @@ void *QY265EncoderOpen(QY265EncConfig *cfg, int *err)
     t->nlanes = top_lanes_wanted(cfg, ndev);
     if (ndev > 1 && t->nlanes == 1) logf_(2, cfg->logLevel, "ks265enc: %d GPUs asked for, but GOP sharding needs enFrameParallel, -rc 0 and a key period >= 32: one GPU\n", ndev);
     t->iper = cfg->iIntraPeriod; t->cur_lane = -1;
+    /* every lane runs four streams (pixel path, key pictures, copy-in, copy-out); the runtime deals streams to FOUR hardware queues unless told otherwise, and a lane's
+     * 27 ms key-picture kernel in the queue of another lane's pixel path stops that lane for as long (measured: 615 -> 686 pictures/s with eight queues, two lanes,
+     * 2160p).  Only effective when this is the process's first use of the runtime; a value the user has set stays. */
+    if (t->nlanes > 1) setenv("GPU_MAX_HW_QUEUES", "8", 0);
     QY265EncConfig lc = *cfg;
     if (t->nlanes > 1) {                                                /* the writer threads are shared out: every lane sees 1 / L of the pictures */
         long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
@@ -1546,7 +1550,7 @@ int QY265EncoderEncodeFrame(void *h, QY265Nal **pNals, int *iNalCount, QY265Pict
         if (t->ch_n) top_close_chunk(t, 0);                              /* the lanes are flushed below */
         t->chunk_left = 0;
         for (int i = 0; i < t->nlanes; ++i) {
-            if (lane_delayed(t->lane[i])) lane_flush_begin(t->lane[i]);
+            if (lane_delayed(t->lane[i])) lane_flush_begin(t->lane[i], 0);
             if (t->lane[i]->sched_err) return t->lane[i]->sched_err;
         }
         r = top_collect(t, 1, out);

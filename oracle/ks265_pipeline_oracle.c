@@ -1158,9 +1158,10 @@ static int intra_filter_flag(int mode, int n)
 static int intra_mode_bits(int mode) { return (mode == 0 || mode == 1 || mode == 26) ? 3 : 6; }   /* default MPM set vs. escape code */
 
 /* best luma mode of one block from source neighbours; returns the cost */
-/* coarse: the candidates of P / B pictures try planar, DC and every fourth angular mode (2, 6, .. 34: 11 of the 35) - measured on the 832x480 clips: +0.5 % bytes
- * (hierarchical B) / none (IPPP) against all 35, for a third of the kernel's work (tools/rd_eval.py) */
-#define INTRA_INTER_MODE_STEP 4
+/* coarse: the candidates of P / B pictures try planar, DC and every second angular mode (2, 4, .. 34: 19 of the 35).  Measured with tools/rd_eval.py on the
+ * 832x480 clips: no loss against all 35 (hierarchical B: 126481 vs 126673 bytes at the same PSNR); every fourth mode (11 of 35) cost +0.5 % there and +1.4 % of
+ * the bytes of the 2160p IPPP bench clip - more than the third of the candidates kernel's time it saved was worth */
+#define INTRA_INTER_MODE_STEP 2
 static uint32_t intra_best_mode(const kso_frame_cfg *cfg, const uint8_t *S, long st, int x, int y, int n, int *best_mode, int coarse)
 {
     uint8_t raw[4 * 32 + 1], fil[4 * 32 + 1], pred[32 * 32];
