@@ -30,8 +30,10 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB
 ALGO_BYTES_P = {
     "me_integer": 2.2,       # source P + padded reference ~1.1 P + PU records
     "me_subpel": 2.2,
-    "cu_decide": 0.05,
+    "intra_candidates": 0.25,  # the source samples of the CTUs the gate lets through (16 - 20 % of them) + their PU records + the packed candidates
+    "cu_decide": 1.6,        # CU decision (PU records) + merge pass: source 1 P + prediction tiles of the candidates ~0.5 P + maps
     "reconstruct": 7.5,      # org 1.5 P + pred 1.5 P + levels 3 P + recon 1.5 P
+    "intra_pass": 0.05,      # the intra CUs of a P picture (under 1 % of its blocks): source, levels, recon of those CUs - a dependency chain, not a streaming kernel
     "deblock": 3.1,
     "sao": 6.0,              # statistics 3 P + apply 3 P (fused in one launch)
 }
@@ -327,6 +329,16 @@ def main():
             t = json.load(open(tfile)).get(f"{W}x{H}", {}).get(dom)
             if t:
                 traffic = t["bytes_per_launch"]
+        # second figure per stage: the VALU-issue fraction = wave-level VALU instructions per launch (SQ_INSTS_VALU of a rocprofv3 --pmc pass,
+        # profiles/sq_counters.json by tools/sq_issue.py) / 1.23e12 per second / the stage's duration - the kernels of this path are bound by latency and issue, not bytes
+        valu = {}
+        sfile = os.path.join(ROOT, "profiles", "sq_counters.json")
+        if os.path.exists(sfile):
+            sq = json.load(open(sfile)).get(f"{W}x{H}", {})
+            for k, v in stage_ms.items():
+                n = sum(sq.get(kk, {}).get("insts_valu_per_launch", 0) for kk in ((k, "merge_pass") if k == "cu_decide" else (k,)))
+                if n and v > 0:
+                    valu[k] = round(n / 1.23e12 / (v * 1e-3), 4)
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "algorithmic_bytes_per_launch": int(algo_bytes), "avg_launch_ms": round(stage_ms[dom], 4),
@@ -334,7 +346,10 @@ def main():
                     "streams_in_run": nstreams,
                     "stage_intervals_ms_in_run": {k: round(v, 4) for k, v in stage_run.items()},
                     "note": "avg_launch_ms / stages_ms / frac: HIP events around each stage with ONE shard on the GPU = the kernel's own duration; it agrees with the rocprofv3 kernel trace of `bench.py --streams 1` (profiles/). With the run's --streams shards in flight the kernels of different shards overlap: stage_intervals_ms_in_run are event-to-event intervals on one shard's stream under that load (queueing behind the other shards' kernels included), the kernel durations of that condition are in the rocprofv3 trace of the default command (profiles/).",
-                    "stages_frac": {k: round(ALGO_BYTES_P[k] * P / (v * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) for k, v in stage_ms.items()}}
+                    "stages_frac": {k: round(ALGO_BYTES_P[k] * P / (v * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) for k, v in stage_ms.items()},
+                    "valu_issue_frac": valu.get(dom), "stages_valu_issue_frac": valu or None,
+                    "bound_note": "no stage of a P picture is limited by HBM bytes: each is a dependency chain per CTU (search state machines, the intra CUs' wavefront) or issue-bound "
+                                  "arithmetic on L2-resident samples; valu_issue_frac = VALU wave-instructions / 1.23e12 per s / duration says how busy the vector ALUs are"}
 
         # ---- CPU baseline on this box's host cores: the reference's own CLI encoder when it is staged (oracle/_ref/appencoder or $KS265_REF_ENCODER,
         #      SURVEY.md §8d-iii), else the oracle port; a bounded sample of the same workload either way

@@ -383,9 +383,10 @@ int ks265_encode_picture(ks265_frame *f, ks265_pic src, ks265_pic ref, int is_ke
 /* a B picture: ref0 = list 0 (past), ref1 = list 1 (future); needs cfg.bframes > 0 at ks265_frame_create */
 int ks265_encode_picture_b(ks265_frame *f, ks265_pic src, ks265_pic ref0, ks265_pic ref1, ks265_pic recon_out);
 /* in-situ stage timing: HIP events recorded on the context's stream between the stages of ks265_encode_picture;
- * ms[] = {(unused, -1 or 0), me_integer, me_subpel, cu_decide, reconstruct, deblock, sao(+padding)} of the last picture, -1 = not run */
+ * ms[] = {me_integer, me_subpel, intra_candidates, cu_decide (+ merge pass), reconstruct, intra_pass, deblock, sao (+ padding)} of the last picture, -1 = not run
+ * (a key picture: intra_candidates = the mode pre-selection, intra_pass = the wavefront reconstruction) */
 int ks265_frame_set_profiling(ks265_frame *f, int enable);
-int ks265_frame_stage_ms(ks265_frame *f, float ms[7]);
+int ks265_frame_stage_ms(ks265_frame *f, float ms[8]);
 /* accessors to the frame object's internal workspace (device pointers) */
 int16_t *ks265_frame_levels(ks265_frame *f, int comp);
 ks265_pu *ks265_frame_pu(ks265_frame *f);

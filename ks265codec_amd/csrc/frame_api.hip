@@ -102,37 +102,39 @@ int ks265_encode_picture(ks265_frame *f, ks265_pic src, ks265_pic ref, int is_ke
         f->ev_valid[stage_done] = true;
         evi = stage_done + 1;
     };
-    mark(0);
     ks265_pic deb = ks_deb_pic(f);
     if (is_key) {
         /* intra picture: mode pre-selection + CU tree on the source, then the wavefront reconstruction */
-        mark(3);
+        mark(2);
         if ((r = ks265_intra_decide(f, src, f->cu8))) return r;
-        mark(4);
+        mark(3);
+        mark(5);
         if ((r = ks265_intra_reconstruct(f, src, f->cu8, f->lvl[0], f->lvl[1], f->lvl[2], deb))) return r;
         f->have_prev = false;
     } else {
         if (!ref.y) return KS265_POINTER;
-        mark(1);
+        mark(0);
         if ((r = ks265_me_integer(f, src, ref, f->have_prev ? f->pu[f->cur_pu ^ 1] : nullptr, pu))) return r;
-        mark(2);
+        mark(1);
         if (f->cfg.subme && (r = ks265_me_subpel(f, src, ref, pu))) return r;
-        mark(3);
+        mark(2);
         const bool ii = f->cfg.intra_inter != 0;              /* intra CUs may compete: their candidates first */
         if (ii && (r = ks265_intra_candidates(f, src, pu, f->icost))) return r;
+        mark(3);
         if (f->cfg.merge) {                                    /* stage C2: the CU decision goes to the spare map, the merge pass writes the final one */
             if ((r = ks265_cu_decide_ii(f, pu, ii ? f->icost : nullptr, f->cu8_tmp))) return r;
             if ((r = ks265_merge_pass(f, src, ref, ks265_pic{nullptr, nullptr, nullptr}, pu, nullptr, f->cu8_tmp, f->cu8))) return r;
         } else if ((r = ks265_cu_decide_ii(f, pu, ii ? f->icost : nullptr, f->cu8))) return r;
         mark(4);
         if ((r = ks265_reconstruct(f, src, ref, f->cu8, f->lvl[0], f->lvl[1], f->lvl[2], deb))) return r;
+        mark(5);
         if (ii && (r = ks265_intra_inter_reconstruct(f, src, f->cu8, f->lvl[0], f->lvl[1], f->lvl[2], deb))) return r;
     }
-    mark(5);
-    if (f->cfg.deblock && (r = ks265_deblock(f, f->cu8, deb))) return r;
     mark(6);
-    if ((r = ks265_sao(f, src, deb, f->sao, recon_out))) return r;
+    if (f->cfg.deblock && (r = ks265_deblock(f, f->cu8, deb))) return r;
     mark(7);
+    if ((r = ks265_sao(f, src, deb, f->sao, recon_out))) return r;
+    mark(8);
     if (!is_key) { f->cur_pu ^= 1; f->have_prev = true; }
     return KS265_OK;
 }
@@ -225,7 +227,7 @@ int ks265_frame_set_profiling(ks265_frame *f, int enable)
 }
 
 /* elapsed milliseconds of the stages of the LAST ks265_encode_picture call (synchronises the stream); -1 = stage not run */
-int ks265_frame_stage_ms(ks265_frame *f, float ms[7])
+int ks265_frame_stage_ms(ks265_frame *f, float ms[8])
 {
     KS_FRAME_CHECK(f);
     if (!ms) return KS265_POINTER;

@@ -5,7 +5,7 @@
 #define KS_PAD_Y 80
 #define KS_PAD_C 40
 #define KS_COST_INVALID 0xFFFFFFFFu
-#define KS_NSTAGE 7                   // (unused: the fractional planes of rounds 1 - 2), me_integer, me_subpel, cu_decide, reconstruct, deblock, sao (+ padding)
+#define KS_NSTAGE 8                   // me_integer, me_subpel, intra_candidates, cu_decide (+ merge pass), reconstruct, intra_pass, deblock, sao (+ padding)
 
 // geometry handed to kernels by value
 struct KsGeom {

@@ -968,6 +968,10 @@ static Enc *lane_open(QY265EncConfig *cfg, int device, int multi, int *err)
     if (e->nthreads > 64) e->nthreads = 64;
 
     if (cfg->rdoq || cfg->transskip || cfg->part || cfg->iAqMode) logf_(1, e->log_level, "ks265enc: rdoq / transskip / part / aq are accepted but not implemented by the pixel path\n");
+    /* options whose VALUE is narrowed (SURVEY.md 8(a) config 5 = -preset veryslow: subme 2, part 1, ref 4): said once, never silently */
+    if (cfg->subme > 1) logf_(1, e->log_level, "ks265enc: -subme %d runs as -subme 1 (eight half- and eight quarter-sample candidates by SATD; the second refinement round is not implemented)\n", cfg->subme);
+    if (cfg->refnum > 4) logf_(1, e->log_level, "ks265enc: -ref %d runs as -ref 4\n", cfg->refnum);
+    if (e->gop_b > 0 && cfg->refnum > 1) logf_(1, e->log_level, "ks265enc: -ref %d with B pictures runs as one reference per list\n", cfg->refnum);
     if (cfg->rc == 5 || cfg->vbv_buffer_size) logf_(1, e->log_level, "ks265enc: CVQ / VBV are not implemented; running the plain controller\n");
 
     /* the SDK's config has no device field: the lane's GPU comes from the handle (KS265_DEVICE: one GPU, default 0; KS265_GPUS / KS265_DEVICES: closed GOPs dealt

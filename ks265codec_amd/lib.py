@@ -384,15 +384,15 @@ class KsFrame:
     def encode_picture(self, src: DevPic, ref: DevPic, is_key: bool, recon_out: DevPic):
         self.ks._chk(self.lib.ks265_encode_picture(self.h, src.c(), ref.c(), C.c_int(1 if is_key else 0), recon_out.c()))
 
-    STAGES = ("unused", "me_integer", "me_subpel", "cu_decide", "reconstruct", "deblock", "sao")
+    STAGES = ("me_integer", "me_subpel", "intra_candidates", "cu_decide", "reconstruct", "intra_pass", "deblock", "sao")
 
     def set_profiling(self, on: bool):
         self.ks._chk(self.lib.ks265_frame_set_profiling(self.h, C.c_int(1 if on else 0)))
 
     def stage_ms(self) -> dict:
-        ms = (C.c_float * 7)()
+        ms = (C.c_float * 8)()
         self.ks._chk(self.lib.ks265_frame_stage_ms(self.h, ms))
-        return {n: float(ms[i]) for i, n in enumerate(self.STAGES) if n != "unused"}    # slot 0 held the fractional-plane stage of rounds 1 - 2
+        return {n: float(ms[i]) for i, n in enumerate(self.STAGES)}
 
     def sse_picture(self, a: DevPic, b: DevPic) -> np.ndarray:
         out = self.ks.zeros(24)

@@ -11,8 +11,8 @@ import csv
 import json
 import sys
 
-STAGE_OF = {"ref_planes_kernel": "ref_planes", "me_int_kernel": "me_integer", "me_subpel_kernel": "me_subpel", "cu_decide_kernel": "cu_decide",
-            "reconstruct_kernel": "reconstruct", "deblock_kernel": "deblock", "sao_ctu_kernel": "sao"}
+STAGE_OF = {"me_int_kernel": "me_integer", "me_subpel_kernel": "me_subpel", "intra_decide_kernel": "intra_candidates", "cu_decide_kernel": "cu_decide", "merge_pass_kernel": "merge_pass",
+            "reconstruct_kernel": "reconstruct", "intra_recon_kernel<true>": "intra_pass", "intra_recon_kernel<false>": "key_picture_intra_pass", "deblock_kernel": "deblock", "sao_ctu_kernel": "sao"}
 
 
 def per_kernel(path, counter):
@@ -20,7 +20,9 @@ def per_kernel(path, counter):
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter:
             continue
-        name = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
+        name = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        if not name.startswith("intra_recon_kernel"):             # (its two instantiations are different stages)
+            name = name.split("<")[0]
         tot[name] += float(r["Counter_Value"])
         cnt[name] += 1
     return {k: tot[k] / cnt[k] for k in tot}, cnt
