@@ -366,7 +366,7 @@ def main():
             "config": {"workload": f"{W}x{H} 4:2:0 8-bit, hot path only (ME + transform/quant/recon + deblock + SAO; CABAC/RC not included), "
                                    f"-rc 0 -qp {qp} (I=Q, P=Q+1, B=Q+2) -iper {args.iper}, -bframes {bf_desc}, -ref {max(1, args.refs)} -ref0 {max(1, args.refs)} ({'one reference picture per list' if args.refs <= 1 else 'every P picture searches that many list-0 pictures'}), -me {me_method} ({args.me.upper()}{', interMeHex below ' + str(args.me_hex_thr) + ' SAD/sample as at -preset slow' if me_method == 2 and args.me_hex_thr else ''}) range 64, subme=8 hpel + 8 qpel SATD, sao on, df on",
                        "pictures_per_step": nstreams, "streams_per_gpu": nstreams,
-                       "key_picture_ms": {"intra_decide": key_ms.get("cu_decide"), "intra_reconstruct": key_ms.get("reconstruct"), "total": round(sum(key_ms.values()), 3),
+                       "key_picture_ms": {"intra_decide": key_ms.get("intra_candidates"), "intra_reconstruct": key_ms.get("intra_pass"), "total": round(sum(key_ms.values()), 3),
                                           "note": f"one intra picture per -iper {args.iper} pictures; it is in the timed region whenever the schedule puts one there"},
                        "sharding": "anchor chain rotating over the ranks + RCCL broadcast of every reconstructed anchor from its owner, B pictures spread over the ranks not coding an anchor" if args.b_spread else f"{nstreams} GOP shard(s) in flight per GPU on separate HIP streams, no data-path collective"},
             "roofline": roofline, "cpu_baseline": cpu,

@@ -161,8 +161,9 @@ __device__ __forceinline__ void tu_pipeline(IntraLds &L, const TuRole &r, const 
             duq[i] = (short)du;                                     // (16 bits, as the reference keeps its deltaU)
         }
     }
-    if (c.rdo_lam2k) {
-        // cfg.rdo (intra CUs of P / B pictures): coefficient-group pruning before sign-data hiding (recon_dev.h rdo_group_prune, the oracle's code_tu)
+    if (c.rdo_lam2k && __builtin_amdgcn_readfirstlane(cp) == 0) {
+        // cfg.rdo (intra CUs of P / B pictures, luma only: a wave's lanes are all luma or all chroma): coefficient-group pruning before sign-data hiding
+        // (recon_dev.h rdo_group_prune, the oracle's code_tu)
         long long gain = 0;
         int bc = 0;                                                   // bits << 8 | levels
 #pragma unroll

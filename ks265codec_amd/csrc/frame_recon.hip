@@ -389,13 +389,13 @@ __global__ __launch_bounds__(256) void reconstruct_kernel(KsGeom g, int qp, cons
         if (nzcnt[tb]) cbf[tid] |= 1;
     }
     __syncthreads();
-    code_region<16, MREF>(g, 1, qpc, rx * 4, ry * 4, blk, tu_log2, Mf, Mt, X, T, P, nzcnt, src_u, ref_u, ref1_u, lvl_u, rec_u, tid, xr.u, sdh, LV, DU, CF, lastcg, 0, rdo_lam2k);
+    code_region<16, MREF>(g, 1, qpc, rx * 4, ry * 4, blk, tu_log2, Mf, Mt, X, T, P, nzcnt, src_u, ref_u, ref1_u, lvl_u, rec_u, tid, xr.u, sdh, LV, DU, CF, lastcg, 0, 0ll);      // chroma: no decimation, no group pruning (2 % of the bytes for 2 dB of chroma PSNR: the oracle's code_tu)
     if (tid < 16 && blk[tid].log2_cu) {
         const int t8 = 1 << tu_log2[tid], tb = ((tid >> 2) & ~(t8 - 1)) * 4 + ((tid & 3) & ~(t8 - 1));
         if (nzcnt[tb]) cbf[tid] |= 2;
     }
     __syncthreads();
-    code_region<16, MREF>(g, 2, qpc, rx * 4, ry * 4, blk, tu_log2, Mf, Mt, X, T, P, nzcnt, src_v, ref_v, ref1_v, lvl_v, rec_v, tid, xr.v, sdh, LV, DU, CF, lastcg, 0, rdo_lam2k);
+    code_region<16, MREF>(g, 2, qpc, rx * 4, ry * 4, blk, tu_log2, Mf, Mt, X, T, P, nzcnt, src_v, ref_v, ref1_v, lvl_v, rec_v, tid, xr.v, sdh, LV, DU, CF, lastcg, 0, 0ll);
     if (tid < 16 && blk[tid].log2_cu) {
         const int t8 = 1 << tu_log2[tid], tb = ((tid >> 2) & ~(t8 - 1)) * 4 + ((tid & 3) & ~(t8 - 1));
         if (nzcnt[tb]) cbf[tid] |= 4;

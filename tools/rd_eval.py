@@ -58,6 +58,7 @@ def encode_ours(clip, W, H, qp, gop, tools, verbose=False, stats=None, pdelta=1,
     bs = w.headers()
     per = []
     ps = []
+    pc = []
     if gop == "ippp":
         seq = [(t, "I" if t == 0 else "P", t - 1 if t else None, None, 0) for t in range(n)]
     else:
@@ -98,11 +99,13 @@ def encode_ours(clip, W, H, qp, gop, tools, verbose=False, stats=None, pdelta=1,
         p = psnr(clip[d][:W * H], rec[:W * H])
         per.append((d, kind, layer, len(b), p))
         ps.append((clip[d][:W * H].astype(np.float64) - rec[:W * H]) ** 2)
+        pc.append((clip[d][W * H:].astype(np.float64) - rec[W * H:]) ** 2)
         if verbose:
             print(f"   {d:3d} {kind} L{layer} {len(b):7d} B  {p:.2f} dB", flush=True)
         for k in [k for k in dpb if k not in needed and k != d and k not in cur]:
             del dpb[k]
     mse = float(np.mean([x.mean() for x in ps]))
+    encode_ours.chroma_psnr = 10 * np.log10(255.0 ** 2 / float(np.mean([x.mean() for x in pc])))
     if stats:
         for k, t in sorted(agg.items()):
             print(f"      {k}: " + "  ".join(f"{nm} {t['bits'][i] / t['n']:.0f}" for i, nm in enumerate(STAT_NAMES)) + "   CUs(n coded intra) " +
@@ -173,7 +176,7 @@ def main():
         for d, k, l, b, e in per:
             bykind.setdefault(f"{k}{l if k == 'B' else ''}", []).append(b)
         pts.append((len(bs), p))
-        print(f"ours {a.tag} qp {qp}: {len(bs):8d} B  {p:.3f} dB   " + "  ".join(f"{k}: {int(np.mean(v))} B x{len(v)}" for k, v in bykind.items()) + f"   ({time.time() - t0:.0f} s)", flush=True)
+        print(f"ours {a.tag} qp {qp}: {len(bs):8d} B  {p:.3f} dB (chroma {encode_ours.chroma_psnr:.2f})   " + "  ".join(f"{k}: {int(np.mean(v))} B x{len(v)}" for k, v in bykind.items()) + f"   ({time.time() - t0:.0f} s)", flush=True)
     if ref and len(pts) >= 2:
         pts.sort(key=lambda t: t[1])
         lo = [t for t in pts if t[1] <= ref[1]]
