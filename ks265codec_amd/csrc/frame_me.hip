@@ -341,6 +341,7 @@ extern "C" int ks265_me_subpel(ks265_frame *f, ks265_pic src, ks265_pic ref, ks2
 // transforms of one TU per CU): 40 for the one-list records of P pictures, 80 for the two-list records (B pictures, multi-reference P).  At 12 (the flags
 // alone, round 1) the P pictures of the test clips were 3-5 % and the P / B pictures of a hierarchical GOP 15 % (qp 27) to 32 % (qp 35) larger for 0.03-0.07 dB
 // (the oracle's comment has the table).
+#define KS_BI_BIAS_SHIFT 5
 #define KS_SPLIT_BITS_P 40
 #define KS_SPLIT_BITS_B 80
 // ------------------------------------------------------------------ Stage C: CU quadtree (64 threads per CTU)
@@ -521,7 +522,8 @@ __global__ __launch_bounds__(256, REFINE ? 2 : 1) void bi_decide_kernel(KsGeom g
         const unsigned dd = pu_group_sum(valid ? sd : 0, level);
         if (valid) {
             if (b.cost < o.cost) { o.cost = b.cost; o.inter_dir = 2; }
-            const unsigned c = dd + (unsigned)mv_cost(a.mvx, a.mvy, a.mvpx, a.mvpy, lam) + (unsigned)mv_cost(b.mvx, b.mvy, b.mvpx, b.mvpy, lam);
+            unsigned c = dd + (unsigned)mv_cost(a.mvx, a.mvy, a.mvpx, a.mvpy, lam) + (unsigned)mv_cost(b.mvx, b.mvy, b.mvpx, b.mvpy, lam);
+            c -= c >> KS_BI_BIAS_SHIFT;                            // a bi-predictive pair counts 31 / 32 of its cost (the oracle's BI_BIAS_SHIFT: - 3.3 % bytes on hierarchical B)
             if (c < o.cost) { o.cost = c; o.inter_dir = 3; }
         }
         if (REFINE) {
@@ -607,8 +609,9 @@ __global__ __launch_bounds__(256, REFINE ? 2 : 1) void bi_decide_kernel(KsGeom g
             for (int i = 0; i < 16; ++i) PK[i] = keep1 ? PB[i] : PA[i];
             const unsigned d2 = pu_group_sum(valid ? satd8x8_avg(f, PK, PO) : 0, level);
             if (valid) {
-                const unsigned c2 = d2 + (unsigned)(keep1 ? mv_cost(b.mvx, b.mvy, b.mvpx, b.mvpy, lam) : mv_cost(a.mvx, a.mvy, a.mvpx, a.mvpy, lam))
-                                    + (unsigned)mv_cost(rbx, rby, opx, opy, lam);
+                unsigned c2 = d2 + (unsigned)(keep1 ? mv_cost(b.mvx, b.mvy, b.mvpx, b.mvpy, lam) : mv_cost(a.mvx, a.mvy, a.mvpx, a.mvpy, lam))
+                              + (unsigned)mv_cost(rbx, rby, opx, opy, lam);
+                c2 -= c2 >> KS_BI_BIAS_SHIFT;
                 if (c2 < o.cost) {
                     o.cost = c2; o.inter_dir = 3;
                     if (keep1) { o.mvx = (int16_t)rbx; o.mvy = (int16_t)rby; } else { o.mv1x = (int16_t)rbx; o.mv1y = (int16_t)rby; }
