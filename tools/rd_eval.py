@@ -43,7 +43,7 @@ def stats_lib():
 STAT_NAMES = ["cu", "merge", "motion", "coef", "sao", "intra"]
 
 
-def encode_ours(clip, W, H, qp, gop, tools, verbose=False, stats=None, pdelta=1, cascade=None, lam_scale=1.0):
+def encode_ours(clip, W, H, qp, gop, tools, verbose=False, stats=None, pdelta=1, cascade=None, lam_scale=1.0, rdo_layers=None, b_lam=None, layer_qp=None):
     from ks265codec_amd import stream as S
     from ks265codec_amd.gop import hier_order
     from ks265codec_amd.synth import lambda_q4, psnr
@@ -65,9 +65,14 @@ def encode_ours(clip, W, H, qp, gop, tools, verbose=False, stats=None, pdelta=1,
         seq = [s for s in itertools.islice(hier_order(G, 1 << 20), n) if s[0] < n]
     dpb = {}
     for i, (d, kind, r0, r1, layer) in enumerate(seq):
-        q = min(51, qp if kind == "I" else qp + pdelta + layer + (cascade[d % len(cascade)] if cascade and gop == "ippp" else 0))
+        lq = layer_qp[min(len(layer_qp) - 1, layer)] if (layer_qp and kind == 'B') else layer      # B layers are numbered 1 (referenced most) .. 3
+        q = min(51, qp if kind == "I" else qp + pdelta + lq + (cascade[d % len(cascade)] if cascade and gop == "ippp" else 0))
         ls = lam_scale if lam_scale > 0 else (min(4.0, max(2.0, (q - 12) / 6.0))) ** 0.5      # <= 0: HM's factor for non-key pictures, clip(2, 4, (qp - 12) / 6) on lambda_mode
+        if kind == 'B' and b_lam:
+            ls *= b_lam[min(len(b_lam) - 1, layer)]
         o.set_qp(q, lambda_q4(q) if kind == "I" else int(round(lambda_q4(q) * ls)))
+        if rdo_layers:
+            o.cfg.rdo = rdo_layers[0] if kind == 'P' else rdo_layers[min(len(rdo_layers) - 1, layer)] if kind == 'B' else tools.get('rdo', 0)
         dpb[d] = o.encode(clip[d], kind, dpb.get(r0), dpb.get(r1))
         rec = o.store(dpb[d])
         later = seq[i + 1:]
@@ -148,11 +153,16 @@ def main():
     ap.add_argument("--pdelta", type=int, default=1)
     ap.add_argument("--cascade", default="")
     ap.add_argument("--lam-scale", type=float, default=1.0)
+    ap.add_argument("--pan", default="", help="pan of the synthetic clip in samples per picture, e.g. 8,5")
+    ap.add_argument("--rdo-layers", default="", help="cfg.rdo of P pictures and of the B layers 1, 2, 3 (comma separated)")
+    ap.add_argument("--b-lam", default="", help="extra lambda factors, indexed by B layer (entry 0 unused)")
+    ap.add_argument("--layer-qp", default="", help="QP offsets on top of the P offset, indexed by B layer (entry 0 unused; default = the layer number)")
     a = ap.parse_args()
     from ks265codec_amd.synth import make_clip
     W, H = (int(x) for x in a.size.split("x"))
     big = W >= 3000
-    clip = make_clip(W, H, a.frames, seed=a.seed, abc=(67, 91, 33) if big else (37, 53, 19), pan=(8, 5) if big else (5, 3))
+    pan = tuple(int(x) for x in a.pan.split(',')) if a.pan else ((8, 5) if big else (5, 3))
+    clip = make_clip(W, H, a.frames, seed=a.seed, abc=(67, 91, 33) if big else (37, 53, 19), pan=pan)
     tools = dict(ENCODER_TOOLS)
     for kv in filter(None, a.tools.split(",")):
         k, v = kv.split("=")
@@ -171,12 +181,15 @@ def main():
     pts = []
     for qp in (int(x) for x in a.qps.split(",")):
         t0 = time.time()
-        bs, p, per = encode_ours(clip, W, H, qp, a.gop, tools, a.v, stats_lib() if a.stats else None, a.pdelta, [int(x) for x in a.cascade.split(',')] if a.cascade else None, a.lam_scale)
-        bykind = {}
+        bs, p, per = encode_ours(clip, W, H, qp, a.gop, tools, a.v, stats_lib() if a.stats else None, a.pdelta, [int(x) for x in a.cascade.split(',')] if a.cascade else None, a.lam_scale,
+                                 [int(x) for x in a.rdo_layers.split(',')] if a.rdo_layers else None, [float(x) for x in a.b_lam.split(',')] if a.b_lam else None,
+                                 [int(x) for x in a.layer_qp.split(',')] if a.layer_qp else None)
+        bykind, pk = {}, {}
         for d, k, l, b, e in per:
             bykind.setdefault(f"{k}{l if k == 'B' else ''}", []).append(b)
+            pk.setdefault(f"{k}{l if k == 'B' else ''}", []).append(e)
         pts.append((len(bs), p))
-        print(f"ours {a.tag} qp {qp}: {len(bs):8d} B  {p:.3f} dB (chroma {encode_ours.chroma_psnr:.2f})   " + "  ".join(f"{k}: {int(np.mean(v))} B x{len(v)}" for k, v in bykind.items()) + f"   ({time.time() - t0:.0f} s)", flush=True)
+        print(f"ours {a.tag} qp {qp}: {len(bs):8d} B  {p:.3f} dB (chroma {encode_ours.chroma_psnr:.2f})   " + "  ".join(f"{k}: {int(np.mean(v))} B x{len(v)} {np.mean(pk[k]):.2f}dB" for k, v in bykind.items()) + f"   ({time.time() - t0:.0f} s)", flush=True)
     if ref and len(pts) >= 2:
         pts.sort(key=lambda t: t[1])
         lo = [t for t in pts if t[1] <= ref[1]]
