@@ -415,10 +415,6 @@ int ks265_frame_pack_records(ks265_frame *f, void *dev_dst, const void *dev_extr
 int ks265_frame_compact_layout(ks265_frame *f, size_t off[8]);
 int ks265_frame_pack_compact(ks265_frame *f, void *dev_dst, const void *dev_extra64);
 int ks265_copy_out_compact_async(ks265_ctx *copy_ctx, ks265_frame *f, void *pinned_host, const void *dev_block);
-/* the same, and when all of it has been stored *pinned_flag (mapped pinned host memory) is set to `value`: a host thread can wait for the records by watching that
- * word instead of calling the runtime.  dev_counter: one zero-initialised word in HBM per copy stream (work-groups count themselves in; left at zero). */
-int ks265_copy_out_compact_flag_async(ks265_ctx *copy_ctx, ks265_frame *f, void *pinned_host, const void *dev_block, uint32_t *dev_counter, volatile uint32_t *pinned_flag,
-                                      uint32_t value);
 /* luma SSE between two padded pictures (PSNR-Y of the bench line; CPSNR_I420::calcPSNR enc@0x4c4060) */
 int ks265_sse_picture(ks265_frame *f, ks265_pic a, ks265_pic b, uint64_t *dev_sse3);
 

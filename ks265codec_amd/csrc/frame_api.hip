@@ -365,21 +365,6 @@ __global__ __launch_bounds__(256) void copy_out_compact_kernel(uint4 *dst, const
     const unsigned long long n16 = fixed16 + (unsigned long long)hdr[2] * (KS_CL_LINE / 16);
     for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (unsigned long long)gridDim.x * 256) dst[i] = src[i];
 }
-// the same copy, and when the last work-group is through a word in pinned host memory is set: a host thread that watches that word learns that the records have
-// arrived without calling the runtime (hipEventSynchronize / hipEventQuery from a second thread contend with the thread that enqueues the next pictures)
-__global__ __launch_bounds__(256) void copy_out_compact_flag_kernel(uint4 *dst, const uint4 *src, unsigned long long fixed16, const unsigned *hdr, unsigned *counter,
-                                                                    volatile unsigned *host_flag, unsigned value)
-{
-    const unsigned long long n16 = fixed16 + (unsigned long long)hdr[2] * (KS_CL_LINE / 16);
-    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (unsigned long long)gridDim.x * 256) dst[i] = src[i];
-    __threadfence_system();                                          // this thread's stores to host memory are visible system-wide ...
-    __syncthreads();                                                 // ... for every thread of the work-group ...
-    if (threadIdx.x == 0 && atomicAdd(counter, 1u) == gridDim.x - 1u) {   // ... and the last work-group to get here has seen all the others arrive
-        atomicExch(counter, 0u);
-        __threadfence_system();
-        *host_flag = value;
-    }
-}
 static void compact_layout(const ks265_frame *f, size_t off[8])
 {
     const size_t npx = (size_t)f->g.W * f->g.H;
@@ -428,16 +413,6 @@ int ks265_copy_out_compact_async(ks265_ctx *ctx, ks265_frame *f, void *pinned_ho
     compact_layout(f, off);
     hipLaunchKernelGGL(copy_out_compact_kernel, dim3(32), dim3(256), 0, ctx->stream, (uint4 *)pinned_host, (const uint4 *)dev_block, (unsigned long long)(off[6] / 16),
                        (const unsigned *)((const uint8_t *)dev_block + off[3]));
-    return ks265_check_launch(ctx);
-}
-int ks265_copy_out_compact_flag_async(ks265_ctx *ctx, ks265_frame *f, void *pinned_host, const void *dev_block, uint32_t *dev_counter, volatile uint32_t *pinned_flag, uint32_t value)
-{
-    if (!ctx || !f || !pinned_host || !dev_block || !dev_counter || !pinned_flag) return KS265_POINTER;
-    ks_use_device(ctx);
-    size_t off[8];
-    compact_layout(f, off);
-    hipLaunchKernelGGL(copy_out_compact_flag_kernel, dim3(32), dim3(256), 0, ctx->stream, (uint4 *)pinned_host, (const uint4 *)dev_block, (unsigned long long)(off[6] / 16),
-                       (const unsigned *)((const uint8_t *)dev_block + off[3]), (unsigned *)dev_counter, (volatile unsigned *)pinned_flag, (unsigned)value);
     return ks265_check_launch(ctx);
 }
 

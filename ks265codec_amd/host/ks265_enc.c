@@ -180,7 +180,6 @@ typedef struct Job {
     uint8_t *recon;                                       /* pinned I420 copy of the reconstruction (only with ks265_enc_set_recon_file / -md5) */
     char md5[3][33];
     void *ev;                                             /* recorded after the D2H copies */
-    volatile uint32_t *flag; uint32_t flag_want;          /* KS265_FLAG_WAIT: set by the copy-out kernel itself when the records are on the host (pinned word) */
     uint8_t *nal; size_t nal_cap; long nal_len;
     int key_headers;                                      /* parameter sets go in front of this picture */
     int rc_delta;                                         /* the controller's QP offset this picture was coded with (rate control) */
@@ -279,7 +278,6 @@ typedef struct Enc {
     /* single-reference P pictures and B pictures as graphs: the launch sequence of a picture (unpack, the pixel path, SSE, packing of the records: ~20 launches) only
      * depends on a few rotating device pointers, the QP and two bits of frame state; each combination is captured once and replayed with one runtime call */
 #define MAX_GRAPHS 256
-    int flag_wait; uint32_t *dev_flag_counter; uint8_t *flag_mem; uint32_t flag_seq;      /* completion by a word in pinned memory instead of an event wait (opt-in) */
     int use_graph, ngraph; struct { uint64_t key[9]; void *exec; } graph[MAX_GRAPHS];
     int recon_fd, recon_on; uint8_t *dev_recon;           /* reconstruction dump (the CLI's -o) and / or plane MD5s (-md5 1): recon_on = the pictures come back to the host */
     int md5, fixqp, psnr_hdr; int md5_next; char (*md5_ring)[3][33]; unsigned char *md5_have;   /* MD5 lines go out in display order (ring of 256 by display index) */
@@ -348,16 +346,7 @@ static void *dispatcher(void *arg)
         Job *j = &e->jobs[e->next_ready];
         pthread_mutex_unlock(&e->mu);
         int err = 0;
-        if (e->flag_wait) {
-            /* watch the word the copy-out kernel sets: no runtime call while waiting (two threads inside the runtime slow the one that enqueues).  After five
-             * seconds without it the event is asked, so that a device error surfaces instead of a silent spin */
-            const double t_spin = now_ms();
-            unsigned spins = 0;
-            while (*j->flag != j->flag_want && !e->quit) {
-                __builtin_ia32_pause();
-                if ((++spins & 0xFFFFu) == 0 && now_ms() - t_spin > 5000.0) { err = ks265_event_wait(e->ctx_out, j->ev); break; }
-            }
-        } else err = ks265_event_wait(e->ctx_out, j->ev);
+        err = ks265_event_wait(e->ctx_out, j->ev);
         /* the device error word of the streams that code pictures (a wavefront that timed out leaves a picture whose levels do not match its reconstruction): the
          * picture - this one or one enqueued after it - fails instead of going out as if nothing had happened */
         if (!err) err = ks265_take_device_error(e->ctx);
@@ -663,8 +652,7 @@ static int submit(Enc *e, Input *in, int kind, int poc, int qp, const int *l0, i
     }
     /* copy-out stream */
     if (!r) r = ks265_stream_wait_event(e->ctx_out, e->ev_staged[k]);
-    if (!r && e->flag_wait) { j->flag_want = ++e->flag_seq; r = ks265_copy_out_compact_flag_async(e->ctx_out, e->frame, j->cmp, e->stg[k], e->dev_flag_counter, j->flag, j->flag_want); }
-    else if (!r) r = ks265_copy_out_compact_async(e->ctx_out, e->frame, j->cmp, e->stg[k]);   /* fixed part + the stored lines only (~2 MB for a P picture at 2160p) */
+    if (!r) r = ks265_copy_out_compact_async(e->ctx_out, e->frame, j->cmp, e->stg[k]);   /* fixed part + the stored lines only (~2 MB for a P picture at 2160p) */
     if (!r) r = ks265_event_record(e->ctx_out, e->ev_drained[k]);
     if (!r) r = ks265_event_record(e->ctx_out, j->ev);
     if (r) return hip_rc(r);
@@ -924,7 +912,6 @@ static void lane_close(Enc *e, int report)
             if (e->ev_drained[k]) ks265_event_destroy(e->ctx, e->ev_drained[k]);
         }
         for (int i = 0; i < e->ngraph; ++i) ks265_graph_destroy(e->ctx, e->graph[i].exec);
-        ks265_dev_free(e->ctx, e->dev_flag_counter); ks265_host_free(e->ctx, e->flag_mem);
         ks265_dev_free(e->ctx, e->dev_sse); ks265_dev_free(e->ctx, e->dev_recon);
         if (e->recon_fd >= 0) close(e->recon_fd);
         if (e->frame) ks265_frame_destroy(e->frame);
@@ -1011,7 +998,6 @@ static Enc *lane_open(QY265EncConfig *cfg, int device, int multi, int *err)
     for (int i = 0; i < e->ndpb && !r; ++i) { r = pic_alloc(e, &e->dpb[i]); e->dpb_poc[i] = -1000000; }
     e->key_overlap = getenv("KS265_NO_KEY_OVERLAP") ? 0 : 1;
     e->use_graph = getenv("KS265_NO_GRAPH") ? 0 : 1;
-    e->flag_wait = getenv("KS265_FLAG_WAIT") ? 1 : 0;
     if (e->key_overlap) {
         if (!r) r = ks265_create(&e->ctx_key, dev_id);
         if (!r) r = ks265_frame_create(e->ctx_key, &e->fcfg, &e->frame_key);
@@ -1027,13 +1013,6 @@ static Enc *lane_open(QY265EncConfig *cfg, int device, int multi, int *err)
     if (e->ring < 24) e->ring = 24;
     if (e->nthreads > e->ring - 14) e->nthreads = e->ring - 14;               /* more writers than pictures that can be in flight would idle */
     const int njobs_alloc = e->ring;
-    if (e->flag_wait) {
-        if (!r) r = ks265_dev_malloc(e->ctx, (void **)&e->dev_flag_counter, 64);
-        if (!r) r = ks265_memset_async(e->ctx, e->dev_flag_counter, 0, 64);
-        if (!r) r = ks265_host_malloc(e->ctx, (void **)&e->flag_mem, (size_t)njobs_alloc * 64);
-        if (!r) { memset(e->flag_mem, 0, (size_t)njobs_alloc * 64); for (int i = 0; i < njobs_alloc; ++i) e->jobs[i].flag = (volatile uint32_t *)(e->flag_mem + (size_t)i * 64); }
-        if (!r) r = ks265_synchronize(e->ctx);
-    }
     for (int i = 0; i < njobs_alloc && !r; ++i) {
         Job *j = &e->jobs[i];
         r = ks265_host_malloc(e->ctx, (void **)&j->cmp, e->cmp_off[7]);

@@ -249,10 +249,3 @@ int ks265_copy_out_compact_async(ks265_ctx *c, ks265_frame *f, void *host, const
     memcpy(host, dev, off[6] + (size_t)((const uint32_t *)((const uint8_t *)dev + off[3]))[2] * 64);     /* the fixed part + the stored lines */
     return KS265_OK;
 }
-int ks265_copy_out_compact_flag_async(ks265_ctx *c, ks265_frame *f, void *host, const void *dev, uint32_t *counter, volatile uint32_t *flag, uint32_t value)
-{
-    (void)counter;
-    const int r = ks265_copy_out_compact_async(c, f, host, dev);
-    __atomic_store_n((uint32_t *)flag, value, __ATOMIC_RELEASE);
-    return r;
-}

@@ -67,7 +67,7 @@ def test_graph_replay_equals_launch_by_launch(stub_lib, bframes):
     iper = 64
     a = run(stub_lib, 170, iper, bframes)
     assert a["vcl"] == 170 and sorted(a["pts"]) == list(range(170))
-    for env in ({"KS265_NO_GRAPH": 1}, {"KS265_STUB_NO_CAPTURE": 1}, {"KS265_STUB_NO_INSTANTIATE": 1}, {"KS265_FLAG_WAIT": 1}):   # the last: completion by a word in pinned memory
+    for env in ({"KS265_NO_GRAPH": 1}, {"KS265_STUB_NO_CAPTURE": 1}, {"KS265_STUB_NO_INSTANTIATE": 1}):   # the last: completion by a word in pinned memory
         b = run(stub_lib, 170, iper, bframes, **env)
         assert b["md5"] == a["md5"], env
     if bframes:
@@ -164,7 +164,7 @@ def test_rate_control_does_not_depend_on_thread_timing(stub_lib, rc, bframes):
     bytes; a budget far below / above what the records cost moves the QP (the stand-in's records depend on the QP)"""
     a = run(stub_lib, 150, 64, bframes, KS_TEST_RC=rc, KS_TEST_BR=40)
     b = run(stub_lib, 150, 64, bframes, KS_TEST_RC=rc, KS_TEST_BR=40, KS265_NO_GRAPH=1)
-    c = run(stub_lib, 150, 64, bframes, KS_TEST_RC=rc, KS_TEST_BR=40, KS265_FLAG_WAIT=1)
+    c = run(stub_lib, 150, 64, bframes, KS_TEST_RC=rc, KS_TEST_BR=40)
     assert a["vcl"] == 150 and a["md5"] == b["md5"] == c["md5"]
     hi = run(stub_lib, 150, 64, bframes, KS_TEST_RC=rc, KS_TEST_BR=400000)
     assert hi["md5"] != a["md5"]                                             # the controller acts: another budget, another stream

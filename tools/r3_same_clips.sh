@@ -13,7 +13,7 @@ echo "# ks265enc only, state of round 3 (inter lambda, coefficient-group pruning
 for cfg in "1920 1080 slow 27" "3840 2160 slow 27"; do set -- $cfg
  for extra in "" "-bframes 0"; do
   echo "## $1x$2 -preset $3 -rc 0 -qp $4 -iper 128 $extra"
-  for dq in 0 2 4; do q=$(( $4 + dq ))
+  for dq in -2 0 2 4; do q=$(( $4 + dq ))
    echo "ks265enc -qp $q: $(./ks265codec_amd/ks265enc -i /dev/shm/clip_$1.yuv -wdt $1 -hgt $2 -fr 50 -preset $3 -rc 0 -qp $q -iper 128 $extra -threads 32 -psnr 1 -b /dev/shm/o.265 | grep -E 'Total|bitrate, psnr' | tr '\n' ' ')"
   done
  done
