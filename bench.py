@@ -112,6 +112,20 @@ def main():
             raise SystemExit("--scaling strong splits closed GOPs over the ranks; --b-spread is the other sharding")
     if args.leg != "hot" and not args.b_spread:
         encoded = encoded_leg(args, torch, dist, rank, world, dev_index, backend, sync_all)
+        # the opt-in configuration next to the default one: two closed GOPs coded at once on the GPU (KS265_GOP_LANES=2), reported beside `value`, never as it
+        encoded["two_lanes"] = None
+        if args.leg == "both" and args.scaling == "weak" and world == 1 and "KS265_GOP_LANES" not in os.environ and encoded.get("gop_lanes", 1) == 1 and not args.hier_b and not args.bframes:
+            import subprocess                                     # a process of its own: the library asks for eight hardware queues, which only a fresh runtime honours
+            try:
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--leg", "encoded", "--steps", str(args.steps), "--warmup", str(args.warmup), "--no-cpu-baseline",
+                                    "--width", str(args.width), "--height", str(args.height), "--qp", str(args.qp), "--iper", str(args.iper), "--me", args.me],
+                                   env=dict(os.environ, KS265_GOP_LANES="2"), capture_output=True, text=True, timeout=240)
+                e2 = json.loads(r.stdout.strip().splitlines()[-1])
+                encoded["two_lanes"] = {"value": e2["value"], "unit": "frames/s", "gop_lanes": e2["config"].get("gop_lanes"), "psnr_y": e2["psnr_y"], "windows": e2["config"].get("windows"),
+                                        "what": "the same encoder with KS265_GOP_LANES=2 (opt-in): two closed GOPs in flight on the one GPU, same stream; each window is a closed piece of "
+                                                "work (flush + synchronize on both sides), so it includes starting from and draining to an empty pipeline"}
+            except Exception as ex:                               # the opt-in leg must never cost the default line
+                encoded["two_lanes"] = {"error": repr(ex)[:200]}
         if args.leg == "encoded":
             if rank == 0:
                 print(json.dumps(encoded_line(args, encoded, world, None, None)), flush=True)
@@ -683,10 +697,10 @@ def encoded_line(args, enc, world, hot, cpu):
                                f"pixel path on the MI355X (-preset {enc['preset']}: -me {args.me}, subme 1, deblock + SAO) -> D2H of CU map / levels / SAO -> CABAC slice data on "
                                f"{enc['host_threads']} host threads -> Annex-B NAL units out; -rc 0 -qp {args.qp} (I=Q, P=Q+1, B=Q+2..) -iper {args.iper}, {enc['gop']}, "
                                f"-ref {max(1, args.refs)}; the stream decodes with the reference's appdecoder to the encoder's reconstruction (tests/test_stream.py)",
-                   "timed": None if strong else (("steady state of the asynchronous encoder with %d GOP lanes (closed GOPs coded concurrently on the one GPU, output in stream order; "
-                             "pictures leave in bursts, so the clock is the OUTPUT side): untimed until two whole rounds of lanes x iper pictures are out, barrier + device synchronize on "
-                             "both sides of each window.  A = the next --steps pictures out (inside a GOP); B = the next whole round of lanes x iper pictures out, one key picture per "
-                             "lane among them.  value = pictures / seconds of B; ms_per_step = 1000 / value per GPU" % enc["gop_lanes"]) if enc.get("gop_lanes", 1) > 1 else
+                   "timed": None if strong else (("the asynchronous encoder with %d GOP lanes (closed GOPs coded concurrently on the one GPU, output in stream order).  A lane buffers a whole GOP "
+                             "of input and goes on coding while the caller sits in a synchronize, so each window is a closed piece of work: flush + barrier + device synchronize on both sides; "
+                             "A = --steps pictures, B = four whole rounds of lanes x iper pictures (one key picture per GOP) fed, coded and flushed in between.  value = pictures / seconds of B "
+                             "(starting from and draining to an empty pipeline included); ms_per_step = 1000 / value per GPU" % enc["gop_lanes"]) if enc.get("gop_lanes", 1) > 1 else
                              "steady state of the asynchronous encoder (pipeline full before and after, back-pressure: one picture in = one picture out), barrier + "
                              "device synchronize on both sides of each window.  A = exactly --steps pictures; B = one whole GOP of -iper pictures incl. its key picture "
                              "(run when A holds no key picture).  value = pictures / seconds of B (of A when A already holds its key pictures); ms_per_step = 1000 / value per GPU"),
@@ -698,14 +712,17 @@ def encoded_line(args, enc, world, hot, cpu):
                    "slice_write_ms_per_picture_per_thread": round(enc["slice_write_ms_per_picture"], 2),
                    "caller_ms_per_picture": enc.get("caller_ms_per_picture"),
                    "in_the_path": "pyramid pre-search, merge pass (merge / skip decided on SATD + rate, signalled where the motion equals a merge candidate), AMVP with the better of the two "
-                                  "predictors, joint refinement of bi-predictive pairs (B pictures), sign-data hiding (signBitHidingHDQ); P / B pictures replayed as captured HIP graphs",
-                   "not_in_the_path": "rate-distortion optimised quantisation (the reference's -rdoq at -preset slow), skip / CU size judged with the residual's cost, intra CUs in P/B pictures, "
-                                      "lookahead / cuTree: at equal PSNR the stream is 1.7x (IPPP) to 3.2x (hierarchical B) the size of appencoder's (BASELINE.md 2b has the same-clip table)",
+                                  "predictors, joint refinement of bi-predictive pairs (B pictures, bi-prediction judged at 31/32), intra CUs in P / B pictures, coefficient-group pruning (luma) and sign-data hiding "
+                                  "(signBitHidingHDQ) at the postQuant seam, P / B lambda table; fractional samples interpolated on the fly; P / B pictures replayed as captured HIP graphs",
+                   "not_in_the_path": "per-coefficient RDOQ (the reference's -rdoq at -preset slow), skip / CU size judged with the residual's cost, generalised B pictures, "
+                                      "lookahead / cuTree: at equal PSNR the stream is 1.29x (IPPP) to 2.1x (hierarchical B) the size of appencoder's (BASELINE.md 2b has the same-clip table)",
                    "sharding": (f"ONE job of {enc['job']['frames']} pictures = {enc['job']['gops']} closed GOPs dealt to the ranks in contiguous runs; every rank encodes its GOPs, the coded bytes are "
                                 f"gathered on rank 0 in stream order (the only exchange step; inside the timed region); stream md5 {enc['md5']}") if strong else
                                "one encoder per GPU (rank), each on its own synthetic clip = its own closed GOPs; no data-path collective"},
         "roofline": None, "cpu_baseline": cpu,
     }
+    if enc.get("two_lanes"):
+        line["two_gop_lanes"] = enc["two_lanes"]
     if strong:
         line["config"]["job"] = {"frames": enc["job"]["frames"], "gops": enc["job"]["gops"], "stream_bytes": enc["job"]["bytes"], "stream_md5": enc["md5"]}
     if hot is not None:
