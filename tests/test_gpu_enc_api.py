@@ -281,3 +281,32 @@ def test_strong_scaling_job_is_rank_count_invariant(tmp_path):
     if os.path.exists(REF_DEC):
         d = subprocess.run([REF_DEC, "-b", str(o2), "-o", str(tmp_path / "d.yuv"), "-threads", "2"], capture_output=True, text=True, cwd=tmp_path)
         assert "decoder passed" in d.stdout and os.path.getsize(tmp_path / "d.yuv") == 24 * 640 * 368 * 3 // 2
+
+
+@pytest.mark.parametrize("W,H,n", [(3840, 2160, 3), (1920, 1080, 12)])
+def test_encoder_reconstruction_equals_the_oracle_pipeline(tmp_path, W, H, n):
+    """what the C host makes the MI355X reconstruct (ks265enc -o: its own tool dict, QP ladder and lambda tables) is picture for picture what the oracle pipeline
+    computes with the same settings - at the bench size (3 pictures: the launch-by-launch path) and at 1080p over 12 pictures (from the ninth on P pictures are replayed
+    as captured graphs).  VERDICT r2 2: the encoder itself against the oracle, not only against the decoder."""
+    from ks265codec_amd import stream
+    from ks265codec_amd.synth import make_clip, lambda_q4
+    from oracle_lib import OraclePipeline
+    from test_gpu_configs import ENCODER_TOOLS
+    stream.build()
+    clip = make_clip(W, H, n, seed=W + n, abc=(67, 91, 33) if W >= 3000 else (37, 53, 19), pan=(8, 5) if W >= 3000 else (5, 3))
+    yuv, out, rec = tmp_path / "in.yuv", tmp_path / "out.265", tmp_path / "rec.yuv"
+    clip.tofile(yuv)
+    r = subprocess.run([stream.CLI, "-i", str(yuv), "-wdt", str(W), "-hgt", str(H), "-fr", "50", "-rc", "0", "-preset", "slow", "-qp", "27", "-bframes", "0", "-ref", "1", "-iper", "128",
+                        "-threads", "8", "-psnr", "1", "-b", str(out), "-o", str(rec)], capture_output=True, text=True)
+    assert r.returncode == 0 and "H265 encoder passed!!!" in r.stdout, r.stdout[-500:] + r.stderr[-500:]
+    a = np.fromfile(rec, np.uint8)
+    fsz = W * H * 3 // 2
+    assert a.size == n * fsz
+    o = OraclePipeline(W, H, 27, lambda_q4(27), me_method=2, me_hex_thr=16, **ENCODER_TOOLS)     # -preset slow: UMH with the HEX shortcut below 16 SAD / sample
+    ref = None
+    for t in range(n):
+        q = 27 if t == 0 else 28                                      # the host's ladder: I = Q, P = Q + 1
+        o.set_qp(q, lambda_q4(q, inter=t > 0))
+        ref = o.encode(clip[t], "I" if t == 0 else "P", ref, None)
+        want = o.store(ref)
+        assert (a[t * fsz:(t + 1) * fsz] == want).all(), f"picture {t}: the encoder's reconstruction differs from the oracle pipeline's"
