@@ -548,7 +548,9 @@ __device__ __forceinline__ int intra_mode_bits(int mode) { return (mode == 0 || 
 // least what an intra CU costs before its first residual bit, lambda x KS_INTRA_GATE_BITS >> 4 (= the bias of the CU decision): where every 8x8 block is predicted
 // better than that, no block goes intra - most CTUs of a P / B picture leave here.
 #define KS_INTRA_GATE_BITS 96
-__global__ __launch_bounds__(256) void intra_decide_kernel(KsGeom g, int lam, const uint8_t *src_y, ks265_cu8 *cu8, unsigned *cost_out, unsigned *best_out, const uint4 *gate_pu, unsigned nlev)
+// (three waves per SIMD: 168 VGPRs with 33 spilled to scratch beat 207 VGPRs at two waves per SIMD - 205 -> 161 us for the candidates of a 2160p P picture; four waves
+//  per SIMD, 75 spills: 170 us)
+__global__ __launch_bounds__(256, 3) void intra_decide_kernel(KsGeom g, int lam, const uint8_t *src_y, ks265_cu8 *cu8, unsigned *cost_out, unsigned *best_out, const uint4 *gate_pu, unsigned nlev)
 {
     __shared__ __attribute__((aligned(16))) DecideLds L;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
