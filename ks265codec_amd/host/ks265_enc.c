@@ -293,6 +293,12 @@ typedef struct Enc {
     int force_key;
     int gop_end, gop_end_seen;                            /* GOP lanes: display index of the last picture of a GOP that ended early (-1: none); what the scheduler has acted on */
     int multi;                                            /* one of several GOP lanes of a handle */
+    /* scene-cut lookahead (-lookahead N > 0; SURVEY.md 8(f) rank 2, scenecut enc@0x47e9d0 lineage): a stream and a frame object of HALF the size of their own; every
+     * input picture is compared with its predecessor before the scheduler sees it (ks265_lookahead_picture: per 8x8 block of the half-size picture the intra
+     * pre-selection cost against the integer-search cost) - where prediction from the previous picture is not clearly cheaper than intra coding a closed GOP starts */
+    int la_on, la_cur, la_have_prev, la_last_key; long la_cuts;
+    ks265_ctx *ctx_la; ks265_frame *frame_la; ks265_frame_geom geom_la; ks265_pic la_pic[2];
+    uint8_t *la_dev_luma; uint32_t *la_cost_ws; uint64_t *la_dev_out, *la_host_out; void *la_ev;
     struct TopWake *wake;                                 /* lanes: the handle's caller sleeps here until a picture of ANY lane is finished */
     Job jobs[MAX_JOBS]; int ring, job_head, job_tail, njobs;   /* ring of `ring` pictures in coding order */
     /* workers */
@@ -914,6 +920,14 @@ static void lane_close(Enc *e, int report)
         for (int i = 0; i < e->ngraph; ++i) ks265_graph_destroy(e->ctx, e->graph[i].exec);
         ks265_dev_free(e->ctx, e->dev_sse); ks265_dev_free(e->ctx, e->dev_recon);
         if (e->recon_fd >= 0) close(e->recon_fd);
+        if (e->ctx_la) {
+            ks265_synchronize(e->ctx_la);
+            for (int i = 0; i < 2; ++i) { ks265_dev_free(e->ctx_la, e->la_pic[i].y); ks265_dev_free(e->ctx_la, e->la_pic[i].u); ks265_dev_free(e->ctx_la, e->la_pic[i].v); }
+            ks265_dev_free(e->ctx_la, e->la_dev_luma); ks265_dev_free(e->ctx_la, e->la_cost_ws); ks265_dev_free(e->ctx_la, e->la_dev_out); ks265_host_free(e->ctx_la, e->la_host_out);
+            if (e->la_ev) ks265_event_destroy(e->ctx_la, e->la_ev);
+            if (e->frame_la) ks265_frame_destroy(e->frame_la);
+            ks265_destroy(e->ctx_la);
+        }
         if (e->frame) ks265_frame_destroy(e->frame);
         if (e->ctx_key) ks265_destroy(e->ctx_key);
         if (e->ctx_in) ks265_destroy(e->ctx_in);
@@ -983,6 +997,31 @@ static Enc *lane_open(QY265EncConfig *cfg, int device, int multi, int *err)
     if (!r) r = ks265_frame_compact_layout(e->frame, e->cmp_off);
     if (!r) r = ks265_create(&e->ctx_in, dev_id);
     if (!r) r = ks265_create(&e->ctx_out, dev_id);
+    if (!r && cfg->lookahead > 0) {
+        const int w = e->W / 2, h = e->H / 2;
+        if ((w & 7) || (h & 7) || w < 16 || h < 16) logf_(1, e->log_level, "ks265enc: -lookahead %d: the scene-cut analysis needs a picture size that is a multiple of 16: off\n", cfg->lookahead);
+        else {
+            ks265_frame_cfg lc; memset(&lc, 0, sizeof lc);
+            lc.width = w; lc.height = h; lc.qp = e->base_qp > 0 ? e->base_qp : 27; lc.lambda_q4 = kLambdaQ4[lc.qp < 52 ? lc.qp : 51]; lc.me_range = 32; lc.me_method = 1; lc.subme = 0;
+            lc.bframes = 0; lc.refs = 1;
+            r = ks265_create(&e->ctx_la, dev_id);
+            if (!r) r = ks265_frame_geometry(&lc, &e->geom_la);
+            if (!r) r = ks265_frame_create(e->ctx_la, &lc, &e->frame_la);
+            for (int i = 0; i < 2 && !r; ++i) {
+                r = ks265_dev_malloc(e->ctx_la, (void **)&e->la_pic[i].y, (size_t)e->geom_la.bytes_y);
+                if (!r) r = ks265_dev_malloc(e->ctx_la, (void **)&e->la_pic[i].u, (size_t)e->geom_la.bytes_c);
+                if (!r) r = ks265_dev_malloc(e->ctx_la, (void **)&e->la_pic[i].v, (size_t)e->geom_la.bytes_c);
+                if (!r) r = ks265_memset_async(e->ctx_la, e->la_pic[i].u, 128, (size_t)e->geom_la.bytes_c);     /* the analysis is luma only */
+                if (!r) r = ks265_memset_async(e->ctx_la, e->la_pic[i].v, 128, (size_t)e->geom_la.bytes_c);
+            }
+            if (!r) r = ks265_dev_malloc(e->ctx_la, (void **)&e->la_dev_luma, (size_t)e->W * e->H);
+            if (!r) r = ks265_dev_malloc(e->ctx_la, (void **)&e->la_cost_ws, (size_t)e->geom_la.ctu_cols * e->geom_la.ctu_rows * 85 * sizeof(uint32_t));
+            if (!r) r = ks265_dev_malloc(e->ctx_la, (void **)&e->la_dev_out, 64);
+            if (!r) r = ks265_host_malloc(e->ctx_la, (void **)&e->la_host_out, 64);
+            if (!r) r = ks265_event_create(e->ctx_la, &e->la_ev);
+            if (!r) { e->la_on = 1; e->la_last_key = -1000000; }
+        }
+    }
     for (int k = 0; k < NPIPE && !r; ++k) {
         r = ks265_dev_malloc(e->ctx, (void **)&e->dev_in[k], fsz);
         if (!r) r = ks265_dev_malloc(e->ctx, (void **)&e->stg[k], e->cmp_off[7]);
@@ -1129,8 +1168,33 @@ static int lane_put(Enc *e, QY265Picture *in, int key)
             memcpy(v + (size_t)y * (e->W / 2), in->yuv->pData[2] + (size_t)y * in->yuv->iStride[2], (size_t)e->W / 2);
         }
     }
+    int cut = 0;
+    if (e->la_on) {                                                    /* scene-cut analysis of this picture against its predecessor (own stream: short, independent of the pipeline) */
+        const int c = e->la_cur, w = e->W / 2, h = e->H / 2;
+        const size_t org = (size_t)e->geom_la.pad_y * e->geom_la.stride_y + e->geom_la.pad_y;
+        int r = ks265_memcpy_h2d_async(e->ctx_la, e->la_dev_luma, slot->i420, (size_t)e->W * e->H);
+        if (!r) r = ks265_downsample_rect(e->ctx_la, e->la_dev_luma, e->W, e->la_pic[c].y + org, e->geom_la.stride_y, w, h);
+        if (!r) r = ks265_pad_picture(e->frame_la, e->la_pic[c]);
+        if (!r && e->la_have_prev) {
+            r = ks265_lookahead_picture(e->frame_la, e->la_pic[c], e->la_pic[c ^ 1], e->la_cost_ws, e->la_dev_out);
+            if (!r) r = ks265_memcpy_d2h_async(e->ctx_la, e->la_host_out, e->la_dev_out, 32);
+            if (!r) r = ks265_event_record(e->ctx_la, e->la_ev);
+            if (!r) r = ks265_event_wait(e->ctx_la, e->la_ev);
+            /* a cut: predicting the picture from its predecessor costs at least 0.7 of coding it intra (both sums over the 8x8 blocks of the half-size picture),
+             * and the last key picture is at least eight pictures back */
+            if (!r && e->la_host_out[1] * 10 >= e->la_host_out[0] * 7 && e->next_disp - e->la_last_key >= 8) cut = 1;
+        }
+        if (r) { pthread_mutex_lock(&e->mu); slot->used = 0; e->sched_err = hip_rc(r); pthread_mutex_unlock(&e->mu); return hip_rc(r); }
+        e->la_cur ^= 1; e->la_have_prev = 1;
+    }
     pthread_mutex_lock(&e->mu);
-    slot->disp = e->next_disp++; slot->pts = in->pts; slot->key = key || e->force_key; slot->base_qp = e->base_qp; slot->iper = e->iper; slot->used = 1;
+    if (e->la_on) {
+        const int nd = e->next_disp, iper = e->iper;
+        const int periodic = iper > 0 && e->la_last_key > -1000000 && nd - e->la_last_key >= iper;    /* (an estimate: the scheduler keeps the exact count) */
+        if (cut) ++e->la_cuts;
+        if (cut || key || e->force_key || nd == 0 || periodic) e->la_last_key = nd;
+    }
+    slot->disp = e->next_disp++; slot->pts = in->pts; slot->key = key || e->force_key || cut; slot->base_qp = e->base_qp; slot->iper = e->iper; slot->used = 1;
     e->force_key = 0;
     pthread_cond_signal(&e->cv_sched);                                 /* the scheduler thread takes it from here */
     pthread_mutex_unlock(&e->mu);

@@ -249,3 +249,28 @@ int ks265_copy_out_compact_async(ks265_ctx *c, ks265_frame *f, void *host, const
     memcpy(host, dev, off[6] + (size_t)((const uint32_t *)((const uint8_t *)dev + off[3]))[2] * 64);     /* the fixed part + the stored lines */
     return KS265_OK;
 }
+
+/* ---- scene-cut lookahead (host: -lookahead N): the half-size picture is real (2x2 averages), the two frame costs are stand-ins with the right behaviour - "intra" = how
+ * far the samples are from mid-grey, "inter" = how far they are from the previous picture's co-located samples (no search) */
+int ks265_downsample_rect(ks265_ctx *c, const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int h)
+{
+    (void)c;
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x)
+            dst[(long)y * ds + x] = (uint8_t)((src[(long)(2 * y) * ss + 2 * x] + src[(long)(2 * y) * ss + 2 * x + 1] + src[(long)(2 * y + 1) * ss + 2 * x] + src[(long)(2 * y + 1) * ss + 2 * x + 1] + 2) >> 2);
+    return KS265_OK;
+}
+int ks265_pad_picture(ks265_frame *f, ks265_pic pic) { (void)f; (void)pic; return KS265_OK; }
+int ks265_lookahead_picture(ks265_frame *f, ks265_pic cur, ks265_pic ref, uint32_t *ws, uint64_t *out)
+{
+    (void)ws;
+    const long org = (long)f->g.pad_y * f->g.stride_y + f->g.pad_y;
+    uint64_t intra = 0, inter = 0;
+    for (int y = 0; y < f->cfg.height; ++y)
+        for (int x = 0; x < f->cfg.width; ++x) {
+            const int a = cur.y[org + (long)y * f->g.stride_y + x], b = ref.y[org + (long)y * f->g.stride_y + x];
+            intra += (uint64_t)(a > 128 ? a - 128 : 128 - a); inter += (uint64_t)(a > b ? a - b : b - a);
+        }
+    out[0] = intra; out[1] = inter; out[2] = intra < inter ? intra : inter; out[3] = (uint64_t)f->cfg.width * f->cfg.height / 64;
+    return KS265_OK;
+}

@@ -14,7 +14,7 @@ rng = np.random.default_rng(3)
 clip = rng.integers(0, 256, (11, W * H * 3 // 2), dtype=np.uint8)
 cfg = (C.c_uint8 * LAY["sizeof_config"])()
 assert lib.QY265ConfigDefaultPreset(cfg, b"medium", None, b"default") == 0
-for k, v in (("wdt", W), ("hgt", H), ("fr", 50), ("rc", int(os.environ.get("KS_TEST_RC", "0"))), ("br", int(os.environ.get("KS_TEST_BR", "1000"))), ("qp", 34), ("iper", iper), ("bframes", bframes), ("threads", 5), ("psnr", 1), ("log", 3)):
+for k, v in (("wdt", W), ("hgt", H), ("fr", 50), ("rc", int(os.environ.get("KS_TEST_RC", "0"))), ("br", int(os.environ.get("KS_TEST_BR", "1000"))), ("qp", 34), ("iper", iper), ("bframes", bframes), ("threads", 5), ("psnr", 1), ("log", 3), ("lookahead", int(os.environ.get("KS_TEST_LOOKAHEAD", "-1")))):
     assert lib.QY265ConfigParse(cfg, k.encode(), str(v).encode()) == 0
 err = C.c_int(0)
 h = C.c_void_p(lib.QY265EncoderOpen(cfg, C.byref(err))); assert h.value, hex(err.value & 0xFFFFFFFF)
@@ -39,8 +39,16 @@ if strided:                                                # planes with padded 
     pad = 24
     yuv.iStride[0], yuv.iStride[1], yuv.iStride[2] = W + pad, W // 2 + pad, W // 2 + pad
     planes = [np.zeros((H, W + pad), np.uint8), np.zeros((H // 2, W // 2 + pad), np.uint8), np.zeros((H // 2, W // 2 + pad), np.uint8)]
+cuts = [int(x) for x in os.environ.get("KS_TEST_CUTS", "").split(",") if x]
+if cuts:                                                   # scenes: one base picture per scene + a little noise per picture, a new base at every cut
+    scene, base = -1, None
+    frames = []
+    for t in range(N):
+        if t == 0 or t in cuts:
+            scene += 1; base = clip[scene % 11].astype(np.int16)
+        frames.append(np.clip(base + rng.integers(-3, 4, base.shape), 0, 255).astype(np.uint8))
 for t in range(N):
-    fr = clip[t % 11]
+    fr = frames[t] if cuts else clip[t % 11]
     if strided:
         planes[0][:, :W] = fr[:W * H].reshape(H, W); planes[0][:, W:] = t & 255
         planes[1][:, :W // 2] = fr[W * H:W * H * 5 // 4].reshape(H // 2, W // 2); planes[2][:, :W // 2] = fr[W * H * 5 // 4:].reshape(H // 2, W // 2)

@@ -310,3 +310,32 @@ def test_encoder_reconstruction_equals_the_oracle_pipeline(tmp_path, W, H, n):
         ref = o.encode(clip[t], "I" if t == 0 else "P", ref, None)
         want = o.store(ref)
         assert (a[t * fsz:(t + 1) * fsz] == want).all(), f"picture {t}: the encoder's reconstruction differs from the oracle pipeline's"
+
+
+def test_scene_cut_lookahead(tmp_path):
+    """-lookahead N (the lookahead's frame-cost kernels composed in the host): two unrelated scenes of 12 pictures each - the first picture of the second
+    scene becomes a key picture, nothing else does, and without the option the stream has its one key picture; the stream still decodes to the encoder's reconstruction"""
+    import re
+    from ks265codec_amd import stream
+    from ks265codec_amd.synth import make_clip
+    stream.build()
+    W, H, n = 832, 480, 24
+    clip = np.concatenate([make_clip(W, H, 12, seed=5, abc=(37, 53, 19), pan=(5, 3)), make_clip(W, H, 12, seed=99, abc=(11, 17, 7), pan=(2, 4))])
+    yuv = tmp_path / "in.yuv"
+    clip.tofile(yuv)
+    kinds = {}
+    for tag, extra in (("plain", []), ("la", ["-lookahead", "8"])):
+        out, rec = tmp_path / f"{tag}.265", tmp_path / f"{tag}.yuv"
+        r = subprocess.run([stream.CLI, "-i", str(yuv), "-wdt", str(W), "-hgt", str(H), "-fr", "50", "-rc", "0", "-preset", "slow", "-qp", "30", "-bframes", "0", "-iper", "128",
+                            "-threads", "8", "-psnr", "2", "-b", str(out), "-o", str(rec), *extra], capture_output=True, text=True)
+        assert r.returncode == 0 and "H265 encoder passed!!!" in r.stdout, r.stdout[-500:] + r.stderr[-500:]
+        per = sorted((int(a), b, int(c)) for a, b, c in re.findall(r"^(\d+)\t([IPB])\t(\d+)\t", r.stdout, re.M))
+        assert len(per) == n
+        kinds[tag] = [k for _, k, _ in per]
+        if tag == "la" and os.path.exists(REF_DEC):
+            dec = tmp_path / "dec.yuv"
+            d = subprocess.run([REF_DEC, "-b", str(out), "-o", str(dec), "-threads", "4"], capture_output=True, text=True, cwd=tmp_path)
+            assert "decoder passed" in d.stdout, d.stdout[-400:]
+            assert (np.fromfile(rec, np.uint8) == np.fromfile(dec, np.uint8)).all()
+    assert kinds["plain"] == ["I"] + ["P"] * (n - 1)
+    assert kinds["la"] == ["I"] + ["P"] * 11 + ["I"] + ["P"] * 11, kinds["la"]

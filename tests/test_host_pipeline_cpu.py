@@ -228,3 +228,16 @@ def test_gops_dealt_to_several_gpus_behind_one_handle(stub_lib, tmp_path):
     e = dict(os.environ, KS265_STUB_LIB=stub_lib, KS265_GPUS="2", KS265_STUB_DEVICES="1")
     r = subprocess.run([sys.executable, os.path.join(HERE, "host_driver.py"), ROOT, "40", "32", "0", "128", "72"], capture_output=True, text=True, timeout=120, env=e)
     assert r.returncode == 0 and json.loads(r.stdout.strip().splitlines()[-1])["lanes"] == 1      # the second GPU is not there: the handle goes on with the lanes it has
+
+
+@pytest.mark.parametrize("bframes", [0, -1, 3])
+def test_scene_cut_starts_a_closed_gop(stub_lib, bframes):
+    """-lookahead N: every input picture is compared with its predecessor on a stream of its own before the scheduler sees it; where prediction is not clearly cheaper
+    than intra coding the picture becomes a key picture (the mini-GOP in front of it is shortened), elsewhere nothing changes"""
+    plain = run(stub_lib, 60, 128, bframes, W=128, H=96, KS_TEST_CUTS="23,41")
+    la = run(stub_lib, 60, 128, bframes, W=128, H=96, KS_TEST_CUTS="23,41", KS_TEST_LOOKAHEAD=8)
+    assert plain["idr"] == 1 and la["idr"] == 3 and sorted(la["pts"]) == list(range(60)), (plain["idr"], la["idr"])
+    calm = run(stub_lib, 60, 128, bframes, W=128, H=96, KS_TEST_CUTS="1000", KS_TEST_LOOKAHEAD=8)                 # one scene: the analysis runs and finds nothing
+    assert calm["idr"] == 1 and calm["md5"] == run(stub_lib, 60, 128, bframes, W=128, H=96, KS_TEST_CUTS="1000")["md5"]
+    close = run(stub_lib, 60, 128, 0, W=128, H=96, KS_TEST_CUTS="20,23,26,40", KS_TEST_LOOKAHEAD=8)               # cuts closer than eight pictures to the last key picture are not key pictures
+    assert close["idr"] == 3, close["idr"]

@@ -63,6 +63,8 @@ def encode_ours(clip, W, H, qp, gop, tools, verbose=False, stats=None, pdelta=1,
         seq = [(t, "I" if t == 0 else "P", t - 1 if t else None, None, 0) for t in range(n)]
     else:
         seq = [s for s in itertools.islice(hier_order(G, 1 << 20), n) if s[0] < n]
+        if os.environ.get('RD_GPB_SAME'):                             # experiment: generalised B at the P positions, both lists = the previous anchor
+            seq = [(d, 'B', r0, r0, 0) if k == 'P' else (d, k, r0, r1, l) for (d, k, r0, r1, l) in seq]
     dpb = {}
     for i, (d, kind, r0, r1, layer) in enumerate(seq):
         lq = layer_qp[min(len(layer_qp) - 1, layer)] if (layer_qp and kind == 'B') else layer      # B layers are numbered 1 (referenced most) .. 3
