@@ -70,8 +70,9 @@ extern "C" int ks265_pad_picture(ks265_frame *f, ks265_pic pic)
     return ks265_check_launch(f->ctx);
 }
 
-// ------------------------------------------------------------------ I420 <-> padded picture (dword per thread)
-// the three planes in one launch: blockIdx.z = plane (chroma planes use the upper-left quarter of the grid)
+// ------------------------------------------------------------------ I420 <-> padded picture
+// the three planes in one launch: blockIdx.z = plane (chroma planes use the upper-left quarter of the grid).  A thread moves 8 bytes of four consecutive rows when every
+// row start is 8-byte aligned (picture widths that are multiples of 16: all the sizes the encoder is run at), else a dword of one row
 struct CopyPlanes { uint8_t *dst[3]; const uint8_t *src[3]; long ds[3], ss[3]; int w, h; };
 __global__ __launch_bounds__(256) void copy_planes_kernel(CopyPlanes a)
 {
@@ -80,9 +81,23 @@ __global__ __launch_bounds__(256) void copy_planes_kernel(CopyPlanes a)
     if (x4 >= w || y >= h) return;
     *(unsigned *)(a.dst[pl] + y * a.ds[pl] + x4) = *(const unsigned *)(a.src[pl] + y * a.ss[pl] + x4);
 }
+__global__ __launch_bounds__(256) void copy_planes8_kernel(CopyPlanes a)
+{
+    const int pl = blockIdx.z, w = pl ? a.w / 2 : a.w, h = pl ? a.h / 2 : a.h;
+    const int x8 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 8, y0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * 4;
+    if (x8 >= w || y0 >= h) return;
+    uint2 v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = y0 + r < h ? *(const uint2 *)(a.src[pl] + (long)(y0 + r) * a.ss[pl] + x8) : make_uint2(0u, 0u);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) if (y0 + r < h) *(uint2 *)(a.dst[pl] + (long)(y0 + r) * a.ds[pl] + x8) = v[r];
+}
 static void launch_copy3(ks265_frame *f, const CopyPlanes &a)
 {
-    hipLaunchKernelGGL(copy_planes_kernel, dim3((a.w / 4 + 63) / 64, (a.h + 3) / 4, 3), dim3(256), 0, f->ctx->stream, a);
+    bool al = (a.w & 15) == 0;
+    for (int p = 0; p < 3 && al; ++p) al = ((uintptr_t)a.dst[p] & 7) == 0 && ((uintptr_t)a.src[p] & 7) == 0 && (a.ds[p] & 7) == 0 && (a.ss[p] & 7) == 0;
+    if (al) hipLaunchKernelGGL(copy_planes8_kernel, dim3((a.w / 8 + 63) / 64, (a.h + 15) / 16, 3), dim3(256), 0, f->ctx->stream, a);
+    else hipLaunchKernelGGL(copy_planes_kernel, dim3((a.w / 4 + 63) / 64, (a.h + 3) / 4, 3), dim3(256), 0, f->ctx->stream, a);
 }
 
 extern "C" int ks265_load_i420(ks265_frame *f, const uint8_t *i420, ks265_pic dst)
@@ -120,12 +135,23 @@ __global__ __launch_bounds__(256) void sse_picture_kernel(KsGeom g, const uint8_
     const uint8_t *a = (pl == 0 ? ay : pl == 1 ? au : av) + org, *b = (pl == 0 ? by : pl == 1 ? bu : bv) + org;
     const int y = blockIdx.x * 8 + (threadIdx.x >> 5);
     unsigned s = 0;
-    if (y < h)
-        for (int x4 = (threadIdx.x & 31) * 4; x4 < w; x4 += 128) {
-            const unsigned va = *(const unsigned *)(a + y * stride + x4), vb = *(const unsigned *)(b + y * stride + x4);
+    if (y < h) {
+        if ((w & 7) == 0 && (((uintptr_t)a | (uintptr_t)b | (uintptr_t)stride) & 7) == 0) {     // 8 bytes per load (every picture the encoder runs at)
+            for (int x8 = (threadIdx.x & 31) * 8; x8 < w; x8 += 256) {
+                const uint2 va = *(const uint2 *)(a + y * stride + x8), vb = *(const uint2 *)(b + y * stride + x8);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { const int d = (int)((va >> (8 * i)) & 255) - (int)((vb >> (8 * i)) & 255); s += (unsigned)(d * d); }
-        }
+                for (int i = 0; i < 4; ++i) {
+                    const int d0 = (int)((va.x >> (8 * i)) & 255) - (int)((vb.x >> (8 * i)) & 255), d1 = (int)((va.y >> (8 * i)) & 255) - (int)((vb.y >> (8 * i)) & 255);
+                    s += (unsigned)(d0 * d0) + (unsigned)(d1 * d1);
+                }
+            }
+        } else
+            for (int x4 = (threadIdx.x & 31) * 4; x4 < w; x4 += 128) {
+                const unsigned va = *(const unsigned *)(a + y * stride + x4), vb = *(const unsigned *)(b + y * stride + x4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { const int d = (int)((va >> (8 * i)) & 255) - (int)((vb >> (8 * i)) & 255); s += (unsigned)(d * d); }
+            }
+    }
     s = wave_sum(s);                                                 // <= 8 rows x 4096 samples x 255^2 per work-group: fits 32 bits up to 8K pictures
     __shared__ unsigned part[4];
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
