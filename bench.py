@@ -48,6 +48,7 @@ def main():
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--qp", type=int, default=27)
+    ap.add_argument("--zero-copy", action="store_true", help="encoded leg: produce every picture straight into one of the encoder's pinned input buffers (ks265_enc_acquire_input) instead of handing in a buffer that is copied")
     ap.add_argument("--iper", type=int, default=128)
     ap.add_argument("--clip-frames", type=int, default=5)
     ap.add_argument("--me", choices=["dia", "hex", "umh"], default="umh", help="integer search: -preset slow resolves to -me 2 (UMH), SURVEY.md §5")
@@ -542,8 +543,12 @@ def encoded_leg(args, torch, dist, rank, world, dev_index, backend, sync_all):
     def feed(n):
         for _ in range(n):
             fr = clip[order[state["t"] % len(order)]]
-            for k, off in enumerate((0, W * H, W * H * 5 // 4)):
-                yuv.pData[k] = C.cast(fr.ctypes.data + off, C.POINTER(C.c_ubyte))
+            if args.zero_copy and lib.ks265_enc_acquire_input(h, C.byref(yuv)) == 0:
+                C.memmove(yuv.pData[0], fr.ctypes.data, W * H * 3 // 2)          # the application's own work: producing the picture where the encoder reads it
+            else:
+                yuv.iStride[0], yuv.iStride[1], yuv.iStride[2] = W, W // 2, W // 2
+                for k, off in enumerate((0, W * H, W * H * 5 // 4)):
+                    yuv.pData[k] = C.cast(fr.ctypes.data + off, C.POINTER(C.c_ubyte))
             pic.pts = state["t"]
             state["t"] += 1
             rc = lib.QY265EncoderEncodeFrame(h, C.byref(nal), C.byref(nn), C.byref(pic), C.byref(outp), 0)

@@ -1140,6 +1140,23 @@ static int lane_delayed(Enc *e)
     return n;
 }
 
+/* zero-copy input: hand the caller one of the lane's pinned input slots to write the next picture into; QY265EncoderEncodeFrame recognises the
+ * pointer and copies nothing.  Never blocks: QY_FAIL when no slot is free right now (the caller then passes its own buffer, which is copied as usual). */
+static int lane_acquire(Enc *e, QY265YUV *yuv)
+{
+    Input *slot = NULL;
+    pthread_mutex_lock(&e->mu);
+    for (int i = 0; i < e->nin && !slot; ++i) if (e->in[i].used == 4) slot = &e->in[i];          /* acquired before and not handed in yet: the same one again */
+    for (int i = 0; i < e->nin && !slot; ++i) if (!e->in[i].used) slot = &e->in[i];
+    if (slot) slot->used = 4;
+    pthread_mutex_unlock(&e->mu);
+    if (!slot) return QY_FAIL;
+    yuv->iWidth = e->W; yuv->iHeight = e->H;
+    yuv->pData[0] = slot->i420; yuv->pData[1] = slot->i420 + (size_t)e->W * e->H; yuv->pData[2] = yuv->pData[1] + (size_t)e->W * e->H / 4;
+    yuv->iStride[0] = e->W; yuv->iStride[1] = e->W / 2; yuv->iStride[2] = e->W / 2;
+    return QY_OK;
+}
+
 /* one picture into the lane: copy to a pinned slot, hand it to the scheduler thread.  key: it starts a closed GOP regardless of the period */
 static int lane_put(Enc *e, QY265Picture *in, int key)
 {
@@ -1152,12 +1169,15 @@ static int lane_put(Enc *e, QY265Picture *in, int key)
      * caller's take_output frees - then go on and collect).  GOP lanes (multi): the input slots are the limit (lane_has_slot) - a lane takes a whole GOP in
      * while it is still coding the previous one, or the caller would wait here while the other lanes run dry */
     while (!e->multi && !e->quit && !e->sched_err && e->next_disp - (e->coded_upto + 1) > 16 && e->njobs <= e->ring - 12) pthread_cond_wait(&e->cv_sched_done, &e->mu);   /* a scheduler that failed makes no more progress */
+    int own = 0;                                                       /* the caller wrote the picture into a slot it had acquired (ks265_enc_acquire_input): nothing to copy */
+    for (int i = 0; i < e->nin && !slot; ++i) if (e->in[i].used == 4 && e->in[i].i420 == in->yuv->pData[0]) { slot = &e->in[i]; own = 1; }
     for (int i = 0; i < e->nin && !slot; ++i) if (!e->in[i].used) slot = &e->in[i];
     if (slot) slot->used = 3;                                          /* being filled */
     pthread_mutex_unlock(&e->mu);
     if (!slot) return QY_FAIL;                                         /* one lane: cannot happen (more input slots than pictures in flight + one mini-GOP); lanes: the caller checked lane_has_slot */
     uint8_t *u = slot->i420 + (size_t)e->W * e->H, *v = u + (size_t)e->W * e->H / 4;
-    if (in->yuv->iStride[0] == e->W && in->yuv->iStride[1] == e->W / 2 && in->yuv->iStride[2] == e->W / 2) {    /* packed planes: three block copies */
+    if (own) { /* in place */ }
+    else if (in->yuv->iStride[0] == e->W && in->yuv->iStride[1] == e->W / 2 && in->yuv->iStride[2] == e->W / 2) {    /* packed planes: three block copies */
         copy_shared(e->pool, slot->i420, in->yuv->pData[0], (size_t)e->W * e->H);
         copy_shared(e->pool, u, in->yuv->pData[1], (size_t)e->W * e->H / 4);
         copy_shared(e->pool, v, in->yuv->pData[2], (size_t)e->W * e->H / 4);
@@ -1304,7 +1324,7 @@ static int lane_has_slot(Enc *e)
 {
     int ok = 0;
     pthread_mutex_lock(&e->mu);
-    for (int i = 0; i < e->nin && !ok; ++i) ok = !e->in[i].used;
+    for (int i = 0; i < e->nin && !ok; ++i) ok = !e->in[i].used || e->in[i].used == 4;     /* (4: in the caller's hands, ks265_enc_acquire_input - it comes back with the next picture) */
     pthread_mutex_unlock(&e->mu);
     return ok;
 }
@@ -1626,6 +1646,15 @@ int ks265_enc_get_stats(void *h, ks265_enc_stats *out)
 }
 
 int ks265_enc_lanes(void *h) { const Top *t = (const Top *)h; return t ? t->nlanes : 0; }
+
+int ks265_enc_acquire_input(void *h, QY265YUV *yuv)
+{
+    Top *t = (Top *)h;
+    if (!t || !yuv) return QY_POINTER;
+    /* the lane the NEXT picture goes to (QY265EncoderEncodeFrame: a new GOP starts on the next lane) */
+    const int lane = t->nlanes == 1 ? 0 : (t->chunk_left <= 0 || t->key_request) ? (t->cur_lane + 1) % t->nlanes : t->cur_lane;
+    return lane_acquire(t->lane[lane], yuv);
+}
 
 int ks265_enc_set_recon_file(void *h, const char *path)
 {

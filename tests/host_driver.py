@@ -28,6 +28,7 @@ yuv.iStride[0], yuv.iStride[1], yuv.iStride[2] = W, W // 2, W // 2
 pic.yuv = C.pointer(yuv)
 md, pts, types, bs = hashlib.md5(), [], [], bytearray()
 maxdelay = 0
+zc = 0
 def take():
     for i in range(nn.value):
         b = C.string_at(nal[i].pPayload, nal[i].iSize); md.update(b); bs.extend(b); types.append(nal[i].naltype)
@@ -53,7 +54,10 @@ for t in range(N):
         planes[0][:, :W] = fr[:W * H].reshape(H, W); planes[0][:, W:] = t & 255
         planes[1][:, :W // 2] = fr[W * H:W * H * 5 // 4].reshape(H // 2, W // 2); planes[2][:, :W // 2] = fr[W * H * 5 // 4:].reshape(H // 2, W // 2)
         for k in range(3): yuv.pData[k] = C.cast(planes[k].ctypes.data, C.POINTER(C.c_ubyte))
+    elif os.environ.get("KS_TEST_ZEROCOPY") and lib.ks265_enc_acquire_input(h, C.byref(yuv)) == 0:      # the picture is produced straight into one of the encoder's own buffers
+        C.memmove(yuv.pData[0], fr.ctypes.data, W * H * 3 // 2); zc += 1
     else:
+        yuv.iStride[0], yuv.iStride[1], yuv.iStride[2] = W, W // 2, W // 2
         for k, off in enumerate((0, W * H, W * H * 5 // 4)): yuv.pData[k] = C.cast(fr.ctypes.data + off, C.POINTER(C.c_ubyte))
     pic.pts = t
     if os.environ.get("KS_TEST_RECONFIG") and t in (40, 90):
@@ -85,4 +89,4 @@ while lib.QY265EncoderDelayedFrames(h):
 lanes = lib.ks265_enc_lanes(h)
 lib.QY265EncoderClose(h)
 if out_path: open(out_path, "wb").write(bytes(bs))
-print(json.dumps({"hdr": hdr_entries, "md5": md.hexdigest(), "lanes": lanes, "pts": pts, "idr": types.count(19), "vcl": len(pts), "bytes": len(bs), "maxdelay": maxdelay}))
+print(json.dumps({"hdr": hdr_entries, "md5": md.hexdigest(), "lanes": lanes, "pts": pts, "idr": types.count(19), "vcl": len(pts), "bytes": len(bs), "maxdelay": maxdelay, "zero_copy": zc}))

@@ -339,3 +339,46 @@ def test_scene_cut_lookahead(tmp_path):
             assert (np.fromfile(rec, np.uint8) == np.fromfile(dec, np.uint8)).all()
     assert kinds["plain"] == ["I"] + ["P"] * (n - 1)
     assert kinds["la"] == ["I"] + ["P"] * 11 + ["I"] + ["P"] * 11, kinds["la"]
+
+
+def test_zero_copy_input_on_the_gpu():
+    """ks265_enc_acquire_input: pictures produced straight into the encoder's pinned input buffers give the stream of the copying path, byte for byte"""
+    from ks265codec_amd import stream
+    lib = C.CDLL(stream.build())
+    lib.QY265EncoderOpen.restype = C.c_void_p
+    W, H, N = 416, 240, 14
+    clip = _clip("hierb4_416x240", N)
+
+    def encode(zero_copy):
+        cfg = (C.c_uint8 * LAY["sizeof_config"])()
+        assert lib.QY265ConfigDefaultPreset(cfg, b"slow", None, b"default") == 0
+        for k, v in (("wdt", W), ("hgt", H), ("fr", 50), ("rc", 0), ("qp", 27), ("iper", 128), ("bframes", 0), ("threads", 4), ("psnr", 1)):
+            assert lib.QY265ConfigParse(cfg, k.encode(), str(v).encode()) == 0
+        err = C.c_int(0)
+        h = C.c_void_p(lib.QY265EncoderOpen(cfg, C.byref(err)))
+        assert h.value, hex(err.value & 0xFFFFFFFF)
+        nal, nn, pic, outp, yuv = C.POINTER(Nal)(), C.c_int(0), Picture(), Picture(), YUV()
+        pic.yuv = C.pointer(yuv)
+        bs, used = bytearray(), 0
+        for t in range(N):
+            if zero_copy and lib.ks265_enc_acquire_input(h, C.byref(yuv)) == 0:
+                C.memmove(yuv.pData[0], clip[t].ctypes.data, W * H * 3 // 2); used += 1
+            else:
+                yuv.iWidth, yuv.iHeight = W, H
+                yuv.iStride[0], yuv.iStride[1], yuv.iStride[2] = W, W // 2, W // 2
+                for k, off in enumerate((0, W * H, W * H * 5 // 4)):
+                    yuv.pData[k] = C.cast(clip[t].ctypes.data + off, C.POINTER(C.c_ubyte))
+            pic.pts = t
+            assert lib.QY265EncoderEncodeFrame(h, C.byref(nal), C.byref(nn), C.byref(pic), C.byref(outp), 0) == 0
+            for i in range(nn.value):
+                bs += C.string_at(nal[i].pPayload, nal[i].iSize)
+        while lib.QY265EncoderDelayedFrames(h):
+            assert lib.QY265EncoderEncodeFrame(h, C.byref(nal), C.byref(nn), None, C.byref(outp), 0) == 0
+            for i in range(nn.value):
+                bs += C.string_at(nal[i].pPayload, nal[i].iSize)
+        lib.QY265EncoderClose(h)
+        return bytes(bs), used
+
+    a, _ = encode(False)
+    b, used = encode(True)
+    assert used == N and a == b

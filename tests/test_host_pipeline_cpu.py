@@ -241,3 +241,11 @@ def test_scene_cut_starts_a_closed_gop(stub_lib, bframes):
     assert calm["idr"] == 1 and calm["md5"] == run(stub_lib, 60, 128, bframes, W=128, H=96, KS_TEST_CUTS="1000")["md5"]
     close = run(stub_lib, 60, 128, 0, W=128, H=96, KS_TEST_CUTS="20,23,26,40", KS_TEST_LOOKAHEAD=8)               # cuts closer than eight pictures to the last key picture are not key pictures
     assert close["idr"] == 3, close["idr"]
+
+
+@pytest.mark.parametrize("lanes", [1, 2])
+def test_zero_copy_input_writes_the_same_stream(stub_lib, lanes):
+    """ks265_enc_acquire_input: the caller produces every picture into one of the encoder's pinned buffers and hands that pointer in - nothing is copied, same stream"""
+    a = run(stub_lib, 150, 32, 0, KS265_GOP_LANES=lanes)
+    b = run(stub_lib, 150, 32, 0, KS265_GOP_LANES=lanes, KS_TEST_ZEROCOPY=1)
+    assert b["zero_copy"] >= 140 and a["md5"] == b["md5"] and b["pts"] == list(range(150)), (b["zero_copy"], a["md5"], b["md5"])
