@@ -1477,6 +1477,7 @@ static int top_lanes_wanted(const QY265EncConfig *cfg, int ndev)
     int n = per * ndev;
     if (n > MAX_LANES) n = MAX_LANES;
     if (!cfg->enFrameParallel || cfg->rc != 0 || cfg->iIntraPeriod < 32 || g_cli.md5) n = 1;    /* the controllers carry state across GOPs; -md5 lines are in one display order */
+    if (cfg->lookahead > 0) n = 1;                                   /* a scene cut restarts the key period: GOP boundaries are not known when the pictures are dealt to lanes */
     return n;
 }
 

@@ -249,3 +249,12 @@ def test_zero_copy_input_writes_the_same_stream(stub_lib, lanes):
     a = run(stub_lib, 150, 32, 0, KS265_GOP_LANES=lanes)
     b = run(stub_lib, 150, 32, 0, KS265_GOP_LANES=lanes, KS_TEST_ZEROCOPY=1)
     assert b["zero_copy"] >= 140 and a["md5"] == b["md5"] and b["pts"] == list(range(150)), (b["zero_copy"], a["md5"], b["md5"])
+
+
+def test_scene_cuts_with_gop_lanes(stub_lib):
+    """a scene cut restarts the key period, so the GOP boundaries are not known when pictures are dealt to lanes: with -lookahead the handle runs one lane (and says so
+    through ks265_enc_lanes), the stream is the one-lane stream"""
+    kw = dict(W=128, H=96, KS_TEST_CUTS="23,41,77,100", KS_TEST_LOOKAHEAD=8)
+    one = run(stub_lib, 150, 32, 0, KS265_GOP_LANES=1, **kw)
+    two = run(stub_lib, 150, 32, 0, KS265_GOP_LANES=2, **kw)
+    assert two["lanes"] == 1 and one["idr"] == two["idr"] == 6 and one["md5"] == two["md5"], (one["idr"], two["idr"], two["lanes"])   # keys at 0, 23, 41, 73, 100, 132
