@@ -142,7 +142,7 @@ def main():
         tstream = None if sidx == 0 else torch.cuda.Stream(device=dev_index)
         with (torch.cuda.stream(tstream) if tstream is not None else contextlib.nullcontext()):
             ks = KsContext(dev_index)
-            fr = KsFrame(ks, W, H, qp, lambda_q4(qp), me_method=me_method, me_hex_thr=(args.me_hex_thr if me_method == 2 else 0), bframes=max(args.bframes, args.hier_b - 1 if args.hier_b else 0), refs=max(1, args.refs), sdh=1, pre_search=0 if args.no_pre_search else 1, merge=1, bi_refine=1, rdo=4, intra_inter=1)
+            fr = KsFrame(ks, W, H, qp, lambda_q4(qp), me_method=me_method, me_hex_thr=(args.me_hex_thr if me_method == 2 else 0), bframes=max(args.bframes, args.hier_b - 1 if args.hier_b else 0), refs=max(1, args.refs), sdh=1, pre_search=0 if args.no_pre_search else 1, merge=1, bi_refine=1, rdo=4, intra_inter=1, propagate=1)
             # synthetic clip of SURVEY.md §8(d), one GOP shard per stream (different seed per shard = different content)
             clip = make_clip(W, H, args.clip_frames, seed=7 + (0 if args.b_spread else rank * nstreams + sidx), abc=(67, 91, 33), pan=(8, 5))
             dev_clip = [ks.dev(c) for c in clip]
@@ -409,7 +409,7 @@ def port_leg(args, clip, order, me_method):
     from oracle_lib import OraclePipeline
     from ks265codec_amd.synth import lambda_q4
     W, H, qp = args.width, args.height, args.qp
-    o = OraclePipeline(W, H, qp, lambda_q4(qp), me_method=me_method, me_hex_thr=(args.me_hex_thr if me_method == 2 else 0), sdh=1, pre_search=0 if args.no_pre_search else 1, merge=1, bi_refine=1, rdo=4, intra_inter=1)
+    o = OraclePipeline(W, H, qp, lambda_q4(qp), me_method=me_method, me_hex_thr=(args.me_hex_thr if me_method == 2 else 0), sdh=1, pre_search=0 if args.no_pre_search else 1, merge=1, bi_refine=1, rdo=4, intra_inter=1, propagate=1)
     nbase = 3
     tc0 = time.perf_counter()
     if args.bframes == 0:

@@ -245,6 +245,8 @@ typedef struct {
                                   around); lambda_mode = (lambda_q4 / 16)^2.  The encoder host uses K = 4 with the P / B lambda table; key pictures are never pruned */
     int32_t intra_inter;       /* 1 = P / B pictures may hold intra CUs (EncIntraMD.cpp lineage: decideLumaMode enc@0x49acc0): the pre-selection cost of ks265_intra_decide competes in
                                   the CU decision, intra CUs are reconstructed after the inter CUs from reconstructed neighbours (CTU wavefront) */
+    int32_t propagate;         /* n > 0: n rounds of ks265_me_propagate between the integer search and the sub-pel step of every search of ks265_encode_picture[_b|_mref]
+                                  (meInitPoint enc@0x48af50 starts from the coded neighbours' vectors; a frame-parallel search gets them this way).  0..4; the encoder host uses 1 */
 } ks265_frame_cfg;
 
 /* geometry of the padded picture buffers the caller allocates (one call, no allocation) */
@@ -300,6 +302,11 @@ int ks265_presearch(ks265_frame *f, ks265_pic src, ks265_pic ref, int16_t *dev_f
  * interMeDia enc@0x48fbe0 over sad4_c); prev_pu = PU records of the previous picture (temporal
  * predictor) or NULL */
 int ks265_me_integer(ks265_frame *f, ks265_pic src, ks265_pic ref, const ks265_pu *dev_prev_pu, ks265_pu *dev_pu);
+/* Stage A2 (cfg.propagate; run by ks265_encode_picture[_b|_mref] itself, exported for stage tests): one round of vector propagation.  Every PU of dev_in (the
+ * records of ks265_me_integer for this src / ref pair - the CTUs' window offsets of that call are used for the vector limits) tries the integer vectors of its
+ * left / above / right / below neighbours of the same size (across CTU borders; skipping vectors outside its CTU's limits, its own and repeats): SAD + its own
+ * vector rate, strict '<', in that order; all 85 records per CTU go to dev_out (!= dev_in: every PU reads the state before the round) */
+int ks265_me_propagate(ks265_frame *f, ks265_pic src, ks265_pic ref, const ks265_pu *dev_in, ks265_pu *dev_out);
 /* Stage B: 8 half-pel + 8 quarter-pel refinement with SATD (subMeSquare enc@0x4b5660 ->
  * subMeHpel_RealInterp / subMeQpel_8Sad_*_RealInterp + had_c) */
 int ks265_me_subpel(ks265_frame *f, ks265_pic src, ks265_pic ref, ks265_pu *dev_pu);

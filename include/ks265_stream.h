@@ -30,6 +30,7 @@ typedef struct {
     int32_t log2_max_poc_lsb;              /* 4..16                                                                                 */
     int32_t sdh;                           /* sign_data_hiding_enabled_flag: the levels were produced with ks265_frame_cfg.sdh = 1                  */
     int32_t wpp;                           /* entropy_coding_sync_enabled_flag: every CTU row is a substream with an entry point (the reference's WPP) */
+    int32_t list_mod;                      /* lists_modification_present_flag: l0_poc / l1_poc may name the used pictures of the RPS in any order (7.3.6.2)  */
 } ks265_stream_cfg;
 
 enum { KS265_SLICE_B = 0, KS265_SLICE_P = 1, KS265_SLICE_I = 2 };
@@ -47,8 +48,9 @@ typedef struct {
     int32_t num_rps;
     int32_t rps_poc[16];
     uint8_t rps_used[16];
-    /* the reference lists in the order the default construction of H.265 8.3.4 yields them (the writer checks this and refuses anything
-     * else: no list modification is signalled); cu8.inter_dir >> 4 indexes list 0 for P pictures (multi-reference search) */
+    /* the reference lists; without cfg.list_mod they must come in the order the default construction of H.265 8.3.4 yields them (the
+     * writer checks this and refuses anything else), with it any order of used pictures is signalled through ref_pic_lists_modification();
+     * cu8.inter_dir >> 4 indexes list 0 for P pictures (multi-reference search) */
     int32_t num_l0, num_l1;
     int32_t l0_poc[4], l1_poc[4];
     /* records of the HIP stages (HOST copies): CU map (W/8 x H/8), levels (W x H, W/2 x H/2 x 2, TU in place), SAO (3 per CTU) */

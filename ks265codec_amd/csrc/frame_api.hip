@@ -24,7 +24,7 @@ int ks265_frame_create(ks265_ctx *ctx, const ks265_frame_cfg *cfg, ks265_frame *
     int r = ks265_frame_geometry(cfg, &geom);
     if (r) return r;
     if (cfg->me_method < 0 || cfg->me_method > 2) return KS265_NOTSUPPORTED;   /* 0 = DIA, 1 = HEX, 2 = UMH (-me); EPZS / Cross not built */
-    if (cfg->refs > 4) return KS265_NOTSUPPORTED;
+    if (cfg->refs > 4 || cfg->propagate < 0 || cfg->propagate > 4) return KS265_NOTSUPPORTED;
     if ((long long)geom.bytes_y >= (1ll << 31)) return KS265_NOTSUPPORTED;         /* stage B addresses a luma plane with 32-bit offsets */
     ks265_frame *f = new ks265_frame();                                            /* every validation above: nothing to undo on those returns */
     f->ctx = ctx; f->cfg = *cfg; f->geom = geom;
@@ -36,6 +36,7 @@ int ks265_frame_create(ks265_ctx *ctx, const ks265_frame_cfg *cfg, ks265_frame *
     const size_t npx = (size_t)g.W * g.H;
     r = KS265_OK;
     for (int i = 0; i < 2 && !r; ++i) r = dev_alloc(ctx, (void **)&f->pu[i], (size_t)geom.bytes_pu, true);
+    if (!r && cfg->propagate) r = dev_alloc(ctx, (void **)&f->pu_s, (size_t)geom.bytes_pu, true);
     if (!r && cfg->bframes > 0) {
         r = dev_alloc(ctx, (void **)&f->pu1, (size_t)geom.bytes_pu, true);
         if (!r) r = dev_alloc(ctx, (void **)&f->pub, (size_t)geom.ctu_cols * geom.ctu_rows * 85 * sizeof(ks265_pu_b), true);
@@ -72,7 +73,7 @@ void ks265_frame_destroy(ks265_frame *f)
     if (f->ctx) { (void)hipSetDevice(f->ctx->device); (void)hipStreamSynchronize(f->ctx->stream); }
     for (int i = 0; i <= KS_NSTAGE; ++i)
         if (f->ev[i]) (void)hipEventDestroy(f->ev[i]);
-    void *ptrs[] = {f->pu1, f->pub, f->pu[0], f->pu[1], f->cu8, f->sao, f->lvl[0], f->lvl[1], f->lvl[2], f->deb[0], f->deb[1], f->deb[2], f->sse, f->sse_acc, f->cu8_tmp, f->progress, f->mats, f->icost, f->pu_x[0], f->pu_x[1], f->pu_x[2]};
+    void *ptrs[] = {f->pu1, f->pu_s, f->pub, f->pu[0], f->pu[1], f->cu8, f->sao, f->lvl[0], f->lvl[1], f->lvl[2], f->deb[0], f->deb[1], f->deb[2], f->sse, f->sse_acc, f->cu8_tmp, f->progress, f->mats, f->icost, f->pu_x[0], f->pu_x[1], f->pu_x[2]};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (uint8_t *p : f->pyr)
@@ -86,6 +87,19 @@ int ks265_frame_set_qp(ks265_frame *f, int qp, int lambda_q4)
     if (qp < 0 || qp > 51 || lambda_q4 < 0) return KS265_NOTSUPPORTED;
     f->cfg.qp = qp; f->cfg.lambda_q4 = lambda_q4;
     return KS265_OK;
+}
+
+/* stage A (+ A2): the integer search of src in one reference picture, then cfg.propagate rounds of vector propagation; the records end up in pu */
+static int me_search(ks265_frame *f, ks265_pic src, ks265_pic ref, const ks265_pu *prev, ks265_pu *pu)
+{
+    const int n = f->cfg.propagate;
+    ks265_pu *a = (n & 1) ? f->pu_s : pu, *b = (n & 1) ? pu : f->pu_s;      /* n rounds swap sides n times */
+    int r = ks265_me_integer(f, src, ref, prev, a);
+    for (int i = 0; i < n && !r; ++i) {
+        r = ks265_me_propagate(f, src, ref, a, b);
+        ks265_pu *t = a; a = b; b = t;
+    }
+    return r;
 }
 
 int ks265_encode_picture(ks265_frame *f, ks265_pic src, ks265_pic ref, int is_key, ks265_pic recon_out)
@@ -114,7 +128,7 @@ int ks265_encode_picture(ks265_frame *f, ks265_pic src, ks265_pic ref, int is_ke
     } else {
         if (!ref.y) return KS265_POINTER;
         mark(0);
-        if ((r = ks265_me_integer(f, src, ref, f->have_prev ? f->pu[f->cur_pu ^ 1] : nullptr, pu))) return r;
+        if ((r = me_search(f, src, ref, f->have_prev ? f->pu[f->cur_pu ^ 1] : nullptr, pu))) return r;
         mark(1);
         if (f->cfg.subme && (r = ks265_me_subpel(f, src, ref, pu))) return r;
         mark(2);
@@ -153,7 +167,7 @@ int ks265_encode_picture_mref(ks265_frame *f, ks265_pic src, const ks265_pic *re
         if (!refs[i].y) return KS265_POINTER;
         ks265_pu *pu = i == 0 ? pu0 : f->pu_x[i - 1];
         /* the temporal predictor (previous picture's vectors) belongs to the nearest picture only */
-        if ((r = ks265_me_integer(f, src, refs[i], i == 0 && f->have_prev ? f->pu[f->cur_pu ^ 1] : nullptr, pu))) return r;
+        if ((r = me_search(f, src, refs[i], i == 0 && f->have_prev ? f->pu[f->cur_pu ^ 1] : nullptr, pu))) return r;
         if (f->cfg.subme && (r = ks265_me_subpel(f, src, refs[i], pu))) return r;
     }
     if ((r = ks265_ref_decide(f, nref, pus, f->pub))) return r;
@@ -175,9 +189,9 @@ int ks265_encode_picture_b(ks265_frame *f, ks265_pic src, ks265_pic ref0, ks265_
     if (!f->pu1) return KS265_NOTSUPPORTED;                   /* created with cfg.bframes == 0 */
     int r;
     ks265_pu *pu0 = f->pu[f->cur_pu];                         /* scratch: the next P picture overwrites it */
-    if ((r = ks265_me_integer(f, src, ref0, nullptr, pu0))) return r;
+    if ((r = me_search(f, src, ref0, nullptr, pu0))) return r;
     if (f->cfg.subme && (r = ks265_me_subpel(f, src, ref0, pu0))) return r;
-    if ((r = ks265_me_integer(f, src, ref1, nullptr, f->pu1))) return r;
+    if ((r = me_search(f, src, ref1, nullptr, f->pu1))) return r;
     if (f->cfg.subme && (r = ks265_me_subpel(f, src, ref1, f->pu1))) return r;
     if ((r = ks265_bi_decide(f, src, ref0, ref1, pu0, f->pu1, f->pub))) return r;
     const bool ii = f->cfg.intra_inter != 0;

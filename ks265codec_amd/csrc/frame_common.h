@@ -26,6 +26,7 @@ struct ks265_frame {
     // (no fractional planes: every consumer interpolates from the reference picture itself, interp_dev.h)
     ks265_pu *pu_x[3] = {nullptr, nullptr, nullptr};
     ks265_pu *pu1 = nullptr;
+    ks265_pu *pu_s = nullptr;            // cfg.propagate: the other side of the propagation rounds
     ks265_pu_b *pub = nullptr;
     ks265_pu *pu[2] = {nullptr, nullptr};
     int cur_pu = 0;

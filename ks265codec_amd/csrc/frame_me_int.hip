@@ -523,6 +523,109 @@ __global__ __launch_bounds__(256, 3) void me_int_kernel(KsGeom g, int range, int
 #endif
 }
 
+// ------------------------------------------------------------------ stage A2: vector propagation between neighbouring PUs (include/ks265_hip.h: ks265_me_propagate)
+// One work-group per CTU.  Step 1: thread p < 85 collects PU p's candidates: the integer vectors of its left / above / right / below neighbours of the same size
+// in `in` (across CTU borders), inside the CTU's limits, not its own, no repeats.  Step 2, per level: thread = (direction k, 8x8 block of the CTU) computes the SAD
+// of its block under candidate k of the PU the block belongs to (source: 8 aligned bytes per row, kept in registers for the four levels; reference: three aligned
+// dwords + v_alignbyte - the candidates are neighbours' vectors, their samples sit in L2); one thread per PU sums its blocks and takes the candidates in order,
+// strict '<' against the running best.  All 85 records go to `out`.
+#define PROP_NONE ((int)0x80000000)
+__global__ __launch_bounds__(256) void me_propagate_kernel(KsGeom g, int range, int lam, const uint8_t *src, const uint8_t *ref, const ks265_pu *in, ks265_pu *out,
+                                                           const short2 *ctu_off)
+{
+    __shared__ int cand[85][4];                // x & 0xFFFF | y << 16, PROP_NONE = no candidate
+    __shared__ unsigned sad8[4][64];           // per direction and 8x8 block: the level in flight
+    const int tid = threadIdx.x;
+    const int ctu = ks_xcd_swizzle(blockIdx.x, g.ctu_cols * g.ctu_rows), cx = ctu % g.ctu_cols, cy = ctu / g.ctu_cols;
+    const ks265_pu *in_ctu = in + (long)ctu * 85;
+    ks265_pu *out_ctu = out + (long)ctu * 85;
+    if (tid < 85) {
+        const int l = tid < 1 ? 0 : tid < 5 ? 1 : tid < 21 ? 2 : 3, n = 1 << l, base = ((1 << (2 * l)) - 1) / 3;
+        const int px = (tid - base) & (n - 1), py = (tid - base) >> l;
+        const ks265_pu o = in_ctu[tid];
+        const short2 ov = ctu_off ? ctu_off[ctu] : make_short2(0, 0);
+        int lox, hix, loy, hiy;
+        ctu_mv_limits(g, range, cx, cy, ov.x, ov.y, lox, hix, loy, hiy);
+        int c0 = PROP_NONE, c1 = PROP_NONE, c2 = PROP_NONE, c3 = PROP_NONE;
+        if (o.cost != KS_COST_INVALID) {
+            const int own_x = o.mvx >> 2, own_y = o.mvy >> 2;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int gx = cx * n + px + (k == 0 ? -1 : k == 2 ? 1 : 0), gy = cy * n + py + (k == 1 ? -1 : k == 3 ? 1 : 0);
+                if (gx < 0 || gy < 0 || gx >= g.ctu_cols * n || gy >= g.ctu_rows * n) continue;
+                const ks265_pu q = in[(long)((gy >> l) * g.ctu_cols + (gx >> l)) * 85 + base + (gy & (n - 1)) * n + (gx & (n - 1))];
+                if (q.cost == KS_COST_INVALID) continue;
+                const int mx = q.mvx >> 2, my = q.mvy >> 2;
+                if (mx < lox || mx > hix || my < loy || my > hiy) continue;
+                if (mx == own_x && my == own_y) continue;
+                const int v = (mx & 0xFFFF) | (int)((unsigned)my << 16);
+                if (v == c0 || v == c1 || v == c2) continue;             // c3 is the last one set
+                if (k == 0) c0 = v; else if (k == 1) c1 = v; else if (k == 2) c2 = v; else c3 = v;
+            }
+        }
+        cand[tid][0] = c0; cand[tid][1] = c1; cand[tid][2] = c2; cand[tid][3] = c3;
+    }
+    __syncthreads();
+    const uint8_t *Sp = ks_org_y(g, src), *R = ks_org_y(g, ref);
+    const int blk = tid & 63, k = tid >> 6, bx = blk & 7, by = blk >> 3;
+    const int x0 = cx * 64 + bx * 8, y0 = cy * 64 + by * 8;
+    const bool inside = x0 + 8 <= g.W && y0 + 8 <= g.H;
+    uint2 s8[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) s8[r] = inside ? *(const uint2 *)(Sp + (long)(y0 + r) * g.sy + x0) : make_uint2(0u, 0u);
+    for (int l = 0; l < 4; ++l) {
+        const int n = 1 << l, base = ((1 << (2 * l)) - 1) / 3, sh = 3 - l;
+        {
+            const int v = cand[base + (by >> sh) * n + (bx >> sh)][k];
+            unsigned sd = 0;
+            if (v != PROP_NONE && inside) {                              // a PU with candidates lies inside the picture, and so do its blocks
+                const int mx = (int)(short)(v & 0xFFFF), my = v >> 16;
+                const long off0 = (long)(y0 + my) * g.sy + x0 + mx;
+                const unsigned shb = (unsigned)(off0 & 3);               // the strides are multiples of 4: the same for every row
+                const uint8_t *p = R + (off0 - (long)shb);
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const unsigned *q = (const unsigned *)(p + (long)r * g.sy);
+                    const unsigned w0 = q[0], w1 = q[1], w2 = q[2];
+                    sd = sad_u8x4(s8[r].x, align_bytes(w1, w0, shb), sd);
+                    sd = sad_u8x4(s8[r].y, align_bytes(w2, w1, shb), sd);
+                }
+            }
+            sad8[k][blk] = sd;
+        }
+        __syncthreads();
+        if (tid < n * n) {
+            const int idx = base + tid, px = tid & (n - 1), py = tid >> l, m = 8 >> l;
+            ks265_pu o = in_ctu[idx];
+            if (o.cost != KS_COST_INVALID) {
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int v = cand[idx][kk];
+                    if (v == PROP_NONE) continue;
+                    unsigned d = 0;
+                    for (int yy = 0; yy < m; ++yy)
+                        for (int xx = 0; xx < m; ++xx) d += sad8[kk][(py * m + yy) * 8 + px * m + xx];
+                    const int mx = (int)(short)(v & 0xFFFF), my = v >> 16;
+                    const unsigned c = d + (unsigned)((lam * se_bits_dev((mx << 2) - o.mvpx)) >> 4) + (unsigned)((lam * se_bits_dev((my << 2) - o.mvpy)) >> 4);
+                    if (c < o.cost) { o.cost = c; o.dist = d; o.mvx = (short)(mx << 2); o.mvy = (short)(my << 2); }
+                }
+            }
+            out_ctu[idx] = o;
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int ks265_me_propagate(ks265_frame *f, ks265_pic src, ks265_pic ref, const ks265_pu *in, ks265_pu *out)
+{
+    KS_FRAME_CHECK(f);
+    if (!src.y || !ref.y || !in || !out) return KS265_POINTER;
+    if (in == out) return KS265_NOTSUPPORTED;
+    const dim3 grid(f->g.ctu_cols * f->g.ctu_rows), block(256);
+    hipLaunchKernelGGL(me_propagate_kernel, grid, block, 0, f->ctx->stream, f->g, f->cfg.me_range, f->cfg.lambda_q4, src.y, ref.y, in, out,
+                       f->cfg.pre_search ? (const short2 *)f->pyr[9] : nullptr);
+    return ks265_check_launch(f->ctx);
+}
+
 extern "C" int ks265_me_integer(ks265_frame *f, ks265_pic src, ks265_pic ref, const ks265_pu *prev_pu, ks265_pu *pu)
 {
     KS_FRAME_CHECK(f);

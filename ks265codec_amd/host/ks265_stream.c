@@ -164,7 +164,7 @@ long ks265_write_pps(const ks265_stream_cfg *cfg, uint8_t *out, size_t cap)
     bw_put(&b, cfg->deblock ? 0 : 1, 1); /* pps_deblocking_filter_disabled_flag */
     if (cfg->deblock) { bw_se(&b, cfg->beta_offset_div2); bw_se(&b, cfg->tc_offset_div2); }
     bw_put(&b, 0, 1);                    /* pps_scaling_list_data_present_flag */
-    bw_put(&b, 0, 1);                    /* lists_modification_present_flag */
+    bw_put(&b, cfg->list_mod ? 1 : 0, 1);/* lists_modification_present_flag */
     bw_ue(&b, 0);                        /* log2_parallel_merge_level_minus2 */
     bw_put(&b, 0, 1);                    /* slice_segment_header_extension_present_flag */
     bw_put(&b, 0, 1);                    /* pps_extension_present_flag */
@@ -937,9 +937,10 @@ static int coding_quadtree(Enc *e, int x, int y, int log2)
 }
 
 /* ------------------------------------------------------------------ slice segment header (7.3.6.1) + data */
-static int check_default_lists(const ks265_slice_in *in)
+/* 8.3.4: RefPicListTemp0 = StCurrBefore (closest first), StCurrAfter (closest first); list 1 the other way round.  Returns the number of
+ * pictures the slice predicts from (NumPicTotalCurr) and the two temporary lists. */
+static int temp_lists(const ks265_slice_in *in, int *t0, int *t1)
 {
-    /* 8.3.4: RefPicListTemp0 = StCurrBefore (closest first), StCurrAfter (closest first); list 1 the other way round */
     int before[16], after[16], nb = 0, na = 0;
     for (int i = 0; i < in->num_rps; ++i) {
         if (!in->rps_used[i]) continue;
@@ -947,18 +948,37 @@ static int check_default_lists(const ks265_slice_in *in)
     }
     for (int i = 0; i < nb; ++i) for (int j = i + 1; j < nb; ++j) if (before[j] > before[i]) { const int t = before[i]; before[i] = before[j]; before[j] = t; }
     for (int i = 0; i < na; ++i) for (int j = i + 1; j < na; ++j) if (after[j] < after[i]) { const int t = after[i]; after[i] = after[j]; after[j] = t; }
-    const int tot = nb + na;
-    if (in->slice_type != KS265_SLICE_I && (tot == 0 || in->num_l0 < 1 || in->num_l0 > 4)) return 0;
-    for (int i = 0; i < in->num_l0 && in->slice_type != KS265_SLICE_I; ++i) {
-        const int k = i % tot, p = k < nb ? before[k] : after[k - nb];
-        if (in->l0_poc[i] != p) return 0;
+    for (int k = 0; k < nb + na; ++k) { t0[k] = k < nb ? before[k] : after[k - nb]; t1[k] = k < na ? after[k] : before[k - na]; }
+    return nb + na;
+}
+
+/* list entries of ref_pic_lists_modification() (7.3.6.2) for one list: ent[i] = index into the temporary list; returns 0 = the default
+ * construction already gives the list, 1 = entries needed, -1 = a picture of the list is not a used picture of the RPS */
+static int list_entries(const int *want, int n, const int *temp, int tot, int *ent)
+{
+    int mod = 0;
+    for (int i = 0; i < n; ++i) {
+        int k = 0;
+        while (k < tot && temp[k] != want[i]) ++k;
+        if (k == tot) return -1;
+        ent[i] = k;
+        if (k != i % tot) mod = 1;
     }
+    return mod;
+}
+
+static int check_lists(const ks265_stream_cfg *cfg, const ks265_slice_in *in)
+{
+    if (in->slice_type == KS265_SLICE_I) return 1;
+    int t0[16], t1[16], ent[4];
+    const int tot = temp_lists(in, t0, t1);
+    if (tot == 0 || in->num_l0 < 1 || in->num_l0 > 4) return 0;
+    int m = list_entries(in->l0_poc, in->num_l0, t0, tot, ent);
+    if (m < 0 || (m && !cfg->list_mod)) return 0;
     if (in->slice_type == KS265_SLICE_B) {
         if (in->num_l1 < 1 || in->num_l1 > 4) return 0;
-        for (int i = 0; i < in->num_l1; ++i) {
-            const int k = i % tot, p = k < na ? after[k] : before[k - na];
-            if (in->l1_poc[i] != p) return 0;
-        }
+        m = list_entries(in->l1_poc, in->num_l1, t1, tot, ent);
+        if (m < 0 || (m && !cfg->list_mod)) return 0;
     }
     return 1;
 }
@@ -971,7 +991,7 @@ static int slice_args_ok(const ks265_stream_cfg *cfg, const ks265_slice_in *in)
     if (in->slice_type < 0 || in->slice_type > 2) return KS265_NOTSUPPORTED;
     const int idr = in->nal_type == KS265_NAL_IDR_W_RADL || in->nal_type == KS265_NAL_IDR_N_LP;
     if (idr && (in->slice_type != KS265_SLICE_I || in->poc != 0)) return KS265_NOTSUPPORTED;
-    if (!idr && !check_default_lists(in)) return KS265_NOTSUPPORTED;
+    if (!idr && !check_lists(cfg, in)) return KS265_NOTSUPPORTED;
     return KS265_OK;
 }
 
@@ -1010,6 +1030,18 @@ static int write_slice_header(BitW *bp, const ks265_stream_cfg *cfg, const ks265
         const int over = in->num_l0 != 1 || (in->slice_type == KS265_SLICE_B && in->num_l1 != 1);
         bw_put(&b, (uint32_t)over, 1);                               /* num_ref_idx_active_override_flag */
         if (over) { bw_ue(&b, (uint32_t)(in->num_l0 - 1)); if (in->slice_type == KS265_SLICE_B) bw_ue(&b, (uint32_t)(in->num_l1 - 1)); }
+        int t0[16], t1[16], ent[4];
+        const int tot = temp_lists(in, t0, t1);
+        if (cfg->list_mod && tot > 1) {                              /* ref_pic_lists_modification(): list_entry_lX is u(Ceil(Log2(NumPicTotalCurr))) */
+            int len = 0;
+            while ((1 << len) < tot) ++len;
+            for (int x = 0; x < (in->slice_type == KS265_SLICE_B ? 2 : 1); ++x) {
+                const int n = x ? in->num_l1 : in->num_l0;
+                const int m = list_entries(x ? in->l1_poc : in->l0_poc, n, x ? t1 : t0, tot, ent);
+                bw_put(&b, (uint32_t)(m > 0), 1);                    /* ref_pic_list_modification_flag_lX */
+                if (m > 0) for (int i = 0; i < n; ++i) bw_put(&b, (uint32_t)ent[i], len);
+            }
+        }
         if (in->slice_type == KS265_SLICE_B) bw_put(&b, 0, 1);       /* mvd_l1_zero_flag */
         bw_ue(&b, 5 - MAX_MERGE);                                    /* five_minus_max_num_merge_cand */
     }

@@ -296,7 +296,9 @@ void kso_presearch(const kso_frame_cfg *cfg, kso_pic src, kso_pic ref, int16_t *
  *     shrinks tME+0x68 from the spread of the neighbouring candidates; closed heuristics);
  *   - mv limits +-me_range around the PU position; candidates further than 66 samples away are skipped (the GPU's staged window). */
 #define ME_TAB 208                      /* |window offset| <= 2 range, + range, + slack */
-void kso_me_integer(const kso_frame_cfg *cfg, kso_pic src, kso_pic ref, const kso_pu *prev_pu, kso_pu *pu)
+void kso_me_integer(const kso_frame_cfg *cfg, kso_pic src, kso_pic ref, const kso_pu *prev_pu, kso_pu *pu) { kso_me_integer_ex(cfg, src, ref, prev_pu, pu, NULL); }
+/* off_out (may be NULL): the CTUs' window offsets the search used, 2 per CTU (zero without cfg->pre_search) - what kso_me_propagate needs for the same limits */
+void kso_me_integer_ex(const kso_frame_cfg *cfg, kso_pic src, kso_pic ref, const kso_pu *prev_pu, kso_pu *pu, int16_t *off_out)
 {
     kso_frame_geom g; kso_frame_geometry(cfg, &g);
     const uint8_t *S = org_y(&g, src.y), *R = org_y(&g, ref.y);
@@ -366,7 +368,60 @@ void kso_me_integer(const kso_frame_cfg *cfg, kso_pic src, kso_pic ref, const ks
                         o->dist = m.cost - (uint32_t)(m.cmx[4 * m.mx] + m.cmy[4 * m.my]);
                     }
         }
+    if (off_out) { if (ctu_off) memcpy(off_out, ctu_off, sizeof(int16_t) * 2 * (size_t)g.ctu_cols * g.ctu_rows); else memset(off_out, 0, sizeof(int16_t) * 2 * (size_t)g.ctu_cols * g.ctu_rows); }
     free(field); free(ctu_off);
+}
+
+/* ------------------------------------------------------------------ Stage A2: vector propagation between neighbouring PUs (cfg->propagate rounds)
+ * meInitPoint enc@0x48af50 starts every search from the vectors of the already coded neighbours (AMVP / merge candidates); a frame-parallel search has none, and
+ * a pattern search that starts from the wrong place cannot find a displaced match in texture without a gradient (a small object in front of a panning background:
+ * the pre-search sees it only where it fills a 32x32 block).  After the integer search every PU therefore tries the integer vectors its four neighbours of the
+ * same size found - left, above, right, below, in that order, across CTU borders, as they were BEFORE the round (in -> out: no order between PUs) - skipping
+ * vectors outside its CTU's limits, its own vector and repeats; cost = SAD + the PU's own vector rate (predictor mvp of its record), strict '<' against the
+ * running best.  ctu_off: the CTUs' window offsets of the search (kso_me_integer_ex), NULL = zero.
+ * Measured with tools/rd_eval.py (832x480 bench-style clip, qp 27, one round): IPPP P pictures -23 % bytes at +0.09 dB, hierarchical-B 8 all P / B pictures
+ * -21 % at +0.1 dB; a second round -1 %, eight neighbours -1 %, parent / child vectors nothing. */
+void kso_me_propagate(const kso_frame_cfg *cfg, kso_pic src, kso_pic ref, const int16_t *ctu_off, const kso_pu *in, kso_pu *out)
+{
+    kso_frame_geom g; kso_frame_geometry(cfg, &g);
+    const uint8_t *S = org_y(&g, src.y), *R = org_y(&g, ref.y);
+    const long st = g.stride_y;
+    const int lam = cfg->lambda_q4;
+    static const int nx[4] = {-1, 0, 1, 0}, ny[4] = {0, -1, 0, 1};
+#pragma omp parallel for collapse(2) schedule(dynamic, 1)
+    for (int cy = 0; cy < g.ctu_rows; ++cy)
+        for (int cx = 0; cx < g.ctu_cols; ++cx) {
+            const long ctu = cy * g.ctu_cols + cx;
+            int lim[4];
+            kso_ctu_mv_limits(cfg, cx, cy, ctu_off ? ctu_off[2 * ctu] : 0, ctu_off ? ctu_off[2 * ctu + 1] : 0, lim);
+            for (int l = 0; l < 4; ++l)
+                for (int py = 0; py < (1 << l); ++py)
+                    for (int px = 0; px < (1 << l); ++px) {
+                        kso_pu o = in[ctu * 85 + pu_index(l, px, py)];
+                        if (o.cost != COST_INVALID) {
+                            const int s = 64 >> l, x0 = cx * 64 + px * s, y0 = cy * 64 + py * s, n = 1 << l;
+                            const int own_x = o.mvx >> 2, own_y = o.mvy >> 2;
+                            int tried[4][2], nt = 0;
+                            for (int k = 0; k < 4; ++k) {
+                                const int gx = cx * n + px + nx[k], gy = cy * n + py + ny[k];                 /* the neighbour in units of this level's PUs */
+                                if (gx < 0 || gy < 0 || gx >= g.ctu_cols * n || gy >= g.ctu_rows * n) continue;
+                                const kso_pu *q = &in[(long)((gy >> l) * g.ctu_cols + (gx >> l)) * 85 + pu_index(l, gx & (n - 1), gy & (n - 1))];
+                                if (q->cost == COST_INVALID) continue;
+                                const int mx = q->mvx >> 2, my = q->mvy >> 2;
+                                if (mx < lim[0] || mx > lim[1] || my < lim[2] || my > lim[3]) continue;
+                                if (mx == own_x && my == own_y) continue;
+                                int dup = 0;
+                                for (int j = 0; j < nt; ++j) dup |= tried[j][0] == mx && tried[j][1] == my;
+                                if (dup) continue;
+                                tried[nt][0] = mx; tried[nt][1] = my; ++nt;
+                                const uint32_t d = ks265o_sad(S + (long)y0 * st + x0, R + (long)(y0 + my) * st + x0 + mx, st, st, s, s);
+                                const uint32_t c = d + (uint32_t)((lam * se_bits((mx << 2) - o.mvpx)) >> 4) + (uint32_t)((lam * se_bits((my << 2) - o.mvpy)) >> 4);
+                                if (c < o.cost) { o.cost = c; o.dist = d; o.mvx = (int16_t)(mx << 2); o.mvy = (int16_t)(my << 2); }
+                            }
+                        }
+                        out[ctu * 85 + pu_index(l, px, py)] = o;
+                    }
+        }
 }
 
 /* ------------------------------------------------------------------ Stage B: sub-pel refinement

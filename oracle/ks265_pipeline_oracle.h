@@ -18,7 +18,7 @@ extern "C" {
 #endif
 
 typedef struct {
-    int32_t width, height, qp, lambda_q4, me_range, me_method, subme, deblock, sao, beta_offset_div2, tc_offset_div2, bframes, refs, me_hex_thr, sdh, pre_search, merge, bi_refine, decimate, rdo, intra_inter;
+    int32_t width, height, qp, lambda_q4, me_range, me_method, subme, deblock, sao, beta_offset_div2, tc_offset_div2, bframes, refs, me_hex_thr, sdh, pre_search, merge, bi_refine, decimate, rdo, intra_inter, propagate;
 } kso_frame_cfg;
 
 typedef struct {
@@ -43,6 +43,9 @@ void kso_presearch(const kso_frame_cfg *cfg, kso_pic src, kso_pic ref, int16_t *
                    int16_t *ctu_off /* ctu_cols x ctu_rows x {ox, oy}: window offset of every CTU */);
 void kso_ctu_mv_limits(const kso_frame_cfg *cfg, int cx, int cy, int ox, int oy, int lim[4]);
 void kso_me_integer(const kso_frame_cfg *cfg, kso_pic src, kso_pic ref, const kso_pu *prev_pu, kso_pu *pu);
+void kso_me_integer_ex(const kso_frame_cfg *cfg, kso_pic src, kso_pic ref, const kso_pu *prev_pu, kso_pu *pu, int16_t *off_out /* 2 per CTU, may be NULL */);
+/* cfg->propagate: one round of vector propagation between neighbouring PUs of the same size (stage A2); in != out */
+void kso_me_propagate(const kso_frame_cfg *cfg, kso_pic src, kso_pic ref, const int16_t *ctu_off, const kso_pu *in, kso_pu *out);
 void kso_me_subpel(const kso_frame_cfg *cfg, kso_pic src, const uint8_t *planes, kso_pu *pu);
 void kso_cu_decide(const kso_frame_cfg *cfg, const kso_pu *pu, kso_cu8 *cu8);
 void kso_cu_flat_intra(const kso_frame_cfg *cfg, kso_cu8 *cu8);

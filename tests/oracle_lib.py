@@ -45,7 +45,7 @@ I = C.c_int
 # ------------------------------------------------------------------ pipeline oracle (ks265_pipeline_oracle.h)
 class OFrameCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("width", "height", "qp", "lambda_q4", "me_range", "me_method", "subme", "deblock", "sao",
-                                          "beta_offset_div2", "tc_offset_div2", "bframes", "refs", "me_hex_thr", "sdh", "pre_search", "merge", "bi_refine", "decimate", "rdo", "intra_inter")]
+                                          "beta_offset_div2", "tc_offset_div2", "bframes", "refs", "me_hex_thr", "sdh", "pre_search", "merge", "bi_refine", "decimate", "rdo", "intra_inter", "propagate")]
 
 
 class OFrameGeom(C.Structure):
@@ -80,10 +80,10 @@ class HostPic:
 class OraclePipeline:
     """CPU restatement of the frame stages (test checker / cpu_baseline 'port')."""
 
-    def __init__(self, width, height, qp, lambda_q4, me_range=64, subme=1, deblock=1, sao=1, me_method=0, intra=True, me_hex_thr=0, sdh=0, pre_search=0, merge=0, bi_refine=0, decimate=0, rdo=0, intra_inter=0):
+    def __init__(self, width, height, qp, lambda_q4, me_range=64, subme=1, deblock=1, sao=1, me_method=0, intra=True, me_hex_thr=0, sdh=0, pre_search=0, merge=0, bi_refine=0, decimate=0, rdo=0, intra_inter=0, propagate=0):
         self.o = lib()
         self.intra = intra                      # key pictures: real intra prediction (True) or the flat stand-in
-        self.cfg = OFrameCfg(width, height, qp, lambda_q4, me_range, me_method, subme, deblock, sao, 0, 0, 1, 4, me_hex_thr, sdh, pre_search, merge, bi_refine, decimate, rdo, intra_inter)
+        self.cfg = OFrameCfg(width, height, qp, lambda_q4, me_range, me_method, subme, deblock, sao, 0, 0, 1, 4, me_hex_thr, sdh, pre_search, merge, bi_refine, decimate, rdo, intra_inter, propagate)
         self.geom = OFrameGeom()
         assert self.o.kso_frame_geometry(C.byref(self.cfg), C.byref(self.geom)) == 0
         g = self.geom
@@ -109,6 +109,20 @@ class OraclePipeline:
         self.o.kso_store_i420(C.byref(self.cfg), pic.c(), ptr(out))
         return out
 
+    def search(self, ref_c: OPic, prev: "np.ndarray | None", pu: np.ndarray) -> None:
+        """stage A (+ A2): the integer search of self.src in one reference picture, then cfg.propagate rounds of vector propagation between neighbouring PUs"""
+        o, cfg = self.o, C.byref(self.cfg)
+        if not self.cfg.propagate:
+            o.kso_me_integer(cfg, self.src.c(), ref_c, ptr(prev) if prev is not None else None, ptr(pu))
+            return
+        off = np.zeros(2 * self.nctu, np.int16)
+        o.kso_me_integer_ex(cfg, self.src.c(), ref_c, ptr(prev) if prev is not None else None, ptr(pu), ptr(off))
+        self.pu_search = pu.copy()                # before the propagation (stage tests)
+        for _ in range(self.cfg.propagate):
+            out = np.zeros_like(pu)
+            o.kso_me_propagate(cfg, self.src.c(), ref_c, ptr(off), ptr(pu), ptr(out))
+            pu[:] = out
+
     def encode(self, i420: np.ndarray, kind: str, ref0: "HostPic | None" = None, ref1: "HostPic | None" = None) -> "HostPic":
         """one picture through all stages; kind 'I' (flat key picture), 'P' (ref0) or 'B' (ref0 = L0 past, ref1 = L1 future);
         returns the reconstructed padded picture.  Intermediate results stay in self.* for stage-by-stage comparison."""
@@ -126,7 +140,7 @@ class OraclePipeline:
             self.have_prev = False
         else:
             o.kso_ref_planes(cfg, r0, ptr(self.planes))
-            o.kso_me_integer(cfg, self.src.c(), r0, ptr(self.prev_pu) if (self.have_prev and kind == "P") else None, ptr(self.pu))
+            self.search(r0, self.prev_pu if (self.have_prev and kind == "P") else None, self.pu)
             self.pu_int = self.pu.copy()
             if self.cfg.subme:
                 o.kso_me_subpel(cfg, self.src.c(), ptr(self.planes), ptr(self.pu))
@@ -149,7 +163,7 @@ class OraclePipeline:
                     self.pu1 = np.zeros(self.nctu * 85, PU)
                     self.pub = np.zeros(self.nctu * 85, PU_B)
                 o.kso_ref_planes(cfg, r1, ptr(self.planes1))
-                o.kso_me_integer(cfg, self.src.c(), r1, None, ptr(self.pu1))
+                self.search(r1, None, self.pu1)
                 self.pu1_int = self.pu1.copy()
                 if self.cfg.subme:
                     o.kso_me_subpel(cfg, self.src.c(), ptr(self.planes1), ptr(self.pu1))
@@ -197,7 +211,7 @@ class OraclePipeline:
         pus = [self.pu] + self.pu_x[:n - 1]
         for i, r in enumerate(refs):
             o.kso_ref_planes(cfg, r.c(), ptr(planes[i]))
-            o.kso_me_integer(cfg, self.src.c(), r.c(), ptr(self.prev_pu) if (i == 0 and self.have_prev) else None, ptr(pus[i]))
+            self.search(r.c(), self.prev_pu if (i == 0 and self.have_prev) else None, pus[i])
             if self.cfg.subme:
                 o.kso_me_subpel(cfg, self.src.c(), ptr(planes[i]), ptr(pus[i]))
         pu_arr = (C.c_void_p * n)(*[p.ctypes.data for p in pus])

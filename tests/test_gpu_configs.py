@@ -26,7 +26,7 @@ def ks():
 
 
 # the tool set the C host (ks265_enc.c) and bench.py switch on for -preset slow: what is timed is what is checked (VERDICT r2 "weak 1a")
-ENCODER_TOOLS = dict(sdh=1, pre_search=1, merge=1, bi_refine=1, rdo=4, intra_inter=1)
+ENCODER_TOOLS = dict(sdh=1, pre_search=1, merge=1, bi_refine=1, rdo=4, intra_inter=1, propagate=1)
 
 
 def _ippp(ks, W, H, qp, me, nfr, seed, abc=(37, 53, 19), pan=(5, 3), hidden_offset=True, hex_thr=0, **tools):
@@ -235,7 +235,7 @@ def test_fuzz_bounded(ks, tmp_path):
     for it in range(40):
         W, H = int(rng.integers(1, 60)) * 8, int(rng.integers(1, 40)) * 8
         qp, me = int(rng.integers(0, 52)), int(rng.integers(0, 3))
-        kw = dict(me_range=int(rng.choice([8, 16, 32, 64])), subme=int(rng.integers(0, 2)), deblock=int(rng.integers(0, 2)), sao=int(rng.integers(0, 2)), me_method=me, me_hex_thr=int(rng.choice([0, 0, 16, 40])), sdh=int(rng.integers(0, 2)), pre_search=int(rng.integers(0, 2)), merge=int(rng.integers(0, 2)), bi_refine=int(rng.integers(0, 2)), decimate=int(rng.integers(0, 4)), rdo=int(rng.choice([0, 0, 2, 4, 9])), intra_inter=int(rng.integers(0, 3)))
+        kw = dict(me_range=int(rng.choice([8, 16, 32, 64])), subme=int(rng.integers(0, 2)), deblock=int(rng.integers(0, 2)), sao=int(rng.integers(0, 2)), me_method=me, me_hex_thr=int(rng.choice([0, 0, 16, 40])), sdh=int(rng.integers(0, 2)), pre_search=int(rng.integers(0, 2)), merge=int(rng.integers(0, 2)), bi_refine=int(rng.integers(0, 2)), decimate=int(rng.integers(0, 4)), rdo=int(rng.choice([0, 0, 2, 4, 9])), intra_inter=int(rng.integers(0, 3)), propagate=int(rng.integers(0, 3)))
         mode = str(rng.choice(["ippp", "mref", "hier"]))
         clip = make_clip(W, H, 9, seed=int(rng.integers(0, 10000)), noisy=bool(rng.integers(0, 2)), pan=(int(rng.integers(0, 100)), int(rng.integers(0, 60))) if it % 3 == 0 else (5, 3))
         o = OraclePipeline(W, H, qp, lambda_q4(qp), **kw)

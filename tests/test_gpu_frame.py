@@ -89,6 +89,55 @@ def test_stages_match_oracle(ks, W, H, seed, me):
     f.close()
 
 
+@pytest.mark.parametrize("W,H,seed,me,pre", [(200, 136, 5, 0, 0), (416, 240, 31, 2, 1), (1280, 720, 21, 2, 1), (1920, 1080, 9, 1, 1)])
+def test_vector_propagation_matches_oracle(ks, W, H, seed, me, pre):
+    """stage A2 (cfg.propagate): ks265_me_propagate on the records of ks265_me_integer == kso_me_propagate, record for record, two rounds; then the whole P
+    picture through ks265_encode_picture with the tool on == the oracle pipeline"""
+    from ks265codec_amd.lib import PU, KsFrame
+    from ks265codec_amd.synth import lambda_q4, make_clip
+    from oracle_lib import OraclePipeline, ptr
+    import ctypes as C
+
+    clip = make_clip(W, H, 3, seed=seed, pan=(8, 5))
+    kw = dict(me_method=me, me_hex_thr=16 if me == 2 else 0, pre_search=pre, propagate=2)
+    o = OraclePipeline(W, H, 27, lambda_q4(27), **kw)
+    with KsFrame(ks, W, H, 27, lambda_q4(27), **kw) as f:
+        g = f.geom
+        src, a, b = f.new_pic(), f.new_pic(), f.new_pic()
+        exp = o.encode_picture(clip[0], True)
+        f.load_i420(ks.dev(clip[0]), src)
+        f.encode_picture(src, a, True, b)                                   # b = the key picture's reconstruction
+        assert (ks.host(f.store_i420(b), np.uint8) == exp).all()
+        # stage by stage on picture 1
+        o.load(o.src, clip[1])
+        opu, off = np.zeros(o.nctu * 85, PU), np.zeros(2 * o.nctu, np.int16)
+        o.o.kso_me_integer_ex(C.byref(o.cfg), o.src.c(), o.ref.c(), None, ptr(opu), ptr(off))
+        f.load_i420(ks.dev(clip[1]), src)
+        pu = [ks.zeros(g.bytes_pu), ks.zeros(g.bytes_pu)]
+        f.me_integer(src, b, None, pu[0])
+        got = ks.host(pu[0], PU)
+        assert (got == opu).all(), f"integer ME: {int((got != opu).sum())} PU records differ"
+        for rnd in range(2):
+            onext = np.zeros_like(opu)
+            o.o.kso_me_propagate(C.byref(o.cfg), o.src.c(), o.ref.c(), ptr(off), ptr(opu), ptr(onext))
+            f.me_propagate(src, b, pu[0], pu[1])
+            got = ks.host(pu[1], PU)
+            bad = np.nonzero(got != onext)[0]
+            assert len(bad) == 0, f"propagation round {rnd}: {len(bad)} PU records differ, first {int(bad[0])} (ctu {int(bad[0]) // 85}, pu {int(bad[0]) % 85}): {got[bad[0]]} != {onext[bad[0]]}"
+            assert int((onext["cost"] != opu["cost"]).sum()) > 0              # the round does something on this clip
+            opu = onext
+            pu.reverse()
+        # the whole picture, then one more (temporal predictors)
+        for t in (1, 2):
+            o.set_qp(28, lambda_q4(28)); f.set_qp(28, lambda_q4(28))
+            exp = o.encode_picture(clip[t], False)
+            f.load_i420(ks.dev(clip[t]), src)
+            f.encode_picture(src, b, False, a)
+            got = ks.host(f.store_i420(a), np.uint8)
+            assert (got == exp).all(), f"picture {t}: {int((got != exp).sum())} samples differ"
+            a, b = b, a
+
+
 @pytest.mark.parametrize("W,H", [(416, 240), (1920, 1080)])
 def test_encode_picture_end_to_end(ks, W, H):
     """ks265_encode_picture (the bench path) == oracle pipeline over a short GOP, via recon I420 + PSNR sanity"""

@@ -193,3 +193,60 @@ def test_bi_refinement_and_decimation_properties():
     diff = cu0["cbf"] != cu2["cbf"]                                  # a dropped 16x16 / 32x32 TU clears the flag of all its 8x8 blocks
     assert blk[diff | blk].any() and ((cu2["cbf"][diff] & 1) == 0).all() and ((cu0["cbf"][diff] & 1) == 1).all()
     assert ((cu0["cbf"] & 6) == (cu2["cbf"] & 6)).all()
+
+
+def test_vector_propagation_properties():
+    """stage A2 (cfg.propagate): no PU's cost rises, every adopted vector is the integer vector of a same-size neighbour before the round and lies inside the CTU's
+    limits, the rate term is the PU's own (predictor unchanged), invalid PUs pass through; a small object in front of a panning background is what it is for: the
+    coded picture gets smaller at the same QP without losing quality"""
+    from oracle_lib import PU
+    W, H = 200, 136                                        # ragged: partial CTUs on both sides
+    clip = make_clip(W, H, 2, seed=5, abc=(17, 23, 9))
+    o = OraclePipeline(W, H, 27, lambda_q4(27), me_method=2, me_hex_thr=16, pre_search=1, propagate=1)
+    ref = o.encode(clip[0], "I")
+    o.load(o.src, clip[1])
+    cfg, g = C.byref(o.cfg), o.geom
+    pu, off = np.zeros(o.nctu * 85, PU), np.zeros(2 * o.nctu, np.int16)
+    o.o.kso_me_integer_ex(cfg, o.src.c(), ref.c(), None, ptr(pu), ptr(off))
+    plain = np.zeros_like(pu)
+    o.o.kso_me_integer(cfg, o.src.c(), ref.c(), None, ptr(plain))
+    assert (plain == pu).all()                             # the _ex form is the same search
+    out = np.zeros_like(pu)
+    o.o.kso_me_propagate(cfg, o.src.c(), ref.c(), ptr(off), ptr(pu), ptr(out))
+    inv = pu["cost"] == 0xFFFFFFFF
+    assert inv.any() and (out[inv] == pu[inv]).all()
+    assert (out["cost"] <= pu["cost"]).all() and (out["mvpx"] == pu["mvpx"]).all() and (out["mvpy"] == pu["mvpy"]).all()
+    moved = np.nonzero((out["mvx"] != pu["mvx"]) | (out["mvy"] != pu["mvy"]))[0]
+    assert len(moved) > 0
+    base = [0, 1, 5, 21]
+    for i in moved:
+        ctu, idx = divmod(int(i), 85)
+        cx, cy = ctu % g.ctu_cols, ctu // g.ctu_cols
+        l = 0 if idx < 1 else 1 if idx < 5 else 2 if idx < 21 else 3
+        n, px, py = 1 << l, (idx - base[l]) & ((1 << l) - 1), (idx - base[l]) >> l
+        nb = set()
+        for dx, dy in ((-1, 0), (0, -1), (1, 0), (0, 1)):
+            gx, gy = cx * n + px + dx, cy * n + py + dy
+            if 0 <= gx < g.ctu_cols * n and 0 <= gy < g.ctu_rows * n:
+                q = pu[((gy >> l) * g.ctu_cols + (gx >> l)) * 85 + base[l] + (gy & (n - 1)) * n + (gx & (n - 1))]
+                if q["cost"] != 0xFFFFFFFF:
+                    nb.add((int(q["mvx"]) >> 2, int(q["mvy"]) >> 2))
+        assert (int(out[i]["mvx"]) >> 2, int(out[i]["mvy"]) >> 2) in nb and out[i]["mvx"] % 4 == 0 and out[i]["mvy"] % 4 == 0
+        lim = (C.c_int * 4)()
+        o.o.kso_ctu_mv_limits(cfg, cx, cy, int(off[2 * ctu]), int(off[2 * ctu + 1]), lim)
+        assert lim[0] <= int(out[i]["mvx"]) >> 2 <= lim[1] and lim[2] <= int(out[i]["mvy"]) >> 2 <= lim[3]
+    # effect on a coded picture: the bench-style clip (squares in front of a pan), same QP
+    W, H = 416, 240
+    clip = make_clip(W, H, 3, seed=7, pan=(8, 5))
+    size = {}
+    for p in (0, 1):
+        o = OraclePipeline(W, H, 27, lambda_q4(27), me_method=2, me_hex_thr=16, pre_search=1, merge=1, rdo=4, intra_inter=1, propagate=p)
+        r = o.encode(clip[0], "I")
+        nz, ps = 0, []
+        for t in (1, 2):
+            o.set_qp(28, lambda_q4(28))
+            r = o.encode(clip[t], "P", r)
+            nz += sum(int((a != 0).sum()) for a in o.lvl)
+            ps.append(psnr(clip[t][:W * H], o.store(r)[:W * H]))
+        size[p] = (nz, min(ps))
+    assert size[1][0] < 0.9 * size[0][0] and size[1][1] > size[0][1] - 0.1, size

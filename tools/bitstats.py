@@ -21,7 +21,7 @@ sched = sc.schedule(kind, G if kind == "hier" else 9)
 n = 1 + max(s[0] for s in sched)
 clip = make_clip(W, H, n, seed=7, abc=(67, 91, 33), pan=(8, 5))
 ks = KsContext(0)
-f = KsFrame(ks, W, H, qp, lambda_q4(qp), me_method=2, me_hex_thr=16, bframes=3, sdh=1, pre_search=1, merge=1, bi_refine=int(os.environ.get("BIR", "1")), rdo=4, intra_inter=1)      # the host's tool set (round 3)
+f = KsFrame(ks, W, H, qp, lambda_q4(qp), me_method=2, me_hex_thr=16, bframes=3, sdh=1, pre_search=1, merge=1, bi_refine=int(os.environ.get("BIR", "1")), rdo=4, intra_inter=1, propagate=1)      # the host's tool set (round 3)
 g = f.geom
 src = f.new_pic()
 dpb = {}

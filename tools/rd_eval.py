@@ -23,7 +23,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-ENCODER_TOOLS = dict(me_method=2, me_hex_thr=16, sdh=1, pre_search=1, merge=1, bi_refine=1, decimate=2)
+ENCODER_TOOLS = dict(me_method=2, me_hex_thr=16, sdh=1, pre_search=1, merge=1, bi_refine=1, decimate=2)   # + --tools intra_inter=1,rdo=4,propagate=1 = the host encoder
 
 
 def stats_lib():
@@ -50,8 +50,8 @@ def encode_ours(clip, W, H, qp, gop, tools, verbose=False, stats=None, pdelta=1,
     from oracle_lib import OraclePipeline
     n = len(clip)
     o = OraclePipeline(W, H, qp, lambda_q4(qp), **tools)
-    G = 8
-    w = S.StreamWriter(W, H, max_dec_pic_buffering=10 if gop == "hier" else 2, max_num_reorder=7 if gop == "hier" else 0, sdh=tools.get("sdh", 0), wpp=0 if stats else 1)
+    G = int(os.environ.get("RD_G", "8"))
+    w = S.StreamWriter(W, H, max_dec_pic_buffering=10 if gop == "hier" else 2, max_num_reorder=7 if gop == "hier" else 0, sdh=tools.get("sdh", 0), wpp=0 if stats else 1, list_mod=1 if os.environ.get('RD_GPB2') else 0)
     import ctypes as C
     st = (C.c_double * 6)()
     agg = {}
@@ -65,6 +65,8 @@ def encode_ours(clip, W, H, qp, gop, tools, verbose=False, stats=None, pdelta=1,
         seq = [s for s in itertools.islice(hier_order(G, 1 << 20), n) if s[0] < n]
         if os.environ.get('RD_GPB_SAME'):                             # experiment: generalised B at the P positions, both lists = the previous anchor
             seq = [(d, 'B', r0, r0, 0) if k == 'P' else (d, k, r0, r1, l) for (d, k, r0, r1, l) in seq]
+        if os.environ.get('RD_GPB2'):                                 # generalised B at the P positions: list 0 = the previous anchor, list 1 = the one before it
+            seq = [(d, 'B', r0, r0 - G if r0 >= G else r0, 0) if k == 'P' else (d, k, r0, r1, l) for (d, k, r0, r1, l) in seq]
     dpb = {}
     for i, (d, kind, r0, r1, layer) in enumerate(seq):
         lq = layer_qp[min(len(layer_qp) - 1, layer)] if (layer_qp and kind == 'B') else layer      # B layers are numbered 1 (referenced most) .. 3
@@ -75,11 +77,17 @@ def encode_ours(clip, W, H, qp, gop, tools, verbose=False, stats=None, pdelta=1,
         o.set_qp(q, lambda_q4(q) if kind == "I" else int(round(lambda_q4(q) * ls)))
         if rdo_layers:
             o.cfg.rdo = rdo_layers[0] if kind == 'P' else rdo_layers[min(len(rdo_layers) - 1, layer)] if kind == 'B' else tools.get('rdo', 0)
-        dpb[d] = o.encode(clip[d], kind, dpb.get(r0), dpb.get(r1))
+        nmref = int(os.environ.get('RD_MREF', '1'))                   # experiment: the anchors of the hierarchy search the last RD_MREF anchors
+        xrefs = lambda dd, kk, rr: [rr - j * G for j in range(nmref) if rr - j * G >= 0] if (kk == 'P' and gop == 'hier' and nmref > 1) else []
+        mr = xrefs(d, kind, r0)
+        if len(mr) > 1:
+            dpb[d] = o.encode_mref(clip[d], [dpb[r] for r in mr])
+        else:
+            dpb[d] = o.encode(clip[d], kind, dpb.get(r0), dpb.get(r1))
         rec = o.store(dpb[d])
         later = seq[i + 1:]
-        needed = {r for (_, _, a, b, _) in later for r in (a, b) if r is not None and r in dpb and r != d}
-        cur = {r for r in (r0, r1) if r is not None}
+        needed = {r for (dd, kk, a, b, _) in later for r in [a, b] + xrefs(dd, kk, a) if r is not None and r in dpb and r != d}
+        cur = {r for r in (r0, r1) if r is not None} | set(mr)
         rps = [(p, p in cur) for p in sorted(needed | cur)]
         isref = any(d in (a, b) for (_, _, a, b, _) in later)
         if stats:
@@ -87,7 +95,7 @@ def encode_ours(clip, W, H, qp, gop, tools, verbose=False, stats=None, pdelta=1,
         if kind == "I":
             b = w.slice(S.NAL_IDR_W_RADL, S.SLICE_I, 0, q, o.cu8, o.lvl, o.sao)
         elif kind == "P":
-            b = w.slice(S.NAL_TRAIL_R, S.SLICE_P, d, q, o.cu8, o.lvl, o.sao, rps=rps, l0=[r0])
+            b = w.slice(S.NAL_TRAIL_R, S.SLICE_P, d, q, o.cu8, o.lvl, o.sao, rps=rps, l0=mr if len(mr) > 1 else [r0])
         else:
             b = w.slice(S.NAL_TRAIL_R if isref else S.NAL_TRAIL_N, S.SLICE_B, d, q, o.cu8, o.lvl, o.sao, rps=rps, l0=[r0], l1=[r1])
         bs += b
