@@ -59,6 +59,7 @@ def main():
                     "B pictures dealt to the other ranks (needs --bframes > 0); default = one GOP shard per rank, no collective")
     ap.add_argument("--streams", type=int, default=3, help="independent GOP shards in flight per GPU, each on its own HIP stream (their kernels overlap: the search kernels are latency bound)")
     ap.add_argument("--refs", type=int, default=1, help="list-0 reference pictures a P picture searches (-ref / -ref0; -preset slow resolves to 1 / 3: three for the first picture of a mini-GOP); IPPP only")
+    ap.add_argument("--propagate", type=int, default=1, help="hot-path leg: rounds of vector propagation between neighbouring PUs after every integer search (stage A2; the encoder runs 1)")
     ap.add_argument("--no-pre-search", action="store_true", help="hot-path leg: stage A without the pyramid pre-search start candidates (the encoder always runs them)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--leg", choices=["both", "encoded", "hot"], default="both", help="encoded: the whole encoder through the SDK-compatible C API (host pictures in, "
@@ -142,7 +143,7 @@ def main():
         tstream = None if sidx == 0 else torch.cuda.Stream(device=dev_index)
         with (torch.cuda.stream(tstream) if tstream is not None else contextlib.nullcontext()):
             ks = KsContext(dev_index)
-            fr = KsFrame(ks, W, H, qp, lambda_q4(qp), me_method=me_method, me_hex_thr=(args.me_hex_thr if me_method == 2 else 0), bframes=max(args.bframes, args.hier_b - 1 if args.hier_b else 0), refs=max(1, args.refs), sdh=1, pre_search=0 if args.no_pre_search else 1, merge=1, bi_refine=1, rdo=4, intra_inter=1, propagate=1)
+            fr = KsFrame(ks, W, H, qp, lambda_q4(qp), me_method=me_method, me_hex_thr=(args.me_hex_thr if me_method == 2 else 0), bframes=max(args.bframes, args.hier_b - 1 if args.hier_b else 0), refs=max(1, args.refs), sdh=1, pre_search=0 if args.no_pre_search else 1, merge=1, bi_refine=1, rdo=4, intra_inter=1, propagate=args.propagate)
             # synthetic clip of SURVEY.md §8(d), one GOP shard per stream (different seed per shard = different content)
             clip = make_clip(W, H, args.clip_frames, seed=7 + (0 if args.b_spread else rank * nstreams + sidx), abc=(67, 91, 33), pan=(8, 5))
             dev_clip = [ks.dev(c) for c in clip]
@@ -409,7 +410,7 @@ def port_leg(args, clip, order, me_method):
     from oracle_lib import OraclePipeline
     from ks265codec_amd.synth import lambda_q4
     W, H, qp = args.width, args.height, args.qp
-    o = OraclePipeline(W, H, qp, lambda_q4(qp), me_method=me_method, me_hex_thr=(args.me_hex_thr if me_method == 2 else 0), sdh=1, pre_search=0 if args.no_pre_search else 1, merge=1, bi_refine=1, rdo=4, intra_inter=1, propagate=1)
+    o = OraclePipeline(W, H, qp, lambda_q4(qp), me_method=me_method, me_hex_thr=(args.me_hex_thr if me_method == 2 else 0), sdh=1, pre_search=0 if args.no_pre_search else 1, merge=1, bi_refine=1, rdo=4, intra_inter=1, propagate=args.propagate)
     nbase = 3
     tc0 = time.perf_counter()
     if args.bframes == 0:

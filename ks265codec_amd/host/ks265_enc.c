@@ -987,7 +987,8 @@ static Enc *lane_open(QY265EncConfig *cfg, int device, int multi, int *err)
     e->fcfg.sdh = 1;                                                    /* the reference's streams have sign_data_hiding_enabled_flag = 1 at every preset */
     e->fcfg.pre_search = 1;                                             /* stage A0: pyramid pre-search vectors as start candidates of the integer search */
     e->fcfg.merge = 1;                                                  /* stage C2: merge pass on the motion field (pictures with one reference per list) */
-    e->fcfg.propagate = 1;                                              /* one round of vector propagation between neighbouring PUs after every integer search (measured: - 21 .. - 23 % bytes of the P / B pictures) */
+    e->fcfg.propagate = getenv("KS265_PROPAGATE") ? atoi(getenv("KS265_PROPAGATE")) & 3 : 1;   /* stage A2: rounds of vector propagation between neighbouring PUs after every
+                                                                         * integer search (measured with one round: - 21 .. - 23 % bytes of the P / B pictures; the variable is a measuring aid) */
     e->fcfg.intra_inter = 1;                                            /* P / B pictures may hold intra CUs (uncovered regions, occlusions); 2 = none of 8x8: measured + 1.6 % bits, no faster */
     e->fcfg.rdo = 4;                                                    /* coefficient-group pruning at lambda x 1 (ks265_frame_cfg.rdo): supersedes the coefficient decimation of round 2 */
     e->fcfg.bi_refine = 1;                                              /* B pictures: joint refinement of the bi-predictive pair (motionSearchBI enc@0x484910) */
