@@ -28,7 +28,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB
 
 # ALGORITHMIC bytes per picture, in units of P = luma samples (DESIGN.md §5 states each derivation)
 ALGO_BYTES_P = {
-    "me_integer": 2.2,       # source P + padded reference ~1.1 P + PU records
+    "me_integer": 2.2,       # source P + padded reference ~1.1 P + PU records (the propagation round of stage A2 re-reads source and candidates from L2: + 13 us, not counted)
     "me_subpel": 2.2,
     "intra_candidates": 0.25,  # the source samples of the CTUs the gate lets through (16 - 20 % of them) + their PU records + the packed candidates
     "cu_decide": 1.6,        # CU decision (PU records) + merge pass: source 1 P + prediction tiles of the candidates ~0.5 P + maps
@@ -718,10 +718,10 @@ def encoded_line(args, enc, world, hot, cpu):
                    "slice_write_ms_per_picture_per_thread": round(enc["slice_write_ms_per_picture"], 2),
                    "caller_ms_per_picture": enc.get("caller_ms_per_picture"),
                    "in_the_path": "pyramid pre-search, merge pass (merge / skip decided on SATD + rate, signalled where the motion equals a merge candidate), AMVP with the better of the two "
-                                  "predictors, joint refinement of bi-predictive pairs (B pictures, bi-prediction judged at 31/32), intra CUs in P / B pictures, coefficient-group pruning (luma) and sign-data hiding "
+                                  "predictors, vector propagation between neighbouring PUs (stage A2, one round), joint refinement of bi-predictive pairs (B pictures, bi-prediction judged at 31/32), intra CUs in P / B pictures, coefficient-group pruning (luma) and sign-data hiding "
                                   "(signBitHidingHDQ) at the postQuant seam, P / B lambda table; fractional samples interpolated on the fly; P / B pictures replayed as captured HIP graphs",
                    "not_in_the_path": "per-coefficient RDOQ (the reference's -rdoq at -preset slow), skip / CU size judged with the residual's cost, generalised B pictures, "
-                                      "lookahead / cuTree: at equal PSNR the stream is 1.29x (IPPP) to 2.1x (hierarchical B) the size of appencoder's (BASELINE.md 2b has the same-clip table)",
+                                      "lookahead / cuTree / adaptive mini-GOP: at equal PSNR the stream is 1.04x (2160p) / 1.10x (1080p) the size of appencoder's for IPPP and 1.93x / 1.51x for hierarchical B (BASELINE.md 2b has the same-clip table)",
                    "sharding": (f"ONE job of {enc['job']['frames']} pictures = {enc['job']['gops']} closed GOPs dealt to the ranks in contiguous runs; every rank encodes its GOPs, the coded bytes are "
                                 f"gathered on rank 0 in stream order (the only exchange step; inside the timed region); stream md5 {enc['md5']}") if strong else
                                "one encoder per GPU (rank), each on its own synthetic clip = its own closed GOPs; no data-path collective"},
