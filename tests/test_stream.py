@@ -62,3 +62,43 @@ def test_reference_decoder_reproduces_the_reconstruction_live():
             assert (dec[d] == recs[d]).all(), f"decoded picture {d} differs"
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+@pytest.mark.skipif(not os.path.exists(DEC), reason="reference decoder only exists in the builder container")
+def test_reference_lists_in_any_order_decode():
+    """cfg.list_mod (lists_modification_present_flag, 7.3.6.2): a B picture whose two lists hold two PAST pictures (the generalised B pictures the reference codes at
+    the P positions of its hierarchy) and a P picture that predicts from the farther of two pictures - lists the default construction does not give; the
+    reference's decoder must reproduce the oracle pipeline's reconstruction.  Without list_mod the writer refuses such lists."""
+    from ks265codec_amd import stream as S
+    from ks265codec_amd.synth import lambda_q4, make_clip
+    from oracle_lib import OraclePipeline
+    W, H = 416, 240
+    clip = make_clip(W, H, 4, seed=11, pan=(5, 3))
+    o = OraclePipeline(W, H, 30, lambda_q4(30), me_method=1, sdh=1, pre_search=1, merge=1, bi_refine=1, propagate=1)
+    w = S.StreamWriter(W, H, max_dec_pic_buffering=4, max_num_reorder=0, sdh=1, wpp=1, list_mod=1)
+    plain = S.StreamWriter(W, H, max_dec_pic_buffering=4, max_num_reorder=0, sdh=1, wpp=1)
+    bs, recs, dpb = w.headers(), {}, {}
+    sched = [(0, "I", None, None, [], S.NAL_IDR_W_RADL), (1, "P", 0, None, [(0, True)], S.NAL_TRAIL_R),
+             (2, "B", 1, 0, [(1, True), (0, True)], S.NAL_TRAIL_R),                 # list 1 = the FARTHER past picture: default construction would give picture 1 twice
+             (3, "P", 0, None, [(2, True), (0, True)], S.NAL_TRAIL_R)]              # list 0 = [0] although picture 2 is nearer
+    for d, kind, r0, r1, rps, nal in sched:
+        dpb[d] = o.encode(clip[d], kind, dpb.get(r0), dpb.get(r1))
+        recs[d] = o.store(dpb[d])
+        st = {"I": S.SLICE_I, "P": S.SLICE_P, "B": S.SLICE_B}[kind]
+        kw = dict(rps=rps, l0=[r0] if r0 is not None else [], l1=[r1] if r1 is not None else [])
+        bs += w.slice(nal, st, d, 30, o.cu8, o.lvl, o.sao, **kw)
+        if d >= 2:
+            with pytest.raises(RuntimeError):
+                plain.slice(nal, st, d, 30, o.cu8, o.lvl, o.sao, **kw)
+    tmp = tempfile.mkdtemp(prefix="ks265dec_")
+    try:
+        shutil.copy(DEC, tmp); os.chmod(os.path.join(tmp, "appdecoder"), 0o755)
+        open(os.path.join(tmp, "t.265"), "wb").write(bs)
+        r = subprocess.run([os.path.join(tmp, "appdecoder"), "-b", "t.265", "-o", "t.yuv", "-threads", "1"], capture_output=True, text=True, cwd=tmp)
+        assert "decoder passed" in r.stdout, r.stdout[-300:]
+        dec = np.fromfile(os.path.join(tmp, "t.yuv"), np.uint8).reshape(-1, W * H * 3 // 2)
+        assert len(dec) == 4
+        for d in range(4):
+            assert (dec[d] == recs[d]).all(), f"decoded picture {d} differs in {int((dec[d] != recs[d]).sum())} samples"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
