@@ -254,7 +254,8 @@ static void copy_shared(CopyPool *p, uint8_t *d, const uint8_t *s, size_t n)
     pthread_mutex_unlock(&p->mu);
 }
 
-typedef struct Input { int used, disp, key, base_qp, iper; long long pts; uint8_t *i420; } Input;     /* pinned; key: this picture starts a closed GOP whatever the period says (GOP lanes,
+#define LA_RING 9                                                      /* half-size pictures kept for the analysis: the current one and eight back */
+typedef struct Input { int used, disp, key, base_qp, iper, mini4; long long pts; uint8_t *i420; } Input;     /* pinned; key: this picture starts a closed GOP whatever the period says (GOP lanes,
                                                                                                  * QY265EncoderKeyFrameRequest); base_qp: the QP in force when the picture was handed in (QY265EncoderReconfig) -
                                                                                                  * iper: the key period in force then - all three travel WITH the picture: the scheduler thread
                                                                                                  * may be several pictures behind the caller */
@@ -296,8 +297,10 @@ typedef struct Enc {
     /* scene-cut lookahead (-lookahead N > 0; SURVEY.md 8(f) rank 2, scenecut enc@0x47e9d0 lineage): a stream and a frame object of HALF the size of their own; every
      * input picture is compared with its predecessor before the scheduler sees it (ks265_lookahead_picture: per 8x8 block of the half-size picture the intra
      * pre-selection cost against the integer-search cost) - where prediction from the previous picture is not clearly cheaper than intra coding a closed GOP starts */
-    int la_on, la_cur, la_have_prev, la_last_key; long la_cuts;
-    ks265_ctx *ctx_la; ks265_frame *frame_la; ks265_frame_geom geom_la; ks265_pic la_pic[2];
+    int la_on, la_have_prev, la_last_key, la_w, la_h; long la_cuts, la_mini4;
+    int mg_adapt, mg4_until;                                          /* slice-type decision (-lookahead N with the hierarchical GOP): a block of 8 pictures is coded as 8 or as 4 + 4; display index up to which 4 is in force */
+    unsigned long long la_c4_prev;                                     /* inter cost of the previous picture on the GOP's grid of 4 against the picture 4 back */
+    ks265_ctx *ctx_la; ks265_frame *frame_la; ks265_frame_geom geom_la; ks265_pic la_pic[LA_RING];
     uint8_t *la_dev_luma; uint32_t *la_cost_ws; uint64_t *la_dev_out, *la_host_out; void *la_ev;
     struct TopWake *wake;                                 /* lanes: the handle's caller sleeps here until a picture of ANY lane is finished */
     Job jobs[MAX_JOBS]; int ring, job_head, job_tail, njobs;   /* ring of `ring` pictures in coding order */
@@ -742,7 +745,7 @@ static int schedule(Enc *e, int flush, int have /* pictures [0, have) have arriv
         const int iper = in ? in->iper : 0;                            /* the period in force when this picture was handed in (QY265EncoderReconfig) */
         const int key = d < 0 || (iper > 0 && nxt - e->gop_start >= iper) || (in && in->key);
         if (key) {
-            e->gop_start = nxt;
+            e->gop_start = nxt; e->mg4_until = -1;
             e->rc_qp_delta = rc_decide(e);                             /* rate control: one offset per key picture / mini-GOP, decided when it is certain to be submitted */
             for (int i = 0; i < e->ndpb + 2 * e->key_overlap; ++i) e->dpb_poc[i] = -1000000;
             int r = submit(e, in, 'I', 0, clampqp(e, in->base_qp + e->rc_qp_delta), NULL, 0, NULL, 0, NULL, 0, 1, 1);
@@ -751,6 +754,13 @@ static int schedule(Enc *e, int flush, int have /* pictures [0, have) have arriv
             continue;
         }
         int span = e->gop_b + 1;                                       /* anchor distance */
+        if (e->mg_adapt && span == 8) {                                /* slice-type decision (lane_put): this block of 8 as two mini-GOPs of 4 */
+            if (d < e->mg4_until) span = 4;                            /* its second half */
+            else {
+                const Input *i8 = d + 8 < have ? input_at(e, d + 8) : NULL;   /* the decision travels with the block's last picture; not there yet: nothing is coded before it arrives (or a key picture / the flush cuts the block short) */
+                if (i8 && i8->mini4 && !i8->key) { span = 4; e->mg4_until = d + 8; }
+            }
+        }
         int a = d + span;
         if (iper > 0 && a - e->gop_start >= iper) a = e->gop_start + iper - 1;   /* the mini-GOP in front of a key picture is shortened */
         for (int k = nxt + 1; k <= a && k < have; ++k) {                 /* a picture asked to be a key picture: the mini-GOP in front of it is shortened as well */
@@ -890,6 +900,7 @@ static void lane_close(Enc *e, int report)
         if (e->ctx_in) ks265_synchronize(e->ctx_in);
         ks265_synchronize(e->ctx);
         if (e->ctx_out) ks265_synchronize(e->ctx_out);
+        if (report && e->la_on) logf_(1, e->log_level, "ks265enc: lookahead: %ld scene cuts, %ld blocks of 8 pictures coded as 4 + 4\n", e->la_cuts, e->la_mini4);
         if (report && e->cfg.calcPsnr && e->st.frames) {
             const double np[3] = {(double)e->W * e->H, (double)e->W * e->H / 4, (double)e->W * e->H / 4};
             double ps[3];
@@ -922,7 +933,7 @@ static void lane_close(Enc *e, int report)
         if (e->recon_fd >= 0) close(e->recon_fd);
         if (e->ctx_la) {
             ks265_synchronize(e->ctx_la);
-            for (int i = 0; i < 2; ++i) { ks265_dev_free(e->ctx_la, e->la_pic[i].y); ks265_dev_free(e->ctx_la, e->la_pic[i].u); ks265_dev_free(e->ctx_la, e->la_pic[i].v); }
+            for (int i = 0; i < LA_RING; ++i) { ks265_dev_free(e->ctx_la, e->la_pic[i].y); ks265_dev_free(e->ctx_la, e->la_pic[i].u); ks265_dev_free(e->ctx_la, e->la_pic[i].v); }
             ks265_dev_free(e->ctx_la, e->la_dev_luma); ks265_dev_free(e->ctx_la, e->la_cost_ws); ks265_dev_free(e->ctx_la, e->la_dev_out); ks265_host_free(e->ctx_la, e->la_host_out);
             if (e->la_ev) ks265_event_destroy(e->ctx_la, e->la_ev);
             if (e->frame_la) ks265_frame_destroy(e->frame_la);
@@ -1000,8 +1011,8 @@ static Enc *lane_open(QY265EncConfig *cfg, int device, int multi, int *err)
     if (!r) r = ks265_create(&e->ctx_in, dev_id);
     if (!r) r = ks265_create(&e->ctx_out, dev_id);
     if (!r && cfg->lookahead > 0) {
-        const int w = e->W / 2, h = e->H / 2;
-        if ((w & 7) || (h & 7) || w < 16 || h < 16) logf_(1, e->log_level, "ks265enc: -lookahead %d: the scene-cut analysis needs a picture size that is a multiple of 16: off\n", cfg->lookahead);
+        const int w = (e->W / 2) & ~7, h = (e->H / 2) & ~7;            /* the analysis sees the picture without its last columns / rows when half the size is no multiple of 8 */
+        if (w < 16 || h < 16) logf_(1, e->log_level, "ks265enc: -lookahead %d: the analysis needs a picture of at least 32 x 32: off\n", cfg->lookahead);
         else {
             ks265_frame_cfg lc; memset(&lc, 0, sizeof lc);
             lc.width = w; lc.height = h; lc.qp = e->base_qp > 0 ? e->base_qp : 27; lc.lambda_q4 = kLambdaQ4[lc.qp < 52 ? lc.qp : 51]; lc.me_range = 32; lc.me_method = 1; lc.subme = 0;
@@ -1009,7 +1020,7 @@ static Enc *lane_open(QY265EncConfig *cfg, int device, int multi, int *err)
             r = ks265_create(&e->ctx_la, dev_id);
             if (!r) r = ks265_frame_geometry(&lc, &e->geom_la);
             if (!r) r = ks265_frame_create(e->ctx_la, &lc, &e->frame_la);
-            for (int i = 0; i < 2 && !r; ++i) {
+            for (int i = 0; i < LA_RING && !r; ++i) {
                 r = ks265_dev_malloc(e->ctx_la, (void **)&e->la_pic[i].y, (size_t)e->geom_la.bytes_y);
                 if (!r) r = ks265_dev_malloc(e->ctx_la, (void **)&e->la_pic[i].u, (size_t)e->geom_la.bytes_c);
                 if (!r) r = ks265_dev_malloc(e->ctx_la, (void **)&e->la_pic[i].v, (size_t)e->geom_la.bytes_c);
@@ -1018,10 +1029,10 @@ static Enc *lane_open(QY265EncConfig *cfg, int device, int multi, int *err)
             }
             if (!r) r = ks265_dev_malloc(e->ctx_la, (void **)&e->la_dev_luma, (size_t)e->W * e->H);
             if (!r) r = ks265_dev_malloc(e->ctx_la, (void **)&e->la_cost_ws, (size_t)e->geom_la.ctu_cols * e->geom_la.ctu_rows * 85 * sizeof(uint32_t));
-            if (!r) r = ks265_dev_malloc(e->ctx_la, (void **)&e->la_dev_out, 64);
-            if (!r) r = ks265_host_malloc(e->ctx_la, (void **)&e->la_host_out, 64);
+            if (!r) r = ks265_dev_malloc(e->ctx_la, (void **)&e->la_dev_out, 128);
+            if (!r) r = ks265_host_malloc(e->ctx_la, (void **)&e->la_host_out, 128);
             if (!r) r = ks265_event_create(e->ctx_la, &e->la_ev);
-            if (!r) { e->la_on = 1; e->la_last_key = -1000000; }
+            if (!r) { e->la_on = 1; e->la_last_key = -1000000; e->la_w = w; e->la_h = h; e->mg_adapt = e->hier; e->mg4_until = -1; }
         }
     }
     for (int k = 0; k < NPIPE && !r; ++k) {
@@ -1190,32 +1201,58 @@ static int lane_put(Enc *e, QY265Picture *in, int key)
             memcpy(v + (size_t)y * (e->W / 2), in->yuv->pData[2] + (size_t)y * in->yuv->iStride[2], (size_t)e->W / 2);
         }
     }
-    int cut = 0;
-    if (e->la_on) {                                                    /* scene-cut analysis of this picture against its predecessor (own stream: short, independent of the pipeline) */
-        const int c = e->la_cur, w = e->W / 2, h = e->H / 2;
+    int cut = 0, mini4 = 0;
+    if (e->la_on) {                                                    /* analysis on half-size pictures, on a stream of its own: short, independent of the pipeline */
+        const int nd = e->next_disp, c = nd % LA_RING, w = e->la_w, h = e->la_h;
         const size_t org = (size_t)e->geom_la.pad_y * e->geom_la.stride_y + e->geom_la.pad_y;
         int r = ks265_memcpy_h2d_async(e->ctx_la, e->la_dev_luma, slot->i420, (size_t)e->W * e->H);
         if (!r) r = ks265_downsample_rect(e->ctx_la, e->la_dev_luma, e->W, e->la_pic[c].y + org, e->geom_la.stride_y, w, h);
         if (!r) r = ks265_pad_picture(e->frame_la, e->la_pic[c]);
-        if (!r && e->la_have_prev) {
-            r = ks265_lookahead_picture(e->frame_la, e->la_pic[c], e->la_pic[c ^ 1], e->la_cost_ws, e->la_dev_out);
+        if (!r && e->la_have_prev) {                                   /* scene cut: this picture against its predecessor */
+            r = ks265_lookahead_picture(e->frame_la, e->la_pic[c], e->la_pic[(nd + LA_RING - 1) % LA_RING], e->la_cost_ws, e->la_dev_out);
             if (!r) r = ks265_memcpy_d2h_async(e->ctx_la, e->la_host_out, e->la_dev_out, 32);
             if (!r) r = ks265_event_record(e->ctx_la, e->la_ev);
             if (!r) r = ks265_event_wait(e->ctx_la, e->la_ev);
             /* a cut: predicting the picture from its predecessor costs at least 0.7 of coding it intra (both sums over the 8x8 blocks of the half-size picture),
              * and the last key picture is at least eight pictures back */
-            if (!r && e->la_host_out[1] * 10 >= e->la_host_out[0] * 7 && e->next_disp - e->la_last_key >= 8) cut = 1;
+            if (!r && e->la_host_out[1] * 10 >= e->la_host_out[0] * 7 && nd - e->la_last_key >= 8) cut = 1;
+        }
+        /* slice types of the hierarchical GOP (the reference's adaptive BiPredFrames): the GOP is laid out in blocks of 8 pictures from its key picture; a block is
+         * coded with its anchor 8 pictures after the previous one, or - when predicting that anchor from 8 pictures back costs more than the two anchors 4 apart cost
+         * together (+ 1/12: the shorter structure pays more B-picture overhead) - as two mini-GOPs of 4.  Costs = the inter sums of the frame-cost kernels, this
+         * picture against the pictures 4 and 8 back; decided at the block's last picture, carried to the scheduler in its input slot. */
+        const int iper0 = e->iper;
+        const int keynow = cut || key || e->force_key || nd == 0 || (iper0 > 0 && e->la_last_key > -1000000 && nd - e->la_last_key >= iper0);
+        if (!r && e->mg_adapt && !keynow) {
+            const int p = nd - e->la_last_key;                          /* position inside the GOP */
+            if (p >= 4 && (p & 3) == 0) {
+                r = ks265_lookahead_picture(e->frame_la, e->la_pic[c], e->la_pic[(nd - 4) % LA_RING], e->la_cost_ws, e->la_dev_out + 4);
+                if (!r && (p & 7) == 0) r = ks265_lookahead_picture(e->frame_la, e->la_pic[c], e->la_pic[(nd - 8) % LA_RING], e->la_cost_ws, e->la_dev_out + 8);
+                if (!r) r = ks265_memcpy_d2h_async(e->ctx_la, e->la_host_out + 4, e->la_dev_out + 4, 64);
+                if (!r) r = ks265_event_record(e->ctx_la, e->la_ev);
+                if (!r) r = ks265_event_wait(e->ctx_la, e->la_ev);
+                if (!r) {
+                    const unsigned long long c4 = e->la_host_out[5];
+                    if ((p & 7) == 0) {
+                        const unsigned long long c8 = e->la_host_out[9], two = c4 + e->la_c4_prev;
+                        mini4 = c8 * 12 > two * 13;
+                        if (mini4) ++e->la_mini4;
+                    }
+                    e->la_c4_prev = c4;
+                }
+            }
         }
         if (r) { pthread_mutex_lock(&e->mu); slot->used = 0; e->sched_err = hip_rc(r); pthread_mutex_unlock(&e->mu); return hip_rc(r); }
-        e->la_cur ^= 1; e->la_have_prev = 1;
+        e->la_have_prev = 1;
     }
     pthread_mutex_lock(&e->mu);
     if (e->la_on) {
         const int nd = e->next_disp, iper = e->iper;
-        const int periodic = iper > 0 && e->la_last_key > -1000000 && nd - e->la_last_key >= iper;    /* (an estimate: the scheduler keeps the exact count) */
+        const int periodic = iper > 0 && e->la_last_key > -1000000 && nd - e->la_last_key >= iper;    /* (the scheduler's own rule: key positions are the same there) */
         if (cut) ++e->la_cuts;
         if (cut || key || e->force_key || nd == 0 || periodic) e->la_last_key = nd;
     }
+    slot->mini4 = mini4;
     slot->disp = e->next_disp++; slot->pts = in->pts; slot->key = key || e->force_key || cut; slot->base_qp = e->base_qp; slot->iper = e->iper; slot->used = 1;
     e->force_key = 0;
     pthread_cond_signal(&e->cv_sched);                                 /* the scheduler thread takes it from here */

@@ -251,7 +251,7 @@ int ks265_copy_out_compact_async(ks265_ctx *c, ks265_frame *f, void *host, const
 }
 
 /* ---- scene-cut lookahead (host: -lookahead N): the half-size picture is real (2x2 averages), the two frame costs are stand-ins with the right behaviour - "intra" = how
- * far the samples are from mid-grey, "inter" = how far they are from the previous picture's co-located samples (no search) */
+ * far the samples are from mid-grey, "inter" = how far they are from the reference picture's co-located samples (no search), growing faster than linearly with that distance */
 int ks265_downsample_rect(ks265_ctx *c, const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int h)
 {
     (void)c;
@@ -271,6 +271,7 @@ int ks265_lookahead_picture(ks265_frame *f, ks265_pic cur, ks265_pic ref, uint32
             const int a = cur.y[org + (long)y * f->g.stride_y + x], b = ref.y[org + (long)y * f->g.stride_y + x];
             intra += (uint64_t)(a > 128 ? a - 128 : 128 - a); inter += (uint64_t)(a > b ? a - b : b - a);
         }
+    inter += inter * inter / ((uint64_t)f->cfg.width * f->cfg.height * 8);      /* like a search with a window: a change twice as large costs more than twice as much */
     out[0] = intra; out[1] = inter; out[2] = intra < inter ? intra : inter; out[3] = (uint64_t)f->cfg.width * f->cfg.height / 64;
     return KS265_OK;
 }

@@ -48,8 +48,12 @@ if cuts:                                                   # scenes: one base pi
         if t == 0 or t in cuts:
             scene += 1; base = clip[scene % 11].astype(np.int16)
         frames.append(np.clip(base + rng.integers(-3, 4, base.shape), 0, 255).astype(np.uint8))
+ramp = [int(x) for x in os.environ.get("KS_TEST_RAMP", "").split(":") if x]          # start:end:step - one scene whose brightness rises by `step` per picture inside [start, end)
+if ramp:
+    base = rng.integers(48, 112, W * H * 3 // 2).astype(np.int16)
+    frames = [np.clip(base + ramp[2] * (min(max(t, ramp[0]), ramp[1]) - ramp[0]) + rng.integers(-3, 4, base.shape), 0, 255).astype(np.uint8) for t in range(N)]
 for t in range(N):
-    fr = frames[t] if cuts else clip[t % 11]
+    fr = frames[t] if (cuts or ramp) else clip[t % 11]
     if strided:
         planes[0][:, :W] = fr[:W * H].reshape(H, W); planes[0][:, W:] = t & 255
         planes[1][:, :W // 2] = fr[W * H:W * H * 5 // 4].reshape(H // 2, W // 2); planes[2][:, :W // 2] = fr[W * H * 5 // 4:].reshape(H // 2, W // 2)

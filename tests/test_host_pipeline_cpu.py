@@ -258,3 +258,47 @@ def test_scene_cuts_with_gop_lanes(stub_lib):
     one = run(stub_lib, 150, 32, 0, KS265_GOP_LANES=1, **kw)
     two = run(stub_lib, 150, 32, 0, KS265_GOP_LANES=2, **kw)
     assert two["lanes"] == 1 and one["idr"] == two["idr"] == 6 and one["md5"] == two["md5"], (one["idr"], two["idr"], two["lanes"])   # keys at 0, 23, 41, 73, 100, 132
+
+
+def _hier_order(d, a):
+    """coding order of the mini-GOP (d, a]: the anchor, then the B pictures breadth first (code_hier)"""
+    out, cur = [a], [(d, a)]
+    while cur:
+        nxt = []
+        for lo, hi in cur:
+            if hi - lo >= 2:
+                mid = (lo + hi) // 2
+                out.append(mid); nxt += [(lo, mid), (mid, hi)]
+        cur = nxt
+    return out
+
+
+def test_slice_type_decision_codes_blocks_of_eight_as_four_plus_four(stub_lib, tmp_path):
+    """-lookahead N with the hierarchical GOP (the reference's adaptive BiPredFrames): a block of 8 pictures is coded with anchors 4 apart when predicting its last
+    picture from 8 back costs more than the two steps of 4 together (+ 1/12).  Clip: one scene, still in [0, 32), brightening by 3 per picture in [32, 64), still again:
+    the blocks inside the ramp are 4 + 4, the blocks outside are 8; coding order, determinism, graph replay, and the stream decodes with the reference decoder"""
+    kw = dict(W=128, H=96, KS_TEST_RAMP="32:64:3")
+    plain = run(stub_lib, 100, 128, -1, **kw)
+    la = run(stub_lib, 100, 128, -1, out=tmp_path / "la.265", KS_TEST_LOOKAHEAD=8, **kw)
+    assert plain["idr"] == la["idr"] == 1 and sorted(la["pts"]) == list(range(100)) and la["vcl"] == 100
+    expect_plain, expect_la = [0], [0]
+    for d in range(0, 96, 8):
+        expect_plain += _hier_order(d, d + 8)
+        expect_la += (_hier_order(d, d + 4) + _hier_order(d + 4, d + 8)) if 32 <= d < 64 else _hier_order(d, d + 8)
+    tail = [99, 97, 98]                                      # the flush: 96 + 3 pictures, not a power of two: an anchor and two plain B pictures
+    assert plain["pts"][:97] == expect_plain, plain["pts"][:40]
+    assert la["pts"][:97] == expect_la, la["pts"][:80]
+    assert sorted(la["pts"][97:]) == sorted(tail)
+    assert la["md5"] != plain["md5"]
+    assert la["md5"] == run(stub_lib, 100, 128, -1, KS_TEST_LOOKAHEAD=8, **kw)["md5"] == run(stub_lib, 100, 128, -1, KS_TEST_LOOKAHEAD=8, KS265_NO_GRAPH=1, **kw)["md5"]
+    still = run(stub_lib, 100, 128, -1, KS_TEST_LOOKAHEAD=8, W=128, H=96, KS_TEST_RAMP="1000:1001:3")       # nothing moves: the analysis runs, every block stays 8
+    assert still["pts"][:97] == expect_plain
+    if os.path.exists(REF_DEC):
+        d = subprocess.run([REF_DEC, "-b", str(tmp_path / "la.265"), "-o", str(tmp_path / "d.yuv"), "-threads", "2"], capture_output=True, text=True, cwd=tmp_path)
+        assert d.returncode == 0 and os.path.getsize(tmp_path / "d.yuv") == 100 * 128 * 96 * 3 // 2, d.stdout[-300:] + d.stderr[-300:]
+    # key pictures inside: the period cuts blocks short, a requested key picture too - the grid of 8 restarts at every key picture
+    per = run(stub_lib, 100, 44, -1, out=tmp_path / "p.265", KS_TEST_LOOKAHEAD=8, KS_TEST_KEYREQ=1, **kw)
+    assert sorted(per["pts"]) == list(range(100)) and per["idr"] >= 3
+    if os.path.exists(REF_DEC):
+        d = subprocess.run([REF_DEC, "-b", str(tmp_path / "p.265"), "-o", str(tmp_path / "d2.yuv"), "-threads", "2"], capture_output=True, text=True, cwd=tmp_path)
+        assert d.returncode == 0 and os.path.getsize(tmp_path / "d2.yuv") == 100 * 128 * 96 * 3 // 2, d.stdout[-300:] + d.stderr[-300:]
