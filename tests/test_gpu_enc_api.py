@@ -341,6 +341,37 @@ def test_scene_cut_lookahead(tmp_path):
     assert kinds["la"] == ["I"] + ["P"] * 11 + ["I"] + ["P"] * 11, kinds["la"]
 
 
+def test_slice_type_decision_on_the_gpu(tmp_path):
+    """-lookahead N with the default (hierarchical) GOP: every block of 8 pictures is coded as 8 or as 4 + 4 from the frame costs at both distances (the reference's adaptive
+    BiPredFrames).  On the bench-style clip (squares in front of a pan of (8, 5): at 8 pictures' distance the edge of the search window) every block becomes 4 + 4, as in
+    the reference's own stream of this clip; without the option the anchors stay 8 apart; both streams decode to the encoder's reconstruction (profiles/r03_minigop.txt is this run)"""
+    import re
+    from ks265codec_amd import stream
+    from ks265codec_amd.synth import make_clip
+    stream.build()
+    W, H, n = 832, 480, 41
+    yuv = tmp_path / "in.yuv"
+    make_clip(W, H, n, seed=7, abc=(37, 53, 19), pan=(8, 5)).tofile(yuv)
+    order = {}
+    for tag, extra in (("plain", []), ("la", ["-lookahead", "8"])):
+        out, rec = tmp_path / f"{tag}.265", tmp_path / f"{tag}.yuv"
+        r = subprocess.run([stream.CLI, "-i", str(yuv), "-wdt", str(W), "-hgt", str(H), "-fr", "50", "-rc", "0", "-preset", "slow", "-qp", "27", "-iper", "128",
+                            "-threads", "8", "-psnr", "2", "-b", str(out), "-o", str(rec), *extra], capture_output=True, text=True)
+        assert r.returncode == 0 and "H265 encoder passed!!!" in r.stdout, r.stdout[-500:] + r.stderr[-500:]
+        order[tag] = [(int(a), b) for a, b in re.findall(r"^(\d+)\t([IPB])\t\d+\t", r.stdout, re.M)]
+        assert sorted(a for a, _ in order[tag]) == list(range(n))
+        if tag == "la":
+            m = re.search(r"lookahead: (\d+) scene cuts, (\d+) blocks of 8 pictures coded as 4 \+ 4", r.stdout)
+            assert m and int(m.group(1)) == 0 and int(m.group(2)) == 5, r.stdout[-600:]
+        if os.path.exists(REF_DEC):
+            dec = tmp_path / "dec.yuv"
+            d = subprocess.run([REF_DEC, "-b", str(out), "-o", str(dec), "-threads", "4"], capture_output=True, text=True, cwd=tmp_path)
+            assert "decoder passed" in d.stdout, d.stdout[-400:]
+            assert (np.fromfile(rec, np.uint8) == np.fromfile(dec, np.uint8)).all()
+    assert [a for a, k in order["plain"] if k == "P"] == [8, 16, 24, 32, 40]
+    assert [a for a, k in order["la"] if k == "P"] == list(range(4, 41, 4)), order["la"][:20]
+
+
 def test_zero_copy_input_on_the_gpu():
     """ks265_enc_acquire_input: pictures produced straight into the encoder's pinned input buffers give the stream of the copying path, byte for byte"""
     from ks265codec_amd import stream
