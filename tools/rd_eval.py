@@ -43,7 +43,7 @@ def stats_lib():
 STAT_NAMES = ["cu", "merge", "motion", "coef", "sao", "intra"]
 
 
-def encode_ours(clip, W, H, qp, gop, tools, verbose=False, stats=None, pdelta=1, cascade=None, lam_scale=1.0, rdo_layers=None, b_lam=None, layer_qp=None):
+def encode_ours(clip, W, H, qp, gop, tools, verbose=False, stats=None, pdelta=1, cascade=None, lam_scale=1.0, rdo_layers=None, b_lam=None, layer_qp=None, seq=None):
     from ks265codec_amd import stream as S
     from ks265codec_amd.gop import hier_order
     from ks265codec_amd.synth import lambda_q4, psnr
@@ -59,7 +59,9 @@ def encode_ours(clip, W, H, qp, gop, tools, verbose=False, stats=None, pdelta=1,
     per = []
     ps = []
     pc = []
-    if gop == "ippp":
+    if seq is not None:
+        pass
+    elif gop == "ippp":
         seq = [(t, "I" if t == 0 else "P", t - 1 if t else None, None, 0) for t in range(n)]
     else:
         seq = [s for s in itertools.islice(hier_order(G, 1 << 20), n) if s[0] < n]
@@ -71,10 +73,10 @@ def encode_ours(clip, W, H, qp, gop, tools, verbose=False, stats=None, pdelta=1,
     for i, (d, kind, r0, r1, layer) in enumerate(seq):
         lq = layer_qp[min(len(layer_qp) - 1, layer)] if (layer_qp and kind == 'B') else layer      # B layers are numbered 1 (referenced most) .. 3
         q = min(51, qp if kind == "I" else qp + pdelta + lq + (cascade[d % len(cascade)] if cascade and gop == "ippp" else 0))
-        ls = lam_scale if lam_scale > 0 else (min(4.0, max(2.0, (q - 12) / 6.0))) ** 0.5      # <= 0: HM's factor for non-key pictures, clip(2, 4, (qp - 12) / 6) on lambda_mode
+        ls = lam_scale if lam_scale > 0 else (min(4.0, max(2.0, (q - 12) / 6.0))) ** 0.5      # <= 0: HM's factor for non-key pictures, clip(2, 4, (qp - 12) / 6) on lambda_mode; -1 = --host
         if kind == 'B' and b_lam:
             ls *= b_lam[min(len(b_lam) - 1, layer)]
-        o.set_qp(q, lambda_q4(q) if kind == "I" else int(round(lambda_q4(q) * ls)))
+        o.set_qp(q, lambda_q4(q) if kind == "I" else (lambda_q4(q, inter=True) if lam_scale == -1 else int(round(lambda_q4(q) * ls))))     # lam_scale -1: the encoder host's integer table (kLambdaInterQ4)
         if rdo_layers:
             o.cfg.rdo = rdo_layers[0] if kind == 'P' else rdo_layers[min(len(rdo_layers) - 1, layer)] if kind == 'B' else tools.get('rdo', 0)
         nmref = int(os.environ.get('RD_MREF', '1'))                   # experiment: the anchors of the hierarchy search the last RD_MREF anchors
@@ -128,6 +130,68 @@ def encode_ours(clip, W, H, qp, gop, tools, verbose=False, stats=None, pdelta=1,
     return bs, 10 * np.log10(255.0 ** 2 / mse), per
 
 
+def mini_gop(lo, hi):
+    """coding order of the mini-GOP (lo, hi] as the host codes it: the anchor, then - a power of two apart - the B pictures breadth first (code_hier), else plain
+    non-reference B pictures between the two anchors at QP + 2 (the flush of a clip that does not end on the grid); entries of encode_ours' seq"""
+    if (hi - lo) & (hi - lo - 1):
+        return [(hi, "P", lo, None, 0)] + [(b, "B", lo, hi, 1) for b in range(lo + 1, hi)]
+    out, cur, layer = [(hi, "P", lo, None, 0)], [(lo, hi)], 1
+    while cur:
+        nxt = []
+        for a, b in cur:
+            if b - a >= 2:
+                mid = (a + b) // 2
+                out.append((mid, "B", a, b, layer)); nxt += [(a, mid), (mid, b)]
+        cur, layer = nxt, layer + 1
+    return out
+
+
+def adaptive_seq(clip, W, H, qp, decide=True):
+    """the host's slice-type decision (-lookahead N, ks265_enc.c lane_put): per block of 8 pictures inter(8) x 12 > (inter(4) + inter(4)') x 13 -> 4 + 4; the inter sums
+    are those of the frame-cost kernels on half-size pictures (here: their oracle restatement, which the GPU tests hold equal)"""
+    import ctypes as C
+    from ks265codec_amd.lib import PU
+    from ks265codec_amd.synth import lambda_q4
+    from oracle_lib import I, HostPic, OraclePipeline, lib as olib, ptr
+    ol, n = olib(), len(clip)
+    w, h = (W // 2) & ~7, (H // 2) & ~7
+    o_full, o_low = OraclePipeline(W, H, qp, lambda_q4(qp)), OraclePipeline(w, h, qp, lambda_q4(qp), me_range=32, me_method=1, subme=0)
+    gf, gl = o_full.geom, o_low.geom
+    of, olo = gf.pad_y * gf.stride_y + gf.pad_y, gl.pad_y * gl.stride_y + gl.pad_y
+    low = {}
+
+    def half(t):
+        if t not in low:
+            o_full.load(o_full.src, clip[t])
+            lo = HostPic(gl)
+            ol.ks265o_downsample(ptr(lo.y, olo), ptr(o_full.src.y, of), I(gl.stride_y), I(gf.stride_y), I(w), I(h))
+            lo.u[:] = 0; lo.v[:] = 0
+            ol.kso_pad_picture(C.byref(o_low.cfg), lo.c())
+            low[t] = lo
+        return low[t]
+
+    def inter(cur, ref):
+        cost, pu, out = np.zeros(o_low.nctu * 85, np.uint32), np.zeros(o_low.nctu * 85, PU), np.zeros(4, np.uint64)
+        ol.kso_intra_decide_ex(C.byref(o_low.cfg), half(cur).c(), ptr(o_low.cu8), ptr(cost))
+        ol.kso_me_integer(C.byref(o_low.cfg), half(cur).c(), half(ref).c(), None, ptr(pu))
+        ol.kso_lookahead_reduce(C.byref(o_low.cfg), ptr(cost), ptr(pu), ptr(out))
+        return int(out[1])
+
+    seq, d, four = [(0, "I", None, None, 0)], 0, 0
+    while d + 8 < n:
+        c4a, c4b, c8 = (inter(d + 4, d), inter(d + 8, d + 4), inter(d + 8, d)) if decide else (1, 1, 0)
+        if c8 * 12 > (c4a + c4b) * 13:
+            seq += mini_gop(d, d + 4) + mini_gop(d + 4, d + 8); four += 1
+        else:
+            seq += mini_gop(d, d + 8)
+        d += 8
+        for k in [k for k in low if k < d]:
+            del low[k]
+    if d < n - 1:                                              # the flush: what is left, as one short mini-GOP (a power of two: pyramid, else the host codes plain B pictures - not mirrored)
+        seq += mini_gop(d, n - 1)
+    return seq, four
+
+
 def encode_ref(yuv_path, W, H, qp, gop, n, threads=4):
     enc = os.path.join(ROOT, "oracle", "_ref", "appencoder")
     if not os.path.exists(enc):
@@ -163,6 +227,9 @@ def main():
     ap.add_argument("--pdelta", type=int, default=1)
     ap.add_argument("--cascade", default="")
     ap.add_argument("--lam-scale", type=float, default=1.0)
+    ap.add_argument("--host", action="store_true", help="exactly what the encoder host does: its tool set (intra_inter=1, rdo=4, propagate=1 on top of ENCODER_TOOLS without the decimation), its P / B lambda table, its QP ladder")
+    ap.add_argument("--adaptive", action="store_true", help="--gop hier: the host's slice-type decision of -lookahead N (blocks of 8 pictures as 8 or 4 + 4)")
+    ap.add_argument("--pingpong", type=int, default=0, metavar="K", help="the clip of the same-clip tables: K pictures of the generator played forth and back, --frames pictures in all")
     ap.add_argument("--pan", default="", help="pan of the synthetic clip in samples per picture, e.g. 8,5")
     ap.add_argument("--rdo-layers", default="", help="cfg.rdo of P pictures and of the B layers 1, 2, 3 (comma separated)")
     ap.add_argument("--b-lam", default="", help="extra lambda factors, indexed by B layer (entry 0 unused)")
@@ -172,8 +239,13 @@ def main():
     W, H = (int(x) for x in a.size.split("x"))
     big = W >= 3000
     pan = tuple(int(x) for x in a.pan.split(',')) if a.pan else ((8, 5) if big else (5, 3))
-    clip = make_clip(W, H, a.frames, seed=a.seed, abc=(67, 91, 33) if big else (37, 53, 19), pan=pan)
+    clip = make_clip(W, H, a.pingpong or a.frames, seed=a.seed, abc=(67, 91, 33) if big else (37, 53, 19), pan=pan)
+    if a.pingpong:
+        order = list(range(a.pingpong)) + list(range(a.pingpong - 2, 0, -1))
+        clip = clip[[order[t % len(order)] for t in range(a.frames)]]
     tools = dict(ENCODER_TOOLS)
+    if a.host:
+        tools.update(decimate=0, intra_inter=1, rdo=4, propagate=1); a.lam_scale = -1.0
     for kv in filter(None, a.tools.split(",")):
         k, v = kv.split("=")
         tools[k] = int(v)
@@ -191,9 +263,14 @@ def main():
     pts = []
     for qp in (int(x) for x in a.qps.split(",")):
         t0 = time.time()
+        seq = None
+        if (a.adaptive or a.host) and a.gop == "hier":               # --host without --adaptive: the host's own layout (blocks of 8, its flush), no decision
+            seq, four = adaptive_seq(clip, W, H, qp, decide=a.adaptive)
+            if a.adaptive:
+                print(f"   slice types at qp {qp}: {four} of {(len(clip) - 1) // 8} blocks of 8 as 4 + 4", flush=True)
         bs, p, per = encode_ours(clip, W, H, qp, a.gop, tools, a.v, stats_lib() if a.stats else None, a.pdelta, [int(x) for x in a.cascade.split(',')] if a.cascade else None, a.lam_scale,
                                  [int(x) for x in a.rdo_layers.split(',')] if a.rdo_layers else None, [float(x) for x in a.b_lam.split(',')] if a.b_lam else None,
-                                 [int(x) for x in a.layer_qp.split(',')] if a.layer_qp else None)
+                                 [int(x) for x in a.layer_qp.split(',')] if a.layer_qp else None, seq=seq)
         bykind, pk = {}, {}
         for d, k, l, b, e in per:
             bykind.setdefault(f"{k}{l if k == 'B' else ''}", []).append(b)
