@@ -32,9 +32,9 @@ CASES = {
     "wpp_ippp_56x200_qp12": (56, 200, 12, 1, 0, 1, 1, "ippp", 3),      # one CTU per row: no context hand-over, every row starts from the initial contexts
     "wpp_ippp_1280x720_umh": (1280, 720, 27, 2, 16, 1, 1, "ippp", 3),
     # everything the C host (ks265_enc.c) switches on: sign-data hiding, pre-search, merge pass, WPP substreams
-    "enc_ippp_416x240_umh": (416, 240, 27, 2, 16, 1, 1, "ippp", 4),
+    "enc_ippp_416x240_umh": (416, 240, 27, 2, 16, 1, 1, "ippph", 4),      # ippph: IPPP with the encoder host's QP ladder (P pictures at + 1 + {0, 2, 1, 2}[position & 3])
     "enc_hierb4_416x240": (416, 240, 30, 1, 0, 1, 1, "hier", 4),
-    "enc_ippp_1280x720_qp32": (1280, 720, 32, 1, 0, 1, 1, "ippp", 3),
+    "enc_ippp_1280x720_qp32": (1280, 720, 32, 1, 0, 1, 1, "ippph", 3),
 }
 
 
@@ -80,13 +80,16 @@ def case_lambda(name: str, q: int, kind: str) -> int:
     return lambda_q4(q, inter=name.startswith("enc_") and kind != "I")
 
 
+HOST_IPPP_CASCADE = (0, 2, 1, 2)      # ks265_enc.c kIpppCascade: the QP of an IPPP P picture is the key picture's + 1 + this, by its position in the GOP (the reference's 30 / 29 / 30 / 28 at -qp 27)
+
+
 def schedule(kind: str, par: int):
     """list of (display index, picture kind, list-0 display indices, list-1 display indices, qp offset, rps [(display index, used)], is reference)"""
     from ks265codec_amd.gop import hier_order
     out = []
-    if kind == "ippp":
+    if kind in ("ippp", "ippph"):
         for t in range(par):
-            out.append((t, "I" if t == 0 else "P", [t - 1] if t else [], [], 0 if t == 0 else 1, [(t - 1, True)] if t else [], True))
+            out.append((t, "I" if t == 0 else "P", [t - 1] if t else [], [], 0 if t == 0 else 1 + (HOST_IPPP_CASCADE[t & 3] if kind == "ippph" else 0), [(t - 1, True)] if t else [], True))
     elif kind == "mref":
         for t in range(par + 3):
             refs = [t - 1 - i for i in range(min(par, t))]

@@ -292,6 +292,7 @@ def test_encoder_reconstruction_equals_the_oracle_pipeline(tmp_path, W, H, n):
     from ks265codec_amd.synth import make_clip, lambda_q4
     from oracle_lib import OraclePipeline
     from test_gpu_configs import ENCODER_TOOLS
+    from stream_cases import HOST_IPPP_CASCADE
     stream.build()
     clip = make_clip(W, H, n, seed=W + n, abc=(67, 91, 33) if W >= 3000 else (37, 53, 19), pan=(8, 5) if W >= 3000 else (5, 3))
     yuv, out, rec = tmp_path / "in.yuv", tmp_path / "out.265", tmp_path / "rec.yuv"
@@ -305,7 +306,7 @@ def test_encoder_reconstruction_equals_the_oracle_pipeline(tmp_path, W, H, n):
     o = OraclePipeline(W, H, 27, lambda_q4(27), me_method=2, me_hex_thr=16, **ENCODER_TOOLS)     # -preset slow: UMH with the HEX shortcut below 16 SAD / sample
     ref = None
     for t in range(n):
-        q = 27 if t == 0 else 28                                      # the host's ladder: I = Q, P = Q + 1
+        q = 27 if t == 0 else 28 + HOST_IPPP_CASCADE[t & 3]           # the host's ladder: I = Q, P = Q + 1 + the IPPP cascade
         o.set_qp(q, lambda_q4(q, inter=t > 0))
         ref = o.encode(clip[t], "I" if t == 0 else "P", ref, None)
         want = o.store(ref)

@@ -209,6 +209,40 @@ def test_cli_prints_the_reference_per_picture_and_md5_lines(stub_lib, tmp_path):
     assert any(re.fullmatch(r"bitrate, psnr: [\d.]+\t[\d.]+\t[\d.]+\t[\d.]+", ln) for ln in lines), [ln for ln in lines if "psnr" in ln]
 
 
+def test_qp_ladders_of_the_host(stub_lib, tmp_path):
+    """the QP every picture is coded with (-psnr 2 prints it): IPPP = the reference's cascade (key picture Q, P pictures Q + 1 + {0, 2, 1, 2}[position in the GOP & 3]:
+    appencoder -bframes 0 -qp 27 codes 27 / 30 / 29 / 30 / 28 ..), the pyramid of the default GOP = Q / Q + 1 for the anchors, + 3 / + 5 / + 6 by B layer, plain B
+    pictures (-bframes 3) Q + 2; the GPU fixtures (tests/stream_cases.py HOST_IPPP_CASCADE, tools/rd_eval.py --host) mirror exactly this"""
+    import re
+    import numpy as np
+    from stream_cases import HOST_IPPP_CASCADE
+    host = os.path.join(ROOT, "ks265codec_amd", "host")
+    exe = str(tmp_path / "ks265enc_stub")
+    subprocess.check_call(["gcc", "-O2", "-std=gnu11", "-Wall", "-Wextra", "-I", os.path.join(ROOT, "include"), "-o", exe, os.path.join(host, "ks265_cli.c"),
+                           os.path.join(host, "ks265_enc.c"), os.path.join(host, "ks265_stream.c"), os.path.join(HERE, "hip_stub.c"),
+                           "-L", os.path.join(ROOT, "oracle"), "-lks265_oracle", "-Wl,-rpath," + os.path.join(ROOT, "oracle"), "-lpthread", "-lm"])
+    W, H, N = 128, 72, 21
+    np.random.default_rng(5).integers(0, 256, N * W * H * 3 // 2, dtype=np.uint8).tofile(tmp_path / "in.yuv")
+
+    def qps(*extra):
+        r = subprocess.run([exe, "-i", str(tmp_path / "in.yuv"), "-wdt", str(W), "-hgt", str(H), "-fr", "50", "-preset", "slow", "-rc", "0", "-qp", "27", "-iper", "12",
+                            "-psnr", "2", "-threads", "3", "-b", str(tmp_path / "o.265"), *extra], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0 and "H265 encoder passed!!!" in r.stdout, r.stdout[-800:] + r.stderr[-800:]
+        got = {int(a): (k, int(q)) for a, k, q in re.findall(r"^(\d+)\t([IPB])\t\d+\t[\d.]+\t[\d.]+\t[\d.]+\t(\d+)$", r.stdout, re.M)}
+        assert sorted(got) == list(range(N))
+        return got
+    ippp = qps("-bframes", "0")
+    for t in range(N):
+        p = t % 12                                                           # position in the GOP (key period 12)
+        assert ippp[t] == (("I", 27) if p == 0 else ("P", 28 + HOST_IPPP_CASCADE[p & 3])), (t, ippp[t])
+    assert [ippp[t][1] for t in range(1, 9)] == [30, 29, 30, 28, 30, 29, 30, 28]
+    hier = qps()                                                             # the default GOP: pyramid of 8 (the GOP of 12 ends with a mini-GOP of 3 = anchor + two plain B pictures)
+    assert [hier[t] for t in range(0, 9)] == [("I", 27), ("B", 33), ("B", 32), ("B", 33), ("B", 30), ("B", 33), ("B", 32), ("B", 33), ("P", 28)], [hier[t] for t in range(9)]
+    assert [hier[t] for t in (9, 10, 11)] == [("B", 29), ("B", 29), ("P", 28)]
+    flat = qps("-bframes", "3")
+    assert [flat[t] for t in range(0, 5)] == [("I", 27), ("B", 29), ("B", 29), ("B", 29), ("P", 28)]
+
+
 def test_gops_dealt_to_several_gpus_behind_one_handle(stub_lib, tmp_path):
     """one handle, N GPUs - KS265_GPUS = N (the CLI's -gpus N) or KS265_DEVICES = list makes every GPU a GOP lane (closed GOPs, no data-path
     collective: SURVEY.md 8e); the stream is byte for byte the one-GPU stream, every listed device gets a context, a device the box does not have fails the open"""

@@ -71,7 +71,7 @@ def encode_ours(clip, W, H, qp, gop, tools, verbose=False, stats=None, pdelta=1,
             seq = [(d, 'B', r0, r0 - G if r0 >= G else r0, 0) if k == 'P' else (d, k, r0, r1, l) for (d, k, r0, r1, l) in seq]
     dpb = {}
     for i, (d, kind, r0, r1, layer) in enumerate(seq):
-        lq = layer_qp[min(len(layer_qp) - 1, layer)] if (layer_qp and kind == 'B') else layer      # B layers are numbered 1 (referenced most) .. 3
+        lq = 1 if layer < 0 else layer_qp[min(len(layer_qp) - 1, layer)] if (layer_qp and kind == 'B') else layer      # B layers are numbered 1 (referenced most) .. 3; -1: a plain B picture outside a pyramid (+ 2)
         q = min(51, qp if kind == "I" else qp + pdelta + lq + (cascade[d % len(cascade)] if cascade and gop == "ippp" else 0))
         ls = lam_scale if lam_scale > 0 else (min(4.0, max(2.0, (q - 12) / 6.0))) ** 0.5      # <= 0: HM's factor for non-key pictures, clip(2, 4, (qp - 12) / 6) on lambda_mode; -1 = --host
         if kind == 'B' and b_lam:
@@ -134,7 +134,7 @@ def mini_gop(lo, hi):
     """coding order of the mini-GOP (lo, hi] as the host codes it: the anchor, then - a power of two apart - the B pictures breadth first (code_hier), else plain
     non-reference B pictures between the two anchors at QP + 2 (the flush of a clip that does not end on the grid); entries of encode_ours' seq"""
     if (hi - lo) & (hi - lo - 1):
-        return [(hi, "P", lo, None, 0)] + [(b, "B", lo, hi, 1) for b in range(lo + 1, hi)]
+        return [(hi, "P", lo, None, 0)] + [(b, "B", lo, hi, -1) for b in range(lo + 1, hi)]
     out, cur, layer = [(hi, "P", lo, None, 0)], [(lo, hi)], 1
     while cur:
         nxt = []
@@ -246,6 +246,10 @@ def main():
     tools = dict(ENCODER_TOOLS)
     if a.host:
         tools.update(decimate=0, intra_inter=1, rdo=4, propagate=1); a.lam_scale = -1.0
+        if a.gop == "ippp" and not a.cascade:
+            a.cascade = "0,2,1,2"                                   # ks265_enc.c kIpppCascade
+        if a.gop == "hier" and not a.layer_qp:
+            a.layer_qp = "0,2,4,5"                                  # ks265_enc.c kHierLayerQp
     for kv in filter(None, a.tools.split(",")):
         k, v = kv.split("=")
         tools[k] = int(v)
