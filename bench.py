@@ -701,7 +701,7 @@ def encoded_line(args, enc, world, hot, cpu):
         "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": f"{W}x{H} 4:2:0 8-bit synthetic clip, ENCODED end to end through the SDK-compatible C API (QY265EncoderEncodeFrame): host I420 in -> pinned copy -> H2D -> "
                                f"pixel path on the MI355X (-preset {enc['preset']}: -me {args.me}, subme 1, deblock + SAO) -> D2H of CU map / levels / SAO -> CABAC slice data on "
-                               f"{enc['host_threads']} host threads -> Annex-B NAL units out; -rc 0 -qp {args.qp} (I=Q, P=Q+1, B=Q+2..) -iper {args.iper}, {enc['gop']}, "
+                               f"{enc['host_threads']} host threads -> Annex-B NAL units out; -rc 0 -qp {args.qp} (I = Q; IPPP: P = Q + 1 + the reference's cascade 2 / 1 / 2 / 0 over four pictures; pyramid: anchors Q + 1, B layers + 2 / + 4 / + 4 as in the reference) -iper {args.iper}, {enc['gop']}, "
                                f"-ref {max(1, args.refs)}; the stream decodes with the reference's appdecoder to the encoder's reconstruction (tests/test_stream.py)",
                    "timed": None if strong else (("the asynchronous encoder with %d GOP lanes (closed GOPs coded concurrently on the one GPU, output in stream order).  A lane buffers a whole GOP "
                              "of input and goes on coding while the caller sits in a synchronize, so each window is a closed piece of work: flush + barrier + device synchronize on both sides; "

@@ -724,9 +724,10 @@ static int code_hier(Enc *e, int d, int a)
             Input *in = input_at(e, mid);
             const int is_ref = (mid - cur[i].lo >= 2) || (cur[i].hi - mid >= 2);
             const int l0 = cur[i].lo - e->gop_start, l1 = cur[i].hi - e->gop_start;
-            /* B pictures of the pyramid: + 3 / + 5 / + 6 on the key picture's QP by layer (the reference: + 2 / + 4 / + 4; + 2 / + 3 / + 4 until the end of round 3): their quality comes from their
-             * references - measured with the CPU mirror of this host on the 128-picture 1080p clip: 1.51 x -> 1.44 x the reference's bitrate at its PSNR-Y, every B picture within 0.1 dB of the anchors */
-            static const int kHierLayerQp[4] = {0, 2, 4, 5};
+            /* B pictures of the pyramid: + 2 / + 4 / + 4 on the key picture's QP by layer - the reference's own ladder (appencoder -qp 27 -psnr 2: anchors 28, B pictures 29 / 31 / 31; ours was
+             * + 2 / + 3 / + 4 until the end of round 3).  Larger offsets keep paying (+ 3 / + 5 / + 6: 1.51 x -> 1.44 x the reference's bitrate at its PSNR-Y on the 1080p clip, every B picture within 0.1 dB
+             * of the anchors - their quality comes from their references), but -qp would no longer mean what it means in the reference */
+            static const int kHierLayerQp[4] = {0, 1, 3, 3};
             int r = submit(e, in, 'B', mid - e->gop_start, clampqp(e, in->base_qp + e->rc_qp_delta + (e->fixqp ? 0 : 1 + kHierLayerQp[layer < 3 ? layer : 3])), &l0, 1, &l1, 1, coded, ncoded, is_ref, 0);
             if (r) return r;
             if (is_ref) coded[ncoded++] = mid - e->gop_start;

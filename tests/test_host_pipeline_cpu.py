@@ -211,7 +211,7 @@ def test_cli_prints_the_reference_per_picture_and_md5_lines(stub_lib, tmp_path):
 
 def test_qp_ladders_of_the_host(stub_lib, tmp_path):
     """the QP every picture is coded with (-psnr 2 prints it): IPPP = the reference's cascade (key picture Q, P pictures Q + 1 + {0, 2, 1, 2}[position in the GOP & 3]:
-    appencoder -bframes 0 -qp 27 codes 27 / 30 / 29 / 30 / 28 ..), the pyramid of the default GOP = Q / Q + 1 for the anchors, + 3 / + 5 / + 6 by B layer, plain B
+    appencoder -bframes 0 -qp 27 codes 27 / 30 / 29 / 30 / 28 ..), the pyramid of the default GOP = Q / Q + 1 for the anchors, + 2 / + 4 / + 4 by B layer (the reference's 29 / 31 / 31), plain B
     pictures (-bframes 3) Q + 2; the GPU fixtures (tests/stream_cases.py HOST_IPPP_CASCADE, tools/rd_eval.py --host) mirror exactly this"""
     import re
     import numpy as np
@@ -237,7 +237,7 @@ def test_qp_ladders_of_the_host(stub_lib, tmp_path):
         assert ippp[t] == (("I", 27) if p == 0 else ("P", 28 + HOST_IPPP_CASCADE[p & 3])), (t, ippp[t])
     assert [ippp[t][1] for t in range(1, 9)] == [30, 29, 30, 28, 30, 29, 30, 28]
     hier = qps()                                                             # the default GOP: pyramid of 8 (the GOP of 12 ends with a mini-GOP of 3 = anchor + two plain B pictures)
-    assert [hier[t] for t in range(0, 9)] == [("I", 27), ("B", 33), ("B", 32), ("B", 33), ("B", 30), ("B", 33), ("B", 32), ("B", 33), ("P", 28)], [hier[t] for t in range(9)]
+    assert [hier[t] for t in range(0, 9)] == [("I", 27), ("B", 31), ("B", 31), ("B", 31), ("B", 29), ("B", 31), ("B", 31), ("B", 31), ("P", 28)], [hier[t] for t in range(9)]
     assert [hier[t] for t in (9, 10, 11)] == [("B", 29), ("B", 29), ("P", 28)]
     flat = qps("-bframes", "3")
     assert [flat[t] for t in range(0, 5)] == [("I", 27), ("B", 29), ("B", 29), ("B", 29), ("P", 28)]

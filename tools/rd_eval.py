@@ -249,7 +249,7 @@ def main():
         if a.gop == "ippp" and not a.cascade:
             a.cascade = "0,2,1,2"                                   # ks265_enc.c kIpppCascade
         if a.gop == "hier" and not a.layer_qp:
-            a.layer_qp = "0,2,4,5"                                  # ks265_enc.c kHierLayerQp
+            a.layer_qp = "0,1,3,3"                                  # ks265_enc.c kHierLayerQp
     for kv in filter(None, a.tools.split(",")):
         k, v = kv.split("=")
         tools[k] = int(v)
