@@ -636,7 +636,7 @@ static int submit(Enc *e, Input *in, int kind, int poc, int qp, const int *l0, i
         e->dpb_poc[slot] = poc;
     } else {
     if (!r) {
-        if (kind == 'I') r = ks265_encode_picture(fr, srcp, out, 1, out);
+        if (kind == 'I') { r = ks265_encode_picture(fr, srcp, out, 1, out); if (!r && fr == e->frame) r = ks265_frame_p_restore(fr, 0); }   /* (see on_key below) */
         else if (kind == 'B') r = ks265_encode_picture_b(fr, srcp, e->dpb[dpb_find(e, l0[0])], e->dpb[dpb_find(e, l1[0])], out);
         else if (nl0 > 1) { ks265_pic refs[4]; for (int i = 0; i < nl0; ++i) refs[i] = e->dpb[dpb_find(e, l0[i])]; r = ks265_encode_picture_mref(fr, srcp, refs, nl0, out); }
         else r = ks265_encode_picture(fr, srcp, e->dpb[dpb_find(e, l0[0])], 0, out);
@@ -656,7 +656,8 @@ static int submit(Enc *e, Input *in, int kind, int poc, int qp, const int *l0, i
     if (on_key) {                                                      /* everything coded after it on the main stream waits for the key picture; its temporal predictors start over */
         if (!r) r = ks265_event_record(cx, e->ev_key);
         if (!r) r = ks265_stream_wait_event(e->ctx, e->ev_key);
-        if (!r) r = ks265_frame_reset_prediction(e->frame);
+        if (!r) r = ks265_frame_p_restore(e->frame, 0);                 /* temporal predictors start over, and so does the ping-pong of the PU record buffers: the graph keys of a GOP's
+                                                                         * pictures (which hold that state) are the same in every GOP - nothing is captured after the first one */
         ++e->nkeys;
     }
     /* copy-out stream */
