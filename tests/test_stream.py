@@ -102,3 +102,21 @@ def test_reference_lists_in_any_order_decode():
             assert (dec[d] == recs[d]).all(), f"decoded picture {d} differs in {int((dec[d] != recs[d]).sum())} samples"
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def test_host_mirror_writes_the_encoder_fixture():
+    """tools/rd_eval.py --host (the encoder host mirrored on the oracle pipeline + writer: its tools, lambda table, QP ladder) writes, for the clip of stream case
+    enc_ippp_416x240_umh, the decoder-verified fixture byte for byte - the stream `ks265enc` writes on the GPU (tests/test_gpu_enc_api.py, profiles/r03_pytest_gpu.txt):
+    what the mirror computes on the CPU is what the product does"""
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import rd_eval as R
+    from ks265codec_amd.synth import make_clip
+    from stream_cases import HOST_IPPP_CASCADE
+    name = "enc_ippp_416x240_umh"
+    clip = make_clip(416, 240, 4, seed=len(name) * 7 + 416, abc=(17, 23, 9))
+    tools = dict(R.ENCODER_TOOLS, decimate=0, intra_inter=1, rdo=4, propagate=1)
+    bs, _, per = R.encode_ours(clip, 416, 240, 27, "ippp", tools, cascade=list(HOST_IPPP_CASCADE), lam_scale=-1.0)
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "stream_md5.json")))[name]
+    assert len(bs) == g["stream_bytes"] and hashlib.md5(bs).hexdigest() == g["stream_md5"]
