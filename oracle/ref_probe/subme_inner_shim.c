@@ -1,0 +1,127 @@
+/* TEST INFRASTRUCTURE - builder container only (needs the reference binary; never runs on the GPU box).
+ *
+ * subme_inner_shim.c = subme_trace_shim.c + hooks on the two INNER steps of subMeSquare (what each step started from, the eight candidate rates it was handed, what it
+ * left): subMeHpel_RealInterp enc@0x4b4e90 (inline hook) and the four entries of the table g_SubMeQpel_8Sad_RealInterpFunc enc@0x6ff6a0 (pointer swap).  The records of
+ * one call are consistent, but the ENCODER'S STREAM CHANGES under the half-sample hook (13 575 -> 13 583 bytes on the test clip; the table swap alone leaves it alone, a
+ * bare trampoline too): that function reads stack it never wrote, any code that runs below it leaves other bytes there.  subme_inner_probe.py reads the dump:
+ *   - quarter step: the eight candidates lie in raster order (-1,-1) .. (1,1) around the half-sample step's winner (all 1 313 calls: the rates it is handed are those of
+ *     these positions), cost = SAD of the normatively interpolated samples + rate, strict '<' against the running best;
+ *   - the table entry = the kind of centre: 0 = the integer position kept (1 126 calls), 1 / 2 / 3 = a horizontal / vertical / diagonal half-sample winner (67 / 66 / 54);
+ *     entry 0: the best cost after the step is reproduced in EVERY call; entries 1 - 3 (187 calls): 154 reproduced; in the other 33 the reference's cost of some candidates is not that of the normative
+ *     samples (it passes over candidates that are cheaper by them) - these variants are not pinned;
+ *   - the cost subMeSquare finally stores differs from SAD + rate by whole multiples of lambda in a third of ALL calls (integer results included): a rate term outside
+ *     the refinement, not part of the measure.
+ * Together: the reference's -subme 1 refinement is SAD-based throughout (ours: Hadamard, a documented deviation), 97.5 % of its quarter steps restated exactly.
+ *
+ * Records what the reference encoder's sub-pel refinement does on real encodes: h265_codec::subMeSquare(TCtuInfo*, TPredUnit*, tME*) enc@0x4b5660, the function
+ * -subme 1 resolves to (it calls subMeHpel_RealInterp enc@0x4b4e90, then subMeQpel_RealInterp enc@0x4b5640).  Same technique as me_trace_shim.c (inline hook on the
+ * non-PIE ELF); the trampoline returns with `jmp [rip + 0]` because rax is LIVE after this function's displaced prologue (mov rax, rdi).
+ *   KS265_SP_LOG=path    one text line per call: block, start vector (quarter samples) and cost (tME+0x90), flags, predictor, result
+ *   KS265_SP_DUMP=path   binary records for the square PUs: header, source block, the reference region (W + 16) x (H + 16) around the start position, the mv cost
+ *                        table slices (tME+0x18 / +0x20, 17 entries around the start vector)
+ * subme_replay.py reads the dump.  What it showed (round 3, 416x240, -preset slow -me 2 -qp 27, 1 392 calls, 258 of them move the vector): the start cost is the
+ * integer search's SAD + rate; the half-sample step picks the minimum of SAD + cost_x[mvx] + cost_y[mvy] over hpel_x / hpel_y (table order, strict '<' against the
+ * start cost) - NOT the Hadamard cost this pipeline uses; under "SAD + rate, both steps" 1 222 of 1 313 calls reproduce the reference's vector, the
+ * rest differ in the quarter-sample step (still open: subMeQpel_RealInterp's candidates / measure).  Nothing of the reference is stored: inputs and outputs only. */
+#define _GNU_SOURCE
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/mman.h>
+#include <unistd.h>
+typedef void (*fn3)(uint8_t *ctu, uint8_t *pu, uint8_t *me);
+typedef void (*fn_h)(uint8_t *ctu, uint8_t *pu, uint32_t *mvc, uint32_t *best, int32_t *idx);
+typedef void (*fn_q)(uint8_t *pu, uint8_t *me, uint8_t *cache, uint32_t *mvc, uint32_t *best, int32_t *idx);
+static fn_h g_orig_h; static fn_q g_orig_q[16];
+/* what the two inner steps did inside the current subMeSquare call: [0] called, [1] start cost, [2..9] the eight candidate rates, [10] best cost after, [11] best index (-1 = none) */
+static int32_t g_h[12], g_q[12];
+/* the two inner functions are called DIRECTLY by subMeSquare (same translation unit: the compiler may know which caller-saved registers they leave alone), so the
+ * hooks preserve every register themselves and call nothing but the original */
+__attribute__((no_caller_saved_registers)) static void hook_h(uint8_t *ctu, uint8_t *pu, uint32_t *mvc, uint32_t *best, int32_t *idx)
+{
+    g_h[0] = 1; g_h[1] = (int32_t)*best; for (int i = 0; i < 8; ++i) g_h[2 + i] = (int32_t)mvc[i];
+    g_orig_h(ctu, pu, mvc, best, idx);
+    g_h[10] = (int32_t)*best; g_h[11] = *idx;
+}
+__attribute__((no_caller_saved_registers)) static void wrap_q(int k, uint8_t *pu, uint8_t *me, uint8_t *cache, uint32_t *mvc, uint32_t *best, int32_t *idx)
+{
+    g_q[0] = 1 + k; g_q[1] = (int32_t)*best; for (int i = 0; i < 8; ++i) g_q[2 + i] = (int32_t)mvc[i];
+    g_orig_q[k](pu, me, cache, mvc, best, idx);
+    g_q[10] = (int32_t)*best; g_q[11] = *idx;
+}
+#define WQ(k) __attribute__((no_caller_saved_registers)) static void wq##k(uint8_t *a, uint8_t *b, uint8_t *c, uint32_t *d, uint32_t *e, int32_t *f) { wrap_q(k, a, b, c, d, e, f); }
+WQ(0) WQ(1) WQ(2) WQ(3) WQ(4) WQ(5) WQ(6) WQ(7)
+static const fn_q kWq[8] = {wq0, wq1, wq2, wq3, wq4, wq5, wq6, wq7};
+static fn3 g_orig; static FILE *g_log, *g_dump; static unsigned long g_call;
+#define RD(T, base, off) (*(T *)((base) + (off)))
+static void hook(uint8_t *ctu, uint8_t *pu, uint8_t *me)
+{
+    const unsigned long idx = g_call++;
+    const int l2w = RD(int8_t, pu, 5), l2h = RD(int8_t, pu, 6), W = 1 << l2w, H = 1 << l2h;
+    const int pux = RD(int32_t, pu, 0xf8), puy = RD(int32_t, pu, 0xfc);
+    uint8_t *plane = RD(uint8_t *, me, 0x8);
+    const uint8_t *fenc = RD(uint8_t *, me, 0x30);
+    const int fstride = RD(int32_t, me, 0x38), stride = RD(int32_t, me, 0x50);
+    const int mx = RD(int16_t, me, 0x54), my = RD(int16_t, me, 0x56), ref = RD(int32_t, me, 0x58);
+    const uint32_t cost0 = RD(uint32_t, me, 0x90);
+    const int f64 = RD(uint8_t, me, 0x64), f65 = RD(uint8_t, me, 0x65), f3bc = RD(int32_t, me, 0x3bc);
+    const uint32_t mvp = RD(uint32_t, pu, 0x1a0 + 4 * ref);
+    const long cur_off = RD(uint8_t *, me, 0x40) - plane;
+    const uint16_t *t10 = RD(uint16_t *, me, 0x10);
+    uint8_t fe[64 * 64];
+    for (int y = 0; y < H; ++y) memcpy(fe + y * W, fenc + (long)y * fstride, W);
+    /* reference region around the block at the integer position: 8 margin */
+    const int ix = mx >> 2, iy = my >> 2;
+    memset(g_h, 0, sizeof g_h); memset(g_q, 0, sizeof g_q);
+    g_orig(ctu, pu, me);
+    const int ox = RD(int16_t, me, 0x54), oy = RD(int16_t, me, 0x56);
+    const uint32_t ocost = RD(uint32_t, me, 0x90);
+    if (g_log) fprintf(g_log, "%lu w%d h%d pu %d %d st %d mv %d %d ref %d cost %u f64 %d f65 %d f3bc %d mvp %d %d cur %ld t10[0..4] %u %u %u %u %u -> %d %d cost %u\n", idx, W, H, pux, puy, stride, mx, my, ref, cost0, f64, f65, f3bc,
+                       (int16_t)(mvp & 0xFFFF), (int16_t)(mvp >> 16), cur_off, t10 ? t10[0] : 0, t10 ? t10[1] : 0, t10 ? t10[2] : 0, t10 ? t10[3] : 0, t10 ? t10[4] : 0, ox, oy, ocost);
+    if (g_dump && f64 == 0 && f65 == 0 && W == H) {
+        /* record: header, fenc, region (W+16) x (H+16) of the plane around the integer position of the START vector, table slice -264..264 */
+        const uint8_t *cur = RD(uint8_t *, me, 0x40);                 /* assumed: block at the start position? logged offset tells */
+        int32_t hdr[16] = {0x53554250, (int32_t)idx, W, H, pux, puy, stride, mx, my, (int32_t)cost0, (int16_t)(mvp & 0xFFFF), (int16_t)(mvp >> 16), ox, oy, (int32_t)ocost, f3bc};
+        fwrite(hdr, 4, 16, g_dump);
+        fwrite(fe, 1, (size_t)W * H, g_dump);
+        const uint8_t *org = plane + (long)(puy + iy - 8) * stride + pux + ix - 8;
+        for (int y = 0; y < H + 16; ++y) fwrite(org + (long)y * stride, 1, (size_t)W + 16, g_dump);
+        { const uint16_t *cmx = RD(uint16_t *, me, 0x18), *cmy = RD(uint16_t *, me, 0x20);
+          for (int d = -8; d <= 8; ++d) fwrite(&cmx[mx + d], 2, 1, g_dump);
+          for (int d = -8; d <= 8; ++d) fwrite(&cmy[my + d], 2, 1, g_dump); }
+        fwrite(g_h, 4, 12, g_dump); fwrite(g_q, 4, 12, g_dump);
+    }
+}
+static void put_jump(uint8_t *at, const void *target) { at[0] = 0x48; at[1] = 0xb8; memcpy(at + 2, &target, 8); at[10] = 0xff; at[11] = 0xe0; }
+static void finish(void) { if (g_log) fclose(g_log); if (g_dump) fclose(g_dump); }
+__attribute__((constructor)) static void ctor(void)
+{
+    const char *lp = getenv("KS265_SP_LOG"), *dp = getenv("KS265_SP_DUMP");
+    if (!lp && !dp) return;
+    if (lp) g_log = fopen(lp, "w");
+    if (dp) g_dump = fopen(dp, "wb");
+    uint8_t *tramp = mmap(NULL, 4096, PROT_READ | PROT_WRITE | PROT_EXEC, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    uint8_t *fn = (uint8_t *)0x4b5660;
+    memcpy(tramp, fn, 13);
+    { uint8_t *t = tramp + 13; const void *back = fn + 13; t[0] = 0xff; t[1] = 0x25; t[2] = t[3] = t[4] = t[5] = 0; memcpy(t + 6, &back, 8); }   /* jmp [rip+0]: no register touched (rax is live here) */
+    g_orig = (fn3)(void *)tramp;
+    const long page = sysconf(_SC_PAGESIZE);
+    uint8_t *pg = (uint8_t *)((uintptr_t)fn & ~(uintptr_t)(page - 1));
+    if (mprotect(pg, 2 * page, PROT_READ | PROT_WRITE | PROT_EXEC)) _exit(5);
+    put_jump(fn, (const void *)hook); fn[12] = 0x90;
+    {   /* subMeHpel_RealInterp enc@0x4b4e90: 12 bytes of pushes / register moves displaced */
+        uint8_t *fh = (uint8_t *)0x4b4e90, *th = tramp + 128;
+        memcpy(th, fh, 12);
+        { uint8_t *t = th + 12; const void *back = fh + 12; t[0] = 0xff; t[1] = 0x25; t[2] = t[3] = t[4] = t[5] = 0; memcpy(t + 6, &back, 8); }
+        g_orig_h = (fn_h)(void *)th;
+        uint8_t *pgh = (uint8_t *)((uintptr_t)fh & ~(uintptr_t)(page - 1));
+        if (mprotect(pgh, 2 * page, PROT_READ | PROT_WRITE | PROT_EXEC)) _exit(6);
+        put_jump(fh, (const void *)hook_h);
+    }
+    {   /* subMeQpel_RealInterp enc@0x4b5640 is a thunk through the table g_SubMeQpel_8Sad_RealInterpFunc enc@0x6ff6a0: wrap the table's entries */
+        fn_q *tab = (fn_q *)0x6ff6a0;
+        for (int k = 0; k < 8; ++k) if (tab[k]) { g_orig_q[k] = tab[k]; tab[k] = kWq[k]; }
+    }
+    atexit(finish);
+}
