@@ -9,6 +9,8 @@
  *   - the table entry = the kind of centre: 0 = the integer position kept (1 126 calls), 1 / 2 / 3 = a horizontal / vertical / diagonal half-sample winner (67 / 66 / 54);
  *     entry 0: the best cost after the step is reproduced in EVERY call; entries 1 - 3 (187 calls): 154 reproduced; in the other 33 the reference's cost of some candidates is not that of the normative
  *     samples (it passes over candidates that are cheaper by them) - these variants are not pinned;
+ *     every candidate index 0 .. 7 is among the passed-over ones, in all three variants (probe4: no pattern): together with the stack reads above this looks like SAD slots that are
+ *     not computed in those calls and hold what an earlier call left there - behaviour that cannot be restated, only observed;
  *   - the cost subMeSquare finally stores differs from SAD + rate by whole multiples of lambda in a third of ALL calls (integer results included): a rate term outside
  *     the refinement, not part of the measure.
  * Together: the reference's -subme 1 refinement is SAD-based throughout (ours: Hadamard, a documented deviation), 97.5 % of its quarter steps restated exactly.
