@@ -39,6 +39,17 @@ ALGO_BYTES_P = {
 }
 
 
+def hot_tools(args, me_method):
+    """the hot-path leg's tool set = the encoder host's at -preset slow (ks265codec_amd.synth.ENCODER_TOOLS: the one dict the GPU tests, smoke() and
+    tools/rd_eval.py --host use too) with this run's command-line overrides"""
+    from ks265codec_amd.synth import ENCODER_TOOLS, subme_knobs
+    t = dict(ENCODER_TOOLS)
+    t.update(me_method=me_method, me_hex_thr=(args.me_hex_thr if me_method == 2 else 0), pre_search=0 if args.no_pre_search else 1, propagate=args.propagate)
+    if args.subme_preset:
+        t.update(subme_knobs(args.subme_preset))
+    return t
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -59,6 +70,7 @@ def main():
                     "B pictures dealt to the other ranks (needs --bframes > 0); default = one GOP shard per rank, no collective")
     ap.add_argument("--streams", type=int, default=3, help="independent GOP shards in flight per GPU, each on its own HIP stream (their kernels overlap: the search kernels are latency bound)")
     ap.add_argument("--refs", type=int, default=1, help="list-0 reference pictures a P picture searches (-ref / -ref0; -preset slow resolves to 1 / 3: three for the first picture of a mini-GOP); IPPP only")
+    ap.add_argument("--subme-preset", default="", help="hot-path leg: the sub-pel refinement's knobs of another preset (ultrafast .. placebo; default: slow's)")
     ap.add_argument("--propagate", type=int, default=1, help="hot-path leg: rounds of vector propagation between neighbouring PUs after every integer search (stage A2; the encoder runs 1)")
     ap.add_argument("--no-pre-search", action="store_true", help="hot-path leg: stage A without the pyramid pre-search start candidates (the encoder always runs them)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -143,7 +155,7 @@ def main():
         tstream = None if sidx == 0 else torch.cuda.Stream(device=dev_index)
         with (torch.cuda.stream(tstream) if tstream is not None else contextlib.nullcontext()):
             ks = KsContext(dev_index)
-            fr = KsFrame(ks, W, H, qp, lambda_q4(qp), me_method=me_method, me_hex_thr=(args.me_hex_thr if me_method == 2 else 0), bframes=max(args.bframes, args.hier_b - 1 if args.hier_b else 0), refs=max(1, args.refs), sdh=1, pre_search=0 if args.no_pre_search else 1, merge=1, bi_refine=1, rdo=4, intra_inter=1, propagate=args.propagate)
+            fr = KsFrame(ks, W, H, qp, lambda_q4(qp), bframes=max(args.bframes, args.hier_b - 1 if args.hier_b else 0), refs=max(1, args.refs), **hot_tools(args, me_method))
             # synthetic clip of SURVEY.md §8(d), one GOP shard per stream (different seed per shard = different content)
             clip = make_clip(W, H, args.clip_frames, seed=7 + (0 if args.b_spread else rank * nstreams + sidx), abc=(67, 91, 33), pan=(8, 5))
             dev_clip = [ks.dev(c) for c in clip]
@@ -380,7 +392,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{W}x{H} 4:2:0 8-bit, hot path only (ME + transform/quant/recon + deblock + SAO; CABAC/RC not included), "
-                                   f"-rc 0 -qp {qp} (I=Q, P=Q+1, B=Q+2) -iper {args.iper}, -bframes {bf_desc}, -ref {max(1, args.refs)} -ref0 {max(1, args.refs)} ({'one reference picture per list' if args.refs <= 1 else 'every P picture searches that many list-0 pictures'}), -me {me_method} ({args.me.upper()}{', interMeHex below ' + str(args.me_hex_thr) + ' SAD/sample as at -preset slow' if me_method == 2 and args.me_hex_thr else ''}) range 64, subme=8 hpel + 8 qpel SATD, sao on, df on",
+                                   f"-rc 0 -qp {qp} (I=Q, P=Q+1, B=Q+2) -iper {args.iper}, -bframes {bf_desc}, -ref {max(1, args.refs)} -ref0 {max(1, args.refs)} ({'one reference picture per list' if args.refs <= 1 else 'every P picture searches that many list-0 pictures'}), -me {me_method} ({args.me.upper()}{', interMeHex below ' + str(args.me_hex_thr) + ' SAD/sample as at -preset slow' if me_method == 2 and args.me_hex_thr else ''}) range 64, -subme 1 as the reference runs it at -preset slow (fast candidate sets judged by SAD + rate; DESIGN.md 5e), sao on, df on",
                        "pictures_per_step": nstreams, "streams_per_gpu": nstreams,
                        "key_picture_ms": {"intra_decide": key_ms.get("intra_candidates"), "intra_reconstruct": key_ms.get("intra_pass"), "total": round(sum(key_ms.values()), 3),
                                           "note": f"one intra picture per -iper {args.iper} pictures; it is in the timed region whenever the schedule puts one there"},
@@ -410,7 +422,7 @@ def port_leg(args, clip, order, me_method):
     from oracle_lib import OraclePipeline
     from ks265codec_amd.synth import lambda_q4
     W, H, qp = args.width, args.height, args.qp
-    o = OraclePipeline(W, H, qp, lambda_q4(qp), me_method=me_method, me_hex_thr=(args.me_hex_thr if me_method == 2 else 0), sdh=1, pre_search=0 if args.no_pre_search else 1, merge=1, bi_refine=1, rdo=4, intra_inter=1, propagate=args.propagate)
+    o = OraclePipeline(W, H, qp, lambda_q4(qp), **hot_tools(args, me_method))
     nbase = 3
     tc0 = time.perf_counter()
     if args.bframes == 0:

@@ -217,7 +217,10 @@ typedef struct {
     int32_t lambda_q4;         /* motion lambda in Q4 fixed point (host-side float setup only)     */
     int32_t me_range;          /* integer search range in pels, <= 64 (all presets use 64)         */
     int32_t me_method;         /* -me: 0 = DIA (interMeDia enc@0x48fbe0), 1 = HEX (interMeHex enc@0x48fde0), 2 = UMH (interMeUMH enc@0x4907b0) */
-    int32_t subme;             /* 0 = integer only, 1 = 8 half-pel + 8 quarter-pel SATD points      */
+    int32_t subme;             /* -subme (qy265enc.h:137): 0 = integer only; 1 = "fast", 2 = "square full": the reference's refinement per PU - getMvResolution
+                                  enc@0x483ca0, subMeSquare enc@0x4b5660 (eight half-sample candidates, order 3 4 1 6 0 2 5 7; eight quarter-sample candidates, order
+                                  1 6 3 0 5 4 2 7; strict '<' against the integer cost; fast = only candidates within +-2 quarter samples of the integer position and
+                                  diagonals next to the running winner) - restated in oracle/ks265_subme_ref.c, pinned on recorded calls (tests/test_subme.py) */
     int32_t deblock;           /* -df                                                               */
     int32_t sao;               /* -sao: 0 off, >0 BO + EO0..3                                        */
     int32_t beta_offset_div2, tc_offset_div2;
@@ -247,6 +250,13 @@ typedef struct {
                                   the CU decision, intra CUs are reconstructed after the inter CUs from reconstructed neighbours (CTU wavefront) */
     int32_t propagate;         /* n > 0: n rounds of ks265_me_propagate between the integer search and the sub-pel step of every search of ks265_encode_picture[_b|_mref]
                                   (meInitPoint enc@0x48af50 starts from the coded neighbours' vectors; a frame-parallel search gets them this way).  0..4; the encoder host uses 1 */
+    /* the sub-pel refinement's knobs = what the reference's presets put into its configuration (read inside real encodes, oracle/ref_probe/subme_shim.c) */
+    int32_t sub_satd;          /* tME+0x64 / TPredUnit+0x40: 0 = candidates judged by SAD (every preset up to slower), 1 = by Hadamard, start cost recomputed (veryslow, placebo) */
+    int32_t sub_thr;           /* cfg+0x464 = tME+0x3c0: > 0 = a PU is refined only if the steepest of the four integer neighbours exceeds the winner's SAD by W H thr / 32, and a
+                                  flat half step skips the quarter step; 80 / 76 / 68 / 56 / 40 / 24 / 24 / 0 / 0 from ultrafast to placebo */
+    int32_t sub_flat;          /* tME+0x3c4: flat = max SAD of the half step - the winner's SAD <= W H flat / 8; 40 / 36 / 16 / 14 / 10 / 8 / 8 / 8 / 8 */
+    int32_t sub_cap, sub_cap_step;   /* cfg+0x498 / +0x49c: > 0 = no refinement above an integer cost of (cap + (6 - log2 H) step) W^2; 6,6 / 6,6 / 12,6 / 0.. */
+    int32_t sub_diag_fast;     /* cfg+0x580: half step skips the diagonals unless a horizontal / vertical candidate won (ultrafast, superfast) */
 } ks265_frame_cfg;
 
 /* geometry of the padded picture buffers the caller allocates (one call, no allocation) */

@@ -36,14 +36,19 @@ __device__ __forceinline__ unsigned pu_group_sum(unsigned v, int level)
     return v;
 }
 
-// Stage B: sub-pel refinement of all 85 PUs of a CTU (subMeSquare enc@0x4b5660 lineage: centre + 8 half-pel, then 8 quarter-pel
-// candidates around the half-pel winner, SATD + mv rate).
+// Stage B: sub-pel refinement of all 85 PUs of a CTU = the reference's, per PU (round 4; restated in oracle/ks265_subme_ref.c and pinned on recorded calls of the reference, tests/test_subme.py):
+//   phase R  getMvResolution enc@0x483ca0: the four integer neighbours' SADs of the integer winner decide whether the PU is refined at all (cfg.sub_thr / sub_cap);
+//   phase H  subMeHpel_RealInterp enc@0x4b4e90: eight half-sample candidates, evaluation order 3 4 1 6 0 2 5 7 (raster indices), cost = SAD (or Hadamard, cfg.sub_satd)
+//            of the normative samples + rate, strict '<' against the integer cost; its "flat cost surface" verdict skips the quarter step (cfg.sub_thr != 0);
+//   phase Q  subMeQpel_8Sad_v{0,2}h{0,2}_RealInterp enc@0x4b2bc0-0x4b43a0: eight quarter-sample candidates around the half-step winner, order 1 6 3 0 5 4 2 7;
+//            cfg.subme 1 ("fast") keeps to +-2 quarter samples around the integer position and tries a diagonal only next to the running winner;
+//   phase F  (this pipeline's own) Hadamard of the chosen prediction + rate becomes the record's cost - the CU tree, merge pass and bi decision compare SATD.
 //
 // The four quadtree levels of a CTU look at the same 64 8x8 tiles, and where a PU and its ancestors search around the same
-// centre (most of them: only ~30 % of the 256 (level, tile) pairs of a CTU are distinct on the bench clip) the tile SATDs of
-// the whole ring are identical.  Each phase therefore (1) builds the list of DISTINCT (tile, centre) items of the CTU,
-// (2) evaluates every ring candidate of every item once, items spread over the threads, SATDs into LDS, and (3) lets each
-// (level, tile) pair pick its item's SATDs, sum them over the PU and keep the winner.  Pure memoisation: every value used is
+// centre (most of them: only ~30 % of the 256 (level, tile) pairs of a CTU are distinct on the bench clip) the tile distortions of
+// the whole ring are identical.  Each phase therefore (1) builds the list of DISTINCT (tile, centre) items of the PUs that take part in it,
+// (2) evaluates every candidate of every item once, items spread over the threads, tile distortions into LDS, and (3) lets each
+// (level, tile) pair pick its item's values, sum them over the PU and walk the candidates in the reference's order.  Pure memoisation: every value used is
 // the one the pair would have computed itself, so the result is that of the straightforward evaluation, bit for bit.
 #ifndef KS_SUBPEL_NC
 #define KS_SUBPEL_NC 8                                             // CTUs pooled per work-group (one wave each)
@@ -51,8 +56,9 @@ __device__ __forceinline__ unsigned pu_group_sum(unsigned v, int level)
 #ifndef KS_SUBPEL_OCC
 #define KS_SUBPEL_OCC 2
 #endif
-template <int NC>
-__global__ __launch_bounds__(NC * 64, KS_SUBPEL_OCC) void me_subpel_kernel(KsGeom g, int lam, const uint8_t *src, const uint8_t *ref, ks265_pu *pus)
+struct KsSubme { int subme, satd, thr, flat, cap, cap_step, diag_fast; };
+template <int NC, bool SATD>
+__global__ __launch_bounds__(NC * 64, KS_SUBPEL_OCC) void me_subpel_kernel(KsGeom g, int lam, KsSubme K, const uint8_t *src, const uint8_t *ref, ks265_pu *pus)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nctu = g.ctu_cols * g.ctu_rows;
@@ -66,14 +72,14 @@ __global__ __launch_bounds__(NC * 64, KS_SUBPEL_OCC) void me_subpel_kernel(KsGeo
     __shared__ unsigned short s_idx[NC][4][64];
     __shared__ unsigned short s_item[NC * 256];
     __shared__ int s_cnt[NC * 4];
-    __shared__ unsigned short s_sat[9][NC * 256];                 // an 8x8 SATD is at most 8 * 8 * 8 * 255 / 4 = 32640
+    __shared__ unsigned short s_sat[9][NC * 256];                 // slot = gy * 3 + gx of the ring (4 = centre); an 8x8 SATD is at most 8 * 8 * 8 * 255 / 4 = 32640, a SAD 16320
     __shared__ __attribute__((aligned(16))) unsigned short s_hx[NC][16][8 * 16 + 8];   // per wave and item column: horizontally filtered rows, [pixel][row 0..15]; + 4 dwords: the 16 columns of a
                                                                                       // block start in different banks (68 = 4 mod 32; unpadded, all of them hit the same)
     if (lane == 0) s_org[wave] = have ? ((ctu % g.ctu_cols) * 64) | (((ctu / g.ctu_cols) * 64) << 16) : 0;
     // Z-order: lane bits (y2 x2 y1 x1 y0 x0)
     const int tx = (lane & 1) | ((lane >> 1) & 2) | ((lane >> 2) & 4), ty = ((lane >> 1) & 1) | ((lane >> 2) & 2) | ((lane >> 3) & 4);
-    bool valid[4];
-    int pidx[4], bx[4], by[4], mvpx[4], mvpy[4];
+    bool valid[4], dosub[4], qrun[4];
+    int pidx[4], bx[4], by[4], mvpx[4], mvpy[4], hmx[4], hmy[4];
     unsigned bc[4], bd[4];
 #pragma unroll
     for (int l = 0; l < 4; ++l) {
@@ -81,17 +87,10 @@ __global__ __launch_bounds__(NC * 64, KS_SUBPEL_OCC) void me_subpel_kernel(KsGeo
         pidx[l] = ks_level_base(l) + py * (1 << l) + px;
         const ks265_pu p = cp[pidx[l]];
         valid[l] = have && p.cost != KS_COST_INVALID;              // the whole PU lies inside the picture
-        bx[l] = p.mvx; by[l] = p.mvy; mvpx[l] = p.mvpx; mvpy[l] = p.mvpy; bc[l] = 0; bd[l] = 0;
+        bx[l] = p.mvx; by[l] = p.mvy; mvpx[l] = p.mvpx; mvpy[l] = p.mvpy; bc[l] = p.cost; bd[l] = 0;
+        dosub[l] = true; qrun[l] = true; hmx[l] = 0; hmy[l] = 0;
     }
-    // Candidates: k = 0 is the centre, k = 1..8 the ring in raster order (hpel_x/y, qpel_x/y tables).
-    // Evaluation order is free as long as the winner is the reference's: smallest cost, ties to the smallest k (the reference
-    // walks k upwards with a strict '<').  Half-pel candidates are visited plane by plane (centre; the two on the vertical
-    // plane; the two on the horizontal plane; the four on the diagonal plane) so that consecutive candidates hit the same
-    // cache lines; quarter-pel candidates in ring order.  Tables: 2-bit fields (d + 1), field n = n-th candidate visited.
-    constexpr unsigned kVisit0 = 0x63154720u;                     // nibble n = k of the n-th half-pel candidate visited (n < 8; n == 8 -> 8)
-    constexpr unsigned kDx[2] = {0x22215u, 0x24891u}, kDy[2] = {0x28161u, 0x2a501u};
-
-    // MFMA operands of the Hadamard SATD (see phase (2) below).  A operand = rows mb*16 + n16 of H = H8 (x) H8 in natural
+    // MFMA operands of the Hadamard SATD (see (2) below).  A operand = rows mb*16 + n16 of H = H8 (x) H8 in natural
     // (Sylvester) order: H[m][k] = (-1)^popcount(m & k); this lane's 16 K slots are k = gk*16 .. gk*16 + 15.
     const int n16 = lane & 15, gk = lane >> 4;
     ks_v4i Hm[4];
@@ -121,17 +120,23 @@ __global__ __launch_bounds__(NC * 64, KS_SUBPEL_OCC) void me_subpel_kernel(KsGeo
         const int zyme = ((ty & 1) << 1) | ((ty & 2) << 2) | ((ty & 4) << 3);
         before |= (row0 << zyme) & cols;
     }
-#pragma unroll
-    for (int phase = 0; phase < 2; ++phase) {                     // 0: centre + half-pel ring, 1: quarter-pel ring
-        const int step = phase == 0 ? 2 : 1;
+    // phases: -1 = R (only when the configuration can say no), 0 = H, 1 = Q, 2 = F (not with sub_satd: the winner's Hadamard cost is the running best)
+#pragma unroll 1
+    for (int phase = (K.thr | K.cap) ? -1 : 0; phase < (SATD ? 2 : 3); ++phase) {
+        const int step = phase == 0 ? 2 : phase == 1 ? 1 : 0;
+        const bool single = phase == 2;                            // F: one candidate, the centre itself
+        const bool had = SATD || single;                           // the measure of this phase's candidates
+        const bool skip_centre = phase == 1 || (phase == 0 && !SATD);   // H by SAD starts from the integer search's cost; Q from H's best
         int owner[4];
+        bool act[4];
         __syncthreads();                                           // the previous phase's readers are done (and s_org is written)
         // (1) the distinct (tile, centre) items of the group
         int key[4];
         unsigned long long bal[4];
 #pragma unroll
         for (int l = 0; l < 4; ++l) {
-            key[l] = valid[l] ? ((bx[l] & 0xFFFF) | (by[l] << 16)) : (int)(0x80000000u | (unsigned)l);
+            act[l] = valid[l] && (phase < 0 || single || (dosub[l] && (phase == 0 || qrun[l])));
+            key[l] = act[l] ? ((bx[l] & 0xFFFF) | (by[l] << 16)) : (int)(0x80000000u | (unsigned)l);
             s_key[wave][l][lane] = key[l];
         }
 #pragma unroll
@@ -139,7 +144,7 @@ __global__ __launch_bounds__(NC * 64, KS_SUBPEL_OCC) void me_subpel_kernel(KsGeo
             owner[l] = l;
 #pragma unroll
             for (int m = 3; m >= 0; --m) if (key[m] == key[l]) owner[l] = m;   // the coarsest level with this centre
-            bal[l] = __ballot(valid[l] && owner[l] == l);
+            bal[l] = __ballot(act[l] && owner[l] == l);
             if (lane == 0) s_cnt[wave * 4 + l] = __popcll(bal[l]);
         }
         __syncthreads();
@@ -150,7 +155,7 @@ __global__ __launch_bounds__(NC * 64, KS_SUBPEL_OCC) void me_subpel_kernel(KsGeo
             for (int q = 0; q < NC * 4; ++q) { const int c = s_cnt[q]; off += q < wave * 4 ? c : 0; nitems += c; }
 #pragma unroll
             for (int l = 0; l < 4; ++l) {
-                if (valid[l] && owner[l] == l) {
+                if (act[l] && owner[l] == l) {
                     const int idx = off + __popcll(bal[l] & before);   // raster order within the level
                     s_idx[wave][l][lane] = (unsigned short)idx;
                     s_item[idx] = (unsigned short)(lane | (l << 6) | (wave << 8));
@@ -159,24 +164,24 @@ __global__ __launch_bounds__(NC * 64, KS_SUBPEL_OCC) void me_subpel_kernel(KsGeo
             }
         }
         __syncthreads();
-        // (2) every candidate of every distinct item, once.  A wave takes 64 items at a time and runs their 8x8 Hadamard
-        // transforms on the matrix cores: with x the 64 pixels of a tile, the 2-D Hadamard transform is the 64x64 +-1 matrix
-        // H = H8 (x) H8 applied to x, i.e. an i8 GEMM  C[64 coefficients][64 tiles] = H . X  with exact i32 accumulation:
-        // 16 v_mfma_i32_16x16x64_i8 per operand matrix.  Two MFMAs chained on one accumulator give the transform of the
+        // (2) every candidate of every distinct item, once.  A wave takes 16 items at a time (lane = (item column n16 = lane & 15, K group gk = lane >> 4): the lane's two rows
+        // 2 gk, 2 gk + 1 of the item's 8x8 tile).
+        // Hadamard (sub_satd, and phase F): the 8x8 transforms run on the matrix cores: with x the 64 pixels of a tile, the 2-D Hadamard transform is the 64x64 +-1 matrix
+        // H = H8 (x) H8 applied to x, i.e. an i8 GEMM  C[64 coefficients][16 tiles] = H . X  with exact i32 accumulation (v_mfma_i32_16x16x64_i8).
+        // Two MFMAs chained on one accumulator give the transform of the
         // DIFFERENCE directly: C = bias + H.(ref - 128) + H.(~(src - 128)), and ~(s - 128) = -(s - 128) - 1 whose "-1" lands
         // on coefficient 0 only (+64 folded into that accumulator's start value).  bias = 2^15 keeps every coefficient
         // positive in 16 bits, so |c| + accumulate is one v_sad_u16 against the bias.  sum |c| does not depend on the order
         // of the Hadamard rows, nor on how the K slots of the A and B operands are numbered (both operands use the same
         // numbering), so the sum equals had_c's (enc@0x47b680) butterfly network bit for bit.
-        // Operand layout: lane = (column n16 = lane & 15, K group gk = lane >> 4); its 16 K slots hold rows 2gk, 2gk+1 of the tile.
+        // SAD (the reference's measure up to -preset slower): four v_sad_u8 per candidate and lane.
         // The candidates' samples are interpolated from the reference picture (no fractional planes): ONE instruction stream for every fraction - horizontal taps of the
         // lane's own fx (the integer position is the tap set {0 0 0 64 0 0 0 0}) into 16-bit intermediates, vertical taps of its own fy, (sum + 2048) >> 12 - which
         // equals the one-dimensional filters' (sum + 32) >> 6 and the plain sample exactly (a factor 64 moves through the shift), so lanes whose centres have
         // different fractions do not diverge.  The three x positions of a ring are filtered ONCE per item: the item's four lanes (K groups) filter four rows each of
         // its 16-row neighbourhood, exchange them through LDS (row pairs packed for v_dot2_i32_i16; a wave's own LDS traffic completes in order, no barrier), and
         // every lane then reads the ten rows its two output rows of the three y positions need.
-        // Items are dealt to the waves in blocks of 16 (one MFMA operand block: lane = (item column n16, K group gk)), block b to wave b mod NC: the pooled
-        // items of the group's CTUs spread evenly over the waves.
+        // Items are dealt to the waves in blocks of 16, block b to wave b mod NC: the pooled items of the group's CTUs spread evenly over the waves.
         // The loads are software-pipelined: the 20 dwords a lane filters for x position gx + 1 (or for the first x position of the wave's NEXT block) are requested
         // before the lane turns to the three y positions of gx - at two waves per SIMD nothing else would cover an L2 round trip per x position.
         struct Item { int ii, cx, cy; unsigned ro; ks_v4i S; };
@@ -190,6 +195,30 @@ __global__ __launch_bounds__(NC * 64, KS_SUBPEL_OCC) void me_subpel_kernel(KsGeo
             const uint2 a0 = *(const uint2 *)(Sp + t.ro), a1 = *(const uint2 *)(Sp + t.ro + (unsigned)g.sy);
             t.S = ks_v4i{(int)(a0.x ^ 0x7F7F7F7Fu), (int)(a0.y ^ 0x7F7F7F7Fu), (int)(a1.x ^ 0x7F7F7F7Fu), (int)(a1.y ^ 0x7F7F7F7Fu)};
         };
+        if (phase < 0) {
+            // R: the SADs of the four integer neighbours (above, below, left, right: sad4_c enc@0x47ae90's order) of the integer winner - plain rows, no filter
+#pragma unroll 1
+            for (int blk = wave; blk * 16 < nitems; blk += NC) {
+                Item t;
+                setup(blk, t);
+                const unsigned s0 = (unsigned)t.S[0] ^ 0x7F7F7F7Fu, s1 = (unsigned)t.S[1] ^ 0x7F7F7F7Fu, s2 = (unsigned)t.S[2] ^ 0x7F7F7F7Fu, s3 = (unsigned)t.S[3] ^ 0x7F7F7F7Fu;
+                const uint8_t *rp = ref + (unsigned)((int)t.ro + (int)g.org_y + (t.cy >> 2) * g.sy + (t.cx >> 2));
+                uint2 rm, r0, r1, r2, l0, l1, q0, q1;
+                __builtin_memcpy(&rm, rp - g.sy, 8); __builtin_memcpy(&r0, rp, 8); __builtin_memcpy(&r1, rp + g.sy, 8); __builtin_memcpy(&r2, rp + 2 * g.sy, 8);
+                __builtin_memcpy(&l0, rp - 1, 8); __builtin_memcpy(&l1, rp + g.sy - 1, 8); __builtin_memcpy(&q0, rp + 1, 8); __builtin_memcpy(&q1, rp + g.sy + 1, 8);
+                unsigned a[4];
+                a[0] = __builtin_amdgcn_sad_u8(s0, rm.x, __builtin_amdgcn_sad_u8(s1, rm.y, __builtin_amdgcn_sad_u8(s2, r0.x, __builtin_amdgcn_sad_u8(s3, r0.y, 0u))));
+                a[1] = __builtin_amdgcn_sad_u8(s0, r1.x, __builtin_amdgcn_sad_u8(s1, r1.y, __builtin_amdgcn_sad_u8(s2, r2.x, __builtin_amdgcn_sad_u8(s3, r2.y, 0u))));
+                a[2] = __builtin_amdgcn_sad_u8(s0, l0.x, __builtin_amdgcn_sad_u8(s1, l0.y, __builtin_amdgcn_sad_u8(s2, l1.x, __builtin_amdgcn_sad_u8(s3, l1.y, 0u))));
+                a[3] = __builtin_amdgcn_sad_u8(s0, q0.x, __builtin_amdgcn_sad_u8(s1, q0.y, __builtin_amdgcn_sad_u8(s2, q1.x, __builtin_amdgcn_sad_u8(s3, q1.y, 0u))));
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    a[k] += (unsigned)__builtin_amdgcn_ds_swizzle((int)a[k], 0x1F | (16 << 10));
+                    a[k] += (unsigned)__shfl_xor((int)a[k], 32, 64);
+                    if (gk == 0 && t.ii < nitems) s_sat[k][t.ii] = (unsigned short)a[k];
+                }
+            }
+        } else {
         unsigned raw[4][5], rsh = 0;
         // rows 4 gk .. 4 gk + 3 of the item's 16-row neighbourhood at x position gx: picture row = tile row (2 gk) + rbase + 2 gk + j
         auto request = [&](const Item &t, int gx) {
@@ -199,10 +228,11 @@ __global__ __launch_bounds__(NC * 64, KS_SUBPEL_OCC) void me_subpel_kernel(KsGeo
 #pragma unroll
             for (int j = 0; j < 4; ++j) luma_hrow8_load(hp + j * g.sy, raw[j]);
         };
+        const int gx_first = single ? 1 : 0;
         Item cur;
         int blk = wave;
         bool more = blk * 16 < nitems;
-        if (more) { setup(blk, cur); request(cur, 0); }
+        if (more) { setup(blk, cur); request(cur, gx_first); }
 #pragma unroll 1
         while (more) {
             const int nblk = blk + NC;
@@ -234,6 +264,7 @@ __global__ __launch_bounds__(NC * 64, KS_SUBPEL_OCC) void me_subpel_kernel(KsGeo
                 }
 #pragma unroll
                 for (int gx = 0; gx < 3; ++gx) {
+                    if (single && gx != 1) continue;
                     const int ax = cx + (gx - 1) * step;
                     int tl, th;
                     luma_taps_packed(ax & 3, tl, th);
@@ -245,8 +276,8 @@ __global__ __launch_bounds__(NC * 64, KS_SUBPEL_OCC) void me_subpel_kernel(KsGeo
 #pragma unroll
                         for (int i = 0; i < 8; ++i) *(unsigned *)&hx[i * 16 + 4 * gk + 2 * jp] = ((unsigned)h0[i] & 0xFFFFu) | ((unsigned)h1[i] << 16);
                     }
-                    if (gx < 2) request(cur, gx + 1);
-                    else if (nmore) { setup(nblk, nxt); request(nxt, 0); }
+                    if (gx < 2 && !single) request(cur, gx + 1);
+                    else if (nmore) { setup(nblk, nxt); request(nxt, gx_first); }
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     unsigned P[8][5];                                    // per pixel: row pairs (0,1) (2,3) .. (8,9) of this lane's ten rows 2 gk .. 2 gk + 9
 #pragma unroll
@@ -256,7 +287,8 @@ __global__ __launch_bounds__(NC * 64, KS_SUBPEL_OCC) void me_subpel_kernel(KsGeo
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the next x position overwrites the exchange area
 #pragma unroll
                     for (int gy = 0; gy < 3; ++gy) {
-                        if (phase == 1 && gx == 1 && gy == 1) continue;  // the centre of the quarter ring is the half-pel winner itself
+                        if (single && gy != 1) continue;
+                        if (skip_centre && gx == 1 && gy == 1) continue;
                         unsigned rw[4];
 #pragma unroll
                         for (int r = 0; r < 2; ++r) {
@@ -271,51 +303,106 @@ __global__ __launch_bounds__(NC * 64, KS_SUBPEL_OCC) void me_subpel_kernel(KsGeo
                             const uint2 pr = ks_pack_row8(px);
                             rw[2 * r] = pr.x; rw[2 * r + 1] = pr.y;
                         }
-                        const ks_v4i B = {(int)(rw[0] ^ 0x80808080u), (int)(rw[1] ^ 0x80808080u), (int)(rw[2] ^ 0x80808080u), (int)(rw[3] ^ 0x80808080u)};
                         unsigned a = 0;
+                        if (had) {
+                            const ks_v4i B = {(int)(rw[0] ^ 0x80808080u), (int)(rw[1] ^ 0x80808080u), (int)(rw[2] ^ 0x80808080u), (int)(rw[3] ^ 0x80808080u)};
 #pragma unroll
-                        for (int mb = 0; mb < 4; ++mb) {
-                            ks_v4i C = __builtin_amdgcn_mfma_i32_16x16x64_i8(Hm[mb], B, mb == 0 ? Cin0 : CinN, 0, 0, 0);
-                            C = __builtin_amdgcn_mfma_i32_16x16x64_i8(Hm[mb], S, C, 0, 0, 0);
+                            for (int mb = 0; mb < 4; ++mb) {
+                                ks_v4i C = __builtin_amdgcn_mfma_i32_16x16x64_i8(Hm[mb], B, mb == 0 ? Cin0 : CinN, 0, 0, 0);
+                                C = __builtin_amdgcn_mfma_i32_16x16x64_i8(Hm[mb], S, C, 0, 0, 0);
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) a = __builtin_amdgcn_sad_u16((unsigned)C[r], 0x8000u, a);
+                                for (int r = 0; r < 4; ++r) a = __builtin_amdgcn_sad_u16((unsigned)C[r], 0x8000u, a);
+                            }
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) a = __builtin_amdgcn_sad_u8(rw[r], (unsigned)S[r] ^ 0x7F7F7F7Fu, a);
                         }
-                        // a = this lane's share (16 of the 64 coefficients) of item n16 of the block: sum over the four K groups
+                        // a = this lane's share of item n16 of the block: sum over the four K groups
                         a += (unsigned)__builtin_amdgcn_ds_swizzle((int)a, 0x1F | (16 << 10));
                         a += (unsigned)__shfl_xor((int)a, 32, 64);
-                        constexpr int kSlot0[9] = {5, 1, 6, 3, 0, 4, 7, 2, 8}, kSlot1[9] = {1, 2, 3, 4, 0, 5, 6, 7, 8};   // [gy * 3 + gx] -> n of the kDx / kDy tables (inverse of those tables)
-                        const int n = phase == 0 ? kSlot0[gy * 3 + gx] : kSlot1[gy * 3 + gx];
-                        if (gk == 0 && ii < nitems) s_sat[n][ii] = (unsigned short)((a + 2) >> 2);
+                        if (gk == 0 && ii < nitems) s_sat[gy * 3 + gx][ii] = (unsigned short)(had ? (a + 2) >> 2 : a);
                     }
                 }
             }
             cur = nxt; blk = nblk; more = nmore;
         }
+        }
         __syncthreads();
-        // (3) per (level, tile): PU sums and the winner.  The mv rate is separable: lambda * (bits(x) + bits(y)) >> 4 with three
-        // possible x and three possible y per PU.
+        // (3) per (level, tile): PU sums, then the reference's walk over the candidates.  The mv rate is separable: lambda * (bits(x) + bits(y)) >> 4 with three
+        // possible x and three possible y per PU.  The group sums are cross-lane operations: every lane computes all of them, the walk itself is per lane (all lanes
+        // of a PU hold the same values and take the same steps).
 #pragma unroll
         for (int l = 0; l < 4; ++l) {
-            const int myitem = valid[l] ? s_idx[wave][owner[l]][lane] : 0;
-            const int cx0 = bx[l], cy0 = by[l];
+            const int myitem = act[l] ? s_idx[wave][owner[l]][lane] : 0;
+            const int cx0 = bx[l], cy0 = by[l], W2 = (64 >> l) * (64 >> l), l2 = 6 - l;
+            if (phase < 0) {
+                unsigned c4[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) c4[k] = pu_group_sum(act[l] ? s_sat[k][myitem] : 0, l);
+                const unsigned rate0 = (unsigned)((lam * (se_bits(cx0 - mvpx[l]) + se_bits(cy0 - mvpy[l]))) >> 4);
+                bool ds = true;
+                if (K.cap && (unsigned)(((6 - l2) * K.cap_step + K.cap) << (2 * l2)) < bc[l]) ds = false;
+                else if (K.thr) {
+                    const int thr = (int)((W2 * K.thr) >> 3);
+                    const unsigned m = max(max(c4[0], c4[1]), max(c4[2], c4[3])) << 2;      // the reference keeps them << 4 and compares >> 2
+                    ds = (int)(m - ((bc[l] - rate0) << 2)) >= thr;
+                }
+                dosub[l] = ds;
+                continue;
+            }
+            if (single) {
+                const unsigned d = pu_group_sum(act[l] ? s_sat[4][myitem] : 0, l);
+                bd[l] = d; bc[l] = d + (unsigned)((lam * (se_bits(cx0 - mvpx[l]) + se_bits(cy0 - mvpy[l]))) >> 4);
+                continue;
+            }
+            unsigned dd[9];
+#pragma unroll
+            for (int s = 0; s < 9; ++s) dd[s] = (s == 4 && skip_centre) ? 0u : pu_group_sum(act[l] ? s_sat[s][myitem] : 0, l);
+            if (!act[l]) continue;
             int bitx[3], bity[3];
 #pragma unroll
             for (int j = 0; j < 3; ++j) { bitx[j] = se_bits(cx0 + (j - 1) * step - mvpx[l]); bity[j] = se_bits(cy0 + (j - 1) * step - mvpy[l]); }
-            int bk = 0;
-#pragma unroll
-            for (int n = phase; n < 9; ++n) {
-                const int k = phase == 0 ? (n == 8 ? 8 : (int)((kVisit0 >> (4 * n)) & 15u)) : n;
-                const int jx = (int)((kDx[phase] >> (2 * n)) & 3u), jy = (int)((kDy[phase] >> (2 * n)) & 3u);
-                const unsigned sd = s_sat[n][myitem];
-                const unsigned dd = pu_group_sum(valid[l] ? sd : 0, l);
-                const unsigned cc = dd + (unsigned)((lam * (bitx[jx] + bity[jy])) >> 4);
-                // phase 0 starts from nothing (n == 0 is the centre); phase 1 starts from the half-pel winner, which every
-                // quarter-pel candidate must beat strictly (it is "earlier" than all of them)
-                const bool first = phase == 0 && n == 0;
-                if (first || cc < bc[l] || (cc == bc[l] && phase == 0 && k < bk)) {
-                    bc[l] = cc; bd[l] = dd; bx[l] = cx0 + (jx - 1) * step; by[l] = cy0 + (jy - 1) * step; bk = k;
+            // ring index k (raster, 0..7) -> slot k + (k > 3); rate of slot s = lambda (bitx[s % 3] + bity[s / 3]) >> 4
+            auto rate = [&](int s) { return (unsigned)((lam * (bitx[s % 3] + bity[s / 3])) >> 4); };
+            int idx = -1, mvdx = 0, mvdy = 0;                     // the winner: ring index, its offset in steps
+            unsigned best = bc[l], brate = 0;
+            if (phase == 0) {
+                const unsigned rate0 = rate(4);
+                brate = rate0;
+                if (SATD) best = dd[4] + rate0;                      // tME+0x64: the start cost recomputed with the sub-pel measure
+                unsigned maxd = best - rate0;                        // the integer position's distortion
+                auto TRY = [&](int k) { const int s = k + (k > 3); const unsigned r = rate(s), c = dd[s] + r; if (c < best) { best = c; idx = k; brate = r; mvdx = s % 3 - 1; mvdy = s / 3 - 1; } maxd = max(maxd, dd[s]); };
+                TRY(3); TRY(4); TRY(1); TRY(6);
+                if (!(K.diag_fast && idx == -1)) {
+                    if (!K.diag_fast) { TRY(0); TRY(2); TRY(5); TRY(7); }
+                    else {
+                        if ((idx & ~2) == 1) TRY(0);
+                        if (idx == 1 || idx == 4) TRY(2);
+                        if (idx == 3 || idx == 6) TRY(5);
+                        if ((idx & ~2) == 4) TRY(7);
+                    }
+                }
+                const int thrf = (int)(((unsigned)W2 * (unsigned)K.flat) >> 3), spread = (int)(maxd - best + brate);
+                qrun[l] = !(K.thr != 0 && thrf >= spread);           // a flat cost surface skips the quarter step when the configuration allows skipping
+                hmx[l] = 2 * mvdx; hmy[l] = 2 * mvdy;
+            } else {
+                const bool fast = K.subme == 1;
+                const bool up = !fast || hmy[l] >= 0, down = !fast || hmy[l] <= 0, left = !fast || hmx[l] >= 0, right = !fast || hmx[l] <= 0;
+                auto TRY = [&](int k) { const int s = k + (k > 3); const unsigned c = dd[s] + rate(s); if (c < best) { best = c; idx = k; mvdx = s % 3 - 1; mvdy = s / 3 - 1; } };
+                if (up) TRY(1);
+                if (down) TRY(6);
+                if (left) {
+                    TRY(3);
+                    if (up && (!fast || (idx & ~2) == 1)) TRY(0);
+                    if (down && (!fast || idx == 3 || idx == 6)) TRY(5);
+                }
+                if (right) {
+                    TRY(4);
+                    if (up && (!fast || idx == 4 || idx == 1)) TRY(2);
+                    if (down && (!fast || (idx & ~2) == 4)) TRY(7);
                 }
             }
+            bc[l] = best; bx[l] = cx0 + mvdx * step; by[l] = cy0 + mvdy * step;
         }
     }
 #pragma unroll
@@ -323,6 +410,7 @@ __global__ __launch_bounds__(NC * 64, KS_SUBPEL_OCC) void me_subpel_kernel(KsGeo
         const int G = 1 << (2 * (3 - l));                          // lanes (tiles) per PU: 64, 16, 4, 1
         if (valid[l] && (lane & (G - 1)) == 0) {
             ks265_pu o;
+            if (SATD) bd[l] = bc[l] - (unsigned)((lam * (se_bits(bx[l] - mvpx[l]) + se_bits(by[l] - mvpy[l]))) >> 4);
             o.mvx = (int16_t)bx[l]; o.mvy = (int16_t)by[l]; o.mvpx = (int16_t)mvpx[l]; o.mvpy = (int16_t)mvpy[l]; o.cost = bc[l]; o.dist = bd[l];
             cp[pidx[l]] = o;
         }
@@ -333,9 +421,14 @@ extern "C" int ks265_me_subpel(ks265_frame *f, ks265_pic src, ks265_pic ref, ks2
 {
     KS_FRAME_CHECK(f);
     if (!src.y || !ref.y || !pu) return KS265_POINTER;
-    hipLaunchKernelGGL(me_subpel_kernel<KS_SUBPEL_NC>, dim3((f->g.ctu_cols * f->g.ctu_rows + KS_SUBPEL_NC - 1) / KS_SUBPEL_NC), dim3(KS_SUBPEL_NC * 64), 0, f->ctx->stream, f->g, f->cfg.lambda_q4, src.y, ref.y, pu);
+    const ks265_frame_cfg &c = f->cfg;
+    const KsSubme K = {c.subme, c.sub_satd, c.sub_thr, c.sub_flat, c.sub_cap, c.sub_cap_step, c.sub_diag_fast};
+    const dim3 grid((f->g.ctu_cols * f->g.ctu_rows + KS_SUBPEL_NC - 1) / KS_SUBPEL_NC), block(KS_SUBPEL_NC * 64);
+    if (c.sub_satd) hipLaunchKernelGGL((me_subpel_kernel<KS_SUBPEL_NC, true>), grid, block, 0, f->ctx->stream, f->g, f->cfg.lambda_q4, K, src.y, ref.y, pu);
+    else hipLaunchKernelGGL((me_subpel_kernel<KS_SUBPEL_NC, false>), grid, block, 0, f->ctx->stream, f->g, f->cfg.lambda_q4, K, src.y, ref.y, pu);
     return ks265_check_launch(f->ctx);
 }
+
 
 // Price of splitting an inter CU into four, in bits at the motion lambda, on top of the children's SATD + vector rate (flags, vectors, the smaller
 // transforms of one TU per CU): 40 for the one-list records of P pictures, 80 for the two-list records (B pictures, multi-reference P).  At 12 (the flags

@@ -103,6 +103,13 @@ static const struct { int me, subme, ref, ref0, part, tuinter, rdoq, sao; } kPre
     {1, 1, 1, 2, 0, 0, 0, 1}, {1, 1, 1, 3, 0, 0, 0, 1}, {1, 1, 1, 3, 0, 0, 0, 3}, {1, 1, 1, 3, 0, 0, 1, 3}, {1, 1, 1, 3, 0, 0, 1, 4},
     {2, 1, 1, 3, 0, 0, 1, 4}, {2, 1, 2, 4, 1, 0, 1, 4}, {2, 2, 4, 4, 1, 1, 1, 4}, {2, 2, 5, 5, 1, 2, 1, 4}};
 
+/* what the reference's presets put into the configuration words its sub-pel refinement reads (cfg+0x464 = tME+0x3c0, tME+0x3c4, cfg+0x498, cfg+0x49c, cfg+0x580,
+ * tME+0x64): measured inside real appencoder runs (oracle/ref_probe/subme_shim.c).  The public QY265EncConfig has no fields for them: they follow the preset.
+ * ks265codec_amd/synth.py SUBME_PRESET holds the same table for the tests. */
+static const struct { int thr, flat, cap, cap_step, diag_fast, satd; } kPresetSubme[9] = {
+    {80, 40, 6, 6, 1, 0}, {76, 36, 6, 6, 1, 0}, {68, 16, 12, 6, 0, 0}, {56, 14, 0, 0, 0, 0}, {40, 10, 0, 0, 0, 0},
+    {24, 8, 0, 0, 0, 0}, {24, 8, 0, 0, 0, 0}, {0, 8, 0, 0, 0, 1}, {0, 8, 0, 0, 0, 1}};
+
 int QY265ConfigDefault(QY265EncConfig *c, QY265Preset preset, QY265Tune tune, QY265Latency latency)
 {
     if (!c) return QY_POINTER;
@@ -973,7 +980,7 @@ static Enc *lane_open(QY265EncConfig *cfg, int device, int multi, int *err)
     e->cfg = *cfg; e->W = cfg->picWidth; e->H = cfg->picHeight; e->log_level = cfg->logLevel;
     e->me_method = cfg->me < 0 ? 1 : cfg->me > 2 ? 2 : cfg->me;        /* EPZS / Cross (-me 3 / 4) are not built: UMH instead */
     e->hex_thr = (e->me_method == 2 && (cfg->preset == QY265PRESET_SLOW || cfg->preset == QY265PRESET_SLOWER)) ? 16 : 0;   /* tME+0x368, SURVEY-measured */
-    e->subme = cfg->subme ? 1 : 0;
+    e->subme = cfg->subme < 0 ? 1 : cfg->subme > 2 ? 2 : cfg->subme;      /* 0 off, 1 fast, 2 square full (qy265enc.h:137): the reference's refinement, ks265_frame_cfg.subme */
     e->refs = cfg->refnum < 1 ? 1 : cfg->refnum > 4 ? 4 : cfg->refnum;
     e->use_sao = cfg->sao > 0; e->use_df = g_cli.df; e->fixqp = g_cli.fixqp; e->md5 = g_cli.md5;
     e->gop_b = cfg->bframes < 0 ? (cfg->latency == QY265LATENCY_DEFAULT ? 7 : 0) : cfg->bframes;
@@ -990,7 +997,6 @@ static Enc *lane_open(QY265EncConfig *cfg, int device, int multi, int *err)
 
     if (cfg->rdoq || cfg->transskip || cfg->part || cfg->iAqMode) logf_(1, e->log_level, "ks265enc: rdoq / transskip / part / aq are accepted but not implemented by the pixel path\n");
     /* options whose VALUE is narrowed (SURVEY.md 8(a) config 5 = -preset veryslow: subme 2, part 1, ref 4): said once, never silently */
-    if (cfg->subme > 1) logf_(1, e->log_level, "ks265enc: -subme %d runs as -subme 1 (eight half- and eight quarter-sample candidates by SATD; the second refinement round is not implemented)\n", cfg->subme);
     if (cfg->refnum > 4) logf_(1, e->log_level, "ks265enc: -ref %d runs as -ref 4\n", cfg->refnum);
     if (e->gop_b > 0 && cfg->refnum > 1) logf_(1, e->log_level, "ks265enc: -ref %d with B pictures runs as one reference per list\n", cfg->refnum);
     if (cfg->rc == 5 || cfg->vbv_buffer_size) logf_(1, e->log_level, "ks265enc: CVQ / VBV are not implemented; running the plain controller\n");
@@ -1003,6 +1009,11 @@ static Enc *lane_open(QY265EncConfig *cfg, int device, int multi, int *err)
     e->fcfg.width = e->W; e->fcfg.height = e->H; e->fcfg.qp = e->base_qp; e->fcfg.lambda_q4 = kLambdaQ4[e->base_qp];
     e->fcfg.me_range = cfg->searchrange < 1 ? 64 : cfg->searchrange > 64 ? 64 : cfg->searchrange;
     e->fcfg.me_method = e->me_method; e->fcfg.subme = e->subme; e->fcfg.deblock = e->use_df; e->fcfg.sao = e->use_sao;
+    {   /* the sub-pel refinement's knobs follow the preset, as in the reference */
+        const int ps = (int)cfg->preset < 0 || (int)cfg->preset > 8 ? QY265PRESET_SLOW : (int)cfg->preset;
+        e->fcfg.sub_satd = kPresetSubme[ps].satd; e->fcfg.sub_thr = kPresetSubme[ps].thr; e->fcfg.sub_flat = kPresetSubme[ps].flat;
+        e->fcfg.sub_cap = kPresetSubme[ps].cap; e->fcfg.sub_cap_step = kPresetSubme[ps].cap_step; e->fcfg.sub_diag_fast = kPresetSubme[ps].diag_fast;
+    }
     e->fcfg.bframes = e->gop_b; e->fcfg.refs = e->refs; e->fcfg.me_hex_thr = e->hex_thr;
     e->fcfg.sdh = 1;                                                    /* the reference's streams have sign_data_hiding_enabled_flag = 1 at every preset */
     e->fcfg.pre_search = 1;                                             /* stage A0: pyramid pre-search vectors as start candidates of the integer search */

@@ -53,3 +53,20 @@ def lambda_q4(qp: int, inter: bool = False) -> int:
     if inter:
         return LAMBDA_INTER_Q4[qp]
     return int(round(16.0 * (0.57 * 2.0 ** ((qp - 12) / 3.0)) ** 0.5))
+
+
+# What the reference's nine presets (ultrafast .. placebo) put into the configuration words its sub-pel refinement reads, measured inside real `appencoder` runs
+# (oracle/ref_probe/subme_shim.c): (subme, sub_satd, sub_thr, sub_flat, sub_cap, sub_cap_step, sub_diag_fast).  host/ks265_enc.c holds the same table.
+SUBME_PRESET = {
+    "ultrafast": (1, 0, 80, 40, 6, 6, 1), "superfast": (1, 0, 76, 36, 6, 6, 1), "veryfast": (1, 0, 68, 16, 12, 6, 0), "fast": (1, 0, 56, 14, 0, 0, 0),
+    "medium": (1, 0, 40, 10, 0, 0, 0), "slow": (1, 0, 24, 8, 0, 0, 0), "slower": (1, 0, 24, 8, 0, 0, 0), "veryslow": (2, 1, 0, 8, 0, 0, 0), "placebo": (2, 1, 0, 8, 0, 0, 0),
+}
+
+
+def subme_knobs(preset: str) -> dict:
+    return dict(zip(("subme", "sub_satd", "sub_thr", "sub_flat", "sub_cap", "sub_cap_step", "sub_diag_fast"), SUBME_PRESET[preset]))
+
+
+# THE tool set of the encoder host at -preset slow (host/ks265_enc.c: encoder_open) - bench.py, __graft_entry__.smoke(), the GPU tests and tools/rd_eval.py --host all
+# import this one dict, so that what is timed is what is tested.
+ENCODER_TOOLS = dict(me_method=2, me_hex_thr=16, sdh=1, pre_search=1, merge=1, bi_refine=1, rdo=4, intra_inter=1, propagate=1, **subme_knobs("slow"))

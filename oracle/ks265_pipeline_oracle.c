@@ -1,6 +1,7 @@
 /* ks265_pipeline_oracle.c — TEST INFRASTRUCTURE, NOT PRODUCT CODE (see ks265_pipeline_oracle.h).
  * Whole-frame stages restated on the CPU from the pinned kernels of ks265_oracle.c. */
 #include "ks265_pipeline_oracle.h"
+#include "ks265_subme_ref.h"
 #include "ks265_me_ref.h"
 #include "ks265_oracle.h"
 #include <stdlib.h>
@@ -424,16 +425,24 @@ void kso_me_propagate(const kso_frame_cfg *cfg, kso_pic src, kso_pic ref, const 
         }
 }
 
-/* ------------------------------------------------------------------ Stage B: sub-pel refinement
- * subMeSquare enc@0x4b5660: 8 half-pel then 8 quarter-pel candidates in the raster order of hpel_x/y, qpel_x/y
- * (SURVEY.md B.11), prediction by the normative filters (here: the precomputed planes), cost = had_c + mv rate. */
+/* ------------------------------------------------------------------ Stage B: sub-pel refinement = the reference's, per PU (round 4)
+ * getMvResolution enc@0x483ca0 -> subMeSquare enc@0x4b5660 (subMeHpel_RealInterp enc@0x4b4e90, subMeQpel_8Sad_*_RealInterp enc@0x4b2bc0-0x4b43a0) as restated in
+ * ks265_subme_ref.c and pinned on 1 840 recorded calls (tests/test_subme.py).  What the frame-parallel stage feeds them:
+ *   start = the integer stage's vector and cost (SAD + rate);   rate = this pipeline's mv_cost around the PU's predictor (the reference: its tables around AMVP);
+ *   the four neighbour SADs getMvResolution looks at are computed at the integer winner (the reference re-uses the search's last sad4 when it is that: 99.6 % of calls);
+ *   cfg->subme 1 / 2 = tME+0x36c, cfg->sub_satd = tME+0x64 / TPredUnit+0x40 (Hadamard; veryslow, placebo), cfg->sub_thr = cfg+0x464 = tME+0x3c0, cfg->sub_flat = tME+0x3c4,
+ *   cfg->sub_cap / sub_cap_step = cfg+0x498 / +0x49c, cfg->sub_diag_fast = cfg+0x580; tME+0x60 = 0 (uni-directional search), cfg+0x568 = 0 (its partner TPredUnit+0x140 comes
+ *   out of the reference's closed RD loop; only ultrafast / superfast set it).
+ * Then - this pipeline's own, not the reference's - the record's cost becomes Hadamard distortion of the chosen prediction + rate: the CU tree, the merge pass and the
+ * bi decision compare SATD-based costs (the reference decides by RD after the search; closed code). */
+typedef struct { int px, py, lam; } sub_rate_ctx;
+static uint32_t sub_rate(void *ctx, int qx, int qy) { const sub_rate_ctx *c = ctx; return (uint32_t)mv_cost(qx, qy, c->px, c->py, c->lam); }
 void kso_me_subpel(const kso_frame_cfg *cfg, kso_pic src, const uint8_t *planes, kso_pu *pu)
 {
     kso_frame_geom g; kso_frame_geometry(cfg, &g);
-    const uint8_t *S = org_y(&g, src.y);
+    const uint8_t *S = org_y(&g, src.y), *R = org_y(&g, (uint8_t *)planes);          /* plane 0 = the padded reference picture */
     long st = g.stride_y;
     int lam = cfg->lambda_q4;
-    static const int ox[8] = {-1, 0, 1, -1, 1, -1, 0, 1}, oy[8] = {-1, -1, -1, 0, 0, 1, 1, 1};
 #pragma omp parallel for collapse(2) schedule(dynamic, 1)
     for (int cy = 0; cy < g.ctu_rows; ++cy)
         for (int cx = 0; cx < g.ctu_cols; ++cx) {
@@ -444,21 +453,28 @@ void kso_me_subpel(const kso_frame_cfg *cfg, kso_pic src, const uint8_t *planes,
                         kso_pu *o = &cp[pu_index(l, px, py)];
                         if (o->cost == COST_INVALID) continue;
                         int s = 64 >> l, x0 = cx * 64 + px * s, y0 = cy * 64 + py * s;
-                        const uint8_t *fenc = S + (long)y0 * st + x0;
-                        int bx = o->mvx, by = o->mvy;
-                        uint32_t bd = ks265o_had(fenc, org_y(&g, (uint8_t *)planes) + (long)(y0 + (by >> 2)) * st + x0 + (bx >> 2), st, st, s, s);
-                        uint32_t bc = bd + (uint32_t)mv_cost(bx, by, o->mvpx, o->mvpy, lam);
-                        for (int step = 2; step >= 1; --step) {
-                            int cx0 = bx, cy0 = by;
-                            for (int k = 0; k < 8; ++k) {
-                                int qx = cx0 + ox[k] * step, qy = cy0 + oy[k] * step;
-                                const uint8_t *pl = org_y(&g, (uint8_t *)planes + (long)((qy & 3) * 4 + (qx & 3)) * g.bytes_y);
-                                uint32_t d = ks265o_had(fenc, pl + (long)(y0 + (qy >> 2)) * st + x0 + (qx >> 2), st, st, s, s);
-                                uint32_t c = d + (uint32_t)mv_cost(qx, qy, o->mvpx, o->mvpy, lam);
-                                if (c < bc) { bc = c; bd = d; bx = qx; by = qy; }
-                            }
+                        sub_rate_ctx rc = {o->mvpx, o->mvpy, lam};
+                        kso_subme m;
+                        memset(&m, 0, sizeof m);
+                        m.fenc = S + (long)y0 * st + x0; m.fstride = (int)st;
+                        m.ref0 = R + (long)(y0 + (o->mvy >> 2)) * st + x0 + (o->mvx >> 2); m.stride = (int)st;
+                        m.log2w = m.log2h = 6 - l;
+                        m.dist = cfg->sub_satd ? ks265o_had : ks265o_sad; m.recost = cfg->sub_satd;
+                        m.subme = cfg->subme; m.mvres_thr = cfg->sub_thr; m.hpel_diag_fast = cfg->sub_diag_fast; m.c568 = 0; m.pu140 = 0x0FFFFFFFu;
+                        m.flat_factor = cfg->sub_flat; m.flat_shift = 0;
+                        m.rate = sub_rate; m.rate_ctx = &rc;
+                        m.mx = o->mvx; m.my = o->mvy; m.cost = o->cost;
+                        {
+                            uint32_t c4[4];
+                            m.do_subpel = kso_ref_mv_resolution(cfg->sub_cap, cfg->sub_cap_step, m.log2w, m.log2h, o->cost, 1, 0, sub_rate(&rc, o->mvx, o->mvy), cfg->sub_thr, 0, c4, 0,
+                                                                cfg->sub_thr, 0, m.fenc, m.fstride, m.ref0, m.stride);
                         }
-                        o->mvx = (int16_t)bx; o->mvy = (int16_t)by; o->cost = bc; o->dist = bd;
+                        kso_ref_subme_square(&m);
+                        {   /* the decision cost of the record: Hadamard of the chosen prediction + rate */
+                            const uint8_t *pl = org_y(&g, (uint8_t *)planes + (long)((m.my & 3) * 4 + (m.mx & 3)) * g.bytes_y);
+                            const uint32_t d = ks265o_had(m.fenc, pl + (long)(y0 + (m.my >> 2)) * st + x0 + (m.mx >> 2), st, st, s, s);
+                            o->mvx = (int16_t)m.mx; o->mvy = (int16_t)m.my; o->dist = d; o->cost = d + (uint32_t)mv_cost(m.mx, m.my, o->mvpx, o->mvpy, lam);
+                        }
                     }
         }
 }

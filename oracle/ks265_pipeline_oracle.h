@@ -18,7 +18,8 @@ extern "C" {
 #endif
 
 typedef struct {
-    int32_t width, height, qp, lambda_q4, me_range, me_method, subme, deblock, sao, beta_offset_div2, tc_offset_div2, bframes, refs, me_hex_thr, sdh, pre_search, merge, bi_refine, decimate, rdo, intra_inter, propagate;
+    int32_t width, height, qp, lambda_q4, me_range, me_method, subme, deblock, sao, beta_offset_div2, tc_offset_div2, bframes, refs, me_hex_thr, sdh, pre_search, merge, bi_refine, decimate, rdo, intra_inter, propagate,
+            sub_satd, sub_thr, sub_flat, sub_cap, sub_cap_step, sub_diag_fast;     /* the sub-pel refinement's knobs (Stage B, ks265_pipeline_oracle.c) */
 } kso_frame_cfg;
 
 typedef struct {

@@ -74,6 +74,13 @@ def case_prop(name: str) -> int:
     return 1 if name.startswith("enc_") else 0            # the C host: one round of vector propagation after every integer search (stage A2)
 
 
+def case_subme(name: str) -> dict:
+    """the sub-pel knobs: the C host's (-preset slow: fast candidate sets judged by SAD) for the enc_ cases, -preset veryslow's (all 8 + 8 candidates judged by
+    Hadamard) for the wpp_ cases, -preset medium's for the hierarchical ones, veryfast's for the rest"""
+    from ks265codec_amd.synth import subme_knobs
+    return subme_knobs("slow" if name.startswith("enc_") else "veryslow" if name.startswith("wpp_") else "medium" if "hier" in name else "veryfast")
+
+
 def case_lambda(name: str, q: int, kind: str) -> int:
     """the C host prices P / B pictures with the inter table (HM's factor for pictures that are not key pictures)"""
     from ks265codec_amd.synth import lambda_q4
@@ -138,7 +145,7 @@ def oracle_encoder(name: str):
     W, H, qp, me, thr, sao, df, kind, par = CASES[name]
     n = 1 + max(s[0] for s in schedule(kind, par))
     clip = make_clip(W, H, n, seed=len(name) * 7 + W, abc=(17, 23, 9))
-    o = OraclePipeline(W, H, qp, lambda_q4(qp), me_method=me, me_hex_thr=thr, sao=sao, deblock=df, sdh=case_sdh(name), pre_search=case_ps(name), merge=case_merge(name), bi_refine=case_bir(name), decimate=case_dec(name), rdo=case_rdo(name), intra_inter=case_ii(name), propagate=case_prop(name))
+    o = OraclePipeline(W, H, qp, lambda_q4(qp), me_method=me, me_hex_thr=thr, sao=sao, deblock=df, sdh=case_sdh(name), pre_search=case_ps(name), merge=case_merge(name), bi_refine=case_bir(name), decimate=case_dec(name), rdo=case_rdo(name), intra_inter=case_ii(name), propagate=case_prop(name), **case_subme(name))
     dpb = {}
 
     def encode(d, k, l0, l1, q):

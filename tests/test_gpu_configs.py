@@ -26,7 +26,8 @@ def ks():
 
 
 # the tool set the C host (ks265_enc.c) and bench.py switch on for -preset slow: what is timed is what is checked (VERDICT r2 "weak 1a")
-ENCODER_TOOLS = dict(sdh=1, pre_search=1, merge=1, bi_refine=1, rdo=4, intra_inter=1, propagate=1)
+from ks265codec_amd.synth import ENCODER_TOOLS as _HOST_TOOLS      # the ONE dict bench.py, smoke() and rd_eval.py --host use too
+ENCODER_TOOLS = {k: v for k, v in _HOST_TOOLS.items() if k not in ("me_method", "me_hex_thr")}     # the search method travels separately in these tests
 
 
 def _ippp(ks, W, H, qp, me, nfr, seed, abc=(37, 53, 19), pan=(5, 3), hidden_offset=True, hex_thr=0, **tools):

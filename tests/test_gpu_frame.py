@@ -89,6 +89,48 @@ def test_stages_match_oracle(ks, W, H, seed, me):
     f.close()
 
 
+@pytest.mark.parametrize("preset", ["ultrafast", "superfast", "veryfast", "fast", "medium", "slow", "slower", "veryslow", "placebo"])
+def test_subpel_refinement_of_every_preset_matches_oracle(ks, preset):
+    """stage B with the configuration words each of the reference's nine presets gives its sub-pel refinement (synth.SUBME_PRESET: fast / full candidate sets, SAD /
+    Hadamard, the getMvResolution and flat-surface thresholds, the cost cap, the half step's fast diagonals): the PU records ks265_me_subpel leaves == the oracle stage
+    (= the restatement pinned on the reference's recorded calls, tests/test_subme.py) on the same integer-search records, on a clip with fast irregular motion; also
+    -subme 2 with the preset's other words"""
+    import ctypes as C
+    from ks265codec_amd.lib import PU, KsFrame
+    from ks265codec_amd.synth import lambda_q4, make_clip, subme_knobs
+    from oracle_lib import OraclePipeline, ptr
+
+    W, H = 416, 240
+    clip = make_clip(W, H, 3, seed=79, abc=(9, 11, 5), pan=(15, 10))
+    for force2 in (0, 1):
+        knobs = subme_knobs(preset)
+        if force2:
+            if knobs["subme"] == 2:
+                continue
+            knobs["subme"] = 2
+        o = OraclePipeline(W, H, 27, lambda_q4(27), me_method=1, **knobs)
+        with KsFrame(ks, W, H, 27, lambda_q4(27), me_method=1, **knobs) as f:
+            g = f.geom
+            src, ref = f.new_pic(), f.new_pic()
+            pu = ks.zeros(g.bytes_pu)
+            moved = changed = 0
+            for t in (1, 2):                                                  # the previous SOURCE picture serves as the reference: the stage alone is under test
+                f.load_i420(ks.dev(clip[t]), src); f.load_i420(ks.dev(clip[t - 1]), ref)
+                f.me_integer(src, ref, None, pu)
+                rec = ks.host(pu, PU).copy()
+                f.me_subpel(src, ref, pu)
+                got = ks.host(pu, PU)
+                o.load(o.src, clip[t]); o.load(o.ref, clip[t - 1])
+                o.o.kso_ref_planes(C.byref(o.cfg), o.ref.c(), ptr(o.planes))
+                exp = rec.copy()
+                o.o.kso_me_subpel(C.byref(o.cfg), o.src.c(), ptr(o.planes), ptr(exp))
+                assert (got == exp).all(), f"{preset} subme {knobs['subme']}: {int((got != exp).sum())} PU records differ after the sub-pel stage (picture {t})"
+                ok = exp["cost"] != 0xFFFFFFFF
+                moved += int((((exp["mvx"] & 3) | (exp["mvy"] & 3)) != 0)[ok].sum())
+                changed += int(((exp["mvx"] != rec["mvx"]) | (exp["mvy"] != rec["mvy"]))[ok].sum())
+            assert moved > 50 and changed > 50, "the clip must exercise the refinement"
+
+
 @pytest.mark.parametrize("W,H,seed,me,pre", [(200, 136, 5, 0, 0), (416, 240, 31, 2, 1), (1280, 720, 21, 2, 1), (1920, 1080, 9, 1, 1)])
 def test_vector_propagation_matches_oracle(ks, W, H, seed, me, pre):
     """stage A2 (cfg.propagate): ks265_me_propagate on the records of ks265_me_integer == kso_me_propagate, record for record, two rounds; then the whole P

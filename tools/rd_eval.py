@@ -23,7 +23,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-ENCODER_TOOLS = dict(me_method=2, me_hex_thr=16, sdh=1, pre_search=1, merge=1, bi_refine=1, decimate=2)   # + --tools intra_inter=1,rdo=4,propagate=1 = the host encoder
+from ks265codec_amd.synth import ENCODER_TOOLS as HOST_TOOLS                                                # the host encoder's tool set (--host)
+ENCODER_TOOLS = dict(me_method=2, me_hex_thr=16, sdh=1, pre_search=1, merge=1, bi_refine=1, decimate=2)   # round 2's set (without --host)
 
 
 def stats_lib():
@@ -245,7 +246,7 @@ def main():
         clip = clip[[order[t % len(order)] for t in range(a.frames)]]
     tools = dict(ENCODER_TOOLS)
     if a.host:
-        tools.update(decimate=0, intra_inter=1, rdo=4, propagate=1); a.lam_scale = -1.0
+        tools = dict(HOST_TOOLS); a.lam_scale = -1.0
         if a.gop == "ippp" and not a.cascade:
             a.cascade = "0,2,1,2"                                   # ks265_enc.c kIpppCascade
         if a.gop == "hier" and not a.layer_qp:
