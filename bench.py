@@ -85,7 +85,7 @@ def main():
 
     import torch
     from ks265codec_amd.lib import KsContext, KsFrame
-    from ks265codec_amd.synth import lambda_q4, make_clip
+    from ks265codec_amd.synth import host_qp_offset, lambda_q4, make_clip
     from ks265codec_amd import gop
 
     rank = int(os.environ.get("RANK", "0"))
@@ -177,7 +177,7 @@ def main():
             def step_hier():
                 d, kind, r0, r1, layer = next(sched)
                 G1 = args.hier_b + 1
-                q = qp if kind == "I" else qp + 1 + layer            # I = Q, P = Q+1, B of layer k = Q+1+k (hidden hierarchy offsets)
+                q = qp + host_qp_offset(kind, layer=layer, hier=True)   # the encoder host's ladder (= the reference's): anchors Q + 1, B layers + 2 / + 4 / + 4
                 fr.set_qp(q, lambda_q4(q, inter=kind != "I"))       # P / B pictures: the encoder host's inter table (ks265_enc.c kLambdaInterQ4)
                 out = dpb[d % G1]
                 if kind == "B":
@@ -221,7 +221,8 @@ def main():
                     fr.encode_picture_b(src_of(d), anchors[cur ^ 1], anchors[cur], bout)   # list 0 = previous anchor, list 1 = the anchor just coded
                     state["last"] = (d, bout)
                 else:
-                    q = qp if kind == "I" else qp + 1
+                    state["pos"] = 0 if kind == "I" else state.get("pos", 0) + 1
+                    q = qp + host_qp_offset(kind, state["pos"])      # the encoder host's IPPP ladder (= the reference's cascade): P = Q + 1 + {0, 2, 1, 2}[position & 3]
                     fr.set_qp(q, lambda_q4(q, inter=kind != "I"))
                     fr.encode_picture(src_of(d), anchors[cur], kind == "I", anchors[cur ^ 1])
                     state["cur"] = cur ^ 1
@@ -392,7 +393,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{W}x{H} 4:2:0 8-bit, hot path only (ME + transform/quant/recon + deblock + SAO; CABAC/RC not included), "
-                                   f"-rc 0 -qp {qp} (I=Q, P=Q+1, B=Q+2) -iper {args.iper}, -bframes {bf_desc}, -ref {max(1, args.refs)} -ref0 {max(1, args.refs)} ({'one reference picture per list' if args.refs <= 1 else 'every P picture searches that many list-0 pictures'}), -me {me_method} ({args.me.upper()}{', interMeHex below ' + str(args.me_hex_thr) + ' SAD/sample as at -preset slow' if me_method == 2 and args.me_hex_thr else ''}) range 64, -subme 1 as the reference runs it at -preset slow (fast candidate sets judged by SAD + rate; DESIGN.md 5e), sao on, df on",
+                                   f"-rc 0 -qp {qp} (the encoder host's ladders = the reference's: I = Q; IPPP P = Q + 1 + 0 / 2 / 1 / 2 over four pictures; pyramid anchors Q + 1, B layers + 2 / + 4 / + 4; plain B = Q + 2) -iper {args.iper}, -bframes {bf_desc}, -ref {max(1, args.refs)} -ref0 {max(1, args.refs)} ({'one reference picture per list' if args.refs <= 1 else 'every P picture searches that many list-0 pictures'}), -me {me_method} ({args.me.upper()}{', interMeHex below ' + str(args.me_hex_thr) + ' SAD/sample as at -preset slow' if me_method == 2 and args.me_hex_thr else ''}) range 64, -subme 1 as the reference runs it at -preset slow (fast candidate sets judged by SAD + rate; DESIGN.md 5e), sao on, df on",
                        "pictures_per_step": nstreams, "streams_per_gpu": nstreams,
                        "key_picture_ms": {"intra_decide": key_ms.get("intra_candidates"), "intra_reconstruct": key_ms.get("intra_pass"), "total": round(sum(key_ms.values()), 3),
                                           "note": f"one intra picture per -iper {args.iper} pictures; it is in the timed region whenever the schedule puts one there"},

@@ -8,8 +8,11 @@
  *
  * Behaviour that differs from the SDK, all of it reported through the log callback at open:
  *   - the encoder's decisions are its own: the stream is a conforming HEVC stream, not appencoder's bytes;
- *   - rate control: rc = 0 (constant QP with the reference's hidden offsets I = Q, P = Q + 1, B = Q + 2 ..) is exact; rc = 3 (CRF) maps
- *     crf to that QP ladder; rc = 1 / 2 / 4 (bitrate targets) run a frame-level controller on top of it; rc = 5 and VBV are not implemented;
+ *   - rate control: rc = 0 is constant QP with the reference's own hidden ladders (read from its -psnr 2 lines): I = Q; IPPP P pictures
+ *     Q + 1 + {0, 2, 1, 2}[position & 3]; hierarchical GOP anchors Q + 1, B layers Q + 2 / + 4 / + 4; P + n plain B: B = Q + 2 (-fixqp 1: one QP);
+ *     rc = 3 (CRF) maps crf to that ladder; rc = 1 / 2 / 4 (bitrate targets) run a frame-level controller on top of it (one offset per
+ *     mini-GOP from the pictures coded so far: deterministic streams); rc = 5 and VBV are not implemented;
+ *   - subme 0 / 1 / 2 and the preset's thresholds run the reference's sub-pel refinement (include/ks265_hip.h ks265_frame_cfg.subme);
  *   - rdoq, transskip, part, tuInter / tuIntra, vpp_*, 2-pass, long-term references, AQ: accepted, ignored (the pixel path has no such
  *     stage yet);
  *   - input pictures are COPIED inside QY265EncoderEncodeFrame: the caller may reuse its buffers at once (the SDK requires them to stay

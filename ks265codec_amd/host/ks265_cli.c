@@ -56,25 +56,27 @@ static void usage(void)
 {
     puts("usage: ks265enc -i in.yuv -wdt W -hgt H [-fr FPS] [-preset ultrafast..placebo] [-latency zerolatency|lowdelay|livestreaming|default] [-tune T]\n"
          "                [-rc 0..5] [-qp Q] [-crf C] [-br KBPS] [-iper N] [-bframes N] [-frms N] [-threads N] [-psnr 0|1|2] [-b out.265] [-o recon.yuv]\n"
-         "                [-me 0|1|2] [-subme 0|1] [-merange R] [-ref N] [-sao 0..4] [-df 0|1] [-fixqp 0|1] [-md5 0|1] [-c config_file] [-gpus N] [-v]\n"
+         "                [-me 0|1|2] [-subme 0|1|2] [-merange R] [-ref N] [-sao 0..4] [-df 0|1] [-fixqp 0|1] [-md5 0|1] [-c config_file] [-gpus N] [-v]\n"
          "  I420 8-bit input; width and height multiples of 8.  Needs one MI355X (gfx950): there is no CPU fallback.");
 }
 
 /* -c file: a text file of further options, `-name value` or `name value` / `name = value` / `name : value` per line, `#` starts a comment; its
  * options are spliced into the command line where -c stood (later options override earlier ones, as on the command line) */
-static int splice_config(int *pargc, char ***pargv)
+static int splice_config(int *pargc, char ***pargv, int depth)
 {
     int argc = *pargc; char **argv = *pargv;
+    if (depth > 8) { fprintf(stderr, "-c nests deeper than 8 config files (a file that names itself?)\n"); return -1; }
     for (int i = 1; i + 1 < argc; ++i) {
         if (strcmp(argv[i], "-c")) continue;
         FILE *f = fopen(argv[i + 1], "r");
         if (!f) { fprintf(stderr, "cannot read the config file %s\n", argv[i + 1]); return -1; }
-        char **nv = (char **)malloc(sizeof(char *) * (size_t)(argc + 2048));
+        const int cap = argc + 2048;                                     /* room for every argument of the command line + 1024 options from the file */
+        char **nv = (char **)malloc(sizeof(char *) * (size_t)cap);
         int n = 0;
         if (!nv) { fclose(f); return -1; }
         for (int k = 0; k < i; ++k) nv[n++] = argv[k];
         char line[1024];
-        while (fgets(line, sizeof line, f) && n < argc + 2000) {
+        while (fgets(line, sizeof line, f) && n + 2 + (argc - i - 2) <= cap) {    /* the arguments behind -c file still have to fit */
             char *h = strchr(line, '#'); if (h) *h = 0;
             char *name = strtok(line, " \t\r\n=:"), *val = name ? strtok(NULL, " \t\r\n=:") : NULL;
             if (!name || !val) continue;
@@ -86,14 +88,14 @@ static int splice_config(int *pargc, char ***pargv)
         fclose(f);
         for (int k = i + 2; k < argc; ++k) nv[n++] = argv[k];
         *pargc = n; *pargv = nv;
-        return splice_config(pargc, pargv);                              /* a second -c (or one inside the file) */
+        return splice_config(pargc, pargv, depth + 1);                   /* a second -c (or one inside the file) */
     }
     return 0;
 }
 
 int main(int argc, char **argv)
 {
-    if (splice_config(&argc, &argv)) return 2;
+    if (splice_config(&argc, &argv, 0)) return 2;
     const char *in_path = NULL, *out_path = NULL, *preset = "medium", *latency = "default", *tune = "default";
     const char *rec_path = NULL;
     int frames = -1;

@@ -41,8 +41,8 @@ static void md5_block(uint32_t st[4], const uint8_t *p)
 {
     static const uint8_t sh[64] = {7, 12, 17, 22, 7, 12, 17, 22, 7, 12, 17, 22, 7, 12, 17, 22, 5, 9, 14, 20, 5, 9, 14, 20, 5, 9, 14, 20, 5, 9, 14, 20,
                                    4, 11, 16, 23, 4, 11, 16, 23, 4, 11, 16, 23, 4, 11, 16, 23, 6, 10, 15, 21, 6, 10, 15, 21, 6, 10, 15, 21, 6, 10, 15, 21};
-    static uint32_t K[64]; static int init;
-    if (!init) { for (int i = 0; i < 64; ++i) K[i] = (uint32_t)(4294967296.0 * fabs(sin((double)(i + 1)))); __atomic_store_n(&init, 1, __ATOMIC_RELEASE); }
+    static const uint32_t K[64] = {   /* floor(2^32 |sin(i + 1)|): a constant table (it used to be filled lazily by whichever writer thread came first) */
+        0xd76aa478u, 0xe8c7b756u, 0x242070dbu, 0xc1bdceeeu, 0xf57c0fafu, 0x4787c62au, 0xa8304613u, 0xfd469501u, 0x698098d8u, 0x8b44f7afu, 0xffff5bb1u, 0x895cd7beu, 0x6b901122u, 0xfd987193u, 0xa679438eu, 0x49b40821u, 0xf61e2562u, 0xc040b340u, 0x265e5a51u, 0xe9b6c7aau, 0xd62f105du, 0x02441453u, 0xd8a1e681u, 0xe7d3fbc8u, 0x21e1cde6u, 0xc33707d6u, 0xf4d50d87u, 0x455a14edu, 0xa9e3e905u, 0xfcefa3f8u, 0x676f02d9u, 0x8d2a4c8au, 0xfffa3942u, 0x8771f681u, 0x6d9d6122u, 0xfde5380cu, 0xa4beea44u, 0x4bdecfa9u, 0xf6bb4b60u, 0xbebfbc70u, 0x289b7ec6u, 0xeaa127fau, 0xd4ef3085u, 0x04881d05u, 0xd9d4d039u, 0xe6db99e5u, 0x1fa27cf8u, 0xc4ac5665u, 0xf4292244u, 0x432aff97u, 0xab9423a7u, 0xfc93a039u, 0x655b59c3u, 0x8f0ccc92u, 0xffeff47du, 0x85845dd1u, 0x6fa87e4fu, 0xfe2ce6e0u, 0xa3014314u, 0x4e0811a1u, 0xf7537e82u, 0xbd3af235u, 0x2ad7d2bbu, 0xeb86d391u};
     uint32_t w[16], a = st[0], b = st[1], c = st[2], d = st[3];
     for (int i = 0; i < 16; ++i) w[i] = (uint32_t)p[4 * i] | (uint32_t)p[4 * i + 1] << 8 | (uint32_t)p[4 * i + 2] << 16 | (uint32_t)p[4 * i + 3] << 24;
     for (int i = 0; i < 64; ++i) {
@@ -183,6 +183,7 @@ typedef struct Job {
     uint8_t *lvlbuf; uint64_t *dirty;                     /* the level planes expanded from it (plain memory) and the lines the previous picture in this slot set */
     ks265_cu8 *cu8; int16_t *lvl[3]; ks265_sao_param *sao; uint64_t *sse;      /* cu8 / sao / sse point into cmp, lvl into lvlbuf */
     int ev_err;
+    long sub_seq;                                         /* this picture's number in submission order (the dispatcher's sticky device error ends at a key picture submitted after the error was seen) */
     void *wpp; ks265_slice_in sin; int started, nrows, next_row, rows_done;   /* row-wise writing of the slice (ks265_wpp_*) */
     uint8_t *recon;                                       /* pinned I420 copy of the reconstruction (only with ks265_enc_set_recon_file / -md5) */
     char md5[3][33];
@@ -190,6 +191,7 @@ typedef struct Job {
     uint8_t *nal; size_t nal_cap; long nal_len;
     int key_headers;                                      /* parameter sets go in front of this picture */
     int rc_delta;                                         /* the controller's QP offset this picture was coded with (rate control) */
+    double rc_budget;                                     /* this picture's share of the bit budget: the bitrate in force when it was handed in / frame rate (QY265EncoderReconfig) */
     double t_write_ms, t_submit, t_event, t_taken, t_done;      /* wall-clock marks: enqueued, records on the host (seen by a writer), writer started */
 } Job;
 
@@ -262,7 +264,7 @@ static void copy_shared(CopyPool *p, uint8_t *d, const uint8_t *s, size_t n)
 }
 
 #define LA_RING 9                                                      /* half-size pictures kept for the analysis: the current one and eight back */
-typedef struct Input { int used, disp, key, base_qp, iper, mini4; long long pts; uint8_t *i420; } Input;     /* pinned; key: this picture starts a closed GOP whatever the period says (GOP lanes,
+typedef struct Input { int used, disp, key, base_qp, iper, mini4, kbps; long long pts; uint8_t *i420; } Input;     /* pinned; key: this picture starts a closed GOP whatever the period says (GOP lanes,
                                                                                                  * QY265EncoderKeyFrameRequest); base_qp: the QP in force when the picture was handed in (QY265EncoderReconfig) -
                                                                                                  * iper: the key period in force then - all three travel WITH the picture: the scheduler thread
                                                                                                  * may be several pictures behind the caller */
@@ -317,6 +319,7 @@ typedef struct Enc {
     pthread_t disp; int disp_on; pthread_cond_t cv_disp; int next_ready, nwait;   /* the one thread that waits for GPU events (in submission order) */
     /* the scheduler thread: GOP decisions + every GPU enqueue of a picture (some thirty runtime calls) happen here, not on the caller's thread */
     pthread_t sched; int sched_on; pthread_cond_t cv_sched, cv_sched_done; int sched_seen, sched_flush, sched_idle, sched_err;
+    int dev_err; long dev_err_seq;                        /* sticky device error of the lane (dispatcher), and how many pictures had been submitted when it was seen */
     struct WorkerArg { struct Enc *e; int idx; } warg[64];
     /* output */
     QY265Nal nals[4 * MAX_JOBS + 8]; uint8_t *hdr; long hdr_len, hdr_part[3];
@@ -328,6 +331,7 @@ typedef struct Enc {
 #define RC_LAG 16
 #define RC_HIST 512
     double rc_sum_norm, rc_hist[RC_HIST]; long rc_acc_seq, rc_sub; int rc_acc_idx; int rc_qp_delta;
+    double rc_sum_budget, rc_bhist[RC_HIST], rc_sum_real, rc_rhist[RC_HIST];   /* the budget and the bits really produced, summed picture by picture like rc_sum_norm */
 } Enc;
 
 static double now_ms(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e3 + t.tv_nsec * 1e-6; }
@@ -370,6 +374,11 @@ static void *dispatcher(void *arg)
         if (err) logf_(2, e->log_level, "ks265enc: device error at picture %d: %s\n", j->disp, "intra wavefront timeout or device error flag (ks265_take_device_error)");
         j->t_event = now_ms();
         pthread_mutex_lock(&e->mu);
+        /* the error word does not say WHICH picture raised it: it may be one enqueued after this one (a key picture running ahead on its own stream), and every picture
+         * predicted from a broken reconstruction is broken too.  So the error sticks to the lane: this picture and all that were already submitted when it was seen fail,
+         * and so does everything after them up to the first key picture (IDR: a closed GOP) submitted later */
+        if (err && !e->dev_err) { e->dev_err = err; e->dev_err_seq = e->rc_sub; }
+        else if (!err && e->dev_err) { if (j->kind == 'I' && j->sub_seq >= e->dev_err_seq) e->dev_err = 0; else err = e->dev_err; }
         j->ev_err = err;
         e->next_ready = (e->next_ready + 1) % e->ring; --e->nwait; ++e->npending;
         pthread_cond_broadcast(&e->cv_work);
@@ -517,6 +526,9 @@ static void rc_account(Enc *e)
         if (!j->used || !j->done) break;
         e->rc_sum_norm += (double)(j->nal_len > 0 ? j->nal_len : 0) * 8.0 * exp2((double)j->rc_delta / 6.0);
         e->rc_hist[e->rc_acc_seq % RC_HIST] = e->rc_sum_norm;
+        e->rc_sum_budget += j->rc_budget; e->rc_bhist[e->rc_acc_seq % RC_HIST] = e->rc_sum_budget;      /* per picture at the bitrate it was handed in with: a later
+                                                                                                           * QY265EncoderReconfig does not re-price the past */
+        e->rc_sum_real += (double)(j->nal_len > 0 ? j->nal_len : 0) * 8.0; e->rc_rhist[e->rc_acc_seq % RC_HIST] = e->rc_sum_real;
         e->rc_acc_idx = (e->rc_acc_idx + 1) % e->ring; ++e->rc_acc_seq;
     }
 }
@@ -534,9 +546,13 @@ static int rc_decide(Enc *e)
     }
     int d = e->rc_qp_delta;
     if (need >= 4 && !e->quit) {
-        const double spent = e->rc_hist[(need - 1) % RC_HIST], budget = (double)need * e->cfg.bitrateInkbps * 1000.0 / e->cfg.frameRate;
+        const double spent = e->rc_hist[(need - 1) % RC_HIST], budget = e->rc_bhist[(need - 1) % RC_HIST], real = e->rc_rhist[(need - 1) % RC_HIST];
         if (spent > 0 && budget > 0) {
-            int want = (int)lrint(6.0 * log2(spent / budget));
+            /* model term: what the stream costs at the base QP against the budget, 6 QP steps per octave; feedback term: the bits really produced so far against the
+             * budget so far (half weight, at most 2 steps) - where the content's rate does not halve every 6 steps the model term alone settles beside the target */
+            double fb = need >= 32 && real > 0 ? 3.0 * log2(real / budget) : 0.0;
+            fb = fb > 2.0 ? 2.0 : fb < -2.0 ? -2.0 : fb;
+            int want = (int)lrint(6.0 * log2(spent / budget) + fb);
             if (want > d + 4) want = d + 4;
             if (want < d - 4) want = d - 4;
             d = want < -51 ? -51 : want > 51 ? 51 : want;
@@ -675,6 +691,7 @@ static int submit(Enc *e, Input *in, int kind, int poc, int qp, const int *l0, i
     if (r) return hip_rc(r);
     ++e->seq;
     j->disp = in->disp; j->pts = in->pts; j->poc = poc; j->kind = kind; j->qp = qp; j->is_ref = is_ref; j->key_headers = key_headers; j->rc_delta = e->rc_qp_delta;
+    j->rc_budget = (double)in->kbps * 1000.0 / (e->cfg.frameRate > 0 ? e->cfg.frameRate : 25.0);
     j->nal_type = kind == 'I' ? KS265_NAL_IDR_W_RADL : is_ref ? KS265_NAL_TRAIL_R : KS265_NAL_TRAIL_N;
     j->nl0 = nl0; j->nl1 = nl1;
     for (int i = 0; i < nl0; ++i) j->l0[i] = l0[i];
@@ -695,6 +712,7 @@ static int submit(Enc *e, Input *in, int kind, int poc, int qp, const int *l0, i
     pthread_mutex_lock(&e->mu);
     in->used = 2;                                                      /* released when the job's event has fired (output time); under the lock: the caller counts the pictures in flight */
     j->done = 0; j->error = 0; j->used = 1; j->started = 0; j->nrows = 0; j->next_row = 0; j->rows_done = 0;
+    j->sub_seq = e->rc_sub;
     e->job_tail = (e->job_tail + 1) % e->ring; ++e->njobs; ++e->nwait; ++e->rc_sub;
     e->st.occ_samples++; e->st.occ_ring += e->njobs; e->st.occ_gpu += e->nwait; e->st.occ_ready += e->npending;
     pthread_cond_signal(&e->cv_disp);
@@ -1107,6 +1125,19 @@ static Enc *lane_open(QY265EncConfig *cfg, int device, int multi, int *err)
     if (getenv("KS265_INPUT_SLOTS")) e->nin = atoi(getenv("KS265_INPUT_SLOTS"));
     if (e->nin < e->ring + 32) e->nin = e->ring + 32;
     if (e->nin > MAX_INPUT) e->nin = MAX_INPUT;
+    {   /* pinned host memory is a machine-wide resource: a lane's input slots stay under KS265_PINNED_MB (default 4096 MB; the ring + one mini-GOP is the floor).  At 2160p
+         * a slot is 12.4 MB: ring + 32 = 132 slots = 1.6 GB; a GOP lane at -iper 128 asks for 260 = 3.2 GB; eight GPUs with two lanes each = 52 GB without the cap */
+        const char *pm = getenv("KS265_PINNED_MB");
+        const long long budget = (pm ? atoll(pm) : 4096) * 1048576LL;
+        const int fit = (int)(budget / (long long)fsz);
+        if (e->nin > fit && fit >= e->ring + 32) {
+            logf_(1, e->log_level, "ks265enc: %d input slots of %.1f MB would pin %.1f GB per lane: %d slots (KS265_PINNED_MB=%lld)\n", e->nin, fsz / 1048576.0, e->nin * (double)fsz / 1073741824.0, fit, budget / 1048576LL);
+            e->nin = fit;
+        } else if (e->nin > fit) {
+            logf_(1, e->log_level, "ks265enc: the ring + one mini-GOP (%d input slots, %.1f GB pinned) is above KS265_PINNED_MB=%lld and is the floor\n", e->ring + 32, (e->ring + 32) * (double)fsz / 1073741824.0, budget / 1048576LL);
+            e->nin = e->ring + 32;
+        }
+    }
     for (int i = 0; i < e->nin && !r; ++i) r = ks265_host_malloc(e->ctx, (void **)&e->in[i].i420, fsz);
     if (r) { *err = hip_rc(r); lane_close(e, 0); return NULL; }
     memset(&e->scfg, 0, sizeof e->scfg);
@@ -1205,6 +1236,8 @@ static int lane_put(Enc *e, QY265Picture *in, int key)
     int own = 0;                                                       /* the caller wrote the picture into a slot it had acquired (ks265_enc_acquire_input): nothing to copy */
     for (int i = 0; i < e->nin && !slot; ++i) if (e->in[i].used == 4 && e->in[i].i420 == in->yuv->pData[0]) { slot = &e->in[i]; own = 1; }
     for (int i = 0; i < e->nin && !slot; ++i) if (!e->in[i].used) slot = &e->in[i];
+    for (int i = 0; i < e->nin && !slot; ++i) if (e->in[i].used == 4) slot = &e->in[i];   /* last resort: a buffer the caller acquired and did not use for this picture - copy into it
+                                                                                            * (the caller's pointer to it is dead from here on, as after any EncodeFrame call) */
     if (slot) slot->used = 3;                                          /* being filled */
     pthread_mutex_unlock(&e->mu);
     if (!slot) return QY_FAIL;                                         /* one lane: cannot happen (more input slots than pictures in flight + one mini-GOP); lanes: the caller checked lane_has_slot */
@@ -1273,7 +1306,7 @@ static int lane_put(Enc *e, QY265Picture *in, int key)
         if (cut || key || e->force_key || nd == 0 || periodic) e->la_last_key = nd;
     }
     slot->mini4 = mini4;
-    slot->disp = e->next_disp++; slot->pts = in->pts; slot->key = key || e->force_key || cut; slot->base_qp = e->base_qp; slot->iper = e->iper; slot->used = 1;
+    slot->disp = e->next_disp++; slot->pts = in->pts; slot->key = key || e->force_key || cut; slot->base_qp = e->base_qp; slot->iper = e->iper; slot->kbps = e->cfg.bitrateInkbps; slot->used = 1;
     e->force_key = 0;
     pthread_cond_signal(&e->cv_sched);                                 /* the scheduler thread takes it from here */
     pthread_mutex_unlock(&e->mu);
@@ -1379,11 +1412,13 @@ typedef struct Top {
     TopWake wake;
 } Top;
 
-static int lane_has_slot(Enc *e)
+/* is there room for the picture whose first plane is `data`?  A slot in the caller's hands (4: ks265_enc_acquire_input) counts only if THIS picture is the one that was
+ * produced into it - a caller may acquire a buffer and then hand in its own, or the picture may be routed to another lane */
+static int lane_has_slot(Enc *e, const uint8_t *data)
 {
     int ok = 0;
     pthread_mutex_lock(&e->mu);
-    for (int i = 0; i < e->nin && !ok; ++i) ok = !e->in[i].used || e->in[i].used == 4;     /* (4: in the caller's hands, ks265_enc_acquire_input - it comes back with the next picture) */
+    for (int i = 0; i < e->nin && !ok; ++i) ok = !e->in[i].used || (e->in[i].used == 4 && e->in[i].i420 == data);
     pthread_mutex_unlock(&e->mu);
     return ok;
 }
@@ -1555,7 +1590,10 @@ void *QY265EncoderOpen(QY265EncConfig *cfg, int *err)
     /* every lane runs four streams (pixel path, key pictures, copy-in, copy-out); the runtime deals streams to FOUR hardware queues unless told otherwise, and a lane's
      * 27 ms key-picture kernel in the queue of another lane's pixel path stops that lane for as long (measured: 615 -> 686 pictures/s with eight queues, two lanes,
      * 2160p).  Only effective when this is the process's first use of the runtime; a value the user has set stays. */
-    if (t->nlanes > 1) setenv("GPU_MAX_HW_QUEUES", "8", 0);
+    if (t->nlanes > 1 && !getenv("GPU_MAX_HW_QUEUES")) {
+        setenv("GPU_MAX_HW_QUEUES", "8", 0);
+        logf_(1, cfg->logLevel, "ks265enc: GPU_MAX_HW_QUEUES=8 set for this process (several GOP lanes; effective if the HIP runtime has not started yet; set it yourself to override)\n");
+    }
     QY265EncConfig lc = *cfg;
     if (t->nlanes > 1) {                                                /* the writer threads are shared out: every lane sees 1 / L of the pictures */
         long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
@@ -1660,7 +1698,7 @@ int QY265EncoderEncodeFrame(void *h, QY265Nal **pNals, int *iNalCount, QY265Pict
         }
         Enc *e = t->lane[t->cur_lane];
         const double t0 = now_ms();
-        while (!lane_has_slot(e)) {                                     /* this lane is as far ahead as its buffers allow: finish older GOPs first */
+        while (!lane_has_slot(e, in->yuv ? in->yuv->pData[0] : NULL)) {                                     /* this lane is as far ahead as its buffers allow: finish older GOPs first */
             r = top_collect(t, 1, out);
             if (r) return r;
         }

@@ -70,3 +70,18 @@ def subme_knobs(preset: str) -> dict:
 # THE tool set of the encoder host at -preset slow (host/ks265_enc.c: encoder_open) - bench.py, __graft_entry__.smoke(), the GPU tests and tools/rd_eval.py --host all
 # import this one dict, so that what is timed is what is tested.
 ENCODER_TOOLS = dict(me_method=2, me_hex_thr=16, sdh=1, pre_search=1, merge=1, bi_refine=1, rdo=4, intra_inter=1, propagate=1, **subme_knobs("slow"))
+
+
+# the encoder host's QP ladders at -rc 0 (host/ks265_enc.c kIpppCascade / kHierLayerQp = the reference's own, read from its -psnr 2 lines): the QP of a picture is the
+# key picture's + host_qp_offset(...).  bench.py's hot-path leg, tests/stream_cases.py and tools/rd_eval.py --host use these.
+HOST_IPPP_CASCADE = (0, 2, 1, 2)
+HOST_HIER_LAYER_QP = (0, 1, 3, 3)
+
+
+def host_qp_offset(kind: str, pos_in_gop: int = 0, layer: int = 0, hier: bool = False) -> int:
+    """kind 'I' / 'P' / 'B'; IPPP: pos_in_gop = the P picture's position behind its key picture; hierarchy: layer 0 = anchors, 1..3 = B layers; plain B: + 2"""
+    if kind == "I":
+        return 0
+    if hier:
+        return 1 + HOST_HIER_LAYER_QP[min(layer, 3)]
+    return 2 if kind == "B" else 1 + HOST_IPPP_CASCADE[pos_in_gop & 3]

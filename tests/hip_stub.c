@@ -34,7 +34,13 @@ int ks265_create(ks265_ctx **out, int device)
 }
 void ks265_destroy(ks265_ctx *c) { if (c) { free(c->ops); free(c); } }
 int ks265_synchronize(ks265_ctx *c) { (void)c; return KS265_OK; }
-int ks265_take_device_error(ks265_ctx *c) { (void)c; return KS265_OK; }
+int ks265_take_device_error(ks265_ctx *c)                              /* KS265_STUB_DEVERR_AT = k: the k-th call finds the device error word set (once), like a wavefront time-out */
+{
+    static int n, at = -2;
+    (void)c;
+    if (at == -2) { const char *e = getenv("KS265_STUB_DEVERR_AT"); at = e ? atoi(e) : -1; }
+    return at >= 0 && __atomic_fetch_add(&n, 1, __ATOMIC_RELAXED) == at ? KS265_FAIL : KS265_OK;
+}
 int ks265_dev_malloc(ks265_ctx *c, void **p, size_t n) { (void)c; *p = calloc(1, n ? n : 1); return *p ? KS265_OK : KS265_OUTOFMEMORY; }
 int ks265_dev_free(ks265_ctx *c, void *p) { (void)c; free(p); return KS265_OK; }
 int ks265_host_malloc(ks265_ctx *c, void **p, size_t n) { return ks265_dev_malloc(c, p, n); }

@@ -87,7 +87,7 @@ def case_lambda(name: str, q: int, kind: str) -> int:
     return lambda_q4(q, inter=name.startswith("enc_") and kind != "I")
 
 
-HOST_IPPP_CASCADE = (0, 2, 1, 2)      # ks265_enc.c kIpppCascade: the QP of an IPPP P picture is the key picture's + 1 + this, by its position in the GOP (the reference's 30 / 29 / 30 / 28 at -qp 27)
+from ks265codec_amd.synth import HOST_IPPP_CASCADE      # ks265_enc.c kIpppCascade: the QP of an IPPP P picture is the key picture's + 1 + this, by its position in the GOP (the reference's 30 / 29 / 30 / 28 at -qp 27)
 
 
 def schedule(kind: str, par: int):

@@ -115,6 +115,32 @@ def test_device_failure_is_reported_not_hung(stub_lib, lanes, at):
     assert r.get("error") == 0x80000001 and r["at"] <= (at + 40 if lanes == 1 else 100), r
 
 
+@pytest.mark.parametrize("bframes", [0, -1])
+def test_device_error_word_sticks_until_the_next_key_picture(stub_lib, tmp_path, bframes):
+    """ks265_take_device_error (a wavefront time-out on the GPU) does not say which picture raised it, and every picture predicted from a broken one is broken: after the
+    error is seen NO picture goes out until a key picture submitted later starts a clean GOP; a caller that keeps feeding pictures after QY_FAIL gets the
+    failure for every such picture, then a stream that starts again with an IDR and decodes"""
+    out = tmp_path / "e.265"
+    clean = run(stub_lib, 200, 32, bframes)
+    r = run(stub_lib, 200, 32, bframes, out=out, KS265_STUB_DEVERR_AT=9, KS_TEST_CONTINUE_ON_ERROR=1)
+    assert r["errors"] >= 1
+    order = clean["pts"]                                         # coding order of the clean run
+    lost = [p for p in order if p not in set(r["pts"])]
+    assert lost, "the failed picture did not go out"
+    first = order.index(lost[0])
+    # from the first lost picture on (coding order) nothing goes out until a key picture, and from that key picture on everything does (how far the caller had run
+    # ahead when the error was seen decides WHICH key picture: all pictures submitted by then fail)
+    resumed = [p for p in order[first:] if p in set(r["pts"])]
+    if resumed:
+        assert resumed[0] % 32 == 0, resumed[:4]
+        k = order.index(resumed[0])
+        assert order[k:] == r["pts"][len(r["pts"]) - len(order[k:]):], "the stream is not whole after the restart"
+        assert all(p not in set(r["pts"]) for p in order[first:k])
+    if os.path.exists(REF_DEC):
+        d = subprocess.run([REF_DEC, "-b", str(out), "-o", str(tmp_path / "d.yuv"), "-threads", "1"], capture_output=True, text=True, cwd=tmp_path)
+        assert "decoder passed" in d.stdout, d.stdout[-300:]
+
+
 @pytest.mark.parametrize("lanes,bframes", [(1, 0), (2, 0), (1, -1)])
 def test_close_without_flush(stub_lib, lanes, bframes):
     """QY265EncoderClose while pictures are waiting for the scheduler, in flight and half written: every thread is joined, nothing hangs"""
