@@ -225,7 +225,10 @@ __device__ __forceinline__ void me_group(const KsGeom &g, int cx, int cy, int ra
         // ---- all lanes of the group: one lane = one 8x8 tile of one candidate; NI items per lane are in flight together (their LDS
         //      round trips - stub, descriptor, table entry, window rows, result slot - overlap instead of queueing behind each other)
         const int items = njobs << l2t;
-        constexpr int NI = 1;
+#ifndef KS_ME_NI
+#define KS_ME_NI 1
+#endif
+        constexpr int NI = KS_ME_NI;
         for (int base = 0; base < items; base += NT * NI) {
             int pu[NI], x[NI], y[NI], key[NI], slot[NI], kk[NI];
             bool live[NI];

@@ -1570,7 +1570,13 @@ static int top_lanes_wanted(const QY265EncConfig *cfg, int ndev)
     if (per < 1) per = 1;
     int n = per * ndev;
     if (n > MAX_LANES) n = MAX_LANES;
-    if (!cfg->enFrameParallel || cfg->rc != 0 || cfg->iIntraPeriod < 32 || g_cli.md5) n = 1;    /* the controllers carry state across GOPs; -md5 lines are in one display order */
+    /* closed GOPs share no pixel; what a rate-control mode shares across GOPs decides whether they can be dealt to lanes:
+     *   rc 0 (constant QP) and rc 3 (CRF = a constant ladder on crf): nothing - the lanes' stream is byte for byte the one-lane stream;
+     *   rc 1 / 2 / 4 (bitrate targets): the controller's state.  With lanes every lane runs its OWN controller on the GOPs dealt to it, each picture carrying the same
+     *   budget share (bitrate / frame rate, rc_account): the host-side bit-budget split of SURVEY.md 8(e) - a scalar per picture, no exchange between GPUs.  The
+     *   stream is deterministic for a given lane count but not the one-lane stream (a lane's offset follows the GOPs it has seen), which the open logs;
+     *   rc 5 / VBV are not implemented at all.  -md5 lines are in one display order: one lane. */
+    if (!cfg->enFrameParallel || cfg->rc < 0 || cfg->rc > 4 || cfg->iIntraPeriod < 32 || g_cli.md5) n = 1;
     if (cfg->lookahead > 0) n = 1;                                   /* a scene cut restarts the key period: GOP boundaries are not known when the pictures are dealt to lanes */
     return n;
 }
@@ -1585,7 +1591,9 @@ void *QY265EncoderOpen(QY265EncConfig *cfg, int *err)
     int dev[MAX_LANES];
     const int ndev = top_devices(dev);
     t->nlanes = top_lanes_wanted(cfg, ndev);
-    if (ndev > 1 && t->nlanes == 1) logf_(2, cfg->logLevel, "ks265enc: %d GPUs asked for, but GOP sharding needs enFrameParallel, -rc 0 and a key period >= 32: one GPU\n", ndev);
+    if (ndev > 1 && t->nlanes == 1) logf_(2, cfg->logLevel, "ks265enc: %d GPUs asked for, but GOP sharding needs enFrameParallel, -rc 0..4, no -lookahead / -md5 and a key period >= 32: one GPU\n", ndev);
+    if (t->nlanes > 1 && (cfg->rc == 1 || cfg->rc == 2 || cfg->rc == 4))
+        logf_(1, cfg->logLevel, "ks265enc: -rc %d over %d GOP lanes: every lane runs its own controller with the same per-picture bit budget (deterministic, not the one-lane stream)\n", cfg->rc, t->nlanes);
     t->iper = cfg->iIntraPeriod; t->cur_lane = -1;
     /* every lane runs four streams (pixel path, key pictures, copy-in, copy-out); the runtime deals streams to FOUR hardware queues unless told otherwise, and a lane's
      * 27 ms key-picture kernel in the queue of another lane's pixel path stops that lane for as long (measured: 615 -> 686 pictures/s with eight queues, two lanes,
