@@ -48,6 +48,7 @@ int ks265_frame_create(ks265_ctx *ctx, const ks265_frame_cfg *cfg, ks265_frame *
     if (!r && cfg->intra_inter) {                                  /* intra candidates of P / B pictures: cost and mode of every block */
         r = dev_alloc(ctx, (void **)&f->icost, (size_t)geom.ctu_cols * geom.ctu_rows * 85 * sizeof(uint32_t), true);
     }
+    if (!r && cfg->part) r = dev_alloc(ctx, &f->rect, (size_t)geom.ctu_cols * geom.ctu_rows * 21 * sizeof(KsRect), true);
     if (!r) r = dev_alloc(ctx, (void **)&f->cu8, (size_t)geom.bytes_cu8, true);
     if (!r && cfg->merge) r = dev_alloc(ctx, (void **)&f->cu8_tmp, (size_t)geom.bytes_cu8, true);
     if (!r) r = dev_alloc(ctx, (void **)&f->sao, (size_t)geom.bytes_sao, true);
@@ -73,7 +74,7 @@ void ks265_frame_destroy(ks265_frame *f)
     if (f->ctx) { (void)hipSetDevice(f->ctx->device); (void)hipStreamSynchronize(f->ctx->stream); }
     for (int i = 0; i <= KS_NSTAGE; ++i)
         if (f->ev[i]) (void)hipEventDestroy(f->ev[i]);
-    void *ptrs[] = {f->pu1, f->pu_s, f->pub, f->pu[0], f->pu[1], f->cu8, f->sao, f->lvl[0], f->lvl[1], f->lvl[2], f->deb[0], f->deb[1], f->deb[2], f->sse, f->sse_acc, f->cu8_tmp, f->progress, f->mats, f->icost, f->pu_x[0], f->pu_x[1], f->pu_x[2]};
+    void *ptrs[] = {f->pu1, f->pu_s, f->pub, f->pu[0], f->pu[1], f->cu8, f->sao, f->lvl[0], f->lvl[1], f->lvl[2], f->deb[0], f->deb[1], f->deb[2], f->sse, f->sse_acc, f->cu8_tmp, f->progress, f->mats, f->icost, f->rect, f->pu_x[0], f->pu_x[1], f->pu_x[2]};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (uint8_t *p : f->pyr)
@@ -135,10 +136,11 @@ int ks265_encode_picture(ks265_frame *f, ks265_pic src, ks265_pic ref, int is_ke
         const bool ii = f->cfg.intra_inter != 0;              /* intra CUs may compete: their candidates first */
         if (ii && (r = ks265_intra_candidates(f, src, pu, f->icost))) return r;
         mark(3);
+        const bool part = f->cfg.part != 0;                    /* -part 1: the halves of every 64 / 32 / 16 CU priced first, the CU decision then picks among 2Nx2N / 2NxN / Nx2N / split */
         if (f->cfg.merge) {                                    /* stage C2: the CU decision goes to the spare map, the merge pass writes the final one */
-            if ((r = ks265_cu_decide_ii(f, pu, ii ? f->icost : nullptr, f->cu8_tmp))) return r;
+            if ((r = part ? ks265_cu_decide_part(f, src, ref, pu, ii ? f->icost : nullptr, f->cu8_tmp) : ks265_cu_decide_ii(f, pu, ii ? f->icost : nullptr, f->cu8_tmp))) return r;
             if ((r = ks265_merge_pass(f, src, ref, ks265_pic{nullptr, nullptr, nullptr}, pu, nullptr, f->cu8_tmp, f->cu8))) return r;
-        } else if ((r = ks265_cu_decide_ii(f, pu, ii ? f->icost : nullptr, f->cu8))) return r;
+        } else if ((r = part ? ks265_cu_decide_part(f, src, ref, pu, ii ? f->icost : nullptr, f->cu8) : ks265_cu_decide_ii(f, pu, ii ? f->icost : nullptr, f->cu8))) return r;
         mark(4);
         if ((r = ks265_reconstruct(f, src, ref, f->cu8, f->lvl[0], f->lvl[1], f->lvl[2], deb))) return r;
         mark(5);

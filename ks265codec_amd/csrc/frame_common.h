@@ -8,6 +8,9 @@
 #define KS_NSTAGE 8                   // me_integer, me_subpel, intra_candidates, cu_decide (+ merge pass), reconstruct, intra_pass, deblock, sao (+ padding)
 
 // geometry handed to kernels by value
+// cfg.part: what a CU of 64 / 32 / 16 samples costs in two halves (ks265_rect_decide): [0] = 2NxN (top, bottom), [1] = Nx2N (left, right); cost KS_COST_INVALID = not considered
+struct KsRect { unsigned cost[2]; short mv[2][2][2]; };
+
 struct KsGeom {
     int W, H;                 // luma size
     int sy, sc;               // strides
@@ -40,6 +43,7 @@ struct ks265_frame {
     unsigned long long *sse_acc = nullptr;   // ks265_sse_picture: three running sums + finished work-groups (zero between calls)
     short *mats = nullptr;              // forward + transposed DCT matrices of all sizes in the kernels' LDS layout (2 x MAT_SHORTS)
     int *progress = nullptr;            // intra wavefront: CTUs finished per CTU row
+    void *rect = nullptr;                                  // cfg.part: the 2NxN / Nx2N records of the P picture being coded (KsRect, 21 per CTU)
     uint32_t *icost = nullptr;                             // cfg.intra_inter: intra candidates of the P / B picture being coded (85 per CTU: cost << 6 | mode)
     uint8_t *pyr[10] = {};              // pre-search (cfg.pre_search): L1 / L2 of the source, L1 / L2 of the reference, L2 / L1 vectors, the 16x16 field, L3 of both, CTU window offsets
     // optional in-situ stage timing (HIP events on the context's stream, between the stages of ks265_encode_picture)

@@ -415,9 +415,9 @@ __global__ __launch_bounds__(256) void intra_recon_kernel(KsGeom g, int qp, cons
             const ks265_cu8 cu = L.cu[ly * 8 + lx];
             if (cu.log2_cu == 0) continue;                          // outside the picture
             if (PMODE && cu.pred_mode != 2) continue;               // an inter CU: reconstructed already
-            const int n8 = 1 << (cu.log2_cu - 3);
+            const int n8 = 1 << ((cu.log2_cu & 15) - 3);
             if ((lx & (n8 - 1)) || (ly & (n8 - 1))) continue;
-            const int n = 8 * n8, log2 = cu.log2_cu;
+            const int n = 8 * n8, log2 = cu.log2_cu & 15;
             c.mode = cu.mvx; c.lx = lx; c.ly = ly; c.x0 = cx * 64 + lx * 8; c.y0 = cy * 64 + ly * 8;
             c.filt = intra_filter_flag(c.mode, n);
             if (n == 32) {

@@ -11,12 +11,12 @@ using namespace ks265;
 
 __device__ __forceinline__ int edge_bs(const ks265_cu8 p, const ks265_cu8 q, int pos8)
 {
-    const int cu8n = 1 << (q.log2_cu - 3), tu8n = min(cu8n, 4);
+    const int part = q.log2_cu >> 4, cu8n = 1 << ((q.log2_cu & 15) - 3), tu8n = min(part ? cu8n >> 1 : cu8n, 4);   // a CU in two partitions (cfg.part) holds four transform units
     const bool tu_edge = (pos8 % tu8n) == 0, cu_edge = (pos8 % cu8n) == 0;
     if (!tu_edge && !cu_edge) return 0;
     if (p.pred_mode != 0 || q.pred_mode != 0) return 2;
     if (tu_edge && ((p.cbf | q.cbf) & 1)) return 1;
-    if (cu_edge) {
+    if (cu_edge || part) {                                   // a prediction-block edge: the CU's border, or the TU edges inside a CU in two partitions (equal vectors: nothing fires)
         // CalcBsInterP enc@0x402960 / CalcBsInterB enc@0x4029d0 with one picture per list
         if (p.inter_dir != q.inter_dir) return 1;
         if ((p.inter_dir & 1) && (abs((int)p.mvx - (int)q.mvx) >= 4 || abs((int)p.mvy - (int)q.mvy) >= 4)) return 1;

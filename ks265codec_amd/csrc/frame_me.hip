@@ -442,11 +442,12 @@ extern "C" int ks265_me_subpel(ks265_frame *f, ks265_pic src, ks265_pic ref, ks2
 // cfg.intra_inter: ibest (85 per CTU from ks265_intra_candidates: cost << 6 | mode, all ones = none; else null) - a block's intra pre-selection cost + lambda x KS_INTRA_BIAS_BITS competes with
 // its inter cost (oracle: node_own_cost)
 #define KS_INTRA_BIAS_BITS 96
+#define KS_PART_BITS 6                                              // what a CU in two partitions costs beyond its halves (the oracle's PART_BITS)
 template <typename REC>
-__global__ __launch_bounds__(64) void cu_decide_kernel(KsGeom g, int lam, const REC *pus, ks265_cu8 *cu8, const unsigned *ibest)
+__global__ __launch_bounds__(64) void cu_decide_kernel(KsGeom g, int lam, const REC *pus, ks265_cu8 *cu8, const unsigned *ibest, const KsRect *rect)
 {
     __shared__ unsigned bestc[85];
-    __shared__ unsigned char split[85], use_intra[85];
+    __shared__ unsigned char split[85], use_intra[85], part[85];
     const int t = threadIdx.x, ctu = blockIdx.x, cx = ctu % g.ctu_cols, cy = ctu / g.ctu_cols;
     const REC *cp = pus + (long)ctu * 85;
     const unsigned pen = (unsigned)((lam * (std::is_same<REC, ks265_pu_b>::value ? KS_SPLIT_BITS_B : KS_SPLIT_BITS_P)) >> 4);
@@ -455,7 +456,13 @@ __global__ __launch_bounds__(64) void cu_decide_kernel(KsGeom g, int lam, const 
         for (int i = t; i < n * n; i += 64) {
             const int px = i & (n - 1), py = i >> l, idx = ks_level_base(l) + i;
             const int x0 = cx * 64 + px * s, y0 = cy * 64 + py * s;
-            unsigned own = cp[idx].cost, res; unsigned char sp = 0, ui = 0;
+            unsigned own = cp[idx].cost, res; unsigned char sp = 0, ui = 0, pm = 0;
+            if (rect && l < 3) {                                     // cfg.part: 2NxN, then Nx2N, each only if strictly cheaper
+                const KsRect rr = rect[(long)ctu * 21 + idx];
+                if (rr.cost[0] < own) { own = rr.cost[0]; pm = 1; }
+                if (rr.cost[1] < own) { own = rr.cost[1]; pm = 2; }
+            }
+            part[idx] = pm;
             if (ibest && l > 0) {
                 const unsigned v = ibest[(long)ctu * 85 + idx];
                 if (v != 0xFFFFFFFFu) {
@@ -486,7 +493,15 @@ __global__ __launch_bounds__(64) void cu_decide_kernel(KsGeom g, int lam, const 
     ks265_cu8 c;
     c.mvx = p.mvx; c.mvy = p.mvy; c.log2_cu = (uint8_t)(6 - l); c.cbf = 0; c.pred_mode = 0;
     if constexpr (std::is_same<REC, ks265_pu_b>::value) { c.mv1x = p.mv1x; c.mv1y = p.mv1y; c.inter_dir = (uint8_t)p.inter_dir; }
-    else { c.mv1x = 0; c.mv1y = 0; c.inter_dir = 1; }
+    else {
+        c.mv1x = 0; c.mv1y = 0; c.inter_dir = 1;
+        const int pm = rect ? part[pidx] : 0;
+        if (pm && !use_intra[pidx]) {                                // this block's half of the CU: 2NxN by its row, Nx2N by its column
+            const KsRect rr = rect[(long)ctu * 21 + pidx];
+            const int hf = pm == 1 ? (by >> (2 - l)) & 1 : (bx >> (2 - l)) & 1;
+            c.mvx = rr.mv[pm - 1][hf][0]; c.mvy = rr.mv[pm - 1][hf][1]; c.log2_cu = (uint8_t)((6 - l) | (pm << 4));
+        }
+    }
     if (use_intra[pidx]) { c.mvx = (int16_t)(ibest[(long)ctu * 85 + pidx] & 63u); c.mvy = 0; c.mv1x = 0; c.mv1y = 0; c.pred_mode = 2; c.inter_dir = 0; }    // an intra CU: mvx = its luma mode
     cu8[(long)(Y >> 3) * g.w8 + (X >> 3)] = c;
 }
@@ -509,7 +524,7 @@ extern "C" int ks265_cu_decide_ii(ks265_frame *f, const ks265_pu *pu, const uint
 {
     KS_FRAME_CHECK(f);
     if (!pu || !cu8) return KS265_POINTER;
-    hipLaunchKernelGGL(cu_decide_kernel<ks265_pu>, dim3(f->g.ctu_cols * f->g.ctu_rows), dim3(64), 0, f->ctx->stream, f->g, f->cfg.lambda_q4, pu, cu8, ibest);
+    hipLaunchKernelGGL(cu_decide_kernel<ks265_pu>, dim3(f->g.ctu_cols * f->g.ctu_rows), dim3(64), 0, f->ctx->stream, f->g, f->cfg.lambda_q4, pu, cu8, ibest, (const KsRect *)nullptr);
     return ks265_check_launch(f->ctx);
 }
 extern "C" int ks265_cu_decide(ks265_frame *f, const ks265_pu *pu, ks265_cu8 *cu8) { return ks265_cu_decide_ii(f, pu, nullptr, cu8); }
@@ -518,7 +533,7 @@ extern "C" int ks265_cu_decide_b_ii(ks265_frame *f, const ks265_pu_b *pub, const
 {
     KS_FRAME_CHECK(f);
     if (!pub || !cu8) return KS265_POINTER;
-    hipLaunchKernelGGL(cu_decide_kernel<ks265_pu_b>, dim3(f->g.ctu_cols * f->g.ctu_rows), dim3(64), 0, f->ctx->stream, f->g, f->cfg.lambda_q4, pub, cu8, ibest);
+    hipLaunchKernelGGL(cu_decide_kernel<ks265_pu_b>, dim3(f->g.ctu_cols * f->g.ctu_rows), dim3(64), 0, f->ctx->stream, f->g, f->cfg.lambda_q4, pub, cu8, ibest, (const KsRect *)nullptr);
     return ks265_check_launch(f->ctx);
 }
 extern "C" int ks265_cu_decide_b(ks265_frame *f, const ks265_pu_b *pub, ks265_cu8 *cu8) { return ks265_cu_decide_b_ii(f, pub, nullptr, cu8); }
@@ -729,6 +744,111 @@ extern "C" int ks265_bi_decide(ks265_frame *f, ks265_pic src, ks265_pic ref0, ks
     return ks265_check_launch(f->ctx);
 }
 
+// ------------------------------------------------------------------ cfg.part: the halves of every 64 / 32 / 16 CU of a P picture (-part 1: 2NxN / Nx2N)
+// The reference searches every rectangular PU on its own inside its RD loop (closed code); the frame-parallel form prices each half with the vectors the square search
+// already refined for this area: the CU's own and those of the half's two quarter-size PUs, by Hadamard cost of the half's prediction + rate against the CU's predictor,
+// first strict minimum in that order (the oracle's rect_eval).  One work-group per CTU, wave = CU level (0 .. 2), lane = 8x8 tile in z-order: a tile needs its SATD under
+// four vectors - the CU's (P), its own quarter's (O) and those of the quarter's horizontal (H) and vertical (V) neighbour; quarter sums by DPP, the neighbour quarters'
+// sums by two lane exchanges; equal vectors share their SATD.
+__device__ __forceinline__ unsigned satd8x8_one(const unsigned (&f)[16], const unsigned (&A)[16])
+{
+    int d[64];
+#pragma unroll
+    for (int w = 0; w < 16; ++w)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) d[w * 4 + i] = (int)((f[w] >> (8 * i)) & 255) - (int)((A[w] >> (8 * i)) & 255);
+    return satd8x8_regs(d);
+}
+__global__ __launch_bounds__(192) void rect_eval_kernel(KsGeom g, int lam, const uint8_t *src, const uint8_t *ref, const ks265_pu *pus, KsRect *rect)
+{
+    const int tid = threadIdx.x, lane = tid & 63, l = tid >> 6;                  // l = level of the CU (0: 64, 1: 32, 2: 16)
+    const int ctu = ks_xcd_swizzle(blockIdx.x, g.ctu_cols * g.ctu_rows), cx = ctu % g.ctu_cols, cy = ctu / g.ctu_cols;
+    const int tx = (lane & 1) | ((lane >> 1) & 2) | ((lane >> 2) & 4), ty = ((lane >> 1) & 1) | ((lane >> 2) & 2) | ((lane >> 3) & 4);
+    const int x0 = cx * 64 + tx * 8, y0 = cy * 64 + ty * 8;
+    const int cux = tx >> (3 - l), cuy = ty >> (3 - l), qx = (tx >> (2 - l)) & 1, qy = (ty >> (2 - l)) & 1;
+    const int pidx = ks_level_base(l) + cuy * (1 << l) + cux;
+    const ks265_pu *cp = pus + (long)ctu * 85;
+    const ks265_pu P = cp[pidx];
+    const bool valid = P.cost != KS_COST_INVALID;                                // the CU lies inside the picture, and so do its quarters
+    const int cb = ks_level_base(l + 1), cw = 2 << l;
+    const ks265_pu cO = cp[cb + (2 * cuy + qy) * cw + 2 * cux + qx], cH = cp[cb + (2 * cuy + qy) * cw + 2 * cux + (qx ^ 1)], cV = cp[cb + (2 * cuy + (qy ^ 1)) * cw + 2 * cux + qx];
+    const int vP = valid ? ((int)(unsigned short)P.mvx | ((int)P.mvy << 16)) : 0;
+    const int vO = valid && cO.cost != KS_COST_INVALID ? ((int)(unsigned short)cO.mvx | ((int)cO.mvy << 16)) : vP;
+    const int vH = valid && cH.cost != KS_COST_INVALID ? ((int)(unsigned short)cH.mvx | ((int)cH.mvy << 16)) : vP;
+    const int vV = valid && cV.cost != KS_COST_INVALID ? ((int)(unsigned short)cV.mvx | ((int)cV.mvy << 16)) : vP;
+    unsigned f[16];
+    {
+        const uint8_t *frow = ks_org_y(g, src) + (long)(valid ? y0 : cy * 64) * g.sy + (valid ? x0 : cx * 64);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { const uint2 v = *(const uint2 *)(frow + (long)r * g.sy); f[2 * r] = v.x; f[2 * r + 1] = v.y; }
+    }
+    const long base = (long)(valid ? y0 : 0) * g.sy + (valid ? x0 : 0) + g.org_y;
+    auto tile = [&](int v) { unsigned A[16]; luma_pred_tile8(ref + base, g.sy, (int)(short)(v & 0xFFFF), v >> 16, A); return satd8x8_one(f, A); };
+    unsigned sP = 0, sO = 0, sH = 0, sV = 0;
+    if (__any(valid)) {
+        sP = tile(vP);
+        sO = sP; sH = sP; sV = sP;
+        if (__any(vO != vP)) { const unsigned t = tile(vO); if (vO != vP) sO = t; }
+        if (__any(vH != vP && vH != vO)) { const unsigned t = tile(vH); if (vH != vP && vH != vO) sH = t; }
+        if (vH == vO) sH = sO;
+        if (__any(vV != vP && vV != vO && vV != vH)) { const unsigned t = tile(vV); if (vV != vP && vV != vO && vV != vH) sV = t; }
+        if (vV == vO) sV = sO; else if (vV == vH && vV != vP) sV = sH;
+    }
+    if (!valid) { sP = sO = sH = sV = 0; }
+    // sums over this tile's quarter (= a PU of level l + 1), then the two neighbour quarters' sums
+    const unsigned qP = pu_group_sum(sP, l + 1), qO = pu_group_sum(sO, l + 1), qH = pu_group_sum(sH, l + 1), qV = pu_group_sum(sV, l + 1);
+    const int gq = 1 << (2 * (2 - l));                                              // lanes per quarter: 16, 4, 1
+    const unsigned hP = (unsigned)__shfl_xor((int)qP, gq, 64), hO = (unsigned)__shfl_xor((int)qO, gq, 64), hH = (unsigned)__shfl_xor((int)qH, gq, 64);
+    const unsigned wP = (unsigned)__shfl_xor((int)qP, 2 * gq, 64), wO = (unsigned)__shfl_xor((int)qO, 2 * gq, 64), wV = (unsigned)__shfl_xor((int)qV, 2 * gq, 64);
+    const int px = P.mvpx, py = P.mvpy;
+    auto rate = [&](int v) { return (unsigned)mv_cost((int)(short)(v & 0xFFFF), v >> 16, px, py, lam); };
+    // this lane's half of each orientation: candidates in the order CU vector, first quarter's, second quarter's (2NxN: quarters (0, qy), (1, qy); Nx2N: (qx, 0), (qx, 1))
+    unsigned best[2]; int bv[2];
+    {
+        const unsigned cP = qP + hP + rate(vP), cMe = qO + hH + rate(vO), cNb = qH + hO + rate(vH);      // 2NxN: the half = my quarter + its horizontal neighbour
+        const unsigned c0 = qx ? cNb : cMe, c1 = qx ? cMe : cNb; const int v0 = qx ? vH : vO, v1 = qx ? vO : vH;
+        best[0] = cP; bv[0] = vP;
+        if (c0 < best[0]) { best[0] = c0; bv[0] = v0; }
+        if (c1 < best[0]) { best[0] = c1; bv[0] = v1; }
+    }
+    {
+        const unsigned cP = qP + wP + rate(vP), cMe = qO + wV + rate(vO), cNb = qV + wO + rate(vV);      // Nx2N: my quarter + its vertical neighbour
+        const unsigned c0 = qy ? cNb : cMe, c1 = qy ? cMe : cNb; const int v0 = qy ? vV : vO, v1 = qy ? vO : vV;
+        best[1] = cP; bv[1] = vP;
+        if (c0 < best[1]) { best[1] = c0; bv[1] = v0; }
+        if (c1 < best[1]) { best[1] = c1; bv[1] = v1; }
+    }
+    // the other half: 2NxN = the quarters below / above (vertical neighbour), Nx2N = the horizontal neighbour
+    const unsigned ob0 = (unsigned)__shfl_xor((int)best[0], 2 * gq, 64), ob1 = (unsigned)__shfl_xor((int)best[1], gq, 64);
+    const int ov0 = __shfl_xor(bv[0], 2 * gq, 64), ov1 = __shfl_xor(bv[1], gq, 64);
+    const int G = 1 << (2 * (3 - l));
+    if (valid && (lane & (G - 1)) == 0) {                                         // the CU's first tile: quarter (0, 0) = first half of both orientations
+        KsRect o;
+        const unsigned long long pen = (unsigned long long)((lam * KS_PART_BITS) >> 4);
+        const unsigned long long t0 = (unsigned long long)best[0] + ob0 + pen, t1 = (unsigned long long)best[1] + ob1 + pen;
+        o.cost[0] = (bv[0] != vP || ov0 != vP) ? (t0 > 0xFFFFFFFEull ? 0xFFFFFFFEu : (unsigned)t0) : KS_COST_INVALID;      // considered only if a half moves off the CU's vector
+        o.cost[1] = (bv[1] != vP || ov1 != vP) ? (t1 > 0xFFFFFFFEull ? 0xFFFFFFFEu : (unsigned)t1) : KS_COST_INVALID;
+        o.mv[0][0][0] = (short)(bv[0] & 0xFFFF); o.mv[0][0][1] = (short)(bv[0] >> 16); o.mv[0][1][0] = (short)(ov0 & 0xFFFF); o.mv[0][1][1] = (short)(ov0 >> 16);
+        o.mv[1][0][0] = (short)(bv[1] & 0xFFFF); o.mv[1][0][1] = (short)(bv[1] >> 16); o.mv[1][1][0] = (short)(ov1 & 0xFFFF); o.mv[1][1][1] = (short)(ov1 >> 16);
+        rect[(long)ctu * 21 + pidx] = o;
+    } else if (!valid && (lane & (G - 1)) == 0) {
+        KsRect o; o.cost[0] = o.cost[1] = KS_COST_INVALID;
+        for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) { o.mv[a][b][0] = 0; o.mv[a][b][1] = 0; }
+        rect[(long)ctu * 21 + pidx] = o;
+    }
+}
+
+extern "C" int ks265_cu_decide_part(ks265_frame *f, ks265_pic src, ks265_pic ref, const ks265_pu *pu, const uint32_t *ibest, ks265_cu8 *cu8)
+{
+    KS_FRAME_CHECK(f);
+    if (!src.y || !ref.y || !pu || !cu8) return KS265_POINTER;
+    if (!f->rect) return KS265_NOTSUPPORTED;                                      // the frame object was created without cfg.part
+    const int nctu = f->g.ctu_cols * f->g.ctu_rows;
+    hipLaunchKernelGGL(rect_eval_kernel, dim3(nctu), dim3(192), 0, f->ctx->stream, f->g, f->cfg.lambda_q4, src.y, ref.y, pu, (KsRect *)f->rect);
+    hipLaunchKernelGGL(cu_decide_kernel<ks265_pu>, dim3(nctu), dim3(64), 0, f->ctx->stream, f->g, f->cfg.lambda_q4, pu, cu8, ibest, (const KsRect *)f->rect);
+    return ks265_check_launch(f->ctx);
+}
+
 // ------------------------------------------------------------------ Stage C2: merge pass (cfg.merge)
 // The reference decides merge / skip per CU against the candidates of already coded neighbours (GetMergeCandsFor*, skipFastDecision; closed code).
 // A frame-parallel decision has no coded neighbours: this pass works on the motion field the CU decision left behind.  Every CU looks at its five
@@ -753,7 +873,7 @@ __device__ __forceinline__ MergeMotion merge_cand(const KsGeom &g, const ks265_c
     const int ctb = (y >> 6) * g.ctu_cols + (x >> 6), nctb = (ny >> 6) * g.ctu_cols + (nx >> 6);
     if (nctb > ctb || (nctb == ctb && z_of_8(nx, ny) >= z_of_8(x, y))) return m;
     const ks265_cu8 c = cu_in[(long)(ny >> 3) * g.w8 + (nx >> 3)];
-    if (c.pred_mode != 0 || c.log2_cu < 3) return m;
+    if (c.pred_mode != 0 || (c.log2_cu & 15) < 3) return m;
     m.dir = c.inter_dir & 3; m.mvx = c.mvx; m.mvy = c.mvy; m.mv1x = c.mv1x; m.mv1y = c.mv1y; m.ok = true;
     // a neighbour's vector may come from a CTU with another window offset: taken over here it must keep this CU's block inside the planes' margin
     if ((m.dir & 1) && (x + (m.mvx >> 2) < -70 || x + (m.mvx >> 2) + n > g.W + 70 || y + (m.mvy >> 2) < -70 || y + (m.mvy >> 2) + n > g.H + 70)) m.ok = false;
@@ -772,11 +892,11 @@ __global__ __launch_bounds__(256) void merge_pass_kernel(KsGeom g, int lam, cons
     ks265_cu8 c;
     c.mvx = c.mvy = c.mv1x = c.mv1y = 0; c.log2_cu = 0; c.cbf = 0; c.pred_mode = 1; c.inter_dir = 0;
     if (inside) c = cu_in[(long)(y0 >> 3) * g.w8 + (x0 >> 3)];
-    const int log2 = c.log2_cu >= 3 ? c.log2_cu : 3, n = 1 << log2, cux = x0 & ~(n - 1), cuy = y0 & ~(n - 1), level = 6 - log2;
+    const int log2 = (c.log2_cu & 15) >= 3 ? (c.log2_cu & 15) : 3, n = 1 << log2, cux = x0 & ~(n - 1), cuy = y0 & ~(n - 1), level = 6 - log2;
     const int leader = lane & ~((1 << (2 * (log2 - 3))) - 1);
     const long rb = (long)ctu * 85 + ks_level_base(level) + ((cuy & 63) >> log2) * (1 << level) + ((cux & 63) >> log2);
     const unsigned cur = is_b ? pub[rb].cost : pu[rb].cost;
-    const bool valid = inside && c.pred_mode == 0 && c.log2_cu >= 3 && cur != KS_COST_INVALID;
+    const bool valid = inside && c.pred_mode == 0 && (c.log2_cu & 15) >= 3 && !(c.log2_cu >> 4) && cur != KS_COST_INVALID;      // (a CU in two partitions keeps its partitions' vectors)
     if (tid < 64) jbest[tid] = ~0ull;
     // which candidates exist for this tile's CU (every tile of a CU computes the same mask)
     unsigned mask = 0;

@@ -378,7 +378,7 @@ __global__ __launch_bounds__(256) void reconstruct_kernel(KsGeom g, int qp, cons
         c.mvx = 0; c.mvy = 0; c.mv1x = 0; c.mv1y = 0; c.log2_cu = 0; c.cbf = 0; c.pred_mode = 0; c.inter_dir = 0;
         if (bx < g.w8 && by < g.h8) c = cu8[(long)by * g.w8 + bx];
         blk[tid] = c;
-        tu_log2[tid] = (unsigned char)(c.log2_cu ? min((int)c.log2_cu - 3, 2) : 0);
+        tu_log2[tid] = (unsigned char)(c.log2_cu ? min((int)(c.log2_cu & 15) - 3 - (c.log2_cu >> 4 ? 1 : 0), 2) : 0);     // TU = min(CU, 32); a CU in two partitions (cfg.part): four TUs (interSplitFlag)
         cbf[tid] = 0;
     }
     __syncthreads();

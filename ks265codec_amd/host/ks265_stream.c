@@ -431,6 +431,14 @@ static int avail_z(const Enc *e, int xc, int yc, int xn, int yn)
     return zaddr(e, xn, yn) <= zaddr(e, xc, yc);
 }
 
+/* 6.4.2: availability for a prediction block at (xp, yp) of the coding block (xc, yc, cs): a location inside the same coding block belongs to the partition decoded
+ * before this one and is available (the N x N exception does not arise: inter CUs here are 2Nx2N, 2NxN or Nx2N); everything else by z-scan order from (xp, yp) */
+static int avail_pb(const Enc *e, int xc, int yc, int cs, int xp, int yp, int xn, int yn)
+{
+    if (xn >= xc && xn < xc + cs && yn >= yc && yn < yc + cs) return !(xn >= xp && yn >= yp);      /* same coding block: the earlier partition only */
+    return avail_z(e, xp, yp, xn, yn);
+}
+
 /* ------------------------------------------------------------------ SAO syntax (7.3.8.3) */
 static void sao_offsets(Enc *e, const ks265_sao_param *p)
 {
@@ -648,14 +656,14 @@ static int nb_cand(const Enc *e, const ks265_cu8 *b, int listx, int target_poc, 
     }
     return 0;
 }
-static void amvp(const Enc *e, int x, int y, int size, int listx, int ref_idx, int cand[2][2])
+static void amvp(const Enc *e, int xc, int yc, int cs, int x, int y, int w, int h, int listx, int ref_idx, int cand[2][2])      /* (xc, yc, cs): the coding block; (x, y, w, h): the prediction block */
 {
     const int target = ref_poc(e, listx, ref_idx);
-    const int nbx[5] = {x - 1, x - 1, x + size, x + size - 1, x - 1}, nby[5] = {y + size, y + size - 1, y - 1, y - 1, y - 1};   /* A0 A1 B0 B1 B2 */
+    const int nbx[5] = {x - 1, x - 1, x + w, x + w - 1, x - 1}, nby[5] = {y + h, y + h - 1, y - 1, y - 1, y - 1};   /* A0 A1 B0 B1 B2 */
     int av[5];
     const ks265_cu8 *nb[5];
     for (int k = 0; k < 5; ++k) {
-        av[k] = avail_z(e, x, y, nbx[k], nby[k]);
+        av[k] = avail_pb(e, xc, yc, cs, x, y, nbx[k], nby[k]);
         nb[k] = av[k] ? cu_at(e, nbx[k], nby[k]) : NULL;
         if (av[k] && is_intra(nb[k])) av[k] = 0;
     }
@@ -694,12 +702,15 @@ static int same_motion(const Motion *a, const Motion *b)
     return 1;
 }
 #define MAX_MERGE 5
-static int merge_candidates(const Enc *e, int x, int y, int size, Motion cand[MAX_MERGE])
+/* (x, y, w, h): the prediction block; part / part_idx: of a CU in two partitions the second one may not merge back into the first (8.5.3.2.3: A1 is out for Nx2N,
+ * B1 for 2NxN) - merging both would be the 2Nx2N CU */
+static int merge_candidates(const Enc *e, int xc, int yc, int cs, int x, int y, int w, int h, int part, int part_idx, Motion cand[MAX_MERGE])
 {
-    const int nx[5] = {x - 1, x + size - 1, x + size, x - 1, x - 1}, ny[5] = {y + size - 1, y - 1, y - 1, y + size, y - 1};   /* A1 B1 B0 A0 B2 */
+    const int nx[5] = {x - 1, x + w - 1, x + w, x - 1, x - 1}, ny[5] = {y + h - 1, y - 1, y - 1, y + h, y - 1};   /* A1 B1 B0 A0 B2 */
     Motion m[5]; int av[5];
     for (int k = 0; k < 5; ++k) {
-        av[k] = avail_z(e, x, y, nx[k], ny[k]);
+        av[k] = avail_pb(e, xc, yc, cs, x, y, nx[k], ny[k]);
+        if (part_idx == 1 && ((part == 2 && k == 0) || (part == 1 && k == 1))) av[k] = 0;
         if (av[k]) { const ks265_cu8 *b = cu_at(e, nx[k], ny[k]); if (is_intra(b)) av[k] = 0; else blk_motion_all(b, &m[k]); }
     }
     /* pruning compares with the neighbouring BLOCK (available and inter), whether or not that block made it into the list itself */
@@ -786,14 +797,16 @@ static int coding_unit(Enc *e, int x, int y, int log2)
     Cabac *c = &e->c;
     const ks265_cu8 *cu = cu_at(e, x, y);
     const int size = 1 << log2, intra = is_intra(cu), st = e->in->slice_type;
+    const int part = intra ? 0 : (cu->log2_cu >> 4) & 3;             /* 0 = 2Nx2N, 1 = 2NxN, 2 = Nx2N (ks265_frame_cfg.part): two prediction units, four transform units */
     if (cu->pred_mode == 1) return KS265_NOTSUPPORTED;               /* the flat-128 stand-in is not an HEVC prediction mode */
     if (intra && log2 > 5) return KS265_NOTSUPPORTED;
+    if (part > 2 || (part && log2 < 4)) return KS265_NOTSUPPORTED;   /* (an 8x8 CU in two partitions would need vectors per 8x4 block) */
     int merge_idx = -1;
     if (st != KS265_SLICE_I) {
         int skip = 0;
-        if (!intra) {
+        if (!intra && !part) {
             Motion cand[MAX_MERGE], mine;
-            const int n = merge_candidates(e, x, y, size, cand);
+            const int n = merge_candidates(e, x, y, size, x, y, size, size, 0, 0, cand);
             blk_motion_all(cu, &mine);
             for (int k = 0; k < n && merge_idx < 0; ++k) if (same_motion(&mine, &cand[k])) merge_idx = k;
             int any = cu->cbf & 7;
@@ -813,7 +826,8 @@ static int coding_unit(Enc *e, int x, int y, int log2)
         }
         cb_bin(c, CX_PRED_MODE, intra);
     } else if (!intra) return KS265_NOTSUPPORTED;
-    if (!intra || log2 == 3) cb_bin(c, CX_PART_MODE, 1);             /* part_mode: PART_2Nx2N */
+    if (part) { cb_bin(c, CX_PART_MODE, 0); cb_bin(c, CX_PART_MODE + 1, part == 1); }   /* part_mode (9.3.3.7, no AMP, above the minimum CU size): 2NxN = 01, Nx2N = 00 */
+    else if (!intra || log2 == 3) cb_bin(c, CX_PART_MODE, 1);        /* PART_2Nx2N */
     if (intra) {
         const int mode = cu->mvx;
         /* most probable modes (8.4.2) */
@@ -844,16 +858,27 @@ static int coding_unit(Enc *e, int x, int y, int log2)
         cb_bin(c, CX_CHROMA_PRED, 0);                                /* intra_chroma_pred_mode = 4: derived from luma */
         CAT(c, CAT_CU);
     } else {
+        for (int pi = 0; pi < (part ? 2 : 1); ++pi) {                /* prediction_unit(): 7.3.8.6 */
+        const int xp = x + (part == 2 && pi ? size >> 1 : 0), yp = y + (part == 1 && pi ? size >> 1 : 0), wp = part == 2 ? size >> 1 : size, hp = part == 1 ? size >> 1 : size;
+        const ks265_cu8 *pc = cu_at(e, xp, yp);
+        int midx = merge_idx;
+        if (part) {                                                  /* does this partition's motion equal one of ITS merge candidates? */
+            Motion cand[MAX_MERGE], mine;
+            const int n = merge_candidates(e, x, y, size, xp, yp, wp, hp, part, pi, cand);
+            blk_motion_all(pc, &mine);
+            midx = -1;
+            for (int k = 0; k < n && midx < 0; ++k) if (same_motion(&mine, &cand[k])) midx = k;
+        }
         CAT(c, CAT_MERGE);
-        cb_bin(c, CX_MERGE_FLAG, merge_idx >= 0);
-        const int dir = cu->inter_dir & 3;
-        if (merge_idx >= 0) {
-            cb_bin(c, CX_MERGE_IDX, merge_idx > 0);
-            for (int k = 1; k < MAX_MERGE - 1 && k <= merge_idx; ++k) cb_bypass(c, merge_idx > k);
+        cb_bin(c, CX_MERGE_FLAG, midx >= 0);
+        const int dir = pc->inter_dir & 3;
+        if (midx >= 0) {
+            cb_bin(c, CX_MERGE_IDX, midx > 0);
+            for (int k = 1; k < MAX_MERGE - 1 && k <= midx; ++k) cb_bypass(c, midx > k);
         } else {
         CAT(c, CAT_MOTION);
         if (st == KS265_SLICE_B) {
-            /* inter_pred_idc: nPbW + nPbH != 12 always (2Nx2N, >= 8x8) */
+            /* inter_pred_idc: nPbW + nPbH != 12 always (prediction blocks of at least 16x8 / 8x16 / 8x8) */
             const int depth = 6 - log2;
             cb_bin(c, CX_INTER_DIR + depth, dir == 3);
             if (dir != 3) cb_bin(c, CX_INTER_DIR + 4, dir == 2);
@@ -861,7 +886,7 @@ static int coding_unit(Enc *e, int x, int y, int log2)
         for (int l = 0; l < 2; ++l) {
             if (!(dir & (1 << l))) continue;
             const int nact = l ? e->in->num_l1 : e->in->num_l0;
-            const int ri = l ? 0 : (cu->inter_dir >> 4);
+            const int ri = l ? 0 : (pc->inter_dir >> 4);
             if (ri >= nact) return KS265_NOTSUPPORTED;
             if (nact > 1) {                                          /* ref_idx_lX: TR, cMax = nact - 1, two context bins then bypass */
                 for (int k = 0; k < nact - 1; ++k) {
@@ -871,32 +896,35 @@ static int coding_unit(Enc *e, int x, int y, int log2)
                 }
             }
             int cand[2][2];
-            amvp(e, x, y, size, l, ri, cand);
-            const int mvx = l ? cu->mv1x : cu->mvx, mvy = l ? cu->mv1y : cu->mvy;
+            amvp(e, x, y, size, xp, yp, wp, hp, l, ri, cand);
+            const int mvx = l ? pc->mv1x : pc->mvx, mvy = l ? pc->mv1y : pc->mvy;
             const int b0 = mvd_bits(mvx - cand[0][0]) + mvd_bits(mvy - cand[0][1]), b1 = mvd_bits(mvx - cand[1][0]) + mvd_bits(mvy - cand[1][1]);
             const int pick = b1 < b0;
             mvd_coding(c, mvx - cand[pick][0], mvy - cand[pick][1]);
             cb_bin(c, CX_MVP, pick);
         }
         }
+        }
         CAT(c, CAT_CU);
     }
-    /* transform tree (7.3.8.8): max_transform_hierarchy_depth = 0 -> one TU per CU, except 64x64 CUs (four 32x32 TUs, split inferred) */
-    if (log2 == 6) {
+    /* transform tree (7.3.8.8): max_transform_hierarchy_depth = 0 -> one TU per CU, except 64x64 CUs (four 32x32 TUs, split inferred: above the maximum TU size) and
+     * inter CUs in two partitions (four TUs of half the size: interSplitFlag, split inferred as well) */
+    if (log2 == 6 || part) {
+        const int hs = size >> 1;
         int any = 0, cby[4], ccb[4], ccr[4], acb = 0, acr = 0;
         for (int k = 0; k < 4; ++k) {
-            const ks265_cu8 *q = cu_at(e, x + (k & 1) * 32, y + (k >> 1) * 32);
+            const ks265_cu8 *q = cu_at(e, x + (k & 1) * hs, y + (k >> 1) * hs);
             cby[k] = q->cbf & 1; ccb[k] = (q->cbf >> 1) & 1; ccr[k] = (q->cbf >> 2) & 1;
             any |= q->cbf & 7; acb |= ccb[k]; acr |= ccr[k];
         }
-        if (merge_idx < 0) { cb_bin(c, CX_ROOT_CBF, any != 0); if (!any) return 0; }      /* rqt_root_cbf: inferred 1 for a merged 2Nx2N CU (which has residual, else it was skipped) */
+        if (merge_idx < 0 || part) { cb_bin(c, CX_ROOT_CBF, any != 0); if (!any) return 0; }      /* rqt_root_cbf: inferred 1 only for a merged 2Nx2N CU (which has residual, else it was skipped) */
         cb_bin(c, CX_CBF_CHROMA + 0, acb);
         cb_bin(c, CX_CBF_CHROMA + 0, acr);
         for (int k = 0; k < 4; ++k) {
             if (acb) cb_bin(c, CX_CBF_CHROMA + 1, ccb[k]);
             if (acr) cb_bin(c, CX_CBF_CHROMA + 1, ccr[k]);
             cb_bin(c, CX_CBF_LUMA + 0, cby[k]);                      /* trafoDepth 1 -> ctxInc 0 */
-            transform_unit(e, x + (k & 1) * 32, y + (k >> 1) * 32, 5, cby[k], ccb[k], ccr[k], 0, 0);
+            transform_unit(e, x + (k & 1) * hs, y + (k >> 1) * hs, log2 - 1, cby[k], ccb[k], ccr[k], 0, 0);
         }
         return 0;
     }
@@ -919,12 +947,12 @@ static int coding_quadtree(Enc *e, int x, int y, int log2)
     int split;
     if (x + size <= e->W && y + size <= e->H && log2 > 3) {
         const ks265_cu8 *cu = cu_at(e, x, y);
-        if (cu->log2_cu > log2 || cu->log2_cu < 3) return KS265_NOTSUPPORTED;
-        split = cu->log2_cu < log2;
+        if ((cu->log2_cu & 15) > log2 || (cu->log2_cu & 15) < 3) return KS265_NOTSUPPORTED;
+        split = (cu->log2_cu & 15) < log2;
         const int depth = 6 - log2;
         int inc = 0;
-        if (x > 0 && 6 - cu_at(e, x - 1, y)->log2_cu > depth) ++inc;
-        if (y > 0 && 6 - cu_at(e, x, y - 1)->log2_cu > depth) ++inc;
+        if (x > 0 && 6 - (cu_at(e, x - 1, y)->log2_cu & 15) > depth) ++inc;
+        if (y > 0 && 6 - (cu_at(e, x, y - 1)->log2_cu & 15) > depth) ++inc;
         cb_bin(c, CX_SPLIT_CU + inc, split);
     } else split = log2 > 3;
     if (!split) return coding_unit(e, x, y, log2);

@@ -11,6 +11,9 @@
 #define PAD_C 40
 #define PLANE_MARGIN 72              /* fractional planes are defined on [-72, W+72) x [-72, H+72) */
 #define COST_INVALID 0xFFFFFFFFu
+/* kso_cu8.log2_cu: bits 0..3 = log2 of the CU, bits 4..5 = inter partition (cfg->part): 0 = 2Nx2N, 1 = 2NxN, 2 = Nx2N (then the CU holds four TUs: interSplitFlag, H.265 7.4.9.8) */
+#define CU_LOG2(c) ((c)->log2_cu & 15)
+#define CU_PART(c) ((c)->log2_cu >> 4)
 
 static inline int imin(int a, int b) { return a < b ? a : b; }
 static inline int imax(int a, int b) { return a > b ? a : b; }
@@ -511,15 +514,67 @@ static uint32_t node_own_cost(const kso_frame_cfg *cfg, uint32_t inter, const ui
     if (inter == COST_INVALID || ic < inter) { use_intra[idx] = 1; return ic > 0xFFFFFFFEu ? 0xFFFFFFFEu : (uint32_t)ic; }
     return inter;
 }
-static uint32_t decide_node(const kso_frame_cfg *cfg, const kso_pu *cp, const uint32_t *icost, int cx, int cy, int l, int px, int py, uint8_t *split /*[85]*/, uint8_t *use_intra /*[85]*/)
+/* cfg->part (-part 1, qy265enc.h:131: 2NxN / Nx2N prediction units; slower, veryslow, placebo): a CU of 64 / 32 / 16 samples may be coded in two halves.  The
+ * reference searches every such PU on its own (motionSearchOneRef enc@0x483f40 per TPredUnit: the traces of tests/golden/subme.npz hold 64x32 .. 8x16 calls) inside its
+ * closed RD loop; the frame-parallel form prices each half with the vectors the square search already refined for this area - the CU's own 2Nx2N vector and the vectors of
+ * the half's two quarter-size PUs - by Hadamard cost of the half's prediction + rate against the CU's predictor, first strict minimum in that order.  A partition is
+ * considered when at least one half moves off the 2Nx2N vector; its cost = both halves + lambda x PART_BITS (part_mode bins, a second merge flag / reference, the CU's
+ * four transform units instead of one).  P pictures with one reference picture; 8x8 CUs are left whole (their halves would need vectors per 8x4 block). */
+#ifndef PART_BITS
+#define PART_BITS 6
+#endif
+typedef struct { uint32_t cost[2]; int16_t mv[2][2][2]; } rect_rec;     /* [orientation: 0 = 2NxN (top, bottom), 1 = Nx2N (left, right)][half][x, y]; cost COST_INVALID = not considered */
+typedef struct { const kso_frame_cfg *cfg; const kso_frame_geom *g; const uint8_t *S, *planes; } rect_ctx;
+static uint32_t rect_half_cost(const rect_ctx *rc, int x0, int y0, int w, int h, int mvx, int mvy, int px, int py)
+{
+    const long st = rc->g->stride_y;
+    const uint8_t *pl = org_y(rc->g, (uint8_t *)rc->planes + (long)((mvy & 3) * 4 + (mvx & 3)) * rc->g->bytes_y);
+    return ks265o_had(rc->S + (long)y0 * st + x0, pl + (long)(y0 + (mvy >> 2)) * st + x0 + (mvx >> 2), st, st, h, w) + (uint32_t)mv_cost(mvx, mvy, px, py, rc->cfg->lambda_q4);
+}
+static void rect_eval(const rect_ctx *rc, const kso_pu *cp, int cx, int cy, int l, int px, int py, rect_rec *out)
+{
+    const int s = 64 >> l, x0 = cx * 64 + px * s, y0 = cy * 64 + py * s;
+    const kso_pu *P = &cp[pu_index(l, px, py)];
+    out->cost[0] = out->cost[1] = COST_INVALID;
+    if (l > 2 || P->cost == COST_INVALID) return;
+    for (int o = 0; o < 2; ++o) {
+        uint64_t tot = (uint64_t)((rc->cfg->lambda_q4 * PART_BITS) >> 4);
+        int moved = 0;
+        for (int hf = 0; hf < 2; ++hf) {
+            const int hx = o ? x0 + hf * (s / 2) : x0, hy = o ? y0 : y0 + hf * (s / 2), w = o ? s / 2 : s, h = o ? s : s / 2;
+            /* the half's two quarter-size PUs: 2NxN half hf = children (0, hf), (1, hf); Nx2N half hf = children (hf, 0), (hf, 1) */
+            const kso_pu *c0 = &cp[pu_index(l + 1, px * 2 + (o ? hf : 0), py * 2 + (o ? 0 : hf))], *c1 = &cp[pu_index(l + 1, px * 2 + (o ? hf : 1), py * 2 + (o ? 1 : hf))];
+            int bx = P->mvx, by = P->mvy;
+            uint32_t best = rect_half_cost(rc, hx, hy, w, h, bx, by, P->mvpx, P->mvpy);
+            const kso_pu *cand[2] = {c0, c1};
+            for (int k = 0; k < 2; ++k) {
+                if (cand[k]->cost == COST_INVALID) continue;
+                const uint32_t c = rect_half_cost(rc, hx, hy, w, h, cand[k]->mvx, cand[k]->mvy, P->mvpx, P->mvpy);
+                if (c < best) { best = c; bx = cand[k]->mvx; by = cand[k]->mvy; }
+            }
+            moved |= bx != P->mvx || by != P->mvy;
+            out->mv[o][hf][0] = (int16_t)bx; out->mv[o][hf][1] = (int16_t)by;
+            tot += best;
+        }
+        if (moved) out->cost[o] = tot > 0xFFFFFFFEu ? 0xFFFFFFFEu : (uint32_t)tot;
+    }
+}
+static uint32_t decide_node(const kso_frame_cfg *cfg, const rect_ctx *rc, const kso_pu *cp, const uint32_t *icost, int cx, int cy, int l, int px, int py, uint8_t *split /*[85]*/, uint8_t *use_intra /*[85]*/,
+                            uint8_t *part /*[85]*/, rect_rec *rect /*[21]*/)
 {
     int s = 64 >> l, x0 = cx * 64 + px * s, y0 = cy * 64 + py * s;
     if (x0 >= cfg->width || y0 >= cfg->height) return 0;           /* not in the picture: nothing to code */
     int idx = pu_index(l, px, py);
-    uint32_t own = node_own_cost(cfg, cp[idx].cost, icost, idx, l, use_intra);
+    uint32_t inter = cp[idx].cost;
+    part[idx] = 0;
+    if (rc && l < 3) {
+        rect_eval(rc, cp, cx, cy, l, px, py, &rect[idx]);
+        for (int o = 0; o < 2; ++o) if (rect[idx].cost[o] < inter) { inter = rect[idx].cost[o]; part[idx] = (uint8_t)(o + 1); }
+    }
+    uint32_t own = node_own_cost(cfg, inter, icost, idx, l, use_intra);
     if (l == 3) { split[idx] = 0; return own; }
     uint64_t sum = (uint64_t)((cfg->lambda_q4 * SPLIT_BITS_P) >> 4); /* what three extra CUs cost beyond their own SATD + vector rate */
-    for (int k = 0; k < 4; ++k) sum += decide_node(cfg, cp, icost, cx, cy, l + 1, px * 2 + (k & 1), py * 2 + (k >> 1), split, use_intra);
+    for (int k = 0; k < 4; ++k) sum += decide_node(cfg, rc, cp, icost, cx, cy, l + 1, px * 2 + (k & 1), py * 2 + (k >> 1), split, use_intra, part, rect);
     if (own != COST_INVALID && (uint64_t)own <= sum) { split[idx] = 0; return own; }
     split[idx] = 1;
     return sum > 0xFFFFFFFEu ? 0xFFFFFFFEu : (uint32_t)sum;
@@ -533,33 +588,47 @@ static void emit_intra(const kso_frame_cfg *cfg, int x0, int y0, int s, int mode
             c->mvx = (int16_t)mode; c->mvy = 0; c->mv1x = 0; c->mv1y = 0; c->log2_cu = (uint8_t)(6 - l); c->cbf = 0; c->pred_mode = 2; c->inter_dir = 0;
         }
 }
-static void emit_node(const kso_frame_cfg *cfg, const kso_pu *cp, const uint8_t *imode, int cx, int cy, int l, int px, int py, const uint8_t *split, const uint8_t *use_intra, kso_cu8 *cu8)
+static void emit_node(const kso_frame_cfg *cfg, const kso_pu *cp, const uint8_t *imode, int cx, int cy, int l, int px, int py, const uint8_t *split, const uint8_t *use_intra,
+                      const uint8_t *part, const rect_rec *rect, kso_cu8 *cu8)
 {
     int s = 64 >> l, x0 = cx * 64 + px * s, y0 = cy * 64 + py * s, w8 = cfg->width / 8;
     if (x0 >= cfg->width || y0 >= cfg->height) return;
     int idx = pu_index(l, px, py);
     if (l < 3 && split[idx]) {
-        for (int k = 0; k < 4; ++k) emit_node(cfg, cp, imode, cx, cy, l + 1, px * 2 + (k & 1), py * 2 + (k >> 1), split, use_intra, cu8);
+        for (int k = 0; k < 4; ++k) emit_node(cfg, cp, imode, cx, cy, l + 1, px * 2 + (k & 1), py * 2 + (k >> 1), split, use_intra, part, rect, cu8);
         return;
     }
     if (use_intra[idx]) { emit_intra(cfg, x0, y0, s, imode[idx], l, cu8); return; }
+    const int pm = part ? part[idx] : 0;
     for (int by = 0; by < s / 8; ++by)
         for (int bx = 0; bx < s / 8; ++bx) {
             kso_cu8 *c = &cu8[(long)(y0 / 8 + by) * w8 + x0 / 8 + bx];
-            c->mvx = cp[idx].mvx; c->mvy = cp[idx].mvy; c->mv1x = 0; c->mv1y = 0; c->log2_cu = (uint8_t)(6 - l); c->cbf = 0; c->pred_mode = 0; c->inter_dir = 1;
+            c->mvx = cp[idx].mvx; c->mvy = cp[idx].mvy;
+            if (pm) { const int hf = pm == 1 ? by >= s / 16 : bx >= s / 16; c->mvx = rect[idx].mv[pm - 1][hf][0]; c->mvy = rect[idx].mv[pm - 1][hf][1]; }
+            c->mv1x = 0; c->mv1y = 0; c->log2_cu = (uint8_t)((6 - l) | (pm << 4)); c->cbf = 0; c->pred_mode = 0; c->inter_dir = 1;
         }
 }
-void kso_cu_decide_ii(const kso_frame_cfg *cfg, const kso_pu *pu, const uint32_t *icost, const uint8_t *imode, kso_cu8 *cu8)
+static void cu_decide_impl(const kso_frame_cfg *cfg, const rect_ctx *rc, const kso_pu *pu, const uint32_t *icost, const uint8_t *imode, kso_cu8 *cu8)
 {
     kso_frame_geom g; kso_frame_geometry(cfg, &g);
+#pragma omp parallel for collapse(2) schedule(dynamic, 1)
     for (int cy = 0; cy < g.ctu_rows; ++cy)
         for (int cx = 0; cx < g.ctu_cols; ++cx) {
             const long cb = (long)(cy * g.ctu_cols + cx) * 85;
-            uint8_t split[85], use_intra[85];
-            memset(split, 0, sizeof split); memset(use_intra, 0, sizeof use_intra);
-            decide_node(cfg, pu + cb, icost ? icost + cb : NULL, cx, cy, 0, 0, 0, split, use_intra);
-            emit_node(cfg, pu + cb, imode ? imode + cb : NULL, cx, cy, 0, 0, 0, split, use_intra, cu8);
+            uint8_t split[85], use_intra[85], part[85];
+            rect_rec rect[21];
+            memset(split, 0, sizeof split); memset(use_intra, 0, sizeof use_intra); memset(part, 0, sizeof part);
+            decide_node(cfg, rc, pu + cb, icost ? icost + cb : NULL, cx, cy, 0, 0, 0, split, use_intra, part, rect);
+            emit_node(cfg, pu + cb, imode ? imode + cb : NULL, cx, cy, 0, 0, 0, split, use_intra, part, rect, cu8);
         }
+}
+void kso_cu_decide_ii(const kso_frame_cfg *cfg, const kso_pu *pu, const uint32_t *icost, const uint8_t *imode, kso_cu8 *cu8) { cu_decide_impl(cfg, NULL, pu, icost, imode, cu8); }
+/* the CU decision of a P picture with cfg->part: needs the pixels (source, the reference's planes) for the halves' Hadamard costs */
+void kso_cu_decide_part(const kso_frame_cfg *cfg, kso_pic src, const uint8_t *planes, const kso_pu *pu, const uint32_t *icost, const uint8_t *imode, kso_cu8 *cu8)
+{
+    kso_frame_geom g; kso_frame_geometry(cfg, &g);
+    const rect_ctx rc = {cfg, &g, org_y(&g, src.y), planes};
+    cu_decide_impl(cfg, cfg->part ? &rc : NULL, pu, icost, imode, cu8);
 }
 void kso_cu_decide(const kso_frame_cfg *cfg, const kso_pu *pu, kso_cu8 *cu8) { kso_cu_decide_ii(cfg, pu, NULL, NULL, cu8); }
 
@@ -589,10 +658,10 @@ void kso_merge_pass(const kso_frame_cfg *cfg, kso_pic src, const uint8_t *planes
     for (int by = 0; by < h8; ++by)
         for (int bx = 0; bx < w8; ++bx) {
             const kso_cu8 *c = &cu_in[(long)by * w8 + bx];
-            if (c->pred_mode != 0 || c->log2_cu < 3) continue;
-            const int n = 1 << c->log2_cu, x = bx * 8, y = by * 8;
+            if (c->pred_mode != 0 || CU_LOG2(c) < 3 || CU_PART(c)) continue;                    /* (a CU in two partitions keeps the vectors of its partitions) */
+            const int n = 1 << CU_LOG2(c), x = bx * 8, y = by * 8;
             if ((x & (n - 1)) || (y & (n - 1))) continue;                         /* a CU is handled at its first 8x8 block */
-            const int cx = x >> 6, cy = y >> 6, l = 6 - c->log2_cu, idx = pu_index(l, (x & 63) >> c->log2_cu, (y & 63) >> c->log2_cu);
+            const int cx = x >> 6, cy = y >> 6, l = 6 - CU_LOG2(c), idx = pu_index(l, (x & 63) >> CU_LOG2(c), (y & 63) >> CU_LOG2(c));
             const long rb = (long)(cy * g.ctu_cols + cx) * 85 + idx;
             const uint32_t cur = (is_b ? pub[rb].cost : pu[rb].cost);
             if (cur == COST_INVALID) continue;
@@ -609,7 +678,7 @@ void kso_merge_pass(const kso_frame_cfg *cfg, kso_pic src, const uint8_t *planes
                     const int nctb = (ny[k] >> 6) * g.ctu_cols + (nx[k] >> 6);
                     if (nctb > ctb || (nctb == ctb && z_of(nx[k], ny[k]) >= zc)) continue;                              /* not yet coded when this CU is */
                     m = cu_in[(long)(ny[k] >> 3) * w8 + (nx[k] >> 3)];
-                    if (m.pred_mode != 0 || m.log2_cu < 3) continue;
+                    if (m.pred_mode != 0 || (m.log2_cu & 15) < 3) continue;
                 } else { memset(&m, 0, sizeof m); m.inter_dir = is_b ? 3 : 1; }
                 const int dir = m.inter_dir & 3;
                 /* a neighbour's vector may come from a CTU with another window offset: taken over here it must keep this CU's block inside the planes' margin */
@@ -911,8 +980,8 @@ static void reconstruct_impl(const kso_frame_cfg *cfg, kso_pic src, const kso_pi
     for (int by = 0; by < h8; ++by)
         for (int bx = 0; bx < w8; ++bx) {
             kso_cu8 *c = &cu8[(long)by * w8 + bx];
-            int n8 = 1 << (c->log2_cu - 3);
-            int tu8 = imin(n8, 4);                              /* TU = min(CU, 32) */
+            int n8 = 1 << (CU_LOG2(c) - 3);
+            int tu8 = imin(CU_PART(c) ? n8 >> 1 : n8, 4);       /* TU = min(CU, 32); a CU in two partitions: four TUs (interSplitFlag) */
             if ((bx % tu8) || (by % tu8)) continue;             /* visit each TU once, at its top-left 8x8 block */
             if (c->pred_mode == 2) continue;                    /* an intra CU of a P / B picture: coded afterwards from reconstructed neighbours (kso_intra_inter_reconstruct) */
             int n = tu8 * 8, x0 = bx * 8, y0 = by * 8, intra = c->pred_mode == 1;
@@ -1007,12 +1076,12 @@ void kso_ref_decide(const kso_frame_cfg *cfg, int nref, const kso_pu *const *pu,
  * horizontal ones (ctuDeblockFilterVer enc@0x403de0 / CtuDeblockFilterHorT enc@0x477200 do the same per CTU). */
 static int edge_bs(const kso_cu8 *p, const kso_cu8 *q, int pos8 /*edge position in 8-sample units along its normal*/)
 {
-    int cu8n = 1 << (q->log2_cu - 3), tu8n = imin(cu8n, 4);
+    int cu8n = 1 << (CU_LOG2(q) - 3), tu8n = imin(CU_PART(q) ? cu8n >> 1 : cu8n, 4);
     int tu_edge = (pos8 % tu8n) == 0, cu_edge = (pos8 % cu8n) == 0;
     if (!tu_edge && !cu_edge) return 0;
     if (p->pred_mode != 0 || q->pred_mode != 0) return 2;
     if (tu_edge && ((p->cbf | q->cbf) & 1)) return 1;
-    if (cu_edge) {
+    if (cu_edge || CU_PART(q)) {                        /* a prediction-block edge: the CU's border, or inside a CU in two partitions (its TU edges; where the vectors are equal nothing fires) */
         /* CalcBsInterP enc@0x402960 / CalcBsInterB enc@0x4029d0 with one picture per list: different reference sets, or any
          * used vector differing by a full sample */
         if (p->inter_dir != q->inter_dir) return 1;
@@ -1359,7 +1428,7 @@ static void intra_code_cu(const kso_frame_cfg *cfg, const kso_frame_geom *g, kso
     int W = cfg->width, H = cfg->height, w8 = W / 8, qp = cfg->qp, qpc = chroma_qp(qp);
     long sy = g->stride_y, sc = g->stride_c;
     kso_cu8 *c = &cu8[(long)by * w8 + bx];
-    int n = 1 << c->log2_cu, x0 = bx * 8, y0 = by * 8, mode = c->mvx, log2 = c->log2_cu, cbf = 0;
+    int n = 1 << CU_LOG2(c), x0 = bx * 8, y0 = by * 8, mode = c->mvx, log2 = CU_LOG2(c), cbf = 0;
     uint8_t raw[4 * 32 + 1], fil[4 * 32 + 1], pred[32 * 32];
     uint8_t *Ry = org_y(g, recon.y);
     intra_gather(Ry, sy, W, H, 0, x0, y0, n, raw + 2 * n);
@@ -1390,7 +1459,7 @@ void kso_intra_reconstruct(const kso_frame_cfg *cfg, kso_pic src, kso_cu8 *cu8, 
                 int lx = (z & 1) | ((z >> 1) & 2) | ((z >> 2) & 4), ly = ((z >> 1) & 1) | ((z >> 2) & 2) | ((z >> 3) & 4);
                 int bx = cx * 8 + lx, by = cy * 8 + ly;
                 if (bx >= w8 || by >= h8) continue;
-                int n8 = 1 << (cu8[(long)by * w8 + bx].log2_cu - 3);
+                int n8 = 1 << ((cu8[(long)by * w8 + bx].log2_cu & 15) - 3);
                 if ((lx % n8) || (ly % n8)) continue;                /* visit each CU once, at its first 8x8 block */
                 intra_code_cu(cfg, &g, src, cu8, bx, by, lvl_y, lvl_u, lvl_v, recon, 1);
             }
@@ -1408,7 +1477,7 @@ void kso_intra_inter_reconstruct(const kso_frame_cfg *cfg, kso_pic src, kso_cu8 
                 int bx = cx * 8 + lx, by = cy * 8 + ly;
                 if (bx >= w8 || by >= h8) continue;
                 if (cu8[(long)by * w8 + bx].pred_mode != 2) continue;
-                int n8 = 1 << (cu8[(long)by * w8 + bx].log2_cu - 3);
+                int n8 = 1 << ((cu8[(long)by * w8 + bx].log2_cu & 15) - 3);
                 if ((lx % n8) || (ly % n8)) continue;
                 intra_code_cu(cfg, &g, src, cu8, bx, by, lvl_y, lvl_u, lvl_v, recon, 0);
             }

@@ -19,7 +19,8 @@ extern "C" {
 
 typedef struct {
     int32_t width, height, qp, lambda_q4, me_range, me_method, subme, deblock, sao, beta_offset_div2, tc_offset_div2, bframes, refs, me_hex_thr, sdh, pre_search, merge, bi_refine, decimate, rdo, intra_inter, propagate,
-            sub_satd, sub_thr, sub_flat, sub_cap, sub_cap_step, sub_diag_fast;     /* the sub-pel refinement's knobs (Stage B, ks265_pipeline_oracle.c) */
+            sub_satd, sub_thr, sub_flat, sub_cap, sub_cap_step, sub_diag_fast,     /* the sub-pel refinement's knobs (Stage B, ks265_pipeline_oracle.c) */
+            part;                                                            /* -part 1: 2NxN / Nx2N partitions of 64 / 32 / 16 CUs in P pictures (kso_cu_decide_part) */
 } kso_frame_cfg;
 
 typedef struct {
@@ -50,6 +51,7 @@ void kso_me_propagate(const kso_frame_cfg *cfg, kso_pic src, kso_pic ref, const 
 void kso_me_subpel(const kso_frame_cfg *cfg, kso_pic src, const uint8_t *planes, kso_pu *pu);
 void kso_cu_decide(const kso_frame_cfg *cfg, const kso_pu *pu, kso_cu8 *cu8);
 void kso_cu_flat_intra(const kso_frame_cfg *cfg, kso_cu8 *cu8);
+void kso_cu_decide_part(const kso_frame_cfg *cfg, kso_pic src, const uint8_t *planes, const kso_pu *pu, const uint32_t *icost, const uint8_t *imode, kso_cu8 *cu8);
 /* cfg->intra_inter: the CU trees with intra candidates (icost / imode: 85 per CTU from kso_intra_candidates; NULL = none), and the intra CUs' reconstruction pass */
 void kso_cu_decide_ii(const kso_frame_cfg *cfg, const kso_pu *pu, const uint32_t *icost, const uint8_t *imode, kso_cu8 *cu8);
 void kso_cu_decide_b_ii(const kso_frame_cfg *cfg, const kso_pu_b *pub, const uint32_t *icost, const uint8_t *imode, kso_cu8 *cu8);

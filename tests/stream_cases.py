@@ -35,27 +35,34 @@ CASES = {
     "enc_ippp_416x240_umh": (416, 240, 27, 2, 16, 1, 1, "ippph", 4),      # ippph: IPPP with the encoder host's QP ladder (P pictures at + 1 + {0, 2, 1, 2}[position & 3])
     "enc_hierb4_416x240": (416, 240, 30, 1, 0, 1, 1, "hier", 4),
     "enc_ippp_1280x720_qp32": (1280, 720, 32, 1, 0, 1, 1, "ippph", 3),
+    # -part 1 (slower / veryslow / placebo): CUs of 64 / 32 / 16 in two 2NxN or Nx2N prediction units with four transform units; the rest as the C host runs it
+    "part_ippp_416x240_umh": (416, 240, 27, 2, 0, 1, 1, "ippph", 4),
+    "part_ippp_200x136_qp34": (200, 136, 34, 1, 0, 1, 1, "ippph", 4),
 }
 
 
+def case_part(name: str) -> int:
+    return 1 if name.startswith("part_") else 0
+
+
 def case_sdh(name: str) -> int:
-    return 1 if name.startswith(("sdh_", "ps_", "wpp_", "enc_")) else 0
+    return 1 if name.startswith(("sdh_", "ps_", "wpp_", "enc_", "part_")) else 0
 
 
 def case_ps(name: str) -> int:
-    return 1 if name.startswith(("ps_", "wpp_", "enc_")) else 0
+    return 1 if name.startswith(("ps_", "wpp_", "enc_", "part_")) else 0
 
 
 def case_wpp(name: str) -> int:
-    return 1 if name.startswith(("wpp_", "enc_")) else 0
+    return 1 if name.startswith(("wpp_", "enc_", "part_")) else 0
 
 
 def case_merge(name: str) -> int:
-    return 1 if name.startswith("enc_") else 0
+    return 1 if name.startswith(("enc_", "part_")) else 0
 
 
 def case_bir(name: str) -> int:
-    return 1 if name.startswith("enc_") else 0
+    return 1 if name.startswith(("enc_", "part_")) else 0
 
 
 def case_dec(name: str) -> int:
@@ -63,28 +70,28 @@ def case_dec(name: str) -> int:
 
 
 def case_rdo(name: str) -> int:
-    return 4 if name.startswith("enc_") else 0            # the C host: coefficient-group pruning (superseded the coefficient decimation of round 2)
+    return 4 if name.startswith(("enc_", "part_")) else 0            # the C host: coefficient-group pruning (superseded the coefficient decimation of round 2)
 
 
 def case_ii(name: str) -> int:
-    return (2 if "1280x720" in name else 1) if name.startswith("enc_") else 0   # the C host: intra CUs in P / B pictures (one case with 2 = 16x16 and 32x32 only)
+    return (2 if "1280x720" in name else 1) if name.startswith(("enc_", "part_")) else 0   # the C host: intra CUs in P / B pictures (one case with 2 = 16x16 and 32x32 only)
 
 
 def case_prop(name: str) -> int:
-    return 1 if name.startswith("enc_") else 0            # the C host: one round of vector propagation after every integer search (stage A2)
+    return 1 if name.startswith(("enc_", "part_")) else 0            # the C host: one round of vector propagation after every integer search (stage A2)
 
 
 def case_subme(name: str) -> dict:
     """the sub-pel knobs: the C host's (-preset slow: fast candidate sets judged by SAD) for the enc_ cases, -preset veryslow's (all 8 + 8 candidates judged by
     Hadamard) for the wpp_ cases, -preset medium's for the hierarchical ones, veryfast's for the rest"""
     from ks265codec_amd.synth import subme_knobs
-    return subme_knobs("slow" if name.startswith("enc_") else "veryslow" if name.startswith("wpp_") else "medium" if "hier" in name else "veryfast")
+    return subme_knobs("slower" if name.startswith("part_") else "slow" if name.startswith("enc_") else "veryslow" if name.startswith("wpp_") else "medium" if "hier" in name else "veryfast")
 
 
 def case_lambda(name: str, q: int, kind: str) -> int:
     """the C host prices P / B pictures with the inter table (HM's factor for pictures that are not key pictures)"""
     from ks265codec_amd.synth import lambda_q4
-    return lambda_q4(q, inter=name.startswith("enc_") and kind != "I")
+    return lambda_q4(q, inter=name.startswith(("enc_", "part_")) and kind != "I")
 
 
 from ks265codec_amd.synth import HOST_IPPP_CASCADE      # ks265_enc.c kIpppCascade: the QP of an IPPP P picture is the key picture's + 1 + this, by its position in the GOP (the reference's 30 / 29 / 30 / 28 at -qp 27)
@@ -145,7 +152,7 @@ def oracle_encoder(name: str):
     W, H, qp, me, thr, sao, df, kind, par = CASES[name]
     n = 1 + max(s[0] for s in schedule(kind, par))
     clip = make_clip(W, H, n, seed=len(name) * 7 + W, abc=(17, 23, 9))
-    o = OraclePipeline(W, H, qp, lambda_q4(qp), me_method=me, me_hex_thr=thr, sao=sao, deblock=df, sdh=case_sdh(name), pre_search=case_ps(name), merge=case_merge(name), bi_refine=case_bir(name), decimate=case_dec(name), rdo=case_rdo(name), intra_inter=case_ii(name), propagate=case_prop(name), **case_subme(name))
+    o = OraclePipeline(W, H, qp, lambda_q4(qp), me_method=me, me_hex_thr=thr, sao=sao, deblock=df, sdh=case_sdh(name), pre_search=case_ps(name), merge=case_merge(name), bi_refine=case_bir(name), decimate=case_dec(name), rdo=case_rdo(name), intra_inter=case_ii(name), propagate=case_prop(name), part=case_part(name), **case_subme(name))
     dpb = {}
 
     def encode(d, k, l0, l1, q):

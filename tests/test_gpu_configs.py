@@ -61,6 +61,21 @@ def test_config2_1080p_umh(ks):
     _ippp(ks, 1920, 1080, 27, 2, 3, seed=42, hex_thr=16)
 
 
+def test_config5_tool_set_1080p(ks):
+    """BASELINE config 5 = -preset veryslow: the tool set the reference resolves it to - UMH always (tME+0x368 = 0), -subme 2 judged by Hadamard, -part 1 (2NxN / Nx2N
+    partitions) - on top of the encoder host's tools, 1920x1080 key picture + two P pictures == oracle"""
+    from ks265codec_amd.synth import subme_knobs
+    tools = dict(ENCODER_TOOLS, part=1, **subme_knobs("veryslow"))
+    _ippp(ks, 1920, 1080, 27, 2, 3, seed=42, hex_thr=0, **tools)
+
+
+def test_config5_tool_set_2160p(ks):
+    """the same tool set at config 5's own size, 3840x2160 (key picture + one P picture == oracle)"""
+    from ks265codec_amd.synth import subme_knobs
+    tools = dict(ENCODER_TOOLS, part=1, **subme_knobs("veryslow"))
+    _ippp(ks, 3840, 2160, 27, 2, 2, seed=7, abc=(67, 91, 33), pan=(8, 5), hex_thr=0, **tools)
+
+
 def test_config5_1080p_umh_always(ks):
     """-preset veryslow resolves tME+0x368 to 0: interMeUMH for every PU"""
     _ippp(ks, 1920, 1080, 27, 2, 3, seed=42, hex_thr=0)

@@ -235,6 +235,8 @@ REF_DEC = os.path.join(ROOT, "oracle", "_ref", "appdecoder")          # staged b
     (1920, 1080, 10, ["-preset", "slow", "-qp", "27", "-bframes", "0", "-iper", "128"]),       # config 2's tools: UMH, three list-0 pictures
     (1920, 1088, 9, ["-preset", "medium", "-qp", "30", "-bframes", "3", "-iper", "128"]),      # anchors + non-reference B pictures
     (3840, 2160, 6, ["-preset", "slow", "-qp", "27", "-iper", "128"]),                         # the bench workload (config 3)
+    (1920, 1080, 8, ["-preset", "veryslow", "-qp", "27", "-bframes", "0", "-ref", "1", "-iper", "128"]),   # config 5's tools on P pictures: -part 1 (two prediction units, four TUs), -subme 2 by Hadamard
+    (3840, 2160, 4, ["-preset", "veryslow", "-qp", "27", "-bframes", "0", "-ref", "1", "-iper", "128"]),
 ])
 def test_reference_decoder_reproduces_the_gpu_reconstruction(tmp_path, W, H, n, opts):
     """the conformance contract end to end ON THIS BOX: what the MI355X reconstructed (ks265enc -o) is byte for byte what the reference's
