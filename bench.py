@@ -331,6 +331,7 @@ def main():
                 elif state["kind"] != "P":             # stage events are recorded by ks265_encode_picture (I / P pictures)
                     continue
                 ms = fr.stage_ms()
+                ms["me_int_kernel"] = fr.me_int_ms()      # the SAD kernel alone (HIP events around its launch on the frame's stream): stage me_integer also holds pre-search + propagation
                 for k, v in ms.items():
                     acc[k] = acc.get(k, 0.0) + v
                 nacc += 1
@@ -348,35 +349,46 @@ def main():
         torch.cuda.synchronize()
         key_ms = {k: round(v, 3) for k, v in fr.stage_ms().items() if v > 0}
         fr.set_profiling(False)
+        me_int_kernel_ms = stage_alone.pop("me_int_kernel"); stage_run.pop("me_int_kernel", None)
         stage_ms = stage_alone
-        dom = max(stage_ms, key=stage_ms.get)
+        dom_stage = max(stage_ms, key=stage_ms.get)
+        # the roofline figure is the SAD kernel's (north_star; VERDICT r3: the kernel alone, not the stage): algorithmic bytes / its own launch duration
+        dom = "me_integer"
         algo_bytes = ALGO_BYTES_P[dom] * P
-        achieved = algo_bytes / (stage_ms[dom] * 1e-3) / 1e9
+        achieved = algo_bytes / (me_int_kernel_ms * 1e-3) / 1e9
+        # counters under profiles/ are inputs measured by a rocprofv3 --pmc run of an EARLIER invocation: they count only if they were taken on this very kernel source
+        from ks265codec_amd.build import source_sha
+        my_sha, stale = source_sha(), []
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")      # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/hbm_traffic.py)
         if os.path.exists(tfile):
-            t = json.load(open(tfile)).get(f"{W}x{H}", {}).get(dom)
-            if t:
-                traffic = t["bytes_per_launch"]
+            tall = json.load(open(tfile)).get(f"{W}x{H}", {})
+            if tall.get("_stamp", {}).get("kernel_src_sha") != my_sha:
+                stale.append("hbm_traffic.json")
+            elif tall.get(dom):
+                traffic = tall[dom]["bytes_per_launch"]
         # second figure per stage: the VALU-issue fraction = wave-level VALU instructions per launch (SQ_INSTS_VALU of a rocprofv3 --pmc pass,
         # profiles/sq_counters.json by tools/sq_issue.py) / 1.23e12 per second / the stage's duration - the kernels of this path are bound by latency and issue, not bytes
         valu = {}
         sfile = os.path.join(ROOT, "profiles", "sq_counters.json")
         if os.path.exists(sfile):
             sq = json.load(open(sfile)).get(f"{W}x{H}", {})
+            if sq.get("_stamp", {}).get("kernel_src_sha") != my_sha:
+                stale.append("sq_counters.json"); sq = {}
             for k, v in stage_ms.items():
                 n = sum(sq.get(kk, {}).get("insts_valu_per_launch", 0) for kk in ((k, "merge_pass") if k == "cu_decide" else (k,)))
                 if n and v > 0:
                     valu[k] = round(n / 1.23e12 / (v * 1e-3), 4)
-        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        roofline = {"bound": "hbm", "kernel": "me_int_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                    "algorithmic_bytes_per_launch": int(algo_bytes), "avg_launch_ms": round(stage_ms[dom], 4),
+                    "counters_stale": stale or None, "kernel_src_sha": my_sha,
+                    "algorithmic_bytes_per_launch": int(algo_bytes), "avg_launch_ms": round(me_int_kernel_ms, 4), "longest_stage": dom_stage,
                     "stages_ms": {k: round(v, 4) for k, v in stage_ms.items()},
                     "streams_in_run": nstreams,
                     "stage_intervals_ms_in_run": {k: round(v, 4) for k, v in stage_run.items()},
                     "note": "avg_launch_ms / stages_ms / frac: HIP events around each stage with ONE shard on the GPU = the kernel's own duration; it agrees with the rocprofv3 kernel trace of `bench.py --streams 1` (profiles/). With the run's --streams shards in flight the kernels of different shards overlap: stage_intervals_ms_in_run are event-to-event intervals on one shard's stream under that load (queueing behind the other shards' kernels included), the kernel durations of that condition are in the rocprofv3 trace of the default command (profiles/).",
                     "stages_frac": {k: round(ALGO_BYTES_P[k] * P / (v * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) for k, v in stage_ms.items()},
-                    "valu_issue_frac": valu.get(dom), "stages_valu_issue_frac": valu or None,
+                    "valu_issue_frac": (round(valu["me_integer"] * stage_ms["me_integer"] / me_int_kernel_ms, 4) if valu.get("me_integer") else None), "stages_valu_issue_frac": valu or None,
                     "bound_note": "no stage of a P picture is limited by HBM bytes: each is a dependency chain per CTU (search state machines, the intra CUs' wavefront) or issue-bound "
                                   "arithmetic on L2-resident samples; valu_issue_frac = VALU wave-instructions / 1.23e12 per s / duration says how busy the vector ALUs are"}
 

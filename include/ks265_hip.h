@@ -409,6 +409,8 @@ int ks265_encode_picture_b(ks265_frame *f, ks265_pic src, ks265_pic ref0, ks265_
  * (a key picture: intra_candidates = the mode pre-selection, intra_pass = the wavefront reconstruction) */
 int ks265_frame_set_profiling(ks265_frame *f, int enable);
 int ks265_frame_stage_ms(ks265_frame *f, float ms[8]);
+/* duration of the last me_int_kernel launch alone (the SAD kernel: stage me_integer also holds the pre-search and the propagation round); -1 = none */
+int ks265_frame_me_int_ms(ks265_frame *f, float *ms);
 /* accessors to the frame object's internal workspace (device pointers) */
 int16_t *ks265_frame_levels(ks265_frame *f, int comp);
 ks265_pu *ks265_frame_pu(ks265_frame *f);

@@ -17,6 +17,16 @@ def sources() -> list[str]:
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
+def source_sha() -> str:
+    """identity of the kernel sources (every .hip / .h under csrc + the C-ABI header): profiles/*.json carry the value they were measured with, bench.py compares it with
+    the running code's and flags stale counters instead of dividing old counts by new durations"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(os.path.dirname(HERE), "include", "ks265_hip.h")]):
+        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def stale() -> bool:
     if not os.path.exists(LIB):
         return True

@@ -238,7 +238,24 @@ int ks265_frame_set_profiling(ks265_frame *f, int enable)
     if (enable && !f->ev[0])
         for (int i = 0; i <= KS_NSTAGE; ++i)
             if (hipEventCreate(&f->ev[i]) != hipSuccess) return KS265_FAIL;
+    if (enable && !f->ev_k[0])
+        for (int i = 0; i < 2; ++i)
+            if (hipEventCreate(&f->ev_k[i]) != hipSuccess) return KS265_FAIL;
     f->profiling = enable != 0;
+    return KS265_OK;
+}
+
+/* the duration of the last me_int_kernel launch alone (HIP events on the frame's stream around that one launch; -1 = none since profiling was switched on): the SAD kernel
+ * of bench.py's roofline figure - stage 0 of ks265_frame_stage_ms also holds the pyramid pre-search and the propagation round */
+int ks265_frame_me_int_ms(ks265_frame *f, float *ms)
+{
+    KS_FRAME_CHECK(f);
+    if (!ms) return KS265_POINTER;
+    if (!f->profiling) return KS265_NOTSUPPORTED;
+    int r = ks265_hip(f->ctx, hipStreamSynchronize(f->ctx->stream));
+    if (r) return r;
+    *ms = -1.0f;
+    if (f->ev_k_valid && hipEventElapsedTime(ms, f->ev_k[0], f->ev_k[1]) != hipSuccess) *ms = -1.0f;
     return KS265_OK;
 }
 

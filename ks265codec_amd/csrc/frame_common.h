@@ -49,6 +49,7 @@ struct ks265_frame {
     // optional in-situ stage timing (HIP events on the context's stream, between the stages of ks265_encode_picture)
     bool profiling = false;
     hipEvent_t ev[KS_NSTAGE + 1] = {};
+    hipEvent_t ev_k[2] = {}; bool ev_k_valid = false;      // profiling: around the me_int_kernel launch alone (the SAD kernel of the roofline figure: stage me_integer also holds pre-search + propagation)
     bool ev_valid[KS_NSTAGE + 1] = {};
 };
 

@@ -641,7 +641,9 @@ extern "C" int ks265_me_integer(ks265_frame *f, ks265_pic src, ks265_pic ref, co
         field = (const short2 *)f->pyr[5];                                   // the L1 vectors: the kernel does the full-resolution step itself
     }
     const dim3 grid(f->g.ctu_cols * f->g.ctu_rows), block(256);
+    if (f->profiling && f->ev_k[0]) (void)hipEventRecord(f->ev_k[0], f->ctx->stream);
     hipLaunchKernelGGL(me_int_kernel, grid, block, 0, f->ctx->stream, f->g, f->cfg.me_range, f->cfg.lambda_q4, f->cfg.me_method, f->cfg.me_hex_thr, src.y, ref.y, prev_pu, pu,
                        field, (f->g.W + 15) / 16, (f->g.H + 15) / 16, field ? (const short2 *)f->pyr[9] : nullptr);
+    if (f->profiling && f->ev_k[1]) { (void)hipEventRecord(f->ev_k[1], f->ctx->stream); f->ev_k_valid = true; }
     return ks265_check_launch(f->ctx);
 }

@@ -60,7 +60,7 @@ EXPORTS = [
     "ks265_load_i420", "ks265_store_i420", "ks265_presearch", "ks265_me_integer", "ks265_me_propagate", "ks265_me_subpel", "ks265_cu_decide_part", "ks265_merge_pass", "ks265_cu_decide",
     "ks265_cu_flat_intra", "ks265_intra_decide", "ks265_intra_decide_ex", "ks265_lookahead_reduce", "ks265_lookahead_picture", "ks265_intra_reconstruct", "ks265_reconstruct", "ks265_reconstruct_b", "ks265_bi_decide", "ks265_bi_full_batch", "ks265_capture_begin", "ks265_capture_end", "ks265_graph_launch", "ks265_graph_destroy", "ks265_frame_p_state", "ks265_frame_p_advance", "ks265_frame_p_restore", "ks265_cu_decide_b", "ks265_deblock", "ks265_sao",
     "ks265_encode_picture", "ks265_encode_picture_b", "ks265_encode_picture_mref", "ks265_ref_decide", "ks265_reconstruct_mref",
-    "ks265_intra_candidates", "ks265_cu_decide_ii", "ks265_cu_decide_b_ii", "ks265_intra_inter_reconstruct", "ks265_frame_set_profiling", "ks265_frame_stage_ms", "ks265_frame_levels", "ks265_frame_pu", "ks265_frame_cu8", "ks265_frame_ibest", "ks265_frame_sao", "ks265_sse_picture",
+    "ks265_intra_candidates", "ks265_cu_decide_ii", "ks265_cu_decide_b_ii", "ks265_intra_inter_reconstruct", "ks265_frame_set_profiling", "ks265_frame_stage_ms", "ks265_frame_me_int_ms", "ks265_frame_levels", "ks265_frame_pu", "ks265_frame_cu8", "ks265_frame_ibest", "ks265_frame_sao", "ks265_sse_picture",
 ]
 
 
@@ -392,6 +392,12 @@ class KsFrame:
 
     def set_profiling(self, on: bool):
         self.ks._chk(self.lib.ks265_frame_set_profiling(self.h, C.c_int(1 if on else 0)))
+
+    def me_int_ms(self) -> float:
+        """duration of the last me_int_kernel launch alone (profiling on)"""
+        v = C.c_float(-1.0)
+        self.ks._chk(self.lib.ks265_frame_me_int_ms(self.h, C.byref(v)))
+        return float(v.value)
 
     def stage_ms(self) -> dict:
         ms = (C.c_float * 8)()

@@ -44,9 +44,15 @@ def main(fetch_csv, write_csv, res, out):
         allres = json.load(open(out))
     except Exception:
         allres = {}
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from ks265codec_amd.build import source_sha
+    data["_stamp"] = {"kernel_src_sha": source_sha(), "git_head": os.environ.get("KS265_GIT_HEAD", "")}      # what these counters were measured on
     allres[res] = data
     json.dump(allres, open(out, "w"), indent=1)
     for k, v in data.items():
+        if k.startswith("_"):
+            continue
         print(f"{k:12s} fetch_raw {v['fetch_size_kb_raw'] / 1024:9.1f} MiB  write_raw {v['write_size_kb_raw'] / 1024:9.1f} MiB  -> {v['bytes_per_launch'] / 1e6:9.1f} MB/launch")
 
 

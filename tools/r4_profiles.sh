@@ -1,0 +1,32 @@
+#!/bin/bash
+# round-4 measurement artefacts in ONE gpurun call: everything on the kernel set of THIS snapshot, every profiles/*.json stamped with the kernel
+# source hash (ks265codec_amd/build.py source_sha) and the git head handed in through KS265_GIT_HEAD; results land in gpurun_out/r04/, the builder copies them to profiles/.
+# usage (builder container):  KS265_GIT_HEAD=$(git rev-parse --short HEAD) gpurun --timeout 900 -- "KS265_GIT_HEAD=$KS265_GIT_HEAD bash tools/r4_profiles.sh"
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r04; mkdir -p $O; cd $R
+export TMPDIR=/tmp
+echo "head ${KS265_GIT_HEAD:-?} kernel_src_sha $(python -c 'from ks265codec_amd.build import source_sha; print(source_sha())')" > $O/stamp.txt
+cd /tmp
+# ---- 1. kernel traces: the hot path alone on one stream (the kernels' own durations), and the default command (the driver's)
+timeout 200 rocprofv3 --kernel-trace --stats -d $O/kt_hot1 -o kt -- python $R/bench.py --leg hot --streams 1 --steps 40 --no-cpu-baseline > /dev/null 2>&1
+python $R/tools/rocpd_stats.py $O/kt_hot1/kt_results.db > $O/kernel_stats_hot_1stream.txt
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/kt_def -o kt -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
+python $R/tools/rocpd_stats.py $O/kt_def/kt_results.db > $O/kernel_stats_default_whole_run.txt
+# ---- 2. HBM traffic: separate PMC passes (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE never together with other counters)
+timeout 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_f -o p -- python $R/bench.py --leg hot --steps 6 --warmup 2 --streams 1 --no-cpu-baseline > /dev/null 2>&1
+timeout 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_w -o p -- python $R/bench.py --leg hot --steps 6 --warmup 2 --streams 1 --no-cpu-baseline > /dev/null 2>&1
+rm -f $O/hbm_traffic.json
+python $R/tools/hbm_traffic.py $(ls $O/pmc_f/*counter_collection.csv | head -1) $(ls $O/pmc_w/*counter_collection.csv | head -1) 3840x2160 $O/hbm_traffic.json > $O/hbm_traffic.txt 2>&1
+# ---- 3. SQ counters: instruction mix (VALU issue fraction) and - north_star - the LDS bank-conflict counters
+timeout 200 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SMEM --output-format csv -d $O/pmc_sq -o p -- python $R/bench.py --leg hot --steps 6 --warmup 2 --streams 1 --no-cpu-baseline > /dev/null 2>&1
+rm -f $O/sq_counters.json
+python $R/tools/sq_issue.py $(ls $O/pmc_sq/*counter_collection.csv | head -1) 3840x2160 $O/sq_counters.json > $O/sq_issue.txt 2>&1
+timeout 200 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $O/pmc_sq2 -o p -- python $R/bench.py --leg hot --steps 6 --warmup 2 --streams 1 --no-cpu-baseline > /dev/null 2>&1
+python $R/tools/sq_summary.py $(ls $O/pmc_sq2/*counter_collection.csv | head -1) > $O/sq_counters.txt 2>&1
+rm -rf $O/pmc_f $O/pmc_w $O/pmc_sq $O/pmc_sq2 $O/kt_hot1 $O/kt_def
+# ---- 4. the bench lines on the stamped counters (the driver's command last, with the fresh profiles/ files in place)
+cp $O/hbm_traffic.json $O/sq_counters.json $R/profiles/ 2>/dev/null
+cd $R
+timeout 150 python bench.py --leg hot --streams 1 --no-cpu-baseline 2>/dev/null | grep '^{' | tail -1 > $O/bench_line_hot_1stream.json
+timeout 200 python bench.py --hier-b 8 --no-cpu-baseline 2>/dev/null | grep '^{' | tail -1 > $O/bench_line_hier8.json
+timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 2>$O/bench_default.err | grep '^{' | tail -1 > $O/bench_line_default.json
+ls -la $O; head -c 600 $O/bench_line_default.json; echo; head -22 $O/kernel_stats_hot_1stream.txt; cat $O/hbm_traffic.txt; head -14 $O/sq_counters.txt | cut -c1-200

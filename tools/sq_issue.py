@@ -36,6 +36,10 @@ def main(path, res, out):
         allres = json.load(open(out))
     except Exception:
         allres = {}
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from ks265codec_amd.build import source_sha
+    data["_stamp"] = {"kernel_src_sha": source_sha(), "git_head": os.environ.get("KS265_GIT_HEAD", "")}      # what these counters were measured on
     allres[res] = data
     json.dump(allres, open(out, "w"), indent=1)
     for k, d in data.items():
