@@ -881,6 +881,14 @@ static int tu_scan_idx(int intra, int mode, int n, int is_chroma)
  *   kept iff (gain >> 2 (7 - log2 N)) << 12 > lambda_q4^2 x bits x K        (lambda_mode = (lambda_q4 / 16)^2; K = 4 is lambda x 1)
  * Inter TUs of every component, and the intra CUs of P / B pictures; key pictures keep every level (their quality is inherited by the whole GOP: measured with
  * tools/rd_eval.py, pruning them costs 3 % at equal PSNR).  Runs before sign-data hiding, which then works on the pruned levels. */
+/* EXPERIMENT: the reference's own rdoQuant (oracle/ks265_rdoq_ref.c, pinned) at the postQuant seam with STATIC bit tables - what a
+ * frame-parallel port could use, since the adaptive context states of the entropy coder do not exist when the device quantises.  Off unless kso_experiment_rdoq is
+ * called (tools/rd_eval.py --rdoq); the product's specification is the code below it. */
+#include "ks265_rdoq_ref.h"
+#include <math.h>
+static const int32_t *g_rq_T;            /* [log2 - 2][chroma][180] */
+static int g_rq_mode, g_rq_mult[4] = {256, 256, 90, 90};
+void kso_experiment_rdoq(const int32_t *T, int mode, const int *mult) { g_rq_T = T; g_rq_mode = mode; if (mult) memcpy(g_rq_mult, mult, sizeof g_rq_mult); }
 static int rdo_level_q2(int a) { return a == 1 ? 14 : a == 2 ? 20 : 26 + 8 * (31 - __builtin_clz((unsigned)(a - 1))); }
 static int code_tu(const uint8_t *org, int so, const uint8_t *pred /*packed n*/, int n, int qp, int intra, int16_t *lvl, int lstride,
                    uint8_t *rec, int rstride, int sdh, int scan_idx, int decimate, int rdo, int lambda_q4)
@@ -898,6 +906,20 @@ static int code_tu(const uint8_t *org, int so, const uint8_t *pred /*packed n*/,
      * Chroma is left alone: measured with this oracle + the stream writer over 19 P pictures (416x240, 832x480; qp 27), K = 2 on chroma saved 1 % of the bytes
      * and cost 2.4 - 3.2 dB of chroma PSNR (nearly all chroma levels are +-1); luma only: -10 % / -18 % of the bytes for -0.31 / -0.37 dB PSNR-Y (one QP step
      * is -17 % for -0.71 dB). */
+    if (g_rq_T && (rdo > 0 || rdo == -1) && (intra != 1 || (g_rq_mode & 4))) {
+        const int chroma = rdo == -1, per = qp / 6;
+        uint16_t sm[64];
+        for (int i = 0; i < n * n; ++i) { const int c = coef[i], a = c < 0 ? -c : c; int q = (int)(((int64_t)a * p.scale + (1ll << (qbits - 1))) >> qbits); if (q > 32767) q = 32767; lv[i] = (int16_t)(c < 0 ? -q : q); }
+        const int last = kso_rdoq_scan_flags(lv, log2n, scan_idx, sm);
+        nz = 0;
+        if (last >= 0) {
+            const double lam = 0.85 * pow(2.0, (qp - 12) / 3.0);
+            nz = kso_ref_rdo_quant(lv, coef, log2n, scan_idx, chroma, p.dq, per, (int64_t)(g_rq_mult[2 * chroma + 1] * lam + 0.5), (int64_t)(g_rq_mult[2 * chroma] * lam + 0.5),
+                                   g_rq_T + ((log2n - 2) * 2 + chroma) * 180, 1, last, sm, 1, sdh, NULL, NULL);
+        }
+        rdo = 0; sdh = 0; decimate = 0;
+    }
+    if (rdo < 0) rdo = 0;
     if (decimate > 0 && !intra && nz > 0 && nz <= decimate * (log2n - 1)) {
         int mx = 0;
         for (int i = 0; i < n * n; ++i) { const int a = lv[i] < 0 ? -lv[i] : lv[i]; if (a > mx) mx = a; }
@@ -1031,7 +1053,7 @@ static void reconstruct_impl(const kso_frame_cfg *cfg, kso_pic src, const kso_pi
                 int16_t *lv = (comp ? lvl_v : lvl_u) + (long)yc * (W / 2) + xc;
                 uint8_t *rc = org_c(&g, comp ? recon.v : recon.u) + (long)yc * sc + xc;
                 const uint8_t *oc = org_c(&g, comp ? src.v : src.u) + (long)yc * sc + xc;
-                if (code_tu(oc, (int)sc, pred, nc, qpc, intra, lv, W / 2, rc, (int)sc, cfg->sdh, 0, 0, 0, cfg->lambda_q4)) cbf |= 2 << comp;      /* no decimation and no group pruning of chroma: see code_tu */
+                if (code_tu(oc, (int)sc, pred, nc, qpc, intra, lv, W / 2, rc, (int)sc, cfg->sdh, 0, 0, (g_rq_mode & 2) ? -1 : 0, cfg->lambda_q4)) cbf |= 2 << comp;      /* no decimation and no group pruning of chroma: see code_tu */
             }
             for (int yy = 0; yy < tu8; ++yy)
                 for (int xx = 0; xx < tu8; ++xx) cu8[(long)(by + yy) * w8 + bx + xx].cbf = (uint8_t)cbf;
@@ -1436,7 +1458,7 @@ static void intra_code_cu(const kso_frame_cfg *cfg, const kso_frame_geom *g, kso
     if (intra_filter_flag(mode, n)) { ks265o_intra_filter_ref(raw + 2 * n, fil + 2 * n, n, 1); r = fil + 2 * n; }
     ks265o_intra_pred(pred, n, r, mode, log2, 1);
     cbf |= code_tu(org_y(g, src.y) + (long)y0 * sy + x0, (int)sy, pred, n, qp, islice ? 1 : 2, lvl_y + (long)y0 * W + x0, W, Ry + (long)y0 * sy + x0, (int)sy, cfg->sdh,
-                   tu_scan_idx(1, mode, n, 0), 0, islice ? 0 : cfg->rdo, cfg->lambda_q4);
+                   tu_scan_idx(1, mode, n, 0), 0, islice ? ((g_rq_mode & 4) ? 1 : 0) : cfg->rdo, cfg->lambda_q4);
     int nc = n / 2, xc = x0 / 2, yc = y0 / 2;
     for (int comp = 0; comp < 2; ++comp) {
         uint8_t *Rc = org_c(g, comp ? recon.v : recon.u);
@@ -1444,7 +1466,7 @@ static void intra_code_cu(const kso_frame_cfg *cfg, const kso_frame_geom *g, kso
         ks265o_intra_pred(pred, nc, raw + 2 * nc, mode, log2 - 1, 0);
         int16_t *lv = (comp ? lvl_v : lvl_u) + (long)yc * (W / 2) + xc;
         const uint8_t *oc = org_c(g, comp ? src.v : src.u) + (long)yc * sc + xc;
-        if (code_tu(oc, (int)sc, pred, nc, qpc, islice ? 1 : 2, lv, W / 2, Rc + (long)yc * sc + xc, (int)sc, cfg->sdh, tu_scan_idx(1, mode, nc, 1), 0, 0, cfg->lambda_q4)) cbf |= 2 << comp;
+        if (code_tu(oc, (int)sc, pred, nc, qpc, islice ? 1 : 2, lv, W / 2, Rc + (long)yc * sc + xc, (int)sc, cfg->sdh, tu_scan_idx(1, mode, nc, 1), 0, (g_rq_mode & 2) ? -1 : 0, cfg->lambda_q4)) cbf |= 2 << comp;
     }
     for (int yy = 0; yy < n / 8; ++yy)
         for (int xx = 0; xx < n / 8; ++xx) cu8[(long)(by + yy) * w8 + bx + xx].cbf = (uint8_t)cbf;

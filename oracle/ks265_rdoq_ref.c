@@ -310,3 +310,20 @@ int kso_ref_rdo_quant(int16_t *lvl, const int16_t *coef, int log2, int scan_idx,
     free(cost_coeff); free(inc_up);
     return nz;
 }
+
+/* what the quantiser's bookkeeping (scanSigFlags enc@0x4a9b00 lineage) hands to rdoQuant: per sub-block (scan order) the mask of non-zero levels (bit 15 - position in
+ * the sub-block's scan) and the scan position of the last non-zero level (-1: none) */
+int kso_rdoq_scan_flags(const int16_t *lvl, int log2, int scan_idx, uint16_t *sigmask /*N*N/16*/)
+{
+    const int N = 1 << log2;
+    int16_t S[1024], G[64];
+    int last = -1;
+    build_scan(log2, scan_idx, S, G);
+    for (int cg = 0; cg < N * N / 16; ++cg) {
+        uint16_t m = 0;
+        for (int k = 0; k < 16; ++k) if (lvl[S[cg * 16 + k]]) { m |= (uint16_t)(1u << (15 - k)); last = cg * 16 + k; }
+        sigmask[cg] = m;
+    }
+    return last;
+}
+

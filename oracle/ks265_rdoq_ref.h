@@ -12,6 +12,8 @@ extern "C" {
  * Returns the number of non-zero levels; *out_last = the new last scan position (-1: none). */
 int kso_ref_rdo_quant(int16_t *lvl, const int16_t *coef, int log2, int scan_idx, int comp, int dq, int per, int64_t lam, int64_t lam_sdh, const int32_t *T,
                       int tu5, int last_pos, uint16_t *sigmask, int flag_a4c0, int sdh, int32_t *out_last, uint64_t *out_cgmask);
+/* the inputs rdoQuant takes from the quantiser: significance masks per sub-block, returns the last scan position */
+int kso_rdoq_scan_flags(const int16_t *lvl, int log2, int scan_idx, uint16_t *sigmask);
 #ifdef __cplusplus
 }
 #endif

@@ -232,6 +232,8 @@ def main():
     ap.add_argument("--adaptive", action="store_true", help="--gop hier: the host's slice-type decision of -lookahead N (blocks of 8 pictures as 8 or 4 + 4)")
     ap.add_argument("--pingpong", type=int, default=0, metavar="K", help="the clip of the same-clip tables: K pictures of the generator played forth and back, --frames pictures in all")
     ap.add_argument("--pan", default="", help="pan of the synthetic clip in samples per picture, e.g. 8,5")
+    ap.add_argument("--rdoq", type=int, default=0, metavar="MODE", help="experiment: the reference's rdoQuant (oracle/ks265_rdoq_ref.c) at the seam with static bit tables (medians of tests/golden/rdoq.npz); 1 = luma of P / B pictures, +2 chroma, +4 key pictures")
+    ap.add_argument("--rdoq-mult", default="", help="the four lambda multipliers (luma sign-hiding, luma, chroma sign-hiding, chroma; reference: 256,256,90,90)")
     ap.add_argument("--rdo-layers", default="", help="cfg.rdo of P pictures and of the B layers 1, 2, 3 (comma separated)")
     ap.add_argument("--b-lam", default="", help="extra lambda factors, indexed by B layer (entry 0 unused)")
     ap.add_argument("--layer-qp", default="", help="QP offsets on top of the P offset, indexed by B layer (entry 0 unused; default = the layer number)")
@@ -254,6 +256,19 @@ def main():
     for kv in filter(None, a.tools.split(",")):
         k, v = kv.split("=")
         tools[k] = int(v)
+    if a.rdoq:
+        import ctypes as C
+        from oracle_lib import lib as olib
+        z = np.load(os.path.join(ROOT, "tests", "golden", "rdoq.npz"))
+        T = np.zeros((4, 2, 180), np.int32)
+        for lg in range(2, 6):
+            for ch in (0, 1):
+                m = (z["meta"][:, 0] == lg) & ((z["meta"][:, 2] > 0) == bool(ch)) & (z["run_of"] < 2)       # the two -preset slow runs with default weights
+                if m.any():
+                    T[lg - 2, ch] = np.median(z["tab"][m], axis=0).astype(np.int32)
+        main._rq_T = T                                                 # keep alive
+        mult = (C.c_int * 4)(*[int(x) for x in a.rdoq_mult.split(",")]) if a.rdoq_mult else None
+        olib().kso_experiment_rdoq(T.ctypes.data_as(C.c_void_p), a.rdoq, mult)
     ref = None
     if not a.no_ref:
         with tempfile.NamedTemporaryFile(suffix=".yuv", delete=False) as f:
