@@ -131,12 +131,17 @@ extern "C" void ks265_me_dbg(unsigned long long *out, int reset) { if (reset) { 
 // One LEVEL of one GROUP of PUs.  WG = true: the group is the CTU's single 64x64 PU and all 256 lanes of the work-group evaluate its
 // candidates (work-group barriers between the steps of a round).  WG = false: the group is the part of a level that lies in one 32x32
 // quadrant (1 / 4 / 16 PUs) and belongs to ONE WAVE: owners = its first lanes, evaluation = its 64 lanes, no barrier at all.
-template <bool WG>
-__device__ __forceinline__ void me_group(const KsGeom &g, int cx, int cy, int range, const MeLim &lm, int lam, int method, int hex_thr, MeLds &L, GroupLds &Q, int level,
-                                         int l2n /* log2 PUs per side of the group */, int qx0, int qy0 /* PU-grid origin of the group */,
+template <bool WG, int LEVEL>
+__device__ __forceinline__ void me_group(const KsGeom &g, int cx, int cy, int range, const MeLim &lm, int lam, int method, int hex_thr, MeLds &L, GroupLds &Q,
+                                         int l2n_ /* log2 PUs per side of the group */, int qx0, int qy0 /* PU-grid origin of the group */,
                                          const ks265_pu *prev_ctu, ks265_pu *out_ctu, const short2 *field, int nb0x, int nb0y, int t /* lane index inside the group's lanes */)
 {
     constexpr int NT = WG ? 256 : 64;
+#ifdef KS_ME_LEVEL_RT
+    const int level = LEVEL < 0 ? l2n_ + 1 : LEVEL, l2n = l2n_;
+#else
+    constexpr int level = LEVEL, l2n = WG ? 0 : LEVEL - 1; (void)l2n_;
+#endif
     const int S = 64 >> level, npu = 1 << (2 * l2n), l2t = 6 - 2 * level;              // tiles per PU = 1 << l2t (64, 16, 4, 1)
     const int tpr = 8 >> level;                                                          // tiles per PU row
     auto sync = [&]() { if (WG) __syncthreads(); else __builtin_amdgcn_wave_barrier(); };
@@ -510,16 +515,16 @@ __global__ __launch_bounds__(256, 3) void me_int_kernel(KsGeom g, int range, int
     return;
 #endif
     // the 64x64 PU: the whole work-group
-    me_group<true>(g, cx, cy, range, lm, lam, method, hex_thr, L, L.grp[0], 0, 0, 0, 0, prev_ctu, out_ctu, field, nb0x, nb0y, tid);
+    me_group<true, 0>(g, cx, cy, range, lm, lam, method, hex_thr, L, L.grp[0], 0, 0, 0, prev_ctu, out_ctu, field, nb0x, nb0y, tid);
     __syncthreads();                                                                    // its vector is the predictor of everything below
 #ifdef KS_EXP_ME_CLOCK
     const long long tk2 = ME_NOW();
 #endif
     // 32x32, 16x16, 8x8: one quadrant per wave, each wave on its own
     const int qx = wave & 1, qy = wave >> 1;
-#pragma unroll 1
-    for (int level = 1; level < 4; ++level)
-        me_group<false>(g, cx, cy, range, lm, lam, method, hex_thr, L, L.grp[wave], level, level - 1, qx << (level - 1), qy << (level - 1), prev_ctu, out_ctu, field, nb0x, nb0y, lane);
+    me_group<false, 1>(g, cx, cy, range, lm, lam, method, hex_thr, L, L.grp[wave], 0, qx, qy, prev_ctu, out_ctu, field, nb0x, nb0y, lane);
+    me_group<false, 2>(g, cx, cy, range, lm, lam, method, hex_thr, L, L.grp[wave], 1, qx << 1, qy << 1, prev_ctu, out_ctu, field, nb0x, nb0y, lane);
+    me_group<false, 3>(g, cx, cy, range, lm, lam, method, hex_thr, L, L.grp[wave], 2, qx << 2, qy << 2, prev_ctu, out_ctu, field, nb0x, nb0y, lane);
 #ifdef KS_EXP_ME_CLOCK
     const long long tk3 = ME_NOW();
     if (lane == 0) { atomicAdd(&ks_me_dbg[6], (unsigned long long)(tk1 - tk0)); atomicAdd(&ks_me_dbg[7], (unsigned long long)(tk2 - tk1)); atomicAdd(&ks_me_dbg[14], (unsigned long long)(tk3 - tk2)); atomicAdd(&ks_me_dbg[15], 1ull); }
