@@ -298,6 +298,9 @@ int ks265_frame_set_qp(ks265_frame *f, int qp, int lambda_q4);
 int ks265_pad_picture(ks265_frame *f, ks265_pic pic);
 /* copy an unpadded I420 frame (dev, W*H*3/2 bytes) into a padded picture and pad it */
 int ks265_load_i420(ks265_frame *f, const uint8_t *dev_i420, ks265_pic dst);
+/* the same on another context's stream (same device): a pipelined host unpacks and pads the NEXT source picture beside the picture being coded; it orders the
+ * streams with events (ks265_event_record / ks265_stream_wait_event) */
+int ks265_load_i420_on(ks265_ctx *cx, ks265_frame *f, const uint8_t *dev_i420, ks265_pic dst);
 /* inverse: padded picture -> packed I420 */
 int ks265_store_i420(ks265_frame *f, ks265_pic src, uint8_t *dev_i420);
 
@@ -438,9 +441,15 @@ int ks265_frame_pack_records(ks265_frame *f, void *dev_dst, const void *dev_extr
  * memory on ANOTHER context's stream (a 32-work-group kernel; the size is read on the device, the host learns it from the header). */
 int ks265_frame_compact_layout(ks265_frame *f, size_t off[8]);
 int ks265_frame_pack_compact(ks265_frame *f, void *dev_dst, const void *dev_extra64);
+/* draining a picture beside the next one: pack (and the SSE) on another context's stream, and the event that ends the drain handed to the frame - the next
+ * ks265_encode_picture* call waits for it right before its first kernel that writes a record (CU map, levels, SAO parameters), its search does not wait.
+ * The fence is consumed by that call. */
+int ks265_frame_pack_compact_on(ks265_ctx *cx, ks265_frame *f, void *dev_dst, const void *dev_extra64);
+int ks265_frame_set_records_fence(ks265_frame *f, void *ev);
 int ks265_copy_out_compact_async(ks265_ctx *copy_ctx, ks265_frame *f, void *pinned_host, const void *dev_block);
 /* luma SSE between two padded pictures (PSNR-Y of the bench line; CPSNR_I420::calcPSNR enc@0x4c4060) */
 int ks265_sse_picture(ks265_frame *f, ks265_pic a, ks265_pic b, uint64_t *dev_sse3);
+int ks265_sse_picture_on(ks265_ctx *cx, ks265_frame *f, ks265_pic a, ks265_pic b, uint64_t *dev_sse3);
 
 #ifdef __cplusplus
 }

@@ -103,6 +103,21 @@ static int me_search(ks265_frame *f, ks265_pic src, ks265_pic ref, const ks265_p
     return r;
 }
 
+/* the records of the previous picture (CU map, levels, SAO parameters) may still be read on another stream (ks265_frame_pack_compact_on): the host names the event that
+ * ends that, and the picture waits for it right before its first kernel that writes a record - its search runs beside the previous picture's drain */
+int ks265_frame_set_records_fence(ks265_frame *f, void *ev)
+{
+    KS_FRAME_CHECK(f);
+    f->rec_fence = ev;
+    return KS265_OK;
+}
+static int records_fence(ks265_frame *f)
+{
+    if (!f->rec_fence) return KS265_OK;
+    void *ev = f->rec_fence;
+    f->rec_fence = nullptr;
+    return ks265_hip(f->ctx, hipStreamWaitEvent(f->ctx->stream, (hipEvent_t)ev, 0));
+}
 int ks265_encode_picture(ks265_frame *f, ks265_pic src, ks265_pic ref, int is_key, ks265_pic recon_out)
 {
     KS_FRAME_CHECK(f);
@@ -121,6 +136,7 @@ int ks265_encode_picture(ks265_frame *f, ks265_pic src, ks265_pic ref, int is_ke
     if (is_key) {
         /* intra picture: mode pre-selection + CU tree on the source, then the wavefront reconstruction */
         mark(2);
+        if ((r = records_fence(f))) return r;
         if ((r = ks265_intra_decide(f, src, f->cu8))) return r;
         mark(3);
         mark(5);
@@ -136,6 +152,7 @@ int ks265_encode_picture(ks265_frame *f, ks265_pic src, ks265_pic ref, int is_ke
         const bool ii = f->cfg.intra_inter != 0;              /* intra CUs may compete: their candidates first */
         if (ii && (r = ks265_intra_candidates(f, src, pu, f->icost))) return r;
         mark(3);
+        if ((r = records_fence(f))) return r;
         const bool part = f->cfg.part != 0;                    /* -part 1: the halves of every 64 / 32 / 16 CU priced first, the CU decision then picks among 2Nx2N / 2NxN / Nx2N / split */
         if (f->cfg.merge) {                                    /* stage C2: the CU decision goes to the spare map, the merge pass writes the final one */
             if ((r = part ? ks265_cu_decide_part(f, src, ref, pu, ii ? f->icost : nullptr, f->cu8_tmp) : ks265_cu_decide_ii(f, pu, ii ? f->icost : nullptr, f->cu8_tmp))) return r;
@@ -173,6 +190,7 @@ int ks265_encode_picture_mref(ks265_frame *f, ks265_pic src, const ks265_pic *re
         if (f->cfg.subme && (r = ks265_me_subpel(f, src, refs[i], pu))) return r;
     }
     if ((r = ks265_ref_decide(f, nref, pus, f->pub))) return r;
+    if ((r = records_fence(f))) return r;
     if ((r = ks265_cu_decide_b(f, f->pub, f->cu8))) return r;
     ks265_pic deb = ks_deb_pic(f);
     if ((r = ks265_reconstruct_mref(f, src, nref, refs, f->cu8, f->lvl[0], f->lvl[1], f->lvl[2], deb))) return r;
@@ -198,6 +216,7 @@ int ks265_encode_picture_b(ks265_frame *f, ks265_pic src, ks265_pic ref0, ks265_
     if ((r = ks265_bi_decide(f, src, ref0, ref1, pu0, f->pu1, f->pub))) return r;
     const bool ii = f->cfg.intra_inter != 0;
     if (ii && (r = ks265_intra_candidates(f, src, f->pub, f->icost))) return r;
+    if ((r = records_fence(f))) return r;
     if (f->cfg.merge) {
         if ((r = ks265_cu_decide_b_ii(f, f->pub, ii ? f->icost : nullptr, f->cu8_tmp))) return r;
         if ((r = ks265_merge_pass(f, src, ref0, ref1, nullptr, f->pub, f->cu8_tmp, f->cu8))) return r;
@@ -416,10 +435,12 @@ int ks265_frame_compact_layout(ks265_frame *f, size_t off[8])
     compact_layout(f, off);
     return KS265_OK;
 }
-int ks265_frame_pack_compact(ks265_frame *f, void *dev_dst, const void *dev_extra64)
+int ks265_frame_pack_compact(ks265_frame *f, void *dev_dst, const void *dev_extra64) { return f ? ks265_frame_pack_compact_on(f->ctx, f, dev_dst, dev_extra64) : KS265_POINTER; }
+int ks265_frame_pack_compact_on(ks265_ctx *cx, ks265_frame *f, void *dev_dst, const void *dev_extra64)
 {
     KS_FRAME_CHECK(f);
-    if (!dev_dst) return KS265_POINTER;
+    if (!dev_dst || !cx) return KS265_POINTER;
+    ks_use_device(cx);
     size_t off[8];
     compact_layout(f, off);
     const size_t npx = (size_t)f->g.W * f->g.H;
@@ -428,15 +449,15 @@ int ks265_frame_pack_compact(ks265_frame *f, void *dev_dst, const void *dev_extr
     const size_t sz[3] = {(size_t)f->geom.bytes_cu8, (size_t)f->geom.bytes_sao, 64};
     for (int i = 0; i < 3; ++i) { sg.src[i] = (const uint8_t *)src[i]; sg.off[i] = off[i]; sg.bytes[i] = sz[i]; }
     const unsigned gx = (unsigned)((sz[0] / 16 + 256 * 8 - 1) / (256 * 8));
-    hipLaunchKernelGGL(pack_records_kernel, dim3(gx ? gx : 1, 3), dim3(256), 0, f->ctx->stream, sg, (uint8_t *)dev_dst);
+    hipLaunchKernelGGL(pack_records_kernel, dim3(gx ? gx : 1, 3), dim3(256), 0, cx->stream, sg, (uint8_t *)dev_dst);
     CompactArgs a;
     const size_t pb[3] = {npx * 2, npx / 2, npx / 2};
     unsigned fl = 0;
     for (int i = 0; i < 3; ++i) { a.plane[i] = (const uint8_t *)f->lvl[i]; a.plane_bytes[i] = pb[i]; a.first_line[i] = fl; fl += (unsigned)((pb[i] + KS_CL_LINE - 1) / KS_CL_LINE); }
     a.first_line[3] = fl; a.nchunk = (fl + KS_CL_CHUNK - 1) / KS_CL_CHUNK;
     uint8_t *d = (uint8_t *)dev_dst;
-    hipLaunchKernelGGL(pack_compact_kernel, dim3(a.nchunk), dim3(256), 0, f->ctx->stream, a, (unsigned *)(d + off[3]), (unsigned *)(d + off[4]), (unsigned long long *)(d + off[5]), (uint4 *)(d + off[6]));
-    return ks265_check_launch(f->ctx);
+    hipLaunchKernelGGL(pack_compact_kernel, dim3(a.nchunk), dim3(256), 0, cx->stream, a, (unsigned *)(d + off[3]), (unsigned *)(d + off[4]), (unsigned long long *)(d + off[5]), (uint4 *)(d + off[6]));
+    return ks265_check_launch(cx);
 }
 int ks265_copy_out_compact_async(ks265_ctx *ctx, ks265_frame *f, void *pinned_host, const void *dev_block)
 {

@@ -58,16 +58,20 @@ __global__ __launch_bounds__(256) void pad_picture_kernel(PadArgs a)
     *(unsigned *)(q.p + (long)y * q.stride + x4) = v;
 }
 
-extern "C" int ks265_pad_picture(ks265_frame *f, ks265_pic pic)
+static int pad_picture_on(ks265_ctx *cx, ks265_frame *f, ks265_pic pic)
 {
-    KS_FRAME_CHECK(f);
     PadArgs a;
     a.pl[0] = PadPlane{pic.y, f->g.sy, f->g.W, f->g.H, KS_PAD_Y};
     a.pl[1] = PadPlane{pic.u, f->g.sc, f->g.W / 2, f->g.H / 2, KS_PAD_C};
     a.pl[2] = PadPlane{pic.v, f->g.sc, f->g.W / 2, f->g.H / 2, KS_PAD_C};
     const int items = 2 * KS_PAD_Y * ((f->g.W + 2 * KS_PAD_Y) / 4) + f->g.H * (2 * KS_PAD_Y / 4);      // luma has the most
-    hipLaunchKernelGGL(pad_picture_kernel, dim3((items + 255) / 256, 3), dim3(256), 0, f->ctx->stream, a);
-    return ks265_check_launch(f->ctx);
+    hipLaunchKernelGGL(pad_picture_kernel, dim3((items + 255) / 256, 3), dim3(256), 0, cx->stream, a);
+    return ks265_check_launch(cx);
+}
+extern "C" int ks265_pad_picture(ks265_frame *f, ks265_pic pic)
+{
+    KS_FRAME_CHECK(f);
+    return pad_picture_on(f->ctx, f, pic);
 }
 
 // ------------------------------------------------------------------ I420 <-> padded picture
@@ -92,25 +96,29 @@ __global__ __launch_bounds__(256) void copy_planes8_kernel(CopyPlanes a)
 #pragma unroll
     for (int r = 0; r < 4; ++r) if (y0 + r < h) *(uint2 *)(a.dst[pl] + (long)(y0 + r) * a.ds[pl] + x8) = v[r];
 }
-static void launch_copy3(ks265_frame *f, const CopyPlanes &a)
+static void launch_copy3(ks265_ctx *cx, const CopyPlanes &a)
 {
     bool al = (a.w & 15) == 0;
     for (int p = 0; p < 3 && al; ++p) al = ((uintptr_t)a.dst[p] & 7) == 0 && ((uintptr_t)a.src[p] & 7) == 0 && (a.ds[p] & 7) == 0 && (a.ss[p] & 7) == 0;
-    if (al) hipLaunchKernelGGL(copy_planes8_kernel, dim3((a.w / 8 + 63) / 64, (a.h + 15) / 16, 3), dim3(256), 0, f->ctx->stream, a);
-    else hipLaunchKernelGGL(copy_planes_kernel, dim3((a.w / 4 + 63) / 64, (a.h + 3) / 4, 3), dim3(256), 0, f->ctx->stream, a);
+    if (al) hipLaunchKernelGGL(copy_planes8_kernel, dim3((a.w / 8 + 63) / 64, (a.h + 15) / 16, 3), dim3(256), 0, cx->stream, a);
+    else hipLaunchKernelGGL(copy_planes_kernel, dim3((a.w / 4 + 63) / 64, (a.h + 3) / 4, 3), dim3(256), 0, cx->stream, a);
 }
 
-extern "C" int ks265_load_i420(ks265_frame *f, const uint8_t *i420, ks265_pic dst)
+/* the _on forms enqueue on ANOTHER context's stream of the same device (a host that prepares the next source picture, or drains the last one's records, beside the
+ * frame's own stream; the host orders the streams with events) */
+extern "C" int ks265_load_i420_on(ks265_ctx *cx, ks265_frame *f, const uint8_t *i420, ks265_pic dst)
 {
     KS_FRAME_CHECK(f);
-    if (!i420) return KS265_POINTER;
+    if (!i420 || !cx) return KS265_POINTER;
+    ks_use_device(cx);
     int W = f->g.W, H = f->g.H;
     CopyPlanes a;
     a.dst[0] = dst.y + f->g.org_y; a.dst[1] = dst.u + f->g.org_c; a.dst[2] = dst.v + f->g.org_c; a.ds[0] = f->g.sy; a.ds[1] = a.ds[2] = f->g.sc;
     a.src[0] = i420; a.src[1] = i420 + (long)W * H; a.src[2] = i420 + (long)W * H * 5 / 4; a.ss[0] = W; a.ss[1] = a.ss[2] = W / 2; a.w = W; a.h = H;
-    launch_copy3(f, a);
-    return ks265_pad_picture(f, dst);
+    launch_copy3(cx, a);
+    return pad_picture_on(cx, f, dst);
 }
+extern "C" int ks265_load_i420(ks265_frame *f, const uint8_t *i420, ks265_pic dst) { return f ? ks265_load_i420_on(f->ctx, f, i420, dst) : KS265_POINTER; }
 
 extern "C" int ks265_store_i420(ks265_frame *f, ks265_pic src, uint8_t *i420)
 {
@@ -120,7 +128,7 @@ extern "C" int ks265_store_i420(ks265_frame *f, ks265_pic src, uint8_t *i420)
     CopyPlanes a;
     a.src[0] = src.y + f->g.org_y; a.src[1] = src.u + f->g.org_c; a.src[2] = src.v + f->g.org_c; a.ss[0] = f->g.sy; a.ss[1] = a.ss[2] = f->g.sc;
     a.dst[0] = i420; a.dst[1] = i420 + (long)W * H; a.dst[2] = i420 + (long)W * H * 5 / 4; a.ds[0] = W; a.ds[1] = a.ds[2] = W / 2; a.w = W; a.h = H;
-    launch_copy3(f, a);
+    launch_copy3(f->ctx, a);
     return ks265_check_launch(f->ctx);
 }
 
@@ -169,10 +177,12 @@ __global__ __launch_bounds__(256) void sse_picture_kernel(KsGeom g, const uint8_
     }
 }
 
-extern "C" int ks265_sse_picture(ks265_frame *f, ks265_pic a, ks265_pic b, uint64_t *sse3)
+extern "C" int ks265_sse_picture_on(ks265_ctx *cx, ks265_frame *f, ks265_pic a, ks265_pic b, uint64_t *sse3)
 {
     KS_FRAME_CHECK(f);
-    if (!sse3) return KS265_POINTER;
-    hipLaunchKernelGGL(sse_picture_kernel, dim3((unsigned)((f->g.H + 7) / 8), 3), dim3(256), 0, f->ctx->stream, f->g, a.y, a.u, a.v, b.y, b.u, b.v, f->sse_acc, (unsigned long long *)sse3);
-    return ks265_check_launch(f->ctx);
+    if (!sse3 || !cx) return KS265_POINTER;
+    ks_use_device(cx);
+    hipLaunchKernelGGL(sse_picture_kernel, dim3((unsigned)((f->g.H + 7) / 8), 3), dim3(256), 0, cx->stream, f->g, a.y, a.u, a.v, b.y, b.u, b.v, f->sse_acc, (unsigned long long *)sse3);
+    return ks265_check_launch(cx);
 }
+extern "C" int ks265_sse_picture(ks265_frame *f, ks265_pic a, ks265_pic b, uint64_t *sse3) { return f ? ks265_sse_picture_on(f->ctx, f, a, b, sse3) : KS265_POINTER; }

@@ -2,7 +2,7 @@
  *
  * Three lookahead decisions of /root/reference/ubuntu_x64/appencoder (v2.6.1.3, binary only) restated from the disassembly:
  *   calcFrameAdaptQuant enc@0x4653c0, cuTreePropagate enc@0x47d460, scenecut enc@0x47e9d0 (its rule; the costs it compares come from calcFrameCost enc@0x4a7410).
- * Pinned by tests/test_lookahead_ref.py on calls recorded inside real `appencoder` runs (tests/golden/lookahead.npz, oracle/ref_probe/gen_la_traces.py).
+ * Pinned by tests/test_lookahead_ref.py on calls recorded inside real `appencoder` runs (tests/golden/lookahead_ref.npz, oracle/ref_probe/gen_la_traces.py).
  * The arithmetic is x264-lineage (adaptive quantisation by block variance, macroblock-tree propagation, scene-cut bias) in the reference's own fixed-point form. */
 #include <math.h>
 #include <stdint.h>

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""TEST INFRASTRUCTURE (builder container only): record the reference's lookahead decisions on real encodes and write tests/golden/lookahead.npz
+"""TEST INFRASTRUCTURE (builder container only): record the reference's lookahead decisions on real encodes and write tests/golden/lookahead_ref.npz
 (pin calcFrameAdaptQuant enc@0x4653c0, cuTreePropagate enc@0x47d460, scenecut enc@0x47e9d0).
 
 Every run encodes a synthetic clip (scene changes and flat pictures included) with `appencoder -threads 1` twice - plain and under la_shim.so - and
@@ -132,7 +132,7 @@ def main():
         if check_all:
             return
         cat = lambda rows, k: np.concatenate([x[k] for x in rows])
-        path = os.path.join(ROOT, "tests", "golden", "lookahead.npz")
+        path = os.path.join(ROOT, "tests", "golden", "lookahead_ref.npz")
         np.savez_compressed(path, runs=np.array([f"{n} {W}x{H}: {' '.join(a)}" for n, W, H, a, _, _ in RUNS]),
                             aq_hdr=np.array([x["h"] for x in aq], np.int32), aq_run=np.array([x["run"] for x in aq], np.int32), aq_strength=np.array([x["strength"] for x in aq]),
                             aq_y=cat(aq, "Y"), aq_u=cat(aq, "U"), aq_v=cat(aq, "V"), aq_off=cat(aq, "off"), aq_inv=cat(aq, "inv"),

@@ -1,5 +1,5 @@
 """The oracle's restatement of three of the reference's LOOKAHEAD decisions (oracle/ks265_lookahead_ref.c: calcFrameAdaptQuant enc@0x4653c0, cuTreePropagate enc@0x47d460,
-scenecut enc@0x47e9d0) replayed on calls recorded inside the reference binary (tests/golden/lookahead.npz, written by
+scenecut enc@0x47e9d0) replayed on calls recorded inside the reference binary (tests/golden/lookahead_ref.npz, written by
 oracle/ref_probe/gen_la_traces.py: real `appencoder` runs with -aq 1, -cutree 1, -scenecut N under -rc 1 / 2 / 3, -bframes 0 / 3 / 7, on a clip with hard cuts, flat
 pictures and a still; the stream checked to be unchanged by the hooks).  Bit-exact: the QP offsets are doubles and must be equal, not close."""
 from __future__ import annotations
@@ -11,7 +11,7 @@ import numpy as np
 
 from oracle_lib import lib, ptr
 
-GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lookahead.npz")
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lookahead_ref.npz")
 
 
 def test_frame_adapt_quant_matches_reference_traces():
