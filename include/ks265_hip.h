@@ -205,6 +205,18 @@ int ks265_bi_full_batch(ks265_ctx *, int use_had, const uint8_t *dev_org, int so
  * N x N block of a w x h plane in raster order (the per-block variance map of calcFrameAdaptQuant enc@0x4653c0) */
 int ks265_ac_energy_batch(ks265_ctx *, const uint8_t *dev_src, int stride, int log2, const int32_t *dev_offs, int n, uint32_t *dev_out);
 int ks265_ac_energy_map(ks265_ctx *, const uint8_t *dev_plane, int stride, int w, int h, int log2, uint32_t *dev_out);
+/* calcFrameAdaptQuant enc@0x4653c0 (TInputPic*, mode = 1, strength) - adaptive quantisation by block variance (iAqMode / fAqStrength, qy265enc.h:145-146): for every 16 x 16
+ * luma block (with its two 8 x 8 chroma blocks) v = log2(AC energy + 2)^2 (_log2 enc@0x4c3c20), then offset = (v - mean) x strength x mean / 6000 (doubles, the mean a
+ * sequential sum divided by `count`) and its inverse qscale factor qy265_exp2fix8 enc@0x4c3c50.  dev_qp_off: nx * ny doubles (TInputPic lookahead block +0x9a8),
+ * dev_inv_qscale: nx * ny u16 (+0x48), dev_scratch2: two doubles.  Bit-exact against oracle/ks265_lookahead_ref.c (pinned on recorded calls of the reference). */
+int ks265_frame_adapt_quant(ks265_ctx *, const uint8_t *dev_y, int stride_y, const uint8_t *dev_u, const uint8_t *dev_v, int stride_c, int nx, int ny, int count,
+                            double strength, double *dev_qp_off, uint16_t *dev_inv_qscale, double *dev_scratch2);
+/* cuTreePropagate enc@0x47d460 (log2, frames, p0, p1, b): one step of the macroblock-tree propagation - every block of picture b hands
+ * ((inv_qscale x intra + 128) >> 8) + own) x (intra - inter) / intra to the (up to) four blocks of each reference its vector points at, weighted by the overlap
+ * (32nds at lg = 3), half each when both lists are used; reference costs saturate at 0xffff.  list bits: 2 per block, 4 blocks per byte; vectors: x = low 16 bits,
+ * y = high 16; dev_ref0 == dev_ref1 when both references are one picture; dev_acc: 2 * nx * ny 64-bit words, ZERO on entry and left zero. */
+int ks265_cutree_propagate(ks265_ctx *, int lg, int nx, int ny, const uint16_t *dev_intra, const uint16_t *dev_inv_qscale, const uint16_t *dev_own, const uint16_t *dev_inter,
+                           const uint8_t *dev_list_bits, const int32_t *dev_mv0, const int32_t *dev_mv1, uint16_t *dev_ref0, uint16_t *dev_ref1, uint64_t *dev_acc);
 
 /* ------------------------------------------------------------------ 3. whole-frame stages (a13 sequencing) */
 

@@ -56,7 +56,7 @@ EXPORTS = [
     "ks265_edge_filter_luma_batch", "ks265_edge_filter_chroma_batch", "ks265_interp_rect",
     "ks265_sao_apply_bo_rect", "ks265_sao_apply_eo_rect", "ks265_sao_stats_batch", "ks265_intra_pred_batch", "ks265_intra_filter_ref_batch",
     "ks265_downsample_rect", "ks265_weight_bi_sad_batch", "ks265_ac_energy_batch", "ks265_ac_energy_map",
-    "ks265_frame_reset_prediction", "ks265_frame_records_layout", "ks265_frame_pack_records", "ks265_frame_compact_layout", "ks265_frame_pack_compact", "ks265_frame_pack_compact_on", "ks265_frame_set_records_fence", "ks265_load_i420_on", "ks265_sse_picture_on", "ks265_copy_out_compact_async", "ks265_frame_geometry", "ks265_frame_create", "ks265_frame_destroy", "ks265_frame_set_qp", "ks265_pad_picture",
+    "ks265_frame_reset_prediction", "ks265_frame_records_layout", "ks265_frame_pack_records", "ks265_frame_compact_layout", "ks265_frame_pack_compact", "ks265_frame_pack_compact_on", "ks265_frame_adapt_quant", "ks265_cutree_propagate", "ks265_frame_set_records_fence", "ks265_load_i420_on", "ks265_sse_picture_on", "ks265_copy_out_compact_async", "ks265_frame_geometry", "ks265_frame_create", "ks265_frame_destroy", "ks265_frame_set_qp", "ks265_pad_picture",
     "ks265_load_i420", "ks265_store_i420", "ks265_presearch", "ks265_me_integer", "ks265_me_propagate", "ks265_me_subpel", "ks265_cu_decide_part", "ks265_merge_pass", "ks265_cu_decide",
     "ks265_cu_flat_intra", "ks265_intra_decide", "ks265_intra_decide_ex", "ks265_lookahead_reduce", "ks265_lookahead_picture", "ks265_intra_reconstruct", "ks265_reconstruct", "ks265_reconstruct_b", "ks265_bi_decide", "ks265_bi_full_batch", "ks265_capture_begin", "ks265_capture_end", "ks265_graph_launch", "ks265_graph_destroy", "ks265_frame_p_state", "ks265_frame_p_advance", "ks265_frame_p_restore", "ks265_cu_decide_b", "ks265_deblock", "ks265_sao",
     "ks265_encode_picture", "ks265_encode_picture_b", "ks265_encode_picture_mref", "ks265_ref_decide", "ks265_reconstruct_mref",
@@ -246,6 +246,18 @@ class KsContext:
         out = self.zeros(4 * n)
         self._chk(self.lib.ks265_ac_energy_map(self.h, _p(plane), C.c_int(stride), C.c_int(w), C.c_int(h), C.c_int(log2), _p(out)))
         return self.host(out, np.uint32, (h >> log2, w >> log2))
+
+    def frame_adapt_quant(self, y, stride_y: int, u, v, stride_c: int, nx: int, ny: int, strength: float, count: int | None = None):
+        """calcFrameAdaptQuant enc@0x4653c0: (QP offsets float64 [ny, nx], inverse qscale factors uint16 [ny, nx]) of a picture's 16x16 blocks; y / u / v: device planes"""
+        n = nx * ny
+        off, inv, scal = self.zeros(8 * n), self.zeros(2 * n), self.zeros(16)
+        self._chk(self.lib.ks265_frame_adapt_quant(self.h, _p(y), C.c_int(stride_y), _p(u), _p(v), C.c_int(stride_c), C.c_int(nx), C.c_int(ny), C.c_int(count or n), C.c_double(strength),
+                                                   _p(off), _p(inv), _p(scal)))
+        return self.host(off, np.float64, (ny, nx)), self.host(inv, np.uint16, (ny, nx))
+
+    def cutree_propagate(self, lg: int, nx: int, ny: int, intra, invq, own, inter, bits, mv0, mv1, ref0, ref1, acc):
+        """cuTreePropagate enc@0x47d460 on device arrays (ref0 / ref1 updated in place; acc: 2 * nx * ny zeroed uint64, left zero)"""
+        self._chk(self.lib.ks265_cutree_propagate(self.h, C.c_int(lg), C.c_int(nx), C.c_int(ny), _p(intra), _p(invq), _p(own), _p(inter), _p(bits), _p(mv0), _p(mv1), _p(ref0), _p(ref1), _p(acc)))
 
     def intra_pred(self, ref, dst, blks: np.ndarray):
         """g_IntraPredFunction: predict every described block from dev `ref` into dev `dst` (in place)"""
