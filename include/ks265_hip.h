@@ -459,6 +459,8 @@ int ks265_frame_pack_compact(ks265_frame *f, void *dev_dst, const void *dev_extr
 int ks265_frame_pack_compact_on(ks265_ctx *cx, ks265_frame *f, void *dev_dst, const void *dev_extra64);
 int ks265_frame_set_records_fence(ks265_frame *f, void *ev);
 int ks265_copy_out_compact_async(ks265_ctx *copy_ctx, ks265_frame *f, void *pinned_host, const void *dev_block);
+/* the same with the copy engine for the fixed part + the first data_bytes of the data area, the kernel for what lies beyond (0 .. all of it) */
+int ks265_copy_out_compact_dma_async(ks265_ctx *, ks265_frame *f, void *pinned_host, const void *dev_block, size_t data_bytes);
 /* luma SSE between two padded pictures (PSNR-Y of the bench line; CPSNR_I420::calcPSNR enc@0x4c4060) */
 int ks265_sse_picture(ks265_frame *f, ks265_pic a, ks265_pic b, uint64_t *dev_sse3);
 int ks265_sse_picture_on(ks265_ctx *cx, ks265_frame *f, ks265_pic a, ks265_pic b, uint64_t *dev_sse3);

@@ -412,10 +412,10 @@ __global__ __launch_bounds__(256) void pack_compact_kernel(CompactArgs a, unsign
     }
 }
 // copy-out of a compact block: the fixed part, then as many data lines as the header says (read on the device: the host does not know the size yet)
-__global__ __launch_bounds__(256) void copy_out_compact_kernel(uint4 *dst, const uint4 *src, unsigned long long fixed16, const unsigned *hdr)
+__global__ __launch_bounds__(256) void copy_out_compact_kernel(uint4 *dst, const uint4 *src, unsigned long long fixed16, const unsigned *hdr, unsigned long long first16)
 {
     const unsigned long long n16 = fixed16 + (unsigned long long)hdr[2] * (KS_CL_LINE / 16);
-    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (unsigned long long)gridDim.x * 256) dst[i] = src[i];
+    for (unsigned long long i = first16 + (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (unsigned long long)gridDim.x * 256) dst[i] = src[i];
 }
 static void compact_layout(const ks265_frame *f, size_t off[8])
 {
@@ -466,7 +466,24 @@ int ks265_copy_out_compact_async(ks265_ctx *ctx, ks265_frame *f, void *pinned_ho
     size_t off[8];
     compact_layout(f, off);
     hipLaunchKernelGGL(copy_out_compact_kernel, dim3(32), dim3(256), 0, ctx->stream, (uint4 *)pinned_host, (const uint4 *)dev_block, (unsigned long long)(off[6] / 16),
-                       (const unsigned *)((const uint8_t *)dev_block + off[3]));
+                       (const unsigned *)((const uint8_t *)dev_block + off[3]), 0ull);
+    return ks265_check_launch(ctx);
+}
+/* the copy engine takes the fixed part and the first `data_bytes` of the data area (one hipMemcpyAsync: no kernel writes host memory - a kernel that does slowed the
+ * kernels running beside it by ~30 us per picture at 2160p), a kernel only what lies beyond - normally nothing: it reads the header and leaves */
+int ks265_copy_out_compact_dma_async(ks265_ctx *ctx, ks265_frame *f, void *pinned_host, const void *dev_block, size_t data_bytes)
+{
+    if (!ctx || !f || !pinned_host || !dev_block) return KS265_POINTER;
+    ks_use_device(ctx);
+    size_t off[8];
+    compact_layout(f, off);
+    data_bytes = (data_bytes + 255) & ~(size_t)255;
+    if (data_bytes > off[7] - off[6]) data_bytes = off[7] - off[6];
+    int r = ks265_hip(ctx, hipMemcpyAsync(pinned_host, dev_block, off[6] + data_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (r) return r;
+    if (data_bytes < off[7] - off[6])
+        hipLaunchKernelGGL(copy_out_compact_kernel, dim3(32), dim3(256), 0, ctx->stream, (uint4 *)pinned_host, (const uint4 *)dev_block, (unsigned long long)(off[6] / 16),
+                           (const unsigned *)((const uint8_t *)dev_block + off[3]), (unsigned long long)((off[6] + data_bytes) / 16));
     return ks265_check_launch(ctx);
 }
 

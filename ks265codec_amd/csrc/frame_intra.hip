@@ -302,14 +302,21 @@ __global__ __launch_bounds__(256) void intra_recon_kernel(KsGeom g, int qp, cons
     // an intra picture: one work-group per CTU ROW walking its CTUs (every CTU has work, the row is the natural unit)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, cy = PMODE ? (int)blockIdx.x / g.ctu_cols : (int)blockIdx.x;
     const int cx_first = PMODE ? (int)blockIdx.x % g.ctu_cols : 0, cx_end = PMODE ? cx_first + 1 : g.ctu_cols;
+    __shared__ int s_need;                                           // PMODE: which of the four neighbour CTUs (bit 0 left, 1 top-left, 2 top, 3 top-right) this CTU's intra CUs read
     if (PMODE) {                                                     // most CTUs of a P / B picture hold no intra CU: leave before any set-up
         __shared__ int s_any;
         if (tid < 64) {
             const int bx = cx_first * 8 + (tid & 7), by = cy * 8 + (tid >> 3);
             bool intra = false;
             if (bx < g.w8 && by < g.h8) { const ks265_cu8 q = cu8[(long)by * g.w8 + bx]; intra = q.pred_mode == 2; }
-            const unsigned long long any = __ballot(intra);
-            if (tid == 0) s_any = any != 0ull;
+            const unsigned long long any = __ballot(intra);              // bit = 8x8 block, raster
+            if (tid == 0) {
+                s_any = any != 0ull;
+                // an intra CU reads a neighbour CTU's samples only across the border it touches: left column -> the left CTU (incl. its below-left samples), block (0, 0) -> the
+                // top-left one, top row -> the top one, top row from x = 32 on -> the top-right one (x0 + 2 n > 64 needs x0 >= 32).  The others need not be waited for: round 4,
+                // the wavefront of a 2160p P picture is cut where intra CUs lie inside their CTUs
+                s_need = ((any & 0x0101010101010101ull) ? 1 : 0) | ((any & 1ull) ? 2 : 0) | ((any & 0xFFull) ? 4 : 0) | ((any & 0xF0ull) ? 8 : 0);
+            }
         }
         __syncthreads();
         if (!s_any) {
@@ -365,11 +372,19 @@ __global__ __launch_bounds__(256) void intra_recon_kernel(KsGeom g, int qp, cons
         };
         if (PMODE) load_own();                                       // nothing of this depends on the neighbours: under way before the wait
         if (PMODE) {
-            // the four neighbour CTUs whose samples this CTU's intra CUs may read (left, top-left, top, top-right) must be through - with or without intra CUs of
+            // the neighbour CTUs whose samples this CTU's intra CUs read (of left, top-left, top, top-right: s_need) must be through - with or without intra CUs of
             // their own (those without flagged themselves at once)
-            if (tid < 4) {
+            if (tid < 4 && ((s_need >> tid) & 1)) {
                 const int nx = tid == 0 ? cx - 1 : cx - 2 + tid, ny = tid == 0 ? cy : cy - 1;
-                if (nx >= 0 && nx < g.ctu_cols && ny >= 0) {
+                // ... and only if that CTU holds an intra CU along the shared border (its right column / bottom-right block / bottom row / left half of its bottom row): what
+                // reconstruct_kernel wrote there is final otherwise
+                bool dep = false;
+                if (nx >= 0 && nx < g.ctu_cols && ny >= 0)
+                    for (int k = 0; k < (tid == 1 ? 1 : tid == 3 ? 4 : 8); ++k) {
+                        const int bx = nx * 8 + (tid == 0 || tid == 1 ? 7 : k), by = ny * 8 + (tid == 0 ? k : 7);
+                        if (bx < g.w8 && by < g.h8 && cu8[(long)by * g.w8 + bx].pred_mode == 2) dep = true;
+                    }
+                if (dep) {
                     int spins = 0;
                     while (__hip_atomic_load(progress + ny * g.ctu_cols + nx, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0) {
                         if (spins++ >= spin_limit) { __hip_atomic_fetch_or(err_word, KS_DEVERR_WAVEFRONT_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }

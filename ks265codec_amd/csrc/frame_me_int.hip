@@ -137,11 +137,7 @@ __device__ __forceinline__ void me_group(const KsGeom &g, int cx, int cy, int ra
                                          const ks265_pu *prev_ctu, ks265_pu *out_ctu, const short2 *field, int nb0x, int nb0y, int t /* lane index inside the group's lanes */)
 {
     constexpr int NT = WG ? 256 : 64;
-#ifdef KS_ME_LEVEL_RT
-    const int level = LEVEL < 0 ? l2n_ + 1 : LEVEL, l2n = l2n_;
-#else
-    constexpr int level = LEVEL, l2n = WG ? 0 : LEVEL - 1; (void)l2n_;
-#endif
+    constexpr int level = LEVEL, l2n = WG ? 0 : LEVEL - 1; (void)l2n_;        // the engine is compiled per level (round 4: - 2.5 % on the kernel; the tile geometry and the DPP sums are constants)
     const int S = 64 >> level, npu = 1 << (2 * l2n), l2t = 6 - 2 * level;              // tiles per PU = 1 << l2t (64, 16, 4, 1)
     const int tpr = 8 >> level;                                                          // tiles per PU row
     auto sync = [&]() { if (WG) __syncthreads(); else __builtin_amdgcn_wave_barrier(); };

@@ -133,7 +133,7 @@ extern "C" int ks265_store_i420(ks265_frame *f, ks265_pic src, uint8_t *i420)
 }
 
 // ------------------------------------------------------------------ picture SSE (PSNR): sse3[plane] += sum of squared differences
-// one launch for the three planes: blockIdx.y = plane, a work-group = 8 rows, a thread = dwords of one row (stride 32 dwords)
+// one launch for the three planes: blockIdx.y = plane, a wave = one row at a time (16 bytes per lane and load where the rows allow), rows dealt round-robin to the work-groups
 __global__ __launch_bounds__(256) void sse_picture_kernel(KsGeom g, const uint8_t *ay, const uint8_t *au, const uint8_t *av, const uint8_t *by, const uint8_t *bu, const uint8_t *bv,
                                                           unsigned long long *acc /* [0..2] running sums, [3] work-groups done; all zero between calls */, unsigned long long *out)
 {
@@ -141,26 +141,43 @@ __global__ __launch_bounds__(256) void sse_picture_kernel(KsGeom g, const uint8_
     const int w = pl ? g.W / 2 : g.W, h = pl ? g.H / 2 : g.H;
     const long stride = pl ? g.sc : g.sy, org = pl ? g.org_c : g.org_y;
     const uint8_t *a = (pl == 0 ? ay : pl == 1 ? au : av) + org, *b = (pl == 0 ? by : pl == 1 ? bu : bv) + org;
-    const int y = blockIdx.x * 8 + (threadIdx.x >> 5);
+    const int lane = threadIdx.x & 63;
     unsigned s = 0;
-    if (y < h) {
-        if ((w & 7) == 0 && (((uintptr_t)a | (uintptr_t)b | (uintptr_t)stride) & 7) == 0) {     // 8 bytes per load (every picture the encoder runs at)
-            for (int x8 = (threadIdx.x & 31) * 8; x8 < w; x8 += 256) {
-                const uint2 va = *(const uint2 *)(a + y * stride + x8), vb = *(const uint2 *)(b + y * stride + x8);
+    auto sq4 = [&](unsigned va, unsigned vb) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int d0 = (int)((va.x >> (8 * i)) & 255) - (int)((vb.x >> (8 * i)) & 255), d1 = (int)((va.y >> (8 * i)) & 255) - (int)((vb.y >> (8 * i)) & 255);
-                    s += (unsigned)(d0 * d0) + (unsigned)(d1 * d1);
+        for (int i = 0; i < 4; ++i) { const int d = (int)((va >> (8 * i)) & 255) - (int)((vb >> (8 * i)) & 255); s += (unsigned)(d * d); }
+    };
+    // few work-groups, each over many rows: every work-group ends in two atomics on the same four words, and 1620 of those WERE the kernel's duration (33 us; 86 x 3: 9 us)
+    for (int y = blockIdx.x * 4 + (threadIdx.x >> 6); y < h; y += gridDim.x * 4) {
+        if ((w & 15) == 0 && (((uintptr_t)a | (uintptr_t)b | (uintptr_t)stride) & 15) == 0) {
+            // all loads of a pass are issued before the first sum (a pass = up to 4 x 16 bytes per lane and picture: 4 KB of the row per wave): the kernel is a latency chain otherwise
+            for (int x0 = 0; x0 < w; x0 += 4096) {
+                uint4 va[4], vb[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int x = x0 + k * 1024 + lane * 16;
+                    va[k] = make_uint4(0, 0, 0, 0); vb[k] = make_uint4(0, 0, 0, 0);
+                    if (x < w) { va[k] = *(const uint4 *)(a + y * stride + x); vb[k] = *(const uint4 *)(b + y * stride + x); }
                 }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { sq4(va[k].x, vb[k].x); sq4(va[k].y, vb[k].y); sq4(va[k].z, vb[k].z); sq4(va[k].w, vb[k].w); }
+            }
+        } else if ((w & 7) == 0 && (((uintptr_t)a | (uintptr_t)b | (uintptr_t)stride) & 7) == 0) {
+            for (int x0 = 0; x0 < w; x0 += 2048) {
+                uint2 va[4], vb[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int x = x0 + k * 512 + lane * 8;
+                    va[k] = make_uint2(0, 0); vb[k] = make_uint2(0, 0);
+                    if (x < w) { va[k] = *(const uint2 *)(a + y * stride + x); vb[k] = *(const uint2 *)(b + y * stride + x); }
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { sq4(va[k].x, vb[k].x); sq4(va[k].y, vb[k].y); }
             }
         } else
-            for (int x4 = (threadIdx.x & 31) * 4; x4 < w; x4 += 128) {
-                const unsigned va = *(const unsigned *)(a + y * stride + x4), vb = *(const unsigned *)(b + y * stride + x4);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) { const int d = (int)((va >> (8 * i)) & 255) - (int)((vb >> (8 * i)) & 255); s += (unsigned)(d * d); }
-            }
+            for (int x = lane * 4; x < w; x += 256) sq4(*(const unsigned *)(a + y * stride + x), *(const unsigned *)(b + y * stride + x));
     }
-    s = wave_sum(s);                                                 // <= 8 rows x 4096 samples x 255^2 per work-group: fits 32 bits up to 8K pictures
+    s = wave_sum(s);                                                 // a lane: <= 8 rows x 64 samples x 255^2 < 2^25 at 2160p (rows / (4 x 86) per wave); 8K pictures: < 2^27
     __shared__ unsigned part[4];
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
     __syncthreads();
@@ -182,7 +199,7 @@ extern "C" int ks265_sse_picture_on(ks265_ctx *cx, ks265_frame *f, ks265_pic a, 
     KS_FRAME_CHECK(f);
     if (!sse3 || !cx) return KS265_POINTER;
     ks_use_device(cx);
-    hipLaunchKernelGGL(sse_picture_kernel, dim3((unsigned)((f->g.H + 7) / 8), 3), dim3(256), 0, cx->stream, f->g, a.y, a.u, a.v, b.y, b.u, b.v, f->sse_acc, (unsigned long long *)sse3);
+    hipLaunchKernelGGL(sse_picture_kernel, dim3(86, 3), dim3(256), 0, cx->stream, f->g, a.y, a.u, a.v, b.y, b.u, b.v, f->sse_acc, (unsigned long long *)sse3);
     return ks265_check_launch(cx);
 }
 extern "C" int ks265_sse_picture(ks265_frame *f, ks265_pic a, ks265_pic b, uint64_t *sse3) { return f ? ks265_sse_picture_on(f->ctx, f, a, b, sse3) : KS265_POINTER; }

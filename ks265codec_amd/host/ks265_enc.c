@@ -287,6 +287,9 @@ typedef struct Enc {
     /* split pipeline (default): the source picture of slot k is unpacked and padded on the copy-in stream into srcq[k], and the picture's drain (SSE, packing of the
      * records) runs on the copy-out stream behind ev_coded[k]; the next picture's search does not wait for either - it waits for ev_packed[k] only where it first writes
      * a record (ks265_frame_set_records_fence).  Measured at 2160p IPPP: 120 us of a 1.11 ms picture period leave the critical path. */
+    int copy_mb;                                          /* KS265_COPYOUT_MB = N: hipMemcpyAsync takes the fixed part + N MB of stored lines per P / B picture (a key picture: everything) and the copy kernel
+                                                           * only what lies beyond; default -1 = the copy kernel alone.  On this runtime the D2H hipMemcpyAsync is itself a kernel (__amd_rocclr_copyBuffer,
+                                                           * 110 us for 4 MB): no better neighbour than ours (50 us for the ~2 MB a picture really holds) - measured both ways, within +- 1.5 % */
     int split; ks265_pic srcq[NPIPE]; void *ev_coded[NPIPE], *ev_packed[NPIPE];
     long seq;                                             /* pictures submitted */
     /* single-reference P pictures and B pictures as graphs: the launch sequence of a picture (unpack, the pixel path, SSE, packing of the records: ~20 launches) only
@@ -703,7 +706,10 @@ static int submit(Enc *e, Input *in, int kind, int poc, int qp, const int *l0, i
     }
     /* copy-out stream */
     if (!r) r = ks265_stream_wait_event(e->ctx_out, e->ev_staged[k]);
-    if (!r) r = ks265_copy_out_compact_async(e->ctx_out, e->frame, j->cmp, e->stg[k]);   /* fixed part + the stored lines only (~2 MB for a P picture at 2160p) */
+    /* the records go home: the fixed part + the stored lines only (~2 MB for a P picture at 2160p), by a kernel that reads the size on the device (or, KS265_COPYOUT_MB,
+     * a fixed amount by hipMemcpyAsync and the rest by that kernel) */
+    if (!r) r = e->copy_mb < 0 ? ks265_copy_out_compact_async(e->ctx_out, e->frame, j->cmp, e->stg[k])
+                               : ks265_copy_out_compact_dma_async(e->ctx_out, e->frame, j->cmp, e->stg[k], kind == 'I' ? e->cmp_off[7] : (size_t)e->copy_mb << 20);
     if (!r) r = ks265_event_record(e->ctx_out, e->ev_drained[k]);
     if (!r) r = ks265_event_record(e->ctx_out, j->ev);
     if (r) return hip_rc(r);
@@ -1097,6 +1103,7 @@ static Enc *lane_open(QY265EncConfig *cfg, int device, int multi, int *err)
         }
     }
     e->split = getenv("KS265_NO_SPLIT") ? 0 : 1;
+    e->copy_mb = getenv("KS265_COPYOUT_MB") ? atoi(getenv("KS265_COPYOUT_MB")) : -1;
     for (int k = 0; k < NPIPE && !r; ++k) {
         r = ks265_dev_malloc(e->ctx, (void **)&e->dev_in[k], fsz);
         if (!r) r = ks265_dev_malloc(e->ctx, (void **)&e->stg[k], e->cmp_off[7]);
