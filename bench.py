@@ -74,6 +74,7 @@ def main():
     ap.add_argument("--propagate", type=int, default=1, help="hot-path leg: rounds of vector propagation between neighbouring PUs after every integer search (stage A2; the encoder runs 1)")
     ap.add_argument("--no-pre-search", action="store_true", help="hot-path leg: stage A without the pyramid pre-search start candidates (the encoder always runs them)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--two-lanes", action="store_true", help="also run the encoded leg with KS265_GOP_LANES=2 in a process of its own (reported beside value, never as it)")
     ap.add_argument("--leg", choices=["both", "encoded", "hot"], default="both", help="encoded: the whole encoder through the SDK-compatible C API (host pictures in, "
                     "Annex-B NAL units out: H2D, pixel path, D2H, CABAC) = the headline value; hot: the device-resident pixel path only (roofline leg)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak", help="weak (default): every rank encodes --steps pictures of its own clip.  strong: ONE fixed job of --job-frames pictures "
@@ -126,9 +127,10 @@ def main():
             raise SystemExit("--scaling strong splits closed GOPs over the ranks; --b-spread is the other sharding")
     if args.leg != "hot" and not args.b_spread:
         encoded = encoded_leg(args, torch, dist, rank, world, dev_index, backend, sync_all)
-        # the opt-in configuration next to the default one: two closed GOPs coded at once on the GPU (KS265_GOP_LANES=2), reported beside `value`, never as it
+        # round 4: the two-lane leg is gone from the default run (opt in with --two-lanes).  Measured: two GOP lanes code 1.00x, two encoder processes 1.15x
+        # what one lane does on the one GPU - every large kernel of the picture fills the CUs on its own - so lanes are for handles that span several GPUs
         encoded["two_lanes"] = None
-        if args.leg == "both" and args.scaling == "weak" and world == 1 and "KS265_GOP_LANES" not in os.environ and encoded.get("gop_lanes", 1) == 1 and not args.hier_b and not args.bframes:
+        if args.two_lanes and args.leg == "both" and args.scaling == "weak" and world == 1 and "KS265_GOP_LANES" not in os.environ and encoded.get("gop_lanes", 1) == 1 and not args.hier_b and not args.bframes:
             import subprocess                                     # a process of its own: the library asks for eight hardware queues, which only a fresh runtime honours
             try:
                 r = subprocess.run([sys.executable, os.path.abspath(__file__), "--leg", "encoded", "--steps", str(args.steps), "--warmup", str(args.warmup), "--no-cpu-baseline",
@@ -744,7 +746,7 @@ def encoded_line(args, enc, world, hot, cpu):
                    "caller_ms_per_picture": enc.get("caller_ms_per_picture"),
                    "in_the_path": "pyramid pre-search, merge pass (merge / skip decided on SATD + rate, signalled where the motion equals a merge candidate), AMVP with the better of the two "
                                   "predictors, vector propagation between neighbouring PUs (stage A2, one round), joint refinement of bi-predictive pairs (B pictures, bi-prediction judged at 31/32), intra CUs in P / B pictures, coefficient-group pruning (luma) and sign-data hiding "
-                                  "(signBitHidingHDQ) at the postQuant seam, P / B lambda table; fractional samples interpolated on the fly; P / B pictures replayed as captured HIP graphs",
+                                  "(signBitHidingHDQ) at the postQuant seam, P / B lambda table; fractional samples interpolated on the fly; the picture's drain (SSE, packing of the records) and the next source picture's unpack on side streams (DESIGN.md 6a)",
                    "not_in_the_path": "per-coefficient RDOQ (the reference's -rdoq at -preset slow), skip / CU size judged with the residual's cost, generalised B pictures, "
                                       "lookahead / cuTree / adaptive mini-GOP: at equal PSNR the stream is 1.04x (2160p) / 1.10x (1080p) the size of appencoder's for IPPP and 1.93x / 1.51x for hierarchical B (BASELINE.md 2b has the same-clip table)",
                    "sharding": (f"ONE job of {enc['job']['frames']} pictures = {enc['job']['gops']} closed GOPs dealt to the ranks in contiguous runs; every rank encodes its GOPs, the coded bytes are "
