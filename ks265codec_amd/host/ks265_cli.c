@@ -56,7 +56,7 @@ static void usage(void)
 {
     puts("usage: ks265enc -i in.yuv -wdt W -hgt H [-fr FPS] [-preset ultrafast..placebo] [-latency zerolatency|lowdelay|livestreaming|default] [-tune T]\n"
          "                [-rc 0..5] [-qp Q] [-crf C] [-br KBPS] [-iper N] [-bframes N] [-frms N] [-threads N] [-psnr 0|1|2] [-b out.265] [-o recon.yuv]\n"
-         "                [-me 0|1|2] [-subme 0|1|2] [-merange R] [-ref N] [-sao 0..4] [-df 0|1] [-fixqp 0|1] [-md5 0|1] [-c config_file] [-gpus N] [-v]\n"
+         "                [-me 0|1|2] [-subme 0|1|2] [-merange R] [-ref N] [-sao 0..4] [-df 0|1] [-fixqp 0|1] [-md5 0|1] [-scenecut N (with -lookahead: the reference's scene-cut rule at threshold N)] [-c config_file] [-gpus N] [-v]\n"
          "  I420 8-bit input; width and height multiples of 8.  Needs one MI355X (gfx950): there is no CPU fallback.");
 }
 
@@ -122,7 +122,7 @@ int main(int argc, char **argv)
         else if (!strcmp(a, "-o")) rec_path = v;
         else if (!strcmp(a, "-frms")) frames = atoi(v);
         else if (!strcmp(a, "-preset") || !strcmp(a, "-latency") || !strcmp(a, "-tune")) continue;
-        else if (!strcmp(a, "-df") || !strcmp(a, "-fixqp") || !strcmp(a, "-md5")) {       /* CLI switches without a QY265EncConfig field */
+        else if (!strcmp(a, "-df") || !strcmp(a, "-fixqp") || !strcmp(a, "-md5") || !strcmp(a, "-scenecut")) {       /* CLI switches without a QY265EncConfig field */
             if (ks265_enc_set_default(a + 1, atoi(v)) != QY_OK) { fprintf(stderr, "bad value for %s: %s\n", a, v); return 2; }
         }
         else if (!strcmp(a, "-gpus")) setenv("KS265_GPUS", v, 1);                            /* closed GOPs dealt to N GPUs behind this one handle (ks265_enc.h) */

@@ -74,13 +74,14 @@ static void md5_hex(const uint8_t *data, size_t n, char out[33])
 
 /* CLI-level switches of `appencoder` that the SDK's QY265EncConfig has no field for (-df, -fixqp, -md5): process-wide defaults a front end
  * sets before QY265EncoderOpen (ks265_enc_set_default) */
-static struct { int df, fixqp, md5; } g_cli = {1, 0, 0};
+static struct { int df, fixqp, md5, scenecut; } g_cli = {1, 0, 0, 0};
 int ks265_enc_set_default(const char *name, int value)
 {
     if (!name) return QY_POINTER;
     if (!strcmp(name, "df")) { if (value < 0 || value > 1) return QY265_PARAM_BAD_VALUE; g_cli.df = value; return QY_OK; }
     if (!strcmp(name, "fixqp")) { if (value < 0 || value > 1) return QY265_PARAM_BAD_VALUE; g_cli.fixqp = value; return QY_OK; }
     if (!strcmp(name, "md5")) { if (value < 0 || value > 1) return QY265_PARAM_BAD_VALUE; g_cli.md5 = value; return QY_OK; }
+    if (!strcmp(name, "scenecut")) { if (value < 0 || value > 100) return QY265_PARAM_BAD_VALUE; g_cli.scenecut = value; return QY_OK; }   /* the reference's hidden -scenecut N */
     return QY265_PARAM_BAD_NAME;
 }
 
@@ -315,6 +316,7 @@ typedef struct Enc {
      * pre-selection cost against the integer-search cost) - where prediction from the previous picture is not clearly cheaper than intra coding a closed GOP starts */
     int la_on, la_have_prev, la_last_key, la_w, la_h; long la_cuts, la_mini4;
     int mg_adapt, mg4_until;                                          /* slice-type decision (-lookahead N with the hierarchical GOP): a block of 8 pictures is coded as 8 or as 4 + 4; display index up to which 4 is in force */
+    long long la_prev_icost;                                           /* -scenecut N: the previous picture's intra cost (-1: none yet) */
     unsigned long long la_c4_prev;                                     /* inter cost of the previous picture on the GOP's grid of 4 against the picture 4 back */
     ks265_ctx *ctx_la; ks265_frame *frame_la; ks265_frame_geom geom_la; ks265_pic la_pic[LA_RING];
     uint8_t *la_dev_luma; uint32_t *la_cost_ws; uint64_t *la_dev_out, *la_host_out; void *la_ev;
@@ -1099,7 +1101,7 @@ static Enc *lane_open(QY265EncConfig *cfg, int device, int multi, int *err)
             if (!r) r = ks265_dev_malloc(e->ctx_la, (void **)&e->la_dev_out, 128);
             if (!r) r = ks265_host_malloc(e->ctx_la, (void **)&e->la_host_out, 128);
             if (!r) r = ks265_event_create(e->ctx_la, &e->la_ev);
-            if (!r) { e->la_on = 1; e->la_last_key = -1000000; e->la_w = w; e->la_h = h; e->mg_adapt = e->hier; e->mg4_until = -1; }
+            if (!r) { e->la_on = 1; e->la_last_key = -1000000; e->la_prev_icost = -1; e->la_w = w; e->la_h = h; e->mg_adapt = e->hier; e->mg4_until = -1; }
         }
     }
     e->split = getenv("KS265_NO_SPLIT") ? 0 : 1;
@@ -1303,6 +1305,25 @@ static int lane_put(Enc *e, QY265Picture *in, int key)
             if (!r) r = ks265_event_wait(e->ctx_la, e->la_ev);
             /* a cut: predicting the picture from its predecessor costs at least 0.7 of coding it intra (both sums over the 8x8 blocks of the half-size picture),
              * and the last key picture is at least eight pictures back */
+            if (!r && g_cli.scenecut > 0) {
+                /* -scenecut N: the reference's verdict (scenecut enc@0x47e9d0, restated in oracle/ks265_lookahead_ref.c and pinned on recorded calls) on this lookahead's
+                 * frame costs: a change of flatness (intra cost below 4 per 8x8 block of the half-size picture) decides at once; else a cut is where predicting the
+                 * picture costs at least (1 - N / 100 x pictures since the key picture / min(key period, 320)) of coding it intra */
+                const long long icost = (long long)e->la_host_out[0], pcost = (long long)e->la_host_out[1], prev = e->la_prev_icost;
+                const long long T = (long long)(w / 8) * (h / 8) * 4;
+                int verdict = -1;
+                if (prev >= 0) {
+                    if (prev < T) { if (icost > T) verdict = 1; else if (icost < T) verdict = 0; }
+                    else if (prev > T && icost < T) verdict = 1;
+                }
+                if (verdict < 0) {
+                    const int keyint = e->iper > 0 ? (e->iper < 320 ? e->iper : 320) : 256;
+                    const double bias = (double)(nd - (e->la_last_key > -1000000 ? e->la_last_key : 0)) * ((double)g_cli.scenecut / 100.0) / (double)keyint;
+                    verdict = (double)pcost >= (1.0 - bias) * (double)icost;
+                }
+                cut = verdict;
+                e->la_prev_icost = icost;
+            } else
             if (!r && e->la_host_out[1] * 10 >= e->la_host_out[0] * 7 && nd - e->la_last_key >= 8) cut = 1;
         }
         /* slice types of the hierarchical GOP (the reference's adaptive BiPredFrames): the GOP is laid out in blocks of 8 pictures from its key picture; a block is

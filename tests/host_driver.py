@@ -14,6 +14,8 @@ rng = np.random.default_rng(3)
 clip = rng.integers(0, 256, (11, W * H * 3 // 2), dtype=np.uint8)
 cfg = (C.c_uint8 * LAY["sizeof_config"])()
 assert lib.QY265ConfigDefaultPreset(cfg, b"medium", None, b"default") == 0
+if os.environ.get("KS_TEST_SCENECUT"):
+    assert lib.ks265_enc_set_default(b"scenecut", int(os.environ["KS_TEST_SCENECUT"])) == 0
 for k, v in (("wdt", W), ("hgt", H), ("fr", 50), ("rc", int(os.environ.get("KS_TEST_RC", "0"))), ("br", int(os.environ.get("KS_TEST_BR", "1000"))), ("qp", 34), ("iper", iper), ("bframes", bframes), ("threads", 5), ("psnr", 1), ("log", 3), ("lookahead", int(os.environ.get("KS_TEST_LOOKAHEAD", "-1")))):
     assert lib.QY265ConfigParse(cfg, k.encode(), str(v).encode()) == 0
 err = C.c_int(0)

@@ -320,6 +320,17 @@ def test_scene_cut_starts_a_closed_gop(stub_lib, bframes):
     assert close["idr"] == 3, close["idr"]
 
 
+def test_scenecut_flag_runs_the_reference_rule(stub_lib):
+    """-scenecut N (the reference's hidden flag): the scene-cut verdict is the rule of scenecut enc@0x47e9d0 (pinned: tests/test_lookahead_ref.py) on this lookahead's frame
+    costs - no distance guard of its own: cuts three pictures apart are all key pictures; a calm clip has none"""
+    la = run(stub_lib, 60, 128, 0, W=128, H=96, KS_TEST_CUTS="23,41", KS_TEST_LOOKAHEAD=8, KS_TEST_SCENECUT=40)
+    assert la["idr"] == 3 and sorted(la["pts"]) == list(range(60)), la["idr"]
+    close = run(stub_lib, 60, 128, 0, W=128, H=96, KS_TEST_CUTS="20,23,26,40", KS_TEST_LOOKAHEAD=8, KS_TEST_SCENECUT=40)
+    assert close["idr"] == 5, close["idr"]
+    calm = run(stub_lib, 60, 128, 0, W=128, H=96, KS_TEST_CUTS="1000", KS_TEST_LOOKAHEAD=8, KS_TEST_SCENECUT=40)
+    assert calm["idr"] == 1 and calm["md5"] == run(stub_lib, 60, 128, 0, W=128, H=96, KS_TEST_CUTS="1000")["md5"]
+
+
 @pytest.mark.parametrize("lanes", [1, 2])
 def test_zero_copy_input_writes_the_same_stream(stub_lib, lanes):
     """ks265_enc_acquire_input: the caller produces every picture into one of the encoder's pinned buffers and hands that pointer in - nothing is copied, same stream"""
