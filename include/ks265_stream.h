@@ -31,6 +31,7 @@ typedef struct {
     int32_t sdh;                           /* sign_data_hiding_enabled_flag: the levels were produced with ks265_frame_cfg.sdh = 1                  */
     int32_t wpp;                           /* entropy_coding_sync_enabled_flag: every CTU row is a substream with an entry point (the reference's WPP) */
     int32_t list_mod;                      /* lists_modification_present_flag: l0_poc / l1_poc may name the used pictures of the RPS in any order (7.3.6.2)  */
+    int32_t cu_qp_delta;                   /* cu_qp_delta_enabled_flag with diff_cu_qp_delta_depth = 0 (quantisation group = CTU): slices carry a QP per CTU (qp_map)     */
 } ks265_stream_cfg;
 
 enum { KS265_SLICE_B = 0, KS265_SLICE_P = 1, KS265_SLICE_I = 2 };
@@ -57,6 +58,8 @@ typedef struct {
     const ks265_cu8 *cu8;
     const int16_t *lvl[3];
     const ks265_sao_param *sao;            /* NULL = SAO off for this picture                                                        */
+    const int8_t *qp_map;                  /* cfg.cu_qp_delta: the QP each CTU's residual was quantised with (raster order); NULL = the slice QP everywhere.
+                                            * cu_qp_delta goes out with the first coded residual of a CTU, predicted from the previous CTU of the row (8.6.1)  */
 } ks265_slice_in;
 
 /* Parameter sets as Annex-B NAL units (start code 00 00 00 01 included).  Return the number of bytes written, < 0 on error

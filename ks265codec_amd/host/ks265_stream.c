@@ -150,7 +150,8 @@ long ks265_write_pps(const ks265_stream_cfg *cfg, uint8_t *out, size_t cap)
     bw_se(&b, 0);                        /* init_qp_minus26 */
     bw_put(&b, 0, 1);                    /* constrained_intra_pred_flag */
     bw_put(&b, 0, 1);                    /* transform_skip_enabled_flag */
-    bw_put(&b, 0, 1);                    /* cu_qp_delta_enabled_flag */
+    bw_put(&b, cfg->cu_qp_delta ? 1 : 0, 1);   /* cu_qp_delta_enabled_flag */
+    if (cfg->cu_qp_delta) bw_ue(&b, 0);  /* diff_cu_qp_delta_depth: one quantisation group per CTU */
     bw_se(&b, 0); bw_se(&b, 0);          /* pps_cb_qp_offset, pps_cr_qp_offset */
     bw_put(&b, 0, 1);                    /* pps_slice_chroma_qp_offsets_present_flag */
     bw_put(&b, 0, 1);                    /* weighted_pred_flag */
@@ -189,7 +190,7 @@ static const uint8_t kTransIdxLps[64] = {0, 0, 1, 2, 2, 4, 4, 5, 6, 7, 8, 9, 9, 
 enum {
     CX_SAO_MERGE = 0, CX_SAO_TYPE = 1, CX_SPLIT_CU = 2, CX_SKIP = 5, CX_PRED_MODE = 8, CX_PART_MODE = 9, CX_PREV_INTRA = 13, CX_CHROMA_PRED = 14,
     CX_MERGE_FLAG = 15, CX_MERGE_IDX = 16, CX_INTER_DIR = 17, CX_REF_IDX = 22, CX_MVP = 24, CX_MVD = 25, CX_ROOT_CBF = 27, CX_SPLIT_TU = 28,
-    CX_CBF_LUMA = 31, CX_CBF_CHROMA = 33, CX_LAST_X = 37, CX_LAST_Y = 55, CX_CSBF = 73, CX_SIG = 77, CX_G1 = 119, CX_G2 = 143, CX_COUNT = 149
+    CX_CBF_LUMA = 31, CX_CBF_CHROMA = 33, CX_LAST_X = 37, CX_LAST_Y = 55, CX_CSBF = 73, CX_SIG = 77, CX_G1 = 119, CX_G2 = 143, CX_DQP = 149 /* cu_qp_delta_abs: first bin, later bins */, CX_COUNT = 151
 };
 /* initValue per context for initType 0 (I), 1 (P), 2 (B): Tables 9-5 .. 9-37.  154 where a syntax element does not occur. */
 static const uint8_t kInit[3][CX_COUNT] = {
@@ -199,21 +200,24 @@ static const uint8_t kInit[3][CX_COUNT] = {
      91, 171, 134, 141,
      111, 111, 125, 110, 110, 94, 124, 108, 124, 107, 125, 141, 179, 153, 125, 107, 125, 141, 179, 153, 125, 107, 125, 141, 179, 153, 125, 140, 139, 182, 182, 152, 136, 152, 136, 153, 136, 139, 111, 136, 139, 111,
      140, 92, 137, 138, 140, 152, 138, 139, 153, 74, 149, 92, 139, 107, 122, 152, 140, 179, 166, 182, 140, 227, 122, 197,
-     138, 153, 136, 167, 152, 152},
+     138, 153, 136, 167, 152, 152,
+     154, 154},
     {153, 185, 107, 139, 126, 197, 185, 201, 149, 154, 139, 154, 154, 154, 152, 110, 122, 95, 79, 63, 31, 31, 153, 153, 168, 140, 198, 79, 124, 138, 94,
      153, 111, 149, 107, 167, 154,
      125, 110, 94, 110, 95, 79, 125, 111, 110, 78, 110, 111, 111, 95, 94, 108, 123, 108, 125, 110, 94, 110, 95, 79, 125, 111, 110, 78, 110, 111, 111, 95, 94, 108, 123, 108,
      121, 140, 61, 154,
      155, 154, 139, 153, 139, 123, 123, 63, 153, 166, 183, 140, 136, 153, 154, 166, 183, 140, 136, 153, 154, 166, 183, 140, 136, 153, 154, 170, 153, 123, 123, 107, 121, 107, 121, 167, 151, 183, 140, 151, 183, 140,
      154, 196, 196, 167, 154, 152, 167, 182, 182, 134, 149, 136, 153, 121, 136, 137, 169, 194, 166, 167, 154, 167, 137, 182,
-     107, 167, 91, 122, 107, 167},
+     107, 167, 91, 122, 107, 167,
+     154, 154},
     {153, 160, 107, 139, 126, 197, 185, 201, 134, 154, 139, 154, 154, 183, 152, 154, 137, 95, 79, 63, 31, 31, 153, 153, 168, 169, 198, 79, 224, 167, 122,
      153, 111, 149, 92, 167, 154,
      125, 110, 124, 110, 95, 94, 125, 111, 111, 79, 125, 126, 111, 111, 79, 108, 123, 93, 125, 110, 124, 110, 95, 94, 125, 111, 111, 79, 125, 126, 111, 111, 79, 108, 123, 93,
      121, 140, 61, 154,
      170, 154, 139, 153, 139, 123, 123, 63, 124, 166, 183, 140, 136, 153, 154, 166, 183, 140, 136, 153, 154, 166, 183, 140, 136, 153, 154, 170, 153, 138, 138, 122, 121, 122, 121, 167, 151, 183, 140, 151, 183, 140,
      154, 196, 167, 167, 154, 152, 167, 182, 182, 134, 149, 136, 153, 121, 136, 122, 169, 208, 166, 167, 154, 152, 167, 182,
-     107, 167, 91, 107, 107, 167}};
+     107, 167, 91, 107, 107, 167,
+     154, 154}};
 
 typedef struct {
     uint8_t *p; size_t cap, pos; int overflow;
@@ -403,6 +407,7 @@ typedef struct {
     Cabac c;
     Scans scans;
     uint8_t *skip;                         /* cu_skip_flag of every 8x8 block coded so far (context of the neighbours) */
+    int qp_prev, qp_want, dqp_coded;       /* cfg.cu_qp_delta: QpY of the previous quantisation group's last CU, this CTU's QP, IsCuQpDeltaCoded */
 } Enc;
 
 size_t ks265_wpp_bytes(const ks265_stream_cfg *cfg);
@@ -779,6 +784,22 @@ static void mvd_coding(Cabac *c, int dx, int dy)                      /* 7.3.8.9
 /* ------------------------------------------------------------------ coding quadtree */
 static void transform_unit(Enc *e, int x, int y, int log2, int cbf_y, int cbf_cb, int cbf_cr, int intra, int luma_mode)
 {
+    if ((cbf_y | cbf_cb | cbf_cr) && e->cfg->cu_qp_delta && !e->dqp_coded) {
+        /* cu_qp_delta_abs: prefix truncated unary (cMax 5; context 0 for the first bin, 1 for the others), suffix EG0 in bypass; then the sign (7.3.8.14, 9.3.3.10) */
+        Cabac *c = &e->c;
+        const int d = e->qp_want - e->qp_prev, a = d < 0 ? -d : d;
+        const int pre = a < 5 ? a : 5;
+        for (int i = 0; i < pre; ++i) cb_bin(c, CX_DQP + (i > 0), 1);
+        if (pre < 5) cb_bin(c, CX_DQP + (pre > 0), 0);
+        else {
+            int v = a - 5, k = 0;
+            while (v >= (1 << k)) { cb_bypass(c, 1); v -= 1 << k; ++k; }
+            cb_bypass(c, 0);
+            while (k--) cb_bypass(c, (v >> k) & 1);
+        }
+        if (a) cb_bypass(c, d < 0);
+        e->dqp_coded = 1;
+    }
     if (cbf_y) {
         int scan = 0;
         if (intra && (log2 == 2 || log2 == 3)) scan = (luma_mode >= 6 && luma_mode <= 14) ? 2 : (luma_mode >= 22 && luma_mode <= 30) ? 1 : 0;
@@ -1167,7 +1188,10 @@ int ks265_wpp_code_row(void *mem, int ry)
         }
         if (!rc) {
             if (sao_on) sao_ctb(e, rx, ry);
+            if (rx == 0) e->qp_prev = in->qp;                          /* first quantisation group of a CTB row under entropy_coding_sync: SliceQpY (8.6.1) */
+            e->dqp_coded = 0; e->qp_want = in->qp_map ? in->qp_map[ry * w->cols + rx] : in->qp;
             rc = coding_quadtree(e, rx << 6, ry << 6, 6);
+            if (e->dqp_coded) e->qp_prev = e->qp_want;
             const int last = ry == w->rows - 1 && rx == w->cols - 1;
             cb_terminate(&e->c, last);                               /* end_of_slice_segment_flag */
             if (!last && rx == w->cols - 1) cb_terminate(&e->c, 1);  /* end_of_subset_one_bit; byte_alignment() comes with the flush below */
@@ -1247,8 +1271,11 @@ long ks265_write_slice(const ks265_stream_cfg *cfg, const ks265_slice_in *in, vo
     for (int ry = 0; ry < e->ctb_rows; ++ry)
         for (int rx = 0; rx < e->ctb_cols; ++rx) {
             if (sao_on) sao_ctb(e, rx, ry);
+            if (rx == 0 && ry == 0) e->qp_prev = in->qp;               /* (no entropy_coding_sync: the predictor runs on across the rows) */
+            e->dqp_coded = 0; e->qp_want = in->qp_map ? in->qp_map[ry * e->ctb_cols + rx] : in->qp;
             r = coding_quadtree(e, rx << 6, ry << 6, 6);
             if (r) return r;
+            if (e->dqp_coded) e->qp_prev = e->qp_want;
             cb_terminate(&e->c, ry == e->ctb_rows - 1 && rx == e->ctb_cols - 1);   /* end_of_slice_segment_flag */
         }
     cb_finish(&e->c);

@@ -20,13 +20,13 @@ NAL_TRAIL_N, NAL_TRAIL_R, NAL_IDR_W_RADL, NAL_IDR_N_LP = 0, 1, 19, 20
 
 class StreamCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("width", "height", "fps_num", "fps_den", "sao", "deblock", "beta_offset_div2", "tc_offset_div2",
-                                          "max_dec_pic_buffering", "max_num_reorder", "log2_max_poc_lsb", "sdh", "wpp", "list_mod")]
+                                          "max_dec_pic_buffering", "max_num_reorder", "log2_max_poc_lsb", "sdh", "wpp", "list_mod", "cu_qp_delta")]
 
 
 class SliceIn(C.Structure):
     _fields_ = [("nal_type", C.c_int32), ("slice_type", C.c_int32), ("poc", C.c_int32), ("qp", C.c_int32), ("num_rps", C.c_int32),
                 ("rps_poc", C.c_int32 * 16), ("rps_used", C.c_uint8 * 16), ("num_l0", C.c_int32), ("num_l1", C.c_int32),
-                ("l0_poc", C.c_int32 * 4), ("l1_poc", C.c_int32 * 4), ("cu8", C.c_void_p), ("lvl", C.c_void_p * 3), ("sao", C.c_void_p)]
+                ("l0_poc", C.c_int32 * 4), ("l1_poc", C.c_int32 * 4), ("cu8", C.c_void_p), ("lvl", C.c_void_p * 3), ("sao", C.c_void_p), ("qp_map", C.c_void_p)]
 
 
 ENC_SRC = [os.path.join(HERE, "host", "ks265_enc.c")]
@@ -64,9 +64,9 @@ class StreamWriter:
     """Annex-B HEVC stream from per-picture records (host numpy arrays with the dtypes of ks265codec_amd.lib)."""
 
     def __init__(self, width: int, height: int, sao: int = 1, deblock: int = 1, beta_offset_div2: int = 0, tc_offset_div2: int = 0,
-                 max_dec_pic_buffering: int = 2, max_num_reorder: int = 0, sdh: int = 0, wpp: int = 0, list_mod: int = 0):
+                 max_dec_pic_buffering: int = 2, max_num_reorder: int = 0, sdh: int = 0, wpp: int = 0, list_mod: int = 0, cu_qp_delta: int = 0):
         self.l = lib()
-        self.cfg = StreamCfg(width, height, 0, 0, sao, deblock, beta_offset_div2, tc_offset_div2, max_dec_pic_buffering, max_num_reorder, 16, sdh, wpp, list_mod)
+        self.cfg = StreamCfg(width, height, 0, 0, sao, deblock, beta_offset_div2, tc_offset_div2, max_dec_pic_buffering, max_num_reorder, 16, sdh, wpp, list_mod, cu_qp_delta)
         self.scratch = np.zeros(self.l.ks265_slice_scratch_bytes(C.byref(self.cfg)), np.uint8)
         self.out = np.zeros(width * height * 4 + 65536, np.uint8)
 
@@ -80,7 +80,7 @@ class StreamWriter:
         return b"".join(self._take(f(C.byref(self.cfg), o, C.c_size_t(self.out.size))) for f in (self.l.ks265_write_vps, self.l.ks265_write_sps, self.l.ks265_write_pps))
 
     def slice(self, nal_type: int, slice_type: int, poc: int, qp: int, cu8: np.ndarray, lvl: "list[np.ndarray]", sao: "np.ndarray | None",
-              rps: "list[tuple[int, bool]]" = (), l0: "list[int]" = (), l1: "list[int]" = ()) -> bytes:
+              rps: "list[tuple[int, bool]]" = (), l0: "list[int]" = (), l1: "list[int]" = (), qp_map: "np.ndarray | None" = None) -> bytes:
         s = SliceIn()
         s.nal_type, s.slice_type, s.poc, s.qp = nal_type, slice_type, poc, qp
         s.num_rps = len(rps)
@@ -98,5 +98,8 @@ class StreamWriter:
         if sao is not None:
             keep.append(np.ascontiguousarray(sao))
             s.sao = keep[-1].ctypes.data
+        if qp_map is not None:                                            # cfg.cu_qp_delta: one QP per CTU, raster order
+            keep.append(np.ascontiguousarray(qp_map, dtype=np.int8))
+            s.qp_map = keep[-1].ctypes.data
         return self._take(self.l.ks265_write_slice(C.byref(self.cfg), C.byref(s), self.scratch.ctypes.data_as(C.c_void_p),
                                                    self.out.ctypes.data_as(C.c_void_p), C.c_size_t(self.out.size)))

@@ -992,16 +992,53 @@ static void pred14_chroma(const uint8_t *ref0, long st, int xc, int yc, int n, i
     }
 }
 
+/* ------------------------------------------------------------------ QP per CTU (round 4: cu_qp_delta with the quantisation group = the CTU; adaptive quantisation)
+ * kso_set_qp_map(map): one QP per CTU in raster order for everything coded after the call (NULL: the slice QP everywhere - the state every other test runs in).  The
+ * residual of a CTU is quantised with its map entry (chroma through the table).  What the DECODER takes as a CU's QpY is not always that value (H.265 8.6.1 with
+ * Log2MinCuQpDeltaSize = CtbLog2SizeY): cu_qp_delta is sent with the first coded residual of the CTU, so the CUs in front of it (z-order, no residual) keep the predicted
+ * QP = the QpY of the previous CTU's last CU (the slice QP at the start of every CTU row: entropy_coding_sync) - the deblocking filter reads those (kso_effective_qp). */
+static const int8_t *g_qpmap;
+void kso_set_qp_map(const int8_t *map) { g_qpmap = map; }
+static int ctu_qp(const kso_frame_cfg *cfg, int x0, int y0) { return g_qpmap ? g_qpmap[(y0 >> 6) * ((cfg->width + 63) >> 6) + (x0 >> 6)] : cfg->qp; }
+/* QpY of every 8x8 block as the decoder derives it; eff: w8 * h8 bytes */
+void kso_effective_qp(const kso_frame_cfg *cfg, const kso_cu8 *cu8, uint8_t *eff)
+{
+    const int W = cfg->width, H = cfg->height, w8 = W / 8, h8 = H / 8, cols = (W + 63) >> 6, rows = (H + 63) >> 6;
+    for (int cy = 0; cy < rows; ++cy) {
+        int prev = cfg->qp;
+        for (int cx = 0; cx < cols; ++cx) {
+            const int want = g_qpmap ? g_qpmap[cy * cols + cx] : cfg->qp;
+            int cur = prev;                                              /* until the CTU's first coded residual */
+            for (int z = 0; z < 64; ++z) {
+                const int lx = (z & 1) | ((z >> 1) & 2) | ((z >> 2) & 4), ly = ((z >> 1) & 1) | ((z >> 2) & 2) | ((z >> 3) & 4);
+                const int bx = cx * 8 + lx, by = cy * 8 + ly;
+                if (bx >= w8 || by >= h8) continue;
+                const kso_cu8 *c = &cu8[(long)by * w8 + bx];
+                const int n8 = 1 << (CU_LOG2(c) - 3);
+                if (!(lx & (n8 - 1)) && !(ly & (n8 - 1)) && cur != want) {      /* a CU starts here: does it carry residual? */
+                    int any = 0;
+                    for (int yy = 0; yy < n8 && !any; ++yy)
+                        for (int xx = 0; xx < n8; ++xx) if (by + yy < h8 && bx + xx < w8 && cu8[(long)(by + yy) * w8 + bx + xx].cbf) { any = 1; break; }
+                    if (any) cur = want;
+                }
+                eff[(long)by * w8 + bx] = (uint8_t)cur;
+            }
+            prev = cur;
+        }
+    }
+}
+
 /* list 0 may hold several reference pictures (multi-reference P pictures, -ref / -ref0): the CU's picture is refs0[inter_dir >> 4] */
 static void reconstruct_impl(const kso_frame_cfg *cfg, kso_pic src, const kso_pic *refs0, const uint8_t *const *planes0, kso_pic ref1, const uint8_t *planes1,
                              kso_cu8 *cu8, int16_t *lvl_y, int16_t *lvl_u, int16_t *lvl_v, kso_pic recon)
 {
     kso_frame_geom g; kso_frame_geometry(cfg, &g);
-    int W = cfg->width, H = cfg->height, w8 = W / 8, h8 = H / 8, qp = cfg->qp, qpc = chroma_qp(qp);
+    int W = cfg->width, H = cfg->height, w8 = W / 8, h8 = H / 8;
     long sy = g.stride_y, sc = g.stride_c;
     for (int by = 0; by < h8; ++by)
         for (int bx = 0; bx < w8; ++bx) {
             kso_cu8 *c = &cu8[(long)by * w8 + bx];
+            const int qp = ctu_qp(cfg, bx * 8, by * 8), qpc = chroma_qp(qp);
             int n8 = 1 << (CU_LOG2(c) - 3);
             int tu8 = imin(CU_PART(c) ? n8 >> 1 : n8, 4);       /* TU = min(CU, 32); a CU in two partitions: four TUs (interSplitFlag) */
             if ((bx % tu8) || (by % tu8)) continue;             /* visit each TU once, at its top-left 8x8 block */
@@ -1119,30 +1156,33 @@ int kso_test_edge_bs(const kso_cu8 *p, const kso_cu8 *q, int pos8) { return edge
 void kso_deblock(const kso_frame_cfg *cfg, const kso_cu8 *cu8, kso_pic recon)
 {
     kso_frame_geom g; kso_frame_geometry(cfg, &g);
-    int W = cfg->width, H = cfg->height, w8 = W / 8, h8 = H / 8, qp = cfg->qp;
-    int beta = ks265o_beta_table[iclip(0, 51, qp + 2 * cfg->beta_offset_div2)];
+    int W = cfg->width, H = cfg->height, w8 = W / 8, h8 = H / 8;
+    uint8_t *eff = NULL;
+    if (g_qpmap) { eff = malloc((size_t)w8 * h8); kso_effective_qp(cfg, cu8, eff); }
     uint8_t *Y = org_y(&g, recon.y);
     for (int dir = 0; dir < 2; ++dir) {
-        /* luma, 8x8 grid */
+        /* luma, 8x8 grid; QpL = (QpP + QpQ + 1) >> 1 of the two CUs (8.7.2.5.3) */
         for (int by = 0; by < h8; ++by)
             for (int bx = 0; bx < w8; ++bx) {
                 if (dir == 0 ? bx == 0 : by == 0) continue;
                 const kso_cu8 *q = &cu8[(long)by * w8 + bx], *p = dir == 0 ? q - 1 : q - w8;
                 int bs = edge_bs(p, q, dir == 0 ? bx : by);
                 if (!bs) continue;
+                const int qp = eff ? (eff[(long)by * w8 + bx] + eff[(long)by * w8 + bx - (dir == 0 ? 1 : w8)] + 1) >> 1 : cfg->qp;
+                int beta = ks265o_beta_table[iclip(0, 51, qp + 2 * cfg->beta_offset_div2)];
                 int tc = ks265o_tc_table[iclip(0, 53, qp + 2 * (bs - 1) + 2 * cfg->tc_offset_div2)];
                 uint8_t *pix = Y + (long)by * 8 * g.stride_y + bx * 8;
                 if (dir == 0) ks265o_edge_filter_luma_ver(pix, g.stride_y, beta, tc, 8, 1, 1);
                 else ks265o_edge_filter_luma_hor(pix, g.stride_y, beta, tc, 8, 1, 1);
             }
-        /* chroma, 8x8 chroma grid = 16 luma samples, only bS == 2 */
-        int qpc = chroma_qp(qp);
+        /* chroma, 8x8 chroma grid = 16 luma samples, only bS == 2; QpC from the table at the average of the two CUs' QpY (8.7.2.5.5) */
         for (int by = 0; by < h8; ++by)
             for (int bx = 0; bx < w8; ++bx) {
                 if (dir == 0 ? (bx == 0 || (bx & 1)) : (by == 0 || (by & 1))) continue;
                 const kso_cu8 *q = &cu8[(long)by * w8 + bx], *p = dir == 0 ? q - 1 : q - w8;
                 if (edge_bs(p, q, dir == 0 ? bx : by) != 2) continue;
-                int tc = ks265o_tc_table[iclip(0, 53, qpc + 2 + 2 * cfg->tc_offset_div2)];
+                const int qp = eff ? (eff[(long)by * w8 + bx] + eff[(long)by * w8 + bx - (dir == 0 ? 1 : w8)] + 1) >> 1 : cfg->qp;
+                int tc = ks265o_tc_table[iclip(0, 53, chroma_qp(qp) + 2 + 2 * cfg->tc_offset_div2)];
                 for (int comp = 0; comp < 2; ++comp) {
                     uint8_t *pix = org_c(&g, comp ? recon.v : recon.u) + (long)by * 4 * g.stride_c + bx * 4;
                     if (dir == 0) ks265o_pixel_filter_chroma_ver(pix, g.stride_c, tc, 4, 1, 1);
@@ -1150,6 +1190,7 @@ void kso_deblock(const kso_frame_cfg *cfg, const kso_cu8 *cu8, kso_pic recon)
                 }
             }
     }
+    free(eff);
 }
 
 /* ------------------------------------------------------------------ Stage F: SAO
@@ -1447,7 +1488,7 @@ void kso_lookahead_reduce(const kso_frame_cfg *cfg, const uint32_t *intra_cost, 
 static void intra_code_cu(const kso_frame_cfg *cfg, const kso_frame_geom *g, kso_pic src, kso_cu8 *cu8, int bx, int by, int16_t *lvl_y, int16_t *lvl_u,
                           int16_t *lvl_v, kso_pic recon, int islice)
 {
-    int W = cfg->width, H = cfg->height, w8 = W / 8, qp = cfg->qp, qpc = chroma_qp(qp);
+    int W = cfg->width, H = cfg->height, w8 = W / 8, qp = ctu_qp(cfg, bx * 8, by * 8), qpc = chroma_qp(qp);
     long sy = g->stride_y, sc = g->stride_c;
     kso_cu8 *c = &cu8[(long)by * w8 + bx];
     int n = 1 << CU_LOG2(c), x0 = bx * 8, y0 = by * 8, mode = c->mvx, log2 = CU_LOG2(c), cbf = 0;

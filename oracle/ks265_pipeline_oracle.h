@@ -80,6 +80,9 @@ void kso_reconstruct_mref(const kso_frame_cfg *cfg, kso_pic src, int nref, const
 void kso_deblock(const kso_frame_cfg *cfg, const kso_cu8 *cu8, kso_pic recon);
 void kso_sao(const kso_frame_cfg *cfg, kso_pic src, kso_pic deblocked, kso_sao_param *sao, kso_pic dst);
 
+/* QP per CTU (cu_qp_delta, quantisation group = CTU): see the comment in ks265_pipeline_oracle.c */
+void kso_set_qp_map(const int8_t *map);
+void kso_effective_qp(const kso_frame_cfg *cfg, const kso_cu8 *cu8, uint8_t *eff);
 #ifdef __cplusplus
 }
 #endif

@@ -102,6 +102,17 @@ class OraclePipeline:
     def set_qp(self, qp, lambda_q4):
         self.cfg.qp, self.cfg.lambda_q4 = qp, lambda_q4
 
+    def set_qp_map(self, qp_map: "np.ndarray | None"):
+        """one QP per CTU (raster) for the pictures coded from here on (None: the slice QP everywhere); the oracle keeps the pointer: the array is held here"""
+        self._qp_map = None if qp_map is None else np.ascontiguousarray(qp_map, dtype=np.int8)
+        self.o.kso_set_qp_map(ptr(self._qp_map) if self._qp_map is not None else None)
+
+    def effective_qp(self) -> np.ndarray:
+        """QpY of every 8x8 block as the decoder derives it from the last coded picture's CU map"""
+        eff = np.zeros((self.cfg.height // 8) * (self.cfg.width // 8), np.uint8)
+        self.o.kso_effective_qp(C.byref(self.cfg), ptr(self.cu8), ptr(eff))
+        return eff
+
     def load(self, pic: HostPic, i420: np.ndarray):
         self.o.kso_load_i420(C.byref(self.cfg), ptr(np.ascontiguousarray(i420)), pic.c())
 
