@@ -304,6 +304,11 @@ int ks265_frame_geometry(const ks265_frame_cfg *cfg, ks265_frame_geom *geom);
 int ks265_frame_create(ks265_ctx *ctx, const ks265_frame_cfg *cfg, ks265_frame **out);
 /* frames keep a pointer to their context: destroy every frame BEFORE ks265_destroy(ctx) */
 void ks265_frame_destroy(ks265_frame *f);
+/* round 4: one QP per CTU (raster order; DEVICE memory that stays valid while pictures coded with it are in flight; NULL = cfg.qp everywhere) for the pictures coded from
+ * here on: every CTU's residual is quantised with its entry (chroma through the table), the deblocking filter runs at the QpY the DECODER derives for each CU
+ * (cu_qp_delta with the quantisation group = the CTU: H.265 8.6.1 - ks265_stream_cfg.cu_qp_delta, ks265_slice_in.qp_map carry it into the stream).  The decisions
+ * (lambda) stay on the picture's QP.  GPU == oracle with random maps: tests/test_gpu_dqp.py; the decoder's verdict on the oracle: tests/test_dqp.py */
+int ks265_frame_set_qp_map(ks265_frame *f, const int8_t *dev_qp_map);
 int ks265_frame_set_qp(ks265_frame *f, int qp, int lambda_q4);
 
 /* expandPicture_c enc@0x4a6ae0: replicate the picture edge into the borders of all three planes */

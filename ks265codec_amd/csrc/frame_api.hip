@@ -79,9 +79,18 @@ void ks265_frame_destroy(ks265_frame *f)
         if (p) (void)hipFree(p);
     for (uint8_t *p : f->pyr)
         if (p) (void)hipFree(p);
+    if (f->qp_eff) (void)hipFree(f->qp_eff);
     delete f;
 }
 
+/* one QP per CTU (raster order, device memory of the host: it must stay valid until the pictures coded with it have run) for every picture coded from here on; null = cfg.qp
+ * everywhere.  The residual of a CTU is quantised with its entry, the deblocking filter reads the QpY the decoder derives (cu_qp_delta, quantisation group = CTU) */
+int ks265_frame_set_qp_map(ks265_frame *f, const int8_t *dev_qp_map)
+{
+    KS_FRAME_CHECK(f);
+    f->qp_map = dev_qp_map;
+    return KS265_OK;
+}
 int ks265_frame_set_qp(ks265_frame *f, int qp, int lambda_q4)
 {
     KS_FRAME_CHECK(f);

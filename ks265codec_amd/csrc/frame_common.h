@@ -43,6 +43,8 @@ struct ks265_frame {
     unsigned long long *sse_acc = nullptr;   // ks265_sse_picture: three running sums + finished work-groups (zero between calls)
     short *mats = nullptr;              // forward + transposed DCT matrices of all sizes in the kernels' LDS layout (2 x MAT_SHORTS)
     int *progress = nullptr;            // intra wavefront: CTUs finished per CTU row
+    const int8_t *qp_map = nullptr;      // round 4: one QP per CTU (ks265_frame_set_qp_map; null = cfg.qp everywhere), device memory of the host
+    uint8_t *qp_eff = nullptr;           // ... and the QpY of every 8x8 block as the decoder derives it (deblocking), w8 * h8 bytes, allocated on first use
     void *rec_fence = nullptr;               // event the next picture waits for before it writes a record (ks265_frame_set_records_fence); consumed by that picture
     void *rect = nullptr;                                  // cfg.part: the 2NxN / Nx2N records of the P picture being coded (KsRect, 21 per CTU)
     uint32_t *icost = nullptr;                             // cfg.intra_inter: intra candidates of the P / B picture being coded (85 per CTU: cost << 6 | mode)

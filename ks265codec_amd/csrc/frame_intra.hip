@@ -295,7 +295,7 @@ __device__ __forceinline__ void tu_pipeline(IntraLds &L, const TuRole &r, const 
 template <bool PMODE>
 __global__ __launch_bounds__(256) void intra_recon_kernel(KsGeom g, int qp, const uint8_t *src_y, const uint8_t *src_u, const uint8_t *src_v, ks265_cu8 *cu8,
                                                           int16_t *lvl_y, int16_t *lvl_u, int16_t *lvl_v, uint8_t *rec_y, uint8_t *rec_u, uint8_t *rec_v,
-                                                          int *progress, unsigned *err_word, int spin_limit, int sdh_on, long long rdo_lam2k)
+                                                          int *progress, unsigned *err_word, int spin_limit, int sdh_on, long long rdo_lam2k, const int8_t *qp_map)
 {
     __shared__ __attribute__((aligned(16))) IntraLds L;
     // PMODE: one work-group per CTU in raster order (a CTU's neighbours have smaller indices, so the work-groups it may wait for were dispatched before it);
@@ -325,21 +325,26 @@ __global__ __launch_bounds__(256) void intra_recon_kernel(KsGeom g, int qp, cons
         }
     }
     build_matrices(L.Mf, L.Mt, tid, 256);                            // (cheaper than fetching the frame's copy: no memory latency)
-    const int qpc = chroma_qp(qp);
     TuCtx c;
     c.sdh = sdh_on != 0;
     c.rdo_lam2k = PMODE ? rdo_lam2k : 0; c.qoff = PMODE ? 85 : 171;
     c.g = &g; c.lvl_y = lvl_y; c.lvl_u = lvl_u; c.lvl_v = lvl_v;
-    // quantiser constants of the two QPs, fetched once (a table load inside the CU loop would sit behind every outstanding store)
-    c.qsc[0] = kQuantScales[qp % 6]; c.qsc[1] = kQuantScales[qpc % 6];
-    c.qdq[0] = kInvQuantScales[qp % 6] << (qp / 6); c.qdq[1] = kInvQuantScales[qpc % 6] << (qpc / 6);
-    c.qp6[0] = qp / 6; c.qp6[1] = qpc / 6;
+    // quantiser constants of the two QPs, fetched once per CTU (a table load inside the CU loop would sit behind every outstanding store); with a QP per CTU
+    // (qp_map: cu_qp_delta, quantisation group = CTU) a key picture's work-group sets them again at every CTU of its row
+    auto set_qp = [&](int q) {
+        const int qc = chroma_qp(q);
+        c.qsc[0] = kQuantScales[q % 6]; c.qsc[1] = kQuantScales[qc % 6];
+        c.qdq[0] = kInvQuantScales[q % 6] << (q / 6); c.qdq[1] = kInvQuantScales[qc % 6] << (qc / 6);
+        c.qp6[0] = q / 6; c.qp6[1] = qc / 6;
+    };
+    set_qp(qp_map ? qp_map[cy * g.ctu_cols + cx_first] : qp);
     // (component pointers are picked with selects, not from an array: a dynamically indexed pointer array loses the global address
     //  space, its stores become FLAT stores, and FLAT stores count against lgkmcnt - every LDS barrier would wait for HBM)
     const uint8_t *const S0 = ks_org_y(g, src_y), *const S1 = ks_org_c(g, src_u), *const S2 = ks_org_c(g, src_v);
     c.R0 = ks_org_y(g, rec_y); c.R1 = ks_org_c(g, rec_u); c.R2 = ks_org_c(g, rec_v);
     for (int cx = cx_first; cx < cx_end; ++cx) {
         __syncthreads();                                             // nobody still walks the previous CTU's map
+        if (!PMODE && qp_map && cx > cx_first) set_qp(qp_map[cy * g.ctu_cols + cx]);
         if (tid < 64) {
             const int bx = cx * 8 + (tid & 7), by = cy * 8 + (tid >> 3);
             ks265_cu8 cu;
@@ -525,7 +530,7 @@ extern "C" int ks265_intra_reconstruct(ks265_frame *f, ks265_pic src, ks265_cu8 
     if (!src.y || !cu8 || !lvl_y || !lvl_u || !lvl_v || !recon.y) return KS265_POINTER;
     if (hipMemsetAsync(f->progress, 0, sizeof(int) * (size_t)f->g.ctu_rows, f->ctx->stream) != hipSuccess) return ks265_hip(f->ctx, hipGetLastError());
     hipLaunchKernelGGL(intra_recon_kernel<false>, dim3(f->g.ctu_rows), dim3(256), 0, f->ctx->stream, f->g, f->cfg.qp, src.y, src.u, src.v, cu8, lvl_y, lvl_u, lvl_v,
-                       recon.y, recon.u, recon.v, f->progress, f->ctx->err_dev, f->ctx->wavefront_spin_limit, f->cfg.sdh, 0ll);
+                       recon.y, recon.u, recon.v, f->progress, f->ctx->err_dev, f->ctx->wavefront_spin_limit, f->cfg.sdh, 0ll, f->qp_map);
     return ks265_check_launch(f->ctx);
 }
 // cfg.intra_inter: the intra CUs of a P / B picture, after ks265_reconstruct[_b / _mref] has written the inter CUs into `recon`
@@ -537,7 +542,7 @@ extern "C" int ks265_intra_inter_reconstruct(ks265_frame *f, ks265_pic src, ks26
     if (hipMemsetAsync(f->progress, 0, sizeof(int) * (size_t)nctu, f->ctx->stream) != hipSuccess) return ks265_hip(f->ctx, hipGetLastError());
     const long long lam2k = (long long)f->cfg.lambda_q4 * f->cfg.lambda_q4 * (f->cfg.rdo > 0 ? f->cfg.rdo : 0);
     hipLaunchKernelGGL(intra_recon_kernel<true>, dim3(nctu), dim3(256), 0, f->ctx->stream, f->g, f->cfg.qp, src.y, src.u, src.v, cu8, lvl_y, lvl_u, lvl_v,
-                       recon.y, recon.u, recon.v, f->progress, f->ctx->err_dev, f->ctx->wavefront_spin_limit, f->cfg.sdh, lam2k);
+                       recon.y, recon.u, recon.v, f->progress, f->ctx->err_dev, f->ctx->wavefront_spin_limit, f->cfg.sdh, lam2k, f->qp_map);
     return ks265_check_launch(f->ctx);
 }
 

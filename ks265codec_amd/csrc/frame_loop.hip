@@ -27,8 +27,9 @@ __device__ __forceinline__ int edge_bs(const ks265_cu8 p, const ks265_cu8 q, int
 
 // DIR 0: vertical edges (filter across x), DIR 1: horizontal edges.
 // thread = (edge block bx/by, 4-line segment); luma first, then the two chroma planes (bS == 2 only)
+// eff (null = the slice QP everywhere): QpY of every 8x8 block as the decoder derives it (qp_eff_kernel); an edge filters at QpL = (QpP + QpQ + 1) >> 1 (8.7.2.5.3)
 template <int DIR>
-__global__ __launch_bounds__(256) void deblock_kernel(KsGeom g, int qp, int beta, int tc_off2, const ks265_cu8 *cu8, uint8_t *ry, uint8_t *ru, uint8_t *rv)
+__global__ __launch_bounds__(256) void deblock_kernel(KsGeom g, int qp, int beta, int beta_off2, int tc_off2, const ks265_cu8 *cu8, uint8_t *ry, uint8_t *ru, uint8_t *rv, const uint8_t *eff)
 {
     const int gid = blockIdx.x * 256 + threadIdx.x;
     const int nseg_l = DIR == 0 ? g.w8 * (g.H / 4) : (g.W / 4) * g.h8;       // luma segments (incl. the skipped picture-edge column/row)
@@ -40,6 +41,7 @@ __global__ __launch_bounds__(256) void deblock_kernel(KsGeom g, int qp, int beta
         const ks265_cu8 q = cu8[(long)by * g.w8 + bx], p = DIR == 0 ? cu8[(long)by * g.w8 + bx - 1] : cu8[(long)(by - 1) * g.w8 + bx];
         const int bs = edge_bs(p, q, DIR == 0 ? bx : by);
         if (!bs) return;
+        if (eff) { qp = (eff[(long)by * g.w8 + bx] + eff[(long)by * g.w8 + bx - (DIR == 0 ? 1 : g.w8)] + 1) >> 1; beta = kBetaTable[clip3(0, 51, qp + beta_off2)]; }
         const int tc = kTcTable[clip3(0, 53, qp + 2 * (bs - 1) + tc_off2)];
         uint8_t *Y = ks_org_y(g, ry);
         int px[4][8];
@@ -87,6 +89,7 @@ __global__ __launch_bounds__(256) void deblock_kernel(KsGeom g, int qp, int beta
     if (DIR == 0 ? (bx == 0 || (bx & 1)) : (by == 0 || (by & 1))) return;
     const ks265_cu8 q = cu8[(long)by * g.w8 + bx], p = DIR == 0 ? cu8[(long)by * g.w8 + bx - 1] : cu8[(long)(by - 1) * g.w8 + bx];
     if (edge_bs(p, q, DIR == 0 ? bx : by) != 2) return;
+    if (eff) qp = (eff[(long)by * g.w8 + bx] + eff[(long)by * g.w8 + bx - (DIR == 0 ? 1 : g.w8)] + 1) >> 1;
     const int tc = kTcTable[clip3(0, 53, chroma_qp(qp) + 2 + tc_off2)];
     uint8_t *C = ks_org_c(g, comp ? rv : ru) + (long)by * 4 * g.sc + bx * 4;
     const long xs = DIR == 0 ? 1 : g.sc, ys = DIR == 0 ? g.sc : 1;
@@ -96,6 +99,34 @@ __global__ __launch_bounds__(256) void deblock_kernel(KsGeom g, int qp, int beta
         int p1 = pp[-2 * xs], p0 = pp[-xs], q0 = pp[0], q1 = pp[xs];
         deblock_chroma_line(p1, p0, q0, q1, tc, true, true);
         pp[-xs] = (uint8_t)p0; pp[0] = (uint8_t)q0;
+    }
+}
+
+// QpY per 8x8 block with a QP per CTU (H.265 8.6.1, Log2MinCuQpDeltaSize = CtbLog2SizeY, entropy_coding_sync): cu_qp_delta arrives with the first coded residual of a
+// CTU, so the CUs in front of it (z-order) keep the predicted QP = the QpY of the previous CTU's last CU, the slice QP at the start of a CTU row.  One thread per CTU row.
+__global__ void qp_eff_kernel(KsGeom g, int slice_qp, const int8_t *qp_map, const ks265_cu8 *cu8, uint8_t *eff)
+{
+    const int cy = blockIdx.x * blockDim.x + threadIdx.x;
+    if (cy >= g.ctu_rows) return;
+    int prev = slice_qp;
+    for (int cx = 0; cx < g.ctu_cols; ++cx) {
+        const int want = qp_map[cy * g.ctu_cols + cx];
+        int cur = prev;
+        for (int z = 0; z < 64; ++z) {
+            const int lx = (z & 1) | ((z >> 1) & 2) | ((z >> 2) & 4), ly = ((z >> 1) & 1) | ((z >> 2) & 2) | ((z >> 3) & 4);
+            const int bx = cx * 8 + lx, by = cy * 8 + ly;
+            if (bx >= g.w8 || by >= g.h8) continue;
+            const ks265_cu8 c = cu8[(long)by * g.w8 + bx];
+            const int n8 = 1 << ((c.log2_cu & 15) - 3);
+            if (cur != want && !(lx & (n8 - 1)) && !(ly & (n8 - 1))) {            // a CU starts here: does it carry residual?
+                bool any = false;
+                for (int yy = 0; yy < n8 && !any; ++yy)
+                    for (int xx = 0; xx < n8; ++xx) if (by + yy < g.h8 && bx + xx < g.w8 && cu8[(long)(by + yy) * g.w8 + bx + xx].cbf) { any = true; break; }
+                if (any) cur = want;
+            }
+            eff[(long)by * g.w8 + bx] = (uint8_t)cur;
+        }
+        prev = cur;
     }
 }
 
@@ -109,9 +140,15 @@ extern "C" int ks265_deblock(ks265_frame *f, const ks265_cu8 *cu8, ks265_pic rec
     static const unsigned char beta_tab[52] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 20, 22, 24,
                                                26, 28, 30, 32, 34, 36, 38, 40, 42, 44, 46, 48, 50, 52, 54, 56, 58, 60, 62, 64};
     const int beta = beta_tab[beta_idx];
+    const uint8_t *eff = nullptr;
+    if (f->qp_map) {
+        if (!f->qp_eff && hipMalloc((void **)&f->qp_eff, (size_t)g.w8 * g.h8) != hipSuccess) return KS265_OUTOFMEMORY;
+        hipLaunchKernelGGL(qp_eff_kernel, dim3((g.ctu_rows + 63) / 64), dim3(64), 0, f->ctx->stream, g, qp, f->qp_map, cu8, f->qp_eff);
+        eff = f->qp_eff;
+    }
     const int n0 = g.w8 * (g.H / 4) + 2 * g.w8 * g.h8, n1 = (g.W / 4) * g.h8 + 2 * g.w8 * g.h8;
-    hipLaunchKernelGGL(deblock_kernel<0>, dim3((n0 + 255) / 256), dim3(256), 0, f->ctx->stream, g, qp, beta, 2 * f->cfg.tc_offset_div2, cu8, recon.y, recon.u, recon.v);
-    hipLaunchKernelGGL(deblock_kernel<1>, dim3((n1 + 255) / 256), dim3(256), 0, f->ctx->stream, g, qp, beta, 2 * f->cfg.tc_offset_div2, cu8, recon.y, recon.u, recon.v);
+    hipLaunchKernelGGL(deblock_kernel<0>, dim3((n0 + 255) / 256), dim3(256), 0, f->ctx->stream, g, qp, beta, 2 * f->cfg.beta_offset_div2, 2 * f->cfg.tc_offset_div2, cu8, recon.y, recon.u, recon.v, eff);
+    hipLaunchKernelGGL(deblock_kernel<1>, dim3((n1 + 255) / 256), dim3(256), 0, f->ctx->stream, g, qp, beta, 2 * f->cfg.beta_offset_div2, 2 * f->cfg.tc_offset_div2, cu8, recon.y, recon.u, recon.v, eff);
     return ks265_check_launch(f->ctx);
 }
 

@@ -348,7 +348,7 @@ template <bool MREF>
 __global__ __launch_bounds__(256) void reconstruct_kernel(KsGeom g, int qp, const uint8_t *src_y, const uint8_t *src_u, const uint8_t *src_v,
                                                           const uint8_t *ref_y, const uint8_t *ref_u, const uint8_t *ref_v,
                                                           const uint8_t *ref1_y, const uint8_t *ref1_u, const uint8_t *ref1_v, ks265_cu8 *cu8,
-                                                          int16_t *lvl_y, int16_t *lvl_u, int16_t *lvl_v, uint8_t *rec_y, uint8_t *rec_u, uint8_t *rec_v, const short *mats, const KsRefExtra xr, int sdh_on, int dec_k, long long rdo_lam2k)
+                                                          int16_t *lvl_y, int16_t *lvl_u, int16_t *lvl_v, uint8_t *rec_y, uint8_t *rec_u, uint8_t *rec_v, const short *mats, const KsRefExtra xr, int sdh_on, int dec_k, long long rdo_lam2k, const int8_t *qp_map)
 {
     __shared__ __attribute__((aligned(16))) short Mf[MAT_SHORTS];
     __shared__ __attribute__((aligned(16))) short Mt[MAT_SHORTS];
@@ -367,6 +367,7 @@ __global__ __launch_bounds__(256) void reconstruct_kernel(KsGeom g, int qp, cons
     // line of the source / prediction / level rows meet in one L2 instead of four (measured: FETCH_SIZE 3.9x the algorithmic reads)
     const int nrx = (g.W + 31) / 32, nreg = nrx * ((g.H + 31) / 32);
     const int reg = ks_xcd_swizzle(blockIdx.x, nreg), rx = reg % nrx, ry = reg / nrx;
+    if (qp_map) qp = qp_map[(ry >> 1) * g.ctu_cols + (rx >> 1)];        // a 32x32 region lies in one CTU: its QP (cu_qp_delta, quantisation group = CTU)
     // transform matrices: built once per frame object (ks265_frame_create), 6.4 KB copied from L2 with 16-byte loads
     for (int i = tid; i < MAT_SHORTS / 8; i += 256) {
         ((uint4 *)Mf)[i] = ((const uint4 *)mats)[i];
@@ -409,7 +410,7 @@ static int launch_reconstruct(ks265_frame *f, ks265_pic src, ks265_pic ref0, ks2
 {
     dim3 grid(((f->g.W + 31) / 32) * ((f->g.H + 31) / 32));
     hipLaunchKernelGGL(reconstruct_kernel<false>, grid, dim3(256), 0, f->ctx->stream, f->g, f->cfg.qp, src.y, src.u, src.v, ref0.y, ref0.u, ref0.v, ref1.y,
-                       ref1.u, ref1.v, cu8, lvl_y, lvl_u, lvl_v, recon.y, recon.u, recon.v, f->mats, KsRefExtra{}, f->cfg.sdh, f->cfg.decimate, ks_rdo_lam2k(f));
+                       ref1.u, ref1.v, cu8, lvl_y, lvl_u, lvl_v, recon.y, recon.u, recon.v, f->mats, KsRefExtra{}, f->cfg.sdh, f->cfg.decimate, ks_rdo_lam2k(f), f->qp_map);
     return ks265_check_launch(f->ctx);
 }
 
@@ -428,7 +429,7 @@ extern "C" int ks265_reconstruct_mref(ks265_frame *f, ks265_pic src, int nref, c
     dim3 grid(((f->g.W + 31) / 32) * ((f->g.H + 31) / 32));
     hipLaunchKernelGGL(reconstruct_kernel<true>, grid, dim3(256), 0, f->ctx->stream, f->g, f->cfg.qp, src.y, src.u, src.v, refs[0].y, refs[0].u, refs[0].v,
                        (const uint8_t *)nullptr, (const uint8_t *)nullptr, (const uint8_t *)nullptr, cu8, lvl_y, lvl_u, lvl_v, recon.y, recon.u,
-                       recon.v, f->mats, xr, f->cfg.sdh, f->cfg.decimate, ks_rdo_lam2k(f));
+                       recon.v, f->mats, xr, f->cfg.sdh, f->cfg.decimate, ks_rdo_lam2k(f), f->qp_map);
     return ks265_check_launch(f->ctx);
 }
 

@@ -220,6 +220,7 @@ int ks265_graph_destroy(ks265_ctx *c, void *exec) { (void)c; Graph *g = (Graph *
 int ks265_load_i420(ks265_frame *f, const uint8_t *i420, ks265_pic dst) { Op o = {OP_LOAD, f, i420, dst, dst, dst, dst, 0, NULL}; return issue(f->ctx, o); }
 int ks265_load_i420_on(ks265_ctx *c, ks265_frame *f, const uint8_t *i420, ks265_pic dst) { (void)c; return ks265_load_i420(f, i420, dst); }   /* the stand-in runs every call at once: streams do not exist */
 int ks265_frame_set_records_fence(ks265_frame *f, void *ev) { (void)f; (void)ev; return KS265_OK; }
+int ks265_frame_set_qp_map(ks265_frame *f, const int8_t *m) { (void)f; (void)m; return KS265_OK; }
 int ks265_store_i420(ks265_frame *f, ks265_pic src, uint8_t *i420)
 {
     const int W = f->cfg.width, H = f->cfg.height;
