@@ -113,7 +113,32 @@ __global__ __launch_bounds__(256) void cutree_clip_kernel(int n, unsigned long l
     }
 }
 
+// the QP of every CTU from the 16x16 blocks' offsets: base + round(mean over the CTU's blocks, summed in raster order), clipped (this build's own rule: the quantisation group
+// is the CTU; the reference applies its offsets per CU inside closed code)
+__global__ __launch_bounds__(64) void aq_ctu_map_kernel(const double *off, int nx, int ny, int base_qp, int lo, int hi, int8_t *map)
+{
+    const int cols = (nx + 3) / 4, rows = (ny + 3) / 4, ctu = blockIdx.x * 64 + threadIdx.x;
+    if (ctu >= cols * rows) return;
+    const int cx = ctu % cols, cy = ctu / cols;
+    double sum = 0.0;
+    int cnt = 0;
+    for (int by = cy * 4; by < min(cy * 4 + 4, ny); ++by)
+        for (int bx = cx * 4; bx < min(cx * 4 + 4, nx); ++bx) { sum += off[by * nx + bx]; ++cnt; }
+    const int q = base_qp + (int)floor(sum / (double)cnt + 0.5);
+    map[ctu] = (int8_t)(q < lo ? lo : q > hi ? hi : q);
+}
+
 extern "C" {
+
+int ks265_aq_ctu_map(ks265_ctx *ctx, const double *dev_qp_off, int nx, int ny, int base_qp, int qp_lo, int qp_hi, int8_t *dev_map)
+{
+    if (!ctx || !dev_qp_off || !dev_map) return KS265_POINTER;
+    if (nx <= 0 || ny <= 0 || qp_lo > qp_hi) return KS265_NOTSUPPORTED;
+    ks_use_device(ctx);
+    const int n = ((nx + 3) / 4) * ((ny + 3) / 4);
+    hipLaunchKernelGGL(aq_ctu_map_kernel, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, dev_qp_off, nx, ny, base_qp, qp_lo, qp_hi, dev_map);
+    return ks265_check_launch(ctx);
+}
 
 int ks265_frame_adapt_quant(ks265_ctx *ctx, const uint8_t *dev_y, int stride_y, const uint8_t *dev_u, const uint8_t *dev_v, int stride_c, int nx, int ny, int count,
                             double strength, double *dev_qp_off, uint16_t *dev_inv_qscale, double *dev_scratch2)

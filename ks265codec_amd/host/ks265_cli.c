@@ -56,7 +56,7 @@ static void usage(void)
 {
     puts("usage: ks265enc -i in.yuv -wdt W -hgt H [-fr FPS] [-preset ultrafast..placebo] [-latency zerolatency|lowdelay|livestreaming|default] [-tune T]\n"
          "                [-rc 0..5] [-qp Q] [-crf C] [-br KBPS] [-iper N] [-bframes N] [-frms N] [-threads N] [-psnr 0|1|2] [-b out.265] [-o recon.yuv]\n"
-         "                [-me 0|1|2] [-subme 0|1|2] [-merange R] [-ref N] [-sao 0..4] [-df 0|1] [-fixqp 0|1] [-md5 0|1] [-scenecut N (with -lookahead: the reference's scene-cut rule at threshold N)] [-c config_file] [-gpus N] [-v]\n"
+         "                [-me 0|1|2] [-subme 0|1|2] [-merange R] [-ref N] [-sao 0..4] [-df 0|1] [-fixqp 0|1] [-md5 0|1] [-scenecut N (with -lookahead: the reference's scene-cut rule at threshold N)] [-aq 0|1 -aqs S (adaptive quantisation: a QP per CTU from the reference's block-variance rule)] [-c config_file] [-gpus N] [-v]\n"
          "  I420 8-bit input; width and height multiples of 8.  Needs one MI355X (gfx950): there is no CPU fallback.");
 }
 

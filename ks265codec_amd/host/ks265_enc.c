@@ -156,9 +156,11 @@ int QY265ConfigParse(QY265EncConfig *c, const char *name, const char *value)
     INTP("rdoq", rdoq, 0, 1) INTP("me", me, 0, 4) INTP("part", part, 0, 1) INTP("do64", do64, 0, 1) INTP("intertu", tuInter, -1, 3) INTP("intratu", tuIntra, -1, 3)
     INTP("sis", smooth, 0, 1) INTP("ts", transskip, 0, 1) INTP("subme", subme, 0, 2) INTP("merange", searchrange, 1, 512) INTP("ref", refnum, 1, 16) INTP("ref0", ref0, 1, 16)
     INTP("sao", sao, 0, 4) INTP("wpp", enWavefront, 0, 1) INTP("fpp", enFrameParallel, 0, 1) INTP("vbv-maxrate", vbv_max_rate, 0, 10000000)
+    INTP("aq", iAqMode, 0, 3)                                  /* the reference's hidden -aq (iAqMode, qy265enc.h:145) */
     INTP("vbv-bufsize", vbv_buffer_size, 0, 10000000) INTP("pass", iPass, 0, 2) INTP("tlayer", temporalLayer, 0, 1) INTP("frameskip", enFrameSkip, 0, 1)
 #undef INTP
     if (!strcmp(name, "fr")) { if (!num_ok || dv <= 0 || dv > 1000) return QY265_PARAM_BAD_VALUE; c->frameRate = dv; return 0; }
+    if (!strcmp(name, "aqs")) { if (!num_ok || dv < 0 || dv > 3.0) return QY265_PARAM_BAD_VALUE; c->fAqStrength = dv; return 0; }   /* -aqs (fAqStrength, qy265enc.h:146) */
     if (!strcmp(name, "ratetol")) { if (!num_ok || dv < 0) return QY265_PARAM_BAD_VALUE; c->fRateTolerance = dv; return 0; }
     if (!strcmp(name, "preset") || !strcmp(name, "latency") || !strcmp(name, "tune")) {
         const int k = find_name(name[0] == 'p' ? kPresetNames : name[0] == 'l' ? kLatencyNames : kTuneNames, value);
@@ -186,6 +188,7 @@ typedef struct Job {
     int ev_err;
     long sub_seq;                                         /* this picture's number in submission order (the dispatcher's sticky device error ends at a key picture submitted after the error was seen) */
     void *wpp; ks265_slice_in sin; int started, nrows, next_row, rows_done;   /* row-wise writing of the slice (ks265_wpp_*) */
+    int8_t *qp_map;                                       /* -aq: the QP of every CTU this picture was coded with (pinned; NULL without) */
     uint8_t *recon;                                       /* pinned I420 copy of the reconstruction (only with ks265_enc_set_recon_file / -md5) */
     char md5[3][33];
     void *ev;                                             /* recorded after the D2H copies */
@@ -288,6 +291,9 @@ typedef struct Enc {
     /* split pipeline (default): the source picture of slot k is unpacked and padded on the copy-in stream into srcq[k], and the picture's drain (SSE, packing of the
      * records) runs on the copy-out stream behind ev_coded[k]; the next picture's search does not wait for either - it waits for ev_packed[k] only where it first writes
      * a record (ks265_frame_set_records_fence).  Measured at 2160p IPPP: 120 us of a 1.11 ms picture period leave the critical path. */
+    /* -aq N (iAqMode != 0): adaptive quantisation = the reference's calcFrameAdaptQuant enc@0x4653c0 on the source picture (ks265_frame_adapt_quant, pinned on recorded
+     * calls), one QP per CTU from it (ks265_aq_ctu_map), the pixel path and the writer on that map (ks265_frame_set_qp_map, cu_qp_delta) */
+    int aq_on, aq_nx, aq_ny; double *aq_off[2], *aq_scratch[2]; uint16_t *aq_inv[2]; int8_t *dev_qmap[NPIPE];   /* [1]: the key pictures' stream */
     int copy_mb;                                          /* KS265_COPYOUT_MB = N: hipMemcpyAsync takes the fixed part + N MB of stored lines per P / B picture (a key picture: everything) and the copy kernel
                                                            * only what lies beyond; default -1 = the copy kernel alone.  On this runtime the D2H hipMemcpyAsync is itself a kernel (__amd_rocclr_copyBuffer,
                                                            * 110 us for 4 MB): no better neighbour than ours (50 us for the ~2 MB a picture really holds) - measured both ways, within +- 1.5 % */
@@ -485,6 +491,7 @@ static void *worker(void *arg)
                 memcpy(s->rps_poc, j->rps_poc, sizeof s->rps_poc); memcpy(s->rps_used, j->rps_used, sizeof s->rps_used);
                 s->num_l0 = j->nl0; s->num_l1 = j->nl1; memcpy(s->l0_poc, j->l0, sizeof s->l0_poc); memcpy(s->l1_poc, j->l1, sizeof s->l1_poc);
                 s->cu8 = j->cu8; s->lvl[0] = j->lvl[0]; s->lvl[1] = j->lvl[1]; s->lvl[2] = j->lvl[2]; s->sao = e->use_sao ? j->sao : NULL;
+                s->qp_map = e->aq_on ? j->qp_map : NULL;
                 err = ks265_wpp_begin(&e->scfg, s, j->wpp);
             }
             pthread_mutex_lock(&e->mu);
@@ -620,6 +627,16 @@ static int submit(Enc *e, Input *in, int kind, int poc, int qp, const int *l0, i
         if (!r) r = ks265_event_record(cx, e->ev_loaded[k]);
     }
     if (!r) r = ks265_frame_set_qp(fr, qp, kind == 'I' ? kLambdaQ4[qp] : kLambdaInterQ4[qp]);
+    if (!r && e->aq_on) {
+        /* the source picture is on the device (this stream waited for it): block variances -> offsets (the reference's arithmetic) -> one QP per CTU around this picture's QP;
+         * the map stays in its rotation slot while the picture's kernels and the copy-home run */
+        const size_t oy = (size_t)e->geom.pad_y * e->geom.stride_y + e->geom.pad_y, oc = (size_t)e->geom.pad_c * e->geom.stride_c + e->geom.pad_c;
+        r = ks265_frame_adapt_quant(cx, srcp.y + oy, e->geom.stride_y, srcp.u + oc, srcp.v + oc, e->geom.stride_c, e->aq_nx, e->aq_ny, e->aq_nx * e->aq_ny, e->cfg.fAqStrength,
+                                    e->aq_off[on_key], e->aq_inv[on_key], e->aq_scratch[on_key]);
+        if (!r) r = ks265_aq_ctu_map(cx, e->aq_off[on_key], e->aq_nx, e->aq_ny, qp, e->cfg.rc ? e->cfg.qpmin : 0, e->cfg.rc && e->cfg.qpmax ? e->cfg.qpmax : 51, e->dev_qmap[k]);
+        if (!r) r = ks265_frame_set_qp_map(fr, e->dev_qmap[k]);
+        if (!r) r = ks265_memcpy_d2h_async(cx, j->qp_map, e->dev_qmap[k], (size_t)e->geom.ctu_cols * e->geom.ctu_rows);
+    }
     int keep[20], nk = 0;
     for (int i = 0; i < nkeep; ++i) keep[nk++] = keep_after[i];
     for (int i = 0; i < nl0; ++i) keep[nk++] = l0[i];
@@ -969,7 +986,7 @@ static void lane_close(Enc *e, int report)
         }
         for (int i = 0; i < MAX_JOBS; ++i) {
             Job *j = &e->jobs[i];
-            ks265_host_free(e->ctx, j->cmp); ks265_host_free(e->ctx, j->recon); free(j->lvlbuf); free(j->dirty);
+            ks265_host_free(e->ctx, j->cmp); ks265_host_free(e->ctx, j->recon); ks265_host_free(e->ctx, j->qp_map); free(j->lvlbuf); free(j->dirty);
             if (j->ev) ks265_event_destroy(e->ctx, j->ev);
             free(j->nal);
         }
@@ -993,6 +1010,8 @@ static void lane_close(Enc *e, int report)
         }
         for (int i = 0; i < e->ngraph; ++i) ks265_graph_destroy(e->ctx, e->graph[i].exec);
         ks265_dev_free(e->ctx, e->dev_sse); ks265_dev_free(e->ctx, e->dev_recon);
+        for (int q = 0; q < 2; ++q) { ks265_dev_free(e->ctx, e->aq_off[q]); ks265_dev_free(e->ctx, e->aq_inv[q]); ks265_dev_free(e->ctx, e->aq_scratch[q]); }
+        for (int k = 0; k < NPIPE; ++k) ks265_dev_free(e->ctx, e->dev_qmap[k]);
         if (e->recon_fd >= 0) close(e->recon_fd);
         if (e->ctx_la) {
             ks265_synchronize(e->ctx_la);
@@ -1042,7 +1061,8 @@ static Enc *lane_open(QY265EncConfig *cfg, int device, int multi, int *err)
     e->nthreads = cfg->threads > 0 ? cfg->threads : (int)(ncpu > 0 ? ncpu : 4);
     if (e->nthreads > 64) e->nthreads = 64;
 
-    if (cfg->rdoq || cfg->transskip || cfg->iAqMode) logf_(1, e->log_level, "ks265enc: rdoq / transskip / aq are accepted but not implemented by the pixel path\n");
+    if (cfg->rdoq || cfg->transskip) logf_(1, e->log_level, "ks265enc: rdoq / transskip are accepted but not implemented by the pixel path\n");
+    if (cfg->iAqMode > 1) logf_(1, e->log_level, "ks265enc: -aq %d runs as -aq 1 (block variance, the mode of the reference's calcFrameAdaptQuant)\n", cfg->iAqMode);
     if (cfg->part && (e->gop_b > 0 || e->refs > 1)) logf_(1, e->log_level, "ks265enc: -part 1 acts on P pictures with one reference picture (2NxN / Nx2N partitions of 64 / 32 / 16 CUs); B pictures and multi-reference P pictures keep 2Nx2N\n");
     /* options whose VALUE is narrowed (SURVEY.md 8(a) config 5 = -preset veryslow: subme 2, part 1, ref 4): said once, never silently */
     if (cfg->refnum > 4) logf_(1, e->log_level, "ks265enc: -ref %d runs as -ref 4\n", cfg->refnum);
@@ -1119,11 +1139,23 @@ static Enc *lane_open(QY265EncConfig *cfg, int device, int multi, int *err)
         if (!r && e->split) r = pic_alloc(e, &e->srcq[k]);
     }
     if (!r) r = ks265_dev_malloc(e->ctx, (void **)&e->dev_sse, 64);
+    e->aq_on = cfg->iAqMode != 0 && cfg->fAqStrength > 0;
+    if (e->aq_on) {
+        e->aq_nx = (e->W + 15) / 16; e->aq_ny = (e->H + 15) / 16;       /* blocks that hang over the picture read its padding (replicated edges) */
+        const size_t nb = (size_t)e->aq_nx * e->aq_ny;
+        for (int q = 0; q < 2 && !r; ++q) {
+            r = ks265_dev_malloc(e->ctx, (void **)&e->aq_off[q], nb * 8);
+            if (!r) r = ks265_dev_malloc(e->ctx, (void **)&e->aq_inv[q], nb * 2);
+            if (!r) r = ks265_dev_malloc(e->ctx, (void **)&e->aq_scratch[q], 16);
+        }
+        for (int k = 0; k < NPIPE && !r; ++k) r = ks265_dev_malloc(e->ctx, (void **)&e->dev_qmap[k], (size_t)e->geom.ctu_cols * e->geom.ctu_rows);
+    }
     if (!r) r = pic_alloc(e, &e->src);
     e->ndpb = e->hier ? 10 : e->gop_b ? 4 : e->refs + 2;
     for (int i = 0; i < e->ndpb && !r; ++i) { r = pic_alloc(e, &e->dpb[i]); e->dpb_poc[i] = -1000000; }
     e->key_overlap = getenv("KS265_NO_KEY_OVERLAP") ? 0 : 1;
     e->use_graph = getenv("KS265_GRAPH") ? 1 : 0;                     /* opt-in since round 4: launch by launch is faster on this runtime (843 against 817 pictures/s, 2160p IPPP) and the split pipeline needs the launches apart */
+    if (e->aq_on) e->use_graph = 0;                                      /* (a captured picture would replay one map) */
     if (e->use_graph) e->split = 0;
     if (e->key_overlap) {
         if (!r) r = ks265_create(&e->ctx_key, dev_id);
@@ -1150,6 +1182,7 @@ static Enc *lane_open(QY265EncConfig *cfg, int device, int multi, int *err)
             j->cu8 = (ks265_cu8 *)(j->cmp + e->cmp_off[0]); j->sao = (ks265_sao_param *)(j->cmp + e->cmp_off[1]); j->sse = (uint64_t *)(j->cmp + e->cmp_off[2]);
             j->lvl[0] = (int16_t *)j->lvlbuf; j->lvl[1] = (int16_t *)(j->lvlbuf + npx * 2); j->lvl[2] = (int16_t *)(j->lvlbuf + npx * 2 + npx / 2);
         }
+        if (!r && e->aq_on) r = ks265_host_malloc(e->ctx, (void **)&j->qp_map, (size_t)e->geom.ctu_cols * e->geom.ctu_rows);
         if (!r) r = ks265_event_create(e->ctx, &j->ev);
         j->nal_cap = npx * 2 + 65536;
         j->nal = (uint8_t *)malloc(j->nal_cap);
@@ -1180,6 +1213,7 @@ static Enc *lane_open(QY265EncConfig *cfg, int device, int multi, int *err)
     memset(&e->scfg, 0, sizeof e->scfg);
     e->scfg.width = e->W; e->scfg.height = e->H; e->scfg.sao = e->use_sao; e->scfg.deblock = e->use_df;
     e->scfg.sdh = e->fcfg.sdh;
+    e->scfg.cu_qp_delta = e->aq_on;
     e->scfg.wpp = 1;                                                    /* CTU rows as substreams: what lets several writer threads share one picture */
     e->scfg.max_dec_pic_buffering = e->hier ? 10 : e->gop_b ? 4 : e->refs + 1; e->scfg.log2_max_poc_lsb = 16;
     /* pictures that precede a picture in decoding order and follow it in output order: the whole GOP for the hierarchy (7, as before), ONE (the anchor) for

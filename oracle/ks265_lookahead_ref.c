@@ -96,3 +96,18 @@ int kso_ref_scenecut(int pcost, int icost, int prev_icost, int blocks, int lg, i
     const double bias = (double)(poc - last_key) * ((double)thr / 100.0) / (double)(keyint < 320 ? keyint : 320);
     return (double)pcost >= (1.0 - bias) * (double)icost;
 }
+
+/* this build's own rule (not the reference's): the QP of every CTU from the 16x16 blocks' offsets - base + round(mean over the CTU's blocks, summed in raster order), clipped */
+void kso_aq_ctu_map(const double *off, int nx, int ny, int base_qp, int lo, int hi, int8_t *map)
+{
+    const int cols = (nx + 3) / 4, rows = (ny + 3) / 4;
+    for (int cy = 0; cy < rows; ++cy)
+        for (int cx = 0; cx < cols; ++cx) {
+            double sum = 0.0; int cnt = 0;
+            for (int by = cy * 4; by < (cy * 4 + 4 < ny ? cy * 4 + 4 : ny); ++by)
+                for (int bx = cx * 4; bx < (cx * 4 + 4 < nx ? cx * 4 + 4 : nx); ++bx) { sum += off[by * nx + bx]; ++cnt; }
+            const int q = base_qp + (int)floor(sum / (double)cnt + 0.5);
+            map[cy * cols + cx] = (int8_t)(q < lo ? lo : q > hi ? hi : q);
+        }
+}
+

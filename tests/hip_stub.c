@@ -221,6 +221,19 @@ int ks265_load_i420(ks265_frame *f, const uint8_t *i420, ks265_pic dst) { Op o =
 int ks265_load_i420_on(ks265_ctx *c, ks265_frame *f, const uint8_t *i420, ks265_pic dst) { (void)c; return ks265_load_i420(f, i420, dst); }   /* the stand-in runs every call at once: streams do not exist */
 int ks265_frame_set_records_fence(ks265_frame *f, void *ev) { (void)f; (void)ev; return KS265_OK; }
 int ks265_frame_set_qp_map(ks265_frame *f, const int8_t *m) { (void)f; (void)m; return KS265_OK; }
+/* -aq: the offsets by the oracle's restatement of calcFrameAdaptQuant on packed copies of the planes, the CTU map by the oracle's rule (the stand-in's pictures do not use it) */
+#include "../oracle/ks265_lookahead_ref.h"
+int ks265_frame_adapt_quant(ks265_ctx *c, const uint8_t *y, int sy, const uint8_t *u, const uint8_t *v, int sc, int nx, int ny, int count, double strength, double *off, uint16_t *inv, double *scratch)
+{
+    (void)c; (void)scratch;
+    uint8_t *Y = malloc((size_t)nx * ny * 256), *U = malloc((size_t)nx * ny * 64), *V = malloc((size_t)nx * ny * 64);
+    for (int r = 0; r < ny * 16; ++r) memcpy(Y + (size_t)r * nx * 16, y + (long)r * sy, (size_t)nx * 16);
+    for (int r = 0; r < ny * 8; ++r) { memcpy(U + (size_t)r * nx * 8, u + (long)r * sc, (size_t)nx * 8); memcpy(V + (size_t)r * nx * 8, v + (long)r * sc, (size_t)nx * 8); }
+    kso_ref_frame_adapt_quant(Y, U, V, nx, ny, count, strength, off, inv);
+    free(Y); free(U); free(V);
+    return KS265_OK;
+}
+int ks265_aq_ctu_map(ks265_ctx *c, const double *off, int nx, int ny, int base, int lo, int hi, int8_t *map) { (void)c; kso_aq_ctu_map(off, nx, ny, base, lo, hi, map); return KS265_OK; }
 int ks265_store_i420(ks265_frame *f, ks265_pic src, uint8_t *i420)
 {
     const int W = f->cfg.width, H = f->cfg.height;

@@ -45,19 +45,44 @@ def _decoder_check(tmp_path, out, rec, n, fsz):
     assert not bad, f"pictures {bad} decode differently from the encoder's reconstruction"
 
 
-def _mirror(clip, W, H, per, refs_of, rec, tools, upto):
+def _aq_map(o, i420, qp, strength):
+    """the host's -aq arithmetic on the CPU: the oracle's restatement of calcFrameAdaptQuant over the padded source picture, then one QP per CTU"""
+    import ctypes as C
+    from oracle_lib import HostPic, ptr
+    g = o.geom
+    W, H = o.cfg.width, o.cfg.height
+    nx, ny = (W + 15) // 16, (H + 15) // 16
+    tmp = HostPic(g)
+    o.load(tmp, i420)
+    Y = np.ascontiguousarray(tmp.y.reshape(-1, g.stride_y)[g.pad_y:g.pad_y + ny * 16, g.pad_y:g.pad_y + nx * 16])
+    U, V = (np.ascontiguousarray(p.reshape(-1, g.stride_c)[g.pad_c:g.pad_c + ny * 8, g.pad_c:g.pad_c + nx * 8]) for p in (tmp.u, tmp.v))
+    off, inv = np.zeros(nx * ny), np.zeros(nx * ny, np.uint16)
+    o.o.kso_ref_frame_adapt_quant(ptr(Y), ptr(U), ptr(V), nx, ny, nx * ny, C.c_double(strength), ptr(off), ptr(inv))
+    qmap = np.zeros(((nx + 3) // 4) * ((ny + 3) // 4), np.int8)
+    o.o.kso_aq_ctu_map(ptr(off), nx, ny, qp, 0, 51, ptr(qmap))
+    return qmap
+
+
+def _mirror(clip, W, H, per, refs_of, rec, tools, upto, aq=0.0):
     """the oracle pipeline with the encoder's per-picture QPs and reference pictures: reconstruction == the encoder's, for the first `upto` pictures in coding order"""
     from ks265codec_amd.synth import lambda_q4
     from oracle_lib import OraclePipeline
     fsz = W * H * 3 // 2
     o = OraclePipeline(W, H, 27, lambda_q4(27), **tools)
     dpb = {}
+    spread = set()
     for i, (poc, kind, _, qp) in enumerate(per[:upto]):
         o.set_qp(qp, lambda_q4(qp, inter=kind != "I"))
+        if aq:
+            qmap = _aq_map(o, clip[poc], qp, aq)
+            o.set_qp_map(qmap)
+            spread |= set(qmap.tolist())
         r0, r1 = refs_of(i, poc, kind)
         dpb[poc] = o.encode(clip[poc], kind, dpb.get(r0), dpb.get(r1))
         want = o.store(dpb[poc])
         assert (rec[poc * fsz:(poc + 1) * fsz] == want).all(), f"picture {poc} ({kind}, qp {qp}, coding position {i}): the encoder's reconstruction differs from the oracle pipeline fed the same QP"
+    o.set_qp_map(None)
+    return spread
 
 
 def test_crf_with_three_b_pictures(tmp_path):
@@ -131,6 +156,33 @@ def test_bitrate_target_at_2160p_decodes(tmp_path):
     log, per, kbps, rec, out = _encode(tmp_path, clip, W, H, ["-preset", "veryslow", "-rc", "1", "-br", "20000", "-iper", "128"])
     assert len(per) == n
     _decoder_check(tmp_path, out, rec, n, W * H * 3 // 2)
+
+
+@pytest.mark.parametrize("gop", ["ippp", "hier"])
+def test_adaptive_quantisation(tmp_path, gop):
+    """-aq 1 -aqs S (iAqMode / fAqStrength, qy265enc.h:145-146): the QP of every CTU follows the reference's calcFrameAdaptQuant on the source picture (device operator pinned on
+    recorded calls of the reference: tests/test_gpu_lookahead_ops.py) - (1) the reference's decoder makes of the stream exactly what the encoder reconstructed, cu_qp_delta
+    and the deblocking at the decoder's QpY included; (2) the oracle pipeline fed the same QPs and maps (computed on the CPU) reproduces it picture for picture"""
+    from ks265codec_amd.synth import ENCODER_TOOLS, make_clip
+    W, H, n = 1920, 1080, 9
+    clip = make_clip(W, H, n, seed=W + n, abc=(37, 53, 19), pan=(5, 3))
+    opts = ["-preset", "slow", "-rc", "0", "-qp", "30", "-iper", "128", "-aq", "1", "-aqs", "1.2"] + (["-bframes", "0"] if gop == "ippp" else [])
+    log, per, kbps, rec, out = _encode(tmp_path, clip, W, H, opts)
+    assert len(per) == n
+    _decoder_check(tmp_path, out, rec, n, W * H * 3 // 2)
+    coded = []
+
+    def refs(i, poc, kind):
+        if kind == "I":
+            coded.append(poc); return None, None
+        lo = max(p for p in coded if p < poc)
+        hi = min((p for p in coded if p > poc), default=None)
+        coded.append(poc)
+        return (lo, None) if kind == "P" else (lo, hi)
+    spread = _mirror(clip, W, H, per, refs, rec, ENCODER_TOOLS, upto=6, aq=1.2)
+    assert len(spread) >= 4, f"the maps hold {sorted(spread)}: adaptive quantisation did nothing"
+    plain = _encode(tmp_path, clip, W, H, [o for o in opts if o not in ("-aq", "1", "-aqs", "1.2")] + ["-aq", "0"], tag="plain")
+    assert open(plain[4], "rb").read() != open(out, "rb").read()
 
 
 def test_crf_job_over_two_lanes(tmp_path):

@@ -320,6 +320,20 @@ def test_scene_cut_starts_a_closed_gop(stub_lib, bframes):
     assert close["idr"] == 3, close["idr"]
 
 
+@pytest.mark.parametrize("bframes", [0, 3])
+def test_adaptive_quantisation_streams_decode(stub_lib, tmp_path, bframes):
+    """-aq 1 on the stand-in: every picture gets a QP per CTU (the oracle's restatement of calcFrameAdaptQuant on the source picture, the CTU rule), the parameter sets
+    switch cu_qp_delta on, the slices carry the deltas - and the reference's decoder takes the stream (the stand-in's pictures are not real: what is checked here is the
+    host's plumbing and the syntax; the pixels are tests/test_dqp.py and tests/test_gpu_rc.py)"""
+    out = tmp_path / "aq.265"
+    r = run(stub_lib, 40, 16, bframes, W=128, H=72, KS_TEST_AQ=1, out=out)
+    plain = run(stub_lib, 40, 16, bframes, W=128, H=72)
+    assert sorted(r["pts"]) == list(range(40)) and r["md5"] != plain["md5"]
+    if os.path.exists(REF_DEC) and out.exists():
+        d = subprocess.run([REF_DEC, "-b", str(out), "-o", str(tmp_path / "d.yuv"), "-threads", "1"], capture_output=True, text=True, cwd=tmp_path)
+        assert "decoder passed" in d.stdout and os.path.getsize(tmp_path / "d.yuv") == 40 * 128 * 72 * 3 // 2, d.stdout[-300:]
+
+
 def test_scenecut_flag_runs_the_reference_rule(stub_lib):
     """-scenecut N (the reference's hidden flag): the scene-cut verdict is the rule of scenecut enc@0x47e9d0 (pinned: tests/test_lookahead_ref.py) on this lookahead's frame
     costs - no distance guard of its own: cuts three pictures apart are all key pictures; a calm clip has none"""
