@@ -696,19 +696,71 @@ __global__ __launch_bounds__(256, REFINE ? 2 : 1) void bi_decide_kernel(KsGeom g
             }
             int rbx = 4 * (sx + (int)(bkey & 7)), rby = 4 * (sy + (int)((bkey >> 3) & 7));
             unsigned bc = bkey >> 6;                                                   // SAD + rate of the integer winner
+            // The two sub-pel rings (half, then quarter steps around the running best).  Round 4: the eight candidates of a ring share their horizontal filtering - the three x
+            // positions are filtered once each over the 16 input rows the three y positions tap (raw 16-bit tap sums, row pairs packed for v_dot2_i32_i16), the vertical taps
+            // of each y position run on those; ONE instruction stream for every fraction (the integer position is the tap set {0 0 0 64 0 0 0 0}; (sum + 2048) >> 12 equals the
+            // one-dimensional filters' (sum + 32) >> 6 and the plain sample exactly), so lanes with different fractions do not diverge.  Before: a full separable
+            // interpolation per candidate and lane, its three fraction cases executed under divergence (750 us per 2160p B picture).
 #pragma unroll 1
             for (int step = 2; step >= 1; --step) {
                 const int c0x = rbx, c0y = rby;
+                const int ybase = (c0y - step) >> 2;                                   // integer row of output row 0 at the ring's top y position
+                unsigned cc[9];
 #pragma unroll 1
-                for (int k = 0; k < 8; ++k) {
-                    const int kk = k < 4 ? k : k + 1;                                  // ring order of stage B: (-1,-1) (0,-1) (1,-1) (-1,0) (1,0) (-1,1) (0,1) (1,1)
-                    const int qx = c0x + (kk % 3 - 1) * step, qy = c0y + (kk / 3 - 1) * step;
-                    unsigned q8[16], sd3 = 0;
-                    luma_pred_tile8(refO + base, g.sy, qx, qy, q8);
+                for (int gx = 0; gx < 3; ++gx) {
+                    const int axq = c0x + (gx - 1) * step;
+                    int tl, th;
+                    luma_taps_packed(axq & 3, tl, th);
+                    const uint8_t *hp = refO + base + (long)(ybase - 3) * g.sy + (axq >> 2);
+                    unsigned HP[8][8];                                                  // [pixel][row pair]: rows 2 j, 2 j + 1 of the 16 filtered rows ybase - 3 .. ybase + 12
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) sd3 = sad_u8x4(T[i], q8[i], sd3);
-                    const unsigned cc = pu_group_sum(valid ? sd3 : 0, level) + (unsigned)mv_cost(qx, qy, opx, opy, lam);
-                    if (cc < bc) { bc = cc; rbx = qx; rby = qy; }
+                    for (int j = 0; j < 8; ++j) {
+                        int h0[8], h1[8];
+                        luma_hrow8(hp + (long)(2 * j) * g.sy, tl, th, h0);
+                        luma_hrow8(hp + (long)(2 * j + 1) * g.sy, tl, th, h1);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) HP[i][j] = ((unsigned)h0[i] & 0xFFFFu) | ((unsigned)h1[i] << 16);
+                    }
+#pragma unroll 1
+                    for (int gy = 0; gy < 3; ++gy) {
+                        if (gx == 1 && gy == 1) continue;
+                        const int ayq = c0y + (gy - 1) * step, roff = (ayq >> 2) - ybase;     // 0 or 1
+                        int c[8];
+                        luma_taps(ayq & 3, c);
+                        // output row r reads input rows r + roff .. r + roff + 7; in pairs: an even start takes (c0 c1)(c2 c3)(c4 c5)(c6 c7), an odd one (0 c0)(c1 c2)(c3 c4)(c5 c6)(c7 0)
+                        unsigned E0[5], E1[5];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) E0[k] = ((unsigned)c[2 * k] & 0xFFFFu) | ((unsigned)c[2 * k + 1] << 16);
+                        E0[4] = 0;
+                        E1[0] = (unsigned)c[0] << 16;
+#pragma unroll
+                        for (int k = 1; k < 4; ++k) E1[k] = ((unsigned)c[2 * k - 1] & 0xFFFFu) | ((unsigned)c[2 * k] << 16);
+                        E1[4] = (unsigned)c[7] & 0xFFFFu;
+                        unsigned We[5], Wo[5];                                            // even r: window of pairs r / 2 ..; odd r: (r - 1) / 2 ..
+#pragma unroll
+                        for (int k = 0; k < 5; ++k) { We[k] = roff ? E1[k] : E0[k]; Wo[k] = roff ? (k ? E0[k - 1] : 0u) : E1[k]; }
+                        unsigned sd3 = 0;
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) {
+                            int px[8];
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) {
+                                int v = 2048;
+#pragma unroll
+                                for (int k = 0; k < 5; ++k)
+                                    v = __builtin_amdgcn_sdot2(__builtin_bit_cast(ks_s16x2, (r & 1) ? Wo[k] : We[k]), __builtin_bit_cast(ks_s16x2, HP[i][(r >> 1) + k < 8 ? (r >> 1) + k : 7]), v, false);
+                                px[i] = clip8(ks_no_pk(v >> 12));
+                            }
+                            const uint2 pr = ks_pack_row8(px);
+                            sd3 = sad_u8x4(T[2 * r], pr.x, sd3); sd3 = sad_u8x4(T[2 * r + 1], pr.y, sd3);
+                        }
+                        cc[gy * 3 + gx] = pu_group_sum(valid ? sd3 : 0, level) + (unsigned)mv_cost(axq, ayq, opx, opy, lam);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int kk = k < 4 ? k : k + 1;                                  // ring order of stage B: (-1,-1) (0,-1) (1,-1) (-1,0) (1,0) (-1,1) (0,1) (1,1), first strict minimum
+                    if (cc[kk] < bc) { bc = cc[kk]; rbx = c0x + (kk % 3 - 1) * step; rby = c0y + (kk / 3 - 1) * step; }
                 }
             }
             unsigned PO[16], PK[16];
