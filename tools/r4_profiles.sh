@@ -29,4 +29,8 @@ cd $R
 timeout 150 python bench.py --leg hot --streams 1 --no-cpu-baseline 2>/dev/null | grep '^{' | tail -1 > $O/bench_line_hot_1stream.json
 timeout 200 python bench.py --hier-b 8 --no-cpu-baseline 2>/dev/null | grep '^{' | tail -1 > $O/bench_line_hier8.json
 timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 2>$O/bench_default.err | grep '^{' | tail -1 > $O/bench_line_default.json
+# ---- 5. the lookahead operators (csrc/lookahead_ops.hip) timed, and the whole GPU suite on this snapshot
+cd /tmp; timeout 120 rocprofv3 --kernel-trace --stats -d $O/kt_la -o kt -- python $R/tools/la_ops_bench.py > $O/la_ops.txt 2>&1
+python $R/tools/rocpd_stats.py $O/kt_la/kt_results.db 2>/dev/null | grep -E 'kernel|aq_|cutree_' >> $O/la_ops.txt; rm -rf $O/kt_la
+cd $R; timeout 1500 python -m pytest tests -q -m gpu 2>&1 | tail -5 > $O/pytest_gpu.txt
 ls -la $O; head -c 600 $O/bench_line_default.json; echo; head -22 $O/kernel_stats_hot_1stream.txt; cat $O/hbm_traffic.txt; head -14 $O/sq_counters.txt | cut -c1-200
