@@ -158,6 +158,19 @@ def test_bitrate_target_at_2160p_decodes(tmp_path):
     _decoder_check(tmp_path, out, rec, n, W * H * 3 // 2)
 
 
+@pytest.mark.parametrize("W,H", [(200, 136), (416, 240)])
+def test_adaptive_quantisation_small_pictures(tmp_path, W, H):
+    """-aq at picture sizes that are no multiple of 16 / 64: the blocks that hang over the picture read the replicated edge, partial CTUs average the blocks they have"""
+    from ks265codec_amd.synth import ENCODER_TOOLS, make_clip
+    n = 7
+    clip = make_clip(W, H, n, seed=W + n, abc=(17, 23, 9), pan=(5, 3))
+    log, per, kbps, rec, out = _encode(tmp_path, clip, W, H, ["-preset", "slow", "-rc", "0", "-qp", "28", "-iper", "128", "-bframes", "0", "-aq", "1", "-aqs", "2.0"])
+    assert len(per) == n
+    _decoder_check(tmp_path, out, rec, n, W * H * 3 // 2)
+    spread = _mirror(clip, W, H, per, lambda i, poc, kind: (None, None) if kind == "I" else (poc - 1, None), rec, ENCODER_TOOLS, upto=n, aq=2.0)
+    assert len(spread) >= 3, sorted(spread)
+
+
 @pytest.mark.parametrize("gop", ["ippp", "hier"])
 def test_adaptive_quantisation(tmp_path, gop):
     """-aq 1 -aqs S (iAqMode / fAqStrength, qy265enc.h:145-146): the QP of every CTU follows the reference's calcFrameAdaptQuant on the source picture (device operator pinned on
