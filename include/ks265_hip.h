@@ -211,7 +211,7 @@ int ks265_ac_energy_map(ks265_ctx *, const uint8_t *dev_plane, int stride, int w
  * dev_inv_qscale: nx * ny u16 (+0x48), dev_scratch2: two doubles.  Bit-exact against oracle/ks265_lookahead_ref.c (pinned on recorded calls of the reference). */
 int ks265_frame_adapt_quant(ks265_ctx *, const uint8_t *dev_y, int stride_y, const uint8_t *dev_u, const uint8_t *dev_v, int stride_c, int nx, int ny, int count,
                             double strength, double *dev_qp_off, uint16_t *dev_inv_qscale, double *dev_scratch2);
-/* the QP of every CTU (raster, (nx + 3) / 4 x (ny + 3) / 4) from the offsets of ks265_frame_adapt_quant: base_qp + round(mean of the CTU's 16 x 16 blocks), clipped to
+/* the QP of every CTU (raster, (nx + 3) / 4 x (ny + 3) / 4) from the offsets of ks265_frame_adapt_quant: base_qp + clip(round(mean of the CTU's 16 x 16 blocks), -12, 12), clipped to
  * [qp_lo, qp_hi] - the map ks265_frame_set_qp_map takes (this build's rule: quantisation group = CTU) */
 int ks265_aq_ctu_map(ks265_ctx *, const double *dev_qp_off, int nx, int ny, int base_qp, int qp_lo, int qp_hi, int8_t *dev_map);
 /* cuTreePropagate enc@0x47d460 (log2, frames, p0, p1, b): one step of the macroblock-tree propagation - every block of picture b hands

@@ -7,21 +7,26 @@
 #include "ks265_dev.h"
 #include "ks265_internal.h"
 #include <cmath>
+#include <mutex>
 
 using namespace ks265;
 
 // _log2 enc@0x4c3c20 / qy265_exp2fix8 enc@0x4c3c50: their tables are closed forms (checked against the file when the oracle was written): filled on the host once
 struct LaTables { double log2_lut[128]; unsigned char exp2_lut[64]; };
 __constant__ LaTables kLa;
-static int la_tables_upload()
+static int la_tables_upload(int device)
 {
-    static bool done = false;
-    if (done) return 0;
+    // per device (a __constant__ symbol lives on each of them; a handle's GOP lanes may sit on several GPUs and call from several threads)
+    static std::mutex mu;
+    static bool done[64];
+    std::lock_guard<std::mutex> lk(mu);
+    if (device < 0 || device >= 64) return 1;
+    if (done[device]) return 0;
     LaTables t;
     for (int i = 0; i < 128; ++i) t.log2_lut[i] = std::round(std::log2((128.0 + i) / 128.0) * 1e5) / 1e5;
     for (int i = 0; i < 64; ++i) t.exp2_lut[i] = (unsigned char)std::lround((std::pow(2.0, i / 64.0) - 1.0) * 256.0);
-    if (hipMemcpyToSymbol(HIP_SYMBOL(kLa), &t, sizeof t) != hipSuccess) return 1;
-    done = true;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(kLa), &t, sizeof t) != hipSuccess) return 1;      // (the caller has made `device` current)
+    done[device] = true;
     return 0;
 }
 
@@ -126,7 +131,7 @@ __global__ __launch_bounds__(256) void cutree_clip_kernel(int n, unsigned long l
     }
 }
 
-// the QP of every CTU from the 16x16 blocks' offsets: base + round(mean over the CTU's blocks, summed in raster order), clipped (this build's own rule: the quantisation group
+// the QP of every CTU from the 16x16 blocks' offsets: base + clip(round(mean over the CTU's blocks, summed in raster order), +-12), clipped to [lo, hi] (this build's own rule: the quantisation group
 // is the CTU; the reference applies its offsets per CU inside closed code)
 __global__ __launch_bounds__(64) void aq_ctu_map_kernel(const double *off, int nx, int ny, int base_qp, int lo, int hi, int8_t *map)
 {
@@ -137,7 +142,9 @@ __global__ __launch_bounds__(64) void aq_ctu_map_kernel(const double *off, int n
     int cnt = 0;
     for (int by = cy * 4; by < min(cy * 4 + 4, ny); ++by)
         for (int bx = cx * 4; bx < min(cx * 4 + 4, nx); ++bx) { sum += off[by * nx + bx]; ++cnt; }
-    const int q = base_qp + (int)floor(sum / (double)cnt + 0.5);
+    int d = (int)floor(sum / (double)cnt + 0.5);
+    d = d < -12 ? -12 : d > 12 ? 12 : d;                       // two CTUs of a row are then at most 24 apart: CuQpDeltaVal stays inside [-26, 25] (7.4.9.14)
+    const int q = base_qp + d;
     map[ctu] = (int8_t)(q < lo ? lo : q > hi ? hi : q);
 }
 
@@ -159,7 +166,7 @@ int ks265_frame_adapt_quant(ks265_ctx *ctx, const uint8_t *dev_y, int stride_y, 
     if (!ctx || !dev_y || !dev_u || !dev_v || !dev_qp_off || !dev_inv_qscale || !dev_scratch2) return KS265_POINTER;
     if (nx <= 0 || ny <= 0 || count <= 0 || (stride_y & 3)) return KS265_NOTSUPPORTED;
     ks_use_device(ctx);
-    if (la_tables_upload()) return KS265_FAIL;
+    if (la_tables_upload(ctx->device)) return KS265_FAIL;
     const int n = nx * ny;
     hipLaunchKernelGGL(aq_energy_kernel, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, dev_y, stride_y, dev_u, dev_v, stride_c, nx, ny, dev_qp_off);
     hipLaunchKernelGGL(aq_mean_kernel, dim3(1), dim3(256), 0, ctx->stream, (const double *)dev_qp_off, n, count, strength, dev_scratch2);

@@ -788,6 +788,7 @@ static void transform_unit(Enc *e, int x, int y, int log2, int cbf_y, int cbf_cb
         /* cu_qp_delta_abs: prefix truncated unary (cMax 5; context 0 for the first bin, 1 for the others), suffix EG0 in bypass; then the sign (7.3.8.14, 9.3.3.10) */
         Cabac *c = &e->c;
         const int d = e->qp_want - e->qp_prev, a = d < 0 ? -d : d;
+        if (d < -26 || d > 25) c->overflow = 1;                          /* outside CuQpDeltaVal's range (7.4.9.14): the slice is refused (KS265_NOTSUPPORTED) */
         const int pre = a < 5 ? a : 5;
         for (int i = 0; i < pre; ++i) cb_bin(c, CX_DQP + (i > 0), 1);
         if (pre < 5) cb_bin(c, CX_DQP + (pre > 0), 0);

@@ -106,7 +106,9 @@ void kso_aq_ctu_map(const double *off, int nx, int ny, int base_qp, int lo, int 
             double sum = 0.0; int cnt = 0;
             for (int by = cy * 4; by < (cy * 4 + 4 < ny ? cy * 4 + 4 : ny); ++by)
                 for (int bx = cx * 4; bx < (cx * 4 + 4 < nx ? cx * 4 + 4 : nx); ++bx) { sum += off[by * nx + bx]; ++cnt; }
-            const int q = base_qp + (int)floor(sum / (double)cnt + 0.5);
+            int d = (int)floor(sum / (double)cnt + 0.5);
+            d = d < -12 ? -12 : d > 12 ? 12 : d;                 /* CuQpDeltaVal between two CTUs stays inside [-26, 25] */
+            const int q = base_qp + d;
             map[cy * cols + cx] = (int8_t)(q < lo ? lo : q > hi ? hi : q);
         }
 }

@@ -144,18 +144,18 @@ def test_gop_lanes_under_a_fast_caller(tmp_path, n, iper):
         res[lanes] = json.loads(r.stdout.strip().splitlines()[-1])
         assert res[lanes]["lanes"] == lanes
     assert res[1]["md5"] == res[2]["md5"] == res[3]["md5"], res
-    # P pictures are replayed as captured graphs from the ninth picture on (ks265_capture_begin / ks265_graph_launch): same stream as the launch-by-launch path
-    r = subprocess.run([sys.executable, "-c", _LANES_DRIVER, ROOT, str(n), str(iper)], capture_output=True, text=True, timeout=120, env=dict(os.environ, KS265_GOP_LANES="1", KS265_NO_GRAPH="1"))
+    # KS265_GRAPH=1 (opt-in since round 4): P pictures are replayed as captured graphs from the ninth picture on (ks265_capture_begin / ks265_graph_launch): same stream as the launch-by-launch path
+    r = subprocess.run([sys.executable, "-c", _LANES_DRIVER, ROOT, str(n), str(iper)], capture_output=True, text=True, timeout=120, env=dict(os.environ, KS265_GOP_LANES="1", KS265_GRAPH="1"))
     assert r.returncode == 0, r.stdout[-800:] + r.stderr[-800:]
     assert json.loads(r.stdout.strip().splitlines()[-1])["md5"] == res[1]["md5"], "graph replay and plain launches disagree"
 
 
 @pytest.mark.parametrize("bframes", [-1, 3])
 def test_b_pictures_replayed_as_graphs(bframes):
-    """hierarchical-B 8 and P + 3 B: from the ninth picture on P and B pictures are replayed as captured graphs (one per rotation of the buffers involved);
+    """hierarchical-B 8 and P + 3 B: with KS265_GRAPH=1, from the ninth picture on P and B pictures are replayed as captured graphs (one per rotation of the buffers involved);
     the stream equals the launch-by-launch one"""
     md5 = {}
-    for tag, env in (("graph", {}), ("plain", {"KS265_NO_GRAPH": "1"})):
+    for tag, env in (("graph", {"KS265_GRAPH": "1"}), ("plain", {})):
         r = subprocess.run([sys.executable, "-c", _LANES_DRIVER, ROOT, "170", "64"], capture_output=True, text=True, timeout=120, env=dict(os.environ, KS_TEST_BFRAMES=str(bframes), **env))
         assert r.returncode == 0, r.stdout[-800:] + r.stderr[-800:]
         md5[tag] = json.loads(r.stdout.strip().splitlines()[-1])["md5"]
