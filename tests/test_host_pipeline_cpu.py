@@ -332,6 +332,9 @@ def test_adaptive_quantisation_streams_decode(stub_lib, tmp_path, bframes):
     if os.path.exists(REF_DEC) and out.exists():
         d = subprocess.run([REF_DEC, "-b", str(out), "-o", str(tmp_path / "d.yuv"), "-threads", "1"], capture_output=True, text=True, cwd=tmp_path)
         assert "decoder passed" in d.stdout and os.path.getsize(tmp_path / "d.yuv") == 40 * 128 * 72 * 3 // 2, d.stdout[-300:]
+    if bframes == 0:                                                       # GOP lanes (several GPUs per handle): every picture's map is its own - the one-lane stream byte for byte
+        one = run(stub_lib, 100, 32, 0, W=128, H=72, KS_TEST_AQ=1)
+        assert one["md5"] == run(stub_lib, 100, 32, 0, W=128, H=72, KS_TEST_AQ=1, KS265_GOP_LANES=3)["md5"]
 
 
 def test_scenecut_flag_runs_the_reference_rule(stub_lib):
