@@ -950,10 +950,27 @@ __global__ __launch_bounds__(256) void merge_pass_kernel(KsGeom g, int lam, cons
     const unsigned cur = is_b ? pub[rb].cost : pu[rb].cost;
     const bool valid = inside && c.pred_mode == 0 && (c.log2_cu & 15) >= 3 && !(c.log2_cu >> 4) && cur != KS_COST_INVALID;      // (a CU in two partitions keeps its partitions' vectors)
     if (tid < 64) jbest[tid] = ~0ull;
-    // which candidates exist for this tile's CU (every tile of a CU computes the same mask)
-    unsigned mask = 0;
+    // which candidates exist for this tile's CU (every tile of a CU computes the same mask), and which of them repeat the motion of an earlier one: a repeat costs what the
+    // first one costs plus a longer index - it never wins (strict '<' in candidate order), so it is not evaluated.  The distinct ones are dealt to the waves in order:
+    // with four or fewer of them (the usual case: neighbours share vectors) no wave does a second evaluation
+    unsigned mask = 0, distinct = 0;
+    {
+        MergeMotion mm[6];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) mask |= (valid && merge_cand(g, cu_in, cux, cuy, n, k, is_b).ok ? 1u : 0u) << k;
+        for (int k = 0; k < 6; ++k) {
+            mm[k] = merge_cand(g, cu_in, cux, cuy, n, k, is_b);
+            const bool ok = valid && mm[k].ok;
+            mask |= (ok ? 1u : 0u) << k;
+            bool rep = false;
+#pragma unroll
+            for (int j = 0; j < k; ++j) {
+                const bool same = mm[j].dir == mm[k].dir && (!(mm[k].dir & 1) || (mm[j].mvx == mm[k].mvx && mm[j].mvy == mm[k].mvy)) &&
+                                  (!(mm[k].dir & 2) || (mm[j].mv1x == mm[k].mv1x && mm[j].mv1y == mm[k].mv1y));
+                rep |= ((mask >> j) & 1u) && same;
+            }
+            distinct |= (ok && !rep ? 1u : 0u) << k;
+        }
+    }
     unsigned f[16];
     {
         const uint8_t *frow = ks_org_y(g, src) + (long)(valid ? y0 : cy * 64) * g.sy + (valid ? x0 : cx * 64);
@@ -963,8 +980,11 @@ __global__ __launch_bounds__(256) void merge_pass_kernel(KsGeom g, int lam, cons
     __syncthreads();
     const long base = (long)(valid ? y0 : 0) * g.sy + (valid ? x0 : 0) + g.org_y;
 #pragma unroll 1
-    for (int k = wave; k < 6; k += 4) {
-        const bool on = (mask >> k) & 1u;
+    for (int it = wave; it < 6; it += 4) {
+        if (!__any(__popc(distinct) > it)) break;                      // nobody in this wave has that many distinct candidates
+        int k = 0;                                                     // the it-th distinct candidate of this lane's CU
+        { unsigned d = distinct; for (int q = 0; q < it; ++q) d &= d - 1u; k = d ? __ffs((int)d) - 1 : 0; }
+        const bool on = __popc(distinct) > it;
         const MergeMotion m = merge_cand(g, cu_in, cux, cuy, n, k, is_b);
         const int ax = on ? m.mvx : 0, ay = on ? m.mvy : 0, bx = on ? m.mv1x : 0, by = on ? m.mv1y : 0, dir = on ? m.dir : 1;
         unsigned sd = 0;
