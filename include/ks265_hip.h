@@ -39,6 +39,8 @@ enum ks265_status {
 };
 
 int ks265_create(ks265_ctx **out, int device);      /* creates its own HIP stream                      */
+/* the same with the device's highest stream priority when high_priority != 0 (a host's long, narrow kernels - the key picture's intra wavefront - underneath wide ones) */
+int ks265_create_prio(ks265_ctx **out, int device, int high_priority);
 void ks265_destroy(ks265_ctx *ctx);
 int ks265_set_stream(ks265_ctx *ctx, void *hip_stream); /* adopt a caller stream (e.g. torch's current) */
 /* waits for the context's stream; also reads (and clears) the device-side error word that kernels set when they could not complete

@@ -9,7 +9,10 @@ extern "C" {
 
 const char *ks265_version(void) { return "ks265hip 0.1 (gfx950) — pixel-kernel path of libqycodec V2.6.1.3"; }
 
-int ks265_create(ks265_ctx **out, int device)
+int ks265_create(ks265_ctx **out, int device) { return ks265_create_prio(out, device, 0); }
+/* high_priority != 0: the context's stream gets the device's highest priority - for a host's long, narrow kernels (a key picture's intra wavefront keeps 34 work-groups
+ * busy for 19 ms) that must make progress underneath wide ones from other streams */
+int ks265_create_prio(ks265_ctx **out, int device, int high_priority)
 {
     if (!out) return KS265_POINTER;
     *out = nullptr;
@@ -17,7 +20,11 @@ int ks265_create(ks265_ctx **out, int device)
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return KS265_NO_DEVICE;
     ks265_ctx *c = new ks265_ctx();
     c->device = device;
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return KS265_FAIL; }
+    int plo = 0, phi = 0;                                            // (numerically lower = higher priority)
+    if (hipSetDevice(device) != hipSuccess) { delete c; return KS265_FAIL; }
+    if (high_priority && hipDeviceGetStreamPriorityRange(&plo, &phi) == hipSuccess && phi < plo) {
+        if (hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, phi) != hipSuccess) { delete c; return KS265_FAIL; }
+    } else if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return KS265_FAIL; }
     c->own_stream = true;
     if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) { ks265_destroy(c); return KS265_FAIL; }
     if (hipHostMalloc((void **)&c->err_host, sizeof(unsigned), hipHostMallocMapped) != hipSuccess ||

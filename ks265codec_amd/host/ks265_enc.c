@@ -1161,7 +1161,7 @@ static Enc *lane_open(QY265EncConfig *cfg, int device, int multi, int *err)
     if (e->aq_on) e->use_graph = 0;                                      /* (a captured picture would replay one map) */
     if (e->use_graph) e->split = 0;
     if (e->key_overlap) {
-        if (!r) r = ks265_create(&e->ctx_key, dev_id);
+        if (!r) r = ks265_create_prio(&e->ctx_key, dev_id, getenv("KS265_KEY_PRIO") ? atoi(getenv("KS265_KEY_PRIO")) : 1);   /* the key picture's wavefront must run underneath the P pictures, not behind them */
         if (!r) r = ks265_frame_create(e->ctx_key, &e->fcfg, &e->frame_key);
         if (!r) r = pic_alloc(e, &e->src_key);
         if (!r) r = ks265_dev_malloc(e->ctx, (void **)&e->dev_sse_key, 64);

@@ -47,7 +47,7 @@ _lib = None
 
 # every symbol include/ks265_hip.h declares (checked by tests/test_abi.py against the header text)
 EXPORTS = [
-    "ks265_create", "ks265_destroy", "ks265_set_stream", "ks265_synchronize", "ks265_take_device_error", "ks265_last_error", "ks265_version",
+    "ks265_create", "ks265_create_prio", "ks265_destroy", "ks265_set_stream", "ks265_synchronize", "ks265_take_device_error", "ks265_last_error", "ks265_version",
     "ks265_timer_start", "ks265_timer_stop_ms", "ks265_marker", "ks265_debug_set",
     "ks265_dev_malloc", "ks265_dev_free", "ks265_host_malloc", "ks265_host_free", "ks265_memcpy_h2d_async", "ks265_memcpy_d2h_async", "ks265_memcpy_d2d_async", "ks265_copy_out_async", "ks265_memset_async",
     "ks265_event_create", "ks265_event_record", "ks265_event_wait", "ks265_stream_wait_event", "ks265_event_destroy",

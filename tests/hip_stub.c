@@ -24,6 +24,8 @@ struct ks265_frame {
 
 const char *ks265_version(void) { return "ks265hip CPU stub (tests only)"; }
 const char *ks265_last_error(ks265_ctx *c) { (void)c; return "stub"; }
+int ks265_create(ks265_ctx **out, int device);
+int ks265_create_prio(ks265_ctx **out, int device, int high_priority) { (void)high_priority; return ks265_create(out, device); }
 int ks265_create(ks265_ctx **out, int device)
 {
     const char *nd = getenv("KS265_STUB_DEVICES");                     /* how many GPUs the stand-in "has" (default 8) */
