@@ -635,7 +635,7 @@ def encoded_leg(args, torch, dist, rank, world, dev_index, backend, sync_all):
         # Weak mode: STEADY-STATE throughput of the asynchronous encoder (output lags input by the SDK's contract).  Untimed: the W warm-up pictures and
         # as many more as it takes to fill the pipeline and to stand just behind a key picture (the ring of pictures in flight is then full and every
         # EncodeFrame call returns only when a picture has left the encoder: back-pressure = one picture in, one picture out).  Timed window A: exactly
-        # K pictures (no key picture among them when K < iper).  Timed window B (only when A holds no key picture): exactly FOUR whole GOPs of -iper
+        # K pictures (no key picture among them when K < iper).  Timed window B (unless A spans four GOPs itself): exactly FOUR whole GOPs of -iper
         # pictures each = iper - 1 P/B pictures + ONE key picture (one GOP when -iper > 256).  `value` is the whole-GOP rate (the key picture's share included); A is reported beside it.
         iper = args.iper if args.iper > 0 else 1 << 30
         if lanes > 1:
@@ -676,7 +676,7 @@ def encoded_leg(args, torch, dist, rank, world, dev_index, backend, sync_all):
             dt_a = time.perf_counter() - t0
             dt, npic = dt_a, args.steps
             win = {"A": {"pictures": args.steps, "seconds": round(dt_a, 5), "key_pictures": (fill + args.steps - 1) // iper - (fill - 1) // iper}}
-            if win["A"]["key_pictures"] == 0 and iper < 1 << 20:
+            if args.steps < 4 * iper and iper < 1 << 20:               # (A itself is the value only when it spans four GOPs or more)
                 pos = fill + args.steps
                 feed(-pos % iper + 1 if pos % iper != 1 else 0)   # untimed: up to the picture right after the next key picture
                 ngop = 4 if iper <= 256 else 1                     # round 4: four whole GOPs, not one - 0.14 s windows moved by 12 % when one key picture was not hidden under its predecessor GOP
@@ -737,7 +737,7 @@ def encoded_line(args, enc, world, hot, cpu):
                              "(starting from and draining to an empty pipeline included); ms_per_step = 1000 / value per GPU" % enc["gop_lanes"]) if enc.get("gop_lanes", 1) > 1 else
                              "steady state of the asynchronous encoder (pipeline full before and after, back-pressure: one picture in = one picture out), barrier + "
                              "device synchronize on both sides of each window.  A = exactly --steps pictures; B = four whole GOPs of -iper pictures incl. their key pictures "
-                             "(run when A holds no key picture).  value = pictures / seconds of B (of A when A already holds its key pictures); ms_per_step = 1000 / value per GPU"),
+                             "(run unless A spans four GOPs itself).  value = pictures / seconds of B (of A in that case); ms_per_step = 1000 / value per GPU"),
                    "gop_lanes": enc.get("gop_lanes", 1),
                    "windows": enc.get("windows"),
                    "pictures_per_step": 1, "host_threads_per_gpu": enc["host_threads"], "host_cores": enc["host_cores"],
