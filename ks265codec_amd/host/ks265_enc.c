@@ -294,6 +294,7 @@ typedef struct Enc {
     /* -aq N (iAqMode != 0): adaptive quantisation = the reference's calcFrameAdaptQuant enc@0x4653c0 on the source picture (ks265_frame_adapt_quant, pinned on recorded
      * calls), one QP per CTU from it (ks265_aq_ctu_map), the pixel path and the writer on that map (ks265_frame_set_qp_map, cu_qp_delta) */
     int aq_on, aq_nx, aq_ny; double *aq_off[2], *aq_scratch[2]; uint16_t *aq_inv[2]; int8_t *dev_qmap[NPIPE];   /* [1]: the key pictures' stream */
+    int zero_latency;                                     /* -latency zerolatency without B pictures / lookahead / lanes: every EncodeFrame call hands out its own picture */
     int copy_mb;                                          /* KS265_COPYOUT_MB = N: hipMemcpyAsync takes the fixed part + N MB of stored lines per P / B picture (a key picture: everything) and the copy kernel
                                                            * only what lies beyond; default -1 = the copy kernel alone.  On this runtime the D2H hipMemcpyAsync is itself a kernel (__amd_rocclr_copyBuffer,
                                                            * 110 us for 4 MB): no better neighbour than ours (50 us for the ~2 MB a picture really holds) - measured both ways, within +- 1.5 % */
@@ -1216,6 +1217,7 @@ static Enc *lane_open(QY265EncConfig *cfg, int device, int multi, int *err)
     memset(&e->scfg, 0, sizeof e->scfg);
     e->scfg.width = e->W; e->scfg.height = e->H; e->scfg.sao = e->use_sao; e->scfg.deblock = e->use_df;
     e->scfg.sdh = e->fcfg.sdh;
+    e->zero_latency = cfg->latency == QY265LATENCY_ZERO && e->gop_b == 0 && !e->la_on && !multi;
     e->scfg.cu_qp_delta = e->aq_on;
     e->scfg.wpp = 1;                                                    /* CTU rows as substreams: what lets several writer threads share one picture */
     e->scfg.max_dec_pic_buffering = e->hier ? 10 : e->gop_b ? 4 : e->refs + 1; e->scfg.log2_max_poc_lsb = 16;
@@ -1435,7 +1437,16 @@ static int lane_encode_frame(Enc *e, QY265Nal **pNals, int *iNalCount, QY265Pict
         /* finished pictures (copied to the output buffer); when the ring of in-flight pictures is nearly full, wait for the oldest ones -
          * only as many as needed, the writers keep running */
         const double t0 = now_ms();
-        r = take_output(e, e->ring - 12, 1 << 30, pNals, iNalCount, out, NULL);
+        int in_flight = e->ring - 12;
+        if (e->zero_latency) {
+            /* -latency zerolatency (QY265LATENCY_ZERO; the SDK's live-streaming mode): the call returns with THIS picture's NAL units - nothing stays behind, QY265EncoderDelayedFrames
+             * is 0 between calls.  The picture goes through the same pipeline (scheduler thread, streams, writer threads sharing its rows); the caller waits for it */
+            pthread_mutex_lock(&e->mu);
+            while (!e->quit && !e->sched_err && (e->sched_seen != e->next_disp || !e->sched_idle)) pthread_cond_wait(&e->cv_sched_done, &e->mu);
+            pthread_mutex_unlock(&e->mu);
+            in_flight = 0;
+        }
+        r = take_output(e, in_flight, 1 << 30, pNals, iNalCount, out, NULL);
         e->st.output_ms += now_ms() - t0;
         return r ? r : e->sched_err;
     }

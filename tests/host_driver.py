@@ -13,7 +13,7 @@ class Nal(C.Structure): _fields_ = [("naltype", C.c_int), ("tid", C.c_int), ("iS
 rng = np.random.default_rng(3)
 clip = rng.integers(0, 256, (11, W * H * 3 // 2), dtype=np.uint8)
 cfg = (C.c_uint8 * LAY["sizeof_config"])()
-assert lib.QY265ConfigDefaultPreset(cfg, b"medium", None, b"default") == 0
+assert lib.QY265ConfigDefaultPreset(cfg, b"medium", None, os.environ.get("KS_TEST_LATENCY", "default").encode()) == 0
 if os.environ.get("KS_TEST_SCENECUT"):
     assert lib.ks265_enc_set_default(b"scenecut", int(os.environ["KS_TEST_SCENECUT"])) == 0
 for k, v in (("wdt", W), ("hgt", H), ("fr", 50), ("rc", int(os.environ.get("KS_TEST_RC", "0"))), ("br", int(os.environ.get("KS_TEST_BR", "1000"))), ("qp", 34), ("iper", iper), ("bframes", bframes), ("threads", 5), ("psnr", 1), ("log", 3), ("lookahead", int(os.environ.get("KS_TEST_LOOKAHEAD", "-1"))), ("aq", int(os.environ.get("KS_TEST_AQ", "0")))):
@@ -101,4 +101,4 @@ while lib.QY265EncoderDelayedFrames(h):
 lanes = lib.ks265_enc_lanes(h)
 lib.QY265EncoderClose(h)
 if out_path: open(out_path, "wb").write(bytes(bs))
-print(json.dumps({"hdr": hdr_entries, "md5": md.hexdigest(), "lanes": lanes, "pts": pts, "idr": types.count(19), "vcl": len(pts), "bytes": len(bs), "maxdelay": maxdelay, "zero_copy": zc, "errors": errors, "err_at": err_at}))
+print(json.dumps({"hdr": hdr_entries, "md5": md.hexdigest(), "lanes": lanes, "pts": pts, "idr": types.count(19), "vcl": len(pts), "bytes": len(bs), "maxdelay": maxdelay, "flush_calls": calls, "zero_copy": zc, "errors": errors, "err_at": err_at}))

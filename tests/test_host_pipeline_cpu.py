@@ -337,6 +337,14 @@ def test_adaptive_quantisation_streams_decode(stub_lib, tmp_path, bframes):
         assert one["md5"] == run(stub_lib, 100, 32, 0, W=128, H=72, KS_TEST_AQ=1, KS265_GOP_LANES=3)["md5"]
 
 
+def test_zero_latency_hands_out_every_picture_at_once(stub_lib):
+    """-latency zerolatency (QY265LATENCY_ZERO, the SDK's live mode): every QY265EncoderEncodeFrame call returns with its own picture, nothing is delayed, no flush is needed;
+    the stream is the one the pipelined modes write for the same GOP (IPPP)"""
+    z = run(stub_lib, 60, 16, 0, KS_TEST_LATENCY="zerolatency")
+    assert z["pts"] == list(range(60)) and z["maxdelay"] == 0 and z["flush_calls"] == 0, (z["maxdelay"], z["flush_calls"])
+    assert z["md5"] == run(stub_lib, 60, 16, 0, KS_TEST_LATENCY="lowdelay")["md5"]
+
+
 def test_scenecut_flag_runs_the_reference_rule(stub_lib):
     """-scenecut N (the reference's hidden flag): the scene-cut verdict is the rule of scenecut enc@0x47e9d0 (pinned: tests/test_lookahead_ref.py) on this lookahead's frame
     costs - no distance guard of its own: cuts three pictures apart are all key pictures; a calm clip has none"""
