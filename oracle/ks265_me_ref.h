@@ -41,6 +41,29 @@ void kso_ref_me_umh(kso_me *m);
 int kso_me_replay(int method, const uint8_t *fenc, int log2w, int log2h, const uint8_t *plane, int rx0, int ry0, int rw, int rh,
                   int pux, int puy, const uint16_t *cmx, int xlo, int xhi, const uint16_t *cmy, int ylo, int yhi,
                   int merange, int range_shift, const int lim[4], int skip_cross, int use_had, int sx, int sy, uint32_t cost0, int32_t out[4]);
+
+/* meInitPoint enc@0x48af50 (+ checkLayerMv enc@0x48ad80): the start point of the integer search.  In: the PU, its two AMVP candidates and the cost of coding
+ * each index, the mv limits, merange, the mvd cost table and lambda, the look-ahead's vector for the block, the two extra vectors the PU carries.
+ * Out: the predictor index chosen, the start mv and its cost / SAD, the search window, the table offsets. */
+typedef struct {
+    int log2w, log2h, pux, puy, stride;               /* TPredUnit+5 / +6 / +0xf8 / +0xfc, tME+0x50                                */
+    int mvp[2][2];                                    /* TPredUnit+0x1a0 / +0x1a4 (quarter pel)                                    */
+    int lim[4];                                       /* tME+0x74 / +0x76 / +0x78 / +0x7a: integer mv limits x0 x1 y0 y1           */
+    int merange, lambda;                              /* tME+0x68, +0x80                                                           */
+    uint32_t idx_cost[2];                             /* tME+0x2e0 / +0x2e4: cost of mvp_idx 0 / 1                                 */
+    int cand_on[2], cand[2][2];                       /* TPredUnit+0x110+l / +0x114+4l and +0x11c+l / +0x120+4l                    */
+    int layer_enabled, layer_on, layer_mv[2];         /* TEncParam+0x4a0; the look-ahead coded the block inter; its half-res vector */
+    int prev_on, prev[2];                             /* TPredUnit+0x1f2+l / +0x1f4+4l before the call                             */
+    const uint16_t *base;                             /* tME+0x10: centre of the mvd cost table, valid for [-256, 256] at least    */
+    uint32_t (*dist)(void *user, long off); void *user;   /* TPredUnit+0x38 on the block at plane offset off                        */
+    int mvp_idx, mx, my; uint32_t cost, sad;          /* tME+0x58, +0x54 / +0x56, +0x90, TPredUnit+0x150                           */
+    int zero_tried, outside, win[4]; long off;        /* tME+0x5c, +0x65, +0x6c..+0x72, +0x40 - plane                              */
+    int prev_on_out, prev_out[2], cmx_off, cmy_off;   /* TPredUnit+0x1f2+l / +0x1f4+4l after; tME+0x18 / +0x20 - tME+0x10          */
+} kso_me_init;
+void kso_ref_me_init_point(kso_me_init *m);
+/* trace replay (tests/test_me_init.py): h = the 64-word record oracle/ref_probe/init_shim.c writes, tab513 = base[-256..256].  The block comparisons are
+ * answered from the record, in order; -1 if the restatement asks for one the reference did not make (or fewer), else 0 and out[] = the results. */
+int kso_me_init_replay(const int32_t h[64], const uint16_t *tab513, int32_t out[20]);
 #ifdef __cplusplus
 }
 #endif
