@@ -799,3 +799,14 @@ extern "C" int ks265_lookahead_picture(ks265_frame *f, ks265_pic cur, ks265_pic 
     if ((r = ks265_me_integer(f, cur, ref, nullptr, f->pu[f->cur_pu]))) return r;
     return ks265_lookahead_reduce(f, cost_ws, f->pu[f->cur_pu], out);
 }
+
+// the same picture against another reference: its intra costs are in cost_ws from the ks265_lookahead_picture call before (one intra pass per picture; the
+// slice-type decision compares a picture with the pictures 1, 4 and 8 back)
+extern "C" int ks265_lookahead_inter(ks265_frame *f, ks265_pic cur, ks265_pic ref, const uint32_t *cost_ws, uint64_t *out)
+{
+    KS_FRAME_CHECK(f);
+    if (!cur.y || !ref.y || !cost_ws || !out) return KS265_POINTER;
+    int r;
+    if ((r = ks265_me_integer(f, cur, ref, nullptr, f->pu[f->cur_pu]))) return r;
+    return ks265_lookahead_reduce(f, cost_ws, f->pu[f->cur_pu], out);
+}

@@ -312,7 +312,7 @@ typedef struct Enc {
      * two GOPs.  Its reconstruction goes to one of two DPB slots of its own; the first P picture of the GOP waits for ev_key. */
     int key_overlap, nkeys; ks265_ctx *ctx_key; ks265_frame *frame_key; ks265_pic src_key; uint64_t *dev_sse_key; void *ev_key, *ev_firstp[2];
     /* scheduling */
-    Input in[MAX_INPUT]; int nin, next_disp;                   /* display index of the next input picture */
+    Input in[MAX_INPUT]; int nin, next_disp, in_disp;          /* next_disp: pictures handed to the scheduler; in_disp: pictures taken in (= next_disp, or with -lookahead one more: la_pend) */
     int gop_start;                                        /* display index of the last key picture */
     int coded_upto;                                       /* display index up to which everything is scheduled */
     int force_key;
@@ -325,6 +325,8 @@ typedef struct Enc {
     int mg_adapt, mg4_until;                                          /* slice-type decision (-lookahead N with the hierarchical GOP): a block of 8 pictures is coded as 8 or as 4 + 4; display index up to which 4 is in force */
     long long la_prev_icost;                                           /* -scenecut N: the previous picture's intra cost (-1: none yet) */
     unsigned long long la_c4_prev;                                     /* inter cost of the previous picture on the GOP's grid of 4 against the picture 4 back */
+    int la_auto;                                                       /* no -lookahead given, hierarchical GOP: the slice-type decision alone (pictures on the GOP's grid of 4), no scene cuts - works in GOP lanes */
+    Input *la_pend; int la_pend_what;                                  /* the picture whose analysis is running (handed to the scheduler by la_finish); 1: against its predecessor, 2: the GOP's grid */
     ks265_ctx *ctx_la; ks265_frame *frame_la; ks265_frame_geom geom_la; ks265_pic la_pic[LA_RING];
     uint8_t *la_dev_luma; uint32_t *la_cost_ws; uint64_t *la_dev_out, *la_host_out; void *la_ev;
     struct TopWake *wake;                                 /* lanes: the handle's caller sleeps here until a picture of ANY lane is finished */
@@ -1103,9 +1105,12 @@ static Enc *lane_open(QY265EncConfig *cfg, int device, int multi, int *err)
     if (!r) r = ks265_frame_compact_layout(e->frame, e->cmp_off);
     if (!r) r = ks265_create(&e->ctx_in, dev_id);
     if (!r) r = ks265_create(&e->ctx_out, dev_id);
-    if (!r && cfg->lookahead > 0) {
+    /* no -lookahead on the command line and the SDK's default GOP (hierarchical B, 8): the slice-type decision runs by itself (round 4: it costs a search of the half-size
+     * picture every fourth picture, and the caller does not wait for it) - the reference's adaptive BiPredFrames is on by default as well.  -lookahead 0 switches it off. */
+    const int la_auto = cfg->lookahead < 0 && e->hier && !getenv("KS265_NO_AUTO_LOOKAHEAD");
+    if (!r && (cfg->lookahead > 0 || la_auto)) {
         const int w = (e->W / 2) & ~7, h = (e->H / 2) & ~7;            /* the analysis sees the picture without its last columns / rows when half the size is no multiple of 8 */
-        if (w < 16 || h < 16) logf_(1, e->log_level, "ks265enc: -lookahead %d: the analysis needs a picture of at least 32 x 32: off\n", cfg->lookahead);
+        if (w < 16 || h < 16) { if (!la_auto) logf_(1, e->log_level, "ks265enc: -lookahead %d: the analysis needs a picture of at least 32 x 32: off\n", cfg->lookahead); }
         else {
             ks265_frame_cfg lc; memset(&lc, 0, sizeof lc);
             lc.width = w; lc.height = h; lc.qp = e->base_qp > 0 ? e->base_qp : 27; lc.lambda_q4 = kLambdaQ4[lc.qp < 52 ? lc.qp : 51]; lc.me_range = 32; lc.me_method = 1; lc.subme = 0;
@@ -1125,7 +1130,7 @@ static Enc *lane_open(QY265EncConfig *cfg, int device, int multi, int *err)
             if (!r) r = ks265_dev_malloc(e->ctx_la, (void **)&e->la_dev_out, 128);
             if (!r) r = ks265_host_malloc(e->ctx_la, (void **)&e->la_host_out, 128);
             if (!r) r = ks265_event_create(e->ctx_la, &e->la_ev);
-            if (!r) { e->la_on = 1; e->la_last_key = -1000000; e->la_prev_icost = -1; e->la_w = w; e->la_h = h; e->mg_adapt = e->hier; e->mg4_until = -1; }
+            if (!r) { e->la_on = 1; e->la_auto = la_auto; e->la_last_key = -1000000; e->la_prev_icost = -1; e->la_w = w; e->la_h = h; e->mg_adapt = e->hier; e->mg4_until = -1; }
         }
     }
     e->split = getenv("KS265_NO_SPLIT") ? 0 : 1;
@@ -1274,7 +1279,7 @@ static int lane_delayed(Enc *e)
     if (!e) return 0;
     int n = 0;
     pthread_mutex_lock(&e->mu);                                        /* one snapshot: a picture moves from "waiting" to "in flight" under this lock */
-    for (int i = 0; i < MAX_INPUT; ++i) if (e->in[i].used == 1) ++n;
+    for (int i = 0; i < MAX_INPUT; ++i) if (e->in[i].used == 1 || e->la_pend == &e->in[i]) ++n;   /* (la_pend: its analysis is running, la_finish hands it on) */
     n += e->njobs;
     pthread_mutex_unlock(&e->mu);
     return n;
@@ -1294,6 +1299,102 @@ static int lane_acquire(Enc *e, QY265YUV *yuv)
     yuv->iWidth = e->W; yuv->iHeight = e->H;
     yuv->pData[0] = slot->i420; yuv->pData[1] = slot->i420 + (size_t)e->W * e->H; yuv->pData[2] = yuv->pData[1] + (size_t)e->W * e->H / 4;
     yuv->iStride[0] = e->W; yuv->iStride[1] = e->W / 2; yuv->iStride[2] = e->W / 2;
+    return QY_OK;
+}
+
+/* a picture whose analysis is through (or which needs none) goes to the scheduler */
+static void la_publish(Enc *e, Input *slot, int cut, int mini4)
+{
+    const int nd = slot->disp;
+    pthread_mutex_lock(&e->mu);
+    const int periodic = slot->iper > 0 && e->la_last_key > -1000000 && nd - e->la_last_key >= slot->iper;    /* (the scheduler's own rule: key positions are the same there) */
+    if (cut) ++e->la_cuts;
+    if (cut || slot->key || nd == 0 || periodic) e->la_last_key = nd;
+    slot->mini4 = mini4; slot->key = slot->key || cut; slot->used = 1; e->next_disp = nd + 1;
+    pthread_cond_signal(&e->cv_sched);
+    pthread_mutex_unlock(&e->mu);
+}
+
+/* -lookahead N, second half: the results of the picture whose analysis la_launch left running - the scene-cut verdict and, with the hierarchical GOP, the slice types of its
+ * block of 8 - then the picture is handed to the scheduler.  Called by the caller's thread only (the next lane_put, or the flush). */
+static int la_finish(Enc *e)
+{
+    Input *slot = e->la_pend;
+    if (!slot) return QY_OK;
+    e->la_pend = NULL;
+    const int nd = slot->disp, w = e->la_w, h = e->la_h;
+    int cut = 0, mini4 = 0;
+    int r = ks265_event_wait(e->ctx_la, e->la_ev);
+    if (!r && (e->la_pend_what & 1)) {                                 /* scene cut: the picture against its predecessor */
+        /* a cut: predicting the picture from its predecessor costs at least 0.7 of coding it intra (both sums over the 8x8 blocks of the half-size picture),
+         * and the last key picture is at least eight pictures back */
+        if (g_cli.scenecut > 0) {
+            /* -scenecut N: the reference's verdict (scenecut enc@0x47e9d0, restated in oracle/ks265_lookahead_ref.c and pinned on recorded calls) on this lookahead's
+             * frame costs: a change of flatness (intra cost below 4 per 8x8 block of the half-size picture) decides at once; else a cut is where predicting the
+             * picture costs at least (1 - N / 100 x pictures since the key picture / min(key period, 320)) of coding it intra */
+            const long long icost = (long long)e->la_host_out[0], pcost = (long long)e->la_host_out[1], prev = e->la_prev_icost;
+            const long long T = (long long)(w / 8) * (h / 8) * 4;
+            int verdict = -1;
+            if (prev >= 0) {
+                if (prev < T) { if (icost > T) verdict = 1; else if (icost < T) verdict = 0; }
+                else if (prev > T && icost < T) verdict = 1;
+            }
+            if (verdict < 0) {
+                const int keyint = slot->iper > 0 ? (slot->iper < 320 ? slot->iper : 320) : 256;
+                const double bias = (double)(nd - (e->la_last_key > -1000000 ? e->la_last_key : 0)) * ((double)g_cli.scenecut / 100.0) / (double)keyint;
+                verdict = (double)pcost >= (1.0 - bias) * (double)icost;
+            }
+            cut = verdict;
+            e->la_prev_icost = icost;
+        } else if (e->la_host_out[1] * 10 >= e->la_host_out[0] * 7 && nd - e->la_last_key >= 8) cut = 1;
+    }
+    /* slice types of the hierarchical GOP (the reference's adaptive BiPredFrames): the GOP is laid out in blocks of 8 pictures from its key picture; a block is
+     * coded with its anchor 8 pictures after the previous one, or - when predicting that anchor from 8 pictures back costs more than the two anchors 4 apart cost
+     * together (+ 1/12: the shorter structure pays more B-picture overhead) - as two mini-GOPs of 4.  Costs = the inter sums of the frame-cost kernels, this
+     * picture against the pictures 4 and 8 back; decided at the block's last picture, carried to the scheduler in its input slot. */
+    if (!r && (e->la_pend_what & 2) && !cut) {                         /* (launched before the verdict was known: a cut starts a GOP here, the grid's sums are not used) */
+        const int p = nd - e->la_last_key;
+        const unsigned long long c4 = e->la_host_out[5];
+        if ((p & 7) == 0) {
+            const unsigned long long c8 = e->la_host_out[9], two = c4 + e->la_c4_prev;
+            mini4 = c8 * 12 > two * 13;
+            if (mini4) ++e->la_mini4;
+        }
+        e->la_c4_prev = c4;
+    }
+    if (r) { pthread_mutex_lock(&e->mu); slot->used = 0; e->sched_err = hip_rc(r); pthread_mutex_unlock(&e->mu); }
+    else la_publish(e, slot, cut, mini4);
+    return r ? hip_rc(r) : QY_OK;
+}
+
+/* -lookahead N, first half: the half-size picture and the frame-cost kernels of this picture (against its predecessor; on the GOP's grid of 4 also against the pictures 4 and
+ * 8 back), results on their way to the host - nobody waits here */
+static int la_launch(Enc *e, Input *slot)
+{
+    const int nd = slot->disp, c = nd % LA_RING, w = e->la_w, h = e->la_h;
+    const size_t org = (size_t)e->geom_la.pad_y * e->geom_la.stride_y + e->geom_la.pad_y;
+    const int keynow = slot->key || nd == 0 || (slot->iper > 0 && e->la_last_key > -1000000 && nd - e->la_last_key >= slot->iper);   /* (but for a scene cut, not known yet) */
+    const int p = keynow ? 0 : nd - e->la_last_key;                    /* position inside the GOP */
+    int what = 0;
+    if (e->la_auto && (p & 3)) { la_publish(e, slot, 0, 0); return QY_OK; }   /* not on the grid: nothing to analyse, nothing to keep */
+    int r = ks265_memcpy_h2d_async(e->ctx_la, e->la_dev_luma, slot->i420, (size_t)e->W * e->H);
+    if (!r) r = ks265_downsample_rect(e->ctx_la, e->la_dev_luma, e->W, e->la_pic[c].y + org, e->geom_la.stride_y, w, h);
+    if (!r) r = ks265_pad_picture(e->frame_la, e->la_pic[c]);
+    if (!r && e->la_have_prev && !e->la_auto) {
+        r = ks265_lookahead_picture(e->frame_la, e->la_pic[c], e->la_pic[(nd + LA_RING - 1) % LA_RING], e->la_cost_ws, e->la_dev_out);
+        what |= 1;
+    }
+    if (!r && e->mg_adapt && p >= 4 && (p & 3) == 0) {
+        /* (explicit -lookahead: the picture's intra costs are in la_cost_ws from the call above - search + sums only; auto: the intra pass runs here, once per grid picture) */
+        r = e->la_auto ? ks265_lookahead_picture(e->frame_la, e->la_pic[c], e->la_pic[(nd - 4) % LA_RING], e->la_cost_ws, e->la_dev_out + 4)
+                       : ks265_lookahead_inter(e->frame_la, e->la_pic[c], e->la_pic[(nd - 4) % LA_RING], e->la_cost_ws, e->la_dev_out + 4);
+        if (!r && (p & 7) == 0) r = ks265_lookahead_inter(e->frame_la, e->la_pic[c], e->la_pic[(nd - 8) % LA_RING], e->la_cost_ws, e->la_dev_out + 8);
+        what |= 2;
+    }
+    if (!r && what) r = ks265_memcpy_d2h_async(e->ctx_la, e->la_host_out, e->la_dev_out, 96);
+    if (!r) r = ks265_event_record(e->ctx_la, e->la_ev);               /* (also orders the next picture's upload into la_dev_luma behind this one's down-sampling: same stream) */
+    if (r) return hip_rc(r);
+    e->la_have_prev = 1; e->la_pend = slot; e->la_pend_what = what;
     return QY_OK;
 }
 
@@ -1330,81 +1431,21 @@ static int lane_put(Enc *e, QY265Picture *in, int key)
             memcpy(v + (size_t)y * (e->W / 2), in->yuv->pData[2] + (size_t)y * in->yuv->iStride[2], (size_t)e->W / 2);
         }
     }
-    int cut = 0, mini4 = 0;
-    if (e->la_on) {                                                    /* analysis on half-size pictures, on a stream of its own: short, independent of the pipeline */
-        const int nd = e->next_disp, c = nd % LA_RING, w = e->la_w, h = e->la_h;
-        const size_t org = (size_t)e->geom_la.pad_y * e->geom_la.stride_y + e->geom_la.pad_y;
-        int r = ks265_memcpy_h2d_async(e->ctx_la, e->la_dev_luma, slot->i420, (size_t)e->W * e->H);
-        if (!r) r = ks265_downsample_rect(e->ctx_la, e->la_dev_luma, e->W, e->la_pic[c].y + org, e->geom_la.stride_y, w, h);
-        if (!r) r = ks265_pad_picture(e->frame_la, e->la_pic[c]);
-        if (!r && e->la_have_prev) {                                   /* scene cut: this picture against its predecessor */
-            r = ks265_lookahead_picture(e->frame_la, e->la_pic[c], e->la_pic[(nd + LA_RING - 1) % LA_RING], e->la_cost_ws, e->la_dev_out);
-            if (!r) r = ks265_memcpy_d2h_async(e->ctx_la, e->la_host_out, e->la_dev_out, 32);
-            if (!r) r = ks265_event_record(e->ctx_la, e->la_ev);
-            if (!r) r = ks265_event_wait(e->ctx_la, e->la_ev);
-            /* a cut: predicting the picture from its predecessor costs at least 0.7 of coding it intra (both sums over the 8x8 blocks of the half-size picture),
-             * and the last key picture is at least eight pictures back */
-            if (!r && g_cli.scenecut > 0) {
-                /* -scenecut N: the reference's verdict (scenecut enc@0x47e9d0, restated in oracle/ks265_lookahead_ref.c and pinned on recorded calls) on this lookahead's
-                 * frame costs: a change of flatness (intra cost below 4 per 8x8 block of the half-size picture) decides at once; else a cut is where predicting the
-                 * picture costs at least (1 - N / 100 x pictures since the key picture / min(key period, 320)) of coding it intra */
-                const long long icost = (long long)e->la_host_out[0], pcost = (long long)e->la_host_out[1], prev = e->la_prev_icost;
-                const long long T = (long long)(w / 8) * (h / 8) * 4;
-                int verdict = -1;
-                if (prev >= 0) {
-                    if (prev < T) { if (icost > T) verdict = 1; else if (icost < T) verdict = 0; }
-                    else if (prev > T && icost < T) verdict = 1;
-                }
-                if (verdict < 0) {
-                    const int keyint = e->iper > 0 ? (e->iper < 320 ? e->iper : 320) : 256;
-                    const double bias = (double)(nd - (e->la_last_key > -1000000 ? e->la_last_key : 0)) * ((double)g_cli.scenecut / 100.0) / (double)keyint;
-                    verdict = (double)pcost >= (1.0 - bias) * (double)icost;
-                }
-                cut = verdict;
-                e->la_prev_icost = icost;
-            } else
-            if (!r && e->la_host_out[1] * 10 >= e->la_host_out[0] * 7 && nd - e->la_last_key >= 8) cut = 1;
-        }
-        /* slice types of the hierarchical GOP (the reference's adaptive BiPredFrames): the GOP is laid out in blocks of 8 pictures from its key picture; a block is
-         * coded with its anchor 8 pictures after the previous one, or - when predicting that anchor from 8 pictures back costs more than the two anchors 4 apart cost
-         * together (+ 1/12: the shorter structure pays more B-picture overhead) - as two mini-GOPs of 4.  Costs = the inter sums of the frame-cost kernels, this
-         * picture against the pictures 4 and 8 back; decided at the block's last picture, carried to the scheduler in its input slot. */
-        const int iper0 = e->iper;
-        const int keynow = cut || key || e->force_key || nd == 0 || (iper0 > 0 && e->la_last_key > -1000000 && nd - e->la_last_key >= iper0);
-        if (!r && e->mg_adapt && !keynow) {
-            const int p = nd - e->la_last_key;                          /* position inside the GOP */
-            if (p >= 4 && (p & 3) == 0) {
-                r = ks265_lookahead_picture(e->frame_la, e->la_pic[c], e->la_pic[(nd - 4) % LA_RING], e->la_cost_ws, e->la_dev_out + 4);
-                if (!r && (p & 7) == 0) r = ks265_lookahead_picture(e->frame_la, e->la_pic[c], e->la_pic[(nd - 8) % LA_RING], e->la_cost_ws, e->la_dev_out + 8);
-                if (!r) r = ks265_memcpy_d2h_async(e->ctx_la, e->la_host_out + 4, e->la_dev_out + 4, 64);
-                if (!r) r = ks265_event_record(e->ctx_la, e->la_ev);
-                if (!r) r = ks265_event_wait(e->ctx_la, e->la_ev);
-                if (!r) {
-                    const unsigned long long c4 = e->la_host_out[5];
-                    if ((p & 7) == 0) {
-                        const unsigned long long c8 = e->la_host_out[9], two = c4 + e->la_c4_prev;
-                        mini4 = c8 * 12 > two * 13;
-                        if (mini4) ++e->la_mini4;
-                    }
-                    e->la_c4_prev = c4;
-                }
-            }
-        }
-        if (r) { pthread_mutex_lock(&e->mu); slot->used = 0; e->sched_err = hip_rc(r); pthread_mutex_unlock(&e->mu); return hip_rc(r); }
-        e->la_have_prev = 1;
-    }
+    /* the picture's own fields travel with it from now; with the analysis it becomes visible to the scheduler one call later (la_finish) */
     pthread_mutex_lock(&e->mu);
-    if (e->la_on) {
-        const int nd = e->next_disp, iper = e->iper;
-        const int periodic = iper > 0 && e->la_last_key > -1000000 && nd - e->la_last_key >= iper;    /* (the scheduler's own rule: key positions are the same there) */
-        if (cut) ++e->la_cuts;
-        if (cut || key || e->force_key || nd == 0 || periodic) e->la_last_key = nd;
-    }
-    slot->mini4 = mini4;
-    slot->disp = e->next_disp++; slot->pts = in->pts; slot->key = key || e->force_key || cut; slot->base_qp = e->base_qp; slot->iper = e->iper; slot->kbps = e->cfg.bitrateInkbps; slot->used = 1;
+    slot->mini4 = 0;
+    slot->disp = e->in_disp++; slot->pts = in->pts; slot->key = key || e->force_key; slot->base_qp = e->base_qp; slot->iper = e->iper; slot->kbps = e->cfg.bitrateInkbps;
     e->force_key = 0;
-    pthread_cond_signal(&e->cv_sched);                                 /* the scheduler thread takes it from here */
+    if (!e->la_on) { slot->used = 1; e->next_disp = e->in_disp; pthread_cond_signal(&e->cv_sched); }   /* the scheduler thread takes it from here */
     pthread_mutex_unlock(&e->mu);
+    if (e->la_on) {
+        /* round 4: the analysis no longer stops the caller.  The previous picture's results - launched one call ago, on a stream of its own - are read now and that picture
+         * goes to the scheduler; then this picture's analysis is launched (its launch needs the GOP position, i.e. the previous picture's verdict) and left running.  Same
+         * decisions as when the caller waited for them (the CPU tests of the lookahead did not change), one picture of delay at the input */
+        int r = la_finish(e);
+        if (!r) r = la_launch(e, slot);
+        if (r) { pthread_mutex_lock(&e->mu); slot->used = 0; e->sched_err = r; pthread_mutex_unlock(&e->mu); return r; }
+    }
     e->st.in_copy_ms += now_ms() - tc0;
     return QY_OK;
 }
@@ -1414,6 +1455,7 @@ static int lane_put(Enc *e, QY265Picture *in, int key)
  * EncodeFrame(NULL) while DelayedFrames() > 0) */
 static int lane_flush_begin(Enc *e, int wait)
 {
+    if (e->la_on) (void)la_finish(e);                                  /* the last picture's analysis: an error is in sched_err */
     pthread_mutex_lock(&e->mu);
     e->sched_flush = 1;
     pthread_cond_signal(&e->cv_sched);
@@ -1465,7 +1507,7 @@ static int lane_encode_frame(Enc *e, QY265Nal **pNals, int *iNalCount, QY265Pict
 static int lane_recon_on(Enc *e)                                       /* the reconstruction of every picture comes back to the host (pinned, per job) */
 {
     if (e->recon_on) return QY_OK;
-    if (e->next_disp != 0) return QY_NOTSUPPORTED;
+    if (e->in_disp != 0) return QY_NOTSUPPORTED;
     e->key_overlap = 0;                                                /* the dump shares one device buffer: key pictures stay on the main stream */
     const size_t fsz = (size_t)e->W * e->H * 3 / 2;
     int r = ks265_dev_malloc(e->ctx, (void **)&e->dev_recon, fsz);
@@ -1477,7 +1519,7 @@ static int lane_recon_on(Enc *e)                                       /* the re
 static int lane_set_recon_file(Enc *e, const char *path)
 {
     if (!e || !path) return QY_POINTER;
-    if (e->next_disp != 0 || e->recon_fd >= 0) return QY_NOTSUPPORTED;
+    if (e->in_disp != 0 || e->recon_fd >= 0) return QY_NOTSUPPORTED;
     const int r = lane_recon_on(e);
     if (r) return r;
     e->recon_fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
@@ -1639,10 +1681,11 @@ static void top_close_chunk(Top *t, int early)
 {
     Chunk *c = &t->ch[(t->ch_head + t->ch_n - 1) % MAX_CHUNKS];
     c->closed = 1;
+    if (t->lane[c->lane]->la_on) (void)la_finish(t->lane[c->lane]);    /* the GOP's last picture does not wait for the lane's next one (an error is in sched_err) */
     if (early) {
         Enc *e = t->lane[c->lane];
         pthread_mutex_lock(&e->mu);
-        e->gop_end = e->next_disp - 1;                                  /* the lane's own index of the GOP's last picture */
+        e->gop_end = e->in_disp - 1;                                  /* the lane's own index of the GOP's last picture */
         pthread_cond_signal(&e->cv_sched);
         pthread_mutex_unlock(&e->mu);
     }
@@ -1803,7 +1846,7 @@ int QY265EncoderEncodeFrame(void *h, QY265Nal **pNals, int *iNalCount, QY265Pict
             t->cur_lane = (t->cur_lane + 1) % t->nlanes;
             Chunk *c = &t->ch[(t->ch_head + t->ch_n) % MAX_CHUNKS];
             memset(c, 0, sizeof *c);
-            c->lane = t->cur_lane; c->base = t->n_in; c->disp0 = t->lane[t->cur_lane]->next_disp;
+            c->lane = t->cur_lane; c->base = t->n_in; c->disp0 = t->lane[t->cur_lane]->in_disp;
             ++t->ch_n;
             t->chunk_left = t->iper > 0 ? t->iper : (1L << 40);
             t->key_request = 0; first = 1;

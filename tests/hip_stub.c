@@ -302,3 +302,4 @@ int ks265_lookahead_picture(ks265_frame *f, ks265_pic cur, ks265_pic ref, uint32
     out[0] = intra; out[1] = inter; out[2] = intra < inter ? intra : inter; out[3] = (uint64_t)f->cfg.width * f->cfg.height / 64;
     return KS265_OK;
 }
+int ks265_lookahead_inter(ks265_frame *f, ks265_pic cur, ks265_pic ref, const uint32_t *ws, uint64_t *out) { return ks265_lookahead_picture(f, cur, ref, (uint32_t *)ws, out); }

@@ -522,5 +522,9 @@ def test_lookahead_frame_cost(ks):
             ol.kso_lookahead_reduce(C.byref(o_low.cfg), ptr(cost), ptr(pu), ptr(exp))
             assert (got == exp).all(), (got, exp)
             res.append(got)
+        # one intra pass per picture: the same picture against a second reference with the intra costs of the call before
+        first = fl.lookahead_picture(low_g[2], low_g[1])
+        again = fl.lookahead_inter(low_g[2], low_g[0])
+        assert (again == fl.lookahead_picture(low_g[2], low_g[0])).all() and again[0] == first[0]
         same, cut = res
         assert same[1] < same[0] // 2 and cut[1] > cut[0], (same, cut)         # continuous motion: inter far cheaper; scene cut: intra cheaper

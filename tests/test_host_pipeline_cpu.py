@@ -391,8 +391,14 @@ def test_slice_type_decision_codes_blocks_of_eight_as_four_plus_four(stub_lib, t
     picture from 8 back costs more than the two steps of 4 together (+ 1/12).  Clip: one scene, still in [0, 32), brightening by 3 per picture in [32, 64), still again:
     the blocks inside the ramp are 4 + 4, the blocks outside are 8; coding order, determinism, graph replay, and the stream decodes with the reference decoder"""
     kw = dict(W=128, H=96, KS_TEST_RAMP="32:64:3")
-    plain = run(stub_lib, 100, 128, -1, **kw)
+    plain = run(stub_lib, 100, 128, -1, KS_TEST_LOOKAHEAD=0, **kw)
     la = run(stub_lib, 100, 128, -1, out=tmp_path / "la.265", KS_TEST_LOOKAHEAD=8, **kw)
+    # no -lookahead given: with the SDK's default GOP the decision runs by itself (pictures on the GOP's grid of 4 only, no scene cuts) - the same slice types, the same stream;
+    # and, unlike -lookahead N, in GOP lanes
+    auto = run(stub_lib, 100, 128, -1, **kw)
+    assert auto["md5"] == la["md5"] and auto["pts"] == la["pts"]
+    lanes = {L: run(stub_lib, 150, 48, -1, KS265_GOP_LANES=L, **kw) for L in (1, 3)}
+    assert lanes[1]["lanes"] == 1 and lanes[3]["lanes"] == 3 and lanes[1]["md5"] == lanes[3]["md5"] and lanes[1]["md5"] != run(stub_lib, 150, 48, -1, KS_TEST_LOOKAHEAD=0, **kw)["md5"]
     assert plain["idr"] == la["idr"] == 1 and sorted(la["pts"]) == list(range(100)) and la["vcl"] == 100
     expect_plain, expect_la = [0], [0]
     for d in range(0, 96, 8):
