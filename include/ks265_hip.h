@@ -74,6 +74,7 @@ int ks265_memset_async(ks265_ctx *, void *dev, int value, size_t bytes);
 int ks265_event_create(ks265_ctx *, void **ev);
 int ks265_event_record(ks265_ctx *, void *ev);
 int ks265_event_wait(ks265_ctx *, void *ev);
+int ks265_event_query(ks265_ctx *, void *ev, int *done);          /* *done = 1 when everything in front of the event's last record has run; never blocks */
 /* everything enqueued on this context's stream after the call waits for the event (recorded on ANOTHER context's stream of the same device):
  * copy-in / compute / copy-out streams of a pipelined host hand pictures over without blocking a host thread */
 int ks265_stream_wait_event(ks265_ctx *, void *ev);

@@ -173,6 +173,15 @@ int ks265_event_create(ks265_ctx *c, void **ev)
 }
 int ks265_event_record(ks265_ctx *c, void *ev) { if (!c || !ev) return KS265_POINTER; ks_use_device(c); return ks265_hip(c, hipEventRecord((hipEvent_t)ev, c->stream)); }
 int ks265_event_wait(ks265_ctx *c, void *ev) { return (!c || !ev) ? KS265_POINTER : ks265_hip(c, hipEventSynchronize((hipEvent_t)ev)); }
+/* has everything in front of the event's last record run?  Never blocks: a host thread that has other work looks again later */
+int ks265_event_query(ks265_ctx *c, void *ev, int *done)
+{
+    if (!c || !ev || !done) return KS265_POINTER;
+    const hipError_t r = hipEventQuery((hipEvent_t)ev);
+    *done = r == hipSuccess;
+    if (r == hipErrorNotReady) { (void)hipGetLastError(); return KS265_OK; }
+    return ks265_hip(c, r);
+}
 /* make everything enqueued on c's stream AFTER this call wait for the event (recorded on another context's stream): the hand-over between the
  * copy-in, compute and copy-out streams of a pipelined host; no host thread blocks */
 int ks265_stream_wait_event(ks265_ctx *c, void *ev) { if (!c || !ev) return KS265_POINTER; ks_use_device(c); return ks265_hip(c, hipStreamWaitEvent(c->stream, (hipEvent_t)ev, 0)); }

@@ -268,7 +268,7 @@ static void copy_shared(CopyPool *p, uint8_t *d, const uint8_t *s, size_t n)
 }
 
 #define LA_RING 9                                                      /* half-size pictures kept for the analysis: the current one and eight back */
-typedef struct Input { int used, disp, key, base_qp, iper, mini4, kbps; long long pts; uint8_t *i420; } Input;     /* pinned; key: this picture starts a closed GOP whatever the period says (GOP lanes,
+typedef struct Input { int used, disp, key, base_qp, iper, mini4, kbps, la_what, la_p, la_buf; long long pts; uint8_t *i420; } Input;     /* pinned; key: this picture starts a closed GOP whatever the period says (GOP lanes,
                                                                                                  * QY265EncoderKeyFrameRequest); base_qp: the QP in force when the picture was handed in (QY265EncoderReconfig) -
                                                                                                  * iper: the key period in force then - all three travel WITH the picture: the scheduler thread
                                                                                                  * may be several pictures behind the caller */
@@ -312,7 +312,7 @@ typedef struct Enc {
      * two GOPs.  Its reconstruction goes to one of two DPB slots of its own; the first P picture of the GOP waits for ev_key. */
     int key_overlap, nkeys; ks265_ctx *ctx_key; ks265_frame *frame_key; ks265_pic src_key; uint64_t *dev_sse_key; void *ev_key, *ev_firstp[2];
     /* scheduling */
-    Input in[MAX_INPUT]; int nin, next_disp, in_disp;          /* next_disp: pictures handed to the scheduler; in_disp: pictures taken in (= next_disp, or with -lookahead one more: la_pend) */
+    Input in[MAX_INPUT]; int nin, next_disp, in_disp;          /* next_disp: pictures handed to the scheduler; in_disp: pictures taken in (= next_disp + the lookahead's queue la_q) */
     int gop_start;                                        /* display index of the last key picture */
     int coded_upto;                                       /* display index up to which everything is scheduled */
     int force_key;
@@ -326,9 +326,9 @@ typedef struct Enc {
     long long la_prev_icost;                                           /* -scenecut N: the previous picture's intra cost (-1: none yet) */
     unsigned long long la_c4_prev;                                     /* inter cost of the previous picture on the GOP's grid of 4 against the picture 4 back */
     int la_auto;                                                       /* no -lookahead given, hierarchical GOP: the slice-type decision alone (pictures on the GOP's grid of 4), no scene cuts - works in GOP lanes */
-    Input *la_pend; int la_pend_what;                                  /* the picture whose analysis is running (handed to the scheduler by la_finish); 1: against its predecessor, 2: the GOP's grid */
+    struct Input *la_q[8]; int la_qn, la_flying, la_seq; void *la_evs[4];   /* pictures handed in and not yet with the scheduler (display order); analyses in flight; their events / result areas, round robin */
     ks265_ctx *ctx_la; ks265_frame *frame_la; ks265_frame_geom geom_la; ks265_pic la_pic[LA_RING];
-    uint8_t *la_dev_luma; uint32_t *la_cost_ws; uint64_t *la_dev_out, *la_host_out; void *la_ev;
+    uint8_t *la_dev_luma; uint32_t *la_cost_ws; uint64_t *la_dev_out, *la_host_out;
     struct TopWake *wake;                                 /* lanes: the handle's caller sleeps here until a picture of ANY lane is finished */
     Job jobs[MAX_JOBS]; int ring, job_head, job_tail, njobs;   /* ring of `ring` pictures in coding order */
     /* workers */
@@ -1023,7 +1023,7 @@ static void lane_close(Enc *e, int report)
             ks265_synchronize(e->ctx_la);
             for (int i = 0; i < LA_RING; ++i) { ks265_dev_free(e->ctx_la, e->la_pic[i].y); ks265_dev_free(e->ctx_la, e->la_pic[i].u); ks265_dev_free(e->ctx_la, e->la_pic[i].v); }
             ks265_dev_free(e->ctx_la, e->la_dev_luma); ks265_dev_free(e->ctx_la, e->la_cost_ws); ks265_dev_free(e->ctx_la, e->la_dev_out); ks265_host_free(e->ctx_la, e->la_host_out);
-            if (e->la_ev) ks265_event_destroy(e->ctx_la, e->la_ev);
+            for (int i = 0; i < 4; ++i) if (e->la_evs[i]) ks265_event_destroy(e->ctx_la, e->la_evs[i]);
             if (e->frame_la) ks265_frame_destroy(e->frame_la);
             ks265_destroy(e->ctx_la);
         }
@@ -1127,9 +1127,9 @@ static Enc *lane_open(QY265EncConfig *cfg, int device, int multi, int *err)
             }
             if (!r) r = ks265_dev_malloc(e->ctx_la, (void **)&e->la_dev_luma, (size_t)e->W * e->H);
             if (!r) r = ks265_dev_malloc(e->ctx_la, (void **)&e->la_cost_ws, (size_t)e->geom_la.ctu_cols * e->geom_la.ctu_rows * 85 * sizeof(uint32_t));
-            if (!r) r = ks265_dev_malloc(e->ctx_la, (void **)&e->la_dev_out, 128);
-            if (!r) r = ks265_host_malloc(e->ctx_la, (void **)&e->la_host_out, 128);
-            if (!r) r = ks265_event_create(e->ctx_la, &e->la_ev);
+            if (!r) r = ks265_dev_malloc(e->ctx_la, (void **)&e->la_dev_out, 4 * 128);
+            if (!r) r = ks265_host_malloc(e->ctx_la, (void **)&e->la_host_out, 4 * 128);
+            for (int i = 0; i < 4 && !r; ++i) r = ks265_event_create(e->ctx_la, &e->la_evs[i]);
             if (!r) { e->la_on = 1; e->la_auto = la_auto; e->la_last_key = -1000000; e->la_prev_icost = -1; e->la_w = w; e->la_h = h; e->mg_adapt = e->hier; e->mg4_until = -1; }
         }
     }
@@ -1200,7 +1200,7 @@ static Enc *lane_open(QY265EncConfig *cfg, int device, int multi, int *err)
     /* input slots: the ring + a mini-GOP.  A GOP lane takes a whole GOP more: the caller hands the GOPs out in stream order, so a lane that could not hold its next GOP
      * while it is still coding the current one would make the caller wait - and the OTHER lanes, whose next GOPs come after, run dry (measured: lanes idle a third of
      * the time with ring + 32 slots) */
-    e->nin = e->ring + 32 + (multi ? (cfg->iIntraPeriod < 256 ? cfg->iIntraPeriod : 256) : 0);
+    e->nin = e->ring + 32 + (e->la_on ? 8 : 0) + (multi ? (cfg->iIntraPeriod < 256 ? cfg->iIntraPeriod : 256) : 0);
     if (getenv("KS265_INPUT_SLOTS")) e->nin = atoi(getenv("KS265_INPUT_SLOTS"));
     if (e->nin < e->ring + 32) e->nin = e->ring + 32;
     if (e->nin > MAX_INPUT) e->nin = MAX_INPUT;
@@ -1279,8 +1279,8 @@ static int lane_delayed(Enc *e)
     if (!e) return 0;
     int n = 0;
     pthread_mutex_lock(&e->mu);                                        /* one snapshot: a picture moves from "waiting" to "in flight" under this lock */
-    for (int i = 0; i < MAX_INPUT; ++i) if (e->in[i].used == 1 || e->la_pend == &e->in[i]) ++n;   /* (la_pend: its analysis is running, la_finish hands it on) */
-    n += e->njobs;
+    for (int i = 0; i < MAX_INPUT; ++i) if (e->in[i].used == 1) ++n;
+    n += e->njobs + e->la_qn;                                          /* (la_q: at the input, their analysis still running) */
     pthread_mutex_unlock(&e->mu);
     return n;
 }
@@ -1302,37 +1302,42 @@ static int lane_acquire(Enc *e, QY265YUV *yuv)
     return QY_OK;
 }
 
+/* ---- the lookahead at the input (-lookahead N, or by itself with the SDK's default GOP).  Round 4: nobody waits for it.  A picture's analysis is launched on a stream of its own
+ *      when the picture is handed in; the picture then sits in a short queue (la_q, display order) until its results have arrived - looked at, not waited for, whenever the caller
+ *      hands in another picture - and only then goes to the scheduler.  The queue holds at most LA_KEEP pictures: a result that is still missing then is waited for (the analysis
+ *      has had several picture times by then).  Same decisions as when the caller waited for every picture (round 3; the CPU tests did not change), a few pictures of delay at
+ *      the input.  All of it runs on the caller's thread. */
+#define LA_KEEP 5
+
 /* a picture whose analysis is through (or which needs none) goes to the scheduler */
 static void la_publish(Enc *e, Input *slot, int cut, int mini4)
 {
     const int nd = slot->disp;
     pthread_mutex_lock(&e->mu);
-    const int periodic = slot->iper > 0 && e->la_last_key > -1000000 && nd - e->la_last_key >= slot->iper;    /* (the scheduler's own rule: key positions are the same there) */
-    if (cut) ++e->la_cuts;
-    if (cut || slot->key || nd == 0 || periodic) e->la_last_key = nd;
+    if (!e->la_auto) {                                                 /* (auto: no scene cuts, the key positions are known when the picture is handed in - la_take keeps them) */
+        const int periodic = slot->iper > 0 && e->la_last_key > -1000000 && nd - e->la_last_key >= slot->iper;    /* (the scheduler's own rule: key positions are the same there) */
+        if (cut) ++e->la_cuts;
+        if (cut || slot->key || nd == 0 || periodic) e->la_last_key = nd;
+    }
     slot->mini4 = mini4; slot->key = slot->key || cut; slot->used = 1; e->next_disp = nd + 1;
     pthread_cond_signal(&e->cv_sched);
     pthread_mutex_unlock(&e->mu);
 }
 
-/* -lookahead N, second half: the results of the picture whose analysis la_launch left running - the scene-cut verdict and, with the hierarchical GOP, the slice types of its
- * block of 8 - then the picture is handed to the scheduler.  Called by the caller's thread only (the next lane_put, or the flush). */
-static int la_finish(Enc *e)
+/* the results of one analysed picture: the scene-cut verdict and, with the hierarchical GOP, the slice types of its block of 8 */
+static void la_decide(Enc *e, const Input *slot, int *cut_out, int *mini4_out)
 {
-    Input *slot = e->la_pend;
-    if (!slot) return QY_OK;
-    e->la_pend = NULL;
     const int nd = slot->disp, w = e->la_w, h = e->la_h;
+    const uint64_t *out = e->la_host_out + 16 * slot->la_buf;
     int cut = 0, mini4 = 0;
-    int r = ks265_event_wait(e->ctx_la, e->la_ev);
-    if (!r && (e->la_pend_what & 1)) {                                 /* scene cut: the picture against its predecessor */
+    if (slot->la_what & 1) {                                           /* scene cut: the picture against its predecessor */
         /* a cut: predicting the picture from its predecessor costs at least 0.7 of coding it intra (both sums over the 8x8 blocks of the half-size picture),
          * and the last key picture is at least eight pictures back */
         if (g_cli.scenecut > 0) {
             /* -scenecut N: the reference's verdict (scenecut enc@0x47e9d0, restated in oracle/ks265_lookahead_ref.c and pinned on recorded calls) on this lookahead's
              * frame costs: a change of flatness (intra cost below 4 per 8x8 block of the half-size picture) decides at once; else a cut is where predicting the
              * picture costs at least (1 - N / 100 x pictures since the key picture / min(key period, 320)) of coding it intra */
-            const long long icost = (long long)e->la_host_out[0], pcost = (long long)e->la_host_out[1], prev = e->la_prev_icost;
+            const long long icost = (long long)out[0], pcost = (long long)out[1], prev = e->la_prev_icost;
             const long long T = (long long)(w / 8) * (h / 8) * 4;
             int verdict = -1;
             if (prev >= 0) {
@@ -1346,56 +1351,89 @@ static int la_finish(Enc *e)
             }
             cut = verdict;
             e->la_prev_icost = icost;
-        } else if (e->la_host_out[1] * 10 >= e->la_host_out[0] * 7 && nd - e->la_last_key >= 8) cut = 1;
+        } else if (out[1] * 10 >= out[0] * 7 && nd - e->la_last_key >= 8) cut = 1;
     }
     /* slice types of the hierarchical GOP (the reference's adaptive BiPredFrames): the GOP is laid out in blocks of 8 pictures from its key picture; a block is
      * coded with its anchor 8 pictures after the previous one, or - when predicting that anchor from 8 pictures back costs more than the two anchors 4 apart cost
      * together (+ 1/12: the shorter structure pays more B-picture overhead) - as two mini-GOPs of 4.  Costs = the inter sums of the frame-cost kernels, this
      * picture against the pictures 4 and 8 back; decided at the block's last picture, carried to the scheduler in its input slot. */
-    if (!r && (e->la_pend_what & 2) && !cut) {                         /* (launched before the verdict was known: a cut starts a GOP here, the grid's sums are not used) */
-        const int p = nd - e->la_last_key;
-        const unsigned long long c4 = e->la_host_out[5];
+    if ((slot->la_what & 2) && !cut) {                                 /* (launched before the verdict was known: a cut starts a GOP here, the grid's sums are not used) */
+        const int p = slot->la_p;
+        const unsigned long long c4 = out[5];
         if ((p & 7) == 0) {
-            const unsigned long long c8 = e->la_host_out[9], two = c4 + e->la_c4_prev;
+            const unsigned long long c8 = out[9], two = c4 + e->la_c4_prev;
             mini4 = c8 * 12 > two * 13;
             if (mini4) ++e->la_mini4;
         }
         e->la_c4_prev = c4;
     }
-    if (r) { pthread_mutex_lock(&e->mu); slot->used = 0; e->sched_err = hip_rc(r); pthread_mutex_unlock(&e->mu); }
-    else la_publish(e, slot, cut, mini4);
-    return r ? hip_rc(r) : QY_OK;
+    *cut_out = cut; *mini4_out = mini4;
 }
 
-/* -lookahead N, first half: the half-size picture and the frame-cost kernels of this picture (against its predecessor; on the GOP's grid of 4 also against the pictures 4 and
- * 8 back), results on their way to the host - nobody waits here */
-static int la_launch(Enc *e, Input *slot)
+/* hand the queue's pictures to the scheduler, oldest first, as far as their results are there; while more than `keep` pictures are queued the oldest one's results are waited for */
+static int la_drain(Enc *e, int keep)
 {
+    while (e->la_qn > 0) {
+        Input *h = e->la_q[0];
+        int cut = 0, mini4 = 0;
+        if (h->la_what >= 0) {
+            int r, done = 1;
+            if (e->la_qn > keep) r = ks265_event_wait(e->ctx_la, e->la_evs[h->la_buf]);
+            else r = ks265_event_query(e->ctx_la, e->la_evs[h->la_buf], &done);
+            if (r) { pthread_mutex_lock(&e->mu); for (int i = 0; i < e->la_qn; ++i) e->la_q[i]->used = 0; e->la_qn = 0; e->sched_err = hip_rc(r); pthread_mutex_unlock(&e->mu); return hip_rc(r); }
+            if (!done) break;
+            la_decide(e, h, &cut, &mini4);
+            --e->la_flying;
+        }
+        la_publish(e, h, cut, mini4);
+        --e->la_qn;
+        memmove(e->la_q, e->la_q + 1, sizeof e->la_q[0] * (size_t)e->la_qn);
+    }
+    return QY_OK;
+}
+
+/* a picture handed in: its half-size picture and the frame-cost kernels it needs (against its predecessor: scene cut; on the GOP's grid of 4 against the pictures 4 and 8
+ * back: slice types), results on their way to the host; into the queue */
+static int la_take(Enc *e, Input *slot)
+{
+    int r;
+    /* -lookahead N: a scene-cut verdict moves the GOP's grid, so the next picture's launch needs every verdict before it; auto: nothing of the launch depends on results.
+     * At most four analyses in flight (their result areas) */
+    if ((r = la_drain(e, e->la_auto ? LA_KEEP : 0))) return r;
+    while (e->la_flying >= 4) if ((r = la_drain(e, e->la_qn - 1))) return r;
     const int nd = slot->disp, c = nd % LA_RING, w = e->la_w, h = e->la_h;
     const size_t org = (size_t)e->geom_la.pad_y * e->geom_la.stride_y + e->geom_la.pad_y;
     const int keynow = slot->key || nd == 0 || (slot->iper > 0 && e->la_last_key > -1000000 && nd - e->la_last_key >= slot->iper);   /* (but for a scene cut, not known yet) */
     const int p = keynow ? 0 : nd - e->la_last_key;                    /* position inside the GOP */
-    int what = 0;
-    if (e->la_auto && (p & 3)) { la_publish(e, slot, 0, 0); return QY_OK; }   /* not on the grid: nothing to analyse, nothing to keep */
-    int r = ks265_memcpy_h2d_async(e->ctx_la, e->la_dev_luma, slot->i420, (size_t)e->W * e->H);
-    if (!r) r = ks265_downsample_rect(e->ctx_la, e->la_dev_luma, e->W, e->la_pic[c].y + org, e->geom_la.stride_y, w, h);
-    if (!r) r = ks265_pad_picture(e->frame_la, e->la_pic[c]);
-    if (!r && e->la_have_prev && !e->la_auto) {
-        r = ks265_lookahead_picture(e->frame_la, e->la_pic[c], e->la_pic[(nd + LA_RING - 1) % LA_RING], e->la_cost_ws, e->la_dev_out);
-        what |= 1;
+    if (e->la_auto && keynow) e->la_last_key = nd;
+    int what = -1;
+    r = 0;
+    if (!e->la_auto || (p & 3) == 0) {                                 /* auto: pictures off the grid are neither analysed nor kept */
+        const int buf = e->la_seq++ & 3;
+        uint64_t *dout = e->la_dev_out + 16 * buf;
+        what = 0;
+        r = ks265_memcpy_h2d_async(e->ctx_la, e->la_dev_luma, slot->i420, (size_t)e->W * e->H);
+        if (!r) r = ks265_downsample_rect(e->ctx_la, e->la_dev_luma, e->W, e->la_pic[c].y + org, e->geom_la.stride_y, w, h);
+        if (!r) r = ks265_pad_picture(e->frame_la, e->la_pic[c]);
+        if (!r && e->la_have_prev && !e->la_auto) {
+            r = ks265_lookahead_picture(e->frame_la, e->la_pic[c], e->la_pic[(nd + LA_RING - 1) % LA_RING], e->la_cost_ws, dout);
+            what |= 1;
+        }
+        if (!r && e->mg_adapt && p >= 4 && (p & 3) == 0) {
+            /* (-lookahead N: the picture's intra costs are in la_cost_ws from the call above - search + sums only; auto: the intra pass runs here, once per grid picture) */
+            r = e->la_auto ? ks265_lookahead_picture(e->frame_la, e->la_pic[c], e->la_pic[(nd - 4) % LA_RING], e->la_cost_ws, dout + 4)
+                           : ks265_lookahead_inter(e->frame_la, e->la_pic[c], e->la_pic[(nd - 4) % LA_RING], e->la_cost_ws, dout + 4);
+            if (!r && (p & 7) == 0) r = ks265_lookahead_inter(e->frame_la, e->la_pic[c], e->la_pic[(nd - 8) % LA_RING], e->la_cost_ws, dout + 8);
+            what |= 2;
+        }
+        if (!r && what) r = ks265_memcpy_d2h_async(e->ctx_la, e->la_host_out + 16 * buf, dout, 96);
+        if (!r) r = ks265_event_record(e->ctx_la, e->la_evs[buf]);     /* (the slot's pinned picture is being read by the upload: the slot stays here until the event has passed) */
+        if (r) return hip_rc(r);
+        e->la_have_prev = 1; slot->la_buf = buf; ++e->la_flying;
     }
-    if (!r && e->mg_adapt && p >= 4 && (p & 3) == 0) {
-        /* (explicit -lookahead: the picture's intra costs are in la_cost_ws from the call above - search + sums only; auto: the intra pass runs here, once per grid picture) */
-        r = e->la_auto ? ks265_lookahead_picture(e->frame_la, e->la_pic[c], e->la_pic[(nd - 4) % LA_RING], e->la_cost_ws, e->la_dev_out + 4)
-                       : ks265_lookahead_inter(e->frame_la, e->la_pic[c], e->la_pic[(nd - 4) % LA_RING], e->la_cost_ws, e->la_dev_out + 4);
-        if (!r && (p & 7) == 0) r = ks265_lookahead_inter(e->frame_la, e->la_pic[c], e->la_pic[(nd - 8) % LA_RING], e->la_cost_ws, e->la_dev_out + 8);
-        what |= 2;
-    }
-    if (!r && what) r = ks265_memcpy_d2h_async(e->ctx_la, e->la_host_out, e->la_dev_out, 96);
-    if (!r) r = ks265_event_record(e->ctx_la, e->la_ev);               /* (also orders the next picture's upload into la_dev_luma behind this one's down-sampling: same stream) */
-    if (r) return hip_rc(r);
-    e->la_have_prev = 1; e->la_pend = slot; e->la_pend_what = what;
-    return QY_OK;
+    slot->la_what = what; slot->la_p = p;
+    e->la_q[e->la_qn++] = slot;
+    return la_drain(e, LA_KEEP);
 }
 
 /* one picture into the lane: copy to a pinned slot, hand it to the scheduler thread.  key: it starts a closed GOP regardless of the period */
@@ -1431,7 +1469,7 @@ static int lane_put(Enc *e, QY265Picture *in, int key)
             memcpy(v + (size_t)y * (e->W / 2), in->yuv->pData[2] + (size_t)y * in->yuv->iStride[2], (size_t)e->W / 2);
         }
     }
-    /* the picture's own fields travel with it from now; with the analysis it becomes visible to the scheduler one call later (la_finish) */
+    /* the picture's own fields travel with it from now; with the lookahead it becomes visible to the scheduler when its results are there (la_drain) */
     pthread_mutex_lock(&e->mu);
     slot->mini4 = 0;
     slot->disp = e->in_disp++; slot->pts = in->pts; slot->key = key || e->force_key; slot->base_qp = e->base_qp; slot->iper = e->iper; slot->kbps = e->cfg.bitrateInkbps;
@@ -1439,11 +1477,7 @@ static int lane_put(Enc *e, QY265Picture *in, int key)
     if (!e->la_on) { slot->used = 1; e->next_disp = e->in_disp; pthread_cond_signal(&e->cv_sched); }   /* the scheduler thread takes it from here */
     pthread_mutex_unlock(&e->mu);
     if (e->la_on) {
-        /* round 4: the analysis no longer stops the caller.  The previous picture's results - launched one call ago, on a stream of its own - are read now and that picture
-         * goes to the scheduler; then this picture's analysis is launched (its launch needs the GOP position, i.e. the previous picture's verdict) and left running.  Same
-         * decisions as when the caller waited for them (the CPU tests of the lookahead did not change), one picture of delay at the input */
-        int r = la_finish(e);
-        if (!r) r = la_launch(e, slot);
+        const int r = la_take(e, slot);
         if (r) { pthread_mutex_lock(&e->mu); slot->used = 0; e->sched_err = r; pthread_mutex_unlock(&e->mu); return r; }
     }
     e->st.in_copy_ms += now_ms() - tc0;
@@ -1455,7 +1489,7 @@ static int lane_put(Enc *e, QY265Picture *in, int key)
  * EncodeFrame(NULL) while DelayedFrames() > 0) */
 static int lane_flush_begin(Enc *e, int wait)
 {
-    if (e->la_on) (void)la_finish(e);                                  /* the last picture's analysis: an error is in sched_err */
+    if (e->la_on) (void)la_drain(e, 0);                                /* the pictures whose analysis is still running: waited for (an error is in sched_err) */
     pthread_mutex_lock(&e->mu);
     e->sched_flush = 1;
     pthread_cond_signal(&e->cv_sched);
@@ -1681,7 +1715,7 @@ static void top_close_chunk(Top *t, int early)
 {
     Chunk *c = &t->ch[(t->ch_head + t->ch_n - 1) % MAX_CHUNKS];
     c->closed = 1;
-    if (t->lane[c->lane]->la_on) (void)la_finish(t->lane[c->lane]);    /* the GOP's last picture does not wait for the lane's next one (an error is in sched_err) */
+    if (t->lane[c->lane]->la_on) (void)la_drain(t->lane[c->lane], 0);  /* the GOP's last pictures do not wait for the lane's next ones (an error is in sched_err) */
     if (early) {
         Enc *e = t->lane[c->lane];
         pthread_mutex_lock(&e->mu);

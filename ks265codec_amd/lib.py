@@ -50,7 +50,7 @@ EXPORTS = [
     "ks265_create", "ks265_create_prio", "ks265_destroy", "ks265_set_stream", "ks265_synchronize", "ks265_take_device_error", "ks265_last_error", "ks265_version",
     "ks265_timer_start", "ks265_timer_stop_ms", "ks265_marker", "ks265_debug_set",
     "ks265_dev_malloc", "ks265_dev_free", "ks265_host_malloc", "ks265_host_free", "ks265_memcpy_h2d_async", "ks265_memcpy_d2h_async", "ks265_memcpy_d2d_async", "ks265_copy_out_async", "ks265_memset_async",
-    "ks265_event_create", "ks265_event_record", "ks265_event_wait", "ks265_stream_wait_event", "ks265_event_destroy",
+    "ks265_event_create", "ks265_event_record", "ks265_event_wait", "ks265_event_query", "ks265_stream_wait_event", "ks265_event_destroy",
     "ks265_sad_batch", "ks265_sad4_batch", "ks265_sad3_batch", "ks265_sad4blk_8x8_batch", "ks265_sse_batch", "ks265_had_batch",
     "ks265_residual_batch", "ks265_fwd_transform_batch", "ks265_quant_batch", "ks265_sign_hiding_batch", "ks265_dequant_batch", "ks265_dequant_rect_batch", "ks265_inv_transform_batch",
     "ks265_edge_filter_luma_batch", "ks265_edge_filter_chroma_batch", "ks265_interp_rect",

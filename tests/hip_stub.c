@@ -51,8 +51,20 @@ int ks265_memcpy_h2d_async(ks265_ctx *c, void *d, const void *s, size_t n) { (vo
 int ks265_memcpy_d2h_async(ks265_ctx *c, void *d, const void *s, size_t n) { (void)c; memcpy(d, s, n); return KS265_OK; }
 int ks265_memset_async(ks265_ctx *c, void *d, int v, size_t n) { (void)c; memset(d, v, n); return KS265_OK; }
 int ks265_event_create(ks265_ctx *c, void **ev) { (void)c; *ev = malloc(4); return *ev ? KS265_OK : KS265_OUTOFMEMORY; }
-int ks265_event_record(ks265_ctx *c, void *ev) { (void)c; (void)ev; return KS265_OK; }
+int ks265_event_record(ks265_ctx *c, void *ev) { (void)c; *(int *)ev = 0; return KS265_OK; }
 int ks265_event_wait(ks265_ctx *c, void *ev) { (void)c; (void)ev; return KS265_OK; }
+/* KS265_STUB_EVENT_LAG = n: an event is reported done only at the n-th query after its record (the device stand-in runs everything at once: this is how the host's
+ * "not ready yet" paths get exercised) */
+int ks265_event_query(ks265_ctx *c, void *ev, int *done)
+{
+    (void)c;
+    static int lag = -1;
+    if (lag < 0) lag = getenv("KS265_STUB_EVENT_LAG") ? atoi(getenv("KS265_STUB_EVENT_LAG")) : 0;
+    int *n = (int *)ev;
+    *done = *n >= lag;
+    ++*n;
+    return KS265_OK;
+}
 int ks265_stream_wait_event(ks265_ctx *c, void *ev) { (void)c; (void)ev; return KS265_OK; }
 int ks265_event_destroy(ks265_ctx *c, void *ev) { (void)c; free(ev); return KS265_OK; }
 

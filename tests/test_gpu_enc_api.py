@@ -356,14 +356,14 @@ def test_slice_type_decision_on_the_gpu(tmp_path):
     yuv = tmp_path / "in.yuv"
     make_clip(W, H, n, seed=7, abc=(37, 53, 19), pan=(8, 5)).tofile(yuv)
     order = {}
-    for tag, extra in (("plain", []), ("la", ["-lookahead", "8"])):
+    for tag, extra in (("plain", ["-lookahead", "0"]), ("la", ["-lookahead", "8"]), ("auto", [])):      # round 4: without the option the decision runs by itself (grid pictures only)
         out, rec = tmp_path / f"{tag}.265", tmp_path / f"{tag}.yuv"
         r = subprocess.run([stream.CLI, "-i", str(yuv), "-wdt", str(W), "-hgt", str(H), "-fr", "50", "-rc", "0", "-preset", "slow", "-qp", "27", "-iper", "128",
                             "-threads", "8", "-psnr", "2", "-b", str(out), "-o", str(rec), *extra], capture_output=True, text=True)
         assert r.returncode == 0 and "H265 encoder passed!!!" in r.stdout, r.stdout[-500:] + r.stderr[-500:]
         order[tag] = [(int(a), b) for a, b in re.findall(r"^(\d+)\t([IPB])\t\d+\t", r.stdout, re.M)]
         assert sorted(a for a, _ in order[tag]) == list(range(n))
-        if tag == "la":
+        if tag != "plain":
             m = re.search(r"lookahead: (\d+) scene cuts, (\d+) blocks of 8 pictures coded as 4 \+ 4", r.stdout)
             assert m and int(m.group(1)) == 0 and int(m.group(2)) == 5, r.stdout[-600:]
         if os.path.exists(REF_DEC):
@@ -373,6 +373,7 @@ def test_slice_type_decision_on_the_gpu(tmp_path):
             assert (np.fromfile(rec, np.uint8) == np.fromfile(dec, np.uint8)).all()
     assert [a for a, k in order["plain"] if k == "P"] == [8, 16, 24, 32, 40]
     assert [a for a, k in order["la"] if k == "P"] == list(range(4, 41, 4)), order["la"][:20]
+    assert order["auto"] == order["la"] and (tmp_path / "auto.265").read_bytes() == (tmp_path / "la.265").read_bytes()
 
 
 def test_zero_copy_input_on_the_gpu():

@@ -314,6 +314,7 @@ def test_scene_cut_starts_a_closed_gop(stub_lib, bframes):
     plain = run(stub_lib, 60, 128, bframes, W=128, H=96, KS_TEST_CUTS="23,41")
     la = run(stub_lib, 60, 128, bframes, W=128, H=96, KS_TEST_CUTS="23,41", KS_TEST_LOOKAHEAD=8)
     assert plain["idr"] == 1 and la["idr"] == 3 and sorted(la["pts"]) == list(range(60)), (plain["idr"], la["idr"])
+    assert la["md5"] == run(stub_lib, 60, 128, bframes, W=128, H=96, KS_TEST_CUTS="23,41", KS_TEST_LOOKAHEAD=8, KS265_STUB_EVENT_LAG=3)["md5"]      # results that arrive late: same verdicts
     calm = run(stub_lib, 60, 128, bframes, W=128, H=96, KS_TEST_CUTS="1000", KS_TEST_LOOKAHEAD=8)                 # one scene: the analysis runs and finds nothing
     assert calm["idr"] == 1 and calm["md5"] == run(stub_lib, 60, 128, bframes, W=128, H=96, KS_TEST_CUTS="1000")["md5"]
     close = run(stub_lib, 60, 128, 0, W=128, H=96, KS_TEST_CUTS="20,23,26,40", KS_TEST_LOOKAHEAD=8)               # cuts closer than eight pictures to the last key picture are not key pictures
@@ -397,7 +398,12 @@ def test_slice_type_decision_codes_blocks_of_eight_as_four_plus_four(stub_lib, t
     # and, unlike -lookahead N, in GOP lanes
     auto = run(stub_lib, 100, 128, -1, **kw)
     assert auto["md5"] == la["md5"] and auto["pts"] == la["pts"]
+    # the caller never waits for an analysis as long as fewer than six pictures are queued at the input: results that arrive late (the stand-in reports an event done at its
+    # n-th query) change nothing but the moment a picture reaches the scheduler
+    for lag in (2, 7, 1000):
+        assert run(stub_lib, 100, 128, -1, KS265_STUB_EVENT_LAG=lag, **kw)["md5"] == la["md5"] == run(stub_lib, 100, 128, -1, KS_TEST_LOOKAHEAD=8, KS265_STUB_EVENT_LAG=lag, **kw)["md5"]
     lanes = {L: run(stub_lib, 150, 48, -1, KS265_GOP_LANES=L, **kw) for L in (1, 3)}
+    assert lanes[1]["md5"] == run(stub_lib, 150, 48, -1, KS265_GOP_LANES=2, KS265_STUB_EVENT_LAG=5, **kw)["md5"]
     assert lanes[1]["lanes"] == 1 and lanes[3]["lanes"] == 3 and lanes[1]["md5"] == lanes[3]["md5"] and lanes[1]["md5"] != run(stub_lib, 150, 48, -1, KS_TEST_LOOKAHEAD=0, **kw)["md5"]
     assert plain["idr"] == la["idr"] == 1 and sorted(la["pts"]) == list(range(100)) and la["vcl"] == 100
     expect_plain, expect_la = [0], [0]
