@@ -193,6 +193,9 @@ int ks265_intra_filter_ref_batch(ks265_ctx *, const uint8_t *dev_src, uint8_t *d
  * enc@0x47e9d0 stays host code - a lowres search is stage A of section 3 run on a half-size frame object).
  * g_downsampleFunc enc@0x707b10 -> downsample_c enc@0x4a6a60 (dst, src, dstStride, srcStride, w, h): 2:1 both ways, w x h = OUTPUT size */
 int ks265_downsample_rect(ks265_ctx *, const uint8_t *dev_src, int srcStride, uint8_t *dev_dst, int dstStride, int w, int h);
+/* the same with the source in pinned host memory (ks265_host_malloc; pointer and stride multiples of 8, dev_dst and dstStride multiples of 4): a kernel of 64 work-groups that
+ * reads the picture over PCIe - no copy-engine transfer that would queue behind a pipelined host's uploads, no machine-filling grid waiting for PCIe */
+int ks265_downsample_from_host(ks265_ctx *, const uint8_t *pinned_src, int srcStride, uint8_t *dev_dst, int dstStride, int w, int h);
 /* weightBi_sad_c enc@0x4a7170 (org, orgStride, ref0, ref1, stride0, stride1, w, h): SAD against the rounded average of two references;
  * descriptor: a_off = org offset, b_off[0] / b_off[1] = offsets in ref0 / ref1 (b_off[2] unused) */
 int ks265_weight_bi_sad_batch(ks265_ctx *, const uint8_t *dev_org, int orgStride, const uint8_t *dev_ref0, int stride0, const uint8_t *dev_ref1, int stride1,

@@ -377,6 +377,44 @@ __global__ __launch_bounds__(256) void downsample_kernel(const uint8_t *src, int
         }
     }
 }
+// the same from PINNED HOST memory (the encoder host's input picture), for the lookahead at the input: 64 work-groups walk the picture - a wave per output row, 8-byte loads, four in
+// flight per lane - so that the kernel is bound by PCIe reads without holding the machine's wave slots while it waits for them (the one-thread-per-4-samples grid above, 8 100
+// waves stalled on PCIe latency, filled every wave slot of the GPU for the duration: - 28 % encoder throughput, measured in round 4)
+__global__ __launch_bounds__(256) void downsample_host_kernel(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int h)
+{
+    const int lane = threadIdx.x & 63;
+    for (int y = blockIdx.x * 4 + (threadIdx.x >> 6); y < h; y += gridDim.x * 4) {
+        const uint8_t *p = src + (long)(2 * y) * ss;
+        for (int x0 = 0; x0 < w; x0 += 512) {                       // 512 output samples per wave iteration: lane = 4 + 4 of them
+            uint2 a[2], b[2];
+            bool on[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int x = x0 + k * 256 + lane * 4;
+                on[k] = x + 4 <= w;
+                if (on[k]) { a[k] = *(const uint2 *)(p + 2 * x); b[k] = *(const uint2 *)(p + ss + 2 * x); }
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int x = x0 + k * 256 + lane * 4;
+                if (on[k]) {
+                    const unsigned long long ra = a[k].x | ((unsigned long long)a[k].y << 32), rb = b[k].x | ((unsigned long long)b[k].y << 32);
+                    unsigned o = 0;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int u = (int)((((ra >> (16 * i)) & 255) + ((rb >> (16 * i)) & 255) + 1) >> 1), v = (int)((((ra >> (16 * i + 8)) & 255) + ((rb >> (16 * i + 8)) & 255) + 1) >> 1);
+                        o |= (unsigned)((u + v + 1) >> 1) << (8 * i);
+                    }
+                    *(unsigned *)(dst + (long)y * ds + x) = o;
+                } else
+                    for (int i = 0; x + i < w; ++i) {
+                        const int u = (p[2 * (x + i)] + p[2 * (x + i) + ss] + 1) >> 1, v = (p[2 * (x + i) + 1] + p[2 * (x + i) + 1 + ss] + 1) >> 1;
+                        dst[(long)y * ds + x + i] = (uint8_t)((u + v + 1) >> 1);
+                    }
+            }
+        }
+    }
+}
 // weightBi_sad_c enc@0x4a7170: one wave per block
 __global__ __launch_bounds__(256) void weight_bi_sad_batch_kernel(const uint8_t *org, int so, const uint8_t *r0, int s0, const uint8_t *r1, int s1,
                                                                   const ks265_blk3 *blks, int n, uint32_t *out)
@@ -661,6 +699,14 @@ int ks265_downsample_rect(ks265_ctx *ctx, const uint8_t *src, int srcStride, uin
 {
     CHECK_CTX(ctx); if (!src || !dst) return KS265_POINTER; if (w <= 0 || h <= 0) return KS265_OK;
     hipLaunchKernelGGL(downsample_kernel, dim3((w + 255) / 256, (h + 3) / 4), dim3(256), 0, ctx->stream, src, srcStride, dst, dstStride, w, h);
+    LAUNCH_END(ctx);
+}
+// src = pinned host memory (ks265_host_malloc), rows 8-byte aligned (srcStride and the pointer multiples of 8); dst = device memory, rows 4-byte aligned
+int ks265_downsample_from_host(ks265_ctx *ctx, const uint8_t *src, int srcStride, uint8_t *dst, int dstStride, int w, int h)
+{
+    CHECK_CTX(ctx); if (!src || !dst) return KS265_POINTER; if (w <= 0 || h <= 0) return KS265_OK;
+    if (((uintptr_t)src | (uintptr_t)srcStride) & 7 || ((uintptr_t)dst | (uintptr_t)dstStride) & 3) return KS265_NOTSUPPORTED;
+    hipLaunchKernelGGL(downsample_host_kernel, dim3(64), dim3(256), 0, ctx->stream, src, srcStride, dst, dstStride, w, h);
     LAUNCH_END(ctx);
 }
 int ks265_weight_bi_sad_batch(ks265_ctx *ctx, const uint8_t *org, int so, const uint8_t *ref0, int s0, const uint8_t *ref1, int s1, const ks265_blk3 *blks, int n,

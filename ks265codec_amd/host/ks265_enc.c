@@ -268,7 +268,8 @@ static void copy_shared(CopyPool *p, uint8_t *d, const uint8_t *s, size_t n)
 }
 
 #define LA_RING 9                                                      /* half-size pictures kept for the analysis: the current one and eight back */
-typedef struct Input { int used, disp, key, base_qp, iper, mini4, kbps, la_what, la_p, la_buf; long long pts; uint8_t *i420; } Input;     /* pinned; key: this picture starts a closed GOP whatever the period says (GOP lanes,
+typedef struct Input { int used, disp, key, base_qp, iper, mini4, kbps, la_what, la_p, la_buf; long long pts; uint8_t *i420; uint8_t *dev; void *ev_up; } Input;   /* dev / ev_up: the slot's twin on the device, uploaded
+                                                                                                 * when the picture is handed in (round 4), and the event behind that upload */     /* pinned; key: this picture starts a closed GOP whatever the period says (GOP lanes,
                                                                                                  * QY265EncoderKeyFrameRequest); base_qp: the QP in force when the picture was handed in (QY265EncoderReconfig) -
                                                                                                  * iper: the key period in force then - all three travel WITH the picture: the scheduler thread
                                                                                                  * may be several pictures behind the caller */
@@ -286,6 +287,8 @@ typedef struct Enc {
 #define NPIPE 3
     ks265_ctx *ctx_in, *ctx_out;
     uint8_t *dev_in[NPIPE]; void *ev_h2d[NPIPE], *ev_loaded[NPIPE];
+    void *spacer[64]; int nspacer;
+    ks265_ctx *ctx_up;                                    /* with the lookahead: = ctx_la, the stream the caller's thread feeds with uploads (the moment a picture is handed in) and with the analysis; else NULL */
     uint8_t *stg[NPIPE]; size_t cmp_off[8];               /* staging blocks of the (compact) records on the device and their layout */
     void *ev_staged[NPIPE], *ev_drained[NPIPE];
     /* split pipeline (default): the source picture of slot k is unpacked and padded on the copy-in stream into srcq[k], and the picture's drain (SSE, packing of the
@@ -326,9 +329,11 @@ typedef struct Enc {
     long long la_prev_icost;                                           /* -scenecut N: the previous picture's intra cost (-1: none yet) */
     unsigned long long la_c4_prev;                                     /* inter cost of the previous picture on the GOP's grid of 4 against the picture 4 back */
     int la_auto;                                                       /* no -lookahead given, hierarchical GOP: the slice-type decision alone (pictures on the GOP's grid of 4), no scene cuts - works in GOP lanes */
+    double la_t_bp, la_t_take, la_t_wait; long la_n_wait, la_n_poll;       /* where the caller's time goes (log level 1) */
+    pthread_mutex_t la_mu;                                             /* the queue below and the decisions' state: the caller's thread fills it, the caller's and the scheduler's threads empty it (lock order: la_mu, then mu) */
     struct Input *la_q[8]; int la_qn, la_flying, la_seq; void *la_evs[4];   /* pictures handed in and not yet with the scheduler (display order); analyses in flight; their events / result areas, round robin */
     ks265_ctx *ctx_la; ks265_frame *frame_la; ks265_frame_geom geom_la; ks265_pic la_pic[LA_RING];
-    uint8_t *la_dev_luma; uint32_t *la_cost_ws; uint64_t *la_dev_out, *la_host_out;
+    uint32_t *la_cost_ws; uint64_t *la_dev_out, *la_host_out;
     struct TopWake *wake;                                 /* lanes: the handle's caller sleeps here until a picture of ANY lane is finished */
     Job jobs[MAX_JOBS]; int ring, job_head, job_tail, njobs;   /* ring of `ring` pictures in coding order */
     /* workers */
@@ -365,6 +370,10 @@ static int hip_rc(int r) { return r == 0 ? QY_OK : r == KS265_OUTOFMEMORY ? QY_O
 
 static int pic_alloc(Enc *e, ks265_pic *p)
 {
+    /* KS265_PIC_SPACER = bytes: an unused allocation in front of every picture (where pictures lie against each other in device memory decides what shares a memory channel:
+     * round 4) */
+    const char *sp = getenv("KS265_PIC_SPACER");
+    if (sp && atol(sp) > 0 && e->nspacer < 64) { void *d = NULL; if (!ks265_dev_malloc(e->ctx, &d, (size_t)atol(sp))) e->spacer[e->nspacer++] = d; }
     int r = ks265_dev_malloc(e->ctx, (void **)&p->y, (size_t)e->geom.bytes_y);
     if (!r) r = ks265_dev_malloc(e->ctx, (void **)&p->u, (size_t)e->geom.bytes_c);
     if (!r) r = ks265_dev_malloc(e->ctx, (void **)&p->v, (size_t)e->geom.bytes_c);
@@ -618,15 +627,22 @@ static int submit(Enc *e, Input *in, int kind, int poc, int qp, const int *l0, i
     ks265_frame *fr = on_key ? e->frame_key : e->frame;
     ks265_pic srcp = on_key ? e->src_key : split ? e->srcq[k] : e->src;
     if (!r && split && recycled) r = ks265_stream_wait_event(e->ctx_in, e->ev_drained[k]);   /* srcq[k]'s last reader (the SSE of three pictures ago) is through */
-    if (!r) r = ks265_memcpy_h2d_async(e->ctx_in, e->dev_in[k], in->i420, fsz);
-    if (!r && split) r = ks265_load_i420_on(e->ctx_in, fr, e->dev_in[k], srcp);
+    /* with the lookahead the picture is on the device already, or on its way: uploaded into the slot's twin when it was handed in (round 4); else an H2D copy here, on this
+     * stream, behind the waits above.  Graph replay needs fixed addresses: a device-to-device copy into the rotation buffer */
+    const uint8_t *din = e->dev_in[k];
+    if (in->dev) {
+        if (!r) r = ks265_stream_wait_event(e->ctx_in, in->ev_up);
+        if (!r && e->use_graph) r = ks265_memcpy_d2d_async(e->ctx_in, e->dev_in[k], in->dev, fsz);
+        else din = in->dev;
+    } else if (!r) r = ks265_memcpy_h2d_async(e->ctx_in, e->dev_in[k], in->i420, fsz);
+    if (!r && split) r = ks265_load_i420_on(e->ctx_in, fr, din, srcp);
     if (!r) r = ks265_event_record(e->ctx_in, e->ev_h2d[k]);
     uint64_t *dsse = on_key ? e->dev_sse_key : e->dev_sse;
     if (!r) r = ks265_stream_wait_event(cx, e->ev_h2d[k]);
     /* graph path: a P picture with one reference on the main stream, once the first pictures have made every lazy allocation */
     const int graphable = e->use_graph && ((kind == 'P' && nl0 == 1) || (kind == 'B' && nl0 == 1 && nl1 == 1)) && !on_key && !e->recon_on && e->seq >= 8;
     if (!graphable && !split) {
-        if (!r) r = ks265_load_i420(fr, e->dev_in[k], srcp);
+        if (!r) r = ks265_load_i420(fr, din, srcp);
         if (!r) r = ks265_event_record(cx, e->ev_loaded[k]);
     }
     if (!r) r = ks265_frame_set_qp(fr, qp, kind == 'I' ? kLambdaQ4[qp] : kLambdaInterQ4[qp]);
@@ -879,12 +895,27 @@ static int schedule(Enc *e, int flush, int have /* pictures [0, have) have arriv
 
 /* ---- the scheduler thread: runs schedule() whenever pictures have arrived (or a flush was asked for).  The caller's thread only copies the input
  *      picture and collects output; this thread takes the GOP decisions and enqueues the GPU work of every picture. */
+static int la_drain(Enc *e, int keep);
 static void *scheduler(void *arg)
 {
     Enc *e = (Enc *)arg;
     pthread_mutex_lock(&e->mu);
     for (;;) {
-        while (!e->quit && e->sched_seen == e->next_disp && !e->sched_flush && e->gop_end_seen == e->gop_end) { e->sched_idle = 1; pthread_cond_broadcast(&e->cv_sched_done); pthread_cond_wait(&e->cv_sched, &e->mu); }
+        while (!e->quit && e->sched_seen == e->next_disp && !e->sched_flush && e->gop_end_seen == e->gop_end) {
+            e->sched_idle = 1; pthread_cond_broadcast(&e->cv_sched_done);
+            if (e->la_on && __atomic_load_n(&e->la_qn, __ATOMIC_ACQUIRE) > 0) {
+                /* pictures sit at the input until their lookahead results have arrived, and the caller only looks when it hands in the next picture - it may be asleep (its
+                 * back-pressure, the output ring): with nothing to schedule this thread looks as well */
+                struct timespec ts; clock_gettime(CLOCK_REALTIME, &ts);
+                ts.tv_nsec += 200000; if (ts.tv_nsec >= 1000000000) { ts.tv_nsec -= 1000000000; ++ts.tv_sec; }
+                pthread_cond_timedwait(&e->cv_sched, &e->mu, &ts);
+                if (e->quit || e->sched_seen != e->next_disp || e->sched_flush) continue;
+                pthread_mutex_unlock(&e->mu);
+                (void)la_drain(e, 8);                                   /* (never waits: 8 = the queue's size) */
+                pthread_mutex_lock(&e->mu);
+                if (e->sched_seen != e->next_disp) ++e->la_n_poll;
+            } else pthread_cond_wait(&e->cv_sched, &e->mu);
+        }
         if (e->quit) break;
         e->sched_idle = 0;
         const int flush = e->sched_flush, have = e->next_disp, gop_end = e->gop_end;
@@ -984,6 +1015,9 @@ static void lane_close(Enc *e, int report)
         ks265_synchronize(e->ctx);
         if (e->ctx_out) ks265_synchronize(e->ctx_out);
         if (report && e->la_on) logf_(1, e->log_level, "ks265enc: lookahead: %ld scene cuts, %ld blocks of 8 pictures coded as 4 + 4\n", e->la_cuts, e->la_mini4);
+        if (report && e->la_on && e->in_disp) logf_(1, e->log_level, "ks265enc: lookahead, caller's ms per picture: launches + queue %.3f, of it waiting for results %.3f (%ld waits); pictures handed on by the scheduler thread: %ld\n",
+                                                    e->la_t_take / e->in_disp, e->la_t_wait / e->in_disp, e->la_n_wait, e->la_n_poll);
+        if (report && e->in_disp) logf_(1, e->log_level, "ks265enc: caller's back-pressure wait %.3f ms per picture\n", e->la_t_bp / e->in_disp);
         if (report && e->cfg.calcPsnr && e->st.frames) {
             const double np[3] = {(double)e->W * e->H, (double)e->W * e->H / 4, (double)e->W * e->H / 4};
             double ps[3];
@@ -996,8 +1030,9 @@ static void lane_close(Enc *e, int report)
             if (j->ev) ks265_event_destroy(e->ctx, j->ev);
             free(j->nal);
         }
-        for (int i = 0; i < MAX_INPUT; ++i) ks265_host_free(e->ctx, e->in[i].i420);
+        for (int i = 0; i < MAX_INPUT; ++i) { ks265_host_free(e->ctx, e->in[i].i420); if (e->in[i].dev) ks265_dev_free(e->ctx, e->in[i].dev); if (e->in[i].ev_up) ks265_event_destroy(e->ctx_up, e->in[i].ev_up); }
         for (int i = 0; i < e->ndpb + 2; ++i) pic_free(e, &e->dpb[i]);
+        for (int i = 0; i < e->nspacer; ++i) ks265_dev_free(e->ctx, e->spacer[i]);
         pic_free(e, &e->src_key); ks265_dev_free(e->ctx, e->dev_sse_key);
         if (e->ev_key) ks265_event_destroy(e->ctx, e->ev_key);
         for (int i = 0; i < 2; ++i) if (e->ev_firstp[i]) ks265_event_destroy(e->ctx, e->ev_firstp[i]);
@@ -1022,7 +1057,7 @@ static void lane_close(Enc *e, int report)
         if (e->ctx_la) {
             ks265_synchronize(e->ctx_la);
             for (int i = 0; i < LA_RING; ++i) { ks265_dev_free(e->ctx_la, e->la_pic[i].y); ks265_dev_free(e->ctx_la, e->la_pic[i].u); ks265_dev_free(e->ctx_la, e->la_pic[i].v); }
-            ks265_dev_free(e->ctx_la, e->la_dev_luma); ks265_dev_free(e->ctx_la, e->la_cost_ws); ks265_dev_free(e->ctx_la, e->la_dev_out); ks265_host_free(e->ctx_la, e->la_host_out);
+            ks265_dev_free(e->ctx_la, e->la_cost_ws); ks265_dev_free(e->ctx_la, e->la_dev_out); ks265_host_free(e->ctx_la, e->la_host_out);
             for (int i = 0; i < 4; ++i) if (e->la_evs[i]) ks265_event_destroy(e->ctx_la, e->la_evs[i]);
             if (e->frame_la) ks265_frame_destroy(e->frame_la);
             ks265_destroy(e->ctx_la);
@@ -1035,6 +1070,7 @@ static void lane_close(Enc *e, int report)
     }
     for (int i = 0; i < MAX_JOBS; ++i) free(e->jobs[i].wpp);
     free(e->hdr); free(e->outbuf); free(e->md5_ring); free(e->md5_have);
+    pthread_mutex_destroy(&e->la_mu);
     pthread_mutex_destroy(&e->mu); pthread_cond_destroy(&e->cv_work); pthread_cond_destroy(&e->cv_done); pthread_cond_destroy(&e->cv_disp); pthread_cond_destroy(&e->cv_sched); pthread_cond_destroy(&e->cv_sched_done);
     free(e);
 }
@@ -1048,6 +1084,7 @@ static Enc *lane_open(QY265EncConfig *cfg, int device, int multi, int *err)
     Enc *e = (Enc *)calloc(1, sizeof *e);
     if (e) e->recon_fd = -1;
     if (!e) { *err = QY_OUTOFMEMORY; return NULL; }
+    pthread_mutex_init(&e->la_mu, NULL);
     pthread_mutex_init(&e->mu, NULL); pthread_cond_init(&e->cv_work, NULL); pthread_cond_init(&e->cv_done, NULL); pthread_cond_init(&e->cv_disp, NULL); pthread_cond_init(&e->cv_sched, NULL); pthread_cond_init(&e->cv_sched_done, NULL);
     e->cfg = *cfg; e->W = cfg->picWidth; e->H = cfg->picHeight; e->log_level = cfg->logLevel;
     e->me_method = cfg->me < 0 ? 1 : cfg->me > 2 ? 2 : cfg->me;        /* EPZS / Cross (-me 3 / 4) are not built: UMH instead */
@@ -1077,6 +1114,14 @@ static Enc *lane_open(QY265EncConfig *cfg, int device, int multi, int *err)
 
     /* the SDK's config has no device field: the lane's GPU comes from the handle (KS265_DEVICE: one GPU, default 0; KS265_GPUS / KS265_DEVICES: closed GOPs dealt
      * to lanes on several GPUs, QY265EncoderOpen) */
+    /* The ORDER in which the streams are created matters (round 4, measured at 2160p): the runtime deals streams to four hardware queues in turn, so the FIFTH stream
+     * shares the queue of the FIRST, and streams in one queue run in the order they were fed.  With four streams (pixel path, copy-in, copy-out, key pictures) nothing is shared.
+     * With the lookahead there are five: created fourth - in front of the key pictures' stream - it pushed that stream into the pixel path's queue, and the key picture's 19 ms
+     * wavefront kernel stopped the P / B pictures for as long: - 25 % (hierarchical B), - 31 % (IPPP), with not one lookahead kernel launched; created last it shares the pixel
+     * path's queue itself: - 8 %; created FIRST, the key pictures' stream shares ITS queue: - 3 %.  (GPU_MAX_HW_QUEUES=8 changed none of this on the ROCm 7.2 runtime here.) */
+    const int la_wanted = e->cfg.lookahead > 0 || (e->cfg.lookahead < 0 && e->hier && !getenv("KS265_NO_AUTO_LOOKAHEAD"));
+    const int la_order = getenv("KS265_LA_ORDER") ? atoi(getenv("KS265_LA_ORDER")) : 0;      /* (experiments: 1 = fourth, 2 = last) */
+    if (la_wanted && la_order == 0 && ks265_create(&e->ctx_la, device)) e->ctx_la = NULL;
     int r = ks265_create(&e->ctx, device);
     if (r) { *err = hip_rc(r); lane_close(e, 0); return NULL; }       /* KS265_NO_DEVICE -> QY_FAIL: there is no CPU fallback */
     memset(&e->fcfg, 0, sizeof e->fcfg);
@@ -1105,34 +1150,7 @@ static Enc *lane_open(QY265EncConfig *cfg, int device, int multi, int *err)
     if (!r) r = ks265_frame_compact_layout(e->frame, e->cmp_off);
     if (!r) r = ks265_create(&e->ctx_in, dev_id);
     if (!r) r = ks265_create(&e->ctx_out, dev_id);
-    /* no -lookahead on the command line and the SDK's default GOP (hierarchical B, 8): the slice-type decision runs by itself (round 4: it costs a search of the half-size
-     * picture every fourth picture, and the caller does not wait for it) - the reference's adaptive BiPredFrames is on by default as well.  -lookahead 0 switches it off. */
-    const int la_auto = cfg->lookahead < 0 && e->hier && !getenv("KS265_NO_AUTO_LOOKAHEAD");
-    if (!r && (cfg->lookahead > 0 || la_auto)) {
-        const int w = (e->W / 2) & ~7, h = (e->H / 2) & ~7;            /* the analysis sees the picture without its last columns / rows when half the size is no multiple of 8 */
-        if (w < 16 || h < 16) { if (!la_auto) logf_(1, e->log_level, "ks265enc: -lookahead %d: the analysis needs a picture of at least 32 x 32: off\n", cfg->lookahead); }
-        else {
-            ks265_frame_cfg lc; memset(&lc, 0, sizeof lc);
-            lc.width = w; lc.height = h; lc.qp = e->base_qp > 0 ? e->base_qp : 27; lc.lambda_q4 = kLambdaQ4[lc.qp < 52 ? lc.qp : 51]; lc.me_range = 32; lc.me_method = 1; lc.subme = 0;
-            lc.bframes = 0; lc.refs = 1;
-            r = ks265_create(&e->ctx_la, dev_id);
-            if (!r) r = ks265_frame_geometry(&lc, &e->geom_la);
-            if (!r) r = ks265_frame_create(e->ctx_la, &lc, &e->frame_la);
-            for (int i = 0; i < LA_RING && !r; ++i) {
-                r = ks265_dev_malloc(e->ctx_la, (void **)&e->la_pic[i].y, (size_t)e->geom_la.bytes_y);
-                if (!r) r = ks265_dev_malloc(e->ctx_la, (void **)&e->la_pic[i].u, (size_t)e->geom_la.bytes_c);
-                if (!r) r = ks265_dev_malloc(e->ctx_la, (void **)&e->la_pic[i].v, (size_t)e->geom_la.bytes_c);
-                if (!r) r = ks265_memset_async(e->ctx_la, e->la_pic[i].u, 128, (size_t)e->geom_la.bytes_c);     /* the analysis is luma only */
-                if (!r) r = ks265_memset_async(e->ctx_la, e->la_pic[i].v, 128, (size_t)e->geom_la.bytes_c);
-            }
-            if (!r) r = ks265_dev_malloc(e->ctx_la, (void **)&e->la_dev_luma, (size_t)e->W * e->H);
-            if (!r) r = ks265_dev_malloc(e->ctx_la, (void **)&e->la_cost_ws, (size_t)e->geom_la.ctu_cols * e->geom_la.ctu_rows * 85 * sizeof(uint32_t));
-            if (!r) r = ks265_dev_malloc(e->ctx_la, (void **)&e->la_dev_out, 4 * 128);
-            if (!r) r = ks265_host_malloc(e->ctx_la, (void **)&e->la_host_out, 4 * 128);
-            for (int i = 0; i < 4 && !r; ++i) r = ks265_event_create(e->ctx_la, &e->la_evs[i]);
-            if (!r) { e->la_on = 1; e->la_auto = la_auto; e->la_last_key = -1000000; e->la_prev_icost = -1; e->la_w = w; e->la_h = h; e->mg_adapt = e->hier; e->mg4_until = -1; }
-        }
-    }
+    if (!r && la_wanted && la_order == 1) r = ks265_create(&e->ctx_la, dev_id);
     e->split = getenv("KS265_NO_SPLIT") ? 0 : 1;
     e->copy_mb = getenv("KS265_COPYOUT_MB") ? atoi(getenv("KS265_COPYOUT_MB")) : -1;
     for (int k = 0; k < NPIPE && !r; ++k) {
@@ -1176,6 +1194,34 @@ static Enc *lane_open(QY265EncConfig *cfg, int device, int multi, int *err)
     }
     /* ring of pictures in flight: a key picture's slice takes one writer thread many picture periods, and output is in coding order - the ring must
      * hold everything that is coded meanwhile, or the GPU idles behind it.  About 6 GB of records (pinned compact block + expanded level planes + pinned input), at least 24 and at most MAX_JOBS pictures. */
+    /* (the lookahead's objects; its stream was created first - see the top of this function) */
+    /* no -lookahead on the command line and the SDK's default GOP (hierarchical B, 8): the slice-type decision runs by itself (round 4: it costs a search of the half-size
+     * picture every fourth picture, and the caller does not wait for it) - the reference's adaptive BiPredFrames is on by default as well.  -lookahead 0 switches it off. */
+    const int la_auto = cfg->lookahead < 0 && e->hier && !getenv("KS265_NO_AUTO_LOOKAHEAD");
+    if (!r && (cfg->lookahead > 0 || la_auto)) {
+        const int w = (e->W / 2) & ~7, h = (e->H / 2) & ~7;            /* the analysis sees the picture without its last columns / rows when half the size is no multiple of 8 */
+        if (w < 16 || h < 16) { if (!la_auto) logf_(1, e->log_level, "ks265enc: -lookahead %d: the analysis needs a picture of at least 32 x 32: off\n", cfg->lookahead); }
+        else {
+            ks265_frame_cfg lc; memset(&lc, 0, sizeof lc);
+            lc.width = w; lc.height = h; lc.qp = e->base_qp > 0 ? e->base_qp : 27; lc.lambda_q4 = kLambdaQ4[lc.qp < 52 ? lc.qp : 51]; lc.me_range = 32; lc.me_method = 1; lc.subme = 0;
+            lc.bframes = 0; lc.refs = 1;
+            r = e->ctx_la ? 0 : getenv("KS265_LA_PRIO") ? ks265_create_prio(&e->ctx_la, dev_id, atoi(getenv("KS265_LA_PRIO"))) : ks265_create(&e->ctx_la, dev_id);
+            if (!r) r = ks265_frame_geometry(&lc, &e->geom_la);
+            if (!r) r = ks265_frame_create(e->ctx_la, &lc, &e->frame_la);
+            for (int i = 0; i < LA_RING && !r; ++i) {
+                r = ks265_dev_malloc(e->ctx_la, (void **)&e->la_pic[i].y, (size_t)e->geom_la.bytes_y);
+                if (!r) r = ks265_dev_malloc(e->ctx_la, (void **)&e->la_pic[i].u, (size_t)e->geom_la.bytes_c);
+                if (!r) r = ks265_dev_malloc(e->ctx_la, (void **)&e->la_pic[i].v, (size_t)e->geom_la.bytes_c);
+                if (!r) r = ks265_memset_async(e->ctx_la, e->la_pic[i].u, 128, (size_t)e->geom_la.bytes_c);     /* the analysis is luma only */
+                if (!r) r = ks265_memset_async(e->ctx_la, e->la_pic[i].v, 128, (size_t)e->geom_la.bytes_c);
+            }
+            if (!r) r = ks265_dev_malloc(e->ctx_la, (void **)&e->la_cost_ws, (size_t)e->geom_la.ctu_cols * e->geom_la.ctu_rows * 85 * sizeof(uint32_t));
+            if (!r) r = ks265_dev_malloc(e->ctx_la, (void **)&e->la_dev_out, 4 * 128);
+            if (!r) r = ks265_host_malloc(e->ctx_la, (void **)&e->la_host_out, 4 * 128);
+            for (int i = 0; i < 4 && !r; ++i) r = ks265_event_create(e->ctx_la, &e->la_evs[i]);
+            if (!r) { e->la_on = 1; e->la_auto = la_auto; e->la_last_key = -1000000; e->la_prev_icost = -1; e->la_w = w; e->la_h = h; e->mg_adapt = e->hier; e->mg4_until = -1; }
+        }
+    }
     e->ring = (int)(((size_t)6 << 30) / (e->cmp_off[7] + npx * 3 + fsz));
     if (e->ring > MAX_JOBS) e->ring = MAX_JOBS;
     if (e->ring < 24) e->ring = 24;
@@ -1218,6 +1264,14 @@ static Enc *lane_open(QY265EncConfig *cfg, int device, int multi, int *err)
         }
     }
     for (int i = 0; i < e->nin && !r; ++i) r = ks265_host_malloc(e->ctx, (void **)&e->in[i].i420, fsz);
+    /* with the lookahead every input slot has a twin on the device, uploaded on the lookahead's stream the moment the picture is handed in (nothing on that stream ever waits for
+     * the pipeline: an upload enqueued on the copy-in stream, or anywhere on the copy engine behind that stream's uploads, sits behind the pipeline's back-pressure and the
+     * analysis would see the picture 10 ms and more late); without it the picture is uploaded when it is scheduled, on the copy-in stream, as before.  One stream for both,
+     * not a sixth: a stream more is a hardware queue shared with somebody (top of this function) */
+    if (e->la_on && e->ctx_la) {
+        e->ctx_up = e->ctx_la;
+        for (int i = 0; i < e->nin && !r; ++i) { r = ks265_dev_malloc(e->ctx, (void **)&e->in[i].dev, fsz); if (!r) r = ks265_event_create(e->ctx_up, &e->in[i].ev_up); }
+    }
     if (r) { *err = hip_rc(r); lane_close(e, 0); return NULL; }
     memset(&e->scfg, 0, sizeof e->scfg);
     e->scfg.width = e->W; e->scfg.height = e->H; e->scfg.sao = e->use_sao; e->scfg.deblock = e->use_df;
@@ -1307,7 +1361,8 @@ static int lane_acquire(Enc *e, QY265YUV *yuv)
  *      hands in another picture - and only then goes to the scheduler.  The queue holds at most LA_KEEP pictures: a result that is still missing then is waited for (the analysis
  *      has had several picture times by then).  Same decisions as when the caller waited for every picture (round 3; the CPU tests did not change), a few pictures of delay at
  *      the input.  All of it runs on the caller's thread. */
-#define LA_KEEP 5
+#define LA_KEEP la_keep()
+static int la_keep(void) { static int v = 0; if (!v) { const char *s = getenv("KS265_LA_KEEP"); v = s && atoi(s) > 0 && atoi(s) < 8 ? atoi(s) : 5; } return v; }
 
 /* a picture whose analysis is through (or which needs none) goes to the scheduler */
 static void la_publish(Enc *e, Input *slot, int cut, int mini4)
@@ -1371,14 +1426,14 @@ static void la_decide(Enc *e, const Input *slot, int *cut_out, int *mini4_out)
 }
 
 /* hand the queue's pictures to the scheduler, oldest first, as far as their results are there; while more than `keep` pictures are queued the oldest one's results are waited for */
-static int la_drain(Enc *e, int keep)
+static int la_drain_locked(Enc *e, int keep)
 {
     while (e->la_qn > 0) {
         Input *h = e->la_q[0];
         int cut = 0, mini4 = 0;
         if (h->la_what >= 0) {
             int r, done = 1;
-            if (e->la_qn > keep) r = ks265_event_wait(e->ctx_la, e->la_evs[h->la_buf]);
+            if (e->la_qn > keep) { const double t0 = now_ms(); r = ks265_event_wait(e->ctx_la, e->la_evs[h->la_buf]); e->la_t_wait += now_ms() - t0; ++e->la_n_wait; }
             else r = ks265_event_query(e->ctx_la, e->la_evs[h->la_buf], &done);
             if (r) { pthread_mutex_lock(&e->mu); for (int i = 0; i < e->la_qn; ++i) e->la_q[i]->used = 0; e->la_qn = 0; e->sched_err = hip_rc(r); pthread_mutex_unlock(&e->mu); return hip_rc(r); }
             if (!done) break;
@@ -1386,21 +1441,28 @@ static int la_drain(Enc *e, int keep)
             --e->la_flying;
         }
         la_publish(e, h, cut, mini4);
-        --e->la_qn;
-        memmove(e->la_q, e->la_q + 1, sizeof e->la_q[0] * (size_t)e->la_qn);
+        memmove(e->la_q, e->la_q + 1, sizeof e->la_q[0] * (size_t)(e->la_qn - 1));
+        __atomic_store_n(&e->la_qn, e->la_qn - 1, __ATOMIC_RELEASE);
     }
     return QY_OK;
+}
+static int la_drain(Enc *e, int keep)
+{
+    pthread_mutex_lock(&e->la_mu);
+    const int r = la_drain_locked(e, keep);
+    pthread_mutex_unlock(&e->la_mu);
+    return r;
 }
 
 /* a picture handed in: its half-size picture and the frame-cost kernels it needs (against its predecessor: scene cut; on the GOP's grid of 4 against the pictures 4 and 8
  * back: slice types), results on their way to the host; into the queue */
-static int la_take(Enc *e, Input *slot)
+static int la_take_locked(Enc *e, Input *slot)
 {
     int r;
     /* -lookahead N: a scene-cut verdict moves the GOP's grid, so the next picture's launch needs every verdict before it; auto: nothing of the launch depends on results.
      * At most four analyses in flight (their result areas) */
-    if ((r = la_drain(e, e->la_auto ? LA_KEEP : 0))) return r;
-    while (e->la_flying >= 4) if ((r = la_drain(e, e->la_qn - 1))) return r;
+    if ((r = la_drain_locked(e, e->la_auto ? LA_KEEP : 0))) return r;
+    while (e->la_flying >= 4) if ((r = la_drain_locked(e, e->la_qn - 1))) return r;
     const int nd = slot->disp, c = nd % LA_RING, w = e->la_w, h = e->la_h;
     const size_t org = (size_t)e->geom_la.pad_y * e->geom_la.stride_y + e->geom_la.pad_y;
     const int keynow = slot->key || nd == 0 || (slot->iper > 0 && e->la_last_key > -1000000 && nd - e->la_last_key >= slot->iper);   /* (but for a scene cut, not known yet) */
@@ -1412,8 +1474,10 @@ static int la_take(Enc *e, Input *slot)
         const int buf = e->la_seq++ & 3;
         uint64_t *dout = e->la_dev_out + 16 * buf;
         what = 0;
-        r = ks265_memcpy_h2d_async(e->ctx_la, e->la_dev_luma, slot->i420, (size_t)e->W * e->H);
-        if (!r) r = ks265_downsample_rect(e->ctx_la, e->la_dev_luma, e->W, e->la_pic[c].y + org, e->geom_la.stride_y, w, h);
+        /* the half-size picture from the slot's twin on the device (uploaded a moment ago on this stream).  Measured in round 4 before that existed: an H2D copy of the
+         * luma plane on this stream (round 3) queues on the copy engine BEHIND the uploads the scheduler had enqueued, which waited for the pipeline's buffers - the results
+         * arrived 10 ms and more late; kernels reading the pinned picture over PCIe instead (ks265_downsample_from_host, 64 work-groups) cost the encoder 28 % */
+        r = ks265_downsample_rect(e->ctx_la, slot->dev, e->W, e->la_pic[c].y + org, e->geom_la.stride_y, w, h);
         if (!r) r = ks265_pad_picture(e->frame_la, e->la_pic[c]);
         if (!r && e->la_have_prev && !e->la_auto) {
             r = ks265_lookahead_picture(e->frame_la, e->la_pic[c], e->la_pic[(nd + LA_RING - 1) % LA_RING], e->la_cost_ws, dout);
@@ -1432,8 +1496,16 @@ static int la_take(Enc *e, Input *slot)
         e->la_have_prev = 1; slot->la_buf = buf; ++e->la_flying;
     }
     slot->la_what = what; slot->la_p = p;
-    e->la_q[e->la_qn++] = slot;
-    return la_drain(e, LA_KEEP);
+    e->la_q[e->la_qn] = slot;
+    __atomic_store_n(&e->la_qn, e->la_qn + 1, __ATOMIC_RELEASE);
+    return la_drain_locked(e, LA_KEEP);
+}
+static int la_take(Enc *e, Input *slot)
+{
+    pthread_mutex_lock(&e->la_mu);
+    const int r = la_take_locked(e, slot);
+    pthread_mutex_unlock(&e->la_mu);
+    return r;
 }
 
 /* one picture into the lane: copy to a pinned slot, hand it to the scheduler thread.  key: it starts a closed GOP regardless of the period */
@@ -1447,7 +1519,8 @@ static int lane_put(Enc *e, QY265Picture *in, int key)
     /* back-pressure on the input side: at most 16 pictures wait for the scheduler thread (it may itself be waiting for ring space, which only the
      * caller's take_output frees - then go on and collect).  GOP lanes (multi): the input slots are the limit (lane_has_slot) - a lane takes a whole GOP in
      * while it is still coding the previous one, or the caller would wait here while the other lanes run dry */
-    while (!e->multi && !e->quit && !e->sched_err && e->next_disp - (e->coded_upto + 1) > 16 && e->njobs <= e->ring - 12) pthread_cond_wait(&e->cv_sched_done, &e->mu);   /* a scheduler that failed makes no more progress */
+    while (!e->multi && !e->quit && !e->sched_err && e->next_disp - (e->coded_upto + 1) > 16 && e->njobs <= e->ring - 12) pthread_cond_wait(&e->cv_sched_done, &e->mu);
+    e->la_t_bp += now_ms() - tc0;   /* a scheduler that failed makes no more progress */
     int own = 0;                                                       /* the caller wrote the picture into a slot it had acquired (ks265_enc_acquire_input): nothing to copy */
     for (int i = 0; i < e->nin && !slot; ++i) if (e->in[i].used == 4 && e->in[i].i420 == in->yuv->pData[0]) { slot = &e->in[i]; own = 1; }
     for (int i = 0; i < e->nin && !slot; ++i) if (!e->in[i].used) slot = &e->in[i];
@@ -1469,6 +1542,11 @@ static int lane_put(Enc *e, QY265Picture *in, int key)
             memcpy(v + (size_t)y * (e->W / 2), in->yuv->pData[2] + (size_t)y * in->yuv->iStride[2], (size_t)e->W / 2);
         }
     }
+    if (slot->dev) {   /* on its way to the device at once, on the lookahead's stream (nothing there waits for the pipeline) */
+        int ru = ks265_memcpy_h2d_async(e->ctx_up, slot->dev, slot->i420, (size_t)e->W * e->H * 3 / 2);
+        if (!ru) ru = ks265_event_record(e->ctx_up, slot->ev_up);
+        if (ru) { pthread_mutex_lock(&e->mu); slot->used = 0; e->sched_err = hip_rc(ru); pthread_mutex_unlock(&e->mu); return hip_rc(ru); }
+    }
     /* the picture's own fields travel with it from now; with the lookahead it becomes visible to the scheduler when its results are there (la_drain) */
     pthread_mutex_lock(&e->mu);
     slot->mini4 = 0;
@@ -1477,7 +1555,9 @@ static int lane_put(Enc *e, QY265Picture *in, int key)
     if (!e->la_on) { slot->used = 1; e->next_disp = e->in_disp; pthread_cond_signal(&e->cv_sched); }   /* the scheduler thread takes it from here */
     pthread_mutex_unlock(&e->mu);
     if (e->la_on) {
+        const double t0 = now_ms();
         const int r = la_take(e, slot);
+        e->la_t_take += now_ms() - t0;
         if (r) { pthread_mutex_lock(&e->mu); slot->used = 0; e->sched_err = r; pthread_mutex_unlock(&e->mu); return r; }
     }
     e->st.in_copy_ms += now_ms() - tc0;
@@ -1776,9 +1856,10 @@ void *QY265EncoderOpen(QY265EncConfig *cfg, int *err)
     if (t->nlanes > 1 && (cfg->rc == 1 || cfg->rc == 2 || cfg->rc == 4))
         logf_(1, cfg->logLevel, "ks265enc: -rc %d over %d GOP lanes: every lane runs its own controller with the same per-picture bit budget (deterministic, not the one-lane stream)\n", cfg->rc, t->nlanes);
     t->iper = cfg->iIntraPeriod; t->cur_lane = -1;
-    /* every lane runs four streams (pixel path, key pictures, copy-in, copy-out); the runtime deals streams to FOUR hardware queues unless told otherwise, and a lane's
-     * 27 ms key-picture kernel in the queue of another lane's pixel path stops that lane for as long (measured: 615 -> 686 pictures/s with eight queues, two lanes,
-     * 2160p).  Only effective when this is the process's first use of the runtime; a value the user has set stays. */
+    /* every lane runs four streams (pixel path, copy-in, copy-out, key pictures; with the lookahead a fifth); the runtime deals streams to FOUR hardware queues unless told
+     * otherwise, and a lane's 19 ms key-picture kernel in the queue of another lane's pixel path stops that lane for as long (measured: 615 -> 686 pictures/s with eight queues,
+     * two lanes, 2160p).  Only effective when this is the process's first use of the runtime; a value the user has set stays.  (One lane: the order in which lane_open creates
+     * its streams keeps the pixel path's queue to itself - see there.) */
     if (t->nlanes > 1 && !getenv("GPU_MAX_HW_QUEUES")) {
         setenv("GPU_MAX_HW_QUEUES", "8", 0);
         logf_(1, cfg->logLevel, "ks265enc: GPU_MAX_HW_QUEUES=8 set for this process (several GOP lanes; effective if the HIP runtime has not started yet; set it yourself to override)\n");

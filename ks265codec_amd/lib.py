@@ -55,7 +55,7 @@ EXPORTS = [
     "ks265_residual_batch", "ks265_fwd_transform_batch", "ks265_quant_batch", "ks265_sign_hiding_batch", "ks265_dequant_batch", "ks265_dequant_rect_batch", "ks265_inv_transform_batch",
     "ks265_edge_filter_luma_batch", "ks265_edge_filter_chroma_batch", "ks265_interp_rect",
     "ks265_sao_apply_bo_rect", "ks265_sao_apply_eo_rect", "ks265_sao_stats_batch", "ks265_intra_pred_batch", "ks265_intra_filter_ref_batch",
-    "ks265_downsample_rect", "ks265_weight_bi_sad_batch", "ks265_ac_energy_batch", "ks265_ac_energy_map",
+    "ks265_downsample_rect", "ks265_downsample_from_host", "ks265_weight_bi_sad_batch", "ks265_ac_energy_batch", "ks265_ac_energy_map",
     "ks265_frame_reset_prediction", "ks265_frame_records_layout", "ks265_frame_pack_records", "ks265_frame_compact_layout", "ks265_frame_pack_compact", "ks265_frame_pack_compact_on", "ks265_frame_adapt_quant", "ks265_aq_ctu_map", "ks265_cutree_propagate", "ks265_frame_set_records_fence", "ks265_load_i420_on", "ks265_sse_picture_on", "ks265_copy_out_compact_async", "ks265_copy_out_compact_dma_async", "ks265_frame_geometry", "ks265_frame_create", "ks265_frame_destroy", "ks265_frame_set_qp", "ks265_frame_set_qp_map", "ks265_pad_picture",
     "ks265_load_i420", "ks265_store_i420", "ks265_presearch", "ks265_me_integer", "ks265_me_propagate", "ks265_me_subpel", "ks265_cu_decide_part", "ks265_merge_pass", "ks265_cu_decide",
     "ks265_cu_flat_intra", "ks265_intra_decide", "ks265_intra_decide_ex", "ks265_lookahead_reduce", "ks265_lookahead_picture", "ks265_lookahead_inter", "ks265_intra_reconstruct", "ks265_reconstruct", "ks265_reconstruct_b", "ks265_bi_decide", "ks265_bi_full_batch", "ks265_capture_begin", "ks265_capture_end", "ks265_graph_launch", "ks265_graph_destroy", "ks265_frame_p_state", "ks265_frame_p_advance", "ks265_frame_p_restore", "ks265_cu_decide_b", "ks265_deblock", "ks265_sao",
@@ -224,6 +224,19 @@ class KsContext:
         dst = self.zeros(ds * h)
         self._chk(self.lib.ks265_downsample_rect(self.h, _p(src), C.c_int(ss), _p(dst), C.c_int(ds), C.c_int(w), C.c_int(h)))
         return self.host(dst, np.uint8, (h, ds))
+
+    def downsample_from_host(self, src: np.ndarray, ss: int, w: int, h: int, ds: int):
+        """the same with the source in pinned host memory of the library (ks265_host_malloc): the kernel reads it over PCIe"""
+        hp = C.c_void_p()
+        self._chk(self.lib.ks265_host_malloc(self.h, C.byref(hp), C.c_size_t(src.size)))
+        try:
+            C.memmove(hp, src.ctypes.data, src.size)
+            dst = self.zeros(ds * h)
+            self._chk(self.lib.ks265_downsample_from_host(self.h, hp, C.c_int(ss), _p(dst), C.c_int(ds), C.c_int(w), C.c_int(h)))
+            self.sync()
+            return self.host(dst, np.uint8, (h, ds))
+        finally:
+            self._chk(self.lib.ks265_host_free(self.h, hp))
 
     def weight_bi_sad(self, org, so: int, r0, s0: int, r1, s1: int, blks: np.ndarray) -> np.ndarray:
         out = self.zeros(4 * len(blks))

@@ -48,6 +48,7 @@ int ks265_dev_free(ks265_ctx *c, void *p) { (void)c; free(p); return KS265_OK; }
 int ks265_host_malloc(ks265_ctx *c, void **p, size_t n) { return ks265_dev_malloc(c, p, n); }
 int ks265_host_free(ks265_ctx *c, void *p) { return ks265_dev_free(c, p); }
 int ks265_memcpy_h2d_async(ks265_ctx *c, void *d, const void *s, size_t n) { (void)c; memcpy(d, s, n); return KS265_OK; }
+int ks265_memcpy_d2d_async(ks265_ctx *c, void *d, const void *s, size_t n) { (void)c; memcpy(d, s, n); return KS265_OK; }
 int ks265_memcpy_d2h_async(ks265_ctx *c, void *d, const void *s, size_t n) { (void)c; memcpy(d, s, n); return KS265_OK; }
 int ks265_memset_async(ks265_ctx *c, void *d, int v, size_t n) { (void)c; memset(d, v, n); return KS265_OK; }
 int ks265_event_create(ks265_ctx *c, void **ev) { (void)c; *ev = malloc(4); return *ev ? KS265_OK : KS265_OUTOFMEMORY; }
@@ -291,6 +292,8 @@ int ks265_copy_out_compact_async(ks265_ctx *c, ks265_frame *f, void *host, const
 
 /* ---- scene-cut lookahead (host: -lookahead N): the half-size picture is real (2x2 averages), the two frame costs are stand-ins with the right behaviour - "intra" = how
  * far the samples are from mid-grey, "inter" = how far they are from the reference picture's co-located samples (no search), growing faster than linearly with that distance */
+int ks265_downsample_rect(ks265_ctx *c, const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int h);
+int ks265_downsample_from_host(ks265_ctx *c, const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int h) { return ks265_downsample_rect(c, src, ss, dst, ds, w, h); }
 int ks265_downsample_rect(ks265_ctx *c, const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int h)
 {
     (void)c;

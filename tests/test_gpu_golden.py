@@ -254,6 +254,22 @@ def test_intra(ks):
         off += len(c["src"])
 
 
+def test_downsample_from_pinned_host_memory(ks):
+    """ks265_downsample_from_host (the encoder host's lookahead reads its pinned input picture over PCIe: 64 work-groups, a wave per row) == ks265_downsample_rect == downsample_c,
+    at 2160p, at a width that leaves a partial group of four at the row end, and at a width below one wave iteration"""
+    rng = np.random.default_rng(5)
+    for W, H in ((3840, 2160), (1928, 1080), (136, 72)):
+        src = rng.integers(0, 256, (H, W), dtype=np.uint8)
+        w, h = (W // 2 - 2 if W == 1928 else W // 2), H // 2       # (962: a partial group of four at the row end)
+        ds = (w + 3) & ~3
+        exp = ks.downsample(ks.dev(src), W, w, h, ds)
+        got = ks.downsample_from_host(src, W, w, h, ds)
+        assert (got[:, :w] == exp[:, :w]).all(), (W, H)
+        a = src.astype(np.int32)
+        ref = (((a[0::2, 0::2] + a[1::2, 0::2] + 1) >> 1) + ((a[0::2, 1::2] + a[1::2, 1::2] + 1) >> 1) + 1) >> 1
+        assert (got[:, :w] == ref[:h, :w]).all()
+
+
 def test_lookahead_kernels(ks):
     """§8(f) rank 2 leaf kernels through the C ABI: downsample_c, weightBi_sad_c, acEnergyPlane_c (+ the whole-plane map)"""
     from ks265codec_amd.lib import BLK3
