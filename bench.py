@@ -54,6 +54,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=128, help="timed steps; the default covers one whole -iper 128 GOP per shard, key picture included")
+    ap.add_argument("--lookahead", type=int, default=-1, metavar="N", help="-lookahead N of the encoder host: -1 = its default (IPPP: off; hierarchical-B 8: the slice-type decision runs by itself), 0 = off, "
+                    "N > 0 = scene cuts + slice types, every picture analysed")
     ap.add_argument("--hier-b", type=int, default=0, metavar="G", help="hierarchical-B mini-GOPs of G pictures (power of two, e.g. 8 = the reference's -latency offline default); B pictures of the inner layers are references")
     ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--width", type=int, default=3840)
@@ -536,7 +538,7 @@ def encoded_leg(args, torch, dist, rank, world, dev_index, backend, sync_all):
     assert lib.QY265ConfigDefaultPreset(cfg, preset, None, b"default") == 0
     gop_b = (args.hier_b - 1) if args.hier_b else args.bframes
     for k, v in (("wdt", W), ("hgt", H), ("fr", 50), ("rc", 0), ("qp", args.qp), ("iper", args.iper), ("bframes", -1 if args.hier_b == 8 else gop_b), ("threads", threads),
-                 ("psnr", 1), ("log", 3), ("me", {"dia": 0, "hex": 1, "umh": 2}[args.me]), ("subme", 1), ("ref", max(1, args.refs))):
+                 ("psnr", 1), ("log", 3), ("lookahead", args.lookahead), ("me", {"dia": 0, "hex": 1, "umh": 2}[args.me]), ("subme", 1), ("ref", max(1, args.refs))):
         assert lib.QY265ConfigParse(cfg, k.encode(), str(v).encode()) == 0, k
     clip = make_clip(W, H, args.clip_frames, seed=7 + rank, abc=(67, 91, 33), pan=(8, 5))
     order = list(range(len(clip))) + list(range(len(clip) - 2, 0, -1))          # ping-pong keeps the motion continuous
@@ -714,6 +716,8 @@ def encoded_leg(args, torch, dist, rank, world, dev_index, backend, sync_all):
                                       "key_picture_slice_wall_ms": round(st.key_wall_ms / max(1, st.keys), 2), "key_picture_slice_thread_ms": round(st.key_cpu_ms / max(1, st.keys), 2),
                                       "ring_occupancy_at_submission": {"in_ring": round(st.occ_ring / max(1, st.occ_samples), 1), "not_through_gpu": round(st.occ_gpu / max(1, st.occ_samples), 1),
                                                                        "waiting_for_a_writer": round(st.occ_ready / max(1, st.occ_samples), 1)}},
+            "lookahead": ("off" if args.lookahead == 0 else f"-lookahead {args.lookahead}: scene cuts + slice types" if args.lookahead > 0 else
+                          "default: slice-type decision (blocks of 8 coded as 8 or 4 + 4) from the half-size pictures on the GOP's grid of 4" if args.hier_b == 8 else "default: off"),
             "gop": f"hierarchical-B {args.hier_b}" if args.hier_b else (f"P + {gop_b} B" if gop_b else "IPPP")}
 
 
@@ -749,7 +753,9 @@ def encoded_line(args, enc, world, hot, cpu):
                                   "predictors, vector propagation between neighbouring PUs (stage A2, one round), joint refinement of bi-predictive pairs (B pictures, bi-prediction judged at 31/32), intra CUs in P / B pictures, coefficient-group pruning (luma) and sign-data hiding "
                                   "(signBitHidingHDQ) at the postQuant seam, P / B lambda table; fractional samples interpolated on the fly; the picture's drain (SSE, packing of the records) and the next source picture's unpack on side streams (DESIGN.md 6a)",
                    "not_in_the_path": "per-coefficient RDOQ (the reference's -rdoq at -preset slow), skip / CU size judged with the residual's cost, generalised B pictures, "
-                                      "lookahead / cuTree / adaptive mini-GOP: at equal PSNR the stream is 1.04x (2160p) / 1.10x (1080p) the size of appencoder's for IPPP and 1.93x / 1.51x for hierarchical B (BASELINE.md 2b has the same-clip table)",
+                                      "cuTree; at equal PSNR the stream is 1.04x (2160p) / 1.10x (1080p) the size of appencoder's for IPPP and 1.93x / 1.51x for hierarchical B with anchors 8 apart - "
+                                      "1.44x at 2160p with the slice-type decision that runs by default since round 4 (BASELINE.md 2b has the same-clip table)",
+                   "lookahead": enc.get("lookahead"),
                    "sharding": (f"ONE job of {enc['job']['frames']} pictures = {enc['job']['gops']} closed GOPs dealt to the ranks in contiguous runs; every rank encodes its GOPs, the coded bytes are "
                                 f"gathered on rank 0 in stream order (the only exchange step; inside the timed region); stream md5 {enc['md5']}") if strong else
                                "one encoder per GPU (rank), each on its own synthetic clip = its own closed GOPs; no data-path collective"},

@@ -34,3 +34,28 @@ cd /tmp; timeout 120 rocprofv3 --kernel-trace --stats -d $O/kt_la -o kt -- pytho
 python $R/tools/rocpd_stats.py $O/kt_la/kt_results.db 2>/dev/null | grep -E 'kernel|aq_|cutree_' >> $O/la_ops.txt; rm -rf $O/kt_la
 cd $R; timeout 1500 python -m pytest tests -q -m gpu 2>&1 | tail -5 > $O/pytest_gpu.txt
 ls -la $O; head -c 600 $O/bench_line_default.json; echo; head -22 $O/kernel_stats_hot_1stream.txt; cat $O/hbm_traffic.txt; head -14 $O/sq_counters.txt | cut -c1-200
+# ---- 6. what the lookahead at the input costs (round 4: not waited for; uploads + analysis on one stream created first): the bench's hierarchical-B leg without it, with the
+#         default (slice types, grid pictures only) and with -lookahead 8 (every picture analysed); IPPP with -lookahead 8; and the CLI on a 2160p clip whose pan puts anchors
+#         8 apart at the edge of the search window (257 pictures): bytes and PSNR without and with the default
+cd $R
+{ for la in 0 -1 8; do echo -n "hierarchical-B 8, --lookahead $la: "; timeout 200 python bench.py --leg encoded --no-cpu-baseline --steps 24 --hier-b 8 --lookahead $la 2>/dev/null | python -c "
+import sys, json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d = json.loads(l); print(d['value'], 'pictures/s,', round(d['config']['bytes_per_picture']), 'B/picture,', d['psnr_y'], 'dB')"; done
+  for la in 0 8; do echo -n "IPPP, --lookahead $la: "; timeout 200 python bench.py --leg encoded --no-cpu-baseline --steps 24 --lookahead $la 2>/dev/null | python -c "
+import sys, json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d = json.loads(l); print(d['value'], 'pictures/s')"; done; } > $O/lookahead_cost.txt 2>&1
+python3 - <<'PY'
+import sys; sys.path.insert(0, '.')
+from ks265codec_amd.synth import make_clip
+b = make_clip(3840, 2160, 17, seed=7, abc=(67, 91, 33), pan=(8, 5))
+o = list(range(17)) + list(range(15, 0, -1))
+with open('/dev/shm/mg.yuv', 'wb') as f:
+    for t in range(257): f.write(b[o[t % len(o)]].tobytes())
+PY
+for extra in "-lookahead 0" ""; do echo "== ks265enc 3840x2160 257 pictures -preset slow -qp 27 -iper 128 (default GOP) $extra"; ./ks265codec_amd/ks265enc -i /dev/shm/mg.yuv -wdt 3840 -hgt 2160 -fr 50 -preset slow -rc 0 -qp 27 -iper 128 $extra -threads 32 -psnr 1 -b /dev/shm/o.265 | grep -E 'lookahead|bitrate, psnr'; done >> $O/lookahead_cost.txt 2>&1
+rm -f /dev/shm/mg.yuv /dev/shm/o.265
+cat $O/lookahead_cost.txt
