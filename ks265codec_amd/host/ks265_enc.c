@@ -818,8 +818,9 @@ static int code_hier(Enc *e, int d, int a)
             /* B pictures of the pyramid: + 2 / + 4 / + 4 on the key picture's QP by layer - the reference's own ladder (appencoder -qp 27 -psnr 2: anchors 28, B pictures 29 / 31 / 31; ours was
              * + 2 / + 3 / + 4 until the end of round 3).  Larger offsets keep paying (+ 3 / + 5 / + 6: 1.51 x -> 1.44 x the reference's bitrate at its PSNR-Y on the 1080p clip, every B picture within 0.1 dB
              * of the anchors - their quality comes from their references), but -qp would no longer mean what it means in the reference */
-            static const int kHierLayerQp[4] = {0, 1, 3, 3};
-            int r = submit(e, in, 'B', mid - e->gop_start, clampqp(e, in->base_qp + e->rc_qp_delta + (e->fixqp ? 0 : 1 + kHierLayerQp[layer < 3 ? layer : 3])), &l0, 1, &l1, 1, coded, ncoded, is_ref, 0);
+            static const int kHierLayerQp[4] = {0, 1, 3, 3}, kPyr4LayerQp[4] = {0, 1, 2, 2};                       /* (-bframes 3: + 2 / + 3) */
+            const int *lq = e->gop_b == 3 ? kPyr4LayerQp : kHierLayerQp;
+            int r = submit(e, in, 'B', mid - e->gop_start, clampqp(e, in->base_qp + e->rc_qp_delta + (e->fixqp ? 0 : 1 + lq[layer < 3 ? layer : 3])), &l0, 1, &l1, 1, coded, ncoded, is_ref, 0);
             if (r) return r;
             if (is_ref) coded[ncoded++] = mid - e->gop_start;
             nxt[nn].lo = cur[i].lo; nxt[nn++].hi = mid; nxt[nn].lo = mid; nxt[nn++].hi = cur[i].hi;
@@ -1093,7 +1094,10 @@ static Enc *lane_open(QY265EncConfig *cfg, int device, int multi, int *err)
     e->refs = cfg->refnum < 1 ? 1 : cfg->refnum > 4 ? 4 : cfg->refnum;
     e->use_sao = cfg->sao > 0; e->use_df = g_cli.df; e->fixqp = g_cli.fixqp; e->md5 = g_cli.md5;
     e->gop_b = cfg->bframes < 0 ? (cfg->latency == QY265LATENCY_DEFAULT ? 7 : 0) : cfg->bframes;
-    e->hier = cfg->bframes < 0 && e->gop_b == 7;
+    /* the pyramid: the SDK's default GOP (8), and - as in the reference, whose -psnr 2 lines show it - explicit -bframes 7 (the same) and -bframes 3: anchors 4 apart, the middle
+     * picture a reference B at Q + 2, the two outer ones non-reference B at Q + 3 (appencoder -bframes 3 -qp 27: 28 / 29 / 30 / 30; until round 4 ours was P + 3 plain B at Q + 2).
+     * -bframes 1 / 2: the reference codes both as anchors 2 apart with one B picture at Q + 2; ours: P + n plain B at Q + 2 */
+    e->hier = e->gop_b == 7 || cfg->bframes == 3;
     if (e->gop_b > 0) e->refs = 1;
     e->base_qp = cfg->rc == 3 ? cfg->crf : cfg->qp;
     if (e->base_qp < 0) e->base_qp = 0;
@@ -1119,7 +1123,7 @@ static Enc *lane_open(QY265EncConfig *cfg, int device, int multi, int *err)
      * With the lookahead there are five: created fourth - in front of the key pictures' stream - it pushed that stream into the pixel path's queue, and the key picture's 19 ms
      * wavefront kernel stopped the P / B pictures for as long: - 25 % (hierarchical B), - 31 % (IPPP), with not one lookahead kernel launched; created last it shares the pixel
      * path's queue itself: - 8 %; created FIRST, the key pictures' stream shares ITS queue: - 3 %.  (GPU_MAX_HW_QUEUES=8 changed none of this on the ROCm 7.2 runtime here.) */
-    const int la_wanted = e->cfg.lookahead > 0 || (e->cfg.lookahead < 0 && e->hier && !getenv("KS265_NO_AUTO_LOOKAHEAD"));
+    const int la_wanted = e->cfg.lookahead > 0 || (e->cfg.lookahead < 0 && e->hier && e->gop_b == 7 && !getenv("KS265_NO_AUTO_LOOKAHEAD"));
     const int la_order = getenv("KS265_LA_ORDER") ? atoi(getenv("KS265_LA_ORDER")) : 0;      /* (experiments: 1 = fourth, 2 = last) */
     if (la_wanted && la_order == 0 && ks265_create(&e->ctx_la, device)) e->ctx_la = NULL;
     int r = ks265_create(&e->ctx, device);
@@ -1197,7 +1201,7 @@ static Enc *lane_open(QY265EncConfig *cfg, int device, int multi, int *err)
     /* (the lookahead's objects; its stream was created first - see the top of this function) */
     /* no -lookahead on the command line and the SDK's default GOP (hierarchical B, 8): the slice-type decision runs by itself (round 4: it costs a search of the half-size
      * picture every fourth picture, and the caller does not wait for it) - the reference's adaptive BiPredFrames is on by default as well.  -lookahead 0 switches it off. */
-    const int la_auto = cfg->lookahead < 0 && e->hier && !getenv("KS265_NO_AUTO_LOOKAHEAD");
+    const int la_auto = cfg->lookahead < 0 && e->hier && e->gop_b == 7 && !getenv("KS265_NO_AUTO_LOOKAHEAD");
     if (!r && (cfg->lookahead > 0 || la_auto)) {
         const int w = (e->W / 2) & ~7, h = (e->H / 2) & ~7;            /* the analysis sees the picture without its last columns / rows when half the size is no multiple of 8 */
         if (w < 16 || h < 16) { if (!la_auto) logf_(1, e->log_level, "ks265enc: -lookahead %d: the analysis needs a picture of at least 32 x 32: off\n", cfg->lookahead); }
@@ -1302,7 +1306,7 @@ static Enc *lane_open(QY265EncConfig *cfg, int device, int multi, int *err)
     if (e->disp_on && !pthread_create(&e->sched, NULL, scheduler, e)) e->sched_on = 1;
     if (!e->nth || !e->disp_on || !e->sched_on) { *err = QY_FAIL; lane_close(e, 0); return NULL; }
     logf_(0, e->log_level, "ks265enc: GPU %d: %dx%d %.2f fps, qp %d, -me %d (hex below %d), subme %d, refs %d, %s, sao %d, key period %d, %d slice writer threads, %s\n", device, e->W, e->H,
-          cfg->frameRate, e->base_qp, e->me_method, e->hex_thr, e->subme, e->refs, e->hier ? "hierarchical-B GOP 8" : e->gop_b ? "P + non-reference B" : "IPPP", e->use_sao, e->iper,
+          cfg->frameRate, e->base_qp, e->me_method, e->hex_thr, e->subme, e->refs, e->hier ? (e->gop_b == 3 ? "hierarchical-B GOP 4" : "hierarchical-B GOP 8") : e->gop_b ? "P + non-reference B" : "IPPP", e->use_sao, e->iper,
           e->nth, ks265_version());
     return e;
 }

@@ -233,7 +233,7 @@ REF_DEC = os.path.join(ROOT, "oracle", "_ref", "appdecoder")          # staged b
 @pytest.mark.parametrize("W,H,n,opts", [
     (1280, 720, 25, ["-preset", "veryfast", "-qp", "32", "-iper", "16"]),                      # the SDK's default GOP: hierarchical B of 8, two closed GOPs
     (1920, 1080, 10, ["-preset", "slow", "-qp", "27", "-bframes", "0", "-iper", "128"]),       # config 2's tools: UMH, three list-0 pictures
-    (1920, 1088, 9, ["-preset", "medium", "-qp", "30", "-bframes", "3", "-iper", "128"]),      # anchors + non-reference B pictures
+    (1920, 1088, 9, ["-preset", "medium", "-qp", "30", "-bframes", "3", "-iper", "128"]),      # a pyramid of 4 (round 4, as in the reference): anchors, a reference B between them, non-reference B pictures; the flush ends on P + plain B
     (3840, 2160, 6, ["-preset", "slow", "-qp", "27", "-iper", "128"]),                         # the bench workload (config 3)
     (1920, 1080, 8, ["-preset", "veryslow", "-qp", "27", "-bframes", "0", "-ref", "1", "-iper", "128"]),   # config 5's tools on P pictures: -part 1 (two prediction units, four TUs), -subme 2 by Hadamard
     (3840, 2160, 4, ["-preset", "veryslow", "-qp", "27", "-bframes", "0", "-ref", "1", "-iper", "128"]),

@@ -91,17 +91,20 @@ def test_crf_with_three_b_pictures(tmp_path):
     W, H, n = 1920, 1080, 13
     clip = make_clip(W, H, n, seed=W + n, abc=(37, 53, 19), pan=(5, 3))
     log, per, kbps, rec, out = _encode(tmp_path, clip, W, H, ["-preset", "slow", "-rc", "3", "-crf", "24", "-bframes", "3", "-iper", "128"])
-    assert len(per) == n and [k for _, k, _, _ in per[:5]] == ["I", "P", "B", "B", "B"]
-    assert {(k, q) for _, k, _, q in per} == {("I", 24), ("P", 25), ("B", 26)}, "crf 24 is the ladder I = 24, P = 25, B = 26"
+    # -bframes 3 is a pyramid of 4 as in the reference (its -psnr 2 lines: coding order 0 4 2 1 3 8 6 5 7 .., QP + 1 / + 2 / + 3 / + 3): the middle picture is a reference B
+    assert len(per) == n and [(p, k) for p, k, _, _ in per[:9]] == [(0, "I"), (4, "P"), (2, "B"), (1, "B"), (3, "B"), (8, "P"), (6, "B"), (5, "B"), (7, "B")]
+    assert {(k, q) for _, k, _, q in per} == {("I", 24), ("P", 25), ("B", 26), ("B", 27)}, "crf 24 is the ladder I = 24, P = 25, B = 26 (reference B) / 27"
+    assert all(q == (26 if p % 4 == 2 else 27) for p, k, _, q in per if k == "B")
     _decoder_check(tmp_path, out, rec, n, W * H * 3 // 2)
-    anchors = [p for p, k, _, _ in per if k != "B"]
+    coded = []
 
-    def refs(i, poc, kind):
+    def refs(i, poc, kind):                                                # the nearest pictures coded before on either side (the outer B pictures of a block come last)
         if kind == "I":
-            return None, None
-        prev = max(a for a in anchors if a < poc) if kind == "P" else max(a for a in anchors if a < poc)
-        nxt = min((a for a in anchors if a > poc), default=None)
-        return (prev, None) if kind == "P" else (prev, nxt)
+            coded.append(poc); return None, None
+        lo = max(p for p in coded if p < poc)
+        hi = min((p for p in coded if p > poc), default=None)
+        coded.append(poc)
+        return (lo, None) if kind == "P" else (lo, hi)
     _mirror(clip, W, H, per, refs, rec, ENCODER_TOOLS, upto=9)
 
 

@@ -237,8 +237,8 @@ def test_cli_prints_the_reference_per_picture_and_md5_lines(stub_lib, tmp_path):
 
 def test_qp_ladders_of_the_host(stub_lib, tmp_path):
     """the QP every picture is coded with (-psnr 2 prints it): IPPP = the reference's cascade (key picture Q, P pictures Q + 1 + {0, 2, 1, 2}[position in the GOP & 3]:
-    appencoder -bframes 0 -qp 27 codes 27 / 30 / 29 / 30 / 28 ..), the pyramid of the default GOP = Q / Q + 1 for the anchors, + 2 / + 4 / + 4 by B layer (the reference's 29 / 31 / 31), plain B
-    pictures (-bframes 3) Q + 2; the GPU fixtures (tests/stream_cases.py HOST_IPPP_CASCADE, tools/rd_eval.py --host) mirror exactly this"""
+    appencoder -bframes 0 -qp 27 codes 27 / 30 / 29 / 30 / 28 ..), the pyramid of the default GOP = Q / Q + 1 for the anchors, + 2 / + 4 / + 4 by B layer (the reference's 29 / 31 / 31), the pyramid of 4 of -bframes 3 + 2 / + 3, plain B
+    pictures (-bframes 2) Q + 2; the GPU fixtures (tests/stream_cases.py HOST_IPPP_CASCADE, tools/rd_eval.py --host) mirror exactly this"""
     import re
     import numpy as np
     from stream_cases import HOST_IPPP_CASCADE
@@ -265,8 +265,12 @@ def test_qp_ladders_of_the_host(stub_lib, tmp_path):
     hier = qps()                                                             # the default GOP: pyramid of 8 (the GOP of 12 ends with a mini-GOP of 3 = anchor + two plain B pictures)
     assert [hier[t] for t in range(0, 9)] == [("I", 27), ("B", 31), ("B", 31), ("B", 31), ("B", 29), ("B", 31), ("B", 31), ("B", 31), ("P", 28)], [hier[t] for t in range(9)]
     assert [hier[t] for t in (9, 10, 11)] == [("B", 29), ("B", 29), ("P", 28)]
-    flat = qps("-bframes", "3")
-    assert [flat[t] for t in range(0, 5)] == [("I", 27), ("B", 29), ("B", 29), ("B", 29), ("P", 28)]
+    # -bframes 3: a pyramid of 4 like the reference's (appencoder -bframes 3 -qp 27 -psnr 2: 28 / 29 / 30 / 30 - anchor, the middle picture a reference B, the outer ones);
+    # -bframes 2: P + 2 plain B pictures at Q + 2
+    pyr4 = qps("-bframes", "3")
+    assert [pyr4[t] for t in range(0, 9)] == [("I", 27), ("B", 30), ("B", 29), ("B", 30), ("P", 28), ("B", 30), ("B", 29), ("B", 30), ("P", 28)]
+    flat = qps("-bframes", "2")
+    assert [flat[t] for t in range(0, 4)] == [("I", 27), ("B", 29), ("B", 29), ("P", 28)]
 
 
 def test_gops_dealt_to_several_gpus_behind_one_handle(stub_lib, tmp_path):
