@@ -9,7 +9,7 @@
  * Behaviour that differs from the SDK, all of it reported through the log callback at open:
  *   - the encoder's decisions are its own: the stream is a conforming HEVC stream, not appencoder's bytes;
  *   - rate control: rc = 0 is constant QP with the reference's own hidden ladders (read from its -psnr 2 lines): I = Q; IPPP P pictures
- *     Q + 1 + {0, 2, 1, 2}[position & 3]; hierarchical GOP anchors Q + 1, B layers Q + 2 / + 4 / + 4; P + n plain B: B = Q + 2 (-fixqp 1: one QP);
+ *     Q + 1 + {0, 2, 1, 2}[position & 3]; hierarchical GOP anchors Q + 1, B layers Q + 2 / + 4 / + 4 (-bframes 3, a pyramid of 4: Q + 2 / + 3); P + n plain B: B = Q + 2 (-fixqp 1: one QP);
  *     rc = 3 (CRF) maps crf to that ladder; rc = 1 / 2 / 4 (bitrate targets) run a frame-level controller on top of it (one offset per
  *     mini-GOP from the pictures coded so far: deterministic streams); rc = 5 and VBV are not implemented;
  *   - subme 0 / 1 / 2 and the preset's thresholds run the reference's sub-pel refinement (include/ks265_hip.h ks265_frame_cfg.subme);
@@ -41,7 +41,7 @@ typedef struct QY265EncConfig {
     int bHeaderBeforeKeyframe;                /* VPS / SPS / PPS in front of every key picture */
     int picWidth, picHeight;                  /* multiples of 8 */
     double frameRate;
-    int bframes;                              /* -1: preset / latency default (hierarchical GOP 8 at default latency, else 0); 0: IPPP; n: n non-reference B pictures per anchor */
+    int bframes;                              /* -1: preset / latency default (hierarchical GOP 8 at default latency, else 0); 0: IPPP; 3 / 7: pyramids of 4 / 8 as in the reference; other n: n non-reference B pictures per anchor */
     int temporalLayer;
     int vpp_denoise, vpp_edge, vpp_color, vpp_hdr; double vpp_hdr_strength; int vpp_hdr_iter; double vpp_hdr_sigma_s, vpp_hdr_sigma_r, vpp_recur_filter;
     int rc;                                   /* 0 CQP, 1 CBR, 2 ABR, 3 CRF, 4 CVBR, 5 CVQ */
