@@ -753,8 +753,8 @@ def encoded_line(args, enc, world, hot, cpu):
                                   "predictors, vector propagation between neighbouring PUs (stage A2, one round), joint refinement of bi-predictive pairs (B pictures, bi-prediction judged at 31/32), intra CUs in P / B pictures, coefficient-group pruning (luma) and sign-data hiding "
                                   "(signBitHidingHDQ) at the postQuant seam, P / B lambda table; fractional samples interpolated on the fly; the picture's drain (SSE, packing of the records) and the next source picture's unpack on side streams (DESIGN.md 6a)",
                    "not_in_the_path": "per-coefficient RDOQ (the reference's -rdoq at -preset slow), skip / CU size judged with the residual's cost, generalised B pictures, "
-                                      "cuTree; at equal PSNR the stream is 1.04x (2160p) / 1.10x (1080p) the size of appencoder's for IPPP and 1.93x / 1.51x for hierarchical B with anchors 8 apart - "
-                                      "1.44x at 2160p with the slice-type decision that runs by default since round 4 (BASELINE.md 2b has the same-clip table)",
+                                      "cuTree; at equal PSNR the stream is 0.99x (2160p) / 1.02x (1080p) the size of appencoder's for IPPP and 1.43x / 1.47x for hierarchical B "
+                                      "(same clips, measured on the MI355X at the end of round 4 with the slice-type decision that runs by default: BASELINE.md 2b)",
                    "lookahead": enc.get("lookahead"),
                    "sharding": (f"ONE job of {enc['job']['frames']} pictures = {enc['job']['gops']} closed GOPs dealt to the ranks in contiguous runs; every rank encodes its GOPs, the coded bytes are "
                                 f"gathered on rank 0 in stream order (the only exchange step; inside the timed region); stream md5 {enc['md5']}") if strong else
