@@ -1364,7 +1364,7 @@ static int lane_acquire(Enc *e, QY265YUV *yuv)
  *      when the picture is handed in; the picture then sits in a short queue (la_q, display order) until its results have arrived - looked at, not waited for, whenever the caller
  *      hands in another picture - and only then goes to the scheduler.  The queue holds at most LA_KEEP pictures: a result that is still missing then is waited for (the analysis
  *      has had several picture times by then).  Same decisions as when the caller waited for every picture (round 3; the CPU tests did not change), a few pictures of delay at
- *      the input.  All of it runs on the caller's thread. */
+ *      the input.  The caller's thread launches; the caller's thread and - when it has nothing to schedule - the scheduler thread look (la_mu). */
 #define LA_KEEP la_keep()
 static int la_keep(void) { static int v = 0; if (!v) { const char *s = getenv("KS265_LA_KEEP"); v = s && atoi(s) > 0 && atoi(s) < 8 ? atoi(s) : 5; } return v; }
 
@@ -1439,7 +1439,7 @@ static int la_drain_locked(Enc *e, int keep)
             int r, done = 1;
             if (e->la_qn > keep) { const double t0 = now_ms(); r = ks265_event_wait(e->ctx_la, e->la_evs[h->la_buf]); e->la_t_wait += now_ms() - t0; ++e->la_n_wait; }
             else r = ks265_event_query(e->ctx_la, e->la_evs[h->la_buf], &done);
-            if (r) { pthread_mutex_lock(&e->mu); for (int i = 0; i < e->la_qn; ++i) e->la_q[i]->used = 0; e->la_qn = 0; e->sched_err = hip_rc(r); pthread_mutex_unlock(&e->mu); return hip_rc(r); }
+            if (r) { pthread_mutex_lock(&e->mu); for (int i = 0; i < e->la_qn; ++i) e->la_q[i]->used = 0; e->la_qn = 0; e->la_flying = 0; e->sched_err = hip_rc(r); pthread_mutex_unlock(&e->mu); return hip_rc(r); }
             if (!done) break;
             la_decide(e, h, &cut, &mini4);
             --e->la_flying;
