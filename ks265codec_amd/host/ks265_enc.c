@@ -1118,11 +1118,11 @@ static Enc *lane_open(QY265EncConfig *cfg, int device, int multi, int *err)
 
     /* the SDK's config has no device field: the lane's GPU comes from the handle (KS265_DEVICE: one GPU, default 0; KS265_GPUS / KS265_DEVICES: closed GOPs dealt
      * to lanes on several GPUs, QY265EncoderOpen) */
-    /* The ORDER in which the streams are created matters (round 4, measured at 2160p): the runtime deals streams to four hardware queues in turn, so the FIFTH stream
-     * shares the queue of the FIRST, and streams in one queue run in the order they were fed.  With four streams (pixel path, copy-in, copy-out, key pictures) nothing is shared.
-     * With the lookahead there are five: created fourth - in front of the key pictures' stream - it pushed that stream into the pixel path's queue, and the key picture's 19 ms
-     * wavefront kernel stopped the P / B pictures for as long: - 25 % (hierarchical B), - 31 % (IPPP), with not one lookahead kernel launched; created last it shares the pixel
-     * path's queue itself: - 8 %; created FIRST, the key pictures' stream shares ITS queue: - 3 %.  (GPU_MAX_HW_QUEUES=8 changed none of this on the ROCm 7.2 runtime here.) */
+    /* The ORDER in which the streams are created matters (round 4, measured at 2160p; DESIGN 6c, tools/hw_queues.hip): a process's normal-priority streams are served by a few
+     * in-order hardware queues (four; three where another runtime user - torch in bench.py - holds one) and share them in pairs that depend on the creation order; a stream that
+     * shares the pixel path's queue runs in turn with it.  With the lookahead there is a fifth stream: created fourth, in front of the key pictures' stream, it cost 25 % (hierarchical
+     * B) / 31 % (IPPP) with not one lookahead kernel launched; created last 8 %; created FIRST nothing measurable - it then pairs with the copy-out stream.  (In the CLI's own
+     * process the four normal streams have a queue each; the key pictures' stream is high-priority and has its own.) */
     const int la_wanted = e->cfg.lookahead > 0 || (e->cfg.lookahead < 0 && e->hier && e->gop_b == 7 && !getenv("KS265_NO_AUTO_LOOKAHEAD"));
     const int la_order = getenv("KS265_LA_ORDER") ? atoi(getenv("KS265_LA_ORDER")) : 0;      /* (experiments: 1 = fourth, 2 = last) */
     if (la_wanted && la_order == 0 && ks265_create(&e->ctx_la, device)) e->ctx_la = NULL;
