@@ -7,16 +7,27 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 __global__ void spin_kernel(long long ticks, int *out) { const long long t0 = wall_clock64(); while (wall_clock64() - t0 < ticks) { } if (out) *out = 1; }
 __global__ void tiny_kernel(int *out) { if (out) *out = 2; }
+extern "C" int hw_queues_probe_pattern(const char *pattern);
 extern "C" int hw_queues_probe(int n, int prio)
 {
+    char pat[65]; int k = 0;
+    for (; k < n && k < 64; ++k) pat[k] = k == prio ? 'P' : 'n';
+    pat[k] = 0;
+    return hw_queues_probe_pattern(pat);
+}
+// pattern: one letter per stream in creation order, 'n' = normal priority, 'P' = high priority
+extern "C" int hw_queues_probe_pattern(const char *pattern)
+{
+    const int n = (int)strlen(pattern);
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
     std::vector<hipStream_t> s(n);
     for (int i = 0; i < n; ++i) {
-        if (i == prio) (void)hipStreamCreateWithPriority(&s[i], hipStreamNonBlocking, hi);
+        if (pattern[i] == 'P') (void)hipStreamCreateWithPriority(&s[i], hipStreamNonBlocking, hi);
         else (void)hipStreamCreateWithFlags(&s[i], hipStreamNonBlocking);
     }
     int *d = nullptr;
@@ -26,11 +37,11 @@ extern "C" int hw_queues_probe(int n, int prio)
     const long long ticks = (long long)rate_khz * 10;                   // 10 ms
     for (int i = 0; i < n; ++i) { hipLaunchKernelGGL(tiny_kernel, dim3(1), dim3(64), 0, s[i], d); }   // every stream has its queue before the measurement
     (void)hipDeviceSynchronize();
-    printf("%d streams%s, GPU_MAX_HW_QUEUES=%s; row = the waiting stream, column = the stream that spins\n    ", n, prio >= 0 ? " (one high-priority)" : "", getenv("GPU_MAX_HW_QUEUES") ? getenv("GPU_MAX_HW_QUEUES") : "(unset)");
-    for (int j = 0; j < n; ++j) printf("%2d%s", j, j == prio ? "p" : " ");
+    printf("streams %s (creation order; P = high priority), GPU_MAX_HW_QUEUES=%s; row = the waiting stream, column = the stream that spins\n    ", pattern, getenv("GPU_MAX_HW_QUEUES") ? getenv("GPU_MAX_HW_QUEUES") : "(unset)");
+    for (int j = 0; j < n; ++j) printf("%2d%s", j, pattern[j] == 'P' ? "p" : " ");
     printf("\n");
     for (int i = 0; i < n; ++i) {
-        printf("%2d%s ", i, i == prio ? "p" : " ");
+        printf("%2d%s ", i, pattern[i] == 'P' ? "p" : " ");
         for (int j = 0; j < n; ++j) {
             if (i == j) { printf(" . "); continue; }
             hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, s[j], ticks, d + 1);
@@ -49,5 +60,5 @@ extern "C" int hw_queues_probe(int n, int prio)
     return 0;
 }
 #ifndef HW_QUEUES_LIB
-int main(int argc, char **argv) { return hw_queues_probe(argc > 1 ? atoi(argv[1]) : 8, argc > 2 ? atoi(argv[2]) : -1); }
+int main(int argc, char **argv) { return argc > 1 && (argv[1][0] == 'n' || argv[1][0] == 'P') ? hw_queues_probe_pattern(argv[1]) : hw_queues_probe(argc > 1 ? atoi(argv[1]) : 8, argc > 2 ? atoi(argv[2]) : -1); }
 #endif
