@@ -273,6 +273,38 @@ def test_qp_ladders_of_the_host(stub_lib, tmp_path):
     assert [flat[t] for t in range(0, 4)] == [("I", 27), ("B", 29), ("B", 29), ("P", 28)]
 
 
+def test_gop_structure_and_qp_ladders_are_the_reference_s(tmp_path):
+    """the scheduler's coding order and QP per picture at constant QP against what the REFERENCE does (tests/golden/ref_gop_structure.json: its own -psnr 2 lines on a 26-picture clip,
+    written by oracle/ref_probe/gen_gop_structure.py): IPPP - order and the cascade 30 / 29 / 30 / 28; -bframes 3 - the pyramid of 4, order 4 2 1 3 and 28 / 29 / 30 / 30; -bframes 1;
+    the default GOP and -bframes 7 - the pyramid of 8 with 28 / 29 / 31 / 31 per layer (the reference codes a block depth first, ours breadth first: QP per picture compared; after its
+    first block the reference's adaptive decision takes over, ours is switched off here)"""
+    import json
+    import re
+    import numpy as np
+    ref = json.load(open(os.path.join(HERE, "golden", "ref_gop_structure.json")))
+    host = os.path.join(ROOT, "ks265codec_amd", "host")
+    exe = str(tmp_path / "ks265enc_stub")
+    subprocess.check_call(["gcc", "-O2", "-std=gnu11", "-I", os.path.join(ROOT, "include"), "-o", exe, os.path.join(host, "ks265_cli.c"),
+                           os.path.join(host, "ks265_enc.c"), os.path.join(host, "ks265_stream.c"), os.path.join(HERE, "hip_stub.c"),
+                           "-L", os.path.join(ROOT, "oracle"), "-lks265_oracle", "-Wl,-rpath," + os.path.join(ROOT, "oracle"), "-lpthread", "-lm"])
+    W, H, N = 128, 72, ref["clip"]["pictures"]
+    np.random.default_rng(5).integers(0, 256, N * W * H * 3 // 2, dtype=np.uint8).tofile(tmp_path / "in.yuv")
+
+    def ours(extra):
+        r = subprocess.run([exe, "-i", str(tmp_path / "in.yuv"), "-wdt", str(W), "-hgt", str(H), "-fr", "50", "-preset", ref["preset"], "-rc", "0", "-qp", str(ref["qp"]), "-iper", "128",
+                            "-psnr", "2", "-threads", "3", "-lookahead", "0", "-b", str(tmp_path / "o.265"), *extra], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0 and "H265 encoder passed!!!" in r.stdout, r.stdout[-800:] + r.stderr[-800:]
+        return [(int(a), k, int(q)) for a, k, q in re.findall(r"^(\d+)\t([IPB])\t\d+\t[\d.]+\t[\d.]+\t[\d.]+\t(\d+)$", r.stdout, re.M)]
+    for name, full_until, same_order in (("ippp", N, True), ("bframes3", 24, True), ("bframes1", 24, True), ("default", 8, False), ("bframes7", 8, False)):
+        want = [(a, q) for a, _, q in ref["cases"][name]["coding_order"] if a <= full_until]
+        got = [(a, q) for a, _, q in ours(ref["cases"][name]["args"]) if a <= full_until]
+        assert dict(got) == dict(want), (name, sorted(set(got) ^ set(want)))
+        if same_order:
+            assert got == want, (name, got[:12], want[:12])
+    kinds = {a: k for a, k, _ in ours(["-bframes", "3"])}
+    assert [kinds[a] for a in range(9)] == ["I", "B", "B", "B", "P", "B", "B", "B", "P"]      # (the reference's anchors are generalised B pictures: 'B' in its lines)
+
+
 def test_gops_dealt_to_several_gpus_behind_one_handle(stub_lib, tmp_path):
     """one handle, N GPUs - KS265_GPUS = N (the CLI's -gpus N) or KS265_DEVICES = list makes every GPU a GOP lane (closed GOPs, no data-path
     collective: SURVEY.md 8e); the stream is byte for byte the one-GPU stream, every listed device gets a context, a device the box does not have fails the open"""
