@@ -51,7 +51,7 @@ def encode_ours(clip, W, H, qp, gop, tools, verbose=False, stats=None, pdelta=1,
     from oracle_lib import OraclePipeline
     n = len(clip)
     o = OraclePipeline(W, H, qp, lambda_q4(qp), **tools)
-    G = int(os.environ.get("RD_G", "8"))
+    G = int(os.environ.get("RD_G", "8").replace("plain", ""))
     w = S.StreamWriter(W, H, max_dec_pic_buffering=10 if gop == "hier" else 2, max_num_reorder=7 if gop == "hier" else 0, sdh=tools.get("sdh", 0), wpp=0 if stats else 1, list_mod=1 if os.environ.get('RD_GPB2') else 0)
     import ctypes as C
     st = (C.c_double * 6)()
@@ -179,6 +179,18 @@ def adaptive_seq(clip, W, H, qp, decide=True):
         return int(out[1])
 
     seq, d, four = [(0, "I", None, None, 0)], 0, 0
+    if os.environ.get("RD_G", "8") == "4plain":                    # the host's -bframes 3 until the end of round 4: P + three plain (non-reference) B pictures at Q + 2
+        while d + 1 < n:
+            a = min(d + 4, n - 1)
+            seq += [(a, "P", d, None, 0)] + [(t, "B", d, a, -1) for t in range(d + 1, a)]
+            d = a
+        return seq, 0
+    if os.environ.get("RD_G", "8") == "4":                         # -bframes 3: the host's (and the reference's) pyramid of 4; run with --layer-qp 0,1,2 (its ladder + 2 / + 3)
+        while d + 4 < n:
+            seq += mini_gop(d, d + 4); d += 4
+        if d < n - 1:
+            seq += mini_gop(d, n - 1)
+        return seq, 0
     while d + 8 < n:
         c4a, c4b, c8 = (inter(d + 4, d), inter(d + 8, d + 4), inter(d + 8, d)) if decide else (1, 1, 0)
         if c8 * 12 > (c4a + c4b) * 13:
@@ -204,6 +216,8 @@ def encode_ref(yuv_path, W, H, qp, gop, n, threads=4):
             "-b", os.path.join(d, "o.265")]
     if gop == "ippp":
         args += ["-bframes", "0"]
+    elif os.environ.get("RD_G", "8") in ("4", "4plain"):
+        args += ["-bframes", "3"]                                    # RD_G=4 --gop hier: the pyramid of 4 = what both encoders make of -bframes 3 (BASELINE config 4's GOP)
     r = subprocess.run(args, capture_output=True, text=True, cwd=d)
     m = re.search(r"bitrate, psnr:\s*([\d.]+)\s+([\d.]+)", r.stdout)
     size = os.path.getsize(os.path.join(d, "o.265"))
