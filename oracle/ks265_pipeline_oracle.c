@@ -646,6 +646,10 @@ static int z_of(int x, int y)                         /* z-scan address of the 8
     for (int b = 0; b < 3; ++b) m |= ((bx >> b) & 1) << (2 * b) | ((by >> b) & 1) << (2 * b + 1);
     return m;
 }
+static int g_split_bits_b = SPLIT_BITS_B;
+void kso_experiment_split_bits_b(int q4) { g_split_bits_b = q4; }
+static int g_merge_bits_b = 32;                       /* experiment (test infrastructure): what explicit motion is taken to cost, in 1/16 bit, when a B picture's CU weighs a merge candidate */
+void kso_experiment_merge_bits_b(int q4) { g_merge_bits_b = q4; }
 void kso_merge_pass(const kso_frame_cfg *cfg, kso_pic src, const uint8_t *planes0, const uint8_t *planes1, const kso_pu *pu, const kso_pu_b *pub,
                     const kso_cu8 *cu_in, kso_cu8 *cu_out)
 {
@@ -665,7 +669,7 @@ void kso_merge_pass(const kso_frame_cfg *cfg, kso_pic src, const uint8_t *planes
             const long rb = (long)(cy * g.ctu_cols + cx) * 85 + idx;
             const uint32_t cur = (is_b ? pub[rb].cost : pu[rb].cost);
             if (cur == COST_INVALID) continue;
-            uint64_t best = (uint64_t)cur + (uint64_t)((lam * 32) >> 4);
+            uint64_t best = (uint64_t)cur + (uint64_t)((lam * (is_b ? g_merge_bits_b : 32)) >> 4);     /* (g_merge_bits_b: experiment hook, tools/rd_eval.py; 32 = the pipeline's value) */
             int bestk = -1;
             kso_cu8 bm = *c;
             const int nx[5] = {x - 1, x + n - 1, x + n, x - 1, x - 1}, ny[5] = {y + n - 1, y - 1, y - 1, y + n, y - 1};   /* A1 B1 B0 A0 B2 */
@@ -803,7 +807,7 @@ static uint32_t decide_node_b(const kso_frame_cfg *cfg, const kso_pu_b *cp, cons
     int idx = pu_index(l, px, py);
     uint32_t own = node_own_cost(cfg, cp[idx].cost, icost, idx, l, use_intra);
     if (l == 3) { split[idx] = 0; return own; }
-    uint64_t sum = (uint64_t)((cfg->lambda_q4 * SPLIT_BITS_B) >> 4);
+    uint64_t sum = (uint64_t)((cfg->lambda_q4 * g_split_bits_b) >> 4);        /* (g_split_bits_b: experiment hook; SPLIT_BITS_B = the pipeline's value) */
     for (int k = 0; k < 4; ++k) sum += decide_node_b(cfg, cp, icost, cx, cy, l + 1, px * 2 + (k & 1), py * 2 + (k >> 1), split, use_intra);
     if (own != COST_INVALID && (uint64_t)own <= sum) { split[idx] = 0; return own; }
     split[idx] = 1;

@@ -189,8 +189,9 @@ class OraclePipeline:
                 else:
                     o.kso_cu_decide_b(cfg, ptr(self.pub), ptr(self.cu8))
                 if self.cfg.merge:
-                    tmp = self.cu8.copy()
-                    o.kso_merge_pass(cfg, self.src.c(), ptr(self.planes), ptr(self.planes1), None, ptr(self.pub), ptr(tmp), ptr(self.cu8))
+                    for _ in range(int(os.environ.get("RD_MERGE_ROUNDS", "1"))):     # (experiment hook of tools/rd_eval.py; the pipeline runs one round)
+                        tmp = self.cu8.copy()
+                        o.kso_merge_pass(cfg, self.src.c(), ptr(self.planes), ptr(self.planes1), None, ptr(self.pub), ptr(tmp), ptr(self.cu8))
                 p1 = ptr(self.planes1)
         if kind == "I" and self.intra:
             o.kso_intra_reconstruct(cfg, self.src.c(), ptr(self.cu8), ptr(self.lvl[0]), ptr(self.lvl[1]), ptr(self.lvl[2]), self.rec.c())

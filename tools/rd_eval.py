@@ -78,6 +78,9 @@ def encode_ours(clip, W, H, qp, gop, tools, verbose=False, stats=None, pdelta=1,
         if kind == 'B' and b_lam:
             ls *= b_lam[min(len(b_lam) - 1, layer)]
         o.set_qp(q, lambda_q4(q) if kind == "I" else (lambda_q4(q, inter=True) if lam_scale == -1 else int(round(lambda_q4(q) * ls))))     # lam_scale -1: the encoder host's integer table (kLambdaInterQ4)
+        if os.environ.get("RD_SPLIT_BITS_B") and kind == 'B':
+            sb = [int(x) for x in os.environ["RD_SPLIT_BITS_B"].split(",")]
+            o.o.kso_experiment_split_bits_b(sb[min(len(sb) - 1, max(layer, 0))])
         if rdo_layers:
             o.cfg.rdo = rdo_layers[0] if kind == 'P' else rdo_layers[min(len(rdo_layers) - 1, layer)] if kind == 'B' else tools.get('rdo', 0)
         nmref = int(os.environ.get('RD_MREF', '1'))                   # experiment: the anchors of the hierarchy search the last RD_MREF anchors
@@ -248,6 +251,8 @@ def main():
     ap.add_argument("--pan", default="", help="pan of the synthetic clip in samples per picture, e.g. 8,5")
     ap.add_argument("--rdoq", type=int, default=0, metavar="MODE", help="experiment: the reference's rdoQuant (oracle/ks265_rdoq_ref.c) at the seam with static bit tables (medians of tests/golden/rdoq.npz); 1 = luma of P / B pictures, +2 chroma, +4 key pictures")
     ap.add_argument("--rdoq-mult", default="", help="the four lambda multipliers (luma sign-hiding, luma, chroma sign-hiding, chroma; reference: 256,256,90,90)")
+    ap.add_argument("--split-bits-b", default="", help="experiment: what a split is taken to cost in a B picture's CU decision (1/16 bit), indexed by B layer (entry 0 unused; pipeline: 80 everywhere)")
+    ap.add_argument("--merge-bits-b", type=int, default=0, metavar="Q4", help="experiment: what explicit motion is taken to cost (1/16 bit) when a B picture's CU weighs a merge candidate (pipeline: 32)")
     ap.add_argument("--rdo-layers", default="", help="cfg.rdo of P pictures and of the B layers 1, 2, 3 (comma separated)")
     ap.add_argument("--b-lam", default="", help="extra lambda factors, indexed by B layer (entry 0 unused)")
     ap.add_argument("--layer-qp", default="", help="QP offsets on top of the P offset, indexed by B layer (entry 0 unused; default = the layer number)")
@@ -283,6 +288,11 @@ def main():
         main._rq_T = T                                                 # keep alive
         mult = (C.c_int * 4)(*[int(x) for x in a.rdoq_mult.split(",")]) if a.rdoq_mult else None
         olib().kso_experiment_rdoq(T.ctypes.data_as(C.c_void_p), a.rdoq, mult)
+    if a.split_bits_b:
+        os.environ["RD_SPLIT_BITS_B"] = a.split_bits_b
+    if a.merge_bits_b:
+        from oracle_lib import lib as olib2
+        olib2().kso_experiment_merge_bits_b(a.merge_bits_b)
     ref = None
     if not a.no_ref:
         with tempfile.NamedTemporaryFile(suffix=".yuv", delete=False) as f:
