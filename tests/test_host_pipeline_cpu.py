@@ -438,8 +438,11 @@ def test_slice_type_decision_codes_blocks_of_eight_as_four_plus_four(stub_lib, t
     # n-th query) change nothing but the moment a picture reaches the scheduler
     for lag in (2, 7, 1000):
         assert run(stub_lib, 100, 128, -1, KS265_STUB_EVENT_LAG=lag, **kw)["md5"] == la["md5"] == run(stub_lib, 100, 128, -1, KS_TEST_LOOKAHEAD=8, KS265_STUB_EVENT_LAG=lag, **kw)["md5"]
+    for seed in (-1, -2, -3, -4, -5, -6):                                # ... or at random moments (a seed: every look is a coin toss) - with the scheduler thread looking as well
+        assert run(stub_lib, 100, 128, -1, KS265_STUB_EVENT_LAG=seed, **kw)["md5"] == la["md5"]
+        assert run(stub_lib, 100, 128, -1, KS_TEST_LOOKAHEAD=8, KS265_STUB_EVENT_LAG=seed, **kw)["md5"] == la["md5"]
     lanes = {L: run(stub_lib, 150, 48, -1, KS265_GOP_LANES=L, **kw) for L in (1, 3)}
-    assert lanes[1]["md5"] == run(stub_lib, 150, 48, -1, KS265_GOP_LANES=2, KS265_STUB_EVENT_LAG=5, **kw)["md5"]
+    assert lanes[1]["md5"] == run(stub_lib, 150, 48, -1, KS265_GOP_LANES=2, KS265_STUB_EVENT_LAG=5, **kw)["md5"] == run(stub_lib, 150, 48, -1, KS265_GOP_LANES=3, KS265_STUB_EVENT_LAG=-9, **kw)["md5"]
     assert lanes[1]["lanes"] == 1 and lanes[3]["lanes"] == 3 and lanes[1]["md5"] == lanes[3]["md5"] and lanes[1]["md5"] != run(stub_lib, 150, 48, -1, KS_TEST_LOOKAHEAD=0, **kw)["md5"]
     assert plain["idr"] == la["idr"] == 1 and sorted(la["pts"]) == list(range(100)) and la["vcl"] == 100
     expect_plain, expect_la = [0], [0]
