@@ -56,14 +56,16 @@ def main():
     ap.add_argument("--steps", type=int, default=128, help="timed steps; the default covers one whole -iper 128 GOP per shard, key picture included")
     ap.add_argument("--lookahead", type=int, default=-1, metavar="N", help="-lookahead N of the encoder host: -1 = its default (IPPP: off; hierarchical-B 8: the slice-type decision runs by itself), 0 = off, "
                     "N > 0 = scene cuts + slice types, every picture analysed")
-    ap.add_argument("--hier-b", type=int, default=0, metavar="G", help="hierarchical-B mini-GOPs of G pictures (power of two, e.g. 8 = the reference's -latency offline default); B pictures of the inner layers are references")
+    ap.add_argument("--hier-b", type=int, default=-1, metavar="G", help="hierarchical-B mini-GOPs of G pictures (power of two). Default (-1): 8 = the GOP the reference codes for this command line "
+                    "(-latency offline default; SURVEY.md 5), with the IPPP variant (-bframes 0) run beside it and reported as `ippp`; 0 = IPPP only (or --bframes N: P + N plain B)")
     ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--qp", type=int, default=27)
     ap.add_argument("--zero-copy", action="store_true", help="encoded leg: produce every picture straight into one of the encoder's pinned input buffers (ks265_enc_acquire_input) instead of handing in a buffer that is copied")
     ap.add_argument("--iper", type=int, default=128)
-    ap.add_argument("--clip-frames", type=int, default=5)
+    ap.add_argument("--clip-frames", type=int, default=33, help="distinct pictures of the synthetic clip (ping-ponged: 2 n - 2 pictures per period); SURVEY.md 8(d) asks for clips, not a handful of pictures - "
+                    "the search kernels' early exits are data dependent")
     ap.add_argument("--me", choices=["dia", "hex", "umh"], default="umh", help="integer search: -preset slow resolves to -me 2 (UMH), SURVEY.md §5")
     ap.add_argument("--me-hex-thr", type=int, default=16, help="tME+0x368 of the reference: with -me 2 a PU whose start-point SAD is below this many units per sample runs "
                     "interMeHex instead of interMeUMH; -preset slow resolves to 16, veryslow to 0 (always UMH)")
@@ -85,6 +87,10 @@ def main():
     ap.add_argument("--out", default=None, help="--scaling strong: rank 0 writes the gathered Annex-B stream here")
     ap.add_argument("--host-threads", type=int, default=0, help="slice-writer threads of the encoded leg per rank (0 = min(32, host cores / ranks))")
     args = ap.parse_args()
+    # round 5: the headline is the GOP the reference itself codes for `-preset slow -rc 0 -qp 27 -iper 128` = hierarchical-B 8; IPPP (`-bframes 0`) runs beside it
+    args.both_gops = args.hier_b < 0 and not args.bframes and args.refs <= 1 and not args.b_spread and args.scaling == "weak"
+    if args.hier_b < 0:
+        args.hier_b = 8 if args.both_gops else 0
 
     import torch
     from ks265codec_amd.lib import KsContext, KsFrame
@@ -123,12 +129,22 @@ def main():
         torch.cuda.synchronize()
 
     encoded = None
+    shared_clip = None
     if args.scaling == "strong":
         args.leg = "encoded"
         if args.b_spread:
             raise SystemExit("--scaling strong splits closed GOPs over the ranks; --b-spread is the other sharding")
     if args.leg != "hot" and not args.b_spread:
-        encoded = encoded_leg(args, torch, dist, rank, world, dev_index, backend, sync_all)
+        import copy
+        shared_clip = None if args.scaling == "strong" else make_clip(W, H, args.clip_frames, seed=7 + rank, abc=(67, 91, 33), pan=(8, 5))
+        encoded = encoded_leg(args, torch, dist, rank, world, dev_index, backend, sync_all, shared_clip)
+        if args.both_gops:
+            a2 = copy.copy(args); a2.hier_b = 0; a2.bframes = 0
+            e2 = encoded_leg(a2, torch, dist, rank, world, dev_index, backend, sync_all, shared_clip)
+            encoded["ippp"] = {"value": round(e2["fps"], 2), "unit": "frames/s", "psnr_y": round(float(e2["psnr_y"]), 3), "bytes_per_picture": int(e2["bytes_per_picture"]),
+                               "kbps_at_50fps": round(e2["bytes_per_picture"] * 8 * 50 / 1000.0, 1), "windows": e2["windows"], "caller_ms_per_picture": e2.get("caller_ms_per_picture"),
+                               "what": "the same encoder, same clip, same run, with -bframes 0 (IPPP): a VARIANT of the metric's command line (BASELINE.md 2: the reference codes the "
+                                       "command line as hierarchical-B 8, which is `value`); rounds 1 - 4 reported this figure as `value`"}
         # round 4: the two-lane leg is gone from the default run (opt in with --two-lanes).  Measured: two GOP lanes code 1.00x, two encoder processes 1.15x
         # what one lane does on the one GPU - every large kernel of the picture fills the CUs on its own - so lanes are for handles that span several GPUs
         encoded["two_lanes"] = None
@@ -151,6 +167,13 @@ def main():
                 dist.barrier(); dist.destroy_process_group()
             return
 
+    # the device-resident leg (roofline / stage times): with the default command it stays on IPPP - every picture but the key picture is a P picture, whose kernels are the ones the
+    # stage events time; the GOP of `value` is the encoded leg's business.  --hier-b G / --bframes N given explicitly run here too
+    args.ref_hier_b = args.hier_b
+    if args.both_gops:
+        args.hier_b = 0
+    shared = shared_clip
+
     def make_shard(sidx):
         """one independent GOP shard: its own context (= HIP stream), frame object, clip, decoded-picture buffer and schedule"""
         # shard 0 lives on torch's default stream; every further shard gets a stream of its own (KsContext adopts the torch stream
@@ -161,7 +184,9 @@ def main():
             ks = KsContext(dev_index)
             fr = KsFrame(ks, W, H, qp, lambda_q4(qp), bframes=max(args.bframes, args.hier_b - 1 if args.hier_b else 0), refs=max(1, args.refs), **hot_tools(args, me_method))
             # synthetic clip of SURVEY.md §8(d), one GOP shard per stream (different seed per shard = different content)
-            clip = make_clip(W, H, args.clip_frames, seed=7 + (0 if args.b_spread else rank * nstreams + sidx), abc=(67, 91, 33), pan=(8, 5))
+            # one clip per rank (the encoded leg's), every shard at its own phase of it (round 5: 33 distinct pictures instead of 5 - one clip per shard would be 1.2 GB of host memory and 3 x the set-up time)
+            clip = shared if shared is not None else make_clip(W, H, args.clip_frames, seed=7 + (0 if args.b_spread else rank), abc=(67, 91, 33), pan=(8, 5))
+            phase = (sidx * (2 * len(clip) - 2)) // max(1, nstreams)
             dev_clip = [ks.dev(c) for c in clip]
             srcs = [fr.new_pic() for _ in clip]
             for d, s in zip(dev_clip, srcs):
@@ -176,7 +201,7 @@ def main():
             state = {"n": 0, "cur": 0, "last": None, "since_key": 0}
 
             def src_of(d):
-                return srcs[order[d % len(order)]]
+                return srcs[order[(d + phase) % len(order)]]
 
             def step_hier():
                 d, kind, r0, r1, layer = next(sched)
@@ -359,6 +384,8 @@ def main():
         # the roofline figure is the SAD kernel's (north_star; VERDICT r3: the kernel alone, not the stage): algorithmic bytes / its own launch duration
         dom = "me_integer"
         algo_bytes = ALGO_BYTES_P[dom] * P
+        if not me_int_kernel_ms or me_int_kernel_ms <= 0:      # ks265_frame_me_int_ms had no valid event pair: fall back to the stage's interval, which contains the kernel
+            me_int_kernel_ms = stage_ms["me_integer"]
         achieved = algo_bytes / (me_int_kernel_ms * 1e-3) / 1e9
         # counters under profiles/ are inputs measured by a rocprofv3 --pmc run of an EARLIER invocation: they count only if they were taken on this very kernel source
         from ks265codec_amd.build import source_sha
@@ -479,7 +506,8 @@ def reference_leg(args, clip, order):
         with open(yuv, "wb") as f:
             for t in range(n):
                 f.write(clip[order[t % len(order)]].tobytes())
-        bf = [] if args.hier_b == 8 else ["-bframes", str(args.hier_b - 1 if args.hier_b else args.bframes)]
+        hb = getattr(args, "ref_hier_b", args.hier_b)                # the GOP of `value` (the hot leg may have switched args.hier_b off for itself)
+        bf = [] if hb == 8 else ["-bframes", str(hb - 1 if hb else args.bframes)]
         cmd = [exe, "-i", yuv, "-wdt", str(W), "-hgt", str(H), "-fr", "50", "-preset", preset, "-rc", "0", "-qp", str(args.qp), "-iper", str(args.iper),
                "-threads", str(threads), "-psnr", "1", "-b", os.path.join(td, "o.265"), *bf]
         t0 = time.perf_counter()
@@ -500,7 +528,7 @@ def reference_leg(args, clip, order):
                       f"same {W}x{H} clip (ping-pong over {len(clip)} pictures), {wall:.1f} s wall incl. reading the .yuv; box has {cores} host threads; FPS as the encoder prints it"}
 
 
-def encoded_leg(args, torch, dist, rank, world, dev_index, backend, sync_all):
+def encoded_leg(args, torch, dist, rank, world, dev_index, backend, sync_all, shared_clip=None):
     """The whole encoder on this rank's GPU through the SDK-compatible C API (libks265enc.so, include/ks265_enc.h): per step one host picture goes
     in (QY265EncoderEncodeFrame: copy to pinned memory, H2D, pixel path, D2H of the records, CABAC on the writer threads), NAL units come out.
     Timed: `steps` pictures incl. the flush that drains the pipeline, bracketed by barriers; the maximum over ranks counts."""
@@ -540,7 +568,7 @@ def encoded_leg(args, torch, dist, rank, world, dev_index, backend, sync_all):
     for k, v in (("wdt", W), ("hgt", H), ("fr", 50), ("rc", 0), ("qp", args.qp), ("iper", args.iper), ("bframes", -1 if args.hier_b == 8 else gop_b), ("threads", threads),
                  ("psnr", 1), ("log", 3), ("lookahead", args.lookahead), ("me", {"dia": 0, "hex": 1, "umh": 2}[args.me]), ("subme", 1), ("ref", max(1, args.refs))):
         assert lib.QY265ConfigParse(cfg, k.encode(), str(v).encode()) == 0, k
-    clip = make_clip(W, H, args.clip_frames, seed=7 + rank, abc=(67, 91, 33), pan=(8, 5))
+    clip = shared_clip if shared_clip is not None else make_clip(W, H, args.clip_frames, seed=7 + rank, abc=(67, 91, 33), pan=(8, 5))
     order = list(range(len(clip))) + list(range(len(clip) - 2, 0, -1))          # ping-pong keeps the motion continuous
     strong = args.scaling == "strong"
     if strong:
@@ -761,6 +789,8 @@ def encoded_line(args, enc, world, hot, cpu):
                                "one encoder per GPU (rank), each on its own synthetic clip = its own closed GOPs; no data-path collective"},
         "roofline": None, "cpu_baseline": cpu,
     }
+    if enc.get("ippp"):
+        line["ippp"] = enc["ippp"]
     if enc.get("two_lanes"):
         line["two_gop_lanes"] = enc["two_lanes"]
     if strong:
@@ -768,7 +798,8 @@ def encoded_line(args, enc, world, hot, cpu):
     if hot is not None:
         line["roofline"] = hot["roofline"]
         line["hot_path"] = {"value": hot["value"], "unit": "frames/s", "psnr_y": hot["psnr_y"], "ms_per_step": hot["ms_per_step"],
-                            "what": "device-resident pixel path only (inputs and outputs stay in HBM, no host): " + hot["config"]["workload"],
+                            "what": "device-resident pixel path only (inputs and outputs stay in HBM, no host), IPPP unless --hier-b / --bframes is given - the leg the stage events and the "
+                                    "roofline of the SAD kernel are taken on (every picture but the key picture is a P picture): " + hot["config"]["workload"],
                             "streams_per_gpu": hot["config"]["streams_per_gpu"], "key_picture_ms": hot["config"]["key_picture_ms"]}
     return line
 

@@ -13,8 +13,11 @@
  *     rc = 3 (CRF) maps crf to that ladder; rc = 1 / 2 / 4 (bitrate targets) run a frame-level controller on top of it (one offset per
  *     mini-GOP from the pictures coded so far: deterministic streams); rc = 5 and VBV are not implemented;
  *   - subme 0 / 1 / 2 and the preset's thresholds run the reference's sub-pel refinement (include/ks265_hip.h ks265_frame_cfg.subme);
- *   - rdoq, transskip, part, tuInter / tuIntra, vpp_*, 2-pass, long-term references, AQ: accepted, ignored (the pixel path has no such
- *     stage yet);
+ *   - part = 1 codes 2NxN / Nx2N prediction units (CUs of 64 / 32 / 16 samples; priced with the vectors of the square search);
+ *     iAqMode / fAqStrength (-aq / -aqs) give every CTU its own QP (cu_qp_delta) from the reference's calcFrameAdaptQuant arithmetic;
+ *   - lookahead: with the default hierarchical GOP (bframes -1 / 7) the slice-type decision (a block of 8 pictures coded as 8 or as 4 + 4)
+ *     runs by itself, so the GOP layout depends on the content unless lookahead = 0; lookahead N > 0 adds scene-cut key pictures;
+ *   - transskip, tuIntra, vpp_*, 2-pass, long-term references, VBV / CVQ: accepted, ignored (the pixel path has no such stage);
  *   - input pictures are COPIED inside QY265EncoderEncodeFrame: the caller may reuse its buffers at once (the SDK requires them to stay
  *     valid until the frame is done).
  */

@@ -177,12 +177,14 @@ __global__ __launch_bounds__(256) void sse_picture_kernel(KsGeom g, const uint8_
         } else
             for (int x = lane * 4; x < w; x += 256) sq4(*(const unsigned *)(a + y * stride + x), *(const unsigned *)(b + y * stride + x));
     }
-    s = wave_sum(s);                                                 // a lane: <= 8 rows x 64 samples x 255^2 < 2^25 at 2160p (rows / (4 x 86) per wave); 8K pictures: < 2^27
-    __shared__ unsigned part[4];
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    // a lane: <= 8 rows x 64 samples x 255^2 < 2^25 at 2160p (rows / (4 x 86) per wave); 8K pictures: < 2^27 - 64 lanes of that pass 2^32, so the wave's sum
+    // is taken in two 16-bit halves (each half's sum < 2^22) and put together in 64 bits
+    const unsigned long long s64 = (unsigned long long)wave_sum(s & 0xffffu) + ((unsigned long long)wave_sum(s >> 16) << 16);
+    __shared__ unsigned long long part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s64;
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned long long t = (unsigned long long)part[0] + part[1] + part[2] + part[3];
+        const unsigned long long t = part[0] + part[1] + part[2] + part[3];
         if (t) atomicAdd(acc + pl, t);
         __threadfence();
         // the last work-group to finish hands the sums out and leaves the accumulators zeroed for the next call (no memset launch per picture)

@@ -94,6 +94,7 @@ __global__ __launch_bounds__(256) void cutree_scatter_kernel(int lg, int nx, int
     if (idx >= nx * ny) return;
     const int bx = idx % nx, by = idx / nx;
     const int sh = lg + 2, unit = 1 << sh, sh2 = 2 * sh, rnd = 1 << (sh2 - 1);
+    if (intra[idx] == 0) return;     // never stored by the reference (calcFrameCost keeps min(cost + 9, 0xffff)); its idiv would trap - skipped here and in the oracle alike
     const long long have = (long long)(((int)((unsigned)invq[idx] * (unsigned)intra[idx] + 128u) >> 8) + (int)own[idx]);
     const int amt = (int)(have * (long long)((int)intra[idx] - (int)inter[idx]) / (long long)intra[idx]);
     if (amt <= 0) return;
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(256) void cutree_scatter_kernel(int lg, int nx, int
             const int tx = x + (k & 1), ty = y + (k >> 1);
             if (tx < 0 || ty < 0 || tx >= nx || ty >= ny) continue;
             const int share = (w[k] * a + rnd) >> sh2;
-            if (share) atomicAdd(&A[ty * nx + tx], (unsigned long long)(share < 0 ? 0 : share));
+            if (share) atomicAdd(&A[ty * nx + tx], (unsigned long long)share);     // a > 0 and the weights are >= 0: never negative
         }
     }
 }

@@ -296,7 +296,7 @@ typedef struct Enc {
      * a record (ks265_frame_set_records_fence).  Measured at 2160p IPPP: 120 us of a 1.11 ms picture period leave the critical path. */
     /* -aq N (iAqMode != 0): adaptive quantisation = the reference's calcFrameAdaptQuant enc@0x4653c0 on the source picture (ks265_frame_adapt_quant, pinned on recorded
      * calls), one QP per CTU from it (ks265_aq_ctu_map), the pixel path and the writer on that map (ks265_frame_set_qp_map, cu_qp_delta) */
-    int aq_on, aq_nx, aq_ny; double *aq_off[2], *aq_scratch[2]; uint16_t *aq_inv[2]; int8_t *dev_qmap[NPIPE];   /* [1]: the key pictures' stream */
+    int aq_on, aq_nx, aq_ny; double *aq_off[2], *aq_scratch[2]; uint16_t *aq_inv[2]; int8_t *dev_qmap[NPIPE], *dev_qmap_key[2];   /* aq_*[1], dev_qmap_key: the key pictures' stream (its own maps, rotating with nkeys: a key picture runs beside the pictures of its rotation slot) */
     int zero_latency;                                     /* -latency zerolatency without B pictures / lookahead / lanes: every EncodeFrame call hands out its own picture */
     int copy_mb;                                          /* KS265_COPYOUT_MB = N: hipMemcpyAsync takes the fixed part + N MB of stored lines per P / B picture (a key picture: everything) and the copy kernel
                                                            * only what lies beyond; default -1 = the copy kernel alone.  On this runtime the D2H hipMemcpyAsync is itself a kernel (__amd_rocclr_copyBuffer,
@@ -654,9 +654,12 @@ static int submit(Enc *e, Input *in, int kind, int poc, int qp, const int *l0, i
         const size_t oy = (size_t)e->geom.pad_y * e->geom.stride_y + e->geom.pad_y, oc = (size_t)e->geom.pad_c * e->geom.stride_c + e->geom.pad_c;
         r = ks265_frame_adapt_quant(ca, srcp.y + oy, e->geom.stride_y, srcp.u + oc, srcp.v + oc, e->geom.stride_c, e->aq_nx, e->aq_ny, e->aq_nx * e->aq_ny, e->cfg.fAqStrength,
                                     e->aq_off[on_key], e->aq_inv[on_key], e->aq_scratch[on_key]);
-        if (!r) r = ks265_aq_ctu_map(ca, e->aq_off[on_key], e->aq_nx, e->aq_ny, qp, e->cfg.rc ? e->cfg.qpmin : 0, e->cfg.rc && e->cfg.qpmax ? e->cfg.qpmax : 51, e->dev_qmap[k]);
-        if (!r) r = ks265_frame_set_qp_map(fr, e->dev_qmap[k]);
-        if (!r) r = ks265_memcpy_d2h_async(ca, j->qp_map, e->dev_qmap[k], (size_t)e->geom.ctu_cols * e->geom.ctu_rows);
+        /* a key picture on its own stream runs beside the pictures of earlier GOPs - among them the one three submissions back, whose kernels still read dev_qmap[k]
+         * (ADVICE r4): it gets a map of its own; everything that touches that one is on the key pictures' stream, in order */
+        int8_t *qm = on_key ? e->dev_qmap_key[e->nkeys & 1] : e->dev_qmap[k];
+        if (!r) r = ks265_aq_ctu_map(ca, e->aq_off[on_key], e->aq_nx, e->aq_ny, qp, e->cfg.rc ? e->cfg.qpmin : 0, e->cfg.rc && e->cfg.qpmax ? e->cfg.qpmax : 51, qm);
+        if (!r) r = ks265_frame_set_qp_map(fr, qm);
+        if (!r) r = ks265_memcpy_d2h_async(ca, j->qp_map, qm, (size_t)e->geom.ctu_cols * e->geom.ctu_rows);
         if (!r && split) { r = ks265_event_record(e->ctx_in, e->ev_h2d[k]); if (!r) r = ks265_stream_wait_event(cx, e->ev_h2d[k]); }   /* (recorded again behind the map: the pixel path waits for this one) */
     }
     int keep[20], nk = 0;
@@ -1055,6 +1058,7 @@ static void lane_close(Enc *e, int report)
         ks265_dev_free(e->ctx, e->dev_sse); ks265_dev_free(e->ctx, e->dev_recon);
         for (int q = 0; q < 2; ++q) { ks265_dev_free(e->ctx, e->aq_off[q]); ks265_dev_free(e->ctx, e->aq_inv[q]); ks265_dev_free(e->ctx, e->aq_scratch[q]); }
         for (int k = 0; k < NPIPE; ++k) ks265_dev_free(e->ctx, e->dev_qmap[k]);
+        for (int q = 0; q < 2; ++q) ks265_dev_free(e->ctx, e->dev_qmap_key[q]);
         if (e->recon_fd >= 0) close(e->recon_fd);
         if (e->ctx_la) {
             ks265_synchronize(e->ctx_la);
@@ -1069,7 +1073,7 @@ static void lane_close(Enc *e, int report)
         if (e->ctx_in) ks265_destroy(e->ctx_in);
         if (e->ctx_out) ks265_destroy(e->ctx_out);
         ks265_destroy(e->ctx);
-    }
+    } else if (e->ctx_la) ks265_destroy(e->ctx_la);                   /* created first (lane_open), before the main context failed: nothing else of the lookahead exists yet */
     for (int i = 0; i < MAX_JOBS; ++i) free(e->jobs[i].wpp);
     free(e->hdr); free(e->outbuf); free(e->md5_ring); free(e->md5_have);
     pthread_mutex_destroy(&e->la_mu);
@@ -1181,6 +1185,7 @@ static Enc *lane_open(QY265EncConfig *cfg, int device, int multi, int *err)
             if (!r) r = ks265_dev_malloc(e->ctx, (void **)&e->aq_scratch[q], 16);
         }
         for (int k = 0; k < NPIPE && !r; ++k) r = ks265_dev_malloc(e->ctx, (void **)&e->dev_qmap[k], (size_t)e->geom.ctu_cols * e->geom.ctu_rows);
+        for (int q = 0; q < 2 && !r; ++q) r = ks265_dev_malloc(e->ctx, (void **)&e->dev_qmap_key[q], (size_t)e->geom.ctu_cols * e->geom.ctu_rows);
     }
     if (!r) r = pic_alloc(e, &e->src);
     e->ndpb = e->hier ? 10 : e->gop_b ? 4 : e->refs + 2;

@@ -56,6 +56,7 @@ void kso_ref_cutree_propagate(int lg, int nx, int ny, const uint16_t *intra, con
         for (int bx = 0; bx < nx; ++bx) {
             const int idx = by * nx + bx;
             /* what this block hands on: (its own cost, AQ-weighted, + what it has inherited) x the share the prediction explains (enc@0x47d5c8..0x47d5fb, 64-bit signed division) */
+            if (intra[idx] == 0) continue;                                    /* the reference's idiv would trap; it never stores 0 (calcFrameCost keeps min(cost + 9, 0xffff)) - same guard as the device operator */
             const int64_t have = ((int)((unsigned)inv_qscale[idx] * (unsigned)intra[idx] + 128u) >> 8) + own[idx];   /* 32-bit product as the reference forms it */
             const int amt = (int)(have * ((int)intra[idx] - (int)inter[idx]) / (int64_t)intra[idx]);
             if (amt <= 0) continue;
