@@ -34,7 +34,6 @@ using namespace ks265;
 #define WIN_STRIDE 204            // 51 dwords (odd): x in [-68, 136)
 #define FENC_STRIDE 68            // 17 dwords (odd)
 #define ME_WLIM 66                // candidates further than this from the PU position are not staged: skipped (oracle chk = 2)
-#define JOB_CAP 256               // job slots per group and round (an owner that does not fit waits a round)
 
 enum { PH_INIT, PH_START, PH_DIA, PH_H6, PH_HSTEP, PH_SQUARE, PH_U1, PH_UCROSS, PH_UHEX6, PH_UBIG, PH_UFINAL, PH_UHW0, PH_UHW, PH_UDW, PH_DONE };
 
@@ -73,12 +72,11 @@ __device__ __forceinline__ unsigned mv_rate(int lam, int x, int y, int pmx, int 
 
 // per-wave engine state (the 64x64 level uses wave 0's copy for the whole work-group)
 struct GroupLds {
-    unsigned short jobs[JOB_CAP];          // stub: owner (4) | candidate index k << 4; 0xFFFF = unused slot
-    int2 desc[16];                         // per PU of the group, published by its owner: centre x | y << 16, candidate-table parameters (DP_*)
+    int4 desc[16];                         // per PU of the group, published by its owner every round: centre x | y << 16, candidate-table parameters (DP_*), number of candidates (0: done)
     unsigned long long best[16][4];        // per PU and slot: (cost << 8 | key) << 32 | (x + 128) << 8 | (y + 128)
     int pred[16];                          // per PU: predictor, x | y << 16
     int fld[16];                           // per PU: pre-search candidate of PH_INIT, x | y << 16
-    int njobs, active;
+    int active;
 };
 struct MeLds {
     uint8_t win[WIN_ROWS * WIN_STRIDE];
@@ -134,7 +132,8 @@ extern "C" void ks265_me_dbg(unsigned long long *out, int reset) { if (reset) { 
 template <bool WG, int LEVEL>
 __device__ __forceinline__ void me_group(const KsGeom &g, int cx, int cy, int range, const MeLim &lm, int lam, int method, int hex_thr, MeLds &L, GroupLds &Q,
                                          int l2n_ /* log2 PUs per side of the group */, int qx0, int qy0 /* PU-grid origin of the group */,
-                                         const ks265_pu *prev_ctu, ks265_pu *out_ctu, const short2 *field, int nb0x, int nb0y, int t /* lane index inside the group's lanes */)
+                                         const ks265_pu *prev_ctu, ks265_pu *out_ctu, const short2 *field, int nb0x, int nb0y, int t /* lane index inside the group's lanes */,
+                                         const unsigned (&fe)[16] /* the lane's source tile: 8 rows x 2 dwords (WG: tile t & 63 of the CTU in raster order; else tile t & 15 of the quadrant in z-order) */)
 {
     constexpr int NT = WG ? 256 : 64;
     constexpr int level = LEVEL, l2n = WG ? 0 : LEVEL - 1; (void)l2n_;        // the engine is compiled per level (round 4: - 2.5 % on the kernel; the tile geometry and the DPP sums are constants)
@@ -148,6 +147,15 @@ __device__ __forceinline__ void me_group(const KsGeom &g, int cx, int cy, int ra
     bool inside = false;
     const int px = qx0 + (t & ((1 << l2n) - 1)), py = qy0 + ((t >> l2n) & ((1 << l2n) - 1));
     const bool is_owner = t < npu;
+    // evaluation geometry of this lane, fixed for the level: its tile, the PU the tile belongs to, which quarter of the PU's candidates it takes
+    int tbx, tby, my_pu, grp; bool first_tile;
+    if (WG) { tbx = (t & 7) * 8; tby = ((t >> 3) & 7) * 8; my_pu = 0; grp = t >> 6; first_tile = (t & 63) == 0; }
+    else {
+        const int z = t & 15, tx = (z & 1) | ((z >> 1) & 2), ty = ((z >> 1) & 1) | ((z >> 2) & 2), shp = 3 - level;
+        tbx = qx0 * S + tx * 8; tby = qy0 * S + ty * 8; grp = t >> 4;
+        my_pu = ((ty >> shp) << l2n) | (tx >> shp);
+        first_tile = level == 3 ? true : level == 2 ? (z & 3) == 0 : z == 0;
+    }
     if (is_owner) {
         inside = ks_pu_inside(g, cx, cy, level, px, py);
         if (inside) {
@@ -192,22 +200,17 @@ __device__ __forceinline__ void me_group(const KsGeom &g, int cx, int cy, int ra
 #ifdef KS_EXP_ME_CLOCK
         const long long tr0 = ME_NOW();
 #endif
-        // ---- owners: publish the phase descriptor, take one job slot per candidate (eligible or not), fill the slots with stubs
-        //      (owner, k); the candidates themselves are expanded by the evaluating lanes
-        bool emitted = false;
+        // ---- owners: publish the phase descriptor (centre, candidate-table parameters, number of candidates) and reset the result slots; the candidates
+        //      themselves are expanded by the evaluating lanes
         const bool pending = o.ph != PH_DONE;
+        bool emitted = false;
         if (WG ? t < 64 : true) {
-            int dp = 0;
-            const int cnt = pending ? phase_desc(o, nstart, dp) : 0;
-            if (t == 0) Q.njobs = 0;
-            __builtin_amdgcn_wave_barrier();
-            if (cnt > 0) {
-                const int base = atomicAdd(&Q.njobs, cnt);                              // slot order is arbitrary: the winner does not depend on it
-                emitted = base + cnt <= JOB_CAP;                                        // an owner that does not fit waits for the next round
-                const int end = min(base + cnt, JOB_CAP);
-                for (int s = base; s < end; ++s) Q.jobs[s] = emitted ? (unsigned short)(t | ((s - base) << 4)) : (unsigned short)0xFFFF;
+            if (is_owner) {
+                int dp = 0;
+                const int cnt = pending ? phase_desc(o, nstart, dp) : 0;
+                emitted = cnt > 0;
+                Q.desc[t] = make_int4((o.mx & 0xFFFF) | (o.my << 16), dp, cnt, 0);
                 if (emitted) {
-                    Q.desc[t] = make_int2((o.mx & 0xFFFF) | (o.my << 16), dp);
                     const unsigned long long inc = (o.ph == PH_INIT || o.ph == PH_START) ? ~0ull : ((unsigned long long)(o.cost << 8) << 32);
                     Q.best[t][0] = inc;
                     if (o.ph == PH_START) { Q.best[t][1] = ~0ull; Q.best[t][2] = ~0ull; Q.best[t][3] = ~0ull; }
@@ -219,90 +222,56 @@ __device__ __forceinline__ void me_group(const KsGeom &g, int cx, int cy, int ra
         bool active;
         if (WG) active = Q.active != 0; else active = __ballot(pending) != 0ull;
         if (!active) break;
-        const int njobs = min(Q.njobs, JOB_CAP);
 #ifdef KS_EXP_ME_CLOCK
         const long long tr1 = ME_NOW();
 #endif
-        // ---- all lanes of the group: one lane = one 8x8 tile of one candidate; NI items per lane are in flight together (their LDS
-        //      round trips - stub, descriptor, table entry, window rows, result slot - overlap instead of queueing behind each other)
-        const int items = njobs << l2t;
-#ifndef KS_ME_NI
-#define KS_ME_NI 1
+        // ---- all lanes: ONE LANE = ONE FIXED 8x8 TILE (its source rows stay in registers, `fe`) x every fourth candidate of the PU the tile belongs to.  Lanes of a PU and a
+        //      candidate group are adjacent (z-order tiles): PU sums by DPP.  No job slots, no source reads from LDS (round 5: the LDS pipe was 55 % busy, 40 % of it source rows)
+        {
+            const int4 dsc = Q.desc[my_pu];
+            const int pr = Q.pred[my_pu];
+            const int dp = dsc.y, cnt = dsc.z;
+            const int cxm = (int)(short)(dsc.x & 0xFFFF), cym = dsc.x >> 16;
+            const int keyadd = (dp >> 24) & 15;
+#ifdef KS_EXP_ME_CLOCK
+            if (t == 0) acc[4] += cnt;
 #endif
-        constexpr int NI = KS_ME_NI;
-        for (int base = 0; base < items; base += NT * NI) {
-            int pu[NI], x[NI], y[NI], key[NI], slot[NI], kk[NI];
-            bool live[NI];
-            unsigned sad[NI], stub[NI];
-            int2 dsc[NI];
-            unsigned ent[NI];
-#pragma unroll
-            for (int n = 0; n < NI; ++n) {
-                const int it = base + n * NT + t;
-                live[n] = it < items;
-                stub[n] = Q.jobs[min(it, items - 1) >> l2t];
-            }
-#pragma unroll
-            for (int n = 0; n < NI; ++n) { pu[n] = stub[n] & 15; kk[n] = (int)(stub[n] >> 4) & 127; dsc[n] = Q.desc[pu[n]]; }
-#pragma unroll
-            for (int n = 0; n < NI; ++n) ent[n] = L.ctab[(dsc[n].y & 63) + (kk[n] & ((dsc[n].y >> 6) & 127))];
-            const uint8_t *p[NI], *f[NI];
-            unsigned sh[NI];
-#pragma unroll
-            for (int n = 0; n < NI; ++n) {
-                const int dp = dsc[n].y, k = kk[n];
-                const unsigned e = ent[n];
+#pragma unroll 1
+            for (int k = grp; k < cnt; k += 4) {
+                const unsigned e = L.ctab[(dp & 63) + (k & ((dp >> 6) & 127))];
                 const int mult = ((dp >> 16) & 15) + ((dp >> 20) & 15) * (k >> ((dp >> 13) & 7));
-                x[n] = (int)(short)(dsc[n].x & 0xFFFF) + (int)(signed char)(e & 0xFF) * mult;
-                y[n] = (dsc[n].x >> 16) + (int)(signed char)((e >> 8) & 0xFF) * mult;
-                const int keyadd = (dp >> 24) & 15;
-                key[n] = keyadd ? k + keyadd : (int)((e >> 16) & 0xFF);
-                slot[n] = (int)(e >> 24);
-                bool cand_on = true;
+                int x = cxm + (int)(signed char)(e & 0xFF) * mult;
+                int y = cym + (int)(signed char)((e >> 8) & 0xFF) * mult;
+                int key = keyadd ? k + keyadd : (int)((e >> 16) & 0xFF);
+                int slot = (int)(e >> 24);
+                bool live = true;
                 if (dp & DP_INIT) {
-                    if (k == 1) { x[n] = 0; y[n] = 0; cand_on = (dp & DP_INIT_ZERO) != 0; }
-                    else if (k == 2) { const int fv = Q.fld[pu[n]]; x[n] = (int)(short)(fv & 0xFFFF); y[n] = fv >> 16; cand_on = (dp & (int)DP_INIT_FIELD) != 0; }
-                    key[n] = k + 1; slot[n] = 0;
+                    if (k == 1) { x = 0; y = 0; live = (dp & DP_INIT_ZERO) != 0; }
+                    else if (k == 2) { const int fv = Q.fld[my_pu]; x = (int)(short)(fv & 0xFFFF); y = fv >> 16; live = (dp & (int)DP_INIT_FIELD) != 0; }
+                    key = k + 1; slot = 0;
                 }
                 // "ranged" phases test the mv range (interMeUMH's cross / hexagon / rings); every candidate must lie in the staged window
-                const bool inr = (dp >> 28) & 1 ? (x[n] >= lm.lox && x[n] <= lm.hix && y[n] >= lm.loy && y[n] <= lm.hiy)
-                                                : (abs(x[n] - lm.ox) <= ME_WLIM && abs(y[n] - lm.oy) <= ME_WLIM);
-                live[n] = live[n] && cand_on && stub[n] != 0xFFFFu && inr;
-                const int tile = (base + n * NT + t) & ((1 << l2t) - 1);
-                const int ppx = qx0 + (pu[n] & ((1 << l2n) - 1)), ppy = qy0 + (pu[n] >> l2n);
-                const int bx = ppx * S + (tile & (tpr - 1)) * 8, by = ppy * S + (tile >> (3 - level)) * 8;
-                const int wx = bx + (live[n] ? x[n] - lm.ox : 0) + WIN_XL, wy = by + (live[n] ? y[n] - lm.oy : 0) + WIN_YT;   // window coordinates are relative to the offset; a dead item reads (and discards) the centre
-                p[n] = L.win + wy * WIN_STRIDE + (wx & ~3);
-                f[n] = L.fenc + by * FENC_STRIDE + bx;
-                sh[n] = wx & 3;
-                sad[n] = 0;
-            }
+                const bool inr = (dp >> 28) & 1 ? (x >= lm.lox && x <= lm.hix && y >= lm.loy && y <= lm.hiy)
+                                                : (abs(x - lm.ox) <= ME_WLIM && abs(y - lm.oy) <= ME_WLIM);
+                live = live && inr;
+                const int wx = tbx + (live ? x - lm.ox : 0) + WIN_XL, wy = tby + (live ? y - lm.oy : 0) + WIN_YT;   // window coordinates are relative to the offset; a dead item reads (and discards) the centre
+                const uint8_t *pw = L.win + wy * WIN_STRIDE + (wx & ~3);
+                const unsigned sh = wx & 3;
+                unsigned sd = 0;
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
-#pragma unroll
-                for (int n = 0; n < NI; ++n) {
-                    const unsigned w0 = *(const unsigned *)(p[n] + r * WIN_STRIDE), w1 = *(const unsigned *)(p[n] + r * WIN_STRIDE + 4), w2 = *(const unsigned *)(p[n] + r * WIN_STRIDE + 8);
-                    const unsigned f0 = *(const unsigned *)(f[n] + r * FENC_STRIDE), f1 = *(const unsigned *)(f[n] + r * FENC_STRIDE + 4);
-                    sad[n] = sad_u8x4(f0, align_bytes(w1, w0, sh[n]), sad[n]);
-                    sad[n] = sad_u8x4(f1, align_bytes(w2, w1, sh[n]), sad[n]);
+                for (int r = 0; r < 8; ++r) {
+                    const unsigned w0 = *(const unsigned *)(pw + r * WIN_STRIDE), w1 = *(const unsigned *)(pw + r * WIN_STRIDE + 4), w2 = *(const unsigned *)(pw + r * WIN_STRIDE + 8);
+                    sd = sad_u8x4(fe[2 * r], align_bytes(w1, w0, sh), sd);
+                    sd = sad_u8x4(fe[2 * r + 1], align_bytes(w2, w1, sh), sd);
                 }
-            }
-#pragma unroll
-            for (int n = 0; n < NI; ++n) {
-                unsigned sd = sad[n];
-                // the tiles of a job are adjacent lanes: 1 / 4 / 16 / 64 of them
-                if (level <= 2) { sd += (unsigned)dpp_mov<KS265_DPP_QUAD_XOR1>((int)sd); sd += (unsigned)dpp_mov<KS265_DPP_QUAD_XOR2>((int)sd); }
+                // the tiles of a PU are adjacent lanes: 1 / 4 / 16 (quadrant levels, z-order) / 64 (the work-group's 64x64 PU: one wave per candidate)
+                if (level == 2 || level <= 1) { sd += (unsigned)dpp_mov<KS265_DPP_QUAD_XOR1>((int)sd); sd += (unsigned)dpp_mov<KS265_DPP_QUAD_XOR2>((int)sd); }
                 if (level <= 1) { sd += (unsigned)dpp_mov<KS265_DPP_ROW_HALF_MIRROR>((int)sd); sd += (unsigned)dpp_mov<KS265_DPP_ROW_MIRROR>((int)sd); }
                 if (level == 0) { sd += (unsigned)__builtin_amdgcn_ds_swizzle((int)sd, 0x1F | (16 << 10)); sd += (unsigned)__shfl_xor((int)sd, 32, 64); }
-                sad[n] = sd;
-            }
-#pragma unroll
-            for (int n = 0; n < NI; ++n) {
-                if (live[n] && ((base + n * NT + t) & ((1 << l2t) - 1)) == 0) {
-                    const int pr = Q.pred[pu[n]];
-                    const unsigned cost = sad[n] + mv_rate(lam, x[n], y[n], (int)(short)(pr & 0xFFFF), pr >> 16);
-                    const unsigned long long v = ((unsigned long long)((cost << 8) | (unsigned)key[n]) << 32) | (unsigned long long)(((unsigned)(x[n] - lm.ox + 128) << 8) | (unsigned)(y[n] - lm.oy + 128));
-                    atomicMin(&Q.best[pu[n]][slot[n]], v);
+                if (live && first_tile) {
+                    const unsigned cost = sd + mv_rate(lam, x, y, (int)(short)(pr & 0xFFFF), pr >> 16);
+                    const unsigned long long v = ((unsigned long long)((cost << 8) | (unsigned)key) << 32) | (unsigned long long)(((unsigned)(x - lm.ox + 128) << 8) | (unsigned)(y - lm.oy + 128));
+                    atomicMin(&Q.best[my_pu][slot], v);
                 }
             }
         }
@@ -398,7 +367,7 @@ __device__ __forceinline__ void me_group(const KsGeom &g, int cx, int cy, int ra
             } while (true);
         }
 #ifdef KS_EXP_ME_CLOCK
-        { const long long tr3 = ME_NOW(); acc[0] += 1; acc[1] += tr1 - tr0; acc[2] += tr2 - tr1; acc[3] += tr3 - tr2; acc[4] += njobs; }
+        { const long long tr3 = ME_NOW(); acc[0] += 1; acc[1] += tr1 - tr0; acc[2] += tr2 - tr1; acc[3] += tr3 - tr2; }
 #endif
     }
 #ifdef KS_EXP_ME_CLOCK
@@ -511,16 +480,28 @@ __global__ __launch_bounds__(256, 3) void me_int_kernel(KsGeom g, int range, int
     return;
 #endif
     // the 64x64 PU: the whole work-group
-    me_group<true, 0>(g, cx, cy, range, lm, lam, method, hex_thr, L, L.grp[0], 0, 0, 0, prev_ctu, out_ctu, field, nb0x, nb0y, tid);
+    unsigned fe[16];
+    {
+        const uint8_t *pf = L.fenc + ((tid >> 3) & 7) * 8 * FENC_STRIDE + (tid & 7) * 8;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { fe[2 * r] = *(const unsigned *)(pf + r * FENC_STRIDE); fe[2 * r + 1] = *(const unsigned *)(pf + r * FENC_STRIDE + 4); }
+    }
+    me_group<true, 0>(g, cx, cy, range, lm, lam, method, hex_thr, L, L.grp[0], 0, 0, 0, prev_ctu, out_ctu, field, nb0x, nb0y, tid, fe);
     __syncthreads();                                                                    // its vector is the predictor of everything below
 #ifdef KS_EXP_ME_CLOCK
     const long long tk2 = ME_NOW();
 #endif
     // 32x32, 16x16, 8x8: one quadrant per wave, each wave on its own
     const int qx = wave & 1, qy = wave >> 1;
-    me_group<false, 1>(g, cx, cy, range, lm, lam, method, hex_thr, L, L.grp[wave], 0, qx, qy, prev_ctu, out_ctu, field, nb0x, nb0y, lane);
-    me_group<false, 2>(g, cx, cy, range, lm, lam, method, hex_thr, L, L.grp[wave], 1, qx << 1, qy << 1, prev_ctu, out_ctu, field, nb0x, nb0y, lane);
-    me_group<false, 3>(g, cx, cy, range, lm, lam, method, hex_thr, L, L.grp[wave], 2, qx << 2, qy << 2, prev_ctu, out_ctu, field, nb0x, nb0y, lane);
+    {
+        const int z = lane & 15, tx = (z & 1) | ((z >> 1) & 2), ty = ((z >> 1) & 1) | ((z >> 2) & 2);
+        const uint8_t *pf = L.fenc + (qy * 32 + ty * 8) * FENC_STRIDE + qx * 32 + tx * 8;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { fe[2 * r] = *(const unsigned *)(pf + r * FENC_STRIDE); fe[2 * r + 1] = *(const unsigned *)(pf + r * FENC_STRIDE + 4); }
+    }
+    me_group<false, 1>(g, cx, cy, range, lm, lam, method, hex_thr, L, L.grp[wave], 0, qx, qy, prev_ctu, out_ctu, field, nb0x, nb0y, lane, fe);
+    me_group<false, 2>(g, cx, cy, range, lm, lam, method, hex_thr, L, L.grp[wave], 1, qx << 1, qy << 1, prev_ctu, out_ctu, field, nb0x, nb0y, lane, fe);
+    me_group<false, 3>(g, cx, cy, range, lm, lam, method, hex_thr, L, L.grp[wave], 2, qx << 2, qy << 2, prev_ctu, out_ctu, field, nb0x, nb0y, lane, fe);
 #ifdef KS_EXP_ME_CLOCK
     const long long tk3 = ME_NOW();
     if (lane == 0) { atomicAdd(&ks_me_dbg[6], (unsigned long long)(tk1 - tk0)); atomicAdd(&ks_me_dbg[7], (unsigned long long)(tk2 - tk1)); atomicAdd(&ks_me_dbg[14], (unsigned long long)(tk3 - tk2)); atomicAdd(&ks_me_dbg[15], 1ull); }

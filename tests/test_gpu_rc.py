@@ -201,6 +201,30 @@ def test_adaptive_quantisation(tmp_path, gop):
     assert open(plain[4], "rb").read() != open(out, "rb").read()
 
 
+@pytest.mark.parametrize("gop", ["ippp", "hier"])
+def test_adaptive_quantisation_with_key_pictures_on_their_own_stream(tmp_path, gop):
+    """ADVICE r4 (high): with -iper >= 32 a key picture is coded on its own stream BESIDE the last pictures of the GOP before it; its QP map used to share the rotation slot's buffer
+    with a picture still running.  The -o dump switches that overlap off, so: (1) with -o (no overlap) the stream decodes to the encoder's reconstruction; (2) WITHOUT -o (overlap on,
+    three key pictures) the encoder writes the same bytes, run after run - a map overwritten under a running picture makes slice and pixels disagree and the bytes move"""
+    from ks265codec_amd import stream
+    from ks265codec_amd.synth import make_clip
+    W, H, n = 1280, 720, 100
+    base = make_clip(W, H, 26, seed=W + n, abc=(37, 53, 19), pan=(5, 3))
+    order = list(range(26)) + list(range(24, 0, -1))
+    clip = base[[order[t % len(order)] for t in range(n)]]
+    opts = ["-preset", "slow", "-rc", "0", "-qp", "30", "-iper", "32", "-aq", "1", "-aqs", "1.5"] + (["-bframes", "0"] if gop == "ippp" else [])
+    log, per, kbps, rec, out = _encode(tmp_path, clip, W, H, opts)
+    assert len(per) == n and sum(k == "I" for _, k, _, _ in per) == 4
+    _decoder_check(tmp_path, out, rec, n, W * H * 3 // 2)
+    want = open(out, "rb").read()
+    yuv = tmp_path / "o.yuv"
+    for run in range(3):
+        o2 = tmp_path / f"overlap{run}.265"
+        r = subprocess.run([stream.CLI, "-i", str(yuv), "-wdt", str(W), "-hgt", str(H), "-fr", "50", *opts, "-threads", "16", "-b", str(o2)], capture_output=True, text=True)
+        assert r.returncode == 0 and "H265 encoder passed!!!" in r.stdout, r.stdout[-600:] + r.stderr[-600:]
+        assert open(o2, "rb").read() == want, f"run {run}: the stream coded with key pictures on their own stream differs from the one coded without the overlap"
+
+
 def test_crf_job_over_two_lanes(tmp_path):
     """VERDICT r3 #9: -rc 3 with the GOPs dealt to two lanes (KS265_DEVICES=0,0 names this box's one GPU twice) is byte for byte the one-lane stream"""
     from ks265codec_amd.synth import make_clip
