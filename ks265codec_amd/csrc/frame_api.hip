@@ -39,6 +39,11 @@ int ks265_frame_create(ks265_ctx *ctx, const ks265_frame_cfg *cfg, ks265_frame *
     if (!r && cfg->propagate) r = dev_alloc(ctx, (void **)&f->pu_s, (size_t)geom.bytes_pu, true);
     if (!r && cfg->bframes > 0) {
         r = dev_alloc(ctx, (void **)&f->pu1, (size_t)geom.bytes_pu, true);
+        if (!r && cfg->propagate) r = dev_alloc(ctx, (void **)&f->pu_s2, (size_t)geom.bytes_pu, true);
+        if (!r) r = ks265_hip(ctx, hipStreamCreateWithFlags(&f->side, hipStreamNonBlocking));
+        if (!r) r = ks265_hip(ctx, hipEventCreateWithFlags(&f->ev_fork, hipEventDisableTiming));
+        if (!r) r = ks265_hip(ctx, hipEventCreateWithFlags(&f->ev_join, hipEventDisableTiming));
+        f->b_parallel = getenv("KS265_B_SERIAL") ? 0 : 1;
         if (!r) r = dev_alloc(ctx, (void **)&f->pub, (size_t)geom.ctu_cols * geom.ctu_rows * 85 * sizeof(ks265_pu_b), true);
     }
     for (int x = 0; x + 1 < cfg->refs && !r; ++x) {              /* list-0 pictures 1..refs-1 of multi-reference P pictures */
@@ -74,7 +79,12 @@ void ks265_frame_destroy(ks265_frame *f)
     if (f->ctx) { (void)hipSetDevice(f->ctx->device); (void)hipStreamSynchronize(f->ctx->stream); }
     for (int i = 0; i <= KS_NSTAGE; ++i)
         if (f->ev[i]) (void)hipEventDestroy(f->ev[i]);
-    void *ptrs[] = {f->pu1, f->pu_s, f->pub, f->pu[0], f->pu[1], f->cu8, f->sao, f->lvl[0], f->lvl[1], f->lvl[2], f->deb[0], f->deb[1], f->deb[2], f->sse, f->sse_acc, f->cu8_tmp, f->progress, f->mats, f->icost, f->rect, f->pu_x[0], f->pu_x[1], f->pu_x[2]};
+    if (f->side) { (void)hipStreamSynchronize(f->side); (void)hipStreamDestroy(f->side); }
+    if (f->ev_fork) (void)hipEventDestroy(f->ev_fork);
+    if (f->ev_join) (void)hipEventDestroy(f->ev_join);
+    for (int i = 0; i < 10; ++i)
+        if (f->pyr2[i] && f->pyr2[i] != f->pyr[i]) (void)hipFree(f->pyr2[i]);
+    void *ptrs[] = {f->pu_s2, f->pu1, f->pu_s, f->pub, f->pu[0], f->pu[1], f->cu8, f->sao, f->lvl[0], f->lvl[1], f->lvl[2], f->deb[0], f->deb[1], f->deb[2], f->sse, f->sse_acc, f->cu8_tmp, f->progress, f->mats, f->icost, f->rect, f->pu_x[0], f->pu_x[1], f->pu_x[2]};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (uint8_t *p : f->pyr)
@@ -218,10 +228,32 @@ int ks265_encode_picture_b(ks265_frame *f, ks265_pic src, ks265_pic ref0, ks265_
     if (!f->pu1) return KS265_NOTSUPPORTED;                   /* created with cfg.bframes == 0 */
     int r;
     ks265_pu *pu0 = f->pu[f->cur_pu];                         /* scratch: the next P picture overwrites it */
+    const bool par = f->b_parallel && f->side && f->cfg.pre_search && (!f->cfg.propagate || f->pu_s2);
+    if (par) {
+        /* the two searches are independent chains (pre-search, integer search, propagation, sub-pel refinement: ~ 0.4 ms each at 2160p, each kernel with a long tail of
+         * half-empty CUs): list 1's is enqueued on the side stream with its own workspace and runs beside list 0's; the join is in front of the bi-predictive decision */
+        if ((r = ks265_presearch_source(f, src))) return r;                        /* the source pyramid both use, once, before the fork */
+        if ((r = ks265_hip(f->ctx, hipEventRecord(f->ev_fork, f->ctx->stream)))) return r;
+        if ((r = ks265_hip(f->ctx, hipStreamWaitEvent(f->side, f->ev_fork, 0)))) return r;
+        hipStream_t mainst = f->ctx->stream;
+        auto swap_ws = [&]() { for (int i = 0; i < 10; ++i) { uint8_t *t = f->pyr[i]; f->pyr[i] = f->pyr2[i]; f->pyr2[i] = t; } ks265_pu *t = f->pu_s; f->pu_s = f->pu_s2; f->pu_s2 = t; };
+        f->src_pyr_ready = true;
+        f->ctx->stream = f->side; swap_ws();
+        r = me_search(f, src, ref1, nullptr, f->pu1);
+        if (!r && f->cfg.subme) r = ks265_me_subpel(f, src, ref1, f->pu1);
+        if (!r) r = ks265_hip(f->ctx, hipEventRecord(f->ev_join, f->side));
+        f->ctx->stream = mainst; swap_ws();
+        if (!r) r = me_search(f, src, ref0, nullptr, pu0);
+        if (!r && f->cfg.subme) r = ks265_me_subpel(f, src, ref0, pu0);
+        f->src_pyr_ready = false;
+        if (r) return r;
+        if ((r = ks265_hip(f->ctx, hipStreamWaitEvent(f->ctx->stream, f->ev_join, 0)))) return r;
+    } else {
     if ((r = me_search(f, src, ref0, nullptr, pu0))) return r;
     if (f->cfg.subme && (r = ks265_me_subpel(f, src, ref0, pu0))) return r;
     if ((r = me_search(f, src, ref1, nullptr, f->pu1))) return r;
     if (f->cfg.subme && (r = ks265_me_subpel(f, src, ref1, f->pu1))) return r;
+    }
     if ((r = ks265_bi_decide(f, src, ref0, ref1, pu0, f->pu1, f->pub))) return r;
     const bool ii = f->cfg.intra_inter != 0;
     if (ii && (r = ks265_intra_candidates(f, src, f->pub, f->icost))) return r;

@@ -49,6 +49,14 @@ struct ks265_frame {
     void *rect = nullptr;                                  // cfg.part: the 2NxN / Nx2N records of the P picture being coded (KsRect, 21 per CTU)
     uint32_t *icost = nullptr;                             // cfg.intra_inter: intra candidates of the P / B picture being coded (85 per CTU: cost << 6 | mode)
     uint8_t *pyr[10] = {};              // pre-search (cfg.pre_search): L1 / L2 of the source, L1 / L2 of the reference, L2 / L1 vectors, the 16x16 field, L3 of both, CTU window offsets
+    // round 5: the two uni-directional searches of a B picture are independent chains of latency-bound kernels - list 1's runs on a side stream beside list 0's
+    // (ks265_encode_picture_b).  Its own pre-search workspace (the source pyramid [0] [1] [7] is shared and built once, before the fork), propagation scratch, stream, fork / join events
+    uint8_t *pyr2[10] = {};
+    ks265_pu *pu_s2 = nullptr;
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool src_pyr_ready = false;         // ks265_presearch: the source picture's pyramid is in place (skip its pyr_down launch)
+    int b_parallel = 1;                 // 0: the two searches one after the other on the context's stream (graph capture, experiments: KS265_B_SERIAL)
     // optional in-situ stage timing (HIP events on the context's stream, between the stages of ks265_encode_picture)
     bool profiling = false;
     hipEvent_t ev[KS_NSTAGE + 1] = {};
@@ -92,6 +100,7 @@ __device__ __forceinline__ void ctu_mv_limits(const KsGeom &g, int range, int cx
 }
 
 int ks265_frame_build_matrices(ks265_frame *f);      // frame_recon.hip
+int ks265_presearch_source(ks265_frame *f, ks265_pic src);   // frame_presearch.hip
 
 // every frame-level entry point: the calling thread's current device is the frame's (a host with one encoder lane per GPU drives several devices from several
 // threads; kernel launches go to the CURRENT device's streams only)

@@ -120,6 +120,12 @@ __device__ __forceinline__ int phase_desc(const Owner &o, int nstart, int &dp)
     }
 }
 
+#ifdef KS_EXP_ME_TRACE
+// experiment build (-DKS_EXP_ME_TRACE, scratch/me_trace.py): per work-group the 100 MHz wall clock at its start, after the prologue, after the 64x64 level and when each of
+// its waves ends, + the compute unit it ran on - where the kernel's time goes between "mean wave lifetime x rounds" and what rocprof reports
+__device__ unsigned long long ks_me_trace[8 * 4096];
+extern "C" void ks265_me_trace(unsigned long long *out, int n) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(ks_me_trace), sizeof(unsigned long long) * (size_t)n); }
+#endif
 #ifdef KS_EXP_ME_CLOCK
 __device__ unsigned long long ks_me_dbg[32];      // per level: [0] rounds, [1] emit, [2] eval, [3] advance cycles, [4] jobs, [5] level cycles (wave 0 lane 0)
 extern "C" void ks265_me_dbg(unsigned long long *out, int reset) { if (reset) { unsigned long long z[32] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(ks_me_dbg), z, sizeof z); } else (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(ks_me_dbg), sizeof(unsigned long long) * 32); }
@@ -393,6 +399,9 @@ __global__ __launch_bounds__(256, 3) void me_int_kernel(KsGeom g, int range, int
     const long long tk0 = ME_NOW();
 #endif
     const int ctu = ks_xcd_swizzle(blockIdx.x, g.ctu_cols * g.ctu_rows), cx = ctu % g.ctu_cols, cy = ctu / g.ctu_cols;
+#ifdef KS_EXP_ME_TRACE
+    if (tid == 0 && ctu < 4096) { unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); ks_me_trace[ctu * 8] = wall_clock64(); ks_me_trace[ctu * 8 + 7] = ((unsigned long long)blockIdx.x << 32) | hw; }
+#endif
     const uint8_t *R = ks_org_y(g, ref), *Sp = ks_org_y(g, src);
     MeLim lm;
     {
@@ -479,6 +488,9 @@ __global__ __launch_bounds__(256, 3) void me_int_kernel(KsGeom g, int range, int
     if (tid == 0) out_ctu[0].cost = L.win[tid * 7] + L.fenc[9];
     return;
 #endif
+#ifdef KS_EXP_ME_TRACE
+    if (tid == 0 && ctu < 4096) ks_me_trace[ctu * 8 + 1] = wall_clock64();
+#endif
     // the 64x64 PU: the whole work-group
     unsigned fe[16];
     {
@@ -491,6 +503,9 @@ __global__ __launch_bounds__(256, 3) void me_int_kernel(KsGeom g, int range, int
 #ifdef KS_EXP_ME_CLOCK
     const long long tk2 = ME_NOW();
 #endif
+#ifdef KS_EXP_ME_TRACE
+    if (tid == 0 && ctu < 4096) ks_me_trace[ctu * 8 + 2] = wall_clock64();
+#endif
     // 32x32, 16x16, 8x8: one quadrant per wave, each wave on its own
     const int qx = wave & 1, qy = wave >> 1;
     {
@@ -502,6 +517,9 @@ __global__ __launch_bounds__(256, 3) void me_int_kernel(KsGeom g, int range, int
     me_group<false, 1>(g, cx, cy, range, lm, lam, method, hex_thr, L, L.grp[wave], 0, qx, qy, prev_ctu, out_ctu, field, nb0x, nb0y, lane, fe);
     me_group<false, 2>(g, cx, cy, range, lm, lam, method, hex_thr, L, L.grp[wave], 1, qx << 1, qy << 1, prev_ctu, out_ctu, field, nb0x, nb0y, lane, fe);
     me_group<false, 3>(g, cx, cy, range, lm, lam, method, hex_thr, L, L.grp[wave], 2, qx << 2, qy << 2, prev_ctu, out_ctu, field, nb0x, nb0y, lane, fe);
+#ifdef KS_EXP_ME_TRACE
+    if (lane == 0 && ctu < 4096) ks_me_trace[ctu * 8 + 3 + wave] = wall_clock64();
+#endif
 #ifdef KS_EXP_ME_CLOCK
     const long long tk3 = ME_NOW();
     if (lane == 0) { atomicAdd(&ks_me_dbg[6], (unsigned long long)(tk1 - tk0)); atomicAdd(&ks_me_dbg[7], (unsigned long long)(tk2 - tk1)); atomicAdd(&ks_me_dbg[14], (unsigned long long)(tk3 - tk2)); atomicAdd(&ks_me_dbg[15], 1ull); }

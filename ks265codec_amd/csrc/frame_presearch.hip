@@ -331,7 +331,27 @@ static int presearch_alloc(ks265_frame *f)
         if (r) return r;
         f->pyr[i] = (uint8_t *)p;
     }
+    if (f->pu1)                                                      /* B pictures: list 1's own reference pyramid, vector fields and window offsets (the source pyramid is shared) */
+        for (int i = 0; i < 10; ++i) {
+            if (i == 0 || i == 1 || i == 7) { f->pyr2[i] = f->pyr[i]; continue; }
+            void *p = nullptr;
+            const int r = ks265_hip(f->ctx, hipMalloc(&p, sz[i]));
+            if (r) return r;
+            f->pyr2[i] = (uint8_t *)p;
+        }
     return KS265_OK;
+}
+
+/* the source picture's pyramid alone (a B picture builds it once for its two searches) */
+int ks265_presearch_source(ks265_frame *f, ks265_pic src)
+{
+    KS_FRAME_CHECK(f);
+    int r = presearch_alloc(f);
+    if (r) return r;
+    const KsGeom &g = f->g;
+    const dim3 gd((unsigned)((g.W + 127) / 128), (unsigned)((g.H + 127) / 128));
+    hipLaunchKernelGGL(pyr_down_kernel, gd, dim3(256), 0, f->ctx->stream, g, src.y, f->pyr[0], f->pyr[1], f->pyr[7]);
+    return ks265_check_launch(f->ctx);
 }
 
 extern "C" int ks265_presearch(ks265_frame *f, ks265_pic src, ks265_pic ref, int16_t *dev_field, int16_t *dev_ctu_off)
@@ -349,7 +369,7 @@ extern "C" int ks265_presearch(ks265_frame *f, ks265_pic src, ks265_pic ref, int
     short2 *ctu_off = dev_ctu_off ? (short2 *)dev_ctu_off : (short2 *)f->pyr[9];
     hipStream_t st = f->ctx->stream;
     const dim3 gd((unsigned)((g.W + 127) / 128), (unsigned)((g.H + 127) / 128));
-    hipLaunchKernelGGL(pyr_down_kernel, gd, dim3(256), 0, st, g, src.y, c1, c2, c3);
+    if (!f->src_pyr_ready) hipLaunchKernelGGL(pyr_down_kernel, gd, dim3(256), 0, st, g, src.y, c1, c2, c3);
     hipLaunchKernelGGL(pyr_down_kernel, gd, dim3(256), 0, st, g, ref.y, r1, r2, r3);
     const int R = max((f->cfg.me_range >> 2) - 1, 1), R3 = max(f->cfg.me_range >> 2, 1), wrows = 8 + ((8 + 2 * R + 7) & ~7);
     if (2 * R + 1 > 64 || (2 * R3 + 1) * (2 * R3 + 1) > 65535) return KS265_NOTSUPPORTED;   // one lane per horizontal displacement (me_range <= 128)
