@@ -137,6 +137,17 @@ int ks265_quant_batch(ks265_ctx *, int n, const int16_t *dev_coef, int16_t *dev_
  * first level's sign; packed N x N blocks, levels in place; scan_idx 0 diagonal, 1 horizontal, 2 vertical (N <= 8 only, as in H.265).
  * Blocks with fewer than two levels are left alone (postQuant does not call the function for them). */
 int ks265_sign_hiding_batch(ks265_ctx *, int n, int scan_idx, int16_t *dev_lvl, const int16_t *dev_coef, const int16_t *dev_deltaU, int nblk);
+/* rdoQuant enc@0x4aac50 (EncQuant.cpp; `rdoq`, qy265enc.h:129: on from -preset fast upward) - the reference's rate-distortion optimised
+ * quantisation of one transform block, batched: one wave per block.  Per block: levels (in: H265QuantBlock's output rounded at 1/2, out: the decision with signs) and
+ * transform coefficients, N x N packed at `off`; dq / per = QuantParam+0xc / +0x14; lam / lam_sdh = the two integer lambdas ((int64)(weight x 0.85 x 2^((qp - 12) / 3) + 0.5),
+ * weights -rdoql / -rdoqls, chroma -rdoqc / -rdoqcs); tab = index of the block's 180-word bit table in dev_tables (estBitRdoq enc@0x46a8a0's output for the block's size and
+ * component: a host snapshot of the entropy coder's context states); last_pos / dev_sigmask (64 words per block, group scan order, bit 15 - position) = what the quantiser's
+ * bookkeeping hands over (scanSigFlags enc@0x4a9b00 lineage), updated; tu5 = TTransUnit+5, flag_a4c0 = TCtuInfo+0xa4c0 (which coded-block-flag words price "all zero");
+ * sdh = sign-data hiding (cfg+0x3e0).  dev_out[2 i] = number of non-zero levels, dev_out[2 i + 1] = new last scan position (-1: none); dev_hidden[i] = groups that hide a sign.
+ * Pinned on calls recorded inside appencoder runs: tests/golden/rdoq.npz, tests/test_gpu_rdoq.py. */
+typedef struct { int32_t off, tab, dq, last_pos; int64_t lam, lam_sdh; int8_t log2, scan_idx, comp, per, tu5, flag_a4c0, sdh, rsv; } ks265_rdoq_tu;
+int ks265_rdoq_batch(ks265_ctx *, const ks265_rdoq_tu *dev_tus, int n, int16_t *dev_lvl, const int16_t *dev_coef, const int32_t *dev_tables, uint16_t *dev_sigmask,
+                     int32_t *dev_out, uint64_t *dev_hidden);
 /* g_DeQuantFuncs (H265DeQuantBlock_c enc@0x439210): full-block form (lastX = lastY = N-1) */
 int ks265_dequant_batch(ks265_ctx *, int n, const int16_t *dev_lvl, int16_t *dev_coef, int scale, int add,
                         int shift, int nblk);

@@ -28,6 +28,7 @@ int ks265_frame_create(ks265_ctx *ctx, const ks265_frame_cfg *cfg, ks265_frame *
     if ((long long)geom.bytes_y >= (1ll << 31)) return KS265_NOTSUPPORTED;         /* stage B addresses a luma plane with 32-bit offsets */
     ks265_frame *f = new ks265_frame();                                            /* every validation above: nothing to undo on those returns */
     f->ctx = ctx; f->cfg = *cfg; f->geom = geom;
+    f->me_order_off = getenv("KS265_ME_ORDER_OFF") ? 1 : 0;
     KsGeom &g = f->g;
     g.W = cfg->width; g.H = cfg->height; g.sy = geom.stride_y; g.sc = geom.stride_c; g.bytes_y = geom.bytes_y; g.bytes_c = geom.bytes_c;
     g.ctu_cols = geom.ctu_cols; g.ctu_rows = geom.ctu_rows; g.w8 = cfg->width / 8; g.h8 = cfg->height / 8;
@@ -80,6 +81,7 @@ void ks265_frame_destroy(ks265_frame *f)
     for (int i = 0; i <= KS_NSTAGE; ++i)
         if (f->ev[i]) (void)hipEventDestroy(f->ev[i]);
     if (f->side) { (void)hipStreamSynchronize(f->side); (void)hipStreamDestroy(f->side); }
+    for (int i = 0; i < 2; ++i) { if (f->me_work_all[i]) (void)hipFree(f->me_work_all[i]); if (f->me_order_all[i]) (void)hipFree(f->me_order_all[i]); }
     if (f->ev_fork) (void)hipEventDestroy(f->ev_fork);
     if (f->ev_join) (void)hipEventDestroy(f->ev_join);
     for (int i = 0; i < 10; ++i)
@@ -236,7 +238,11 @@ int ks265_encode_picture_b(ks265_frame *f, ks265_pic src, ks265_pic ref0, ks265_
         if ((r = ks265_hip(f->ctx, hipEventRecord(f->ev_fork, f->ctx->stream)))) return r;
         if ((r = ks265_hip(f->ctx, hipStreamWaitEvent(f->side, f->ev_fork, 0)))) return r;
         hipStream_t mainst = f->ctx->stream;
-        auto swap_ws = [&]() { for (int i = 0; i < 10; ++i) { uint8_t *t = f->pyr[i]; f->pyr[i] = f->pyr2[i]; f->pyr2[i] = t; } ks265_pu *t = f->pu_s; f->pu_s = f->pu_s2; f->pu_s2 = t; };
+        auto swap_ws = [&]() {
+            for (int i = 0; i < 10; ++i) { uint8_t *t = f->pyr[i]; f->pyr[i] = f->pyr2[i]; f->pyr2[i] = t; }
+            ks265_pu *t = f->pu_s; f->pu_s = f->pu_s2; f->pu_s2 = t;
+            if (f->me_work) { const bool side = f->me_work == f->me_work_all[0]; f->me_work = f->me_work_all[side]; f->me_order = f->me_order_all[side]; }
+        };
         f->src_pyr_ready = true;
         f->ctx->stream = f->side; swap_ws();
         r = me_search(f, src, ref1, nullptr, f->pu1);

@@ -55,6 +55,10 @@ struct ks265_frame {
     ks265_pu *pu_s2 = nullptr;
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // heavy-first dispatch of the integer search (frame_me_int.hip me_order_kernel): rounds per CTU wave of the previous search, the order built from them; [1] = the side stream's
+    unsigned *me_work = nullptr, *me_work_all[2] = {nullptr, nullptr};
+    int *me_order = nullptr, *me_order_all[2] = {nullptr, nullptr};
+    int me_order_off = 0;               // KS265_ME_ORDER_OFF: experiments
     bool src_pyr_ready = false;         // ks265_presearch: the source picture's pyramid is in place (skip its pyr_down launch)
     int b_parallel = 1;                 // 0: the two searches one after the other on the context's stream (graph capture, experiments: KS265_B_SERIAL)
     // optional in-situ stage timing (HIP events on the context's stream, between the stages of ks265_encode_picture)

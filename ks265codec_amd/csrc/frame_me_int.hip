@@ -136,7 +136,7 @@ extern "C" void ks265_me_dbg(unsigned long long *out, int reset) { if (reset) { 
 // candidates (work-group barriers between the steps of a round).  WG = false: the group is the part of a level that lies in one 32x32
 // quadrant (1 / 4 / 16 PUs) and belongs to ONE WAVE: owners = its first lanes, evaluation = its 64 lanes, no barrier at all.
 template <bool WG, int LEVEL>
-__device__ __forceinline__ void me_group(const KsGeom &g, int cx, int cy, int range, const MeLim &lm, int lam, int method, int hex_thr, MeLds &L, GroupLds &Q,
+__device__ __forceinline__ int me_group(const KsGeom &g, int cx, int cy, int range, const MeLim &lm, int lam, int method, int hex_thr, MeLds &L, GroupLds &Q,
                                          int l2n_ /* log2 PUs per side of the group */, int qx0, int qy0 /* PU-grid origin of the group */,
                                          const ks265_pu *prev_ctu, ks265_pu *out_ctu, const short2 *field, int nb0x, int nb0y, int t /* lane index inside the group's lanes */,
                                          const unsigned (&fe)[16] /* the lane's source tile: 8 rows x 2 dwords (WG: tile t & 63 of the CTU in raster order; else tile t & 15 of the quadrant in z-order) */)
@@ -201,8 +201,9 @@ __device__ __forceinline__ void me_group(const KsGeom &g, int cx, int cy, int ra
     long long acc[5] = {0, 0, 0, 0, 0}; const long long tl0 = ME_NOW();
 #endif
 
+    int rounds = 0;
 #pragma unroll 1
-    for (;;) {
+    for (;; ++rounds) {
 #ifdef KS_EXP_ME_CLOCK
         const long long tr0 = ME_NOW();
 #endif
@@ -388,17 +389,57 @@ __device__ __forceinline__ void me_group(const KsGeom &g, int cx, int cy, int ra
         e.cost = o.cost; e.dist = o.cost - mv_rate(lam, o.mx, o.my, o.pmx, o.pmy);
         out_ctu[idx] = e;
     }
+    return rounds;
+}
+
+// Heavy CTUs first (round 5).  A work-group's life is its number of search rounds (1.2 - 1.7 us each under load): 29 us on average, but a few dozen CTUs of a picture - a PU
+// that walks a hexagon and a diamond for merange / 2 steps each - live 60 - 110 us, and when one of them is dispatched late the kernel ends with 35 % of its duration on
+// fewer than 30 of 768 work-group slots (scratch/me_trace.py: 140 us for 78 us of slot time).  The kernel therefore leaves every CTU's rounds behind (work: one word per
+// wave); the next search of this frame object - next picture or other list, the same content a few samples on - dispatches the CTUs that were in the heaviest tenth first,
+// the rest in the usual XCD-aware order.  Scheduling only: every CTU computes what it always computed.
+__global__ __launch_bounds__(1024) void me_order_kernel(int n, const unsigned *work, int *order)
+{
+    __shared__ unsigned hist[256];
+    __shared__ int scan[1024];
+    __shared__ int s_thr, s_nheavy, s_fill;
+    const int tid = threadIdx.x;
+    if (tid < 256) hist[tid] = 0;
+    if (tid == 0) s_fill = 0;
+    __syncthreads();
+    auto score = [&](int ctu) { const uint4 w = *(const uint4 *)(work + 4 * (long)ctu); return (int)min(255u, max(max(w.x, w.y), max(w.z, w.w))); };
+    for (int b = tid; b < n; b += 1024) atomicAdd(&hist[score(ks_xcd_swizzle(b, n))], 1u);
+    __syncthreads();
+    if (tid == 0) {                                              // threshold: the heaviest scores that together hold at most a tenth of the CTUs (none when all are alike)
+        int acc = 0, thr = 256;
+        for (int v = 255; v > 0; --v) { if (acc + (int)hist[v] > n / 10) break; acc += (int)hist[v]; thr = v; }
+        s_thr = thr; s_nheavy = acc;
+    }
+    __syncthreads();
+    const int thr = s_thr, nheavy = s_nheavy;
+    const int per = (n + 1023) / 1024, b0 = tid * per, b1 = min(n, b0 + per);
+    int light = 0;
+    for (int b = b0; b < b1; ++b) light += score(ks_xcd_swizzle(b, n)) < thr;
+    scan[tid] = light;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) { const int v = tid >= d ? scan[tid - d] : 0; __syncthreads(); scan[tid] += v; __syncthreads(); }
+    int pos = nheavy + scan[tid] - light;
+    for (int b = b0; b < b1; ++b) {
+        const int ctu = ks_xcd_swizzle(b, n);
+        if (score(ctu) < thr) order[pos++] = ctu;
+        else order[atomicAdd(&s_fill, 1)] = ctu;
+    }
 }
 
 __global__ __launch_bounds__(256, 3) void me_int_kernel(KsGeom g, int range, int lam, int method, int hex_thr, const uint8_t *src, const uint8_t *ref,
-                                                        const ks265_pu *prev, ks265_pu *out, const short2 *field, int nb0x, int nb0y, const short2 *ctu_off)
+                                                        const ks265_pu *prev, ks265_pu *out, const short2 *field, int nb0x, int nb0y, const short2 *ctu_off,
+                                                        const int *order, unsigned *work)
 {
     __shared__ __attribute__((aligned(16))) MeLds L;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifdef KS_EXP_ME_CLOCK
     const long long tk0 = ME_NOW();
 #endif
-    const int ctu = ks_xcd_swizzle(blockIdx.x, g.ctu_cols * g.ctu_rows), cx = ctu % g.ctu_cols, cy = ctu / g.ctu_cols;
+    const int ctu = order ? order[blockIdx.x] : ks_xcd_swizzle(blockIdx.x, g.ctu_cols * g.ctu_rows), cx = ctu % g.ctu_cols, cy = ctu / g.ctu_cols;
 #ifdef KS_EXP_ME_TRACE
     if (tid == 0 && ctu < 4096) { unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); ks_me_trace[ctu * 8] = wall_clock64(); ks_me_trace[ctu * 8 + 7] = ((unsigned long long)blockIdx.x << 32) | hw; }
 #endif
@@ -498,7 +539,7 @@ __global__ __launch_bounds__(256, 3) void me_int_kernel(KsGeom g, int range, int
 #pragma unroll
         for (int r = 0; r < 8; ++r) { fe[2 * r] = *(const unsigned *)(pf + r * FENC_STRIDE); fe[2 * r + 1] = *(const unsigned *)(pf + r * FENC_STRIDE + 4); }
     }
-    me_group<true, 0>(g, cx, cy, range, lm, lam, method, hex_thr, L, L.grp[0], 0, 0, 0, prev_ctu, out_ctu, field, nb0x, nb0y, tid, fe);
+    int rounds = me_group<true, 0>(g, cx, cy, range, lm, lam, method, hex_thr, L, L.grp[0], 0, 0, 0, prev_ctu, out_ctu, field, nb0x, nb0y, tid, fe);
     __syncthreads();                                                                    // its vector is the predictor of everything below
 #ifdef KS_EXP_ME_CLOCK
     const long long tk2 = ME_NOW();
@@ -514,9 +555,10 @@ __global__ __launch_bounds__(256, 3) void me_int_kernel(KsGeom g, int range, int
 #pragma unroll
         for (int r = 0; r < 8; ++r) { fe[2 * r] = *(const unsigned *)(pf + r * FENC_STRIDE); fe[2 * r + 1] = *(const unsigned *)(pf + r * FENC_STRIDE + 4); }
     }
-    me_group<false, 1>(g, cx, cy, range, lm, lam, method, hex_thr, L, L.grp[wave], 0, qx, qy, prev_ctu, out_ctu, field, nb0x, nb0y, lane, fe);
-    me_group<false, 2>(g, cx, cy, range, lm, lam, method, hex_thr, L, L.grp[wave], 1, qx << 1, qy << 1, prev_ctu, out_ctu, field, nb0x, nb0y, lane, fe);
-    me_group<false, 3>(g, cx, cy, range, lm, lam, method, hex_thr, L, L.grp[wave], 2, qx << 2, qy << 2, prev_ctu, out_ctu, field, nb0x, nb0y, lane, fe);
+    rounds += me_group<false, 1>(g, cx, cy, range, lm, lam, method, hex_thr, L, L.grp[wave], 0, qx, qy, prev_ctu, out_ctu, field, nb0x, nb0y, lane, fe);
+    rounds += me_group<false, 2>(g, cx, cy, range, lm, lam, method, hex_thr, L, L.grp[wave], 1, qx << 1, qy << 1, prev_ctu, out_ctu, field, nb0x, nb0y, lane, fe);
+    rounds += me_group<false, 3>(g, cx, cy, range, lm, lam, method, hex_thr, L, L.grp[wave], 2, qx << 2, qy << 2, prev_ctu, out_ctu, field, nb0x, nb0y, lane, fe);
+    if (work && lane == 0) work[4 * (long)ctu + wave] = (unsigned)rounds;
 #ifdef KS_EXP_ME_TRACE
     if (lane == 0 && ctu < 4096) ks_me_trace[ctu * 8 + 3 + wave] = wall_clock64();
 #endif
@@ -640,10 +682,20 @@ extern "C" int ks265_me_integer(ks265_frame *f, ks265_pic src, ks265_pic ref, co
         if (r) return r;
         field = (const short2 *)f->pyr[5];                                   // the L1 vectors: the kernel does the full-resolution step itself
     }
-    const dim3 grid(f->g.ctu_cols * f->g.ctu_rows), block(256);
+    const int nctu = f->g.ctu_cols * f->g.ctu_rows;
+    const dim3 grid(nctu), block(256);
+    if (!f->me_work && !f->me_order_off) {                                   // (first search of this frame object: the counters start at zero = the usual order)
+        for (int i = 0; i < 2; ++i) {
+            if (hipMalloc((void **)&f->me_work_all[i], (size_t)nctu * 16) != hipSuccess || hipMalloc((void **)&f->me_order_all[i], (size_t)nctu * 4) != hipSuccess) return KS265_OUTOFMEMORY;
+            (void)hipMemsetAsync(f->me_work_all[i], 0, (size_t)nctu * 16, f->ctx->stream);
+        }
+        if (hipStreamSynchronize(f->ctx->stream) != hipSuccess) return KS265_FAIL;      // (once per frame object: the side stream's first search reads its counters too)
+        f->me_work = f->me_work_all[0]; f->me_order = f->me_order_all[0];
+    }
+    if (f->me_work) hipLaunchKernelGGL(me_order_kernel, dim3(1), dim3(1024), 0, f->ctx->stream, nctu, f->me_work, f->me_order);
     if (f->profiling && f->ev_k[0]) (void)hipEventRecord(f->ev_k[0], f->ctx->stream);
     hipLaunchKernelGGL(me_int_kernel, grid, block, 0, f->ctx->stream, f->g, f->cfg.me_range, f->cfg.lambda_q4, f->cfg.me_method, f->cfg.me_hex_thr, src.y, ref.y, prev_pu, pu,
-                       field, (f->g.W + 15) / 16, (f->g.H + 15) / 16, field ? (const short2 *)f->pyr[9] : nullptr);
+                       field, (f->g.W + 15) / 16, (f->g.H + 15) / 16, field ? (const short2 *)f->pyr[9] : nullptr, (const int *)f->me_order, f->me_work);
     if (f->profiling && f->ev_k[1]) { (void)hipEventRecord(f->ev_k[1], f->ctx->stream); f->ev_k_valid = true; }
     return ks265_check_launch(f->ctx);
 }

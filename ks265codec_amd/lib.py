@@ -20,6 +20,8 @@ INTRA_REF = np.dtype([("src_off", "<i4"), ("dst_off", "<i4"), ("size", "<i4"), (
 PU = np.dtype([("mvx", "<i2"), ("mvy", "<i2"), ("mvpx", "<i2"), ("mvpy", "<i2"), ("cost", "<u4"), ("dist", "<u4")])
 CU8 = np.dtype([("mvx", "<i2"), ("mvy", "<i2"), ("mv1x", "<i2"), ("mv1y", "<i2"), ("log2_cu", "u1"), ("cbf", "u1"), ("pred_mode", "u1"), ("inter_dir", "u1")])
 PU_B = np.dtype([("mvx", "<i2"), ("mvy", "<i2"), ("mv1x", "<i2"), ("mv1y", "<i2"), ("cost", "<u4"), ("inter_dir", "<u4")])
+RDOQ_TU = np.dtype([("off", "<i4"), ("tab", "<i4"), ("dq", "<i4"), ("last_pos", "<i4"), ("lam", "<i8"), ("lam_sdh", "<i8"), ("log2", "i1"), ("scan_idx", "i1"), ("comp", "i1"), ("per", "i1"),
+                    ("tu5", "i1"), ("flag_a4c0", "i1"), ("sdh", "i1"), ("rsv", "i1")])      # ks265_rdoq_tu
 SAO_PARAM = np.dtype([("type", "i1"), ("band", "i1"), ("offset", "i1", 4), ("rsv", "i1", 2)])
 
 
@@ -52,7 +54,7 @@ EXPORTS = [
     "ks265_dev_malloc", "ks265_dev_free", "ks265_host_malloc", "ks265_host_free", "ks265_memcpy_h2d_async", "ks265_memcpy_d2h_async", "ks265_memcpy_d2d_async", "ks265_copy_out_async", "ks265_memset_async",
     "ks265_event_create", "ks265_event_record", "ks265_event_wait", "ks265_event_query", "ks265_stream_wait_event", "ks265_event_destroy",
     "ks265_sad_batch", "ks265_sad4_batch", "ks265_sad3_batch", "ks265_sad4blk_8x8_batch", "ks265_sse_batch", "ks265_had_batch",
-    "ks265_residual_batch", "ks265_fwd_transform_batch", "ks265_quant_batch", "ks265_sign_hiding_batch", "ks265_dequant_batch", "ks265_dequant_rect_batch", "ks265_inv_transform_batch",
+    "ks265_residual_batch", "ks265_fwd_transform_batch", "ks265_quant_batch", "ks265_sign_hiding_batch", "ks265_rdoq_batch", "ks265_dequant_batch", "ks265_dequant_rect_batch", "ks265_inv_transform_batch",
     "ks265_edge_filter_luma_batch", "ks265_edge_filter_chroma_batch", "ks265_interp_rect",
     "ks265_sao_apply_bo_rect", "ks265_sao_apply_eo_rect", "ks265_sao_stats_batch", "ks265_intra_pred_batch", "ks265_intra_filter_ref_batch",
     "ks265_downsample_rect", "ks265_downsample_from_host", "ks265_weight_bi_sad_batch", "ks265_ac_energy_batch", "ks265_ac_energy_map",
@@ -184,6 +186,15 @@ class KsContext:
         dl, dc, du = self.dev(lvl.astype(np.int16)), self.dev(coef.astype(np.int16)), self.dev(delta_u.astype(np.int16))
         self._chk(self.lib.ks265_sign_hiding_batch(self.h, C.c_int(n), C.c_int(scan_idx), _p(dl), _p(dc), _p(du), C.c_int(lvl.shape[0])))
         return self.host(dl, np.int16, lvl.shape)
+
+    def rdoq(self, tus: np.ndarray, lvl: np.ndarray, coef: np.ndarray, tables: np.ndarray, sigmask: np.ndarray):
+        """ks265_rdoq_batch (rdoQuant enc@0x4aac50): tus = RDOQ_TU records; lvl / coef flat int16; tables [ntab, 180] int32; sigmask [n, 64] uint16.
+        Returns (levels, sigmask, out [n, 2] = (non-zero levels, last scan position), hidden [n])"""
+        n = len(tus)
+        dl, dc, dt, dm = self.dev(lvl.astype(np.int16)), self.dev(coef.astype(np.int16)), self.dev(np.ascontiguousarray(tables, np.int32)), self.dev(np.ascontiguousarray(sigmask, np.uint16))
+        out, hid = self.zeros(8 * n), self.zeros(8 * n)
+        self._chk(self.lib.ks265_rdoq_batch(self.h, _p(self.dev(tus)), C.c_int(n), _p(dl), _p(dc), _p(dt), _p(dm), _p(out), _p(hid)))
+        return self.host(dl, np.int16), self.host(dm, np.uint16, (n, 64)), self.host(out, np.int32, (n, 2)), self.host(hid, np.uint64)
 
     def dequant(self, n: int, lvl: np.ndarray, scale: int, add: int, shift: int) -> np.ndarray:
         nblk = lvl.shape[0]
