@@ -289,7 +289,7 @@ typedef struct {
     int32_t sub_flat;          /* tME+0x3c4: flat = max SAD of the half step - the winner's SAD <= W H flat / 8; 40 / 36 / 16 / 14 / 10 / 8 / 8 / 8 / 8 */
     int32_t sub_cap, sub_cap_step;   /* cfg+0x498 / +0x49c: > 0 = no refinement above an integer cost of (cap + (6 - log2 H) step) W^2; 6,6 / 6,6 / 12,6 / 0.. */
     int32_t sub_diag_fast;     /* cfg+0x580: half step skips the diagonals unless a horizontal / vertical candidate won (ultrafast, superfast) */
-    int32_t part;              /* -part (qy265enc.h:131; slower, veryslow, placebo): 1 = a CU of 64 / 32 / 16 samples of a P picture may be coded as two 2NxN or Nx2N prediction units
+    int32_t part;              /* -part (qy265enc.h:131; slower, veryslow, placebo): 1 = a CU of 64 / 32 / 16 samples of a P or B picture (one reference per list) may be coded as two 2NxN or Nx2N prediction units
                                   (ks265_cu8.log2_cu bits 4..5); each half is priced with the refined vectors of the CU and of its two quarter-size PUs (ks265_rect_decide), the CU then
                                   holds four transform units (interSplitFlag).  The reference searches such PUs on their own inside its RD loop (closed code) */
 } ks265_frame_cfg;
@@ -365,6 +365,11 @@ int ks265_me_propagate(ks265_frame *f, ks265_pic src, ks265_pic ref, const ks265
 int ks265_me_subpel(ks265_frame *f, ks265_pic src, ks265_pic ref, ks265_pu *dev_pu);
 /* cfg.part: the CU decision of a P picture with 2NxN / Nx2N partitions (prices the halves of every 64 / 32 / 16 CU first); dev_ibest as for ks265_cu_decide_ii (may be null) */
 int ks265_cu_decide_part(ks265_frame *f, ks265_pic src, ks265_pic ref, const ks265_pu *dev_pu, const uint32_t *dev_ibest, ks265_cu8 *dev_cu8);
+/* the same for a B picture (round 5): a half takes the MOTION - direction and vector(s) - of the CU's record or of one of its two quarter-size records in dev_pub, priced by the
+ * Hadamard cost of its prediction (bi: rounded average) + the rate of every vector used against the CU's predictors (dev_pu0 / dev_pu1: the uni-directional searches' records),
+ * a bi-predictive half at 31 / 32; ks265_cu8.inter_dir / mv1 then differ between the halves too */
+int ks265_cu_decide_part_b(ks265_frame *f, ks265_pic src, ks265_pic ref0, ks265_pic ref1, const ks265_pu *dev_pu0, const ks265_pu *dev_pu1, const ks265_pu_b *dev_pub,
+                           const uint32_t *dev_ibest, ks265_cu8 *dev_cu8);
 /* Stage C2 (cfg.merge; run by ks265_encode_picture[_b] itself, exported for stage tests): merge pass on the motion field of the CU decision.
  * Per CU the five spatial merge neighbours of H.265 8.5.3.2.3 (inside the picture, earlier in z-scan order, inter) and the zero vector are tried as the
  * CU's own motion: SATD of the prediction (bi = rounded average) + lambda x (position + 1) against the search cost + 2 lambda.

@@ -72,6 +72,10 @@ long ks265_write_pps(const ks265_stream_cfg *cfg, uint8_t *out, size_t cap);
  * bytes. */
 size_t ks265_slice_scratch_bytes(const ks265_stream_cfg *cfg);
 long ks265_write_slice(const ks265_stream_cfg *cfg, const ks265_slice_in *in, void *scratch, uint8_t *out, size_t cap);
+/* the entropy coder's context states at the end of the slice `scratch` wrote last (pStateIdx << 1 | valMps; with substreams: those saved after the second CTU of the last CTU
+ * row) and where the residual-coding groups start (layout[10]: cbf_luma, cbf_chroma, coded_sub_block_flag, sig_coeff_flag, last x, last y, greater1, greater2, rqt_root_cbf,
+ * count) - what a host snapshots into the bit tables of rdoQuant (estBitRdoq enc@0x46a8a0) for the pictures that follow.  Returns the number of states. */
+int ks265_slice_final_contexts(const ks265_stream_cfg *cfg, const void *scratch, uint8_t *out, int cap, int *layout);
 
 /* cfg->wpp = 1: the same picture row by row, so that SEVERAL host threads can write one picture (the reference's WPP tasks, qy265executeEncCtuTaskWpp
  * enc@0x475d20).  ks265_wpp_begin prepares the job in `mem` (ks265_wpp_bytes), ks265_wpp_code_row codes one CTU row into its substream - thread-safe for

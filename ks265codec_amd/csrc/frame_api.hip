@@ -264,10 +264,10 @@ int ks265_encode_picture_b(ks265_frame *f, ks265_pic src, ks265_pic ref0, ks265_
     const bool ii = f->cfg.intra_inter != 0;
     if (ii && (r = ks265_intra_candidates(f, src, f->pub, f->icost))) return r;
     if ((r = records_fence(f))) return r;
-    if (f->cfg.merge) {
-        if ((r = ks265_cu_decide_b_ii(f, f->pub, ii ? f->icost : nullptr, f->cu8_tmp))) return r;
-        if ((r = ks265_merge_pass(f, src, ref0, ref1, nullptr, f->pub, f->cu8_tmp, f->cu8))) return r;
-    } else if ((r = ks265_cu_decide_b_ii(f, f->pub, ii ? f->icost : nullptr, f->cu8))) return r;
+    const bool part = f->cfg.part != 0;                        /* -part 1: the halves of every 64 / 32 / 16 CU priced with the motions of the CU and of its quarters (round 5: B pictures too) */
+    ks265_cu8 *cud = f->cfg.merge ? f->cu8_tmp : f->cu8;
+    if ((r = part ? ks265_cu_decide_part_b(f, src, ref0, ref1, pu0, f->pu1, f->pub, ii ? f->icost : nullptr, cud) : ks265_cu_decide_b_ii(f, f->pub, ii ? f->icost : nullptr, cud))) return r;
+    if (f->cfg.merge && (r = ks265_merge_pass(f, src, ref0, ref1, nullptr, f->pub, f->cu8_tmp, f->cu8))) return r;
     ks265_pic deb = ks_deb_pic(f);
     if ((r = ks265_reconstruct_b(f, src, ref0, ref1, f->cu8, f->lvl[0], f->lvl[1], f->lvl[2], deb))) return r;
     if (ii && (r = ks265_intra_inter_reconstruct(f, src, f->cu8, f->lvl[0], f->lvl[1], f->lvl[2], deb))) return r;

@@ -9,7 +9,7 @@
 
 // geometry handed to kernels by value
 // cfg.part: what a CU of 64 / 32 / 16 samples costs in two halves (ks265_rect_decide): [0] = 2NxN (top, bottom), [1] = Nx2N (left, right); cost KS_COST_INVALID = not considered
-struct KsRect { unsigned cost[2]; short mv[2][2][2]; };
+struct KsRect { unsigned cost[2]; short mv[2][2][2]; short mv1[2][2][2]; unsigned char dir[2][2]; };   // B pictures: mv1 / dir = the half's list-1 vector and direction (ks265_cu_decide_part_b)
 
 struct KsGeom {
     int W, H;                 // luma size

@@ -492,8 +492,16 @@ __global__ __launch_bounds__(64) void cu_decide_kernel(KsGeom g, int lam, const 
     const REC p = cp[pidx];
     ks265_cu8 c;
     c.mvx = p.mvx; c.mvy = p.mvy; c.log2_cu = (uint8_t)(6 - l); c.cbf = 0; c.pred_mode = 0;
-    if constexpr (std::is_same<REC, ks265_pu_b>::value) { c.mv1x = p.mv1x; c.mv1y = p.mv1y; c.inter_dir = (uint8_t)p.inter_dir; }
-    else {
+    if constexpr (std::is_same<REC, ks265_pu_b>::value) {
+        c.mv1x = p.mv1x; c.mv1y = p.mv1y; c.inter_dir = (uint8_t)p.inter_dir;
+        const int pm = rect ? part[pidx] : 0;
+        if (pm && !use_intra[pidx]) {                                // this block's half of the CU: its own direction and vector(s)
+            const KsRect rr = rect[(long)ctu * 21 + pidx];
+            const int hf = pm == 1 ? (by >> (2 - l)) & 1 : (bx >> (2 - l)) & 1;
+            c.mvx = rr.mv[pm - 1][hf][0]; c.mvy = rr.mv[pm - 1][hf][1]; c.mv1x = rr.mv1[pm - 1][hf][0]; c.mv1y = rr.mv1[pm - 1][hf][1];
+            c.inter_dir = rr.dir[pm - 1][hf]; c.log2_cu = (uint8_t)((6 - l) | (pm << 4));
+        }
+    } else {
         c.mv1x = 0; c.mv1y = 0; c.inter_dir = 1;
         const int pm = rect ? part[pidx] : 0;
         if (pm && !use_intra[pidx]) {                                // this block's half of the CU: 2NxN by its row, Nx2N by its column
@@ -888,6 +896,122 @@ __global__ __launch_bounds__(192) void rect_eval_kernel(KsGeom g, int lam, const
         for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) { o.mv[a][b][0] = 0; o.mv[a][b][1] = 0; }
         rect[(long)ctu * 21 + pidx] = o;
     }
+}
+
+// cfg.part in B pictures (round 5): the halves take MOTIONS - direction and vector(s) of the CU's own record or of one of the half's two quarter-size records, as the
+// bi-predictive decision left them (oracle: rect_eval_b).  Same lane layout and exchanges as rect_eval_kernel; a tile's SATD under a motion is against the interpolated
+// samples of its list or against the rounded average of both lists' 8-bit predictions (bi_decide_kernel's measure), a bi-predictive half counts 31 / 32.
+struct KsMot { int v0, v1, dir; };
+__device__ __forceinline__ bool mot_same(const KsMot &a, const KsMot &b) { return a.dir == b.dir && (!(a.dir & 1) || a.v0 == b.v0) && (!(a.dir & 2) || a.v1 == b.v1); }
+__global__ __launch_bounds__(192) void rect_eval_b_kernel(KsGeom g, int lam, const uint8_t *src, const uint8_t *ref0, const uint8_t *ref1, const ks265_pu *pu0, const ks265_pu *pu1,
+                                                          const ks265_pu_b *pubs, KsRect *rect)
+{
+    const int tid = threadIdx.x, lane = tid & 63, l = tid >> 6;
+    const int ctu = ks_xcd_swizzle(blockIdx.x, g.ctu_cols * g.ctu_rows), cx = ctu % g.ctu_cols, cy = ctu / g.ctu_cols;
+    const int tx = (lane & 1) | ((lane >> 1) & 2) | ((lane >> 2) & 4), ty = ((lane >> 1) & 1) | ((lane >> 2) & 2) | ((lane >> 3) & 4);
+    const int x0 = cx * 64 + tx * 8, y0 = cy * 64 + ty * 8;
+    const int cux = tx >> (3 - l), cuy = ty >> (3 - l), qx = (tx >> (2 - l)) & 1, qy = (ty >> (2 - l)) & 1;
+    const int pidx = ks_level_base(l) + cuy * (1 << l) + cux;
+    const ks265_pu_b *cp = pubs + (long)ctu * 85;
+    const ks265_pu_b P = cp[pidx];
+    const ks265_pu a = pu0[(long)ctu * 85 + pidx], b = pu1[(long)ctu * 85 + pidx];
+    const bool valid = P.cost != KS_COST_INVALID;
+    const int cb = ks_level_base(l + 1), cw = 2 << l;
+    const ks265_pu_b cO = cp[cb + (2 * cuy + qy) * cw + 2 * cux + qx], cH = cp[cb + (2 * cuy + qy) * cw + 2 * cux + (qx ^ 1)], cV = cp[cb + (2 * cuy + (qy ^ 1)) * cw + 2 * cux + qx];
+    auto mot = [&](const ks265_pu_b &r) { KsMot m; m.v0 = (int)(unsigned short)r.mvx | ((int)r.mvy << 16); m.v1 = (int)(unsigned short)r.mv1x | ((int)r.mv1y << 16); m.dir = (int)(r.inter_dir & 3u); return m; };
+    KsMot mP = mot(P);
+    if (!valid) { mP.v0 = 0; mP.v1 = 0; mP.dir = 1; }
+    const KsMot mO = valid && cO.cost != KS_COST_INVALID ? mot(cO) : mP, mH = valid && cH.cost != KS_COST_INVALID ? mot(cH) : mP, mV = valid && cV.cost != KS_COST_INVALID ? mot(cV) : mP;
+    unsigned f[16];
+    {
+        const uint8_t *frow = ks_org_y(g, src) + (long)(valid ? y0 : cy * 64) * g.sy + (valid ? x0 : cx * 64);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { const uint2 v = *(const uint2 *)(frow + (long)r * g.sy); f[2 * r] = v.x; f[2 * r + 1] = v.y; }
+    }
+    const long base = (long)(valid ? y0 : 0) * g.sy + (valid ? x0 : 0) + g.org_y;
+    auto tile = [&](const KsMot &m) {
+        unsigned A[16], B[16];
+        if (__any(m.dir & 1)) luma_pred_tile8(ref0 + base, g.sy, (int)(short)(m.v0 & 0xFFFF), m.v0 >> 16, A);
+        if (__any(m.dir & 2)) luma_pred_tile8(ref1 + base, g.sy, (int)(short)(m.v1 & 0xFFFF), m.v1 >> 16, B);
+        if (m.dir == 1) { for (int i = 0; i < 16; ++i) B[i] = A[i]; }
+        else if (m.dir == 2) { for (int i = 0; i < 16; ++i) A[i] = B[i]; }
+        return satd8x8_avg(f, A, B);                                  // one list: (p + p + 1) >> 1 = p
+    };
+    unsigned sP = 0, sO = 0, sH = 0, sV = 0;
+    if (__any(valid)) {
+        sP = tile(mP);
+        sO = sP; sH = sP; sV = sP;
+        const bool nO = !mot_same(mO, mP);
+        if (__any(nO)) { const unsigned t = tile(mO); if (nO) sO = t; }
+        const bool nH = !mot_same(mH, mP) && !mot_same(mH, mO);
+        if (__any(nH)) { const unsigned t = tile(mH); if (nH) sH = t; }
+        if (mot_same(mH, mO)) sH = sO;
+        const bool nV = !mot_same(mV, mP) && !mot_same(mV, mO) && !mot_same(mV, mH);
+        if (__any(nV)) { const unsigned t = tile(mV); if (nV) sV = t; }
+        if (mot_same(mV, mO)) sV = sO; else if (mot_same(mV, mH) && !mot_same(mV, mP)) sV = sH;
+    }
+    if (!valid) { sP = sO = sH = sV = 0; }
+    const unsigned qP = pu_group_sum(sP, l + 1), qO = pu_group_sum(sO, l + 1), qH = pu_group_sum(sH, l + 1), qV = pu_group_sum(sV, l + 1);
+    const int gq = 1 << (2 * (2 - l));
+    const unsigned hP = (unsigned)__shfl_xor((int)qP, gq, 64), hO = (unsigned)__shfl_xor((int)qO, gq, 64), hH = (unsigned)__shfl_xor((int)qH, gq, 64);
+    const unsigned wP = (unsigned)__shfl_xor((int)qP, 2 * gq, 64), wO = (unsigned)__shfl_xor((int)qO, 2 * gq, 64), wV = (unsigned)__shfl_xor((int)qV, 2 * gq, 64);
+    auto price = [&](unsigned satd, const KsMot &m) {                 // Hadamard cost of the half + the rate of every vector used against the CU's predictor of that list; bi at 31 / 32
+        unsigned c = satd;
+        if (m.dir & 1) c += (unsigned)mv_cost((int)(short)(m.v0 & 0xFFFF), m.v0 >> 16, a.mvpx, a.mvpy, lam);
+        if (m.dir & 2) c += (unsigned)mv_cost((int)(short)(m.v1 & 0xFFFF), m.v1 >> 16, b.mvpx, b.mvpy, lam);
+        if (m.dir == 3) c -= c >> KS_BI_BIAS_SHIFT;
+        return c;
+    };
+    unsigned best[2]; KsMot bm[2];
+    {
+        const unsigned cP = price(qP + hP, mP), cMe = price(qO + hH, mO), cNb = price(qH + hO, mH);      // 2NxN: the half = my quarter + its horizontal neighbour
+        const unsigned c0 = qx ? cNb : cMe, c1 = qx ? cMe : cNb; const KsMot m0 = qx ? mH : mO, m1 = qx ? mO : mH;
+        best[0] = cP; bm[0] = mP;
+        if (c0 < best[0]) { best[0] = c0; bm[0] = m0; }
+        if (c1 < best[0]) { best[0] = c1; bm[0] = m1; }
+    }
+    {
+        const unsigned cP = price(qP + wP, mP), cMe = price(qO + wV, mO), cNb = price(qV + wO, mV);      // Nx2N: my quarter + its vertical neighbour
+        const unsigned c0 = qy ? cNb : cMe, c1 = qy ? cMe : cNb; const KsMot m0 = qy ? mV : mO, m1 = qy ? mO : mV;
+        best[1] = cP; bm[1] = mP;
+        if (c0 < best[1]) { best[1] = c0; bm[1] = m0; }
+        if (c1 < best[1]) { best[1] = c1; bm[1] = m1; }
+    }
+    const unsigned ob0 = (unsigned)__shfl_xor((int)best[0], 2 * gq, 64), ob1 = (unsigned)__shfl_xor((int)best[1], gq, 64);
+    KsMot om[2];
+    om[0].v0 = __shfl_xor(bm[0].v0, 2 * gq, 64); om[0].v1 = __shfl_xor(bm[0].v1, 2 * gq, 64); om[0].dir = __shfl_xor(bm[0].dir, 2 * gq, 64);
+    om[1].v0 = __shfl_xor(bm[1].v0, gq, 64); om[1].v1 = __shfl_xor(bm[1].v1, gq, 64); om[1].dir = __shfl_xor(bm[1].dir, gq, 64);
+    const int G = 1 << (2 * (3 - l));
+    if ((lane & (G - 1)) == 0) {
+        KsRect o;
+        if (valid) {
+            const unsigned long long pen = (unsigned long long)((lam * KS_PART_BITS) >> 4);
+            for (int k = 0; k < 2; ++k) {
+                const unsigned long long t = (unsigned long long)best[k] + (k ? ob1 : ob0) + pen;
+                o.cost[k] = (!mot_same(bm[k], mP) || !mot_same(om[k], mP)) ? (t > 0xFFFFFFFEull ? 0xFFFFFFFEu : (unsigned)t) : KS_COST_INVALID;      // considered only if a half's motion is not the CU's
+                const KsMot h2[2] = {bm[k], om[k]};
+                for (int hf = 0; hf < 2; ++hf) {
+                    o.mv[k][hf][0] = (short)(h2[hf].v0 & 0xFFFF); o.mv[k][hf][1] = (short)(h2[hf].v0 >> 16);
+                    o.mv1[k][hf][0] = (short)(h2[hf].v1 & 0xFFFF); o.mv1[k][hf][1] = (short)(h2[hf].v1 >> 16); o.dir[k][hf] = (unsigned char)h2[hf].dir;
+                }
+            }
+        } else {
+            o.cost[0] = o.cost[1] = KS_COST_INVALID;
+            for (int k = 0; k < 2; ++k) for (int hf = 0; hf < 2; ++hf) { o.mv[k][hf][0] = o.mv[k][hf][1] = o.mv1[k][hf][0] = o.mv1[k][hf][1] = 0; o.dir[k][hf] = 1; }
+        }
+        rect[(long)ctu * 21 + pidx] = o;
+    }
+}
+
+extern "C" int ks265_cu_decide_part_b(ks265_frame *f, ks265_pic src, ks265_pic ref0, ks265_pic ref1, const ks265_pu *pu0, const ks265_pu *pu1, const ks265_pu_b *pub, const uint32_t *ibest, ks265_cu8 *cu8)
+{
+    KS_FRAME_CHECK(f);
+    if (!src.y || !ref0.y || !ref1.y || !pu0 || !pu1 || !pub || !cu8) return KS265_POINTER;
+    if (!f->rect) return KS265_NOTSUPPORTED;                                      // the frame object was created without cfg.part
+    const int nctu = f->g.ctu_cols * f->g.ctu_rows;
+    hipLaunchKernelGGL(rect_eval_b_kernel, dim3(nctu), dim3(192), 0, f->ctx->stream, f->g, f->cfg.lambda_q4, src.y, ref0.y, ref1.y, pu0, pu1, pub, (KsRect *)f->rect);
+    hipLaunchKernelGGL(cu_decide_kernel<ks265_pu_b>, dim3(nctu), dim3(64), 0, f->ctx->stream, f->g, f->cfg.lambda_q4, pub, cu8, ibest, (const KsRect *)f->rect);
+    return ks265_check_launch(f->ctx);
 }
 
 extern "C" int ks265_cu_decide_part(ks265_frame *f, ks265_pic src, ks265_pic ref, const ks265_pu *pu, const uint32_t *ibest, ks265_cu8 *cu8)

@@ -397,7 +397,7 @@ __device__ __forceinline__ int me_group(const KsGeom &g, int cx, int cy, int ran
 // fewer than 30 of 768 work-group slots (scratch/me_trace.py: 140 us for 78 us of slot time).  The kernel therefore leaves every CTU's rounds behind (work: one word per
 // wave); the next search of this frame object - next picture or other list, the same content a few samples on - dispatches the CTUs that were in the heaviest tenth first,
 // the rest in the usual XCD-aware order.  Scheduling only: every CTU computes what it always computed.
-__global__ __launch_bounds__(1024) void me_order_kernel(int n, const unsigned *work, int *order)
+__global__ __launch_bounds__(1024) void me_order_kernel(int n, int cols, const unsigned *work, int *order)
 {
     __shared__ unsigned hist[256];
     __shared__ int scan[1024];
@@ -406,7 +406,19 @@ __global__ __launch_bounds__(1024) void me_order_kernel(int n, const unsigned *w
     if (tid < 256) hist[tid] = 0;
     if (tid == 0) s_fill = 0;
     __syncthreads();
-    auto score = [&](int ctu) { const uint4 w = *(const uint4 *)(work + 4 * (long)ctu); return (int)min(255u, max(max(w.x, w.y), max(w.z, w.w))); };
+    // a CTU's score: the most rounds any wave of it or of its eight neighbours ran last time (what made a CTU heavy - a moving edge - is in it or next to it now)
+    auto score = [&](int ctu) {
+        const int cx = ctu % cols, cy = ctu / cols, rows = n / cols;
+        unsigned m = 0;
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int x = cx + dx, y = cy + dy;
+                if (x < 0 || y < 0 || x >= cols || y >= rows) continue;
+                const uint4 w = *(const uint4 *)(work + 4 * ((long)y * cols + x));
+                m = max(m, max(max(w.x, w.y), max(w.z, w.w)));
+            }
+        return (int)min(255u, m);
+    };
     for (int b = tid; b < n; b += 1024) atomicAdd(&hist[score(ks_xcd_swizzle(b, n))], 1u);
     __syncthreads();
     if (tid == 0) {                                              // threshold: the heaviest scores that together hold at most a tenth of the CTUs (none when all are alike)
@@ -692,7 +704,7 @@ extern "C" int ks265_me_integer(ks265_frame *f, ks265_pic src, ks265_pic ref, co
         if (hipStreamSynchronize(f->ctx->stream) != hipSuccess) return KS265_FAIL;      // (once per frame object: the side stream's first search reads its counters too)
         f->me_work = f->me_work_all[0]; f->me_order = f->me_order_all[0];
     }
-    if (f->me_work) hipLaunchKernelGGL(me_order_kernel, dim3(1), dim3(1024), 0, f->ctx->stream, nctu, f->me_work, f->me_order);
+    if (f->me_work) hipLaunchKernelGGL(me_order_kernel, dim3(1), dim3(1024), 0, f->ctx->stream, nctu, f->g.ctu_cols, f->me_work, f->me_order);
     if (f->profiling && f->ev_k[0]) (void)hipEventRecord(f->ev_k[0], f->ctx->stream);
     hipLaunchKernelGGL(me_int_kernel, grid, block, 0, f->ctx->stream, f->g, f->cfg.me_range, f->cfg.lambda_q4, f->cfg.me_method, f->cfg.me_hex_thr, src.y, ref.y, prev_pu, pu,
                        field, (f->g.W + 15) / 16, (f->g.H + 15) / 16, field ? (const short2 *)f->pyr[9] : nullptr, (const int *)f->me_order, f->me_work);

@@ -1115,7 +1115,7 @@ static Enc *lane_open(QY265EncConfig *cfg, int device, int multi, int *err)
 
     if (cfg->rdoq || cfg->transskip) logf_(1, e->log_level, "ks265enc: rdoq / transskip are accepted but not implemented by the pixel path\n");
     if (cfg->iAqMode > 1) logf_(1, e->log_level, "ks265enc: -aq %d runs as -aq 1 (block variance, the mode of the reference's calcFrameAdaptQuant)\n", cfg->iAqMode);
-    if (cfg->part && (e->gop_b > 0 || e->refs > 1)) logf_(1, e->log_level, "ks265enc: -part 1 acts on P pictures with one reference picture (2NxN / Nx2N partitions of 64 / 32 / 16 CUs); B pictures and multi-reference P pictures keep 2Nx2N\n");
+    if (cfg->part && e->refs > 1) logf_(1, e->log_level, "ks265enc: -part 1 (2NxN / Nx2N partitions of 64 / 32 / 16 CUs) acts on P and B pictures with one reference picture per list; multi-reference P pictures keep 2Nx2N\n");
     /* options whose VALUE is narrowed (SURVEY.md 8(a) config 5 = -preset veryslow: subme 2, part 1, ref 4): said once, never silently */
     if (cfg->refnum > 4) logf_(1, e->log_level, "ks265enc: -ref %d runs as -ref 4\n", cfg->refnum);
     if (e->gop_b > 0 && cfg->refnum > 1) logf_(1, e->log_level, "ks265enc: -ref %d with B pictures runs as one reference per list\n", cfg->refnum);
@@ -1150,7 +1150,7 @@ static Enc *lane_open(QY265EncConfig *cfg, int device, int multi, int *err)
                                                                          * integer search (measured with one round: - 21 .. - 23 % bytes of the P / B pictures; the variable is a measuring aid) */
     e->fcfg.intra_inter = 1;                                            /* P / B pictures may hold intra CUs (uncovered regions, occlusions); 2 = none of 8x8: measured + 1.6 % bits, no faster */
     e->fcfg.rdo = 4;                                                    /* coefficient-group pruning at lambda x 1 (ks265_frame_cfg.rdo): supersedes the coefficient decimation of round 2 */
-    e->fcfg.part = cfg->part ? 1 : 0;                                   /* -part 1 (slower, veryslow, placebo): 2NxN / Nx2N prediction units in P pictures (ks265_frame_cfg.part) */
+    e->fcfg.part = cfg->part ? 1 : 0;                                   /* -part 1 (slower, veryslow, placebo): 2NxN / Nx2N prediction units in P and B pictures (ks265_frame_cfg.part) */
     e->fcfg.bi_refine = 1;                                              /* B pictures: joint refinement of the bi-predictive pair (motionSearchBI enc@0x484910) */
     r = ks265_frame_geometry(&e->fcfg, &e->geom);
     if (!r) r = ks265_frame_create(e->ctx, &e->fcfg, &e->frame);

@@ -1246,6 +1246,21 @@ long ks265_wpp_finish(void *mem, uint8_t *out, size_t cap)
     return (long)o;
 }
 
+/* the entropy coder's context states at the end of the slice `scratch` wrote last (without substreams: the whole slice's; with them: those saved after the second CTU of
+ * the last CTU row, i.e. after two CTUs of every row) - what a host snapshots into rate tables for the pictures that follow (estBitRdoq enc@0x46a8a0 builds rdoQuant's bit
+ * tables from exactly these states).  out: n <= cap bytes, pStateIdx << 1 | valMps each; layout[12] = first index of: cbf_luma, cbf_chroma, coded_sub_block_flag (luma 2,
+ * chroma 2), sig_coeff_flag (luma 27, chroma 15), last x prefix (luma 15, chroma 3), last y prefix, greater1 (luma 16, chroma 8), greater2 (luma 4, chroma 2), rqt_root_cbf,
+ * then the count.  Returns the number of states. */
+int ks265_slice_final_contexts(const ks265_stream_cfg *cfg, const void *scratch, uint8_t *out, int cap, int *layout)
+{
+    if (!cfg || !scratch || !out) return KS265_POINTER;
+    if (cap < CX_COUNT) return KS265_NOTSUPPORTED;
+    if (cfg->wpp) { const Wpp *w = (const Wpp *)scratch; memcpy(out, w->snap + (size_t)(w->rows - 1) * CX_COUNT, CX_COUNT); }
+    else memcpy(out, ((const Enc *)scratch)->c.state, CX_COUNT);
+    if (layout) { const int l[10] = {CX_CBF_LUMA, CX_CBF_CHROMA, CX_CSBF, CX_SIG, CX_LAST_X, CX_LAST_Y, CX_G1, CX_G2, CX_ROOT_CBF, CX_COUNT}; memcpy(layout, l, sizeof l); }
+    return CX_COUNT;
+}
+
 long ks265_write_slice(const ks265_stream_cfg *cfg, const ks265_slice_in *in, void *scratch, uint8_t *out, size_t cap)
 {
     if (!scratch || !out) return KS265_POINTER;

@@ -79,6 +79,14 @@ class StreamWriter:
         o = self.out.ctypes.data_as(C.c_void_p)
         return b"".join(self._take(f(C.byref(self.cfg), o, C.c_size_t(self.out.size))) for f in (self.l.ks265_write_vps, self.l.ks265_write_sps, self.l.ks265_write_pps))
 
+    def final_contexts(self):
+        """(states, layout) of the slice written last: ks265_slice_final_contexts"""
+        st, lay = np.zeros(256, np.uint8), (C.c_int * 10)()
+        n = self.l.ks265_slice_final_contexts(C.byref(self.cfg), self.scratch.ctypes.data_as(C.c_void_p), st.ctypes.data_as(C.c_void_p), C.c_int(256), lay)
+        if n < 0:
+            raise RuntimeError(f"ks265_slice_final_contexts rc={n}")
+        return st[:n].copy(), list(lay)
+
     def slice(self, nal_type: int, slice_type: int, poc: int, qp: int, cu8: np.ndarray, lvl: "list[np.ndarray]", sao: "np.ndarray | None",
               rps: "list[tuple[int, bool]]" = (), l0: "list[int]" = (), l1: "list[int]" = (), qp_map: "np.ndarray | None" = None) -> bytes:
         s = SliceIn()

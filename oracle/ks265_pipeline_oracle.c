@@ -523,7 +523,7 @@ static uint32_t node_own_cost(const kso_frame_cfg *cfg, uint32_t inter, const ui
 #ifndef PART_BITS
 #define PART_BITS 6
 #endif
-typedef struct { uint32_t cost[2]; int16_t mv[2][2][2]; } rect_rec;     /* [orientation: 0 = 2NxN (top, bottom), 1 = Nx2N (left, right)][half][x, y]; cost COST_INVALID = not considered */
+typedef struct { uint32_t cost[2]; int16_t mv[2][2][2]; int16_t mv1[2][2][2]; uint8_t dir[2][2]; } rect_rec;     /* [orientation: 0 = 2NxN (top, bottom), 1 = Nx2N (left, right)][half][x, y]; cost COST_INVALID = not considered; B pictures: mv1 / dir = the half's list-1 vector and direction */
 typedef struct { const kso_frame_cfg *cfg; const kso_frame_geom *g; const uint8_t *S, *planes; } rect_ctx;
 static uint32_t rect_half_cost(const rect_ctx *rc, int x0, int y0, int w, int h, int mvx, int mvy, int px, int py)
 {
@@ -800,47 +800,129 @@ void kso_bi_decide(const kso_frame_cfg *cfg, kso_pic src, const uint8_t *planes0
         }
 }
 
-static uint32_t decide_node_b(const kso_frame_cfg *cfg, const kso_pu_b *cp, const uint32_t *icost, int cx, int cy, int l, int px, int py, uint8_t *split, uint8_t *use_intra)
+/* cfg->part in B pictures (round 5; -preset veryslow = config 5 codes hierarchical B with part 1): the same frame-parallel form as rect_eval, on MOTIONS instead of vectors.  A half
+ * may take the motion the bi-predictive decision left for the CU itself or for one of the half's two quarter-size PUs - direction and vector(s) together - priced like the
+ * decision prices a PU: Hadamard cost of the half's prediction (one list: the interpolated samples; both: the rounded average of the two 8-bit predictions) + the rate of
+ * every vector used against the CU's predictor of that list, a bi-predictive half at 31 / 32 (BI_BIAS_SHIFT); first strict minimum in the order CU, first quarter, second
+ * quarter.  Considered when a half's motion differs from the CU's; cost = both halves + lambda x PART_BITS. */
+typedef struct { const kso_frame_cfg *cfg; const kso_frame_geom *g; const uint8_t *S, *planes0, *planes1; const kso_pu *pu0, *pu1; } rect_ctx_b;
+static uint32_t rect_half_cost_b(const rect_ctx_b *rc, int x0, int y0, int w, int h, const kso_pu_b *M, const kso_pu *a, const kso_pu *b)
+{
+    const long st = rc->g->stride_y;
+    const int dir = (int)(M->inter_dir & 3), lam = rc->cfg->lambda_q4;
+    const uint8_t *p0 = org_y(rc->g, (uint8_t *)rc->planes0 + (long)((M->mvy & 3) * 4 + (M->mvx & 3)) * rc->g->bytes_y) + (long)(y0 + (M->mvy >> 2)) * st + x0 + (M->mvx >> 2);
+    const uint8_t *p1 = org_y(rc->g, (uint8_t *)rc->planes1 + (long)((M->mv1y & 3) * 4 + (M->mv1x & 3)) * rc->g->bytes_y) + (long)(y0 + (M->mv1y >> 2)) * st + x0 + (M->mv1x >> 2);
+    const uint8_t *S = rc->S + (long)y0 * st + x0;
+    if (dir == 1) return ks265o_had(S, p0, st, st, h, w) + (uint32_t)mv_cost(M->mvx, M->mvy, a->mvpx, a->mvpy, lam);
+    if (dir == 2) return ks265o_had(S, p1, st, st, h, w) + (uint32_t)mv_cost(M->mv1x, M->mv1y, b->mvpx, b->mvpy, lam);
+    uint8_t avg[64 * 64];
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) avg[y * w + x] = (uint8_t)((p0[(long)y * st + x] + p1[(long)y * st + x] + 1) >> 1);
+    uint32_t c = ks265o_had(S, avg, st, w, h, w) + (uint32_t)mv_cost(M->mvx, M->mvy, a->mvpx, a->mvpy, lam) + (uint32_t)mv_cost(M->mv1x, M->mv1y, b->mvpx, b->mvpy, lam);
+    c -= c >> BI_BIAS_SHIFT;
+    return c;
+}
+static int same_motion_b(const kso_pu_b *m, const kso_pu_b *n)
+{
+    const int d = (int)(m->inter_dir & 3);
+    if (d != (int)(n->inter_dir & 3)) return 0;
+    if ((d & 1) && (m->mvx != n->mvx || m->mvy != n->mvy)) return 0;
+    if ((d & 2) && (m->mv1x != n->mv1x || m->mv1y != n->mv1y)) return 0;
+    return 1;
+}
+static void rect_eval_b(const rect_ctx_b *rc, const kso_pu_b *cp, long cb, int cx, int cy, int l, int px, int py, rect_rec *out)
+{
+    const int s = 64 >> l, x0 = cx * 64 + px * s, y0 = cy * 64 + py * s, idx = pu_index(l, px, py);
+    const kso_pu_b *P = &cp[idx];
+    const kso_pu *a = &rc->pu0[cb + idx], *b = &rc->pu1[cb + idx];
+    out->cost[0] = out->cost[1] = COST_INVALID;
+    if (l > 2 || P->cost == COST_INVALID) return;
+    for (int o = 0; o < 2; ++o) {
+        uint64_t tot = (uint64_t)((rc->cfg->lambda_q4 * PART_BITS) >> 4);
+        int moved = 0;
+        for (int hf = 0; hf < 2; ++hf) {
+            const int hx = o ? x0 + hf * (s / 2) : x0, hy = o ? y0 : y0 + hf * (s / 2), w = o ? s / 2 : s, h = o ? s : s / 2;
+            const int i0 = pu_index(l + 1, px * 2 + (o ? hf : 0), py * 2 + (o ? 0 : hf)), i1 = pu_index(l + 1, px * 2 + (o ? hf : 1), py * 2 + (o ? 1 : hf));
+            const kso_pu_b *cand[2] = {&cp[i0], &cp[i1]}, *bm = P;
+            uint32_t best = rect_half_cost_b(rc, hx, hy, w, h, P, a, b);
+            for (int k = 0; k < 2; ++k) {
+                if (cand[k]->cost == COST_INVALID) continue;
+                const uint32_t c = rect_half_cost_b(rc, hx, hy, w, h, cand[k], a, b);
+                if (c < best) { best = c; bm = cand[k]; }
+            }
+            moved |= !same_motion_b(bm, P);
+            out->mv[o][hf][0] = bm->mvx; out->mv[o][hf][1] = bm->mvy; out->mv1[o][hf][0] = bm->mv1x; out->mv1[o][hf][1] = bm->mv1y; out->dir[o][hf] = (uint8_t)(bm->inter_dir & 3);
+            tot += best;
+        }
+        if (moved) out->cost[o] = tot > 0xFFFFFFFEu ? 0xFFFFFFFEu : (uint32_t)tot;
+    }
+}
+static uint32_t decide_node_b(const kso_frame_cfg *cfg, const rect_ctx_b *rc, long cb, const kso_pu_b *cp, const uint32_t *icost, int cx, int cy, int l, int px, int py, uint8_t *split, uint8_t *use_intra,
+                              uint8_t *part, rect_rec *rect)
 {
     int s = 64 >> l, x0 = cx * 64 + px * s, y0 = cy * 64 + py * s;
     if (x0 >= cfg->width || y0 >= cfg->height) return 0;
     int idx = pu_index(l, px, py);
-    uint32_t own = node_own_cost(cfg, cp[idx].cost, icost, idx, l, use_intra);
+    uint32_t inter = cp[idx].cost;
+    part[idx] = 0;
+    if (rc && l < 3) {
+        rect_eval_b(rc, cp, cb, cx, cy, l, px, py, &rect[idx]);
+        for (int o = 0; o < 2; ++o) if (rect[idx].cost[o] < inter) { inter = rect[idx].cost[o]; part[idx] = (uint8_t)(o + 1); }
+    }
+    uint32_t own = node_own_cost(cfg, inter, icost, idx, l, use_intra);
     if (l == 3) { split[idx] = 0; return own; }
     uint64_t sum = (uint64_t)((cfg->lambda_q4 * g_split_bits_b) >> 4);        /* (g_split_bits_b: experiment hook; SPLIT_BITS_B = the pipeline's value) */
-    for (int k = 0; k < 4; ++k) sum += decide_node_b(cfg, cp, icost, cx, cy, l + 1, px * 2 + (k & 1), py * 2 + (k >> 1), split, use_intra);
+    for (int k = 0; k < 4; ++k) sum += decide_node_b(cfg, rc, cb, cp, icost, cx, cy, l + 1, px * 2 + (k & 1), py * 2 + (k >> 1), split, use_intra, part, rect);
     if (own != COST_INVALID && (uint64_t)own <= sum) { split[idx] = 0; return own; }
     split[idx] = 1;
     return sum > 0xFFFFFFFEu ? 0xFFFFFFFEu : (uint32_t)sum;
 }
-static void emit_node_b(const kso_frame_cfg *cfg, const kso_pu_b *cp, const uint8_t *imode, int cx, int cy, int l, int px, int py, const uint8_t *split, const uint8_t *use_intra, kso_cu8 *cu8)
+static void emit_node_b(const kso_frame_cfg *cfg, const kso_pu_b *cp, const uint8_t *imode, int cx, int cy, int l, int px, int py, const uint8_t *split, const uint8_t *use_intra,
+                        const uint8_t *part, const rect_rec *rect, kso_cu8 *cu8)
 {
     int s = 64 >> l, x0 = cx * 64 + px * s, y0 = cy * 64 + py * s, w8 = cfg->width / 8;
     if (x0 >= cfg->width || y0 >= cfg->height) return;
     int idx = pu_index(l, px, py);
     if (l < 3 && split[idx]) {
-        for (int k = 0; k < 4; ++k) emit_node_b(cfg, cp, imode, cx, cy, l + 1, px * 2 + (k & 1), py * 2 + (k >> 1), split, use_intra, cu8);
+        for (int k = 0; k < 4; ++k) emit_node_b(cfg, cp, imode, cx, cy, l + 1, px * 2 + (k & 1), py * 2 + (k >> 1), split, use_intra, part, rect, cu8);
         return;
     }
     if (use_intra[idx]) { emit_intra(cfg, x0, y0, s, imode[idx], l, cu8); return; }
+    const int pm = part[idx];
     for (int by = 0; by < s / 8; ++by)
         for (int bx = 0; bx < s / 8; ++bx) {
             kso_cu8 *c = &cu8[(long)(y0 / 8 + by) * w8 + x0 / 8 + bx];
             c->mvx = cp[idx].mvx; c->mvy = cp[idx].mvy; c->mv1x = cp[idx].mv1x; c->mv1y = cp[idx].mv1y;
             c->log2_cu = (uint8_t)(6 - l); c->cbf = 0; c->pred_mode = 0; c->inter_dir = (uint8_t)cp[idx].inter_dir;
+            if (pm) {
+                const int hf = pm == 1 ? by >= s / 16 : bx >= s / 16;
+                c->mvx = rect[idx].mv[pm - 1][hf][0]; c->mvy = rect[idx].mv[pm - 1][hf][1]; c->mv1x = rect[idx].mv1[pm - 1][hf][0]; c->mv1y = rect[idx].mv1[pm - 1][hf][1];
+                c->inter_dir = rect[idx].dir[pm - 1][hf]; c->log2_cu = (uint8_t)((6 - l) | (pm << 4));
+            }
         }
 }
-void kso_cu_decide_b_ii(const kso_frame_cfg *cfg, const kso_pu_b *pub, const uint32_t *icost, const uint8_t *imode, kso_cu8 *cu8)
+static void cu_decide_b_impl(const kso_frame_cfg *cfg, const rect_ctx_b *rc, const kso_pu_b *pub, const uint32_t *icost, const uint8_t *imode, kso_cu8 *cu8)
 {
     kso_frame_geom g; kso_frame_geometry(cfg, &g);
+#pragma omp parallel for collapse(2) schedule(dynamic, 1)
     for (int cy = 0; cy < g.ctu_rows; ++cy)
         for (int cx = 0; cx < g.ctu_cols; ++cx) {
             const long cb = (long)(cy * g.ctu_cols + cx) * 85;
-            uint8_t split[85], use_intra[85];
-            memset(split, 0, sizeof split); memset(use_intra, 0, sizeof use_intra);
-            decide_node_b(cfg, pub + cb, icost ? icost + cb : NULL, cx, cy, 0, 0, 0, split, use_intra);
-            emit_node_b(cfg, pub + cb, imode ? imode + cb : NULL, cx, cy, 0, 0, 0, split, use_intra, cu8);
+            uint8_t split[85], use_intra[85], part[85];
+            rect_rec rect[21];
+            memset(split, 0, sizeof split); memset(use_intra, 0, sizeof use_intra); memset(part, 0, sizeof part);
+            decide_node_b(cfg, rc, cb, pub + cb, icost ? icost + cb : NULL, cx, cy, 0, 0, 0, split, use_intra, part, rect);
+            emit_node_b(cfg, pub + cb, imode ? imode + cb : NULL, cx, cy, 0, 0, 0, split, use_intra, part, rect, cu8);
         }
+}
+void kso_cu_decide_b_ii(const kso_frame_cfg *cfg, const kso_pu_b *pub, const uint32_t *icost, const uint8_t *imode, kso_cu8 *cu8) { cu_decide_b_impl(cfg, NULL, pub, icost, imode, cu8); }
+/* the CU decision of a B picture with cfg->part: pu0 / pu1 = the two uni-directional searches' records (the predictors the rates are counted against) */
+void kso_cu_decide_part_b(const kso_frame_cfg *cfg, kso_pic src, const uint8_t *planes0, const uint8_t *planes1, const kso_pu *pu0, const kso_pu *pu1, const kso_pu_b *pub,
+                          const uint32_t *icost, const uint8_t *imode, kso_cu8 *cu8)
+{
+    kso_frame_geom g; kso_frame_geometry(cfg, &g);
+    const rect_ctx_b rc = {cfg, &g, org_y(&g, src.y), planes0, planes1, pu0, pu1};
+    cu_decide_b_impl(cfg, cfg->part ? &rc : NULL, pub, icost, imode, cu8);
 }
 void kso_cu_decide_b(const kso_frame_cfg *cfg, const kso_pu_b *pub, kso_cu8 *cu8) { kso_cu_decide_b_ii(cfg, pub, NULL, NULL, cu8); }
 

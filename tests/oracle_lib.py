@@ -184,7 +184,10 @@ class OraclePipeline:
                 o.kso_bi_decide(cfg, self.src.c(), ptr(self.planes), ptr(self.planes1), ptr(self.pu), ptr(self.pu1), ptr(self.pub))
                 if ii:
                     o.kso_intra_candidates(cfg, self.src.c(), ptr(self.pub), ptr(self.icost), ptr(self.imode))
-                if ii:
+                if self.cfg.part:                        # -part 1 in B pictures: the halves take the motions of the CU and of its quarters
+                    o.kso_cu_decide_part_b(cfg, self.src.c(), ptr(self.planes), ptr(self.planes1), ptr(self.pu), ptr(self.pu1), ptr(self.pub),
+                                           ptr(self.icost) if ii else None, ptr(self.imode) if ii else None, ptr(self.cu8))
+                elif ii:
                     o.kso_cu_decide_b_ii(cfg, ptr(self.pub), ptr(self.icost), ptr(self.imode), ptr(self.cu8))
                 else:
                     o.kso_cu_decide_b(cfg, ptr(self.pub), ptr(self.cu8))

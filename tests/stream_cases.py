@@ -38,6 +38,9 @@ CASES = {
     # -part 1 (slower / veryslow / placebo): CUs of 64 / 32 / 16 in two 2NxN or Nx2N prediction units with four transform units; the rest as the C host runs it
     "part_ippp_416x240_umh": (416, 240, 27, 2, 0, 1, 1, "ippph", 4),
     "part_ippp_200x136_qp34": (200, 136, 34, 1, 0, 1, 1, "ippph", 4),
+    # round 5: -part 1 in B pictures (config 5 = -preset veryslow codes hierarchical B with part 1): the halves of a CU differ in direction and vectors
+    "part_hierb4_416x240": (416, 240, 28, 2, 0, 1, 1, "hier", 4),
+    "part_hierb4_200x136_qp34": (200, 136, 34, 1, 0, 1, 1, "hier", 4),
 }
 
 

@@ -212,6 +212,43 @@ def test_hier_b8_1080p_encoder_tools(ks):
     assert nintra > 0, "the clip should make some CU of a P / B picture intra"
 
 
+@pytest.mark.parametrize("W,H,G,seed", [(1920, 1080, 4, 46), (3840, 2160, 2, 7)])
+def test_config5_hierarchical_b_with_partitions(ks, W, H, G, seed):
+    """round 5: config 5's tool set IN ITS B PICTURES - -preset veryslow codes a hierarchical-B GOP with -part 1: UMH always, -subme 2 judged by Hadamard,
+    2NxN / Nx2N partitions whose halves take direction and vectors of their own (ks265_cu_decide_part_b) - every picture of a mini-GOP == oracle, and B pictures do hold
+    partitioned CUs of every direction"""
+    from ks265codec_amd.gop import hier_order
+    from ks265codec_amd.lib import KsFrame
+    from ks265codec_amd.synth import lambda_q4, make_clip, subme_knobs
+    from oracle_lib import OraclePipeline
+    tools = dict(ENCODER_TOOLS, me_hex_thr=0, part=1, **subme_knobs("veryslow"))
+    clip = make_clip(W, H, G + 1, seed=seed, abc=(37, 53, 19) if W < 3000 else (67, 91, 33), pan=(5, 3) if W < 3000 else (8, 5))
+    o = OraclePipeline(W, H, 27, lambda_q4(27), **tools)
+    dirs = np.zeros(4, np.int64)
+    with KsFrame(ks, W, H, 27, lambda_q4(27), bframes=3, **tools) as f:
+        src = f.new_pic()
+        dg, do = [f.new_pic() for _ in range(G + 1)], {}
+        for d, kind, r0, r1, layer in itertools.islice(hier_order(G, 128), G + 1):
+            q = 27 if kind == "I" else 28 + layer
+            lam = lambda_q4(q, inter=kind != "I")
+            o.set_qp(q, lam); f.set_qp(q, lam)
+            do[d] = o.encode(clip[d], kind, do.get(r0), do.get(r1))
+            f.load_i420(ks.dev(clip[d]), src)
+            out = dg[d % (G + 1)]
+            if kind == "B":
+                f.encode_picture_b(src, dg[r0 % (G + 1)], dg[r1 % (G + 1)], out)
+            else:
+                f.encode_picture(src, dg[r0 % (G + 1)] if r0 is not None else out, kind == "I", out)
+            cu = f.cu8()
+            assert (cu == o.cu8).all(), f"picture {d} ({kind}): {int((cu != o.cu8).sum())} CU records differ"
+            got, exp = ks.host(f.store_i420(out), np.uint8), o.store(do[d])
+            assert (got == exp).all(), f"picture {d} ({kind}, layer {layer}): {int((got != exp).sum())} bytes differ"
+            if kind == "B":
+                part = o.cu8["log2_cu"] >> 4
+                dirs += np.bincount(o.cu8["inter_dir"][part > 0] & 3, minlength=4)
+    assert dirs[1] > 0 and dirs[2] > 0 and dirs[3] > 0, f"partitioned CUs of B pictures by direction: {dirs.tolist()}"
+
+
 def test_full_size_properties_2160p_umh(ks):
     """3840x2160 with the bench's search method: run-to-run determinism and PSNR sanity over a 4-picture GOP head"""
     from ks265codec_amd.lib import KsFrame

@@ -130,14 +130,14 @@ def test_bitrate_target_ippp(tmp_path):
 
 def test_config5_command_line(tmp_path):
     """config 5's command line at 1920x1080: -preset veryslow -latency offline(= default) -rc 1 -br N with the SDK's default (hierarchical) GOP - the sub-pel refinement
-    runs as -subme 2 with the Hadamard measure (what veryslow resolves to); -part 1 acts on the P pictures; what the host still narrows (4 references per list with B pictures) is in its log"""
+    runs as -subme 2 with the Hadamard measure (what veryslow resolves to); -part 1 acts on P and B pictures (round 5); what the host still narrows (4 references per list with B pictures) is in its log"""
     from ks265codec_amd.synth import ENCODER_TOOLS, make_clip, subme_knobs
     W, H, n = 1920, 1080, 25
     clip = make_clip(W, H, n, seed=W + n, abc=(37, 53, 19), pan=(5, 3))
     log, per, kbps, rec, out = _encode(tmp_path, clip, W, H, ["-preset", "veryslow", "-rc", "1", "-br", "5000", "-iper", "128"])
     assert len(per) == n and "subme 2" in log, log[:800]
     _decoder_check(tmp_path, out, rec, n, W * H * 3 // 2)
-    tools = dict(ENCODER_TOOLS, me_hex_thr=0, part=1, **subme_knobs("veryslow"))    # veryslow: always UMH, -subme 2 judged by Hadamard, -part 1 (P pictures)
+    tools = dict(ENCODER_TOOLS, me_hex_thr=0, part=1, **subme_knobs("veryslow"))    # veryslow: always UMH, -subme 2 judged by Hadamard, -part 1 (P and B pictures)
     kinds = {p: k for p, k, _, _ in per}
     coded = []
 

@@ -86,6 +86,8 @@ def encode_ours(clip, W, H, qp, gop, tools, verbose=False, stats=None, pdelta=1,
         nmref = int(os.environ.get('RD_MREF', '1'))                   # experiment: the anchors of the hierarchy search the last RD_MREF anchors
         xrefs = lambda dd, kk, rr: [rr - j * G for j in range(nmref) if rr - j * G >= 0] if (kk == 'P' and gop == 'hier' and nmref > 1) else []
         mr = xrefs(d, kind, r0)
+        if getattr(encode_ours, "rdoq_select", None):
+            encode_ours.rdoq_select(kind)
         if len(mr) > 1:
             dpb[d] = o.encode_mref(clip[d], [dpb[r] for r in mr])
         else:
@@ -105,6 +107,8 @@ def encode_ours(clip, W, H, qp, gop, tools, verbose=False, stats=None, pdelta=1,
         else:
             b = w.slice(S.NAL_TRAIL_R if isref else S.NAL_TRAIL_N, S.SLICE_B, d, q, o.cu8, o.lvl, o.sao, rps=rps, l0=[r0], l1=[r1])
         bs += b
+        if getattr(encode_ours, "rdoq_adaptive", None):                  # --rdoq-adaptive: the tables of the NEXT picture of this kind come from this slice's final context states
+            encode_ours.rdoq_adaptive(kind, w)
         if stats:
             stats.ks265_bit_stats(st, 1)
             cu = o.cu8.reshape(H // 8, W // 8)
@@ -250,6 +254,7 @@ def main():
     ap.add_argument("--pingpong", type=int, default=0, metavar="K", help="the clip of the same-clip tables: K pictures of the generator played forth and back, --frames pictures in all")
     ap.add_argument("--pan", default="", help="pan of the synthetic clip in samples per picture, e.g. 8,5")
     ap.add_argument("--rdoq", type=int, default=0, metavar="MODE", help="experiment: the reference's rdoQuant (oracle/ks265_rdoq_ref.c) at the seam with static bit tables (medians of tests/golden/rdoq.npz); 1 = luma of P / B pictures, +2 chroma, +4 key pictures")
+    ap.add_argument("--rdoq-adaptive", action="store_true", help="with --rdoq: the bit tables follow the stream - built (pinned estBitRdoq) from the context states the writer ended the previous picture of the same kind with")
     ap.add_argument("--rdoq-mult", default="", help="the four lambda multipliers (luma sign-hiding, luma, chroma sign-hiding, chroma; reference: 256,256,90,90)")
     ap.add_argument("--split-bits-b", default="", help="experiment: what a split is taken to cost in a B picture's CU decision (1/16 bit), indexed by B layer (entry 0 unused; pipeline: 80 everywhere)")
     ap.add_argument("--merge-bits-b", type=int, default=0, metavar="Q4", help="experiment: what explicit motion is taken to cost (1/16 bit) when a B picture's CU weighs a merge candidate (pipeline: 32)")
@@ -288,6 +293,39 @@ def main():
         main._rq_T = T                                                 # keep alive
         mult = (C.c_int * 4)(*[int(x) for x in a.rdoq_mult.split(",")]) if a.rdoq_mult else None
         olib().kso_experiment_rdoq(T.ctypes.data_as(C.c_void_p), a.rdoq, mult)
+        if a.rdoq_adaptive:
+            # ADAPTIVE tables - what a device-side rdoQuant could be fed: after every slice the writer's final context states (ks265_slice_final_contexts) go
+            # through the pinned estBitRdoq (oracle) into the eight tables (4 sizes x luma / chroma) the next picture of the same kind is quantised with; the first picture of a
+            # kind starts from the static medians.  The entropy values are the reference's (tests/golden/estbits.npz `table` cases = HM's table).
+            ez = np.load(os.path.join(ROOT, "tests", "golden", "estbits.npz"))
+            ent = np.zeros(128, np.int32)
+            for i in range(int(ez["__n__"])):
+                if str(ez[f"c{i}__kind"]) == "table":
+                    ent[int(ez[f"c{i}__ctx"][0])] = ez[f"c{i}__exp"][0]
+            assert ent[0] == 0x7B23 and (ent > 0).all()
+            tabs = {k: T.copy() for k in "IPB"}
+            main._rq_tabs = tabs
+
+            def to_ref_layout(st, lay):
+                cbf_l, cbf_c, csbf, sig, lx, ly, g1, g2, root, _ = lay
+                c = np.zeros(256, np.uint8)
+                c[0x0d:0x0d + 2] = st[cbf_l:cbf_l + 2]; c[0x12:0x12 + 4] = st[cbf_c:cbf_c + 4]
+                c[0x1d:0x1d + 4] = st[csbf:csbf + 4]
+                c[0x21:0x21 + 42] = st[sig:sig + 42]
+                c[0x4b:0x4b + 18] = st[lx:lx + 18]; c[0x69:0x69 + 18] = st[ly:ly + 18]
+                c[0x87:0x87 + 24] = st[g1:g1 + 24]; c[0x9f:0x9f + 6] = st[g2:g2 + 6]
+                c[0xaa] = st[root]
+                return c
+
+            def adapt(kind, w):
+                st, lay = w.final_contexts()
+                c = to_ref_layout(st, lay)
+                for lg in range(2, 6):
+                    for ch in (0, 1):
+                        out = tabs[kind][lg - 2, ch]                      # (words the function does not write keep the static values)
+                        olib().ks265o_est_bit_rdoq(out.ctypes.data_as(C.c_void_p), lg, int(not ch), c.ctypes.data_as(C.c_void_p), ent.ctypes.data_as(C.c_void_p))
+            encode_ours.rdoq_adaptive = adapt
+            encode_ours.rdoq_select = lambda kind: olib().kso_experiment_rdoq(tabs[kind].ctypes.data_as(C.c_void_p), a.rdoq, mult)
     if a.split_bits_b:
         os.environ["RD_SPLIT_BITS_B"] = a.split_bits_b
     if a.merge_bits_b:
