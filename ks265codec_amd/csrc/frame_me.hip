@@ -63,7 +63,11 @@ __global__ __launch_bounds__(NC * 64, KS_SUBPEL_OCC) void me_subpel_kernel(KsGeo
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nctu = g.ctu_cols * g.ctu_rows;
     const int grp = ks_xcd_swizzle(blockIdx.x, (nctu + NC - 1) / NC);
+#ifdef KS_SUBPEL_STRIDED
+    const int ctu = wave * ((nctu + NC - 1) / NC) + grp;           // experiment: a work-group's CTUs spread over the picture (its work = the sum over them: evens out between work-groups)
+#else
     const int ctu = grp * NC + wave;                               // this wave keeps the books of one CTU, all four levels
+#endif
     const bool have = ctu < nctu;
     ks265_pu *cp = pus + (long)(have ? ctu : 0) * 85;
     const uint8_t *Sp = ks_org_y(g, src);
