@@ -63,10 +63,13 @@ __global__ __launch_bounds__(NC * 64, KS_SUBPEL_OCC) void me_subpel_kernel(KsGeo
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nctu = g.ctu_cols * g.ctu_rows;
     const int grp = ks_xcd_swizzle(blockIdx.x, (nctu + NC - 1) / NC);
-#ifdef KS_SUBPEL_STRIDED
-    const int ctu = wave * ((nctu + NC - 1) / NC) + grp;           // experiment: a work-group's CTUs spread over the picture (its work = the sum over them: evens out between work-groups)
+    // this wave keeps the books of one CTU, all four levels.  The group's CTUs are SPREAD over the picture (wave w takes CTU w x groups + g), not neighbours: at 2160p the kernel is
+    // one round of 255 work-groups on 256 compute units, so it lasts as long as its busiest work-group, and a work-group's work is the number of distinct (tile, centre) items of
+    // its eight CTUs - busy CTUs are neighbours (a moving edge), spread they even out: 0.182 -> 0.157 ms (round 5; KS_SUBPEL_ADJACENT restores the old grouping)
+#ifdef KS_SUBPEL_ADJACENT
+    const int ctu = grp * NC + wave;
 #else
-    const int ctu = grp * NC + wave;                               // this wave keeps the books of one CTU, all four levels
+    const int ctu = wave * ((nctu + NC - 1) / NC) + grp;
 #endif
     const bool have = ctu < nctu;
     ks265_pu *cp = pus + (long)(have ? ctu : 0) * 85;
