@@ -451,6 +451,14 @@ int ks265_encode_picture_mref(ks265_frame *f, ks265_pic src, const ks265_pic *re
 int ks265_encode_picture(ks265_frame *f, ks265_pic src, ks265_pic ref, int is_key, ks265_pic recon_out);
 /* a B picture: ref0 = list 0 (past), ref1 = list 1 (future); needs cfg.bframes > 0 at ks265_frame_create */
 int ks265_encode_picture_b(ks265_frame *f, ks265_pic src, ks265_pic ref0, ks265_pic ref1, ks265_pic recon_out);
+/* a B picture with several reference pictures per list (round 5; cfg.refs > 1 at ks265_frame_create; -ref with B pictures: -preset veryslow = 4 / 4): refs0 = pictures BEFORE this one
+ * in display order, nearest first (n0 <= cfg.refs), refs1 = pictures after it, nearest first; no picture in both lists.  One search per picture, ks265_ref_pick keeps per PU and list the
+ * picture with the smallest cost + lambda x ref_idx bits (truncated unary; ties to the nearest), the bi-predictive decision pairs the lists' winners; ks265_cu8.inter_dir =
+ * direction | idx0 << 4 | idx1 << 6 (an unused list's index is 0).  HOST arrays */
+int ks265_encode_picture_b_mref(ks265_frame *f, ks265_pic src, const ks265_pic *refs0, int n0, const ks265_pic *refs1, int n1, ks265_pic recon_out);
+/* one list's per-PU choice: dev_pu[r] = the records of the search in the list's picture r (HOST array of device pointers); out (may be dev_pu[0]) = the winner's record with the index
+ * bits in its cost, dev_idx = its picture, one byte per record */
+int ks265_ref_pick(ks265_frame *f, int nref, const ks265_pu *const *dev_pu, ks265_pu *dev_out, uint8_t *dev_idx);
 /* in-situ stage timing: HIP events recorded on the context's stream between the stages of ks265_encode_picture;
  * ms[] = {me_integer, me_subpel, intra_candidates, cu_decide (+ merge pass), reconstruct, intra_pass, deblock, sao (+ padding)} of the last picture, -1 = not run
  * (a key picture: intra_candidates = the mode pre-selection, intra_pass = the wavefront reconstruction) */

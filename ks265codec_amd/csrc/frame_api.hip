@@ -51,6 +51,10 @@ int ks265_frame_create(ks265_ctx *ctx, const ks265_frame_cfg *cfg, ks265_frame *
         r = dev_alloc(ctx, (void **)&f->pu_x[x], (size_t)geom.bytes_pu, true);
     }
     if (cfg->refs > 1 && !f->pub && !r) r = dev_alloc(ctx, (void **)&f->pub, (size_t)geom.ctu_cols * geom.ctu_rows * 85 * sizeof(ks265_pu_b), true);
+    if (cfg->refs > 1 && cfg->bframes > 0) {                       /* multi-reference B pictures: list 1's pictures 1 .. refs - 1, and per list the index of every PU's picture */
+        for (int x = 0; x + 1 < cfg->refs && !r; ++x) r = dev_alloc(ctx, (void **)&f->pu1_x[x], (size_t)geom.bytes_pu, true);
+        for (int l = 0; l < 2 && !r; ++l) r = dev_alloc(ctx, (void **)&f->ridx[l], (size_t)geom.ctu_cols * geom.ctu_rows * 85, true);
+    }
     if (!r && cfg->intra_inter) {                                  /* intra candidates of P / B pictures: cost and mode of every block */
         r = dev_alloc(ctx, (void **)&f->icost, (size_t)geom.ctu_cols * geom.ctu_rows * 85 * sizeof(uint32_t), true);
     }
@@ -86,7 +90,7 @@ void ks265_frame_destroy(ks265_frame *f)
     if (f->ev_join) (void)hipEventDestroy(f->ev_join);
     for (int i = 0; i < 10; ++i)
         if (f->pyr2[i] && f->pyr2[i] != f->pyr[i]) (void)hipFree(f->pyr2[i]);
-    void *ptrs[] = {f->pu_s2, f->pu1, f->pu_s, f->pub, f->pu[0], f->pu[1], f->cu8, f->sao, f->lvl[0], f->lvl[1], f->lvl[2], f->deb[0], f->deb[1], f->deb[2], f->sse, f->sse_acc, f->cu8_tmp, f->progress, f->mats, f->icost, f->rect, f->pu_x[0], f->pu_x[1], f->pu_x[2]};
+    void *ptrs[] = {f->pu1_x[0], f->pu1_x[1], f->pu1_x[2], f->ridx[0], f->ridx[1], f->pu_s2, f->pu1, f->pu_s, f->pub, f->pu[0], f->pu[1], f->cu8, f->sao, f->lvl[0], f->lvl[1], f->lvl[2], f->deb[0], f->deb[1], f->deb[2], f->sse, f->sse_acc, f->cu8_tmp, f->progress, f->mats, f->icost, f->rect, f->pu_x[0], f->pu_x[1], f->pu_x[2]};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (uint8_t *p : f->pyr)
@@ -223,13 +227,50 @@ int ks265_encode_picture_mref(ks265_frame *f, ks265_pic src, const ks265_pic *re
 
 /* B picture: both uni-directional searches, the bi candidate, the CU tree, then the common back end.
  * The temporal predictor chain of the P pictures (pu ping-pong) is left untouched. */
+static int encode_b_lists(ks265_frame *f, ks265_pic src, const ks265_pic *refs0, int n0, const ks265_pic *refs1, int n1, ks265_pic recon_out);
 int ks265_encode_picture_b(ks265_frame *f, ks265_pic src, ks265_pic ref0, ks265_pic ref1, ks265_pic recon_out)
 {
     KS_FRAME_CHECK(f);
     if (!src.y || !ref0.y || !ref1.y || !recon_out.y) return KS265_POINTER;
     if (!f->pu1) return KS265_NOTSUPPORTED;                   /* created with cfg.bframes == 0 */
+    return encode_b_lists(f, src, &ref0, 1, &ref1, 1, recon_out);
+}
+/* a B picture with n0 / n1 <= cfg.refs pictures per list (round 5; -ref with B pictures: config 5 = -preset veryslow resolves to 4 / 4): list 0 = pictures BEFORE this one in
+ * display order, nearest first; list 1 = pictures after it, nearest first; no picture in both lists (the boundary strength compares list indices).  Every picture of a list is
+ * searched on its own (list 1's chain on the side stream beside list 0's), ks265_ref_pick keeps per PU and list the cheapest (+ lambda x ref_idx bits), the bi-predictive decision
+ * pairs the winners; ks265_cu8.inter_dir = direction | idx0 << 4 | idx1 << 6 */
+int ks265_encode_picture_b_mref(ks265_frame *f, ks265_pic src, const ks265_pic *refs0, int n0, const ks265_pic *refs1, int n1, ks265_pic recon_out)
+{
+    KS_FRAME_CHECK(f);
+    if (!src.y || !refs0 || !refs1 || !recon_out.y) return KS265_POINTER;
+    if (!f->pu1) return KS265_NOTSUPPORTED;
+    const int cap = f->cfg.refs > 1 ? f->cfg.refs : 1;
+    if (n0 < 1 || n1 < 1 || n0 > cap || n1 > cap || n0 > 4 || n1 > 4) return KS265_NOTSUPPORTED;
+    if ((n0 > 1 || n1 > 1) && (!f->ridx[0] || !f->pu_x[0])) return KS265_NOTSUPPORTED;
+    for (int i = 0; i < n0; ++i) if (!refs0[i].y) return KS265_POINTER;
+    for (int i = 0; i < n1; ++i) if (!refs1[i].y) return KS265_POINTER;
+    return encode_b_lists(f, src, refs0, n0, refs1, n1, recon_out);
+}
+static int encode_b_lists(ks265_frame *f, ks265_pic src, const ks265_pic *refs0, int n0, const ks265_pic *refs1, int n1, ks265_pic recon_out)
+{
+    const ks265_pic ref0 = refs0[0], ref1 = refs1[0];
+    const bool mr = n0 > 1 || n1 > 1;
     int r;
     ks265_pu *pu0 = f->pu[f->cur_pu];                         /* scratch: the next P picture overwrites it */
+    /* one list's chain on the stream the context holds at the moment: every picture of the list searched and refined, then (several pictures) the per-PU choice */
+    auto chain = [&](int l) -> int {
+        const ks265_pic *refs = l ? refs1 : refs0; const int n = l ? n1 : n0;
+        const ks265_pu *pus[4];
+        int rr = 0;
+        for (int i = 0; i < n && !rr; ++i) {
+            ks265_pu *pu = i == 0 ? (l ? f->pu1 : pu0) : (l ? f->pu1_x[i - 1] : f->pu_x[i - 1]);
+            pus[i] = pu;
+            rr = me_search(f, src, refs[i], nullptr, pu);
+            if (!rr && f->cfg.subme) rr = ks265_me_subpel(f, src, refs[i], pu);
+        }
+        if (!rr && mr) rr = ks265_ref_pick(f, n, pus, l ? f->pu1 : pu0, f->ridx[l]);
+        return rr;
+    };
     const bool par = f->b_parallel && f->side && f->cfg.pre_search && (!f->cfg.propagate || f->pu_s2);
     if (par) {
         /* the two searches are independent chains (pre-search, integer search, propagation, sub-pel refinement: ~ 0.4 ms each at 2160p, each kernel with a long tail of
@@ -245,20 +286,22 @@ int ks265_encode_picture_b(ks265_frame *f, ks265_pic src, ks265_pic ref0, ks265_
         };
         f->src_pyr_ready = true;
         f->ctx->stream = f->side; swap_ws();
-        r = me_search(f, src, ref1, nullptr, f->pu1);
-        if (!r && f->cfg.subme) r = ks265_me_subpel(f, src, ref1, f->pu1);
+        r = chain(1);
         if (!r) r = ks265_hip(f->ctx, hipEventRecord(f->ev_join, f->side));
         f->ctx->stream = mainst; swap_ws();
-        if (!r) r = me_search(f, src, ref0, nullptr, pu0);
-        if (!r && f->cfg.subme) r = ks265_me_subpel(f, src, ref0, pu0);
+        if (!r) r = chain(0);
         f->src_pyr_ready = false;
         if (r) return r;
         if ((r = ks265_hip(f->ctx, hipStreamWaitEvent(f->ctx->stream, f->ev_join, 0)))) return r;
     } else {
-    if ((r = me_search(f, src, ref0, nullptr, pu0))) return r;
-    if (f->cfg.subme && (r = ks265_me_subpel(f, src, ref0, pu0))) return r;
-    if ((r = me_search(f, src, ref1, nullptr, f->pu1))) return r;
-    if (f->cfg.subme && (r = ks265_me_subpel(f, src, ref1, f->pu1))) return r;
+    if ((r = chain(0))) return r;
+    if ((r = chain(1))) return r;
+    }
+    /* several pictures per list: from here to the reconstruction every stage takes a block's pictures from its record */
+    struct MrScope { ks265_frame *f; ~MrScope() { f->mrefb = false; } } scope{f};
+    if (mr) {
+        f->mrefb = true; f->mr_n[0] = n0; f->mr_n[1] = n1;
+        for (int i = 0; i < 4; ++i) { f->mr_pic[0][i] = refs0[i < n0 ? i : n0 - 1]; f->mr_pic[1][i] = refs1[i < n1 ? i : n1 - 1]; }
     }
     if ((r = ks265_bi_decide(f, src, ref0, ref1, pu0, f->pu1, f->pub))) return r;
     const bool ii = f->cfg.intra_inter != 0;

@@ -11,6 +11,13 @@
 // cfg.part: what a CU of 64 / 32 / 16 samples costs in two halves (ks265_rect_decide): [0] = 2NxN (top, bottom), [1] = Nx2N (left, right); cost KS_COST_INVALID = not considered
 struct KsRect { unsigned cost[2]; short mv[2][2][2]; short mv1[2][2][2]; unsigned char dir[2][2]; };   // B pictures: mv1 / dir = the half's list-1 vector and direction (ks265_cu_decide_part_b)
 
+// Multi-reference B pictures (round 5; -preset veryslow = config 5: ref 4 / 4).  A block's pictures come from its record: inter_dir = direction | idx0 << 4 | idx1 << 6 (an
+// index of a list the block does not use is 0: equal bytes = equal pictures, which is what the boundary strength compares).  Kernels pick a list's picture with selects - an
+// indexed pointer array would lose the global address space.  idx0 / idx1: per PU record (85 per CTU) the picture ks265_ref_pick chose for the list; bits: lambda x ref_idx bits.
+struct KsRefList { const uint8_t *p[4]; };
+__device__ __forceinline__ const uint8_t *ks_pick(const KsRefList &r, int i) { return i == 0 ? r.p[0] : (i == 1 ? r.p[1] : (i == 2 ? r.p[2] : r.p[3])); }
+struct KsMrefB { KsRefList y0, y1; const uint8_t *idx0, *idx1; int bits0[4], bits1[4]; };
+
 struct KsGeom {
     int W, H;                 // luma size
     int sy, sc;               // strides
@@ -59,6 +66,13 @@ struct ks265_frame {
     unsigned *me_work = nullptr, *me_work_all[2] = {nullptr, nullptr};
     int *me_order = nullptr, *me_order_all[2] = {nullptr, nullptr};
     int me_order_off = 0;               // KS265_ME_ORDER_OFF: experiments
+    // multi-reference B picture being coded (ks265_encode_picture_b_mref sets it for the duration of the picture: ks265_bi_decide, ks265_merge_pass, ks265_cu_decide_part_b and
+    // ks265_reconstruct_b then take every block's pictures from its record); host-side copies of the lists + the per-PU index arrays and the extra list-1 PU records
+    bool mrefb = false;
+    int mr_n[2] = {1, 1};
+    ks265_pic mr_pic[2][4] = {};
+    uint8_t *ridx[2] = {nullptr, nullptr};
+    ks265_pu *pu1_x[3] = {nullptr, nullptr, nullptr};
     bool src_pyr_ready = false;         // ks265_presearch: the source picture's pyramid is in place (skip its pyr_down launch)
     int b_parallel = 1;                 // 0: the two searches one after the other on the context's stream (graph capture, experiments: KS265_B_SERIAL)
     // optional in-situ stage timing (HIP events on the context's stream, between the stages of ks265_encode_picture)

@@ -616,9 +616,9 @@ __device__ __forceinline__ unsigned satd8x8_avg(const unsigned (&f)[16], const u
 // register rows (v_sad_u8, static v_alignbyte per column), summed over the PU's lanes by DPP, + vector rate, first minimum in row-major order
 // (key = cost << 6 | position).  Sub-pel step: the two rings of stage B on T, SAD + rate like the integer step.  The refined pair replaces the decision when
 // its SATD against the rounded average + both vector rates is lower.
-template <bool REFINE>
-__global__ __launch_bounds__(256, REFINE ? 2 : 1) void bi_decide_kernel(KsGeom g, int lam, const uint8_t *src, const uint8_t *ref0, const uint8_t *ref1,
-                                                        const ks265_pu *pu0, const ks265_pu *pu1, ks265_pu_b *pub)
+template <bool REFINE, bool MR>
+__global__ __launch_bounds__(256, REFINE ? 2 : 1) void bi_decide_kernel(KsGeom g, int lam, const uint8_t *src, const uint8_t *ref0_, const uint8_t *ref1_,
+                                                        const ks265_pu *pu0, const ks265_pu *pu1, ks265_pu_b *pub, const KsMrefB mr)
 {
     const int tid = threadIdx.x, lane = tid & 63, level = tid >> 6;
     const int ctu = ks_xcd_swizzle(blockIdx.x, g.ctu_cols * g.ctu_rows), cx = ctu % g.ctu_cols, cy = ctu / g.ctu_cols;
@@ -628,8 +628,13 @@ __global__ __launch_bounds__(256, REFINE ? 2 : 1) void bi_decide_kernel(KsGeom g
     const int px = tx >> (3 - level), py = ty >> (3 - level), pidx = ks_level_base(level) + py * (1 << level) + px;
     const ks265_pu a = pu0[(long)ctu * 85 + pidx], b = pu1[(long)ctu * 85 + pidx];
     const bool valid = a.cost != KS_COST_INVALID;
+    // several pictures per list (MR): the two records are the lists' winners (ks265_ref_pick: their costs hold the index bits), i0 / i1 their pictures
+    const int i0 = MR ? mr.idx0[(long)ctu * 85 + pidx] : 0, i1 = MR ? mr.idx1[(long)ctu * 85 + pidx] : 0;
+    const uint8_t *const ref0 = MR ? ks_pick(mr.y0, i0) : ref0_, *const ref1 = MR ? ks_pick(mr.y1, i1) : ref1_;
+    const unsigned rbits = MR ? (unsigned)((i0 == 0 ? mr.bits0[0] : i0 == 1 ? mr.bits0[1] : i0 == 2 ? mr.bits0[2] : mr.bits0[3]) + (i1 == 0 ? mr.bits1[0] : i1 == 1 ? mr.bits1[1] : i1 == 2 ? mr.bits1[2] : mr.bits1[3])) : 0u;
+    auto bidir = [&](unsigned d) { return d | ((d & 1u) ? (unsigned)i0 << 4 : 0u) | ((d & 2u) ? (unsigned)i1 << 6 : 0u); };
     ks265_pu_b o;
-    o.mvx = a.mvx; o.mvy = a.mvy; o.mv1x = b.mvx; o.mv1y = b.mvy; o.cost = a.cost; o.inter_dir = 1;
+    o.mvx = a.mvx; o.mvy = a.mvy; o.mv1x = b.mvx; o.mv1y = b.mvy; o.cost = a.cost; o.inter_dir = bidir(1);
     if (__any(valid)) {
         const uint8_t *Sp = ks_org_y(g, src);
         unsigned f[16];
@@ -644,10 +649,10 @@ __global__ __launch_bounds__(256, REFINE ? 2 : 1) void bi_decide_kernel(KsGeom g
         const unsigned sd = satd8x8_avg(f, PA, PB);
         const unsigned dd = pu_group_sum(valid ? sd : 0, level);
         if (valid) {
-            if (b.cost < o.cost) { o.cost = b.cost; o.inter_dir = 2; }
-            unsigned c = dd + (unsigned)mv_cost(a.mvx, a.mvy, a.mvpx, a.mvpy, lam) + (unsigned)mv_cost(b.mvx, b.mvy, b.mvpx, b.mvpy, lam);
+            if (b.cost < o.cost) { o.cost = b.cost; o.inter_dir = bidir(2); }
+            unsigned c = dd + (unsigned)mv_cost(a.mvx, a.mvy, a.mvpx, a.mvpy, lam) + (unsigned)mv_cost(b.mvx, b.mvy, b.mvpx, b.mvpy, lam) + rbits;
             c -= c >> KS_BI_BIAS_SHIFT;                            // a bi-predictive pair counts 31 / 32 of its cost (the oracle's BI_BIAS_SHIFT: - 3.3 % bytes on hierarchical B)
-            if (c < o.cost) { o.cost = c; o.inter_dir = 3; }
+            if (c < o.cost) { o.cost = c; o.inter_dir = bidir(3); }
         }
         if (REFINE) {
             const bool keep1 = valid && b.cost < a.cost;                 // list whose vector stays (uniform over the PU's lanes)
@@ -785,10 +790,10 @@ __global__ __launch_bounds__(256, REFINE ? 2 : 1) void bi_decide_kernel(KsGeom g
             const unsigned d2 = pu_group_sum(valid ? satd8x8_avg(f, PK, PO) : 0, level);
             if (valid) {
                 unsigned c2 = d2 + (unsigned)(keep1 ? mv_cost(b.mvx, b.mvy, b.mvpx, b.mvpy, lam) : mv_cost(a.mvx, a.mvy, a.mvpx, a.mvpy, lam))
-                              + (unsigned)mv_cost(rbx, rby, opx, opy, lam);
+                              + (unsigned)mv_cost(rbx, rby, opx, opy, lam) + rbits;
                 c2 -= c2 >> KS_BI_BIAS_SHIFT;
                 if (c2 < o.cost) {
-                    o.cost = c2; o.inter_dir = 3;
+                    o.cost = c2; o.inter_dir = bidir(3);
                     if (keep1) { o.mvx = (int16_t)rbx; o.mvy = (int16_t)rby; } else { o.mv1x = (int16_t)rbx; o.mv1y = (int16_t)rby; }
                 }
             }
@@ -797,17 +802,34 @@ __global__ __launch_bounds__(256, REFINE ? 2 : 1) void bi_decide_kernel(KsGeom g
     if ((lane & (G - 1)) == 0) pub[(long)ctu * 85 + pidx] = o;
 }
 
+// the lists of the multi-reference B picture being coded as kernel arguments (entries past a list's size repeat its last picture); all zero when none is
+static KsMrefB ks_mrefb(const ks265_frame *f)
+{
+    KsMrefB m{};
+    if (!f->mrefb) return m;
+    for (int i = 0; i < 4; ++i) {
+        m.y0.p[i] = f->mr_pic[0][i < f->mr_n[0] ? i : f->mr_n[0] - 1].y; m.y1.p[i] = f->mr_pic[1][i < f->mr_n[1] ? i : f->mr_n[1] - 1].y;
+        const int b0 = f->mr_n[0] <= 1 ? 0 : (i < f->mr_n[0] - 1 ? i + 1 : f->mr_n[0] - 1), b1 = f->mr_n[1] <= 1 ? 0 : (i < f->mr_n[1] - 1 ? i + 1 : f->mr_n[1] - 1);
+        m.bits0[i] = (f->cfg.lambda_q4 * b0) >> 4; m.bits1[i] = (f->cfg.lambda_q4 * b1) >> 4;
+    }
+    m.idx0 = f->ridx[0]; m.idx1 = f->ridx[1];
+    return m;
+}
+
 extern "C" int ks265_bi_decide(ks265_frame *f, ks265_pic src, ks265_pic ref0, ks265_pic ref1, const ks265_pu *pu0, const ks265_pu *pu1,
                                ks265_pu_b *pub)
 {
     KS_FRAME_CHECK(f);
     if (!src.y || !ref0.y || !ref1.y || !pu0 || !pu1 || !pub) return KS265_POINTER;
-    if (f->cfg.bi_refine)
-        hipLaunchKernelGGL(bi_decide_kernel<true>, dim3(f->g.ctu_cols * f->g.ctu_rows), dim3(256), 0, f->ctx->stream, f->g, f->cfg.lambda_q4, src.y, ref0.y,
-                           ref1.y, pu0, pu1, pub);
-    else
-        hipLaunchKernelGGL(bi_decide_kernel<false>, dim3(f->g.ctu_cols * f->g.ctu_rows), dim3(256), 0, f->ctx->stream, f->g, f->cfg.lambda_q4, src.y, ref0.y,
-                           ref1.y, pu0, pu1, pub);
+    const dim3 grid(f->g.ctu_cols * f->g.ctu_rows), block(256);
+    const KsMrefB mr = ks_mrefb(f);
+    if (f->mrefb) {
+        if (f->cfg.bi_refine) hipLaunchKernelGGL((bi_decide_kernel<true, true>), grid, block, 0, f->ctx->stream, f->g, f->cfg.lambda_q4, src.y, ref0.y, ref1.y, pu0, pu1, pub, mr);
+        else hipLaunchKernelGGL((bi_decide_kernel<false, true>), grid, block, 0, f->ctx->stream, f->g, f->cfg.lambda_q4, src.y, ref0.y, ref1.y, pu0, pu1, pub, mr);
+    } else {
+        if (f->cfg.bi_refine) hipLaunchKernelGGL((bi_decide_kernel<true, false>), grid, block, 0, f->ctx->stream, f->g, f->cfg.lambda_q4, src.y, ref0.y, ref1.y, pu0, pu1, pub, mr);
+        else hipLaunchKernelGGL((bi_decide_kernel<false, false>), grid, block, 0, f->ctx->stream, f->g, f->cfg.lambda_q4, src.y, ref0.y, ref1.y, pu0, pu1, pub, mr);
+    }
     return ks265_check_launch(f->ctx);
 }
 
@@ -910,8 +932,9 @@ __global__ __launch_bounds__(192) void rect_eval_kernel(KsGeom g, int lam, const
 // samples of its list or against the rounded average of both lists' 8-bit predictions (bi_decide_kernel's measure), a bi-predictive half counts 31 / 32.
 struct KsMot { int v0, v1, dir; };
 __device__ __forceinline__ bool mot_same(const KsMot &a, const KsMot &b) { return a.dir == b.dir && (!(a.dir & 1) || a.v0 == b.v0) && (!(a.dir & 2) || a.v1 == b.v1); }
+template <bool MR>
 __global__ __launch_bounds__(192) void rect_eval_b_kernel(KsGeom g, int lam, const uint8_t *src, const uint8_t *ref0, const uint8_t *ref1, const ks265_pu *pu0, const ks265_pu *pu1,
-                                                          const ks265_pu_b *pubs, KsRect *rect)
+                                                          const ks265_pu_b *pubs, KsRect *rect, const KsMrefB mr)
 {
     const int tid = threadIdx.x, lane = tid & 63, l = tid >> 6;
     const int ctu = ks_xcd_swizzle(blockIdx.x, g.ctu_cols * g.ctu_rows), cx = ctu % g.ctu_cols, cy = ctu / g.ctu_cols;
@@ -925,7 +948,7 @@ __global__ __launch_bounds__(192) void rect_eval_b_kernel(KsGeom g, int lam, con
     const bool valid = P.cost != KS_COST_INVALID;
     const int cb = ks_level_base(l + 1), cw = 2 << l;
     const ks265_pu_b cO = cp[cb + (2 * cuy + qy) * cw + 2 * cux + qx], cH = cp[cb + (2 * cuy + qy) * cw + 2 * cux + (qx ^ 1)], cV = cp[cb + (2 * cuy + (qy ^ 1)) * cw + 2 * cux + qx];
-    auto mot = [&](const ks265_pu_b &r) { KsMot m; m.v0 = (int)(unsigned short)r.mvx | ((int)r.mvy << 16); m.v1 = (int)(unsigned short)r.mv1x | ((int)r.mv1y << 16); m.dir = (int)(r.inter_dir & 3u); return m; };
+    auto mot = [&](const ks265_pu_b &r) { KsMot m; m.v0 = (int)(unsigned short)r.mvx | ((int)r.mvy << 16); m.v1 = (int)(unsigned short)r.mv1x | ((int)r.mv1y << 16); m.dir = (int)(MR ? (r.inter_dir & 255u) : (r.inter_dir & 3u)); return m; };      // (several pictures per list: the whole byte - the motion's pictures belong to it)
     KsMot mP = mot(P);
     if (!valid) { mP.v0 = 0; mP.v1 = 0; mP.dir = 1; }
     const KsMot mO = valid && cO.cost != KS_COST_INVALID ? mot(cO) : mP, mH = valid && cH.cost != KS_COST_INVALID ? mot(cH) : mP, mV = valid && cV.cost != KS_COST_INVALID ? mot(cV) : mP;
@@ -938,10 +961,11 @@ __global__ __launch_bounds__(192) void rect_eval_b_kernel(KsGeom g, int lam, con
     const long base = (long)(valid ? y0 : 0) * g.sy + (valid ? x0 : 0) + g.org_y;
     auto tile = [&](const KsMot &m) {
         unsigned A[16], B[16];
-        if (__any(m.dir & 1)) luma_pred_tile8(ref0 + base, g.sy, (int)(short)(m.v0 & 0xFFFF), m.v0 >> 16, A);
-        if (__any(m.dir & 2)) luma_pred_tile8(ref1 + base, g.sy, (int)(short)(m.v1 & 0xFFFF), m.v1 >> 16, B);
-        if (m.dir == 1) { for (int i = 0; i < 16; ++i) B[i] = A[i]; }
-        else if (m.dir == 2) { for (int i = 0; i < 16; ++i) A[i] = B[i]; }
+        const uint8_t *r0 = MR ? ks_pick(mr.y0, (m.dir >> 4) & 3) : ref0, *r1 = MR ? ks_pick(mr.y1, (m.dir >> 6) & 3) : ref1;
+        if (__any(m.dir & 1)) luma_pred_tile8(r0 + base, g.sy, (int)(short)(m.v0 & 0xFFFF), m.v0 >> 16, A);
+        if (__any(m.dir & 2)) luma_pred_tile8(r1 + base, g.sy, (int)(short)(m.v1 & 0xFFFF), m.v1 >> 16, B);
+        if ((m.dir & 3) == 1) { for (int i = 0; i < 16; ++i) B[i] = A[i]; }
+        else if ((m.dir & 3) == 2) { for (int i = 0; i < 16; ++i) A[i] = B[i]; }
         return satd8x8_avg(f, A, B);                                  // one list: (p + p + 1) >> 1 = p
     };
     unsigned sP = 0, sO = 0, sH = 0, sV = 0;
@@ -966,7 +990,7 @@ __global__ __launch_bounds__(192) void rect_eval_b_kernel(KsGeom g, int lam, con
         unsigned c = satd;
         if (m.dir & 1) c += (unsigned)mv_cost((int)(short)(m.v0 & 0xFFFF), m.v0 >> 16, a.mvpx, a.mvpy, lam);
         if (m.dir & 2) c += (unsigned)mv_cost((int)(short)(m.v1 & 0xFFFF), m.v1 >> 16, b.mvpx, b.mvpy, lam);
-        if (m.dir == 3) c -= c >> KS_BI_BIAS_SHIFT;
+        if ((m.dir & 3) == 3) c -= c >> KS_BI_BIAS_SHIFT;
         return c;
     };
     unsigned best[2]; KsMot bm[2];
@@ -1016,7 +1040,8 @@ extern "C" int ks265_cu_decide_part_b(ks265_frame *f, ks265_pic src, ks265_pic r
     if (!src.y || !ref0.y || !ref1.y || !pu0 || !pu1 || !pub || !cu8) return KS265_POINTER;
     if (!f->rect) return KS265_NOTSUPPORTED;                                      // the frame object was created without cfg.part
     const int nctu = f->g.ctu_cols * f->g.ctu_rows;
-    hipLaunchKernelGGL(rect_eval_b_kernel, dim3(nctu), dim3(192), 0, f->ctx->stream, f->g, f->cfg.lambda_q4, src.y, ref0.y, ref1.y, pu0, pu1, pub, (KsRect *)f->rect);
+    if (f->mrefb) hipLaunchKernelGGL(rect_eval_b_kernel<true>, dim3(nctu), dim3(192), 0, f->ctx->stream, f->g, f->cfg.lambda_q4, src.y, ref0.y, ref1.y, pu0, pu1, pub, (KsRect *)f->rect, ks_mrefb(f));
+    else hipLaunchKernelGGL(rect_eval_b_kernel<false>, dim3(nctu), dim3(192), 0, f->ctx->stream, f->g, f->cfg.lambda_q4, src.y, ref0.y, ref1.y, pu0, pu1, pub, (KsRect *)f->rect, KsMrefB{});
     hipLaunchKernelGGL(cu_decide_kernel<ks265_pu_b>, dim3(nctu), dim3(64), 0, f->ctx->stream, f->g, f->cfg.lambda_q4, pub, cu8, ibest, (const KsRect *)f->rect);
     return ks265_check_launch(f->ctx);
 }
@@ -1046,6 +1071,7 @@ __device__ __forceinline__ int z_of_8(int x, int y)
     const int bx = (x >> 3) & 7, by = (y >> 3) & 7;
     return (bx & 1) | ((by & 1) << 1) | ((bx & 2) << 1) | ((by & 2) << 2) | ((bx & 4) << 2) | ((by & 4) << 3);
 }
+template <bool MR>
 __device__ __forceinline__ MergeMotion merge_cand(const KsGeom &g, const ks265_cu8 *cu_in, int x, int y, int n, int k, bool is_b)
 {
     MergeMotion m; m.dir = is_b ? 3 : 1; m.mvx = m.mvy = m.mv1x = m.mv1y = 0; m.ok = true;
@@ -1057,14 +1083,15 @@ __device__ __forceinline__ MergeMotion merge_cand(const KsGeom &g, const ks265_c
     if (nctb > ctb || (nctb == ctb && z_of_8(nx, ny) >= z_of_8(x, y))) return m;
     const ks265_cu8 c = cu_in[(long)(ny >> 3) * g.w8 + (nx >> 3)];
     if (c.pred_mode != 0 || (c.log2_cu & 15) < 3) return m;
-    m.dir = c.inter_dir & 3; m.mvx = c.mvx; m.mvy = c.mvy; m.mv1x = c.mv1x; m.mv1y = c.mv1y; m.ok = true;
+    m.dir = MR ? (int)c.inter_dir : (c.inter_dir & 3); m.mvx = c.mvx; m.mvy = c.mvy; m.mv1x = c.mv1x; m.mv1y = c.mv1y; m.ok = true;      // (MR: the neighbour's pictures come with its motion)
     // a neighbour's vector may come from a CTU with another window offset: taken over here it must keep this CU's block inside the planes' margin
     if ((m.dir & 1) && (x + (m.mvx >> 2) < -70 || x + (m.mvx >> 2) + n > g.W + 70 || y + (m.mvy >> 2) < -70 || y + (m.mvy >> 2) + n > g.H + 70)) m.ok = false;
     if ((m.dir & 2) && (x + (m.mv1x >> 2) < -70 || x + (m.mv1x >> 2) + n > g.W + 70 || y + (m.mv1y >> 2) < -70 || y + (m.mv1y >> 2) + n > g.H + 70)) m.ok = false;
     return m;
 }
+template <bool MR>
 __global__ __launch_bounds__(256) void merge_pass_kernel(KsGeom g, int lam, const uint8_t *src, const uint8_t *ref0, const uint8_t *ref1, const ks265_pu *pu,
-                                                         const ks265_pu_b *pub, const ks265_cu8 *cu_in, ks265_cu8 *cu_out)
+                                                         const ks265_pu_b *pub, const ks265_cu8 *cu_in, ks265_cu8 *cu_out, const KsMrefB mr)
 {
     __shared__ unsigned long long jbest[64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1089,7 +1116,7 @@ __global__ __launch_bounds__(256) void merge_pass_kernel(KsGeom g, int lam, cons
         MergeMotion mm[6];
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
-            mm[k] = merge_cand(g, cu_in, cux, cuy, n, k, is_b);
+            mm[k] = merge_cand<MR>(g, cu_in, cux, cuy, n, k, is_b);
             const bool ok = valid && mm[k].ok;
             mask |= (ok ? 1u : 0u) << k;
             bool rep = false;
@@ -1116,13 +1143,14 @@ __global__ __launch_bounds__(256) void merge_pass_kernel(KsGeom g, int lam, cons
         int k = 0;                                                     // the it-th distinct candidate of this lane's CU
         { unsigned d = distinct; for (int q = 0; q < it; ++q) d &= d - 1u; k = d ? __ffs((int)d) - 1 : 0; }
         const bool on = __popc(distinct) > it;
-        const MergeMotion m = merge_cand(g, cu_in, cux, cuy, n, k, is_b);
+        const MergeMotion m = merge_cand<MR>(g, cu_in, cux, cuy, n, k, is_b);
         const int ax = on ? m.mvx : 0, ay = on ? m.mvy : 0, bx = on ? m.mv1x : 0, by = on ? m.mv1y : 0, dir = on ? m.dir : 1;
         unsigned sd = 0;
         if (__any(on)) {
             unsigned PA[16], PB[16];                                   // the candidate's prediction tiles, interpolated from the reference pictures (interp_dev.h)
-            if (dir & 1) luma_pred_tile8(ref0 + base, g.sy, ax, ay, PA);
-            if (dir & 2) luma_pred_tile8(ref1 + base, g.sy, bx, by, PB);
+            const uint8_t *r0 = MR ? ks_pick(mr.y0, (dir >> 4) & 3) : ref0, *r1 = MR ? ks_pick(mr.y1, (dir >> 6) & 3) : ref1;
+            if (dir & 1) luma_pred_tile8(r0 + base, g.sy, ax, ay, PA);
+            if (dir & 2) luma_pred_tile8(r1 + base, g.sy, bx, by, PB);
 #pragma unroll
             for (int i = 0; i < 16; ++i) { if (!(dir & 1)) PA[i] = PB[i]; if (!(dir & 2)) PB[i] = PA[i]; }
             sd = satd8x8_avg(f, PA, PB);
@@ -1146,8 +1174,8 @@ __global__ __launch_bounds__(256) void merge_pass_kernel(KsGeom g, int lam, cons
         if (valid) {
             const unsigned long long jb = jbest[leader], jc = (unsigned long long)cur + (unsigned long long)((lam * 32) >> 4);
             if ((jb >> 8) < jc) {
-                const MergeMotion m = merge_cand(g, cu_in, cux, cuy, n, (int)(jb & 255ull), is_b);
-                o.mvx = (int16_t)m.mvx; o.mvy = (int16_t)m.mvy; o.mv1x = (int16_t)m.mv1x; o.mv1y = (int16_t)m.mv1y; o.inter_dir = (uint8_t)(m.dir & 3);
+                const MergeMotion m = merge_cand<MR>(g, cu_in, cux, cuy, n, (int)(jb & 255ull), is_b);
+                o.mvx = (int16_t)m.mvx; o.mvy = (int16_t)m.mvy; o.mv1x = (int16_t)m.mv1x; o.mv1y = (int16_t)m.mv1y; o.inter_dir = (uint8_t)(MR ? m.dir : (m.dir & 3));
             }
         }
         cu_out[(long)(y0 >> 3) * g.w8 + (x0 >> 3)] = o;
@@ -1159,7 +1187,8 @@ extern "C" int ks265_merge_pass(ks265_frame *f, ks265_pic src, ks265_pic ref0, k
 {
     KS_FRAME_CHECK(f);
     if (!src.y || !ref0.y || !cu_in || !cu_out || cu_in == cu_out || (!pu && !pub) || (pub && !ref1.y)) return KS265_POINTER;
-    hipLaunchKernelGGL(merge_pass_kernel, dim3(f->g.ctu_cols * f->g.ctu_rows), dim3(256), 0, f->ctx->stream, f->g, f->cfg.lambda_q4, src.y, ref0.y, ref1.y, pu, pub, cu_in, cu_out);
+    if (f->mrefb && pub) hipLaunchKernelGGL(merge_pass_kernel<true>, dim3(f->g.ctu_cols * f->g.ctu_rows), dim3(256), 0, f->ctx->stream, f->g, f->cfg.lambda_q4, src.y, ref0.y, ref1.y, pu, pub, cu_in, cu_out, ks_mrefb(f));
+    else hipLaunchKernelGGL(merge_pass_kernel<false>, dim3(f->g.ctu_cols * f->g.ctu_rows), dim3(256), 0, f->ctx->stream, f->g, f->cfg.lambda_q4, src.y, ref0.y, ref1.y, pu, pub, cu_in, cu_out, KsMrefB{});
     return ks265_check_launch(f->ctx);
 }
 
@@ -1192,6 +1221,36 @@ __global__ __launch_bounds__(256) void ref_decide_kernel(long n, int nref, int l
         }
     }
     pub[i] = o;
+}
+
+// one list of a multi-reference B picture: per PU the picture with the smallest cost + lambda x ref_idx bits (the oracle's kso_ref_pick); out may be p0 (in place)
+__global__ __launch_bounds__(256) void ref_pick_kernel(long n, int nref, int lam, const ks265_pu *p0, const ks265_pu *p1, const ks265_pu *p2, const ks265_pu *p3, ks265_pu *out, uint8_t *idx)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const ks265_pu a = p0[i];
+    ks265_pu o = a; int bi = 0;
+    if (a.cost != KS_COST_INVALID) {
+        unsigned best = KS_COST_INVALID;
+        for (int r = 0; r < nref; ++r) {
+            const ks265_pu q = r == 0 ? a : (r == 1 ? p1[i] : (r == 2 ? p2[i] : p3[i]));
+            const int bits = nref <= 1 ? 0 : (r < nref - 1 ? r + 1 : nref - 1);
+            const unsigned long long c = (unsigned long long)q.cost + (unsigned long long)((lam * bits) >> 4);
+            if (c < best) { best = (unsigned)c; o = q; o.cost = best; bi = r; }
+        }
+    }
+    out[i] = o; idx[i] = (uint8_t)bi;
+}
+extern "C" int ks265_ref_pick(ks265_frame *f, int nref, const ks265_pu *const *pu, ks265_pu *out, uint8_t *dev_idx)
+{
+    KS_FRAME_CHECK(f);
+    if (!pu || !out || !dev_idx) return KS265_POINTER;
+    if (nref < 1 || nref > 4) return KS265_NOTSUPPORTED;
+    for (int r = 0; r < nref; ++r) if (!pu[r]) return KS265_POINTER;
+    const long n = (long)f->g.ctu_cols * f->g.ctu_rows * 85;
+    hipLaunchKernelGGL(ref_pick_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, f->ctx->stream, n, nref, f->cfg.lambda_q4, pu[0], nref > 1 ? pu[1] : pu[0],
+                       nref > 2 ? pu[2] : pu[0], nref > 3 ? pu[3] : pu[0], out, dev_idx);
+    return ks265_check_launch(f->ctx);
 }
 
 extern "C" int ks265_ref_decide(ks265_frame *f, int nref, const ks265_pu *const *pu, ks265_pu_b *pub)

@@ -105,7 +105,7 @@ __device__ __forceinline__ int uni_round(int kind, int v) { return kind == 0 ? v
 __device__ __forceinline__ int to14(int kind, int v) { return kind == 0 ? v << 6 : kind == 1 ? v : v >> 6; }
 
 // further list-0 reference pictures (multi-reference P pictures): this component's planes of pictures 1..3
-struct KsCompRefs { const uint8_t *r[3]; };
+struct KsCompRefs { const uint8_t *r[3]; const uint8_t *s[3]; };   // s: list 1's pictures 1 .. 3 (multi-reference B pictures, round 5)
 
 template <int RS /*region size in samples: 32 luma, 16 chroma*/, bool MREF>
 __device__ __forceinline__ void code_region(const KsGeom &g, int comp, int qp, int rx8, int ry8, const ks265_cu8 *blk /*LDS [16]*/,
@@ -141,8 +141,9 @@ __device__ __forceinline__ void code_region(const KsGeom &g, int comp, int qp, i
                 // ref / ref1 are the planes of THIS component (luma for comp 0: only used by bi-prediction)
                 const int dir = c.inter_dir & 3;
                 if (MREF) {                                         // list-0 picture of this CU: inter_dir >> 4 (selects, not an indexed array: keeps the global address space)
-                    const int ri = c.inter_dir >> 4;
+                    const int ri = (c.inter_dir >> 4) & 3, ri1 = (c.inter_dir >> 6) & 3;      // (B pictures: list 1's picture in bits 6 .. 7)
                     ref = ri == 0 ? ref : (ri == 1 ? xr.r[0] : (ri == 2 ? xr.r[1] : xr.r[2]));
+                    ref1 = ri1 == 0 ? ref1 : (ri1 == 1 ? xr.s[0] : (ri1 == 2 ? xr.s[1] : xr.s[2]));
                 }
                 if (dir == 3) {
                     // bi-prediction: exact 14-bit average of the two lists (DefaultWeightedBi_c enc@0x435160)
@@ -446,5 +447,17 @@ extern "C" int ks265_reconstruct_b(ks265_frame *f, ks265_pic src, ks265_pic ref0
 {
     KS_FRAME_CHECK(f);
     if (!src.y || !ref0.y || !ref1.y || !cu8 || !lvl_y || !lvl_u || !lvl_v || !recon.y) return KS265_POINTER;
+    if (f->mrefb) {                                                   // several pictures per list: every CU's pictures from its record (the lists of ks265_encode_picture_b_mref)
+        KsRefExtra xr{};
+        for (int r = 1; r < 4; ++r) {
+            const ks265_pic a = f->mr_pic[0][r < f->mr_n[0] ? r : f->mr_n[0] - 1], b = f->mr_pic[1][r < f->mr_n[1] ? r : f->mr_n[1] - 1];
+            xr.y.r[r - 1] = a.y; xr.u.r[r - 1] = a.u; xr.v.r[r - 1] = a.v; xr.y.s[r - 1] = b.y; xr.u.s[r - 1] = b.u; xr.v.s[r - 1] = b.v;
+        }
+        const ks265_pic a0 = f->mr_pic[0][0], b0 = f->mr_pic[1][0];
+        dim3 grid(((f->g.W + 31) / 32) * ((f->g.H + 31) / 32));
+        hipLaunchKernelGGL(reconstruct_kernel<true>, grid, dim3(256), 0, f->ctx->stream, f->g, f->cfg.qp, src.y, src.u, src.v, a0.y, a0.u, a0.v, b0.y, b0.u, b0.v, cu8, lvl_y, lvl_u, lvl_v,
+                           recon.y, recon.u, recon.v, f->mats, xr, f->cfg.sdh, f->cfg.decimate, ks_rdo_lam2k(f), f->qp_map);
+        return ks265_check_launch(f->ctx);
+    }
     return launch_reconstruct(f, src, ref0, ref1, cu8, lvl_y, lvl_u, lvl_v, recon);
 }

@@ -313,6 +313,7 @@ typedef struct Enc {
     /* key pictures on their own stream and frame object: an intra picture keeps 34 of 256 compute units busy for ~26 ms (2160p); coded as soon as its
      * input arrives - the pixel path is tens of pictures behind the input - it runs underneath the P pictures of the previous GOP instead of between
      * two GOPs.  Its reconstruction goes to one of two DPB slots of its own; the first P picture of the GOP waits for ev_key. */
+    int refs_b;                                           /* reference pictures per list of a pyramid's B pictures (1 .. 4) */
     int key_overlap, nkeys; ks265_ctx *ctx_key; ks265_frame *frame_key; ks265_pic src_key; uint64_t *dev_sse_key; void *ev_key, *ev_firstp[2];
     /* scheduling */
     Input in[MAX_INPUT]; int nin, next_disp, in_disp;          /* next_disp: pictures handed to the scheduler; in_disp: pictures taken in (= next_disp + the lookahead's queue la_q) */
@@ -662,7 +663,7 @@ static int submit(Enc *e, Input *in, int kind, int poc, int qp, const int *l0, i
         if (!r) r = ks265_memcpy_d2h_async(ca, j->qp_map, qm, (size_t)e->geom.ctu_cols * e->geom.ctu_rows);
         if (!r && split) { r = ks265_event_record(e->ctx_in, e->ev_h2d[k]); if (!r) r = ks265_stream_wait_event(cx, e->ev_h2d[k]); }   /* (recorded again behind the map: the pixel path waits for this one) */
     }
-    int keep[20], nk = 0;
+    int keep[32], nk = 0;
     for (int i = 0; i < nkeep; ++i) keep[nk++] = keep_after[i];
     for (int i = 0; i < nl0; ++i) keep[nk++] = l0[i];
     for (int i = 0; i < nl1; ++i) keep[nk++] = l1[i];
@@ -714,6 +715,12 @@ static int submit(Enc *e, Input *in, int kind, int poc, int qp, const int *l0, i
     } else {
     if (!r) {
         if (kind == 'I') { r = ks265_encode_picture(fr, srcp, out, 1, out); if (!r && fr == e->frame) r = ks265_frame_p_restore(fr, 0); }   /* (see on_key below) */
+        else if (kind == 'B' && (nl0 > 1 || nl1 > 1)) {
+            ks265_pic r0[4], r1[4];
+            for (int i = 0; i < nl0; ++i) r0[i] = e->dpb[dpb_find(e, l0[i])];
+            for (int i = 0; i < nl1; ++i) r1[i] = e->dpb[dpb_find(e, l1[i])];
+            r = ks265_encode_picture_b_mref(fr, srcp, r0, nl0, r1, nl1, out);
+        }
         else if (kind == 'B') r = ks265_encode_picture_b(fr, srcp, e->dpb[dpb_find(e, l0[0])], e->dpb[dpb_find(e, l1[0])], out);
         else if (nl0 > 1) { ks265_pic refs[4]; for (int i = 0; i < nl0; ++i) refs[i] = e->dpb[dpb_find(e, l0[i])]; r = ks265_encode_picture_mref(fr, srcp, refs, nl0, out); }
         else r = ks265_encode_picture(fr, srcp, e->dpb[dpb_find(e, l0[0])], 0, out);
@@ -817,14 +824,28 @@ static int code_hier(Enc *e, int d, int a)
             const int mid = (cur[i].lo + cur[i].hi) / 2;
             Input *in = input_at(e, mid);
             const int is_ref = (mid - cur[i].lo >= 2) || (cur[i].hi - mid >= 2);
-            const int l0 = cur[i].lo - e->gop_start, l1 = cur[i].hi - e->gop_start;
+            /* list 0: the nearest pictures before `mid` among those this mini-GOP keeps (all its reference pictures coded so far), nearest first; list 1: those after it.  The
+             * interval's ends come first; -ref > 1 adds the next nearest ones */
+            int l0[4], l1[4], nl0 = 0, nl1 = 0;
+            {
+                const int pm = mid - e->gop_start;
+                for (int want = 0; want < e->refs_b; ++want) {
+                    int b0 = -1000000, b1 = 1000000;
+                    for (int q = 0; q < ncoded; ++q) {
+                        if (coded[q] < pm && coded[q] > b0 && (nl0 == 0 || coded[q] < l0[nl0 - 1])) b0 = coded[q];
+                        if (coded[q] > pm && coded[q] < b1 && (nl1 == 0 || coded[q] > l1[nl1 - 1])) b1 = coded[q];
+                    }
+                    if (b0 > -1000000) l0[nl0++] = b0;
+                    if (b1 < 1000000) l1[nl1++] = b1;
+                }
+            }
             /* B pictures of the pyramid: + 2 / + 4 / + 4 on the key picture's QP by layer - the reference's own ladder (appencoder -qp 27 -psnr 2: anchors 28, B pictures 29 / 31 / 31; ours was
              * + 2 / + 3 / + 4 until the end of round 3).  Larger offsets keep paying (+ 3 / + 5 / + 6: 1.51 x -> 1.44 x the reference's bitrate at its PSNR-Y on the 1080p clip, every B picture within 0.1 dB
              * of the anchors - their quality comes from their references), but -qp would no longer mean what it means in the reference */
             static const int kHierLayerQp[4] = {0, 1, 3, 3}, kPyr4LayerQp[4] = {0, 1, 2, 2};                       /* (-bframes 3: + 2 / + 3) */
             /* (the adaptive GOP's blocks of 4 keep + 2 / + 4: the reference's + 2 / + 3 there cost 1.3 % more bytes for + 0.004 dB on the 2160p clip, measured on the GPU at the end of round 4) */
             const int *lq = e->gop_b == 3 ? kPyr4LayerQp : kHierLayerQp;
-            int r = submit(e, in, 'B', mid - e->gop_start, clampqp(e, in->base_qp + e->rc_qp_delta + (e->fixqp ? 0 : 1 + lq[layer < 3 ? layer : 3])), &l0, 1, &l1, 1, coded, ncoded, is_ref, 0);
+            int r = submit(e, in, 'B', mid - e->gop_start, clampqp(e, in->base_qp + e->rc_qp_delta + (e->fixqp ? 0 : 1 + lq[layer < 3 ? layer : 3])), l0, nl0, l1, nl1, coded, ncoded, is_ref, 0);
             if (r) return r;
             if (is_ref) coded[ncoded++] = mid - e->gop_start;
             nxt[nn].lo = cur[i].lo; nxt[nn++].hi = mid; nxt[nn].lo = mid; nxt[nn++].hi = cur[i].hi;
@@ -1103,6 +1124,9 @@ static Enc *lane_open(QY265EncConfig *cfg, int device, int multi, int *err)
      * picture a reference B at Q + 2, the two outer ones non-reference B at Q + 3 (appencoder -bframes 3 -qp 27: 28 / 29 / 30 / 30; until round 4 ours was P + 3 plain B at Q + 2).
      * -bframes 1 / 2: the reference codes both as anchors 2 apart with one B picture at Q + 2; ours: P + n plain B at Q + 2 */
     e->hier = e->gop_b == 7 || cfg->bframes == 3;
+    /* with B pictures the anchors keep one reference; round 5: the B pictures of the pyramid search up to -ref pictures per list (ks265_encode_picture_b_mref: config 5 = -preset
+     * veryslow resolves to 4 / 4) - of the pictures the mini-GOP keeps anyway (code_hier), so the reference picture sets do not change */
+    e->refs_b = e->hier ? e->refs : 1;
     if (e->gop_b > 0) e->refs = 1;
     e->base_qp = cfg->rc == 3 ? cfg->crf : cfg->qp;
     if (e->base_qp < 0) e->base_qp = 0;
@@ -1118,7 +1142,8 @@ static Enc *lane_open(QY265EncConfig *cfg, int device, int multi, int *err)
     if (cfg->part && e->refs > 1) logf_(1, e->log_level, "ks265enc: -part 1 (2NxN / Nx2N partitions of 64 / 32 / 16 CUs) acts on P and B pictures with one reference picture per list; multi-reference P pictures keep 2Nx2N\n");
     /* options whose VALUE is narrowed (SURVEY.md 8(a) config 5 = -preset veryslow: subme 2, part 1, ref 4): said once, never silently */
     if (cfg->refnum > 4) logf_(1, e->log_level, "ks265enc: -ref %d runs as -ref 4\n", cfg->refnum);
-    if (e->gop_b > 0 && cfg->refnum > 1) logf_(1, e->log_level, "ks265enc: -ref %d with B pictures runs as one reference per list\n", cfg->refnum);
+    if (e->gop_b > 0 && cfg->refnum > 1 && !e->hier) logf_(1, e->log_level, "ks265enc: -ref %d with plain (non-pyramid) B pictures runs as one reference per list\n", cfg->refnum);
+    if (e->hier && e->refs_b > 1) logf_(1, e->log_level, "ks265enc: B pictures search up to %d pictures per list (list 0: the nearest coded pictures before, list 1: after; the anchors keep one reference)\n", e->refs_b);
     if (cfg->rc == 5 || cfg->vbv_buffer_size) logf_(1, e->log_level, "ks265enc: CVQ / VBV are not implemented; running the plain controller\n");
 
     /* the SDK's config has no device field: the lane's GPU comes from the handle (KS265_DEVICE: one GPU, default 0; KS265_GPUS / KS265_DEVICES: closed GOPs dealt
@@ -1142,7 +1167,7 @@ static Enc *lane_open(QY265EncConfig *cfg, int device, int multi, int *err)
         e->fcfg.sub_satd = kPresetSubme[ps].satd; e->fcfg.sub_thr = kPresetSubme[ps].thr; e->fcfg.sub_flat = kPresetSubme[ps].flat;
         e->fcfg.sub_cap = kPresetSubme[ps].cap; e->fcfg.sub_cap_step = kPresetSubme[ps].cap_step; e->fcfg.sub_diag_fast = kPresetSubme[ps].diag_fast;
     }
-    e->fcfg.bframes = e->gop_b; e->fcfg.refs = e->refs; e->fcfg.me_hex_thr = e->hex_thr;
+    e->fcfg.bframes = e->gop_b; e->fcfg.refs = e->refs > e->refs_b ? e->refs : e->refs_b; e->fcfg.me_hex_thr = e->hex_thr;
     e->fcfg.sdh = 1;                                                    /* the reference's streams have sign_data_hiding_enabled_flag = 1 at every preset */
     e->fcfg.pre_search = 1;                                             /* stage A0: pyramid pre-search vectors as start candidates of the integer search */
     e->fcfg.merge = 1;                                                  /* stage C2: merge pass on the motion field (pictures with one reference per list) */

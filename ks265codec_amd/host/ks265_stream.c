@@ -633,9 +633,9 @@ static int ref_poc(const Enc *e, int list, int idx) { return list ? e->in->l1_po
 static int blk_motion(const ks265_cu8 *b, int list, int *ref_idx, int *mvx, int *mvy)
 {
     if (b->pred_mode != 0) return 0;
-    if (list == 0) { if (!(b->inter_dir & 1)) return 0; *ref_idx = b->inter_dir >> 4; *mvx = b->mvx; *mvy = b->mvy; return 1; }
+    if (list == 0) { if (!(b->inter_dir & 1)) return 0; *ref_idx = (b->inter_dir >> 4) & 3; *mvx = b->mvx; *mvy = b->mvy; return 1; }
     if (!(b->inter_dir & 2)) return 0;
-    *ref_idx = 0; *mvx = b->mv1x; *mvy = b->mv1y;
+    *ref_idx = (b->inter_dir >> 6) & 3; *mvx = b->mv1x; *mvy = b->mv1y;      /* round 5: several pictures in list 1 too (inter_dir = direction | idx0 << 4 | idx1 << 6) */
     return 1;
 }
 static int clip3i(int lo, int hi, int v) { return v < lo ? lo : v > hi ? hi : v; }
@@ -908,7 +908,7 @@ static int coding_unit(Enc *e, int x, int y, int log2)
         for (int l = 0; l < 2; ++l) {
             if (!(dir & (1 << l))) continue;
             const int nact = l ? e->in->num_l1 : e->in->num_l0;
-            const int ri = l ? 0 : (pc->inter_dir >> 4);
+            const int ri = l ? (pc->inter_dir >> 6) & 3 : (pc->inter_dir >> 4) & 3;
             if (ri >= nact) return KS265_NOTSUPPORTED;
             if (nact > 1) {                                          /* ref_idx_lX: TR, cMax = nact - 1, two context bins then bypass */
                 for (int k = 0; k < nact - 1; ++k) {

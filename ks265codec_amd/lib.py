@@ -61,7 +61,7 @@ EXPORTS = [
     "ks265_frame_reset_prediction", "ks265_frame_records_layout", "ks265_frame_pack_records", "ks265_frame_compact_layout", "ks265_frame_pack_compact", "ks265_frame_pack_compact_on", "ks265_frame_adapt_quant", "ks265_aq_ctu_map", "ks265_cutree_propagate", "ks265_frame_set_records_fence", "ks265_load_i420_on", "ks265_sse_picture_on", "ks265_copy_out_compact_async", "ks265_copy_out_compact_dma_async", "ks265_frame_geometry", "ks265_frame_create", "ks265_frame_destroy", "ks265_frame_set_qp", "ks265_frame_set_qp_map", "ks265_pad_picture",
     "ks265_load_i420", "ks265_store_i420", "ks265_presearch", "ks265_me_integer", "ks265_me_propagate", "ks265_me_subpel", "ks265_cu_decide_part", "ks265_cu_decide_part_b", "ks265_merge_pass", "ks265_cu_decide",
     "ks265_cu_flat_intra", "ks265_intra_decide", "ks265_intra_decide_ex", "ks265_lookahead_reduce", "ks265_lookahead_picture", "ks265_lookahead_inter", "ks265_intra_reconstruct", "ks265_reconstruct", "ks265_reconstruct_b", "ks265_bi_decide", "ks265_bi_full_batch", "ks265_capture_begin", "ks265_capture_end", "ks265_graph_launch", "ks265_graph_destroy", "ks265_frame_p_state", "ks265_frame_p_advance", "ks265_frame_p_restore", "ks265_cu_decide_b", "ks265_deblock", "ks265_sao",
-    "ks265_encode_picture", "ks265_encode_picture_b", "ks265_encode_picture_mref", "ks265_ref_decide", "ks265_reconstruct_mref",
+    "ks265_encode_picture", "ks265_encode_picture_b", "ks265_encode_picture_mref", "ks265_encode_picture_b_mref", "ks265_ref_pick", "ks265_ref_decide", "ks265_reconstruct_mref",
     "ks265_intra_candidates", "ks265_cu_decide_ii", "ks265_cu_decide_b_ii", "ks265_intra_inter_reconstruct", "ks265_frame_set_profiling", "ks265_frame_stage_ms", "ks265_frame_me_int_ms", "ks265_frame_levels", "ks265_frame_pu", "ks265_frame_cu8", "ks265_frame_ibest", "ks265_frame_sao", "ks265_sse_picture",
 ]
 
@@ -415,6 +415,11 @@ class KsFrame:
         """P picture searching len(refs) list-0 pictures (nearest first); needs KsFrame(refs >= len(refs))"""
         arr = (Pic * len(refs))(*[r.c() for r in refs])
         self.ks._chk(self.lib.ks265_encode_picture_mref(self.h, src.c(), arr, C.c_int(len(refs)), out.c()))
+
+    def encode_picture_b_mref(self, src: DevPic, refs0: list, refs1: list, out: DevPic):
+        """B picture with several pictures per list (refs0: before it, nearest first; refs1: after it, nearest first); needs KsFrame(refs >= both lengths, bframes > 0)"""
+        a0, a1 = (Pic * len(refs0))(*[r.c() for r in refs0]), (Pic * len(refs1))(*[r.c() for r in refs1])
+        self.ks._chk(self.lib.ks265_encode_picture_b_mref(self.h, src.c(), a0, C.c_int(len(refs0)), a1, C.c_int(len(refs1)), out.c()))
 
     def ref_decide(self, pus: list, pub):
         arr = (C.c_void_p * len(pus))(*[p.data_ptr() for p in pus])

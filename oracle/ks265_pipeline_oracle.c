@@ -632,6 +632,32 @@ void kso_cu_decide_part(const kso_frame_cfg *cfg, kso_pic src, const uint8_t *pl
 }
 void kso_cu_decide(const kso_frame_cfg *cfg, const kso_pu *pu, kso_cu8 *cu8) { kso_cu_decide_ii(cfg, pu, NULL, NULL, cu8); }
 
+/* ------------------------------------------------------------------ multi-reference B pictures (round 5; -preset veryslow = config 5: ref 4 / 4)
+ * Frame-parallel form of "motionSearchOneRef enc@0x483f40 once per reference picture of each list": every picture of a list is searched on its own (stages A0 / A / A2 / B),
+ * kso_ref_pick keeps per PU and list the picture with the smallest cost + lambda x ref_idx bits (truncated unary; ties to the nearest picture), the bi-predictive decision
+ * pairs the two lists' winners, and every later stage takes a block's pictures from its record: ks265_cu8.inter_dir = direction | idx0 << 4 | idx1 << 6, an index of a
+ * list the block does not use is 0 (so that equal bytes = equal reference pictures: the boundary strength compares them).  List 0 holds past pictures only, list 1 future
+ * ones: no picture is in both lists.  The stage functions keep their one-picture-per-list arguments; while a context is set (kso_set_mref) they take planes / pictures from it. */
+static const kso_mref *g_mr;                                      /* (kso_mref: ks265_pipeline_oracle.h; idx0 / idx1 = per PU record the list's chosen picture) */
+void kso_set_mref(const kso_mref *m) { g_mr = m; }
+#define MR_PL0(arg, i) (g_mr ? g_mr->planes0[i] : (arg))
+#define MR_PL1(arg, i) (g_mr ? g_mr->planes1[i] : (arg))
+static int ref_idx_bits(int r, int nref) { return nref <= 1 ? 0 : (r < nref - 1 ? r + 1 : nref - 1); }
+void kso_ref_pick(const kso_frame_cfg *cfg, int nref, const kso_pu *const *pu, kso_pu *out, uint8_t *idx)
+{
+    kso_frame_geom g; kso_frame_geometry(cfg, &g);
+    const long n = (long)g.ctu_cols * g.ctu_rows * 85;
+    for (long i = 0; i < n; ++i) {
+        out[i] = pu[0][i]; idx[i] = 0;
+        if (pu[0][i].cost == COST_INVALID) continue;
+        uint32_t best = COST_INVALID;
+        for (int r = 0; r < nref; ++r) {
+            const uint64_t c = (uint64_t)pu[r][i].cost + (uint64_t)((cfg->lambda_q4 * ref_idx_bits(r, nref)) >> 4);
+            if (c < best) { best = (uint32_t)c; out[i] = pu[r][i]; out[i].cost = best; idx[i] = (uint8_t)r; }
+        }
+    }
+}
+
 /* ------------------------------------------------------------------ Stage C2: merge pass (cfg->merge)
  * The reference decides merge / skip per CU against the candidates of already coded neighbours (GetMergeCandsFor*, skipFastDecision; closed code,
  * SURVEY.md B.9).  A frame-parallel decision has no coded neighbours, so this pass works on the motion field the CU decision left behind: every CU
@@ -689,8 +715,8 @@ void kso_merge_pass(const kso_frame_cfg *cfg, kso_pic src, const uint8_t *planes
                 if ((dir & 1) && (x + (m.mvx >> 2) < -70 || x + (m.mvx >> 2) + n > cfg->width + 70 || y + (m.mvy >> 2) < -70 || y + (m.mvy >> 2) + n > cfg->height + 70)) continue;
                 if ((dir & 2) && (x + (m.mv1x >> 2) < -70 || x + (m.mv1x >> 2) + n > cfg->width + 70 || y + (m.mv1y >> 2) < -70 || y + (m.mv1y >> 2) + n > cfg->height + 70)) continue;
                 const uint8_t *p0 = NULL, *p1 = NULL;
-                if (dir & 1) p0 = org_y(&g, (uint8_t *)planes0 + (long)((m.mvy & 3) * 4 + (m.mvx & 3)) * g.bytes_y) + (long)(y + (m.mvy >> 2)) * st + x + (m.mvx >> 2);
-                if (dir & 2) p1 = org_y(&g, (uint8_t *)planes1 + (long)((m.mv1y & 3) * 4 + (m.mv1x & 3)) * g.bytes_y) + (long)(y + (m.mv1y >> 2)) * st + x + (m.mv1x >> 2);
+                if (dir & 1) p0 = org_y(&g, (uint8_t *)MR_PL0(planes0, (m.inter_dir >> 4) & 3) + (long)((m.mvy & 3) * 4 + (m.mvx & 3)) * g.bytes_y) + (long)(y + (m.mvy >> 2)) * st + x + (m.mvx >> 2);
+                if (dir & 2) p1 = org_y(&g, (uint8_t *)MR_PL1(planes1, (m.inter_dir >> 6) & 3) + (long)((m.mv1y & 3) * 4 + (m.mv1x & 3)) * g.bytes_y) + (long)(y + (m.mv1y >> 2)) * st + x + (m.mv1x >> 2);
                 if (!p0) p0 = p1;
                 if (!p1) p1 = p0;
                 uint8_t avg[64 * 64];
@@ -704,7 +730,7 @@ void kso_merge_pass(const kso_frame_cfg *cfg, kso_pic src, const uint8_t *planes
             for (int yy = 0; yy < n / 8; ++yy)
                 for (int xx = 0; xx < n / 8; ++xx) {
                     kso_cu8 *o = &cu_out[(long)(by + yy) * w8 + bx + xx];
-                    o->mvx = bm.mvx; o->mvy = bm.mvy; o->mv1x = bm.mv1x; o->mv1y = bm.mv1y; o->inter_dir = (uint8_t)(bm.inter_dir & 3);
+                    o->mvx = bm.mvx; o->mvy = bm.mvy; o->mv1x = bm.mv1x; o->mv1y = bm.mv1y; o->inter_dir = (uint8_t)(g_mr ? bm.inter_dir : (bm.inter_dir & 3));   /* (several pictures per list: the neighbour's pictures come with its motion) */
                 }
         }
 }
@@ -725,7 +751,7 @@ void kso_merge_pass(const kso_frame_cfg *cfg, kso_pic src, const uint8_t *planes
  * errors cancel, in chroma too, and the smaller residual costs fewer bits than its SATD says).  Measured with tools/rd_eval.py (832x480, hierarchical B, 33 pictures):
  * - 3.3 % bytes at the same PSNR-Y, chroma + 0.6 dB; the top-layer B pictures - 17 %; a bias of 1 / 16 and more loses again. */
 #define BI_BIAS_SHIFT 5
-void kso_bi_decide(const kso_frame_cfg *cfg, kso_pic src, const uint8_t *planes0, const uint8_t *planes1, const kso_pu *pu0, const kso_pu *pu1,
+void kso_bi_decide(const kso_frame_cfg *cfg, kso_pic src, const uint8_t *planes0_, const uint8_t *planes1_, const kso_pu *pu0, const kso_pu *pu1,
                    kso_pu_b *pub)
 {
     kso_frame_geom g; kso_frame_geometry(cfg, &g);
@@ -742,9 +768,14 @@ void kso_bi_decide(const kso_frame_cfg *cfg, kso_pic src, const uint8_t *planes0
                         int i = pu_index(l, px, py);
                         const kso_pu *a = &pu0[cb + i], *b = &pu1[cb + i];
                         kso_pu_b *o = &pub[cb + i];
-                        o->mvx = a->mvx; o->mvy = a->mvy; o->mv1x = b->mvx; o->mv1y = b->mvy; o->cost = a->cost; o->inter_dir = 1;
+                        /* several pictures per list (kso_set_mref): the two records are the lists' winners (kso_ref_pick: their costs hold the index bits), i0 / i1 their pictures */
+                        const int i0 = g_mr ? g_mr->idx0[cb + i] : 0, i1 = g_mr ? g_mr->idx1[cb + i] : 0;
+                        const uint8_t *const planes0 = MR_PL0(planes0_, i0), *const planes1 = MR_PL1(planes1_, i1);
+                        const uint32_t rbits = g_mr ? (uint32_t)((lam * (ref_idx_bits(i0, g_mr->n0) + ref_idx_bits(i1, g_mr->n1))) >> 4) : 0u;
+                        #define BI_DIR(d) ((uint32_t)(d) | (((d) & 1) ? (uint32_t)i0 << 4 : 0u) | (((d) & 2) ? (uint32_t)i1 << 6 : 0u))
+                        o->mvx = a->mvx; o->mvy = a->mvy; o->mv1x = b->mvx; o->mv1y = b->mvy; o->cost = a->cost; o->inter_dir = BI_DIR(1);
                         if (a->cost == COST_INVALID) continue;
-                        if (b->cost < o->cost) { o->cost = b->cost; o->inter_dir = 2; }
+                        if (b->cost < o->cost) { o->cost = b->cost; o->inter_dir = BI_DIR(2); }
                         int s = 64 >> l, x0 = cx * 64 + px * s, y0 = cy * 64 + py * s;
                         const uint8_t *p0 = org_y(&g, (uint8_t *)planes0 + (long)((a->mvy & 3) * 4 + (a->mvx & 3)) * g.bytes_y) + (long)(y0 + (a->mvy >> 2)) * st + x0 + (a->mvx >> 2);
                         const uint8_t *p1 = org_y(&g, (uint8_t *)planes1 + (long)((b->mvy & 3) * 4 + (b->mvx & 3)) * g.bytes_y) + (long)(y0 + (b->mvy >> 2)) * st + x0 + (b->mvx >> 2);
@@ -752,9 +783,9 @@ void kso_bi_decide(const kso_frame_cfg *cfg, kso_pic src, const uint8_t *planes0
                         for (int y = 0; y < s; ++y)
                             for (int x = 0; x < s; ++x) avg[y * s + x] = (uint8_t)((p0[(long)y * st + x] + p1[(long)y * st + x] + 1) >> 1);
                         uint32_t d = ks265o_had(S + (long)y0 * st + x0, avg, st, s, s, s);
-                        uint32_t c = d + (uint32_t)mv_cost(a->mvx, a->mvy, a->mvpx, a->mvpy, lam) + (uint32_t)mv_cost(b->mvx, b->mvy, b->mvpx, b->mvpy, lam);
+                        uint32_t c = d + (uint32_t)mv_cost(a->mvx, a->mvy, a->mvpx, a->mvpy, lam) + (uint32_t)mv_cost(b->mvx, b->mvy, b->mvpx, b->mvpy, lam) + rbits;
                         c -= c >> BI_BIAS_SHIFT;
-                        if (c < o->cost) { o->cost = c; o->inter_dir = 3; }
+                        if (c < o->cost) { o->cost = c; o->inter_dir = BI_DIR(3); }
                         if (!cfg->bi_refine) continue;
                         const int keep1 = b->cost < a->cost;                         /* list whose vector stays */
                         const kso_pu *K = keep1 ? b : a, *O = keep1 ? a : b;
@@ -790,10 +821,10 @@ void kso_bi_decide(const kso_frame_cfg *cfg, kso_pic src, const uint8_t *planes0
                         for (int y = 0; y < s; ++y)
                             for (int x = 0; x < s; ++x) avg[y * s + x] = (uint8_t)((kp[y * s + x] + po[(long)y * st + x] + 1) >> 1);
                         uint32_t c2 = ks265o_had(S + (long)y0 * st + x0, avg, st, s, s, s) + (uint32_t)mv_cost(K->mvx, K->mvy, K->mvpx, K->mvpy, lam)
-                                      + (uint32_t)mv_cost(bx, by, O->mvpx, O->mvpy, lam);
+                                      + (uint32_t)mv_cost(bx, by, O->mvpx, O->mvpy, lam) + rbits;
                         c2 -= c2 >> BI_BIAS_SHIFT;
                         if (c2 < o->cost) {
-                            o->cost = c2; o->inter_dir = 3;
+                            o->cost = c2; o->inter_dir = BI_DIR(3);
                             if (keep1) { o->mvx = (int16_t)bx; o->mvy = (int16_t)by; } else { o->mv1x = (int16_t)bx; o->mv1y = (int16_t)by; }
                         }
                     }
@@ -810,8 +841,8 @@ static uint32_t rect_half_cost_b(const rect_ctx_b *rc, int x0, int y0, int w, in
 {
     const long st = rc->g->stride_y;
     const int dir = (int)(M->inter_dir & 3), lam = rc->cfg->lambda_q4;
-    const uint8_t *p0 = org_y(rc->g, (uint8_t *)rc->planes0 + (long)((M->mvy & 3) * 4 + (M->mvx & 3)) * rc->g->bytes_y) + (long)(y0 + (M->mvy >> 2)) * st + x0 + (M->mvx >> 2);
-    const uint8_t *p1 = org_y(rc->g, (uint8_t *)rc->planes1 + (long)((M->mv1y & 3) * 4 + (M->mv1x & 3)) * rc->g->bytes_y) + (long)(y0 + (M->mv1y >> 2)) * st + x0 + (M->mv1x >> 2);
+    const uint8_t *p0 = org_y(rc->g, (uint8_t *)MR_PL0(rc->planes0, (M->inter_dir >> 4) & 3) + (long)((M->mvy & 3) * 4 + (M->mvx & 3)) * rc->g->bytes_y) + (long)(y0 + (M->mvy >> 2)) * st + x0 + (M->mvx >> 2);
+    const uint8_t *p1 = org_y(rc->g, (uint8_t *)MR_PL1(rc->planes1, (M->inter_dir >> 6) & 3) + (long)((M->mv1y & 3) * 4 + (M->mv1x & 3)) * rc->g->bytes_y) + (long)(y0 + (M->mv1y >> 2)) * st + x0 + (M->mv1x >> 2);
     const uint8_t *S = rc->S + (long)y0 * st + x0;
     if (dir == 1) return ks265o_had(S, p0, st, st, h, w) + (uint32_t)mv_cost(M->mvx, M->mvy, a->mvpx, a->mvpy, lam);
     if (dir == 2) return ks265o_had(S, p1, st, st, h, w) + (uint32_t)mv_cost(M->mv1x, M->mv1y, b->mvpx, b->mvpy, lam);
@@ -825,7 +856,7 @@ static uint32_t rect_half_cost_b(const rect_ctx_b *rc, int x0, int y0, int w, in
 static int same_motion_b(const kso_pu_b *m, const kso_pu_b *n)
 {
     const int d = (int)(m->inter_dir & 3);
-    if (d != (int)(n->inter_dir & 3)) return 0;
+    if (m->inter_dir != n->inter_dir) return 0;                     /* direction and the pictures of the lists used (unused indices are 0) */
     if ((d & 1) && (m->mvx != n->mvx || m->mvy != n->mvy)) return 0;
     if ((d & 2) && (m->mv1x != n->mv1x || m->mv1y != n->mv1y)) return 0;
     return 1;
@@ -851,7 +882,7 @@ static void rect_eval_b(const rect_ctx_b *rc, const kso_pu_b *cp, long cb, int c
                 if (c < best) { best = c; bm = cand[k]; }
             }
             moved |= !same_motion_b(bm, P);
-            out->mv[o][hf][0] = bm->mvx; out->mv[o][hf][1] = bm->mvy; out->mv1[o][hf][0] = bm->mv1x; out->mv1[o][hf][1] = bm->mv1y; out->dir[o][hf] = (uint8_t)(bm->inter_dir & 3);
+            out->mv[o][hf][0] = bm->mvx; out->mv[o][hf][1] = bm->mvy; out->mv1[o][hf][0] = bm->mv1x; out->mv1[o][hf][1] = bm->mv1y; out->dir[o][hf] = (uint8_t)bm->inter_dir;
             tot += best;
         }
         if (moved) out->cost[o] = tot > 0xFFFFFFFEu ? 0xFFFFFFFEu : (uint32_t)tot;
@@ -1115,7 +1146,7 @@ void kso_effective_qp(const kso_frame_cfg *cfg, const kso_cu8 *cu8, uint8_t *eff
 }
 
 /* list 0 may hold several reference pictures (multi-reference P pictures, -ref / -ref0): the CU's picture is refs0[inter_dir >> 4] */
-static void reconstruct_impl(const kso_frame_cfg *cfg, kso_pic src, const kso_pic *refs0, const uint8_t *const *planes0, kso_pic ref1, const uint8_t *planes1,
+static void reconstruct_impl(const kso_frame_cfg *cfg, kso_pic src, const kso_pic *refs0, const uint8_t *const *planes0, kso_pic ref1_, const uint8_t *planes1_,
                              kso_cu8 *cu8, int16_t *lvl_y, int16_t *lvl_u, int16_t *lvl_v, kso_pic recon)
 {
     kso_frame_geom g; kso_frame_geometry(cfg, &g);
@@ -1134,8 +1165,10 @@ static void reconstruct_impl(const kso_frame_cfg *cfg, kso_pic src, const kso_pi
             uint8_t pred[32 * 32];
             /* luma */
             const int dir = intra ? 0 : (c->inter_dir & 3), mv1x = c->mv1x, mv1y = c->mv1y;
-            const kso_pic ref = refs0[intra ? 0 : (c->inter_dir >> 4)];
-            const uint8_t *planes = planes0[intra ? 0 : (c->inter_dir >> 4)];
+            const kso_pic ref = refs0[intra ? 0 : ((c->inter_dir >> 4) & 3)];
+            const uint8_t *planes = planes0[intra ? 0 : ((c->inter_dir >> 4) & 3)];
+            const kso_pic ref1 = g_mr ? g_mr->pic1[intra ? 0 : ((c->inter_dir >> 6) & 3)] : ref1_;      /* several list-1 pictures: kso_set_mref */
+            const uint8_t *planes1 = g_mr ? g_mr->planes1[intra ? 0 : ((c->inter_dir >> 6) & 3)] : planes1_;
             if (intra) memset(pred, 128, sizeof pred);
             else if (dir == 3) {                                /* bi: DefaultWeightedBi_c enc@0x435160 on the two 14-bit predictions */
                 int16_t a0[32 * 32], a1[32 * 32];

@@ -52,6 +52,10 @@ void kso_me_subpel(const kso_frame_cfg *cfg, kso_pic src, const uint8_t *planes,
 void kso_cu_decide(const kso_frame_cfg *cfg, const kso_pu *pu, kso_cu8 *cu8);
 void kso_cu_flat_intra(const kso_frame_cfg *cfg, kso_cu8 *cu8);
 void kso_cu_decide_part(const kso_frame_cfg *cfg, kso_pic src, const uint8_t *planes, const kso_pu *pu, const uint32_t *icost, const uint8_t *imode, kso_cu8 *cu8);
+/* multi-reference B pictures: the lists' pictures of the B picture being coded (kso_set_mref(NULL) ends it); kso_ref_pick: per PU the cheapest picture of one list */
+typedef struct { int n0, n1; const uint8_t *planes0[4], *planes1[4]; kso_pic pic0[4], pic1[4]; const uint8_t *idx0, *idx1; } kso_mref;
+void kso_set_mref(const kso_mref *m);
+void kso_ref_pick(const kso_frame_cfg *cfg, int nref, const kso_pu *const *pu, kso_pu *out, uint8_t *idx);
 void kso_cu_decide_part_b(const kso_frame_cfg *cfg, kso_pic src, const uint8_t *planes0, const uint8_t *planes1, const kso_pu *pu0, const kso_pu *pu1, const kso_pu_b *pub,
                           const uint32_t *icost, const uint8_t *imode, kso_cu8 *cu8);
 /* cfg->intra_inter: the CU trees with intra candidates (icost / imode: 85 per CTU from kso_intra_candidates; NULL = none), and the intra CUs' reconstruction pass */

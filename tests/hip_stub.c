@@ -283,6 +283,7 @@ int ks265_encode_picture_b(ks265_frame *f, ks265_pic src, ks265_pic r0, ks265_pi
     return issue(f->ctx, o);
 }
 int ks265_encode_picture_mref(ks265_frame *f, ks265_pic src, const ks265_pic *refs, int nref, ks265_pic out) { return ks265_encode_picture(f, src, refs[nref - 1], 0, out); }
+int ks265_encode_picture_b_mref(ks265_frame *f, ks265_pic src, const ks265_pic *refs0, int n0, const ks265_pic *refs1, int n1, ks265_pic out) { (void)n0; (void)n1; return ks265_encode_picture_b(f, src, refs0[0], refs1[0], out); }
 int ks265_sse_picture(ks265_frame *f, ks265_pic a, ks265_pic b, uint64_t *sse3) { Op o = {OP_SSE, f, NULL, a, b, b, b, 0, sse3}; return issue(f->ctx, o); }
 int ks265_frame_pack_compact(ks265_frame *f, void *dst, const void *extra) { Op o = {OP_PACK, f, extra, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}, 0, dst}; return issue(f->ctx, o); }
 int ks265_copy_out_compact_dma_async(ks265_ctx *c, ks265_frame *f, void *host, const void *dev, size_t n) { (void)n; return ks265_copy_out_compact_async(c, f, host, dev); }

@@ -59,6 +59,10 @@ class OPic(C.Structure):
     _fields_ = [("y", C.c_void_p), ("u", C.c_void_p), ("v", C.c_void_p)]
 
 
+class OMref(C.Structure):                   # kso_mref
+    _fields_ = [("n0", C.c_int), ("n1", C.c_int), ("planes0", C.c_void_p * 4), ("planes1", C.c_void_p * 4), ("pic0", OPic * 4), ("pic1", OPic * 4), ("idx0", C.c_void_p), ("idx1", C.c_void_p)]
+
+
 PU = np.dtype([("mvx", "<i2"), ("mvy", "<i2"), ("mvpx", "<i2"), ("mvpy", "<i2"), ("cost", "<u4"), ("dist", "<u4")])
 CU8 = np.dtype([("mvx", "<i2"), ("mvy", "<i2"), ("mv1x", "<i2"), ("mv1y", "<i2"), ("log2_cu", "u1"), ("cbf", "u1"), ("pred_mode", "u1"), ("inter_dir", "u1")])
 PU_B = np.dtype([("mvx", "<i2"), ("mvy", "<i2"), ("mv1x", "<i2"), ("mv1y", "<i2"), ("cost", "<u4"), ("inter_dir", "<u4")])
@@ -211,6 +215,71 @@ class OraclePipeline:
         if kind == "P":
             self.prev_pu, self.pu = self.pu, self.prev_pu
             self.have_prev = True
+        return out
+
+    def encode_b_mref(self, i420: np.ndarray, refs0: "list[HostPic]", refs1: "list[HostPic]") -> "HostPic":
+        """B picture with several pictures per list (round 5; list 0 = past pictures nearest first, list 1 = future ones nearest first, no picture in both): one search per
+        picture, per PU and list the cheapest picture (kso_ref_pick), then the stages of encode('B') taking every block's pictures from its record (kso_set_mref)"""
+        o, cfg = self.o, C.byref(self.cfg)
+        if len(refs0) == 1 and len(refs1) == 1:
+            return self.encode(i420, "B", refs0[0], refs1[0])
+        self.load(self.src, i420)
+        lists = (refs0, refs1)
+        if not hasattr(self, "mr_planes"):
+            self.mr_planes = [[np.zeros(16 * self.geom.bytes_y, np.uint8) for _ in range(4)] for _ in range(2)]
+            self.mr_pu = [[np.zeros(self.nctu * 85, PU) for _ in range(4)] for _ in range(2)]
+            self.mr_idx = [np.zeros(self.nctu * 85, np.uint8) for _ in range(2)]
+        if not hasattr(self, "pub"):
+            self.pu1 = np.zeros(self.nctu * 85, PU)
+            self.pub = np.zeros(self.nctu * 85, PU_B)
+        if not hasattr(self, "pu1"):
+            self.pu1 = np.zeros(self.nctu * 85, PU)
+        best = (self.pu, self.pu1)
+        for L in range(2):
+            for i, r in enumerate(lists[L]):
+                o.kso_ref_planes(cfg, r.c(), ptr(self.mr_planes[L][i]))
+                self.search(r.c(), None, self.mr_pu[L][i])
+                if self.cfg.subme:
+                    o.kso_me_subpel(cfg, self.src.c(), ptr(self.mr_planes[L][i]), ptr(self.mr_pu[L][i]))
+            n = len(lists[L])
+            arr = (C.c_void_p * n)(*[p.ctypes.data for p in self.mr_pu[L][:n]])
+            o.kso_ref_pick(cfg, C.c_int(n), arr, ptr(best[L]), ptr(self.mr_idx[L]))
+        mr = OMref()
+        mr.n0, mr.n1 = len(refs0), len(refs1)
+        for i in range(4):
+            mr.planes0[i] = self.mr_planes[0][min(i, mr.n0 - 1)].ctypes.data; mr.planes1[i] = self.mr_planes[1][min(i, mr.n1 - 1)].ctypes.data
+            mr.pic0[i] = refs0[min(i, mr.n0 - 1)].c(); mr.pic1[i] = refs1[min(i, mr.n1 - 1)].c()
+        mr.idx0, mr.idx1 = self.mr_idx[0].ctypes.data, self.mr_idx[1].ctypes.data
+        o.kso_set_mref(C.byref(mr))
+        try:
+            pl0, pl1 = ptr(self.mr_planes[0][0]), ptr(self.mr_planes[1][0])
+            o.kso_bi_decide(cfg, self.src.c(), pl0, pl1, ptr(self.pu), ptr(self.pu1), ptr(self.pub))
+            ii = self.cfg.intra_inter
+            if ii and not hasattr(self, "icost"):
+                self.icost, self.imode = np.zeros(self.nctu * 85, np.uint32), np.zeros(self.nctu * 85, np.uint8)
+            if ii:
+                o.kso_intra_candidates(cfg, self.src.c(), ptr(self.pub), ptr(self.icost), ptr(self.imode))
+            if self.cfg.part:
+                o.kso_cu_decide_part_b(cfg, self.src.c(), pl0, pl1, ptr(self.pu), ptr(self.pu1), ptr(self.pub), ptr(self.icost) if ii else None, ptr(self.imode) if ii else None, ptr(self.cu8))
+            elif ii:
+                o.kso_cu_decide_b_ii(cfg, ptr(self.pub), ptr(self.icost), ptr(self.imode), ptr(self.cu8))
+            else:
+                o.kso_cu_decide_b(cfg, ptr(self.pub), ptr(self.cu8))
+            if self.cfg.merge:
+                tmp = self.cu8.copy()
+                o.kso_merge_pass(cfg, self.src.c(), pl0, pl1, None, ptr(self.pub), ptr(tmp), ptr(self.cu8))
+            ref_arr = (OPic * mr.n0)(*[r.c() for r in refs0])
+            pl_arr = (C.c_void_p * mr.n0)(*[p.ctypes.data for p in self.mr_planes[0][:mr.n0]])
+            o.kso_reconstruct_mref(cfg, self.src.c(), C.c_int(mr.n0), ref_arr, pl_arr, ptr(self.cu8), ptr(self.lvl[0]), ptr(self.lvl[1]), ptr(self.lvl[2]), self.rec.c())
+            if self.cfg.intra_inter:
+                o.kso_intra_inter_reconstruct(cfg, self.src.c(), ptr(self.cu8), ptr(self.lvl[0]), ptr(self.lvl[1]), ptr(self.lvl[2]), self.rec.c())
+        finally:
+            o.kso_set_mref(None)
+        self.rec_pre = [self.rec.y.copy(), self.rec.u.copy(), self.rec.v.copy()]
+        if self.cfg.deblock:
+            o.kso_deblock(cfg, ptr(self.cu8), self.rec.c())
+        out = HostPic(self.geom)
+        o.kso_sao(cfg, self.src.c(), self.rec.c(), ptr(self.sao), out.c())
         return out
 
     def encode_mref(self, i420: np.ndarray, refs: "list[HostPic]") -> "HostPic":

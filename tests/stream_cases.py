@@ -41,6 +41,9 @@ CASES = {
     # round 5: -part 1 in B pictures (config 5 = -preset veryslow codes hierarchical B with part 1): the halves of a CU differ in direction and vectors
     "part_hierb4_416x240": (416, 240, 28, 2, 0, 1, 1, "hier", 4),
     "part_hierb4_200x136_qp34": (200, 136, 34, 1, 0, 1, 1, "hier", 4),
+    # round 5: several reference pictures per list in B pictures (config 5: -ref 4): list 0 = the nearest past pictures, list 1 = the nearest future ones, ref_idx_l0 / _l1 per PU
+    "enc_hiermr4_416x240": (416, 240, 29, 2, 16, 1, 1, "hiermr", 4),
+    "part_hiermr4_200x136_qp33": (200, 136, 33, 1, 0, 1, 1, "hiermr", 4),
 }
 
 
@@ -111,6 +114,31 @@ def schedule(kind: str, par: int):
         for t in range(par + 3):
             refs = [t - 1 - i for i in range(min(par, t))]
             out.append((t, "I" if t == 0 else "P", refs, [], 0 if t == 0 else 1, [(p, True) for p in refs], True))
+    elif kind == "hiermr":
+        # the hierarchy of "hier", B pictures with up to two pictures per list: of the pictures coded so far that are not older than the previous mini-GOP's first anchor,
+        # list 0 = the nearest two before the picture, list 1 = the nearest two after it; anchors keep their one reference.  The RPS of a picture = every picture a later one uses.
+        G = par
+        seq = list(itertools.islice(hier_order(G, 128), 2 * G + 1))
+        lists, done = [], []
+        for d, k, r0, r1, layer in seq:
+            if k == "B":
+                lo = ((d - 1) // G) * G - G
+                av = [p for p in done if p >= lo]
+                l0 = sorted([p for p in av if p < d], reverse=True)[:2]
+                l1 = sorted([p for p in av if p > d])[:2]
+            else:
+                l0, l1 = ([r0] if r0 is not None else []), []
+            lists.append((l0, l1))
+            done.append(d)
+        for i, (d, k, r0, r1, layer) in enumerate(seq):
+            l0, l1 = lists[i]
+            later = lists[i + 1:]
+            coded = {s[0] for s in seq[:i]}
+            needed = {r for (a, b) in later for r in a + b if r in coded}
+            cur = set(l0) | set(l1)
+            rps = [(p, p in cur) for p in sorted(needed | cur)]
+            isref = any(d in a + b for (a, b) in later)
+            out.append((d, k, l0, l1, 0 if k == "I" else 1 + layer, rps, isref))
     else:
         G = par
         seq = list(itertools.islice(hier_order(G, 128), 2 * G + 1))
@@ -133,8 +161,8 @@ def make_stream(name: str, encode):
     W, H, qp, me, thr, sao, df, kind, par = CASES[name]
     sched = schedule(kind, par)
     nref = max([len(s[2]) + len(s[3]) for s in sched] + [1])
-    reorder = par if kind == "hier" else 0
-    w = S.StreamWriter(W, H, sao=sao, deblock=df, max_dec_pic_buffering=(par + 2) if kind == "hier" else nref + 1, max_num_reorder=reorder, sdh=case_sdh(name), wpp=case_wpp(name))      # the C host's rule (ks265_enc.c)
+    reorder = par if kind in ("hier", "hiermr") else 0
+    w = S.StreamWriter(W, H, sao=sao, deblock=df, max_dec_pic_buffering=(par + 4) if kind == "hiermr" else (par + 2) if kind == "hier" else nref + 1, max_num_reorder=reorder, sdh=case_sdh(name), wpp=case_wpp(name))      # the C host's rule (ks265_enc.c)
     bs = w.headers()
     recs = {}
     for d, k, l0, l1, dq, rps, isref in sched:
@@ -162,6 +190,8 @@ def oracle_encoder(name: str):
         o.set_qp(q, case_lambda(name, q, k))
         if k == "P" and len(l0) > 1:
             dpb[d] = o.encode_mref(clip[d], [dpb[r] for r in l0])
+        elif k == "B" and (len(l0) > 1 or len(l1) > 1):
+            dpb[d] = o.encode_b_mref(clip[d], [dpb[r] for r in l0], [dpb[r] for r in l1])
         else:
             dpb[d] = o.encode(clip[d], k, dpb.get(l0[0]) if l0 else None, dpb.get(l1[0]) if l1 else None)
         return o.cu8.copy(), [a.copy() for a in o.lvl], o.sao.copy(), o.store(dpb[d])

@@ -249,6 +249,50 @@ def test_config5_hierarchical_b_with_partitions(ks, W, H, G, seed):
     assert dirs[1] > 0 and dirs[2] > 0 and dirs[3] > 0, f"partitioned CUs of B pictures by direction: {dirs.tolist()}"
 
 
+def test_config5_b_pictures_with_several_references_per_list(ks):
+    """round 5: -ref N in B pictures - config 5's tool set (UMH always, -subme 2 by Hadamard, -part 1) at 1920x1080 on a pyramid whose B pictures search two
+    pictures per list (ks265_encode_picture_b_mref: one search per picture, ks265_ref_pick per list, every later stage takes a block's pictures from its record): CU records and
+    reconstruction of every picture == oracle, and both lists' second pictures are used"""
+    from ks265codec_amd.lib import CU8, KsFrame
+    from ks265codec_amd.synth import lambda_q4, make_clip, subme_knobs
+    from oracle_lib import OraclePipeline
+    from stream_cases import schedule
+    W, H = 1920, 1080
+    tools = dict(ENCODER_TOOLS, me_hex_thr=0, part=1, **subme_knobs("veryslow"))
+    sched = schedule("hiermr", 4)[:7]                                          # I0 P4 B2 B1 B3 P8 B6
+    clip = make_clip(W, H, 9, seed=47, abc=(37, 53, 19), pan=(5, 3))
+    o = OraclePipeline(W, H, 27, lambda_q4(27), **tools)
+    used = np.zeros(2, np.int64)
+    with KsFrame(ks, W, H, 27, lambda_q4(27), bframes=3, refs=2, **tools) as f:
+        src = f.new_pic()
+        dg, do = {}, {}
+        for d, kind, l0, l1, dq, rps, isref in sched:
+            q = 27 + dq
+            lam = lambda_q4(q, inter=kind != "I")
+            o.set_qp(q, lam); f.set_qp(q, lam)
+            f.load_i420(ks.dev(clip[d]), src)
+            out = f.new_pic()
+            if kind == "B" and (len(l0) > 1 or len(l1) > 1):
+                do[d] = o.encode_b_mref(clip[d], [do[r] for r in l0], [do[r] for r in l1])
+                f.encode_picture_b_mref(src, [dg[r] for r in l0], [dg[r] for r in l1], out)
+            elif kind == "B":
+                do[d] = o.encode(clip[d], "B", do[l0[0]], do[l1[0]])
+                f.encode_picture_b(src, dg[l0[0]], dg[l1[0]], out)
+            else:
+                do[d] = o.encode(clip[d], kind, do.get(l0[0]) if l0 else None, None)
+                f.encode_picture(src, dg[l0[0]] if l0 else out, kind == "I", out)
+            dg[d] = out
+            cu = f.ws_read("cu8", f.geom.bytes_cu8).view(CU8)
+            assert (cu == o.cu8.view(CU8).ravel()).all(), f"picture {d} ({kind}, lists {l0} {l1}): CU records differ"
+            got, exp = ks.host(f.store_i420(out), np.uint8), o.store(do[d])
+            assert (got == exp).all(), f"picture {d} ({kind}, lists {l0} {l1}): {int((got != exp).sum())} bytes differ"
+            if kind == "B":
+                c, inter = o.cu8, o.cu8["pred_mode"] == 0
+                used[0] += int((inter & ((c["inter_dir"] & 1) > 0) & (((c["inter_dir"] >> 4) & 3) == 1)).sum())
+                used[1] += int((inter & ((c["inter_dir"] & 2) > 0) & (((c["inter_dir"] >> 6) & 3) == 1)).sum())
+    assert used[0] > 0 and used[1] > 0, f"blocks predicting from the second picture of list 0 / list 1: {used.tolist()}"
+
+
 def test_full_size_properties_2160p_umh(ks):
     """3840x2160 with the bench's search method: run-to-run determinism and PSNR sanity over a 4-picture GOP head"""
     from ks265codec_amd.lib import KsFrame

@@ -78,7 +78,10 @@ def _mirror(clip, W, H, per, refs_of, rec, tools, upto, aq=0.0):
             o.set_qp_map(qmap)
             spread |= set(qmap.tolist())
         r0, r1 = refs_of(i, poc, kind)
-        dpb[poc] = o.encode(clip[poc], kind, dpb.get(r0), dpb.get(r1))
+        if isinstance(r0, list):                                          # several pictures per list (B pictures under -ref N): [nearest first]
+            dpb[poc] = o.encode_b_mref(clip[poc], [dpb[r] for r in r0], [dpb[r] for r in r1])
+        else:
+            dpb[poc] = o.encode(clip[poc], kind, dpb.get(r0), dpb.get(r1))
         want = o.store(dpb[poc])
         assert (rec[poc * fsz:(poc + 1) * fsz] == want).all(), f"picture {poc} ({kind}, qp {qp}, coding position {i}): the encoder's reconstruction differs from the oracle pipeline fed the same QP"
     o.set_qp_map(None)
@@ -138,17 +141,21 @@ def test_config5_command_line(tmp_path):
     assert len(per) == n and "subme 2" in log, log[:800]
     _decoder_check(tmp_path, out, rec, n, W * H * 3 // 2)
     tools = dict(ENCODER_TOOLS, me_hex_thr=0, part=1, **subme_knobs("veryslow"))    # veryslow: always UMH, -subme 2 judged by Hadamard, -part 1 (P and B pictures)
-    kinds = {p: k for p, k, _, _ in per}
-    coded = []
+    assert "up to 4 pictures per list" in log, log[:1200]
+    st = {"keep": [], "anchor": None}                                          # the host's code_hier: the reference pictures of the mini-GOP coded so far (its two ends first)
 
-    def refs(i, poc, kind):                                                    # the pyramid of 8: the nearest coded pictures on either side
+    def refs(i, poc, kind):
         if kind == "I":
-            coded.append(poc); return None, None
-        lo = max(p for p in coded if p < poc)
-        hi = min((p for p in coded if p > poc), default=None)
-        coded.append(poc)
-        return (lo, None) if kind == "P" else (lo, hi)
+            st["anchor"] = poc; st["keep"] = [poc]; return None, None
+        if kind == "P":
+            lo = st["anchor"]; st["keep"] = [lo, poc]; st["anchor"] = poc
+            return lo, None
+        before, after = sorted([p for p in st["keep"] if p < poc], reverse=True)[:4], sorted([p for p in st["keep"] if p > poc])[:4]
+        if poc - before[0] >= 2 or after[0] - poc >= 2:                        # a B picture others predict from
+            st["keep"].append(poc)
+        return before, after
     _mirror(clip, W, H, per, refs, rec, tools, upto=9)
+    assert any(k == "B" for _, k, _, _ in per[:9])
 
 
 def test_bitrate_target_at_2160p_decodes(tmp_path):

@@ -30,7 +30,7 @@ def hip_encoder(ks, name):
     W, H, qp, me, thr, sao, df, kind, par = CASES[name]
     n = 1 + max(s[0] for s in schedule(kind, par))
     clip = make_clip(W, H, n, seed=len(name) * 7 + W, abc=(17, 23, 9))
-    f = KsFrame(ks, W, H, qp, lambda_q4(qp), me_method=me, me_hex_thr=thr, sao=sao, deblock=df, bframes=3 if kind == "hier" else 0, refs=par if kind == "mref" else 1,
+    f = KsFrame(ks, W, H, qp, lambda_q4(qp), me_method=me, me_hex_thr=thr, sao=sao, deblock=df, bframes=3 if kind in ("hier", "hiermr") else 0, refs=par if kind == "mref" else 2 if kind == "hiermr" else 1,
                 sdh=case_sdh(name), pre_search=case_ps(name), merge=case_merge(name), bi_refine=case_bir(name), decimate=case_dec(name), rdo=case_rdo(name), intra_inter=case_ii(name), propagate=case_prop(name), part=case_part(name), **case_subme(name))
     g = f.geom
     src = f.new_pic()
@@ -40,7 +40,9 @@ def hip_encoder(ks, name):
         f.set_qp(q, case_lambda(name, q, k))
         f.load_i420(ks.dev(clip[d]), src)
         out = f.new_pic()
-        if k == "B":
+        if k == "B" and (len(l0) > 1 or len(l1) > 1):
+            f.encode_picture_b_mref(src, [dpb[r] for r in l0], [dpb[r] for r in l1], out)
+        elif k == "B":
             f.encode_picture_b(src, dpb[l0[0]], dpb[l1[0]], out)
         elif k == "P" and len(l0) > 1:
             f.encode_picture_mref(src, [dpb[r] for r in l0], out)

@@ -183,6 +183,18 @@ def test_every_bframes_value_opens_and_decodes(stub_lib, tmp_path, bframes):
         assert d.returncode == 0 and os.path.getsize(tmp_path / "d.yuv") == 70 * 128 * 72 * 3 // 2, d.stdout[-300:] + d.stderr[-300:]
 
 
+@pytest.mark.parametrize("bframes,ref", [(-1, 2), (-1, 4), (3, 3)])
+def test_pyramid_b_pictures_with_several_references_per_list(stub_lib, tmp_path, bframes, ref):
+    """round 5: -ref N with the pyramid GOPs - the B pictures' lists hold up to N of the pictures the mini-GOP keeps anyway (list 0 before, list 1 after the picture, nearest
+    first): slice headers with num_ref_idx_active > 1 on both lists, reference picture sets, default list construction - the reference decoder takes the stream, every
+    picture comes out, over several GOPs and a shortened last mini-GOP"""
+    r = run(stub_lib, 75, 32, bframes, out=tmp_path / "m.265", KS_TEST_REF=ref, KS_TEST_LOOKAHEAD=0)
+    assert r["vcl"] == 75 and sorted(r["pts"]) == list(range(75)) and r["idr"] == 3
+    if os.path.exists(REF_DEC):
+        d = subprocess.run([REF_DEC, "-b", str(tmp_path / "m.265"), "-o", str(tmp_path / "d.yuv"), "-threads", "2"], capture_output=True, text=True, cwd=tmp_path)
+        assert d.returncode == 0 and "decoder passed" in d.stdout and os.path.getsize(tmp_path / "d.yuv") == 75 * 128 * 72 * 3 // 2, d.stdout[-300:] + d.stderr[-300:]
+
+
 @pytest.mark.parametrize("rc,bframes", [(2, 0), (1, -1)])
 def test_rate_control_does_not_depend_on_thread_timing(stub_lib, rc, bframes):
     """the frame-level controller (rc 1 / 2 / 4) decides the QP offset of a mini-GOP from exactly the pictures coded RC_LAG earlier in coding order (the
