@@ -1223,7 +1223,7 @@ __global__ __launch_bounds__(256) void ref_decide_kernel(long n, int nref, int l
     pub[i] = o;
 }
 
-// one list of a multi-reference B picture: per PU the picture with the smallest cost + lambda x ref_idx bits (the oracle's kso_ref_pick); out may be p0 (in place)
+// one list of a multi-reference B picture: per PU the picture with the smallest cost + lambda x ref_idx bits (the same rule the oracle pipeline states); out may be p0 (in place)
 __global__ __launch_bounds__(256) void ref_pick_kernel(long n, int nref, int lam, const ks265_pu *p0, const ks265_pu *p1, const ks265_pu *p2, const ks265_pu *p3, ks265_pu *out, uint8_t *idx)
 {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
