@@ -771,7 +771,7 @@ void kso_bi_decide(const kso_frame_cfg *cfg, kso_pic src, const uint8_t *planes0
                         /* several pictures per list (kso_set_mref): the two records are the lists' winners (kso_ref_pick: their costs hold the index bits), i0 / i1 their pictures */
                         const int i0 = g_mr ? g_mr->idx0[cb + i] : 0, i1 = g_mr ? g_mr->idx1[cb + i] : 0;
                         const uint8_t *const planes0 = MR_PL0(planes0_, i0), *const planes1 = MR_PL1(planes1_, i1);
-                        const uint32_t rbits = g_mr ? (uint32_t)((lam * (ref_idx_bits(i0, g_mr->n0) + ref_idx_bits(i1, g_mr->n1))) >> 4) : 0u;
+                        const uint32_t rbits = g_mr ? (uint32_t)((lam * ref_idx_bits(i0, g_mr->n0)) >> 4) + (uint32_t)((lam * ref_idx_bits(i1, g_mr->n1)) >> 4) : 0u;   /* (each list's index rate as kso_ref_pick counted it) */
                         #define BI_DIR(d) ((uint32_t)(d) | (((d) & 1) ? (uint32_t)i0 << 4 : 0u) | (((d) & 2) ? (uint32_t)i1 << 6 : 0u))
                         o->mvx = a->mvx; o->mvy = a->mvy; o->mv1x = b->mvx; o->mv1y = b->mvy; o->cost = a->cost; o->inter_dir = BI_DIR(1);
                         if (a->cost == COST_INVALID) continue;

@@ -259,7 +259,7 @@ def test_config5_b_pictures_with_several_references_per_list(ks):
     from stream_cases import schedule
     W, H = 1920, 1080
     tools = dict(ENCODER_TOOLS, me_hex_thr=0, part=1, **subme_knobs("veryslow"))
-    sched = schedule("hiermr", 4)[:7]                                          # I0 P4 B2 B1 B3 P8 B6
+    sched = schedule("hiermr", 4)[:8]                                          # I0 P4 B2 B1 B3 P8 B6 B5 (B5: two pictures in BOTH lists - both index rates in a pair's cost)
     clip = make_clip(W, H, 9, seed=47, abc=(37, 53, 19), pan=(5, 3))
     o = OraclePipeline(W, H, 27, lambda_q4(27), **tools)
     used = np.zeros(2, np.int64)
