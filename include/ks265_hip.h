@@ -292,6 +292,9 @@ typedef struct {
     int32_t part;              /* -part (qy265enc.h:131; slower, veryslow, placebo): 1 = a CU of 64 / 32 / 16 samples of a P or B picture (one reference per list) may be coded as two 2NxN or Nx2N prediction units
                                   (ks265_cu8.log2_cu bits 4..5); each half is priced with the refined vectors of the CU and of its two quarter-size PUs (ks265_rect_decide), the CU then
                                   holds four transform units (interSplitFlag).  The reference searches such PUs on their own inside its RD loop (closed code) */
+    int32_t tu_inter;          /* -intertu 1 (tuInter, qy265enc.h:133; veryslow, placebo: the residual quadtree of inter CUs one level deep): a 2Nx2N inter CU of 32 / 16 samples is coded with four
+                                  transform units (split_transform_flag; ks265_cu8.log2_cu bits 4..5 = 3, set by ks265_reconstruct*) when its luma residual sits in part of it - the quarters'
+                                  residual SADs under the CU's final motion: max > 4 x min + (N / 2)^2.  The reference decides this inside its RD loop (tuDecision enc@0x4825a0, closed code) */
 } ks265_frame_cfg;
 
 /* geometry of the padded picture buffers the caller allocates (one call, no allocation) */

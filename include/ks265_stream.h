@@ -32,6 +32,8 @@ typedef struct {
     int32_t wpp;                           /* entropy_coding_sync_enabled_flag: every CTU row is a substream with an entry point (the reference's WPP) */
     int32_t list_mod;                      /* lists_modification_present_flag: l0_poc / l1_poc may name the used pictures of the RPS in any order (7.3.6.2)  */
     int32_t cu_qp_delta;                   /* cu_qp_delta_enabled_flag with diff_cu_qp_delta_depth = 0 (quantisation group = CTU): slices carry a QP per CTU (qp_map)     */
+    int32_t tu_inter;                      /* max_transform_hierarchy_depth_inter = 1 (-intertu 1): inter CUs of 32 / 16 / 8 samples code split_transform_flag; ks265_cu8.log2_cu
+                                              bits 4..5 = 3 marks a 2Nx2N CU with four transform units (ks265_frame_cfg.tu_inter)                                          */
 } ks265_stream_cfg;
 
 enum { KS265_SLICE_B = 0, KS265_SLICE_P = 1, KS265_SLICE_I = 2 };

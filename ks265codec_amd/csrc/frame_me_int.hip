@@ -397,48 +397,54 @@ __device__ __forceinline__ int me_group(const KsGeom &g, int cx, int cy, int ran
 // fewer than 30 of 768 work-group slots (scratch/me_trace.py: 140 us for 78 us of slot time).  The kernel therefore leaves every CTU's rounds behind (work: one word per
 // wave); the next search of this frame object - next picture or other list, the same content a few samples on - dispatches the CTUs that were in the heaviest tenth first,
 // the rest in the usual XCD-aware order.  Scheduling only: every CTU computes what it always computed.
-__global__ __launch_bounds__(1024) void me_order_kernel(int n, int cols, const unsigned *work, int *order)
+__global__ __launch_bounds__(256) void me_score_kernel(int n, int cols, const unsigned *work, unsigned char *score)
 {
-    __shared__ unsigned hist[256];
-    __shared__ int scan[1024];
-    __shared__ int s_thr, s_nheavy, s_fill;
-    const int tid = threadIdx.x;
-    if (tid < 256) hist[tid] = 0;
-    if (tid == 0) s_fill = 0;
-    __syncthreads();
     // a CTU's score: the most rounds any wave of it or of its eight neighbours ran last time (what made a CTU heavy - a moving edge - is in it or next to it now)
-    auto score = [&](int ctu) {
-        const int cx = ctu % cols, cy = ctu / cols, rows = n / cols;
-        unsigned m = 0;
-        for (int dy = -1; dy <= 1; ++dy)
-            for (int dx = -1; dx <= 1; ++dx) {
-                const int x = cx + dx, y = cy + dy;
-                if (x < 0 || y < 0 || x >= cols || y >= rows) continue;
-                const uint4 w = *(const uint4 *)(work + 4 * ((long)y * cols + x));
-                m = max(m, max(max(w.x, w.y), max(w.z, w.w)));
-            }
-        return (int)min(255u, m);
-    };
-    for (int b = tid; b < n; b += 1024) atomicAdd(&hist[score(ks_xcd_swizzle(b, n))], 1u);
+    const int ctu = blockIdx.x * 256 + threadIdx.x;
+    if (ctu >= n) return;
+    const int cx = ctu % cols, cy = ctu / cols, rows = n / cols;
+    unsigned m = 0;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int x = min(max(cx + dx, 0), cols - 1), y = min(max(cy + dy, 0), rows - 1);
+            const uint4 w = *(const uint4 *)(work + 4 * ((long)y * cols + x));
+            m = max(m, max(max(w.x, w.y), max(w.z, w.w)));
+        }
+    score[ctu] = (unsigned char)min(255u, m);
+}
+// The order: block index b runs on XCD b % 8, and ks_xcd_swizzle gives every XCD a contiguous raster range of CTUs (neighbours share window halos in one L2).  Each XCD's range
+// keeps its XCD: within it the heavy CTUs (the heaviest scores that together hold at most a tenth of the picture's CTUs) come first, the others follow in their usual order;
+// the k-th CTU of XCD x's list is dispatched as block 8 k + x.  One wave per XCD, ranks by ballots.
+#define ME_ORDER_MAX 16384
+__global__ __launch_bounds__(512) void me_order_kernel(int n, const unsigned char *score, int *order)
+{
+    __shared__ unsigned char sc[ME_ORDER_MAX];
+    __shared__ unsigned hist[256];
+    __shared__ int s_thr;
+    const int tid = threadIdx.x, lane = tid & 63, x = tid >> 6;
+    if (tid < 256) hist[tid] = 0;
     __syncthreads();
-    if (tid == 0) {                                              // threshold: the heaviest scores that together hold at most a tenth of the CTUs (none when all are alike)
+    for (int i = tid; i < n; i += 512) { const unsigned char v = score[i]; sc[i] = v; atomicAdd(&hist[v], 1u); }
+    __syncthreads();
+    if (tid == 0) {
         int acc = 0, thr = 256;
         for (int v = 255; v > 0; --v) { if (acc + (int)hist[v] > n / 10) break; acc += (int)hist[v]; thr = v; }
-        s_thr = thr; s_nheavy = acc;
+        s_thr = thr;
     }
     __syncthreads();
-    const int thr = s_thr, nheavy = s_nheavy;
-    const int per = (n + 1023) / 1024, b0 = tid * per, b1 = min(n, b0 + per);
-    int light = 0;
-    for (int b = b0; b < b1; ++b) light += score(ks_xcd_swizzle(b, n)) < thr;
-    scan[tid] = light;
-    __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) { const int v = tid >= d ? scan[tid - d] : 0; __syncthreads(); scan[tid] += v; __syncthreads(); }
-    int pos = nheavy + scan[tid] - light;
-    for (int b = b0; b < b1; ++b) {
-        const int ctu = ks_xcd_swizzle(b, n);
-        if (score(ctu) < thr) order[pos++] = ctu;
-        else order[atomicAdd(&s_fill, 1)] = ctu;
+    const int thr = s_thr, per = n >> 3, rem = n & 7, cnt = per + (x < rem ? 1 : 0), first = x * per + min(x, rem);     // XCD x's CTUs: first .. first + cnt - 1 (ks_xcd_swizzle)
+    int nheavy = 0;
+    for (int j0 = 0; j0 < cnt; j0 += 64) { const int j = j0 + lane; nheavy += __popcll(__ballot(j < cnt && sc[first + j] >= thr)); }
+    int hs = 0, ls = 0;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int j0 = 0; j0 < cnt; j0 += 64) {
+        const int j = j0 + lane;
+        const bool in = j < cnt, h = in && sc[first + j] >= thr, l = in && !h;
+        const unsigned long long bh = __ballot(h), bl = __ballot(l);
+        if (in) { const int k = h ? hs + __popcll(bh & lt) : nheavy + ls + __popcll(bl & lt); order[8 * k + x] = first + j; }
+        hs += __popcll(bh); ls += __popcll(bl);
     }
 }
 
@@ -696,15 +702,18 @@ extern "C" int ks265_me_integer(ks265_frame *f, ks265_pic src, ks265_pic ref, co
     }
     const int nctu = f->g.ctu_cols * f->g.ctu_rows;
     const dim3 grid(nctu), block(256);
-    if (!f->me_work && !f->me_order_off) {                                   // (first search of this frame object: the counters start at zero = the usual order)
+    if (!f->me_work && !f->me_order_off && nctu <= ME_ORDER_MAX) {                                   // (first search of this frame object: the counters start at zero = the usual order)
         for (int i = 0; i < 2; ++i) {
-            if (hipMalloc((void **)&f->me_work_all[i], (size_t)nctu * 16) != hipSuccess || hipMalloc((void **)&f->me_order_all[i], (size_t)nctu * 4) != hipSuccess) return KS265_OUTOFMEMORY;
+            if (hipMalloc((void **)&f->me_work_all[i], (size_t)nctu * 16) != hipSuccess || hipMalloc((void **)&f->me_order_all[i], (size_t)nctu * 5 + 16) != hipSuccess) return KS265_OUTOFMEMORY;
             (void)hipMemsetAsync(f->me_work_all[i], 0, (size_t)nctu * 16, f->ctx->stream);
         }
         if (hipStreamSynchronize(f->ctx->stream) != hipSuccess) return KS265_FAIL;      // (once per frame object: the side stream's first search reads its counters too)
         f->me_work = f->me_work_all[0]; f->me_order = f->me_order_all[0];
     }
-    if (f->me_work) hipLaunchKernelGGL(me_order_kernel, dim3(1), dim3(1024), 0, f->ctx->stream, nctu, f->g.ctu_cols, f->me_work, f->me_order);
+    if (f->me_work) {
+        hipLaunchKernelGGL(me_score_kernel, dim3((unsigned)((nctu + 255) / 256)), dim3(256), 0, f->ctx->stream, nctu, f->g.ctu_cols, f->me_work, (unsigned char *)(f->me_order + nctu));
+        hipLaunchKernelGGL(me_order_kernel, dim3(1), dim3(512), 0, f->ctx->stream, nctu, (const unsigned char *)(f->me_order + nctu), f->me_order);
+    }
     if (f->profiling && f->ev_k[0]) (void)hipEventRecord(f->ev_k[0], f->ctx->stream);
     hipLaunchKernelGGL(me_int_kernel, grid, block, 0, f->ctx->stream, f->g, f->cfg.me_range, f->cfg.lambda_q4, f->cfg.me_method, f->cfg.me_hex_thr, src.y, ref.y, prev_pu, pu,
                        field, (f->g.W + 15) / 16, (f->g.H + 15) / 16, field ? (const short2 *)f->pyr[9] : nullptr, (const int *)f->me_order, f->me_work);

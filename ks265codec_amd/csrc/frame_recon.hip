@@ -108,11 +108,12 @@ __device__ __forceinline__ int to14(int kind, int v) { return kind == 0 ? v << 6
 struct KsCompRefs { const uint8_t *r[3]; const uint8_t *s[3]; };   // s: list 1's pictures 1 .. 3 (multi-reference B pictures, round 5)
 
 template <int RS /*region size in samples: 32 luma, 16 chroma*/, bool MREF>
-__device__ __forceinline__ void code_region(const KsGeom &g, int comp, int qp, int rx8, int ry8, const ks265_cu8 *blk /*LDS [16]*/,
-                                            const unsigned char *tu_log2 /*LDS [16]: log2 of TU size in 8x8 blocks*/, const short *Mf, const short *Mt,
+__device__ __forceinline__ void code_region(const KsGeom &g, int comp, int qp, int rx8, int ry8, ks265_cu8 *blk /*LDS [16]*/,
+                                            unsigned char *tu_log2 /*LDS [16]: log2 of TU size in 8x8 blocks*/, const short *Mf, const short *Mt,
                                             short *X, short *T, unsigned char *P, int *nzcnt /*LDS [16]*/, const uint8_t *src, const uint8_t *ref,
                                             const uint8_t *ref1, int16_t *lvl, uint8_t *rec, int tid, const KsCompRefs xr,
-                                            bool sdh, short *LV, short *DU, short *CF, int *lastcg /*LDS [16]*/, int dec_k, long long rdo_lam2k /* lambda_q4^2 x cfg.rdo, 0 = off */)
+                                            bool sdh, short *LV, short *DU, short *CF, int *lastcg /*LDS [16]*/, int dec_k, long long rdo_lam2k /* lambda_q4^2 x cfg.rdo, 0 = off */,
+                                            bool tu_split = false /* cfg.tu_inter, the luma call: decide which 2Nx2N inter CUs of 32 / 16 carry four transform units */)
 {
     constexpr int UNIT = RS / 4;                      // samples per 8x8-luma block along one axis
     constexpr int NQ = RS * RS / 4;                   // quads (4 adjacent samples of one row)
@@ -126,13 +127,8 @@ __device__ __forceinline__ void code_region(const KsGeom &g, int comp, int qp, i
     const int b = has_quad ? (qy / UNIT) * 4 + qx / UNIT : 0;
     const ks265_cu8 c = blk[b];
     const bool coded = has_quad && c.log2_cu != 0 && c.pred_mode != 2;     // block inside the picture; an intra CU of a P / B picture (pred_mode 2) is coded afterwards (ks265_intra_inter_reconstruct)
-    // TU geometry of the quad
-    const int t8 = 1 << tu_log2[b], tbx = (b & 3) & ~(t8 - 1), tby = (b >> 2) & ~(t8 - 1), tb = tby * 4 + tbx;
-    const int ox = tbx * UNIT, oy = tby * UNIT, n = t8 * UNIT, log2n = tu_log2[b] + (RS == 32 ? 3 : 2);
-    const short *mf = Mf + mat_off(log2n), *mt = Mt + mat_off(log2n);
-    const int mp = n + 4;                                          // matrix row pitch
-
     if (tid < 16) { nzcnt[tid] = 0; lastcg[tid] = 0; }
+    if (tu_split) __syncthreads();                                 // (the residual stage adds into lastcg)
     // ---- prediction + residual
     if (has_quad) {
         int pred[4] = {128, 128, 128, 128}, res[4] = {0, 0, 0, 0};
@@ -180,11 +176,41 @@ __device__ __forceinline__ void code_region(const KsGeom &g, int comp, int qp, i
             const unsigned sv = *(const unsigned *)(S + (long)(Y0 + qy) * stride + X0 + qx);
 #pragma unroll
             for (int i = 0; i < 4; ++i) res[i] = (int)((sv >> (8 * i)) & 255) - pred[i];
+            if (tu_split && c.pred_mode == 0) atomicAdd(&lastcg[b], abs(res[0]) + abs(res[1]) + abs(res[2]) + abs(res[3]));      // residual SAD of the 8x8 block (lastcg is free until the sign-hiding phase)
         }
         *(unsigned *)(P + qy * RS + qx) = (unsigned)pred[0] | ((unsigned)pred[1] << 8) | ((unsigned)pred[2] << 16) | ((unsigned)pred[3] << 24);
         *(uint2 *)(X + qy * RP + qx) = make_uint2(((unsigned)res[0] & 0xFFFF) | ((unsigned)res[1] << 16), ((unsigned)res[2] & 0xFFFF) | ((unsigned)res[3] << 16));
     }
     __syncthreads();
+    if (tu_split) {
+        // cfg.tu_inter (-intertu 1; the oracle's rule in reconstruct_impl): a 2Nx2N inter CU of 32 / 16 samples gets four transform units when its luma residual is concentrated in
+        // part of it - the quarters' residual SADs: max > 4 x min + (N / 2)^2.  The thread of the CU's first block decides; log2_cu bits 4..5 = 3 mark the CU for every later reader
+        if (tid < 16) {
+            const ks265_cu8 q = blk[tid];
+            const int l2 = q.log2_cu & 15, n8 = l2 >= 3 ? 1 << (l2 - 3) : 1, bx = tid & 3, by = tid >> 2;
+            if (q.log2_cu != 0 && q.pred_mode == 0 && !(q.log2_cu >> 4) && (n8 == 2 || n8 == 4) && !(bx & (n8 - 1)) && !(by & (n8 - 1))) {
+                const int h = n8 >> 1, N = n8 * 8;
+                int mn = 0x7fffffff, mx = 0;
+                for (int k = 0; k < 4; ++k) {
+                    int sq = 0;
+                    for (int yy = 0; yy < h; ++yy)
+                        for (int xx = 0; xx < h; ++xx) sq += lastcg[(by + (k >> 1) * h + yy) * 4 + bx + (k & 1) * h + xx];
+                    mn = min(mn, sq); mx = max(mx, sq);
+                }
+                if (mx > 4 * mn + (N / 2) * (N / 2))
+                    for (int yy = 0; yy < n8; ++yy)
+                        for (int xx = 0; xx < n8; ++xx) { const int o = (by + yy) * 4 + bx + xx; blk[o].log2_cu = (uint8_t)(q.log2_cu | 0x30); tu_log2[o] = (unsigned char)(l2 - 4); }
+            }
+        }
+        __syncthreads();
+        if (tid < 16) lastcg[tid] = 0;
+        __syncthreads();
+    }
+    // TU geometry of the quad
+    const int t8 = 1 << tu_log2[b], tbx = (b & 3) & ~(t8 - 1), tby = (b >> 2) & ~(t8 - 1), tb = tby * 4 + tbx;
+    const int ox = tbx * UNIT, oy = tby * UNIT, n = t8 * UNIT, log2n = tu_log2[b] + (RS == 32 ? 3 : 2);
+    const short *mf = Mf + mat_off(log2n), *mt = Mt + mat_off(log2n);
+    const int mp = n + 4;                                          // matrix row pitch
     // ---- forward pass 1: T[k][j] = rnd(M[k] . X[j], 2 log2N - 2)
     if (has_quad) {
         const int k = qy - oy, j = qx - ox, s1 = 2 * log2n - 2;
@@ -349,7 +375,8 @@ template <bool MREF>
 __global__ __launch_bounds__(256) void reconstruct_kernel(KsGeom g, int qp, const uint8_t *src_y, const uint8_t *src_u, const uint8_t *src_v,
                                                           const uint8_t *ref_y, const uint8_t *ref_u, const uint8_t *ref_v,
                                                           const uint8_t *ref1_y, const uint8_t *ref1_u, const uint8_t *ref1_v, ks265_cu8 *cu8,
-                                                          int16_t *lvl_y, int16_t *lvl_u, int16_t *lvl_v, uint8_t *rec_y, uint8_t *rec_u, uint8_t *rec_v, const short *mats, const KsRefExtra xr, int sdh_on, int dec_k, long long rdo_lam2k, const int8_t *qp_map)
+                                                          int16_t *lvl_y, int16_t *lvl_u, int16_t *lvl_v, uint8_t *rec_y, uint8_t *rec_u, uint8_t *rec_v, const short *mats, const KsRefExtra xr, int sdh_on, int dec_k, long long rdo_lam2k, const int8_t *qp_map,
+                                                          int tu_inter)
 {
     __shared__ __attribute__((aligned(16))) short Mf[MAT_SHORTS];
     __shared__ __attribute__((aligned(16))) short Mt[MAT_SHORTS];
@@ -385,7 +412,7 @@ __global__ __launch_bounds__(256) void reconstruct_kernel(KsGeom g, int qp, cons
     }
     __syncthreads();
     const int qpc = chroma_qp(qp);
-    code_region<32, MREF>(g, 0, qp, rx * 4, ry * 4, blk, tu_log2, Mf, Mt, X, T, P, nzcnt, src_y, ref_y, ref1_y, lvl_y, rec_y, tid, xr.y, sdh, LV, DU, CF, lastcg, dec_k, rdo_lam2k);
+    code_region<32, MREF>(g, 0, qp, rx * 4, ry * 4, blk, tu_log2, Mf, Mt, X, T, P, nzcnt, src_y, ref_y, ref1_y, lvl_y, rec_y, tid, xr.y, sdh, LV, DU, CF, lastcg, dec_k, rdo_lam2k, tu_inter != 0);
     if (tid < 16 && blk[tid].log2_cu) {
         const int t8 = 1 << tu_log2[tid], tb = ((tid >> 2) & ~(t8 - 1)) * 4 + ((tid & 3) & ~(t8 - 1));
         if (nzcnt[tb]) cbf[tid] |= 1;
@@ -403,6 +430,7 @@ __global__ __launch_bounds__(256) void reconstruct_kernel(KsGeom g, int qp, cons
         if (nzcnt[tb]) cbf[tid] |= 4;
         const int bx = rx * 4 + (tid & 3), by = ry * 4 + (tid >> 2);
         cu8[(long)by * g.w8 + bx].cbf = (uint8_t)cbf[tid];
+        if (tu_inter) cu8[(long)by * g.w8 + bx].log2_cu = blk[tid].log2_cu;      // (bits 4..5 = 3: four transform units)
     }
 }
 
@@ -411,7 +439,7 @@ static int launch_reconstruct(ks265_frame *f, ks265_pic src, ks265_pic ref0, ks2
 {
     dim3 grid(((f->g.W + 31) / 32) * ((f->g.H + 31) / 32));
     hipLaunchKernelGGL(reconstruct_kernel<false>, grid, dim3(256), 0, f->ctx->stream, f->g, f->cfg.qp, src.y, src.u, src.v, ref0.y, ref0.u, ref0.v, ref1.y,
-                       ref1.u, ref1.v, cu8, lvl_y, lvl_u, lvl_v, recon.y, recon.u, recon.v, f->mats, KsRefExtra{}, f->cfg.sdh, f->cfg.decimate, ks_rdo_lam2k(f), f->qp_map);
+                       ref1.u, ref1.v, cu8, lvl_y, lvl_u, lvl_v, recon.y, recon.u, recon.v, f->mats, KsRefExtra{}, f->cfg.sdh, f->cfg.decimate, ks_rdo_lam2k(f), f->qp_map, f->cfg.tu_inter);
     return ks265_check_launch(f->ctx);
 }
 
@@ -430,7 +458,7 @@ extern "C" int ks265_reconstruct_mref(ks265_frame *f, ks265_pic src, int nref, c
     dim3 grid(((f->g.W + 31) / 32) * ((f->g.H + 31) / 32));
     hipLaunchKernelGGL(reconstruct_kernel<true>, grid, dim3(256), 0, f->ctx->stream, f->g, f->cfg.qp, src.y, src.u, src.v, refs[0].y, refs[0].u, refs[0].v,
                        (const uint8_t *)nullptr, (const uint8_t *)nullptr, (const uint8_t *)nullptr, cu8, lvl_y, lvl_u, lvl_v, recon.y, recon.u,
-                       recon.v, f->mats, xr, f->cfg.sdh, f->cfg.decimate, ks_rdo_lam2k(f), f->qp_map);
+                       recon.v, f->mats, xr, f->cfg.sdh, f->cfg.decimate, ks_rdo_lam2k(f), f->qp_map, f->cfg.tu_inter);
     return ks265_check_launch(f->ctx);
 }
 
@@ -456,7 +484,7 @@ extern "C" int ks265_reconstruct_b(ks265_frame *f, ks265_pic src, ks265_pic ref0
         const ks265_pic a0 = f->mr_pic[0][0], b0 = f->mr_pic[1][0];
         dim3 grid(((f->g.W + 31) / 32) * ((f->g.H + 31) / 32));
         hipLaunchKernelGGL(reconstruct_kernel<true>, grid, dim3(256), 0, f->ctx->stream, f->g, f->cfg.qp, src.y, src.u, src.v, a0.y, a0.u, a0.v, b0.y, b0.u, b0.v, cu8, lvl_y, lvl_u, lvl_v,
-                           recon.y, recon.u, recon.v, f->mats, xr, f->cfg.sdh, f->cfg.decimate, ks_rdo_lam2k(f), f->qp_map);
+                           recon.y, recon.u, recon.v, f->mats, xr, f->cfg.sdh, f->cfg.decimate, ks_rdo_lam2k(f), f->qp_map, f->cfg.tu_inter);
         return ks265_check_launch(f->ctx);
     }
     return launch_reconstruct(f, src, ref0, ref1, cu8, lvl_y, lvl_u, lvl_v, recon);

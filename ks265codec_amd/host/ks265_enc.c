@@ -1137,7 +1137,9 @@ static Enc *lane_open(QY265EncConfig *cfg, int device, int multi, int *err)
     e->nthreads = cfg->threads > 0 ? cfg->threads : (int)(ncpu > 0 ? ncpu : 4);
     if (e->nthreads > 64) e->nthreads = 64;
 
-    if (cfg->rdoq || cfg->transskip) logf_(1, e->log_level, "ks265enc: rdoq / transskip are accepted but not implemented by the pixel path\n");
+    if (cfg->rdoq || cfg->transskip) logf_(1, e->log_level, "ks265enc: rdoq / transskip are accepted but not implemented by the pixel path (rdoQuant exists as a device operator, ks265_rdoq_batch; at the seam it buys <= 1 %% with adaptive tables: DESIGN.md 9)\n");
+    if (cfg->tuInter > 1) logf_(1, e->log_level, "ks265enc: -intertu %d runs as -intertu 1 (the residual quadtree of inter CUs one level deep)\n", cfg->tuInter);
+    if (cfg->tuIntra > 0) logf_(2, e->log_level, "ks265enc: -intratu is accepted but not implemented (intra CUs carry one transform unit)\n");
     if (cfg->iAqMode > 1) logf_(1, e->log_level, "ks265enc: -aq %d runs as -aq 1 (block variance, the mode of the reference's calcFrameAdaptQuant)\n", cfg->iAqMode);
     if (cfg->part && e->refs > 1) logf_(1, e->log_level, "ks265enc: -part 1 (2NxN / Nx2N partitions of 64 / 32 / 16 CUs) acts on P and B pictures with one reference picture per list; multi-reference P pictures keep 2Nx2N\n");
     /* options whose VALUE is narrowed (SURVEY.md 8(a) config 5 = -preset veryslow: subme 2, part 1, ref 4): said once, never silently */
@@ -1175,6 +1177,7 @@ static Enc *lane_open(QY265EncConfig *cfg, int device, int multi, int *err)
                                                                          * integer search (measured with one round: - 21 .. - 23 % bytes of the P / B pictures; the variable is a measuring aid) */
     e->fcfg.intra_inter = 1;                                            /* P / B pictures may hold intra CUs (uncovered regions, occlusions); 2 = none of 8x8: measured + 1.6 % bits, no faster */
     e->fcfg.rdo = 4;                                                    /* coefficient-group pruning at lambda x 1 (ks265_frame_cfg.rdo): supersedes the coefficient decimation of round 2 */
+    e->fcfg.tu_inter = cfg->tuInter > 0 ? 1 : 0;                        /* -intertu N (tuInter; veryslow 1, placebo 2): the residual quadtree of inter CUs ONE level deep (ks265_frame_cfg.tu_inter); deeper values run as 1 */
     e->fcfg.part = cfg->part ? 1 : 0;                                   /* -part 1 (slower, veryslow, placebo): 2NxN / Nx2N prediction units in P and B pictures (ks265_frame_cfg.part) */
     e->fcfg.bi_refine = 1;                                              /* B pictures: joint refinement of the bi-predictive pair (motionSearchBI enc@0x484910) */
     r = ks265_frame_geometry(&e->fcfg, &e->geom);
@@ -1313,6 +1316,7 @@ static Enc *lane_open(QY265EncConfig *cfg, int device, int multi, int *err)
     e->scfg.sdh = e->fcfg.sdh;
     e->zero_latency = cfg->latency == QY265LATENCY_ZERO && e->gop_b == 0 && !e->la_on && !multi;
     e->scfg.cu_qp_delta = e->aq_on;
+    e->scfg.tu_inter = e->fcfg.tu_inter;
     e->scfg.wpp = 1;                                                    /* CTU rows as substreams: what lets several writer threads share one picture */
     e->scfg.max_dec_pic_buffering = e->hier ? 10 : e->gop_b ? 4 : e->refs + 1; e->scfg.log2_max_poc_lsb = 16;
     /* pictures that precede a picture in decoding order and follow it in output order: the whole GOP for the hierarchy (7, as before), ONE (the anchor) for

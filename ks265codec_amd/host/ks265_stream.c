@@ -118,7 +118,7 @@ long ks265_write_sps(const ks265_stream_cfg *cfg, uint8_t *out, size_t cap)
     bw_ue(&b, 3);                        /* log2_diff_max_min_luma_coding_block_size: 64 */
     bw_ue(&b, 0);                        /* log2_min_luma_transform_block_size_minus2: 4 */
     bw_ue(&b, 3);                        /* log2_diff_max_min_luma_transform_block_size: 32 */
-    bw_ue(&b, 0);                        /* max_transform_hierarchy_depth_inter */
+    bw_ue(&b, cfg->tu_inter ? 1 : 0);    /* max_transform_hierarchy_depth_inter */
     bw_ue(&b, 0);                        /* max_transform_hierarchy_depth_intra */
     bw_put(&b, 0, 1);                    /* scaling_list_enabled_flag */
     bw_put(&b, 0, 1);                    /* amp_enabled_flag */
@@ -819,7 +819,11 @@ static int coding_unit(Enc *e, int x, int y, int log2)
     Cabac *c = &e->c;
     const ks265_cu8 *cu = cu_at(e, x, y);
     const int size = 1 << log2, intra = is_intra(cu), st = e->in->slice_type;
-    const int part = intra ? 0 : (cu->log2_cu >> 4) & 3;             /* 0 = 2Nx2N, 1 = 2NxN, 2 = Nx2N (ks265_frame_cfg.part): two prediction units, four transform units */
+    const int pm = intra ? 0 : (cu->log2_cu >> 4) & 3;
+    const int part = pm == 3 ? 0 : pm;                               /* 0 = 2Nx2N, 1 = 2NxN, 2 = Nx2N (ks265_frame_cfg.part): two prediction units, four transform units */
+    const int tsplit = pm == 3;                                      /* 2Nx2N with four transform units (ks265_frame_cfg.tu_inter: split_transform_flag = 1) */
+    const int rqt = e->cfg->tu_inter && !intra && log2 <= 5;         /* max_transform_hierarchy_depth_inter = 1: split_transform_flag is coded at depth 0 (no interSplitFlag inference) */
+    if (tsplit && (!e->cfg->tu_inter || log2 > 5 || log2 < 4)) return KS265_NOTSUPPORTED;
     if (cu->pred_mode == 1) return KS265_NOTSUPPORTED;               /* the flat-128 stand-in is not an HEVC prediction mode */
     if (intra && log2 > 5) return KS265_NOTSUPPORTED;
     if (part > 2 || (part && log2 < 4)) return KS265_NOTSUPPORTED;   /* (an 8x8 CU in two partitions would need vectors per 8x4 block) */
@@ -832,7 +836,7 @@ static int coding_unit(Enc *e, int x, int y, int log2)
             blk_motion_all(cu, &mine);
             for (int k = 0; k < n && merge_idx < 0; ++k) if (same_motion(&mine, &cand[k])) merge_idx = k;
             int any = cu->cbf & 7;
-            if (log2 == 6) for (int k = 1; k < 4; ++k) any |= cu_at(e, x + (k & 1) * 32, y + (k >> 1) * 32)->cbf & 7;
+            if (log2 == 6 || tsplit) for (int k = 1; k < 4; ++k) any |= cu_at(e, x + (k & 1) * (size >> 1), y + (k >> 1) * (size >> 1))->cbf & 7;
             skip = merge_idx >= 0 && !any;
         }
         const int inc = (x > 0 && e->skip[(long)(y >> 3) * e->w8 + ((x - 1) >> 3)]) + (y > 0 && e->skip[(long)((y - 1) >> 3) * e->w8 + (x >> 3)]);
@@ -931,7 +935,7 @@ static int coding_unit(Enc *e, int x, int y, int log2)
     }
     /* transform tree (7.3.8.8): max_transform_hierarchy_depth = 0 -> one TU per CU, except 64x64 CUs (four 32x32 TUs, split inferred: above the maximum TU size) and
      * inter CUs in two partitions (four TUs of half the size: interSplitFlag, split inferred as well) */
-    if (log2 == 6 || part) {
+    if (log2 == 6 || part || tsplit) {
         const int hs = size >> 1;
         int any = 0, cby[4], ccb[4], ccr[4], acb = 0, acr = 0;
         for (int k = 0; k < 4; ++k) {
@@ -940,6 +944,7 @@ static int coding_unit(Enc *e, int x, int y, int log2)
             any |= q->cbf & 7; acb |= ccb[k]; acr |= ccr[k];
         }
         if (merge_idx < 0 || part) { cb_bin(c, CX_ROOT_CBF, any != 0); if (!any) return 0; }      /* rqt_root_cbf: inferred 1 only for a merged 2Nx2N CU (which has residual, else it was skipped) */
+        if (rqt) cb_bin(c, CX_SPLIT_TU + 5 - log2, 1);               /* split_transform_flag (ctxInc = 5 - log2TrafoSize): explicit with the residual quadtree on, for partitioned CUs too */
         cb_bin(c, CX_CBF_CHROMA + 0, acb);
         cb_bin(c, CX_CBF_CHROMA + 0, acr);
         for (int k = 0; k < 4; ++k) {
@@ -955,6 +960,7 @@ static int coding_unit(Enc *e, int x, int y, int log2)
         cb_bin(c, CX_ROOT_CBF, (cu->cbf & 7) != 0);
         if (!(cu->cbf & 7)) return 0;
     }
+    if (rqt) cb_bin(c, CX_SPLIT_TU + 5 - log2, 0);                   /* one transform unit (8x8 CUs are never split: their chroma would sit at the parent) */
     cb_bin(c, CX_CBF_CHROMA + 0, cbf_cb);
     cb_bin(c, CX_CBF_CHROMA + 0, cbf_cr);
     if (intra || cbf_cb || cbf_cr) cb_bin(c, CX_CBF_LUMA + 1, cbf_y); /* trafoDepth 0 -> ctxInc 1; else inferred 1 */

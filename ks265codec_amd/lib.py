@@ -27,7 +27,7 @@ SAO_PARAM = np.dtype([("type", "i1"), ("band", "i1"), ("offset", "i1", 4), ("rsv
 
 class FrameCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("width", "height", "qp", "lambda_q4", "me_range", "me_method", "subme", "deblock", "sao",
-                                          "beta_offset_div2", "tc_offset_div2", "bframes", "refs", "me_hex_thr", "sdh", "pre_search", "merge", "bi_refine", "decimate", "rdo", "intra_inter", "propagate", "sub_satd", "sub_thr", "sub_flat", "sub_cap", "sub_cap_step", "sub_diag_fast", "part")]
+                                          "beta_offset_div2", "tc_offset_div2", "bframes", "refs", "me_hex_thr", "sdh", "pre_search", "merge", "bi_refine", "decimate", "rdo", "intra_inter", "propagate", "sub_satd", "sub_thr", "sub_flat", "sub_cap", "sub_cap_step", "sub_diag_fast", "part", "tu_inter")]
 
 
 class FrameGeom(C.Structure):
@@ -306,9 +306,9 @@ class KsFrame:
 
     def __init__(self, ks: KsContext, width: int, height: int, qp: int, lambda_q4: int, me_range: int = 64, subme: int = 1,
                  deblock: int = 1, sao: int = 1, me_method: int = 0, bframes: int = 0, refs: int = 1, me_hex_thr: int = 0, sdh: int = 0, pre_search: int = 0, merge: int = 0, bi_refine: int = 0, decimate: int = 0, rdo: int = 0, intra_inter: int = 0, propagate: int = 0,
-                 sub_satd: int = 0, sub_thr: int = 24, sub_flat: int = 8, sub_cap: int = 0, sub_cap_step: int = 0, sub_diag_fast: int = 0, part: int = 0):     # the sub-pel knobs of -preset slow (synth.SUBME_PRESET)
+                 sub_satd: int = 0, sub_thr: int = 24, sub_flat: int = 8, sub_cap: int = 0, sub_cap_step: int = 0, sub_diag_fast: int = 0, part: int = 0, tu_inter: int = 0):     # the sub-pel knobs of -preset slow (synth.SUBME_PRESET)
         self.ks, self.lib = ks, ks.lib
-        self.cfg = FrameCfg(width, height, qp, lambda_q4, me_range, me_method, subme, deblock, sao, 0, 0, bframes, refs, me_hex_thr, sdh, pre_search, merge, bi_refine, decimate, rdo, intra_inter, propagate, sub_satd, sub_thr, sub_flat, sub_cap, sub_cap_step, sub_diag_fast, part)
+        self.cfg = FrameCfg(width, height, qp, lambda_q4, me_range, me_method, subme, deblock, sao, 0, 0, bframes, refs, me_hex_thr, sdh, pre_search, merge, bi_refine, decimate, rdo, intra_inter, propagate, sub_satd, sub_thr, sub_flat, sub_cap, sub_cap_step, sub_diag_fast, part, tu_inter)
         self.geom = FrameGeom()
         ks._chk(self.lib.ks265_frame_geometry(C.byref(self.cfg), C.byref(self.geom)))
         h = C.c_void_p()

@@ -20,7 +20,7 @@ NAL_TRAIL_N, NAL_TRAIL_R, NAL_IDR_W_RADL, NAL_IDR_N_LP = 0, 1, 19, 20
 
 class StreamCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("width", "height", "fps_num", "fps_den", "sao", "deblock", "beta_offset_div2", "tc_offset_div2",
-                                          "max_dec_pic_buffering", "max_num_reorder", "log2_max_poc_lsb", "sdh", "wpp", "list_mod", "cu_qp_delta")]
+                                          "max_dec_pic_buffering", "max_num_reorder", "log2_max_poc_lsb", "sdh", "wpp", "list_mod", "cu_qp_delta", "tu_inter")]
 
 
 class SliceIn(C.Structure):
@@ -64,9 +64,9 @@ class StreamWriter:
     """Annex-B HEVC stream from per-picture records (host numpy arrays with the dtypes of ks265codec_amd.lib)."""
 
     def __init__(self, width: int, height: int, sao: int = 1, deblock: int = 1, beta_offset_div2: int = 0, tc_offset_div2: int = 0,
-                 max_dec_pic_buffering: int = 2, max_num_reorder: int = 0, sdh: int = 0, wpp: int = 0, list_mod: int = 0, cu_qp_delta: int = 0):
+                 max_dec_pic_buffering: int = 2, max_num_reorder: int = 0, sdh: int = 0, wpp: int = 0, list_mod: int = 0, cu_qp_delta: int = 0, tu_inter: int = 0):
         self.l = lib()
-        self.cfg = StreamCfg(width, height, 0, 0, sao, deblock, beta_offset_div2, tc_offset_div2, max_dec_pic_buffering, max_num_reorder, 16, sdh, wpp, list_mod, cu_qp_delta)
+        self.cfg = StreamCfg(width, height, 0, 0, sao, deblock, beta_offset_div2, tc_offset_div2, max_dec_pic_buffering, max_num_reorder, 16, sdh, wpp, list_mod, cu_qp_delta, tu_inter)
         self.scratch = np.zeros(self.l.ks265_slice_scratch_bytes(C.byref(self.cfg)), np.uint8)
         self.out = np.zeros(width * height * 4 + 65536, np.uint8)
 

@@ -1146,6 +1146,11 @@ void kso_effective_qp(const kso_frame_cfg *cfg, const kso_cu8 *cu8, uint8_t *eff
 }
 
 /* list 0 may hold several reference pictures (multi-reference P pictures, -ref / -ref0): the CU's picture is refs0[inter_dir >> 4] */
+#ifndef TU_SPLIT_K
+#define TU_SPLIT_K 4
+#endif
+static int g_tu_split_k = TU_SPLIT_K;                    /* (experiment hook of tools/rd_eval.py: kso_experiment_tu_split_k) */
+void kso_experiment_tu_split_k(int k) { g_tu_split_k = k; }
 static void reconstruct_impl(const kso_frame_cfg *cfg, kso_pic src, const kso_pic *refs0, const uint8_t *const *planes0, kso_pic ref1_, const uint8_t *planes1_,
                              kso_cu8 *cu8, int16_t *lvl_y, int16_t *lvl_u, int16_t *lvl_v, kso_pic recon)
 {
@@ -1157,7 +1162,38 @@ static void reconstruct_impl(const kso_frame_cfg *cfg, kso_pic src, const kso_pi
             kso_cu8 *c = &cu8[(long)by * w8 + bx];
             const int qp = ctu_qp(cfg, bx * 8, by * 8), qpc = chroma_qp(qp);
             int n8 = 1 << (CU_LOG2(c) - 3);
-            int tu8 = imin(CU_PART(c) ? n8 >> 1 : n8, 4);       /* TU = min(CU, 32); a CU in two partitions: four TUs (interSplitFlag) */
+            /* cfg->tu_inter (round 5; -intertu 1 = tuInter, qy265enc.h:133: the residual quadtree of inter CUs one level deep; the reference decides it inside its closed RD code,
+             * tuDecision enc@0x4825a0): a 2Nx2N inter CU of 32 or 16 samples is coded with FOUR transform units when its luma residual is concentrated in part of it - the
+             * quarters' residual SADs under the CU's final motion: max > TU_SPLIT_K x min + (N / 2)^2 - so that the quiet quarters cost a coded-block flag instead of sharing a
+             * large transform's spread.  Decided at the CU's first block; log2_cu bits 4..5 = 3 mark it (2Nx2N, four TUs) for every later reader */
+            if (cfg->tu_inter && c->pred_mode == 0 && !CU_PART(c) && (n8 == 2 || n8 == 4) && !(bx % n8) && !(by % n8)) {
+                const int N = n8 * 8, cx0 = bx * 8, cy0 = by * 8, d = c->inter_dir & 3;
+                uint8_t pc[32 * 32];
+                const kso_pic rf = refs0[(c->inter_dir >> 4) & 3];
+                const uint8_t *pl0 = planes0[(c->inter_dir >> 4) & 3];
+                const kso_pic rf1 = g_mr ? g_mr->pic1[(c->inter_dir >> 6) & 3] : ref1_;
+                const uint8_t *pl1 = g_mr ? g_mr->planes1[(c->inter_dir >> 6) & 3] : planes1_;
+                if (d == 3) {
+                    int16_t a0[32 * 32], a1[32 * 32];
+                    pred14_luma(org_y(&g, rf.y), sy, cx0, cy0, N, c->mvx, c->mvy, a0);
+                    pred14_luma(org_y(&g, rf1.y), sy, cx0, cy0, N, c->mv1x, c->mv1y, a1);
+                    ks265o_default_weighted_bi(pc, a0, a1, N, N, N, N);
+                } else {
+                    const uint8_t *pb = d == 2 ? pl1 : pl0;
+                    const int ux = d == 2 ? c->mv1x : c->mvx, uy = d == 2 ? c->mv1y : c->mvy;
+                    const uint8_t *pl = org_y(&g, (uint8_t *)pb + (long)((uy & 3) * 4 + (ux & 3)) * g.bytes_y) + (long)(cy0 + (uy >> 2)) * sy + cx0 + (ux >> 2);
+                    for (int y = 0; y < N; ++y) memcpy(pc + y * N, pl + (long)y * sy, (size_t)N);
+                }
+                int q[4] = {0, 0, 0, 0};
+                const uint8_t *So = org_y(&g, src.y) + (long)cy0 * sy + cx0;
+                for (int y = 0; y < N; ++y)
+                    for (int x = 0; x < N; ++x) q[(y >= N / 2) * 2 + (x >= N / 2)] += iabs_((int)So[(long)y * sy + x] - (int)pc[y * N + x]);
+                const int mn = imin(imin(q[0], q[1]), imin(q[2], q[3])), mx = imax(imax(q[0], q[1]), imax(q[2], q[3]));
+                if (mx > g_tu_split_k * mn + (N / 2) * (N / 2))
+                    for (int yy = 0; yy < n8; ++yy)
+                        for (int xx = 0; xx < n8; ++xx) cu8[(long)(by + yy) * w8 + bx + xx].log2_cu |= 3 << 4;
+            }
+            int tu8 = imin(CU_PART(c) ? n8 >> 1 : n8, 4);       /* TU = min(CU, 32); a CU in two partitions (or 2Nx2N with split transform units): four TUs */
             if ((bx % tu8) || (by % tu8)) continue;             /* visit each TU once, at its top-left 8x8 block */
             if (c->pred_mode == 2) continue;                    /* an intra CU of a P / B picture: coded afterwards from reconstructed neighbours (kso_intra_inter_reconstruct) */
             int n = tu8 * 8, x0 = bx * 8, y0 = by * 8, intra = c->pred_mode == 1;

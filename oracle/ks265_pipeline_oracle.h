@@ -20,7 +20,8 @@ extern "C" {
 typedef struct {
     int32_t width, height, qp, lambda_q4, me_range, me_method, subme, deblock, sao, beta_offset_div2, tc_offset_div2, bframes, refs, me_hex_thr, sdh, pre_search, merge, bi_refine, decimate, rdo, intra_inter, propagate,
             sub_satd, sub_thr, sub_flat, sub_cap, sub_cap_step, sub_diag_fast,     /* the sub-pel refinement's knobs (Stage B, ks265_pipeline_oracle.c) */
-            part;                                                            /* -part 1: 2NxN / Nx2N partitions of 64 / 32 / 16 CUs in P pictures (kso_cu_decide_part) */
+            part,                                                            /* -part 1: 2NxN / Nx2N partitions of 64 / 32 / 16 CUs in P / B pictures (kso_cu_decide_part[_b]) */
+            tu_inter;                                                        /* -intertu 1 (tuInter: veryslow, placebo): a 2Nx2N inter CU of 32 / 16 samples may carry four transform units (split_transform_flag) */
 } kso_frame_cfg;
 
 typedef struct {

@@ -45,7 +45,7 @@ I = C.c_int
 # ------------------------------------------------------------------ pipeline oracle (ks265_pipeline_oracle.h)
 class OFrameCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("width", "height", "qp", "lambda_q4", "me_range", "me_method", "subme", "deblock", "sao",
-                                          "beta_offset_div2", "tc_offset_div2", "bframes", "refs", "me_hex_thr", "sdh", "pre_search", "merge", "bi_refine", "decimate", "rdo", "intra_inter", "propagate", "sub_satd", "sub_thr", "sub_flat", "sub_cap", "sub_cap_step", "sub_diag_fast", "part")]
+                                          "beta_offset_div2", "tc_offset_div2", "bframes", "refs", "me_hex_thr", "sdh", "pre_search", "merge", "bi_refine", "decimate", "rdo", "intra_inter", "propagate", "sub_satd", "sub_thr", "sub_flat", "sub_cap", "sub_cap_step", "sub_diag_fast", "part", "tu_inter")]
 
 
 class OFrameGeom(C.Structure):
@@ -85,10 +85,10 @@ class OraclePipeline:
     """CPU restatement of the frame stages (test checker / cpu_baseline 'port')."""
 
     def __init__(self, width, height, qp, lambda_q4, me_range=64, subme=1, deblock=1, sao=1, me_method=0, intra=True, me_hex_thr=0, sdh=0, pre_search=0, merge=0, bi_refine=0, decimate=0, rdo=0, intra_inter=0, propagate=0,
-                 sub_satd=0, sub_thr=24, sub_flat=8, sub_cap=0, sub_cap_step=0, sub_diag_fast=0, part=0):
+                 sub_satd=0, sub_thr=24, sub_flat=8, sub_cap=0, sub_cap_step=0, sub_diag_fast=0, part=0, tu_inter=0):
         self.o = lib()
         self.intra = intra                      # key pictures: real intra prediction (True) or the flat stand-in
-        self.cfg = OFrameCfg(width, height, qp, lambda_q4, me_range, me_method, subme, deblock, sao, 0, 0, 1, 4, me_hex_thr, sdh, pre_search, merge, bi_refine, decimate, rdo, intra_inter, propagate, sub_satd, sub_thr, sub_flat, sub_cap, sub_cap_step, sub_diag_fast, part)
+        self.cfg = OFrameCfg(width, height, qp, lambda_q4, me_range, me_method, subme, deblock, sao, 0, 0, 1, 4, me_hex_thr, sdh, pre_search, merge, bi_refine, decimate, rdo, intra_inter, propagate, sub_satd, sub_thr, sub_flat, sub_cap, sub_cap_step, sub_diag_fast, part, tu_inter)
         self.geom = OFrameGeom()
         assert self.o.kso_frame_geometry(C.byref(self.cfg), C.byref(self.geom)) == 0
         g = self.geom

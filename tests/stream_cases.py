@@ -42,33 +42,41 @@ CASES = {
     "part_hierb4_416x240": (416, 240, 28, 2, 0, 1, 1, "hier", 4),
     "part_hierb4_200x136_qp34": (200, 136, 34, 1, 0, 1, 1, "hier", 4),
     # round 5: several reference pictures per list in B pictures (config 5: -ref 4): list 0 = the nearest past pictures, list 1 = the nearest future ones, ref_idx_l0 / _l1 per PU
+    # round 5: -intertu 1 (tuInter: veryslow, placebo): 2Nx2N inter CUs of 32 / 16 with four transform units where the residual sits in part of the CU; split_transform_flag in the stream
+    "rqt_ippp_416x240_umh": (416, 240, 27, 2, 0, 1, 1, "ippph", 4),
+    "rqt_part_hierb4_416x240": (416, 240, 29, 2, 0, 1, 1, "hier", 4),
+    "rqt_part_hiermr4_200x136": (200, 136, 31, 1, 0, 1, 1, "hiermr", 4),
     "enc_hiermr4_416x240": (416, 240, 29, 2, 16, 1, 1, "hiermr", 4),
     "part_hiermr4_200x136_qp33": (200, 136, 33, 1, 0, 1, 1, "hiermr", 4),
 }
 
 
 def case_part(name: str) -> int:
-    return 1 if name.startswith("part_") else 0
+    return 1 if name.startswith("part_") or name.startswith("rqt_part_") else 0
+
+
+def case_rqt(name: str) -> int:
+    return 1 if name.startswith("rqt_") else 0
 
 
 def case_sdh(name: str) -> int:
-    return 1 if name.startswith(("sdh_", "ps_", "wpp_", "enc_", "part_")) else 0
+    return 1 if name.startswith(("sdh_", "ps_", "wpp_", "enc_", "part_", "rqt_")) else 0
 
 
 def case_ps(name: str) -> int:
-    return 1 if name.startswith(("ps_", "wpp_", "enc_", "part_")) else 0
+    return 1 if name.startswith(("ps_", "wpp_", "enc_", "part_", "rqt_")) else 0
 
 
 def case_wpp(name: str) -> int:
-    return 1 if name.startswith(("wpp_", "enc_", "part_")) else 0
+    return 1 if name.startswith(("wpp_", "enc_", "part_", "rqt_")) else 0
 
 
 def case_merge(name: str) -> int:
-    return 1 if name.startswith(("enc_", "part_")) else 0
+    return 1 if name.startswith(("enc_", "part_", "rqt_")) else 0
 
 
 def case_bir(name: str) -> int:
-    return 1 if name.startswith(("enc_", "part_")) else 0
+    return 1 if name.startswith(("enc_", "part_", "rqt_")) else 0
 
 
 def case_dec(name: str) -> int:
@@ -76,28 +84,28 @@ def case_dec(name: str) -> int:
 
 
 def case_rdo(name: str) -> int:
-    return 4 if name.startswith(("enc_", "part_")) else 0            # the C host: coefficient-group pruning (superseded the coefficient decimation of round 2)
+    return 4 if name.startswith(("enc_", "part_", "rqt_")) else 0            # the C host: coefficient-group pruning (superseded the coefficient decimation of round 2)
 
 
 def case_ii(name: str) -> int:
-    return (2 if "1280x720" in name else 1) if name.startswith(("enc_", "part_")) else 0   # the C host: intra CUs in P / B pictures (one case with 2 = 16x16 and 32x32 only)
+    return (2 if "1280x720" in name else 1) if name.startswith(("enc_", "part_", "rqt_")) else 0   # the C host: intra CUs in P / B pictures (one case with 2 = 16x16 and 32x32 only)
 
 
 def case_prop(name: str) -> int:
-    return 1 if name.startswith(("enc_", "part_")) else 0            # the C host: one round of vector propagation after every integer search (stage A2)
+    return 1 if name.startswith(("enc_", "part_", "rqt_")) else 0            # the C host: one round of vector propagation after every integer search (stage A2)
 
 
 def case_subme(name: str) -> dict:
     """the sub-pel knobs: the C host's (-preset slow: fast candidate sets judged by SAD) for the enc_ cases, -preset veryslow's (all 8 + 8 candidates judged by
     Hadamard) for the wpp_ cases, -preset medium's for the hierarchical ones, veryfast's for the rest"""
     from ks265codec_amd.synth import subme_knobs
-    return subme_knobs("slower" if name.startswith("part_") else "slow" if name.startswith("enc_") else "veryslow" if name.startswith("wpp_") else "medium" if "hier" in name else "veryfast")
+    return subme_knobs("veryslow" if name.startswith("rqt_") else "slower" if name.startswith("part_") else "slow" if name.startswith("enc_") else "veryslow" if name.startswith("wpp_") else "medium" if "hier" in name else "veryfast")
 
 
 def case_lambda(name: str, q: int, kind: str) -> int:
     """the C host prices P / B pictures with the inter table (HM's factor for pictures that are not key pictures)"""
     from ks265codec_amd.synth import lambda_q4
-    return lambda_q4(q, inter=name.startswith(("enc_", "part_")) and kind != "I")
+    return lambda_q4(q, inter=name.startswith(("enc_", "part_", "rqt_")) and kind != "I")
 
 
 from ks265codec_amd.synth import HOST_IPPP_CASCADE      # ks265_enc.c kIpppCascade: the QP of an IPPP P picture is the key picture's + 1 + this, by its position in the GOP (the reference's 30 / 29 / 30 / 28 at -qp 27)
@@ -162,7 +170,7 @@ def make_stream(name: str, encode):
     sched = schedule(kind, par)
     nref = max([len(s[2]) + len(s[3]) for s in sched] + [1])
     reorder = par if kind in ("hier", "hiermr") else 0
-    w = S.StreamWriter(W, H, sao=sao, deblock=df, max_dec_pic_buffering=(par + 4) if kind == "hiermr" else (par + 2) if kind == "hier" else nref + 1, max_num_reorder=reorder, sdh=case_sdh(name), wpp=case_wpp(name))      # the C host's rule (ks265_enc.c)
+    w = S.StreamWriter(W, H, sao=sao, deblock=df, max_dec_pic_buffering=(par + 4) if kind == "hiermr" else (par + 2) if kind == "hier" else nref + 1, max_num_reorder=reorder, sdh=case_sdh(name), wpp=case_wpp(name), tu_inter=case_rqt(name))      # the C host's rule (ks265_enc.c)
     bs = w.headers()
     recs = {}
     for d, k, l0, l1, dq, rps, isref in sched:
@@ -183,7 +191,7 @@ def oracle_encoder(name: str):
     W, H, qp, me, thr, sao, df, kind, par = CASES[name]
     n = 1 + max(s[0] for s in schedule(kind, par))
     clip = make_clip(W, H, n, seed=len(name) * 7 + W, abc=(17, 23, 9))
-    o = OraclePipeline(W, H, qp, lambda_q4(qp), me_method=me, me_hex_thr=thr, sao=sao, deblock=df, sdh=case_sdh(name), pre_search=case_ps(name), merge=case_merge(name), bi_refine=case_bir(name), decimate=case_dec(name), rdo=case_rdo(name), intra_inter=case_ii(name), propagate=case_prop(name), part=case_part(name), **case_subme(name))
+    o = OraclePipeline(W, H, qp, lambda_q4(qp), me_method=me, me_hex_thr=thr, sao=sao, deblock=df, sdh=case_sdh(name), pre_search=case_ps(name), merge=case_merge(name), bi_refine=case_bir(name), decimate=case_dec(name), rdo=case_rdo(name), intra_inter=case_ii(name), propagate=case_prop(name), part=case_part(name), tu_inter=case_rqt(name), **case_subme(name))
     dpb = {}
 
     def encode(d, k, l0, l1, q):

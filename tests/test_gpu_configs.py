@@ -221,7 +221,7 @@ def test_config5_hierarchical_b_with_partitions(ks, W, H, G, seed):
     from ks265codec_amd.lib import CU8, KsFrame
     from ks265codec_amd.synth import lambda_q4, make_clip, subme_knobs
     from oracle_lib import OraclePipeline
-    tools = dict(ENCODER_TOOLS, me_hex_thr=0, part=1, **subme_knobs("veryslow"))
+    tools = dict(ENCODER_TOOLS, me_hex_thr=0, part=1, tu_inter=1, **subme_knobs("veryslow"))
     clip = make_clip(W, H, G + 1, seed=seed, abc=(37, 53, 19) if W < 3000 else (67, 91, 33), pan=(5, 3) if W < 3000 else (8, 5))
     o = OraclePipeline(W, H, 27, lambda_q4(27), **tools)
     dirs = np.zeros(4, np.int64)
@@ -258,7 +258,7 @@ def test_config5_b_pictures_with_several_references_per_list(ks):
     from oracle_lib import OraclePipeline
     from stream_cases import schedule
     W, H = 1920, 1080
-    tools = dict(ENCODER_TOOLS, me_hex_thr=0, part=1, **subme_knobs("veryslow"))
+    tools = dict(ENCODER_TOOLS, me_hex_thr=0, part=1, tu_inter=1, **subme_knobs("veryslow"))
     sched = schedule("hiermr", 4)[:8]                                          # I0 P4 B2 B1 B3 P8 B6 B5 (B5: two pictures in BOTH lists - both index rates in a pair's cost)
     clip = make_clip(W, H, 9, seed=47, abc=(37, 53, 19), pan=(5, 3))
     o = OraclePipeline(W, H, 27, lambda_q4(27), **tools)
