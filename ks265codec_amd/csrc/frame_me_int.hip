@@ -421,20 +421,25 @@ __global__ __launch_bounds__(256) void me_score_kernel(int n, int cols, const un
 __global__ __launch_bounds__(512) void me_order_kernel(int n, const unsigned char *score, int *order)
 {
     __shared__ unsigned char sc[ME_ORDER_MAX];
-    __shared__ unsigned hist[256];
-    __shared__ int s_thr;
+    __shared__ int part[2][8];
     const int tid = threadIdx.x, lane = tid & 63, x = tid >> 6;
-    if (tid < 256) hist[tid] = 0;
+    for (int i = tid; i < n; i += 512) sc[i] = score[i];
     __syncthreads();
-    for (int i = tid; i < n; i += 512) { const unsigned char v = score[i]; sc[i] = v; atomicAdd(&hist[v], 1u); }
-    __syncthreads();
-    if (tid == 0) {
-        int acc = 0, thr = 256;
-        for (int v = 255; v > 0; --v) { if (acc + (int)hist[v] > n / 10) break; acc += (int)hist[v]; thr = v; }
-        s_thr = thr;
+    // the threshold: the smallest score v >= 1 with at most n / 10 CTUs at or above it (256: none).  The count falls with v: eight halvings, each a count by ballots (no
+    // histogram - most scores are the same few values, 2 000 atomics on three LDS words were most of this kernel's 15 us)
+    int lo = 1, hi = 256;
+    for (int it = 0; it < 8; ++it) {
+        const int mid = (lo + hi) >> 1;
+        int c = 0;
+        for (int i = tid; i < n; i += 512) c += sc[i] >= mid;
+        c = (int)wave_sum((unsigned)c);
+        if (lane == 0) part[it & 1][x] = c;
+        __syncthreads();
+        int tot = 0;
+        for (int w = 0; w < 8; ++w) tot += part[it & 1][w];
+        if (tot <= n / 10) hi = mid; else lo = mid + 1;
     }
-    __syncthreads();
-    const int thr = s_thr, per = n >> 3, rem = n & 7, cnt = per + (x < rem ? 1 : 0), first = x * per + min(x, rem);     // XCD x's CTUs: first .. first + cnt - 1 (ks_xcd_swizzle)
+    const int thr = hi, per = n >> 3, rem = n & 7, cnt = per + (x < rem ? 1 : 0), first = x * per + min(x, rem);     // XCD x's CTUs: first .. first + cnt - 1 (ks_xcd_swizzle)
     int nheavy = 0;
     for (int j0 = 0; j0 < cnt; j0 += 64) { const int j = j0 + lane; nheavy += __popcll(__ballot(j < cnt && sc[first + j] >= thr)); }
     int hs = 0, ls = 0;
