@@ -172,7 +172,7 @@ int QY265ConfigParse(QY265EncConfig *c, const char *name, const char *value)
 }
 
 /* ------------------------------------------------------------------ encoder */
-#define MAX_DPB 14
+#define MAX_DPB 18
 #define MAX_JOBS 128                                      /* upper bound of the ring of pictures in flight; the encoder sizes its ring (Enc::ring) by picture size */
 typedef struct TopWake { pthread_mutex_t mu; pthread_cond_t cv; unsigned long seq; } TopWake;
 #define MAX_INPUT (MAX_JOBS + 32 + 256)                /* input slots: the ring + a mini-GOP (+ in a GOP lane: a whole GOP of the next round, Enc::nin) */
@@ -314,6 +314,11 @@ typedef struct Enc {
      * input arrives - the pixel path is tens of pictures behind the input - it runs underneath the P pictures of the previous GOP instead of between
      * two GOPs.  Its reconstruction goes to one of two DPB slots of its own; the first P picture of the GOP waits for ev_key. */
     int refs_b;                                           /* reference pictures per list of a pyramid's B pictures (1 .. 4) */
+    /* round 5 - the ANCHOR LANE of the pyramid GOPs: a mini-GOP's anchor P picture predicts from the anchor before it and from nothing else, so the chain of anchors is coded on a
+     * stream and frame object of its own (like the key pictures), ahead of the B pictures of the mini-GOPs behind it: its kernels - and the long intra chain pass of a picture
+     * 4 or 8 away from its reference - run beside the B pictures' instead of in front of them.  Four DPB slots of its own, rotating; a slot is overwritten only after the B
+     * pictures that read its previous content have run on the main stream (ev_mg: one mark per mini-GOP, recorded behind its last B picture) */
+    int anc_on, nanch, last_on_anc; ks265_ctx *ctx_anc; ks265_frame *frame_anc; ks265_pic src_anc; uint64_t *dev_sse_anc; void *ev_anc, *ev_mg[8];
     int key_overlap, nkeys; ks265_ctx *ctx_key; ks265_frame *frame_key; ks265_pic src_key; uint64_t *dev_sse_key; void *ev_key, *ev_firstp[2];
     /* scheduling */
     Input in[MAX_INPUT]; int nin, next_disp, in_disp;          /* next_disp: pictures handed to the scheduler; in_disp: pictures taken in (= next_disp + the lookahead's queue la_q) */
@@ -591,7 +596,7 @@ static int rc_decide(Enc *e)
     return d;
 }
 
-static int dpb_find(Enc *e, int poc) { for (int i = 0; i < e->ndpb + 2 * e->key_overlap; ++i) if (e->dpb_poc[i] == poc) return i; return -1; }   /* incl. the key pictures' own slots */
+static int dpb_find(Enc *e, int poc) { for (int i = 0; i < e->ndpb + 2 + 4; ++i) if (e->dpb_poc[i] == poc) return i; return -1; }   /* incl. the key pictures' and the anchor lane's own slots (unused ones hold no POC) */
 static int dpb_free_slot(Enc *e, const int *keep, int nkeep)
 {
     for (int i = 0; i < e->ndpb; ++i) {
@@ -623,10 +628,11 @@ static int submit(Enc *e, Input *in, int kind, int poc, int qp, const int *l0, i
     int r = recycled ? ks265_stream_wait_event(e->ctx_in, e->ev_loaded[k]) : 0;
     /* pixel path: the main stream / frame object, or the key pictures' own */
     const int on_key = kind == 'I' && e->key_overlap && (in->iper <= 0 || in->iper >= 32);
-    const int split = e->split && !on_key;
-    ks265_ctx *cx = on_key ? e->ctx_key : e->ctx;
-    ks265_frame *fr = on_key ? e->frame_key : e->frame;
-    ks265_pic srcp = on_key ? e->src_key : split ? e->srcq[k] : e->src;
+    const int on_anc = kind == 'P' && e->anc_on && e->key_overlap && nl0 == 1;      /* (key_overlap goes off with the reconstruction dump: everything on the main stream then) */
+    const int split = e->split && !on_key && !on_anc;
+    ks265_ctx *cx = on_key ? e->ctx_key : on_anc ? e->ctx_anc : e->ctx;
+    ks265_frame *fr = on_key ? e->frame_key : on_anc ? e->frame_anc : e->frame;
+    ks265_pic srcp = on_key ? e->src_key : on_anc ? e->src_anc : split ? e->srcq[k] : e->src;
     if (!r && split && recycled) r = ks265_stream_wait_event(e->ctx_in, e->ev_drained[k]);   /* srcq[k]'s last reader (the SSE of three pictures ago) is through */
     /* with the lookahead the picture is on the device already, or on its way: uploaded into the slot's twin when it was handed in (round 4); else an H2D copy here, on this
      * stream, behind the waits above.  Graph replay needs fixed addresses: a device-to-device copy into the rotation buffer */
@@ -638,10 +644,10 @@ static int submit(Enc *e, Input *in, int kind, int poc, int qp, const int *l0, i
     } else if (!r) r = ks265_memcpy_h2d_async(e->ctx_in, e->dev_in[k], in->i420, fsz);
     if (!r && split) r = ks265_load_i420_on(e->ctx_in, fr, din, srcp);
     if (!r) r = ks265_event_record(e->ctx_in, e->ev_h2d[k]);
-    uint64_t *dsse = on_key ? e->dev_sse_key : e->dev_sse;
+    uint64_t *dsse = on_key ? e->dev_sse_key : on_anc ? e->dev_sse_anc : e->dev_sse;
     if (!r) r = ks265_stream_wait_event(cx, e->ev_h2d[k]);
     /* graph path: a P picture with one reference on the main stream, once the first pictures have made every lazy allocation */
-    const int graphable = e->use_graph && ((kind == 'P' && nl0 == 1) || (kind == 'B' && nl0 == 1 && nl1 == 1)) && !on_key && !e->recon_on && e->seq >= 8;
+    const int graphable = e->use_graph && ((kind == 'P' && nl0 == 1) || (kind == 'B' && nl0 == 1 && nl1 == 1)) && !on_key && !on_anc && !e->recon_on && e->seq >= 8;
     if (!graphable && !split) {
         if (!r) r = ks265_load_i420(fr, din, srcp);
         if (!r) r = ks265_event_record(cx, e->ev_loaded[k]);
@@ -674,6 +680,10 @@ static int submit(Enc *e, Input *in, int kind, int poc, int qp, const int *l0, i
          * The slot written now held the key picture two GOPs back: wait for the mark set when the previous key picture was submitted */
         if (!r && e->nkeys >= 1) r = ks265_event_record(e->ctx, e->ev_firstp[(e->nkeys - 1) & 1]);
         if (!r && e->nkeys >= 2) r = ks265_stream_wait_event(cx, e->ev_firstp[e->nkeys & 1]);
+    } else if (on_anc) {
+        slot = e->ndpb + 2 + (e->nanch & 3);
+        /* the slot held the anchor four back, which closed mini-GOP nanch - 4; its readers on the main stream were the B pictures of mini-GOPs nanch - 4 and nanch - 3 */
+        if (!r && e->nanch >= 4) r = ks265_stream_wait_event(cx, e->ev_mg[(e->nanch - 3) & 7]);
     } else slot = dpb_free_slot(e, keep, nk);
     if (slot < 0) return QY_FAIL;
     ks265_pic out = e->dpb[slot];
@@ -753,7 +763,19 @@ static int submit(Enc *e, Input *in, int kind, int poc, int qp, const int *l0, i
         if (!r) r = ks265_stream_wait_event(e->ctx, e->ev_key);
         if (!r) r = ks265_frame_p_restore(e->frame, 0);                 /* temporal predictors start over, and so does the ping-pong of the PU record buffers: the graph keys of a GOP's
                                                                          * pictures (which hold that state) are the same in every GOP - nothing is captured after the first one */
+        if (!r && e->anc_on) { r = ks265_stream_wait_event(e->ctx_anc, e->ev_key); if (!r) r = ks265_frame_p_restore(e->frame_anc, 0); }   /* the first anchor predicts from it */
         ++e->nkeys;
+    }
+    if (kind == 'I' && !on_key && e->anc_on) {                         /* a key picture on the main stream (short intra period): the anchors' stream waits for it there */
+        if (!r) r = ks265_event_record(e->ctx, e->ev_key);
+        if (!r) r = ks265_stream_wait_event(e->ctx_anc, e->ev_key);
+        if (!r) r = ks265_frame_p_restore(e->frame_anc, 0);
+    }
+    e->last_on_anc = on_anc;
+    if (on_anc) {                                                      /* the B pictures in front of it (and everything else the main stream codes from here on) wait for the anchor */
+        if (!r) r = ks265_event_record(cx, e->ev_anc);
+        if (!r) r = ks265_stream_wait_event(e->ctx, e->ev_anc);
+        ++e->nanch;
     }
     /* copy-out stream */
     if (!r) r = ks265_stream_wait_event(e->ctx_out, e->ev_staged[k]);
@@ -868,7 +890,7 @@ static int schedule(Enc *e, int flush, int have /* pictures [0, have) have arriv
         if (key) {
             e->gop_start = nxt; e->mg4_until = -1;
             e->rc_qp_delta = rc_decide(e);                             /* rate control: one offset per key picture / mini-GOP, decided when it is certain to be submitted */
-            for (int i = 0; i < e->ndpb + 2 * e->key_overlap; ++i) e->dpb_poc[i] = -1000000;
+            for (int i = 0; i < e->ndpb + 2 + 4; ++i) e->dpb_poc[i] = -1000000;
             int r = submit(e, in, 'I', 0, clampqp(e, in->base_qp + e->rc_qp_delta), NULL, 0, NULL, 0, NULL, 0, 1, 1);
             if (r) return r;
             pthread_mutex_lock(&e->mu); e->coded_upto = nxt; pthread_mutex_unlock(&e->mu);
@@ -904,6 +926,7 @@ static int schedule(Enc *e, int flush, int have /* pictures [0, have) have arriv
         const int casc = e->gop_b == 0 ? kIpppCascade[pa & 3] : 0;
         int r = submit(e, ina, 'P', pa, clampqp(e, ina->base_qp + e->rc_qp_delta + (e->fixqp ? 0 : 1 + casc)), l0, nl0, NULL, 0, keep, nkeep, 1, 0);
         if (r) return r;
+        const int anchor_on_lane = e->last_on_anc;
         if (a - d > 1) {
             if (e->hier && ((a - d) & (a - d - 1)) == 0) { r = code_hier(e, d, a); if (r) return r; }
             else {
@@ -914,6 +937,10 @@ static int schedule(Enc *e, int flush, int have /* pictures [0, have) have arriv
                     if (r) return r;
                 }
             }
+        }
+        if (e->anc_on && anchor_on_lane) {   /* every B picture that reads the anchors of this mini-GOP is on the main stream now */
+            r = hip_rc(ks265_event_record(e->ctx, e->ev_mg[(e->nanch - 1) & 7]));
+            if (r) return r;
         }
         pthread_mutex_lock(&e->mu); e->coded_upto = a; pthread_mutex_unlock(&e->mu);
     }
@@ -1064,6 +1091,12 @@ static void lane_close(Enc *e, int report)
         for (int i = 0; i < 2; ++i) if (e->ev_firstp[i]) ks265_event_destroy(e->ctx, e->ev_firstp[i]);
         if (e->ctx_key) ks265_synchronize(e->ctx_key);
         if (e->frame_key) ks265_frame_destroy(e->frame_key);
+        if (e->ctx_anc) ks265_synchronize(e->ctx_anc);
+        if (e->frame_anc) ks265_frame_destroy(e->frame_anc);
+        pic_free(e, &e->src_anc); ks265_dev_free(e->ctx, e->dev_sse_anc);
+        if (e->ev_anc) ks265_event_destroy(e->ctx, e->ev_anc);
+        for (int i = 0; i < 8; ++i) if (e->ev_mg[i]) ks265_event_destroy(e->ctx, e->ev_mg[i]);
+        for (int i = 0; i < 4; ++i) pic_free(e, &e->dpb[e->ndpb + 2 + i]);
         pic_free(e, &e->src);
         for (int k = 0; k < NPIPE; ++k) {
             ks265_dev_free(e->ctx, e->dev_in[k]); ks265_dev_free(e->ctx, e->stg[k]);
@@ -1091,6 +1124,7 @@ static void lane_close(Enc *e, int report)
         }
         if (e->frame) ks265_frame_destroy(e->frame);
         if (e->ctx_key) ks265_destroy(e->ctx_key);
+        if (e->ctx_anc) ks265_destroy(e->ctx_anc);
         if (e->ctx_in) ks265_destroy(e->ctx_in);
         if (e->ctx_out) ks265_destroy(e->ctx_out);
         ks265_destroy(e->ctx);
@@ -1217,7 +1251,8 @@ static Enc *lane_open(QY265EncConfig *cfg, int device, int multi, int *err)
     }
     if (!r) r = pic_alloc(e, &e->src);
     e->ndpb = e->hier ? 10 : e->gop_b ? 4 : e->refs + 2;
-    for (int i = 0; i < e->ndpb && !r; ++i) { r = pic_alloc(e, &e->dpb[i]); e->dpb_poc[i] = -1000000; }
+    for (int i = 0; i < MAX_DPB; ++i) e->dpb_poc[i] = -1000000;
+    for (int i = 0; i < e->ndpb && !r; ++i) r = pic_alloc(e, &e->dpb[i]);
     e->key_overlap = getenv("KS265_NO_KEY_OVERLAP") ? 0 : 1;
     e->use_graph = getenv("KS265_GRAPH") ? 1 : 0;                     /* opt-in since round 4: launch by launch is faster on this runtime (843 against 817 pictures/s, 2160p IPPP) and the split pipeline needs the launches apart */
     if (e->aq_on) e->use_graph = 0;                                      /* (a captured picture would replay one map) */
@@ -1229,6 +1264,16 @@ static Enc *lane_open(QY265EncConfig *cfg, int device, int multi, int *err)
         if (!r) r = ks265_dev_malloc(e->ctx, (void **)&e->dev_sse_key, 64);
         if (!r) r = ks265_event_create(e->ctx, &e->ev_key);
         for (int i = 0; i < 2 && !r; ++i) { r = pic_alloc(e, &e->dpb[e->ndpb + i]); e->dpb_poc[e->ndpb + i] = -1000000; if (!r) r = ks265_event_create(e->ctx, &e->ev_firstp[i]); }
+    }
+    e->anc_on = e->hier && e->key_overlap && !e->aq_on && !e->use_graph && !getenv("KS265_NO_ANCHOR_LANE");
+    if (e->anc_on) {
+        if (!r) r = ks265_create_prio(&e->ctx_anc, dev_id, 1);
+        if (!r) r = ks265_frame_create(e->ctx_anc, &e->fcfg, &e->frame_anc);
+        if (!r) r = pic_alloc(e, &e->src_anc);
+        if (!r) r = ks265_dev_malloc(e->ctx, (void **)&e->dev_sse_anc, 64);
+        if (!r) r = ks265_event_create(e->ctx, &e->ev_anc);
+        for (int i = 0; i < 8 && !r; ++i) r = ks265_event_create(e->ctx, &e->ev_mg[i]);
+        for (int i = 0; i < 4 && !r; ++i) { r = pic_alloc(e, &e->dpb[e->ndpb + 2 + i]); e->dpb_poc[e->ndpb + 2 + i] = -1000000; }
     }
     /* ring of pictures in flight: a key picture's slice takes one writer thread many picture periods, and output is in coding order - the ring must
      * hold everything that is coded meanwhile, or the GPU idles behind it.  About 6 GB of records (pinned compact block + expanded level planes + pinned input), at least 24 and at most MAX_JOBS pictures. */

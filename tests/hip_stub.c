@@ -272,14 +272,16 @@ static int fail_now(void)                                      /* KS265_STUB_FAI
 int ks265_encode_picture(ks265_frame *f, ks265_pic src, ks265_pic ref, int is_key, ks265_pic out)
 {
     if (fail_now()) return KS265_FAIL;
-    Op o = {OP_ENC, f, NULL, src, ref, ref, out, (is_key ? 0 : 1) | (ks265_frame_p_state(f) << 2), NULL};
+    Op o = {OP_ENC, f, NULL, src, ref, ref, out, (is_key ? 0 : 1) | (is_key && getenv("KS265_STUB_B_STATELESS") ? 0 : ks265_frame_p_state(f) << 2), NULL};   /* (a key picture on the main stream: see below) */
     const int r = issue(f->ctx, o);
     if (!is_key) { f->cur_pu ^= 1; f->have_prev = 1; } else f->have_prev = 0;
     return r;
 }
 int ks265_encode_picture_b(ks265_frame *f, ks265_pic src, ks265_pic r0, ks265_pic r1, ks265_pic out)
 {
-    Op o = {OP_ENC, f, NULL, src, r0, r1, out, 2 | (ks265_frame_p_state(f) << 2), NULL};
+    /* (the P chain's state goes into the record so that a replayed graph with the wrong state shows; KS265_STUB_B_STATELESS leaves it out - the real B pictures do not depend
+     * on it, and the host's anchor lane moves the P chain to another frame object) */
+    Op o = {OP_ENC, f, NULL, src, r0, r1, out, 2 | (getenv("KS265_STUB_B_STATELESS") ? 0 : ks265_frame_p_state(f) << 2), NULL};
     return issue(f->ctx, o);
 }
 int ks265_encode_picture_mref(ks265_frame *f, ks265_pic src, const ks265_pic *refs, int nref, ks265_pic out) { return ks265_encode_picture(f, src, refs[nref - 1], 0, out); }
