@@ -637,15 +637,20 @@ static int submit(Enc *e, Input *in, int kind, int poc, int qp, const int *l0, i
     /* with the lookahead the picture is on the device already, or on its way: uploaded into the slot's twin when it was handed in (round 4); else an H2D copy here, on this
      * stream, behind the waits above.  Graph replay needs fixed addresses: a device-to-device copy into the rotation buffer */
     const uint8_t *din = e->dev_in[k];
-    if (in->dev) {
+    /* an anchor on its lane whose picture is on the device already waits for the upload itself: a mark on the copy-in stream would sit behind that stream's work for the
+     * pictures in front of it - and, HIP streams sharing hardware queues (four by default), behind whatever else runs in that queue: measured, the anchor then starts when
+     * the last B picture of the mini-GOP before it has left the device */
+    const int direct = on_anc && in->dev && !e->use_graph;
+    if (direct) { if (!r) r = ks265_stream_wait_event(cx, in->ev_up); din = in->dev; }
+    else if (in->dev) {
         if (!r) r = ks265_stream_wait_event(e->ctx_in, in->ev_up);
         if (!r && e->use_graph) r = ks265_memcpy_d2d_async(e->ctx_in, e->dev_in[k], in->dev, fsz);
         else din = in->dev;
     } else if (!r) r = ks265_memcpy_h2d_async(e->ctx_in, e->dev_in[k], in->i420, fsz);
     if (!r && split) r = ks265_load_i420_on(e->ctx_in, fr, din, srcp);
-    if (!r) r = ks265_event_record(e->ctx_in, e->ev_h2d[k]);
+    if (!r && !direct) r = ks265_event_record(e->ctx_in, e->ev_h2d[k]);
     uint64_t *dsse = on_key ? e->dev_sse_key : on_anc ? e->dev_sse_anc : e->dev_sse;
-    if (!r) r = ks265_stream_wait_event(cx, e->ev_h2d[k]);
+    if (!r && !direct) r = ks265_stream_wait_event(cx, e->ev_h2d[k]);
     /* graph path: a P picture with one reference on the main stream, once the first pictures have made every lazy allocation */
     const int graphable = e->use_graph && ((kind == 'P' && nl0 == 1) || (kind == 'B' && nl0 == 1 && nl1 == 1)) && !on_key && !on_anc && !e->recon_on && e->seq >= 8;
     if (!graphable && !split) {
@@ -1265,9 +1270,12 @@ static Enc *lane_open(QY265EncConfig *cfg, int device, int multi, int *err)
         if (!r) r = ks265_event_create(e->ctx, &e->ev_key);
         for (int i = 0; i < 2 && !r; ++i) { r = pic_alloc(e, &e->dpb[e->ndpb + i]); e->dpb_poc[e->ndpb + i] = -1000000; if (!r) r = ks265_event_create(e->ctx, &e->ev_firstp[i]); }
     }
-    e->anc_on = e->hier && e->key_overlap && !e->aq_on && !e->use_graph && !getenv("KS265_NO_ANCHOR_LANE");
+    /* opt-in (KS265_ANCHOR_LANE=1): measured on the MI355X at 2160p, default GOP - 561 pictures/s without, 568 with the lane at normal stream priority, 440 at high priority
+     * (and 382 before the anchor waited for its upload directly); with 8 hardware queues (GPU_MAX_HW_QUEUES) 449 without and 515 with.  The kernels of a picture fill the
+     * device: an anchor running beside B pictures slows them by what it gains */
+    e->anc_on = e->hier && e->key_overlap && !e->aq_on && !e->use_graph && getenv("KS265_ANCHOR_LANE") && atoi(getenv("KS265_ANCHOR_LANE")) > 0;
     if (e->anc_on) {
-        if (!r) r = ks265_create_prio(&e->ctx_anc, dev_id, 1);
+        if (!r) r = ks265_create_prio(&e->ctx_anc, dev_id, getenv("KS265_ANC_PRIO") ? atoi(getenv("KS265_ANC_PRIO")) : 0);
         if (!r) r = ks265_frame_create(e->ctx_anc, &e->fcfg, &e->frame_anc);
         if (!r) r = pic_alloc(e, &e->src_anc);
         if (!r) r = ks265_dev_malloc(e->ctx, (void **)&e->dev_sse_anc, 64);

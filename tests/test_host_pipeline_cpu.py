@@ -65,7 +65,7 @@ def test_graph_replay_equals_launch_by_launch(stub_lib, bframes):
     """IPPP, hierarchical B (8) and P + 3 B: replay of captured pictures, plain launches, a runtime without capture and one whose instantiation fails all write the same
     stream (the last two fall back for good after the first attempt)"""
     iper = 64
-    a = run(stub_lib, 170, iper, bframes, KS265_NO_ANCHOR_LANE=1)           # (graphs are opt-in since round 4: KS265_GRAPH=1; they switch the anchor lane off)
+    a = run(stub_lib, 170, iper, bframes)                                   # (graphs are opt-in since round 4: KS265_GRAPH=1)
     assert a["vcl"] == 170 and sorted(a["pts"]) == list(range(170))
     for env in ({"KS265_GRAPH": 1}, {"KS265_GRAPH": 1, "KS265_STUB_NO_CAPTURE": 1}, {"KS265_GRAPH": 1, "KS265_STUB_NO_INSTANTIATE": 1}):   # the last: completion by a word in pinned memory
         b = run(stub_lib, 170, iper, bframes, **env)
@@ -79,8 +79,8 @@ def test_anchor_lane_writes_the_same_stream(stub_lib, bframes, iper, n):
     """pyramid GOPs: the anchors' P chain on a stream, frame object and DPB slots of its own (round 5) or on the main stream - the same stream, with long and short intra
     periods (key pictures on their own stream / on the main stream), mini-GOPs cut short in front of key pictures and at the flush, and key-picture requests in between"""
     for extra in ({}, {"KS_TEST_KEYREQ": 1}, {"KS265_GOP_LANES": 2}):
-        on = run(stub_lib, n, iper, bframes, KS265_STUB_B_STATELESS=1, **extra)
-        off = run(stub_lib, n, iper, bframes, KS265_STUB_B_STATELESS=1, KS265_NO_ANCHOR_LANE=1, **extra)
+        on = run(stub_lib, n, iper, bframes, KS265_STUB_B_STATELESS=1, KS265_ANCHOR_LANE=1, **extra)
+        off = run(stub_lib, n, iper, bframes, KS265_STUB_B_STATELESS=1, **extra)
         assert on["vcl"] == off["vcl"] == n and on["md5"] == off["md5"], (bframes, iper, extra)
         assert sorted(on["pts"]) == list(range(n))
 
@@ -93,8 +93,7 @@ def test_key_frame_requests(stub_lib):
         assert r["vcl"] == 100 and r["pts"] == list(range(100)) and r["idr"] == 5, (L, r["idr"])    # 0, the requested 18, 19, 41, and 73 = 41 + the period
     assert res[1]["md5"] == res[2]["md5"] == res[3]["md5"]                  # the request travels with the next picture: no dependence on the scheduler's lag
     for bframes in (-1, 3):                                                 # with B pictures the mini-GOP in front of the requested key picture is shortened
-        sl = {"KS265_STUB_B_STATELESS": 1}                                  # (graphs switch the anchor lane off: B and key pictures then meet another P-chain state in the stand-in)
-        a, b = run(stub_lib, 100, 32, bframes, KS_TEST_KEYREQ=1, **sl), run(stub_lib, 100, 32, bframes, KS_TEST_KEYREQ=1, KS265_GRAPH=1, **sl)
+        a, b = run(stub_lib, 100, 32, bframes, KS_TEST_KEYREQ=1), run(stub_lib, 100, 32, bframes, KS_TEST_KEYREQ=1, KS265_GRAPH=1)
         assert a["vcl"] == 100 and sorted(a["pts"]) == list(range(100)) and a["idr"] == 5 and a["md5"] == b["md5"], (bframes, a["idr"])
         c = run(stub_lib, 100, 32, bframes, KS_TEST_KEYREQ=1, KS265_GOP_LANES=2)     # lanes: the GOP that ends early is told so (its lane schedules what it has)
         assert c["md5"] == a["md5"]
@@ -212,10 +211,9 @@ def test_rate_control_does_not_depend_on_thread_timing(stub_lib, rc, bframes):
     """the frame-level controller (rc 1 / 2 / 4) decides the QP offset of a mini-GOP from exactly the pictures coded RC_LAG earlier in coding order (the
     scheduler waits for those), so two runs - one of them with a single writer thread's worth of jitter (KS265_GRAPH changes the enqueue timing) - write the same
     bytes; a budget far below / above what the records cost moves the QP (the stand-in's records depend on the QP)"""
-    sl = {"KS265_STUB_B_STATELESS": 1}                                      # (graphs switch the anchor lane off)
-    a = run(stub_lib, 150, 64, bframes, KS_TEST_RC=rc, KS_TEST_BR=40, **sl)
-    b = run(stub_lib, 150, 64, bframes, KS_TEST_RC=rc, KS_TEST_BR=40, KS265_GRAPH=1, **sl)
-    c = run(stub_lib, 150, 64, bframes, KS_TEST_RC=rc, KS_TEST_BR=40, **sl)
+    a = run(stub_lib, 150, 64, bframes, KS_TEST_RC=rc, KS_TEST_BR=40)
+    b = run(stub_lib, 150, 64, bframes, KS_TEST_RC=rc, KS_TEST_BR=40, KS265_GRAPH=1)
+    c = run(stub_lib, 150, 64, bframes, KS_TEST_RC=rc, KS_TEST_BR=40)
     assert a["vcl"] == 150 and a["md5"] == b["md5"] == c["md5"]
     hi = run(stub_lib, 150, 64, bframes, KS_TEST_RC=rc, KS_TEST_BR=400000)
     assert hi["md5"] != a["md5"]                                             # the controller acts: another budget, another stream
@@ -479,9 +477,7 @@ def test_slice_type_decision_codes_blocks_of_eight_as_four_plus_four(stub_lib, t
     assert la["pts"][:97] == expect_la, la["pts"][:80]
     assert sorted(la["pts"][97:]) == sorted(tail)
     assert la["md5"] != plain["md5"]
-    assert la["md5"] == run(stub_lib, 100, 128, -1, KS_TEST_LOOKAHEAD=8, **kw)["md5"]
-    sl = {"KS265_STUB_B_STATELESS": 1}                                   # (graphs switch the anchor lane off)
-    assert run(stub_lib, 100, 128, -1, KS_TEST_LOOKAHEAD=8, **sl, **kw)["md5"] == run(stub_lib, 100, 128, -1, KS_TEST_LOOKAHEAD=8, KS265_GRAPH=1, **sl, **kw)["md5"]
+    assert la["md5"] == run(stub_lib, 100, 128, -1, KS_TEST_LOOKAHEAD=8, **kw)["md5"] == run(stub_lib, 100, 128, -1, KS_TEST_LOOKAHEAD=8, KS265_GRAPH=1, **kw)["md5"]
     still = run(stub_lib, 100, 128, -1, KS_TEST_LOOKAHEAD=8, W=128, H=96, KS_TEST_RAMP="1000:1001:3")       # nothing moves: the analysis runs, every block stays 8
     assert still["pts"][:97] == expect_plain
     if os.path.exists(REF_DEC):
