@@ -269,7 +269,9 @@ typedef struct {
                                   (ks265_merge_pass; the reference's merge / skip decision: GetMergeCandsFor*, skipFastDecision) - single reference per list */
     int32_t bi_refine;         /* 1 = B pictures: joint refinement of the bi-predictive pair inside ks265_bi_decide (motionSearchBI enc@0x484910): the cheaper
                                   list stays, the other one is searched again against clip8(2 org - pred) (calcBiMeOrg enc@0x47b1a0) over the 8 x 8 integer
-                                  window of interMeBiFull enc@0x4896d0 / interMeBiFull_opt enc@0x4898e0, then over the sub-pel ring */
+                                  window of interMeBiFull enc@0x4896d0 / interMeBiFull_opt enc@0x4898e0, then over the sub-pel ring.
+                                  2 (round 5; what the encoder host runs) = the same refinement AFTER the CU decision, for the 2N x 2N inter CUs it chose
+                                  (ks265_bi_refine_chosen, in front of the merge pass): every picture area refined once instead of once per quadtree level */
     int32_t decimate;          /* K > 0: coefficient decimation at the postQuant seam of inter LUMA TUs - a block whose levels are all +-1 and at most 2K (8x8),
                                   3K (16x16), 4K (32x32) of them is dropped (prediction only, cbf 0); chroma is left alone; the encoder host uses 2.  Where the reference makes this kind of
                                   decision is inside its closed RD code (tuDecision enc@0x4825a0 lineage); measured effect: DESIGN.md 8 */
@@ -397,6 +399,10 @@ int ks265_reconstruct_b(ks265_frame *f, ks265_pic src, ks265_pic ref0, ks265_pic
  * their winners (SATD against the rounded average; interMeBi* enc@0x486c10.. lineage, no joint refinement yet) */
 int ks265_bi_decide(ks265_frame *f, ks265_pic src, ks265_pic ref0, ks265_pic ref1, const ks265_pu *dev_pu0,
                     const ks265_pu *dev_pu1, ks265_pu_b *dev_pub);
+/* cfg.bi_refine == 2: the joint refinement of motionSearchBI enc@0x484910 for the CUs the decision chose (dev_cu8 = what the CU decision wrote, in front of the merge
+ * pass): a 2N x 2N inter CU whose refined pair is cheaper takes it - into its PU record (cost, vectors, direction) and into its 8 x 8 blocks.  One wave per CTU. */
+int ks265_bi_refine_chosen(ks265_frame *f, ks265_pic src, ks265_pic ref0, ks265_pic ref1, const ks265_pu *dev_pu0, const ks265_pu *dev_pu1,
+                           ks265_pu_b *dev_pub, ks265_cu8 *dev_cu8);
 int ks265_cu_decide_b(ks265_frame *f, const ks265_pu_b *dev_pub, ks265_cu8 *dev_cu8);
 /* cfg.intra_inter - intra CUs in P / B pictures (EncIntraMD.cpp lineage: decideLumaMode enc@0x49acc0 is closed RD code).  ks265_intra_candidates: per 8x8 / 16x16 /
  * 32x32 block the pre-selection cost and best luma mode from source neighbours (the arithmetic of ks265_intra_decide, no CU tree), packed cost << 6 | mode in

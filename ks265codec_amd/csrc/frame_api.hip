@@ -310,6 +310,7 @@ static int encode_b_lists(ks265_frame *f, ks265_pic src, const ks265_pic *refs0,
     const bool part = f->cfg.part != 0;                        /* -part 1: the halves of every 64 / 32 / 16 CU priced with the motions of the CU and of its quarters (round 5: B pictures too) */
     ks265_cu8 *cud = f->cfg.merge ? f->cu8_tmp : f->cu8;
     if ((r = part ? ks265_cu_decide_part_b(f, src, ref0, ref1, pu0, f->pu1, f->pub, ii ? f->icost : nullptr, cud) : ks265_cu_decide_b_ii(f, f->pub, ii ? f->icost : nullptr, cud))) return r;
+    if (f->cfg.bi_refine == 2 && (r = ks265_bi_refine_chosen(f, src, ref0, ref1, pu0, f->pu1, f->pub, cud))) return r;   /* the joint refinement, for the CUs the decision chose (round 5) */
     if (f->cfg.merge && (r = ks265_merge_pass(f, src, ref0, ref1, nullptr, f->pub, f->cu8_tmp, f->cu8))) return r;
     ks265_pic deb = ks_deb_pic(f);
     if ((r = ks265_reconstruct_b(f, src, ref0, ref1, f->cu8, f->lvl[0], f->lvl[1], f->lvl[2], deb))) return r;

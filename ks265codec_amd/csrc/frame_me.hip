@@ -36,6 +36,22 @@ __device__ __forceinline__ unsigned pu_group_sum(unsigned v, int level)
     return v;
 }
 
+struct KsGroupUniform { int level; __device__ __forceinline__ unsigned operator()(unsigned v) const { return pu_group_sum(v, level); } };
+// the same with a level per lane (lanes of one PU agree): all three sums, each lane takes its own
+struct KsGroupPerLane {
+    int level;
+    __device__ __forceinline__ unsigned operator()(unsigned v) const
+    {
+        unsigned s2 = v + (unsigned)dpp_mov<KS265_DPP_QUAD_XOR1>((int)v);
+        s2 += (unsigned)dpp_mov<KS265_DPP_QUAD_XOR2>((int)s2);
+        unsigned s1 = s2 + (unsigned)dpp_mov<KS265_DPP_ROW_HALF_MIRROR>((int)s2);
+        s1 += (unsigned)dpp_mov<KS265_DPP_ROW_MIRROR>((int)s1);
+        unsigned s0 = s1 + (unsigned)__builtin_amdgcn_ds_swizzle((int)s1, 0x1F | (16 << 10));
+        s0 += (unsigned)__shfl_xor((int)s0, 32, 64);
+        return level == 3 ? v : level == 2 ? s2 : level == 1 ? s1 : s0;
+    }
+};
+
 // Stage B: sub-pel refinement of all 85 PUs of a CTU = the reference's, per PU (round 4; restated in oracle/ks265_subme_ref.c and pinned on recorded calls of the reference, tests/test_subme.py):
 //   phase R  getMvResolution enc@0x483ca0: the four integer neighbours' SADs of the integer winner decide whether the PU is refined at all (cfg.sub_thr / sub_cap);
 //   phase H  subMeHpel_RealInterp enc@0x4b4e90: eight half-sample candidates, evaluation order 3 4 1 6 0 2 5 7 (raster indices), cost = SAD (or Hadamard, cfg.sub_satd)
@@ -616,6 +632,158 @@ __device__ __forceinline__ unsigned satd8x8_avg(const unsigned (&f)[16], const u
 // register rows (v_sad_u8, static v_alignbyte per column), summed over the PU's lanes by DPP, + vector rate, first minimum in row-major order
 // (key = cost << 6 | position).  Sub-pel step: the two rings of stage B on T, SAD + rate like the integer step.  The refined pair replaces the decision when
 // its SATD against the rounded average + both vector rates is lower.
+// The joint refinement of a bi-predictive pair for the lane's 8 x 8 tile of its PU: a / b = the lists' records, PA / PB their prediction tiles, f the source
+// tile, gs = the sum over the PU's lanes, o = the decision so far (takes the refined pair if it is cheaper).  Called by every lane of the wave.
+template <class GS>
+__device__ __forceinline__ void bi_refine_lane(const KsGeom &g, int lam, int cx, int cy, long base, bool valid, const GS &gs, const ks265_pu &a, const ks265_pu &b,
+                                               const uint8_t *ref0, const uint8_t *ref1, const unsigned (&f)[16], const unsigned (&PA)[16], const unsigned (&PB)[16],
+                                               unsigned rbits, unsigned dir3, ks265_pu_b &o)
+{
+    const int ax = valid ? a.mvx : 0, ay = valid ? a.mvy : 0, bx = valid ? b.mvx : 0, by = valid ? b.mvy : 0;
+    const bool keep1 = valid && b.cost < a.cost;                 // list whose vector stays (uniform over the PU's lanes)
+    const uint8_t *refO = keep1 ? ref0 : ref1;
+    const int omx = keep1 ? ax : bx, omy = keep1 ? ay : by;
+    const int opx = valid ? (keep1 ? a.mvpx : b.mvpx) : 0, opy = valid ? (keep1 ? a.mvpy : b.mvpy) : 0;
+    unsigned T[16];
+    {
+        unsigned k[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) k[i] = keep1 ? PB[i] : PA[i];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            unsigned w = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int v = 2 * (int)((f[i] >> (8 * q)) & 255) - (int)((k[i] >> (8 * q)) & 255);
+                w |= (unsigned)clip3(0, 255, v) << (8 * q);
+            }
+            T[i] = w;
+        }
+    }
+    const int xe = min(cx * 64 + 64, g.W), ye = min(cy * 64 + 64, g.H);
+    const int lox = -64 - cx * 64, hix = g.W + 64 - xe, loy = -64 - cy * 64, hiy = g.H + 64 - ye;
+    int imx = clip3(4 * lox, 4 * hix, omx) >> 2, imy = clip3(4 * loy, 4 * hiy, omy) >> 2;
+    imx = imx <= lox + 3 ? lox + 4 : (imx >= hix - 3 ? hix - 4 : imx);
+    imy = imy <= loy + 3 ? loy + 4 : (imy >= hiy - 3 ? hiy - 4 : imy);
+    const int sx = valid ? imx - 3 - (opx < 0) : 0, sy = valid ? imy - 3 - (opy < 0) : 0;   // idle lanes read around the picture origin
+    unsigned long long bitx = 0;                                   // eight column bit counts (< 64 each), one byte apiece: indexed by the runtime column
+    int bity[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { bitx |= (unsigned long long)se_bits(4 * (sx + i) - opx) << (8 * i); bity[i] = se_bits(4 * (sy + i) - opy); }
+    unsigned bkey = 0xFFFFFFFFu;
+    {
+        unsigned w[15][4];
+        const uint8_t *r0 = refO + base + (long)sy * g.sy + sx;
+        const unsigned sh = (unsigned)((uintptr_t)r0 & 3);
+        const uint8_t *q0 = r0 - sh;
+#pragma unroll
+        for (int r = 0; r < 15; ++r) {
+            const unsigned *rw = (const unsigned *)(q0 + (long)r * g.sy);
+            const unsigned a0 = rw[0], a1 = rw[1], a2 = rw[2], a3 = rw[3], a4 = rw[4];
+            w[r][0] = align_bytes(a1, a0, sh); w[r][1] = align_bytes(a2, a1, sh); w[r][2] = align_bytes(a3, a2, sh); w[r][3] = align_bytes(a4, a3, sh);
+        }
+#pragma unroll 1
+        for (int dx = 0; dx < 8; ++dx) {                          // columns one after the other: the window rows move one byte per step
+#pragma unroll
+            for (int dy = 0; dy < 8; ++dy) {
+                unsigned sd2 = 0;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) { sd2 = sad_u8x4(T[2 * r], w[dy + r][0], sd2); sd2 = sad_u8x4(T[2 * r + 1], w[dy + r][1], sd2); }
+                const unsigned tot = gs(valid ? sd2 : 0) + (unsigned)((lam * (bitx_of(bitx, dx) + bity[dy])) >> 4);
+                bkey = min(bkey, (tot << 6) | (unsigned)(dy * 8 + dx));
+            }
+#pragma unroll
+            for (int r = 0; r < 15; ++r) {
+                w[r][0] = align_bytes(w[r][1], w[r][0], 1); w[r][1] = align_bytes(w[r][2], w[r][1], 1);
+                w[r][2] = align_bytes(w[r][3], w[r][2], 1); w[r][3] >>= 8;
+            }
+        }
+    }
+    int rbx = 4 * (sx + (int)(bkey & 7)), rby = 4 * (sy + (int)((bkey >> 3) & 7));
+    unsigned bc = bkey >> 6;                                                   // SAD + rate of the integer winner
+    // The two sub-pel rings (half, then quarter steps around the running best).  Round 4: the eight candidates of a ring share their horizontal filtering - the three x
+    // positions are filtered once each over the 16 input rows the three y positions tap (raw 16-bit tap sums, row pairs packed for v_dot2_i32_i16), the vertical taps
+    // of each y position run on those; ONE instruction stream for every fraction (the integer position is the tap set {0 0 0 64 0 0 0 0}; (sum + 2048) >> 12 equals the
+    // one-dimensional filters' (sum + 32) >> 6 and the plain sample exactly), so lanes with different fractions do not diverge.  Before: a full separable
+    // interpolation per candidate and lane, its three fraction cases executed under divergence (750 us per 2160p B picture).
+#pragma unroll 1
+    for (int step = 2; step >= 1; --step) {
+        const int c0x = rbx, c0y = rby;
+        const int ybase = (c0y - step) >> 2;                                   // integer row of output row 0 at the ring's top y position
+        unsigned cc[9];
+#pragma unroll 1
+        for (int gx = 0; gx < 3; ++gx) {
+            const int axq = c0x + (gx - 1) * step;
+            int tl, th;
+            luma_taps_packed(axq & 3, tl, th);
+            const uint8_t *hp = refO + base + (long)(ybase - 3) * g.sy + (axq >> 2);
+            unsigned HP[8][8];                                                  // [pixel][row pair]: rows 2 j, 2 j + 1 of the 16 filtered rows ybase - 3 .. ybase + 12
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                int h0[8], h1[8];
+                luma_hrow8(hp + (long)(2 * j) * g.sy, tl, th, h0);
+                luma_hrow8(hp + (long)(2 * j + 1) * g.sy, tl, th, h1);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) HP[i][j] = ((unsigned)h0[i] & 0xFFFFu) | ((unsigned)h1[i] << 16);
+            }
+#pragma unroll 1
+            for (int gy = 0; gy < 3; ++gy) {
+                if (gx == 1 && gy == 1) continue;
+                const int ayq = c0y + (gy - 1) * step, roff = (ayq >> 2) - ybase;     // 0 or 1
+                int c[8];
+                luma_taps(ayq & 3, c);
+                // output row r reads input rows r + roff .. r + roff + 7; in pairs: an even start takes (c0 c1)(c2 c3)(c4 c5)(c6 c7), an odd one (0 c0)(c1 c2)(c3 c4)(c5 c6)(c7 0)
+                unsigned E0[5], E1[5];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) E0[k] = ((unsigned)c[2 * k] & 0xFFFFu) | ((unsigned)c[2 * k + 1] << 16);
+                E0[4] = 0;
+                E1[0] = (unsigned)c[0] << 16;
+#pragma unroll
+                for (int k = 1; k < 4; ++k) E1[k] = ((unsigned)c[2 * k - 1] & 0xFFFFu) | ((unsigned)c[2 * k] << 16);
+                E1[4] = (unsigned)c[7] & 0xFFFFu;
+                unsigned We[5], Wo[5];                                            // even r: window of pairs r / 2 ..; odd r: (r - 1) / 2 ..
+#pragma unroll
+                for (int k = 0; k < 5; ++k) { We[k] = roff ? E1[k] : E0[k]; Wo[k] = roff ? (k ? E0[k - 1] : 0u) : E1[k]; }
+                unsigned sd3 = 0;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    int px[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        int v = 2048;
+#pragma unroll
+                        for (int k = 0; k < 5; ++k)
+                            v = __builtin_amdgcn_sdot2(__builtin_bit_cast(ks_s16x2, (r & 1) ? Wo[k] : We[k]), __builtin_bit_cast(ks_s16x2, HP[i][(r >> 1) + k < 8 ? (r >> 1) + k : 7]), v, false);
+                        px[i] = clip8(ks_no_pk(v >> 12));
+                    }
+                    const uint2 pr = ks_pack_row8(px);
+                    sd3 = sad_u8x4(T[2 * r], pr.x, sd3); sd3 = sad_u8x4(T[2 * r + 1], pr.y, sd3);
+                }
+                cc[gy * 3 + gx] = gs(valid ? sd3 : 0) + (unsigned)mv_cost(axq, ayq, opx, opy, lam);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int kk = k < 4 ? k : k + 1;                                  // ring order of stage B: (-1,-1) (0,-1) (1,-1) (-1,0) (1,0) (-1,1) (0,1) (1,1), first strict minimum
+            if (cc[kk] < bc) { bc = cc[kk]; rbx = c0x + (kk % 3 - 1) * step; rby = c0y + (kk / 3 - 1) * step; }
+        }
+    }
+    unsigned PO[16], PK[16];
+    luma_pred_tile8(refO + base, g.sy, rbx, rby, PO);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) PK[i] = keep1 ? PB[i] : PA[i];
+    const unsigned d2 = gs(valid ? satd8x8_avg(f, PK, PO) : 0);
+    if (valid) {
+        unsigned c2 = d2 + (unsigned)(keep1 ? mv_cost(b.mvx, b.mvy, b.mvpx, b.mvpy, lam) : mv_cost(a.mvx, a.mvy, a.mvpx, a.mvpy, lam))
+                      + (unsigned)mv_cost(rbx, rby, opx, opy, lam) + rbits;
+        c2 -= c2 >> KS_BI_BIAS_SHIFT;
+        if (c2 < o.cost) {
+            o.cost = c2; o.inter_dir = dir3;
+            if (keep1) { o.mvx = (int16_t)rbx; o.mvy = (int16_t)rby; } else { o.mv1x = (int16_t)rbx; o.mv1y = (int16_t)rby; }
+        }
+    }
+}
+
 template <bool REFINE, bool MR>
 __global__ __launch_bounds__(256, REFINE ? 2 : 1) void bi_decide_kernel(KsGeom g, int lam, const uint8_t *src, const uint8_t *ref0_, const uint8_t *ref1_,
                                                         const ks265_pu *pu0, const ks265_pu *pu1, ks265_pu_b *pub, const KsMrefB mr)
@@ -654,152 +822,51 @@ __global__ __launch_bounds__(256, REFINE ? 2 : 1) void bi_decide_kernel(KsGeom g
             c -= c >> KS_BI_BIAS_SHIFT;                            // a bi-predictive pair counts 31 / 32 of its cost (the oracle's BI_BIAS_SHIFT: - 3.3 % bytes on hierarchical B)
             if (c < o.cost) { o.cost = c; o.inter_dir = bidir(3); }
         }
-        if (REFINE) {
-            const bool keep1 = valid && b.cost < a.cost;                 // list whose vector stays (uniform over the PU's lanes)
-            const uint8_t *refO = keep1 ? ref0 : ref1;
-            const int omx = keep1 ? ax : bx, omy = keep1 ? ay : by;
-            const int opx = valid ? (keep1 ? a.mvpx : b.mvpx) : 0, opy = valid ? (keep1 ? a.mvpy : b.mvpy) : 0;
-            unsigned T[16];
-            {
-                unsigned k[16];
-#pragma unroll
-                for (int i = 0; i < 16; ++i) k[i] = keep1 ? PB[i] : PA[i];
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    unsigned w = 0;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int v = 2 * (int)((f[i] >> (8 * q)) & 255) - (int)((k[i] >> (8 * q)) & 255);
-                        w |= (unsigned)clip3(0, 255, v) << (8 * q);
-                    }
-                    T[i] = w;
-                }
-            }
-            const int xe = min(cx * 64 + 64, g.W), ye = min(cy * 64 + 64, g.H);
-            const int lox = -64 - cx * 64, hix = g.W + 64 - xe, loy = -64 - cy * 64, hiy = g.H + 64 - ye;
-            int imx = clip3(4 * lox, 4 * hix, omx) >> 2, imy = clip3(4 * loy, 4 * hiy, omy) >> 2;
-            imx = imx <= lox + 3 ? lox + 4 : (imx >= hix - 3 ? hix - 4 : imx);
-            imy = imy <= loy + 3 ? loy + 4 : (imy >= hiy - 3 ? hiy - 4 : imy);
-            const int sx = valid ? imx - 3 - (opx < 0) : 0, sy = valid ? imy - 3 - (opy < 0) : 0;   // idle lanes read around the picture origin
-            unsigned long long bitx = 0;                                   // eight column bit counts (< 64 each), one byte apiece: indexed by the runtime column
-            int bity[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) { bitx |= (unsigned long long)se_bits(4 * (sx + i) - opx) << (8 * i); bity[i] = se_bits(4 * (sy + i) - opy); }
-            unsigned bkey = 0xFFFFFFFFu;
-            {
-                unsigned w[15][4];
-                const uint8_t *r0 = refO + base + (long)sy * g.sy + sx;
-                const unsigned sh = (unsigned)((uintptr_t)r0 & 3);
-                const uint8_t *q0 = r0 - sh;
-#pragma unroll
-                for (int r = 0; r < 15; ++r) {
-                    const unsigned *rw = (const unsigned *)(q0 + (long)r * g.sy);
-                    const unsigned a0 = rw[0], a1 = rw[1], a2 = rw[2], a3 = rw[3], a4 = rw[4];
-                    w[r][0] = align_bytes(a1, a0, sh); w[r][1] = align_bytes(a2, a1, sh); w[r][2] = align_bytes(a3, a2, sh); w[r][3] = align_bytes(a4, a3, sh);
-                }
-#pragma unroll 1
-                for (int dx = 0; dx < 8; ++dx) {                          // columns one after the other: the window rows move one byte per step
-#pragma unroll
-                    for (int dy = 0; dy < 8; ++dy) {
-                        unsigned sd2 = 0;
-#pragma unroll
-                        for (int r = 0; r < 8; ++r) { sd2 = sad_u8x4(T[2 * r], w[dy + r][0], sd2); sd2 = sad_u8x4(T[2 * r + 1], w[dy + r][1], sd2); }
-                        const unsigned tot = pu_group_sum(valid ? sd2 : 0, level) + (unsigned)((lam * (bitx_of(bitx, dx) + bity[dy])) >> 4);
-                        bkey = min(bkey, (tot << 6) | (unsigned)(dy * 8 + dx));
-                    }
-#pragma unroll
-                    for (int r = 0; r < 15; ++r) {
-                        w[r][0] = align_bytes(w[r][1], w[r][0], 1); w[r][1] = align_bytes(w[r][2], w[r][1], 1);
-                        w[r][2] = align_bytes(w[r][3], w[r][2], 1); w[r][3] >>= 8;
-                    }
-                }
-            }
-            int rbx = 4 * (sx + (int)(bkey & 7)), rby = 4 * (sy + (int)((bkey >> 3) & 7));
-            unsigned bc = bkey >> 6;                                                   // SAD + rate of the integer winner
-            // The two sub-pel rings (half, then quarter steps around the running best).  Round 4: the eight candidates of a ring share their horizontal filtering - the three x
-            // positions are filtered once each over the 16 input rows the three y positions tap (raw 16-bit tap sums, row pairs packed for v_dot2_i32_i16), the vertical taps
-            // of each y position run on those; ONE instruction stream for every fraction (the integer position is the tap set {0 0 0 64 0 0 0 0}; (sum + 2048) >> 12 equals the
-            // one-dimensional filters' (sum + 32) >> 6 and the plain sample exactly), so lanes with different fractions do not diverge.  Before: a full separable
-            // interpolation per candidate and lane, its three fraction cases executed under divergence (750 us per 2160p B picture).
-#pragma unroll 1
-            for (int step = 2; step >= 1; --step) {
-                const int c0x = rbx, c0y = rby;
-                const int ybase = (c0y - step) >> 2;                                   // integer row of output row 0 at the ring's top y position
-                unsigned cc[9];
-#pragma unroll 1
-                for (int gx = 0; gx < 3; ++gx) {
-                    const int axq = c0x + (gx - 1) * step;
-                    int tl, th;
-                    luma_taps_packed(axq & 3, tl, th);
-                    const uint8_t *hp = refO + base + (long)(ybase - 3) * g.sy + (axq >> 2);
-                    unsigned HP[8][8];                                                  // [pixel][row pair]: rows 2 j, 2 j + 1 of the 16 filtered rows ybase - 3 .. ybase + 12
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        int h0[8], h1[8];
-                        luma_hrow8(hp + (long)(2 * j) * g.sy, tl, th, h0);
-                        luma_hrow8(hp + (long)(2 * j + 1) * g.sy, tl, th, h1);
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) HP[i][j] = ((unsigned)h0[i] & 0xFFFFu) | ((unsigned)h1[i] << 16);
-                    }
-#pragma unroll 1
-                    for (int gy = 0; gy < 3; ++gy) {
-                        if (gx == 1 && gy == 1) continue;
-                        const int ayq = c0y + (gy - 1) * step, roff = (ayq >> 2) - ybase;     // 0 or 1
-                        int c[8];
-                        luma_taps(ayq & 3, c);
-                        // output row r reads input rows r + roff .. r + roff + 7; in pairs: an even start takes (c0 c1)(c2 c3)(c4 c5)(c6 c7), an odd one (0 c0)(c1 c2)(c3 c4)(c5 c6)(c7 0)
-                        unsigned E0[5], E1[5];
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) E0[k] = ((unsigned)c[2 * k] & 0xFFFFu) | ((unsigned)c[2 * k + 1] << 16);
-                        E0[4] = 0;
-                        E1[0] = (unsigned)c[0] << 16;
-#pragma unroll
-                        for (int k = 1; k < 4; ++k) E1[k] = ((unsigned)c[2 * k - 1] & 0xFFFFu) | ((unsigned)c[2 * k] << 16);
-                        E1[4] = (unsigned)c[7] & 0xFFFFu;
-                        unsigned We[5], Wo[5];                                            // even r: window of pairs r / 2 ..; odd r: (r - 1) / 2 ..
-#pragma unroll
-                        for (int k = 0; k < 5; ++k) { We[k] = roff ? E1[k] : E0[k]; Wo[k] = roff ? (k ? E0[k - 1] : 0u) : E1[k]; }
-                        unsigned sd3 = 0;
-#pragma unroll
-                        for (int r = 0; r < 8; ++r) {
-                            int px[8];
-#pragma unroll
-                            for (int i = 0; i < 8; ++i) {
-                                int v = 2048;
-#pragma unroll
-                                for (int k = 0; k < 5; ++k)
-                                    v = __builtin_amdgcn_sdot2(__builtin_bit_cast(ks_s16x2, (r & 1) ? Wo[k] : We[k]), __builtin_bit_cast(ks_s16x2, HP[i][(r >> 1) + k < 8 ? (r >> 1) + k : 7]), v, false);
-                                px[i] = clip8(ks_no_pk(v >> 12));
-                            }
-                            const uint2 pr = ks_pack_row8(px);
-                            sd3 = sad_u8x4(T[2 * r], pr.x, sd3); sd3 = sad_u8x4(T[2 * r + 1], pr.y, sd3);
-                        }
-                        cc[gy * 3 + gx] = pu_group_sum(valid ? sd3 : 0, level) + (unsigned)mv_cost(axq, ayq, opx, opy, lam);
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const int kk = k < 4 ? k : k + 1;                                  // ring order of stage B: (-1,-1) (0,-1) (1,-1) (-1,0) (1,0) (-1,1) (0,1) (1,1), first strict minimum
-                    if (cc[kk] < bc) { bc = cc[kk]; rbx = c0x + (kk % 3 - 1) * step; rby = c0y + (kk / 3 - 1) * step; }
-                }
-            }
-            unsigned PO[16], PK[16];
-            luma_pred_tile8(refO + base, g.sy, rbx, rby, PO);
-#pragma unroll
-            for (int i = 0; i < 16; ++i) PK[i] = keep1 ? PB[i] : PA[i];
-            const unsigned d2 = pu_group_sum(valid ? satd8x8_avg(f, PK, PO) : 0, level);
-            if (valid) {
-                unsigned c2 = d2 + (unsigned)(keep1 ? mv_cost(b.mvx, b.mvy, b.mvpx, b.mvpy, lam) : mv_cost(a.mvx, a.mvy, a.mvpx, a.mvpy, lam))
-                              + (unsigned)mv_cost(rbx, rby, opx, opy, lam) + rbits;
-                c2 -= c2 >> KS_BI_BIAS_SHIFT;
-                if (c2 < o.cost) {
-                    o.cost = c2; o.inter_dir = bidir(3);
-                    if (keep1) { o.mvx = (int16_t)rbx; o.mvy = (int16_t)rby; } else { o.mv1x = (int16_t)rbx; o.mv1y = (int16_t)rby; }
-                }
-            }
-        }
+        if (REFINE) bi_refine_lane(g, lam, cx, cy, base, valid, KsGroupUniform{level}, a, b, ref0, ref1, f, PA, PB, rbits, bidir(3), o);
     }
     if ((lane & (G - 1)) == 0) pub[(long)ctu * 85 + pidx] = o;
+}
+
+// cfg.bi_refine == 2 (round 5): the joint refinement AFTER the CU decision, for the CUs it chose - every picture area refined once, not once per quadtree level
+// (bi_decide_kernel<false> has paired the lists' winners).  One wave per CTU, lane = 8 x 8 tile = one ks265_cu8 record; the lane's PU is the
+// 2N x 2N inter CU its block belongs to (lanes of intra CUs, of CUs in halves and outside the picture idle), the level differs from lane to lane (KsGroupPerLane).
+// A refined pair that is cheaper goes into the PU's record (the merge pass compares against its cost) and into the CU's blocks.
+template <bool MR>
+__global__ __launch_bounds__(64, 2) void bi_refine_chosen_kernel(KsGeom g, int lam, const uint8_t *src, const uint8_t *ref0_, const uint8_t *ref1_,
+                                                                 const ks265_pu *pu0, const ks265_pu *pu1, ks265_pu_b *pub, ks265_cu8 *cu8, const KsMrefB mr)
+{
+    const int lane = threadIdx.x;
+    const int ctu = ks_xcd_swizzle(blockIdx.x, g.ctu_cols * g.ctu_rows), cx = ctu % g.ctu_cols, cy = ctu / g.ctu_cols;
+    const int tx = (lane & 1) | ((lane >> 1) & 2) | ((lane >> 2) & 4), ty = ((lane >> 1) & 1) | ((lane >> 2) & 2) | ((lane >> 3) & 4);
+    const int x0 = cx * 64 + tx * 8, y0 = cy * 64 + ty * 8, w8 = g.W >> 3;
+    const bool inside = x0 < g.W && y0 < g.H;
+    ks265_cu8 *const blk = cu8 + (long)(inside ? y0 >> 3 : 0) * w8 + (inside ? x0 >> 3 : 0);
+    const ks265_cu8 c = *blk;
+    const bool chosen = inside && c.pred_mode == 0 && c.log2_cu >= 3 && c.log2_cu <= 6;      // (bits 4..5 set: a CU in halves)
+    const int level = chosen ? 6 - c.log2_cu : 3;
+    const int px = tx >> (3 - level), py = ty >> (3 - level), pidx = ks_level_base(level) + py * (1 << level) + px;
+    const ks265_pu a = pu0[(long)ctu * 85 + pidx], b = pu1[(long)ctu * 85 + pidx];
+    const bool valid = chosen && a.cost != KS_COST_INVALID;
+    if (!__any(valid)) return;
+    const int i0 = MR ? mr.idx0[(long)ctu * 85 + pidx] : 0, i1 = MR ? mr.idx1[(long)ctu * 85 + pidx] : 0;
+    const uint8_t *const ref0 = MR ? ks_pick(mr.y0, i0) : ref0_, *const ref1 = MR ? ks_pick(mr.y1, i1) : ref1_;
+    const unsigned rbits = MR ? (unsigned)((i0 == 0 ? mr.bits0[0] : i0 == 1 ? mr.bits0[1] : i0 == 2 ? mr.bits0[2] : mr.bits0[3]) + (i1 == 0 ? mr.bits1[0] : i1 == 1 ? mr.bits1[1] : i1 == 2 ? mr.bits1[2] : mr.bits1[3])) : 0u;
+    ks265_pu_b o = pub[(long)ctu * 85 + pidx];
+    const unsigned before = o.cost;
+    const uint8_t *Sp = ks_org_y(g, src);
+    unsigned f[16];
+    const uint8_t *frow = Sp + (long)(valid ? y0 : cy * 64) * g.sy + (valid ? x0 : cx * 64);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { const uint2 v = *(const uint2 *)(frow + (long)r * g.sy); f[2 * r] = v.x; f[2 * r + 1] = v.y; }
+    const long base = (long)(valid ? y0 : 0) * g.sy + (valid ? x0 : 0) + g.org_y;
+    unsigned PA[16], PB[16];
+    luma_pred_tile8(ref0 + base, g.sy, valid ? a.mvx : 0, valid ? a.mvy : 0, PA);
+    luma_pred_tile8(ref1 + base, g.sy, valid ? b.mvx : 0, valid ? b.mvy : 0, PB);
+    bi_refine_lane(g, lam, cx, cy, base, valid, KsGroupPerLane{level}, a, b, ref0, ref1, f, PA, PB, rbits, 3u | (unsigned)i0 << 4 | (unsigned)i1 << 6, o);
+    if (valid && o.cost != before) {
+        if ((lane & ((1 << (2 * (3 - level))) - 1)) == 0) pub[(long)ctu * 85 + pidx] = o;
+        blk->mvx = o.mvx; blk->mvy = o.mvy; blk->mv1x = o.mv1x; blk->mv1y = o.mv1y; blk->inter_dir = (uint8_t)o.inter_dir;
+    }
 }
 
 // the lists of the multi-reference B picture being coded as kernel arguments (entries past a list's size repeat its last picture); all zero when none is
@@ -824,12 +891,24 @@ extern "C" int ks265_bi_decide(ks265_frame *f, ks265_pic src, ks265_pic ref0, ks
     const dim3 grid(f->g.ctu_cols * f->g.ctu_rows), block(256);
     const KsMrefB mr = ks_mrefb(f);
     if (f->mrefb) {
-        if (f->cfg.bi_refine) hipLaunchKernelGGL((bi_decide_kernel<true, true>), grid, block, 0, f->ctx->stream, f->g, f->cfg.lambda_q4, src.y, ref0.y, ref1.y, pu0, pu1, pub, mr);
+        if (f->cfg.bi_refine == 1) hipLaunchKernelGGL((bi_decide_kernel<true, true>), grid, block, 0, f->ctx->stream, f->g, f->cfg.lambda_q4, src.y, ref0.y, ref1.y, pu0, pu1, pub, mr);
         else hipLaunchKernelGGL((bi_decide_kernel<false, true>), grid, block, 0, f->ctx->stream, f->g, f->cfg.lambda_q4, src.y, ref0.y, ref1.y, pu0, pu1, pub, mr);
     } else {
-        if (f->cfg.bi_refine) hipLaunchKernelGGL((bi_decide_kernel<true, false>), grid, block, 0, f->ctx->stream, f->g, f->cfg.lambda_q4, src.y, ref0.y, ref1.y, pu0, pu1, pub, mr);
+        if (f->cfg.bi_refine == 1) hipLaunchKernelGGL((bi_decide_kernel<true, false>), grid, block, 0, f->ctx->stream, f->g, f->cfg.lambda_q4, src.y, ref0.y, ref1.y, pu0, pu1, pub, mr);
         else hipLaunchKernelGGL((bi_decide_kernel<false, false>), grid, block, 0, f->ctx->stream, f->g, f->cfg.lambda_q4, src.y, ref0.y, ref1.y, pu0, pu1, pub, mr);
     }
+    return ks265_check_launch(f->ctx);
+}
+
+extern "C" int ks265_bi_refine_chosen(ks265_frame *f, ks265_pic src, ks265_pic ref0, ks265_pic ref1, const ks265_pu *pu0, const ks265_pu *pu1,
+                                      ks265_pu_b *pub, ks265_cu8 *cu8)
+{
+    KS_FRAME_CHECK(f);
+    if (!src.y || !ref0.y || !ref1.y || !pu0 || !pu1 || !pub || !cu8) return KS265_POINTER;
+    const dim3 grid(f->g.ctu_cols * f->g.ctu_rows), block(64);
+    const KsMrefB mr = ks_mrefb(f);
+    if (f->mrefb) hipLaunchKernelGGL((bi_refine_chosen_kernel<true>), grid, block, 0, f->ctx->stream, f->g, f->cfg.lambda_q4, src.y, ref0.y, ref1.y, pu0, pu1, pub, cu8, mr);
+    else hipLaunchKernelGGL((bi_refine_chosen_kernel<false>), grid, block, 0, f->ctx->stream, f->g, f->cfg.lambda_q4, src.y, ref0.y, ref1.y, pu0, pu1, pub, cu8, mr);
     return ks265_check_launch(f->ctx);
 }
 

@@ -1218,7 +1218,7 @@ static Enc *lane_open(QY265EncConfig *cfg, int device, int multi, int *err)
     e->fcfg.rdo = 4;                                                    /* coefficient-group pruning at lambda x 1 (ks265_frame_cfg.rdo): supersedes the coefficient decimation of round 2 */
     e->fcfg.tu_inter = cfg->tuInter > 0 ? 1 : 0;                        /* -intertu N (tuInter; veryslow 1, placebo 2): the residual quadtree of inter CUs ONE level deep (ks265_frame_cfg.tu_inter); deeper values run as 1 */
     e->fcfg.part = cfg->part ? 1 : 0;                                   /* -part 1 (slower, veryslow, placebo): 2NxN / Nx2N prediction units in P and B pictures (ks265_frame_cfg.part) */
-    e->fcfg.bi_refine = 1;                                              /* B pictures: joint refinement of the bi-predictive pair (motionSearchBI enc@0x484910) */
+    e->fcfg.bi_refine = getenv("KS265_BI_REFINE") ? atoi(getenv("KS265_BI_REFINE")) : 2;   /* (2, round 5: after the CU decision, for the CUs it chose - the same bytes within 0.04 %, a third of the time; 1 = for every PU of the quadtree) */                                              /* B pictures: joint refinement of the bi-predictive pair (motionSearchBI enc@0x484910) */
     r = ks265_frame_geometry(&e->fcfg, &e->geom);
     if (!r) r = ks265_frame_create(e->ctx, &e->fcfg, &e->frame);
     const size_t fsz = (size_t)e->W * e->H * 3 / 2, npx = (size_t)e->W * e->H;

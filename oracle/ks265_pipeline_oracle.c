@@ -751,6 +751,60 @@ void kso_merge_pass(const kso_frame_cfg *cfg, kso_pic src, const uint8_t *planes
  * errors cancel, in chroma too, and the smaller residual costs fewer bits than its SATD says).  Measured with tools/rd_eval.py (832x480, hierarchical B, 33 pictures):
  * - 3.3 % bytes at the same PSNR-Y, chroma + 0.6 dB; the top-layer B pictures - 17 %; a bias of 1 / 16 and more loses again. */
 #define BI_BIAS_SHIFT 5
+#define BI_DIR_OF(d, i0, i1) ((uint32_t)(d) | (((d) & 1) ? (uint32_t)(i0) << 4 : 0u) | (((d) & 2) ? (uint32_t)(i1) << 6 : 0u))
+/* the joint refinement of one PU's pair (see kso_bi_decide): a / b = the lists' records, o = the decision so far (updated if the refined pair is cheaper) */
+static void bi_refine_pu(const kso_frame_cfg *cfg, const kso_frame_geom *gp, const uint8_t *S, const uint8_t *planes0, const uint8_t *planes1, uint32_t rbits,
+                         int i0, int i1, int cx, int cy, int l, int px, int py, const kso_pu *a, const kso_pu *b, kso_pu_b *o)
+{
+    const kso_frame_geom g = *gp;
+    const long st = g.stride_y;
+    const int lam = cfg->lambda_q4;
+    const int s = 64 >> l, x0 = cx * 64 + px * s, y0 = cy * 64 + py * s;
+    const uint8_t *p0 = org_y(&g, (uint8_t *)planes0 + (long)((a->mvy & 3) * 4 + (a->mvx & 3)) * g.bytes_y) + (long)(y0 + (a->mvy >> 2)) * st + x0 + (a->mvx >> 2);
+    const uint8_t *p1 = org_y(&g, (uint8_t *)planes1 + (long)((b->mvy & 3) * 4 + (b->mvx & 3)) * g.bytes_y) + (long)(y0 + (b->mvy >> 2)) * st + x0 + (b->mvx >> 2);
+    uint8_t avg[64 * 64];
+    const int keep1 = b->cost < a->cost;                         /* list whose vector stays */
+    const kso_pu *K = keep1 ? b : a, *O = keep1 ? a : b;
+    const uint8_t *pk = keep1 ? p1 : p0, *planesO = keep1 ? planes0 : planes1;
+    uint8_t T[64 * 64], orgp[64 * 64], kp[64 * 64];
+    for (int y = 0; y < s; ++y) { memcpy(orgp + y * s, S + (long)(y0 + y) * st + x0, (size_t)s); memcpy(kp + y * s, pk + (long)y * st, (size_t)s); }
+    ks265o_calc_bi_me_org(T, kp, orgp, s, s, s);
+    const int xe = imin(cx * 64 + 64, cfg->width), ye = imin(cy * 64 + 64, cfg->height);
+    const int lox = -64 - cx * 64, hix = cfg->width + 64 - xe, loy = -64 - cy * 64, hiy = cfg->height + 64 - ye;
+    int imx = iclip(4 * lox, 4 * hix, O->mvx) >> 2, imy = iclip(4 * loy, 4 * hiy, O->mvy) >> 2;
+    if (imx <= lox + 3) imx = lox + 4; else if (imx >= hix - 3) imx = hix - 4;
+    if (imy <= loy + 3) imy = loy + 4; else if (imy >= hiy - 3) imy = hiy - 4;
+    const int sx = imx - 3 - (O->mvpx < 0), sy = imy - 3 - (O->mvpy < 0);
+    const uint8_t *R = org_y(&g, (uint8_t *)planesO);
+    uint32_t bc = 0xfffffffu; int bx = 0, by = 0;
+    for (int y = 0; y < 8; ++y)
+        for (int x = 0; x < 8; ++x) {
+            uint32_t cc = ks265o_sad(T, R + (long)(y0 + sy + y) * st + x0 + sx + x, s, st, s, s)
+                          + (uint32_t)mv_cost(4 * (sx + x), 4 * (sy + y), O->mvpx, O->mvpy, lam);
+            if (cc < bc) { bc = cc; bx = 4 * (sx + x); by = 4 * (sy + y); }
+        }
+    static const int rx[8] = {-1, 0, 1, -1, 1, -1, 0, 1}, ry[8] = {-1, -1, -1, 0, 0, 1, 1, 1};
+    for (int step = 2; step >= 1; --step) {                       /* bc carries on: SAD + rate of the integer winner */
+        int cx0 = bx, cy0 = by;
+        for (int k = 0; k < 8; ++k) {
+            int qx = cx0 + rx[k] * step, qy = cy0 + ry[k] * step;
+            const uint8_t *pl = org_y(&g, (uint8_t *)planesO + (long)((qy & 3) * 4 + (qx & 3)) * g.bytes_y);
+            uint32_t cc = ks265o_sad(T, pl + (long)(y0 + (qy >> 2)) * st + x0 + (qx >> 2), s, st, s, s) + (uint32_t)mv_cost(qx, qy, O->mvpx, O->mvpy, lam);
+            if (cc < bc) { bc = cc; bx = qx; by = qy; }
+        }
+    }
+    const uint8_t *po = org_y(&g, (uint8_t *)planesO + (long)((by & 3) * 4 + (bx & 3)) * g.bytes_y) + (long)(y0 + (by >> 2)) * st + x0 + (bx >> 2);
+    for (int y = 0; y < s; ++y)
+        for (int x = 0; x < s; ++x) avg[y * s + x] = (uint8_t)((kp[y * s + x] + po[(long)y * st + x] + 1) >> 1);
+    uint32_t c2 = ks265o_had(S + (long)y0 * st + x0, avg, st, s, s, s) + (uint32_t)mv_cost(K->mvx, K->mvy, K->mvpx, K->mvpy, lam)
+                  + (uint32_t)mv_cost(bx, by, O->mvpx, O->mvpy, lam) + rbits;
+    c2 -= c2 >> BI_BIAS_SHIFT;
+    if (c2 < o->cost) {
+        o->cost = c2; o->inter_dir = BI_DIR_OF(3, i0, i1);
+        if (keep1) { o->mvx = (int16_t)bx; o->mvy = (int16_t)by; } else { o->mv1x = (int16_t)bx; o->mv1y = (int16_t)by; }
+    }
+}
+
 void kso_bi_decide(const kso_frame_cfg *cfg, kso_pic src, const uint8_t *planes0_, const uint8_t *planes1_, const kso_pu *pu0, const kso_pu *pu1,
                    kso_pu_b *pub)
 {
@@ -786,47 +840,44 @@ void kso_bi_decide(const kso_frame_cfg *cfg, kso_pic src, const uint8_t *planes0
                         uint32_t c = d + (uint32_t)mv_cost(a->mvx, a->mvy, a->mvpx, a->mvpy, lam) + (uint32_t)mv_cost(b->mvx, b->mvy, b->mvpx, b->mvpy, lam) + rbits;
                         c -= c >> BI_BIAS_SHIFT;
                         if (c < o->cost) { o->cost = c; o->inter_dir = BI_DIR(3); }
-                        if (!cfg->bi_refine) continue;
-                        const int keep1 = b->cost < a->cost;                         /* list whose vector stays */
-                        const kso_pu *K = keep1 ? b : a, *O = keep1 ? a : b;
-                        const uint8_t *pk = keep1 ? p1 : p0, *planesO = keep1 ? planes0 : planes1;
-                        uint8_t T[64 * 64], orgp[64 * 64], kp[64 * 64];
-                        for (int y = 0; y < s; ++y) { memcpy(orgp + y * s, S + (long)(y0 + y) * st + x0, (size_t)s); memcpy(kp + y * s, pk + (long)y * st, (size_t)s); }
-                        ks265o_calc_bi_me_org(T, kp, orgp, s, s, s);
-                        const int xe = imin(cx * 64 + 64, cfg->width), ye = imin(cy * 64 + 64, cfg->height);
-                        const int lox = -64 - cx * 64, hix = cfg->width + 64 - xe, loy = -64 - cy * 64, hiy = cfg->height + 64 - ye;
-                        int imx = iclip(4 * lox, 4 * hix, O->mvx) >> 2, imy = iclip(4 * loy, 4 * hiy, O->mvy) >> 2;
-                        if (imx <= lox + 3) imx = lox + 4; else if (imx >= hix - 3) imx = hix - 4;
-                        if (imy <= loy + 3) imy = loy + 4; else if (imy >= hiy - 3) imy = hiy - 4;
-                        const int sx = imx - 3 - (O->mvpx < 0), sy = imy - 3 - (O->mvpy < 0);
-                        const uint8_t *R = org_y(&g, (uint8_t *)planesO);
-                        uint32_t bc = 0xfffffffu; int bx = 0, by = 0;
-                        for (int y = 0; y < 8; ++y)
-                            for (int x = 0; x < 8; ++x) {
-                                uint32_t cc = ks265o_sad(T, R + (long)(y0 + sy + y) * st + x0 + sx + x, s, st, s, s)
-                                              + (uint32_t)mv_cost(4 * (sx + x), 4 * (sy + y), O->mvpx, O->mvpy, lam);
-                                if (cc < bc) { bc = cc; bx = 4 * (sx + x); by = 4 * (sy + y); }
+                        if (cfg->bi_refine == 1) bi_refine_pu(cfg, &g, S, planes0, planes1, rbits, i0, i1, cx, cy, l, px, py, a, b, o);   /* (2: after the CU decision, kso_bi_refine_chosen) */
+                    }
+        }
+}
+
+/* cfg->bi_refine == 2 (round 5): the joint refinement AFTER the CU decision, for the CUs it chose - one refinement per picture area instead of one per quadtree level
+ * (kso_bi_decide then only pairs the lists' winners; the decision sees unrefined pairs).  A 2N x 2N inter CU's record and its 8 x 8 blocks take the refined pair if it is
+ * cheaper than what the CU had; CUs in halves (cfg->part) and intra CUs stay as they are.  Runs in front of the merge pass. */
+void kso_bi_refine_chosen(const kso_frame_cfg *cfg, kso_pic src, const uint8_t *planes0_, const uint8_t *planes1_, const kso_pu *pu0, const kso_pu *pu1,
+                          kso_pu_b *pub, kso_cu8 *cu8)
+{
+    kso_frame_geom g; kso_frame_geometry(cfg, &g);
+    const uint8_t *S = org_y(&g, src.y);
+    const int lam = cfg->lambda_q4, w8 = cfg->width / 8;
+#pragma omp parallel for collapse(2) schedule(dynamic, 1)
+    for (int cy = 0; cy < g.ctu_rows; ++cy)
+        for (int cx = 0; cx < g.ctu_cols; ++cx) {
+            const long cb = (long)(cy * g.ctu_cols + cx) * 85;
+            for (int l = 0; l < 4; ++l)
+                for (int py = 0; py < (1 << l); ++py)
+                    for (int px = 0; px < (1 << l); ++px) {
+                        const int s = 64 >> l, x0 = cx * 64 + px * s, y0 = cy * 64 + py * s, i = pu_index(l, px, py);
+                        if (x0 >= cfg->width || y0 >= cfg->height) continue;
+                        const kso_cu8 *c0 = &cu8[(long)(y0 / 8) * w8 + x0 / 8];
+                        if (c0->pred_mode != 0 || c0->log2_cu != 6 - l) continue;           /* another size, an intra CU, or a CU in halves (bits 4..5) */
+                        const kso_pu *a = &pu0[cb + i], *b = &pu1[cb + i];
+                        kso_pu_b *o = &pub[cb + i];
+                        if (a->cost == COST_INVALID) continue;
+                        const int i0 = g_mr ? g_mr->idx0[cb + i] : 0, i1 = g_mr ? g_mr->idx1[cb + i] : 0;
+                        const uint32_t rbits = g_mr ? (uint32_t)((lam * ref_idx_bits(i0, g_mr->n0)) >> 4) + (uint32_t)((lam * ref_idx_bits(i1, g_mr->n1)) >> 4) : 0u;
+                        const uint32_t before = o->cost;
+                        bi_refine_pu(cfg, &g, S, MR_PL0(planes0_, i0), MR_PL1(planes1_, i1), rbits, i0, i1, cx, cy, l, px, py, a, b, o);
+                        if (o->cost == before) continue;
+                        for (int by = 0; by < s / 8; ++by)
+                            for (int bx = 0; bx < s / 8; ++bx) {
+                                kso_cu8 *c = &cu8[(long)(y0 / 8 + by) * w8 + x0 / 8 + bx];
+                                c->mvx = o->mvx; c->mvy = o->mvy; c->mv1x = o->mv1x; c->mv1y = o->mv1y; c->inter_dir = (uint8_t)o->inter_dir;
                             }
-                        static const int rx[8] = {-1, 0, 1, -1, 1, -1, 0, 1}, ry[8] = {-1, -1, -1, 0, 0, 1, 1, 1};
-                        for (int step = 2; step >= 1; --step) {                       /* bc carries on: SAD + rate of the integer winner */
-                            int cx0 = bx, cy0 = by;
-                            for (int k = 0; k < 8; ++k) {
-                                int qx = cx0 + rx[k] * step, qy = cy0 + ry[k] * step;
-                                const uint8_t *pl = org_y(&g, (uint8_t *)planesO + (long)((qy & 3) * 4 + (qx & 3)) * g.bytes_y);
-                                uint32_t cc = ks265o_sad(T, pl + (long)(y0 + (qy >> 2)) * st + x0 + (qx >> 2), s, st, s, s) + (uint32_t)mv_cost(qx, qy, O->mvpx, O->mvpy, lam);
-                                if (cc < bc) { bc = cc; bx = qx; by = qy; }
-                            }
-                        }
-                        const uint8_t *po = org_y(&g, (uint8_t *)planesO + (long)((by & 3) * 4 + (bx & 3)) * g.bytes_y) + (long)(y0 + (by >> 2)) * st + x0 + (bx >> 2);
-                        for (int y = 0; y < s; ++y)
-                            for (int x = 0; x < s; ++x) avg[y * s + x] = (uint8_t)((kp[y * s + x] + po[(long)y * st + x] + 1) >> 1);
-                        uint32_t c2 = ks265o_had(S + (long)y0 * st + x0, avg, st, s, s, s) + (uint32_t)mv_cost(K->mvx, K->mvy, K->mvpx, K->mvpy, lam)
-                                      + (uint32_t)mv_cost(bx, by, O->mvpx, O->mvpy, lam) + rbits;
-                        c2 -= c2 >> BI_BIAS_SHIFT;
-                        if (c2 < o->cost) {
-                            o->cost = c2; o->inter_dir = BI_DIR(3);
-                            if (keep1) { o->mvx = (int16_t)bx; o->mvy = (int16_t)by; } else { o->mv1x = (int16_t)bx; o->mv1y = (int16_t)by; }
-                        }
                     }
         }
 }

@@ -69,6 +69,9 @@ void kso_reconstruct(const kso_frame_cfg *cfg, kso_pic src, kso_pic ref, const u
 /* B pictures: per-PU choice among L0, L1 and the bi-predictive average (interMeBi* lineage), then the CU quadtree on it */
 void kso_bi_decide(const kso_frame_cfg *cfg, kso_pic src, const uint8_t *planes0, const uint8_t *planes1, const kso_pu *pu0, const kso_pu *pu1,
                    kso_pu_b *pub);
+/* cfg->bi_refine == 2: the joint refinement after the CU decision, for the 2N x 2N inter CUs it chose (in front of the merge pass) */
+void kso_bi_refine_chosen(const kso_frame_cfg *cfg, kso_pic src, const uint8_t *planes0, const uint8_t *planes1, const kso_pu *pu0, const kso_pu *pu1,
+                          kso_pu_b *pub, kso_cu8 *cu8);
 void kso_cu_decide_b(const kso_frame_cfg *cfg, const kso_pu_b *pub, kso_cu8 *cu8);
 /* stage C2 (cfg->merge): every CU may adopt the motion of one of its spatial merge neighbours (or the zero vector); pu for P pictures, pub for B pictures (the other NULL) */
 void kso_merge_pass(const kso_frame_cfg *cfg, kso_pic src, const uint8_t *planes0, const uint8_t *planes1, const kso_pu *pu, const kso_pu_b *pub,

@@ -195,6 +195,8 @@ class OraclePipeline:
                     o.kso_cu_decide_b_ii(cfg, ptr(self.pub), ptr(self.icost), ptr(self.imode), ptr(self.cu8))
                 else:
                     o.kso_cu_decide_b(cfg, ptr(self.pub), ptr(self.cu8))
+                if self.cfg.bi_refine == 2:              # the joint refinement for the CUs the decision chose (round 5)
+                    o.kso_bi_refine_chosen(cfg, self.src.c(), ptr(self.planes), ptr(self.planes1), ptr(self.pu), ptr(self.pu1), ptr(self.pub), ptr(self.cu8))
                 if self.cfg.merge:
                     for _ in range(int(os.environ.get("RD_MERGE_ROUNDS", "1"))):     # (experiment hook of tools/rd_eval.py; the pipeline runs one round)
                         tmp = self.cu8.copy()
@@ -265,6 +267,8 @@ class OraclePipeline:
                 o.kso_cu_decide_b_ii(cfg, ptr(self.pub), ptr(self.icost), ptr(self.imode), ptr(self.cu8))
             else:
                 o.kso_cu_decide_b(cfg, ptr(self.pub), ptr(self.cu8))
+            if self.cfg.bi_refine == 2:
+                o.kso_bi_refine_chosen(cfg, self.src.c(), pl0, pl1, ptr(self.pu), ptr(self.pu1), ptr(self.pub), ptr(self.cu8))
             if self.cfg.merge:
                 tmp = self.cu8.copy()
                 o.kso_merge_pass(cfg, self.src.c(), pl0, pl1, None, ptr(self.pub), ptr(tmp), ptr(self.cu8))

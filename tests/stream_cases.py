@@ -48,6 +48,11 @@ CASES = {
     "rqt_part_hiermr4_200x136": (200, 136, 31, 1, 0, 1, 1, "hiermr", 4),
     "enc_hiermr4_416x240": (416, 240, 29, 2, 16, 1, 1, "hiermr", 4),
     "part_hiermr4_200x136_qp33": (200, 136, 33, 1, 0, 1, 1, "hiermr", 4),
+    # round 5: cfg.bi_refine = 2 (what the C host runs from round 5 on): the joint refinement of a bi-predictive pair after the CU decision, for the CUs it chose
+    "enc_hierb4_416x240_bir2": (416, 240, 30, 1, 0, 1, 1, "hier", 4),
+    "enc_hiermr4_416x240_bir2": (416, 240, 29, 2, 16, 1, 1, "hiermr", 4),
+    "part_hierb4_200x136_qp34_bir2": (200, 136, 34, 1, 0, 1, 1, "hier", 4),
+    "rqt_part_hiermr4_200x136_bir2": (200, 136, 31, 1, 0, 1, 1, "hiermr", 4),
 }
 
 
@@ -76,7 +81,7 @@ def case_merge(name: str) -> int:
 
 
 def case_bir(name: str) -> int:
-    return 1 if name.startswith(("enc_", "part_", "rqt_")) else 0
+    return 2 if name.endswith("_bir2") else 1 if name.startswith(("enc_", "part_", "rqt_")) else 0
 
 
 def case_dec(name: str) -> int:

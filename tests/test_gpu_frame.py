@@ -313,18 +313,20 @@ def test_full_size_properties_2160p(ks):
 
 
 @pytest.mark.parametrize("W,H,seed,me,refine", [(416, 240, 5, 1, 0), (200, 136, 6, 0, 0), (1280, 720, 7, 2, 0),
-                                                (416, 240, 5, 1, 1), (200, 136, 6, 0, 1), (72, 56, 8, 1, 1), (1280, 720, 7, 2, 1)])
+                                                (416, 240, 5, 1, 1), (200, 136, 6, 0, 1), (72, 56, 8, 1, 1), (1280, 720, 7, 2, 1),
+                                                (416, 240, 5, 1, 2), (200, 136, 6, 0, 2), (72, 56, 8, 1, 2), (1280, 720, 7, 2, 2)])
 def test_b_pictures_match_oracle(ks, W, H, seed, me, refine):
     """B pictures (two lists, bi-prediction with the exact 14-bit average): stage by stage and through ks265_encode_picture_b,
     coding order I0 P4 B1 B2 B3 like -bframes 3.  refine = 1: with the joint refinement of the pair (cfg.bi_refine: motionSearchBI enc@0x484910,
-    interMeBiFull enc@0x4896d0) - the PU records after ks265_bi_decide must equal the oracle's, refined vectors included."""
+    interMeBiFull enc@0x4896d0) - the PU records after ks265_bi_decide must equal the oracle's, refined vectors included.  refine = 2 (round 5, what the host runs): the
+    refinement after the CU decision for the CUs it chose (ks265_bi_refine_chosen) - the PU records and the CU records behind it must equal the oracle's."""
     from ks265codec_amd.lib import CU8, PU, PU_B, KsFrame
     from ks265codec_amd.synth import lambda_q4, make_clip
     from oracle_lib import OraclePipeline
 
     clip = make_clip(W, H, 5, seed=seed, abc=(17, 23, 9))
-    o = OraclePipeline(W, H, 27, lambda_q4(27), me_method=me, bi_refine=refine, decimate=2 * refine)       # refine = 1 also switches the coefficient decimation on
-    f = KsFrame(ks, W, H, 27, lambda_q4(27), me_method=me, bframes=3, bi_refine=refine, decimate=2 * refine)
+    o = OraclePipeline(W, H, 27, lambda_q4(27), me_method=me, bi_refine=refine, decimate=2 * (refine > 0))       # refine also switches the coefficient decimation on
+    f = KsFrame(ks, W, H, 27, lambda_q4(27), me_method=me, bframes=3, bi_refine=refine, decimate=2 * (refine > 0))
     g = f.geom
     org_y, org_c = g.pad_y * g.stride_y + g.pad_y, g.pad_c * g.stride_c + g.pad_c
     src = f.new_pic()
@@ -350,11 +352,18 @@ def test_b_pictures_match_oracle(ks, W, H, seed, me, refine):
             assert (ks.host(pu0, PU) == o.pu).all() and (ks.host(pu1, PU) == o.pu1).all(), "list searches differ"
             f.bi_decide(src, dpb_g[r0], dpb_g[r1], pu0, pu1, pub)
             gb = ks.host(pub, PU_B)
+            if refine == 2:                                # the oracle's records are those behind the late refinement: decide, refine the chosen CUs, compare then
+                before = gb.copy()
+                f.cu_decide_b(pub, cu8)
+                f.bi_refine_chosen(src, dpb_g[r0], dpb_g[r1], pu0, pu1, pub, cu8)
+                gb = ks.host(pub, PU_B)
+                assert ((gb["cost"] <= before["cost"]) | (before["cost"] == 0xFFFFFFFF)).all()
             assert (gb == o.pub).all(), f"bi decision differs for {int((gb != o.pub).sum())} PUs"
             assert len(set(np.unique(gb["inter_dir"][gb["cost"] != 0xFFFFFFFF]))) == 3, "fixture should exercise L0, L1 and bi"
             h0, h1 = ks.host(pu0, PU), ks.host(pu1, PU)
             refined[0] += int(((gb["inter_dir"] == 3) & ((gb["mvx"] != h0["mvx"]) | (gb["mvy"] != h0["mvy"]) | (gb["mv1x"] != h1["mvx"]) | (gb["mv1y"] != h1["mvy"]))).sum())
-            f.cu_decide_b(pub, cu8)
+            if refine != 2:
+                f.cu_decide_b(pub, cu8)
             f.reconstruct_b(src, dpb_g[r0], dpb_g[r1], cu8, lvl, deb)
             assert (ks.host(cu8, CU8) == o.cu8).all()
             for c in range(3):

@@ -163,7 +163,7 @@ def test_bi_refinement_and_decimation_properties():
     W, H = 200, 136
     clip = make_clip(W, H, 5, seed=6, abc=(17, 23, 9))
     pubs = {}
-    for r in (0, 1):
+    for r in (0, 1, 2):
         o = OraclePipeline(W, H, 27, lambda_q4(27), me_method=1, bi_refine=r)
         d = {0: o.encode(clip[0], "I")}
         o.set_qp(28, lambda_q4(28)); d[4] = o.encode(clip[4], "P", d[0])
@@ -176,6 +176,11 @@ def test_bi_refinement_and_decimation_properties():
     assert moved.any() and (b["inter_dir"][moved] == 3).all()
     for k in ("mvx", "mv1x"):
         assert (np.abs(b[k][valid].astype(int)) <= 4 * (W + 80)).all()
+    # cfg.bi_refine = 2 (round 5): the same refinement after the CU decision - only records of PUs that are CUs of the final tree change, each into what mode 1 makes of it
+    # (same inputs: the lists' records and the unrefined pair), and the CU records carry the refined motion
+    c = pubs[2][0]
+    late = valid & (c["cost"] != a["cost"])
+    assert late.any() and (c[late] == b[late]).all() and (c[~late] == a[~late]).all() and late.sum() < (b["cost"] != a["cost"]).sum()
     # decimation: same key picture, same motion search on the first P picture -> only levels of dropped luma TUs differ
     lv = {}
     for k in (0, 2):
