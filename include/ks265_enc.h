@@ -107,7 +107,10 @@ int ks265_enc_lanes(void *pEncoder);
 int ks265_enc_set_default(const char *name, int value);
 /* extension: zero-copy input.  Fills `yuv` with the planes of one of the encoder's pinned input buffers (packed I420, strides = width, width / 2); the caller writes the
  * next picture there and passes the same QY265YUV to QY265EncoderEncodeFrame, which then copies nothing (0.35 ms of the calling thread per 2160p picture otherwise).
- * Never blocks: QY_FAIL when no buffer is free at the moment - pass your own buffer then, it is copied as usual.  At most one buffer is out at a time. */
+ * Never blocks: QY_FAIL when no buffer is free at the moment - pass your own buffer then, it is copied as usual.  At most one buffer is out at a time.
+ * CONTRACT: the buffer belongs to the caller only until the NEXT QY265EncoderEncodeFrame call on this handle, whatever picture that call hands in - if it hands in another
+ * buffer and no free input slot is left, the encoder copies that picture into the acquired buffer (its last resort; anything the caller had written there is lost).  Acquire,
+ * fill and hand in the same buffer, one picture at a time.  With the lookahead every input slot also has a twin in device memory (picture size each; logged at open). */
 int ks265_enc_acquire_input(void *pEncoder, QY265YUV *yuv);
 /* extension: write the reconstruction (I420, display order) to `path` - the reference CLI's `-o`; call between Open and the first picture */
 int ks265_enc_set_recon_file(void *pEncoder, const char *path);

@@ -1362,6 +1362,7 @@ static Enc *lane_open(QY265EncConfig *cfg, int device, int multi, int *err)
     if (e->la_on && e->ctx_la) {
         e->ctx_up = e->ctx_la;
         for (int i = 0; i < e->nin && !r; ++i) { r = ks265_dev_malloc(e->ctx, (void **)&e->in[i].dev, fsz); if (!r) r = ks265_event_create(e->ctx_up, &e->in[i].ev_up); }
+        logf_(2, e->log_level, "ks265enc: %d input slots with a device twin each: %.2f GB of device memory per lane (KS265_INPUT_SLOTS / KS265_PINNED_MB bound the slot count)\n", e->nin, e->nin * (double)fsz / 1073741824.0);
     }
     if (r) { *err = hip_rc(r); lane_close(e, 0); return NULL; }
     memset(&e->scfg, 0, sizeof e->scfg);

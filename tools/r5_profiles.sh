@@ -21,7 +21,9 @@ rm -f $O/sq_counters.json
 python $R/tools/sq_issue.py $(ls $O/pmc_sq/*counter_collection.csv | head -1) 3840x2160 $O/sq_counters.json > $O/sq_issue.txt 2>&1
 timeout 200 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $O/pmc_sq2 -o p -- python $R/bench.py --leg hot --steps 6 --warmup 2 --streams 1 --no-cpu-baseline > /dev/null 2>&1
 python $R/tools/sq_summary.py $(ls $O/pmc_sq2/*counter_collection.csv | head -1) > $O/sq_counters.txt 2>&1
-rm -rf $O/pmc_f $O/pmc_w $O/pmc_sq $O/pmc_sq2 $O/kt_hot1 $O/kt_def $O/kt_hier
+timeout 200 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $O/pmc_sq3 -o p -- python $R/bench.py --leg hot --hier-b 8 --steps 16 --warmup 2 --streams 1 --no-cpu-baseline > /dev/null 2>&1
+python $R/tools/sq_summary.py $(ls $O/pmc_sq3/*counter_collection.csv | head -1) > $O/sq_counters_hier8.txt 2>&1
+rm -rf $O/pmc_f $O/pmc_w $O/pmc_sq $O/pmc_sq2 $O/pmc_sq3 $O/kt_hot1 $O/kt_def $O/kt_hier
 cp $O/hbm_traffic.json $O/sq_counters.json $R/profiles/ 2>/dev/null
 cd $R
 timeout 150 python bench.py --leg hot --streams 1 --no-cpu-baseline 2>/dev/null | grep '^{' | tail -1 > $O/bench_line_hot_1stream.json
