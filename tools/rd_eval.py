@@ -52,7 +52,7 @@ def encode_ours(clip, W, H, qp, gop, tools, verbose=False, stats=None, pdelta=1,
     n = len(clip)
     o = OraclePipeline(W, H, qp, lambda_q4(qp), **tools)
     G = int(os.environ.get("RD_G", "8").replace("plain", ""))
-    w = S.StreamWriter(W, H, max_dec_pic_buffering=10 if gop == "hier" else 2, max_num_reorder=7 if gop == "hier" else 0, sdh=tools.get("sdh", 0), wpp=0 if stats else 1, list_mod=1 if os.environ.get('RD_GPB2') else 0)
+    w = S.StreamWriter(W, H, max_dec_pic_buffering=10 if gop == "hier" else 2, max_num_reorder=7 if gop == "hier" else 0, sdh=tools.get("sdh", 0), wpp=0 if stats else 1, list_mod=1 if os.environ.get('RD_GPB2') else 0, tu_inter=tools.get("tu_inter", 0))
     import ctypes as C
     st = (C.c_double * 6)()
     agg = {}
