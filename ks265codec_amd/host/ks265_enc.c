@@ -1822,11 +1822,13 @@ static int top_collect_pass(Top *t, QY265Picture *out, long *progress, long *pen
         }
         QY265Nal *nals; int n = 0, pics = 0;
         const int r = take_output(t->lane[c->lane], MAX_JOBS + 1, (int)(c->count - c->delivered), &nals, &n, out, &pics);
-        if (r) return r;
-        if (!pics) break;
-        const int ra = top_append(t, nals, n);
-        if (ra) return ra;
+        /* (a picture that failed on the device has left the lane's ring like any other - without a payload: it is on the books before the error goes up, or this GOP
+         *  would wait for it for ever) */
+        const int ra = pics ? top_append(t, nals, n) : QY_OK;
         c->delivered += pics; *progress += pics;
+        if (r) return r;
+        if (ra) return ra;
+        if (!pics) break;
         if (out) out->poc = (int)(c->base + (out->poc - c->disp0));    /* the lane reports its own display index */
     }
     /* the GOPs behind the head: whatever their lanes have finished goes into the stash (a lane hands its pictures out in its own order: only its oldest unfinished
@@ -1844,11 +1846,11 @@ static int top_collect_pass(Top *t, QY265Picture *out, long *progress, long *pen
             if (left <= 0) break;
             QY265Nal *nals; int n = 0, pics = 0;
             const int r = take_output(t->lane[c->lane], MAX_JOBS + 1, (int)left, &nals, &n, &c->sout, &pics);
-            if (r) return r;
-            if (!pics) break;
-            const int ra = nal_append(&c->snal, &c->soff, &c->sn, &c->sn_cap, &c->sbuf, &c->scap, &c->spos, nals, n);
-            if (ra) return ra;
+            const int ra = pics ? nal_append(&c->snal, &c->soff, &c->sn, &c->sn_cap, &c->sbuf, &c->scap, &c->spos, nals, n) : QY_OK;
             c->stashed += pics; *progress += pics; *pending -= pics;
+            if (r) return r;
+            if (ra) return ra;
+            if (!pics) break;
         }
     }
     return QY_OK;
@@ -1920,7 +1922,11 @@ static int top_devices(int dev[MAX_LANES])
 static int top_lanes_wanted(const QY265EncConfig *cfg, int ndev)
 {
     const char *env = getenv("KS265_GOP_LANES");
-    int per = env ? atoi(env) : 1;
+    /* round 5: two lanes per GPU by default for the pyramid GOPs (the SDK's default GOP and -bframes 3): a B picture's kernels leave the device under-filled - two closed GOPs
+     * side by side code 700 pictures/s where one codes 631 (2160p, same stream; IPPP loses with lanes - 970 -> 890 - and stays at one).  KS265_GOP_LANES=1 switches it off */
+    const int gop_b = cfg->bframes < 0 ? (cfg->latency == QY265LATENCY_DEFAULT ? 7 : 0) : cfg->bframes;        /* (as lane_open resolves it) */
+    const int pyramid = gop_b == 7 || gop_b == 3;
+    int per = env ? atoi(env) : pyramid && ndev == 1 ? 2 : 1;       /* (several GPUs behind one handle: the calling thread feeds them all - one lane each unless asked) */
     if (per < 1) per = 1;
     int n = per * ndev;
     if (n > MAX_LANES) n = MAX_LANES;

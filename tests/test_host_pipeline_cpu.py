@@ -126,14 +126,16 @@ def test_device_failure_is_reported_not_hung(stub_lib, lanes, at):
     assert r.get("error") == 0x80000001 and r["at"] <= (at + 40 if lanes == 1 else 100), r
 
 
-@pytest.mark.parametrize("bframes", [0, -1])
-def test_device_error_word_sticks_until_the_next_key_picture(stub_lib, tmp_path, bframes):
+@pytest.mark.parametrize("bframes,lanes", [(0, 1), (-1, 1), (0, 2), (-1, 2), (-1, 3)])
+def test_device_error_word_sticks_until_the_next_key_picture(stub_lib, tmp_path, bframes, lanes):
     """ks265_take_device_error (a wavefront time-out on the GPU) does not say which picture raised it, and every picture predicted from a broken one is broken: after the
     error is seen NO picture goes out until a key picture submitted later starts a clean GOP; a caller that keeps feeding pictures after QY_FAIL gets the
     failure for every such picture, then a stream that starts again with an IDR and decodes"""
     out = tmp_path / "e.265"
-    clean = run(stub_lib, 200, 32, bframes)
-    r = run(stub_lib, 200, 32, bframes, out=out, KS265_STUB_DEVERR_AT=9, KS_TEST_CONTINUE_ON_ERROR=1)
+    # (round 5: with GOP lanes - two by default for the pyramid GOPs - the failed GOP's pictures leave their lane without payload and are counted, the other lanes' GOPs go on:
+    #  before, the handle waited for ever for the pictures that were never written)
+    clean = run(stub_lib, 200, 32, bframes, KS265_GOP_LANES=lanes)
+    r = run(stub_lib, 200, 32, bframes, out=out, KS265_STUB_DEVERR_AT=9, KS_TEST_CONTINUE_ON_ERROR=1, KS265_GOP_LANES=lanes)
     assert r["errors"] >= 1
     order = clean["pts"]                                         # coding order of the clean run
     lost = [p for p in order if p not in set(r["pts"])]
