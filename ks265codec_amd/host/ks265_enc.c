@@ -268,6 +268,8 @@ static void copy_shared(CopyPool *p, uint8_t *d, const uint8_t *s, size_t n)
 }
 
 #define LA_RING 9                                                      /* half-size pictures kept for the analysis: the current one and eight back */
+#define LA_QMAX 64                                                     /* pictures that may wait at the input for their analysis (a GOP lane runs a whole GOP ahead of its pixel path) */
+#define LA_FLY 16                                                      /* analyses in flight = result areas */
 typedef struct Input { int used, disp, key, base_qp, iper, mini4, kbps, la_what, la_p, la_buf; long long pts; uint8_t *i420; uint8_t *dev; void *ev_up; } Input;   /* dev / ev_up: the slot's twin on the device, uploaded
                                                                                                  * when the picture is handed in (round 4), and the event behind that upload */     /* pinned; key: this picture starts a closed GOP whatever the period says (GOP lanes,
                                                                                                  * QY265EncoderKeyFrameRequest); base_qp: the QP in force when the picture was handed in (QY265EncoderReconfig) -
@@ -337,7 +339,7 @@ typedef struct Enc {
     int la_auto;                                                       /* no -lookahead given, hierarchical GOP: the slice-type decision alone (pictures on the GOP's grid of 4), no scene cuts - works in GOP lanes */
     double la_t_bp, la_t_take, la_t_wait; long la_n_wait, la_n_poll;       /* where the caller's time goes (log level 1) */
     pthread_mutex_t la_mu;                                             /* the queue below and the decisions' state: the caller's thread fills it, the caller's and the scheduler's threads empty it (lock order: la_mu, then mu) */
-    struct Input *la_q[8]; int la_qn, la_flying, la_seq; void *la_evs[4];   /* pictures handed in and not yet with the scheduler (display order); analyses in flight; their events / result areas, round robin */
+    struct Input *la_q[LA_QMAX]; int la_qn, la_flying, la_seq, la_keep; void *la_evs[LA_FLY];   /* pictures handed in and not yet with the scheduler (display order); analyses in flight; their events / result areas, round robin */
     ks265_ctx *ctx_la; ks265_frame *frame_la; ks265_frame_geom geom_la; ks265_pic la_pic[LA_RING];
     uint32_t *la_cost_ws; uint64_t *la_dev_out, *la_host_out;
     struct TopWake *wake;                                 /* lanes: the handle's caller sleeps here until a picture of ANY lane is finished */
@@ -969,7 +971,7 @@ static void *scheduler(void *arg)
                 pthread_cond_timedwait(&e->cv_sched, &e->mu, &ts);
                 if (e->quit || e->sched_seen != e->next_disp || e->sched_flush) continue;
                 pthread_mutex_unlock(&e->mu);
-                (void)la_drain(e, 8);                                   /* (never waits: 8 = the queue's size) */
+                (void)la_drain(e, LA_QMAX);                             /* (never waits: the queue's size) */
                 pthread_mutex_lock(&e->mu);
                 if (e->sched_seen != e->next_disp) ++e->la_n_poll;
             } else pthread_cond_wait(&e->cv_sched, &e->mu);
@@ -1123,7 +1125,7 @@ static void lane_close(Enc *e, int report)
             ks265_synchronize(e->ctx_la);
             for (int i = 0; i < LA_RING; ++i) { ks265_dev_free(e->ctx_la, e->la_pic[i].y); ks265_dev_free(e->ctx_la, e->la_pic[i].u); ks265_dev_free(e->ctx_la, e->la_pic[i].v); }
             ks265_dev_free(e->ctx_la, e->la_cost_ws); ks265_dev_free(e->ctx_la, e->la_dev_out); ks265_host_free(e->ctx_la, e->la_host_out);
-            for (int i = 0; i < 4; ++i) if (e->la_evs[i]) ks265_event_destroy(e->ctx_la, e->la_evs[i]);
+            for (int i = 0; i < LA_FLY; ++i) if (e->la_evs[i]) ks265_event_destroy(e->ctx_la, e->la_evs[i]);
             if (e->frame_la) ks265_frame_destroy(e->frame_la);
             ks265_destroy(e->ctx_la);
         }
@@ -1307,9 +1309,12 @@ static Enc *lane_open(QY265EncConfig *cfg, int device, int multi, int *err)
                 if (!r) r = ks265_memset_async(e->ctx_la, e->la_pic[i].v, 128, (size_t)e->geom_la.bytes_c);
             }
             if (!r) r = ks265_dev_malloc(e->ctx_la, (void **)&e->la_cost_ws, (size_t)e->geom_la.ctu_cols * e->geom_la.ctu_rows * 85 * sizeof(uint32_t));
-            if (!r) r = ks265_dev_malloc(e->ctx_la, (void **)&e->la_dev_out, 4 * 128);
-            if (!r) r = ks265_host_malloc(e->ctx_la, (void **)&e->la_host_out, 4 * 128);
-            for (int i = 0; i < 4 && !r; ++i) r = ks265_event_create(e->ctx_la, &e->la_evs[i]);
+            if (!r) r = ks265_dev_malloc(e->ctx_la, (void **)&e->la_dev_out, LA_FLY * 128);
+            if (!r) r = ks265_host_malloc(e->ctx_la, (void **)&e->la_host_out, LA_FLY * 128);
+            for (int i = 0; i < LA_FLY && !r; ++i) r = ks265_event_create(e->ctx_la, &e->la_evs[i]);
+            /* how many pictures may wait for their analysis before the caller waits for the oldest one: five with one lane (the caller is paced by the output anyway); a GOP lane
+             * takes a whole GOP in ahead of its pixel path - its analyses queue up behind two lanes' kernels, and a caller that waited for them fed 770 pictures/s (round 5) */
+            e->la_keep = getenv("KS265_LA_KEEP") && atoi(getenv("KS265_LA_KEEP")) > 0 && atoi(getenv("KS265_LA_KEEP")) < LA_QMAX - 8 ? atoi(getenv("KS265_LA_KEEP")) : multi ? 48 : 5;
             if (!r) { e->la_on = 1; e->la_auto = la_auto; e->la_last_key = -1000000; e->la_prev_icost = -1; e->la_w = w; e->la_h = h; e->mg_adapt = e->hier; e->mg4_until = -1; }
         }
     }
@@ -1454,8 +1459,7 @@ static int lane_acquire(Enc *e, QY265YUV *yuv)
  *      hands in another picture - and only then goes to the scheduler.  The queue holds at most LA_KEEP pictures: a result that is still missing then is waited for (the analysis
  *      has had several picture times by then).  Same decisions as when the caller waited for every picture (round 3; the CPU tests did not change), a few pictures of delay at
  *      the input.  The caller's thread launches; the caller's thread and - when it has nothing to schedule - the scheduler thread look (la_mu). */
-#define LA_KEEP la_keep()
-static int la_keep(void) { static int v = 0; if (!v) { const char *s = getenv("KS265_LA_KEEP"); v = s && atoi(s) > 0 && atoi(s) < 8 ? atoi(s) : 5; } return v; }
+#define LA_KEEP (e->la_keep)
 
 /* a picture whose analysis is through (or which needs none) goes to the scheduler */
 static void la_publish(Enc *e, Input *slot, int cut, int mini4)
@@ -1555,7 +1559,7 @@ static int la_take_locked(Enc *e, Input *slot)
     /* -lookahead N: a scene-cut verdict moves the GOP's grid, so the next picture's launch needs every verdict before it; auto: nothing of the launch depends on results.
      * At most four analyses in flight (their result areas) */
     if ((r = la_drain_locked(e, e->la_auto ? LA_KEEP : 0))) return r;
-    while (e->la_flying >= 4) if ((r = la_drain_locked(e, e->la_qn - 1))) return r;
+    while (e->la_flying >= LA_FLY || e->la_qn >= LA_QMAX - 1) if ((r = la_drain_locked(e, e->la_qn - 1))) return r;
     const int nd = slot->disp, c = nd % LA_RING, w = e->la_w, h = e->la_h;
     const size_t org = (size_t)e->geom_la.pad_y * e->geom_la.stride_y + e->geom_la.pad_y;
     const int keynow = slot->key || nd == 0 || (slot->iper > 0 && e->la_last_key > -1000000 && nd - e->la_last_key >= slot->iper);   /* (but for a scene cut, not known yet) */
@@ -1564,7 +1568,7 @@ static int la_take_locked(Enc *e, Input *slot)
     int what = -1;
     r = 0;
     if (!e->la_auto || (p & 3) == 0) {                                 /* auto: pictures off the grid are neither analysed nor kept */
-        const int buf = e->la_seq++ & 3;
+        const int buf = e->la_seq++ % LA_FLY;
         uint64_t *dout = e->la_dev_out + 16 * buf;
         what = 0;
         /* the half-size picture from the slot's twin on the device (uploaded a moment ago on this stream).  Measured in round 4 before that existed: an H2D copy of the
