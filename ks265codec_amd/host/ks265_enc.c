@@ -1746,7 +1746,8 @@ static int lane_set_recon_file(Enc *e, const char *path)
  * enFrameParallel (frames of one stream coded concurrently on CPU threads) is the switch: lanes run with enFrameParallel != 0, fixed QP (-rc 0) and a key
  * period of at least 32 pictures (the rate controllers carry state across GOPs).  Every GOP structure works: the scheduler closes a GOP in front of a key picture
  * (the mini-GOP there is shortened to end in a P picture), so nothing references across lanes.  Cost: output lags the input by up to L GOPs, and L pipelines' worth of buffers.
- * Off by default (KS265_GOP_LANES = 2..4 switches it on): measured at 2160p on the round-2 box, two lanes reach 1.05x of one (1123 vs 1068 frames/s) -
+ * Round 5: TWO lanes by default for the pyramid GOPs on one GPU (top_lanes_wanted: 631 -> 700 pictures/s at 2160p, GPU-bound at both), one otherwise.  IPPP, measured at 2160p
+ * on the round-2 box: two lanes reach 1.05x of one (1123 vs 1068 frames/s; round 5: 890 against 970) -
  * with twice the pictures in flight the slice writers, not the GPU, set the pace (their time per picture grows from 19 to 59 ms of thread time as the
  * threads spread over the host), DESIGN.md section 6. */
 #define MAX_LANES 16

@@ -47,7 +47,9 @@ int ks265_dev_malloc(ks265_ctx *c, void **p, size_t n) { (void)c; *p = calloc(1,
 int ks265_dev_free(ks265_ctx *c, void *p) { (void)c; free(p); return KS265_OK; }
 int ks265_host_malloc(ks265_ctx *c, void **p, size_t n) { return ks265_dev_malloc(c, p, n); }
 int ks265_host_free(ks265_ctx *c, void *p) { return ks265_dev_free(c, p); }
-int ks265_memcpy_h2d_async(ks265_ctx *c, void *d, const void *s, size_t n) { (void)c; memcpy(d, s, n); return KS265_OK; }
+static int stub_fast(void);
+int ks265_memcpy_h2d_async(ks265_ctx *c, void *d, const void *s, size_t n) { (void)c; if (n > (1u << 20) && stub_fast()) return KS265_OK;   /* (KS265_STUB_FAST: a picture's upload is the copy engine's time, not the caller's) */
+    memcpy(d, s, n); return KS265_OK; }
 int ks265_memcpy_d2d_async(ks265_ctx *c, void *d, const void *s, size_t n) { (void)c; memcpy(d, s, n); return KS265_OK; }
 int ks265_memcpy_d2h_async(ks265_ctx *c, void *d, const void *s, size_t n) { (void)c; memcpy(d, s, n); return KS265_OK; }
 int ks265_memset_async(ks265_ctx *c, void *d, int v, size_t n) { (void)c; memset(d, v, n); return KS265_OK; }
@@ -121,6 +123,7 @@ static void do_load(ks265_frame *f, const uint8_t *i420, ks265_pic dst)
         memcpy(dst.v + (size_t)(f->g.pad_c + y) * f->g.stride_c + f->g.pad_c, v + (size_t)y * (W / 2), (size_t)W / 2);
     }
 }
+static int stub_fast(void) { static int fast = -1; if (fast < 0) fast = getenv("KS265_STUB_FAST") ? 1 : 0; return fast; }
 static void do_encode(ks265_frame *f, int kind /*0 key, 1 P, 2 B*/, ks265_pic src, ks265_pic r0, ks265_pic r1, ks265_pic out, int state_at_capture)
 {
     const int w8 = f->cfg.width / 8, h8 = f->cfg.height / 8;
@@ -128,6 +131,16 @@ static void do_encode(ks265_frame *f, int kind /*0 key, 1 P, 2 B*/, ks265_pic sr
     /* of the frame state only "a previous P picture exists" may show in the result (the PU ping-pong buffer is an implementation detail: two lanes are at different
      * parities for the same picture) */
     const uint64_t mix = hs ^ (h0 * 3) ^ (h1 * 5) ^ ((uint64_t)f->cfg.qp << 40) ^ ((uint64_t)((state_at_capture >> 1) & 1) << 50);
+    /* KS265_STUB_FAST (tools/caller_ceiling.py): a "device" that costs the host next to nothing - every block a skipped 8x8 CU, no levels, no reconstruction - so that at
+     * 2160p with eight lanes the CALLING thread becomes the limit and its ceiling can be read off */
+    if (stub_fast()) {
+        ks265_cu8 c; memset(&c, 0, sizeof c);
+        c.log2_cu = 3; if (kind == 0) { c.pred_mode = 2; c.mvx = 1; } else c.inter_dir = 1;
+        for (int i = 0; i < w8 * h8; ++i) f->cu8[i] = c;
+        for (int i = 0; i < f->g.ctu_cols * f->g.ctu_rows * 3; ++i) { memset(&f->sao[i], 0, sizeof f->sao[i]); f->sao[i].type = -1; }
+        f->kind_hash = mix;
+        return;
+    }
     for (int i = 0; i < w8 * h8; ++i) {
         ks265_cu8 c; memset(&c, 0, sizeof c);
         c.log2_cu = 3;
@@ -177,6 +190,8 @@ static void do_pack(ks265_frame *f, uint8_t *dst, const uint64_t *extra)
     uint8_t *data = dst + off[6];
     memset(bm, 0, nchunk * 128);
     uint32_t stored = 0;
+    if (stub_fast()) memset(table, 0, nchunk * 4);               /* (no levels: nothing stored, nothing to look through) */
+    else
     for (size_t L = 0; L < nlines; ++L) {                        /* the stored lines in line order; the device packs chunk by chunk in any order, the table says where */
         if ((L & 1023) == 0) table[L >> 10] = stored;
         const int p = L >= first[2] ? 2 : L >= first[1] ? 1 : 0;
@@ -209,7 +224,7 @@ enum { OP_LOAD, OP_ENC, OP_SSE, OP_PACK };
 static int run_op(const Op *o)
 {
     switch (o->kind) {
-    case OP_LOAD: do_load(o->f, (const uint8_t *)o->a, o->p0); break;
+    case OP_LOAD: if (!stub_fast()) do_load(o->f, (const uint8_t *)o->a, o->p0); break;
     case OP_ENC: do_encode(o->f, o->i0 & 3, o->p0, o->p1, o->p2, o->p3, o->i0 >> 2); break;
     case OP_SSE: { uint64_t *d = (uint64_t *)o->dst; d[0] = o->f->kind_hash & 0xFFFFF; d[1] = 17; d[2] = 23; break; }
     case OP_PACK: do_pack(o->f, (uint8_t *)o->dst, (const uint64_t *)o->a); break;
@@ -307,6 +322,7 @@ int ks265_downsample_from_host(ks265_ctx *c, const uint8_t *src, int ss, uint8_t
 int ks265_downsample_rect(ks265_ctx *c, const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int h)
 {
     (void)c;
+    if (stub_fast()) return KS265_OK;                           /* (a real device takes these launches asynchronously: nothing of them is the calling thread's time) */
     for (int y = 0; y < h; ++y)
         for (int x = 0; x < w; ++x)
             dst[(long)y * ds + x] = (uint8_t)((src[(long)(2 * y) * ss + 2 * x] + src[(long)(2 * y) * ss + 2 * x + 1] + src[(long)(2 * y + 1) * ss + 2 * x] + src[(long)(2 * y + 1) * ss + 2 * x + 1] + 2) >> 2);
@@ -316,6 +332,7 @@ int ks265_pad_picture(ks265_frame *f, ks265_pic pic) { (void)f; (void)pic; retur
 int ks265_lookahead_picture(ks265_frame *f, ks265_pic cur, ks265_pic ref, uint32_t *ws, uint64_t *out)
 {
     (void)ws;
+    if (stub_fast()) { out[0] = 1000; out[1] = 100; out[2] = 100; out[3] = (uint64_t)f->cfg.width * f->cfg.height / 64; return KS265_OK; }
     const long org = (long)f->g.pad_y * f->g.stride_y + f->g.pad_y;
     uint64_t intra = 0, inter = 0;
     for (int y = 0; y < f->cfg.height; ++y)
