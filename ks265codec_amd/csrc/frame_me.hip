@@ -96,8 +96,8 @@ __global__ __launch_bounds__(NC * 64, KS_SUBPEL_OCC) void me_subpel_kernel(KsGeo
     __shared__ unsigned short s_item[NC * 256];
     __shared__ int s_cnt[NC * 4];
     __shared__ unsigned short s_sat[9][NC * 256];                 // slot = gy * 3 + gx of the ring (4 = centre); an 8x8 SATD is at most 8 * 8 * 8 * 255 / 4 = 32640, a SAD 16320
-    __shared__ __attribute__((aligned(16))) unsigned short s_hx[NC][16][8 * 16 + 8];   // per wave and item column: horizontally filtered rows, [pixel][row 0..15]; + 4 dwords: the 16 columns of a
-                                                                                      // block start in different banks (68 = 4 mod 32; unpadded, all of them hit the same)
+    __shared__ __attribute__((aligned(16))) unsigned short s_hx[NC][16][200];   // per wave and item column: horizontally filtered rows, [pixel][row 0..15]; + 4 dwords: the 16 columns of a
+                                                                                      // block start in different banks (100 dwords = 4 mod 32; unpadded, all of them hit the same); nine pixel columns in phase H's shared form
     if (lane == 0) s_org[wave] = have ? ((ctu % g.ctu_cols) * 64) | (((ctu / g.ctu_cols) * 64) << 16) : 0;
     // Z-order: lane bits (y2 x2 y1 x1 y0 x0)
     const int tx = (lane & 1) | ((lane >> 1) & 2) | ((lane >> 2) & 4), ty = ((lane >> 1) & 1) | ((lane >> 2) & 2) | ((lane >> 3) & 4);
@@ -218,6 +218,11 @@ __global__ __launch_bounds__(NC * 64, KS_SUBPEL_OCC) void me_subpel_kernel(KsGeo
             const uint2 a0 = *(const uint2 *)(Sp + t.ro), a1 = *(const uint2 *)(Sp + t.ro + (unsigned)g.sy);
             t.S = ks_v4i{(int)(a0.x ^ 0x7F7F7F7Fu), (int)(a0.y ^ 0x7F7F7F7Fu), (int)(a1.x ^ 0x7F7F7F7Fu), (int)(a1.y ^ 0x7F7F7F7Fu)};
         };
+        // phase H with every centre on an integer position (always, after the integer search and the propagation): the shared form below
+        bool lane_int = true;
+#pragma unroll
+        for (int l = 0; l < 4; ++l) lane_int = lane_int && (!act[l] || ((bx[l] | by[l]) & 3) == 0);
+        const bool h_shared = phase == 0 && __syncthreads_and(lane_int ? 1 : 0) != 0;
         if (phase < 0) {
             // R: the SADs of the four integer neighbours (above, below, left, right: sad4_c enc@0x47ae90's order) of the integer winner - plain rows, no filter
 #pragma unroll 1
@@ -255,6 +260,142 @@ __global__ __launch_bounds__(NC * 64, KS_SUBPEL_OCC) void me_subpel_kernel(KsGeo
         Item cur;
         int blk = wave;
         bool more = blk * 16 < nitems;
+        // measure of one candidate (this lane's two rows of it), summed over the item's four lanes, into the item's slot
+        auto finish = [&](const unsigned (&rw)[4], const ks_v4i &S, int slot, int ii) {
+            unsigned a = 0;
+            if (had) {
+                const ks_v4i B = {(int)(rw[0] ^ 0x80808080u), (int)(rw[1] ^ 0x80808080u), (int)(rw[2] ^ 0x80808080u), (int)(rw[3] ^ 0x80808080u)};
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) {
+                    ks_v4i C = __builtin_amdgcn_mfma_i32_16x16x64_i8(Hm[mb], B, mb == 0 ? Cin0 : CinN, 0, 0, 0);
+                    C = __builtin_amdgcn_mfma_i32_16x16x64_i8(Hm[mb], S, C, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) a = __builtin_amdgcn_sad_u16((unsigned)C[r], 0x8000u, a);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) a = __builtin_amdgcn_sad_u8(rw[r], (unsigned)S[r] ^ 0x7F7F7F7Fu, a);
+            }
+            a += (unsigned)__builtin_amdgcn_ds_swizzle((int)a, 0x1F | (16 << 10));
+            a += (unsigned)__shfl_xor((int)a, 32, 64);
+            if (gk == 0 && ii < nitems) s_sat[slot][ii] = (unsigned short)(had ? (a + 2) >> 2 : a);
+        };
+        if (h_shared) {
+            // ---- phase H around integer centres (round 5): the candidates at x - 1/2 and x + 1/2 are the SAME nine half-sample columns read one apart, those at y - 1/2 and
+            //      y + 1/2 the same rows read one apart, the integer column needs no horizontal filter and the integer row no vertical one.  Per item: 9 instead of 24 filtered
+            //      samples per input row, and per lane and column three vertically filtered rows (taps starting at its rows 2 gk, 2 gk + 1, 2 gk + 2) serve both y positions of both x
+            //      positions.  Every value is the one the general form computes (same taps, same rounding): the candidates' costs are unchanged.
+            auto request9 = [&](const Item &t) {
+                const uint8_t *hp = ref + (unsigned)((int)t.ro + (int)g.org_y + ((t.cy >> 2) - 4 + 2 * gk) * g.sy + (t.cx >> 2) - 1);
+                rsh = luma_hrow8_shift(hp);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) luma_hrow8_load(hp + j * g.sy, raw[j]);
+            };
+            // the half filter's taps as row-pair weights: an even start takes (c0 c1)(c2 c3)(c4 c5)(c6 c7), an odd one (0 c0)(c1 c2)(c3 c4)(c5 c6)(c7 0)
+            const unsigned E0[4] = {0x0004FFFFu, 0x0028FFF5u, 0xFFF50028u, 0xFFFF0004u};
+            const unsigned E1[5] = {0xFFFF0000u, 0xFFF50004u, 0x00280028u, 0x0004FFF5u, 0x0000FFFFu};
+            // three vertically filtered samples of one pixel column (row pairs p[0..4] = this lane's ten rows): taps starting at row 0, 1, 2
+            auto vert3 = [&](const unsigned (&p)[5], int (&o)[3]) {
+                int v0 = 2048, v1 = 2048, v2 = 2048;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    v0 = __builtin_amdgcn_sdot2(__builtin_bit_cast(ks_s16x2, E0[k]), __builtin_bit_cast(ks_s16x2, p[k]), v0, false);
+                    v2 = __builtin_amdgcn_sdot2(__builtin_bit_cast(ks_s16x2, E0[k]), __builtin_bit_cast(ks_s16x2, p[k + 1]), v2, false);
+                }
+#pragma unroll
+                for (int k = 0; k < 5; ++k) v1 = __builtin_amdgcn_sdot2(__builtin_bit_cast(ks_s16x2, E1[k]), __builtin_bit_cast(ks_s16x2, p[k]), v1, false);
+                o[0] = clip8(ks_no_pk(v0 >> 12)); o[1] = clip8(ks_no_pk(v1 >> 12)); o[2] = clip8(ks_no_pk(v2 >> 12));
+            };
+            if (more) { setup(blk, cur); request9(cur); }
+#pragma unroll 1
+            while (more) {
+                const int nblk = blk + NC;
+                const bool nmore = nblk * 16 < nitems;
+                Item nxt = cur;
+                const int ii = cur.ii;
+                const ks_v4i S = cur.S;
+                unsigned short *hx = &s_hx[wave][n16][0];                    // [pixel 0..8][row 0..15] of this item
+                unsigned Gp[2][8];                                            // the plain samples x 64 of this lane's four rows, row pairs (the integer column's "filtered" rows)
+#pragma unroll
+                for (int jp = 0; jp < 2; ++jp) {
+                    int h0[9], h1[9], g0[8], g1[8];
+                    luma_hrow9_half(raw[2 * jp], rsh, h0, g0);
+                    luma_hrow9_half(raw[2 * jp + 1], rsh, h1, g1);
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) *(unsigned *)&hx[i * 16 + 4 * gk + 2 * jp] = ((unsigned)h0[i] & 0xFFFFu) | ((unsigned)h1[i] << 16);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) Gp[jp][i] = (unsigned)g0[i] | ((unsigned)g1[i] << 16);
+                }
+                if (nmore) { setup(nblk, nxt); request9(nxt); }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                {
+                    // the half-sample columns: x - 1/2 = columns 0 .. 7, x + 1/2 = columns 1 .. 8; per column the three vertical samples and the two rows of the integer y position
+                    unsigned P[9][5];
+#pragma unroll
+                    for (int i = 0; i < 9; ++i)
+#pragma unroll
+                        for (int k = 0; k < 5; ++k) P[i][k] = ((const unsigned *)hx)[i * 8 + gk + k];
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the integer column overwrites the exchange area
+                    int va[9], vb[9], vc[9], ia[9], ib[9];                    // taps from row 0 / 1 / 2; integer y: rows 4, 5 of the ten (the pair P[.][2])
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) {
+                        int o[3];
+                        vert3(P[i], o);
+                        va[i] = o[0]; vb[i] = o[1]; vc[i] = o[2];
+                        ia[i] = clip8(ks_no_pk(((int)(short)(P[i][2] & 0xFFFFu) + 32) >> 6)); ib[i] = clip8(ks_no_pk(((int)P[i][2] >> 16) + 32 >> 6));
+                    }
+#pragma unroll
+                    for (int gx = 0; gx < 3; gx += 2) {
+                        const int o = gx >> 1;                                 // column offset 0 (x - 1/2) or 1 (x + 1/2)
+                        int r0[8], r1[8];
+                        unsigned rw[4];
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) { r0[i] = va[i + o]; r1[i] = vb[i + o]; }
+                        { const uint2 q0 = ks_pack_row8(r0), q1 = ks_pack_row8(r1); rw[0] = q0.x; rw[1] = q0.y; rw[2] = q1.x; rw[3] = q1.y; }
+                        finish(rw, S, 0 * 3 + gx, ii);                         // y - 1/2
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) { r0[i] = vb[i + o]; r1[i] = vc[i + o]; }
+                        { const uint2 q0 = ks_pack_row8(r0), q1 = ks_pack_row8(r1); rw[0] = q0.x; rw[1] = q0.y; rw[2] = q1.x; rw[3] = q1.y; }
+                        finish(rw, S, 2 * 3 + gx, ii);                         // y + 1/2
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) { r0[i] = ia[i + o]; r1[i] = ib[i + o]; }
+                        { const uint2 q0 = ks_pack_row8(r0), q1 = ks_pack_row8(r1); rw[0] = q0.x; rw[1] = q0.y; rw[2] = q1.x; rw[3] = q1.y; }
+                        finish(rw, S, 1 * 3 + gx, ii);                         // y
+                    }
+                }
+                {
+                    // the integer column: its rows through the same exchange, vertical half filter only (the centre itself is not a candidate of this phase unless the
+                    // Hadamard measure recomputes the start cost)
+#pragma unroll
+                    for (int jp = 0; jp < 2; ++jp)
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) *(unsigned *)&hx[i * 16 + 4 * gk + 2 * jp] = Gp[jp][i];
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    unsigned P[8][5];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+#pragma unroll
+                        for (int k = 0; k < 5; ++k) P[i][k] = ((const unsigned *)hx)[i * 8 + gk + k];
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the next block overwrites the exchange area
+                    int va[8], vb[8], vc[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { int o[3]; vert3(P[i], o); va[i] = o[0]; vb[i] = o[1]; vc[i] = o[2]; }
+                    unsigned rw[4];
+                    { const uint2 q0 = ks_pack_row8(va), q1 = ks_pack_row8(vb); rw[0] = q0.x; rw[1] = q0.y; rw[2] = q1.x; rw[3] = q1.y; }
+                    finish(rw, S, 0 * 3 + 1, ii);
+                    { const uint2 q0 = ks_pack_row8(vb), q1 = ks_pack_row8(vc); rw[0] = q0.x; rw[1] = q0.y; rw[2] = q1.x; rw[3] = q1.y; }
+                    finish(rw, S, 2 * 3 + 1, ii);
+                    if (!skip_centre) {
+                        int c0[8], c1[8];
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) { c0[i] = (int)(P[i][2] & 0xFFFFu) >> 6; c1[i] = (int)(P[i][2] >> 16) >> 6; }
+                        { const uint2 q0 = ks_pack_row8(c0), q1 = ks_pack_row8(c1); rw[0] = q0.x; rw[1] = q0.y; rw[2] = q1.x; rw[3] = q1.y; }
+                        finish(rw, S, 4, ii);
+                    }
+                }
+                cur = nxt; blk = nblk; more = nmore;
+            }
+        }
         if (more) { setup(blk, cur); request(cur, gx_first); }
 #pragma unroll 1
         while (more) {

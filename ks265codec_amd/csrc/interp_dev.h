@@ -64,6 +64,27 @@ __device__ __forceinline__ void luma_hrow8(const uint8_t *row, int tl, int th, i
     luma_hrow8_calc(a, luma_hrow8_shift(row), tl, th, h);
 }
 
+// The half-sample step around an INTEGER position x0 (me_subpel_kernel's phase H): the candidates at x0 - 1/2 and x0 + 1/2 are the same nine half samples, read one apart -
+// h[j] = the raw tap sum of the half sample between x0 - 1 + j and x0 + j (j = 0 .. 8), from the five dwords luma_hrow8_load(row = x0 - 1) fetched; g[i] = 64 x the plain sample
+// x0 + i (what the tap set {0 0 0 64 0 0 0 0} makes of it).  The same values luma_hrow8_calc returns for the three x positions, for 9 instead of 24 filtered samples.
+__device__ __forceinline__ void luma_hrow9_half(const unsigned (&a)[5], unsigned sh, int (&h)[9], int (&g)[8])
+{
+    const unsigned a0 = a[0] ^ 0x80808080u, a1 = a[1] ^ 0x80808080u, a2 = a[2] ^ 0x80808080u, a3 = a[3] ^ 0x80808080u, a4 = a[4] ^ 0x80808080u;
+    unsigned w[4];
+    w[0] = align_bytes(a1, a0, sh); w[1] = align_bytes(a2, a1, sh); w[2] = align_bytes(a3, a2, sh); w[3] = align_bytes(a4, a3, sh);   // bytes -3..0, 1..4, 5..8, 9..12 of the row pointer = samples x0 - 4 .. x0 + 11
+    const int tl = 0x28f504ff, th = (int)0xff04f528u;                                                                                       // {-1 4 -11 40} {40 -11 4 -1}
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int k = i >> 2, s = i & 3;
+        const unsigned lo = s ? align_bytes(w[k + 1], w[k], s) : w[k], hi = s ? align_bytes(w[k + 2], w[k + 1], s) : w[k + 1];
+        h[i] = __builtin_amdgcn_sdot4((int)hi, th, __builtin_amdgcn_sdot4((int)lo, tl, 8192, false), false);
+    }
+    h[8] = __builtin_amdgcn_sdot4((int)w[3], th, __builtin_amdgcn_sdot4((int)w[2], tl, 8192, false), false);
+    const unsigned u1 = w[1] ^ 0x80808080u, u2 = w[2] ^ 0x80808080u;                                                                        // samples x0 .. x0 + 3, x0 + 4 .. x0 + 7
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { g[i] = (int)(((u1 >> (8 * i)) & 255u) << 6); g[4 + i] = (int)(((u2 >> (8 * i)) & 255u) << 6); }
+}
+
 // 8 samples of one row, unfiltered (fx = 0)
 __device__ __forceinline__ void luma_row8(const uint8_t *row, int (&h)[8])
 {

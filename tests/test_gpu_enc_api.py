@@ -132,6 +132,37 @@ print(json.dumps({"md5": md.hexdigest(), "lanes": lanes}))
 """
 
 
+def test_pyramid_gops_run_on_two_lanes_by_default(tmp_path):
+    """round 5: the SDK's default GOP (hierarchical B, 8, slice-type decision) and -bframes 3 open two GOP lanes on one GPU by themselves; the stream is the one-lane stream
+    (KS265_GOP_LANES=1), the reference decoder takes it, -bframes 0 stays on one lane"""
+    from ks265codec_amd import stream
+    from ks265codec_amd.synth import make_clip
+    stream.build()
+    W, H, n, iper = 416, 240, 210, 48
+    clip = make_clip(W, H, 23, seed=78, abc=(17, 23, 9))
+    yuv = tmp_path / "in.yuv"
+    with open(yuv, "wb") as f:
+        for t in range(n):
+            f.write(clip[t % 23].tobytes())
+    env0 = {k: v for k, v in os.environ.items() if k != "KS265_GOP_LANES"}
+    for extra, tag in (([], "default"), (["-bframes", "3"], "b3")):
+        md5 = {}
+        for lanes in (None, 1):
+            out = tmp_path / f"{tag}_{lanes}.265"
+            r = subprocess.run([stream.CLI, "-i", str(yuv), "-wdt", str(W), "-hgt", str(H), "-fr", "50", "-preset", "slow", "-rc", "0", "-qp", "30", "-iper", str(iper), *extra,
+                                "-threads", "6", "-psnr", "1", "-b", str(out)], capture_output=True, text=True, env=dict(env0, **({"KS265_GOP_LANES": "1"} if lanes else {})))
+            assert r.returncode == 0 and f"Total Frames: {n}" in r.stdout and "H265 encoder passed!!!" in r.stdout, r.stdout[-500:] + r.stderr[-500:]
+            assert ("2 GOP lanes" in (r.stdout + r.stderr)) == (lanes is None), r.stdout[:600] + r.stderr[:600]
+            md5[lanes] = hashlib.md5(open(out, "rb").read()).hexdigest()
+        assert md5[None] == md5[1], (tag, md5)
+        if os.path.exists(REF_DEC):
+            d = subprocess.run([REF_DEC, "-b", str(tmp_path / f"{tag}_None.265"), "-o", str(tmp_path / "d.yuv"), "-threads", "2"], capture_output=True, text=True, cwd=tmp_path)
+            assert d.returncode == 0 and os.path.getsize(tmp_path / "d.yuv") == n * W * H * 3 // 2, d.stdout[-300:] + d.stderr[-300:]
+    r = subprocess.run([stream.CLI, "-i", str(yuv), "-wdt", str(W), "-hgt", str(H), "-fr", "50", "-preset", "slow", "-rc", "0", "-qp", "30", "-iper", str(iper), "-bframes", "0",
+                        "-threads", "6", "-frms", "60", "-b", str(tmp_path / "p.265")], capture_output=True, text=True, env=env0)
+    assert r.returncode == 0 and "GOP lanes" not in (r.stdout + r.stderr)
+
+
 @pytest.mark.parametrize("n,iper", [(1500, 300), (700, 64)])
 def test_gop_lanes_under_a_fast_caller(tmp_path, n, iper):
     """the caller feeds as fast as the API takes pictures (no file read in between): with GOPs longer than a lane's ring the lanes fill up completely, input
