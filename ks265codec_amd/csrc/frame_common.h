@@ -54,6 +54,7 @@ struct ks265_frame {
     uint8_t *qp_eff = nullptr;           // ... and the QpY of every 8x8 block as the decoder derives it (deblocking), w8 * h8 bytes, allocated on first use
     void *rec_fence = nullptr;               // event the next picture waits for before it writes a record (ks265_frame_set_records_fence); consumed by that picture
     void *rect = nullptr;                                  // cfg.part: the 2NxN / Nx2N records of the P picture being coded (KsRect, 21 per CTU)
+    int *ic_work = nullptr;                                // ... the CTUs that passed the candidates' gate: [0] = count, [4 ..] = CTU indices (round 5)
     uint32_t *icost = nullptr;                             // cfg.intra_inter: intra candidates of the P / B picture being coded (85 per CTU: cost << 6 | mode)
     uint8_t *pyr[10] = {};              // pre-search (cfg.pre_search): L1 / L2 of the source, L1 / L2 of the reference, L2 / L1 vectors, the 16x16 field, L3 of both, CTU window offsets
     // round 5: the two uni-directional searches of a B picture are independent chains of latency-bound kernels - list 1's runs on a side stream beside list 0's

@@ -567,20 +567,34 @@ __device__ __forceinline__ int intra_mode_bits(int mode) { return (mode == 0 || 
 // caller sets the array to 0xFFFFFFFF = "no candidate").  Gate: a CTU is evaluated only if one of its 8x8 PUs costs at
 // least what an intra CU costs before its first residual bit, lambda x KS_INTRA_GATE_BITS >> 4 (= the bias of the CU decision): where every 8x8 block is predicted
 // better than that, no block goes intra - most CTUs of a P / B picture leave here.
-#define KS_INTRA_GATE_BITS 96
 // (three waves per SIMD: 168 VGPRs with 33 spilled to scratch beat 207 VGPRs at two waves per SIMD - 205 -> 161 us for the candidates of a 2160p P picture; four waves
 //  per SIMD, 75 spills: 170 us)
-__global__ __launch_bounds__(256, 3) void intra_decide_kernel(KsGeom g, int lam, const uint8_t *src_y, ks265_cu8 *cu8, unsigned *cost_out, unsigned *best_out, const uint4 *gate_pu, unsigned nlev)
+#define KS_INTRA_GATE_BITS 96
+// the gate of the candidates (see intra_decide_kernel) as a kernel of its own, one wave per CTU: the CTUs that pass go into a list (work[0] = how many, work[4 ..] = which; any
+// order - every CTU's results are its own).  Round 5: the candidates kernel then finds its heavy work-groups at the FRONT of the grid instead of scattered over it (a work-group
+// that evaluates a level lives 50 - 70 us, one that leaves at the gate 2; with a tenth of the CTUs passing, the last heavy one started when the kernel could have ended)
+__global__ __launch_bounds__(256) void intra_gate_kernel(int nctu, int lam, const uint4 *gate_pu, int *work)
 {
+    const int lane = threadIdx.x & 63, ctu = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ctu >= nctu) return;
+    const unsigned c = gate_pu[(long)ctu * 85 + 21 + lane].z;                          // cost of 8x8 PU `lane`
+    const unsigned long long any = __ballot(c != KS_COST_INVALID && c >= (unsigned)((lam * KS_INTRA_GATE_BITS) >> 4));
+    if (lane == 0 && any) work[4 + atomicAdd(&work[0], 1)] = ctu;
+}
+
+__global__ __launch_bounds__(256, 3) void intra_decide_kernel(KsGeom g, int lam, const uint8_t *src_y, ks265_cu8 *cu8, unsigned *cost_out, unsigned *best_out, const uint4 *gate_pu, unsigned nlev,
+                                                                const int *work)
+{
+    if (work && (int)(blockIdx.x / nlev) >= work[0]) return;         // candidates: past the list of the CTUs that passed the gate
     __shared__ __attribute__((aligned(16))) DecideLds L;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lsel = gate_pu ? 1 + (int)(blockIdx.x % nlev) : 0;      // lsel: the one level this work-group handles (0 = all); nlev = 3, or 2: no 8x8 candidates
     // the modes by index: key pictures all 35; candidates planar, DC and every second angular mode (2, 4 .. 34: the oracle's INTRA_INTER_MODE_STEP - no measurable
     // loss against all 35)
     const int mi0 = 0, mi1 = gate_pu ? 19 : 35;
-    const int ctu = ks_xcd_swizzle(gate_pu ? (int)(blockIdx.x / nlev) : (int)blockIdx.x, g.ctu_cols * g.ctu_rows), cx = ctu % g.ctu_cols, cy = ctu / g.ctu_cols;
+    const int ctu = work ? work[4 + blockIdx.x / nlev] : ks_xcd_swizzle(gate_pu ? (int)(blockIdx.x / nlev) : (int)blockIdx.x, g.ctu_cols * g.ctu_rows), cx = ctu % g.ctu_cols, cy = ctu / g.ctu_cols;
     const uint8_t *S = ks_org_y(g, src_y);
-    if (gate_pu) {
+    if (gate_pu && !work) {
         __shared__ int s_go;
         if (tid < 64) {
             const unsigned c = gate_pu[(long)ctu * 85 + 21 + tid].z;                    // cost of 8x8 PU `tid`
@@ -739,7 +753,7 @@ extern "C" int ks265_intra_decide_ex(ks265_frame *f, ks265_pic src, ks265_cu8 *c
 {
     KS_FRAME_CHECK(f);
     if (!src.y || !cu8) return KS265_POINTER;
-    hipLaunchKernelGGL(intra_decide_kernel, dim3(f->g.ctu_cols * f->g.ctu_rows), dim3(256), 0, f->ctx->stream, f->g, f->cfg.lambda_q4, src.y, cu8, cost_out, (unsigned *)nullptr, (const uint4 *)nullptr, 3u);
+    hipLaunchKernelGGL(intra_decide_kernel, dim3(f->g.ctu_cols * f->g.ctu_rows), dim3(256), 0, f->ctx->stream, f->g, f->cfg.lambda_q4, src.y, cu8, cost_out, (unsigned *)nullptr, (const uint4 *)nullptr, 3u, (const int *)nullptr);
     return ks265_check_launch(f->ctx);
 }
 // cfg.intra_inter: the intra candidates of a P / B picture - per block (85 per CTU, PU indexing) cost << 6 | best mode, 0xFFFFFFFF where there is none (a CTU the
@@ -752,8 +766,15 @@ extern "C" int ks265_intra_candidates(ks265_frame *f, ks265_pic src, const void 
     const int nctu = f->g.ctu_cols * f->g.ctu_rows;
     if (hipMemsetAsync(dev_best, 0xFF, sizeof(uint32_t) * 85 * (size_t)nctu, f->ctx->stream) != hipSuccess) return ks265_hip(f->ctx, hipGetLastError());
     const unsigned nlev = f->cfg.intra_inter >= 2 ? 2u : 3u;        // intra_inter 2: 32x32 and 16x16 candidates only
+    if (!f->ic_work && !getenv("KS265_IC_SCATTERED")) {
+        if (hipMalloc((void **)&f->ic_work, sizeof(int) * ((size_t)nctu + 4)) != hipSuccess) return ks265_hip(f->ctx, hipGetLastError());
+    }
+    if (f->ic_work) {
+        if (hipMemsetAsync(f->ic_work, 0, 16, f->ctx->stream) != hipSuccess) return ks265_hip(f->ctx, hipGetLastError());
+        hipLaunchKernelGGL(intra_gate_kernel, dim3((nctu + 3) / 4), dim3(256), 0, f->ctx->stream, nctu, f->cfg.lambda_q4, (const uint4 *)dev_pu_records, f->ic_work);
+    }
     hipLaunchKernelGGL(intra_decide_kernel, dim3(nctu * nlev), dim3(256), 0, f->ctx->stream, f->g, f->cfg.lambda_q4, src.y, (ks265_cu8 *)nullptr, (unsigned *)nullptr, dev_best,
-                       (const uint4 *)dev_pu_records, nlev);
+                       (const uint4 *)dev_pu_records, nlev, (const int *)f->ic_work);
     return ks265_check_launch(f->ctx);
 }
 extern "C" int ks265_intra_decide(ks265_frame *f, ks265_pic src, ks265_cu8 *cu8) { return ks265_intra_decide_ex(f, src, cu8, nullptr); }

@@ -1,6 +1,6 @@
 #!/bin/bash
-# round 5, run s: me_subpel_kernel's phase H in its shared form: parity (every preset's knobs, configs, streams), kernel time
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r05/s; mkdir -p $O; cd $R
+# round 5, run s/t: kernel changes at the end of the round (phase H shared, candidates gate list): parity + kernel times
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r05/${RUN:-s}; mkdir -p $O; cd $R
 export TMPDIR=/tmp
 timeout 1200 python -m pytest tests/test_gpu_frame.py tests/test_gpu_golden.py tests/test_gpu_stream.py -q -m gpu -x 2>&1 | tail -6 > $O/pytest_s.txt
 timeout 1200 python -m pytest tests/test_gpu_configs.py -q -m gpu -x 2>&1 | tail -6 >> $O/pytest_s.txt
