@@ -573,10 +573,14 @@ __device__ __forceinline__ int intra_mode_bits(int mode) { return (mode == 0 || 
 // the gate of the candidates (see intra_decide_kernel) as a kernel of its own, one wave per CTU: the CTUs that pass go into a list (work[0] = how many, work[4 ..] = which; any
 // order - every CTU's results are its own).  Round 5: the candidates kernel then finds its heavy work-groups at the FRONT of the grid instead of scattered over it (a work-group
 // that evaluates a level lives 50 - 70 us, one that leaves at the gate 2; with a tenth of the CTUs passing, the last heavy one started when the kernel could have ended)
-__global__ __launch_bounds__(256) void intra_gate_kernel(int nctu, int lam, const uint4 *gate_pu, int *work)
+// It also does the memset the stage needed: every CTU's candidates start as "none".  (The list's counter is zeroed by a 16-byte memset in front of it: a ticket per
+// work-group of the candidates kernel - the last one to arrive resets the counter - cost 140 us of same-address atomics.)
+__global__ __launch_bounds__(256) void intra_gate_kernel(int nctu, int lam, const uint4 *gate_pu, int *work, unsigned *best_out)
 {
     const int lane = threadIdx.x & 63, ctu = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (ctu >= nctu) return;
+    best_out[(long)ctu * 85 + lane] = 0xFFFFFFFFu;
+    if (lane < 21) best_out[(long)ctu * 85 + 64 + lane] = 0xFFFFFFFFu;
     const unsigned c = gate_pu[(long)ctu * 85 + 21 + lane].z;                          // cost of 8x8 PU `lane`
     const unsigned long long any = __ballot(c != KS_COST_INVALID && c >= (unsigned)((lam * KS_INTRA_GATE_BITS) >> 4));
     if (lane == 0 && any) work[4 + atomicAdd(&work[0], 1)] = ctu;
@@ -764,17 +768,16 @@ extern "C" int ks265_intra_candidates(ks265_frame *f, ks265_pic src, const void 
     if (!src.y || !dev_pu_records || !dev_best) return KS265_POINTER;
     static_assert(sizeof(ks265_pu) == 16 && sizeof(ks265_pu_b) == 16 && offsetof(ks265_pu, cost) == 8 && offsetof(ks265_pu_b, cost) == 8, "the gate reads the cost of either record type at byte 8");
     const int nctu = f->g.ctu_cols * f->g.ctu_rows;
-    if (hipMemsetAsync(dev_best, 0xFF, sizeof(uint32_t) * 85 * (size_t)nctu, f->ctx->stream) != hipSuccess) return ks265_hip(f->ctx, hipGetLastError());
     const unsigned nlev = f->cfg.intra_inter >= 2 ? 2u : 3u;        // intra_inter 2: 32x32 and 16x16 candidates only
     if (!f->ic_work && !getenv("KS265_IC_SCATTERED")) {
         if (hipMalloc((void **)&f->ic_work, sizeof(int) * ((size_t)nctu + 4)) != hipSuccess) return ks265_hip(f->ctx, hipGetLastError());
-    }
-    if (f->ic_work) {
         if (hipMemsetAsync(f->ic_work, 0, 16, f->ctx->stream) != hipSuccess) return ks265_hip(f->ctx, hipGetLastError());
-        hipLaunchKernelGGL(intra_gate_kernel, dim3((nctu + 3) / 4), dim3(256), 0, f->ctx->stream, nctu, f->cfg.lambda_q4, (const uint4 *)dev_pu_records, f->ic_work);
     }
+    if (f->ic_work && hipMemsetAsync(f->ic_work, 0, 16, f->ctx->stream) != hipSuccess) return ks265_hip(f->ctx, hipGetLastError());
+    if (f->ic_work) hipLaunchKernelGGL(intra_gate_kernel, dim3((nctu + 3) / 4), dim3(256), 0, f->ctx->stream, nctu, f->cfg.lambda_q4, (const uint4 *)dev_pu_records, f->ic_work, dev_best);
+    else if (hipMemsetAsync(dev_best, 0xFF, sizeof(uint32_t) * 85 * (size_t)nctu, f->ctx->stream) != hipSuccess) return ks265_hip(f->ctx, hipGetLastError());
     hipLaunchKernelGGL(intra_decide_kernel, dim3(nctu * nlev), dim3(256), 0, f->ctx->stream, f->g, f->cfg.lambda_q4, src.y, (ks265_cu8 *)nullptr, (unsigned *)nullptr, dev_best,
-                       (const uint4 *)dev_pu_records, nlev, (const int *)f->ic_work);
+                       (const uint4 *)dev_pu_records, nlev, f->ic_work);
     return ks265_check_launch(f->ctx);
 }
 extern "C" int ks265_intra_decide(ks265_frame *f, ks265_pic src, ks265_cu8 *cu8) { return ks265_intra_decide_ex(f, src, cu8, nullptr); }
