@@ -29,4 +29,5 @@ cd $R
 timeout 150 python bench.py --leg hot --streams 1 --no-cpu-baseline 2>/dev/null | grep '^{' | tail -1 > $O/bench_line_hot_1stream.json
 timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 2>$O/bench_default.err | grep '^{' | tail -1 > $O/bench_line_default.json
 timeout 1500 python -m pytest tests -q -m gpu 2>&1 | tail -6 > $O/pytest_gpu.txt
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print(\"smoke ok\")" > $O/smoke.txt 2>&1; tail -2 $O/smoke.txt
 ls $O; head -c 700 $O/bench_line_default.json; echo; head -20 $O/kernel_stats_hot_1stream.txt | cut -c1-150; head -14 $O/kernel_stats_hier8_hot_1stream.txt | cut -c1-150; cat $O/hbm_traffic.txt | head -20; head -12 $O/sq_counters.txt | cut -c1-200; cat $O/pytest_gpu.txt
