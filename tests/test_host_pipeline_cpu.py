@@ -144,7 +144,23 @@ def test_device_error_word_sticks_until_the_next_key_picture(stub_lib, tmp_path,
     # from the first lost picture on (coding order) nothing goes out until a key picture, and from that key picture on everything does (how far the caller had run
     # ahead when the error was seen decides WHICH key picture: all pictures submitted by then fail)
     resumed = [p for p in order[first:] if p in set(r["pts"])]
-    if resumed:
+    if lanes > 1:
+        # GOPs are dealt to the lanes in turn and every lane recovers at ITS next key picture: a GOP goes out whole, or up to the picture where its lane saw the error and
+        # nothing after it (how far the caller had run ahead decides how many of that lane's GOPs are hit); GOPs of the other lanes are not touched; output stays in stream order
+        got = r["pts"]
+        by_gop = {}
+        for p in order:
+            by_gop.setdefault(p // 32, []).append(p)
+        pos = 0
+        for g in sorted(by_gop):
+            mine = [p for p in got if p // 32 == g]
+            assert mine == by_gop[g][:len(mine)], (g, mine[:6], by_gop[g][:6])
+            assert got[pos:pos + len(mine)] == mine, "GOPs out of stream order"
+            pos += len(mine)
+        hit = [g for g in by_gop if len([p for p in got if p // 32 == g]) < len(by_gop[g])]
+        assert hit and all(g % lanes == hit[0] % lanes for g in hit), hit                   # one lane's GOPs only
+        assert len([p for p in got if p // 32 == max(by_gop)]) == len(by_gop[max(by_gop)]) or max(by_gop) % lanes == hit[0] % lanes
+    elif resumed:
         assert resumed[0] % 32 == 0, resumed[:4]
         k = order.index(resumed[0])
         assert order[k:] == r["pts"][len(r["pts"]) - len(order[k:]):], "the stream is not whole after the restart"
