@@ -92,6 +92,10 @@ def main():
     if args.hier_b < 0:
         args.hier_b = 8 if args.both_gops else 0
 
+    # GOP lanes (the encoder host's default for the pyramid GOPs: two closed GOPs side by side on the one GPU) need more than the runtime's four hardware queues - with four,
+    # two lanes' streams share queues and code 561 pictures/s where eight give 700.  The library sets this itself when it opens several lanes, which only works if the HIP
+    # runtime has not started; here torch (and, with several ranks, RCCL) starts it first - so it is set before anything touches the runtime.  A value the user set stays.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import torch
     from ks265codec_amd.lib import KsContext, KsFrame
     from ks265codec_amd.synth import host_qp_offset, lambda_q4, make_clip
