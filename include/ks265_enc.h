@@ -100,7 +100,7 @@ typedef struct { long frames; long long bytes; double sse[3]; double gpu_ms; dou
 } ks265_enc_stats;
 int ks265_enc_get_stats(void *pEncoder, ks265_enc_stats *out);
 /* extension: closed GOPs coded concurrently by this handle ("GOP lanes": KS265_GOP_LANES = 2..4 with enFrameParallel, -rc 0, key period >= 32, any GOP structure;
- * default: 2 for the pyramid GOPs - the SDK's default GOP and -bframes 3 - on one GPU (round 5: their B pictures leave the device under-filled, two closed GOPs side by side
+ * default: 2 for the pyramid GOPs - the SDK's default GOP and -bframes 3 - on one GPU with -rc 0 / -rc 3, where lanes leave the stream as it is (round 5: their B pictures leave the device under-filled, two closed GOPs side by side
  * code 700 pictures/s where one codes 631 at 2160p), 1 otherwise; KS265_GOP_LANES=1 switches it off).  Output stays in stream order and is byte for byte the one-lane stream;
  * it lags the input by up to that many GOPs, and every lane buffers a GOP of input (pinned host memory + a device twin per picture, capped by KS265_PINNED_MB per lane). */
 int ks265_enc_lanes(void *pEncoder);

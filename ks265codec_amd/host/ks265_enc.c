@@ -1931,7 +1931,8 @@ static int top_lanes_wanted(const QY265EncConfig *cfg, int ndev)
      * side by side code 700 pictures/s where one codes 631 (2160p, same stream; IPPP loses with lanes - 970 -> 890 - and stays at one).  KS265_GOP_LANES=1 switches it off */
     const int gop_b = cfg->bframes < 0 ? (cfg->latency == QY265LATENCY_DEFAULT ? 7 : 0) : cfg->bframes;        /* (as lane_open resolves it) */
     const int pyramid = gop_b == 7 || gop_b == 3;
-    int per = env ? atoi(env) : pyramid && ndev == 1 ? 2 : 1;       /* (several GPUs behind one handle: the calling thread feeds them all - one lane each unless asked) */
+    /* (several GPUs behind one handle: the calling thread feeds them all - one lane each unless asked; -rc 1 / 2 / 4: lanes change the stream - a controller per lane - so only when asked) */
+    int per = env ? atoi(env) : pyramid && ndev == 1 && (cfg->rc == 0 || cfg->rc == 3) ? 2 : 1;
     if (per < 1) per = 1;
     int n = per * ndev;
     if (n > MAX_LANES) n = MAX_LANES;
