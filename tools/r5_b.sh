@@ -3,7 +3,7 @@
 # hot-leg kernel traces and rates, the encoded leg
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r05/b; mkdir -p $O; cd $R
 export TMPDIR=/tmp
-timeout 300 python scratch/me_trace.py scratch/v/libks265hip_trace.so > $O/me_trace.txt 2>&1
+timeout 300 python tools/me_trace.py build/variants/libks265hip_trace.so > $O/me_trace.txt 2>&1
 timeout 900 python -m pytest tests/test_gpu_configs.py tests/test_gpu_frame.py tests/test_gpu_stream.py -q -m gpu -x 2>&1 | tail -6 > $O/pytest_b.txt
 for mode in par ser; do
   if [ $mode = ser ]; then export KS265_B_SERIAL=1; else unset KS265_B_SERIAL; fi

@@ -4,7 +4,7 @@ R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r05/c; mkdir -p $O; cd $R
 export TMPDIR=/tmp
 timeout 600 python -m pytest tests/test_gpu_rdoq.py -q -m gpu 2>&1 | tail -30 > $O/pytest_rdoq.txt
 timeout 900 python -m pytest tests/test_gpu_configs.py tests/test_gpu_frame.py -q -m gpu -x 2>&1 | tail -6 > $O/pytest_c.txt
-timeout 300 python scratch/me_trace.py scratch/v/libks265hip_trace.so > $O/me_trace.txt 2>&1
+timeout 300 python tools/me_trace.py build/variants/libks265hip_trace.so > $O/me_trace.txt 2>&1
 cd /tmp
 timeout 200 rocprofv3 --kernel-trace --stats -d $O/kt_hot1 -o kt -- python $R/bench.py --leg hot --streams 1 --steps 40 --no-cpu-baseline > $O/hot1.json 2>/dev/null
 python $R/tools/rocpd_stats.py $O/kt_hot1/kt_results.db > $O/kernel_stats_hot_1stream.txt; rm -rf $O/kt_hot1
