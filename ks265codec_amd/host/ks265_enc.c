@@ -14,6 +14,7 @@
 #define _GNU_SOURCE
 #include "ks265_enc.h"
 #include "ks265_stream.h"
+#include <dirent.h>
 #include <fcntl.h>
 #include <math.h>
 #include <pthread.h>
@@ -1924,6 +1925,24 @@ static int top_devices(int dev[MAX_LANES])
     if (!n) dev[n++] = one ? atoi(one) : 0;
     return n;
 }
+/* has this process opened the GPU driver yet (an fd on /dev/kfd)?  The HIP runtime reads GPU_MAX_HW_QUEUES once, when it starts: a process that has used the runtime
+ * before the encoder opens (torch, RCCL) keeps the four hardware queues it started with whatever is exported now */
+static int gpu_runtime_started(void)
+{
+    DIR *d = opendir("/proc/self/fd");
+    if (!d) return 0;
+    int yes = 0;
+    struct dirent *en;
+    while (!yes && (en = readdir(d))) {
+        char path[288], to[64];
+        if (en->d_name[0] == '.') continue;
+        snprintf(path, sizeof path, "/proc/self/fd/%s", en->d_name);
+        const ssize_t n = readlink(path, to, sizeof to - 1);
+        if (n > 0) { to[n] = 0; if (!strcmp(to, "/dev/kfd")) yes = 1; }
+    }
+    closedir(d);
+    return yes;
+}
 static int top_lanes_wanted(const QY265EncConfig *cfg, int ndev)
 {
     const char *env = getenv("KS265_GOP_LANES");
@@ -1933,6 +1952,16 @@ static int top_lanes_wanted(const QY265EncConfig *cfg, int ndev)
     const int pyramid = gop_b == 7 || gop_b == 3;
     /* (several GPUs behind one handle: the calling thread feeds them all - one lane each unless asked; -rc 1 / 2 / 4: lanes change the stream - a controller per lane - so only when asked) */
     int per = env ? atoi(env) : pyramid && ndev == 1 && (cfg->rc == 0 || cfg->rc == 3) ? 2 : 1;
+    if (!env && per > 1) {
+        /* two lanes need more than the runtime's four hardware queues (measured: 561 pictures/s with four, one lane 632, two lanes with eight 700): the library exports
+         * GPU_MAX_HW_QUEUES=8 when it opens several lanes, which takes effect only if the runtime has not started - a process that is already on the GPU and did not export
+         * it itself stays on one lane */
+        const char *q = getenv("GPU_MAX_HW_QUEUES");
+        if (q ? atoi(q) < 8 : gpu_runtime_started()) {
+            logf_(1, cfg->logLevel, "ks265enc: one GOP lane (two would be the default for this GOP, but this process runs the GPU runtime with %s hardware queues: export GPU_MAX_HW_QUEUES=8 before its first use)\n", q ? q : "its default four");
+            per = 1;
+        }
+    }
     if (per < 1) per = 1;
     int n = per * ndev;
     if (n > MAX_LANES) n = MAX_LANES;
