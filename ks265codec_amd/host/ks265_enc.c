@@ -176,6 +176,7 @@ int QY265ConfigParse(QY265EncConfig *c, const char *name, const char *value)
 #define MAX_DPB 18
 #define MAX_JOBS 128                                      /* upper bound of the ring of pictures in flight; the encoder sizes its ring (Enc::ring) by picture size */
 typedef struct TopWake { pthread_mutex_t mu; pthread_cond_t cv; unsigned long seq; } TopWake;
+#undef MAX_INPUT                                         /* (<dirent.h> brings the terminal limit of that name along) */
 #define MAX_INPUT (MAX_JOBS + 32 + 256)                /* input slots: the ring + a mini-GOP (+ in a GOP lane: a whole GOP of the next round, Enc::nin) */
 
 typedef struct Job {
