@@ -435,7 +435,8 @@ int ks265_intra_decide_ex(ks265_frame *, ks265_pic src, ks265_cu8 *dev_cu8, uint
  * KS265_NOTSUPPORTED. */
 int ks265_lookahead_reduce(ks265_frame *, const uint32_t *dev_intra_cost, const ks265_pu *dev_pu, uint64_t *dev_out);
 int ks265_lookahead_picture(ks265_frame *, ks265_pic cur_lowres, ks265_pic ref_lowres, uint32_t *dev_cost_ws /* nctu x 85 */, uint64_t *dev_out);
-/* cur against another reference, with the intra costs the ks265_lookahead_picture call for cur left in dev_cost_ws (search + sums only) */
+/* cur against another reference, with the intra costs the ks265_lookahead_picture call for cur left in dev_cost_ws (search + sums only).  dev_cost_ws = NULL: no intra
+ * costs - dev_out[1] (the search's sum) as always, dev_out[0] = dev_out[2] = the same (the host's slice-type decision reads dev_out[1] alone; ks265_lookahead_reduce likewise) */
 int ks265_lookahead_inter(ks265_frame *, ks265_pic cur_lowres, ks265_pic ref_lowres, const uint32_t *dev_cost_ws, uint64_t *dev_out);
 int ks265_intra_reconstruct(ks265_frame *, ks265_pic src, ks265_cu8 *dev_cu8, int16_t *dev_lvl_y, int16_t *dev_lvl_u, int16_t *dev_lvl_v, ks265_pic recon);
 /* Stage E: in-place deblocking of a reconstructed picture (CalcBsInterP enc@0x402960, ctuDeblockFilterVer

@@ -791,7 +791,7 @@ __global__ __launch_bounds__(256) void lookahead_reduce_kernel(long nctu, const 
     unsigned long long v[4] = {0, 0, 0, 0};
     if (i < nctu * 64) {
         const long k = (i >> 6) * 85 + 21 + (i & 63);
-        const unsigned a = intra_cost[k], b = pu[k].cost;
+        const unsigned b = pu[k].cost, a = intra_cost ? intra_cost[k] : b;      // (no intra costs: the sums of the search alone - a block's two costs are valid together, inside the picture)
         if (a != KS_COST_INVALID && b != KS_COST_INVALID) { v[0] = a; v[1] = b; v[2] = min(a, b); v[3] = 1ull | ((unsigned long long)(a < b) << 32); }
     }
 #pragma unroll
@@ -805,7 +805,7 @@ __global__ __launch_bounds__(256) void lookahead_reduce_kernel(long nctu, const 
 extern "C" int ks265_lookahead_reduce(ks265_frame *f, const uint32_t *intra_cost, const ks265_pu *pu, uint64_t *out)
 {
     KS_FRAME_CHECK(f);
-    if (!intra_cost || !pu || !out) return KS265_POINTER;
+    if (!pu || !out) return KS265_POINTER;
     const long nctu = (long)f->g.ctu_cols * f->g.ctu_rows;
     if (hipMemsetAsync(out, 0, 32, f->ctx->stream) != hipSuccess) return ks265_hip(f->ctx, hipGetLastError());
     hipLaunchKernelGGL(lookahead_reduce_kernel, dim3((unsigned)((nctu * 64 + 255) / 256)), dim3(256), 0, f->ctx->stream, nctu, intra_cost, pu, (unsigned long long *)out);
@@ -825,11 +825,12 @@ extern "C" int ks265_lookahead_picture(ks265_frame *f, ks265_pic cur, ks265_pic 
 }
 
 // the same picture against another reference: its intra costs are in cost_ws from the ks265_lookahead_picture call before (one intra pass per picture; the
-// slice-type decision compares a picture with the pictures 1, 4 and 8 back)
+// slice-type decision compares a picture with the pictures 1, 4 and 8 back).  cost_ws = null (round 5): no intra costs at all - out[1] = the search's sum as always,
+// out[0] = out[2] = the same, no block counted as intra-cheaper: what the slice-type decision alone needs (it reads out[1]), without the 0.3 ms intra pass
 extern "C" int ks265_lookahead_inter(ks265_frame *f, ks265_pic cur, ks265_pic ref, const uint32_t *cost_ws, uint64_t *out)
 {
     KS_FRAME_CHECK(f);
-    if (!cur.y || !ref.y || !cost_ws || !out) return KS265_POINTER;
+    if (!cur.y || !ref.y || !out) return KS265_POINTER;
     int r;
     if ((r = ks265_me_integer(f, cur, ref, nullptr, f->pu[f->cur_pu]))) return r;
     return ks265_lookahead_reduce(f, cost_ws, f->pu[f->cur_pu], out);

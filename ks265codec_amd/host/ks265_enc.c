@@ -1583,10 +1583,11 @@ static int la_take_locked(Enc *e, Input *slot)
             what |= 1;
         }
         if (!r && e->mg_adapt && p >= 4 && (p & 3) == 0) {
-            /* (-lookahead N: the picture's intra costs are in la_cost_ws from the call above - search + sums only; auto: the intra pass runs here, once per grid picture) */
-            r = e->la_auto ? ks265_lookahead_picture(e->frame_la, e->la_pic[c], e->la_pic[(nd - 4) % LA_RING], e->la_cost_ws, dout + 4)
-                           : ks265_lookahead_inter(e->frame_la, e->la_pic[c], e->la_pic[(nd - 4) % LA_RING], e->la_cost_ws, dout + 4);
-            if (!r && (p & 7) == 0) r = ks265_lookahead_inter(e->frame_la, e->la_pic[c], e->la_pic[(nd - 8) % LA_RING], e->la_cost_ws, dout + 8);
+            /* (-lookahead N: the picture's intra costs are in la_cost_ws from the call above - search + sums only; auto: NO intra pass since round 5 - the slice-type decision
+             *  reads the searches' sums alone (la_decide: out[5], out[9]), and the pass was 0.3 ms per grid picture = 6 % of the device's time with the default GOP) */
+            const uint32_t *ws = e->la_auto ? NULL : e->la_cost_ws;
+            r = ks265_lookahead_inter(e->frame_la, e->la_pic[c], e->la_pic[(nd - 4) % LA_RING], ws, dout + 4);
+            if (!r && (p & 7) == 0) r = ks265_lookahead_inter(e->frame_la, e->la_pic[c], e->la_pic[(nd - 8) % LA_RING], ws, dout + 8);
             what |= 2;
         }
         if (!r && what) r = ks265_memcpy_d2h_async(e->ctx_la, e->la_host_out + 16 * buf, dout, 96);
