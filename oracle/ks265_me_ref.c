@@ -261,14 +261,15 @@ int kso_me_replay(int method, const uint8_t *fenc, int log2w, int log2h, const u
  * The mvd cost of a quarter-pel difference d: the table tME+0x10 holds for |d| <= 256 (enc@0x48b220, 0x48b263); beyond it the function
  * computes lambda x (3 + 2 floor(log2 |d|)) in a loop (enc@0x48b22c..0x48b24e, 0x48b4c0..0x48b4dd), the product taken on the 16-bit count. */
 static int clamp_s16(int v, int lo, int hi) { return (int16_t)v < (int16_t)lo ? lo : ((int16_t)v <= (int16_t)hi ? v : hi); }   /* enc@0x48afce..0x48b02f: 16-bit signed compares */
-static uint32_t init_mvd_cost(const kso_me_init *m, int d)
+uint32_t kso_ref_mvd_cost_far(const uint16_t *base, int lambda, int d)
 {
     int a = d < 0 ? -d : d;
-    if (a <= 0x100) return m->base[d];
+    if (a <= 0x100) return base[d];
     int n = 1;
     for (a *= 2; ; ) { a >>= 1; n += 2; if (a == 1) break; }
-    return (uint32_t)((uint16_t)n * m->lambda);
+    return (uint32_t)((uint16_t)n * lambda);
 }
+static uint32_t init_mvd_cost(const kso_me_init *m, int d) { return kso_ref_mvd_cost_far(m->base, m->lambda, d); }
 static long init_off(const kso_me_init *m, int x, int y) { return (long)((m->puy + y) * m->stride) + (m->pux + x); }   /* 32-bit product, enc@0x48b072 / 0x48ae7f */
 /* checkLayerMv enc@0x48ad80: one more candidate (quarter-pel v) against the best so far; seen[] = the two packed AMVP start points */
 static void init_check(kso_me_init *m, const int v[2], const uint32_t seen[2])

@@ -61,6 +61,8 @@ typedef struct {
     int prev_on_out, prev_out[2], cmx_off, cmy_off;   /* TPredUnit+0x1f2+l / +0x1f4+4l after; tME+0x18 / +0x20 - tME+0x10          */
 } kso_me_init;
 void kso_ref_me_init_point(kso_me_init *m);
+/* the cost of a quarter-pel difference d as meInitPoint prices a start point outside its window: base[d] for |d| <= 256, else lambda x (3 + 2 floor(log2 |d|)) */
+uint32_t kso_ref_mvd_cost_far(const uint16_t *base, int lambda, int d);
 /* trace replay (tests/test_me_init.py): h = the 64-word record oracle/ref_probe/init_shim.c writes, tab513 = base[-256..256].  The block comparisons are
  * answered from the record, in order; -1 if the restatement asks for one the reference did not make (or fewer), else 0 and out[] = the results. */
 int kso_me_init_replay(const int32_t h[64], const uint16_t *tab513, int32_t out[20]);

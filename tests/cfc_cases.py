@@ -1,0 +1,129 @@
+"""calcFrameCost enc@0x4a7410 / cuTree finish enc@0x480964: the ctypes mirror of kso_cfc (oracle/ks265_lookahead_ref.h) and the replay of one recorded call.
+TEST INFRASTRUCTURE: used by tests/test_calc_frame_cost.py, tests/test_gpu_lookahead_ops.py and oracle/ref_probe/gen_cfc_traces.py (which writes tests/golden/calc_frame_cost.npz)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "calc_frame_cost.npz")
+CFG_WORDS = ("merange", "lg", "zero_thr", "fast_intra", "scenecut", "preset", "p8", "aq", "b_intra", "f3a8", "f36c", "f538", "f3b4")
+ARR = (("intra", np.uint16, 1), ("imode", np.uint8, 1), ("invq", np.uint16, 1), ("inter", np.uint16, 1), ("bits", np.uint8, 0), ("mv0", np.int32, 1), ("c0", np.int32, 1), ("mv1", np.int32, 1), ("c1", np.int32, 1))
+
+
+class KsoCfc(C.Structure):
+    _fields_ = [("cur", C.c_void_p), ("ref0", C.c_void_p), ("ref1", C.c_void_p), ("stride", C.c_int),
+                ("w", C.c_int), ("h", C.c_int), ("nx", C.c_int), ("ny", C.c_int), ("cnt", C.c_int),
+                ("d0", C.c_int), ("d1", C.c_int), ("flag", C.c_int), ("slice_type", C.c_int),
+                *[(n, C.c_int) for n in CFG_WORDS],
+                ("lambda_tab", C.c_void_p), ("do_list", C.c_int * 2), ("intra_done", C.c_int),
+                ("intra", C.c_void_p), ("imode", C.c_void_p), ("invq", C.c_void_p), ("inter", C.c_void_p), ("bits", C.c_void_p),
+                ("mv", C.c_void_p * 2), ("cost", C.c_void_p * 2),
+                ("intra_wins", C.c_int32), ("sum_intra", C.c_int32), ("sum_intra_aq", C.c_int32), ("sum", C.c_int32), ("sum_aq", C.c_int32), ("stats", C.c_int32 * 4),
+                ("ret", C.c_int), ("margin_x", C.c_int), ("margin_y", C.c_int), ("oob", C.c_int), ("table_oob", C.c_int)]
+
+
+BITS = None
+
+
+
+
+def set_bits_table(o):
+    global BITS
+    o.kso_mvd_bits.restype = C.c_int
+    BITS = np.array([o.kso_mvd_bits(d) for d in range(-4096, 4097)], np.int64)
+
+
+def replay_call(o, r, planes=None):
+    """run the oracle on one recorded call; planes: optional dict name -> array (fixture replay)"""
+    from oracle_lib import ptr
+    h = r["h"]
+    w, hh, nx, ny = (int(v) for v in h[7:11]); d0, d1 = int(h[3]), int(h[4])
+    mx, my = int(h[34]), int(h[35]); stride = w + 2 * mx
+    c = KsoCfc()
+    keep = []
+    for k in ("cur", "ref0", "ref1"):
+        a = np.ascontiguousarray(r[k]); keep.append(a)
+        setattr(c, k, a.ctypes.data + my * stride + mx if a.size > 1 else None)
+    c.stride = stride; c.w, c.h, c.nx, c.ny, c.cnt = w, hh, nx, ny, int(h[11])
+    c.d0, c.d1, c.flag, c.slice_type = d0, d1, int(h[5]), int(h[17])
+    for i, n in enumerate(("merange", "lg", "zero_thr", "fast_intra", "scenecut", "preset", "p8", "aq", "b_intra", "f3a8", "f36c", "f538", "f3b4")):
+        setattr(c, n, int(h[18 + i]))
+    c.lambda_tab = r["lam"].ctypes.data; c.do_list[0], c.do_list[1] = int(h[32]), int(h[33]); c.intra_done = int(h[12])
+    st = {name: r["b_" + name].copy() for name, _, _ in ARR}
+    c.intra, c.imode, c.invq, c.inter, c.bits = (st[k].ctypes.data for k in ("intra", "imode", "invq", "inter", "bits"))
+    c.mv[0], c.mv[1], c.cost[0], c.cost[1] = st["mv0"].ctypes.data, st["mv1"].ctypes.data, st["c0"].ctypes.data, st["c1"].ctypes.data
+    c.intra_wins, c.sum_intra, c.sum_intra_aq = int(h[36]), int(h[37]), int(h[38])
+    c.sum, c.sum_aq = int(h[39]), int(h[40])
+    for i in range(4):
+        c.stats[i] = int(h[46 + i])
+    c.margin_x, c.margin_y = mx, my
+    # the recorded table must be what the oracle builds from the lambda table: row q = lambda(q) x bits(d)
+    m_row = int(h[56]); assert m_row == 8 * int(h[18]) + 33
+    f = 12 * m_row + m_row // 2 + np.arange(-1024, 1025)
+    ok = (f >= 0) & (f // m_row < 52)
+    exp = np.where(ok, r["lam"][np.clip(f // m_row, 0, 51)].astype(np.int64) * BITS[(f % m_row - m_row // 2) + 4096], 0xffff).astype(np.uint16)
+    bad = []
+    if not (r["tab"] == exp).all():
+        bad.append("table")
+    o.kso_ref_calc_frame_cost(C.byref(c))
+    if c.oob:
+        return ["oob"]
+    idx = d0 * 9 + d1
+    for name, _, _ in ARR:
+        if name == "invq":
+            continue
+        if not (st[name] == r["a_" + name]).all():
+            bad.append(f"{name}:{int((st[name] != r['a_' + name]).sum())}")
+    got = [c.intra_wins, c.sum_intra, c.sum_intra_aq, c.sum if idx else c.sum_intra, c.sum_aq if idx else c.sum_intra_aq]
+    if got != [int(v) for v in h[41:46]]:
+        bad.append(f"sums {got} != {[int(v) for v in h[41:46]]}")
+    if [c.stats[i] for i in range(4)] != [int(v) for v in h[50:54]]:
+        bad.append(f"stats {[c.stats[i] for i in range(4)]} != {[int(v) for v in h[50:54]]}")
+    if c.ret != int(h[6]):
+        bad.append(f"ret {c.ret} != {int(h[6])}")
+    if c.intra_done != int(h[13]):
+        bad.append("intra_done")
+    if c.table_oob:
+        bad.append(f"(table_oob {c.table_oob})")
+    return bad
+
+
+def replay_finish(o, r):
+    from oracle_lib import ptr
+    h = r["h"]
+    if not h[5]:                                      # not a reference picture: the offsets are the AQ offsets (or zero)
+        return bool((r["out"] == (r["aq"] if h[12] else 0)).all())
+    out = np.full(int(h[11]), np.nan)
+    dbl = int(bool(h[8]) and h[6] == 0)
+    o.kso_ref_cutree_finish(int(h[11]), ptr(r["intra"]), ptr(r["invq"]), ptr(r["prop"]), ptr(r["aq"]), dbl, ptr(out))
+    m = ~np.isnan(out)
+    return bool((out[m] == r["out"][m]).all())
+
+
+
+def load_fixture():
+    """the fixture as the list of call records / finish records gen_cfc_traces.parse() returns"""
+    z = np.load(GOLD)
+    hdr, plane_of = z["hdr"], z["plane_of"]
+    ends = np.cumsum(z["plane_len"]); starts = ends - z["plane_len"]
+    pdata = z["plane_data"]
+    plane = lambda i: pdata[starts[i]:ends[i]] if i >= 0 else np.zeros(1, np.uint8)
+    calls, pos = [], {t + n: 0 for t in ("b_", "a_") for n, _, _ in ARR}
+    for i, h in enumerate(hdr):
+        n = int(h[9]) * int(h[10])
+        r = dict(h=h, lam=z["lam"][i], tab=z["tab"][i], run=int(z["run"][i]), cur=plane(plane_of[i][0]), ref0=plane(plane_of[i][1]), ref1=plane(plane_of[i][2]))
+        for t in ("b_", "a_"):
+            for name, _, per in ARR:
+                cnt = n if per else (n + 3) // 4
+                r[t + name] = z[t + name][pos[t + name]:pos[t + name] + cnt]; pos[t + name] += cnt
+        calls.append(r)
+    fin, fp = [], dict(intra=0, invq=0, prop=0, aq=0, out=0)
+    for h in z["fin_hdr"]:
+        n, cnt = int(h[9]) * int(h[10]), int(h[11])
+        r = dict(h=h)
+        for k, c in (("intra", n), ("invq", n), ("prop", n), ("aq", cnt), ("out", cnt)):
+            r[k] = np.ascontiguousarray(z["fin_" + k][fp[k]:fp[k] + c]); fp[k] += c
+        fin.append(r)
+    return [str(x) for x in z["runs"]], calls, fin
