@@ -58,7 +58,7 @@ EXPORTS = [
     "ks265_edge_filter_luma_batch", "ks265_edge_filter_chroma_batch", "ks265_interp_rect",
     "ks265_sao_apply_bo_rect", "ks265_sao_apply_eo_rect", "ks265_sao_stats_batch", "ks265_intra_pred_batch", "ks265_intra_filter_ref_batch",
     "ks265_downsample_rect", "ks265_downsample_from_host", "ks265_weight_bi_sad_batch", "ks265_ac_energy_batch", "ks265_ac_energy_map",
-    "ks265_frame_reset_prediction", "ks265_frame_records_layout", "ks265_frame_pack_records", "ks265_frame_compact_layout", "ks265_frame_pack_compact", "ks265_frame_pack_compact_on", "ks265_frame_adapt_quant", "ks265_aq_ctu_map", "ks265_cutree_propagate", "ks265_frame_set_records_fence", "ks265_load_i420_on", "ks265_sse_picture_on", "ks265_copy_out_compact_async", "ks265_copy_out_compact_dma_async", "ks265_frame_geometry", "ks265_frame_create", "ks265_frame_destroy", "ks265_frame_set_qp", "ks265_frame_set_qp_map", "ks265_pad_picture",
+    "ks265_frame_reset_prediction", "ks265_frame_records_layout", "ks265_frame_pack_records", "ks265_frame_compact_layout", "ks265_frame_pack_compact", "ks265_frame_pack_compact_on", "ks265_frame_adapt_quant", "ks265_aq_ctu_map", "ks265_cutree_propagate", "ks265_calc_frame_cost", "ks265_calc_frame_cost_workspace", "ks265_cutree_finish", "ks265_frame_set_records_fence", "ks265_load_i420_on", "ks265_sse_picture_on", "ks265_copy_out_compact_async", "ks265_copy_out_compact_dma_async", "ks265_frame_geometry", "ks265_frame_create", "ks265_frame_destroy", "ks265_frame_set_qp", "ks265_frame_set_qp_map", "ks265_pad_picture",
     "ks265_load_i420", "ks265_store_i420", "ks265_presearch", "ks265_me_integer", "ks265_me_propagate", "ks265_me_subpel", "ks265_cu_decide_part", "ks265_cu_decide_part_b", "ks265_merge_pass", "ks265_cu_decide",
     "ks265_cu_flat_intra", "ks265_intra_decide", "ks265_intra_decide_ex", "ks265_lookahead_reduce", "ks265_lookahead_picture", "ks265_lookahead_inter", "ks265_intra_reconstruct", "ks265_reconstruct", "ks265_reconstruct_b", "ks265_bi_decide", "ks265_bi_refine_chosen", "ks265_bi_full_batch", "ks265_capture_begin", "ks265_capture_end", "ks265_graph_launch", "ks265_graph_destroy", "ks265_frame_p_state", "ks265_frame_p_advance", "ks265_frame_p_restore", "ks265_cu_decide_b", "ks265_deblock", "ks265_sao",
     "ks265_encode_picture", "ks265_encode_picture_b", "ks265_encode_picture_mref", "ks265_encode_picture_b_mref", "ks265_ref_pick", "ks265_ref_decide", "ks265_reconstruct_mref",
@@ -283,12 +283,33 @@ class KsContext:
         """cuTreePropagate enc@0x47d460 on device arrays (ref0 / ref1 updated in place; acc: 2 * nx * ny zeroed uint64, left zero)"""
         self._chk(self.lib.ks265_cutree_propagate(self.h, C.c_int(lg), C.c_int(nx), C.c_int(ny), _p(intra), _p(invq), _p(own), _p(inter), _p(bits), _p(mv0), _p(mv1), _p(ref0), _p(ref1), _p(acc)))
 
+    def calc_frame_cost(self, prm: "CfcParams", cur, ref0, ref1, arr: dict, sums: np.ndarray):
+        """calcFrameCost enc@0x4a7410 on device data.  cur / ref0 / ref1: (tensor, byte offset of sample (0, 0)) or None; arr: device tensors intra (u16), imode (u8), invq (u16),
+        inter (u16), bits (u8), mv0 / c0 / mv1 / c1 (i32) - updated in place; sums: 11 int32 (ks265_cfc_sums) in, the updated words out"""
+        at = lambda t: C.c_void_p(t[0].data_ptr() + int(t[1])) if t is not None else None
+        self.lib.ks265_calc_frame_cost_workspace.restype = C.c_size_t
+        ws = self.zeros(int(self.lib.ks265_calc_frame_cost_workspace(C.c_int(prm.nx), C.c_int(prm.ny))))
+        ds = self.dev(np.ascontiguousarray(sums, np.int32))
+        g = lambda k: _p(arr[k]) if arr.get(k) is not None else None
+        self._chk(self.lib.ks265_calc_frame_cost(self.h, C.byref(prm), at(cur), at(ref0), at(ref1), g("intra"), g("imode"), g("invq"), g("inter"), g("bits"), g("mv0"), g("c0"), g("mv1"), g("c1"),
+                                                 _p(ds), _p(ws)))
+        return self.host(ds, np.int32)
+
+    def cutree_finish(self, cnt: int, intra, invq, prop, aq_off, dbl: int, out):
+        """the cuTree finish (enc@0x480964..0x480a54) on device arrays; out (float64) updated in place"""
+        self._chk(self.lib.ks265_cutree_finish(self.h, C.c_int(cnt), _p(intra), _p(invq), _p(prop), _p(aq_off), C.c_int(dbl), _p(out)))
+
     def intra_pred(self, ref, dst, blks: np.ndarray):
         """g_IntraPredFunction: predict every described block from dev `ref` into dev `dst` (in place)"""
         self._chk(self.lib.ks265_intra_pred_batch(self.h, _p(ref), _p(dst), _p(self.dev(blks)), C.c_int(len(blks))))
 
     def intra_filter_ref(self, src, dst, refs: np.ndarray):
         self._chk(self.lib.ks265_intra_filter_ref_batch(self.h, _p(src), _p(dst), _p(self.dev(refs)), C.c_int(len(refs))))
+
+
+class CfcParams(C.Structure):                 # ks265_cfc_params (include/ks265_hip.h)
+    _fields_ = [*[(n, C.c_int32) for n in ("w", "h", "nx", "ny", "cnt", "stride", "d0", "d1", "flag", "slice_type", "merange", "lg", "zero_thr", "fast_intra", "scenecut", "preset", "p8",
+                                             "aq", "b_intra", "f3a8", "f36c", "f538", "f3b4")], ("do_list", C.c_int32 * 2), ("intra_done", C.c_int32), ("lambda_tab", C.c_uint16 * 52)]
 
 
 class DevPic:

@@ -127,3 +127,59 @@ def load_fixture():
             r[k] = np.ascontiguousarray(z["fin_" + k][fp[k]:fp[k] + c]); fp[k] += c
         fin.append(r)
     return [str(x) for x in z["runs"]], calls, fin
+
+
+# ---- the device operator (ks265_calc_frame_cost) and the oracle on the same inputs ---------------------------------------------------------------------------------------------
+PAD = 40                                        # the margin the device operator's planes carry (the reference pads its half-size pictures by 32, edge-replicated)
+
+
+def repad(plane: np.ndarray, w: int, h: int, mx: int, my: int) -> np.ndarray:
+    """a recorded plane (margin mx / my, of which the reference initialises 32) -> the picture with a PAD-wide edge-replicated margin"""
+    inner = plane.reshape(h + 2 * my, w + 2 * mx)[my:my + h, mx:mx + w]
+    return np.ascontiguousarray(np.pad(inner, PAD, mode="edge"))
+
+
+def oracle_run(o, w, h, nx, ny, cfgw: dict, lam: np.ndarray, cur, ref0, ref1, d0, d1, flag, slice_type, do_list, intra_done, arrays: dict, sums: list, stats: list, cnt=None):
+    """kso_ref_calc_frame_cost on PAD-padded planes (2-D uint8 arrays, or None); arrays: dict of numpy arrays (updated in place); returns (sums after [5], stats [4], ret, intra_done)"""
+    c = KsoCfc()
+    stride = w + 2 * PAD
+    for k, a in (("cur", cur), ("ref0", ref0), ("ref1", ref1)):
+        setattr(c, k, a.ctypes.data + PAD * stride + PAD if a is not None else None)
+    c.stride = stride; c.w, c.h, c.nx, c.ny, c.cnt = w, h, nx, ny, cnt or nx * ny
+    c.d0, c.d1, c.flag, c.slice_type = d0, d1, flag, slice_type
+    for n in CFG_WORDS:
+        setattr(c, n, int(cfgw[n]))
+    lam = np.ascontiguousarray(lam, np.uint16)
+    c.lambda_tab = lam.ctypes.data; c.do_list[0], c.do_list[1] = do_list; c.intra_done = intra_done
+    c.intra, c.imode, c.invq, c.inter, c.bits = (arrays[k].ctypes.data for k in ("intra", "imode", "invq", "inter", "bits"))
+    c.mv[0], c.mv[1], c.cost[0], c.cost[1] = arrays["mv0"].ctypes.data, arrays["mv1"].ctypes.data, arrays["c0"].ctypes.data, arrays["c1"].ctypes.data
+    c.intra_wins, c.sum_intra, c.sum_intra_aq, c.sum, c.sum_aq = sums
+    for i in range(4):
+        c.stats[i] = stats[i]
+    c.margin_x = c.margin_y = PAD
+    o.kso_ref_calc_frame_cost(C.byref(c))
+    assert not c.oob
+    idx = d0 * 9 + d1
+    return [c.intra_wins, c.sum_intra, c.sum_intra_aq, c.sum if idx else c.sum_intra, c.sum_aq if idx else c.sum_intra_aq], [c.stats[i] for i in range(4)], c.ret, c.intra_done
+
+
+def device_run(ks, w, h, nx, ny, cfgw: dict, lam, cur, ref0, ref1, d0, d1, flag, slice_type, do_list, intra_done, arrays: dict, sums: list, stats: list, cnt=None):
+    """ks265_calc_frame_cost on the same inputs; arrays (numpy) are uploaded and the updated copies returned"""
+    from ks265codec_amd.lib import CfcParams
+    prm = CfcParams()
+    stride = w + 2 * PAD
+    prm.w, prm.h, prm.nx, prm.ny, prm.cnt, prm.stride = w, h, nx, ny, cnt or nx * ny, stride
+    prm.d0, prm.d1, prm.flag, prm.slice_type = d0, d1, flag, slice_type
+    for n in CFG_WORDS:
+        setattr(prm, n, int(cfgw[n]))
+    prm.do_list[0], prm.do_list[1] = do_list; prm.intra_done = intra_done
+    for i in range(52):
+        prm.lambda_tab[i] = int(lam[i])
+    pl = lambda a: (ks.dev(a), PAD * stride + PAD) if a is not None else None
+    d = {k: ks.dev(np.ascontiguousarray(v)) for k, v in arrays.items()}
+    s_in = np.array([*sums, *stats, 0, intra_done], np.int32)
+    out = ks.calc_frame_cost(prm, pl(cur), pl(ref0), pl(ref1), d, s_in)
+    got = {k: ks.host(d[k], arrays[k].dtype) for k in arrays}
+    idx = d0 * 9 + d1
+    s = [int(v) for v in out]
+    return got, [s[0], s[1], s[2], s[3] if idx else s[1], s[4] if idx else s[2]], s[5:9], s[9], s[10]
