@@ -39,6 +39,9 @@ ALGO_BYTES_P = {
 }
 
 
+USER_LANES = None
+
+
 def hot_tools(args, me_method):
     """the hot-path leg's tool set = the encoder host's at -preset slow (ks265codec_amd.synth.ENCODER_TOOLS: the one dict the GPU tests, smoke() and
     tools/rd_eval.py --host use too) with this run's command-line overrides"""
@@ -92,10 +95,11 @@ def main():
     if args.hier_b < 0:
         args.hier_b = 8 if args.both_gops else 0
 
-    # GOP lanes (the encoder host's default for the pyramid GOPs: two closed GOPs side by side on the one GPU) need more than the runtime's four hardware queues - with four,
-    # two lanes' streams share queues and code 561 pictures/s where eight give 700.  The library sets this itself when it opens several lanes, which only works if the HIP
-    # runtime has not started; here torch (and, with several ranks, RCCL) starts it first - so it is set before anything touches the runtime.  A value the user set stays.
+    # GOP lanes (two closed GOPs side by side on the one GPU) need more than the runtime's four hardware queues - with four, two lanes' streams share queues and code 561
+    # pictures/s where eight give 700.  The runtime reads the variable once, when it starts: set before torch (and, with several ranks, RCCL) touches it.  A value the user set stays.
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    global USER_LANES
+    USER_LANES = os.environ.get("KS265_GOP_LANES")       # round 6: the library defaults to ONE lane and never touches the environment; two lanes for the pyramid GOPs are this application's decision (run_encoded), as in the CLI
     import torch
     from ks265codec_amd.lib import KsContext, KsFrame
     from ks265codec_amd.synth import host_qp_offset, lambda_q4, make_clip
@@ -152,7 +156,7 @@ def main():
         # round 4: the two-lane leg is gone from the default run (opt in with --two-lanes).  Measured: two GOP lanes code 1.00x, two encoder processes 1.15x
         # what one lane does on the one GPU - every large kernel of the picture fills the CUs on its own - so lanes are for handles that span several GPUs
         encoded["two_lanes"] = None
-        if args.two_lanes and args.leg == "both" and args.scaling == "weak" and world == 1 and "KS265_GOP_LANES" not in os.environ and encoded.get("gop_lanes", 1) == 1 and not args.hier_b and not args.bframes:
+        if args.two_lanes and args.leg == "both" and args.scaling == "weak" and world == 1 and USER_LANES is None and encoded.get("gop_lanes", 1) == 1 and not args.hier_b and not args.bframes:
             import subprocess                                     # a process of its own: the library asks for eight hardware queues, which only a fresh runtime honours
             try:
                 r = subprocess.run([sys.executable, os.path.abspath(__file__), "--leg", "encoded", "--steps", str(args.steps), "--warmup", str(args.warmup), "--no-cpu-baseline",
@@ -580,6 +584,8 @@ def encoded_leg(args, torch, dist, rank, world, dev_index, backend, sync_all, sh
 
     def open_encoder():
         err = C.c_int(0)
+        if USER_LANES is None:                           # the application's choice, as ks265enc makes it: two closed GOPs side by side for the pyramid GOPs, one lane for IPPP / plain B
+            os.environ["KS265_GOP_LANES"] = "2" if (args.hier_b == 8 or gop_b == 3) and args.iper >= 32 and not strong else "1"
         hh = C.c_void_p(lib.QY265EncoderOpen(cfg, C.byref(err)))
         if not hh.value:
             raise SystemExit(f"QY265EncoderOpen failed: 0x{err.value & 0xFFFFFFFF:08x} (the encoder needs the MI355X: there is no CPU fallback)")

@@ -265,6 +265,11 @@ int ks265_calc_frame_cost(ks265_ctx *, const ks265_cfc_params *, const uint8_t *
 /* the cuTree finish inlined in CInputPicManage::updateQueue (enc@0x480964..0x480a54): out[i] = clip(aq_off[i] - 1.8 (log2(propagate[i] (x 2 if dbl) + intra'[i]) - log2(intra'[i])), -15, 20)
  * with intra' = (intra x inv_qscale + 128) >> 8 and the reference's table log2 (_log2 enc@0x4c3c20); blocks with intra' = 0 keep what out holds */
 int ks265_cutree_finish(ks265_ctx *, int cnt, const uint16_t *dev_intra, const uint16_t *dev_inv_qscale, const uint16_t *dev_propagate, const double *dev_aq_off, int dbl, double *dev_out);
+/* helpers of the host's cuTree pass (host/ks265_enc.c ct_*): edge replication around a plane (pointer to sample (0, 0)); a constant into a u16 plane (the inverse qscale 256 of a
+ * picture without adaptive quantisation); one QP per CTU from the offsets of the lookahead's blocks (2^(lg + 1) luma samples each: 4 x 4 or 2 x 2 per CTU) by ks265_aq_ctu_map's rule */
+int ks265_pad_plane(ks265_ctx *, uint8_t *dev_p00, int stride, int w, int h, int pad);
+int ks265_fill_u16(ks265_ctx *, uint16_t *dev, int n, int value);
+int ks265_qoff_ctu_map(ks265_ctx *, const double *dev_off, int nx, int ny, int lg, int ctu_cols, int ctu_rows, int base_qp, int qp_lo, int qp_hi, int8_t *dev_map);
 
 /* ------------------------------------------------------------------ 3. whole-frame stages (a13 sequencing) */
 

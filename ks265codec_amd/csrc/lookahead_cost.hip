@@ -351,6 +351,34 @@ __global__ __launch_bounds__(256) void cutree_finish_kernel(int cnt, const uint1
     out[i] = -15.0 > q ? -15.0 : (q < 20.0 ? q : 20.0);
 }
 
+
+// ---- helpers of the host's cuTree pass -----------------------------------------------------------------------------------------------------------------------------------------
+// edge replication around a w x h plane (the reference pads its half-size pictures by 32; the search may leave the picture by merange / 2 + 1 and the block grid may overhang it)
+__global__ __launch_bounds__(256) void pad_plane_kernel(uint8_t *p00, int stride, int w, int h, int pad)
+{
+    const int W2 = w + 2 * pad, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= W2 * (h + 2 * pad)) return;
+    const int y = i / W2 - pad, x = i % W2 - pad;
+    if (x >= 0 && x < w && y >= 0 && y < h) return;
+    p00[(long)y * stride + x] = p00[(long)min(max(y, 0), h - 1) * stride + min(max(x, 0), w - 1)];
+}
+__global__ __launch_bounds__(256) void fill_u16_kernel(uint16_t *d, int n, int v) { const int i = blockIdx.x * 256 + threadIdx.x; if (i < n) d[i] = (uint16_t)v; }
+// one QP per CTU from the per-block offsets (blocks of 2^(lg + 1) luma samples: 4 x 4 or 2 x 2 per CTU): base + clip(round(mean, summed in raster order), +-12), clipped to [lo, hi] -
+// this build's rule (quantisation group = CTU), the same as ks265_aq_ctu_map's
+__global__ __launch_bounds__(64) void qoff_ctu_map_kernel(const double *off, int nx, int ny, int bpc, int cols, int rows, int base_qp, int lo, int hi, int8_t *map)
+{
+    const int ctu = blockIdx.x * 64 + threadIdx.x;
+    if (ctu >= cols * rows) return;
+    const int cx = ctu % cols, cy = ctu / cols;
+    double sum = 0.0; int cnt = 0;
+    for (int by = cy * bpc; by < min(cy * bpc + bpc, ny); ++by)
+        for (int bx = cx * bpc; bx < min(cx * bpc + bpc, nx); ++bx) { sum += off[by * nx + bx]; ++cnt; }
+    int d = cnt ? (int)floor(sum / (double)cnt + 0.5) : 0;
+    d = d < -12 ? -12 : d > 12 ? 12 : d;
+    const int q = base_qp + d;
+    map[ctu] = (int8_t)(q < lo ? lo : q > hi ? hi : q);
+}
+
 extern "C" {
 
 size_t ks265_calc_frame_cost_workspace(int nx, int ny)
@@ -417,6 +445,33 @@ int ks265_cutree_finish(ks265_ctx *ctx, int cnt, const uint16_t *dev_intra, cons
         }
     }
     hipLaunchKernelGGL(cutree_finish_kernel, dim3((cnt + 255) / 256), dim3(256), 0, ctx->stream, cnt, dev_intra, dev_inv_qscale, dev_propagate, dev_aq_off, dbl, dev_out);
+    return ks265_check_launch(ctx);
+}
+
+int ks265_pad_plane(ks265_ctx *ctx, uint8_t *dev_p00, int stride, int w, int h, int pad)
+{
+    if (!ctx || !dev_p00) return KS265_POINTER;
+    if (w <= 0 || h <= 0 || pad < 0 || stride < w + 2 * pad) return KS265_NOTSUPPORTED;
+    ks_use_device(ctx);
+    const int n = (w + 2 * pad) * (h + 2 * pad);
+    hipLaunchKernelGGL(pad_plane_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, dev_p00, stride, w, h, pad);
+    return ks265_check_launch(ctx);
+}
+int ks265_fill_u16(ks265_ctx *ctx, uint16_t *dev, int n, int value)
+{
+    if (!ctx || !dev) return KS265_POINTER;
+    if (n <= 0) return KS265_NOTSUPPORTED;
+    ks_use_device(ctx);
+    hipLaunchKernelGGL(fill_u16_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, dev, n, value);
+    return ks265_check_launch(ctx);
+}
+int ks265_qoff_ctu_map(ks265_ctx *ctx, const double *dev_off, int nx, int ny, int lg, int ctu_cols, int ctu_rows, int base_qp, int qp_lo, int qp_hi, int8_t *dev_map)
+{
+    if (!ctx || !dev_off || !dev_map) return KS265_POINTER;
+    if (nx <= 0 || ny <= 0 || (lg != 3 && lg != 4) || ctu_cols <= 0 || ctu_rows <= 0 || qp_lo > qp_hi) return KS265_NOTSUPPORTED;
+    ks_use_device(ctx);
+    const int n = ctu_cols * ctu_rows;
+    hipLaunchKernelGGL(qoff_ctu_map_kernel, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, dev_off, nx, ny, 64 >> (lg + 1), ctu_cols, ctu_rows, base_qp, qp_lo, qp_hi, dev_map);
     return ks265_check_launch(ctx);
 }
 

@@ -56,7 +56,7 @@ static void usage(void)
 {
     puts("usage: ks265enc -i in.yuv -wdt W -hgt H [-fr FPS] [-preset ultrafast..placebo] [-latency zerolatency|lowdelay|livestreaming|default] [-tune T]\n"
          "                [-rc 0..5] [-qp Q] [-crf C] [-br KBPS] [-iper N] [-bframes N] [-frms N] [-threads N] [-psnr 0|1|2] [-b out.265] [-o recon.yuv]\n"
-         "                [-me 0|1|2] [-subme 0|1|2] [-merange R] [-ref N] [-sao 0..4] [-df 0|1] [-fixqp 0|1] [-md5 0|1] [-scenecut N (with -lookahead: the reference's scene-cut rule at threshold N)] [-aq 0|1 -aqs S (adaptive quantisation: a QP per CTU from the reference's block-variance rule)] [-c config_file] [-gpus N] [-v]\n"
+         "                [-me 0|1|2] [-subme 0|1|2] [-merange R] [-ref N] [-sao 0..4] [-df 0|1] [-fixqp 0|1] [-md5 0|1] [-scenecut N (with -lookahead: the reference's scene-cut rule at threshold N)] [-cutree 0|1 (-rc 3: the reference's macroblock tree over the lookahead, a QP per CTU; default 1)] [-aq 0|1 -aqs S (adaptive quantisation: a QP per CTU from the reference's block-variance rule)] [-c config_file] [-gpus N] [-v]\n"
          "  I420 8-bit input; width and height multiples of 8.  Needs one MI355X (gfx950): there is no CPU fallback.");
 }
 
@@ -122,7 +122,7 @@ int main(int argc, char **argv)
         else if (!strcmp(a, "-o")) rec_path = v;
         else if (!strcmp(a, "-frms")) frames = atoi(v);
         else if (!strcmp(a, "-preset") || !strcmp(a, "-latency") || !strcmp(a, "-tune")) continue;
-        else if (!strcmp(a, "-df") || !strcmp(a, "-fixqp") || !strcmp(a, "-md5") || !strcmp(a, "-scenecut")) {       /* CLI switches without a QY265EncConfig field */
+        else if (!strcmp(a, "-df") || !strcmp(a, "-fixqp") || !strcmp(a, "-md5") || !strcmp(a, "-scenecut") || !strcmp(a, "-cutree")) {       /* CLI switches without a QY265EncConfig field */
             if (ks265_enc_set_default(a + 1, atoi(v)) != QY_OK) { fprintf(stderr, "bad value for %s: %s\n", a, v); return 2; }
         }
         else if (!strcmp(a, "-gpus")) setenv("KS265_GPUS", v, 1);                            /* closed GOPs dealt to N GPUs behind this one handle (ks265_enc.h) */
@@ -135,6 +135,11 @@ int main(int argc, char **argv)
     if (!in_path || cfg.picWidth <= 0 || cfg.picHeight <= 0) { usage(); return 2; }
     FILE *fi = fopen(in_path, "rb"), *fo = out_path ? fopen(out_path, "wb") : NULL;
     if (!fi || (out_path && !fo)) { perror("open"); return 1; }
+    {   /* this process is the encoder's alone and has not touched the GPU yet: for the pyramid GOPs under -rc 0 / 3 it opts into two GOP lanes on eight hardware queues (DESIGN.md 6e;
+         * the library itself never changes the environment and defaults to one lane).  KS265_GOP_LANES / GPU_MAX_HW_QUEUES set by the user stay. */
+        const int gop_b = cfg.bframes < 0 ? (cfg.latency == QY265LATENCY_DEFAULT ? 7 : 0) : cfg.bframes;
+        if ((gop_b == 7 || gop_b == 3) && (cfg.rc == 0 || cfg.rc == 3) && cfg.enFrameParallel && cfg.iIntraPeriod >= 32) { setenv("KS265_GOP_LANES", "2", 0); setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+    }
     int err = 0;
     void *h = QY265EncoderOpen(&cfg, &err);
     if (!h) { fprintf(stderr, "QY265EncoderOpen failed: 0x%08x\n", (unsigned)err); return 1; }

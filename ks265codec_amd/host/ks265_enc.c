@@ -75,7 +75,7 @@ static void md5_hex(const uint8_t *data, size_t n, char out[33])
 
 /* CLI-level switches of `appencoder` that the SDK's QY265EncConfig has no field for (-df, -fixqp, -md5): process-wide defaults a front end
  * sets before QY265EncoderOpen (ks265_enc_set_default) */
-static struct { int df, fixqp, md5, scenecut; } g_cli = {1, 0, 0, 0};
+static struct { int df, fixqp, md5, scenecut, cutree; } g_cli = {1, 0, 0, 0, 1};
 int ks265_enc_set_default(const char *name, int value)
 {
     if (!name) return QY_POINTER;
@@ -83,6 +83,7 @@ int ks265_enc_set_default(const char *name, int value)
     if (!strcmp(name, "fixqp")) { if (value < 0 || value > 1) return QY265_PARAM_BAD_VALUE; g_cli.fixqp = value; return QY_OK; }
     if (!strcmp(name, "md5")) { if (value < 0 || value > 1) return QY265_PARAM_BAD_VALUE; g_cli.md5 = value; return QY_OK; }
     if (!strcmp(name, "scenecut")) { if (value < 0 || value > 100) return QY265_PARAM_BAD_VALUE; g_cli.scenecut = value; return QY_OK; }   /* the reference's hidden -scenecut N */
+    if (!strcmp(name, "cutree")) { if (value < 0 || value > 1) return QY265_PARAM_BAD_VALUE; g_cli.cutree = value; return QY_OK; }        /* the reference's hidden -cutree N (on by default, as there) */
     return QY265_PARAM_BAD_NAME;
 }
 
@@ -344,6 +345,15 @@ typedef struct Enc {
     struct Input *la_q[LA_QMAX]; int la_qn, la_flying, la_seq, la_keep; void *la_evs[LA_FLY];   /* pictures handed in and not yet with the scheduler (display order); analyses in flight; their events / result areas, round robin */
     ks265_ctx *ctx_la; ks265_frame *frame_la; ks265_frame_geom geom_la; ks265_pic la_pic[LA_RING];
     uint32_t *la_cost_ws; uint64_t *la_dev_out, *la_host_out;
+    /* cuTree (-rc 3 with -cutree 1, the default; round 6): the reference's macroblock-tree over the lookahead window.  Before a key picture / a mini-GOP is
+     * submitted the scheduler thread runs, on a stream of its own, the reference's calcFrameCost enc@0x4a7410 (ks265_calc_frame_cost) for every picture of the window against the
+     * pictures it will be predicted from, cuTreePropagate enc@0x47d460 from the window's end back to the mini-GOP (reverse coding order, as CInputPicManage::updateQueue does), and the
+     * finish (enc@0x480964: offset = AQ offset - 1.8 log2((propagated + intra') / intra')) for the pictures about to be coded; their QP per CTU = picture QP + the mean of the CTU's
+     * block offsets (ks265_qoff_ctu_map), through the -aq plumbing (ks265_frame_set_qp_map, cu_qp_delta).  Costs are cached per picture and reference pair. */
+#define CT_RING 128
+    int ct_on, ct_lg, ct_nx, ct_ny, ct_w, ct_h, ct_stride, ct_pad, ct_depth, ct_preset, qmap_on, qmap_fd;
+    struct CtPic { int disp, p0, p1, intra_done, used; uint8_t *blk, *low; uint16_t *intra, *invq, *prop, *inter; uint8_t *imode, *bits; int32_t *mv0, *c0, *mv1, *c1; double *aq_off, *qoff; ks265_cfc_sums *sums; void *ev_used; } ct[CT_RING];
+    ks265_ctx *ctx_ct; void *ct_ws, *ct_ev; uint64_t *ct_acc; double *ct_scratch; uint8_t *ct_full;
     struct TopWake *wake;                                 /* lanes: the handle's caller sleeps here until a picture of ANY lane is finished */
     Job jobs[MAX_JOBS]; int ring, job_head, job_tail, njobs;   /* ring of `ring` pictures in coding order */
     /* workers */
@@ -513,7 +523,12 @@ static void *worker(void *arg)
                 memcpy(s->rps_poc, j->rps_poc, sizeof s->rps_poc); memcpy(s->rps_used, j->rps_used, sizeof s->rps_used);
                 s->num_l0 = j->nl0; s->num_l1 = j->nl1; memcpy(s->l0_poc, j->l0, sizeof s->l0_poc); memcpy(s->l1_poc, j->l1, sizeof s->l1_poc);
                 s->cu8 = j->cu8; s->lvl[0] = j->lvl[0]; s->lvl[1] = j->lvl[1]; s->lvl[2] = j->lvl[2]; s->sao = e->use_sao ? j->sao : NULL;
-                s->qp_map = e->aq_on ? j->qp_map : NULL;
+                s->qp_map = e->qmap_on ? j->qp_map : NULL;
+                if (e->qmap_on && e->qmap_fd >= 0) {                     /* KS265_DUMP_QPMAP=file (tests): display index, kind, QP, CTU count, then the map - one record per picture, whole records only */
+                    const int nct = e->geom.ctu_cols * e->geom.ctu_rows;
+                    uint8_t *rec = (uint8_t *)malloc(16 + (size_t)nct);
+                    if (rec) { const int32_t hd[4] = {j->disp, j->kind, j->qp, nct}; memcpy(rec, hd, 16); memcpy(rec + 16, j->qp_map, (size_t)nct); if (write(e->qmap_fd, rec, 16 + (size_t)nct) < 0) { /* diagnostics only */ } free(rec); }
+                }
                 err = ks265_wpp_begin(&e->scfg, s, j->wpp);
             }
             pthread_mutex_lock(&e->mu);
@@ -611,6 +626,174 @@ static int dpb_free_slot(Enc *e, const int *keep, int nkeep)
     return -1;
 }
 
+/* ---- cuTree: the lookahead window's costs, propagation and finish (scheduler thread only; see Enc::ct_on) -------------------------------------------------------------------- */
+static Input *input_at(Enc *e, int disp);
+typedef struct CtNode { int b, p0, p1, is_ref; } CtNode;
+/* the integer motion lambda of every QP (TEncParam+0x720 as recorded inside the reference: x264's table; the lookahead searches with entry 12 = 1, the others only matter where the
+ * reference's cost table is overrun into its neighbouring rows) */
+static const uint16_t kCtLambda[52] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 5, 5, 6, 7, 7, 8, 9, 11, 12, 13, 15, 17, 19, 21, 24, 27, 30, 34, 38, 42, 47, 53, 60, 67};
+/* TEncParam words calcFrameCost reads, by preset (read inside the reference with every preset, -rc 3: zero_thr +0x3a0, fast_intra +0x3a4, +0x36c, +0x538, +0x3b4; +0x3a8 = 13 and
+ * +0x8 = 0 throughout); blocks of 16 x 16 half-size samples from 1280 x 720 up and for ultrafast .. veryfast, else 8 x 8 */
+static const struct { int zero_thr, fast_intra, f36c, f538, f3b4, lg4; } kCtPreset[9] = {{4, 4, 0, 120, 2, 1}, {4, 4, 0, 120, 2, 1}, {4, 1, 0, 0, 1, 1}, {0, 0, 1, 0, 1, 0}, {0, 0, 1, 0, 1, 0},
+                                                                                              {0, 0, 1, 0, 1, 0}, {0, 0, 1, 0, 1, 0}, {0, 0, 1, 0, 1, 0}, {0, 0, 0, 0, 1, 0}};
+static struct CtPic *ct_slot(Enc *e, int disp) { return &e->ct[((disp % CT_RING) + CT_RING) % CT_RING]; }
+static int ct_open(Enc *e, int device)
+{
+    const int ps = e->ct_preset;
+    e->ct_w = e->W / 2; e->ct_h = e->H / 2;
+    e->ct_lg = (kCtPreset[ps].lg4 || (long)e->W * e->H >= 1280L * 720) ? 4 : 3;
+    const int bs = 1 << e->ct_lg;
+    e->ct_nx = (e->ct_w + bs - 1) / bs; e->ct_ny = (e->ct_h + bs - 1) / bs;
+    e->ct_pad = 40 + bs;                                               /* the search leaves the picture by at most merange / 2 + 1 = 33; the last block row / column may overhang it */
+    e->ct_stride = (e->ct_w + 2 * e->ct_pad + 63) & ~63;
+    const size_t n = (size_t)e->ct_nx * e->ct_ny, lowsz = (size_t)e->ct_stride * (size_t)(e->ct_h + 2 * e->ct_pad);
+    int r = ks265_create(&e->ctx_ct, device);
+    /* one block of device memory per picture of the ring: the padded half-size plane, then the per-block arrays (64-byte aligned) */
+    const size_t a64 = 63;
+    size_t off[16], o = (lowsz + a64) & ~a64;
+    const size_t sz[14] = {n * 2, n * 2, n * 2, n * 2, n, (n + 3) / 4, n * 4, n * 4, n * 4, n * 4, n * 8, n * 8, sizeof(ks265_cfc_sums), 0};
+    for (int k = 0; k < 13; ++k) { off[k] = o; o = (o + sz[k] + a64) & ~a64; }
+    for (int i = 0; i < CT_RING && !r; ++i) {
+        struct CtPic *c = &e->ct[i];
+        c->disp = -1000000;
+        r = ks265_dev_malloc(e->ctx_ct, (void **)&c->blk, o);
+        if (r) break;
+        c->low = c->blk + (size_t)e->ct_pad * e->ct_stride + e->ct_pad;
+        c->intra = (uint16_t *)(c->blk + off[0]); c->invq = (uint16_t *)(c->blk + off[1]); c->prop = (uint16_t *)(c->blk + off[2]); c->inter = (uint16_t *)(c->blk + off[3]);
+        c->imode = c->blk + off[4]; c->bits = c->blk + off[5]; c->mv0 = (int32_t *)(c->blk + off[6]); c->c0 = (int32_t *)(c->blk + off[7]); c->mv1 = (int32_t *)(c->blk + off[8]);
+        c->c1 = (int32_t *)(c->blk + off[9]); c->aq_off = (double *)(c->blk + off[10]); c->qoff = (double *)(c->blk + off[11]); c->sums = (ks265_cfc_sums *)(c->blk + off[12]);
+        r = ks265_event_create(e->ctx_ct, &c->ev_used);
+    }
+    if (!r) r = ks265_dev_malloc(e->ctx_ct, &e->ct_ws, ks265_calc_frame_cost_workspace(e->ct_nx, e->ct_ny));
+    if (!r) r = ks265_dev_malloc(e->ctx_ct, (void **)&e->ct_acc, n * 16);
+    if (!r) r = ks265_memset_async(e->ctx_ct, e->ct_acc, 0, n * 16);
+    if (!r) r = ks265_dev_malloc(e->ctx_ct, (void **)&e->ct_scratch, 16);
+    if (!r && e->aq_on) r = ks265_dev_malloc(e->ctx_ct, (void **)&e->ct_full, (size_t)e->W * e->H * 3 / 2);
+    if (!r) r = ks265_event_create(e->ctx_ct, &e->ct_ev);
+    return r;
+}
+static void ct_close(Enc *e)
+{
+    if (!e->ctx_ct) return;
+    ks265_synchronize(e->ctx_ct);
+    for (int i = 0; i < CT_RING; ++i) { ks265_dev_free(e->ctx_ct, e->ct[i].blk); if (e->ct[i].ev_used) ks265_event_destroy(e->ctx_ct, e->ct[i].ev_used); }
+    ks265_dev_free(e->ctx_ct, e->ct_ws); ks265_dev_free(e->ctx_ct, e->ct_acc); ks265_dev_free(e->ctx_ct, e->ct_scratch); ks265_dev_free(e->ctx_ct, e->ct_full);
+    if (e->ct_ev) ks265_event_destroy(e->ctx_ct, e->ct_ev);
+    ks265_destroy(e->ctx_ct); e->ctx_ct = NULL;
+}
+/* picture `disp` in the ring: its half-size picture (downsample_c enc@0x4a6a60, edges replicated), its AQ offsets / inverse qscale factors (calcFrameAdaptQuant enc@0x4653c0 on the
+ * lookahead's block grid, as the reference calls it; without -aq: zero offsets, factor 256) */
+static int ct_prepare(Enc *e, int disp)
+{
+    struct CtPic *c = ct_slot(e, disp);
+    if (c->disp == disp) return 0;
+    Input *in = input_at(e, disp);
+    if (!in) return KS265_FAIL;
+    ks265_ctx *cx = e->ctx_ct;
+    const int n = e->ct_nx * e->ct_ny;
+    int r = c->used ? ks265_stream_wait_event(cx, c->ev_used) : 0;       /* the picture that held this slot CT_RING pictures ago: its QP map has been taken */
+    c->disp = disp; c->p0 = c->p1 = -1000000; c->intra_done = 0;
+    const uint8_t *full = NULL;
+    if (in->dev) { if (!r) r = ks265_stream_wait_event(cx, in->ev_up); full = in->dev; }
+    else if (e->ct_full) { if (!r) r = ks265_memcpy_h2d_async(cx, e->ct_full, in->i420, (size_t)e->W * e->H * 3 / 2); full = e->ct_full; }
+    if (!r) r = full ? ks265_downsample_rect(cx, full, e->W, c->low, e->ct_stride, e->ct_w, e->ct_h) : ks265_downsample_from_host(cx, in->i420, e->W, c->low, e->ct_stride, e->ct_w, e->ct_h);
+    if (!r) r = ks265_pad_plane(cx, c->low, e->ct_stride, e->ct_w, e->ct_h, e->ct_pad);
+    if (!r && e->aq_on) r = ks265_frame_adapt_quant(cx, full, e->W, full + (size_t)e->W * e->H, full + (size_t)e->W * e->H * 5 / 4, e->W / 2, e->ct_nx, e->ct_ny, n, e->cfg.fAqStrength, c->aq_off, c->invq, e->ct_scratch);
+    else if (!r) { r = ks265_memset_async(cx, c->aq_off, 0, (size_t)n * 8); if (!r) r = ks265_fill_u16(cx, c->invq, n, 256); }
+    if (!r) r = ks265_memset_async(cx, c->sums, 0xff, sizeof(ks265_cfc_sums));      /* L+0x684 / +0x7c8 = -1: nothing computed yet */
+    return r;
+}
+/* calcFrameCost of picture b against (p0, p1) (display indices; p1 < 0: none; p0 < 0: the intra pass alone), unless that is what its arrays hold */
+static int ct_cost(Enc *e, int b, int p0, int p1)
+{
+    struct CtPic *c = ct_slot(e, b);
+    if (p0 < 0) { if (c->intra_done) return 0; }
+    else if (c->p0 == p0 && c->p1 == p1) return 0;
+    const int ps = e->ct_preset;
+    ks265_cfc_params q; memset(&q, 0, sizeof q);
+    q.w = e->ct_w; q.h = e->ct_h; q.nx = e->ct_nx; q.ny = e->ct_ny; q.cnt = e->ct_nx * e->ct_ny; q.stride = e->ct_stride;
+    q.d0 = p0 < 0 ? 0 : b - p0; q.d1 = p0 < 0 || p1 < 0 ? 0 : p1 - b; q.flag = 0; q.slice_type = p0 < 0 ? 2 : q.d1 ? 0 : 1;
+    q.merange = 64; q.lg = e->ct_lg; q.zero_thr = kCtPreset[ps].zero_thr; q.fast_intra = kCtPreset[ps].fast_intra; q.scenecut = g_cli.scenecut ? g_cli.scenecut : 30; q.preset = ps; q.p8 = 0;
+    q.aq = e->aq_on; q.b_intra = 1; q.f3a8 = 13; q.f36c = kCtPreset[ps].f36c; q.f538 = kCtPreset[ps].f538; q.f3b4 = kCtPreset[ps].f3b4;
+    q.do_list[0] = q.d0 > 0; q.do_list[1] = q.d1 > 0; q.intra_done = c->intra_done;
+    memcpy(q.lambda_tab, kCtLambda, sizeof q.lambda_tab);
+    const int r = ks265_calc_frame_cost(e->ctx_ct, &q, c->low, q.d0 ? ct_slot(e, p0)->low : NULL, q.d1 ? ct_slot(e, p1)->low : NULL, c->intra, c->imode, c->invq, c->inter, c->bits,
+                                        c->mv0, c->c0, c->mv1, c->c1, c->sums, e->ct_ws);
+    if (p0 >= 0) { c->p0 = p0; c->p1 = p1; }
+    if (q.d1 == 0) c->intra_done = 1;                                  /* (the reference marks the intra costs done after a pass without a list-1 picture only, enc@0x4a8be5) */
+    return r;
+}
+/* the pictures of (lo, end] in coding order as this scheduler will code them: mini-GOPs (lo, hi], (hi, hi + span], .. - the anchor P picture first, then the B pictures (pyramid:
+ * breadth first, references = the interval's ends; else every B picture between the two anchors) */
+static int ct_structure(const Enc *e, int lo, int hi, int end, CtNode *out, int cap)
+{
+    int n = 0;
+    const int span = e->gop_b + 1;
+    while (lo < end && n < cap) {
+        if (hi > end) hi = end;
+        out[n++] = (CtNode){hi, lo, -1, 1};
+        if (hi - lo > 1) {
+            if (e->hier && ((hi - lo) & (hi - lo - 1)) == 0) {
+                struct { int lo, hi; } cur[8], nxt[8]; int nc = 1;
+                cur[0].lo = lo; cur[0].hi = hi;
+                while (nc) {
+                    int nn = 0;
+                    for (int i = 0; i < nc; ++i) {
+                        if (cur[i].hi - cur[i].lo < 2) continue;
+                        const int mid = (cur[i].lo + cur[i].hi) / 2;
+                        if (n < cap) out[n++] = (CtNode){mid, cur[i].lo, cur[i].hi, (mid - cur[i].lo >= 2) || (cur[i].hi - mid >= 2)};
+                        nxt[nn].lo = cur[i].lo; nxt[nn++].hi = mid; nxt[nn].lo = mid; nxt[nn++].hi = cur[i].hi;
+                    }
+                    memcpy(cur, nxt, sizeof cur); nc = nn;
+                }
+            } else for (int b = lo + 1; b < hi && n < cap; ++b) out[n++] = (CtNode){b, lo, hi, 0};
+        }
+        lo = hi; hi = lo + span;
+    }
+    return n;
+}
+/* the window's end for a mini-GOP that ends at display index a: ct_depth pictures further, inside this closed GOP, inside what has arrived.  -1: not all of it is there yet */
+static int ct_window_end(Enc *e, int a, int iper, int have, int flush, int gop_end)
+{
+    int end = a + e->ct_depth;
+    if (iper > 0 && end > e->gop_start + iper - 1) end = e->gop_start + iper - 1;
+    if (gop_end >= a && end > gop_end) end = gop_end;
+    for (int k = a + 1; k <= end && k < have; ++k) { const Input *ik = input_at(e, k); if (ik && ik->key) { end = k - 1; break; } }   /* a requested key picture closes the GOP in front of it */
+    if (end >= have) { if (!flush) return -1; end = have - 1; }
+    return end < a ? a : end;
+}
+/* costs + propagation over (first, end], then the offsets of the pictures in [fin_lo, fin_hi] (the key picture itself when key >= 0) */
+static int ct_run(Enc *e, int key, int d, int a, int end)
+{
+    CtNode nodes[CT_RING];
+    const int first = key >= 0 ? key : d;
+    if (end - first >= CT_RING - 2) end = first + CT_RING - 3;
+    const int nn = key >= 0 ? ct_structure(e, key, key + e->gop_b + 1, end, nodes, CT_RING) : ct_structure(e, d, a, end, nodes, CT_RING);
+    const int n = e->ct_nx * e->ct_ny;
+    int r = 0;
+    for (int k = first; k <= end && !r; ++k) r = ct_prepare(e, k);
+    for (int k = first; k <= end && !r; ++k) r = ks265_memset_async(e->ctx_ct, ct_slot(e, k)->prop, 0, (size_t)n * 2);       /* (the reference clears L+0x40 of the window before every pass, enc@0x480116) */
+    if (!r && key >= 0) r = ct_cost(e, key, -1, -1);                  /* the key picture's intra costs (enc@0x480bb1) */
+    for (int i = nn - 1; i >= 0 && !r; --i) {
+        const CtNode *nd = &nodes[i];
+        struct CtPic *c = ct_slot(e, nd->b), *r0 = ct_slot(e, nd->p0), *r1 = nd->p1 >= 0 ? ct_slot(e, nd->p1) : r0;
+        r = ct_cost(e, nd->b, nd->p0, nd->p1);
+        if (!r) r = ks265_cutree_propagate(e->ctx_ct, e->ct_lg, e->ct_nx, e->ct_ny, c->intra, c->invq, c->prop, c->inter, c->bits, c->mv0, nd->p1 >= 0 ? c->mv1 : c->mv0, r0->prop, r1->prop, e->ct_acc);
+    }
+    /* the finish for what is about to be coded: reference pictures get the tree's offsets, the others their AQ offsets alone (enc@0x480854..0x480a54) */
+    for (int i = -1; i < nn && !r; ++i) {
+        int b, is_ref, dbl = 0;
+        if (i < 0) { if (key < 0) continue; b = key; is_ref = 1; }
+        else { if (key >= 0 || nodes[i].b > a) continue; b = nodes[i].b; is_ref = nodes[i].is_ref; dbl = nodes[i].p1 < 0 && end == a; }   /* nothing of the window lies behind this mini-GOP: its anchor's
+                                                                                                                                             * propagated cost counts twice (enc@0x480c6a, 0x4809d2) */
+        struct CtPic *c = ct_slot(e, b);
+        r = ks265_memcpy_d2d_async(e->ctx_ct, c->qoff, c->aq_off, (size_t)n * 8);
+        if (!r && is_ref) r = ks265_cutree_finish(e->ctx_ct, n, c->intra, c->invq, c->prop, c->aq_off, dbl, c->qoff);
+    }
+    if (!r) r = ks265_event_record(e->ctx_ct, e->ct_ev);
+    return r;
+}
+
 /* enqueue one picture: GPU work + copies on the stream, then hand it to the writers */
 static int submit(Enc *e, Input *in, int kind, int poc, int qp, const int *l0, int nl0, const int *l1, int nl1, const int *keep_after, int nkeep, int is_ref, int key_headers)
 {
@@ -662,7 +845,20 @@ static int submit(Enc *e, Input *in, int kind, int poc, int qp, const int *l0, i
         if (!r) r = ks265_event_record(cx, e->ev_loaded[k]);
     }
     if (!r) r = ks265_frame_set_qp(fr, qp, kind == 'I' ? kLambdaQ4[qp] : kLambdaInterQ4[qp]);
-    if (!r && e->aq_on) {
+    if (!r && e->ct_on) {
+        /* cuTree: the picture's block offsets were finished on the lookahead's stream when its mini-GOP was scheduled (ct_run): one QP per CTU around this picture's QP */
+        ks265_ctx *ca = split ? e->ctx_in : cx;
+        struct CtPic *cp = ct_slot(e, in->disp);
+        int8_t *qm = on_key ? e->dev_qmap_key[e->nkeys & 1] : e->dev_qmap[k];
+        if (cp->disp != in->disp) r = KS265_FAIL;
+        if (!r) r = ks265_stream_wait_event(ca, e->ct_ev);
+        if (!r) r = ks265_qoff_ctu_map(ca, cp->qoff, e->ct_nx, e->ct_ny, e->ct_lg, e->geom.ctu_cols, e->geom.ctu_rows, qp, e->cfg.qpmin, e->cfg.qpmax ? e->cfg.qpmax : 51, qm);
+        if (!r) r = ks265_event_record(ca, cp->ev_used);
+        cp->used = 1;
+        if (!r) r = ks265_frame_set_qp_map(fr, qm);
+        if (!r) r = ks265_memcpy_d2h_async(ca, j->qp_map, qm, (size_t)e->geom.ctu_cols * e->geom.ctu_rows);
+        if (!r && split) { r = ks265_event_record(e->ctx_in, e->ev_h2d[k]); if (!r) r = ks265_stream_wait_event(cx, e->ev_h2d[k]); }
+    } else if (!r && e->aq_on) {
         /* the source picture is on the device: block variances -> offsets (the reference's arithmetic) -> one QP per CTU around this picture's QP.  With the split pipeline
          * this runs on the copy-in stream right behind the unpack (off the pixel path's chain: the mean is a sequential sum, 0.15 ms at 2160p); the map stays in its rotation
          * slot while the picture's kernels and the copy-home run */
@@ -896,6 +1092,16 @@ static int schedule(Enc *e, int flush, int have /* pictures [0, have) have arriv
         Input *in = input_at(e, nxt);
         const int iper = in ? in->iper : 0;                            /* the period in force when this picture was handed in (QY265EncoderReconfig) */
         const int key = d < 0 || (iper > 0 && nxt - e->gop_start >= iper) || (in && in->key);
+        if (key && e->ct_on) {                                         /* cuTree: the key picture's offsets need the window behind it */
+            const int gs = e->gop_start; e->gop_start = nxt;
+            const int end = ct_window_end(e, nxt, iper, have, flush, gop_end);
+            e->gop_start = gs;
+            if (end < 0) return QY_OK;
+            e->gop_start = nxt;
+            const int rr = ct_run(e, nxt, nxt, nxt, end);
+            e->gop_start = gs;
+            if (rr) return hip_rc(rr);
+        }
         if (key) {
             e->gop_start = nxt; e->mg4_until = -1;
             e->rc_qp_delta = rc_decide(e);                             /* rate control: one offset per key picture / mini-GOP, decided when it is certain to be submitted */
@@ -921,6 +1127,12 @@ static int schedule(Enc *e, int flush, int have /* pictures [0, have) have arriv
         }
         if (gop_end >= nxt && a > gop_end) a = gop_end;                 /* the GOP was closed behind this picture (its successor goes to another lane) */
         if (a >= have) { if (!flush) return QY_OK; a = have - 1; }
+        if (e->ct_on) {                                                /* cuTree: costs and propagation over the window behind this mini-GOP, offsets for its pictures */
+            const int end = ct_window_end(e, a, iper, have, flush, gop_end);
+            if (end < 0) return QY_OK;
+            const int rr = ct_run(e, -1, d, a, end);
+            if (rr) return hip_rc(rr);
+        }
         const int pd = d - e->gop_start, pa = a - e->gop_start;
         int l0[4], nl0 = 0, keep[8], nkeep = 0;
         if (span == 1) {                                               /* IPPP: the most recent pictures, nearest first */
@@ -1123,6 +1335,8 @@ static void lane_close(Enc *e, int report)
         for (int k = 0; k < NPIPE; ++k) ks265_dev_free(e->ctx, e->dev_qmap[k]);
         for (int q = 0; q < 2; ++q) ks265_dev_free(e->ctx, e->dev_qmap_key[q]);
         if (e->recon_fd >= 0) close(e->recon_fd);
+        if (e->qmap_fd >= 0) close(e->qmap_fd);
+        ct_close(e);
         if (e->ctx_la) {
             ks265_synchronize(e->ctx_la);
             for (int i = 0; i < LA_RING; ++i) { ks265_dev_free(e->ctx_la, e->la_pic[i].y); ks265_dev_free(e->ctx_la, e->la_pic[i].u); ks265_dev_free(e->ctx_la, e->la_pic[i].v); }
@@ -1152,7 +1366,7 @@ static Enc *lane_open(QY265EncConfig *cfg, int device, int multi, int *err)
     if (!cfg) { *err = QY_POINTER; return NULL; }
     if (cfg->picWidth <= 0 || cfg->picHeight <= 0 || (cfg->picWidth & 7) || (cfg->picHeight & 7) || cfg->frameRate <= 0 || cfg->rc < 0 || cfg->rc > 5) { *err = QY_NOTSUPPORTED; return NULL; }
     Enc *e = (Enc *)calloc(1, sizeof *e);
-    if (e) e->recon_fd = -1;
+    if (e) { e->recon_fd = -1; e->qmap_fd = -1; }
     if (!e) { *err = QY_OUTOFMEMORY; return NULL; }
     pthread_mutex_init(&e->la_mu, NULL);
     pthread_mutex_init(&e->mu, NULL); pthread_cond_init(&e->cv_work, NULL); pthread_cond_init(&e->cv_done, NULL); pthread_cond_init(&e->cv_disp, NULL); pthread_cond_init(&e->cv_sched, NULL); pthread_cond_init(&e->cv_sched_done, NULL);
@@ -1247,7 +1461,29 @@ static Enc *lane_open(QY265EncConfig *cfg, int device, int multi, int *err)
     }
     if (!r) r = ks265_dev_malloc(e->ctx, (void **)&e->dev_sse, 64);
     e->aq_on = cfg->iAqMode != 0 && cfg->fAqStrength > 0;
-    if (e->aq_on) {
+    /* cuTree: -rc 3 (CRF) with the reference's -cutree 1 (its default), B pictures (with -bframes 0 the reference runs no tree: TEncParam+0x388 = 0, every offset it leaves is zero)
+     * and a lookahead (not -lookahead 0, not zero latency): a QP per CTU from the lookahead window */
+    e->ct_preset = (int)cfg->preset < 0 || (int)cfg->preset > 8 ? QY265PRESET_SLOW : (int)cfg->preset;
+    e->ct_on = cfg->rc == 3 && g_cli.cutree && e->gop_b > 0 && cfg->lookahead != 0 && cfg->latency != QY265LATENCY_ZERO && e->W >= 64 && e->H >= 64 && !getenv("KS265_NO_CUTREE");
+    {   /* how far behind a key picture / a mini-GOP's anchor the window reaches - measured inside the reference (the calcFrameCost calls of every batch, -bframes 3): veryfast 8,
+         * fast / medium 12, slow / veryslow 60, -lookahead 20: 16 - i.e. a queue of L pictures (12 / 16 / 64 by preset, or -lookahead N) in whole mini-GOPs: ((L - 1) / span) span */
+        const int L = cfg->lookahead > 0 ? cfg->lookahead : e->ct_preset <= 2 ? 12 : e->ct_preset <= 4 ? 16 : 64, span = e->gop_b + 1;
+        e->ct_depth = ((L - 1) / span) * span;
+    }
+    if (e->ct_depth < e->gop_b + 1) e->ct_depth = e->gop_b + 1;
+    if (e->ct_depth > CT_RING - 40) e->ct_depth = CT_RING - 40;
+    e->qmap_on = e->aq_on || e->ct_on;
+    if (e->qmap_on && getenv("KS265_DUMP_QPMAP")) e->qmap_fd = open(getenv("KS265_DUMP_QPMAP"), O_WRONLY | O_CREAT | O_APPEND, 0644);
+    if (!r && e->ct_on) {
+        r = ct_open(e, dev_id);
+        logf_(1, e->log_level, "ks265enc: -rc 3: cuTree over a lookahead of %d pictures (%d x %d blocks of %d half-size samples; -cutree 0 / -lookahead 0 switch it off): QP per CTU = picture QP + the tree's mean offset\n",
+              e->ct_depth, e->ct_nx, e->ct_ny, 1 << e->ct_lg);
+    }
+    if (e->qmap_on) {
+        for (int k = 0; k < NPIPE && !r; ++k) r = ks265_dev_malloc(e->ctx, (void **)&e->dev_qmap[k], (size_t)e->geom.ctu_cols * e->geom.ctu_rows);
+        for (int q = 0; q < 2 && !r; ++q) r = ks265_dev_malloc(e->ctx, (void **)&e->dev_qmap_key[q], (size_t)e->geom.ctu_cols * e->geom.ctu_rows);
+    }
+    if (e->aq_on && !e->ct_on) {
         e->aq_nx = (e->W + 15) / 16; e->aq_ny = (e->H + 15) / 16;       /* blocks that hang over the picture read its padding (replicated edges) */
         const size_t nb = (size_t)e->aq_nx * e->aq_ny;
         for (int q = 0; q < 2 && !r; ++q) {
@@ -1255,8 +1491,6 @@ static Enc *lane_open(QY265EncConfig *cfg, int device, int multi, int *err)
             if (!r) r = ks265_dev_malloc(e->ctx, (void **)&e->aq_inv[q], nb * 2);
             if (!r) r = ks265_dev_malloc(e->ctx, (void **)&e->aq_scratch[q], 16);
         }
-        for (int k = 0; k < NPIPE && !r; ++k) r = ks265_dev_malloc(e->ctx, (void **)&e->dev_qmap[k], (size_t)e->geom.ctu_cols * e->geom.ctu_rows);
-        for (int q = 0; q < 2 && !r; ++q) r = ks265_dev_malloc(e->ctx, (void **)&e->dev_qmap_key[q], (size_t)e->geom.ctu_cols * e->geom.ctu_rows);
     }
     if (!r) r = pic_alloc(e, &e->src);
     e->ndpb = e->hier ? 10 : e->gop_b ? 4 : e->refs + 2;
@@ -1264,7 +1498,7 @@ static Enc *lane_open(QY265EncConfig *cfg, int device, int multi, int *err)
     for (int i = 0; i < e->ndpb && !r; ++i) r = pic_alloc(e, &e->dpb[i]);
     e->key_overlap = getenv("KS265_NO_KEY_OVERLAP") ? 0 : 1;
     e->use_graph = getenv("KS265_GRAPH") ? 1 : 0;                     /* opt-in since round 4: launch by launch is faster on this runtime (843 against 817 pictures/s, 2160p IPPP) and the split pipeline needs the launches apart */
-    if (e->aq_on) e->use_graph = 0;                                      /* (a captured picture would replay one map) */
+    if (e->qmap_on) e->use_graph = 0;                                    /* (a captured picture would replay one map) */
     if (e->use_graph) e->split = 0;
     if (e->key_overlap) {
         if (!r) r = ks265_create_prio(&e->ctx_key, dev_id, getenv("KS265_KEY_PRIO") ? atoi(getenv("KS265_KEY_PRIO")) : 1);   /* the key picture's wavefront must run underneath the P pictures, not behind them */
@@ -1277,7 +1511,7 @@ static Enc *lane_open(QY265EncConfig *cfg, int device, int multi, int *err)
     /* opt-in (KS265_ANCHOR_LANE=1): measured on the MI355X at 2160p, default GOP - 561 pictures/s without, 568 with the lane at normal stream priority, 440 at high priority
      * (and 382 before the anchor waited for its upload directly); with 8 hardware queues (GPU_MAX_HW_QUEUES) 449 without and 515 with.  The kernels of a picture fill the
      * device: an anchor running beside B pictures slows them by what it gains */
-    e->anc_on = e->hier && e->key_overlap && !e->aq_on && !e->use_graph && getenv("KS265_ANCHOR_LANE") && atoi(getenv("KS265_ANCHOR_LANE")) > 0;
+    e->anc_on = e->hier && e->key_overlap && !e->qmap_on && !e->use_graph && getenv("KS265_ANCHOR_LANE") && atoi(getenv("KS265_ANCHOR_LANE")) > 0;
     if (e->anc_on) {
         if (!r) r = ks265_create_prio(&e->ctx_anc, dev_id, getenv("KS265_ANC_PRIO") ? atoi(getenv("KS265_ANC_PRIO")) : 0);
         if (!r) r = ks265_frame_create(e->ctx_anc, &e->fcfg, &e->frame_anc);
@@ -1335,7 +1569,7 @@ static Enc *lane_open(QY265EncConfig *cfg, int device, int multi, int *err)
             j->cu8 = (ks265_cu8 *)(j->cmp + e->cmp_off[0]); j->sao = (ks265_sao_param *)(j->cmp + e->cmp_off[1]); j->sse = (uint64_t *)(j->cmp + e->cmp_off[2]);
             j->lvl[0] = (int16_t *)j->lvlbuf; j->lvl[1] = (int16_t *)(j->lvlbuf + npx * 2); j->lvl[2] = (int16_t *)(j->lvlbuf + npx * 2 + npx / 2);
         }
-        if (!r && e->aq_on) r = ks265_host_malloc(e->ctx, (void **)&j->qp_map, (size_t)e->geom.ctu_cols * e->geom.ctu_rows);
+        if (!r && e->qmap_on) r = ks265_host_malloc(e->ctx, (void **)&j->qp_map, (size_t)e->geom.ctu_cols * e->geom.ctu_rows);
         if (!r) r = ks265_event_create(e->ctx, &j->ev);
         j->nal_cap = npx * 2 + 65536;
         j->nal = (uint8_t *)malloc(j->nal_cap);
@@ -1344,7 +1578,7 @@ static Enc *lane_open(QY265EncConfig *cfg, int device, int multi, int *err)
     /* input slots: the ring + a mini-GOP.  A GOP lane takes a whole GOP more: the caller hands the GOPs out in stream order, so a lane that could not hold its next GOP
      * while it is still coding the current one would make the caller wait - and the OTHER lanes, whose next GOPs come after, run dry (measured: lanes idle a third of
      * the time with ring + 32 slots) */
-    e->nin = e->ring + 32 + (e->la_on ? 8 : 0) + (multi ? (cfg->iIntraPeriod < 256 ? cfg->iIntraPeriod : 256) : 0);
+    e->nin = e->ring + 32 + (e->la_on ? 8 : 0) + (e->ct_on ? e->ct_depth : 0) + (multi ? (cfg->iIntraPeriod < 256 ? cfg->iIntraPeriod : 256) : 0);
     if (getenv("KS265_INPUT_SLOTS")) e->nin = atoi(getenv("KS265_INPUT_SLOTS"));
     if (e->nin < e->ring + 32) e->nin = e->ring + 32;
     if (e->nin > MAX_INPUT) e->nin = MAX_INPUT;
@@ -1376,7 +1610,7 @@ static Enc *lane_open(QY265EncConfig *cfg, int device, int multi, int *err)
     e->scfg.width = e->W; e->scfg.height = e->H; e->scfg.sao = e->use_sao; e->scfg.deblock = e->use_df;
     e->scfg.sdh = e->fcfg.sdh;
     e->zero_latency = cfg->latency == QY265LATENCY_ZERO && e->gop_b == 0 && !e->la_on && !multi;
-    e->scfg.cu_qp_delta = e->aq_on;
+    e->scfg.cu_qp_delta = e->qmap_on;
     e->scfg.tu_inter = e->fcfg.tu_inter;
     e->scfg.wpp = 1;                                                    /* CTU rows as substreams: what lets several writer threads share one picture */
     e->scfg.max_dec_pic_buffering = e->hier ? 10 : e->gop_b ? 4 : e->refs + 1; e->scfg.log2_max_poc_lsb = 16;
@@ -1927,42 +2161,17 @@ static int top_devices(int dev[MAX_LANES])
     if (!n) dev[n++] = one ? atoi(one) : 0;
     return n;
 }
-/* has this process opened the GPU driver yet (an fd on /dev/kfd)?  The HIP runtime reads GPU_MAX_HW_QUEUES once, when it starts: a process that has used the runtime
- * before the encoder opens (torch, RCCL) keeps the four hardware queues it started with whatever is exported now */
-static int gpu_runtime_started(void)
-{
-    DIR *d = opendir("/proc/self/fd");
-    if (!d) return 0;
-    int yes = 0;
-    struct dirent *en;
-    while (!yes && (en = readdir(d))) {
-        char path[288], to[64];
-        if (en->d_name[0] == '.') continue;
-        snprintf(path, sizeof path, "/proc/self/fd/%s", en->d_name);
-        const ssize_t n = readlink(path, to, sizeof to - 1);
-        if (n > 0) { to[n] = 0; if (!strcmp(to, "/dev/kfd")) yes = 1; }
-    }
-    closedir(d);
-    return yes;
-}
 static int top_lanes_wanted(const QY265EncConfig *cfg, int ndev)
 {
+    /* one lane per GPU unless asked (round 6): two closed GOPs side by side fill what the B pictures of a pyramid GOP leave of the device (2160p: 700 pictures/s
+     * against 631), but a lane runs a whole GOP behind its input - twice the lag and twice the pinned input of one - and needs more than the runtime's four hardware queues
+     * (GPU_MAX_HW_QUEUES=8, exported BEFORE the process first touches the GPU; with four: 561).  Both are the application's decisions: the CLI and bench.py take them
+     * (KS265_GOP_LANES=2 + GPU_MAX_HW_QUEUES=8 for the pyramid GOPs under -rc 0 / 3), the library never changes the environment. */
     const char *env = getenv("KS265_GOP_LANES");
-    /* round 5: two lanes per GPU by default for the pyramid GOPs (the SDK's default GOP and -bframes 3): a B picture's kernels leave the device under-filled - two closed GOPs
-     * side by side code 700 pictures/s where one codes 631 (2160p, same stream; IPPP loses with lanes - 970 -> 890 - and stays at one).  KS265_GOP_LANES=1 switches it off */
-    const int gop_b = cfg->bframes < 0 ? (cfg->latency == QY265LATENCY_DEFAULT ? 7 : 0) : cfg->bframes;        /* (as lane_open resolves it) */
-    const int pyramid = gop_b == 7 || gop_b == 3;
-    /* (several GPUs behind one handle: the calling thread feeds them all - one lane each unless asked; -rc 1 / 2 / 4: lanes change the stream - a controller per lane - so only when asked) */
-    int per = env ? atoi(env) : pyramid && ndev == 1 && (cfg->rc == 0 || cfg->rc == 3) ? 2 : 1;
-    if (!env && per > 1) {
-        /* two lanes need more than the runtime's four hardware queues (measured: 561 pictures/s with four, one lane 632, two lanes with eight 700): the library exports
-         * GPU_MAX_HW_QUEUES=8 when it opens several lanes, which takes effect only if the runtime has not started - a process that is already on the GPU and did not export
-         * it itself stays on one lane */
+    int per = env ? atoi(env) : 1;
+    if (per > 1) {
         const char *q = getenv("GPU_MAX_HW_QUEUES");
-        if (q ? atoi(q) < 8 : gpu_runtime_started()) {
-            logf_(1, cfg->logLevel, "ks265enc: one GOP lane (two would be the default for this GOP, but this process runs the GPU runtime with %s hardware queues: export GPU_MAX_HW_QUEUES=8 before its first use)\n", q ? q : "its default four");
-            per = 1;
-        }
+        if (!q || atoi(q) < 8) logf_(1, cfg->logLevel, "ks265enc: %d GOP lanes with %s hardware queues: export GPU_MAX_HW_QUEUES=8 before the process first uses the GPU (measured: two lanes on four queues are slower than one)\n", per, q ? q : "the runtime's default four");
     }
     if (per < 1) per = 1;
     int n = per * ndev;
@@ -1992,14 +2201,6 @@ void *QY265EncoderOpen(QY265EncConfig *cfg, int *err)
     if (t->nlanes > 1 && (cfg->rc == 1 || cfg->rc == 2 || cfg->rc == 4))
         logf_(1, cfg->logLevel, "ks265enc: -rc %d over %d GOP lanes: every lane runs its own controller with the same per-picture bit budget (deterministic, not the one-lane stream)\n", cfg->rc, t->nlanes);
     t->iper = cfg->iIntraPeriod; t->cur_lane = -1;
-    /* every lane runs four streams (pixel path, copy-in, copy-out, key pictures; with the lookahead a fifth); the runtime deals streams to FOUR hardware queues unless told
-     * otherwise, and a lane's 19 ms key-picture kernel in the queue of another lane's pixel path stops that lane for as long (measured: 615 -> 686 pictures/s with eight queues,
-     * two lanes, 2160p).  Only effective when this is the process's first use of the runtime; a value the user has set stays.  (One lane: the order in which lane_open creates
-     * its streams keeps the pixel path's queue to itself - see there.) */
-    if (t->nlanes > 1 && !getenv("GPU_MAX_HW_QUEUES")) {
-        setenv("GPU_MAX_HW_QUEUES", "8", 0);
-        logf_(1, cfg->logLevel, "ks265enc: GPU_MAX_HW_QUEUES=8 set for this process (several GOP lanes; effective if the HIP runtime has not started yet; set it yourself to override)\n");
-    }
     QY265EncConfig lc = *cfg;
     if (t->nlanes > 1) {                                                /* the writer threads are shared out: every lane sees 1 / L of the pictures */
         long ncpu = sysconf(_SC_NPROCESSORS_ONLN);

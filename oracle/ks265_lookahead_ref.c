@@ -332,3 +332,19 @@ void kso_ref_cutree_finish(int cnt, const uint16_t *intra, const uint16_t *inv_q
         out[i] = -15.0 > q ? -15.0 : (q < 20.0 ? q : 20.0);
     }
 }
+
+/* this build's own rule (not the reference's), the mirror of ks265_qoff_ctu_map: one QP per CTU from the offsets of the lookahead's blocks (2^(lg + 1) luma samples: 4 x 4 or 2 x 2 per CTU) */
+void kso_qoff_ctu_map(const double *off, int nx, int ny, int lg, int cols, int rows, int base_qp, int lo, int hi, int8_t *map)
+{
+    const int bpc = 64 >> (lg + 1);
+    for (int cy = 0; cy < rows; ++cy)
+        for (int cx = 0; cx < cols; ++cx) {
+            double sum = 0.0; int cnt = 0;
+            for (int by = cy * bpc; by < (cy * bpc + bpc < ny ? cy * bpc + bpc : ny); ++by)
+                for (int bx = cx * bpc; bx < (cx * bpc + bpc < nx ? cx * bpc + bpc : nx); ++bx) { sum += off[by * nx + bx]; ++cnt; }
+            int d = cnt ? (int)floor(sum / (double)cnt + 0.5) : 0;
+            d = d < -12 ? -12 : d > 12 ? 12 : d;
+            const int q = base_qp + d;
+            map[cy * cols + cx] = (int8_t)(q < lo ? lo : q > hi ? hi : q);
+        }
+}

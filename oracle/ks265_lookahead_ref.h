@@ -16,6 +16,7 @@ void kso_ref_cutree_propagate(int lg, int nx, int ny, const uint16_t *intra, con
  * blocks = nx * ny, lg = cfg+0x3c0, thr = cfg+0x390 (-scenecut), keyint = cfg+0x50, poc = the picture's number, last_key = cfg+0x6e0 */
 int kso_ref_scenecut(int pcost, int icost, int prev_icost, int blocks, int lg, int thr, int keyint, int poc, int last_key);
 void kso_aq_ctu_map(const double *off, int nx, int ny, int base_qp, int lo, int hi, int8_t *map);
+void kso_qoff_ctu_map(const double *off, int nx, int ny, int lg, int cols, int rows, int base_qp, int lo, int hi, int8_t *map);
 double kso_ref_log2(uint32_t x);
 int kso_ref_exp2fix8(double x);
 

@@ -42,6 +42,17 @@ RUNS = [
 from cfc_cases import ARR, KsoCfc, replay_call, replay_finish, set_bits_table   # tests/cfc_cases.py: the struct and the replay the CPU test uses too
 
 
+# whole runs (name, width, height, pictures, encoder args, the mirror's arguments): clips without cuts, a length of 4 k + 1 so that the pyramid of 4 has no partial mini-GOP
+CLIP_ARGS = dict(seed=11, abc=(17, 23, 9), pan=(3, 2))
+WHOLE_RUNS = [
+    ("crf_b3_33", 208, 128, 33, ["-preset", "slow", "-rc", "3", "-crf", "26", "-bframes", "3", "-iper", "64"], dict(preset=5, gop_b=3, hier=True, iper=64)),
+    ("crf_b3_aq_25", 208, 128, 25, ["-preset", "slow", "-rc", "3", "-crf", "24", "-bframes", "3", "-iper", "64", "-aq", "1", "-aqs", "1.2"], dict(preset=5, gop_b=3, hier=True, iper=64, aq_strength=1.2)),
+    ("crf_b3_la20_41", 208, 128, 41, ["-preset", "slow", "-rc", "3", "-crf", "26", "-bframes", "3", "-iper", "64", "-lookahead", "20"], dict(preset=5, gop_b=3, hier=True, iper=64, lookahead=20)),
+    ("crf_b7_33", 256, 144, 33, ["-preset", "slow", "-rc", "3", "-crf", "28", "-bframes", "7", "-iper", "64"], dict(preset=5, gop_b=7, hier=True, iper=64)),
+    ("crf_veryfast_b3_17", 256, 144, 17, ["-preset", "veryfast", "-rc", "3", "-crf", "28", "-bframes", "3", "-iper", "64"], dict(preset=2, gop_b=3, hier=True, iper=64)),
+]
+
+
 def parse(path):
     data = open(path, "rb").read()
     p, calls, fin = 0, [], []
@@ -119,8 +130,31 @@ def main():
                   f"{len(kc)} {'replayed' if check_all else 'kept'}, {nbad} differ), cuTree finish {len(fin)} pictures ({len(kf)}, {fbad} differ)", flush=True)
             if not check_all:
                 kept_calls += [dict(calls[i], run=ri) for i in kc]; kept_fin += [dict(fin[i], run=ri) for i in kf]
+        # a WHOLE run: the offsets the reference left for every picture of a clip without cuts - what the composition of the pinned pieces (the host's cuTree pass, restated in
+        # tests/cutree_mirror.py) has to reproduce picture for picture
+        from ks265codec_amd.synth import make_clip
+        from cutree_mirror import CuTree
+        whole = {}
+        for name, W, H, nfr, args, kw in WHOLE_RUNS:
+            clip = make_clip(W, H, nfr, **CLIP_ARGS)
+            yuv = os.path.join(tmp, "w.yuv"); clip.tofile(yuv)
+            dump = os.path.join(tmp, "w.bin")
+            cmd = [enc, "-i", yuv, "-wdt", str(W), "-hgt", str(H), "-fr", "30", "-threads", "1", *args]
+            subprocess.run(cmd + ["-b", os.path.join(tmp, "plain.265")], capture_output=True, check=True, cwd=tmp)
+            subprocess.run(cmd + ["-b", os.path.join(tmp, "hook.265")], env=dict(os.environ, LD_PRELOAD=shim, KS265_CFC_DUMP=dump, KS265_CFC_ADDLEN=str(len(ADD_PROLOGUE))), capture_output=True, check=True, cwd=tmp)
+            assert open(os.path.join(tmp, "plain.265"), "rb").read() == open(os.path.join(tmp, "hook.265"), "rb").read(), f"{name}: the hooks changed the stream"
+            calls, fin = parse(dump)
+            assert sorted(int(f["h"][3]) for f in fin) == list(range(nfr))
+            ct = CuTree(clip, W, H, **kw); ct.run()
+            same = sum(bool((ct.maps_qoff[int(f["h"][3])] == f["out"]).all()) for f in fin)
+            print(f"{name}: {len(calls)} calcFrameCost calls, {len(fin)} pictures handed on; the mirror of the host's pass leaves the reference's offsets in {same} of {len(fin)} pictures", flush=True)
+            by = {int(f["h"][3]): f for f in fin}
+            whole[name] = dict(same=np.array([bool((ct.maps_qoff[t] == by[t]["out"]).all()) for t in range(nfr)]), args=np.array(" ".join(args)), size=np.array([W, H, nfr], np.int32),
+                               kw=np.array(repr(kw)), off=np.array([by[t]["out"] for t in range(nfr)]), kind=np.array([by[t]["h"][4] for t in range(nfr)], np.int32), isref=np.array([by[t]["h"][5] for t in range(nfr)], np.int32),
+                               order=np.array([[c["h"][14], c["h"][15], c["h"][16]] for c in calls], np.int32))
         if check_all:
             return
+        np.savez_compressed(os.path.join(ROOT, "tests", "golden", "cutree_run.npz"), names=np.array(list(whole)), **{f"{n}_{k}": v for n, d in whole.items() for k, v in d.items()})
         # every distinct plane once
         planes, index = [], {}
         def pid(a):

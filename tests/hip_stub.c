@@ -271,6 +271,47 @@ int ks265_frame_adapt_quant(ks265_ctx *c, const uint8_t *y, int sy, const uint8_
     return KS265_OK;
 }
 int ks265_aq_ctu_map(ks265_ctx *c, const double *off, int nx, int ny, int base, int lo, int hi, int8_t *map) { (void)c; kso_aq_ctu_map(off, nx, ny, base, lo, hi, map); return KS265_OK; }
+/* cuTree (-rc 3): the oracle's restatements of calcFrameCost, cuTreePropagate and the finish ARE the stand-in's "device" operators, so the host's pass over the lookahead window can
+ * be held against the Python mirror of that pass picture for picture (tests/test_host_pipeline_cpu.py) */
+size_t ks265_calc_frame_cost_workspace(int nx, int ny) { (void)nx; (void)ny; return 64; }
+int ks265_calc_frame_cost(ks265_ctx *c, const ks265_cfc_params *q, const uint8_t *cur, const uint8_t *ref0, const uint8_t *ref1, uint16_t *intra, uint8_t *imode, const uint16_t *invq,
+                          uint16_t *inter, uint8_t *bits, int32_t *mv0, int32_t *c0, int32_t *mv1, int32_t *c1, ks265_cfc_sums *s, void *ws)
+{
+    (void)c; (void)ws;
+    kso_cfc k; memset(&k, 0, sizeof k);
+    k.cur = cur; k.ref0 = ref0; k.ref1 = ref1; k.stride = q->stride; k.w = q->w; k.h = q->h; k.nx = q->nx; k.ny = q->ny; k.cnt = q->cnt;
+    k.d0 = q->d0; k.d1 = q->d1; k.flag = q->flag; k.slice_type = q->slice_type;
+    k.merange = q->merange; k.lg = q->lg; k.zero_thr = q->zero_thr; k.fast_intra = q->fast_intra; k.scenecut = q->scenecut; k.preset = q->preset; k.p8 = q->p8; k.aq = q->aq;
+    k.b_intra = q->b_intra; k.f3a8 = q->f3a8; k.f36c = q->f36c; k.f538 = q->f538; k.f3b4 = q->f3b4; k.lambda_tab = q->lambda_tab;
+    k.do_list[0] = q->d0 ? q->do_list[0] : 0; k.do_list[1] = q->d1 ? q->do_list[1] : 0; k.intra_done = q->intra_done;
+    k.intra = intra; k.imode = imode; k.invq = invq; k.inter = inter; k.bits = bits; k.mv[0] = mv0; k.mv[1] = mv1; k.cost[0] = c0; k.cost[1] = c1;
+    k.intra_wins = s->intra_wins; k.sum_intra = s->sum_intra; k.sum_intra_aq = s->sum_intra_aq; k.sum = -1; k.sum_aq = -1; memcpy(k.stats, s->stats, sizeof k.stats);
+    if (q->d0 + q->d1 == 0) k.sum_intra = -1;                        /* (the operator always computes: the "already there" shortcut is the caller's) */
+    k.margin_x = k.margin_y = 40;
+    kso_ref_calc_frame_cost(&k);
+    s->intra_wins = k.intra_wins; s->sum_intra = k.sum_intra; s->sum_intra_aq = k.sum_intra_aq; s->sum = q->d0 + q->d1 ? k.sum : k.sum_intra; s->sum_aq = q->d0 + q->d1 ? k.sum_aq : k.sum_intra_aq;
+    memcpy(s->stats, k.stats, sizeof k.stats); s->ret = k.ret; s->intra_done = k.intra_done;
+    return k.oob ? KS265_FAIL : KS265_OK;
+}
+int ks265_cutree_propagate(ks265_ctx *c, int lg, int nx, int ny, const uint16_t *intra, const uint16_t *invq, const uint16_t *own, const uint16_t *inter, const uint8_t *bits, const int32_t *mv0,
+                           const int32_t *mv1, uint16_t *ref0, uint16_t *ref1, uint64_t *acc)
+{
+    (void)c; (void)acc;
+    kso_ref_cutree_propagate(lg, nx, ny, intra, invq, own, inter, bits, mv0, mv1, ref0, ref1);
+    return KS265_OK;
+}
+int ks265_cutree_finish(ks265_ctx *c, int cnt, const uint16_t *intra, const uint16_t *invq, const uint16_t *prop, const double *aq, int dbl, double *out) { (void)c; kso_ref_cutree_finish(cnt, intra, invq, prop, aq, dbl, out);
+    return KS265_OK; }
+int ks265_pad_plane(ks265_ctx *c, uint8_t *p, int stride, int w, int h, int pad)
+{
+    (void)c;
+    for (int y = -pad; y < h + pad; ++y)
+        for (int x = -pad; x < w + pad; ++x)
+            if (x < 0 || x >= w || y < 0 || y >= h) p[(long)y * stride + x] = p[(long)(y < 0 ? 0 : y >= h ? h - 1 : y) * stride + (x < 0 ? 0 : x >= w ? w - 1 : x)];
+    return KS265_OK;
+}
+int ks265_fill_u16(ks265_ctx *c, uint16_t *d, int n, int v) { (void)c; for (int i = 0; i < n; ++i) d[i] = (uint16_t)v; return KS265_OK; }
+int ks265_qoff_ctu_map(ks265_ctx *c, const double *off, int nx, int ny, int lg, int cols, int rows, int base, int lo, int hi, int8_t *map) { (void)c; kso_qoff_ctu_map(off, nx, ny, lg, cols, rows, base, lo, hi, map); return KS265_OK; }
 int ks265_store_i420(ks265_frame *f, ks265_pic src, uint8_t *i420)
 {
     const int W = f->cfg.width, H = f->cfg.height;
@@ -318,14 +359,13 @@ int ks265_copy_out_compact_async(ks265_ctx *c, ks265_frame *f, void *host, const
 /* ---- scene-cut lookahead (host: -lookahead N): the half-size picture is real (2x2 averages), the two frame costs are stand-ins with the right behaviour - "intra" = how
  * far the samples are from mid-grey, "inter" = how far they are from the reference picture's co-located samples (no search), growing faster than linearly with that distance */
 int ks265_downsample_rect(ks265_ctx *c, const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int h);
+void ks265o_downsample(uint8_t *dst, const uint8_t *src, int dstStride, int srcStride, int w, int h);
 int ks265_downsample_from_host(ks265_ctx *c, const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int h) { return ks265_downsample_rect(c, src, ss, dst, ds, w, h); }
 int ks265_downsample_rect(ks265_ctx *c, const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int h)
 {
     (void)c;
     if (stub_fast()) return KS265_OK;                           /* (a real device takes these launches asynchronously: nothing of them is the calling thread's time) */
-    for (int y = 0; y < h; ++y)
-        for (int x = 0; x < w; ++x)
-            dst[(long)y * ds + x] = (uint8_t)((src[(long)(2 * y) * ss + 2 * x] + src[(long)(2 * y) * ss + 2 * x + 1] + src[(long)(2 * y + 1) * ss + 2 * x] + src[(long)(2 * y + 1) * ss + 2 * x + 1] + 2) >> 2);
+    ks265o_downsample(dst, src, ds, ss, w, h);                  /* downsample_c enc@0x4a6a60, as the device operator */
     return KS265_OK;
 }
 int ks265_pad_picture(ks265_frame *f, ks265_pic pic) { (void)f; (void)pic; return KS265_OK; }

@@ -5,6 +5,8 @@ flat pictures and a still; the stream checked to be unchanged by the hooks).  Bi
 picture sums, the motion statistics and the return value; the QP offsets of the finish are doubles and must be equal, not close."""
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 from cfc_cases import load_fixture, replay_call, replay_finish, set_bits_table
@@ -48,3 +50,28 @@ def test_cutree_finish_matches_reference_traces():
     assert refd >= 25
     spread = max(float(np.ptp(r["out"])) for r in fin if r["h"][5])
     assert spread > 3.0, "the offsets are not trivial"
+
+
+def test_cutree_pass_reproduces_whole_reference_runs():
+    """the COMPOSITION: tests/cutree_mirror.py - the host's cuTree pass (ks265_enc.c ct_run: which picture is costed against which, the window behind a mini-GOP, propagation in reverse coding
+    order, the finish and its end-of-window doubling) written with the oracle's pinned pieces - against the offsets the REFERENCE left for every picture of whole CLI runs
+    (tests/golden/cutree_run.npz: L+0x9b0 of each picture when it leaves the lookahead, recorded by oracle/ref_probe/gen_cfc_traces.py; the clips are make_clip's, regenerated here).
+    Exact (doubles equal) for config 4's GOP - -preset slow -rc 3 -bframes 3, with and without -aq, whole-clip and depth-limited (-lookahead 20) windows; for -bframes 7 the reference's
+    adaptive anchor placement and for veryfast two pictures differ: held to what the fixture recorded"""
+    from cutree_mirror import CuTree
+    from ks265codec_amd.synth import make_clip
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cutree_run.npz"))
+    names = [str(n) for n in z["names"]]
+    assert {"crf_b3_33", "crf_b3_aq_25", "crf_b3_la20_41"} <= set(names)
+    for name in names:
+        W, H, n = (int(v) for v in z[name + "_size"])
+        kw = eval(str(z[name + "_kw"]), {"dict": dict, "True": True, "False": False})
+        clip = make_clip(W, H, n, seed=11, abc=(17, 23, 9), pan=(3, 2))
+        ct = CuTree(clip, W, H, **kw); ct.run()
+        off, rec = z[name + "_off"], z[name + "_same"]
+        same = np.array([bool((ct.maps_qoff[t] == off[t]).all()) for t in range(n)])
+        if name.startswith("crf_b3"):
+            assert same.all(), f"{name} ({z[name + '_args']}): pictures {np.nonzero(~same)[0].tolist()} differ from the reference's offsets"
+            assert float(np.abs(off).max()) > 3.0 and (off[z[name + "_isref"] == 0] == 0).all() == ("aq" not in name)
+        else:
+            assert (same | ~rec).all(), f"{name}: pictures {np.nonzero(~same & rec)[0].tolist()} matched when the fixture was written and do not now"

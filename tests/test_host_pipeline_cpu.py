@@ -507,3 +507,50 @@ def test_slice_type_decision_codes_blocks_of_eight_as_four_plus_four(stub_lib, t
     if os.path.exists(REF_DEC):
         d = subprocess.run([REF_DEC, "-b", str(tmp_path / "p.265"), "-o", str(tmp_path / "d2.yuv"), "-threads", "2"], capture_output=True, text=True, cwd=tmp_path)
         assert d.returncode == 0 and os.path.getsize(tmp_path / "d2.yuv") == 100 * 128 * 96 * 3 // 2, d.stdout[-300:] + d.stderr[-300:]
+
+
+@pytest.mark.parametrize("opts,n,W,H", [(["-bframes", "3"], 26, 192, 128), (["-bframes", "3", "-lookahead", "12", "-aq", "1", "-aqs", "1.0"], 22, 192, 128), (["-bframes", "3", "-iper", "10"], 23, 128, 128)])
+def test_crf_runs_the_cutree_pass_of_the_lookahead(tmp_path, opts, n, W, H):
+    """-rc 3 (config 4's rate control): the host's cuTree pass - calcFrameCost over the lookahead window, propagation in reverse coding order, the finish, one QP per CTU - linked against
+    the stand-in whose operators ARE the oracle's pinned restatements, against tests/cutree_mirror.py (the same pass written independently in Python): the same QP per CTU for every
+    picture; the maps are not flat, reference pictures carry the tree's (negative) offsets, non-reference B pictures stay at their picture QP"""
+    import re
+    import numpy as np
+    from ks265codec_amd.synth import make_clip
+    from cutree_mirror import CuTree, read_qpmap_dump
+    host = os.path.join(ROOT, "ks265codec_amd", "host")
+    exe = str(tmp_path / "ks265enc_stub")
+    subprocess.check_call(["gcc", "-O2", "-std=gnu11", "-Wall", "-Wextra", "-I", os.path.join(ROOT, "include"), "-o", exe, os.path.join(host, "ks265_cli.c"),
+                           os.path.join(host, "ks265_enc.c"), os.path.join(host, "ks265_stream.c"), os.path.join(HERE, "hip_stub.c"),
+                           "-L", os.path.join(ROOT, "oracle"), "-lks265_oracle", "-Wl,-rpath," + os.path.join(ROOT, "oracle"), "-lpthread", "-lm"])
+    clip = make_clip(W, H, n, seed=11, abc=(17, 23, 9), pan=(3, 2))
+    clip.tofile(tmp_path / "in.yuv")
+    dump = tmp_path / "maps.bin"
+    args = [exe, "-i", str(tmp_path / "in.yuv"), "-wdt", str(W), "-hgt", str(H), "-fr", "50", "-preset", "slow", "-rc", "3", "-crf", "26", "-iper", "64", "-psnr", "2", "-threads", "3", "-b", str(tmp_path / "o.265"), *opts]
+    r = subprocess.run(args, capture_output=True, text=True, timeout=300, env=dict(os.environ, KS265_DUMP_QPMAP=str(dump)))
+    assert r.returncode == 0 and "H265 encoder passed!!!" in r.stdout, r.stdout[-800:] + r.stderr[-800:]
+    assert "cuTree over a lookahead" in r.stdout + r.stderr
+    got = read_qpmap_dump(dump)
+    assert sorted(got) == list(range(n))
+    kw = dict(zip(opts[::2], opts[1::2]))
+    gop_b = int(kw["-bframes"]); iper = int(kw.get("-iper", 64))
+    keys = [d for d in got if got[d][0] == "I" and d > 0]                     # (-lookahead N also runs the scene-cut lookahead: the stand-in's costs cut every 8 pictures)
+    assert bool(keys) == ("-lookahead" in kw or iper < n)
+    ct = CuTree(clip, W, H, preset=5, gop_b=gop_b, hier=gop_b == 3, iper=iper, lookahead=int(kw.get("-lookahead", -1)), aq_strength=float(kw.get("-aqs", 0)) if "-aq" in kw else 0.0, keys=keys)
+    ct.run()
+    spread = 0
+    for d in range(n):
+        kind, qp, m = got[d]
+        want = ct.ctu_map(d, qp)
+        assert (m == want).all(), f"picture {d} ({kind}, qp {qp}): {m.tolist()} != {want.tolist()}"
+        spread = max(spread, int(m.max()) - int(m.min()))
+        if "-aq" not in kw:
+            assert (m <= qp).all(), "the tree only lowers QPs"
+            if kind == "B" and d % 4 != 2 and iper >= n:
+                assert (m == qp).all(), "non-reference B pictures keep their picture QP"
+    assert spread >= (2 if iper >= n else 1), "the maps are not flat"
+    # -cutree 0: the ladder alone, no cu_qp_delta
+    r0 = subprocess.run(args + ["-cutree", "0"], capture_output=True, text=True, timeout=300, env=dict(os.environ, KS265_DUMP_QPMAP=str(tmp_path / "none.bin")))
+    assert r0.returncode == 0 and "cuTree" not in r0.stdout + r0.stderr
+    if "-aq" not in kw:
+        assert not os.path.exists(tmp_path / "none.bin") or os.path.getsize(tmp_path / "none.bin") == 0
