@@ -1853,7 +1853,8 @@ static int lane_put(Enc *e, QY265Picture *in, int key)
     /* back-pressure on the input side: at most 16 pictures wait for the scheduler thread (it may itself be waiting for ring space, which only the
      * caller's take_output frees - then go on and collect).  GOP lanes (multi): the input slots are the limit (lane_has_slot) - a lane takes a whole GOP in
      * while it is still coding the previous one, or the caller would wait here while the other lanes run dry */
-    while (!e->multi && !e->quit && !e->sched_err && e->next_disp - (e->coded_upto + 1) > 16 && e->njobs <= e->ring - 12) pthread_cond_wait(&e->cv_sched_done, &e->mu);
+    /* (cuTree: the scheduler itself holds a mini-GOP back until its window has arrived - that many more may wait) */
+    while (!e->multi && !e->quit && !e->sched_err && e->next_disp - (e->coded_upto + 1) > 16 + (e->ct_on ? e->ct_depth + e->gop_b + 1 : 0) && e->njobs <= e->ring - 12) pthread_cond_wait(&e->cv_sched_done, &e->mu);
     e->la_t_bp += now_ms() - tc0;   /* a scheduler that failed makes no more progress */
     int own = 0;                                                       /* the caller wrote the picture into a slot it had acquired (ks265_enc_acquire_input): nothing to copy */
     for (int i = 0; i < e->nin && !slot; ++i) if (e->in[i].used == 4 && e->in[i].i420 == in->yuv->pData[0]) { slot = &e->in[i]; own = 1; }

@@ -63,7 +63,7 @@ def _aq_map(o, i420, qp, strength):
     return qmap
 
 
-def _mirror(clip, W, H, per, refs_of, rec, tools, upto, aq=0.0):
+def _mirror(clip, W, H, per, refs_of, rec, tools, upto, aq=0.0, maps=None):
     """the oracle pipeline with the encoder's per-picture QPs and reference pictures: reconstruction == the encoder's, for the first `upto` pictures in coding order"""
     from ks265codec_amd.synth import lambda_q4
     from oracle_lib import OraclePipeline
@@ -73,7 +73,9 @@ def _mirror(clip, W, H, per, refs_of, rec, tools, upto, aq=0.0):
     spread = set()
     for i, (poc, kind, _, qp) in enumerate(per[:upto]):
         o.set_qp(qp, lambda_q4(qp, inter=kind != "I"))
-        if aq:
+        if maps is not None:
+            o.set_qp_map(maps[poc]); spread |= set(maps[poc].tolist())
+        elif aq:
             qmap = _aq_map(o, clip[poc], qp, aq)
             o.set_qp_map(qmap)
             spread |= set(qmap.tolist())
@@ -88,17 +90,30 @@ def _mirror(clip, W, H, per, refs_of, rec, tools, upto, aq=0.0):
     return spread
 
 
-def test_crf_with_three_b_pictures(tmp_path):
-    """config 4's command line at 1920x1080: -preset slow -rc 3 -crf 24 -bframes 3"""
+def _crf_case(tmp_path, W, H, n, upto, extra=()):
+    """config 4's command line: -preset slow -rc 3 -crf 24 -bframes 3.  The picture QPs are the ladder on crf (I = crf, anchors + 1, B + 2 / + 3: the reference's CRF with its tree on keeps
+    picture QPs near-constant too); the QP of every CTU comes from the cuTree pass over the lookahead window (calcFrameCost enc@0x4a7410, cuTreePropagate enc@0x47d460, the finish) -
+    held against tests/cutree_mirror.py, whose pass reproduces the reference's own per-picture offsets on whole runs (tests/test_calc_frame_cost.py)"""
+    from cutree_mirror import CuTree, read_qpmap_dump
     from ks265codec_amd.synth import ENCODER_TOOLS, make_clip
-    W, H, n = 1920, 1080, 13
     clip = make_clip(W, H, n, seed=W + n, abc=(37, 53, 19), pan=(5, 3))
-    log, per, kbps, rec, out = _encode(tmp_path, clip, W, H, ["-preset", "slow", "-rc", "3", "-crf", "24", "-bframes", "3", "-iper", "128"])
+    dump = tmp_path / "maps.bin"
+    log, per, kbps, rec, out = _encode(tmp_path, clip, W, H, ["-preset", "slow", "-rc", "3", "-crf", "24", "-bframes", "3", "-iper", "128", *extra], env={"KS265_DUMP_QPMAP": str(dump)})
+    assert "cuTree over a lookahead" in log, log[:1500]
     # -bframes 3 is a pyramid of 4 as in the reference (its -psnr 2 lines: coding order 0 4 2 1 3 8 6 5 7 .., QP + 1 / + 2 / + 3 / + 3): the middle picture is a reference B
     assert len(per) == n and [(p, k) for p, k, _, _ in per[:9]] == [(0, "I"), (4, "P"), (2, "B"), (1, "B"), (3, "B"), (8, "P"), (6, "B"), (5, "B"), (7, "B")]
-    assert {(k, q) for _, k, _, q in per} == {("I", 24), ("P", 25), ("B", 26), ("B", 27)}, "crf 24 is the ladder I = 24, P = 25, B = 26 (reference B) / 27"
-    assert all(q == (26 if p % 4 == 2 else 27) for p, k, _, q in per if k == "B")
+    assert {(k, q) for _, k, _, q in per} == {("I", 24), ("P", 25), ("B", 26), ("B", 27)}
     _decoder_check(tmp_path, out, rec, n, W * H * 3 // 2)
+    got = read_qpmap_dump(dump)
+    kw = dict(zip(extra[::2], extra[1::2]))
+    ct = CuTree(clip, W, H, preset=5, gop_b=3, hier=True, iper=128, lookahead=int(kw.get("-lookahead", -1)), aq_strength=float(kw.get("-aqs", 1.0)) if kw.get("-aq") == "1" else 0.0)
+    ct.run()
+    maps, lowered = {}, 0
+    for poc, kind, _, qp in per:
+        maps[poc] = ct.ctu_map(poc, qp)
+        assert got[poc][1] == qp and (got[poc][2] == maps[poc]).all(), f"picture {poc} ({kind}, qp {qp}): the encoder's QP per CTU differs from the cuTree mirror's in {int((got[poc][2] != maps[poc]).sum())} CTUs"
+        lowered += int((maps[poc] < qp).sum())
+    assert lowered > len(per), "the tree lowers QPs where later pictures predict from"
     coded = []
 
     def refs(i, poc, kind):                                                # the nearest pictures coded before on either side (the outer B pictures of a block come last)
@@ -108,7 +123,24 @@ def test_crf_with_three_b_pictures(tmp_path):
         hi = min((p for p in coded if p > poc), default=None)
         coded.append(poc)
         return (lo, None) if kind == "P" else (lo, hi)
-    _mirror(clip, W, H, per, refs, rec, ENCODER_TOOLS, upto=9)
+    spread = _mirror(clip, W, H, per, refs, rec, ENCODER_TOOLS, upto=upto, maps=maps)
+    assert len(spread) >= 3
+    return log
+
+
+def test_crf_with_three_b_pictures(tmp_path):
+    """config 4's command line at 1920x1080"""
+    _crf_case(tmp_path, 1920, 1080, 13, upto=9)
+
+
+def test_crf_with_three_b_pictures_and_adaptive_quantisation(tmp_path):
+    """... with -aq 1: the tree's offsets start from the block-variance offsets (calcFrameAdaptQuant enc@0x4653c0 on the lookahead's grid, as the reference calls it); 1280x720, a window of 16"""
+    _crf_case(tmp_path, 1280, 720, 21, upto=5, extra=("-aq", "1", "-aqs", "1.0", "-lookahead", "20"))
+
+
+def test_crf_with_three_b_pictures_at_2160p(tmp_path):
+    """config 4's command line at its own size, 3840x2160: decoder == -o, the QP per CTU == the cuTree mirror's for every picture, the oracle pipeline on those maps == -o for the first pictures"""
+    _crf_case(tmp_path, 3840, 2160, 9, upto=3)
 
 
 def test_bitrate_target_ippp(tmp_path):

@@ -509,7 +509,7 @@ def test_slice_type_decision_codes_blocks_of_eight_as_four_plus_four(stub_lib, t
         assert d.returncode == 0 and os.path.getsize(tmp_path / "d2.yuv") == 100 * 128 * 96 * 3 // 2, d.stdout[-300:] + d.stderr[-300:]
 
 
-@pytest.mark.parametrize("opts,n,W,H", [(["-bframes", "3"], 26, 192, 128), (["-bframes", "3", "-lookahead", "12", "-aq", "1", "-aqs", "1.0"], 22, 192, 128), (["-bframes", "3", "-iper", "10"], 23, 128, 128)])
+@pytest.mark.parametrize("opts,n,W,H", [(["-bframes", "3"], 26, 192, 128), (["-bframes", "3", "-iper", "100"], 90, 128, 128), (["-bframes", "3", "-lookahead", "24", "-aq", "1", "-aqs", "1.0"], 40, 192, 128), (["-bframes", "3", "-iper", "10"], 23, 128, 128)])
 def test_crf_runs_the_cutree_pass_of_the_lookahead(tmp_path, opts, n, W, H):
     """-rc 3 (config 4's rate control): the host's cuTree pass - calcFrameCost over the lookahead window, propagation in reverse coding order, the finish, one QP per CTU - linked against
     the stand-in whose operators ARE the oracle's pinned restatements, against tests/cutree_mirror.py (the same pass written independently in Python): the same QP per CTU for every
