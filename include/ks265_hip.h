@@ -64,7 +64,12 @@ int ks265_dev_malloc(ks265_ctx *, void **dev, size_t bytes);
 int ks265_dev_free(ks265_ctx *, void *dev);
 int ks265_host_malloc(ks265_ctx *, void **host, size_t bytes);
 int ks265_host_free(ks265_ctx *, void *host);
+/* memory of the application pinned and mapped IN PLACE (hipHostRegister) so that ks265_memcpy_h2d_async can read it by DMA: the encoder host uploads the caller's picture planes
+ * without a copy into pinned memory of its own.  A range is registered once (a second registration of overlapping memory fails); failure is not an error of the context */
+int ks265_host_register(ks265_ctx *, void *host, size_t bytes);
+int ks265_host_unregister(ks265_ctx *, void *host);
 int ks265_memcpy_h2d_async(ks265_ctx *, void *dev, const void *host, size_t bytes);
+int ks265_memcpy_h2d_sync(ks265_ctx *, void *dev, const void *host, size_t bytes);     /* on no stream of the library's; returns when the data is on the device */
 int ks265_memcpy_d2h_async(ks265_ctx *, void *host, const void *dev, size_t bytes);
 int ks265_memcpy_d2d_async(ks265_ctx *, void *dev_dst, const void *dev_src, size_t bytes);
 /* device -> pinned host memory of ks265_host_malloc as a kernel of 32 work-groups on the context's stream (stores straight over PCIe): unlike a runtime

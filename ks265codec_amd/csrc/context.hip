@@ -119,6 +119,32 @@ int ks265_host_free(ks265_ctx *c, void *host)
     if (!c) return KS265_POINTER;
     return host ? ks265_hip(c, hipHostFree(host)) : KS265_OK;
 }
+/* the caller's own memory made DMA-able in place (hipHostRegister: the pages are pinned and mapped, the data does not move) - the encoder host uploads straight from the
+ * application's picture buffers instead of copying them into pinned memory of its own first */
+int ks265_host_register(ks265_ctx *c, void *host, size_t bytes)
+{
+    if (!c || !host) return KS265_POINTER;
+    if (!bytes) return KS265_NOTSUPPORTED;
+    (void)hipSetDevice(c->device);
+    const hipError_t e = hipHostRegister(host, bytes, hipHostRegisterDefault);
+    if (e != hipSuccess) (void)hipGetLastError();                       /* (not sticky: the caller falls back to its copying path) */
+    return ks265_hip(c, e);
+}
+int ks265_host_unregister(ks265_ctx *c, void *host)
+{
+    if (!c || !host) return KS265_POINTER;
+    const hipError_t e = hipHostUnregister(host);
+    if (e != hipSuccess) (void)hipGetLastError();
+    return ks265_hip(c, e);
+}
+/* host -> device NOW, on no stream of the library's (the runtime's null stream; the contexts' streams are non-blocking and do not order against it): returns when the data is
+ * on the device.  For memory of ks265_host_register / ks265_host_malloc this is one DMA */
+int ks265_memcpy_h2d_sync(ks265_ctx *c, void *dev, const void *host, size_t bytes)
+{
+    if (!c || !dev || !host) return KS265_POINTER;
+    ks_use_device(c);
+    return ks265_hip(c, hipMemcpy(dev, host, bytes, hipMemcpyHostToDevice));
+}
 int ks265_memcpy_h2d_async(ks265_ctx *c, void *dev, const void *host, size_t bytes)
 {
     if (!c || !dev || !host) return KS265_POINTER;

@@ -273,7 +273,7 @@ static void copy_shared(CopyPool *p, uint8_t *d, const uint8_t *s, size_t n)
 #define LA_RING 9                                                      /* half-size pictures kept for the analysis: the current one and eight back */
 #define LA_QMAX 64                                                     /* pictures that may wait at the input for their analysis (a GOP lane runs a whole GOP ahead of its pixel path) */
 #define LA_FLY 16                                                      /* analyses in flight = result areas */
-typedef struct Input { int used, disp, key, base_qp, iper, mini4, kbps, la_what, la_p, la_buf; long long pts; uint8_t *i420; uint8_t *dev; void *ev_up; } Input;   /* dev / ev_up: the slot's twin on the device, uploaded
+typedef struct Input { int used, disp, key, base_qp, iper, mini4, kbps, la_what, la_p, la_buf, up_sync; long long pts; uint8_t *i420; uint8_t *dev; void *ev_up; } Input;   /* up_sync: the twin was filled by a host-synchronous copy (nothing to wait for) */   /* dev / ev_up: the slot's twin on the device, uploaded
                                                                                                  * when the picture is handed in (round 4), and the event behind that upload */     /* pinned; key: this picture starts a closed GOP whatever the period says (GOP lanes,
                                                                                                  * QY265EncoderKeyFrameRequest); base_qp: the QP in force when the picture was handed in (QY265EncoderReconfig) -
                                                                                                  * iper: the key period in force then - all three travel WITH the picture: the scheduler thread
@@ -293,6 +293,10 @@ typedef struct Enc {
     ks265_ctx *ctx_in, *ctx_out;
     uint8_t *dev_in[NPIPE]; void *ev_h2d[NPIPE], *ev_loaded[NPIPE];
     void *spacer[64]; int nspacer;
+    /* round 6: the caller's planes are pinned in place (ks265_host_register, cached by address) and uploaded by DMA straight into the slot's device twin - no copy into pinned memory of
+     * the encoder's own (KS265_INPUT_COPY=1: the copying path; pictures under 1 MB always copy).  The upload is waited for before QY265EncoderEncodeFrame returns - the SDK's own callers
+     * refill ONE buffer for every picture (encoderwrapper.c:367-379) - unless KS265_INPUT_HOLD=1 (the caller keeps every buffer until its picture has come out, qy265enc.h:153-156) */
+    int direct_in, hold_in; ks265_ctx *ctx_upl; struct Input *pending_up;
     ks265_ctx *ctx_up;                                    /* with the lookahead: = ctx_la, the stream the caller's thread feeds with uploads (the moment a picture is handed in) and with the analysis; else NULL */
     uint8_t *stg[NPIPE]; size_t cmp_off[8];               /* staging blocks of the (compact) records on the device and their layout */
     void *ev_staged[NPIPE], *ev_drained[NPIPE];
@@ -694,7 +698,7 @@ static int ct_prepare(Enc *e, int disp)
     int r = c->used ? ks265_stream_wait_event(cx, c->ev_used) : 0;       /* the picture that held this slot CT_RING pictures ago: its QP map has been taken */
     c->disp = disp; c->p0 = c->p1 = -1000000; c->intra_done = 0;
     const uint8_t *full = NULL;
-    if (in->dev) { if (!r) r = ks265_stream_wait_event(cx, in->ev_up); full = in->dev; }
+    if (in->dev) { if (!r && !in->up_sync) r = ks265_stream_wait_event(cx, in->ev_up); full = in->dev; }
     else if (e->ct_full) { if (!r) r = ks265_memcpy_h2d_async(cx, e->ct_full, in->i420, (size_t)e->W * e->H * 3 / 2); full = e->ct_full; }
     if (!r) r = full ? ks265_downsample_rect(cx, full, e->W, c->low, e->ct_stride, e->ct_w, e->ct_h) : ks265_downsample_from_host(cx, in->i420, e->W, c->low, e->ct_stride, e->ct_w, e->ct_h);
     if (!r) r = ks265_pad_plane(cx, c->low, e->ct_stride, e->ct_w, e->ct_h, e->ct_pad);
@@ -828,9 +832,9 @@ static int submit(Enc *e, Input *in, int kind, int poc, int qp, const int *l0, i
      * pictures in front of it - and, HIP streams sharing hardware queues (four by default), behind whatever else runs in that queue: measured, the anchor then starts when
      * the last B picture of the mini-GOP before it has left the device */
     const int direct = on_anc && in->dev && !e->use_graph;
-    if (direct) { if (!r) r = ks265_stream_wait_event(cx, in->ev_up); din = in->dev; }
+    if (direct) { if (!r && !in->up_sync) r = ks265_stream_wait_event(cx, in->ev_up); din = in->dev; }
     else if (in->dev) {
-        if (!r) r = ks265_stream_wait_event(e->ctx_in, in->ev_up);
+        if (!r && !in->up_sync) r = ks265_stream_wait_event(e->ctx_in, in->ev_up);
         if (!r && e->use_graph) r = ks265_memcpy_d2d_async(e->ctx_in, e->dev_in[k], in->dev, fsz);
         else din = in->dev;
     } else if (!r) r = ks265_memcpy_h2d_async(e->ctx_in, e->dev_in[k], in->i420, fsz);
@@ -1170,6 +1174,7 @@ static int schedule(Enc *e, int flush, int have /* pictures [0, have) have arriv
 /* ---- the scheduler thread: runs schedule() whenever pictures have arrived (or a flush was asked for).  The caller's thread only copies the input
  *      picture and collects output; this thread takes the GOP decisions and enqueues the GPU work of every picture. */
 static int la_drain(Enc *e, int keep);
+static void reg_handle(ks265_ctx *c, int open);
 static void *scheduler(void *arg)
 {
     Enc *e = (Enc *)arg;
@@ -1345,13 +1350,15 @@ static void lane_close(Enc *e, int report)
             if (e->frame_la) ks265_frame_destroy(e->frame_la);
             ks265_destroy(e->ctx_la);
         }
+        if (e->ctx_up) reg_handle(e->ctx, 0);
+        if (e->ctx_upl) { ks265_synchronize(e->ctx_upl); ks265_destroy(e->ctx_upl); }
         if (e->frame) ks265_frame_destroy(e->frame);
         if (e->ctx_key) ks265_destroy(e->ctx_key);
         if (e->ctx_anc) ks265_destroy(e->ctx_anc);
         if (e->ctx_in) ks265_destroy(e->ctx_in);
         if (e->ctx_out) ks265_destroy(e->ctx_out);
         ks265_destroy(e->ctx);
-    } else if (e->ctx_la) ks265_destroy(e->ctx_la);                   /* created first (lane_open), before the main context failed: nothing else of the lookahead exists yet */
+    } else { if (e->ctx_la) ks265_destroy(e->ctx_la); if (e->ctx_upl) ks265_destroy(e->ctx_upl); }                   /* created first (lane_open), before the main context failed: nothing else of the lookahead exists yet */
     for (int i = 0; i < MAX_JOBS; ++i) free(e->jobs[i].wpp);
     free(e->hdr); free(e->outbuf); free(e->md5_ring); free(e->md5_have);
     pthread_mutex_destroy(&e->la_mu);
@@ -1414,7 +1421,18 @@ static Enc *lane_open(QY265EncConfig *cfg, int device, int multi, int *err)
      * process the four normal streams have a queue each; the key pictures' stream is high-priority and has its own.) */
     const int la_wanted = e->cfg.lookahead > 0 || (e->cfg.lookahead < 0 && e->hier && e->gop_b == 7 && !getenv("KS265_NO_AUTO_LOOKAHEAD"));
     const int la_order = getenv("KS265_LA_ORDER") ? atoi(getenv("KS265_LA_ORDER")) : 0;      /* (experiments: 1 = fourth, 2 = last) */
+    if (!getenv("KS265_INPUT_COPY") && getenv("KS265_UPL_ORDER") && atoi(getenv("KS265_UPL_ORDER")) == -1 && (size_t)e->W * e->H * 3 / 2 >= ((size_t)1 << 20)) { if (ks265_create(&e->ctx_upl, device)) e->ctx_upl = NULL; }
     if (la_wanted && la_order == 0 && ks265_create(&e->ctx_la, device)) e->ctx_la = NULL;
+    e->direct_in = !getenv("KS265_INPUT_COPY") && (size_t)e->W * e->H * 3 / 2 >= ((size_t)1 << 20) && !(cfg->latency == QY265LATENCY_ZERO && !multi);
+    e->hold_in = getenv("KS265_INPUT_HOLD") && atoi(getenv("KS265_INPUT_HOLD")) > 0;
+    /* the uploads' stream: created first, like the lookahead's.  Its own even beside the lookahead's: the caller waits for the upload, and behind the analysis kernels of the picture
+     * before (measured: 1.17 ms per call instead of the 0.3 ms the DMA takes) it would wait for those too */
+    /* how the upload out of the caller's memory runs.  4 (default): host-synchronous, on no stream of the lane's (ks265_memcpy_h2d_sync): the call returns when the picture is on the device.
+     * 0 / -1 / 1 / 2 (experiments): asynchronously on a stream of its own created first / in front of the lookahead's / after the copy streams / last, waited for at the end of the call.
+     * Measured at 2160p (profiles/r06_input_upload.txt): ANY stream more costs the two-lane default GOP a third of its rate (754 -> 515 .. 600 pictures/s: hardware queues are shared in
+     * creation order) although the caller's input time falls to 0.33 ms; without one the default GOP codes 777 (copying path 758) and IPPP 1 028 (1 025), input 0.88 / 0.26 ms */
+    const int upl_order = getenv("KS265_UPL_ORDER") ? atoi(getenv("KS265_UPL_ORDER")) : 4;
+    if (e->direct_in && upl_order == 0 && ks265_create(&e->ctx_upl, device)) { e->ctx_upl = NULL; e->direct_in = 0; }
     int r = ks265_create(&e->ctx, device);
     if (r) { *err = hip_rc(r); lane_close(e, 0); return NULL; }       /* KS265_NO_DEVICE -> QY_FAIL: there is no CPU fallback */
     memset(&e->fcfg, 0, sizeof e->fcfg);
@@ -1444,6 +1462,7 @@ static Enc *lane_open(QY265EncConfig *cfg, int device, int multi, int *err)
     if (!r) r = ks265_frame_compact_layout(e->frame, e->cmp_off);
     if (!r) r = ks265_create(&e->ctx_in, dev_id);
     if (!r) r = ks265_create(&e->ctx_out, dev_id);
+    if (!r && e->direct_in && upl_order == 1) { if (ks265_create(&e->ctx_upl, dev_id)) { e->ctx_upl = NULL; e->direct_in = 0; } }
     if (!r && la_wanted && la_order == 1) r = ks265_create(&e->ctx_la, dev_id);
     e->split = getenv("KS265_NO_SPLIT") ? 0 : 1;
     e->copy_mb = getenv("KS265_COPYOUT_MB") ? atoi(getenv("KS265_COPYOUT_MB")) : -1;
@@ -1600,8 +1619,13 @@ static Enc *lane_open(QY265EncConfig *cfg, int device, int multi, int *err)
      * the pipeline: an upload enqueued on the copy-in stream, or anywhere on the copy engine behind that stream's uploads, sits behind the pipeline's back-pressure and the
      * analysis would see the picture 10 ms and more late); without it the picture is uploaded when it is scheduled, on the copy-in stream, as before.  One stream for both,
      * not a sixth: a stream more is a hardware queue shared with somebody (top of this function) */
-    if (e->la_on && e->ctx_la) {
-        e->ctx_up = e->ctx_la;
+    if (e->direct_in && upl_order == 2) { if (ks265_create(&e->ctx_upl, dev_id)) { e->ctx_upl = NULL; e->direct_in = 0; } }
+    if (e->direct_in && upl_order == 4) e->direct_in = 2;              /* host-synchronous uploads: no stream of their own */
+    if (e->direct_in == 1 && !e->ctx_upl) e->direct_in = 0;
+
+    if ((e->la_on && e->ctx_la) || e->direct_in) {
+        e->ctx_up = e->direct_in == 1 && e->ctx_upl ? e->ctx_upl : e->ctx_la ? e->ctx_la : e->ctx;
+        reg_handle(e->ctx, 1);
         for (int i = 0; i < e->nin && !r; ++i) { r = ks265_dev_malloc(e->ctx, (void **)&e->in[i].dev, fsz); if (!r) r = ks265_event_create(e->ctx_up, &e->in[i].ev_up); }
         logf_(2, e->log_level, "ks265enc: %d input slots with a device twin each: %.2f GB of device memory per lane (KS265_INPUT_SLOTS / KS265_PINNED_MB bound the slot count)\n", e->nin, e->nin * (double)fsz / 1073741824.0);
     }
@@ -1810,7 +1834,8 @@ static int la_take_locked(Enc *e, Input *slot)
         /* the half-size picture from the slot's twin on the device (uploaded a moment ago on this stream).  Measured in round 4 before that existed: an H2D copy of the
          * luma plane on this stream (round 3) queues on the copy engine BEHIND the uploads the scheduler had enqueued, which waited for the pipeline's buffers - the results
          * arrived 10 ms and more late; kernels reading the pinned picture over PCIe instead (ks265_downsample_from_host, 64 work-groups) cost the encoder 28 % */
-        r = ks265_downsample_rect(e->ctx_la, slot->dev, e->W, e->la_pic[c].y + org, e->geom_la.stride_y, w, h);
+        r = e->ctx_up != e->ctx_la && !slot->up_sync ? ks265_stream_wait_event(e->ctx_la, slot->ev_up) : 0;      /* (the upload runs on a stream of its own) */
+        if (!r) r = ks265_downsample_rect(e->ctx_la, slot->dev, e->W, e->la_pic[c].y + org, e->geom_la.stride_y, w, h);
         if (!r) r = ks265_pad_picture(e->frame_la, e->la_pic[c]);
         if (!r && e->la_have_prev && !e->la_auto) {
             r = ks265_lookahead_picture(e->frame_la, e->la_pic[c], e->la_pic[(nd + LA_RING - 1) % LA_RING], e->la_cost_ws, dout);
@@ -1843,6 +1868,39 @@ static int la_take(Enc *e, Input *slot)
 }
 
 /* one picture into the lane: copy to a pinned slot, hand it to the scheduler thread.  key: it starts a closed GOP regardless of the period */
+/* ---- the application's picture buffers, pinned in place once and remembered (process-wide: hipHostRegister refuses memory that is registered already) --------------------------- */
+#define REG_MAX 160
+static struct { pthread_mutex_t mu; struct { uint8_t *base; size_t n; unsigned long stamp; } ent[REG_MAX]; int n; unsigned long clock; uint8_t *bad[32]; int nbad; int handles; } g_reg = {.mu = PTHREAD_MUTEX_INITIALIZER};
+static int reg_get(ks265_ctx *c, uint8_t *p, size_t n, int may_evict)
+{
+    int ok = 0;
+    pthread_mutex_lock(&g_reg.mu);
+    ++g_reg.clock;
+    for (int i = 0; i < g_reg.n && !ok; ++i)
+        if (p >= g_reg.ent[i].base && p + n <= g_reg.ent[i].base + g_reg.ent[i].n) { g_reg.ent[i].stamp = g_reg.clock; ok = 1; }
+    for (int i = 0; i < g_reg.nbad && !ok; ++i) if (g_reg.bad[i] == p) { pthread_mutex_unlock(&g_reg.mu); return 0; }
+    if (!ok) {
+        for (int i = 0; i < g_reg.n; )                                 /* a buffer that overlaps an older registration: that memory has been given back and handed out again */
+            if (p < g_reg.ent[i].base + g_reg.ent[i].n && g_reg.ent[i].base < p + n) { (void)ks265_host_unregister(c, g_reg.ent[i].base); g_reg.ent[i] = g_reg.ent[--g_reg.n]; } else ++i;
+        if (g_reg.n == REG_MAX && may_evict) {                         /* least recently used */
+            int lru = 0;
+            for (int i = 1; i < g_reg.n; ++i) if (g_reg.ent[i].stamp < g_reg.ent[lru].stamp) lru = i;
+            (void)ks265_host_unregister(c, g_reg.ent[lru].base); g_reg.ent[lru] = g_reg.ent[--g_reg.n];
+        }
+        if (g_reg.n < REG_MAX && ks265_host_register(c, p, n) == KS265_OK) { g_reg.ent[g_reg.n].base = p; g_reg.ent[g_reg.n].n = n; g_reg.ent[g_reg.n++].stamp = g_reg.clock; ok = 1; }
+        else if (g_reg.nbad < 32) g_reg.bad[g_reg.nbad++] = p;         /* memory the runtime cannot pin: that buffer is copied from now on */
+    }
+    pthread_mutex_unlock(&g_reg.mu);
+    return ok;
+}
+static void reg_handle(ks265_ctx *c, int open)
+{
+    pthread_mutex_lock(&g_reg.mu);
+    g_reg.handles += open ? 1 : -1;
+    if (!open && g_reg.handles == 0) { for (int i = 0; i < g_reg.n; ++i) (void)ks265_host_unregister(c, g_reg.ent[i].base); g_reg.n = 0; g_reg.nbad = 0; }   /* the last lane of the process lets go of the application's memory */
+    pthread_mutex_unlock(&g_reg.mu);
+}
+
 static int lane_put(Enc *e, QY265Picture *in, int key)
 {
     if (!in->yuv || !in->yuv->pData[0] || !in->yuv->pData[1] || !in->yuv->pData[2]) return QY_POINTER;
@@ -1861,11 +1919,33 @@ static int lane_put(Enc *e, QY265Picture *in, int key)
     for (int i = 0; i < e->nin && !slot; ++i) if (!e->in[i].used) slot = &e->in[i];
     for (int i = 0; i < e->nin && !slot; ++i) if (e->in[i].used == 4) slot = &e->in[i];   /* last resort: a buffer the caller acquired and did not use for this picture - copy into it
                                                                                             * (the caller's pointer to it is dead from here on, as after any EncodeFrame call) */
-    if (slot) slot->used = 3;                                          /* being filled */
+    if (slot) { slot->used = 3; slot->up_sync = 0; }                   /* being filled */
     pthread_mutex_unlock(&e->mu);
     if (!slot) return QY_FAIL;                                         /* one lane: cannot happen (more input slots than pictures in flight + one mini-GOP); lanes: the caller checked lane_has_slot */
     uint8_t *u = slot->i420 + (size_t)e->W * e->H, *v = u + (size_t)e->W * e->H / 4;
-    if (own) { /* in place */ }
+    int direct = 0;
+    if (e->direct_in && !own && slot->dev && in->yuv->iStride[0] == e->W && in->yuv->iStride[1] == e->W / 2 && in->yuv->iStride[2] == e->W / 2) {
+        const size_t ny = (size_t)e->W * e->H, nc = ny / 4;
+        uint8_t *p0 = in->yuv->pData[0], *p1 = in->yuv->pData[1], *p2 = in->yuv->pData[2];
+        const int whole = p1 == p0 + ny && p2 == p1 + nc, evict = !e->hold_in;      /* (hold: an old registration may still be read by a DMA in flight - then the table only grows) */
+        int ru = KS265_OK;
+        if (whole ? reg_get(e->ctx_up, p0, ny + 2 * nc, evict) : (reg_get(e->ctx_up, p0, ny, evict) && reg_get(e->ctx_up, p1, nc, evict) && reg_get(e->ctx_up, p2, nc, evict))) {
+            if (e->direct_in == 2) {                                    /* no stream: the call returns when the picture is on the device */
+                if (whole) ru = ks265_memcpy_h2d_sync(e->ctx, slot->dev, p0, ny + 2 * nc);
+                else { ru = ks265_memcpy_h2d_sync(e->ctx, slot->dev, p0, ny); if (!ru) ru = ks265_memcpy_h2d_sync(e->ctx, slot->dev + ny, p1, nc); if (!ru) ru = ks265_memcpy_h2d_sync(e->ctx, slot->dev + ny + nc, p2, nc); }
+                slot->up_sync = 1;
+            } else {
+            if (whole) ru = ks265_memcpy_h2d_async(e->ctx_up, slot->dev, p0, ny + 2 * nc);
+            else { ru = ks265_memcpy_h2d_async(e->ctx_up, slot->dev, p0, ny); if (!ru) ru = ks265_memcpy_h2d_async(e->ctx_up, slot->dev + ny, p1, nc); if (!ru) ru = ks265_memcpy_h2d_async(e->ctx_up, slot->dev + ny + nc, p2, nc); }
+            if (!ru) ru = ks265_event_record(e->ctx_up, slot->ev_up);
+            if (!e->hold_in) e->pending_up = slot;                      /* waited for at the end of the call, behind the output's hand-over */
+            }
+            if (ru) { e->pending_up = NULL; pthread_mutex_lock(&e->mu); slot->used = 0; e->sched_err = hip_rc(ru); pthread_mutex_unlock(&e->mu); return hip_rc(ru); }
+            direct = 1;
+        }
+    }
+    if (direct) { /* on its way from the caller's own memory */ }
+    else if (own) { /* in place */ }
     else if (in->yuv->iStride[0] == e->W && in->yuv->iStride[1] == e->W / 2 && in->yuv->iStride[2] == e->W / 2) {    /* packed planes: three block copies */
         copy_shared(e->pool, slot->i420, in->yuv->pData[0], (size_t)e->W * e->H);
         copy_shared(e->pool, u, in->yuv->pData[1], (size_t)e->W * e->H / 4);
@@ -1877,7 +1957,7 @@ static int lane_put(Enc *e, QY265Picture *in, int key)
             memcpy(v + (size_t)y * (e->W / 2), in->yuv->pData[2] + (size_t)y * in->yuv->iStride[2], (size_t)e->W / 2);
         }
     }
-    if (slot->dev) {   /* on its way to the device at once, on the lookahead's stream (nothing there waits for the pipeline) */
+    if (slot->dev && !direct) {   /* on its way to the device at once, on the lookahead's stream (nothing there waits for the pipeline) */
         int ru = ks265_memcpy_h2d_async(e->ctx_up, slot->dev, slot->i420, (size_t)e->W * e->H * 3 / 2);
         if (!ru) ru = ks265_event_record(e->ctx_up, slot->ev_up);
         if (ru) { pthread_mutex_lock(&e->mu); slot->used = 0; e->sched_err = hip_rc(ru); pthread_mutex_unlock(&e->mu); return hip_rc(ru); }
@@ -1939,6 +2019,13 @@ static int lane_encode_frame(Enc *e, QY265Nal **pNals, int *iNalCount, QY265Pict
         }
         r = take_output(e, in_flight, 1 << 30, pNals, iNalCount, out, NULL);
         e->st.output_ms += now_ms() - t0;
+        if (e->pending_up) {                                           /* the caller's buffer is its own again when the call returns: the upload out of it has finished */
+            const double tw = now_ms();
+            const int ru = ks265_event_wait(e->ctx_up, e->pending_up->ev_up);
+            e->pending_up = NULL;
+            e->st.in_copy_ms += now_ms() - tw;
+            if (ru && !r) r = hip_rc(ru);
+        }
         return r ? r : e->sched_err;
     }
     /* flush: then every picture in flight is collected */
@@ -2317,6 +2404,13 @@ int QY265EncoderEncodeFrame(void *h, QY265Nal **pNals, int *iNalCount, QY265Pict
         const double t1 = now_ms();
         r = top_collect(t, 0, out);
         t->output_ms += now_ms() - t1;
+        if (e->pending_up) {                                            /* the caller's buffer is its own again when the call returns (lane_encode_frame) */
+            const double tw = now_ms();
+            const int ru = ks265_event_wait(e->ctx_up, e->pending_up->ev_up);
+            e->pending_up = NULL;
+            e->st.in_copy_ms += now_ms() - tw;
+            if (ru && !r) r = hip_rc(ru);
+        }
         if (!r) for (int i = 0; i < t->nlanes && !r; ++i) r = t->lane[i]->sched_err;
     } else {
         const double t0 = now_ms();

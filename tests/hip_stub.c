@@ -46,6 +46,9 @@ int ks265_take_device_error(ks265_ctx *c)                              /* KS265_
 int ks265_dev_malloc(ks265_ctx *c, void **p, size_t n) { (void)c; *p = calloc(1, n ? n : 1); return *p ? KS265_OK : KS265_OUTOFMEMORY; }
 int ks265_dev_free(ks265_ctx *c, void *p) { (void)c; free(p); return KS265_OK; }
 int ks265_host_malloc(ks265_ctx *c, void **p, size_t n) { return ks265_dev_malloc(c, p, n); }
+int ks265_host_register(ks265_ctx *c, void *p, size_t n) { (void)c; (void)p; (void)n; return getenv("KS265_STUB_NO_REGISTER") ? KS265_FAIL : KS265_OK; }   /* (every byte of the stand-in's host is "DMA-able") */
+int ks265_host_unregister(ks265_ctx *c, void *p) { (void)c; (void)p; return KS265_OK; }
+int ks265_memcpy_h2d_sync(ks265_ctx *c, void *d, const void *s, size_t n) { (void)c; memcpy(d, s, n); return KS265_OK; }
 int ks265_host_free(ks265_ctx *c, void *p) { return ks265_dev_free(c, p); }
 static int stub_fast(void);
 int ks265_memcpy_h2d_async(ks265_ctx *c, void *d, const void *s, size_t n) { (void)c; if (n > (1u << 20) && stub_fast()) return KS265_OK;   /* (KS265_STUB_FAST: a picture's upload is the copy engine's time, not the caller's) */

@@ -56,8 +56,11 @@ ramp = [int(x) for x in os.environ.get("KS_TEST_RAMP", "").split(":") if x]     
 if ramp:
     base = rng.integers(48, 112, W * H * 3 // 2).astype(np.int16)
     frames = [np.clip(base + ramp[2] * (min(max(t, ramp[0]), ramp[1]) - ramp[0]) + rng.integers(-3, 4, base.shape), 0, 255).astype(np.uint8) for t in range(N)]
+one = np.zeros(W * H * 3 // 2, np.uint8) if os.environ.get("KS_TEST_ONE_BUFFER") else None    # the SDK's own callers (encoderwrapper.c:367-379) refill ONE buffer for every picture
 for t in range(N):
     fr = frames[t] if (cuts or ramp) else clip[t % 11]
+    if one is not None:
+        one[:] = fr; fr = one
     if strided:
         planes[0][:, :W] = fr[:W * H].reshape(H, W); planes[0][:, W:] = t & 255
         planes[1][:, :W // 2] = fr[W * H:W * H * 5 // 4].reshape(H // 2, W // 2); planes[2][:, :W // 2] = fr[W * H * 5 // 4:].reshape(H // 2, W // 2)
@@ -79,6 +82,7 @@ for t in range(N):
     if rc and os.environ.get("KS_TEST_CONTINUE_ON_ERROR"):
         errors += 1; err_at.append(t); take(False); continue
     assert rc == 0, hex(rc & 0xFFFFFFFF)
+    if one is not None: one[:] = 0xA5                       # the call has returned: the buffer is the caller's again (scribbled over before it is refilled)
     take(errors == 0)
     maxdelay = max(maxdelay, lib.QY265EncoderDelayedFrames(h))
     if os.environ.get("KS_TEST_KEYREQ") and t in (17, 18, 40): lib.QY265EncoderKeyFrameRequest(h)

@@ -460,3 +460,66 @@ def test_zero_copy_input_on_the_gpu():
     a, _ = encode(False)
     b, used = encode(True)
     assert used == N and a == b
+
+
+@pytest.mark.parametrize("bframes", [0, -1])
+def test_input_straight_from_the_callers_buffers_on_the_gpu(bframes):
+    """round 6: pictures of 1 MB and more are uploaded by DMA from the CALLER's planes (pinned in place once, remembered by address) - no copy into the encoder's pinned memory first.
+    The upload has finished when QY265EncoderEncodeFrame returns: a caller that refills ONE buffer for every picture (the SDK's own demo callers, encoderwrapper.c:367-379) and scribbles
+    over it right after the call gets the stream of the copying path (KS265_INPUT_COPY=1), byte for byte; so do distinct buffers, and buffers the caller keeps (KS265_INPUT_HOLD=1)"""
+    from ks265codec_amd import stream
+    from ks265codec_amd.synth import make_clip
+    lib = C.CDLL(stream.build())
+    lib.QY265EncoderOpen.restype = C.c_void_p
+    W, H, N = 1920, 1080, 19
+    clip = make_clip(W, H, N, seed=5, abc=(37, 53, 19), pan=(5, 3))
+
+    def encode(one_buffer, **env):
+        old = {k: os.environ.get(k) for k in ("KS265_INPUT_COPY", "KS265_INPUT_HOLD")}
+        for k in old:
+            os.environ.pop(k, None)
+        os.environ.update({k: str(v) for k, v in env.items()})
+        try:
+            cfg = (C.c_uint8 * LAY["sizeof_config"])()
+            assert lib.QY265ConfigDefaultPreset(cfg, b"slow", None, b"default") == 0
+            for k, v in (("wdt", W), ("hgt", H), ("fr", 50), ("rc", 0), ("qp", 30), ("iper", 128), ("bframes", bframes), ("threads", 8), ("psnr", 1)):
+                assert lib.QY265ConfigParse(cfg, k.encode(), str(v).encode()) == 0
+            err = C.c_int(0)
+            h = C.c_void_p(lib.QY265EncoderOpen(cfg, C.byref(err)))
+            assert h.value, hex(err.value & 0xFFFFFFFF)
+        finally:
+            for k, v in old.items():
+                os.environ.pop(k, None)
+                if v is not None:
+                    os.environ[k] = v
+        nal, nn, pic, outp, yuv = C.POINTER(Nal)(), C.c_int(0), Picture(), Picture(), YUV()
+        pic.yuv = C.pointer(yuv)
+        yuv.iWidth, yuv.iHeight = W, H
+        yuv.iStride[0], yuv.iStride[1], yuv.iStride[2] = W, W // 2, W // 2
+        one = np.zeros(W * H * 3 // 2, np.uint8)
+        bs = bytearray()
+        for t in range(N):
+            src = clip[t]
+            if one_buffer:
+                one[:] = clip[t]; src = one
+            for k, off in enumerate((0, W * H, W * H * 5 // 4)):
+                yuv.pData[k] = C.cast(src.ctypes.data + off, C.POINTER(C.c_ubyte))
+            pic.pts = t
+            assert lib.QY265EncoderEncodeFrame(h, C.byref(nal), C.byref(nn), C.byref(pic), C.byref(outp), 0) == 0
+            if one_buffer:
+                one[:] = 0x5A                                         # the buffer is the caller's again
+            for i in range(nn.value):
+                bs += C.string_at(nal[i].pPayload, nal[i].iSize)
+        while lib.QY265EncoderDelayedFrames(h):
+            assert lib.QY265EncoderEncodeFrame(h, C.byref(nal), C.byref(nn), None, C.byref(outp), 0) == 0
+            for i in range(nn.value):
+                bs += C.string_at(nal[i].pPayload, nal[i].iSize)
+        lib.QY265EncoderClose(h)
+        return bytes(bs)
+
+    ref = encode(False, KS265_INPUT_COPY=1)
+    assert len(ref) > 10000
+    assert encode(True) == ref, "one refilled buffer"
+    assert encode(False) == ref, "distinct buffers"
+    assert encode(False, KS265_INPUT_HOLD=1) == ref, "buffers the caller keeps"
+    assert encode(True, KS265_INPUT_COPY=1) == ref

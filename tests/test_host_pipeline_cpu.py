@@ -554,3 +554,17 @@ def test_crf_runs_the_cutree_pass_of_the_lookahead(tmp_path, opts, n, W, H):
     assert r0.returncode == 0 and "cuTree" not in r0.stdout + r0.stderr
     if "-aq" not in kw:
         assert not os.path.exists(tmp_path / "none.bin") or os.path.getsize(tmp_path / "none.bin") == 0
+
+
+@pytest.mark.parametrize("lanes,bframes", [(1, 0), (2, -1)])
+def test_input_straight_from_the_callers_buffers(stub_lib, lanes, bframes):
+    """pictures of 1 MB and more are uploaded from the caller's own planes (pinned in place once, remembered by address) instead of being copied first: the same stream as the
+    copying path (KS265_INPUT_COPY=1), with distinct buffers, with ONE buffer refilled (and scribbled over) after every call as the SDK's demo callers do, with buffers the runtime
+    refuses to pin (fallback to the copy), and without waiting for the upload (KS265_INPUT_HOLD=1: the caller keeps its buffers)"""
+    W, H, n = 1024, 704, 70
+    env = {"KS265_GOP_LANES": lanes} if lanes > 1 else {}
+    ref = run(stub_lib, n, 32, bframes, W, H, KS265_INPUT_COPY=1, **env)
+    assert ref["vcl"] == n and ref["lanes"] == lanes
+    for extra in ({}, {"KS_TEST_ONE_BUFFER": 1}, {"KS265_STUB_NO_REGISTER": 1}, {"KS265_INPUT_HOLD": 1}, {"KS_TEST_ONE_BUFFER": 1, "KS265_INPUT_COPY": 1}):
+        got = run(stub_lib, n, 32, bframes, W, H, **env, **extra)
+        assert got["md5"] == ref["md5"] and got["pts"] == ref["pts"], extra
