@@ -558,6 +558,9 @@ struct DecideLds {
     // the source samples every reference array is gathered from: row 0 = the row above the CTU (x = -4 .. 131), rows 1 .. 64 = the CTU with the four samples left
     // of it; sample (x, y) of the CTU at [(1 + y) * 136 + 4 + x] (a byte load per reference sample from HBM / L2 was this kernel's critical path)
     __attribute__((aligned(16))) unsigned char W[65 * 136];
+    // round 6: the two MFMA operand sets that do not change over the modes - the Hadamard rows and the source tiles (the same for all four waves) - live here, 16 bytes per lane and
+    // set, instead of in 32 registers per lane: at three waves per SIMD those were the 34 dwords the compiler spilled (136 bytes of scratch per lane = 24.7 MiB of HBM writes per launch)
+    __attribute__((aligned(16))) int Hm[4][64][4], Sop[4][64][4];
 };
 
 __device__ __forceinline__ int intra_mode_bits(int mode) { return (mode == 0 || mode == 1 || mode == 26) ? 3 : 6; }   // default MPM set vs. escape code
@@ -644,26 +647,30 @@ __global__ __launch_bounds__(256, 3) void intra_decide_kernel(KsGeom g, int lam,
     // ---- (2) all 35 modes of every block: SATD of (source - prediction) on the matrix cores (see me_subpel_kernel for the operand
     //      layout: lane = (tile column n16, row pair gk); tiles numbered in Z-order so that a block is an aligned lane group)
     const int n16 = lane & 15, gk = lane >> 4;
-    ks_v4i Hm[4];
+    int ttx[4], tty[4];                                             // tile coordinates (8-sample units) of this lane's four operand columns
     {
         const unsigned pat = (n16 & 2) ? ((n16 & 1) ? 0x01FFFF01u : 0xFFFF0101u) : ((n16 & 1) ? 0xFF01FF01u : 0x01010101u);
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb)
+        for (int nb = 0; nb < 4; ++nb) {
+            const int t = nb * 16 + n16;
+            ttx[nb] = (t & 1) | ((t >> 1) & 2) | ((t >> 2) & 4); tty[nb] = ((t >> 1) & 1) | ((t >> 2) & 2) | ((t >> 3) & 4);
+        }
+        if (wave == 0) {
 #pragma unroll
-            for (int w = 0; w < 4; ++w) Hm[mb][w] = (int)((__popc((mb * 16 + n16) & (gk * 16 + w * 4)) & 1) ? pat ^ 0xFEFEFEFEu : pat);
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int w = 0; w < 4; ++w) L.Hm[mb][lane][w] = (int)((__popc((mb * 16 + n16) & (gk * 16 + w * 4)) & 1) ? pat ^ 0xFEFEFEFEu : pat);
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                const uint8_t *p = S + (long)(cy * 64 + tty[nb] * 8 + 2 * gk) * g.sy + cx * 64 + ttx[nb] * 8;
+                const uint2 a0 = *(const uint2 *)p, a1 = *(const uint2 *)(p + g.sy);
+                L.Sop[nb][lane][0] = (int)(a0.x ^ 0x7F7F7F7Fu); L.Sop[nb][lane][1] = (int)(a0.y ^ 0x7F7F7F7Fu); L.Sop[nb][lane][2] = (int)(a1.x ^ 0x7F7F7F7Fu); L.Sop[nb][lane][3] = (int)(a1.y ^ 0x7F7F7F7Fu);
+            }
+        }
     }
+    __syncthreads();
     const ks_v4i CinN = {0x8000, 0x8000, 0x8000, 0x8000};
     const ks_v4i Cin0 = {gk == 0 ? 0x8000 + 64 : 0x8000, 0x8000, 0x8000, 0x8000};
-    ks_v4i Sop[4];
-    int ttx[4], tty[4];                                             // tile coordinates (8-sample units) of this lane's four operand columns
-#pragma unroll
-    for (int nb = 0; nb < 4; ++nb) {
-        const int t = nb * 16 + n16;
-        ttx[nb] = (t & 1) | ((t >> 1) & 2) | ((t >> 2) & 4); tty[nb] = ((t >> 1) & 1) | ((t >> 2) & 2) | ((t >> 3) & 4);
-        const uint8_t *p = S + (long)(cy * 64 + tty[nb] * 8 + 2 * gk) * g.sy + cx * 64 + ttx[nb] * 8;
-        const uint2 a0 = *(const uint2 *)p, a1 = *(const uint2 *)(p + g.sy);
-        Sop[nb] = ks_v4i{(int)(a0.x ^ 0x7F7F7F7Fu), (int)(a0.y ^ 0x7F7F7F7Fu), (int)(a1.x ^ 0x7F7F7F7Fu), (int)(a1.y ^ 0x7F7F7F7Fu)};
-    }
     const int ltx = (lane & 1) | ((lane >> 1) & 2) | ((lane >> 2) & 4), lty = ((lane >> 1) & 1) | ((lane >> 2) & 2) | ((lane >> 3) & 4);
 #pragma unroll 1
     for (int l = 1; l <= 3; ++l) {
@@ -677,17 +684,21 @@ __global__ __launch_bounds__(256, 3) void intra_decide_kernel(KsGeom g, int lam,
             unsigned acc[4];
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb) {
-                const int b = base + (tty[nb] / t8) * (1 << l) + ttx[nb] / t8;
+                const int tt = nb * 16 + n16, tx_ = (tt & 1) | ((tt >> 1) & 2) | ((tt >> 2) & 4), ty_ = ((tt >> 1) & 1) | ((tt >> 2) & 2) | ((tt >> 3) & 4);   // (recomputed: eight registers less than keeping ttx / tty)
+                const int b = base + (ty_ >> (3 - l)) * (1 << l) + (tx_ >> (3 - l));
                 const unsigned char *ref = &L.ref[b][which][66];
-                const int ox = (ttx[nb] % t8) * 8, oy = (tty[nb] % t8) * 8 + 2 * gk, dc = L.dc[b];
+                const int ox = (tx_ & (t8 - 1)) * 8, oy = (ty_ & (t8 - 1)) * 8 + 2 * gk, dc = L.dc[b];
                 unsigned w[4];
                 intra_rows2x8(ref, mode, log2, ox, oy, dc, true, w);
                 const ks_v4i B = {(int)(w[0] ^ 0x80808080u), (int)(w[1] ^ 0x80808080u), (int)(w[2] ^ 0x80808080u), (int)(w[3] ^ 0x80808080u)};
                 unsigned a = 0;
+                asm volatile("" ::: "memory");                              // (the operands are loop-invariant: without this the compiler hoists the loads and keeps all 32 dwords in registers again)
+                const ks_v4i sop = *(const ks_v4i *)&L.Sop[nb][lane][0];
 #pragma unroll
                 for (int mb = 0; mb < 4; ++mb) {
-                    ks_v4i C = __builtin_amdgcn_mfma_i32_16x16x64_i8(Hm[mb], B, mb == 0 ? Cin0 : CinN, 0, 0, 0);
-                    C = __builtin_amdgcn_mfma_i32_16x16x64_i8(Hm[mb], Sop[nb], C, 0, 0, 0);
+                    const ks_v4i hm = *(const ks_v4i *)&L.Hm[mb][lane][0];
+                    ks_v4i C = __builtin_amdgcn_mfma_i32_16x16x64_i8(hm, B, mb == 0 ? Cin0 : CinN, 0, 0, 0);
+                    C = __builtin_amdgcn_mfma_i32_16x16x64_i8(hm, sop, C, 0, 0, 0);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) a = __builtin_amdgcn_sad_u16((unsigned)C[r], 0x8000u, a);
                 }

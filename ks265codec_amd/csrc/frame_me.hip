@@ -622,9 +622,9 @@ __global__ __launch_bounds__(64) void cu_decide_kernel(KsGeom g, int lam, const 
             const int x0 = cx * 64 + px * s, y0 = cy * 64 + py * s;
             unsigned own = cp[idx].cost, res; unsigned char sp = 0, ui = 0, pm = 0;
             if (rect && l < 3) {                                     // cfg.part: 2NxN, then Nx2N, each only if strictly cheaper
-                const KsRect rr = rect[(long)ctu * 21 + idx];
-                if (rr.cost[0] < own) { own = rr.cost[0]; pm = 1; }
-                if (rr.cost[1] < own) { own = rr.cost[1]; pm = 2; }
+                const KsRect *rr = &rect[(long)ctu * 21 + idx];         // (read in place: a copy of the record indexed by pm / hf below would live in scratch memory)
+                if (rr->cost[0] < own) { own = rr->cost[0]; pm = 1; }
+                if (rr->cost[1] < own) { own = rr->cost[1]; pm = 2; }
             }
             part[idx] = pm;
             if (ibest && l > 0) {
@@ -660,18 +660,18 @@ __global__ __launch_bounds__(64) void cu_decide_kernel(KsGeom g, int lam, const 
         c.mv1x = p.mv1x; c.mv1y = p.mv1y; c.inter_dir = (uint8_t)p.inter_dir;
         const int pm = rect ? part[pidx] : 0;
         if (pm && !use_intra[pidx]) {                                // this block's half of the CU: its own direction and vector(s)
-            const KsRect rr = rect[(long)ctu * 21 + pidx];
+            const KsRect *rr = &rect[(long)ctu * 21 + pidx];
             const int hf = pm == 1 ? (by >> (2 - l)) & 1 : (bx >> (2 - l)) & 1;
-            c.mvx = rr.mv[pm - 1][hf][0]; c.mvy = rr.mv[pm - 1][hf][1]; c.mv1x = rr.mv1[pm - 1][hf][0]; c.mv1y = rr.mv1[pm - 1][hf][1];
-            c.inter_dir = rr.dir[pm - 1][hf]; c.log2_cu = (uint8_t)((6 - l) | (pm << 4));
+            c.mvx = rr->mv[pm - 1][hf][0]; c.mvy = rr->mv[pm - 1][hf][1]; c.mv1x = rr->mv1[pm - 1][hf][0]; c.mv1y = rr->mv1[pm - 1][hf][1];
+            c.inter_dir = rr->dir[pm - 1][hf]; c.log2_cu = (uint8_t)((6 - l) | (pm << 4));
         }
     } else {
         c.mv1x = 0; c.mv1y = 0; c.inter_dir = 1;
         const int pm = rect ? part[pidx] : 0;
         if (pm && !use_intra[pidx]) {                                // this block's half of the CU: 2NxN by its row, Nx2N by its column
-            const KsRect rr = rect[(long)ctu * 21 + pidx];
+            const KsRect *rr = &rect[(long)ctu * 21 + pidx];
             const int hf = pm == 1 ? (by >> (2 - l)) & 1 : (bx >> (2 - l)) & 1;
-            c.mvx = rr.mv[pm - 1][hf][0]; c.mvy = rr.mv[pm - 1][hf][1]; c.log2_cu = (uint8_t)((6 - l) | (pm << 4));
+            c.mvx = rr->mv[pm - 1][hf][0]; c.mvy = rr->mv[pm - 1][hf][1]; c.log2_cu = (uint8_t)((6 - l) | (pm << 4));
         }
     }
     if (use_intra[pidx]) { c.mvx = (int16_t)(ibest[(long)ctu * 85 + pidx] & 63u); c.mvy = 0; c.mv1x = 0; c.mv1y = 0; c.pred_mode = 2; c.inter_dir = 0; }    // an intra CU: mvx = its luma mode

@@ -31,7 +31,10 @@ using namespace ks265;
 #define WIN_XL 68                 // LDS window column 0 is picture x = ctu_x*64 - 68
 #define WIN_YT 66                 // window row 0 is picture y = ctu_y*64 - 66
 #define WIN_ROWS 196              // y in [-66, 130)
-#define WIN_STRIDE 204            // 51 dwords (odd): x in [-68, 136)
+#ifndef KS_WIN_STRIDE
+#define KS_WIN_STRIDE 204
+#endif
+#define WIN_STRIDE KS_WIN_STRIDE  // 204 = 51 dwords (odd): x in [-68, 136); KS_WIN_STRIDE: experiments with the row pitch (bank conflicts, tools/r6_me_stride.sh)
 #define FENC_STRIDE 68            // 17 dwords (odd)
 #define ME_WLIM 66                // candidates further than this from the PU position are not staged: skipped (oracle chk = 2)
 

@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void cfc_intra_kernel(CfcP p, const uint8_t *c
     int dc = BS;
     for (int i = 0; i < BS; ++i) dc += unf[1 + i] + unf[-1 - i];
     dc >>= (LG + 1);
-    auto sad_mode = [&](int mode) -> unsigned {
+    auto sad_mode = [&](int mode) __attribute__((always_inline)) -> unsigned {
         const uint8_t *r = (!p.fast_intra && intra_filter_flag(mode, BS)) ? fil : unf;   // g_intraNeedFilter enc@0x4df3a0 = the standard's filter rule (rows 8 and 16 checked)
         unsigned s = 0;
 #pragma unroll
