@@ -387,6 +387,36 @@ def main():
         key_ms = {k: round(v, 3) for k, v in fr.stage_ms().items() if v > 0}
         fr.set_profiling(False)
         me_int_kernel_ms = stage_alone.pop("me_int_kernel"); stage_run.pop("me_int_kernel", None)
+        # round 6: the roofline's kernel ON THE GOP OF `value`.  With the default command `value` is the hierarchical-B 8 GOP; there me_int_kernel is launched once
+        # per P picture and twice per B picture (list 1's search runs beside list 0's on the frame's side stream), so a launch takes longer than alone in an IPPP chain.
+        # A device-resident pyramid of 8 on a frame object of its own (one stream), HIP events around the MAIN chain's launch of every picture (ks265_frame_me_int_ms)
+        hier_me_ms = None
+        if getattr(args, "ref_hier_b", 0) == 8 and not args.hier_b:
+            frh = KsFrame(ks, W, H, qp, lambda_q4(qp), bframes=7, refs=1, **hot_tools(args, me_method))
+            frh.set_profiling(True)
+            hd = [frh.new_pic() for _ in range(9)]
+            hs = gop.hier_order(8, args.iper)
+            acc_p, acc_b, n_p, n_b = 0.0, 0.0, 0, 0
+            for i in range(1 + 8 * 6):
+                d, kind, r0, r1, layer = next(hs)
+                q = qp + host_qp_offset(kind, layer=layer, hier=True)
+                frh.set_qp(q, lambda_q4(q, inter=kind != "I"))
+                out = hd[d % 9]
+                if kind == "B":
+                    frh.encode_picture_b(src_of(d), hd[r0 % 9], hd[r1 % 9], out)
+                else:
+                    frh.encode_picture(src_of(d), hd[r0 % 9] if r0 is not None else out, kind == "I", out)
+                torch.cuda.synchronize()
+                if i > 8 and kind != "I":                       # (the first mini-GOP warms the frame object up)
+                    v = frh.me_int_ms()
+                    if v > 0:
+                        if kind == "B": acc_b += v; n_b += 1
+                        else: acc_p += v; n_p += 1
+            frh.set_profiling(False); frh.close()
+            if n_p and n_b:
+                tp, tb = acc_p / n_p, acc_b / n_b
+                hier_me_ms = {"p_picture": round(tp, 4), "b_picture_list0": round(tb, 4), "per_launch": round((tp + 14 * tb) / 15, 4),
+                              "launches_per_mini_gop": 15, "what": "me_int_kernel by HIP events in a device-resident pyramid of 8 on one stream: 1 launch per P picture, 2 per B picture (the two lists' searches side by side: the event pair times list 0's launch while list 1's runs on the side stream)"}
         stage_ms = stage_alone
         dom_stage = max(stage_ms, key=stage_ms.get)
         # the roofline figure is the SAD kernel's (north_star; VERDICT r3: the kernel alone, not the stage): algorithmic bytes / its own launch duration
@@ -418,8 +448,13 @@ def main():
                 n = sum(sq.get(kk, {}).get("insts_valu_per_launch", 0) for kk in ((k, "merge_pass") if k == "cu_decide" else (k,)))
                 if n and v > 0:
                     valu[k] = round(n / 1.23e12 / (v * 1e-3), 4)
+        ippp_fig = {"achieved": round(achieved, 2), "frac": round(achieved / HBM_PEAK_GBS, 5), "avg_launch_ms": round(me_int_kernel_ms, 4), "gop": "IPPP (device-resident leg)"}
+        if hier_me_ms:                                            # the headline's GOP: this is the figure of `roofline`; the IPPP one stays beside it
+            me_int_kernel_ms = hier_me_ms["per_launch"]
+            achieved = algo_bytes / (me_int_kernel_ms * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": "me_int_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "gop": "hierarchical-B 8 (the GOP of value)" if hier_me_ms else "the device-resident leg's",
+                    "in_the_gop_of_value": hier_me_ms, "roofline_ippp": ippp_fig if hier_me_ms else None,
                     "counters_stale": stale or None, "kernel_src_sha": my_sha,
                     "algorithmic_bytes_per_launch": int(algo_bytes), "avg_launch_ms": round(me_int_kernel_ms, 4), "longest_stage": dom_stage,
                     "stages_ms": {k: round(v, 4) for k, v in stage_ms.items()},
@@ -427,7 +462,7 @@ def main():
                     "stage_intervals_ms_in_run": {k: round(v, 4) for k, v in stage_run.items()},
                     "note": "avg_launch_ms / stages_ms / frac: HIP events around each stage with ONE shard on the GPU = the kernel's own duration; it agrees with the rocprofv3 kernel trace of `bench.py --streams 1` (profiles/). With the run's --streams shards in flight the kernels of different shards overlap: stage_intervals_ms_in_run are event-to-event intervals on one shard's stream under that load (queueing behind the other shards' kernels included), the kernel durations of that condition are in the rocprofv3 trace of the default command (profiles/).",
                     "stages_frac": {k: round(ALGO_BYTES_P[k] * P / (v * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) for k, v in stage_ms.items()},
-                    "valu_issue_frac": (round(valu["me_integer"] * stage_ms["me_integer"] / me_int_kernel_ms, 4) if valu.get("me_integer") else None), "stages_valu_issue_frac": valu or None,
+                    "valu_issue_frac": (round(valu["me_integer"] * stage_ms["me_integer"] / ippp_fig["avg_launch_ms"], 4) if valu.get("me_integer") else None), "stages_valu_issue_frac": valu or None,
                     "bound_note": "no stage of a P picture is limited by HBM bytes: each is a dependency chain per CTU (search state machines, the intra CUs' wavefront) or issue-bound "
                                   "arithmetic on L2-resident samples; valu_issue_frac = VALU wave-instructions / 1.23e12 per s / duration says how busy the vector ALUs are"}
 
@@ -507,7 +542,7 @@ def reference_leg(args, clip, order):
     W, H = args.width, args.height
     cores = host_cores()
     threads = int(os.environ.get("KS265_REF_THREADS", "0")) or min(cores, 64)
-    n = int(os.environ.get("KS265_REF_FRAMES", "0")) or int(min(256, max(64, 64 * (3840 * 2160) // (W * H))))
+    n = int(os.environ.get("KS265_REF_FRAMES", "0")) or int(min(256, max(128, 128 * (3840 * 2160) // (W * H))))     # round 6: a whole -iper 128 GOP at 2160p - the reference's frame-parallel pipeline needs that many pictures to fill (64 pictures: 45 pictures/s, 128: 55 - 59)
     preset = "slow" if args.me == "umh" and args.me_hex_thr == 16 else "veryslow" if args.me == "umh" else "medium"
     with tempfile.TemporaryDirectory(prefix="ks265_ref_") as td:
         yuv = os.path.join(td, "clip.yuv")

@@ -211,13 +211,14 @@ int ks265_event_query(ks265_ctx *c, void *ev, int *done)
 /* make everything enqueued on c's stream AFTER this call wait for the event (recorded on another context's stream): the hand-over between the
  * copy-in, compute and copy-out streams of a pipelined host; no host thread blocks */
 int ks265_stream_wait_event(ks265_ctx *c, void *ev) { if (!c || !ev) return KS265_POINTER; ks_use_device(c); return ks265_hip(c, hipStreamWaitEvent(c->stream, (hipEvent_t)ev, 0)); }
-int ks265_capture_begin(ks265_ctx *c) { if (!c) return KS265_POINTER; ks_use_device(c); return ks265_hip(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed)); }
+int ks265_capture_begin(ks265_ctx *c) { if (!c) return KS265_POINTER; ks_use_device(c); const int r = ks265_hip(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed)); c->capturing = r == KS265_OK; return r; }
 int ks265_capture_end(ks265_ctx *c, void **graph_exec)
 {
     if (!c || !graph_exec) return KS265_POINTER;
     *graph_exec = nullptr;
     hipGraph_t g = nullptr;
     ks_use_device(c);
+    c->capturing = false;
     int r = ks265_hip(c, hipStreamEndCapture(c->stream, &g));
     if (r || !g) return r ? r : KS265_FAIL;
     hipGraphExec_t ex = nullptr;

@@ -271,7 +271,7 @@ static int encode_b_lists(ks265_frame *f, ks265_pic src, const ks265_pic *refs0,
         if (!rr && mr) rr = ks265_ref_pick(f, n, pus, l ? f->pu1 : pu0, f->ridx[l]);
         return rr;
     };
-    const bool par = f->b_parallel && f->side && f->cfg.pre_search && (!f->cfg.propagate || f->pu_s2);
+    const bool par = f->b_parallel && !f->ctx->capturing && f->side && f->cfg.pre_search && (!f->cfg.propagate || f->pu_s2);   /* (a picture being captured as a graph stays on the one stream: the fork's host-side workspace swaps are not part of a graph) */
     if (par) {
         /* the two searches are independent chains (pre-search, integer search, propagation, sub-pel refinement: ~ 0.4 ms each at 2160p, each kernel with a long tail of
          * half-empty CUs): list 1's is enqueued on the side stream with its own workspace and runs beside list 0's; the join is in front of the bi-predictive decision */
@@ -287,12 +287,15 @@ static int encode_b_lists(ks265_frame *f, ks265_pic src, const ks265_pic *refs0,
         f->src_pyr_ready = true;
         f->ctx->stream = f->side; swap_ws();
         r = chain(1);
-        if (!r) r = ks265_hip(f->ctx, hipEventRecord(f->ev_join, f->side));
+        /* the join is recorded and waited for whatever happened after the fork: what the side stream has been handed keeps reading src / refs and writing this frame's
+         * workspace, and the host recycles those on its error path */
+        const int rj = ks265_hip(f->ctx, hipEventRecord(f->ev_join, f->side));
         f->ctx->stream = mainst; swap_ws();
         if (!r) r = chain(0);
         f->src_pyr_ready = false;
+        const int rw = rj ? ks265_hip(f->ctx, hipStreamSynchronize(f->side)) : ks265_hip(f->ctx, hipStreamWaitEvent(f->ctx->stream, f->ev_join, 0));
         if (r) return r;
-        if ((r = ks265_hip(f->ctx, hipStreamWaitEvent(f->ctx->stream, f->ev_join, 0)))) return r;
+        if (rw) return rw;
     } else {
     if ((r = chain(0))) return r;
     if ((r = chain(1))) return r;

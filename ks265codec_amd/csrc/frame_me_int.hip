@@ -722,9 +722,10 @@ extern "C" int ks265_me_integer(ks265_frame *f, ks265_pic src, ks265_pic ref, co
         hipLaunchKernelGGL(me_score_kernel, dim3((unsigned)((nctu + 255) / 256)), dim3(256), 0, f->ctx->stream, nctu, f->g.ctu_cols, f->me_work, (unsigned char *)(f->me_order + nctu));
         hipLaunchKernelGGL(me_order_kernel, dim3(1), dim3(512), 0, f->ctx->stream, nctu, (const unsigned char *)(f->me_order + nctu), f->me_order);
     }
-    if (f->profiling && f->ev_k[0]) (void)hipEventRecord(f->ev_k[0], f->ctx->stream);
+    const bool timed = f->profiling && f->ev_k[0] && !(f->side && f->ctx->stream == f->side);      // the main chain's launch alone (a B picture's list-1 search runs on the side stream: its marks would pair with list 0's)
+    if (timed) (void)hipEventRecord(f->ev_k[0], f->ctx->stream);
     hipLaunchKernelGGL(me_int_kernel, grid, block, 0, f->ctx->stream, f->g, f->cfg.me_range, f->cfg.lambda_q4, f->cfg.me_method, f->cfg.me_hex_thr, src.y, ref.y, prev_pu, pu,
                        field, (f->g.W + 15) / 16, (f->g.H + 15) / 16, field ? (const short2 *)f->pyr[9] : nullptr, (const int *)f->me_order, f->me_work);
-    if (f->profiling && f->ev_k[1]) { (void)hipEventRecord(f->ev_k[1], f->ctx->stream); f->ev_k_valid = true; }
+    if (timed && f->ev_k[1]) { (void)hipEventRecord(f->ev_k[1], f->ctx->stream); f->ev_k_valid = true; }
     return ks265_check_launch(f->ctx);
 }

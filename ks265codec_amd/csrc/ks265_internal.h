@@ -15,6 +15,7 @@ struct ks265_ctx {
     // device-side error word: pinned, device-mapped host memory that kernels OR error bits into (KS_DEVERR_*); ks265_synchronize
     // reads and clears it after the stream has drained and turns a set bit into KS265_FAIL
     unsigned *err_host = nullptr, *err_dev = nullptr;
+    bool capturing = false;                      // between ks265_capture_begin and ks265_capture_end on this context
     int wavefront_spin_limit = 1 << 22;          // ks265_debug_set(KS265_DBG_WAVEFRONT_SPINS): test hook for the timeout path
 };
 #define KS_DEVERR_WAVEFRONT_TIMEOUT 1u           // intra wavefront: the CTU row above did not make progress in time

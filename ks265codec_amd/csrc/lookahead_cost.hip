@@ -118,45 +118,87 @@ __global__ __launch_bounds__(256) void cfc_intra_kernel(CfcP p, const uint8_t *c
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------------ the search chains
+// One wave per block row and list; the row walks right to left.  What a block needs from its neighbours is ONE word each - the vector of the block to its right (this wave's own,
+// in a register) and of the block below (the wave of the row below; the last column also the lower-left one) - so the vector plane itself is the progress mark: it is filled
+// with the reference's own "not there yet" word 0x7fff before the launch, a block's vector is stored with release order after its cost, and the row above polls that word.
+// Everything else of a block is in LDS before its turn comes: while block bx is being searched the window of the reference around block bx - 1 (the block's place +- CFC_RB
+// samples) and its source samples are on their way (registers, written to the other LDS buffer at the end of the turn).  Start points, the zero vector and the diamond walk read
+// that window; a candidate or a walk that leaves it (a vector beyond +- CFC_RB) falls back to global loads / a window re-centred on the walk.  A turn is then one L2 round trip
+// (the poll) + LDS arithmetic instead of four dependent round trips: 2.18 -> see profiles/r06_crf.txt for a 1920 x 1080 half-size picture (120 + 68 turns).
+#define CFC_SENTINEL 0x7fff
+#define CFC_RB 20
 template <int LG>
 __global__ __launch_bounds__(64) void cfc_search_kernel(CfcP p, const uint8_t *cur, const uint8_t *ref0, const uint8_t *ref1, int32_t *mv0, int32_t *c0, int32_t *mv1, int32_t *c1,
-                                                        int l_first, int *progress, unsigned *err_word, int spin_limit)
+                                                        int l_first, unsigned *err_word, int spin_limit)
 {
-    constexpr int BS = 1 << LG, P = BS * BS / 64, R = 6, WS = BS + 2 * R;
-    __shared__ uint8_t win[WS * WS];
-    const int lane = threadIdx.x, l = l_first + (int)blockIdx.y, by = p.ny - 1 - (int)blockIdx.x, nx = p.nx;
+    constexpr int BS = 1 << LG, P = BS * BS / 64, RB = CFC_RB, WS = BS + 2 * RB, WP = WS + 4, WD = WP / 4, ND = (WS * WD + 63) / 64;
+    __shared__ __attribute__((aligned(16))) uint8_t win[2][WS * WP];
+    const int lane = threadIdx.x, l = l_first + (int)blockIdx.y, by = p.ny - 1 - (int)blockIdx.x, nx = p.nx, py = by << LG;
     const uint8_t *ref = l ? ref1 : ref0;
     int32_t *mv = l ? mv1 : mv0, *cs = l ? c1 : c0;
-    int *prog = progress + l * p.ny;
     const int thr = (int)((unsigned)p.zero_thr << (2 * LG)) >> 1;
     const int iters = p.mer >> (p.preset > 1 ? 0 : (p.p8 != 4));
     int xs[P], ys[P];
 #pragma unroll
     for (int k = 0; k < P; ++k) { const int idx = lane + 64 * k; ys[k] = idx >> LG; xs[k] = idx & (BS - 1); }
-    int right = 0;
-    for (int bx = nx - 1; bx >= 0; --bx) {
-        const int px = bx << LG, py = by << LG, blk = by * nx + bx;
-        int below = 0, below_l = 0;
-        if (by < p.ny - 1) {
-            // the row below must have finished the block under this one; the last column also reads the lower-left block (enc@0x4a7dfb..0x4a7e2f)
-            const int need = bx == nx - 1 ? min(nx, 2) : nx - bx;
-            int spins = 0;
-            while (__hip_atomic_load(prog + by + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < need) {
-                if (spins++ >= spin_limit) { __hip_atomic_fetch_or(err_word, KS_DEVERR_WAVEFRONT_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
-                __builtin_amdgcn_s_sleep(2);
-            }
-            below = __hip_atomic_load(mv + blk + nx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (bx == nx - 1 && bx > 0) below_l = __hip_atomic_load(mv + blk + nx - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        // the first two of {right, below, lower-left, lower-right} that exist become the AMVP pair (enc@0x4a7dc0..0x4a7e73)
-        int cand[2] = {0, 0};
-        if (bx < nx - 1) { cand[0] = right; if (by < p.ny - 1) cand[1] = below; }
-        else if (by < p.ny - 1) { cand[0] = below; if (bx > 0) cand[1] = below_l; }
-        const uint8_t *fenc = cur + (long)py * p.stride + px, *r00 = ref + (long)py * p.stride + px;
-        int f[P];
+    // window of the block at picture column px: origin (ox, oy), ox dword-aligned in memory
+    auto win_ox = [&](int px_) { const int x = px_ - RB; return x - (int)((uintptr_t)(ref + x) & 3u); };
+    unsigned pre[ND]; int fpre[P];
+    auto fetch = [&](int px_) {                                    // the loads of a block's window and source samples (all in flight together)
+        const uint8_t *src = ref + (long)(py - RB) * p.stride + win_ox(px_);
 #pragma unroll
-        for (int k = 0; k < P; ++k) f[k] = fenc[(long)ys[k] * p.stride + xs[k]];
-        // meInitPoint enc@0x48af50 (no CTU object: no look-ahead vector, no stored candidates)
+        for (int k = 0; k < ND; ++k) {
+            const int q = lane + 64 * k, yy = q / WD, xx = q - yy * WD;
+            pre[k] = q < WS * WD ? *(const unsigned *)(src + (long)yy * p.stride + 4 * xx) : 0u;
+        }
+        const uint8_t *fe = cur + (long)py * p.stride + px_;
+#pragma unroll
+        for (int k = 0; k < P; ++k) fpre[k] = fe[(long)ys[k] * p.stride + xs[k]];
+    };
+    auto commit = [&](int buf) {
+#pragma unroll
+        for (int k = 0; k < ND; ++k) { const int q = lane + 64 * k; if (q < WS * WD) *(unsigned *)&win[buf][4 * q] = pre[k]; }
+    };
+    int cb = 0, right = 0;
+    fetch((nx - 1) << LG); commit(0);
+    int f[P];
+#pragma unroll
+    for (int k = 0; k < P; ++k) f[k] = fpre[k];
+    __syncthreads();
+    for (int bx = nx - 1; bx >= 0; --bx) {
+        const int px = bx << LG, blk = by * nx + bx;
+        if (bx > 0) fetch((bx - 1) << LG);                          // the next turn's data: under way while this block is searched
+        int ox = win_ox(px), oy = py - RB;                          // the window in win[cb]
+        const uint8_t *W = win[cb];
+        auto inside = [&](int X, int Y) { return X >= ox && X + BS <= ox + WP && Y >= oy && Y + BS <= oy + WS; };
+        auto sad_at = [&](int X, int Y) -> unsigned {              // SAD of the source block against the reference block at picture position (X, Y); wave-uniform
+            unsigned s = 0;
+            if (inside(X, Y)) {
+                const uint8_t *w = W + (Y - oy) * WP + (X - ox);
+#pragma unroll
+                for (int k = 0; k < P; ++k) s += (unsigned)abs(f[k] - (int)w[ys[k] * WP + xs[k]]);
+            } else {
+                const uint8_t *g = ref + (long)Y * p.stride + X;
+#pragma unroll
+                for (int k = 0; k < P; ++k) s += (unsigned)abs(f[k] - (int)g[(long)ys[k] * p.stride + xs[k]]);
+            }
+            return wave_sum(s);
+        };
+        // ---- the neighbours' vectors (enc@0x4a7dc0..0x4a7e73: the first two of {right, below, lower-left, lower-right} that exist become the AMVP pair)
+        int cand[2] = {0, 0};
+        if (by < p.ny - 1) {
+            auto poll = [&](const int32_t *q) -> int {
+                int v, spins = 0;
+                while ((v = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == CFC_SENTINEL) {     // (relaxed: the word itself is all that is read of the other row)
+                    if (spins++ >= spin_limit) { __hip_atomic_fetch_or(err_word, KS_DEVERR_WAVEFRONT_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); v = 0; break; }
+                }
+                return v;
+            };
+            const int below = poll(mv + blk + nx);
+            if (bx < nx - 1) { cand[0] = right; cand[1] = below; }
+            else { cand[0] = below; if (bx > 0) cand[1] = poll(mv + blk + nx - 1); }
+        } else if (bx < nx - 1) cand[0] = right;
+        // ---- meInitPoint enc@0x48af50 (no CTU object: no look-ahead vector, no stored candidates)
         const int lim0 = -px, lim1 = p.w - px - BS, lim2 = -py, lim3 = p.h - py - BS;
         int mvpx[2], mvpy[2], cx[2], cy[2];
 #pragma unroll
@@ -164,19 +206,25 @@ __global__ __launch_bounds__(64) void cfc_search_kernel(CfcP p, const uint8_t *c
             mvpx[k] = (short)(cand[k] & 0xffff); mvpy[k] = cand[k] >> 16;
             cx[k] = clamp16((mvpx[k] + 2) >> 2, lim0, lim1); cy[k] = clamp16((mvpy[k] + 2) >> 2, lim2, lim3);
         }
-        unsigned s0 = 0, s1 = 0, sz = 0;
-        {
-            const uint8_t *a = r00 + (long)cy[0] * p.stride + cx[0], *b = r00 + (long)cy[1] * p.stride + cx[1];
-#pragma unroll
-            for (int k = 0; k < P; ++k) {
-                const long o = (long)ys[k] * p.stride + xs[k];
-                s0 += (unsigned)abs(f[k] - (int)a[o]); s1 += (unsigned)abs(f[k] - (int)b[o]); sz += (unsigned)abs(f[k] - (int)r00[o]);   // the zero vector's SAD rides along
-            }
-            s0 = wave_sum(s0); s1 = wave_sum(s1); sz = wave_sum(sz);
-        }
         const bool same = cx[0] == cx[1] && cy[0] == cy[1];
+        auto sad_raw = [&](int X, int Y) -> unsigned {              // this lane's part of sad_at
+            unsigned t = 0;
+            if (inside(X, Y)) {
+                const uint8_t *w2 = W + (Y - oy) * WP + (X - ox);
+#pragma unroll
+                for (int k = 0; k < P; ++k) t += (unsigned)abs(f[k] - (int)w2[ys[k] * WP + xs[k]]);
+            } else {
+                const uint8_t *g = ref + (long)Y * p.stride + X;
+#pragma unroll
+                for (int k = 0; k < P; ++k) t += (unsigned)abs(f[k] - (int)g[(long)ys[k] * p.stride + xs[k]]);
+            }
+            return t;
+        };
+        unsigned s0, s1;
+        if (same) s0 = s1 = sad_at(px + cx[0], py + cy[0]);
+        else { const unsigned t = wave_sum(sad_raw(px + cx[0], py + cy[0]) | (sad_raw(px + cx[1], py + cy[1]) << 16)); s0 = t & 0xffffu; s1 = t >> 16; }
         const int i = same ? 0 : (s0 + 0u > s1 + 1u);              // index costs tME+0x2e0 / +0x2e4 = 0 / 1 (enc@0x4a7e7d..0x4a7e8a)
-        const unsigned sad = same ? s0 : (i ? s1 : s0);
+        const unsigned sad = i ? s1 : s0;
         const bool zero_tried = (cx[0] == 0 && cy[0] == 0) || (cx[1] == 0 && cy[1] == 0);
         int mx = cx[i], my = cy[i];
         const int pxq = mvpx[i], pyq = mvpy[i], cmx = -pxq, cmy = -pyq;
@@ -190,29 +238,32 @@ __global__ __launch_bounds__(64) void cfc_search_kernel(CfcP p, const uint8_t *c
         unsigned cost = outside ? sad + (far_cost(p, 4 * mx - pxq) + far_cost(p, 4 * my - pyq)) : sad + (tab_cost(p, cmx + 4 * mx) + tab_cost(p, cmy + 4 * my));
         if (!((unsigned long long)sad < (unsigned long long)(long long)thr)) {      // enc@0x4a7f30..0x4a7f50
             if (!zero_tried) {                                                       // enc@0x4a8198..0x4a82db
-                const unsigned cz = sz + far_cost(p, -pyq) + far_cost(p, -pxq);
+                const unsigned cz = sad_at(px, py) + far_cost(p, -pyq) + far_cost(p, -pxq);
                 if (cz < cost) { cost = cz; mx = my = 0; }
             }
-            // interMeDia enc@0x48fbe0 on a window of the reference in LDS; the walk re-centres the window when it reaches its rim
-            int wx0 = mx, wy0 = my;
-            bool loaded = false;
+            // interMeDia enc@0x48fbe0: the four neighbours of the centre per step
             unsigned b = cost << 4;
             for (int it = 0; it < iters; ++it) {
-                if (!loaded || max(abs(mx - wx0), abs(my - wy0)) + 1 > R) {
-                    wx0 = mx; wy0 = my; loaded = true;
+                const int X = px + mx, Y = py + my;
+                if (!(X - 1 >= ox && X + 1 + BS <= ox + WP && Y - 1 >= oy && Y + 1 + BS <= oy + WS)) {      // the walk has reached the window's rim: a window around where it is now
                     __syncthreads();
-                    const uint8_t *src = r00 + (long)(wy0 - R) * p.stride + (wx0 - R);
-                    for (int q = lane; q < WS * WS; q += 64) { const int yy = q / WS, xx = q - yy * WS; win[q] = src[(long)yy * p.stride + xx]; }
+                    ox = X - RB - (int)((uintptr_t)(ref + (X - RB)) & 3u); oy = Y - RB;
+                    const uint8_t *src = ref + (long)oy * p.stride + ox;
+                    for (int q = lane; q < WS * WD; q += 64) { const int yy = q / WD, xx = q - yy * WD; *(unsigned *)&win[cb][4 * q] = *(const unsigned *)(src + (long)yy * p.stride + 4 * xx); }
                     __syncthreads();
                 }
                 unsigned su = 0, sd = 0, sl = 0, sr = 0;
+                const uint8_t *wc = W + (Y - oy) * WP + (X - ox);
 #pragma unroll
                 for (int k = 0; k < P; ++k) {
-                    const int o = (R + my - wy0 + ys[k]) * WS + R + mx - wx0 + xs[k];
-                    su += (unsigned)abs(f[k] - (int)win[o - WS]); sd += (unsigned)abs(f[k] - (int)win[o + WS]);
-                    sl += (unsigned)abs(f[k] - (int)win[o - 1]); sr += (unsigned)abs(f[k] - (int)win[o + 1]);
+                    const uint8_t *q = wc + ys[k] * WP + xs[k];
+                    su += (unsigned)abs(f[k] - (int)q[-WP]); sd += (unsigned)abs(f[k] - (int)q[WP]);
+                    sl += (unsigned)abs(f[k] - (int)q[-1]); sr += (unsigned)abs(f[k] - (int)q[1]);
                 }
-                su = wave_sum(su); sd = wave_sum(sd); sl = wave_sum(sl); sr = wave_sum(sr);
+                {   // two sums per reduction: a SAD of at most 256 samples fits 16 bits
+                    const unsigned a = wave_sum(su | (sd << 16)), c2 = wave_sum(sl | (sr << 16));
+                    su = a & 0xffffu; sd = a >> 16; sl = c2 & 0xffffu; sr = c2 >> 16;
+                }
                 const unsigned tx = tab_cost(p, cmx + 4 * mx), ty = tab_cost(p, cmy + 4 * my);
                 b = min(b, ((su + tx + tab_cost(p, cmy + 4 * (my - 1))) << 4) + 1u);
                 b = min(b, ((sd + tx + tab_cost(p, cmy + 4 * (my + 1))) << 4) + 3u);
@@ -227,11 +278,26 @@ __global__ __launch_bounds__(64) void cfc_search_kernel(CfcP p, const uint8_t *c
         const int packed = (int)((unsigned)(unsigned short)(short)(mx << 2) | ((unsigned)(unsigned short)(short)(my << 2) << 16));
         right = packed;
         if (lane == 0) {
-            mv[blk] = packed; cs[blk] = (int)cost;
-            __threadfence();
-            __hip_atomic_store(prog + by, nx - bx, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            cs[blk] = (int)cost;
+            __hip_atomic_store(mv + blk, packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the vector is the progress mark of the row above (its cost is read by the next kernel only)
+        }
+        if (bx > 0) {                                               // the next turn's window and source samples have arrived by now
+            __syncthreads();
+            commit(cb ^ 1); cb ^= 1;
+#pragma unroll
+            for (int k = 0; k < P; ++k) f[k] = fpre[k];
+            __syncthreads();
         }
     }
+}
+
+// the vector planes of the lists about to be searched start as "not there yet" (the reference's own mark, 0x7fff in the first word: here in every word - the search polls them)
+__global__ __launch_bounds__(256) void cfc_mark_kernel(int32_t *mv0, int32_t *mv1, int n)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    if (mv0) mv0[i] = CFC_SENTINEL;
+    if (mv1) mv1[i] = CFC_SENTINEL;
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------------ decision + sums (all blocks at once)
@@ -393,6 +459,7 @@ int ks265_calc_frame_cost(ks265_ctx *ctx, const ks265_cfc_params *q, const uint8
     if (!ctx || !q || !dev_cur || !dev_intra || !dev_imode || !dev_list_bits || !dev_sums || !dev_ws) return KS265_POINTER;
     if (q->lg != 3 && q->lg != 4) return KS265_NOTSUPPORTED;
     if (!q->fast_intra && q->scenecut == 0 && q->preset <= 1) return KS265_NOTSUPPORTED;          /* two intra modes AND the refinement: no preset combines them */
+    if (q->stride & 3) return KS265_NOTSUPPORTED;                                                      /* the search stages windows of the planes by dwords */
     if (q->nx <= 0 || q->ny <= 0 || q->d0 < 0 || q->d1 < 0 || (q->d0 == 0 && q->d1 != 0)) return KS265_NOTSUPPORTED;
     if ((q->d0 && (!dev_ref0 || !dev_mv0 || !dev_cost0)) || (q->d1 && (!dev_ref1 || !dev_mv1 || !dev_cost1)) || ((q->d0 + q->d1) && !dev_inter) || (q->aq && !dev_inv_qscale)) return KS265_POINTER;
     ks_use_device(ctx);
@@ -410,15 +477,16 @@ int ks265_calc_frame_cost(ks265_ctx *ctx, const ks265_cfc_params *q, const uint8
     p.bigthr = (int)(t * 4.0);
     for (int i = 0; i < 52; ++i) p.lam[i] = q->lambda_tab[i];
     const int n = p.nx * p.ny;
-    int *acc = (int *)dev_ws, *progress = acc + ACC_N;
-    unsigned *ws_intra = (unsigned *)(progress + 2 * p.ny);
+    int *acc = (int *)dev_ws;
+    unsigned *ws_intra = (unsigned *)(acc + ACC_N + 2 * p.ny);
     hipStream_t st = ctx->stream;
     const bool need_intra = !p.intra_done && !(p.d1 > 0 && !p.b_intra);
     const int nl = (p.do_list[0] ? 1 : 0) + (p.do_list[1] ? 1 : 0), l_first = p.do_list[0] ? 0 : 1;
-    if (hipMemsetAsync(dev_ws, 0, (size_t)(ACC_N + 2 * p.ny) * sizeof(int), st) != hipSuccess) return ks265_hip(ctx, hipGetLastError());
+    if (hipMemsetAsync(dev_ws, 0, (size_t)ACC_N * sizeof(int), st) != hipSuccess) return ks265_hip(ctx, hipGetLastError());
+    if (nl) hipLaunchKernelGGL(cfc_mark_kernel, dim3((n + 255) / 256), dim3(256), 0, st, p.do_list[0] ? dev_mv0 : (int32_t *)nullptr, p.do_list[1] ? dev_mv1 : (int32_t *)nullptr, n);
 #define CFC_LAUNCH(LG) do { \
         if (need_intra) hipLaunchKernelGGL(cfc_intra_kernel<LG>, dim3((n + 3) / 4), dim3(256), 0, st, p, dev_cur, ws_intra); \
-        if (nl) hipLaunchKernelGGL(cfc_search_kernel<LG>, dim3(p.ny, nl), dim3(64), 0, st, p, dev_cur, dev_ref0, dev_ref1, dev_mv0, dev_cost0, dev_mv1, dev_cost1, l_first, progress, \
+        if (nl) hipLaunchKernelGGL(cfc_search_kernel<LG>, dim3(p.ny, nl), dim3(64), 0, st, p, dev_cur, dev_ref0, dev_ref1, dev_mv0, dev_cost0, dev_mv1, dev_cost1, l_first, \
                                    ctx->err_dev, ctx->wavefront_spin_limit); \
         hipLaunchKernelGGL(cfc_combine_kernel<LG>, dim3((n + 15) / 16), dim3(256), 0, st, p, dev_cur, dev_ref0, dev_ref1, (const int32_t *)dev_mv0, (const int32_t *)dev_cost0, \
                            (const int32_t *)dev_mv1, (const int32_t *)dev_cost1, (const unsigned *)ws_intra, dev_intra, dev_imode, dev_inv_qscale, dev_inter, dev_list_bits, acc); \
