@@ -523,3 +523,17 @@ def test_input_straight_from_the_callers_buffers_on_the_gpu(bframes):
     assert encode(False) == ref, "distinct buffers"
     assert encode(False, KS265_INPUT_HOLD=1) == ref, "buffers the caller keeps"
     assert encode(True, KS265_INPUT_COPY=1) == ref
+
+
+def test_b_spread_runs_hip_code_on_one_device(tmp_path):
+    """bench.py --b-spread - the one path with a collective (config 5: the anchor chain rotates over the ranks, every reconstructed anchor is broadcast, the B pictures are spread) -
+    with two ranks on ONE MI355X (KS265_BENCH_ONE_DEVICE=1, host-side gloo broadcast): the sharding logic that the gloo CPU tests pin (tests/test_distributed_cpu.py) has run the HIP
+    pixel path once, and rank 0 prints a well-formed line.  The 8-GPU RCCL run itself is the driver's."""
+    port = 29600 + os.getpid() % 200
+    env = dict(os.environ, KS265_BENCH_ONE_DEVICE="1", KS265_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--b-spread", "--bframes", "3", "--width", "1280", "--height", "720", "--steps", "16", "--warmup", "4", "--no-cpu-baseline", "--clip-frames", "9"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-800:] + r.stderr[-1500:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and "anchor chain rotating" in line["config"]["sharding"], line["config"]
