@@ -77,6 +77,7 @@ def main():
                     "B pictures dealt to the other ranks (needs --bframes > 0); default = one GOP shard per rank, no collective")
     ap.add_argument("--streams", type=int, default=3, help="independent GOP shards in flight per GPU, each on its own HIP stream (their kernels overlap: the search kernels are latency bound)")
     ap.add_argument("--refs", type=int, default=1, help="list-0 reference pictures a P picture searches (-ref / -ref0; -preset slow resolves to 1 / 3: three for the first picture of a mini-GOP); IPPP only")
+    ap.add_argument("--ref0", type=int, default=3, help="list-0 pictures an ANCHOR of the pyramid GOPs searches (-ref0; -preset slow resolves to 3: the encoder host's default) - the hot-path leg's --hier-b schedule follows it")
     ap.add_argument("--subme-preset", default="", help="hot-path leg: the sub-pel refinement's knobs of another preset (ultrafast .. placebo; default: slow's)")
     ap.add_argument("--propagate", type=int, default=1, help="hot-path leg: rounds of vector propagation between neighbouring PUs after every integer search (stage A2; the encoder runs 1)")
     ap.add_argument("--no-pre-search", action="store_true", help="hot-path leg: stage A without the pyramid pre-search start candidates (the encoder always runs them)")
@@ -190,7 +191,7 @@ def main():
         tstream = None if sidx == 0 else torch.cuda.Stream(device=dev_index)
         with (torch.cuda.stream(tstream) if tstream is not None else contextlib.nullcontext()):
             ks = KsContext(dev_index)
-            fr = KsFrame(ks, W, H, qp, lambda_q4(qp), bframes=max(args.bframes, args.hier_b - 1 if args.hier_b else 0), refs=max(1, args.refs), **hot_tools(args, me_method))
+            fr = KsFrame(ks, W, H, qp, lambda_q4(qp), bframes=max(args.bframes, args.hier_b - 1 if args.hier_b else 0), refs=max(1, args.refs, args.ref0 if args.hier_b else 1), **hot_tools(args, me_method))
             # synthetic clip of SURVEY.md §8(d), one GOP shard per stream (different seed per shard = different content)
             # one clip per rank (the encoded leg's), every shard at its own phase of it (round 5: 33 distinct pictures instead of 5 - one clip per shard would be 1.2 GB of host memory and 3 x the set-up time)
             clip = shared if shared is not None else make_clip(W, H, args.clip_frames, seed=7 + (0 if args.b_spread else rank), abc=(67, 91, 33), pan=(8, 5))
@@ -205,24 +206,35 @@ def main():
             bout = fr.new_pic()
 
             sched = gop.hier_order(args.hier_b, args.iper) if args.hier_b else gop.coding_order(nb, args.iper)
-            dpb = [fr.new_pic() for _ in range(args.hier_b + 1)] if args.hier_b else []      # slot = display index mod (G + 1)
-            state = {"n": 0, "cur": 0, "last": None, "since_key": 0}
+            R0 = max(1, min(4, args.ref0))
+            dpb = [fr.new_pic() for _ in range(R0 * args.hier_b + 1)] if args.hier_b else []      # slot = display index mod (ref0 x G + 1): an anchor stays until the anchor ref0 mini-GOPs later is coded
+            state = {"n": 0, "cur": 0, "last": None, "since_key": 0, "hist": []}
 
             def src_of(d):
                 return srcs[order[(d + phase) % len(order)]]
 
             def step_hier():
                 d, kind, r0, r1, layer = next(sched)
-                G1 = args.hier_b + 1
+                G1 = len(dpb)
                 q = qp + host_qp_offset(kind, layer=layer, hier=True)   # the encoder host's ladder (= the reference's): anchors Q + 1, B layers + 2 / + 4 / + 4
                 fr.set_qp(q, lambda_q4(q, inter=kind != "I"))       # P / B pictures: the encoder host's inter table (ks265_enc.c kLambdaInterQ4)
                 out = dpb[d % G1]
+                hist = state["hist"]                                # the GOP's anchors so far, nearest first (-ref0: an anchor searches the last ref0 of them, as the encoder host schedules it)
+                multi = kind == "P" and R0 > 1 and len(hist) > 1 and hist[0] == r0
                 if kind == "B":
                     fr.encode_picture_b(src_of(d), dpb[r0 % G1], dpb[r1 % G1], out)
+                elif multi:
+                    fr.encode_picture_mref(src_of(d), [dpb[p % G1] for p in hist[:R0]], out)
                 else:
                     fr.encode_picture(src_of(d), dpb[r0 % G1] if r0 is not None else out, kind == "I", out)
+                if kind == "I":
+                    hist[:] = [d]
+                elif kind == "P":
+                    hist.insert(0, d); del hist[4:]
                 state["last"] = (d, out)
-                state["kind"] = kind
+                if multi:
+                    state["ref0"] = dpb[r0 % G1]
+                state["kind"] = "Pm" if multi else kind               # "Pm": several references; ks265_encode_picture_mref records no stage events
                 state["n"] += 1
 
             ring = [fr.new_pic() for _ in range(args.refs + 1)] if args.refs > 1 else []   # multi-reference IPPP: the picture being written + the most recent ones
@@ -392,20 +404,29 @@ def main():
         # A device-resident pyramid of 8 on a frame object of its own (one stream), HIP events around the MAIN chain's launch of every picture (ks265_frame_me_int_ms)
         hier_me_ms = None
         if getattr(args, "ref_hier_b", 0) == 8 and not args.hier_b:
-            frh = KsFrame(ks, W, H, qp, lambda_q4(qp), bframes=7, refs=1, **hot_tools(args, me_method))
+            R0 = max(1, min(4, args.ref0))
+            frh = KsFrame(ks, W, H, qp, lambda_q4(qp), bframes=7, refs=R0, **hot_tools(args, me_method))
             frh.set_profiling(True)
-            hd = [frh.new_pic() for _ in range(9)]
+            NH = 8 * R0 + 1
+            hd = [frh.new_pic() for _ in range(NH)]
             hs = gop.hier_order(8, args.iper)
             acc_p, acc_b, n_p, n_b = 0.0, 0.0, 0, 0
+            hist = []
             for i in range(1 + 8 * 6):
                 d, kind, r0, r1, layer = next(hs)
                 q = qp + host_qp_offset(kind, layer=layer, hier=True)
                 frh.set_qp(q, lambda_q4(q, inter=kind != "I"))
-                out = hd[d % 9]
+                out = hd[d % NH]
                 if kind == "B":
-                    frh.encode_picture_b(src_of(d), hd[r0 % 9], hd[r1 % 9], out)
+                    frh.encode_picture_b(src_of(d), hd[r0 % NH], hd[r1 % NH], out)
+                elif kind == "P" and R0 > 1 and len(hist) > 1 and hist[0] == r0:      # -ref0: the anchor searches the last ref0 anchors (one me_int_kernel launch per picture searched; the events time the last one)
+                    frh.encode_picture_mref(src_of(d), [hd[p % NH] for p in hist[:R0]], out)
                 else:
-                    frh.encode_picture(src_of(d), hd[r0 % 9] if r0 is not None else out, kind == "I", out)
+                    frh.encode_picture(src_of(d), hd[r0 % NH] if r0 is not None else out, kind == "I", out)
+                if kind == "I":
+                    hist = [d]
+                elif kind == "P":
+                    hist = [d] + hist[:3]
                 torch.cuda.synchronize()
                 if i > 8 and kind != "I":                       # (the first mini-GOP warms the frame object up)
                     v = frh.me_int_ms()
@@ -415,8 +436,8 @@ def main():
             frh.set_profiling(False); frh.close()
             if n_p and n_b:
                 tp, tb = acc_p / n_p, acc_b / n_b
-                hier_me_ms = {"p_picture": round(tp, 4), "b_picture_list0": round(tb, 4), "per_launch": round((tp + 14 * tb) / 15, 4),
-                              "launches_per_mini_gop": 15, "what": "me_int_kernel by HIP events in a device-resident pyramid of 8 on one stream: 1 launch per P picture, 2 per B picture (the two lists' searches side by side: the event pair times list 0's launch while list 1's runs on the side stream)"}
+                hier_me_ms = {"p_picture": round(tp, 4), "b_picture_list0": round(tb, 4), "per_launch": round((R0 * tp + 14 * tb) / (R0 + 14), 4),
+                              "launches_per_mini_gop": R0 + 14, "what": f"me_int_kernel by HIP events in a device-resident pyramid of 8 on one stream: {R0} launches per anchor (-ref0 {R0}: one per picture searched), 2 per B picture (the two lists' searches side by side: the event pair times list 0's launch while list 1's runs on the side stream)"}
         stage_ms = stage_alone
         dom_stage = max(stage_ms, key=stage_ms.get)
         # the roofline figure is the SAD kernel's (north_star; VERDICT r3: the kernel alone, not the stage): algorithmic bytes / its own launch duration
@@ -479,7 +500,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{W}x{H} 4:2:0 8-bit, hot path only (ME + transform/quant/recon + deblock + SAO; CABAC/RC not included), "
-                                   f"-rc 0 -qp {qp} (the encoder host's ladders = the reference's: I = Q; IPPP P = Q + 1 + 0 / 2 / 1 / 2 over four pictures; pyramid anchors Q + 1, B layers + 2 / + 4 / + 4; plain B = Q + 2) -iper {args.iper}, -bframes {bf_desc}, -ref {max(1, args.refs)} -ref0 {max(1, args.refs)} ({'one reference picture per list' if args.refs <= 1 else 'every P picture searches that many list-0 pictures'}), -me {me_method} ({args.me.upper()}{', interMeHex below ' + str(args.me_hex_thr) + ' SAD/sample as at -preset slow' if me_method == 2 and args.me_hex_thr else ''}) range 64, -subme 1 as the reference runs it at -preset slow (fast candidate sets judged by SAD + rate; DESIGN.md 5e), sao on, df on",
+                                   f"-rc 0 -qp {qp} (the encoder host's ladders = the reference's: I = Q; IPPP P = Q + 1 + 0 / 2 / 1 / 2 over four pictures; pyramid anchors Q + 1, B layers + 2 / + 4 / + 4; plain B = Q + 2) -iper {args.iper}, -bframes {bf_desc}, -ref {max(1, args.refs)} -ref0 {max(1, args.ref0) if args.hier_b else max(1, args.refs)} ({'the anchors of the pyramid search the last ref0 anchors of their GOP, B pictures one picture per list' if args.hier_b else 'one reference picture per list' if args.refs <= 1 else 'every P picture searches that many list-0 pictures'}), -me {me_method} ({args.me.upper()}{', interMeHex below ' + str(args.me_hex_thr) + ' SAD/sample as at -preset slow' if me_method == 2 and args.me_hex_thr else ''}) range 64, -subme 1 as the reference runs it at -preset slow (fast candidate sets judged by SAD + rate; DESIGN.md 5e), sao on, df on",
                        "pictures_per_step": nstreams, "streams_per_gpu": nstreams,
                        "key_picture_ms": {"intra_decide": key_ms.get("intra_candidates"), "intra_reconstruct": key_ms.get("intra_pass"), "total": round(sum(key_ms.values()), 3),
                                           "note": f"one intra picture per -iper {args.iper} pictures; it is in the timed region whenever the schedule puts one there"},
@@ -807,7 +828,7 @@ def encoded_line(args, enc, world, hot, cpu):
         "config": {"workload": f"{W}x{H} 4:2:0 8-bit synthetic clip, ENCODED end to end through the SDK-compatible C API (QY265EncoderEncodeFrame): host I420 in -> pinned copy -> H2D -> "
                                f"pixel path on the MI355X (-preset {enc['preset']}: -me {args.me}, subme 1, deblock + SAO) -> D2H of CU map / levels / SAO -> CABAC slice data on "
                                f"{enc['host_threads']} host threads -> Annex-B NAL units out; -rc 0 -qp {args.qp} (I = Q; IPPP: P = Q + 1 + the reference's cascade 2 / 1 / 2 / 0 over four pictures; pyramid: anchors Q + 1, B layers + 2 / + 4 / + 4 as in the reference) -iper {args.iper}, {enc['gop']}, "
-                               f"-ref {max(1, args.refs)}; the stream decodes with the reference's appdecoder to the encoder's reconstruction (tests/test_stream.py)",
+                               f"-ref {max(1, args.refs)} -ref0 3 (the preset's: an anchor of a pyramid GOP searches the last three anchors of its GOP); the stream decodes with the reference's appdecoder to the encoder's reconstruction (tests/test_stream.py)",
                    "timed": None if strong else (("the asynchronous encoder with %d GOP lanes (closed GOPs coded concurrently on the one GPU, output in stream order).  A lane buffers a whole GOP "
                              "of input and goes on coding while the caller sits in a synchronize, so each window is a closed piece of work: flush + barrier + device synchronize on both sides; "
                              "A = --steps pictures, B = four whole rounds of lanes x iper pictures (one key picture per GOP) fed, coded and flushed in between.  value = pictures / seconds of B "

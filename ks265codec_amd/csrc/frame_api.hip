@@ -215,10 +215,23 @@ int ks265_encode_picture_mref(ks265_frame *f, ks265_pic src, const ks265_pic *re
         if (f->cfg.subme && (r = ks265_me_subpel(f, src, refs[i], pu))) return r;
     }
     if ((r = ks265_ref_decide(f, nref, pus, f->pub))) return r;
+    /* round 6 (-ref0: the anchors of the pyramid GOPs search several past anchors): the two-list records go through the stages a one-reference P picture has - intra candidates
+     * against them (cfg.intra_inter), the CU tree, the merge pass on the records' pictures (cfg.merge), the intra CUs' pass; -part 1 stays with one reference picture */
+    const bool ii = f->cfg.intra_inter != 0 && f->icost;
+    if (ii && (r = ks265_intra_candidates(f, src, f->pub, f->icost))) return r;
     if ((r = records_fence(f))) return r;
-    if ((r = ks265_cu_decide_b(f, f->pub, f->cu8))) return r;
+    const bool mg = f->cfg.merge && f->cu8_tmp;
+    if ((r = ks265_cu_decide_b_ii(f, f->pub, ii ? f->icost : nullptr, mg ? f->cu8_tmp : f->cu8))) return r;
+    if (mg) {
+        /* the merge pass takes a candidate's picture from its record (the multi-reference form); list 1 does not exist: mr_pslice makes the zero candidate uni-directional */
+        struct MrScope { ks265_frame *f; ~MrScope() { f->mrefb = false; f->mr_pslice = false; } } scope{f};
+        f->mrefb = true; f->mr_pslice = true; f->mr_n[0] = nref; f->mr_n[1] = 1;
+        for (int i = 0; i < 4; ++i) { f->mr_pic[0][i] = refs[i < nref ? i : nref - 1]; f->mr_pic[1][i] = refs[0]; }
+        if ((r = ks265_merge_pass(f, src, refs[0], refs[0], nullptr, f->pub, f->cu8_tmp, f->cu8))) return r;
+    }
     ks265_pic deb = ks_deb_pic(f);
     if ((r = ks265_reconstruct_mref(f, src, nref, refs, f->cu8, f->lvl[0], f->lvl[1], f->lvl[2], deb))) return r;
+    if (ii && (r = ks265_intra_inter_reconstruct(f, src, f->cu8, f->lvl[0], f->lvl[1], f->lvl[2], deb))) return r;
     if (f->cfg.deblock && (r = ks265_deblock(f, f->cu8, deb))) return r;
     if ((r = ks265_sao(f, src, deb, f->sao, recon_out))) return r;
     f->cur_pu ^= 1; f->have_prev = true;                          /* the nearest picture's vectors seed the next picture */

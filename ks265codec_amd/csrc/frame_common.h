@@ -70,6 +70,7 @@ struct ks265_frame {
     // multi-reference B picture being coded (ks265_encode_picture_b_mref sets it for the duration of the picture: ks265_bi_decide, ks265_merge_pass, ks265_cu_decide_part_b and
     // ks265_reconstruct_b then take every block's pictures from its record); host-side copies of the lists + the per-PU index arrays and the extra list-1 PU records
     bool mrefb = false;
+    bool mr_pslice = false;             // round 6: the context is a multi-reference P picture's (ks265_encode_picture_mref: two-list records, one list in the slice - the merge pass's zero candidate is uni-directional)
     int mr_n[2] = {1, 1};
     ks265_pic mr_pic[2][4] = {};
     uint8_t *ridx[2] = {nullptr, nullptr};

@@ -1292,9 +1292,9 @@ __device__ __forceinline__ int z_of_8(int x, int y)
     return (bx & 1) | ((by & 1) << 1) | ((bx & 2) << 1) | ((by & 2) << 2) | ((bx & 4) << 2) | ((by & 4) << 3);
 }
 template <bool MR>
-__device__ __forceinline__ MergeMotion merge_cand(const KsGeom &g, const ks265_cu8 *cu_in, int x, int y, int n, int k, bool is_b)
+__device__ __forceinline__ MergeMotion merge_cand(const KsGeom &g, const ks265_cu8 *cu_in, int x, int y, int n, int k, bool bi_zero)
 {
-    MergeMotion m; m.dir = is_b ? 3 : 1; m.mvx = m.mvy = m.mv1x = m.mv1y = 0; m.ok = true;
+    MergeMotion m; m.dir = bi_zero ? 3 : 1; m.mvx = m.mvy = m.mv1x = m.mv1y = 0; m.ok = true;
     if (k == 5) return m;
     const int nx = k == 1 ? x + n - 1 : k == 2 ? x + n : x - 1, ny = k == 0 ? y + n - 1 : k == 3 ? y + n : y - 1;       // A1 B1 B0 A0 B2
     m.ok = false;
@@ -1311,14 +1311,14 @@ __device__ __forceinline__ MergeMotion merge_cand(const KsGeom &g, const ks265_c
 }
 template <bool MR>
 __global__ __launch_bounds__(256) void merge_pass_kernel(KsGeom g, int lam, const uint8_t *src, const uint8_t *ref0, const uint8_t *ref1, const ks265_pu *pu,
-                                                         const ks265_pu_b *pub, const ks265_cu8 *cu_in, ks265_cu8 *cu_out, const KsMrefB mr)
+                                                         const ks265_pu_b *pub, const ks265_cu8 *cu_in, ks265_cu8 *cu_out, const KsMrefB mr, int p_slice)
 {
     __shared__ unsigned long long jbest[64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ctu = ks_xcd_swizzle(blockIdx.x, g.ctu_cols * g.ctu_rows), cx = ctu % g.ctu_cols, cy = ctu / g.ctu_cols;
     const int tx = (lane & 1) | ((lane >> 1) & 2) | ((lane >> 2) & 4), ty = ((lane >> 1) & 1) | ((lane >> 2) & 2) | ((lane >> 3) & 4);
     const int x0 = cx * 64 + tx * 8, y0 = cy * 64 + ty * 8;
-    const bool inside = x0 < g.W && y0 < g.H, is_b = pub != nullptr;
+    const bool inside = x0 < g.W && y0 < g.H, is_b = pub != nullptr, bi_zero = is_b && !p_slice;   // (p_slice: the two-list records of a multi-reference P picture - the zero candidate has one list)
     ks265_cu8 c;
     c.mvx = c.mvy = c.mv1x = c.mv1y = 0; c.log2_cu = 0; c.cbf = 0; c.pred_mode = 1; c.inter_dir = 0;
     if (inside) c = cu_in[(long)(y0 >> 3) * g.w8 + (x0 >> 3)];
@@ -1336,7 +1336,7 @@ __global__ __launch_bounds__(256) void merge_pass_kernel(KsGeom g, int lam, cons
         MergeMotion mm[6];
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
-            mm[k] = merge_cand<MR>(g, cu_in, cux, cuy, n, k, is_b);
+            mm[k] = merge_cand<MR>(g, cu_in, cux, cuy, n, k, bi_zero);
             const bool ok = valid && mm[k].ok;
             mask |= (ok ? 1u : 0u) << k;
             bool rep = false;
@@ -1363,7 +1363,7 @@ __global__ __launch_bounds__(256) void merge_pass_kernel(KsGeom g, int lam, cons
         int k = 0;                                                     // the it-th distinct candidate of this lane's CU
         { unsigned d = distinct; for (int q = 0; q < it; ++q) d &= d - 1u; k = d ? __ffs((int)d) - 1 : 0; }
         const bool on = __popc(distinct) > it;
-        const MergeMotion m = merge_cand<MR>(g, cu_in, cux, cuy, n, k, is_b);
+        const MergeMotion m = merge_cand<MR>(g, cu_in, cux, cuy, n, k, bi_zero);
         const int ax = on ? m.mvx : 0, ay = on ? m.mvy : 0, bx = on ? m.mv1x : 0, by = on ? m.mv1y : 0, dir = on ? m.dir : 1;
         unsigned sd = 0;
         if (__any(on)) {
@@ -1394,7 +1394,7 @@ __global__ __launch_bounds__(256) void merge_pass_kernel(KsGeom g, int lam, cons
         if (valid) {
             const unsigned long long jb = jbest[leader], jc = (unsigned long long)cur + (unsigned long long)((lam * 32) >> 4);
             if ((jb >> 8) < jc) {
-                const MergeMotion m = merge_cand<MR>(g, cu_in, cux, cuy, n, (int)(jb & 255ull), is_b);
+                const MergeMotion m = merge_cand<MR>(g, cu_in, cux, cuy, n, (int)(jb & 255ull), bi_zero);
                 o.mvx = (int16_t)m.mvx; o.mvy = (int16_t)m.mvy; o.mv1x = (int16_t)m.mv1x; o.mv1y = (int16_t)m.mv1y; o.inter_dir = (uint8_t)(MR ? m.dir : (m.dir & 3));
             }
         }
@@ -1407,8 +1407,8 @@ extern "C" int ks265_merge_pass(ks265_frame *f, ks265_pic src, ks265_pic ref0, k
 {
     KS_FRAME_CHECK(f);
     if (!src.y || !ref0.y || !cu_in || !cu_out || cu_in == cu_out || (!pu && !pub) || (pub && !ref1.y)) return KS265_POINTER;
-    if (f->mrefb && pub) hipLaunchKernelGGL(merge_pass_kernel<true>, dim3(f->g.ctu_cols * f->g.ctu_rows), dim3(256), 0, f->ctx->stream, f->g, f->cfg.lambda_q4, src.y, ref0.y, ref1.y, pu, pub, cu_in, cu_out, ks_mrefb(f));
-    else hipLaunchKernelGGL(merge_pass_kernel<false>, dim3(f->g.ctu_cols * f->g.ctu_rows), dim3(256), 0, f->ctx->stream, f->g, f->cfg.lambda_q4, src.y, ref0.y, ref1.y, pu, pub, cu_in, cu_out, KsMrefB{});
+    if (f->mrefb && pub) hipLaunchKernelGGL(merge_pass_kernel<true>, dim3(f->g.ctu_cols * f->g.ctu_rows), dim3(256), 0, f->ctx->stream, f->g, f->cfg.lambda_q4, src.y, ref0.y, ref1.y, pu, pub, cu_in, cu_out, ks_mrefb(f), f->mr_pslice ? 1 : 0);
+    else hipLaunchKernelGGL(merge_pass_kernel<false>, dim3(f->g.ctu_cols * f->g.ctu_rows), dim3(256), 0, f->ctx->stream, f->g, f->cfg.lambda_q4, src.y, ref0.y, ref1.y, pu, pub, cu_in, cu_out, KsMrefB{}, 0);
     return ks265_check_launch(f->ctx);
 }
 

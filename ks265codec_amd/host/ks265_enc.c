@@ -284,6 +284,7 @@ typedef struct Enc {
     int W, H, log_level;
     CopyPool *pool;                                       /* shared by the lanes of one handle (owned by it) */
     int me_method, hex_thr, subme, refs, use_sao, use_df, gop_b, hier;                  /* resolved tools */
+    int refs0, anc_hist[4], n_anc;                                                      /* -ref0 (qy265enc.h:142, the reference's ActiveRefNumFrm0InGop): how many past anchors an anchor of the pyramid searches; the last anchors' POCs, nearest first */
     int base_qp, iper, nthreads;
     ks265_ctx *ctx; ks265_frame *frame; ks265_frame_geom geom; ks265_frame_cfg fcfg; ks265_stream_cfg scfg;
     /* device: three streams - copy-in (ctx_in), the pixel path (ctx), copy-out (ctx_out) - so that the H2D of picture n+1 and the D2H of
@@ -1076,7 +1077,12 @@ static int code_hier(Enc *e, int d, int a)
             static const int kHierLayerQp[4] = {0, 1, 3, 3}, kPyr4LayerQp[4] = {0, 1, 2, 2};                       /* (-bframes 3: + 2 / + 3) */
             /* (the adaptive GOP's blocks of 4 keep + 2 / + 4: the reference's + 2 / + 3 there cost 1.3 % more bytes for + 0.004 dB on the 2160p clip, measured on the GPU at the end of round 4) */
             const int *lq = e->gop_b == 3 ? kPyr4LayerQp : kHierLayerQp;
-            int r = submit(e, in, 'B', mid - e->gop_start, clampqp(e, in->base_qp + e->rc_qp_delta + (e->fixqp ? 0 : 1 + lq[layer < 3 ? layer : 3])), l0, nl0, l1, nl1, coded, ncoded, is_ref, 0);
+            /* -ref0: the anchors the NEXT anchor searches besides d and a stay in this picture's reference picture set (they are in no list of it: the lists above are built
+             * from the mini-GOP's own pictures) */
+            int keepx[24], nkx = 0;
+            for (int q = 0; q < ncoded; ++q) keepx[nkx++] = coded[q];
+            for (int q = 2; q < e->refs0 && q < e->n_anc; ++q) keepx[nkx++] = e->anc_hist[q];
+            int r = submit(e, in, 'B', mid - e->gop_start, clampqp(e, in->base_qp + e->rc_qp_delta + (e->fixqp ? 0 : 1 + lq[layer < 3 ? layer : 3])), l0, nl0, l1, nl1, keepx, nkx, is_ref, 0);
             if (r) return r;
             if (is_ref) coded[ncoded++] = mid - e->gop_start;
             nxt[nn].lo = cur[i].lo; nxt[nn++].hi = mid; nxt[nn].lo = mid; nxt[nn++].hi = cur[i].hi;
@@ -1108,6 +1114,7 @@ static int schedule(Enc *e, int flush, int have /* pictures [0, have) have arriv
         }
         if (key) {
             e->gop_start = nxt; e->mg4_until = -1;
+            e->anc_hist[0] = 0; e->n_anc = 1;                           /* the key picture is the GOP's first anchor (POC 0) */
             e->rc_qp_delta = rc_decide(e);                             /* rate control: one offset per key picture / mini-GOP, decided when it is certain to be submitted */
             for (int i = 0; i < e->ndpb + 2 + 4; ++i) e->dpb_poc[i] = -1000000;
             int r = submit(e, in, 'I', 0, clampqp(e, in->base_qp + e->rc_qp_delta), NULL, 0, NULL, 0, NULL, 0, 1, 1);
@@ -1142,6 +1149,10 @@ static int schedule(Enc *e, int flush, int have /* pictures [0, have) have arriv
         if (span == 1) {                                               /* IPPP: the most recent pictures, nearest first */
             for (int i = 0; i < e->refs && pa - 1 - i >= 0; ++i) l0[nl0++] = pa - 1 - i;
             for (int i = 0; i < e->refs - 1 && pa - 1 - i >= 0; ++i) keep[nkeep++] = pa - 1 - i;   /* still needed by the next picture */
+        } else if (e->refs0 > 1 && e->n_anc > 0 && e->anc_hist[0] == pd) {
+            /* -ref0: the last anchors of this GOP, nearest first (the first one is the previous anchor); all of them but the oldest are the next anchor's too */
+            for (int i = 0; i < e->refs0 && i < e->n_anc; ++i) l0[nl0++] = e->anc_hist[i];
+            for (int i = 0; i < e->refs0 - 1 && i < e->n_anc; ++i) keep[nkeep++] = e->anc_hist[i];
         } else { l0[nl0++] = pd; keep[nkeep++] = pd; }
         Input *ina = input_at(e, a);
         e->rc_qp_delta = rc_decide(e);
@@ -1151,14 +1162,19 @@ static int schedule(Enc *e, int flush, int have /* pictures [0, have) have arriv
         const int casc = e->gop_b == 0 ? kIpppCascade[pa & 3] : 0;
         int r = submit(e, ina, 'P', pa, clampqp(e, ina->base_qp + e->rc_qp_delta + (e->fixqp ? 0 : 1 + casc)), l0, nl0, NULL, 0, keep, nkeep, 1, 0);
         if (r) return r;
+        if (span > 1) {                                                /* the anchors' history: this one in front */
+            for (int i = 3; i > 0; --i) e->anc_hist[i] = e->anc_hist[i - 1];
+            e->anc_hist[0] = pa; if (e->n_anc < 4) ++e->n_anc;
+        }
         const int anchor_on_lane = e->last_on_anc;
         if (a - d > 1) {
             if (e->hier && ((a - d) & (a - d - 1)) == 0) { r = code_hier(e, d, a); if (r) return r; }
             else {
-                const int kp[2] = {pd, pa};
+                int kp[6] = {pd, pa}, nkp = 2;
+                for (int i = 2; i < e->refs0 && i < e->n_anc; ++i) kp[nkp++] = e->anc_hist[i];      /* (-ref0: what the next anchor still searches) */
                 for (int b = d + 1; b < a; ++b) {
                     Input *inb = input_at(e, b);
-                    r = submit(e, inb, 'B', b - e->gop_start, clampqp(e, inb->base_qp + e->rc_qp_delta + (e->fixqp ? 0 : 2)), &pd, 1, &pa, 1, kp, 2, 0, 0);
+                    r = submit(e, inb, 'B', b - e->gop_start, clampqp(e, inb->base_qp + e->rc_qp_delta + (e->fixqp ? 0 : 2)), &pd, 1, &pa, 1, kp, nkp, 0, 0);
                     if (r) return r;
                 }
             }
@@ -1392,6 +1408,10 @@ static Enc *lane_open(QY265EncConfig *cfg, int device, int multi, int *err)
      * veryslow resolves to 4 / 4) - of the pictures the mini-GOP keeps anyway (code_hier), so the reference picture sets do not change */
     e->refs_b = e->hier ? e->refs : 1;
     if (e->gop_b > 0) e->refs = 1;
+    /* round 6: -ref0 (-preset slow resolves to ref 1 / ref0 3): the anchors of a pyramid search the last ref0 anchors of their GOP (ks265_encode_picture_mref, list 0
+     * nearest first = the default list construction); the older anchors stay in every reference picture set in between.  KS265_REF0 overrides (experiments: 1 = round 5's anchors) */
+    e->refs0 = e->hier ? (cfg->ref0 < 1 ? 1 : cfg->ref0 > 4 ? 4 : cfg->ref0) : 1;
+    if (getenv("KS265_REF0") && e->hier) { const int v = atoi(getenv("KS265_REF0")); e->refs0 = v < 1 ? 1 : v > 4 ? 4 : v; }
     e->base_qp = cfg->rc == 3 ? cfg->crf : cfg->qp;
     if (e->base_qp < 0) e->base_qp = 0;
     if (e->base_qp > 51) e->base_qp = 51;
@@ -1409,7 +1429,10 @@ static Enc *lane_open(QY265EncConfig *cfg, int device, int multi, int *err)
     /* options whose VALUE is narrowed (SURVEY.md 8(a) config 5 = -preset veryslow: subme 2, part 1, ref 4): said once, never silently */
     if (cfg->refnum > 4) logf_(1, e->log_level, "ks265enc: -ref %d runs as -ref 4\n", cfg->refnum);
     if (e->gop_b > 0 && cfg->refnum > 1 && !e->hier) logf_(1, e->log_level, "ks265enc: -ref %d with plain (non-pyramid) B pictures runs as one reference per list\n", cfg->refnum);
-    if (e->hier && e->refs_b > 1) logf_(1, e->log_level, "ks265enc: B pictures search up to %d pictures per list (list 0: the nearest coded pictures before, list 1: after; the anchors keep one reference)\n", e->refs_b);
+    if (e->hier && e->refs_b > 1) logf_(1, e->log_level, "ks265enc: B pictures search up to %d pictures per list (list 0: the nearest coded pictures before, list 1: after)\n", e->refs_b);
+    if (e->hier && cfg->ref0 > 4) logf_(1, e->log_level, "ks265enc: -ref0 %d runs as -ref0 4\n", cfg->ref0);
+    if (!e->hier && e->gop_b > 0 && cfg->ref0 > 1) logf_(1, e->log_level, "ks265enc: -ref0 %d with plain (non-pyramid) B pictures runs as one reference for the anchors\n", cfg->ref0);
+    if (e->hier && e->refs0 > 1) logf_(2, e->log_level, "ks265enc: the anchors of the pyramid search the last %d anchors (-ref0)\n", e->refs0);
     if (cfg->rc == 5 || cfg->vbv_buffer_size) logf_(1, e->log_level, "ks265enc: CVQ / VBV are not implemented; running the plain controller\n");
 
     /* the SDK's config has no device field: the lane's GPU comes from the handle (KS265_DEVICE: one GPU, default 0; KS265_GPUS / KS265_DEVICES: closed GOPs dealt
@@ -1444,7 +1467,7 @@ static Enc *lane_open(QY265EncConfig *cfg, int device, int multi, int *err)
         e->fcfg.sub_satd = kPresetSubme[ps].satd; e->fcfg.sub_thr = kPresetSubme[ps].thr; e->fcfg.sub_flat = kPresetSubme[ps].flat;
         e->fcfg.sub_cap = kPresetSubme[ps].cap; e->fcfg.sub_cap_step = kPresetSubme[ps].cap_step; e->fcfg.sub_diag_fast = kPresetSubme[ps].diag_fast;
     }
-    e->fcfg.bframes = e->gop_b; e->fcfg.refs = e->refs > e->refs_b ? e->refs : e->refs_b; e->fcfg.me_hex_thr = e->hex_thr;
+    e->fcfg.bframes = e->gop_b; e->fcfg.refs = e->refs > e->refs_b ? e->refs : e->refs_b; if (e->refs0 > e->fcfg.refs) e->fcfg.refs = e->refs0; e->fcfg.me_hex_thr = e->hex_thr;
     e->fcfg.sdh = 1;                                                    /* the reference's streams have sign_data_hiding_enabled_flag = 1 at every preset */
     e->fcfg.pre_search = 1;                                             /* stage A0: pyramid pre-search vectors as start candidates of the integer search */
     e->fcfg.merge = 1;                                                  /* stage C2: merge pass on the motion field (pictures with one reference per list) */
@@ -1530,7 +1553,7 @@ static Enc *lane_open(QY265EncConfig *cfg, int device, int multi, int *err)
     /* opt-in (KS265_ANCHOR_LANE=1): measured on the MI355X at 2160p, default GOP - 561 pictures/s without, 568 with the lane at normal stream priority, 440 at high priority
      * (and 382 before the anchor waited for its upload directly); with 8 hardware queues (GPU_MAX_HW_QUEUES) 449 without and 515 with.  The kernels of a picture fill the
      * device: an anchor running beside B pictures slows them by what it gains */
-    e->anc_on = e->hier && e->key_overlap && !e->qmap_on && !e->use_graph && getenv("KS265_ANCHOR_LANE") && atoi(getenv("KS265_ANCHOR_LANE")) > 0;
+    e->anc_on = e->hier && e->refs0 == 1 && e->key_overlap && !e->qmap_on && !e->use_graph && getenv("KS265_ANCHOR_LANE") && atoi(getenv("KS265_ANCHOR_LANE")) > 0;
     if (e->anc_on) {
         if (!r) r = ks265_create_prio(&e->ctx_anc, dev_id, getenv("KS265_ANC_PRIO") ? atoi(getenv("KS265_ANC_PRIO")) : 0);
         if (!r) r = ks265_frame_create(e->ctx_anc, &e->fcfg, &e->frame_anc);

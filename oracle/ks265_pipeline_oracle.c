@@ -709,7 +709,7 @@ void kso_merge_pass(const kso_frame_cfg *cfg, kso_pic src, const uint8_t *planes
                     if (nctb > ctb || (nctb == ctb && z_of(nx[k], ny[k]) >= zc)) continue;                              /* not yet coded when this CU is */
                     m = cu_in[(long)(ny[k] >> 3) * w8 + (nx[k] >> 3)];
                     if (m.pred_mode != 0 || (m.log2_cu & 15) < 3) continue;
-                } else { memset(&m, 0, sizeof m); m.inter_dir = is_b ? 3 : 1; }
+                } else { memset(&m, 0, sizeof m); m.inter_dir = (is_b && !(g_mr && g_mr->n1 == 0)) ? 3 : 1; }     /* (a context without list-1 pictures = a multi-reference P picture: its records are two-list records, its slice has one list) */
                 const int dir = m.inter_dir & 3;
                 /* a neighbour's vector may come from a CTU with another window offset: taken over here it must keep this CU's block inside the planes' margin */
                 if ((dir & 1) && (x + (m.mvx >> 2) < -70 || x + (m.mvx >> 2) + n > cfg->width + 70 || y + (m.mvy >> 2) < -70 || y + (m.mvy >> 2) + n > cfg->height + 70)) continue;

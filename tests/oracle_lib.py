@@ -307,10 +307,33 @@ class OraclePipeline:
                 o.kso_me_subpel(cfg, self.src.c(), ptr(planes[i]), ptr(pus[i]))
         pu_arr = (C.c_void_p * n)(*[p.ctypes.data for p in pus])
         o.kso_ref_decide(cfg, C.c_int(n), pu_arr, ptr(self.pub))
-        o.kso_cu_decide_b(cfg, ptr(self.pub), ptr(self.cu8))
+        # round 6 (-ref0: the anchors of the pyramid GOPs search several past anchors): the two-list records go through the stages a one-reference P picture has - intra
+        # candidates against them (cfg.intra_inter), the CU tree, the merge pass on the records' pictures (cfg.merge; a context without list-1 pictures), the intra CUs' pass
+        ii = self.cfg.intra_inter
+        if ii and not hasattr(self, "icost"):
+            self.icost, self.imode = np.zeros(self.nctu * 85, np.uint32), np.zeros(self.nctu * 85, np.uint8)
+        if ii:
+            o.kso_intra_candidates(cfg, self.src.c(), ptr(self.pub), ptr(self.icost), ptr(self.imode))
+            o.kso_cu_decide_b_ii(cfg, ptr(self.pub), ptr(self.icost), ptr(self.imode), ptr(self.cu8))
+        else:
+            o.kso_cu_decide_b(cfg, ptr(self.pub), ptr(self.cu8))
+        if self.cfg.merge:
+            mr = OMref()
+            mr.n0, mr.n1 = n, 0
+            for i in range(4):
+                mr.planes0[i] = planes[min(i, n - 1)].ctypes.data; mr.planes1[i] = planes[0].ctypes.data
+                mr.pic0[i] = refs[min(i, n - 1)].c(); mr.pic1[i] = refs[0].c()
+            o.kso_set_mref(C.byref(mr))
+            try:
+                tmp = self.cu8.copy()
+                o.kso_merge_pass(cfg, self.src.c(), ptr(planes[0]), None, None, ptr(self.pub), ptr(tmp), ptr(self.cu8))
+            finally:
+                o.kso_set_mref(None)
         ref_arr = (OPic * n)(*[r.c() for r in refs])
         pl_arr = (C.c_void_p * n)(*[p.ctypes.data for p in planes])
         o.kso_reconstruct_mref(cfg, self.src.c(), C.c_int(n), ref_arr, pl_arr, ptr(self.cu8), ptr(self.lvl[0]), ptr(self.lvl[1]), ptr(self.lvl[2]), self.rec.c())
+        if ii:
+            o.kso_intra_inter_reconstruct(cfg, self.src.c(), ptr(self.cu8), ptr(self.lvl[0]), ptr(self.lvl[1]), ptr(self.lvl[2]), self.rec.c())
         self.rec_pre = [self.rec.y.copy(), self.rec.u.copy(), self.rec.v.copy()]
         if self.cfg.deblock:
             o.kso_deblock(cfg, ptr(self.cu8), self.rec.c())

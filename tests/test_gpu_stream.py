@@ -30,7 +30,7 @@ def hip_encoder(ks, name):
     W, H, qp, me, thr, sao, df, kind, par = CASES[name]
     n = 1 + max(s[0] for s in schedule(kind, par))
     clip = make_clip(W, H, n, seed=len(name) * 7 + W, abc=(17, 23, 9))
-    f = KsFrame(ks, W, H, qp, lambda_q4(qp), me_method=me, me_hex_thr=thr, sao=sao, deblock=df, bframes=3 if kind in ("hier", "hiermr") else 0, refs=par if kind == "mref" else 2 if kind == "hiermr" else 1,
+    f = KsFrame(ks, W, H, qp, lambda_q4(qp), me_method=me, me_hex_thr=thr, sao=sao, deblock=df, bframes=3 if kind in ("hier", "hiermr", "hiera") else 0, refs=par if kind == "mref" else 2 if kind == "hiermr" else 3 if kind == "hiera" else 1,
                 sdh=case_sdh(name), pre_search=case_ps(name), merge=case_merge(name), bi_refine=case_bir(name), decimate=case_dec(name), rdo=case_rdo(name), intra_inter=case_ii(name), propagate=case_prop(name), part=case_part(name), tu_inter=case_rqt(name), **case_subme(name))
     g = f.geom
     src = f.new_pic()

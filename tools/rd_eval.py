@@ -71,6 +71,17 @@ def encode_ours(clip, W, H, qp, gop, tools, verbose=False, stats=None, pdelta=1,
         if os.environ.get('RD_GPB2'):                                 # generalised B at the P positions: list 0 = the previous anchor, list 1 = the one before it
             seq = [(d, 'B', r0, r0 - G if r0 >= G else r0, 0) if k == 'P' else (d, k, r0, r1, l) for (d, k, r0, r1, l) in seq]
     dpb = {}
+    # -ref0 (round 6; the host's default under --host: 3 = what -preset slow resolves to): the anchors of the hierarchy search the last RD_MREF anchors of their GOP, nearest first
+    nmref = int(os.environ.get('RD_MREF', '3' if lam_scale == -1 else '1'))
+    mrs, hist = [], []
+    for (d, kind, r0, r1, layer) in seq:
+        if kind == 'I':
+            hist = [d]; mrs.append([])
+        elif kind == 'P':
+            mrs.append(hist[:nmref] if (gop == 'hier' and nmref > 1 and hist and hist[0] == r0) else [])
+            hist = [d] + hist
+        else:
+            mrs.append([])
     for i, (d, kind, r0, r1, layer) in enumerate(seq):
         lq = 1 if layer < 0 else layer_qp[min(len(layer_qp) - 1, layer)] if (layer_qp and kind == 'B') else layer      # B layers are numbered 1 (referenced most) .. 3; -1: a plain B picture outside a pyramid (+ 2)
         q = min(51, qp if kind == "I" else qp + pdelta + lq + (cascade[d % len(cascade)] if cascade and gop == "ippp" else 0))
@@ -83,9 +94,7 @@ def encode_ours(clip, W, H, qp, gop, tools, verbose=False, stats=None, pdelta=1,
             o.o.kso_experiment_split_bits_b(sb[min(len(sb) - 1, max(layer, 0))])
         if rdo_layers:
             o.cfg.rdo = rdo_layers[0] if kind == 'P' else rdo_layers[min(len(rdo_layers) - 1, layer)] if kind == 'B' else tools.get('rdo', 0)
-        nmref = int(os.environ.get('RD_MREF', '1'))                   # experiment: the anchors of the hierarchy search the last RD_MREF anchors
-        xrefs = lambda dd, kk, rr: [rr - j * G for j in range(nmref) if rr - j * G >= 0] if (kk == 'P' and gop == 'hier' and nmref > 1) else []
-        mr = xrefs(d, kind, r0)
+        mr = mrs[i]
         if getattr(encode_ours, "rdoq_select", None):
             encode_ours.rdoq_select(kind)
         if len(mr) > 1:
@@ -94,7 +103,7 @@ def encode_ours(clip, W, H, qp, gop, tools, verbose=False, stats=None, pdelta=1,
             dpb[d] = o.encode(clip[d], kind, dpb.get(r0), dpb.get(r1))
         rec = o.store(dpb[d])
         later = seq[i + 1:]
-        needed = {r for (dd, kk, a, b, _) in later for r in [a, b] + xrefs(dd, kk, a) if r is not None and r in dpb and r != d}
+        needed = {r for j, (dd, kk, a, b, _) in enumerate(later) for r in [a, b] + mrs[i + 1 + j] if r is not None and r in dpb and r != d}
         cur = {r for r in (r0, r1) if r is not None} | set(mr)
         rps = [(p, p in cur) for p in sorted(needed | cur)]
         isref = any(d in (a, b) for (_, _, a, b, _) in later)
@@ -342,6 +351,9 @@ def main():
         for d, k, b, e in per:
             bykind.setdefault(k, []).append(b)
         print(f"reference  qp {a.ref_qp}: {size:8d} B  {p:.3f} dB   " + "  ".join(f"{k}: {int(np.mean(v))} B x{len(v)}" for k, v in bykind.items()), flush=True)
+        if a.v:
+            for d, k, b, e in sorted(per):
+                print(f"   ref {d:3d} {k} {b:7d} B  {e:.2f} dB")
     pts = []
     for qp in (int(x) for x in a.qps.split(",")):
         t0 = time.time()
