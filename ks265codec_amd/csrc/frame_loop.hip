@@ -323,8 +323,9 @@ __device__ __forceinline__ void sao_apply_block(const SaoTile<TS> &t, int bx4, i
     constexpr int TP = SaoTile<TS>::TP;
     const int x4 = bx4 * 4, y4 = by4 * 4;
     if (x4 >= w || y4 >= h) return;
-    const int dxs[4] = {1, 0, 1, -1}, dys[4] = {0, 1, 1, 1};
-    const int k = p.type > 0 ? p.type - 1 : 0, dx = dxs[k], dy = dys[k];
+    // (no run-time indexed arrays: the record's four offsets as one word, the class's direction by arithmetic - indexing put 12 bytes per lane into scratch memory)
+    const int k = p.type > 0 ? p.type - 1 : 0, dx = k == 1 ? 0 : k == 3 ? -1 : 1, dy = k == 0 ? 0 : 1;
+    const unsigned offs = (unsigned)(uint8_t)p.offset[0] | ((unsigned)(uint8_t)p.offset[1] << 8) | ((unsigned)(uint8_t)p.offset[2] << 16) | ((unsigned)(uint8_t)p.offset[3] << 24);
 #pragma unroll
     for (int yy = 0; yy < 4; ++yy) {
         if (y4 + yy >= h) break;
@@ -337,13 +338,13 @@ __device__ __forceinline__ void sao_apply_block(const SaoTile<TS> &t, int bx4, i
             int off = 0;
             if (p.type == 0) {
                 const int kk = (c >> 3) - p.band;
-                if (kk >= 0 && kk < 4) off = p.offset[kk];
+                if (kk >= 0 && kk < 4) off = (int)(int8_t)(offs >> (8 * kk));
             } else if (p.type > 0) {
                 const int X = gx + lx, Y = gy + ly;
                 const int ax = X - dx, ay = Y - dy, bx = X + dx, by = Y + dy;
                 if (!(ax < 0 || bx < 0 || ax >= picW || bx >= picW || ay < 0 || by >= picH)) {
                     const int e = eo_index(c, (int)r[-dy * TP - dx], (int)r[dy * TP + dx]);
-                    if (e != 2) off = p.offset[e < 2 ? e : e - 1];
+                    if (e != 2) off = (int)(int8_t)(offs >> (8 * (e < 2 ? e : e - 1)));
                 }
             }
             o |= (unsigned)clip8(c + off) << (8 * xx);

@@ -1433,7 +1433,9 @@ __global__ __launch_bounds__(256) void ref_decide_kernel(long n, int nref, int l
     o.mvx = a.mvx; o.mvy = a.mvy; o.mv1x = 0; o.mv1y = 0; o.cost = a.cost; o.inter_dir = 1;
     if (a.cost != KS_COST_INVALID) {
         unsigned best = KS_COST_INVALID;
-        for (int r = 0; r < nref; ++r) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {                                  // (unrolled: a run-time choice among the four pointers put the record into scratch memory)
+            if (r >= nref) break;
             const ks265_pu q = r == 0 ? a : (r == 1 ? p1[i] : (r == 2 ? p2[i] : p3[i]));
             const int bits = nref == 1 ? 0 : (r < nref - 1 ? r + 1 : nref - 1);
             const unsigned c = q.cost + (unsigned)((lam * bits) >> 4);
@@ -1452,7 +1454,9 @@ __global__ __launch_bounds__(256) void ref_pick_kernel(long n, int nref, int lam
     ks265_pu o = a; int bi = 0;
     if (a.cost != KS_COST_INVALID) {
         unsigned best = KS_COST_INVALID;
-        for (int r = 0; r < nref; ++r) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (r >= nref) break;
             const ks265_pu q = r == 0 ? a : (r == 1 ? p1[i] : (r == 2 ? p2[i] : p3[i]));
             const int bits = nref <= 1 ? 0 : (r < nref - 1 ? r + 1 : nref - 1);
             const unsigned long long c = (unsigned long long)q.cost + (unsigned long long)((lam * bits) >> 4);

@@ -57,6 +57,17 @@ __device__ __forceinline__ int clamp16(int v, int lo, int hi) { return v < lo ? 
 
 // ------------------------------------------------------------------------------------------------------------------------------------ intra (all blocks at once)
 // ws[4 blk + v] = SAD << 8 | mode of: v = 0 best of {planar, DC}; 1 best of the first four; 2 best of the seven; 3 the seven refined by +-2, +-1 (full intra only)
+// SAD of one intra mode over the block (a function with the reference arrays as arguments, not a lambda that captures them: the captured LDS pointers went through scratch memory
+// as generic pointers - 304 bytes per lane at 16 x 16 - and their loads became FLAT loads)
+template <int LG, int P>
+__device__ __forceinline__ unsigned cfc_sad_mode(const uint8_t *unf, const uint8_t *fil, bool fast_intra, int mode, const int (&f)[P], const int (&xs)[P], const int (&ys)[P], int dc)
+{
+    const uint8_t *r = (!fast_intra && intra_filter_flag(mode, 1 << LG)) ? fil : unf;   // g_intraNeedFilter enc@0x4df3a0 = the standard's filter rule (rows 8 and 16 checked)
+    unsigned s = 0;
+#pragma unroll
+    for (int k = 0; k < P; ++k) s += (unsigned)abs(f[k] - intra_sample(r, mode, LG, xs[k], ys[k], dc, true));
+    return wave_sum(s);
+}
 template <int LG>
 __global__ __launch_bounds__(256) void cfc_intra_kernel(CfcP p, const uint8_t *cur, unsigned *ws)
 {
@@ -84,13 +95,8 @@ __global__ __launch_bounds__(256) void cfc_intra_kernel(CfcP p, const uint8_t *c
     int dc = BS;
     for (int i = 0; i < BS; ++i) dc += unf[1 + i] + unf[-1 - i];
     dc >>= (LG + 1);
-    auto sad_mode = [&](int mode) __attribute__((always_inline)) -> unsigned {
-        const uint8_t *r = (!p.fast_intra && intra_filter_flag(mode, BS)) ? fil : unf;   // g_intraNeedFilter enc@0x4df3a0 = the standard's filter rule (rows 8 and 16 checked)
-        unsigned s = 0;
-#pragma unroll
-        for (int k = 0; k < P; ++k) s += (unsigned)abs(f[k] - intra_sample(r, mode, LG, xs[k], ys[k], dc, true));
-        return wave_sum(s);
-    };
+    const bool fast = p.fast_intra != 0;
+#define sad_mode(m) cfc_sad_mode<LG, P>(unf, fil, fast, (m), f, xs, ys, dc)
     unsigned best = 0xfffffffu; int bm = 0;
     unsigned out[4];
 #pragma unroll
@@ -104,6 +110,7 @@ __global__ __launch_bounds__(256) void cfc_intra_kernel(CfcP p, const uint8_t *c
     out[2] = best << 8 | (unsigned)bm;
     if (!p.fast_intra) {                                             // enc@0x4a863e..0x4a8818
         int centre = bm, curm = bm;
+#pragma unroll
         for (int step = 2; step >= 1; --step) {
             int m2 = centre + step; curm = centre;
             if ((unsigned)(m2 - 3) <= 31u) { const unsigned s = sad_mode(m2); if (s < best) { best = s; curm = m2; } }
@@ -115,6 +122,7 @@ __global__ __launch_bounds__(256) void cfc_intra_kernel(CfcP p, const uint8_t *c
     }
     out[3] = best << 8 | (unsigned)bm;
     if (live && lane < 4) ws[4 * blk + lane] = lane == 0 ? out[0] : (lane == 1 ? out[1] : (lane == 2 ? out[2] : out[3]));
+#undef sad_mode
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------------ the search chains
