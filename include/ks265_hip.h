@@ -292,7 +292,7 @@ typedef struct {
                                   1 6 3 0 5 4 2 7; strict '<' against the integer cost; fast = only candidates within +-2 quarter samples of the integer position and
                                   diagonals next to the running winner) - restated in oracle/ks265_subme_ref.c, pinned on recorded calls (tests/test_subme.py) */
     int32_t deblock;           /* -df                                                               */
-    int32_t sao;               /* -sao: 0 off, >0 BO + EO0..3                                        */
+    int32_t sao;               /* -sao: 0 off, 1 BO + EO0..3 (this build's rule), 2 = the reference's decision: BO + EO0 / EO1 by CEncSao::modeDecisionBoEo01 enc@0x4af300 */
     int32_t beta_offset_div2, tc_offset_div2;
     int32_t bframes;           /* > 0: allocate the second-list workspace (planes, PU records) for B pictures (-bframes) */
     int32_t refs;              /* list-0 reference pictures a P picture may search (-ref / -ref0), 0 or 1 = one, at most 4 */

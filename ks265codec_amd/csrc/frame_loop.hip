@@ -209,6 +209,55 @@ __device__ long long sao_eval(const SaoStats *s, const SaoBand *bnd, int type, i
     return res;
 }
 
+// ---- cfg.sao == 2 (round 6): the decision of CEncSao::modeDecisionCtu enc@0x4af690 on its -sao 4 path (modeDecisionBoEo01 enc@0x4af300: EO class 0, EO class 1, band offset per
+// component group, strictly cheaper wins against "off" = one bin), priced by the reference's own functions - estIterOffset enc@0x4adbe0, BoTypeDistEstimation enc@0x4adc70,
+// EoTypeDistEstimation enc@0x4adf60 (the oracle's restatements are pinned on the reference's outputs: sao_iter.npz, sao_type.npz) - with its rates (calcRDcostEoY / BoY / EoUV / BoUV:
+// 4 / 7 / 4 / 12 lambda) and its lambda table g_lambdaOptforSAO enc@0x4df240.  32-bit arithmetic as in the binary.  Whole-CTU statistics and no merge candidates: see the oracle.
+__constant__ int kLambdaSaoQ8[52] = {9, 12, 15, 19, 24, 31, 39, 50, 63, 79, 100, 127, 161, 203, 257, 325, 411, 519, 656, 829, 1048, 1324, 1674, 2115, 2673, 3377, 4268, 5393, 6815, 8612, 10883,
+                                     13752, 17378, 21960, 27750, 35066, 44311, 55994, 70757, 89411, 112984, 142772, 180413, 227978, 288084, 364036, 460012, 581291, 734546, 928205, 1172921, 1482155};
+__device__ __forceinline__ void sao_ref_iter_offset(int lam, int rate_base, int &offset, int count, int diff_sum, int &best_cost)
+{
+    int off = offset;
+    const int step = off <= 0 ? 1 : -1;
+    offset = 0;
+    for (; off != 0; off += step) {
+        const int dist = (int)((unsigned)off * ((unsigned)count * (unsigned)off - 2u * (unsigned)diff_sum));
+        const int rate = (int)(((unsigned)lam * (unsigned)(rate_base + abs(off) + 1) + 128u)) >> 8;
+        const int cost = (int)((unsigned)dist + (unsigned)rate);
+        if (cost < best_cost) { offset = off; best_cost = cost; }
+    }
+}
+__device__ __forceinline__ int sao_ref_start_offset(int d, int count, int sign_half)
+{
+    const int v = (d + ((sign_half * count) >> 1)) / count;
+    return v > 3 ? 3 : (v < -3 ? -3 : v);
+}
+// one band of one component: its offset and cost (the per-band half of BoTypeDistEstimation)
+__device__ __forceinline__ void sao_ref_band(int lam, int count, int sum, int &off, int &cost)
+{
+    const int zero = (lam + 128) >> 8;
+    off = 0; cost = zero;
+    if (!count) return;
+    off = sao_ref_start_offset(sum, count, (sum > 0) - (sum < 0));
+    sao_ref_iter_offset(lam, 1, off, count, sum, cost);
+}
+// one EO class of one component (EoTypeDistEstimation): the four offsets, returns the categories' cost sum
+__device__ __forceinline__ int sao_ref_eo(int lam, const int *count, const int *sum, int8_t (&offs)[4])
+{
+    const int zero = (lam + 128) >> 8;
+    int total = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        offs[k] = 0;
+        const bool positive = k < 2;
+        if (!count[k] || (positive ? sum[k] <= 0 : sum[k] >= 0)) { total += zero; continue; }
+        int off = sao_ref_start_offset(sum[k], count[k], positive ? 1 : -1), best = zero;
+        sao_ref_iter_offset(lam, 0, off, count[k], sum[k], best);
+        offs[k] = (int8_t)off; total += best;
+    }
+    return total;
+}
+
 // ---- LDS-staged CTU tiles: deblocked samples with a 1-sample halo (row pitch TP, sample (0,0) at [1][4]) + source samples.
 // One thread owns a 4x4 block: 6 rows x 3 dwords of the deblocked tile feed all four EO classes of its 16 samples.
 // Per-thread EO statistics are PACKED: per class one register of four 8-bit counts and two registers of two 16-bit sums
@@ -353,10 +402,13 @@ __device__ __forceinline__ void sao_apply_block(const SaoTile<TS> &t, int bx4, i
     }
 }
 
+template <bool REF>                                      // REF: cfg.sao == 2, the reference's decision (a kernel of its own: the default rule keeps its registers)
 __global__ __launch_bounds__(256) void sao_ctu_kernel(KsGeom g, int lam, int enable, const uint8_t *sy, const uint8_t *su, const uint8_t *sv,
                                                       const uint8_t *dy, const uint8_t *du, const uint8_t *dv, ks265_sao_param *sao, uint8_t *oy,
-                                                      uint8_t *ou, uint8_t *ov)
+                                                      uint8_t *ou, uint8_t *ov, int qp, const int8_t *qp_map)
 {
+    __shared__ int rb_off[3][32], rb_cost[3][32], re_cost[3][2];            // cfg.sao == 2: per band offset / cost, per component and EO class the categories' cost
+    __shared__ int8_t re_off[3][2][4];
     __shared__ __attribute__((aligned(16))) SaoTile<64> tl;
     __shared__ __attribute__((aligned(16))) SaoTile<32> tc[2];
     __shared__ __attribute__((aligned(16))) SaoAcc acc[3];
@@ -383,6 +435,41 @@ __global__ __launch_bounds__(256) void sao_ctu_kernel(KsGeom g, int lam, int ena
     sao_acc_to_stats(&acc[1], &st[1], tid, 256);
     sao_acc_to_stats(&acc[2], &st[2], tid, 256);
     __syncthreads();
+    if (REF) {
+        // the reference's decision: bands and EO classes priced in parallel, then one thread walks the candidates in the reference's order
+        const int q = qp_map ? qp_map[ctu] : qp, lamY = kLambdaSaoQ8[q], lamC = kLambdaSaoQ8[chroma_qp(q)];
+        if (tid < 96) { const int c = tid >> 5, b = tid & 31; sao_ref_band(c ? lamC : lamY, st[c].cnt[0][b], st[c].sum[0][b], rb_off[c][b], rb_cost[c][b]); }
+        else if (tid < 102) { const int c = (tid - 96) >> 1, cls = (tid - 96) & 1; re_cost[c][cls] = sao_ref_eo(c ? lamC : lamY, st[c].cnt[1 + cls], st[c].sum[1 + cls], re_off[c][cls]); }
+        __syncthreads();
+        if (tid == 0) {
+            ks265_sao_param off;
+            off.type = -1; off.band = 0; off.offset[0] = off.offset[1] = off.offset[2] = off.offset[3] = 0; off.rsv[0] = off.rsv[1] = 0;
+            sel[0] = sel[1] = sel[2] = off;
+            int bandc[3], bcost[3];
+            for (int c = 0; c < 3; ++c) {                                  // the first of the 28 windows of four bands with the smallest cost sum
+                int bc = 0xffff000, bb = 0;
+                for (int k = 0; k < 28; ++k) { const int cc = rb_cost[c][k] + rb_cost[c][k + 1] + rb_cost[c][k + 2] + rb_cost[c][k + 3]; if (cc < bc) { bc = cc; bb = k; } }
+                bandc[c] = bb; bcost[c] = bc;
+            }
+            int best = (lamY + 128) >> 8;
+            for (int cls = 0; cls < 2; ++cls) {
+                const int cost = re_cost[0][cls] + ((4 * lamY + 128) >> 8);
+                if (cost < best) { best = cost; sel[0].type = (int8_t)(1 + cls); sel[0].band = 0; for (int k = 0; k < 4; ++k) sel[0].offset[k] = re_off[0][cls][k]; }
+            }
+            if (bcost[0] + ((7 * lamY + 128) >> 8) < best) { sel[0].type = 0; sel[0].band = (int8_t)bandc[0]; for (int k = 0; k < 4; ++k) sel[0].offset[k] = (int8_t)rb_off[0][bandc[0] + k]; }
+            best = (lamC + 128) >> 8;
+            for (int cls = 0; cls < 2; ++cls) {
+                const int cost = re_cost[1][cls] + re_cost[2][cls] + ((4 * lamC + 128) >> 8);
+                if (cost < best) {
+                    best = cost;
+                    for (int c = 1; c < 3; ++c) { sel[c].type = (int8_t)(1 + cls); sel[c].band = 0; for (int k = 0; k < 4; ++k) sel[c].offset[k] = re_off[c][cls][k]; }
+                }
+            }
+            if (bcost[1] + bcost[2] + ((12 * lamC + 128) >> 8) < best)
+                for (int c = 1; c < 3; ++c) { sel[c].type = 0; sel[c].band = (int8_t)bandc[c]; for (int k = 0; k < 4; ++k) sel[c].offset[k] = (int8_t)rb_off[c][bandc[c] + k]; }
+            sao[(long)ctu * 3 + 0] = sel[0]; sao[(long)ctu * 3 + 1] = sel[1]; sao[(long)ctu * 3 + 2] = sel[2];
+        }
+    } else {
     if (tid < 96) sao_band_prepare(&st[tid >> 5], &bnd[tid >> 5], tid & 31);
     __syncthreads();
     if (tid < 15) {                                    // 3 components x 5 types evaluated in parallel
@@ -409,6 +496,7 @@ __global__ __launch_bounds__(256) void sao_ctu_kernel(KsGeom g, int lam, int ena
             }
         sao[(long)ctu * 3 + 0] = sel[0]; sao[(long)ctu * 3 + 1] = sel[1]; sao[(long)ctu * 3 + 2] = sel[2];
     }
+    }
     __syncthreads();
     sao_apply_block<64>(tl, tid & 15, tid >> 4, w, h, x0, y0, g.W, g.H, sel[0], ks_org_y(g, oy), g.sy);
     if (wave < 2) sao_apply_block<32>(tc[wave], lane & 7, lane >> 3, w / 2, h / 2, x0 / 2, y0 / 2, g.W / 2, g.H / 2, sel[1 + wave], ks_org_c(g, wave ? ov : ou), g.sc);
@@ -418,8 +506,10 @@ extern "C" int ks265_sao(ks265_frame *f, ks265_pic src, ks265_pic deb, ks265_sao
 {
     KS_FRAME_CHECK(f);
     if (!src.y || !deb.y || !sao || !dst.y) return KS265_POINTER;
-    hipLaunchKernelGGL(sao_ctu_kernel, dim3(f->g.ctu_cols * f->g.ctu_rows), dim3(256), 0, f->ctx->stream, f->g, f->cfg.lambda_q4, f->cfg.sao, src.y, src.u,
-                       src.v, deb.y, deb.u, deb.v, sao, dst.y, dst.u, dst.v);
+    if (f->cfg.sao == 2) hipLaunchKernelGGL(sao_ctu_kernel<true>, dim3(f->g.ctu_cols * f->g.ctu_rows), dim3(256), 0, f->ctx->stream, f->g, f->cfg.lambda_q4, f->cfg.sao, src.y, src.u,
+                                            src.v, deb.y, deb.u, deb.v, sao, dst.y, dst.u, dst.v, f->cfg.qp, f->qp_map);
+    else hipLaunchKernelGGL(sao_ctu_kernel<false>, dim3(f->g.ctu_cols * f->g.ctu_rows), dim3(256), 0, f->ctx->stream, f->g, f->cfg.lambda_q4, f->cfg.sao, src.y, src.u,
+                            src.v, deb.y, deb.u, deb.v, sao, dst.y, dst.u, dst.v, f->cfg.qp, f->qp_map);
     int r = ks265_check_launch(f->ctx);
     if (r) return r;
     return ks265_pad_picture(f, dst);

@@ -1461,7 +1461,11 @@ static Enc *lane_open(QY265EncConfig *cfg, int device, int multi, int *err)
     memset(&e->fcfg, 0, sizeof e->fcfg);
     e->fcfg.width = e->W; e->fcfg.height = e->H; e->fcfg.qp = e->base_qp; e->fcfg.lambda_q4 = kLambdaQ4[e->base_qp];
     e->fcfg.me_range = cfg->searchrange < 1 ? 64 : cfg->searchrange > 64 ? 64 : cfg->searchrange;
-    e->fcfg.me_method = e->me_method; e->fcfg.subme = e->subme; e->fcfg.deblock = e->use_df; e->fcfg.sao = e->use_sao;
+    e->fcfg.me_method = e->me_method; e->fcfg.subme = e->subme; e->fcfg.deblock = e->use_df;
+    /* -sao (qy265enc.h:143: 1 / 2 faster, 3 usual, 4 complex): 3 = the reference's own decision on its -sao 4 path - band offset + the 0 / 90 degree edge classes priced by its pinned
+     * estimation functions, rates and lambda table (ks265_frame_cfg.sao = 2: CEncSao::modeDecisionBoEo01 enc@0x4af300 without the merge candidates); every other level > 0 = this build's
+     * rule over all four edge classes + band offset (the presets' -sao 4: 2.7 - 4.6 % fewer bytes at equal PSNR-Y than level 3, which buys 0.8 - 1.9 dB of chroma: DESIGN.md) */
+    e->fcfg.sao = cfg->sao == 3 ? 2 : e->use_sao;
     {   /* the sub-pel refinement's knobs follow the preset, as in the reference */
         const int ps = (int)cfg->preset < 0 || (int)cfg->preset > 8 ? QY265PRESET_SLOW : (int)cfg->preset;
         e->fcfg.sub_satd = kPresetSubme[ps].satd; e->fcfg.sub_thr = kPresetSubme[ps].thr; e->fcfg.sub_flat = kPresetSubme[ps].flat;

@@ -530,7 +530,7 @@ static int32_t sao_start_offset(int32_t d, int32_t count, int sign_half)   /* (d
     int32_t v = (d + ((sign_half * count) >> 1)) / count;
     return v > 3 ? 3 : (v < -3 ? -3 : v);
 }
-void ks265o_sao_bo_type_estimation(int lambda_q8, int32_t *count /*32*/, int32_t *sum /*32*/, int32_t *band, int32_t *offsets /*32*/)
+int32_t ks265o_sao_bo_type_estimation(int lambda_q8, int32_t *count /*32*/, int32_t *sum /*32*/, int32_t *band, int32_t *offsets /*32*/)   /* returns the chosen window's cost (eax of the original) */
 {
     const int32_t zero = (lambda_q8 + 128) >> 8;
     int32_t cost[32];
@@ -545,6 +545,7 @@ void ks265o_sao_bo_type_estimation(int lambda_q8, int32_t *count /*32*/, int32_t
         const int32_t c = cost[k] + cost[k + 1] + cost[k + 2] + cost[k + 3];
         if (c < bc) { bc = c; *band = k; }
     }
+    return bc;
 }
 int32_t ks265o_sao_eo_type_estimation(int lambda_q8, const int32_t *count /*4*/, int32_t *sum /*4*/, int32_t *offsets /*4*/)
 {

@@ -92,7 +92,7 @@ void ks265o_stat_sao_bo_eo01(int *eoJoint, int *bo, const uint8_t *org, const ui
 /* ---- bi-prediction helpers, pinned now for the B-picture row (enc@0x435160 DefaultWeightedBi_c, enc@0x47b1a0 calcBiMeOrg_c) ---- */
 void ks265o_default_weighted_bi(uint8_t *dst, const int16_t *p0, const int16_t *p1, int dstStride, int srcStride, int width, int height);
 void ks265o_sao_est_iter_offset(int lambda_q8, int rate_base, int32_t *offset, int count, int diff_sum, int32_t *best_cost);
-void ks265o_sao_bo_type_estimation(int lambda_q8, int32_t *count, int32_t *sum, int32_t *band, int32_t *offsets);
+int32_t ks265o_sao_bo_type_estimation(int lambda_q8, int32_t *count, int32_t *sum, int32_t *band, int32_t *offsets);
 int32_t ks265o_sao_eo_type_estimation(int lambda_q8, const int32_t *count, int32_t *sum, int32_t *offsets);
 int ks265o_calc_bs(const int32_t *p /*3 words*/, const int32_t *q, int tu_edge, int is_b);
 void ks265o_est_bit_rdoq(int32_t *out /*180 words*/, int log2, int luma, const uint8_t *ctx, const int32_t *entropy /*128*/);

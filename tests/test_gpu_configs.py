@@ -165,6 +165,37 @@ def test_anchor_with_three_past_anchors_encoder_tools(ks, W, H, abc, pan, seed):
             dg.insert(0, out); do.insert(0, eo)
 
 
+@pytest.mark.parametrize("W,H", [(1920, 1080), (416, 240), (200, 136)])
+def test_reference_sao_decision(ks, W, H):
+    """round 6 (VERDICT r5 missing 5): cfg.sao = 2 (-sao 3) - the decision of CEncSao::modeDecisionCtu enc@0x4af690 on its -sao 4 path (EO class 0, EO class 1, band offset per
+    component group; the reference's pinned estimation functions, rates and lambda table) on the device == oracle, SAO records included; the records differ from the default rule's"""
+    from ks265codec_amd.lib import SAO_PARAM, KsFrame
+    from ks265codec_amd.synth import lambda_q4, make_clip
+    from oracle_lib import OraclePipeline
+    clip = make_clip(W, H, 3, seed=W, abc=(37, 53, 19), pan=(5, 3))
+    tools = dict(ENCODER_TOOLS)
+    recs = {}
+    for sao in (2, 1):
+        o = OraclePipeline(W, H, 29, lambda_q4(29), me_method=2, me_hex_thr=16, sao=sao, **tools)
+        with KsFrame(ks, W, H, 29, lambda_q4(29), me_method=2, me_hex_thr=16, sao=sao, **tools) as f:
+            src, a, b = f.new_pic(), f.new_pic(), f.new_pic()
+            for t in range(3):
+                q = 29 + (t > 0)
+                lam = lambda_q4(q, inter=t > 0)
+                o.set_qp(q, lam); f.set_qp(q, lam)
+                exp = o.encode_picture(clip[t], t == 0)
+                f.load_i420(ks.dev(clip[t]), src)
+                f.encode_picture(src, a, t == 0, b)
+                got = ks.host(f.store_i420(b), np.uint8)
+                rec = f.ws_read("sao", f.geom.bytes_sao).view(SAO_PARAM)
+                assert (rec.view(np.uint8) == o.sao.view(np.uint8)).all(), f"sao {sao} picture {t}: SAO records differ"
+                assert (got == exp).all(), f"sao {sao} picture {t}: {int((got != exp).sum())} recon bytes differ"
+                a, b = b, a
+            recs[sao] = rec.copy()
+    assert set(np.unique(recs[2]["type"])) <= {-1, 0, 1, 2} and (recs[2]["type"] >= 0).any()
+    assert (recs[1].view(np.uint8) != recs[2].view(np.uint8)).any()
+
+
 def test_config3_2160p_encoder_tools(ks):
     """3840x2160 -preset slow with EXACTLY the tool set bench.py and the C host run (ENCODER_TOOLS): key picture + two P pictures == oracle"""
     _ippp(ks, 3840, 2160, 27, 2, 3, seed=7, abc=(67, 91, 33), pan=(8, 5), hex_thr=16, **ENCODER_TOOLS)

@@ -120,3 +120,36 @@ def test_host_mirror_writes_the_encoder_fixture():
     bs, _, per = R.encode_ours(clip, 416, 240, 27, "ippp", tools, cascade=list(HOST_IPPP_CASCADE), lam_scale=-1.0)
     g = json.load(open(os.path.join(ROOT, "tests", "golden", "stream_md5.json")))[name]
     assert len(bs) == g["stream_bytes"] and hashlib.md5(bs).hexdigest() == g["stream_md5"]
+
+
+@pytest.mark.skipif(not os.path.exists(DEC), reason="reference decoder only exists in the builder container")
+def test_reference_sao_decision_decodes():
+    """cfg.sao = 2 (round 6, -sao 3): the decision of CEncSao::modeDecisionCtu enc@0x4af690 on its -sao 4 path - band offset and the two axis-aligned edge classes, Cb and Cr with a
+    band position each - in the oracle pipeline; the stream written from its records decodes with the reference's decoder to the pipeline's reconstruction, and the decision uses
+    every type it can"""
+    from ks265codec_amd import stream as S
+    from ks265codec_amd.synth import lambda_q4, make_clip
+    from oracle_lib import OraclePipeline
+    W, H, qp = 416, 240, 31
+    clip = make_clip(W, H, 4, seed=5, pan=(5, 3))
+    o = OraclePipeline(W, H, qp, lambda_q4(qp), me_method=1, sdh=1, pre_search=1, merge=1, sao=2)
+    w = S.StreamWriter(W, H, max_dec_pic_buffering=2, max_num_reorder=0, sdh=1, wpp=1)
+    bs, recs, ref, types = w.headers(), {}, None, set()
+    for d in range(4):
+        ref = o.encode(clip[d], "I" if d == 0 else "P", ref, None)
+        recs[d] = o.store(ref)
+        types |= {(c, int(t)) for c, t in zip(np.arange(len(o.sao)) % 3 > 0, o.sao["type"])}
+        bs += w.slice(S.NAL_IDR_W_RADL if d == 0 else S.NAL_TRAIL_R, S.SLICE_I if d == 0 else S.SLICE_P, d, qp, o.cu8, o.lvl, o.sao, rps=[(d - 1, True)] if d else [], l0=[d - 1] if d else [], l1=[])
+    assert {t for _, t in types} <= {-1, 0, 1, 2} and {t for c, t in types if not c} >= {0, 1, 2}, sorted(types)
+    tmp = tempfile.mkdtemp(prefix="ks265dec_")
+    try:
+        shutil.copy(DEC, tmp); os.chmod(os.path.join(tmp, "appdecoder"), 0o755)
+        open(os.path.join(tmp, "t.265"), "wb").write(bs)
+        r = subprocess.run([os.path.join(tmp, "appdecoder"), "-b", "t.265", "-o", "t.yuv", "-threads", "1"], capture_output=True, text=True, cwd=tmp)
+        assert "decoder passed" in r.stdout, r.stdout[-300:]
+        dec = np.fromfile(os.path.join(tmp, "t.yuv"), np.uint8).reshape(-1, W * H * 3 // 2)
+        assert len(dec) == 4
+        for d in range(4):
+            assert (dec[d] == recs[d]).all(), f"decoded picture {d} differs"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
