@@ -17,12 +17,16 @@
  *     iAqMode / fAqStrength (-aq / -aqs) give every CTU its own QP (cu_qp_delta) from the reference's calcFrameAdaptQuant arithmetic;
  *   - lookahead: with the default hierarchical GOP (bframes -1 / 7) the slice-type decision (a block of 8 pictures coded as 8 or as 4 + 4)
  *     runs by itself, so the GOP layout depends on the content unless lookahead = 0; lookahead N > 0 adds scene-cut key pictures;
- *   - refnum with the pyramid GOPs gives the B pictures up to 4 reference pictures per list (round 5; the anchors keep one); tuInter >= 1 codes 2Nx2N inter CUs of 32 / 16
- *     samples with four transform units where the residual sits in part of the CU (one level of the residual quadtree; deeper values run as 1);
- *   - rdoq, transskip, tuIntra, vpp_*, 2-pass, long-term references, VBV / CVQ: accepted, ignored (the pixel path has no such stage; the reference's rdoQuant exists as a
- *     device operator, ks265_rdoq_batch, and was measured at the seam with adaptive tables: <= 1 % - DESIGN.md 9);
- *   - input pictures are COPIED inside QY265EncoderEncodeFrame: the caller may reuse its buffers at once (the SDK requires them to stay
- *     valid until the frame is done).
+ *   - refnum with the pyramid GOPs gives the B pictures up to 4 reference pictures per list (round 5); ref0 (round 6; every preset from superfast up resolves to 3) gives the
+ *     anchors of a pyramid the last ref0 anchors of their GOP to search; tuInter >= 1 codes 2Nx2N inter CUs of 32 / 16 samples with four transform units where the residual sits
+ *     in part of the CU (one level of the residual quadtree; deeper values run as 1);
+ *   - rdoq (round 6): the presets' rdoq = 1 runs this build's own seam (dead zone, coefficient-group pruning, sign-data hiding); rdoq set BY NAME (QY265ConfigParse "rdoq" "1" =
+ *     `-rdoq 1`, stored as 2) sends the luma transform blocks of inter CUs through the reference's rdoQuant with bit tables that follow the stream; "0" = the seam;
+ *   - sao: 3 = the reference's decision on its -sao 4 path (band offset + the 0 / 90 degree edge classes, its estimation functions, rates and lambda table, no merge candidates);
+ *     every other level > 0 = this build's rule over all four edge classes + band offset;
+ *   - transskip, tuIntra, vpp_*, 2-pass, long-term references, VBV / CVQ: accepted, ignored;
+ *   - input pictures: the caller's planes are pinned in place and uploaded from where they lie inside QY265EncoderEncodeFrame; the caller may reuse its buffers when the call returns
+ *     (the SDK requires them to stay valid until the frame is done).
  */
 #ifndef KS265_ENC_H
 #define KS265_ENC_H

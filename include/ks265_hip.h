@@ -482,6 +482,11 @@ int ks265_intra_reconstruct(ks265_frame *, ks265_pic src, ks265_cu8 *dev_cu8, in
 int ks265_deblock(ks265_frame *f, const ks265_cu8 *dev_cu8, ks265_pic recon);
 /* Stage F: SAO statistics + decision + apply (CEncSao::modeDecisionCtu enc@0x4af690, qy265SaoApplyOffset
  * enc@0x43fc00); dst becomes the next reference picture (borders padded) */
+/* cfg.rdoq (round 6; the SDK's rdoq field, qy265enc.h:129): with tables set, ks265_reconstruct / _b / _mref send the luma transform blocks of inter CUs through the reference's
+ * rdoQuant (the operator of ks265_rdoq_batch: levels q / q - 1 / 0, last position, all-zero groups, sign-data hiding by RD cost) between a front half (transform, levels rounded at
+ * 1 / 2) and a back half (dequantisation, inverse transform) - in place of dead zone + coefficient-group pruning + sign-data hiding at the seam.  host_tables: [4 sizes][luma,
+ * chroma][180] words of estBitRdoq enc@0x46a8a0; host_lam / host_lam_sdh: rdoQuant's two lambdas by QP [52].  All null: back to the default seam.  P / B pictures (intra CUs keep the seam) */
+int ks265_frame_set_rdoq(ks265_frame *f, const int32_t *host_tables, const int64_t *host_lam, const int64_t *host_lam_sdh);
 int ks265_sao(ks265_frame *f, ks265_pic src, ks265_pic deblocked, ks265_sao_param *dev_sao, ks265_pic dst);
 
 /* Multi-reference P pictures (-ref / -ref0; motionSearchOneRef enc@0x483f40 runs once per reference picture): search every picture

@@ -78,6 +78,9 @@ long ks265_write_slice(const ks265_stream_cfg *cfg, const ks265_slice_in *in, vo
  * row) and where the residual-coding groups start (layout[10]: cbf_luma, cbf_chroma, coded_sub_block_flag, sig_coeff_flag, last x, last y, greater1, greater2, rqt_root_cbf,
  * count) - what a host snapshots into the bit tables of rdoQuant (estBitRdoq enc@0x46a8a0) for the pictures that follow.  Returns the number of states. */
 int ks265_slice_final_contexts(const ks265_stream_cfg *cfg, const void *scratch, uint8_t *out, int cap, int *layout);
+/* -rdoq 1 (round 6): the eight bit tables [4 sizes][luma, chroma][180] rdoQuant enc@0x4aac50 prices with (estBitRdoq enc@0x46a8a0), from the context states a slice ended with
+ * (states = ks265_slice_final_contexts' output: the tables follow the stream) or, states = NULL, from the initial states of a slice of slice_type at qp */
+int ks265_rdoq_tables(const ks265_stream_cfg *cfg, const uint8_t *states, int slice_type, int qp, int32_t *tables);
 
 /* cfg->wpp = 1: the same picture row by row, so that SEVERAL host threads can write one picture (the reference's WPP tasks, qy265executeEncCtuTaskWpp
  * enc@0x475d20).  ks265_wpp_begin prepares the job in `mem` (ks265_wpp_bytes), ks265_wpp_code_row codes one CTU row into its substream - thread-safe for

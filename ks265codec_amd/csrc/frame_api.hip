@@ -90,7 +90,7 @@ void ks265_frame_destroy(ks265_frame *f)
     if (f->ev_join) (void)hipEventDestroy(f->ev_join);
     for (int i = 0; i < 10; ++i)
         if (f->pyr2[i] && f->pyr2[i] != f->pyr[i]) (void)hipFree(f->pyr2[i]);
-    void *ptrs[] = {f->ic_work, f->pu1_x[0], f->pu1_x[1], f->pu1_x[2], f->ridx[0], f->ridx[1], f->pu_s2, f->pu1, f->pu_s, f->pub, f->pu[0], f->pu[1], f->cu8, f->sao, f->lvl[0], f->lvl[1], f->lvl[2], f->deb[0], f->deb[1], f->deb[2], f->sse, f->sse_acc, f->cu8_tmp, f->progress, f->mats, f->icost, f->rect, f->pu_x[0], f->pu_x[1], f->pu_x[2]};
+    void *ptrs[] = {f->rq_coef, f->rq_pack_lvl, f->rq_pack_coef, f->rq_tus, f->rq_pos, f->rq_ctr, f->rq_out, f->rq_tab, f->rq_lam, f->rq_sigmask, f->rq_hidden, f->ic_work, f->pu1_x[0], f->pu1_x[1], f->pu1_x[2], f->ridx[0], f->ridx[1], f->pu_s2, f->pu1, f->pu_s, f->pub, f->pu[0], f->pu[1], f->cu8, f->sao, f->lvl[0], f->lvl[1], f->lvl[2], f->deb[0], f->deb[1], f->deb[2], f->sse, f->sse_acc, f->cu8_tmp, f->progress, f->mats, f->icost, f->rect, f->pu_x[0], f->pu_x[1], f->pu_x[2]};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (uint8_t *p : f->pyr)

@@ -69,6 +69,17 @@ struct ks265_frame {
     int me_order_off = 0;               // KS265_ME_ORDER_OFF: experiments
     // multi-reference B picture being coded (ks265_encode_picture_b_mref sets it for the duration of the picture: ks265_bi_decide, ks265_merge_pass, ks265_cu_decide_part_b and
     // ks265_reconstruct_b then take every block's pictures from its record); host-side copies of the lists + the per-PU index arrays and the extra list-1 PU records
+    // cfg.rdoq (round 6; -rdoq 1 = the SDK's rdoq field, qy265enc.h:129): the luma transform blocks of inter CUs go through the reference's rdoQuant (rdoq_ops.hip) - front half of
+    // ks265_reconstruct* (coefficients + levels rounded at 1 / 2 to planes), rdoq_prep_kernel (the blocks listed, packed, their significance masks and last positions), rdoq_kernel,
+    // rdoq_unpack_kernel, back half (dequantisation, inverse transform, reconstruction).  Workspace allocated by ks265_frame_set_rdoq; tables + lambdas from the host per picture
+    int16_t *rq_coef = nullptr, *rq_pack_lvl = nullptr, *rq_pack_coef = nullptr;
+    ks265_rdoq_tu *rq_tus = nullptr;
+    int *rq_pos = nullptr, *rq_ctr = nullptr, *rq_out = nullptr;
+    int32_t *rq_tab = nullptr;
+    long long *rq_lam = nullptr;
+    uint16_t *rq_sigmask = nullptr;
+    unsigned long long *rq_hidden = nullptr;
+    bool rq_ready = false;
     bool mrefb = false;
     bool mr_pslice = false;             // round 6: the context is a multi-reference P picture's (ks265_encode_picture_mref: two-list records, one list in the slice - the merge pass's zero candidate is uni-directional)
     int mr_n[2] = {1, 1};

@@ -113,7 +113,9 @@ __device__ __forceinline__ void code_region(const KsGeom &g, int comp, int qp, i
                                             short *X, short *T, unsigned char *P, int *nzcnt /*LDS [16]*/, const uint8_t *src, const uint8_t *ref,
                                             const uint8_t *ref1, int16_t *lvl, uint8_t *rec, int tid, const KsCompRefs xr,
                                             bool sdh, short *LV, short *DU, short *CF, int *lastcg /*LDS [16]*/, int dec_k, long long rdo_lam2k /* lambda_q4^2 x cfg.rdo, 0 = off */,
-                                            bool tu_split = false /* cfg.tu_inter, the luma call: decide which 2Nx2N inter CUs of 32 / 16 carry four transform units */)
+                                            bool tu_split = false /* cfg.tu_inter, the luma call: decide which 2Nx2N inter CUs of 32 / 16 carry four transform units */,
+                                            int rq_mode = 0 /* cfg.rdoq, the luma call: 1 = front half (coefficients + levels rounded at 1 / 2 to the planes, nothing else), 2 = back half (levels from the plane) */,
+                                            int16_t *coefp = nullptr)
 {
     constexpr int UNIT = RS / 4;                      // samples per 8x8-luma block along one axis
     constexpr int NQ = RS * RS / 4;                   // quads (4 adjacent samples of one row)
@@ -211,6 +213,23 @@ __device__ __forceinline__ void code_region(const KsGeom &g, int comp, int qp, i
     const int ox = tbx * UNIT, oy = tby * UNIT, n = t8 * UNIT, log2n = tu_log2[b] + (RS == 32 ? 3 : 2);
     const short *mf = Mf + mat_off(log2n), *mt = Mt + mat_off(log2n);
     const int mp = n + 4;                                          // matrix row pitch
+    if (rq_mode == 2) {
+        // ---- cfg.rdoq, back half: the levels rdoQuant left in the plane -> dequantised (transposed) tile, coded-block counts; then the inverse passes below
+        if (has_quad && coded) {
+            const int k = qy - oy, j = qx - ox, shift = log2n - 1, dqs = kInvQuantScales[qp % 6] << (qp / 6);
+            const uint2 lw = *(const uint2 *)(lvl + (long)(Y0 + qy) * lstride + X0 + qx);
+            int nz = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const unsigned w = i < 2 ? lw.x : lw.y;
+                const int l = (int)(short)((i & 1) ? (w >> 16) : (w & 0xFFFFu));
+                nz += l != 0;
+                X[(oy + j + i) * RP + ox + k] = (short)dequant_one(l, dqs, 1 << (shift - 1), shift);
+            }
+            if (nz) atomicAdd(&nzcnt[tb], nz);
+        }
+        __syncthreads();
+    } else {
     // ---- forward pass 1: T[k][j] = rnd(M[k] . X[j], 2 log2N - 2)
     if (has_quad) {
         const int k = qy - oy, j = qx - ox, s1 = 2 * log2n - 2;
@@ -232,6 +251,21 @@ __device__ __forceinline__ void code_region(const KsGeom &g, int comp, int qp, i
         const int qbits = 21 + qp6 - log2n, off = (c.pred_mode != 0 ? 171 : 85) << (qbits - 9), shift = log2n - 1;
         unsigned short lv[4];
         int nz = 0;
+        if (rq_mode == 1) {
+            // ---- cfg.rdoq, front half: the transform coefficients and the quantiser's levels rounded at 1 / 2 (what rdoQuant enc@0x4aac50 is handed) go to their planes
+            unsigned short cf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int coef = (short)((acc[i] + 64) >> 7), a = coef < 0 ? -coef : coef;
+                int q = coded ? (int)(((long long)a * scale + (1ll << (qbits - 1))) >> qbits) : 0;
+                if (q > 32767) q = 32767;
+                lv[i] = (unsigned short)(short)(coef < 0 ? -q : q); cf[i] = (unsigned short)(short)(coded ? coef : 0);
+            }
+            if (coded) {
+                *(uint2 *)(lvl + (long)(Y0 + qy) * lstride + X0 + qx) = make_uint2(lv[0] | ((unsigned)lv[1] << 16), lv[2] | ((unsigned)lv[3] << 16));
+                *(uint2 *)(coefp + (long)(Y0 + qy) * lstride + X0 + qx) = make_uint2(cf[0] | ((unsigned)cf[1] << 16), cf[2] | ((unsigned)cf[3] << 16));
+            }
+        } else
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int coef = (short)((acc[i] + 64) >> 7);
@@ -245,7 +279,7 @@ __device__ __forceinline__ void code_region(const KsGeom &g, int comp, int qp, i
             if (sdh || rdo_lam2k) { const int o = (oy + k) * RP + ox + j + i; LV[o] = (short)l; DU[o] = (short)du; CF[o] = (short)coef; }
             X[(oy + j + i) * RP + ox + k] = (short)dqv;
         }
-        if (coded) {
+        if (coded && rq_mode != 1) {
             *(uint2 *)(lvl + (long)(Y0 + qy) * lstride + X0 + qx) = make_uint2(lv[0] | ((unsigned)lv[1] << 16), lv[2] | ((unsigned)lv[3] << 16));
             if (nz) {
                 atomicAdd(&nzcnt[tb], nz);
@@ -259,6 +293,7 @@ __device__ __forceinline__ void code_region(const KsGeom &g, int comp, int qp, i
         }
     }
     __syncthreads();
+    if (rq_mode == 1) return;                                      // (uniform: the front half ends here - no levels counted, no reconstruction)
     if (dec_k) {
         // ---- cfg.decimate (luma only: the chroma calls pass 0): a TU holding nothing but a few +-1 levels is dropped (levels zeroed in HBM, no residual, cbf 0)
         if (tid < 16) {
@@ -330,6 +365,7 @@ __device__ __forceinline__ void code_region(const KsGeom &g, int comp, int qp, i
         }
         __syncthreads();
     }
+    }   // rq_mode != 2
     const bool live = has_quad && nzcnt[tb] != 0;
     // ---- inverse pass 1: T[y][x] = clip16((Mt[y] . Ct[x] + 64) >> 7)
     if (has_quad) {
@@ -376,7 +412,7 @@ __global__ __launch_bounds__(256) void reconstruct_kernel(KsGeom g, int qp, cons
                                                           const uint8_t *ref_y, const uint8_t *ref_u, const uint8_t *ref_v,
                                                           const uint8_t *ref1_y, const uint8_t *ref1_u, const uint8_t *ref1_v, ks265_cu8 *cu8,
                                                           int16_t *lvl_y, int16_t *lvl_u, int16_t *lvl_v, uint8_t *rec_y, uint8_t *rec_u, uint8_t *rec_v, const short *mats, const KsRefExtra xr, int sdh_on, int dec_k, long long rdo_lam2k, const int8_t *qp_map,
-                                                          int tu_inter)
+                                                          int tu_inter, int rq_mode, int16_t *coef_y)
 {
     __shared__ __attribute__((aligned(16))) short Mf[MAT_SHORTS];
     __shared__ __attribute__((aligned(16))) short Mt[MAT_SHORTS];
@@ -412,10 +448,17 @@ __global__ __launch_bounds__(256) void reconstruct_kernel(KsGeom g, int qp, cons
     }
     __syncthreads();
     const int qpc = chroma_qp(qp);
-    code_region<32, MREF>(g, 0, qp, rx * 4, ry * 4, blk, tu_log2, Mf, Mt, X, T, P, nzcnt, src_y, ref_y, ref1_y, lvl_y, rec_y, tid, xr.y, sdh, LV, DU, CF, lastcg, dec_k, rdo_lam2k, tu_inter != 0);
+    code_region<32, MREF>(g, 0, qp, rx * 4, ry * 4, blk, tu_log2, Mf, Mt, X, T, P, nzcnt, src_y, ref_y, ref1_y, lvl_y, rec_y, tid, xr.y, sdh, LV, DU, CF, lastcg, dec_k, rdo_lam2k, tu_inter != 0 && rq_mode != 2, rq_mode, coef_y);
     if (tid < 16 && blk[tid].log2_cu) {
         const int t8 = 1 << tu_log2[tid], tb = ((tid >> 2) & ~(t8 - 1)) * 4 + ((tid & 3) & ~(t8 - 1));
         if (nzcnt[tb]) cbf[tid] |= 1;
+    }
+    if (rq_mode == 2) {                                            // cfg.rdoq, back half: luma only - the chroma bits of the front half stay
+        if (tid < 16 && blk[tid].log2_cu && blk[tid].pred_mode != 2) {
+            const int bx = rx * 4 + (tid & 3), by = ry * 4 + (tid >> 2);
+            cu8[(long)by * g.w8 + bx].cbf = (uint8_t)((blk[tid].cbf & 6) | (cbf[tid] & 1));
+        }
+        return;
     }
     __syncthreads();
     code_region<16, MREF>(g, 1, qpc, rx * 4, ry * 4, blk, tu_log2, Mf, Mt, X, T, P, nzcnt, src_u, ref_u, ref1_u, lvl_u, rec_u, tid, xr.u, sdh, LV, DU, CF, lastcg, 0, 0ll);      // chroma: no decimation, no group pruning (2 % of the bytes for 2 dB of chroma PSNR: the oracle's code_tu)
@@ -434,13 +477,128 @@ __global__ __launch_bounds__(256) void reconstruct_kernel(KsGeom g, int qp, cons
     }
 }
 
+// ------------------------------------------------------------------ cfg.rdoq: the reference's rdoQuant between the two halves of the reconstruction
+int ks265_rdoq_listed(ks265_ctx *ctx, const ks265_rdoq_tu *dev_tus, const int *dev_n, int max_n, int16_t *dev_lvl, const int16_t *dev_coef, const int32_t *dev_tables, uint16_t *dev_sigmask,
+                      int32_t *dev_out, uint64_t *dev_hidden);      // rdoq_ops.hip
+// One wave per 8x8 block position; the wave of a luma transform block's first block (inter CU: TU = min(CU, 32), four TUs for a CU in two partitions / with split transform units)
+// packs the block's levels and coefficients (planes, row pitch W) into contiguous N x N arrays, builds what rdoQuant is handed - per 4x4 group in scan order the mask of the
+// positions the quantiser left non-zero (bit 15 - k = scan position k: scanSigFlags enc@0x4a9b00 lineage, the oracle's kso_rdoq_scan_flags) and the last significant scan position -
+// and appends the descriptor.  A block without a level is not listed (its plane is zero already).  ctr[0] = blocks listed, ctr[1] = packed elements.
+__global__ __launch_bounds__(256) void rdoq_prep_kernel(KsGeom g, int qp, const int8_t *qp_map, int sdh, const ks265_cu8 *cu8, const int16_t *lvl, const int16_t *coef, int16_t *pack_lvl,
+                                                        int16_t *pack_coef, ks265_rdoq_tu *tus, int *pos, int *ctr, unsigned short *sigmask, const long long *lam)
+{
+    __shared__ unsigned mask_s[4][64];
+    __shared__ int last_s[4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, b = blockIdx.x * 4 + wave;
+    if (b >= g.w8 * g.h8) return;                                   // (whole waves leave: no work-group barrier below)
+    const int bx = b % g.w8, by = b / g.w8;
+    const ks265_cu8 c = cu8[b];
+    if (c.log2_cu == 0 || c.pred_mode == 2) return;
+    const int tl = min((int)(c.log2_cu & 15) - 3 - (c.log2_cu >> 4 ? 1 : 0), 2), t8 = 1 << tl;
+    if ((bx & (t8 - 1)) || (by & (t8 - 1))) return;
+    const int n = 8 * t8, log2n = 3 + tl, w = n >> 2, NN = n * n, x0 = bx * 8, y0 = by * 8;
+    mask_s[wave][lane] = 0;
+    if (lane == 0) last_s[wave] = -1;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // lane = (row chunk): every lane walks its share of the NN elements in rows of four
+    for (int e = lane * 4; e < NN; e += 256) {
+        const int y = e / n, x = e - y * n;
+        const uint2 lw = *(const uint2 *)(lvl + (long)(y0 + y) * g.W + x0 + x);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned wd = i < 2 ? lw.x : lw.y;
+            const int l = (int)(short)((i & 1) ? (wd >> 16) : (wd & 0xFFFFu));
+            if (l) {
+                const int xx = x + i, gidx = sbh_group_order(0, w, xx >> 2, y >> 2);
+                const int k = (int)((0xfda6eb73c8419520ull >> (4 * ((y & 3) * 4 + (xx & 3)))) & 15ull);        // scan position of (x, y) inside its group (up-right diagonal)
+                atomicOr(&mask_s[wave][gidx], 1u << (15 - k));
+                atomicMax(&last_s[wave], gidx * 16 + k);
+            }
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int last = last_s[wave];
+    if (last < 0) return;
+    int ti = 0, off = 0;
+    if (lane == 0) { ti = atomicAdd(&ctr[0], 1); off = atomicAdd(&ctr[1], NN); }
+    ti = __builtin_amdgcn_readfirstlane(ti); off = __builtin_amdgcn_readfirstlane(off);
+    for (int e = lane * 4; e < NN; e += 256) {
+        const int y = e / n, x = e - y * n;
+        *(uint2 *)(pack_lvl + off + e) = *(const uint2 *)(lvl + (long)(y0 + y) * g.W + x0 + x);
+        *(uint2 *)(pack_coef + off + e) = *(const uint2 *)(coef + (long)(y0 + y) * g.W + x0 + x);
+    }
+    sigmask[(long)ti * 64 + lane] = (unsigned short)mask_s[wave][lane];
+    if (lane == 0) {
+        const int q = qp_map ? qp_map[(by >> 3) * g.ctu_cols + (bx >> 3)] : qp;
+        ks265_rdoq_tu d;
+        d.off = off; d.tab = (log2n - 2) * 2; d.dq = kInvQuantScales[q % 6] << (q / 6); d.last_pos = last; d.lam = lam[q]; d.lam_sdh = lam[52 + q];
+        d.log2 = (int8_t)log2n; d.scan_idx = 0; d.comp = 0; d.per = (int8_t)(q / 6); d.tu5 = 1; d.flag_a4c0 = 1; d.sdh = (int8_t)(sdh != 0); d.rsv = 0;
+        tus[ti] = d;
+        pos[2 * ti] = x0; pos[2 * ti + 1] = y0;
+    }
+}
+// the levels rdoQuant decided, back to the level plane (one wave per listed block)
+__global__ __launch_bounds__(256) void rdoq_unpack_kernel(KsGeom g, const ks265_rdoq_tu *tus, const int *pos, const int *ctr, const int16_t *pack_lvl, int16_t *lvl)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, ti = blockIdx.x * 4 + wave;
+    if (ti >= ctr[0]) return;
+    const ks265_rdoq_tu d = tus[ti];
+    const int n = 1 << d.log2, NN = n * n, x0 = pos[2 * ti], y0 = pos[2 * ti + 1];
+    for (int e = lane * 4; e < NN; e += 256) {
+        const int y = e / n, x = e - y * n;
+        *(uint2 *)(lvl + (long)(y0 + y) * g.W + x0 + x) = *(const uint2 *)(pack_lvl + d.off + e);
+    }
+}
+
+/* cfg.rdoq: the workspace (first call) and, per picture, the bit tables + lambdas the host built: tables = [4 sizes][luma, chroma][180] words of estBitRdoq enc@0x46a8a0 (the
+ * host keeps them adaptive: from the context states the slice writer ended the previous picture of the kind with), lam / lam_sdh = [52] by QP (rdoQuant's two lambdas) */
+extern "C" int ks265_frame_set_rdoq(ks265_frame *f, const int32_t *host_tables, const int64_t *host_lam, const int64_t *host_lam_sdh)
+{
+    KS_FRAME_CHECK(f);
+    if (!host_tables || !host_lam || !host_lam_sdh) { f->rq_ready = false; return host_tables || host_lam || host_lam_sdh ? KS265_POINTER : KS265_OK; }     // all null: back to the default seam
+    if (f->ctx->capturing) return KS265_NOTSUPPORTED;
+    const size_t npx = (size_t)f->g.W * f->g.H, nb = (size_t)f->g.w8 * f->g.h8;
+    if (!f->rq_coef) {
+        hipError_t e = hipSuccess;
+        auto al = [&](void **p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes); };
+        al((void **)&f->rq_coef, npx * 2); al((void **)&f->rq_pack_lvl, npx * 2); al((void **)&f->rq_pack_coef, npx * 2); al((void **)&f->rq_tus, nb * sizeof(ks265_rdoq_tu));
+        al((void **)&f->rq_pos, nb * 8); al((void **)&f->rq_ctr, 16); al((void **)&f->rq_out, nb * 8); al((void **)&f->rq_tab, 8 * 180 * 4); al((void **)&f->rq_lam, 104 * 8);
+        al((void **)&f->rq_sigmask, nb * 64 * 2); al((void **)&f->rq_hidden, nb * 8);
+        if (e != hipSuccess) return ks265_hip(f->ctx, e);
+    }
+    int r = ks265_hip(f->ctx, hipMemcpyAsync(f->rq_tab, host_tables, 8 * 180 * 4, hipMemcpyHostToDevice, f->ctx->stream));
+    if (!r) r = ks265_hip(f->ctx, hipMemcpyAsync(f->rq_lam, host_lam, 52 * 8, hipMemcpyHostToDevice, f->ctx->stream));
+    if (!r) r = ks265_hip(f->ctx, hipMemcpyAsync(f->rq_lam + 52, host_lam_sdh, 52 * 8, hipMemcpyHostToDevice, f->ctx->stream));
+    f->rq_ready = !r;
+    return r;
+}
+
+// every reconstruction entry point ends here: `launch(rq_mode)` enqueues reconstruct_kernel in that mode
+template <typename L>
+static int reconstruct_sequence(ks265_frame *f, ks265_cu8 *cu8, int16_t *lvl_y, L launch)
+{
+    if (!f->rq_ready) { launch(0); return ks265_check_launch(f->ctx); }
+    int r = ks265_hip(f->ctx, hipMemsetAsync(f->rq_ctr, 0, 16, f->ctx->stream));
+    if (r) return r;
+    launch(1);
+    const int nb = f->g.w8 * f->g.h8;
+    hipLaunchKernelGGL(rdoq_prep_kernel, dim3((nb + 3) / 4), dim3(256), 0, f->ctx->stream, f->g, f->cfg.qp, f->qp_map, f->cfg.sdh, cu8, lvl_y, f->rq_coef, f->rq_pack_lvl, f->rq_pack_coef,
+                       f->rq_tus, f->rq_pos, f->rq_ctr, f->rq_sigmask, f->rq_lam);
+    if ((r = ks265_check_launch(f->ctx))) return r;
+    if ((r = ks265_rdoq_listed(f->ctx, f->rq_tus, f->rq_ctr, nb, f->rq_pack_lvl, f->rq_pack_coef, f->rq_tab, f->rq_sigmask, f->rq_out, (uint64_t *)f->rq_hidden))) return r;
+    hipLaunchKernelGGL(rdoq_unpack_kernel, dim3((nb + 3) / 4), dim3(256), 0, f->ctx->stream, f->g, f->rq_tus, f->rq_pos, f->rq_ctr, f->rq_pack_lvl, lvl_y);
+    launch(2);
+    return ks265_check_launch(f->ctx);
+}
+
 static int launch_reconstruct(ks265_frame *f, ks265_pic src, ks265_pic ref0, ks265_pic ref1, ks265_cu8 *cu8,
                               int16_t *lvl_y, int16_t *lvl_u, int16_t *lvl_v, ks265_pic recon)
 {
     dim3 grid(((f->g.W + 31) / 32) * ((f->g.H + 31) / 32));
+    return reconstruct_sequence(f, cu8, lvl_y, [&](int rq_mode) {
     hipLaunchKernelGGL(reconstruct_kernel<false>, grid, dim3(256), 0, f->ctx->stream, f->g, f->cfg.qp, src.y, src.u, src.v, ref0.y, ref0.u, ref0.v, ref1.y,
-                       ref1.u, ref1.v, cu8, lvl_y, lvl_u, lvl_v, recon.y, recon.u, recon.v, f->mats, KsRefExtra{}, f->cfg.sdh, f->cfg.decimate, ks_rdo_lam2k(f), f->qp_map, f->cfg.tu_inter);
-    return ks265_check_launch(f->ctx);
+                       ref1.u, ref1.v, cu8, lvl_y, lvl_u, lvl_v, recon.y, recon.u, recon.v, f->mats, KsRefExtra{}, f->cfg.sdh, f->cfg.decimate, ks_rdo_lam2k(f), f->qp_map, f->cfg.tu_inter, rq_mode, f->rq_coef);
+    });
 }
 
 // multi-reference P pictures (-ref / -ref0): list 0 holds nref <= 4 pictures, the CU's picture is refs[inter_dir >> 4]
@@ -456,10 +614,11 @@ extern "C" int ks265_reconstruct_mref(ks265_frame *f, ks265_pic src, int nref, c
         xr.y.r[r - 1] = refs[r].y; xr.u.r[r - 1] = refs[r].u; xr.v.r[r - 1] = refs[r].v;
     }
     dim3 grid(((f->g.W + 31) / 32) * ((f->g.H + 31) / 32));
+    return reconstruct_sequence(f, cu8, lvl_y, [&](int rq_mode) {
     hipLaunchKernelGGL(reconstruct_kernel<true>, grid, dim3(256), 0, f->ctx->stream, f->g, f->cfg.qp, src.y, src.u, src.v, refs[0].y, refs[0].u, refs[0].v,
                        (const uint8_t *)nullptr, (const uint8_t *)nullptr, (const uint8_t *)nullptr, cu8, lvl_y, lvl_u, lvl_v, recon.y, recon.u,
-                       recon.v, f->mats, xr, f->cfg.sdh, f->cfg.decimate, ks_rdo_lam2k(f), f->qp_map, f->cfg.tu_inter);
-    return ks265_check_launch(f->ctx);
+                       recon.v, f->mats, xr, f->cfg.sdh, f->cfg.decimate, ks_rdo_lam2k(f), f->qp_map, f->cfg.tu_inter, rq_mode, f->rq_coef);
+    });
 }
 
 extern "C" int ks265_reconstruct(ks265_frame *f, ks265_pic src, ks265_pic ref, ks265_cu8 *cu8, int16_t *lvl_y, int16_t *lvl_u,
@@ -483,9 +642,10 @@ extern "C" int ks265_reconstruct_b(ks265_frame *f, ks265_pic src, ks265_pic ref0
         }
         const ks265_pic a0 = f->mr_pic[0][0], b0 = f->mr_pic[1][0];
         dim3 grid(((f->g.W + 31) / 32) * ((f->g.H + 31) / 32));
+        return reconstruct_sequence(f, cu8, lvl_y, [&](int rq_mode) {
         hipLaunchKernelGGL(reconstruct_kernel<true>, grid, dim3(256), 0, f->ctx->stream, f->g, f->cfg.qp, src.y, src.u, src.v, a0.y, a0.u, a0.v, b0.y, b0.u, b0.v, cu8, lvl_y, lvl_u, lvl_v,
-                           recon.y, recon.u, recon.v, f->mats, xr, f->cfg.sdh, f->cfg.decimate, ks_rdo_lam2k(f), f->qp_map, f->cfg.tu_inter);
-        return ks265_check_launch(f->ctx);
+                           recon.y, recon.u, recon.v, f->mats, xr, f->cfg.sdh, f->cfg.decimate, ks_rdo_lam2k(f), f->qp_map, f->cfg.tu_inter, rq_mode, f->rq_coef);
+        });
     }
     return launch_reconstruct(f, src, ref0, ref1, cu8, lvl_y, lvl_u, lvl_v, recon);
 }

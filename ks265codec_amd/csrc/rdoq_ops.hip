@@ -63,10 +63,12 @@ __device__ __forceinline__ int remain_bits_thr(unsigned sym, int r, unsigned thr
     return extra + remain_bits_cap(sym, r);
 }
 
-__global__ __launch_bounds__(64) void rdoq_kernel(const ks265_rdoq_tu *tus, int n, short *lvl_g, const short *coef_g, const int *tabs, unsigned short *sigmask_g, int *out, unsigned long long *hidden_g)
+__global__ __launch_bounds__(64) void rdoq_kernel(const ks265_rdoq_tu *tus, int n, short *lvl_g, const short *coef_g, const int *tabs, unsigned short *sigmask_g, int *out, unsigned long long *hidden_g,
+                                                  const int *n_dev /* the pixel path (cfg.rdoq): the number of blocks is on the device, the grid is its upper bound */)
 {
     __shared__ RdoqLds L;
     const int lane = threadIdx.x, ti = blockIdx.x;
+    if (n_dev) n = *n_dev;
     if (ti >= n) return;
     const ks265_rdoq_tu d = tus[ti];
     const int log2 = d.log2, N = 1 << log2, NN = N * N, w = N >> 2, ncg = w * w, scan_idx = d.scan_idx, luma = d.comp == 0;
@@ -385,6 +387,17 @@ extern "C" int ks265_rdoq_batch(ks265_ctx *ctx, const ks265_rdoq_tu *dev_tus, in
     if (n <= 0) return n == 0 ? KS265_OK : KS265_NOTSUPPORTED;
     ks_use_device(ctx);
     hipLaunchKernelGGL(rdoq_kernel, dim3((unsigned)n), dim3(64), 0, ctx->stream, dev_tus, n, (short *)dev_lvl, (const short *)dev_coef, (const int *)dev_tables, (unsigned short *)dev_sigmask,
-                       (int *)dev_out, (unsigned long long *)dev_hidden);
+                       (int *)dev_out, (unsigned long long *)dev_hidden, (const int *)nullptr);
+    return ks265_check_launch(ctx);
+}
+
+// the pixel path's form (frame_recon.hip, cfg.rdoq): the transform blocks were listed on the device - one work-group per list slot up to max_n, those past *dev_n leave at once
+int ks265_rdoq_listed(ks265_ctx *ctx, const ks265_rdoq_tu *dev_tus, const int *dev_n, int max_n, int16_t *dev_lvl, const int16_t *dev_coef, const int32_t *dev_tables, uint16_t *dev_sigmask,
+                      int32_t *dev_out, uint64_t *dev_hidden)
+{
+    if (!ctx || !dev_tus || !dev_n || !dev_lvl || !dev_coef || !dev_tables || !dev_sigmask || !dev_out || !dev_hidden) return KS265_POINTER;
+    if (max_n <= 0) return KS265_OK;
+    hipLaunchKernelGGL(rdoq_kernel, dim3((unsigned)max_n), dim3(64), 0, ctx->stream, dev_tus, max_n, (short *)dev_lvl, (const short *)dev_coef, (const int *)dev_tables, (unsigned short *)dev_sigmask,
+                       (int *)dev_out, (unsigned long long *)dev_hidden, dev_n);
     return ks265_check_launch(ctx);
 }

@@ -155,7 +155,10 @@ int QY265ConfigParse(QY265EncConfig *c, const char *name, const char *value)
     INTP("wdt", picWidth, 8, 8192) INTP("hgt", picHeight, 8, 8192) INTP("bframes", bframes, -1, 15) INTP("rc", rc, 0, 5) INTP("br", bitrateInkbps, 1, 1000000)
     INTP("qp", qp, 0, 51) INTP("crf", crf, 0, 51) INTP("iper", iIntraPeriod, -1, 100000) INTP("qpmin", qpmin, 0, 51) INTP("qpmax", qpmax, 0, 51)
     INTP("threads", threads, 0, 1024) INTP("psnr", calcPsnr, 0, 2) INTP("ssim", calcSsim, 0, 2) INTP("log", logLevel, -1, 3) INTP("lookahead", lookahead, -1, 250)
-    INTP("rdoq", rdoq, 0, 1) INTP("me", me, 0, 4) INTP("part", part, 0, 1) INTP("do64", do64, 0, 1) INTP("intertu", tuInter, -1, 3) INTP("intratu", tuIntra, -1, 3)
+    /* rdoq (qy265enc.h:129): every preset from `fast` up resolves to 1, which this build runs as its own seam (dead zone, coefficient-group pruning, sign-data hiding); asked for BY
+     * NAME, rdoq 1 is stored as 2 = the reference's rdoQuant between the two halves of the reconstruction (ks265_frame_set_rdoq), so that the presets' streams stay what they are */
+    if (!strcmp(name, "rdoq")) { if (!num_ok || iv < 0 || iv > 1) return QY265_PARAM_BAD_VALUE; c->rdoq = iv ? 2 : 0; return 0; }
+    INTP("me", me, 0, 4) INTP("part", part, 0, 1) INTP("do64", do64, 0, 1) INTP("intertu", tuInter, -1, 3) INTP("intratu", tuIntra, -1, 3)
     INTP("sis", smooth, 0, 1) INTP("ts", transskip, 0, 1) INTP("subme", subme, 0, 2) INTP("merange", searchrange, 1, 512) INTP("ref", refnum, 1, 16) INTP("ref0", ref0, 1, 16)
     INTP("sao", sao, 0, 4) INTP("wpp", enWavefront, 0, 1) INTP("fpp", enFrameParallel, 0, 1) INTP("vbv-maxrate", vbv_max_rate, 0, 10000000)
     INTP("aq", iAqMode, 0, 3)                                  /* the reference's hidden -aq (iAqMode, qy265enc.h:145) */
@@ -189,6 +192,7 @@ typedef struct Job {
     uint8_t *lvlbuf; uint64_t *dirty;                     /* the level planes expanded from it (plain memory) and the lines the previous picture in this slot set */
     ks265_cu8 *cu8; int16_t *lvl[3]; ks265_sao_param *sao; uint64_t *sse;      /* cu8 / sao / sse point into cmp, lvl into lvlbuf */
     int ev_err;
+    uint8_t fctx[192]; int fctx_ok; int32_t *rq_host;     /* -rdoq 1: the context states the slice ended with (ks265_slice_final_contexts); the tables + lambdas the picture was quantised with (pinned) */
     long sub_seq;                                         /* this picture's number in submission order (the dispatcher's sticky device error ends at a key picture submitted after the error was seen) */
     void *wpp; ks265_slice_in sin; int started, nrows, next_row, rows_done;   /* row-wise writing of the slice (ks265_wpp_*) */
     int8_t *qp_map;                                       /* -aq: the QP of every CTU this picture was coded with (pinned; NULL without) */
@@ -378,6 +382,11 @@ typedef struct Enc {
      * the sums are updated under mu in coding order (rc_account) */
 #define RC_LAG 16
 #define RC_HIST 512
+    /* -rdoq 1 (the reference's rdoQuant in the pixel path, round 6): its bit tables follow the stream - a P / B picture is quantised with the tables built from the context states of
+     * the latest picture of its kind that was coded at least RC_LAG + 1 pictures earlier (rq_hist: tables per accounted picture, like rc_hist: what a picture is coded with does
+     * not depend on how fast the writers were), else from the initial states of its slice type at its QP; Job::rq_host: the picture's tables + lambdas, pinned */
+#define RQ_HIST 64
+    int rdoq_on; int32_t *rq_hist; char rq_hist_kind[RQ_HIST]; int64_t rq_lam[104]; long rq_gop_seq;   /* rq_gop_seq: the submission number of the current GOP's key picture - tables never cross a key picture (closed GOPs: the stream does not depend on how GOPs are dealt to lanes) */
     double rc_sum_norm, rc_hist[RC_HIST]; long rc_acc_seq, rc_sub; int rc_acc_idx; int rc_qp_delta;
     double rc_sum_budget, rc_bhist[RC_HIST], rc_sum_real, rc_rhist[RC_HIST];   /* the budget and the bits really produced, summed picture by picture like rc_sum_norm */
 } Enc;
@@ -560,6 +569,7 @@ static void *worker(void *arg)
                 pthread_mutex_unlock(&e->mu);
                 const double t1 = now_ms();
                 const long n = ks265_wpp_finish(j->wpp, j->nal, j->nal_cap);
+                j->fctx_ok = e->rdoq_on && n >= 0 && ks265_slice_final_contexts(&e->scfg, j->wpp, j->fctx, (int)sizeof j->fctx, NULL) > 0;
                 memcpy(j->dirty, j->cmp + e->cmp_off[5], e->cmp_off[6] - e->cmp_off[5]);      /* what the next picture in this slot has to clear */
                 pthread_mutex_lock(&e->mu);
                 j->t_write_ms += now_ms() - t1;
@@ -582,6 +592,11 @@ static void rc_account(Enc *e)
     while (e->rc_acc_seq < e->rc_sub) {
         Job *j = &e->jobs[e->rc_acc_idx];
         if (!j->used || !j->done) break;
+        if (e->rdoq_on) {                                         /* the tables this picture's final states give, for the pictures of its kind RC_LAG and more pictures on */
+            const int slot = (int)(e->rc_acc_seq % RQ_HIST);
+            e->rq_hist_kind[slot] = 0;
+            if (j->fctx_ok && !j->error && ks265_rdoq_tables(&e->scfg, j->fctx, 0, 0, e->rq_hist + (size_t)slot * 1440) == 0) e->rq_hist_kind[slot] = (char)j->kind;
+        }
         e->rc_sum_norm += (double)(j->nal_len > 0 ? j->nal_len : 0) * 8.0 * exp2((double)j->rc_delta / 6.0);
         e->rc_hist[e->rc_acc_seq % RC_HIST] = e->rc_sum_norm;
         e->rc_sum_budget += j->rc_budget; e->rc_bhist[e->rc_acc_seq % RC_HIST] = e->rc_sum_budget;      /* per picture at the bitrate it was handed in with: a later
@@ -850,6 +865,21 @@ static int submit(Enc *e, Input *in, int kind, int poc, int qp, const int *l0, i
         if (!r) r = ks265_event_record(cx, e->ev_loaded[k]);
     }
     if (!r) r = ks265_frame_set_qp(fr, qp, kind == 'I' ? kLambdaQ4[qp] : kLambdaInterQ4[qp]);
+    if (e->rdoq_on && kind == 'I') e->rq_gop_seq = e->rc_sub;
+    if (!r && e->rdoq_on && kind != 'I') {
+        /* -rdoq 1: wait until every picture up to RC_LAG before this one is accounted (as the rate controller does), then the latest tables of this picture's kind among them */
+        int32_t *tb = j->rq_host;
+        pthread_mutex_lock(&e->mu);
+        const long s0 = e->rc_sub, need = s0 - RC_LAG;
+        for (;;) { rc_account(e); if (e->rc_acc_seq >= need || e->quit) break; pthread_cond_wait(&e->cv_done, &e->mu); }
+        int found = 0;
+        for (long q = need - 1; q >= 0 && q > e->rq_gop_seq && q >= need - (RQ_HIST - RC_LAG - 8) && !found; --q)
+            if (e->rq_hist_kind[q % RQ_HIST] == (char)kind) { memcpy(tb, e->rq_hist + (size_t)(q % RQ_HIST) * 1440, 1440 * sizeof(int32_t)); found = 1; }
+        pthread_mutex_unlock(&e->mu);
+        if (!found) r = ks265_rdoq_tables(&e->scfg, NULL, kind == 'P' ? KS265_SLICE_P : KS265_SLICE_B, qp, tb) ? KS265_FAIL : 0;
+        memcpy(tb + 1440, e->rq_lam, sizeof e->rq_lam);
+        if (!r) r = ks265_frame_set_rdoq(fr, tb, (const int64_t *)(tb + 1440), (const int64_t *)(tb + 1440) + 52);
+    }
     if (!r && e->ct_on) {
         /* cuTree: the picture's block offsets were finished on the lookahead's stream when its mini-GOP was scheduled (ct_run): one QP per CTU around this picture's QP */
         ks265_ctx *ca = split ? e->ctx_in : cx;
@@ -1321,7 +1351,7 @@ static void lane_close(Enc *e, int report)
         }
         for (int i = 0; i < MAX_JOBS; ++i) {
             Job *j = &e->jobs[i];
-            ks265_host_free(e->ctx, j->cmp); ks265_host_free(e->ctx, j->recon); ks265_host_free(e->ctx, j->qp_map); free(j->lvlbuf); free(j->dirty);
+            ks265_host_free(e->ctx, j->cmp); ks265_host_free(e->ctx, j->recon); ks265_host_free(e->ctx, j->qp_map); ks265_host_free(e->ctx, j->rq_host); free(j->lvlbuf); free(j->dirty);
             if (j->ev) ks265_event_destroy(e->ctx, j->ev);
             free(j->nal);
         }
@@ -1376,7 +1406,7 @@ static void lane_close(Enc *e, int report)
         ks265_destroy(e->ctx);
     } else { if (e->ctx_la) ks265_destroy(e->ctx_la); if (e->ctx_upl) ks265_destroy(e->ctx_upl); }                   /* created first (lane_open), before the main context failed: nothing else of the lookahead exists yet */
     for (int i = 0; i < MAX_JOBS; ++i) free(e->jobs[i].wpp);
-    free(e->hdr); free(e->outbuf); free(e->md5_ring); free(e->md5_have);
+    free(e->hdr); free(e->outbuf); free(e->md5_ring); free(e->md5_have); free(e->rq_hist);
     pthread_mutex_destroy(&e->la_mu);
     pthread_mutex_destroy(&e->mu); pthread_cond_destroy(&e->cv_work); pthread_cond_destroy(&e->cv_done); pthread_cond_destroy(&e->cv_disp); pthread_cond_destroy(&e->cv_sched); pthread_cond_destroy(&e->cv_sched_done);
     free(e);
@@ -1421,7 +1451,9 @@ static Enc *lane_open(QY265EncConfig *cfg, int device, int multi, int *err)
     e->nthreads = cfg->threads > 0 ? cfg->threads : (int)(ncpu > 0 ? ncpu : 4);
     if (e->nthreads > 64) e->nthreads = 64;
 
-    if (cfg->rdoq || cfg->transskip) logf_(1, e->log_level, "ks265enc: rdoq / transskip are accepted but not implemented by the pixel path (rdoQuant exists as a device operator, ks265_rdoq_batch; at the seam it buys <= 1 %% with adaptive tables: DESIGN.md 9)\n");
+    e->rdoq_on = cfg->rdoq == 2;                                      /* asked for by name (QY265ConfigParse); the presets' rdoq 1 = this build's seam */
+    if (e->rdoq_on) logf_(2, e->log_level, "ks265enc: -rdoq 1: the luma transform blocks of inter CUs go through the reference's rdoQuant (bit tables from the context states of the stream, %d pictures behind)\n", RC_LAG + 1);
+    if (cfg->transskip) logf_(1, e->log_level, "ks265enc: transskip is accepted but not implemented by the pixel path\n");
     if (cfg->tuInter > 1) logf_(1, e->log_level, "ks265enc: -intertu %d runs as -intertu 1 (the residual quadtree of inter CUs one level deep)\n", cfg->tuInter);
     if (cfg->tuIntra > 0) logf_(2, e->log_level, "ks265enc: -intratu is accepted but not implemented (intra CUs carry one transform unit)\n");
     if (cfg->iAqMode > 1) logf_(1, e->log_level, "ks265enc: -aq %d runs as -aq 1 (block variance, the mode of the reference's calcFrameAdaptQuant)\n", cfg->iAqMode);
@@ -1545,6 +1577,13 @@ static Enc *lane_open(QY265EncConfig *cfg, int device, int multi, int *err)
     e->key_overlap = getenv("KS265_NO_KEY_OVERLAP") ? 0 : 1;
     e->use_graph = getenv("KS265_GRAPH") ? 1 : 0;                     /* opt-in since round 4: launch by launch is faster on this runtime (843 against 817 pictures/s, 2160p IPPP) and the split pipeline needs the launches apart */
     if (e->qmap_on) e->use_graph = 0;                                    /* (a captured picture would replay one map) */
+    if (e->rdoq_on) {
+        e->use_graph = 0;                                                /* (a captured picture would replay one set of tables) */
+        e->rq_hist = (int32_t *)calloc((size_t)RQ_HIST * 1440, sizeof(int32_t));
+        if (!e->rq_hist) r = KS265_OUTOFMEMORY;
+        /* rdoQuant's two lambdas by QP (luma weights 256 / 256 = -rdoql / -rdoqls of the reference): (int64)(weight x 0.85 x 2^((qp - 12) / 3) + 0.5) */
+        for (int q = 0; q < 52; ++q) { const double lam = 0.85 * pow(2.0, (q - 12) / 3.0); e->rq_lam[q] = e->rq_lam[52 + q] = (int64_t)(256 * lam + 0.5); }
+    }
     if (e->use_graph) e->split = 0;
     if (e->key_overlap) {
         if (!r) r = ks265_create_prio(&e->ctx_key, dev_id, getenv("KS265_KEY_PRIO") ? atoi(getenv("KS265_KEY_PRIO")) : 1);   /* the key picture's wavefront must run underneath the P pictures, not behind them */
@@ -1616,6 +1655,7 @@ static Enc *lane_open(QY265EncConfig *cfg, int device, int multi, int *err)
             j->lvl[0] = (int16_t *)j->lvlbuf; j->lvl[1] = (int16_t *)(j->lvlbuf + npx * 2); j->lvl[2] = (int16_t *)(j->lvlbuf + npx * 2 + npx / 2);
         }
         if (!r && e->qmap_on) r = ks265_host_malloc(e->ctx, (void **)&j->qp_map, (size_t)e->geom.ctu_cols * e->geom.ctu_rows);
+        if (!r && e->rdoq_on) r = ks265_host_malloc(e->ctx, (void **)&j->rq_host, 1440 * sizeof(int32_t) + 104 * sizeof(int64_t));
         if (!r) r = ks265_event_create(e->ctx, &j->ev);
         j->nal_cap = npx * 2 + 65536;
         j->nal = (uint8_t *)malloc(j->nal_cap);

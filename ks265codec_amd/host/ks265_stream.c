@@ -1267,6 +1267,68 @@ int ks265_slice_final_contexts(const ks265_stream_cfg *cfg, const void *scratch,
     return CX_COUNT;
 }
 
+/* ---- the bit tables of the reference's rate-distortion optimised quantisation (-rdoq 1; round 6).  rdoQuant enc@0x4aac50 prices its decisions with the 180-word tables
+ * estBitRdoq enc@0x46a8a0 builds from the entropy coder's context states (TEstBitsSbac: [0..3] coded_sub_block_flag [2][2]; [4..45] / [46..87] sig_coeff_flag = 0 / 1 per context;
+ * [88..97] / [98..107] last x / y prefix; [108..139] greater1 [16][2]; [156..163] greater2 [4][2]; [168..177] cbf [5][2]; [178..179] rqt_root_cbf; bits x 2^15).  The states are
+ * gathered in the order that function reads them (cbf at 0x0d, + 5 chroma; group flags at 0x1d, + 2; sig flags at 0x21 luma / 0x3c chroma; last x / y at 0x4b / 0x69; greater1 at
+ * 0x87 luma / 0x97 chroma; greater2 at 0x9f / 0xa3; root cbf at 0xaa - entries this writer has no state for read state 0, as they do when the function is fed this writer's
+ * states in the tests' mirror), the entropy values are the standard's fractional-bit table of the 64 probability states (kEntropyBits: bits x 2^15 of the less probable / more
+ * probable symbol per state).  states = what ks265_slice_final_contexts returned for a slice (the tables then follow the stream), or NULL = the initial states of a slice of
+ * `slice_type` at `qp`.  tables: [4 sizes 4 .. 32][luma, chroma][180] words, all written (words the function leaves alone are 0). */
+static const int32_t kEntropyBits[128] = {
+    0x7b23, 0x85f9, 0x74a0, 0x8cbc, 0x6ee4, 0x9354, 0x67f4, 0x9c1b, 0x60b0, 0xa62a, 0x5a9c, 0xaf5b, 0x548d, 0xb955, 0x4f56, 0xc2a9, 0x4a87, 0xcbf7, 0x45d6, 0xd5c3, 0x4144, 0xe01b, 0x3d88, 0xe937,
+    0x39e0, 0xf2cd, 0x3663, 0xfc9e, 0x3347, 0x10600, 0x3050, 0x10f95, 0x2d4d, 0x11a02, 0x2ad3, 0x12333, 0x286e, 0x12cad, 0x2604, 0x136df, 0x2425, 0x13f48, 0x21f4, 0x149c4, 0x203e, 0x1527b,
+    0x1e4d, 0x15d00, 0x1c99, 0x166de, 0x1b18, 0x17017, 0x19a5, 0x17988, 0x1841, 0x18327, 0x16df, 0x18d50, 0x15d9, 0x19547, 0x147c, 0x1a083, 0x138e, 0x1a8a3, 0x1251, 0x1b418, 0x1166, 0x1bd27,
+    0x1068, 0x1c77b, 0xf7f, 0x1d18e, 0xeda, 0x1d91a, 0xe19, 0x1e254, 0xd4f, 0x1ec9a, 0xc90, 0x1f6e0, 0xc01, 0x1fef8, 0xb5f, 0x208b1, 0xab6, 0x21362, 0xa15, 0x21e46, 0x988, 0x2285d, 0x934,
+    0x22ea8, 0x8a8, 0x239b2, 0x81d, 0x24577, 0x7c9, 0x24ce6, 0x763, 0x25663, 0x710, 0x25e8f, 0x6a0, 0x26a26, 0x672, 0x26f23, 0x5e8, 0x27ef8, 0x5ba, 0x284b5, 0x55e, 0x29057, 0x50c, 0x29bab,
+    0x4c1, 0x2a674, 0x4a7, 0x2aa5e, 0x46f, 0x2b32f, 0x41f, 0x2c0ad, 0x3e7, 0x2ca8d, 0x3ba, 0x2d323, 0x10c, 0x3bfbb};
+int ks265_rdoq_tables(const ks265_stream_cfg *cfg, const uint8_t *states, int slice_type, int qp, int32_t *tables)
+{
+    if (!cfg || !tables) return KS265_POINTER;
+    uint8_t st[CX_COUNT];
+    if (states) memcpy(st, states, CX_COUNT);
+    else {
+        Cabac tmp; uint8_t dummy[4];
+        cb_init(&tmp, dummy, sizeof dummy, slice_type == KS265_SLICE_I ? 0 : slice_type == KS265_SLICE_P ? 1 : 2, qp);
+        memcpy(st, tmp.state, CX_COUNT);
+    }
+    uint8_t c[256];
+    memset(c, 0, sizeof c);
+    memcpy(c + 0x0d, st + CX_CBF_LUMA, 2); memcpy(c + 0x12, st + CX_CBF_CHROMA, 4);
+    memcpy(c + 0x1d, st + CX_CSBF, 4);
+    memcpy(c + 0x21, st + CX_SIG, 42);
+    memcpy(c + 0x4b, st + CX_LAST_X, 18); memcpy(c + 0x69, st + CX_LAST_Y, 18);
+    memcpy(c + 0x87, st + CX_G1, 24); memcpy(c + 0x9f, st + CX_G2, 6);
+    c[0xaa] = st[CX_ROOT_CBF];
+    const int32_t *E = kEntropyBits;
+    memset(tables, 0, sizeof(int32_t) * 8 * 180);
+    for (int log2 = 2; log2 <= 5; ++log2)
+        for (int ch = 0; ch < 2; ++ch) {
+            int32_t *o = tables + ((log2 - 2) * 2 + ch) * 180;
+            const int luma = !ch;
+            const uint8_t *p = c + 0x0d + (luma ? 0 : 5);
+            for (int i = 0; i < 5; ++i) { o[168 + 2 * i] = E[p[i]]; o[169 + 2 * i] = E[p[i] ^ 1]; }
+            o[178] = E[c[0xaa]]; o[179] = E[c[0xaa] ^ 1];
+            p = c + 0x1d + (luma ? 0 : 2);
+            for (int i = 0; i < 2; ++i) { o[2 * i] = E[p[i]]; o[2 * i + 1] = E[p[i] ^ 1]; }
+            p = c + (luma ? 0x21 : 0x3c);
+            const int first = log2 > 3 ? (luma ? 21 : 12) : log2 == 3 ? 9 : 1, end = log2 > 3 ? (luma ? 27 : 15) : log2 == 3 ? (luma ? 21 : 12) : 9;
+            o[4] = E[p[0]]; o[46] = E[p[0] ^ 1];
+            for (int i = first; i < end; ++i) { o[4 + i] = E[p[i]]; o[46 + i] = E[p[i] ^ 1]; }
+            const int off = luma ? 3 * log2 - 6 + ((log2 - 1) >> 2) : 15, shift = luma ? (log2 + 1) >> 2 : log2 - 2, n = 2 * log2 - 1;
+            for (int d = 0; d < 2; ++d) {
+                const uint8_t *l = c + 0x4b + 0x1e * d;
+                int32_t bits = 0;
+                for (int k = 0; k < n; ++k) { const uint8_t s = l[off + (k >> shift)]; o[88 + 10 * d + k] = bits + E[s]; bits += E[s ^ 1]; }
+                o[88 + 10 * d + n] = bits;
+            }
+            const int g1 = luma ? 0x87 : 0x97, n1 = luma ? 16 : 8, g2 = luma ? 0x9f : 0xa3, n2 = luma ? 4 : 2;
+            for (int i = 0; i < n1; ++i) { o[108 + 2 * i] = E[c[g1 + i]]; o[109 + 2 * i] = E[c[g1 + i] ^ 1]; }
+            for (int i = 0; i < n2; ++i) { o[156 + 2 * i] = E[c[g2 + i]]; o[157 + 2 * i] = E[c[g2 + i] ^ 1]; }
+        }
+    return KS265_OK;
+}
+
 long ks265_write_slice(const ks265_stream_cfg *cfg, const ks265_slice_in *in, void *scratch, uint8_t *out, size_t cap)
 {
     if (!scratch || !out) return KS265_POINTER;

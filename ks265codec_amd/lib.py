@@ -58,7 +58,7 @@ EXPORTS = [
     "ks265_edge_filter_luma_batch", "ks265_edge_filter_chroma_batch", "ks265_interp_rect",
     "ks265_sao_apply_bo_rect", "ks265_sao_apply_eo_rect", "ks265_sao_stats_batch", "ks265_intra_pred_batch", "ks265_intra_filter_ref_batch",
     "ks265_downsample_rect", "ks265_downsample_from_host", "ks265_weight_bi_sad_batch", "ks265_ac_energy_batch", "ks265_ac_energy_map",
-    "ks265_frame_reset_prediction", "ks265_frame_records_layout", "ks265_frame_pack_records", "ks265_frame_compact_layout", "ks265_frame_pack_compact", "ks265_frame_pack_compact_on", "ks265_frame_adapt_quant", "ks265_aq_ctu_map", "ks265_cutree_propagate", "ks265_calc_frame_cost", "ks265_calc_frame_cost_workspace", "ks265_cutree_finish", "ks265_host_register", "ks265_memcpy_h2d_sync", "ks265_host_unregister", "ks265_pad_plane", "ks265_fill_u16", "ks265_qoff_ctu_map", "ks265_frame_set_records_fence", "ks265_load_i420_on", "ks265_sse_picture_on", "ks265_copy_out_compact_async", "ks265_copy_out_compact_dma_async", "ks265_frame_geometry", "ks265_frame_create", "ks265_frame_destroy", "ks265_frame_set_qp", "ks265_frame_set_qp_map", "ks265_pad_picture",
+    "ks265_frame_reset_prediction", "ks265_frame_records_layout", "ks265_frame_pack_records", "ks265_frame_compact_layout", "ks265_frame_pack_compact", "ks265_frame_pack_compact_on", "ks265_frame_adapt_quant", "ks265_aq_ctu_map", "ks265_cutree_propagate", "ks265_calc_frame_cost", "ks265_calc_frame_cost_workspace", "ks265_cutree_finish", "ks265_host_register", "ks265_memcpy_h2d_sync", "ks265_host_unregister", "ks265_pad_plane", "ks265_fill_u16", "ks265_qoff_ctu_map", "ks265_frame_set_records_fence", "ks265_load_i420_on", "ks265_sse_picture_on", "ks265_copy_out_compact_async", "ks265_copy_out_compact_dma_async", "ks265_frame_geometry", "ks265_frame_create", "ks265_frame_destroy", "ks265_frame_set_qp", "ks265_frame_set_qp_map", "ks265_frame_set_rdoq", "ks265_pad_picture",
     "ks265_load_i420", "ks265_store_i420", "ks265_presearch", "ks265_me_integer", "ks265_me_propagate", "ks265_me_subpel", "ks265_cu_decide_part", "ks265_cu_decide_part_b", "ks265_merge_pass", "ks265_cu_decide",
     "ks265_cu_flat_intra", "ks265_intra_decide", "ks265_intra_decide_ex", "ks265_lookahead_reduce", "ks265_lookahead_picture", "ks265_lookahead_inter", "ks265_intra_reconstruct", "ks265_reconstruct", "ks265_reconstruct_b", "ks265_bi_decide", "ks265_bi_refine_chosen", "ks265_bi_full_batch", "ks265_capture_begin", "ks265_capture_end", "ks265_graph_launch", "ks265_graph_destroy", "ks265_frame_p_state", "ks265_frame_p_advance", "ks265_frame_p_restore", "ks265_cu_decide_b", "ks265_deblock", "ks265_sao",
     "ks265_encode_picture", "ks265_encode_picture_b", "ks265_encode_picture_mref", "ks265_encode_picture_b_mref", "ks265_ref_pick", "ks265_ref_decide", "ks265_reconstruct_mref",
@@ -366,6 +366,16 @@ class KsFrame:
         """one QP per CTU (device int8 array, raster; None = off) for the pictures coded from here on; the caller keeps the array alive"""
         self._qp_map = dev_map
         self.ks._chk(self.lib.ks265_frame_set_qp_map(self.h, _p(dev_map) if dev_map is not None else None))
+
+    def set_rdoq(self, tables: "np.ndarray | None", lam: "np.ndarray | None" = None, lam_sdh: "np.ndarray | None" = None):
+        """cfg.rdoq (-rdoq 1): the reference's rdoQuant for the luma transform blocks of inter CUs from the next picture on - tables int32 [4][2][180] (estBitRdoq), the two lambdas
+        int64 [52] by QP; None = back to the default seam.  The copies are enqueued: the arrays are kept alive here"""
+        if tables is None:
+            self.ks._chk(self.lib.ks265_frame_set_rdoq(self.h, None, None, None)); return
+        self._rq = (np.ascontiguousarray(tables, np.int32), np.ascontiguousarray(lam, np.int64), np.ascontiguousarray(lam_sdh if lam_sdh is not None else lam, np.int64))
+        assert self._rq[0].size == 1440 and self._rq[1].size == 52 and self._rq[2].size == 52
+        self.ks._chk(self.lib.ks265_frame_set_rdoq(self.h, *(a.ctypes.data_as(C.c_void_p) for a in self._rq)))
+        self.ks.sync()
 
     def load_i420(self, dev_i420, pic: DevPic):
         self.ks._chk(self.lib.ks265_load_i420(self.h, _p(dev_i420), pic.c()))

