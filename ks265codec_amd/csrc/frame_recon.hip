@@ -482,7 +482,7 @@ int ks265_rdoq_listed(ks265_ctx *ctx, const ks265_rdoq_tu *dev_tus, const int *d
                       int32_t *dev_out, uint64_t *dev_hidden);      // rdoq_ops.hip
 // One wave per 8x8 block position; the wave of a luma transform block's first block (inter CU: TU = min(CU, 32), four TUs for a CU in two partitions / with split transform units)
 // packs the block's levels and coefficients (planes, row pitch W) into contiguous N x N arrays, builds what rdoQuant is handed - per 4x4 group in scan order the mask of the
-// positions the quantiser left non-zero (bit 15 - k = scan position k: scanSigFlags enc@0x4a9b00 lineage, the oracle's kso_rdoq_scan_flags) and the last significant scan position -
+// positions the quantiser left non-zero (bit 15 - k = scan position k: scanSigFlags enc@0x4a9b00 lineage) and the last significant scan position -
 // and appends the descriptor.  A block without a level is not listed (its plane is zero already).  ctr[0] = blocks listed, ctr[1] = packed elements.
 __global__ __launch_bounds__(256) void rdoq_prep_kernel(KsGeom g, int qp, const int8_t *qp_map, int sdh, const ks265_cu8 *cu8, const int16_t *lvl, const int16_t *coef, int16_t *pack_lvl,
                                                         int16_t *pack_coef, ks265_rdoq_tu *tus, int *pos, int *ctr, unsigned short *sigmask, const long long *lam)
