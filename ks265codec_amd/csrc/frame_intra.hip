@@ -67,6 +67,30 @@ __device__ __forceinline__ int intra_ref_sample(const uint8_t *plane, int stride
 }
 
 // ------------------------------------------------------------------ reconstruction (wavefront)
+#ifdef KS_INTRA_CLOCK
+// experiment build (-DKS_INTRA_CLOCK; tools/intra_clock.py reads the sums): where the time of the intra chain goes - cycles of wave 0 per phase over all work-groups.
+// Measured in round 6 at 2160p (profiles/r06_intra_clock.txt): a CU is 25 - 30 dependent LDS round trips, not arithmetic - 8x8: 11.9 K cycles (TU pipeline 8.5 K: sign-data
+// hiding 3.9 K, prediction + residual 2.0 K, the four transform passes 3.3 K), 16x16: 14.4 K, 32x32: 25 K (its luma block alone; coding chroma beside it on two more waves
+// changed nothing).  Cheaper exchanges (DPP for the coefficient groups' rows) and a horizontal-mode fast path changed nothing either.
+__device__ unsigned long long g_iclk[2][32];
+#define ICLK_DECL unsigned long long ick_t = __builtin_amdgcn_s_memtime(); unsigned long long ick_a[24] = {}, g_tclk_acc[9] = {}
+#define ICLK(i) do { const unsigned long long ick_n = __builtin_amdgcn_s_memtime(); ick_a[i] += ick_n - ick_t; ick_t = ick_n; } while (0)
+#define ICLK_CNT(i) do { ick_a[i] += 1; } while (0)
+#define TCLK(i) do { if (ck) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); ck[i] += tn - *ckt; *ckt = tn; } } while (0)
+#define TCLK_ARGS , unsigned long long *ck = nullptr, unsigned long long *ckt = nullptr
+extern "C" int ks265_debug_clock_read(unsigned long long *out64, int reset)
+{
+    if (hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_iclk), sizeof(unsigned long long) * 64) != hipSuccess) return -1;
+    if (reset) { static unsigned long long z[64]; if (hipMemcpyToSymbol(HIP_SYMBOL(g_iclk), z, sizeof z) != hipSuccess) return -1; }
+    return 0;
+}
+#else
+#define ICLK_DECL
+#define ICLK(i)
+#define ICLK_CNT(i)
+#define TCLK(i)
+#define TCLK_ARGS
+#endif
 struct IntraLds {
     short Mf[MAT_SHORTS], Mt[MAT_SHORTS];
     short X[3][32 * RP], T[3][32 * RP];                  // [component]; chroma uses the first 16 rows
@@ -113,7 +137,7 @@ __device__ __forceinline__ void tu_sync()
 // prediction -> residual -> forward transform -> quant -> dequant -> inverse transform -> reconstructed samples of one quad
 // (the reconstruct() chain enc@0x481da0, same arithmetic as code_region of frame_recon.hip with the intra rounding offset 171)
 template <bool BLOCK>
-__device__ __forceinline__ void tu_pipeline(IntraLds &L, const TuRole &r, const TuCtx &c)
+__device__ __forceinline__ void tu_pipeline(IntraLds &L, const TuRole &r, const TuCtx &c TCLK_ARGS)
 {
     const int cp = r.comp, nn = r.n, l2 = r.log2n, mp = nn + 4;
     short *X = L.X[cp], *T = L.T[cp];
@@ -134,6 +158,7 @@ __device__ __forceinline__ void tu_pipeline(IntraLds &L, const TuRole &r, const 
         *(uint2 *)(X + r.qy * RP + r.qx) = make_uint2(res[0] | ((unsigned)res[1] << 16), res[2] | ((unsigned)res[3] << 16));
     }
     tu_sync<BLOCK>();
+    TCLK(0);
     if (r.on) {                                                     // forward pass 1: T[k][j] = rnd(M[k] . X[j], 2 log2N - 2)
         const int s1 = 2 * l2 - 2;
         int acc[4];
@@ -144,6 +169,7 @@ __device__ __forceinline__ void tu_pipeline(IntraLds &L, const TuRole &r, const 
         *(uint2 *)(T + r.qy * RP + r.qx) = make_uint2(o[0] | ((unsigned)o[1] << 16), o[2] | ((unsigned)o[3] << 16));
     }
     tu_sync<BLOCK>();
+    TCLK(1);
     // ---- forward pass 2 + quantisation, then the postQuant seam IN REGISTERS: a lane holds one row of four coefficients of its 4x4 coefficient group, the group's four
     // rows sit Q = N / 4 lanes apart in the same wave, so what a group needs to know about itself travels by two xor-shuffles - no LDS round trip, no lane walking
     // sixteen coefficients on its own (that serial walk, not the transforms, was the time of a TU: 5.4 of 11.2 us for a 16x16 TU, 2160p, round 3).
@@ -161,6 +187,7 @@ __device__ __forceinline__ void tu_pipeline(IntraLds &L, const TuRole &r, const 
             duq[i] = (short)du;                                     // (16 bits, as the reference keeps its deltaU)
         }
     }
+    TCLK(2);
     if (c.rdo_lam2k && __builtin_amdgcn_readfirstlane(cp) == 0) {
         // cfg.rdo (intra CUs of P / B pictures, luma only: a wave's lanes are all luma or all chroma): coefficient-group pruning before sign-data hiding
         // (recon_dev.h rdo_group_prune, the oracle's code_tu)
@@ -182,6 +209,7 @@ __device__ __forceinline__ void tu_pipeline(IntraLds &L, const TuRole &r, const 
         const int cnt = bc & 255, bits = (bc >> 8) + 10 + (16 - cnt);
         if (cnt && ((gain >> (2 * (7 - l2))) << 12) <= c.rdo_lam2k * bits) { lvq[0] = 0; lvq[1] = 0; lvq[2] = 0; lvq[3] = 0; }
     }
+    TCLK(3);
     {   // levels per component of this wave (a wave holds one component, the chroma wave of a small CU both chroma components)
         const int cp0 = __builtin_amdgcn_readfirstlane(cp);
 #pragma unroll
@@ -192,6 +220,7 @@ __device__ __forceinline__ void tu_pipeline(IntraLds &L, const TuRole &r, const 
             if (cnt && (threadIdx.x & 63) == 0) atomicAdd(&L.nz[cp0 + k], cnt);
         }
     }
+    TCLK(4);
     int qpos[4] = {0, 0, 0, 0};
     unsigned nzmask = 0, negmask = 0;
     int csum = 0, gorder = 0;
@@ -254,6 +283,7 @@ __device__ __forceinline__ void tu_pipeline(IntraLds &L, const TuRole &r, const 
                 }
         }
     }
+    TCLK(5);
     if (r.on) {                                                     // the final levels: to the level plane, dequantised (transposed) for the inverse transform
         unsigned short lv[4];
 #pragma unroll
@@ -265,6 +295,7 @@ __device__ __forceinline__ void tu_pipeline(IntraLds &L, const TuRole &r, const 
             make_uint2(lv[0] | ((unsigned)lv[1] << 16), lv[2] | ((unsigned)lv[3] << 16));
     }
     tu_sync<BLOCK>();
+    TCLK(6);
     const bool live = r.on && L.nz[cp] != 0;
     if (r.on) {                                                     // inverse pass 1: T[y][x] = clip16((Mt[y] . Ct[x] + 64) >> 7)
         int acc[4] = {0, 0, 0, 0};
@@ -275,6 +306,7 @@ __device__ __forceinline__ void tu_pipeline(IntraLds &L, const TuRole &r, const 
         *(uint2 *)(T + r.qy * RP + r.qx) = make_uint2(o[0] | ((unsigned)o[1] << 16), o[2] | ((unsigned)o[3] << 16));
     }
     tu_sync<BLOCK>();
+    TCLK(7);
     if (r.on) {                                                     // inverse pass 2 + prediction -> reconstructed samples
         int acc[4] = {0, 0, 0, 0};
         if (live) quad_dot(T + r.qy * RP, mt + r.qx * mp, mp, nn, acc);
@@ -287,6 +319,7 @@ __device__ __forceinline__ void tu_pipeline(IntraLds &L, const TuRole &r, const 
         else *(unsigned *)&L.WC[cp - 1][(1 + c.ly * 4 + r.qy) * 72 + 4 + c.lx * 4 + r.qx] = o;
     }
     tu_sync<BLOCK>();
+    TCLK(8);
 }
 
 // PMODE = false: an intra picture (every CU).  PMODE = true (cfg.intra_inter): the intra CUs (pred_mode 2) of a P / B picture AFTER reconstruct_kernel has written every
@@ -324,6 +357,7 @@ __global__ __launch_bounds__(256) void intra_recon_kernel(KsGeom g, int qp, cons
             return;
         }
     }
+    ICLK_DECL;
     build_matrices(L.Mf, L.Mt, tid, 256);                            // (cheaper than fetching the frame's copy: no memory latency)
     TuCtx c;
     c.sdh = sdh_on != 0;
@@ -375,6 +409,7 @@ __global__ __launch_bounds__(256) void intra_recon_kernel(KsGeom g, int qp, cons
                 dc[0] = wc.x; dc[1] = wc.y;
             }
         };
+        ICLK(0);                                                     // [0] set-up: matrices, map load
         if (PMODE) load_own();                                       // nothing of this depends on the neighbours: under way before the wait
         if (PMODE) {
             // the neighbour CTUs whose samples this CTU's intra CUs read (of left, top-left, top, top-right: s_need) must be through - with or without intra CUs of
@@ -410,6 +445,7 @@ __global__ __launch_bounds__(256) void intra_recon_kernel(KsGeom g, int qp, cons
             }
         }
         __syncthreads();
+        ICLK(1);                                                     // [1] waiting for the neighbour CTUs
         if (!PMODE) load_own();
         if (PMODE && cx > 0) {                                       // the left neighbour column: another work-group's stores (L2-coherent loads)
             if (tid < 64) L.WY[(1 + tid) * 136 + 3] = __hip_atomic_load(c.R0 + (long)(cy * 64 + tid) * g.sy + cx * 64 - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -429,6 +465,7 @@ __global__ __launch_bounds__(256) void intra_recon_kernel(KsGeom g, int qp, cons
             }
         }
         __syncthreads();
+        ICLK(2);                                                     // [2] window loads
 #pragma unroll 1
         for (int z = 0; z < 64; ++z) {                              // 8x8 blocks of the CTU in z-order; a CU is coded at its first block
             const int lx = (z & 1) | ((z >> 1) & 2) | ((z >> 2) & 4), ly = ((z >> 1) & 1) | ((z >> 2) & 2) | ((z >> 3) & 4);
@@ -440,6 +477,8 @@ __global__ __launch_bounds__(256) void intra_recon_kernel(KsGeom g, int qp, cons
             const int n = 8 * n8, log2 = cu.log2_cu & 15;
             c.mode = cu.mvx; c.lx = lx; c.ly = ly; c.x0 = cx * 64 + lx * 8; c.y0 = cy * 64 + ly * 8;
             c.filt = intra_filter_flag(c.mode, n);
+            ICLK(3);                                                 // [3] walking the z loop (skipped blocks included)
+            ICLK_CNT(16 + (n == 32 ? 2 : n == 16 ? 1 : 0));          // [16..18] CUs of 8 / 16 / 32
             if (n == 32) {
                 // ---- 32x32: the luma TU needs all four waves (256 quads) -> work-group barriers; chroma as a second phase
                 lds_barrier();                                       // waves 0 / 1 may still be inside a small CU
@@ -466,6 +505,7 @@ __global__ __launch_bounds__(256) void intra_recon_kernel(KsGeom g, int qp, cons
                 tu_pipeline<true>(L, r, c);
                 r.on = tid < 128; r.comp = 1 + ((tid >> 6) & 1); r.n = 16; r.log2n = 4; r.qx = (tid & 3) * 4; r.qy = (tid & 63) >> 2;
                 tu_pipeline<true>(L, r, c);
+                ICLK(4);                                             // [4] a 32x32 CU, everything
                 if (tid < 16 && (L.nz[0] | L.nz[1] | L.nz[2])) L.cbf[(ly + (tid >> 2)) * 8 + lx + (tid & 3)] = (L.nz[0] ? 1 : 0) | (L.nz[1] ? 2 : 0) | (L.nz[2] ? 4 : 0);
                 lds_barrier();
             } else if (wave < 2) {
@@ -475,8 +515,10 @@ __global__ __launch_bounds__(256) void intra_recon_kernel(KsGeom g, int qp, cons
                 TuRole r;
                 if (wave == 0) {
                     if (lane == 0) { L.nz[0] = 0; L.lastcg[0] = 0; }
+                    ICLK(5);                                         // [5] small CU: availability mask
                     for (int q = lane; q <= 4 * n; q += 64) L.raw[0][66 - 2 * n + q] = (unsigned char)intra_ref_sample<false>(&L.WY[136 + 4], 136, mask, lx * 8, ly * 8, n, 8, q);
                     tu_sync<false>();
+                    ICLK(6);                                         // [6] reference gather
                     if (c.filt) {
                         for (int q = lane; q <= 4 * n; q += 64) L.fil[66 - 2 * n + q] = (unsigned char)intra_filtered(&L.raw[0][66], n, q - 2 * n, false);
                     } else if (c.mode == 1) {
@@ -488,7 +530,15 @@ __global__ __launch_bounds__(256) void intra_recon_kernel(KsGeom g, int qp, cons
                     tu_sync<false>();
                     const int sh = log2 - 2;                         // quads per row = n / 4
                     r.on = lane < (n * n >> 2); r.comp = 0; r.n = n; r.log2n = log2; r.qx = (lane & ((1 << sh) - 1)) * 4; r.qy = lane >> sh;
+                    ICLK(7);                                         // [7] smoothing / DC
+#ifdef KS_INTRA_CLOCK
+                    unsigned long long tk[9] = {}, tkt = ick_t;
+                    tu_pipeline<false>(L, r, c, tk, &tkt);
+                    for (int i = 0; i < 9; ++i) g_tclk_acc[i] += tk[i];
+#else
                     tu_pipeline<false>(L, r, c);
+#endif
+                    ICLK(n == 8 ? 8 : 9);                            // [8] / [9] the TU pipeline of an 8x8 / 16x16 luma block
                     if (lane < n8 * n8 && L.nz[0]) atomicOr(&L.cbf[(ly + lane / n8) * 8 + lx + lane % n8], 1);
                 } else {
                     const int nc = n >> 1, lenC = 2 * n + 1;
@@ -520,6 +570,12 @@ __global__ __launch_bounds__(256) void intra_recon_kernel(KsGeom g, int qp, cons
         }
         __threadfence();                                             // this CTU's samples are in L2 before the row below is released
         __syncthreads();
+        ICLK(11);                                                    // [11] cbf write-back, fence
+        ICLK_CNT(19);                                                // [19] CTUs coded
+#ifdef KS_INTRA_CLOCK
+        if (tid == 0) for (int i = 0; i < 24; ++i) if (ick_a[i]) { atomicAdd(&g_iclk[PMODE ? 1 : 0][i], ick_a[i]); ick_a[i] = 0; }
+        if (tid == 0) for (int i = 0; i < 9; ++i) if (g_tclk_acc[i]) { atomicAdd(&g_iclk[PMODE ? 1 : 0][20 + i], g_tclk_acc[i]); g_tclk_acc[i] = 0; }
+#endif
         if (tid == 0) __hip_atomic_store(progress + (PMODE ? (int)blockIdx.x : cy), PMODE ? 1 : cx + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
