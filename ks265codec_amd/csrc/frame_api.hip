@@ -207,13 +207,40 @@ int ks265_encode_picture_mref(ks265_frame *f, ks265_pic src, const ks265_pic *re
     int r;
     ks265_pu *pu0 = f->pu[f->cur_pu];
     const ks265_pu *pus[4] = {pu0, f->pu_x[0], f->pu_x[1], f->pu_x[2]};
-    for (int i = 0; i < nref; ++i) {
-        if (!refs[i].y) return KS265_POINTER;
+    for (int i = 0; i < nref; ++i) if (!refs[i].y) return KS265_POINTER;
+    /* one picture's chain: pre-search, integer search, propagation, sub-pel refinement; the temporal predictor (previous picture's vectors) belongs to the nearest picture only */
+    auto chain = [&](int i) -> int {
         ks265_pu *pu = i == 0 ? pu0 : f->pu_x[i - 1];
-        /* the temporal predictor (previous picture's vectors) belongs to the nearest picture only */
-        if ((r = me_search(f, src, refs[i], i == 0 && f->have_prev ? f->pu[f->cur_pu ^ 1] : nullptr, pu))) return r;
-        if (f->cfg.subme && (r = ks265_me_subpel(f, src, refs[i], pu))) return r;
-    }
+        int rr = me_search(f, src, refs[i], i == 0 && f->have_prev ? f->pu[f->cur_pu ^ 1] : nullptr, pu);
+        if (!rr && f->cfg.subme) rr = ks265_me_subpel(f, src, refs[i], pu);
+        return rr;
+    };
+    const bool par = f->b_parallel && !f->ctx->capturing && f->side && f->pyr2[0] && f->cfg.pre_search && (!f->cfg.propagate || f->pu_s2);
+    if (par) {
+        /* round 6: the chains of the farther pictures on the side stream beside the nearest picture's (the B pictures' two lists do the same, encode_b_lists): chains of
+         * latency-bound kernels that leave most of the device idle - an anchor with three pictures takes two chains' time instead of three */
+        if ((r = ks265_presearch_source(f, src))) return r;
+        if ((r = ks265_hip(f->ctx, hipEventRecord(f->ev_fork, f->ctx->stream)))) return r;
+        if ((r = ks265_hip(f->ctx, hipStreamWaitEvent(f->side, f->ev_fork, 0)))) return r;
+        hipStream_t mainst = f->ctx->stream;
+        auto swap_ws = [&]() {
+            for (int i = 0; i < 10; ++i) { uint8_t *t = f->pyr[i]; f->pyr[i] = f->pyr2[i]; f->pyr2[i] = t; }
+            ks265_pu *t = f->pu_s; f->pu_s = f->pu_s2; f->pu_s2 = t;
+            if (f->me_work) { const bool side = f->me_work == f->me_work_all[0]; f->me_work = f->me_work_all[side]; f->me_order = f->me_order_all[side]; }
+        };
+        f->src_pyr_ready = true;
+        f->ctx->stream = f->side; swap_ws();
+        r = 0;
+        for (int i = 1; i < nref && !r; ++i) r = chain(i);
+        const int rj = ks265_hip(f->ctx, hipEventRecord(f->ev_join, f->side));      /* (joined whatever happened after the fork: see encode_b_lists) */
+        f->ctx->stream = mainst; swap_ws();
+        if (!r) r = chain(0);
+        f->src_pyr_ready = false;
+        const int rw = rj ? ks265_hip(f->ctx, hipStreamSynchronize(f->side)) : ks265_hip(f->ctx, hipStreamWaitEvent(f->ctx->stream, f->ev_join, 0));
+        if (r) return r;
+        if (rw) return rw;
+    } else
+        for (int i = 0; i < nref; ++i) if ((r = chain(i))) return r;
     if ((r = ks265_ref_decide(f, nref, pus, f->pub))) return r;
     /* round 6 (-ref0: the anchors of the pyramid GOPs search several past anchors): the two-list records go through the stages a one-reference P picture has - intra candidates
      * against them (cfg.intra_inter), the CU tree, the merge pass on the records' pictures (cfg.merge), the intra CUs' pass; -part 1 stays with one reference picture */
