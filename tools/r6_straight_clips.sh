@@ -15,13 +15,13 @@ echo "# 128 distinct pictures per clip (no ping-pong); head ${KS265_GIT_HEAD:-?}
 for cfg in "1920 1080 slow 27" "3840 2160 slow 27"; do set -- $cfg
  for extra in "" "-bframes 0"; do
   echo "## $1x$2 -preset $3 -rc 0 -qp $4 -iper 128 $extra"
-  ( cd /dev/shm && cp $R/oracle/_ref/appencoder ./appencoder_s && echo "reference appencoder -threads 64: $(./appencoder_s -i /dev/shm/sclip_$1.yuv -wdt $1 -hgt $2 -fr 50 -preset $3 -rc 0 -qp $4 -iper 128 $extra -threads 64 -psnr 1 -b /dev/shm/r.265 | grep -E 'Total|bitrate, psnr' | tr '\n' ' ')" )
+  ( mkdir -p /tmp/ks_s && cd /tmp/ks_s && cp $R/oracle/_ref/appencoder ./appencoder_s && chmod +x ./appencoder_s && echo "reference appencoder -threads 64: $(./appencoder_s -i /dev/shm/sclip_$1.yuv -wdt $1 -hgt $2 -fr 50 -preset $3 -rc 0 -qp $4 -iper 128 $extra -threads 64 -psnr 1 -b /dev/shm/r.265 | grep -E 'Total|bitrate, psnr' | tr '\n' ' ')" )
   for dq in -2 0 2 4; do q=$(( $4 + dq ))
    echo "ks265enc -qp $q: $(./ks265codec_amd/ks265enc -i /dev/shm/sclip_$1.yuv -wdt $1 -hgt $2 -fr 50 -preset $3 -rc 0 -qp $q -iper 128 $extra -threads 32 -psnr 1 -b /dev/shm/o.265 | grep -E 'Total|bitrate, psnr' | tr '\n' ' ')"
   done
  done
 done
 } > $O/$TAG.txt 2>&1
-rm -f /dev/shm/sclip_*.yuv /dev/shm/o.265 /dev/shm/r.265 /dev/shm/appencoder_s
+rm -rf /dev/shm/sclip_*.yuv /dev/shm/o.265 /dev/shm/r.265 /tmp/ks_s
 cut -c1-200 $O/$TAG.txt
 python tools/equal_psnr.py $O/$TAG.txt | tee $O/${TAG}_equal_psnr.txt
