@@ -563,6 +563,82 @@ int32_t ks265o_sao_eo_type_estimation(int lambda_q8, const int32_t *count /*4*/,
     return total;
 }
 
+/* CEncSao::modeDecisionCtu enc@0x4af690 on its `-sao 4` path (also what an I slice takes at level 3), restated from the disassembly and pinned on calls recorded inside real
+ * encodes (oracle/ref_probe/sao_shim.c, tests/golden/sao_decision.npz):
+ *   stats = the object's statistics, 312 words: counts - band offset Y [0..32), U [32..64), V [64..96), edge classes Y at 96 + 5 class, U at 116 + 5 class, V at 136 + 5 class
+ *           (four categories each) - then the sums in the same layout from word 156 on;
+ *   records (32 bytes): [0] luma type (-1 off, 0 / 1 = edge class 0 / 90 degrees, 4 = band offset), [1] chroma type, [2] luma band, [3] / [4] Cb / Cr band, [5..8] luma offsets,
+ *           [0xa..0xd] Cb, [0xf..0x12] Cr, [0x14] merge left, [0x15] merge up.
+ * modeDecisionBoEo01 enc@0x4af300: luma EO 0, EO 1, BO, then chroma EO 0, EO 1, BO - calcRDcostEoY enc@0x4ae290 (+ (4 lambda + 128) >> 8), calcRDcostBoY enc@0x4ade40 (7 lambda),
+ * calcRDcostEoUV enc@0x4ae2e0 (both components + 4 lambda_c), calcRDcostBoUV enc@0x4adeb0 (12 lambda_c, a band per component); checkRDCostY / UV enc@0x4ad810 / 0x4ad860: strictly
+ * cheaper than the best so far, which starts at one bin ((lambda + 128) >> 8).  Then the merge candidates: the sum of the two bests + ((lambda_avg if an upper CTU exists) + 128) >> 8
+ * against checkMerge enc@0x4ae7f0 of the left CTU's FINAL record (the distortion its offsets give on this CTU's statistics; 0xfffffff when it uses a type outside the masks) and of
+ * the upper one's + (lambda_avg + 128) >> 8; strictly cheaper copies the neighbour's record (24 bytes) and sets the flag.  32-bit arithmetic as in the binary. */
+static int32_t sao_merge_dist(const int32_t *st, const int8_t *p, int mask_y, int mask_uv)
+{
+    const int ty = p[0], tuv = p[1];
+    if (ty != -1 && !((mask_y >> ty) & 1)) return 0xfffffff;
+    if (tuv != -1 && !((mask_uv >> tuv) & 1)) return 0xfffffff;
+    uint32_t d = 0;
+    if (ty != -1) {
+        const int32_t *cnt = ty == 4 ? st + p[2] : st + 96 + 5 * ty, *sum = ty == 4 ? st + 156 + p[2] : st + 156 + 96 + 5 * ty;
+        for (int i = 0; i < 4; ++i) { const int32_t o = p[5 + i]; d += (uint32_t)(((uint32_t)cnt[i] * (uint32_t)o - 2u * (uint32_t)sum[i]) * (uint32_t)o); }
+    }
+    if (tuv != -1)
+        for (int c = 0; c < 2; ++c) {
+            const int32_t *cnt = tuv == 4 ? st + 32 + 32 * c + p[3 + c] : st + 116 + 20 * c + 5 * tuv, *sum = tuv == 4 ? st + 156 + 32 + 32 * c + p[3 + c] : st + 156 + 116 + 20 * c + 5 * tuv;
+            for (int i = 0; i < 4; ++i) { const int32_t o = p[0xa + 5 * c + i]; d += (uint32_t)(((uint32_t)cnt[i] * (uint32_t)o - 2u * (uint32_t)sum[i]) * (uint32_t)o); }
+        }
+    return (int32_t)d;
+}
+void ks265o_sao_mode_decision(const int32_t *stats /*312*/, int lam_y, int lam_c, int left_avail, int up_avail, const int8_t *left /*32 or NULL*/, const int8_t *up, int mask_y, int mask_uv,
+                              int8_t *out /*32: only the bytes the function writes are touched*/, int32_t *best /*2*/)
+{
+    const int32_t lam_avg = (lam_y + lam_c + 1) >> 1;
+    out[0] = out[1] = -1; out[0x14] = out[0x15] = 0;
+    int32_t by = (lam_y + 128) >> 8, buv = (lam_c + 128) >> 8;
+    for (int cls = 0; cls < 2; ++cls) {
+        int32_t cnt[4], sum[4], off[4];
+        for (int k = 0; k < 4; ++k) { cnt[k] = stats[96 + 5 * cls + k]; sum[k] = stats[156 + 96 + 5 * cls + k]; }
+        const int32_t cost = ks265o_sao_eo_type_estimation(lam_y, cnt, sum, off) + ((4 * lam_y + 128) >> 8);
+        if (by > cost) { by = cost; out[0] = (int8_t)cls; out[2] = 0; for (int k = 0; k < 4; ++k) out[5 + k] = (int8_t)off[k]; }
+    }
+    {
+        int32_t cnt[32], sum[32], off[32], band = 0;
+        memcpy(cnt, stats, sizeof cnt); memcpy(sum, stats + 156, sizeof sum);
+        const int32_t cost = ks265o_sao_bo_type_estimation(lam_y, cnt, sum, &band, off) + ((7 * lam_y + 128) >> 8);
+        if (by > cost) { by = cost; out[0] = 4; out[2] = (int8_t)band; for (int k = 0; k < 4; ++k) out[5 + k] = (int8_t)off[band + k]; }
+    }
+    for (int cls = 0; cls < 2; ++cls) {
+        int32_t off[2][4], cost = (4 * lam_c + 128) >> 8;
+        for (int c = 0; c < 2; ++c) {
+            int32_t cnt[4], sum[4];
+            for (int k = 0; k < 4; ++k) { cnt[k] = stats[116 + 20 * c + 5 * cls + k]; sum[k] = stats[156 + 116 + 20 * c + 5 * cls + k]; }
+            cost += ks265o_sao_eo_type_estimation(lam_c, cnt, sum, off[c]);
+        }
+        if (buv > cost) { buv = cost; out[1] = (int8_t)cls; out[3] = out[4] = 0; for (int k = 0; k < 4; ++k) { out[0xa + k] = (int8_t)off[0][k]; out[0xf + k] = (int8_t)off[1][k]; } }
+    }
+    {
+        int32_t off[2][32], band[2] = {0, 0}, cost = (12 * lam_c + 128) >> 8;
+        for (int c = 0; c < 2; ++c) {
+            int32_t cnt[32], sum[32];
+            memcpy(cnt, stats + 32 + 32 * c, sizeof cnt); memcpy(sum, stats + 156 + 32 + 32 * c, sizeof sum);
+            cost += ks265o_sao_bo_type_estimation(lam_c, cnt, sum, &band[c], off[c]);
+        }
+        if (buv > cost) { buv = cost; out[1] = 4; out[3] = (int8_t)band[0]; out[4] = (int8_t)band[1]; for (int k = 0; k < 4; ++k) { out[0xa + k] = (int8_t)off[0][band[0] + k]; out[0xf + k] = (int8_t)off[1][band[1] + k]; } }
+    }
+    if (best) { best[0] = by; best[1] = buv; }
+    int32_t tot = by + buv + (((up_avail ? lam_avg : 0) + 128) >> 8);
+    if (left_avail && left) {
+        const int32_t c = sao_merge_dist(stats, left, mask_y, mask_uv);
+        if (tot > c) { tot = c; memcpy(out, left, 24); out[0x15] = 0; out[0x14] = 1; }
+    }
+    if (up_avail && up) {
+        const int32_t c = sao_merge_dist(stats, up, mask_y, mask_uv) + ((lam_avg + 128) >> 8);
+        if (tot > c) { memcpy(out, up, 24); out[0x15] = 1; out[0x14] = 0; }
+    }
+}
+
 /* CalcBsInterP enc@0x402960 / CalcBsInterB enc@0x4029d0 (TNborData *p, TNborData *q, int transform edge): boundary strength of the edge between two blocks
  * (H.265 8.7.2.4 in the reference's data layout).  A block record is three words: word 0 - bits 2..3 lists used (0 = intra), bits 16..19 / 20..23 the reference
  * PICTURE id of list 0 / 1 (ids compare across lists), bit 24 coded residual; bytes 4..7 the list-0 vector, 8..11 the list-1 vector (quarter samples).

@@ -94,6 +94,7 @@ void ks265o_default_weighted_bi(uint8_t *dst, const int16_t *p0, const int16_t *
 void ks265o_sao_est_iter_offset(int lambda_q8, int rate_base, int32_t *offset, int count, int diff_sum, int32_t *best_cost);
 int32_t ks265o_sao_bo_type_estimation(int lambda_q8, int32_t *count, int32_t *sum, int32_t *band, int32_t *offsets);
 int32_t ks265o_sao_eo_type_estimation(int lambda_q8, const int32_t *count, int32_t *sum, int32_t *offsets);
+void ks265o_sao_mode_decision(const int32_t *stats, int lam_y, int lam_c, int left_avail, int up_avail, const int8_t *left, const int8_t *up, int mask_y, int mask_uv, int8_t *out, int32_t *best);
 int ks265o_calc_bs(const int32_t *p /*3 words*/, const int32_t *q, int tu_edge, int is_b);
 void ks265o_est_bit_rdoq(int32_t *out /*180 words*/, int log2, int luma, const uint8_t *ctx, const int32_t *entropy /*128*/);
 uint32_t ks265o_inter_me_bi_full(int32_t *best, const uint8_t *org, const uint8_t *ref, int orgStride, int refStride, const uint16_t *mvcost, int h, int log2w, int use_had);

@@ -1479,41 +1479,24 @@ static const int32_t kLambdaSaoQ8[52] = {9, 12, 15, 19, 24, 31, 39, 50, 63, 79, 
 static int chroma_qp(int qp);
 static void sao_decide_ref(const sao_stats *st /*[3]*/, int qp, kso_sao_param *out /*[3]*/)
 {
-    const int32_t lamY = kLambdaSaoQ8[qp], lamC = kLambdaSaoQ8[chroma_qp(qp)];
-    for (int c = 0; c < 3; ++c) { memset(&out[c], 0, sizeof out[c]); out[c].type = -1; }
-    int32_t best = (lamY + 128) >> 8;
-    for (int cls = 0; cls < 2; ++cls) {
-        int32_t sum[4], off[4];
-        for (int k = 0; k < 4; ++k) sum[k] = st[0].sum[1 + cls][k];
-        const int32_t cost = ks265o_sao_eo_type_estimation(lamY, st[0].cnt[1 + cls], sum, off) + ((4 * lamY + 128) >> 8);
-        if (cost < best) { best = cost; out[0].type = (int8_t)(1 + cls); out[0].band = 0; for (int k = 0; k < 4; ++k) out[0].offset[k] = (int8_t)off[k]; }
+    /* the pinned restatement (ks265o_sao_mode_decision: replayed on 630 recorded calls, tests/golden/sao_decision.npz) on this CTU's statistics in the object's layout, no
+     * neighbour records: the candidates, their order, rates and lambdas are the reference's, the merge step is not taken */
+    int32_t stats[312];
+    int8_t rec[32];
+    memset(stats, 0, sizeof stats);
+    for (int c = 0; c < 3; ++c) {
+        for (int b = 0; b < 32; ++b) { stats[32 * c + b] = st[c].cnt[0][b]; stats[156 + 32 * c + b] = st[c].sum[0][b]; }
+        for (int cls = 0; cls < 2; ++cls)
+            for (int k = 0; k < 4; ++k) { stats[96 + 20 * c + 5 * cls + k] = st[c].cnt[1 + cls][k]; stats[156 + 96 + 20 * c + 5 * cls + k] = st[c].sum[1 + cls][k]; }
     }
-    {
-        int32_t cnt[32], sum[32], off[32], band = 0;
-        memcpy(cnt, st[0].cnt[0], sizeof cnt); memcpy(sum, st[0].sum[0], sizeof sum);
-        const int32_t cost = ks265o_sao_bo_type_estimation(lamY, cnt, sum, &band, off) + ((7 * lamY + 128) >> 8);
-        if (cost < best) { best = cost; out[0].type = 0; out[0].band = (int8_t)band; for (int k = 0; k < 4; ++k) out[0].offset[k] = (int8_t)off[band + k]; }
-    }
-    best = (lamC + 128) >> 8;
-    for (int cls = 0; cls < 2; ++cls) {
-        int32_t sum[2][4], off[2][4], cost = (4 * lamC + 128) >> 8;
-        for (int c = 0; c < 2; ++c) {
-            for (int k = 0; k < 4; ++k) sum[c][k] = st[1 + c].sum[1 + cls][k];
-            cost += ks265o_sao_eo_type_estimation(lamC, st[1 + c].cnt[1 + cls], sum[c], off[c]);
-        }
-        if (cost < best) {
-            best = cost;
-            for (int c = 0; c < 2; ++c) { out[1 + c].type = (int8_t)(1 + cls); out[1 + c].band = 0; for (int k = 0; k < 4; ++k) out[1 + c].offset[k] = (int8_t)off[c][k]; }
-        }
-    }
-    {
-        int32_t cnt[2][32], sum[2][32], off[2][32], band[2] = {0, 0}, cost = (12 * lamC + 128) >> 8;
-        for (int c = 0; c < 2; ++c) {
-            memcpy(cnt[c], st[1 + c].cnt[0], sizeof cnt[c]); memcpy(sum[c], st[1 + c].sum[0], sizeof sum[c]);
-            cost += ks265o_sao_bo_type_estimation(lamC, cnt[c], sum[c], &band[c], off[c]);
-        }
-        if (cost < best)
-            for (int c = 0; c < 2; ++c) { out[1 + c].type = 0; out[1 + c].band = (int8_t)band[c]; for (int k = 0; k < 4; ++k) out[1 + c].offset[k] = (int8_t)off[c][band[c] + k]; }
+    ks265o_sao_mode_decision(stats, kLambdaSaoQ8[qp], kLambdaSaoQ8[chroma_qp(qp)], 0, 0, NULL, NULL, 0x13, 0x13, rec, NULL);
+    for (int c = 0; c < 3; ++c) {
+        memset(&out[c], 0, sizeof out[c]);
+        const int t = rec[c ? 1 : 0];
+        out[c].type = (int8_t)(t == -1 ? -1 : t == 4 ? 0 : 1 + t);           /* this pipeline's codes: -1 off, 0 band offset, 1 + edge class */
+        if (t == -1) continue;
+        out[c].band = (int8_t)(t == 4 ? rec[c == 0 ? 2 : 2 + c] : 0);
+        for (int k = 0; k < 4; ++k) out[c].offset[k] = rec[(c == 0 ? 5 : c == 1 ? 0xa : 0xf) + k];
     }
 }
 
