@@ -335,6 +335,10 @@ typedef struct {
     int32_t tu_inter;          /* -intertu 1 (tuInter, qy265enc.h:133; veryslow, placebo: the residual quadtree of inter CUs one level deep): a 2Nx2N inter CU of 32 / 16 samples is coded with four
                                   transform units (split_transform_flag; ks265_cu8.log2_cu bits 4..5 = 3, set by ks265_reconstruct*) when its luma residual sits in part of it - the quarters'
                                   residual SADs under the CU's final motion: max > 4 x min + (N / 2)^2.  The reference decides this inside its RD loop (tuDecision enc@0x4825a0, closed code) */
+    int32_t skip_rd;           /* round 6 - Stage D2, the skip pass (ks265_skip_pass; run by ks265_encode_picture* after the reconstruction of the inter CUs): per CTU, top-down over the nodes of
+                                  64 / 32 / 16 / 8 samples that hold inter CUs only, the node becomes ONE CU without residual carrying a merge candidate's motion when SSE(source, that
+                                  prediction) + lambda x (1 + position) bits is below SSE(source, reconstruction) + lambda x (level + syntax bits) of what the node holds now - the decision on the
+                                  coded distortion the reference takes in skipFastDecision enc@0x486090 / skipFullMergeDecision enc@0x482da0 (closed code).  Needs the spare CU map (cfg.merge or this) */
 } ks265_frame_cfg;
 
 /* geometry of the padded picture buffers the caller allocates (one call, no allocation) */
@@ -419,6 +423,10 @@ int ks265_cu_decide_part_b(ks265_frame *f, ks265_pic src, ks265_pic ref0, ks265_
  * dev_pu for P pictures (ref1 = null picture), dev_pub for B pictures (the other NULL); cu_in and cu_out must differ (all CUs decide on the same input field). */
 int ks265_merge_pass(ks265_frame *f, ks265_pic src, ks265_pic ref0, ks265_pic ref1, const ks265_pu *dev_pu, const ks265_pu_b *dev_pub,
                      const ks265_cu8 *dev_cu_in, ks265_cu8 *dev_cu_out);
+/* Stage D2 (cfg.skip_rd; run by ks265_encode_picture[_b|_mref|_b_mref] itself, exported for stage tests): after ks265_reconstruct* - dev_cu8 with its coded-block flags, the
+ * level planes and the reconstruction are updated in place for the nodes that become one CU without residual; ref1 = null picture for P pictures; a multi-reference picture's
+ * context (ks265_encode_picture_mref / _b_mref) supplies the pictures of every candidate.  Intra CUs are not touched (and keep a node from being looked at). */
+int ks265_skip_pass(ks265_frame *f, ks265_pic src, ks265_pic ref0, ks265_pic ref1, ks265_cu8 *dev_cu8, int16_t *dev_lvl_y, int16_t *dev_lvl_u, int16_t *dev_lvl_v, ks265_pic recon);
 /* Stage C: CU quadtree decision from the PU costs (the bottom-up compare of processTree enc@0x4722a0) */
 int ks265_cu_decide(ks265_frame *f, const ks265_pu *dev_pu, ks265_cu8 *dev_cu8);
 /* Stage C': key picture — every CU 32x32-TU "flat" intra (pred = 128); stands in for the out-of-scope

@@ -60,7 +60,7 @@ int ks265_frame_create(ks265_ctx *ctx, const ks265_frame_cfg *cfg, ks265_frame *
     }
     if (!r && cfg->part) r = dev_alloc(ctx, &f->rect, (size_t)geom.ctu_cols * geom.ctu_rows * 21 * sizeof(KsRect), true);
     if (!r) r = dev_alloc(ctx, (void **)&f->cu8, (size_t)geom.bytes_cu8, true);
-    if (!r && cfg->merge) r = dev_alloc(ctx, (void **)&f->cu8_tmp, (size_t)geom.bytes_cu8, true);
+    if (!r && (cfg->merge || cfg->skip_rd)) r = dev_alloc(ctx, (void **)&f->cu8_tmp, (size_t)geom.bytes_cu8, true);      /* the CU decision's map in front of the merge pass; the skip pass's snapshot */
     if (!r) r = dev_alloc(ctx, (void **)&f->sao, (size_t)geom.bytes_sao, true);
     if (!r) r = dev_alloc(ctx, (void **)&f->lvl[0], npx * 2, true);
     if (!r) r = dev_alloc(ctx, (void **)&f->lvl[1], npx / 2, true);
@@ -185,6 +185,7 @@ int ks265_encode_picture(ks265_frame *f, ks265_pic src, ks265_pic ref, int is_ke
         } else if ((r = part ? ks265_cu_decide_part(f, src, ref, pu, ii ? f->icost : nullptr, f->cu8) : ks265_cu_decide_ii(f, pu, ii ? f->icost : nullptr, f->cu8))) return r;
         mark(4);
         if ((r = ks265_reconstruct(f, src, ref, f->cu8, f->lvl[0], f->lvl[1], f->lvl[2], deb))) return r;
+        if (f->cfg.skip_rd && (r = ks265_skip_pass(f, src, ref, ks265_pic{nullptr, nullptr, nullptr}, f->cu8, f->lvl[0], f->lvl[1], f->lvl[2], deb))) return r;   /* stage D2: on the coded distortion */
         mark(5);
         if (ii && (r = ks265_intra_inter_reconstruct(f, src, f->cu8, f->lvl[0], f->lvl[1], f->lvl[2], deb))) return r;
     }
@@ -249,15 +250,17 @@ int ks265_encode_picture_mref(ks265_frame *f, ks265_pic src, const ks265_pic *re
     if ((r = records_fence(f))) return r;
     const bool mg = f->cfg.merge && f->cu8_tmp;
     if ((r = ks265_cu_decide_b_ii(f, f->pub, ii ? f->icost : nullptr, mg ? f->cu8_tmp : f->cu8))) return r;
-    if (mg) {
-        /* the merge pass takes a candidate's picture from its record (the multi-reference form); list 1 does not exist: mr_pslice makes the zero candidate uni-directional */
+    /* the merge pass and the skip pass take a candidate's picture from its record (the multi-reference form); list 1 does not exist: mr_pslice makes the zero candidate uni-directional */
+    auto mr_scope = [&](auto &&body) -> int {
         struct MrScope { ks265_frame *f; ~MrScope() { f->mrefb = false; f->mr_pslice = false; } } scope{f};
         f->mrefb = true; f->mr_pslice = true; f->mr_n[0] = nref; f->mr_n[1] = 1;
         for (int i = 0; i < 4; ++i) { f->mr_pic[0][i] = refs[i < nref ? i : nref - 1]; f->mr_pic[1][i] = refs[0]; }
-        if ((r = ks265_merge_pass(f, src, refs[0], refs[0], nullptr, f->pub, f->cu8_tmp, f->cu8))) return r;
-    }
+        return body();
+    };
+    if (mg && (r = mr_scope([&] { return ks265_merge_pass(f, src, refs[0], refs[0], nullptr, f->pub, f->cu8_tmp, f->cu8); }))) return r;
     ks265_pic deb = ks_deb_pic(f);
     if ((r = ks265_reconstruct_mref(f, src, nref, refs, f->cu8, f->lvl[0], f->lvl[1], f->lvl[2], deb))) return r;
+    if (f->cfg.skip_rd && f->cu8_tmp && (r = mr_scope([&] { return ks265_skip_pass(f, src, refs[0], ks265_pic{nullptr, nullptr, nullptr}, f->cu8, f->lvl[0], f->lvl[1], f->lvl[2], deb); }))) return r;
     if (ii && (r = ks265_intra_inter_reconstruct(f, src, f->cu8, f->lvl[0], f->lvl[1], f->lvl[2], deb))) return r;
     if (f->cfg.deblock && (r = ks265_deblock(f, f->cu8, deb))) return r;
     if ((r = ks265_sao(f, src, deb, f->sao, recon_out))) return r;
@@ -357,6 +360,7 @@ static int encode_b_lists(ks265_frame *f, ks265_pic src, const ks265_pic *refs0,
     if (f->cfg.merge && (r = ks265_merge_pass(f, src, ref0, ref1, nullptr, f->pub, f->cu8_tmp, f->cu8))) return r;
     ks265_pic deb = ks_deb_pic(f);
     if ((r = ks265_reconstruct_b(f, src, ref0, ref1, f->cu8, f->lvl[0], f->lvl[1], f->lvl[2], deb))) return r;
+    if (f->cfg.skip_rd && (r = ks265_skip_pass(f, src, ref0, ref1, f->cu8, f->lvl[0], f->lvl[1], f->lvl[2], deb))) return r;
     if (ii && (r = ks265_intra_inter_reconstruct(f, src, f->cu8, f->lvl[0], f->lvl[1], f->lvl[2], deb))) return r;
     if (f->cfg.deblock && (r = ks265_deblock(f, f->cu8, deb))) return r;
     return ks265_sao(f, src, deb, f->sao, recon_out);

@@ -27,7 +27,7 @@ SAO_PARAM = np.dtype([("type", "i1"), ("band", "i1"), ("offset", "i1", 4), ("rsv
 
 class FrameCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("width", "height", "qp", "lambda_q4", "me_range", "me_method", "subme", "deblock", "sao",
-                                          "beta_offset_div2", "tc_offset_div2", "bframes", "refs", "me_hex_thr", "sdh", "pre_search", "merge", "bi_refine", "decimate", "rdo", "intra_inter", "propagate", "sub_satd", "sub_thr", "sub_flat", "sub_cap", "sub_cap_step", "sub_diag_fast", "part", "tu_inter")]
+                                          "beta_offset_div2", "tc_offset_div2", "bframes", "refs", "me_hex_thr", "sdh", "pre_search", "merge", "bi_refine", "decimate", "rdo", "intra_inter", "propagate", "sub_satd", "sub_thr", "sub_flat", "sub_cap", "sub_cap_step", "sub_diag_fast", "part", "tu_inter", "skip_rd")]
 
 
 class FrameGeom(C.Structure):
@@ -59,7 +59,7 @@ EXPORTS = [
     "ks265_sao_apply_bo_rect", "ks265_sao_apply_eo_rect", "ks265_sao_stats_batch", "ks265_intra_pred_batch", "ks265_intra_filter_ref_batch",
     "ks265_downsample_rect", "ks265_downsample_from_host", "ks265_weight_bi_sad_batch", "ks265_ac_energy_batch", "ks265_ac_energy_map",
     "ks265_frame_reset_prediction", "ks265_frame_records_layout", "ks265_frame_pack_records", "ks265_frame_compact_layout", "ks265_frame_pack_compact", "ks265_frame_pack_compact_on", "ks265_frame_adapt_quant", "ks265_aq_ctu_map", "ks265_cutree_propagate", "ks265_calc_frame_cost", "ks265_calc_frame_cost_workspace", "ks265_cutree_finish", "ks265_host_register", "ks265_memcpy_h2d_sync", "ks265_host_unregister", "ks265_pad_plane", "ks265_fill_u16", "ks265_qoff_ctu_map", "ks265_frame_set_records_fence", "ks265_load_i420_on", "ks265_sse_picture_on", "ks265_copy_out_compact_async", "ks265_copy_out_compact_dma_async", "ks265_frame_geometry", "ks265_frame_create", "ks265_frame_destroy", "ks265_frame_set_qp", "ks265_frame_set_qp_map", "ks265_frame_set_rdoq", "ks265_pad_picture",
-    "ks265_load_i420", "ks265_store_i420", "ks265_presearch", "ks265_me_integer", "ks265_me_propagate", "ks265_me_subpel", "ks265_cu_decide_part", "ks265_cu_decide_part_b", "ks265_merge_pass", "ks265_cu_decide",
+    "ks265_load_i420", "ks265_store_i420", "ks265_presearch", "ks265_me_integer", "ks265_me_propagate", "ks265_me_subpel", "ks265_cu_decide_part", "ks265_cu_decide_part_b", "ks265_merge_pass", "ks265_skip_pass", "ks265_cu_decide",
     "ks265_cu_flat_intra", "ks265_intra_decide", "ks265_intra_decide_ex", "ks265_lookahead_reduce", "ks265_lookahead_picture", "ks265_lookahead_inter", "ks265_intra_reconstruct", "ks265_reconstruct", "ks265_reconstruct_b", "ks265_bi_decide", "ks265_bi_refine_chosen", "ks265_bi_full_batch", "ks265_capture_begin", "ks265_capture_end", "ks265_graph_launch", "ks265_graph_destroy", "ks265_frame_p_state", "ks265_frame_p_advance", "ks265_frame_p_restore", "ks265_cu_decide_b", "ks265_deblock", "ks265_sao",
     "ks265_encode_picture", "ks265_encode_picture_b", "ks265_encode_picture_mref", "ks265_encode_picture_b_mref", "ks265_ref_pick", "ks265_ref_decide", "ks265_reconstruct_mref",
     "ks265_intra_candidates", "ks265_cu_decide_ii", "ks265_cu_decide_b_ii", "ks265_intra_inter_reconstruct", "ks265_frame_set_profiling", "ks265_frame_stage_ms", "ks265_frame_me_int_ms", "ks265_frame_levels", "ks265_frame_pu", "ks265_frame_cu8", "ks265_frame_ibest", "ks265_frame_sao", "ks265_sse_picture",
@@ -327,9 +327,9 @@ class KsFrame:
 
     def __init__(self, ks: KsContext, width: int, height: int, qp: int, lambda_q4: int, me_range: int = 64, subme: int = 1,
                  deblock: int = 1, sao: int = 1, me_method: int = 0, bframes: int = 0, refs: int = 1, me_hex_thr: int = 0, sdh: int = 0, pre_search: int = 0, merge: int = 0, bi_refine: int = 0, decimate: int = 0, rdo: int = 0, intra_inter: int = 0, propagate: int = 0,
-                 sub_satd: int = 0, sub_thr: int = 24, sub_flat: int = 8, sub_cap: int = 0, sub_cap_step: int = 0, sub_diag_fast: int = 0, part: int = 0, tu_inter: int = 0):     # the sub-pel knobs of -preset slow (synth.SUBME_PRESET)
+                 sub_satd: int = 0, sub_thr: int = 24, sub_flat: int = 8, sub_cap: int = 0, sub_cap_step: int = 0, sub_diag_fast: int = 0, part: int = 0, tu_inter: int = 0, skip_rd: int = 0):     # the sub-pel knobs of -preset slow (synth.SUBME_PRESET)
         self.ks, self.lib = ks, ks.lib
-        self.cfg = FrameCfg(width, height, qp, lambda_q4, me_range, me_method, subme, deblock, sao, 0, 0, bframes, refs, me_hex_thr, sdh, pre_search, merge, bi_refine, decimate, rdo, intra_inter, propagate, sub_satd, sub_thr, sub_flat, sub_cap, sub_cap_step, sub_diag_fast, part, tu_inter)
+        self.cfg = FrameCfg(width, height, qp, lambda_q4, me_range, me_method, subme, deblock, sao, 0, 0, bframes, refs, me_hex_thr, sdh, pre_search, merge, bi_refine, decimate, rdo, intra_inter, propagate, sub_satd, sub_thr, sub_flat, sub_cap, sub_cap_step, sub_diag_fast, part, tu_inter, skip_rd)
         self.geom = FrameGeom()
         ks._chk(self.lib.ks265_frame_geometry(C.byref(self.cfg), C.byref(self.geom)))
         h = C.c_void_p()
@@ -435,6 +435,10 @@ class KsFrame:
 
     def reconstruct_b(self, src: DevPic, ref0: DevPic, ref1: DevPic, cu8, lvl, recon: DevPic):
         self.ks._chk(self.lib.ks265_reconstruct_b(self.h, src.c(), ref0.c(), ref1.c(), _p(cu8), _p(lvl[0]), _p(lvl[1]), _p(lvl[2]), recon.c()))
+
+    def skip_pass(self, src: DevPic, ref0: DevPic, ref1: "DevPic | None", cu8, lvl, recon: DevPic):
+        """stage D2 after reconstruct[_b]: cu8 / lvl / recon updated in place (ref1 None: a P picture)"""
+        self.ks._chk(self.lib.ks265_skip_pass(self.h, src.c(), ref0.c(), ref1.c() if ref1 is not None else Pic(None, None, None), _p(cu8), _p(lvl[0]), _p(lvl[1]), _p(lvl[2]), recon.c()))
 
     def bi_decide(self, src: DevPic, ref0: DevPic, ref1: DevPic, pu0, pu1, pub):
         self.ks._chk(self.lib.ks265_bi_decide(self.h, src.c(), ref0.c(), ref1.c(), _p(pu0), _p(pu1), _p(pub)))

@@ -45,7 +45,7 @@ I = C.c_int
 # ------------------------------------------------------------------ pipeline oracle (ks265_pipeline_oracle.h)
 class OFrameCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("width", "height", "qp", "lambda_q4", "me_range", "me_method", "subme", "deblock", "sao",
-                                          "beta_offset_div2", "tc_offset_div2", "bframes", "refs", "me_hex_thr", "sdh", "pre_search", "merge", "bi_refine", "decimate", "rdo", "intra_inter", "propagate", "sub_satd", "sub_thr", "sub_flat", "sub_cap", "sub_cap_step", "sub_diag_fast", "part", "tu_inter")]
+                                          "beta_offset_div2", "tc_offset_div2", "bframes", "refs", "me_hex_thr", "sdh", "pre_search", "merge", "bi_refine", "decimate", "rdo", "intra_inter", "propagate", "sub_satd", "sub_thr", "sub_flat", "sub_cap", "sub_cap_step", "sub_diag_fast", "part", "tu_inter", "skip_rd")]
 
 
 class OFrameGeom(C.Structure):
@@ -85,10 +85,13 @@ class OraclePipeline:
     """CPU restatement of the frame stages (test checker / cpu_baseline 'port')."""
 
     def __init__(self, width, height, qp, lambda_q4, me_range=64, subme=1, deblock=1, sao=1, me_method=0, intra=True, me_hex_thr=0, sdh=0, pre_search=0, merge=0, bi_refine=0, decimate=0, rdo=0, intra_inter=0, propagate=0,
-                 sub_satd=0, sub_thr=24, sub_flat=8, sub_cap=0, sub_cap_step=0, sub_diag_fast=0, part=0, tu_inter=0):
+                 sub_satd=0, sub_thr=24, sub_flat=8, sub_cap=0, sub_cap_step=0, sub_diag_fast=0, part=0, tu_inter=0, skip_rd=0):
         self.o = lib()
         self.intra = intra                      # key pictures: real intra prediction (True) or the flat stand-in
-        self.cfg = OFrameCfg(width, height, qp, lambda_q4, me_range, me_method, subme, deblock, sao, 0, 0, 1, 4, me_hex_thr, sdh, pre_search, merge, bi_refine, decimate, rdo, intra_inter, propagate, sub_satd, sub_thr, sub_flat, sub_cap, sub_cap_step, sub_diag_fast, part, tu_inter)
+        self.skip_rd = int(os.environ.get("RD_SKIP", skip_rd))         # (RD_SKIP / RD_SKIP_PARAMS: experiment hooks of tools/rd_eval.py)
+        if os.environ.get("RD_SKIP_PARAMS"):
+            self.o.kso_experiment_skip((C.c_int * 8)(*[int(x) for x in os.environ["RD_SKIP_PARAMS"].split(",")]))
+        self.cfg = OFrameCfg(width, height, qp, lambda_q4, me_range, me_method, subme, deblock, sao, 0, 0, 1, 4, me_hex_thr, sdh, pre_search, merge, bi_refine, decimate, rdo, intra_inter, propagate, sub_satd, sub_thr, sub_flat, sub_cap, sub_cap_step, sub_diag_fast, part, tu_inter, self.skip_rd)
         self.geom = OFrameGeom()
         assert self.o.kso_frame_geometry(C.byref(self.cfg), C.byref(self.geom)) == 0
         g = self.geom
@@ -102,6 +105,34 @@ class OraclePipeline:
         self.lvl = [np.zeros(width * height, np.int16), np.zeros(width * height // 4, np.int16), np.zeros(width * height // 4, np.int16)]
         self.src, self.rec, self.deb = HostPic(g), HostPic(g), HostPic(g)
         self.ref = HostPic(g)
+
+    def skip_pass(self, r0: OPic, r1: OPic) -> None:
+        """stage D2 (round 6): after the reconstruction of the inter CUs - nodes whose merge candidate without residual is the cheaper coding become one CU (kso_skip_pass)"""
+        tmp = self.cu8.copy()
+        self.cu_pre_skip = tmp
+        self.o.kso_skip_pass(C.byref(self.cfg), self.src.c(), r0, r1, ptr(tmp), ptr(self.cu8), ptr(self.lvl[0]), ptr(self.lvl[1]), ptr(self.lvl[2]), self.rec.c())
+        if os.environ.get("RD_SKIP_DEBUG"):
+            w8, h8 = self.cfg.width // 8, self.cfg.height // 8
+            a, b = tmp.reshape(h8, w8), self.cu8.reshape(h8, w8)
+            n = m = 0
+            for y in range(h8):
+                for x in range(w8):
+                    c = b[y, x]
+                    if c == a[y, x] or c["pred_mode"] != 0:
+                        continue
+                    n8 = 1 << (int(c["log2_cu"] & 15) - 3)
+                    if (x & (n8 - 1)) or (y & (n8 - 1)):
+                        continue
+                    n += 1
+                    key = lambda q: (int(q["mvx"]), int(q["mvy"]), int(q["mv1x"]), int(q["mv1y"]), int(q["inter_dir"]))
+                    cands = []
+                    if x > 0: cands.append(b[y + n8 - 1, x - 1])
+                    if y > 0: cands.append(b[y - 1, x + n8 - 1])
+                    if y > 0 and x + n8 < w8 and ((x + n8) % 8 != 0 or True): cands.append(b[y - 1, x + n8])
+                    if x > 0 and y > 0: cands.append(b[y - 1, x - 1])
+                    ok = any(q["pred_mode"] == 0 and key(q) == key(c) for q in cands) or key(c)[:4] == (0, 0, 0, 0)
+                    m += ok
+            print(f"      skip pass: {n} union CUs, {m} of them with a final-field neighbour (A1/B1/B0/B2) of the same motion or zero", flush=True)
 
     def set_qp(self, qp, lambda_q4):
         self.cfg.qp, self.cfg.lambda_q4 = qp, lambda_q4
@@ -207,6 +238,8 @@ class OraclePipeline:
         else:
             o.kso_reconstruct(cfg, self.src.c(), r0, ptr(self.planes), r1, p1, ptr(self.cu8), ptr(self.lvl[0]), ptr(self.lvl[1]), ptr(self.lvl[2]),
                               self.rec.c())
+            if self.skip_rd and kind != "I":
+                self.skip_pass(r0, r1)
             if self.cfg.intra_inter:
                 o.kso_intra_inter_reconstruct(cfg, self.src.c(), ptr(self.cu8), ptr(self.lvl[0]), ptr(self.lvl[1]), ptr(self.lvl[2]), self.rec.c())
         self.rec_pre = [self.rec.y.copy(), self.rec.u.copy(), self.rec.v.copy()]
@@ -275,6 +308,8 @@ class OraclePipeline:
             ref_arr = (OPic * mr.n0)(*[r.c() for r in refs0])
             pl_arr = (C.c_void_p * mr.n0)(*[p.ctypes.data for p in self.mr_planes[0][:mr.n0]])
             o.kso_reconstruct_mref(cfg, self.src.c(), C.c_int(mr.n0), ref_arr, pl_arr, ptr(self.cu8), ptr(self.lvl[0]), ptr(self.lvl[1]), ptr(self.lvl[2]), self.rec.c())
+            if self.skip_rd:
+                self.skip_pass(refs0[0].c(), refs1[0].c())
             if self.cfg.intra_inter:
                 o.kso_intra_inter_reconstruct(cfg, self.src.c(), ptr(self.cu8), ptr(self.lvl[0]), ptr(self.lvl[1]), ptr(self.lvl[2]), self.rec.c())
         finally:
@@ -332,6 +367,17 @@ class OraclePipeline:
         ref_arr = (OPic * n)(*[r.c() for r in refs])
         pl_arr = (C.c_void_p * n)(*[p.ctypes.data for p in planes])
         o.kso_reconstruct_mref(cfg, self.src.c(), C.c_int(n), ref_arr, pl_arr, ptr(self.cu8), ptr(self.lvl[0]), ptr(self.lvl[1]), ptr(self.lvl[2]), self.rec.c())
+        if self.skip_rd:
+            mr = OMref()
+            mr.n0, mr.n1 = n, 0
+            for i in range(4):
+                mr.planes0[i] = planes[min(i, n - 1)].ctypes.data; mr.planes1[i] = planes[0].ctypes.data
+                mr.pic0[i] = refs[min(i, n - 1)].c(); mr.pic1[i] = refs[0].c()
+            o.kso_set_mref(C.byref(mr))
+            try:
+                self.skip_pass(refs[0].c(), OPic(None, None, None))
+            finally:
+                o.kso_set_mref(None)
         if ii:
             o.kso_intra_inter_reconstruct(cfg, self.src.c(), ptr(self.cu8), ptr(self.lvl[0]), ptr(self.lvl[1]), ptr(self.lvl[2]), self.rec.c())
         self.rec_pre = [self.rec.y.copy(), self.rec.u.copy(), self.rec.v.copy()]

@@ -57,6 +57,13 @@ CASES = {
     # tool set (intra candidates against the two-list records, merge pass on the records' pictures, intra CUs), three mini-GOPs so that the last anchor has three pictures
     "enc_hiera3_416x240_bir2": (416, 240, 29, 2, 16, 1, 1, "hiera", 4),
     "enc_hiera3_200x136_qp34_bir2": (200, 136, 34, 1, 0, 1, 1, "hiera", 4),
+    # round 6: cfg.skip_rd (stage D2, what the C host runs from round 6 on): after the reconstruction, nodes whose merge candidate without residual is the cheaper coding become one CU -
+    # P pictures, B pictures, multi-reference anchors, multi-reference B pictures with -part 1 / -intertu 1 around them
+    "enc_ippp_416x240_umh_skip": (416, 240, 27, 2, 16, 1, 1, "ippph", 4),
+    "enc_hierb4_416x240_skip_bir2": (416, 240, 30, 1, 0, 1, 1, "hier", 4),
+    "enc_hiera3_416x240_skip_bir2": (416, 240, 29, 2, 16, 1, 1, "hiera", 4),
+    "enc_hiera3_200x136_qp34_skip_bir2": (200, 136, 34, 1, 0, 1, 1, "hiera", 4),
+    "rqt_part_hiermr4_200x136_skip_bir2": (200, 136, 31, 1, 0, 1, 1, "hiermr", 4),
 }
 
 
@@ -66,6 +73,10 @@ def case_part(name: str) -> int:
 
 def case_rqt(name: str) -> int:
     return 1 if name.startswith("rqt_") else 0
+
+
+def case_skip(name: str) -> int:
+    return 1 if "_skip" in name else 0
 
 
 def case_sdh(name: str) -> int:
@@ -219,7 +230,7 @@ def oracle_encoder(name: str):
     W, H, qp, me, thr, sao, df, kind, par = CASES[name]
     n = 1 + max(s[0] for s in schedule(kind, par))
     clip = make_clip(W, H, n, seed=len(name) * 7 + W, abc=(17, 23, 9))
-    o = OraclePipeline(W, H, qp, lambda_q4(qp), me_method=me, me_hex_thr=thr, sao=sao, deblock=df, sdh=case_sdh(name), pre_search=case_ps(name), merge=case_merge(name), bi_refine=case_bir(name), decimate=case_dec(name), rdo=case_rdo(name), intra_inter=case_ii(name), propagate=case_prop(name), part=case_part(name), tu_inter=case_rqt(name), **case_subme(name))
+    o = OraclePipeline(W, H, qp, lambda_q4(qp), me_method=me, me_hex_thr=thr, sao=sao, deblock=df, sdh=case_sdh(name), pre_search=case_ps(name), merge=case_merge(name), bi_refine=case_bir(name), decimate=case_dec(name), rdo=case_rdo(name), intra_inter=case_ii(name), propagate=case_prop(name), part=case_part(name), tu_inter=case_rqt(name), skip_rd=case_skip(name), **case_subme(name))
     dpb = {}
 
     def encode(d, k, l0, l1, q):

@@ -41,7 +41,7 @@ def test_struct_layouts_match_header(lib):
     assert L.BLK.itemsize == 16 and L.BLK3.itemsize == 24 and L.EDGE.itemsize == 12 and L.SAO_RECT.itemsize == 16
     assert L.PU.itemsize == 16 and L.CU8.itemsize == 12 and L.PU_B.itemsize == 16 and L.SAO_PARAM.itemsize == 8
     assert L.INTRA_BLK.itemsize == 16 and L.INTRA_REF.itemsize == 16
-    assert C.sizeof(L.FrameCfg) == 120 and C.sizeof(L.FrameGeom) == 80         # 30 x int32 (..., rdo, intra_inter, propagate, sub_satd, sub_thr, sub_flat, sub_cap, sub_cap_step, sub_diag_fast, part, tu_inter)
+    assert C.sizeof(L.FrameCfg) == 124 and C.sizeof(L.FrameGeom) == 80         # 31 x int32 (..., rdo, intra_inter, propagate, sub_satd, sub_thr, sub_flat, sub_cap, sub_cap_step, sub_diag_fast, part, tu_inter, skip_rd)
 
 
 def test_geometry_and_argument_errors_without_gpu(lib):
@@ -85,7 +85,7 @@ def test_header_is_plain_c(tmp_path):
     import subprocess
     src = tmp_path / "h.c"
     src.write_text('#include "ks265_hip.h"\nint main(void) { ks265_frame_cfg c = {0}; (void)c;\n'
-                   '  return sizeof(ks265_intra_blk) == 16 && sizeof(ks265_cu8) == 12 && sizeof(ks265_pu) == 16 && sizeof(ks265_frame_cfg) == 120 ? 0 : 1; }\n')
+                   '  return sizeof(ks265_intra_blk) == 16 && sizeof(ks265_cu8) == 12 && sizeof(ks265_pu) == 16 && sizeof(ks265_frame_cfg) == 124 ? 0 : 1; }\n')
     exe = tmp_path / "h"
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     assert subprocess.call([str(exe)]) == 0

@@ -10,7 +10,7 @@ import os
 import numpy as np
 import pytest
 
-from stream_cases import CASES, case_bir, case_dec, case_ii, case_lambda, case_merge, case_prop, case_ps, case_rdo, case_part, case_rqt, case_sdh, case_subme, make_stream, schedule
+from stream_cases import CASES, case_bir, case_dec, case_ii, case_lambda, case_merge, case_prop, case_ps, case_rdo, case_part, case_rqt, case_sdh, case_skip, case_subme, make_stream, schedule
 
 pytestmark = pytest.mark.gpu
 GOLD = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "stream_md5.json")))
@@ -31,7 +31,7 @@ def hip_encoder(ks, name):
     n = 1 + max(s[0] for s in schedule(kind, par))
     clip = make_clip(W, H, n, seed=len(name) * 7 + W, abc=(17, 23, 9))
     f = KsFrame(ks, W, H, qp, lambda_q4(qp), me_method=me, me_hex_thr=thr, sao=sao, deblock=df, bframes=3 if kind in ("hier", "hiermr", "hiera") else 0, refs=par if kind == "mref" else 2 if kind == "hiermr" else 3 if kind == "hiera" else 1,
-                sdh=case_sdh(name), pre_search=case_ps(name), merge=case_merge(name), bi_refine=case_bir(name), decimate=case_dec(name), rdo=case_rdo(name), intra_inter=case_ii(name), propagate=case_prop(name), part=case_part(name), tu_inter=case_rqt(name), **case_subme(name))
+                sdh=case_sdh(name), pre_search=case_ps(name), merge=case_merge(name), bi_refine=case_bir(name), decimate=case_dec(name), rdo=case_rdo(name), intra_inter=case_ii(name), propagate=case_prop(name), part=case_part(name), tu_inter=case_rqt(name), skip_rd=case_skip(name), **case_subme(name))
     g = f.geom
     src = f.new_pic()
     dpb = {}
