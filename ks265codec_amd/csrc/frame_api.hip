@@ -185,7 +185,7 @@ int ks265_encode_picture(ks265_frame *f, ks265_pic src, ks265_pic ref, int is_ke
         } else if ((r = part ? ks265_cu_decide_part(f, src, ref, pu, ii ? f->icost : nullptr, f->cu8) : ks265_cu_decide_ii(f, pu, ii ? f->icost : nullptr, f->cu8))) return r;
         mark(4);
         if ((r = ks265_reconstruct(f, src, ref, f->cu8, f->lvl[0], f->lvl[1], f->lvl[2], deb))) return r;
-        if (f->cfg.skip_rd && (r = ks265_skip_pass(f, src, ref, ks265_pic{nullptr, nullptr, nullptr}, f->cu8, f->lvl[0], f->lvl[1], f->lvl[2], deb))) return r;   /* stage D2: on the coded distortion */
+        if (f->cfg.skip_rd >= 2 && (r = ks265_skip_pass(f, src, ref, ks265_pic{nullptr, nullptr, nullptr}, f->cu8, f->lvl[0], f->lvl[1], f->lvl[2], deb))) return r;   /* stage D2: on the coded distortion (1: B pictures only) */
         mark(5);
         if (ii && (r = ks265_intra_inter_reconstruct(f, src, f->cu8, f->lvl[0], f->lvl[1], f->lvl[2], deb))) return r;
     }
@@ -260,7 +260,7 @@ int ks265_encode_picture_mref(ks265_frame *f, ks265_pic src, const ks265_pic *re
     if (mg && (r = mr_scope([&] { return ks265_merge_pass(f, src, refs[0], refs[0], nullptr, f->pub, f->cu8_tmp, f->cu8); }))) return r;
     ks265_pic deb = ks_deb_pic(f);
     if ((r = ks265_reconstruct_mref(f, src, nref, refs, f->cu8, f->lvl[0], f->lvl[1], f->lvl[2], deb))) return r;
-    if (f->cfg.skip_rd && f->cu8_tmp && (r = mr_scope([&] { return ks265_skip_pass(f, src, refs[0], ks265_pic{nullptr, nullptr, nullptr}, f->cu8, f->lvl[0], f->lvl[1], f->lvl[2], deb); }))) return r;
+    if (f->cfg.skip_rd >= 2 && f->cu8_tmp && (r = mr_scope([&] { return ks265_skip_pass(f, src, refs[0], ks265_pic{nullptr, nullptr, nullptr}, f->cu8, f->lvl[0], f->lvl[1], f->lvl[2], deb); }))) return r;
     if (ii && (r = ks265_intra_inter_reconstruct(f, src, f->cu8, f->lvl[0], f->lvl[1], f->lvl[2], deb))) return r;
     if (f->cfg.deblock && (r = ks265_deblock(f, f->cu8, deb))) return r;
     if ((r = ks265_sao(f, src, deb, f->sao, recon_out))) return r;

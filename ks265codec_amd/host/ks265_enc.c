@@ -1511,8 +1511,9 @@ static Enc *lane_open(QY265EncConfig *cfg, int device, int multi, int *err)
                                                                          * integer search (measured with one round: - 21 .. - 23 % bytes of the P / B pictures; the variable is a measuring aid) */
     e->fcfg.intra_inter = 1;                                            /* P / B pictures may hold intra CUs (uncovered regions, occlusions); 2 = none of 8x8: measured + 1.6 % bits, no faster */
     e->fcfg.rdo = 4;                                                    /* coefficient-group pruning at lambda x 1 (ks265_frame_cfg.rdo): supersedes the coefficient decimation of round 2 */
-    e->fcfg.skip_rd = getenv("KS265_SKIP_RD") ? atoi(getenv("KS265_SKIP_RD")) & 1 : 1;   /* stage D2 (round 6): after the reconstruction, nodes whose merge candidate without residual is the
-                                                                         * cheaper coding - on the coded distortion - become one CU (ks265_frame_cfg.skip_rd; the variable is a measuring aid) */
+    e->fcfg.skip_rd = getenv("KS265_SKIP_RD") ? atoi(getenv("KS265_SKIP_RD")) & 3 : 1;   /* stage D2 (round 6): after the reconstruction of a B picture, nodes whose merge candidate without
+                                                                         * residual is the cheaper coding - on the coded distortion - become one CU (ks265_frame_cfg.skip_rd; 2 = P pictures
+                                                                         * too, where it gains nothing measurable; the variable is a measuring aid) */
     e->fcfg.tu_inter = cfg->tuInter > 0 ? 1 : 0;                        /* -intertu N (tuInter; veryslow 1, placebo 2): the residual quadtree of inter CUs ONE level deep (ks265_frame_cfg.tu_inter); deeper values run as 1 */
     e->fcfg.part = cfg->part ? 1 : 0;                                   /* -part 1 (slower, veryslow, placebo): 2NxN / Nx2N prediction units in P and B pictures (ks265_frame_cfg.part) */
     e->fcfg.bi_refine = getenv("KS265_BI_REFINE") ? atoi(getenv("KS265_BI_REFINE")) : 2;   /* (2, round 5: after the CU decision, for the CUs it chose - the same bytes within 0.04 %, a third of the time; 1 = for every PU of the quadtree) */                                              /* B pictures: joint refinement of the bi-predictive pair (motionSearchBI enc@0x484910) */

@@ -1317,23 +1317,22 @@ void kso_reconstruct_mref(const kso_frame_cfg *cfg, kso_pic src, int nref, const
 }
 
 /* ------------------------------------------------------------------ Stage D2: skip pass (cfg->skip_rd; round 6)
- * The reference decides skip / merge / CU size on the distortion the coded block really has (skipFastDecision enc@0x486090, skipFullMergeDecision enc@0x482da0,
- * tuDecisionSkipMerge enc@0x482990 under processCuMdInter enc@0x485800: closed code).  The CU tree and the merge pass of this pipeline judge on Hadamard cost + rate, which
- * cannot know that a residual quantises to nothing: they reward small CUs whose vectors fit noise.  This pass runs AFTER the reconstruction, where both sides of the
- * comparison exist: per CTU, top-down over the nodes of 64 / 32 / 16 (/ 8) samples that lie inside the picture and hold inter CUs only,
- *   J_cur  = SSE(source, reconstruction) of Y + Cb + Cr  +  lambda x (bits of the levels in the node + the syntax of its CUs)
- *   J_skip = min over the node's merge candidates k (A1 B1 B0 A0 B2 of H.265 8.5.3.2.3 at the node's geometry + the zero vector, taken from the field the pass reads -
- *            as in the merge pass) of  SSE(source, prediction with k's motion) of Y + Cb + Cr  +  lambda x (1 + position of k) bits
- * and J_skip < J_cur turns the node into ONE CU without residual carrying k's motion: its levels are cleared, its reconstruction becomes the prediction (the exact one:
- * bi-prediction from the 14-bit intermediates), its descendants are not looked at.  The prediction of a node is exact, its distortion therefore too; the bits are estimates:
- * levels as the coefficient-group pruning prices them (rdo_level_q2 + 10 + 16 - n per 4 x 4 group, quarter bits), a CU without residual 2 bits, with residual 6, 1.25 per
- * CU below the node for the split flags.  lambda_mode = (lambda_q4 / 16)^2: J x 1024 = SSE << 10 + lambda_q4^2 x quarter bits.  All nodes of all CTUs decide on the same
- * input field (cu_in -> cu_out): no order; a node whose adopted motion is no longer a merge candidate when the slice is written is coded with explicit motion and
- * rqt_root_cbf = 0.  Nodes that are one CU without residual already are left alone. */
-static int g_sp[8] = {8, 24, 5, 4, 4, 16, 2, 4};         /* syntax of a CU without / with residual, per CU below the node, skip base, per position (quarter bits); lambda scale (1/16); deepest level looked at; weight of the chroma distortion (1/4) */
+ * The reference decides skip / merge on the distortion the coded block really has (skipFastDecision enc@0x486090, skipFullMergeDecision enc@0x482da0, tuDecisionSkipMerge
+ * enc@0x482990 under processCuMdInter enc@0x485800: closed code).  The CU tree and the merge pass of this pipeline judge on Hadamard cost + rate, which cannot know what a
+ * residual costs and what it buys.  This pass runs AFTER the reconstruction, where both sides of the comparison exist.  Every inter CU that carries residual:
+ *   J_cur  = SSE(source, reconstruction) of Y + 4 (Cb + Cr)  +  lambda x (bits of the CU's levels + 6)
+ *   J_skip = min over the first two DISTINCT merge candidates k (of A1 B1 B0 A0 B2 of H.265 8.5.3.2.3 + the zero vector, taken from the field the pass reads - as in the
+ *            merge pass: no order between CUs) of  SSE(source, prediction with k's motion) of Y + 4 (Cb + Cr)  +  lambda x (1 + position of k) bits
+ * and J_skip < J_cur makes the CU a 2Nx2N CU without residual carrying k's motion: levels cleared, reconstruction = the prediction (the exact one: bi-prediction from the
+ * 14-bit intermediates).  Distortions are exact, bits estimates: levels as the coefficient-group pruning prices them (rdo_level_q2 + 10 + 16 - n per 4 x 4 group, quarter
+ * bits).  lambda = 1.5 x lambda_mode = 1.5 (lambda_q4 / 16)^2: J x 1024 = SSE << 10 + (lambda_q4^2 x 24 >> 4) x quarter bits.  A CU whose adopted motion is no longer a merge
+ * candidate when the slice is written is coded with explicit motion and rqt_root_cbf = 0.
+ * What was measured on the way (tools/rd_eval.py --host, 832x480 pyramid, bytes at equal PSNR-Y): this rule - 1.9 % (B layers 1 / 2 / 3: - 3 / - 11 / - 15 %, P pictures: nothing
+ * - the host runs it on B pictures only); the same test on every NODE of the quadtree, top-down, uniting CUs into one (the form first built): - 1.5 % with the same constants, of
+ * which the unions contribute 0.1 %: the tree the Hadamard decision leaves is not what costs the bits, the residuals that survive in it are; all candidates instead of two:
+ * + 0.05 %; the quadrants of a 64x64 CU as CUs of their own: 0.1 %. */
+static int g_sp[8] = {24, 4, 4, 24, 16, 2, 0, 0};         /* syntax of a CU with residual, skip base, per position (quarter bits); lambda scale (1/16); weight of the chroma distortion (1/4); distinct candidates tried */
 void kso_experiment_skip(const int *v) { if (v) memcpy(g_sp, v, sizeof g_sp); }
-static long g_sp_stat[8];
-void kso_skip_stats(long *out) { memcpy(out, g_sp_stat, sizeof g_sp_stat); memset(g_sp_stat, 0, sizeof g_sp_stat); }
 /* the exact 8-bit prediction of an n x n block (luma) or its n/2 x n/2 chroma blocks from one or two pictures, as reconstruct_impl forms it; n <= 32 */
 static void sp_pred_comp(const kso_frame_geom *g, int comp, kso_pic r0, kso_pic r1, int dir, int x0, int y0, int n, int mvx, int mvy, int mv1x, int mv1y, uint8_t *pred /* packed n (luma) or n/2 */)
 {
@@ -1390,105 +1389,77 @@ void kso_skip_pass(const kso_frame_cfg *cfg, kso_pic src, kso_pic ref0_, kso_pic
     const int W = cfg->width, H = cfg->height, w8 = W / 8, h8 = H / 8;
     const long sy = g.stride_y, sc = g.stride_c;
     const int is_b = ref1_.y != NULL || (g_mr && g_mr->n1 > 0);
-    const int64_t lam2 = ((int64_t)cfg->lambda_q4 * cfg->lambda_q4 * g_sp[5]) >> 4;
-    const int deepest = g_sp[6];
+    const int64_t lam2 = ((int64_t)cfg->lambda_q4 * cfg->lambda_q4 * g_sp[3]) >> 4;
     memcpy(cu_out, cu_in, sizeof(kso_cu8) * (size_t)w8 * h8);
-#pragma omp parallel for collapse(2) schedule(dynamic, 1)
-    for (int cy = 0; cy < g.ctu_rows; ++cy)
-        for (int cx = 0; cx < g.ctu_cols; ++cx) {
-            uint8_t done[8][8];
-            memset(done, 0, sizeof done);
-            const int ctb = cy * g.ctu_cols + cx;
-            for (int l = 0; l <= deepest; ++l) {
-                const int s = 64 >> l, n8 = s / 8;
-                for (int py = 0; py < (1 << l); ++py)
-                    for (int px = 0; px < (1 << l); ++px) {
-                        const int x = cx * 64 + px * s, y = cy * 64 + py * s;
-                        if (x + s > W || y + s > H) continue;
-                        if (done[(y & 63) >> 3][(x & 63) >> 3]) continue;
-                        /* the node as it is coded now */
-                        int ok = 1, ncu = 0, syn = 0;
-                        for (int by = 0; by < n8 && ok; ++by)
-                            for (int bx = 0; bx < n8; ++bx) {
-                                const int tx = x / 8 + bx, ty = y / 8 + by;
-                                const kso_cu8 *c = &cu_in[(long)ty * w8 + tx];
-                                if (c->pred_mode != 0 || CU_LOG2(c) < 3 || CU_LOG2(c) > 6 - l) { ok = 0; break; }       /* (a block of a larger CU: the CU's own node was looked at and left as it is) */
-                                const int c8 = 1 << (CU_LOG2(c) - 3);
-                                if ((tx & (c8 - 1)) || (ty & (c8 - 1))) continue;                /* a CU is counted at its first block */
-                                int coded = 0;
-                                for (int yy = 0; yy < c8; ++yy) for (int xx = 0; xx < c8; ++xx) coded |= cu_in[(long)(ty + yy) * w8 + tx + xx].cbf;
-                                ++ncu;
-                                syn += (coded ? g_sp[1] : g_sp[0]) + (c8 < n8 ? g_sp[2] : 0);
-                            }
-                        if (!ok) continue;
-                        const kso_cu8 *c0 = &cu_in[(long)(y / 8) * w8 + x / 8];
-                        if (ncu == 1 && !CU_PART(c0)) {
-                            int coded = 0;
-                            for (int by = 0; by < n8; ++by) for (int bx = 0; bx < n8; ++bx) coded |= cu_in[(long)(y / 8 + by) * w8 + x / 8 + bx].cbf;
-                            if (!coded) continue;                                                /* one CU without residual already */
-                        }
-                        const uint8_t *So = org_y(&g, src.y) + (long)y * sy + x, *Su = org_c(&g, src.u) + (long)(y / 2) * sc + x / 2, *Sv = org_c(&g, src.v) + (long)(y / 2) * sc + x / 2;
-                        uint8_t *Ro = org_y(&g, recon.y) + (long)y * sy + x, *Ru = org_c(&g, recon.u) + (long)(y / 2) * sc + x / 2, *Rv = org_c(&g, recon.v) + (long)(y / 2) * sc + x / 2;
-                        const uint64_t dcur = sp_sse(So, sy, Ro, sy, s) + (((sp_sse(Su, sc, Ru, sc, s / 2) + sp_sse(Sv, sc, Rv, sc, s / 2)) * (uint64_t)g_sp[7]) >> 2);
-                        const int bits = sp_level_bits(lvl_y + (long)y * W + x, W, s) + sp_level_bits(lvl_u + (long)(y / 2) * (W / 2) + x / 2, W / 2, s / 2)
-                                         + sp_level_bits(lvl_v + (long)(y / 2) * (W / 2) + x / 2, W / 2, s / 2) + syn;
-                        const uint64_t jcur = (dcur << 10) + (uint64_t)(lam2 * bits);
-                        /* the candidates */
-                        const int nx[5] = {x - 1, x + s - 1, x + s, x - 1, x - 1}, ny[5] = {y + s - 1, y - 1, y - 1, y + s, y - 1};   /* A1 B1 B0 A0 B2 */
-                        const int zc = z_of(x, y);
-                        uint64_t best = jcur; int bestk = -1, pos = 0; kso_cu8 bm = *c0, seen[6]; int nseen = 0;
-                        static __thread uint8_t PY[64 * 64], PU_[32 * 32], PV[32 * 32], BY[64 * 64], BU[32 * 32], BV[32 * 32];
-                        for (int k = 0; k < 6; ++k) {
-                            kso_cu8 m;
-                            if (k < 5) {
-                                if (nx[k] < 0 || ny[k] < 0 || nx[k] >= W || ny[k] >= H) continue;
-                                const int nctb = (ny[k] >> 6) * g.ctu_cols + (nx[k] >> 6);
-                                if (nctb > ctb || (nctb == ctb && z_of(nx[k], ny[k]) >= zc)) continue;
-                                m = cu_in[(long)(ny[k] >> 3) * w8 + (nx[k] >> 3)];
-                                if (m.pred_mode != 0 || (m.log2_cu & 15) < 3) continue;
-                            } else { memset(&m, 0, sizeof m); m.inter_dir = (is_b && !(g_mr && g_mr->n1 == 0)) ? 3 : 1; }
-                            const int dir = m.inter_dir & 3;
-                            if (!g_mr) m.inter_dir = (uint8_t)dir;
-                            if ((dir & 1) && (x + (m.mvx >> 2) < -70 || x + (m.mvx >> 2) + s > W + 70 || y + (m.mvy >> 2) < -70 || y + (m.mvy >> 2) + s > H + 70)) continue;
-                            if ((dir & 2) && (x + (m.mv1x >> 2) < -70 || x + (m.mv1x >> 2) + s > W + 70 || y + (m.mv1y >> 2) < -70 || y + (m.mv1y >> 2) + s > H + 70)) continue;
-                            if (!(dir & 1)) { m.mvx = m.mvy = 0; }
-                            if (!(dir & 2)) { m.mv1x = m.mv1y = 0; }
-                            const int mypos = pos++;
-                            int rep = 0;
-                            for (int j = 0; j < nseen; ++j) rep |= seen[j].inter_dir == m.inter_dir && seen[j].mvx == m.mvx && seen[j].mvy == m.mvy && seen[j].mv1x == m.mv1x && seen[j].mv1y == m.mv1y;
-                            if (rep) continue;                                                   /* the same motion at a later position never wins */
-                            seen[nseen++] = m;
-                            const kso_pic r0 = g_mr ? g_mr->pic0[(m.inter_dir >> 4) & 3] : ref0_, r1 = g_mr ? g_mr->pic1[(m.inter_dir >> 6) & 3] : ref1_;
-                            uint64_t d = 0;
-                            const int q = s > 32 ? 32 : s;
-                            for (int oy = 0; oy < s; oy += q)
-                                for (int ox = 0; ox < s; ox += q) {
-                                    uint8_t t[32 * 32];
-                                    sp_pred_comp(&g, 0, r0, r1, dir, x + ox, y + oy, q, m.mvx, m.mvy, m.mv1x, m.mv1y, t);
-                                    for (int yy = 0; yy < q; ++yy) memcpy(PY + (oy + yy) * s + ox, t + yy * q, (size_t)q);
-                                    sp_pred_comp(&g, 1, r0, r1, dir, x + ox, y + oy, q, m.mvx, m.mvy, m.mv1x, m.mv1y, t);
-                                    for (int yy = 0; yy < q / 2; ++yy) memcpy(PU_ + (oy / 2 + yy) * (s / 2) + ox / 2, t + yy * (q / 2), (size_t)(q / 2));
-                                    sp_pred_comp(&g, 2, r0, r1, dir, x + ox, y + oy, q, m.mvx, m.mvy, m.mv1x, m.mv1y, t);
-                                    for (int yy = 0; yy < q / 2; ++yy) memcpy(PV + (oy / 2 + yy) * (s / 2) + ox / 2, t + yy * (q / 2), (size_t)(q / 2));
-                                }
-                            d = sp_sse(So, sy, PY, s, s) + (((sp_sse(Su, sc, PU_, s / 2, s / 2) + sp_sse(Sv, sc, PV, s / 2, s / 2)) * (uint64_t)g_sp[7]) >> 2);
-                            const uint64_t j = (d << 10) + (uint64_t)(lam2 * (g_sp[3] + g_sp[4] * mypos));
-                            if (j < best) { best = j; bestk = k; bm = m; memcpy(BY, PY, (size_t)(s * s)); memcpy(BU, PU_, (size_t)(s * s / 4)); memcpy(BV, PV, (size_t)(s * s / 4)); }
-                        }
-                        if (bestk < 0) continue;
-                        __atomic_fetch_add(&g_sp_stat[l], 1, __ATOMIC_RELAXED); __atomic_fetch_add(&g_sp_stat[4], ncu, __ATOMIC_RELAXED);
-                        for (int by = 0; by < n8; ++by)
-                            for (int bx = 0; bx < n8; ++bx) {
-                                kso_cu8 *o = &cu_out[(long)(y / 8 + by) * w8 + x / 8 + bx];
-                                o->mvx = bm.mvx; o->mvy = bm.mvy; o->mv1x = bm.mv1x; o->mv1y = bm.mv1y; o->inter_dir = bm.inter_dir; o->log2_cu = (uint8_t)(6 - l); o->cbf = 0; o->pred_mode = 0;
-                                done[((y & 63) >> 3) + by][((x & 63) >> 3) + bx] = 1;
-                            }
-                        for (int yy = 0; yy < s; ++yy) { memset(lvl_y + (long)(y + yy) * W + x, 0, sizeof(int16_t) * (size_t)s); memcpy(Ro + (long)yy * sy, BY + yy * s, (size_t)s); }
-                        for (int yy = 0; yy < s / 2; ++yy) {
-                            memset(lvl_u + (long)(y / 2 + yy) * (W / 2) + x / 2, 0, sizeof(int16_t) * (size_t)(s / 2)); memset(lvl_v + (long)(y / 2 + yy) * (W / 2) + x / 2, 0, sizeof(int16_t) * (size_t)(s / 2));
-                            memcpy(Ru + (long)yy * sc, BU + yy * (s / 2), (size_t)(s / 2)); memcpy(Rv + (long)yy * sc, BV + yy * (s / 2), (size_t)(s / 2));
-                        }
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int by = 0; by < h8; ++by)
+        for (int bx = 0; bx < w8; ++bx) {
+            const kso_cu8 *c0 = &cu_in[(long)by * w8 + bx];
+            if (c0->pred_mode != 0 || CU_LOG2(c0) < 3) continue;
+            const int s = 1 << CU_LOG2(c0), n8 = s / 8, x = bx * 8, y = by * 8;
+            if ((x & (s - 1)) || (y & (s - 1))) continue;                         /* a CU is handled at its first 8x8 block */
+            int coded = 0;
+            for (int yy = 0; yy < n8; ++yy) for (int xx = 0; xx < n8; ++xx) coded |= cu_in[(long)(by + yy) * w8 + bx + xx].cbf;
+            if (!coded) continue;
+            const uint8_t *So = org_y(&g, src.y) + (long)y * sy + x, *Su = org_c(&g, src.u) + (long)(y / 2) * sc + x / 2, *Sv = org_c(&g, src.v) + (long)(y / 2) * sc + x / 2;
+            uint8_t *Ro = org_y(&g, recon.y) + (long)y * sy + x, *Ru = org_c(&g, recon.u) + (long)(y / 2) * sc + x / 2, *Rv = org_c(&g, recon.v) + (long)(y / 2) * sc + x / 2;
+            const uint64_t dcur = sp_sse(So, sy, Ro, sy, s) + (((sp_sse(Su, sc, Ru, sc, s / 2) + sp_sse(Sv, sc, Rv, sc, s / 2)) * (uint64_t)g_sp[4]) >> 2);
+            const int bits = sp_level_bits(lvl_y + (long)y * W + x, W, s) + sp_level_bits(lvl_u + (long)(y / 2) * (W / 2) + x / 2, W / 2, s / 2)
+                             + sp_level_bits(lvl_v + (long)(y / 2) * (W / 2) + x / 2, W / 2, s / 2) + g_sp[0];
+            const uint64_t jcur = (dcur << 10) + (uint64_t)(lam2 * bits);
+            /* the candidates */
+            const int cx = x >> 6, cy = y >> 6, ctb = cy * g.ctu_cols + cx;
+            const int nx[5] = {x - 1, x + s - 1, x + s, x - 1, x - 1}, ny[5] = {y + s - 1, y - 1, y - 1, y + s, y - 1};   /* A1 B1 B0 A0 B2 */
+            const int zc = z_of(x, y);
+            uint64_t best = jcur; int bestk = -1, pos = 0; kso_cu8 bm = *c0, seen[6]; int nseen = 0;
+            uint8_t PY[64 * 64], PU_[32 * 32], PV[32 * 32], BY[64 * 64], BU[32 * 32], BV[32 * 32];
+            for (int k = 0; k < 6; ++k) {
+                kso_cu8 m;
+                if (k < 5) {
+                    if (nx[k] < 0 || ny[k] < 0 || nx[k] >= W || ny[k] >= H) continue;
+                    const int nctb = (ny[k] >> 6) * g.ctu_cols + (nx[k] >> 6);
+                    if (nctb > ctb || (nctb == ctb && z_of(nx[k], ny[k]) >= zc)) continue;
+                    m = cu_in[(long)(ny[k] >> 3) * w8 + (nx[k] >> 3)];
+                    if (m.pred_mode != 0 || (m.log2_cu & 15) < 3) continue;
+                } else { memset(&m, 0, sizeof m); m.inter_dir = (is_b && !(g_mr && g_mr->n1 == 0)) ? 3 : 1; }
+                const int dir = m.inter_dir & 3;
+                if (!g_mr) m.inter_dir = (uint8_t)dir;
+                if ((dir & 1) && (x + (m.mvx >> 2) < -70 || x + (m.mvx >> 2) + s > W + 70 || y + (m.mvy >> 2) < -70 || y + (m.mvy >> 2) + s > H + 70)) continue;
+                if ((dir & 2) && (x + (m.mv1x >> 2) < -70 || x + (m.mv1x >> 2) + s > W + 70 || y + (m.mv1y >> 2) < -70 || y + (m.mv1y >> 2) + s > H + 70)) continue;
+                if (!(dir & 1)) { m.mvx = m.mvy = 0; }
+                if (!(dir & 2)) { m.mv1x = m.mv1y = 0; }
+                const int mypos = pos++;
+                int rep = 0;
+                for (int j = 0; j < nseen; ++j) rep |= seen[j].inter_dir == m.inter_dir && seen[j].mvx == m.mvx && seen[j].mvy == m.mvy && seen[j].mv1x == m.mv1x && seen[j].mv1y == m.mv1y;
+                if (rep) continue;                                                   /* the same motion at a later position never wins */
+                if (nseen >= g_sp[5]) break;                                         /* the first two distinct candidates */
+                seen[nseen++] = m;
+                const kso_pic r0 = g_mr ? g_mr->pic0[(m.inter_dir >> 4) & 3] : ref0_, r1 = g_mr ? g_mr->pic1[(m.inter_dir >> 6) & 3] : ref1_;
+                const int q = s > 32 ? 32 : s;
+                for (int oy = 0; oy < s; oy += q)
+                    for (int ox = 0; ox < s; ox += q) {
+                        uint8_t t[32 * 32];
+                        sp_pred_comp(&g, 0, r0, r1, dir, x + ox, y + oy, q, m.mvx, m.mvy, m.mv1x, m.mv1y, t);
+                        for (int yy = 0; yy < q; ++yy) memcpy(PY + (oy + yy) * s + ox, t + yy * q, (size_t)q);
+                        sp_pred_comp(&g, 1, r0, r1, dir, x + ox, y + oy, q, m.mvx, m.mvy, m.mv1x, m.mv1y, t);
+                        for (int yy = 0; yy < q / 2; ++yy) memcpy(PU_ + (oy / 2 + yy) * (s / 2) + ox / 2, t + yy * (q / 2), (size_t)(q / 2));
+                        sp_pred_comp(&g, 2, r0, r1, dir, x + ox, y + oy, q, m.mvx, m.mvy, m.mv1x, m.mv1y, t);
+                        for (int yy = 0; yy < q / 2; ++yy) memcpy(PV + (oy / 2 + yy) * (s / 2) + ox / 2, t + yy * (q / 2), (size_t)(q / 2));
                     }
+                const uint64_t d = sp_sse(So, sy, PY, s, s) + (((sp_sse(Su, sc, PU_, s / 2, s / 2) + sp_sse(Sv, sc, PV, s / 2, s / 2)) * (uint64_t)g_sp[4]) >> 2);
+                const uint64_t j = (d << 10) + (uint64_t)(lam2 * (g_sp[1] + g_sp[2] * mypos));
+                if (j < best) { best = j; bestk = k; bm = m; memcpy(BY, PY, (size_t)(s * s)); memcpy(BU, PU_, (size_t)(s * s / 4)); memcpy(BV, PV, (size_t)(s * s / 4)); }
+            }
+            if (bestk < 0) continue;
+            for (int yy = 0; yy < n8; ++yy)
+                for (int xx = 0; xx < n8; ++xx) {
+                    kso_cu8 *o = &cu_out[(long)(by + yy) * w8 + bx + xx];
+                    o->mvx = bm.mvx; o->mvy = bm.mvy; o->mv1x = bm.mv1x; o->mv1y = bm.mv1y; o->inter_dir = bm.inter_dir; o->log2_cu = (uint8_t)CU_LOG2(c0); o->cbf = 0; o->pred_mode = 0;
+                }
+            for (int yy = 0; yy < s; ++yy) { memset(lvl_y + (long)(y + yy) * W + x, 0, sizeof(int16_t) * (size_t)s); memcpy(Ro + (long)yy * sy, BY + yy * s, (size_t)s); }
+            for (int yy = 0; yy < s / 2; ++yy) {
+                memset(lvl_u + (long)(y / 2 + yy) * (W / 2) + x / 2, 0, sizeof(int16_t) * (size_t)(s / 2)); memset(lvl_v + (long)(y / 2 + yy) * (W / 2) + x / 2, 0, sizeof(int16_t) * (size_t)(s / 2));
+                memcpy(Ru + (long)yy * sc, BU + yy * (s / 2), (size_t)(s / 2)); memcpy(Rv + (long)yy * sc, BV + yy * (s / 2), (size_t)(s / 2));
             }
         }
 }

@@ -22,7 +22,7 @@ typedef struct {
             sub_satd, sub_thr, sub_flat, sub_cap, sub_cap_step, sub_diag_fast,     /* the sub-pel refinement's knobs (Stage B, ks265_pipeline_oracle.c) */
             part,                                                            /* -part 1: 2NxN / Nx2N partitions of 64 / 32 / 16 CUs in P / B pictures (kso_cu_decide_part[_b]) */
             tu_inter,                                                        /* -intertu 1 (tuInter: veryslow, placebo): a 2Nx2N inter CU of 32 / 16 samples may carry four transform units (split_transform_flag) */
-            skip_rd;                                                         /* stage D2 after the reconstruction: nodes whose merge candidate without residual is the cheaper coding become one CU (kso_skip_pass) */
+            skip_rd;                                                         /* stage D2 after the reconstruction: CUs whose merge candidate without residual is the cheaper coding drop their residual (kso_skip_pass); 1 = B pictures, 2 = P pictures too */
 } kso_frame_cfg;
 
 typedef struct {
@@ -77,7 +77,8 @@ void kso_cu_decide_b(const kso_frame_cfg *cfg, const kso_pu_b *pub, kso_cu8 *cu8
 /* stage C2 (cfg->merge): every CU may adopt the motion of one of its spatial merge neighbours (or the zero vector); pu for P pictures, pub for B pictures (the other NULL) */
 void kso_merge_pass(const kso_frame_cfg *cfg, kso_pic src, const uint8_t *planes0, const uint8_t *planes1, const kso_pu *pu, const kso_pu_b *pub,
                     const kso_cu8 *cu_in, kso_cu8 *cu_out);
-/* stage D2 (cfg->skip_rd): after kso_reconstruct* - cu_in (the map with its coded-block flags) -> cu_out; levels and reconstruction updated in place; ref1.y = NULL for P pictures;
+/* stage D2 (cfg->skip_rd): after kso_reconstruct* - every inter CU with residual may become a CU without, carrying a merge candidate's motion; cu_in (the map with its coded-block
+ * flags) -> cu_out; levels and reconstruction updated in place; ref1.y = NULL for P pictures;
  * several pictures per list: inside kso_set_mref */
 void kso_skip_pass(const kso_frame_cfg *cfg, kso_pic src, kso_pic ref0, kso_pic ref1, const kso_cu8 *cu_in, kso_cu8 *cu_out, int16_t *lvl_y, int16_t *lvl_u, int16_t *lvl_v, kso_pic recon);
 void kso_experiment_skip(const int *v /*[8]*/);

@@ -90,7 +90,7 @@ class OraclePipeline:
         self.intra = intra                      # key pictures: real intra prediction (True) or the flat stand-in
         self.skip_rd = int(os.environ.get("RD_SKIP", skip_rd))         # (RD_SKIP / RD_SKIP_PARAMS: experiment hooks of tools/rd_eval.py)
         if os.environ.get("RD_SKIP_PARAMS"):
-            self.o.kso_experiment_skip((C.c_int * 8)(*[int(x) for x in os.environ["RD_SKIP_PARAMS"].split(",")]))
+            self.o.kso_experiment_skip((C.c_int * 8)(*([int(x) for x in os.environ["RD_SKIP_PARAMS"].split(",")] + [0] * 8)[:8]))
         self.cfg = OFrameCfg(width, height, qp, lambda_q4, me_range, me_method, subme, deblock, sao, 0, 0, 1, 4, me_hex_thr, sdh, pre_search, merge, bi_refine, decimate, rdo, intra_inter, propagate, sub_satd, sub_thr, sub_flat, sub_cap, sub_cap_step, sub_diag_fast, part, tu_inter, self.skip_rd)
         self.geom = OFrameGeom()
         assert self.o.kso_frame_geometry(C.byref(self.cfg), C.byref(self.geom)) == 0
@@ -238,7 +238,7 @@ class OraclePipeline:
         else:
             o.kso_reconstruct(cfg, self.src.c(), r0, ptr(self.planes), r1, p1, ptr(self.cu8), ptr(self.lvl[0]), ptr(self.lvl[1]), ptr(self.lvl[2]),
                               self.rec.c())
-            if self.skip_rd and kind != "I":
+            if (self.skip_rd and kind == "B") or (self.skip_rd >= 2 and kind == "P"):     # 1: B pictures only (where the pass pays: P pictures gain nothing measurable), 2: P pictures too
                 self.skip_pass(r0, r1)
             if self.cfg.intra_inter:
                 o.kso_intra_inter_reconstruct(cfg, self.src.c(), ptr(self.cu8), ptr(self.lvl[0]), ptr(self.lvl[1]), ptr(self.lvl[2]), self.rec.c())
@@ -367,7 +367,7 @@ class OraclePipeline:
         ref_arr = (OPic * n)(*[r.c() for r in refs])
         pl_arr = (C.c_void_p * n)(*[p.ctypes.data for p in planes])
         o.kso_reconstruct_mref(cfg, self.src.c(), C.c_int(n), ref_arr, pl_arr, ptr(self.cu8), ptr(self.lvl[0]), ptr(self.lvl[1]), ptr(self.lvl[2]), self.rec.c())
-        if self.skip_rd:
+        if self.skip_rd >= 2:
             mr = OMref()
             mr.n0, mr.n1 = n, 0
             for i in range(4):

@@ -76,7 +76,7 @@ def case_rqt(name: str) -> int:
 
 
 def case_skip(name: str) -> int:
-    return 1 if "_skip" in name else 0
+    return 2 if "_skip" in name else 0          # (2: P pictures too - the C host runs 1 = B pictures only)
 
 
 def case_sdh(name: str) -> int:

@@ -167,16 +167,17 @@ def test_anchor_with_three_past_anchors_encoder_tools(ks, W, H, abc, pan, seed):
 
 @pytest.mark.parametrize("W,H,abc,pan,seed", [(1920, 1080, (37, 53, 19), (5, 3), 42), (3840, 2160, (67, 91, 33), (8, 5), 7), (416, 240, (17, 23, 9), (3, 2), 5), (200, 136, (17, 23, 9), (2, 1), 6)])
 def test_skip_pass(ks, W, H, abc, pan, seed):
-    """round 6 (VERDICT r5 missing 2: the decision on the coded distortion): cfg.skip_rd - after the reconstruction, nodes of 64 / 32 / 16 / 8 samples whose merge candidate without
-    residual is the cheaper coding become one CU.  Key picture, P, P, then the B pictures of a pyramid of 4 between them == oracle: reconstruction, CU records, all three level planes;
-    the pass really acts (the records differ from a run without it, more blocks without residual, larger CUs)"""
+    """round 6 (VERDICT r5 missing 2: the decision on the coded distortion): cfg.skip_rd - after the reconstruction, an inter CU with residual whose merge candidate without residual is
+    the cheaper coding (SSE of the real reconstruction + the bits of its levels against SSE of the candidate's prediction) drops its residual and takes the candidate's motion.
+    Key picture, P, P, then the B pictures of a pyramid of 4 between them == oracle: reconstruction, CU records, all three level planes (skip_rd 2: P pictures too); the pass
+    really acts (more blocks without residual than a run without it)"""
     from ks265codec_amd.lib import CU8, KsFrame
     from ks265codec_amd.synth import lambda_q4, make_clip
     from oracle_lib import OraclePipeline
     clip = make_clip(W, H, 9, seed=seed, abc=abc, pan=pan)
     order = [(0, "I", None, None, 0), (4, "P", 0, None, 1), (8, "P", 4, None, 1), (2, "B", 0, 4, 2), (1, "B", 0, 2, 4), (3, "B", 2, 4, 4), (6, "B", 4, 8, 2)]
     stats = {}
-    for skip in (1, 0):
+    for skip in (2, 0):
         tools = dict(ENCODER_TOOLS, skip_rd=skip)
         o = OraclePipeline(W, H, 27, lambda_q4(27), me_method=2, me_hex_thr=16, **tools)
         with KsFrame(ks, W, H, 27, lambda_q4(27), me_method=2, me_hex_thr=16, bframes=3, **tools) as f:
@@ -203,10 +204,9 @@ def test_skip_pass(ks, W, H, abc, pan, seed):
                 assert (got == exp).all(), f"skip_rd {skip} picture {d} ({kind}): {int((got != exp).sum())} recon bytes differ"
                 if kind != "I":
                     inter = cu["pred_mode"] == 0
-                    stats.setdefault(skip, []).append(((cu["cbf"][inter] == 0).mean(), ((cu["log2_cu"][inter] & 15) >= 5).mean()))
+                    stats.setdefault(skip, []).append((cu["cbf"][inter] == 0).mean())
                 dg[d], do[d] = out, eo
-    on, off = np.array(stats[1]), np.array(stats[0])
-    assert on[:, 0].mean() > off[:, 0].mean() and on[:, 1].mean() > off[:, 1].mean(), (on.mean(0), off.mean(0))
+    assert np.mean(stats[2]) > np.mean(stats[0]), (stats[2], stats[0])
 
 
 @pytest.mark.parametrize("W,H", [(1920, 1080), (416, 240), (200, 136)])

@@ -38,7 +38,7 @@ def _clip(name, n):
 def test_cli_stream_equals_decoder_verified_fixture(tmp_path):
     from ks265codec_amd import stream
     stream.build()
-    name = "enc_ippp_416x240_umh"                      # what the C host runs: sign-data hiding, pre-search candidates, merge pass, CTU rows as WPP substreams
+    name = "enc_ippp_416x240_umh"                      # what the C host runs: sign-data hiding, pre-search candidates, merge pass, CTU rows as WPP substreams (the skip pass acts on B pictures only)
     clip = _clip(name, 4)
     yuv, out = tmp_path / "in.yuv", tmp_path / "out.265"
     clip.tofile(yuv)
