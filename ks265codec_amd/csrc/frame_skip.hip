@@ -245,6 +245,7 @@ __global__ __launch_bounds__(128, KS_SKIP_OCC) void skip_pass_kernel(KsGeom g, l
                                                                      const ks265_cu8 *snap, ks265_cu8 *cu8, int16_t *lvl_y, int16_t *lvl_u, int16_t *lvl_v, uint8_t *rec_y, uint8_t *rec_u, uint8_t *rec_v)
 {
     __shared__ unsigned red[16][2];
+    __shared__ unsigned keep[12][128];                             // the winning candidate's samples of every lane (lane-private columns: no hand-over between lanes)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, z = tid >> 1, sub = tid & 1;
     const int ctu = ks_xcd_swizzle(blockIdx.x, g.ctu_cols * g.ctu_rows), cx = ctu % g.ctu_cols, cy = ctu / g.ctu_cols;
     const int tx = (z & 1) | ((z >> 1) & 2) | ((z >> 2) & 4), ty = ((z >> 1) & 1) | ((z >> 2) & 2) | ((z >> 3) & 4);
@@ -333,8 +334,10 @@ __global__ __launch_bounds__(128, KS_SKIP_OCC) void skip_pass_kernel(KsGeom g, l
         const SpMotion m = motion_of(on, k);
         const int dir = m.dir8 & 3, i0 = MR ? (m.dir8 >> 4) & 3 : 0, i1 = MR ? (m.dir8 >> 6) & 3 : 0;
         unsigned eY = 0;
+        uint2 pY[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pY[r] = make_uint2(0u, 0u);
         if (__any(on)) {
-            uint2 pY[4];
             sp_pred_luma(ks_org_y(g, (dir & 1) ? sp_pick(R.y0, i0) : sp_pick(R.y1, i1)), ks_org_y(g, sp_pick(R.y1, i1)), g.sy, lx, ly, m, pY);
 #pragma unroll
             for (int r = 0; r < 4; ++r) eY += sp_sse4(sY[r].x, pY[r].x) + sp_sse4(sY[r].y, pY[r].y);
@@ -346,8 +349,8 @@ __global__ __launch_bounds__(128, KS_SKIP_OCC) void skip_pass_kernel(KsGeom g, l
         const bool need_c = on && (((unsigned long long)nY << 10) + rate < best);
         if (!__syncthreads_or(need_c ? 1 : 0)) continue;
         unsigned eC = 0;
+        unsigned pC[4] = {0u, 0u, 0u, 0u};
         if (__any(need_c)) {
-            unsigned pC[4];
             sp_pred_chroma(ks_org_c(g, (dir & 1) ? (sub ? sp_pick(R.v0, i0) : sp_pick(R.u0, i0)) : (sub ? sp_pick(R.v1, i1) : sp_pick(R.u1, i1))),
                            ks_org_c(g, sub ? sp_pick(R.v1, i1) : sp_pick(R.u1, i1)), g.sc, cxx, cyy, m, pC);
 #pragma unroll
@@ -356,33 +359,28 @@ __global__ __launch_bounds__(128, KS_SKIP_OCC) void skip_pass_kernel(KsGeom g, l
         const unsigned nC = cusum(need_c ? eC : 0u);
         if (need_c) {
             const unsigned long long j = ((unsigned long long)(nY + ((unsigned)(((unsigned long long)nC * SP_CHROMA_W) >> 2))) << 10) + rate;
-            if (j < best) { best = j; bestk = k; }
+            if (j < best) {
+                best = j; bestk = k;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { keep[2 * r][tid] = pY[r].x; keep[2 * r + 1][tid] = pY[r].y; keep[8 + r][tid] = pC[r]; }
+            }
         }
     }
-    // ---- a CU that drops its residual: its lanes write their samples' prediction and clear their levels, the tile's first lane the record
-    if (__any(bestk >= 0)) {
-        const bool acc = bestk >= 0;
-        const SpMotion m = motion_of(acc, acc ? bestk : 5);
-        const int dir = m.dir8 & 3, i0 = MR ? (m.dir8 >> 4) & 3 : 0, i1 = MR ? (m.dir8 >> 6) & 3 : 0;
-        uint2 pY[4];
-        unsigned pC[4];
-        sp_pred_luma(ks_org_y(g, (dir & 1) ? sp_pick(R.y0, i0) : sp_pick(R.y1, i1)), ks_org_y(g, sp_pick(R.y1, i1)), g.sy, lx, ly, m, pY);
-        sp_pred_chroma(ks_org_c(g, (dir & 1) ? (sub ? sp_pick(R.v0, i0) : sp_pick(R.u0, i0)) : (sub ? sp_pick(R.v1, i1) : sp_pick(R.u1, i1))),
-                       ks_org_c(g, sub ? sp_pick(R.v1, i1) : sp_pick(R.u1, i1)), g.sc, cxx, cyy, m, pC);
-        if (acc) {
+    // ---- a CU that drops its residual: its lanes write the samples they kept and clear their levels, the tile's first lane the record
+    if (bestk >= 0) {
+        const SpMotion m = sp_cand<MR>(g, snap, cux, cuy, n, bestk, bi_zero);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                *(uint2 *)(Ry + (long)(ly + r) * g.sy + lx) = pY[r];
-                *(uint4 *)(lvl_y + (long)(ly + r) * g.W + lx) = make_uint4(0u, 0u, 0u, 0u);
-                *(unsigned *)(Rc + (long)(cyy + r) * g.sc + cxx) = pC[r];
-                *(uint2 *)(lvl_c + (long)(cyy + r) * (g.W / 2) + cxx) = make_uint2(0u, 0u);
-            }
-            if (sub == 0) {
-                ks265_cu8 o;
-                o.mvx = (int16_t)m.mvx; o.mvy = (int16_t)m.mvy; o.mv1x = (int16_t)m.mv1x; o.mv1y = (int16_t)m.mv1y;
-                o.log2_cu = (uint8_t)log2c; o.cbf = 0; o.pred_mode = 0; o.inter_dir = (uint8_t)m.dir8;
-                cu8[(long)(y0 >> 3) * g.w8 + (x0 >> 3)] = o;
-            }
+        for (int r = 0; r < 4; ++r) {
+            *(uint2 *)(Ry + (long)(ly + r) * g.sy + lx) = make_uint2(keep[2 * r][tid], keep[2 * r + 1][tid]);
+            *(uint4 *)(lvl_y + (long)(ly + r) * g.W + lx) = make_uint4(0u, 0u, 0u, 0u);
+            *(unsigned *)(Rc + (long)(cyy + r) * g.sc + cxx) = keep[8 + r][tid];
+            *(uint2 *)(lvl_c + (long)(cyy + r) * (g.W / 2) + cxx) = make_uint2(0u, 0u);
+        }
+        if (sub == 0) {
+            ks265_cu8 o;
+            o.mvx = (int16_t)m.mvx; o.mvy = (int16_t)m.mvy; o.mv1x = (int16_t)m.mv1x; o.mv1y = (int16_t)m.mv1y;
+            o.log2_cu = (uint8_t)log2c; o.cbf = 0; o.pred_mode = 0; o.inter_dir = (uint8_t)m.dir8;
+            cu8[(long)(y0 >> 3) * g.w8 + (x0 >> 3)] = o;
         }
     }
 }
