@@ -27,7 +27,7 @@ int ks265_frame_create(ks265_ctx *ctx, const ks265_frame_cfg *cfg, ks265_frame *
     if (cfg->refs > 4 || cfg->propagate < 0 || cfg->propagate > 4) return KS265_NOTSUPPORTED;
     if ((long long)geom.bytes_y >= (1ll << 31)) return KS265_NOTSUPPORTED;         /* stage B addresses a luma plane with 32-bit offsets */
     ks265_frame *f = new ks265_frame();                                            /* every validation above: nothing to undo on those returns */
-    f->ctx = ctx; f->cfg = *cfg; f->geom = geom;
+    f->ctx = ctx; f->cfg = *cfg; f->cfg0 = *cfg; f->geom = geom;
     f->me_order_off = getenv("KS265_ME_ORDER_OFF") ? 1 : 0;
     KsGeom &g = f->g;
     g.W = cfg->width; g.H = cfg->height; g.sy = geom.stride_y; g.sc = geom.stride_c; g.bytes_y = geom.bytes_y; g.bytes_c = geom.bytes_c;
@@ -112,6 +112,15 @@ int ks265_frame_set_qp(ks265_frame *f, int qp, int lambda_q4)
     KS_FRAME_CHECK(f);
     if (qp < 0 || qp > 51 || lambda_q4 < 0) return KS265_NOTSUPPORTED;
     f->cfg.qp = qp; f->cfg.lambda_q4 = lambda_q4;
+    return KS265_OK;
+}
+
+int ks265_frame_set_picture_tools(ks265_frame *f, int intra_inter, int bi_refine, int sao)
+{
+    KS_FRAME_CHECK(f);
+    const int ii = intra_inter < 0 ? f->cfg0.intra_inter : intra_inter, br = bi_refine < 0 ? f->cfg0.bi_refine : bi_refine, so = sao < 0 ? f->cfg0.sao : sao;
+    if ((ii && ii != f->cfg0.intra_inter) || (br && br != f->cfg0.bi_refine) || (so && so != f->cfg0.sao)) return KS265_NOTSUPPORTED;   /* off, or what the workspace was made for */
+    f->cfg.intra_inter = ii; f->cfg.bi_refine = br; f->cfg.sao = so;
     return KS265_OK;
 }
 
@@ -358,11 +367,13 @@ static int encode_b_lists(ks265_frame *f, ks265_pic src, const ks265_pic *refs0,
     if ((r = part ? ks265_cu_decide_part_b(f, src, ref0, ref1, pu0, f->pu1, f->pub, ii ? f->icost : nullptr, cud) : ks265_cu_decide_b_ii(f, f->pub, ii ? f->icost : nullptr, cud))) return r;
     if (f->cfg.bi_refine == 2 && (r = ks265_bi_refine_chosen(f, src, ref0, ref1, pu0, f->pu1, f->pub, cud))) return r;   /* the joint refinement, for the CUs the decision chose (round 5) */
     if (f->cfg.merge && (r = ks265_merge_pass(f, src, ref0, ref1, nullptr, f->pub, f->cu8_tmp, f->cu8))) return r;
-    ks265_pic deb = ks_deb_pic(f);
+    const bool no_sao = f->cfg.sao == 0;                       /* without SAO the picture is reconstructed and deblocked where it is handed over: no SAO launch, no copy */
+    ks265_pic deb = no_sao ? recon_out : ks_deb_pic(f);
     if ((r = ks265_reconstruct_b(f, src, ref0, ref1, f->cu8, f->lvl[0], f->lvl[1], f->lvl[2], deb))) return r;
     if (f->cfg.skip_rd && (r = ks265_skip_pass(f, src, ref0, ref1, f->cu8, f->lvl[0], f->lvl[1], f->lvl[2], deb))) return r;
     if (ii && (r = ks265_intra_inter_reconstruct(f, src, f->cu8, f->lvl[0], f->lvl[1], f->lvl[2], deb))) return r;
     if (f->cfg.deblock && (r = ks265_deblock(f, f->cu8, deb))) return r;
+    if (no_sao) return ks265_sao_off(f, f->sao, recon_out);
     return ks265_sao(f, src, deb, f->sao, recon_out);
 }
 

@@ -30,6 +30,7 @@ struct KsGeom {
 struct ks265_frame {
     ks265_ctx *ctx = nullptr;
     ks265_frame_cfg cfg{};
+    ks265_frame_cfg cfg0{};             // the tools the frame object was created with (ks265_frame_set_picture_tools lowers and restores cfg's)
     ks265_frame_geom geom{};
     KsGeom g{};
     // workspace (device)
@@ -132,6 +133,7 @@ __device__ __forceinline__ void ctu_mv_limits(const KsGeom &g, int range, int cx
 
 int ks265_frame_build_matrices(ks265_frame *f);      // frame_recon.hip
 int ks265_presearch_source(ks265_frame *f, ks265_pic src);   // frame_presearch.hip
+int ks265_sao_off(ks265_frame *f, ks265_sao_param *sao, ks265_pic dst);   // frame_loop.hip: the tail of a picture coded without SAO, in place
 
 // every frame-level entry point: the calling thread's current device is the frame's (a host with one encoder lane per GPU drives several devices from several
 // threads; kernel launches go to the CURRENT device's streams only)

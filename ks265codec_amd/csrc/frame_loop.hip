@@ -502,6 +502,27 @@ __global__ __launch_bounds__(256) void sao_ctu_kernel(KsGeom g, int lam, int ena
     if (wave < 2) sao_apply_block<32>(tc[wave], lane & 7, lane >> 3, w / 2, h / 2, x0 / 2, y0 / 2, g.W / 2, g.H / 2, sel[1 + wave], ks_org_c(g, wave ? ov : ou), g.sc);
 }
 
+// a picture without SAO (cfg.sao = 0 per picture, ks265_frame_set_picture_tools): every record "off" - what sao_ctu_kernel writes with enable = 0
+__global__ void sao_off_kernel(int n, ks265_sao_param *sao)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    ks265_sao_param off;
+    off.type = -1; off.band = 0; off.offset[0] = off.offset[1] = off.offset[2] = off.offset[3] = 0; off.rsv[0] = off.rsv[1] = 0;
+    sao[i] = off;
+}
+// the tail of a picture that was reconstructed and deblocked in dst itself: records off, borders padded
+int ks265_sao_off(ks265_frame *f, ks265_sao_param *sao, ks265_pic dst)
+{
+    KS_FRAME_CHECK(f);
+    if (!sao || !dst.y) return KS265_POINTER;
+    const int n = f->g.ctu_cols * f->g.ctu_rows * 3;
+    hipLaunchKernelGGL(sao_off_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, f->ctx->stream, n, sao);
+    int r = ks265_check_launch(f->ctx);
+    if (r) return r;
+    return ks265_pad_picture(f, dst);
+}
+
 extern "C" int ks265_sao(ks265_frame *f, ks265_pic src, ks265_pic deb, ks265_sao_param *sao, ks265_pic dst)
 {
     KS_FRAME_CHECK(f);

@@ -186,6 +186,7 @@ typedef struct TopWake { pthread_mutex_t mu; pthread_cond_t cv; unsigned long se
 typedef struct Job {
     int used, done, error;
     int disp, poc, kind, qp, nal_type, is_ref;            /* kind: 'I' 'P' 'B' */
+    int no_sao;                                           /* the picture was coded without SAO (lean B pictures): slice_sao_luma_flag = slice_sao_chroma_flag = 0 */
     long long pts;
     int nl0, nl1, l0[4], l1[4], nrps, rps_poc[16]; unsigned char rps_used[16];
     uint8_t *cmp;                                         /* pinned host copy of the GPU's records in compact form (ks265_frame_compact_layout) */
@@ -288,6 +289,7 @@ typedef struct Enc {
     int W, H, log_level;
     CopyPool *pool;                                       /* shared by the lanes of one handle (owned by it) */
     int me_method, hex_thr, subme, refs, use_sao, use_df, gop_b, hier;                  /* resolved tools */
+    int lean_b;                                                                         /* B pictures nothing predicts from: no intra candidates, no joint refinement, no SAO (KS265_LEAN_B=0: as the others) */
     int refs0, anc_hist[4], n_anc;                                                      /* -ref0 (qy265enc.h:142, the reference's ActiveRefNumFrm0InGop): how many past anchors an anchor of the pyramid searches; the last anchors' POCs, nearest first */
     int base_qp, iper, nthreads;
     ks265_ctx *ctx; ks265_frame *frame; ks265_frame_geom geom; ks265_frame_cfg fcfg; ks265_stream_cfg scfg;
@@ -536,7 +538,7 @@ static void *worker(void *arg)
                 s->poc = j->poc; s->qp = j->qp; s->num_rps = j->nrps;
                 memcpy(s->rps_poc, j->rps_poc, sizeof s->rps_poc); memcpy(s->rps_used, j->rps_used, sizeof s->rps_used);
                 s->num_l0 = j->nl0; s->num_l1 = j->nl1; memcpy(s->l0_poc, j->l0, sizeof s->l0_poc); memcpy(s->l1_poc, j->l1, sizeof s->l1_poc);
-                s->cu8 = j->cu8; s->lvl[0] = j->lvl[0]; s->lvl[1] = j->lvl[1]; s->lvl[2] = j->lvl[2]; s->sao = e->use_sao ? j->sao : NULL;
+                s->cu8 = j->cu8; s->lvl[0] = j->lvl[0]; s->lvl[1] = j->lvl[1]; s->lvl[2] = j->lvl[2]; s->sao = e->use_sao && !j->no_sao ? j->sao : NULL;
                 s->qp_map = e->qmap_on ? j->qp_map : NULL;
                 if (e->qmap_on && e->qmap_fd >= 0) {                     /* KS265_DUMP_QPMAP=file (tests): display index, kind, QP, CTU count, then the map - one record per picture, whole records only */
                     const int nct = e->geom.ctu_cols * e->geom.ctu_rows;
@@ -865,6 +867,10 @@ static int submit(Enc *e, Input *in, int kind, int poc, int qp, const int *l0, i
         if (!r) r = ks265_event_record(cx, e->ev_loaded[k]);
     }
     if (!r) r = ks265_frame_set_qp(fr, qp, kind == 'I' ? kLambdaQ4[qp] : kLambdaInterQ4[qp]);
+    /* round 6: a B picture nothing predicts from (half the pictures of a pyramid of 8) runs without intra candidates, without the joint refinement of its bi-predictive CUs and
+     * without SAO - on the CPU mirror and on the MI355X its bytes at equal PSNR-Y stay (the refinement even costs bytes at QP + 4), a quarter of its kernel time goes */
+    const int lean = e->lean_b && kind == 'B' && !is_ref;
+    if (!r) r = lean ? ks265_frame_set_picture_tools(fr, 0, 0, 0) : ks265_frame_set_picture_tools(fr, -1, -1, -1);
     if (e->rdoq_on && kind == 'I') e->rq_gop_seq = e->rc_sub;
     if (!r && e->rdoq_on && kind != 'I') {
         /* -rdoq 1: wait until every picture up to RC_LAG before this one is accounted (as the rate controller does), then the latest tables of this picture's kind among them */
@@ -930,7 +936,7 @@ static int submit(Enc *e, Input *in, int kind, int poc, int qp, const int *l0, i
     if (!r && graphable) {
         const ks265_pic refp = e->dpb[dpb_find(e, l0[0])], ref1p = kind == 'B' ? e->dpb[dpb_find(e, l1[0])] : refp;
         const uint64_t key[9] = {(uint64_t)(uintptr_t)refp.y, (uint64_t)(uintptr_t)out.y, (uint64_t)(uintptr_t)e->dev_in[k], (uint64_t)(uintptr_t)e->stg[k],
-                                 (uint64_t)qp, (uint64_t)ks265_frame_p_state(fr), (uint64_t)(e->cfg.calcPsnr != 0), (uint64_t)kind, (uint64_t)(uintptr_t)ref1p.y};
+                                 (uint64_t)qp, (uint64_t)ks265_frame_p_state(fr), (uint64_t)(e->cfg.calcPsnr != 0), (uint64_t)kind | ((uint64_t)lean << 8), (uint64_t)(uintptr_t)ref1p.y};
         void *exec = NULL;
         for (int i = 0; i < e->ngraph && !exec; ++i) if (!memcmp(e->graph[i].key, key, sizeof key)) exec = e->graph[i].exec;
         if (recycled) r = ks265_stream_wait_event(cx, e->ev_drained[k]);       /* the staging block of this rotation slot has been copied out */
@@ -1027,6 +1033,7 @@ static int submit(Enc *e, Input *in, int kind, int poc, int qp, const int *l0, i
     if (!r) r = ks265_event_record(e->ctx_out, j->ev);
     if (r) return hip_rc(r);
     ++e->seq;
+    j->no_sao = lean;
     j->disp = in->disp; j->pts = in->pts; j->poc = poc; j->kind = kind; j->qp = qp; j->is_ref = is_ref; j->key_headers = key_headers; j->rc_delta = e->rc_qp_delta;
     j->rc_budget = (double)in->kbps * 1000.0 / (e->cfg.frameRate > 0 ? e->cfg.frameRate : 25.0);
     j->nal_type = kind == 'I' ? KS265_NAL_IDR_W_RADL : is_ref ? KS265_NAL_TRAIL_R : KS265_NAL_TRAIL_N;
@@ -1511,6 +1518,7 @@ static Enc *lane_open(QY265EncConfig *cfg, int device, int multi, int *err)
                                                                          * integer search (measured with one round: - 21 .. - 23 % bytes of the P / B pictures; the variable is a measuring aid) */
     e->fcfg.intra_inter = 1;                                            /* P / B pictures may hold intra CUs (uncovered regions, occlusions); 2 = none of 8x8: measured + 1.6 % bits, no faster */
     e->fcfg.rdo = 4;                                                    /* coefficient-group pruning at lambda x 1 (ks265_frame_cfg.rdo): supersedes the coefficient decimation of round 2 */
+    e->lean_b = getenv("KS265_LEAN_B") ? atoi(getenv("KS265_LEAN_B")) != 0 : 1;           /* non-reference B pictures without intra candidates / joint refinement / SAO (submit) */
     e->fcfg.skip_rd = getenv("KS265_SKIP_RD") ? atoi(getenv("KS265_SKIP_RD")) & 3 : 1;   /* stage D2 (round 6): after the reconstruction of a B picture, nodes whose merge candidate without
                                                                          * residual is the cheaper coding - on the coded distortion - become one CU (ks265_frame_cfg.skip_rd; 2 = P pictures
                                                                          * too, where it gains nothing measurable; the variable is a measuring aid) */

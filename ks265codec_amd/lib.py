@@ -58,7 +58,7 @@ EXPORTS = [
     "ks265_edge_filter_luma_batch", "ks265_edge_filter_chroma_batch", "ks265_interp_rect",
     "ks265_sao_apply_bo_rect", "ks265_sao_apply_eo_rect", "ks265_sao_stats_batch", "ks265_intra_pred_batch", "ks265_intra_filter_ref_batch",
     "ks265_downsample_rect", "ks265_downsample_from_host", "ks265_weight_bi_sad_batch", "ks265_ac_energy_batch", "ks265_ac_energy_map",
-    "ks265_frame_reset_prediction", "ks265_frame_records_layout", "ks265_frame_pack_records", "ks265_frame_compact_layout", "ks265_frame_pack_compact", "ks265_frame_pack_compact_on", "ks265_frame_adapt_quant", "ks265_aq_ctu_map", "ks265_cutree_propagate", "ks265_calc_frame_cost", "ks265_calc_frame_cost_workspace", "ks265_cutree_finish", "ks265_host_register", "ks265_memcpy_h2d_sync", "ks265_host_unregister", "ks265_pad_plane", "ks265_fill_u16", "ks265_qoff_ctu_map", "ks265_frame_set_records_fence", "ks265_load_i420_on", "ks265_sse_picture_on", "ks265_copy_out_compact_async", "ks265_copy_out_compact_dma_async", "ks265_frame_geometry", "ks265_frame_create", "ks265_frame_destroy", "ks265_frame_set_qp", "ks265_frame_set_qp_map", "ks265_frame_set_rdoq", "ks265_pad_picture",
+    "ks265_frame_reset_prediction", "ks265_frame_records_layout", "ks265_frame_pack_records", "ks265_frame_compact_layout", "ks265_frame_pack_compact", "ks265_frame_pack_compact_on", "ks265_frame_adapt_quant", "ks265_aq_ctu_map", "ks265_cutree_propagate", "ks265_calc_frame_cost", "ks265_calc_frame_cost_workspace", "ks265_cutree_finish", "ks265_host_register", "ks265_memcpy_h2d_sync", "ks265_host_unregister", "ks265_pad_plane", "ks265_fill_u16", "ks265_qoff_ctu_map", "ks265_frame_set_records_fence", "ks265_load_i420_on", "ks265_sse_picture_on", "ks265_copy_out_compact_async", "ks265_copy_out_compact_dma_async", "ks265_frame_geometry", "ks265_frame_create", "ks265_frame_destroy", "ks265_frame_set_qp", "ks265_frame_set_picture_tools", "ks265_frame_set_qp_map", "ks265_frame_set_rdoq", "ks265_pad_picture",
     "ks265_load_i420", "ks265_store_i420", "ks265_presearch", "ks265_me_integer", "ks265_me_propagate", "ks265_me_subpel", "ks265_cu_decide_part", "ks265_cu_decide_part_b", "ks265_merge_pass", "ks265_skip_pass", "ks265_cu_decide",
     "ks265_cu_flat_intra", "ks265_intra_decide", "ks265_intra_decide_ex", "ks265_lookahead_reduce", "ks265_lookahead_picture", "ks265_lookahead_inter", "ks265_intra_reconstruct", "ks265_reconstruct", "ks265_reconstruct_b", "ks265_bi_decide", "ks265_bi_refine_chosen", "ks265_bi_full_batch", "ks265_capture_begin", "ks265_capture_end", "ks265_graph_launch", "ks265_graph_destroy", "ks265_frame_p_state", "ks265_frame_p_advance", "ks265_frame_p_restore", "ks265_cu_decide_b", "ks265_deblock", "ks265_sao",
     "ks265_encode_picture", "ks265_encode_picture_b", "ks265_encode_picture_mref", "ks265_encode_picture_b_mref", "ks265_ref_pick", "ks265_ref_decide", "ks265_reconstruct_mref",
@@ -361,6 +361,10 @@ class KsFrame:
     def set_qp(self, qp: int, lambda_q4: int):
         self.cfg.qp, self.cfg.lambda_q4 = qp, lambda_q4
         self.ks._chk(self.lib.ks265_frame_set_qp(self.h, C.c_int(qp), C.c_int(lambda_q4)))
+
+    def set_picture_tools(self, intra_inter: int = -1, bi_refine: int = -1, sao: int = -1):
+        """tools of the pictures coded from here on (-1 = as created, else 0 or the created value): ks265_frame_set_picture_tools"""
+        self.ks._chk(self.lib.ks265_frame_set_picture_tools(self.h, C.c_int(intra_inter), C.c_int(bi_refine), C.c_int(sao)))
 
     def set_qp_map(self, dev_map):
         """one QP per CTU (device int8 array, raster; None = off) for the pictures coded from here on; the caller keeps the array alive"""

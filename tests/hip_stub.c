@@ -19,6 +19,7 @@ struct ks265_frame {
     ks265_ctx *ctx; ks265_frame_cfg cfg; ks265_frame_geom g;
     int cur_pu, have_prev;
     ks265_cu8 *cu8; ks265_sao_param *sao; uint64_t kind_hash, rq_hash;
+    int tools0[3];                                            /* intra_inter, bi_refine, sao as created (ks265_frame_set_picture_tools) */
     int16_t *lvl[3];                                          /* level planes, W x H and two W/2 x H/2, packed */
 };
 
@@ -97,6 +98,7 @@ int ks265_frame_create(ks265_ctx *ctx, const ks265_frame_cfg *cfg, ks265_frame *
     ks265_frame *f = (ks265_frame *)calloc(1, sizeof *f);
     if (!f) return KS265_OUTOFMEMORY;
     f->ctx = ctx; f->cfg = *cfg;
+    f->tools0[0] = cfg->intra_inter; f->tools0[1] = cfg->bi_refine; f->tools0[2] = cfg->sao;
     if (ks265_frame_geometry(cfg, &f->g)) { free(f); return KS265_NOTSUPPORTED; }
     f->cu8 = (ks265_cu8 *)calloc(1, (size_t)f->g.bytes_cu8); f->sao = (ks265_sao_param *)calloc(1, (size_t)f->g.bytes_sao);
     const size_t npx = (size_t)cfg->width * cfg->height;
@@ -106,6 +108,27 @@ int ks265_frame_create(ks265_ctx *ctx, const ks265_frame_cfg *cfg, ks265_frame *
 }
 void ks265_frame_destroy(ks265_frame *f) { if (f) { free(f->cu8); free(f->sao); free(f->lvl[0]); free(f->lvl[1]); free(f->lvl[2]); free(f); } }
 int ks265_frame_set_qp(ks265_frame *f, int qp, int l) { f->cfg.qp = qp; f->cfg.lambda_q4 = l; return KS265_OK; }
+/* tools per picture: the stand-in's pictures do not depend on them; KS265_STUB_TOOLS_LOG = file: one line per inter picture handed in - kind, the three values - so that a
+ * host test sees which pictures the host lowered them for */
+int ks265_frame_set_picture_tools(ks265_frame *f, int ii, int br, int so)
+{
+    const int v[3] = {ii, br, so};
+    for (int i = 0; i < 3; ++i) {
+        const int x = v[i] < 0 ? f->tools0[i] : v[i];
+        if (x && x != f->tools0[i]) return KS265_NOTSUPPORTED;
+    }
+    f->cfg.intra_inter = ii < 0 ? f->tools0[0] : ii; f->cfg.bi_refine = br < 0 ? f->tools0[1] : br; f->cfg.sao = so < 0 ? f->tools0[2] : so;
+    return KS265_OK;
+}
+static void tools_log(const ks265_frame *f, char kind)
+{
+    const char *p = getenv("KS265_STUB_TOOLS_LOG");
+    if (!p) return;
+    FILE *fp = fopen(p, "a");
+    if (!fp) return;
+    fprintf(fp, "%c %d %d %d\n", kind, f->cfg.intra_inter, f->cfg.bi_refine, f->cfg.sao);
+    fclose(fp);
+}
 int ks265_frame_p_state(ks265_frame *f) { return (f->cur_pu & 1) | (f->have_prev ? 2 : 0); }
 int ks265_frame_p_advance(ks265_frame *f) { f->cur_pu ^= 1; f->have_prev = 1; return KS265_OK; }
 int ks265_frame_p_restore(ks265_frame *f, int s) { f->cur_pu = s & 1; f->have_prev = (s >> 1) & 1; return KS265_OK; }
@@ -338,6 +361,7 @@ static int fail_now(void)                                      /* KS265_STUB_FAI
 int ks265_encode_picture(ks265_frame *f, ks265_pic src, ks265_pic ref, int is_key, ks265_pic out)
 {
     if (fail_now()) return KS265_FAIL;
+    tools_log(f, is_key ? 'I' : 'P');
     Op o = {OP_ENC, f, NULL, src, ref, ref, out, (is_key ? 0 : 1) | (is_key && getenv("KS265_STUB_B_STATELESS") ? 0 : ks265_frame_p_state(f) << 2), NULL};   /* (a key picture on the main stream: see below) */
     const int r = issue(f->ctx, o);
     if (!is_key) { f->cur_pu ^= 1; f->have_prev = 1; } else f->have_prev = 0;
@@ -347,6 +371,7 @@ int ks265_encode_picture_b(ks265_frame *f, ks265_pic src, ks265_pic r0, ks265_pi
 {
     /* (the P chain's state goes into the record so that a replayed graph with the wrong state shows; KS265_STUB_B_STATELESS leaves it out - the real B pictures do not depend
      * on it, and the host's anchor lane moves the P chain to another frame object) */
+    tools_log(f, 'B');
     Op o = {OP_ENC, f, NULL, src, r0, r1, out, 2 | (getenv("KS265_STUB_B_STATELESS") ? 0 : ks265_frame_p_state(f) << 2), NULL};
     return issue(f->ctx, o);
 }

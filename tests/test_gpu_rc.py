@@ -71,15 +71,22 @@ def _mirror(clip, W, H, per, refs_of, rec, tools, upto, aq=0.0, maps=None, ref0=
     o = OraclePipeline(W, H, 27, lambda_q4(27), **tools)
     dpb = {}
     spread = set()
+    # the references of every picture first: a B picture nothing predicts from is coded without intra candidates, joint refinement and SAO (the host's lean B pictures, ks265_enc.c submit)
+    all_refs = [refs_of(i, poc, kind) for i, (poc, kind, _, _) in enumerate(per)]
+    used = set()
+    for a, b in all_refs:
+        for r in (a, b):
+            used |= set(r) if isinstance(r, list) else ({r} if r is not None else set())
     for i, (poc, kind, _, qp) in enumerate(per[:upto]):
         o.set_qp(qp, lambda_q4(qp, inter=kind != "I"))
+        o.set_picture_tools(*((0, 0, 0) if kind == "B" and poc not in used else (-1, -1, -1)))
         if maps is not None:
             o.set_qp_map(maps[poc]); spread |= set(maps[poc].tolist())
         elif aq:
             qmap = _aq_map(o, clip[poc], qp, aq)
             o.set_qp_map(qmap)
             spread |= set(qmap.tolist())
-        r0, r1 = refs_of(i, poc, kind)
+        r0, r1 = all_refs[i]
         if kind == "P" and r0 is not None and not isinstance(r0, list):    # round 6: an anchor of a pyramid searches the last ref0 anchors of its GOP, nearest first (-ref0; ks265_enc.c)
             last_key = max(j for j, (_, k, _, _) in enumerate(per[:i]) if k == "I")
             hist = [p for p, k, _, _ in per[last_key:i] if k != "B"][::-1]

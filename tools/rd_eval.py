@@ -70,6 +70,7 @@ def encode_ours(clip, W, H, qp, gop, tools, verbose=False, stats=None, pdelta=1,
             seq = [(d, 'B', r0, r0, 0) if k == 'P' else (d, k, r0, r1, l) for (d, k, r0, r1, l) in seq]
         if os.environ.get('RD_GPB2'):                                 # generalised B at the P positions: list 0 = the previous anchor, list 1 = the one before it
             seq = [(d, 'B', r0, r0 - G if r0 >= G else r0, 0) if k == 'P' else (d, k, r0, r1, l) for (d, k, r0, r1, l) in seq]
+    encode_ours._cfg0 = {nm: getattr(o.cfg, nm) for nm in ('sao', 'bi_refine', 'propagate', 'intra_inter', 'merge', 'rdo')}
     dpb = {}
     # -ref0 (round 6; the host's default under --host: 3 = what -preset slow resolves to): the anchors of the hierarchy search the last RD_MREF anchors of their GOP, nearest first
     nmref = int(os.environ.get('RD_MREF', '3' if lam_scale == -1 else '1'))
@@ -94,6 +95,18 @@ def encode_ours(clip, W, H, qp, gop, tools, verbose=False, stats=None, pdelta=1,
             o.o.kso_experiment_split_bits_b(sb[min(len(sb) - 1, max(layer, 0))])
         if rdo_layers:
             o.cfg.rdo = rdo_layers[0] if kind == 'P' else rdo_layers[min(len(rdo_layers) - 1, layer)] if kind == 'B' else tools.get('rdo', 0)
+        if os.environ.get('RD_II_LAYERS') and kind == 'B':            # experiment: intra CUs per B layer (1 .. 3), e.g. 1,1,0 = none in the top layer
+            iil = [int(x) for x in os.environ['RD_II_LAYERS'].split(',')]
+            o.cfg.intra_inter = iil[min(len(iil) - 1, max(layer, 1) - 1)]
+        elif os.environ.get('RD_II_LAYERS'):
+            o.cfg.intra_inter = tools.get('intra_inter', 0)
+        if os.environ.get('RD_LAYER_TOOLS'):                          # experiment: cfg fields per B layer (1 .. 3), e.g. sao=1,1,0;bi_refine=2,2,0 (the other pictures keep the tool set's values)
+            for spec in os.environ['RD_LAYER_TOOLS'].split(';'):
+                nm, vals = spec.split('='); vals = [int(x) for x in vals.split(',')]
+                setattr(o.cfg, nm, vals[min(len(vals) - 1, max(layer, 1) - 1)] if kind == 'B' else tools.get(nm, getattr(encode_ours, '_cfg0', {}).get(nm, 0)))
+        if lam_scale == -1 and not os.environ.get('RD_NO_LEAN_B'):     # --host: the host's lean B pictures (ks265_enc.c submit) - a B picture nothing predicts from runs without intra candidates, joint refinement, SAO
+            lean = kind == 'B' and not any(d in (a, b) for (_, _, a, b, _) in seq[i + 1:])
+            o.set_picture_tools(*((0, 0, 0) if lean else (-1, -1, -1)))
         mr = mrs[i]
         if getattr(encode_ours, "rdoq_select", None):
             encode_ours.rdoq_select(kind)
@@ -114,7 +127,7 @@ def encode_ours(clip, W, H, qp, gop, tools, verbose=False, stats=None, pdelta=1,
         elif kind == "P":
             b = w.slice(S.NAL_TRAIL_R, S.SLICE_P, d, q, o.cu8, o.lvl, o.sao, rps=rps, l0=mr if len(mr) > 1 else [r0])
         else:
-            b = w.slice(S.NAL_TRAIL_R if isref else S.NAL_TRAIL_N, S.SLICE_B, d, q, o.cu8, o.lvl, o.sao, rps=rps, l0=[r0], l1=[r1])
+            b = w.slice(S.NAL_TRAIL_R if isref else S.NAL_TRAIL_N, S.SLICE_B, d, q, o.cu8, o.lvl, o.sao if o.cfg.sao else None, rps=rps, l0=[r0], l1=[r1])
         bs += b
         if getattr(encode_ours, "rdoq_adaptive", None):                  # --rdoq-adaptive: the tables of the NEXT picture of this kind come from this slice's final context states
             encode_ours.rdoq_adaptive(kind, w)
