@@ -381,9 +381,10 @@ int ks265_frame_set_qp(ks265_frame *f, int qp, int lambda_q4);
 /* round 6 - tools per picture: a host that codes a whole pyramid on one frame object lowers tools for some of its pictures (host/ks265_enc.c: the B pictures nothing predicts
  * from run without intra candidates, without the joint refinement and without SAO - measured on the CPU mirror and on the MI355X: the bytes at equal PSNR-Y stay, a quarter
  * of such a picture's kernel time goes).  Each argument: -1 = the value the frame object was created with, else the value cfg.intra_inter / cfg.bi_refine / cfg.sao take for
- * the pictures coded from now on - 0 or the created value (the workspace is the creation's).  With cfg.sao = 0 a B picture is reconstructed and deblocked straight in
+ * the pictures coded from now on - 0 or the created value (the workspace is the creation's); me_method: -1 = as created, else 0 .. 2 (interMeDia / interMeHex / interMeUMH: the
+ * search method needs no workspace of its own).  With cfg.sao = 0 a B picture is reconstructed and deblocked straight in
  * recon_out (no SAO launch, no copy); its SAO records are written as "off" and the host passes ks265_slice_in.sao = NULL (slice_sao_luma_flag = slice_sao_chroma_flag = 0). */
-int ks265_frame_set_picture_tools(ks265_frame *f, int intra_inter, int bi_refine, int sao);
+int ks265_frame_set_picture_tools(ks265_frame *f, int intra_inter, int bi_refine, int sao, int me_method);
 
 /* expandPicture_c enc@0x4a6ae0: replicate the picture edge into the borders of all three planes */
 int ks265_pad_picture(ks265_frame *f, ks265_pic pic);

@@ -115,12 +115,13 @@ int ks265_frame_set_qp(ks265_frame *f, int qp, int lambda_q4)
     return KS265_OK;
 }
 
-int ks265_frame_set_picture_tools(ks265_frame *f, int intra_inter, int bi_refine, int sao)
+int ks265_frame_set_picture_tools(ks265_frame *f, int intra_inter, int bi_refine, int sao, int me_method)
 {
     KS_FRAME_CHECK(f);
     const int ii = intra_inter < 0 ? f->cfg0.intra_inter : intra_inter, br = bi_refine < 0 ? f->cfg0.bi_refine : bi_refine, so = sao < 0 ? f->cfg0.sao : sao;
     if ((ii && ii != f->cfg0.intra_inter) || (br && br != f->cfg0.bi_refine) || (so && so != f->cfg0.sao)) return KS265_NOTSUPPORTED;   /* off, or what the workspace was made for */
-    f->cfg.intra_inter = ii; f->cfg.bi_refine = br; f->cfg.sao = so;
+    if (me_method > 2) return KS265_NOTSUPPORTED;
+    f->cfg.intra_inter = ii; f->cfg.bi_refine = br; f->cfg.sao = so; f->cfg.me_method = me_method < 0 ? f->cfg0.me_method : me_method;
     return KS265_OK;
 }
 

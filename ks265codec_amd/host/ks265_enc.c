@@ -870,7 +870,7 @@ static int submit(Enc *e, Input *in, int kind, int poc, int qp, const int *l0, i
     /* round 6: a B picture nothing predicts from (half the pictures of a pyramid of 8) runs without intra candidates, without the joint refinement of its bi-predictive CUs and
      * without SAO - on the CPU mirror and on the MI355X its bytes at equal PSNR-Y stay (the refinement even costs bytes at QP + 4), a quarter of its kernel time goes */
     const int lean = e->lean_b && kind == 'B' && !is_ref;
-    if (!r) r = lean ? ks265_frame_set_picture_tools(fr, 0, 0, 0) : ks265_frame_set_picture_tools(fr, -1, -1, -1);
+    if (!r) r = lean ? ks265_frame_set_picture_tools(fr, 0, 0, 0, e->lean_b >= 2 && e->me_method == 2 ? 1 : -1) : ks265_frame_set_picture_tools(fr, -1, -1, -1, -1);
     if (e->rdoq_on && kind == 'I') e->rq_gop_seq = e->rc_sub;
     if (!r && e->rdoq_on && kind != 'I') {
         /* -rdoq 1: wait until every picture up to RC_LAG before this one is accounted (as the rate controller does), then the latest tables of this picture's kind among them */
@@ -1518,7 +1518,7 @@ static Enc *lane_open(QY265EncConfig *cfg, int device, int multi, int *err)
                                                                          * integer search (measured with one round: - 21 .. - 23 % bytes of the P / B pictures; the variable is a measuring aid) */
     e->fcfg.intra_inter = 1;                                            /* P / B pictures may hold intra CUs (uncovered regions, occlusions); 2 = none of 8x8: measured + 1.6 % bits, no faster */
     e->fcfg.rdo = 4;                                                    /* coefficient-group pruning at lambda x 1 (ks265_frame_cfg.rdo): supersedes the coefficient decimation of round 2 */
-    e->lean_b = getenv("KS265_LEAN_B") ? atoi(getenv("KS265_LEAN_B")) != 0 : 1;           /* non-reference B pictures without intra candidates / joint refinement / SAO (submit) */
+    e->lean_b = getenv("KS265_LEAN_B") ? atoi(getenv("KS265_LEAN_B")) : 1;           /* non-reference B pictures without intra candidates / joint refinement / SAO (submit) */
     e->fcfg.skip_rd = getenv("KS265_SKIP_RD") ? atoi(getenv("KS265_SKIP_RD")) & 3 : 1;   /* stage D2 (round 6): after the reconstruction of a B picture, nodes whose merge candidate without
                                                                          * residual is the cheaper coding - on the coded distortion - become one CU (ks265_frame_cfg.skip_rd; 2 = P pictures
                                                                          * too, where it gains nothing measurable; the variable is a measuring aid) */

@@ -362,9 +362,9 @@ class KsFrame:
         self.cfg.qp, self.cfg.lambda_q4 = qp, lambda_q4
         self.ks._chk(self.lib.ks265_frame_set_qp(self.h, C.c_int(qp), C.c_int(lambda_q4)))
 
-    def set_picture_tools(self, intra_inter: int = -1, bi_refine: int = -1, sao: int = -1):
+    def set_picture_tools(self, intra_inter: int = -1, bi_refine: int = -1, sao: int = -1, me_method: int = -1):
         """tools of the pictures coded from here on (-1 = as created, else 0 or the created value): ks265_frame_set_picture_tools"""
-        self.ks._chk(self.lib.ks265_frame_set_picture_tools(self.h, C.c_int(intra_inter), C.c_int(bi_refine), C.c_int(sao)))
+        self.ks._chk(self.lib.ks265_frame_set_picture_tools(self.h, C.c_int(intra_inter), C.c_int(bi_refine), C.c_int(sao), C.c_int(me_method)))
 
     def set_qp_map(self, dev_map):
         """one QP per CTU (device int8 array, raster; None = off) for the pictures coded from here on; the caller keeps the array alive"""

@@ -19,7 +19,7 @@ struct ks265_frame {
     ks265_ctx *ctx; ks265_frame_cfg cfg; ks265_frame_geom g;
     int cur_pu, have_prev;
     ks265_cu8 *cu8; ks265_sao_param *sao; uint64_t kind_hash, rq_hash;
-    int tools0[3];                                            /* intra_inter, bi_refine, sao as created (ks265_frame_set_picture_tools) */
+    int me0, tools0[3];                                            /* intra_inter, bi_refine, sao as created (ks265_frame_set_picture_tools) */
     int16_t *lvl[3];                                          /* level planes, W x H and two W/2 x H/2, packed */
 };
 
@@ -98,7 +98,7 @@ int ks265_frame_create(ks265_ctx *ctx, const ks265_frame_cfg *cfg, ks265_frame *
     ks265_frame *f = (ks265_frame *)calloc(1, sizeof *f);
     if (!f) return KS265_OUTOFMEMORY;
     f->ctx = ctx; f->cfg = *cfg;
-    f->tools0[0] = cfg->intra_inter; f->tools0[1] = cfg->bi_refine; f->tools0[2] = cfg->sao;
+    f->me0 = cfg->me_method; f->tools0[0] = cfg->intra_inter; f->tools0[1] = cfg->bi_refine; f->tools0[2] = cfg->sao;
     if (ks265_frame_geometry(cfg, &f->g)) { free(f); return KS265_NOTSUPPORTED; }
     f->cu8 = (ks265_cu8 *)calloc(1, (size_t)f->g.bytes_cu8); f->sao = (ks265_sao_param *)calloc(1, (size_t)f->g.bytes_sao);
     const size_t npx = (size_t)cfg->width * cfg->height;
@@ -110,8 +110,10 @@ void ks265_frame_destroy(ks265_frame *f) { if (f) { free(f->cu8); free(f->sao); 
 int ks265_frame_set_qp(ks265_frame *f, int qp, int l) { f->cfg.qp = qp; f->cfg.lambda_q4 = l; return KS265_OK; }
 /* tools per picture: the stand-in's pictures do not depend on them; KS265_STUB_TOOLS_LOG = file: one line per inter picture handed in - kind, the three values - so that a
  * host test sees which pictures the host lowered them for */
-int ks265_frame_set_picture_tools(ks265_frame *f, int ii, int br, int so)
+int ks265_frame_set_picture_tools(ks265_frame *f, int ii, int br, int so, int me)
 {
+    if (me > 2) return KS265_NOTSUPPORTED;
+    f->cfg.me_method = me < 0 ? f->me0 : me;
     const int v[3] = {ii, br, so};
     for (int i = 0; i < 3; ++i) {
         const int x = v[i] < 0 ? f->tools0[i] : v[i];
@@ -126,7 +128,7 @@ static void tools_log(const ks265_frame *f, char kind)
     if (!p) return;
     FILE *fp = fopen(p, "a");
     if (!fp) return;
-    fprintf(fp, "%c %d %d %d\n", kind, f->cfg.intra_inter, f->cfg.bi_refine, f->cfg.sao);
+    fprintf(fp, "%c %d %d %d %d\n", kind, f->cfg.intra_inter, f->cfg.bi_refine, f->cfg.sao, f->cfg.me_method);
     fclose(fp);
 }
 int ks265_frame_p_state(ks265_frame *f) { return (f->cur_pu & 1) | (f->have_prev ? 2 : 0); }

@@ -106,11 +106,11 @@ class OraclePipeline:
         self.src, self.rec, self.deb = HostPic(g), HostPic(g), HostPic(g)
         self.ref = HostPic(g)
 
-    def set_picture_tools(self, intra_inter: int = -1, bi_refine: int = -1, sao: int = -1) -> None:
+    def set_picture_tools(self, intra_inter: int = -1, bi_refine: int = -1, sao: int = -1, me_method: int = -1) -> None:
         """ks265_frame_set_picture_tools: the tools of the pictures coded from here on (-1 = as created)"""
         if not hasattr(self, "_tools0"):
-            self._tools0 = (self.cfg.intra_inter, self.cfg.bi_refine, self.cfg.sao)
-        self.cfg.intra_inter, self.cfg.bi_refine, self.cfg.sao = (t0 if v < 0 else v for v, t0 in zip((intra_inter, bi_refine, sao), self._tools0))
+            self._tools0 = (self.cfg.intra_inter, self.cfg.bi_refine, self.cfg.sao, self.cfg.me_method)
+        self.cfg.intra_inter, self.cfg.bi_refine, self.cfg.sao, self.cfg.me_method = (t0 if v < 0 else v for v, t0 in zip((intra_inter, bi_refine, sao, me_method), self._tools0))
 
     def skip_pass(self, r0: OPic, r1: OPic) -> None:
         """stage D2 (round 6): after the reconstruction of the inter CUs - nodes whose merge candidate without residual is the cheaper coding become one CU (kso_skip_pass)"""

@@ -230,7 +230,7 @@ def test_tools_per_picture(ks, W, H, abc, pan, seed):
             q = 27 + dq
             lam = lambda_q4(q, inter=kind != "I")
             o.set_qp(q, lam); f.set_qp(q, lam)
-            t = (0, 0, 0) if lean else (-1, -1, -1)
+            t = ((0, 0, 0, 1) if W == 1920 else (0, 0, 0)) if lean else (-1, -1, -1)       # (1080p: the lean pictures also search with interMeHex instead of interMeUMH)
             o.set_picture_tools(*t); f.set_picture_tools(*t)
             f.load_i420(ks.dev(clip[d]), src)
             out = f.new_pic()

@@ -221,8 +221,8 @@ def test_b_pictures_nothing_predicts_from_are_coded_lean(stub_lib, tmp_path, bfr
     r = run(stub_lib, 33, 128, bframes, out=tmp_path / "l.265", KS265_STUB_TOOLS_LOG=log)
     lines = [ln.split() for ln in open(log).read().splitlines()]
     assert len(lines) == 33 and r["vcl"] == 33
-    lean = [ln for ln in lines if ln[1:] == ["0", "0", "0"]]
-    full = [ln for ln in lines if ln[1:] != ["0", "0", "0"]]
+    lean = [ln for ln in lines if ln[1:4] == ["0", "0", "0"]]
+    full = [ln for ln in lines if ln[1:4] != ["0", "0", "0"]]
     assert all(k == "B" for k, *_ in lean) and len(lean) == lean_of_8 * 4 if bframes != 2 else len(lean) > 0, (len(lean), lines[:12])
     assert len({tuple(ln[1:]) for ln in full}) == 1 and full[0][3] != "0", full[:4]              # everything else: the one full tool set, SAO on
     if os.path.exists(REF_DEC):
