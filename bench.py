@@ -219,7 +219,8 @@ def main():
                 q = qp + host_qp_offset(kind, layer=layer, hier=True)   # the encoder host's ladder (= the reference's): anchors Q + 1, B layers + 2 / + 4 / + 4
                 fr.set_qp(q, lambda_q4(q, inter=kind != "I"))       # P / B pictures: the encoder host's inter table (ks265_enc.c kLambdaInterQ4)
                 lean = kind == "B" and (1 << layer) == args.hier_b and not os.environ.get("KS265_LEAN_B") == "0"     # the host's lean B pictures: the top layer (nothing predicts from it) without intra candidates, joint refinement, SAO
-                fr.set_picture_tools(*((0, 0, 0, 1 if os.environ.get("KS265_LEAN_B") == "2" and me_method == 2 else -1) if lean else (-1, -1, -1, -1)))
+                near = kind == "B" and (2 << layer) == args.hier_b and os.environ.get("KS265_LEAN_B") not in ("0", "3")      # ... the layer above it (references two pictures away): without intra candidates and SAO
+                fr.set_picture_tools(*((0, 0, 0, 1 if os.environ.get("KS265_LEAN_B") == "2" and me_method == 2 else -1) if lean else (0, -1, 0, -1) if near else (-1, -1, -1, -1)))
                 out = dpb[d % G1]
                 hist = state["hist"]                                # the GOP's anchors so far, nearest first (-ref0: an anchor searches the last ref0 of them, as the encoder host schedules it)
                 multi = kind == "P" and R0 > 1 and len(hist) > 1 and hist[0] == r0
@@ -418,7 +419,7 @@ def main():
                 d, kind, r0, r1, layer = next(hs)
                 q = qp + host_qp_offset(kind, layer=layer, hier=True)
                 frh.set_qp(q, lambda_q4(q, inter=kind != "I"))
-                frh.set_picture_tools(*((0, 0, 0, 1 if os.environ.get("KS265_LEAN_B") == "2" and me_method == 2 else -1) if kind == "B" and layer == 3 and not os.environ.get("KS265_LEAN_B") == "0" else (-1, -1, -1, -1)))      # the host's lean B pictures
+                frh.set_picture_tools(*((0, 0, 0, 1 if os.environ.get("KS265_LEAN_B") == "2" and me_method == 2 else -1) if kind == "B" and layer == 3 and not os.environ.get("KS265_LEAN_B") == "0" else (0, -1, 0, -1) if kind == "B" and layer == 2 and os.environ.get("KS265_LEAN_B") not in ("0", "3") else (-1, -1, -1, -1)))      # the host's lean B pictures
                 out = hd[d % NH]
                 if kind == "B":
                     frh.encode_picture_b(src_of(d), hd[r0 % NH], hd[r1 % NH], out)

@@ -869,8 +869,11 @@ static int submit(Enc *e, Input *in, int kind, int poc, int qp, const int *l0, i
     if (!r) r = ks265_frame_set_qp(fr, qp, kind == 'I' ? kLambdaQ4[qp] : kLambdaInterQ4[qp]);
     /* round 6: a B picture nothing predicts from (half the pictures of a pyramid of 8) runs without intra candidates, without the joint refinement of its bi-predictive CUs and
      * without SAO - on the CPU mirror and on the MI355X its bytes at equal PSNR-Y stay (the refinement even costs bytes at QP + 4), a quarter of its kernel time goes */
-    const int lean = e->lean_b && kind == 'B' && !is_ref;
-    if (!r) r = lean ? ks265_frame_set_picture_tools(fr, 0, 0, 0, e->lean_b >= 2 && e->me_method == 2 ? 1 : -1) : ks265_frame_set_picture_tools(fr, -1, -1, -1, -1);
+    /* ... and a B picture others predict from whose own references are at most two pictures away (the second-deepest layer of a pyramid) keeps the refinement but runs without intra
+     * candidates and without SAO: neutral at equal PSNR-Y on the mirror's three clips (profiles/r06_lean_b.txt) */
+    const int near = kind == 'B' && is_ref && nl0 > 0 && nl1 > 0 && poc - l0[0] <= 2 && l1[0] - poc <= 2;
+    const int lean = !e->lean_b || kind != 'B' ? 0 : !is_ref ? 2 : near && e->lean_b != 3 ? 1 : 0;          /* (KS265_LEAN_B=3: the non-reference pictures alone) */
+    if (!r) r = lean == 2 ? ks265_frame_set_picture_tools(fr, 0, 0, 0, e->lean_b == 2 && e->me_method == 2 ? 1 : -1) : lean == 1 ? ks265_frame_set_picture_tools(fr, 0, -1, 0, -1) : ks265_frame_set_picture_tools(fr, -1, -1, -1, -1);
     if (e->rdoq_on && kind == 'I') e->rq_gop_seq = e->rc_sub;
     if (!r && e->rdoq_on && kind != 'I') {
         /* -rdoq 1: wait until every picture up to RC_LAG before this one is accounted (as the rate controller does), then the latest tables of this picture's kind among them */
@@ -1033,7 +1036,7 @@ static int submit(Enc *e, Input *in, int kind, int poc, int qp, const int *l0, i
     if (!r) r = ks265_event_record(e->ctx_out, j->ev);
     if (r) return hip_rc(r);
     ++e->seq;
-    j->no_sao = lean;
+    j->no_sao = lean != 0;
     j->disp = in->disp; j->pts = in->pts; j->poc = poc; j->kind = kind; j->qp = qp; j->is_ref = is_ref; j->key_headers = key_headers; j->rc_delta = e->rc_qp_delta;
     j->rc_budget = (double)in->kbps * 1000.0 / (e->cfg.frameRate > 0 ? e->cfg.frameRate : 25.0);
     j->nal_type = kind == 'I' ? KS265_NAL_IDR_W_RADL : is_ref ? KS265_NAL_TRAIL_R : KS265_NAL_TRAIL_N;

@@ -79,7 +79,10 @@ def _mirror(clip, W, H, per, refs_of, rec, tools, upto, aq=0.0, maps=None, ref0=
             used |= set(r) if isinstance(r, list) else ({r} if r is not None else set())
     for i, (poc, kind, _, qp) in enumerate(per[:upto]):
         o.set_qp(qp, lambda_q4(qp, inter=kind != "I"))
-        o.set_picture_tools(*((0, 0, 0) if kind == "B" and poc not in used else (-1, -1, -1)))
+        a0, a1 = all_refs[i]
+        n0, n1 = (a0[0] if isinstance(a0, list) else a0), (a1[0] if isinstance(a1, list) else a1)
+        near = kind == "B" and poc - n0 <= 2 and n1 - poc <= 2                    # ... and one others predict from whose references are at most two pictures away: no intra candidates, no SAO
+        o.set_picture_tools(*((0, 0, 0) if kind == "B" and poc not in used else (0, -1, 0) if near else (-1, -1, -1)))
         if maps is not None:
             o.set_qp_map(maps[poc]); spread |= set(maps[poc].tolist())
         elif aq:

@@ -212,25 +212,34 @@ def test_every_bframes_value_opens_and_decodes(stub_lib, tmp_path, bframes):
         assert d.returncode == 0 and os.path.getsize(tmp_path / "d.yuv") == 70 * 128 * 72 * 3 // 2, d.stdout[-300:] + d.stderr[-300:]
 
 
-@pytest.mark.parametrize("bframes,lean_of_8", [(-1, 4), (3, 4), (2, 4), (0, 0)])
-def test_b_pictures_nothing_predicts_from_are_coded_lean(stub_lib, tmp_path, bframes, lean_of_8):
-    """round 6: the host lowers the tools (ks265_frame_set_picture_tools: no intra candidates, no joint refinement, no SAO) exactly for the B pictures nothing predicts from - half
-    the pictures of a pyramid of 8 - and restores them for every other picture; such a picture's slice carries slice_sao_luma_flag = slice_sao_chroma_flag = 0 (the writer gets no
-    SAO records) and the stream still decodes; KS265_LEAN_B=0 keeps every picture on the full tool set"""
+@pytest.mark.parametrize("bframes,lean32,near32", [(-1, 16, 8), (3, 16, 8), (2, 1, 0), (0, 0, 0)])
+def test_b_pictures_nothing_predicts_from_are_coded_lean(stub_lib, tmp_path, bframes, lean32, near32):
+    """round 6: the host lowers the tools (ks265_frame_set_picture_tools) exactly for the B pictures nothing predicts from - half the pictures of a pyramid of 8: no intra
+    candidates, no joint refinement, no SAO - and, keeping the refinement, for the reference B pictures whose own references are at most two pictures away (the layer above);
+    every other picture runs the full set; a picture without SAO carries slice_sao_luma_flag = slice_sao_chroma_flag = 0 (the writer gets no SAO records) and the stream still
+    decodes; KS265_LEAN_B=3 lowers the non-reference pictures alone, KS265_LEAN_B=0 none"""
     log = tmp_path / "tools.txt"
     r = run(stub_lib, 33, 128, bframes, out=tmp_path / "l.265", KS265_STUB_TOOLS_LOG=log)
     lines = [ln.split() for ln in open(log).read().splitlines()]
     assert len(lines) == 33 and r["vcl"] == 33
+    full = [ln for ln in lines if ln[1] != "0"]
+    tools0 = full[0][1:]
     lean = [ln for ln in lines if ln[1:4] == ["0", "0", "0"]]
-    full = [ln for ln in lines if ln[1:4] != ["0", "0", "0"]]
-    assert all(k == "B" for k, *_ in lean) and len(lean) == lean_of_8 * 4 if bframes != 2 else len(lean) > 0, (len(lean), lines[:12])
-    assert len({tuple(ln[1:]) for ln in full}) == 1 and full[0][3] != "0", full[:4]              # everything else: the one full tool set, SAO on
+    near = [ln for ln in lines if ln[1:4] == ["0", tools0[1], "0"]]
+    assert len(full) + len(lean) + len(near) == 33 and all(k == "B" for k, *_ in lean + near), lines[:12]
+    assert (len(lean), len(near)) == (lean32, near32) if bframes != 2 else len(lean) > 0 and not near, (len(lean), len(near), lines[:12])
+    assert len({tuple(ln[1:]) for ln in full}) == 1 and tools0[2] != "0", full[:4]                   # everything else: the one full tool set, SAO on
     if os.path.exists(REF_DEC):
         d = subprocess.run([REF_DEC, "-b", str(tmp_path / "l.265"), "-o", str(tmp_path / "d.yuv"), "-threads", "2"], capture_output=True, text=True, cwd=tmp_path)
         assert d.returncode == 0 and os.path.getsize(tmp_path / "d.yuv") == 33 * 128 * 72 * 3 // 2, d.stdout[-300:] + d.stderr[-300:]
     os.remove(log)
+    r3 = run(stub_lib, 33, 128, bframes, out=tmp_path / "n.265", KS265_STUB_TOOLS_LOG=log, KS265_LEAN_B=3)
+    l3 = [ln.split() for ln in open(log).read().splitlines()]
+    assert sum(ln[1:4] == ["0", "0", "0"] for ln in l3) == len(lean) and sum(ln[1:] == tools0 for ln in l3) == 33 - len(lean)
+    assert (r3["md5"] != r["md5"]) == (len(near) > 0)
+    os.remove(log)
     r0 = run(stub_lib, 33, 128, bframes, out=tmp_path / "f.265", KS265_STUB_TOOLS_LOG=log, KS265_LEAN_B=0)
-    assert all(ln.split()[1:] == full[0][1:] for ln in open(log).read().splitlines())
+    assert all(ln.split()[1:] == tools0 for ln in open(log).read().splitlines())
     assert (r0["md5"] != r["md5"]) == (len(lean) > 0)                                               # the slice headers differ where SAO is off
 
 

@@ -102,7 +102,8 @@ def encode_ours(clip, W, H, qp, gop, tools, verbose=False, stats=None, pdelta=1,
             o.cfg.intra_inter = tools.get('intra_inter', 0)
         if lam_scale == -1 and not os.environ.get('RD_NO_LEAN_B'):     # --host: the host's lean B pictures (ks265_enc.c submit) - a B picture nothing predicts from runs without intra candidates, joint refinement, SAO
             lean = kind == 'B' and not any(d in (a, b) for (_, _, a, b, _) in seq[i + 1:])
-            o.set_picture_tools(*((0, 0, 0) if lean else (-1, -1, -1)))
+            near = kind == 'B' and not lean and d - r0 <= 2 and r1 - d <= 2 and not os.environ.get('RD_LEAN_NONREF_ONLY')      # a reference B picture with both references at most two pictures away: no intra candidates, no SAO
+            o.set_picture_tools(*((0, 0, 0) if lean else (0, -1, 0) if near else (-1, -1, -1)))
         if os.environ.get('RD_LAYER_TOOLS'):                          # experiment: cfg fields per B layer (1 .. 3), e.g. sao=1,1,0;bi_refine=2,2,0 (the other pictures keep the tool set's values)
             for spec in os.environ['RD_LAYER_TOOLS'].split(';'):
                 nm, vals = spec.split('='); vals = [int(x) for x in vals.split(',')]
