@@ -848,7 +848,7 @@ def encoded_line(args, enc, world, hot, cpu):
                    "slice_write_ms_per_picture_per_thread": round(enc["slice_write_ms_per_picture"], 2),
                    "caller_ms_per_picture": enc.get("caller_ms_per_picture"),
                    "in_the_path": "pyramid pre-search, merge pass (merge / skip decided on SATD + rate, signalled where the motion equals a merge candidate), AMVP with the better of the two "
-                                  "predictors, vector propagation between neighbouring PUs (stage A2, one round), joint refinement of bi-predictive pairs (B pictures, bi-prediction judged at 31/32), the anchors of a pyramid searching the last three anchors (-ref0 3), intra CUs in P / B pictures, the skip pass over B pictures (a CU with residual against its first two merge candidates without residual: SSE of the real reconstruction + level bits), lean B pictures (the B pictures nothing predicts from - half of a pyramid of 8 - without intra candidates, joint refinement and SAO: ks265_frame_set_picture_tools; bytes at equal PSNR-Y unchanged), coefficient-group pruning (luma) and sign-data hiding "
+                                  "predictors, vector propagation between neighbouring PUs (stage A2, one round), bi-prediction judged at 31/32 (the joint refinement of the pairs runs from -preset slower on: at -preset slow it cost 0.5 - 0.7 % bytes at equal PSNR-Y and 134 us per B picture, measured), the anchors of a pyramid searching the last three anchors (-ref0 3), intra CUs in P / B pictures, the skip pass over B pictures (a CU with residual against its first two merge candidates without residual: SSE of the real reconstruction + level bits), lean B pictures (the B pictures nothing predicts from - half of a pyramid of 8 - without intra candidates, joint refinement and SAO: ks265_frame_set_picture_tools; bytes at equal PSNR-Y unchanged), coefficient-group pruning (luma) and sign-data hiding "
                                   "(signBitHidingHDQ) at the postQuant seam, P / B lambda table; fractional samples interpolated on the fly; the picture's drain (SSE, packing of the records) and the next source picture's unpack on side streams (DESIGN.md 6a)",
                    "not_in_the_path": "the reference's rdoQuant (an option: -rdoq 1; the presets' rdoq = 1 runs this build's seam), CU size judged with the residual's cost, generalised B pictures; "
                                       "at equal PSNR-Y the stream is 0.99x (2160p) / 1.02x (1080p) the size of appencoder's for IPPP and 1.21x / 1.01x for the default GOP on the same (ping-pong) clips, "

@@ -1527,7 +1527,7 @@ static Enc *lane_open(QY265EncConfig *cfg, int device, int multi, int *err)
                                                                          * too, where it gains nothing measurable; the variable is a measuring aid) */
     e->fcfg.tu_inter = cfg->tuInter > 0 ? 1 : 0;                        /* -intertu N (tuInter; veryslow 1, placebo 2): the residual quadtree of inter CUs ONE level deep (ks265_frame_cfg.tu_inter); deeper values run as 1 */
     e->fcfg.part = cfg->part ? 1 : 0;                                   /* -part 1 (slower, veryslow, placebo): 2NxN / Nx2N prediction units in P and B pictures (ks265_frame_cfg.part) */
-    e->fcfg.bi_refine = getenv("KS265_BI_REFINE") ? atoi(getenv("KS265_BI_REFINE")) : 2;   /* (2, round 5: after the CU decision, for the CUs it chose - the same bytes within 0.04 %, a third of the time; 1 = for every PU of the quadtree) */                                              /* B pictures: joint refinement of the bi-predictive pair (motionSearchBI enc@0x484910) */
+    e->fcfg.bi_refine = getenv("KS265_BI_REFINE") ? atoi(getenv("KS265_BI_REFINE")) : (cfg->preset >= QY265PRESET_SLOWER && cfg->preset <= QY265PRESET_PLACEBO ? 2 : 0);   /* 2 (round 5): after the CU decision, for the CUs it chose; 1 = for every PU of the quadtree.  End of round 6: up to -preset slow it is off - measured on the MI355X at 1080p and 2160p it COSTS 0.5 - 0.7 % bytes at equal PSNR-Y (it lowers the Hadamard cost of residuals the quantiser drops, and pays vector bits) and 134 us per B picture; the presets that trade speed for tools (slower .. placebo) keep it */                                              /* B pictures: joint refinement of the bi-predictive pair (motionSearchBI enc@0x484910) */
     r = ks265_frame_geometry(&e->fcfg, &e->geom);
     if (!r) r = ks265_frame_create(e->ctx, &e->fcfg, &e->frame);
     const size_t fsz = (size_t)e->W * e->H * 3 / 2, npx = (size_t)e->W * e->H;

@@ -69,7 +69,7 @@ def subme_knobs(preset: str) -> dict:
 
 # THE tool set of the encoder host at -preset slow (host/ks265_enc.c: encoder_open) - bench.py, __graft_entry__.smoke(), the GPU tests and tools/rd_eval.py --host all
 # import this one dict, so that what is timed is what is tested.
-ENCODER_TOOLS = dict(me_method=2, me_hex_thr=16, sdh=1, pre_search=1, merge=1, bi_refine=2, rdo=4, intra_inter=1, propagate=1, skip_rd=1, **subme_knobs("slow"))
+ENCODER_TOOLS = dict(me_method=2, me_hex_thr=16, sdh=1, pre_search=1, merge=1, bi_refine=0, rdo=4, intra_inter=1, propagate=1, skip_rd=1, **subme_knobs("slow"))     # (bi_refine: 2 from -preset slower on)
 
 
 # the encoder host's QP ladders at -rc 0 (host/ks265_enc.c kIpppCascade / kHierLayerQp = the reference's own, read from its -psnr 2 lines): the QP of a picture is the

@@ -21,7 +21,10 @@ REF_DEC = os.path.join(os.path.dirname(HERE), "oracle", "_ref", "appdecoder")
 GOLD = os.path.join(HERE, "golden", "dqp_md5.json")
 
 
-def encode(W, H, n, qp, seed, spread, kinds="IPPP", tools=ENCODER_TOOLS):
+FIXTURE_TOOLS = dict(ENCODER_TOOLS, bi_refine=2)              # the tool set the decoder-verified fixtures were written with (the host's up to the end of round 6; from -preset slower on since)
+
+
+def encode(W, H, n, qp, seed, spread, kinds="IPPP", tools=FIXTURE_TOOLS):
     clip = make_clip(W, H, n, seed=seed, abc=(17, 23, 9), pan=(5, 3))
     rng = np.random.default_rng(seed)
     cols, rows = (W + 63) // 64, (H + 63) // 64

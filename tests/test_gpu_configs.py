@@ -219,7 +219,7 @@ def test_tools_per_picture(ks, W, H, abc, pan, seed):
     from oracle_lib import OraclePipeline
     clip = make_clip(W, H, 9, seed=seed, abc=abc, pan=pan)
     order = [(0, "I", None, None, 0, False), (4, "P", 0, None, 1, False), (2, "B", 0, 4, 2, False), (1, "B", 0, 2, 4, True), (3, "B", 2, 4, 4, True), (8, "P", 4, None, 1, False), (6, "B", 4, 8, 2, False), (5, "B", 4, 6, 4, True)]
-    tools = dict(ENCODER_TOOLS)
+    tools = dict(ENCODER_TOOLS, bi_refine=2)                            # (the joint refinement as from -preset slower on: switched per picture here)
     o = OraclePipeline(W, H, 27, lambda_q4(27), me_method=2, me_hex_thr=16, **tools)
     with KsFrame(ks, W, H, 27, lambda_q4(27), me_method=2, me_hex_thr=16, bframes=3, **tools) as f:
         with pytest.raises(Exception):

@@ -26,7 +26,7 @@ def test_qp_per_ctu_matches_oracle(ks, W, H, spread, seed):
     clip = make_clip(W, H, n, seed=seed, abc=(17, 23, 9), pan=(5, 3))
     rng = np.random.default_rng(seed)
     cols, rows = (W + 63) // 64, (H + 63) // 64
-    tools = dict(ENCODER_TOOLS, bframes=1)
+    tools = dict(ENCODER_TOOLS, bframes=1, bi_refine=2)                  # (with the joint refinement, as from -preset slower on: the B pictures' QP maps reach it too)
     o = OraclePipeline(W, H, 30, lambda_q4(30), **{k: v for k, v in tools.items() if k != "bframes"})
     with KsFrame(ks, W, H, 30, lambda_q4(30), **tools) as f:
         src = f.new_pic()

@@ -189,7 +189,7 @@ def test_config5_command_line(tmp_path):
     log, per, kbps, rec, out = _encode(tmp_path, clip, W, H, ["-preset", "veryslow", "-rc", "1", "-br", "5000", "-iper", "128"])
     assert len(per) == n and "subme 2" in log, log[:800]
     _decoder_check(tmp_path, out, rec, n, W * H * 3 // 2)
-    tools = dict(ENCODER_TOOLS, me_hex_thr=0, part=1, tu_inter=1, **subme_knobs("veryslow"))    # veryslow: always UMH, -subme 2 judged by Hadamard, -part 1 (P and B pictures)
+    tools = dict(ENCODER_TOOLS, me_hex_thr=0, part=1, tu_inter=1, bi_refine=2, **subme_knobs("veryslow"))    # veryslow: always UMH, -subme 2 judged by Hadamard, -part 1 (P and B pictures)
     assert "up to 4 pictures per list" in log, log[:1200]
     st = {"keep": [], "anchor": None}                                          # the host's code_hier: the reference pictures of the mini-GOP coded so far (its two ends first)
 

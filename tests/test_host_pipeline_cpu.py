@@ -217,9 +217,10 @@ def test_b_pictures_nothing_predicts_from_are_coded_lean(stub_lib, tmp_path, bfr
     """round 6: the host lowers the tools (ks265_frame_set_picture_tools) exactly for the B pictures nothing predicts from - half the pictures of a pyramid of 8: no intra
     candidates, no joint refinement, no SAO - and, keeping the refinement, for the reference B pictures whose own references are at most two pictures away (the layer above);
     every other picture runs the full set; a picture without SAO carries slice_sao_luma_flag = slice_sao_chroma_flag = 0 (the writer gets no SAO records) and the stream still
-    decodes; KS265_LEAN_B=3 lowers the non-reference pictures alone, KS265_LEAN_B=0 none"""
+    decodes; KS265_LEAN_B=3 lowers the non-reference pictures alone, KS265_LEAN_B=0 none
+    (run with the joint refinement on, as from -preset slower on, so that the two rules show apart in the stand-in's log)"""
     log = tmp_path / "tools.txt"
-    r = run(stub_lib, 33, 128, bframes, out=tmp_path / "l.265", KS265_STUB_TOOLS_LOG=log)
+    r = run(stub_lib, 33, 128, bframes, out=tmp_path / "l.265", KS265_STUB_TOOLS_LOG=log, KS265_BI_REFINE=2)
     lines = [ln.split() for ln in open(log).read().splitlines()]
     assert len(lines) == 33 and r["vcl"] == 33
     full = [ln for ln in lines if ln[1] != "0"]
@@ -233,12 +234,12 @@ def test_b_pictures_nothing_predicts_from_are_coded_lean(stub_lib, tmp_path, bfr
         d = subprocess.run([REF_DEC, "-b", str(tmp_path / "l.265"), "-o", str(tmp_path / "d.yuv"), "-threads", "2"], capture_output=True, text=True, cwd=tmp_path)
         assert d.returncode == 0 and os.path.getsize(tmp_path / "d.yuv") == 33 * 128 * 72 * 3 // 2, d.stdout[-300:] + d.stderr[-300:]
     os.remove(log)
-    r3 = run(stub_lib, 33, 128, bframes, out=tmp_path / "n.265", KS265_STUB_TOOLS_LOG=log, KS265_LEAN_B=3)
+    r3 = run(stub_lib, 33, 128, bframes, out=tmp_path / "n.265", KS265_STUB_TOOLS_LOG=log, KS265_LEAN_B=3, KS265_BI_REFINE=2)
     l3 = [ln.split() for ln in open(log).read().splitlines()]
     assert sum(ln[1:4] == ["0", "0", "0"] for ln in l3) == len(lean) and sum(ln[1:] == tools0 for ln in l3) == 33 - len(lean)
     assert (r3["md5"] != r["md5"]) == (len(near) > 0)
     os.remove(log)
-    r0 = run(stub_lib, 33, 128, bframes, out=tmp_path / "f.265", KS265_STUB_TOOLS_LOG=log, KS265_LEAN_B=0)
+    r0 = run(stub_lib, 33, 128, bframes, out=tmp_path / "f.265", KS265_STUB_TOOLS_LOG=log, KS265_LEAN_B=0, KS265_BI_REFINE=2)
     assert all(ln.split()[1:] == tools0 for ln in open(log).read().splitlines())
     assert (r0["md5"] != r["md5"]) == (len(lean) > 0)                                               # the slice headers differ where SAO is off
 
