@@ -22,8 +22,9 @@
  *     in part of the CU (one level of the residual quadtree; deeper values run as 1);
  *   - rdoq (round 6): the presets' rdoq = 1 runs this build's own seam (dead zone, coefficient-group pruning, sign-data hiding); rdoq set BY NAME (QY265ConfigParse "rdoq" "1" =
  *     `-rdoq 1`, stored as 2) sends the luma transform blocks of inter CUs through the reference's rdoQuant with bit tables that follow the stream; "0" = the seam;
- *   - sao: 3 = the reference's decision on its -sao 4 path (band offset + the 0 / 90 degree edge classes, its estimation functions, rates and lambda table, no merge candidates);
- *     every other level > 0 = this build's rule over all four edge classes + band offset;
+ *   - sao: every level > 0, the presets' 3 (veryfast, fast) included, = this build's rule over all four edge classes + band offset; sao 3 set BY NAME (QY265ConfigParse "sao" "3" =
+ *     `-sao 3`, stored as 5) = the reference's decision on its -sao 4 path (band offset + the 0 / 90 degree edge classes, its estimation functions, rates and lambda table, no merge
+ *     candidates) - measured on configs[0]: 5.5 % more bytes at equal PSNR-Y than the build's rule, which is why the presets do not select it;
  *   - transskip, tuIntra, vpp_*, 2-pass, long-term references, VBV / CVQ: accepted, ignored;
  *   - input pictures: the caller's planes are pinned in place and uploaded from where they lie inside QY265EncoderEncodeFrame; the caller may reuse its buffers when the call returns
  *     (the SDK requires them to stay valid until the frame is done).
