@@ -400,33 +400,30 @@ __device__ __forceinline__ int me_group(const KsGeom &g, int cx, int cy, int ran
 // fewer than 30 of 768 work-group slots (scratch/me_trace.py: 140 us for 78 us of slot time).  The kernel therefore leaves every CTU's rounds behind (work: one word per
 // wave); the next search of this frame object - next picture or other list, the same content a few samples on - dispatches the CTUs that were in the heaviest tenth first,
 // the rest in the usual XCD-aware order.  Scheduling only: every CTU computes what it always computed.
-__global__ __launch_bounds__(256) void me_score_kernel(int n, int cols, const unsigned *work, unsigned char *score)
-{
-    // a CTU's score: the most rounds any wave of it or of its eight neighbours ran last time (what made a CTU heavy - a moving edge - is in it or next to it now)
-    const int ctu = blockIdx.x * 256 + threadIdx.x;
-    if (ctu >= n) return;
-    const int cx = ctu % cols, cy = ctu / cols, rows = n / cols;
-    unsigned m = 0;
-#pragma unroll
-    for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-        for (int dx = -1; dx <= 1; ++dx) {
-            const int x = min(max(cx + dx, 0), cols - 1), y = min(max(cy + dy, 0), rows - 1);
-            const uint4 w = *(const uint4 *)(work + 4 * ((long)y * cols + x));
-            m = max(m, max(max(w.x, w.y), max(w.z, w.w)));
-        }
-    score[ctu] = (unsigned char)min(255u, m);
-}
 // The order: block index b runs on XCD b % 8, and ks_xcd_swizzle gives every XCD a contiguous raster range of CTUs (neighbours share window halos in one L2).  Each XCD's range
 // keeps its XCD: within it the heavy CTUs (the heaviest scores that together hold at most a tenth of the picture's CTUs) come first, the others follow in their usual order;
 // the k-th CTU of XCD x's list is dispatched as block 8 k + x.  One wave per XCD, ranks by ballots.
 #define ME_ORDER_MAX 16384
-__global__ __launch_bounds__(512) void me_order_kernel(int n, const unsigned char *score, int *order)
+__global__ __launch_bounds__(512) void me_order_kernel(int n, int cols, const unsigned *work, int *order)
 {
     __shared__ unsigned char sc[ME_ORDER_MAX];
     __shared__ int part[2][8];
     const int tid = threadIdx.x, lane = tid & 63, x = tid >> 6;
-    for (int i = tid; i < n; i += 512) sc[i] = score[i];
+    // a CTU's score: the most rounds any wave of it or of its eight neighbours ran last time (what made a CTU heavy - a moving edge - is in it or next to it now).  Computed here
+    // (until the end of round 6 a kernel of its own in front of this one: two dependent launches in front of every search, ~ 17 us of a chain that is all latency)
+    for (int ctu = tid; ctu < n; ctu += 512) {
+        const int cx = ctu % cols, cy = ctu / cols, rows = n / cols;
+        unsigned m = 0;
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int xx = min(max(cx + dx, 0), cols - 1), yy = min(max(cy + dy, 0), rows - 1);
+                const uint4 w = *(const uint4 *)(work + 4 * ((long)yy * cols + xx));
+                m = max(m, max(max(w.x, w.y), max(w.z, w.w)));
+            }
+        sc[ctu] = (unsigned char)min(255u, m);
+    }
     __syncthreads();
     // the threshold: the smallest score v >= 1 with at most n / 10 CTUs at or above it (256: none).  The count falls with v: eight halvings, each a count by ballots (no
     // histogram - most scores are the same few values, 2 000 atomics on three LDS words were most of this kernel's 15 us)
@@ -719,8 +716,7 @@ extern "C" int ks265_me_integer(ks265_frame *f, ks265_pic src, ks265_pic ref, co
         f->me_work = f->me_work_all[0]; f->me_order = f->me_order_all[0];
     }
     if (f->me_work) {
-        hipLaunchKernelGGL(me_score_kernel, dim3((unsigned)((nctu + 255) / 256)), dim3(256), 0, f->ctx->stream, nctu, f->g.ctu_cols, f->me_work, (unsigned char *)(f->me_order + nctu));
-        hipLaunchKernelGGL(me_order_kernel, dim3(1), dim3(512), 0, f->ctx->stream, nctu, (const unsigned char *)(f->me_order + nctu), f->me_order);
+        hipLaunchKernelGGL(me_order_kernel, dim3(1), dim3(512), 0, f->ctx->stream, nctu, f->g.ctu_cols, (const unsigned *)f->me_work, f->me_order);
     }
     const bool timed = f->profiling && f->ev_k[0] && !(f->side && f->ctx->stream == f->side);      // the main chain's launch alone (a B picture's list-1 search runs on the side stream: its marks would pair with list 0's)
     if (timed) (void)hipEventRecord(f->ev_k[0], f->ctx->stream);
