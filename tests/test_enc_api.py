@@ -56,6 +56,9 @@ def test_config_functions_and_error_codes():
     assert lib.QY265ConfigParse(buf, b"qp", b"99") == -2                 # QY265_PARAM_BAD_VALUE
     assert lib.QY265ConfigParse(buf, b"nosuchflag", b"1") == -1          # QY265_PARAM_BAD_NAME
     assert lib.QY265ConfigParse(buf, b"preset", b"slow") == 0 and i32("preset") == 5
+    # tools asked for BY NAME that select the reference's own restated functions are stored apart from the presets' values (the presets' streams stay this build's)
+    assert lib.QY265ConfigParse(buf, b"sao", b"3") == 0 and i32("sao") == 5 and lib.QY265ConfigParse(buf, b"sao", b"4") == 0 and i32("sao") == 4 and lib.QY265ConfigParse(buf, b"sao", b"5") == -2
+    assert lib.QY265ConfigParse(buf, b"rdoq", b"1") == 0 and i32("rdoq") == 2
     err = C.c_int(0)
     lib.QY265EncoderOpen.restype = C.c_void_p
     assert lib.QY265EncoderOpen(None, C.byref(err)) is None and (err.value & 0xFFFFFFFF) == 0x80000003      # QY_POINTER
