@@ -1098,6 +1098,7 @@ static int code_hier(Enc *e, int d, int a)
             if (cur[i].hi - cur[i].lo < 2) continue;
             const int mid = (cur[i].lo + cur[i].hi) / 2;
             Input *in = input_at(e, mid);
+            if (!in) return QY_FAIL;                                   /* (the picture has left the input table: the encoder is being torn down after an error) */
             const int is_ref = (mid - cur[i].lo >= 2) || (cur[i].hi - mid >= 2);
             /* list 0: the nearest pictures before `mid` among those this mini-GOP keeps (all its reference pictures coded so far), nearest first; list 1: those after it.  The
              * interval's ends come first; -ref > 1 adds the next nearest ones */
@@ -1156,6 +1157,7 @@ static int schedule(Enc *e, int flush, int have /* pictures [0, have) have arriv
             if (rr) return hip_rc(rr);
         }
         if (key) {
+            if (!in) return QY_FAIL;
             e->gop_start = nxt; e->mg4_until = -1;
             e->anc_hist[0] = 0; e->n_anc = 1;                           /* the key picture is the GOP's first anchor (POC 0) */
             e->rc_qp_delta = rc_decide(e);                             /* rate control: one offset per key picture / mini-GOP, decided when it is certain to be submitted */
@@ -1198,6 +1200,7 @@ static int schedule(Enc *e, int flush, int have /* pictures [0, have) have arriv
             for (int i = 0; i < e->refs0 - 1 && i < e->n_anc; ++i) keep[nkeep++] = e->anc_hist[i];
         } else { l0[nl0++] = pd; keep[nkeep++] = pd; }
         Input *ina = input_at(e, a);
+        if (!ina) return QY_FAIL;                                      /* (as above: an error elsewhere emptied the input table under the scheduler) */
         e->rc_qp_delta = rc_decide(e);
         /* the QP ladder of P pictures: + 1 on the key picture's; IPPP: the reference's own cascade over four pictures (appencoder -bframes 0 -qp 27 -psnr 2: 30 / 29 / 30 / 28 / 30 ..),
          * measured with the CPU mirror of this host: - 12 % bytes of the P pictures for - 0.09 dB */
@@ -1217,6 +1220,7 @@ static int schedule(Enc *e, int flush, int have /* pictures [0, have) have arriv
                 for (int i = 2; i < e->refs0 && i < e->n_anc; ++i) kp[nkp++] = e->anc_hist[i];      /* (-ref0: what the next anchor still searches) */
                 for (int b = d + 1; b < a; ++b) {
                     Input *inb = input_at(e, b);
+                    if (!inb) return QY_FAIL;
                     r = submit(e, inb, 'B', b - e->gop_start, clampqp(e, inb->base_qp + e->rc_qp_delta + (e->fixqp ? 0 : 2)), &pd, 1, &pa, 1, kp, nkp, 0, 0);
                     if (r) return r;
                 }
