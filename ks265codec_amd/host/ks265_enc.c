@@ -1495,7 +1495,9 @@ static Enc *lane_open(QY265EncConfig *cfg, int device, int multi, int *err)
     const int la_order = getenv("KS265_LA_ORDER") ? atoi(getenv("KS265_LA_ORDER")) : 0;      /* (experiments: 1 = fourth, 2 = last) */
     if (!getenv("KS265_INPUT_COPY") && getenv("KS265_UPL_ORDER") && atoi(getenv("KS265_UPL_ORDER")) == -1 && (size_t)e->W * e->H * 3 / 2 >= ((size_t)1 << 20)) { if (ks265_create(&e->ctx_upl, device)) e->ctx_upl = NULL; }
     if (la_wanted && la_order == 0 && ks265_create(&e->ctx_la, device)) e->ctx_la = NULL;
-    e->direct_in = !getenv("KS265_INPUT_COPY") && (size_t)e->W * e->H * 3 / 2 >= ((size_t)1 << 20) && !(cfg->latency == QY265LATENCY_ZERO && !multi);
+    /* (not with KS265_GRAPH: the host-synchronous copy out of the caller's memory runs on the runtime's null stream from the CALLING thread, and while another thread has a capture open
+     * that fails - 4 of 6 runs of the 2160p default GOP ended in QY_FAIL, 6 of 6 pass with the copying path; found and fixed at the end of round 6) */
+    e->direct_in = !getenv("KS265_INPUT_COPY") && !getenv("KS265_GRAPH") && (size_t)e->W * e->H * 3 / 2 >= ((size_t)1 << 20) && !(cfg->latency == QY265LATENCY_ZERO && !multi);
     e->hold_in = getenv("KS265_INPUT_HOLD") && atoi(getenv("KS265_INPUT_HOLD")) > 0;
     /* the uploads' stream: created first, like the lookahead's.  Its own even beside the lookahead's: the caller waits for the upload, and behind the analysis kernels of the picture
      * before (measured: 1.17 ms per call instead of the 0.3 ms the DMA takes) it would wait for those too */
