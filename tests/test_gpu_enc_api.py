@@ -193,6 +193,23 @@ def test_b_pictures_replayed_as_graphs(bframes):
     assert md5["graph"] == md5["plain"], md5
 
 
+def test_graph_replay_at_2160p_beside_the_callers_uploads(tmp_path):
+    """KS265_GRAPH=1 at the bench's size with the default GOP (two lanes, lookahead): pictures this large used to go up by a host-synchronous copy from the CALLING thread, which fails
+    while a lane's thread has a capture open (end of round 6: 2 of 6 runs passed) - with graphs the input now takes the copying path; three runs, each == the launch-by-launch stream"""
+    from ks265codec_amd import stream
+    from ks265codec_amd.synth import make_clip
+    stream.build()
+    W, H, n = 3840, 2160, 40
+    make_clip(W, H, n, seed=7, abc=(67, 91, 33), pan=(8, 5)).tofile(tmp_path / "in.yuv")
+    md5 = []
+    for env in ({}, {"KS265_GRAPH": "1"}, {"KS265_GRAPH": "1"}, {"KS265_GRAPH": "1"}):
+        r = subprocess.run([stream.CLI, "-i", str(tmp_path / "in.yuv"), "-wdt", str(W), "-hgt", str(H), "-fr", "50", "-rc", "0", "-preset", "slow", "-qp", "27", "-iper", "128", "-threads", "8",
+                            "-psnr", "1", "-b", str(tmp_path / "o.265")], capture_output=True, text=True, env=dict(os.environ, **env))
+        assert r.returncode == 0 and "H265 encoder passed!!!" in r.stdout, (env, r.stdout[-500:] + r.stderr[-500:])
+        md5.append(hashlib.md5(open(tmp_path / "o.265", "rb").read()).hexdigest())
+    assert len(set(md5)) == 1, md5
+
+
 @pytest.mark.parametrize("bframes,iper,n", [(-1, 64, 100), (-1, 20, 70), (3, 48, 110)])
 def test_anchor_lane_writes_the_same_stream(bframes, iper, n):
     """round 5: a pyramid's anchor P pictures run on a stream, frame object and DPB slots of their own, beside the B pictures of the mini-GOP behind them; with the lane
