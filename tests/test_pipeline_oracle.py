@@ -255,3 +255,44 @@ def test_vector_propagation_properties():
             ps.append(psnr(clip[t][:W * H], o.store(r)[:W * H]))
         size[p] = (nz, min(ps))
     assert size[1][0] < 0.9 * size[0][0] and size[1][1] > size[0][1] - 0.1, size
+
+
+def test_tools_per_picture_carry_no_state():
+    """round 6 (lean B pictures): OraclePipeline.set_picture_tools - the checker's side of ks265_frame_set_picture_tools - switches tools for the pictures coded from there on and
+    nothing else: a B picture coded lean on a pipeline created with every tool == the same picture on a pipeline CREATED with the lean set fed the same reference pictures, a full
+    picture after it == one on a pipeline that never left the full set, and a lean picture holds no intra CU, no refined pair and only "off" SAO records"""
+    from ks265codec_amd.synth import ENCODER_TOOLS
+    W, H = 200, 136
+    clip = make_clip(W, H, 5, seed=6, abc=(17, 23, 9), pan=(2, 1))
+    full = dict(ENCODER_TOOLS, bi_refine=2)
+    lean = dict(full, intra_inter=0, bi_refine=0, sao=0)
+
+    def run(tools, switch):
+        o = OraclePipeline(W, H, 27, lambda_q4(27), **tools)
+        i0 = o.encode(clip[0], "I")
+        o.set_qp(28, lambda_q4(28, inter=True)); p4 = o.encode(clip[4], "P", i0)
+        o.set_qp(29, lambda_q4(29, inter=True)); b2 = o.encode(clip[2], "B", i0, p4)
+        recs = [o.store(b2).copy()]
+        if switch:
+            o.set_picture_tools(0, 0, 0)
+        o.set_qp(31, lambda_q4(31, inter=True)); b1 = o.encode(clip[1], "B", i0, b2)
+        recs.append((o.store(b1).copy(), o.cu8.copy(), [a.copy() for a in o.lvl], o.sao.copy()))
+        if switch:
+            o.set_picture_tools(-1, -1, -1)
+        b3 = o.encode(clip[3], "B", b2, p4)
+        recs.append((o.store(b3).copy(), o.cu8.copy(), o.sao.copy()))
+        return i0, p4, b2, recs
+
+    i0, p4, b2, sw = run(full, True)
+    _, _, _, never = run(full, False)
+    # the lean picture on a pipeline created lean, fed the switched pipeline's reference pictures
+    ol = OraclePipeline(W, H, 31, lambda_q4(31, inter=True), **lean)
+    ol.set_qp(31, lambda_q4(31, inter=True))
+    b1 = ol.encode(clip[1], "B", i0, b2)
+    assert (ol.store(b1) == sw[1][0]).all() and (ol.cu8.view(np.uint8) == sw[1][1].view(np.uint8)).all() and all((a == b).all() for a, b in zip(ol.lvl, sw[1][2]))
+    assert (sw[1][3]["type"] == -1).all() and (sw[1][1]["pred_mode"] == 0).all()
+    assert (sw[0] == never[0]).all()
+    assert not (sw[1][0] == never[1][0]).all(), "the lean picture differs from the full one (SAO alone changes samples)"
+    # the picture after the switch back: the full set again (its references differ from the never-switched run's only through b1, which it does not use)
+    assert (sw[2][0] == never[2][0]).all() and (sw[2][1].view(np.uint8) == never[2][1].view(np.uint8)).all() and (sw[2][2].view(np.uint8) == never[2][2].view(np.uint8)).all()
+    assert (sw[2][2]["type"] != -1).any()
