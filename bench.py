@@ -851,8 +851,8 @@ def encoded_line(args, enc, world, hot, cpu):
                                   "predictors, vector propagation between neighbouring PUs (stage A2, one round), bi-prediction judged at 31/32 (the joint refinement of the pairs runs from -preset slower on: at -preset slow it cost 0.5 - 0.7 % bytes at equal PSNR-Y and 134 us per B picture, measured), the anchors of a pyramid searching the last three anchors (-ref0 3), intra CUs in P / B pictures, the skip pass over B pictures (a CU with residual against its first two merge candidates without residual: SSE of the real reconstruction + level bits), lean B pictures (the B pictures nothing predicts from - half of a pyramid of 8 - without intra candidates, joint refinement and SAO: ks265_frame_set_picture_tools; bytes at equal PSNR-Y unchanged), coefficient-group pruning (luma) and sign-data hiding "
                                   "(signBitHidingHDQ) at the postQuant seam, P / B lambda table; fractional samples interpolated on the fly; the picture's drain (SSE, packing of the records) and the next source picture's unpack on side streams (DESIGN.md 6a)",
                    "not_in_the_path": "the reference's rdoQuant (an option: -rdoq 1; the presets' rdoq = 1 runs this build's seam), CU size judged with the residual's cost, generalised B pictures; "
-                                      "at equal PSNR-Y the stream is 0.99x (2160p) / 1.02x (1080p) the size of appencoder's for IPPP and 1.21x / 1.01x for the default GOP on the same (ping-pong) clips, "
-                                      "1.18x / 1.19x and 1.08x / 1.12x on clips without repeats (measured on the MI355X in round 6: profiles/r06_same_clips_equal_psnr.txt, r06_straight_clips_equal_psnr.txt)",
+                                      "at equal PSNR-Y the stream is 0.99x (2160p) / 1.02x (1080p) the size of appencoder's for IPPP and 1.19x / 1.00x for the default GOP on the same (ping-pong) clips, "
+                                      "1.14x / 1.14x and 1.08x / 1.12x on clips without repeats (measured on the MI355X in round 6: profiles/r06_same_clips_equal_psnr.txt, r06_straight_clips_equal_psnr.txt)",
                    "lookahead": enc.get("lookahead"),
                    "sharding": (f"ONE job of {enc['job']['frames']} pictures = {enc['job']['gops']} closed GOPs dealt to the ranks in contiguous runs; every rank encodes its GOPs, the coded bytes are "
                                 f"gathered on rank 0 in stream order (the only exchange step; inside the timed region); stream md5 {enc['md5']}") if strong else
