@@ -1,6 +1,7 @@
 """Randomised end-to-end parity sweep (GPU box): random picture sizes (8..472 x 8..312), QP 0..51, DIA/HEX/UMH, search range, sub-pel / deblock /
 SAO switches, and the three GOP structures (IPPP, multi-reference P, hierarchical B): every reconstructed picture of the HIP pipeline must equal the
-oracle's.  Not collected by pytest (no test_ prefix): run `python tests/fuzz_parity.py SEED COUNT` through gpurun.  Round 1: seeds 1..4, 300 cases, 0 failures."""
+oracle's.  Not collected by pytest (no test_ prefix): run `python tests/fuzz_parity.py SEED COUNT` through gpurun.  Round 1: seeds 1..4, 300 cases, 0 failures.  Round 6: half of the pyramid cases run the host's tool set with the tools of every B picture drawn at random
+(ks265_frame_set_picture_tools)."""
 import sys, itertools, numpy as np
 sys.path.insert(0,'tests'); sys.path.insert(0,'.')
 from oracle_lib import OraclePipeline
@@ -17,6 +18,8 @@ for it in range(int(sys.argv[2]) if len(sys.argv)>2 else 30):
     n=6
     clip=make_clip(W,H,9,seed=int(rng.integers(0,10000)),noisy=bool(rng.integers(0,2)))
     kw=dict(me_range=rangev,subme=subme,deblock=df,sao=sao,me_method=me)
+    lean_mix=mode=="hier" and bool(rng.integers(0,2))     # round 6: the host's tool set with tools switched per B picture (ks265_frame_set_picture_tools: lean / near-lean / full / + interMeHex)
+    if lean_mix: kw.update(sdh=1,pre_search=1,merge=1,bi_refine=int(rng.choice([0,2])),rdo=4,intra_inter=1,propagate=1,skip_rd=1,sao=1,me_hex_thr=16 if me==2 else 0)
     o=OraclePipeline(W,H,qp,lambda_q4(qp),**kw)
     try:
         with KsFrame(ks,W,H,qp,lambda_q4(qp),bframes=3,refs=3,**kw) as f:
@@ -26,6 +29,9 @@ for it in range(int(sys.argv[2]) if len(sys.argv)>2 else 30):
                 for d,kind,r0,r1,layer in itertools.islice(hier_order(G,128),2*G+1):
                     q=min(51,qp if kind=="I" else qp+1+layer)
                     o.set_qp(q,lambda_q4(q)); f.set_qp(q,lambda_q4(q))
+                    if lean_mix:
+                        t=[(-1,-1,-1,-1),(0,0,0,-1),(0,-1,0,-1),(0,0,0,1 if me==2 else -1)][int(rng.integers(0,4))] if kind=="B" else (-1,-1,-1,-1)
+                        o.set_picture_tools(*t); f.set_picture_tools(*t)
                     do[d]=o.encode(clip[d],kind,do.get(r0),do.get(r1))
                     f.load_i420(ks.dev(clip[d]),src); out=dg[d%(G+1)]
                     if kind=="B": f.encode_picture_b(src,dg[r0%(G+1)],dg[r1%(G+1)],out)
@@ -45,7 +51,7 @@ for it in range(int(sys.argv[2]) if len(sys.argv)>2 else 30):
                     got,exp=ks.host(f.store_i420(out),np.uint8),o.store(eo)
                     assert (got==exp).all(),(t,int((got!=exp).sum()))
                     dpo.insert(0,eo); dpg.insert(0,out)
-        print("ok",W,H,qp,me,rangev,subme,df,sao,mode)
+        print("ok",W,H,qp,me,rangev,subme,df,sao,mode,"lean-mix" if lean_mix else "")
     except AssertionError as e:
         nfail+=1; print("FAIL",W,H,qp,me,rangev,subme,df,sao,mode,e)
 print("failures",nfail)
